@@ -1,0 +1,158 @@
+/* rgx.h -- C ABI of the MI355X-native matching backend for regengo.
+ *
+ * The reference (KromDaniel/regengo, /root/reference) has NO FFI boundary: its matchers are emitted
+ * Go code.  This header DEFINES the boundary that north_star asks for: the code generator emits the
+ * compiled automaton as a flat table blob plus a thin cgo stub, and the stub's methods -- the
+ * generated `Compiled<Name>` API, README.md:99-146 -- call the entry points below.  Each entry point
+ * cites the reference function whose body it replaces.  INTEGRATION.md shows the cgo stub.
+ *
+ * Conventions
+ *   - plain C, plain pointers and sizes; no C++/torch types.
+ *   - every function returns >= 0 on success (a count where documented) or a negative rgx_status.
+ *   - "device pointer" arguments are HIP device addresses on the program's device; "host" ones are
+ *     ordinary memory.  Nothing here falls back to a CPU matcher: without a usable GPU the compute
+ *     entry points return RGX_E_NO_DEVICE (the Go stub then keeps its pure-Go path).
+ *   - spans are int32 byte offsets into the buffer handed to the call, `ncap = 2*(groups+1)` per
+ *     match, laid out exactly like the reference's `var captures [NumCap]int`
+ *     (internal/compiler/find.go:215): [0]=match start, [1]=match end, [2k],[2k+1] = group k.
+ *     Unmatched groups read (0,0) -- the reference zero-initialises the array and never writes -1
+ *     (find.go:215, find.go:394-406: such a group becomes `input[0:0]`).  Pass
+ *     RGX_FLAG_UNMATCHED_MINUS1 at program creation to get (-1,-1) instead (stdlib convention).
+ *   - a program handle is immutable after creation and may be shared by threads; calls that use the
+ *     same `rgx_stream_ctx` must be serialised by the caller.
+ */
+#ifndef RGX_H
+#define RGX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RGX_ABI_VERSION 1
+
+typedef enum rgx_status {
+  RGX_OK = 0,
+  RGX_E_INVALID = -1,        /* bad argument                                                   */
+  RGX_E_SYNTAX = -2,         /* pattern rejected by the front-end (Go regexp/syntax rules)       */
+  RGX_E_UNSUPPORTED = -3,    /* valid pattern, feature not covered by the table compiler yet     */
+  RGX_E_TOO_LARGE = -4,      /* automaton exceeds the state budget / buffer > 2^31-1 bytes       */
+  RGX_E_NO_DEVICE = -5,      /* no HIP device / HIP runtime error at init                        */
+  RGX_E_HIP = -6,            /* HIP runtime error during a call (rgx_last_error has the text)    */
+  RGX_E_NOMEM = -7,
+  RGX_E_CAPACITY = -8,       /* output capacity too small; count is in rgx_result.total          */
+  RGX_E_BAD_BLOB = -9,
+  RGX_E_BUFFER_TOO_SMALL = -10 /* stream.ErrBufferTooSmall, stream/stream.go:85-101              */
+} rgx_status;
+
+enum {
+  RGX_FLAG_UNMATCHED_MINUS1 = 1u << 0, /* unmatched group = (-1,-1) instead of the reference's (0,0) */
+  RGX_FLAG_STDLIB_SEMANTICS = 1u << 1  /* MatchBytes / FindBytes / FindReader without quirks Q1/Q4
+                                          (see DESIGN.md): plain leftmost-first search            */
+};
+
+typedef struct rgx_program rgx_program;       /* compiled pattern: host tables + device copy      */
+typedef struct rgx_stream_ctx rgx_stream_ctx; /* per-call-site scratch: HIP stream, device buffers */
+
+/* ---- compile time: replaces regengo.Compile's front half + the table emitter ------------------
+ * regengo.go:86-110 (Parse(Perl) -> Simplify -> Compile), compiler.go:59-184 (analysis),
+ * tdfa.go:584-794 (table literals).  `pattern` is UTF-8, NUL-terminated, Go/RE2 syntax.            */
+int rgx_compile(const char* pattern, uint32_t flags, rgx_program** out);
+/* Serialised table blob: what the code generator writes next to the cgo stub (`<Name>_tables.bin`). */
+int64_t rgx_program_blob_size(const rgx_program* p);
+int64_t rgx_program_blob_write(const rgx_program* p, void* dst, size_t cap);
+int rgx_program_from_blob(const void* blob, size_t len, rgx_program** out);
+void rgx_program_destroy(rgx_program* p);
+
+typedef struct rgx_info {
+  int32_t abi_version;
+  int32_t ncap;            /* syntax.Prog.NumCap = 2*(groups+1)                                  */
+  int32_t min_match_len;   /* <Name>MinMatchLen, analysis_match_len.go:34-138                    */
+  int32_t max_match_len;   /* <Name>MaxMatchLen, -1 = unbounded, analysis_match_len.go:142-251   */
+  int32_t default_max_leftover; /* DefaultMaxLeftover(), streaming.go:87-96                      */
+  int32_t min_buffer_size; /* streaming.go:56-62                                                 */
+  int32_t n_inst;          /* len(Prog.Inst)                                                     */
+  int32_t n_states;        /* DFA states incl. dead                                              */
+  int32_t n_classes;       /* byte classes (excl. the end-of-text class)                         */
+  int32_t anchored;        /* isAnchored(), analysis.go:117-124                                  */
+  int32_t fixed_captures;  /* 1: every capture slot is a constant offset from match start/end    */
+  int32_t can_match_empty;
+  int32_t ref_match_engine; /* what the reference would emit: 0 backtracking, 1 thompson, 2 memo */
+  int32_t ref_find_engine;  /* 0 backtracking, 1 tdfa-or-tnfa (catastrophic risk), 2 tnfa, -1 none (no captures) */
+  int32_t lookahead_mode;  /* 1: pattern has $ / \b / \B / (?m)$ (match flag is on the next-byte edge) */
+  int32_t table_bytes;     /* bytes of transition table staged in LDS                            */
+} rgx_info;
+int rgx_program_info(const rgx_program* p, rgx_info* out);
+/* NUL-separated capture names, group 0 first ("" for unnamed); returns bytes written or needed.    */
+int64_t rgx_program_capture_names(const rgx_program* p, char* dst, size_t cap);
+
+/* ---- device binding --------------------------------------------------------------------------- */
+int rgx_device_count(void);
+/* Upload tables to `device` (HIP ordinal).  Idempotent.  RGX_E_NO_DEVICE when there is none.        */
+int rgx_program_to_device(rgx_program* p, int device);
+int rgx_stream_ctx_create(const rgx_program* p, rgx_stream_ctx** out);
+void rgx_stream_ctx_destroy(rgx_stream_ctx* c);
+/* The HIP stream (hipStream_t) a ctx launches on; lets a caller order its own copies/events.       */
+void* rgx_stream_ctx_hip_stream(const rgx_stream_ctx* c);
+
+/* ---- run time ---------------------------------------------------------------------------------- */
+typedef struct rgx_result {
+  int64_t total;        /* matches found (before `n` and capacity clipping)                       */
+  int64_t written;      /* records written to `spans`                                             */
+  int32_t ncap;         /* ints per record                                                        */
+  int32_t unsynced;     /* slices that needed the serial carry path (DESIGN.md "sync points")     */
+  float kernel_ms;      /* scan-kernel time measured with HIP events on the ctx stream (0 if off) */
+} rgx_result;
+
+/* MatchBytes(input []byte) bool  -- compiler.go:740-871 / thompson.go:69-131.
+ * `d_buf` device pointer.  *matched = 0/1.                                                          */
+int rgx_match_bytes_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len,
+                           int* matched);
+
+/* FindAllBytes(input []byte, n int) -- find.go:113-124,130-466 (TDFA flavour compiler.go:602-655).
+ * `d_buf`, `d_spans` device pointers; `cap_records` = capacity of d_spans in records of ncap int32.
+ * n < 0: all matches; n == 0: nothing (returns 0, like `return s`); n > 0: first n.
+ * Records are written in increasing match-start order.  Returns written count or <0.              */
+int64_t rgx_find_all_bytes_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len,
+                                  int64_t n, int32_t* d_spans, size_t cap_records, rgx_result* res);
+/* Same, host buffers: H2D copy of the input, D2H copy of the spans (PCIe-bound).     */
+int64_t rgx_find_all_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* buf, size_t len, int64_t n,
+                           int32_t* spans, size_t cap_records, rgx_result* res);
+/* Count only (FindReaderCount's hot loop; no span traffic).                                        */
+int64_t rgx_count_all_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len,
+                             rgx_result* res);
+
+/* Batch: one independent input per string (BASELINE config C3: FindBytes over 10M strings).
+ * `d_concat` all strings back to back, `d_offsets` nstr+1 uint64 CSR offsets, outputs `d_found`
+ * (uint8 per string) and `d_spans` (nstr records of ncap int32, relative to the string's start).
+ * Semantics per string: FindBytesReuse, find.go:469-591 (first leftmost-first match).              */
+int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_concat,
+                              const uint64_t* d_offsets, size_t nstr, uint8_t* d_found, int32_t* d_spans);
+/* MatchBytes per string of a batch.                                                                */
+int64_t rgx_match_batch_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_concat,
+                               const uint64_t* d_offsets, size_t nstr, uint8_t* d_matched);
+
+/* ---- streaming: FindReader (streaming.go:85-255) ------------------------------------------------
+ * The stub keeps the Go read loop (r.Read is the only I/O boundary, streaming.go:123).  Each filled
+ * chunk (leftover + fresh bytes) is handed down; matches are returned chunk-relative together with
+ * `keep_from`, the offset the caller must carry into the next chunk -- the function computes the
+ * commit/defer decisions of streaming.go:183-244 (MaxLeftover deferral, committed, keepFrom).        */
+typedef struct rgx_stream_config {  /* stream.Config, stream/stream.go:21-39 */
+  int64_t buffer_size;
+  int64_t max_leftover;
+} rgx_stream_config;
+/* Config.Validate + ApplyDefaults with this pattern's minBuffer/defaultLeftover (stream.go:96-134). */
+int rgx_stream_config_resolve(const rgx_program* p, const rgx_stream_config* in, rgx_stream_config* out);
+int64_t rgx_find_chunk(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* chunk, size_t data_len,
+                       int is_full, int64_t max_leftover, int32_t* spans, size_t cap_records,
+                       int64_t* committed, int64_t* keep_from, rgx_result* res);
+
+const char* rgx_last_error(void);
+const char* rgx_status_str(int status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RGX_H */

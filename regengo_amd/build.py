@@ -1,0 +1,126 @@
+"""In-tree builds (no pip, no JIT cache): hipcc for the product library, g++/gcc for the test-only
+host walker and the oracle's C restatement.  Everything lands next to the sources so that a `gpurun`
+snapshot carries the binaries to the GPU box.
+"""
+from __future__ import annotations
+
+import hashlib
+import os
+import shutil
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CSRC = os.path.join(ROOT, "regengo_amd", "csrc")
+LIBDIR = os.path.join(ROOT, "regengo_amd", "lib")
+ORACLE = os.path.join(ROOT, "oracle")
+
+PRODUCT_SOURCES = ["rgx_syntax.cc", "rgx_dfa.cc", "rgx_program.cc", "rgx_kernels.hip", "rgx_capi.cc"]
+HOSTTEST_SOURCES = ["rgx_syntax.cc", "rgx_dfa.cc", "hosttest/rgx_hosttest.cc"]
+
+
+def _hipcc() -> str:
+    for c in ("/opt/rocm/bin/hipcc", shutil.which("hipcc") or ""):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: the product library cannot be built")
+
+
+def _stamp(paths, extra=""):
+    h = hashlib.sha256(extra.encode())
+    for p in sorted(paths):
+        h.update(p.encode())
+        with open(p, "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()
+
+
+def _needs(target: str, deps, extra="") -> str | None:
+    st = _stamp(deps, extra)
+    sf = target + ".stamp"
+    if os.path.exists(target) and os.path.exists(sf) and open(sf).read() == st:
+        return None
+    return st
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    if r.returncode != 0:
+        sys.stderr.write(" ".join(cmd) + "\n" + r.stdout + "\n")
+        raise RuntimeError("build failed: " + " ".join(cmd[:3]))
+    return r.stdout
+
+
+def _all_headers():
+    hs = [os.path.join(ROOT, "include", "rgx.h")]
+    for d, _, fs in os.walk(CSRC):
+        hs += [os.path.join(d, f) for f in fs if f.endswith(".h")]
+    return hs
+
+
+def product_lib_path() -> str:
+    return os.path.join(LIBDIR, "librgx_hip.so")
+
+
+def hosttest_lib_path() -> str:
+    return os.path.join(LIBDIR, "librgx_hosttest.so")
+
+
+def oracle_lib_path() -> str:
+    return os.path.join(ORACLE, "_build", "liboracle_bt.so")
+
+
+def build_product(verbose=False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    out = product_lib_path()
+    srcs = [os.path.join(CSRC, s) for s in PRODUCT_SOURCES]
+    flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
+             "-I" + CSRC, "-Wno-unused-result", "-fvisibility=hidden", "-DRGX_BUILDING"]
+    st = _needs(out, srcs + _all_headers(), " ".join(flags))
+    if st is None:
+        return out
+    # hipcc treats .cc as host C++ and .hip as HIP; one link step produces the .so
+    cmd = [_hipcc()] + flags + srcs + ["-o", out]
+    log = _run(cmd)
+    if verbose:
+        print(log)
+    open(out + ".stamp", "w").write(st)
+    return out
+
+
+def build_hosttest() -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    out = hosttest_lib_path()
+    srcs = [os.path.join(CSRC, s) for s in HOSTTEST_SOURCES]
+    flags = ["-O2", "-std=c++17", "-fPIC", "-shared", "-I" + CSRC]
+    st = _needs(out, srcs + _all_headers(), " ".join(flags))
+    if st is None:
+        return out
+    _run(["g++"] + flags + srcs + ["-o", out])
+    open(out + ".stamp", "w").write(st)
+    return out
+
+
+def build_oracle() -> str:
+    """The oracle's C restatement (checker only; never linked into the product)."""
+    bdir = os.path.join(ORACLE, "_build")
+    os.makedirs(bdir, exist_ok=True)
+    out = oracle_lib_path()
+    srcs = [os.path.join(ORACLE, "backtrack.c")]
+    if not os.path.exists(srcs[0]):
+        return ""
+    flags = ["-O2", "-std=c11", "-fPIC", "-shared"]
+    st = _needs(out, srcs, " ".join(flags))
+    if st is None:
+        return out
+    _run(["gcc"] + flags + srcs + ["-o", out, "-lpthread"])
+    open(out + ".stamp", "w").write(st)
+    return out
+
+
+def build_all(verbose=False):
+    return {"product": build_product(verbose), "hosttest": build_hosttest(), "oracle": build_oracle()}
+
+
+if __name__ == "__main__":
+    print(build_all(verbose=True))

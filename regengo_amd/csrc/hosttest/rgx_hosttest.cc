@@ -1,0 +1,169 @@
+// TEST-ONLY library (librgx_hosttest.so).  NOT linked into the product library and never reachable
+// from any rgx_* entry point: it exists so that the no-GPU test tier (`pytest -m "not gpu"`) can check the
+// host logic -- front-end, table compiler, blob round-trip -- by walking the SAME tables the HIP kernels
+// walk, on the CPU, against the oracle.  The product has no CPU matcher (include/rgx.h).
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../rgx_dfa.h"
+#include "../rgx_syntax.h"
+
+using namespace rgx;
+
+namespace {
+thread_local std::string g_err;
+
+struct Handle {
+  Tables t;
+};
+
+// One anchored walk from `pos`; returns match end or -1.  Optionally records the state trace.
+int64_t Walk(const Tables& t, const uint8_t* buf, int64_t len, int64_t pos, std::vector<uint16_t>* trace, int* ctx_out) {
+  const int stride = t.ncls + 1;
+  int ctx = pos == 0 ? kCtxBOT : t.ctx_of_byte[buf[pos - 1]];
+  if (ctx_out) *ctx_out = ctx;
+  uint16_t q = t.start[ctx];
+  int64_t end = (!t.lookahead_mode && t.start_accept[ctx]) ? pos : -1;
+  if (trace) { trace->clear(); trace->push_back(q); }
+  for (int64_t i = pos;; i++) {
+    int k = i < len ? t.cls[buf[i]] : t.ncls;
+    uint16_t e = t.trans[(size_t)q * stride + k];
+    if (e & kMatchBefore) end = i;
+    if (e & kMatchAfter) end = i + 1;
+    q = e & kStateMask;
+    if (trace) trace->push_back(q);
+    if (q == kDead || k == t.ncls) break;
+  }
+  return end;
+}
+
+void Captures(const Tables& t, const uint8_t* buf, int64_t len, int64_t s, int64_t e, int32_t* out) {
+  const bool minus1 = t.flags & 1u;
+  for (int c = 0; c < t.ncap; c++) out[c] = minus1 ? -1 : 0;
+  out[0] = (int32_t)s; out[1] = (int32_t)e;
+  if (t.fixed_captures) {
+    for (int c = 2; c < t.ncap; c++) out[c] = (int32_t)(t.cap_kind[c] == kCapFromStart ? s + t.cap_delta[c] : e - t.cap_delta[c]);
+    return;
+  }
+  // back-trace over the recorded state sequence (see DESIGN.md "capture back-trace")
+  std::vector<uint16_t> trace;
+  int ctx;
+  Walk(t, buf, len, s, &trace, &ctx);
+  const int stride = t.ncls + 1;
+  std::vector<char> set(t.ncap, 0);
+  auto apply = [&](uint32_t ops, int64_t pos) {
+    for (int c = 2; c < t.ncap; c++) if ((ops >> c) & 1u) if (!set[c]) { set[c] = 1; out[c] = (int32_t)pos; }
+  };
+  int j;
+  if (t.lookahead_mode) {
+    // match event is on the edge taken at position e (byte e or end of text)
+    uint16_t q = trace[e - s];
+    int k = e < len ? t.cls[buf[e]] : t.ncls;
+    uint32_t m = t.bt_match[(size_t)q * stride + k];
+    j = (int)(m >> 24);
+    apply(m & 0xFFFFFF, e);
+    for (int64_t i = e - 1; i >= s; i--) {
+      uint16_t qi = trace[i - s];
+      int ki = t.cls[buf[i]];
+      uint32_t base = t.bt_base[(size_t)qi * stride + ki];
+      apply(t.bt_ops[base + j], i);
+      j = t.bt_parent[base + j];
+    }
+  } else {
+    if (e == s) {
+      j = (int)t.st_nthreads[trace[0]] - 1;
+    } else {
+      uint16_t qe = trace[e - s];
+      j = (int)t.st_nthreads[qe] - 1;
+      for (int64_t i = e - 1; i >= s; i--) {
+        uint16_t qi = trace[i - s];
+        int ki = t.cls[buf[i]];
+        uint32_t base = t.bt_base[(size_t)qi * stride + ki];
+        apply(t.bt_ops[base + j], i + 1);
+        j = t.bt_parent[base + j];
+      }
+    }
+    apply(t.start_ops_pool[t.start_ops[ctx] + j], s);
+  }
+  // a group whose end slot is unset but start is set cannot happen on a winning path
+}
+}  // namespace
+
+extern "C" {
+
+const char* rgxt_last_error() { return g_err.c_str(); }
+
+void* rgxt_compile(const char* pattern, uint32_t flags) {
+  try {
+    auto* h = new Handle();
+    h->t = BuildTables(pattern, flags);
+    return h;
+  } catch (const SyntaxError& e) { g_err = "syntax: " + e.msg; }
+  catch (const Unsupported& e) { g_err = "unsupported: " + e.msg; }
+  catch (const TooLarge& e) { g_err = "too large: " + e.msg; }
+  return nullptr;
+}
+void rgxt_free(void* h) { delete (Handle*)h; }
+
+// Round-trip through the blob (exercises Serialize/Deserialize).
+void* rgxt_roundtrip(void* h) {
+  auto blob = SerializeTables(((Handle*)h)->t);
+  auto* n = new Handle();
+  if (!DeserializeTables(blob.data(), blob.size(), &n->t)) { delete n; g_err = "bad blob"; return nullptr; }
+  return n;
+}
+
+int rgxt_prog_dump(const char* pattern, char* dst, int cap) {
+  try {
+    RegexpPtr ast = Simplify(Parse(pattern, kPerl));
+    Prog p = Compile(ast);
+    std::string s = ast->Dump() + "\n" + p.Dump();
+    if ((int)s.size() + 1 > cap) return -(int)s.size() - 1;
+    memcpy(dst, s.c_str(), s.size() + 1);
+    return (int)s.size();
+  } catch (const SyntaxError& e) { g_err = "syntax: " + e.msg; return -1; }
+}
+
+int rgxt_info(void* hh, int32_t* out) {
+  const Tables& t = ((Handle*)hh)->t;
+  int32_t v[] = {t.ncap, t.min_len, t.max_len, t.n_inst, t.nstates, t.ncls, t.anchored, t.fixed_captures, t.can_match_empty,
+                 t.ref_match_engine, t.ref_find_engine, t.lookahead_mode, t.max_threads};
+  memcpy(out, v, sizeof v);
+  return sizeof v / sizeof v[0];
+}
+
+int rgxt_reset_bytes(void* hh, uint8_t* out256) { memcpy(out256, ((Handle*)hh)->t.reset_byte, 256); return 0; }
+
+// FindAllBytes semantics (find.go:130-316) on the tables.
+int64_t rgxt_find_all(void* hh, const uint8_t* buf, int64_t len, int64_t n, int32_t* spans, int64_t cap) {
+  const Tables& t = ((Handle*)hh)->t;
+  if (n == 0) return 0;
+  int64_t count = 0, pos = 0;
+  while (true) {
+    if (n > 0 && count >= n) break;
+    if (t.anchored && pos > 0) break;
+    if (pos >= len) break;
+    int64_t end = Walk(t, buf, len, pos, nullptr, nullptr);
+    if (end >= 0) {
+      if (count < cap) Captures(t, buf, len, pos, end, spans + count * t.ncap);
+      count++;
+      pos = end > pos ? end : pos + 1;
+    } else {
+      pos++;
+    }
+  }
+  return count;
+}
+
+// Plain leftmost-first "is there a match" (MatchBytes without the reference's Q1 restart quirk).
+int rgxt_match(void* hh, const uint8_t* buf, int64_t len) {
+  const Tables& t = ((Handle*)hh)->t;
+  for (int64_t pos = 0; pos <= len; pos++) {
+    if (t.anchored && pos > 0) break;
+    if (Walk(t, buf, len, pos, nullptr, nullptr) >= 0) return 1;
+  }
+  return 0;
+}
+}

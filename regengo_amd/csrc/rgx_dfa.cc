@@ -1,0 +1,520 @@
+// Table compiler (see rgx_dfa.h).  Subset construction over ORDERED thread lists so that the DFA
+// reproduces leftmost-first (backtracking-priority) match ends -- the semantics of the reference's
+// emitted StepSelect machine (/root/reference/internal/compiler/find.go:130-466): Alt prefers Out
+// (instructions.go:359-400), a thread list is cut below the first Match, the walk keeps the last match seen.
+#include "rgx_dfa.h"
+
+#include <algorithm>
+#include <bitset>
+#include <cstring>
+#include <functional>
+#include <map>
+
+namespace rgx {
+
+namespace {
+
+constexpr int kMatchNode = 1 << 30;
+
+struct Node {
+  std::bitset<256> bytes;
+  int next_node = -1;  // mid-sequence successor (multi-byte literal), else -1
+  int out_pc = -1;     // instruction to continue at when the rune is complete
+};
+
+struct Leaf {
+  int node;       // node id, or kMatchNode
+  int parent;     // index into the source list
+  uint32_t ops;   // capture slots assigned on the epsilon path
+};
+
+struct Builder {
+  const Prog& p;
+  int ninst;
+  std::vector<Node> nodes;  // index = node id (ids < ninst are rune instructions; others unused)
+  bool has_bol = false, has_eol = false, has_bot = false, has_eot = false, has_wb = false;
+  bool lookahead = false;
+  std::bitset<256> word_bytes, nl_bytes;
+  uint8_t cls[256];
+  int ncls = 0;
+  std::vector<std::bitset<256>> class_bytes;
+  std::vector<uint8_t> class_is_word, class_is_nl;
+
+  explicit Builder(const Prog& prog) : p(prog), ninst((int)prog.inst.size()) {
+    nodes.resize(ninst);
+    for (int c = 0; c < 256; c++)
+      if ((c >= '0' && c <= '9') || (c >= 'A' && c <= 'Z') || c == '_' || (c >= 'a' && c <= 'z')) word_bytes.set(c);
+    nl_bytes.set('\n');
+    for (int pc = 0; pc < ninst; pc++) {
+      const Inst& in = p.inst[pc];
+      switch (in.op) {
+        case InstRune1: {
+          int32_t r = in.rune[0];
+          if (r < 128) { nodes[pc].bytes.set(r); nodes[pc].out_pc = in.out; }
+          else {
+            // multi-byte literal: compare the UTF-8 bytes (instructions.go:134-175)
+            uint8_t e[4];
+            int n = EncodeRune(r, e);
+            int cur = pc;
+            for (int j = 0; j < n; j++) {
+              nodes[cur].bytes.set(e[j]);
+              if (j + 1 < n) { nodes.push_back(Node()); nodes[cur].next_node = (int)nodes.size() - 1; cur = nodes[cur].next_node; }
+              else nodes[cur].out_pc = in.out;
+            }
+          }
+          break;
+        }
+        case InstRune: {
+          const auto& R = in.rune;
+          if (R.size() == 1) {
+            // fold-case single rune (the reference's emitter is broken here, charclass.go:11-13); ASCII orbit.
+            int32_t r = R[0];
+            if (r >= 128) throw Unsupported{"case-folded non-ASCII literal"};
+            nodes[pc].bytes.set(r);
+            for (int32_t f = SimpleFold(r); f != r; f = SimpleFold(f)) if (f < 128) nodes[pc].bytes.set(f);
+            nodes[pc].out_pc = in.out;
+            break;
+          }
+          for (size_t i = 0; i + 1 < R.size(); i += 2)
+            if (R[i + 1] >= 128) throw Unsupported{"character class with non-ASCII runes (UTF-8 decoding classes)"};
+          for (size_t i = 0; i + 1 < R.size(); i += 2)
+            for (int32_t c = R[i]; c <= R[i + 1]; c++) nodes[pc].bytes.set(c);
+          nodes[pc].out_pc = in.out;
+          break;
+        }
+        case InstRuneAny:  // one BYTE (instructions.go:298-311), not one rune
+          nodes[pc].bytes.set();
+          nodes[pc].out_pc = in.out;
+          break;
+        case InstRuneAnyNotNL:
+          nodes[pc].bytes.set();
+          nodes[pc].bytes.reset('\n');
+          nodes[pc].out_pc = in.out;
+          break;
+        case InstEmptyWidth:
+          if (in.arg & EmptyBeginLine) has_bol = true;
+          if (in.arg & EmptyEndLine) has_eol = true;
+          if (in.arg & EmptyBeginText) has_bot = true;
+          if (in.arg & EmptyEndText) has_eot = true;
+          if (in.arg & (EmptyWordBoundary | EmptyNoWordBoundary)) has_wb = true;
+          break;
+        default: break;
+      }
+    }
+    lookahead = has_eol || has_eot || has_wb;
+    ComputeClasses();
+  }
+
+  void ComputeClasses() {
+    std::vector<std::bitset<256>> sets;
+    for (auto& n : nodes) if (n.bytes.any()) sets.push_back(n.bytes);
+    if (has_bol || has_eol) sets.push_back(nl_bytes);
+    if (has_wb) sets.push_back(word_bytes);
+    std::map<std::vector<bool>, int> sig2cls;
+    for (int c = 0; c < 256; c++) {
+      std::vector<bool> sig(sets.size());
+      for (size_t i = 0; i < sets.size(); i++) sig[i] = sets[i][c];
+      auto it = sig2cls.find(sig);
+      if (it == sig2cls.end()) { it = sig2cls.emplace(sig, (int)sig2cls.size()).first; class_bytes.emplace_back(); }
+      cls[c] = (uint8_t)it->second;
+      class_bytes[it->second].set(c);
+    }
+    ncls = (int)sig2cls.size();
+    class_is_word.resize(ncls);
+    class_is_nl.resize(ncls);
+    for (int k = 0; k < ncls; k++) {
+      int rep = 0;
+      while (!class_bytes[k][rep]) rep++;
+      class_is_word[k] = word_bytes[rep];
+      class_is_nl[k] = rep == '\n';
+    }
+  }
+
+  int ReduceCtx(int ctx) const {
+    if (ctx == kCtxWord && !has_wb) ctx = kCtxOther;
+    if (ctx == kCtxNL && !has_bol) ctx = kCtxOther;
+    if (ctx == kCtxBOT && !has_bot && !has_bol) ctx = kCtxOther;
+    return ctx;
+  }
+  int CtxOfClass(int k) const {
+    if (class_is_nl[k]) return ReduceCtx(kCtxNL);
+    if (class_is_word[k]) return ReduceCtx(kCtxWord);
+    return kCtxOther;
+  }
+  bool NodeAccepts(int node, int k) const {
+    int rep = 0;
+    while (!class_bytes[k][rep]) rep++;
+    return nodes[node].bytes[rep];
+  }
+
+  // Ordered epsilon-closure.  k: lookahead class (-1: none available = eager mode; ncls: end of text).
+  void Expand(const std::vector<int>& pre, int ctx, int k, std::vector<Leaf>* leaves, bool* matched, int* mparent,
+              uint32_t* mops) const {
+    std::vector<char> seen(nodes.size(), 0);
+    bool stop = false;
+    *matched = false;
+    std::function<void(int, int, uint32_t)> add = [&](int id, int parent, uint32_t ops) {
+      if (stop) return;
+      if (id >= ninst) {
+        if (!seen[id]) { seen[id] = 1; leaves->push_back({id, parent, ops}); }
+        return;
+      }
+      if (seen[id]) return;
+      seen[id] = 1;
+      const Inst& in = p.inst[id];
+      switch (in.op) {
+        case InstFail: return;
+        case InstMatch:
+          *matched = true; *mparent = parent; *mops = ops;
+          stop = true;  // threads below the first Match can never win (leftmost-first)
+          return;
+        case InstNop: add(in.out, parent, ops); return;
+        case InstCapture:
+          if (in.arg >= 32) throw Unsupported{"more than 15 capture groups"};
+          add(in.out, parent, ops | (1u << in.arg));
+          return;
+        case InstAlt: case InstAltMatch:
+          add(in.out, parent, ops);
+          add(in.arg, parent, ops);
+          return;
+        case InstEmptyWidth: {
+          uint32_t a = in.arg;
+          bool ok = true;
+          if ((a & EmptyBeginText) && ctx != kCtxBOT) ok = false;
+          if ((a & EmptyBeginLine) && !(ctx == kCtxBOT || ctx == kCtxNL)) ok = false;
+          if (a & (EmptyEndText | EmptyEndLine | EmptyWordBoundary | EmptyNoWordBoundary)) {
+            // needs the next byte: only legal in lookahead mode
+            bool eot = k == ncls;
+            if ((a & EmptyEndText) && !eot) ok = false;
+            if ((a & EmptyEndLine) && !(eot || class_is_nl[k])) ok = false;
+            bool pw = ctx == kCtxWord;
+            bool cw = !eot && class_is_word[k];
+            if ((a & EmptyWordBoundary) && pw == cw) ok = false;
+            if ((a & EmptyNoWordBoundary) && pw != cw) ok = false;
+          }
+          if (ok) add(in.out, parent, ops);
+          return;
+        }
+        default:  // byte-consuming
+          leaves->push_back({id, parent, ops});
+          return;
+      }
+    };
+    for (size_t i = 0; i < pre.size(); i++) add(pre[i], (int)i, 0);
+  }
+};
+
+// distance analysis for fixed capture templates
+constexpr int kUnknown = -1, kVar = -2;
+
+int InstWidth(const Prog& p, int pc) {
+  const Inst& in = p.inst[pc];
+  switch (in.op) {
+    case InstRune1: return in.rune[0] < 128 ? 1 : RuneLen(in.rune[0]);
+    case InstRune: case InstRuneAny: case InstRuneAnyNotNL: return 1;
+    default: return 0;
+  }
+}
+std::vector<int> Successors(const Prog& p, int pc) {
+  const Inst& in = p.inst[pc];
+  if (in.op == InstAlt || in.op == InstAltMatch) return {(int)in.out, (int)in.arg};
+  if (in.op == InstMatch || in.op == InstFail) return {};
+  return {(int)in.out};
+}
+
+}  // namespace
+
+Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOptions& opt) {
+  RegexpPtr ast = Simplify(Parse(pattern, kPerl));
+  Prog prog = Compile(ast);
+  Tables t;
+  t.pattern = pattern;
+  t.flags = flags;
+  t.ncap = prog.numcap;
+  t.n_inst = (int)prog.inst.size();
+  t.min_len = MinMatchLen(ast.get());
+  t.max_len = MaxMatchLen(ast.get());
+  t.anchored = IsAnchored(prog);
+  t.can_match_empty = t.min_len == 0;
+  t.cap_names = CaptureNames(ast);
+  t.cap_names.resize(prog.numcap / 2);
+  {
+    bool cat = DetectNestedQuantifiers(ast.get()), nl = DetectComplexity(prog), ea = HasEndAnchor(prog);
+    bool thompson = (cat || nl) && !ea;
+    t.ref_match_engine = (thompson && prog.inst.size() <= 64) ? 1 : ((nl || cat) ? 2 : 0);
+    t.ref_find_engine = prog.numcap <= 2 ? -1 : (cat ? 1 : 0);
+  }
+
+  Builder b(prog);
+  t.lookahead_mode = b.lookahead;
+  t.ncls = b.ncls;
+  memcpy(t.cls, b.cls, 256);
+  const int ncls = b.ncls, stride = ncls + 1;
+  for (int c = 0; c < 256; c++) t.ctx_of_byte[c] = (uint8_t)b.CtxOfClass(b.cls[c]);
+  t.ctx_sensitive = b.has_wb || b.has_bol;
+  t.bot_sensitive = b.has_bot || b.has_bol;
+
+  // ---- subset construction
+  struct St { std::vector<int> list; int ctx; };
+  std::map<std::pair<std::vector<int>, int>, int> ids;
+  std::vector<St> states;
+  states.push_back({{}, 0});  // dead
+  ids[{{}, 0}] = 0;
+  std::vector<std::vector<Leaf>> state_leaves;  // eager mode: leaves of each state (for parents)
+  state_leaves.emplace_back();
+
+  auto intern = [&](const std::vector<int>& list, int ctx) -> int {
+    if (list.empty()) return 0;
+    auto key = std::make_pair(list, ctx);
+    auto it = ids.find(key);
+    if (it != ids.end()) return it->second;
+    if ((int)states.size() >= opt.max_states || states.size() >= kStateMask) throw TooLarge{"DFA state budget exceeded"};
+    int id = (int)states.size();
+    states.push_back({list, ctx});
+    ids.emplace(key, id);
+    return id;
+  };
+
+  // eager mode: state list = leaf node ids (+kMatchNode last); lazy: pre-closure entries + ctx.
+  auto make_eager_state = [&](const std::vector<int>& pre, int ctx, std::vector<Leaf>* out_leaves) -> int {
+    std::vector<Leaf> leaves;
+    bool m; int mp = 0; uint32_t mo = 0;
+    b.Expand(pre, ctx, -1, &leaves, &m, &mp, &mo);
+    if (m) leaves.push_back({kMatchNode, mp, mo});
+    std::vector<int> list;
+    for (auto& l : leaves) list.push_back(l.node);
+    *out_leaves = leaves;
+    return intern(list, 0);
+  };
+
+  int start_ids[4];
+  std::vector<std::vector<Leaf>> start_leaves(4);
+  for (int ctx = 0; ctx < 4; ctx++) {
+    int rc = b.ReduceCtx(ctx);
+    if (!b.lookahead) {
+      start_ids[ctx] = make_eager_state({prog.start}, rc, &start_leaves[ctx]);
+    } else {
+      start_ids[ctx] = intern({prog.start}, rc);
+    }
+  }
+
+  // transition tables grow with the states
+  std::vector<uint16_t> trans;
+  std::vector<uint32_t> bt_base, bt_match, bt_ops;
+  std::vector<uint8_t> bt_parent;
+  for (size_t q = 0; q < states.size(); q++) {
+    trans.resize((q + 1) * stride, 0);
+    bt_base.resize((q + 1) * stride, 0xFFFFFFFFu);
+    bt_match.resize((q + 1) * stride, 0xFFFFFFFFu);
+    if (q == 0) continue;
+    const St st = states[q];
+    for (int k = 0; k <= ncls; k++) {
+      std::vector<Leaf> leaves;     // consuming leaves of the SOURCE state, with parents into st.list
+      bool matched = false; int mp = 0; uint32_t mo = 0;
+      if (b.lookahead) {
+        b.Expand(st.list, st.ctx, k, &leaves, &matched, &mp, &mo);
+        if (matched) {
+          if (mp > 255) throw TooLarge{"thread index"};
+          bt_match[q * stride + k] = ((uint32_t)mp << 24) | (mo & 0xFFFFFF);
+          if (mo >> 24) throw Unsupported{"more than 11 capture groups in lookahead mode"};
+        }
+      } else {
+        for (size_t j = 0; j < st.list.size(); j++)
+          if (st.list[j] != kMatchNode) leaves.push_back({st.list[j], (int)j, 0});
+      }
+      if (k == ncls) {  // end of text: nothing to consume
+        trans[q * stride + k] = matched ? kMatchBefore : 0;
+        continue;
+      }
+      // step
+      std::vector<int> pre; std::vector<int> pre_parent; std::vector<uint32_t> pre_ops;
+      for (auto& l : leaves) {
+        if (!b.NodeAccepts(l.node, k)) continue;
+        const Node& nd = b.nodes[l.node];
+        int target = nd.next_node >= 0 ? nd.next_node : nd.out_pc;
+        if (std::find(pre.begin(), pre.end(), target) != pre.end()) continue;  // lower priority duplicate
+        pre.push_back(target); pre_parent.push_back(l.parent); pre_ops.push_back(l.ops);
+      }
+      int nq;
+      uint16_t fl = matched ? kMatchBefore : 0;
+      size_t base = bt_parent.size();
+      if (b.lookahead) {
+        nq = intern(pre, b.CtxOfClass(k));
+        for (size_t j = 0; j < pre.size(); j++) {
+          if (pre_parent[j] > 255) throw TooLarge{"thread index"};
+          bt_parent.push_back((uint8_t)pre_parent[j]); bt_ops.push_back(pre_ops[j]);
+        }
+      } else {
+        std::vector<Leaf> nl;
+        nq = make_eager_state(pre, b.CtxOfClass(k), &nl);
+        for (auto& l : nl) {
+          int par = pre_parent[l.parent];
+          if (par > 255) throw TooLarge{"thread index"};
+          bt_parent.push_back((uint8_t)par); bt_ops.push_back(l.ops);
+        }
+        if (!nl.empty() && nl.back().node == kMatchNode) fl |= kMatchAfter;
+      }
+      if (nq != 0) bt_base[q * stride + k] = (uint32_t)base;
+      else { bt_parent.resize(base); bt_ops.resize(base); }
+      trans[q * stride + k] = (uint16_t)nq | fl;
+    }
+  }
+  t.nstates = (int)states.size();
+  t.trans = trans;
+  t.bt_base = bt_base; t.bt_match = bt_match; t.bt_parent = bt_parent; t.bt_ops = bt_ops;
+  t.st_nthreads.resize(states.size());
+  for (size_t q = 0; q < states.size(); q++) {
+    t.st_nthreads[q] = (uint32_t)states[q].list.size();
+    t.max_threads = std::max(t.max_threads, (int)states[q].list.size());
+  }
+  t.start_ops.resize(4);
+  for (int ctx = 0; ctx < 4; ctx++) {
+    t.start[ctx] = (uint16_t)start_ids[ctx];
+    t.start_ops[ctx] = (uint32_t)t.start_ops_pool.size();
+    if (!b.lookahead) {
+      for (auto& l : start_leaves[ctx]) t.start_ops_pool.push_back(l.ops);
+      t.start_accept[ctx] = !start_leaves[ctx].empty() && start_leaves[ctx].back().node == kMatchNode;
+    }
+  }
+
+  // ---- reset classes: every live state dies on the byte
+  for (int k = 0; k < ncls; k++) {
+    bool all_dead = true;
+    for (int q = 1; q < t.nstates && all_dead; q++)
+      if ((trans[q * stride + k] & kStateMask) != kDead) all_dead = false;
+    if (all_dead)
+      for (int c = 0; c < 256; c++) if (b.cls[c] == k) t.reset_byte[c] = 1;
+  }
+
+  // ---- fixed capture templates
+  {
+    const int n = (int)prog.inst.size();
+    auto propagate = [&](bool forward) {
+      std::vector<int> d(n, kUnknown);
+      std::vector<std::vector<int>> adj(n);
+      for (int pc = 0; pc < n; pc++)
+        for (int s : Successors(prog, pc)) { if (forward) adj[pc].push_back(s); else adj[s].push_back(pc); }
+      int match_pc = -1;
+      for (int pc = 0; pc < n; pc++) if (prog.inst[pc].op == InstMatch) match_pc = pc;
+      std::vector<int> work;
+      int root = forward ? prog.start : match_pc;
+      d[root] = 0;
+      work.push_back(root);
+      while (!work.empty()) {
+        int u = work.back(); work.pop_back();
+        for (int v : adj[u]) {
+          // forward: dist[v] = dist[u] + width(u); backward: dist[v] = dist[u] + width(v)
+          int w = forward ? InstWidth(prog, u) : InstWidth(prog, v);
+          int nv = d[u] == kVar ? kVar : d[u] + w;
+          if (nv > 1000000) nv = kVar;
+          if (d[v] == kUnknown) { d[v] = nv; work.push_back(v); }
+          else if (d[v] != nv && d[v] != kVar) { d[v] = kVar; work.push_back(v); }
+        }
+      }
+      return d;
+    };
+    std::vector<int> dfs = propagate(true), dtm = propagate(false);
+    auto mandatory = [&](int pc) {
+      std::vector<char> seen(n, 0);
+      std::vector<int> st{prog.start};
+      if (prog.start == pc) return true;
+      seen[prog.start] = 1;
+      while (!st.empty()) {
+        int u = st.back(); st.pop_back();
+        if (prog.inst[u].op == InstMatch) return false;
+        for (int v : Successors(prog, u)) if (v != pc && !seen[v]) { seen[v] = 1; st.push_back(v); }
+      }
+      return true;
+    };
+    t.cap_kind.assign(t.ncap, kCapDynamic);
+    t.cap_delta.assign(t.ncap, 0);
+    t.cap_kind[0] = kCapFromStart; t.cap_kind[1] = kCapFromEnd;
+    bool all_fixed = true;
+    for (int c = 2; c < t.ncap; c++) {
+      std::vector<int> pcs;
+      for (int pc = 0; pc < n; pc++) if (prog.inst[pc].op == InstCapture && (int)prog.inst[pc].arg == c) pcs.push_back(pc);
+      if (pcs.size() == 1 && dfs[pcs[0]] != kUnknown && mandatory(pcs[0])) {
+        int pc = pcs[0];
+        if (dfs[pc] >= 0) { t.cap_kind[c] = kCapFromStart; t.cap_delta[c] = dfs[pc]; continue; }
+        if (dtm[pc] >= 0) { t.cap_kind[c] = kCapFromEnd; t.cap_delta[c] = dtm[pc]; continue; }
+      }
+      all_fixed = false;
+    }
+    t.fixed_captures = all_fixed;
+  }
+  return t;
+}
+
+std::string Tables::Describe() const {
+  char buf[256];
+  snprintf(buf, sizeof buf, "states=%d classes=%d lookahead=%d fixed_caps=%d anchored=%d min=%d max=%d threads<=%d", nstates,
+           ncls, (int)lookahead_mode, (int)fixed_captures, (int)anchored, min_len, max_len, max_threads);
+  return buf;
+}
+
+// ---------------------------------------------------------------- blob
+namespace {
+struct W {
+  std::vector<uint8_t> b;
+  template <class T> void pod(const T& v) { const uint8_t* p = (const uint8_t*)&v; b.insert(b.end(), p, p + sizeof(T)); }
+  template <class T> void vec(const std::vector<T>& v) { pod<uint64_t>(v.size()); const uint8_t* p = (const uint8_t*)v.data(); b.insert(b.end(), p, p + v.size() * sizeof(T)); }
+  void str(const std::string& s) { pod<uint64_t>(s.size()); b.insert(b.end(), s.begin(), s.end()); }
+  void raw(const void* p, size_t n) { b.insert(b.end(), (const uint8_t*)p, (const uint8_t*)p + n); }
+};
+struct R {
+  const uint8_t* p; size_t n; size_t o = 0; bool ok = true;
+  template <class T> void pod(T& v) { if (o + sizeof(T) > n) { ok = false; return; } memcpy(&v, p + o, sizeof(T)); o += sizeof(T); }
+  template <class T> void vec(std::vector<T>& v) {
+    uint64_t k = 0; pod(k);
+    if (!ok || k > (n - o) / sizeof(T)) { ok = false; return; }
+    v.resize(k); memcpy(v.data(), p + o, k * sizeof(T)); o += k * sizeof(T);
+  }
+  void str(std::string& s) { uint64_t k = 0; pod(k); if (!ok || k > n - o) { ok = false; return; } s.assign((const char*)p + o, k); o += k; }
+  void raw(void* d, size_t k) { if (o + k > n) { ok = false; return; } memcpy(d, p + o, k); o += k; }
+};
+constexpr uint32_t kMagic = 0x54584752;  // "RGXT"
+constexpr uint32_t kBlobVersion = 1;
+}  // namespace
+
+std::vector<uint8_t> SerializeTables(const Tables& t) {
+  W w;
+  w.pod(kMagic); w.pod(kBlobVersion);
+  w.str(t.pattern); w.pod(t.flags); w.pod<int32_t>(t.ncap); w.pod<int32_t>(t.n_inst); w.pod<int32_t>(t.min_len); w.pod<int32_t>(t.max_len);
+  w.pod<uint8_t>(t.anchored); w.pod<uint8_t>(t.can_match_empty); w.pod<uint8_t>(t.lookahead_mode); w.pod<uint8_t>(t.fixed_captures);
+  w.pod<int32_t>(t.ref_match_engine); w.pod<int32_t>(t.ref_find_engine);
+  w.pod<uint64_t>(t.cap_names.size());
+  for (auto& s : t.cap_names) w.str(s);
+  w.pod<int32_t>(t.ncls); w.raw(t.cls, 256); w.pod<int32_t>(t.nstates); w.vec(t.trans);
+  w.raw(t.start, sizeof t.start); w.raw(t.start_accept, sizeof t.start_accept); w.raw(t.ctx_of_byte, 256);
+  w.pod<uint8_t>(t.ctx_sensitive); w.pod<uint8_t>(t.bot_sensitive); w.raw(t.reset_byte, 256);
+  w.vec(t.cap_kind); w.vec(t.cap_delta); w.vec(t.st_nthreads); w.vec(t.bt_base); w.vec(t.bt_parent); w.vec(t.bt_ops);
+  w.vec(t.bt_match); w.vec(t.start_ops); w.vec(t.start_ops_pool); w.pod<int32_t>(t.max_threads);
+  return w.b;
+}
+
+bool DeserializeTables(const uint8_t* p, size_t n, Tables* t) {
+  R r{p, n};
+  uint32_t magic = 0, ver = 0;
+  r.pod(magic); r.pod(ver);
+  if (!r.ok || magic != kMagic || ver != kBlobVersion) return false;
+  int32_t i32; uint8_t u8;
+  r.str(t->pattern); r.pod(t->flags);
+  r.pod(i32); t->ncap = i32; r.pod(i32); t->n_inst = i32; r.pod(i32); t->min_len = i32; r.pod(i32); t->max_len = i32;
+  r.pod(u8); t->anchored = u8; r.pod(u8); t->can_match_empty = u8; r.pod(u8); t->lookahead_mode = u8; r.pod(u8); t->fixed_captures = u8;
+  r.pod(i32); t->ref_match_engine = i32; r.pod(i32); t->ref_find_engine = i32;
+  uint64_t k = 0; r.pod(k);
+  if (!r.ok || k > 4096) return false;
+  t->cap_names.resize(k);
+  for (auto& s : t->cap_names) r.str(s);
+  r.pod(i32); t->ncls = i32; r.raw(t->cls, 256); r.pod(i32); t->nstates = i32; r.vec(t->trans);
+  r.raw(t->start, sizeof t->start); r.raw(t->start_accept, sizeof t->start_accept); r.raw(t->ctx_of_byte, 256);
+  r.pod(u8); t->ctx_sensitive = u8; r.pod(u8); t->bot_sensitive = u8; r.raw(t->reset_byte, 256);
+  r.vec(t->cap_kind); r.vec(t->cap_delta); r.vec(t->st_nthreads); r.vec(t->bt_base); r.vec(t->bt_parent); r.vec(t->bt_ops);
+  r.vec(t->bt_match); r.vec(t->start_ops); r.vec(t->start_ops_pool); r.pod(i32); t->max_threads = i32;
+  if (!r.ok) return false;
+  if (t->ncls < 1 || t->ncls > 256 || t->nstates < 1 || t->trans.size() != (size_t)t->nstates * (t->ncls + 1)) return false;
+  if ((int)t->cap_kind.size() != t->ncap || (int)t->cap_delta.size() != t->ncap) return false;
+  return true;
+}
+
+}  // namespace rgx

@@ -1,0 +1,85 @@
+// Table compiler: syntax.Prog -> anchored leftmost-first DFA over byte classes, plus the side tables the
+// kernels need (sync/"reset" classes, fixed capture templates, per-transition thread parents for capture
+// back-tracing).  This replaces the reference's per-instruction Go emitters
+// (/root/reference/internal/compiler/instructions.go:51-605, charclass.go:10-269) and its TDFA table
+// emitter (tdfa.go:111-539,584-794) with one flat, LDS-sized representation.
+#pragma once
+#include <cstdint>
+#include <string>
+#include <vector>
+
+#include "rgx_syntax.h"
+
+namespace rgx {
+
+constexpr uint16_t kDead = 0;          // state 0 is the dead state
+constexpr uint16_t kStateMask = 0x3FFF;
+constexpr uint16_t kMatchAfter = 0x4000;   // a match ends right AFTER the byte of this edge
+constexpr uint16_t kMatchBefore = 0x8000;  // a match ends right BEFORE the byte of this edge (lookahead mode)
+
+enum StartCtx { kCtxBOT = 0, kCtxNL = 1, kCtxWord = 2, kCtxOther = 3 };
+
+enum CapKind : uint8_t { kCapFromStart = 0, kCapFromEnd = 1, kCapUnset = 2, kCapDynamic = 3 };
+
+struct Unsupported {
+  std::string msg;
+};
+struct TooLarge {
+  std::string msg;
+};
+
+struct Tables {
+  // ---- identity / analysis (rgx_info)
+  std::string pattern;
+  uint32_t flags = 0;
+  int ncap = 2;
+  int n_inst = 0;
+  int min_len = 0, max_len = 0;
+  bool anchored = false;
+  bool can_match_empty = false;
+  bool lookahead_mode = false;
+  bool fixed_captures = false;
+  int ref_match_engine = 0, ref_find_engine = 0;
+  std::vector<std::string> cap_names;
+
+  // ---- automaton
+  int ncls = 0;                   // byte classes; class id ncls is end-of-text
+  uint8_t cls[256] = {0};
+  int nstates = 0;                // including dead state 0
+  std::vector<uint16_t> trans;    // [nstates][ncls+1]
+  uint16_t start[4] = {0, 0, 0, 0};     // per StartCtx
+  uint8_t start_accept[4] = {0, 0, 0, 0};  // eager mode: empty match at the start position
+  uint8_t ctx_of_byte[256] = {0}; // StartCtx implied by the previous byte (kCtxNL/kCtxWord/kCtxOther)
+  bool ctx_sensitive = false;     // start state depends on the previous byte
+  bool bot_sensitive = false;     // start state at offset 0 differs
+  uint8_t reset_byte[256] = {0};  // 1: every live state dies on this byte => the next offset is a sync point
+
+  // ---- captures
+  std::vector<uint8_t> cap_kind;  // [ncap]
+  std::vector<int32_t> cap_delta; // [ncap]
+  // back-trace tables (dynamic captures): per state an offset into a thread pool; per (state, class, thread)
+  // the parent thread index in the source state and the capture slots assigned on that edge.
+  std::vector<uint32_t> st_nthreads;   // [nstates]
+  std::vector<uint32_t> bt_base;       // [nstates*(ncls+1)] -> index into bt_parent/bt_ops, or 0xFFFFFFFF
+  std::vector<uint8_t> bt_parent;      // parent thread index per target thread
+  std::vector<uint32_t> bt_ops;        // capture-slot bitmask set on the edge
+  std::vector<uint32_t> bt_match;      // [nstates*(ncls+1)]: (parent<<24 | ops) for the match event, or 0xFFFFFFFF
+  std::vector<uint32_t> start_ops;     // per ctx: offset into start_ops_pool
+  std::vector<uint32_t> start_ops_pool;// capture masks assigned by the initial closure, per thread
+  int max_threads = 0;
+
+  std::string Describe() const;
+};
+
+struct BuildOptions {
+  int max_states = 12000;
+};
+
+// Throws SyntaxError / Unsupported / TooLarge.
+Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOptions& opt = BuildOptions());
+
+// Blob (versioned, little-endian, self-describing) -- what the code generator would write beside the cgo stub.
+std::vector<uint8_t> SerializeTables(const Tables& t);
+bool DeserializeTables(const uint8_t* p, size_t n, Tables* out);
+
+}  // namespace rgx
