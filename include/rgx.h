@@ -96,6 +96,8 @@ int rgx_stream_ctx_create(const rgx_program* p, rgx_stream_ctx** out);
 void rgx_stream_ctx_destroy(rgx_stream_ctx* c);
 /* The HIP stream (hipStream_t) a ctx launches on; lets a caller order its own copies/events.       */
 void* rgx_stream_ctx_hip_stream(const rgx_stream_ctx* c);
+/* Bracket the scan kernel with HIP events on the ctx stream; rgx_result.kernel_ms then holds its duration. */
+int rgx_stream_ctx_set_timing(rgx_stream_ctx* c, int on);
 
 /* ---- run time ---------------------------------------------------------------------------------- */
 typedef struct rgx_result {

@@ -1,0 +1,109 @@
+"""ctypes binding of the C ABI in include/rgx.h (librgx_hip.so, built in-tree by regengo_amd/build.py).
+
+There is deliberately no fallback: if the library is missing, or a compute call is made without a usable
+GPU, this raises.  The matching itself only ever runs in the HIP kernels.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+from . import build as _build
+
+
+class RgxError(RuntimeError):
+    def __init__(self, status: int, msg: str):
+        super().__init__("rgx status %d (%s): %s" % (status, _STATUS.get(status, "?"), msg))
+        self.status = status
+
+
+_STATUS = {0: "ok", -1: "invalid", -2: "syntax", -3: "unsupported", -4: "too large", -5: "no device", -6: "hip",
+           -7: "nomem", -8: "capacity", -9: "bad blob", -10: "buffer too small"}
+
+RGX_OK = 0
+RGX_E_SYNTAX = -2
+RGX_E_UNSUPPORTED = -3
+RGX_E_NO_DEVICE = -5
+RGX_E_CAPACITY = -8
+RGX_E_BUFFER_TOO_SMALL = -10
+FLAG_UNMATCHED_MINUS1 = 1
+FLAG_STDLIB_SEMANTICS = 2
+
+
+class Info(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "abi_version", "ncap", "min_match_len", "max_match_len", "default_max_leftover", "min_buffer_size", "n_inst",
+        "n_states", "n_classes", "anchored", "fixed_captures", "can_match_empty", "ref_match_engine", "ref_find_engine",
+        "lookahead_mode", "table_bytes")]
+
+
+class Result(C.Structure):
+    _fields_ = [("total", C.c_int64), ("written", C.c_int64), ("ncap", C.c_int32), ("unsynced", C.c_int32),
+                ("kernel_ms", C.c_float)]
+
+
+class StreamConfig(C.Structure):
+    _fields_ = [("buffer_size", C.c_int64), ("max_leftover", C.c_int64)]
+
+
+# every symbol include/rgx.h declares; tests check the library exports each of them
+SYMBOLS = {
+    "rgx_compile": (C.c_int, [C.c_char_p, C.c_uint32, C.POINTER(C.c_void_p)]),
+    "rgx_program_blob_size": (C.c_int64, [C.c_void_p]),
+    "rgx_program_blob_write": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rgx_program_from_blob": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "rgx_program_destroy": (None, [C.c_void_p]),
+    "rgx_program_info": (C.c_int, [C.c_void_p, C.POINTER(Info)]),
+    "rgx_program_capture_names": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rgx_device_count": (C.c_int, []),
+    "rgx_program_to_device": (C.c_int, [C.c_void_p, C.c_int]),
+    "rgx_stream_ctx_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rgx_stream_ctx_destroy": (None, [C.c_void_p]),
+    "rgx_stream_ctx_hip_stream": (C.c_void_p, [C.c_void_p]),
+    "rgx_stream_ctx_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "rgx_match_bytes_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
+    "rgx_find_all_bytes_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p,
+                                              C.c_size_t, C.POINTER(Result)]),
+    "rgx_find_all_bytes": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t,
+                                       C.POINTER(Result)]),
+    "rgx_count_all_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Result)]),
+    "rgx_find_batch_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
+                                          C.c_void_p]),
+    "rgx_match_batch_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rgx_stream_config_resolve": (C.c_int, [C.c_void_p, C.POINTER(StreamConfig), C.POINTER(StreamConfig)]),
+    "rgx_find_chunk": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int64, C.c_void_p,
+                                   C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(Result)]),
+    "rgx_last_error": (C.c_char_p, []),
+    "rgx_status_str": (C.c_char_p, [C.c_int]),
+}
+
+_lib = None
+
+
+def lib():
+    """Load librgx_hip.so (building it if the sources changed).  Raises if it cannot be had."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.product_lib_path()
+    if os.environ.get("RGX_NO_BUILD") != "1":
+        try:
+            path = _build.build_product()
+        except Exception:
+            if not os.path.exists(path):
+                raise
+    if not os.path.exists(path):
+        raise RuntimeError("librgx_hip.so is missing: the HIP extension is required (no CPU fallback exists)")
+    L = C.CDLL(path)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(L, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = L
+    return L
+
+
+def check(rc: int) -> int:
+    if rc < 0:
+        raise RgxError(int(rc), (lib().rgx_last_error() or b"").decode("utf-8", "replace"))
+    return rc

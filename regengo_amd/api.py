@@ -1,0 +1,298 @@
+"""Host-side mirror of the reference's generated `Compiled<Name>` API over the C ABI.
+
+The reference emits, per pattern, a zero-size struct with ~40 methods (README.md:99-146).  This module keeps
+the names, argument meaning and error behaviour of the hot-path ones -- MatchBytes, FindBytes, FindAllBytes,
+FindReader, FindReaderCount, FindReaderFirst, MatchLengthInfo, DefaultMaxLeftover -- so the parity tests read
+like the reference's own generated tests (internal/compiler/test_gen.go:72-239).  PyTorch is used for device
+memory only; the matching runs in librgx_hip.so.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Callable, List, Optional, Sequence
+
+from . import _capi
+from .stream import Config, ErrBufferTooSmall, Match
+
+
+def upper_first(s: str) -> str:  # internal/codegen/constants.go:34-40
+    return s[:1].upper() + s[1:] if s else s
+
+
+def field_names(cap_names: Sequence[str]) -> List[str]:
+    """Result-struct field names, captures.go:63-76: UpperFirst(name) | Group<i>, collision -> suffix <i>."""
+    used = {"Match"}
+    out = ["Match"]
+    for i in range(1, len(cap_names)):
+        f = upper_first(cap_names[i]) if cap_names[i] else "Group%d" % i
+        if f in used:
+            f = "%s%d" % (f, i)
+        used.add(f)
+        out.append(f)
+    return out
+
+
+class BytesResult:
+    """`<Name>BytesResult` (captures.go:45-118): one `[]byte` per group, aliasing the input."""
+    __slots__ = ("_fields", "_vals", "spans")
+
+    def __init__(self, fields, vals, spans):
+        self._fields = fields
+        self._vals = vals
+        self.spans = spans
+
+    def __getattr__(self, k):
+        try:
+            return self._vals[self._fields.index(k)]
+        except ValueError:
+            raise AttributeError(k)
+
+    def CaptureByIndex(self, idx: int):
+        return self._vals[idx] if 0 <= idx < len(self._vals) else None
+
+    def __repr__(self):
+        return "BytesResult(%s)" % ", ".join("%s=%r" % kv for kv in zip(self._fields, self._vals))
+
+
+class Compiled:
+    def __init__(self, pattern: str, name: str = "Pattern", flags: int = 0, device: Optional[int] = None):
+        self._lib = _capi.lib()
+        self.pattern = pattern
+        self.name = name
+        h = C.c_void_p()
+        _capi.check(self._lib.rgx_compile(pattern.encode("utf-8"), flags, C.byref(h)))
+        self._h = h
+        self._ctx = None
+        self._device = None
+        info = _capi.Info()
+        _capi.check(self._lib.rgx_program_info(self._h, C.byref(info)))
+        self.info = info
+        n = self._lib.rgx_program_capture_names(self._h, None, 0)
+        buf = C.create_string_buffer(int(n) + 1)
+        self._lib.rgx_program_capture_names(self._h, buf, n)
+        self.capture_names = buf.raw[:n].decode("utf-8").split("\0")[:-1]
+        self.fields = field_names(self.capture_names)
+        self.ncap = info.ncap
+        self.MinMatchLen = info.min_match_len
+        self.MaxMatchLen = info.max_match_len
+        if device is not None:
+            self.to(device)
+
+    # ---- lifecycle
+    def __del__(self):
+        try:
+            if getattr(self, "_ctx", None):
+                self._lib.rgx_stream_ctx_destroy(self._ctx)
+            if getattr(self, "_h", None):
+                self._lib.rgx_program_destroy(self._h)
+        except Exception:
+            pass
+
+    def blob(self) -> bytes:
+        n = _capi.check(self._lib.rgx_program_blob_size(self._h))
+        b = C.create_string_buffer(n)
+        _capi.check(self._lib.rgx_program_blob_write(self._h, b, n))
+        return b.raw
+
+    def to(self, device: int = 0) -> "Compiled":
+        _capi.check(self._lib.rgx_program_to_device(self._h, device))
+        if self._ctx is None:
+            c = C.c_void_p()
+            _capi.check(self._lib.rgx_stream_ctx_create(self._h, C.byref(c)))
+            self._ctx = c
+        self._device = device
+        return self
+
+    def set_timing(self, on: bool = True):
+        self._need_dev()
+        self._lib.rgx_stream_ctx_set_timing(self._ctx, 1 if on else 0)
+
+    def _need_dev(self):
+        if self._ctx is None:
+            self.to(0)
+
+    # ---- generated-API surface
+    def MatchLengthInfo(self):
+        return self.MinMatchLen, self.MaxMatchLen
+
+    def DefaultMaxLeftover(self) -> int:
+        return self.info.default_max_leftover
+
+    def _as_device(self, data):
+        """bytes-like or torch tensor -> (tensor on the program's device, length)."""
+        import torch
+        if isinstance(data, torch.Tensor):
+            t = data
+            if t.dtype != torch.uint8:
+                raise TypeError("input tensor must be uint8")
+            if not t.is_cuda:
+                t = t.to("cuda:%d" % self._device)
+            return t.contiguous(), t.numel()
+        b = bytes(data)
+        t = torch.frombuffer(bytearray(b), dtype=torch.uint8) if len(b) else torch.empty(0, dtype=torch.uint8)
+        return t.to("cuda:%d" % self._device), len(b)
+
+    def MatchBytes(self, data) -> bool:
+        self._need_dev()
+        t, n = self._as_device(data)
+        m = C.c_int(0)
+        _capi.check(self._lib.rgx_match_bytes_device(self._h, self._ctx, t.data_ptr() if n else None, n, C.byref(m)))
+        return bool(m.value)
+
+    MatchString = MatchBytes
+
+    def FindAllSpans(self, data, n: int = -1, capacity: Optional[int] = None, out=None):
+        """Flat accessor next to the drop-in slice-of-structs: int32 tensor [count, ncap] on the device.
+        Returns (spans, result)."""
+        import torch
+        self._need_dev()
+        t, ln = self._as_device(data)
+        res = _capi.Result()
+        if n == 0 or ln == 0:
+            return torch.empty((0, self.ncap), dtype=torch.int32, device=t.device), res
+        if capacity is None:
+            capacity = ln // max(self.MinMatchLen, 1) + 1
+            if n > 0:
+                capacity = min(capacity, n)
+        if out is None or out.numel() < capacity * self.ncap:
+            out = torch.empty((capacity, self.ncap), dtype=torch.int32, device=t.device)
+        w = self._lib.rgx_find_all_bytes_device(self._h, self._ctx, t.data_ptr(), ln, n, out.data_ptr(), capacity,
+                                                C.byref(res))
+        _capi.check(w)
+        return out.view(-1, self.ncap)[:w], res
+
+    def CountAll(self, data):
+        self._need_dev()
+        t, ln = self._as_device(data)
+        res = _capi.Result()
+        w = _capi.check(self._lib.rgx_count_all_device(self._h, self._ctx, t.data_ptr() if ln else None, ln, C.byref(res)))
+        return int(w), res
+
+    def _make_result(self, src: bytes, rec) -> BytesResult:
+        vals = []
+        for g in range(self.ncap // 2):
+            a, b = int(rec[2 * g]), int(rec[2 * g + 1])
+            # find.go:394-406: `if captures[a] <= captures[b] && captures[b] <= len(input) { input[a:b] } else { nil }`
+            vals.append(src[a:b] if 0 <= a <= b <= len(src) else None)
+        return BytesResult(self.fields, vals, [int(x) for x in rec])
+
+    def FindAllBytes(self, data, n: int = -1) -> List[BytesResult]:
+        src = bytes(data) if not hasattr(data, "is_cuda") else bytes(data.cpu().numpy().tobytes())
+        spans, _ = self.FindAllSpans(data, n)
+        return [self._make_result(src, r) for r in spans.cpu().tolist()]
+
+    def FindBytes(self, data):
+        """(result, ok).  First leftmost-first match (FindBytesReuse without the Q1 restart quirk)."""
+        r = self.FindBatch([bytes(data)])
+        return (r[0], True) if r[0] is not None else (None, False)
+
+    def FindBatch(self, strings: Sequence[bytes]):
+        import torch
+        self._need_dev()
+        offs = [0]
+        for s in strings:
+            offs.append(offs[-1] + len(s))
+        dev = "cuda:%d" % self._device
+        concat = torch.frombuffer(bytearray(b"".join(strings) or b"\0"), dtype=torch.uint8).to(dev)
+        offsets = torch.tensor(offs, dtype=torch.int64, device=dev)
+        found, spans = self.FindBatchDevice(concat, offsets)
+        f = found.cpu().tolist()
+        sp = spans.cpu().tolist()
+        return [self._make_result(strings[i], sp[i]) if f[i] else None for i in range(len(strings))]
+
+    def FindBatchDevice(self, concat, offsets):
+        import torch
+        self._need_dev()
+        nstr = offsets.numel() - 1
+        found = torch.empty(nstr, dtype=torch.uint8, device=concat.device)
+        spans = torch.empty((nstr, self.ncap), dtype=torch.int32, device=concat.device)
+        _capi.check(self._lib.rgx_find_batch_device(self._h, self._ctx, concat.data_ptr(), offsets.data_ptr(), nstr,
+                                                    found.data_ptr(), spans.data_ptr()))
+        return found, spans
+
+    def MatchBatchDevice(self, concat, offsets):
+        import torch
+        self._need_dev()
+        nstr = offsets.numel() - 1
+        m = torch.empty(nstr, dtype=torch.uint8, device=concat.device)
+        _capi.check(self._lib.rgx_match_batch_device(self._h, self._ctx, concat.data_ptr(), offsets.data_ptr(), nstr,
+                                                     m.data_ptr()))
+        return m
+
+    # ---- streaming (streaming.go:85-317)
+    def _resolve(self, cfg: Config) -> Config:
+        cin = _capi.StreamConfig(cfg.BufferSize, cfg.MaxLeftover)
+        cout = _capi.StreamConfig()
+        rc = self._lib.rgx_stream_config_resolve(self._h, C.byref(cin), C.byref(cout))
+        if rc == _capi.RGX_E_BUFFER_TOO_SMALL:
+            raise ErrBufferTooSmall(cfg.BufferSize, self.info.min_buffer_size)
+        _capi.check(rc)
+        return Config(cout.buffer_size, cout.max_leftover)
+
+    def FindReader(self, r, cfg: Config, on_match: Callable[[Match], bool]) -> None:
+        """`r.read(k)` returns up to k bytes, b"" at EOF.  Raises ErrBufferTooSmall like Config.Validate; reader
+        errors propagate.  Results are only valid during the callback (stream.go:51-65)."""
+        self._need_dev()
+        cfg = self._resolve(cfg)
+        buf = bytearray(cfg.BufferSize)
+        leftover = 0
+        stream_offset = 0
+        chunk_index = 0
+        cap = cfg.BufferSize // max(self.MinMatchLen, 1) + 2
+        spans = (C.c_int32 * (cap * self.ncap))()
+        committed = C.c_int64()
+        keep = C.c_int64()
+        res = _capi.Result()
+        while True:
+            data = r.read(cfg.BufferSize - leftover)
+            n = len(data)
+            if n == 0:
+                is_full, data_len = False, leftover
+                if leftover == 0:
+                    return
+            else:
+                buf[leftover:leftover + n] = data
+                data_len = leftover + n
+                is_full = n == cfg.BufferSize - leftover
+            cbuf = (C.c_uint8 * data_len).from_buffer(buf)
+            w = _capi.check(self._lib.rgx_find_chunk(self._h, self._ctx, cbuf, data_len, 1 if is_full else 0,
+                                                     cfg.MaxLeftover, spans, cap, C.byref(committed), C.byref(keep),
+                                                     C.byref(res)))
+            del cbuf
+            chunk = bytes(buf[:data_len])
+            for i in range(w):
+                rec = spans[i * self.ncap:(i + 1) * self.ncap]
+                m = Match(self._make_result(chunk, rec), stream_offset + rec[0], chunk_index)
+                if not on_match(m):
+                    return
+            if n == 0:
+                return
+            if is_full:
+                k = keep.value
+                leftover = data_len - k
+                stream_offset += k
+                buf[:leftover] = buf[k:data_len]
+            else:
+                leftover = 0
+            chunk_index += 1
+
+    def FindReaderCount(self, r, cfg: Config) -> int:
+        cnt = 0
+
+        def cb(_m):
+            nonlocal cnt
+            cnt += 1
+            return True
+
+        self.FindReader(r, cfg, cb)
+        return cnt
+
+    def FindReaderFirst(self, r, cfg: Config):
+        out = [None, 0]
+
+        def cb(m):
+            out[0], out[1] = m.Result, m.StreamOffset
+            return False
+
+        self.FindReader(r, cfg, cb)
+        return out[0], out[1]

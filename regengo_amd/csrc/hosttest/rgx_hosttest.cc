@@ -157,6 +157,30 @@ int64_t rgxt_find_all(void* hh, const uint8_t* buf, int64_t len, int64_t n, int3
   return count;
 }
 
+// Same, but driven the way the scan kernel's Shift-And path is: level-set candidates, DFA verification
+// (or none when the level sets are exact).  Returns -2 when the pattern has no prefilter.
+int64_t rgxt_find_all_sa(void* hh, const uint8_t* buf, int64_t len, int32_t* spans, int64_t cap) {
+  const Tables& t = ((Handle*)hh)->t;
+  if (t.sa_k <= 0 || t.anchored) return -2;
+  const int K = t.sa_k;
+  const uint32_t top = 1u << (K - 1);
+  int64_t count = 0, pos = 0;
+  uint32_t D = 0;
+  for (int64_t i = 0; i < len; i++) {
+    D = ((D << 1) | 1u) & t.sa_mask[buf[i]];
+    if (!(D & top)) continue;
+    int64_t s = i - K + 1;
+    if (s < pos) continue;
+    int64_t e = t.sa_exact ? s + K : Walk(t, buf, len, s, nullptr, nullptr);
+    if (e < 0) continue;
+    if (count < cap) Captures(t, buf, len, s, e, spans + count * t.ncap);
+    count++;
+    pos = e > s ? e : s + 1;
+  }
+  return count;
+}
+int rgxt_sa_info(void* hh, int32_t* k, int32_t* exact) { *k = ((Handle*)hh)->t.sa_k; *exact = ((Handle*)hh)->t.sa_exact; return 0; }
+
 // Plain leftmost-first "is there a match" (MatchBytes without the reference's Q1 restart quirk).
 int rgxt_match(void* hh, const uint8_t* buf, int64_t len) {
   const Tables& t = ((Handle*)hh)->t;

@@ -1,0 +1,419 @@
+// extern "C" surface (include/rgx.h).  No CPU matcher lives here: every compute entry point launches the HIP
+// kernels or fails with a negative status.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "rgx.h"
+#include "rgx_kernels.h"
+#include "rgx_program.h"
+
+#define RGX_API extern "C" __attribute__((visibility("default")))
+
+using namespace rgx;
+
+struct rgx_program {
+  Program p;
+};
+
+struct rgx_stream_ctx {
+  const rgx_program* prog = nullptr;
+  int device = -1;
+  hipStream_t stream = nullptr;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool timing = false;
+  // device scratch
+  unsigned long long* d_desc = nullptr; int64_t desc_cap = 0;
+  uint32_t* d_counters = nullptr;            // [4]
+  unsigned long long* d_total = nullptr;     // [2]: total, trace cursor
+  uint8_t* d_unsynced = nullptr; int32_t* d_carry = nullptr; int64_t slice_cap = 0;
+  uint16_t* d_trace = nullptr; int64_t trace_cap = 0;
+  uint8_t* d_in = nullptr; int64_t in_cap = 0;       // staging for the host-buffer entry points
+  int32_t* d_out = nullptr; int64_t out_cap = 0;
+  // pinned host readback
+  unsigned long long* h_read = nullptr;      // [4]: total, unsynced, ...
+};
+
+namespace {
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      SetError(std::string(#expr) + ": " + hipGetErrorString(_e));                            \
+      return RGX_E_HIP;                                                                       \
+    }                                                                                         \
+  } while (0)
+
+template <class T>
+int Ensure(T** ptr, int64_t* cap, int64_t need) {
+  if (*cap >= need && *ptr) return RGX_OK;
+  if (*ptr) { hipFree(*ptr); *ptr = nullptr; *cap = 0; }
+  int64_t n = std::max<int64_t>(need, 16);
+  if (hipMalloc((void**)ptr, (size_t)n * sizeof(T)) != hipSuccess) { SetError("hipMalloc failed"); (void)hipGetLastError(); return RGX_E_NOMEM; }
+  *cap = n;
+  return RGX_OK;
+}
+
+int CheckCtx(const rgx_program* p, rgx_stream_ctx* c) {
+  if (!p || !c || c->prog != p) { SetError("bad program/ctx"); return RGX_E_INVALID; }
+  if (!p->p.d_arena) { SetError("program not on a device (rgx_program_to_device)"); return RGX_E_NO_DEVICE; }
+  if (hipSetDevice(c->device) != hipSuccess) { SetError("hipSetDevice"); return RGX_E_HIP; }
+  return RGX_OK;
+}
+
+// Core: scan (+ carry fallback) (+ captures).  Inputs/outputs are device pointers.
+int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n, int32_t* d_spans,
+                      size_t cap_records, bool count_only, rgx_result* res) {
+  const DevTables& T = p->p.dev;
+  if (res) memset(res, 0, sizeof *res);
+  if (res) res->ncap = T.ncap;
+  if (n == 0 || len == 0) return 0;  // find.go:142-144 (`n == 0`), find.go:209-211 (no attempt at searchStart >= l)
+  if (len > 0x7FFFFF00ull) { SetError("buffer larger than 2^31-256 bytes: shard it (FindReader path)"); return RGX_E_TOO_LARGE; }
+  if ((uintptr_t)d_buf & 15) { SetError("input device pointer must be 16-byte aligned"); return RGX_E_INVALID; }
+  if (!count_only && ((uintptr_t)d_spans & 15)) { SetError("span device pointer must be 16-byte aligned"); return RGX_E_INVALID; }
+  const int32_t ilen = (int32_t)len;
+  const int32_t ntiles = (ilen + kTileBytes - 1) / kTileBytes;
+  const int32_t nslices = (ilen + kSliceBytes - 1) / kSliceBytes;
+  int rc;
+  if ((rc = Ensure(&c->d_desc, &c->desc_cap, ntiles)) != RGX_OK) return rc;
+
+  ScanParams P{};
+  P.buf = d_buf; P.len = ilen; P.ntiles = ntiles; P.spans = d_spans; P.cap_records = (int64_t)cap_records;
+  P.tile_desc = c->d_desc; P.counters = c->d_counters; P.total = c->d_total; P.carry_in = nullptr; P.slice_unsynced = nullptr;
+  P.count_only = count_only ? 1 : 0;
+
+  auto run_scan = [&](bool time_it) -> int {
+    HIP_TRY(hipMemsetAsync(c->d_desc, 0, (size_t)ntiles * 8, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 16, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_total, 0, 16, c->stream));
+    if (time_it) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(LaunchScan(T, P, c->stream));
+    if (time_it) HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipMemcpyAsync(&c->h_read[0], c->d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&c->h_read[1], c->d_counters, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RGX_OK;
+  };
+  if ((rc = run_scan(c->timing)) != RGX_OK) return rc;
+  float ms = 0;
+  if (c->timing) hipEventElapsedTime(&ms, c->ev0, c->ev1);
+  uint32_t unsynced = ((uint32_t*)&c->h_read[1])[1];
+  if (unsynced) {
+    // rare path: some slices found no sync point; resolve their entry positions serially and rescan.
+    if ((rc = Ensure(&c->d_unsynced, &c->slice_cap, nslices)) != RGX_OK) return rc;
+    int64_t cc = 0;
+    if (c->d_carry) { hipFree(c->d_carry); c->d_carry = nullptr; }
+    if ((rc = Ensure(&c->d_carry, &cc, nslices)) != RGX_OK) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_unsynced, 0, nslices, c->stream));
+    P.slice_unsynced = c->d_unsynced;
+    if ((rc = run_scan(false)) != RGX_OK) return rc;            // marks the unsynced slices
+    HIP_TRY(hipMemsetAsync(c->d_carry, 0xFF, (size_t)nslices * 4, c->stream));
+    HIP_TRY(LaunchCarry(T, d_buf, ilen, c->d_unsynced, c->d_carry, nslices, c->stream));
+    P.slice_unsynced = nullptr;
+    P.carry_in = c->d_carry;
+    if ((rc = run_scan(false)) != RGX_OK) return rc;
+  }
+  const int64_t total = (int64_t)c->h_read[0];
+  int64_t written = count_only ? 0 : std::min<int64_t>(total, (int64_t)cap_records);
+  if (res) { res->total = total; res->unsynced = (int32_t)unsynced; res->kernel_ms = ms; }
+  if (count_only) return total;
+  if (total > (int64_t)cap_records && (n < 0 || n > (int64_t)cap_records)) {
+    if (res) res->written = 0;
+    SetError("span capacity too small");
+    return RGX_E_CAPACITY;
+  }
+  if (n > 0) written = std::min<int64_t>(written, n);
+  if (!T.fixed_captures && written > 0) {
+    // dynamic capture groups: second kernel over the (much smaller) match list
+    int64_t need = (int64_t)len + written + 64;
+    if ((rc = Ensure(&c->d_trace, &c->trace_cap, need)) != RGX_OK) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_total + 1, 0, 8, c->stream));
+    HIP_TRY(LaunchCaptures(T, d_buf, ilen, d_spans, written, c->d_trace, c->d_total + 1, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  if (res) res->written = written;
+  return written;
+}
+
+}  // namespace
+
+// ---------------------------------------------------------------- compile time
+RGX_API int rgx_compile(const char* pattern, uint32_t flags, rgx_program** out) {
+  if (!pattern || !out) return RGX_E_INVALID;
+  *out = nullptr;
+  try {
+    auto* h = new rgx_program();
+    h->p.t = BuildTables(pattern, flags);
+    *out = h;
+    return RGX_OK;
+  } catch (const SyntaxError& e) {
+    if (e.msg.rfind("unsupported", 0) == 0) { SetError(e.msg); return RGX_E_UNSUPPORTED; }
+    SetError("syntax: " + e.msg);
+    return RGX_E_SYNTAX;
+  } catch (const Unsupported& e) { SetError("unsupported: " + e.msg); return RGX_E_UNSUPPORTED; }
+  catch (const TooLarge& e) { SetError("too large: " + e.msg); return RGX_E_TOO_LARGE; }
+  catch (const std::bad_alloc&) { return RGX_E_NOMEM; }
+}
+
+RGX_API int64_t rgx_program_blob_size(const rgx_program* p) {
+  if (!p) return RGX_E_INVALID;
+  auto* m = const_cast<rgx_program*>(p);
+  std::lock_guard<std::mutex> lock(m->p.mu);
+  if (m->p.blob_cache.empty()) m->p.blob_cache = SerializeTables(p->p.t);
+  return (int64_t)m->p.blob_cache.size();
+}
+RGX_API int64_t rgx_program_blob_write(const rgx_program* p, void* dst, size_t cap) {
+  int64_t n = rgx_program_blob_size(p);
+  if (n < 0) return n;
+  if ((size_t)n > cap || !dst) return RGX_E_CAPACITY;
+  memcpy(dst, p->p.blob_cache.data(), (size_t)n);
+  return n;
+}
+RGX_API int rgx_program_from_blob(const void* blob, size_t len, rgx_program** out) {
+  if (!blob || !out) return RGX_E_INVALID;
+  auto* h = new rgx_program();
+  if (!DeserializeTables((const uint8_t*)blob, len, &h->p.t)) { delete h; SetError("bad table blob"); return RGX_E_BAD_BLOB; }
+  *out = h;
+  return RGX_OK;
+}
+RGX_API void rgx_program_destroy(rgx_program* p) { delete p; }
+
+static int DefaultMaxLeftover(int max_len) {  // streaming.go:87-96
+  if (max_len == -1) return 1 << 20;
+  int d = max_len * 10;
+  if (d < 1024) d = 1024;
+  if (d > (1 << 20)) d = 1 << 20;
+  return d;
+}
+static int MinBuffer(int max_len) {  // streaming.go:56-62
+  int mb = 64 * 1024;
+  if (max_len > 0) mb = std::max(max_len * 2, 64 * 1024);
+  return mb;
+}
+
+RGX_API int rgx_program_info(const rgx_program* p, rgx_info* o) {
+  if (!p || !o) return RGX_E_INVALID;
+  const Tables& t = p->p.t;
+  memset(o, 0, sizeof *o);
+  o->abi_version = RGX_ABI_VERSION;
+  o->ncap = t.ncap; o->min_match_len = t.min_len; o->max_match_len = t.max_len;
+  o->default_max_leftover = DefaultMaxLeftover(t.max_len); o->min_buffer_size = MinBuffer(t.max_len);
+  o->n_inst = t.n_inst; o->n_states = t.nstates; o->n_classes = t.ncls; o->anchored = t.anchored;
+  o->fixed_captures = t.fixed_captures; o->can_match_empty = t.can_match_empty;
+  o->ref_match_engine = t.ref_match_engine; o->ref_find_engine = t.ref_find_engine; o->lookahead_mode = t.lookahead_mode;
+  o->table_bytes = p->p.d_arena ? p->p.dev.table_bytes : (int32_t)((size_t)t.nstates * (t.ncls + 1) * 2);
+  return RGX_OK;
+}
+
+RGX_API int64_t rgx_program_capture_names(const rgx_program* p, char* dst, size_t cap) {
+  if (!p) return RGX_E_INVALID;
+  std::string s;
+  for (auto& n : p->p.t.cap_names) { s += n; s.push_back('\0'); }
+  if (dst && cap >= s.size()) memcpy(dst, s.data(), s.size());
+  return (int64_t)s.size();
+}
+
+// ---------------------------------------------------------------- device binding
+RGX_API int rgx_device_count(void) {
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess) { (void)hipGetLastError(); return 0; }
+  return n;
+}
+RGX_API int rgx_program_to_device(rgx_program* p, int device) {
+  if (!p) return RGX_E_INVALID;
+  return ProgramToDevice(&p->p, device);
+}
+
+RGX_API int rgx_stream_ctx_create(const rgx_program* p, rgx_stream_ctx** out) {
+  if (!p || !out) return RGX_E_INVALID;
+  *out = nullptr;
+  if (!p->p.d_arena) { SetError("program not on a device (rgx_program_to_device)"); return RGX_E_NO_DEVICE; }
+  auto* c = new rgx_stream_ctx();
+  c->prog = p;
+  c->device = p->p.device;
+  if (hipSetDevice(c->device) != hipSuccess) { delete c; return RGX_E_NO_DEVICE; }
+  bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+            hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
+            hipMalloc((void**)&c->d_counters, 16) == hipSuccess && hipMalloc((void**)&c->d_total, 16) == hipSuccess &&
+            hipHostMalloc((void**)&c->h_read, 64, hipHostMallocDefault) == hipSuccess;
+  if (!ok) { SetError("ctx allocation failed"); rgx_stream_ctx_destroy(c); return RGX_E_HIP; }
+  *out = c;
+  return RGX_OK;
+}
+RGX_API void rgx_stream_ctx_destroy(rgx_stream_ctx* c) {
+  if (!c) return;
+  hipSetDevice(c->device);
+  if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
+  if (c->ev0) hipEventDestroy(c->ev0);
+  if (c->ev1) hipEventDestroy(c->ev1);
+  for (void* p : {(void*)c->d_desc, (void*)c->d_counters, (void*)c->d_total, (void*)c->d_unsynced, (void*)c->d_carry,
+                  (void*)c->d_trace, (void*)c->d_in, (void*)c->d_out})
+    if (p) hipFree(p);
+  if (c->h_read) hipHostFree(c->h_read);
+  delete c;
+}
+RGX_API void* rgx_stream_ctx_hip_stream(const rgx_stream_ctx* c) { return c ? (void*)c->stream : nullptr; }
+RGX_API int rgx_stream_ctx_set_timing(rgx_stream_ctx* c, int on) { if (!c) return RGX_E_INVALID; c->timing = on != 0; return RGX_OK; }
+
+// ---------------------------------------------------------------- run time
+RGX_API int64_t rgx_find_all_bytes_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n,
+                                          int32_t* d_spans, size_t cap_records, rgx_result* res) {
+  int rc = CheckCtx(p, c);
+  if (rc != RGX_OK) return rc;
+  return FindAllDevice(p, c, d_buf, len, n, d_spans, cap_records, false, res);
+}
+
+RGX_API int64_t rgx_count_all_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, rgx_result* res) {
+  int rc = CheckCtx(p, c);
+  if (rc != RGX_OK) return rc;
+  return FindAllDevice(p, c, d_buf, len, -1, nullptr, 0, true, res);
+}
+
+RGX_API int64_t rgx_find_all_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* buf, size_t len, int64_t n,
+                                   int32_t* spans, size_t cap_records, rgx_result* res) {
+  int rc = CheckCtx(p, c);
+  if (rc != RGX_OK) return rc;
+  if (n == 0 || len == 0) { if (res) { memset(res, 0, sizeof *res); res->ncap = p->p.dev.ncap; } return 0; }
+  if (!buf || (!spans && cap_records)) return RGX_E_INVALID;
+  const int ncap = p->p.dev.ncap;
+  if ((rc = Ensure(&c->d_in, &c->in_cap, (int64_t)len + 64)) != RGX_OK) return rc;
+  if ((rc = Ensure(&c->d_out, &c->out_cap, (int64_t)cap_records * ncap + 16)) != RGX_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream));
+  int64_t w = FindAllDevice(p, c, c->d_in, len, n, c->d_out, cap_records, false, res);
+  if (w > 0) HIP_TRY(hipMemcpy(spans, c->d_out, (size_t)w * ncap * 4, hipMemcpyDeviceToHost));
+  return w;
+}
+
+RGX_API int rgx_match_bytes_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int* matched) {
+  int rc = CheckCtx(p, c);
+  if (rc != RGX_OK) return rc;
+  if (!matched) return RGX_E_INVALID;
+  // A whole-buffer MatchBytes is "does FindAll find anything", except that the search also tries the empty
+  // match at offset len (compiler.go:845-853 retries while l > offset) which FindAll never does (find.go:209-211).
+  const Tables& t = p->p.t;
+  if (t.can_match_empty) {
+    // one-string batch covers the attempt at offset len exactly
+    uint64_t h_off[2] = {0, (uint64_t)len};
+    uint64_t* d_off = nullptr; uint8_t* d_found = nullptr;
+    HIP_TRY(hipMalloc((void**)&d_off, 16)); HIP_TRY(hipMalloc((void**)&d_found, 16));
+    HIP_TRY(hipMemcpyAsync(d_off, h_off, 16, hipMemcpyHostToDevice, c->stream));
+    hipError_t e = LaunchBatch(p->p.dev, d_buf, d_off, 1, d_found, nullptr, nullptr, 0, c->stream);
+    uint8_t f = 0;
+    if (e == hipSuccess) e = hipMemcpyAsync(&f, d_found, 1, hipMemcpyDeviceToHost, c->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
+    hipFree(d_off); hipFree(d_found);
+    HIP_TRY(e);
+    *matched = f;
+    return RGX_OK;
+  }
+  rgx_result r;
+  int64_t total = FindAllDevice(p, c, d_buf, len, -1, nullptr, 0, true, &r);
+  if (total < 0) return (int)total;
+  *matched = total > 0;
+  return RGX_OK;
+}
+
+RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_concat, const uint64_t* d_offsets,
+                                      size_t nstr, uint8_t* d_found, int32_t* d_spans) {
+  int rc = CheckCtx(p, c);
+  if (rc != RGX_OK) return rc;
+  if (nstr == 0) return 0;
+  if (!d_concat || !d_offsets || !d_found || !d_spans) return RGX_E_INVALID;
+  const DevTables& T = p->p.dev;
+  uint16_t* trace = nullptr;
+  int64_t stride = 0;
+  if (!T.fixed_captures) {
+    // matches longer than the LDS trace need global scratch: size it by the longest string
+    // (one pass over the offsets on the host would need a D2H copy; bound by total bytes instead)
+    uint64_t h_last = 0;
+    HIP_TRY(hipMemcpyAsync(&h_last, d_offsets + nstr, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    // trace region per string = its own length + 2, laid out at 2*offset + 2*index: use stride 0 and the CSR offsets
+    int64_t need = (int64_t)h_last + 2 * (int64_t)nstr + 64;
+    if ((rc = Ensure(&c->d_trace, &c->trace_cap, need)) != RGX_OK) return rc;
+    trace = c->d_trace;
+    stride = -1;  // "CSR-shaped": resolved in the kernel as offsets[i] + 2*i
+  }
+  HIP_TRY(LaunchBatch(T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, trace, stride, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return (int64_t)nstr;
+}
+
+RGX_API int64_t rgx_match_batch_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_concat, const uint64_t* d_offsets,
+                                       size_t nstr, uint8_t* d_matched) {
+  int rc = CheckCtx(p, c);
+  if (rc != RGX_OK) return rc;
+  if (nstr == 0) return 0;
+  if (!d_concat || !d_offsets || !d_matched) return RGX_E_INVALID;
+  HIP_TRY(LaunchBatch(p->p.dev, d_concat, d_offsets, (int64_t)nstr, d_matched, nullptr, nullptr, 0, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return (int64_t)nstr;
+}
+
+// ---------------------------------------------------------------- streaming
+RGX_API int rgx_stream_config_resolve(const rgx_program* p, const rgx_stream_config* in, rgx_stream_config* out) {
+  if (!p || !in || !out) return RGX_E_INVALID;
+  const int min_buf = MinBuffer(p->p.t.max_len), def_left = DefaultMaxLeftover(p->p.t.max_len);
+  if (in->buffer_size > 0 && in->buffer_size < min_buf) { SetError("stream: buffer size too small"); return RGX_E_BUFFER_TOO_SMALL; }
+  rgx_stream_config r = *in;
+  if (r.buffer_size == 0) r.buffer_size = 64 * 1024;
+  if (r.buffer_size < min_buf) r.buffer_size = min_buf;
+  if (r.max_leftover == 0) r.max_leftover = def_left;
+  int64_t mx = r.buffer_size / 2;
+  if (r.max_leftover != -1 && r.max_leftover > mx) r.max_leftover = mx;
+  *out = r;
+  return RGX_OK;
+}
+
+RGX_API int64_t rgx_find_chunk(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* chunk, size_t data_len, int is_full,
+                               int64_t max_leftover, int32_t* spans, size_t cap_records, int64_t* committed, int64_t* keep_from,
+                               rgx_result* res) {
+  // streaming.go:175-244.  All matches of the chunk are found in one scan; the commit/defer rule is applied
+  // to the ordered list: the first match whose end crosses dataLen-MaxLeftover (when the buffer was full)
+  // stops the loop, exactly like the `break` at streaming.go:204-207.
+  if (!committed || !keep_from) return RGX_E_INVALID;
+  rgx_result r;
+  int64_t w = rgx_find_all_bytes(p, c, chunk, data_len, -1, spans, cap_records, &r);
+  if (w < 0) return w;
+  const int ncap = r.ncap ? r.ncap : p->p.t.ncap;
+  int64_t comm = 0, emitted = 0;
+  for (int64_t i = 0; i < w; i++) {
+    int64_t me = spans[i * ncap + 1];
+    if (is_full && me > (int64_t)data_len - max_leftover) break;
+    comm = me;
+    emitted++;
+  }
+  int64_t keep = 0;
+  if (is_full) {
+    keep = (int64_t)data_len - max_leftover;
+    if (keep < comm) keep = comm;
+  } else {
+    keep = (int64_t)data_len;
+  }
+  *committed = comm;
+  *keep_from = keep;
+  if (res) { *res = r; res->written = emitted; }
+  return emitted;
+}
+
+RGX_API const char* rgx_last_error(void) { return GetError().c_str(); }
+RGX_API const char* rgx_status_str(int s) {
+  switch (s) {
+    case RGX_OK: return "ok";
+    case RGX_E_INVALID: return "invalid argument";
+    case RGX_E_SYNTAX: return "syntax error";
+    case RGX_E_UNSUPPORTED: return "unsupported pattern feature";
+    case RGX_E_TOO_LARGE: return "too large";
+    case RGX_E_NO_DEVICE: return "no HIP device";
+    case RGX_E_HIP: return "HIP runtime error";
+    case RGX_E_NOMEM: return "out of memory";
+    case RGX_E_CAPACITY: return "output capacity too small";
+    case RGX_E_BAD_BLOB: return "bad table blob";
+    case RGX_E_BUFFER_TOO_SMALL: return "stream: buffer size too small";
+  }
+  return "unknown";
+}

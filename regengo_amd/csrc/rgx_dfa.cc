@@ -441,7 +441,62 @@ Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOption
       all_fixed = false;
     }
     t.fixed_captures = all_fixed;
+    {
+      int match_pc = -1;
+      for (int pc = 0; pc < n; pc++) if (prog.inst[pc].op == InstMatch) match_pc = pc;
+      t.fixed_len = (match_pc >= 0 && dfs[match_pc] >= 0) ? dfs[match_pc] : -1;
+    }
   }
+  // ---- Shift-And level sets (prefilter; exact for fixed-length class chains)
+  {
+    std::vector<char> cur(t.nstates, 0);
+    for (int c = 0; c < 4; c++) cur[t.start[c]] = 1;
+    cur[0] = 0;
+    int K = 0;
+    bool single_chain = true;
+    for (int j = 0; j < 32; j++) {
+      // can a match end at depth j?
+      bool can_end = false;
+      int live = 0;
+      for (int q = 1; q < t.nstates; q++) {
+        if (!cur[q]) continue;
+        live++;
+        if (b.lookahead) {
+          for (int k = 0; k <= ncls; k++) if (trans[q * stride + k] & kMatchBefore) can_end = true;
+        }
+      }
+      if (!b.lookahead) {
+        if (j == 0) { for (int c = 0; c < 4; c++) if (t.start_accept[c]) can_end = true; }
+        // eager: acceptance is flagged on the edge INTO the state; tracked below via `accepting`
+      }
+      if (can_end || live == 0) break;
+      if (live != 1) single_chain = false;
+      std::vector<char> nxt(t.nstates, 0);
+      bool next_accepts = false;
+      std::vector<char> cls_live(ncls, 0);
+      for (int q = 1; q < t.nstates; q++) {
+        if (!cur[q]) continue;
+        for (int k = 0; k < ncls; k++) {
+          uint16_t e = trans[q * stride + k];
+          if ((e & kStateMask) != kDead) { cls_live[k] = 1; nxt[e & kStateMask] = 1; }
+          if (e & kMatchAfter) next_accepts = true;
+        }
+      }
+      for (int c = 0; c < 256; c++) if (cls_live[b.cls[c]]) t.sa_mask[c] |= (1u << j);
+      K = j + 1;
+      cur = nxt;
+      if (next_accepts) break;  // a match can end after K bytes: levels beyond K are not mandatory
+    }
+    t.sa_k = K;
+    t.sa_exact = false;
+    if (K > 0) {
+      int live = 0;
+      for (int q = 1; q < t.nstates; q++) live += cur[q];
+      t.sa_exact = single_chain && live == 1 && !b.lookahead && !t.ctx_sensitive && !t.bot_sensitive && t.fixed_len == K;
+    }
+    if (K == 0) memset(t.sa_mask, 0, sizeof t.sa_mask);
+  }
+
   return t;
 }
 
@@ -488,7 +543,8 @@ std::vector<uint8_t> SerializeTables(const Tables& t) {
   w.raw(t.start, sizeof t.start); w.raw(t.start_accept, sizeof t.start_accept); w.raw(t.ctx_of_byte, 256);
   w.pod<uint8_t>(t.ctx_sensitive); w.pod<uint8_t>(t.bot_sensitive); w.raw(t.reset_byte, 256);
   w.vec(t.cap_kind); w.vec(t.cap_delta); w.vec(t.st_nthreads); w.vec(t.bt_base); w.vec(t.bt_parent); w.vec(t.bt_ops);
-  w.vec(t.bt_match); w.vec(t.start_ops); w.vec(t.start_ops_pool); w.pod<int32_t>(t.max_threads);
+  w.vec(t.bt_match); w.vec(t.start_ops); w.vec(t.start_ops_pool); w.pod<int32_t>(t.max_threads); w.pod<int32_t>(t.fixed_len);
+  w.raw(t.sa_mask, sizeof t.sa_mask); w.pod<int32_t>(t.sa_k); w.pod<uint8_t>(t.sa_exact);
   return w.b;
 }
 
@@ -510,7 +566,8 @@ bool DeserializeTables(const uint8_t* p, size_t n, Tables* t) {
   r.raw(t->start, sizeof t->start); r.raw(t->start_accept, sizeof t->start_accept); r.raw(t->ctx_of_byte, 256);
   r.pod(u8); t->ctx_sensitive = u8; r.pod(u8); t->bot_sensitive = u8; r.raw(t->reset_byte, 256);
   r.vec(t->cap_kind); r.vec(t->cap_delta); r.vec(t->st_nthreads); r.vec(t->bt_base); r.vec(t->bt_parent); r.vec(t->bt_ops);
-  r.vec(t->bt_match); r.vec(t->start_ops); r.vec(t->start_ops_pool); r.pod(i32); t->max_threads = i32;
+  r.vec(t->bt_match); r.vec(t->start_ops); r.vec(t->start_ops_pool); r.pod(i32); t->max_threads = i32; r.pod(i32); t->fixed_len = i32;
+  r.raw(t->sa_mask, sizeof t->sa_mask); r.pod(i32); t->sa_k = i32; r.pod(u8); t->sa_exact = u8;
   if (!r.ok) return false;
   if (t->ncls < 1 || t->ncls > 256 || t->nstates < 1 || t->trans.size() != (size_t)t->nstates * (t->ncls + 1)) return false;
   if ((int)t->cap_kind.size() != t->ncap || (int)t->cap_delta.size() != t->ncap) return false;

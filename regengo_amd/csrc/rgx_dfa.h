@@ -39,6 +39,7 @@ struct Tables {
   bool can_match_empty = false;
   bool lookahead_mode = false;
   bool fixed_captures = false;
+  int fixed_len = -1;             // byte length of every match when it is a constant, else -1
   int ref_match_engine = 0, ref_find_engine = 0;
   std::vector<std::string> cap_names;
 
@@ -53,6 +54,12 @@ struct Tables {
   bool ctx_sensitive = false;     // start state depends on the previous byte
   bool bot_sensitive = false;     // start state at offset 0 differs
   uint8_t reset_byte[256] = {0};  // 1: every live state dies on this byte => the next offset is a sync point
+  // Shift-And prefilter over "level sets": bit j of sa_mask[c] = byte c can be the (j+1)-th byte of a match.
+  // sa_k = number of levels (true minimum match length in bytes, capped at 32; 0 = no prefilter).
+  // sa_exact: the level sets ARE the language (fixed-length chain of byte classes): no DFA verification needed.
+  uint32_t sa_mask[256] = {0};
+  int sa_k = 0;
+  bool sa_exact = false;
 
   // ---- captures
   std::vector<uint8_t> cap_kind;  // [ncap]

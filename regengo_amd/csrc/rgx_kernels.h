@@ -1,0 +1,42 @@
+// Launch interface between the C ABI (rgx_capi.cc) and the HIP kernels (rgx_kernels.hip).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+
+#include "rgx_program.h"
+
+namespace rgx {
+
+struct ScanParams {
+  const uint8_t* buf;            // device, 16-byte aligned
+  int32_t len;
+  int32_t ntiles;
+  int32_t* spans;                // device, [cap_records][ncap]
+  int64_t cap_records;
+  unsigned long long* tile_desc; // [ntiles] look-back descriptors, zeroed before launch
+  uint32_t* counters;            // [0] tile ticket, [1] unsynced slices; zeroed before launch
+  unsigned long long* total;     // total matches; zeroed before launch
+  const int32_t* carry_in;       // nullable; per slice: -1 = find a sync point locally, else search position
+  uint8_t* slice_unsynced;       // nullable; set to 1 for slices that found no sync point
+  int32_t count_only;
+};
+
+// FindAllBytes scan: one pass over the input, ordered span records out.
+hipError_t LaunchScan(const DevTables& T, const ScanParams& P, hipStream_t stream);
+size_t ScanSharedBytes(const DevTables& T);
+
+// Serial carry resolution for slices without a local sync point (rare path).
+hipError_t LaunchCarry(const DevTables& T, const uint8_t* buf, int32_t len, const uint8_t* slice_unsynced, int32_t* carry_in,
+                       int32_t nslices, hipStream_t stream);
+
+// Capture groups for patterns whose captures are not a fixed template: per-match state trace + back-trace.
+// `trace` is scratch of at least (len + nmatches + 64) uint16; `trace_cursor` a zeroed uint64.
+hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, int32_t* spans, int64_t nmatches, uint16_t* trace,
+                          unsigned long long* trace_cursor, hipStream_t stream);
+
+// Batch (one string per lane): FindBytes / MatchBytes per string, CSR offsets.
+hipError_t LaunchBatch(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,
+                       int32_t* spans /* nullable: match only */, uint16_t* trace, int64_t trace_stride, hipStream_t stream);
+
+}  // namespace rgx

@@ -1,0 +1,560 @@
+// HIP kernels for gfx950 (MI355X, CDNA4): the FindAllBytes / FindBytes / MatchBytes hot path of regengo as a
+// table walk.  This is HBM-bound byte work -- no MFMA anywhere (a per-byte dependent table lookup is not a
+// contraction).  Design (DESIGN.md has the long form):
+//
+//   scan_kernel   one workgroup = 256 lanes = one 16 KiB tile of input, staged ONCE from HBM into LDS with
+//                 coalesced 16-byte loads; the transition table sits next to it in LDS.  Each lane owns a
+//                 contiguous 64-byte slice of candidate START positions and runs the reference's FindAll loop
+//                 (internal/compiler/find.go:130-316: try at searchStart, on match jump to its end, else
+//                 searchStart++) over it with the DFA as the per-attempt matcher.  A lane begins at a *sync
+//                 point* at or before its slice -- the offset after a "reset" byte, on which every DFA state
+//                 dies -- so no lane needs another lane's result.  Match starts are kept as a 64-bit mask per
+//                 lane, counted with popcount, ordered by a wave/block prefix sum and a decoupled look-back
+//                 across tiles (single pass, no second read of the input), then written as span records.
+//   carry_kernel  serial resolution for slices with no sync point in reach (pathological inputs only).
+//   caps_kernel   capture groups for patterns whose groups are not a fixed template: re-walk the match
+//                 recording the DFA state per byte, then walk the thread-parent tables backwards.
+//   batch_kernel  one string per lane (CSR), FindBytes/MatchBytes per string.
+#include <hip/hip_runtime.h>
+
+#include "rgx_kernels.h"
+
+namespace rgx {
+
+namespace {
+
+constexpr int kWindow = kHaloL + kTileBytes + kHaloR;          // bytes of input visible in LDS
+constexpr int kPaddedWindow = kWindow + (kWindow / 64) * 4;    // 64-byte rows padded to 68: lane stride 17 dwords
+constexpr unsigned long long kDescAgg = 1ull << 62;
+constexpr unsigned long long kDescPrefix = 2ull << 62;
+constexpr unsigned long long kDescValMask = (1ull << 62) - 1;
+
+__device__ __forceinline__ int PadAddr(int rel) { return rel + ((rel >> 6) << 2); }
+
+// ---- table access ---------------------------------------------------------------------------------------
+template <int MODE>
+struct Tab {
+  const uint16_t* t;   // LDS (modes 0,1) or global (mode 2)
+  const uint8_t* cls;  // LDS
+  int stride;
+  int nstates;
+  __device__ __forceinline__ unsigned Step(unsigned q, int c) const {
+    if (MODE == kModeDirect) return t[(q << 8) + c];
+    return t[q * stride + cls[c]];
+  }
+  __device__ __forceinline__ unsigned StepEot(unsigned q) const {
+    if (MODE == kModeDirect) return t[(nstates << 8) + q];
+    return t[q * stride + (stride - 1)];
+  }
+};
+
+struct Input {
+  const uint8_t* g;       // global
+  const uint8_t* tile;    // LDS window (padded rows)
+  int wb;                 // absolute offset of window byte 0 (may be negative)
+  int wvalid;             // number of window bytes actually staged
+  int len;
+  __device__ __forceinline__ int At(int i) const {
+    unsigned rel = (unsigned)(i - wb);
+    if (rel < (unsigned)wvalid) return tile[PadAddr((int)rel)];
+    return g[i];
+  }
+};
+
+// One anchored attempt from `pos` (the body of the reference's per-searchStart machine run).  Returns the
+// match end or -1.
+template <int MODE>
+__device__ __forceinline__ int Walk(const Tab<MODE>& tab, const Input& in, const DevTables& T, const uint8_t* ctx_of_byte,
+                                    int pos) {
+  int ctx = kCtxOther;
+  if (pos == 0) ctx = kCtxBOT;
+  else if (T.ctx_sensitive) ctx = ctx_of_byte[in.At(pos - 1)];
+  unsigned q = T.start[ctx];
+  int end = (T.start_accept[ctx]) ? pos : -1;
+  int i = pos;
+  while (true) {
+    unsigned e;
+    bool eot = i >= in.len;
+    if (eot) e = tab.StepEot(q);
+    else e = tab.Step(q, in.At(i));
+    if (e & kMatchBefore) end = i;
+    if (e & kMatchAfter) end = i + 1;
+    q = e & kStateMask;
+    if (q == kDead || eot) break;
+    ++i;
+  }
+  return end;
+}
+
+__device__ __forceinline__ unsigned long long WaveInclusiveScan(unsigned v, int lane) {
+  unsigned x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    unsigned y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  return x;
+}
+
+__device__ __forceinline__ unsigned long long WaveSum64(unsigned long long v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+__device__ __forceinline__ void WriteRecordFixed(int32_t* rec, int ncap, const uint8_t* kind, const int32_t* delta, int s, int e) {
+  if ((ncap & 3) == 0) {
+    for (int c = 0; c < ncap; c += 4) {
+      int4 v;
+      v.x = kind[c] == kCapFromStart ? s + delta[c] : e - delta[c];
+      v.y = kind[c + 1] == kCapFromStart ? s + delta[c + 1] : e - delta[c + 1];
+      v.z = kind[c + 2] == kCapFromStart ? s + delta[c + 2] : e - delta[c + 2];
+      v.w = kind[c + 3] == kCapFromStart ? s + delta[c + 3] : e - delta[c + 3];
+      *reinterpret_cast<int4*>(rec + c) = v;
+    }
+  } else {
+    for (int c = 0; c < ncap; c++) rec[c] = kind[c] == kCapFromStart ? s + delta[c] : e - delta[c];
+  }
+}
+
+// ---- the scan kernel ------------------------------------------------------------------------------------
+// SA: 0 = try every start with the DFA; 1 = Shift-And level-set prefilter, DFA verifies the survivors;
+//     2 = the level sets are exact (fixed-length chain of byte classes): no DFA in the loop at all.
+template <int MODE, int SA>
+__global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned char* s_tile = smem;                                   // kPaddedWindow
+  uint16_t* s_tab = reinterpret_cast<uint16_t*>(smem + ((kPaddedWindow + 15) & ~15));
+  const int tab_bytes = (T.table_bytes + 15) & ~15;
+  unsigned char* s_cls = reinterpret_cast<unsigned char*>(s_tab) + tab_bytes;  // 256
+  unsigned char* s_reset = s_cls + 256;                                       // 256
+  unsigned char* s_ctx = s_reset + 256;                                       // 256
+  int32_t* s_delta = reinterpret_cast<int32_t*>(s_ctx + 256);                 // 32
+  unsigned char* s_kind = reinterpret_cast<unsigned char*>(s_delta + 32);     // 32
+  unsigned* s_misc = reinterpret_cast<unsigned*>(s_kind + 32);                // [0] tile, [1..4] wave totals, [8..9] base
+  unsigned* s_sa = s_misc + 16;                                               // 256 level-set masks
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+
+  // dynamic tile id: a ticket guarantees every predecessor tile is already owned by a running workgroup,
+  // which is what makes the look-back below deadlock-free without any residency assumption.
+  if (tid == 0) s_misc[0] = atomicAdd(&P.counters[0], 1u);
+  // stage the tables while the ticket is in flight
+  {
+    const int nwords = SA == 2 ? 0 : (T.table_bytes >> 2);   // the exact Shift-And path never touches the DFA
+    const uint32_t* src = reinterpret_cast<const uint32_t*>(T.trans);
+    uint32_t* dst = reinterpret_cast<uint32_t*>(s_tab);
+    for (int w = tid; w < nwords; w += kBlockThreads) dst[w] = src[w];
+    if ((T.table_bytes & 3) && tid == 0) s_tab[(T.table_bytes >> 1) - 1] = T.trans[(T.table_bytes >> 1) - 1];
+    s_cls[tid] = T.cls[tid];
+    s_reset[tid] = T.reset_byte[tid];
+    s_ctx[tid] = T.ctx_of_byte[tid];
+    if (tid < T.ncap) { s_delta[tid] = T.cap_delta[tid]; s_kind[tid] = T.cap_kind[tid]; }
+    if (SA) s_sa[tid] = T.sa_mask[tid];
+  }
+  __syncthreads();
+  const int tile = (int)s_misc[0];
+  if (tile >= P.ntiles) return;
+  const int len = P.len;
+  const int tb = tile * kTileBytes;
+  const int wb = tb - kHaloL;
+
+  // ---- stage the input window: coalesced 16-byte global loads -> padded LDS rows
+  int wvalid;
+  {
+    const int first = wb < 0 ? 0 : wb;                 // first absolute byte staged
+    int last = tb + kTileBytes + kHaloR;               // one past the last byte wanted
+    if (last > len) last = len;
+    wvalid = last - wb;                                // window bytes [0,wvalid) valid (those < first-wb unused)
+    const int nchunks = (last - first + 15) >> 4;
+    const uint4* gsrc = reinterpret_cast<const uint4*>(P.buf + first);
+    for (int c = tid; c < nchunks; c += kBlockThreads) {
+      const int abs0 = first + (c << 4);
+      const int rel = abs0 - wb;
+      uint32_t* dst = reinterpret_cast<uint32_t*>(s_tile + PadAddr(rel));
+      if (abs0 + 16 <= len) {
+        uint4 v = gsrc[c];
+        dst[0] = v.x; dst[1] = v.y; dst[2] = v.z; dst[3] = v.w;
+      } else {
+        for (int b = 0; abs0 + b < len; ++b) s_tile[PadAddr(rel + b)] = P.buf[abs0 + b];
+      }
+    }
+  }
+  __syncthreads();
+
+  Tab<MODE> tab;
+  tab.t = (MODE == kModeClassGlobal) ? T.trans : s_tab;
+  tab.cls = s_cls;
+  tab.stride = T.stride;
+  tab.nstates = T.nstates;
+  Input in{P.buf, s_tile, wb, wvalid, len};
+
+  // ---- phase 1: per-lane FindAll over the slice
+  const int slice = tile * kBlockThreads + tid;
+  const int a = tb + tid * kSliceBytes;
+  int slice_end = a + kSliceBytes;
+  if (slice_end > len) slice_end = len;
+  unsigned long long mask = 0;
+  if (a < len) {
+    int pos;
+    bool synced = true;
+    const int carried = P.carry_in ? P.carry_in[slice] : -1;
+    if (carried >= 0) pos = carried;
+    else if (a == 0) pos = 0;
+    else {
+      int lower = wb < 0 ? 0 : wb;
+      int j = a - 1;
+      while (j >= lower && !s_reset[in.At(j)]) --j;
+      if (j >= lower) pos = j + 1;
+      else if (lower == 0) pos = 0;   // reached the start of the buffer: offset 0 is a sync point
+      else { synced = false; pos = slice_end; }
+    }
+    if (!synced) {
+      atomicAdd(&P.counters[1], 1u);
+      if (P.slice_unsynced) P.slice_unsynced[slice] = 1;
+    }
+    if (T.anchored) {
+      // reference: `if anchored && searchStart > 0 { break }` (find.go:199-205): one attempt, at offset 0
+      if (a == 0 && len > 0) {
+        int end = Walk<MODE>(tab, in, T, s_ctx, 0);
+        if (end >= 0) mask = 1ull;
+      }
+    } else if (SA == 0) {
+      while (pos < slice_end) {
+        int end = Walk<MODE>(tab, in, T, s_ctx, pos);
+        if (end >= 0) {
+          if (pos >= a) mask |= 1ull << (pos - a);
+          pos = end > pos ? end : pos + 1;         // find.go:452-457
+        } else {
+          ++pos;
+        }
+      }
+    } else {
+      // Shift-And over level sets: D bit j = "the last j+1 bytes can be the first j+1 bytes of a match".
+      // The F lookups are independent of D, so four of them are in flight per dword; the dependent chain is
+      // three VALU ops per byte.  A start position s is a candidate when bit K-1 comes up at byte s+K-1.
+      const int K = T.sa_k;
+      const unsigned top = 1u << (K - 1);
+      int end_i = slice_end + K - 1;
+      if (end_i > len) end_i = len;
+      int i = pos & ~3;
+      unsigned D = 0;
+      auto candidate = [&](int s) {
+        if (s < pos) return;
+        int e;
+        if (SA == 2) e = s + K;
+        else e = Walk<MODE>(tab, in, T, s_ctx, s);
+        if (e >= 0) {
+          if (s >= a) mask |= 1ull << (s - a);
+          pos = e > s ? e : s + 1;
+        }
+      };
+      while (i + 4 <= end_i) {
+        const unsigned w = *reinterpret_cast<const unsigned*>(s_tile + PadAddr(i - wb));
+        const unsigned f0 = s_sa[w & 255u], f1 = s_sa[(w >> 8) & 255u], f2 = s_sa[(w >> 16) & 255u], f3 = s_sa[w >> 24];
+        const unsigned D0 = ((D << 1) | 1u) & f0;
+        const unsigned D1 = ((D0 << 1) | 1u) & f1;
+        const unsigned D2 = ((D1 << 1) | 1u) & f2;
+        const unsigned D3 = ((D2 << 1) | 1u) & f3;
+        D = D3;
+        if ((D0 | D1 | D2 | D3) & top) {
+          if (D0 & top) candidate(i - K + 1);
+          if (D1 & top) candidate(i - K + 2);
+          if (D2 & top) candidate(i - K + 3);
+          if (D3 & top) candidate(i - K + 4);
+        }
+        i += 4;
+      }
+      while (i < end_i) {
+        D = ((D << 1) | 1u) & s_sa[in.At(i)];
+        if (D & top) candidate(i - K + 1);
+        ++i;
+      }
+    }
+  }
+
+  // ---- phase 2: ordered offsets.  lane -> wave -> block prefix sums, then decoupled look-back over tiles.
+  const unsigned cnt = (unsigned)__popcll(mask);
+  const unsigned incl = (unsigned)WaveInclusiveScan(cnt, lane);
+  if (lane == 63) s_misc[1 + wave] = incl;
+  __syncthreads();
+  unsigned wave_off = 0, block_total = 0;
+#pragma unroll
+  for (int w = 0; w < kBlockThreads / 64; ++w) {
+    unsigned t = s_misc[1 + w];
+    if (w < wave) wave_off += t;
+    block_total += t;
+  }
+  if (P.count_only) {
+    if (tid == 0 && block_total) atomicAdd(P.total, (unsigned long long)block_total);
+    return;
+  }
+  if (wave == 0) {
+    unsigned long long excl = 0;
+    if (lane == 0) {
+      __hip_atomic_store(&P.tile_desc[tile], (tile == 0 ? kDescPrefix : kDescAgg) | block_total, __ATOMIC_RELAXED,
+                         __HIP_MEMORY_SCOPE_AGENT);
+      if (block_total) atomicAdd(P.total, (unsigned long long)block_total);
+    }
+    if (tile > 0) {
+      int idx = tile - 1 - lane;
+      while (true) {
+        unsigned long long d = kDescPrefix;  // tiles before 0: prefix 0
+        if (idx >= 0) {
+          d = __hip_atomic_load(&P.tile_desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          while ((d >> 62) == 0) {
+            __builtin_amdgcn_s_sleep(1);
+            d = __hip_atomic_load(&P.tile_desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        const unsigned long long pm = __ballot((d >> 62) == 2);
+        const int first = pm ? __builtin_ctzll(pm) : 64;
+        excl += WaveSum64(lane <= first ? (d & kDescValMask) : 0ull);
+        if (pm) break;
+        idx -= 64;
+      }
+      if (lane == 0)
+        __hip_atomic_store(&P.tile_desc[tile], kDescPrefix | (excl + block_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (lane == 0) { s_misc[8] = (unsigned)excl; s_misc[9] = (unsigned)(excl >> 32); }
+  }
+  __syncthreads();
+  const unsigned long long base = ((unsigned long long)s_misc[9] << 32) | s_misc[8];
+
+  // ---- phase 3: emit span records in match order
+  if (mask) {
+    unsigned long long idx = base + wave_off + (incl - cnt);
+    const int ncap = T.ncap;
+    while (mask) {
+      const int b = __builtin_ctzll(mask);
+      mask &= mask - 1;
+      const int s = a + b;
+      const int e = T.fixed_len >= 0 ? s + T.fixed_len : Walk<MODE>(tab, in, T, s_ctx, s);
+      if (idx < (unsigned long long)P.cap_records) {
+        int32_t* rec = P.spans + idx * ncap;
+        if (T.fixed_captures) WriteRecordFixed(rec, ncap, s_kind, s_delta, s, e);
+        else { rec[0] = s; rec[1] = e; }
+      }
+      ++idx;
+    }
+  }
+}
+
+// ---- serial carry resolution (rare path) -----------------------------------------------------------------
+// Launched with one lane per slice; only the head of each run of unsynced slices does work: it re-derives the
+// search position entering the run from the preceding (synced) slice and walks the run sequentially.
+__device__ __forceinline__ unsigned StepG(const DevTables& T, unsigned q, int c) { return T.trans[q * T.stride + T.cls[c]]; }
+__device__ __forceinline__ unsigned StepDirectG(const DevTables& T, unsigned q, int c) { return T.trans[(q << 8) + c]; }
+
+__device__ int WalkGlobal(const DevTables& T, const uint8_t* buf, int len, int pos) {
+  int ctx = pos == 0 ? kCtxBOT : T.ctx_of_byte[buf[pos - 1]];
+  unsigned q = T.start[ctx];
+  int end = T.start_accept[ctx] ? pos : -1;
+  const bool direct = T.mode == kModeDirect;
+  for (int i = pos;; ++i) {
+    unsigned e;
+    const bool eot = i >= len;
+    if (eot) e = direct ? T.trans[(T.nstates << 8) + q] : T.trans[q * T.stride + T.ncls];
+    else e = direct ? StepDirectG(T, q, buf[i]) : StepG(T, q, buf[i]);
+    if (e & kMatchBefore) end = i;
+    if (e & kMatchAfter) end = i + 1;
+    q = e & kStateMask;
+    if (q == kDead || eot) break;
+  }
+  return end;
+}
+
+__global__ void carry_kernel(DevTables T, const uint8_t* buf, int32_t len, const uint8_t* unsynced, int32_t* carry_in,
+                             int32_t nslices) {
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= nslices || !unsynced[s]) return;
+  if (s > 0 && unsynced[s - 1]) return;  // not the head of a run
+  // search position entering slice s: replay the preceding synced slice from its own sync point
+  int pos = 0;
+  if (s > 0) {
+    const int a_prev = (s - 1) * kSliceBytes;
+    int j = a_prev - 1;
+    while (j >= 0 && !T.reset_byte[buf[j]]) --j;   // the scan kernel found one within its window, so this terminates early
+    pos = j + 1;
+  }
+  int cur = s;
+  const int run_begin = s * kSliceBytes;
+  // advance to the run
+  while (pos < run_begin) {
+    int end = WalkGlobal(T, buf, len, pos);
+    pos = (end >= 0) ? (end > pos ? end : pos + 1) : pos + 1;
+  }
+  while (cur < nslices && unsynced[cur]) {
+    const int a = cur * kSliceBytes;
+    int e_slice = a + kSliceBytes;
+    if (e_slice > len) e_slice = len;
+    carry_in[cur] = pos < a ? a : pos;
+    if (pos < a) pos = a;
+    while (pos < e_slice) {
+      int end = WalkGlobal(T, buf, len, pos);
+      pos = (end >= 0) ? (end > pos ? end : pos + 1) : pos + 1;
+    }
+    ++cur;
+  }
+}
+
+// ---- capture back-trace ------------------------------------------------------------------------------------
+// Walk [s, e] again recording the state before each byte, then follow thread parents backwards; the first
+// assignment met going backwards is the last one the winning thread made going forwards.
+__device__ void ResolveCaptures(const DevTables& T, const uint8_t* buf, int len, int s, int e, uint16_t* trace, int32_t* rec) {
+  const int ncap = T.ncap;
+  const int unset = T.unmatched_minus1 ? -1 : 0;
+  int ctx = s == 0 ? kCtxBOT : T.ctx_of_byte[buf[s - 1]];
+  unsigned q = T.start[ctx];
+  const int n = e - s;
+  const bool direct = T.mode == kModeDirect;
+  for (int i = 0; i <= n; ++i) {
+    trace[i] = (uint16_t)q;
+    if (i == n) break;
+    unsigned ed = direct ? StepDirectG(T, q, buf[s + i]) : StepG(T, q, buf[s + i]);
+    q = ed & kStateMask;
+  }
+  unsigned setmask = 3u;
+  int32_t vals[32];
+  for (int c = 0; c < ncap; ++c) vals[c] = unset;
+  vals[0] = s; vals[1] = e;
+  int j;
+  if (T.lookahead) {
+    const unsigned qe = trace[n];
+    const int k = e < len ? T.cls[buf[e]] : T.ncls;
+    const unsigned m = T.bt_match[qe * T.stride + k];
+    j = (int)(m >> 24);
+    unsigned ops = (m & 0xFFFFFFu) & ~setmask;
+    while (ops) { int c = __builtin_ctz(ops); ops &= ops - 1; vals[c] = e; setmask |= 1u << c; }
+    for (int i = n - 1; i >= 0; --i) {
+      const unsigned base = T.bt_base[(unsigned)trace[i] * T.stride + T.cls[buf[s + i]]];
+      unsigned o = T.bt_ops[base + j] & ~setmask;
+      while (o) { int c = __builtin_ctz(o); o &= o - 1; vals[c] = s + i; setmask |= 1u << c; }
+      j = T.bt_parent[base + j];
+    }
+  } else {
+    j = (int)T.st_nthreads[trace[n]] - 1;
+    for (int i = n - 1; i >= 0; --i) {
+      const unsigned base = T.bt_base[(unsigned)trace[i] * T.stride + T.cls[buf[s + i]]];
+      unsigned o = T.bt_ops[base + j] & ~setmask;
+      while (o) { int c = __builtin_ctz(o); o &= o - 1; vals[c] = s + i + 1; setmask |= 1u << c; }
+      j = T.bt_parent[base + j];
+    }
+    unsigned o = T.start_ops_pool[T.start_ops[ctx] + j] & ~setmask;
+    while (o) { int c = __builtin_ctz(o); o &= o - 1; vals[c] = s; setmask |= 1u << c; }
+  }
+  for (int c = 0; c < ncap; ++c) rec[c] = vals[c];
+}
+
+constexpr int kCapsLdsTrace = 96;  // uint16 entries of LDS trace per lane (matches up to 95 bytes stay on chip)
+
+__global__ __launch_bounds__(64) void caps_kernel(DevTables T, const uint8_t* buf, int32_t len, int32_t* spans, int64_t nmatches,
+                                                  uint16_t* trace, unsigned long long* cursor) {
+  __shared__ uint16_t s_trace[64 * kCapsLdsTrace];
+  const int64_t m = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (m >= nmatches) return;
+  int32_t* rec = spans + m * T.ncap;
+  const int s = rec[0], e = rec[1];
+  const int need = e - s + 1;
+  uint16_t* tr;
+  if (need <= kCapsLdsTrace) tr = s_trace + threadIdx.x * kCapsLdsTrace;
+  else tr = trace + atomicAdd(cursor, (unsigned long long)need);
+  ResolveCaptures(T, buf, len, s, e, tr, rec);
+}
+
+// ---- batch: one string per lane --------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void batch_kernel(DevTables T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr,
+                                                   uint8_t* found, int32_t* spans, uint16_t* trace, int64_t trace_stride) {
+  __shared__ uint16_t s_trace[64 * kCapsLdsTrace];
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= nstr) return;
+  const uint64_t o0 = offsets[i], o1 = offsets[i + 1];
+  const uint8_t* buf = concat + o0;
+  const int len = (int)(o1 - o0);
+  int s = -1, e = -1;
+  // leftmost-first search: first start position with a match (an attempt AT len is allowed: find.go:545-569
+  // restarts while l > offset, so offset can reach l)
+  for (int pos = 0; pos <= len; ++pos) {
+    if (T.anchored && pos > 0) break;
+    int end = WalkGlobal(T, buf, len, pos);
+    if (end >= 0) { s = pos; e = end; break; }
+  }
+  found[i] = s >= 0;
+  if (!spans) return;
+  int32_t* rec = spans + i * T.ncap;
+  if (s < 0) { for (int c = 0; c < T.ncap; ++c) rec[c] = T.unmatched_minus1 ? -1 : 0; return; }
+  if (T.fixed_captures) {
+    for (int c = 0; c < T.ncap; ++c) rec[c] = T.cap_kind[c] == kCapFromStart ? s + T.cap_delta[c] : e - T.cap_delta[c];
+    return;
+  }
+  const int need = e - s + 1;
+  // trace_stride < 0: CSR-shaped scratch (string i owns [offsets[i] + 2i, offsets[i+1] + 2i + 2))
+  uint16_t* tr = need <= kCapsLdsTrace ? s_trace + threadIdx.x * kCapsLdsTrace
+                                       : (trace_stride < 0 ? trace + o0 + 2 * i : trace + i * trace_stride);
+  ResolveCaptures(T, buf, len, s, e, tr, rec);
+}
+
+}  // namespace
+
+size_t ScanSharedBytes(const DevTables& T) {
+  size_t b = (kPaddedWindow + 15) & ~15;
+  b += (T.table_bytes + 15) & ~15;
+  b += 256 * 3 + 32 * 4 + 32 + 16 * 4 + 256 * 4;
+  return (b + 15) & ~size_t(15);
+}
+
+hipError_t LaunchScan(const DevTables& T, const ScanParams& P, hipStream_t stream) {
+  const size_t shmem = ScanSharedBytes(T);
+  dim3 grid(P.ntiles), block(kBlockThreads);
+  static bool attr_set[8] = {false, false, false, false, false, false, false, false};
+  auto set_attr = [&](const void* fn, int mode) {
+    if (!attr_set[mode]) {
+      hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr_set[mode] = true;
+    }
+  };
+#define RGX_LAUNCH(M, S, SLOT)                                                        \
+  do {                                                                                \
+    set_attr((const void*)scan_kernel<M, S>, SLOT);                                   \
+    hipLaunchKernelGGL((scan_kernel<M, S>), grid, block, shmem, stream, T, P);        \
+  } while (0)
+  const int sa = (T.sa_k > 0 && !T.anchored) ? (T.sa_exact ? 2 : 1) : 0;
+  if (sa == 2) {
+    RGX_LAUNCH(kModeDirect, 2, 0);
+  } else if (T.mode == kModeDirect) {
+    if (sa) RGX_LAUNCH(kModeDirect, 1, 1); else RGX_LAUNCH(kModeDirect, 0, 2);
+  } else if (T.mode == kModeClassLds) {
+    if (sa) RGX_LAUNCH(kModeClassLds, 1, 3); else RGX_LAUNCH(kModeClassLds, 0, 4);
+  } else {
+    if (sa) RGX_LAUNCH(kModeClassGlobal, 1, 5); else RGX_LAUNCH(kModeClassGlobal, 0, 6);
+  }
+#undef RGX_LAUNCH
+  return hipGetLastError();
+}
+
+hipError_t LaunchCarry(const DevTables& T, const uint8_t* buf, int32_t len, const uint8_t* slice_unsynced, int32_t* carry_in,
+                       int32_t nslices, hipStream_t stream) {
+  dim3 block(256), grid((nslices + 255) / 256);
+  hipLaunchKernelGGL(carry_kernel, grid, block, 0, stream, T, buf, len, slice_unsynced, carry_in, nslices);
+  return hipGetLastError();
+}
+
+hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, int32_t* spans, int64_t nmatches, uint16_t* trace,
+                          unsigned long long* trace_cursor, hipStream_t stream) {
+  if (nmatches <= 0) return hipSuccess;
+  dim3 block(64), grid((unsigned)((nmatches + 63) / 64));
+  hipLaunchKernelGGL(caps_kernel, grid, block, 0, stream, T, buf, len, spans, nmatches, trace, trace_cursor);
+  return hipGetLastError();
+}
+
+hipError_t LaunchBatch(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,
+                       int32_t* spans, uint16_t* trace, int64_t trace_stride, hipStream_t stream) {
+  if (nstr <= 0) return hipSuccess;
+  dim3 block(64), grid((unsigned)((nstr + 63) / 64));
+  hipLaunchKernelGGL(batch_kernel, grid, block, 0, stream, T, concat, offsets, nstr, found, spans, trace, trace_stride);
+  return hipGetLastError();
+}
+
+}  // namespace rgx

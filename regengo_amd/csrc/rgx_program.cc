@@ -1,0 +1,108 @@
+#include "rgx_program.h"
+
+#include <cstring>
+
+#include "rgx.h"
+
+namespace rgx {
+
+static thread_local std::string g_error;
+void SetError(const std::string& s) { g_error = s; }
+const std::string& GetError() { return g_error; }
+
+Program::~Program() {
+  if (d_arena) {
+    hipSetDevice(device);
+    hipFree(d_arena);
+  }
+}
+
+namespace {
+struct Arena {
+  std::vector<uint8_t> host;
+  size_t Add(const void* p, size_t n) {
+    size_t off = (host.size() + 255) & ~size_t(255);
+    host.resize(off + (n ? n : 1));
+    if (n) memcpy(host.data() + off, p, n);
+    return off;
+  }
+  template <class T> size_t AddVec(const std::vector<T>& v) { return Add(v.data(), v.size() * sizeof(T)); }
+};
+}  // namespace
+
+int ProgramToDevice(Program* p, int device) {
+  std::lock_guard<std::mutex> lock(p->mu);
+  if (p->d_arena) {
+    if (p->device == device) return RGX_OK;
+    SetError("program already bound to another device");
+    return RGX_E_INVALID;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    SetError("no usable HIP device (hipGetDeviceCount)");
+    (void)hipGetLastError();
+    return RGX_E_NO_DEVICE;
+  }
+  if (hipSetDevice(device) != hipSuccess) { SetError("hipSetDevice failed"); return RGX_E_NO_DEVICE; }
+
+  const Tables& t = p->t;
+  const int stride = t.ncls + 1;
+  DevTables d{};
+  d.nstates = t.nstates; d.ncls = t.ncls; d.stride = stride; d.ncap = t.ncap; d.fixed_len = t.fixed_len;
+  for (int i = 0; i < 4; i++) { d.start[i] = t.start[i]; d.start_accept[i] = t.start_accept[i]; }
+  d.lookahead = t.lookahead_mode; d.ctx_sensitive = t.ctx_sensitive; d.bot_sensitive = t.bot_sensitive; d.anchored = t.anchored;
+  d.sa_k = t.sa_k; d.sa_exact = t.sa_exact;
+  d.fixed_captures = t.fixed_captures; d.unmatched_minus1 = (t.flags & RGX_FLAG_UNMATCHED_MINUS1) ? 1 : 0;
+
+  // choose the LDS layout
+  Arena a;
+  size_t off_trans;
+  const size_t direct_bytes = (size_t)t.nstates * 257 * 2;
+  const size_t class_bytes = (size_t)t.nstates * stride * 2;
+  if (direct_bytes <= 40 * 1024) {
+    d.mode = kModeDirect;
+    p->direct_table.assign((size_t)t.nstates * 257, 0);
+    for (int q = 0; q < t.nstates; q++) {
+      for (int c = 0; c < 256; c++) p->direct_table[(size_t)q * 256 + c] = t.trans[(size_t)q * stride + t.cls[c]];
+      p->direct_table[(size_t)t.nstates * 256 + q] = t.trans[(size_t)q * stride + t.ncls];
+    }
+    off_trans = a.AddVec(p->direct_table);
+    d.table_bytes = (int32_t)direct_bytes;
+  } else if (class_bytes <= 96 * 1024) {
+    d.mode = kModeClassLds;
+    off_trans = a.AddVec(t.trans);
+    d.table_bytes = (int32_t)class_bytes;
+  } else {
+    d.mode = kModeClassGlobal;
+    off_trans = a.AddVec(t.trans);
+    d.table_bytes = 0;
+  }
+  size_t off_cls = a.Add(t.cls, 256), off_reset = a.Add(t.reset_byte, 256), off_ctx = a.Add(t.ctx_of_byte, 256);
+  size_t off_delta = a.AddVec(t.cap_delta), off_kind = a.AddVec(t.cap_kind);
+  size_t off_nth = a.AddVec(t.st_nthreads), off_base = a.AddVec(t.bt_base), off_par = a.AddVec(t.bt_parent);
+  size_t off_ops = a.AddVec(t.bt_ops), off_bm = a.AddVec(t.bt_match), off_so = a.AddVec(t.start_ops);
+  size_t off_sop = a.AddVec(t.start_ops_pool);
+  size_t off_sa = a.Add(t.sa_mask, sizeof t.sa_mask);
+
+  void* dptr = nullptr;
+  if (hipMalloc(&dptr, a.host.size()) != hipSuccess) { SetError("hipMalloc(tables) failed"); return RGX_E_NOMEM; }
+  if (hipMemcpy(dptr, a.host.data(), a.host.size(), hipMemcpyHostToDevice) != hipSuccess) {
+    hipFree(dptr);
+    SetError("hipMemcpy(tables) failed");
+    return RGX_E_HIP;
+  }
+  uint8_t* b = (uint8_t*)dptr;
+  d.trans = (const uint16_t*)(b + off_trans);
+  d.cls = b + off_cls; d.reset_byte = b + off_reset; d.ctx_of_byte = b + off_ctx;
+  d.cap_delta = (const int32_t*)(b + off_delta); d.cap_kind = b + off_kind;
+  d.st_nthreads = (const uint32_t*)(b + off_nth); d.bt_base = (const uint32_t*)(b + off_base); d.bt_parent = b + off_par;
+  d.bt_ops = (const uint32_t*)(b + off_ops); d.bt_match = (const uint32_t*)(b + off_bm);
+  d.start_ops = (const uint32_t*)(b + off_so); d.start_ops_pool = (const uint32_t*)(b + off_sop);
+  d.sa_mask = (const uint32_t*)(b + off_sa);
+  p->dev = d;
+  p->d_arena = dptr;
+  p->device = device;
+  return RGX_OK;
+}
+
+}  // namespace rgx

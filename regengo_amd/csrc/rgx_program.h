@@ -1,0 +1,73 @@
+// Program object behind the C ABI: host tables + their device image + per-call scratch.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "rgx_dfa.h"
+
+namespace rgx {
+
+// Geometry of the scan kernel (see rgx_kernels.hip / DESIGN.md).
+constexpr int kSliceBytes = 64;                       // input bytes owned by one lane
+constexpr int kBlockThreads = 256;                    // 4 waves
+constexpr int kTileBytes = kSliceBytes * kBlockThreads;  // 16 KiB of input per workgroup
+constexpr int kHaloL = 256;                           // look-behind staged in LDS (sync-point search)
+constexpr int kHaloR = 256;                           // look-ahead staged in LDS (walks crossing the tile end)
+
+enum TableMode : int {
+  kModeDirect = 0,     // LDS: uint16 next[state][256] + eot[state]      (small DFAs: one lookup per byte)
+  kModeClassLds = 1,   // LDS: uint8 cls[256] + uint16 next[state][ncls+1]
+  kModeClassGlobal = 2 // cls in LDS, transition table read through L1/L2 (too big for LDS)
+};
+
+// Flat device image of one compiled pattern.  All pointers are device addresses.
+struct DevTables {
+  const uint16_t* trans;      // layout depends on mode (direct: [nstates][256] then eot[nstates])
+  const uint8_t* cls;         // [256]
+  const uint8_t* reset_byte;  // [256]
+  const uint8_t* ctx_of_byte; // [256]
+  const int32_t* cap_delta;   // [ncap]
+  const uint8_t* cap_kind;    // [ncap]
+  // capture back-trace
+  const uint32_t* st_nthreads;
+  const uint32_t* bt_base;
+  const uint8_t* bt_parent;
+  const uint32_t* bt_ops;
+  const uint32_t* bt_match;
+  const uint32_t* start_ops;      // [4]
+  const uint32_t* start_ops_pool;
+  const uint32_t* sa_mask;        // [256] Shift-And level-set masks (prefilter)
+  int32_t nstates, ncls, stride;  // stride = ncls+1 (class layouts)
+  int32_t mode;
+  int32_t table_bytes;            // bytes staged into LDS for the transition table
+  int32_t ncap;
+  int32_t fixed_len;
+  int32_t sa_k;                   // 0: no prefilter
+  int32_t sa_exact;
+  uint16_t start[4];
+  uint8_t start_accept[4];
+  uint8_t lookahead, ctx_sensitive, bot_sensitive, anchored, fixed_captures, unmatched_minus1, pad0, pad1;
+};
+
+struct Program {
+  Tables t;
+  std::vector<uint8_t> blob_cache;
+  // device side
+  std::mutex mu;
+  int device = -1;
+  void* d_arena = nullptr;  // one allocation holding every table
+  DevTables dev{};
+  std::vector<uint16_t> direct_table;  // host copy of the direct layout (mode 0)
+  ~Program();
+};
+
+int ProgramToDevice(Program* p, int device);  // RGX_OK or negative status
+
+void SetError(const std::string& s);
+const std::string& GetError();
+
+}  // namespace rgx

@@ -1,0 +1,117 @@
+"""Synthetic inputs for BASELINE.json's configs.  One PRNG (splitmix64, counter mode: byte i depends only on
+(seed, i)) so numpy, torch-on-GPU and C produce identical bytes; Go's math/rand(42) stream used by the
+reference's PatternedReader (tests/integration/streaming/memory_test.go:13-48) is not reproducible without Go.
+
+C2  "date log": period 50 = "2024-01-15" + 40 noise bytes from "abcdefghijk \\n\\t"  (same shape as the
+    reference's PatternedReader("2024-01-15", 50, n)).  Closed form: a match at every multiple of 50 that fits.
+C2b adversarial: noise alphabet widened with digits and '-' so that candidates overlap / near-miss.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+NOISE = b"abcdefghijk \n\t"
+NOISE_ADV = b"abcdefghijk \n\t0123456789--"
+PATTERN = b"2024-01-15"
+MASK64 = (1 << 64) - 1
+
+
+def splitmix64_np(seed: int, idx: np.ndarray) -> np.ndarray:
+    with np.errstate(over="ignore"):
+        z = (np.uint64(seed) + (idx.astype(np.uint64) + np.uint64(1)) * np.uint64(0x9E3779B97F4A7C15))
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+def date_log_np(n: int, seed: int = 42, every: int = 50, adversarial: bool = False, start: int = 0) -> np.ndarray:
+    """Bytes [start, start+n) of the infinite date-log stream."""
+    alphabet = np.frombuffer(NOISE_ADV if adversarial else NOISE, dtype=np.uint8)
+    idx = np.arange(start, start + n, dtype=np.uint64)
+    r = splitmix64_np(seed, idx)
+    out = alphabet[((r >> np.uint64(33)) % np.uint64(len(alphabet))).astype(np.int64)]
+    pic = (idx % np.uint64(every)).astype(np.int64)
+    pat = np.frombuffer(PATTERN, dtype=np.uint8)
+    m = pic < len(pat)
+    out = out.copy()
+    out[m] = pat[pic[m]]
+    return out
+
+
+def _splitmix64_torch(seed: int, idx):
+    import torch
+
+    def lsr(x, k):  # logical shift right on int64
+        return (x >> k) & ((1 << (64 - k)) - 1)
+
+    def c(v):  # python int -> wrapped int64 constant
+        return v - (1 << 64) if v >= (1 << 63) else v
+
+    z = (idx + 1) * c(0x9E3779B97F4A7C15) + c(seed & MASK64)
+    z = (z ^ lsr(z, 30)) * c(0xBF58476D1CE4E5B9)
+    z = (z ^ lsr(z, 27)) * c(0x94D049BB133111EB)
+    z = z ^ lsr(z, 31)
+    return z
+
+
+def date_log_torch(n: int, device, seed: int = 42, every: int = 50, adversarial: bool = False, start: int = 0,
+                   chunk: int = 1 << 26):
+    """Same bytes as date_log_np, generated on `device` in chunks (1 GiB takes well under a second on MI355X)."""
+    import torch
+    alpha = NOISE_ADV if adversarial else NOISE
+    alphabet = torch.tensor(list(alpha), dtype=torch.uint8, device=device)
+    pat = torch.tensor(list(PATTERN), dtype=torch.uint8, device=device)
+    out = torch.empty(n, dtype=torch.uint8, device=device)
+    for o in range(0, n, chunk):
+        m = min(chunk, n - o)
+        idx = torch.arange(start + o, start + o + m, dtype=torch.int64, device=device)
+        r = _splitmix64_torch(seed, idx)
+        sel = ((r >> 33) & ((1 << 31) - 1)) % len(alpha)
+        b = alphabet[sel]
+        pic = idx % every
+        mk = pic < len(PATTERN)
+        b[mk] = pat[pic[mk]]
+        out[o:o + m] = b
+        del idx, r, sel, b, pic, mk
+    return out
+
+
+def date_log_expected(n: int, every: int = 50):
+    """Closed-form FindAllBytes result for the non-adversarial date log: starts 0, every, 2*every, ... while the
+    whole 10-byte date fits."""
+    plen = len(PATTERN)
+    if n < plen:
+        return np.zeros((0, 8), dtype=np.int32)
+    cnt = (n - plen) // every + 1
+    s = (np.arange(cnt, dtype=np.int64) * every).astype(np.int32)
+    return np.stack([s, s + 10, s, s + 4, s + 5, s + 7, s + 8, s + 10], axis=1)
+
+
+def email_batch_np(nstr: int, seed: int = 0x5EED0003):
+    """C3: strings for (?P<user>\\w+)@(?P<domain>\\w+): length U[8,40]; 80% contain word@word with padding, 10% no '@',
+    5% leading/trailing '@', 5% contain a byte >= 0x80.  Returns (concat uint8, offsets int64[nstr+1])."""
+    ids = np.arange(nstr, dtype=np.uint64)
+    r0 = splitmix64_np(seed, ids * np.uint64(4))
+    r1 = splitmix64_np(seed, ids * np.uint64(4) + np.uint64(1))
+    r2 = splitmix64_np(seed, ids * np.uint64(4) + np.uint64(2))
+    lens = (8 + (r0 >> np.uint64(40)) % np.uint64(33)).astype(np.int64)
+    offsets = np.zeros(nstr + 1, dtype=np.int64)
+    np.cumsum(lens, out=offsets[1:])
+    total = int(offsets[-1])
+    # base: word characters and spaces
+    alphabet = np.frombuffer(b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789_   ..--", dtype=np.uint8)
+    bidx = np.arange(total, dtype=np.uint64)
+    rb = splitmix64_np(seed ^ 0xABCDEF, bidx)
+    data = alphabet[((rb >> np.uint64(33)) % np.uint64(len(alphabet))).astype(np.int64)].copy()
+    kind = ((r1 >> np.uint64(33)) % np.uint64(100)).astype(np.int64)
+    at_pos = (1 + (r2 >> np.uint64(33)) % (lens.astype(np.uint64) - np.uint64(2))).astype(np.int64)  # interior
+    has_at = kind < 80
+    data[offsets[:-1][has_at] + at_pos[has_at]] = ord("@")
+    lead = (kind >= 90) & (kind < 93)
+    data[offsets[:-1][lead]] = ord("@")
+    trail = (kind >= 93) & (kind < 95)
+    data[offsets[1:][trail] - 1] = ord("@")
+    hi = kind >= 95
+    data[offsets[:-1][hi] + at_pos[hi]] = 0xC3
+    return data, offsets
