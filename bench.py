@@ -1,0 +1,184 @@
+#!/usr/bin/env python3
+"""Headline benchmark (BASELINE.json): input GB/s of FindAllBytes over a 1 GiB synthetic date-log buffer per
+MI355X, bit-exact offsets, at 1/2/4/8 GPUs.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N>1: launched by torch.distributed.run, one rank per GPU, backend nccl == RCCL)
+
+One "step" = one FindAllBytes pass over this rank's 1 GiB shard, input already resident in HBM, producing the full
+ordered span table [matches, 8] int32 in HBM, plus (N>1) the all_gather of per-rank match counts that fixes every
+rank's global row base.  Weak scaling: N GPUs scan N GiB of one stream.  `value` = total input bytes of all ranks /
+max-over-ranks wall time of the K timed steps.  The spans stay rank-local (row-sharded result); moving all rows to
+rank 0 is measured separately (`gather_ms`) because 32 B/match is as large as the input.
+
+Extra objects: `roofline` (HBM; algorithmic bytes = 1 byte per input byte per launch / scan-kernel duration from HIP
+events on the launch stream) and `cpu_baseline` (the oracle's generated-C port of the reference's emitted matcher,
+one core, on a bounded sample of the same workload).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+DATE = r"(?P<year>\d{4})-(?P<month>\d{2})-(?P<day>\d{2})"
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--bytes", type=int, default=1 << 30, help="shard size per GPU")
+    ap.add_argument("--adversarial", action="store_true", help="noise alphabet with digits and '-' (config C2b)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--gather-spans", action="store_true", help="also time the variable-length gather of all rows to rank 0")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
+    dev = "cuda:%d" % local_rank
+    torch.cuda.set_device(local_rank)
+
+    from regengo_amd import Compiled, synth
+    from regengo_amd.dist import ShardedFinder, plan_shards
+
+    L = args.bytes
+    c = Compiled(DATE, name="Date").to(local_rank)
+    c.set_timing(True)
+    shards = plan_shards(L * world, world, c.MaxMatchLen)
+    sh = shards[rank]
+    window = synth.date_log_torch(sh.win_hi - sh.win_lo, dev, adversarial=args.adversarial, start=sh.win_lo)
+    finder = ShardedFinder.for_compiled(c, dev)
+    cap = (sh.win_hi - sh.win_lo) // c.MinMatchLen + 1
+    out = torch.empty((cap, c.ncap), dtype=torch.int32, device=dev)
+
+    def scan(w):
+        spans, res = c.FindAllSpans(w, out=out, capacity=cap)
+        return spans, {"kernel_ms": res.kernel_ms, "unsynced": int(res.unsynced)}
+
+    finder.scan = scan
+
+    def step():
+        owned, cnt, info = finder.find_all_local(window, sh)
+        base, total, counts = finder.global_row_base(cnt, dev)
+        return owned, cnt, info, base, total, counts
+
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    kms = []
+    for _ in range(args.steps):
+        owned, cnt, info, base, total, counts = step()
+        kms.append(info["kernel_ms"])
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+    dt = float(tmax.item())
+
+    # parity gate: the timed path's result equals the closed form (every date at a multiple of 50 of the GLOBAL stream)
+    parity = None
+    if not args.adversarial:
+        import numpy as np
+        g0 = -(-sh.lo // 50) * 50
+        starts = torch.arange(g0, sh.hi, 50, dtype=torch.int64, device=dev)
+        starts = starts[starts + 10 <= L * world]
+        rel = (starts - sh.win_lo).to(torch.int32)
+        exp = torch.stack([rel, rel + 10, rel, rel + 4, rel + 5, rel + 7, rel + 8, rel + 10], dim=1)
+        parity = bool(owned.shape == exp.shape and torch.equal(owned, exp))
+    pt = torch.tensor([1 if parity in (True, None) else 0], dtype=torch.int64, device=dev)
+    if world > 1:
+        dist.all_reduce(pt, op=dist.ReduceOp.MIN)
+    parity_all = bool(pt.item())
+
+    gather_ms = None
+    if args.gather_spans and world > 1:
+        torch.cuda.synchronize(); dist.barrier()
+        g0t = time.perf_counter()
+        finder.gather_spans(owned, sh, counts)
+        torch.cuda.synchronize(); dist.barrier()
+        gather_ms = (time.perf_counter() - g0t) * 1e3
+
+    if rank == 0:
+        ms_per_step = dt / args.steps * 1e3
+        total_bytes = float(L) * world
+        value = total_bytes / (dt / args.steps) / 1e9
+        k_ms = sum(kms) / len(kms)
+        win_bytes = sh.win_hi - sh.win_lo
+        achieved = win_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+        traffic = None
+        pj = os.path.join(ROOT, "profiles", "r01_pmc.json")
+        if os.path.exists(pj):
+            try:
+                traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        line = {
+            "metric": "input GB/s (FindAllBytes, 1 GiB buf) at 1/2/4/8 MI355X; bit-exact offsets",
+            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "C2: Date DFA FindAllBytes over a 1 GiB synthetic date-log buffer per GPU"
+                                   + (" (adversarial noise)" if args.adversarial else ""),
+                       "pattern": DATE, "bytes_per_gpu": L, "matches_per_gpu": int(cnt), "matches_total": int(total),
+                       "span_record_bytes": 4 * c.ncap, "parallelism": "shard%d" % world, "parity_closed_form": parity_all,
+                       "gather_ms": gather_ms},
+            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+                         "kernel": "scan_kernel", "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": win_bytes},
+        }
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.adversarial)
+        print(json.dumps(line))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def cpu_baseline(adversarial: bool):
+    """The oracle's generated-C port of the reference's emitted FindAllBytes machine (oracle/gen_c.py), ONE core,
+    timed on a bounded sample of the same workload: the first 1 GiB of the stream, 4 passes (~10 s)."""
+    import numpy as np
+    from oracle.gen_c import CMatcher
+    from regengo_amd import synth
+    n = 1 << 30
+    buf = np.empty(n, dtype=np.uint8)
+    step = 1 << 26
+    for o in range(0, n, step):
+        buf[o:o + step] = synth.date_log_np(step, adversarial=adversarial, start=o)
+    cm = CMatcher(DATE)
+    out = np.empty((n // 10 + 1, 8), dtype=np.int32)
+    passes = 4
+    t0 = time.perf_counter()
+    cnt = 0
+    for _ in range(passes):
+        cnt = cm.lib.m_find_all(buf.ctypes.data, n, -1, out.ctypes.data, out.shape[0])
+    dt = time.perf_counter() - t0
+    return {"value": round(n * passes / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": "first 1 GiB of the same stream, %d passes, FindAllBytes with full span output; matches=%d" % (passes, cnt),
+            "host_cores_available": os.cpu_count()}
+
+
+if __name__ == "__main__":
+    main()

@@ -87,6 +87,9 @@ typedef struct rgx_info {
 int rgx_program_info(const rgx_program* p, rgx_info* out);
 /* NUL-separated capture names, group 0 first ("" for unnamed); returns bytes written or needed.    */
 int64_t rgx_program_capture_names(const rgx_program* p, char* dst, size_t cap);
+/* 256 flags: 1 = every automaton state dies on this byte, so the next offset is a FindAll sync point (used by
+ * callers that shard one input across GPUs; DESIGN.md "sync points").                                   */
+int rgx_program_reset_bytes(const rgx_program* p, uint8_t* dst256);
 
 /* ---- device binding --------------------------------------------------------------------------- */
 int rgx_device_count(void);

@@ -1,0 +1,197 @@
+"""ORACLE (test infrastructure, not product): emit a pattern-specialised C matcher shaped like the code the
+reference's generator emits in Go -- one labelled block per `syntax.Inst`, a `StepSelect` switch, an explicit
+backtracking stack, `TryFallback` (internal/compiler/instructions.go:21-33,51-605; find.go:130-466;
+compiler.go:740-871; backtracking.go).  Compiled with gcc -O2 it is the `cpu_baseline` ("port") of bench.py and
+the bulk checker for sizes the pure-Python machine (oracle/engines.py) cannot reach; tests pin it against
+engines.py on the golden corpus.  Byte semantics only (ASCII classes, multi-byte literals as byte sequences);
+Unicode-decoding classes are refused.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this.
+"""
+from __future__ import annotations
+
+import ctypes
+import hashlib
+import os
+import subprocess
+from typing import List, Optional
+
+from . import engines as E
+from . import syntax as S
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BUILD = os.path.join(HERE, "_build")
+
+
+def _cond_fail(ins: S.Inst) -> str:
+    """C expression that is TRUE when the byte at input[offset] does NOT match (the emitted `if ... goto TryFallback`)."""
+    if ins.op == S.InstRuneAny:
+        return "0"
+    if ins.op == S.InstRuneAnyNotNL:
+        return "input[offset] == 0x0a"
+    if ins.op == S.InstRune1:
+        return "input[offset] != 0x%02x" % ins.rune[0]
+    r = ins.rune
+    if len(r) == 0:
+        return "1"
+    if any(r[i + 1] >= 128 for i in range(0, len(r), 2)):
+        raise NotImplementedError("unicode class")
+    parts = []
+    for i in range(0, len(r), 2):
+        lo, hi = r[i], r[i + 1]
+        parts.append("(c == 0x%02x)" % lo if lo == hi else "(c >= 0x%02x && c <= 0x%02x)" % (lo, hi))
+    return "!(%s)" % " || ".join(parts)
+
+
+def emit_c(prog: S.Prog, memo: bool, name: str = "m") -> str:
+    ninst = len(prog.inst)
+    ncap = prog.numcap
+    anchored = E.is_anchored(prog)
+    o: List[str] = []
+    w = o.append
+    w("#include <stdint.h>\n#include <stdlib.h>\n#include <string.h>\n")
+    w("#define NCAP %d\n#define NINST %d\n" % (ncap, ninst))
+    w("static inline int is_word(uint8_t c){return (c>='0'&&c<='9')||(c>='A'&&c<='Z')||c=='_'||(c>='a'&&c<='z');}\n")
+    w("typedef struct { int64_t off; int32_t pc; } frame_t;\n")
+    # one attempt from `start`; captures in caps; returns 1 on match (offset in *end), else 0 (failure offset in *end)
+    w("static int attempt(const uint8_t* input, int64_t l, int64_t start, int64_t* caps, int64_t* end,"
+      " frame_t** stk, int64_t** cstk, int64_t* scap, uint32_t* visited) {\n")
+    w("  int64_t offset = start; int64_t sp = 0; int next = %d; frame_t* stack = *stk; int64_t* cstack = *cstk;\n" % prog.start)
+    w("  goto StepSelect;\n")
+    w("TryFallback:\n  if (sp > 0) { sp--; offset = stack[sp].off; next = stack[sp].pc; memcpy(caps, cstack + sp*NCAP, sizeof(int64_t)*NCAP); goto StepSelect; }\n")
+    w("  *end = offset; return 0;\n")
+    w("StepSelect:\n  switch (next) {\n")
+    for i in range(ninst):
+        w("    case %d: goto Ins%d;\n" % (i, i))
+    w("  }\n  *end = offset; return 0;\n")
+    for i, ins in enumerate(prog.inst):
+        w("Ins%d: {\n" % i)
+        op = ins.op
+        if op == S.InstFail:
+            w("  goto TryFallback;\n")
+        elif op == S.InstMatch:
+            w("  *end = offset; return 1;\n")
+        elif op == S.InstNop or op == S.InstAltMatch:
+            w("  goto Ins%d;\n" % ins.out)
+        elif op == S.InstCapture:
+            w("  caps[%d] = offset; next = %d; goto StepSelect;\n" % (ins.arg, ins.out))
+        elif op == S.InstAlt:
+            if memo:
+                w("  { int64_t idx = (int64_t)%d * (l + 1) + offset; uint32_t bit = 1u << (idx & 31);\n" % i)
+                w("    if (visited[idx >> 5] & bit) goto TryFallback; visited[idx >> 5] |= bit; }\n")
+            w("  if (sp == *scap) { *scap *= 2; stack = *stk = (frame_t*)realloc(stack, sizeof(frame_t) * *scap);"
+              " cstack = *cstk = (int64_t*)realloc(cstack, sizeof(int64_t) * NCAP * *scap); }\n")
+            w("  stack[sp].off = offset; stack[sp].pc = %d; memcpy(cstack + sp*NCAP, caps, sizeof(int64_t)*NCAP); sp++;\n" % ins.arg)
+            w("  goto Ins%d;\n" % ins.out)
+        elif op == S.InstEmptyWidth:
+            a = ins.arg
+            if a & S.EmptyBeginText:
+                w("  if (offset != 0) goto TryFallback;\n")
+            if a & S.EmptyEndText:
+                w("  if (offset != l) goto TryFallback;\n")
+            if a & S.EmptyBeginLine:
+                w("  if (offset != 0 && input[offset-1] != 0x0a) goto TryFallback;\n")
+            if a & S.EmptyEndLine:
+                w("  if (offset != l && input[offset] != 0x0a) goto TryFallback;\n")
+            if a & (S.EmptyWordBoundary | S.EmptyNoWordBoundary):
+                w("  { int pw = offset > 0 && is_word(input[offset-1]); int cw = offset < l && is_word(input[offset]);\n")
+                if a & S.EmptyWordBoundary:
+                    w("    if (pw == cw) goto TryFallback;\n")
+                if a & S.EmptyNoWordBoundary:
+                    w("    if (pw != cw) goto TryFallback;\n")
+                w("  }\n")
+            w("  goto Ins%d;\n" % ins.out)
+        elif op == S.InstRune1 and ins.rune[0] > 127:
+            enc = E.encode_rune(ins.rune[0])
+            n = len(enc)
+            w("  if (l <= offset + %d) goto TryFallback;\n" % (n - 1))
+            w("  if (%s) goto TryFallback;\n" % " || ".join("input[offset+%d] != 0x%02x" % (k, b) for k, b in enumerate(enc)))
+            w("  offset += %d; goto Ins%d;\n" % (n, ins.out))
+        else:
+            w("  if (l <= offset) goto TryFallback;\n")
+            w("  { uint8_t c = input[offset]; (void)c; if (%s) goto TryFallback; }\n" % _cond_fail(ins))
+            w("  offset++; goto Ins%d;\n" % ins.out)
+        w("}\n")
+    w("}\n\n")
+    # FindAllBytesAppend (find.go:130-316)
+    w("int64_t %s_find_all(const uint8_t* input, int64_t l, int64_t n, int32_t* out, int64_t cap) {\n" % name)
+    w("  if (n == 0) return 0;\n  int64_t count = 0, ss = 0, scap = 64, end;\n")
+    w("  frame_t* stack = (frame_t*)malloc(sizeof(frame_t) * scap); int64_t* cstack = (int64_t*)malloc(sizeof(int64_t) * NCAP * scap);\n")
+    if memo:
+        w("  int64_t vwords = ((int64_t)NINST * (l + 1) + 31) / 32; uint32_t* visited = (uint32_t*)calloc(vwords, 4);\n")
+    else:
+        w("  uint32_t* visited = 0;\n")
+    w("  for (;;) {\n    if (n > 0 && count >= n) break;\n")
+    if anchored:
+        w("    if (ss > 0) break;\n")
+    w("    if (ss >= l) break;\n    int64_t caps[NCAP]; memset(caps, 0, sizeof caps); caps[0] = ss;\n")
+    w("    if (attempt(input, l, ss, caps, &end, &stack, &cstack, &scap, visited)) {\n      caps[1] = end;\n")
+    w("      if (count < cap) for (int c = 0; c < NCAP; c++) out[count*NCAP + c] = (int32_t)caps[c];\n      count++;\n")
+    w("      if (caps[1] > ss) ss = caps[1]; else ss++;\n    } else ss++;\n  }\n")
+    w("  free(stack); free(cstack); free(visited);\n  return count;\n}\n\n")
+    # FindBytesReuse (find.go:469-591): Q1 restart from the failure offset
+    w("int %s_find(const uint8_t* input, int64_t l, int32_t* out) {\n" % name)
+    w("  int64_t off = 0, scap = 64, end; int64_t caps[NCAP]; memset(caps, 0, sizeof caps);\n")
+    w("  frame_t* stack = (frame_t*)malloc(sizeof(frame_t) * scap); int64_t* cstack = (int64_t*)malloc(sizeof(int64_t) * NCAP * scap);\n")
+    if memo:
+        w("  int64_t vwords = ((int64_t)NINST * (l + 1) + 31) / 32; uint32_t* visited = (uint32_t*)calloc(vwords, 4);\n")
+    else:
+        w("  uint32_t* visited = 0; int64_t vwords = 0;\n")
+    w("  int found = 0;\n  for (;;) {\n")
+    w("    if (attempt(input, l, off, caps, &end, &stack, &cstack, &scap, visited)) { caps[1] = end; found = 1; break; }\n")
+    if anchored:
+        w("    break;\n")
+    else:
+        w("    if (l > end) { off = end + 1; memset(caps, 0, sizeof caps); caps[0] = off; if (visited) memset(visited, 0, vwords * 4); } else break;\n")
+    w("  }\n  if (found) for (int c = 0; c < NCAP; c++) out[c] = (int32_t)caps[c];\n")
+    w("  free(stack); free(cstack); free(visited); (void)vwords;\n  return found;\n}\n")
+    return "".join(o)
+
+
+class CMatcher:
+    """gcc-compiled specialised matcher for one pattern (cached by source hash under oracle/_build/)."""
+
+    def __init__(self, pattern: str, opt: str = "-O2"):
+        self.pattern = pattern
+        ast, prog = S.compile_pattern(pattern)
+        self.prog = prog
+        sel = E.select(ast, prog)
+        self.ncap = prog.numcap
+        src = emit_c(prog, sel.find_memo)
+        os.makedirs(BUILD, exist_ok=True)
+        h = hashlib.sha256((src + opt).encode()).hexdigest()[:16]
+        so = os.path.join(BUILD, "m_%s.so" % h)
+        if not os.path.exists(so):
+            cfile = os.path.join(BUILD, "m_%s.c" % h)
+            with open(cfile, "w") as f:
+                f.write(src)
+            subprocess.run(["gcc", opt, "-std=c11", "-fPIC", "-shared", cfile, "-o", so + ".tmp"], check=True)
+            os.replace(so + ".tmp", so)
+        self.lib = ctypes.CDLL(so)
+        self.lib.m_find_all.restype = ctypes.c_int64
+        self.lib.m_find_all.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
+        self.lib.m_find.restype = ctypes.c_int
+        self.lib.m_find.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+
+    def find_all_np(self, buf, n: int = -1, cap: Optional[int] = None):
+        """buf: numpy uint8 array (contiguous).  Returns int32 array [count, ncap]."""
+        import numpy as np
+        l = int(buf.size)
+        if cap is None:
+            cap = l + 1
+        out = np.empty((cap, self.ncap), dtype=np.int32)
+        c = self.lib.m_find_all(buf.ctypes.data, l, n, out.ctypes.data, cap)
+        return out[:min(c, cap)], int(c)
+
+    def find_all(self, b: bytes, n: int = -1):
+        import numpy as np
+        arr = np.frombuffer(b, dtype=np.uint8) if len(b) else np.zeros(0, dtype=np.uint8)
+        out, c = self.find_all_np(np.ascontiguousarray(arr), n)
+        return out.tolist()
+
+    def find(self, b: bytes):
+        import numpy as np
+        arr = np.frombuffer(b, dtype=np.uint8) if len(b) else np.zeros(1, dtype=np.uint8)
+        out = np.zeros(self.ncap, dtype=np.int32)
+        ok = self.lib.m_find(np.ascontiguousarray(arr).ctypes.data, len(b), out.ctypes.data)
+        return out.tolist() if ok else None

@@ -55,6 +55,7 @@ SYMBOLS = {
     "rgx_program_destroy": (None, [C.c_void_p]),
     "rgx_program_info": (C.c_int, [C.c_void_p, C.POINTER(Info)]),
     "rgx_program_capture_names": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_size_t]),
+    "rgx_program_reset_bytes": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rgx_device_count": (C.c_int, []),
     "rgx_program_to_device": (C.c_int, [C.c_void_p, C.c_int]),
     "rgx_stream_ctx_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -94,6 +94,11 @@ class Compiled:
         _capi.check(self._lib.rgx_program_blob_write(self._h, b, n))
         return b.raw
 
+    def reset_bytes(self) -> bytes:
+        b = C.create_string_buffer(256)
+        _capi.check(self._lib.rgx_program_reset_bytes(self._h, b))
+        return b.raw
+
     def to(self, device: int = 0) -> "Compiled":
         _capi.check(self._lib.rgx_program_to_device(self._h, device))
         if self._ctx is None:

@@ -66,10 +66,6 @@ def hosttest_lib_path() -> str:
     return os.path.join(LIBDIR, "librgx_hosttest.so")
 
 
-def oracle_lib_path() -> str:
-    return os.path.join(ORACLE, "_build", "liboracle_bt.so")
-
-
 def build_product(verbose=False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     out = product_lib_path()
@@ -101,21 +97,21 @@ def build_hosttest() -> str:
     return out
 
 
+BENCH_PATTERNS = [
+    r"(?P<year>\d{4})-(?P<month>\d{2})-(?P<day>\d{2})",      # BASELINE configs C1/C2
+    r"(?P<user>\w+)@(?P<domain>\w+)",                          # C3
+]
+
+
 def build_oracle() -> str:
-    """The oracle's C restatement (checker only; never linked into the product)."""
-    bdir = os.path.join(ORACLE, "_build")
-    os.makedirs(bdir, exist_ok=True)
-    out = oracle_lib_path()
-    srcs = [os.path.join(ORACLE, "backtrack.c")]
-    if not os.path.exists(srcs[0]):
-        return ""
-    flags = ["-O2", "-std=c11", "-fPIC", "-shared"]
-    st = _needs(out, srcs, " ".join(flags))
-    if st is None:
-        return out
-    _run(["gcc"] + flags + srcs + ["-o", out, "-lpthread"])
-    open(out + ".stamp", "w").write(st)
-    return out
+    """The oracle's C restatement (checker / cpu_baseline only; never linked into the product): pre-generate and
+    compile the pattern-specialised matchers bench.py and the GPU tests need, so they exist on the GPU box."""
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    from oracle import gen_c
+    for p in BENCH_PATTERNS:
+        gen_c.CMatcher(p)
+    return os.path.join(ORACLE, "_build")
 
 
 def build_all(verbose=False):

@@ -217,6 +217,12 @@ RGX_API int64_t rgx_program_capture_names(const rgx_program* p, char* dst, size_
   return (int64_t)s.size();
 }
 
+RGX_API int rgx_program_reset_bytes(const rgx_program* p, uint8_t* dst256) {
+  if (!p || !dst256) return RGX_E_INVALID;
+  memcpy(dst256, p->p.t.reset_byte, 256);
+  return RGX_OK;
+}
+
 // ---------------------------------------------------------------- device binding
 RGX_API int rgx_device_count(void) {
   int n = 0;

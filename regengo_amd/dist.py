@@ -1,0 +1,197 @@
+"""Multi-GPU sharding of one large input (the reference has no parallelism of any kind).
+
+One process per GPU (`torch.distributed`, backend "nccl" == RCCL over xGMI; "gloo" in the CPU tests).  The input
+[0, L) is cut into `world` contiguous ranges; rank r OWNS the matches whose START lies in its range
+[lo_r, hi_r).  Each rank scans a slightly larger local window
+
+        [lo_r - halo_left, hi_r + halo_right)          (clipped to [0, L))
+
+and keeps the matches it owns:
+  * halo_right lets an owned match extend past hi_r (MaxMatchLen-1 bytes suffice for bounded patterns; unbounded
+    patterns use the reference's own 1 MiB leftover cap, streaming.go:87-96, and a match that touches the end of a
+    non-final window is reported as `truncated`);
+  * halo_left supplies a sync point: FindAll's search position is only known at offset 0 of the whole input, but
+    right after a "reset" byte (every DFA state dies on it) it is known too -- the same argument the scan kernel
+    uses per 64-byte slice.  If a rank's left halo holds no reset byte, ranks fall back to a one-int64 hand-off of
+    the search position r -> r+1 (a 1-hop send/recv chain; never needed on log-like text).
+
+The only data-path collective is an all_gather of the per-rank match COUNTS (8 bytes each): its exclusive scan is
+the global row index of each rank's first span, so the distributed result is a row-sharded [total, ncap] array in
+match order.  `gather_spans()` optionally moves the rows to rank 0 (variable-length gather, each peer on its own
+xGMI link); the bench reports that time separately because 32 B/match dwarfs the scan itself.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import List, Optional, Tuple
+
+
+@dataclass
+class Shard:
+    rank: int
+    world: int
+    total_len: int
+    lo: int          # owned range [lo, hi)
+    hi: int
+    win_lo: int      # local window [win_lo, win_hi)
+    win_hi: int
+
+
+def plan_shards(total_len: int, world: int, max_match_len: int, halo_left: int = 4096, unbounded_halo: int = 1 << 20,
+                align: int = 16) -> List[Shard]:
+    """Pure arithmetic (unit-tested on CPU).  Owned ranges tile [0, total_len) exactly; range starts are aligned
+    so every local window starts on a 16-byte boundary of the global stream."""
+    per = -(-total_len // world)
+    per = -(-per // align) * align
+    halo_r = (max_match_len - 1) if max_match_len > 0 else unbounded_halo
+    if max_match_len == 0:
+        halo_r = 0
+    out = []
+    for r in range(world):
+        lo = min(r * per, total_len)
+        hi = min((r + 1) * per, total_len)
+        wl = max(0, lo - halo_left)
+        wl -= wl % align
+        wh = min(total_len, hi + halo_r)
+        out.append(Shard(r, world, total_len, lo, hi, wl, wh))
+    return out
+
+
+def own_filter(spans, shard: Shard):
+    """Rows of `spans` (window-relative int32 [n, ncap], sorted by start) whose start lies in the owned range.
+    Returns (rows converted to GLOBAL offsets as int64, first_row, last_row)."""
+    import torch
+    if spans.shape[0] == 0:
+        return spans.to(torch.int64), 0, 0
+    starts = spans[:, 0].contiguous()
+    lo_rel = shard.lo - shard.win_lo
+    hi_rel = shard.hi - shard.win_lo
+    a = int(torch.searchsorted(starts, torch.tensor([lo_rel], dtype=starts.dtype, device=starts.device)).item())
+    b = int(torch.searchsorted(starts, torch.tensor([hi_rel], dtype=starts.dtype, device=starts.device)).item())
+    return spans[a:b], a, b
+
+
+class ShardedFinder:
+    """FindAllBytes over a sharded input.
+
+    scan_fn(window_uint8_tensor) -> (int32 spans [n, ncap] relative to the window, info dict): on a GPU box this is
+    `Compiled.FindAllSpans` (the HIP path); the CPU tests inject the test-only table walker to exercise the sharding
+    logic under gloo.  reset_table: uint8/bool tensor [256], 1 for bytes on which every DFA state dies."""
+
+    def __init__(self, scan_fn, reset_table, group=None):
+        self.scan = scan_fn
+        self.reset_table = reset_table
+        self.group = group
+
+    @classmethod
+    def for_compiled(cls, compiled, device, group=None):
+        import torch
+        rt = torch.tensor(list(compiled.reset_bytes()), dtype=torch.uint8, device=device)
+
+        def scan(window):
+            spans, res = compiled.FindAllSpans(window)
+            return spans, {"kernel_ms": res.kernel_ms, "unsynced": int(res.unsynced)}
+
+        return cls(scan, rt, group)
+
+    def _dist(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            return dist
+        return None
+
+    def find_all_local(self, window, shard: Shard):
+        """Scan this rank's window (bytes [win_lo, win_hi) of the input).  Returns (owned spans, window-relative
+        int32, sorted; count; info).  Exact whenever the left halo holds a sync point; otherwise ranks chain a
+        one-int64 search position r -> r+1 and each scans from it."""
+        import torch
+        dist = self._dist()
+        ok_local = has_sync_in_left_halo(window, shard, self.reset_table)
+        all_ok = ok_local
+        if dist is not None:
+            flag = torch.tensor([0 if ok_local else 1], dtype=torch.int64, device=window.device)
+            dist.all_reduce(flag, group=self.group)
+            all_ok = int(flag.item()) == 0
+        chained = False
+        if all_ok:
+            spans, info = self.scan(window)
+            owned, a, b = own_filter(spans, shard)
+        else:
+            chained = True
+            rank, world = shard.rank, shard.world
+            carry = torch.zeros(1, dtype=torch.int64, device=window.device)
+            if rank > 0:
+                dist.recv(carry, src=rank - 1, group=self.group)
+            pos = max(int(carry.item()), shard.win_lo if rank == 0 else shard.lo)
+            if rank == 0:
+                pos = 0
+            off = pos - shard.win_lo
+            # keep the kernel's 16-byte alignment contract: scan from an aligned copy
+            sub = window[off:].clone() if off else window
+            spans, info = self.scan(sub)
+            if spans.shape[0]:
+                spans = spans + off
+            owned, a, b = own_filter(spans, shard)
+            nxt = shard.hi
+            if owned.shape[0]:
+                nxt = max(nxt, int(owned[-1, 1].item()) + shard.win_lo)
+            if rank + 1 < world:
+                dist.send(torch.tensor([nxt], dtype=torch.int64, device=window.device), dst=rank + 1, group=self.group)
+        truncated = False
+        if shard.win_hi < shard.total_len and owned.shape[0] > 0:
+            truncated = bool(int(owned[-1, 1].item()) >= shard.win_hi - shard.win_lo)
+        info = dict(info)
+        info.update({"truncated": truncated, "chained": chained})
+        return owned, int(owned.shape[0]), info
+
+    def global_row_base(self, count: int, device) -> Tuple[int, int, List[int]]:
+        """all_gather of the per-rank counts -> (row index of this rank's first span, global total, all counts)."""
+        import torch
+        import torch.distributed as dist
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return 0, count, [count]
+        world = dist.get_world_size(self.group)
+        rank = dist.get_rank(self.group)
+        mine = torch.tensor([count], dtype=torch.int64, device=device)
+        allc = torch.empty(world, dtype=torch.int64, device=device)
+        dist.all_gather_into_tensor(allc, mine, group=self.group)
+        counts = allc.cpu().tolist()
+        return sum(counts[:rank]), sum(counts), counts
+
+    def gather_spans(self, owned, shard: Shard, counts: List[int], dst: int = 0):
+        """Variable-length gather of GLOBAL-offset span rows to rank `dst` (each peer -> dst over its own link)."""
+        import torch
+        import torch.distributed as dist
+        glob = owned.to(torch.int64) + shard.win_lo
+        if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(self.group) == 1:
+            return glob
+        world = dist.get_world_size(self.group)
+        rank = dist.get_rank(self.group)
+        ncap = glob.shape[1]
+        if rank == dst:
+            parts = []
+            reqs = []
+            for r in range(world):
+                if r == dst:
+                    parts.append(glob)
+                    continue
+                buf = torch.empty((counts[r], ncap), dtype=torch.int64, device=glob.device)
+                parts.append(buf)
+                if counts[r]:
+                    reqs.append(dist.irecv(buf, src=r, group=self.group))
+            for q in reqs:
+                q.wait()
+            return torch.cat(parts, dim=0)
+        if counts[rank]:
+            dist.send(glob.contiguous(), dst=dst, group=self.group)
+        return None
+
+
+def has_sync_in_left_halo(window, shard: Shard, reset_table) -> bool:
+    """True when the left halo [win_lo, lo) contains a reset byte (or the window starts at offset 0)."""
+    if shard.win_lo == 0:
+        return True
+    h = shard.lo - shard.win_lo
+    if h <= 0:
+        return False
+    return bool(reset_table[window[:h].long()].any().item())

@@ -1,0 +1,82 @@
+"""ctypes view of librgx_hosttest.so: the TEST-ONLY CPU walker over the product's tables (never part of the product)."""
+import ctypes as C
+
+from regengo_amd import build
+
+_lib = C.CDLL(build.build_hosttest())
+_lib.rgxt_compile.restype = C.c_void_p
+_lib.rgxt_compile.argtypes = [C.c_char_p, C.c_uint32]
+_lib.rgxt_free.argtypes = [C.c_void_p]
+_lib.rgxt_last_error.restype = C.c_char_p
+_lib.rgxt_find_all.restype = C.c_int64
+_lib.rgxt_find_all.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64]
+_lib.rgxt_find_all_sa.restype = C.c_int64
+_lib.rgxt_find_all_sa.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p, C.c_int64]
+_lib.rgxt_prog_dump.argtypes = [C.c_char_p, C.c_char_p, C.c_int]
+_lib.rgxt_info.argtypes = [C.c_void_p, C.c_void_p]
+_lib.rgxt_match.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+_lib.rgxt_roundtrip.restype = C.c_void_p
+_lib.rgxt_roundtrip.argtypes = [C.c_void_p]
+_lib.rgxt_sa_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+_lib.rgxt_reset_bytes.argtypes = [C.c_void_p, C.c_void_p]
+
+INFO = ["ncap", "min", "max", "ninst", "nstates", "ncls", "anchored", "fixed", "empty", "refm", "reff", "look", "maxthr"]
+
+
+class HostProgram:
+    def __init__(self, pattern: str, flags: int = 0, handle=None):
+        if handle is None:
+            handle = _lib.rgxt_compile(pattern.encode("utf-8"), flags)
+            if not handle:
+                raise ValueError(_lib.rgxt_last_error().decode())
+        self.h = C.c_void_p(handle)
+        a = (C.c_int32 * 16)()
+        n = _lib.rgxt_info(self.h, a)
+        self.info = dict(zip(INFO, list(a)[:n]))
+        k, ex = C.c_int32(), C.c_int32()
+        _lib.rgxt_sa_info(self.h, C.byref(k), C.byref(ex))
+        self.sa_k, self.sa_exact = k.value, bool(ex.value)
+
+    def __del__(self):
+        try:
+            _lib.rgxt_free(self.h)
+        except Exception:
+            pass
+
+    def roundtrip(self) -> "HostProgram":
+        h = _lib.rgxt_roundtrip(self.h)
+        if not h:
+            raise ValueError("blob round trip failed")
+        return HostProgram("", handle=h)
+
+    def find_all(self, b: bytes, n: int = -1):
+        ncap = self.info["ncap"]
+        cap = len(b) + 2
+        out = (C.c_int32 * (cap * ncap))()
+        c = _lib.rgxt_find_all(self.h, b, len(b), n, out, cap)
+        return [list(out[i * ncap:(i + 1) * ncap]) for i in range(c)]
+
+    def find_all_sa(self, b: bytes):
+        ncap = self.info["ncap"]
+        cap = len(b) + 2
+        out = (C.c_int32 * (cap * ncap))()
+        c = _lib.rgxt_find_all_sa(self.h, b, len(b), out, cap)
+        if c < 0:
+            return None
+        return [list(out[i * ncap:(i + 1) * ncap]) for i in range(c)]
+
+    def match(self, b: bytes) -> bool:
+        return bool(_lib.rgxt_match(self.h, b, len(b)))
+
+    def reset_bytes(self):
+        a = (C.c_uint8 * 256)()
+        _lib.rgxt_reset_bytes(self.h, a)
+        return bytes(a)
+
+
+def prog_dump(pattern: str) -> str:
+    buf = C.create_string_buffer(1 << 16)
+    r = _lib.rgxt_prog_dump(pattern.encode("utf-8"), buf, 1 << 16)
+    if r < 0:
+        raise ValueError(_lib.rgxt_last_error().decode())
+    return buf.value.decode("utf-8")

@@ -1,0 +1,122 @@
+"""Host logic (CPU tier): the product's C++ front-end and table compiler, exercised through the TEST-ONLY CPU
+walker over the very tables the HIP kernels consume, against the oracle."""
+import random
+
+import pytest
+
+from oracle import engines as E
+from oracle import syntax as S
+
+
+def _oracle_dump(pattern):
+    ast, prog = S.compile_pattern(pattern)
+    return ast.dump() + "\n" + "start %d numcap %d\n" % (prog.start, prog.numcap) + "".join(
+        "%d %s %d %d%s\n" % (i, S.INST_NAMES[x.op], x.out, x.arg, "".join(" %d" % r for r in x.rune))
+        for i, x in enumerate(prog.inst))
+
+
+def test_cpp_frontend_equals_oracle_frontend(corpus, kats, hostlib):
+    """AST (after Simplify) and Prog identical, instruction for instruction, on every corpus + curated pattern."""
+    pats = [e["pattern"] for e in corpus] + [c["pattern"] for c in kats["curated_cases"]]
+    ok = 0
+    for p in pats:
+        try:
+            cc = hostlib.prog_dump(p)
+        except ValueError as ex:
+            assert "unsupported" in str(ex), (p, ex)
+            continue
+        assert cc == _oracle_dump(p), p
+        ok += 1
+    assert ok >= 245
+
+
+def test_cpp_frontend_reproduces_go_progs(progs, hostlib):
+    for e in progs:
+        if "inst" not in e:
+            continue
+        lines = hostlib.prog_dump(e["pattern"]).split("\n")[2:]
+        assert len([l for l in lines if l]) == len(e["inst"]), e["file"]
+        for i, b in enumerate(e["inst"]):
+            f = lines[i].split()
+            assert f[1] == b["op"], (e["file"], i)
+            if b["op"] in ("alt", "cap", "empty"):
+                assert (int(f[2]), int(f[3])) == (b["out"], b["arg"]), (e["file"], i)
+
+
+def test_info_matches_reference_constants(progs, hostlib):
+    for e in progs:
+        hp = hostlib.HostProgram(e["pattern"])
+        if "MinMatchLen" in e:
+            assert (hp.info["min"], hp.info["max"]) == (e["MinMatchLen"], e["MaxMatchLen"]), e["file"]
+        sel = E.select(*S.compile_pattern(e["pattern"]))
+        assert hp.info["anchored"] == int(sel.anchored)
+        assert (hp.info["refm"] == 1) == sel.thompson_for_match
+
+
+def _mutations(inputs, rng):
+    bs = [s.encode() for s in inputs]
+    out = list(bs)
+    out.append(b" ".join(bs))
+    alpha = b"".join(bs) or b"a"
+    for s in bs:
+        out.append(b"x" + s)
+        out.append(s[:-1])
+        out.append(s + s)
+    for _ in range(12):
+        out.append(bytes(rng.choice(alpha) for _ in range(rng.randint(0, 48))))
+    return out
+
+
+def test_table_walk_equals_oracle_findall(corpus, kats, hostlib):
+    """Match offsets AND capture spans (fixed template or back-trace) bit-exact vs the oracle's FindAllBytes on the
+    corpus inputs, their mutations and random strings over each pattern's alphabet."""
+    rng = random.Random(1234)
+    total = unsupported = 0
+    items = [(e["pattern"], e["inputs"]) for e in corpus] + [(c["pattern"], c["inputs"]) for c in kats["curated_cases"]]
+    for p, inputs in items:
+        try:
+            hp = hostlib.HostProgram(p)
+        except ValueError:
+            unsupported += 1
+            continue
+        o = E.Compiled(p)
+        rt = hp.roundtrip()
+        for b in _mutations(inputs, rng):
+            exp = o.find_machine.find_all(b)
+            assert hp.find_all(b) == exp, (p, b)
+            assert rt.find_all(b) == exp, ("blob round trip", p, b)
+            sa = hp.find_all_sa(b)
+            if sa is not None:
+                assert sa == exp, ("shift-and path", p, b)
+            total += 1
+    assert total > 5000
+    assert unsupported <= 16
+
+
+def test_n_argument(hostlib):
+    hp = hostlib.HostProgram(r"(\d+)")
+    o = E.Compiled(r"(\d+)")
+    b = b"1 22 333 4444"
+    for n in (-1, 0, 1, 2, 10):
+        assert hp.find_all(b, n) == o.FindAllBytes(b, n)
+
+
+def test_unmatched_group_convention(hostlib):
+    """Reference: zero-initialised captures (find.go:215) => (0,0); flag 1 => (-1,-1)."""
+    p = r"(a)|(b)"
+    assert hostlib.HostProgram(p).find_all(b"xb") == [[1, 2, 0, 0, 1, 2]]
+    assert hostlib.HostProgram(p, 1).find_all(b"xb") == [[1, 2, -1, -1, 1, 2]]
+    assert E.Compiled(p).FindAllBytes(b"xb") == [[1, 2, 0, 0, 1, 2]]
+
+
+def test_exact_shift_and_for_date(hostlib):
+    hp = hostlib.HostProgram(r"(?P<year>\d{4})-(?P<month>\d{2})-(?P<day>\d{2})")
+    assert hp.sa_k == 10 and hp.sa_exact and hp.info["fixed"] == 1
+    rb = hp.reset_bytes()
+    assert rb[ord("a")] == 1 and rb[ord("5")] == 0 and rb[ord("-")] == 0
+
+
+def test_unsupported_features_are_refused(hostlib):
+    for p in (r"\p{L}+", r"[α-ω]+"):
+        with pytest.raises(ValueError):
+            hostlib.HostProgram(p)
