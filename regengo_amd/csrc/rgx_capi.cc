@@ -76,7 +76,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   if ((uintptr_t)d_buf & 15) { SetError("input device pointer must be 16-byte aligned"); return RGX_E_INVALID; }
   if (!count_only && ((uintptr_t)d_spans & 15)) { SetError("span device pointer must be 16-byte aligned"); return RGX_E_INVALID; }
   const int32_t ilen = (int32_t)len;
-  const int32_t ntiles = (ilen + kTileBytes - 1) / kTileBytes;
+  const int32_t ntiles = ScanNumTiles(T, ilen);
   const int32_t nslices = (ilen + kSliceBytes - 1) / kSliceBytes;
   int rc;
   if ((rc = Ensure(&c->d_desc, &c->desc_cap, ntiles)) != RGX_OK) return rc;

@@ -1,0 +1,61 @@
+// Device helpers shared by the scan kernels: wave scans and the decoupled look-back over tile descriptors.
+#pragma once
+#include <hip/hip_runtime.h>
+
+namespace rgx {
+
+// Look-back descriptor: one 8-byte granule per tile/group, written by ONE relaxed agent-scope store and polled with
+// relaxed agent-scope loads -- the data is the flag (cdna_hip_programming.md guideline 16, form R2); no other
+// memory is exchanged between workgroups, so no fence is needed.
+constexpr unsigned long long kDescAgg = 1ull << 62;      // value = this tile's own count
+constexpr unsigned long long kDescPrefix = 2ull << 62;   // value = inclusive count up to and including this tile
+constexpr unsigned long long kDescValMask = (1ull << 62) - 1;
+
+__device__ __forceinline__ unsigned WaveInclusiveScan(unsigned v, int lane) {
+  unsigned x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    unsigned y = __shfl_up(x, d, 64);
+    if (lane >= d) x += y;
+  }
+  return x;
+}
+
+__device__ __forceinline__ unsigned long long WaveSum64(unsigned long long v) {
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
+  return v;
+}
+
+// Executed by ONE full wave.  Publishes `own` for descriptor `id`, sums the counts of all predecessors by walking
+// back 64 descriptors at a time until one carries an inclusive prefix, publishes the inclusive prefix, and returns
+// the exclusive prefix (same value in every lane).  Predecessors are guaranteed to be owned by running workgroups
+// because ids are handed out by a ticket counter.
+__device__ __forceinline__ unsigned long long LookBack(unsigned long long* desc, int id, unsigned long long own, int lane) {
+  unsigned long long excl = 0;
+  if (lane == 0)
+    __hip_atomic_store(&desc[id], (id == 0 ? kDescPrefix : kDescAgg) | own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (id > 0) {
+    int idx = id - 1 - lane;
+    while (true) {
+      unsigned long long d = kDescPrefix;  // ids below 0: prefix 0
+      if (idx >= 0) {
+        d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        while ((d >> 62) == 0) {
+          __builtin_amdgcn_s_sleep(1);
+          d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      const unsigned long long pm = __ballot((d >> 62) == 2);
+      const int first = pm ? __builtin_ctzll(pm) : 64;
+      excl += WaveSum64(lane <= first ? (d & kDescValMask) : 0ull);
+      if (pm) break;
+      idx -= 64;
+    }
+    if (lane == 0)
+      __hip_atomic_store(&desc[id], kDescPrefix | (excl + own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return excl;
+}
+
+}  // namespace rgx

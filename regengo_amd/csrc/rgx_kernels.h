@@ -20,11 +20,17 @@ struct ScanParams {
   const int32_t* carry_in;       // nullable; per slice: -1 = find a sync point locally, else search position
   uint8_t* slice_unsynced;       // nullable; set to 1 for slices that found no sync point
   int32_t count_only;
+  int32_t debug;                 // experiment switches (RGX_DEBUG): 1 = unordered base (no look-back), 2 = no span stores
 };
 
 // FindAllBytes scan: one pass over the input, ordered span records out.
 hipError_t LaunchScan(const DevTables& T, const ScanParams& P, hipStream_t stream);
 size_t ScanSharedBytes(const DevTables& T);
+int32_t ScanNumTiles(const DevTables& T, int32_t len);
+// rgx_scan_exact.hip: the branch-free Shift-And kernel for fixed-length class chains
+bool UseExactKernel(const DevTables& T, int32_t len);
+int ExactTileBytes();
+hipError_t LaunchScanExact(const DevTables& T, const ScanParams& P, hipStream_t stream);  // tiles (= look-back descriptors) the scan of `len` bytes uses
 
 // Serial carry resolution for slices without a local sync point (rare path).
 hipError_t LaunchCarry(const DevTables& T, const uint8_t* buf, int32_t len, const uint8_t* slice_unsynced, int32_t* carry_in,

@@ -17,6 +17,9 @@
 //   batch_kernel  one string per lane (CSR), FindBytes/MatchBytes per string.
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
+
+#include "rgx_device_util.h"
 #include "rgx_kernels.h"
 
 namespace rgx {
@@ -25,10 +28,6 @@ namespace {
 
 constexpr int kWindow = kHaloL + kTileBytes + kHaloR;          // bytes of input visible in LDS
 constexpr int kPaddedWindow = kWindow + (kWindow / 64) * 4;    // 64-byte rows padded to 68: lane stride 17 dwords
-constexpr unsigned long long kDescAgg = 1ull << 62;
-constexpr unsigned long long kDescPrefix = 2ull << 62;
-constexpr unsigned long long kDescValMask = (1ull << 62) - 1;
-
 __device__ __forceinline__ int PadAddr(int rel) { return rel + ((rel >> 6) << 2); }
 
 // ---- table access ---------------------------------------------------------------------------------------
@@ -84,22 +83,6 @@ __device__ __forceinline__ int Walk(const Tab<MODE>& tab, const Input& in, const
     ++i;
   }
   return end;
-}
-
-__device__ __forceinline__ unsigned long long WaveInclusiveScan(unsigned v, int lane) {
-  unsigned x = v;
-#pragma unroll
-  for (int d = 1; d < 64; d <<= 1) {
-    unsigned y = __shfl_up(x, d, 64);
-    if (lane >= d) x += y;
-  }
-  return x;
-}
-
-__device__ __forceinline__ unsigned long long WaveSum64(unsigned long long v) {
-#pragma unroll
-  for (int d = 32; d >= 1; d >>= 1) v += __shfl_xor(v, d, 64);
-  return v;
 }
 
 __device__ __forceinline__ void WriteRecordFixed(int32_t* rec, int ncap, const uint8_t* kind, const int32_t* delta, int s, int e) {
@@ -505,7 +488,13 @@ size_t ScanSharedBytes(const DevTables& T) {
   return (b + 15) & ~size_t(15);
 }
 
+int32_t ScanNumTiles(const DevTables& T, int32_t len) {
+  const int per = UseExactKernel(T, len) ? ExactTileBytes() : kTileBytes;
+  return (len + per - 1) / per;
+}
+
 hipError_t LaunchScan(const DevTables& T, const ScanParams& P, hipStream_t stream) {
+  if (UseExactKernel(T, P.len)) return LaunchScanExact(T, P, stream);
   const size_t shmem = ScanSharedBytes(T);
   dim3 grid(P.ntiles), block(kBlockThreads);
   static bool attr_set[8] = {false, false, false, false, false, false, false, false};

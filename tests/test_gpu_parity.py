@@ -213,17 +213,40 @@ def test_find_reader_equals_oracle_stream(torch_dev):
     """FindReader over a 3 MiB stream with small buffers == the oracle's FindReader (same chunk protocol)."""
     from oracle import engines as E
     from regengo_amd import Config, synth
-    data = synth.date_log_np(3 << 20, adversarial=True).tobytes()
-    c = _gpu(r"(\d{4}-\d{2}-\d{2})")
-    o = E.Compiled(r"(\d{4}-\d{2}-\d{2})")
     from oracle.gen_c import CMatcher
-    cm = CMatcher(r"(\d{4}-\d{2}-\d{2})")
-    exp = []
-    E.find_reader(cm.find, o.sel.max_len, io.BytesIO(data).read, E.StreamConfig(BufferSize=1 << 16),
-                  lambda m: exp.append((m.StreamOffset, m.match_bytes)) or True)
-    got = []
-    c.FindReader(io.BytesIO(data), Config(BufferSize=1 << 16), lambda m: got.append((m.StreamOffset, m.Result.Match)) or True)
-    assert got == exp and len(got) > 60000
+    pat = r"(\d{4}-\d{2}-\d{2})"
+    c = _gpu(pat)
+    o = E.Compiled(pat)
+    cm = CMatcher(pat)
+
+    def run_oracle(data, find_fn):
+        exp = []
+        E.find_reader(find_fn, o.sel.max_len, io.BytesIO(data).read, E.StreamConfig(BufferSize=1 << 16),
+                      lambda m: exp.append((m.StreamOffset, m.match_bytes)) or True)
+        return exp
+
+    def run_gpu(data):
+        got = []
+        c.FindReader(io.BytesIO(data), Config(BufferSize=1 << 16), lambda m: got.append((m.StreamOffset, m.Result.Match)) or True)
+        return got
+
+    # (a) log-like text: the reference's FindReader (FindBytesReuse incl. its Q1 restart rule) == the GPU path
+    data = synth.date_log_np(3 << 20).tobytes()
+    got = run_gpu(data)
+    assert got == run_oracle(data, cm.find) and len(got) > 60000
+
+    # (b) adversarial noise: the reference's FindBytesReuse skips candidate starts after a failed attempt (Q1,
+    # DESIGN.md), so its FindReader misses matches its own FindAllBytes reports.  The GPU path follows FindAllBytes;
+    # the same chunk protocol driven by a quirk-free "first match" must agree exactly.
+    def first_match(b):
+        r = cm.find_all(b, 1)
+        return r[0] if r else None
+
+    adv = synth.date_log_np(1 << 20, adversarial=True).tobytes()
+    got = run_gpu(adv)
+    assert got == run_oracle(adv, first_match)
+    q1 = run_oracle(adv, cm.find)
+    assert len(q1) <= len(got)          # the quirk only ever loses matches
 
 
 def test_batch_find_and_match(torch_dev):
