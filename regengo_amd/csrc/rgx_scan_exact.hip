@@ -50,12 +50,20 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int K = T.sa_k;
-  const int sh = 32 - K;
+  // Shift-And state layout (32 bits): bit p0 = "1 byte of a match seen" ... bit 28 = "K bytes seen" (accept), bits
+  // 29..31 = the accept bits of the three previous bytes (the level-set words carry 1s there, so they pass through).
+  // That lets FOUR bytes be folded into one state update: with S(E,F) = ((E<<1)|o)&F,
+  //   S(S(S(S(E,F0),F1),F2),F3) = ((E<<4)|o4) & g,   g = ((g01<<2)|o2)&g23,  g01 = ((F0<<1)|o)&F1,  g23 likewise
+  // (distributivity of | over &).  g depends on the input bytes only, so everything except two ops per dword is off
+  // the dependent chain, and the four accept bits land in bits 31..28 for one funnel shift into the detection mask.
+  const int sh = 29 - K;                 // p0 (the launcher guarantees K <= 29)
   const unsigned one = 1u << sh;
+  const unsigned one2 = (one << 1) | one;
+  const unsigned one4 = (one2 << 2) | one2;
   const int len = P.len;
   const int ncap = T.ncap;
 
-  L.sa[tid] = T.sa_mask[tid] << sh;
+  L.sa[tid] = (T.sa_mask[tid] << sh) | (7u << 29);
   if (tid < ncap) L.off[tid] = T.cap_kind[tid] == kCapFromStart ? T.cap_delta[tid] : K - T.cap_delta[tid];
   if (tid == 0) L.misc[0] = atomicAdd(&P.counters[0], 1u);
   __syncthreads();
@@ -68,6 +76,27 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
   unsigned ttot[G];           // matches in the tile (uniform)
   unsigned group_run = 0;     // matches in this group's tiles so far (uniform)
 
+  // Software pipeline over the group's tiles: the five 16-byte global loads of tile g+1 are issued (into VGPRs)
+  // before tile g is processed, so the HBM round trip overlaps the byte loop instead of preceding it.  Loads are
+  // unconditional, from a clamped in-bounds address, so the values stay in VGPRs (a conditional load into an array
+  // made hipcc spill to scratch, which serialised the five round trips).
+  const int safe = (len - 16) & ~15;   // last fully readable 16-byte chunk (the launcher guarantees len >= 64)
+  const int c0 = tid, c1 = tid + kBlockThreads, c2 = tid + 2 * kBlockThreads, c3 = tid + 3 * kBlockThreads,
+            c4 = tid + 4 * kBlockThreads;          // chunk ids; c4 only exists for tid < 4 (257 rows * 4 = 1028)
+  uint4 v0, v1, v2, v3, v4;
+#define RGX_FULL(c, tb) ((c) < kExactRows * 4 && (tb) + ((c) << 4) >= 0 && (tb) + ((c) << 4) + 16 <= len)
+#define RGX_LOAD(v, c, tb) v = *reinterpret_cast<const uint4*>(P.buf + (RGX_FULL(c, tb) ? (tb) + ((c) << 4) : safe));
+#define RGX_LOAD_TILE(tb) { RGX_LOAD(v0, c0, tb) RGX_LOAD(v1, c1, tb) RGX_LOAD(v2, c2, tb) RGX_LOAD(v3, c3, tb) RGX_LOAD(v4, c4, tb) }
+#define RGX_PUT(v, c, tb)                                                                      \
+  {                                                                                            \
+    unsigned char* dst = L.tile + ((c) >> 2) * kRowBytes + (((c) & 3) << 4);                   \
+    const int ab = (tb) + ((c) << 4);                                                          \
+    if (RGX_FULL(c, tb)) *reinterpret_cast<uint4*>(dst) = v;                                   \
+    else if ((c) < kExactRows * 4 && ab >= 0 && ab < len)                                      \
+      for (int b = 0; ab + b < len; ++b) dst[b] = P.buf[ab + b];                               \
+  }
+  if (first_tile < P.ntiles) RGX_LOAD_TILE(first_tile * kExactOwnedBytes - kSliceBytes)
+
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     sel[g] = 0;
@@ -76,30 +105,10 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
     if (tile >= P.ntiles) continue;                     // uniform across the workgroup
     const int tb0 = tile * kExactOwnedBytes - kSliceBytes;   // absolute offset of slice 0 (-64 for tile 0)
 
-    // ---- stage rows [0, 257): five 16-byte loads per lane, all issued before the first LDS store
-    // (loads are unconditional, from a clamped in-bounds address, so the values live in VGPRs -- a conditional
-    // load into an array made hipcc spill it to scratch and serialise the five HBM round trips)
-    {
-      const int safe = (len - 16) & ~15;   // last fully readable 16-byte chunk (the launcher guarantees len >= 64)
-#define RGX_CHUNK(k)                                                                           \
-      const int c##k = tid + (k) * kBlockThreads;                                               \
-      const int abs##k = tb0 + (c##k << 4);                                                     \
-      const bool in##k = c##k < kExactRows * 4;                                                 \
-      const bool full##k = in##k && abs##k >= 0 && abs##k + 16 <= len;                          \
-      const uint4 v##k = *reinterpret_cast<const uint4*>(P.buf + (full##k ? abs##k : safe));
-      RGX_CHUNK(0) RGX_CHUNK(1) RGX_CHUNK(2) RGX_CHUNK(3) RGX_CHUNK(4)
-#undef RGX_CHUNK
-#define RGX_PUT(k)                                                                             \
-      {                                                                                          \
-        unsigned char* dst = L.tile + (c##k >> 2) * kRowBytes + ((c##k & 3) << 4);             \
-        if (full##k) *reinterpret_cast<uint4*>(dst) = v##k;                                     \
-        else if (in##k && abs##k >= 0 && abs##k < len)                                          \
-          for (int b = 0; abs##k + b < len; ++b) dst[b] = P.buf[abs##k + b];                    \
-      }
-      RGX_PUT(0) RGX_PUT(1) RGX_PUT(2) RGX_PUT(3) RGX_PUT(4)
-#undef RGX_PUT
-    }
+    // ---- stage rows [0, 257) of this tile from the prefetched registers, then prefetch the next tile
+    RGX_PUT(v0, c0, tb0) RGX_PUT(v1, c1, tb0) RGX_PUT(v2, c2, tb0) RGX_PUT(v3, c3, tb0) RGX_PUT(v4, c4, tb0)
     __syncthreads();
+    if (g + 1 < G && tile + 1 < P.ntiles) RGX_LOAD_TILE(tb0 + kExactOwnedBytes)
 
     // ---- phase 1: candidate mask of this lane's slice (match starts in [a, a+64))
     const int a = tb0 + tid * kSliceBytes;
@@ -109,14 +118,16 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
       const uint4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
       const uint4 n0 = row[5], n1 = row[6];   // next row: 80-byte stride = 5 uint4
       unsigned E = 0, det0 = 0, det1 = 0, det2 = 0;
-#define RGX_BYTE(W, B, DET)                                                                          \
+#define RGX_LU(W, B) (*reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(L.sa) + ((((W) >> (8 * (B))) & 0xFFu) << 2)))
+#define RGX_WORD(W, DET)                                                                             \
       {                                                                                                \
-        const unsigned f = *reinterpret_cast<const unsigned*>(                                        \
-            reinterpret_cast<const unsigned char*>(L.sa) + ((((W) >> (8 * (B))) & 0xFFu) << 2));      \
-        E = ((E << 1) | one) & f;                                                                      \
-        DET = __builtin_amdgcn_alignbit(DET, E, 31);                                                   \
+        const unsigned f0 = RGX_LU(W, 0), f1 = RGX_LU(W, 1), f2 = RGX_LU(W, 2), f3 = RGX_LU(W, 3);     \
+        const unsigned g01 = ((f0 << 1) | one) & f1;                                                   \
+        const unsigned g23 = ((f2 << 1) | one) & f3;                                                   \
+        const unsigned gq = ((g01 << 2) | one2) & g23;                                                 \
+        E = ((E << 4) | one4) & gq;                                                                    \
+        DET = __builtin_amdgcn_alignbit(DET, E, 28);                                                   \
       }
-#define RGX_WORD(W, DET) RGX_BYTE(W, 0, DET) RGX_BYTE(W, 1, DET) RGX_BYTE(W, 2, DET) RGX_BYTE(W, 3, DET)
       RGX_WORD(r0.x, det0) RGX_WORD(r0.y, det0) RGX_WORD(r0.z, det0) RGX_WORD(r0.w, det0)
       RGX_WORD(r1.x, det0) RGX_WORD(r1.y, det0) RGX_WORD(r1.z, det0) RGX_WORD(r1.w, det0)
       RGX_WORD(r2.x, det1) RGX_WORD(r2.y, det1) RGX_WORD(r2.z, det1) RGX_WORD(r2.w, det1)
@@ -132,7 +143,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
       if (tail > 24) { RGX_WORD(n1.z, det2) } else { det2 <<= 4; }
       if (tail > 28) { RGX_WORD(n1.w, det2) } else { det2 <<= 4; }
 #undef RGX_WORD
-#undef RGX_BYTE
+#undef RGX_LU
       // the funnel shift filled the masks MSB-first: reverse so that bit i = "accept bit up after byte i"
       det0 = __builtin_bitreverse32(det0);
       det1 = __builtin_bitreverse32(det1);
@@ -216,6 +227,11 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
     group_run += tile_total;
   }
 
+#undef RGX_PUT
+#undef RGX_LOAD_TILE
+#undef RGX_LOAD
+#undef RGX_FULL
+
   if (P.count_only) {
     if (tid == 0 && group_run) atomicAdd(P.total, (unsigned long long)group_run);
     return;
@@ -286,7 +302,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
 }  // namespace
 
 bool UseExactKernel(const DevTables& T, int32_t len) {
-  return len >= 64 && T.sa_exact && T.sa_k >= 1 && T.sa_k <= 32 && T.fixed_captures && !T.anchored && T.ncap <= 32;
+  return len >= 64 && T.sa_exact && T.sa_k >= 1 && T.sa_k <= 29 && T.fixed_captures && !T.anchored && T.ncap <= 32;
 }
 
 int ExactTileBytes() { return kExactOwnedBytes; }
