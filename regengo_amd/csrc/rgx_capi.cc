@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -98,7 +99,16 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RGX_OK;
   };
+  static const bool force_tickets = getenv("RGX_TICKETS") != nullptr;
+  P.use_tickets = force_tickets ? 1 : 0;
   if ((rc = run_scan(c->timing)) != RGX_OK) return rc;
+  if (((uint32_t*)&c->h_read[1])[3]) {
+    // a look-back spin hit its bound (block ids assumed dispatch order and the assumption failed): repeat with tickets,
+    // which need no assumption at all
+    P.use_tickets = 1;
+    if ((rc = run_scan(c->timing)) != RGX_OK) return rc;
+    if (((uint32_t*)&c->h_read[1])[3]) { SetError("look-back timed out in ticket mode"); return RGX_E_HIP; }
+  }
   float ms = 0;
   if (c->timing) hipEventElapsedTime(&ms, c->ev0, c->ev1);
   uint32_t unsynced = ((uint32_t*)&c->h_read[1])[1];

@@ -11,6 +11,9 @@ constexpr unsigned long long kDescAgg = 1ull << 62;      // value = this tile's 
 constexpr unsigned long long kDescPrefix = 2ull << 62;   // value = inclusive count up to and including this tile
 constexpr unsigned long long kDescValMask = (1ull << 62) - 1;
 
+// Every spin is bounded: a poll costs ~1 us, a legitimate wait is far below a millisecond.
+constexpr unsigned kLookBackSpinLimit = 50000;
+
 __device__ __forceinline__ unsigned WaveInclusiveScan(unsigned v, int lane) {
   unsigned x = v;
 #pragma unroll
@@ -29,22 +32,34 @@ __device__ __forceinline__ unsigned long long WaveSum64(unsigned long long v) {
 
 // Executed by ONE full wave.  Publishes `own` for descriptor `id`, sums the counts of all predecessors by walking
 // back 64 descriptors at a time until one carries an inclusive prefix, publishes the inclusive prefix, and returns
-// the exclusive prefix (same value in every lane).  Predecessors are guaranteed to be owned by running workgroups
-// because ids are handed out by a ticket counter.
-__device__ __forceinline__ unsigned long long LookBack(unsigned long long* desc, int id, unsigned long long own, int lane) {
+// the exclusive prefix (same value in every lane).
+//
+// Forward progress: ids either come from a ticket counter (every predecessor is then owned by a running workgroup
+// by construction) or equal blockIdx.x (predecessors were dispatched earlier on every GPU observed, but HIP does not
+// promise dispatch order) -- so the spin is bounded and a timeout raises *timeout_flag; the host then repeats the
+// scan in ticket mode.  Results never depend on the assumption, only speed does.
+__device__ __forceinline__ unsigned long long LookBack(unsigned long long* desc, int id, unsigned long long own, int lane,
+                                                        unsigned* timeout_flag) {
   unsigned long long excl = 0;
   if (lane == 0)
     __hip_atomic_store(&desc[id], (id == 0 ? kDescPrefix : kDescAgg) | own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (id > 0) {
     int idx = id - 1 - lane;
+    bool dead = false;
     while (true) {
       unsigned long long d = kDescPrefix;  // ids below 0: prefix 0
       if (idx >= 0) {
         d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
         while ((d >> 62) == 0) {
+          if (++spins > kLookBackSpinLimit) { dead = true; break; }
           __builtin_amdgcn_s_sleep(1);
           d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+      }
+      if (__any(dead)) {
+        if (lane == 0) atomicExch(timeout_flag, 1u);
+        break;
       }
       const unsigned long long pm = __ballot((d >> 62) == 2);
       const int first = pm ? __builtin_ctzll(pm) : 64;

@@ -15,11 +15,12 @@ struct ScanParams {
   int32_t* spans;                // device, [cap_records][ncap]
   int64_t cap_records;
   unsigned long long* tile_desc; // [ntiles] look-back descriptors, zeroed before launch
-  uint32_t* counters;            // [0] tile ticket, [1] unsynced slices; zeroed before launch
+  uint32_t* counters;            // [0] tile ticket, [1] unsynced slices, [2] stats, [3] look-back timeout; zeroed before launch
   unsigned long long* total;     // total matches; zeroed before launch
   const int32_t* carry_in;       // nullable; per slice: -1 = find a sync point locally, else search position
   uint8_t* slice_unsynced;       // nullable; set to 1 for slices that found no sync point
   int32_t count_only;
+  int32_t use_tickets;           // 1: tile/group ids from the ticket counter; 0: blockIdx.x (bounded spin, host falls back)
   int32_t debug;                 // experiment switches (RGX_DEBUG): 1 = unordered base (no look-back), 2 = no span stores
 };
 

@@ -123,7 +123,9 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
 
   // dynamic tile id: a ticket guarantees every predecessor tile is already owned by a running workgroup,
   // which is what makes the look-back below deadlock-free without any residency assumption.
-  if (tid == 0) s_misc[0] = atomicAdd(&P.counters[0], 1u);
+  // tile id: blockIdx.x, or (use_tickets) a ticket, which makes the look-back deadlock-free without assuming
+  // anything about dispatch order -- see rgx_device_util.h
+  if (tid == 0) s_misc[0] = P.use_tickets ? atomicAdd(&P.counters[0], 1u) : blockIdx.x;
   // stage the tables while the ticket is in flight
   {
     const int nwords = SA == 2 ? 0 : (T.table_bytes >> 2);   // the exact Shift-And path never touches the DFA
@@ -275,32 +277,8 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
     return;
   }
   if (wave == 0) {
-    unsigned long long excl = 0;
-    if (lane == 0) {
-      __hip_atomic_store(&P.tile_desc[tile], (tile == 0 ? kDescPrefix : kDescAgg) | block_total, __ATOMIC_RELAXED,
-                         __HIP_MEMORY_SCOPE_AGENT);
-      if (block_total) atomicAdd(P.total, (unsigned long long)block_total);
-    }
-    if (tile > 0) {
-      int idx = tile - 1 - lane;
-      while (true) {
-        unsigned long long d = kDescPrefix;  // tiles before 0: prefix 0
-        if (idx >= 0) {
-          d = __hip_atomic_load(&P.tile_desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          while ((d >> 62) == 0) {
-            __builtin_amdgcn_s_sleep(1);
-            d = __hip_atomic_load(&P.tile_desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          }
-        }
-        const unsigned long long pm = __ballot((d >> 62) == 2);
-        const int first = pm ? __builtin_ctzll(pm) : 64;
-        excl += WaveSum64(lane <= first ? (d & kDescValMask) : 0ull);
-        if (pm) break;
-        idx -= 64;
-      }
-      if (lane == 0)
-        __hip_atomic_store(&P.tile_desc[tile], kDescPrefix | (excl + block_total), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    if (lane == 0 && block_total) atomicAdd(P.total, (unsigned long long)block_total);
+    const unsigned long long excl = LookBack(P.tile_desc, tile, block_total, lane, &P.counters[3]);
     if (lane == 0) { s_misc[8] = (unsigned)excl; s_misc[9] = (unsigned)(excl >> 32); }
   }
   __syncthreads();

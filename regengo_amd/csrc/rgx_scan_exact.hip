@@ -63,12 +63,17 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
   const int len = P.len;
   const int ncap = T.ncap;
 
-  L.sa[tid] = (T.sa_mask[tid] << sh) | (7u << 29);
-  if (tid < ncap) L.off[tid] = T.cap_kind[tid] == kCapFromStart ? T.cap_delta[tid] : K - T.cap_delta[tid];
-  if (tid == 0) L.misc[0] = atomicAdd(&P.counters[0], 1u);
-  __syncthreads();
-  const int group = (int)L.misc[0];
+  // Group id: blockIdx.x, or a ticket when the host asks for it.  One device-scope counter hands out only ~88
+  // tickets/us (measured: 65794 tickets = 0.75 ms, 16449 = 0.19 ms of pure skeleton time), so the default avoids the
+  // atomic altogether; the look-back spin is bounded and the host repeats the scan with tickets if it ever times out.
+  int group = (int)blockIdx.x;
+  if (P.use_tickets) {
+    if (tid == 0) L.misc[0] = atomicAdd(&P.counters[0], 1u);
+    __syncthreads();
+    group = (int)L.misc[0];
+  }
   const int first_tile = group * G;
+  const int ntile_here = G;
 
   unsigned long long sel[G];
   unsigned toff[G];           // this lane's first record index inside its tile
@@ -95,25 +100,28 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
     else if ((c) < kExactRows * 4 && ab >= 0 && ab < len)                                      \
       for (int b = 0; ab + b < len; ++b) dst[b] = P.buf[ab + b];                               \
   }
-  if (first_tile < P.ntiles) RGX_LOAD_TILE(first_tile * kExactOwnedBytes - kSliceBytes)
+  if (first_tile < P.ntiles && !(P.debug & 16)) RGX_LOAD_TILE(first_tile * kExactOwnedBytes - kSliceBytes)
+  // tables (covered by the first barrier of the tile loop); their L2 round trip overlaps the tile's HBM round trip
+  L.sa[tid] = (T.sa_mask[tid] << sh) | (7u << 29);
+  if (tid < ncap) L.off[tid] = T.cap_kind[tid] == kCapFromStart ? T.cap_delta[tid] : K - T.cap_delta[tid];
 
 #pragma unroll
   for (int g = 0; g < G; ++g) {
     sel[g] = 0;
     toff[g] = 0; tbase[g] = 0; ttot[g] = 0;
     const int tile = first_tile + g;
-    if (tile >= P.ntiles) continue;                     // uniform across the workgroup
+    if (g >= ntile_here || tile >= P.ntiles) continue;  // uniform across the workgroup
     const int tb0 = tile * kExactOwnedBytes - kSliceBytes;   // absolute offset of slice 0 (-64 for tile 0)
 
     // ---- stage rows [0, 257) of this tile from the prefetched registers, then prefetch the next tile
-    RGX_PUT(v0, c0, tb0) RGX_PUT(v1, c1, tb0) RGX_PUT(v2, c2, tb0) RGX_PUT(v3, c3, tb0) RGX_PUT(v4, c4, tb0)
+    if (!(P.debug & 16)) { RGX_PUT(v0, c0, tb0) RGX_PUT(v1, c1, tb0) RGX_PUT(v2, c2, tb0) RGX_PUT(v3, c3, tb0) RGX_PUT(v4, c4, tb0) }
     __syncthreads();
-    if (g + 1 < G && tile + 1 < P.ntiles) RGX_LOAD_TILE(tb0 + kExactOwnedBytes)
+    if (g + 1 < ntile_here && tile + 1 < P.ntiles && !(P.debug & 16)) RGX_LOAD_TILE(tb0 + kExactOwnedBytes)
 
     // ---- phase 1: candidate mask of this lane's slice (match starts in [a, a+64))
     const int a = tb0 + tid * kSliceBytes;
     unsigned long long cur = 0;
-    if (a >= 0 && a < len) {
+    if (a >= 0 && a < len && !(P.debug & 8)) {
       const uint4* row = reinterpret_cast<const uint4*>(L.tile + tid * kRowBytes);
       const uint4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
       const uint4 n0 = row[5], n1 = row[6];   // next row: 80-byte stride = 5 uint4
@@ -241,11 +249,11 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
   if (wave == 0) {
     unsigned long long excl;
     if (P.debug & 1) { unsigned long long t = 0; if (lane == 0) t = atomicAdd(P.total, (unsigned long long)group_run); excl = __shfl(t, 0, 64); }
-    else excl = LookBack(P.tile_desc, group, group_run, lane);
+    else excl = LookBack(P.tile_desc, group, group_run, lane, &P.counters[3]);
     if (lane == 0) {
       L.misc[8] = (unsigned)excl;
       L.misc[9] = (unsigned)(excl >> 32);
-      if (!(P.debug & 1) && first_tile + G >= P.ntiles) *P.total = excl + group_run;   // the last group knows the grand total
+      if (!(P.debug & 1) && first_tile + ntile_here >= P.ntiles) *P.total = excl + group_run;   // the last group knows the grand total
     }
   }
   __syncthreads();
