@@ -80,38 +80,38 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   const int32_t ntiles = ScanNumTiles(T, ilen);
   const int32_t nslices = (ilen + kSliceBytes - 1) / kSliceBytes;
   int rc;
-  if ((rc = Ensure(&c->d_desc, &c->desc_cap, ntiles)) != RGX_OK) return rc;
+  // one device buffer: [total u64][trace cursor u64][counters 4 x u32][look-back descriptors ...] -> one memset, one readback
+  if ((rc = Ensure(&c->d_desc, &c->desc_cap, (int64_t)ntiles + 4)) != RGX_OK) return rc;
+  c->d_total = c->d_desc;
+  c->d_counters = (uint32_t*)(c->d_desc + 2);
 
   ScanParams P{};
   P.buf = d_buf; P.len = ilen; P.ntiles = ntiles; P.spans = d_spans; P.cap_records = (int64_t)cap_records;
-  P.tile_desc = c->d_desc; P.counters = c->d_counters; P.total = c->d_total; P.carry_in = nullptr; P.slice_unsynced = nullptr;
+  P.tile_desc = c->d_desc + 4; P.counters = c->d_counters; P.total = c->d_total; P.carry_in = nullptr; P.slice_unsynced = nullptr;
   P.count_only = count_only ? 1 : 0;
 
   auto run_scan = [&](bool time_it) -> int {
-    HIP_TRY(hipMemsetAsync(c->d_desc, 0, (size_t)ntiles * 8, c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_counters, 0, 16, c->stream));
-    HIP_TRY(hipMemsetAsync(c->d_total, 0, 16, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_desc, 0, ((size_t)ntiles + 4) * 8, c->stream));
     if (time_it) HIP_TRY(hipEventRecord(c->ev0, c->stream));
     HIP_TRY(LaunchScan(T, P, c->stream));
     if (time_it) HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(hipMemcpyAsync(&c->h_read[0], c->d_total, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipMemcpyAsync(&c->h_read[1], c->d_counters, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&c->h_read[0], c->d_desc, 32, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return RGX_OK;
   };
   static const bool force_tickets = getenv("RGX_TICKETS") != nullptr;
   P.use_tickets = force_tickets ? 1 : 0;
   if ((rc = run_scan(c->timing)) != RGX_OK) return rc;
-  if (((uint32_t*)&c->h_read[1])[3]) {
+  if (((uint32_t*)&c->h_read[2])[3]) {
     // a look-back spin hit its bound (block ids assumed dispatch order and the assumption failed): repeat with tickets,
     // which need no assumption at all
     P.use_tickets = 1;
     if ((rc = run_scan(c->timing)) != RGX_OK) return rc;
-    if (((uint32_t*)&c->h_read[1])[3]) { SetError("look-back timed out in ticket mode"); return RGX_E_HIP; }
+    if (((uint32_t*)&c->h_read[2])[3]) { SetError("look-back timed out in ticket mode"); return RGX_E_HIP; }
   }
   float ms = 0;
   if (c->timing) hipEventElapsedTime(&ms, c->ev0, c->ev1);
-  uint32_t unsynced = ((uint32_t*)&c->h_read[1])[1];
+  uint32_t unsynced = ((uint32_t*)&c->h_read[2])[1];
   if (unsynced) {
     // rare path: some slices found no sync point; resolve their entry positions serially and rescan.
     if ((rc = Ensure(&c->d_unsynced, &c->slice_cap, nslices)) != RGX_OK) return rc;
@@ -254,8 +254,7 @@ RGX_API int rgx_stream_ctx_create(const rgx_program* p, rgx_stream_ctx** out) {
   if (hipSetDevice(c->device) != hipSuccess) { delete c; return RGX_E_NO_DEVICE; }
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
-            hipMalloc((void**)&c->d_counters, 16) == hipSuccess && hipMalloc((void**)&c->d_total, 16) == hipSuccess &&
-            hipHostMalloc((void**)&c->h_read, 64, hipHostMallocDefault) == hipSuccess;
+                        hipHostMalloc((void**)&c->h_read, 64, hipHostMallocDefault) == hipSuccess;
   if (!ok) { SetError("ctx allocation failed"); rgx_stream_ctx_destroy(c); return RGX_E_HIP; }
   *out = c;
   return RGX_OK;
@@ -266,7 +265,7 @@ RGX_API void rgx_stream_ctx_destroy(rgx_stream_ctx* c) {
   if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
-  for (void* p : {(void*)c->d_desc, (void*)c->d_counters, (void*)c->d_total, (void*)c->d_unsynced, (void*)c->d_carry,
+  for (void* p : {(void*)c->d_desc, (void*)c->d_unsynced, (void*)c->d_carry,
                   (void*)c->d_trace, (void*)c->d_in, (void*)c->d_out})
     if (p) hipFree(p);
   if (c->h_read) hipHostFree(c->h_read);

@@ -115,7 +115,10 @@ class ShardedFinder:
         chained = False
         if all_ok:
             spans, info = self.scan(window)
-            owned, a, b = own_filter(spans, shard)
+            if shard.world == 1:
+                owned = spans            # the window IS the input: every match is owned
+            else:
+                owned, a, b = own_filter(spans, shard)
         else:
             chained = True
             rank, world = shard.rank, shard.world

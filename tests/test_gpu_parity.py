@@ -125,14 +125,30 @@ def test_one_gib_date_log(torch_dev):
 
 
 def test_unsynced_fallback_is_exact(torch_dev):
-    """No reset byte within reach (a long run of digits and dashes): the serial carry path must give the same answer."""
+    """Inputs with no sync point in reach must take the serial carry path and still give the reference's answer.
+    (a) exact Shift-And kernel: candidates every 8 bytes ("1234-56-" repeated: each one overlaps the next) block
+        every 64-byte look-behind window; (b) table-walk kernel: a 200 KB run of digits/dashes has no reset byte."""
     from oracle.gen_c import CMatcher
-    rng = np.random.default_rng(5)
-    body = rng.choice(np.frombuffer(b"0123456789-", dtype=np.uint8), size=200000)
-    buf = np.concatenate([np.frombuffer(b"abc ", dtype=np.uint8), body, np.frombuffer(b" tail 2024-01-15", dtype=np.uint8)])
+    head, tail = np.frombuffer(b"abc ", dtype=np.uint8), np.frombuffer(b" tail 2024-01-15", dtype=np.uint8)
+    dense = np.frombuffer(b"1234-56-" * 30000, dtype=np.uint8)
+    buf = np.concatenate([head, dense, tail])
     c = _gpu(DATE)
     spans, res = c.FindAllSpans(torch_dev.from_numpy(buf).cuda())
     assert res.unsynced > 0
+    exp, cnt = CMatcher(DATE).find_all_np(buf)
+    assert res.total == cnt and np.array_equal(spans.cpu().numpy(), exp)
+
+    rng = np.random.default_rng(5)
+    body = rng.choice(np.frombuffer(b"0123456789-", dtype=np.uint8), size=200000)
+    buf = np.concatenate([head, body, tail])
+    pat = r"(\d{4})-(\d{2})-(\d{2,3})"          # variable length: not a class chain -> table-walk kernel
+    c2 = _gpu(pat)
+    spans, res = c2.FindAllSpans(torch_dev.from_numpy(buf).cuda())
+    assert res.unsynced > 0
+    exp, cnt = CMatcher(pat).find_all_np(buf)
+    assert res.total == cnt and np.array_equal(spans.cpu().numpy(), exp)
+    # and the exact kernel on the same random run (mask-based sync finds its own sync points here)
+    spans, res = c.FindAllSpans(torch_dev.from_numpy(buf).cuda())
     exp, cnt = CMatcher(DATE).find_all_np(buf)
     assert res.total == cnt and np.array_equal(spans.cpu().numpy(), exp)
 
