@@ -48,8 +48,14 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        backend = os.environ.get("RGX_BENCH_BACKEND", "nccl")   # "gloo" lets the N>1 code path run on a 1-GPU box
+        if os.environ.get("RGX_BENCH_ONE_DEVICE") == "1":
+            local_rank = 0
         torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
     dev = "cuda:%d" % local_rank
     torch.cuda.set_device(local_rank)
@@ -73,9 +79,11 @@ def main():
 
     finder.scan = scan
 
+    cdev_early = dev if (world == 1 or dist.get_backend() == "nccl") else "cpu"
+
     def step():
         owned, cnt, info = finder.find_all_local(window, sh)
-        base, total, counts = finder.global_row_base(cnt, dev)
+        base, total, counts = finder.global_row_base(cnt, cdev_early)
         return owned, cnt, info, base, total, counts
 
     for _ in range(args.warmup):
@@ -92,7 +100,8 @@ def main():
     if world > 1:
         dist.barrier()
     dt = time.perf_counter() - t0
-    tmax = torch.tensor([dt], dtype=torch.float64, device=dev)
+    cdev = dev if (world == 1 or dist.get_backend() == "nccl") else "cpu"   # where small collectives live
+    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
     if world > 1:
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
     dt = float(tmax.item())
@@ -107,7 +116,7 @@ def main():
         rel = (starts - sh.win_lo).to(torch.int32)
         exp = torch.stack([rel, rel + 10, rel, rel + 4, rel + 5, rel + 7, rel + 8, rel + 10], dim=1)
         parity = bool(owned.shape == exp.shape and torch.equal(owned, exp))
-    pt = torch.tensor([1 if parity in (True, None) else 0], dtype=torch.int64, device=dev)
+    pt = torch.tensor([1 if parity in (True, None) else 0], dtype=torch.int64, device=cdev)
     if world > 1:
         dist.all_reduce(pt, op=dist.ReduceOp.MIN)
     parity_all = bool(pt.item())

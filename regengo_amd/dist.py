@@ -57,18 +57,25 @@ def plan_shards(total_len: int, world: int, max_match_len: int, halo_left: int =
     return out
 
 
+_BOUNDS_CACHE = {}
+
+
 def own_filter(spans, shard: Shard):
     """Rows of `spans` (window-relative int32 [n, ncap], sorted by start) whose start lies in the owned range.
-    Returns (rows converted to GLOBAL offsets as int64, first_row, last_row)."""
+    Returns (owned rows (a view), first_row, last_row, end offset of the last owned match or -1).  One device op
+    chain and ONE host sync."""
     import torch
     if spans.shape[0] == 0:
-        return spans.to(torch.int64), 0, 0
-    starts = spans[:, 0].contiguous()
-    lo_rel = shard.lo - shard.win_lo
-    hi_rel = shard.hi - shard.win_lo
-    a = int(torch.searchsorted(starts, torch.tensor([lo_rel], dtype=starts.dtype, device=starts.device)).item())
-    b = int(torch.searchsorted(starts, torch.tensor([hi_rel], dtype=starts.dtype, device=starts.device)).item())
-    return spans[a:b], a, b
+        return spans, 0, 0, -1
+    key = (shard.lo - shard.win_lo, shard.hi - shard.win_lo, str(spans.device))
+    bounds = _BOUNDS_CACHE.get(key)
+    if bounds is None:
+        bounds = torch.tensor([key[0], key[1]], dtype=torch.int32, device=spans.device)
+        _BOUNDS_CACHE[key] = bounds
+    idx = torch.searchsorted(spans[:, 0].contiguous(), bounds)
+    last_end = spans[torch.clamp(idx[1] - 1, min=0), 1]
+    a, b, e = torch.cat([idx, last_end.reshape(1).to(idx.dtype)]).tolist()
+    return spans[a:b], int(a), int(b), (int(e) if b > a else -1)
 
 
 class ShardedFinder:
@@ -109,16 +116,18 @@ class ShardedFinder:
         ok_local = has_sync_in_left_halo(window, shard, self.reset_table)
         all_ok = ok_local
         if dist is not None:
-            flag = torch.tensor([0 if ok_local else 1], dtype=torch.int64, device=window.device)
+            cdev = window.device if dist.get_backend(self.group) == "nccl" else "cpu"
+            flag = torch.tensor([0 if ok_local else 1], dtype=torch.int64, device=cdev)
             dist.all_reduce(flag, group=self.group)
             all_ok = int(flag.item()) == 0
         chained = False
         if all_ok:
             spans, info = self.scan(window)
+            last_end = -1
             if shard.world == 1:
                 owned = spans            # the window IS the input: every match is owned
             else:
-                owned, a, b = own_filter(spans, shard)
+                owned, a, b, last_end = own_filter(spans, shard)
         else:
             chained = True
             rank, world = shard.rank, shard.world
@@ -134,15 +143,13 @@ class ShardedFinder:
             spans, info = self.scan(sub)
             if spans.shape[0]:
                 spans = spans + off
-            owned, a, b = own_filter(spans, shard)
+            owned, a, b, last_end = own_filter(spans, shard)
             nxt = shard.hi
-            if owned.shape[0]:
-                nxt = max(nxt, int(owned[-1, 1].item()) + shard.win_lo)
+            if last_end >= 0:
+                nxt = max(nxt, last_end + shard.win_lo)
             if rank + 1 < world:
                 dist.send(torch.tensor([nxt], dtype=torch.int64, device=window.device), dst=rank + 1, group=self.group)
-        truncated = False
-        if shard.win_hi < shard.total_len and owned.shape[0] > 0:
-            truncated = bool(int(owned[-1, 1].item()) >= shard.win_hi - shard.win_lo)
+        truncated = shard.win_hi < shard.total_len and last_end >= shard.win_hi - shard.win_lo
         info = dict(info)
         info.update({"truncated": truncated, "chained": chained})
         return owned, int(owned.shape[0]), info
