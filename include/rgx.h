@@ -125,6 +125,14 @@ int64_t rgx_find_all_bytes_device(const rgx_program* p, rgx_stream_ctx* c, const
 /* Same, host buffers: H2D copy of the input, D2H copy of the spans (PCIe-bound).     */
 int64_t rgx_find_all_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* buf, size_t len, int64_t n,
                            int32_t* spans, size_t cap_records, rgx_result* res);
+/* Compact variant for programs whose capture groups are a fixed template (rgx_info.fixed_captures && fixed_match_len >= 0):
+ * writes ONE int32 per match, its start offset, in match order; every span is start + a constant obtained once from
+ * rgx_program_capture_template.  RGX_E_UNSUPPORTED for other programs.  (The span table of the Date pattern is 32 B per
+ * match, 64 % as large as the input it was found in; this form is 4 B per match.)                                    */
+int64_t rgx_find_all_starts_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n,
+                                   int32_t* d_starts, size_t cap, rgx_result* res);
+/* offsets[c] for c in [0, ncap): span slot c of a match starting at s is s + offsets[c]; returns fixed match length or <0. */
+int rgx_program_capture_template(const rgx_program* p, int32_t* offsets);
 /* Count only (FindReaderCount's hot loop; no span traffic).                                        */
 int64_t rgx_count_all_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len,
                              rgx_result* res);

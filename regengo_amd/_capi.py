@@ -67,6 +67,9 @@ SYMBOLS = {
                                               C.c_size_t, C.POINTER(Result)]),
     "rgx_find_all_bytes": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t,
                                        C.POINTER(Result)]),
+    "rgx_find_all_starts_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p,
+                                              C.c_size_t, C.POINTER(Result)]),
+    "rgx_program_capture_template": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rgx_count_all_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Result)]),
     "rgx_find_batch_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,
                                           C.c_void_p]),

@@ -166,6 +166,28 @@ class Compiled:
         _capi.check(w)
         return out.view(-1, self.ncap)[:w], res
 
+    def capture_template(self):
+        """(offsets[ncap], match_len) for fixed-template patterns: span slot c = start + offsets[c]."""
+        o = (C.c_int32 * self.ncap)()
+        k = _capi.check(self._lib.rgx_program_capture_template(self._h, o))
+        return list(o), k
+
+    def FindAllStarts(self, data, n: int = -1, capacity: Optional[int] = None, out=None):
+        """Compact result for fixed-template patterns: int32 tensor [count] of match starts (device)."""
+        import torch
+        self._need_dev()
+        t, ln = self._as_device(data)
+        res = _capi.Result()
+        if n == 0 or ln == 0:
+            return torch.empty(0, dtype=torch.int32, device=t.device), res
+        if capacity is None:
+            capacity = ln // max(self.MinMatchLen, 1) + 1
+        if out is None or out.numel() < capacity:
+            out = torch.empty(capacity, dtype=torch.int32, device=t.device)
+        w = _capi.check(self._lib.rgx_find_all_starts_device(self._h, self._ctx, t.data_ptr(), ln, n, out.data_ptr(), capacity,
+                                                             C.byref(res)))
+        return out[:w], res
+
     def CountAll(self, data):
         self._need_dev()
         t, ln = self._as_device(data)

@@ -68,7 +68,7 @@ int CheckCtx(const rgx_program* p, rgx_stream_ctx* c) {
 
 // Core: scan (+ carry fallback) (+ captures).  Inputs/outputs are device pointers.
 int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n, int32_t* d_spans,
-                      size_t cap_records, bool count_only, rgx_result* res) {
+                      size_t cap_records, bool count_only, rgx_result* res, bool starts_only = false) {
   const DevTables& T = p->p.dev;
   if (res) memset(res, 0, sizeof *res);
   if (res) res->ncap = T.ncap;
@@ -89,6 +89,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   P.buf = d_buf; P.len = ilen; P.ntiles = ntiles; P.spans = d_spans; P.cap_records = (int64_t)cap_records;
   P.tile_desc = c->d_desc + 4; P.counters = c->d_counters; P.total = c->d_total; P.carry_in = nullptr; P.slice_unsynced = nullptr;
   P.count_only = count_only ? 1 : 0;
+  P.starts_only = starts_only ? 1 : 0;
 
   auto run_scan = [&](bool time_it) -> int {
     HIP_TRY(hipMemsetAsync(c->d_desc, 0, ((size_t)ntiles + 4) * 8, c->stream));
@@ -137,7 +138,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     return RGX_E_CAPACITY;
   }
   if (n > 0) written = std::min<int64_t>(written, n);
-  if (!T.fixed_captures && written > 0) {
+  if (!T.fixed_captures && written > 0 && !starts_only) {
     // dynamic capture groups: second kernel over the (much smaller) match list
     int64_t need = (int64_t)len + written + 64;
     if ((rc = Ensure(&c->d_trace, &c->trace_cap, need)) != RGX_OK) return rc;
@@ -280,6 +281,25 @@ RGX_API int64_t rgx_find_all_bytes_device(const rgx_program* p, rgx_stream_ctx* 
   int rc = CheckCtx(p, c);
   if (rc != RGX_OK) return rc;
   return FindAllDevice(p, c, d_buf, len, n, d_spans, cap_records, false, res);
+}
+
+RGX_API int64_t rgx_find_all_starts_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n,
+                                           int32_t* d_starts, size_t cap, rgx_result* res) {
+  int rc = CheckCtx(p, c);
+  if (rc != RGX_OK) return rc;
+  if (!UseExactKernel(p->p.dev, len > 0x7FFFFF00ull ? 0 : (int32_t)len) && len != 0) {
+    SetError("starts-only results need a fixed-template pattern (rgx_info.fixed_captures) and len >= 64");
+    return RGX_E_UNSUPPORTED;
+  }
+  return FindAllDevice(p, c, d_buf, len, n, d_starts, cap, false, res, true);
+}
+
+RGX_API int rgx_program_capture_template(const rgx_program* p, int32_t* offsets) {
+  if (!p || !offsets) return RGX_E_INVALID;
+  const Tables& t = p->p.t;
+  if (!t.fixed_captures || t.fixed_len < 0) return RGX_E_UNSUPPORTED;
+  for (int c = 0; c < t.ncap; c++) offsets[c] = t.cap_kind[c] == kCapFromStart ? t.cap_delta[c] : t.fixed_len - t.cap_delta[c];
+  return t.fixed_len;
 }
 
 RGX_API int64_t rgx_count_all_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, rgx_result* res) {

@@ -20,6 +20,7 @@ struct ScanParams {
   const int32_t* carry_in;       // nullable; per slice: -1 = find a sync point locally, else search position
   uint8_t* slice_unsynced;       // nullable; set to 1 for slices that found no sync point
   int32_t count_only;
+  int32_t starts_only;           // fixed-template patterns: write one int32 (match start) per match instead of ncap
   int32_t use_tickets;           // 1: tile/group ids from the ticket counter; 0: blockIdx.x (bounded spin, host falls back)
   int32_t debug;                 // experiment switches (RGX_DEBUG): 1 = unordered base (no look-back), 2 = no span stores
 };

@@ -270,7 +270,16 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
     if (ttot[g] == 0) continue;                               // uniform
     const int a = (first_tile + g) * kExactOwnedBytes - kSliceBytes + tid * kSliceBytes;
     const unsigned long long rbase = base + tbase[g];
-    if ((ncap & 3) == 0 && ttot[g] <= kStartsCap) {
+    if (P.starts_only) {
+      // compact result: the capture groups of a fixed template are start + constants, so only the start travels
+      unsigned long long m = sel[g];
+      unsigned long long idx = rbase + toff[g];
+      while (m) {
+        if (idx < (unsigned long long)P.cap_records) P.spans[idx] = a + __builtin_ctzll(m);
+        m &= m - 1;
+        ++idx;
+      }
+    } else if ((ncap & 3) == 0 && ttot[g] <= kStartsCap) {
       unsigned long long m = sel[g];
       unsigned k = toff[g];
       while (m) {

@@ -23,3 +23,6 @@ from oracle.gen_c import CMatcher
 e2, n2 = CMatcher(r"(?P<year>\d{4})-(?P<month>\d{2})-(?P<day>\d{2})").find_all_np(adv.cpu().numpy())
 s2, r3 = c.FindAllSpans(adv)
 print("adversarial 64MiB parity", bool((s2.cpu().numpy() == e2).all()) and r3.total == n2, r3.total, "unsynced", r3.unsynced)
+st, r4 = c.FindAllStarts(big)
+ks3 = [c.FindAllStarts(big)[1].kernel_ms for _ in range(5)]
+print("starts-only kernel_ms min %.3f | parity %s" % (min(ks3), bool(torch.equal(st, exp[:, 0].contiguous()))), c.capture_template())

@@ -285,3 +285,20 @@ def test_batch_find_and_match(torch_dev):
         if cnt:
             assert spans[i].tolist() == exp[0].tolist(), i
     assert 0.5 < found.mean() < 0.95
+
+
+def test_starts_only_form(torch_dev):
+    """Compact result for fixed-template patterns: starts + template reproduce the full span table bit for bit."""
+    from regengo_amd import _capi, synth
+    torch = torch_dev
+    c = _gpu(DATE)
+    tmpl, mlen = c.capture_template()
+    assert (tmpl, mlen) == ([0, 10, 0, 4, 5, 7, 8, 10], 10)
+    for n, adv in ((100000, True), (1 << 22, False), (70, True)):
+        buf = torch.from_numpy(synth.date_log_np(n, adversarial=adv)).cuda()
+        full, r1 = c.FindAllSpans(buf)
+        st, r2 = c.FindAllStarts(buf)
+        assert r1.total == r2.total
+        assert torch.equal(st[:, None] + torch.tensor(tmpl, dtype=torch.int32, device="cuda:0")[None, :], full)
+    with pytest.raises(_capi.RgxError):
+        _gpu(EMAIL).FindAllStarts(b"a@b " * 100)
