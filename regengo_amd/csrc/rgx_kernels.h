@@ -32,7 +32,11 @@ int32_t ScanNumTiles(const DevTables& T, int32_t len);
 // rgx_scan_exact.hip: the branch-free Shift-And kernel for fixed-length class chains
 bool UseExactKernel(const DevTables& T, int32_t len);
 int ExactTileBytes();
-hipError_t LaunchScanExact(const DevTables& T, const ScanParams& P, hipStream_t stream);  // tiles (= look-back descriptors) the scan of `len` bytes uses
+hipError_t LaunchScanExact(const DevTables& T, const ScanParams& P, hipStream_t stream);
+// rgx_scan_sa.hip: same structure, Shift-And as a prefilter + DFA verification (variable-length matches)
+bool UseSaKernel(const DevTables& T, int32_t len);
+int SaTileBytes();
+hipError_t LaunchScanSa(const DevTables& T, const ScanParams& P, const uint16_t* class_table, hipStream_t stream);  // tiles (= look-back descriptors) the scan of `len` bytes uses
 
 // Serial carry resolution for slices without a local sync point (rare path).
 hipError_t LaunchCarry(const DevTables& T, const uint8_t* buf, int32_t len, const uint8_t* slice_unsynced, int32_t* carry_in,

@@ -101,8 +101,8 @@ __device__ __forceinline__ void WriteRecordFixed(int32_t* rec, int ncap, const u
 }
 
 // ---- the scan kernel ------------------------------------------------------------------------------------
-// SA: 0 = try every start with the DFA; 1 = Shift-And level-set prefilter, DFA verifies the survivors;
-//     2 = the level sets are exact (fixed-length chain of byte classes): no DFA in the loop at all.
+// SA: 0 = try every start with the DFA; 1 = Shift-And level-set prefilter, the DFA walks only the survivors.
+// (Patterns whose level sets are exact take rgx_scan_exact.hip instead.)
 template <int MODE, int SA>
 __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -128,7 +128,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
   if (tid == 0) s_misc[0] = P.use_tickets ? atomicAdd(&P.counters[0], 1u) : blockIdx.x;
   // stage the tables while the ticket is in flight
   {
-    const int nwords = SA == 2 ? 0 : (T.table_bytes >> 2);   // the exact Shift-And path never touches the DFA
+    const int nwords = T.table_bytes >> 2;
     const uint32_t* src = reinterpret_cast<const uint32_t*>(T.trans);
     uint32_t* dst = reinterpret_cast<uint32_t*>(s_tab);
     for (int w = tid; w < nwords; w += kBlockThreads) dst[w] = src[w];
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
     s_reset[tid] = T.reset_byte[tid];
     s_ctx[tid] = T.ctx_of_byte[tid];
     if (tid < T.ncap) { s_delta[tid] = T.cap_delta[tid]; s_kind[tid] = T.cap_kind[tid]; }
-    if (SA) s_sa[tid] = T.sa_mask[tid];
+    if (SA) s_sa[tid] = (T.sa_mask[tid] << (29 - T.sa_k)) | (7u << 29);   // accept bit at 28, history at 29..31
   }
   __syncthreads();
   const int tile = (int)s_misc[0];
@@ -217,45 +217,53 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
         }
       }
     } else {
-      // Shift-And over level sets: D bit j = "the last j+1 bytes can be the first j+1 bytes of a match".
-      // The F lookups are independent of D, so four of them are in flight per dword; the dependent chain is
-      // three VALU ops per byte.  A start position s is a candidate when bit K-1 comes up at byte s+K-1.
+      // Shift-And over level sets as a PREFILTER (same 4-bytes-per-update composition as rgx_scan_exact.hip): a start
+      // position can only match if its first K bytes pass the level sets, so only those positions get a DFA walk.
+      // Detection bits are gathered 32 bytes at a time without a branch; the (rare, divergent) walks run after each
+      // 32-byte chunk, in position order, under the FindAll rule.
       const int K = T.sa_k;
-      const unsigned top = 1u << (K - 1);
+      const int sh = 29 - K;
+      const unsigned one = 1u << sh, one2 = (one << 1) | one, one4 = (one2 << 2) | one2;
+      const unsigned dead = 7u << 29;             // level-set word of "no byte": history passes, no level survives
       int end_i = slice_end + K - 1;
       if (end_i > len) end_i = len;
       int i = pos & ~3;
-      unsigned D = 0;
-      auto candidate = [&](int s) {
-        if (s < pos) return;
-        int e;
-        if (SA == 2) e = s + K;
-        else e = Walk<MODE>(tab, in, T, s_ctx, s);
-        if (e >= 0) {
-          if (s >= a) mask |= 1ull << (s - a);
-          pos = e > s ? e : s + 1;
-        }
-      };
-      while (i + 4 <= end_i) {
-        const unsigned w = *reinterpret_cast<const unsigned*>(s_tile + PadAddr(i - wb));
-        const unsigned f0 = s_sa[w & 255u], f1 = s_sa[(w >> 8) & 255u], f2 = s_sa[(w >> 16) & 255u], f3 = s_sa[w >> 24];
-        const unsigned D0 = ((D << 1) | 1u) & f0;
-        const unsigned D1 = ((D0 << 1) | 1u) & f1;
-        const unsigned D2 = ((D1 << 1) | 1u) & f2;
-        const unsigned D3 = ((D2 << 1) | 1u) & f3;
-        D = D3;
-        if ((D0 | D1 | D2 | D3) & top) {
-          if (D0 & top) candidate(i - K + 1);
-          if (D1 & top) candidate(i - K + 2);
-          if (D2 & top) candidate(i - K + 3);
-          if (D3 & top) candidate(i - K + 4);
-        }
-        i += 4;
-      }
+      unsigned E = 0;
       while (i < end_i) {
-        D = ((D << 1) | 1u) & s_sa[in.At(i)];
-        if (D & top) candidate(i - K + 1);
-        ++i;
+        const int chunk0 = i;
+        unsigned det = 0;
+#pragma unroll
+        for (int d = 0; d < 8; ++d) {
+          if (i < end_i) {
+            const unsigned w = *reinterpret_cast<const unsigned*>(s_tile + PadAddr(i - wb));
+            unsigned f0 = s_sa[w & 255u], f1 = s_sa[(w >> 8) & 255u], f2 = s_sa[(w >> 16) & 255u], f3 = s_sa[w >> 24];
+            if (i + 4 > end_i) {                    // last, partial dword of the lane's range
+              if (i + 1 >= end_i) f1 = dead;
+              if (i + 2 >= end_i) f2 = dead;
+              f3 = dead;
+            }
+            const unsigned g01 = ((f0 << 1) | one) & f1;
+            const unsigned g23 = ((f2 << 1) | one) & f3;
+            const unsigned gq = ((g01 << 2) | one2) & g23;
+            E = ((E << 4) | one4) & gq;
+            det = __builtin_amdgcn_alignbit(det, E, 28);
+          } else {
+            det <<= 4;
+          }
+          i += 4;
+        }
+        det = __builtin_bitreverse32(det);          // bit j: the accept level came up after byte chunk0 + j
+        while (det) {
+          const int j = __builtin_ctz(det);
+          det &= det - 1;
+          const int s = chunk0 + j - (K - 1);
+          if (s < pos) continue;
+          const int e = Walk<MODE>(tab, in, T, s_ctx, s);
+          if (e >= 0) {
+            if (s >= a) mask |= 1ull << (s - a);
+            pos = e > s ? e : s + 1;
+          }
+        }
       }
     }
   }
@@ -467,12 +475,13 @@ size_t ScanSharedBytes(const DevTables& T) {
 }
 
 int32_t ScanNumTiles(const DevTables& T, int32_t len) {
-  const int per = UseExactKernel(T, len) ? ExactTileBytes() : kTileBytes;
+  const int per = UseExactKernel(T, len) ? ExactTileBytes() : ((UseSaKernel(T, len) && !getenv("RGX_NO_SA_KERNEL")) ? SaTileBytes() : kTileBytes);
   return (len + per - 1) / per;
 }
 
 hipError_t LaunchScan(const DevTables& T, const ScanParams& P, hipStream_t stream) {
   if (UseExactKernel(T, P.len)) return LaunchScanExact(T, P, stream);
+  if (UseSaKernel(T, P.len) && !getenv("RGX_NO_SA_KERNEL")) return LaunchScanSa(T, P, T.trans_cls, stream);
   const size_t shmem = ScanSharedBytes(T);
   dim3 grid(P.ntiles), block(kBlockThreads);
   static bool attr_set[8] = {false, false, false, false, false, false, false, false};
@@ -487,10 +496,8 @@ hipError_t LaunchScan(const DevTables& T, const ScanParams& P, hipStream_t strea
     set_attr((const void*)scan_kernel<M, S>, SLOT);                                   \
     hipLaunchKernelGGL((scan_kernel<M, S>), grid, block, shmem, stream, T, P);        \
   } while (0)
-  const int sa = (T.sa_k > 0 && !T.anchored) ? (T.sa_exact ? 2 : 1) : 0;
-  if (sa == 2) {
-    RGX_LAUNCH(kModeDirect, 2, 0);
-  } else if (T.mode == kModeDirect) {
+  const int sa = (T.sa_k > 0 && T.sa_k <= 29 && !T.anchored) ? 1 : 0;
+  if (T.mode == kModeDirect) {
     if (sa) RGX_LAUNCH(kModeDirect, 1, 1); else RGX_LAUNCH(kModeDirect, 0, 2);
   } else if (T.mode == kModeClassLds) {
     if (sa) RGX_LAUNCH(kModeClassLds, 1, 3); else RGX_LAUNCH(kModeClassLds, 0, 4);

@@ -52,6 +52,8 @@ int ProgramToDevice(Program* p, int device) {
   for (int i = 0; i < 4; i++) { d.start[i] = t.start[i]; d.start_accept[i] = t.start_accept[i]; }
   d.lookahead = t.lookahead_mode; d.ctx_sensitive = t.ctx_sensitive; d.bot_sensitive = t.bot_sensitive; d.anchored = t.anchored;
   d.sa_k = t.sa_k; d.sa_exact = t.sa_exact;
+  d.sa_first_bytes = 0;
+  for (int c = 0; c < 256; c++) d.sa_first_bytes += (int)(t.sa_mask[c] & 1u);
   d.fixed_captures = t.fixed_captures; d.unmatched_minus1 = (t.flags & RGX_FLAG_UNMATCHED_MINUS1) ? 1 : 0;
 
   // choose the LDS layout
@@ -83,6 +85,7 @@ int ProgramToDevice(Program* p, int device) {
   size_t off_ops = a.AddVec(t.bt_ops), off_bm = a.AddVec(t.bt_match), off_so = a.AddVec(t.start_ops);
   size_t off_sop = a.AddVec(t.start_ops_pool);
   size_t off_sa = a.Add(t.sa_mask, sizeof t.sa_mask);
+  size_t off_tcls = a.AddVec(t.trans);
 
   void* dptr = nullptr;
   if (hipMalloc(&dptr, a.host.size()) != hipSuccess) { SetError("hipMalloc(tables) failed"); return RGX_E_NOMEM; }
@@ -99,6 +102,7 @@ int ProgramToDevice(Program* p, int device) {
   d.bt_ops = (const uint32_t*)(b + off_ops); d.bt_match = (const uint32_t*)(b + off_bm);
   d.start_ops = (const uint32_t*)(b + off_so); d.start_ops_pool = (const uint32_t*)(b + off_sop);
   d.sa_mask = (const uint32_t*)(b + off_sa);
+  d.trans_cls = (const uint16_t*)(b + off_tcls);
   p->dev = d;
   p->d_arena = dptr;
   p->device = device;

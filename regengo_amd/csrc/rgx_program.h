@@ -27,6 +27,7 @@ enum TableMode : int {
 // Flat device image of one compiled pattern.  All pointers are device addresses.
 struct DevTables {
   const uint16_t* trans;      // layout depends on mode (direct: [nstates][256] then eot[nstates])
+  const uint16_t* trans_cls;  // always the class-compressed layout [nstates][ncls+1]
   const uint8_t* cls;         // [256]
   const uint8_t* reset_byte;  // [256]
   const uint8_t* ctx_of_byte; // [256]
@@ -48,6 +49,7 @@ struct DevTables {
   int32_t fixed_len;
   int32_t sa_k;                   // 0: no prefilter
   int32_t sa_exact;
+  int32_t sa_first_bytes;         // number of byte values that can start a match (selectivity of the prefilter)
   uint16_t start[4];
   uint8_t start_accept[4];
   uint8_t lookahead, ctx_sensitive, bot_sensitive, anchored, fixed_captures, unmatched_minus1, pad0, pad1;

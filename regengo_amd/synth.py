@@ -115,3 +115,44 @@ def email_batch_np(nstr: int, seed: int = 0x5EED0003):
     hi = kind >= 95
     data[offsets[:-1][hi] + at_pos[hi]] = 0xC3
     return data, offsets
+
+
+def web_log_tile(nbytes: int = 1 << 20, seed: int = 0x5EED0004) -> bytes:
+    """C4/C5 corpus tile: access-log-like text with URLs (~1 per 120 B), e-mail addresses, dates, words.  Deterministic
+    (splitmix64-driven choices); repeat it to any size with `tile_repeat_torch`."""
+    protos = [b"http://", b"https://", b"ftp://", b"http:/", b"htp://"]
+    hosts = [b"example.com", b"a.b-c.org", b"sub0.host9.net", b"localhost", b"x_y.io", b"10.0.0.1"]
+    paths = [b"", b"/", b"/index.html", b"/a/b/c.d", b"/api/v1/users", b"/img/logo.png"]
+    ports = [b"", b"", b"", b":80", b":8080", b":443"]
+    users = [b"bob", b"alice_1", b"j.doe", b"x", b"first.last+tag", b"admin"]
+    words = [b"GET", b"POST", b"200", b"404", b"error", b"warn", b"user", b"login", b"from", b"to", b"the", b"request", b"took",
+             b"ms", b"id=", b"ref", b"[INFO]", b"[WARN]", b"-", b"--", b"@", b"a@", b"@b", b"::", b"//"]
+    out = bytearray()
+    k = 0
+
+    def r(n):
+        nonlocal k
+        k += 1
+        return int(splitmix64_np(seed, np.array([k], dtype=np.uint64))[0] >> np.uint64(33)) % n
+
+    while len(out) < nbytes:
+        out += b"2024-%02d-%02d %02d:%02d:%02d " % (1 + r(12), 1 + r(28), r(24), r(60), r(60))
+        for _ in range(3 + r(6)):
+            t = r(10)
+            if t < 2:
+                out += protos[r(len(protos))] + hosts[r(len(hosts))] + ports[r(len(ports))] + paths[r(len(paths))]
+            elif t < 3:
+                out += users[r(len(users))] + b"@" + hosts[r(len(hosts))]
+            else:
+                out += words[r(len(words))]
+            out += b" "
+        out[-1:] = b"\n"
+    return bytes(out[:nbytes])
+
+
+def tile_repeat_torch(tile: bytes, n: int, device):
+    """n bytes made of `tile` repeated (device tensor)."""
+    import torch
+    t = torch.frombuffer(bytearray(tile), dtype=torch.uint8).to(device)
+    reps = -(-n // len(tile))
+    return t.repeat(reps)[:n].contiguous()
