@@ -54,6 +54,18 @@ int ProgramToDevice(Program* p, int device) {
   d.sa_k = t.sa_k; d.sa_exact = t.sa_exact;
   d.sa_first_bytes = 0;
   for (int c = 0; c < 256; c++) d.sa_first_bytes += (int)(t.sa_mask[c] & 1u);
+  // smallest shift at which the class chain can overlap itself: shift s is possible iff every pair of positions
+  // (j, j+s) shares a byte value
+  d.sa_smin = t.sa_k;
+  for (int s = 1; s < t.sa_k && d.sa_smin == t.sa_k; s++) {
+    bool possible = true;
+    for (int j = 0; j + s < t.sa_k && possible; j++) {
+      bool share = false;
+      for (int c = 0; c < 256 && !share; c++) share = ((t.sa_mask[c] >> j) & 1u) && ((t.sa_mask[c] >> (j + s)) & 1u);
+      possible = share;
+    }
+    if (possible) d.sa_smin = s;
+  }
   d.fixed_captures = t.fixed_captures; d.unmatched_minus1 = (t.flags & RGX_FLAG_UNMATCHED_MINUS1) ? 1 : 0;
 
   // choose the LDS layout

@@ -50,6 +50,7 @@ struct DevTables {
   int32_t sa_k;                   // 0: no prefilter
   int32_t sa_exact;
   int32_t sa_first_bytes;         // number of byte values that can start a match (selectivity of the prefilter)
+  int32_t sa_smin;                // exact chains: smallest shift s>=1 at which two matches can overlap (sa_k: never)
   uint16_t start[4];
   uint8_t start_accept[4];
   uint8_t lookahead, ctx_sensitive, bot_sensitive, anchored, fixed_captures, unmatched_minus1, pad0, pad1;

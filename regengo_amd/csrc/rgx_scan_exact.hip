@@ -1,25 +1,29 @@
-// The exact Shift-And scan kernel for gfx950: FindAllBytes for patterns that are a fixed-length chain of byte
+// The exact Shift-Or scan kernel for gfx950: FindAllBytes for patterns that are a fixed-length chain of byte
 // classes (the BASELINE headline pattern (?P<year>\d{4})-(?P<month>\d{2})-(?P<day>\d{2}) is one).  For such a
 // pattern the level sets of the DFA ARE its language, so "the reference's machine matches at s"
-// (internal/compiler/find.go:130-316 running instructions.go's byte tests) is exactly "bit K-1 of the Shift-And
-// state comes up at byte s+K-1" -- no table walk, no branch per byte.  HBM-bound byte work: no MFMA.
+// (internal/compiler/find.go:130-316 running instructions.go's byte tests) is exactly "bit K-1 of the Shift-Or
+// state is clear after byte s+K-1" -- no table walk, no branch per byte.  HBM-bound byte work: no MFMA.
 //
-// Work decomposition
-//   ticket  -> a GROUP of G consecutive tiles handled by one workgroup (256 lanes).  One device-scope counter
-//              hands out only ~88 tickets/us (MI355X_MICROARCH.md, "dequeue"): one ticket per 16 KiB tile would
-//              cap a 1 GiB scan near 0.75 ms, so a ticket buys G tiles.
-//   tile    -> 256 slices of 64 bytes staged once from HBM into LDS (16-byte coalesced loads, all in flight before
-//              the first LDS store).  Slice 0 re-reads the last slice of the previous tile (0.4 % overlap) so every
-//              owned slice has its predecessor's candidate mask in LDS.  Rows are 80 bytes (64 + 16 pad): 16-byte
-//              aligned and conflict-free for ds_read_b128 (lane stride 20 dwords, 5 coprime with 16).
-//   lane    -> one slice: 4+2 ds_read_b128 bring 64+31 bytes into VGPRs; per byte one ds_read_b32 of the level-set
-//              word (address formed by ONE SDWA shift of the packed byte), then shift-or, and, and a funnel shift
-//              (v_alignbit) that drops the accept bit into a 96-bit detection mask.  Candidate masks go through
-//              LDS; the FindAll chain (leftmost match wins, search resumes at its end, find.go:452-457) is resolved
-//              per lane on 64-bit masks starting from a sync point: x is one iff no candidate starts in [x-K+1, x).
-//   order   -> matches are counted with popcount, ordered by a wave scan + block scan inside the tile, a running sum
-//              across the group's tiles, and ONE decoupled look-back per group; span records are then written in
-//              match order.  The input is read exactly once.
+// Work decomposition (everything is WAVE-autonomous: after the table is staged there is no workgroup barrier)
+//   group   -> one wavefront owns G consecutive wave-tiles and ONE look-back descriptor; group id =
+//              4*blockIdx.x + wave (or 4*ticket + wave in the fallback mode).
+//   tile    -> 64 slices of 64 bytes staged once from HBM into the wave's private LDS rows with four coalesced
+//              16-byte loads per lane (1 KiB per wave-instruction; the next tile's loads are in flight while this one
+//              is processed).  Slice 0 re-reads the last slice of the previous tile (1.6 % overlap, L2 hits) so every
+//              owned slice finds its predecessor's candidate mask in the neighbouring lane (one DPP move).  Rows are
+//              80 bytes (64 + 16 pad): 16-byte aligned and conflict-free for ds_read_b128 (lane stride 20 dwords).
+//   lane    -> one slice: 4+2 ds_read_b128 bring 64+28 bytes into VGPRs; per byte ONE SDWA shift forms the table
+//              address, one ds_read_b32 fetches the inverted level-set word and ONE v_lshl_or_b32 advances the
+//              Shift-Or state  E = (E << 1) | F[c].  Bits K-1.. of E keep the accept bits of the previous bytes, so
+//              they are harvested once per 16 bytes (K <= 17) with a shift and a funnel shift.
+//   chain   -> FindAll keeps the leftmost candidate and resumes at its end (find.go:452-457).  If no candidate of a
+//              wave has another candidate within K-1 positions before it, every candidate is a match (the common
+//              case: two ballots decide); otherwise the lanes resolve the chain on 64-bit masks from a sync point
+//              (x is one iff no candidate starts in [x-K+1, x)), and a slice without one is reported for the serial
+//              carry pass.
+//   order   -> popcounts summed over the group's tiles, ONE decoupled look-back per group, then per tile a DPP scan
+//              gives every lane its record index; match starts are compacted into LDS and expanded by the whole wave
+//              into span records with contiguous 16-byte stores (1 KiB per wave-instruction).
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
@@ -32,144 +36,178 @@ namespace rgx {
 namespace {
 
 constexpr int kRowBytes = 80;
-constexpr int kExactRows = kBlockThreads + 1;                    // 256 slices + one look-ahead row
-constexpr int kExactOwnedBytes = (kBlockThreads - 1) * kSliceBytes;   // 16320 bytes of input owned per tile
+constexpr int kWaveSlices = 63;                               // owned slices per wave-tile
+constexpr int kWaveTileBytes = kWaveSlices * kSliceBytes;     // 4032 bytes of input owned per wave-tile
+constexpr int kWaveRows = 65;                                 // 64 slices + one look-ahead row
+constexpr int kWaveLds = kWaveRows * kRowBytes;               // 5200 bytes
+constexpr int kGroupTiles = 8;                                // wave-tiles per look-back descriptor
+constexpr int kStartsCap = kWaveLds / 4;                      // match starts staged per flush
+
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef int v4i __attribute__((ext_vector_type(4)));
 
 struct ExactLds {
-  unsigned sa[256];          // level-set masks, pre-shifted so that the accept bit is bit 31
+  unsigned sa[256];          // Shift-Or words: bit j set = byte cannot be the (j+1)-th byte of a match; bits >= K clear
   int off[32];               // capture template: slot c = match start + off[c]
-  unsigned misc[16];         // [0] ticket, [1..4] wave totals, [8..9] exclusive prefix of the group
-  unsigned long long cur[kBlockThreads];   // candidate mask of every slice of the current tile
-  __attribute__((aligned(16))) unsigned char tile[kExactRows * kRowBytes];
+  unsigned ticket;
+  unsigned pad[3];
+  __attribute__((aligned(16))) unsigned char tile[kBlockThreads / 64][kWaveLds];
 };
 
-template <int G>
+__device__ __forceinline__ unsigned DppWaveShr1(unsigned x) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xF, 0xF, true);   // lane l <- lane l-1, lane 0 <- 0
+}
+
+// inclusive scan over the 64 lanes, all in DPP (no LDS traffic)
+__device__ __forceinline__ unsigned DppInclusiveScan(unsigned x) {
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);   // row_shr:1
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);   // row_shr:2
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);   // row_shr:4
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);   // row_shr:8
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, true);   // row_bcast:15 -> rows 1,3
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, true);   // row_bcast:31 -> rows 2,3
+  return x;
+}
+
+// PER = dwords between two harvests of the accept history: 4*PER <= 33-K.
+template <int PER>
 __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, ScanParams P) {
   __shared__ ExactLds L;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int K = T.sa_k;
-  // Shift-And state layout (32 bits): bit p0 = "1 byte of a match seen" ... bit 28 = "K bytes seen" (accept), bits
-  // 29..31 = the accept bits of the three previous bytes (the level-set words carry 1s there, so they pass through).
-  // That lets FOUR bytes be folded into one state update: with S(E,F) = ((E<<1)|o)&F,
-  //   S(S(S(S(E,F0),F1),F2),F3) = ((E<<4)|o4) & g,   g = ((g01<<2)|o2)&g23,  g01 = ((F0<<1)|o)&F1,  g23 likewise
-  // (distributivity of | over &).  g depends on the input bytes only, so everything except two ops per dword is off
-  // the dependent chain, and the four accept bits land in bits 31..28 for one funnel shift into the detection mask.
-  const int sh = 29 - K;                 // p0 (the launcher guarantees K <= 29)
-  const unsigned one = 1u << sh;
-  const unsigned one2 = (one << 1) | one;
-  const unsigned one4 = (one2 << 2) | one2;
+  const int smin = T.sa_smin;            // smallest shift at which the pattern can overlap itself (K: never)
   const int len = P.len;
   const int ncap = T.ncap;
 
-  // Group id: blockIdx.x, or a ticket when the host asks for it.  One device-scope counter hands out only ~88
-  // tickets/us (measured: 65794 tickets = 0.75 ms, 16449 = 0.19 ms of pure skeleton time), so the default avoids the
-  // atomic altogether; the look-back spin is bounded and the host repeats the scan with tickets if it ever times out.
-  int group = (int)blockIdx.x;
+  int blk = (int)blockIdx.x;
   if (P.use_tickets) {
-    if (tid == 0) L.misc[0] = atomicAdd(&P.counters[0], 1u);
+    // One device-scope counter hands out only ~88 tickets/us (MI355X_MICROARCH.md, "dequeue"), so ids default to
+    // blockIdx.x with a bounded look-back spin; the host repeats the scan with tickets if a spin ever times out.
+    if (tid == 0) L.ticket = atomicAdd(&P.counters[0], 1u);
     __syncthreads();
-    group = (int)L.misc[0];
+    blk = (int)L.ticket;
   }
-  const int first_tile = group * G;
-  const int ntile_here = G;
-
-  unsigned long long sel[G];
-  unsigned toff[G];           // this lane's first record index inside its tile
-  unsigned tbase[G];          // matches in the group's earlier tiles (uniform)
-  unsigned ttot[G];           // matches in the tile (uniform)
-  unsigned group_run = 0;     // matches in this group's tiles so far (uniform)
-
-  // Software pipeline over the group's tiles: the five 16-byte global loads of tile g+1 are issued (into VGPRs)
-  // before tile g is processed, so the HBM round trip overlaps the byte loop instead of preceding it.  Loads are
-  // unconditional, from a clamped in-bounds address, so the values stay in VGPRs (a conditional load into an array
-  // made hipcc spill to scratch, which serialised the five round trips).
-  const int safe = (len - 16) & ~15;   // last fully readable 16-byte chunk (the launcher guarantees len >= 64)
-  const int c0 = tid, c1 = tid + kBlockThreads, c2 = tid + 2 * kBlockThreads, c3 = tid + 3 * kBlockThreads,
-            c4 = tid + 4 * kBlockThreads;          // chunk ids; c4 only exists for tid < 4 (257 rows * 4 = 1028)
-  uint4 v0, v1, v2, v3, v4;
-#define RGX_FULL(c, tb) ((c) < kExactRows * 4 && (tb) + ((c) << 4) >= 0 && (tb) + ((c) << 4) + 16 <= len)
-#define RGX_LOAD(v, c, tb) v = *reinterpret_cast<const uint4*>(P.buf + (RGX_FULL(c, tb) ? (tb) + ((c) << 4) : safe));
-#define RGX_LOAD_TILE(tb) { RGX_LOAD(v0, c0, tb) RGX_LOAD(v1, c1, tb) RGX_LOAD(v2, c2, tb) RGX_LOAD(v3, c3, tb) RGX_LOAD(v4, c4, tb) }
-#define RGX_PUT(v, c, tb)                                                                      \
-  {                                                                                            \
-    unsigned char* dst = L.tile + ((c) >> 2) * kRowBytes + (((c) & 3) << 4);                   \
-    const int ab = (tb) + ((c) << 4);                                                          \
-    if (RGX_FULL(c, tb)) *reinterpret_cast<uint4*>(dst) = v;                                   \
-    else if ((c) < kExactRows * 4 && ab >= 0 && ab < len)                                      \
-      for (int b = 0; ab + b < len; ++b) dst[b] = P.buf[ab + b];                               \
-  }
-  if (first_tile < P.ntiles && !(P.debug & 16)) RGX_LOAD_TILE(first_tile * kExactOwnedBytes - kSliceBytes)
-  // tables (covered by the first barrier of the tile loop); their L2 round trip overlaps the tile's HBM round trip
-  L.sa[tid] = (T.sa_mask[tid] << sh) | (7u << 29);
+  L.sa[tid] = ~T.sa_mask[tid] & ((K >= 32) ? ~0u : ((1u << K) - 1u));
   if (tid < ncap) L.off[tid] = T.cap_kind[tid] == kCapFromStart ? T.cap_delta[tid] : K - T.cap_delta[tid];
+  __syncthreads();   // the only barrier: from here on every wave runs on its own
+
+  const int group = blk * (kBlockThreads / 64) + wave;
+  if (group >= P.ntiles) return;
+  unsigned char* const wt = L.tile[wave];
+  const int last16 = (len - 1) & ~15;     // the aligned 16-byte chunk holding the last byte never crosses a page
+  const int first_tile = group * kGroupTiles;
+
+  v4u v0, v1, v2, v3, v4 = {0u, 0u, 0u, 0u};
+  // chunk c of a tile = bytes [tb + 16c, tb + 16c + 16); lane l loads chunks l, l+64, l+128, l+192 and (l < 2) 256+l.
+  // Addresses are clamped into the buffer: what a clamped chunk holds is never used (validity mask below).
+#define RGX_ADDR(tb, c) (P.buf + min(max((tb) + ((c) << 4), 0), last16))
+#define RGX_LOAD_TILE(tb)                                                                        \
+  {                                                                                              \
+    v0 = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(RGX_ADDR(tb, lane)));         \
+    v1 = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(RGX_ADDR(tb, lane + 64)));    \
+    v2 = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(RGX_ADDR(tb, lane + 128)));   \
+    v3 = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(RGX_ADDR(tb, lane + 192)));   \
+    if (lane < 2) v4 = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(RGX_ADDR(tb, lane + 256))); \
+  }
+  RGX_LOAD_TILE(first_tile * kWaveTileBytes - kSliceBytes)
+
+  unsigned long long sel[kGroupTiles];
+  unsigned lane_cnt = 0;      // this lane's matches over the group's tiles
+  const int put = (lane >> 2) * kRowBytes + ((lane & 3) << 4);
+  const int nla = (K + 2) >> 2;          // look-ahead dwords: ceil((K-1)/4)
 
 #pragma unroll
-  for (int g = 0; g < G; ++g) {
+  for (int g = 0; g < kGroupTiles; ++g) {
     sel[g] = 0;
-    toff[g] = 0; tbase[g] = 0; ttot[g] = 0;
-    const int tile = first_tile + g;
-    if (g >= ntile_here || tile >= P.ntiles) continue;  // uniform across the workgroup
-    const int tb0 = tile * kExactOwnedBytes - kSliceBytes;   // absolute offset of slice 0 (-64 for tile 0)
+    const int tb0 = (first_tile + g) * kWaveTileBytes - kSliceBytes;   // absolute offset of slice 0 (-64 for tile 0)
+    if (tb0 + kSliceBytes >= len) continue;                            // uniform: nothing owned by this tile
 
-    // ---- stage rows [0, 257) of this tile from the prefetched registers, then prefetch the next tile
-    if (!(P.debug & 16)) { RGX_PUT(v0, c0, tb0) RGX_PUT(v1, c1, tb0) RGX_PUT(v2, c2, tb0) RGX_PUT(v3, c3, tb0) RGX_PUT(v4, c4, tb0) }
-    __syncthreads();
-    if (g + 1 < ntile_here && tile + 1 < P.ntiles && !(P.debug & 16)) RGX_LOAD_TILE(tb0 + kExactOwnedBytes)
+    // ---- stage this tile from the prefetched registers, then prefetch the next one
+    *reinterpret_cast<v4u*>(wt + put) = v0;
+    *reinterpret_cast<v4u*>(wt + put + 16 * kRowBytes) = v1;
+    *reinterpret_cast<v4u*>(wt + put + 32 * kRowBytes) = v2;
+    *reinterpret_cast<v4u*>(wt + put + 48 * kRowBytes) = v3;
+    if (lane < 2) *reinterpret_cast<v4u*>(wt + 64 * kRowBytes + (lane << 4)) = v4;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    if (g + 1 < kGroupTiles && tb0 + kWaveTileBytes + kSliceBytes < len) RGX_LOAD_TILE(tb0 + kWaveTileBytes)
 
-    // ---- phase 1: candidate mask of this lane's slice (match starts in [a, a+64))
-    const int a = tb0 + tid * kSliceBytes;
-    unsigned long long cur = 0;
-    if (a >= 0 && a < len && !(P.debug & 8)) {
-      const uint4* row = reinterpret_cast<const uint4*>(L.tile + tid * kRowBytes);
+    // ---- candidate mask of this lane's slice (match starts in [a, a+64))
+    const int a = tb0 + lane * kSliceBytes;
+    unsigned long long cur;
+    {
+      const uint4* row = reinterpret_cast<const uint4*>(wt + lane * kRowBytes);
       const uint4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
       const uint4 n0 = row[5], n1 = row[6];   // next row: 80-byte stride = 5 uint4
-      unsigned E = 0, det0 = 0, det1 = 0, det2 = 0;
+      unsigned E = ~0u, det0 = 0, det1 = 0, det2 = ~0u;
+      const int hsh = 33 - K - 4 * PER;      // left shift that puts the 4*PER freshest accept bits at the top
 #define RGX_LU(W, B) (*reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(L.sa) + ((((W) >> (8 * (B))) & 0xFFu) << 2)))
-#define RGX_WORD(W, DET)                                                                             \
-      {                                                                                                \
-        const unsigned f0 = RGX_LU(W, 0), f1 = RGX_LU(W, 1), f2 = RGX_LU(W, 2), f3 = RGX_LU(W, 3);     \
-        const unsigned g01 = ((f0 << 1) | one) & f1;                                                   \
-        const unsigned g23 = ((f2 << 1) | one) & f3;                                                   \
-        const unsigned gq = ((g01 << 2) | one2) & g23;                                                 \
-        E = ((E << 4) | one4) & gq;                                                                    \
-        DET = __builtin_amdgcn_alignbit(DET, E, 28);                                                   \
+#define RGX_WORD(W)                                         \
+      {                                                     \
+        E = (E << 1) | RGX_LU(W, 0);                        \
+        E = (E << 1) | RGX_LU(W, 1);                        \
+        E = (E << 1) | RGX_LU(W, 2);                        \
+        E = (E << 1) | RGX_LU(W, 3);                        \
       }
-      RGX_WORD(r0.x, det0) RGX_WORD(r0.y, det0) RGX_WORD(r0.z, det0) RGX_WORD(r0.w, det0)
-      RGX_WORD(r1.x, det0) RGX_WORD(r1.y, det0) RGX_WORD(r1.z, det0) RGX_WORD(r1.w, det0)
-      RGX_WORD(r2.x, det1) RGX_WORD(r2.y, det1) RGX_WORD(r2.z, det1) RGX_WORD(r2.w, det1)
-      RGX_WORD(r3.x, det1) RGX_WORD(r3.y, det1) RGX_WORD(r3.z, det1) RGX_WORD(r3.w, det1)
-      // look-ahead: K-1 more bytes, whole dwords (surplus detection bits are shifted out below)
-      const int tail = K - 1;
-      if (tail > 0) { RGX_WORD(n0.x, det2) } else { det2 <<= 4; }
-      if (tail > 4) { RGX_WORD(n0.y, det2) } else { det2 <<= 4; }
-      if (tail > 8) { RGX_WORD(n0.z, det2) } else { det2 <<= 4; }
-      if (tail > 12) { RGX_WORD(n0.w, det2) } else { det2 <<= 4; }
-      if (tail > 16) { RGX_WORD(n1.x, det2) } else { det2 <<= 4; }
-      if (tail > 20) { RGX_WORD(n1.y, det2) } else { det2 <<= 4; }
-      if (tail > 24) { RGX_WORD(n1.z, det2) } else { det2 <<= 4; }
-      if (tail > 28) { RGX_WORD(n1.w, det2) } else { det2 <<= 4; }
+#define RGX_HARVEST(DET, NBITS) DET = __builtin_amdgcn_alignbit(DET, E << (33 - K - (NBITS)), 32 - (NBITS));
+#define RGX_STEP(W, IDX, DET)                                                     \
+      RGX_WORD(W)                                                                 \
+      if (((IDX) + 1) % PER == 0) { DET = __builtin_amdgcn_alignbit(DET, E << hsh, 32 - 4 * PER); }
+      RGX_STEP(r0.x, 0, det0) RGX_STEP(r0.y, 1, det0) RGX_STEP(r0.z, 2, det0) RGX_STEP(r0.w, 3, det0)
+      RGX_STEP(r1.x, 4, det0) RGX_STEP(r1.y, 5, det0) RGX_STEP(r1.z, 6, det0) RGX_STEP(r1.w, 7, det0)
+      RGX_STEP(r2.x, 8, det1) RGX_STEP(r2.y, 9, det1) RGX_STEP(r2.z, 10, det1) RGX_STEP(r2.w, 11, det1)
+      RGX_STEP(r3.x, 12, det1) RGX_STEP(r3.y, 13, det1) RGX_STEP(r3.z, 14, det1) RGX_STEP(r3.w, 15, det1)
+      // look-ahead: nla whole dwords of the next slice; harvested every PER dwords and once more at the end
+#define RGX_LA(W, J)                                                              \
+      if (nla > (J)) {                                                            \
+        RGX_WORD(W)                                                               \
+        if (((J) + 1) % PER == 0) { det2 = __builtin_amdgcn_alignbit(det2, E << hsh, 32 - 4 * PER); } \
+        else if (nla == (J) + 1) { RGX_HARVEST(det2, 4 * (((J) % PER) + 1)) }    \
+      }
+      RGX_LA(n0.x, 0) RGX_LA(n0.y, 1) RGX_LA(n0.z, 2) RGX_LA(n0.w, 3)
+      RGX_LA(n1.x, 4) RGX_LA(n1.y, 5) RGX_LA(n1.z, 6)
+#undef RGX_LA
+#undef RGX_STEP
+#undef RGX_HARVEST
 #undef RGX_WORD
 #undef RGX_LU
-      // the funnel shift filled the masks MSB-first: reverse so that bit i = "accept bit up after byte i"
-      det0 = __builtin_bitreverse32(det0);
-      det1 = __builtin_bitreverse32(det1);
-      det2 = __builtin_bitreverse32(det2);
+      // det* hold inverted accept bits, first byte at the top.  Positive logic, bit i = "a match ends at byte i":
+      const unsigned p0 = __builtin_bitreverse32(~det0);
+      const unsigned p1 = __builtin_bitreverse32(~det1);
+      const unsigned p2 = nla ? __builtin_bitreverse32(~det2 << (32 - 4 * nla)) : 0u;
       // a match whose last byte is byte i starts at i-(K-1)
-      const unsigned lo = __builtin_amdgcn_alignbit(det1, det0, K - 1);
-      const unsigned hi = __builtin_amdgcn_alignbit(det2, det1, K - 1);
+      const unsigned lo = __builtin_amdgcn_alignbit(p1, p0, K - 1);
+      const unsigned hi = __builtin_amdgcn_alignbit(p2, p1, K - 1);
       cur = ((unsigned long long)hi << 32) | lo;
+    }
+    if (tb0 < 0 || tb0 + kWaveRows * kSliceBytes + 32 > len) {          // uniform: first tile, or a tile near the end
       const int nvalid = len - K - a + 1;   // starts too close to the end of the buffer cannot match
-      if (nvalid <= 0) cur = 0;
+      if (a < 0 || nvalid <= 0) cur = 0;
       else if (nvalid < 64) cur &= (1ull << nvalid) - 1ull;
     }
-    L.cur[tid] = cur;
-    __syncthreads();
 
-    // ---- phase 1b: resolve the FindAll chain on the masks (owned slices only: tid >= 1)
-    unsigned long long s_sel = 0;
-    if (tid >= 1 && a < len) {
+    // ---- resolve the FindAll chain (owned slices: lane >= 1)
+    const unsigned prev_lo = DppWaveShr1((unsigned)cur);
+    const unsigned prev_hi = DppWaveShr1((unsigned)(cur >> 32));
+    unsigned long long s_sel = lane ? cur : 0ull;
+    bool slow = P.carry_in != nullptr;
+    if (K > 1 && smin < K && !slow) {
+      // candidates of the previous slice within K-1 positions of a: bit u <-> position a-(K-1)+u
+      const unsigned pt = prev_hi >> (33 - K);
+      unsigned long long blocked = pt ? ((2ull << (31 - __builtin_clz(pt))) - 1ull) : 0ull;
+      unsigned long long B = cur << smin;            // positions covered by shifts smin..K-1 of the own candidates
+      int covered = 1;
+      const int w = K - smin;
+      while (covered * 2 <= w) { B |= B << covered; covered *= 2; }
+      if (w > covered) B |= B << (w - covered);
+      blocked |= B;
+      slow = __ballot(lane && (cur & blocked) != 0ull) != 0ull;
+    }
+    if (slow && lane && a < len) {
+      s_sel = 0;
+      const unsigned long long prev = ((unsigned long long)prev_hi << 32) | prev_lo;
       const int slice = a >> 6;
       const int carried = P.carry_in ? P.carry_in[slice] : -1;
       int pos = a;           // search position, absolute
@@ -177,7 +215,6 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
       if (carried >= 0) {
         pos = carried;
       } else if (a > 0 && K > 1) {
-        const unsigned long long prev = L.cur[tid - 1];
         // x = a is a sync point iff no candidate starts in [a-K+1, a)
         if (prev >> (65 - K)) {
           // blocked(j) = OR_{d=1..K-1} prev[j-d], j relative to a-64; take the highest free j in [K-1, 63]
@@ -216,104 +253,89 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
       }
     }
     sel[g] = s_sel;
-
-    // ---- phase 2: offsets inside the tile (wave scan + block scan), running sum across the group
-    const unsigned cnt = (unsigned)__popcll(s_sel);
-    const unsigned incl = WaveInclusiveScan(cnt, lane);
-    if (lane == 63) L.misc[1 + wave] = incl;
-    __syncthreads();
-    unsigned wave_off = 0, tile_total = 0;
-#pragma unroll
-    for (int w = 0; w < kBlockThreads / 64; ++w) {
-      const unsigned t = L.misc[1 + w];
-      if (w < wave) wave_off += t;
-      tile_total += t;
-    }
-    toff[g] = wave_off + (incl - cnt);
-    tbase[g] = group_run;
-    ttot[g] = tile_total;
-    group_run += tile_total;
+    lane_cnt += (unsigned)__popcll(s_sel);
   }
-
-#undef RGX_PUT
 #undef RGX_LOAD_TILE
-#undef RGX_LOAD
-#undef RGX_FULL
+#undef RGX_ADDR
 
-  if (P.count_only) {
-    if (tid == 0 && group_run) atomicAdd(P.total, (unsigned long long)group_run);
-    return;
-  }
+  // ---- one decoupled look-back per group
+  const unsigned group_total = __builtin_amdgcn_readlane((int)DppInclusiveScan(lane_cnt), 63);
+  unsigned long long base = LookBack(P.tile_desc, group, group_total, lane, &P.counters[3]);
+  if (group + 1 >= P.ntiles && lane == 0) *P.total = base + group_total;   // the last group knows the grand total
+  if (P.count_only) return;
 
-  // ---- one decoupled look-back per group, then the span records in match order
-  if (wave == 0) {
-    unsigned long long excl;
-    if (P.debug & 1) { unsigned long long t = 0; if (lane == 0) t = atomicAdd(P.total, (unsigned long long)group_run); excl = __shfl(t, 0, 64); }
-    else excl = LookBack(P.tile_desc, group, group_run, lane, &P.counters[3]);
-    if (lane == 0) {
-      L.misc[8] = (unsigned)excl;
-      L.misc[9] = (unsigned)(excl >> 32);
-      if (!(P.debug & 1) && first_tile + ntile_here >= P.ntiles) *P.total = excl + group_run;   // the last group knows the grand total
-    }
-  }
-  __syncthreads();
-  const unsigned long long base = ((unsigned long long)L.misc[9] << 32) | L.misc[8];
-  // Records are 4*ncap bytes; written lane-per-match they reach HBM as scattered 16-byte pieces (measured: 0.56 ms
-  // for 687 MB).  Instead the lanes drop their match STARTS, compacted in match order, into LDS (the tile buffer is
-  // free now) and the whole workgroup expands them into records with fully coalesced 16-byte stores: lane t writes
-  // chunk t, so every 128-byte line leaves in one instruction.
-  unsigned* st = reinterpret_cast<unsigned*>(L.tile);
-  constexpr unsigned kStartsCap = sizeof(L.tile) / 4;
+  // ---- span records in match order.  Lane-per-match stores reach HBM as scattered 16-byte pieces, so the lanes drop
+  // their match STARTS, compacted in match order, into the wave's LDS rows (free now) and the whole wave expands
+  // them into records: lane t writes 16-byte chunk t of the batch, so every wave-instruction stores 1 KiB contiguous.
+  unsigned* const st = reinterpret_cast<unsigned*>(wt);
   const int cpr = ncap >> 2;   // 16-byte chunks per record
-#pragma unroll
-  for (int g = 0; g < G; ++g) {
-    if (ttot[g] == 0) continue;                               // uniform
-    const int a = (first_tile + g) * kExactOwnedBytes - kSliceBytes + tid * kSliceBytes;
-    const unsigned long long rbase = base + tbase[g];
+  const bool staged_ok = P.starts_only || (ncap & 3) == 0;
+  unsigned fill = 0;           // starts staged and not yet flushed (uniform)
+  auto flush = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     if (P.starts_only) {
-      // compact result: the capture groups of a fixed template are start + constants, so only the start travels
-      unsigned long long m = sel[g];
-      unsigned long long idx = rbase + toff[g];
-      while (m) {
-        if (idx < (unsigned long long)P.cap_records) P.spans[idx] = a + __builtin_ctzll(m);
-        m &= m - 1;
-        ++idx;
+      for (unsigned j = lane; j < fill; j += 64) {
+        const unsigned long long idx = base + j;
+        if (idx < (unsigned long long)P.cap_records) P.spans[idx] = (int)st[j];
       }
-    } else if ((ncap & 3) == 0 && ttot[g] <= kStartsCap) {
-      unsigned long long m = sel[g];
-      unsigned k = toff[g];
-      while (m) {
-        st[k++] = (unsigned)(a + __builtin_ctzll(m));
-        m &= m - 1;
-      }
-      __syncthreads();
-      const unsigned nchunks = ttot[g] * (unsigned)cpr;
-      for (unsigned j = tid; j < nchunks; j += kBlockThreads) {
+    } else {
+      const unsigned nchunks = fill * (unsigned)cpr;
+      for (unsigned j = lane; j < nchunks; j += 64) {
         unsigned r, c;
         if (cpr == 2) { r = j >> 1; c = j & 1; }
         else if (cpr == 1) { r = j; c = 0; }
         else { r = j / (unsigned)cpr; c = j - r * (unsigned)cpr; }
         const int s = (int)st[r];
         const int4 o = *reinterpret_cast<const int4*>(&L.off[c << 2]);
-        const unsigned long long idx = rbase + r;
-        if (idx < (unsigned long long)P.cap_records && !(P.debug & 2))
-          *reinterpret_cast<int4*>(P.spans + idx * ncap + (c << 2)) = make_int4(s + o.x, s + o.y, s + o.z, s + o.w);
+        const unsigned long long idx = base + r;
+        if (idx < (unsigned long long)P.cap_records)
+          __builtin_nontemporal_store(v4i{s + o.x, s + o.y, s + o.z, s + o.w},
+                                      reinterpret_cast<v4i*>(P.spans + idx * ncap + (c << 2)));
       }
-      __syncthreads();   // st is reused by the next tile
-    } else {
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    base += fill;
+    fill = 0;
+  };
+#pragma unroll
+  for (int g = 0; g < kGroupTiles; ++g) {
+    const unsigned cnt = (unsigned)__popcll(sel[g]);
+    const unsigned incl = DppInclusiveScan(cnt);
+    const unsigned ttot = __builtin_amdgcn_readlane((int)incl, 63);
+    if (ttot == 0) continue;                                 // uniform
+    const int a = (first_tile + g) * kWaveTileBytes - kSliceBytes + lane * kSliceBytes;
+    if (staged_ok && ttot <= (unsigned)kStartsCap) {
+      if (fill + ttot > (unsigned)kStartsCap) flush();
       unsigned long long m = sel[g];
-      unsigned long long idx = rbase + toff[g];
+      unsigned k = fill + incl - cnt;
+      while (m) {
+        st[k++] = (unsigned)(a + __builtin_ctzll(m));
+        m &= m - 1;
+      }
+      fill += ttot;
+    } else {
+      // more matches than the staging rows hold (K < 4), or records that are not a multiple of 16 bytes
+      if (fill) flush();
+      unsigned long long m = sel[g];
+      unsigned long long idx = base + incl - cnt;
       while (m) {
         const int s = a + __builtin_ctzll(m);
         m &= m - 1;
         if (idx < (unsigned long long)P.cap_records) {
-          int32_t* rec = P.spans + idx * ncap;
-          for (int c = 0; c < ncap; ++c) rec[c] = s + L.off[c];
+          if (P.starts_only) P.spans[idx] = s;
+          else {
+            int32_t* rec = P.spans + idx * ncap;
+            for (int c = 0; c < ncap; ++c) rec[c] = s + L.off[c];
+          }
         }
         ++idx;
       }
+      base += ttot;
     }
   }
+  if (fill) flush();
 }
 
 }  // namespace
@@ -322,29 +344,16 @@ bool UseExactKernel(const DevTables& T, int32_t len) {
   return len >= 64 && T.sa_exact && T.sa_k >= 1 && T.sa_k <= 29 && T.fixed_captures && !T.anchored && T.ncap <= 32;
 }
 
-int ExactTileBytes() { return kExactOwnedBytes; }
+// bytes of input per look-back descriptor (ScanParams::ntiles counts descriptors = wave groups)
+int ExactTileBytes() { return kGroupTiles * kWaveTileBytes; }
 
 hipError_t LaunchScanExact(const DevTables& T, const ScanParams& P, hipStream_t stream) {
-  static int group = 0;
-  if (!group) {
-    const char* e = getenv("RGX_GROUP");
-    group = e ? atoi(e) : 4;
-  }
   dim3 block(kBlockThreads);
-  static int debug = -1;
-  if (debug < 0) { const char* e = getenv("RGX_DEBUG"); debug = e ? atoi(e) : 0; }
-  ScanParams Q = P;
-  Q.debug = debug;
-#define RGX_GO(G)                                                                                       \
-  do {                                                                                                  \
-    dim3 grid((P.ntiles + (G) - 1) / (G));                                                              \
-    hipLaunchKernelGGL((scan_exact_kernel<G>), grid, block, 0, stream, T, Q);                           \
-  } while (0)
-  if (group >= 8) RGX_GO(8);
-  else if (group >= 4) RGX_GO(4);
-  else if (group >= 2) RGX_GO(2);
-  else RGX_GO(1);
-#undef RGX_GO
+  dim3 grid((P.ntiles + (kBlockThreads / 64) - 1) / (kBlockThreads / 64));
+  const int K = T.sa_k;
+  if (K <= 17) hipLaunchKernelGGL((scan_exact_kernel<4>), grid, block, 0, stream, T, P);
+  else if (K <= 25) hipLaunchKernelGGL((scan_exact_kernel<2>), grid, block, 0, stream, T, P);
+  else hipLaunchKernelGGL((scan_exact_kernel<1>), grid, block, 0, stream, T, P);
   return hipGetLastError();
 }
 
