@@ -4,9 +4,9 @@
 // (internal/compiler/find.go:130-316 running instructions.go's byte tests) is exactly "bit K-1 of the Shift-Or
 // state is clear after byte s+K-1" -- no table walk, no branch per byte.  HBM-bound byte work: no MFMA.
 //
-// Work decomposition (everything is WAVE-autonomous: after the table is staged there is no workgroup barrier)
-//   group   -> one wavefront owns G consecutive wave-tiles and ONE look-back descriptor; group id =
-//              4*blockIdx.x + wave (or 4*ticket + wave in the fallback mode).
+// Work decomposition (the tile loop is WAVE-autonomous: no workgroup barrier between staging the table and the look-back)
+//   group   -> one wavefront owns G consecutive wave-tiles; group id = 4*blockIdx.x + wave (or 4*ticket + wave in
+//              the fallback mode).  The four waves of a workgroup meet once, after counting, for ONE look-back.
 //   tile    -> 64 slices of 64 bytes staged once from HBM into the wave's private LDS rows with four coalesced
 //              16-byte loads per lane (1 KiB per wave-instruction; the next tile's loads are in flight while this one
 //              is processed).  Slice 0 re-reads the last slice of the previous tile (1.6 % overlap, L2 hits) so every
@@ -48,9 +48,12 @@ typedef int v4i __attribute__((ext_vector_type(4)));
 
 struct ExactLds {
   unsigned sa[256];          // Shift-Or words: bit j set = byte cannot be the (j+1)-th byte of a match; bits >= K clear
+                             // (W16: 256 uint16 entries instead -- 4 byte values per LDS bank instead of 8)
   int off[32];               // capture template: slot c = match start + off[c]
   unsigned ticket;
-  unsigned pad[3];
+  unsigned wtot[kBlockThreads / 64];   // matches per wave of this workgroup
+  unsigned base_lo, base_hi;           // exclusive prefix of the workgroup (from the look-back)
+  unsigned pad[1];
   __attribute__((aligned(16))) unsigned char tile[kBlockThreads / 64][kWaveLds];
 };
 
@@ -69,8 +72,9 @@ __device__ __forceinline__ unsigned DppInclusiveScan(unsigned x) {
   return x;
 }
 
-// PER = dwords between two harvests of the accept history: 4*PER <= 33-K.
-template <int PER>
+// PER = dwords between two harvests of the accept history: 4*PER <= 33-K.  W16 (K <= 16): 16-bit table entries, which
+// halves the number of distinct byte values sharing an LDS bank (on ASCII text: far fewer bank conflicts).
+template <int PER, bool W16>
 __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, ScanParams P) {
   __shared__ ExactLds L;
   const int tid = threadIdx.x;
@@ -89,29 +93,39 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
     __syncthreads();
     blk = (int)L.ticket;
   }
-  L.sa[tid] = ~T.sa_mask[tid] & ((K >= 32) ? ~0u : ((1u << K) - 1u));
+  {
+    const unsigned f = ~T.sa_mask[tid] & ((K >= 32) ? ~0u : ((1u << K) - 1u));
+    if (W16) reinterpret_cast<unsigned short*>(L.sa)[tid] = (unsigned short)f;
+    else L.sa[tid] = f;
+  }
   if (tid < ncap) L.off[tid] = T.cap_kind[tid] == kCapFromStart ? T.cap_delta[tid] : K - T.cap_delta[tid];
   __syncthreads();   // the only barrier: from here on every wave runs on its own
 
-  const int group = blk * (kBlockThreads / 64) + wave;
-  if (group >= P.ntiles) return;
+  const int group = blk * (kBlockThreads / 64) + wave;   // this wave's range of tiles; one look-back descriptor per BLOCK
   unsigned char* const wt = L.tile[wave];
   const int last16 = (len - 1) & ~15;     // the aligned 16-byte chunk holding the last byte never crosses a page
   const int first_tile = group * kGroupTiles;
 
-  v4u v0, v1, v2, v3, v4 = {0u, 0u, 0u, 0u};
+  // Prefetch depth 2: the 4 KiB of tiles g+1 and g+2 are in flight (in VGPRs) while tile g is processed -- one tile
+  // ahead leaves only ~96 KiB per CU in flight, which measured 4.6 TB/s; HBM wants more.
+  v4u pv[2][5];
+  pv[0][4] = v4u{0u, 0u, 0u, 0u};
+  pv[1][4] = v4u{0u, 0u, 0u, 0u};
   // chunk c of a tile = bytes [tb + 16c, tb + 16c + 16); lane l loads chunks l, l+64, l+128, l+192 and (l < 2) 256+l.
   // Addresses are clamped into the buffer: what a clamped chunk holds is never used (validity mask below).
 #define RGX_ADDR(tb, c) (P.buf + min(max((tb) + ((c) << 4), 0), last16))
-#define RGX_LOAD_TILE(tb)                                                                        \
-  {                                                                                              \
-    v0 = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(RGX_ADDR(tb, lane)));         \
-    v1 = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(RGX_ADDR(tb, lane + 64)));    \
-    v2 = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(RGX_ADDR(tb, lane + 128)));   \
-    v3 = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(RGX_ADDR(tb, lane + 192)));   \
-    if (lane < 2) v4 = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(RGX_ADDR(tb, lane + 256))); \
+#define RGX_LOAD_TILE(S, tb)                                                                          \
+  {                                                                                                   \
+    pv[S][0] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(RGX_ADDR(tb, lane)));          \
+    pv[S][1] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(RGX_ADDR(tb, lane + 64)));     \
+    pv[S][2] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(RGX_ADDR(tb, lane + 128)));    \
+    pv[S][3] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(RGX_ADDR(tb, lane + 192)));    \
+    if (lane < 2) pv[S][4] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(RGX_ADDR(tb, lane + 256))); \
   }
-  RGX_LOAD_TILE(first_tile * kWaveTileBytes - kSliceBytes)
+  if (!(P.debug & 16)) {
+    RGX_LOAD_TILE(0, first_tile * kWaveTileBytes - kSliceBytes)
+    RGX_LOAD_TILE(1, (first_tile + 1) * kWaveTileBytes - kSliceBytes)
+  }
 
   unsigned long long sel[kGroupTiles];
   unsigned lane_cnt = 0;      // this lane's matches over the group's tiles
@@ -125,25 +139,27 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
     if (tb0 + kSliceBytes >= len) continue;                            // uniform: nothing owned by this tile
 
     // ---- stage this tile from the prefetched registers, then prefetch the next one
-    *reinterpret_cast<v4u*>(wt + put) = v0;
-    *reinterpret_cast<v4u*>(wt + put + 16 * kRowBytes) = v1;
-    *reinterpret_cast<v4u*>(wt + put + 32 * kRowBytes) = v2;
-    *reinterpret_cast<v4u*>(wt + put + 48 * kRowBytes) = v3;
-    if (lane < 2) *reinterpret_cast<v4u*>(wt + 64 * kRowBytes + (lane << 4)) = v4;
+    *reinterpret_cast<v4u*>(wt + put) = pv[g & 1][0];
+    *reinterpret_cast<v4u*>(wt + put + 16 * kRowBytes) = pv[g & 1][1];
+    *reinterpret_cast<v4u*>(wt + put + 32 * kRowBytes) = pv[g & 1][2];
+    *reinterpret_cast<v4u*>(wt + put + 48 * kRowBytes) = pv[g & 1][3];
+    if (lane < 2) *reinterpret_cast<v4u*>(wt + 64 * kRowBytes + (lane << 4)) = pv[g & 1][4];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (g + 1 < kGroupTiles && tb0 + kWaveTileBytes + kSliceBytes < len) RGX_LOAD_TILE(tb0 + kWaveTileBytes)
+    if (g + 2 < kGroupTiles && tb0 + 2 * kWaveTileBytes + kSliceBytes < len && !(P.debug & 16)) RGX_LOAD_TILE(g & 1, tb0 + 2 * kWaveTileBytes)
 
     // ---- candidate mask of this lane's slice (match starts in [a, a+64))
     const int a = tb0 + lane * kSliceBytes;
-    unsigned long long cur;
-    {
+    unsigned long long cur = 0;
+    if (!(P.debug & 8)) {
       const uint4* row = reinterpret_cast<const uint4*>(wt + lane * kRowBytes);
       const uint4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
       const uint4 n0 = row[5], n1 = row[6];   // next row: 80-byte stride = 5 uint4
       unsigned E = ~0u, det0 = 0, det1 = 0, det2 = ~0u;
       const int hsh = 33 - K - 4 * PER;      // left shift that puts the 4*PER freshest accept bits at the top
-#define RGX_LU(W, B) (*reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(L.sa) + ((((W) >> (8 * (B))) & 0xFFu) << 2)))
+#define RGX_LU(W, B)                                                                                                              \
+  (W16 ? (unsigned)*reinterpret_cast<const unsigned short*>(reinterpret_cast<const unsigned char*>(L.sa) + ((((W) >> (8 * (B))) & 0xFFu) << 1)) \
+       : *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(L.sa) + ((((W) >> (8 * (B))) & 0xFFu) << 2)))
 #define RGX_WORD(W)                                         \
       {                                                     \
         E = (E << 1) | RGX_LU(W, 0);                        \
@@ -260,8 +276,26 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
 
   // ---- one decoupled look-back per group
   const unsigned group_total = __builtin_amdgcn_readlane((int)DppInclusiveScan(lane_cnt), 63);
-  unsigned long long base = LookBack(P.tile_desc, group, group_total, lane, &P.counters[3]);
-  if (group + 1 >= P.ntiles && lane == 0) *P.total = base + group_total;   // the last group knows the grand total
+  // The workgroup, not the wave, takes part in the look-back: its throughput is ~64 descriptors per L2 round trip, and
+  // one descriptor per wave (33k for 1 GiB) measured slower than one per workgroup.
+  if (lane == 0) L.wtot[wave] = group_total;
+  __syncthreads();
+  if (wave == 0) {
+    unsigned long long block_total = 0;
+#pragma unroll
+    for (int w = 0; w < kBlockThreads / 64; ++w) block_total += L.wtot[w];
+    unsigned long long excl = 0;
+    if (!(P.debug & 1)) excl = LookBack(P.tile_desc, blk, block_total, lane, &P.counters[3]);
+    if (lane == 0) {
+      L.base_lo = (unsigned)excl;
+      L.base_hi = (unsigned)(excl >> 32);
+      if (blk + 1 >= P.ntiles) *P.total = excl + block_total;   // the last workgroup knows the grand total
+    }
+  }
+  __syncthreads();
+  unsigned long long base = ((unsigned long long)L.base_hi << 32) | L.base_lo;
+#pragma unroll
+  for (int w = 0; w < kBlockThreads / 64; ++w) if (w < wave) base += L.wtot[w];
   if (P.count_only) return;
 
   // ---- span records in match order.  Lane-per-match stores reach HBM as scattered 16-byte pieces, so the lanes drop
@@ -345,15 +379,21 @@ bool UseExactKernel(const DevTables& T, int32_t len) {
 }
 
 // bytes of input per look-back descriptor (ScanParams::ntiles counts descriptors = wave groups)
-int ExactTileBytes() { return kGroupTiles * kWaveTileBytes; }
+int ExactTileBytes() { return (kBlockThreads / 64) * kGroupTiles * kWaveTileBytes; }
 
 hipError_t LaunchScanExact(const DevTables& T, const ScanParams& P, hipStream_t stream) {
   dim3 block(kBlockThreads);
-  dim3 grid((P.ntiles + (kBlockThreads / 64) - 1) / (kBlockThreads / 64));
+  dim3 grid(P.ntiles);
   const int K = T.sa_k;
-  if (K <= 17) hipLaunchKernelGGL((scan_exact_kernel<4>), grid, block, 0, stream, T, P);
-  else if (K <= 25) hipLaunchKernelGGL((scan_exact_kernel<2>), grid, block, 0, stream, T, P);
-  else hipLaunchKernelGGL((scan_exact_kernel<1>), grid, block, 0, stream, T, P);
+  static int debug = -1;   // experiment switches (RGX_DEBUG): 8 = skip the byte loop, 16 = skip the global loads
+  if (debug < 0) { const char* e = getenv("RGX_DEBUG"); debug = e ? atoi(e) : 0; }
+  ScanParams Q = P;
+  Q.debug = debug;
+  static const bool no16 = getenv("RGX_NO_W16") != nullptr;
+  if (K <= 16 && !no16) hipLaunchKernelGGL((scan_exact_kernel<4, true>), grid, block, 0, stream, T, Q);
+  else if (K <= 17) hipLaunchKernelGGL((scan_exact_kernel<4, false>), grid, block, 0, stream, T, Q);
+  else if (K <= 25) hipLaunchKernelGGL((scan_exact_kernel<2, false>), grid, block, 0, stream, T, Q);
+  else hipLaunchKernelGGL((scan_exact_kernel<1, false>), grid, block, 0, stream, T, Q);
   return hipGetLastError();
 }
 
