@@ -81,15 +81,14 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   const int32_t nslices = (ilen + kSliceBytes - 1) / kSliceBytes;
   int rc;
   // one device buffer: [total u64][trace cursor u64][counters 4 x u32][look-back descriptors ...] -> one memset, one readback
-  const int64_t nsup = ((int64_t)ntiles + 63) / 64;
-  const size_t desc_words = (size_t)ntiles + 4 + 2 * (size_t)nsup;
+  const size_t desc_words = (size_t)ntiles + 4;
   if ((rc = Ensure(&c->d_desc, &c->desc_cap, (int64_t)desc_words)) != RGX_OK) return rc;
   c->d_total = c->d_desc;
   c->d_counters = (uint32_t*)(c->d_desc + 2);
 
   ScanParams P{};
   P.buf = d_buf; P.len = ilen; P.ntiles = ntiles; P.spans = d_spans; P.cap_records = (int64_t)cap_records;
-  P.tile_desc = c->d_desc + 4; P.sup_desc = c->d_desc + 4 + ntiles; P.counters = c->d_counters; P.total = c->d_total; P.carry_in = nullptr; P.slice_unsynced = nullptr;
+  P.tile_desc = c->d_desc + 4; P.counters = c->d_counters; P.total = c->d_total; P.carry_in = nullptr; P.slice_unsynced = nullptr;
   P.count_only = count_only ? 1 : 0;
   P.starts_only = starts_only ? 1 : 0;
 

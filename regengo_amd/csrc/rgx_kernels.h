@@ -15,7 +15,6 @@ struct ScanParams {
   int32_t* spans;                // device, [cap_records][ncap]
   int64_t cap_records;
   unsigned long long* tile_desc; // [ntiles] look-back descriptors, zeroed before launch
-  unsigned long long* sup_desc;  // [2 * nsup] two-level look-back (exact kernel): arrival words, then prefixes; nsup = ceil(ntiles/64); zeroed
   uint32_t* counters;            // [0] tile ticket, [1] unsynced slices, [2] stats, [3] look-back timeout; zeroed before launch
   unsigned long long* total;     // total matches; zeroed before launch
   const int32_t* carry_in;       // nullable; per slice: -1 = find a sync point locally, else search position

@@ -85,6 +85,11 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
   const int len = P.len;
   const int ncap = T.ncap;
 
+  // table words first (oldest loads), tile prefetch next, LDS staging of the table last: the first tiles are in
+  // flight while the workgroup sets up
+  const unsigned f_raw = T.sa_mask[tid];
+  int off_raw = 0;
+  if (tid < ncap) off_raw = T.cap_kind[tid] == kCapFromStart ? T.cap_delta[tid] : K - T.cap_delta[tid];
   int blk = (int)blockIdx.x;
   if (P.use_tickets) {
     // One device-scope counter hands out only ~88 tickets/us (MI355X_MICROARCH.md, "dequeue"), so ids default to
@@ -93,14 +98,6 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
     __syncthreads();
     blk = (int)L.ticket;
   }
-  {
-    const unsigned f = ~T.sa_mask[tid] & ((K >= 32) ? ~0u : ((1u << K) - 1u));
-    if (W16) reinterpret_cast<unsigned short*>(L.sa)[tid] = (unsigned short)f;
-    else L.sa[tid] = f;
-  }
-  if (tid < ncap) L.off[tid] = T.cap_kind[tid] == kCapFromStart ? T.cap_delta[tid] : K - T.cap_delta[tid];
-  __syncthreads();   // the only barrier: from here on every wave runs on its own
-
   const int group = blk * (kBlockThreads / 64) + wave;   // this wave's range of tiles; one look-back descriptor per BLOCK
   unsigned char* const wt = L.tile[wave];
   const int last16 = (len - 1) & ~15;     // the aligned 16-byte chunk holding the last byte never crosses a page
@@ -126,6 +123,14 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
     RGX_LOAD_TILE(0, first_tile * kWaveTileBytes - kSliceBytes)
     RGX_LOAD_TILE(1, (first_tile + 1) * kWaveTileBytes - kSliceBytes)
   }
+
+  {
+    const unsigned f = ~f_raw & ((K >= 32) ? ~0u : ((1u << K) - 1u));
+    if (W16) reinterpret_cast<unsigned short*>(L.sa)[tid] = (unsigned short)f;
+    else L.sa[tid] = f;
+  }
+  if (tid < ncap) L.off[tid] = off_raw;
+  __syncthreads();   // from here to the look-back every wave runs on its own
 
   unsigned long long sel[kGroupTiles];
   unsigned lane_cnt = 0;      // this lane's matches over the group's tiles
@@ -285,7 +290,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
 #pragma unroll
     for (int w = 0; w < kBlockThreads / 64; ++w) block_total += L.wtot[w];
     unsigned long long excl = 0;
-    if (!(P.debug & 1)) excl = LookBack(P.tile_desc, blk, block_total, lane, &P.counters[3]);
+    if (!(P.debug & 1)) excl = LookBack(P.tile_desc, blk, block_total, lane, &P.counters[3], 4);
     if (lane == 0) {
       L.base_lo = (unsigned)excl;
       L.base_hi = (unsigned)(excl >> 32);
