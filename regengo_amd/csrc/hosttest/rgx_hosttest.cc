@@ -107,6 +107,77 @@ void* rgxt_compile(const char* pattern, uint32_t flags) {
 }
 void rgxt_free(void* h) { delete (Handle*)h; }
 
+// The search automaton (BuildOptions::unanchored_search) the per-string kernels walk.
+void* rgxt_compile_search(const char* pattern, uint32_t flags) {
+  try {
+    auto* h = new Handle();
+    BuildOptions opt;
+    opt.unanchored_search = true;
+    opt.max_states = 4000;
+    h->t = BuildTables(pattern, flags, opt);
+    return h;
+  } catch (const SyntaxError& e) { g_err = "syntax: " + e.msg; }
+  catch (const Unsupported& e) { g_err = "unsupported: " + e.msg; }
+  catch (const TooLarge& e) { g_err = "too large: " + e.msg; }
+  return nullptr;
+}
+
+// FindBytes by ONE forward walk of the search automaton + thread-parent back-trace (what batch_search_kernel does).
+// hm = the pattern's ordinary tables (capture template, flags).  Returns 1 and fills out[ncap], or 0.
+int rgxt_search_first(void* hs, void* hm, const uint8_t* buf, int64_t len, int32_t* out) {
+  const Tables& t = ((Handle*)hs)->t;
+  const Tables& m = ((Handle*)hm)->t;
+  const int stride = t.ncls + 1;
+  const int ctx = kCtxBOT;
+  uint16_t q = t.start[ctx];
+  int64_t end = (!t.lookahead_mode && t.start_accept[ctx]) ? 0 : -1;
+  std::vector<uint16_t> trace;
+  trace.push_back(q);
+  for (int64_t i = 0;; i++) {
+    const int k = i < len ? t.cls[buf[i]] : t.ncls;
+    const uint16_t e = t.trans[(size_t)q * stride + k];
+    if (e & kMatchBefore) end = i;
+    if (e & kMatchAfter) end = i + 1;
+    q = e & kStateMask;
+    trace.push_back(q);
+    if (q == kDead || k == t.ncls) break;
+  }
+  if (end < 0) return 0;
+  const bool minus1 = m.flags & 1u;
+  for (int c = 0; c < m.ncap; c++) out[c] = minus1 ? -1 : 0;
+  out[1] = (int32_t)end;
+  std::vector<char> set(m.ncap, 0);
+  set[1] = 1;
+  auto apply = [&](uint32_t ops, int64_t pos) {
+    for (int c = 0; c < m.ncap; c++) if ((ops >> c) & 1u) if (!set[c]) { set[c] = 1; out[c] = (int32_t)pos; }
+  };
+  int j;
+  if (t.lookahead_mode) {
+    const uint16_t qe = trace[end];
+    const int k = end < len ? t.cls[buf[end]] : t.ncls;
+    const uint32_t mm = t.bt_match[(size_t)qe * stride + k];
+    j = (int)(mm >> 24);
+    apply(mm & 0xFFFFFF, end);
+    for (int64_t i = end - 1; i >= 0 && !set[0]; i--) {
+      const uint32_t base = t.bt_base[(size_t)trace[i] * stride + t.cls[buf[i]]];
+      apply(t.bt_ops[base + j], i);
+      j = t.bt_parent[base + j];
+    }
+  } else {
+    j = (int)t.st_nthreads[trace[end]] - 1;
+    for (int64_t i = end - 1; i >= 0 && !set[0]; i--) {
+      const uint32_t base = t.bt_base[(size_t)trace[i] * stride + t.cls[buf[i]]];
+      apply(t.bt_ops[base + j], i + 1);
+      j = t.bt_parent[base + j];
+    }
+    if (!set[0]) apply(t.start_ops_pool[t.start_ops[ctx] + j], 0);
+  }
+  if (!set[0]) return -1;   // cannot happen: every winning thread passed Capture 0
+  if (m.fixed_captures)
+    for (int c = 2; c < m.ncap; c++) out[c] = (int32_t)(m.cap_kind[c] == kCapFromStart ? out[0] + m.cap_delta[c] : end - m.cap_delta[c]);
+  return 1;
+}
+
 // Round-trip through the blob (exercises Serialize/Deserialize).
 void* rgxt_roundtrip(void* h) {
   auto blob = SerializeTables(((Handle*)h)->t);

@@ -360,6 +360,19 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
   if (nstr == 0) return 0;
   if (!d_concat || !d_offsets || !d_found || !d_spans) return RGX_E_INVALID;
   const DevTables& T = p->p.dev;
+  static const bool no_search = getenv("RGX_NO_SEARCH_DFA") != nullptr;
+  const DevTables* U = no_search ? nullptr : SearchTables(const_cast<Program*>(&p->p));
+  if (U && BatchSearchFits(*U, T, true, d_concat)) {
+    // scratch for strings longer than the LDS trace: (bytes + 2 per string) entries
+    uint64_t h_last = 0;
+    HIP_TRY(hipMemcpyAsync(&h_last, d_offsets + nstr, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    const int64_t need = ((int64_t)h_last + 2 * (int64_t)nstr + 64 + 1) / 2 * (U->nstates <= 256 ? 1 : 2);   // in uint16 units
+    if ((rc = Ensure(&c->d_trace, &c->trace_cap, need)) != RGX_OK) return rc;
+    HIP_TRY(LaunchBatchSearch(*U, T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, c->d_trace, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return (int64_t)nstr;
+  }
   uint16_t* trace = nullptr;
   int64_t stride = 0;
   if (!T.fixed_captures) {
@@ -385,6 +398,15 @@ RGX_API int64_t rgx_match_batch_device(const rgx_program* p, rgx_stream_ctx* c, 
   if (rc != RGX_OK) return rc;
   if (nstr == 0) return 0;
   if (!d_concat || !d_offsets || !d_matched) return RGX_E_INVALID;
+  {
+    static const bool no_search = getenv("RGX_NO_SEARCH_DFA") != nullptr;
+    const DevTables* U = no_search ? nullptr : SearchTables(const_cast<Program*>(&p->p));
+    if (U && BatchSearchFits(*U, p->p.dev, false, d_concat)) {
+      HIP_TRY(LaunchBatchSearch(*U, p->p.dev, d_concat, d_offsets, (int64_t)nstr, d_matched, nullptr, nullptr, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      return (int64_t)nstr;
+    }
+  }
   HIP_TRY(LaunchBatch(p->p.dev, d_concat, d_offsets, (int64_t)nstr, d_matched, nullptr, nullptr, 0, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return (int64_t)nstr;

@@ -245,6 +245,15 @@ Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOption
     t.ref_find_engine = prog.numcap <= 2 ? -1 : (cat ? 1 : 0);
   }
 
+  if (opt.unanchored_search) {
+    const uint32_t L = (uint32_t)prog.inst.size(), C0 = L + 1, A = L + 2;
+    Inst alt; alt.op = InstAlt; alt.out = C0; alt.arg = A;
+    Inst cap; cap.op = InstCapture; cap.arg = 0; cap.out = (uint32_t)prog.start;
+    Inst any; any.op = InstRuneAny; any.out = L;
+    prog.inst.push_back(alt); prog.inst.push_back(cap); prog.inst.push_back(any);
+    prog.start = (int)L;
+  }
+
   Builder b(prog);
   t.lookahead_mode = b.lookahead;
   t.ncls = b.ncls;

@@ -80,6 +80,12 @@ struct Tables {
 
 struct BuildOptions {
   int max_states = 12000;
+  // Search automaton: the program is prefixed with a lowest-priority skip loop  L: Alt(Capture0 -> start, AnyByte -> L),
+  // so ONE forward walk from offset 0 finds what the reference's restart loop finds (find.go:545-569: the first start
+  // position with a match, leftmost-first) -- earlier starts sit higher in the ordered thread list, the list is cut
+  // below the first Match, the walk keeps the last match seen.  The match START is capture slot 0, recovered like any
+  // other group by the thread-parent back-trace.
+  bool unanchored_search = false;
 };
 
 // Throws SyntaxError / Unsupported / TooLarge.

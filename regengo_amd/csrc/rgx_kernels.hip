@@ -465,6 +465,456 @@ __global__ __launch_bounds__(64) void batch_kernel(DevTables T, const uint8_t* c
   ResolveCaptures(T, buf, len, s, e, tr, rec);
 }
 
+
+// ---- batch, staged (BASELINE config C3) -------------------------------------------------------------------
+// The per-lane kernel above reads everything -- tables, input bytes, back-trace pools -- through L1/L2 with one
+// dependent global load per DFA step (27 GB/s on 10 M short strings).  Here a persistent workgroup stages the
+// transition table, the class map and (when they fit) the capture back-trace pools into LDS once, then takes groups of
+// 256 consecutive strings: their bytes are one contiguous range of `concat`, staged with coalesced 16-byte loads, every
+// lane runs the reference's FindBytes loop (find.go:545-569: first start position with a match) on LDS bytes and LDS
+// tables, and the span records leave through LDS as contiguous 16-byte stores.
+constexpr int kBatchWindow = 16384;      // input bytes staged per group of 256 strings (longer groups read the rest from L2)
+constexpr int kBatchTrace = 64;          // uint16 state-trace entries per lane kept in LDS (matches up to 63 bytes)
+
+struct BtTabs {
+  const uint32_t* st_nthreads;
+  const uint32_t* bt_base;
+  const uint8_t* bt_parent;
+  const uint32_t* bt_ops;
+  const uint32_t* bt_match;
+  const uint32_t* start_ops;
+  const uint32_t* start_ops_pool;
+};
+
+struct BatchInput {
+  const uint8_t* g;       // global: first byte of this lane's string
+  const uint8_t* lds;     // LDS window
+  int rel0;               // offset of the string's first byte inside the window (may exceed wvalid)
+  int wvalid;
+  int len;
+  __device__ __forceinline__ int At(int i) const {
+    const unsigned r = (unsigned)(rel0 + i);
+    if (r < (unsigned)wvalid) return lds[r];
+    return g[i];
+  }
+};
+
+template <int MODE>
+__device__ __forceinline__ int WalkBatch(const Tab<MODE>& tab, const BatchInput& in, const DevTables& T, const uint8_t* ctx_of_byte,
+                                         int pos) {
+  int ctx = kCtxOther;
+  if (pos == 0) ctx = kCtxBOT;
+  else if (T.ctx_sensitive) ctx = ctx_of_byte[in.At(pos - 1)];
+  unsigned q = T.start[ctx];
+  int end = (T.start_accept[ctx]) ? pos : -1;
+  int i = pos;
+  while (true) {
+    unsigned e;
+    const bool eot = i >= in.len;
+    if (eot) e = tab.StepEot(q);
+    else e = tab.Step(q, in.At(i));
+    if (e & kMatchBefore) end = i;
+    if (e & kMatchAfter) end = i + 1;
+    q = e & kStateMask;
+    if (q == kDead || eot) break;
+    ++i;
+  }
+  return end;
+}
+
+// ResolveCaptures over LDS-resident tables; rec points into LDS.
+template <int MODE>
+__device__ __forceinline__ void ResolveCapturesBatch(const Tab<MODE>& tab, const BtTabs& B, const DevTables& T, const uint8_t* cls,
+                                                     const uint8_t* ctx_of_byte, const BatchInput& in, int s, int e, uint16_t* trace,
+                                                     int32_t* rec) {
+  const int ncap = T.ncap;
+  const int unset = T.unmatched_minus1 ? -1 : 0;
+  const int len = in.len;
+  const int ctx = s == 0 ? kCtxBOT : ctx_of_byte[in.At(s - 1)];
+  unsigned q = T.start[ctx];
+  const int n = e - s;
+  for (int i = 0; i <= n; ++i) {
+    trace[i] = (uint16_t)q;
+    if (i == n) break;
+    q = tab.Step(q, in.At(s + i)) & kStateMask;
+  }
+  unsigned setmask = 3u;
+  for (int c = 2; c < ncap; ++c) rec[c] = unset;
+  rec[0] = s; rec[1] = e;
+  const int stride = T.stride;
+  int j;
+  if (T.lookahead) {
+    const unsigned qe = trace[n];
+    const int k = e < len ? cls[in.At(e)] : T.ncls;
+    const unsigned m = B.bt_match[qe * stride + k];
+    j = (int)(m >> 24);
+    unsigned ops = (m & 0xFFFFFFu) & ~setmask;
+    while (ops) { const int c = __builtin_ctz(ops); ops &= ops - 1; rec[c] = e; setmask |= 1u << c; }
+    for (int i = n - 1; i >= 0; --i) {
+      const unsigned base = B.bt_base[(unsigned)trace[i] * stride + cls[in.At(s + i)]];
+      unsigned o = B.bt_ops[base + j] & ~setmask;
+      while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = s + i; setmask |= 1u << c; }
+      j = B.bt_parent[base + j];
+    }
+  } else {
+    j = (int)B.st_nthreads[trace[n]] - 1;
+    for (int i = n - 1; i >= 0; --i) {
+      const unsigned base = B.bt_base[(unsigned)trace[i] * stride + cls[in.At(s + i)]];
+      unsigned o = B.bt_ops[base + j] & ~setmask;
+      while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = s + i + 1; setmask |= 1u << c; }
+      j = B.bt_parent[base + j];
+    }
+    unsigned o = B.start_ops_pool[B.start_ops[ctx] + j] & ~setmask;
+    while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = s; setmask |= 1u << c; }
+  }
+}
+
+struct BatchLayout {     // byte offsets into dynamic LDS (host and device compute it the same way)
+  int trans, cls, ctx, bt_nth, bt_base, bt_parent, bt_ops, bt_match, st_ops, st_pool, window, trace, recs, total;
+  int bt_in_lds;
+};
+
+__host__ __device__ inline BatchLayout BatchLdsLayout(const DevTables& T, bool want_spans) {
+  BatchLayout L{};
+  int o = 0;
+  auto take = [&](int bytes) { const int at = o; o += (bytes + 15) & ~15; return at; };
+  L.trans = take(T.table_bytes);
+  L.cls = take(256);
+  L.ctx = take(256);
+  const bool dyn = want_spans && !T.fixed_captures;
+  const int cells = T.nstates * T.stride;
+  const int bt_bytes = T.nstates * 4 + cells * 8 + T.bt_pool_n * 5 + 16 + T.start_pool_n * 4 + 64;
+  L.bt_in_lds = dyn && bt_bytes <= 48 * 1024;
+  if (L.bt_in_lds) {
+    L.bt_nth = take(T.nstates * 4);
+    L.bt_base = take(cells * 4);
+    L.bt_match = take(cells * 4);
+    L.bt_ops = take(T.bt_pool_n * 4);
+    L.bt_parent = take(T.bt_pool_n);
+    L.st_ops = take(16);
+    L.st_pool = take(T.start_pool_n * 4);
+  }
+  L.window = take(kBatchWindow + 16);
+  if (dyn) L.trace = take(kBlockThreads * kBatchTrace * 2);
+  if (want_spans) L.recs = take(kBlockThreads * T.ncap * 4);
+  L.total = o;
+  return L;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(kBlockThreads) void batch_lds_kernel(DevTables T, const uint8_t* concat, const uint64_t* offsets,
+                                                                   int64_t nstr, uint8_t* found, int32_t* spans, uint16_t* gtrace,
+                                                                   int64_t trace_stride, int debug) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const bool want_spans = spans != nullptr;
+  const BatchLayout Y = BatchLdsLayout(T, want_spans);
+  const int ncap = T.ncap;
+  // ---- stage the tables once per workgroup
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(T.trans);
+    uint4* dst = reinterpret_cast<uint4*>(smem + Y.trans);
+    const int n16 = (T.table_bytes + 15) >> 4;          // the arena pads every table to 256 bytes
+    for (int i = tid; i < n16; i += kBlockThreads) dst[i] = src[i];
+    smem[Y.cls + tid] = T.cls[tid];
+    smem[Y.ctx + tid] = T.ctx_of_byte[tid];
+    if (Y.bt_in_lds) {
+      const int cells = T.nstates * T.stride;
+      uint32_t* d;
+      d = reinterpret_cast<uint32_t*>(smem + Y.bt_nth);   for (int i = tid; i < T.nstates; i += kBlockThreads) d[i] = T.st_nthreads[i];
+      d = reinterpret_cast<uint32_t*>(smem + Y.bt_base);  for (int i = tid; i < cells; i += kBlockThreads) d[i] = T.bt_base[i];
+      d = reinterpret_cast<uint32_t*>(smem + Y.bt_match); for (int i = tid; i < cells; i += kBlockThreads) d[i] = T.bt_match[i];
+      d = reinterpret_cast<uint32_t*>(smem + Y.bt_ops);   for (int i = tid; i < T.bt_pool_n; i += kBlockThreads) d[i] = T.bt_ops[i];
+      for (int i = tid; i < T.bt_pool_n; i += kBlockThreads) smem[Y.bt_parent + i] = T.bt_parent[i];
+      d = reinterpret_cast<uint32_t*>(smem + Y.st_ops);   if (tid < 4) d[tid] = T.start_ops[tid];
+      d = reinterpret_cast<uint32_t*>(smem + Y.st_pool);  for (int i = tid; i < T.start_pool_n; i += kBlockThreads) d[i] = T.start_ops_pool[i];
+    }
+  }
+  Tab<MODE> tab;
+  tab.t = reinterpret_cast<const uint16_t*>(smem + Y.trans);
+  tab.cls = smem + Y.cls;
+  tab.stride = T.stride;
+  tab.nstates = T.nstates;
+  const uint8_t* ctx_of_byte = smem + Y.ctx;
+  BtTabs B;
+  if (Y.bt_in_lds) {
+    B.st_nthreads = reinterpret_cast<const uint32_t*>(smem + Y.bt_nth);
+    B.bt_base = reinterpret_cast<const uint32_t*>(smem + Y.bt_base);
+    B.bt_match = reinterpret_cast<const uint32_t*>(smem + Y.bt_match);
+    B.bt_ops = reinterpret_cast<const uint32_t*>(smem + Y.bt_ops);
+    B.bt_parent = smem + Y.bt_parent;
+    B.start_ops = reinterpret_cast<const uint32_t*>(smem + Y.st_ops);
+    B.start_ops_pool = reinterpret_cast<const uint32_t*>(smem + Y.st_pool);
+  } else {
+    B.st_nthreads = T.st_nthreads; B.bt_base = T.bt_base; B.bt_match = T.bt_match; B.bt_ops = T.bt_ops;
+    B.bt_parent = T.bt_parent; B.start_ops = T.start_ops; B.start_ops_pool = T.start_ops_pool;
+  }
+  unsigned char* const win = smem + Y.window;
+  int32_t* const recs = reinterpret_cast<int32_t*>(smem + Y.recs);
+  const bool dyn = want_spans && !T.fixed_captures;
+  const int64_t ngroups = (nstr + kBlockThreads - 1) / kBlockThreads;
+
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t i0 = grp * kBlockThreads;
+    const int64_t i = i0 + tid;
+    const int64_t ilast = min(i0 + (int64_t)kBlockThreads, nstr);
+    const uint64_t gb = offsets[i0], ge = offsets[ilast];            // the group's byte range (uniform loads)
+    const uint64_t wb = gb & ~15ull;                                   // window base, 16-byte aligned down
+    const int wvalid = (int)min((uint64_t)kBatchWindow, ((ge - wb) + 15ull) & ~15ull);   // whole 16-byte chunks; over-read
+    __syncthreads();                                                   // stays inside the aligned chunk (never a page)
+    for (int c = tid; c < (wvalid >> 4); c += kBlockThreads)
+      *reinterpret_cast<uint4*>(win + (c << 4)) = *reinterpret_cast<const uint4*>(concat + wb + ((uint64_t)c << 4));
+    uint64_t o0 = 0, o1 = 0;
+    if (i < nstr) { o0 = offsets[i]; o1 = offsets[i + 1]; }
+    __syncthreads();
+    int s = -1, e = -1;
+    BatchInput in;
+    in.g = concat + o0; in.lds = win; in.rel0 = (int)min(o0 - wb, (uint64_t)0x3FFFFFFF); in.wvalid = wvalid; in.len = (int)(o1 - o0);
+    if (i < nstr && !(debug & 2)) {
+      // leftmost-first search: first start position with a match (an attempt AT len is allowed: find.go:545-569
+      // restarts while l > offset, so offset can reach l).  ONE flat loop, one DFA step per trip: nested
+      // attempt/step loops made a wave pay sum-over-starts of the LONGEST walk of its 64 strings.
+      int pos = 0, at = 0, end = -1;
+      unsigned q = 0;
+      bool fresh = true;
+      while (true) {
+        if (fresh) {
+          int ctx = kCtxOther;
+          if (pos == 0) ctx = kCtxBOT;
+          else if (T.ctx_sensitive) ctx = ctx_of_byte[in.At(pos - 1)];
+          q = T.start[ctx];
+          end = T.start_accept[ctx] ? pos : -1;
+          at = pos;
+          fresh = false;
+        }
+        const bool eot = at >= in.len;
+        const unsigned ed = eot ? tab.StepEot(q) : tab.Step(q, in.At(at));
+        if (ed & kMatchBefore) end = at;
+        if (ed & kMatchAfter) end = at + 1;
+        q = ed & kStateMask;
+        if (q == kDead || eot) {
+          if (end >= 0) { s = pos; e = end; break; }
+          ++pos;
+          if (pos > in.len || T.anchored) break;
+          fresh = true;
+        } else {
+          ++at;
+        }
+      }
+      found[i] = s >= 0;
+    }
+    if (!want_spans) continue;
+    int32_t* rec = recs + tid * ncap;
+    if (i < nstr) {
+      if (s < 0) {
+        for (int c = 0; c < ncap; ++c) rec[c] = T.unmatched_minus1 ? -1 : 0;
+      } else if (T.fixed_captures || (debug & 1)) {
+        for (int c = 0; c < ncap; ++c) rec[c] = T.cap_kind[c] == kCapFromStart ? s + T.cap_delta[c] : e - T.cap_delta[c];
+      } else {
+        const int need = e - s + 1;
+        uint16_t* tr = need <= kBatchTrace ? reinterpret_cast<uint16_t*>(smem + Y.trace) + tid * kBatchTrace
+                                           : (trace_stride < 0 ? gtrace + o0 + 2 * i : gtrace + i * trace_stride);
+        ResolveCapturesBatch<MODE>(tab, B, T, tab.cls, ctx_of_byte, in, s, e, tr, rec);
+      }
+    }
+    __syncthreads();
+    // records of the group are contiguous in `spans`: coalesced copy out of LDS
+    const int nrec_words = (int)(ilast - i0) * ncap;
+    int32_t* const dst = spans + i0 * ncap;
+    if (((i0 * ncap) & 3) == 0) {
+      for (int w = tid * 4; w < nrec_words; w += kBlockThreads * 4) {
+        if (w + 4 <= nrec_words) *reinterpret_cast<int4*>(dst + w) = *reinterpret_cast<const int4*>(recs + w);
+        else for (int k = w; k < nrec_words; ++k) dst[k] = recs[k];
+      }
+    } else {
+      for (int w = tid; w < nrec_words; w += kBlockThreads) dst[w] = recs[w];
+    }
+  }
+}
+
+
+// ---- batch, search automaton -------------------------------------------------------------------------------
+// The restart loop costs a \w-heavy string of n bytes up to n^2/2 DFA steps (every start inside a word walks the rest of
+// the word), and a wave pays for its slowest string: 10 M short strings took 4-10 ms even from LDS.  The search
+// automaton (rgx_dfa.h: BuildOptions::unanchored_search) finds the same leftmost-first match in ONE forward walk; the
+// match start is capture slot 0 and comes out of the thread-parent back-trace together with the other groups.
+// U = the search automaton's tables, F = the pattern's ordinary tables (capture template, flags).
+struct SearchLayout {
+  int trans, cls, bt_nth, bt_base, bt_parent, bt_ops, bt_match, st_ops, st_pool, window, trace, recs, total;
+  int bt_in_lds;
+};
+
+__host__ __device__ inline SearchLayout SearchLdsLayout(const DevTables& U, int ncap, bool want_spans, int trace_entry_bytes) {
+  SearchLayout L{};
+  int o = 0;
+  auto take = [&](int bytes) { const int at = o; o += (bytes + 15) & ~15; return at; };
+  L.trans = take(U.table_bytes);
+  L.cls = take(256);
+  const int cells = U.nstates * U.stride;
+  const int bt_bytes = U.nstates * 4 + cells * 8 + U.bt_pool_n * 5 + 16 + U.start_pool_n * 4 + 96;
+  L.bt_in_lds = want_spans && bt_bytes <= 64 * 1024;
+  if (L.bt_in_lds) {
+    L.bt_nth = take(U.nstates * 4);
+    L.bt_base = take(cells * 4);
+    L.bt_match = take(cells * 4);
+    L.bt_ops = take(U.bt_pool_n * 4);
+    L.bt_parent = take(U.bt_pool_n);
+    L.st_ops = take(16);
+    L.st_pool = take(U.start_pool_n * 4);
+  }
+  L.window = take(kBatchWindow + 16);
+  if (want_spans) {
+    L.trace = take(kBlockThreads * kBatchTrace * trace_entry_bytes);
+    L.recs = take(kBlockThreads * ncap * 4);
+  }
+  L.total = o;
+  return L;
+}
+
+template <int MODE, class TraceT>
+__global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U, DevTables F, const uint8_t* concat,
+                                                                      const uint64_t* offsets, int64_t nstr, uint8_t* found,
+                                                                      int32_t* spans, TraceT* gtrace) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const bool want_spans = spans != nullptr;
+  const int ncap = F.ncap;
+  const SearchLayout Y = SearchLdsLayout(U, ncap, want_spans, (int)sizeof(TraceT));
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(U.trans);
+    uint4* dst = reinterpret_cast<uint4*>(smem + Y.trans);
+    const int n16 = (U.table_bytes + 15) >> 4;
+    for (int i = tid; i < n16; i += kBlockThreads) dst[i] = src[i];
+    smem[Y.cls + tid] = U.cls[tid];
+    if (Y.bt_in_lds) {
+      const int cells = U.nstates * U.stride;
+      uint32_t* d;
+      d = reinterpret_cast<uint32_t*>(smem + Y.bt_nth);   for (int i = tid; i < U.nstates; i += kBlockThreads) d[i] = U.st_nthreads[i];
+      d = reinterpret_cast<uint32_t*>(smem + Y.bt_base);  for (int i = tid; i < cells; i += kBlockThreads) d[i] = U.bt_base[i];
+      d = reinterpret_cast<uint32_t*>(smem + Y.bt_match); for (int i = tid; i < cells; i += kBlockThreads) d[i] = U.bt_match[i];
+      d = reinterpret_cast<uint32_t*>(smem + Y.bt_ops);   for (int i = tid; i < U.bt_pool_n; i += kBlockThreads) d[i] = U.bt_ops[i];
+      for (int i = tid; i < U.bt_pool_n; i += kBlockThreads) smem[Y.bt_parent + i] = U.bt_parent[i];
+      d = reinterpret_cast<uint32_t*>(smem + Y.st_ops);   if (tid < 4) d[tid] = U.start_ops[tid];
+      d = reinterpret_cast<uint32_t*>(smem + Y.st_pool);  for (int i = tid; i < U.start_pool_n; i += kBlockThreads) d[i] = U.start_ops_pool[i];
+    }
+  }
+  Tab<MODE> tab;
+  tab.t = reinterpret_cast<const uint16_t*>(smem + Y.trans);
+  tab.cls = smem + Y.cls;
+  tab.stride = U.stride;
+  tab.nstates = U.nstates;
+  BtTabs B;
+  if (Y.bt_in_lds) {
+    B.st_nthreads = reinterpret_cast<const uint32_t*>(smem + Y.bt_nth);
+    B.bt_base = reinterpret_cast<const uint32_t*>(smem + Y.bt_base);
+    B.bt_match = reinterpret_cast<const uint32_t*>(smem + Y.bt_match);
+    B.bt_ops = reinterpret_cast<const uint32_t*>(smem + Y.bt_ops);
+    B.bt_parent = smem + Y.bt_parent;
+    B.start_ops = reinterpret_cast<const uint32_t*>(smem + Y.st_ops);
+    B.start_ops_pool = reinterpret_cast<const uint32_t*>(smem + Y.st_pool);
+  } else {
+    B.st_nthreads = U.st_nthreads; B.bt_base = U.bt_base; B.bt_match = U.bt_match; B.bt_ops = U.bt_ops;
+    B.bt_parent = U.bt_parent; B.start_ops = U.start_ops; B.start_ops_pool = U.start_ops_pool;
+  }
+  unsigned char* const win = smem + Y.window;
+  int32_t* const recs = reinterpret_cast<int32_t*>(smem + Y.recs);
+  const int64_t ngroups = (nstr + kBlockThreads - 1) / kBlockThreads;
+  const unsigned q0 = U.start[kCtxBOT];
+  const int end0 = U.start_accept[kCtxBOT] ? 0 : -1;
+  const int unset = F.unmatched_minus1 ? -1 : 0;
+  const int stride = U.stride;
+
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t i0 = grp * kBlockThreads;
+    const int64_t i = i0 + tid;
+    const int64_t ilast = min(i0 + (int64_t)kBlockThreads, nstr);
+    const uint64_t gb = offsets[i0], ge = offsets[ilast];
+    const uint64_t wb = gb & ~15ull;
+    const int wvalid = (int)min((uint64_t)kBatchWindow, ((ge - wb) + 15ull) & ~15ull);
+    __syncthreads();
+    for (int c = tid; c < (wvalid >> 4); c += kBlockThreads)
+      *reinterpret_cast<uint4*>(win + (c << 4)) = *reinterpret_cast<const uint4*>(concat + wb + ((uint64_t)c << 4));
+    uint64_t o0 = 0, o1 = 0;
+    if (i < nstr) { o0 = offsets[i]; o1 = offsets[i + 1]; }
+    __syncthreads();
+    BatchInput in;
+    in.g = concat + o0; in.lds = win; in.rel0 = (int)min(o0 - wb, (uint64_t)0x3FFFFFFF); in.wvalid = wvalid; in.len = (int)(o1 - o0);
+    int end = -1;
+    TraceT* tr = nullptr;
+    if (i < nstr) {
+      // ---- one forward walk; trace[k] = state after k bytes (only kept when spans are wanted)
+      if (want_spans)
+        tr = in.len + 2 <= kBatchTrace ? reinterpret_cast<TraceT*>(smem + Y.trace) + tid * kBatchTrace : gtrace + o0 + 2 * i;
+      unsigned q = q0;
+      end = end0;
+      if (want_spans) tr[0] = (TraceT)q;
+      for (int at = 0;; ++at) {
+        const bool eot = at >= in.len;
+        const unsigned ed = eot ? tab.StepEot(q) : tab.Step(q, in.At(at));
+        if (ed & kMatchBefore) end = at;
+        if (ed & kMatchAfter) end = at + 1;
+        q = ed & kStateMask;
+        if (q == kDead || eot) break;
+        if (want_spans) tr[at + 1] = (TraceT)q;
+        else if (end >= 0) break;       // MatchBytes: any match will do
+      }
+      found[i] = end >= 0;
+    }
+    if (!want_spans) continue;
+    int32_t* rec = recs + tid * ncap;
+    if (i < nstr) {
+      for (int c = 0; c < ncap; ++c) rec[c] = unset;
+      if (end >= 0) {
+        // ---- back-trace from the winning thread at `end` until it passes Capture 0 (the match start)
+        unsigned setmask = 2u;
+        rec[1] = end;
+        int j;
+        if (U.lookahead) {
+          const unsigned qe = tr[end];
+          const int k = end < in.len ? tab.cls[in.At(end)] : U.ncls;
+          const unsigned m = B.bt_match[qe * stride + k];
+          j = (int)(m >> 24);
+          unsigned ops = (m & 0xFFFFFFu) & ~setmask;
+          while (ops) { const int c = __builtin_ctz(ops); ops &= ops - 1; rec[c] = end; setmask |= 1u << c; }
+          for (int p = end - 1; p >= 0 && !(setmask & 1u); --p) {
+            const unsigned base = B.bt_base[(unsigned)tr[p] * stride + tab.cls[in.At(p)]];
+            unsigned o = B.bt_ops[base + j] & ~setmask;
+            while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = p; setmask |= 1u << c; }
+            j = B.bt_parent[base + j];
+          }
+        } else {
+          j = (int)B.st_nthreads[tr[end]] - 1;
+          for (int p = end - 1; p >= 0 && !(setmask & 1u); --p) {
+            const unsigned base = B.bt_base[(unsigned)tr[p] * stride + tab.cls[in.At(p)]];
+            unsigned o = B.bt_ops[base + j] & ~setmask;
+            while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = p + 1; setmask |= 1u << c; }
+            j = B.bt_parent[base + j];
+          }
+          if (!(setmask & 1u)) {
+            unsigned o = B.start_ops_pool[B.start_ops[kCtxBOT] + j] & ~setmask;
+            while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = 0; setmask |= 1u << c; }
+          }
+        }
+        if (F.fixed_captures) {
+          const int s = rec[0];
+          for (int c = 2; c < ncap; ++c) rec[c] = F.cap_kind[c] == kCapFromStart ? s + F.cap_delta[c] : end - F.cap_delta[c];
+        }
+      }
+    }
+    __syncthreads();
+    const int nrec_words = (int)(ilast - i0) * ncap;
+    int32_t* const dst = spans + i0 * ncap;
+    if (((i0 * ncap) & 3) == 0) {
+      for (int w = tid * 4; w < nrec_words; w += kBlockThreads * 4) {
+        if (w + 4 <= nrec_words) *reinterpret_cast<int4*>(dst + w) = *reinterpret_cast<const int4*>(recs + w);
+        else for (int k = w; k < nrec_words; ++k) dst[k] = recs[k];
+      }
+    } else {
+      for (int w = tid; w < nrec_words; w += kBlockThreads) dst[w] = recs[w];
+    }
+  }
+}
+
 }  // namespace
 
 size_t ScanSharedBytes(const DevTables& T) {
@@ -523,9 +973,78 @@ hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, i
   return hipGetLastError();
 }
 
+hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8_t* concat, const uint64_t* offsets, int64_t nstr,
+                             uint8_t* found, int32_t* spans, void* trace, hipStream_t stream) {
+  if (nstr <= 0) return hipSuccess;
+  const bool t8 = U.nstates <= 256;
+  const SearchLayout Y = SearchLdsLayout(U, F.ncap, spans != nullptr, t8 ? 1 : 2);
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+  }
+  const int64_t ngroups = (nstr + kBlockThreads - 1) / kBlockThreads;
+  int per_cu = (160 * 1024) / (Y.total + 1024);
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 8) per_cu = 8;
+  int64_t grid = (int64_t)cus * per_cu * 4;
+  if (grid > ngroups) grid = ngroups;
+#define RGX_GO(MODE, TT)                                                                                              \
+  do {                                                                                                                \
+    static bool attr = false;                                                                                         \
+    if (!attr) {                                                                                                      \
+      hipError_t e = hipFuncSetAttribute((const void*)batch_search_kernel<MODE, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      if (e != hipSuccess) return e;                                                                                  \
+      attr = true;                                                                                                    \
+    }                                                                                                                 \
+    hipLaunchKernelGGL((batch_search_kernel<MODE, TT>), dim3((unsigned)grid), dim3(kBlockThreads), (size_t)Y.total, stream, U, F,   \
+                       concat, offsets, nstr, found, spans, (TT*)trace);                                              \
+  } while (0)
+  if (U.mode == kModeDirect) { if (t8) RGX_GO(kModeDirect, uint8_t); else RGX_GO(kModeDirect, uint16_t); }
+  else { if (t8) RGX_GO(kModeClassLds, uint8_t); else RGX_GO(kModeClassLds, uint16_t); }
+#undef RGX_GO
+  return hipGetLastError();
+}
+
+bool BatchSearchFits(const DevTables& U, const DevTables& F, bool want_spans, const uint8_t* concat) {
+  if (U.mode == kModeClassGlobal || F.ncap > 32 || (((uintptr_t)concat) & 15) != 0) return false;
+  return SearchLdsLayout(U, F.ncap, want_spans, U.nstates <= 256 ? 1 : 2).total <= 150 * 1024;
+}
+
 hipError_t LaunchBatch(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,
                        int32_t* spans, uint16_t* trace, int64_t trace_stride, hipStream_t stream) {
   if (nstr <= 0) return hipSuccess;
+  static const bool force_old = getenv("RGX_BATCH_OLD") != nullptr;
+  const BatchLayout Y = BatchLdsLayout(T, spans != nullptr);
+  if (!force_old && T.mode != kModeClassGlobal && Y.total <= 150 * 1024 && (((uintptr_t)concat) & 15) == 0 && T.ncap <= 32) {
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    }
+    const int64_t ngroups = (nstr + kBlockThreads - 1) / kBlockThreads;
+    int per_cu = (160 * 1024) / (Y.total + 1024);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 6) per_cu = 6;
+    int64_t grid = (int64_t)cus * per_cu * 4;      // a few groups per workgroup amortise the table staging; tail stays short
+    if (grid > ngroups) grid = ngroups;
+    static const int dbg = getenv("RGX_BATCH_DEBUG") ? atoi(getenv("RGX_BATCH_DEBUG")) : 0;
+    static bool attr_set[2] = {false, false};
+    const void* fn = T.mode == kModeDirect ? (const void*)batch_lds_kernel<kModeDirect> : (const void*)batch_lds_kernel<kModeClassLds>;
+    const int mi = T.mode == kModeDirect ? 0 : 1;
+    if (!attr_set[mi]) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      attr_set[mi] = true;
+    }
+    if (T.mode == kModeDirect)
+      hipLaunchKernelGGL((batch_lds_kernel<kModeDirect>), dim3((unsigned)grid), dim3(kBlockThreads), (size_t)Y.total, stream, T, concat,
+                         offsets, nstr, found, spans, trace, trace_stride, dbg);
+    else
+      hipLaunchKernelGGL((batch_lds_kernel<kModeClassLds>), dim3((unsigned)grid), dim3(kBlockThreads), (size_t)Y.total, stream, T, concat,
+                         offsets, nstr, found, spans, trace, trace_stride, dbg);
+    return hipGetLastError();
+  }
   dim3 block(64), grid((unsigned)((nstr + 63) / 64));
   hipLaunchKernelGGL(batch_kernel, grid, block, 0, stream, T, concat, offsets, nstr, found, spans, trace, trace_stride);
   return hipGetLastError();

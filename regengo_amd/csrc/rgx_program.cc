@@ -11,9 +11,10 @@ void SetError(const std::string& s) { g_error = s; }
 const std::string& GetError() { return g_error; }
 
 Program::~Program() {
-  if (d_arena) {
+  if (d_arena || d_arena_u) {
     hipSetDevice(device);
-    hipFree(d_arena);
+    if (d_arena) hipFree(d_arena);
+    if (d_arena_u) hipFree(d_arena_u);
   }
 }
 
@@ -30,22 +31,9 @@ struct Arena {
 };
 }  // namespace
 
-int ProgramToDevice(Program* p, int device) {
-  std::lock_guard<std::mutex> lock(p->mu);
-  if (p->d_arena) {
-    if (p->device == device) return RGX_OK;
-    SetError("program already bound to another device");
-    return RGX_E_INVALID;
-  }
-  int ndev = 0;
-  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
-    SetError("no usable HIP device (hipGetDeviceCount)");
-    (void)hipGetLastError();
-    return RGX_E_NO_DEVICE;
-  }
-  if (hipSetDevice(device) != hipSuccess) { SetError("hipSetDevice failed"); return RGX_E_NO_DEVICE; }
-
-  const Tables& t = p->t;
+namespace {
+// Builds the device image of one table set: picks the LDS layout, packs every table into one arena, uploads it.
+int UploadTables(const Tables& t, std::vector<uint16_t>* direct_table, DevTables* out, void** out_arena) {
   const int stride = t.ncls + 1;
   DevTables d{};
   d.nstates = t.nstates; d.ncls = t.ncls; d.stride = stride; d.ncap = t.ncap; d.fixed_len = t.fixed_len;
@@ -66,6 +54,8 @@ int ProgramToDevice(Program* p, int device) {
     }
     if (possible) d.sa_smin = s;
   }
+  d.bt_pool_n = (int32_t)t.bt_parent.size();
+  d.start_pool_n = (int32_t)t.start_ops_pool.size();
   d.fixed_captures = t.fixed_captures; d.unmatched_minus1 = (t.flags & RGX_FLAG_UNMATCHED_MINUS1) ? 1 : 0;
 
   // choose the LDS layout
@@ -75,12 +65,12 @@ int ProgramToDevice(Program* p, int device) {
   const size_t class_bytes = (size_t)t.nstates * stride * 2;
   if (direct_bytes <= 40 * 1024) {
     d.mode = kModeDirect;
-    p->direct_table.assign((size_t)t.nstates * 257, 0);
+    (*direct_table).assign((size_t)t.nstates * 257, 0);
     for (int q = 0; q < t.nstates; q++) {
-      for (int c = 0; c < 256; c++) p->direct_table[(size_t)q * 256 + c] = t.trans[(size_t)q * stride + t.cls[c]];
-      p->direct_table[(size_t)t.nstates * 256 + q] = t.trans[(size_t)q * stride + t.ncls];
+      for (int c = 0; c < 256; c++) (*direct_table)[(size_t)q * 256 + c] = t.trans[(size_t)q * stride + t.cls[c]];
+      (*direct_table)[(size_t)t.nstates * 256 + q] = t.trans[(size_t)q * stride + t.ncls];
     }
-    off_trans = a.AddVec(p->direct_table);
+    off_trans = a.AddVec((*direct_table));
     d.table_bytes = (int32_t)direct_bytes;
   } else if (class_bytes <= 96 * 1024) {
     d.mode = kModeClassLds;
@@ -115,10 +105,57 @@ int ProgramToDevice(Program* p, int device) {
   d.start_ops = (const uint32_t*)(b + off_so); d.start_ops_pool = (const uint32_t*)(b + off_sop);
   d.sa_mask = (const uint32_t*)(b + off_sa);
   d.trans_cls = (const uint16_t*)(b + off_tcls);
+  *out = d;
+  *out_arena = dptr;
+  return RGX_OK;
+}
+}  // namespace
+
+int ProgramToDevice(Program* p, int device) {
+  std::lock_guard<std::mutex> lock(p->mu);
+  if (p->d_arena) {
+    if (p->device == device) return RGX_OK;
+    SetError("program already bound to another device");
+    return RGX_E_INVALID;
+  }
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) {
+    SetError("no usable HIP device (hipGetDeviceCount)");
+    (void)hipGetLastError();
+    return RGX_E_NO_DEVICE;
+  }
+  if (hipSetDevice(device) != hipSuccess) { SetError("hipSetDevice failed"); return RGX_E_NO_DEVICE; }
+
+  DevTables d{};
+  void* dptr = nullptr;
+  const int rc = UploadTables(p->t, &p->direct_table, &d, &dptr);
+  if (rc != RGX_OK) return rc;
   p->dev = d;
   p->d_arena = dptr;
   p->device = device;
   return RGX_OK;
+}
+
+const DevTables* SearchTables(Program* p) {
+  std::lock_guard<std::mutex> lock(p->mu);
+  if (p->u_state == 0) {
+    p->u_state = -1;
+    if (!p->t.anchored && p->d_arena) {
+      try {
+        BuildOptions opt;
+        opt.unanchored_search = true;
+        opt.max_states = 4000;
+        p->u = BuildTables(p->t.pattern, p->t.flags, opt);
+        if (UploadTables(p->u, &p->direct_table_u, &p->udev, &p->d_arena_u) == RGX_OK) {
+          p->udev.unmatched_minus1 = p->dev.unmatched_minus1;
+          p->u_state = 1;
+        }
+      } catch (...) {
+        p->u_state = -1;   // too many states / unsupported: the restart loop over the anchored DFA still works
+      }
+    }
+  }
+  return p->u_state == 1 ? &p->udev : nullptr;
 }
 
 }  // namespace rgx

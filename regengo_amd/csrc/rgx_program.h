@@ -50,6 +50,7 @@ struct DevTables {
   int32_t sa_k;                   // 0: no prefilter
   int32_t sa_exact;
   int32_t sa_first_bytes;         // number of byte values that can start a match (selectivity of the prefilter)
+  int32_t bt_pool_n, start_pool_n; // entries in bt_parent/bt_ops and in start_ops_pool
   int32_t sa_smin;                // exact chains: smallest shift s>=1 at which two matches can overlap (sa_k: never)
   uint16_t start[4];
   uint8_t start_accept[4];
@@ -59,16 +60,25 @@ struct DevTables {
 struct Program {
   Tables t;
   std::vector<uint8_t> blob_cache;
+  // search automaton (BuildOptions::unanchored_search) for the per-string entry points; built lazily, absent when the
+  // pattern is anchored or the automaton exceeds its state budget
+  Tables u;
+  int u_state = 0;          // 0: not tried, 1: built, -1: unavailable
   // device side
   std::mutex mu;
   int device = -1;
   void* d_arena = nullptr;  // one allocation holding every table
+  void* d_arena_u = nullptr;
   DevTables dev{};
+  DevTables udev{};
   std::vector<uint16_t> direct_table;  // host copy of the direct layout (mode 0)
+  std::vector<uint16_t> direct_table_u;
   ~Program();
 };
 
 int ProgramToDevice(Program* p, int device);  // RGX_OK or negative status
+// Device image of the search automaton, or nullptr when the pattern has none (callers then restart the anchored DFA).
+const DevTables* SearchTables(Program* p);
 
 void SetError(const std::string& s);
 const std::string& GetError();

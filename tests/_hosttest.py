@@ -7,6 +7,9 @@ _lib = C.CDLL(build.build_hosttest())
 _lib.rgxt_compile.restype = C.c_void_p
 _lib.rgxt_compile.argtypes = [C.c_char_p, C.c_uint32]
 _lib.rgxt_free.argtypes = [C.c_void_p]
+_lib.rgxt_compile_search.restype = C.c_void_p
+_lib.rgxt_compile_search.argtypes = [C.c_char_p, C.c_uint32]
+_lib.rgxt_search_first.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p]
 _lib.rgxt_last_error.restype = C.c_char_p
 _lib.rgxt_find_all.restype = C.c_int64
 _lib.rgxt_find_all.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64]
@@ -64,6 +67,17 @@ class HostProgram:
         if c < 0:
             return None
         return [list(out[i * ncap:(i + 1) * ncap]) for i in range(c)]
+
+    def search_program(self, pattern: str, flags: int = 0):
+        """The search automaton of `pattern` (None when it exceeds its state budget)."""
+        h = _lib.rgxt_compile_search(pattern.encode("utf-8"), flags)
+        return HostProgram("", handle=h) if h else None
+
+    def search_first(self, sp: "HostProgram", b: bytes):
+        out = (C.c_int32 * self.info["ncap"])()
+        r = _lib.rgxt_search_first(sp.h, self.h, b, len(b), out)
+        assert r >= 0, "winning thread without Capture 0"
+        return list(out) if r == 1 else None
 
     def match(self, b: bytes) -> bool:
         return bool(_lib.rgxt_match(self.h, b, len(b)))

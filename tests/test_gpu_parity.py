@@ -287,6 +287,47 @@ def test_batch_find_and_match(torch_dev):
     assert 0.5 < found.mean() < 0.95
 
 
+def test_batch_search_automaton_corpus(torch_dev, corpus, kats):
+    """FindBatch (one forward walk of the search automaton per string + back-trace) == the oracle's first match with
+    all capture spans, for every corpus and curated pattern over its inputs and their mutations."""
+    import random
+    from oracle import engines as E
+    from regengo_amd import Compiled, _capi
+    rng = random.Random(99)
+    items = [(e["pattern"], e["inputs"]) for e in corpus] + [(c["pattern"], c["inputs"]) for c in kats["curated_cases"]]
+    checked = pats = 0
+    for pat, inputs in items:
+        try:
+            c = Compiled(pat).to(0)
+        except _capi.RgxError:
+            continue
+        o = E.Compiled(pat)
+        bs = [s.encode() for s in inputs]
+        strings = list(bs) + [b"x" + s for s in bs] + [s + s for s in bs] + [s[:-1] for s in bs] + [b" ".join(bs)]
+        alpha = b"".join(bs) or b"a"
+        strings += [bytes(rng.choice(alpha) for _ in range(rng.randint(0, 90))) for _ in range(6)]
+        res = c.FindBatch(strings)
+        mt = c.MatchBatchDevice(*_csr(torch_dev, strings)).cpu().tolist()
+        for b, r, m in zip(strings, res, mt):
+            exp = o.find_machine.find_all(b, 1)
+            if exp:
+                assert r is not None and r.spans == exp[0], (pat, b, r and r.spans, exp[0])
+            elif r is not None:      # FindBytes also tries at offset len(b) (find.go:545-569); FindAll does not
+                assert r.spans[0] == len(b) and r.spans[1] == len(b), (pat, b, r.spans)
+            assert bool(m) == (r is not None), (pat, b)
+            checked += 1
+        pats += 1
+    assert pats >= 230 and checked > 4000
+
+
+def _csr(torch, strings):
+    offs = [0]
+    for s in strings:
+        offs.append(offs[-1] + len(s))
+    concat = torch.frombuffer(bytearray(b"".join(strings) or b"\0"), dtype=torch.uint8).cuda()
+    return concat, torch.tensor(offs, dtype=torch.int64, device="cuda:0")
+
+
 def test_starts_only_form(torch_dev):
     """Compact result for fixed-template patterns: starts + template reproduce the full span table bit for bit."""
     from regengo_amd import _capi, synth

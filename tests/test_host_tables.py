@@ -93,6 +93,39 @@ def test_table_walk_equals_oracle_findall(corpus, kats, hostlib):
     assert unsupported <= 16
 
 
+def test_search_automaton_equals_restart_loop(corpus, kats, hostlib):
+    """FindBytes by ONE forward walk of the search automaton (skip-loop prefix, start = capture slot 0 from the
+    back-trace) == the first result of the restart loop == the oracle, spans included, on the whole corpus."""
+    rng = random.Random(4321)
+    total = nosearch = 0
+    items = [(e["pattern"], e["inputs"]) for e in corpus] + [(c["pattern"], c["inputs"]) for c in kats["curated_cases"]]
+    for p, inputs in items:
+        try:
+            hp = hostlib.HostProgram(p)
+        except ValueError:
+            continue
+        if hp.info["anchored"]:
+            continue
+        sp = hp.search_program(p)
+        if sp is None:
+            nosearch += 1
+            continue
+        o = E.Compiled(p)
+        for b in _mutations(inputs, rng):
+            exp = o.find_machine.find_all(b, 1)
+            # the restart loop makes no attempt at offset len(b) in FindAll (find.go:209-211) but FindBytes does
+            # (find.go:545-569): compare with the quirk-free FindBytes = first FindAll result, or an empty match at len
+            got = hp.search_first(sp, b)
+            if exp:
+                assert got == exp[0], (p, b, got, exp[0])
+            else:
+                if got is not None:
+                    assert got[0] == len(b) and got[1] == len(b), (p, b, got)
+            total += 1
+    assert total > 2000
+    assert nosearch <= 8
+
+
 def test_n_argument(hostlib):
     hp = hostlib.HostProgram(r"(\d+)")
     o = E.Compiled(r"(\d+)")
