@@ -37,6 +37,7 @@ def main():
     ap.add_argument("--adversarial", action="store_true", help="noise alphabet with digits and '-' (config C2b)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--gather-spans", action="store_true", help="also time the variable-length gather of all rows to rank 0")
+    ap.add_argument("--no-alt", action="store_true", help="skip the starts-only alternative result form (keeps profiler passes to one kernel variant)")
     args = ap.parse_args()
 
     import torch
@@ -125,6 +126,8 @@ def main():
     # (rgx_find_all_starts_device).  Reported next to the headline, never instead of it.
     alt = None
     try:
+        if args.no_alt:
+            raise RuntimeError("skipped (--no-alt)")
         starts_out = torch.empty(cap, dtype=torch.int32, device=dev)
         for _ in range(2):
             c.FindAllStarts(window, out=starts_out, capacity=cap)
@@ -181,7 +184,7 @@ def main():
                        "gather_ms": gather_ms, "alt_result_form": alt},
             "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "scan_kernel", "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": win_bytes},
+                         "kernel": "rgx::scan_exact_kernel<4,true>", "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": win_bytes},
         }
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.adversarial)

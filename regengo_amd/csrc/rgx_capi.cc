@@ -27,7 +27,9 @@ struct rgx_stream_ctx {
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timing = false;
   // device scratch
-  unsigned long long* d_desc = nullptr; int64_t desc_cap = 0;
+  unsigned long long* d_desc = nullptr; int64_t desc_cap = 0;   // two scratch sets, see FindAllDevice
+  int64_t set_words = 0, dirty[2] = {0, 0};
+  int cur_set = 0;
   uint32_t* d_counters = nullptr;            // [4]
   unsigned long long* d_total = nullptr;     // [2]: total, trace cursor
   uint8_t* d_unsynced = nullptr; int32_t* d_carry = nullptr; int64_t slice_cap = 0;
@@ -36,6 +38,7 @@ struct rgx_stream_ctx {
   int32_t* d_out = nullptr; int64_t out_cap = 0;
   // pinned host readback
   unsigned long long* h_read = nullptr;      // [4]: total, unsynced, ...
+  unsigned long long* h_read_dev = nullptr;  // the same pinned words as the device sees them
 };
 
 namespace {
@@ -80,25 +83,61 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   const int32_t ntiles = ScanNumTiles(T, ilen);
   const int32_t nslices = (ilen + kSliceBytes - 1) / kSliceBytes;
   int rc;
-  // one device buffer: [total u64][trace cursor u64][counters 4 x u32][look-back descriptors ...] -> one memset, one readback
+  // Device scratch: TWO sets of [total u64][trace cursor u64][counters 4 x u32][look-back descriptors ...], used
+  // alternately.  A scan needs its set zeroed; the exact kernel zeroes the OTHER set on its way (one 8-byte store per
+  // workgroup) and writes its total straight into pinned host memory, so a steady stream of scans costs one kernel
+  // launch and one stream synchronise each -- no memset node, no copy node.  `dirty[s]` = leading words of set s that
+  // are not known to be zero; anything the kernel cannot vouch for is cleared with a real memset.
   const size_t desc_words = (size_t)ntiles + 4;
-  if ((rc = Ensure(&c->d_desc, &c->desc_cap, (int64_t)desc_words)) != RGX_OK) return rc;
-  c->d_total = c->d_desc;
-  c->d_counters = (uint32_t*)(c->d_desc + 2);
+  if (c->desc_cap < (int64_t)(2 * desc_words) || !c->d_desc) {
+    if (c->d_desc) { hipFree(c->d_desc); c->d_desc = nullptr; c->desc_cap = 0; }
+    if ((rc = Ensure(&c->d_desc, &c->desc_cap, (int64_t)(2 * desc_words + 64))) != RGX_OK) return rc;
+    c->set_words = c->desc_cap / 2;
+    c->dirty[0] = c->dirty[1] = c->set_words;
+    c->cur_set = 0;
+  }
+  const bool self_clean = UseExactKernel(T, ilen) && getenv("RGX_NO_SELF_CLEAN") == nullptr;
 
   ScanParams P{};
   P.buf = d_buf; P.len = ilen; P.ntiles = ntiles; P.spans = d_spans; P.cap_records = (int64_t)cap_records;
-  P.tile_desc = c->d_desc + 4; P.counters = c->d_counters; P.total = c->d_total; P.carry_in = nullptr; P.slice_unsynced = nullptr;
+  P.carry_in = nullptr; P.slice_unsynced = nullptr;
   P.count_only = count_only ? 1 : 0;
   P.starts_only = starts_only ? 1 : 0;
 
   auto run_scan = [&](bool time_it) -> int {
-    HIP_TRY(hipMemsetAsync(c->d_desc, 0, desc_words * 8, c->stream));
+    const int s = c->cur_set;
+    unsigned long long* set = c->d_desc + (size_t)s * c->set_words;
+    unsigned long long* other = c->d_desc + (size_t)(1 - s) * c->set_words;
+    if (c->dirty[s] > 0) {
+      HIP_TRY(hipMemsetAsync(set, 0, (size_t)c->dirty[s] * 8, c->stream));
+      c->dirty[s] = 0;
+    }
+    c->d_total = set;
+    c->d_counters = (uint32_t*)(set + 2);
+    P.tile_desc = set + 4; P.counters = c->d_counters; P.total = c->d_total;
+    P.clean_next = self_clean ? other : nullptr;
+    P.host_result = self_clean ? c->h_read_dev : nullptr;
+    c->h_read[0] = 0; c->h_read[1] = 0; c->h_read[2] = 0; c->h_read[3] = 0;
     if (time_it) HIP_TRY(hipEventRecord(c->ev0, c->stream));
     HIP_TRY(LaunchScan(T, P, c->stream));
     if (time_it) HIP_TRY(hipEventRecord(c->ev1, c->stream));
-    HIP_TRY(hipMemcpyAsync(&c->h_read[0], c->d_desc, 32, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->dirty[s] = (int64_t)desc_words;
+    if (self_clean) {
+      if (c->dirty[1 - s] <= (int64_t)desc_words) c->dirty[1 - s] = 0;
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (c->h_read[1]) {   // a rare-path flag is up: fetch the counters the usual way
+        const unsigned long long total = c->h_read[0];
+        HIP_TRY(hipMemcpyAsync(&c->h_read[0], set, 32, hipMemcpyDeviceToHost, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+        c->h_read[0] = total;
+      } else {
+        c->h_read[1] = 0; c->h_read[2] = 0; c->h_read[3] = 0;
+      }
+    } else {
+      HIP_TRY(hipMemcpyAsync(&c->h_read[0], set, 32, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    c->cur_set = 1 - s;
     return RGX_OK;
   };
   static const bool force_tickets = getenv("RGX_TICKETS") != nullptr;
@@ -256,7 +295,8 @@ RGX_API int rgx_stream_ctx_create(const rgx_program* p, rgx_stream_ctx** out) {
   if (hipSetDevice(c->device) != hipSuccess) { delete c; return RGX_E_NO_DEVICE; }
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
-                        hipHostMalloc((void**)&c->h_read, 64, hipHostMallocDefault) == hipSuccess;
+                        hipHostMalloc((void**)&c->h_read, 64, hipHostMallocMapped) == hipSuccess &&
+            hipHostGetDevicePointer((void**)&c->h_read_dev, c->h_read, 0) == hipSuccess;
   if (!ok) { SetError("ctx allocation failed"); rgx_stream_ctx_destroy(c); return RGX_E_HIP; }
   *out = c;
   return RGX_OK;

@@ -39,7 +39,8 @@ __device__ __forceinline__ unsigned long long WaveSum64(unsigned long long v) {
 // promise dispatch order) -- so the spin is bounded and a timeout raises *timeout_flag; the host then repeats the
 // scan in ticket mode.  Results never depend on the assumption, only speed does.
 __device__ __forceinline__ unsigned long long LookBack(unsigned long long* desc, int id, unsigned long long own, int lane,
-                                                        unsigned* timeout_flag, int nap = 1) {
+                                                        unsigned* timeout_flag, int nap = 1,
+                                                        unsigned long long* host_flag = nullptr) {
   unsigned long long excl = 0;
   if (lane == 0)
     __hip_atomic_store(&desc[id], (id == 0 ? kDescPrefix : kDescAgg) | own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -58,7 +59,10 @@ __device__ __forceinline__ unsigned long long LookBack(unsigned long long* desc,
         }
       }
       if (__any(dead)) {
-        if (lane == 0) atomicExch(timeout_flag, 1u);
+        if (lane == 0) {
+          atomicExch(timeout_flag, 1u);
+          if (host_flag) __hip_atomic_store(host_flag, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
         break;
       }
       const unsigned long long pm = __ballot((d >> 62) == 2);

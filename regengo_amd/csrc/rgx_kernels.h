@@ -17,6 +17,8 @@ struct ScanParams {
   unsigned long long* tile_desc; // [ntiles] look-back descriptors, zeroed before launch
   uint32_t* counters;            // [0] tile ticket, [1] unsynced slices, [2] stats, [3] look-back timeout; zeroed before launch
   unsigned long long* total;     // total matches; zeroed before launch
+  unsigned long long* clean_next;   // nullable: the scratch set of the NEXT scan; this launch zeroes its first ntiles+4 words
+  unsigned long long* host_result;  // nullable: pinned host words [0] = total, [1] = 1 if a rare-path counter is nonzero
   const int32_t* carry_in;       // nullable; per slice: -1 = find a sync point locally, else search position
   uint8_t* slice_unsynced;       // nullable; set to 1 for slices that found no sync point
   int32_t count_only;

@@ -61,6 +61,17 @@ __device__ __forceinline__ unsigned DppWaveShr1(unsigned x) {
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xF, 0xF, true);   // lane l <- lane l-1, lane 0 <- 0
 }
 
+// (byte B of w) << sh in ONE instruction (SDWA source select); hipcc spends two on byte 0
+template <int B>
+__device__ __forceinline__ unsigned ByteTimes(unsigned w, unsigned sh) {
+  unsigned r;
+  if (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(sh), "v"(w));
+  else if (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(sh), "v"(w));
+  else if (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(sh), "v"(w));
+  else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(sh), "v"(w));
+  return r;
+}
+
 // inclusive scan over the 64 lanes, all in DPP (no LDS traffic)
 __device__ __forceinline__ unsigned DppInclusiveScan(unsigned x) {
   x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);   // row_shr:1
@@ -98,9 +109,13 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
     __syncthreads();
     blk = (int)L.ticket;
   }
+  if (P.clean_next && tid < 4) {
+    // housekeeping for the next scan of this context: it will find its scratch set zeroed without a memset node
+    if (tid == 0) P.clean_next[4 + blk] = 0;
+    if (blk == 0) P.clean_next[tid] = 0;
+  }
   const int group = blk * (kBlockThreads / 64) + wave;   // this wave's range of tiles; one look-back descriptor per BLOCK
   unsigned char* const wt = L.tile[wave];
-  const int last16 = (len - 1) & ~15;     // the aligned 16-byte chunk holding the last byte never crosses a page
   const int first_tile = group * kGroupTiles;
 
   // Prefetch depth 2: the 4 KiB of tiles g+1 and g+2 are in flight (in VGPRs) while tile g is processed -- one tile
@@ -109,15 +124,19 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
   pv[0][4] = v4u{0u, 0u, 0u, 0u};
   pv[1][4] = v4u{0u, 0u, 0u, 0u};
   // chunk c of a tile = bytes [tb + 16c, tb + 16c + 16); lane l loads chunks l, l+64, l+128, l+192 and (l < 2) 256+l.
-  // Addresses are clamped into the buffer: what a clamped chunk holds is never used (validity mask below).
-#define RGX_ADDR(tb, c) (P.buf + min(max((tb) + ((c) << 4), 0), last16))
+  // Buffer loads: the descriptor's range check does the clamping (an out-of-range chunk reads as zero; the validity mask
+  // below ignores it anyway), the four chunks of a lane differ only in the instruction's immediate offset, so a tile costs
+  // ONE address add.  num_records is rounded up to the 16-byte chunk holding the last byte (same page, base is aligned).
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(P.buf), 0, (len + 15) & ~15, 0x00020000);
+  const int lane16 = lane << 4;
 #define RGX_LOAD_TILE(S, tb)                                                                          \
   {                                                                                                   \
-    pv[S][0] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(RGX_ADDR(tb, lane)));          \
-    pv[S][1] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(RGX_ADDR(tb, lane + 64)));     \
-    pv[S][2] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(RGX_ADDR(tb, lane + 128)));    \
-    pv[S][3] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(RGX_ADDR(tb, lane + 192)));    \
-    if (lane < 2) pv[S][4] = __builtin_nontemporal_load(reinterpret_cast<const v4u*>(RGX_ADDR(tb, lane + 256))); \
+    const int vo = (tb) + lane16;                                                                     \
+    pv[S][0] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo, 0, 2);                                 \
+    pv[S][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo + 1024, 0, 2);                          \
+    pv[S][2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo + 2048, 0, 2);                          \
+    pv[S][3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo + 3072, 0, 2);                          \
+    if (lane < 2) pv[S][4] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo + 4096, 0, 2);            \
   }
   if (!(P.debug & 16)) {
     RGX_LOAD_TILE(0, first_tile * kWaveTileBytes - kSliceBytes)
@@ -161,10 +180,11 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
       const uint4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
       const uint4 n0 = row[5], n1 = row[6];   // next row: 80-byte stride = 5 uint4
       unsigned E = ~0u, det0 = 0, det1 = 0, det2 = ~0u;
-      const int hsh = 33 - K - 4 * PER;      // left shift that puts the 4*PER freshest accept bits at the top
+      const int hsh = 33 - K - 4 * PER;
+      const unsigned tsh = W16 ? 1u : 2u;     // table entry size as a shift      // left shift that puts the 4*PER freshest accept bits at the top
 #define RGX_LU(W, B)                                                                                                              \
-  (W16 ? (unsigned)*reinterpret_cast<const unsigned short*>(reinterpret_cast<const unsigned char*>(L.sa) + ((((W) >> (8 * (B))) & 0xFFu) << 1)) \
-       : *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(L.sa) + ((((W) >> (8 * (B))) & 0xFFu) << 2)))
+  (W16 ? (unsigned)*reinterpret_cast<const unsigned short*>(reinterpret_cast<const unsigned char*>(L.sa) + ByteTimes<B>(W, tsh)) \
+       : *reinterpret_cast<const unsigned*>(reinterpret_cast<const unsigned char*>(L.sa) + ByteTimes<B>(W, tsh)))
 #define RGX_WORD(W)                                         \
       {                                                     \
         E = (E << 1) | RGX_LU(W, 0);                        \
@@ -262,6 +282,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
       }
       if (!synced) {
         atomicAdd(&P.counters[1], 1u);
+        if (P.host_result) __hip_atomic_store(&P.host_result[1], 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         if (P.slice_unsynced) P.slice_unsynced[slice] = 1;
       } else {
         unsigned long long m = cur;
@@ -277,7 +298,6 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
     lane_cnt += (unsigned)__popcll(s_sel);
   }
 #undef RGX_LOAD_TILE
-#undef RGX_ADDR
 
   // ---- one decoupled look-back per group
   const unsigned group_total = __builtin_amdgcn_readlane((int)DppInclusiveScan(lane_cnt), 63);
@@ -290,11 +310,14 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
 #pragma unroll
     for (int w = 0; w < kBlockThreads / 64; ++w) block_total += L.wtot[w];
     unsigned long long excl = 0;
-    if (!(P.debug & 1)) excl = LookBack(P.tile_desc, blk, block_total, lane, &P.counters[3], 4);
+    if (!(P.debug & 1)) excl = LookBack(P.tile_desc, blk, block_total, lane, &P.counters[3], 4, P.host_result ? P.host_result + 1 : nullptr);
     if (lane == 0) {
       L.base_lo = (unsigned)excl;
       L.base_hi = (unsigned)(excl >> 32);
-      if (blk + 1 >= P.ntiles) *P.total = excl + block_total;   // the last workgroup knows the grand total
+      if (blk + 1 >= P.ntiles) {                                // the last workgroup knows the grand total
+        *P.total = excl + block_total;
+        if (P.host_result) __hip_atomic_store(&P.host_result[0], excl + block_total, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
     }
   }
   __syncthreads();

@@ -5,7 +5,7 @@ OUT=gpurun_out/$1; shift
 mkdir -p /tmp/p $OUT
 run() { # name counters...
   name=$1; shift
-  rocprofv3 --pmc "$@" --output-format csv -d /tmp/p/$name -o $name -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline $BARGS > /tmp/$name.log 2>&1
+  rocprofv3 --pmc "$@" --output-format csv -d /tmp/p/$name -o $name -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-alt $BARGS > /tmp/$name.log 2>&1
   python - "$name" <<'PY' >> $OUT/summary.txt
 import csv, glob, sys, collections
 name = sys.argv[1]

@@ -4,7 +4,7 @@ export TMPDIR=/tmp
 TAG=$1; shift
 OUT=gpurun_out/prof_$TAG
 rm -rf /tmp/p; mkdir -p /tmp/p $OUT
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p/kt -o bench -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline "$@" > $OUT/bench_under_rocprof.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p/kt -o bench -- python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-alt "$@" > $OUT/bench_under_rocprof.log 2>&1
 python - <<'PY' > $OUT/kernel_stats.csv
 import csv, glob
 rows = list(csv.DictReader(open(glob.glob("/tmp/p/kt/*kernel_stats.csv")[0])))
@@ -14,8 +14,8 @@ for r in keep:
     r["Name"] = r["Name"][:150]
     w.writerow(r)
 PY
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p/f -o f -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > /tmp/f.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p/w -o w -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline "$@" > /tmp/w.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d /tmp/p/f -o f -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt "$@" > /tmp/f.log 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d /tmp/p/w -o w -- python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-alt "$@" > /tmp/w.log 2>&1
 python - "$OUT" <<'PY'
 import csv, glob, json, sys
 out = sys.argv[1]
