@@ -72,31 +72,48 @@ def main():
     window = synth.date_log_torch(sh.win_hi - sh.win_lo, dev, adversarial=args.adversarial, start=sh.win_lo)
     finder = ShardedFinder.for_compiled(c, dev)
     cap = (sh.win_hi - sh.win_lo) // c.MinMatchLen + 1
-    out = torch.empty((cap, c.ncap), dtype=torch.int32, device=dev)
+    outs = [torch.empty((cap, c.ncap), dtype=torch.int32, device=dev) for _ in range(2)]   # step k's spans stay intact
+    out = outs[0]                                                                           # while step k+1 scans
+    flip = [0]
 
     def scan(w):
-        spans, res = c.FindAllSpans(w, out=out, capacity=cap)
+        flip[0] ^= 1
+        spans, res = c.FindAllSpans(w, out=outs[flip[0]], capacity=cap)
         return spans, {"kernel_ms": res.kernel_ms, "unsynced": int(res.unsynced)}
 
     finder.scan = scan
 
+    def scan_owned(w, lo, hi):
+        flip[0] ^= 1
+        spans, res = c.FindAllSpans(w, out=outs[flip[0]], capacity=cap, own=(lo, hi))
+        return spans, {"kernel_ms": res.kernel_ms, "unsynced": int(res.unsynced)}
+
+    finder.scan_owned = scan_owned
+
     cdev_early = dev if (world == 1 or dist.get_backend() == "nccl") else "cpu"
 
     def step():
-        owned, cnt, info = finder.find_all_local(window, sh)
-        base, total, counts = finder.global_row_base(cnt, cdev_early)
-        return owned, cnt, info, base, total, counts
+        return finder.find_all_sharded(window, sh, cdev_early, defer=True)
 
     for _ in range(args.warmup):
-        step()
+        step()()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     kms = []
+    # Every step = scan (kernel + result on the host) + the count exchange.  The exchange of step k is finished after the
+    # scan of step k+1 has been launched (N>1: the 16-byte all_gather's latency hides behind that scan); all K steps are
+    # complete -- spans in HBM, counts and row bases on the host -- before the clock stops.
+    pending = None
     for _ in range(args.steps):
-        owned, cnt, info, base, total, counts = step()
-        kms.append(info["kernel_ms"])
+        nxt = step()
+        if pending is not None:
+            owned, cnt, info, base, total, counts = pending()
+            kms.append(info["kernel_ms"])
+        pending = nxt
+    owned, cnt, info, base, total, counts = pending()
+    kms.append(info["kernel_ms"])
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

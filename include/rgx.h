@@ -122,6 +122,12 @@ int rgx_match_bytes_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_
  * Records are written in increasing match-start order.  Returns written count or <0.              */
 int64_t rgx_find_all_bytes_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len,
                                   int64_t n, int32_t* d_spans, size_t cap_records, rgx_result* res);
+/* Sharded FindReader / FindAll (streaming.go:85-255 cut into per-GPU windows): the window [0, len) is this shard's owned
+ * range plus its halos; the FindAll chain is resolved over the whole window but only matches whose START lies in
+ * [own_lo, own_hi) are counted and written.  Offsets stay window-relative.                           */
+int64_t rgx_find_all_bytes_device_owned(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len,
+                                        int64_t n, int32_t* d_spans, size_t cap_records, int64_t own_lo, int64_t own_hi,
+                                        rgx_result* res);
 /* Same, host buffers: H2D copy of the input, D2H copy of the spans (PCIe-bound).     */
 int64_t rgx_find_all_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* buf, size_t len, int64_t n,
                            int32_t* spans, size_t cap_records, rgx_result* res);

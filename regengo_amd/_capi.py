@@ -65,6 +65,8 @@ SYMBOLS = {
     "rgx_match_bytes_device": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int)]),
     "rgx_find_all_bytes_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p,
                                               C.c_size_t, C.POINTER(Result)]),
+    "rgx_find_all_bytes_device_owned": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p,
+                                                    C.c_size_t, C.c_int64, C.c_int64, C.POINTER(Result)]),
     "rgx_find_all_bytes": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t,
                                        C.POINTER(Result)]),
     "rgx_find_all_starts_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p,

@@ -146,9 +146,10 @@ class Compiled:
 
     MatchString = MatchBytes
 
-    def FindAllSpans(self, data, n: int = -1, capacity: Optional[int] = None, out=None):
+    def FindAllSpans(self, data, n: int = -1, capacity: Optional[int] = None, out=None, own=None):
         """Flat accessor next to the drop-in slice-of-structs: int32 tensor [count, ncap] on the device.
-        Returns (spans, result)."""
+        Returns (spans, result).  own=(lo, hi): shard mode -- the FindAll chain runs over the whole buffer, only matches
+        whose start lies in [lo, hi) are reported (rgx_find_all_bytes_device_owned)."""
         import torch
         self._need_dev()
         t, ln = self._as_device(data)
@@ -161,8 +162,12 @@ class Compiled:
                 capacity = min(capacity, n)
         if out is None or out.numel() < capacity * self.ncap:
             out = torch.empty((capacity, self.ncap), dtype=torch.int32, device=t.device)
-        w = self._lib.rgx_find_all_bytes_device(self._h, self._ctx, t.data_ptr(), ln, n, out.data_ptr(), capacity,
-                                                C.byref(res))
+        if own is None:
+            w = self._lib.rgx_find_all_bytes_device(self._h, self._ctx, t.data_ptr(), ln, n, out.data_ptr(), capacity,
+                                                    C.byref(res))
+        else:
+            w = self._lib.rgx_find_all_bytes_device_owned(self._h, self._ctx, t.data_ptr(), ln, n, out.data_ptr(), capacity,
+                                                          int(own[0]), int(own[1]), C.byref(res))
         _capi.check(w)
         return out.view(-1, self.ncap)[:w], res
 

@@ -71,7 +71,8 @@ int CheckCtx(const rgx_program* p, rgx_stream_ctx* c) {
 
 // Core: scan (+ carry fallback) (+ captures).  Inputs/outputs are device pointers.
 int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n, int32_t* d_spans,
-                      size_t cap_records, bool count_only, rgx_result* res, bool starts_only = false) {
+                      size_t cap_records, bool count_only, rgx_result* res, bool starts_only = false, int64_t own_lo = 0,
+                      int64_t own_hi = -1) {
   const DevTables& T = p->p.dev;
   if (res) memset(res, 0, sizeof *res);
   if (res) res->ncap = T.ncap;
@@ -101,6 +102,8 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   ScanParams P{};
   P.buf = d_buf; P.len = ilen; P.ntiles = ntiles; P.spans = d_spans; P.cap_records = (int64_t)cap_records;
   P.carry_in = nullptr; P.slice_unsynced = nullptr;
+  P.own_lo = (int32_t)std::max<int64_t>(0, std::min<int64_t>(own_lo, ilen));
+  P.own_hi = own_hi < 0 ? ilen : (int32_t)std::max<int64_t>(P.own_lo, std::min<int64_t>(own_hi, ilen));
   P.count_only = count_only ? 1 : 0;
   P.starts_only = starts_only ? 1 : 0;
 
@@ -322,6 +325,15 @@ RGX_API int64_t rgx_find_all_bytes_device(const rgx_program* p, rgx_stream_ctx* 
   int rc = CheckCtx(p, c);
   if (rc != RGX_OK) return rc;
   return FindAllDevice(p, c, d_buf, len, n, d_spans, cap_records, false, res);
+}
+
+RGX_API int64_t rgx_find_all_bytes_device_owned(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n,
+                                                int32_t* d_spans, size_t cap_records, int64_t own_lo, int64_t own_hi,
+                                                rgx_result* res) {
+  int rc = CheckCtx(p, c);
+  if (rc != RGX_OK) return rc;
+  if (own_lo < 0 || own_hi < own_lo) { SetError("bad owned range"); return RGX_E_INVALID; }
+  return FindAllDevice(p, c, d_buf, len, n, d_spans, cap_records, false, res, false, own_lo, own_hi);
 }
 
 RGX_API int64_t rgx_find_all_starts_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n,

@@ -14,6 +14,16 @@ constexpr unsigned long long kDescValMask = (1ull << 62) - 1;
 // Every spin is bounded: a poll costs ~1 us, a legitimate wait is far below a millisecond.
 constexpr unsigned kLookBackSpinLimit = 50000;
 
+// Bits b of a slice starting at absolute offset a whose position a+b lies in [lo, hi).
+__device__ __forceinline__ unsigned long long OwnMask(int a, int lo, int hi) {
+  int b0 = lo - a, b1 = hi - a;
+  b0 = b0 < 0 ? 0 : (b0 > 64 ? 64 : b0);
+  b1 = b1 < 0 ? 0 : (b1 > 64 ? 64 : b1);
+  const unsigned long long below_b1 = b1 >= 64 ? ~0ull : ((1ull << b1) - 1ull);
+  const unsigned long long below_b0 = b0 >= 64 ? ~0ull : ((1ull << b0) - 1ull);
+  return below_b1 & ~below_b0;
+}
+
 __device__ __forceinline__ unsigned WaveInclusiveScan(unsigned v, int lane) {
   unsigned x = v;
 #pragma unroll

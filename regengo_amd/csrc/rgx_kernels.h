@@ -19,6 +19,7 @@ struct ScanParams {
   unsigned long long* total;     // total matches; zeroed before launch
   unsigned long long* clean_next;   // nullable: the scratch set of the NEXT scan; this launch zeroes its first ntiles+4 words
   unsigned long long* host_result;  // nullable: pinned host words [0] = total, [1] = 1 if a rare-path counter is nonzero
+  int32_t own_lo, own_hi;           // only matches whose START lies in [own_lo, own_hi) are counted and written (shard ownership)
   const int32_t* carry_in;       // nullable; per slice: -1 = find a sync point locally, else search position
   uint8_t* slice_unsynced;       // nullable; set to 1 for slices that found no sync point
   int32_t count_only;

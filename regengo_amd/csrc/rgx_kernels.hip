@@ -269,6 +269,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
   }
 
   // ---- phase 2: ordered offsets.  lane -> wave -> block prefix sums, then decoupled look-back over tiles.
+  if (P.own_lo > 0 || P.own_hi < len) mask &= OwnMask(a, P.own_lo, P.own_hi);   // shard ownership
   const unsigned cnt = (unsigned)__popcll(mask);
   const unsigned incl = (unsigned)WaveInclusiveScan(cnt, lane);
   if (lane == 63) s_misc[1 + wave] = incl;

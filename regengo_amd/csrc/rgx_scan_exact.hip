@@ -294,6 +294,8 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
         }
       }
     }
+    // shard ownership: the chain is resolved over the whole window, only owned starts are reported (uniform test)
+    if (P.own_lo > tb0 || P.own_hi < tb0 + kWaveRows * kSliceBytes) s_sel &= OwnMask(a, P.own_lo, P.own_hi);
     sel[g] = s_sel;
     lane_cnt += (unsigned)__popcll(s_sel);
   }

@@ -254,6 +254,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_sa_kernel(DevTables T, Sca
   }
 
   // ---- phase 2: ordered offsets
+  if (P.own_lo > 0 || P.own_hi < len) sel &= OwnMask(a, P.own_lo, P.own_hi);   // shard ownership
   const unsigned cnt = (unsigned)__popcll(sel);
   const unsigned incl = WaveInclusiveScan(cnt, lane);
   if (lane == 63) L.misc[1 + wave] = incl;

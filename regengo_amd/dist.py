@@ -85,8 +85,10 @@ class ShardedFinder:
     `Compiled.FindAllSpans` (the HIP path); the CPU tests inject the test-only table walker to exercise the sharding
     logic under gloo.  reset_table: uint8/bool tensor [256], 1 for bytes on which every DFA state dies."""
 
-    def __init__(self, scan_fn, reset_table, group=None):
+    def __init__(self, scan_fn, reset_table, group=None, scan_owned_fn=None, bounded=False):
         self.scan = scan_fn
+        self.scan_owned = scan_owned_fn     # scan_owned(window, lo, hi): the kernel keeps only starts in [lo, hi)
+        self.bounded = bounded              # MaxMatchLen known: an owned match cannot run past the right halo
         self.reset_table = reset_table
         self.group = group
 
@@ -99,7 +101,60 @@ class ShardedFinder:
             spans, res = compiled.FindAllSpans(window)
             return spans, {"kernel_ms": res.kernel_ms, "unsynced": int(res.unsynced)}
 
-        return cls(scan, rt, group)
+        def scan_owned(window, lo, hi):
+            spans, res = compiled.FindAllSpans(window, own=(lo, hi))
+            return spans, {"kernel_ms": res.kernel_ms, "unsynced": int(res.unsynced)}
+
+        return cls(scan, rt, group, scan_owned, compiled.MaxMatchLen >= 0)
+
+    def find_all_sharded(self, window, shard: Shard, cdev=None, defer: bool = False):
+        """One step of the sharded FindAll: scan + the count exchange.  Returns (owned spans, count, info, row base,
+        global total, all counts).  With an ownership-aware scan (the HIP path) this is ONE kernel, ONE host sync for
+        its result and ONE 16-byte all_gather carrying [count, left-halo-has-no-sync-point]; if any rank reports a
+        halo without a sync point the step is redone through the r -> r+1 hand-off chain (find_all_local).
+        defer=True returns a zero-argument callable instead: the all_gather is in flight and the caller finishes the step
+        (calls it) after launching the next scan, so the collective's latency hides behind that scan -- the way a
+        FindReader pipeline consumes chunks."""
+        import torch
+        dist = self._dist()
+        if dist is None or self.scan_owned is None:
+            owned, cnt, info = self.find_all_local(window, shard)
+            base, total, counts = self.global_row_base(cnt, cdev if cdev is not None else window.device)
+            res = (owned, cnt, info, base, total, counts)
+            return (lambda: res) if defer else res
+        if cdev is None:
+            cdev = window.device if dist.get_backend(self.group) == "nccl" else "cpu"
+        h = shard.lo - shard.win_lo
+        if shard.win_lo == 0:
+            notok = torch.zeros(1, dtype=torch.int64, device=cdev)
+        elif h <= 0:
+            notok = torch.ones(1, dtype=torch.int64, device=cdev)
+        else:   # stays on the device: no host sync here
+            notok = (~self.reset_table[window[:h].long()].any()).to(torch.int64).reshape(1).to(cdev)
+        owned, info = self.scan_owned(window, shard.lo - shard.win_lo, shard.hi - shard.win_lo)
+        cnt = int(owned.shape[0])
+        mine = torch.cat([torch.tensor([cnt], dtype=torch.int64, device=cdev), notok])
+        world = dist.get_world_size(self.group)
+        allc = torch.empty(2 * world, dtype=torch.int64, device=cdev)
+        work = dist.all_gather_into_tensor(allc, mine, group=self.group, async_op=True)
+
+        def finish():
+            nonlocal owned, cnt, info
+            work.wait()
+            rows = allc.cpu().view(world, 2).tolist()
+            if any(r[1] for r in rows):
+                owned, cnt, info = self.find_all_local(window, shard)
+                base, total, counts = self.global_row_base(cnt, cdev)
+                return owned, cnt, info, base, total, counts
+            counts = [int(r[0]) for r in rows]
+            truncated = False
+            if not self.bounded and shard.win_hi < shard.total_len and cnt:
+                truncated = int(owned[cnt - 1, 1].item()) >= shard.win_hi - shard.win_lo
+            info2 = dict(info)
+            info2.update({"truncated": truncated, "chained": False})
+            return owned, cnt, info2, sum(counts[:shard.rank]), sum(counts), counts
+
+        return finish if defer else finish()
 
     def _dist(self):
         import torch.distributed as dist

@@ -22,7 +22,7 @@ def _free_port():
     return p
 
 
-def _worker(rank, world, port, pattern, data_bytes, halo_left, q):
+def _worker(rank, world, port, pattern, data_bytes, halo_left, q, combined=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -41,10 +41,19 @@ def _worker(rank, world, port, pattern, data_bytes, halo_left, q):
             t = torch.tensor(rows, dtype=torch.int32).reshape(-1, hp.info["ncap"])
             return t, {"kernel_ms": 0.0, "unsynced": 0}
 
+        def scan_owned(w, lo, hi):     # what rgx_find_all_bytes_device_owned does: whole-window chain, owned starts only
+            t, info = scan(w)
+            keep = (t[:, 0] >= lo) & (t[:, 0] < hi) if t.shape[0] else torch.zeros(0, dtype=torch.bool)
+            return t[keep], info
+
         rt = torch.tensor(list(hp.reset_bytes()), dtype=torch.uint8)
-        f = ShardedFinder(scan, rt)
-        owned, cnt, info = f.find_all_local(window, sh)
-        base, total, counts = f.global_row_base(cnt, "cpu")
+        if combined:
+            f = ShardedFinder(scan, rt, scan_owned_fn=scan_owned, bounded=hp.info["max"] >= 0)
+            owned, cnt, info, base, total, counts = f.find_all_sharded(window, sh, "cpu")
+        else:
+            f = ShardedFinder(scan, rt)
+            owned, cnt, info = f.find_all_local(window, sh)
+            base, total, counts = f.global_row_base(cnt, "cpu")
         allrows = f.gather_spans(owned, sh, counts)
         if rank == 0:
             q.put((allrows.tolist(), total, counts, info["chained"]))
@@ -54,11 +63,11 @@ def _worker(rank, world, port, pattern, data_bytes, halo_left, q):
         dist.destroy_process_group()
 
 
-def _run(pattern, data, halo_left=4096, world=2):
+def _run(pattern, data, halo_left=4096, world=2, combined=False):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, pattern, data, halo_left, q)) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, pattern, data, halo_left, q, combined)) for r in range(world)]
     for p in procs:
         p.start()
     outs = [q.get(timeout=120) for _ in range(world)]
@@ -115,3 +124,22 @@ def test_unbounded_pattern_two_ranks(built):
     exp, cnt = CMatcher(pat).find_all_np(np.frombuffer(data, dtype=np.uint8))
     assert total == cnt
     assert rows == exp.astype(np.int64).tolist()
+
+
+def test_combined_step_two_ranks(built):
+    """find_all_sharded (what bench.py times for N>1): ownership-aware scan + ONE all_gather of [count, no-sync flag];
+    both its fast path and its fall-back to the hand-off chain equal the single scan."""
+    from oracle.gen_c import CMatcher
+    from regengo_amd import synth
+    data = synth.date_log_np(200000, adversarial=True).tobytes()
+    (rows, total, counts, chained), outs = _run(DATE, data, combined=True)
+    exp, cnt = CMatcher(DATE).find_all_np(np.frombuffer(data, dtype=np.uint8))
+    assert total == cnt and sum(counts) == cnt and not chained
+    assert rows == exp.astype(np.int64).tolist()
+    rng = np.random.default_rng(5)
+    body = rng.choice(np.frombuffer(b"0123456789-", dtype=np.uint8), size=30000).tobytes()
+    data = b"start " + body + b" end 2024-01-15 "
+    (rows, total, counts, chained), outs = _run(DATE, data, halo_left=64, combined=True)
+    exp, cnt = CMatcher(DATE).find_all_np(np.frombuffer(data, dtype=np.uint8))
+    assert all(o[3] for o in outs), "expected the fall-back to the chained path"
+    assert total == cnt and rows == exp.astype(np.int64).tolist()

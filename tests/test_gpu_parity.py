@@ -328,6 +328,26 @@ def _csr(torch, strings):
     return concat, torch.tensor(offs, dtype=torch.int64, device="cuda:0")
 
 
+def test_owned_range_scan(torch_dev):
+    """rgx_find_all_bytes_device_owned (shard mode): chain over the whole window, only starts in [lo, hi) reported --
+    equal to filtering the full result, for all three scan kernels, with cut points inside matches and tiles."""
+    from regengo_amd import synth
+    torch = torch_dev
+    cases = [(DATE, synth.date_log_np(300000, adversarial=True)), (EMAIL, np.frombuffer(synth.web_log_tile()[:200000], dtype=np.uint8)),
+             (r"(\d+)", synth.date_log_np(100000, adversarial=True)), (r"\b[a-z]+\b", np.frombuffer(synth.web_log_tile()[:150000], dtype=np.uint8))]
+    for pat, arr in cases:
+        c = _gpu(pat)
+        buf = torch.from_numpy(arr.copy()).cuda()
+        full, r0 = c.FindAllSpans(buf)
+        full = full.cpu().numpy()
+        n = len(arr)
+        for lo, hi in ((0, n), (0, 0), (1, n - 1), (4097, 99991), (16320, 16321), (n // 2, n // 2 + 64), (n - 5, n), (n, n)):
+            got, r = c.FindAllSpans(buf, own=(lo, hi))
+            keep = (full[:, 0] >= lo) & (full[:, 0] < hi)
+            assert r.total == int(keep.sum()), (pat, lo, hi)
+            assert np.array_equal(got.cpu().numpy(), full[keep]), (pat, lo, hi)
+
+
 def test_starts_only_form(torch_dev):
     """Compact result for fixed-template patterns: starts + template reproduce the full span table bit for bit."""
     from regengo_amd import _capi, synth
