@@ -34,7 +34,7 @@ size_t ScanSharedBytes(const DevTables& T);
 int32_t ScanNumTiles(const DevTables& T, int32_t len);
 // rgx_scan_exact.hip: the branch-free Shift-And kernel for fixed-length class chains
 bool UseExactKernel(const DevTables& T, int32_t len);
-int ExactTileBytes();
+int ExactNumBlocks(int32_t len);
 hipError_t LaunchScanExact(const DevTables& T, const ScanParams& P, hipStream_t stream);
 // rgx_scan_sa.hip: same structure, Shift-And as a prefilter + DFA verification (variable-length matches)
 bool UseSaKernel(const DevTables& T, int32_t len);

@@ -926,7 +926,8 @@ size_t ScanSharedBytes(const DevTables& T) {
 }
 
 int32_t ScanNumTiles(const DevTables& T, int32_t len) {
-  const int per = UseExactKernel(T, len) ? ExactTileBytes() : ((UseSaKernel(T, len) && !getenv("RGX_NO_SA_KERNEL")) ? SaTileBytes() : kTileBytes);
+  if (UseExactKernel(T, len)) return ExactNumBlocks(len);
+  const int per = (UseSaKernel(T, len) && !getenv("RGX_NO_SA_KERNEL")) ? SaTileBytes() : kTileBytes;
   return (len + per - 1) / per;
 }
 

@@ -43,6 +43,19 @@ constexpr int kWaveLds = kWaveRows * kRowBytes;               // 5200 bytes
 constexpr int kGroupTiles = 8;                                // wave-tiles per look-back descriptor
 constexpr int kStartsCap = kWaveLds / 4;                      // match starts staged per flush
 
+// Work plan: workgroup b owns `g` wave-tiles per wave, starting at wave-tile `tile`; segments of equal g.  Sizes ramp
+// UP over the first wave of resident workgroups (they all start together: with equal sizes they would all finish
+// counting together and the look-back would be a chain through every one of them; with growing sizes a workgroup's
+// predecessors have already published) and ramp DOWN at the end (a short tail instead of half a chunk of idle CUs).
+constexpr int kPlanSegs = 16;
+struct ExactPlan {
+  int nseg;
+  int nblocks;
+  int seg_block[kPlanSegs];   // first workgroup of the segment
+  int seg_tile[kPlanSegs];    // its first wave-tile
+  int seg_g[kPlanSegs];       // wave-tiles per wave in the segment (1..kGroupTiles)
+};
+
 typedef unsigned v4u __attribute__((ext_vector_type(4)));
 typedef int v4i __attribute__((ext_vector_type(4)));
 
@@ -86,7 +99,7 @@ __device__ __forceinline__ unsigned DppInclusiveScan(unsigned x) {
 // PER = dwords between two harvests of the accept history: 4*PER <= 33-K.  W16 (K <= 16): 16-bit table entries, which
 // halves the number of distinct byte values sharing an LDS bank (on ASCII text: far fewer bank conflicts).
 template <int PER, bool W16>
-__global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, ScanParams P) {
+__global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, ScanParams P, ExactPlan plan) {
   __shared__ ExactLds L;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -114,9 +127,12 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
     if (tid == 0) P.clean_next[4 + blk] = 0;
     if (blk == 0) P.clean_next[tid] = 0;
   }
-  const int group = blk * (kBlockThreads / 64) + wave;   // this wave's range of tiles; one look-back descriptor per BLOCK
+  // this wave's range of tiles (one look-back descriptor per BLOCK)
+  int seg = 0;
+  for (int i = 1; i < plan.nseg; ++i) if (blk >= plan.seg_block[i]) seg = i;      // uniform, <= 15 scalar compares
+  const int G = plan.seg_g[seg];
+  const int first_tile = plan.seg_tile[seg] + ((blk - plan.seg_block[seg]) * (kBlockThreads / 64) + wave) * G;
   unsigned char* const wt = L.tile[wave];
-  const int first_tile = group * kGroupTiles;
 
   // Prefetch depth 2: the 4 KiB of tiles g+1 and g+2 are in flight (in VGPRs) while tile g is processed -- one tile
   // ahead leaves only ~96 KiB per CU in flight, which measured 4.6 TB/s; HBM wants more.
@@ -128,7 +144,12 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
   // below ignores it anyway), the four chunks of a lane differ only in the instruction's immediate offset, so a tile costs
   // ONE address add.  num_records is rounded up to the 16-byte chunk holding the last byte (same page, base is aligned).
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(P.buf), 0, (len + 15) & ~15, 0x00020000);
-  const int lane16 = lane << 4;
+  // Which 16-byte chunk of each 1 KiB a lane moves: a ds_write_b128 is served 8 lanes at a time over 32 banks, and rows
+  // r, r+1 of the 80-byte layout overlap in 4 banks -- so a group of 8 lanes takes rows r and r+4 instead (disjoint
+  // bank sets).  Any permutation inside the 1 KiB is equally coalesced for the global load.
+  const int wg8 = lane >> 3, wk = lane & 7;
+  const int srow = ((wg8 >> 2) << 3) + (wg8 & 3) + ((wk >> 2) << 2);   // row (0..15) within the 16 rows of one load
+  const int lane16 = (srow << 6) + ((wk & 3) << 4);                       // byte offset of the chunk inside the 1 KiB
 #define RGX_LOAD_TILE(S, tb)                                                                          \
   {                                                                                                   \
     const int vo = (tb) + lane16;                                                                     \
@@ -153,14 +174,14 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
 
   unsigned long long sel[kGroupTiles];
   unsigned lane_cnt = 0;      // this lane's matches over the group's tiles
-  const int put = (lane >> 2) * kRowBytes + ((lane & 3) << 4);
+  const int put = srow * kRowBytes + ((wk & 3) << 4);
   const int nla = (K + 2) >> 2;          // look-ahead dwords: ceil((K-1)/4)
 
 #pragma unroll
   for (int g = 0; g < kGroupTiles; ++g) {
     sel[g] = 0;
     const int tb0 = (first_tile + g) * kWaveTileBytes - kSliceBytes;   // absolute offset of slice 0 (-64 for tile 0)
-    if (tb0 + kSliceBytes >= len) continue;                            // uniform: nothing owned by this tile
+    if (g >= G || tb0 + kSliceBytes >= len) continue;                  // uniform: nothing owned by this tile
 
     // ---- stage this tile from the prefetched registers, then prefetch the next one
     *reinterpret_cast<v4u*>(wt + put) = pv[g & 1][0];
@@ -170,7 +191,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
     if (lane < 2) *reinterpret_cast<v4u*>(wt + 64 * kRowBytes + (lane << 4)) = pv[g & 1][4];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (g + 2 < kGroupTiles && tb0 + 2 * kWaveTileBytes + kSliceBytes < len && !(P.debug & 16)) RGX_LOAD_TILE(g & 1, tb0 + 2 * kWaveTileBytes)
+    if (g + 2 < G && tb0 + 2 * kWaveTileBytes + kSliceBytes < len && !(P.debug & 16)) RGX_LOAD_TILE(g & 1, tb0 + 2 * kWaveTileBytes)
 
     // ---- candidate mask of this lane's slice (match starts in [a, a+64))
     const int a = tb0 + lane * kSliceBytes;
@@ -408,22 +429,68 @@ bool UseExactKernel(const DevTables& T, int32_t len) {
   return len >= 64 && T.sa_exact && T.sa_k >= 1 && T.sa_k <= 29 && T.fixed_captures && !T.anchored && T.ncap <= 32;
 }
 
-// bytes of input per look-back descriptor (ScanParams::ntiles counts descriptors = wave groups)
-int ExactTileBytes() { return (kBlockThreads / 64) * kGroupTiles * kWaveTileBytes; }
+namespace {
+
+int ResidentWorkgroups() {
+  static int r = 0;
+  if (r) return r;
+  int dev = 0, cus = 0, occ = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_exact_kernel<4, true>, kBlockThreads, 0) != hipSuccess || occ <= 0) occ = 5;
+  (void)hipGetLastError();
+  const char* e = getenv("RGX_RESIDENT");
+  r = e ? atoi(e) : cus * occ;
+  if (r < 8) r = 8;
+  return r;
+}
+
+ExactPlan MakePlan(int32_t len) {
+  ExactPlan p{};
+  const int wpb = kBlockThreads / 64;
+  const long long W = ((long long)len + kWaveTileBytes - 1) / kWaveTileBytes;      // wave-tiles in the input
+  const int L = ResidentWorkgroups() / kGroupTiles;                                 // workgroups per ramp level
+  long long ramp = 0;
+  for (int v = 1; v < kGroupTiles; ++v) ramp += 2LL * L * wpb * v;
+  static const bool flat = getenv("RGX_FLAT_PLAN") != nullptr;
+  int nseg = 0;
+  long long blk = 0, tile = 0;
+  auto add = [&](int g, long long nb) {
+    if (nb <= 0) return;
+    p.seg_block[nseg] = (int)blk; p.seg_tile[nseg] = (int)tile; p.seg_g[nseg] = g; ++nseg;
+    blk += nb; tile += nb * wpb * g;
+  };
+  if (flat || W <= ramp + 4LL * L * wpb * kGroupTiles) {
+    add(kGroupTiles, (W + wpb * kGroupTiles - 1) / (wpb * kGroupTiles));
+  } else {
+    for (int v = 1; v < kGroupTiles; ++v) add(v, L);
+    const long long bulk = W - ramp;
+    add(kGroupTiles, (bulk + wpb * kGroupTiles - 1) / (wpb * kGroupTiles));
+    for (int v = kGroupTiles - 1; v >= 1; --v) add(v, L);
+  }
+  p.nseg = nseg;
+  p.nblocks = (int)blk;
+  return p;
+}
+
+}  // namespace
+
+// look-back descriptors (= workgroups) the scan of `len` bytes uses
+int ExactNumBlocks(int32_t len) { return MakePlan(len).nblocks; }
 
 hipError_t LaunchScanExact(const DevTables& T, const ScanParams& P, hipStream_t stream) {
   dim3 block(kBlockThreads);
-  dim3 grid(P.ntiles);
+  const ExactPlan plan = MakePlan(P.len);
+  dim3 grid(plan.nblocks);
   const int K = T.sa_k;
   static int debug = -1;   // experiment switches (RGX_DEBUG): 8 = skip the byte loop, 16 = skip the global loads
   if (debug < 0) { const char* e = getenv("RGX_DEBUG"); debug = e ? atoi(e) : 0; }
   ScanParams Q = P;
   Q.debug = debug;
   static const bool no16 = getenv("RGX_NO_W16") != nullptr;
-  if (K <= 16 && !no16) hipLaunchKernelGGL((scan_exact_kernel<4, true>), grid, block, 0, stream, T, Q);
-  else if (K <= 17) hipLaunchKernelGGL((scan_exact_kernel<4, false>), grid, block, 0, stream, T, Q);
-  else if (K <= 25) hipLaunchKernelGGL((scan_exact_kernel<2, false>), grid, block, 0, stream, T, Q);
-  else hipLaunchKernelGGL((scan_exact_kernel<1, false>), grid, block, 0, stream, T, Q);
+  if (K <= 16 && !no16) hipLaunchKernelGGL((scan_exact_kernel<4, true>), grid, block, 0, stream, T, Q, plan);
+  else if (K <= 17) hipLaunchKernelGGL((scan_exact_kernel<4, false>), grid, block, 0, stream, T, Q, plan);
+  else if (K <= 25) hipLaunchKernelGGL((scan_exact_kernel<2, false>), grid, block, 0, stream, T, Q, plan);
+  else hipLaunchKernelGGL((scan_exact_kernel<1, false>), grid, block, 0, stream, T, Q, plan);
   return hipGetLastError();
 }
 
