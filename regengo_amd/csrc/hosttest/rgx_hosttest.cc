@@ -252,6 +252,20 @@ int64_t rgxt_find_all_sa(void* hh, const uint8_t* buf, int64_t len, int32_t* spa
 }
 int rgxt_sa_info(void* hh, int32_t* k, int32_t* exact) { *k = ((Handle*)hh)->t.sa_k; *exact = ((Handle*)hh)->t.sa_exact; return 0; }
 
+// Sync automaton: flags[i] = 1 iff W, started in its "every position" state at offset y, is EMPTY at offset i
+// (y < i <= len): no match that began before i can still be running there.  Returns the number of W states (0: none).
+int rgxt_w_sync(void* hh, const uint8_t* buf, int64_t len, int64_t y, uint8_t* flags) {
+  const Tables& t = ((Handle*)hh)->t;
+  memset(flags, 0, (size_t)len + 1);
+  if (t.w_nstates == 0) return 0;
+  unsigned q = t.w_start;
+  for (int64_t i = y; i < len; i++) {
+    q = t.w_trans[(size_t)q * t.ncls + t.cls[buf[i]]];
+    if (q == 0) flags[i + 1] = 1;
+  }
+  return t.w_nstates;
+}
+
 // Plain leftmost-first "is there a match" (MatchBytes without the reference's Q1 restart quirk).
 int rgxt_match(void* hh, const uint8_t* buf, int64_t len) {
   const Tables& t = ((Handle*)hh)->t;

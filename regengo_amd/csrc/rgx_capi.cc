@@ -26,6 +26,7 @@ struct rgx_stream_ctx {
   hipStream_t stream = nullptr;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool timing = false;
+  bool prefer_w = false;       // an earlier scan needed the sync automaton: start with it
   // device scratch
   unsigned long long* d_desc = nullptr; int64_t desc_cap = 0;   // two scratch sets, see FindAllDevice
   int64_t set_words = 0, dirty[2] = {0, 0};
@@ -81,7 +82,13 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   if ((uintptr_t)d_buf & 15) { SetError("input device pointer must be 16-byte aligned"); return RGX_E_INVALID; }
   if (!count_only && ((uintptr_t)d_spans & 15)) { SetError("span device pointer must be 16-byte aligned"); return RGX_E_INVALID; }
   const int32_t ilen = (int32_t)len;
-  const int32_t ntiles = ScanNumTiles(T, ilen);
+  // sync points: reset bytes by default; the sync automaton W (rgx_dfa.h) when the pattern has no reset byte at all or
+  // when an earlier scan of this context found slices without one (then the scan kernel takes W, ScanParams::use_w)
+  static const bool force_w = getenv("RGX_FORCE_W") != nullptr;
+  const bool w_ok = ScanSupportsW(T, ilen);
+  bool use_w = w_ok && (c->prefer_w || T.reset_values == 0 || force_w);
+  int32_t ntiles = ScanNumTiles(T, ilen, use_w);
+  const int32_t ntiles_max = std::max(ntiles, std::max(ScanNumTiles(T, ilen, false), ScanNumTiles(T, ilen, true)));
   const int32_t nslices = (ilen + kSliceBytes - 1) / kSliceBytes;
   int rc;
   // Device scratch: TWO sets of [total u64][trace cursor u64][counters 4 x u32][look-back descriptors ...], used
@@ -89,7 +96,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   // workgroup) and writes its total straight into pinned host memory, so a steady stream of scans costs one kernel
   // launch and one stream synchronise each -- no memset node, no copy node.  `dirty[s]` = leading words of set s that
   // are not known to be zero; anything the kernel cannot vouch for is cleared with a real memset.
-  const size_t desc_words = (size_t)ntiles + 4;
+  const size_t desc_words = (size_t)ntiles_max + 4;
   if (c->desc_cap < (int64_t)(2 * desc_words) || !c->d_desc) {
     if (c->d_desc) { hipFree(c->d_desc); c->d_desc = nullptr; c->desc_cap = 0; }
     if ((rc = Ensure(&c->d_desc, &c->desc_cap, (int64_t)(2 * desc_words + 64))) != RGX_OK) return rc;
@@ -100,7 +107,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   const bool self_clean = UseExactKernel(T, ilen) && getenv("RGX_NO_SELF_CLEAN") == nullptr;
 
   ScanParams P{};
-  P.buf = d_buf; P.len = ilen; P.ntiles = ntiles; P.spans = d_spans; P.cap_records = (int64_t)cap_records;
+  P.buf = d_buf; P.len = ilen; P.ntiles = ntiles; P.use_w = use_w ? 1 : 0; P.spans = d_spans; P.cap_records = (int64_t)cap_records;
   P.carry_in = nullptr; P.slice_unsynced = nullptr;
   P.own_lo = (int32_t)std::max<int64_t>(0, std::min<int64_t>(own_lo, ilen));
   P.own_hi = own_hi < 0 ? ilen : (int32_t)std::max<int64_t>(P.own_lo, std::min<int64_t>(own_hi, ilen));
@@ -156,6 +163,17 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   float ms = 0;
   if (c->timing) hipEventElapsedTime(&ms, c->ev0, c->ev1);
   uint32_t unsynced = ((uint32_t*)&c->h_read[2])[1];
+  if (unsynced && w_ok && !use_w) {
+    // slices without a reset byte in reach: take the sync points from W from now on (this context remembers)
+    use_w = true;
+    c->prefer_w = true;
+    ntiles = ScanNumTiles(T, ilen, true);
+    P.ntiles = ntiles;
+    P.use_w = 1;
+    if ((rc = run_scan(c->timing)) != RGX_OK) return rc;
+    if (c->timing) hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    unsynced = ((uint32_t*)&c->h_read[2])[1];
+  }
   if (unsynced) {
     // rare path: some slices found no sync point; resolve their entry positions serially and rescan.
     if ((rc = Ensure(&c->d_unsynced, &c->slice_cap, nslices)) != RGX_OK) return rc;

@@ -50,7 +50,7 @@ __device__ __forceinline__ unsigned long long WaveSum64(unsigned long long v) {
 // scan in ticket mode.  Results never depend on the assumption, only speed does.
 __device__ __forceinline__ unsigned long long LookBack(unsigned long long* desc, int id, unsigned long long own, int lane,
                                                         unsigned* timeout_flag, int nap = 1,
-                                                        unsigned long long* host_flag = nullptr) {
+                                                        unsigned long long* host_flag = nullptr, bool bounded = true) {
   unsigned long long excl = 0;
   if (lane == 0)
     __hip_atomic_store(&desc[id], (id == 0 ? kDescPrefix : kDescAgg) | own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -63,7 +63,7 @@ __device__ __forceinline__ unsigned long long LookBack(unsigned long long* desc,
         d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
         while ((d >> 62) == 0) {
-          if (++spins > kLookBackSpinLimit) { dead = true; break; }
+          if (bounded && ++spins > kLookBackSpinLimit) { dead = true; break; }   // ticket ids cannot deadlock: wait as long as it takes
           for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(8);
           d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }

@@ -202,6 +202,28 @@ struct Builder {
     };
     for (size_t i = 0; i < pre.size(); i++) add(pre[i], (int)i, 0);
   }
+
+  // Unordered closure for the sync automaton: every byte-consuming position reachable from `pre` through epsilon
+  // edges, zero-width assertions taken as true, Match ignored.
+  void ExpandAll(const std::vector<int>& pre, std::vector<int>* leaves) const {
+    std::vector<char> seen(nodes.size(), 0);
+    std::function<void(int)> add = [&](int id) {
+      if (id >= ninst) {
+        if (!seen[id]) { seen[id] = 1; leaves->push_back(id); }
+        return;
+      }
+      if (seen[id]) return;
+      seen[id] = 1;
+      const Inst& in = p.inst[id];
+      switch (in.op) {
+        case InstFail: case InstMatch: return;
+        case InstNop: case InstCapture: case InstEmptyWidth: add(in.out); return;
+        case InstAlt: case InstAltMatch: add(in.out); add(in.arg); return;
+        default: leaves->push_back(id); return;
+      }
+    };
+    for (int x : pre) add(x);
+  }
 };
 
 // distance analysis for fixed capture templates
@@ -506,6 +528,51 @@ Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOption
     if (K == 0) memset(t.sa_mask, 0, sizeof t.sa_mask);
   }
 
+  // ---- sync automaton W (see rgx_dfa.h)
+  if (!opt.unanchored_search) {
+    constexpr int kMaxW = 1024;
+    std::vector<int> fresh;
+    b.ExpandAll({prog.start}, &fresh);
+    std::sort(fresh.begin(), fresh.end());
+    std::vector<int> all;
+    for (int id = 0; id < (int)b.nodes.size(); id++) if (b.nodes[id].bytes.any()) all.push_back(id);
+    std::map<std::vector<int>, int> wid;
+    std::vector<std::vector<int>> wstates;
+    wid[{}] = 0; wstates.push_back({});
+    bool ok = true;
+    auto wintern = [&](const std::vector<int>& v) -> int {
+      auto it = wid.find(v);
+      if (it != wid.end()) return it->second;
+      if ((int)wstates.size() >= kMaxW) { ok = false; return 0; }
+      int id = (int)wstates.size();
+      wid.emplace(v, id); wstates.push_back(v);
+      return id;
+    };
+    const int w_all = wintern(all);
+    std::vector<uint16_t> wt;
+    for (size_t q = 0; q < wstates.size() && ok; q++) {
+      wt.resize((q + 1) * ncls, 0);
+      std::vector<int> src = wstates[q];
+      src.insert(src.end(), fresh.begin(), fresh.end());   // threads starting at the current offset are "earlier" one byte on
+      std::sort(src.begin(), src.end());
+      src.erase(std::unique(src.begin(), src.end()), src.end());
+      for (int k = 0; k < ncls && ok; k++) {
+        std::vector<int> targets;
+        for (int node : src) {
+          if (!b.NodeAccepts(node, k)) continue;
+          const Node& nd = b.nodes[node];
+          targets.push_back(nd.next_node >= 0 ? nd.next_node : nd.out_pc);
+        }
+        std::vector<int> leaves;
+        b.ExpandAll(targets, &leaves);
+        std::sort(leaves.begin(), leaves.end());
+        leaves.erase(std::unique(leaves.begin(), leaves.end()), leaves.end());
+        wt[q * ncls + k] = (uint16_t)wintern(leaves);
+      }
+    }
+    if (ok) { t.w_nstates = (int)wstates.size(); t.w_start = (uint16_t)w_all; t.w_trans = wt; }
+  }
+
   return t;
 }
 
@@ -537,7 +604,7 @@ struct R {
   void raw(void* d, size_t k) { if (o + k > n) { ok = false; return; } memcpy(d, p + o, k); o += k; }
 };
 constexpr uint32_t kMagic = 0x54584752;  // "RGXT"
-constexpr uint32_t kBlobVersion = 1;
+constexpr uint32_t kBlobVersion = 2;
 }  // namespace
 
 std::vector<uint8_t> SerializeTables(const Tables& t) {
@@ -554,6 +621,7 @@ std::vector<uint8_t> SerializeTables(const Tables& t) {
   w.vec(t.cap_kind); w.vec(t.cap_delta); w.vec(t.st_nthreads); w.vec(t.bt_base); w.vec(t.bt_parent); w.vec(t.bt_ops);
   w.vec(t.bt_match); w.vec(t.start_ops); w.vec(t.start_ops_pool); w.pod<int32_t>(t.max_threads); w.pod<int32_t>(t.fixed_len);
   w.raw(t.sa_mask, sizeof t.sa_mask); w.pod<int32_t>(t.sa_k); w.pod<uint8_t>(t.sa_exact);
+  w.pod<int32_t>(t.w_nstates); w.pod<uint16_t>(t.w_start); w.vec(t.w_trans);
   return w.b;
 }
 
@@ -577,7 +645,9 @@ bool DeserializeTables(const uint8_t* p, size_t n, Tables* t) {
   r.vec(t->cap_kind); r.vec(t->cap_delta); r.vec(t->st_nthreads); r.vec(t->bt_base); r.vec(t->bt_parent); r.vec(t->bt_ops);
   r.vec(t->bt_match); r.vec(t->start_ops); r.vec(t->start_ops_pool); r.pod(i32); t->max_threads = i32; r.pod(i32); t->fixed_len = i32;
   r.raw(t->sa_mask, sizeof t->sa_mask); r.pod(i32); t->sa_k = i32; r.pod(u8); t->sa_exact = u8;
+  r.pod(i32); t->w_nstates = i32; r.pod(t->w_start); r.vec(t->w_trans);
   if (!r.ok) return false;
+  if (t->w_nstates < 0 || t->w_trans.size() != (size_t)t->w_nstates * t->ncls || (t->w_nstates && t->w_start >= t->w_nstates)) return false;
   if (t->ncls < 1 || t->ncls > 256 || t->nstates < 1 || t->trans.size() != (size_t)t->nstates * (t->ncls + 1)) return false;
   if ((int)t->cap_kind.size() != t->ncap || (int)t->cap_delta.size() != t->ncap) return false;
   return true;

@@ -24,6 +24,7 @@ struct ScanParams {
   uint8_t* slice_unsynced;       // nullable; set to 1 for slices that found no sync point
   int32_t count_only;
   int32_t starts_only;           // fixed-template patterns: write one int32 (match start) per match instead of ncap
+  int32_t use_w;                 // sync points from the sync automaton W (rgx_dfa.h) instead of reset bytes: scan_kernel only
   int32_t use_tickets;           // 1: tile/group ids from the ticket counter; 0: blockIdx.x (bounded spin, host falls back)
   int32_t debug;                 // experiment switches (RGX_DEBUG): 1 = unordered base (no look-back), 2 = no span stores
 };
@@ -31,7 +32,7 @@ struct ScanParams {
 // FindAllBytes scan: one pass over the input, ordered span records out.
 hipError_t LaunchScan(const DevTables& T, const ScanParams& P, hipStream_t stream);
 size_t ScanSharedBytes(const DevTables& T);
-int32_t ScanNumTiles(const DevTables& T, int32_t len);
+int32_t ScanNumTiles(const DevTables& T, int32_t len, bool use_w = false);
 // rgx_scan_exact.hip: the branch-free Shift-And kernel for fixed-length class chains
 bool UseExactKernel(const DevTables& T, int32_t len);
 int ExactNumBlocks(int32_t len);
@@ -44,6 +45,8 @@ hipError_t LaunchScanSa(const DevTables& T, const ScanParams& P, const uint16_t*
 // Serial carry resolution for slices without a local sync point (rare path).
 hipError_t LaunchCarry(const DevTables& T, const uint8_t* buf, int32_t len, const uint8_t* slice_unsynced, int32_t* carry_in,
                        int32_t nslices, hipStream_t stream);
+// true when the scan of `len` bytes would run a kernel that can take its sync points from W (ScanParams::use_w)
+bool ScanSupportsW(const DevTables& T, int32_t len);
 
 // Capture groups for patterns whose captures are not a fixed template: per-match state trace + back-trace.
 // `trace` is scratch of at least (len + nmatches + 64) uint16; `trace_cursor` a zeroed uint64.

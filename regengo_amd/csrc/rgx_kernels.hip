@@ -27,6 +27,7 @@ namespace rgx {
 namespace {
 
 constexpr int kWindow = kHaloL + kTileBytes + kHaloR;          // bytes of input visible in LDS
+constexpr int kMaxLookBehind = 1024;                           // a lane re-walks at most this far from its sync point
 constexpr int kPaddedWindow = kWindow + (kWindow / 64) * 4;    // 64-byte rows padded to 68: lane stride 17 dwords
 __device__ __forceinline__ int PadAddr(int rel) { return rel + ((rel >> 6) << 2); }
 
@@ -116,6 +117,8 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
   unsigned char* s_kind = reinterpret_cast<unsigned char*>(s_delta + 32);     // 32
   unsigned* s_misc = reinterpret_cast<unsigned*>(s_kind + 32);                // [0] tile, [1..4] wave totals, [8..9] base
   unsigned* s_sa = s_misc + 16;                                               // 256 level-set masks
+  int* s_sync = reinterpret_cast<int*>(s_sa + 256);                           // [4 halo slices + 256 slices] last W sync point
+  uint16_t* s_w = reinterpret_cast<uint16_t*>(s_sync + 4 + kBlockThreads);    // sync automaton [w_nstates][ncls]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -138,6 +141,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
     s_ctx[tid] = T.ctx_of_byte[tid];
     if (tid < T.ncap) { s_delta[tid] = T.cap_delta[tid]; s_kind[tid] = T.cap_kind[tid]; }
     if (SA) s_sa[tid] = (T.sa_mask[tid] << (29 - T.sa_k)) | (7u << 29);   // accept bit at 28, history at 29..31
+    if (P.use_w) for (int w = tid; w < T.w_nstates * T.ncls; w += kBlockThreads) s_w[w] = T.w_trans[w];
   }
   __syncthreads();
   const int tile = (int)s_misc[0];
@@ -181,6 +185,28 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
   const int a = tb + tid * kSliceBytes;
   int slice_end = a + kSliceBytes;
   if (slice_end > len) slice_end = len;
+  const bool use_w = P.use_w && T.w_nstates > 0;   // uniform
+  if (use_w) {
+    // Sync points from the sync automaton: every lane walks W, blind, over its own slice (lanes 0..3 also over the four
+    // halo slices) and publishes the LAST offset at which W was empty; a lane then starts from the nearest such offset
+    // in the slices before its own.  Works for patterns without a single reset byte (`\s+(?P<msg>.*)`).
+    const int ncls = T.ncls;
+    auto walk = [&](int from, int to) {
+      int sp = -1;
+      unsigned q = (unsigned)T.w_start;
+      for (int i = from; i < to; ++i) {
+        q = s_w[q * ncls + s_cls[in.At(i)]];
+        if (q == 0) sp = i + 1;
+      }
+      return sp;
+    };
+    s_sync[4 + tid] = a < len ? walk(a, slice_end) : -1;
+    if (tid < 4) {
+      const int ha = tb - kHaloL + tid * kSliceBytes;
+      s_sync[tid] = ha >= 0 ? walk(ha, ha + kSliceBytes) : -1;
+    }
+    __syncthreads();
+  }
   unsigned long long mask = 0;
   if (a < len) {
     int pos;
@@ -188,8 +214,17 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
     const int carried = P.carry_in ? P.carry_in[slice] : -1;
     if (carried >= 0) pos = carried;
     else if (a == 0) pos = 0;
-    else {
+    else if (use_w) {
+      // a sync point further back than kMaxLookBehind is not worth the re-walk: leave the slice to the carry pass
+      int s = 4 + tid - 1;
+      const int s_min = s - kMaxLookBehind / kSliceBytes > 0 ? s - kMaxLookBehind / kSliceBytes : 0;
+      while (s >= s_min && s_sync[s] < 0) --s;
+      if (s >= s_min) pos = s_sync[s];
+      else if (wb <= 0 && a <= kMaxLookBehind) pos = 0;      // close to the start of the buffer: offset 0 is a sync point
+      else { synced = false; pos = slice_end; }
+    } else {
       int lower = wb < 0 ? 0 : wb;
+      if (lower < a - kMaxLookBehind) lower = a - kMaxLookBehind;   // further back is not worth the re-walk
       int j = a - 1;
       while (j >= lower && !s_reset[in.At(j)]) --j;
       if (j >= lower) pos = j + 1;
@@ -287,7 +322,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
   }
   if (wave == 0) {
     if (lane == 0 && block_total) atomicAdd(P.total, (unsigned long long)block_total);
-    const unsigned long long excl = LookBack(P.tile_desc, tile, block_total, lane, &P.counters[3]);
+    const unsigned long long excl = LookBack(P.tile_desc, tile, block_total, lane, &P.counters[3], 1, nullptr, !P.use_tickets);
     if (lane == 0) { s_misc[8] = (unsigned)excl; s_misc[9] = (unsigned)(excl >> 32); }
   }
   __syncthreads();
@@ -345,9 +380,24 @@ __global__ void carry_kernel(DevTables T, const uint8_t* buf, int32_t len, const
   int pos = 0;
   if (s > 0) {
     const int a_prev = (s - 1) * kSliceBytes;
-    int j = a_prev - 1;
-    while (j >= 0 && !T.reset_byte[buf[j]]) --j;   // the scan kernel found one within its window, so this terminates early
-    pos = j + 1;
+    if (T.w_nstates > 0) {
+      // nearest offset <= a_prev at which the sync automaton, walked blind over a growing look-behind, is empty
+      int found = -1;
+      for (int back = 256; found < 0; back <<= 1) {
+        const int y = a_prev - back > 0 ? a_prev - back : 0;
+        unsigned q = (unsigned)T.w_start;
+        for (int i = y; i < a_prev; ++i) {
+          q = T.w_trans[q * T.ncls + T.cls[buf[i]]];
+          if (q == 0) found = i + 1;
+        }
+        if (y == 0) break;
+      }
+      pos = found < 0 ? 0 : found;
+    } else {
+      int j = a_prev - 1;
+      while (j >= 0 && !T.reset_byte[buf[j]]) --j;   // the scan kernel found one within its window, so this terminates early
+      pos = j + 1;
+    }
   }
   int cur = s;
   const int run_begin = s * kSliceBytes;
@@ -922,18 +972,21 @@ size_t ScanSharedBytes(const DevTables& T) {
   size_t b = (kPaddedWindow + 15) & ~15;
   b += (T.table_bytes + 15) & ~15;
   b += 256 * 3 + 32 * 4 + 32 + 16 * 4 + 256 * 4;
+  b += (4 + kBlockThreads) * 4 + ((T.w_nstates * T.ncls * 2 + 15) & ~15);
   return (b + 15) & ~size_t(15);
 }
 
-int32_t ScanNumTiles(const DevTables& T, int32_t len) {
+int32_t ScanNumTiles(const DevTables& T, int32_t len, bool use_w) {
   if (UseExactKernel(T, len)) return ExactNumBlocks(len);
-  const int per = (UseSaKernel(T, len) && !getenv("RGX_NO_SA_KERNEL")) ? SaTileBytes() : kTileBytes;
+  const int per = (UseSaKernel(T, len) && !getenv("RGX_NO_SA_KERNEL") && !use_w) ? SaTileBytes() : kTileBytes;
   return (len + per - 1) / per;
 }
 
+bool ScanSupportsW(const DevTables& T, int32_t len) { return T.w_nstates > 0 && !UseExactKernel(T, len) && !T.anchored; }
+
 hipError_t LaunchScan(const DevTables& T, const ScanParams& P, hipStream_t stream) {
   if (UseExactKernel(T, P.len)) return LaunchScanExact(T, P, stream);
-  if (UseSaKernel(T, P.len) && !getenv("RGX_NO_SA_KERNEL")) return LaunchScanSa(T, P, T.trans_cls, stream);
+  if (UseSaKernel(T, P.len) && !getenv("RGX_NO_SA_KERNEL") && !P.use_w) return LaunchScanSa(T, P, T.trans_cls, stream);
   const size_t shmem = ScanSharedBytes(T);
   dim3 grid(P.ntiles), block(kBlockThreads);
   static bool attr_set[8] = {false, false, false, false, false, false, false, false};

@@ -88,6 +88,11 @@ int UploadTables(const Tables& t, std::vector<uint16_t>* direct_table, DevTables
   size_t off_sop = a.AddVec(t.start_ops_pool);
   size_t off_sa = a.Add(t.sa_mask, sizeof t.sa_mask);
   size_t off_tcls = a.AddVec(t.trans);
+  size_t off_w = a.AddVec(t.w_trans);
+  d.w_nstates = ((size_t)t.w_nstates * t.ncls * 2 <= 8 * 1024) ? t.w_nstates : 0;   // kept in LDS by the kernels
+  d.w_start = t.w_start;
+  d.reset_values = 0;
+  for (int c = 0; c < 256; c++) d.reset_values += t.reset_byte[c] ? 1 : 0;
 
   void* dptr = nullptr;
   if (hipMalloc(&dptr, a.host.size()) != hipSuccess) { SetError("hipMalloc(tables) failed"); return RGX_E_NOMEM; }
@@ -105,6 +110,7 @@ int UploadTables(const Tables& t, std::vector<uint16_t>* direct_table, DevTables
   d.start_ops = (const uint32_t*)(b + off_so); d.start_ops_pool = (const uint32_t*)(b + off_sop);
   d.sa_mask = (const uint32_t*)(b + off_sa);
   d.trans_cls = (const uint16_t*)(b + off_tcls);
+  d.w_trans = (const uint16_t*)(b + off_w);
   *out = d;
   *out_arena = dptr;
   return RGX_OK;

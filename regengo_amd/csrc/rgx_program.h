@@ -42,6 +42,10 @@ struct DevTables {
   const uint32_t* start_ops;      // [4]
   const uint32_t* start_ops_pool;
   const uint32_t* sa_mask;        // [256] Shift-And level-set masks (prefilter)
+  const uint16_t* w_trans;        // sync automaton [w_nstates][ncls] (rgx_dfa.h); state 0 = no earlier thread alive
+  int32_t w_nstates;              // 0: none (or too large for LDS)
+  int32_t w_start;
+  int32_t reset_values;           // number of byte values on which every DFA state dies
   int32_t nstates, ncls, stride;  // stride = ncls+1 (class layouts)
   int32_t mode;
   int32_t table_bytes;            // bytes staged into LDS for the transition table

@@ -333,7 +333,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
 #pragma unroll
     for (int w = 0; w < kBlockThreads / 64; ++w) block_total += L.wtot[w];
     unsigned long long excl = 0;
-    if (!(P.debug & 1)) excl = LookBack(P.tile_desc, blk, block_total, lane, &P.counters[3], 4, P.host_result ? P.host_result + 1 : nullptr);
+    if (!(P.debug & 1)) excl = LookBack(P.tile_desc, blk, block_total, lane, &P.counters[3], 4, P.host_result ? P.host_result + 1 : nullptr, !P.use_tickets);
     if (lane == 0) {
       L.base_lo = (unsigned)excl;
       L.base_hi = (unsigned)(excl >> 32);

@@ -271,7 +271,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_sa_kernel(DevTables T, Sca
     return;
   }
   if (wave == 0) {
-    const unsigned long long excl = LookBack(P.tile_desc, tile, tile_total, lane, &P.counters[3]);
+    const unsigned long long excl = LookBack(P.tile_desc, tile, tile_total, lane, &P.counters[3], 1, nullptr, !P.use_tickets);
     if (lane == 0) {
       L.misc[8] = (unsigned)excl;
       L.misc[9] = (unsigned)(excl >> 32);

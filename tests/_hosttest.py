@@ -9,6 +9,7 @@ _lib.rgxt_compile.argtypes = [C.c_char_p, C.c_uint32]
 _lib.rgxt_free.argtypes = [C.c_void_p]
 _lib.rgxt_compile_search.restype = C.c_void_p
 _lib.rgxt_compile_search.argtypes = [C.c_char_p, C.c_uint32]
+_lib.rgxt_w_sync.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64, C.c_void_p]
 _lib.rgxt_search_first.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p]
 _lib.rgxt_last_error.restype = C.c_char_p
 _lib.rgxt_find_all.restype = C.c_int64
@@ -78,6 +79,12 @@ class HostProgram:
         r = _lib.rgxt_search_first(sp.h, self.h, b, len(b), out)
         assert r >= 0, "winning thread without Capture 0"
         return list(out) if r == 1 else None
+
+    def w_sync(self, b: bytes, y: int = 0):
+        """(number of W states, flags[len+1]): flags[i] = the sync automaton started blind at y is empty at offset i."""
+        f = (C.c_uint8 * (len(b) + 1))()
+        n = _lib.rgxt_w_sync(self.h, b, len(b), y, f)
+        return n, bytes(f)
 
     def match(self, b: bytes) -> bool:
         return bool(_lib.rgxt_match(self.h, b, len(b)))

@@ -127,7 +127,8 @@ def test_one_gib_date_log(torch_dev):
 def test_unsynced_fallback_is_exact(torch_dev):
     """Inputs with no sync point in reach must take the serial carry path and still give the reference's answer.
     (a) exact Shift-And kernel: candidates every 8 bytes ("1234-56-" repeated: each one overlaps the next) block
-        every 64-byte look-behind window; (b) table-walk kernel: a 200 KB run of digits/dashes has no reset byte."""
+        every 64-byte look-behind window; (b) table-walk kernel: a 200 KB run of digits/dashes has no reset byte, the
+        sync automaton takes over; (c) a pattern for which even the sync automaton never empties inside the run."""
     from oracle.gen_c import CMatcher
     head, tail = np.frombuffer(b"abc ", dtype=np.uint8), np.frombuffer(b" tail 2024-01-15", dtype=np.uint8)
     dense = np.frombuffer(b"1234-56-" * 30000, dtype=np.uint8)
@@ -144,8 +145,17 @@ def test_unsynced_fallback_is_exact(torch_dev):
     pat = r"(\d{4})-(\d{2})-(\d{2,3})"          # variable length: not a class chain -> table-walk kernel
     c2 = _gpu(pat)
     spans, res = c2.FindAllSpans(torch_dev.from_numpy(buf).cuda())
-    assert res.unsynced > 0
+    # no reset byte in the run: the first pass reports unsynced slices, the rerun takes its sync points from the sync
+    # automaton W ("--" kills every thread), so nothing is left for the carry path
     exp, cnt = CMatcher(pat).find_all_np(buf)
+    assert res.total == cnt and np.array_equal(spans.cpu().numpy(), exp)
+    # (c) a pattern whose threads live for up to 40 bytes (a new one starts at every byte) inside the run: W is never empty there either -> carry path
+    pat3 = r"[\d-]{1,40}x"
+    c3 = _gpu(pat3)
+    buf3 = np.concatenate([head, body[:150000], np.frombuffer(b"x ", dtype=np.uint8), body[150000:], tail])
+    spans, res = c3.FindAllSpans(torch_dev.from_numpy(buf3).cuda())
+    assert res.unsynced > 0
+    exp, cnt = CMatcher(pat3).find_all_np(buf3)
     assert res.total == cnt and np.array_equal(spans.cpu().numpy(), exp)
     # and the exact kernel on the same random run (mask-based sync finds its own sync points here)
     spans, res = c.FindAllSpans(torch_dev.from_numpy(buf).cuda())

@@ -126,6 +126,42 @@ def test_search_automaton_equals_restart_loop(corpus, kats, hostlib):
     assert nosearch <= 8
 
 
+def test_sync_automaton_is_sound(corpus, kats, hostlib):
+    """Wherever the sync automaton W -- started blind, anywhere -- reports the empty set, no FindAll match of the
+    oracle that began earlier is still running: a worker may start there knowing nothing else.  Also: W exists for
+    (almost) every corpus pattern and finds sync points on patterns that have NO reset byte."""
+    rng = random.Random(777)
+    items = [(e["pattern"], e["inputs"]) for e in corpus] + [(c["pattern"], c["inputs"]) for c in kats["curated_cases"]]
+    built = total = with_sync = 0
+    for p, inputs in items:
+        try:
+            hp = hostlib.HostProgram(p)
+        except ValueError:
+            continue
+        total += 1
+        o = E.Compiled(p)
+        bs = [s.encode() for s in inputs]
+        big = b"\n".join(bs * 3) + b"\n"
+        for b in [big] + _mutations(inputs, rng)[:12]:
+            for y in (0, len(b) // 3, len(b) // 2):
+                n, fl = hp.w_sync(b, y)
+                if n == 0:
+                    break
+                for s_, e_ in [(m[0], m[1]) for m in o.find_machine.find_all(b)]:
+                    assert not any(fl[s_ + 1:e_]), (p, b, y, s_, e_)
+                with_sync += any(fl)
+        built += n > 0
+    assert built >= total - 3
+    assert with_sync > 1000
+    # a pattern whose states survive every single byte value: no reset byte, yet sync points after each line
+    p = r"\[(?P<level>\w+)\]\s+(?P<message>.*)"
+    hp = hostlib.HostProgram(p)
+    assert not any(hp.reset_bytes())
+    text = b"[INFO] hello world\n[WARN] x\nplain line\n[ERR]   spaced out\n"
+    n, fl = hp.w_sync(text, 0)
+    assert n > 0 and sum(fl) >= 3
+
+
 def test_n_argument(hostlib):
     hp = hostlib.HostProgram(r"(\d+)")
     o = E.Compiled(r"(\d+)")
