@@ -83,6 +83,9 @@ typedef struct rgx_info {
   int32_t ref_find_engine;  /* 0 backtracking, 1 tdfa-or-tnfa (catastrophic risk), 2 tnfa, -1 none (no captures) */
   int32_t lookahead_mode;  /* 1: pattern has $ / \b / \B / (?m)$ (match flag is on the next-byte edge) */
   int32_t table_bytes;     /* bytes of transition table staged in LDS                            */
+  int32_t needs_valid_utf8; /* 1: the pattern has a class with non-ASCII runes (incl. negated ASCII classes);
+                             * results are exact on ASCII / valid UTF-8 input, see DESIGN.md "UTF-8 classes"        */
+  int32_t sync_states;     /* states of the sync automaton W (0: none), DESIGN.md 4.1                         */
 } rgx_info;
 int rgx_program_info(const rgx_program* p, rgx_info* out);
 /* NUL-separated capture names, group 0 first ("" for unnamed); returns bytes written or needed.    */

@@ -34,13 +34,39 @@ def _cond_fail(ins: S.Inst) -> str:
     r = ins.rune
     if len(r) == 0:
         return "1"
-    if any(r[i + 1] >= 128 for i in range(0, len(r), 2)):
-        raise NotImplementedError("unicode class")
     parts = []
     for i in range(0, len(r), 2):
         lo, hi = r[i], r[i + 1]
         parts.append("(c == 0x%02x)" % lo if lo == hi else "(c >= 0x%02x && c <= 0x%02x)" % (lo, hi))
     return "!(%s)" % " || ".join(parts)
+
+
+def _is_unicode_class(ins: S.Inst) -> bool:
+    return ins.op == S.InstRune and len(ins.rune) > 1 and any(ins.rune[i + 1] >= 128 for i in range(0, len(ins.rune), 2))
+
+
+_DECODE_RUNE_C = r"""
+/* utf8.DecodeRune (Go stdlib), as the reference's Unicode class path uses it (instructions.go:258-267) */
+static inline int32_t decode_rune(const uint8_t* b, int64_t l, int64_t off, int* w) {
+  int64_t n = l - off; uint8_t b0 = b[off]; int need; uint8_t lo = 0x80, hi = 0xBF;
+  if (b0 < 0x80) { *w = 1; return b0; }
+  *w = 1;
+  if (b0 < 0xC2 || b0 > 0xF4) return 0xFFFD;
+  if (b0 < 0xE0) need = 2;
+  else if (b0 < 0xF0) { need = 3; if (b0 == 0xE0) lo = 0xA0; else if (b0 == 0xED) hi = 0x9F; }
+  else { need = 4; if (b0 == 0xF0) lo = 0x90; else if (b0 == 0xF4) hi = 0x8F; }
+  if (n < need) return 0xFFFD;
+  uint8_t b1 = b[off + 1];
+  if (b1 < lo || b1 > hi) return 0xFFFD;
+  if (need == 2) { *w = 2; return ((b0 & 0x1F) << 6) | (b1 & 0x3F); }
+  uint8_t b2 = b[off + 2];
+  if (b2 < 0x80 || b2 > 0xBF) return 0xFFFD;
+  if (need == 3) { *w = 3; return ((b0 & 0x0F) << 12) | ((b1 & 0x3F) << 6) | (b2 & 0x3F); }
+  uint8_t b3 = b[off + 3];
+  if (b3 < 0x80 || b3 > 0xBF) return 0xFFFD;
+  *w = 4; return ((b0 & 0x07) << 18) | ((b1 & 0x3F) << 12) | ((b2 & 0x3F) << 6) | (b3 & 0x3F);
+}
+"""
 
 
 def emit_c(prog: S.Prog, memo: bool, name: str = "m") -> str:
@@ -51,6 +77,8 @@ def emit_c(prog: S.Prog, memo: bool, name: str = "m") -> str:
     w = o.append
     w("#include <stdint.h>\n#include <stdlib.h>\n#include <string.h>\n")
     w("#define NCAP %d\n#define NINST %d\n" % (ncap, ninst))
+    if any(_is_unicode_class(i) for i in prog.inst):
+        w(_DECODE_RUNE_C)
     w("static inline int is_word(uint8_t c){return (c>='0'&&c<='9')||(c>='A'&&c<='Z')||c=='_'||(c>='a'&&c<='z');}\n")
     w("typedef struct { int64_t off; int32_t pc; } frame_t;\n")
     # one attempt from `start`; captures in caps; returns 1 on match (offset in *end), else 0 (failure offset in *end)
@@ -107,6 +135,14 @@ def emit_c(prog: S.Prog, memo: bool, name: str = "m") -> str:
             w("  if (l <= offset + %d) goto TryFallback;\n" % (n - 1))
             w("  if (%s) goto TryFallback;\n" % " || ".join("input[offset+%d] != 0x%02x" % (k, b) for k, b in enumerate(enc)))
             w("  offset += %d; goto Ins%d;\n" % (n, ins.out))
+        elif _is_unicode_class(ins):
+            # engines.Machine._consume: ASCII fast path when the class has ASCII members, else decode one rune
+            r = ins.rune
+            conds = " || ".join("(r == %d)" % r[k] if r[k] == r[k + 1] else "(r >= %d && r <= %d)" % (r[k], r[k + 1])
+                                for k in range(0, len(r), 2))
+            w("  if (l <= offset) goto TryFallback;\n")
+            w("  { int wd; int32_t r = decode_rune(input, l, offset, &wd); if (!(%s)) goto TryFallback; offset += wd; }\n" % conds)
+            w("  goto Ins%d;\n" % ins.out)
         else:
             w("  if (l <= offset) goto TryFallback;\n")
             w("  { uint8_t c = input[offset]; (void)c; if (%s) goto TryFallback; }\n" % _cond_fail(ins))

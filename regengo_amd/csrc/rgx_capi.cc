@@ -277,6 +277,7 @@ RGX_API int rgx_program_info(const rgx_program* p, rgx_info* o) {
   o->n_inst = t.n_inst; o->n_states = t.nstates; o->n_classes = t.ncls; o->anchored = t.anchored;
   o->fixed_captures = t.fixed_captures; o->can_match_empty = t.can_match_empty;
   o->ref_match_engine = t.ref_match_engine; o->ref_find_engine = t.ref_find_engine; o->lookahead_mode = t.lookahead_mode;
+  o->needs_valid_utf8 = t.needs_valid_utf8; o->sync_states = t.w_nstates;
   o->table_bytes = p->p.d_arena ? p->p.dev.table_bytes : (int32_t)((size_t)t.nstates * (t.ncls + 1) * 2);
   return RGX_OK;
 }

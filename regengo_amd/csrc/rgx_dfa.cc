@@ -32,6 +32,8 @@ struct Builder {
   const Prog& p;
   int ninst;
   std::vector<Node> nodes;  // index = node id (ids < ninst are rune instructions; others unused)
+  std::vector<std::vector<int>> alt_heads;   // per instruction: heads of the UTF-8 sequence chains of a non-ASCII class
+  bool has_utf8_class = false;
   bool has_bol = false, has_eol = false, has_bot = false, has_eot = false, has_wb = false;
   bool lookahead = false;
   std::bitset<256> word_bytes, nl_bytes;
@@ -40,8 +42,56 @@ struct Builder {
   std::vector<std::bitset<256>> class_bytes;
   std::vector<uint8_t> class_is_word, class_is_nl;
 
+  // ---- UTF-8 decoding classes (instructions.go:205-295: the reference decodes one rune with utf8.DecodeRune and tests
+  // the class).  Here the class becomes byte-level alternatives: its ASCII bytes (the instruction's own node), one
+  // chain of byte-range nodes per UTF-8 sequence shape of its non-ASCII ranges (the standard range split, Go's validity
+  // table: no overlongs, no surrogates, <= U+10FFFF), and -- when the class contains U+FFFD, as every negated class does
+  // -- the bytes that can never begin a rune (80-BF, C0, C1, F5-FF), which DecodeRune reports as (RuneError, 1).
+  // Limitation (rgx_info.needs_valid_utf8): a lead byte followed by a wrong continuation byte is (RuneError, 1) in the
+  // reference too; that needs look-ahead and is not modelled, so results are exact on ASCII / valid UTF-8 input.
+  void AddChain(int pc, const std::vector<std::pair<int, int>>& seq, int out) {
+    int head = -1, cur = -1;
+    for (size_t j = 0; j < seq.size(); j++) {
+      nodes.push_back(Node());
+      const int id = (int)nodes.size() - 1;
+      for (int b = seq[j].first; b <= seq[j].second; b++) nodes[id].bytes.set(b);
+      if (cur >= 0) nodes[cur].next_node = id; else head = id;
+      cur = id;
+    }
+    nodes[cur].out_pc = out;
+    alt_heads[pc].push_back(head);
+  }
+  void Utf8Split(int pc, int32_t lo, int32_t hi, int out) {
+    if (lo > hi) return;
+    if (lo < 0x80) lo = 0x80;
+    if (lo > hi) return;
+    if (lo <= 0xDFFF && hi >= 0xD800) {   // surrogates are not encodable
+      Utf8Split(pc, lo, 0xD7FF, out);
+      Utf8Split(pc, 0xE000, hi, out);
+      return;
+    }
+    static const int32_t maxv[3] = {0x7FF, 0xFFFF, 0x10FFFF};
+    for (int i = 0; i < 2; i++)
+      if (lo <= maxv[i] && hi > maxv[i]) { Utf8Split(pc, lo, maxv[i], out); Utf8Split(pc, maxv[i] + 1, hi, out); return; }
+    if (hi > 0x10FFFF) hi = 0x10FFFF;
+    for (int i = 1; i < 4; i++) {
+      const int32_t m = (1 << (6 * i)) - 1;
+      if ((lo & ~m) != (hi & ~m)) {
+        if ((lo & m) != 0) { Utf8Split(pc, lo, lo | m, out); Utf8Split(pc, (lo | m) + 1, hi, out); return; }
+        if ((hi & m) != m) { Utf8Split(pc, lo, (hi & ~m) - 1, out); Utf8Split(pc, hi & ~m, hi, out); return; }
+      }
+    }
+    uint8_t a[4], b[4];
+    const int n = EncodeRune(lo, a), n2 = EncodeRune(hi, b);
+    if (n != n2) throw Unsupported{"internal: UTF-8 range split"};
+    std::vector<std::pair<int, int>> seq;
+    for (int j = 0; j < n; j++) seq.push_back({a[j], b[j]});
+    AddChain(pc, seq, out);
+  }
+
   explicit Builder(const Prog& prog) : p(prog), ninst((int)prog.inst.size()) {
     nodes.resize(ninst);
+    alt_heads.resize(ninst);
     for (int c = 0; c < 256; c++)
       if ((c >= '0' && c <= '9') || (c >= 'A' && c <= 'Z') || c == '_' || (c >= 'a' && c <= 'z')) word_bytes.set(c);
     nl_bytes.set('\n');
@@ -75,10 +125,21 @@ struct Builder {
             nodes[pc].out_pc = in.out;
             break;
           }
-          for (size_t i = 0; i + 1 < R.size(); i += 2)
-            if (R[i + 1] >= 128) throw Unsupported{"character class with non-ASCII runes (UTF-8 decoding classes)"};
-          for (size_t i = 0; i + 1 < R.size(); i += 2)
-            for (int32_t c = R[i]; c <= R[i + 1]; c++) nodes[pc].bytes.set(c);
+          bool has_fffd = false;
+          for (size_t i = 0; i + 1 < R.size(); i += 2) {
+            for (int32_t c = R[i]; c <= R[i + 1] && c < 128; c++) nodes[pc].bytes.set(c);
+            if (R[i + 1] >= 128) {
+              has_utf8_class = true;
+              Utf8Split(pc, R[i], R[i + 1], (int)in.out);
+              if (R[i] <= 0xFFFD && R[i + 1] >= 0xFFFD) has_fffd = true;
+            }
+          }
+          if (has_fffd) {   // bytes that cannot begin a rune decode as (RuneError, 1)
+            std::vector<std::pair<int, int>> one;
+            AddChain(pc, {{0x80, 0xBF}}, (int)in.out);
+            AddChain(pc, {{0xC0, 0xC1}}, (int)in.out);
+            AddChain(pc, {{0xF5, 0xFF}}, (int)in.out);
+          }
           nodes[pc].out_pc = in.out;
           break;
         }
@@ -196,7 +257,8 @@ struct Builder {
           return;
         }
         default:  // byte-consuming
-          leaves->push_back({id, parent, ops});
+          if (nodes[id].bytes.any() || alt_heads[id].empty()) leaves->push_back({id, parent, ops});
+          for (int h : alt_heads[id]) if (!seen[h]) { seen[h] = 1; leaves->push_back({h, parent, ops}); }
           return;
       }
     };
@@ -219,7 +281,10 @@ struct Builder {
         case InstFail: case InstMatch: return;
         case InstNop: case InstCapture: case InstEmptyWidth: add(in.out); return;
         case InstAlt: case InstAltMatch: add(in.out); add(in.arg); return;
-        default: leaves->push_back(id); return;
+        default:
+          if (nodes[id].bytes.any() || alt_heads[id].empty()) leaves->push_back(id);
+          for (int h : alt_heads[id]) if (!seen[h]) { seen[h] = 1; leaves->push_back(h); }
+          return;
       }
     };
     for (int x : pre) add(x);
@@ -233,7 +298,10 @@ int InstWidth(const Prog& p, int pc) {
   const Inst& in = p.inst[pc];
   switch (in.op) {
     case InstRune1: return in.rune[0] < 128 ? 1 : RuneLen(in.rune[0]);
-    case InstRune: case InstRuneAny: case InstRuneAnyNotNL: return 1;
+    case InstRune:
+      for (size_t i = 1; i < in.rune.size(); i += 2) if (in.rune[i] >= 128 && in.rune.size() > 1) return -1;   // 1..4 bytes
+      return 1;
+    case InstRuneAny: case InstRuneAnyNotNL: return 1;
     default: return 0;
   }
 }
@@ -278,6 +346,7 @@ Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOption
 
   Builder b(prog);
   t.lookahead_mode = b.lookahead;
+  t.needs_valid_utf8 = b.has_utf8_class;
   t.ncls = b.ncls;
   memcpy(t.cls, b.cls, 256);
   const int ncls = b.ncls, stride = ncls + 1;
@@ -436,7 +505,7 @@ Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOption
         for (int v : adj[u]) {
           // forward: dist[v] = dist[u] + width(u); backward: dist[v] = dist[u] + width(v)
           int w = forward ? InstWidth(prog, u) : InstWidth(prog, v);
-          int nv = d[u] == kVar ? kVar : d[u] + w;
+          int nv = (d[u] == kVar || w < 0) ? kVar : d[u] + w;
           if (nv > 1000000) nv = kVar;
           if (d[v] == kUnknown) { d[v] = nv; work.push_back(v); }
           else if (d[v] != nv && d[v] != kVar) { d[v] = kVar; work.push_back(v); }
@@ -621,7 +690,7 @@ std::vector<uint8_t> SerializeTables(const Tables& t) {
   w.vec(t.cap_kind); w.vec(t.cap_delta); w.vec(t.st_nthreads); w.vec(t.bt_base); w.vec(t.bt_parent); w.vec(t.bt_ops);
   w.vec(t.bt_match); w.vec(t.start_ops); w.vec(t.start_ops_pool); w.pod<int32_t>(t.max_threads); w.pod<int32_t>(t.fixed_len);
   w.raw(t.sa_mask, sizeof t.sa_mask); w.pod<int32_t>(t.sa_k); w.pod<uint8_t>(t.sa_exact);
-  w.pod<int32_t>(t.w_nstates); w.pod<uint16_t>(t.w_start); w.vec(t.w_trans);
+  w.pod<int32_t>(t.w_nstates); w.pod<uint16_t>(t.w_start); w.vec(t.w_trans); w.pod<uint8_t>(t.needs_valid_utf8);
   return w.b;
 }
 
@@ -645,7 +714,7 @@ bool DeserializeTables(const uint8_t* p, size_t n, Tables* t) {
   r.vec(t->cap_kind); r.vec(t->cap_delta); r.vec(t->st_nthreads); r.vec(t->bt_base); r.vec(t->bt_parent); r.vec(t->bt_ops);
   r.vec(t->bt_match); r.vec(t->start_ops); r.vec(t->start_ops_pool); r.pod(i32); t->max_threads = i32; r.pod(i32); t->fixed_len = i32;
   r.raw(t->sa_mask, sizeof t->sa_mask); r.pod(i32); t->sa_k = i32; r.pod(u8); t->sa_exact = u8;
-  r.pod(i32); t->w_nstates = i32; r.pod(t->w_start); r.vec(t->w_trans);
+  r.pod(i32); t->w_nstates = i32; r.pod(t->w_start); r.vec(t->w_trans); r.pod(u8); t->needs_valid_utf8 = u8;
   if (!r.ok) return false;
   if (t->w_nstates < 0 || t->w_trans.size() != (size_t)t->w_nstates * t->ncls || (t->w_nstates && t->w_start >= t->w_nstates)) return false;
   if (t->ncls < 1 || t->ncls > 256 || t->nstates < 1 || t->trans.size() != (size_t)t->nstates * (t->ncls + 1)) return false;

@@ -186,6 +186,29 @@ def test_exact_shift_and_for_date(hostlib):
 
 
 def test_unsupported_features_are_refused(hostlib):
-    for p in (r"\p{L}+", r"[α-ω]+"):
+    for p in (r"\p{L}+", r"[\p{L}\p{N}]+"):
         with pytest.raises(ValueError):
             hostlib.HostProgram(p)
+
+
+def test_utf8_decoding_classes(hostlib):
+    """Classes with non-ASCII runes -- every negated class ([^"], \\S) is one -- decode one rune like the reference
+    (instructions.go:205-295): ASCII bytes, valid UTF-8 sequences of runes in the class, and bytes that cannot begin a
+    rune as (RuneError, 1).  Bit-exact vs the oracle on valid UTF-8 text with stray invalid bytes sprinkled in."""
+    rng = random.Random(2024)
+    alphabet = ["a", "b", "\"", " ", "\n", "é", "ω", "α", "ת", "א", "日", "本", "€", "😀", "\U0010FFFF", "\ud7ff".encode("utf-8", "surrogatepass").decode("utf-8", "replace")]
+    stray = [b"\xff", b"\x80", b"\xbf", b"\xc0", b"\xc1", b"\xf5", b"\xfe"]
+    pats = [r'[^"]*', r'"(?P<v>[^"]*)"', r"\S+", r"[^\s]+", r"a[^b]c", r"[α-ω]+", r"[a-zα-ω]+", r"[א-ת]+", r"[^a-zα-ω\s]+",
+            r"(?P<k>[^=\s]+)=(?P<v>[^\s]*)", r"[\x{80}-\x{7FF}]+", r"[\x{800}-\x{FFFF}]", r"[\x{10000}-\x{10FFFF}]+", r"x[^\x00-\x7F]y"]
+    n = 0
+    for p in pats:
+        hp = hostlib.HostProgram(p)
+        o = E.Compiled(p)
+        for _ in range(60):
+            parts = []
+            for _ in range(rng.randint(0, 14)):
+                parts.append(rng.choice(alphabet).encode("utf-8") if rng.random() < 0.85 else rng.choice(stray))
+            b = b"".join(parts)
+            assert hp.find_all(b) == o.find_machine.find_all(b), (p, b)
+            n += 1
+    assert n == 60 * len(pats)
