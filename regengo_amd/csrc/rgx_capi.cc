@@ -174,16 +174,41 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     if (c->timing) hipEventElapsedTime(&ms, c->ev0, c->ev1);
     unsynced = ((uint32_t*)&c->h_read[2])[1];
   }
+  bool carry_ready = false;
+  if (unsynced && w_ok && (int64_t)unsynced * 1024 > (int64_t)nslices) {
+    // (a handful of unsynced slices goes straight to the carry pass below)
+    // the blind walk proves nothing for this pattern on this text (a thread may survive any byte): exact sync points
+    // from the optimistic chunk walk + ordered repair, handed to the scan as per-slice start positions
+    int64_t cc = 0;
+    if (c->d_carry) { hipFree(c->d_carry); c->d_carry = nullptr; }
+    if ((rc = Ensure(&c->d_carry, &cc, (int64_t)nslices + 64)) != RGX_OK) return rc;
+    const int32_t nchunks = WSyncChunks(ilen);
+    if ((rc = Ensure(&c->d_trace, &c->trace_cap, 2 * (int64_t)nchunks + 64)) != RGX_OK) return rc;   // per-chunk scratch (uint16)
+    uint32_t* d_stats = (uint32_t*)(c->d_carry + nslices + 8);
+    HIP_TRY(LaunchWSync(T, d_buf, ilen, c->d_carry, c->d_trace, d_stats, c->stream));
+    uint32_t h_stats[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(h_stats, d_stats, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (h_stats[1]) HIP_TRY(LaunchWSyncOrdered(T, d_buf, ilen, c->d_carry, c->d_trace, d_stats, c->stream));   // a thread really spans > 4 KiB
+    HIP_TRY(LaunchWSyncFill(c->d_carry, ilen, c->stream));
+    P.carry_in = c->d_carry;
+    if ((rc = run_scan(c->timing)) != RGX_OK) return rc;
+    if (c->timing) hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    unsynced = ((uint32_t*)&c->h_read[2])[1];
+    carry_ready = true;
+  }
   if (unsynced) {
     // rare path: some slices found no sync point; resolve their entry positions serially and rescan.
     if ((rc = Ensure(&c->d_unsynced, &c->slice_cap, nslices)) != RGX_OK) return rc;
-    int64_t cc = 0;
-    if (c->d_carry) { hipFree(c->d_carry); c->d_carry = nullptr; }
-    if ((rc = Ensure(&c->d_carry, &cc, nslices)) != RGX_OK) return rc;
+    if (!carry_ready) {
+      int64_t cc = 0;
+      if (c->d_carry) { hipFree(c->d_carry); c->d_carry = nullptr; }
+      if ((rc = Ensure(&c->d_carry, &cc, nslices)) != RGX_OK) return rc;
+    }
     HIP_TRY(hipMemsetAsync(c->d_unsynced, 0, nslices, c->stream));
     P.slice_unsynced = c->d_unsynced;
     if ((rc = run_scan(false)) != RGX_OK) return rc;            // marks the unsynced slices
-    HIP_TRY(hipMemsetAsync(c->d_carry, 0xFF, (size_t)nslices * 4, c->stream));
+    if (!carry_ready) HIP_TRY(hipMemsetAsync(c->d_carry, 0xFF, (size_t)nslices * 4, c->stream));
     HIP_TRY(LaunchCarry(T, d_buf, ilen, c->d_unsynced, c->d_carry, nslices, c->stream));
     P.slice_unsynced = nullptr;
     P.carry_in = c->d_carry;

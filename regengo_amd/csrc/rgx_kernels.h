@@ -45,6 +45,15 @@ hipError_t LaunchScanSa(const DevTables& T, const ScanParams& P, const uint16_t*
 // Serial carry resolution for slices without a local sync point (rare path).
 hipError_t LaunchCarry(const DevTables& T, const uint8_t* buf, int32_t len, const uint8_t* slice_unsynced, int32_t* carry_in,
                        int32_t nslices, hipStream_t stream);
+// Exact sync points from the sync automaton walked optimistically over 4 KiB chunks + ordered repair (rgx_kernels.hip):
+// carry_in[slice] = the slice's offset where FindAll provably stands there, else -1.  scratch: 2*WSyncChunks(len)+16
+// uint16; stats: one uint32 (chunks walked in the serial pass).
+hipError_t LaunchWSync(const DevTables& T, const uint8_t* buf, int32_t len, int32_t* carry_in, uint16_t* scratch, uint32_t* stats,
+                       hipStream_t stream);
+hipError_t LaunchWSyncOrdered(const DevTables& T, const uint8_t* buf, int32_t len, int32_t* carry_in, uint16_t* scratch, uint32_t* stats,
+                              hipStream_t stream);
+hipError_t LaunchWSyncFill(int32_t* carry_in, int32_t len, hipStream_t stream);
+int32_t WSyncChunks(int32_t len);
 // true when the scan of `len` bytes would run a kernel that can take its sync points from W (ScanParams::use_w)
 bool ScanSupportsW(const DevTables& T, int32_t len);
 

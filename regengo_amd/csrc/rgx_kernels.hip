@@ -380,7 +380,15 @@ __global__ void carry_kernel(DevTables T, const uint8_t* buf, int32_t len, const
   int pos = 0;
   if (s > 0) {
     const int a_prev = (s - 1) * kSliceBytes;
-    if (T.w_nstates > 0) {
+    // an exact sync point published for an earlier slice (LaunchWSync ran before): nearest one within 256 KiB
+    int known = -1;
+    for (int k = s - 1; k >= 0 && k >= s - 4096; --k) {
+      const int v = carry_in[k];
+      if (v == k * kSliceBytes && !unsynced[k]) { known = v; break; }   // proven: the loop stands at the slice's own offset
+    }
+    if (known >= 0) {
+      pos = known;
+    } else if (T.w_nstates > 0) {
       // nearest offset <= a_prev at which the sync automaton, walked blind over a growing look-behind, is empty
       int found = -1;
       for (int back = 256; found < 0; back <<= 1) {
@@ -417,6 +425,170 @@ __global__ void carry_kernel(DevTables T, const uint8_t* buf, int32_t len, const
       pos = (end >= 0) ? (end > pos ? end : pos + 1) : pos + 1;
     }
     ++cur;
+  }
+}
+
+// ---- exact sync points from the sync automaton, optimistically (rare path) -----------------------------------
+// Some patterns keep a thread alive across ANY byte until a delimiter that the text may never contain
+// (`<tag attr="[^"]*"`: "inside the quotes"), or start a thread on very common bytes (a digit-led pattern on a log), so
+// a blind walk proves too few sync points -- yet "no earlier thread is alive here" is simply TRUE almost everywhere.
+//   w_opt_kernel   one lane per 4 KiB chunk walks W twice at once: optimistically (as if the chunk began with no earlier
+//                  thread alive; true at offset 0) and blind (every position alive).  Per 64-byte slice it records
+//                  whether the optimistic state is empty at the slice's first byte; per chunk the optimistic exit state
+//                  and whether the blind walk emptied somewhere inside (then the chunk's exit state does not depend on
+//                  its entry state at all: both walks are identical from there on).
+//   w_fix_kernel   one wave walks the chunk list in order, but only chunks that never emptied blind need their true exit
+//                  computed from their true entry (a real serial chain, e.g. inside one enormous quoted string); all
+//                  others hand on their optimistic exit.  It records the true entry state of every chunk.
+//   w_repair_kernel one lane per chunk whose true entry state is not empty re-walks from it until the state empties --
+//                  from there the optimistic answers are the true ones (W is monotone in its start set).
+// Result: carry_in[slice] = the slice's own offset where the FindAll loop provably stands at that offset, -1 elsewhere.
+constexpr int kWChunkSlices = 64;
+constexpr int kWChunkBytes = kWChunkSlices * kSliceBytes;
+constexpr unsigned kWMaxSerial = 4096;     // serial budget of w_fix_kernel (chunks walked in order)
+
+// walks slice [a, a+64) (or to len) with state q; whole-dword loads
+__device__ __forceinline__ unsigned WalkWSlice(const uint16_t* w, const uint8_t* cls, int ncls, const uint8_t* buf, int len, int a,
+                                               unsigned q) {
+  if (a + kSliceBytes <= len) {
+    const uint4* src = reinterpret_cast<const uint4*>(buf + a);
+#pragma unroll 1
+    for (int v = 0; v < 4; ++v) {
+      const uint4 x = src[v];
+      const unsigned ws[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) q = w[q * ncls + cls[(ws[d] >> (8 * b)) & 0xFFu]];
+    }
+  } else {
+    for (int i = a; i < len; ++i) q = w[q * ncls + cls[buf[i]]];
+  }
+  return q;
+}
+
+__device__ __forceinline__ void StageW(const DevTables& T, unsigned char* smem, int tid, int nthreads) {
+  uint8_t* s_cls = smem;
+  uint16_t* s_w = reinterpret_cast<uint16_t*>(smem + 256);
+  for (int i = tid; i < 256; i += nthreads) s_cls[i] = T.cls[i];
+  for (int i = tid; i < T.w_nstates * T.ncls; i += nthreads) s_w[i] = T.w_trans[i];
+  __syncthreads();
+}
+
+// chunk_info[c] = optimistic exit state | (blind walk emptied inside the chunk) << 15
+__global__ __launch_bounds__(kBlockThreads) void w_opt_kernel(DevTables T, const uint8_t* buf, int32_t len, int32_t* carry_in,
+                                                               uint16_t* chunk_info, int32_t nchunks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  StageW(T, smem, threadIdx.x, kBlockThreads);
+  const uint8_t* s_cls = smem;
+  const uint16_t* s_w = reinterpret_cast<const uint16_t*>(smem + 256);
+  const int c = blockIdx.x * kBlockThreads + threadIdx.x;
+  if (c >= nchunks) return;
+  const int ncls = T.ncls;
+  unsigned qo = 0, qb = (unsigned)T.w_start;
+  bool emptied = false;
+  for (int j = 0; j < kWChunkSlices; ++j) {
+    const int a = c * kWChunkBytes + j * kSliceBytes;
+    if (a >= len) break;
+    carry_in[a >> 6] = qo == 0 ? a : -1;
+    qo = WalkWSlice(s_w, s_cls, ncls, buf, len, a, qo);
+    if (!emptied) {
+      // the blind walk is only needed until it empties (checked per byte inside the slice would be finer; per slice
+      // boundary is enough: empty at a boundary => equal to the optimistic walk from there on)
+      qb = WalkWSlice(s_w, s_cls, ncls, buf, len, a, qb);
+      if (qb == 0 || qb == qo) emptied = true;     // identical states => identical futures
+    }
+  }
+  chunk_info[c] = (uint16_t)(qo | (emptied ? 0x8000u : 0u));
+}
+
+// entry[c] = true W state entering chunk c (0xFFFF: unknown, serial budget exhausted)
+__global__ __launch_bounds__(64) void w_fix_kernel(DevTables T, const uint8_t* buf, int32_t len, const uint16_t* chunk_info,
+                                                    uint16_t* entry, int32_t nchunks, uint32_t* stats) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  StageW(T, smem, threadIdx.x, 64);
+  const uint8_t* s_cls = smem;
+  const uint16_t* s_w = reinterpret_cast<const uint16_t*>(smem + 256);
+  const int lane = threadIdx.x;
+  unsigned q_in = 0;        // true state entering chunk g (uniform)
+  unsigned n_serial = 0;
+  bool lost = false;
+  for (int g = 0; g < nchunks; g += 64) {
+    const unsigned info = g + lane < nchunks ? (unsigned)chunk_info[g + lane] : 0x8000u;
+    const unsigned long long indep = __ballot((info & 0x8000u) != 0);      // exit independent of entry
+    // entry of chunk g+lane+1 when every chunk up to it is independent: its predecessor's optimistic exit
+    if (indep == ~0ull && !lost) {
+      const unsigned prev_exit = (unsigned)__shfl_up((int)(info & 0x7FFFu), 1, 64);
+      if (g + lane < nchunks) entry[g + lane] = (uint16_t)(lane == 0 ? q_in : prev_exit);
+      q_in = (unsigned)__shfl((int)(info & 0x7FFFu), 63, 64);
+      continue;
+    }
+    for (int k = 0; k < 64 && g + k < nchunks; ++k) {
+      const unsigned ik = (unsigned)__shfl((int)info, k, 64);
+      if (lane == 0) entry[g + k] = (uint16_t)(lost ? 0xFFFFu : q_in);
+      if (ik & 0x8000u) { q_in = ik & 0x7FFFu; lost = false; continue; }   // exit known whatever the entry was
+      if (lost) continue;
+      if (q_in == 0) { q_in = ik & 0x7FFFu; continue; }                      // entered empty: the optimistic walk was the true one
+      if (n_serial >= kWMaxSerial) { lost = true; continue; }               // give up until a chunk with a known exit
+      // walk from the true entry state; once it is empty the optimistic walk (a subset of it, hence empty too) is
+      // the true one and the chunk's optimistic exit stands
+      unsigned q = q_in;
+      bool merged = false;
+      for (int j = 0; j < kWChunkSlices; ++j) {
+        const int a = (g + k) * kWChunkBytes + j * kSliceBytes;
+        if (a >= len) break;
+        q = WalkWSlice(s_w, s_cls, T.ncls, buf, len, a, q);
+        if (q == 0) { merged = true; break; }
+      }
+      q_in = merged ? (ik & 0x7FFFu) : q;
+      ++n_serial;
+    }
+  }
+  if (lane == 0) stats[0] = n_serial;
+}
+
+// Speculation that needs no ordered pass at all: assume every chunk is entered in its predecessor's OPTIMISTIC exit
+// state.  Lane c walks from that state until it empties (from there the optimistic answers stand) and fixes the slice
+// flags on the way.  If every chunk either is entered empty or empties inside, induction from chunk 0 (entered empty)
+// shows every assumption was right; chunks that do not empty are counted in *n_bad and the ordered pass takes over.
+__global__ __launch_bounds__(kBlockThreads) void w_spec_kernel(DevTables T, const uint8_t* buf, int32_t len, int32_t* carry_in,
+                                                                const uint16_t* chunk_info, int32_t nchunks, uint32_t* n_bad) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  StageW(T, smem, threadIdx.x, kBlockThreads);
+  const uint8_t* s_cls = smem;
+  const uint16_t* s_w = reinterpret_cast<const uint16_t*>(smem + 256);
+  const int c = blockIdx.x * kBlockThreads + threadIdx.x;
+  if (c >= nchunks || c == 0) return;
+  unsigned q = chunk_info[c - 1] & 0x7FFFu;
+  if (q == 0) return;
+  for (int j = 0; j < kWChunkSlices; ++j) {
+    const int a = c * kWChunkBytes + j * kSliceBytes;
+    if (a >= len) return;
+    carry_in[a >> 6] = -1;
+    q = WalkWSlice(s_w, s_cls, T.ncls, buf, len, a, q);
+    if (q == 0) return;
+  }
+  atomicAdd(n_bad, 1u);
+}
+
+__global__ __launch_bounds__(kBlockThreads) void w_repair_kernel(DevTables T, const uint8_t* buf, int32_t len, int32_t* carry_in,
+                                                                  const uint16_t* entry, int32_t nchunks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  StageW(T, smem, threadIdx.x, kBlockThreads);
+  const uint8_t* s_cls = smem;
+  const uint16_t* s_w = reinterpret_cast<const uint16_t*>(smem + 256);
+  const int c = blockIdx.x * kBlockThreads + threadIdx.x;
+  if (c >= nchunks) return;
+  unsigned q = entry[c];
+  if (q == 0) return;                         // the optimistic answers of this chunk are the true ones
+  const bool unknown = q == 0xFFFFu;
+  for (int j = 0; j < kWChunkSlices; ++j) {
+    const int a = c * kWChunkBytes + j * kSliceBytes;
+    if (a >= len) break;
+    if (unknown) { carry_in[a >> 6] = -1; continue; }      // nothing is vouched for in this chunk
+    if (q == 0) break;                                     // converged: the rest was right already
+    carry_in[a >> 6] = -1;
+    q = WalkWSlice(s_w, s_cls, T.ncls, buf, len, a, q);
   }
 }
 
@@ -1012,6 +1184,53 @@ hipError_t LaunchScan(const DevTables& T, const ScanParams& P, hipStream_t strea
 #undef RGX_LAUNCH
   return hipGetLastError();
 }
+
+namespace {
+// A slice whose first byte is not a sync point starts from the nearest proven one behind it (within the scan kernels'
+// re-walk budget): carry_in[s] = that offset (< the slice's own offset).  Entries equal to their slice's own offset are
+// the proven ones; only those are read, so concurrent fills do not interfere.
+__global__ __launch_bounds__(kBlockThreads) void w_fill_kernel(int32_t* carry_in, int32_t nslices) {
+  const int s = blockIdx.x * kBlockThreads + threadIdx.x;
+  if (s >= nslices || carry_in[s] >= 0) return;
+  for (int k = s - 1; k >= 0 && k >= s - 1024 / kSliceBytes; --k) {
+    if (carry_in[k] == k * kSliceBytes) { carry_in[s] = k * kSliceBytes; return; }
+  }
+}
+}  // namespace
+
+// stage 1: optimistic chunk walk + parallel speculation; stats[1] = chunks the speculation could not settle
+hipError_t LaunchWSync(const DevTables& T, const uint8_t* buf, int32_t len, int32_t* carry_in, uint16_t* scratch, uint32_t* stats,
+                       hipStream_t stream) {
+  const int nchunks = (len + kWChunkBytes - 1) / kWChunkBytes;
+  const size_t shmem = 256 + (((size_t)T.w_nstates * T.ncls * 2 + 15) & ~size_t(15));
+  uint16_t* chunk_info = scratch;
+  const dim3 grid((nchunks + kBlockThreads - 1) / kBlockThreads), block(kBlockThreads);
+  hipError_t e = hipMemsetAsync(stats, 0, 8, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(w_opt_kernel, grid, block, shmem, stream, T, buf, len, carry_in, chunk_info, nchunks);
+  hipLaunchKernelGGL(w_spec_kernel, grid, block, shmem, stream, T, buf, len, carry_in, chunk_info, nchunks, stats + 1);
+  return hipGetLastError();
+}
+// stage 2 (only when stats[1] != 0): redo the flags from scratch with the ordered pass
+hipError_t LaunchWSyncOrdered(const DevTables& T, const uint8_t* buf, int32_t len, int32_t* carry_in, uint16_t* scratch, uint32_t* stats,
+                              hipStream_t stream) {
+  const int nchunks = (len + kWChunkBytes - 1) / kWChunkBytes;
+  const size_t shmem = 256 + (((size_t)T.w_nstates * T.ncls * 2 + 15) & ~size_t(15));
+  uint16_t* chunk_info = scratch;
+  uint16_t* entry = scratch + nchunks + 8;
+  const dim3 grid((nchunks + kBlockThreads - 1) / kBlockThreads), block(kBlockThreads);
+  hipLaunchKernelGGL(w_opt_kernel, grid, block, shmem, stream, T, buf, len, carry_in, chunk_info, nchunks);
+  hipLaunchKernelGGL(w_fix_kernel, dim3(1), dim3(64), shmem, stream, T, buf, len, chunk_info, entry, nchunks, stats);
+  hipLaunchKernelGGL(w_repair_kernel, grid, block, shmem, stream, T, buf, len, carry_in, entry, nchunks);
+  return hipGetLastError();
+}
+// stage 3: slices that are not sync points start from the nearest proven one behind them
+hipError_t LaunchWSyncFill(int32_t* carry_in, int32_t len, hipStream_t stream) {
+  const int nslices = (len + kSliceBytes - 1) / kSliceBytes;
+  hipLaunchKernelGGL(w_fill_kernel, dim3((nslices + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, stream, carry_in, nslices);
+  return hipGetLastError();
+}
+int32_t WSyncChunks(int32_t len) { return (len + kWChunkBytes - 1) / kWChunkBytes; }
 
 hipError_t LaunchCarry(const DevTables& T, const uint8_t* buf, int32_t len, const uint8_t* slice_unsynced, int32_t* carry_in,
                        int32_t nslices, hipStream_t stream) {

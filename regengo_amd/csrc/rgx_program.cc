@@ -89,7 +89,7 @@ int UploadTables(const Tables& t, std::vector<uint16_t>* direct_table, DevTables
   size_t off_sa = a.Add(t.sa_mask, sizeof t.sa_mask);
   size_t off_tcls = a.AddVec(t.trans);
   size_t off_w = a.AddVec(t.w_trans);
-  d.w_nstates = ((size_t)t.w_nstates * t.ncls * 2 <= 8 * 1024) ? t.w_nstates : 0;   // kept in LDS by the kernels
+  d.w_nstates = ((size_t)t.w_nstates * t.ncls * 2 <= 40 * 1024) ? t.w_nstates : 0;   // kept in LDS by the kernels
   d.w_start = t.w_start;
   d.reset_values = 0;
   for (int c = 0; c < 256; c++) d.reset_values += t.reset_byte[c] ? 1 : 0;
