@@ -39,4 +39,4 @@ def test_c5_pattern_suite(built):
         r = _runner().run_c5(0, 0, mib=32)
     finally:
         os.chdir(cwd)
-    assert r["bad"] == [] and r["ok"] >= 240 and r["unsupported"] <= 12 and r["oracle_timeout"] == 0
+    assert r["bad"] == [] and r["ok"] >= 248 and r["unsupported"] <= 5 and r["oracle_timeout"] == 0
