@@ -140,6 +140,18 @@ int64_t rgx_find_all_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8_
  * match, 64 % as large as the input it was found in; this form is 4 B per match.)                                    */
 int64_t rgx_find_all_starts_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n,
                                    int32_t* d_starts, size_t cap, rgx_result* res);
+/* ReplaceAllBytes / ReplaceFirstBytes(input, template) -- replace.go:205-323, 325-363; template syntax of
+ * replace/template.go:45-148 ($0 $1..$99 ${n} $name ${name} $$).  Every leftmost-first match (FindAllBytes order, plus the
+ * loop's extra attempt at offset len for patterns that match empty) is replaced by the template's expansion; unknown
+ * names and out-of-range indices expand to nothing (replace.go:393-453).  `d_out` receives the result; *out_len is
+ * always set; RGX_E_CAPACITY when cap_out is too small (call again with *out_len bytes).  A malformed template is
+ * RGX_E_INVALID (the reference panics).  Matches are taken in their true context: the reference's re-slicing quirks
+ * (DESIGN.md Q1/Q4'/Q12) are not reproduced.                                                          */
+int64_t rgx_replace_all_bytes_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len,
+                                     const char* tmpl, size_t tmpl_len, int first_only, uint8_t* d_out, size_t cap_out,
+                                     int64_t* out_len, rgx_result* res);
+/* RGX_OK, or RGX_E_INVALID with the parser's message in rgx_last_error().                                */
+int rgx_replace_template_check(const char* tmpl, size_t tmpl_len);
 /* offsets[c] for c in [0, ncap): span slot c of a match starting at s is s + offsets[c]; returns fixed match length or <0. */
 int rgx_program_capture_template(const rgx_program* p, int32_t* offsets);
 /* Count only (FindReaderCount's hot loop; no span traffic).                                        */

@@ -21,6 +21,7 @@ _STATUS = {0: "ok", -1: "invalid", -2: "syntax", -3: "unsupported", -4: "too lar
            -7: "nomem", -8: "capacity", -9: "bad blob", -10: "buffer too small"}
 
 RGX_OK = 0
+RGX_E_INVALID = -1
 RGX_E_SYNTAX = -2
 RGX_E_UNSUPPORTED = -3
 RGX_E_NO_DEVICE = -5
@@ -71,6 +72,9 @@ SYMBOLS = {
                                        C.POINTER(Result)]),
     "rgx_find_all_starts_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p,
                                               C.c_size_t, C.POINTER(Result)]),
+    "rgx_replace_all_bytes_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int,
+                                                 C.c_void_p, C.c_size_t, C.POINTER(C.c_int64), C.POINTER(Result)]),
+    "rgx_replace_template_check": (C.c_int, [C.c_char_p, C.c_size_t]),
     "rgx_program_capture_template": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rgx_count_all_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Result)]),
     "rgx_find_batch_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,

@@ -218,6 +218,36 @@ class Compiled:
         r = self.FindBatch([bytes(data)])
         return (r[0], True) if r[0] is not None else (None, False)
 
+    # ---- Replace path (replace.go:205-363; template syntax replace/template.go)
+    def ReplaceAllDevice(self, data, template: str, first_only: bool = False):
+        """data: bytes or a device uint8 tensor.  Returns (device uint8 tensor with the result, matches replaced).
+        A malformed template raises RgxError(RGX_E_INVALID) -- the reference panics (replace.go:215-217)."""
+        import torch
+        self._need_dev()
+        t, ln = self._as_device(data)
+        tb = template.encode("utf-8")
+        res = _capi.Result()
+        need = C.c_int64(0)
+        cap = ln + max(64, ln // 8)
+        out = torch.empty(max(cap, 1), dtype=torch.uint8, device=t.device)
+        for _ in range(2):
+            w = self._lib.rgx_replace_all_bytes_device(self._h, self._ctx, t.data_ptr() if ln else None, ln, tb, len(tb),
+                                                       1 if first_only else 0, out.data_ptr(), out.numel(), C.byref(need), C.byref(res))
+            if w == _capi.RGX_E_CAPACITY:
+                out = torch.empty(max(int(need.value), 1), dtype=torch.uint8, device=t.device)
+                continue
+            break
+        _capi.check(w)
+        return out[:int(need.value)], int(res.total)
+
+    def ReplaceAllBytes(self, data, template: str) -> bytes:
+        out, _ = self.ReplaceAllDevice(data, template)
+        return bytes(out.cpu().numpy().tobytes())
+
+    def ReplaceFirstBytes(self, data, template: str) -> bytes:
+        out, _ = self.ReplaceAllDevice(data, template, first_only=True)
+        return bytes(out.cpu().numpy().tobytes())
+
     def FindBatch(self, strings: Sequence[bytes]):
         import torch
         self._need_dev()

@@ -36,6 +36,10 @@ struct rgx_stream_ctx {
   uint8_t* d_unsynced = nullptr; int32_t* d_carry = nullptr; int64_t slice_cap = 0;
   uint16_t* d_trace = nullptr; int64_t trace_cap = 0;
   uint8_t* d_in = nullptr; int64_t in_cap = 0;       // staging for the host-buffer entry points
+  // Replace path scratch
+  int32_t* d_rspans = nullptr; int64_t rspans_cap = 0;
+  long long* d_rdelta = nullptr; int64_t rdelta_cap = 0;     // [delta n+1][shift n+1]
+  uint8_t* d_rtemp = nullptr; int64_t rtemp_cap = 0;         // hipcub temp + segments + literals
   int32_t* d_out = nullptr; int64_t out_cap = 0;
   // pinned host readback
   unsigned long long* h_read = nullptr;      // [4]: total, unsynced, ...
@@ -355,7 +359,7 @@ RGX_API void rgx_stream_ctx_destroy(rgx_stream_ctx* c) {
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
   for (void* p : {(void*)c->d_desc, (void*)c->d_unsynced, (void*)c->d_carry,
-                  (void*)c->d_trace, (void*)c->d_in, (void*)c->d_out})
+                  (void*)c->d_trace, (void*)c->d_in, (void*)c->d_out, (void*)c->d_rspans, (void*)c->d_rdelta, (void*)c->d_rtemp})
     if (p) hipFree(p);
   if (c->h_read) hipHostFree(c->h_read);
   delete c;
@@ -378,6 +382,182 @@ RGX_API int64_t rgx_find_all_bytes_device_owned(const rgx_program* p, rgx_stream
   if (rc != RGX_OK) return rc;
   if (own_lo < 0 || own_hi < own_lo) { SetError("bad owned range"); return RGX_E_INVALID; }
   return FindAllDevice(p, c, d_buf, len, n, d_spans, cap_records, false, res, false, own_lo, own_hi);
+}
+
+// ---------------------------------------------------------------- Replace path
+namespace {
+struct ParsedTemplate {
+  std::vector<ReplSeg> segs;     // resolved against the program's capture names
+  std::vector<uint8_t> lits;
+};
+
+bool IsLatin1Letter(unsigned c) {
+  return (c >= 'A' && c <= 'Z') || (c >= 'a' && c <= 'z') || c == 0xAA || c == 0xB5 || c == 0xBA || (c >= 0xC0 && c <= 0xD6) ||
+         (c >= 0xD8 && c <= 0xF6) || (c >= 0xF8 && c <= 0xFF);
+}
+bool NameStart(unsigned c) { return c == '_' || IsLatin1Letter(c); }
+bool NameCont(unsigned c) { return NameStart(c) || (c >= '0' && c <= '9'); }
+
+// replace.Parse (template.go:45-148) over the BYTES of the template, then the run-time lookup rules of
+// replace.go:393-453 (unknown name / index beyond the groups: nothing).  Returns false with a message on a parse error.
+bool ParseTemplate(const char* t, size_t n, const Tables* tab, ParsedTemplate* out, std::string* err) {
+  auto lit = [&](const char* p, size_t k) {
+    if (!k) return;
+    if (!out->segs.empty() && out->segs.back().kind == 0 && out->segs.back().a + out->segs.back().b == (int32_t)out->lits.size()) {
+      out->segs.back().b += (int32_t)k;
+    } else {
+      out->segs.push_back({0, (int32_t)out->lits.size(), (int32_t)k});
+    }
+    out->lits.insert(out->lits.end(), p, p + k);
+  };
+  auto group = [&](int g) {
+    const int ngroups = tab ? tab->ncap / 2 - 1 : 99;
+    if (g >= 0 && g <= ngroups) out->segs.push_back({1, g, 0});
+  };
+  auto named = [&](const std::string& name) {
+    if (!tab) return;
+    for (size_t g = 1; g < tab->cap_names.size(); g++)
+      if (!tab->cap_names[g].empty() && tab->cap_names[g] == name) { group((int)g); return; }
+  };
+  size_t i = 0, lit0 = 0;
+  while (i < n) {
+    if (t[i] != '$') { i++; continue; }
+    lit(t + lit0, i - lit0);
+    if (i + 1 >= n) { lit("$", 1); i++; lit0 = i; continue; }
+    const unsigned nxt = (unsigned char)t[i + 1];
+    if (nxt == '$') { lit("$", 1); i += 2; }
+    else if (nxt == '{') {
+      size_t close = i;
+      while (close < n && t[close] != '}') close++;
+      if (close >= n) { *err = "invalid replace template: unclosed ${"; return false; }
+      const std::string content(t + i + 2, close - (i + 2));
+      if (content.empty()) { *err = "invalid replace template: empty ${}"; return false; }
+      if (content[0] >= '0' && content[0] <= '9') {
+        long idx = 0;
+        for (char ch : content) {
+          if (ch < '0' || ch > '9') { *err = "invalid replace template: mixed digits and non-digits in ${}"; return false; }
+          idx = idx * 10 + (ch - '0');
+          if (idx > 1000000) idx = 1000000;
+        }
+        group((int)idx);
+      } else {
+        bool ok = true;
+        for (size_t k = 0; k < content.size() && ok; k++) {
+          const unsigned ch = (unsigned char)content[k];
+          ok = ch >= 0x80 ? true : (k == 0 ? NameStart(ch) : NameCont(ch));   // non-ASCII runes: taken as letters (see header)
+        }
+        if (!ok) { *err = "invalid replace template: invalid capture name in ${}"; return false; }
+        named(content);
+      }
+      i = close + 1;
+    } else if (nxt == '0') { group(0); i += 2; }
+    else if (nxt >= '1' && nxt <= '9') {
+      int idx = (int)(nxt - '0');
+      size_t used = 2;
+      if (i + 2 < n && t[i + 2] >= '0' && t[i + 2] <= '9') { idx = idx * 10 + (t[i + 2] - '0'); used = 3; }
+      group(idx);
+      i += used;
+    } else if (NameStart(nxt)) {
+      size_t end = i + 2;
+      while (end < n && NameCont((unsigned char)t[end])) end++;
+      named(std::string(t + i + 1, end - (i + 1)));
+      i = end;
+    } else { lit("$", 1); i++; }
+    lit0 = i;
+  }
+  lit(t + lit0, i - lit0);
+  return true;
+}
+}  // namespace
+
+RGX_API int rgx_replace_template_check(const char* tmpl, size_t tmpl_len) {
+  if (!tmpl && tmpl_len) return RGX_E_INVALID;
+  ParsedTemplate pt;
+  std::string err;
+  if (!ParseTemplate(tmpl, tmpl_len, nullptr, &pt, &err)) { SetError(err); return RGX_E_INVALID; }
+  return RGX_OK;
+}
+
+RGX_API int64_t rgx_replace_all_bytes_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, const char* tmpl,
+                                             size_t tmpl_len, int first_only, uint8_t* d_out, size_t cap_out, int64_t* out_len,
+                                             rgx_result* res) {
+  int rc = CheckCtx(p, c);
+  if (rc != RGX_OK) return rc;
+  if (!out_len || (!tmpl && tmpl_len)) return RGX_E_INVALID;
+  const Tables& t = p->p.t;
+  const DevTables& T = p->p.dev;
+  ParsedTemplate pt;
+  std::string err;
+  if (!ParseTemplate(tmpl, tmpl_len, &t, &pt, &err)) { SetError(err); return RGX_E_INVALID; }
+  if (len > 0x7FFFFF00ull) { SetError("buffer larger than 2^31-256 bytes: shard it"); return RGX_E_TOO_LARGE; }
+  const int32_t ilen = (int32_t)len;
+  const int ncap = T.ncap;
+  // 1. the ordered span table (device scratch of the context)
+  const int64_t cap_rec = (int64_t)(len / (size_t)std::max(t.min_len, 1)) + 4;
+  if ((rc = Ensure(&c->d_rspans, &c->rspans_cap, cap_rec * ncap)) != RGX_OK) return rc;
+  rgx_result r{};
+  int64_t n = 0;
+  if (len > 0) {
+    n = FindAllDevice(p, c, d_buf, len, first_only ? 1 : -1, c->d_rspans, (size_t)cap_rec - 2, false, &r);
+    if (n < 0) return n;
+  }
+  // 2. the emitted loop also tries at offset len (FindBytesReuse on the empty remainder, find.go:545-569)
+  if (t.can_match_empty && (!t.anchored || len == 0) && !(first_only && n > 0)) {
+    int32_t* d_end = (int32_t*)(c->d_rspans + (cap_rec - 1) * ncap);
+    int32_t h_end = -1;
+    if (len > 0) {
+      HIP_TRY(LaunchAttemptAt(T, d_buf, ilen, ilen, d_end, c->stream));
+      HIP_TRY(hipMemcpyAsync(&h_end, d_end, 4, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+    } else {
+      h_end = 0;   // an empty input: the pattern matches empty at 0 by definition of can_match_empty... checked below
+      // (start_accept for begin-of-text context; patterns in lookahead mode decide at end of text)
+      HIP_TRY(LaunchAttemptAt(T, d_buf ? d_buf : (const uint8_t*)c->d_rspans, 0, 0, d_end, c->stream));
+      HIP_TRY(hipMemcpyAsync(&h_end, d_end, 4, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    if (h_end == ilen) {
+      std::vector<int32_t> rec(ncap, (t.flags & RGX_FLAG_UNMATCHED_MINUS1) ? -1 : 0);
+      rec[0] = ilen; rec[1] = ilen;
+      if (t.fixed_captures)
+        for (int k = 2; k < ncap; k++) rec[k] = t.cap_kind[k] == kCapFromStart ? ilen + t.cap_delta[k] : ilen - t.cap_delta[k];
+      HIP_TRY(hipMemcpyAsync(c->d_rspans + n * ncap, rec.data(), (size_t)ncap * 4, hipMemcpyHostToDevice, c->stream));
+      if (!t.fixed_captures) {
+        int64_t need = (int64_t)len + 64;
+        if ((rc = Ensure(&c->d_trace, &c->trace_cap, need)) != RGX_OK) return rc;
+        HIP_TRY(hipMemsetAsync(c->d_total + 1, 0, 8, c->stream));
+        HIP_TRY(LaunchCaptures(T, d_buf ? d_buf : (const uint8_t*)c->d_rspans, ilen, c->d_rspans + n * ncap, 1, c->d_trace, c->d_total + 1,
+                               c->stream));
+      }
+      n++;
+    }
+  }
+  // 3. sizes and the prefix sum
+  const size_t temp_bytes = ReplaceScanTempBytes(n);
+  const size_t seg_bytes = (pt.segs.size() * sizeof(ReplSeg) + 15) & ~size_t(15);
+  const size_t lit_bytes = (pt.lits.size() + 15) & ~size_t(15);
+  if ((rc = Ensure(&c->d_rdelta, &c->rdelta_cap, 2 * (n + 1) + 2)) != RGX_OK) return rc;
+  if ((rc = Ensure(&c->d_rtemp, &c->rtemp_cap, (int64_t)(temp_bytes + 256 + seg_bytes + lit_bytes + 64))) != RGX_OK) return rc;
+  uint8_t* base = c->d_rtemp;
+  ReplSeg* d_segs = (ReplSeg*)base;
+  uint8_t* d_lits = base + seg_bytes;
+  void* d_temp = base + seg_bytes + lit_bytes + ((256 - ((seg_bytes + lit_bytes) & 255)) & 255);
+  if (!pt.segs.empty()) HIP_TRY(hipMemcpyAsync(d_segs, pt.segs.data(), pt.segs.size() * sizeof(ReplSeg), hipMemcpyHostToDevice, c->stream));
+  if (!pt.lits.empty()) HIP_TRY(hipMemcpyAsync(d_lits, pt.lits.data(), pt.lits.size(), hipMemcpyHostToDevice, c->stream));
+  long long* d_delta = c->d_rdelta;
+  long long* d_shift = c->d_rdelta + (n + 1);
+  HIP_TRY(LaunchReplaceSizes(c->d_rspans, n, ncap, d_segs, (int)pt.segs.size(), d_delta, d_shift, d_temp, temp_bytes, c->stream));
+  long long gain = 0;
+  HIP_TRY(hipMemcpyAsync(&gain, d_shift + n, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  *out_len = (int64_t)len + gain;
+  if (res) { *res = r; res->total = n; res->written = n; }
+  if ((size_t)*out_len > cap_out || (!d_out && *out_len > 0)) { SetError("output capacity too small"); return RGX_E_CAPACITY; }
+  // 4. gaps and replacements
+  if (*out_len > 0)
+    HIP_TRY(LaunchReplaceWrite(d_buf, ilen, c->d_rspans, n, ncap, d_segs, (int)pt.segs.size(), d_lits, d_shift, d_out, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return *out_len;
 }
 
 RGX_API int64_t rgx_find_all_starts_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n,

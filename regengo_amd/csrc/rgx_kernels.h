@@ -73,4 +73,18 @@ bool BatchSearchFits(const DevTables& U, const DevTables& F, bool want_spans, co
 hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8_t* concat, const uint64_t* offsets, int64_t nstr,
                              uint8_t* found, int32_t* spans, void* trace, hipStream_t stream);
 
+// ---- Replace path (rgx_replace.hip).  A resolved template segment: kind 0 = literal bytes lits[a, a+b); kind 1 = the text of
+// capture group a (0 = the whole match).
+struct ReplSeg {
+  int32_t kind, a, b;
+};
+size_t ReplaceScanTempBytes(int64_t nmatches);
+// delta[i] = replacement length - match length (i < n), shift = exclusive sum over n+1 entries (shift[n] = total gain)
+hipError_t LaunchReplaceSizes(const int32_t* spans, int64_t n, int ncap, const ReplSeg* d_segs, int nseg, long long* d_delta, long long* d_shift,
+                              void* d_temp, size_t temp_bytes, hipStream_t stream);
+hipError_t LaunchReplaceWrite(const uint8_t* in, int32_t len, const int32_t* spans, int64_t n, int ncap, const ReplSeg* d_segs, int nseg,
+                              const uint8_t* d_lits, const long long* d_shift, uint8_t* out, hipStream_t stream);
+// one anchored attempt at `pos` (the loop's extra try at offset len, find.go:545-569): *out_end = match end or -1
+hipError_t LaunchAttemptAt(const DevTables& T, const uint8_t* buf, int32_t len, int32_t pos, int32_t* out_end, hipStream_t stream);
+
 }  // namespace rgx

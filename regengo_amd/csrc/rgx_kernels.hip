@@ -1232,6 +1232,16 @@ hipError_t LaunchWSyncFill(int32_t* carry_in, int32_t len, hipStream_t stream) {
 }
 int32_t WSyncChunks(int32_t len) { return (len + kWChunkBytes - 1) / kWChunkBytes; }
 
+namespace {
+__global__ void attempt_at_kernel(DevTables T, const uint8_t* buf, int32_t len, int32_t pos, int32_t* out_end) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *out_end = WalkGlobal(T, buf, len, pos);
+}
+}  // namespace
+hipError_t LaunchAttemptAt(const DevTables& T, const uint8_t* buf, int32_t len, int32_t pos, int32_t* out_end, hipStream_t stream) {
+  hipLaunchKernelGGL(attempt_at_kernel, dim3(1), dim3(64), 0, stream, T, buf, len, pos, out_end);
+  return hipGetLastError();
+}
+
 hipError_t LaunchCarry(const DevTables& T, const uint8_t* buf, int32_t len, const uint8_t* slice_unsynced, int32_t* carry_in,
                        int32_t nslices, hipStream_t stream) {
   dim3 block(256), grid((nslices + 255) / 256);

@@ -1,0 +1,93 @@
+"""GPU tier: the Replace path (ReplaceAllBytes / ReplaceFirstBytes with run-time templates) through the C ABI against the
+oracle's restatement of the emitted loop, read quirk-free (oracle/replace.py: true leftmost-first matches in their real
+context; the reference's re-slicing quirks Q1/Q4'/Q12 are documented in DESIGN.md and reproduced by quirks=True)."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TEMPLATES = ["", "X", "$0", "[$0]", "<$1>", "$2-$1", "${1}x$$", "$name $user ${domain} $nope", "$9$12", "a$", "$ $$ ${0}${0}",
+             "€$1é"]
+
+
+@pytest.fixture(scope="module")
+def gpu(built):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU; there is no CPU fallback")
+    return torch
+
+
+def test_template_errors(gpu):
+    from regengo_amd import Compiled, _capi
+    c = Compiled(r"(\w+)@(\w+)").to(0)
+    for bad in ("${unclosed", "${}", "${1abc}", "${123abc}"):
+        with pytest.raises(_capi.RgxError) as ei:
+            c.ReplaceAllBytes(b"a@b", bad)
+        assert ei.value.status == _capi.RGX_E_INVALID
+        assert _capi.lib().rgx_replace_template_check(bad.encode(), len(bad.encode())) == _capi.RGX_E_INVALID
+    assert _capi.lib().rgx_replace_template_check(b"$1 ${name} $$", 13) == 0
+
+
+def test_replace_matches_oracle_on_corpus(gpu, corpus, kats):
+    from oracle import engines as E
+    from oracle import replace as R
+    from regengo_amd import Compiled, _capi
+    rng = random.Random(31)
+    items = [(e["pattern"], e["inputs"]) for e in corpus] + [(c["pattern"], c["inputs"]) for c in kats["curated_cases"]]
+    checked = pats = 0
+    for pat, inputs in items:
+        try:
+            c = Compiled(pat).to(0)
+        except _capi.RgxError:
+            continue
+        o = E.Compiled(pat)
+        if c.info.lookahead_mode or "^" in pat or "\\b" in pat or "\\B" in pat or "\\A" in pat:
+            continue          # context-sensitive: the reference's re-slicing (Q12) changes what `^`/`\b` see; not the GPU's reading
+        bs = [s.encode() for s in inputs]
+        texts = bs + [b" ".join(bs), b"\n".join(bs * 3), b""]
+        alpha = b"".join(bs) or b"a"
+        texts += [bytes(rng.choice(alpha) for _ in range(rng.randint(0, 150))) for _ in range(3)]
+        tmpls = rng.sample(TEMPLATES, 4) + ["[$0]"]
+        for b in texts:
+            for t in tmpls:
+                exp = R.replace_all(o, b, t)
+                got = c.ReplaceAllBytes(b, t)
+                assert got == exp, (pat, b, t, got, exp)
+                checked += 1
+            assert c.ReplaceFirstBytes(b, "<$0>") == R.replace_all(o, b, "<$0>", first_only=True), (pat, b)
+        pats += 1
+    assert pats >= 75 and checked > 2500
+
+
+def test_replace_large_and_closed_form(gpu):
+    """64 MiB date log: every date YYYY-MM-DD -> DD/MM/YYYY (same length) and -> <YYYY> (shorter): checked against the
+    closed form of the synthetic stream and against the oracle on a prefix."""
+    from oracle import engines as E
+    from oracle import replace as R
+    from regengo_amd import Compiled, synth
+    torch = gpu
+    n = 1 << 26
+    DATE = r"(?P<year>\d{4})-(?P<month>\d{2})-(?P<day>\d{2})"
+    buf = synth.date_log_torch(n, "cuda:0")
+    c = Compiled(DATE).to(0)
+    out, cnt = c.ReplaceAllDevice(buf, "$day/$month/$year")
+    assert cnt == n // 50 + 1 and out.numel() == n
+    host = buf[: 1 << 16].cpu().numpy().tobytes()
+    assert out[: 1 << 16].cpu().numpy().tobytes()[: (1 << 16) - 16] == R.replace_all(E.Compiled(DATE), host, "$day/$month/$year")[: (1 << 16) - 16]
+    out2, cnt2 = c.ReplaceAllDevice(buf, "<$1>")
+    assert cnt2 == cnt and out2.numel() == n - 4 * cnt
+    # every 46-byte period of the result starts with "<2024>"
+    per = out2[: 46 * 1000].view(1000, 46)
+    assert bool((per[:, :6] == torch.tensor(list(b"<2024>"), dtype=torch.uint8, device="cuda:0")[None, :]).all())
+    # and the bytes outside matches are untouched, in order
+    keep = torch.ones(n, dtype=torch.bool, device="cuda:0")
+    idx = (torch.arange(0, n, 50, device="cuda:0")[:, None] + torch.arange(10, device="cuda:0")[None, :]).flatten()
+    keep[idx[idx < n]] = False
+    gaps_in = buf[keep]
+    keep2 = torch.ones(out2.numel(), dtype=torch.bool, device="cuda:0")
+    idx2 = (torch.arange(0, out2.numel(), 46, device="cuda:0")[:, None] + torch.arange(6, device="cuda:0")[None, :]).flatten()
+    keep2[idx2[idx2 < out2.numel()]] = False
+    assert torch.equal(out2[keep2], gaps_in)
