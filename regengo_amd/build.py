@@ -54,7 +54,7 @@ def _run(cmd):
 def _all_headers():
     hs = [os.path.join(ROOT, "include", "rgx.h")]
     for d, _, fs in os.walk(CSRC):
-        hs += [os.path.join(d, f) for f in fs if f.endswith(".h")]
+        hs += [os.path.join(d, f) for f in fs if f.endswith(".h") or f.endswith(".inc")]
     return hs
 
 

@@ -20,6 +20,9 @@ struct Node {
   std::bitset<256> bytes;
   int next_node = -1;  // mid-sequence successor (multi-byte literal), else -1
   int out_pc = -1;     // instruction to continue at when the rune is complete
+  // UTF-8 decoding classes: a node of the class's byte trie.  Disjoint byte sets, each leading to another trie node
+  // (>= 0) or completing the rune (-1: continue at out_pc).  Empty for ordinary nodes.
+  std::vector<std::pair<std::bitset<256>, int>> edges;
 };
 
 struct Leaf {
@@ -32,7 +35,6 @@ struct Builder {
   const Prog& p;
   int ninst;
   std::vector<Node> nodes;  // index = node id (ids < ninst are rune instructions; others unused)
-  std::vector<std::vector<int>> alt_heads;   // per instruction: heads of the UTF-8 sequence chains of a non-ASCII class
   bool has_utf8_class = false;
   bool has_bol = false, has_eol = false, has_bot = false, has_eot = false, has_wb = false;
   bool lookahead = false;
@@ -49,49 +51,84 @@ struct Builder {
   // -- the bytes that can never begin a rune (80-BF, C0, C1, F5-FF), which DecodeRune reports as (RuneError, 1).
   // Limitation (rgx_info.needs_valid_utf8): a lead byte followed by a wrong continuation byte is (RuneError, 1) in the
   // reference too; that needs look-ahead and is not modelled, so results are exact on ASCII / valid UTF-8 input.
-  void AddChain(int pc, const std::vector<std::pair<int, int>>& seq, int out) {
-    int head = -1, cur = -1;
-    for (size_t j = 0; j < seq.size(); j++) {
-      nodes.push_back(Node());
-      const int id = (int)nodes.size() - 1;
-      for (int b = seq[j].first; b <= seq[j].second; b++) nodes[id].bytes.set(b);
-      if (cur >= 0) nodes[cur].next_node = id; else head = id;
-      cur = id;
-    }
-    nodes[cur].out_pc = out;
-    alt_heads[pc].push_back(head);
-  }
-  void Utf8Split(int pc, int32_t lo, int32_t hi, int out) {
+  typedef std::vector<std::pair<int, int>> ByteSeq;   // one UTF-8 sequence shape: a byte range per position
+  void Utf8Split(int32_t lo, int32_t hi, std::vector<ByteSeq>* out) {
     if (lo > hi) return;
     if (lo < 0x80) lo = 0x80;
     if (lo > hi) return;
     if (lo <= 0xDFFF && hi >= 0xD800) {   // surrogates are not encodable
-      Utf8Split(pc, lo, 0xD7FF, out);
-      Utf8Split(pc, 0xE000, hi, out);
+      Utf8Split(lo, 0xD7FF, out);
+      Utf8Split(0xE000, hi, out);
       return;
     }
     static const int32_t maxv[3] = {0x7FF, 0xFFFF, 0x10FFFF};
     for (int i = 0; i < 2; i++)
-      if (lo <= maxv[i] && hi > maxv[i]) { Utf8Split(pc, lo, maxv[i], out); Utf8Split(pc, maxv[i] + 1, hi, out); return; }
+      if (lo <= maxv[i] && hi > maxv[i]) { Utf8Split(lo, maxv[i], out); Utf8Split(maxv[i] + 1, hi, out); return; }
     if (hi > 0x10FFFF) hi = 0x10FFFF;
     for (int i = 1; i < 4; i++) {
       const int32_t m = (1 << (6 * i)) - 1;
       if ((lo & ~m) != (hi & ~m)) {
-        if ((lo & m) != 0) { Utf8Split(pc, lo, lo | m, out); Utf8Split(pc, (lo | m) + 1, hi, out); return; }
-        if ((hi & m) != m) { Utf8Split(pc, lo, (hi & ~m) - 1, out); Utf8Split(pc, hi & ~m, hi, out); return; }
+        if ((lo & m) != 0) { Utf8Split(lo, lo | m, out); Utf8Split((lo | m) + 1, hi, out); return; }
+        if ((hi & m) != m) { Utf8Split(lo, (hi & ~m) - 1, out); Utf8Split(hi & ~m, hi, out); return; }
       }
     }
     uint8_t a[4], b[4];
     const int n = EncodeRune(lo, a), n2 = EncodeRune(hi, b);
     if (n != n2) throw Unsupported{"internal: UTF-8 range split"};
-    std::vector<std::pair<int, int>> seq;
+    ByteSeq seq;
     for (int j = 0; j < n; j++) seq.push_back({a[j], b[j]});
-    AddChain(pc, seq, out);
+    out->push_back(seq);
+  }
+  // Deterministic byte trie over a set of sequence shapes, suffixes shared (memo on the set of remaining suffixes).
+  // Returns the node id of the trie for `seqs` taken from position `depth`; -1 = "rune complete".
+  int BuildTrie(const std::vector<ByteSeq>& all, std::vector<int> idx, int depth, int out, std::map<std::pair<std::vector<int>, int>, int>* memo,
+                int force_id = -1) {
+    auto key = std::make_pair(idx, depth);
+    if (force_id < 0) {
+      auto it = memo->find(key);
+      if (it != memo->end()) return it->second;
+    }
+    int id = force_id;
+    if (id < 0) { nodes.push_back(Node()); id = (int)nodes.size() - 1; }
+    (*memo)[key] = id;
+    // child (as a set of sequence indices) per byte value
+    std::map<std::vector<int>, std::bitset<256>> groups;
+    std::bitset<256> complete;
+    for (int b = 0; b < 256; b++) {
+      std::vector<int> sub;
+      bool done = false;
+      for (int i : idx) {
+        const ByteSeq& q = all[i];
+        if (b < q[depth].first || b > q[depth].second) continue;
+        if ((int)q.size() == depth + 1) done = true; else sub.push_back(i);
+      }
+      if (done) complete.set(b);
+      else if (!sub.empty()) groups[sub].set(b);
+    }
+    std::vector<std::pair<std::bitset<256>, int>> edges;
+    if (complete.any()) edges.push_back({complete, -1});
+    for (auto& g : groups) {
+      const int child = BuildTrie(all, g.first, depth + 1, out, memo);
+      edges.push_back({g.second, child});
+    }
+    Node& nd = nodes[id];
+    nd.edges = edges;
+    nd.out_pc = out;
+    for (auto& e : edges) nd.bytes |= e.first;
+    return id;
+  }
+  // successor of `node` on a byte of class k: another node id (>= ninst) or an instruction index
+  int Target(int node, int k) const {
+    const Node& nd = nodes[node];
+    if (nd.edges.empty()) return nd.next_node >= 0 ? nd.next_node : nd.out_pc;
+    int rep = 0;
+    while (!class_bytes[k][rep]) rep++;
+    for (auto& e : nd.edges) if (e.first[rep]) return e.second >= 0 ? e.second : nd.out_pc;
+    return nd.out_pc;   // not reached: callers test NodeAccepts first
   }
 
   explicit Builder(const Prog& prog) : p(prog), ninst((int)prog.inst.size()) {
     nodes.resize(ninst);
-    alt_heads.resize(ninst);
     for (int c = 0; c < 256; c++)
       if ((c >= '0' && c <= '9') || (c >= 'A' && c <= 'Z') || c == '_' || (c >= 'a' && c <= 'z')) word_bytes.set(c);
     nl_bytes.set('\n');
@@ -125,20 +162,27 @@ struct Builder {
             nodes[pc].out_pc = in.out;
             break;
           }
-          bool has_fffd = false;
+          // one deterministic byte trie per class: ASCII members, UTF-8 sequences of the non-ASCII ranges, and (class
+          // contains U+FFFD) the bytes that cannot begin a rune
+          std::vector<ByteSeq> seqs;
+          bool has_fffd = false, non_ascii = false;
           for (size_t i = 0; i + 1 < R.size(); i += 2) {
-            for (int32_t c = R[i]; c <= R[i + 1] && c < 128; c++) nodes[pc].bytes.set(c);
+            if (R[i] < 128) seqs.push_back({{(int)R[i], (int)std::min<int32_t>(R[i + 1], 127)}});
             if (R[i + 1] >= 128) {
-              has_utf8_class = true;
-              Utf8Split(pc, R[i], R[i + 1], (int)in.out);
+              non_ascii = true;
+              Utf8Split(R[i], R[i + 1], &seqs);
               if (R[i] <= 0xFFFD && R[i + 1] >= 0xFFFD) has_fffd = true;
             }
           }
-          if (has_fffd) {   // bytes that cannot begin a rune decode as (RuneError, 1)
-            std::vector<std::pair<int, int>> one;
-            AddChain(pc, {{0x80, 0xBF}}, (int)in.out);
-            AddChain(pc, {{0xC0, 0xC1}}, (int)in.out);
-            AddChain(pc, {{0xF5, 0xFF}}, (int)in.out);
+          if (!non_ascii) {
+            for (auto& q : seqs) for (int c = q[0].first; c <= q[0].second; c++) nodes[pc].bytes.set(c);
+          } else {
+            has_utf8_class = true;
+            if (has_fffd) { seqs.push_back({{0x80, 0xBF}}); seqs.push_back({{0xC0, 0xC1}}); seqs.push_back({{0xF5, 0xFF}}); }
+            std::vector<int> idx(seqs.size());
+            for (size_t i = 0; i < seqs.size(); i++) idx[i] = (int)i;
+            std::map<std::pair<std::vector<int>, int>, int> memo;
+            BuildTrie(seqs, idx, 0, (int)in.out, &memo, pc);
           }
           nodes[pc].out_pc = in.out;
           break;
@@ -168,7 +212,10 @@ struct Builder {
 
   void ComputeClasses() {
     std::vector<std::bitset<256>> sets;
-    for (auto& n : nodes) if (n.bytes.any()) sets.push_back(n.bytes);
+    for (auto& n : nodes) {
+      if (n.edges.empty()) { if (n.bytes.any()) sets.push_back(n.bytes); }
+      else for (auto& e : n.edges) sets.push_back(e.first);
+    }
     if (has_bol || has_eol) sets.push_back(nl_bytes);
     if (has_wb) sets.push_back(word_bytes);
     std::map<std::vector<bool>, int> sig2cls;
@@ -257,8 +304,7 @@ struct Builder {
           return;
         }
         default:  // byte-consuming
-          if (nodes[id].bytes.any() || alt_heads[id].empty()) leaves->push_back({id, parent, ops});
-          for (int h : alt_heads[id]) if (!seen[h]) { seen[h] = 1; leaves->push_back({h, parent, ops}); }
+          leaves->push_back({id, parent, ops});
           return;
       }
     };
@@ -282,8 +328,7 @@ struct Builder {
         case InstNop: case InstCapture: case InstEmptyWidth: add(in.out); return;
         case InstAlt: case InstAltMatch: add(in.out); add(in.arg); return;
         default:
-          if (nodes[id].bytes.any() || alt_heads[id].empty()) leaves->push_back(id);
-          for (int h : alt_heads[id]) if (!seen[h]) { seen[h] = 1; leaves->push_back(h); }
+          leaves->push_back(id);
           return;
       }
     };
@@ -431,7 +476,7 @@ Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOption
       for (auto& l : leaves) {
         if (!b.NodeAccepts(l.node, k)) continue;
         const Node& nd = b.nodes[l.node];
-        int target = nd.next_node >= 0 ? nd.next_node : nd.out_pc;
+        int target = b.Target(l.node, k);
         if (std::find(pre.begin(), pre.end(), target) != pre.end()) continue;  // lower priority duplicate
         pre.push_back(target); pre_parent.push_back(l.parent); pre_ops.push_back(l.ops);
       }
@@ -630,7 +675,7 @@ Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOption
         for (int node : src) {
           if (!b.NodeAccepts(node, k)) continue;
           const Node& nd = b.nodes[node];
-          targets.push_back(nd.next_node >= 0 ? nd.next_node : nd.out_pc);
+          targets.push_back(b.Target(node, k));
         }
         std::vector<int> leaves;
         b.ExpandAll(targets, &leaves);

@@ -210,6 +210,7 @@ static Runes NegateClass(const Runes& r) {
 }
 
 struct Group { int sign; Runes cls; };
+#include "rgx_unicode_tables.inc"
 static const std::map<std::string, Group>& PerlGroups() {
   static const std::map<std::string, Group> g = {
       {"\\d", {+1, {0x30, 0x39}}}, {"\\D", {-1, {0x30, 0x39}}},
@@ -733,11 +734,37 @@ struct Parser {
     t = i + 2;
     return true;
   }
-  bool ParseUnicodeClass(const Str& s, size_t t) {
+  // \p{Name} \pN \P{Name} \p{^Name} (parse.go: parseUnicodeClass).  Tables: rgx_unicode_tables.inc.
+  bool ParseUnicodeClass(const Str& s, size_t& t, Runes& r) {
     if (!(flags & kUnicodeGroups) || s.size() - t < 2 || s[t] != '\\' || (s[t + 1] != 'p' && s[t + 1] != 'P')) return false;
-    // Unicode property tables are not carried by this front-end (yet): a valid Go pattern, an
-    // unsupported feature here.  Signalled with a distinguished message the C API maps to RGX_E_UNSUPPORTED.
-    throw SyntaxError{"unsupported: \\p{..} Unicode class"};
+    int sign = s[t + 1] == 'P' ? -1 : +1;
+    size_t i = t + 2;
+    if (i >= s.size()) throw SyntaxError{"invalid character class range"};
+    std::string name;
+    if (s[i] != '{') {
+      if (s[i] > 127) throw SyntaxError{"invalid character class range"};
+      name.push_back((char)s[i]);
+      i++;
+    } else {
+      size_t end = i;
+      while (end < s.size() && s[end] != '}') end++;
+      if (end >= s.size()) throw SyntaxError{"invalid character class range"};
+      for (size_t k = i + 1; k < end; k++) { if (s[k] > 127) throw SyntaxError{"invalid character class range"}; name.push_back((char)s[k]); }
+      i = end + 1;
+    }
+    if (!name.empty() && name[0] == '^') { sign = -sign; name.erase(0, 1); }
+    Runes tab;
+    if (name == "Any") { tab = {0, kMaxRune}; }
+    else {
+      const UniTable* found = nullptr;
+      for (const UniTable& u : kUniTables) if (name == u.name) found = &u;
+      if (!found) throw SyntaxError{"unsupported: \\p{" + name + "} (no table for this Unicode class)"};
+      tab.assign(found->r, found->r + 2 * found->npairs);
+    }
+    if (flags & kFoldCase) { Runes tmp; AppendFoldedClass(tmp, tab); tab = CleanClass(tmp); }
+    if (sign > 0) AppendClass(r, tab); else AppendNegatedClass(r, CleanClass(tab));
+    t = i;
+    return true;
   }
 
   size_t ParseClass(const Str& s, size_t start) {
@@ -755,7 +782,7 @@ struct Parser {
         throw SyntaxError{"invalid character class range"};
       first = false;
       if (s.size() - t > 2 && s[t] == '[' && s[t + 1] == ':') { if (ParseNamedClass(s, t, cls)) continue; }
-      ParseUnicodeClass(s, t);
+      if (ParseUnicodeClass(s, t, cls)) continue;
       if (ParsePerlClassEscape(s, t, cls)) continue;
       int32_t lo = ParseClassChar(s, t), hi = lo;
       if (s.size() - t >= 2 && s[t] == '-' && s[t + 1] != ']') {
@@ -843,8 +870,8 @@ struct Parser {
           }
           if (handled) break;
           auto re = NewRe(OpCharClass, flags);
-          if (s.size() - t >= 2 && (s[t + 1] == 'p' || s[t + 1] == 'P')) ParseUnicodeClass(s, t);
           Runes r;
+          if (s.size() - t >= 2 && (s[t + 1] == 'p' || s[t + 1] == 'P') && ParseUnicodeClass(s, t, r)) { re->rune = r; Push(re); break; }
           if (ParsePerlClassEscape(s, t, r)) { re->rune = r; Push(re); break; }
           Literal(ParseEscape(s, t));
           break;

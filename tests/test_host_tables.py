@@ -186,9 +186,19 @@ def test_exact_shift_and_for_date(hostlib):
 
 
 def test_unsupported_features_are_refused(hostlib):
-    for p in (r"\p{L}+", r"[\p{L}\p{N}]+"):
+    for p in (r"\p{Han}+", "(a)" * 16):       # no table carried for the script / more than 15 capture groups
         with pytest.raises(ValueError):
             hostlib.HostProgram(p)
+
+
+def test_unicode_property_classes(hostlib):
+    """\\p{..} classes (tables generated from the same source the oracle uses): bit-exact vs the oracle."""
+    texts = ["héllo wörld 123 ΑΒΓ αβγ שלום 日本語 x".encode(), b"abc \xff def", "Ωx ωx ".encode(), b"", "a😀b\U0010FFFFc ٣٤".encode()]
+    for p in (r"\p{L}+", r"\p{Greek}+", r"[\p{L}\p{N}]+", r"\p{Hebrew}+", r"\P{L}+", r"\pN+", r"[^\p{Lu}\s]+", r"\p{^Greek}x", r"\p{Nd}{2}"):
+        hp = hostlib.HostProgram(p)
+        o = E.Compiled(p)
+        for b in texts:
+            assert hp.find_all(b) == o.find_machine.find_all(b), (p, b)
 
 
 def test_utf8_decoding_classes(hostlib):
