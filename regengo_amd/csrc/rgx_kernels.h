@@ -35,7 +35,7 @@ size_t ScanSharedBytes(const DevTables& T);
 int32_t ScanNumTiles(const DevTables& T, int32_t len, bool use_w = false);
 // rgx_scan_exact.hip: the branch-free Shift-And kernel for fixed-length class chains
 bool UseExactKernel(const DevTables& T, int32_t len);
-int ExactNumBlocks(int32_t len);
+int ExactNumBlocks(const DevTables& T, int32_t len);
 hipError_t LaunchScanExact(const DevTables& T, const ScanParams& P, hipStream_t stream);
 // rgx_scan_sa.hip: same structure, Shift-And as a prefilter + DFA verification (variable-length matches)
 bool UseSaKernel(const DevTables& T, int32_t len);

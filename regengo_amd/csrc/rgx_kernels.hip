@@ -1149,7 +1149,7 @@ size_t ScanSharedBytes(const DevTables& T) {
 }
 
 int32_t ScanNumTiles(const DevTables& T, int32_t len, bool use_w) {
-  if (UseExactKernel(T, len)) return ExactNumBlocks(len);
+  if (UseExactKernel(T, len)) return ExactNumBlocks(T, len);
   const int per = (UseSaKernel(T, len) && !getenv("RGX_NO_SA_KERNEL") && !use_w) ? SaTileBytes() : kTileBytes;
   return (len + per - 1) / per;
 }

@@ -35,9 +35,14 @@ namespace rgx {
 
 namespace {
 
+// 8 waves per workgroup: one look-back descriptor per 8 x 8 wave-tiles.  The look-back keeps up with ~64 descriptors per L2
+// round trip; at 4 waves per workgroup a 1 GiB scan retires ~41 workgroups/us and every workgroup sat several round trips
+// in it with no loads in flight (measured: 0.04 ms of a 0.20 ms scan).
+constexpr int kExactThreads = 512;
 constexpr int kRowBytes = 80;
 constexpr int kWaveSlices = 63;                               // owned slices per wave-tile
 constexpr int kWaveTileBytes = kWaveSlices * kSliceBytes;     // 4032 bytes of input owned per wave-tile
+constexpr int kWaveTileBytesLag = 62 * kSliceBytes;           // K <= 16: lane 63 only supplies its neighbour's look-ahead
 constexpr int kWaveRows = 65;                                 // 64 slices + one look-ahead row
 constexpr int kWaveLds = kWaveRows * kRowBytes;               // 5200 bytes
 constexpr int kGroupTiles = 8;                                // wave-tiles per look-back descriptor
@@ -47,7 +52,7 @@ constexpr int kStartsCap = kWaveLds / 4;                      // match starts st
 // UP over the first wave of resident workgroups (they all start together: with equal sizes they would all finish
 // counting together and the look-back would be a chain through every one of them; with growing sizes a workgroup's
 // predecessors have already published) and ramp DOWN at the end (a short tail instead of half a chunk of idle CUs).
-constexpr int kPlanSegs = 16;
+constexpr int kPlanSegs = 34;
 struct ExactPlan {
   int nseg;
   int nblocks;
@@ -64,11 +69,15 @@ struct ExactLds {
                              // (W16: 256 uint16 entries instead -- 4 byte values per LDS bank instead of 8)
   int off[32];               // capture template: slot c = match start + off[c]
   unsigned ticket;
-  unsigned wtot[kBlockThreads / 64];   // matches per wave of this workgroup
+  unsigned wtot[kExactThreads / 64];   // matches per wave of this workgroup
   unsigned base_lo, base_hi;           // exclusive prefix of the workgroup (from the look-back)
   unsigned pad[1];
-  __attribute__((aligned(16))) unsigned char tile[kBlockThreads / 64][kWaveLds];
+  __attribute__((aligned(16))) unsigned char tile[kExactThreads / 64][kWaveLds];
 };
+
+__device__ __forceinline__ unsigned DppWaveShl1(unsigned x) {
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x130, 0xF, 0xF, true);   // lane l <- lane l+1, lane 63 <- 0
+}
 
 __device__ __forceinline__ unsigned DppWaveShr1(unsigned x) {
   return (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x138, 0xF, 0xF, true);   // lane l <- lane l-1, lane 0 <- 0
@@ -99,19 +108,25 @@ __device__ __forceinline__ unsigned DppInclusiveScan(unsigned x) {
 // PER = dwords between two harvests of the accept history: 4*PER <= 33-K.  W16 (K <= 16): 16-bit table entries, which
 // halves the number of distinct byte values sharing an LDS bank (on ASCII text: far fewer bank conflicts).
 template <int PER, bool W16>
-__global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, ScanParams P, ExactPlan plan) {
+__global__ __launch_bounds__(kExactThreads) void scan_exact_kernel(DevTables T, ScanParams P, ExactPlan plan) {
   __shared__ ExactLds L;
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int K = T.sa_k;
+  // K <= 16 (W16): the look-ahead costs no lookups.  Shift-Or is linear -- E after n more bytes is (E << n) | G with
+  // G = OR of the bytes' table words at their shifts -- and with E starting at 0 a lane's own E after its first 4*nla
+  // bytes IS that G (the bogus accepts an all-zero start produces end before the slice: dropped with the K-1 shift).
+  // So lane l takes its look-ahead from lane l+1 with one DPP move and one shift-or; lane 63 owns nothing.
+  constexpr bool LAG = W16;
+  constexpr int TB = LAG ? kWaveTileBytesLag : kWaveTileBytes;   // input bytes owned per wave-tile
   const int smin = T.sa_smin;            // smallest shift at which the pattern can overlap itself (K: never)
   const int len = P.len;
   const int ncap = T.ncap;
 
   // table words first (oldest loads), tile prefetch next, LDS staging of the table last: the first tiles are in
   // flight while the workgroup sets up
-  const unsigned f_raw = T.sa_mask[tid];
+  const unsigned f_raw = T.sa_mask[tid & 255];
   int off_raw = 0;
   if (tid < ncap) off_raw = T.cap_kind[tid] == kCapFromStart ? T.cap_delta[tid] : K - T.cap_delta[tid];
   int blk = (int)blockIdx.x;
@@ -131,7 +146,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
   int seg = 0;
   for (int i = 1; i < plan.nseg; ++i) if (blk >= plan.seg_block[i]) seg = i;      // uniform, <= 15 scalar compares
   const int G = plan.seg_g[seg];
-  const int first_tile = plan.seg_tile[seg] + ((blk - plan.seg_block[seg]) * (kBlockThreads / 64) + wave) * G;
+  const int first_tile = plan.seg_tile[seg] + ((blk - plan.seg_block[seg]) * (kExactThreads / 64) + wave) * G;
   unsigned char* const wt = L.tile[wave];
 
   // Prefetch depth 2: the 4 KiB of tiles g+1 and g+2 are in flight (in VGPRs) while tile g is processed -- one tile
@@ -157,17 +172,19 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
     pv[S][1] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo + 1024, 0, 2);                          \
     pv[S][2] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo + 2048, 0, 2);                          \
     pv[S][3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo + 3072, 0, 2);                          \
-    if (lane < 2) pv[S][4] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo + 4096, 0, 2);            \
+    if (!LAG && lane < 2) pv[S][4] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo + 4096, 0, 2);    \
   }
   if (!(P.debug & 16)) {
-    RGX_LOAD_TILE(0, first_tile * kWaveTileBytes - kSliceBytes)
-    RGX_LOAD_TILE(1, (first_tile + 1) * kWaveTileBytes - kSliceBytes)
+    RGX_LOAD_TILE(0, first_tile * TB - kSliceBytes)
+    RGX_LOAD_TILE(1, (first_tile + 1) * TB - kSliceBytes)
   }
 
   {
     const unsigned f = ~f_raw & ((K >= 32) ? ~0u : ((1u << K) - 1u));
-    if (W16) reinterpret_cast<unsigned short*>(L.sa)[tid] = (unsigned short)f;
-    else L.sa[tid] = f;
+    if (tid < 256) {
+      if (W16) reinterpret_cast<unsigned short*>(L.sa)[tid] = (unsigned short)f;
+      else L.sa[tid] = f;
+    }
   }
   if (tid < ncap) L.off[tid] = off_raw;
   __syncthreads();   // from here to the look-back every wave runs on its own
@@ -180,7 +197,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
 #pragma unroll
   for (int g = 0; g < kGroupTiles; ++g) {
     sel[g] = 0;
-    const int tb0 = (first_tile + g) * kWaveTileBytes - kSliceBytes;   // absolute offset of slice 0 (-64 for tile 0)
+    const int tb0 = (first_tile + g) * TB - kSliceBytes;   // absolute offset of slice 0 (-64 for tile 0)
     if (g >= G || tb0 + kSliceBytes >= len) continue;                  // uniform: nothing owned by this tile
 
     // ---- stage this tile from the prefetched registers, then prefetch the next one
@@ -188,10 +205,10 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
     *reinterpret_cast<v4u*>(wt + put + 16 * kRowBytes) = pv[g & 1][1];
     *reinterpret_cast<v4u*>(wt + put + 32 * kRowBytes) = pv[g & 1][2];
     *reinterpret_cast<v4u*>(wt + put + 48 * kRowBytes) = pv[g & 1][3];
-    if (lane < 2) *reinterpret_cast<v4u*>(wt + 64 * kRowBytes + (lane << 4)) = pv[g & 1][4];
+    if (!LAG && lane < 2) *reinterpret_cast<v4u*>(wt + 64 * kRowBytes + (lane << 4)) = pv[g & 1][4];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (g + 2 < G && tb0 + 2 * kWaveTileBytes + kSliceBytes < len && !(P.debug & 16)) RGX_LOAD_TILE(g & 1, tb0 + 2 * kWaveTileBytes)
+    if (g + 2 < G && tb0 + 2 * TB + kSliceBytes < len && !(P.debug & 16)) RGX_LOAD_TILE(g & 1, tb0 + 2 * TB)
 
     // ---- candidate mask of this lane's slice (match starts in [a, a+64))
     const int a = tb0 + lane * kSliceBytes;
@@ -200,7 +217,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
       const uint4* row = reinterpret_cast<const uint4*>(wt + lane * kRowBytes);
       const uint4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
       const uint4 n0 = row[5], n1 = row[6];   // next row: 80-byte stride = 5 uint4
-      unsigned E = ~0u, det0 = 0, det1 = 0, det2 = ~0u;
+      unsigned E = LAG ? 0u : ~0u, det0 = 0, det1 = 0, det2 = ~0u, Gla = 0;
       const int hsh = 33 - K - 4 * PER;
       const unsigned tsh = W16 ? 1u : 2u;     // table entry size as a shift      // left shift that puts the 4*PER freshest accept bits at the top
 #define RGX_LU(W, B)                                                                                                              \
@@ -216,6 +233,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
 #define RGX_HARVEST(DET, NBITS) DET = __builtin_amdgcn_alignbit(DET, E << (33 - K - (NBITS)), 32 - (NBITS));
 #define RGX_STEP(W, IDX, DET)                                                     \
       RGX_WORD(W)                                                                 \
+      if (LAG && (IDX) < 4 && (IDX) + 1 == nla) Gla = E;                          \
       if (((IDX) + 1) % PER == 0) { DET = __builtin_amdgcn_alignbit(DET, E << hsh, 32 - 4 * PER); }
       RGX_STEP(r0.x, 0, det0) RGX_STEP(r0.y, 1, det0) RGX_STEP(r0.z, 2, det0) RGX_STEP(r0.w, 3, det0)
       RGX_STEP(r1.x, 4, det0) RGX_STEP(r1.y, 5, det0) RGX_STEP(r1.z, 6, det0) RGX_STEP(r1.w, 7, det0)
@@ -228,8 +246,15 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
         if (((J) + 1) % PER == 0) { det2 = __builtin_amdgcn_alignbit(det2, E << hsh, 32 - 4 * PER); } \
         else if (nla == (J) + 1) { RGX_HARVEST(det2, 4 * (((J) % PER) + 1)) }    \
       }
-      RGX_LA(n0.x, 0) RGX_LA(n0.y, 1) RGX_LA(n0.z, 2) RGX_LA(n0.w, 3)
-      RGX_LA(n1.x, 4) RGX_LA(n1.y, 5) RGX_LA(n1.z, 6)
+      if (LAG) {
+        if (nla) {
+          E = (E << (4 * nla)) | DppWaveShl1(Gla);
+          RGX_HARVEST(det2, 4 * nla)
+        }
+      } else {
+        RGX_LA(n0.x, 0) RGX_LA(n0.y, 1) RGX_LA(n0.z, 2) RGX_LA(n0.w, 3)
+        RGX_LA(n1.x, 4) RGX_LA(n1.y, 5) RGX_LA(n1.z, 6)
+      }
 #undef RGX_LA
 #undef RGX_STEP
 #undef RGX_HARVEST
@@ -253,7 +278,9 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
     // ---- resolve the FindAll chain (owned slices: lane >= 1)
     const unsigned prev_lo = DppWaveShr1((unsigned)cur);
     const unsigned prev_hi = DppWaveShr1((unsigned)(cur >> 32));
-    unsigned long long s_sel = lane ? cur : 0ull;
+    const bool owner = lane >= 1 && (!LAG || lane < 63);   // lane 0 re-reads the previous slice; LAG: lane 63 has no look-ahead
+    if (LAG && lane == 63) cur = 0;
+    unsigned long long s_sel = owner ? cur : 0ull;
     bool slow = P.carry_in != nullptr;
     if (K > 1 && smin < K && !slow) {
       // candidates of the previous slice within K-1 positions of a: bit u <-> position a-(K-1)+u
@@ -265,9 +292,9 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
       while (covered * 2 <= w) { B |= B << covered; covered *= 2; }
       if (w > covered) B |= B << (w - covered);
       blocked |= B;
-      slow = __ballot(lane && (cur & blocked) != 0ull) != 0ull;
+      slow = __ballot(owner && (cur & blocked) != 0ull) != 0ull;
     }
-    if (slow && lane && a < len) {
+    if (slow && owner && a < len) {
       s_sel = 0;
       const unsigned long long prev = ((unsigned long long)prev_hi << 32) | prev_lo;
       const int slice = a >> 6;
@@ -331,7 +358,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
   if (wave == 0) {
     unsigned long long block_total = 0;
 #pragma unroll
-    for (int w = 0; w < kBlockThreads / 64; ++w) block_total += L.wtot[w];
+    for (int w = 0; w < kExactThreads / 64; ++w) block_total += L.wtot[w];
     unsigned long long excl = 0;
     if (!(P.debug & 1)) excl = LookBack(P.tile_desc, blk, block_total, lane, &P.counters[3], 4, P.host_result ? P.host_result + 1 : nullptr, !P.use_tickets);
     if (lane == 0) {
@@ -346,7 +373,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
   __syncthreads();
   unsigned long long base = ((unsigned long long)L.base_hi << 32) | L.base_lo;
 #pragma unroll
-  for (int w = 0; w < kBlockThreads / 64; ++w) if (w < wave) base += L.wtot[w];
+  for (int w = 0; w < kExactThreads / 64; ++w) if (w < wave) base += L.wtot[w];
   if (P.count_only) return;
 
   // ---- span records in match order.  Lane-per-match stores reach HBM as scattered 16-byte pieces, so the lanes drop
@@ -374,9 +401,12 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
         const int s = (int)st[r];
         const int4 o = *reinterpret_cast<const int4*>(&L.off[c << 2]);
         const unsigned long long idx = base + r;
-        if (idx < (unsigned long long)P.cap_records)
-          __builtin_nontemporal_store(v4i{s + o.x, s + o.y, s + o.z, s + o.w},
-                                      reinterpret_cast<v4i*>(P.spans + idx * ncap + (c << 2)));
+        if (idx < (unsigned long long)P.cap_records && !(P.debug & 4))
+        {
+          if (P.debug & 32) *reinterpret_cast<v4i*>(P.spans + idx * ncap + (c << 2)) = v4i{s + o.x, s + o.y, s + o.z, s + o.w};
+          else __builtin_nontemporal_store(v4i{s + o.x, s + o.y, s + o.z, s + o.w},
+                                           reinterpret_cast<v4i*>(P.spans + idx * ncap + (c << 2)));
+        }
       }
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -390,7 +420,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_exact_kernel(DevTables T, 
     const unsigned incl = DppInclusiveScan(cnt);
     const unsigned ttot = __builtin_amdgcn_readlane((int)incl, 63);
     if (ttot == 0) continue;                                 // uniform
-    const int a = (first_tile + g) * kWaveTileBytes - kSliceBytes + lane * kSliceBytes;
+    const int a = (first_tile + g) * TB - kSliceBytes + lane * kSliceBytes;
     if (staged_ok && ttot <= (unsigned)kStartsCap) {
       if (fill + ttot > (unsigned)kStartsCap) flush();
       unsigned long long m = sel[g];
@@ -436,7 +466,7 @@ int ResidentWorkgroups() {
   if (r) return r;
   int dev = 0, cus = 0, occ = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_exact_kernel<4, true>, kBlockThreads, 0) != hipSuccess || occ <= 0) occ = 5;
+  if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_exact_kernel<4, true>, kExactThreads, 0) != hipSuccess || occ <= 0) occ = 5;
   (void)hipGetLastError();
   const char* e = getenv("RGX_RESIDENT");
   r = e ? atoi(e) : cus * occ;
@@ -444,10 +474,10 @@ int ResidentWorkgroups() {
   return r;
 }
 
-ExactPlan MakePlan(int32_t len) {
+ExactPlan MakePlan(int32_t len, int tile_bytes) {
   ExactPlan p{};
-  const int wpb = kBlockThreads / 64;
-  const long long W = ((long long)len + kWaveTileBytes - 1) / kWaveTileBytes;      // wave-tiles in the input
+  const int wpb = kExactThreads / 64;
+  const long long W = ((long long)len + tile_bytes - 1) / tile_bytes;      // wave-tiles in the input
   const int L = ResidentWorkgroups() / kGroupTiles;                                 // workgroups per ramp level
   long long ramp = 0;
   for (int v = 1; v < kGroupTiles; ++v) ramp += 2LL * L * wpb * v;
@@ -475,11 +505,15 @@ ExactPlan MakePlan(int32_t len) {
 }  // namespace
 
 // look-back descriptors (= workgroups) the scan of `len` bytes uses
-int ExactNumBlocks(int32_t len) { return MakePlan(len).nblocks; }
+static int ExactTileBytesFor(const DevTables& T) {
+  static const bool no16 = getenv("RGX_NO_W16") != nullptr;
+  return (T.sa_k <= 16 && !no16) ? kWaveTileBytesLag : kWaveTileBytes;
+}
+int ExactNumBlocks(const DevTables& T, int32_t len) { return MakePlan(len, ExactTileBytesFor(T)).nblocks; }
 
 hipError_t LaunchScanExact(const DevTables& T, const ScanParams& P, hipStream_t stream) {
-  dim3 block(kBlockThreads);
-  const ExactPlan plan = MakePlan(P.len);
+  dim3 block(kExactThreads);
+  const ExactPlan plan = MakePlan(P.len, ExactTileBytesFor(T));
   dim3 grid(plan.nblocks);
   const int K = T.sa_k;
   static int debug = -1;   // experiment switches (RGX_DEBUG): 8 = skip the byte loop, 16 = skip the global loads
@@ -487,7 +521,8 @@ hipError_t LaunchScanExact(const DevTables& T, const ScanParams& P, hipStream_t 
   ScanParams Q = P;
   Q.debug = debug;
   static const bool no16 = getenv("RGX_NO_W16") != nullptr;
-  if (K <= 16 && !no16) hipLaunchKernelGGL((scan_exact_kernel<4, true>), grid, block, 0, stream, T, Q, plan);
+  static const int extra_lds = getenv("RGX_EXTRA_LDS") ? atoi(getenv("RGX_EXTRA_LDS")) : 0;   // experiment: caps workgroups per CU
+  if (K <= 16 && !no16) hipLaunchKernelGGL((scan_exact_kernel<4, true>), grid, block, extra_lds, stream, T, Q, plan);
   else if (K <= 17) hipLaunchKernelGGL((scan_exact_kernel<4, false>), grid, block, 0, stream, T, Q, plan);
   else if (K <= 25) hipLaunchKernelGGL((scan_exact_kernel<2, false>), grid, block, 0, stream, T, Q, plan);
   else hipLaunchKernelGGL((scan_exact_kernel<1, false>), grid, block, 0, stream, T, Q, plan);
