@@ -400,7 +400,8 @@ __global__ __launch_bounds__(kExactThreads) void scan_exact_kernel(DevTables T, 
         else { r = j / (unsigned)cpr; c = j - r * (unsigned)cpr; }
         const int s = (int)st[r];
         const int4 o = *reinterpret_cast<const int4*>(&L.off[c << 2]);
-        const unsigned long long idx = base + r;
+        unsigned long long idx = base + r;
+        if (P.debug & 64) idx &= 0xFFFFull;      // experiment: all records land in 2 MiB (stays in L2)
         if (idx < (unsigned long long)P.cap_records && !(P.debug & 4))
         {
           if (P.debug & 32) *reinterpret_cast<v4i*>(P.spans + idx * ncap + (c << 2)) = v4i{s + o.x, s + o.y, s + o.z, s + o.w};
