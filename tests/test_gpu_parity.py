@@ -338,6 +338,34 @@ def _csr(torch, strings):
     return concat, torch.tensor(offs, dtype=torch.int64, device="cuda:0")
 
 
+@pytest.mark.parametrize("pat,k", [
+    (r"x", 1), (r"ab", 2), (r"[0-9][a-f]\d", 3), (r"(\d{4})-(\d{2})", 7), (r"(?P<a>[a-c]{8})(?P<b>\d{8})", 16),
+    (r"\d{8}-[a-f]{8}", 17), (r"[a-f0-9]{8}-[a-f0-9]{4}-[a-f0-9]{4}", 18), (r"(\d{10})([a-z]{10})", 20), (r"[ab]{25}", 25),
+    (r"\d{4}-\d{2}-\d{2}T\d{2}:\d{2}:\d{2}\.\d{6}", 26), (r"[a-c]{29}", 29)])
+def test_exact_kernel_variants(torch_dev, pat, k):
+    """Every instantiation of the fixed-length-chain kernel: 16-bit tables with the DPP look-ahead (K <= 16), 32-bit
+    tables with a look-ahead row (K = 17), harvest every 8 bytes (K <= 25) and every 4 (K <= 29); dense and sparse
+    candidates, overlapping candidates, sizes around wave-tile and workgroup boundaries."""
+    from oracle.gen_c import CMatcher
+    from regengo_amd import Compiled
+    c = Compiled(pat).to(0)
+    assert c.info.min_match_len == k and c.info.max_match_len == k
+    cm = CMatcher(pat)
+    rng = np.random.default_rng(k)
+    alpha = np.frombuffer(b"abcabcabdf0123456789--T:.x ", dtype=np.uint8)
+    for n in (64, 65, 3967, 3968, 4031, 4032, 4033, 8 * 3968 + 5, 8 * 4032 + 70, 64 * 3968 + 1, 300001, (1 << 21) + 17):
+        buf = rng.choice(alpha, size=n)
+        if k >= 16:   # plant some real matches of long chains
+            for pos in range(7, n - 64, 997):
+                seg = {16: b"abcabcab01234567", 17: b"12345678-abcdefab", 18: b"deadbeef-0123-4567", 20: b"0123456789abcdefghij",
+                       25: b"ab" * 12 + b"a", 26: b"2024-01-15T10:22:33.123456", 29: b"abc" * 9 + b"ab"}[k]
+                buf[pos:pos + len(seg)] = np.frombuffer(seg, dtype=np.uint8)
+        spans, res = c.FindAllSpans(torch_dev.from_numpy(buf).cuda())
+        exp, cnt = cm.find_all_np(np.ascontiguousarray(buf))
+        assert res.total == cnt, (pat, n)
+        assert np.array_equal(spans.cpu().numpy(), exp), (pat, n)
+
+
 def test_owned_range_scan(torch_dev):
     """rgx_find_all_bytes_device_owned (shard mode): chain over the whole window, only starts in [lo, hi) reported --
     equal to filtering the full result, for all three scan kernels, with cut points inside matches and tiles."""
