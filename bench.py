@@ -203,7 +203,7 @@ def main():
                          "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                          "kernel": "rgx::scan_exact_kernel<4,true>", "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": win_bytes},
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU leg runs at N=1 only
             line["cpu_baseline"] = cpu_baseline(args.adversarial)
         print(json.dumps(line))
     if world > 1:
