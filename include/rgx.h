@@ -152,6 +152,33 @@ int64_t rgx_replace_all_bytes_device(const rgx_program* p, rgx_stream_ctx* c, co
                                      int64_t* out_len, rgx_result* res);
 /* RGX_OK, or RGX_E_INVALID with the parser's message in rgx_last_error().                                */
 int rgx_replace_template_check(const char* tmpl, size_t tmpl_len);
+
+/* ---- streaming Transform: one buffer of processTransform / processSelect / processReject ----------------------------
+ * Replaces the body of the emitted processors (internal/compiler/transform.go:96-170, 380-431, 485-571) for the three
+ * callbacks that need no host code per match:
+ *   RGX_TRANSFORM_REPLACE  ReplaceReader(r, template)          transform.go:172-256
+ *   RGX_TRANSFORM_SELECT   SelectReader(r, always-true)        only the matches, back to back
+ *   RGX_TRANSFORM_REJECT   RejectReader(r, always-true)        everything but the matches
+ * The read loop, buffer compaction and the MaxLeftover rule stay in stream.Transformer (stream/transformer.go:258-322),
+ * i.e. in the Go stub: it hands down `data` = everything read and not yet consumed, and whether the source hit EOF.
+ * One call = FindAllBytes over `data` + the splice: *processed is what processTransform returns (is_eof: len; else
+ * REPLACE/REJECT: max(end of last match, len - DefaultMaxLeftover/10); SELECT: end of the last match) and d_out
+ * receives exactly the bytes the processor would have passed to emitOut, *out_len of them (RGX_E_CAPACITY when cap_out is
+ * too small; call again with *out_len).
+ * Template: replace.Parse + ValidateAndResolve (replace/template.go:45-291): an unknown name or an index beyond the
+ * groups is RGX_E_INVALID (the reference returns a reader that yields the error); group texts go through
+ * getCaptureByIndex (transform.go:288-320), which knows NAMED groups only -- `$1` of an unnamed group expands to nothing.
+ * Patterns that can match empty are RGX_E_UNSUPPORTED: the emitted loop drops a byte per empty match and panics on one
+ * at the end of the data; keep the Go path for them.  Predicates and arbitrary callbacks run on the host
+ * over rgx_find_all_bytes spans with the same *processed rule.                                     */
+#define RGX_TRANSFORM_REPLACE 0
+#define RGX_TRANSFORM_SELECT 1
+#define RGX_TRANSFORM_REJECT 2
+int64_t rgx_transform_chunk_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_data, size_t len, int is_eof,
+                                   int mode, const char* tmpl, size_t tmpl_len, uint8_t* d_out, size_t cap_out,
+                                   int64_t* out_len, int64_t* processed, rgx_result* res);
+/* ValidateAndResolve against this program's groups: RGX_OK or RGX_E_INVALID (+ rgx_last_error()).        */
+int rgx_transform_template_check(const rgx_program* p, const char* tmpl, size_t tmpl_len);
 /* offsets[c] for c in [0, ncap): span slot c of a match starting at s is s + offsets[c]; returns fixed match length or <0. */
 int rgx_program_capture_template(const rgx_program* p, int32_t* offsets);
 /* Count only (FindReaderCount's hot loop; no span traffic).                                        */

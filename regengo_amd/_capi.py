@@ -27,6 +27,7 @@ RGX_E_UNSUPPORTED = -3
 RGX_E_NO_DEVICE = -5
 RGX_E_CAPACITY = -8
 RGX_E_BUFFER_TOO_SMALL = -10
+TRANSFORM_REPLACE, TRANSFORM_SELECT, TRANSFORM_REJECT = 0, 1, 2
 FLAG_UNMATCHED_MINUS1 = 1
 FLAG_STDLIB_SEMANTICS = 2
 
@@ -75,6 +76,9 @@ SYMBOLS = {
     "rgx_replace_all_bytes_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int,
                                                  C.c_void_p, C.c_size_t, C.POINTER(C.c_int64), C.POINTER(Result)]),
     "rgx_replace_template_check": (C.c_int, [C.c_char_p, C.c_size_t]),
+    "rgx_transform_chunk_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_char_p, C.c_size_t,
+                                               C.c_void_p, C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(Result)]),
+    "rgx_transform_template_check": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "rgx_program_capture_template": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rgx_count_all_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Result)]),
     "rgx_find_batch_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p,

@@ -2,7 +2,8 @@
 
 The reference emits, per pattern, a zero-size struct with ~40 methods (README.md:99-146).  This module keeps
 the names, argument meaning and error behaviour of the hot-path ones -- MatchBytes, FindBytes, FindAllBytes,
-FindReader, FindReaderCount, FindReaderFirst, MatchLengthInfo, DefaultMaxLeftover -- so the parity tests read
+FindReader, FindReaderCount, FindReaderFirst, MatchLengthInfo, DefaultMaxLeftover, ReplaceAllBytes, ReplaceReader,
+SelectReader, RejectReader, NewTransformReader -- so the parity tests read
 like the reference's own generated tests (internal/compiler/test_gen.go:72-239).  PyTorch is used for device
 memory only; the matching runs in librgx_hip.so.
 """
@@ -12,6 +13,7 @@ import ctypes as C
 from typing import Callable, List, Optional, Sequence
 
 from . import _capi
+from . import transform as _transform
 from .stream import Config, ErrBufferTooSmall, Match
 
 
@@ -337,6 +339,12 @@ class Compiled:
             else:
                 leftover = 0
             chunk_index += 1
+
+    # ---- streaming Transform (transform.go:28-571; regengo_amd/transform.py)
+    NewTransformReader = _transform.NewTransformReader
+    ReplaceReader = _transform.ReplaceReader
+    SelectReader = _transform.SelectReader
+    RejectReader = _transform.RejectReader
 
     def FindReaderCount(self, r, cfg: Config) -> int:
         cnt = 0

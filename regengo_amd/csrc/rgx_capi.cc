@@ -400,7 +400,10 @@ bool NameCont(unsigned c) { return NameStart(c) || (c >= '0' && c <= '9'); }
 
 // replace.Parse (template.go:45-148) over the BYTES of the template, then the run-time lookup rules of
 // replace.go:393-453 (unknown name / index beyond the groups: nothing).  Returns false with a message on a parse error.
-bool ParseTemplate(const char* t, size_t n, const Tables* tab, ParsedTemplate* out, std::string* err) {
+// strict = the Transform flavour: ValidateAndResolve (template.go:262-291) rejects unknown names and indices beyond the
+// groups, and getCaptureByIndex (transform.go:288-320) only knows named groups -- an unnamed group's text is nothing.
+bool ParseTemplate(const char* t, size_t n, const Tables* tab, ParsedTemplate* out, std::string* err, bool strict = false) {
+  bool bad_ref = false;
   auto lit = [&](const char* p, size_t k) {
     if (!k) return;
     if (!out->segs.empty() && out->segs.back().kind == 0 && out->segs.back().a + out->segs.back().b == (int32_t)out->lits.size()) {
@@ -412,12 +415,15 @@ bool ParseTemplate(const char* t, size_t n, const Tables* tab, ParsedTemplate* o
   };
   auto group = [&](int g) {
     const int ngroups = tab ? tab->ncap / 2 - 1 : 99;
+    if (strict && g > ngroups) { *err = "invalid replace template: capture group " + std::to_string(g) + " out of range"; bad_ref = true; return; }
+    if (strict && g >= 1 && ((size_t)g >= tab->cap_names.size() || tab->cap_names[g].empty())) return;
     if (g >= 0 && g <= ngroups) out->segs.push_back({1, g, 0});
   };
   auto named = [&](const std::string& name) {
     if (!tab) return;
     for (size_t g = 1; g < tab->cap_names.size(); g++)
       if (!tab->cap_names[g].empty() && tab->cap_names[g] == name) { group((int)g); return; }
+    if (strict) { *err = "invalid replace template: capture group \"" + name + "\" not found"; bad_ref = true; }
   };
   size_t i = 0, lit0 = 0;
   while (i < n) {
@@ -466,7 +472,43 @@ bool ParseTemplate(const char* t, size_t n, const Tables* tab, ParsedTemplate* o
     lit0 = i;
   }
   lit(t + lit0, i - lit0);
-  return true;
+  return !bad_ref;
+}
+}  // namespace
+
+namespace {
+struct SplicePlan {
+  ReplSeg* d_segs = nullptr;
+  uint8_t* d_lits = nullptr;
+  long long* d_shift = nullptr;
+  int nseg = 0;
+};
+
+// Uploads the resolved template, sizes every replacement and prefix-sums them over the n matches in c->d_rspans.
+// *gain = sum of the deltas (select: total output bytes); *last_end (optional, n > 0) = end of the last match.
+int SpliceSizes(const rgx_program* p, rgx_stream_ctx* c, int64_t n, const ParsedTemplate& pt, bool select, SplicePlan* sp, long long* gain,
+                int32_t* last_end) {
+  int rc;
+  const int ncap = p->p.dev.ncap;
+  const size_t temp_bytes = ReplaceScanTempBytes(n);
+  const size_t seg_bytes = (pt.segs.size() * sizeof(ReplSeg) + 15) & ~size_t(15);
+  const size_t lit_bytes = (pt.lits.size() + 15) & ~size_t(15);
+  if ((rc = Ensure(&c->d_rdelta, &c->rdelta_cap, 2 * (n + 1) + 2)) != RGX_OK) return rc;
+  if ((rc = Ensure(&c->d_rtemp, &c->rtemp_cap, (int64_t)(temp_bytes + 256 + seg_bytes + lit_bytes + 64))) != RGX_OK) return rc;
+  uint8_t* base = c->d_rtemp;
+  sp->d_segs = (ReplSeg*)base;
+  sp->d_lits = base + seg_bytes;
+  sp->nseg = (int)pt.segs.size();
+  void* d_temp = base + seg_bytes + lit_bytes + ((256 - ((seg_bytes + lit_bytes) & 255)) & 255);
+  if (!pt.segs.empty()) HIP_TRY(hipMemcpyAsync(sp->d_segs, pt.segs.data(), pt.segs.size() * sizeof(ReplSeg), hipMemcpyHostToDevice, c->stream));
+  if (!pt.lits.empty()) HIP_TRY(hipMemcpyAsync(sp->d_lits, pt.lits.data(), pt.lits.size(), hipMemcpyHostToDevice, c->stream));
+  long long* d_delta = c->d_rdelta;
+  sp->d_shift = c->d_rdelta + (n + 1);
+  HIP_TRY(LaunchReplaceSizes(c->d_rspans, n, ncap, sp->d_segs, sp->nseg, d_delta, sp->d_shift, d_temp, temp_bytes, select, c->stream));
+  HIP_TRY(hipMemcpyAsync(gain, sp->d_shift + n, 8, hipMemcpyDeviceToHost, c->stream));
+  if (last_end) HIP_TRY(hipMemcpyAsync(last_end, c->d_rspans + (n - 1) * ncap + 1, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return RGX_OK;
 }
 }  // namespace
 
@@ -532,30 +574,73 @@ RGX_API int64_t rgx_replace_all_bytes_device(const rgx_program* p, rgx_stream_ct
       n++;
     }
   }
-  // 3. sizes and the prefix sum
-  const size_t temp_bytes = ReplaceScanTempBytes(n);
-  const size_t seg_bytes = (pt.segs.size() * sizeof(ReplSeg) + 15) & ~size_t(15);
-  const size_t lit_bytes = (pt.lits.size() + 15) & ~size_t(15);
-  if ((rc = Ensure(&c->d_rdelta, &c->rdelta_cap, 2 * (n + 1) + 2)) != RGX_OK) return rc;
-  if ((rc = Ensure(&c->d_rtemp, &c->rtemp_cap, (int64_t)(temp_bytes + 256 + seg_bytes + lit_bytes + 64))) != RGX_OK) return rc;
-  uint8_t* base = c->d_rtemp;
-  ReplSeg* d_segs = (ReplSeg*)base;
-  uint8_t* d_lits = base + seg_bytes;
-  void* d_temp = base + seg_bytes + lit_bytes + ((256 - ((seg_bytes + lit_bytes) & 255)) & 255);
-  if (!pt.segs.empty()) HIP_TRY(hipMemcpyAsync(d_segs, pt.segs.data(), pt.segs.size() * sizeof(ReplSeg), hipMemcpyHostToDevice, c->stream));
-  if (!pt.lits.empty()) HIP_TRY(hipMemcpyAsync(d_lits, pt.lits.data(), pt.lits.size(), hipMemcpyHostToDevice, c->stream));
-  long long* d_delta = c->d_rdelta;
-  long long* d_shift = c->d_rdelta + (n + 1);
-  HIP_TRY(LaunchReplaceSizes(c->d_rspans, n, ncap, d_segs, (int)pt.segs.size(), d_delta, d_shift, d_temp, temp_bytes, c->stream));
+  // 3. sizes and the prefix sum, 4. gaps and replacements
+  SplicePlan sp;
   long long gain = 0;
-  HIP_TRY(hipMemcpyAsync(&gain, d_shift + n, 8, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if ((rc = SpliceSizes(p, c, n, pt, false, &sp, &gain, nullptr)) != RGX_OK) return rc;
   *out_len = (int64_t)len + gain;
   if (res) { *res = r; res->total = n; res->written = n; }
   if ((size_t)*out_len > cap_out || (!d_out && *out_len > 0)) { SetError("output capacity too small"); return RGX_E_CAPACITY; }
-  // 4. gaps and replacements
   if (*out_len > 0)
-    HIP_TRY(LaunchReplaceWrite(d_buf, ilen, c->d_rspans, n, ncap, d_segs, (int)pt.segs.size(), d_lits, d_shift, d_out, c->stream));
+    HIP_TRY(LaunchReplaceWrite(d_buf, ilen, c->d_rspans, n, ncap, sp.d_segs, sp.nseg, sp.d_lits, sp.d_shift, d_out, false, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return *out_len;
+}
+
+RGX_API int rgx_transform_template_check(const rgx_program* p, const char* tmpl, size_t tmpl_len) {
+  if (!p || (!tmpl && tmpl_len)) return RGX_E_INVALID;
+  ParsedTemplate pt;
+  std::string err;
+  if (!ParseTemplate(tmpl, tmpl_len, &p->p.t, &pt, &err, true)) { SetError(err); return RGX_E_INVALID; }
+  return RGX_OK;
+}
+
+RGX_API int64_t rgx_transform_chunk_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_data, size_t len, int is_eof, int mode,
+                                           const char* tmpl, size_t tmpl_len, uint8_t* d_out, size_t cap_out, int64_t* out_len,
+                                           int64_t* processed, rgx_result* res) {
+  int rc = CheckCtx(p, c);
+  if (rc != RGX_OK) return rc;
+  if (!out_len || !processed || mode < RGX_TRANSFORM_REPLACE || mode > RGX_TRANSFORM_REJECT) return RGX_E_INVALID;
+  if (mode == RGX_TRANSFORM_REPLACE && !tmpl && tmpl_len) return RGX_E_INVALID;
+  const Tables& t = p->p.t;
+  const DevTables& T = p->p.dev;
+  if (t.can_match_empty) {
+    SetError("Transform of a pattern that matches empty: the emitted loop loses bytes and panics (DESIGN.md Q13); not offered");
+    return RGX_E_UNSUPPORTED;
+  }
+  ParsedTemplate pt;
+  std::string err;
+  if (mode == RGX_TRANSFORM_REPLACE) {
+    if (!ParseTemplate(tmpl, tmpl_len, &t, &pt, &err, true)) { SetError(err); return RGX_E_INVALID; }
+  } else if (mode == RGX_TRANSFORM_SELECT) {
+    pt.segs.push_back({1, 0, 0});       // the match text itself
+  }                                      // REJECT: the empty replacement
+  if (len > 0x7FFFFF00ull) { SetError("buffer larger than 2^31-256 bytes"); return RGX_E_TOO_LARGE; }
+  const int ncap = T.ncap;
+  const bool select = mode == RGX_TRANSFORM_SELECT;
+  const int64_t cap_rec = (int64_t)(len / (size_t)std::max(t.min_len, 1)) + 4;
+  if ((rc = Ensure(&c->d_rspans, &c->rspans_cap, cap_rec * ncap)) != RGX_OK) return rc;
+  rgx_result r{};
+  int64_t n = 0;
+  if (len > 0) {
+    n = FindAllDevice(p, c, d_data, len, -1, c->d_rspans, (size_t)cap_rec - 2, false, &r);
+    if (n < 0) return n;
+  }
+  SplicePlan sp;
+  long long gain = 0;
+  int32_t last_end = 0;
+  if ((rc = SpliceSizes(p, c, n, pt, select, &sp, &gain, n > 0 ? &last_end : nullptr)) != RGX_OK) return rc;
+  // what processTransform / processSelect / processReject return (transform.go:119-135, 399-404, 504-520)
+  int64_t done;
+  if (is_eof) done = (int64_t)len;
+  else if (select) done = last_end;
+  else done = std::max<int64_t>(last_end, (int64_t)len - DefaultMaxLeftover(t.max_len) / 10);
+  *processed = done;
+  *out_len = select ? gain : done + gain;
+  if (res) { *res = r; res->total = n; res->written = n; }
+  if ((size_t)*out_len > cap_out || (!d_out && *out_len > 0)) { SetError("output capacity too small"); return RGX_E_CAPACITY; }
+  if (*out_len > 0)
+    HIP_TRY(LaunchReplaceWrite(d_data, (int32_t)done, c->d_rspans, n, ncap, sp.d_segs, sp.nseg, sp.d_lits, sp.d_shift, d_out, select, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return *out_len;
 }

@@ -81,9 +81,10 @@ struct ReplSeg {
 size_t ReplaceScanTempBytes(int64_t nmatches);
 // delta[i] = replacement length - match length (i < n), shift = exclusive sum over n+1 entries (shift[n] = total gain)
 hipError_t LaunchReplaceSizes(const int32_t* spans, int64_t n, int ncap, const ReplSeg* d_segs, int nseg, long long* d_delta, long long* d_shift,
-                              void* d_temp, size_t temp_bytes, hipStream_t stream);
+                              void* d_temp, size_t temp_bytes, bool select, hipStream_t stream);
+// select: only the replacements are written, back to back (SelectReader); otherwise gaps of in[0, len) + replacements
 hipError_t LaunchReplaceWrite(const uint8_t* in, int32_t len, const int32_t* spans, int64_t n, int ncap, const ReplSeg* d_segs, int nseg,
-                              const uint8_t* d_lits, const long long* d_shift, uint8_t* out, hipStream_t stream);
+                              const uint8_t* d_lits, const long long* d_shift, uint8_t* out, bool select, hipStream_t stream);
 // one anchored attempt at `pos` (the loop's extra try at offset len, find.go:545-569): *out_end = match end or -1
 hipError_t LaunchAttemptAt(const DevTables& T, const uint8_t* buf, int32_t len, int32_t pos, int32_t* out_end, hipStream_t stream);
 

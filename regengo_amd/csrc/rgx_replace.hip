@@ -16,7 +16,7 @@ namespace rgx {
 namespace {
 
 __global__ __launch_bounds__(kBlockThreads) void replen_kernel(const int32_t* spans, int64_t n, int ncap, const ReplSeg* segs, int nseg,
-                                                               long long* delta) {
+                                                               int select, long long* delta) {
   const int64_t i = (int64_t)blockIdx.x * kBlockThreads + threadIdx.x;
   if (i > n) return;
   if (i == n) { delta[n] = 0; return; }
@@ -26,7 +26,8 @@ __global__ __launch_bounds__(kBlockThreads) void replen_kernel(const int32_t* sp
     const ReplSeg s = segs[k];
     rl += s.kind == 0 ? s.b : (long long)(r[2 * s.a + 1] - r[2 * s.a]);
   }
-  delta[i] = rl - (long long)(r[1] - r[0]);
+  // select (SelectReader: only the replacements are kept, no gaps): the sum is the output offset itself
+  delta[i] = select ? rl : rl - (long long)(r[1] - r[0]);
 }
 
 __global__ __launch_bounds__(kBlockThreads) void gaps_kernel(const uint8_t* in, int32_t len, const int32_t* spans, int64_t n, int ncap,
@@ -57,11 +58,11 @@ __global__ __launch_bounds__(kBlockThreads) void gaps_kernel(const uint8_t* in, 
 
 __global__ __launch_bounds__(kBlockThreads) void reps_kernel(const uint8_t* in, const int32_t* spans, int64_t n, int ncap,
                                                              const ReplSeg* segs, int nseg, const uint8_t* lits, const long long* shift,
-                                                             uint8_t* out) {
+                                                             int select, uint8_t* out) {
   const int64_t i = (int64_t)blockIdx.x * kBlockThreads + threadIdx.x;
   if (i >= n) return;
   const int32_t* r = spans + i * ncap;
-  long long o = (long long)r[0] + shift[i];
+  long long o = select ? shift[i] : (long long)r[0] + shift[i];
   for (int k = 0; k < nseg; ++k) {
     const ReplSeg s = segs[k];
     if (s.kind == 0) {
@@ -84,22 +85,22 @@ size_t ReplaceScanTempBytes(int64_t n) {
 }
 
 hipError_t LaunchReplaceSizes(const int32_t* spans, int64_t n, int ncap, const ReplSeg* d_segs, int nseg, long long* d_delta, long long* d_shift,
-                              void* d_temp, size_t temp_bytes, hipStream_t stream) {
+                              void* d_temp, size_t temp_bytes, bool select, hipStream_t stream) {
   const dim3 block(kBlockThreads), grid((unsigned)((n + 1 + kBlockThreads - 1) / kBlockThreads));
-  hipLaunchKernelGGL(replen_kernel, grid, block, 0, stream, spans, n, ncap, d_segs, nseg, d_delta);
+  hipLaunchKernelGGL(replen_kernel, grid, block, 0, stream, spans, n, ncap, d_segs, nseg, select ? 1 : 0, d_delta);
   return hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, d_delta, d_shift, (int)(n + 1), stream);
 }
 
 hipError_t LaunchReplaceWrite(const uint8_t* in, int32_t len, const int32_t* spans, int64_t n, int ncap, const ReplSeg* d_segs, int nseg,
-                              const uint8_t* d_lits, const long long* d_shift, uint8_t* out, hipStream_t stream) {
+                              const uint8_t* d_lits, const long long* d_shift, uint8_t* out, bool select, hipStream_t stream) {
   const dim3 block(kBlockThreads);
-  const int64_t nslices = ((int64_t)len + kSliceBytes - 1) / kSliceBytes;
+  const int64_t nslices = select ? 0 : ((int64_t)len + kSliceBytes - 1) / kSliceBytes;
   if (nslices > 0)
     hipLaunchKernelGGL(gaps_kernel, dim3((unsigned)((nslices + kBlockThreads - 1) / kBlockThreads)), block, 0, stream, in, len, spans, n, ncap,
                        d_shift, out);
   if (n > 0)
     hipLaunchKernelGGL(reps_kernel, dim3((unsigned)((n + kBlockThreads - 1) / kBlockThreads)), block, 0, stream, in, spans, n, ncap, d_segs,
-                       nseg, d_lits, d_shift, out);
+                       nseg, d_lits, d_shift, select ? 1 : 0, out);
   return hipGetLastError();
 }
 

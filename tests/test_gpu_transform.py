@@ -1,0 +1,223 @@
+"""GPU tier: the streaming Transform path (ReplaceReader / SelectReader / RejectReader / NewTransformReader) through
+the C ABI (rgx_transform_chunk_device, rgx_find_all_bytes_device) and the host read loop of regengo_amd/transform.py,
+against (1) the literal vectors of the reference's own transform tests and (2) the oracle's restatement of
+stream.Transformer + the emitted processors, read quirk-free (oracle/transform.py)."""
+import json
+import os
+import random
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def gpu(built):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU; there is no CPU fallback")
+    return torch
+
+
+@pytest.fixture(scope="module")
+def tkats():
+    return json.load(open(os.path.join(GOLDEN, "transform_kats.json")))
+
+
+_c = {}
+
+
+def dev(pattern):
+    from regengo_amd import Compiled
+    if pattern not in _c:
+        _c[pattern] = Compiled(pattern).to(0)
+    return _c[pattern]
+
+
+class PieceReader:
+    """io.Reader that hands out ragged pieces (never more than asked)."""
+
+    def __init__(self, data: bytes, rng=None, max_piece=None):
+        self.d, self.p, self.rng, self.mp = data, 0, rng, max_piece
+
+    def read(self, k):
+        if self.rng is not None:
+            k = min(k, self.rng.randrange(1, self.mp))
+        out = self.d[self.p:self.p + k]
+        self.p += len(out)
+        return out
+
+
+def gpu_pred(c, pr):
+    if pr["kind"] == "all":
+        return None
+    field = [f for f in c.fields if f.lower() == pr["group"]][0]
+    val = pr["value"].encode()
+    return lambda m: getattr(m, field) == val
+
+
+def test_reference_vectors(gpu, tkats):
+    from regengo_amd.stream import Config
+    from tests.test_transform_oracle import check_case
+    for case in tkats["integration"]:
+        inputs = case["inputs"] if "inputs" in case else [case["input"]]
+        for s in inputs:
+            src = PieceReader(s.encode())
+            first = True
+            for st in case["steps"]:
+                c = dev(st["pattern"])
+                cfg = Config(case.get("buffer_size", 0) if first else 0, case.get("max_leftover", 0) if first else 0)
+                if st["op"] == "replace":
+                    src = c.ReplaceReader(src, st["template"])
+                elif st["op"] == "transform":
+                    lits = [e.encode() for e in st["emits"]]
+                    src = c.NewTransformReader(src, cfg, lambda m, emit, lits=lits: [emit(x) for x in lits])
+                elif st["op"] == "select":
+                    src = c.SelectReader(src, gpu_pred(c, st["pred"]))
+                else:
+                    src = c.RejectReader(src, gpu_pred(c, st["pred"]))
+                first = False
+            if case.get("read_piece"):
+                out = bytearray()
+                while True:
+                    b = src.read(1)
+                    if not b:
+                        break
+                    out += b
+                out = bytes(out)
+            else:
+                out = src.read_all()
+            if case.get("expect") == "same_as_replace_all":
+                assert out == dev(case["steps"][0]["pattern"]).ReplaceAllBytes(s.encode(), case["steps"][0]["template"]), s
+            else:
+                check_case(case, out)
+
+
+def test_template_rules(gpu):
+    from regengo_amd import _capi
+    c = dev(r"(\d{4})-(?P<m>\d{2})")
+    # getCaptureByIndex knows named groups only: $1 of the unnamed group is nothing here, unlike ReplaceAllBytes
+    assert c.ReplaceReader(b"on 2024-05 ok", "<$1|$m|$0>").read_all() == b"on <|05|2024-05> ok"
+    assert c.ReplaceAllBytes(b"on 2024-05 ok", "<$1|$m|$0>") == b"on <2024|05|2024-05> ok"
+    for bad in ("$nosuch", "$3", "${", "${1x}"):
+        r = c.ReplaceReader(b"2024-05", bad)
+        with pytest.raises(_capi.RgxError) as ei:
+            r.read(10)
+        assert ei.value.status == _capi.RGX_E_INVALID
+    with pytest.raises(_capi.RgxError) as ei:
+        dev(r"x*").ReplaceReader(b"abc", "-")
+    assert ei.value.status == _capi.RGX_E_UNSUPPORTED
+
+
+PATTERNS = [
+    (r"(?P<y>\d{4})-(?P<m>\d{2})-(?P<d>\d{2})", "$d/$m/$y", b"abcdefghijk \n\t"),
+    (r"(?P<user>[\w.+-]+)@(?P<domain>[\w.-]+\.\w+)", "<$domain:$user>", b"ab.@ \n-+_9"),
+    (r"(\d{1,3}\.\d{1,3}\.\d{1,3}\.\d{1,3})", "[$0]", b"0123456789. x"),
+    (r"(?P<proto>https?|ftp)://(?P<host>[\w.-]+)(?P<port>:\d+)?", "${proto}|$host|$port|$$", b"htpsf:/.w-1 \n"),
+    (r"(?:foo|foobar|ba+r)(?P<n>\d)?", "{$n}", b"fobar12 "),
+]
+
+
+def make_input(rng, alphabet: bytes, seeds, n: int) -> bytes:
+    out = bytearray()
+    while len(out) < n:
+        out += bytes(rng.choice(alphabet) for _ in range(rng.randrange(0, 40)))
+        if rng.random() < 0.7:
+            out += rng.choice(seeds)
+    return bytes(out[:n])
+
+
+SEEDS = {
+    0: [b"2024-01-15", b"1999-12-31", b"12024-01-151", b"2024-1-15"],
+    1: [b"john@example.com", b"a@b.c", b"x.y+z@host-1.org", b"@nope", b"q@r"],
+    2: [b"192.168.1.1", b"10.0.0.256", b"1.2.3", b"255.255.255.255.255"],
+    3: [b"https://host.example:8080", b"ftp://f-1.x", b"http://", b"httpx://y"],
+    4: [b"foobar7", b"foo", b"baaar3", b"br"],
+}
+
+
+@pytest.mark.parametrize("pi", range(len(PATTERNS)))
+def test_chunk_protocol_matches_oracle(gpu, pi):
+    """Every reader kind, several buffer sizes and ragged source reads: byte-identical output and the same number of
+    processor calls as the oracle's Transformer (so `processed` agreed on every buffer)."""
+    from oracle import engines as E
+    from oracle import transform as T
+    from regengo_amd.stream import Config
+    pat, tmpl, alphabet = PATTERNS[pi]
+    c, o = dev(pat), E.Compiled(pat)
+    rng = random.Random(100 + pi)
+    dl = c.info.default_max_leftover
+    for trial in range(6):
+        inp = make_input(rng, alphabet, SEEDS[pi], rng.choice([0, 1, 700, 5000, 30000]))
+        # buffers large enough for the reference not to spin (MaxLeftover < BufferSize), small enough for many chunks
+        bs = rng.choice([dl + 300, dl + 2048, 2 * dl + 5000]) if dl < (1 << 20) else rng.choice([4096, 20000])
+        ml = 0 if dl < (1 << 20) else rng.choice([64, 1000])
+        ragged = trial % 2 == 1
+
+        def srcs():
+            seed = rng.random()
+            if not ragged:
+                return PieceReader(inp), T.bytes_reader(inp)
+            ra, rb = random.Random(seed), random.Random(seed)
+            pr = PieceReader(inp, rb, 3000)
+            # (a zero-length Read of a full buffer must not draw from the generator: our loop skips that call)
+            return PieceReader(inp, ra, 3000), (lambda k: (b"", None) if k == 0 and pr.p < len(inp) else
+                                                ((pr.read(k), None) if pr.p < len(inp) else (b"", T.EOF)))
+
+        # ReplaceReader (device splice) -- cfg extension = NewTransformReader with the template callback in the oracle
+        g, r = srcs()
+        got = c.ReplaceReader(g, tmpl, Config(bs, ml))
+        want = T.replace_reader(o, r, tmpl, quirks=False, buffer_size=bs, max_leftover=ml)
+        wout, werr = want.read_all(777)
+        assert werr is None
+        assert got.read_all() == wout, ("replace", trial, bs, ml, len(inp))
+        assert got.chunks == want.chunks
+        # NewTransformReader with a host callback (spans from the device, splice on the host)
+        g, r = srcs()
+        gcb = lambda m, emit: (emit(b"<"), emit(m.Match[::-1]), emit(b">"))
+        ocb = lambda text, caps, emit: (emit(b"<"), emit(text[caps[0]:caps[1]][::-1]), emit(b">"))
+        got = c.NewTransformReader(g, Config(bs, ml), gcb)
+        want = T.new_transform_reader(o, r, bs, ml, ocb, quirks=False)
+        assert got.read_all() == want.read_all(500)[0], ("transform", trial, bs, ml)
+        assert got.chunks == want.chunks
+        if dl < (1 << 20) or len(inp) < 60000:
+            # Select / Reject use DefaultTransformConfig + MaxLeftover = the pattern default (transform.go:340-343)
+            sbs = bs if dl < (1 << 20) else 0
+            for kind, gfn, ofn in (("select", c.SelectReader, T.select_reader), ("reject", c.RejectReader, T.reject_reader)):
+                for pred in (None, lambda m: len(m.Match) % 2 == 0):
+                    g, r = srcs()
+                    opred = (lambda text, caps: True) if pred is None else (lambda text, caps: (caps[1] - caps[0]) % 2 == 0)
+                    try:
+                        wout = ofn(o, r, opred, quirks=False, buffer_size=sbs or 64 * 1024).read_all(900)[0]
+                    except RuntimeError:
+                        # the reference spins (full buffer, nothing selected, MaxLeftover >= BufferSize): ours raises too
+                        with pytest.raises(RuntimeError):
+                            gfn(g, pred, Config(sbs, 0)).read_all()
+                        continue
+                    assert gfn(g, pred, Config(sbs, 0)).read_all() == wout, (kind, pred is None, trial, sbs)
+
+
+def test_large_replace_reader_closed_form(gpu):
+    """64 MiB date log through ReplaceReader with an 8 MiB buffer: every date re-formatted, nothing else touched."""
+    from regengo_amd import synth
+    from regengo_amd.stream import Config
+    n = 64 << 20
+    t = synth.date_log_torch(n, "cuda:0")
+    data = t.cpu().numpy().tobytes()
+    c = dev(r"(?P<year>\d{4})-(?P<month>\d{2})-(?P<day>\d{2})")
+    r = c.ReplaceReader(PieceReader(data), "$day/$month/$year", Config(8 << 20, 0))
+    out = r.read_all()
+    assert len(out) == n and r.matches == n // 50 + 1
+    import numpy as np
+    a = np.frombuffer(out, dtype=np.uint8)
+    src = np.frombuffer(data, dtype=np.uint8)
+    pos = np.arange(0, n - 9, 50)
+    want = np.frombuffer(b"15/01/2024", dtype=np.uint8)
+    for k in range(10):
+        assert (a[pos + k] == want[k]).all()
+    mask = np.ones(n, dtype=bool)
+    for k in range(10):
+        mask[pos + k] = False
+    assert (a[mask] == src[mask]).all()
