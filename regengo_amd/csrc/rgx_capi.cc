@@ -482,23 +482,28 @@ struct SplicePlan {
   uint8_t* d_lits = nullptr;
   long long* d_shift = nullptr;
   int nseg = 0;
+  int32_t* d_tile_k0 = nullptr;
+  int nlits = 0;
 };
 
 // Uploads the resolved template, sizes every replacement and prefix-sums them over the n matches in c->d_rspans.
 // *gain = sum of the deltas (select: total output bytes); *last_end (optional, n > 0) = end of the last match.
-int SpliceSizes(const rgx_program* p, rgx_stream_ctx* c, int64_t n, const ParsedTemplate& pt, bool select, SplicePlan* sp, long long* gain,
-                int32_t* last_end) {
+int SpliceSizes(const rgx_program* p, rgx_stream_ctx* c, int64_t len, int64_t n, const ParsedTemplate& pt, bool select, SplicePlan* sp,
+                long long* gain, int32_t* last_end) {
   int rc;
   const int ncap = p->p.dev.ncap;
   const size_t temp_bytes = ReplaceScanTempBytes(n);
   const size_t seg_bytes = (pt.segs.size() * sizeof(ReplSeg) + 15) & ~size_t(15);
   const size_t lit_bytes = (pt.lits.size() + 15) & ~size_t(15);
   if ((rc = Ensure(&c->d_rdelta, &c->rdelta_cap, 2 * (n + 1) + 2)) != RGX_OK) return rc;
-  if ((rc = Ensure(&c->d_rtemp, &c->rtemp_cap, (int64_t)(temp_bytes + 256 + seg_bytes + lit_bytes + 64))) != RGX_OK) return rc;
-  uint8_t* base = c->d_rtemp;
+  const size_t tile_bytes = (ReplaceTileIndexBytes(len) + 255) & ~size_t(255);
+  if ((rc = Ensure(&c->d_rtemp, &c->rtemp_cap, (int64_t)(tile_bytes + temp_bytes + 256 + seg_bytes + lit_bytes + 64))) != RGX_OK) return rc;
+  sp->d_tile_k0 = (int32_t*)c->d_rtemp;
+  uint8_t* base = c->d_rtemp + tile_bytes;
   sp->d_segs = (ReplSeg*)base;
   sp->d_lits = base + seg_bytes;
   sp->nseg = (int)pt.segs.size();
+  sp->nlits = (int)pt.lits.size();
   void* d_temp = base + seg_bytes + lit_bytes + ((256 - ((seg_bytes + lit_bytes) & 255)) & 255);
   if (!pt.segs.empty()) HIP_TRY(hipMemcpyAsync(sp->d_segs, pt.segs.data(), pt.segs.size() * sizeof(ReplSeg), hipMemcpyHostToDevice, c->stream));
   if (!pt.lits.empty()) HIP_TRY(hipMemcpyAsync(sp->d_lits, pt.lits.data(), pt.lits.size(), hipMemcpyHostToDevice, c->stream));
@@ -577,12 +582,12 @@ RGX_API int64_t rgx_replace_all_bytes_device(const rgx_program* p, rgx_stream_ct
   // 3. sizes and the prefix sum, 4. gaps and replacements
   SplicePlan sp;
   long long gain = 0;
-  if ((rc = SpliceSizes(p, c, n, pt, false, &sp, &gain, nullptr)) != RGX_OK) return rc;
+  if ((rc = SpliceSizes(p, c, (int64_t)len, n, pt, false, &sp, &gain, nullptr)) != RGX_OK) return rc;
   *out_len = (int64_t)len + gain;
   if (res) { *res = r; res->total = n; res->written = n; }
   if ((size_t)*out_len > cap_out || (!d_out && *out_len > 0)) { SetError("output capacity too small"); return RGX_E_CAPACITY; }
   if (*out_len > 0)
-    HIP_TRY(LaunchReplaceWrite(d_buf, ilen, c->d_rspans, n, ncap, sp.d_segs, sp.nseg, sp.d_lits, sp.d_shift, d_out, false, c->stream));
+    HIP_TRY(LaunchReplaceWrite(d_buf, ilen, c->d_rspans, n, ncap, sp.d_segs, sp.nseg, sp.d_lits, sp.nlits, sp.d_shift, sp.d_tile_k0, d_out, false, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return *out_len;
 }
@@ -629,7 +634,7 @@ RGX_API int64_t rgx_transform_chunk_device(const rgx_program* p, rgx_stream_ctx*
   SplicePlan sp;
   long long gain = 0;
   int32_t last_end = 0;
-  if ((rc = SpliceSizes(p, c, n, pt, select, &sp, &gain, n > 0 ? &last_end : nullptr)) != RGX_OK) return rc;
+  if ((rc = SpliceSizes(p, c, (int64_t)len, n, pt, select, &sp, &gain, n > 0 ? &last_end : nullptr)) != RGX_OK) return rc;
   // what processTransform / processSelect / processReject return (transform.go:119-135, 399-404, 504-520)
   int64_t done;
   if (is_eof) done = (int64_t)len;
@@ -640,7 +645,7 @@ RGX_API int64_t rgx_transform_chunk_device(const rgx_program* p, rgx_stream_ctx*
   if (res) { *res = r; res->total = n; res->written = n; }
   if ((size_t)*out_len > cap_out || (!d_out && *out_len > 0)) { SetError("output capacity too small"); return RGX_E_CAPACITY; }
   if (*out_len > 0)
-    HIP_TRY(LaunchReplaceWrite(d_data, (int32_t)done, c->d_rspans, n, ncap, sp.d_segs, sp.nseg, sp.d_lits, sp.d_shift, d_out, select, c->stream));
+    HIP_TRY(LaunchReplaceWrite(d_data, (int32_t)done, c->d_rspans, n, ncap, sp.d_segs, sp.nseg, sp.d_lits, sp.nlits, sp.d_shift, sp.d_tile_k0, d_out, select, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return *out_len;
 }

@@ -4,8 +4,9 @@
 // away -- then gaps and replacements are written independently.  HBM-bound byte movement, no MFMA.
 //   replen_kernel   lane per match: replacement length - match length
 //   (hipcub)        exclusive sum over the matches -> shift[i] = bytes the output has gained before match i
-//   gaps_kernel     lane per 64-byte input slice: bytes outside matches move to offset + shift of the next match
-//   reps_kernel     lane per match: literals and group texts of the template
+//   tilek_kernel    lane per 16 KiB input tile: index of the first match ending beyond the tile start
+//   gaps_kernel     workgroup per tile, dword per lane: bytes outside matches move to offset + shift of the next match
+//   reps_kernel     lane per match, records and match texts staged in LDS: literals and group texts of the template
 #include <hip/hip_runtime.h>
 #include <hipcub/hipcub.hpp>
 
@@ -30,48 +31,171 @@ __global__ __launch_bounds__(kBlockThreads) void replen_kernel(const int32_t* sp
   delta[i] = select ? rl : rl - (long long)(r[1] - r[0]);
 }
 
-__global__ __launch_bounds__(kBlockThreads) void gaps_kernel(const uint8_t* in, int32_t len, const int32_t* spans, int64_t n, int ncap,
-                                                             const long long* shift, uint8_t* out) {
-  const int64_t sl = (int64_t)blockIdx.x * kBlockThreads + threadIdx.x;
-  const int64_t p0 = sl * kSliceBytes;
-  if (p0 >= len) return;
-  const int p1 = (int)(p0 + kSliceBytes < len ? p0 + kSliceBytes : len);
-  // k = first match whose END lies beyond p0 (matches are ordered and do not overlap)
-  int64_t lo = 0, hi = n;
+// ---- gaps: every input byte outside the matches moves to its place in the output ------------------------------------
+// HBM-bound copy with a data-dependent shift.  A workgroup owns a 16 KiB tile of the input, a wave 4 KiB of it, a lane
+// 64 contiguous bytes (four 16-byte loads in flight per lane).  The matches that touch the tile (tile_k0[t] ..
+// tile_k0[t+1], found by tilek_kernel's binary searches) are staged in LDS as (start, end, shift); every lane keeps the
+// entry of the first match ending beyond its position in registers and stores 16, 4 or 1 bytes at a time depending on
+// how close the next match boundary is (the store address is q + shift[k]; unaligned stores are fine on gfx950).
+constexpr int kGapThreads = 256;
+constexpr int kGapIters = 16;                                   // dwords per lane
+constexpr int kGapWaveBytes = 64 * 4 * kGapIters;               // 4 KiB per wave
+constexpr int kGapTileBytes = kGapWaveBytes * (kGapThreads / 64);
+constexpr int kGapWindow = 1024;                                // matches per tile held in LDS (16 KiB)
+
+__global__ __launch_bounds__(kBlockThreads) void tilek_kernel(const int32_t* spans, int64_t n, int ncap, int64_t ntiles, int32_t* tile_k0) {
+  const int64_t t = (int64_t)blockIdx.x * kBlockThreads + threadIdx.x;
+  if (t > ntiles) return;
+  const int64_t p0 = t * kGapTileBytes;
+  int64_t lo = 0, hi = n;            // first match whose END lies beyond p0 (ordered, non-overlapping)
   while (lo < hi) {
     const int64_t mid = (lo + hi) >> 1;
     if (spans[mid * ncap + 1] <= p0) lo = mid + 1; else hi = mid;
   }
-  int64_t k = lo;
-  int p = (int)p0;
-  while (p < p1) {
-    // an empty match at p does not cover p: skip matches that end at or before p
-    while (k < n && spans[k * ncap + 1] <= p) ++k;
-    int ms = k < n ? spans[k * ncap] : len, me = k < n ? spans[k * ncap + 1] : len;
-    if (p >= ms && p < me) { p = me < p1 ? me : p1; continue; }     // inside match k
-    const int stop = ms < p1 ? ms : p1;                             // gap [p, stop) precedes match k
-    const long long sh = shift[k];
-    for (int q = p; q < stop; ++q) out[q + sh] = in[q];
-    p = stop;     // an empty match at p is passed by the loop head: its replacement precedes byte p
+  tile_k0[t] = (int32_t)lo;
+}
+
+__global__ __launch_bounds__(kGapThreads) void gaps_kernel(const uint8_t* __restrict__ in, int32_t len, const int32_t* __restrict__ spans,
+                                                           int64_t n, int ncap, const long long* __restrict__ shift,
+                                                           const int32_t* __restrict__ tile_k0, uint8_t* __restrict__ out) {
+  __shared__ int32_t s_start[kGapWindow];
+  __shared__ int32_t s_end[kGapWindow];
+  __shared__ long long s_shift[kGapWindow];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t tile = blockIdx.x;
+  const int32_t k0 = tile_k0[tile];
+  const int32_t klast = tile_k0[tile + 1] < n ? tile_k0[tile + 1] : (int32_t)n;     // virtual entry n: start = end = +inf
+  const int mw = klast - k0 + 1;
+  const bool lds = mw <= kGapWindow;
+  if (lds) {
+    for (int e = tid; e < mw; e += kGapThreads) {
+      const int64_t k = (int64_t)k0 + e;
+      s_start[e] = k < n ? spans[k * ncap] : 0x7FFFFFFF;
+      s_end[e] = k < n ? spans[k * ncap + 1] : 0x7FFFFFFF;
+      s_shift[e] = shift[k];
+    }
+  }
+  __syncthreads();
+  auto Start = [&](int e) -> int32_t { return lds ? s_start[e] : ((int64_t)k0 + e < n ? spans[((int64_t)k0 + e) * ncap] : 0x7FFFFFFF); };
+  auto End = [&](int e) -> int32_t { return lds ? s_end[e] : ((int64_t)k0 + e < n ? spans[((int64_t)k0 + e) * ncap + 1] : 0x7FFFFFFF); };
+  auto Shift = [&](int e) -> long long { return lds ? s_shift[e] : shift[(int64_t)k0 + e]; };
+
+  // lane l of wave w owns the 64 contiguous bytes at tile + w * 4 KiB + l * 64: four 16-byte loads issued up front; the
+  // entry it is at (first match ending beyond the position) lives in registers and only moves when a match is passed
+  const int64_t q0 = tile * kGapTileBytes + (int64_t)wave * kGapWaveBytes + lane * (kGapIters * 4);
+  if (q0 >= len) return;
+  int e;
+  {
+    int lo = 0, hi = mw - 1;         // the last entry always qualifies
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (End(mid) <= q0) lo = mid + 1; else hi = mid;
+    }
+    e = lo;
+  }
+  uint32_t v[kGapIters];
+  if (q0 + kGapIters * 4 <= len) {
+#pragma unroll
+    for (int j = 0; j < kGapIters / 4; ++j) {
+      const uint4 t = *reinterpret_cast<const uint4*>(in + q0 + 16 * j);
+      v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int it = 0; it < kGapIters; ++it) {
+      v[it] = 0;
+      for (int b = 0; b < 4 && q0 + it * 4 + b < len; ++b) v[it] |= (uint32_t)in[q0 + it * 4 + b] << (8 * b);
+    }
+  }
+  int32_t ms = Start(e), me = End(e);
+  long long sh = Shift(e);
+#pragma unroll
+  for (int j = 0; j < kGapIters / 4; ++j) {
+    const int64_t q16 = q0 + 16 * j;
+    if (q16 >= len) break;
+    while (me <= q16) { ++e; ms = Start(e); me = End(e); sh = Shift(e); }
+    if (q16 + 16 <= ms && q16 + 16 <= len) {        // all 16 bytes in the gap before match e: one (unaligned) 16-byte store
+      const uint4 t = make_uint4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
+      __builtin_memcpy(out + q16 + sh, &t, 16);
+      continue;
+    }
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const int64_t q = q16 + 4 * d;
+      const uint32_t w = v[4 * j + d];
+      while (me <= q) { ++e; ms = Start(e); me = End(e); sh = Shift(e); }
+      if (q + 4 <= ms && q + 4 <= len) {
+        __builtin_memcpy(out + q + sh, &w, 4);
+        continue;
+      }
+      for (int b = 0; b < 4 && q + b < len; ++b) {
+        const int32_t p = (int32_t)(q + b);
+        while (me <= p) { ++e; ms = Start(e); me = End(e); sh = Shift(e); }     // an empty match at p does not cover p
+        if (p >= ms) continue;                                                   // inside match e
+        out[p + sh] = (uint8_t)(w >> (8 * b));
+      }
+    }
   }
 }
 
-__global__ __launch_bounds__(kBlockThreads) void reps_kernel(const uint8_t* in, const int32_t* spans, int64_t n, int ncap,
-                                                             const ReplSeg* segs, int nseg, const uint8_t* lits, const long long* shift,
-                                                             int select, uint8_t* out) {
-  const int64_t i = (int64_t)blockIdx.x * kBlockThreads + threadIdx.x;
+// ---- replacements: a lane per match ----------------------------------------------------------------------------------
+// Latency, not bandwidth, is what this kernel has to beat (a record, a few bytes of text and a few bytes of output per
+// match): the span records of the workgroup's 256 matches are staged in LDS with coalesced loads, every lane then
+// requests its whole match text at once (dwords, every group text lies inside its match) into its own LDS slot, and the
+// replacement is assembled from LDS -- two memory round trips per workgroup of 256 matches.
+constexpr int kRepMaxCap = 16;                 // span slots per record held in LDS (else: global reads)
+constexpr int kRepText = 64;                   // match bytes held in LDS (longer matches: global reads)
+constexpr int kRepLits = 512;
+
+__global__ __launch_bounds__(kBlockThreads) void reps_kernel(const uint8_t* __restrict__ in, const int32_t* __restrict__ spans, int64_t n, int ncap,
+                                                             const ReplSeg* __restrict__ segs, int nseg, const uint8_t* __restrict__ lits,
+                                                             int nlits, const long long* __restrict__ shift, int select,
+                                                             uint8_t* __restrict__ out) {
+  __shared__ int32_t s_rec[kBlockThreads * kRepMaxCap];
+  __shared__ uint32_t s_text[kBlockThreads][kRepText / 4 + 1];      // +1: odd dword stride, conflict-free byte reads
+  __shared__ uint8_t s_lits[kRepLits];
+  const int tid = threadIdx.x;
+  const int64_t i0 = (int64_t)blockIdx.x * kBlockThreads;
+  const int64_t i = i0 + tid;
+  const bool rec_lds = ncap <= kRepMaxCap, lit_lds = nlits <= kRepLits;
+  if (rec_lds) {
+    const int64_t cnt = (n - i0 < kBlockThreads ? n - i0 : kBlockThreads) * ncap;
+    for (int j = tid; j < cnt; j += kBlockThreads) s_rec[j] = spans[i0 * ncap + j];
+  }
+  if (lit_lds)
+    for (int j = tid; j < nlits; j += kBlockThreads) s_lits[j] = lits[j];
+  __syncthreads();
   if (i >= n) return;
-  const int32_t* r = spans + i * ncap;
-  long long o = select ? shift[i] : (long long)r[0] + shift[i];
+  auto Rec = [&](int slot) -> int32_t { return rec_lds ? s_rec[tid * ncap + slot] : spans[i * ncap + slot]; };
+  const int32_t ms = Rec(0), me = Rec(1);
+  const bool text_lds = me - ms <= kRepText;
+  uint8_t* mytext = reinterpret_cast<uint8_t*>(&s_text[tid][0]);
+  if (text_lds) {
+    const int nd = (me - ms) >> 2;
+    uint32_t w[kRepText / 4];
+#pragma unroll
+    for (int j = 0; j < kRepText / 4; ++j)
+      if (j < nd) __builtin_memcpy(&w[j], in + ms + 4 * j, 4);
+#pragma unroll
+    for (int j = 0; j < kRepText / 4; ++j)
+      if (j < nd) s_text[tid][j] = w[j];
+    for (int b = nd * 4; b < me - ms; ++b) mytext[b] = in[ms + b];
+  }
+  long long o = select ? shift[i] : (long long)ms + shift[i];
   for (int k = 0; k < nseg; ++k) {
     const ReplSeg s = segs[k];
     if (s.kind == 0) {
-      for (int b = 0; b < s.b; ++b) out[o + b] = lits[s.a + b];
+      const uint8_t* src = lit_lds ? s_lits + s.a : lits + s.a;
+      for (int b = 0; b < s.b; ++b) out[o + b] = src[b];
       o += s.b;
     } else {
-      const int gs = r[2 * s.a], ge = r[2 * s.a + 1];
-      for (int b = gs; b < ge; ++b) out[o + (b - gs)] = in[b];
-      o += ge - gs;
+      const int gs = Rec(2 * s.a), ge = Rec(2 * s.a + 1);
+      const int L = ge - gs;
+      // a group that took part in the match lies inside it; anything else (stale slots of unmatched groups) reads global
+      const bool inside = text_lds && gs >= ms && ge <= me;
+      const uint8_t* src = inside ? mytext + (gs - ms) : in + gs;
+      for (int b = 0; b < L; ++b) out[o + b] = src[b];
+      o += L;
     }
   }
 }
@@ -91,16 +215,21 @@ hipError_t LaunchReplaceSizes(const int32_t* spans, int64_t n, int ncap, const R
   return hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, d_delta, d_shift, (int)(n + 1), stream);
 }
 
+size_t ReplaceTileIndexBytes(int64_t len) { return (size_t)((len + kGapTileBytes - 1) / kGapTileBytes + 2) * sizeof(int32_t); }
+
 hipError_t LaunchReplaceWrite(const uint8_t* in, int32_t len, const int32_t* spans, int64_t n, int ncap, const ReplSeg* d_segs, int nseg,
-                              const uint8_t* d_lits, const long long* d_shift, uint8_t* out, bool select, hipStream_t stream) {
+                              const uint8_t* d_lits, int nlits, const long long* d_shift, int32_t* d_tile_k0, uint8_t* out, bool select,
+                              hipStream_t stream) {
   const dim3 block(kBlockThreads);
-  const int64_t nslices = select ? 0 : ((int64_t)len + kSliceBytes - 1) / kSliceBytes;
-  if (nslices > 0)
-    hipLaunchKernelGGL(gaps_kernel, dim3((unsigned)((nslices + kBlockThreads - 1) / kBlockThreads)), block, 0, stream, in, len, spans, n, ncap,
-                       d_shift, out);
-  if (n > 0)
-    hipLaunchKernelGGL(reps_kernel, dim3((unsigned)((n + kBlockThreads - 1) / kBlockThreads)), block, 0, stream, in, spans, n, ncap, d_segs,
-                       nseg, d_lits, d_shift, select ? 1 : 0, out);
+  const int64_t ntiles = select ? 0 : ((int64_t)len + kGapTileBytes - 1) / kGapTileBytes;
+  if (ntiles > 0) {
+    hipLaunchKernelGGL(tilek_kernel, dim3((unsigned)((ntiles + 1 + kBlockThreads - 1) / kBlockThreads)), block, 0, stream, spans, n, ncap, ntiles,
+                       d_tile_k0);
+    hipLaunchKernelGGL(gaps_kernel, dim3((unsigned)ntiles), dim3(kGapThreads), 0, stream, in, len, spans, n, ncap, d_shift, d_tile_k0, out);
+  }
+  if (n > 0 && nseg > 0)          // (an empty replacement -- RejectReader, template "" -- writes nothing)
+    hipLaunchKernelGGL(reps_kernel, dim3((unsigned)((n + kBlockThreads - 1) / kBlockThreads)), block, 0, stream, in, spans, n, ncap, d_segs, nseg,
+                       d_lits, nlits, d_shift, select ? 1 : 0, out);
   return hipGetLastError();
 }
 
