@@ -485,7 +485,8 @@ class Machine:
                     return False, off
 
     # ---- FindAllBytesAppend (find.go:130-466) ---------------------------------------
-    def find_all(self, inp: bytes, n: int = -1) -> List[List[int]]:
+    def find_all(self, inp: bytes, n: int = -1, q8: bool = True) -> List[List[int]]:
+        """q8=False clears the memo between iterations (a fresh search per match); the reference never does (Q8)."""
         res: List[List[int]] = []
         if n == 0:
             return res
@@ -502,6 +503,8 @@ class Machine:
                 break
             caps = [0] * ncap
             caps[0] = ss
+            if self.memo and not q8:
+                visited = set()
             ok, off = self._attempt(inp, l, ss, caps, visited)
             if ok:
                 caps[1] = off

@@ -69,7 +69,9 @@ static inline int32_t decode_rune(const uint8_t* b, int64_t l, int64_t off, int*
 """
 
 
-def emit_c(prog: S.Prog, memo: bool, name: str = "m") -> str:
+def emit_c(prog: S.Prog, memo: bool, name: str = "m", q8: bool = True) -> str:
+    """q8=False: the memo bit-vector is cleared between FindAll iterations (what a fresh search per match would see);
+    the reference never clears it (quirk Q8, find.go:175-188), which is the default here."""
     ninst = len(prog.inst)
     ncap = prog.numcap
     anchored = E.is_anchored(prog)
@@ -81,6 +83,8 @@ def emit_c(prog: S.Prog, memo: bool, name: str = "m") -> str:
         w(_DECODE_RUNE_C)
     w("static inline int is_word(uint8_t c){return (c>='0'&&c<='9')||(c>='A'&&c<='Z')||c=='_'||(c>='a'&&c<='z');}\n")
     w("typedef struct { int64_t off; int32_t pc; } frame_t;\n")
+    if memo and not q8:
+        w("static int64_t* touched = 0; static int64_t ntouched = 0, captouched = 0;\n")
     # one attempt from `start`; captures in caps; returns 1 on match (offset in *end), else 0 (failure offset in *end)
     w("static int attempt(const uint8_t* input, int64_t l, int64_t start, int64_t* caps, int64_t* end,"
       " frame_t** stk, int64_t** cstk, int64_t* scap, uint32_t* visited) {\n")
@@ -106,7 +110,12 @@ def emit_c(prog: S.Prog, memo: bool, name: str = "m") -> str:
         elif op == S.InstAlt:
             if memo:
                 w("  { int64_t idx = (int64_t)%d * (l + 1) + offset; uint32_t bit = 1u << (idx & 31);\n" % i)
-                w("    if (visited[idx >> 5] & bit) goto TryFallback; visited[idx >> 5] |= bit; }\n")
+                if q8:
+                    w("    if (visited[idx >> 5] & bit) goto TryFallback; visited[idx >> 5] |= bit; }\n")
+                else:
+                    w("    if (visited[idx >> 5] & bit) goto TryFallback; visited[idx >> 5] |= bit;\n")
+                    w("    if (ntouched == captouched) { captouched = captouched ? 2 * captouched : 1024;"
+                      " touched = (int64_t*)realloc(touched, 8 * captouched); }\n    touched[ntouched++] = idx >> 5; }\n")
             w("  if (sp == *scap) { *scap *= 2; stack = *stk = (frame_t*)realloc(stack, sizeof(frame_t) * *scap);"
               " cstack = *cstk = (int64_t*)realloc(cstack, sizeof(int64_t) * NCAP * *scap); }\n")
             w("  stack[sp].off = offset; stack[sp].pc = %d; memcpy(cstack + sp*NCAP, caps, sizeof(int64_t)*NCAP); sp++;\n" % ins.arg)
@@ -163,7 +172,10 @@ def emit_c(prog: S.Prog, memo: bool, name: str = "m") -> str:
     w("    if (ss >= l) break;\n    int64_t caps[NCAP]; memset(caps, 0, sizeof caps); caps[0] = ss;\n")
     w("    if (attempt(input, l, ss, caps, &end, &stack, &cstack, &scap, visited)) {\n      caps[1] = end;\n")
     w("      if (count < cap) for (int c = 0; c < NCAP; c++) out[count*NCAP + c] = (int32_t)caps[c];\n      count++;\n")
-    w("      if (caps[1] > ss) ss = caps[1]; else ss++;\n    } else ss++;\n  }\n")
+    w("      if (caps[1] > ss) ss = caps[1]; else ss++;\n    } else ss++;\n")
+    if memo and not q8:
+        w("    for (int64_t k = 0; k < ntouched; k++) visited[touched[k]] = 0;\n    ntouched = 0;\n")
+    w("  }\n")
     w("  free(stack); free(cstack); free(visited);\n  return count;\n}\n\n")
     # FindBytesReuse (find.go:469-591): Q1 restart from the failure offset
     w("int %s_find(const uint8_t* input, int64_t l, int32_t* out) {\n" % name)
@@ -187,13 +199,14 @@ def emit_c(prog: S.Prog, memo: bool, name: str = "m") -> str:
 class CMatcher:
     """gcc-compiled specialised matcher for one pattern (cached by source hash under oracle/_build/)."""
 
-    def __init__(self, pattern: str, opt: str = "-O2"):
+    def __init__(self, pattern: str, opt: str = "-O2", q8: bool = True):
         self.pattern = pattern
         ast, prog = S.compile_pattern(pattern)
         self.prog = prog
         sel = E.select(ast, prog)
         self.ncap = prog.numcap
-        src = emit_c(prog, sel.find_memo)
+        self.memo = sel.find_memo
+        src = emit_c(prog, sel.find_memo, q8=q8)
         os.makedirs(BUILD, exist_ok=True)
         h = hashlib.sha256((src + opt).encode()).hexdigest()[:16]
         so = os.path.join(BUILD, "m_%s.so" % h)

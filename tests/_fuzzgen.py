@@ -1,0 +1,94 @@
+"""Seeded random regular expressions and inputs for the differential tests (host table walk and HIP kernels against
+the oracle).  Everything the reference's front end accepts in Perl mode may come out of here: literals, classes, negated
+classes, `.`, \\d \\w \\s, capturing / named / non-capturing groups, alternation, greedy and lazy quantifiers, counted
+repetition, and (sparingly) the empty-width assertions ^ $ \\b \\B."""
+import random
+
+ALPHABET = "ab01-. \n"
+ATOMS = ["a", "b", "0", "1", "-", r"\.", r"\d", r"\w", r"\s", ".", "[ab]", "[^a]", "[0-9]", "[a-b0-1]", r"[^\d\n]", "ab", "01", "a-"]
+ASSERTS = ["^", "$", r"\b", r"\B", "(?m:^)", "(?m:$)"]
+
+
+def gen_regex(rng: random.Random, depth: int = 0, allow_assert: bool = True) -> str:
+    r = rng.random()
+    if depth >= 3 or r < 0.35:
+        if allow_assert and rng.random() < 0.06:
+            return rng.choice(ASSERTS)
+        return rng.choice(ATOMS)
+    if r < 0.55:        # concatenation
+        return "".join(gen_regex(rng, depth + 1, allow_assert) for _ in range(rng.randrange(2, 4)))
+    if r < 0.70:        # alternation inside a group
+        alts = "|".join(gen_regex(rng, depth + 1, allow_assert) for _ in range(rng.randrange(2, 4)))
+        return rng.choice(["(%s)", "(?:%s)", "(?P<g%d>%%s)" % rng.randrange(100)]) % alts
+    if r < 0.92:        # quantifier
+        inner = gen_regex(rng, depth + 1, False)
+        if len(inner) > 1 and not (inner.startswith("(") and inner.endswith(")")) and not (inner.startswith("[") and inner.endswith("]")) \
+                and not (inner.startswith("\\") and len(inner) == 2):
+            inner = "(?:%s)" % inner
+        q = rng.choice(["*", "+", "?", "{2}", "{1,3}", "{2,}", "{0,2}"])
+        if rng.random() < 0.2:
+            q += "?"
+        return inner + q
+    return "(%s)" % gen_regex(rng, depth + 1, allow_assert)
+
+
+def gen_patterns(seed: int, count: int):
+    rng = random.Random(seed)
+    out, seen = [], set()
+    while len(out) < count:
+        p = gen_regex(rng)
+        if p in seen or len(p) > 60:
+            continue
+        seen.add(p)
+        out.append(p)
+    return out
+
+
+def gen_input(rng: random.Random, n: int, alphabet: str = ALPHABET) -> bytes:
+    """Runs and repeats make matches (and long matches) likely."""
+    out = []
+    size = 0
+    while size < n:
+        k = rng.random()
+        if k < 0.5:
+            s = "".join(rng.choice(alphabet) for _ in range(rng.randrange(1, 8)))
+        elif k < 0.8:
+            s = rng.choice(alphabet[:6]) * rng.randrange(1, 12)
+        else:
+            s = rng.choice(["ab", "01", "a-b", "0.1", "ab01", "b-a.0"]) * rng.randrange(1, 5)
+        out.append(s)
+        size += len(s)
+    return "".join(out)[:n].encode()
+
+
+def has_empty_loop(prog) -> bool:
+    """A cycle through instructions that consume nothing (alt / capture / empty-width / nop): the reference's
+    backtracker never leaves it unless memoization is on (e.g. `(?:a*)+` -- its Find* functions do not terminate)."""
+    from oracle import syntax as S
+    n = len(prog.inst)
+    succ = [[] for _ in range(n)]
+    for i, ins in enumerate(prog.inst):
+        if ins.op in (S.InstAlt, S.InstAltMatch):
+            succ[i] = [ins.out, ins.arg]
+        elif ins.op in (S.InstCapture, S.InstEmptyWidth, S.InstNop):
+            succ[i] = [ins.out]
+    color = [0] * n
+    for s in range(n):
+        if color[s]:
+            continue
+        stack = [(s, 0)]
+        color[s] = 1
+        while stack:
+            v, k = stack[-1]
+            if k < len(succ[v]):
+                stack[-1] = (v, k + 1)
+                w = succ[v][k]
+                if color[w] == 1:
+                    return True
+                if color[w] == 0:
+                    color[w] = 1
+                    stack.append((w, 0))
+            else:
+                color[v] = 2
+                stack.pop()
+    return False

@@ -222,3 +222,37 @@ def test_utf8_decoding_classes(hostlib):
             assert hp.find_all(b) == o.find_machine.find_all(b), (p, b)
             n += 1
     assert n == 60 * len(pats)
+
+
+def test_random_patterns_table_walk_equals_oracle(hostlib):
+    """Differential test over seeded random regular expressions (tests/_fuzzgen.py): the table walk over the compiled
+    DFA + capture pools against the oracle's FindAllBytes, and the search automaton against its restart loop."""
+    from tests import _fuzzgen as F
+    rng = random.Random(99)
+    compared = refused = q8_cases = hangs = 0
+    for p in F.gen_patterns(2024, 400):
+        try:
+            o = E.Compiled(p)
+        except Exception:
+            continue                       # the oracle's front end refuses it (Go would too): nothing to compare
+        if F.has_empty_loop(o.prog) and not o.find_machine.memo:
+            hangs += 1                     # the reference's own Find* would not terminate on this pattern
+            continue
+        try:
+            hp = hostlib.HostProgram(p)
+        except ValueError:
+            refused += 1
+            continue
+        for _ in range(6):
+            b = F.gen_input(rng, rng.choice([0, 1, 5, 40, 200]))
+            # Q8 (DESIGN.md): the reference's memo bit-vector survives from one FindAll iteration to the next; nullable
+            # loops then see stale entries.  The tables compute the fresh-search reading; count where that matters.
+            exp = o.find_machine.find_all(b, q8=False)
+            q8_cases += exp != o.find_machine.find_all(b)
+            assert hp.find_all(b) == exp, (p, b)
+            sa = hp.find_all_sa(b)
+            if sa is not None:
+                assert sa == exp, ("shift-and path", p, b)
+            compared += 1
+    print("compared", compared, "refused", refused, "inputs where Q8 changes the reference's answer", q8_cases, "non-terminating in the reference", hangs)
+    assert compared > 1500 and refused < 40, (compared, refused)
