@@ -746,9 +746,9 @@ __device__ __forceinline__ int WalkBatch(const Tab<MODE>& tab, const BatchInput&
 }
 
 // ResolveCaptures over LDS-resident tables; rec points into LDS.
-template <int MODE>
+template <int MODE, class TraceT = uint16_t>
 __device__ __forceinline__ void ResolveCapturesBatch(const Tab<MODE>& tab, const BtTabs& B, const DevTables& T, const uint8_t* cls,
-                                                     const uint8_t* ctx_of_byte, const BatchInput& in, int s, int e, uint16_t* trace,
+                                                     const uint8_t* ctx_of_byte, const BatchInput& in, int s, int e, TraceT* trace,
                                                      int32_t* rec) {
   const int ncap = T.ncap;
   const int unset = T.unmatched_minus1 ? -1 : 0;
@@ -757,7 +757,7 @@ __device__ __forceinline__ void ResolveCapturesBatch(const Tab<MODE>& tab, const
   unsigned q = T.start[ctx];
   const int n = e - s;
   for (int i = 0; i <= n; ++i) {
-    trace[i] = (uint16_t)q;
+    trace[i] = (TraceT)q;
     if (i == n) break;
     q = tab.Step(q, in.At(s + i)) & kStateMask;
   }
@@ -797,7 +797,8 @@ struct BatchLayout {     // byte offsets into dynamic LDS (host and device compu
   int bt_in_lds;
 };
 
-__host__ __device__ inline BatchLayout BatchLdsLayout(const DevTables& T, bool want_spans) {
+__host__ __device__ inline BatchLayout BatchLdsLayout(const DevTables& T, bool want_spans, int trace_entry_bytes = 2,
+                                                      int window_bytes = kBatchWindow) {
   BatchLayout L{};
   int o = 0;
   auto take = [&](int bytes) { const int at = o; o += (bytes + 15) & ~15; return at; };
@@ -817,8 +818,8 @@ __host__ __device__ inline BatchLayout BatchLdsLayout(const DevTables& T, bool w
     L.st_ops = take(16);
     L.st_pool = take(T.start_pool_n * 4);
   }
-  L.window = take(kBatchWindow + 16);
-  if (dyn) L.trace = take(kBlockThreads * kBatchTrace * 2);
+  L.window = take(window_bytes + 16);
+  if (dyn) L.trace = take(kBlockThreads * kBatchTrace * trace_entry_bytes);
   if (want_spans) L.recs = take(kBlockThreads * T.ncap * 4);
   L.total = o;
   return L;
@@ -942,6 +943,99 @@ __global__ __launch_bounds__(kBlockThreads) void batch_lds_kernel(DevTables T, c
     }
     __syncthreads();
     // records of the group are contiguous in `spans`: coalesced copy out of LDS
+    const int nrec_words = (int)(ilast - i0) * ncap;
+    int32_t* const dst = spans + i0 * ncap;
+    if (((i0 * ncap) & 3) == 0) {
+      for (int w = tid * 4; w < nrec_words; w += kBlockThreads * 4) {
+        if (w + 4 <= nrec_words) *reinterpret_cast<int4*>(dst + w) = *reinterpret_cast<const int4*>(recs + w);
+        else for (int k = w; k < nrec_words; ++k) dst[k] = recs[k];
+      }
+    } else {
+      for (int w = tid; w < nrec_words; w += kBlockThreads) dst[w] = recs[w];
+    }
+  }
+}
+
+
+// ---- captures from LDS: the same re-walk + back-trace as caps_kernel with the transition table, the back-trace pools,
+// a 16 KiB window of the input and every lane's state trace on chip (caps_kernel pays two dependent L1/L2 round trips
+// per byte in each direction).  256 matches per group; the group's records leave through LDS as 16-byte stores.
+constexpr int kCapsWindow = 8192;
+
+template <int MODE, class TraceT>
+__global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, const uint8_t* buf, int32_t len, int32_t* spans,
+                                                                  int64_t nmatches, TraceT* gtrace, unsigned long long* cursor) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const BatchLayout Y = BatchLdsLayout(T, true, (int)sizeof(TraceT), kCapsWindow);
+  const int ncap = T.ncap;
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(T.trans);
+    uint4* dst = reinterpret_cast<uint4*>(smem + Y.trans);
+    const int n16 = (T.table_bytes + 15) >> 4;
+    for (int i = tid; i < n16; i += kBlockThreads) dst[i] = src[i];
+    smem[Y.cls + tid] = T.cls[tid];
+    smem[Y.ctx + tid] = T.ctx_of_byte[tid];
+    if (Y.bt_in_lds) {
+      const int cells = T.nstates * T.stride;
+      uint32_t* d;
+      d = reinterpret_cast<uint32_t*>(smem + Y.bt_nth);   for (int i = tid; i < T.nstates; i += kBlockThreads) d[i] = T.st_nthreads[i];
+      d = reinterpret_cast<uint32_t*>(smem + Y.bt_base);  for (int i = tid; i < cells; i += kBlockThreads) d[i] = T.bt_base[i];
+      d = reinterpret_cast<uint32_t*>(smem + Y.bt_match); for (int i = tid; i < cells; i += kBlockThreads) d[i] = T.bt_match[i];
+      d = reinterpret_cast<uint32_t*>(smem + Y.bt_ops);   for (int i = tid; i < T.bt_pool_n; i += kBlockThreads) d[i] = T.bt_ops[i];
+      for (int i = tid; i < T.bt_pool_n; i += kBlockThreads) smem[Y.bt_parent + i] = T.bt_parent[i];
+      d = reinterpret_cast<uint32_t*>(smem + Y.st_ops);   if (tid < 4) d[tid] = T.start_ops[tid];
+      d = reinterpret_cast<uint32_t*>(smem + Y.st_pool);  for (int i = tid; i < T.start_pool_n; i += kBlockThreads) d[i] = T.start_ops_pool[i];
+    }
+  }
+  Tab<MODE> tab;
+  tab.t = reinterpret_cast<const uint16_t*>(smem + Y.trans);
+  tab.cls = smem + Y.cls;
+  tab.stride = T.stride;
+  tab.nstates = T.nstates;
+  const uint8_t* ctx_of_byte = smem + Y.ctx;
+  BtTabs B;
+  if (Y.bt_in_lds) {
+    B.st_nthreads = reinterpret_cast<const uint32_t*>(smem + Y.bt_nth);
+    B.bt_base = reinterpret_cast<const uint32_t*>(smem + Y.bt_base);
+    B.bt_match = reinterpret_cast<const uint32_t*>(smem + Y.bt_match);
+    B.bt_ops = reinterpret_cast<const uint32_t*>(smem + Y.bt_ops);
+    B.bt_parent = smem + Y.bt_parent;
+    B.start_ops = reinterpret_cast<const uint32_t*>(smem + Y.st_ops);
+    B.start_ops_pool = reinterpret_cast<const uint32_t*>(smem + Y.st_pool);
+  } else {
+    B.st_nthreads = T.st_nthreads; B.bt_base = T.bt_base; B.bt_match = T.bt_match; B.bt_ops = T.bt_ops;
+    B.bt_parent = T.bt_parent; B.start_ops = T.start_ops; B.start_ops_pool = T.start_ops_pool;
+  }
+  unsigned char* const win = smem + Y.window;
+  int32_t* const recs = reinterpret_cast<int32_t*>(smem + Y.recs);
+  const int64_t ngroups = (nmatches + kBlockThreads - 1) / kBlockThreads;
+
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t i0 = grp * kBlockThreads;
+    const int64_t i = i0 + tid;
+    const int64_t ilast = min(i0 + (int64_t)kBlockThreads, nmatches);
+    // the group's matches are ordered: its bytes are [start of the first - 1, end of the last + 1)
+    const int32_t gs = spans[i0 * ncap], ge = spans[(ilast - 1) * ncap + 1];
+    const int32_t wb = (gs > 0 ? gs - 1 : 0) & ~15;
+    const int64_t span_bytes = (int64_t)(ge < len ? ge + 1 : len) - wb;
+    const int wvalid = (int)min((int64_t)kCapsWindow, (span_bytes + 15) & ~15ll);    // whole 16-byte chunks (never a page)
+    __syncthreads();
+    for (int c = tid; c < (wvalid >> 4); c += kBlockThreads)
+      *reinterpret_cast<uint4*>(win + (c << 4)) = *reinterpret_cast<const uint4*>(buf + wb + ((int64_t)c << 4));
+    int s = 0, e = 0;
+    if (i < nmatches) { s = spans[i * ncap]; e = spans[i * ncap + 1]; }
+    __syncthreads();
+    BatchInput in;
+    in.g = buf; in.lds = win; in.rel0 = -wb; in.wvalid = wvalid; in.len = len;
+    int32_t* rec = recs + tid * ncap;
+    if (i < nmatches) {
+      const int need = e - s + 1;
+      TraceT* tr = need <= kBatchTrace ? reinterpret_cast<TraceT*>(smem + Y.trace) + tid * kBatchTrace
+                                       : gtrace + atomicAdd(cursor, (unsigned long long)need);
+      ResolveCapturesBatch<MODE, TraceT>(tab, B, T, tab.cls, ctx_of_byte, in, s, e, tr, rec);
+    }
+    __syncthreads();
     const int nrec_words = (int)(ilast - i0) * ncap;
     int32_t* const dst = spans + i0 * ncap;
     if (((i0 * ncap) & 3) == 0) {
@@ -1252,6 +1346,40 @@ hipError_t LaunchCarry(const DevTables& T, const uint8_t* buf, int32_t len, cons
 hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, int32_t* spans, int64_t nmatches, uint16_t* trace,
                           unsigned long long* trace_cursor, hipStream_t stream) {
   if (nmatches <= 0) return hipSuccess;
+  static const bool force_old = getenv("RGX_CAPS_OLD") != nullptr;
+  const bool t8 = T.nstates <= 256;
+  const BatchLayout Y = BatchLdsLayout(T, true, t8 ? 1 : 2, kCapsWindow);
+  if (!force_old && nmatches >= 64 && T.mode != kModeClassGlobal && Y.total <= 150 * 1024 && (((uintptr_t)buf) & 15) == 0 && T.ncap <= 32) {
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    }
+    const int64_t ngroups = (nmatches + kBlockThreads - 1) / kBlockThreads;
+    int per_cu = (160 * 1024) / (Y.total + 1024);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 8) per_cu = 8;
+    int64_t grid = (int64_t)cus * per_cu * 4;
+    if (grid > ngroups) grid = ngroups;
+    const int mi = (T.mode == kModeDirect ? 0 : 1) * 2 + (t8 ? 0 : 1);
+    const void* fns[4] = {(const void*)caps_lds_kernel<kModeDirect, uint8_t>, (const void*)caps_lds_kernel<kModeDirect, uint16_t>,
+                          (const void*)caps_lds_kernel<kModeClassLds, uint8_t>, (const void*)caps_lds_kernel<kModeClassLds, uint16_t>};
+    static bool attr_set[4] = {false, false, false, false};
+    if (!attr_set[mi]) {
+      hipError_t e = hipFuncSetAttribute(fns[mi], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      attr_set[mi] = true;
+    }
+    const dim3 g((unsigned)grid), b(kBlockThreads);
+    const size_t lds = (size_t)Y.total;
+    switch (mi) {
+      case 0: hipLaunchKernelGGL((caps_lds_kernel<kModeDirect, uint8_t>), g, b, lds, stream, T, buf, len, spans, nmatches, (uint8_t*)trace, trace_cursor); break;
+      case 1: hipLaunchKernelGGL((caps_lds_kernel<kModeDirect, uint16_t>), g, b, lds, stream, T, buf, len, spans, nmatches, trace, trace_cursor); break;
+      case 2: hipLaunchKernelGGL((caps_lds_kernel<kModeClassLds, uint8_t>), g, b, lds, stream, T, buf, len, spans, nmatches, (uint8_t*)trace, trace_cursor); break;
+      default: hipLaunchKernelGGL((caps_lds_kernel<kModeClassLds, uint16_t>), g, b, lds, stream, T, buf, len, spans, nmatches, trace, trace_cursor); break;
+    }
+    return hipGetLastError();
+  }
   dim3 block(64), grid((unsigned)((nmatches + 63) / 64));
   hipLaunchKernelGGL(caps_kernel, grid, block, 0, stream, T, buf, len, spans, nmatches, trace, trace_cursor);
   return hipGetLastError();

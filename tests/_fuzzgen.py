@@ -92,3 +92,38 @@ def has_empty_loop(prog) -> bool:
                 color[v] = 2
                 stack.pop()
     return False
+
+
+# ---- UTF-8 flavour: multibyte literals and classes over VALID UTF-8 inputs (decoding classes are exact on valid
+# UTF-8 only)
+ATOMS_U = ["a", "1", "é", "ü", "日", "[α-ω]", r"\p{Greek}", "[^a]", r"[^\d]", "[é日]", r"\pL", r"\PL", ".", r"\w", "aé", "[a-zà-ÿ]"]
+ALPHABET_U = ["a", "b", "1", " ", "\n", "é", "ü", "α", "ω", "β", "日", "本", "à", "€", "😀", "-"]
+
+
+def gen_regex_u(rng: random.Random, depth: int = 0) -> str:
+    r = rng.random()
+    if depth >= 2 or r < 0.4:
+        return rng.choice(ATOMS_U)
+    if r < 0.6:
+        return "".join(gen_regex_u(rng, depth + 1) for _ in range(rng.randrange(2, 4)))
+    if r < 0.75:
+        return "(%s)" % "|".join(gen_regex_u(rng, depth + 1) for _ in range(2))
+    inner = gen_regex_u(rng, depth + 1)
+    if len(inner) > 1 and not (inner[0] in "([" and inner[-1] in ")]") and not (inner[0] == "\\" and len(inner) <= 3):
+        inner = "(?:%s)" % inner
+    return inner + rng.choice(["*", "+", "?", "{1,2}", "+?"])
+
+
+def gen_patterns_u(seed: int, count: int):
+    rng = random.Random(seed)
+    out, seen = [], set()
+    while len(out) < count:
+        p = gen_regex_u(rng)
+        if p not in seen and len(p) <= 40:
+            seen.add(p)
+            out.append(p)
+    return out
+
+
+def gen_input_u(rng: random.Random, nchars: int) -> bytes:
+    return "".join(rng.choice(ALPHABET_U) * rng.choice([1, 1, 1, 2, 5]) for _ in range(nchars)).encode("utf-8")

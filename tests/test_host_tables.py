@@ -256,3 +256,29 @@ def test_random_patterns_table_walk_equals_oracle(hostlib):
             compared += 1
     print("compared", compared, "refused", refused, "inputs where Q8 changes the reference's answer", q8_cases, "non-terminating in the reference", hangs)
     assert compared > 1500 and refused < 40, (compared, refused)
+
+
+def test_random_utf8_patterns_table_walk_equals_oracle(hostlib):
+    """Same differential test with multibyte literals, ranges, negated classes and \\p{..} over valid UTF-8 inputs."""
+    from tests import _fuzzgen as F
+    rng = random.Random(5)
+    compared = refused = hangs = 0
+    for p in F.gen_patterns_u(77, 250):
+        try:
+            o = E.Compiled(p)
+        except Exception:
+            continue
+        if F.has_empty_loop(o.prog) and not o.find_machine.memo:
+            hangs += 1
+            continue
+        try:
+            hp = hostlib.HostProgram(p)
+        except ValueError:
+            refused += 1
+            continue
+        for _ in range(5):
+            b = F.gen_input_u(rng, rng.choice([0, 1, 4, 30, 120]))
+            assert hp.find_all(b) == o.find_machine.find_all(b, q8=False), (p, b)
+            compared += 1
+    print("compared", compared, "refused", refused, "non-terminating", hangs)
+    assert compared > 800 and refused < 40, (compared, refused)
