@@ -177,6 +177,11 @@ int rgx_replace_template_check(const char* tmpl, size_t tmpl_len);
 int64_t rgx_transform_chunk_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_data, size_t len, int is_eof,
                                    int mode, const char* tmpl, size_t tmpl_len, uint8_t* d_out, size_t cap_out,
                                    int64_t* out_len, int64_t* processed, rgx_result* res);
+/* The same with host buffers (what the Go stub calls from the Processor): stages `data` into the context's device
+ * buffer, runs the call above and copies the output bytes back into `out`.                                */
+int64_t rgx_transform_chunk(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* data, size_t len, int is_eof, int mode,
+                            const char* tmpl, size_t tmpl_len, uint8_t* out, size_t cap_out, int64_t* out_len,
+                            int64_t* processed, rgx_result* res);
 /* ValidateAndResolve against this program's groups: RGX_OK or RGX_E_INVALID (+ rgx_last_error()).        */
 int rgx_transform_template_check(const rgx_program* p, const char* tmpl, size_t tmpl_len);
 /* offsets[c] for c in [0, ncap): span slot c of a match starting at s is s + offsets[c]; returns fixed match length or <0. */

@@ -78,6 +78,8 @@ SYMBOLS = {
     "rgx_replace_template_check": (C.c_int, [C.c_char_p, C.c_size_t]),
     "rgx_transform_chunk_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_char_p, C.c_size_t,
                                                C.c_void_p, C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(Result)]),
+    "rgx_transform_chunk": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_char_p, C.c_size_t,
+                                        C.c_void_p, C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(Result)]),
     "rgx_transform_template_check": (C.c_int, [C.c_void_p, C.c_char_p, C.c_size_t]),
     "rgx_program_capture_template": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rgx_count_all_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(Result)]),

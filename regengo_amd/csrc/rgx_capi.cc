@@ -650,6 +650,29 @@ RGX_API int64_t rgx_transform_chunk_device(const rgx_program* p, rgx_stream_ctx*
   return *out_len;
 }
 
+RGX_API int64_t rgx_transform_chunk(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* data, size_t len, int is_eof, int mode,
+                                    const char* tmpl, size_t tmpl_len, uint8_t* out, size_t cap_out, int64_t* out_len, int64_t* processed,
+                                    rgx_result* res) {
+  int rc = CheckCtx(p, c);
+  if (rc != RGX_OK) return rc;
+  if (!out_len || !processed || (!data && len) || (!out && cap_out)) return RGX_E_INVALID;
+  if ((rc = Ensure(&c->d_in, &c->in_cap, (int64_t)len + 64)) != RGX_OK) return rc;
+  if (len) HIP_TRY(hipMemcpyAsync(c->d_in, data, len, hipMemcpyHostToDevice, c->stream));
+  int64_t want = (int64_t)std::max<size_t>(cap_out, len + len / 4 + 256);
+  int64_t w = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if ((rc = Ensure(&c->d_out, &c->out_cap, want / 4 + 16)) != RGX_OK) return rc;
+    w = rgx_transform_chunk_device(p, c, c->d_in, len, is_eof, mode, tmpl, tmpl_len, (uint8_t*)c->d_out, (size_t)c->out_cap * 4, out_len,
+                                   processed, res);
+    if (w != RGX_E_CAPACITY) break;
+    want = *out_len + 256;
+  }
+  if (w < 0) return w;
+  if ((size_t)w > cap_out) { SetError("output capacity too small"); return RGX_E_CAPACITY; }
+  if (w > 0) HIP_TRY(hipMemcpy(out, c->d_out, (size_t)w, hipMemcpyDeviceToHost));
+  return w;
+}
+
 RGX_API int64_t rgx_find_all_starts_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n,
                                            int32_t* d_starts, size_t cap, rgx_result* res) {
   int rc = CheckCtx(p, c);

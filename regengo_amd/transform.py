@@ -7,7 +7,7 @@
   SelectReader/RejectReader transform.go:322-378, 433-483                 -> Compiled.SelectReader / RejectReader
 
 Where the bytes go: every buffer the Transformer hands to the processor is matched on the GPU.  ReplaceReader,
-SelectReader(pred=None) and RejectReader(pred=None) splice on the device too (rgx_transform_chunk_device: FindAllBytes +
+SelectReader(pred=None) and RejectReader(pred=None) splice on the device too (rgx_transform_chunk: FindAllBytes +
 prefix-summed output offsets + gap/replacement kernels) and only the output bytes come back; arbitrary callbacks and
 predicates run on the host over the span table of the buffer (FindAllBytes on the device), following the emitted
 processTransform / processSelect / processReject loops.  There is no CPU matcher here: without the HIP library this
@@ -87,11 +87,13 @@ class Transformer:
         self.out = bytearray()
         self.ostart = 0
         self.source_eof = False
-        dev = "cuda:%d" % self.c._device
-        self._d_in = torch.empty(buffer_size + 64, dtype=torch.uint8, device=dev)
-        self._h_in = torch.empty(buffer_size, dtype=torch.uint8).pin_memory()
-        self._d_out = torch.empty(buffer_size + buffer_size // 4 + 256, dtype=torch.uint8, device=dev)
         self._torch = torch
+        if self.device_splice:
+            self._h_out = bytearray(buffer_size + buffer_size // 4 + 256)
+        else:
+            dev = "cuda:%d" % self.c._device
+            self._d_in = torch.empty(buffer_size + 64, dtype=torch.uint8, device=dev)
+            self._h_in = torch.empty(buffer_size, dtype=torch.uint8).pin_memory()
         self.chunks = 0
         self.matches = 0
 
@@ -167,27 +169,33 @@ class Transformer:
         torch.cuda.current_stream(self._d_in.device).synchronize()
 
     def _process(self, n: int, is_eof: bool) -> int:
-        self._upload(n)
         if self.device_splice:
             return self._process_device(n, is_eof)
+        self._upload(n)
         return self._process_host(n, is_eof)
 
     def _process_device(self, n: int, is_eof: bool) -> int:
+        """One rgx_transform_chunk call: the buffer goes down, the processor's output bytes come back."""
         lib = self.c._lib
         need, done, res = C.c_int64(0), C.c_int64(0), _capi.Result()
         tb = self.template or b""
-        for _ in range(2):
-            w = lib.rgx_transform_chunk_device(self.c._h, self.c._ctx, self._d_in.data_ptr(), n, 1 if is_eof else 0, self.mode, tb,
-                                               len(tb), self._d_out.data_ptr(), self._d_out.numel(), C.byref(need), C.byref(done),
-                                               C.byref(res))
-            if w == _capi.RGX_E_CAPACITY:
-                self._d_out = self._torch.empty(int(need.value) + 256, dtype=self._torch.uint8, device=self._d_in.device)
-                continue
-            break
+        cin = (C.c_uint8 * n).from_buffer(self.input)
+        try:
+            for _ in range(2):
+                cout = (C.c_uint8 * len(self._h_out)).from_buffer(self._h_out)
+                w = lib.rgx_transform_chunk(self.c._h, self.c._ctx, cin, n, 1 if is_eof else 0, self.mode, tb, len(tb), cout,
+                                            len(self._h_out), C.byref(need), C.byref(done), C.byref(res))
+                del cout
+                if w == _capi.RGX_E_CAPACITY:
+                    self._h_out = bytearray(int(need.value) + 256)
+                    continue
+                break
+        finally:
+            del cin
         _capi.check(w)
         self.matches += int(res.total)
         if w > 0:
-            self.out += self._d_out[:w].cpu().numpy().tobytes()
+            self.out += memoryview(self._h_out)[:w]
         return int(done.value)
 
     def _process_host(self, n: int, is_eof: bool) -> int:
