@@ -75,12 +75,20 @@ def build_product(verbose=False) -> str:
     st = _needs(out, srcs + _all_headers(), " ".join(flags))
     if st is None:
         return out
-    # hipcc treats .cc as host C++ and .hip as HIP; one link step produces the .so
-    cmd = [_hipcc()] + flags + srcs + ["-o", out]
-    log = _run(cmd)
-    if verbose:
-        print(log)
-    open(out + ".stamp", "w").write(st)
+    # several ranks of one job may get here at once: one builds (into a temporary, then an atomic rename), the rest wait
+    import fcntl
+    with open(os.path.join(LIBDIR, ".build.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if _needs(out, srcs + _all_headers(), " ".join(flags)) is None:
+            return out
+        # hipcc treats .cc as host C++ and .hip as HIP; one link step produces the .so
+        tmp = out + ".tmp%d" % os.getpid()
+        cmd = [_hipcc()] + flags + srcs + ["-o", tmp]
+        log = _run(cmd)
+        if verbose:
+            print(log)
+        os.replace(tmp, out)
+        open(out + ".stamp", "w").write(st)
     return out
 
 
