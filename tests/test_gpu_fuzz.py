@@ -72,3 +72,48 @@ def test_random_patterns_bit_exact(torch_dev, seed):
             batch += 1
     print("seed", seed, "compared", compared, "refused", refused, "non-terminating in the reference", hangs, "unsynced slices", unsynced, "batch strings", batch)
     assert compared > 200 and refused <= 5
+
+
+def test_random_patterns_replace_and_transform(torch_dev):
+    """The Replace and Transform rows on random patterns: ReplaceAllBytes / ReplaceFirstBytes against oracle/replace.py and
+    ReplaceReader / SelectReader / RejectReader (device splice, small buffers) against oracle/transform.py, both read
+    quirk-free.  Patterns that can match empty or look at their context are left out (Q12/Q13)."""
+    from oracle import engines as E
+    from oracle import replace as R
+    from oracle import transform as T
+    from regengo_amd import Compiled, _capi
+    from regengo_amd.stream import Config
+    from tests import _fuzzgen as F
+    rng = random.Random(321)
+    templates = ["", "<$0>", "[$1|$2]", "$$x${1}y", "$g7$0$0"]
+    done = 0
+    for p in F.gen_patterns(4242, 120):
+        if any(a in p for a in ("^", "$", "\\b", "\\B")):
+            continue
+        try:
+            o = E.Compiled(p)
+            c = Compiled(p).to(0)
+        except Exception:
+            continue
+        if c.info.can_match_empty or (F.has_empty_loop(o.prog) and not o.find_machine.memo):
+            continue
+        names = {n: i for i, n in enumerate(c.names) if i and n} if hasattr(c, "names") else {}
+        for _ in range(3):
+            b = F.gen_input(rng, rng.choice([0, 7, 300, 2500]))
+            for tmpl in templates:
+                assert c.ReplaceAllBytes(b, tmpl) == R.replace_all(o, b, tmpl), (p, tmpl, b)
+            assert c.ReplaceFirstBytes(b, "<$0>") == R.replace_all(o, b, "<$0>", first_only=True), (p, b)
+            # streaming: buffers just above the pattern's MaxLeftover so that many chunks are cut
+            dl = c.info.default_max_leftover
+            bs = dl + 200 if dl < (1 << 20) else 700
+            ml = 0 if dl < (1 << 20) else 100
+            for tmpl in ("", "<$0>"):
+                want = T.replace_reader(o, T.bytes_reader(b), tmpl, quirks=False, buffer_size=bs, max_leftover=ml)
+                wout, werr = want.read_all(333)
+                got = c.ReplaceReader(b, tmpl, Config(bs, ml))
+                if werr is not None:
+                    continue
+                assert got.read_all() == wout, ("reader", p, tmpl, bs, ml, b)
+        done += 1
+    print("patterns", done)
+    assert done >= 40
