@@ -41,6 +41,8 @@ struct rgx_stream_ctx {
   long long* d_rdelta = nullptr; int64_t rdelta_cap = 0;     // [delta n+1][shift n+1]
   uint8_t* d_rtemp = nullptr; int64_t rtemp_cap = 0;         // hipcub temp + segments + literals
   int32_t* d_out = nullptr; int64_t out_cap = 0;
+  uint8_t* d_tmpl = nullptr; int64_t tmpl_cap = 0;           // resolved template (segments + literals) of the last splice
+  std::string tmpl_key;                                      // what d_tmpl holds: "" = nothing
   // pinned host readback
   unsigned long long* h_read = nullptr;      // [4]: total, unsynced, ...
   unsigned long long* h_read_dev = nullptr;  // the same pinned words as the device sees them
@@ -359,7 +361,7 @@ RGX_API void rgx_stream_ctx_destroy(rgx_stream_ctx* c) {
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
   for (void* p : {(void*)c->d_desc, (void*)c->d_unsynced, (void*)c->d_carry,
-                  (void*)c->d_trace, (void*)c->d_in, (void*)c->d_out, (void*)c->d_rspans, (void*)c->d_rdelta, (void*)c->d_rtemp})
+                  (void*)c->d_trace, (void*)c->d_in, (void*)c->d_out, (void*)c->d_rspans, (void*)c->d_rdelta, (void*)c->d_rtemp, (void*)c->d_tmpl})
     if (p) hipFree(p);
   if (c->h_read) hipHostFree(c->h_read);
   delete c;
@@ -486,33 +488,45 @@ struct SplicePlan {
   int nlits = 0;
 };
 
-// Uploads the resolved template, sizes every replacement and prefix-sums them over the n matches in c->d_rspans.
-// *gain = sum of the deltas (select: total output bytes); *last_end (optional, n > 0) = end of the last match.
-int SpliceSizes(const rgx_program* p, rgx_stream_ctx* c, int64_t len, int64_t n, const ParsedTemplate& pt, bool select, SplicePlan* sp,
-                long long* gain, int32_t* last_end) {
+// Uploads the resolved template (skipped when `key` says the context's device copy is already this one), sizes every
+// replacement and prefix-sums them over the n matches in c->d_rspans.
+// *gain = sum of the deltas (select: total output bytes); *last_end (optional, n > 0) = end of the last match; both come back
+// through pinned host words with ONE stream synchronisation.
+int SpliceSizes(const rgx_program* p, rgx_stream_ctx* c, int64_t len, int64_t n, const ParsedTemplate& pt, const std::string& key, bool select,
+                SplicePlan* sp, long long* gain, int32_t* last_end) {
   int rc;
   const int ncap = p->p.dev.ncap;
-  const size_t temp_bytes = ReplaceScanTempBytes(n);
+  const bool small = n + 1 <= ReplaceSmallScanMax();
+  const size_t temp_bytes = small ? 0 : ReplaceScanTempBytes(n);
   const size_t seg_bytes = (pt.segs.size() * sizeof(ReplSeg) + 15) & ~size_t(15);
   const size_t lit_bytes = (pt.lits.size() + 15) & ~size_t(15);
   if ((rc = Ensure(&c->d_rdelta, &c->rdelta_cap, 2 * (n + 1) + 2)) != RGX_OK) return rc;
   const size_t tile_bytes = (ReplaceTileIndexBytes(len) + 255) & ~size_t(255);
-  if ((rc = Ensure(&c->d_rtemp, &c->rtemp_cap, (int64_t)(tile_bytes + temp_bytes + 256 + seg_bytes + lit_bytes + 64))) != RGX_OK) return rc;
+  if ((rc = Ensure(&c->d_rtemp, &c->rtemp_cap, (int64_t)(tile_bytes + temp_bytes + 256))) != RGX_OK) return rc;
   sp->d_tile_k0 = (int32_t*)c->d_rtemp;
-  uint8_t* base = c->d_rtemp + tile_bytes;
-  sp->d_segs = (ReplSeg*)base;
-  sp->d_lits = base + seg_bytes;
+  void* d_temp = c->d_rtemp + tile_bytes;
+  if ((int64_t)(seg_bytes + lit_bytes + 16) > c->tmpl_cap) c->tmpl_key.clear();
+  if ((rc = Ensure(&c->d_tmpl, &c->tmpl_cap, (int64_t)(seg_bytes + lit_bytes + 16))) != RGX_OK) return rc;
+  sp->d_segs = (ReplSeg*)c->d_tmpl;
+  sp->d_lits = c->d_tmpl + seg_bytes;
   sp->nseg = (int)pt.segs.size();
   sp->nlits = (int)pt.lits.size();
-  void* d_temp = base + seg_bytes + lit_bytes + ((256 - ((seg_bytes + lit_bytes) & 255)) & 255);
-  if (!pt.segs.empty()) HIP_TRY(hipMemcpyAsync(sp->d_segs, pt.segs.data(), pt.segs.size() * sizeof(ReplSeg), hipMemcpyHostToDevice, c->stream));
-  if (!pt.lits.empty()) HIP_TRY(hipMemcpyAsync(sp->d_lits, pt.lits.data(), pt.lits.size(), hipMemcpyHostToDevice, c->stream));
+  if (key.empty() || key != c->tmpl_key) {
+    if (!pt.segs.empty()) HIP_TRY(hipMemcpyAsync(sp->d_segs, pt.segs.data(), pt.segs.size() * sizeof(ReplSeg), hipMemcpyHostToDevice, c->stream));
+    if (!pt.lits.empty()) HIP_TRY(hipMemcpyAsync(sp->d_lits, pt.lits.data(), pt.lits.size(), hipMemcpyHostToDevice, c->stream));
+    // (pageable sources: the copies have left the host buffers when the calls return)
+    c->tmpl_key = key;
+  }
   long long* d_delta = c->d_rdelta;
   sp->d_shift = c->d_rdelta + (n + 1);
   HIP_TRY(LaunchReplaceSizes(c->d_rspans, n, ncap, sp->d_segs, sp->nseg, d_delta, sp->d_shift, d_temp, temp_bytes, select, c->stream));
-  HIP_TRY(hipMemcpyAsync(gain, sp->d_shift + n, 8, hipMemcpyDeviceToHost, c->stream));
-  if (last_end) HIP_TRY(hipMemcpyAsync(last_end, c->d_rspans + (n - 1) * ncap + 1, 4, hipMemcpyDeviceToHost, c->stream));
+  unsigned long long* h = c->h_read + 4;      // pinned words 4, 5
+  h[0] = 0; h[1] = 0;
+  HIP_TRY(hipMemcpyAsync(&h[0], sp->d_shift + n, 8, hipMemcpyDeviceToHost, c->stream));
+  if (last_end) HIP_TRY(hipMemcpyAsync(&h[1], c->d_rspans + (n - 1) * ncap + 1, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
+  *gain = (long long)h[0];
+  if (last_end) *last_end = (int32_t)(uint32_t)h[1];
   return RGX_OK;
 }
 }  // namespace
@@ -582,7 +596,7 @@ RGX_API int64_t rgx_replace_all_bytes_device(const rgx_program* p, rgx_stream_ct
   // 3. sizes and the prefix sum, 4. gaps and replacements
   SplicePlan sp;
   long long gain = 0;
-  if ((rc = SpliceSizes(p, c, (int64_t)len, n, pt, false, &sp, &gain, nullptr)) != RGX_OK) return rc;
+  if ((rc = SpliceSizes(p, c, (int64_t)len, n, pt, std::string(), false, &sp, &gain, nullptr)) != RGX_OK) return rc;
   *out_len = (int64_t)len + gain;
   if (res) { *res = r; res->total = n; res->written = n; }
   if ((size_t)*out_len > cap_out || (!d_out && *out_len > 0)) { SetError("output capacity too small"); return RGX_E_CAPACITY; }
@@ -600,9 +614,20 @@ RGX_API int rgx_transform_template_check(const rgx_program* p, const char* tmpl,
   return RGX_OK;
 }
 
+namespace {
+int64_t TransformChunkDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_data, size_t len, int is_eof, int mode, const char* tmpl,
+                             size_t tmpl_len, uint8_t* d_out, size_t cap_out, int64_t* out_len, int64_t* processed, rgx_result* res,
+                             bool final_sync);
+}
 RGX_API int64_t rgx_transform_chunk_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_data, size_t len, int is_eof, int mode,
                                            const char* tmpl, size_t tmpl_len, uint8_t* d_out, size_t cap_out, int64_t* out_len,
                                            int64_t* processed, rgx_result* res) {
+  return TransformChunkDevice(p, c, d_data, len, is_eof, mode, tmpl, tmpl_len, d_out, cap_out, out_len, processed, res, true);
+}
+namespace {
+int64_t TransformChunkDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_data, size_t len, int is_eof, int mode, const char* tmpl,
+                             size_t tmpl_len, uint8_t* d_out, size_t cap_out, int64_t* out_len, int64_t* processed, rgx_result* res,
+                             bool final_sync) {
   int rc = CheckCtx(p, c);
   if (rc != RGX_OK) return rc;
   if (!out_len || !processed || mode < RGX_TRANSFORM_REPLACE || mode > RGX_TRANSFORM_REJECT) return RGX_E_INVALID;
@@ -614,12 +639,16 @@ RGX_API int64_t rgx_transform_chunk_device(const rgx_program* p, rgx_stream_ctx*
     return RGX_E_UNSUPPORTED;
   }
   ParsedTemplate pt;
-  std::string err;
+  std::string err, key;
   if (mode == RGX_TRANSFORM_REPLACE) {
     if (!ParseTemplate(tmpl, tmpl_len, &t, &pt, &err, true)) { SetError(err); return RGX_E_INVALID; }
+    key.assign(1, 'T'); key.append(tmpl, tmpl_len);
   } else if (mode == RGX_TRANSFORM_SELECT) {
     pt.segs.push_back({1, 0, 0});       // the match text itself
-  }                                      // REJECT: the empty replacement
+    key = "S";
+  } else {
+    key = "R";                           // REJECT: the empty replacement
+  }
   if (len > 0x7FFFFF00ull) { SetError("buffer larger than 2^31-256 bytes"); return RGX_E_TOO_LARGE; }
   const int ncap = T.ncap;
   const bool select = mode == RGX_TRANSFORM_SELECT;
@@ -634,7 +663,7 @@ RGX_API int64_t rgx_transform_chunk_device(const rgx_program* p, rgx_stream_ctx*
   SplicePlan sp;
   long long gain = 0;
   int32_t last_end = 0;
-  if ((rc = SpliceSizes(p, c, (int64_t)len, n, pt, select, &sp, &gain, n > 0 ? &last_end : nullptr)) != RGX_OK) return rc;
+  if ((rc = SpliceSizes(p, c, (int64_t)len, n, pt, key, select, &sp, &gain, n > 0 ? &last_end : nullptr)) != RGX_OK) return rc;
   // what processTransform / processSelect / processReject return (transform.go:119-135, 399-404, 504-520)
   int64_t done;
   if (is_eof) done = (int64_t)len;
@@ -646,9 +675,10 @@ RGX_API int64_t rgx_transform_chunk_device(const rgx_program* p, rgx_stream_ctx*
   if ((size_t)*out_len > cap_out || (!d_out && *out_len > 0)) { SetError("output capacity too small"); return RGX_E_CAPACITY; }
   if (*out_len > 0)
     HIP_TRY(LaunchReplaceWrite(d_data, (int32_t)done, c->d_rspans, n, ncap, sp.d_segs, sp.nseg, sp.d_lits, sp.nlits, sp.d_shift, sp.d_tile_k0, d_out, select, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (final_sync) HIP_TRY(hipStreamSynchronize(c->stream));
   return *out_len;
 }
+}  // namespace
 
 RGX_API int64_t rgx_transform_chunk(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* data, size_t len, int is_eof, int mode,
                                     const char* tmpl, size_t tmpl_len, uint8_t* out, size_t cap_out, int64_t* out_len, int64_t* processed,
@@ -662,14 +692,15 @@ RGX_API int64_t rgx_transform_chunk(const rgx_program* p, rgx_stream_ctx* c, con
   int64_t w = 0;
   for (int attempt = 0; attempt < 2; ++attempt) {
     if ((rc = Ensure(&c->d_out, &c->out_cap, want / 4 + 16)) != RGX_OK) return rc;
-    w = rgx_transform_chunk_device(p, c, c->d_in, len, is_eof, mode, tmpl, tmpl_len, (uint8_t*)c->d_out, (size_t)c->out_cap * 4, out_len,
-                                   processed, res);
+    w = TransformChunkDevice(p, c, c->d_in, len, is_eof, mode, tmpl, tmpl_len, (uint8_t*)c->d_out, (size_t)c->out_cap * 4, out_len,
+                             processed, res, false);       // the D2H copy below is ordered behind the kernels on the stream
     if (w != RGX_E_CAPACITY) break;
     want = *out_len + 256;
   }
   if (w < 0) return w;
   if ((size_t)w > cap_out) { SetError("output capacity too small"); return RGX_E_CAPACITY; }
-  if (w > 0) HIP_TRY(hipMemcpy(out, c->d_out, (size_t)w, hipMemcpyDeviceToHost));
+  if (w > 0) HIP_TRY(hipMemcpyAsync(out, c->d_out, (size_t)w, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
   return w;
 }
 

@@ -86,7 +86,8 @@ hipError_t LaunchReplaceSizes(const int32_t* spans, int64_t n, int ncap, const R
 hipError_t LaunchReplaceWrite(const uint8_t* in, int32_t len, const int32_t* spans, int64_t n, int ncap, const ReplSeg* d_segs, int nseg,
                               const uint8_t* d_lits, int nlits, const long long* d_shift, int32_t* d_tile_k0, uint8_t* out, bool select,
                               hipStream_t stream);
-size_t ReplaceTileIndexBytes(int64_t len);     // scratch LaunchReplaceWrite needs for d_tile_k0
+size_t ReplaceTileIndexBytes(int64_t len);
+int64_t ReplaceSmallScanMax();                 // up to this many entries LaunchReplaceSizes uses one single-workgroup launch     // scratch LaunchReplaceWrite needs for d_tile_k0
 // one anchored attempt at `pos` (the loop's extra try at offset len, find.go:545-569): *out_end = match end or -1
 hipError_t LaunchAttemptAt(const DevTables& T, const uint8_t* buf, int32_t len, int32_t pos, int32_t* out_end, hipStream_t stream);
 

@@ -202,6 +202,53 @@ __global__ __launch_bounds__(kBlockThreads) void reps_kernel(const uint8_t* __re
 
 }  // namespace
 
+// ---- sizes + prefix sum in ONE launch for short match lists (streaming buffers): a single workgroup, each lane a
+// contiguous run of matches, Hillis-Steele over the 1024 partial sums in LDS.  (hipCUB's scan is three launches.)
+constexpr int kSmallScanThreads = 1024;
+constexpr int kSmallScanPer = 8;
+
+__global__ __launch_bounds__(kSmallScanThreads) void replen_scan_small_kernel(const int32_t* spans, int64_t n, int ncap, const ReplSeg* segs,
+                                                                              int nseg, int select, long long* shift) {
+  __shared__ long long s_part[kSmallScanThreads];
+  const int tid = threadIdx.x;
+  const int64_t total = n + 1;                       // entries 0..n; entry n has delta 0
+  const int64_t per = (total + kSmallScanThreads - 1) / kSmallScanThreads;
+  const int64_t i0 = (int64_t)tid * per;
+  long long d[kSmallScanPer];
+  long long sum = 0;
+  for (int k = 0; k < kSmallScanPer; ++k) {
+    const int64_t i = i0 + k;
+    long long v = 0;
+    if (k < per && i < n) {
+      const int32_t* r = spans + i * ncap;
+      long long rl = 0;
+      for (int q = 0; q < nseg; ++q) {
+        const ReplSeg sg = segs[q];
+        rl += sg.kind == 0 ? sg.b : (long long)(r[2 * sg.a + 1] - r[2 * sg.a]);
+      }
+      v = select ? rl : rl - (long long)(r[1] - r[0]);
+    }
+    d[k] = v;
+    sum += v;
+  }
+  s_part[tid] = sum;
+  __syncthreads();
+  for (int off = 1; off < kSmallScanThreads; off <<= 1) {
+    const long long add = tid >= off ? s_part[tid - off] : 0;
+    __syncthreads();
+    s_part[tid] += add;
+    __syncthreads();
+  }
+  long long run = s_part[tid] - sum;                 // exclusive prefix of this lane's run
+  for (int k = 0; k < kSmallScanPer; ++k) {
+    const int64_t i = i0 + k;
+    if (k < per && i < total) shift[i] = run;
+    run += d[k];
+  }
+}
+
+int64_t ReplaceSmallScanMax() { return (int64_t)kSmallScanThreads * kSmallScanPer; }
+
 size_t ReplaceScanTempBytes(int64_t n) {
   size_t bytes = 0;
   hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const long long*)nullptr, (long long*)nullptr, (int)(n + 1));
@@ -210,6 +257,11 @@ size_t ReplaceScanTempBytes(int64_t n) {
 
 hipError_t LaunchReplaceSizes(const int32_t* spans, int64_t n, int ncap, const ReplSeg* d_segs, int nseg, long long* d_delta, long long* d_shift,
                               void* d_temp, size_t temp_bytes, bool select, hipStream_t stream) {
+  if (n + 1 <= ReplaceSmallScanMax()) {
+    hipLaunchKernelGGL(replen_scan_small_kernel, dim3(1), dim3(kSmallScanThreads), 0, stream, spans, n, ncap, d_segs, nseg, select ? 1 : 0,
+                       d_shift);
+    return hipGetLastError();
+  }
   const dim3 block(kBlockThreads), grid((unsigned)((n + 1 + kBlockThreads - 1) / kBlockThreads));
   hipLaunchKernelGGL(replen_kernel, grid, block, 0, stream, spans, n, ncap, d_segs, nseg, select ? 1 : 0, d_delta);
   return hipcub::DeviceScan::ExclusiveSum(d_temp, temp_bytes, d_delta, d_shift, (int)(n + 1), stream);
