@@ -696,7 +696,7 @@ __global__ __launch_bounds__(64) void batch_kernel(DevTables T, const uint8_t* c
 // 256 consecutive strings: their bytes are one contiguous range of `concat`, staged with coalesced 16-byte loads, every
 // lane runs the reference's FindBytes loop (find.go:545-569: first start position with a match) on LDS bytes and LDS
 // tables, and the span records leave through LDS as contiguous 16-byte stores.
-constexpr int kBatchWindow = 16384;      // input bytes staged per group of 256 strings (longer groups read the rest from L2)
+constexpr int kBatchWindow = 8192;       // input bytes staged per group of 256 strings (longer groups read the rest from L2)
 constexpr int kBatchTrace = 64;          // uint16 state-trace entries per lane kept in LDS (matches up to 63 bytes)
 
 struct BtTabs {
