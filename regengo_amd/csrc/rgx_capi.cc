@@ -62,8 +62,12 @@ namespace {
 template <class T>
 int Ensure(T** ptr, int64_t* cap, int64_t need) {
   if (*cap >= need && *ptr) return RGX_OK;
+  // growing a buffer that already exists: leave 1/8 slack, so that a stream of slightly larger requests (windows with a few
+  // more matches each) does not free and re-allocate gigabytes on every call
+  const bool regrow = *ptr != nullptr;
   if (*ptr) { hipFree(*ptr); *ptr = nullptr; *cap = 0; }
   int64_t n = std::max<int64_t>(need, 16);
+  if (regrow) n += n / 8;
   if (hipMalloc((void**)ptr, (size_t)n * sizeof(T)) != hipSuccess) { SetError("hipMalloc failed"); (void)hipGetLastError(); return RGX_E_NOMEM; }
   *cap = n;
   return RGX_OK;
@@ -789,12 +793,14 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
     HIP_TRY(hipStreamSynchronize(c->stream));
     const int64_t need = ((int64_t)h_last + 2 * (int64_t)nstr + 64 + 1) / 2 * (U->nstates <= 256 ? 1 : 2);   // in uint16 units
     if ((rc = Ensure(&c->d_trace, &c->trace_cap, need)) != RGX_OK) return rc;
-    HIP_TRY(LaunchBatchSearch(*U, T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, c->d_trace, c->stream));
+    HIP_TRY(LaunchBatchSearch(*U, T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, c->d_trace, c->stream,
+                              BatchWindowFor((int64_t)h_last, (int64_t)nstr)));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return (int64_t)nstr;
   }
   uint16_t* trace = nullptr;
   int64_t stride = 0;
+  int window = 0;
   if (!T.fixed_captures) {
     // matches longer than the LDS trace need global scratch: size it by the longest string
     // (one pass over the offsets on the host would need a D2H copy; bound by total bytes instead)
@@ -806,8 +812,9 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
     if ((rc = Ensure(&c->d_trace, &c->trace_cap, need)) != RGX_OK) return rc;
     trace = c->d_trace;
     stride = -1;  // "CSR-shaped": resolved in the kernel as offsets[i] + 2*i
+    window = BatchWindowFor((int64_t)h_last, (int64_t)nstr);
   }
-  HIP_TRY(LaunchBatch(T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, trace, stride, c->stream));
+  HIP_TRY(LaunchBatch(T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, trace, stride, c->stream, window));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return (int64_t)nstr;
 }
@@ -818,16 +825,23 @@ RGX_API int64_t rgx_match_batch_device(const rgx_program* p, rgx_stream_ctx* c, 
   if (rc != RGX_OK) return rc;
   if (nstr == 0) return 0;
   if (!d_concat || !d_offsets || !d_matched) return RGX_E_INVALID;
+  int window = 0;
+  if (nstr >= 4096) {       // big batches: size the LDS input window by the average string length
+    uint64_t h_last = 0;
+    HIP_TRY(hipMemcpyAsync(&h_last, d_offsets + nstr, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    window = BatchWindowFor((int64_t)h_last, (int64_t)nstr);
+  }
   {
     static const bool no_search = getenv("RGX_NO_SEARCH_DFA") != nullptr;
     const DevTables* U = no_search ? nullptr : SearchTables(const_cast<Program*>(&p->p));
     if (U && BatchSearchFits(*U, p->p.dev, false, d_concat)) {
-      HIP_TRY(LaunchBatchSearch(*U, p->p.dev, d_concat, d_offsets, (int64_t)nstr, d_matched, nullptr, nullptr, c->stream));
+      HIP_TRY(LaunchBatchSearch(*U, p->p.dev, d_concat, d_offsets, (int64_t)nstr, d_matched, nullptr, nullptr, c->stream, window));
       HIP_TRY(hipStreamSynchronize(c->stream));
       return (int64_t)nstr;
     }
   }
-  HIP_TRY(LaunchBatch(p->p.dev, d_concat, d_offsets, (int64_t)nstr, d_matched, nullptr, nullptr, 0, c->stream));
+  HIP_TRY(LaunchBatch(p->p.dev, d_concat, d_offsets, (int64_t)nstr, d_matched, nullptr, nullptr, 0, c->stream, window));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return (int64_t)nstr;
 }

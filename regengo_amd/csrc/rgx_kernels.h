@@ -64,14 +64,17 @@ hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, i
 
 // Batch (one string per lane): FindBytes / MatchBytes per string, CSR offsets.
 hipError_t LaunchBatch(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,
-                       int32_t* spans /* nullable: match only */, uint16_t* trace, int64_t trace_stride, hipStream_t stream);
+                       int32_t* spans /* nullable: match only */, uint16_t* trace, int64_t trace_stride, hipStream_t stream,
+                       int window_bytes = 0);
+// LDS input window for a batch of nstr strings holding total_bytes (0 / unknown: the large window)
+int BatchWindowFor(int64_t total_bytes, int64_t nstr);
 
 // Same entry points through the search automaton U (rgx_program.h: SearchTables): one forward walk per string.
 // `trace` is scratch of (total bytes + 2*nstr + 64) entries of uint8 (U.nstates <= 256) or uint16, used by strings
 // longer than the LDS trace.
 bool BatchSearchFits(const DevTables& U, const DevTables& F, bool want_spans, const uint8_t* concat);
 hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8_t* concat, const uint64_t* offsets, int64_t nstr,
-                             uint8_t* found, int32_t* spans, void* trace, hipStream_t stream);
+                             uint8_t* found, int32_t* spans, void* trace, hipStream_t stream, int window_bytes = 0);
 
 // ---- Replace path (rgx_replace.hip).  A resolved template segment: kind 0 = literal bytes lits[a, a+b); kind 1 = the text of
 // capture group a (0 = the whole match).

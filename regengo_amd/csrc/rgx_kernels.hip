@@ -696,7 +696,8 @@ __global__ __launch_bounds__(64) void batch_kernel(DevTables T, const uint8_t* c
 // 256 consecutive strings: their bytes are one contiguous range of `concat`, staged with coalesced 16-byte loads, every
 // lane runs the reference's FindBytes loop (find.go:545-569: first start position with a match) on LDS bytes and LDS
 // tables, and the span records leave through LDS as contiguous 16-byte stores.
-constexpr int kBatchWindow = 8192;       // input bytes staged per group of 256 strings (longer groups read the rest from L2)
+constexpr int kBatchWindow = 16384;      // input bytes staged per group of 256 strings (longer groups read the rest from L2);
+                                         // launches over short strings pass 8192: one more workgroup fits a CU
 constexpr int kBatchTrace = 64;          // uint16 state-trace entries per lane kept in LDS (matches up to 63 bytes)
 
 struct BtTabs {
@@ -828,11 +829,11 @@ __host__ __device__ inline BatchLayout BatchLdsLayout(const DevTables& T, bool w
 template <int MODE>
 __global__ __launch_bounds__(kBlockThreads) void batch_lds_kernel(DevTables T, const uint8_t* concat, const uint64_t* offsets,
                                                                    int64_t nstr, uint8_t* found, int32_t* spans, uint16_t* gtrace,
-                                                                   int64_t trace_stride, int debug) {
+                                                                   int64_t trace_stride, int debug, int window_bytes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const bool want_spans = spans != nullptr;
-  const BatchLayout Y = BatchLdsLayout(T, want_spans);
+  const BatchLayout Y = BatchLdsLayout(T, want_spans, 2, window_bytes);
   const int ncap = T.ncap;
   // ---- stage the tables once per workgroup
   {
@@ -884,7 +885,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_lds_kernel(DevTables T, c
     const int64_t ilast = min(i0 + (int64_t)kBlockThreads, nstr);
     const uint64_t gb = offsets[i0], ge = offsets[ilast];            // the group's byte range (uniform loads)
     const uint64_t wb = gb & ~15ull;                                   // window base, 16-byte aligned down
-    const int wvalid = (int)min((uint64_t)kBatchWindow, ((ge - wb) + 15ull) & ~15ull);   // whole 16-byte chunks; over-read
+    const int wvalid = (int)min((uint64_t)window_bytes, ((ge - wb) + 15ull) & ~15ull);   // whole 16-byte chunks; over-read
     __syncthreads();                                                   // stays inside the aligned chunk (never a page)
     for (int c = tid; c < (wvalid >> 4); c += kBlockThreads)
       *reinterpret_cast<uint4*>(win + (c << 4)) = *reinterpret_cast<const uint4*>(concat + wb + ((uint64_t)c << 4));
@@ -1061,7 +1062,8 @@ struct SearchLayout {
   int bt_in_lds;
 };
 
-__host__ __device__ inline SearchLayout SearchLdsLayout(const DevTables& U, int ncap, bool want_spans, int trace_entry_bytes) {
+__host__ __device__ inline SearchLayout SearchLdsLayout(const DevTables& U, int ncap, bool want_spans, int trace_entry_bytes,
+                                                        int window_bytes = kBatchWindow) {
   SearchLayout L{};
   int o = 0;
   auto take = [&](int bytes) { const int at = o; o += (bytes + 15) & ~15; return at; };
@@ -1079,7 +1081,7 @@ __host__ __device__ inline SearchLayout SearchLdsLayout(const DevTables& U, int 
     L.st_ops = take(16);
     L.st_pool = take(U.start_pool_n * 4);
   }
-  L.window = take(kBatchWindow + 16);
+  L.window = take(window_bytes + 16);
   if (want_spans) {
     L.trace = take(kBlockThreads * kBatchTrace * trace_entry_bytes);
     L.recs = take(kBlockThreads * ncap * 4);
@@ -1091,12 +1093,12 @@ __host__ __device__ inline SearchLayout SearchLdsLayout(const DevTables& U, int 
 template <int MODE, class TraceT>
 __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U, DevTables F, const uint8_t* concat,
                                                                       const uint64_t* offsets, int64_t nstr, uint8_t* found,
-                                                                      int32_t* spans, TraceT* gtrace) {
+                                                                      int32_t* spans, TraceT* gtrace, int window_bytes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const bool want_spans = spans != nullptr;
   const int ncap = F.ncap;
-  const SearchLayout Y = SearchLdsLayout(U, ncap, want_spans, (int)sizeof(TraceT));
+  const SearchLayout Y = SearchLdsLayout(U, ncap, want_spans, (int)sizeof(TraceT), window_bytes);
   {
     const uint4* src = reinterpret_cast<const uint4*>(U.trans);
     uint4* dst = reinterpret_cast<uint4*>(smem + Y.trans);
@@ -1147,7 +1149,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
     const int64_t ilast = min(i0 + (int64_t)kBlockThreads, nstr);
     const uint64_t gb = offsets[i0], ge = offsets[ilast];
     const uint64_t wb = gb & ~15ull;
-    const int wvalid = (int)min((uint64_t)kBatchWindow, ((ge - wb) + 15ull) & ~15ull);
+    const int wvalid = (int)min((uint64_t)window_bytes, ((ge - wb) + 15ull) & ~15ull);
     __syncthreads();
     for (int c = tid; c < (wvalid >> 4); c += kBlockThreads)
       *reinterpret_cast<uint4*>(win + (c << 4)) = *reinterpret_cast<const uint4*>(concat + wb + ((uint64_t)c << 4));
@@ -1385,11 +1387,18 @@ hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, i
   return hipGetLastError();
 }
 
+int BatchWindowFor(int64_t total_bytes, int64_t nstr) {
+  // a group of 256 strings should fit the window; short strings get the small window (one more workgroup per CU)
+  if (nstr <= 0 || total_bytes < 0) return kBatchWindow;
+  return (total_bytes / nstr) * kBlockThreads <= 7168 ? 8192 : kBatchWindow;
+}
+
 hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8_t* concat, const uint64_t* offsets, int64_t nstr,
-                             uint8_t* found, int32_t* spans, void* trace, hipStream_t stream) {
+                             uint8_t* found, int32_t* spans, void* trace, hipStream_t stream, int window_bytes) {
   if (nstr <= 0) return hipSuccess;
+  if (window_bytes <= 0) window_bytes = kBatchWindow;
   const bool t8 = U.nstates <= 256;
-  const SearchLayout Y = SearchLdsLayout(U, F.ncap, spans != nullptr, t8 ? 1 : 2);
+  const SearchLayout Y = SearchLdsLayout(U, F.ncap, spans != nullptr, t8 ? 1 : 2, window_bytes);
   static int cus = 0;
   if (!cus) {
     int dev = 0;
@@ -1410,7 +1419,7 @@ hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8
       attr = true;                                                                                                    \
     }                                                                                                                 \
     hipLaunchKernelGGL((batch_search_kernel<MODE, TT>), dim3((unsigned)grid), dim3(kBlockThreads), (size_t)Y.total, stream, U, F,   \
-                       concat, offsets, nstr, found, spans, (TT*)trace);                                              \
+                       concat, offsets, nstr, found, spans, (TT*)trace, window_bytes);                                \
   } while (0)
   if (U.mode == kModeDirect) { if (t8) RGX_GO(kModeDirect, uint8_t); else RGX_GO(kModeDirect, uint16_t); }
   else { if (t8) RGX_GO(kModeClassLds, uint8_t); else RGX_GO(kModeClassLds, uint16_t); }
@@ -1424,10 +1433,11 @@ bool BatchSearchFits(const DevTables& U, const DevTables& F, bool want_spans, co
 }
 
 hipError_t LaunchBatch(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,
-                       int32_t* spans, uint16_t* trace, int64_t trace_stride, hipStream_t stream) {
+                       int32_t* spans, uint16_t* trace, int64_t trace_stride, hipStream_t stream, int window_bytes) {
   if (nstr <= 0) return hipSuccess;
+  if (window_bytes <= 0) window_bytes = kBatchWindow;
   static const bool force_old = getenv("RGX_BATCH_OLD") != nullptr;
-  const BatchLayout Y = BatchLdsLayout(T, spans != nullptr);
+  const BatchLayout Y = BatchLdsLayout(T, spans != nullptr, 2, window_bytes);
   if (!force_old && T.mode != kModeClassGlobal && Y.total <= 150 * 1024 && (((uintptr_t)concat) & 15) == 0 && T.ncap <= 32) {
     static int cus = 0;
     if (!cus) {
@@ -1451,10 +1461,10 @@ hipError_t LaunchBatch(const DevTables& T, const uint8_t* concat, const uint64_t
     }
     if (T.mode == kModeDirect)
       hipLaunchKernelGGL((batch_lds_kernel<kModeDirect>), dim3((unsigned)grid), dim3(kBlockThreads), (size_t)Y.total, stream, T, concat,
-                         offsets, nstr, found, spans, trace, trace_stride, dbg);
+                         offsets, nstr, found, spans, trace, trace_stride, dbg, window_bytes);
     else
       hipLaunchKernelGGL((batch_lds_kernel<kModeClassLds>), dim3((unsigned)grid), dim3(kBlockThreads), (size_t)Y.total, stream, T, concat,
-                         offsets, nstr, found, spans, trace, trace_stride, dbg);
+                         offsets, nstr, found, spans, trace, trace_stride, dbg, window_bytes);
     return hipGetLastError();
   }
   dim3 block(64), grid((unsigned)((nstr + 63) / 64));

@@ -132,6 +132,7 @@ def run_c4(gib):
         spans, res = c.FindAllSpans(window, out=out, capacity=cap, own=(lo - wl, hi - wl))
         torch.cuda.synchronize()
         t_all += time.perf_counter() - t0
+        print("c4 window %d: wall %.2f ms, scan kernel %.3f ms" % (w, (time.perf_counter() - t0) * 1e3, res.kernel_ms), flush=True)
         kms.append(res.kernel_ms)
         rows_total += spans.shape[0]
         # rows of this window are the rows of tiles [w*win_tiles, (w+1)*win_tiles): compare with the closed form
