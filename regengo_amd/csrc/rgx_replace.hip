@@ -33,10 +33,9 @@ __global__ __launch_bounds__(kBlockThreads) void replen_kernel(const int32_t* sp
 
 // ---- gaps: every input byte outside the matches moves to its place in the output ------------------------------------
 // HBM-bound copy with a data-dependent shift.  A workgroup owns a 16 KiB tile of the input, a wave 4 KiB of it, a lane
-// 64 contiguous bytes (four 16-byte loads in flight per lane).  The matches that touch the tile (tile_k0[t] ..
-// tile_k0[t+1], found by tilek_kernel's binary searches) are staged in LDS as (start, end, shift); every lane keeps the
-// entry of the first match ending beyond its position in registers and stores 16, 4 or 1 bytes at a time depending on
-// how close the next match boundary is (the store address is q + shift[k]; unaligned stores are fine on gfx950).
+// 64 contiguous bytes.  The matches that touch the tile (tile_k0[t] .. tile_k0[t+1], found by tilek_kernel's binary
+// searches) are staged in LDS as (start, end, shift); every lane walks the gaps of its 64 bytes (the store address is
+// q + shift[k]; unaligned loads and stores are fine on gfx950).
 constexpr int kGapThreads = 256;
 constexpr int kGapIters = 16;                                   // dwords per lane
 constexpr int kGapWaveBytes = 64 * 4 * kGapIters;               // 4 KiB per wave
@@ -80,8 +79,10 @@ __global__ __launch_bounds__(kGapThreads) void gaps_kernel(const uint8_t* __rest
   auto End = [&](int e) -> int32_t { return lds ? s_end[e] : ((int64_t)k0 + e < n ? spans[((int64_t)k0 + e) * ncap + 1] : 0x7FFFFFFF); };
   auto Shift = [&](int e) -> long long { return lds ? s_shift[e] : shift[(int64_t)k0 + e]; };
 
-  // lane l of wave w owns the 64 contiguous bytes at tile + w * 4 KiB + l * 64: four 16-byte loads issued up front; the
-  // entry it is at (first match ending beyond the position) lives in registers and only moves when a match is passed
+  // lane l of wave w owns the 64 contiguous bytes at tile + w * 4 KiB + l * 64 and copies them gap by gap: a gap is a run of
+  // bytes between two matches, all with the same shift, moved in 16-byte pieces -- the last piece slid back to end exactly
+  // on the gap's end (it rewrites a few bytes with the same values), shorter gaps with two overlapping 8- or 4-byte pieces
+  // -- so a match boundary costs a couple of wide (unaligned) load/store pairs instead of a byte loop.
   const int64_t q0 = tile * kGapTileBytes + (int64_t)wave * kGapWaveBytes + lane * (kGapIters * 4);
   if (q0 >= len) return;
   int e;
@@ -93,48 +94,31 @@ __global__ __launch_bounds__(kGapThreads) void gaps_kernel(const uint8_t* __rest
     }
     e = lo;
   }
-  uint32_t v[kGapIters];
-  if (q0 + kGapIters * 4 <= len) {
-#pragma unroll
-    for (int j = 0; j < kGapIters / 4; ++j) {
-      const uint4 t = *reinterpret_cast<const uint4*>(in + q0 + 16 * j);
-      v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+  const int32_t qend = (int32_t)(q0 + kGapIters * 4 < len ? q0 + kGapIters * 4 : len);
+  int32_t q = (int32_t)q0;
+  while (q < qend) {
+    while (End(e) <= q) ++e;                        // first match ending beyond q (an empty match at q does not cover q)
+    const int32_t ms = Start(e);
+    if (q >= ms) { q = End(e); continue; }          // inside match e: on to its end
+    const int32_t ge = ms < qend ? ms : qend;       // the gap [q, ge) precedes match e
+    const uint8_t* src = in + q;
+    uint8_t* dst = out + (q + Shift(e));
+    const int L = ge - q;
+    if (L >= 16) {
+      for (int o = 0; o + 16 <= L; o += 16) { uint4 t; __builtin_memcpy(&t, src + o, 16); __builtin_memcpy(dst + o, &t, 16); }
+      if (L & 15) { uint4 t; __builtin_memcpy(&t, src + L - 16, 16); __builtin_memcpy(dst + L - 16, &t, 16); }
+    } else if (L >= 8) {
+      uint2 t0, t1;
+      __builtin_memcpy(&t0, src, 8); __builtin_memcpy(&t1, src + L - 8, 8);
+      __builtin_memcpy(dst, &t0, 8); __builtin_memcpy(dst + L - 8, &t1, 8);
+    } else if (L >= 4) {
+      uint32_t t0, t1;
+      __builtin_memcpy(&t0, src, 4); __builtin_memcpy(&t1, src + L - 4, 4);
+      __builtin_memcpy(dst, &t0, 4); __builtin_memcpy(dst + L - 4, &t1, 4);
+    } else {
+      for (int b2 = 0; b2 < L; ++b2) dst[b2] = src[b2];
     }
-  } else {
-#pragma unroll
-    for (int it = 0; it < kGapIters; ++it) {
-      v[it] = 0;
-      for (int b = 0; b < 4 && q0 + it * 4 + b < len; ++b) v[it] |= (uint32_t)in[q0 + it * 4 + b] << (8 * b);
-    }
-  }
-  int32_t ms = Start(e), me = End(e);
-  long long sh = Shift(e);
-#pragma unroll
-  for (int j = 0; j < kGapIters / 4; ++j) {
-    const int64_t q16 = q0 + 16 * j;
-    if (q16 >= len) break;
-    while (me <= q16) { ++e; ms = Start(e); me = End(e); sh = Shift(e); }
-    if (q16 + 16 <= ms && q16 + 16 <= len) {        // all 16 bytes in the gap before match e: one (unaligned) 16-byte store
-      const uint4 t = make_uint4(v[4 * j], v[4 * j + 1], v[4 * j + 2], v[4 * j + 3]);
-      __builtin_memcpy(out + q16 + sh, &t, 16);
-      continue;
-    }
-#pragma unroll
-    for (int d = 0; d < 4; ++d) {
-      const int64_t q = q16 + 4 * d;
-      const uint32_t w = v[4 * j + d];
-      while (me <= q) { ++e; ms = Start(e); me = End(e); sh = Shift(e); }
-      if (q + 4 <= ms && q + 4 <= len) {
-        __builtin_memcpy(out + q + sh, &w, 4);
-        continue;
-      }
-      for (int b = 0; b < 4 && q + b < len; ++b) {
-        const int32_t p = (int32_t)(q + b);
-        while (me <= p) { ++e; ms = Start(e); me = End(e); sh = Shift(e); }     // an empty match at p does not cover p
-        if (p >= ms) continue;                                                   // inside match e
-        out[p + sh] = (uint8_t)(w >> (8 * b));
-      }
-    }
+    q = ge;
   }
 }
 
