@@ -110,6 +110,13 @@ def lib():
                 raise
     if not os.path.exists(path):
         raise RuntimeError("librgx_hip.so is missing: the HIP extension is required (no CPU fallback exists)")
+    # PyTorch's wheel carries its own libamdhip64; whichever copy is loaded first serves the whole process.  Load torch's
+    # first (as bench.py and the tests always did): device pointers are shared with torch tensors, and a process that
+    # loaded /opt/rocm's runtime through this library first makes torch's later device initialisation fail.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = C.CDLL(path)
     for name, (res, args) in SYMBOLS.items():
         fn = getattr(L, name)

@@ -1,0 +1,46 @@
+"""One-off wide sweep of the differential test (tests/test_gpu_fuzz.py runs three seeds): many seeds, ASCII and UTF-8
+pattern generators, FindAllBytes on the GPU against the C oracle (Q8 off).  usage: gpu_fuzz_sweep.py [first_seed] [nseeds]"""
+import random, sys, time
+sys.path.insert(0, ".")
+import numpy as np
+from oracle import engines as E
+from oracle.gen_c import CMatcher
+from regengo_amd import Compiled, _capi
+from tests import _fuzzgen as F
+
+first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
+nseeds = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+t0 = time.time()
+tot = bad = refused = 0
+for seed in range(first, first + nseeds):
+    rng = random.Random(seed)
+    pats = [(p, False) for p in F.gen_patterns(seed, 30)] + [(p, True) for p in F.gen_patterns_u(seed, 12)]
+    for p, uni in pats:
+        try:
+            o = E.Compiled(p)
+        except Exception:
+            continue
+        if F.has_empty_loop(o.prog) and not o.find_machine.memo:
+            continue
+        try:
+            c = Compiled(p).to(0)
+        except _capi.RgxError:
+            refused += 1
+            continue
+        cm = CMatcher(p, q8=False)
+        for n in (0, 3, 64, 1000, 70000):
+            if n >= 20000 and cm.memo:
+                continue
+            b = F.gen_input_u(rng, max(n // 2, 1) if n else 0) if uni else F.gen_input(rng, n)
+            arr = np.frombuffer(b, dtype=np.uint8).copy() if len(b) else np.zeros(0, dtype=np.uint8)
+            exp, cnt = cm.find_all_np(arr)
+            spans, res = c.FindAllSpans(b)
+            got = spans.cpu().numpy()
+            tot += 1
+            if not (res.total == cnt and got.shape == exp.shape and np.array_equal(got, exp)):
+                bad += 1
+                print("MISMATCH seed", seed, repr(p), "n", len(b), "gpu", int(res.total), "oracle", cnt, flush=True)
+                if bad > 20:
+                    sys.exit(1)
+    print("seed", seed, "done; compared", tot, "bad", bad, "refused", refused, "%.0fs" % (time.time() - t0), flush=True)
+print("TOTAL compared", tot, "bad", bad, "refused", refused)
