@@ -140,6 +140,16 @@ int64_t rgx_find_all_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8_
  * match, 64 % as large as the input it was found in; this form is 4 B per match.)                                    */
 int64_t rgx_find_all_starts_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n,
                                    int32_t* d_starts, size_t cap, rgx_result* res);
+/* Asynchronous pair for back-to-back scans: rgx_find_all_submit launches the scan of one buffer and returns at once,
+ * rgx_find_all_wait blocks until the OLDEST submitted scan of this context is done and returns exactly what
+ * rgx_find_all_bytes_device_owned would have (count written, *res; own_hi < 0 = no ownership filter).  At most two scans
+ * are in flight per context; the buffers handed to submit must stay untouched until their wait returns.  This is how the
+ * stub overlaps FindReader's chunk k+1 with the callbacks of chunk k (streaming.go:85-255 is sequential; the results are
+ * the same, only the waiting moves).  RGX_E_UNSUPPORTED from submit: this pattern / buffer takes a kernel that is only
+ * offered synchronously -- call rgx_find_all_bytes_device(_owned) instead (nothing was queued).                          */
+int rgx_find_all_submit(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n,
+                        int32_t* d_spans, size_t cap_records, int64_t own_lo, int64_t own_hi);
+int64_t rgx_find_all_wait(const rgx_program* p, rgx_stream_ctx* c, rgx_result* res);
 /* ReplaceAllBytes / ReplaceFirstBytes(input, template) -- replace.go:205-323, 325-363; template syntax of
  * replace/template.go:45-148 ($0 $1..$99 ${n} $name ${name} $$).  Every leftmost-first match (FindAllBytes order, plus the
  * loop's extra attempt at offset len for patterns that match empty) is replaced by the template's expansion; unknown

@@ -69,6 +69,9 @@ SYMBOLS = {
                                               C.c_size_t, C.POINTER(Result)]),
     "rgx_find_all_bytes_device_owned": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p,
                                                     C.c_size_t, C.c_int64, C.c_int64, C.POINTER(Result)]),
+    "rgx_find_all_submit": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t, C.c_int64,
+                                      C.c_int64]),
+    "rgx_find_all_wait": (C.c_int64, [C.c_void_p, C.c_void_p, C.POINTER(Result)]),
     "rgx_find_all_bytes": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t,
                                        C.POINTER(Result)]),
     "rgx_find_all_starts_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p,

@@ -173,6 +173,40 @@ class Compiled:
         _capi.check(w)
         return out.view(-1, self.ncap)[:w], res
 
+    # ---- the same scan, asynchronously (rgx_find_all_submit / rgx_find_all_wait): at most two in flight
+    def FindAllSubmit(self, data, n: int = -1, capacity: Optional[int] = None, out=None, own=None) -> None:
+        """Queue the scan of `data` (a device uint8 tensor; it and `out` must stay untouched until FindAllWait returns
+        it).  Patterns / buffers the asynchronous launch is not offered for are scanned right here, synchronously; the
+        result is handed out by FindAllWait in order all the same."""
+        import torch
+        self._need_dev()
+        if not hasattr(self, "_pending"):
+            self._pending = []
+        t, ln = self._as_device(data)
+        if capacity is None:
+            capacity = ln // max(self.MinMatchLen, 1) + 1
+            if n > 0:
+                capacity = min(capacity, n)
+        if out is None or out.numel() < capacity * self.ncap:
+            out = torch.empty((max(capacity, 1), self.ncap), dtype=torch.int32, device=t.device)
+        lo, hi = (int(own[0]), int(own[1])) if own is not None else (0, -1)
+        rc = self._lib.rgx_find_all_submit(self._h, self._ctx, t.data_ptr() if ln else None, ln, n, out.data_ptr(), capacity, lo, hi)
+        if rc == _capi.RGX_E_UNSUPPORTED:
+            self._pending.append(("done", self.FindAllSpans(t, n, capacity, out, own)))
+            return
+        _capi.check(rc)
+        self._pending.append(("queued", (t, out)))
+
+    def FindAllWait(self):
+        """(spans, result) of the oldest FindAllSubmit."""
+        kind, payload = self._pending.pop(0)
+        if kind == "done":
+            return payload
+        t, out = payload
+        res = _capi.Result()
+        w = _capi.check(self._lib.rgx_find_all_wait(self._h, self._ctx, C.byref(res)))
+        return out.view(-1, self.ncap)[:w], res
+
     def capture_template(self):
         """(offsets[ncap], match_len) for fixed-template patterns: span slot c = start + offsets[c]."""
         o = (C.c_int32 * self.ncap)()

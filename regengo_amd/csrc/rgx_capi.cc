@@ -44,8 +44,16 @@ struct rgx_stream_ctx {
   uint8_t* d_tmpl = nullptr; int64_t tmpl_cap = 0;           // resolved template (segments + literals) of the last splice
   std::string tmpl_key;                                      // what d_tmpl holds: "" = nothing
   // pinned host readback
-  unsigned long long* h_read = nullptr;      // [4]: total, unsynced, ...
-  unsigned long long* h_read_dev = nullptr;  // the same pinned words as the device sees them
+  unsigned long long* h_read = nullptr;      // [16]: 0-3 the synchronous scan (total, rare-path flag, counters), 4-5 the splice,
+  unsigned long long* h_read_dev = nullptr;  //       8-11 / 12-15 the two in-flight scans of submit/wait; same words, device view
+  // submit / wait (rgx_find_all_submit): up to two scans in flight
+  struct Pending {
+    const uint8_t* d_buf; size_t len; int64_t n; int32_t* d_spans; size_t cap; int64_t own_lo, own_hi;
+    int slot; bool trivial;
+  };
+  Pending pend[2];
+  int pend_head = 0, pend_count = 0;
+  hipEvent_t pev0[2] = {nullptr, nullptr}, pev1[2] = {nullptr, nullptr}, pdone[2] = {nullptr, nullptr};
 };
 
 namespace {
@@ -352,7 +360,7 @@ RGX_API int rgx_stream_ctx_create(const rgx_program* p, rgx_stream_ctx** out) {
   if (hipSetDevice(c->device) != hipSuccess) { delete c; return RGX_E_NO_DEVICE; }
   bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
-                        hipHostMalloc((void**)&c->h_read, 64, hipHostMallocMapped) == hipSuccess &&
+                        hipHostMalloc((void**)&c->h_read, 128, hipHostMallocMapped) == hipSuccess &&
             hipHostGetDevicePointer((void**)&c->h_read_dev, c->h_read, 0) == hipSuccess;
   if (!ok) { SetError("ctx allocation failed"); rgx_stream_ctx_destroy(c); return RGX_E_HIP; }
   *out = c;
@@ -364,6 +372,8 @@ RGX_API void rgx_stream_ctx_destroy(rgx_stream_ctx* c) {
   if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
+  for (int i = 0; i < 2; ++i)
+    for (hipEvent_t e : {c->pev0[i], c->pev1[i], c->pdone[i]}) if (e) hipEventDestroy(e);
   for (void* p : {(void*)c->d_desc, (void*)c->d_unsynced, (void*)c->d_carry,
                   (void*)c->d_trace, (void*)c->d_in, (void*)c->d_out, (void*)c->d_rspans, (void*)c->d_rdelta, (void*)c->d_rtemp, (void*)c->d_tmpl})
     if (p) hipFree(p);
@@ -388,6 +398,109 @@ RGX_API int64_t rgx_find_all_bytes_device_owned(const rgx_program* p, rgx_stream
   if (rc != RGX_OK) return rc;
   if (own_lo < 0 || own_hi < own_lo) { SetError("bad owned range"); return RGX_E_INVALID; }
   return FindAllDevice(p, c, d_buf, len, n, d_spans, cap_records, false, res, false, own_lo, own_hi);
+}
+
+// ---- submit / wait: the same scan without the host waiting behind every launch (a FindReader-style pipeline scans chunk
+// k+1 while chunk k's results are consumed).  Only the exact kernel's fast path is launched asynchronously -- its total
+// arrives in pinned host memory and it leaves the other scratch set clean for the next launch; anything else, and any
+// launch that raises the rare-path flag, is (re)done by the synchronous path inside rgx_find_all_wait.
+RGX_API int rgx_find_all_submit(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n, int32_t* d_spans,
+                                size_t cap_records, int64_t own_lo, int64_t own_hi) {
+  int rc = CheckCtx(p, c);
+  if (rc != RGX_OK) return rc;
+  if (c->pend_count >= 2) { SetError("two scans already in flight: call rgx_find_all_wait"); return RGX_E_INVALID; }
+  if (own_lo < 0 || (own_hi >= 0 && own_hi < own_lo)) { SetError("bad owned range"); return RGX_E_INVALID; }
+  const DevTables& T = p->p.dev;
+  if (len > 0x7FFFFF00ull) { SetError("buffer larger than 2^31-256 bytes: shard it (FindReader path)"); return RGX_E_TOO_LARGE; }
+  if (((uintptr_t)d_buf & 15) || ((uintptr_t)d_spans & 15)) { SetError("device pointers must be 16-byte aligned"); return RGX_E_INVALID; }
+  const int slot = (c->pend_head + c->pend_count) & 1;
+  rgx_stream_ctx::Pending& pd = c->pend[slot];
+  pd = {d_buf, len, n, d_spans, cap_records, own_lo, own_hi, slot, n == 0 || len == 0};
+  if (pd.trivial) { c->pend_count++; return RGX_OK; }
+  const int32_t ilen = (int32_t)len;
+  static const bool no_self_clean = getenv("RGX_NO_SELF_CLEAN") != nullptr;
+  if (!UseExactKernel(T, ilen) || no_self_clean || c->prefer_w) {
+    SetError("asynchronous launch is offered for the exact kernel only");
+    return RGX_E_UNSUPPORTED;
+  }
+  for (int i = 0; i < 2; ++i) {
+    if (!c->pev0[i] && (hipEventCreate(&c->pev0[i]) != hipSuccess || hipEventCreate(&c->pev1[i]) != hipSuccess ||
+                        hipEventCreateWithFlags(&c->pdone[i], hipEventDisableTiming) != hipSuccess)) {
+      SetError("event allocation failed");
+      return RGX_E_HIP;
+    }
+  }
+  const int32_t ntiles = ScanNumTiles(T, ilen, false);
+  const int32_t ntiles_max = std::max(ntiles, ScanNumTiles(T, ilen, true));
+  const size_t desc_words = (size_t)ntiles_max + 4;
+  if (c->desc_cap < (int64_t)(2 * desc_words) || !c->d_desc) {
+    if (c->pend_count) HIP_TRY(hipStreamSynchronize(c->stream));      // (a scan in flight still uses the old sets)
+    if (c->d_desc) { hipFree(c->d_desc); c->d_desc = nullptr; c->desc_cap = 0; }
+    if ((rc = Ensure(&c->d_desc, &c->desc_cap, (int64_t)(2 * desc_words + 64))) != RGX_OK) return rc;
+    c->set_words = c->desc_cap / 2;
+    c->dirty[0] = c->dirty[1] = c->set_words;
+    c->cur_set = 0;
+  }
+  ScanParams P{};
+  P.buf = d_buf; P.len = ilen; P.ntiles = ntiles; P.use_w = 0; P.spans = d_spans; P.cap_records = (int64_t)cap_records;
+  P.own_lo = (int32_t)std::max<int64_t>(0, std::min<int64_t>(own_lo, ilen));
+  P.own_hi = own_hi < 0 ? ilen : (int32_t)std::max<int64_t>(P.own_lo, std::min<int64_t>(own_hi, ilen));
+  static const bool force_tickets = getenv("RGX_TICKETS") != nullptr;
+  P.use_tickets = force_tickets ? 1 : 0;
+  const int s = c->cur_set;
+  unsigned long long* set = c->d_desc + (size_t)s * c->set_words;
+  unsigned long long* other = c->d_desc + (size_t)(1 - s) * c->set_words;
+  if (c->dirty[s] > 0) {
+    HIP_TRY(hipMemsetAsync(set, 0, (size_t)c->dirty[s] * 8, c->stream));
+    c->dirty[s] = 0;
+  }
+  P.tile_desc = set + 4; P.counters = (uint32_t*)(set + 2); P.total = set;
+  P.clean_next = other;
+  unsigned long long* h = c->h_read + 8 + 4 * slot;
+  h[0] = 0; h[1] = 0; h[2] = 0; h[3] = 0;
+  P.host_result = c->h_read_dev + 8 + 4 * slot;
+  if (c->timing) HIP_TRY(hipEventRecord(c->pev0[slot], c->stream));
+  HIP_TRY(LaunchScan(T, P, c->stream));
+  if (c->timing) HIP_TRY(hipEventRecord(c->pev1[slot], c->stream));
+  HIP_TRY(hipEventRecord(c->pdone[slot], c->stream));
+  c->dirty[s] = (int64_t)desc_words;
+  if (c->dirty[1 - s] <= (int64_t)desc_words) c->dirty[1 - s] = 0;
+  c->cur_set = 1 - s;
+  c->pend_count++;
+  return RGX_OK;
+}
+
+RGX_API int64_t rgx_find_all_wait(const rgx_program* p, rgx_stream_ctx* c, rgx_result* res) {
+  int rc = CheckCtx(p, c);
+  if (rc != RGX_OK) return rc;
+  if (c->pend_count == 0) { SetError("nothing in flight"); return RGX_E_INVALID; }
+  const rgx_stream_ctx::Pending pd = c->pend[c->pend_head];
+  c->pend_head = (c->pend_head + 1) & 1;
+  c->pend_count--;
+  const DevTables& T = p->p.dev;
+  if (res) { memset(res, 0, sizeof *res); res->ncap = T.ncap; }
+  if (pd.trivial) return 0;
+  HIP_TRY(hipEventSynchronize(c->pdone[pd.slot]));
+  const unsigned long long* h = c->h_read + 8 + 4 * pd.slot;
+  if (h[1] != 0) {
+    // the rare-path flag (a slice without a sync point, or a bounded look-back spin gave up): let everything in flight
+    // finish, forget what the scratch sets hold, and redo this buffer through the synchronous path
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    c->dirty[0] = c->dirty[1] = c->set_words;
+    return FindAllDevice(p, c, pd.d_buf, pd.len, pd.n, pd.d_spans, pd.cap, false, res, false, pd.own_lo, pd.own_hi);
+  }
+  const int64_t total = (int64_t)h[0];
+  float ms = 0;
+  if (c->timing) hipEventElapsedTime(&ms, c->pev0[pd.slot], c->pev1[pd.slot]);
+  if (res) { res->total = total; res->unsynced = 0; res->kernel_ms = ms; }
+  if (total > (int64_t)pd.cap && (pd.n < 0 || pd.n > (int64_t)pd.cap)) {
+    SetError("span capacity too small");
+    return RGX_E_CAPACITY;
+  }
+  int64_t written = std::min<int64_t>(total, (int64_t)pd.cap);
+  if (pd.n > 0) written = std::min<int64_t>(written, pd.n);
+  if (res) res->written = written;
+  return written;
 }
 
 // ---------------------------------------------------------------- Replace path

@@ -401,3 +401,63 @@ def test_starts_only_form(torch_dev):
         assert torch.equal(st[:, None] + torch.tensor(tmpl, dtype=torch.int32, device="cuda:0")[None, :], full)
     with pytest.raises(_capi.RgxError):
         _gpu(EMAIL).FindAllStarts(b"a@b " * 100)
+
+
+def test_submit_wait_equals_synchronous_scan(torch_dev):
+    """rgx_find_all_submit / rgx_find_all_wait: two scans in flight, results in submission order and bit-identical to the
+    synchronous entry point -- plain, owned-range, adversarial input (rare-path flag -> redone synchronously inside wait),
+    a pattern the asynchronous launch is not offered for, empty input, capacity error."""
+    from regengo_amd import Compiled, _capi, synth
+    torch = torch_dev
+    c = _gpu(DATE)
+    bufs = [synth.date_log_torch(n, "cuda:0", adversarial=adv) for n, adv in ((1 << 20, False), (3 << 20, True), (5000, False), (1 << 22, False))]
+    want = [c.FindAllSpans(b)[0].clone() for b in bufs]
+    # two in flight, interleaved
+    c.FindAllSubmit(bufs[0])
+    c.FindAllSubmit(bufs[1])
+    got0, r0 = c.FindAllWait()
+    c.FindAllSubmit(bufs[2])
+    got1, r1 = c.FindAllWait()
+    c.FindAllSubmit(bufs[3])
+    got2, r2 = c.FindAllWait()
+    got3, r3 = c.FindAllWait()
+    for g, w, r in ((got0, want[0], r0), (got1, want[1], r1), (got2, want[2], r2), (got3, want[3], r3)):
+        assert r.total == w.shape[0] and torch.equal(g, w)
+    with pytest.raises(_capi.RgxError):
+        c.FindAllWait() if False else _capi.check(_capi.lib().rgx_find_all_wait(c._h, c._ctx, None))   # nothing in flight
+    # the rare-path flag: candidates every 8 bytes leave slices without a sync point -> wait() redoes the buffer through the
+    # synchronous path (carry pass), with another scan queued behind it
+    dense = torch_dev.from_numpy(np.concatenate([np.frombuffer(b"abc ", dtype=np.uint8), np.frombuffer(b"1234-56-" * 30000, dtype=np.uint8),
+                                                 np.frombuffer(b" tail 2024-01-15", dtype=np.uint8)])).cuda()
+    wd, rd = c.FindAllSpans(dense)
+    assert rd.unsynced > 0
+    wd = wd.clone()
+    c.FindAllSubmit(dense)
+    c.FindAllSubmit(bufs[0])
+    gd, r = c.FindAllWait()
+    assert torch.equal(gd, wd) and r.unsynced > 0
+    g, r = c.FindAllWait()
+    assert torch.equal(g, want[0])
+    c.FindAllSubmit(bufs[3])          # and the context keeps working afterwards
+    assert torch.equal(c.FindAllWait()[0], want[3])
+    # owned range
+    lo, hi = 4096, (1 << 22) - 70000
+    c.FindAllSubmit(bufs[3], own=(lo, hi))
+    g, r = c.FindAllWait()
+    w = c.FindAllSpans(bufs[3], own=(lo, hi))[0]
+    assert torch.equal(g, w) and g.shape[0] < want[3].shape[0]
+    # empty input and n == 0 keep their place in the queue
+    c.FindAllSubmit(torch.empty(0, dtype=torch.uint8, device="cuda:0"))
+    c.FindAllSubmit(bufs[0], n=0)
+    assert c.FindAllWait()[0].shape[0] == 0 and c.FindAllWait()[0].shape[0] == 0
+    # capacity error surfaces at wait
+    c.FindAllSubmit(bufs[0], capacity=10)
+    with pytest.raises(_capi.RgxError) as ei:
+        c.FindAllWait()
+    assert ei.value.status == _capi.RGX_E_CAPACITY
+    # a pattern that takes the generic kernels: scanned synchronously at submit, same interface
+    e = _gpu(EMAIL)
+    tile = torch.frombuffer(bytearray(synth.web_log_tile()[:200000]), dtype=torch.uint8).cuda()
+    e.FindAllSubmit(tile)
+    g, r = e.FindAllWait()
+    assert torch.equal(g, e.FindAllSpans(tile)[0]) and r.total == g.shape[0] > 0
