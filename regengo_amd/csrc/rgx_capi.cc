@@ -49,7 +49,7 @@ struct rgx_stream_ctx {
   // submit / wait (rgx_find_all_submit): up to two scans in flight
   struct Pending {
     const uint8_t* d_buf; size_t len; int64_t n; int32_t* d_spans; size_t cap; int64_t own_lo, own_hi;
-    int slot; bool trivial;
+    int slot; bool trivial; bool timed;
   };
   Pending pend[2];
   int pend_head = 0, pend_count = 0;
@@ -415,7 +415,7 @@ RGX_API int rgx_find_all_submit(const rgx_program* p, rgx_stream_ctx* c, const u
   if (((uintptr_t)d_buf & 15) || ((uintptr_t)d_spans & 15)) { SetError("device pointers must be 16-byte aligned"); return RGX_E_INVALID; }
   const int slot = (c->pend_head + c->pend_count) & 1;
   rgx_stream_ctx::Pending& pd = c->pend[slot];
-  pd = {d_buf, len, n, d_spans, cap_records, own_lo, own_hi, slot, n == 0 || len == 0};
+  pd = {d_buf, len, n, d_spans, cap_records, own_lo, own_hi, slot, n == 0 || len == 0, false};
   if (pd.trivial) { c->pend_count++; return RGX_OK; }
   const int32_t ilen = (int32_t)len;
   static const bool no_self_clean = getenv("RGX_NO_SELF_CLEAN") != nullptr;
@@ -459,10 +459,12 @@ RGX_API int rgx_find_all_submit(const rgx_program* p, rgx_stream_ctx* c, const u
   unsigned long long* h = c->h_read + 8 + 4 * slot;
   h[0] = 0; h[1] = 0; h[2] = 0; h[3] = 0;
   P.host_result = c->h_read_dev + 8 + 4 * slot;
-  if (c->timing) HIP_TRY(hipEventRecord(c->pev0[slot], c->stream));
+  // one event behind the launch serves both as "done" and, when timing, as the stop timestamp (every event is a barrier
+  // packet in the queue: a few microseconds each between back-to-back kernels)
+  pd.timed = c->timing;
+  if (pd.timed) HIP_TRY(hipEventRecord(c->pev0[slot], c->stream));
   HIP_TRY(LaunchScan(T, P, c->stream));
-  if (c->timing) HIP_TRY(hipEventRecord(c->pev1[slot], c->stream));
-  HIP_TRY(hipEventRecord(c->pdone[slot], c->stream));
+  HIP_TRY(hipEventRecord(pd.timed ? c->pev1[slot] : c->pdone[slot], c->stream));
   c->dirty[s] = (int64_t)desc_words;
   if (c->dirty[1 - s] <= (int64_t)desc_words) c->dirty[1 - s] = 0;
   c->cur_set = 1 - s;
@@ -480,7 +482,7 @@ RGX_API int64_t rgx_find_all_wait(const rgx_program* p, rgx_stream_ctx* c, rgx_r
   const DevTables& T = p->p.dev;
   if (res) { memset(res, 0, sizeof *res); res->ncap = T.ncap; }
   if (pd.trivial) return 0;
-  HIP_TRY(hipEventSynchronize(c->pdone[pd.slot]));
+  HIP_TRY(hipEventSynchronize(pd.timed ? c->pev1[pd.slot] : c->pdone[pd.slot]));
   const unsigned long long* h = c->h_read + 8 + 4 * pd.slot;
   if (h[1] != 0) {
     // the rare-path flag (a slice without a sync point, or a bounded look-back spin gave up): let everything in flight
@@ -491,7 +493,7 @@ RGX_API int64_t rgx_find_all_wait(const rgx_program* p, rgx_stream_ctx* c, rgx_r
   }
   const int64_t total = (int64_t)h[0];
   float ms = 0;
-  if (c->timing) hipEventElapsedTime(&ms, c->pev0[pd.slot], c->pev1[pd.slot]);
+  if (pd.timed) hipEventElapsedTime(&ms, c->pev0[pd.slot], c->pev1[pd.slot]);
   if (res) { res->total = total; res->unsynced = 0; res->kernel_ms = ms; }
   if (total > (int64_t)pd.cap && (pd.n < 0 || pd.n > (int64_t)pd.cap)) {
     SetError("span capacity too small");

@@ -156,6 +156,63 @@ class ShardedFinder:
 
         return finish if defer else finish()
 
+    def find_all_sharded_async(self, window, shard: Shard, cdev=None):
+        """The same step with the scan only QUEUED (rgx_find_all_submit): returns a zero-argument callable that waits for
+        the scan and does the count exchange.  A caller that queues step k+1 before finishing step k keeps the GPU busy
+        while the host waits, reads the result and gathers the counts.  Needs `submit_owned` / `wait_owned` (the HIP path sets
+        them); without them this is find_all_sharded(defer=True)."""
+        import torch
+        if getattr(self, "submit_owned", None) is None or self.scan_owned is None:
+            return self.find_all_sharded(window, shard, cdev, defer=True)
+        dist = self._dist()
+        if dist is None:
+            # one rank: the window is the whole input (if it is not, the halo rules below apply to a group of one)
+            whole = shard.world == 1 and shard.win_lo == 0 and shard.win_hi == shard.total_len
+            if not whole:
+                return self.find_all_sharded(window, shard, cdev, defer=True)
+            self.submit_owned(window, None)
+
+            def finish_one():
+                owned, info = self.wait_owned()
+                cnt = int(owned.shape[0])
+                info2 = dict(info)
+                info2.update({"truncated": False, "chained": False})
+                return owned, cnt, info2, 0, cnt, [cnt]
+
+            return finish_one
+        if cdev is None:
+            cdev = window.device if dist.get_backend(self.group) == "nccl" else "cpu"
+        h = shard.lo - shard.win_lo
+        if shard.win_lo == 0:
+            notok = torch.zeros(1, dtype=torch.int64, device=cdev)
+        elif h <= 0:
+            notok = torch.ones(1, dtype=torch.int64, device=cdev)
+        else:   # stays on the device: no host sync here
+            notok = (~self.reset_table[window[:h].long()].any()).to(torch.int64).reshape(1).to(cdev)
+        self.submit_owned(window, (shard.lo - shard.win_lo, shard.hi - shard.win_lo))
+        world = dist.get_world_size(self.group)
+
+        def finish():
+            owned, info = self.wait_owned()
+            cnt = int(owned.shape[0])
+            mine = torch.cat([torch.tensor([cnt], dtype=torch.int64, device=cdev), notok])
+            allc = torch.empty(2 * world, dtype=torch.int64, device=cdev)
+            dist.all_gather_into_tensor(allc, mine, group=self.group)
+            rows = allc.cpu().view(world, 2).tolist()
+            if any(r[1] for r in rows):
+                owned, cnt, info = self.find_all_local(window, shard)
+                base, total, counts = self.global_row_base(cnt, cdev)
+                return owned, cnt, info, base, total, counts
+            counts = [int(r[0]) for r in rows]
+            truncated = False
+            if not self.bounded and shard.win_hi < shard.total_len and cnt:
+                truncated = int(owned[cnt - 1, 1].item()) >= shard.win_hi - shard.win_lo
+            info2 = dict(info)
+            info2.update({"truncated": truncated, "chained": False})
+            return owned, cnt, info2, sum(counts[:shard.rank]), sum(counts), counts
+
+        return finish
+
     def _dist(self):
         import torch.distributed as dist
         if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
