@@ -118,7 +118,8 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
   unsigned* s_misc = reinterpret_cast<unsigned*>(s_kind + 32);                // [0] tile, [1..4] wave totals, [8..9] base
   unsigned* s_sa = s_misc + 16;                                               // 256 level-set masks
   int* s_sync = reinterpret_cast<int*>(s_sa + 256);                           // [4 halo slices + 256 slices] last W sync point
-  uint16_t* s_w = reinterpret_cast<uint16_t*>(s_sync + 4 + kBlockThreads);    // sync automaton [w_nstates][ncls]
+  unsigned* s_rz = reinterpret_cast<unsigned*>(s_sync + 4 + kBlockThreads);   // 256: required-class bit 0, reset bit 16
+  uint16_t* s_w = reinterpret_cast<uint16_t*>(s_rz + 256);                    // sync automaton [w_nstates][ncls]
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -141,6 +142,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
     s_ctx[tid] = T.ctx_of_byte[tid];
     if (tid < T.ncap) { s_delta[tid] = T.cap_delta[tid]; s_kind[tid] = T.cap_kind[tid]; }
     if (SA) s_sa[tid] = (T.sa_mask[tid] << (29 - T.sa_k)) | (7u << 29);   // accept bit at 28, history at 29..31
+    if (SA) s_rz[tid] = T.sa_rz[tid];
     if (P.use_w) for (int w = tid; w < T.w_nstates * T.ncls; w += kBlockThreads) s_w[w] = T.w_trans[w];
   }
   __syncthreads();
@@ -264,14 +266,24 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
       if (end_i > len) end_i = len;
       int i = pos & ~3;
       unsigned E = 0;
+      // second necessary condition (rgx_program.cc: ComputeRequiredClass): the first byte at or after a start that is either
+      // of the required class or a reset byte must be a required one.  One more table word per byte (bit 0 required, bit 16
+      // reset), 16 bytes per accumulator, then a 5-step parallel-prefix per 32-byte chunk.
+      const bool use_req = T.has_req != 0;          // uniform
       while (i < end_i) {
         const int chunk0 = i;
-        unsigned det = 0;
+        unsigned det = 0, rz = 0, Rm = 0, Zm = 0;
 #pragma unroll
         for (int d = 0; d < 8; ++d) {
           if (i < end_i) {
             const unsigned w = *reinterpret_cast<const unsigned*>(s_tile + PadAddr(i - wb));
             unsigned f0 = s_sa[w & 255u], f1 = s_sa[(w >> 8) & 255u], f2 = s_sa[(w >> 16) & 255u], f3 = s_sa[w >> 24];
+            if (use_req) {
+              rz = (rz << 1) | s_rz[w & 255u];
+              rz = (rz << 1) | s_rz[(w >> 8) & 255u];
+              rz = (rz << 1) | s_rz[(w >> 16) & 255u];
+              rz = (rz << 1) | s_rz[w >> 24];
+            }
             if (i + 4 > end_i) {                    // last, partial dword of the lane's range
               if (i + 1 >= end_i) f1 = dead;
               if (i + 2 >= end_i) f2 = dead;
@@ -284,10 +296,28 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
             det = __builtin_amdgcn_alignbit(det, E, 28);
           } else {
             det <<= 4;
+            rz <<= 4;
+          }
+          if (use_req && (d & 3) == 3) {            // 16 bytes done: low half = required bits, high half = reset bits
+            Rm = (Rm << 16) | (rz & 0xFFFFu);
+            Zm = (Zm << 16) | (rz >> 16);
+            rz = 0;
           }
           i += 4;
         }
         det = __builtin_bitreverse32(det);          // bit j: the accept level came up after byte chunk0 + j
+        if (use_req) {
+          const unsigned R = __builtin_bitreverse32(Rm), Z = __builtin_bitreverse32(Zm);    // bit j: byte chunk0 + j
+          unsigned Gk = R, Pk = ~(R | Z);
+          Gk |= Pk & 0x80000000u;                   // the run reaches the end of the chunk: not known here, keep
+          Gk |= Pk & (Gk >> 1); Pk &= Pk >> 1;      // ok(p) = R(p) | (neutral(p) & ok(p+1)), Kogge-Stone
+          Gk |= Pk & (Gk >> 2); Pk &= Pk >> 2;
+          Gk |= Pk & (Gk >> 4); Pk &= Pk >> 4;
+          Gk |= Pk & (Gk >> 8); Pk &= Pk >> 8;
+          Gk |= Pk & (Gk >> 16);
+          // det bit j = the K-byte prefix ENDS at byte chunk0 + j: its start is K-1 bytes earlier (starts before the chunk: keep)
+          det &= (Gk << (K - 1)) | ((1u << (K - 1)) - 1u);
+        }
         while (det) {
           const int j = __builtin_ctz(det);
           det &= det - 1;
@@ -1240,7 +1270,7 @@ size_t ScanSharedBytes(const DevTables& T) {
   size_t b = (kPaddedWindow + 15) & ~15;
   b += (T.table_bytes + 15) & ~15;
   b += 256 * 3 + 32 * 4 + 32 + 16 * 4 + 256 * 4;
-  b += (4 + kBlockThreads) * 4 + ((T.w_nstates * T.ncls * 2 + 15) & ~15);
+  b += (4 + kBlockThreads) * 4 + 256 * 4 + ((T.w_nstates * T.ncls * 2 + 15) & ~15);
   return (b + 15) & ~size_t(15);
 }
 

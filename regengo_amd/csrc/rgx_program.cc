@@ -19,6 +19,60 @@ Program::~Program() {
 }
 
 namespace {
+// A byte class is REQUIRED when no accepting path of the DFA avoids it: every match consumes at least one byte of the
+// class.  Together with the reset bytes (every state dies) this gives the scan kernels a cheap necessary condition for a
+// start position p: the first byte at or after p that is either required or reset must be a required one -- a match cannot
+// reach past a reset byte and must contain a required byte (`\w+@\w+`: no '@' before the next blank, no match from here).
+// Chooses the required class with the fewest byte values.  rz[c] = (c in class) | (reset_byte[c] << 16).
+bool ComputeRequiredClass(const Tables& t, uint32_t rz[256]) {
+  for (int c = 0; c < 256; c++) rz[c] = t.reset_byte[c] ? (1u << 16) : 0u;
+  const int ncls = t.ncls, stride = ncls + 1;
+  for (int ctx = 0; ctx < 4; ctx++) if (t.start_accept[ctx]) return false;      // the empty match needs no byte at all
+  int best = -1, best_n = 257;
+  std::vector<int> count(ncls, 0);
+  for (int c = 0; c < 256; c++) count[t.cls[c]]++;
+  std::vector<uint8_t> seen(t.nstates);
+  std::vector<int> work;
+  for (int k = 0; k < ncls; k++) {
+    if (count[k] == 0 || count[k] >= best_n) continue;
+    std::fill(seen.begin(), seen.end(), 0);
+    work.clear();
+    for (int ctx = 0; ctx < 4; ctx++) {
+      const int q = t.start[ctx];
+      if (q != kDead && q < t.nstates && !seen[q]) { seen[q] = 1; work.push_back(q); }
+    }
+    bool accept = false;
+    while (!work.empty() && !accept) {
+      const int q = work.back();
+      work.pop_back();
+      if (t.trans[(size_t)q * stride + ncls] & (kMatchBefore | kMatchAfter)) { accept = true; break; }   // at end of text
+      for (int c = 0; c < ncls; c++) {
+        const uint16_t e = t.trans[(size_t)q * stride + c];
+        if (e & kMatchBefore) { accept = true; break; }       // ends BEFORE this byte: the byte is not part of the match
+        if (c == k) continue;
+        if (e & kMatchAfter) { accept = true; break; }
+        const int nq = e & kStateMask;
+        if (nq != kDead && !seen[nq]) { seen[nq] = 1; work.push_back(nq); }
+      }
+    }
+    if (!accept) { best = k; best_n = count[k]; }
+  }
+  if (best < 0) return false;
+  // no use when every byte that can begin a match is itself of the required class (`\d+`: the test always passes)
+  bool other_first = false;
+  for (int ctx = 0; ctx < 4 && !other_first; ctx++) {
+    const int q = t.start[ctx];
+    if (q == kDead || q >= t.nstates) continue;
+    for (int c = 0; c < ncls; c++)
+      if (c != best && (t.trans[(size_t)q * stride + c] & (kStateMask | kMatchAfter)) != kDead) other_first = true;
+  }
+  if (!other_first) return false;
+  for (int c = 0; c < 256; c++) if (t.cls[c] == best) rz[c] |= 1u;
+  return true;
+}
+}  // namespace
+
+namespace {
 struct Arena {
   std::vector<uint8_t> host;
   size_t Add(const void* p, size_t n) {
@@ -87,6 +141,9 @@ int UploadTables(const Tables& t, std::vector<uint16_t>* direct_table, DevTables
   size_t off_ops = a.AddVec(t.bt_ops), off_bm = a.AddVec(t.bt_match), off_so = a.AddVec(t.start_ops);
   size_t off_sop = a.AddVec(t.start_ops_pool);
   size_t off_sa = a.Add(t.sa_mask, sizeof t.sa_mask);
+  uint32_t rz[256];
+  d.has_req = ComputeRequiredClass(t, rz) ? 1 : 0;
+  size_t off_rz = a.Add(rz, sizeof rz);
   size_t off_tcls = a.AddVec(t.trans);
   size_t off_w = a.AddVec(t.w_trans);
   d.w_nstates = ((size_t)t.w_nstates * t.ncls * 2 <= 40 * 1024) ? t.w_nstates : 0;   // kept in LDS by the kernels
@@ -109,6 +166,7 @@ int UploadTables(const Tables& t, std::vector<uint16_t>* direct_table, DevTables
   d.bt_ops = (const uint32_t*)(b + off_ops); d.bt_match = (const uint32_t*)(b + off_bm);
   d.start_ops = (const uint32_t*)(b + off_so); d.start_ops_pool = (const uint32_t*)(b + off_sop);
   d.sa_mask = (const uint32_t*)(b + off_sa);
+  d.sa_rz = (const uint32_t*)(b + off_rz);
   d.trans_cls = (const uint16_t*)(b + off_tcls);
   d.w_trans = (const uint16_t*)(b + off_w);
   *out = d;

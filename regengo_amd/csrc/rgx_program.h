@@ -42,6 +42,8 @@ struct DevTables {
   const uint32_t* start_ops;      // [4]
   const uint32_t* start_ops_pool;
   const uint32_t* sa_mask;        // [256] Shift-And level-set masks (prefilter)
+  const uint32_t* sa_rz;          // [256] bit 0: byte of the REQUIRED class, bit 16: reset byte (prefilter's second test)
+  int32_t has_req;                // 1: every match consumes a byte of one class (sa_rz bit 0), see ComputeRequiredClass
   const uint16_t* w_trans;        // sync automaton [w_nstates][ncls] (rgx_dfa.h); state 0 = no earlier thread alive
   int32_t w_nstates;              // 0: none (or too large for LDS)
   int32_t w_start;
