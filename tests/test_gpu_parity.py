@@ -461,3 +461,32 @@ def test_submit_wait_equals_synchronous_scan(torch_dev):
     e.FindAllSubmit(tile)
     g, r = e.FindAllWait()
     assert torch.equal(g, e.FindAllSpans(tile)[0]) and r.total == g.shape[0] > 0
+
+
+@pytest.mark.parametrize("pat,seed", [(r"(\w+)@(\w+)", b"bob@ex"), (r"[a-z]+:[0-9]+", b"ab:09"), (r"x[^y\n]*y", b"xaby"),
+                                      (r"(?:ab|cd)+-z", b"abcd-z"), (r"q\w*\.\w+", b"qa.b1")])
+def test_required_class_prefilter_boundaries(torch_dev, pat, seed):
+    """The generic kernel's required-class test works on 32-byte chunks of a lane's 64-byte slice: tokens of every length
+    with the required byte present / absent at every offset relative to those boundaries, against the C oracle."""
+    from oracle.gen_c import CMatcher
+    cm = CMatcher(pat)
+    c = _gpu(pat)
+    rng = np.random.default_rng(11)
+    alphabet = np.frombuffer(b"abcdxyzq019@:.-_ \n", dtype=np.uint8)
+    parts = []
+    for ln in range(1, 80):
+        for _ in range(4):
+            tok = rng.choice(alphabet[:13], size=ln)                      # word-ish bytes
+            if rng.random() < 0.6:
+                tok[rng.integers(0, ln)] = rng.choice(alphabet[11:16])    # a required / separator byte somewhere
+            parts.append(tok)
+            if rng.random() < 0.15:
+                parts.append(np.frombuffer(seed, dtype=np.uint8))              # a real match glued to the token
+            parts.append(rng.choice(alphabet[15:], size=rng.integers(1, 3)))
+    buf = np.concatenate(parts)
+    for shift in range(0, 33, 3):                                         # slide everything across the chunk grid
+        b = np.ascontiguousarray(np.concatenate([np.full(shift, ord(" "), dtype=np.uint8), buf]))
+        exp, cnt = cm.find_all_np(b)
+        spans, res = c.FindAllSpans(torch_dev.from_numpy(b).cuda())
+        assert res.total == cnt and np.array_equal(spans.cpu().numpy(), exp), (pat, shift)
+    assert cnt > 20
