@@ -210,6 +210,18 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
     __syncthreads();
   }
   unsigned long long mask = 0;
+  // ends of the matches recorded in `mask`, as a 128-bit set relative to a: the k-th start pairs with the k-th end (matches
+  // are ordered and do not overlap), so phase 3 need not walk a match a second time.  Off for patterns that can match empty
+  // (an empty match right after a match shares its end) and whenever an end falls outside [a, a+128).
+  unsigned long long ends_lo = 0, ends_hi = 0;
+  bool ends_ok = T.fixed_len < 0 && !P.count_only && !(T.start_accept[0] | T.start_accept[1] | T.start_accept[2] | T.start_accept[3]);
+#define RGX_NOTE_END(E)                                                   \
+  if (ends_ok) {                                                          \
+    const int re_ = (E) - a;                                              \
+    if (re_ >= 0 && re_ < 64) ends_lo |= 1ull << re_;                     \
+    else if (re_ >= 64 && re_ < 128) ends_hi |= 1ull << (re_ - 64);       \
+    else ends_ok = false;                                                 \
+  }
   if (a < len) {
     int pos;
     bool synced = true;
@@ -241,13 +253,13 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
       // reference: `if anchored && searchStart > 0 { break }` (find.go:199-205): one attempt, at offset 0
       if (a == 0 && len > 0) {
         int end = Walk<MODE>(tab, in, T, s_ctx, 0);
-        if (end >= 0) mask = 1ull;
+        if (end >= 0) { mask = 1ull; RGX_NOTE_END(end) }
       }
     } else if (SA == 0) {
       while (pos < slice_end) {
         int end = Walk<MODE>(tab, in, T, s_ctx, pos);
         if (end >= 0) {
-          if (pos >= a) mask |= 1ull << (pos - a);
+          if (pos >= a) { mask |= 1ull << (pos - a); RGX_NOTE_END(end) }
           pos = end > pos ? end : pos + 1;         // find.go:452-457
         } else {
           ++pos;
@@ -325,7 +337,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
           if (s < pos) continue;
           const int e = Walk<MODE>(tab, in, T, s_ctx, s);
           if (e >= 0) {
-            if (s >= a) mask |= 1ull << (s - a);
+            if (s >= a) { mask |= 1ull << (s - a); RGX_NOTE_END(e) }
             pos = e > s ? e : s + 1;
           }
         }
@@ -334,6 +346,8 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
   }
 
   // ---- phase 2: ordered offsets.  lane -> wave -> block prefix sums, then decoupled look-back over tiles.
+#undef RGX_NOTE_END
+  const unsigned long long mask_all = mask;      // every match of the slice, for the start/end pairing in phase 3
   if (P.own_lo > 0 || P.own_hi < len) mask &= OwnMask(a, P.own_lo, P.own_hi);   // shard ownership
   const unsigned cnt = (unsigned)__popcll(mask);
   const unsigned incl = (unsigned)WaveInclusiveScan(cnt, lane);
@@ -362,11 +376,19 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
   if (mask) {
     unsigned long long idx = base + wave_off + (incl - cnt);
     const int ncap = T.ncap;
-    while (mask) {
-      const int b = __builtin_ctzll(mask);
-      mask &= mask - 1;
+    unsigned long long pair = ends_ok ? mask_all : mask;      // with recorded ends: walk ALL starts to keep the pairing
+    while (pair) {
+      const int b = __builtin_ctzll(pair);
+      pair &= pair - 1;
       const int s = a + b;
-      const int e = T.fixed_len >= 0 ? s + T.fixed_len : Walk<MODE>(tab, in, T, s_ctx, s);
+      int e;
+      if (ends_ok) {
+        if (ends_lo) { e = a + __builtin_ctzll(ends_lo); ends_lo &= ends_lo - 1; }
+        else { e = a + 64 + __builtin_ctzll(ends_hi); ends_hi &= ends_hi - 1; }
+        if (!((mask >> b) & 1ull)) continue;                  // a match of the slice this shard does not own
+      } else {
+        e = T.fixed_len >= 0 ? s + T.fixed_len : Walk<MODE>(tab, in, T, s_ctx, s);
+      }
       if (idx < (unsigned long long)P.cap_records) {
         int32_t* rec = P.spans + idx * ncap;
         if (T.fixed_captures) WriteRecordFixed(rec, ncap, s_kind, s_delta, s, e);
