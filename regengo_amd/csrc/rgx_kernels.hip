@@ -1307,7 +1307,26 @@ bool ScanSupportsW(const DevTables& T, int32_t len) { return T.w_nstates > 0 && 
 hipError_t LaunchScan(const DevTables& T, const ScanParams& P, hipStream_t stream) {
   if (UseExactKernel(T, P.len)) return LaunchScanExact(T, P, stream);
   if (UseSaKernel(T, P.len) && !getenv("RGX_NO_SA_KERNEL") && !P.use_w) return LaunchScanSa(T, P, T.trans_cls, stream);
-  const size_t shmem = ScanSharedBytes(T);
+  // The generic kernel stages its transition table once per 16 KiB tile: a table that is not small next to the tile costs
+  // more L2->LDS traffic than the input itself and, through its LDS footprint, most of the CU's occupancy (`\\p{L}+`: 75 KB
+  // per tile, one workgroup per CU, 26.5 ms per GiB against 5.7 ms with the table read through L1/L2).  So the kernel gets a
+  // VIEW of the tables: direct layout only up to 12 KiB (23 states), class layout in LDS up to 24 KiB, beyond that the class
+  // table stays in global memory.  (The batch and capture kernels keep a table per persistent workgroup: not affected.)
+  DevTables V = T;
+  {
+    const size_t class_bytes = (size_t)T.nstates * T.stride * 2;
+    static const size_t direct_max = getenv("RGX_DIRECT_MAX") ? (size_t)atol(getenv("RGX_DIRECT_MAX")) : (size_t)12 * 1024;
+    static const size_t class_max = getenv("RGX_CLASS_LDS_MAX") ? (size_t)atol(getenv("RGX_CLASS_LDS_MAX")) : (size_t)24 * 1024;
+    if (T.mode == kModeDirect && (size_t)T.table_bytes > direct_max) {
+      V.trans = T.trans_cls;
+      if (class_bytes <= class_max) { V.mode = kModeClassLds; V.table_bytes = (int32_t)class_bytes; }
+      else { V.mode = kModeClassGlobal; V.table_bytes = 0; }
+    } else if (T.mode == kModeClassLds && (size_t)T.table_bytes > class_max) {
+      V.mode = kModeClassGlobal;
+      V.table_bytes = 0;
+    }
+  }
+  const size_t shmem = ScanSharedBytes(V);
   dim3 grid(P.ntiles), block(kBlockThreads);
   static bool attr_set[8] = {false, false, false, false, false, false, false, false};
   auto set_attr = [&](const void* fn, int mode) {
@@ -1319,12 +1338,12 @@ hipError_t LaunchScan(const DevTables& T, const ScanParams& P, hipStream_t strea
 #define RGX_LAUNCH(M, S, SLOT)                                                        \
   do {                                                                                \
     set_attr((const void*)scan_kernel<M, S>, SLOT);                                   \
-    hipLaunchKernelGGL((scan_kernel<M, S>), grid, block, shmem, stream, T, P);        \
+    hipLaunchKernelGGL((scan_kernel<M, S>), grid, block, shmem, stream, V, P);        \
   } while (0)
   const int sa = (T.sa_k > 0 && T.sa_k <= 29 && !T.anchored) ? 1 : 0;
-  if (T.mode == kModeDirect) {
+  if (V.mode == kModeDirect) {
     if (sa) RGX_LAUNCH(kModeDirect, 1, 1); else RGX_LAUNCH(kModeDirect, 0, 2);
-  } else if (T.mode == kModeClassLds) {
+  } else if (V.mode == kModeClassLds) {
     if (sa) RGX_LAUNCH(kModeClassLds, 1, 3); else RGX_LAUNCH(kModeClassLds, 0, 4);
   } else {
     if (sa) RGX_LAUNCH(kModeClassGlobal, 1, 5); else RGX_LAUNCH(kModeClassGlobal, 0, 6);
