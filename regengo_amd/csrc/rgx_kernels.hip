@@ -215,8 +215,9 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
   // (an empty match right after a match shares its end) and whenever an end falls outside [a, a+128).
   unsigned long long ends_lo = 0, ends_hi = 0;
   bool ends_ok = T.fixed_len < 0 && !P.count_only && !(T.start_accept[0] | T.start_accept[1] | T.start_accept[2] | T.start_accept[3]);
-#define RGX_NOTE_END(E)                                                   \
-  if (ends_ok) {                                                          \
+#define RGX_NOTE_END(S, E)                                                \
+  if ((E) == (S)) ends_ok = false;       /* an empty match (lookahead patterns have them without start_accept) */ \
+  else if (ends_ok) {                                                     \
     const int re_ = (E) - a;                                              \
     if (re_ >= 0 && re_ < 64) ends_lo |= 1ull << re_;                     \
     else if (re_ >= 64 && re_ < 128) ends_hi |= 1ull << (re_ - 64);       \
@@ -253,13 +254,13 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
       // reference: `if anchored && searchStart > 0 { break }` (find.go:199-205): one attempt, at offset 0
       if (a == 0 && len > 0) {
         int end = Walk<MODE>(tab, in, T, s_ctx, 0);
-        if (end >= 0) { mask = 1ull; RGX_NOTE_END(end) }
+        if (end >= 0) { mask = 1ull; RGX_NOTE_END(0, end) }
       }
     } else if (SA == 0) {
       while (pos < slice_end) {
         int end = Walk<MODE>(tab, in, T, s_ctx, pos);
         if (end >= 0) {
-          if (pos >= a) { mask |= 1ull << (pos - a); RGX_NOTE_END(end) }
+          if (pos >= a) { mask |= 1ull << (pos - a); RGX_NOTE_END(pos, end) }
           pos = end > pos ? end : pos + 1;         // find.go:452-457
         } else {
           ++pos;
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
           if (s < pos) continue;
           const int e = Walk<MODE>(tab, in, T, s_ctx, s);
           if (e >= 0) {
-            if (s >= a) { mask |= 1ull << (s - a); RGX_NOTE_END(e) }
+            if (s >= a) { mask |= 1ull << (s - a); RGX_NOTE_END(s, e) }
             pos = e > s ? e : s + 1;
           }
         }

@@ -28,13 +28,20 @@ for seed in range(first, first + nseeds):
             refused += 1
             continue
         cm = CMatcher(p, q8=False)
+        if len(sys.argv) > 3:
+            print("pattern", repr(p), flush=True)
         for n in (0, 3, 64, 1000, 70000):
             if n >= 20000 and cm.memo:
                 continue
             b = F.gen_input_u(rng, max(n // 2, 1) if n else 0) if uni else F.gen_input(rng, n)
             arr = np.frombuffer(b, dtype=np.uint8).copy() if len(b) else np.zeros(0, dtype=np.uint8)
+            t1 = time.time()
             exp, cnt = cm.find_all_np(arr)
+            t2 = time.time()
             spans, res = c.FindAllSpans(b)
+            t3 = time.time()
+            if len(sys.argv) > 3 and (t2 - t1 > 2 or t3 - t2 > 2):
+                print("SLOW", repr(p), "n", len(b), "oracle %.1fs gpu %.1fs" % (t2 - t1, t3 - t2), "matches", cnt, flush=True)
             got = spans.cpu().numpy()
             tot += 1
             if not (res.total == cnt and got.shape == exp.shape and np.array_equal(got, exp)):
