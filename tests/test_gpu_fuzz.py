@@ -117,3 +117,24 @@ def test_random_patterns_replace_and_transform(torch_dev):
         done += 1
     print("patterns", done)
     assert done >= 40
+
+
+@pytest.mark.parametrize("pat", [r"(?:a|\B)", r"(?:b|(?:01aa-)?|\B)", r"(?:ab)?\b", r"(\w+|\B)", r"(?:0+|\b)"])
+def test_lookahead_empty_matches_regression(torch_dev, pat):
+    """Empty matches that come from an empty-width assertion (no start_accept in the tables): a match and the empty match
+    right behind it share their end -- the generic kernel's start/end pairing has to give up there (found by the sweep,
+    scripts/gpu_fuzz_sweep.py; a wrong end used to reach the capture kernel)."""
+    from oracle.gen_c import CMatcher
+    from regengo_amd import Compiled
+    from tests import _fuzzgen as F
+    c = Compiled(pat).to(0)
+    cm = CMatcher(pat, q8=False)
+    rng = random.Random(9)
+    for n in (64, 1000, 70000):
+        b = F.gen_input(rng, n)
+        arr = np.frombuffer(b, dtype=np.uint8).copy()
+        if n >= 20000 and cm.memo:
+            continue
+        exp, cnt = cm.find_all_np(arr)
+        spans, res = c.FindAllSpans(b)
+        assert res.total == cnt and np.array_equal(spans.cpu().numpy(), exp), (pat, n)
