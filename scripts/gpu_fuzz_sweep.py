@@ -1,5 +1,7 @@
 """One-off wide sweep of the differential test (tests/test_gpu_fuzz.py runs three seeds): many seeds, ASCII and UTF-8
-pattern generators, FindAllBytes on the GPU against the C oracle (Q8 off).  usage: gpu_fuzz_sweep.py [first_seed] [nseeds]"""
+pattern generators, FindAllBytes on the GPU against the C oracle (Q8 off).  usage: gpu_fuzz_sweep.py [first_seed] [nseeds]
+Run it under `timeout`: the oracle is the reference's backtracker and some random patterns are catastrophic for it (seed 420
+held a 25-minute call; the GPU side of the same pattern takes microseconds)."""
 import random, sys, time
 sys.path.insert(0, ".")
 import numpy as np
@@ -30,14 +32,16 @@ for seed in range(first, first + nseeds):
         cm = CMatcher(p, q8=False)
         if len(sys.argv) > 3:
             print("pattern", repr(p), flush=True)
+        slow_oracle = False
         for n in (0, 3, 64, 1000, 70000):
-            if n >= 20000 and cm.memo:
-                continue
+            if n >= 20000 and (cm.memo or slow_oracle):
+                continue                   # (the reference's backtracker can be super-linear: keep the sweep moving)
             b = F.gen_input_u(rng, max(n // 2, 1) if n else 0) if uni else F.gen_input(rng, n)
             arr = np.frombuffer(b, dtype=np.uint8).copy() if len(b) else np.zeros(0, dtype=np.uint8)
             t1 = time.time()
             exp, cnt = cm.find_all_np(arr)
             t2 = time.time()
+            slow_oracle = slow_oracle or (t2 - t1 > 0.005 * max(1, len(b) // 1000))   # super-linear oracle: no 70 KB call
             spans, res = c.FindAllSpans(b)
             t3 = time.time()
             if len(sys.argv) > 3 and (t2 - t1 > 2 or t3 - t2 > 2):
