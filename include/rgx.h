@@ -86,6 +86,8 @@ typedef struct rgx_info {
   int32_t needs_valid_utf8; /* 1: the pattern has a class with non-ASCII runes (incl. negated ASCII classes);
                              * results are exact on ASCII / valid UTF-8 input, see DESIGN.md "UTF-8 classes"        */
   int32_t sync_states;     /* states of the sync automaton W (0: none), DESIGN.md 4.1                         */
+  int32_t unicode_version; /* UCD version behind \p{..}: 0xMMmmpp (0x0E0000 = 14.0.0).  The reference's tables are Go 1.24's
+                            * `unicode` package = 15.0.0: code points first assigned in 15.0 are unassigned here       */
 } rgx_info;
 int rgx_program_info(const rgx_program* p, rgx_info* out);
 /* NUL-separated capture names, group 0 first ("" for unnamed); returns bytes written or needed.    */
@@ -93,6 +95,10 @@ int64_t rgx_program_capture_names(const rgx_program* p, char* dst, size_t cap);
 /* 256 flags: 1 = every automaton state dies on this byte, so the next offset is a FindAll sync point (used by
  * callers that shard one input across GPUs; DESIGN.md "sync points").                                   */
 int rgx_program_reset_bytes(const rgx_program* p, uint8_t* dst256);
+/* The range table behind \p{name} (unicode.Categories / unicode.Scripts of regexp/syntax, parse.go: unicodeTable): writes up
+ * to cap_pairs [lo, hi] pairs into dst (int32 each) and returns the number of pairs the table has, or RGX_E_INVALID for a
+ * name the front-end does not know.  Lets a caller audit the tables against another UCD copy.                   */
+int64_t rgx_unicode_table(const char* name, int32_t* dst, size_t cap_pairs);
 
 /* ---- device binding --------------------------------------------------------------------------- */
 int rgx_device_count(void);

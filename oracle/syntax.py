@@ -281,6 +281,36 @@ _SCRIPTS = {
 }
 
 
+def _script_table(name: str, names_only: bool = False) -> Optional[List[int]]:
+    """unicode.Scripts[name]: the Script property read from the third-party `regex` module's UCD copy (a newer Unicode than
+    Go 1.24's 15.0: code points assigned later are extra here; CPython's own unicodedata has no Script property).  Only
+    the long names of Scripts.txt are keys of unicode.Scripts (no aliases such as Hani, no Unknown)."""
+    import re as _re
+    if not _re.fullmatch(r"[A-Z][A-Za-z]*(_[A-Z][A-Za-z]*)*", name) or name in ("Unknown", "Katakana_Or_Hiragana"):
+        return None
+    try:
+        import regex as _regex
+        rx = _regex.compile(r"\p{Script=%s}" % name)
+    except Exception:
+        return None
+    # ISO 15924 codes (Hani, Latn, Grek ...) are accepted by the regex module but are not keys of unicode.Scripts; the
+    # four-letter names that ARE long names:
+    if len(name) == 4 and name not in ("Ahom", "Cham", "Lisu", "Miao", "Modi", "Newa", "Thai", "Toto", "Kawi"):
+        return None
+    if names_only:
+        return []
+    out: List[int] = []
+    for cp in range(0, MAX_RUNE + 1):
+        if 0xD800 <= cp <= 0xDFFF:
+            continue
+        if rx.match(chr(cp)):
+            if out and out[-1] == cp - 1:
+                out[-1] = cp
+            else:
+                out.extend((cp, cp))
+    return out or None
+
+
 def unicode_table(name: str) -> Optional[List[int]]:
     if name == "Any":
         return [0, MAX_RUNE]
@@ -292,7 +322,10 @@ def unicode_table(name: str) -> Optional[List[int]]:
             "Ps", "Pe", "Pi", "Pf", "Po", "S", "Sm", "Sc", "Sk", "So", "Z", "Zs", "Zl", "Zp", "C", "Cc", "Cf",
             "Cs", "Co"}
     if name not in cats:
-        return None
+        out = _script_table(name)
+        if out is not None:
+            _UNI_CACHE[name] = out
+        return out
     out: List[int] = []
     for cp in range(0, MAX_RUNE + 1):
         c = unicodedata.category(chr(cp))

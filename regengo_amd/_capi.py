@@ -36,7 +36,7 @@ class Info(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "ncap", "min_match_len", "max_match_len", "default_max_leftover", "min_buffer_size", "n_inst",
         "n_states", "n_classes", "anchored", "fixed_captures", "can_match_empty", "ref_match_engine", "ref_find_engine",
-        "lookahead_mode", "table_bytes", "needs_valid_utf8", "sync_states")]
+        "lookahead_mode", "table_bytes", "needs_valid_utf8", "sync_states", "unicode_version")]
 
 
 class Result(C.Structure):
@@ -58,6 +58,7 @@ SYMBOLS = {
     "rgx_program_info": (C.c_int, [C.c_void_p, C.POINTER(Info)]),
     "rgx_program_capture_names": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "rgx_program_reset_bytes": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "rgx_unicode_table": (C.c_int64, [C.c_char_p, C.c_void_p, C.c_size_t]),
     "rgx_device_count": (C.c_int, []),
     "rgx_program_to_device": (C.c_int, [C.c_void_p, C.c_int]),
     "rgx_stream_ctx_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),

@@ -321,8 +321,18 @@ RGX_API int rgx_program_info(const rgx_program* p, rgx_info* o) {
   o->fixed_captures = t.fixed_captures; o->can_match_empty = t.can_match_empty;
   o->ref_match_engine = t.ref_match_engine; o->ref_find_engine = t.ref_find_engine; o->lookahead_mode = t.lookahead_mode;
   o->needs_valid_utf8 = t.needs_valid_utf8; o->sync_states = t.w_nstates;
+  o->unicode_version = UnicodeVersion();
   o->table_bytes = p->p.d_arena ? p->p.dev.table_bytes : (int32_t)((size_t)t.nstates * (t.ncls + 1) * 2);
   return RGX_OK;
+}
+
+RGX_API int64_t rgx_unicode_table(const char* name, int32_t* dst, size_t cap_pairs) {
+  if (!name) return RGX_E_INVALID;
+  std::vector<int32_t> tab;
+  if (!UnicodeTable(name, &tab)) return RGX_E_INVALID;
+  const size_t n = tab.size() / 2;
+  if (dst) memcpy(dst, tab.data(), std::min(n, cap_pairs) * 2 * sizeof(int32_t));
+  return (int64_t)n;
 }
 
 RGX_API int64_t rgx_program_capture_names(const rgx_program* p, char* dst, size_t cap) {

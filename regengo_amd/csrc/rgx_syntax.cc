@@ -211,6 +211,13 @@ static Runes NegateClass(const Runes& r) {
 
 struct Group { int sign; Runes cls; };
 #include "rgx_unicode_tables.inc"
+bool UnicodeTable(const std::string& name, std::vector<int32_t>* out) {
+  if (name == "Any") { *out = {0, kMaxRune}; return true; }
+  for (const UniTable& u : kUniTables)
+    if (name == u.name) { out->assign(u.r, u.r + 2 * u.npairs); return true; }
+  return false;
+}
+int UnicodeVersion() { return RGX_UNICODE_VERSION; }
 static const std::map<std::string, Group>& PerlGroups() {
   static const std::map<std::string, Group> g = {
       {"\\d", {+1, {0x30, 0x39}}}, {"\\D", {-1, {0x30, 0x39}}},
@@ -754,13 +761,8 @@ struct Parser {
     }
     if (!name.empty() && name[0] == '^') { sign = -sign; name.erase(0, 1); }
     Runes tab;
-    if (name == "Any") { tab = {0, kMaxRune}; }
-    else {
-      const UniTable* found = nullptr;
-      for (const UniTable& u : kUniTables) if (name == u.name) found = &u;
-      if (!found) throw SyntaxError{"unsupported: \\p{" + name + "} (no table for this Unicode class)"};
-      tab.assign(found->r, found->r + 2 * found->npairs);
-    }
+    // parse.go unicodeTable: "Any", unicode.Categories, unicode.Scripts; anything else is a syntax error
+    if (!UnicodeTable(name, &tab)) throw SyntaxError{"invalid character class range: \\p{" + name + "}"};
     if (flags & kFoldCase) { Runes tmp; AppendFoldedClass(tmp, tab); tab = CleanClass(tmp); }
     if (sign > 0) AppendClass(r, tab); else AppendNegatedClass(r, CleanClass(tab));
     t = i;

@@ -79,6 +79,9 @@ bool HasEndAnchor(const Prog& p);
 bool IsAnchored(const Prog& p);
 
 int32_t SimpleFold(int32_t r);
+// \p{name} range table (pairs), false for unknown names; UCD version 0xMMmmpp of the tables (rgx_unicode_tables.inc)
+bool UnicodeTable(const std::string& name, std::vector<int32_t>* out);
+int UnicodeVersion();
 int RuneLen(int32_t r);
 int EncodeRune(int32_t r, uint8_t out[4]);
 

@@ -1,0 +1,116 @@
+"""\\p{..} tables: the product's (generated from ICU 70's UCD, Unicode 14.0 -- regengo_amd/csrc/gen_unicode_tables.py) against
+two UCD copies it was NOT generated from: CPython's unicodedata (13.0, general categories; the oracle's source) and the
+`regex` module (a newer Unicode; Script property; the oracle's source for scripts).  The reference's tables are Go 1.24's
+`unicode` package (15.0.0; /root/reference/regengo.go:92 -> regexp/syntax parse.go unicodeTable); no copy of 15.0 exists in
+this image, so the product is pinned on both sides: everything assigned in 13.0 must agree with the 13.0 copy, and every
+difference to the newer copy must lie on code points the older copies do not assign."""
+import ctypes as C
+import os
+import subprocess
+import unicodedata
+
+import pytest
+
+from regengo_amd import _capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+CATS = ["L", "Lu", "Ll", "Lt", "Lm", "Lo", "M", "Mn", "Mc", "Me", "N", "Nd", "Nl", "No", "P", "Pc", "Pd", "Ps", "Pe", "Pi", "Pf", "Po",
+        "S", "Sm", "Sc", "Sk", "So", "Z", "Zs", "Zl", "Zp", "C", "Cc", "Cf", "Cs", "Co"]
+# General_Category changes of already-assigned characters between Unicode 13.0 and 14.0 (UCD 14.0 UnicodeData.txt):
+# U+1734 HANUNOO SIGN PAMUDPOD Mn -> Mc.
+GC_CHANGED_IN_14 = {0x1734}
+
+
+def product_table(name):
+    lib = _capi.lib()
+    n = lib.rgx_unicode_table(name.encode(), None, 0)
+    if n < 0:
+        return None
+    buf = (C.c_int32 * (2 * n))()
+    assert lib.rgx_unicode_table(name.encode(), buf, n) == n
+    return list(buf)
+
+
+def as_set(tab):
+    s = set()
+    for i in range(0, len(tab), 2):
+        assert tab[i] <= tab[i + 1]
+        s.update(range(tab[i], tab[i + 1] + 1))
+    return s
+
+
+def test_product_does_not_import_the_oracle():
+    # the oracle is test infrastructure: nothing under regengo_amd/ may import it (build.py only compiles the checker)
+    out = subprocess.run(["grep", "-rlE", r"^\s*(from|import)\s+oracle", os.path.join(ROOT, "regengo_amd")], capture_output=True, text=True).stdout
+    hits = sorted(os.path.relpath(p, ROOT) for p in out.split() if not p.endswith(".pyc"))
+    assert hits == ['regengo_amd/build.py'], hits       # build_oracle(): compiling the checker is not using it
+    gen = open(os.path.join(ROOT, "regengo_amd", "csrc", "gen_unicode_tables.py")).read()
+    assert "import oracle" not in gen and "from oracle" not in gen
+
+
+def test_unicode_version_is_reported():
+    from regengo_amd import Compiled
+    info = Compiled(r"\p{L}+").info
+    assert info.unicode_version == 0x0E0000          # ICU 70 = Unicode 14.0.0; Go 1.24 = 15.0.0 (stated gap)
+
+
+def test_general_categories_agree_with_cpython_ucd_on_everything_assigned_in_13():
+    assigned13 = [unicodedata.category(chr(cp)) for cp in range(0x110000)]
+    for name in CATS:
+        prod = as_set(product_table(name))
+        ref = {cp for cp, c in enumerate(assigned13) if c != "Cn" and (c == name or (len(name) == 1 and c[0] == name))}
+        # (a) nothing the 13.0 copy has is missing or re-categorised, except the listed UCD changes
+        assert (ref - prod) <= GC_CHANGED_IN_14, (name, sorted(ref - prod)[:10])
+        # (b) everything extra is a code point 13.0 does not assign (first assigned in 14.0), or a listed change
+        extra = prod - ref
+        bad = [cp for cp in extra if assigned13[cp] != "Cn" and cp not in GC_CHANGED_IN_14]
+        assert bad == [], (name, [hex(c) for c in bad[:10]])
+
+
+def test_oracle_tables_equal_product_tables_where_both_ucd_copies_assign():
+    from oracle import syntax as S
+    assert S.unicode_table("Nope") is None and product_table("Nope") is None
+    assert S.unicode_table("Hani") is None and product_table("Hani") is None      # ISO 15924 codes are not keys of unicode.Scripts
+    for name in CATS + ["Greek", "Hebrew"]:
+        a, b = as_set(S.unicode_table(name)), as_set(product_table(name))
+        diff = a ^ b
+        assert all(unicodedata.category(chr(cp)) == "Cn" or cp in GC_CHANGED_IN_14 for cp in diff), name
+
+
+@pytest.mark.parametrize("name", ["Latin", "Han", "Cyrillic", "Arabic", "Common", "Inherited", "Hiragana", "Katakana", "Thai",
+                                  "Devanagari", "Hangul", "Armenian", "Georgian", "Old_Italic", "Phags_Pa", "Nko", "SignWriting"])
+def test_scripts_agree_with_the_regex_modules_ucd(name):
+    regex = pytest.importorskip("regex")
+    from oracle import syntax as S
+    prod = as_set(product_table(name))
+    ref = as_set(S.unicode_table(name))
+    assert prod, name
+    diff = prod ^ ref
+    # the regex module's UCD is newer than 14.0: a differing code point must be unassigned in CPython's 13.0 copy, i.e. it
+    # was assigned (or given this script) after 13.0; characters of 13.0 must carry the same script in both
+    moved = sorted(cp for cp in diff if unicodedata.category(chr(cp)) != "Cn")
+    assert moved == [], (name, [hex(c) for c in moved[:10]])
+
+
+def test_every_product_script_name_is_known_to_the_oracle():
+    pytest.importorskip("regex")
+    from oracle import syntax as S
+    inc = open(os.path.join(ROOT, "regengo_amd", "csrc", "rgx_unicode_tables.inc")).read()
+    import re
+    names = [n for n in re.findall(r'\{"(\w+)", kUni_', inc) if n not in CATS]
+    assert len(names) >= 160
+    for n in names:
+        assert S._script_table(n, names_only=True) is not None, n
+
+
+def test_compiled_class_uses_the_table():
+    # \\p{Han} and \\P{Latin} compile now (round 1: only Greek and Hebrew existed); AST and Prog equal the oracle's
+    from oracle import syntax as S
+    from tests import _hosttest as H
+    for pat in [r"\p{Han}+", r"[\p{Latin}\d]+x", r"a\P{Cyrillic}"]:
+        ast, prog = S.compile_pattern(pat)
+        want = ast.dump() + "\n" + "start %d numcap %d\n" % (prog.start, prog.numcap)
+        got = H.prog_dump(pat)
+        # the oracle's Script tables come from a newer UCD: compare the structure (ops), not the range lists
+        assert got.split("\n")[1] == want.split("\n")[1], pat
+        assert len(got.split("\n")) == len(want.split("\n")) + len(prog.inst), pat
