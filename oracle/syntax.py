@@ -311,7 +311,15 @@ def _script_table(name: str, names_only: bool = False) -> Optional[List[int]]:
     return out or None
 
 
+# Tests that compare ASTs / Progs range for range (tests/test_host_tables.py) install the table source of the library
+# under test here, so that they check the front-end's LOGIC (class parsing, folding, negation, compilation); the table
+# DATA is audited separately, against UCD copies neither side was generated from (tests/test_unicode_tables.py).
+TABLE_OVERRIDE = None
+
+
 def unicode_table(name: str) -> Optional[List[int]]:
+    if TABLE_OVERRIDE is not None:
+        return TABLE_OVERRIDE(name)
     if name == "Any":
         return [0, MAX_RUNE]
     if name in _SCRIPTS:
