@@ -7,7 +7,8 @@ One process per GPU (`torch.distributed`, backend "nccl" == RCCL over xGMI; "glo
         [lo_r - halo_left, hi_r + halo_right)          (clipped to [0, L))
 
 and keeps the matches it owns:
-  * halo_right lets an owned match extend past hi_r (MaxMatchLen-1 bytes suffice for bounded patterns; unbounded
+  * halo_right lets an owned match extend past hi_r and still see the byte behind its end (MaxMatchLen bytes for
+    bounded patterns: trailing \\b / $ look one byte ahead; unbounded
     patterns use the reference's own 1 MiB leftover cap, streaming.go:87-96, and a match that touches the end of a
     non-final window is reported as `truncated`);
   * halo_left supplies a sync point: FindAll's search position is only known at offset 0 of the whole input, but
@@ -43,9 +44,10 @@ def plan_shards(total_len: int, world: int, max_match_len: int, halo_left: int =
     so every local window starts on a 16-byte boundary of the global stream."""
     per = -(-total_len // world)
     per = -(-per // align) * align
-    halo_r = (max_match_len - 1) if max_match_len > 0 else unbounded_halo
-    if max_match_len == 0:
-        halo_r = 0
+    # An owned match may start at hi-1 and be max_match_len long; the byte AFTER it must be in the window too, because
+    # the scan takes the window's end for the end of the text and trailing assertions (\b, \B, $, (?m)$) look at it:
+    # max_match_len bytes of right halo, not max_match_len - 1 (and never 0: an empty match at hi-1 looks ahead as well).
+    halo_r = max(max_match_len, 1) if max_match_len >= 0 else unbounded_halo
     out = []
     for r in range(world):
         lo = min(r * per, total_len)

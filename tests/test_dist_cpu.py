@@ -88,7 +88,7 @@ def test_plan_shards_tiles_exactly():
                 assert a.hi == b.lo
             for s in sh:
                 assert s.win_lo <= s.lo and s.win_hi >= s.hi and s.win_lo % 16 == 0
-                assert s.win_hi == min(total, s.hi + 9)
+                assert s.win_hi == min(total, s.hi + 10)
 
 
 def test_two_ranks_equal_single_scan(built):
@@ -143,3 +143,27 @@ def test_combined_step_two_ranks(built):
     exp, cnt = CMatcher(DATE).find_all_np(np.frombuffer(data, dtype=np.uint8))
     assert all(o[3] for o in outs), "expected the fall-back to the chained path"
     assert total == cnt and rows == exp.astype(np.int64).tolist()
+
+
+@pytest.mark.parametrize("pattern,mid", [(r"ab\b", b"abc"), (r"ab\b", b"ab c"), (r"(?m)foo$", b"foox"), (r"(?m)foo$", b"foo\nx"),
+                                         (r"ab\B", b"abc"), (r"ab\B", b"ab c"), (r"\bab", b"xab"), (r"x*\b", b"a b")])
+def test_lookahead_assertions_across_the_shard_boundary(built, pattern, mid):
+    """A maximal-length owned match ending exactly where the right halo used to end (MaxMatchLen-1): the window's end
+    was taken for the end of the text and trailing \\b / $ / \\B were evaluated without their real next byte."""
+    from oracle.engines import Compiled as OC
+    from regengo_amd.dist import plan_shards
+    from tests._hosttest import HostProgram
+    hp = HostProgram(pattern)
+    o = OC(pattern)
+    L = 64
+    for shift in range(0, len(mid) + 1):
+        at = L // 2 - shift          # the owned range of rank 0 ends at 32: slide `mid` across it
+        data = bytearray(b" " * L)
+        data[at:at + len(mid)] = mid
+        data = bytes(data)
+        want = [tuple(m[:2]) for m in o.find_machine.find_all(data)]
+        got = []
+        for sh in plan_shards(L, 2, hp.info["max"], halo_left=16):
+            rows = hp.find_all(data[sh.win_lo:sh.win_hi])
+            got += [(r[0] + sh.win_lo, r[1] + sh.win_lo) for r in rows if sh.lo <= r[0] + sh.win_lo < sh.hi]
+        assert got == want, (pattern, data, got, want)
