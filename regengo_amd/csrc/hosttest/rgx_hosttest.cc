@@ -275,4 +275,79 @@ int rgxt_match(void* hh, const uint8_t* buf, int64_t len) {
   }
   return 0;
 }
+
+// ---- start-tracking search automaton (rgx_dfa.h: StartSearch): FindAll as one table step per byte, the loop the
+// scan_us kernel runs per lane.  Returns the handle, or nullptr with the reason in rgxt_last_error ("ineligible: ...").
+struct UsHandle { StartSearch u; };
+void* rgxt_compile_us(const char* pattern, uint32_t flags, int max_states, int max_regs) {
+  try {
+    auto* h = new UsHandle();
+    h->u = BuildStartSearch(pattern, flags, max_states > 0 ? max_states : 3000, max_regs > 0 ? max_regs : kUsRegs);
+    if (!h->u.ok) { g_err = "ineligible: " + h->u.why; delete h; return nullptr; }
+    return h;
+  } catch (const SyntaxError& e) { g_err = "syntax: " + e.msg; }
+  catch (const Unsupported& e) { g_err = "unsupported: " + e.msg; }
+  catch (const TooLarge& e) { g_err = "too large: " + e.msg; }
+  return nullptr;
+}
+void rgxt_free_us(void* h) { delete (UsHandle*)h; }
+int rgxt_us_info(void* hh, int32_t* out) {
+  const StartSearch& u = ((UsHandle*)hh)->u;
+  out[0] = u.nstates; out[1] = u.ncls; out[2] = u.lookahead; out[3] = u.ctx_sensitive; out[4] = u.nregs;
+  return 5;
+}
+// (start, end) pairs of every FindAll match of buf[from_pos..len) with the search standing at from_pos.  `slice` > 0: the
+// walk is cut into windows of start positions [a, a+slice) the way the kernel's lanes own them -- each window begins at a
+// sync point (the end of the last match / from_pos) and STOPS by the `oldest` rule -- which exercises that rule too.
+int64_t rgxt_us_find_all(void* hh, const uint8_t* buf, int64_t len, int64_t from_pos, int32_t* spans, int64_t cap, int64_t slice) {
+  const StartSearch& u = ((UsHandle*)hh)->u;
+  const int stride = u.ncls + 1;
+  int64_t count = 0, pos = from_pos;
+  int64_t reg[kUsRegs] = {0};
+  auto start_of = [&](uint8_t info, int64_t at) -> int64_t { return (info & kUsFromReg) ? reg[info & 7] : at - (info & 0x7F); };
+  while (pos < len) {
+    const int64_t slice_end = slice > 0 ? (pos / slice + 1) * slice : len + 2;
+    // one lane: owns starts in [pos, slice_end)
+    bool stopped_by_rule = false;
+    while (pos < len && pos < slice_end) {
+      const int ctx = pos == 0 ? kCtxBOT : u.ctx_of_byte[buf[pos - 1]];
+      uint32_t q = u.start[ctx];
+      reg[0] = pos;
+      int64_t pe = -1, ps = -1, i = pos;
+      while (true) {
+        if (i >= slice_end && pe < 0) {
+          // past the slice with nothing pending: stop unless a thread that began inside the slice is still alive
+          const uint8_t o = u.oldest[q];
+          if (o == kUsNone || start_of(o, i) >= slice_end) { stopped_by_rule = true; break; }
+        }
+        if (i >= slice_end && pe >= 0) {
+          const uint8_t o = u.oldest[q];
+          if (ps >= slice_end && (o == kUsNone || start_of(o, i) >= slice_end)) { stopped_by_rule = true; pe = -1; break; }
+        }
+        const int k = i < len ? u.cls[buf[i]] : u.ncls;
+        const uint32_t e = u.trans[(size_t)q * stride + k];
+        const uint16_t mi = u.minfo[(size_t)q * stride + k];
+        if (e & kUsBefore) { pe = i; ps = start_of((uint8_t)(mi & 0xFF), i); }
+        if (e & kUsSet) reg[(e >> kUsRegShift) & 7] = i + 1 - (int64_t)((e >> kUsDeltaShift) & 0x7F);
+        if (e & kUsAfter) { pe = i + 1; ps = start_of((uint8_t)(mi >> 8), i + 1); }
+        q = e & kUsStateMask;
+        i++;
+        if (q == 0 || k == u.ncls) break;
+      }
+      if (stopped_by_rule) break;
+      if (pe < 0) { pos = len; break; }
+      if (pe <= ps) return -1;      // cannot happen: eligible patterns have no empty match
+      if (ps >= slice_end) { pos = ps; stopped_by_rule = true; break; }   // the next lane's match: it will find it again
+      if (count < cap) { spans[2 * count] = (int32_t)ps; spans[2 * count + 1] = (int32_t)pe; }
+      count++;
+      pos = pe;
+    }
+    if (stopped_by_rule) {
+      // the next lane starts at the first sync point at or after slice_end: every offset not inside a match is one; the
+      // sequential truth is simply "continue from slice_end unless a match covers it" -- which the rule just proved absent
+      if (pos < slice_end) pos = slice_end;
+    }
+  }
+  return count;
+}
 }

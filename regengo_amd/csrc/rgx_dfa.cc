@@ -690,6 +690,177 @@ Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOption
   return t;
 }
 
+// ---------------------------------------------------------------- start-tracking search automaton (rgx_dfa.h)
+StartSearch BuildStartSearch(const std::string& pattern, uint32_t flags, int max_states, int max_regs) {
+  (void)flags;
+  StartSearch u;
+  RegexpPtr ast = Simplify(Parse(pattern, kPerl));
+  Prog prog = Compile(ast);
+  if (IsAnchored(prog)) { u.why = "anchored"; return u; }
+  if (MinMatchLen(ast.get()) < 1) { u.why = "can match empty"; return u; }
+  // the search prefix  L: Alt(Capture0 -> start, AnyByte -> L)  (BuildOptions::unanchored_search)
+  const uint32_t L = (uint32_t)prog.inst.size(), C0 = L + 1, A = L + 2;
+  {
+    Inst alt; alt.op = InstAlt; alt.out = C0; alt.arg = A;
+    Inst cap; cap.op = InstCapture; cap.arg = 0; cap.out = (uint32_t)prog.start;
+    Inst any; any.op = InstRuneAny; any.out = L;
+    prog.inst.push_back(alt); prog.inst.push_back(cap); prog.inst.push_back(any);
+    prog.start = (int)L;
+  }
+  Builder b(prog);
+  u.lookahead = b.lookahead;
+  u.ncls = b.ncls;
+  memcpy(u.cls, b.cls, 256);
+  const int ncls = b.ncls, stride = ncls + 1;
+  for (int c = 0; c < 256; c++) u.ctx_of_byte[c] = (uint8_t)b.CtxOfClass(b.cls[c]);
+  u.ctx_sensitive = b.has_wb || b.has_bol;
+  if (max_regs > kUsRegs) max_regs = kUsRegs;
+
+  // thread tags: exact age >= 0; kSkip = the search loop itself; register j = -(2 + j)
+  constexpr int kSkip = -1;
+  auto is_reg = [](int t) { return t <= -2; };
+  auto reg_of = [](int t) { return -t - 2; };
+  auto reg_tag = [](int j) { return -(2 + j); };
+  typedef std::pair<int, int> Th;                       // (node or pc, tag)
+  struct St { std::vector<Th> list; int ctx; };
+  std::map<std::pair<std::vector<Th>, int>, int> ids;
+  std::vector<St> states;
+  states.push_back({{}, 0});
+  ids[{{}, 0}] = 0;
+  bool fail = false;
+  auto intern = [&](const std::vector<Th>& list, int ctx) -> int {
+    if (list.empty()) return 0;
+    auto key = std::make_pair(list, ctx);
+    auto it = ids.find(key);
+    if (it != ids.end()) return it->second;
+    if ((int)states.size() >= max_states || states.size() >= kUsStateMask) { fail = true; u.why = "state budget"; return 0; }
+    const int id = (int)states.size();
+    states.push_back({list, ctx});
+    ids.emplace(key, id);
+    return id;
+  };
+  // the tag a closure leaf inherits: threads born from the search loop pass Capture 0 (age 0), the loop itself stays the loop
+  auto leaf_tag = [&](const Leaf& l, const std::vector<Th>& src) -> int {
+    const int t = src[l.parent].second;
+    if (t != kSkip) return t;
+    return (l.ops & 1u) ? 0 : kSkip;
+  };
+  // Promote the oldest exact group into a free register (one per edge); returns the register operation of the edge.
+  // A register the edge's match still reads is not free on this edge.
+  auto normalise = [&](std::vector<Th>* list, int* match_tag) -> uint32_t {
+    bool used[kUsRegs] = {false};
+    int oldest = -1;
+    for (auto& t : *list) {
+      if (t.second == kSkip) continue;
+      if (is_reg(t.second)) used[reg_of(t.second)] = true; else oldest = std::max(oldest, t.second);
+    }
+    if (match_tag && is_reg(*match_tag)) used[reg_of(*match_tag)] = true;
+    if (oldest < 0) return 0;
+    int j = 0;
+    while (j < max_regs && used[j]) j++;
+    if (j >= max_regs) return 0;                       // every register is held by an older group: this one keeps its age
+    for (auto& t : *list) if (t.second == oldest) t.second = reg_tag(j);
+    if (match_tag && *match_tag == oldest) *match_tag = reg_tag(j);
+    u.nregs = std::max(u.nregs, j + 1);
+    return kUsSet | ((uint32_t)oldest << kUsDeltaShift) | ((uint32_t)j << kUsRegShift);
+  };
+  auto info_byte = [&](int tag) -> uint16_t { return is_reg(tag) ? (uint16_t)(kUsFromReg | reg_of(tag)) : (uint16_t)tag; };
+
+  // start states
+  for (int ctx = 0; ctx < 4 && !fail; ctx++) {
+    const int rc = b.ReduceCtx(ctx);
+    if (b.lookahead) {
+      u.start[ctx] = (uint16_t)intern({{prog.start, kSkip}}, rc);
+    } else {
+      std::vector<Leaf> leaves;
+      bool m; int mp = 0; uint32_t mo = 0;
+      b.Expand({prog.start}, rc, -1, &leaves, &m, &mp, &mo);
+      if (m) { u.why = "empty match"; return u; }
+      std::vector<Th> src{{prog.start, kSkip}}, list;
+      for (auto& l : leaves) list.push_back({l.node, leaf_tag(l, src)});
+      normalise(&list, nullptr);          // the (re)start itself loads reg[0] := position
+      u.start[ctx] = (uint16_t)intern(list, 0);
+    }
+  }
+
+  for (size_t q = 0; q < states.size() && !fail; q++) {
+    u.trans.resize((q + 1) * stride, 0);
+    u.minfo.resize((q + 1) * stride, 0);
+    if (q == 0) continue;
+    const St st = states[q];
+    for (int k = 0; k <= ncls && !fail; k++) {
+      uint32_t ent = 0;
+      uint16_t mi = 0;
+      // consuming leaves of the source state, each with its tag at the current position
+      std::vector<std::pair<int, int>> leaves;      // (node, tag)
+      if (b.lookahead) {
+        std::vector<int> pre;
+        for (auto& t : st.list) pre.push_back(t.first);
+        std::vector<Leaf> lv;
+        bool matched = false; int mp = 0; uint32_t mo = 0;
+        b.Expand(pre, st.ctx, k, &lv, &matched, &mp, &mo);
+        if (matched) {
+          const int mt = st.list[mp].second;
+          if (mt == kSkip) { fail = true; u.why = "empty match"; break; }
+          ent |= kUsBefore;
+          mi |= info_byte(mt);
+        }
+        for (auto& l : lv) leaves.push_back({l.node, leaf_tag(l, st.list)});
+      } else {
+        for (auto& t : st.list) leaves.push_back(t);
+      }
+      if (k == ncls) { u.trans[q * stride + k] = ent; u.minfo[q * stride + k] = mi; continue; }
+      // step over one byte of class k
+      std::vector<Th> pre;
+      for (auto& l : leaves) {
+        if (!b.NodeAccepts(l.first, k)) continue;
+        const int target = b.Target(l.first, k);
+        bool dup = false;
+        for (auto& x : pre) if (x.first == target) { dup = true; break; }
+        if (dup) continue;                          // lower-priority duplicate
+        int tag = l.second;
+        if (tag >= 0) { tag++; if (tag > kUsMaxAge) { fail = true; u.why = "age"; break; } }
+        pre.push_back({target, tag});
+      }
+      if (fail) break;
+      int nq;
+      if (b.lookahead) {
+        ent |= normalise(&pre, nullptr);
+        nq = intern(pre, b.CtxOfClass(k));
+      } else {
+        std::vector<int> pre_nodes;
+        for (auto& t : pre) pre_nodes.push_back(t.first);
+        std::vector<Leaf> lv;
+        bool matched = false; int mp = 0; uint32_t mo = 0;
+        b.Expand(pre_nodes, b.CtxOfClass(k), -1, &lv, &matched, &mp, &mo);
+        std::vector<Th> list;
+        for (auto& l : lv) list.push_back({l.node, leaf_tag(l, pre)});
+        int mt = 0;
+        if (matched) {
+          mt = pre[mp].second;
+          if (mt == kSkip) { fail = true; u.why = "empty match"; break; }
+        }
+        ent |= normalise(&list, matched ? &mt : nullptr);
+        if (matched) { ent |= kUsAfter; mi |= (uint16_t)(info_byte(mt) << 8); }
+        nq = intern(list, 0);
+      }
+      u.trans[q * stride + k] = ent | (uint32_t)nq;
+      u.minfo[q * stride + k] = mi;
+    }
+  }
+  if (fail) { u.trans.clear(); u.minfo.clear(); return u; }
+  u.nstates = (int)states.size();
+  u.oldest.assign(u.nstates, kUsNone);
+  for (int q = 1; q < u.nstates; q++)
+    for (auto& t : states[q].list) {
+      if (t.second == kSkip) continue;
+      u.oldest[q] = (uint8_t)info_byte(t.second);      // lists are ordered oldest first
+      break;
+    }
+  u.ok = true;
+  return u;
+}
+
 std::string Tables::Describe() const {
   char buf[256];
   snprintf(buf, sizeof buf, "states=%d classes=%d lookahead=%d fixed_caps=%d anchored=%d min=%d max=%d threads<=%d", nstates,

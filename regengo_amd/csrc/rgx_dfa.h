@@ -99,6 +99,47 @@ struct BuildOptions {
   bool unanchored_search = false;
 };
 
+// ---- start-tracking search automaton ("US"): FindAll as ONE table step per input byte ------------------------------------
+// The search automaton (BuildOptions::unanchored_search) finds where the next match ENDS in one forward walk; what it does
+// not know is where that match began.  US is the same subset construction plus a small register file: threads that began
+// at the same offset form a group, groups are ordered by age in the thread list, and every group is tagged either with a
+// register ("my start offset is in register j") or with its exact age in bytes.  The oldest groups hold the registers; an
+// edge may load one register (reg[j] := offset after the byte - delta, when a group is promoted into a free register) and a
+// match edge says where its thread began (reg[j], or match end - age).  Exact ages are part of the state identity and capped
+// (kUsMaxAge): a pattern that keeps more groups alive in loops than there are registers is not eligible (`ok` false) and
+// takes the per-start kernels.
+// The walk from a FindAll sync point: state = start[ctx], reg[0] = position; per byte one entry; a match is final when the
+// state dies (or at the end of the text); FindAll resumes at its end.  Replaces the per-searchStart attempts of
+// find.go:195-300 (try at searchStart, on failure searchStart++) by one pass: same matches, same order.
+constexpr uint32_t kUsStateMask = 0x3FFF;
+constexpr uint32_t kUsBefore = 1u << 14;     // a match ends BEFORE the byte of this edge (lookahead mode); start info = low byte of minfo
+constexpr uint32_t kUsAfter = 1u << 15;      // a match ends AFTER it; start info = high byte of minfo
+constexpr uint32_t kUsSet = 1u << 16;        // reg[j] := (index of the byte + 1) - delta
+constexpr int kUsDeltaShift = 17;            // delta: bits 17..23
+constexpr int kUsRegShift = 24;              // j: bits 24..26
+constexpr int kUsMaxAge = 100;
+constexpr int kUsRegs = 8;
+constexpr uint8_t kUsFromReg = 0x80;         // minfo / oldest byte: 0x80 | j = reg[j] (before the edge's load for kUsBefore, after it
+                                             // for kUsAfter); else the byte is an age: start = match end - age
+constexpr uint8_t kUsNone = 0xFF;            // oldest[q]: no thread alive but the search loop itself
+struct StartSearch {
+  bool ok = false;
+  std::string why;                // why not, when !ok
+  int ncls = 0;                   // class id ncls = end of text
+  uint8_t cls[256] = {0};
+  int nstates = 0;                // including dead state 0
+  int nregs = 0;                  // registers in use (<= kUsRegs)
+  std::vector<uint32_t> trans;    // [nstates][ncls+1]
+  std::vector<uint16_t> minfo;    // [nstates][ncls+1]
+  std::vector<uint8_t> oldest;    // [nstates]: where the OLDEST thread alive in this state began: 0x80|j, or its age (start =
+                                  // current offset - age), or kUsNone.  A walk past the end of a slice of start positions may stop
+                                  // as soon as that start lies beyond the slice.
+  uint16_t start[4] = {0, 0, 0, 0};
+  uint8_t ctx_of_byte[256] = {0};
+  bool ctx_sensitive = false, lookahead = false;
+};
+StartSearch BuildStartSearch(const std::string& pattern, uint32_t flags, int max_states = 3000, int max_regs = kUsRegs);
+
 // Throws SyntaxError / Unsupported / TooLarge.
 Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOptions& opt = BuildOptions());
 

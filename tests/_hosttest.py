@@ -24,6 +24,13 @@ _lib.rgxt_roundtrip.argtypes = [C.c_void_p]
 _lib.rgxt_sa_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
 _lib.rgxt_reset_bytes.argtypes = [C.c_void_p, C.c_void_p]
 
+_lib.rgxt_compile_us.restype = C.c_void_p
+_lib.rgxt_compile_us.argtypes = [C.c_char_p, C.c_uint32, C.c_int, C.c_int]
+_lib.rgxt_free_us.argtypes = [C.c_void_p]
+_lib.rgxt_us_info.argtypes = [C.c_void_p, C.c_void_p]
+_lib.rgxt_us_find_all.restype = C.c_int64
+_lib.rgxt_us_find_all.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64]
+
 INFO = ["ncap", "min", "max", "ninst", "nstates", "ncls", "anchored", "fixed", "empty", "refm", "reff", "look", "maxthr"]
 
 
@@ -101,3 +108,27 @@ def prog_dump(pattern: str) -> str:
     if r < 0:
         raise ValueError(_lib.rgxt_last_error().decode())
     return buf.value.decode("utf-8")
+
+
+class StartSearch:
+    """The start-tracking search automaton (rgx_dfa.h: StartSearch) walked on the CPU the way the scan_us kernel walks it."""
+
+    def __init__(self, pattern: str, flags: int = 0, max_states: int = 0, max_regs: int = 0):
+        self.h = _lib.rgxt_compile_us(pattern.encode("utf-8"), flags, max_states, max_regs)
+        if not self.h:
+            raise ValueError(_lib.rgxt_last_error().decode())
+        a = (C.c_int32 * 5)()
+        _lib.rgxt_us_info(self.h, a)
+        self.nstates, self.ncls, self.lookahead, self.ctx_sensitive, self.nregs = list(a)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            _lib.rgxt_free_us(self.h)
+            self.h = None
+
+    def find_all(self, b: bytes, from_pos: int = 0, slice: int = 0):
+        cap = len(b) + 1
+        out = (C.c_int32 * (2 * cap))()
+        n = _lib.rgxt_us_find_all(self.h, b, len(b), from_pos, out, cap, slice)
+        assert n >= 0
+        return [(out[2 * i], out[2 * i + 1]) for i in range(n)]
