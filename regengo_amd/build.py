@@ -15,7 +15,7 @@ CSRC = os.path.join(ROOT, "regengo_amd", "csrc")
 LIBDIR = os.path.join(ROOT, "regengo_amd", "lib")
 ORACLE = os.path.join(ROOT, "oracle")
 
-PRODUCT_SOURCES = ["rgx_syntax.cc", "rgx_dfa.cc", "rgx_program.cc", "rgx_kernels.hip", "rgx_scan_exact.hip", "rgx_scan_sa.hip", "rgx_replace.hip", "rgx_capi.cc"]
+PRODUCT_SOURCES = ["rgx_syntax.cc", "rgx_dfa.cc", "rgx_program.cc", "rgx_kernels.hip", "rgx_scan_exact.hip", "rgx_scan_sa.hip", "rgx_scan_us.hip", "rgx_replace.hip", "rgx_capi.cc"]
 HOSTTEST_SOURCES = ["rgx_syntax.cc", "rgx_dfa.cc", "hosttest/rgx_hosttest.cc"]
 
 

@@ -42,6 +42,11 @@ bool UseSaKernel(const DevTables& T, int32_t len);
 int SaTileBytes();
 hipError_t LaunchScanSa(const DevTables& T, const ScanParams& P, const uint16_t* class_table, hipStream_t stream);  // tiles (= look-back descriptors) the scan of `len` bytes uses
 
+// rgx_scan_us.hip: one table step per input byte over the start-tracking search automaton (rgx_program.h: UsDev); takes
+// unanchored patterns that cannot match empty whenever sync points come from reset bytes or the carry pass (not use_w)
+bool UseUsKernel(const DevTables& T, int32_t len, bool use_w);
+hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t stream);
+
 // Serial carry resolution for slices without a local sync point (rare path).
 hipError_t LaunchCarry(const DevTables& T, const uint8_t* buf, int32_t len, const uint8_t* slice_unsynced, int32_t* carry_in,
                        int32_t nslices, hipStream_t stream);

@@ -1299,6 +1299,7 @@ size_t ScanSharedBytes(const DevTables& T) {
 
 int32_t ScanNumTiles(const DevTables& T, int32_t len, bool use_w) {
   if (UseExactKernel(T, len)) return ExactNumBlocks(T, len);
+  if (UseUsKernel(T, len, use_w)) return (len + kTileBytes - 1) / kTileBytes;
   const int per = (UseSaKernel(T, len) && !getenv("RGX_NO_SA_KERNEL") && !use_w) ? SaTileBytes() : kTileBytes;
   return (len + per - 1) / per;
 }
@@ -1307,6 +1308,7 @@ bool ScanSupportsW(const DevTables& T, int32_t len) { return T.w_nstates > 0 && 
 
 hipError_t LaunchScan(const DevTables& T, const ScanParams& P, hipStream_t stream) {
   if (UseExactKernel(T, P.len)) return LaunchScanExact(T, P, stream);
+  if (UseUsKernel(T, P.len, P.use_w != 0)) return LaunchScanUs(T, P, stream);
   if (UseSaKernel(T, P.len) && !getenv("RGX_NO_SA_KERNEL") && !P.use_w) return LaunchScanSa(T, P, T.trans_cls, stream);
   // The generic kernel stages its transition table once per 16 KiB tile: a table that is not small next to the tile costs
   // more L2->LDS traffic than the input itself and, through its LDS footprint, most of the CU's occupancy (`\\p{L}+`: 75 KB

@@ -1,5 +1,6 @@
 #include "rgx_program.h"
 
+#include <cstdlib>
 #include <cstring>
 
 #include "rgx.h"
@@ -11,10 +12,11 @@ void SetError(const std::string& s) { g_error = s; }
 const std::string& GetError() { return g_error; }
 
 Program::~Program() {
-  if (d_arena || d_arena_u) {
+  if (d_arena || d_arena_u || d_arena_us) {
     hipSetDevice(device);
     if (d_arena) hipFree(d_arena);
     if (d_arena_u) hipFree(d_arena_u);
+    if (d_arena_us) hipFree(d_arena_us);
   }
 }
 
@@ -175,6 +177,68 @@ int UploadTables(const Tables& t, std::vector<uint16_t>* direct_table, DevTables
 }
 }  // namespace
 
+namespace {
+constexpr int kUsMaxEntries = 4096;      // 32 KiB of LDS for the table at most (most automata: a few hundred bytes)
+
+// Start-tracking search automaton: the fewest registers (1, 2, 4) with which the pattern is eligible and the table fits.
+bool BuildUs(Program* p) {
+  static const bool off = getenv("RGX_NO_US") != nullptr;
+  if (off || p->t.anchored || p->t.can_match_empty) return false;
+  for (int regs : {1, 2, 4}) {
+    try {
+      StartSearch u = BuildStartSearch(p->t.pattern, p->t.flags, 2000, regs);
+      if (!u.ok || (int64_t)u.nstates * (u.ncls + 1) > kUsMaxEntries) continue;
+      p->us = std::move(u);
+      return true;
+    } catch (...) {
+      return false;
+    }
+  }
+  return false;
+}
+
+int UploadUs(Program* p) {
+  const StartSearch& u = p->us;
+  const int stride = u.ncls + 1;
+  const int nent = u.nstates * stride;
+  std::vector<unsigned long long> ent((size_t)nent, 0);
+  for (int q = 0; q < u.nstates; q++)
+    for (int k = 0; k < stride; k++) {
+      const uint32_t e = u.trans[(size_t)q * stride + k];
+      const uint16_t mi = u.minfo[(size_t)q * stride + k];
+      const uint32_t nq = e & kUsStateMask;
+      uint32_t lo = (nq * (uint32_t)stride) | (e & (kUsBefore | kUsAfter));
+      if (e & kUsSet) lo |= (1u << (16 + ((e >> kUsRegShift) & 7))) | (((e >> kUsDeltaShift) & 0x7Fu) << 20);
+      const uint32_t hi = (uint32_t)mi | ((uint32_t)u.oldest[nq] << 16);
+      ent[(size_t)q * stride + k] = ((unsigned long long)hi << 32) | lo;
+    }
+  std::vector<uint16_t> srow(stride);
+  std::vector<uint8_t> rst(stride, 0);
+  for (int k = 0; k < u.ncls; k++) {
+    int rep = 0;
+    while (u.cls[rep] != k) rep++;
+    srow[k] = (uint16_t)(u.start[u.ctx_of_byte[rep]] * stride);
+    bool all = true;
+    for (int c = 0; c < 256; c++) if (u.cls[c] == k && !p->t.reset_byte[c]) all = false;
+    rst[k] = all ? 1 : 0;
+  }
+  srow[u.ncls] = (uint16_t)(u.start[kCtxBOT] * stride);
+  Arena a;
+  const size_t off_ent = a.AddVec(ent), off_cls = a.Add(u.cls, 256), off_srow = a.AddVec(srow), off_rst = a.AddVec(rst);
+  void* dptr = nullptr;
+  if (hipMalloc(&dptr, a.host.size()) != hipSuccess) { SetError("hipMalloc(us tables) failed"); return RGX_E_NOMEM; }
+  if (hipMemcpy(dptr, a.host.data(), a.host.size(), hipMemcpyHostToDevice) != hipSuccess) { hipFree(dptr); SetError("hipMemcpy(us tables) failed"); return RGX_E_HIP; }
+  uint8_t* b = (uint8_t*)dptr;
+  UsDev d{};
+  d.ent = (const unsigned long long*)(b + off_ent); d.cls = b + off_cls;
+  d.start_row_of_cls = (const uint16_t*)(b + off_srow); d.reset_of_cls = b + off_rst;
+  d.nent = nent; d.stride = stride; d.ncls = u.ncls; d.nregs = u.nregs <= 1 ? 1 : (u.nregs <= 2 ? 2 : 4); d.lookahead = u.lookahead ? 1 : 0;
+  p->usdev = d;
+  p->d_arena_us = dptr;
+  return RGX_OK;
+}
+}  // namespace
+
 int ProgramToDevice(Program* p, int device) {
   std::lock_guard<std::mutex> lock(p->mu);
   if (p->d_arena) {
@@ -197,6 +261,9 @@ int ProgramToDevice(Program* p, int device) {
   p->dev = d;
   p->d_arena = dptr;
   p->device = device;
+  p->us_ok = BuildUs(p);
+  if (p->us_ok && UploadUs(p) != RGX_OK) p->us_ok = false;
+  p->dev.us = p->us_ok ? &p->usdev : nullptr;
   return RGX_OK;
 }
 

@@ -24,6 +24,8 @@ enum TableMode : int {
   kModeClassGlobal = 2 // cls in LDS, transition table read through L1/L2 (too big for LDS)
 };
 
+struct UsDev;
+
 // Flat device image of one compiled pattern.  All pointers are device addresses.
 struct DevTables {
   const uint16_t* trans;      // layout depends on mode (direct: [nstates][256] then eot[nstates])
@@ -58,13 +60,36 @@ struct DevTables {
   int32_t sa_first_bytes;         // number of byte values that can start a match (selectivity of the prefilter)
   int32_t bt_pool_n, start_pool_n; // entries in bt_parent/bt_ops and in start_ops_pool
   int32_t sa_smin;                // exact chains: smallest shift s>=1 at which two matches can overlap (sa_k: never)
+  const UsDev* us;                // HOST pointer to the program's UsDev when the pattern is eligible for rgx_scan_us.hip, else nullptr
   uint16_t start[4];
   uint8_t start_accept[4];
   uint8_t lookahead, ctx_sensitive, bot_sensitive, anchored, fixed_captures, unmatched_minus1, pad0, pad1;
 };
 
+// Device image of the start-tracking search automaton (rgx_dfa.h: StartSearch) for rgx_scan_us.hip.  Entries are 64 bit:
+//   low word   [0..13] row of the next state (entry index of its first column; 0 = dead)  [14] match ends before the byte
+//              [15] match ends after it   [16..19] load mask: reg[j] := offset after the byte - delta   [20..26] delta
+//   high word  [0..7] start info of the before-match  [8..15] of the after-match  [16..23] where the oldest thread of the
+//              NEXT state began (kUsFromReg | j, an age, or kUsNone) -- the rule that ends a lane's walk past its slice
+struct UsDev {
+  const unsigned long long* ent;  // [nent]
+  const uint8_t* cls;             // [256] byte -> class (class ncls = end of text)
+  const uint16_t* start_row_of_cls;   // [ncls+1]: row of the start state after a byte of this class (index ncls: offset 0 of the text)
+  const uint8_t* reset_of_cls;    // [ncls+1]: 1 = every anchored thread dies on a byte of this class (sync point behind it)
+  int32_t nent;                   // entries = nstates * stride
+  int32_t stride;                 // ncls + 1
+  int32_t ncls;
+  int32_t nregs;                  // registers the automaton uses (1, 2 or 4 in the kernel's instantiations)
+  int32_t lookahead;              // 1: match flags are kUsBefore (lazy construction), 0: kUsAfter
+};
+
 struct Program {
   Tables t;
+  // start-tracking search automaton for the one-step-per-byte scan kernel; built at upload; us_ok false: not eligible
+  StartSearch us;
+  bool us_ok = false;
+  UsDev usdev{};
+  void* d_arena_us = nullptr;
   std::vector<uint8_t> blob_cache;
   // search automaton (BuildOptions::unanchored_search) for the per-string entry points; built lazily, absent when the
   // pattern is anchored or the automaton exceeds its state budget
