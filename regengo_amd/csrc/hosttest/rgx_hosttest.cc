@@ -312,26 +312,37 @@ int64_t rgxt_us_find_all(void* hh, const uint8_t* buf, int64_t len, int64_t from
     while (pos < len && pos < slice_end) {
       const int ctx = pos == 0 ? kCtxBOT : u.ctx_of_byte[buf[pos - 1]];
       uint32_t q = u.start[ctx];
-      reg[0] = pos;
       int64_t pe = -1, ps = -1, i = pos;
+      bool final_seen = false;
+      int64_t final_ps = 0;
       while (true) {
         if (i >= slice_end && pe < 0) {
           // past the slice with nothing pending: stop unless a thread that began inside the slice is still alive
           const uint8_t o = u.oldest[q];
           if (o == kUsNone || start_of(o, i) >= slice_end) { stopped_by_rule = true; break; }
         }
-        if (i >= slice_end && pe >= 0) {
-          const uint8_t o = u.oldest[q];
-          if (ps >= slice_end && (o == kUsNone || start_of(o, i) >= slice_end)) { stopped_by_rule = true; pe = -1; break; }
-        }
         const int k = i < len ? u.cls[buf[i]] : u.ncls;
         const uint32_t e = u.trans[(size_t)q * stride + k];
         const uint16_t mi = u.minfo[(size_t)q * stride + k];
         if (e & kUsBefore) { pe = i; ps = start_of((uint8_t)(mi & 0xFF), i); }
+        if (e & kUsFinal) {
+          // the pending match ends here, for good, and the search has resumed at this byte
+          if (pe != i || pe <= ps) return -2;
+          if (ps < slice_end) {
+            if (count < cap) { spans[2 * count] = (int32_t)ps; spans[2 * count + 1] = (int32_t)pe; }
+            count++;
+          } else {
+            final_seen = true;     // the next lane's match
+            final_ps = ps;
+          }
+          pe = -1;
+          pos = i;               // the search stands here now
+        }
         if (e & kUsSet) reg[(e >> kUsRegShift) & 7] = i + 1 - (int64_t)((e >> kUsDeltaShift) & 0x7F);
         if (e & kUsAfter) { pe = i + 1; ps = start_of((uint8_t)(mi >> 8), i + 1); }
         q = e & kUsStateMask;
         i++;
+        if (final_seen) { stopped_by_rule = true; pos = final_ps; break; }
         if (q == 0 || k == u.ncls) break;
       }
       if (stopped_by_rule) break;

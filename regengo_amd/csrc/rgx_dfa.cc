@@ -722,21 +722,25 @@ StartSearch BuildStartSearch(const std::string& pattern, uint32_t flags, int max
   auto reg_of = [](int t) { return -t - 2; };
   auto reg_tag = [](int j) { return -(2 + j); };
   typedef std::pair<int, int> Th;                       // (node or pc, tag)
-  struct St { std::vector<Th> list; int ctx; };
+  // State identity.  Lazy (lookahead) construction: thread list before the closure + the previous byte's context.  Eager:
+  // thread list after the closure + (patterns with (?m)^ only) the previous byte's context + kAccBit when a match ends exactly
+  // where the state stands + kFreshBit when, besides, every thread began right there (the search has resumed at that match's end).
+  constexpr int kAccBit = 16, kFreshBit = 32;
+  struct St { std::vector<Th> list; int key; };
   std::map<std::pair<std::vector<Th>, int>, int> ids;
   std::vector<St> states;
   states.push_back({{}, 0});
   ids[{{}, 0}] = 0;
   bool fail = false;
-  auto intern = [&](const std::vector<Th>& list, int ctx) -> int {
+  auto intern = [&](const std::vector<Th>& list, int key) -> int {
     if (list.empty()) return 0;
-    auto key = std::make_pair(list, ctx);
-    auto it = ids.find(key);
+    auto k2 = std::make_pair(list, key);
+    auto it = ids.find(k2);
     if (it != ids.end()) return it->second;
     if ((int)states.size() >= max_states || states.size() >= kUsStateMask) { fail = true; u.why = "state budget"; return 0; }
     const int id = (int)states.size();
-    states.push_back({list, ctx});
-    ids.emplace(key, id);
+    states.push_back({list, key});
+    ids.emplace(k2, id);
     return id;
   };
   // the tag a closure leaf inherits: threads born from the search loop pass Capture 0 (age 0), the loop itself stays the loop
@@ -746,7 +750,7 @@ StartSearch BuildStartSearch(const std::string& pattern, uint32_t flags, int max
     return (l.ops & 1u) ? 0 : kSkip;
   };
   // Promote the oldest exact group into a free register (one per edge); returns the register operation of the edge.
-  // A register the edge's match still reads is not free on this edge.
+  // A register the edge's match reads is not free on this edge.
   auto normalise = [&](std::vector<Th>* list, int* match_tag) -> uint32_t {
     bool used[kUsRegs] = {false};
     int oldest = -1;
@@ -755,7 +759,8 @@ StartSearch BuildStartSearch(const std::string& pattern, uint32_t flags, int max
       if (is_reg(t.second)) used[reg_of(t.second)] = true; else oldest = std::max(oldest, t.second);
     }
     if (match_tag && is_reg(*match_tag)) used[reg_of(*match_tag)] = true;
-    if (oldest < 0) return 0;
+    if (oldest < 1) return 0;        // threads born at the current offset (age 0) are promoted once they survive a byte:
+                                     // every register load is then an explicit part of an edge, also after a (re)start
     int j = 0;
     while (j < max_regs && used[j]) j++;
     if (j >= max_regs) return 0;                       // every register is held by an older group: this one keeps its age
@@ -765,6 +770,16 @@ StartSearch BuildStartSearch(const std::string& pattern, uint32_t flags, int max
     return kUsSet | ((uint32_t)oldest << kUsDeltaShift) | ((uint32_t)j << kUsRegShift);
   };
   auto info_byte = [&](int tag) -> uint16_t { return is_reg(tag) ? (uint16_t)(kUsFromReg | reg_of(tag)) : (uint16_t)tag; };
+  // eager mode: the start state's thread list for a previous-byte context (fresh threads: age 0)
+  auto eager_start_list = [&](int rc, std::vector<Th>* list) -> bool {
+    std::vector<Leaf> leaves;
+    bool m; int mp = 0; uint32_t mo = 0;
+    b.Expand({prog.start}, rc, -1, &leaves, &m, &mp, &mo);
+    if (m) return false;
+    std::vector<Th> src{{prog.start, kSkip}};
+    for (auto& l : leaves) list->push_back({l.node, leaf_tag(l, src)});
+    return true;
+  };
 
   // start states
   for (int ctx = 0; ctx < 4 && !fail; ctx++) {
@@ -772,25 +787,25 @@ StartSearch BuildStartSearch(const std::string& pattern, uint32_t flags, int max
     if (b.lookahead) {
       u.start[ctx] = (uint16_t)intern({{prog.start, kSkip}}, rc);
     } else {
-      std::vector<Leaf> leaves;
-      bool m; int mp = 0; uint32_t mo = 0;
-      b.Expand({prog.start}, rc, -1, &leaves, &m, &mp, &mo);
-      if (m) { u.why = "empty match"; return u; }
-      std::vector<Th> src{{prog.start, kSkip}}, list;
-      for (auto& l : leaves) list.push_back({l.node, leaf_tag(l, src)});
-      normalise(&list, nullptr);          // the (re)start itself loads reg[0] := position
-      u.start[ctx] = (uint16_t)intern(list, 0);
+      std::vector<Th> list;
+      if (!eager_start_list(rc, &list)) { u.why = "empty match"; return u; }
+      u.start[ctx] = (uint16_t)intern(list, b.has_bol ? rc : 0);
     }
   }
 
+  struct Fold { int q, k, sctx; bool all; };
+  std::vector<Fold> fold;      // edges that end a match and resume the search on the same byte (kUsFinal)
   for (size_t q = 0; q < states.size() && !fail; q++) {
     u.trans.resize((q + 1) * stride, 0);
     u.minfo.resize((q + 1) * stride, 0);
     if (q == 0) continue;
     const St st = states[q];
+    const int st_ctx = st.key & 15;
     for (int k = 0; k <= ncls && !fail; k++) {
       uint32_t ent = 0;
       uint16_t mi = 0;
+      int look_mt = 0;
+      bool look_matched = false;
       // consuming leaves of the source state, each with its tag at the current position
       std::vector<std::pair<int, int>> leaves;      // (node, tag)
       if (b.lookahead) {
@@ -798,12 +813,14 @@ StartSearch BuildStartSearch(const std::string& pattern, uint32_t flags, int max
         for (auto& t : st.list) pre.push_back(t.first);
         std::vector<Leaf> lv;
         bool matched = false; int mp = 0; uint32_t mo = 0;
-        b.Expand(pre, st.ctx, k, &lv, &matched, &mp, &mo);
+        b.Expand(pre, st_ctx, k, &lv, &matched, &mp, &mo);
         if (matched) {
           const int mt = st.list[mp].second;
           if (mt == kSkip) { fail = true; u.why = "empty match"; break; }
           ent |= kUsBefore;
           mi |= info_byte(mt);
+          look_mt = mt;
+          look_matched = true;
         }
         for (auto& l : lv) leaves.push_back({l.node, leaf_tag(l, st.list)});
       } else {
@@ -825,14 +842,17 @@ StartSearch BuildStartSearch(const std::string& pattern, uint32_t flags, int max
       if (fail) break;
       int nq;
       if (b.lookahead) {
-        ent |= normalise(&pre, nullptr);
+        ent |= normalise(&pre, look_matched ? &look_mt : nullptr);     // the register the match reads is not reloaded on its edge
         nq = intern(pre, b.CtxOfClass(k));
+        // the match ends before this byte and nothing survives it: the search resumes AT this byte
+        if (look_matched && pre.empty() && st_ctx != kCtxBOT) fold.push_back({(int)q, k, st_ctx, false});
       } else {
         std::vector<int> pre_nodes;
         for (auto& t : pre) pre_nodes.push_back(t.first);
         std::vector<Leaf> lv;
         bool matched = false; int mp = 0; uint32_t mo = 0;
-        b.Expand(pre_nodes, b.CtxOfClass(k), -1, &lv, &matched, &mp, &mo);
+        const int cxk = b.CtxOfClass(k);
+        b.Expand(pre_nodes, cxk, -1, &lv, &matched, &mp, &mo);
         std::vector<Th> list;
         for (auto& l : lv) list.push_back({l.node, leaf_tag(l, pre)});
         int mt = 0;
@@ -842,13 +862,40 @@ StartSearch BuildStartSearch(const std::string& pattern, uint32_t flags, int max
         }
         ent |= normalise(&list, matched ? &mt : nullptr);
         if (matched) { ent |= kUsAfter; mi |= (uint16_t)(info_byte(mt) << 8); }
-        nq = intern(list, 0);
+        const int cx = b.has_bol ? cxk : 0;
+        if (matched && list.empty()) {
+          // the match ends after this byte and nothing else is alive: the search resumes behind it -- the next state is the
+          // start state for this byte's context, marked "a match ends here, every thread is fresh": all its edges are final
+          std::vector<Th> sl;
+          eager_start_list(b.ReduceCtx(cxk), &sl);
+          nq = intern(sl, cx | kAccBit | kFreshBit);
+          ent &= ~(kUsSet | (0x7Fu << kUsDeltaShift) | (7u << kUsRegShift));     // (no thread left: nothing was promoted)
+        } else {
+          nq = intern(list, cx | (matched ? kAccBit : 0));
+          // a state where a match ends dies on the very next byte: the search resumes at that byte
+          if (list.empty() && (st.key & kAccBit) && !(st.key & kFreshBit)) fold.push_back({(int)q, k, b.has_bol ? st_ctx : (int)kCtxOther, false});
+        }
       }
       u.trans[q * stride + k] = ent | (uint32_t)nq;
       u.minfo[q * stride + k] = mi;
     }
+    if (!b.lookahead && (st.key & kFreshBit))
+      for (int k = 0; k < ncls; k++) fold.push_back({(int)q, k, b.has_bol ? st_ctx : (int)kCtxOther, true});
   }
   if (fail) { u.trans.clear(); u.minfo.clear(); return u; }
+  // kUsFinal edges: the pending match is final and the edge is the start state's own edge for the byte.  (A fresh state IS the
+  // start state plus the pending match, so its own entries already are those edges.)
+  for (const Fold& f : fold) {
+    uint32_t& e = u.trans[(size_t)f.q * stride + f.k];
+    uint16_t& m = u.minfo[(size_t)f.q * stride + f.k];
+    if (f.all) { e |= kUsFinal; continue; }
+    const int s0 = u.start[f.sctx];
+    const uint32_t e0 = u.trans[(size_t)s0 * stride + f.k];
+    const uint16_t m0 = u.minfo[(size_t)s0 * stride + f.k];
+    if (e0 & (kUsBefore | kUsFinal)) continue;               // (cannot happen: the start state has no match before its first byte)
+    e = (e & kUsBefore) | kUsFinal | e0;
+    m = (uint16_t)((m & 0x00FF) | (m0 & 0xFF00));
+  }
   u.nstates = (int)states.size();
   u.oldest.assign(u.nstates, kUsNone);
   for (int q = 1; q < u.nstates; q++)

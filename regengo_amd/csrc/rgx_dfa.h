@@ -108,8 +108,8 @@ struct BuildOptions {
 // match edge says where its thread began (reg[j], or match end - age).  Exact ages are part of the state identity and capped
 // (kUsMaxAge): a pattern that keeps more groups alive in loops than there are registers is not eligible (`ok` false) and
 // takes the per-start kernels.
-// The walk from a FindAll sync point: state = start[ctx], reg[0] = position; per byte one entry; a match is final when the
-// state dies (or at the end of the text); FindAll resumes at its end.  Replaces the per-searchStart attempts of
+// The walk from a FindAll sync point: state = start[ctx] (registers need no initial value); per byte one entry; a match is final on a kUsFinal
+// edge, or when the state dies with a match pending (the walk then rewinds to the match's end), or at the end of the text.  Replaces the per-searchStart attempts of
 // find.go:195-300 (try at searchStart, on failure searchStart++) by one pass: same matches, same order.
 constexpr uint32_t kUsStateMask = 0x3FFF;
 constexpr uint32_t kUsBefore = 1u << 14;     // a match ends BEFORE the byte of this edge (lookahead mode); start info = low byte of minfo
@@ -117,6 +117,10 @@ constexpr uint32_t kUsAfter = 1u << 15;      // a match ends AFTER it; start inf
 constexpr uint32_t kUsSet = 1u << 16;        // reg[j] := (index of the byte + 1) - delta
 constexpr int kUsDeltaShift = 17;            // delta: bits 17..23
 constexpr int kUsRegShift = 24;              // j: bits 24..26
+constexpr uint32_t kUsFinal = 1u << 27;      // the pending match (it ends at the offset of this edge's byte) is FINAL and the search
+                                             // has already resumed there: the rest of the entry is the start state's own edge for the
+                                             // byte.  The common death of a match -- the byte right behind it kills every thread --
+                                             // costs no extra step this way.
 constexpr int kUsMaxAge = 100;
 constexpr int kUsRegs = 8;
 constexpr uint8_t kUsFromReg = 0x80;         // minfo / oldest byte: 0x80 | j = reg[j] (before the edge's load for kUsBefore, after it

@@ -187,7 +187,7 @@ bool BuildUs(Program* p) {
   for (int regs : {1, 2, 4}) {
     try {
       StartSearch u = BuildStartSearch(p->t.pattern, p->t.flags, 2000, regs);
-      if (!u.ok || (int64_t)u.nstates * (u.ncls + 1) > kUsMaxEntries) continue;
+      if (!u.ok || (int64_t)u.nstates * (u.ncls + 1) > kUsMaxEntries || u.ncls + 1 > 32) continue;   // class * 8 is one byte of the LDS tile
       p->us = std::move(u);
       return true;
     } catch (...) {
@@ -207,8 +207,12 @@ int UploadUs(Program* p) {
       const uint32_t e = u.trans[(size_t)q * stride + k];
       const uint16_t mi = u.minfo[(size_t)q * stride + k];
       const uint32_t nq = e & kUsStateMask;
-      uint32_t lo = (nq * (uint32_t)stride) | (e & (kUsBefore | kUsAfter));
-      if (e & kUsSet) lo |= (1u << (16 + ((e >> kUsRegShift) & 7))) | (((e >> kUsDeltaShift) & 0x7Fu) << 20);
+      uint32_t lo = nq * (uint32_t)stride * 8u;            // byte offset of the next state's row
+      lo |= ((e >> kUsDeltaShift) & 0x7Fu) << 16;
+      if (nq == 0 && q != 0) lo |= 1u << 24;               // every thread dies on this edge (the dead state's own row stays all zero)
+      if (e & kUsFinal) lo |= 1u << 25;
+      if (e & (kUsBefore | kUsAfter)) lo |= 1u << 26;      // one flag: a construction is either lazy (before) or eager (after)
+      if (e & kUsSet) lo |= 1u << (31 - ((e >> kUsRegShift) & 7));
       const uint32_t hi = (uint32_t)mi | ((uint32_t)u.oldest[nq] << 16);
       ent[(size_t)q * stride + k] = ((unsigned long long)hi << 32) | lo;
     }
@@ -217,12 +221,12 @@ int UploadUs(Program* p) {
   for (int k = 0; k < u.ncls; k++) {
     int rep = 0;
     while (u.cls[rep] != k) rep++;
-    srow[k] = (uint16_t)(u.start[u.ctx_of_byte[rep]] * stride);
+    srow[k] = (uint16_t)(u.start[u.ctx_of_byte[rep]] * stride * 8);
     bool all = true;
     for (int c = 0; c < 256; c++) if (u.cls[c] == k && !p->t.reset_byte[c]) all = false;
     rst[k] = all ? 1 : 0;
   }
-  srow[u.ncls] = (uint16_t)(u.start[kCtxBOT] * stride);
+  srow[u.ncls] = (uint16_t)(u.start[kCtxBOT] * stride * 8);
   Arena a;
   const size_t off_ent = a.AddVec(ent), off_cls = a.Add(u.cls, 256), off_srow = a.AddVec(srow), off_rst = a.AddVec(rst);
   void* dptr = nullptr;

@@ -67,14 +67,16 @@ struct DevTables {
 };
 
 // Device image of the start-tracking search automaton (rgx_dfa.h: StartSearch) for rgx_scan_us.hip.  Entries are 64 bit:
-//   low word   [0..13] row of the next state (entry index of its first column; 0 = dead)  [14] match ends before the byte
-//              [15] match ends after it   [16..19] load mask: reg[j] := offset after the byte - delta   [20..26] delta
+//   low word   [0..15] BYTE offset of the next state's row in the table (0 = dead)   [16..22] delta of the register load
+//              [24] every thread dies on this edge   [25] kUsFinal   [26] a match ends here (before the byte in a lazy
+//              construction, after it in an eager one)   [31..28] load reg 0..3 := offset after the byte - delta
 //   high word  [0..7] start info of the before-match  [8..15] of the after-match  [16..23] where the oldest thread of the
 //              NEXT state began (kUsFromReg | j, an age, or kUsNone) -- the rule that ends a lane's walk past its slice
+// The dead state's own row (row 0) is all zero: a lane parked there raises no flag and loads nothing.
 struct UsDev {
   const unsigned long long* ent;  // [nent]
   const uint8_t* cls;             // [256] byte -> class (class ncls = end of text)
-  const uint16_t* start_row_of_cls;   // [ncls+1]: row of the start state after a byte of this class (index ncls: offset 0 of the text)
+  const uint16_t* start_row_of_cls;   // [ncls+1]: row (byte offset) of the start state after a byte of this class (index ncls: offset 0 of the text)
   const uint8_t* reset_of_cls;    // [ncls+1]: 1 = every anchored thread dies on a byte of this class (sync point behind it)
   int32_t nent;                   // entries = nstates * stride
   int32_t stride;                 // ncls + 1

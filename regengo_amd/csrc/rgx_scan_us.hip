@@ -6,12 +6,19 @@
 // ends, and a register file of at most four offsets (VGPRs) says where it began.
 //
 //   tile     one workgroup = 256 lanes = 16 KiB of input (+ 256 B of look-behind and look-ahead), staged from HBM with
-//            coalesced 16-byte loads and TRANSLATED TO BYTE CLASSES on the way into LDS (one 256-byte map lookup per byte,
-//            off the walk's dependency chain): the walk's table index is row + class, one 64-bit LDS read per step.
+//            coalesced 16-byte loads and TRANSLATED TO BYTE CLASSES (x8: the byte offset of a table column) on the way into
+//            LDS -- one 256-byte map lookup per byte, off the walk's dependency chain.
 //   lane     owns the 64 START positions of its slice (the other scan kernels' ownership rule, so carry positions, shard
 //            ownership and the sync machinery are shared).  It starts at a FindAll sync point at or before its slice --
 //            after a reset byte, or where the carry pass says -- walks to the end of its slice and on until no thread that
-//            began inside the slice is alive (entry field "oldest"), restarting at the end of every match.
+//            began inside the slice is alive (entry field "oldest").
+//   loop     wave-uniform: the first version branched per lane on every event and was bound by the SCALAR unit (34 SALU
+//            instructions per step for the exec-mask bookkeeping).  Now every lane executes every step: four steps per trip
+//            over one aligned dword of classes (table address = one SDWA add), per-lane conditions are selects, lanes that
+//            are done park in the dead state's row (all-zero entries: no flags, no loads), and ONE branch per step enters the
+//            event block when any lane of the wave ends a match (kUsFinal) or dies.  A walk that has to rewind (a match
+//            followed by bytes that kept older threads alive) or leaves the LDS window is finished by the per-lane
+//            single-step walker below -- rare.
 //   order    per-lane popcounts -> wave scan -> block scan -> decoupled look-back over tiles; records leave in match order.
 // HBM-bound byte work, no MFMA (a dependent table walk is not a contraction).
 #include <hip/hip_runtime.h>
@@ -30,27 +37,22 @@ constexpr int kUPadded = kUWindow + (kUWindow / 64) * 4;    // 64-byte rows padd
 constexpr int kUMaxLookBehind = 1024;                       // a lane re-walks at most this far from its sync point
 __device__ __forceinline__ int UPad(int rel) { return rel + ((rel >> 6) << 2); }
 
+// device entry fields (rgx_program.h: UsDev)
+constexpr unsigned kEDead = 1u << 24, kEFinal = 1u << 25, kEMatch = 1u << 26;
+constexpr unsigned kELoad0 = 1u << 31, kELoad1 = 1u << 30, kELoad2 = 1u << 29, kELoad3 = 1u << 28;
+
 struct UIn {
   const uint8_t* g;          // global input
   const uint8_t* gcls;       // global byte -> class map (bytes outside the LDS window)
-  const unsigned char* tile; // LDS window of CLASS ids
-  int wb, wvalid, len, eot;
-  __device__ __forceinline__ int At(int i) const {
+  const unsigned char* tile; // LDS window: class id * 8
+  int wb, wlim, len, eot8;   // wlim: staged positions (those at or beyond len hold the end-of-text class)
+  __device__ __forceinline__ unsigned At8(int i) const {
     const unsigned rel = (unsigned)(i - wb);
-    if (rel < (unsigned)wvalid) return tile[UPad((int)rel)];
-    if (i >= len) return eot;
-    return gcls[g[i]];
+    if (rel < (unsigned)wlim) return tile[UPad((int)rel)];
+    if (i >= len) return (unsigned)eot8;
+    return (unsigned)gcls[g[i]] << 3;
   }
 };
-
-template <int NREG>
-__device__ __forceinline__ int UsReg(const int (&r)[NREG], unsigned info) {
-  if (NREG == 1) return r[0];
-  if (NREG == 2) return (info & 1u) ? r[1] : r[0];
-  const int lo = (info & 1u) ? r[1 % NREG] : r[0];
-  const int hi = (info & 1u) ? r[3 % NREG] : r[2 % NREG];
-  return (info & 2u) ? hi : lo;
-}
 
 __device__ __forceinline__ void UsWriteFixed(int32_t* rec, int ncap, const uint8_t* kind, const int32_t* delta, int s, int e) {
   if ((ncap & 3) == 0) {
@@ -85,6 +87,77 @@ __host__ __device__ inline UsLayout UsLds(int nent, int stride) {
   return L;
 }
 
+struct UsOut {
+  unsigned long long mask;   // starts of the lane's matches, bit s - a
+  unsigned long long ends;   // their ends, bit e - a - 1 (the k-th start pairs with the k-th end); the last may lie beyond:
+  int last_end;
+};
+
+#define US_START(info) (NREG == 1 ? r0 : (NREG == 2 ? (((info) & 1u) ? r1 : r0) : (((info) & 2u) ? (((info) & 1u) ? r3 : r2) : (((info) & 1u) ? r1 : r0))))
+#define US_INFO(word) (LOOK ? ((word) & 255u) : (((word) >> 8) & 255u))
+
+// Per-lane single-step walker: from the sync point `pos` to the end of the slice [a, slice_end) and on until no thread that
+// began inside the slice is alive.  Reads anything the LDS window lacks from global memory.  The finishing path of the
+// wave-uniform loop below (rewinds, walks that leave the window) -- correct for every walk, just slow.
+template <int NREG, bool LOOK>
+__device__ __noinline__ void UsWalkSlow(const unsigned char* s_entb, const uint16_t* s_srow, const UIn& in, int pos, int a, int slice_end,
+                                        UsOut& out) {
+#define US_RECORD(S, E)                                               \
+  if ((S) >= a && (S) < slice_end) {                                  \
+    out.mask |= 1ull << ((S) - a);                                    \
+    const int re_ = (E) - a - 1;                                      \
+    if (re_ < 64) out.ends |= 1ull << re_; else out.last_end = (E);   \
+  }
+  int i = pos;
+  unsigned row = s_srow[(i > 0 ? in.At8(i - 1) : (unsigned)in.eot8) >> 3];   // offset 0: the begin-of-text start state sits in the EOT column
+  int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+  (void)r1; (void)r2; (void)r3;
+  int pend = -1;
+  unsigned pinfo = 0;
+  for (;;) {
+    const unsigned k8 = in.At8(i);
+    const uint2 ent = *reinterpret_cast<const uint2*>(s_entb + (row & 0xFFFFu) + k8);
+    const unsigned lo = ent.x, hi = ent.y;
+    const int i1 = i + 1;
+    if (LOOK && (lo & kEMatch)) { pend = i; pinfo = hi; }
+    if (lo & kEFinal) {
+      // the pending match ends at this byte for good and the search has resumed here (rgx_dfa.h: kUsFinal)
+      const unsigned inf = US_INFO(pinfo);
+      const int ps = (inf & 0x80u) ? US_START(inf) : pend - (int)(inf & 0x7Fu);
+      US_RECORD(ps, pend)
+      pend = -1;
+    }
+    const int v = i1 - (int)((lo >> 16) & 0x7Fu);
+    if (lo & kELoad0) r0 = v;
+    if (NREG > 1 && (lo & kELoad1)) r1 = v;
+    if (NREG > 2 && (lo & kELoad2)) r2 = v;
+    if (NREG > 2 && (lo & kELoad3)) r3 = v;
+    if (!LOOK && (lo & kEMatch)) { pend = i1; pinfo = hi; }
+    row = lo;
+    i = i1;
+    if (lo & kEDead) {
+      // every thread died (or the end of the text was consumed): a pending match is final; the search rewinds to its end
+      if (pend < 0) break;
+      const unsigned inf = US_INFO(pinfo);
+      const int ps = (inf & 0x80u) ? US_START(inf) : pend - (int)(inf & 0x7Fu);
+      if (ps >= slice_end) break;                          // a later lane's match
+      US_RECORD(ps, pend)
+      if (pend >= slice_end || pend >= in.len) break;      // find.go:209-211: no attempt at searchStart >= len
+      i = pend;                                            // find.go:452-457: the search resumes at the end of the match
+      row = s_srow[in.At8(i - 1) >> 3];
+      pend = -1;
+      continue;
+    }
+    if (i >= slice_end && pend < 0) {
+      // past the slice with nothing pending: go on only while a thread that began inside the slice is alive
+      const unsigned o = (hi >> 16) & 255u;
+      const int so = o == 255u ? 0x7FFFFFFF : ((o & 0x80u) ? US_START(o) : i - (int)o);
+      if (so >= slice_end) break;
+    }
+  }
+#undef US_RECORD
+}
+
 template <int NREG, bool LOOK>
 __global__ __launch_bounds__(kBlockThreads) void scan_us_kernel(DevTables T, UsDev U, ScanParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -105,7 +178,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_kernel(DevTables T, UsD
 
   if (tid == 0) s_misc[0] = P.use_tickets ? atomicAdd(&P.counters[0], 1u) : blockIdx.x;
   for (int w = tid; w < U.nent; w += kBlockThreads) s_ent[w] = U.ent[w];
-  s_cls[tid] = U.cls[tid];
+  s_cls[tid] = (unsigned char)(U.cls[tid] << 3);
   if (tid <= ncls) { s_srow[tid] = U.start_row_of_cls[tid]; s_rst[tid] = U.reset_of_cls[tid]; }
   if (tid < T.ncap) { s_delta[tid] = T.cap_delta[tid]; s_kind[tid] = T.cap_kind[tid]; }
   __syncthreads();
@@ -114,48 +187,55 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_kernel(DevTables T, UsD
   const int len = P.len;
   const int tb = tile * kTileBytes;
   const int wb = tb - kHaloL;
+  const unsigned eot8 = (unsigned)ncls << 3;
 
-  // ---- stage the window: coalesced 16-byte global loads, bytes -> classes, padded LDS rows
-  int wvalid;
+  // ---- stage the window: coalesced 16-byte global loads, bytes -> classes (x8), padded LDS rows; the 16-byte piece that
+  // holds offset `len` (and every byte of it at or beyond len) reads as the end-of-text class
+  int wlim;
   {
     const int first = wb < 0 ? 0 : wb;
     int last = tb + kTileBytes + kHaloR;
-    if (last > len) last = len;
-    wvalid = last - wb;
-    const int nchunks = (last - first + 15) >> 4;
+    const int len_ext = ((len >> 4) + 1) << 4;
+    if (last > len_ext) last = len_ext;
+    wlim = last - wb;
+    const int nchunks = (last - first) >> 4;
     const uint4* gsrc = reinterpret_cast<const uint4*>(P.buf + first);
     for (int c = tid; c < nchunks; c += kBlockThreads) {
       const int abs0 = first + (c << 4);
       uint32_t* dst = reinterpret_cast<uint32_t*>(s_tile + UPad(abs0 - wb));
-      unsigned w[4];
       if (abs0 + 16 <= len) {
         const uint4 v = gsrc[c];
-        w[0] = v.x; w[1] = v.y; w[2] = v.z; w[3] = v.w;
-      } else {
-        w[0] = w[1] = w[2] = w[3] = 0;
-        for (int b = 0; abs0 + b < len; ++b) w[b >> 2] |= (unsigned)P.buf[abs0 + b] << (8 * (b & 3));
-      }
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const unsigned x = w[d];
-        dst[d] = (unsigned)s_cls[x & 255u] | ((unsigned)s_cls[(x >> 8) & 255u] << 8) | ((unsigned)s_cls[(x >> 16) & 255u] << 16) |
-                 ((unsigned)s_cls[x >> 24] << 24);
+        for (int d = 0; d < 4; ++d) {
+          const unsigned x = w[d];
+          dst[d] = (unsigned)s_cls[x & 255u] | ((unsigned)s_cls[(x >> 8) & 255u] << 8) | ((unsigned)s_cls[(x >> 16) & 255u] << 16) |
+                   ((unsigned)s_cls[x >> 24] << 24);
+        }
+      } else {
+        for (int d = 0; d < 4; ++d) {
+          unsigned x = 0;
+          for (int b = 0; b < 4; ++b) {
+            const int at = abs0 + 4 * d + b;
+            x |= (at < len ? (unsigned)s_cls[P.buf[at]] : eot8) << (8 * b);
+          }
+          dst[d] = x;
+        }
       }
     }
   }
   __syncthreads();
-  const UIn in{P.buf, U.cls, s_tile, wb, wvalid, len, ncls};
+  const UIn in{P.buf, U.cls, s_tile, wb, wlim, len, (int)eot8};
+  const unsigned char* s_entb = reinterpret_cast<const unsigned char*>(s_ent);
 
   // ---- phase 1: the lane's walk
   const int slice = tile * kBlockThreads + tid;
   const int a = tb + tid * kSliceBytes;
   int slice_end = a + kSliceBytes;
   if (slice_end > len) slice_end = len;
-  unsigned long long mask = 0;     // starts of the lane's matches, relative to a
-  unsigned long long ends = 0;     // their ends, bit e-a-1 (the k-th start pairs with the k-th end); the last may lie beyond:
-  int last_end = -1;
+  UsOut out{0ull, 0ull, -1};
+  int pos = -1;                       // the lane's sync point; -1: nothing to walk
   if (a < len) {
-    int pos;
     bool synced = true;
     const int carried = P.carry_in ? P.carry_in[slice] : -1;
     if (carried >= 0) pos = carried;
@@ -164,68 +244,106 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_kernel(DevTables T, UsD
       int lower = wb < 0 ? 0 : wb;
       if (lower < a - kUMaxLookBehind) lower = a - kUMaxLookBehind;
       int j = a - 1;
-      while (j >= lower && !s_rst[in.At(j)]) --j;
+      while (j >= lower && !s_rst[in.At8(j) >> 3]) --j;
       if (j >= lower) pos = j + 1;
       else if (lower == 0) pos = 0;
-      else { synced = false; pos = slice_end; }
+      else { synced = false; pos = -1; }
     }
     if (!synced) {
       atomicAdd(&P.counters[1], 1u);
       if (P.slice_unsynced) P.slice_unsynced[slice] = 1;
     }
-    if (pos < slice_end) {
-      int i = pos;
-      unsigned row = s_srow[i == 0 ? ncls : in.At(i - 1)];
-      int r[NREG];
-#pragma unroll
-      for (int j = 0; j < NREG; ++j) r[j] = i;
-      int pe = -1, ps = 0;
-      while (true) {
-        const int k = in.At(i);
-        const unsigned long long ent = s_ent[row + k];
-        const unsigned lo = (unsigned)ent, hi = (unsigned)(ent >> 32);
-        if (LOOK) {
-          if (lo & (1u << 14)) {
-            const unsigned ib = hi & 255u;
-            pe = i;
-            ps = (ib & 0x80u) ? UsReg<NREG>(r, ib) : i - (int)ib;
-          }
-        }
-        const int v = i + 1 - (int)((lo >> 20) & 0x7Fu);
-#pragma unroll
-        for (int j = 0; j < NREG; ++j) r[j] = (lo & (1u << (16 + j))) ? v : r[j];
-        if (!LOOK) {
-          if (lo & (1u << 15)) {
-            const unsigned ia = (hi >> 8) & 255u;
-            pe = i + 1;
-            ps = (ia & 0x80u) ? UsReg<NREG>(r, ia) : i + 1 - (int)ia;
-          }
-        }
-        row = lo & 0x3FFFu;
-        ++i;
-        if (row == 0) {
-          // the state died (or the end of the text was consumed): the pending match, if any, is final
-          if (pe < 0 || ps >= slice_end) break;          // nothing pending / the match belongs to a later lane
-          if (ps >= a) {
-            mask |= 1ull << (ps - a);
-            const int re = pe - a - 1;
-            if (re < 64) ends |= 1ull << re; else last_end = pe;
-          }
-          if (pe >= slice_end || pe >= len) break;       // find.go:209-211: no attempt at searchStart >= len
-          i = pe;                                        // find.go:452-457: the search resumes at the end of the match
-          row = s_srow[in.At(i - 1)];
-#pragma unroll
-          for (int j = 0; j < NREG; ++j) r[j] = i;
-          pe = -1;
-        } else if (i >= slice_end) {
-          // past the slice: go on only while a thread that began inside it is alive
-          const unsigned o = (hi >> 16) & 255u;
-          const int so = o == 255u ? 0x7FFFFFFF : ((o & 0x80u) ? UsReg<NREG>(r, o) : i - (int)o);
-          if (so >= slice_end) break;
-        }
+    if (pos >= slice_end) pos = -1;
+  }
+  // Wave-uniform walk.  Per lane: i = offset of the dword being consumed (multiple of 4), p = its LDS address, row = the entry
+  // taken last (its low 16 bits: the current state's row), r0..r3 the start registers, pend/pinfo the pending match, lim = the
+  // end of the slice (INT_MAX once the lane is parked), cont = where the single-step walker has to go on (-1: nowhere;
+  // -2: the walk left the LDS window, repeat it from the sync point).
+  int cont = -1;
+  {
+    const int first_valid = wb < 0 ? 0 : wb;
+    bool fast = pos >= 0;
+    if (fast && pos < first_valid) { fast = false; cont = -2; }       // a carried sync point before the window
+    int i = fast ? (pos & ~3) : first_valid;
+    unsigned startrow = 0;
+    if (fast) startrow = s_srow[(pos > 0 ? in.At8(pos - 1) : eot8) >> 3];
+    const unsigned phase = fast ? (unsigned)(pos & 3) : 4u;            // the sub-step at which the lane enters its start state
+    int lim = fast ? slice_end : 0x7FFFFFFF;
+    unsigned row = 0;                 // parked until its sub-step comes
+    int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    (void)r1; (void)r2; (void)r3;
+    int pend = -1;
+    unsigned pinfo = 0, hi_last = 0;
+    const int send = slice_end;
+    const unsigned pmax = (unsigned)UPad((wlim - 4) & ~3);
+    bool first = true;
+    while (__any(lim != 0x7FFFFFFF)) {
+      unsigned p = (unsigned)UPad(i - wb);
+      p = p > pmax ? pmax : p;        // parked lanes keep reading inside the window
+      const unsigned w = *reinterpret_cast<const unsigned*>(s_tile + p);
+#define US_STEP(N)                                                                                              \
+  {                                                                                                             \
+    if (first) row = phase == (unsigned)(N) ? startrow : row;                                                   \
+    const unsigned addr = (row & 0xFFFFu) + ((w >> (8 * (N))) & 255u);                                          \
+    const uint2 ent = *reinterpret_cast<const uint2*>(s_entb + addr);                                           \
+    const unsigned lo = ent.x, hi = ent.y;                                                                      \
+    const int i1 = i + (N) + 1;                                                                                 \
+    if (LOOK) {                                                                                                 \
+      const bool fb = (lo & kEMatch) != 0;                                                                      \
+      pend = fb ? i1 - 1 : pend;                                                                                \
+      pinfo = fb ? hi : pinfo;                                                                                  \
+    }                                                                                                           \
+    if (__any((lo & (kEFinal | kEDead)) != 0)) {                                                                \
+      /* event block, every lane predicated: a match ends for good (kUsFinal), or every thread died */         \
+      const bool fin = (lo & kEFinal) != 0, dead = (lo & kEDead) != 0;                                          \
+      const unsigned inf = US_INFO(pinfo);                                                                      \
+      const int ps = (inf & 0x80u) ? US_START(inf) : pend - (int)(inf & 0x7Fu);                                 \
+      const bool ev = (fin || dead) && pend >= 0;                                                               \
+      const bool rec = ev && ps >= a && ps < send;                                                              \
+      const int re = pend - a - 1;                                                                              \
+      out.mask |= rec ? 1ull << ((ps - a) & 63) : 0ull;                                                         \
+      out.ends |= (rec && re < 64) ? 1ull << (re & 63) : 0ull;                                                  \
+      out.last_end = (rec && re >= 64) ? pend : out.last_end;                                                   \
+      /* a dead lane parks; if its pending match leaves room before the slice's end the search has to rewind there */ \
+      const bool stop = pend < 0 || ps >= send || pend >= send || pend >= len;                                  \
+      cont = (dead && !stop && lim != 0x7FFFFFFF) ? pend : cont;                                                \
+      lim = dead ? 0x7FFFFFFF : lim;                                                                            \
+      pend = (fin || dead) ? -1 : pend;                                                                         \
+    }                                                                                                           \
+    const int v = i1 - (int)((lo >> 16) & 0x7Fu);                                                               \
+    r0 = ((int)lo < 0) ? v : r0;                                                                                \
+    if (NREG > 1) r1 = (lo & kELoad1) ? v : r1;                                                                 \
+    if (NREG > 2) { r2 = (lo & kELoad2) ? v : r2; r3 = (lo & kELoad3) ? v : r3; }                               \
+    if (!LOOK) {                                                                                                \
+      const bool fa = (lo & kEMatch) != 0;                                                                      \
+      pend = fa ? i1 : pend;                                                                                    \
+      pinfo = fa ? hi : pinfo;                                                                                  \
+    }                                                                                                           \
+    row = lo;                                                                                                   \
+    hi_last = hi;                                                                                               \
+  }
+      US_STEP(0) US_STEP(1) US_STEP(2) US_STEP(3)
+#undef US_STEP
+      first = false;
+      i += 4;
+      if (__any(i >= lim && pend < 0)) {
+        // past the slice with nothing pending: a lane goes on only while a thread that began inside its slice is alive
+        const unsigned o = (hi_last >> 16) & 255u;
+        const int so = o == 255u ? 0x7FFFFFFF : ((o & 0x80u) ? US_START(o) : i - (int)o);
+        if (i >= lim && pend < 0 && so >= send) { lim = 0x7FFFFFFF; row = 0; }
+      }
+      if (__any(lim != 0x7FFFFFFF && i + 4 > wb + wlim)) {
+        // the walk is about to leave the LDS window: the single-step walker repeats it
+        if (lim != 0x7FFFFFFF && i + 4 > wb + wlim) { lim = 0x7FFFFFFF; row = 0; cont = -2; }
       }
     }
   }
+  if (cont != -1) {
+    if (cont == -2) { out.mask = 0; out.ends = 0; out.last_end = -1; cont = pos; }
+    UsWalkSlow<NREG, LOOK>(s_entb, s_srow, in, cont, a, slice_end, out);
+  }
+  unsigned long long mask = out.mask, ends = out.ends;
+  const int last_end = out.last_end;
 
   // ---- phase 2: ordered offsets.  lane -> wave -> block prefix sums, then decoupled look-back over tiles.
   const unsigned long long mask_all = mask;
@@ -279,6 +397,8 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_kernel(DevTables T, UsD
     }
   }
 }
+#undef US_START
+#undef US_INFO
 
 }  // namespace
 
