@@ -362,3 +362,51 @@ int64_t rgxt_us_find_all(void* hh, const uint8_t* buf, int64_t len, int64_t from
   return count;
 }
 }
+
+// The register-free walk of "simple" automata (StartSearch::simple; rgx_scan_us.hip: scan_us_simple_kernel): record the
+// offsets of register loads (L) and of final edges (E); a match ending at e began at the last load before e.  Returns the
+// match count, -3 when the automaton is not simple.
+extern "C" int64_t rgxt_us_find_all_simple(void* hh, const uint8_t* buf, int64_t len, int32_t* spans, int64_t cap) {
+  const StartSearch& u = ((UsHandle*)hh)->u;
+  if (!u.simple) return -3;
+  const int stride = u.ncls + 1;
+  std::vector<uint8_t> Lb((size_t)len + 2, 0), Eb((size_t)len + 2, 0);
+  int64_t pos = 0;
+  while (pos < len) {
+    const int ctx = pos == 0 ? kCtxBOT : u.ctx_of_byte[buf[pos - 1]];
+    uint32_t q = u.start[ctx];
+    int64_t pend = -1, i = pos;
+    bool stopped = false;
+    while (true) {
+      const int k = i < len ? u.cls[buf[i]] : u.ncls;
+      const uint32_t e = u.trans[(size_t)q * stride + k];
+      const uint32_t nq = e & kUsStateMask;
+      bool fin = (e & kUsFinal) != 0;
+      if (k == u.ncls) fin = (e & kUsBefore) || (u.sflags[q] & 2);     // a match that ends with the text
+      if (e & kUsBefore) pend = i;
+      if (fin) { Eb[i] = 1; pend = -1; }
+      if (e & kUsSet) Lb[i] = 1;
+      if (e & kUsAfter) pend = i + 1;
+      i++;
+      if (k == u.ncls) { if (pend < 0) stopped = true; break; }
+      if (nq == 0) break;
+      q = nq;
+    }
+    if (stopped || pend < 0) break;
+    // the state died with an older match pending: it is final, the search rewinds to its end
+    Eb[pend] = 1;
+    pos = pend;
+  }
+  int64_t count = 0, last_load = -1;
+  for (int64_t x = 0; x <= len; x++) {
+    if (Eb[x]) {
+      if (last_load < 0) return -4;
+      if (count < cap) { spans[2 * count] = (int32_t)last_load; spans[2 * count + 1] = (int32_t)x; }
+      count++;
+    }
+    if (Lb[x]) last_load = x;      // a load AT the end of a match belongs to the next one
+  }
+  return count;
+}
+// 1: every register load has delta 1 and every match reads register 0 (the "simple" class of rgx_scan_us.hip), else 0
+extern "C" int rgxt_us_simple(void* hh) { return ((UsHandle*)hh)->u.simple ? 1 : 0; }

@@ -904,6 +904,18 @@ StartSearch BuildStartSearch(const std::string& pattern, uint32_t flags, int max
       u.oldest[q] = (uint8_t)info_byte(t.second);      // lists are ordered oldest first
       break;
     }
+  u.sflags.assign(u.nstates, 0);
+  for (int q = 1; q < u.nstates; q++) {
+    for (auto& t : states[q].list) if (t.second == kSkip) u.sflags[q] |= 1;
+    if (!b.lookahead && (states[q].key & kAccBit)) u.sflags[q] |= 2;
+  }
+  u.simple = u.nregs <= 1;
+  for (size_t x = 0; x < u.trans.size() && u.simple; x++) {
+    const uint32_t e = u.trans[x];
+    if ((e & kUsSet) && (((e >> kUsDeltaShift) & 0x7F) != 1 || ((e >> kUsRegShift) & 7) != 0)) u.simple = false;
+    if ((e & kUsBefore) && (u.minfo[x] & 0xFF) != kUsFromReg) u.simple = false;
+    if ((e & kUsAfter) && (u.minfo[x] >> 8) != kUsFromReg) u.simple = false;
+  }
   u.ok = true;
   return u;
 }

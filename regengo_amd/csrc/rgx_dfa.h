@@ -138,9 +138,15 @@ struct StartSearch {
   std::vector<uint8_t> oldest;    // [nstates]: where the OLDEST thread alive in this state began: 0x80|j, or its age (start =
                                   // current offset - age), or kUsNone.  A walk past the end of a slice of start positions may stop
                                   // as soon as that start lies beyond the slice.
+  std::vector<uint8_t> sflags;    // [nstates]: bit 0 = the search loop is alive (no match pending), bit 1 = (eager) a match ends
+                                  // exactly where the state stands
   uint16_t start[4] = {0, 0, 0, 0};
   uint8_t ctx_of_byte[256] = {0};
   bool ctx_sensitive = false, lookahead = false;
+  // "simple": one register, every load has delta 1 and every match reads the register.  Then the start of a match is the
+  // offset of the last load before its end, and a walk needs no register at all: it records the offsets of loads and of
+  // kUsFinal edges (rgx_scan_us.hip, scan_us_simple_kernel).
+  bool simple = false;
 };
 StartSearch BuildStartSearch(const std::string& pattern, uint32_t flags, int max_states = 3000, int max_regs = kUsRegs);
 

@@ -30,6 +30,9 @@ _lib.rgxt_free_us.argtypes = [C.c_void_p]
 _lib.rgxt_us_info.argtypes = [C.c_void_p, C.c_void_p]
 _lib.rgxt_us_find_all.restype = C.c_int64
 _lib.rgxt_us_find_all.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64, C.c_int64]
+_lib.rgxt_us_simple.argtypes = [C.c_void_p]
+_lib.rgxt_us_find_all_simple.restype = C.c_int64
+_lib.rgxt_us_find_all_simple.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p, C.c_int64]
 
 INFO = ["ncap", "min", "max", "ninst", "nstates", "ncls", "anchored", "fixed", "empty", "refm", "reff", "look", "maxthr"]
 
@@ -131,4 +134,16 @@ class StartSearch:
         out = (C.c_int32 * (2 * cap))()
         n = _lib.rgxt_us_find_all(self.h, b, len(b), from_pos, out, cap, slice)
         assert n >= 0
+        return [(out[2 * i], out[2 * i + 1]) for i in range(n)]
+
+    @property
+    def simple(self) -> bool:
+        return bool(_lib.rgxt_us_simple(self.h))
+
+    def find_all_simple(self, b: bytes):
+        """The register-free walk of simple automata: offsets of loads and final edges, starts derived afterwards."""
+        cap = len(b) + 1
+        out = (C.c_int32 * (2 * cap))()
+        n = _lib.rgxt_us_find_all_simple(self.h, b, len(b), out, cap)
+        assert n >= 0, n
         return [(out[2 * i], out[2 * i + 1]) for i in range(n)]

@@ -17,7 +17,7 @@ def _items(corpus, kats):
 
 def test_start_search_equals_oracle_findall_on_corpus(corpus, kats, hostlib):
     rng = random.Random(99)
-    eligible = total = 0
+    eligible = total = simple_total = 0
     why = {}
     for p, inputs in _items(corpus, kats):
         try:
@@ -35,11 +35,14 @@ def test_start_search_equals_oracle_findall_on_corpus(corpus, kats, hostlib):
             # cut into slices of start positions the way the kernel's lanes own them (stop rule: StartSearch.oldest)
             assert u.find_all(b, 0, 5) == exp, ("slices of 5", p, b)
             assert u.find_all(b, 0, 64) == exp, ("slices of 64", p, b)
+            if u.simple:
+                assert u.find_all_simple(b) == exp, ("register-free walk", p, b)
+                simple_total += 1
             total += 1
     # anchored patterns (156 of the corpus) and patterns that can match empty take other kernels
     assert set(why) <= {"ineligible: anchored", "ineligible: can match empty", "ineligible: age", "ineligible: state budget"}, why
     assert why.get("ineligible: age", 0) + why.get("ineligible: state budget", 0) <= 2, why
-    assert eligible >= 95 and total > 2000, (eligible, total, why)
+    assert eligible >= 95 and total > 2000 and simple_total > 1000, (eligible, total, simple_total, why)
 
 
 def test_start_search_from_a_later_position(hostlib):
@@ -79,6 +82,8 @@ def test_start_search_random_patterns(hostlib, seed):
             exp = [tuple(m[:2]) for m in o.find_machine.find_all(b, q8=False)]
             assert u.find_all(b) == exp, (p, b)
             assert u.find_all(b, 0, 3) == exp, ("slices of 3", p, b)
+            if u.simple:
+                assert u.find_all_simple(b) == exp, ("register-free walk", p, b)
             done += 1
     assert eligible > 60 and done > 360, (eligible, done)
 
