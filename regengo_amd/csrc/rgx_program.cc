@@ -187,7 +187,9 @@ bool BuildUs(Program* p) {
   for (int regs : {1, 2, 4}) {
     try {
       StartSearch u = BuildStartSearch(p->t.pattern, p->t.flags, 2000, regs);
-      if (!u.ok || (int64_t)u.nstates * (u.ncls + 1) > kUsMaxEntries || u.ncls + 1 > 32) continue;   // class * 8 is one byte of the LDS tile
+      if (!u.ok || (int64_t)u.nstates * (u.ncls + 1) > kUsMaxEntries) continue;
+      const bool simple = u.simple && u.ncls + 1 <= 64 && (int64_t)(u.nstates + 1) * (u.ncls + 1) <= 4096;
+      if (!simple && u.ncls + 1 > 32) continue;            // class * 8 (class * 4 for simple automata) is one byte of the LDS tile
       p->us = std::move(u);
       return true;
     } catch (...) {
@@ -227,8 +229,46 @@ int UploadUs(Program* p) {
     rst[k] = all ? 1 : 0;
   }
   srow[u.ncls] = (uint16_t)(u.start[kCtxBOT] * stride * 8);
+  // simple automata: the register-free image (rgx_program.h: UsDev::ent4)
+  std::vector<uint32_t> ent4;
+  std::vector<uint16_t> srow4(stride);
+  unsigned long long rstmask = 0;
+  const bool simple = u.simple && stride <= 64 && (int64_t)(u.nstates + 1) * stride <= 4096;
+  if (simple) {
+    const uint32_t zoff = (uint32_t)stride * 4u;
+    auto off = [&](uint32_t q) { return (q + 1) * (uint32_t)stride * 4u; };
+    ent4.assign((size_t)(u.nstates + 1) * stride, 0);
+    for (int k = 0; k < stride; k++) ent4[(size_t)stride + k] = zoff;         // row 1 stays in row 1
+    for (int q = 1; q < u.nstates; q++)
+      for (int k = 0; k < stride; k++) {
+        const uint32_t e = u.trans[(size_t)q * stride + k];
+        const uint32_t nq = e & kUsStateMask;
+        uint32_t v = 0;
+        if (k == u.ncls) {
+          // the end of the text: a match that ends with it is final; a state with the search loop alive has nothing pending;
+          // anything else has an older match pending: the single-step walker sorts it out
+          if ((e & kUsBefore) || (u.sflags[q] & 2)) v = 1u << 30;
+          else if (!(u.sflags[q] & 1)) v = zoff;
+        } else if (e & kUsFinal) {
+          v = (nq ? off(nq) : zoff) | (1u << 30);
+        } else {
+          v = nq ? off(nq) : zoff;       // a state dies with an older match pending: rewind (the loop never dies otherwise)
+        }
+        if (k != u.ncls && (e & kUsSet)) v |= 1u << 31;
+        if (e & (kUsBefore | kUsAfter)) v |= 1u << 29;
+        ent4[(size_t)(q + 1) * stride + k] = v;
+      }
+    for (int k = 0; k < u.ncls; k++) {
+      int rep = 0;
+      while (u.cls[rep] != k) rep++;
+      srow4[k] = (uint16_t)off(u.start[u.ctx_of_byte[rep]]);
+      if (rst[k]) rstmask |= 1ull << k;
+    }
+    srow4[u.ncls] = (uint16_t)off(u.start[kCtxBOT]);
+  }
   Arena a;
   const size_t off_ent = a.AddVec(ent), off_cls = a.Add(u.cls, 256), off_srow = a.AddVec(srow), off_rst = a.AddVec(rst);
+  const size_t off_ent4 = a.AddVec(ent4), off_srow4 = a.AddVec(srow4);
   void* dptr = nullptr;
   if (hipMalloc(&dptr, a.host.size()) != hipSuccess) { SetError("hipMalloc(us tables) failed"); return RGX_E_NOMEM; }
   if (hipMemcpy(dptr, a.host.data(), a.host.size(), hipMemcpyHostToDevice) != hipSuccess) { hipFree(dptr); SetError("hipMemcpy(us tables) failed"); return RGX_E_HIP; }
@@ -237,6 +277,10 @@ int UploadUs(Program* p) {
   d.ent = (const unsigned long long*)(b + off_ent); d.cls = b + off_cls;
   d.start_row_of_cls = (const uint16_t*)(b + off_srow); d.reset_of_cls = b + off_rst;
   d.nent = nent; d.stride = stride; d.ncls = u.ncls; d.nregs = u.nregs <= 1 ? 1 : (u.nregs <= 2 ? 2 : 4); d.lookahead = u.lookahead ? 1 : 0;
+  if (simple) {
+    d.ent4 = (const uint32_t*)(b + off_ent4); d.start_row4 = (const uint16_t*)(b + off_srow4);
+    d.nent4 = (int32_t)ent4.size(); d.rstmask = rstmask;
+  }
   p->usdev = d;
   p->d_arena_us = dptr;
   return RGX_OK;

@@ -83,6 +83,14 @@ struct UsDev {
   int32_t ncls;
   int32_t nregs;                  // registers the automaton uses (1, 2 or 4 in the kernel's instantiations)
   int32_t lookahead;              // 1: match flags are kUsBefore (lazy construction), 0: kUsAfter
+  // "simple" automata (StartSearch::simple): register-free walk, scan_us_simple_kernel.  32-bit entries:
+  //   [0..15] byte offset of the next row (row 0: parked, walk over; row 1: parked, the single-step walker must repeat the
+  //   stretch -- both rows all-"stay", no flags)   [29] a match ends here (single-step walker only)   [30] kUsFinal: a match
+  //   ends at this byte for good   [31] register load: a thread that began at this byte survived it
+  const uint32_t* ent4;           // [nent4] or nullptr
+  const uint16_t* start_row4;     // [ncls+1] like start_row_of_cls, in ent4 offsets
+  int32_t nent4;                  // (nstates + 1) * stride
+  unsigned long long rstmask;     // bit k: class k is a reset class (ncls <= 63 for simple)
 };
 
 struct Program {

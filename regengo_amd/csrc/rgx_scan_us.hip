@@ -400,17 +400,385 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_kernel(DevTables T, UsD
 #undef US_START
 #undef US_INFO
 
+
+// =====================================================================================================================
+// Register-free variant for "simple" automata (StartSearch::simple: one register, every load is "a thread that began at this
+// byte survived it", every match reads the register) -- \w+@\w+, (\d+), \b[a-z]+\b, the URL pattern and 53 more of the corpus.
+// The start of a match is then the offset of the last register load before its end, so the walk needs neither registers nor a
+// pending-match record: per byte it ORs two flags of a 32-bit entry into two bit sets -- L (loads) and E (ends: kUsFinal edges)
+// -- kept as LDS bitmaps over the tile.  Five VALU instructions per byte, no event block at all.
+//   stretches   the tile's bytes are walked exactly once: the lane whose 64-byte slice holds a sync point starts at the first
+//               one and walks to the first sync point of the next such lane (no look-behind re-walk, no tail); the last stretch
+//               of a tile ends at the first sync point at or after the next tile's start, and the tile owns every match that
+//               begins inside its stretches (a partition of the matches in stream order).
+//   rare        a state that dies with an older match pending (the search has to rewind), and stretches that leave the LDS
+//               window, park the lane in row 1; the single-step walker below repeats that lane's stretch.
+constexpr int kSReach = 1152;                          // bytes past the tile's end the last stretch may run
+constexpr int kSBits = kTileBytes + kSReach;           // bit positions of L and E
+constexpr int kSWords = kSBits / 32;                   // 548
+
+struct UsSLayout {
+  int tile, ent, cls, srow, L, E, sync, delta, kind, misc, total;
+};
+__host__ __device__ inline UsSLayout UsSLds(int nent4, int stride) {
+  UsSLayout l;
+  int o = 0;
+  l.tile = o; o += (kUPadded + 15) & ~15;
+  l.ent = o; o += (nent4 * 4 + 15) & ~15;
+  l.cls = o; o += 256;
+  l.srow = o; o += (stride * 2 + 15) & ~15;
+  l.L = o; o += (kSWords * 4 + 15) & ~15;
+  l.E = o; o += (kSWords * 4 + 15) & ~15;
+  l.sync = o; o += kBlockThreads * 4;
+  l.delta = o; o += 32 * 4;
+  l.kind = o; o += 32;
+  l.misc = o; o += 32 * 4;
+  l.total = (o + 15) & ~15;
+  return l;
+}
+
+struct SIn {
+  const uint8_t* g;
+  const uint8_t* gcls;
+  const unsigned char* tile;   // LDS window: class id * 4
+  int wb, wlim, len, eot4;
+  __device__ __forceinline__ unsigned At4(int i) const {
+    const unsigned rel = (unsigned)(i - wb);
+    if (rel < (unsigned)wlim) return tile[UPad((int)rel)];
+    if (i >= len) return (unsigned)eot4;
+    return (unsigned)gcls[g[i]] << 2;
+  }
+};
+
+// First sync point inside slice k = [k*64, k*64+64): the carried search position when the carry pass supplied one, else the
+// offset behind the first reset byte from k*64-1 on (offset 0 of the text is one).  -1: none.
+__device__ __forceinline__ int SliceStart(const SIn& in, const int32_t* carry_in, unsigned long long rstmask, int k) {
+  const int a = k * kSliceBytes;
+  if (a >= in.len) return -1;
+  if (carry_in) {
+    const int c = carry_in[k];
+    if (c >= 0) return (c >= a && c < a + kSliceBytes && c < in.len) ? c : -1;
+  }
+  if (a == 0) return 0;
+  for (int j = a - 1; j < a + kSliceBytes - 1 && j + 1 < in.len; ++j)
+    if ((rstmask >> (in.At4(j) >> 2)) & 1ull) return j + 1;
+  return -1;
+}
+
+// Single-step walker of one stretch [s, e]: consumes bytes s..e, records loads at [s, e) and ends at (s, e] (bit sets in LDS;
+// an end beyond the bit sets goes to *far).  Handles what the wave-uniform loop does not: rewinds, bytes outside the window.
+__device__ __noinline__ void UsSimpleSlow(const unsigned* s_ent4, const uint16_t* s_srow, unsigned* s_L, unsigned* s_E, int* far,
+                                          const SIn& in, int tb, int s, int e, int lookahead, unsigned zoff) {
+  int i = s;
+  unsigned row = s_srow[(i > 0 ? in.At4(i - 1) : (unsigned)in.eot4) >> 2];
+  int pend = -1;
+  auto set_e = [&](int at) {
+    const unsigned b = (unsigned)(at - tb);
+    if (b < (unsigned)kSBits) atomicOr(&s_E[b >> 5], 1u << (b & 31)); else *far = at;
+  };
+  while (i <= e) {
+    const unsigned k4 = in.At4(i);
+    const unsigned ent = s_ent4[((row & 0xFFFFu) + k4) >> 2];
+    if (lookahead && (ent & (1u << 29))) pend = i;
+    if (ent & (1u << 30)) { set_e(i); pend = -1; }
+    if ((ent & (1u << 31)) && i < e) {
+      const unsigned b = (unsigned)(i - tb);
+      if (b < (unsigned)kSBits) atomicOr(&s_L[b >> 5], 1u << (b & 31));
+    }
+    if (!lookahead && (ent & (1u << 29))) pend = i + 1;
+    row = ent & 0xFFFFu;
+    ++i;
+    if (row == zoff) {
+      // the state died with an older match pending: it is final and the search rewinds to its end (find.go:452-457)
+      if (pend < 0 || pend > e) break;
+      set_e(pend);
+      if (pend >= in.len) break;
+      i = pend;
+      row = s_srow[in.At4(i - 1) >> 2];
+      pend = -1;
+    } else if (row == 0) {
+      break;                                   // the end of the text
+    }
+  }
+}
+
+__global__ __launch_bounds__(kBlockThreads) void scan_us_simple_kernel(DevTables T, UsDev U, ScanParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const UsSLayout Ly = UsSLds(U.nent4, U.stride);
+  unsigned char* s_tile = smem + Ly.tile;
+  unsigned* s_ent4 = reinterpret_cast<unsigned*>(smem + Ly.ent);
+  unsigned char* s_cls = smem + Ly.cls;
+  uint16_t* s_srow = reinterpret_cast<uint16_t*>(smem + Ly.srow);
+  unsigned* s_L = reinterpret_cast<unsigned*>(smem + Ly.L);
+  unsigned* s_E = reinterpret_cast<unsigned*>(smem + Ly.E);
+  int* s_sync = reinterpret_cast<int*>(smem + Ly.sync);
+  int32_t* s_delta = reinterpret_cast<int32_t*>(smem + Ly.delta);
+  unsigned char* s_kind = smem + Ly.kind;
+  unsigned* s_misc = reinterpret_cast<unsigned*>(smem + Ly.misc);   // [0] tile [1..4] wave totals [5] tail total [8..9] base [10] far end
+  int* s_far = reinterpret_cast<int*>(s_misc + 10);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int ncls = U.ncls;
+  const unsigned zoff = (unsigned)U.stride * 4u;
+
+  if (tid == 0) { s_misc[0] = P.use_tickets ? atomicAdd(&P.counters[0], 1u) : blockIdx.x; *s_far = -1; }
+  for (int w = tid; w < U.nent4; w += kBlockThreads) s_ent4[w] = U.ent4[w];
+  s_cls[tid] = (unsigned char)(U.cls[tid] << 2);
+  if (tid <= ncls) s_srow[tid] = U.start_row4[tid];
+  if (tid < T.ncap) { s_delta[tid] = T.cap_delta[tid]; s_kind[tid] = T.cap_kind[tid]; }
+  for (int w = tid; w < kSWords; w += kBlockThreads) { s_L[w] = 0; s_E[w] = 0; }
+  __syncthreads();
+  const int tile = (int)s_misc[0];
+  if (tile >= P.ntiles) return;
+  const int len = P.len;
+  const int tb = tile * kTileBytes;
+  const int wb = tb - kHaloL;
+  const unsigned eot4 = (unsigned)ncls << 2;
+
+  int wlim;
+  {
+    const int first = wb < 0 ? 0 : wb;
+    int last = tb + kTileBytes + kHaloR;
+    const int len_ext = ((len >> 4) + 1) << 4;
+    if (last > len_ext) last = len_ext;
+    wlim = last - wb;
+    const int nchunks = (last - first) >> 4;
+    const uint4* gsrc = reinterpret_cast<const uint4*>(P.buf + first);
+    for (int c = tid; c < nchunks; c += kBlockThreads) {
+      const int abs0 = first + (c << 4);
+      uint32_t* dst = reinterpret_cast<uint32_t*>(s_tile + UPad(abs0 - wb));
+      if (abs0 + 16 <= len) {
+        const uint4 v = gsrc[c];
+        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const unsigned x = w[d];
+          dst[d] = (unsigned)s_cls[x & 255u] | ((unsigned)s_cls[(x >> 8) & 255u] << 8) | ((unsigned)s_cls[(x >> 16) & 255u] << 16) |
+                   ((unsigned)s_cls[x >> 24] << 24);
+        }
+      } else {
+        for (int d = 0; d < 4; ++d) {
+          unsigned x = 0;
+          for (int b = 0; b < 4; ++b) {
+            const int at = abs0 + 4 * d + b;
+            x |= (at < len ? (unsigned)s_cls[P.buf[at]] : eot4) << (8 * b);
+          }
+          dst[d] = x;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  const SIn in{P.buf, U.cls, s_tile, wb, wlim, len, (int)eot4};
+  const unsigned long long rstmask = U.rstmask;
+
+  // ---- the lane's stretch [s, e]
+  const int slice = tile * kBlockThreads + tid;
+  const int a = tb + tid * kSliceBytes;
+  int s = SliceStart(in, P.carry_in, rstmask, slice);
+  if (s < 0 && a < len && !(P.carry_in && P.carry_in[slice] >= 0)) {
+    // no sync point in the slice: some earlier lane walks it -- unless none is in reach behind either (the other scan kernels'
+    // rule: the slice is "unsynced", the host resolves such runs with the carry pass)
+    int lower = a - 1 - kUMaxLookBehind;
+    if (lower < 0) lower = 0;
+    int j = a - 2;
+    while (j >= lower && !((rstmask >> (in.At4(j) >> 2)) & 1ull)) --j;
+    if (j < lower && lower > 0) {
+      atomicAdd(&P.counters[1], 1u);
+      if (P.slice_unsynced) P.slice_unsynced[slice] = 1;
+    }
+  }
+  s_sync[tid] = s;
+  __syncthreads();
+  int e = 0x7FFFFFF0;
+  bool slow = false;
+  if (s >= 0) {
+    int t = tid + 1;
+    while (t < kBlockThreads && s_sync[t] < 0) ++t;
+    if (t < kBlockThreads) {
+      e = s_sync[t];
+    } else {
+      // the tile's last stretch ends at the first sync point at or after the next tile's start
+      const int k0 = (tile + 1) * kBlockThreads;
+      int found = -1;
+      for (int k = k0; k < k0 + kSReach / kSliceBytes - 1 && k * kSliceBytes < len && found < 0; ++k) found = SliceStart(in, P.carry_in, rstmask, k);
+      if (found >= 0) e = found;
+      else if (k0 * kSliceBytes + kSReach - kSliceBytes < len) {
+        // no sync point in reach and the text goes on: leave the stretch to the carry pass
+        atomicAdd(&P.counters[1], 1u);
+        if (P.slice_unsynced && k0 * kSliceBytes < len) P.slice_unsynced[k0] = 1;
+        s = -1;
+      }
+    }
+  }
+  // wave-uniform walk: i = offset of the dword being consumed; a lane enters its start state at sub-step (s & 3) of its first
+  // trip and parks (row 0: every entry "stay, no flags") once it has consumed byte e
+  {
+    const int first_valid = wb < 0 ? 0 : wb;
+    bool fast = s >= 0;
+    const int e_eff = e < len ? e : len;           // the last byte the stretch consumes (len: the end-of-text step)
+    if (fast && (s < first_valid || e_eff >= wb + wlim)) { fast = false; slow = true; }
+    int i = fast ? (s & ~3) : first_valid;
+    unsigned startrow = 0;
+    if (fast) startrow = s_srow[(s > 0 ? in.At4(s - 1) : eot4) >> 2];
+    const unsigned phase = fast ? (unsigned)(s & 3) : 4u;
+    unsigned row = 0;
+    bool active = fast, first = true;
+    const unsigned pmax = (unsigned)UPad((wlim - 4) & ~3);
+    const unsigned char* s_entb = reinterpret_cast<const unsigned char*>(s_ent4);
+    while (__any(active)) {
+      unsigned p = (unsigned)UPad(i - wb);
+      p = p > pmax ? pmax : p;
+      const unsigned w = *reinterpret_cast<const unsigned*>(s_tile + p);
+      const unsigned irel = (unsigned)(i - tb);
+      const unsigned b0 = 1u << (irel & 31u);
+      unsigned lacc = 0, eacc = 0;
+#define USS_STEP(N)                                                                                     \
+  {                                                                                                     \
+    if (first) row = phase == (unsigned)(N) ? startrow : row;                                           \
+    const unsigned ent = *reinterpret_cast<const unsigned*>(s_entb + (row & 0xFFFFu) + ((w >> (8 * (N))) & 255u)); \
+    lacc |= (unsigned)((int)ent >> 31) & (b0 << (N));                                                   \
+    eacc |= (unsigned)((int)(ent << 1) >> 31) & (b0 << (N));                                            \
+    row = ent;                                                                                          \
+  }
+      USS_STEP(0) USS_STEP(1) USS_STEP(2) USS_STEP(3)
+#undef USS_STEP
+      first = false;
+      if (__any(active && i + 4 > e)) {
+        // the stretch ends inside this trip: loads count at [.., e), ends at [.., e]
+        const int kl = e - i;                        // positions of this trip that may carry a load
+        const unsigned ml = kl >= 4 ? 0xFu : (kl <= 0 ? 0u : (1u << kl) - 1u);
+        const unsigned me = kl >= 3 ? 0xFu : (kl < 0 ? 0u : (2u << kl) - 1u);
+        lacc &= ml << (irel & 31u);
+        eacc &= me << (irel & 31u);
+      }
+      if (active) {
+        if (lacc) atomicOr(&s_L[irel >> 5], lacc);
+        if (eacc) atomicOr(&s_E[irel >> 5], eacc);
+      }
+      i += 4;
+      const unsigned ro = row & 0xFFFFu;
+      if (ro == zoff && active) slow = true;         // rewind needed: the single-step walker repeats the stretch
+      if (ro <= zoff || i > e) { active = false; row = 0; }
+    }
+  }
+  if (slow && s >= 0)
+    UsSimpleSlow(s_ent4, s_srow, s_L, s_E, s_far, in, tb, s, e < len ? e : len, U.lookahead, zoff);
+  __syncthreads();
+
+  // ---- phase 2: the tile's matches = the set bits of E, in order.  Lane t counts E bits [64t, 64t+64); the bits past the
+  // tile's end (the last stretch) are the "tail" words, counted by the first lanes of wave 0.
+  constexpr int kTailChunks = kSReach / 64;          // 18
+  const unsigned long long* E64 = reinterpret_cast<const unsigned long long*>(s_E);
+  auto start_of = [&](int pe) -> int {
+    // the last load before pe (a load AT pe belongs to the next match)
+    int b = pe - tb - 1;
+    int wi = b >> 5;
+    unsigned m = s_L[wi] & (0xFFFFFFFFu >> (31 - (b & 31)));
+    while (m == 0 && wi > 0) m = s_L[--wi];
+    return tb + (wi << 5) + 31 - __builtin_clz(m);
+  };
+  const bool filter = P.own_lo > 0 || P.own_hi < len;
+  auto owned_bits = [&](unsigned long long bits, int chunk) -> unsigned long long {
+    if (!filter) return bits;
+    unsigned long long keep = 0, x = bits;
+    while (x) {
+      const int b = __builtin_ctzll(x);
+      x &= x - 1;
+      const int st = start_of(tb + chunk * 64 + b);
+      if (st >= P.own_lo && st < P.own_hi) keep |= 1ull << b;
+    }
+    return keep;
+  };
+  unsigned long long mbits = owned_bits(E64[tid], tid);
+  unsigned long long tbits = (tid < kTailChunks) ? owned_bits(E64[kBlockThreads + tid], kBlockThreads + tid) : 0ull;
+  const int far = *s_far;
+  unsigned farcnt = 0;
+  if (tid == 0 && far >= 0) {
+    const int st = start_of(tb + kSBits);
+    farcnt = (!filter || (st >= P.own_lo && st < P.own_hi)) ? 1u : 0u;
+  }
+  const unsigned cnt = (unsigned)__popcll(mbits);
+  const unsigned tcnt = (unsigned)__popcll(tbits);
+  const unsigned incl = (unsigned)WaveInclusiveScan(cnt, lane);
+  const unsigned tincl = (wave == 0) ? (unsigned)WaveInclusiveScan(tcnt, lane) : 0u;
+  if (lane == 63) s_misc[1 + wave] = incl;
+  if (tid == 63) s_misc[5] = tincl;
+  if (tid == 0) s_misc[6] = farcnt;          // a match that ends beyond the bit sets is the tile's last one
+  __syncthreads();
+  unsigned wave_off = 0, main_total = 0;
+#pragma unroll
+  for (int w = 0; w < kBlockThreads / 64; ++w) {
+    const unsigned t = s_misc[1 + w];
+    if (w < wave) wave_off += t;
+    main_total += t;
+  }
+  const unsigned block_total = main_total + s_misc[5] + s_misc[6];
+  if (P.count_only) {
+    if (tid == 0 && block_total) atomicAdd(P.total, (unsigned long long)block_total);
+    return;
+  }
+  if (wave == 0) {
+    if (lane == 0 && block_total) atomicAdd(P.total, (unsigned long long)block_total);
+    const unsigned long long excl = LookBack(P.tile_desc, tile, block_total, lane, &P.counters[3], 1, nullptr, !P.use_tickets);
+    if (lane == 0) { s_misc[8] = (unsigned)excl; s_misc[9] = (unsigned)(excl >> 32); }
+  }
+  __syncthreads();
+  const unsigned long long base = ((unsigned long long)s_misc[9] << 32) | s_misc[8];
+
+  // ---- phase 3: span records in match order
+  const int ncap = T.ncap;
+  auto emit = [&](unsigned long long idx, int st, int pe) {
+    if (idx >= (unsigned long long)P.cap_records) return;
+    if (P.starts_only) { P.spans[idx] = st; return; }
+    int32_t* rec = P.spans + idx * ncap;
+    if (T.fixed_captures) UsWriteFixed(rec, ncap, s_kind, s_delta, st, pe);
+    else { rec[0] = st; rec[1] = pe; }
+  };
+  {
+    unsigned long long idx = base + wave_off + (incl - cnt);
+    unsigned long long x = mbits;
+    while (x) {
+      const int b = __builtin_ctzll(x);
+      x &= x - 1;
+      const int pe = tb + tid * 64 + b;
+      emit(idx++, start_of(pe), pe);
+    }
+  }
+  if (tid < kTailChunks) {
+    unsigned long long idx = base + main_total + (tincl - tcnt);
+    unsigned long long x = tbits;
+    while (x) {
+      const int b = __builtin_ctzll(x);
+      x &= x - 1;
+      const int pe = tb + (kBlockThreads + tid) * 64 + b;
+      emit(idx++, start_of(pe), pe);
+    }
+  }
+  if (tid == 0 && farcnt) emit(base + block_total - 1, start_of(tb + kSBits), far);
+}
+
 }  // namespace
 
 bool UseUsKernel(const DevTables& T, int32_t len, bool use_w) {
   static const bool off = getenv("RGX_NO_US_KERNEL") != nullptr;
-  return !off && T.us != nullptr && !use_w && len >= 64 && !UseExactKernel(T, len) && !T.anchored && T.ncap <= 32;
+  if (off || T.us == nullptr || use_w || len < 64 || UseExactKernel(T, len) || T.anchored || T.ncap > 32) return false;
+  return T.us->ent4 != nullptr || T.us->stride <= 32;     // the register kernel keeps class * 8 in one byte
 }
 
 hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t stream) {
   const UsDev& U = *T.us;
-  const size_t shmem = (size_t)UsLds(U.nent, U.stride).total;
   dim3 grid(P.ntiles), block(kBlockThreads);
+  static const bool no_simple = getenv("RGX_NO_US_SIMPLE") != nullptr;
+  if (U.ent4 && !no_simple) {
+    static bool attr = false;
+    if (!attr) { hipFuncSetAttribute((const void*)scan_us_simple_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    hipLaunchKernelGGL(scan_us_simple_kernel, grid, block, (size_t)UsSLds(U.nent4, U.stride).total, stream, T, U, P);
+    return hipGetLastError();
+  }
+  const size_t shmem = (size_t)UsLds(U.nent, U.stride).total;
 #define RGX_US(N, LK)                                                                                   \
   do {                                                                                                  \
     static bool attr = false;                                                                           \
