@@ -72,6 +72,7 @@ def build_product(verbose=False) -> str:
     srcs = [os.path.join(CSRC, s) for s in PRODUCT_SOURCES]
     flags = ["--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-shared", "-I" + os.path.join(ROOT, "include"),
              "-I" + CSRC, "-Wno-unused-result", "-fvisibility=hidden", "-DRGX_BUILDING"]
+    flags += os.environ.get("RGX_EXTRA_FLAGS", "").split()      # experiments only (e.g. -DRGX_US_PROFILE); part of the build stamp
     st = _needs(out, srcs + _all_headers(), " ".join(flags))
     if st is None:
         return out

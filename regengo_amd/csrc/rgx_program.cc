@@ -188,8 +188,7 @@ bool BuildUs(Program* p) {
     try {
       StartSearch u = BuildStartSearch(p->t.pattern, p->t.flags, 2000, regs);
       if (!u.ok || (int64_t)u.nstates * (u.ncls + 1) > kUsMaxEntries) continue;
-      const bool simple = u.simple && u.ncls + 1 <= 64 && (int64_t)(u.nstates + 1) * (u.ncls + 1) <= 4096;
-      if (!simple && u.ncls + 1 > 32) continue;            // class * 8 (class * 4 for simple automata) is one byte of the LDS tile
+      if (u.ncls + 1 > 32) continue;                       // class * 8 (class * 4 for simple automata) is one byte of the LDS tile
       p->us = std::move(u);
       return true;
     } catch (...) {
@@ -229,16 +228,19 @@ int UploadUs(Program* p) {
     rst[k] = all ? 1 : 0;
   }
   srow[u.ncls] = (uint16_t)(u.start[kCtxBOT] * stride * 8);
-  // simple automata: the register-free image (rgx_program.h: UsDev::ent4)
+  // simple automata: the register-free image (rgx_program.h: UsDev::ent4).  Rows are 256 bytes: 32 entries, then the same 32
+  // again -- the LDS tile holds class * 4 per byte with bit 7 marking reset bytes, and row + byte must hit the entry either way.
   std::vector<uint32_t> ent4;
   std::vector<uint16_t> srow4(stride);
+  std::vector<uint8_t> cls4(256, 0);
   unsigned long long rstmask = 0;
-  const bool simple = u.simple && stride <= 64 && (int64_t)(u.nstates + 1) * stride <= 4096;
+  const bool simple = u.simple && stride <= 32 && u.nstates + 1 <= 250;
+  constexpr uint32_t kPitch = 260, kPitchW = 65;      // bytes / dwords per row: 64 entries + one dword of padding (LDS banks)
   if (simple) {
-    const uint32_t zoff = (uint32_t)stride * 4u;
-    auto off = [&](uint32_t q) { return (q + 1) * (uint32_t)stride * 4u; };
-    ent4.assign((size_t)(u.nstates + 1) * stride, 0);
-    for (int k = 0; k < stride; k++) ent4[(size_t)stride + k] = zoff;         // row 1 stays in row 1
+    const uint32_t zoff = kPitch;
+    auto off = [&](uint32_t q) { return (q + 1) * kPitch; };
+    ent4.assign((size_t)(u.nstates + 1) * kPitchW, 0);
+    for (int k = 0; k < 64; k++) ent4[kPitchW + k] = zoff;                     // row 1 stays in row 1
     for (int q = 1; q < u.nstates; q++)
       for (int k = 0; k < stride; k++) {
         const uint32_t e = u.trans[(size_t)q * stride + k];
@@ -256,7 +258,8 @@ int UploadUs(Program* p) {
         }
         if (k != u.ncls && (e & kUsSet)) v |= 1u << 31;
         if (e & (kUsBefore | kUsAfter)) v |= 1u << 29;
-        ent4[(size_t)(q + 1) * stride + k] = v;
+        ent4[(size_t)(q + 1) * kPitchW + k] = v;
+        ent4[(size_t)(q + 1) * kPitchW + 32 + k] = v;
       }
     for (int k = 0; k < u.ncls; k++) {
       int rep = 0;
@@ -265,10 +268,11 @@ int UploadUs(Program* p) {
       if (rst[k]) rstmask |= 1ull << k;
     }
     srow4[u.ncls] = (uint16_t)off(u.start[kCtxBOT]);
+    for (int c = 0; c < 256; c++) cls4[c] = (uint8_t)((u.cls[c] << 2) | (rst[u.cls[c]] ? 0x80 : 0));
   }
   Arena a;
   const size_t off_ent = a.AddVec(ent), off_cls = a.Add(u.cls, 256), off_srow = a.AddVec(srow), off_rst = a.AddVec(rst);
-  const size_t off_ent4 = a.AddVec(ent4), off_srow4 = a.AddVec(srow4);
+  const size_t off_ent4 = a.AddVec(ent4), off_srow4 = a.AddVec(srow4), off_cls4 = a.AddVec(cls4);
   void* dptr = nullptr;
   if (hipMalloc(&dptr, a.host.size()) != hipSuccess) { SetError("hipMalloc(us tables) failed"); return RGX_E_NOMEM; }
   if (hipMemcpy(dptr, a.host.data(), a.host.size(), hipMemcpyHostToDevice) != hipSuccess) { hipFree(dptr); SetError("hipMemcpy(us tables) failed"); return RGX_E_HIP; }
@@ -279,7 +283,7 @@ int UploadUs(Program* p) {
   d.nent = nent; d.stride = stride; d.ncls = u.ncls; d.nregs = u.nregs <= 1 ? 1 : (u.nregs <= 2 ? 2 : 4); d.lookahead = u.lookahead ? 1 : 0;
   if (simple) {
     d.ent4 = (const uint32_t*)(b + off_ent4); d.start_row4 = (const uint16_t*)(b + off_srow4);
-    d.nent4 = (int32_t)ent4.size(); d.rstmask = rstmask;
+    d.nent4 = (int32_t)ent4.size(); d.rstmask = rstmask; d.cls4 = b + off_cls4;
   }
   p->usdev = d;
   p->d_arena_us = dptr;

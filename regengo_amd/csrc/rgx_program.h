@@ -83,13 +83,15 @@ struct UsDev {
   int32_t ncls;
   int32_t nregs;                  // registers the automaton uses (1, 2 or 4 in the kernel's instantiations)
   int32_t lookahead;              // 1: match flags are kUsBefore (lazy construction), 0: kUsAfter
-  // "simple" automata (StartSearch::simple): register-free walk, scan_us_simple_kernel.  32-bit entries:
+  // "simple" automata (StartSearch::simple): register-free walk, scan_us_simple_kernel.  32-bit entries, rows of 260 bytes
+  // (32 entries twice: the tile byte is class * 4, bit 7 set on reset bytes; one dword of padding spreads the rows over banks):
   //   [0..15] byte offset of the next row (row 0: parked, walk over; row 1: parked, the single-step walker must repeat the
   //   stretch -- both rows all-"stay", no flags)   [29] a match ends here (single-step walker only)   [30] kUsFinal: a match
   //   ends at this byte for good   [31] register load: a thread that began at this byte survived it
   const uint32_t* ent4;           // [nent4] or nullptr
-  const uint16_t* start_row4;     // [ncls+1] like start_row_of_cls, in ent4 offsets
-  int32_t nent4;                  // (nstates + 1) * stride
+  const uint16_t* start_row4;     // [ncls+1] like start_row_of_cls, in ent4 byte offsets
+  const uint8_t* cls4;            // [256] byte -> class * 4 | 0x80 on reset bytes
+  int32_t nent4;                  // (nstates + 1) * 65
   unsigned long long rstmask;     // bit k: class k is a reset class (ncls <= 63 for simple)
 };
 

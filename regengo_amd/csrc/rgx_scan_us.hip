@@ -416,6 +416,8 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_kernel(DevTables T, UsD
 constexpr int kSReach = 1152;                          // bytes past the tile's end the last stretch may run
 constexpr int kSBits = kTileBytes + kSReach;           // bit positions of L and E
 constexpr int kSWords = kSBits / 32;                   // 548
+constexpr unsigned kSPitch = 260;                      // bytes per table row: 64 entries + one dword, so that rows start in different banks
+constexpr unsigned kSZoff = kSPitch;                   // row 1: "the single-step walker must repeat this stretch"
 
 struct UsSLayout {
   int tile, ent, cls, srow, L, E, sync, delta, kind, misc, total;
@@ -423,7 +425,7 @@ struct UsSLayout {
 __host__ __device__ inline UsSLayout UsSLds(int nent4, int stride) {
   UsSLayout l;
   int o = 0;
-  l.tile = o; o += (kUPadded + 15) & ~15;
+  l.tile = o; o += (kUPadded + 15) & ~15;            // 64-byte rows padded to 68: the lanes' cursors sit ~64 bytes apart
   l.ent = o; o += (nent4 * 4 + 15) & ~15;
   l.cls = o; o += 256;
   l.srow = o; o += (stride * 2 + 15) & ~15;
@@ -439,20 +441,31 @@ __host__ __device__ inline UsSLayout UsSLds(int nent4, int stride) {
 
 struct SIn {
   const uint8_t* g;
-  const uint8_t* gcls;
-  const unsigned char* tile;   // LDS window: class id * 4
+  const uint8_t* gcls4;        // byte -> class * 4 | 0x80 on reset bytes
+  const unsigned char* tile;   // LDS window of the same
   int wb, wlim, len, eot4;
   __device__ __forceinline__ unsigned At4(int i) const {
     const unsigned rel = (unsigned)(i - wb);
     if (rel < (unsigned)wlim) return tile[UPad((int)rel)];
     if (i >= len) return (unsigned)eot4;
-    return (unsigned)gcls[g[i]] << 2;
+    return gcls4[g[i]];
   }
 };
 
+// (row & 0xFFFF) + byte N of w: the table address of one step, one instruction
+template <int N>
+__device__ __forceinline__ unsigned RowPlusByte(unsigned row, unsigned w) {
+  unsigned r;
+  if (N == 0) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:BYTE_0" : "=v"(r) : "v"(row), "v"(w));
+  else if (N == 1) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:BYTE_1" : "=v"(r) : "v"(row), "v"(w));
+  else if (N == 2) asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:BYTE_2" : "=v"(r) : "v"(row), "v"(w));
+  else asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:BYTE_3" : "=v"(r) : "v"(row), "v"(w));
+  return r;
+}
+
 // First sync point inside slice k = [k*64, k*64+64): the carried search position when the carry pass supplied one, else the
 // offset behind the first reset byte from k*64-1 on (offset 0 of the text is one).  -1: none.
-__device__ __forceinline__ int SliceStart(const SIn& in, const int32_t* carry_in, unsigned long long rstmask, int k) {
+__device__ __forceinline__ int SliceStart(const SIn& in, const int32_t* carry_in, int k) {
   const int a = k * kSliceBytes;
   if (a >= in.len) return -1;
   if (carry_in) {
@@ -460,17 +473,31 @@ __device__ __forceinline__ int SliceStart(const SIn& in, const int32_t* carry_in
     if (c >= 0) return (c >= a && c < a + kSliceBytes && c < in.len) ? c : -1;
   }
   if (a == 0) return 0;
-  for (int j = a - 1; j < a + kSliceBytes - 1 && j + 1 < in.len; ++j)
-    if ((rstmask >> (in.At4(j) >> 2)) & 1ull) return j + 1;
-  return -1;
+  int r = -1;
+  if ((unsigned)(a - 4 - in.wb) < (unsigned)in.wlim && a + kSliceBytes - in.wb <= in.wlim) {
+    // the slice and the byte before it sit in the window: four bytes per test (bit 7 of a tile byte = reset byte)
+    const unsigned char* row = in.tile + UPad(a - in.wb);  // the slice is one padded row of the tile
+    unsigned m = *reinterpret_cast<const unsigned*>(in.tile + UPad(a - 4 - in.wb)) & 0x80000000u;   // offset a - 1
+    int base = a - 4;
+    for (int d = 0; m == 0 && d < 16; ++d) {
+      m = reinterpret_cast<const unsigned*>(row)[d] & 0x80808080u;
+      if (d == 15) m &= 0x00808080u;                       // offset a + 63 would give a sync point in the next slice
+      base = a + 4 * d;
+    }
+    if (m) r = base + (__builtin_ctz(m) >> 3) + 1;
+  } else {
+    for (int j = a - 1; j < a + kSliceBytes - 1 && r < 0; ++j)
+      if (in.At4(j) & 0x80u) r = j + 1;
+  }
+  return (r >= 0 && r < in.len) ? r : -1;
 }
 
 // Single-step walker of one stretch [s, e]: consumes bytes s..e, records loads at [s, e) and ends at (s, e] (bit sets in LDS;
 // an end beyond the bit sets goes to *far).  Handles what the wave-uniform loop does not: rewinds, bytes outside the window.
-__device__ __noinline__ void UsSimpleSlow(const unsigned* s_ent4, const uint16_t* s_srow, unsigned* s_L, unsigned* s_E, int* far,
-                                          const SIn& in, int tb, int s, int e, int lookahead, unsigned zoff) {
+__device__ __noinline__ void UsSimpleSlow(const unsigned char* s_entb, const uint16_t* s_srow, unsigned* s_L, unsigned* s_E, int* far,
+                                          const SIn& in, int tb, int s, int e, int lookahead) {
   int i = s;
-  unsigned row = s_srow[(i > 0 ? in.At4(i - 1) : (unsigned)in.eot4) >> 2];
+  unsigned row = s_srow[((i > 0 ? in.At4(i - 1) : (unsigned)in.eot4) & 0x7Cu) >> 2];
   int pend = -1;
   auto set_e = [&](int at) {
     const unsigned b = (unsigned)(at - tb);
@@ -478,7 +505,7 @@ __device__ __noinline__ void UsSimpleSlow(const unsigned* s_ent4, const uint16_t
   };
   while (i <= e) {
     const unsigned k4 = in.At4(i);
-    const unsigned ent = s_ent4[((row & 0xFFFFu) + k4) >> 2];
+    const unsigned ent = *reinterpret_cast<const unsigned*>(s_entb + (row & 0xFFFFu) + k4);
     if (lookahead && (ent & (1u << 29))) pend = i;
     if (ent & (1u << 30)) { set_e(i); pend = -1; }
     if ((ent & (1u << 31)) && i < e) {
@@ -488,13 +515,13 @@ __device__ __noinline__ void UsSimpleSlow(const unsigned* s_ent4, const uint16_t
     if (!lookahead && (ent & (1u << 29))) pend = i + 1;
     row = ent & 0xFFFFu;
     ++i;
-    if (row == zoff) {
+    if (row == kSZoff) {
       // the state died with an older match pending: it is final and the search rewinds to its end (find.go:452-457)
       if (pend < 0 || pend > e) break;
       set_e(pend);
       if (pend >= in.len) break;
       i = pend;
-      row = s_srow[in.At4(i - 1) >> 2];
+      row = s_srow[(in.At4(i - 1) & 0x7Cu) >> 2];
       pend = -1;
     } else if (row == 0) {
       break;                                   // the end of the text
@@ -514,18 +541,25 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_simple_kernel(DevTables
   int* s_sync = reinterpret_cast<int*>(smem + Ly.sync);
   int32_t* s_delta = reinterpret_cast<int32_t*>(smem + Ly.delta);
   unsigned char* s_kind = smem + Ly.kind;
-  unsigned* s_misc = reinterpret_cast<unsigned*>(smem + Ly.misc);   // [0] tile [1..4] wave totals [5] tail total [8..9] base [10] far end
+  unsigned* s_misc = reinterpret_cast<unsigned*>(smem + Ly.misc);   // [0] tile [1..4] wave totals [5] tail total [6] far count [8..9] base [10] far end
   int* s_far = reinterpret_cast<int*>(s_misc + 10);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int ncls = U.ncls;
-  const unsigned zoff = (unsigned)U.stride * 4u;
+#ifdef RGX_US_PROFILE
+  long long tstamp[8];
+  int nstamp = 0;
+#define US_STAMP() tstamp[nstamp++] = (long long)__builtin_readcyclecounter();
+#else
+#define US_STAMP()
+#endif
+  US_STAMP()
 
   if (tid == 0) { s_misc[0] = P.use_tickets ? atomicAdd(&P.counters[0], 1u) : blockIdx.x; *s_far = -1; }
   for (int w = tid; w < U.nent4; w += kBlockThreads) s_ent4[w] = U.ent4[w];
-  s_cls[tid] = (unsigned char)(U.cls[tid] << 2);
+  s_cls[tid] = U.cls4[tid];
   if (tid <= ncls) s_srow[tid] = U.start_row4[tid];
   if (tid < T.ncap) { s_delta[tid] = T.cap_delta[tid]; s_kind[tid] = T.cap_kind[tid]; }
   for (int w = tid; w < kSWords; w += kBlockThreads) { s_L[w] = 0; s_E[w] = 0; }
@@ -546,17 +580,29 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_simple_kernel(DevTables
     wlim = last - wb;
     const int nchunks = (last - first) >> 4;
     const uint4* gsrc = reinterpret_cast<const uint4*>(P.buf + first);
-    for (int c = tid; c < nchunks; c += kBlockThreads) {
+    // every 16-byte load of the thread is issued before the first one is used (five at most: 1056 pieces, 256 threads)
+    constexpr int kMaxPieces = (kUWindow / 16 + kBlockThreads - 1) / kBlockThreads;
+    uint4 v[kMaxPieces];
+#pragma unroll
+    for (int q = 0; q < kMaxPieces; ++q) {
+      const int c = tid + q * kBlockThreads;
+      v[q] = make_uint4(0, 0, 0, 0);
+      if (c < nchunks && first + (c << 4) + 16 <= len) v[q] = gsrc[c];
+    }
+#pragma unroll
+    for (int q = 0; q < kMaxPieces; ++q) {
+      const int c = tid + q * kBlockThreads;
+      if (c >= nchunks) break;
       const int abs0 = first + (c << 4);
-      uint32_t* dst = reinterpret_cast<uint32_t*>(s_tile + UPad(abs0 - wb));
+      uint32_t* dst = reinterpret_cast<uint32_t*>(s_tile + UPad(abs0 - wb));     // (a padded row is only 4-byte aligned)
+      unsigned o[4];
       if (abs0 + 16 <= len) {
-        const uint4 v = gsrc[c];
-        const unsigned w[4] = {v.x, v.y, v.z, v.w};
+        const unsigned w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
 #pragma unroll
         for (int d = 0; d < 4; ++d) {
           const unsigned x = w[d];
-          dst[d] = (unsigned)s_cls[x & 255u] | ((unsigned)s_cls[(x >> 8) & 255u] << 8) | ((unsigned)s_cls[(x >> 16) & 255u] << 16) |
-                   ((unsigned)s_cls[x >> 24] << 24);
+          o[d] = (unsigned)s_cls[x & 255u] | ((unsigned)s_cls[(x >> 8) & 255u] << 8) | ((unsigned)s_cls[(x >> 16) & 255u] << 16) |
+                 ((unsigned)s_cls[x >> 24] << 24);
         }
       } else {
         for (int d = 0; d < 4; ++d) {
@@ -565,32 +611,36 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_simple_kernel(DevTables
             const int at = abs0 + 4 * d + b;
             x |= (at < len ? (unsigned)s_cls[P.buf[at]] : eot4) << (8 * b);
           }
-          dst[d] = x;
+          o[d] = x;
         }
       }
+      dst[0] = o[0]; dst[1] = o[1]; dst[2] = o[2]; dst[3] = o[3];
     }
   }
+  US_STAMP()
   __syncthreads();
-  const SIn in{P.buf, U.cls, s_tile, wb, wlim, len, (int)eot4};
-  const unsigned long long rstmask = U.rstmask;
+  US_STAMP()
+  const SIn in{P.buf, U.cls4, s_tile, wb, wlim, len, (int)eot4};
+  const unsigned char* s_entb = reinterpret_cast<const unsigned char*>(s_ent4);
 
   // ---- the lane's stretch [s, e]
   const int slice = tile * kBlockThreads + tid;
   const int a = tb + tid * kSliceBytes;
-  int s = SliceStart(in, P.carry_in, rstmask, slice);
+  int s = SliceStart(in, P.carry_in, slice);
   if (s < 0 && a < len && !(P.carry_in && P.carry_in[slice] >= 0)) {
     // no sync point in the slice: some earlier lane walks it -- unless none is in reach behind either (the other scan kernels'
     // rule: the slice is "unsynced", the host resolves such runs with the carry pass)
     int lower = a - 1 - kUMaxLookBehind;
     if (lower < 0) lower = 0;
     int j = a - 2;
-    while (j >= lower && !((rstmask >> (in.At4(j) >> 2)) & 1ull)) --j;
+    while (j >= lower && !(in.At4(j) & 0x80u)) --j;
     if (j < lower && lower > 0) {
       atomicAdd(&P.counters[1], 1u);
       if (P.slice_unsynced) P.slice_unsynced[slice] = 1;
     }
   }
   s_sync[tid] = s;
+  US_STAMP()
   __syncthreads();
   int e = 0x7FFFFFF0;
   bool slow = false;
@@ -603,7 +653,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_simple_kernel(DevTables
       // the tile's last stretch ends at the first sync point at or after the next tile's start
       const int k0 = (tile + 1) * kBlockThreads;
       int found = -1;
-      for (int k = k0; k < k0 + kSReach / kSliceBytes - 1 && k * kSliceBytes < len && found < 0; ++k) found = SliceStart(in, P.carry_in, rstmask, k);
+      for (int k = k0; k < k0 + kSReach / kSliceBytes - 1 && k * kSliceBytes < len && found < 0; ++k) found = SliceStart(in, P.carry_in, k);
       if (found >= 0) e = found;
       else if (k0 * kSliceBytes + kSReach - kSliceBytes < len) {
         // no sync point in reach and the text goes on: leave the stretch to the carry pass
@@ -613,60 +663,94 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_simple_kernel(DevTables
       }
     }
   }
-  // wave-uniform walk: i = offset of the dword being consumed; a lane enters its start state at sub-step (s & 3) of its first
-  // trip and parks (row 0: every entry "stay, no flags") once it has consumed byte e
+  // Wave-uniform walk.  Every lane of the wave makes the same number of trips (four steps over one aligned dword of the
+  // tile each); a lane enters its start state at sub-step (s & 3) of the first trip; after the trip that consumes byte e it
+  // parks in row 0 (every entry: stay, no flags), and flags at offsets outside its stretch are masked off.
   {
     const int first_valid = wb < 0 ? 0 : wb;
     bool fast = s >= 0;
-    const int e_eff = e < len ? e : len;           // the last byte the stretch consumes (len: the end-of-text step)
+    int e_eff = e < len ? e : len;                 // the last byte the stretch consumes (len: the end-of-text step)
     if (fast && (s < first_valid || e_eff >= wb + wlim)) { fast = false; slow = true; }
-    int i = fast ? (s & ~3) : first_valid;
+    const int i0 = fast ? (s & ~3) : first_valid;
+    int ntrips = fast ? ((e_eff - i0) >> 2) + 1 : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(ntrips, d, 64); ntrips = o > ntrips ? o : ntrips; }
+    const int trips = __builtin_amdgcn_readfirstlane(ntrips);
+    US_STAMP()
     unsigned startrow = 0;
-    if (fast) startrow = s_srow[(s > 0 ? in.At4(s - 1) : eot4) >> 2];
+    if (fast) startrow = s_srow[((s > 0 ? in.At4(s - 1) : eot4) & 0x7Cu) >> 2];
     const unsigned phase = fast ? (unsigned)(s & 3) : 4u;
-    unsigned row = 0;
-    bool active = fast, first = true;
-    const unsigned pmax = (unsigned)UPad((wlim - 4) & ~3);
-    const unsigned char* s_entb = reinterpret_cast<const unsigned char*>(s_ent4);
-    while (__any(active)) {
-      unsigned p = (unsigned)UPad(i - wb);
-      p = p > pmax ? pmax : p;
-      const unsigned w = *reinterpret_cast<const unsigned*>(s_tile + p);
-      const unsigned irel = (unsigned)(i - tb);
-      const unsigned b0 = 1u << (irel & 31u);
-      unsigned lacc = 0, eacc = 0;
-#define USS_STEP(N)                                                                                     \
-  {                                                                                                     \
-    if (first) row = phase == (unsigned)(N) ? startrow : row;                                           \
-    const unsigned ent = *reinterpret_cast<const unsigned*>(s_entb + (row & 0xFFFFu) + ((w >> (8 * (N))) & 255u)); \
-    lacc |= (unsigned)((int)ent >> 31) & (b0 << (N));                                                   \
-    eacc |= (unsigned)((int)(ent << 1) >> 31) & (b0 << (N));                                            \
-    row = ent;                                                                                          \
+    if (!fast) e_eff = -1;                          // nothing of this lane's is recorded
+    unsigned row = 0, zrow = 0;
+    unsigned lacc = 0, eacc = 0, lword = 0, eword = 0;
+    const unsigned relmax = (unsigned)(wlim - 4);
+    unsigned rel = (unsigned)(i0 - wb);
+    int kl = e_eff - i0;                            // offsets of the trip at which loads still count: [0, kl), ends: [0, kl]
+    unsigned irel = (unsigned)(i0 - tb);
+#define USS_STEP(N, FIRST)                                                              \
+  {                                                                                     \
+    if (FIRST) row = phase == (unsigned)(N) ? startrow : row;                           \
+    const unsigned ent = *reinterpret_cast<const unsigned*>(s_entb + RowPlusByte<N>(row, w)); \
+    lacc = __builtin_amdgcn_alignbit(lacc, ent, 31);     /* (lacc << 1) | load flag */  \
+    eacc = __builtin_amdgcn_alignbit(eacc, ent + ent, 31);                              \
+    row = ent;                                                                          \
   }
-      USS_STEP(0) USS_STEP(1) USS_STEP(2) USS_STEP(3)
-#undef USS_STEP
-      first = false;
-      if (__any(active && i + 4 > e)) {
-        // the stretch ends inside this trip: loads count at [.., e), ends at [.., e]
-        const int kl = e - i;                        // positions of this trip that may carry a load
-        const unsigned ml = kl >= 4 ? 0xFu : (kl <= 0 ? 0u : (1u << kl) - 1u);
-        const unsigned me = kl >= 3 ? 0xFu : (kl < 0 ? 0u : (2u << kl) - 1u);
-        lacc &= ml << (irel & 31u);
-        eacc &= me << (irel & 31u);
-      }
-      if (active) {
-        if (lacc) atomicOr(&s_L[irel >> 5], lacc);
-        if (eacc) atomicOr(&s_E[irel >> 5], eacc);
-      }
-      i += 4;
-      const unsigned ro = row & 0xFFFFu;
-      if (ro == zoff && active) slow = true;         // rewind needed: the single-step walker repeats the stretch
-      if (ro <= zoff || i > e) { active = false; row = 0; }
+#define USS_FLUSH()                                                                     \
+  {                                                                                     \
+    unsigned ln = __builtin_bitreverse32(lacc) >> 28, en = __builtin_bitreverse32(eacc) >> 28;   /* sub-step N at bit N */ \
+    bool parking = false;                                                               \
+    if (__any(kl < 4)) {                                                                \
+      const int kc = kl < 0 ? 0 : (kl > 4 ? 4 : kl);                                    \
+      ln &= (1u << kc) - 1u;                                                            \
+      en &= kl < 0 ? 0u : (2u << kc) - 1u;                                              \
+      parking = kl < 4;                                                                 \
+      zrow = parking ? row : zrow;                 /* the stretch is over: remember where it ended, then park */ \
+      row = parking ? 0u : row;                                                         \
+      kl = parking ? 0x3FFFFFFF : kl;              /* (a parked lane raises no flags: no masking needed any more) */ \
+    }                                                                                   \
+    const unsigned sh = irel & 31u;                                                     \
+    lword |= ln << sh;                                                                  \
+    eword |= en << sh;                                                                  \
+    /* the lane's bits of one 32-bit word leave together: when its last nibble is done, or when the lane parks */ \
+    const bool flush = parking || (sh == 28u && kl < 0x30000000);                       \
+    if (__any(flush)) {                                                                 \
+      if (flush) {                                                                      \
+        const unsigned wi = irel >> 5 > (unsigned)(kSWords - 1) ? (unsigned)(kSWords - 1) : irel >> 5; \
+        if (lword) atomicOr(&s_L[wi], lword);                                           \
+        if (eword) atomicOr(&s_E[wi], eword);                                           \
+        lword = 0; eword = 0;                                                           \
+      }                                                                                 \
+    }                                                                                   \
+    kl -= 4;                                                                            \
+    irel += 4;                                                                          \
+    rel += 4;                                                                           \
+    rel = rel > relmax ? relmax : rel;                                                  \
+  }
+    if (trips > 0) {
+      const unsigned w = *reinterpret_cast<const unsigned*>(s_tile + rel + ((rel >> 6) << 2));
+      USS_STEP(0, true) USS_STEP(1, true) USS_STEP(2, true) USS_STEP(3, true)
+      USS_FLUSH()
     }
+    for (int t = 1; t < trips; ++t) {
+      const unsigned w = *reinterpret_cast<const unsigned*>(s_tile + rel + ((rel >> 6) << 2));
+      USS_STEP(0, false) USS_STEP(1, false) USS_STEP(2, false) USS_STEP(3, false)
+      USS_FLUSH()
+    }
+#undef USS_STEP
+#undef USS_FLUSH
+    if (fast && (zrow & 0xFFFFu) == kSZoff) slow = true;     // a rewind was needed: the single-step walker repeats the stretch
   }
+  US_STAMP()
   if (slow && s >= 0)
-    UsSimpleSlow(s_ent4, s_srow, s_L, s_E, s_far, in, tb, s, e < len ? e : len, U.lookahead, zoff);
+    UsSimpleSlow(s_entb, s_srow, s_L, s_E, s_far, in, tb, s, e < len ? e : len, U.lookahead);
   __syncthreads();
+  US_STAMP()
+#ifdef RGX_US_PROFILE
+  if ((blockIdx.x == 20000 || blockIdx.x == 40001) && (tid == 0 || tid == 130)) {
+    printf("blk %d tid %d: tables+zero %lld | stage(own) %lld | barrier %lld | sync search %lld | barrier+end+setup %lld | walk %lld | slow+barrier %lld\n", blockIdx.x, tid,
+           tstamp[1] - tstamp[0] > 0 ? 0LL : 0LL, tstamp[1] - tstamp[0], tstamp[2] - tstamp[1], tstamp[3] - tstamp[2], tstamp[4] - tstamp[3], tstamp[5] - tstamp[4], tstamp[6] - tstamp[5]);
+  }
+#endif
 
   // ---- phase 2: the tile's matches = the set bits of E, in order.  Lane t counts E bits [64t, 64t+64); the bits past the
   // tile's end (the last stretch) are the "tail" words, counted by the first lanes of wave 0.
