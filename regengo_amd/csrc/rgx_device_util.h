@@ -87,6 +87,45 @@ __device__ __forceinline__ unsigned long long LookBack(unsigned long long* desc,
   return excl;
 }
 
+// The same in two halves, for kernels that publish a tile's count, go on with other work and come back for the prefix once the
+// predecessors have long published theirs (rgx_scan_us.hip: the look-back of tile t is resolved after the walk of tile t+1).
+__device__ __forceinline__ void LookBackPublish(unsigned long long* desc, int id, unsigned long long own, int lane) {
+  if (lane == 0)
+    __hip_atomic_store(&desc[id], (id == 0 ? kDescPrefix : kDescAgg) | own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ unsigned long long LookBackResolve(unsigned long long* desc, int id, unsigned long long own, int lane,
+                                                               unsigned* timeout_flag, bool bounded = true) {
+  unsigned long long excl = 0;
+  if (id > 0) {
+    int idx = id - 1 - lane;
+    bool dead = false;
+    while (true) {
+      unsigned long long d = kDescPrefix;
+      if (idx >= 0) {
+        d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        while ((d >> 62) == 0) {
+          if (bounded && ++spins > kLookBackSpinLimit) { dead = true; break; }
+          __builtin_amdgcn_s_sleep(8);
+          d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (__any(dead)) {
+        if (lane == 0) atomicExch(timeout_flag, 1u);
+        break;
+      }
+      const unsigned long long pm = __ballot((d >> 62) == 2);
+      const int first = pm ? __builtin_ctzll(pm) : 64;
+      excl += WaveSum64(lane <= first ? (d & kDescValMask) : 0ull);
+      if (pm) break;
+      idx -= 64;
+    }
+    if (lane == 0)
+      __hip_atomic_store(&desc[id], kDescPrefix | (excl + own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  return excl;
+}
+
 // (A two-level variant, a 256-descriptor window (four per lane) -- super-blocks of 64 groups with an arrival atomic per group -- and persistent workgroups with
 // ticketed or round-robin chunk ids were both measured SLOWER on the 1 GiB scan than this one-level form with one
 // descriptor per workgroup: the returning atomics and the per-round simultaneous finishes cost more than they saved.)

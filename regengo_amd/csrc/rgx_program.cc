@@ -270,7 +270,42 @@ int UploadUs(Program* p) {
     srow4[u.ncls] = (uint16_t)off(u.start[kCtxBOT]);
     for (int c = 0; c < 256; c++) cls4[c] = (uint8_t)((u.cls[c] << 2) | (rst[u.cls[c]] ? 0x80 : 0));
   }
+  // pair tables (rgx_program.h: UsDev::ent2): the composition of two single steps, parked rows and the "no byte" nibble included
+  std::vector<uint32_t> ent2;
+  std::vector<uint16_t> srow2(stride);
+  std::vector<uint8_t> cls2(256, 0);
+  const bool pairs = simple && stride <= 15 && u.nstates + 1 <= 63;
+  if (pairs) {
+    constexpr uint32_t kPitch2W = 257;                  // dwords per row; row offsets are kept in DWORDS (row + index is one SDWA add)
+    const int nrows = u.nstates + 1;
+    // one step of the single-byte image: row index r (0, 1 = parked; q + 1), class k (15: no byte) -> (row index, load, final, match)
+    auto step1 = [&](int r, int k, int* nr, bool* ld, bool* fin, bool* mt) {
+      *ld = *fin = *mt = false;
+      if (r < 2 || k == 15 || k >= stride) { *nr = r; return; }
+      const uint32_t v = ent4[(size_t)r * kPitchW + k];
+      *nr = (int)((v & 0xFFFFu) / kPitch);
+      *ld = (v >> 31) & 1; *fin = (v >> 30) & 1; *mt = (v >> 29) & 1;
+    };
+    ent2.assign((size_t)nrows * kPitch2W, 0);
+    for (int r = 0; r < nrows; r++)
+      for (int k1 = 0; k1 < 16; k1++)
+        for (int k2 = 0; k2 < 16; k2++) {
+          int r1, r2; bool l1, f1, m1, l2, f2, m2;
+          step1(r, k1, &r1, &l1, &f1, &m1);
+          step1(r1, k2, &r2, &l2, &f2, &m2);
+          uint32_t v = (uint32_t)r2 * kPitch2W;
+          if (l1) v |= 1u << 31;
+          if (l2) v |= 1u << 30;
+          if (f1) v |= 1u << 29;
+          if (f2) v |= 1u << 28;
+          if (m1) v |= 1u << 27;
+          ent2[(size_t)r * kPitch2W + (k1 | (k2 << 4))] = v;
+        }
+    for (int k = 0; k < stride; k++) srow2[k] = (uint16_t)((srow4[k] / kPitch) * kPitch2W);
+    for (int c = 0; c < 256; c++) cls2[c] = (uint8_t)(u.cls[c] | (rst[u.cls[c]] ? 0x80 : 0));
+  }
   Arena a;
+  const size_t off_ent2 = a.AddVec(ent2), off_srow2 = a.AddVec(srow2), off_cls2 = a.AddVec(cls2);
   const size_t off_ent = a.AddVec(ent), off_cls = a.Add(u.cls, 256), off_srow = a.AddVec(srow), off_rst = a.AddVec(rst);
   const size_t off_ent4 = a.AddVec(ent4), off_srow4 = a.AddVec(srow4), off_cls4 = a.AddVec(cls4);
   void* dptr = nullptr;
@@ -284,6 +319,10 @@ int UploadUs(Program* p) {
   if (simple) {
     d.ent4 = (const uint32_t*)(b + off_ent4); d.start_row4 = (const uint16_t*)(b + off_srow4);
     d.nent4 = (int32_t)ent4.size(); d.rstmask = rstmask; d.cls4 = b + off_cls4;
+  }
+  if (pairs) {
+    d.ent2 = (const uint32_t*)(b + off_ent2); d.start_row2 = (const uint16_t*)(b + off_srow2); d.cls2 = b + off_cls2;
+    d.nent2 = (int32_t)ent2.size();
   }
   p->usdev = d;
   p->d_arena_us = dptr;

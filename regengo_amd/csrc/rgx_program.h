@@ -93,6 +93,16 @@ struct UsDev {
   const uint8_t* cls4;            // [256] byte -> class * 4 | 0x80 on reset bytes
   int32_t nent4;                  // (nstates + 1) * 65
   unsigned long long rstmask;     // bit k: class k is a reset class (ncls <= 63 for simple)
+  // simple automata with at most 15 classes (the end-of-text class included): TWO input bytes per table look-up
+  // (scan_us_pair_kernel).  The tile holds one byte per two input bytes -- low nibble = class of the first, high nibble =
+  // class of the second, nibble 15 = "no byte" (the state stays) -- and a row has 256 entries (+1 dword of padding):
+  //   [0..15] DWORD offset of the row after both bytes (rows 0 and 1 park, as above)   [31] load at the first byte
+  //   [30] load at the second   [29] kUsFinal at the first   [28] at the second   [27] a match ends at the first byte
+  //   (single-step use: second nibble 15)
+  const uint32_t* ent2;           // [nent2] or nullptr
+  const uint16_t* start_row2;     // [ncls+1] in ent2 dword offsets
+  const uint8_t* cls2;            // [256] byte -> class | 0x80 on reset bytes
+  int32_t nent2;                  // (nstates + 1) * 257
 };
 
 struct Program {

@@ -492,6 +492,128 @@ __device__ __forceinline__ int SliceStart(const SIn& in, const int32_t* carry_in
   return (r >= 0 && r < in.len) ? r : -1;
 }
 
+// Phases 2 and 3 of the register-free kernels: count the tile's matches (the set bits of E), order them across tiles with the
+// decoupled look-back, derive every start from L and write the records.
+struct UsTileOut {      // what a thread keeps of a counted tile until its records are written
+  unsigned long long mbits, tbits;     // this lane's E bits: chunk tid of the tile, and (first lanes) a chunk of the tail words
+  unsigned cnt, incl, tcnt, tincl, wave_off, main_total, block_total, farcnt;
+  int far, tile, tb;
+};
+
+// the last load before pe (a load AT pe belongs to the next match)
+__device__ __forceinline__ int UsStartOf(const unsigned* s_L, int tb, int pe) {
+  const int b = pe - tb - 1;
+  int wi = b >> 5;
+  unsigned m = s_L[wi] & (0xFFFFFFFFu >> (31 - (b & 31)));
+  while (m == 0 && wi > 0) m = s_L[--wi];
+  return tb + (wi << 5) + 31 - __builtin_clz(m);
+}
+
+// Phase 2: lane t counts E bits [64t, 64t+64); the bits past the tile's end (the last stretch) are the "tail" words, counted by
+// the first lanes of wave 0.  Contains one __syncthreads.
+__device__ __forceinline__ UsTileOut UsCountTile(const ScanParams& P, int tile, int tb, int len, const unsigned* s_L, const unsigned* s_E,
+                                                 unsigned* s_misc, int far) {
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  constexpr int kTailChunks = kSReach / 64;          // 18
+  const unsigned long long* E64 = reinterpret_cast<const unsigned long long*>(s_E);
+  const bool filter = P.own_lo > 0 || P.own_hi < len;
+  auto owned_bits = [&](unsigned long long bits, int chunk) -> unsigned long long {
+    if (!filter) return bits;
+    unsigned long long keep = 0, x = bits;
+    while (x) {
+      const int b = __builtin_ctzll(x);
+      x &= x - 1;
+      const int st = UsStartOf(s_L, tb, tb + chunk * 64 + b);
+      if (st >= P.own_lo && st < P.own_hi) keep |= 1ull << b;
+    }
+    return keep;
+  };
+  UsTileOut o;
+  o.tile = tile; o.tb = tb; o.far = far;
+  o.mbits = owned_bits(E64[tid], tid);
+  o.tbits = (tid < kTailChunks) ? owned_bits(E64[kBlockThreads + tid], kBlockThreads + tid) : 0ull;
+  o.farcnt = 0;
+  if (tid == 0 && far >= 0) {
+    const int st = UsStartOf(s_L, tb, tb + kSBits);
+    o.farcnt = (!filter || (st >= P.own_lo && st < P.own_hi)) ? 1u : 0u;
+  }
+  o.cnt = (unsigned)__popcll(o.mbits);
+  o.tcnt = (unsigned)__popcll(o.tbits);
+  o.incl = (unsigned)WaveInclusiveScan(o.cnt, lane);
+  o.tincl = (wave == 0) ? (unsigned)WaveInclusiveScan(o.tcnt, lane) : 0u;
+  if (lane == 63) s_misc[1 + wave] = o.incl;
+  if (tid == 63) s_misc[5] = o.tincl;
+  if (tid == 0) s_misc[6] = o.farcnt;        // a match that ends beyond the bit sets is the tile's last one
+  __syncthreads();
+  o.wave_off = 0; o.main_total = 0;
+#pragma unroll
+  for (int w = 0; w < kBlockThreads / 64; ++w) {
+    const unsigned t = s_misc[1 + w];
+    if (w < wave) o.wave_off += t;
+    o.main_total += t;
+  }
+  o.block_total = o.main_total + s_misc[5] + s_misc[6];
+  o.farcnt = s_misc[6];
+  return o;
+}
+
+// Phase 3: span records in match order, `base` = matches before this tile
+__device__ __forceinline__ void UsEmitTile(const DevTables& T, const ScanParams& P, const UsTileOut& o, unsigned long long base,
+                                           const unsigned* s_L, const int32_t* s_delta, const unsigned char* s_kind) {
+  const int tid = threadIdx.x;
+  constexpr int kTailChunks = kSReach / 64;
+  const int ncap = T.ncap;
+  auto emit = [&](unsigned long long idx, int st, int pe) {
+    if (idx >= (unsigned long long)P.cap_records) return;
+    if (P.starts_only) { P.spans[idx] = st; return; }
+    int32_t* rec = P.spans + idx * ncap;
+    if (T.fixed_captures) UsWriteFixed(rec, ncap, s_kind, s_delta, st, pe);
+    else { rec[0] = st; rec[1] = pe; }
+  };
+  {
+    unsigned long long idx = base + o.wave_off + (o.incl - o.cnt);
+    unsigned long long x = o.mbits;
+    while (x) {
+      const int b = __builtin_ctzll(x);
+      x &= x - 1;
+      const int pe = o.tb + tid * 64 + b;
+      emit(idx++, UsStartOf(s_L, o.tb, pe), pe);
+    }
+  }
+  if (tid < kTailChunks) {
+    unsigned long long idx = base + o.main_total + (o.tincl - o.tcnt);
+    unsigned long long x = o.tbits;
+    while (x) {
+      const int b = __builtin_ctzll(x);
+      x &= x - 1;
+      const int pe = o.tb + (kBlockThreads + tid) * 64 + b;
+      emit(idx++, UsStartOf(s_L, o.tb, pe), pe);
+    }
+  }
+  if (tid == 0 && o.farcnt) emit(base + o.block_total - 1, UsStartOf(s_L, o.tb, o.tb + kSBits), o.far);
+}
+
+// count + look-back + records of one tile, back to back (scan_us_simple_kernel: one tile per workgroup)
+__device__ __forceinline__ void UsFinishTile(const DevTables& T, const ScanParams& P, int tile, int tb, int len, const unsigned* s_L,
+                                             const unsigned* s_E, unsigned* s_misc, const int* s_far, const int32_t* s_delta,
+                                             const unsigned char* s_kind) {
+  const int tid = threadIdx.x;
+  const UsTileOut o = UsCountTile(P, tile, tb, len, s_L, s_E, s_misc, *s_far);
+  if (P.count_only) {
+    if (tid == 0 && o.block_total) atomicAdd(P.total, (unsigned long long)o.block_total);
+    return;
+  }
+  if ((tid >> 6) == 0) {
+    if (tid == 0 && o.block_total) atomicAdd(P.total, (unsigned long long)o.block_total);
+    const unsigned long long excl = LookBack(P.tile_desc, tile, o.block_total, tid & 63, &P.counters[3], 1, nullptr, !P.use_tickets);
+    if (tid == 0) { s_misc[8] = (unsigned)excl; s_misc[9] = (unsigned)(excl >> 32); }
+  }
+  __syncthreads();
+  UsEmitTile(T, P, o, ((unsigned long long)s_misc[9] << 32) | s_misc[8], s_L, s_delta, s_kind);
+}
+
 // Single-step walker of one stretch [s, e]: consumes bytes s..e, records loads at [s, e) and ends at (s, e] (bit sets in LDS;
 // an end beyond the bit sets goes to *far).  Handles what the wave-uniform loop does not: rewinds, bytes outside the window.
 __device__ __noinline__ void UsSimpleSlow(const unsigned char* s_entb, const uint16_t* s_srow, unsigned* s_L, unsigned* s_E, int* far,
@@ -752,96 +874,405 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_simple_kernel(DevTables
   }
 #endif
 
-  // ---- phase 2: the tile's matches = the set bits of E, in order.  Lane t counts E bits [64t, 64t+64); the bits past the
-  // tile's end (the last stretch) are the "tail" words, counted by the first lanes of wave 0.
-  constexpr int kTailChunks = kSReach / 64;          // 18
-  const unsigned long long* E64 = reinterpret_cast<const unsigned long long*>(s_E);
-  auto start_of = [&](int pe) -> int {
-    // the last load before pe (a load AT pe belongs to the next match)
-    int b = pe - tb - 1;
-    int wi = b >> 5;
-    unsigned m = s_L[wi] & (0xFFFFFFFFu >> (31 - (b & 31)));
-    while (m == 0 && wi > 0) m = s_L[--wi];
-    return tb + (wi << 5) + 31 - __builtin_clz(m);
-  };
-  const bool filter = P.own_lo > 0 || P.own_hi < len;
-  auto owned_bits = [&](unsigned long long bits, int chunk) -> unsigned long long {
-    if (!filter) return bits;
-    unsigned long long keep = 0, x = bits;
-    while (x) {
-      const int b = __builtin_ctzll(x);
-      x &= x - 1;
-      const int st = start_of(tb + chunk * 64 + b);
-      if (st >= P.own_lo && st < P.own_hi) keep |= 1ull << b;
-    }
-    return keep;
-  };
-  unsigned long long mbits = owned_bits(E64[tid], tid);
-  unsigned long long tbits = (tid < kTailChunks) ? owned_bits(E64[kBlockThreads + tid], kBlockThreads + tid) : 0ull;
-  const int far = *s_far;
-  unsigned farcnt = 0;
-  if (tid == 0 && far >= 0) {
-    const int st = start_of(tb + kSBits);
-    farcnt = (!filter || (st >= P.own_lo && st < P.own_hi)) ? 1u : 0u;
-  }
-  const unsigned cnt = (unsigned)__popcll(mbits);
-  const unsigned tcnt = (unsigned)__popcll(tbits);
-  const unsigned incl = (unsigned)WaveInclusiveScan(cnt, lane);
-  const unsigned tincl = (wave == 0) ? (unsigned)WaveInclusiveScan(tcnt, lane) : 0u;
-  if (lane == 63) s_misc[1 + wave] = incl;
-  if (tid == 63) s_misc[5] = tincl;
-  if (tid == 0) s_misc[6] = farcnt;          // a match that ends beyond the bit sets is the tile's last one
-  __syncthreads();
-  unsigned wave_off = 0, main_total = 0;
-#pragma unroll
-  for (int w = 0; w < kBlockThreads / 64; ++w) {
-    const unsigned t = s_misc[1 + w];
-    if (w < wave) wave_off += t;
-    main_total += t;
-  }
-  const unsigned block_total = main_total + s_misc[5] + s_misc[6];
-  if (P.count_only) {
-    if (tid == 0 && block_total) atomicAdd(P.total, (unsigned long long)block_total);
-    return;
-  }
-  if (wave == 0) {
-    if (lane == 0 && block_total) atomicAdd(P.total, (unsigned long long)block_total);
-    const unsigned long long excl = LookBack(P.tile_desc, tile, block_total, lane, &P.counters[3], 1, nullptr, !P.use_tickets);
-    if (lane == 0) { s_misc[8] = (unsigned)excl; s_misc[9] = (unsigned)(excl >> 32); }
-  }
-  __syncthreads();
-  const unsigned long long base = ((unsigned long long)s_misc[9] << 32) | s_misc[8];
+  UsFinishTile(T, P, tile, tb, len, s_L, s_E, s_misc, s_far, s_delta, s_kind);
+}
 
-  // ---- phase 3: span records in match order
-  const int ncap = T.ncap;
-  auto emit = [&](unsigned long long idx, int st, int pe) {
-    if (idx >= (unsigned long long)P.cap_records) return;
-    if (P.starts_only) { P.spans[idx] = st; return; }
-    int32_t* rec = P.spans + idx * ncap;
-    if (T.fixed_captures) UsWriteFixed(rec, ncap, s_kind, s_delta, st, pe);
-    else { rec[0] = st; rec[1] = pe; }
+
+// =====================================================================================================================
+// Two input bytes per table look-up: simple automata with at most 15 byte classes (the end-of-text class included).  The
+// tile holds ONE byte per two input bytes (class nibbles), a row of the table has 256 entries -- the composition of two
+// single steps -- and an entry carries the load / final flags of both bytes: half the dependent look-ups, half the
+// instructions per input byte of scan_us_simple_kernel.  Reset bytes are kept as a bit per input byte next to the tile,
+// so the first sync point of a slice costs three dword reads.  Everything else -- stretches, L and E bit sets, parked rows,
+// the single-step walker for rewinds, phases 2 and 3 -- is the scheme of scan_us_simple_kernel.
+constexpr int kPWindowP = kUWindow / 2;                           // packed bytes in the window
+constexpr int kPPadded = kPWindowP + (kPWindowP / 32) * 4;        // 32-byte rows (one slice) padded to 36: a lane stride of 9 dwords
+constexpr unsigned kPZoff = 257;                                  // row 1, in dwords (a row: 256 entries + one dword of padding)
+constexpr int kPRWords = kUWindow / 32;                           // reset bits over the window
+__device__ __forceinline__ int PPad(int relp) { return relp + ((relp >> 5) << 2); }
+
+struct UsPLayout {
+  int cls, tile, ent, srow, R, L, E, sync, delta, kind, misc, total;
+};
+__host__ __device__ inline UsPLayout UsPLds(int nent2, int stride) {
+  UsPLayout l;
+  int o = 0;
+  l.cls = o; o += 256;                                 // at offset 0: the translate look-ups need no address arithmetic
+  l.tile = o; o += (kPPadded + 15) & ~15;
+  l.ent = o; o += (nent2 * 4 + 15) & ~15;
+  l.srow = o; o += (stride * 2 + 15) & ~15;
+  l.R = o; o += (kPRWords * 4 + 15) & ~15;
+  l.L = o; o += 2 * ((kSWords * 4 + 15) & ~15);     // two sets: a tile's records are written after the next tile's walk
+  l.E = o; o += 2 * ((kSWords * 4 + 15) & ~15);
+  l.sync = o; o += kBlockThreads * 4;
+  l.delta = o; o += 32 * 4;
+  l.kind = o; o += 32;
+  l.misc = o; o += 32 * 4;
+  l.total = (o + 15) & ~15;
+  return l;
+}
+
+struct PIn {
+  const uint8_t* g;
+  const uint8_t* gcls2;        // byte -> class | 0x80 on reset bytes
+  const unsigned char* tile;   // LDS: packed class nibbles
+  const unsigned* R;           // LDS: reset bits over the window
+  int wb, wlim, len, eot;
+  __device__ __forceinline__ unsigned Cls(int i) const {          // class of byte i (the end-of-text class from len on)
+    const unsigned rel = (unsigned)(i - wb);
+    if (rel < (unsigned)wlim) return (tile[PPad((int)(rel >> 1))] >> ((rel & 1u) << 2)) & 15u;
+    if (i >= len) return (unsigned)eot;
+    return gcls2[g[i]] & 15u;
+  }
+  __device__ __forceinline__ bool Reset(int i) const {
+    const unsigned rel = (unsigned)(i - wb);
+    if (rel < (unsigned)wlim) return (R[rel >> 5] >> (rel & 31u)) & 1u;
+    if (i >= len) return false;
+    return (gcls2[g[i]] & 0x80u) != 0;
+  }
+};
+
+__device__ __forceinline__ int PSliceStart(const PIn& in, const int32_t* carry_in, int k) {
+  const int a = k * kSliceBytes;
+  if (a >= in.len) return -1;
+  if (carry_in) {
+    const int c = carry_in[k];
+    if (c >= 0) return (c >= a && c < a + kSliceBytes && c < in.len) ? c : -1;
+  }
+  if (a == 0) return 0;
+  int r = -1;
+  const int rel = a - in.wb;
+  if (rel >= 32 && rel + kSliceBytes <= in.wlim) {
+    // reset bits of offsets a-1 .. a+62 (a+63 would give a sync point in the next slice)
+    const unsigned w0 = in.R[(rel >> 5) - 1] & 0x80000000u, w1 = in.R[rel >> 5], w2 = in.R[(rel >> 5) + 1] & 0x7FFFFFFFu;
+    if (w0) r = a;
+    else if (w1) r = a + __builtin_ctz(w1) + 1;
+    else if (w2) r = a + 32 + __builtin_ctz(w2) + 1;
+  } else {
+    for (int j = a - 1; j < a + kSliceBytes - 1 && r < 0; ++j)
+      if (in.Reset(j)) r = j + 1;
+  }
+  return (r >= 0 && r < in.len) ? r : -1;
+}
+
+// single-step walker (second nibble = "no byte"): rewinds, bytes outside the window
+__device__ __noinline__ void UsPairSlow(const unsigned char* s_entb, const uint16_t* s_srow, unsigned* s_L, unsigned* s_E, int* far,
+                                        const PIn& in, int tb, int s, int e, int lookahead) {
+  int i = s;
+  unsigned row = s_srow[i > 0 ? in.Cls(i - 1) : (unsigned)in.eot];
+  int pend = -1;
+  auto set_e = [&](int at) {
+    const unsigned b = (unsigned)(at - tb);
+    if (b < (unsigned)kSBits) atomicOr(&s_E[b >> 5], 1u << (b & 31)); else *far = at;
   };
+  while (i <= e) {
+    const unsigned ent = *reinterpret_cast<const unsigned*>(s_entb + (((row & 0xFFFFu) + (in.Cls(i) | 0xF0u)) << 2));
+    if (lookahead && (ent & (1u << 27))) pend = i;
+    if (ent & (1u << 29)) { set_e(i); pend = -1; }
+    if ((ent & (1u << 31)) && i < e) {
+      const unsigned b = (unsigned)(i - tb);
+      if (b < (unsigned)kSBits) atomicOr(&s_L[b >> 5], 1u << (b & 31));
+    }
+    if (!lookahead && (ent & (1u << 27))) pend = i + 1;
+    row = ent & 0xFFFFu;
+    ++i;
+    if (row == kPZoff) {
+      if (pend < 0 || pend > e) break;
+      set_e(pend);
+      if (pend >= in.len) break;
+      i = pend;
+      row = s_srow[in.Cls(i - 1)];
+      pend = -1;
+    } else if (row == 0) {
+      break;
+    }
+  }
+}
+
+// byte address of the entry: ((row & 0xFFFF) + byte N of w) * 4 -- row offsets are in dwords, so the sum is one SDWA add
+template <int N>
+__device__ __forceinline__ unsigned PairEntryAddr(unsigned row, unsigned w) {
+  return RowPlusByte<N>(row, w) << 2;
+}
+
+__global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T, UsDev U, ScanParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const UsPLayout Ly = UsPLds(U.nent2, U.stride);
+  unsigned char* s_cls = smem + Ly.cls;
+  unsigned char* s_tile = smem + Ly.tile;
+  unsigned* s_ent2 = reinterpret_cast<unsigned*>(smem + Ly.ent);
+  uint16_t* s_srow = reinterpret_cast<uint16_t*>(smem + Ly.srow);
+  unsigned* s_R = reinterpret_cast<unsigned*>(smem + Ly.R);
+  constexpr int kSetBytes = (kSWords * 4 + 15) & ~15;
+  unsigned* s_L = reinterpret_cast<unsigned*>(smem + Ly.L);          // the current tile's bit sets (swapped with the other pair per tile)
+  unsigned* s_E = reinterpret_cast<unsigned*>(smem + Ly.E);
+  unsigned* s_L2 = reinterpret_cast<unsigned*>(smem + Ly.L + kSetBytes);
+  unsigned* s_E2 = reinterpret_cast<unsigned*>(smem + Ly.E + kSetBytes);
+  int* s_sync = reinterpret_cast<int*>(smem + Ly.sync);
+  int32_t* s_delta = reinterpret_cast<int32_t*>(smem + Ly.delta);
+  unsigned char* s_kind = smem + Ly.kind;
+  unsigned* s_misc = reinterpret_cast<unsigned*>(smem + Ly.misc);
+  int* s_far = reinterpret_cast<int*>(s_misc + 10);
+
+  const int tid = threadIdx.x;
+  const int ncls = U.ncls;
+#ifdef RGX_US_PROFILE
+  long long tstamp[10];
+  int nstamp = 0;
+#endif
+  US_STAMP()
+
+  // Persistent workgroups: the grid is what the chip holds at once (LaunchScanUs), the tables are staged once, and workgroup
+  // b takes tiles b, b + gridDim.x, ... -- the predecessors a tile's look-back waits for belong to the other workgroups' same
+  // round.  The 16-byte loads of the NEXT tile are issued before the walk of the current one (kept in registers).
+  for (int w = tid; w < U.nent2; w += kBlockThreads) s_ent2[w] = U.ent2[w];
+  s_cls[tid] = U.cls2[tid];
+  if (tid <= ncls) s_srow[tid] = U.start_row2[tid];
+  if (tid < T.ncap) { s_delta[tid] = T.cap_delta[tid]; s_kind[tid] = T.cap_kind[tid]; }
+  const int len = P.len;
+  const unsigned eot = (unsigned)ncls;
+  const unsigned char* s_entb = reinterpret_cast<const unsigned char*>(s_ent2);
+  constexpr int kMaxPieces = (kUWindow / 16 + kBlockThreads - 1) / kBlockThreads;
+  uint4 v[kMaxPieces];
+  auto issue_loads = [&](int t) {
+    // pieces of tile t's window that lie wholly inside the text (the last, partial one is read byte by byte at staging)
+    const int wb_ = t * kTileBytes - kHaloL;
+    const int first = wb_ < 0 ? 0 : wb_;
+    int last = t * kTileBytes + kTileBytes + kHaloR;
+    const int len_ext = ((len >> 5) + 1) << 5;
+    if (last > len_ext) last = len_ext;
+    const int nchunks = (last - first) >> 4;
+    const uint4* gsrc = reinterpret_cast<const uint4*>(P.buf + first);
+#pragma unroll
+    for (int q = 0; q < kMaxPieces; ++q) {
+      const int c = tid + q * kBlockThreads;
+      v[q] = make_uint4(0, 0, 0, 0);
+      if (t < P.ntiles && c < nchunks && first + (c << 4) + 16 <= len) v[q] = gsrc[c];
+    }
+  };
+  if (tid == 0) s_misc[0] = P.use_tickets ? atomicAdd(&P.counters[0], 1u) : blockIdx.x;
+  __syncthreads();
+  int tile = (int)s_misc[0];
+  unsigned long long group_total = 0;
+  UsTileOut prev{};
+  bool have_prev = false;
+  // records of the previous tile: its look-back is resolved only now, one whole walk after its count was published -- the
+  // predecessors' counts are there by then, nobody waits
+  auto emit_prev = [&]() {
+    if (tid < 64) {
+      const unsigned long long excl = LookBackResolve(P.tile_desc, prev.tile, prev.block_total, tid, &P.counters[3], !P.use_tickets);
+      if (tid == 0) { s_misc[8] = (unsigned)excl; s_misc[9] = (unsigned)(excl >> 32); }
+    }
+    __syncthreads();
+    UsEmitTile(T, P, prev, ((unsigned long long)s_misc[9] << 32) | s_misc[8], s_L2, s_delta, s_kind);
+  };
+  issue_loads(tile);
+ while (tile < P.ntiles) {
+  __syncthreads();                       // everybody has read s_misc; the previous tile's bit sets are no longer needed
+  if (tid == 0) { *s_far = -1; if (P.use_tickets) s_misc[11] = atomicAdd(&P.counters[0], 1u); }
+  for (int w = tid; w < kSWords; w += kBlockThreads) { s_L[w] = 0; s_E[w] = 0; }
+  US_STAMP()
+  const int tb = tile * kTileBytes;
+  const int wb = tb - kHaloL;
+
+  // ---- stage the window: 16 input bytes -> 16 class look-ups -> 8 packed bytes + 16 reset bits
+  int wlim;
   {
-    unsigned long long idx = base + wave_off + (incl - cnt);
-    unsigned long long x = mbits;
-    while (x) {
-      const int b = __builtin_ctzll(x);
-      x &= x - 1;
-      const int pe = tb + tid * 64 + b;
-      emit(idx++, start_of(pe), pe);
+    const int first = wb < 0 ? 0 : wb;
+    int last = tb + kTileBytes + kHaloR;
+    const int len_ext = ((len >> 5) + 1) << 5;           // whole 32-byte groups: the reset words are written two pieces at a time
+    if (last > len_ext) last = len_ext;
+    wlim = last - wb;
+    const int nchunks = (last - first) >> 4;
+#pragma unroll
+    for (int q = 0; q < kMaxPieces; ++q) {
+      const int c = tid + q * kBlockThreads;
+      if (c >= nchunks) break;
+      const int abs0 = first + (c << 4);
+      unsigned cw[4];                                     // four class bytes (class | 0x80 on reset bytes) per input dword
+      if (abs0 + 16 <= len) {
+        const unsigned w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const unsigned x = w[d];
+          cw[d] = (unsigned)s_cls[x & 255u] | ((unsigned)s_cls[(x >> 8) & 255u] << 8) | ((unsigned)s_cls[(x >> 16) & 255u] << 16) |
+                  ((unsigned)s_cls[x >> 24] << 24);
+        }
+      } else {
+        for (int d = 0; d < 4; ++d) {
+          unsigned x = 0;
+          for (int b = 0; b < 4; ++b) {
+            const int at = abs0 + 4 * d + b;
+            x |= (at < len ? (unsigned)s_cls[P.buf[at]] : eot) << (8 * b);
+          }
+          cw[d] = x;
+        }
+      }
+      unsigned packed[2] = {0, 0}, rbits = 0;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        unsigned t = cw[d] & 0x0F0F0F0Fu;
+        t |= t >> 4;                                      // byte 0 = c0 | c1 << 4, byte 2 = c2 | c3 << 4
+        const unsigned two = (t & 0xFFu) | ((t >> 8) & 0xFF00u);
+        packed[d >> 1] |= two << (16 * (d & 1));
+        const unsigned y = (cw[d] >> 7) & 0x01010101u;    // reset flags of the four bytes at bits 0, 8, 16, 24
+        rbits |= ((y * 0x01020408u) >> 24 & 15u) << (4 * d);
+      }
+      const int relp = (abs0 - wb) >> 1;                  // packed offset: 8 bytes per piece, a 32-byte row holds four pieces
+      uint32_t* dst = reinterpret_cast<uint32_t*>(s_tile + PPad(relp));
+      dst[0] = packed[0]; dst[1] = packed[1];
+      reinterpret_cast<uint16_t*>(s_R)[(abs0 - wb) >> 4] = (uint16_t)rbits;
     }
   }
-  if (tid < kTailChunks) {
-    unsigned long long idx = base + main_total + (tincl - tcnt);
-    unsigned long long x = tbits;
-    while (x) {
-      const int b = __builtin_ctzll(x);
-      x &= x - 1;
-      const int pe = tb + (kBlockThreads + tid) * 64 + b;
-      emit(idx++, start_of(pe), pe);
+  US_STAMP()
+  __syncthreads();
+  US_STAMP()
+  const int next_tile = P.use_tickets ? (int)s_misc[11] : tile + (int)gridDim.x;
+  issue_loads(next_tile);                // in flight during this tile's walk
+  const PIn in{P.buf, U.cls2, s_tile, s_R, wb, wlim, len, (int)eot};
+
+  // ---- the lane's stretch [s, e] (scan_us_simple_kernel has the commentary)
+  const int slice = tile * kBlockThreads + tid;
+  const int a = tb + tid * kSliceBytes;
+  int s = PSliceStart(in, P.carry_in, slice);
+  if (s < 0 && a < len && !(P.carry_in && P.carry_in[slice] >= 0)) {
+    int lower = a - 1 - kUMaxLookBehind;
+    if (lower < 0) lower = 0;
+    int j = a - 2;
+    while (j >= lower && !in.Reset(j)) --j;
+    if (j < lower && lower > 0) {
+      atomicAdd(&P.counters[1], 1u);
+      if (P.slice_unsynced) P.slice_unsynced[slice] = 1;
     }
   }
-  if (tid == 0 && farcnt) emit(base + block_total - 1, start_of(tb + kSBits), far);
+  s_sync[tid] = s;
+  US_STAMP()
+  __syncthreads();
+  int e = 0x7FFFFFF0;
+  bool slow = false;
+  if (s >= 0) {
+    int t = tid + 1;
+    while (t < kBlockThreads && s_sync[t] < 0) ++t;
+    if (t < kBlockThreads) {
+      e = s_sync[t];
+    } else {
+      const int k0 = (tile + 1) * kBlockThreads;
+      int found = -1;
+      for (int k = k0; k < k0 + kSReach / kSliceBytes - 1 && k * kSliceBytes < len && found < 0; ++k) found = PSliceStart(in, P.carry_in, k);
+      if (found >= 0) e = found;
+      else if (k0 * kSliceBytes + kSReach - kSliceBytes < len) {
+        atomicAdd(&P.counters[1], 1u);
+        if (P.slice_unsynced && k0 * kSliceBytes < len) P.slice_unsynced[k0] = 1;
+        s = -1;
+      }
+    }
+  }
+  // ---- wave-uniform walk: a trip = one dword of the packed tile = eight input bytes = four look-ups
+  {
+    const int first_valid = wb < 0 ? 0 : wb;
+    bool fast = s >= 0;
+    int e_eff = e < len ? e : len;
+    if (fast && (s < first_valid || e_eff >= wb + wlim)) { fast = false; slow = true; }
+    const int i0 = fast ? (s & ~7) : first_valid;
+    int ntrips = fast ? ((e_eff - i0) >> 3) + 1 : 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(ntrips, d, 64); ntrips = o > ntrips ? o : ntrips; }
+    const int trips = __builtin_amdgcn_readfirstlane(ntrips);
+    US_STAMP()
+    unsigned startrow = 0;
+    if (fast) startrow = s_srow[s > 0 ? in.Cls(s - 1) : eot];
+    const unsigned phase = fast ? (unsigned)(s & 7) : 8u;       // the byte of the first trip at which the lane enters its start state
+    const unsigned sub0 = phase >> 1;                            // ... i.e. look-up sub0, with the first nibble made "no byte" when phase is odd
+    const unsigned xmask = (fast && (phase & 1u)) ? 0xFu << (8 * sub0) : 0u;
+    if (!fast) e_eff = -1;
+    unsigned row = 0, zrow = 0;
+    unsigned lacc = 0, eacc = 0, lword = 0, eword = 0;
+    const unsigned relmax = (unsigned)((wlim >> 1) - 4);
+    unsigned relp = (unsigned)(i0 - wb) >> 1;
+    int kl = e_eff - i0;                                         // loads count at offsets [0, kl) of the trip, ends at [0, kl]
+    unsigned irel = (unsigned)(i0 - tb);
+#define USP_STEP(N, FIRST)                                                              \
+  {                                                                                     \
+    if (FIRST) row = sub0 == (unsigned)(N) ? startrow : row;                            \
+    const unsigned ent = *reinterpret_cast<const unsigned*>(s_entb + PairEntryAddr<N>(row, w)); \
+    lacc = __builtin_amdgcn_alignbit(lacc, ent, 30);     /* (lacc << 2) | the two load flags */ \
+    eacc = __builtin_amdgcn_alignbit(eacc, ent << 2, 30);                               \
+    row = ent;                                                                          \
+  }
+#define USP_FLUSH()                                                                     \
+  {                                                                                     \
+    unsigned ln = __builtin_bitreverse32(lacc) >> 24, en = __builtin_bitreverse32(eacc) >> 24;   /* byte j of the trip at bit j */ \
+    bool parking = false;                                                               \
+    if (__any(kl < 8)) {                                                                \
+      const int kc = kl < 0 ? 0 : (kl > 8 ? 8 : kl);                                    \
+      ln &= (1u << kc) - 1u;                                                            \
+      en &= kl < 0 ? 0u : (2u << kc) - 1u;                                              \
+      parking = kl < 8;                                                                 \
+      zrow = parking ? row : zrow;                                                      \
+      row = parking ? 0u : row;                                                         \
+      kl = parking ? 0x3FFFFFFF : kl;                                                   \
+    }                                                                                   \
+    const unsigned sh = irel & 31u;                                                     \
+    lword |= ln << sh;                                                                  \
+    eword |= en << sh;                                                                  \
+    const bool flush = parking || (sh == 24u && kl < 0x30000000);                       \
+    if (__any(flush)) {                                                                 \
+      if (flush) {                                                                      \
+        const unsigned wi = irel >> 5 > (unsigned)(kSWords - 1) ? (unsigned)(kSWords - 1) : irel >> 5; \
+        if (lword) atomicOr(&s_L[wi], lword);                                           \
+        if (eword) atomicOr(&s_E[wi], eword);                                           \
+        lword = 0; eword = 0;                                                           \
+      }                                                                                 \
+    }                                                                                   \
+    kl -= 8;                                                                            \
+    irel += 8;                                                                          \
+    relp += 4;                                                                          \
+    relp = relp > relmax ? relmax : relp;                                               \
+  }
+    if (trips > 0) {
+      const unsigned w = *reinterpret_cast<const unsigned*>(s_tile + relp + ((relp >> 5) << 2)) | xmask;
+      USP_STEP(0, true) USP_STEP(1, true) USP_STEP(2, true) USP_STEP(3, true)
+      USP_FLUSH()
+    }
+    for (int t = 1; t < trips; ++t) {
+      const unsigned w = *reinterpret_cast<const unsigned*>(s_tile + relp + ((relp >> 5) << 2));
+      USP_STEP(0, false) USP_STEP(1, false) USP_STEP(2, false) USP_STEP(3, false)
+      USP_FLUSH()
+    }
+#undef USP_STEP
+#undef USP_FLUSH
+    if (fast && (zrow & 0xFFFFu) == kPZoff) slow = true;
+  }
+  US_STAMP()
+  if (slow && s >= 0)
+    UsPairSlow(s_entb, s_srow, s_L, s_E, s_far, in, tb, s, e < len ? e : len, U.lookahead);
+  __syncthreads();
+  US_STAMP()
+  if (have_prev) emit_prev();
+  {
+    const UsTileOut o = UsCountTile(P, tile, tb, len, s_L, s_E, s_misc, *s_far);
+    group_total += o.block_total;
+    if (!P.count_only) {
+      LookBackPublish(P.tile_desc, tile, o.block_total, tid);       // (lane 0 of wave 0 stores)
+      prev = o;
+      have_prev = true;
+    }
+    unsigned* t1 = s_L; s_L = s_L2; s_L2 = t1;
+    unsigned* t2 = s_E; s_E = s_E2; s_E2 = t2;
+  }
+  US_STAMP()
+#ifdef RGX_US_PROFILE
+  if ((blockIdx.x == 200 || blockIdx.x == 901) && (tid == 0 || tid == 130) && tile > 20000 && tile < 22000)
+    printf("blk %d tid %d tile %d: zero %lld | stage %lld | barrier %lld | sync search %lld | barrier+end+setup %lld | walk %lld | slow+barrier %lld | finish %lld\n",
+           blockIdx.x, tid, tile, tstamp[1] - tstamp[0], tstamp[2] - tstamp[1], tstamp[3] - tstamp[2], tstamp[4] - tstamp[3], tstamp[5] - tstamp[4],
+           tstamp[6] - tstamp[5], tstamp[7] - tstamp[6], tstamp[8] - tstamp[7]);
+  nstamp = 0;
+  US_STAMP()
+#endif
+  tile = next_tile;
+ }
+  if (have_prev) { __syncthreads(); emit_prev(); }
+  if (tid == 0 && group_total) atomicAdd(P.total, group_total);
 }
 
 }  // namespace
@@ -856,6 +1287,29 @@ hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t str
   const UsDev& U = *T.us;
   dim3 grid(P.ntiles), block(kBlockThreads);
   static const bool no_simple = getenv("RGX_NO_US_SIMPLE") != nullptr;
+  static const bool no_pairs = getenv("RGX_NO_US_PAIRS") != nullptr;
+  if (U.ent2 && !no_simple && !no_pairs) {
+    static bool attr2 = false;
+    if (!attr2) { hipFuncSetAttribute((const void*)scan_us_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr2 = true; }
+    // persistent workgroups: as many as the chip holds at once (one fewer per CU than the occupancy query says: it is known to
+    // over-report by one for SGPR-heavy kernels, and a workgroup that is not resident would stall every look-back behind it
+    // until the bounded spin sends the scan to ticket mode)
+    const size_t shp = (size_t)UsPLds(U.nent2, U.stride).total;
+    static int per_cu = 0, ncu = 0;
+    if (per_cu == 0) {
+      int dev = 0;
+      hipGetDevice(&dev);
+      hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, scan_us_pair_kernel, kBlockThreads, shp) != hipSuccess || per_cu < 1) per_cu = 1;
+      if (per_cu > 2) per_cu -= 1;
+      if (per_cu > 4) per_cu = 4;              // measured: 4 per CU is the best (16 waves; more adds nothing, fewer idles the SIMDs)
+      if (getenv("RGX_US_PER_CU")) per_cu = atoi(getenv("RGX_US_PER_CU"));
+    }
+    int nblk = per_cu * ncu;
+    if (nblk > P.ntiles) nblk = P.ntiles;
+    hipLaunchKernelGGL(scan_us_pair_kernel, dim3(nblk), block, shp, stream, T, U, P);
+    return hipGetLastError();
+  }
   if (U.ent4 && !no_simple) {
     static bool attr = false;
     if (!attr) { hipFuncSetAttribute((const void*)scan_us_simple_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
