@@ -1291,9 +1291,9 @@ hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t str
   if (U.ent2 && !no_simple && !no_pairs) {
     static bool attr2 = false;
     if (!attr2) { hipFuncSetAttribute((const void*)scan_us_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr2 = true; }
-    // persistent workgroups: as many as the chip holds at once (one fewer per CU than the occupancy query says: it is known to
-    // over-report by one for SGPR-heavy kernels, and a workgroup that is not resident would stall every look-back behind it
-    // until the bounded spin sends the scan to ticket mode)
+    // persistent workgroups: no more than the chip holds at once (the occupancy query is known to over-report by one for
+    // SGPR-heavy kernels, and a workgroup that is not resident would stall every look-back behind it until the bounded spin
+    // sends the scan to ticket mode)
     const size_t shp = (size_t)UsPLds(U.nent2, U.stride).total;
     static int per_cu = 0, ncu = 0;
     if (per_cu == 0) {
@@ -1301,8 +1301,9 @@ hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t str
       hipGetDevice(&dev);
       hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, scan_us_pair_kernel, kBlockThreads, shp) != hipSuccess || per_cu < 1) per_cu = 1;
-      if (per_cu > 2) per_cu -= 1;
-      if (per_cu > 4) per_cu = 4;              // measured: 4 per CU is the best (16 waves; more adds nothing, fewer idles the SIMDs)
+      // 4 per CU measured best (16 waves: 3 leaves the SIMDs idle, 5 adds nothing); LDS admits 5 and the SGPR count 6, so 4 is
+      // resident with a margin even where the query over-reports by one
+      if (per_cu > 4) per_cu = 4; else if (per_cu > 2) per_cu -= 1;
       if (getenv("RGX_US_PER_CU")) per_cu = atoi(getenv("RGX_US_PER_CU"));
     }
     int nblk = per_cu * ncu;
