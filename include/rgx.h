@@ -86,6 +86,10 @@ typedef struct rgx_info {
   int32_t needs_valid_utf8; /* 1: the pattern has a class with non-ASCII runes (incl. negated ASCII classes);
                              * results are exact on ASCII / valid UTF-8 input, see DESIGN.md "UTF-8 classes"        */
   int32_t sync_states;     /* states of the sync automaton W (0: none), DESIGN.md 4.1                         */
+  int32_t scan_kernel;     /* which FindAll kernel a large buffer takes once the program is on a device (0 before): 1 exact
+                            * (fixed-length class chain), 2 prefilter + verify, 3 generic (one attempt per start), 4 one step
+                            * per byte with start registers, 5 register-free (simple automata), 6 register-free, two bytes
+                            * per look-up; DESIGN.md section 4 */
   int32_t unicode_version; /* UCD version behind \p{..}: 0xMMmmpp (0x0E0000 = 14.0.0).  The reference's tables are Go 1.24's
                             * `unicode` package = 15.0.0: code points first assigned in 15.0 are unassigned here       */
 } rgx_info;

@@ -36,7 +36,7 @@ class Info(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "ncap", "min_match_len", "max_match_len", "default_max_leftover", "min_buffer_size", "n_inst",
         "n_states", "n_classes", "anchored", "fixed_captures", "can_match_empty", "ref_match_engine", "ref_find_engine",
-        "lookahead_mode", "table_bytes", "needs_valid_utf8", "sync_states", "unicode_version")]
+        "lookahead_mode", "table_bytes", "needs_valid_utf8", "sync_states", "scan_kernel", "unicode_version")]
 
 
 class Result(C.Structure):

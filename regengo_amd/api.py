@@ -108,6 +108,7 @@ class Compiled:
             _capi.check(self._lib.rgx_stream_ctx_create(self._h, C.byref(c)))
             self._ctx = c
         self._device = device
+        _capi.check(self._lib.rgx_program_info(self._h, C.byref(self.info)))     # table_bytes / scan_kernel are known now
         return self
 
     def set_timing(self, on: bool = True):

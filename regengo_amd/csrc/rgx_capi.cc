@@ -181,6 +181,28 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   float ms = 0;
   if (c->timing) hipEventElapsedTime(&ms, c->ev0, c->ev1);
   uint32_t unsynced = ((uint32_t*)&c->h_read[2])[1];
+  if (unsynced && !use_w && UseUsKernel(T, ilen, false)) {
+    // the one-step-per-byte kernels: slices without a sync point in reach get their search positions from ONE walk of the
+    // start-tracking automaton per run (LaunchCarryUs) -- linear, where the attempt-per-start carry pass below is quadratic
+    // in the length of such a run (a 5 KB word cost it seconds)
+    if ((rc = Ensure(&c->d_unsynced, &c->slice_cap, nslices)) != RGX_OK) return rc;
+    {
+      int64_t cc = 0;
+      if (c->d_carry) { hipFree(c->d_carry); c->d_carry = nullptr; }
+      if ((rc = Ensure(&c->d_carry, &cc, (int64_t)nslices + 64)) != RGX_OK) return rc;
+    }
+    HIP_TRY(hipMemsetAsync(c->d_unsynced, 0, nslices, c->stream));
+    P.slice_unsynced = c->d_unsynced;
+    if ((rc = run_scan(false)) != RGX_OK) return rc;            // marks the unsynced slices
+    HIP_TRY(hipMemsetAsync(c->d_carry, 0xFF, (size_t)nslices * 4, c->stream));
+    HIP_TRY(LaunchCarryUs(T, d_buf, ilen, c->d_unsynced, c->d_carry, nslices, c->stream));
+    P.slice_unsynced = nullptr;
+    P.carry_in = c->d_carry;
+    if ((rc = run_scan(c->timing)) != RGX_OK) return rc;
+    if (c->timing) hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    const uint32_t still = ((uint32_t*)&c->h_read[2])[1];
+    if (still) { SetError("slices without a search position after the carry pass"); return RGX_E_HIP; }
+  } else
   if (unsynced && w_ok && !use_w) {
     // slices without a reset byte in reach: take the sync points from W from now on (this context remembers)
     use_w = true;
@@ -193,6 +215,10 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     unsynced = ((uint32_t*)&c->h_read[2])[1];
   }
   bool carry_ready = false;
+  const bool us_done = P.carry_in != nullptr && UseUsKernel(T, ilen, false) && !use_w;     // the branch above settled it
+  if (us_done) {
+    // nothing left to do
+  } else
   if (unsynced && w_ok && (int64_t)unsynced * 1024 > (int64_t)nslices) {
     // (a handful of unsynced slices goes straight to the carry pass below)
     // the blind walk proves nothing for this pattern on this text (a thread may survive any byte): exact sync points
@@ -215,7 +241,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     unsynced = ((uint32_t*)&c->h_read[2])[1];
     carry_ready = true;
   }
-  if (unsynced) {
+  if (unsynced && !us_done) {
     // rare path: some slices found no sync point; resolve their entry positions serially and rescan.
     if ((rc = Ensure(&c->d_unsynced, &c->slice_cap, nslices)) != RGX_OK) return rc;
     if (!carry_ready) {
@@ -322,6 +348,7 @@ RGX_API int rgx_program_info(const rgx_program* p, rgx_info* o) {
   o->ref_match_engine = t.ref_match_engine; o->ref_find_engine = t.ref_find_engine; o->lookahead_mode = t.lookahead_mode;
   o->needs_valid_utf8 = t.needs_valid_utf8; o->sync_states = t.w_nstates;
   o->unicode_version = UnicodeVersion();
+  o->scan_kernel = p->p.d_arena ? ScanKernelKind(p->p.dev, 1 << 24) : 0;
   o->table_bytes = p->p.d_arena ? p->p.dev.table_bytes : (int32_t)((size_t)t.nstates * (t.ncls + 1) * 2);
   return RGX_OK;
 }

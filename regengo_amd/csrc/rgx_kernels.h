@@ -46,6 +46,10 @@ hipError_t LaunchScanSa(const DevTables& T, const ScanParams& P, const uint16_t*
 // unanchored patterns that cannot match empty whenever sync points come from reset bytes or the carry pass (not use_w)
 bool UseUsKernel(const DevTables& T, int32_t len, bool use_w);
 hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t stream);
+hipError_t LaunchCarryUs(const DevTables& T, const uint8_t* buf, int32_t len, const uint8_t* slice_unsynced, int32_t* carry_in,
+                         int32_t nslices, hipStream_t stream);   // linear-time carry pass (needs T.us with the register tables)
+int UsKernelVariant(const DevTables& T);   // 4 registers, 5 register-free, 6 register-free pairs (rgx_info.scan_kernel)
+int ScanKernelKind(const DevTables& T, int32_t len);
 
 // Serial carry resolution for slices without a local sync point (rare path).
 hipError_t LaunchCarry(const DevTables& T, const uint8_t* buf, int32_t len, const uint8_t* slice_unsynced, int32_t* carry_in,

@@ -1304,6 +1304,13 @@ int32_t ScanNumTiles(const DevTables& T, int32_t len, bool use_w) {
   return (len + per - 1) / per;
 }
 
+int ScanKernelKind(const DevTables& T, int32_t len) {
+  if (UseExactKernel(T, len)) return 1;
+  if (UseUsKernel(T, len, false)) return UsKernelVariant(T);
+  if (UseSaKernel(T, len) && !getenv("RGX_NO_SA_KERNEL")) return 2;
+  return 3;
+}
+
 bool ScanSupportsW(const DevTables& T, int32_t len) { return T.w_nstates > 0 && !UseExactKernel(T, len) && !T.anchored; }
 
 hipError_t LaunchScan(const DevTables& T, const ScanParams& P, hipStream_t stream) {

@@ -258,6 +258,7 @@ int UploadUs(Program* p) {
         }
         if (k != u.ncls && (e & kUsSet)) v |= 1u << 31;
         if (e & (kUsBefore | kUsAfter)) v |= 1u << 29;
+        if (k != u.ncls && nq && !(u.sflags[nq] & 1)) v |= 1u << 26;      // the next state has a match pending (no search loop)
         ent4[(size_t)(q + 1) * kPitchW + k] = v;
         ent4[(size_t)(q + 1) * kPitchW + 32 + k] = v;
       }
@@ -299,6 +300,7 @@ int UploadUs(Program* p) {
           if (f1) v |= 1u << 29;
           if (f2) v |= 1u << 28;
           if (m1) v |= 1u << 27;
+          if (r2 >= 2 && !(u.sflags[r2 - 1] & 1)) v |= 1u << 26;         // the state after both bytes has a match pending
           ent2[(size_t)r * kPitch2W + (k1 | (k2 << 4))] = v;
         }
     for (int k = 0; k < stride; k++) srow2[k] = (uint16_t)((srow4[k] / kPitch) * kPitch2W);

@@ -86,7 +86,8 @@ struct UsDev {
   // "simple" automata (StartSearch::simple): register-free walk, scan_us_simple_kernel.  32-bit entries, rows of 260 bytes
   // (32 entries twice: the tile byte is class * 4, bit 7 set on reset bytes; one dword of padding spreads the rows over banks):
   //   [0..15] byte offset of the next row (row 0: parked, walk over; row 1: parked, the single-step walker must repeat the
-  //   stretch -- both rows all-"stay", no flags)   [29] a match ends here (single-step walker only)   [30] kUsFinal: a match
+  //   stretch -- both rows all-"stay", no flags)   [26] the next state has a match pending   [29] a match ends here (single-step
+  //   walker only)   [30] kUsFinal: a match
   //   ends at this byte for good   [31] register load: a thread that began at this byte survived it
   const uint32_t* ent4;           // [nent4] or nullptr
   const uint16_t* start_row4;     // [ncls+1] like start_row_of_cls, in ent4 byte offsets
@@ -98,7 +99,7 @@ struct UsDev {
   // class of the second, nibble 15 = "no byte" (the state stays) -- and a row has 256 entries (+1 dword of padding):
   //   [0..15] DWORD offset of the row after both bytes (rows 0 and 1 park, as above)   [31] load at the first byte
   //   [30] load at the second   [29] kUsFinal at the first   [28] at the second   [27] a match ends at the first byte
-  //   (single-step use: second nibble 15)
+  //   (single-step use: second nibble 15)   [26] the state after both bytes has a match pending
   const uint32_t* ent2;           // [nent2] or nullptr
   const uint16_t* start_row2;     // [ncls+1] in ent2 dword offsets
   const uint8_t* cls2;            // [256] byte -> class | 0x80 on reset bytes

@@ -397,8 +397,6 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_kernel(DevTables T, UsD
     }
   }
 }
-#undef US_START
-#undef US_INFO
 
 
 // =====================================================================================================================
@@ -625,6 +623,7 @@ __device__ __noinline__ void UsSimpleSlow(const unsigned char* s_entb, const uin
     const unsigned b = (unsigned)(at - tb);
     if (b < (unsigned)kSBits) atomicOr(&s_E[b >> 5], 1u << (b & 31)); else *far = at;
   };
+  for (;;) {
   while (i <= e) {
     const unsigned k4 = in.At4(i);
     const unsigned ent = *reinterpret_cast<const unsigned*>(s_entb + (row & 0xFFFFu) + k4);
@@ -646,8 +645,17 @@ __device__ __noinline__ void UsSimpleSlow(const unsigned char* s_entb, const uin
       row = s_srow[(in.At4(i - 1) & 0x7Cu) >> 2];
       pend = -1;
     } else if (row == 0) {
-      break;                                   // the end of the text
+      return;                                  // the end of the text
     }
+  }
+  // the stretch ends at a position the search stands at: a match still pending there cannot grow any more -- it is final,
+  // and the search goes on from its end (the rest of the stretch is walked again: the reference's own quadratic case)
+  if (pend < 0 || pend > e) return;
+  set_e(pend);
+  if (pend >= e || pend >= in.len) return;
+  i = pend;
+  row = s_srow[(in.At4(i - 1) & 0x7Cu) >> 2];
+  pend = -1;
   }
 }
 
@@ -775,9 +783,11 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_simple_kernel(DevTables
       // the tile's last stretch ends at the first sync point at or after the next tile's start
       const int k0 = (tile + 1) * kBlockThreads;
       int found = -1;
-      for (int k = k0; k < k0 + kSReach / kSliceBytes - 1 && k * kSliceBytes < len && found < 0; ++k) found = SliceStart(in, P.carry_in, k);
+      // (with the carry pass's positions at hand the search goes as far as it must: a match may run for kilobytes past the tile)
+      const int klim = P.carry_in ? 0x7FFFFFF : k0 + kSReach / kSliceBytes - 1;
+      for (int k = k0; k < klim && k * kSliceBytes < len && found < 0; ++k) found = SliceStart(in, P.carry_in, k);
       if (found >= 0) e = found;
-      else if (k0 * kSliceBytes + kSReach - kSliceBytes < len) {
+      else if (!P.carry_in && k0 * kSliceBytes + kSReach - kSliceBytes < len) {
         // no sync point in reach and the text goes on: leave the stretch to the carry pass
         atomicAdd(&P.counters[1], 1u);
         if (P.slice_unsynced && k0 * kSliceBytes < len) P.slice_unsynced[k0] = 1;
@@ -860,7 +870,9 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_simple_kernel(DevTables
     }
 #undef USS_STEP
 #undef USS_FLUSH
-    if (fast && (zrow & 0xFFFFu) == kSZoff) slow = true;     // a rewind was needed: the single-step walker repeats the stretch
+    // a rewind was needed, or the stretch ends (at a search position handed down by the carry pass) with a match still
+    // pending: the single-step walker repeats the stretch
+    if (fast && ((zrow & 0xFFFFu) == kSZoff || (zrow & (1u << 26)))) slow = true;
   }
   US_STAMP()
   if (slow && s >= 0)
@@ -965,6 +977,7 @@ __device__ __noinline__ void UsPairSlow(const unsigned char* s_entb, const uint1
     const unsigned b = (unsigned)(at - tb);
     if (b < (unsigned)kSBits) atomicOr(&s_E[b >> 5], 1u << (b & 31)); else *far = at;
   };
+  for (;;) {
   while (i <= e) {
     const unsigned ent = *reinterpret_cast<const unsigned*>(s_entb + (((row & 0xFFFFu) + (in.Cls(i) | 0xF0u)) << 2));
     if (lookahead && (ent & (1u << 27))) pend = i;
@@ -984,8 +997,15 @@ __device__ __noinline__ void UsPairSlow(const unsigned char* s_entb, const uint1
       row = s_srow[in.Cls(i - 1)];
       pend = -1;
     } else if (row == 0) {
-      break;
+      return;
     }
+  }
+  if (pend < 0 || pend > e) return;            // (see UsSimpleSlow)
+  set_e(pend);
+  if (pend >= e || pend >= in.len) return;
+  i = pend;
+  row = s_srow[in.Cls(i - 1)];
+  pend = -1;
   }
 }
 
@@ -1158,9 +1178,10 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
     } else {
       const int k0 = (tile + 1) * kBlockThreads;
       int found = -1;
-      for (int k = k0; k < k0 + kSReach / kSliceBytes - 1 && k * kSliceBytes < len && found < 0; ++k) found = PSliceStart(in, P.carry_in, k);
+      const int klim = P.carry_in ? 0x7FFFFFF : k0 + kSReach / kSliceBytes - 1;
+      for (int k = k0; k < klim && k * kSliceBytes < len && found < 0; ++k) found = PSliceStart(in, P.carry_in, k);
       if (found >= 0) e = found;
-      else if (k0 * kSliceBytes + kSReach - kSliceBytes < len) {
+      else if (!P.carry_in && k0 * kSliceBytes + kSReach - kSliceBytes < len) {
         atomicAdd(&P.counters[1], 1u);
         if (P.slice_unsynced && k0 * kSliceBytes < len) P.slice_unsynced[k0] = 1;
         s = -1;
@@ -1241,7 +1262,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
     }
 #undef USP_STEP
 #undef USP_FLUSH
-    if (fast && (zrow & 0xFFFFu) == kPZoff) slow = true;
+    if (fast && ((zrow & 0xFFFFu) == kPZoff || (zrow & (1u << 26)))) slow = true;    // rewind, or a match pending at the stretch's end
   }
   US_STAMP()
   if (slow && s >= 0)
@@ -1275,12 +1296,108 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
   if (tid == 0 && group_total) atomicAdd(P.total, group_total);
 }
 
+
+// =====================================================================================================================
+// Linear-time carry pass.  The other kernels' carry_kernel (rgx_kernels.hip) resolves slices without a sync point by replaying
+// the reference's loop -- an attempt per start position, quadratic in the length of a run without sync points (a 5 KB word took
+// it 5 s: one lane, tables in global memory).  With the start-tracking automaton the same answer is ONE walk over the run:
+// the lane that heads a run of unsynced slices starts at the nearest reset-byte sync point before it and walks once; a slice's
+// search position is its own offset unless a match covers it (then the match's end), and it is known as soon as the oldest
+// thread alive began at or behind the slice (entry field "oldest") or a match ends.
+template <int NREG, bool LOOK>
+__global__ __launch_bounds__(64) void carry_us_kernel(DevTables T, UsDev U, const uint8_t* buf, int32_t len, const uint8_t* unsynced,
+                                                      int32_t* carry_in, int32_t nslices) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  unsigned long long* s_ent = reinterpret_cast<unsigned long long*>(smem);
+  uint16_t* s_srow = reinterpret_cast<uint16_t*>(smem + U.nent * 8);
+  for (int w = threadIdx.x; w < U.nent; w += 64) s_ent[w] = U.ent[w];
+  if ((int)threadIdx.x <= U.ncls) s_srow[threadIdx.x] = U.start_row_of_cls[threadIdx.x];
+  __syncthreads();
+  const int s0 = blockIdx.x * 64 + threadIdx.x;
+  if (s0 >= nslices || !unsynced[s0]) return;
+  if (s0 > 0 && unsynced[s0 - 1]) return;  // not the head of a run
+  // the nearest reset-byte sync point before the run (the slice before the run found one within its reach)
+  int pos = 0;
+  if (s0 > 0) {
+    int j = s0 * kSliceBytes - 1;
+    while (j >= 0 && !T.reset_byte[buf[j]]) --j;
+    pos = j + 1;
+  }
+  const unsigned char* s_entb = reinterpret_cast<const unsigned char*>(s_ent);
+  int cur = s0;                                   // the next slice of the run that wants its search position
+  int a_cur = cur * kSliceBytes;
+  auto cls8 = [&](int i) -> unsigned { return i < len ? (unsigned)U.cls[buf[i]] << 3 : (unsigned)U.ncls << 3; };
+  // settle every slice of the run whose start lies at or before `upto`, given the last match (ms, me) that ended (ms = -1: none)
+  auto settle = [&](int upto, int ms, int me) {
+    while (cur < nslices && unsynced[cur] && a_cur <= upto) {
+      carry_in[cur] = (ms >= 0 && a_cur > ms && a_cur < me) ? me : a_cur;
+      ++cur;
+      a_cur += kSliceBytes;
+    }
+  };
+  while (cur < nslices && unsynced[cur] && pos < len) {
+    int i = pos;
+    unsigned row = s_srow[(i > 0 ? cls8(i - 1) : (unsigned)U.ncls << 3) >> 3];
+    int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
+    (void)r1; (void)r2; (void)r3;
+    int pend = -1;
+    unsigned pinfo = 0;
+    bool restarted = false;
+    while (!restarted) {
+      const unsigned k8 = cls8(i);
+      const uint2 ent = *reinterpret_cast<const uint2*>(s_entb + (row & 0xFFFFu) + k8);
+      const unsigned lo = ent.x, hi = ent.y;
+      const int i1 = i + 1;
+      if (LOOK && (lo & kEMatch)) { pend = i; pinfo = hi; }
+      if (lo & kEFinal) {
+        const unsigned inf = US_INFO(pinfo);
+        const int ps = (inf & 0x80u) ? US_START(inf) : pend - (int)(inf & 0x7Fu);
+        settle(pend, ps, pend);                    // slices up to the match's end: before it, or covered by it
+        pend = -1;
+      }
+      const int v = i1 - (int)((lo >> 16) & 0x7Fu);
+      if (lo & kELoad0) r0 = v;
+      if (NREG > 1 && (lo & kELoad1)) r1 = v;
+      if (NREG > 2 && (lo & kELoad2)) r2 = v;
+      if (NREG > 2 && (lo & kELoad3)) r3 = v;
+      if (!LOOK && (lo & kEMatch)) { pend = i1; pinfo = hi; }
+      row = lo;
+      i = i1;
+      if (lo & kEDead) {
+        if (pend < 0) { settle(len, -1, -1); pos = len; break; }     // the end of the text: nothing covers the rest
+        const unsigned inf = US_INFO(pinfo);
+        const int ps = (inf & 0x80u) ? US_START(inf) : pend - (int)(inf & 0x7Fu);
+        settle(pend, ps, pend);
+        pos = pend;                                 // the search rewinds to the end of the match
+        restarted = true;
+      } else if (pend < 0 && a_cur < i) {
+        // nothing pending: slices behind which no thread is alive any more are settled
+        const unsigned o = (hi >> 16) & 255u;
+        const int so = o == 255u ? i : ((o & 0x80u) ? US_START(o) : i - (int)o);
+        settle(so < i ? so : i - 1, -1, -1);
+      }
+      if (!(cur < nslices && unsynced[cur])) { restarted = true; pos = len; }   // the run is done
+    }
+  }
+}
+
+#undef US_START
+#undef US_INFO
+
 }  // namespace
 
 bool UseUsKernel(const DevTables& T, int32_t len, bool use_w) {
   static const bool off = getenv("RGX_NO_US_KERNEL") != nullptr;
   if (off || T.us == nullptr || use_w || len < 64 || UseExactKernel(T, len) || T.anchored || T.ncap > 32) return false;
   return T.us->ent4 != nullptr || T.us->stride <= 32;     // the register kernel keeps class * 8 in one byte
+}
+
+int UsKernelVariant(const DevTables& T) {
+  const UsDev& U = *T.us;
+  static const bool no_simple = getenv("RGX_NO_US_SIMPLE") != nullptr, no_pairs = getenv("RGX_NO_US_PAIRS") != nullptr;
+  if (U.ent2 && !no_simple && !no_pairs) return 6;
+  if (U.ent4 && !no_simple) return 5;
+  return 4;
 }
 
 hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t stream) {
@@ -1333,4 +1450,22 @@ hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t str
   return hipGetLastError();
 }
 
+}  // namespace rgx
+
+namespace rgx {
+// carry_in[slice] for every slice marked unsynced, by one walk of the start-tracking automaton per run (rgx_kernels.h)
+hipError_t LaunchCarryUs(const DevTables& T, const uint8_t* buf, int32_t len, const uint8_t* slice_unsynced, int32_t* carry_in,
+                         int32_t nslices, hipStream_t stream) {
+  const UsDev& U = *T.us;
+  const size_t shmem = (size_t)U.nent * 8 + 64;
+  dim3 block(64), grid((nslices + 63) / 64);
+#define RGX_CU(N, LK) hipLaunchKernelGGL((carry_us_kernel<N, LK>), grid, block, shmem, stream, T, U, buf, len, slice_unsynced, carry_in, nslices)
+  if (U.lookahead) {
+    if (U.nregs <= 1) RGX_CU(1, true); else if (U.nregs <= 2) RGX_CU(2, true); else RGX_CU(4, true);
+  } else {
+    if (U.nregs <= 1) RGX_CU(1, false); else if (U.nregs <= 2) RGX_CU(2, false); else RGX_CU(4, false);
+  }
+#undef RGX_CU
+  return hipGetLastError();
+}
 }  // namespace rgx

@@ -1,0 +1,129 @@
+"""GPU tier: the one-step-per-byte scan kernels (rgx_scan_us.hip) against the oracle's C restatement of the reference's
+FindAllBytes (find.go:130-466; oracle/gen_c.py) -- each of the three variants (start registers / register-free / register-free
+with two bytes per look-up), on inputs built to hit what is special about them: stretches that cross tile borders, matches that
+end where a stretch ends, rewinds (a match followed by bytes that kept older threads alive), the end of the text inside a
+look-up pair, texts without a single sync point, shard ownership."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+URL = r"(?P<full>(?P<proto>https?|ftp)://(?P<host>[\w.-]+)(?P<port>:\d+)?(?P<path>/[\w./-]*)?)"
+CASES = [
+    # (pattern, expected rgx_info.scan_kernel, alphabet)
+    (r"(?P<user>\w+)@(?P<domain>\w+)", 6, "ab_9@ .\n"),
+    (r"(\d+)", 6, "0123 ab-\n"),
+    (r"\b[a-z]+\b", 6, "abz_ 09.\n"),
+    (URL, 6, "htps:/f.w-1 \n"),
+    (r"\[(INFO|WARN)\]", 6, "[]INFOWAR x\n"),
+    (r"ab+c|a", 6, "abc x"),                      # rewinds: "abbbx" ends the match [0,1) only when x arrives
+    (r"(?m)^foo\d+$", 6, "fo0\n9x"),
+    (r"x[a-z]*y|x", 6, "xay b\n"),                # long overshoot before the rewind
+    (r"[\w.+-]+@[\w.-]+\.[a-z]{2,}", 4, "ab.@-+ z\n"),          # two start registers
+    (r"(?P<major>\d+)\.(?P<minor>\d+)\.(?P<patch>\d+)", 4, "0123. a\n"),   # three
+    (r"[a-q]+[0-9]|[c-z]{3}!", None, "acz09! "),
+    (r"[^\s\"]+\"", None, "ab\" \n\t9"),
+]
+
+
+@pytest.fixture(scope="module")
+def torch_dev(built):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU; there is no CPU fallback")
+    return torch
+
+
+def _texts(rng, alphabet, sizes):
+    out = []
+    for n in sizes:
+        k = rng.random()
+        if k < 0.4:
+            b = "".join(rng.choice(alphabet) for _ in range(n))
+        elif k < 0.7:
+            # long runs: matches and stretches much longer than a 64-byte slice, some longer than a tile's look-ahead
+            parts = []
+            size = 0
+            while size < n:
+                run = rng.choice(alphabet) * rng.choice([1, 3, 70, 300, 1500, 3000])
+                parts.append(run)
+                size += len(run)
+            b = "".join(parts)[:n]
+        else:
+            words = ["".join(rng.choice(alphabet) for _ in range(rng.randrange(1, 9))) for _ in range(40)]
+            b = "".join(rng.choice(words) for _ in range(n // 4 + 1))[:n]
+        out.append(b.encode())
+    return out
+
+
+@pytest.mark.parametrize("pattern,kernel,alphabet", CASES)
+def test_us_kernels_equal_oracle(torch_dev, pattern, kernel, alphabet):
+    from oracle.gen_c import CMatcher
+    from regengo_amd import Compiled
+    c = Compiled(pattern).to(0)
+    if kernel is not None:
+        assert c.info.scan_kernel == kernel, (pattern, c.info.scan_kernel)
+    cm = CMatcher(pattern, q8=False)
+    rng = random.Random(hash(pattern) & 0xFFFF)
+    sizes = [64, 65, 127, 128, 129, 1000, 16383, 16384, 16385, 16384 + 255, 16384 + 257, 32768, 40000, 70001, 200000]
+    # (runs without a sync point are kept to a few KiB: the carry pass that resolves them restates the reference's loop, which
+    # is quadratic in the length of such a run -- as the reference itself is)
+    for b in _texts(rng, alphabet, sizes) + [b"", b"a", (alphabet[0] * 5000).encode(), (alphabet[-1] * 3000 + alphabet[0] * 2500).encode()]:
+        arr = np.frombuffer(b, dtype=np.uint8).copy() if b else np.zeros(0, dtype=np.uint8)
+        exp, cnt = cm.find_all_np(arr)
+        spans, res = c.FindAllSpans(b)
+        got = spans.cpu().numpy()
+        assert res.total == cnt and got.shape == exp.shape and np.array_equal(got, exp), (pattern, len(b), cnt, int(res.total))
+        n, _ = c.CountAll(torch_dev.from_numpy(arr).cuda()) if len(b) else (0, None)
+        assert n == cnt, (pattern, len(b))
+        # shard ownership: only matches that START inside [lo, hi)
+        if len(b) >= 1000:
+            lo, hi = len(b) // 3, 2 * len(b) // 3 + 1
+            own, _ = c.FindAllSpans(b, own=(lo, hi))
+            keep = exp[(exp[:, 0] >= lo) & (exp[:, 0] < hi)]
+            assert np.array_equal(own.cpu().numpy(), keep), (pattern, len(b), "owned range")
+
+
+def test_us_kernel_matches_at_tile_and_stretch_borders(torch_dev):
+    """One-byte and maximal matches placed at every offset around a tile border and around the end of the text."""
+    from oracle.gen_c import CMatcher
+    from regengo_amd import Compiled
+    for pattern, unit in [(r"(\d+)", b"7"), (r"\w+@\w+", b"a@b"), (r"ab+c|a", b"abbb")]:
+        c = Compiled(pattern).to(0)
+        cm = CMatcher(pattern, q8=False)
+        for border in (16384, 32768):
+            for shift in range(-6, 7):
+                for tail in (0, 1, 2, 5):
+                    buf = bytearray(b" " * (border + 300))
+                    at = border + shift
+                    buf[at:at + len(unit)] = unit
+                    b = bytes(buf[:at + len(unit) + tail])
+                    arr = np.frombuffer(b, dtype=np.uint8).copy()
+                    exp, cnt = cm.find_all_np(arr)
+                    spans, res = c.FindAllSpans(b)
+                    assert res.total == cnt and np.array_equal(spans.cpu().numpy(), exp), (pattern, border, shift, tail)
+
+
+def test_us_kernel_without_sync_points_takes_the_carry_path(torch_dev):
+    """Runs of several KiB without a reset byte (one enormous word): slices report themselves unsynced, the host resolves them
+    (sync automaton / carry pass) and the result is still the oracle's.  (Kept to a few KiB per run: the carry pass restates the
+    reference's loop, quadratic in the length of such a run.)"""
+    from oracle.gen_c import CMatcher
+    from regengo_amd import Compiled
+    pattern = r"(?P<user>\w+)@(?P<domain>\w+)"
+    c = Compiled(pattern).to(0)
+    cm = CMatcher(pattern, q8=False)
+    rng = random.Random(5)
+    word = lambda n: "".join(rng.choice("abcdefgh") for _ in range(n))
+    texts = [("x " + word(6000) + "@" + word(3000) + " y@z " + word(9000) + " q").encode(),
+             (" ".join(word(rng.choice([5, 2500, 4000])) + rng.choice(["", "@b"]) for _ in range(40))).encode()]
+    seen_unsynced = 0
+    for b in texts:
+        arr = np.frombuffer(b, dtype=np.uint8).copy()
+        exp, cnt = cm.find_all_np(arr)
+        spans, res = c.FindAllSpans(b)
+        seen_unsynced += int(res.unsynced)
+        assert res.total == cnt and np.array_equal(spans.cpu().numpy(), exp), (len(b), cnt, int(res.total))
+    assert seen_unsynced > 0
