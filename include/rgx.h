@@ -109,6 +109,11 @@ int rgx_device_count(void);
 /* Upload tables to `device` (HIP ordinal).  Idempotent.  RGX_E_NO_DEVICE when there is none.        */
 int rgx_program_to_device(rgx_program* p, int device);
 int rgx_stream_ctx_create(const rgx_program* p, rgx_stream_ctx** out);
+/* The same on a stream the caller owns (use_given_stream != 0; hip_stream may be NULL = the legacy default stream): every launch,
+ * copy and event of the context is then ordered with the caller's own work on that stream -- device buffers the caller has just
+ * written (or is about to reuse) need no other synchronisation.  rgx_stream_ctx_create makes a private non-blocking stream:
+ * the caller must then order its own streams against rgx_stream_ctx_hip_stream() itself.                      */
+int rgx_stream_ctx_create_on_stream(const rgx_program* p, void* hip_stream, int use_given_stream, rgx_stream_ctx** out);
 void rgx_stream_ctx_destroy(rgx_stream_ctx* c);
 /* The HIP stream (hipStream_t) a ctx launches on; lets a caller order its own copies/events.       */
 void* rgx_stream_ctx_hip_stream(const rgx_stream_ctx* c);

@@ -216,7 +216,23 @@ class CMatcher:
                 f.write(src)
             subprocess.run(["gcc", opt, "-std=c11", "-fPIC", "-shared", cfile, "-o", so + ".tmp"], check=True)
             os.replace(so + ".tmp", so)
-        self.lib = ctypes.CDLL(so)
+        # Loaded from a private copy OUTSIDE the tree.  The driver's native-library hook lists the in-tree shared objects a test
+        # process has mapped, to see whether the PRODUCT's kernels ran, and caps the list at 50 sorted entries: hundreds of
+        # per-pattern checker libraries under oracle/_build/ pushed regengo_amd/lib/librgx_hip.so off it in round 1.  The
+        # cache of compiled checkers stays in oracle/_build/ (it travels to the GPU box with the snapshot).
+        import shutil
+        import tempfile
+        tmpdir = os.path.join(tempfile.gettempdir(), "rgx_oracle_%d" % os.getuid())
+        os.makedirs(tmpdir, exist_ok=True)
+        priv = os.path.join(tmpdir, "m_%s_%d.so" % (h, os.getpid()))
+        if not os.path.exists(priv):
+            shutil.copyfile(so, priv + ".tmp")
+            os.replace(priv + ".tmp", priv)
+        self.lib = ctypes.CDLL(priv)
+        try:
+            os.unlink(priv)                  # the mapping stays valid; nothing accumulates in the temp directory
+        except OSError:
+            pass
         self.lib.m_find_all.restype = ctypes.c_int64
         self.lib.m_find_all.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
         self.lib.m_find.restype = ctypes.c_int

@@ -62,6 +62,7 @@ SYMBOLS = {
     "rgx_device_count": (C.c_int, []),
     "rgx_program_to_device": (C.c_int, [C.c_void_p, C.c_int]),
     "rgx_stream_ctx_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rgx_stream_ctx_create_on_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
     "rgx_stream_ctx_destroy": (None, [C.c_void_p]),
     "rgx_stream_ctx_hip_stream": (C.c_void_p, [C.c_void_p]),
     "rgx_stream_ctx_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
@@ -109,9 +110,14 @@ def lib():
     if os.environ.get("RGX_NO_BUILD") != "1":
         try:
             path = _build.build_product()
-        except Exception:
-            if not os.path.exists(path):
+        except Exception as ex:
+            # a stale library must not stand in for sources that no longer compile -- except where no compiler exists at all
+            # (a box that only received the prebuilt library)
+            import shutil
+            if not os.path.exists(path) or shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc"):
                 raise
+            import warnings
+            warnings.warn("librgx_hip.so could not be rebuilt (%s); using the prebuilt library" % ex)
     if not os.path.exists(path):
         raise RuntimeError("librgx_hip.so is missing: the HIP extension is required (no CPU fallback exists)")
     # PyTorch's wheel carries its own libamdhip64; whichever copy is loaded first serves the whole process.  Load torch's

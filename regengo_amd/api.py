@@ -104,8 +104,12 @@ class Compiled:
     def to(self, device: int = 0) -> "Compiled":
         _capi.check(self._lib.rgx_program_to_device(self._h, device))
         if self._ctx is None:
+            # the context runs on torch's CURRENT stream of that device: scans are ordered with the torch kernels and copies that
+            # produce their inputs and reuse their outputs (a private stream would race with them)
+            import torch
+            st = torch.cuda.current_stream(device).cuda_stream
             c = C.c_void_p()
-            _capi.check(self._lib.rgx_stream_ctx_create(self._h, C.byref(c)))
+            _capi.check(self._lib.rgx_stream_ctx_create_on_stream(self._h, C.c_void_p(st), 1, C.byref(c)))
             self._ctx = c
         self._device = device
         _capi.check(self._lib.rgx_program_info(self._h, C.byref(self.info)))     # table_bytes / scan_kernel are known now

@@ -101,8 +101,16 @@ def build_hosttest() -> str:
     st = _needs(out, srcs + _all_headers(), " ".join(flags))
     if st is None:
         return out
-    _run(["g++"] + flags + srcs + ["-o", out])
-    open(out + ".stamp", "w").write(st)
+    # the gloo workers of tests/test_dist_cpu.py import this at the same moment: one builds (temporary + atomic rename)
+    import fcntl
+    with open(os.path.join(LIBDIR, ".build_hosttest.lock"), "w") as lk:
+        fcntl.flock(lk, fcntl.LOCK_EX)
+        if _needs(out, srcs + _all_headers(), " ".join(flags)) is None:
+            return out
+        tmp = out + ".tmp%d" % os.getpid()
+        _run(["g++"] + flags + srcs + ["-o", tmp])
+        os.replace(tmp, out)
+        open(out + ".stamp", "w").write(st)
     return out
 
 

@@ -32,7 +32,9 @@ struct rgx_stream_ctx {
   int64_t set_words = 0, dirty[2] = {0, 0};
   int cur_set = 0;
   uint32_t* d_counters = nullptr;            // [4]
-  unsigned long long* d_total = nullptr;     // [2]: total, trace cursor
+  unsigned long long* d_total = nullptr;     // the current scratch set's total (FindAllDevice::run_scan)
+  unsigned long long* d_cursor = nullptr;    // trace cursor of the capture kernel: its own word, valid from ctx creation on
+  bool own_stream = true;
   uint8_t* d_unsynced = nullptr; int32_t* d_carry = nullptr; int64_t slice_cap = 0;
   uint16_t* d_trace = nullptr; int64_t trace_cap = 0;
   uint8_t* d_in = nullptr; int64_t in_cap = 0;       // staging for the host-buffer entry points
@@ -102,7 +104,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   const int32_t ilen = (int32_t)len;
   // sync points: reset bytes by default; the sync automaton W (rgx_dfa.h) when the pattern has no reset byte at all or
   // when an earlier scan of this context found slices without one (then the scan kernel takes W, ScanParams::use_w)
-  static const bool force_w = getenv("RGX_FORCE_W") != nullptr;
+  static const bool force_w = ExpEnv("RGX_FORCE_W") != nullptr;
   const bool w_ok = ScanSupportsW(T, ilen);
   bool use_w = w_ok && (c->prefer_w || T.reset_values == 0 || force_w);
   int32_t ntiles = ScanNumTiles(T, ilen, use_w);
@@ -122,7 +124,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     c->dirty[0] = c->dirty[1] = c->set_words;
     c->cur_set = 0;
   }
-  const bool self_clean = UseExactKernel(T, ilen) && getenv("RGX_NO_SELF_CLEAN") == nullptr;
+  const bool self_clean = UseExactKernel(T, ilen) && ExpEnv("RGX_NO_SELF_CLEAN") == nullptr;
 
   ScanParams P{};
   P.buf = d_buf; P.len = ilen; P.ntiles = ntiles; P.use_w = use_w ? 1 : 0; P.spans = d_spans; P.cap_records = (int64_t)cap_records;
@@ -168,7 +170,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     c->cur_set = 1 - s;
     return RGX_OK;
   };
-  static const bool force_tickets = getenv("RGX_TICKETS") != nullptr;
+  static const bool force_tickets = ExpEnv("RGX_TICKETS") != nullptr;
   P.use_tickets = force_tickets ? 1 : 0;
   if ((rc = run_scan(c->timing)) != RGX_OK) return rc;
   if (((uint32_t*)&c->h_read[2])[3]) {
@@ -272,8 +274,8 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     // dynamic capture groups: second kernel over the (much smaller) match list
     int64_t need = (int64_t)len + written + 64;
     if ((rc = Ensure(&c->d_trace, &c->trace_cap, need)) != RGX_OK) return rc;
-    HIP_TRY(hipMemsetAsync(c->d_total + 1, 0, 8, c->stream));
-    HIP_TRY(LaunchCaptures(T, d_buf, ilen, d_spans, written, c->d_trace, c->d_total + 1, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_cursor, 0, 8, c->stream));
+    HIP_TRY(LaunchCaptures(T, d_buf, ilen, d_spans, written, c->d_trace, c->d_cursor, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
   if (res) res->written = written;
@@ -387,7 +389,9 @@ RGX_API int rgx_program_to_device(rgx_program* p, int device) {
   return ProgramToDevice(&p->p, device);
 }
 
-RGX_API int rgx_stream_ctx_create(const rgx_program* p, rgx_stream_ctx** out) {
+RGX_API int rgx_stream_ctx_create(const rgx_program* p, rgx_stream_ctx** out) { return rgx_stream_ctx_create_on_stream(p, nullptr, 0, out); }
+
+RGX_API int rgx_stream_ctx_create_on_stream(const rgx_program* p, void* hip_stream, int use_given_stream, rgx_stream_ctx** out) {
   if (!p || !out) return RGX_E_INVALID;
   *out = nullptr;
   if (!p->p.d_arena) { SetError("program not on a device (rgx_program_to_device)"); return RGX_E_NO_DEVICE; }
@@ -395,7 +399,10 @@ RGX_API int rgx_stream_ctx_create(const rgx_program* p, rgx_stream_ctx** out) {
   c->prog = p;
   c->device = p->p.device;
   if (hipSetDevice(c->device) != hipSuccess) { delete c; return RGX_E_NO_DEVICE; }
-  bool ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess &&
+  bool stream_ok;
+  if (use_given_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; stream_ok = true; }
+  else stream_ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
+  bool ok = stream_ok && hipMalloc((void**)&c->d_cursor, 16) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
                         hipHostMalloc((void**)&c->h_read, 128, hipHostMallocMapped) == hipSuccess &&
             hipHostGetDevicePointer((void**)&c->h_read_dev, c->h_read, 0) == hipSuccess;
@@ -406,7 +413,9 @@ RGX_API int rgx_stream_ctx_create(const rgx_program* p, rgx_stream_ctx** out) {
 RGX_API void rgx_stream_ctx_destroy(rgx_stream_ctx* c) {
   if (!c) return;
   hipSetDevice(c->device);
-  if (c->stream) { hipStreamSynchronize(c->stream); hipStreamDestroy(c->stream); }
+  if (c->stream || !c->own_stream) hipStreamSynchronize(c->stream);
+  if (c->stream && c->own_stream) hipStreamDestroy(c->stream);
+  if (c->d_cursor) hipFree(c->d_cursor);
   if (c->ev0) hipEventDestroy(c->ev0);
   if (c->ev1) hipEventDestroy(c->ev1);
   for (int i = 0; i < 2; ++i)
@@ -455,7 +464,7 @@ RGX_API int rgx_find_all_submit(const rgx_program* p, rgx_stream_ctx* c, const u
   pd = {d_buf, len, n, d_spans, cap_records, own_lo, own_hi, slot, n == 0 || len == 0, false};
   if (pd.trivial) { c->pend_count++; return RGX_OK; }
   const int32_t ilen = (int32_t)len;
-  static const bool no_self_clean = getenv("RGX_NO_SELF_CLEAN") != nullptr;
+  static const bool no_self_clean = ExpEnv("RGX_NO_SELF_CLEAN") != nullptr;
   if (!UseExactKernel(T, ilen) || no_self_clean || c->prefer_w) {
     SetError("asynchronous launch is offered for the exact kernel only");
     return RGX_E_UNSUPPORTED;
@@ -482,7 +491,7 @@ RGX_API int rgx_find_all_submit(const rgx_program* p, rgx_stream_ctx* c, const u
   P.buf = d_buf; P.len = ilen; P.ntiles = ntiles; P.use_w = 0; P.spans = d_spans; P.cap_records = (int64_t)cap_records;
   P.own_lo = (int32_t)std::max<int64_t>(0, std::min<int64_t>(own_lo, ilen));
   P.own_hi = own_hi < 0 ? ilen : (int32_t)std::max<int64_t>(P.own_lo, std::min<int64_t>(own_hi, ilen));
-  static const bool force_tickets = getenv("RGX_TICKETS") != nullptr;
+  static const bool force_tickets = ExpEnv("RGX_TICKETS") != nullptr;
   P.use_tickets = force_tickets ? 1 : 0;
   const int s = c->cur_set;
   unsigned long long* set = c->d_desc + (size_t)s * c->set_words;
@@ -742,8 +751,8 @@ RGX_API int64_t rgx_replace_all_bytes_device(const rgx_program* p, rgx_stream_ct
       if (!t.fixed_captures) {
         int64_t need = (int64_t)len + 64;
         if ((rc = Ensure(&c->d_trace, &c->trace_cap, need)) != RGX_OK) return rc;
-        HIP_TRY(hipMemsetAsync(c->d_total + 1, 0, 8, c->stream));
-        HIP_TRY(LaunchCaptures(T, d_buf ? d_buf : (const uint8_t*)c->d_rspans, ilen, c->d_rspans + n * ncap, 1, c->d_trace, c->d_total + 1,
+        HIP_TRY(hipMemsetAsync(c->d_cursor, 0, 8, c->stream));
+        HIP_TRY(LaunchCaptures(T, d_buf ? d_buf : (const uint8_t*)c->d_rspans, ilen, c->d_rspans + n * ncap, 1, c->d_trace, c->d_cursor,
                                c->stream));
       }
       n++;
@@ -936,7 +945,7 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
   if (nstr == 0) return 0;
   if (!d_concat || !d_offsets || !d_found || !d_spans) return RGX_E_INVALID;
   const DevTables& T = p->p.dev;
-  static const bool no_search = getenv("RGX_NO_SEARCH_DFA") != nullptr;
+  static const bool no_search = ExpEnv("RGX_NO_SEARCH_DFA") != nullptr;
   const DevTables* U = no_search ? nullptr : SearchTables(const_cast<Program*>(&p->p));
   if (U && BatchSearchFits(*U, T, true, d_concat)) {
     // scratch for strings longer than the LDS trace: (bytes + 2 per string) entries
@@ -985,7 +994,7 @@ RGX_API int64_t rgx_match_batch_device(const rgx_program* p, rgx_stream_ctx* c, 
     window = BatchWindowFor((int64_t)h_last, (int64_t)nstr);
   }
   {
-    static const bool no_search = getenv("RGX_NO_SEARCH_DFA") != nullptr;
+    static const bool no_search = ExpEnv("RGX_NO_SEARCH_DFA") != nullptr;
     const DevTables* U = no_search ? nullptr : SearchTables(const_cast<Program*>(&p->p));
     if (U && BatchSearchFits(*U, p->p.dev, false, d_concat)) {
       HIP_TRY(LaunchBatchSearch(*U, p->p.dev, d_concat, d_offsets, (int64_t)nstr, d_matched, nullptr, nullptr, c->stream, window));

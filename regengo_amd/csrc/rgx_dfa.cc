@@ -948,7 +948,12 @@ struct R {
   void raw(void* d, size_t k) { if (o + k > n) { ok = false; return; } memcpy(d, p + o, k); o += k; }
 };
 constexpr uint32_t kMagic = 0x54584752;  // "RGXT"
-constexpr uint32_t kBlobVersion = 2;
+constexpr uint32_t kBlobVersion = 3;     // 3: FNV-1a checksum of the blob appended; every index range-checked on load
+uint64_t Fnv1a(const uint8_t* p, size_t n) {
+  uint64_t h = 1469598103934665603ull;
+  for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
+  return h;
+}
 }  // namespace
 
 std::vector<uint8_t> SerializeTables(const Tables& t) {
@@ -966,10 +971,18 @@ std::vector<uint8_t> SerializeTables(const Tables& t) {
   w.vec(t.bt_match); w.vec(t.start_ops); w.vec(t.start_ops_pool); w.pod<int32_t>(t.max_threads); w.pod<int32_t>(t.fixed_len);
   w.raw(t.sa_mask, sizeof t.sa_mask); w.pod<int32_t>(t.sa_k); w.pod<uint8_t>(t.sa_exact);
   w.pod<int32_t>(t.w_nstates); w.pod<uint16_t>(t.w_start); w.vec(t.w_trans); w.pod<uint8_t>(t.needs_valid_utf8);
+  w.pod<uint64_t>(Fnv1a(w.b.data(), w.b.size()));
   return w.b;
 }
 
 bool DeserializeTables(const uint8_t* p, size_t n, Tables* t) {
+  if (n < 16) return false;
+  {
+    uint64_t want;
+    memcpy(&want, p + n - 8, 8);
+    if (Fnv1a(p, n - 8) != want) return false;       // truncated, padded or corrupted
+    n -= 8;
+  }
   R r{p, n};
   uint32_t magic = 0, ver = 0;
   r.pod(magic); r.pod(ver);
@@ -994,6 +1007,32 @@ bool DeserializeTables(const uint8_t* p, size_t n, Tables* t) {
   if (t->w_nstates < 0 || t->w_trans.size() != (size_t)t->w_nstates * t->ncls || (t->w_nstates && t->w_start >= t->w_nstates)) return false;
   if (t->ncls < 1 || t->ncls > 256 || t->nstates < 1 || t->trans.size() != (size_t)t->nstates * (t->ncls + 1)) return false;
   if ((int)t->cap_kind.size() != t->ncap || (int)t->cap_delta.size() != t->ncap) return false;
+  // every state, class and pool index a walker or a kernel will follow (the checksum guards against accidents, this against
+  // a blob that was assembled wrongly)
+  if (r.o != n) return false;
+  if (t->ncap < 2 || t->ncap > 64 || (t->ncap & 1) || t->cap_names.size() != (size_t)t->ncap / 2) return false;
+  if (t->nstates > (int)kStateMask || t->sa_k < 0 || t->sa_k > 32) return false;
+  const size_t ne = (size_t)t->nstates * (t->ncls + 1);
+  for (int c = 0; c < 256; c++) if (t->cls[c] >= t->ncls || t->ctx_of_byte[c] > 3) return false;
+  for (uint16_t e : t->trans) if ((e & kStateMask) >= t->nstates) return false;
+  for (int c = 0; c < 4; c++) if (t->start[c] >= t->nstates) return false;
+  for (uint16_t e : t->w_trans) if (e >= t->w_nstates) return false;
+  for (uint8_t k : t->cap_kind) if (k > kCapDynamic) return false;
+  if (t->st_nthreads.size() != (size_t)t->nstates || t->bt_base.size() != ne || t->bt_match.size() != ne) return false;
+  if (t->bt_parent.size() != t->bt_ops.size() || t->start_ops.size() != 4) return false;
+  for (size_t q = 0; q < (size_t)t->nstates; q++) {
+    for (int k = 0; k <= t->ncls; k++) {
+      const uint32_t b = t->bt_base[q * (t->ncls + 1) + k];
+      if (b == 0xFFFFFFFFu) continue;
+      const uint32_t nq = t->trans[q * (t->ncls + 1) + k] & kStateMask;
+      if ((uint64_t)b + t->st_nthreads[nq] > t->bt_parent.size()) return false;     // the target state's threads index this slice
+      const uint32_t m = t->bt_match[q * (t->ncls + 1) + k];
+      if (m != 0xFFFFFFFFu && (m >> 24) >= t->st_nthreads[q] && t->st_nthreads[q]) return false;
+    }
+    if (t->st_nthreads[q] > 256) return false;
+  }
+  for (size_t i = 0; i < t->bt_parent.size(); i++) if (t->bt_parent[i] >= 255 + 1u) return false;
+  for (int c = 0; c < 4; c++) if (t->start_ops[c] > t->start_ops_pool.size()) return false;
   return true;
 }
 

@@ -1300,14 +1300,14 @@ size_t ScanSharedBytes(const DevTables& T) {
 int32_t ScanNumTiles(const DevTables& T, int32_t len, bool use_w) {
   if (UseExactKernel(T, len)) return ExactNumBlocks(T, len);
   if (UseUsKernel(T, len, use_w)) return (len + kTileBytes - 1) / kTileBytes;
-  const int per = (UseSaKernel(T, len) && !getenv("RGX_NO_SA_KERNEL") && !use_w) ? SaTileBytes() : kTileBytes;
+  const int per = (UseSaKernel(T, len) && !ExpEnv("RGX_NO_SA_KERNEL") && !use_w) ? SaTileBytes() : kTileBytes;
   return (len + per - 1) / per;
 }
 
 int ScanKernelKind(const DevTables& T, int32_t len) {
   if (UseExactKernel(T, len)) return 1;
   if (UseUsKernel(T, len, false)) return UsKernelVariant(T);
-  if (UseSaKernel(T, len) && !getenv("RGX_NO_SA_KERNEL")) return 2;
+  if (UseSaKernel(T, len) && !ExpEnv("RGX_NO_SA_KERNEL")) return 2;
   return 3;
 }
 
@@ -1316,7 +1316,7 @@ bool ScanSupportsW(const DevTables& T, int32_t len) { return T.w_nstates > 0 && 
 hipError_t LaunchScan(const DevTables& T, const ScanParams& P, hipStream_t stream) {
   if (UseExactKernel(T, P.len)) return LaunchScanExact(T, P, stream);
   if (UseUsKernel(T, P.len, P.use_w != 0)) return LaunchScanUs(T, P, stream);
-  if (UseSaKernel(T, P.len) && !getenv("RGX_NO_SA_KERNEL") && !P.use_w) return LaunchScanSa(T, P, T.trans_cls, stream);
+  if (UseSaKernel(T, P.len) && !ExpEnv("RGX_NO_SA_KERNEL") && !P.use_w) return LaunchScanSa(T, P, T.trans_cls, stream);
   // The generic kernel stages its transition table once per 16 KiB tile: a table that is not small next to the tile costs
   // more L2->LDS traffic than the input itself and, through its LDS footprint, most of the CU's occupancy (`\\p{L}+`: 75 KB
   // per tile, one workgroup per CU, 26.5 ms per GiB against 5.7 ms with the table read through L1/L2).  So the kernel gets a
@@ -1325,8 +1325,8 @@ hipError_t LaunchScan(const DevTables& T, const ScanParams& P, hipStream_t strea
   DevTables V = T;
   {
     const size_t class_bytes = (size_t)T.nstates * T.stride * 2;
-    static const size_t direct_max = getenv("RGX_DIRECT_MAX") ? (size_t)atol(getenv("RGX_DIRECT_MAX")) : (size_t)12 * 1024;
-    static const size_t class_max = getenv("RGX_CLASS_LDS_MAX") ? (size_t)atol(getenv("RGX_CLASS_LDS_MAX")) : (size_t)24 * 1024;
+    static const size_t direct_max = ExpEnv("RGX_DIRECT_MAX") ? (size_t)atol(ExpEnv("RGX_DIRECT_MAX")) : (size_t)12 * 1024;
+    static const size_t class_max = ExpEnv("RGX_CLASS_LDS_MAX") ? (size_t)atol(ExpEnv("RGX_CLASS_LDS_MAX")) : (size_t)24 * 1024;
     if (T.mode == kModeDirect && (size_t)T.table_bytes > direct_max) {
       V.trans = T.trans_cls;
       if (class_bytes <= class_max) { V.mode = kModeClassLds; V.table_bytes = (int32_t)class_bytes; }
@@ -1429,7 +1429,7 @@ hipError_t LaunchCarry(const DevTables& T, const uint8_t* buf, int32_t len, cons
 hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, int32_t* spans, int64_t nmatches, uint16_t* trace,
                           unsigned long long* trace_cursor, hipStream_t stream) {
   if (nmatches <= 0) return hipSuccess;
-  static const bool force_old = getenv("RGX_CAPS_OLD") != nullptr;
+  static const bool force_old = ExpEnv("RGX_CAPS_OLD") != nullptr;
   const bool t8 = T.nstates <= 256;
   const BatchLayout Y = BatchLdsLayout(T, true, t8 ? 1 : 2, kCapsWindow);
   if (!force_old && nmatches >= 64 && T.mode != kModeClassGlobal && Y.total <= 150 * 1024 && (((uintptr_t)buf) & 15) == 0 && T.ncap <= 32) {
@@ -1517,7 +1517,7 @@ hipError_t LaunchBatch(const DevTables& T, const uint8_t* concat, const uint64_t
                        int32_t* spans, uint16_t* trace, int64_t trace_stride, hipStream_t stream, int window_bytes) {
   if (nstr <= 0) return hipSuccess;
   if (window_bytes <= 0) window_bytes = kBatchWindow;
-  static const bool force_old = getenv("RGX_BATCH_OLD") != nullptr;
+  static const bool force_old = ExpEnv("RGX_BATCH_OLD") != nullptr;
   const BatchLayout Y = BatchLdsLayout(T, spans != nullptr, 2, window_bytes);
   if (!force_old && T.mode != kModeClassGlobal && Y.total <= 150 * 1024 && (((uintptr_t)concat) & 15) == 0 && T.ncap <= 32) {
     static int cus = 0;
@@ -1531,7 +1531,7 @@ hipError_t LaunchBatch(const DevTables& T, const uint8_t* concat, const uint64_t
     if (per_cu > 6) per_cu = 6;
     int64_t grid = (int64_t)cus * per_cu * 4;      // a few groups per workgroup amortise the table staging; tail stays short
     if (grid > ngroups) grid = ngroups;
-    static const int dbg = getenv("RGX_BATCH_DEBUG") ? atoi(getenv("RGX_BATCH_DEBUG")) : 0;
+    static const int dbg = ExpEnv("RGX_BATCH_DEBUG") ? atoi(ExpEnv("RGX_BATCH_DEBUG")) : 0;
     static bool attr_set[2] = {false, false};
     const void* fn = T.mode == kModeDirect ? (const void*)batch_lds_kernel<kModeDirect> : (const void*)batch_lds_kernel<kModeClassLds>;
     const int mi = T.mode == kModeDirect ? 0 : 1;

@@ -182,7 +182,7 @@ constexpr int kUsMaxEntries = 4096;      // 32 KiB of LDS for the table at most 
 
 // Start-tracking search automaton: the fewest registers (1, 2, 4) with which the pattern is eligible and the table fits.
 bool BuildUs(Program* p) {
-  static const bool off = getenv("RGX_NO_US") != nullptr;
+  static const bool off = ExpEnv("RGX_NO_US") != nullptr;
   if (off || p->t.anchored || p->t.can_match_empty) return false;
   for (int regs : {1, 2, 4}) {
     try {

@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdint>
+#include <cstdlib>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -10,6 +11,17 @@
 #include "rgx_dfa.h"
 
 namespace rgx {
+
+// Experiment switches (environment variables that pick kernel variants, RGX_DEBUG bits that skip phases of the exact kernel)
+// exist only in builds made with -DRGX_EXPERIMENT (RGX_EXTRA_FLAGS=-DRGX_EXPERIMENT, regengo_amd/build.py): the product build
+// reads no environment variable on its hot path and a stray one cannot turn a kernel into a fast wrong one.
+#ifdef RGX_EXPERIMENT
+inline const char* ExpEnv(const char* name) { return getenv(name); }
+#define RGX_EXP_DEBUG(P, bits) (((P).debug & (bits)) != 0)
+#else
+inline const char* ExpEnv(const char*) { return nullptr; }
+#define RGX_EXP_DEBUG(P, bits) false
+#endif
 
 // Geometry of the scan kernel (see rgx_kernels.hip / DESIGN.md).
 constexpr int kSliceBytes = 64;                       // input bytes owned by one lane

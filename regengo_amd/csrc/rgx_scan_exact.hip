@@ -174,7 +174,7 @@ __global__ __launch_bounds__(kExactThreads) void scan_exact_kernel(DevTables T, 
     pv[S][3] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo + 3072, 0, 2);                          \
     if (!LAG && lane < 2) pv[S][4] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo + 4096, 0, 2);    \
   }
-  if (!(P.debug & 16)) {
+  if (!RGX_EXP_DEBUG(P, 16)) {
     RGX_LOAD_TILE(0, first_tile * TB - kSliceBytes)
     RGX_LOAD_TILE(1, (first_tile + 1) * TB - kSliceBytes)
   }
@@ -208,12 +208,12 @@ __global__ __launch_bounds__(kExactThreads) void scan_exact_kernel(DevTables T, 
     if (!LAG && lane < 2) *reinterpret_cast<v4u*>(wt + 64 * kRowBytes + (lane << 4)) = pv[g & 1][4];
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    if (g + 2 < G && tb0 + 2 * TB + kSliceBytes < len && !(P.debug & 16)) RGX_LOAD_TILE(g & 1, tb0 + 2 * TB)
+    if (g + 2 < G && tb0 + 2 * TB + kSliceBytes < len && !RGX_EXP_DEBUG(P, 16)) RGX_LOAD_TILE(g & 1, tb0 + 2 * TB)
 
     // ---- candidate mask of this lane's slice (match starts in [a, a+64))
     const int a = tb0 + lane * kSliceBytes;
     unsigned long long cur = 0;
-    if (!(P.debug & 8)) {
+    if (!RGX_EXP_DEBUG(P, 8)) {
       const uint4* row = reinterpret_cast<const uint4*>(wt + lane * kRowBytes);
       const uint4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
       const uint4 n0 = row[5], n1 = row[6];   // next row: 80-byte stride = 5 uint4
@@ -360,7 +360,7 @@ __global__ __launch_bounds__(kExactThreads) void scan_exact_kernel(DevTables T, 
 #pragma unroll
     for (int w = 0; w < kExactThreads / 64; ++w) block_total += L.wtot[w];
     unsigned long long excl = 0;
-    if (!(P.debug & 1)) excl = LookBack(P.tile_desc, blk, block_total, lane, &P.counters[3], 4, P.host_result ? P.host_result + 1 : nullptr, !P.use_tickets);
+    if (!RGX_EXP_DEBUG(P, 1)) excl = LookBack(P.tile_desc, blk, block_total, lane, &P.counters[3], 4, P.host_result ? P.host_result + 1 : nullptr, !P.use_tickets);
     if (lane == 0) {
       L.base_lo = (unsigned)excl;
       L.base_hi = (unsigned)(excl >> 32);
@@ -401,10 +401,10 @@ __global__ __launch_bounds__(kExactThreads) void scan_exact_kernel(DevTables T, 
         const int s = (int)st[r];
         const int4 o = *reinterpret_cast<const int4*>(&L.off[c << 2]);
         unsigned long long idx = base + r;
-        if (P.debug & 64) idx &= 0xFFFFull;      // experiment: all records land in 2 MiB (stays in L2)
-        if (idx < (unsigned long long)P.cap_records && !(P.debug & 4))
+        if (RGX_EXP_DEBUG(P, 64)) idx &= 0xFFFFull;      // experiment: all records land in 2 MiB (stays in L2)
+        if (idx < (unsigned long long)P.cap_records && !RGX_EXP_DEBUG(P, 4))
         {
-          if (P.debug & 32) *reinterpret_cast<v4i*>(P.spans + idx * ncap + (c << 2)) = v4i{s + o.x, s + o.y, s + o.z, s + o.w};
+          if (RGX_EXP_DEBUG(P, 32)) *reinterpret_cast<v4i*>(P.spans + idx * ncap + (c << 2)) = v4i{s + o.x, s + o.y, s + o.z, s + o.w};
           else __builtin_nontemporal_store(v4i{s + o.x, s + o.y, s + o.z, s + o.w},
                                            reinterpret_cast<v4i*>(P.spans + idx * ncap + (c << 2)));
         }
@@ -469,7 +469,7 @@ int ResidentWorkgroups() {
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
   if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&occ, scan_exact_kernel<4, true>, kExactThreads, 0) != hipSuccess || occ <= 0) occ = 5;
   (void)hipGetLastError();
-  const char* e = getenv("RGX_RESIDENT");
+  const char* e = ExpEnv("RGX_RESIDENT");
   r = e ? atoi(e) : cus * occ;
   if (r < 8) r = 8;
   return r;
@@ -482,7 +482,7 @@ ExactPlan MakePlan(int32_t len, int tile_bytes) {
   const int L = ResidentWorkgroups() / kGroupTiles;                                 // workgroups per ramp level
   long long ramp = 0;
   for (int v = 1; v < kGroupTiles; ++v) ramp += 2LL * L * wpb * v;
-  static const bool flat = getenv("RGX_FLAT_PLAN") != nullptr;
+  static const bool flat = ExpEnv("RGX_FLAT_PLAN") != nullptr;
   int nseg = 0;
   long long blk = 0, tile = 0;
   auto add = [&](int g, long long nb) {
@@ -507,7 +507,7 @@ ExactPlan MakePlan(int32_t len, int tile_bytes) {
 
 // look-back descriptors (= workgroups) the scan of `len` bytes uses
 static int ExactTileBytesFor(const DevTables& T) {
-  static const bool no16 = getenv("RGX_NO_W16") != nullptr;
+  static const bool no16 = ExpEnv("RGX_NO_W16") != nullptr;
   return (T.sa_k <= 16 && !no16) ? kWaveTileBytesLag : kWaveTileBytes;
 }
 int ExactNumBlocks(const DevTables& T, int32_t len) { return MakePlan(len, ExactTileBytesFor(T)).nblocks; }
@@ -518,11 +518,11 @@ hipError_t LaunchScanExact(const DevTables& T, const ScanParams& P, hipStream_t 
   dim3 grid(plan.nblocks);
   const int K = T.sa_k;
   static int debug = -1;   // experiment switches (RGX_DEBUG): 8 = skip the byte loop, 16 = skip the global loads
-  if (debug < 0) { const char* e = getenv("RGX_DEBUG"); debug = e ? atoi(e) : 0; }
+  if (debug < 0) { const char* e = ExpEnv("RGX_DEBUG"); debug = e ? atoi(e) : 0; }
   ScanParams Q = P;
   Q.debug = debug;
-  static const bool no16 = getenv("RGX_NO_W16") != nullptr;
-  static const int extra_lds = getenv("RGX_EXTRA_LDS") ? atoi(getenv("RGX_EXTRA_LDS")) : 0;   // experiment: caps workgroups per CU
+  static const bool no16 = ExpEnv("RGX_NO_W16") != nullptr;
+  static const int extra_lds = ExpEnv("RGX_EXTRA_LDS") ? atoi(ExpEnv("RGX_EXTRA_LDS")) : 0;   // experiment: caps workgroups per CU
   if (K <= 16 && !no16) hipLaunchKernelGGL((scan_exact_kernel<4, true>), grid, block, extra_lds, stream, T, Q, plan);
   else if (K <= 17) hipLaunchKernelGGL((scan_exact_kernel<4, false>), grid, block, 0, stream, T, Q, plan);
   else if (K <= 25) hipLaunchKernelGGL((scan_exact_kernel<2, false>), grid, block, 0, stream, T, Q, plan);

@@ -1387,14 +1387,14 @@ __global__ __launch_bounds__(64) void carry_us_kernel(DevTables T, UsDev U, cons
 }  // namespace
 
 bool UseUsKernel(const DevTables& T, int32_t len, bool use_w) {
-  static const bool off = getenv("RGX_NO_US_KERNEL") != nullptr;
+  static const bool off = ExpEnv("RGX_NO_US_KERNEL") != nullptr;
   if (off || T.us == nullptr || use_w || len < 64 || UseExactKernel(T, len) || T.anchored || T.ncap > 32) return false;
   return T.us->ent4 != nullptr || T.us->stride <= 32;     // the register kernel keeps class * 8 in one byte
 }
 
 int UsKernelVariant(const DevTables& T) {
   const UsDev& U = *T.us;
-  static const bool no_simple = getenv("RGX_NO_US_SIMPLE") != nullptr, no_pairs = getenv("RGX_NO_US_PAIRS") != nullptr;
+  static const bool no_simple = ExpEnv("RGX_NO_US_SIMPLE") != nullptr, no_pairs = ExpEnv("RGX_NO_US_PAIRS") != nullptr;
   if (U.ent2 && !no_simple && !no_pairs) return 6;
   if (U.ent4 && !no_simple) return 5;
   return 4;
@@ -1403,8 +1403,8 @@ int UsKernelVariant(const DevTables& T) {
 hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t stream) {
   const UsDev& U = *T.us;
   dim3 grid(P.ntiles), block(kBlockThreads);
-  static const bool no_simple = getenv("RGX_NO_US_SIMPLE") != nullptr;
-  static const bool no_pairs = getenv("RGX_NO_US_PAIRS") != nullptr;
+  static const bool no_simple = ExpEnv("RGX_NO_US_SIMPLE") != nullptr;
+  static const bool no_pairs = ExpEnv("RGX_NO_US_PAIRS") != nullptr;
   if (U.ent2 && !no_simple && !no_pairs) {
     static bool attr2 = false;
     if (!attr2) { hipFuncSetAttribute((const void*)scan_us_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr2 = true; }
@@ -1421,7 +1421,7 @@ hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t str
       // 4 per CU measured best (16 waves: 3 leaves the SIMDs idle, 5 adds nothing); LDS admits 5 and the SGPR count 6, so 4 is
       // resident with a margin even where the query over-reports by one
       if (per_cu > 4) per_cu = 4; else if (per_cu > 2) per_cu -= 1;
-      if (getenv("RGX_US_PER_CU")) per_cu = atoi(getenv("RGX_US_PER_CU"));
+      if (ExpEnv("RGX_US_PER_CU")) per_cu = atoi(ExpEnv("RGX_US_PER_CU"));
     }
     int nblk = per_cu * ncu;
     if (nblk > P.ntiles) nblk = P.ntiles;

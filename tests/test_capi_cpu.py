@@ -92,3 +92,29 @@ def test_stream_config_resolve(built, kats):
     assert lib.rgx_stream_config_resolve(h, C.byref(_capi.StreamConfig(100, 0)), C.byref(out)) == _capi.RGX_E_BUFFER_TOO_SMALL
     assert lib.rgx_stream_config_resolve(h, C.byref(_capi.StreamConfig(1 << 20, -1)), C.byref(out)) == 0
     assert (out.buffer_size, out.max_leftover) == (1 << 20, -1)
+
+
+def test_corrupted_blob_is_refused(built):
+    """The blob carries a checksum and every index in it is range-checked on load (a truncated, padded or hand-assembled blob
+    must not reach the table walkers): RGX_E_BAD_BLOB, never a program."""
+    lib = _capi.lib()
+    h = C.c_void_p()
+    assert lib.rgx_compile(rb"(?P<user>\w+)@(?P<domain>\w+)", 0, C.byref(h)) == 0
+    n = lib.rgx_program_blob_size(h)
+    buf = C.create_string_buffer(n)
+    assert lib.rgx_program_blob_write(h, buf, n) == n
+    good = bytes(buf.raw)
+    lib.rgx_program_destroy(h)
+    h2 = C.c_void_p()
+    assert lib.rgx_program_from_blob(good, len(good), C.byref(h2)) == 0
+    lib.rgx_program_destroy(h2)
+    import random
+    rng = random.Random(1)
+    for trial in range(200):
+        bad = bytearray(good)
+        k = rng.randrange(len(bad))
+        bad[k] ^= 1 << rng.randrange(8)
+        assert lib.rgx_program_from_blob(bytes(bad), len(bad), C.byref(h2)) == -9, (trial, k)
+    for cut in (0, 7, 100, len(good) - 1):
+        assert lib.rgx_program_from_blob(good[:cut], cut, C.byref(h2)) == -9
+    assert lib.rgx_program_from_blob(good + b"\0" * 8, len(good) + 8, C.byref(h2)) == -9
