@@ -49,8 +49,11 @@ typedef enum rgx_status {
 
 enum {
   RGX_FLAG_UNMATCHED_MINUS1 = 1u << 0, /* unmatched group = (-1,-1) instead of the reference's (0,0) */
-  RGX_FLAG_STDLIB_SEMANTICS = 1u << 1  /* MatchBytes / FindBytes / FindReader without quirks Q1/Q4
-                                          (see DESIGN.md): plain leftmost-first search            */
+  RGX_FLAG_STDLIB_SEMANTICS = 1u << 1  /* MatchBytes / FindBytes (single and batch) as a plain leftmost-first search.  Default
+                                          (flag clear): the REFERENCE's behaviour -- after a failed attempt the emitted loops
+                                          resume behind the offset their last alternative failed at, not at start+1
+                                          (compiler.go:845-853, find.go:545-569), which steps over some
+                                          matches.  FindAllBytes has no such rule and is the same in both modes.       */
 };
 
 typedef struct rgx_program rgx_program;       /* compiled pattern: host tables + device copy      */
@@ -133,6 +136,17 @@ typedef struct rgx_result {
  * `d_buf` device pointer.  *matched = 0/1.                                                          */
 int rgx_match_bytes_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len,
                            int* matched);
+
+/* The same on a host buffer (what the stub's MatchBytes(input []byte) calls: the bytes go through the context's device staging
+ * buffer).  PCIe-bound; below a few KiB the stub's pure-Go path is faster.                  */
+int rgx_match_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* buf, size_t len, int* matched);
+
+/* FindBytes / FindBytesReuse(input []byte, r) -- find.go:469-591: the FIRST match and its capture spans; *found = 0/1, spans =
+ * ncap int32 (zeroes when nothing matches: the emitted function returns (nil, false)).  Host buffers.  Reference semantics by
+ * default: the emitted loop restarts behind its failure offset, not at start+1 -- `12024-01-15` has no Date
+ * match in the reference; RGX_FLAG_STDLIB_SEMANTICS gives the plain leftmost-first search.  RGX_E_UNSUPPORTED: the reference
+ * emits a memoising or TDFA engine for this pattern, whose restart offsets are not reproduced -- keep the Go path. */
+int rgx_find_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* buf, size_t len, int32_t* spans, int* found);
 
 /* FindAllBytes(input []byte, n int) -- find.go:113-124,130-466 (TDFA flavour compiler.go:602-655).
  * `d_buf`, `d_spans` device pointers; `cap_records` = capacity of d_spans in records of ncap int32.
@@ -221,6 +235,9 @@ int64_t rgx_count_all_device(const rgx_program* p, rgx_stream_ctx* c, const uint
  * Semantics per string: FindBytesReuse, find.go:469-591 (first leftmost-first match).              */
 int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_concat,
                               const uint64_t* d_offsets, size_t nstr, uint8_t* d_found, int32_t* d_spans);
+/* The same with host buffers (concat, offsets, found, spans): staged through the context's device buffers.             */
+int64_t rgx_find_batch(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* concat, const uint64_t* offsets, size_t nstr,
+                       uint8_t* found, int32_t* spans);
 /* MatchBytes per string of a batch.                                                                */
 int64_t rgx_match_batch_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_concat,
                                const uint64_t* d_offsets, size_t nstr, uint8_t* d_matched);

@@ -57,10 +57,16 @@ class BytesResult:
 
 
 class Compiled:
-    def __init__(self, pattern: str, name: str = "Pattern", flags: int = 0, device: Optional[int] = None):
+    def __init__(self, pattern: str, name: str = "Pattern", flags: int = 0, device: Optional[int] = None, stdlib: bool = False):
+        """stdlib=False (the default): MatchBytes / FindBytes / FindBatch behave like the reference's emitted functions,
+        restart rule included (SURVEY 5.9 Q1: a failed attempt resumes behind its failure offset, stepping over some matches);
+        stdlib=True: the plain leftmost-first search (RGX_FLAG_STDLIB_SEMANTICS).  FindAllBytes is the same in both."""
         self._lib = _capi.lib()
         self.pattern = pattern
         self.name = name
+        if stdlib:
+            flags |= _capi.FLAG_STDLIB_SEMANTICS
+        self.stdlib = bool(flags & _capi.FLAG_STDLIB_SEMANTICS)
         h = C.c_void_p()
         _capi.check(self._lib.rgx_compile(pattern.encode("utf-8"), flags, C.byref(h)))
         self._h = h
@@ -145,9 +151,15 @@ class Compiled:
         return t.to("cuda:%d" % self._device), len(b)
 
     def MatchBytes(self, data) -> bool:
+        """compiler.go:740-871.  Host bytes go through rgx_match_bytes (what the cgo stub calls), device tensors through
+        rgx_match_bytes_device."""
         self._need_dev()
-        t, n = self._as_device(data)
         m = C.c_int(0)
+        if isinstance(data, (bytes, bytearray, memoryview)):
+            b = bytes(data)
+            _capi.check(self._lib.rgx_match_bytes(self._h, self._ctx, b, len(b), C.byref(m)))
+            return bool(m.value)
+        t, n = self._as_device(data)
         _capi.check(self._lib.rgx_match_bytes_device(self._h, self._ctx, t.data_ptr() if n else None, n, C.byref(m)))
         return bool(m.value)
 
@@ -255,9 +267,13 @@ class Compiled:
         return [self._make_result(src, r) for r in spans.cpu().tolist()]
 
     def FindBytes(self, data):
-        """(result, ok).  First leftmost-first match (FindBytesReuse without the Q1 restart quirk)."""
-        r = self.FindBatch([bytes(data)])
-        return (r[0], True) if r[0] is not None else (None, False)
+        """(result, ok): FindBytes / FindBytesReuse, find.go:469-591, through the host-buffer entry point rgx_find_bytes."""
+        self._need_dev()
+        b = bytes(data)
+        spans = (C.c_int32 * self.ncap)()
+        f = C.c_int(0)
+        _capi.check(self._lib.rgx_find_bytes(self._h, self._ctx, b, len(b), spans, C.byref(f)))
+        return (self._make_result(b, list(spans)), True) if f.value else (None, False)
 
     # ---- Replace path (replace.go:205-363; template syntax replace/template.go)
     def ReplaceAllDevice(self, data, template: str, first_only: bool = False):

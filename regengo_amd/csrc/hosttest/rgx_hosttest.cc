@@ -276,6 +276,66 @@ int rgxt_match(void* hh, const uint8_t* buf, int64_t len) {
   return 0;
 }
 
+// ---- reference mode (Q1): FindBytesReuse / MatchBytes with the emitted code's restart rule, over the anchored tables and the
+// right-most path automaton (rgx_dfa.h: rm_*) -- the loop ref_batch_kernel runs per string.  -3: not offered for this pattern.
+static int64_t RmFailOffset(const Tables& t, int v, const uint8_t* buf, int64_t len, int64_t off) {
+  const int stride = t.ncls + 1;
+  const int ctx = off == 0 ? kCtxBOT : t.ctx_of_byte[buf[off - 1]];
+  unsigned st = t.rm_start[v][ctx];
+  for (int64_t i = off;; i++) {
+    const int k = i < len ? t.cls[buf[i]] : t.ncls;
+    const uint16_t nx = t.rm_trans[v][(size_t)st * stride + k];
+    if (nx == 0xFFFF) return i - t.rm_depth[v][st];
+    st = nx;
+  }
+}
+int rgxt_ref_find(void* hh, const uint8_t* buf, int64_t len, int32_t* out) {
+  const Tables& t = ((Handle*)hh)->t;
+  if (t.ref_memo || t.ref_find_engine > 0) return -3;
+  int64_t off = 0;
+  while (true) {
+    const int64_t end = Walk(t, buf, len, off, nullptr, nullptr);
+    if (end >= 0) { Captures(t, buf, len, off, end, out); return 1; }
+    if (t.anchored) return 0;
+    const int64_t fo = RmFailOffset(t, 0, buf, len, off);
+    if (!(len > fo)) return 0;
+    off = fo + 1;
+  }
+}
+int rgxt_ref_match(void* hh, const uint8_t* buf, int64_t len) {
+  const Tables& t = ((Handle*)hh)->t;
+  if (t.ref_match_engine == 1) {                         // the Thompson matcher has no restart quirk: plain existence
+    for (int64_t pos = 0; pos <= len; pos++) {
+      if (t.anchored && pos > 0) break;
+      if (Walk(t, buf, len, pos, nullptr, nullptr) >= 0) return 1;
+    }
+    return 0;
+  }
+  if (t.ref_memo || t.ref_has_fail) return -3;
+  int64_t off = 0;
+  const bool has_prefix = t.ref_prefix >= 0;
+  if (has_prefix) {
+    const void* p = len ? memchr(buf, t.ref_prefix, (size_t)len) : nullptr;
+    if (!p) return 0;
+    off = (const uint8_t*)p - buf;
+  }
+  while (true) {
+    if (Walk(t, buf, len, off, nullptr, nullptr) >= 0) return 1;
+    if (t.anchored) return 0;
+    int64_t fo = RmFailOffset(t, 1, buf, len, off);
+    if (has_prefix) {
+      fo += 1;
+      if (!(len > fo)) return 0;
+      const void* p = memchr(buf + fo, t.ref_prefix, (size_t)(len - fo));
+      if (!p) return 0;
+      off = (const uint8_t*)p - buf;
+    } else {
+      if (!(len > fo)) return 0;
+      off = fo + 1;
+    }
+  }
+}
+
 // ---- start-tracking search automaton (rgx_dfa.h: StartSearch): FindAll as one table step per byte, the loop the
 // scan_us kernel runs per lane.  Returns the handle, or nullptr with the reason in rgxt_last_error ("ineligible: ...").
 struct UsHandle { StartSearch u; };

@@ -916,13 +916,25 @@ RGX_API int rgx_match_bytes_device(const rgx_program* p, rgx_stream_ctx* c, cons
   // A whole-buffer MatchBytes is "does FindAll find anything", except that the search also tries the empty
   // match at offset len (compiler.go:845-853 retries while l > offset) which FindAll never does (find.go:209-211).
   const Tables& t = p->p.t;
-  if (t.can_match_empty) {
+  const bool ref_rule = !(t.flags & RGX_FLAG_STDLIB_SEMANTICS) && p->p.dev.ref_match_kind != 1;
+  if (ref_rule && p->p.dev.ref_match_kind == 2) { SetError("reference-mode MatchBytes is not offered for this pattern (memoising engine): keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS"); return RGX_E_UNSUPPORTED; }
+  if (ref_rule && !t.can_match_empty) {
+    // The reference's MatchBytes only ever reports true matches, so "no leftmost-first match anywhere" (the parallel scan) is
+    // its answer too; where one exists the emitted loop itself decides -- its restart rule may step over it (Q1) -- and that
+    // loop is sequential: one lane, which stops at the first match it accepts.
+    rgx_result r0;
+    const int64_t any = FindAllDevice(p, c, d_buf, len, -1, nullptr, 0, true, &r0);
+    if (any < 0) return (int)any;
+    if (any == 0) { *matched = 0; return RGX_OK; }
+  }
+  if (t.can_match_empty || ref_rule) {
     // one-string batch covers the attempt at offset len exactly
     uint64_t h_off[2] = {0, (uint64_t)len};
     uint64_t* d_off = nullptr; uint8_t* d_found = nullptr;
     HIP_TRY(hipMalloc((void**)&d_off, 16)); HIP_TRY(hipMalloc((void**)&d_found, 16));
     HIP_TRY(hipMemcpyAsync(d_off, h_off, 16, hipMemcpyHostToDevice, c->stream));
-    hipError_t e = LaunchBatch(p->p.dev, d_buf, d_off, 1, d_found, nullptr, nullptr, 0, c->stream);
+    hipError_t e = ref_rule ? LaunchBatchRef(p->p.dev, d_buf, d_off, 1, d_found, nullptr, nullptr, c->stream)
+                            : LaunchBatch(p->p.dev, d_buf, d_off, 1, d_found, nullptr, nullptr, 0, c->stream);
     uint8_t f = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&f, d_found, 1, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
@@ -945,6 +957,17 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
   if (nstr == 0) return 0;
   if (!d_concat || !d_offsets || !d_found || !d_spans) return RGX_E_INVALID;
   const DevTables& T = p->p.dev;
+  if (!(p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS)) {
+    // reference mode: FindBytesReuse's own restart rule (find.go:545-569)
+    if (!T.ref_find_ok) { SetError("reference-mode FindBytes is not offered for this pattern (memoising / TDFA engine): keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS"); return RGX_E_UNSUPPORTED; }
+    uint64_t h_last = 0;
+    HIP_TRY(hipMemcpyAsync(&h_last, d_offsets + nstr, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((rc = Ensure(&c->d_trace, &c->trace_cap, (int64_t)h_last + 2 * (int64_t)nstr + 64)) != RGX_OK) return rc;
+    HIP_TRY(LaunchBatchRef(T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, c->d_trace, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return (int64_t)nstr;
+  }
   static const bool no_search = ExpEnv("RGX_NO_SEARCH_DFA") != nullptr;
   const DevTables* U = no_search ? nullptr : SearchTables(const_cast<Program*>(&p->p));
   if (U && BatchSearchFits(*U, T, true, d_concat)) {
@@ -986,6 +1009,14 @@ RGX_API int64_t rgx_match_batch_device(const rgx_program* p, rgx_stream_ctx* c, 
   if (rc != RGX_OK) return rc;
   if (nstr == 0) return 0;
   if (!d_concat || !d_offsets || !d_matched) return RGX_E_INVALID;
+  if (!(p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS) && p->p.dev.ref_match_kind != 1) {
+    // reference mode: MatchBytes' restart rule and prefix skip (compiler.go:740-871); the Thompson flavour (kind 1) has no such
+    // rule and takes the plain path below
+    if (p->p.dev.ref_match_kind == 2) { SetError("reference-mode MatchBytes is not offered for this pattern (memoising engine): keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS"); return RGX_E_UNSUPPORTED; }
+    HIP_TRY(LaunchBatchRef(p->p.dev, d_concat, d_offsets, (int64_t)nstr, d_matched, nullptr, nullptr, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return (int64_t)nstr;
+  }
   int window = 0;
   if (nstr >= 4096) {       // big batches: size the LDS input window by the average string length
     uint64_t h_last = 0;
@@ -1005,6 +1036,53 @@ RGX_API int64_t rgx_match_batch_device(const rgx_program* p, rgx_stream_ctx* c, 
   HIP_TRY(LaunchBatch(p->p.dev, d_concat, d_offsets, (int64_t)nstr, d_matched, nullptr, nullptr, 0, c->stream, window));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return (int64_t)nstr;
+}
+
+// ---------------------------------------------------------------- host-buffer forms of MatchBytes / FindBytes / batch
+RGX_API int rgx_match_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* buf, size_t len, int* matched) {
+  int rc = CheckCtx(p, c);
+  if (rc != RGX_OK) return rc;
+  if (!matched || (len && !buf)) return RGX_E_INVALID;
+  if (len > 0x7FFFFF00ull) { SetError("buffer larger than 2^31-256 bytes"); return RGX_E_TOO_LARGE; }
+  if ((rc = Ensure(&c->d_in, &c->in_cap, (int64_t)len + 64)) != RGX_OK) return rc;
+  if (len) HIP_TRY(hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream));
+  return rgx_match_bytes_device(p, c, c->d_in, len, matched);
+}
+
+RGX_API int64_t rgx_find_batch(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* concat, const uint64_t* offsets, size_t nstr,
+                               uint8_t* found, int32_t* spans) {
+  int rc = CheckCtx(p, c);
+  if (rc != RGX_OK) return rc;
+  if (nstr == 0) return 0;
+  if (!offsets || !found || !spans) return RGX_E_INVALID;
+  const uint64_t total = offsets[nstr];
+  if (total && !concat) return RGX_E_INVALID;
+  const int ncap = p->p.t.ncap;
+  // device staging: [concat | pad to 8][offsets (nstr+1) x u64], outputs [found nstr bytes | pad][spans]
+  const size_t off_offsets = (total + 71) & ~size_t(7);
+  if ((rc = Ensure(&c->d_in, &c->in_cap, (int64_t)(off_offsets + (nstr + 1) * 8 + 64))) != RGX_OK) return rc;
+  const size_t off_spans = (nstr + 15) & ~size_t(15);
+  if ((rc = Ensure(&c->d_out, &c->out_cap, (int64_t)(off_spans / 4 + nstr * ncap + 16))) != RGX_OK) return rc;
+  if (total) HIP_TRY(hipMemcpyAsync(c->d_in, concat, total, hipMemcpyHostToDevice, c->stream));
+  HIP_TRY(hipMemcpyAsync(c->d_in + off_offsets, offsets, (nstr + 1) * 8, hipMemcpyHostToDevice, c->stream));
+  uint8_t* d_found = (uint8_t*)c->d_out;
+  int32_t* d_spans = c->d_out + off_spans / 4;
+  const int64_t r = rgx_find_batch_device(p, c, c->d_in, (const uint64_t*)(c->d_in + off_offsets), nstr, d_found, d_spans);
+  if (r < 0) return r;
+  HIP_TRY(hipMemcpyAsync(found, d_found, nstr, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipMemcpyAsync(spans, d_spans, nstr * (size_t)ncap * 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return r;
+}
+
+RGX_API int rgx_find_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* buf, size_t len, int32_t* spans, int* found) {
+  if (!found || !spans) return RGX_E_INVALID;
+  const uint64_t offs[2] = {0, (uint64_t)len};
+  uint8_t f = 0;
+  const int64_t r = rgx_find_batch(p, c, buf, offs, 1, &f, spans);
+  if (r < 0) return (int)r;
+  *found = f;
+  return RGX_OK;
 }
 
 // ---------------------------------------------------------------- streaming

@@ -642,6 +642,87 @@ Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOption
     if (K == 0) memset(t.sa_mask, 0, sizeof t.sa_mask);
   }
 
+  // ---- reference-mode restart rule: the right-most path as an automaton (rgx_dfa.h: rm_*)
+  if (!opt.unanchored_search) {
+    const bool cat = DetectNestedQuantifiers(ast.get()), nl = DetectComplexity(prog), ea = HasEndAnchor(prog);
+    const bool use_thompson = (cat || nl) && !ea;
+    t.ref_memo = nl || (cat && !use_thompson);
+    {
+      int pc = prog.start;
+      while (prog.inst[pc].op == InstNop || prog.inst[pc].op == InstCapture) pc = (int)prog.inst[pc].out;
+      const Inst& in = prog.inst[pc];
+      if (in.op == InstRune1 && in.rune.size() == 1 && in.rune[0] < 128 && !t.anchored) t.ref_prefix = (int)in.rune[0];
+    }
+    auto simple_greedy = [&](int k) {
+      const Inst& in = prog.inst[k];
+      if (!((int)in.out < k)) return false;
+      const InstOp o = prog.inst[in.out].op;
+      return o == InstRune || o == InstRune1 || o == InstRuneAny || o == InstRuneAnyNotNL;
+    };
+    for (int v = 0; v < 2; v++) {
+      // closure along the branch a depth-first search takes LAST: a consuming node, or -1 (the path fails here)
+      auto closure = [&](int id, int ctx, int k) -> int {
+        for (int guard = 0; guard < 4 * (int)prog.inst.size() + 8; guard++) {
+          if (id >= b.ninst) return id;                       // mid-rune node
+          const Inst& in = prog.inst[id];
+          switch (in.op) {
+            case InstFail: t.ref_has_fail = t.ref_has_fail || id != 0; return -1;
+            case InstMatch: return -1;                        // (a failed attempt never gets here)
+            case InstNop: case InstCapture: id = (int)in.out; break;
+            case InstAltMatch: id = (int)in.out; break;
+            case InstAlt: id = (v == 1 && simple_greedy(id)) ? (int)in.out : (int)in.arg; break;
+            case InstEmptyWidth: {
+              const uint32_t a = in.arg;
+              bool ok = true;
+              if ((a & EmptyBeginText) && ctx != kCtxBOT) ok = false;
+              if ((a & EmptyBeginLine) && !(ctx == kCtxBOT || ctx == kCtxNL)) ok = false;
+              const bool eot = k == ncls;
+              if ((a & EmptyEndText) && !eot) ok = false;
+              if ((a & EmptyEndLine) && !(eot || b.class_is_nl[k])) ok = false;
+              const bool pw = ctx == kCtxWord, cw = !eot && b.class_is_word[k];
+              if ((a & EmptyWordBoundary) && pw == cw) ok = false;
+              if ((a & EmptyNoWordBoundary) && pw != cw) ok = false;
+              if (!ok) return -1;
+              id = (int)in.out;
+              break;
+            }
+            default: return id;                               // byte-consuming
+          }
+        }
+        return -1;                                            // an empty loop: the reference would not terminate either
+      };
+      std::map<std::pair<int, int>, int> ids;                 // (pre-closure id, ctx) -> state
+      std::vector<std::pair<int, int>> st;
+      std::vector<int> depth;
+      auto intern2 = [&](int id, int ctx, int d) -> int {
+        auto key = std::make_pair(id, ctx);
+        auto it = ids.find(key);
+        if (it != ids.end()) return it->second;
+        const int n = (int)st.size();
+        ids.emplace(key, n);
+        st.push_back(key);
+        depth.push_back(d);
+        return n;
+      };
+      // the context of the previous byte matters only for the assertions the builder tracks (ReduceCtx collapses the rest)
+      for (int c = 0; c < 4; c++) t.rm_start[v][c] = (uint16_t)intern2(prog.start, b.ReduceCtx(c), 0);
+      std::vector<uint16_t>& tr = t.rm_trans[v];
+      for (size_t q = 0; q < st.size(); q++) {
+        tr.resize((q + 1) * stride, 0xFFFF);
+        if (st.size() > 60000) throw TooLarge{"restart automaton"};
+        const int id = st[q].first, ctx = st[q].second;
+        for (int k = 0; k <= ncls; k++) {
+          const int node = closure(id, ctx, k);
+          if (node < 0 || k == ncls || !b.NodeAccepts(node, k)) continue;          // fails at this byte
+          const int target = b.Target(node, k);
+          const bool mid = target >= b.ninst;                                       // still inside a multi-byte rune
+          tr[q * stride + k] = (uint16_t)intern2(target, b.CtxOfClass(k), mid ? depth[q] + 1 : 0);
+        }
+      }
+      t.rm_depth[v].assign(depth.begin(), depth.end());
+    }
+  }
+
   // ---- sync automaton W (see rgx_dfa.h)
   if (!opt.unanchored_search) {
     constexpr int kMaxW = 1024;
@@ -948,7 +1029,7 @@ struct R {
   void raw(void* d, size_t k) { if (o + k > n) { ok = false; return; } memcpy(d, p + o, k); o += k; }
 };
 constexpr uint32_t kMagic = 0x54584752;  // "RGXT"
-constexpr uint32_t kBlobVersion = 3;     // 3: FNV-1a checksum of the blob appended; every index range-checked on load
+constexpr uint32_t kBlobVersion = 4;     // 3: FNV-1a checksum of the blob appended; every index range-checked on load
 uint64_t Fnv1a(const uint8_t* p, size_t n) {
   uint64_t h = 1469598103934665603ull;
   for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
@@ -971,6 +1052,8 @@ std::vector<uint8_t> SerializeTables(const Tables& t) {
   w.vec(t.bt_match); w.vec(t.start_ops); w.vec(t.start_ops_pool); w.pod<int32_t>(t.max_threads); w.pod<int32_t>(t.fixed_len);
   w.raw(t.sa_mask, sizeof t.sa_mask); w.pod<int32_t>(t.sa_k); w.pod<uint8_t>(t.sa_exact);
   w.pod<int32_t>(t.w_nstates); w.pod<uint16_t>(t.w_start); w.vec(t.w_trans); w.pod<uint8_t>(t.needs_valid_utf8);
+  for (int v = 0; v < 2; v++) { w.vec(t.rm_trans[v]); w.vec(t.rm_depth[v]); w.raw(t.rm_start[v], sizeof t.rm_start[v]); }
+  w.pod<uint8_t>(t.ref_memo); w.pod<uint8_t>(t.ref_has_fail); w.pod<int32_t>(t.ref_prefix);
   w.pod<uint64_t>(Fnv1a(w.b.data(), w.b.size()));
   return w.b;
 }
@@ -1003,7 +1086,16 @@ bool DeserializeTables(const uint8_t* p, size_t n, Tables* t) {
   r.vec(t->bt_match); r.vec(t->start_ops); r.vec(t->start_ops_pool); r.pod(i32); t->max_threads = i32; r.pod(i32); t->fixed_len = i32;
   r.raw(t->sa_mask, sizeof t->sa_mask); r.pod(i32); t->sa_k = i32; r.pod(u8); t->sa_exact = u8;
   r.pod(i32); t->w_nstates = i32; r.pod(t->w_start); r.vec(t->w_trans); r.pod(u8); t->needs_valid_utf8 = u8;
+  for (int v = 0; v < 2; v++) { r.vec(t->rm_trans[v]); r.vec(t->rm_depth[v]); r.raw(t->rm_start[v], sizeof t->rm_start[v]); }
+  r.pod(u8); t->ref_memo = u8; r.pod(u8); t->ref_has_fail = u8; r.pod(i32); t->ref_prefix = i32;
   if (!r.ok) return false;
+  for (int v = 0; v < 2; v++) {
+    const size_t ns = t->rm_depth[v].size();
+    if (t->rm_trans[v].size() != ns * (size_t)(t->ncls + 1)) return false;
+    for (uint16_t e : t->rm_trans[v]) if (e != 0xFFFF && e >= ns) return false;
+    for (int c = 0; c < 4; c++) if (ns && t->rm_start[v][c] >= ns) return false;
+  }
+  if (t->ref_prefix < -1 || t->ref_prefix > 127) return false;
   if (t->w_nstates < 0 || t->w_trans.size() != (size_t)t->w_nstates * t->ncls || (t->w_nstates && t->w_start >= t->w_nstates)) return false;
   if (t->ncls < 1 || t->ncls > 256 || t->nstates < 1 || t->trans.size() != (size_t)t->nstates * (t->ncls + 1)) return false;
   if ((int)t->cap_kind.size() != t->ncap || (int)t->cap_delta.size() != t->ncap) return false;

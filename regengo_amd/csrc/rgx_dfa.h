@@ -86,6 +86,21 @@ struct Tables {
   std::vector<uint32_t> start_ops_pool;// capture masks assigned by the initial closure, per thread
   int max_threads = 0;
 
+  // ---- reference-mode restart rule.  The emitted MatchBytes / FindBytesReuse do not retry at start+1 after a
+  // failed attempt: they resume behind the offset the machine held when its LAST alternative failed (compiler.go:845-853,
+  // backtracking.go:47-50,96-97, find.go:545-569).  A depth-first search visits its right-most path last, so that offset is
+  // where the path that takes the last branch of every Alt dies.  rm_* is that single path as an automaton over byte classes:
+  // rm_trans[v][state * (ncls+1) + class] = next state or 0xFFFF (the path fails AT this byte); the failure offset is the byte's
+  // offset minus rm_depth[v][state] (bytes already consumed of a multi-byte rune).  v = 0: FindBytesReuse's branch order
+  // (Alt: out first), v = 1: MatchBytes' (simple greedy loops try the exit first, instructions.go:331-336,458-476).
+  std::vector<uint16_t> rm_trans[2];
+  std::vector<uint8_t> rm_depth[2];
+  uint16_t rm_start[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+  bool ref_memo = false;          // the reference memoises (analysis.go complexity / nested quantifiers): its restart offsets
+                                  // depend on the visited set -- reference mode is not offered, the Go path keeps those functions
+  bool ref_has_fail = false;      // a reachable InstFail: MatchBytes returns false outright there (instructions.go:62-66)
+  int ref_prefix = -1;            // MatchBytes' required first byte (compiler.go:719-737), -1: none
+
   std::string Describe() const;
 };
 

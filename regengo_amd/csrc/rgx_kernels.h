@@ -78,6 +78,12 @@ hipError_t LaunchBatch(const DevTables& T, const uint8_t* concat, const uint64_t
 // LDS input window for a batch of nstr strings holding total_bytes (0 / unknown: the large window)
 int BatchWindowFor(int64_t total_bytes, int64_t nstr);
 
+// Reference mode (Q1): FindBytesReuse / MatchBytes per string with the emitted code's restart rule -- a failed attempt resumes
+// behind the offset its right-most path died at (DevTables::rm_*), not at start + 1.  spans == nullptr: MatchBytes (branch
+// order v = 1, required-prefix skip).  `trace`: scratch as for LaunchBatch (CSR-shaped, trace_stride < 0).
+hipError_t LaunchBatchRef(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,
+                          int32_t* spans, uint16_t* trace, hipStream_t stream);
+
 // Same entry points through the search automaton U (rgx_program.h: SearchTables): one forward walk per string.
 // `trace` is scratch of (total bytes + 2*nstr + 64) entries of uint8 (U.nstates <= 256) or uint16, used by strings
 // longer than the LDS trace.

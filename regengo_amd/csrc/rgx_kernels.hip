@@ -742,6 +742,65 @@ __global__ __launch_bounds__(64) void batch_kernel(DevTables T, const uint8_t* c
 }
 
 
+// ---- batch, reference mode (Q1): one string per lane, the emitted loop of find.go:545-569 / compiler.go:845-853 --------
+__device__ __forceinline__ int RmFailOffset(const DevTables& T, int v, const uint8_t* buf, int len, int off) {
+  const int ctx = off == 0 ? kCtxBOT : T.ctx_of_byte[buf[off - 1]];
+  unsigned st = T.rm_start[v][ctx];
+  for (int i = off;; ++i) {
+    const int k = i < len ? T.cls[buf[i]] : T.ncls;
+    const unsigned nx = T.rm_trans[v][st * T.stride + k];
+    if (nx == 0xFFFFu) return i - (int)T.rm_depth[v][st];
+    st = nx;
+  }
+}
+
+__global__ __launch_bounds__(64) void ref_batch_kernel(DevTables T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr,
+                                                       uint8_t* found, int32_t* spans, uint16_t* trace) {
+  __shared__ uint16_t s_trace[64 * kCapsLdsTrace];
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= nstr) return;
+  const uint64_t o0 = offsets[i], o1 = offsets[i + 1];
+  const uint8_t* buf = concat + o0;
+  const int len = (int)(o1 - o0);
+  const bool want_spans = spans != nullptr;
+  const int v = want_spans ? 0 : 1;
+  int s = -1, e = -1;
+  int off = 0;
+  bool go = true;
+  const bool has_prefix = !want_spans && T.ref_prefix >= 0;
+  auto next_prefix = [&](int from) -> int {          // bytes.IndexByte(input[from:], prefix) + from, or -1
+    for (int j = from; j < len; ++j) if (buf[j] == (uint8_t)T.ref_prefix) return j;
+    return -1;
+  };
+  if (has_prefix) { off = next_prefix(0); go = off >= 0; }
+  while (go) {
+    const int end = WalkGlobal(T, buf, len, off);
+    if (end >= 0) { s = off; e = end; break; }
+    if (T.anchored) break;
+    int fo = RmFailOffset(T, v, buf, len, off);
+    if (has_prefix) {
+      fo += 1;
+      if (!(len > fo)) break;
+      off = next_prefix(fo);
+      if (off < 0) break;
+    } else {
+      if (!(len > fo)) break;
+      off = fo + 1;
+    }
+  }
+  found[i] = s >= 0;
+  if (!want_spans) return;
+  int32_t* rec = spans + i * T.ncap;
+  if (s < 0) { for (int c = 0; c < T.ncap; ++c) rec[c] = T.unmatched_minus1 ? -1 : 0; return; }
+  if (T.fixed_captures) {
+    for (int c = 0; c < T.ncap; ++c) rec[c] = T.cap_kind[c] == kCapFromStart ? s + T.cap_delta[c] : e - T.cap_delta[c];
+    return;
+  }
+  const int need = e - s + 1;
+  uint16_t* tr = need <= kCapsLdsTrace ? s_trace + threadIdx.x * kCapsLdsTrace : trace + o0 + 2 * i;
+  ResolveCaptures(T, buf, len, s, e, tr, rec);
+}
+
 // ---- batch, staged (BASELINE config C3) -------------------------------------------------------------------
 // The per-lane kernel above reads everything -- tables, input bytes, back-trace pools -- through L1/L2 with one
 // dependent global load per DFA step (27 GB/s on 10 M short strings).  Here a persistent workgroup stages the
@@ -1465,6 +1524,13 @@ hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, i
   }
   dim3 block(64), grid((unsigned)((nmatches + 63) / 64));
   hipLaunchKernelGGL(caps_kernel, grid, block, 0, stream, T, buf, len, spans, nmatches, trace, trace_cursor);
+  return hipGetLastError();
+}
+
+hipError_t LaunchBatchRef(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,
+                          int32_t* spans, uint16_t* trace, hipStream_t stream) {
+  dim3 block(64), grid((unsigned)((nstr + 63) / 64));
+  hipLaunchKernelGGL(ref_batch_kernel, grid, block, 0, stream, T, concat, offsets, nstr, found, spans, trace);
   return hipGetLastError();
 }
 

@@ -148,6 +148,7 @@ int UploadTables(const Tables& t, std::vector<uint16_t>* direct_table, DevTables
   size_t off_rz = a.Add(rz, sizeof rz);
   size_t off_tcls = a.AddVec(t.trans);
   size_t off_w = a.AddVec(t.w_trans);
+  size_t off_rmt[2] = {a.AddVec(t.rm_trans[0]), a.AddVec(t.rm_trans[1])}, off_rmd[2] = {a.AddVec(t.rm_depth[0]), a.AddVec(t.rm_depth[1])};
   d.w_nstates = ((size_t)t.w_nstates * t.ncls * 2 <= 40 * 1024) ? t.w_nstates : 0;   // kept in LDS by the kernels
   d.w_start = t.w_start;
   d.reset_values = 0;
@@ -171,6 +172,15 @@ int UploadTables(const Tables& t, std::vector<uint16_t>* direct_table, DevTables
   d.sa_rz = (const uint32_t*)(b + off_rz);
   d.trans_cls = (const uint16_t*)(b + off_tcls);
   d.w_trans = (const uint16_t*)(b + off_w);
+  for (int v = 0; v < 2; v++) {
+    d.rm_trans[v] = (const uint16_t*)(b + off_rmt[v]);
+    d.rm_depth[v] = b + off_rmd[v];
+    for (int c = 0; c < 4; c++) d.rm_start[v][c] = t.rm_start[v][c];
+  }
+  d.ref_prefix = t.ref_prefix;
+  const bool have_rm = !t.rm_depth[0].empty() && !t.rm_depth[1].empty();
+  d.ref_find_ok = (have_rm && !t.ref_memo && t.ref_find_engine <= 0) ? 1 : 0;
+  d.ref_match_kind = t.ref_match_engine == 1 ? 1 : ((have_rm && !t.ref_memo && !t.ref_has_fail) ? 0 : 2);
   *out = d;
   *out_arena = dptr;
   return RGX_OK;

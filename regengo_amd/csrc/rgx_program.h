@@ -72,6 +72,13 @@ struct DevTables {
   int32_t sa_first_bytes;         // number of byte values that can start a match (selectivity of the prefilter)
   int32_t bt_pool_n, start_pool_n; // entries in bt_parent/bt_ops and in start_ops_pool
   int32_t sa_smin;                // exact chains: smallest shift s>=1 at which two matches can overlap (sa_k: never)
+  // reference-mode restart rule (rgx_dfa.h: rm_*): v = 0 FindBytesReuse's branch order, v = 1 MatchBytes'
+  const uint16_t* rm_trans[2];
+  const uint8_t* rm_depth[2];
+  uint16_t rm_start[2][4];
+  int32_t ref_prefix;             // MatchBytes' required first byte, -1: none
+  int32_t ref_find_ok;            // 1: FindBytesReuse in reference mode is offered (plain backtracking engine, no memo)
+  int32_t ref_match_kind;         // 0: restart rule over rm_*[1]; 1: the Thompson matcher (plain existence); 2: not offered
   const UsDev* us;                // HOST pointer to the program's UsDev when the pattern is eligible for rgx_scan_us.hip, else nullptr
   uint16_t start[4];
   uint8_t start_accept[4];

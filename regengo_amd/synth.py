@@ -5,6 +5,9 @@ reference's PatternedReader (tests/integration/streaming/memory_test.go:13-48) i
 C2  "date log": period 50 = "2024-01-15" + 40 noise bytes from "abcdefghijk \\n\\t"  (same shape as the
     reference's PatternedReader("2024-01-15", 50, n)).  Closed form: a match at every multiple of 50 that fits.
 C2b adversarial: noise alphabet widened with digits and '-' so that candidates overlap / near-miss.
+C1  "date lines": 1000 lines, seed 0x5EED0001, length U[64,160], `<date?> <hh:mm:ss> [LEVEL] <noise>`; 70 % hold one
+    date, 10 % two, 10 % none, 10 % a near miss (`12024-01-15`, `2024-1-15`, `2024-01-1x`, a date cut by the end of the line) --
+    the class on which the reference's MatchString (restart rule, Q1) and a plain search disagree.
 """
 from __future__ import annotations
 
@@ -156,3 +159,52 @@ def tile_repeat_torch(tile: bytes, n: int, device):
     t = torch.frombuffer(bytearray(tile), dtype=torch.uint8).to(device)
     reps = -(-n // len(tile))
     return t.repeat(reps)[:n].contiguous()
+
+
+def _sm64(seed: int, i: int) -> int:
+    z = (seed + (i + 1) * 0x9E3779B97F4A7C15) & MASK64
+    z = ((z ^ (z >> 30)) * 0xBF58476D1CE4E5B9) & MASK64
+    z = ((z ^ (z >> 27)) * 0x94D049BB133111EB) & MASK64
+    return z ^ (z >> 31)
+
+
+def date_lines(n: int = 1000, seed: int = 0x5EED0001):
+    """BASELINE config C1: `n` log lines (bytes, without the newline).  Deterministic: line k depends on (seed, k) only."""
+    levels = [b"INFO", b"WARN", b"ERROR", b"DEBUG"]
+    noise = b"abcdefghijklmnopqrstuvwxyz  ABCDEF_.,;"
+    out = []
+    for k in range(n):
+        ctr = [0]
+
+        def r(m):
+            ctr[0] += 1
+            return _sm64(seed, k * 4096 + ctr[0]) % m
+
+        def date():
+            return b"%04d-%02d-%02d" % (1990 + r(40), 1 + r(12), 1 + r(28))
+
+        kind = r(10)
+        if kind < 7:
+            head = date()
+        elif kind == 7:
+            head = date() + b" -> " + date()
+        elif kind == 8:
+            head = b"undated"
+        else:
+            d = date()
+            near = r(4)
+            head = [b"1" + d, d[:5] + d[6:], d[:9] + b"x", None][near]
+        t = b"%02d:%02d:%02d" % (r(24), r(60), r(60))
+        length = 64 + r(97)
+        if head is None:
+            # a date cut by the end of the line: it goes last, truncated
+            body = t + b" [" + levels[r(4)] + b"] "
+            tail = date()[:4 + r(6)]
+            pad = max(0, length - len(body) - len(tail))
+            line = body + bytes(noise[r(len(noise))] for _ in range(pad)) + tail
+        else:
+            line = head + b" " + t + b" [" + levels[r(4)] + b"] "
+            pad = max(0, length - len(line))
+            line += bytes(noise[r(len(noise))] for _ in range(pad))
+        out.append(line)
+    return out

@@ -189,7 +189,7 @@ def run_c5(gib, max_patterns, mib=0, skip=()):
         log.write("%d start %r\n" % (pi, p)); log.flush()
         t_pat = time.perf_counter()
         try:
-            c = Compiled(p).to(0)
+            c = Compiled(p, stdlib=True).to(0)
         except _capi.RgxError:
             stats["unsupported"] += 1
             continue

@@ -33,6 +33,8 @@ _lib.rgxt_us_find_all.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_int64, 
 _lib.rgxt_us_simple.argtypes = [C.c_void_p]
 _lib.rgxt_us_find_all_simple.restype = C.c_int64
 _lib.rgxt_us_find_all_simple.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p, C.c_int64]
+_lib.rgxt_ref_find.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p]
+_lib.rgxt_ref_match.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
 
 INFO = ["ncap", "min", "max", "ninst", "nstates", "ncls", "anchored", "fixed", "empty", "refm", "reff", "look", "maxthr"]
 
@@ -98,6 +100,18 @@ class HostProgram:
 
     def match(self, b: bytes) -> bool:
         return bool(_lib.rgxt_match(self.h, b, len(b)))
+
+    def ref_find(self, b: bytes):
+        """FindBytesReuse with the reference's restart rule (Q1): spans, None, or NotImplemented."""
+        out = (C.c_int32 * self.info["ncap"])()
+        r = _lib.rgxt_ref_find(self.h, b, len(b), out)
+        if r == -3:
+            return NotImplemented
+        return list(out) if r == 1 else None
+
+    def ref_match(self, b: bytes):
+        r = _lib.rgxt_ref_match(self.h, b, len(b))
+        return NotImplemented if r == -3 else bool(r)
 
     def reset_bytes(self):
         a = (C.c_uint8 * 256)()

@@ -22,9 +22,9 @@ def torch_dev(built):
     return torch
 
 
-def _gpu(pattern, flags=0):
+def _gpu(pattern, flags=0, stdlib=False):
     from regengo_amd import Compiled
-    return Compiled(pattern, flags=flags).to(0)
+    return Compiled(pattern, flags=flags, stdlib=stdlib).to(0)
 
 
 def test_library_is_the_hip_one(torch_dev):
@@ -197,25 +197,33 @@ def test_n_capacity_and_flags(torch_dev):
 
 
 def test_match_bytes(torch_dev, corpus):
-    """MatchBytes == "a leftmost-first match exists" (stdlib semantics; the reference's Q1 restart quirk is documented
-    in DESIGN.md and modelled by the oracle's Machine.match)."""
+    """MatchBytes, both semantics.  stdlib: "a leftmost-first match exists".  reference (the default): the emitted function's
+    own answer, restart rule and prefix skip included (compiler.go:740-871; the oracle's Machine.match / ThompsonMatcher) --
+    where the reference emits a memoising engine the library says RGX_E_UNSUPPORTED instead of guessing."""
     from oracle.engines import Compiled as O
     from regengo_amd import _capi
-    checked = q1 = 0
+    checked = q1 = refmode = unsupported = 0
     for e in corpus[::5]:
         try:
-            c = _gpu(e["pattern"])
+            c = _gpu(e["pattern"], stdlib=True)
+            cr = _gpu(e["pattern"])
         except _capi.RgxError:
             continue
         o = O(e["pattern"])
-        for s in e["inputs"]:
+        for s in e["inputs"] + ["x12024-01-15", "aa " + e["inputs"][0]]:
             b = s.encode()
             truth = len(o.find_machine.find_all_stdlib_like(b)) > 0
             assert c.MatchBytes(b) == truth, (e["pattern"], b)
-            if o.match_machine.match(b) != truth:
-                q1 += 1
+            ref = o.MatchBytes(b)
+            try:
+                assert cr.MatchBytes(b) == ref, ("reference mode", e["pattern"], b)
+                refmode += 1
+            except _capi.RgxError as ex:
+                assert ex.status == _capi.RGX_E_UNSUPPORTED
+                unsupported += 1
+            q1 += ref != truth
             checked += 1
-    assert checked > 150
+    assert checked > 150 and refmode > 120, (checked, refmode, unsupported, q1)
 
 
 def test_find_reader_boundary_kat(torch_dev, kats):
@@ -281,7 +289,7 @@ def test_batch_find_and_match(torch_dev):
     from regengo_amd import synth
     torch = torch_dev
     data, offsets = synth.email_batch_np(200000)
-    c = _gpu(EMAIL)
+    c = _gpu(EMAIL, stdlib=True)
     found, spans = c.FindBatchDevice(torch.from_numpy(data).cuda(), torch.from_numpy(offsets).cuda())
     found = found.cpu().numpy()
     spans = spans.cpu().numpy()
@@ -308,7 +316,7 @@ def test_batch_search_automaton_corpus(torch_dev, corpus, kats):
     checked = pats = 0
     for pat, inputs in items:
         try:
-            c = Compiled(pat).to(0)
+            c = Compiled(pat, stdlib=True).to(0)
         except _capi.RgxError:
             continue
         o = E.Compiled(pat)

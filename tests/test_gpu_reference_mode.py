@@ -1,0 +1,97 @@
+"""GPU tier: MatchBytes / FindBytes / the batch rows in REFERENCE mode (the library's default) against the oracle's restatement
+of the emitted functions -- `Machine.match` (compiler.go:740-871: restart behind the failure offset, required-prefix skip, the
+exit-first order of simple greedy loops), `ThompsonMatcher.match` (thompson.go:69-131) and `Machine.find` (find.go:469-591) --
+and BASELINE config C1: Date MatchString over 1000 synthetic lines, both boolean vectors (reference mode and plain search)."""
+import random
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+DATE = r"(?P<year>\d{4})-(?P<month>\d{2})-(?P<day>\d{2})"
+
+
+@pytest.fixture(scope="module")
+def torch_dev(built):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU; there is no CPU fallback")
+    return torch
+
+
+def _csr(torch, strings):
+    offs = [0]
+    for s in strings:
+        offs.append(offs[-1] + len(s))
+    concat = torch.frombuffer(bytearray(b"".join(strings) or b"\0"), dtype=torch.uint8).cuda()
+    return concat, torch.tensor(offs, dtype=torch.int64).cuda()
+
+
+def test_config_c1_date_lines_both_semantics(torch_dev):
+    """BASELINE config C1: 1000 lines, seed 0x5EED0001; the near-miss class is where the reference's MatchString
+    and a plain search disagree (`12024-01-15`: the emitted loop restarts behind offset 4 and never tries offset 1)."""
+    from oracle.engines import Compiled as O
+    from regengo_amd import Compiled, synth
+    lines = synth.date_lines(1000)
+    assert len(lines) == 1000 and all(64 <= len(x) <= 175 for x in lines)
+    o = O(DATE)
+    ref = [o.MatchBytes(x) for x in lines]                                  # the generated Go matcher's answers
+    std = [len(o.find_machine.find_all_stdlib_like(x)) > 0 for x in lines]  # stdlib regexp's
+    assert sum(a != b for a, b in zip(ref, std)) >= 5                       # the near-miss lines
+    assert all(s or not r for r, s in zip(ref, std))                        # the reference only ever misses matches
+    cr = Compiled(DATE, name="Date").to(0)
+    cs = Compiled(DATE, name="Date", stdlib=True).to(0)
+    concat, offs = _csr(torch_dev, lines)
+    assert cr.MatchBatchDevice(concat, offs).cpu().numpy().astype(bool).tolist() == ref
+    assert cs.MatchBatchDevice(concat, offs).cpu().numpy().astype(bool).tolist() == std
+    # the single-call forms (host bytes, as the cgo stub passes them) on the lines where the two differ, and a few others
+    for i, x in enumerate(lines):
+        if ref[i] != std[i] or i % 97 == 0:
+            assert cr.MatchBytes(x) == ref[i] and cs.MatchBytes(x) == std[i], x
+            got, ok = cr.FindBytes(x)
+            exp = o.find_machine.find(x)
+            assert ok == (exp is not None) and (not ok or got.spans == exp), x
+    # FindBytes over the whole batch, reference mode
+    res = cr.FindBatch(lines)
+    for x, r in zip(lines, res):
+        exp = o.find_machine.find(x)
+        assert (r is None) == (exp is None) and (r is None or r.spans == exp), x
+
+
+def test_reference_mode_equals_the_emitted_functions_on_the_corpus(torch_dev, corpus, kats):
+    from oracle import engines as E
+    from regengo_amd import Compiled, _capi
+    rng = random.Random(7)
+    items = [(e["pattern"], e["inputs"]) for e in corpus] + [(c["pattern"], c["inputs"]) for c in kats["curated_cases"]]
+    nm = nf = un_m = un_f = 0
+    for pat, inputs in items:
+        try:
+            c = Compiled(pat).to(0)
+        except _capi.RgxError:
+            continue
+        o = E.Compiled(pat)
+        bs = [s.encode() for s in inputs]
+        strings = list(bs) + [b"x" + s for s in bs] + [s + s for s in bs] + [s[:-1] for s in bs] + [b" ".join(bs), b"", b"12024-01-15"]
+        alpha = b"".join(bs) or b"a"
+        strings += [bytes(rng.choice(alpha) for _ in range(rng.randint(0, 90))) for _ in range(6)]
+        concat, offs = _csr(torch_dev, strings)
+        try:
+            mt = c.MatchBatchDevice(concat, offs).cpu().tolist()
+            for b, m in zip(strings, mt):
+                assert bool(m) == o.MatchBytes(b), ("MatchBytes", pat, b)
+                nm += 1
+        except _capi.RgxError as ex:
+            assert ex.status == _capi.RGX_E_UNSUPPORTED and o.sel.match_memo, pat
+            un_m += 1
+        try:
+            res = c.FindBatch(strings)
+            for b, r in zip(strings, res):
+                exp = o.find_machine.find(b)
+                assert (r is None) == (exp is None) and (r is None or r.spans == exp), ("FindBytes", pat, b, r and r.spans, exp)
+                nf += 1
+        except _capi.RgxError as ex:
+            assert ex.status == _capi.RGX_E_UNSUPPORTED and (o.sel.find_memo or o.sel.find_engine != "backtracking"), pat
+            un_f += 1
+    print("MatchBytes compared", nm, "patterns not offered", un_m, "| FindBytes compared", nf, "patterns not offered", un_f)
+    assert nm > 4000 and nf > 3500
