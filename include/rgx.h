@@ -93,6 +93,9 @@ typedef struct rgx_info {
                             * (fixed-length class chain), 2 prefilter + verify, 3 generic (one attempt per start), 4 one step
                             * per byte with start registers, 5 register-free (simple automata), 6 register-free, two bytes
                             * per look-up; DESIGN.md section 4 */
+  int32_t ref_match_offered; /* 1: MatchBytes in reference mode (the default) is offered: plain backtracking or Thompson engine; 0: the
+                              * reference memoises -- RGX_E_UNSUPPORTED, the generated stub keeps the Go function           */
+  int32_t ref_find_offered;  /* the same for FindBytes / FindBytesReuse (plain backtracking engine only)                      */
   int32_t unicode_version; /* UCD version behind \p{..}: 0xMMmmpp (0x0E0000 = 14.0.0).  The reference's tables are Go 1.24's
                             * `unicode` package = 15.0.0: code points first assigned in 15.0 are unassigned here       */
 } rgx_info;
@@ -189,6 +192,10 @@ int64_t rgx_find_all_wait(const rgx_program* p, rgx_stream_ctx* c, rgx_result* r
 int64_t rgx_replace_all_bytes_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len,
                                      const char* tmpl, size_t tmpl_len, int first_only, uint8_t* d_out, size_t cap_out,
                                      int64_t* out_len, rgx_result* res);
+/* Same, host buffers (what the generated ReplaceAllBytesAppend / ReplaceFirstBytes stubs call): H2D copy of the input, D2H
+ * copy of the result.                                                                                        */
+int64_t rgx_replace_all_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* buf, size_t len, const char* tmpl,
+                              size_t tmpl_len, int first_only, uint8_t* out, size_t cap_out, int64_t* out_len, rgx_result* res);
 /* RGX_OK, or RGX_E_INVALID with the parser's message in rgx_last_error().                                */
 int rgx_replace_template_check(const char* tmpl, size_t tmpl_len);
 

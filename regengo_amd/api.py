@@ -297,11 +297,32 @@ class Compiled:
         _capi.check(w)
         return out[:int(need.value)], int(res.total)
 
+    def _replace_host(self, data, template: str, first_only: bool) -> bytes:
+        """Host buffers in and out: rgx_replace_all_bytes, what the generated ReplaceAllBytesAppend / ReplaceFirstBytes call."""
+        self._need_dev()
+        b = bytes(data)
+        tb = template.encode("utf-8")
+        need = C.c_int64(0)
+        out = C.create_string_buffer(len(b) + max(64, len(b) // 8))
+        for _ in range(2):
+            w = self._lib.rgx_replace_all_bytes(self._h, self._ctx, b, len(b), tb, len(tb), 1 if first_only else 0, out, len(out),
+                                                C.byref(need), None)
+            if w == _capi.RGX_E_CAPACITY:
+                out = C.create_string_buffer(max(int(need.value), 1))
+                continue
+            break
+        _capi.check(w)
+        return out.raw[:int(w)]
+
     def ReplaceAllBytes(self, data, template: str) -> bytes:
+        if isinstance(data, (bytes, bytearray, memoryview)):
+            return self._replace_host(data, template, False)
         out, _ = self.ReplaceAllDevice(data, template)
         return bytes(out.cpu().numpy().tobytes())
 
     def ReplaceFirstBytes(self, data, template: str) -> bytes:
+        if isinstance(data, (bytes, bytearray, memoryview)):
+            return self._replace_host(data, template, True)
         out, _ = self.ReplaceAllDevice(data, template, first_only=True)
         return bytes(out.cpu().numpy().tobytes())
 

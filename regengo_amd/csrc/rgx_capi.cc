@@ -350,6 +350,11 @@ RGX_API int rgx_program_info(const rgx_program* p, rgx_info* o) {
   o->ref_match_engine = t.ref_match_engine; o->ref_find_engine = t.ref_find_engine; o->lookahead_mode = t.lookahead_mode;
   o->needs_valid_utf8 = t.needs_valid_utf8; o->sync_states = t.w_nstates;
   o->unicode_version = UnicodeVersion();
+  {
+    const bool have_rm = !t.rm_depth[0].empty() && !t.rm_depth[1].empty();
+    o->ref_find_offered = (have_rm && !t.ref_memo && t.ref_find_engine <= 0) ? 1 : 0;
+    o->ref_match_offered = (t.ref_match_engine == 1 || (have_rm && !t.ref_memo && !t.ref_has_fail)) ? 1 : 0;
+  }
   o->scan_kernel = p->p.d_arena ? ScanKernelKind(p->p.dev, 1 << 24) : 0;
   o->table_bytes = p->p.d_arena ? p->p.dev.table_bytes : (int32_t)((size_t)t.nstates * (t.ncls + 1) * 2);
   return RGX_OK;
@@ -859,6 +864,29 @@ RGX_API int64_t rgx_transform_chunk(const rgx_program* p, rgx_stream_ctx* c, con
     if ((rc = Ensure(&c->d_out, &c->out_cap, want / 4 + 16)) != RGX_OK) return rc;
     w = TransformChunkDevice(p, c, c->d_in, len, is_eof, mode, tmpl, tmpl_len, (uint8_t*)c->d_out, (size_t)c->out_cap * 4, out_len,
                              processed, res, false);       // the D2H copy below is ordered behind the kernels on the stream
+    if (w != RGX_E_CAPACITY) break;
+    want = *out_len + 256;
+  }
+  if (w < 0) return w;
+  if ((size_t)w > cap_out) { SetError("output capacity too small"); return RGX_E_CAPACITY; }
+  if (w > 0) HIP_TRY(hipMemcpyAsync(out, c->d_out, (size_t)w, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return w;
+}
+
+RGX_API int64_t rgx_replace_all_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* buf, size_t len, const char* tmpl,
+                                      size_t tmpl_len, int first_only, uint8_t* out, size_t cap_out, int64_t* out_len, rgx_result* res) {
+  int rc = CheckCtx(p, c);
+  if (rc != RGX_OK) return rc;
+  if (!out_len || (!buf && len) || (!out && cap_out)) return RGX_E_INVALID;
+  if ((rc = Ensure(&c->d_in, &c->in_cap, (int64_t)len + 64)) != RGX_OK) return rc;
+  if (len) HIP_TRY(hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream));
+  int64_t want = (int64_t)std::max<size_t>(cap_out, len + len / 4 + 256);
+  int64_t w = 0;
+  for (int attempt = 0; attempt < 2; ++attempt) {
+    if ((rc = Ensure(&c->d_out, &c->out_cap, want / 4 + 16)) != RGX_OK) return rc;   // the scan's records live in d_rspans
+    w = rgx_replace_all_bytes_device(p, c, c->d_in, len, tmpl, tmpl_len, first_only, (uint8_t*)c->d_out, (size_t)c->out_cap * 4,
+                                     out_len, res);
     if (w != RGX_E_CAPACITY) break;
     want = *out_len + 256;
   }
