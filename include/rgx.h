@@ -236,6 +236,10 @@ int rgx_program_capture_template(const rgx_program* p, int32_t* offsets);
 int64_t rgx_count_all_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len,
                              rgx_result* res);
 
+/* Count only, shard mode: matches whose START lies in [own_lo, own_hi) of the window (the sharded FindReaderCount).  */
+int64_t rgx_count_all_device_owned(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t own_lo,
+                                   int64_t own_hi, rgx_result* res);
+
 /* Batch: one independent input per string (BASELINE config C3: FindBytes over 10M strings).
  * `d_concat` all strings back to back, `d_offsets` nstr+1 uint64 CSR offsets, outputs `d_found`
  * (uint8 per string) and `d_spans` (nstr records of ncap int32, relative to the string's start).
@@ -263,6 +267,12 @@ int rgx_stream_config_resolve(const rgx_program* p, const rgx_stream_config* in,
 int64_t rgx_find_chunk(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* chunk, size_t data_len,
                        int is_full, int64_t max_leftover, int32_t* spans, size_t cap_records,
                        int64_t* committed, int64_t* keep_from, rgx_result* res);
+
+/* FindReaderCount's chunk (streaming.go:258-277): the commit/defer rule of rgx_find_chunk without the span table leaving the
+ * device.  Returns the number of matches the emitted loop would have reported from this chunk; *keep_from as above;
+ * *committed = end of the last one (-1 for a chunk that is not full: nothing is carried over from it).          */
+int64_t rgx_count_chunk(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* chunk, size_t data_len, int is_full,
+                        int64_t max_leftover, int64_t* committed, int64_t* keep_from, rgx_result* res);
 
 const char* rgx_last_error(void);
 const char* rgx_status_str(int status);

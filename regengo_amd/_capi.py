@@ -99,6 +99,10 @@ SYMBOLS = {
     "rgx_stream_config_resolve": (C.c_int, [C.c_void_p, C.POINTER(StreamConfig), C.POINTER(StreamConfig)]),
     "rgx_find_chunk": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int64, C.c_void_p,
                                    C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(Result)]),
+    "rgx_count_chunk": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int64, C.POINTER(C.c_int64),
+                                    C.POINTER(C.c_int64), C.POINTER(Result)]),
+    "rgx_count_all_device_owned": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int64,
+                                               C.POINTER(Result)]),
     "rgx_last_error": (C.c_char_p, []),
     "rgx_status_str": (C.c_char_p, [C.c_int]),
 }

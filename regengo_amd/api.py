@@ -253,6 +253,13 @@ class Compiled:
         w = _capi.check(self._lib.rgx_count_all_device(self._h, self._ctx, t.data_ptr() if ln else None, ln, C.byref(res)))
         return int(w), res
 
+    def CountAllOwned(self, data, own) -> int:
+        """Shard mode of CountAll: matches whose start lies in own=(lo, hi) of the window (rgx_count_all_device_owned)."""
+        self._need_dev()
+        t, ln = self._as_device(data)
+        return int(_capi.check(self._lib.rgx_count_all_device_owned(self._h, self._ctx, t.data_ptr() if ln else None, ln,
+                                                                    int(own[0]), int(own[1]), None)))
+
     def _make_result(self, src: bytes, rec) -> BytesResult:
         vals = []
         for g in range(self.ncap // 2):
@@ -423,15 +430,39 @@ class Compiled:
     RejectReader = _transform.RejectReader
 
     def FindReaderCount(self, r, cfg: Config) -> int:
+        """streaming.go:258-277: the number of callbacks FindReader would make.  Same read loop and commit/defer rule, but per
+        chunk rgx_count_chunk: no span table crosses PCIe and no result struct is built."""
+        self._need_dev()
+        cfg = self._resolve(cfg)
+        buf = bytearray(cfg.BufferSize)
+        leftover = 0
         cnt = 0
-
-        def cb(_m):
-            nonlocal cnt
-            cnt += 1
-            return True
-
-        self.FindReader(r, cfg, cb)
-        return cnt
+        committed = C.c_int64()
+        keep = C.c_int64()
+        while True:
+            data = r.read(cfg.BufferSize - leftover)
+            n = len(data)
+            if n == 0:
+                is_full, data_len = False, leftover
+                if leftover == 0:
+                    return cnt
+            else:
+                buf[leftover:leftover + n] = data
+                data_len = leftover + n
+                is_full = n == cfg.BufferSize - leftover
+            cbuf = (C.c_uint8 * data_len).from_buffer(buf)
+            w = _capi.check(self._lib.rgx_count_chunk(self._h, self._ctx, cbuf, data_len, 1 if is_full else 0, cfg.MaxLeftover,
+                                                      C.byref(committed), C.byref(keep), None))
+            del cbuf
+            cnt += int(w)
+            if n == 0:
+                return cnt
+            if is_full:
+                k = keep.value
+                leftover = data_len - k
+                buf[:leftover] = buf[k:data_len]
+            else:
+                leftover = 0
 
     def FindReaderFirst(self, r, cfg: Config):
         out = [None, 0]

@@ -1159,6 +1159,58 @@ RGX_API int64_t rgx_find_chunk(const rgx_program* p, rgx_stream_ctx* c, const ui
   return emitted;
 }
 
+RGX_API int64_t rgx_count_chunk(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* chunk, size_t data_len, int is_full,
+                                int64_t max_leftover, int64_t* committed, int64_t* keep_from, rgx_result* res) {
+  // FindReaderCount's chunk (streaming.go:258-277 over 175-244): the same commit/defer rule as rgx_find_chunk, but the span table
+  // never leaves the device -- a chunk that is not full (the last one) does not even build it.
+  int rc = CheckCtx(p, c);
+  if (rc != RGX_OK) return rc;
+  if (!committed || !keep_from || (!chunk && data_len)) return RGX_E_INVALID;
+  rgx_result r{};
+  r.ncap = p->p.dev.ncap;
+  *committed = 0;
+  *keep_from = is_full ? std::max<int64_t>((int64_t)data_len - max_leftover, 0) : (int64_t)data_len;
+  if (data_len == 0) { if (res) *res = r; return 0; }
+  if ((rc = Ensure(&c->d_in, &c->in_cap, (int64_t)data_len + 64)) != RGX_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_in, chunk, data_len, hipMemcpyHostToDevice, c->stream));
+  if (!is_full) {
+    int64_t total = FindAllDevice(p, c, c->d_in, data_len, -1, nullptr, 0, true, &r);
+    if (total < 0) return total;
+    total = r.total;
+    *committed = -1;                 // not needed by the caller: nothing is carried over from a chunk that is not full
+    if (res) { *res = r; res->written = 0; }
+    return total;
+  }
+  const int ncap = p->p.dev.ncap;
+  const int64_t cap_records = (int64_t)(data_len / (size_t)std::max(p->p.t.min_len, 1)) + 2;
+  if ((rc = Ensure(&c->d_out, &c->out_cap, cap_records * ncap + 16)) != RGX_OK) return rc;
+  int64_t w = FindAllDevice(p, c, c->d_in, data_len, -1, c->d_out, (size_t)cap_records, false, &r);
+  if (w < 0) return w;
+  long long h2[2] = {0, 0};
+  if (w > 0) {
+    if ((rc = Ensure(&c->d_rdelta, &c->rdelta_cap, 4)) != RGX_OK) return rc;
+    long long* d2 = c->d_rdelta;
+    HIP_TRY(LaunchCommitPoint(c->d_out, w, ncap, (int32_t)((int64_t)data_len - max_leftover), d2, c->stream));
+    HIP_TRY(hipMemcpyAsync(h2, d2, 16, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  *committed = h2[1];
+  *keep_from = std::max<int64_t>((int64_t)data_len - max_leftover, h2[1]);
+  if (res) { *res = r; res->written = 0; }
+  return h2[0];
+}
+
+RGX_API int64_t rgx_count_all_device_owned(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t own_lo,
+                                           int64_t own_hi, rgx_result* res) {
+  int rc = CheckCtx(p, c);
+  if (rc != RGX_OK) return rc;
+  if (own_lo < 0 || own_hi < own_lo) { SetError("bad owned range"); return RGX_E_INVALID; }
+  rgx_result r{};
+  int64_t w = FindAllDevice(p, c, d_buf, len, -1, nullptr, 0, true, &r, false, own_lo, own_hi);
+  if (res) *res = r;
+  return w < 0 ? w : r.total;
+}
+
 RGX_API const char* rgx_last_error(void) { return GetError().c_str(); }
 RGX_API const char* rgx_status_str(int s) {
   switch (s) {

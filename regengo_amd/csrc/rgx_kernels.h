@@ -109,4 +109,7 @@ int64_t ReplaceSmallScanMax();                 // up to this many entries Launch
 // one anchored attempt at `pos` (the loop's extra try at offset len, find.go:545-569): *out_end = match end or -1
 hipError_t LaunchAttemptAt(const DevTables& T, const uint8_t* buf, int32_t len, int32_t pos, int32_t* out_end, hipStream_t stream);
 
+// commit point of one FindReader chunk (streaming.go:204-207): out2[0] = leading rows whose end <= limit, out2[1] = end of the last
+hipError_t LaunchCommitPoint(const int32_t* spans, int64_t n, int ncap, int32_t limit, long long* out2, hipStream_t stream);
+
 }  // namespace rgx

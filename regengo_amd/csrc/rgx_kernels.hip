@@ -1478,6 +1478,25 @@ hipError_t LaunchAttemptAt(const DevTables& T, const uint8_t* buf, int32_t len, 
   return hipGetLastError();
 }
 
+namespace {
+// streaming.go:204-207 on an ordered span table: the first match whose end lies beyond `limit` stops the chunk's loop.  Match ends
+// increase with the row index, so the commit point is a binary search: out[0] = rows committed, out[1] = end of the last one.
+__global__ void commit_point_kernel(const int32_t* spans, long long n, int ncap, int32_t limit, long long* out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  long long lo = 0, hi = n;
+  while (lo < hi) {
+    const long long mid = (lo + hi) >> 1;
+    if (spans[mid * ncap + 1] > limit) hi = mid; else lo = mid + 1;
+  }
+  out[0] = lo;
+  out[1] = lo > 0 ? spans[(lo - 1) * ncap + 1] : 0;
+}
+}  // namespace
+hipError_t LaunchCommitPoint(const int32_t* spans, int64_t n, int ncap, int32_t limit, long long* out2, hipStream_t stream) {
+  hipLaunchKernelGGL(commit_point_kernel, dim3(1), dim3(64), 0, stream, spans, (long long)n, ncap, limit, out2);
+  return hipGetLastError();
+}
+
 hipError_t LaunchCarry(const DevTables& T, const uint8_t* buf, int32_t len, const uint8_t* slice_unsynced, int32_t* carry_in,
                        int32_t nslices, hipStream_t stream) {
   dim3 block(256), grid((nslices + 255) / 256);

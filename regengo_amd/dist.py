@@ -132,7 +132,7 @@ class ShardedFinder:
         elif h <= 0:
             notok = torch.ones(1, dtype=torch.int64, device=cdev)
         else:   # stays on the device: no host sync here
-            notok = (~self.reset_table[window[:h].long()].any()).to(torch.int64).reshape(1).to(cdev)
+            notok = (~self.reset_table[window[:h].long()].bool().any()).to(torch.int64).reshape(1).to(cdev)   # .bool(): any() of uint8 is uint8, ~ of it is never 0
         owned, info = self.scan_owned(window, shard.lo - shard.win_lo, shard.hi - shard.win_lo)
         cnt = int(owned.shape[0])
         mine = torch.cat([torch.tensor([cnt], dtype=torch.int64, device=cdev), notok])
@@ -146,6 +146,7 @@ class ShardedFinder:
             rows = allc.cpu().view(world, 2).tolist()
             if any(r[1] for r in rows):
                 owned, cnt, info = self.find_all_local(window, shard)
+                info["redone"] = True        # the ownership-aware scan's result was thrown away
                 base, total, counts = self.global_row_base(cnt, cdev)
                 return owned, cnt, info, base, total, counts
             counts = [int(r[0]) for r in rows]
@@ -153,7 +154,7 @@ class ShardedFinder:
             if not self.bounded and shard.win_hi < shard.total_len and cnt:
                 truncated = int(owned[cnt - 1, 1].item()) >= shard.win_hi - shard.win_lo
             info2 = dict(info)
-            info2.update({"truncated": truncated, "chained": False})
+            info2.update({"truncated": truncated, "chained": False, "redone": False})
             return owned, cnt, info2, sum(counts[:shard.rank]), sum(counts), counts
 
         return finish if defer else finish()
@@ -190,7 +191,7 @@ class ShardedFinder:
         elif h <= 0:
             notok = torch.ones(1, dtype=torch.int64, device=cdev)
         else:   # stays on the device: no host sync here
-            notok = (~self.reset_table[window[:h].long()].any()).to(torch.int64).reshape(1).to(cdev)
+            notok = (~self.reset_table[window[:h].long()].bool().any()).to(torch.int64).reshape(1).to(cdev)   # .bool(): any() of uint8 is uint8, ~ of it is never 0
         self.submit_owned(window, (shard.lo - shard.win_lo, shard.hi - shard.win_lo))
         world = dist.get_world_size(self.group)
 
@@ -203,6 +204,7 @@ class ShardedFinder:
             rows = allc.cpu().view(world, 2).tolist()
             if any(r[1] for r in rows):
                 owned, cnt, info = self.find_all_local(window, shard)
+                info["redone"] = True        # the ownership-aware scan's result was thrown away
                 base, total, counts = self.global_row_base(cnt, cdev)
                 return owned, cnt, info, base, total, counts
             counts = [int(r[0]) for r in rows]
@@ -210,7 +212,7 @@ class ShardedFinder:
             if not self.bounded and shard.win_hi < shard.total_len and cnt:
                 truncated = int(owned[cnt - 1, 1].item()) >= shard.win_hi - shard.win_lo
             info2 = dict(info)
-            info2.update({"truncated": truncated, "chained": False})
+            info2.update({"truncated": truncated, "chained": False, "redone": False})
             return owned, cnt, info2, sum(counts[:shard.rank]), sum(counts), counts
 
         return finish
@@ -319,3 +321,372 @@ def has_sync_in_left_halo(window, shard: Shard, reset_table) -> bool:
     if h <= 0:
         return False
     return bool(reset_table[window[:h].long()].any().item())
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# FindReader over the ranks (streaming.go:85-317 cut into per-GPU windows)
+# ----------------------------------------------------------------------------------------------------------------------
+
+def to_global(spans, base: int):
+    """Window-relative int32 rows -> stream-absolute int64 rows.  Slots of a group that did not take part stay (0, 0), the
+    reference's convention for an unset group (find.go:394-406 turns it into an empty slice either way)."""
+    import torch
+    g = spans.to(torch.int64)
+    if g.shape[0] == 0 or base == 0:
+        return g
+    pairs = g.view(g.shape[0], -1, 2)
+    unset = (pairs[:, :, 0] == 0) & (pairs[:, :, 1] == 0)
+    unset[:, 0] = False
+    return torch.where(unset[:, :, None], pairs, pairs + base).view(g.shape)
+
+
+@dataclass
+class StreamWindow:
+    k: int           # window index: owned range [k*W, (k+1)*W) of the stream
+    lo: int
+    hi: int
+    win_lo: int      # the bytes handed to the scan: [win_lo, win_hi)
+    win_hi: int
+    last: bool       # win_hi is the end of the stream
+    data: object     # uint8 tensor of win_hi - win_lo bytes on the scan device
+    halo_max: bool   # the left halo cannot be made any larger (it is everything this source still holds)
+
+
+class DeviceSource:
+    """A stream that already lives on (or is produced on) the device: gen(lo, hi) -> uint8 tensor with bytes [lo, hi), its
+    base 16-byte aligned; the total length is known.  The bench's synthetic streams and any upstream GPU stage look like
+    this."""
+
+    def __init__(self, gen, total_len: int):
+        self.gen, self.total_len = gen, int(total_len)
+
+    def window(self, k: int, W: int, halo_l: int, halo_r: int):
+        L = self.total_len
+        lo = k * W
+        if lo >= L:
+            return None
+        hi = min(L, lo + W)
+        wl = max(0, lo - halo_l)
+        wl -= wl % 16
+        wh = min(L, hi + halo_r)
+        return StreamWindow(k, lo, hi, wl, wh, wh >= L, self.gen(wl, wh), wl == 0)
+
+    def windows(self, rank: int, world: int, W: int, halo_l: int, halo_r: int):
+        k = rank
+        while True:
+            w = self.window(k, W, halo_l, halo_r)
+            if w is None:
+                return
+            yield w
+            k += world
+
+
+class ReaderSource:
+    """A sequential reader (`read(n)` -> up to n bytes, b"" at EOF), opened by every rank over the same stream.  Each rank walks the
+    stream front to back, keeps only the bytes of its own windows (+ halos) and stages them through a pinned host buffer; a
+    seekable reader is advanced with seek() instead of read-and-drop.  Windows come out in stream order; the stream's length is
+    discovered at EOF."""
+
+    def __init__(self, reader, device, block: int = 8 << 20):
+        self.r, self.device, self.block = reader, device, block
+        self.buf = bytearray()
+        self.buf_lo = 0            # stream offset of buf[0]
+        self.eof = False
+        self._pinned = [None, None]
+        self._flip = 0
+
+    def _drop_to(self, pos: int):
+        have = self.buf_lo + len(self.buf)
+        if pos <= self.buf_lo:
+            return
+        if pos < have:
+            del self.buf[:pos - self.buf_lo]
+            self.buf_lo = pos
+            return
+        self.buf.clear()
+        self.buf_lo = have
+        skip = pos - have
+        if skip and not self.eof and hasattr(self.r, "seekable") and self.r.seekable():
+            # a seek past EOF is not an error for files: the read below reports it
+            self.r.seek(skip, 1)
+            self.buf_lo = pos
+            return
+        while skip > 0 and not self.eof:
+            b = self.r.read(min(skip, self.block))
+            if not b:
+                self.eof = True
+                break
+            skip -= len(b)
+            self.buf_lo += len(b)
+
+    def _fill_to(self, pos: int):
+        while self.buf_lo + len(self.buf) < pos and not self.eof:
+            b = self.r.read(min(self.block, pos - self.buf_lo - len(self.buf)))
+            if not b:
+                self.eof = True
+                break
+            self.buf += b
+
+    def windows(self, rank: int, world: int, W: int, halo_l: int, halo_r: int):
+        import torch
+        k = rank
+        while True:
+            lo = k * W
+            wl = max(0, lo - halo_l)
+            wl -= wl % 16
+            self._drop_to(wl)
+            if self.buf_lo < wl:          # the stream ended before this window
+                return
+            self._fill_to(lo + W + halo_r + 1)        # one byte more than the window: tells "ends here" from "goes on"
+            end = self.buf_lo + len(self.buf)
+            if end <= lo:
+                return
+            hi = min(end, lo + W)
+            wh = min(end, hi + halo_r)
+            last = self.eof and wh >= end
+            n = wh - wl
+            pin = self._pinned[self._flip]
+            use_pin = str(self.device) != "cpu" and torch.cuda.is_available()
+            if pin is None or pin.numel() < n:
+                pin = torch.empty(max(n, 1), dtype=torch.uint8, pin_memory=use_pin)
+                self._pinned[self._flip] = pin
+            self._flip ^= 1
+            pin[:n] = torch.frombuffer(memoryview(self.buf)[:n], dtype=torch.uint8)
+            data = pin[:n].to(self.device, non_blocking=True) if str(self.device) != "cpu" else pin[:n].clone()
+            yield StreamWindow(k, lo, hi, wl, wh, last, data, wl == 0)
+            if last:
+                return
+            k += world
+
+
+class ShardedReader:
+    """FindReader / FindReaderCount (streaming.go:85-317) over one stream, sharded across the ranks of a process group.
+
+    The stream is cut into windows of `window_bytes`; window k is OWNED by rank k mod world (round t = windows t*world ..
+    t*world+world-1, one per rank, so a round's rows are contiguous in the stream and the ranks finish together).  A rank scans
+    its window plus halos -- right: MaxMatchLen bytes (1 MiB for unbounded patterns, the reference's own leftover cap); left:
+    `halo_left` bytes that must hold a sync point (a byte on which every DFA state dies: the FindAll chain is known right after
+    it) -- and reports the matches that START in the owned range (rgx_find_all_bytes_device_owned), with stream-absolute
+    offsets.  A left halo without a sync point is widened (16x per attempt, to at most `halo_max` bytes); if that fails too the
+    reader raises: the stream has a run longer than `halo_max` in which a match could be pending throughout, and the
+    single-GPU FindReader is the tool for it.
+
+    Per round ONE collective: an all_gather of [count, have-window, stop] (24 bytes per rank) whose exclusive scan gives every
+    rank its global row base.  The scan of round t+1 is queued (rgx_find_all_submit) before round t is finished, so the
+    collective, the callbacks and the host wait of round t hide behind it.
+
+    Delivery: `on_rows(rows, window index, global row index of rows[0])` gets each owned window's rows as an int64 tensor
+    [n, ncap] of stream-absolute offsets, on the owning rank, in that rank's stream order; with gather=True every round's rows are moved to rank 0 first (each peer on
+    its own xGMI link) and rank 0 alone gets them, in global stream order.  `on_match(match) -> bool` is the reference's
+    per-match callback (stream.Match: Result, StreamOffset, ChunkIndex) built from the same rows; returning False stops the
+    reader: the request travels with the next round's exchange, every rank stops there and that round's rows are dropped.  count_only=True is FindReaderCount: no rows are produced at all
+    (rgx_count_all_device_owned)."""
+
+    def __init__(self, compiled=None, device=None, group=None, window_bytes: int = 1 << 30, halo_left: int = 4096,
+                 halo_max: int = 1 << 20, unbounded_halo: int = 1 << 20, scan=None):
+        """scan: the per-window primitives, a dict with `submit(window, own, slot)`, `wait() -> (rows int32, info)`,
+        `count(window, own) -> int`, `reset_table`, `max_match_len`, `ncap` -- taken from `compiled` (the HIP path) when not
+        given; the CPU tests inject the test-only table walker."""
+        self.group = group
+        self.W = int(window_bytes)
+        self.W -= self.W % 16
+        assert self.W >= 16
+        self.halo_left, self.halo_max, self.device = halo_left, halo_max, device
+        self.scan = scan if scan is not None else self._scan_of(compiled, device)
+        mm = self.scan["max_match_len"]
+        self.halo_r = max(mm, 1) if mm >= 0 else unbounded_halo
+        self.bounded = mm >= 0
+
+    @staticmethod
+    def _scan_of(c, device):
+        import torch
+        outs = [None, None]
+
+        def submit(window, own, slot):
+            cap = window.numel() // max(c.MinMatchLen, 1) + 16
+            if outs[slot] is None or outs[slot].shape[0] < cap:
+                outs[slot] = None      # release before the larger allocation
+                outs[slot] = torch.empty((cap, c.ncap), dtype=torch.int32, device=window.device)
+            c.FindAllSubmit(window, out=outs[slot], capacity=cap, own=own)
+
+        def wait():
+            spans, res = c.FindAllWait()
+            return spans, {"kernel_ms": res.kernel_ms, "unsynced": int(res.unsynced)}
+
+        def count(window, own):
+            return c.CountAllOwned(window, own)
+
+        return {"submit": submit, "wait": wait, "count": count, "max_match_len": c.MaxMatchLen, "ncap": c.ncap,
+                "reset_table": torch.tensor(list(c.reset_bytes()), dtype=torch.uint8, device=device)}
+
+    def _dist(self):
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(self.group) > 1:
+            return dist
+        return None
+
+    def find_reader(self, source, on_rows=None, on_match=None, gather: bool = False, count_only: bool = False, make_result=None):
+        """Returns {"count": matches in the whole stream, "rounds", "windows" (this rank), "bytes" (owned by this rank),
+        "truncated_windows", "widened_halos", "kernel_ms" (sum over this rank's windows), "stopped"}."""
+        import torch
+        dist = self._dist()
+        world = dist.get_world_size(self.group) if dist else 1
+        rank = dist.get_rank(self.group) if dist else 0
+        cdev = "cpu"
+        if dist and dist.get_backend(self.group) == "nccl":
+            cdev = self.device
+        rt = self.scan["reset_table"]
+        it = source.windows(rank, world, self.W, self.halo_left, self.halo_r)
+        stats = {"count": 0, "rounds": 0, "windows": 0, "bytes": 0, "truncated_windows": 0, "widened_halos": 0, "kernel_ms": 0.0,
+                 "stopped": False}
+        stop_local = [False]
+        inflight = [0]        # scans queued and not yet waited for
+        stash = []            # results taken out of the queue early (see the widened-halo path)
+
+        def take():
+            if stash:
+                return stash.pop(0)
+            inflight[0] -= 1
+            return self.scan["wait"]()
+
+        def launch(w, slot):
+            """Queue window w's scan; returns what finish() needs."""
+            if w is None:
+                return None
+            h = w.lo - w.win_lo
+            if w.win_lo == 0:
+                notok = None
+            elif h <= 0:
+                notok = True
+            else:
+                notok = ~rt[w.data[:h].long()].bool().any()   # stays on the device until finish()
+            own = (w.lo - w.win_lo, w.hi - w.win_lo)
+            if count_only:
+                return (w, notok, None)
+            self.scan["submit"](w.data, own, slot)
+            inflight[0] += 1
+            return (w, notok, slot)
+
+        def widen(w):
+            """The left halo of w holds no sync point: take a larger one."""
+            hl = max(self.halo_left, 16)
+            while True:
+                hl = min(hl * 16, self.halo_max)
+                w2 = source.window(w.k, self.W, hl, self.halo_r) if hasattr(source, "window") else None
+                if w2 is None:
+                    raise RuntimeError("ShardedReader: window %d has no sync point in its %d-byte left halo and the source "
+                                       "cannot be re-read; raise halo_left" % (w.k, w.lo - w.win_lo))
+                h = w2.lo - w2.win_lo
+                if w2.win_lo == 0 or bool(rt[w2.data[:h].long()].any().item()):
+                    return w2
+                if hl >= self.halo_max:
+                    raise RuntimeError("ShardedReader: no sync point within %d bytes before stream offset %d: a match could be "
+                                       "pending across the whole halo; use the single-GPU FindReader for this stream"
+                                       % (self.halo_max, w.lo))
+
+        def finish(st):
+            """Wait for the round's scan, exchange the counts, deliver."""
+            rows = None
+            cnt = 0
+            w = None
+            if st is not None:
+                w, notok, slot = st
+                bad = bool(notok) if isinstance(notok, bool) else (bool(notok.item()) if notok is not None else False)
+                if not count_only:
+                    rows, info = take()
+                if bad:
+                    w = widen(w)
+                    stats["widened_halos"] += 1
+                    own = (w.lo - w.win_lo, w.hi - w.win_lo)
+                    if not count_only:
+                        # results come back in submit order: take the scan already queued for the next round out first
+                        if inflight[0]:
+                            stash.append(self.scan["wait"]())
+                            inflight[0] -= 1
+                        self.scan["submit"](w.data, own, slot)
+                        rows, info = self.scan["wait"]()
+                own = (w.lo - w.win_lo, w.hi - w.win_lo)
+                if count_only:
+                    cnt = int(self.scan["count"](w.data, own))
+                else:
+                    cnt = int(rows.shape[0])
+                    stats["kernel_ms"] += float(info.get("kernel_ms", 0.0))
+                    if not self.bounded and not w.last and cnt and int(rows[cnt - 1, 1].item()) >= w.win_hi - w.win_lo:
+                        stats["truncated_windows"] += 1
+                stats["windows"] += 1
+                stats["bytes"] += w.hi - w.lo
+            have = 1 if st is not None else 0
+            counts, haves, stops = [cnt], [have], [1 if stop_local[0] else 0]
+            if dist:
+                mine = torch.tensor([cnt, have, stops[0]], dtype=torch.int64, device=cdev)
+                allc = torch.empty(3 * world, dtype=torch.int64, device=cdev)
+                dist.all_gather_into_tensor(allc, mine, group=self.group)
+                tri = allc.cpu().view(world, 3).tolist()
+                counts, haves, stops = [int(t[0]) for t in tri], [int(t[1]) for t in tri], [int(t[2]) for t in tri]
+            stopped = any(stops)      # requests from the callbacks of earlier rounds: this round's rows are not delivered
+            if stopped:
+                return True, True
+            base = stats["count"] + sum(counts[:rank])
+            stats["count"] += sum(counts)
+            stats["rounds"] += 1
+            if not count_only:
+                glob = to_global(rows, w.win_lo) if st is not None else None
+                deliver = []
+                if gather and dist:
+                    deliver = self._gather_round(glob, counts, rank, world)     # rank 0: [(rows, src rank)], others: []
+                elif st is not None:
+                    deliver = [(glob, rank)]
+                for g, src in deliver:
+                    kidx = (stats["rounds"] - 1) * world + src
+                    if stop_local[0]:
+                        break
+                    if on_rows is not None and on_rows(g, kidx, base) is False:
+                        stop_local[0] = True
+                    if on_match is not None and not stop_local[0]:
+                        for row in g.tolist():
+                            res = make_result(row) if make_result is not None else row
+                            if not on_match({"Result": res, "StreamOffset": row[0], "ChunkIndex": kidx}):
+                                stop_local[0] = True
+                                break
+                    base += int(g.shape[0])
+            return (0 in haves), False
+
+        # ---- the pipeline: queue round t+1, then finish round t.  Every rank runs the same number of exchanges: the loop's exits
+        # depend on the gathered flags only.
+        slot = 0
+        cur = launch(next(it, None), slot)
+        while True:
+            slot ^= 1
+            nxt = launch(next(it, None), slot)
+            ended, stopped = finish(cur)
+            if ended or stopped:
+                if nxt is not None and not count_only:
+                    take()                     # drain the queued scan (its rows are not delivered)
+                stats["stopped"] = stopped or stop_local[0]
+                break
+            cur = nxt
+        return stats
+
+    def _gather_round(self, glob, counts, rank, world, dst: int = 0):
+        import torch
+        import torch.distributed as dist
+        ncap = self.scan["ncap"]
+        if rank == dst:
+            parts, reqs = [], []
+            for r in range(world):
+                if r == dst:
+                    if glob is not None:
+                        parts.append((glob, r))
+                    continue
+                if counts[r] == 0:
+                    continue
+                buf = torch.empty((counts[r], ncap), dtype=torch.int64, device=glob.device if glob is not None else self.device)
+                parts.append((buf, r))
+                reqs.append(dist.irecv(buf, src=r, group=self.group))
+            for q in reqs:
+                q.wait()
+            parts.sort(key=lambda t: t[1])
+            return parts
+        if glob is not None and glob.shape[0]:
+            dist.send(glob.contiguous(), dst=dst, group=self.group)
+        return []

@@ -56,9 +56,9 @@ def _worker(rank, world, port, pattern, data_bytes, halo_left, q, combined=False
             base, total, counts = f.global_row_base(cnt, "cpu")
         allrows = f.gather_spans(owned, sh, counts)
         if rank == 0:
-            q.put((allrows.tolist(), total, counts, info["chained"]))
+            q.put((allrows.tolist(), total, counts, info["chained"], info.get("redone")))
         else:
-            q.put((None, total, counts, info["chained"]))
+            q.put((None, total, counts, info["chained"], info.get("redone")))
     finally:
         dist.destroy_process_group()
 
@@ -95,7 +95,7 @@ def test_two_ranks_equal_single_scan(built):
     from oracle.gen_c import CMatcher
     from regengo_amd import synth
     data = synth.date_log_np(300000, adversarial=True).tobytes()
-    (rows, total, counts, chained), outs = _run(DATE, data)
+    (rows, total, counts, chained, _redone), outs = _run(DATE, data)
     exp, cnt = CMatcher(DATE).find_all_np(np.frombuffer(data, dtype=np.uint8))
     assert total == cnt and sum(counts) == cnt and not chained
     assert rows == exp.astype(np.int64).tolist()
@@ -107,7 +107,7 @@ def test_carry_chain_when_no_sync_in_halo(built):
     rng = np.random.default_rng(11)
     body = rng.choice(np.frombuffer(b"0123456789-", dtype=np.uint8), size=40000).tobytes()
     data = b"start " + body + b" end 2024-01-15 "
-    (rows, total, counts, chained), outs = _run(DATE, data, halo_left=64)
+    (rows, total, counts, chained, _redone), outs = _run(DATE, data, halo_left=64)
     exp, cnt = CMatcher(DATE).find_all_np(np.frombuffer(data, dtype=np.uint8))
     assert all(o[3] for o in outs), "expected the chained path"
     assert total == cnt
@@ -120,7 +120,7 @@ def test_unbounded_pattern_two_ranks(built):
     rng = np.random.default_rng(2)
     words = [b"bob", b"alice_1", b"@", b" ", b"host9", b"a@b", b"\n", b"x@", b"@y"]
     data = b"".join(words[i] for i in rng.integers(0, len(words), size=60000))
-    (rows, total, counts, chained), outs = _run(pat, data)
+    (rows, total, counts, chained, _redone), outs = _run(pat, data)
     exp, cnt = CMatcher(pat).find_all_np(np.frombuffer(data, dtype=np.uint8))
     assert total == cnt
     assert rows == exp.astype(np.int64).tolist()
@@ -132,14 +132,15 @@ def test_combined_step_two_ranks(built):
     from oracle.gen_c import CMatcher
     from regengo_amd import synth
     data = synth.date_log_np(200000, adversarial=True).tobytes()
-    (rows, total, counts, chained), outs = _run(DATE, data, combined=True)
+    (rows, total, counts, chained, redone), outs = _run(DATE, data, combined=True)
     exp, cnt = CMatcher(DATE).find_all_np(np.frombuffer(data, dtype=np.uint8))
     assert total == cnt and sum(counts) == cnt and not chained
+    assert all(o[4] is False for o in outs), "the fast path must not be redone when every left halo holds a sync point"
     assert rows == exp.astype(np.int64).tolist()
     rng = np.random.default_rng(5)
     body = rng.choice(np.frombuffer(b"0123456789-", dtype=np.uint8), size=30000).tobytes()
     data = b"start " + body + b" end 2024-01-15 "
-    (rows, total, counts, chained), outs = _run(DATE, data, halo_left=64, combined=True)
+    (rows, total, counts, chained, redone), outs = _run(DATE, data, halo_left=64, combined=True)
     exp, cnt = CMatcher(DATE).find_all_np(np.frombuffer(data, dtype=np.uint8))
     assert all(o[3] for o in outs), "expected the fall-back to the chained path"
     assert total == cnt and rows == exp.astype(np.int64).tolist()
