@@ -1,22 +1,33 @@
 #!/usr/bin/env python3
-"""Headline benchmark (BASELINE.json): input GB/s of FindAllBytes over a 1 GiB synthetic date-log buffer per
-MI355X, bit-exact offsets, at 1/2/4/8 GPUs.
+"""Benchmarks of the MI355X regex backend on BASELINE.json's configurations.
 
-  python bench.py --gpus N --steps K --warmup W
+  python bench.py [--config c2|c3|c4|c5] --gpus N --steps K --warmup W
   (N>1: launched by torch.distributed.run, one rank per GPU, backend nccl == RCCL)
 
-One "step" = one FindAllBytes pass over this rank's 1 GiB shard, input already resident in HBM, producing the full
-ordered span table [matches, 8] int32 in HBM, plus (N>1) the all_gather of per-rank match counts that fixes every
-rank's global row base.  Weak scaling: N GPUs scan N GiB of one stream.  `value` = total input bytes of all ranks /
-max-over-ranks wall time of the K timed steps.  The spans stay rank-local (row-sharded result); moving all rows to
-rank 0 is measured separately (`gather_ms`) because 32 B/match is as large as the input.
+Default (and the headline, BASELINE.json `metric`): C2 -- input GB/s of FindAllBytes over a 1 GiB synthetic date-log buffer
+per MI355X, bit-exact offsets.  One "step" = one pass of the hot path over this rank's batch of synthetic input, already
+resident in HBM:
 
-Extra objects: `roofline` (HBM; algorithmic bytes = 1 byte per input byte per launch / scan-kernel duration from HIP
-events on the launch stream) and `cpu_baseline` (the oracle's generated-C port of the reference's emitted matcher,
-one core, on a bounded sample of the same workload).
+  c2  Date DFA FindAllBytes over a 1 GiB shard per GPU, full ordered span table [matches, 8] int32 in HBM, plus (N>1) the
+      all_gather of per-rank match counts that fixes every rank's global row base.  Weak scaling.
+  c3  Email pattern FindBytes over a batch of 10M strings per GPU (rgx_find_batch_device): found flag + span record per string.
+  c4  URL-with-alternation FindReader over a 64 GiB stream: 8 GiB per GPU in 1 GiB windows with halos, owned round-robin by
+      the ranks (regengo_amd/dist.py: ShardedReader), stream-absolute rows; the gather of all rows to rank 0 is timed apart.
+  c5  the reference's 255-pattern suite (e2e corpus + benchmarks/curated), one launch per pattern over a shared 1 GiB corpus
+      (^/$-anchored patterns per line over a CSR view of the lines); with N GPUs the patterns are dealt round-robin.
+
+`value` = total input bytes of all ranks / max-over-ranks wall time per step.  The timed region is K steps repeated until it
+lasts at least 0.5 s (`repeats`), bracketed by barrier + synchronize: the sustained rate, not a cold one.
+
+Extra objects: `roofline` (HBM: algorithmic bytes per launch of the dominant kernel / its duration from HIP events on the launch
+stream; `traffic` from the PMC passes kept under profiles/, named in `traffic_source`) and `cpu_baseline` (the oracle's
+generated-C port of the reference's emitted matcher on the host cores, bounded sample; rank 0 at N=1 only).  Parity inside
+every run: the timed path's output against the closed form the synthetic input allows (c2), a vectorised restatement of the
+generator's ground truth (c3), or the committed oracle fixtures extended periodically (c4, c5: tests/golden/).
 """
 import argparse
 import json
+import math
 import os
 import sys
 import time
@@ -25,262 +36,751 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 DATE = r"(?P<year>\d{4})-(?P<month>\d{2})-(?P<day>\d{2})"
+EMAIL = r"(?P<user>\w+)@(?P<domain>\w+)"
+URL = r"(?P<full>(?P<proto>https?|ftp)://(?P<host>[\w.-]+)(?P<port>:\d+)?(?P<path>/[\w./-]*)?)"
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+METRIC = "input GB/s (FindAllBytes, 1 GiB buf) at 1/2/4/8 MI355X; bit-exact offsets"
+MIN_TIMED_SECONDS = 0.5
+KERNEL_NAMES = {1: "rgx::scan_exact_kernel", 2: "rgx::scan_rows_kernel (prefilter + verify)", 3: "rgx::scan_kernel (one attempt per start)",
+                4: "rgx::scan_us_kernel", 5: "rgx::scan_us_simple_kernel", 6: "rgx::scan_us_pair_kernel"}
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--bytes", type=int, default=1 << 30, help="shard size per GPU")
-    ap.add_argument("--adversarial", action="store_true", help="noise alphabet with digits and '-' (config C2b)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--gather-spans", action="store_true", help="also time the variable-length gather of all rows to rank 0")
-    ap.add_argument("--no-alt", action="store_true", help="skip the starts-only alternative result form (keeps profiler passes to one kernel variant)")
-    args = ap.parse_args()
+class Env:
+    """Process group, device and the small collectives the timing needs."""
 
-    import torch
-    import torch.distributed as dist
+    def __init__(self, args):
+        import torch
+        import torch.distributed as dist
+        self.torch, self.dist = torch, dist
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+        if self.world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+            backend = os.environ.get("RGX_BENCH_BACKEND", "nccl")   # "gloo" lets the N>1 code path run on a 1-GPU box
+            if os.environ.get("RGX_BENCH_ONE_DEVICE") == "1":
+                self.local_rank = 0
+            torch.cuda.set_device(self.local_rank)
+            if backend == "nccl":
+                dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
+            else:
+                dist.init_process_group(backend)
+        assert self.world == args.gpus or self.world == 1, "launch with torch.distributed.run for --gpus > 1"
+        self.dev = "cuda:%d" % self.local_rank
+        torch.cuda.set_device(self.local_rank)
+        self.cdev = self.dev if (self.world == 1 or dist.get_backend() == "nccl") else "cpu"   # where small collectives live
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        backend = os.environ.get("RGX_BENCH_BACKEND", "nccl")   # "gloo" lets the N>1 code path run on a 1-GPU box
-        if os.environ.get("RGX_BENCH_ONE_DEVICE") == "1":
-            local_rank = 0
-        torch.cuda.set_device(local_rank)
-        if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-        else:
-            dist.init_process_group(backend)
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run for --gpus > 1"
-    dev = "cuda:%d" % local_rank
-    torch.cuda.set_device(local_rank)
+    def barrier(self):
+        self.torch.cuda.synchronize()
+        if self.world > 1:
+            self.dist.barrier()
 
+    def allmax(self, x: float) -> float:
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.cdev)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MAX)
+        return float(t.item())
+
+    def allsum(self, x: float) -> float:
+        t = self.torch.tensor([x], dtype=self.torch.float64, device=self.cdev)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM)
+        return float(t.item())
+
+    def allmin_int(self, x: int) -> int:
+        t = self.torch.tensor([x], dtype=self.torch.int64, device=self.cdev)
+        if self.world > 1:
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN)
+        return int(t.item())
+
+    def close(self):
+        if self.world > 1:
+            self.dist.barrier()
+            self.dist.destroy_process_group()
+
+
+def sustained(env, run_steps, steps, warmup):
+    """run_steps(k): k steps to completion.  `warmup` untimed steps, then one untimed pass of `steps` to size the region, then
+    `steps` x repeats steps timed between barrier + synchronize on both sides.  Returns (seconds of the timed region, max over
+    ranks; repeats)."""
+    if warmup > 0:
+        run_steps(warmup)
+    env.barrier()
+    t0 = time.perf_counter()
+    run_steps(steps)
+    env.torch.cuda.synchronize()
+    est = env.allmax(time.perf_counter() - t0)
+    reps = max(1, int(math.ceil(MIN_TIMED_SECONDS / max(est, 1e-6))))
+    env.barrier()
+    t0 = time.perf_counter()
+    run_steps(steps * reps)
+    env.barrier()
+    dt = env.allmax(time.perf_counter() - t0)
+    return dt, reps
+
+
+def load_traffic(name):
+    """HBM bytes per launch of the dominant kernel from the PMC passes kept under profiles/ (rocprofv3 --pmc in its own runs,
+    corrected as MI355X_MICROARCH.md prescribes: scripts/pmc_traffic.sh).  (traffic, source) or (None, None)."""
+    for rnd in ("r02",):
+        pj = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, name))
+        if os.path.exists(pj):
+            try:
+                return json.load(open(pj)).get("hbm_bytes_per_launch"), "profiles/%s_pmc_%s.json" % (rnd, name)
+            except (OSError, ValueError):
+                pass
+    return None, None
+
+
+def base_line(env, args, value, ms_per_step, reps, dtype="u8", scaling="weak"):
+    return {"metric": METRIC, "value": round(value, 2), "unit": "GB/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
+            "repeats": reps, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "dtype": dtype, "data": "synthetic"}
+
+
+# ------------------------------------------------------------------------------------------------------------------- C2
+def run_c2(env, args):
+    torch, dist = env.torch, env.dist
     from regengo_amd import Compiled, synth
     from regengo_amd.dist import ShardedFinder, plan_shards
+    world, rank, dev = env.world, env.rank, env.dev
+    c = Compiled(DATE, name="Date").to(env.local_rank)
+    c.set_timing(True)
+    use_async = os.environ.get("RGX_BENCH_SYNC") != "1"
+
+    def build(L_total):
+        """One sharded scan job over a stream of L_total bytes: (step(), shard, window)."""
+        shards = plan_shards(L_total, world, c.MaxMatchLen)
+        sh = shards[rank]
+        window = synth.date_log_torch(sh.win_hi - sh.win_lo, dev, adversarial=args.adversarial, start=sh.win_lo)
+        finder = ShardedFinder.for_compiled(c, dev)
+        cap = (sh.win_hi - sh.win_lo) // c.MinMatchLen + 1
+        outs = [torch.empty((cap, c.ncap), dtype=torch.int32, device=dev) for _ in range(2)]   # step k's spans stay intact
+        flip = [0]                                                                              # while step k+1 scans
+
+        def scan(w):
+            flip[0] ^= 1
+            spans, res = c.FindAllSpans(w, out=outs[flip[0]], capacity=cap)
+            return spans, {"kernel_ms": res.kernel_ms, "unsynced": int(res.unsynced)}
+
+        def scan_owned(w, lo, hi):
+            flip[0] ^= 1
+            spans, res = c.FindAllSpans(w, out=outs[flip[0]], capacity=cap, own=(lo, hi))
+            return spans, {"kernel_ms": res.kernel_ms, "unsynced": int(res.unsynced)}
+
+        # asynchronous launch (rgx_find_all_submit / rgx_find_all_wait): step k+1 is queued before step k is finished, so the
+        # GPU does not idle while the host waits for a result and gathers the counts.  RGX_BENCH_SYNC=1: the synchronous calls.
+        def submit_owned(w, own):
+            flip[0] ^= 1
+            c.FindAllSubmit(w, out=outs[flip[0]], capacity=cap, own=own)
+
+        def wait_owned():
+            spans, res = c.FindAllWait()
+            return spans, {"kernel_ms": res.kernel_ms, "unsynced": int(res.unsynced)}
+
+        finder.scan, finder.scan_owned = scan, scan_owned
+        if use_async:
+            finder.submit_owned, finder.wait_owned = submit_owned, wait_owned
+
+        def step():
+            if use_async:
+                return finder.find_all_sharded_async(window, sh, env.cdev)
+            return finder.find_all_sharded(window, sh, env.cdev, defer=True)
+
+        return step, sh, window, finder, outs, cap
+
+    def runner(step, sink):
+        # Every step = scan (kernel + result on the host) + the count exchange.  The exchange of step k is finished after the
+        # scan of step k+1 has been launched (N>1: the 16-byte all_gather's latency hides behind that scan); all steps are
+        # complete -- spans in HBM, counts and row bases on the host -- before run_steps returns.
+        def run_steps(k):
+            pending = None
+            for _ in range(k):
+                nxt = step()
+                if pending is not None:
+                    sink.append(pending())
+                pending = nxt
+            sink.append(pending())
+        return run_steps
 
     L = args.bytes
-    c = Compiled(DATE, name="Date").to(local_rank)
-    c.set_timing(True)
-    shards = plan_shards(L * world, world, c.MaxMatchLen)
-    sh = shards[rank]
-    window = synth.date_log_torch(sh.win_hi - sh.win_lo, dev, adversarial=args.adversarial, start=sh.win_lo)
-    finder = ShardedFinder.for_compiled(c, dev)
-    cap = (sh.win_hi - sh.win_lo) // c.MinMatchLen + 1
-    outs = [torch.empty((cap, c.ncap), dtype=torch.int32, device=dev) for _ in range(2)]   # step k's spans stay intact
-    out = outs[0]                                                                           # while step k+1 scans
-    flip = [0]
-
-    def scan(w):
-        flip[0] ^= 1
-        spans, res = c.FindAllSpans(w, out=outs[flip[0]], capacity=cap)
-        return spans, {"kernel_ms": res.kernel_ms, "unsynced": int(res.unsynced)}
-
-    finder.scan = scan
-
-    def scan_owned(w, lo, hi):
-        flip[0] ^= 1
-        spans, res = c.FindAllSpans(w, out=outs[flip[0]], capacity=cap, own=(lo, hi))
-        return spans, {"kernel_ms": res.kernel_ms, "unsynced": int(res.unsynced)}
-
-    finder.scan_owned = scan_owned
-
-    # asynchronous launch (rgx_find_all_submit / rgx_find_all_wait): step k+1 is queued before step k is finished, so the
-    # GPU does not idle while the host waits for a result and gathers the counts.  RGX_BENCH_SYNC=1: the synchronous calls.
-    def submit_owned(w, own):
-        flip[0] ^= 1
-        c.FindAllSubmit(w, out=outs[flip[0]], capacity=cap, own=own)
-
-    def wait_owned():
-        spans, res = c.FindAllWait()
-        return spans, {"kernel_ms": res.kernel_ms, "unsynced": int(res.unsynced)}
-
-    use_async = os.environ.get("RGX_BENCH_SYNC") != "1"
-    if use_async:
-        finder.submit_owned, finder.wait_owned = submit_owned, wait_owned
-
-    cdev_early = dev if (world == 1 or dist.get_backend() == "nccl") else "cpu"
-
-    def step():
-        if use_async:
-            return finder.find_all_sharded_async(window, sh, cdev_early)
-        return finder.find_all_sharded(window, sh, cdev_early, defer=True)
-
-    for _ in range(args.warmup):
-        step()()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    kms = []
-    # Every step = scan (kernel + result on the host) + the count exchange.  The exchange of step k is finished after the
-    # scan of step k+1 has been launched (N>1: the 16-byte all_gather's latency hides behind that scan); all K steps are
-    # complete -- spans in HBM, counts and row bases on the host -- before the clock stops.
-    pending = None
-    for _ in range(args.steps):
-        nxt = step()
-        if pending is not None:
-            owned, cnt, info, base, total, counts = pending()
-            kms.append(info["kernel_ms"])
-        pending = nxt
-    owned, cnt, info, base, total, counts = pending()
-    kms.append(info["kernel_ms"])
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    dt = time.perf_counter() - t0
-    cdev = dev if (world == 1 or dist.get_backend() == "nccl") else "cpu"   # where small collectives live
-    tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
-    if world > 1:
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-    dt = float(tmax.item())
+    step, sh, window, finder, outs, cap = build(L * world)
+    results = []
+    dt, reps = sustained(env, runner(step, results), args.steps, args.warmup)
+    timed = results[-args.steps * reps:]
+    owned, cnt, info, base, total, counts = timed[-1]
+    kms = [r[2]["kernel_ms"] for r in timed]
+    redone = sum(1 for r in timed if r[2].get("redone") or r[2].get("chained"))
 
     # parity gate: the timed path's result equals the closed form (every date at a multiple of 50 of the GLOBAL stream)
     parity = None
     if not args.adversarial:
-        import numpy as np
         g0 = -(-sh.lo // 50) * 50
         starts = torch.arange(g0, sh.hi, 50, dtype=torch.int64, device=dev)
         starts = starts[starts + 10 <= L * world]
         rel = (starts - sh.win_lo).to(torch.int32)
         exp = torch.stack([rel, rel + 10, rel, rel + 4, rel + 5, rel + 7, rel + 8, rel + 10], dim=1)
         parity = bool(owned.shape == exp.shape and torch.equal(owned, exp))
-    pt = torch.tensor([1 if parity in (True, None) else 0], dtype=torch.int64, device=cdev)
-    if world > 1:
-        dist.all_reduce(pt, op=dist.ReduceOp.MIN)
-    parity_all = bool(pt.item())
+    parity_all = bool(env.allmin_int(1 if parity in (True, None) else 0))
 
     # alternative result form for fixed-template patterns: one int32 (match start) per match, spans = start + constants
     # (rgx_find_all_starts_device).  Reported next to the headline, never instead of it.
     alt = None
-    try:
-        if args.no_alt:
-            raise RuntimeError("skipped (--no-alt)")
-        starts_out = torch.empty(cap, dtype=torch.int32, device=dev)
-        for _ in range(2):
-            c.FindAllStarts(window, out=starts_out, capacity=cap)
-        torch.cuda.synchronize()
-        ta = time.perf_counter()
-        ak = []
-        for _ in range(args.steps):
-            st, ares = c.FindAllStarts(window, out=starts_out, capacity=cap)
-            ak.append(ares.kernel_ms)
-        torch.cuda.synchronize()
-        adt = (time.perf_counter() - ta) / args.steps
-        tmpl, mlen = c.capture_template()
-        sp_full = c.FindAllSpans(window, out=out, capacity=cap)[0]
-        same = bool(torch.equal(st[:, None] + torch.tensor(tmpl, dtype=torch.int32, device=dev)[None, :], sp_full))
-        akm = sum(ak) / len(ak)
-        alt = {"form": "starts_only (4 B/match) + capture template", "ms_per_step": round(adt * 1e3, 4), "kernel_ms": round(akm, 4),
-               "GBps_kernel": round((sh.win_hi - sh.win_lo) / (akm * 1e-3) / 1e9, 1),
-               "frac_of_hbm_peak": round((sh.win_hi - sh.win_lo) / (akm * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-               "spans_reconstructed_equal_full": same}
-    except Exception as ex:  # pragma: no cover
-        alt = {"error": str(ex)}
+    if args.no_alt:
+        alt = {"skipped": "--no-alt"}
+    else:
+        from regengo_amd import _capi
+        try:
+            starts_out = torch.empty(cap, dtype=torch.int32, device=dev)
+            for _ in range(2):
+                c.FindAllStarts(window, out=starts_out, capacity=cap)
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            ak = []
+            for _ in range(args.steps):
+                st, ares = c.FindAllStarts(window, out=starts_out, capacity=cap)
+                ak.append(ares.kernel_ms)
+            torch.cuda.synchronize()
+            adt = (time.perf_counter() - ta) / args.steps
+            tmpl, mlen = c.capture_template()
+            sp_full = c.FindAllSpans(window, out=outs[0], capacity=cap)[0]
+            same = bool(torch.equal(st[:, None] + torch.tensor(tmpl, dtype=torch.int32, device=dev)[None, :], sp_full))
+            akm = sum(ak) / len(ak)
+            alt = {"form": "starts_only (4 B/match) + capture template", "ms_per_step": round(adt * 1e3, 4), "kernel_ms": round(akm, 4),
+                   "GBps_kernel": round((sh.win_hi - sh.win_lo) / (akm * 1e-3) / 1e9, 1),
+                   "frac_of_hbm_peak": round((sh.win_hi - sh.win_lo) / (akm * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                   "spans_reconstructed_equal_full": same}
+        except _capi.RgxError as ex:
+            alt = {"error": str(ex)}
 
+    # N>1: moving every row to rank 0 (32 B/match is as large as the input), and the strong-scaling point: ONE 1 GiB stream
+    # cut across the ranks
     gather_ms = None
-    if args.gather_spans and world > 1:
-        torch.cuda.synchronize(); dist.barrier()
+    strong = None
+    if world > 1:
+        env.barrier()
         g0t = time.perf_counter()
         finder.gather_spans(owned, sh, counts)
-        torch.cuda.synchronize(); dist.barrier()
-        gather_ms = (time.perf_counter() - g0t) * 1e3
+        env.barrier()
+        gather_ms = env.allmax((time.perf_counter() - g0t) * 1e3)
+        del window, outs, owned, timed, results
+        torch.cuda.empty_cache()
+        s_step, s_sh, s_window, s_finder, s_outs, s_cap = build(L)
+        s_res = []
+        s_dt, s_reps = sustained(env, runner(s_step, s_res), args.steps, 2)
+        s_tot = s_res[-1][4]
+        strong = {"bytes_total": L, "ms_per_step": round(s_dt / (args.steps * s_reps) * 1e3, 4), "repeats": s_reps,
+                  "value_GBps": round(L / (s_dt / (args.steps * s_reps)) / 1e9, 2), "matches_total": int(s_tot),
+                  "parity_count": bool(args.adversarial or s_tot == (L - 10) // 50 + 1)}
 
-    if rank == 0:
-        ms_per_step = dt / args.steps * 1e3
-        total_bytes = float(L) * world
-        value = total_bytes / (dt / args.steps) / 1e9
-        k_ms = sum(kms) / len(kms)
-        win_bytes = sh.win_hi - sh.win_lo
-        achieved = win_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-        traffic = None
-        pj = os.path.join(ROOT, "profiles", "r01_pmc.json")
-        if os.path.exists(pj):
-            try:
-                traffic = json.load(open(pj)).get("hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        line = {
-            "metric": "input GB/s (FindAllBytes, 1 GiB buf) at 1/2/4/8 MI355X; bit-exact offsets",
-            "value": round(value, 2), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "u8", "data": "synthetic",
-            "config": {"workload": "C2: Date DFA FindAllBytes over a 1 GiB synthetic date-log buffer per GPU"
-                                   + (" (adversarial noise)" if args.adversarial else ""),
-                       "pattern": DATE, "bytes_per_gpu": L, "matches_per_gpu": int(cnt), "matches_total": int(total),
-                       "span_record_bytes": 4 * c.ncap, "parallelism": "shard%d" % world,
-                       "launch": "async (submit/wait, 2 scans in flight)" if use_async else "sync", "parity_closed_form": parity_all,
-                       "gather_ms": gather_ms, "alt_result_form": alt},
-            "roofline": {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                         "kernel": "rgx::scan_exact_kernel<4,true>", "kernel_ms": round(k_ms, 4), "algorithmic_bytes_per_launch": win_bytes},
-        }
-        if not args.no_cpu_baseline and world == 1:      # the CPU leg runs at N=1 only
-            line["cpu_baseline"] = cpu_baseline(args.adversarial)
-        print(json.dumps(line))
+    nsteps = args.steps * reps
+    ms_per_step = dt / nsteps * 1e3
+    value = float(L) * world / (dt / nsteps) / 1e9
+    k_ms = sum(kms) / len(kms)
+    win_bytes = sh.win_hi - sh.win_lo
+    achieved = win_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    traffic, tsrc = load_traffic("c2")
+    line = base_line(env, args, value, ms_per_step, reps)
+    line["config"] = {"workload": "C2: Date DFA FindAllBytes over a 1 GiB synthetic date-log buffer per GPU"
+                                  + (" (adversarial noise)" if args.adversarial else ""),
+                      "pattern": DATE, "bytes_per_gpu": L, "matches_per_gpu": int(cnt), "matches_total": int(total),
+                      "span_record_bytes": 4 * c.ncap, "parallelism": "shard%d" % world,
+                      "launch": "async (submit/wait, 2 scans in flight)" if use_async else "sync", "parity_closed_form": parity_all,
+                      "steps_redone": redone, "gather_ms": None if gather_ms is None else round(gather_ms, 3),
+                      "strong_scaling": strong, "alt_result_form": alt}
+    line["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
+                        "kernel": KERNEL_NAMES.get(c.info.scan_kernel, "rgx scan kernel"), "kernel_ms": round(k_ms, 4),
+                        "algorithmic_bytes_per_launch": win_bytes, "timed_launches": len(kms)}
+    if not args.no_cpu_baseline and world == 1:      # the CPU leg runs at N=1 only
+        line["cpu_baseline"] = cpu_baseline_findall(DATE, "c2", args.adversarial)
+    return line
+
+
+# ------------------------------------------------------------------------------------------------------------------- C3
+def email_truth_np(data, offsets):
+    """Ground truth of FindBytes for (\\w+)@(\\w+) per string, vectorised: the first '@' with a word byte on both sides inside
+    the string decides; user = the word run that ends at it, domain = the run that starts behind it.  (A restatement of what
+    the synthetic generator plants, not of the matcher: leftmost-first over this pattern has no other candidate -- any earlier
+    start lies in a word run that is not followed by '@'.)  Returns (found u8 [nstr], spans int32 [nstr, 6] string-relative)."""
+    import numpy as np
+    n = len(data)
+    nstr = len(offsets) - 1
+    word = np.zeros(256, dtype=bool)
+    for ch in b"abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789_":
+        word[ch] = True
+    w = word[data]
+    sid = np.repeat(np.arange(nstr, dtype=np.int64), np.diff(offsets))
+    pos = np.arange(n, dtype=np.int64)
+    first = pos == offsets[:-1][sid]
+    last = pos == offsets[1:][sid] - 1
+    wprev = np.concatenate([[False], w[:-1]]) & ~first
+    wnext = np.concatenate([w[1:], [False]]) & ~last
+    good = (data == ord("@")) & wprev & wnext
+    big = np.int64(1) << 40
+    cand = np.where(good, pos, big)
+    at = np.minimum.reduceat(cand, offsets[:-1])
+    found = at < big
+    # start of the word run that ends at at-1: one past the last non-word byte (or string start) before `at`
+    nonword_pos = np.where(~w | first, np.where(first & w, pos - 1, pos), -1)     # a string start acts as a boundary in front of it
+    run_lo = np.maximum.accumulate(nonword_pos) + 1
+    # end of the word run that starts at at+1: the next non-word byte (or string end) behind `at`
+    nw_next = np.where(~w | last, np.where(last & w, pos + 1, pos), big)
+    run_hi = np.minimum.accumulate(nw_next[::-1])[::-1]
+    atc = np.where(found, at, 0)
+    us = run_lo[np.maximum(atc - 1, 0)]
+    de = run_hi[np.minimum(atc + 1, n - 1)]
+    base = offsets[:-1]
+    spans = np.zeros((nstr, 6), dtype=np.int32)
+    f = found
+    spans[f, 0] = (us - base)[f]
+    spans[f, 1] = (de - base)[f]
+    spans[f, 2] = (us - base)[f]
+    spans[f, 3] = (atc - base)[f]
+    spans[f, 4] = (atc + 1 - base)[f]
+    spans[f, 5] = (de - base)[f]
+    return found.astype(np.uint8), spans
+
+
+def run_c3(env, args):
+    torch = env.torch
+    import numpy as np
+    from regengo_amd import Compiled, synth
+    nstr = args.strings
+    c = Compiled(EMAIL, name="Email").to(env.local_rank)
+    data, offsets = synth.email_batch_np(nstr, seed=0x5EED0003 + env.rank)
+    concat = torch.from_numpy(data).to(env.dev)
+    offs = torch.from_numpy(offsets).to(env.dev)
+    nbytes = int(offsets[-1])
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    kms = []
+    last = [None]
+
+    def run_steps(k):
+        for _ in range(k):
+            ev[0].record()
+            last[0] = c.FindBatchDevice(concat, offs)
+            ev[1].record()
+            ev[1].synchronize()             # the call itself returns with the results complete; the events are on its stream
+            kms.append(ev[0].elapsed_time(ev[1]))
+
+    dt, reps = sustained(env, run_steps, args.steps, args.warmup)
+    nsteps = args.steps * reps
+    kms = kms[-nsteps:]
+    found, spans = last[0]
+    # parity on a bounded prefix: the vectorised ground truth of the generator
+    npar = min(nstr, 1_000_000)
+    tf, ts = email_truth_np(data[:int(offsets[npar])], offsets[:npar + 1])
+    gf = found[:npar].cpu().numpy()
+    gs = spans[:npar].cpu().numpy()
+    parity = bool((gf == tf).all() and (gs[tf == 1] == ts[tf == 1]).all())
+    parity_all = bool(env.allmin_int(1 if parity else 0))
+    nfound = int(found.sum().item())
+    ms_per_step = dt / nsteps * 1e3
+    value = float(nbytes) * env.world / (dt / nsteps) / 1e9
+    k_ms = sum(kms) / len(kms)
+    alg = nbytes + 8 * (nstr + 1) + nstr + nstr * c.ncap * 4      # input bytes + CSR offsets + found flags + span records
+    achieved = alg / (k_ms * 1e-3) / 1e9
+    traffic, tsrc = load_traffic("c3")
+    line = base_line(env, args, value, ms_per_step, reps)
+    line["config"] = {"workload": "C3: Email pattern FindBytes over a batch of %d strings per GPU (reference semantics), found flag + "
+                                  "span record per string" % nstr,
+                      "pattern": EMAIL, "strings_per_gpu": nstr, "bytes_per_gpu": nbytes, "mean_string_bytes": round(nbytes / nstr, 2),
+                      "strings_per_second": round(nstr * env.world / (dt / nsteps)), "found_per_gpu": nfound,
+                      "span_record_bytes": 4 * c.ncap, "parallelism": "shard%d (independent batches)" % env.world,
+                      "parity_generator_truth": parity_all, "parity_strings_checked": npar}
+    line["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
+                        "kernel": "rgx batch kernel (ref_batch_kernel / batch_lds_kernel)", "kernel_ms": round(k_ms, 4),
+                        "algorithmic_bytes_per_launch": alg, "timed_launches": len(kms),
+                        "note": "event-bracketed call: includes the launch of the call's kernels"}
+    if not args.no_cpu_baseline and env.world == 1:
+        line["cpu_baseline"] = cpu_baseline_batch(EMAIL, data, offsets)
+    return line
+
+
+# ------------------------------------------------------------------------------------------------------------------- C4
+def corpus_tile():
+    from regengo_amd import synth
+    t = synth.web_log_tile()
+    return t[:t.rfind(b"\n") + 1]
+
+
+def check_tile(tile, sha_expected):
+    import hashlib
+    if hashlib.sha256(tile).hexdigest() != sha_expected:
+        raise RuntimeError("the synthetic corpus tile differs from the one the golden fixtures were made with")
+
+
+def run_c4(env, args):
+    torch, dist = env.torch, env.dist
+    import numpy as np
+    from regengo_amd import Compiled
+    from regengo_amd.dist import DeviceSource, ShardedReader
+    world, rank, dev = env.world, env.rank, env.dev
+    tile = corpus_tile()
+    T = len(tile)
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "c4_url_rows.npz"))
+    check_tile(tile, bytes(fx["tile_sha256"]).hex())
+    A, U, Z = fx["a"].astype(np.int64), fx["u"].astype(np.int64), fx["z"].astype(np.int64)
+    c = Compiled(URL, name="URL").to(env.local_rank)
+    c.set_timing(True)
+    tiles_per_window = (1 << 30) // T
+    W = tiles_per_window * T                    # ~1 GiB, a whole number of tiles
+    nwin_total = args.windows * world           # weak scaling: `windows` (default 8 = 8 GiB) per GPU; 8 GPUs = the 64 GiB stream
+    Ltot = nwin_total * W
+    tt = torch.frombuffer(bytearray(tile), dtype=torch.uint8).to(dev)
+    resident = {}
+
+    def gen(lo, hi):
+        """Bytes [lo, hi) of the periodic stream.  The rank's windows are generated once and stay resident in HBM (the timed
+        region starts with the input in place, as for the other configs)."""
+        key = (lo, hi)
+        t = resident.get(key)
+        if t is None:
+            ph = lo % T
+            reps = -(-(hi - lo + ph) // T)
+            t = tt.repeat(reps)[ph:ph + (hi - lo)].clone()      # fresh allocation: 16-byte aligned base
+            resident[key] = t
+        return t
+
+    reader = ShardedReader(c, dev, window_bytes=W, halo_left=4096)
+    src = DeviceSource(gen, Ltot)
+    st_last = [None]
+
+    def one_pass(on_rows=None, gather=False):
+        st_last[0] = reader.find_reader(src, on_rows=on_rows, gather=gather)
+        return st_last[0]
+
+    def run_steps(k):
+        for _ in range(k):
+            one_pass()
+
+    one_pass()                                  # generates and pins the windows in HBM (untimed)
+    dt, reps = sustained(env, run_steps, args.steps, args.warmup)
+    nsteps = args.steps * reps
+    st = st_last[0]
+    # parity pass (untimed, same path): every window's rows against the oracle's rows on the tile, extended periodically
+    ntiles = Ltot // T
+    exp_total = len(A) + (ntiles - 2) * len(U) + len(Z)
+    okflag = [True]
+    checked = [0]
+    Ud = torch.from_numpy(U).to(dev)
+    Ad = torch.from_numpy(A).to(dev)
+    Zd = torch.from_numpy(Z).to(dev)
+
+    def shift(ref, by):
+        pairs = ref.view(ref.shape[0], -1, 2)
+        unset = (pairs[:, :, 0] == 0) & (pairs[:, :, 1] == 0)
+        unset[:, 0] = False
+        return torch.where(unset[:, :, None], pairs, pairs + by).view(ref.shape)
+
+    def rows_of_tile(tix):
+        return len(A) if tix == 0 else (len(Z) if tix == ntiles - 1 else len(U))
+
+    def on_rows(rows, k, base):
+        # window k owns tiles [k*tpw, (k+1)*tpw): tile 0 -> A, the last tile of the stream -> Z shifted, the others U shifted
+        t0 = k * tiles_per_window
+        n_exp = sum(rows_of_tile(t) for t in (t0, t0 + tiles_per_window - 1)) + (tiles_per_window - 2) * len(U)
+        if rows.shape[0] != n_exp:
+            okflag[0] = False
+            return
+        for tix in sorted({t0, t0 + 1, t0 + tiles_per_window // 2, t0 + tiles_per_window - 1}):
+            ref = Ad if tix == 0 else (shift(Zd, (ntiles - 3) * T) if tix == ntiles - 1 else shift(Ud, (tix - 1) * T))
+            lo = 0 if tix == t0 else rows_of_tile(t0) + (tix - t0 - 1) * len(U)
+            okflag[0] &= bool(torch.equal(rows[lo:lo + ref.shape[0]], ref))
+            checked[0] += 1
+
+    stp = one_pass(on_rows=on_rows)
+    parity = okflag[0] and stp["count"] == exp_total and stp["truncated_windows"] == 0
+    parity_all = bool(env.allmin_int(1 if parity else 0))
+    gather_ms = None
     if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+        env.barrier()
+        g0 = time.perf_counter()
+        one_pass(gather=True)
+        env.barrier()
+        gather_ms = max(0.0, env.allmax((time.perf_counter() - g0) * 1e3) - dt / nsteps * 1e3)   # a pass with the gather minus one without
+    ms_per_step = dt / nsteps * 1e3
+    value = float(Ltot) / (dt / nsteps) / 1e9
+    k_ms = st["kernel_ms"] / max(st["windows"], 1)
+    win_bytes = W + 4096 + reader.halo_r
+    achieved = win_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    traffic, tsrc = load_traffic("c4")
+    line = base_line(env, args, value, ms_per_step, reps)
+    line["config"] = {"workload": "C4: URL-with-alternation FindReader over a %.0f GiB stream, %d x ~1 GiB windows per GPU with halos, owned "
+                                  "round-robin by the ranks (ShardedReader), stream-absolute span rows" % (Ltot / 2**30, args.windows),
+                      "pattern": URL, "stream_bytes": Ltot, "bytes_per_gpu": args.windows * W, "window_bytes": W,
+                      "halo_left": 4096, "halo_right": reader.halo_r, "matches_total": int(stp["count"]), "expected_matches": int(exp_total),
+                      "span_record_bytes": 4 * c.ncap, "parallelism": "window round-robin over %d rank(s)" % world,
+                      "rounds": st["rounds"], "widened_halos": st["widened_halos"], "parity_oracle_fixture_periodic": parity_all,
+                      "parity_pieces_checked": checked[0], "gather_ms": None if gather_ms is None else round(gather_ms, 3)}
+    line["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
+                        "kernel": KERNEL_NAMES.get(c.info.scan_kernel, "rgx scan kernel"), "kernel_ms": round(k_ms, 4),
+                        "algorithmic_bytes_per_launch": win_bytes, "timed_launches": st["windows"]}
+    if not args.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_baseline_findall(URL, "c4", False)
+    return line
 
 
-def cpu_baseline(adversarial: bool):
-    """The oracle's generated-C port of the reference's emitted FindAllBytes machine (oracle/gen_c.py), ONE core,
-    timed on a bounded sample of the same workload: the first 1 GiB of the stream, 4 passes (~10 s)."""
+# ------------------------------------------------------------------------------------------------------------------- C5
+def run_c5(env, args):
+    torch = env.torch
+    from regengo_amd import Compiled, _capi
+    world, rank, dev = env.world, env.rank, env.dev
+    tile = corpus_tile()
+    T = len(tile)
+    fx = json.load(open(os.path.join(ROOT, "tests", "golden", "c5_counts.json")))
+    check_tile(tile, fx["tile_sha256"])
+    ntiles = args.bytes // T
+    N = ntiles * T
+    big = torch.frombuffer(bytearray(tile), dtype=torch.uint8).to(dev).repeat(ntiles).contiguous()
+    ents = fx["patterns"]
+    if args.max_patterns:
+        ents = ents[:args.max_patterns]
+    mine = [(i, e) for i, e in enumerate(ents) if i % world == rank]
+    progs = []
+    skipped = []
+    lines = offs = None
+    t_setup = time.perf_counter()
+    for i, e in mine:
+        if e["mode"] == "unsupported":
+            skipped.append(i)
+            continue
+        try:
+            stdlib = not (e["mode"] == "line" and e.get("semantics") == "reference")
+            c = Compiled(e["pattern"], stdlib=stdlib).to(env.local_rank)
+        except _capi.RgxError:
+            skipped.append(i)
+            continue
+        c.set_timing(True)
+        if e["mode"] == "line" and lines is None:
+            # per-line view: the lines without their newline, back to back, + CSR offsets (every tile ends with '\n')
+            nl = big == 10
+            ends = torch.nonzero(nl).flatten()
+            starts = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), ends[:-1] + 1])
+            lens = ends - starts
+            lines = big[~nl].contiguous()
+            offs = torch.cat([torch.zeros(1, dtype=torch.int64, device=dev), torch.cumsum(lens, 0)]).contiguous()
+        progs.append((i, e, c))
+    setup_s = time.perf_counter() - t_setup
+    # one span table large enough for the densest pattern of this rank (records of ncap int32)
+    need = 16
+    count_only = set()
+    for i, e, c in progs:
+        if e["mode"] == "scan":
+            ints = (e["a"] + (ntiles - 2) * e["u"] + e["z"] + 16) * c.ncap
+            if ints * 4 > args.max_span_gib << 30:
+                count_only.add(i)        # the span table alone would be larger than --max-span-gib: FindReaderCount's form
+            else:
+                need = max(need, ints)
+    out_flat = torch.empty(need, dtype=torch.int32, device=dev)
+    counts = {}
+    kms = {}
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+
+    def run_steps(k):
+        for _ in range(k):
+            for i, e, c in progs:
+                if e["mode"] == "scan" and i in count_only:
+                    w, res = c.CountAll(big)
+                    counts[i] = int(w)
+                    kms[i] = float(res.kernel_ms)
+                elif e["mode"] == "scan":
+                    cap = need // c.ncap
+                    spans, res = c.FindAllSpans(big, out=out_flat[:cap * c.ncap].view(cap, c.ncap), capacity=cap)
+                    counts[i] = int(res.total)
+                    kms[i] = float(res.kernel_ms)
+                else:
+                    ev[0].record()
+                    found, spans = c.FindBatchDevice(lines, offs)
+                    ev[1].record()
+                    counts[i] = int(found.sum().item())
+                    kms[i] = ev[0].elapsed_time(ev[1])
+
+    dt, reps = sustained(env, run_steps, args.steps, args.warmup)
+    nsteps = args.steps * reps
+    # parity: counts against the oracle fixture extended periodically
+    bad = []
+    nlines_tile = None
+    for i, e, c in progs:
+        if e.get("oracle_timeout"):
+            continue
+        if e["mode"] == "scan":
+            exp = e["a"] + (ntiles - 2) * e["u"] + e["z"] if ntiles >= 3 else None
+            if exp is not None and counts[i] != exp:
+                bad.append(i)
+        elif "found" in e:
+            if counts[i] != e["found"] * ntiles:
+                bad.append(i)
+        else:
+            if not (e["found_min"] * ntiles <= counts[i] <= e["found_max"] * ntiles):
+                bad.append(i)
+    nbad = int(env.allsum(len(bad)))
+    npat = int(env.allsum(len(progs)))
+    nskip = int(env.allsum(len(skipped)))
+    scan_ms = sum(kms[i] for i, e, c in progs if e["mode"] == "scan")
+    nscan = sum(1 for i, e, c in progs if e["mode"] == "scan")
+    line_ms = sum(kms[i] for i, e, c in progs if e["mode"] == "line")
+    nline = len(progs) - nscan
+    tot_scan_ms, tot_nscan = env.allsum(scan_ms), env.allsum(nscan)
+    tot_line_ms, tot_nline = env.allsum(line_ms), env.allsum(nline)
+    ms_per_step = dt / nsteps * 1e3
+    total_bytes = float(N) * npat
+    value = total_bytes / (dt / nsteps) / 1e9
+    achieved = (N * tot_nscan) / (tot_scan_ms * 1e-3) / 1e9 if tot_scan_ms > 0 else 0.0
+    slow = sorted(((kms[i], e["pattern"][:60], e["mode"]) for i, e, c in progs), reverse=True)[:5]
+    line = base_line(env, args, value, ms_per_step, reps)
+    line["config"] = {"workload": "C5: the reference's %d-pattern suite (e2e corpus + benchmarks/curated), one launch per pattern over a "
+                                  "shared %.2f GiB corpus; ^/$-anchored patterns per line (CSR view)" % (len(ents), N / 2**30),
+                      "patterns": npat, "patterns_skipped": nskip, "scan_mode": int(tot_nscan), "line_mode": int(tot_nline),
+                      "corpus_bytes": N, "bytes_scanned_per_step": int(total_bytes), "parallelism": "patterns round-robin over %d rank(s)" % world,
+                      "count_only_patterns": int(env.allsum(len(count_only))), "parity_counts_vs_oracle_fixture": nbad == 0, "patterns_with_wrong_count": nbad,
+                      "scan_mode_mean_kernel_ms": round(tot_scan_ms / max(tot_nscan, 1), 4),
+                      "line_mode_mean_call_ms": round(tot_line_ms / max(tot_nline, 1), 4),
+                      "setup_compile_s": round(setup_s, 1), "slowest_on_rank0": [[round(a, 3), b, m] for a, b, m in slow]}
+    line["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,
+                        "kernel": "rgx scan kernels of the scan-mode patterns (exact / us_simple / us_pair / us / per-start), summed",
+                        "kernel_ms": round(tot_scan_ms, 3), "algorithmic_bytes_per_launch": N, "timed_launches": int(tot_nscan)}
+    if not args.no_cpu_baseline and world == 1:
+        line["cpu_baseline"] = cpu_baseline_suite([e for _, e, _ in progs if e["mode"] == "scan"][:12], tile)
+    return line
+
+
+# ------------------------------------------------------------------------------------------------------- CPU baselines
+def cpu_baseline_findall(pattern, which, adversarial):
+    """The oracle's generated-C port of the reference's emitted FindAllBytes machine (oracle/gen_c.py), ONE core, timed on a
+    bounded sample of the same workload, then the same port on every host core over disjoint slices."""
     import numpy as np
     from oracle.gen_c import CMatcher
     from regengo_amd import synth
-    n = 1 << 30
-    buf = np.empty(n, dtype=np.uint8)
-    step = 1 << 26
-    for o in range(0, n, step):
-        buf[o:o + step] = synth.date_log_np(step, adversarial=adversarial, start=o)
-    cm = CMatcher(DATE)
-    out = np.empty((n // 10 + 1, 8), dtype=np.int32)
-    passes = 4
+    cm = CMatcher(pattern)
+    if which == "c2":
+        n = 1 << 30
+        buf = np.empty(n, dtype=np.uint8)
+        step = 1 << 26
+        for o in range(0, n, step):
+            buf[o:o + step] = synth.date_log_np(step, adversarial=adversarial, start=o)
+        passes, period, what = 4, 50, "first 1 GiB of the same stream"
+    else:
+        tile = corpus_tile()
+        reps = (1 << 28) // len(tile)
+        buf = np.frombuffer(tile * reps, dtype=np.uint8).copy()
+        n = len(buf)
+        passes, period, what = 2, len(tile), "first 256 MiB of the same stream"
+    out = np.empty((n // 8 + 1, cm.ncap), dtype=np.int32)
     t0 = time.perf_counter()
     cnt = 0
     for _ in range(passes):
         cnt = cm.lib.m_find_all(buf.ctypes.data, n, -1, out.ctypes.data, out.shape[0])
     dt = time.perf_counter() - t0
     base = {"value": round(n * passes / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
-            "sample": "first 1 GiB of the same stream, %d passes, FindAllBytes with full span output; matches=%d" % (passes, cnt),
+            "sample": "%s, %d passes, FindAllBytes with full span output; matches=%d" % (what, passes, cnt),
             "host_cores_available": os.cpu_count()}
-    # the same port on every host core: disjoint slices (+9 bytes of look-ahead), one thread each (ctypes drops the GIL).
-    # Reported next to the one-core figure, never instead of it; slices begin on period boundaries of the synthetic stream,
-    # so the per-slice counts add up to the sequential count.
-    try:
-        import threading
-        ncores = os.cpu_count() or 1
-        per = -(-n // ncores)
-        per += (-per) % 50
-        outs = [np.empty((per // 10 + 2, 8), dtype=np.int32) for _ in range(ncores)]
-        counts = [0] * ncores
+    # the same port on every host core: disjoint slices cut on period boundaries of the synthetic stream (+ look-ahead), one
+    # thread each (ctypes drops the GIL).  Reported next to the one-core figure, never instead of it.
+    import threading
+    ncores = os.cpu_count() or 1
+    per = -(-n // ncores)
+    per += (-per) % period
+    look = 9 if which == "c2" else 0
+    outs = [np.empty((per // 8 + 2, cm.ncap), dtype=np.int32) for _ in range(ncores)]
+    counts = [0] * ncores
 
-        def work(i):
-            lo, hi = i * per, min(n, (i + 1) * per + 9)
-            if lo < n:
-                counts[i] = cm.lib.m_find_all(buf.ctypes.data + lo, hi - lo, -1, outs[i].ctypes.data, outs[i].shape[0])
+    def work(i):
+        lo, hi = i * per, min(n, (i + 1) * per + look)
+        if lo < n:
+            counts[i] = cm.lib.m_find_all(buf.ctypes.data + lo, hi - lo, -1, outs[i].ctypes.data, outs[i].shape[0])
 
-        best = None
-        for _ in range(3):
-            th = [threading.Thread(target=work, args=(i,)) for i in range(ncores)]
-            t1 = time.perf_counter()
-            for t in th:
-                t.start()
-            for t in th:
-                t.join()
-            d1 = time.perf_counter() - t1
-            best = d1 if best is None else min(best, d1)
-        base["all_cores"] = {"value": round(n / best / 1e9, 2), "unit": "GB/s", "cores": ncores, "matches": int(sum(counts)),
-                             "sample": "the same 1 GiB cut into %d slices, one thread per host core, best of 3" % ncores}
-    except Exception as ex:  # pragma: no cover
-        base["all_cores"] = {"error": str(ex)}
+    best = None
+    for _ in range(3):
+        th = [threading.Thread(target=work, args=(i,)) for i in range(ncores)]
+        t1 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        d1 = time.perf_counter() - t1
+        best = d1 if best is None else min(best, d1)
+    base["all_cores"] = {"value": round(n / best / 1e9, 2), "unit": "GB/s", "cores": ncores, "matches": int(sum(counts)),
+                         "sample": "the same bytes cut into %d slices, one thread per host core, best of 3" % ncores}
     return base
+
+
+def cpu_baseline_batch(pattern, data, offsets):
+    """FindBytes per string with the generated-C port (m_find), one core, on the first 2M strings of the batch."""
+    import numpy as np
+    from oracle.gen_c import CMatcher
+    cm = CMatcher(pattern)
+    n = min(len(offsets) - 1, 2_000_000)
+    out = np.zeros(cm.ncap, dtype=np.int32)
+    d = np.ascontiguousarray(data)
+    base = d.ctypes.data
+    offs = offsets.tolist()
+    find = cm.lib.m_find
+    optr = out.ctypes.data
+    t0 = time.perf_counter()
+    found = 0
+    for i in range(n):
+        found += find(base + offs[i], offs[i + 1] - offs[i], optr)
+    dt = time.perf_counter() - t0
+    nb = int(offsets[n])
+    return {"value": round(nb / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": "first %d strings of the batch (%d bytes), FindBytes per string through ctypes (call overhead included: "
+                      "%.2f us per string); found=%d" % (n, nb, dt / n * 1e6, found),
+            "strings_per_second": round(n / dt), "host_cores_available": os.cpu_count()}
+
+
+def cpu_baseline_suite(ents, tile):
+    """The first scan-mode patterns of the suite, each over 64 MiB of the corpus with the generated-C port, one core."""
+    import numpy as np
+    from oracle.gen_c import CMatcher
+    reps = (1 << 26) // len(tile)
+    buf = np.frombuffer(tile * reps, dtype=np.uint8).copy()
+    n = len(buf)
+    tot_b, tot_t = 0, 0.0
+    for e in ents:
+        cm = CMatcher(e["pattern"])
+        out = np.empty(((max(e["a"], e["u"], e["z"]) + 4) * (reps + 1), cm.ncap), dtype=np.int32)
+        t0 = time.perf_counter()
+        cm.lib.m_find_all(buf.ctypes.data, n, -1, out.ctypes.data, out.shape[0])
+        tot_t += time.perf_counter() - t0
+        tot_b += n
+        if tot_t > 25:
+            break
+    return {"value": round(tot_b / tot_t / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+            "sample": "the first scan-mode patterns of the suite over 64 MiB of the corpus each, FindAllBytes with span output, "
+                      "%.0f s of CPU" % tot_t, "host_cores_available": os.cpu_count()}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"])
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--bytes", type=int, default=1 << 30, help="c2: shard size per GPU; c5: corpus size")
+    ap.add_argument("--strings", type=int, default=10_000_000, help="c3: strings per GPU")
+    ap.add_argument("--windows", type=int, default=8, help="c4: ~1 GiB windows per GPU")
+    ap.add_argument("--max-patterns", type=int, default=0, help="c5: only the first K patterns of the suite")
+    ap.add_argument("--max-span-gib", type=int, default=48, help="c5: patterns whose span table would be larger are counted only")
+    ap.add_argument("--adversarial", action="store_true", help="c2: noise alphabet with digits and '-' (config C2b)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-alt", action="store_true", help="c2: skip the starts-only alternative result form (keeps profiler passes to one kernel variant)")
+    args = ap.parse_args()
+    defaults = {"c2": (20, 3), "c3": (10, 2), "c4": (3, 1), "c5": (1, 1)}
+    if args.steps is None:
+        args.steps = defaults[args.config][0]
+    if args.warmup is None:
+        args.warmup = defaults[args.config][1]
+    env = Env(args)
+    line = {"c2": run_c2, "c3": run_c3, "c4": run_c4, "c5": run_c5}[args.config](env, args)
+    if env.rank == 0:
+        print(json.dumps(line))
+    env.close()
 
 
 if __name__ == "__main__":

@@ -489,7 +489,6 @@ class ShardedReader:
         given; the CPU tests inject the test-only table walker."""
         self.group = group
         self.W = int(window_bytes)
-        self.W -= self.W % 16
         assert self.W >= 16
         self.halo_left, self.halo_max, self.device = halo_left, halo_max, device
         self.scan = scan if scan is not None else self._scan_of(compiled, device)
