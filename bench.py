@@ -544,6 +544,7 @@ def run_c5(env, args):
     progs = []
     skipped = []
     lines = offs = None
+    first_prog = [None]
     t_setup = time.perf_counter()
     for i, e in mine:
         if e["mode"] == "unsupported":
@@ -551,10 +552,12 @@ def run_c5(env, args):
             continue
         try:
             stdlib = not (e["mode"] == "line" and e.get("semantics") == "reference")
-            c = Compiled(e["pattern"], stdlib=stdlib).to(env.local_rank)
+            c = Compiled(e["pattern"], stdlib=stdlib).to(env.local_rank, ctx_of=first_prog[0])      # one context for the whole suite
         except _capi.RgxError:
             skipped.append(i)
             continue
+        if first_prog[0] is None:
+            first_prog[0] = c
         c.set_timing(True)
         if e["mode"] == "line" and lines is None:
             # per-line view: the lines without their newline, back to back, + CSR offsets (every tile ends with '\n')

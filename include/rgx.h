@@ -120,6 +120,9 @@ int rgx_stream_ctx_create(const rgx_program* p, rgx_stream_ctx** out);
  * written (or is about to reuse) need no other synchronisation.  rgx_stream_ctx_create makes a private non-blocking stream:
  * the caller must then order its own streams against rgx_stream_ctx_hip_stream() itself.                      */
 int rgx_stream_ctx_create_on_stream(const rgx_program* p, void* hip_stream, int use_given_stream, rgx_stream_ctx** out);
+/* Hand an idle context (no scan in flight) to another program of the same device: a package of generated patterns keeps one
+ * pool of contexts, not one per pattern (the device scratch behind a context grows with the largest buffer it has scanned).   */
+int rgx_stream_ctx_rebind(rgx_stream_ctx* c, const rgx_program* p);
 void rgx_stream_ctx_destroy(rgx_stream_ctx* c);
 /* The HIP stream (hipStream_t) a ctx launches on; lets a caller order its own copies/events.       */
 void* rgx_stream_ctx_hip_stream(const rgx_stream_ctx* c);

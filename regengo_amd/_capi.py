@@ -63,6 +63,7 @@ SYMBOLS = {
     "rgx_program_to_device": (C.c_int, [C.c_void_p, C.c_int]),
     "rgx_stream_ctx_create": (C.c_int, [C.c_void_p, C.POINTER(C.c_void_p)]),
     "rgx_stream_ctx_create_on_stream": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.POINTER(C.c_void_p)]),
+    "rgx_stream_ctx_rebind": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rgx_stream_ctx_destroy": (None, [C.c_void_p]),
     "rgx_stream_ctx_hip_stream": (C.c_void_p, [C.c_void_p]),
     "rgx_stream_ctx_set_timing": (C.c_int, [C.c_void_p, C.c_int]),

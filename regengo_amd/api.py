@@ -71,6 +71,8 @@ class Compiled:
         _capi.check(self._lib.rgx_compile(pattern.encode("utf-8"), flags, C.byref(h)))
         self._h = h
         self._ctx = None
+        self._ctx_owner = None      # another Compiled whose context this one shares (to(ctx_of=...))
+        self._ctx_shared = False
         self._device = None
         info = _capi.Info()
         _capi.check(self._lib.rgx_program_info(self._h, C.byref(info)))
@@ -89,7 +91,7 @@ class Compiled:
     # ---- lifecycle
     def __del__(self):
         try:
-            if getattr(self, "_ctx", None):
+            if getattr(self, "_ctx", None) and getattr(self, "_ctx_owner", None) is None:
                 self._lib.rgx_stream_ctx_destroy(self._ctx)
             if getattr(self, "_h", None):
                 self._lib.rgx_program_destroy(self._h)
@@ -107,8 +109,14 @@ class Compiled:
         _capi.check(self._lib.rgx_program_reset_bytes(self._h, b))
         return b.raw
 
-    def to(self, device: int = 0) -> "Compiled":
+    def to(self, device: int = 0, ctx_of: Optional["Compiled"] = None) -> "Compiled":
+        """ctx_of: share that object's context (stream + device scratch) instead of creating one -- many patterns over the same
+        large buffers then need the scratch once (rgx_stream_ctx_rebind before every call; one call at a time)."""
         _capi.check(self._lib.rgx_program_to_device(self._h, device))
+        if ctx_of is not None and self._ctx is None:
+            ctx_of._need_dev()
+            self._ctx, self._ctx_owner, self._ctx_shared = ctx_of._ctx, ctx_of, True
+            ctx_of._ctx_shared = True
         if self._ctx is None:
             # the context runs on torch's CURRENT stream of that device: scans are ordered with the torch kernels and copies that
             # produce their inputs and reuse their outputs (a private stream would race with them)
@@ -128,6 +136,8 @@ class Compiled:
     def _need_dev(self):
         if self._ctx is None:
             self.to(0)
+        if self._ctx_shared:
+            _capi.check(self._lib.rgx_stream_ctx_rebind(self._ctx, self._h))
 
     # ---- generated-API surface
     def MatchLengthInfo(self):

@@ -353,8 +353,8 @@ void* rgxt_compile_us(const char* pattern, uint32_t flags, int max_states, int m
 void rgxt_free_us(void* h) { delete (UsHandle*)h; }
 int rgxt_us_info(void* hh, int32_t* out) {
   const StartSearch& u = ((UsHandle*)hh)->u;
-  out[0] = u.nstates; out[1] = u.ncls; out[2] = u.lookahead; out[3] = u.ctx_sensitive; out[4] = u.nregs;
-  return 5;
+  out[0] = u.nstates; out[1] = u.ncls; out[2] = u.lookahead; out[3] = u.ctx_sensitive; out[4] = u.nregs; out[5] = u.nstates_raw;
+  return 6;
 }
 // (start, end) pairs of every FindAll match of buf[from_pos..len) with the search standing at from_pos.  `slice` > 0: the
 // walk is cut into windows of start positions [a, a+slice) the way the kernel's lanes own them -- each window begins at a

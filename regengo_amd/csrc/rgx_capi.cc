@@ -431,6 +431,19 @@ RGX_API void rgx_stream_ctx_destroy(rgx_stream_ctx* c) {
   if (c->h_read) hipHostFree(c->h_read);
   delete c;
 }
+RGX_API int rgx_stream_ctx_rebind(rgx_stream_ctx* c, const rgx_program* p) {
+  // One context (stream + device scratch) serving several programs of the same device in turn: a package of generated patterns
+  // keeps ONE pool of contexts, not one per pattern (the scratch of a 1 GiB scan is gigabytes).
+  if (!c || !p) return RGX_E_INVALID;
+  if (c->prog == p) return RGX_OK;
+  if (!p->p.d_arena) { SetError("program not on a device (rgx_program_to_device)"); return RGX_E_NO_DEVICE; }
+  if (p->p.device != c->device) { SetError("context and program live on different devices"); return RGX_E_INVALID; }
+  if (c->pend_count != 0) { SetError("context has scans in flight (rgx_find_all_wait first)"); return RGX_E_INVALID; }
+  c->prog = p;
+  c->prefer_w = false;
+  c->tmpl_key.clear();
+  return RGX_OK;
+}
 RGX_API void* rgx_stream_ctx_hip_stream(const rgx_stream_ctx* c) { return c ? (void*)c->stream : nullptr; }
 RGX_API int rgx_stream_ctx_set_timing(rgx_stream_ctx* c, int on) { if (!c) return RGX_E_INVALID; c->timing = on != 0; return RGX_OK; }
 

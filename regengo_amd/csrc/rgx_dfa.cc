@@ -772,6 +772,72 @@ Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOption
 }
 
 // ---------------------------------------------------------------- start-tracking search automaton (rgx_dfa.h)
+// Moore partition refinement over the finished automaton.  Two states are merged when nothing a walker can observe tells them
+// apart: the same per-state attributes (oldest, sflags) and, for every class, the same edge bits (match before / after, final,
+// register load with its delta and register), the same match info and equivalent targets.  The subset construction distinguishes
+// thread lists that behave alike from here on (a pattern with an alternation of literals easily doubles its states); the kernels
+// stage one table row per state in LDS, so every merged state is a kilobyte of LDS and, past a threshold, a resident workgroup.
+static void MinimizeStartSearch(StartSearch* pu) {
+  StartSearch& u = *pu;
+  const int n = u.nstates, stride = u.ncls + 1;
+  if (n <= 2) return;
+  std::vector<int> part(n, 0);
+  {
+    std::map<std::pair<int, int>, int> ids;
+    for (int q = 0; q < n; q++) {
+      const auto key = std::make_pair(q == 0 ? -1 : (int)u.oldest[q], q == 0 ? -1 : (int)u.sflags[q]);
+      auto it = ids.find(key);
+      if (it == ids.end()) it = ids.emplace(key, (int)ids.size()).first;
+      part[q] = it->second;
+    }
+  }
+  int nparts = 0;
+  for (int q = 0; q < n; q++) nparts = std::max(nparts, part[q] + 1);
+  while (true) {
+    std::map<std::vector<uint64_t>, int> ids;
+    std::vector<int> next(n);
+    std::vector<uint64_t> sig((size_t)stride + 1);
+    for (int q = 0; q < n; q++) {
+      sig[0] = (uint64_t)part[q];
+      for (int k = 0; k < stride; k++) {
+        const uint32_t e = u.trans[(size_t)q * stride + k];
+        const uint32_t tgt = e & 0x3FFFu;
+        // edge bits 14..27 | match info (16 bits) | the target's class (< 2^14): disjoint fields
+        sig[(size_t)k + 1] = ((uint64_t)(e >> 14) << 30) | ((uint64_t)u.minfo[(size_t)q * stride + k] << 14) | (uint64_t)part[tgt];
+      }
+      auto it = ids.find(sig);
+      if (it == ids.end()) it = ids.emplace(sig, (int)ids.size()).first;
+      next[q] = it->second;
+    }
+    const int np = (int)ids.size();
+    part.swap(next);
+    if (np == nparts) break;
+    nparts = np;
+  }
+  if (nparts == n) return;
+  // renumber: the dead state stays 0, the others in order of first appearance
+  std::vector<int> newid(nparts, -1), rep;
+  newid[part[0]] = 0; rep.push_back(0);
+  for (int q = 1; q < n; q++)
+    if (newid[part[q]] < 0) { newid[part[q]] = (int)rep.size(); rep.push_back(q); }
+  const int m = (int)rep.size();
+  std::vector<uint32_t> trans((size_t)m * stride);
+  std::vector<uint16_t> minfo((size_t)m * stride);
+  std::vector<uint8_t> oldest(m), sflags(m);
+  for (int i = 0; i < m; i++) {
+    const int q = rep[i];
+    oldest[i] = u.oldest[q]; sflags[i] = u.sflags[q];
+    for (int k = 0; k < stride; k++) {
+      const uint32_t e = u.trans[(size_t)q * stride + k];
+      trans[(size_t)i * stride + k] = (e & ~0x3FFFu) | (uint32_t)newid[part[e & 0x3FFFu]];
+      minfo[(size_t)i * stride + k] = u.minfo[(size_t)q * stride + k];
+    }
+  }
+  for (int c = 0; c < 4; c++) u.start[c] = (uint16_t)newid[part[u.start[c]]];
+  u.trans.swap(trans); u.minfo.swap(minfo); u.oldest.swap(oldest); u.sflags.swap(sflags);
+  u.nstates = m;
+}
+
 StartSearch BuildStartSearch(const std::string& pattern, uint32_t flags, int max_states, int max_regs) {
   (void)flags;
   StartSearch u;
@@ -998,6 +1064,8 @@ StartSearch BuildStartSearch(const std::string& pattern, uint32_t flags, int max
     if ((e & kUsAfter) && (u.minfo[x] >> 8) != kUsFromReg) u.simple = false;
   }
   u.ok = true;
+  u.nstates_raw = u.nstates;
+  MinimizeStartSearch(&u);
   return u;
 }
 

@@ -147,6 +147,7 @@ struct StartSearch {
   int ncls = 0;                   // class id ncls = end of text
   uint8_t cls[256] = {0};
   int nstates = 0;                // including dead state 0
+  int nstates_raw = 0;            // before minimisation (diagnostics)
   int nregs = 0;                  // registers in use (<= kUsRegs)
   std::vector<uint32_t> trans;    // [nstates][ncls+1]
   std::vector<uint16_t> minfo;    // [nstates][ncls+1]

@@ -23,6 +23,9 @@
 // HBM-bound byte work, no MFMA (a dependent table walk is not a contraction).
 #include <hip/hip_runtime.h>
 
+#include <map>
+#include <mutex>
+
 #include <cstdlib>
 
 #include "rgx_device_util.h"
@@ -463,6 +466,7 @@ __device__ __forceinline__ unsigned RowPlusByte(unsigned row, unsigned w) {
 
 // First sync point inside slice k = [k*64, k*64+64): the carried search position when the carry pass supplied one, else the
 // offset behind the first reset byte from k*64-1 on (offset 0 of the text is one).  -1: none.
+__device__ __forceinline__ bool found_carry(const int32_t* carry_in, int k) { return carry_in[k] >= 0; }
 __device__ __forceinline__ int SliceStart(const SIn& in, const int32_t* carry_in, int k) {
   const int a = k * kSliceBytes;
   if (a >= in.len) return -1;
@@ -774,18 +778,20 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_simple_kernel(DevTables
   __syncthreads();
   int e = 0x7FFFFFF0;
   bool slow = false;
+  int ek = -1;                           // the slice whose search position ends this lane's stretch
   if (s >= 0) {
     int t = tid + 1;
     while (t < kBlockThreads && s_sync[t] < 0) ++t;
     if (t < kBlockThreads) {
       e = s_sync[t];
+      ek = tile * kBlockThreads + t;
     } else {
       // the tile's last stretch ends at the first sync point at or after the next tile's start
       const int k0 = (tile + 1) * kBlockThreads;
       int found = -1;
       // (with the carry pass's positions at hand the search goes as far as it must: a match may run for kilobytes past the tile)
       const int klim = P.carry_in ? 0x7FFFFFF : k0 + kSReach / kSliceBytes - 1;
-      for (int k = k0; k < klim && k * kSliceBytes < len && found < 0; ++k) found = SliceStart(in, P.carry_in, k);
+      for (int k = k0; k < klim && k * kSliceBytes < len && found < 0; ++k) { found = SliceStart(in, P.carry_in, k); ek = k; }
       if (found >= 0) e = found;
       else if (!P.carry_in && k0 * kSliceBytes + kSReach - kSliceBytes < len) {
         // no sync point in reach and the text goes on: leave the stretch to the carry pass
@@ -872,7 +878,12 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_simple_kernel(DevTables
 #undef USS_FLUSH
     // a rewind was needed, or the stretch ends (at a search position handed down by the carry pass) with a match still
     // pending: the single-step walker repeats the stretch
-    if (fast && ((zrow & 0xFFFFu) == kSZoff || (zrow & (1u << 26)))) slow = true;
+    // A stretch that ends at a position the carry pass computed (not behind a reset byte) may end with a match pending -- the
+    // position IS that match's end, and the byte that would make it final lies beyond the stretch: the single-step walker
+    // finishes such stretches.  (Behind a reset byte nothing is pending, so the common scan never takes this path; testing the
+    // parked row's pending bit instead sent every lane whose TRIP ended inside a later match to the slow walker: 5x.)
+    const bool carry_end = P.carry_in != nullptr && ek >= 0 && found_carry(P.carry_in, ek);
+    if (fast && ((zrow & 0xFFFFu) == kSZoff || carry_end)) slow = true;
   }
   US_STAMP()
   if (slow && s >= 0)
@@ -1170,16 +1181,18 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
   __syncthreads();
   int e = 0x7FFFFFF0;
   bool slow = false;
+  int ek = -1;
   if (s >= 0) {
     int t = tid + 1;
     while (t < kBlockThreads && s_sync[t] < 0) ++t;
     if (t < kBlockThreads) {
       e = s_sync[t];
+      ek = tile * kBlockThreads + t;
     } else {
       const int k0 = (tile + 1) * kBlockThreads;
       int found = -1;
       const int klim = P.carry_in ? 0x7FFFFFF : k0 + kSReach / kSliceBytes - 1;
-      for (int k = k0; k < klim && k * kSliceBytes < len && found < 0; ++k) found = PSliceStart(in, P.carry_in, k);
+      for (int k = k0; k < klim && k * kSliceBytes < len && found < 0; ++k) { found = PSliceStart(in, P.carry_in, k); ek = k; }
       if (found >= 0) e = found;
       else if (!P.carry_in && k0 * kSliceBytes + kSReach - kSliceBytes < len) {
         atomicAdd(&P.counters[1], 1u);
@@ -1262,7 +1275,9 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
     }
 #undef USP_STEP
 #undef USP_FLUSH
-    if (fast && ((zrow & 0xFFFFu) == kPZoff || (zrow & (1u << 26)))) slow = true;    // rewind, or a match pending at the stretch's end
+    // rewind, or a stretch that ends at a carry-pass position (scan_us_simple_kernel has the commentary)
+    const bool carry_end = P.carry_in != nullptr && ek >= 0 && found_carry(P.carry_in, ek);
+    if (fast && ((zrow & 0xFFFFu) == kPZoff || carry_end)) slow = true;
   }
   US_STAMP()
   if (slow && s >= 0)
@@ -1412,16 +1427,30 @@ hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t str
     // SGPR-heavy kernels, and a workgroup that is not resident would stall every look-back behind it until the bounded spin
     // sends the scan to ticket mode)
     const size_t shp = (size_t)UsPLds(U.nent2, U.stride).total;
-    static int per_cu = 0, ncu = 0;
-    if (per_cu == 0) {
-      int dev = 0;
-      hipGetDevice(&dev);
-      hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, scan_us_pair_kernel, kBlockThreads, shp) != hipSuccess || per_cu < 1) per_cu = 1;
-      // 4 per CU measured best (16 waves: 3 leaves the SIMDs idle, 5 adds nothing); LDS admits 5 and the SGPR count 6, so 4 is
-      // resident with a margin even where the query over-reports by one
-      if (per_cu > 4) per_cu = 4; else if (per_cu > 2) per_cu -= 1;
-      if (ExpEnv("RGX_US_PER_CU")) per_cu = atoi(ExpEnv("RGX_US_PER_CU"));
+    // residency depends on the pattern's table size: asked per LDS footprint (and remembered), never carried over from another
+    // pattern -- a grid sized for a small table deadlocks the look-back of a large one until the bounded spin gives up (1.4 s)
+    static std::mutex mu;
+    static std::map<size_t, int> per_cu_of;
+    static int ncu = 0;
+    int per_cu = 0;
+    {
+      std::lock_guard<std::mutex> lock(mu);
+      if (ncu == 0) {
+        int dev = 0;
+        hipGetDevice(&dev);
+        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+      }
+      auto it = per_cu_of.find(shp);
+      if (it == per_cu_of.end()) {
+        int q = 0;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, scan_us_pair_kernel, kBlockThreads, shp) != hipSuccess || q < 1) q = 1;
+        // 4 per CU measured best (16 waves: 3 leaves the SIMDs idle, 5 adds nothing); the SGPR count admits 6, so 4 is resident
+        // with a margin even where the query over-reports by one; below that, one less than the query says
+        if (q > 4) q = 4; else if (q > 2) q -= 1;
+        if (ExpEnv("RGX_US_PER_CU")) q = atoi(ExpEnv("RGX_US_PER_CU"));
+        it = per_cu_of.emplace(shp, q).first;
+      }
+      per_cu = it->second;
     }
     int nblk = per_cu * ncu;
     if (nblk > P.ntiles) nblk = P.ntiles;

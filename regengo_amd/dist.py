@@ -454,7 +454,7 @@ class ReaderSource:
             pin[:n] = torch.frombuffer(memoryview(self.buf)[:n], dtype=torch.uint8)
             data = pin[:n].to(self.device, non_blocking=True) if str(self.device) != "cpu" else pin[:n].clone()
             yield StreamWindow(k, lo, hi, wl, wh, last, data, wl == 0)
-            if last:
+            if self.eof and hi >= end:        # the owned range reaches the end of the stream (seeing it in the halo is not enough)
                 return
             k += world
 

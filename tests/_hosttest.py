@@ -134,9 +134,9 @@ class StartSearch:
         self.h = _lib.rgxt_compile_us(pattern.encode("utf-8"), flags, max_states, max_regs)
         if not self.h:
             raise ValueError(_lib.rgxt_last_error().decode())
-        a = (C.c_int32 * 5)()
+        a = (C.c_int32 * 6)()
         _lib.rgxt_us_info(self.h, a)
-        self.nstates, self.ncls, self.lookahead, self.ctx_sensitive, self.nregs = list(a)
+        self.nstates, self.ncls, self.lookahead, self.ctx_sensitive, self.nregs, self.nstates_raw = list(a)
 
     def __del__(self):
         if getattr(self, "h", None):

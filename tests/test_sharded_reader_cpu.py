@@ -208,3 +208,14 @@ def test_to_global_keeps_unset_groups():
     from regengo_amd.dist import to_global
     t = torch.tensor([[5, 9, 0, 0, 6, 7], [0, 3, 0, 2, 0, 0]], dtype=torch.int32)
     assert to_global(t, 100).tolist() == [[105, 109, 0, 0, 106, 107], [100, 103, 100, 102, 0, 0]]
+
+
+def test_reader_source_with_a_right_halo_longer_than_the_stream(built):
+    # an unbounded pattern's right halo (here 64 KiB) sees the end of the stream from the first window on: the following
+    # windows must still be produced
+    pat = r"(?P<w>[a-z]+)=(?P<v>\d+)"
+    data = b"key=1 other=22 x=333 " * 1500
+    exp = _expect(pat, data)
+    for world in (1, 2):
+        outs = _run(pat, data, world=world, W=4096, reader=True, unbounded_halo=1 << 16)
+        assert _merge(outs, world) == exp
