@@ -450,7 +450,9 @@ def run_c4(env, args):
     st_last = [None]
 
     def one_pass(on_rows=None, gather=False):
-        st_last[0] = reader.find_reader(src, on_rows=on_rows, gather=gather)
+        # a step leaves every window's rows in HBM as the kernel wrote them (int32, window-relative) plus the window's stream
+        # offset and global row base on the host; the gather pass turns them into stream-absolute int64 rows on rank 0
+        st_last[0] = reader.find_reader(src, on_rows=on_rows, gather=gather, absolute=gather)
         return st_last[0]
 
     def run_steps(k):
@@ -479,17 +481,18 @@ def run_c4(env, args):
     def rows_of_tile(tix):
         return len(A) if tix == 0 else (len(Z) if tix == ntiles - 1 else len(U))
 
-    def on_rows(rows, k, base):
-        # window k owns tiles [k*tpw, (k+1)*tpw): tile 0 -> A, the last tile of the stream -> Z shifted, the others U shifted
+    def on_rows(rows, k, base, win_lo):
+        # window k owns tiles [k*tpw, (k+1)*tpw): tile 0 -> A, the last tile of the stream -> Z shifted, the others U shifted.
+        # rows are window-relative int32: the fixture rows are shifted into the window's frame
         t0 = k * tiles_per_window
         n_exp = sum(rows_of_tile(t) for t in (t0, t0 + tiles_per_window - 1)) + (tiles_per_window - 2) * len(U)
-        if rows.shape[0] != n_exp:
+        if rows.shape[0] != n_exp or base != (0 if k == 0 else len(A) + (t0 - 1) * len(U)):
             okflag[0] = False
             return
         for tix in sorted({t0, t0 + 1, t0 + tiles_per_window // 2, t0 + tiles_per_window - 1}):
-            ref = Ad if tix == 0 else (shift(Zd, (ntiles - 3) * T) if tix == ntiles - 1 else shift(Ud, (tix - 1) * T))
+            ref = Ad if tix == 0 else (shift(Zd, (ntiles - 3) * T - win_lo) if tix == ntiles - 1 else shift(Ud, (tix - 1) * T - win_lo))
             lo = 0 if tix == t0 else rows_of_tile(t0) + (tix - t0 - 1) * len(U)
-            okflag[0] &= bool(torch.equal(rows[lo:lo + ref.shape[0]], ref))
+            okflag[0] &= bool(torch.equal(rows[lo:lo + ref.shape[0]].to(torch.int64), ref))
             checked[0] += 1
 
     stp = one_pass(on_rows=on_rows)

@@ -998,17 +998,25 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
   if (nstr == 0) return 0;
   if (!d_concat || !d_offsets || !d_found || !d_spans) return RGX_E_INVALID;
   const DevTables& T = p->p.dev;
-  if (!(p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS)) {
+  const bool ref_mode = !(p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS);
+  if (ref_mode && !T.ref_find_ok) {
     // reference mode: FindBytesReuse's own restart rule (find.go:545-569)
-    if (!T.ref_find_ok) { SetError("reference-mode FindBytes is not offered for this pattern (memoising / TDFA engine): keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS"); return RGX_E_UNSUPPORTED; }
+    SetError("reference-mode FindBytes is not offered for this pattern (memoising / TDFA engine): keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS");
+    return RGX_E_UNSUPPORTED;
+  }
+  static const bool ref_one_pass = ExpEnv("RGX_REF_ONE_PASS") != nullptr;
+  if (ref_mode && (ref_one_pass || T.anchored)) {
+    // (anchored patterns make one attempt: nothing to replay -- the staged loop is the whole answer)
     uint64_t h_last = 0;
     HIP_TRY(hipMemcpyAsync(&h_last, d_offsets + nstr, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if ((rc = Ensure(&c->d_trace, &c->trace_cap, (int64_t)h_last + 2 * (int64_t)nstr + 64)) != RGX_OK) return rc;
-    HIP_TRY(LaunchBatchRef(T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, c->d_trace, c->stream));
+    HIP_TRY(LaunchBatchRef(T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, c->d_trace, c->stream,
+                           BatchWindowFor((int64_t)h_last, (int64_t)nstr)));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return (int64_t)nstr;
   }
+  // Reference mode otherwise: the plain search below, then LaunchBatchRefFix over its result (rgx_kernels.h).
   static const bool no_search = ExpEnv("RGX_NO_SEARCH_DFA") != nullptr;
   const DevTables* U = no_search ? nullptr : SearchTables(const_cast<Program*>(&p->p));
   if (U && BatchSearchFits(*U, T, true, d_concat)) {
@@ -1017,16 +1025,18 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
     HIP_TRY(hipMemcpyAsync(&h_last, d_offsets + nstr, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     const int64_t need = ((int64_t)h_last + 2 * (int64_t)nstr + 64 + 1) / 2 * (U->nstates <= 256 ? 1 : 2);   // in uint16 units
-    if ((rc = Ensure(&c->d_trace, &c->trace_cap, need)) != RGX_OK) return rc;
+    int64_t need_fix = ref_mode ? (int64_t)h_last + 2 * (int64_t)nstr + 64 : 0;
+    if ((rc = Ensure(&c->d_trace, &c->trace_cap, std::max(need, need_fix))) != RGX_OK) return rc;
     HIP_TRY(LaunchBatchSearch(*U, T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, c->d_trace, c->stream,
                               BatchWindowFor((int64_t)h_last, (int64_t)nstr)));
+    if (ref_mode) HIP_TRY(LaunchBatchRefFix(T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, c->d_trace, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return (int64_t)nstr;
   }
   uint16_t* trace = nullptr;
   int64_t stride = 0;
   int window = 0;
-  if (!T.fixed_captures) {
+  if (!T.fixed_captures || ref_mode) {
     // matches longer than the LDS trace need global scratch: size it by the longest string
     // (one pass over the offsets on the host would need a D2H copy; bound by total bytes instead)
     uint64_t h_last = 0;
@@ -1040,6 +1050,7 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
     window = BatchWindowFor((int64_t)h_last, (int64_t)nstr);
   }
   HIP_TRY(LaunchBatch(T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, trace, stride, c->stream, window));
+  if (ref_mode) HIP_TRY(LaunchBatchRefFix(T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, trace, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return (int64_t)nstr;
 }

@@ -82,7 +82,13 @@ int BatchWindowFor(int64_t total_bytes, int64_t nstr);
 // behind the offset its right-most path died at (DevTables::rm_*), not at start + 1.  spans == nullptr: MatchBytes (branch
 // order v = 1, required-prefix skip).  `trace`: scratch as for LaunchBatch (CSR-shaped, trace_stride < 0).
 hipError_t LaunchBatchRef(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,
-                          int32_t* spans, uint16_t* trace, hipStream_t stream);
+                          int32_t* spans, uint16_t* trace, hipStream_t stream, int window_bytes = 0);
+
+// FindBytes in reference mode as two launches: the plain search (LaunchBatchSearch / LaunchBatch), then this pass over its result,
+// which replays the reference's attempt offsets with failure offsets only (linear; the attempt-per-offset loop is quadratic in
+// the length of a word).  Not for anchored patterns (nothing to replay) -- harmless there.
+hipError_t LaunchBatchRefFix(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,
+                             int32_t* spans, uint16_t* trace, hipStream_t stream);
 
 // Same entry points through the search automaton U (rgx_program.h: SearchTables): one forward walk per string.
 // `trace` is scratch of (total bytes + 2*nstr + 64) entries of uint8 (U.nstates <= 256) or uint16, used by strings

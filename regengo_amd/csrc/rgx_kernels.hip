@@ -801,6 +801,50 @@ __global__ __launch_bounds__(64) void ref_batch_kernel(DevTables T, const uint8_
   ResolveCaptures(T, buf, len, s, e, tr, rec);
 }
 
+// ---- batch, reference mode, second half: the plain search has run (found flags + records of the LEFTMOST-FIRST match of every
+// string, start s in slot 0); this kernel replays only the reference's sequence of attempt offsets.  Every attempt before s
+// fails -- s is the leftmost start with a match -- so its failure offset (one walk of the right-most-path automaton, short for
+// FindBytes' branch order) is all that is needed: off = 0; off = fail(off) + 1; ... .  The sequence either lands on s (the record
+// stands), runs out of text (no match for the reference: the record is cleared) or steps over s (rare: the emitted loop goes
+// on from there with full attempts, as ref_batch_kernel does).  The attempt-per-offset loop walks a word of n bytes n/2 times
+// (quadratic: 7.7 ms on the C3 batch against 1 ms for the plain search); this is linear.
+__global__ __launch_bounds__(64) void ref_fix_kernel(DevTables T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr,
+                                                     uint8_t* found, int32_t* spans, uint16_t* trace) {
+  __shared__ uint16_t s_trace[64 * kCapsLdsTrace];
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= nstr || !found[i]) return;           // no match anywhere in the string: the emitted loop finds none either
+  const uint64_t o0 = offsets[i], o1 = offsets[i + 1];
+  const uint8_t* buf = concat + o0;
+  const int len = (int)(o1 - o0);
+  int32_t* rec = spans + i * T.ncap;
+  const int s0 = rec[0];
+  int off = 0;
+  bool lost = false;
+  while (off < s0) {
+    const int fo = RmFailOffset(T, 0, buf, len, off);
+    if (!(len > fo)) { lost = true; break; }
+    off = fo + 1;
+  }
+  if (!lost && off == s0) return;                // the attempt at s0 is made, and it is the one that matches
+  int s = -1, e = -1;
+  while (!lost) {                                // stepped over s0: full attempts from here on (find.go:545-569)
+    const int end = WalkGlobal(T, buf, len, off);
+    if (end >= 0) { s = off; e = end; break; }
+    const int fo = RmFailOffset(T, 0, buf, len, off);
+    if (!(len > fo)) break;
+    off = fo + 1;
+  }
+  found[i] = s >= 0;
+  if (s < 0) { for (int c = 0; c < T.ncap; ++c) rec[c] = T.unmatched_minus1 ? -1 : 0; return; }
+  if (T.fixed_captures) {
+    for (int c = 0; c < T.ncap; ++c) rec[c] = T.cap_kind[c] == kCapFromStart ? s + T.cap_delta[c] : e - T.cap_delta[c];
+    return;
+  }
+  const int need = e - s + 1;
+  uint16_t* tr = need <= kCapsLdsTrace ? s_trace + threadIdx.x * kCapsLdsTrace : trace + o0 + 2 * i;
+  ResolveCaptures(T, buf, len, s, e, tr, rec);
+}
+
 // ---- batch, staged (BASELINE config C3) -------------------------------------------------------------------
 // The per-lane kernel above reads everything -- tables, input bytes, back-trace pools -- through L1/L2 with one
 // dependent global load per DFA step (27 GB/s on 10 M short strings).  Here a persistent workgroup stages the
@@ -861,8 +905,15 @@ __device__ __forceinline__ int WalkBatch(const Tab<MODE>& tab, const BatchInput&
 // ResolveCaptures over LDS-resident tables; rec points into LDS.
 template <int MODE, class TraceT = uint16_t>
 __device__ __forceinline__ void ResolveCapturesBatch(const Tab<MODE>& tab, const BtTabs& B, const DevTables& T, const uint8_t* cls,
-                                                     const uint8_t* ctx_of_byte, const BatchInput& in, int s, int e, TraceT* trace,
-                                                     int32_t* rec) {
+                                                     const uint8_t* ctx_of_byte, const BatchInput& in, int s, int e, TraceT* trace_base,
+                                                     int ts, int32_t* rec) {
+  // trace entry i lives at trace_base[i * ts]: the LDS traces of a workgroup are interleaved (ts = workgroup size, lane l starts at
+  // base + l), so step i of every lane is one conflict-free row; a lane-major layout (ts = 1, 64 or 128 bytes per lane) puts the
+  // same step of all lanes into the same bank -- a 32- to 64-way conflict on every access (6.7 ms of 7.7 on the C3 batch)
+  struct Tr {
+    TraceT* b; int ts;
+    __device__ __forceinline__ TraceT& operator[](int i) const { return b[i * ts]; }
+  } trace{trace_base, ts};
   const int ncap = T.ncap;
   const int unset = T.unmatched_minus1 ? -1 : 0;
   const int len = in.len;
@@ -906,12 +957,12 @@ __device__ __forceinline__ void ResolveCapturesBatch(const Tab<MODE>& tab, const
 }
 
 struct BatchLayout {     // byte offsets into dynamic LDS (host and device compute it the same way)
-  int trans, cls, ctx, bt_nth, bt_base, bt_parent, bt_ops, bt_match, st_ops, st_pool, window, trace, recs, total;
+  int trans, cls, ctx, bt_nth, bt_base, bt_parent, bt_ops, bt_match, st_ops, st_pool, window, trace, recs, rm_trans, rm_depth, total;
   int bt_in_lds;
 };
 
 __host__ __device__ inline BatchLayout BatchLdsLayout(const DevTables& T, bool want_spans, int trace_entry_bytes = 2,
-                                                      int window_bytes = kBatchWindow) {
+                                                      int window_bytes = kBatchWindow, bool ref_mode = false) {
   BatchLayout L{};
   int o = 0;
   auto take = [&](int bytes) { const int at = o; o += (bytes + 15) & ~15; return at; };
@@ -934,18 +985,37 @@ __host__ __device__ inline BatchLayout BatchLdsLayout(const DevTables& T, bool w
   L.window = take(window_bytes + 16);
   if (dyn) L.trace = take(kBlockThreads * kBatchTrace * trace_entry_bytes);
   if (want_spans) L.recs = take(kBlockThreads * T.ncap * 4);
+  if (ref_mode) {     // the right-most-path automaton of the reference's restart rule (rgx_dfa.h: rm_*), one variant per launch
+    const int v = want_spans ? 0 : 1;
+    L.rm_trans = take(T.rm_nstates[v] * T.stride * 2);
+    L.rm_depth = take(T.rm_nstates[v]);
+  }
   L.total = o;
   return L;
 }
 
-template <int MODE>
+// REF: the reference's emitted loop instead of the plain search (ref_batch_kernel above is the same rule with
+// everything in global memory): a failed attempt does not resume at start + 1 but behind the offset at which the depth-first
+// search's right-most path died.  That path is an automaton of its own (rm_*), walked in the same flat loop as the DFA, one
+// more LDS look-up per byte until it fails; MatchBytes' variant also jumps to the next occurrence of the required first byte.
+template <int MODE, bool REF = false>
 __global__ __launch_bounds__(kBlockThreads) void batch_lds_kernel(DevTables T, const uint8_t* concat, const uint64_t* offsets,
                                                                    int64_t nstr, uint8_t* found, int32_t* spans, uint16_t* gtrace,
                                                                    int64_t trace_stride, int debug, int window_bytes) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const bool want_spans = spans != nullptr;
-  const BatchLayout Y = BatchLdsLayout(T, want_spans, 2, window_bytes);
+  const BatchLayout Y = BatchLdsLayout(T, want_spans, 2, window_bytes, REF);
+  const int rv = want_spans ? 0 : 1;
+  if (REF) {
+    const int n = T.rm_nstates[rv] * T.stride;
+    uint16_t* d = reinterpret_cast<uint16_t*>(smem + Y.rm_trans);
+    for (int i = tid; i < n; i += kBlockThreads) d[i] = T.rm_trans[rv][i];
+    for (int i = tid; i < T.rm_nstates[rv]; i += kBlockThreads) smem[Y.rm_depth + i] = T.rm_depth[rv][i];
+  }
+  const uint16_t* const rm_trans = reinterpret_cast<const uint16_t*>(smem + Y.rm_trans);
+  const uint8_t* const rm_depth = smem + Y.rm_depth;
+  const bool has_prefix = REF && !want_spans && T.ref_prefix >= 0;
   const int ncap = T.ncap;
   // ---- stage the tables once per workgroup
   {
@@ -1012,28 +1082,56 @@ __global__ __launch_bounds__(kBlockThreads) void batch_lds_kernel(DevTables T, c
       // restarts while l > offset, so offset can reach l).  ONE flat loop, one DFA step per trip: nested
       // attempt/step loops made a wave pay sum-over-starts of the LONGEST walk of its 64 strings.
       int pos = 0, at = 0, end = -1;
-      unsigned q = 0;
-      bool fresh = true;
-      while (true) {
+      unsigned q = 0, rq = 0;
+      int rfo = -1;                      // REF: the offset at which the right-most path of this attempt failed, once known
+      bool fresh = true, go = true;
+      auto next_prefix = [&](int from) -> int {          // bytes.IndexByte(input[from:], prefix) + from, or -1
+        for (int j = from; j < in.len; ++j) if (in.At(j) == (unsigned)T.ref_prefix) return j;
+        return -1;
+      };
+      if (has_prefix) { pos = next_prefix(0); go = pos >= 0; }
+      while (go) {
         if (fresh) {
           int ctx = kCtxOther;
           if (pos == 0) ctx = kCtxBOT;
-          else if (T.ctx_sensitive) ctx = ctx_of_byte[in.At(pos - 1)];
+          else if (T.ctx_sensitive || REF) ctx = ctx_of_byte[in.At(pos - 1)];
           q = T.start[ctx];
           end = T.start_accept[ctx] ? pos : -1;
           at = pos;
           fresh = false;
+          if (REF) { rq = T.rm_start[rv][ctx]; rfo = -1; }
         }
         const bool eot = at >= in.len;
-        const unsigned ed = eot ? tab.StepEot(q) : tab.Step(q, in.At(at));
+        const unsigned byte = eot ? 0u : (unsigned)in.At(at);
+        const unsigned ed = eot ? tab.StepEot(q) : tab.Step(q, byte);
         if (ed & kMatchBefore) end = at;
         if (ed & kMatchAfter) end = at + 1;
         q = ed & kStateMask;
+        if (REF && rfo < 0) {
+          const unsigned nx = rm_trans[rq * T.stride + (eot ? (unsigned)T.ncls : (unsigned)tab.cls[byte])];
+          if (nx == 0xFFFFu) rfo = at - (int)rm_depth[rq]; else rq = nx;
+        }
         if (q == kDead || eot) {
           if (end >= 0) { s = pos; e = end; break; }
-          ++pos;
-          if (pos > in.len || T.anchored) break;
-          fresh = true;
+          if (!REF) {
+            ++pos;
+            if (pos > in.len || T.anchored) break;
+            fresh = true;
+          } else {
+            if (T.anchored) break;
+            if (rfo < 0 && !eot) { ++at; continue; }      // (the DFA is dead, the right-most path is not: walk on until it is)
+            int fo = rfo < 0 ? at : rfo;
+            if (has_prefix) {
+              fo += 1;
+              if (!(in.len > fo)) break;
+              pos = next_prefix(fo);
+              if (pos < 0) break;
+            } else {
+              if (!(in.len > fo)) break;
+              pos = fo + 1;
+            }
+            fresh = true;
+          }
         } else {
           ++at;
         }
@@ -1049,9 +1147,10 @@ __global__ __launch_bounds__(kBlockThreads) void batch_lds_kernel(DevTables T, c
         for (int c = 0; c < ncap; ++c) rec[c] = T.cap_kind[c] == kCapFromStart ? s + T.cap_delta[c] : e - T.cap_delta[c];
       } else {
         const int need = e - s + 1;
-        uint16_t* tr = need <= kBatchTrace ? reinterpret_cast<uint16_t*>(smem + Y.trace) + tid * kBatchTrace
-                                           : (trace_stride < 0 ? gtrace + o0 + 2 * i : gtrace + i * trace_stride);
-        ResolveCapturesBatch<MODE>(tab, B, T, tab.cls, ctx_of_byte, in, s, e, tr, rec);
+        const bool in_lds = need <= kBatchTrace;
+        uint16_t* tr = in_lds ? reinterpret_cast<uint16_t*>(smem + Y.trace) + tid
+                              : (trace_stride < 0 ? gtrace + o0 + 2 * i : gtrace + i * trace_stride);
+        ResolveCapturesBatch<MODE>(tab, B, T, tab.cls, ctx_of_byte, in, s, e, tr, in_lds ? kBlockThreads : 1, rec);
       }
     }
     __syncthreads();
@@ -1144,9 +1243,9 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
     int32_t* rec = recs + tid * ncap;
     if (i < nmatches) {
       const int need = e - s + 1;
-      TraceT* tr = need <= kBatchTrace ? reinterpret_cast<TraceT*>(smem + Y.trace) + tid * kBatchTrace
-                                       : gtrace + atomicAdd(cursor, (unsigned long long)need);
-      ResolveCapturesBatch<MODE, TraceT>(tab, B, T, tab.cls, ctx_of_byte, in, s, e, tr, rec);
+      const bool in_lds = need <= kBatchTrace;
+      TraceT* tr = in_lds ? reinterpret_cast<TraceT*>(smem + Y.trace) + tid : gtrace + atomicAdd(cursor, (unsigned long long)need);
+      ResolveCapturesBatch<MODE, TraceT>(tab, B, T, tab.cls, ctx_of_byte, in, s, e, tr, in_lds ? kBlockThreads : 1, rec);
     }
     __syncthreads();
     const int nrec_words = (int)(ilast - i0) * ncap;
@@ -1271,11 +1370,17 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
     BatchInput in;
     in.g = concat + o0; in.lds = win; in.rel0 = (int)min(o0 - wb, (uint64_t)0x3FFFFFFF); in.wvalid = wvalid; in.len = (int)(o1 - o0);
     int end = -1;
-    TraceT* tr = nullptr;
+    // trace entry k at tr[k]: interleaved across the workgroup in LDS (conflict-free rows), contiguous in the global fallback
+    struct Tr {
+      TraceT* b; int ts;
+      __device__ __forceinline__ TraceT& operator[](int k) const { return b[k * ts]; }
+    } tr{nullptr, 1};
     if (i < nstr) {
       // ---- one forward walk; trace[k] = state after k bytes (only kept when spans are wanted)
-      if (want_spans)
-        tr = in.len + 2 <= kBatchTrace ? reinterpret_cast<TraceT*>(smem + Y.trace) + tid * kBatchTrace : gtrace + o0 + 2 * i;
+      if (want_spans) {
+        if (in.len + 2 <= kBatchTrace) { tr.b = reinterpret_cast<TraceT*>(smem + Y.trace) + tid; tr.ts = kBlockThreads; }
+        else { tr.b = gtrace + o0 + 2 * i; tr.ts = 1; }
+      }
       unsigned q = q0;
       end = end0;
       if (want_spans) tr[0] = (TraceT)q;
@@ -1547,9 +1652,50 @@ hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, i
 }
 
 hipError_t LaunchBatchRef(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,
-                          int32_t* spans, uint16_t* trace, hipStream_t stream) {
+                          int32_t* spans, uint16_t* trace, hipStream_t stream, int window_bytes) {
+  if (nstr <= 0) return hipSuccess;
+  if (window_bytes <= 0) window_bytes = kBatchWindow;
+  static const bool force_old = ExpEnv("RGX_BATCH_OLD") != nullptr;
+  const BatchLayout Y = BatchLdsLayout(T, spans != nullptr, 2, window_bytes, true);
+  if (!force_old && T.mode != kModeClassGlobal && Y.total <= 150 * 1024 && (((uintptr_t)concat) & 15) == 0 && T.ncap <= 32) {
+    static int cus = 0;
+    if (!cus) {
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+    }
+    const int64_t ngroups = (nstr + kBlockThreads - 1) / kBlockThreads;
+    int per_cu = (160 * 1024) / (Y.total + 1024);
+    if (per_cu < 1) per_cu = 1;
+    if (per_cu > 6) per_cu = 6;
+    int64_t grid = (int64_t)cus * per_cu * 4;
+    if (grid > ngroups) grid = ngroups;
+    static bool attr_set[2] = {false, false};
+    const void* fn = T.mode == kModeDirect ? (const void*)batch_lds_kernel<kModeDirect, true> : (const void*)batch_lds_kernel<kModeClassLds, true>;
+    const int mi = T.mode == kModeDirect ? 0 : 1;
+    if (!attr_set[mi]) {
+      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (e != hipSuccess) return e;
+      attr_set[mi] = true;
+    }
+    // scratch trace for matches longer than the LDS trace: CSR-shaped (string i owns [offsets[i] + 2i, offsets[i+1] + 2i + 2))
+    if (T.mode == kModeDirect)
+      hipLaunchKernelGGL((batch_lds_kernel<kModeDirect, true>), dim3((unsigned)grid), dim3(kBlockThreads), (size_t)Y.total, stream, T, concat,
+                         offsets, nstr, found, spans, trace, (int64_t)-1, 0, window_bytes);
+    else
+      hipLaunchKernelGGL((batch_lds_kernel<kModeClassLds, true>), dim3((unsigned)grid), dim3(kBlockThreads), (size_t)Y.total, stream, T, concat,
+                         offsets, nstr, found, spans, trace, (int64_t)-1, 0, window_bytes);
+    return hipGetLastError();
+  }
   dim3 block(64), grid((unsigned)((nstr + 63) / 64));
   hipLaunchKernelGGL(ref_batch_kernel, grid, block, 0, stream, T, concat, offsets, nstr, found, spans, trace);
+  return hipGetLastError();
+}
+
+hipError_t LaunchBatchRefFix(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,
+                             int32_t* spans, uint16_t* trace, hipStream_t stream) {
+  if (nstr <= 0) return hipSuccess;
+  dim3 block(64), grid((unsigned)((nstr + 63) / 64));
+  hipLaunchKernelGGL(ref_fix_kernel, grid, block, 0, stream, T, concat, offsets, nstr, found, spans, trace);
   return hipGetLastError();
 }
 

@@ -175,6 +175,7 @@ int UploadTables(const Tables& t, std::vector<uint16_t>* direct_table, DevTables
   for (int v = 0; v < 2; v++) {
     d.rm_trans[v] = (const uint16_t*)(b + off_rmt[v]);
     d.rm_depth[v] = b + off_rmd[v];
+    d.rm_nstates[v] = (int32_t)t.rm_depth[v].size();
     for (int c = 0; c < 4; c++) d.rm_start[v][c] = t.rm_start[v][c];
   }
   d.ref_prefix = t.ref_prefix;

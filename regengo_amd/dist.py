@@ -524,8 +524,12 @@ class ShardedReader:
             return dist
         return None
 
-    def find_reader(self, source, on_rows=None, on_match=None, gather: bool = False, count_only: bool = False, make_result=None):
-        """Returns {"count": matches in the whole stream, "rounds", "windows" (this rank), "bytes" (owned by this rank),
+    def find_reader(self, source, on_rows=None, on_match=None, gather: bool = False, count_only: bool = False, make_result=None,
+                    absolute: bool = True):
+        """absolute=False: rows stay as the kernel wrote them -- int32, relative to the window's first byte -- and on_rows gets that
+        byte's stream offset as a fourth argument (rows + offset = stream-absolute; the int64 conversion of a 1 GiB window's rows
+        costs as much as its scan).  Not with gather or on_match.
+        Returns {"count": matches in the whole stream, "rounds", "windows" (this rank), "bytes" (owned by this rank),
         "truncated_windows", "widened_halos", "kernel_ms" (sum over this rank's windows), "stopped"}."""
         import torch
         dist = self._dist()
@@ -628,7 +632,12 @@ class ShardedReader:
             base = stats["count"] + sum(counts[:rank])
             stats["count"] += sum(counts)
             stats["rounds"] += 1
-            if not count_only:
+            if not count_only and not absolute:
+                assert not gather and on_match is None
+                if st is not None and on_rows is not None and not stop_local[0]:
+                    if on_rows(rows, (stats["rounds"] - 1) * world + rank, base, w.win_lo) is False:
+                        stop_local[0] = True
+            elif not count_only:
                 glob = to_global(rows, w.win_lo) if st is not None else None
                 deliver = []
                 if gather and dist:
