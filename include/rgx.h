@@ -107,7 +107,8 @@ int64_t rgx_program_capture_names(const rgx_program* p, char* dst, size_t cap);
 int rgx_program_reset_bytes(const rgx_program* p, uint8_t* dst256);
 /* The range table behind \p{name} (unicode.Categories / unicode.Scripts of regexp/syntax, parse.go: unicodeTable): writes up
  * to cap_pairs [lo, hi] pairs into dst (int32 each) and returns the number of pairs the table has, or RGX_E_INVALID for a
- * name the front-end does not know.  Lets a caller audit the tables against another UCD copy.                   */
+ * name the front-end does not know.  Lets a caller audit the tables against another UCD copy.  The name "SimpleFold" gives
+ * the case-folding orbits behind (?i) instead: pairs (r, unicode.SimpleFold(r)) for every r with a non-trivial orbit.  */
 int64_t rgx_unicode_table(const char* name, int32_t* dst, size_t cap_pairs);
 
 /* ---- device binding --------------------------------------------------------------------------- */

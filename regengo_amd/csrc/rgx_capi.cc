@@ -363,7 +363,8 @@ RGX_API int rgx_program_info(const rgx_program* p, rgx_info* o) {
 RGX_API int64_t rgx_unicode_table(const char* name, int32_t* dst, size_t cap_pairs) {
   if (!name) return RGX_E_INVALID;
   std::vector<int32_t> tab;
-  if (!UnicodeTable(name, &tab)) return RGX_E_INVALID;
+  if (std::string(name) == "SimpleFold") SimpleFoldTable(&tab);       // not a \\p name: the (r, unicode.SimpleFold(r)) pairs behind (?i)
+  else if (!UnicodeTable(name, &tab)) return RGX_E_INVALID;
   const size_t n = tab.size() / 2;
   if (dst) memcpy(dst, tab.data(), std::min(n, cap_pairs) * 2 * sizeof(int32_t));
   return (int64_t)n;

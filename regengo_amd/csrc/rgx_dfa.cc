@@ -153,25 +153,27 @@ struct Builder {
         }
         case InstRune: {
           const auto& R = in.rune;
+          std::vector<int32_t> orbit_ranges;
           if (R.size() == 1) {
-            // fold-case single rune (the reference's emitter is broken here, charclass.go:11-13); ASCII orbit.
-            int32_t r = R[0];
-            if (r >= 128) throw Unsupported{"case-folded non-ASCII literal"};
-            nodes[pc].bytes.set(r);
-            for (int32_t f = SimpleFold(r); f != r; f = SimpleFold(f)) if (f < 128) nodes[pc].bytes.set(f);
-            nodes[pc].out_pc = in.out;
-            break;
+            // fold-case single rune: regexp's MatchRunePos accepts the whole SimpleFold orbit of the rune (`(?i)k` matches K, k
+            // and U+212A KELVIN SIGN).  The reference's emitter is broken here (charclass.go:11-13 indexes runes[i+1] of a
+            // one-element list: generation fails), so there is no emitted behaviour to match; this is Go regexp's.
+            std::vector<int32_t> orbit{R[0]};
+            for (int32_t f = SimpleFold(R[0]); f != R[0]; f = SimpleFold(f)) orbit.push_back(f);
+            std::sort(orbit.begin(), orbit.end());
+            for (int32_t x : orbit) { orbit_ranges.push_back(x); orbit_ranges.push_back(x); }
           }
+          const std::vector<int32_t>& RR = R.size() == 1 ? orbit_ranges : in.rune;
           // one deterministic byte trie per class: ASCII members, UTF-8 sequences of the non-ASCII ranges, and (class
           // contains U+FFFD) the bytes that cannot begin a rune
           std::vector<ByteSeq> seqs;
           bool has_fffd = false, non_ascii = false;
-          for (size_t i = 0; i + 1 < R.size(); i += 2) {
-            if (R[i] < 128) seqs.push_back({{(int)R[i], (int)std::min<int32_t>(R[i + 1], 127)}});
-            if (R[i + 1] >= 128) {
+          for (size_t i = 0; i + 1 < RR.size(); i += 2) {
+            if (RR[i] < 128) seqs.push_back({{(int)RR[i], (int)std::min<int32_t>(RR[i + 1], 127)}});
+            if (RR[i + 1] >= 128) {
               non_ascii = true;
-              Utf8Split(R[i], R[i + 1], &seqs);
-              if (R[i] <= 0xFFFD && R[i + 1] >= 0xFFFD) has_fffd = true;
+              Utf8Split(RR[i], RR[i + 1], &seqs);
+              if (RR[i] <= 0xFFFD && RR[i + 1] >= 0xFFFD) has_fffd = true;
             }
           }
           if (!non_ascii) {

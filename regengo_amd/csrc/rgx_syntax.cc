@@ -56,21 +56,24 @@ static std::vector<int32_t> DecodeUtf8(const std::string& s) {
   return out;
 }
 
+#include "rgx_unicode_tables.inc"
+
 int32_t SimpleFold(int32_t r) {
-  // ASCII orbits exact; the two non-ASCII members of ASCII orbits (K, S) included.  Other non-ASCII
-  // letters fold to themselves here (documented limit; the reference's corpus has no (?i)).
-  if (r >= 'A' && r <= 'Z') {
-    if (r == 'K') return 'k';
-    if (r == 'S') return 's';
-    return r + 32;
+  // unicode.SimpleFold: the next larger code point of r's orbit under Unicode simple case folding, the largest wraps to the
+  // smallest; r itself when the orbit is trivial.  Table from ICU 70's UCD (gen_unicode_tables.py: kFoldNext, Unicode 14.0).
+  if (r < kFoldMin || r > kFoldMax) return r;
+  if (r < 128) {
+    if (r >= 'A' && r <= 'Z') return (r == 'K' || r == 'S') ? r + 32 : r + 32;
+    if (r >= 'a' && r <= 'z') { if (r == 'k') return 0x212A; if (r == 's') return 0x17F; return r - 32; }
+    return r;
   }
-  if (r >= 'a' && r <= 'z') {
-    if (r == 'k') return 0x212A;
-    if (r == 's') return 0x17F;
-    return r - 32;
+  int lo = 0, hi = kFoldNextPairs - 1;
+  while (lo <= hi) {
+    const int mid = (lo + hi) >> 1;
+    const int32_t v = kFoldNext[2 * mid];
+    if (v == r) return kFoldNext[2 * mid + 1];
+    if (v < r) lo = mid + 1; else hi = mid - 1;
   }
-  if (r == 0x212A) return 'K';
-  if (r == 0x17F) return 'S';
   return r;
 }
 
@@ -173,17 +176,20 @@ static void AppendRange(Runes& r, int32_t lo, int32_t hi) {
   r.push_back(lo); r.push_back(hi);
 }
 
-static const int32_t kMinFold = 0x41, kMaxFold = 0x1E943;
+static const int32_t kMinFold = kFoldMin, kMaxFold = kFoldMax;     // parse.go: minFold / maxFold (0x41, 0x1E943)
 static void AppendFoldedRange(Runes& r, int32_t lo, int32_t hi) {
+  // parse.go appendFoldedRange: the range plus the whole orbit of every code point in it.
   if (lo <= kMinFold && hi >= kMaxFold) { AppendRange(r, lo, hi); return; }
   if (hi < kMinFold || lo > kMaxFold) { AppendRange(r, lo, hi); return; }
   if (lo < kMinFold) { AppendRange(r, lo, kMinFold - 1); lo = kMinFold; }
   if (hi > kMaxFold) { AppendRange(r, kMaxFold + 1, hi); hi = kMaxFold; }
-  // Only ASCII letters (and K/S relatives) fold in this implementation; bulk-append the rest.
-  for (int32_t c = lo; c <= hi; c++) {
-    if (c > 0x212A) { AppendRange(r, c, hi); break; }
-    AppendRange(r, c, c);
-    for (int32_t f = SimpleFold(c); f != c; f = SimpleFold(f)) AppendRange(r, f, f);
+  AppendRange(r, lo, hi);
+  // only code points with a non-trivial orbit add anything: walk the table's entries inside [lo, hi]
+  int a = 0, b = kFoldNextPairs;
+  while (a < b) { const int mid = (a + b) >> 1; if (kFoldNext[2 * mid] < lo) a = mid + 1; else b = mid; }
+  for (int i = a; i < kFoldNextPairs && kFoldNext[2 * i] <= hi; i++) {
+    const int32_t c = kFoldNext[2 * i];
+    for (int32_t f = SimpleFold(c); f != c; f = SimpleFold(f)) if (f < lo || f > hi) AppendRange(r, f, f);
   }
 }
 static void AppendLiteral(Runes& r, int32_t x, uint32_t flags) {
@@ -210,7 +216,6 @@ static Runes NegateClass(const Runes& r) {
 }
 
 struct Group { int sign; Runes cls; };
-#include "rgx_unicode_tables.inc"
 bool UnicodeTable(const std::string& name, std::vector<int32_t>* out) {
   if (name == "Any") { *out = {0, kMaxRune}; return true; }
   for (const UniTable& u : kUniTables)
@@ -218,6 +223,7 @@ bool UnicodeTable(const std::string& name, std::vector<int32_t>* out) {
   return false;
 }
 int UnicodeVersion() { return RGX_UNICODE_VERSION; }
+void SimpleFoldTable(std::vector<int32_t>* out) { out->assign(kFoldNext, kFoldNext + 2 * kFoldNextPairs); }
 static const std::map<std::string, Group>& PerlGroups() {
   static const std::map<std::string, Group> g = {
       {"\\d", {+1, {0x30, 0x39}}}, {"\\D", {-1, {0x30, 0x39}}},

@@ -79,6 +79,7 @@ bool HasEndAnchor(const Prog& p);
 bool IsAnchored(const Prog& p);
 
 int32_t SimpleFold(int32_t r);
+void SimpleFoldTable(std::vector<int32_t>* out);   // (r, SimpleFold(r)) pairs of every non-trivial orbit, sorted by r
 // \p{name} range table (pairs), false for unknown names; UCD version 0xMMmmpp of the tables (rgx_unicode_tables.inc)
 bool UnicodeTable(const std::string& name, std::vector<int32_t>* out);
 int UnicodeVersion();

@@ -114,3 +114,68 @@ def test_compiled_class_uses_the_table():
         # the oracle's Script tables come from a newer UCD: compare the structure (ops), not the range lists
         assert got.split("\n")[1] == want.split("\n")[1], pat
         assert len(got.split("\n")) == len(want.split("\n")) + len(prog.inst), pat
+
+
+def test_simple_fold_orbits_and_case_insensitive_matching(built):
+    """(?i): unicode.SimpleFold orbits from ICU's simple case folding (gen_unicode_tables.py: kFoldNext).  Cross-checked against an
+    independent source -- CPython's UCD: two code points are in one orbit iff their simple lower/upper/title mappings connect them --
+    on every code point both databases know (13.0 vs 14.0: orbits that involve code points assigned after 13.0 are skipped), and
+    exercised through the host walker on the classic cases (KELVIN SIGN, LONG S, the three-member DŽ orbit, final sigma)."""
+    import unicodedata
+    from tests._hosttest import HostProgram
+
+    def hits(pattern, text):
+        b = text.encode("utf-8")
+        hp = HostProgram(pattern)
+        nc = hp.info["ncap"]
+        return [b[r[0]:r[1]].decode("utf-8") for r in hp.find_all(b)]
+
+    assert hits(r"(?i)k", "k K \u212a x") == ["k", "K", "\u212a"]                          # KELVIN SIGN
+    assert hits(r"(?i)s+", "sS\u017f t") == ["sS\u017f"]                                   # LONG S
+    assert hits(r"(?i)\x{1C6}", "\u01c4 \u01c5 \u01c6 d") == ["\u01c4", "\u01c5", "\u01c6"]   # the three-member DZ-caron orbit
+    assert hits(r"(?i)\x{3C3}", "\u03a3 \u03c3 \u03c2") == ["\u03a3", "\u03c3", "\u03c2"]   # sigma, final sigma
+    # simple folding: sharp s ~ capital sharp s only, never "ss"
+    assert hits("(?i)stra\u00dfe", "STRA\u00dfE strasse Stra\u1e9ee") == ["STRA\u00dfE", "Stra\u1e9ee"]
+    assert hits(r"(?i)[k-l]+", "KL\u212al") == ["KL\u212al"]
+    assert hits("(?i)\u00e9", "\u00e9 \u00c9 e") == ["\u00e9", "\u00c9"]
+    # a negated class holds U+FFFD, and the emitted loop restarts at the next BYTE (find.go:545-569), not the next rune: the
+    # continuation bytes of the KELVIN SIGN it just rejected are each (RuneError, 1) to utf8.DecodeRune and match
+    hp = HostProgram(r"(?i)[^k]")
+    b = "kK\u212aa".encode("utf-8")
+    assert [b[r[0]:r[1]] for r in hp.find_all(b)] == [b"\x84", b"\xaa", b"a"]
+    # orbit partition against CPython's case mappings
+    lib = __import__("regengo_amd._capi", fromlist=["lib"]).lib()
+    import ctypes as C
+    n = lib.rgx_unicode_table(b"SimpleFold", None, 0)
+    assert n > 2000
+    buf = (C.c_int32 * (2 * n))()
+    assert lib.rgx_unicode_table(b"SimpleFold", buf, n) == n
+    nxt = {buf[2 * i]: buf[2 * i + 1] for i in range(n)}
+    seen = set()
+    checked = 0
+    for r in sorted(nxt):
+        if r in seen:
+            continue
+        orbit = [r]
+        f = nxt[r]
+        while f != r:
+            orbit.append(f)
+            f = nxt[f]
+        seen.update(orbit)
+        assert len(orbit) >= 2 and orbit == sorted(orbit), orbit     # walked from its smallest member: increasing, then the wrap
+        if any(unicodedata.category(chr(c)) == "Cn" for c in orbit):
+            continue                                   # assigned after Unicode 13.0: CPython does not know it
+        for c in orbit:                                # single-character lower / upper mappings never leave the orbit
+            for t in (chr(c).lower(), chr(c).upper()):
+                if len(t) == 1:
+                    assert ord(t) in orbit, (hex(c), hex(ord(t)), [hex(x) for x in orbit])
+        checked += 1
+    assert checked > 1300
+    # and no orbit is missing: a code point whose single-character lower/upper differs from it must be in the table
+    for c in range(0x110000):
+        ch = chr(c)
+        if unicodedata.category(ch) in ("Cn", "Cs"):
+            continue
+        for t in (ch.lower(), ch.upper()):
+            if len(t) == 1 and t != ch and c not in (0x130, 0x131):          # Turkic dotted/dotless i: no simple folding
+                assert c in nxt, hex(c)
