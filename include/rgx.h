@@ -86,8 +86,7 @@ typedef struct rgx_info {
   int32_t ref_find_engine;  /* 0 backtracking, 1 tdfa-or-tnfa (catastrophic risk), 2 tnfa, -1 none (no captures) */
   int32_t lookahead_mode;  /* 1: pattern has $ / \b / \B / (?m)$ (match flag is on the next-byte edge) */
   int32_t table_bytes;     /* bytes of transition table staged in LDS                            */
-  int32_t needs_valid_utf8; /* 1: the pattern has a class with non-ASCII runes (incl. negated ASCII classes);
-                             * results are exact on ASCII / valid UTF-8 input, see DESIGN.md "UTF-8 classes"        */
+  int32_t needs_valid_utf8; /* always 0 (kept for the layout): broken UTF-8 is handled at run time, see utf8_screened             */
   int32_t sync_states;     /* states of the sync automaton W (0: none), DESIGN.md 4.1                         */
   int32_t scan_kernel;     /* which FindAll kernel a large buffer takes once the program is on a device (0 before): 1 exact
                             * (fixed-length class chain), 2 prefilter + verify, 3 generic (one attempt per start), 4 one step
@@ -98,6 +97,10 @@ typedef struct rgx_info {
   int32_t ref_find_offered;  /* the same for FindBytes / FindBytesReuse (plain backtracking engine only)                      */
   int32_t unicode_version; /* UCD version behind \p{..}: 0xMMmmpp (0x0E0000 = 14.0.0).  The reference's tables are Go 1.24's
                             * `unicode` package = 15.0.0: code points first assigned in 15.0 are unassigned here       */
+  int32_t utf8_screened;   /* 1: the pattern has a decoding class that holds U+FFFD (every negated class, \W, \P{..}): a lead byte
+                            * without its continuation bytes is (RuneError, 1) to it, as to utf8.DecodeRune.  The entry points
+                            * screen the input for such bytes (one streaming pass) and match an input that has them through a
+                            * sanitised copy (DESIGN.md "UTF-8 classes"): results are exact on any bytes                       */
 } rgx_info;
 int rgx_program_info(const rgx_program* p, rgx_info* out);
 /* NUL-separated capture names, group 0 first ("" for unnamed); returns bytes written or needed.    */

@@ -351,6 +351,27 @@ void* rgxt_compile_us(const char* pattern, uint32_t flags, int max_states, int m
   return nullptr;
 }
 void rgxt_free_us(void* h) { delete (UsHandle*)h; }
+// The run time's view of an input with broken UTF-8 (rgx_kernels.hip: utf8_screen_kernel, restated for the host): every lead byte
+// that utf8.DecodeRune would report as (RuneError, 1) reads 0xFF.  Returns the number of bytes replaced.
+int64_t rgxt_sanitize_utf8(const uint8_t* src, int64_t len, uint8_t* dst) {
+  int64_t n = 0;
+  for (int64_t i = 0; i < len; i++) {
+    const unsigned b0 = src[i];
+    bool broken = false;
+    if (b0 >= 0xC2 && b0 <= 0xF4) {
+      const int size = b0 < 0xE0 ? 2 : (b0 < 0xF0 ? 3 : 4);
+      unsigned lo = 0x80, hi = 0xBF;
+      if (b0 == 0xE0) lo = 0xA0; else if (b0 == 0xED) hi = 0x9F; else if (b0 == 0xF0) lo = 0x90; else if (b0 == 0xF4) hi = 0x8F;
+      if (i + size > len) broken = true;
+      else if (src[i + 1] < lo || src[i + 1] > hi) broken = true;
+      else if (size > 2 && (src[i + 2] < 0x80 || src[i + 2] > 0xBF)) broken = true;
+      else if (size > 3 && (src[i + 3] < 0x80 || src[i + 3] > 0xBF)) broken = true;
+    }
+    dst[i] = broken ? 0xFF : (uint8_t)b0;
+    n += broken;
+  }
+  return n;
+}
 int rgxt_us_info(void* hh, int32_t* out) {
   const StartSearch& u = ((UsHandle*)hh)->u;
   out[0] = u.nstates; out[1] = u.ncls; out[2] = u.lookahead; out[3] = u.ctx_sensitive; out[4] = u.nregs; out[5] = u.nstates_raw;

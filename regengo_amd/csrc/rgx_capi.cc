@@ -38,6 +38,7 @@ struct rgx_stream_ctx {
   uint8_t* d_unsynced = nullptr; int32_t* d_carry = nullptr; int64_t slice_cap = 0;
   uint16_t* d_trace = nullptr; int64_t trace_cap = 0;
   uint8_t* d_in = nullptr; int64_t in_cap = 0;       // staging for the host-buffer entry points
+  uint8_t* d_san = nullptr; int64_t san_cap = 0;     // the sanitised copy of an input with broken UTF-8 (MatchView)
   // Replace path scratch
   int32_t* d_rspans = nullptr; int64_t rspans_cap = 0;
   long long* d_rdelta = nullptr; int64_t rdelta_cap = 0;     // [delta n+1][shift n+1]
@@ -90,6 +91,44 @@ int CheckCtx(const rgx_program* p, rgx_stream_ctx* c) {
   return RGX_OK;
 }
 
+// The bytes to MATCH on.  Programs with a decoding class that holds U+FFFD (Tables::needs_valid_utf8: every negated class, \W,
+// \P{..}) see a lead byte without its continuation bytes as (RuneError, 1), like utf8.DecodeRune (instructions.go:205-295); the
+// automaton cannot look three bytes ahead, so the input is screened (one streaming pass) and, only if it holds such a byte,
+// matched through a copy in which those bytes read 0xFF -- the same (RuneError, 1) to every instruction, same offsets.
+int MatchView(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, const uint8_t** out) {
+  *out = d_buf;
+  if (!p->p.t.needs_valid_utf8 || len == 0 || !d_buf) return RGX_OK;
+  unsigned* flag = reinterpret_cast<unsigned*>(c->d_cursor + 1);
+  unsigned h = 0;
+  HIP_TRY(hipMemsetAsync(flag, 0, 4, c->stream));
+  HIP_TRY(LaunchUtf8Screen(d_buf, (int64_t)len, nullptr, flag, c->stream));
+  HIP_TRY(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (!h) return RGX_OK;
+  int rc;
+  if ((rc = Ensure(&c->d_san, &c->san_cap, (int64_t)len + 64)) != RGX_OK) return rc;
+  HIP_TRY(LaunchUtf8Screen(d_buf, (int64_t)len, c->d_san, flag, c->stream));
+  *out = c->d_san;
+  return RGX_OK;
+}
+// Batch flavour (sequences stay inside their string): the copy is made in the same pass.
+int MatchViewBatch(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_concat, const uint64_t* d_offsets, size_t nstr,
+                   const uint8_t** out) {
+  *out = d_concat;
+  if (!p->p.t.needs_valid_utf8 || nstr == 0) return RGX_OK;
+  uint64_t h_last = 0;
+  HIP_TRY(hipMemcpyAsync(&h_last, d_offsets + nstr, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (h_last == 0) return RGX_OK;
+  int rc;
+  if ((rc = Ensure(&c->d_san, &c->san_cap, (int64_t)h_last + 64)) != RGX_OK) return rc;
+  unsigned* flag = reinterpret_cast<unsigned*>(c->d_cursor + 1);
+  HIP_TRY(hipMemsetAsync(flag, 0, 4, c->stream));
+  HIP_TRY(LaunchUtf8ScreenBatch(d_concat, d_offsets, (int64_t)nstr, c->d_san, flag, c->stream));
+  *out = c->d_san;
+  return RGX_OK;
+}
+
 // Core: scan (+ carry fallback) (+ captures).  Inputs/outputs are device pointers.
 int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n, int32_t* d_spans,
                       size_t cap_records, bool count_only, rgx_result* res, bool starts_only = false, int64_t own_lo = 0,
@@ -101,6 +140,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   if (len > 0x7FFFFF00ull) { SetError("buffer larger than 2^31-256 bytes: shard it (FindReader path)"); return RGX_E_TOO_LARGE; }
   if ((uintptr_t)d_buf & 15) { SetError("input device pointer must be 16-byte aligned"); return RGX_E_INVALID; }
   if (!count_only && ((uintptr_t)d_spans & 15)) { SetError("span device pointer must be 16-byte aligned"); return RGX_E_INVALID; }
+  { int vrc = MatchView(p, c, d_buf, len, &d_buf); if (vrc != RGX_OK) return vrc; }      // from here on d_buf = the bytes to match on
   const int32_t ilen = (int32_t)len;
   // sync points: reset bytes by default; the sync automaton W (rgx_dfa.h) when the pattern has no reset byte at all or
   // when an earlier scan of this context found slices without one (then the scan kernel takes W, ScanParams::use_w)
@@ -348,7 +388,8 @@ RGX_API int rgx_program_info(const rgx_program* p, rgx_info* o) {
   o->n_inst = t.n_inst; o->n_states = t.nstates; o->n_classes = t.ncls; o->anchored = t.anchored;
   o->fixed_captures = t.fixed_captures; o->can_match_empty = t.can_match_empty;
   o->ref_match_engine = t.ref_match_engine; o->ref_find_engine = t.ref_find_engine; o->lookahead_mode = t.lookahead_mode;
-  o->needs_valid_utf8 = t.needs_valid_utf8; o->sync_states = t.w_nstates;
+  o->needs_valid_utf8 = 0;          // (historic field: broken UTF-8 is handled at run time since the input screen, rgx.h)
+  o->utf8_screened = t.needs_valid_utf8 ? 1 : 0; o->sync_states = t.w_nstates;
   o->unicode_version = UnicodeVersion();
   {
     const bool have_rm = !t.rm_depth[0].empty() && !t.rm_depth[1].empty();
@@ -427,7 +468,7 @@ RGX_API void rgx_stream_ctx_destroy(rgx_stream_ctx* c) {
   for (int i = 0; i < 2; ++i)
     for (hipEvent_t e : {c->pev0[i], c->pev1[i], c->pdone[i]}) if (e) hipEventDestroy(e);
   for (void* p : {(void*)c->d_desc, (void*)c->d_unsynced, (void*)c->d_carry,
-                  (void*)c->d_trace, (void*)c->d_in, (void*)c->d_out, (void*)c->d_rspans, (void*)c->d_rdelta, (void*)c->d_rtemp, (void*)c->d_tmpl})
+                  (void*)c->d_trace, (void*)c->d_in, (void*)c->d_san, (void*)c->d_out, (void*)c->d_rspans, (void*)c->d_rdelta, (void*)c->d_rtemp, (void*)c->d_tmpl})
     if (p) hipFree(p);
   if (c->h_read) hipHostFree(c->h_read);
   delete c;
@@ -484,7 +525,7 @@ RGX_API int rgx_find_all_submit(const rgx_program* p, rgx_stream_ctx* c, const u
   if (pd.trivial) { c->pend_count++; return RGX_OK; }
   const int32_t ilen = (int32_t)len;
   static const bool no_self_clean = ExpEnv("RGX_NO_SELF_CLEAN") != nullptr;
-  if (!UseExactKernel(T, ilen) || no_self_clean || c->prefer_w) {
+  if (!UseExactKernel(T, ilen) || no_self_clean || c->prefer_w || p->p.t.needs_valid_utf8) {
     SetError("asynchronous launch is offered for the exact kernel only");
     return RGX_E_UNSUPPORTED;
   }
@@ -958,6 +999,7 @@ RGX_API int rgx_match_bytes_device(const rgx_program* p, rgx_stream_ctx* c, cons
   // A whole-buffer MatchBytes is "does FindAll find anything", except that the search also tries the empty
   // match at offset len (compiler.go:845-853 retries while l > offset) which FindAll never does (find.go:209-211).
   const Tables& t = p->p.t;
+  if ((rc = MatchView(p, c, d_buf, len, &d_buf)) != RGX_OK) return rc;       // broken UTF-8: match on the sanitised copy
   const bool ref_rule = !(t.flags & RGX_FLAG_STDLIB_SEMANTICS) && p->p.dev.ref_match_kind != 1;
   if (ref_rule && p->p.dev.ref_match_kind == 2) { SetError("reference-mode MatchBytes is not offered for this pattern (memoising engine): keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS"); return RGX_E_UNSUPPORTED; }
   if (ref_rule && !t.can_match_empty) {
@@ -998,6 +1040,7 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
   if (rc != RGX_OK) return rc;
   if (nstr == 0) return 0;
   if (!d_concat || !d_offsets || !d_found || !d_spans) return RGX_E_INVALID;
+  if ((rc = MatchViewBatch(p, c, d_concat, d_offsets, nstr, &d_concat)) != RGX_OK) return rc;
   const DevTables& T = p->p.dev;
   const bool ref_mode = !(p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS);
   if (ref_mode && !T.ref_find_ok) {
@@ -1062,6 +1105,7 @@ RGX_API int64_t rgx_match_batch_device(const rgx_program* p, rgx_stream_ctx* c, 
   if (rc != RGX_OK) return rc;
   if (nstr == 0) return 0;
   if (!d_concat || !d_offsets || !d_matched) return RGX_E_INVALID;
+  if ((rc = MatchViewBatch(p, c, d_concat, d_offsets, nstr, &d_concat)) != RGX_OK) return rc;
   if (!(p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS) && p->p.dev.ref_match_kind != 1) {
     // reference mode: MatchBytes' restart rule and prefix skip (compiler.go:740-871); the Thompson flavour (kind 1) has no such
     // rule and takes the plain path below

@@ -36,6 +36,7 @@ struct Builder {
   int ninst;
   std::vector<Node> nodes;  // index = node id (ids < ninst are rune instructions; others unused)
   bool has_utf8_class = false;
+  bool has_fffd_class = false;    // a decoding class that holds U+FFFD (every negated class does): broken UTF-8 matters to it
   bool has_bol = false, has_eol = false, has_bot = false, has_eot = false, has_wb = false;
   bool lookahead = false;
   std::bitset<256> word_bytes, nl_bytes;
@@ -49,8 +50,11 @@ struct Builder {
   // chain of byte-range nodes per UTF-8 sequence shape of its non-ASCII ranges (the standard range split, Go's validity
   // table: no overlongs, no surrogates, <= U+10FFFF), and -- when the class contains U+FFFD, as every negated class does
   // -- the bytes that can never begin a rune (80-BF, C0, C1, F5-FF), which DecodeRune reports as (RuneError, 1).
-  // Limitation (rgx_info.needs_valid_utf8): a lead byte followed by a wrong continuation byte is (RuneError, 1) in the
-  // reference too; that needs look-ahead and is not modelled, so results are exact on ASCII / valid UTF-8 input.
+  // A lead byte (C2-F4) that is NOT followed by its continuation bytes is (RuneError, 1) in the reference too; deciding that
+  // takes up to three bytes of look-ahead, which a byte-at-a-time automaton does not have.  It is settled outside the
+  // automaton: programs with such a class (Tables::needs_valid_utf8) have their input screened, and an input that holds a
+  // broken sequence is matched through a copy in which every broken lead byte reads 0xFF -- a byte that can never begin a rune,
+  // i.e. the same (RuneError, 1) to every instruction (rgx_kernels.hip: utf8_screen_kernel; offsets are unchanged).
   typedef std::vector<std::pair<int, int>> ByteSeq;   // one UTF-8 sequence shape: a byte range per position
   void Utf8Split(int32_t lo, int32_t hi, std::vector<ByteSeq>* out) {
     if (lo > hi) return;
@@ -180,6 +184,7 @@ struct Builder {
             for (auto& q : seqs) for (int c = q[0].first; c <= q[0].second; c++) nodes[pc].bytes.set(c);
           } else {
             has_utf8_class = true;
+            if (has_fffd) has_fffd_class = true;
             if (has_fffd) { seqs.push_back({{0x80, 0xBF}}); seqs.push_back({{0xC0, 0xC1}}); seqs.push_back({{0xF5, 0xFF}}); }
             std::vector<int> idx(seqs.size());
             for (size_t i = 0; i < seqs.size(); i++) idx[i] = (int)i;
@@ -393,7 +398,7 @@ Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOption
 
   Builder b(prog);
   t.lookahead_mode = b.lookahead;
-  t.needs_valid_utf8 = b.has_utf8_class;
+  t.needs_valid_utf8 = b.has_fffd_class;     // = "screen the input for broken sequences" (rgx_dfa.h)
   t.ncls = b.ncls;
   memcpy(t.cls, b.cls, 256);
   const int ncls = b.ncls, stride = ncls + 1;

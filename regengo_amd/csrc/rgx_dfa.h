@@ -39,7 +39,8 @@ struct Tables {
   bool can_match_empty = false;
   bool lookahead_mode = false;
   bool fixed_captures = false;
-  bool needs_valid_utf8 = false;  // a class with non-ASCII runes: exact on ASCII / valid UTF-8 input (rgx_dfa.cc, Builder)
+  bool needs_valid_utf8 = false;  // a decoding class that holds U+FFFD: the run time screens the input for lead bytes without their
+                                  // continuation bytes and matches such input through a sanitised copy (rgx_dfa.cc, Builder)
   int fixed_len = -1;             // byte length of every match when it is a constant, else -1
   int ref_match_engine = 0, ref_find_engine = 0;
   std::vector<std::string> cap_names;

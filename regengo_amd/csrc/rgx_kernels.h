@@ -118,4 +118,10 @@ hipError_t LaunchAttemptAt(const DevTables& T, const uint8_t* buf, int32_t len, 
 // commit point of one FindReader chunk (streaming.go:204-207): out2[0] = leading rows whose end <= limit, out2[1] = end of the last
 hipError_t LaunchCommitPoint(const int32_t* spans, int64_t n, int ncap, int32_t limit, long long* out2, hipStream_t stream);
 
+// Broken UTF-8 for programs with decoding classes that hold U+FFFD (Tables::needs_valid_utf8): dst == nullptr reports whether the
+// text holds a lead byte without its continuation bytes (*flag |= 1); with dst, writes the copy in which those bytes read 0xFF
+// (DecodeRune's (RuneError, 1) for every instruction; offsets unchanged).  The batch flavour keeps sequences inside their string.
+hipError_t LaunchUtf8Screen(const uint8_t* src, int64_t len, uint8_t* dst, unsigned* flag, hipStream_t stream);
+hipError_t LaunchUtf8ScreenBatch(const uint8_t* src, const uint64_t* offsets, int64_t nstr, uint8_t* dst, unsigned* flag, hipStream_t stream);
+
 }  // namespace rgx

@@ -1602,6 +1602,75 @@ hipError_t LaunchCommitPoint(const int32_t* spans, int64_t n, int ncap, int32_t 
   return hipGetLastError();
 }
 
+// ---- broken UTF-8 (instructions.go:205-295 decode with utf8.DecodeRune) ------------------------------------------------------
+// DecodeRune's verdict on a lead byte, restated (unicode/utf8: first[], acceptRanges): the lead byte at buf[i] heads a valid
+// sequence iff the next size-1 bytes exist before `end` and lie in the accept ranges; otherwise it is (RuneError, 1).
+namespace {
+__device__ __forceinline__ bool Utf8BrokenLead(const uint8_t* buf, long long i, long long end) {
+  const unsigned b0 = buf[i];
+  if (b0 < 0xC2u || b0 > 0xF4u) return false;                 // ASCII, or a byte that can never begin a rune (already RuneError)
+  const int size = b0 < 0xE0u ? 2 : (b0 < 0xF0u ? 3 : 4);
+  if (i + size > end) return true;                            // truncated by the end of the text
+  unsigned lo = 0x80u, hi = 0xBFu;
+  if (b0 == 0xE0u) lo = 0xA0u; else if (b0 == 0xEDu) hi = 0x9Fu; else if (b0 == 0xF0u) lo = 0x90u; else if (b0 == 0xF4u) hi = 0x8Fu;
+  const unsigned b1 = buf[i + 1];
+  if (b1 < lo || b1 > hi) return true;
+  if (size > 2) { const unsigned b2 = buf[i + 2]; if (b2 < 0x80u || b2 > 0xBFu) return true; }
+  if (size > 3) { const unsigned b3 = buf[i + 3]; if (b3 < 0x80u || b3 > 0xBFu) return true; }
+  return false;
+}
+// One lane per 16 input bytes.  dst == nullptr: only report (flag[0] |= 1 when a broken lead exists); else copy src to dst with
+// every broken lead byte replaced by 0xFF.
+__global__ __launch_bounds__(256) void utf8_screen_kernel(const uint8_t* src, long long len, uint8_t* dst, unsigned* flag) {
+  const long long c = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long i0 = c << 4;
+  bool any = false;
+  if (i0 < len) {
+    uint4 v;
+    unsigned char b[16];
+    if (i0 + 16 <= len) v = *reinterpret_cast<const uint4*>(src + i0);
+    else { v = make_uint4(0, 0, 0, 0); unsigned char* q = reinterpret_cast<unsigned char*>(&v); for (long long k = i0; k < len; ++k) q[k - i0] = src[k]; }
+    *reinterpret_cast<uint4*>(b) = v;
+    if ((v.x | v.y | v.z | v.w) & 0x80808080u) {             // ASCII chunks (the common case) stop here
+      for (int k = 0; k < 16 && i0 + k < len; ++k)
+        if (b[k] >= 0xC2u && Utf8BrokenLead(src, i0 + k, len)) { any = true; b[k] = 0xFF; }
+    }
+    if (dst) {
+      if (i0 + 16 <= len) *reinterpret_cast<uint4*>(dst + i0) = *reinterpret_cast<const uint4*>(b);
+      else for (long long k = i0; k < len; ++k) dst[k] = b[k - i0];
+    }
+  }
+  if (!dst && __any(any) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+// Batch flavour: a sequence may not borrow continuation bytes from the next string.  One lane per string; always writes the copy
+// (the strings of a batch are short: one pass instead of a screen and a copy) and reports whether anything was replaced.
+__global__ __launch_bounds__(256) void utf8_screen_batch_kernel(const uint8_t* src, const uint64_t* offsets, long long nstr, uint8_t* dst,
+                                                                unsigned* flag) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  bool any = false;
+  if (i < nstr) {
+    const long long o0 = (long long)offsets[i], o1 = (long long)offsets[i + 1];
+    for (long long k = o0; k < o1; ++k) {
+      unsigned char x = src[k];
+      if (x >= 0xC2u && Utf8BrokenLead(src, k, o1)) { x = 0xFF; any = true; }
+      dst[k] = x;
+    }
+  }
+  if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+}  // namespace
+hipError_t LaunchUtf8Screen(const uint8_t* src, int64_t len, uint8_t* dst, unsigned* flag, hipStream_t stream) {
+  if (len <= 0) return hipSuccess;
+  const long long chunks = (len + 15) >> 4;
+  hipLaunchKernelGGL(utf8_screen_kernel, dim3((unsigned)((chunks + 255) / 256)), dim3(256), 0, stream, src, (long long)len, dst, flag);
+  return hipGetLastError();
+}
+hipError_t LaunchUtf8ScreenBatch(const uint8_t* src, const uint64_t* offsets, int64_t nstr, uint8_t* dst, unsigned* flag, hipStream_t stream) {
+  if (nstr <= 0) return hipSuccess;
+  hipLaunchKernelGGL(utf8_screen_batch_kernel, dim3((unsigned)((nstr + 255) / 256)), dim3(256), 0, stream, src, offsets, (long long)nstr, dst, flag);
+  return hipGetLastError();
+}
+
 hipError_t LaunchCarry(const DevTables& T, const uint8_t* buf, int32_t len, const uint8_t* slice_unsynced, int32_t* carry_in,
                        int32_t nslices, hipStream_t stream) {
   dim3 block(256), grid((nslices + 255) / 256);

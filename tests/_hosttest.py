@@ -24,6 +24,9 @@ _lib.rgxt_roundtrip.argtypes = [C.c_void_p]
 _lib.rgxt_sa_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
 _lib.rgxt_reset_bytes.argtypes = [C.c_void_p, C.c_void_p]
 
+_lib.rgxt_sanitize_utf8.restype = C.c_int64
+_lib.rgxt_sanitize_utf8.argtypes = [C.c_char_p, C.c_int64, C.c_void_p]
+
 _lib.rgxt_compile_us.restype = C.c_void_p
 _lib.rgxt_compile_us.argtypes = [C.c_char_p, C.c_uint32, C.c_int, C.c_int]
 _lib.rgxt_free_us.argtypes = [C.c_void_p]
@@ -37,6 +40,13 @@ _lib.rgxt_ref_find.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p]
 _lib.rgxt_ref_match.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
 
 INFO = ["ncap", "min", "max", "ninst", "nstates", "ncls", "anchored", "fixed", "empty", "refm", "reff", "look", "maxthr"]
+
+
+def sanitize_utf8(b: bytes):
+    """(bytes as the run time matches them, number of broken lead bytes replaced by 0xFF)."""
+    out = C.create_string_buffer(max(len(b), 1))
+    n = _lib.rgxt_sanitize_utf8(b, len(b), out)
+    return out.raw[:len(b)], int(n)
 
 
 class HostProgram:
