@@ -269,12 +269,11 @@ def run_c5(gib, max_patterns, mib=0, skip=()):
                 stats["ok"] += 1
             else:
                 stats["bad"].append(p)
-        except (Timeout, NotImplementedError, Exception) as ex:
-            if isinstance(ex, _capi.RgxError):
-                stats["bad"].append(p + "  [" + str(ex)[:80] + "]")
-            else:
-                stats["oracle_timeout"] += 1
-                log.write("%d oracle/other failure %r\n" % (pi, str(ex)[:100])); log.flush()
+        except _capi.RgxError as ex:           # a status from the library is a failure of the product: reported as bad
+            stats["bad"].append(p + "  [" + str(ex)[:80] + "]")
+        except (Timeout, NotImplementedError) as ex:      # the ORACLE gave up (super-linear pattern, unsupported construct)
+            stats["oracle_timeout"] += 1
+            log.write("%d oracle gave up %r\n" % (pi, str(ex)[:100])); log.flush()
     stats.pop("lines_buf", None)
     stats["aggregate_GBps_wall"] = round(stats["bytes_scanned"] / max(stats["wall_s"], 1e-9) / 1e9, 1)
     stats["elapsed_s"] = round(time.perf_counter() - t_start, 1)
