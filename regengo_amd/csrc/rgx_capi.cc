@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -18,6 +19,9 @@ using namespace rgx;
 
 struct rgx_program {
   Program p;
+  // learned at run time, kept with the PROGRAM so that every context (and a context handed from program to program,
+  // rgx_stream_ctx_rebind) starts where the last scan ended: this pattern's texts need the sync automaton W
+  mutable std::atomic<int> prefer_w{0};
 };
 
 struct rgx_stream_ctx {
@@ -249,6 +253,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     // slices without a reset byte in reach: take the sync points from W from now on (this context remembers)
     use_w = true;
     c->prefer_w = true;
+    p->prefer_w.store(1, std::memory_order_relaxed);
     ntiles = ScanNumTiles(T, ilen, true);
     P.ntiles = ntiles;
     P.use_w = 1;
@@ -444,6 +449,7 @@ RGX_API int rgx_stream_ctx_create_on_stream(const rgx_program* p, void* hip_stre
   if (!p->p.d_arena) { SetError("program not on a device (rgx_program_to_device)"); return RGX_E_NO_DEVICE; }
   auto* c = new rgx_stream_ctx();
   c->prog = p;
+  c->prefer_w = p->prefer_w.load(std::memory_order_relaxed) != 0;
   c->device = p->p.device;
   if (hipSetDevice(c->device) != hipSuccess) { delete c; return RGX_E_NO_DEVICE; }
   bool stream_ok;
@@ -482,7 +488,7 @@ RGX_API int rgx_stream_ctx_rebind(rgx_stream_ctx* c, const rgx_program* p) {
   if (p->p.device != c->device) { SetError("context and program live on different devices"); return RGX_E_INVALID; }
   if (c->pend_count != 0) { SetError("context has scans in flight (rgx_find_all_wait first)"); return RGX_E_INVALID; }
   c->prog = p;
-  c->prefer_w = false;
+  c->prefer_w = p->prefer_w.load(std::memory_order_relaxed) != 0;
   c->tmpl_key.clear();
   return RGX_OK;
 }

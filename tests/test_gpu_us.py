@@ -127,3 +127,28 @@ def test_us_kernel_without_sync_points_takes_the_carry_path(torch_dev):
         seen_unsynced += int(res.unsynced)
         assert res.total == cnt and np.array_equal(spans.cpu().numpy(), exp), (len(b), cnt, int(res.total))
     assert seen_unsynced > 0
+
+
+def test_patterns_without_reset_bytes(torch_dev):
+    """Patterns whose every byte keeps some thread alive (a tail that survives the newline, a negated class, (?s).*) have no
+    reset-byte sync points: they are eligible for the start-tracking automaton but must take the sync automaton W (generic
+    kernel).  Rows against the oracle's generated-C matcher on the web-log text, on text with very long lines, and on text
+    without any sync point for kilobytes."""
+    import numpy as np
+    from oracle.gen_c import CMatcher
+    from regengo_amd import Compiled, synth
+    tile = synth.web_log_tile(1 << 19)
+    long_lines = (b"x" * 700 + b" bob@example.com rest of the line " + b"y" * 900 + b"\n") * 150
+    texts = [tile, long_lines, tile[:70_000] + b"a@b " + b"q" * 9000 + b"\n" + tile[:50_000]]
+    pats = [r"(?P<full>(?P<name>[\w.+-]+)@(?P<host>[\w.-]+))(?P<extra>\s.*)?", r"(?P<k>[a-z]+)=(?P<v>[^;]*)", r"(?s)GET.*?\d",
+            r"(?P<w>\w+)(?P<rest>\s[^\n]*)?", r"\[(?P<level>\w+)\]\s+(?P<msg>.*)"]
+    for pat in pats:
+        c = Compiled(pat, stdlib=True).to(0)
+        cm = CMatcher(pat)
+        for t in texts:
+            exp, cnt = cm.find_all_np(np.frombuffer(t, dtype=np.uint8))
+            spans, res = c.FindAllSpans(t)
+            assert res.total == cnt, (pat, res.total, cnt)
+            assert np.array_equal(spans.cpu().numpy(), exp), pat
+            n, _r = c.CountAll(t)
+            assert n == cnt
