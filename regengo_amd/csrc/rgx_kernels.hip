@@ -856,15 +856,22 @@ constexpr int kBatchWindow = 16384;      // input bytes staged per group of 256 
                                          // launches over short strings pass 8192: one more workgroup fits a CU
 constexpr int kBatchTrace = 64;          // uint16 state-trace entries per lane kept in LDS (matches up to 63 bytes)
 
-struct BtTabs {
-  const uint32_t* st_nthreads;
-  const uint32_t* bt_base;
-  const uint8_t* bt_parent;
-  const uint32_t* bt_ops;
-  const uint32_t* bt_match;
-  const uint32_t* start_ops;
-  const uint32_t* start_ops_pool;
+// Back-trace tables: in LDS (address-space-qualified pointers: ds_read) or in global memory.  A plain pointer that may be either
+// makes every access a FLAT load -- 41 M of them per 9 M matches in the capture pass, which then took longer than the scan it follows.
+typedef const uint32_t __attribute__((address_space(3)))* Lds32;
+typedef const uint8_t __attribute__((address_space(3)))* Lds8;
+template <class P32, class P8>
+struct BtTabsT {
+  P32 st_nthreads;
+  P32 bt_base;
+  P8 bt_parent;
+  P32 bt_ops;
+  P32 bt_match;
+  P32 start_ops;
+  P32 start_ops_pool;
 };
+typedef BtTabsT<const uint32_t*, const uint8_t*> BtTabs;
+typedef BtTabsT<Lds32, Lds8> BtTabsLds;
 
 struct BatchInput {
   const uint8_t* g;       // global: first byte of this lane's string
@@ -903,16 +910,16 @@ __device__ __forceinline__ int WalkBatch(const Tab<MODE>& tab, const BatchInput&
 }
 
 // ResolveCaptures over LDS-resident tables; rec points into LDS.
-template <int MODE, class TraceT = uint16_t>
-__device__ __forceinline__ void ResolveCapturesBatch(const Tab<MODE>& tab, const BtTabs& B, const DevTables& T, const uint8_t* cls,
-                                                     const uint8_t* ctx_of_byte, const BatchInput& in, int s, int e, TraceT* trace_base,
+template <int MODE, class TraceT = uint16_t, class In = BatchInput, class BT = BtTabs, class TraceP = TraceT*>
+__device__ __forceinline__ void ResolveCapturesBatch(const Tab<MODE>& tab, const BT& B, const DevTables& T, const uint8_t* cls,
+                                                     const uint8_t* ctx_of_byte, const In& in, int s, int e, TraceP trace_base,
                                                      int ts, int32_t* rec) {
   // trace entry i lives at trace_base[i * ts]: the LDS traces of a workgroup are interleaved (ts = workgroup size, lane l starts at
   // base + l), so step i of every lane is one conflict-free row; a lane-major layout (ts = 1, 64 or 128 bytes per lane) puts the
   // same step of all lanes into the same bank -- a 32- to 64-way conflict on every access (6.7 ms of 7.7 on the C3 batch)
   struct Tr {
-    TraceT* b; int ts;
-    __device__ __forceinline__ TraceT& operator[](int i) const { return b[i * ts]; }
+    TraceP b; int ts;
+    __device__ __forceinline__ auto& operator[](int i) const { return b[i * ts]; }
   } trace{trace_base, ts};
   const int ncap = T.ncap;
   const int unset = T.unmatched_minus1 ? -1 : 0;
@@ -1172,7 +1179,25 @@ __global__ __launch_bounds__(kBlockThreads) void batch_lds_kernel(DevTables T, c
 // ---- captures from LDS: the same re-walk + back-trace as caps_kernel with the transition table, the back-trace pools,
 // a 16 KiB window of the input and every lane's state trace on chip (caps_kernel pays two dependent L1/L2 round trips
 // per byte in each direction).  256 matches per group; the group's records leave through LDS as 16-byte stores.
-constexpr int kCapsWindow = 8192;
+// Input bytes of the capture pass: every lane keeps the bytes of ITS match -- [start - 1, end] plus alignment, up to kCapsRow --
+// in LDS, dword j of lane l at dword j * 256 + l (a byte read of all lanes at the same offset touches every bank once).  The
+// matches of a group are spread over far more input than they cover (URLs: 256 matches of ~30 bytes over 30 KB), so a shared
+// window of the group's span misses most of them (with 8 KiB three quarters of the lanes walked through global loads).
+constexpr int kCapsRow = 96;                                  // bytes per lane: six 16-byte loads
+constexpr int kCapsWindow = kCapsRow * kBlockThreads;         // 24 KiB
+struct PrivInput {
+  const uint8_t* g;        // global: byte 0 of the text
+  Lds8 row;                // LDS: this lane's dword 0 (dword j at row + j * 1024)
+  int p0;                  // text offset of the row's first byte (16-byte aligned)
+  int nrow;                // valid bytes in the row
+  int len;
+  __device__ __forceinline__ int At(int i) const {
+    const unsigned r = (unsigned)(i - p0);
+    if (r < (unsigned)nrow) return row[((r >> 2) << 10) + (r & 3u)];
+    return g[i];
+  }
+};
+
 
 template <int MODE, class TraceT>
 __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, const uint8_t* buf, int32_t len, int32_t* spans,
@@ -1206,19 +1231,19 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
   tab.stride = T.stride;
   tab.nstates = T.nstates;
   const uint8_t* ctx_of_byte = smem + Y.ctx;
-  BtTabs B;
-  if (Y.bt_in_lds) {
-    B.st_nthreads = reinterpret_cast<const uint32_t*>(smem + Y.bt_nth);
-    B.bt_base = reinterpret_cast<const uint32_t*>(smem + Y.bt_base);
-    B.bt_match = reinterpret_cast<const uint32_t*>(smem + Y.bt_match);
-    B.bt_ops = reinterpret_cast<const uint32_t*>(smem + Y.bt_ops);
-    B.bt_parent = smem + Y.bt_parent;
-    B.start_ops = reinterpret_cast<const uint32_t*>(smem + Y.st_ops);
-    B.start_ops_pool = reinterpret_cast<const uint32_t*>(smem + Y.st_pool);
-  } else {
-    B.st_nthreads = T.st_nthreads; B.bt_base = T.bt_base; B.bt_match = T.bt_match; B.bt_ops = T.bt_ops;
-    B.bt_parent = T.bt_parent; B.start_ops = T.start_ops; B.start_ops_pool = T.start_ops_pool;
-  }
+  BtTabsLds BL;
+  BL.st_nthreads = (Lds32)(smem + Y.bt_nth);
+  BL.bt_base = (Lds32)(smem + Y.bt_base);
+  BL.bt_match = (Lds32)(smem + Y.bt_match);
+  BL.bt_ops = (Lds32)(smem + Y.bt_ops);
+  BL.bt_parent = (Lds8)(smem + Y.bt_parent);
+  BL.start_ops = (Lds32)(smem + Y.st_ops);
+  BL.start_ops_pool = (Lds32)(smem + Y.st_pool);
+  BtTabs BG;
+  BG.st_nthreads = T.st_nthreads; BG.bt_base = T.bt_base; BG.bt_match = T.bt_match; BG.bt_ops = T.bt_ops;
+  BG.bt_parent = T.bt_parent; BG.start_ops = T.start_ops; BG.start_ops_pool = T.start_ops_pool;
+  const bool bt_lds = Y.bt_in_lds != 0;
+  typedef TraceT __attribute__((address_space(3)))* LdsTrace;
   unsigned char* const win = smem + Y.window;
   int32_t* const recs = reinterpret_cast<int32_t*>(smem + Y.recs);
   const int64_t ngroups = (nmatches + kBlockThreads - 1) / kBlockThreads;
@@ -1227,25 +1252,40 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
     const int64_t i0 = grp * kBlockThreads;
     const int64_t i = i0 + tid;
     const int64_t ilast = min(i0 + (int64_t)kBlockThreads, nmatches);
-    // the group's matches are ordered: its bytes are [start of the first - 1, end of the last + 1)
-    const int32_t gs = spans[i0 * ncap], ge = spans[(ilast - 1) * ncap + 1];
-    const int32_t wb = (gs > 0 ? gs - 1 : 0) & ~15;
-    const int64_t span_bytes = (int64_t)(ge < len ? ge + 1 : len) - wb;
-    const int wvalid = (int)min((int64_t)kCapsWindow, (span_bytes + 15) & ~15ll);    // whole 16-byte chunks (never a page)
-    __syncthreads();
-    for (int c = tid; c < (wvalid >> 4); c += kBlockThreads)
-      *reinterpret_cast<uint4*>(win + (c << 4)) = *reinterpret_cast<const uint4*>(buf + wb + ((int64_t)c << 4));
     int s = 0, e = 0;
     if (i < nmatches) { s = spans[i * ncap]; e = spans[i * ncap + 1]; }
-    __syncthreads();
-    BatchInput in;
-    in.g = buf; in.lds = win; in.rel0 = -wb; in.wvalid = wvalid; in.len = len;
+    __syncthreads();                                   // the previous group's records have left `recs`
+    PrivInput in;
+    in.g = buf; in.row = (Lds8)(win + (tid << 2)); in.len = len;
+    in.p0 = (s > 0 ? s - 1 : 0) & ~15;
+    {
+      // whole 16-byte chunks that begin inside the text (the last one may run past `len` inside its chunk: never a page)
+      int n = ((len - in.p0) + 15) & ~15;
+      in.nrow = n < kCapsRow ? (n < 0 ? 0 : n) : kCapsRow;
+      if (i >= nmatches) in.nrow = 0;
+      uint4 v[kCapsRow / 16];
+#pragma unroll
+      for (int c = 0; c < kCapsRow / 16; ++c)
+        v[c] = (c << 4) < in.nrow ? *reinterpret_cast<const uint4*>(buf + in.p0 + (c << 4)) : make_uint4(0, 0, 0, 0);
+      unsigned* rowd = reinterpret_cast<unsigned*>(win) + tid;
+#pragma unroll
+      for (int c = 0; c < kCapsRow / 16; ++c) {
+        rowd[(4 * c + 0) << 8] = v[c].x; rowd[(4 * c + 1) << 8] = v[c].y; rowd[(4 * c + 2) << 8] = v[c].z; rowd[(4 * c + 3) << 8] = v[c].w;
+      }
+    }
+    // (a lane reads only its own row: no barrier between the staging and the walk)
     int32_t* rec = recs + tid * ncap;
     if (i < nmatches) {
       const int need = e - s + 1;
-      const bool in_lds = need <= kBatchTrace;
-      TraceT* tr = in_lds ? reinterpret_cast<TraceT*>(smem + Y.trace) + tid : gtrace + atomicAdd(cursor, (unsigned long long)need);
-      ResolveCapturesBatch<MODE, TraceT>(tab, B, T, tab.cls, ctx_of_byte, in, s, e, tr, in_lds ? kBlockThreads : 1, rec);
+      if (need <= kBatchTrace) {
+        LdsTrace tr = (LdsTrace)(smem + Y.trace) + tid;
+        if (bt_lds) ResolveCapturesBatch<MODE, TraceT, PrivInput, BtTabsLds, LdsTrace>(tab, BL, T, tab.cls, ctx_of_byte, in, s, e, tr, kBlockThreads, rec);
+        else ResolveCapturesBatch<MODE, TraceT, PrivInput, BtTabs, LdsTrace>(tab, BG, T, tab.cls, ctx_of_byte, in, s, e, tr, kBlockThreads, rec);
+      } else {
+        TraceT* tr = gtrace + atomicAdd(cursor, (unsigned long long)need);
+        if (bt_lds) ResolveCapturesBatch<MODE, TraceT, PrivInput, BtTabsLds, TraceT*>(tab, BL, T, tab.cls, ctx_of_byte, in, s, e, tr, 1, rec);
+        else ResolveCapturesBatch<MODE, TraceT, PrivInput, BtTabs, TraceT*>(tab, BG, T, tab.cls, ctx_of_byte, in, s, e, tr, 1, rec);
+      }
     }
     __syncthreads();
     const int nrec_words = (int)(ilast - i0) * ncap;
