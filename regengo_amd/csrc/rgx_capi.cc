@@ -1077,9 +1077,12 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
     const int64_t need = ((int64_t)h_last + 2 * (int64_t)nstr + 64 + 1) / 2 * (U->nstates <= 256 ? 1 : 2);   // in uint16 units
     int64_t need_fix = ref_mode ? (int64_t)h_last + 2 * (int64_t)nstr + 64 : 0;
     if ((rc = Ensure(&c->d_trace, &c->trace_cap, std::max(need, need_fix))) != RGX_OK) return rc;
+    // reference mode: the search kernel replays the attempt offsets itself (on the staged bytes); the strings it flags -- the
+    // sequence stepped over the leftmost-first start -- are finished by the second launch
+    const bool fused = ref_mode && BatchSearchFits(*U, T, true, d_concat, true);
     HIP_TRY(LaunchBatchSearch(*U, T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, c->d_trace, c->stream,
-                              BatchWindowFor((int64_t)h_last, (int64_t)nstr)));
-    if (ref_mode) HIP_TRY(LaunchBatchRefFix(T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, c->d_trace, c->stream));
+                              BatchWindowFor((int64_t)h_last, (int64_t)nstr), fused ? 1 : 0));
+    if (ref_mode) HIP_TRY(LaunchBatchRefFix(T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, c->d_trace, c->stream, fused ? 1 : 0));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return (int64_t)nstr;
   }

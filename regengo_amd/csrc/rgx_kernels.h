@@ -88,14 +88,14 @@ hipError_t LaunchBatchRef(const DevTables& T, const uint8_t* concat, const uint6
 // which replays the reference's attempt offsets with failure offsets only (linear; the attempt-per-offset loop is quadratic in
 // the length of a word).  Not for anchored patterns (nothing to replay) -- harmless there.
 hipError_t LaunchBatchRefFix(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,
-                             int32_t* spans, uint16_t* trace, hipStream_t stream);
+                             int32_t* spans, uint16_t* trace, hipStream_t stream, int only_flagged = 0);
 
 // Same entry points through the search automaton U (rgx_program.h: SearchTables): one forward walk per string.
 // `trace` is scratch of (total bytes + 2*nstr + 64) entries of uint8 (U.nstates <= 256) or uint16, used by strings
 // longer than the LDS trace.
-bool BatchSearchFits(const DevTables& U, const DevTables& F, bool want_spans, const uint8_t* concat);
+bool BatchSearchFits(const DevTables& U, const DevTables& F, bool want_spans, const uint8_t* concat, bool with_ref = false);
 hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8_t* concat, const uint64_t* offsets, int64_t nstr,
-                             uint8_t* found, int32_t* spans, void* trace, hipStream_t stream, int window_bytes = 0);
+                             uint8_t* found, int32_t* spans, void* trace, hipStream_t stream, int window_bytes = 0, int ref = 0);
 
 // ---- Replace path (rgx_replace.hip).  A resolved template segment: kind 0 = literal bytes lits[a, a+b); kind 1 = the text of
 // capture group a (0 = the whole match).

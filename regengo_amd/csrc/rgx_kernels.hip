@@ -809,10 +809,11 @@ __global__ __launch_bounds__(64) void ref_batch_kernel(DevTables T, const uint8_
 // on from there with full attempts, as ref_batch_kernel does).  The attempt-per-offset loop walks a word of n bytes n/2 times
 // (quadratic: 7.7 ms on the C3 batch against 1 ms for the plain search); this is linear.
 __global__ __launch_bounds__(64) void ref_fix_kernel(DevTables T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr,
-                                                     uint8_t* found, int32_t* spans, uint16_t* trace) {
+                                                     uint8_t* found, int32_t* spans, uint16_t* trace, int only_flagged) {
   __shared__ uint16_t s_trace[64 * kCapsLdsTrace];
   const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (i >= nstr || !found[i]) return;           // no match anywhere in the string: the emitted loop finds none either
+  if (only_flagged && found[i] != 2) return;    // (the search kernel has replayed the others itself)
   const uint64_t o0 = offsets[i], o1 = offsets[i + 1];
   const uint8_t* buf = concat + o0;
   const int len = (int)(o1 - o0);
@@ -825,7 +826,7 @@ __global__ __launch_bounds__(64) void ref_fix_kernel(DevTables T, const uint8_t*
     if (!(len > fo)) { lost = true; break; }
     off = fo + 1;
   }
-  if (!lost && off == s0) return;                // the attempt at s0 is made, and it is the one that matches
+  if (!lost && off == s0) { found[i] = 1; return; }   // the attempt at s0 is made, and it is the one that matches
   int s = -1, e = -1;
   while (!lost) {                                // stepped over s0: full attempts from here on (find.go:545-569)
     const int end = WalkGlobal(T, buf, len, off);
@@ -1344,12 +1345,31 @@ __host__ __device__ inline SearchLayout SearchLdsLayout(const DevTables& U, int 
 template <int MODE, class TraceT>
 __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U, DevTables F, const uint8_t* concat,
                                                                       const uint64_t* offsets, int64_t nstr, uint8_t* found,
-                                                                      int32_t* spans, TraceT* gtrace, int window_bytes) {
+                                                                      int32_t* spans, TraceT* gtrace, int window_bytes, int ref) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const bool want_spans = spans != nullptr;
   const int ncap = F.ncap;
   const SearchLayout Y = SearchLdsLayout(U, ncap, want_spans, (int)sizeof(TraceT), window_bytes);
+  // ref (FindBytes in reference mode, spans wanted): the replay of the reference's attempt offsets (ref_fix_kernel has the
+  // commentary) runs right here, on the staged bytes, with the right-most-path automaton of F staged behind the layout:
+  // [rm_trans u16][rm_depth u8][F.cls 256][F.ctx_of_byte 256].  Strings whose sequence steps over the leftmost-first start get
+  // found = 2 and are finished by ref_fix_kernel (rare).
+  const int rm_cells = ref ? F.rm_nstates[0] * F.stride : 0;
+  unsigned char* const rm_base = smem + Y.total;
+  const uint16_t* const s_rm = reinterpret_cast<const uint16_t*>(rm_base);
+  const uint8_t* const s_rmd = rm_base + ((rm_cells * 2 + 15) & ~15);
+  const uint8_t* const s_fcls = s_rmd + ((F.rm_nstates[0] + 15) & ~15);
+  const uint8_t* const s_fctx = s_fcls + 256;
+  if (ref) {
+    uint16_t* d = reinterpret_cast<uint16_t*>(rm_base);
+    for (int i = tid; i < rm_cells; i += kBlockThreads) d[i] = F.rm_trans[0][i];
+    unsigned char* dd = rm_base + ((rm_cells * 2 + 15) & ~15);
+    for (int i = tid; i < F.rm_nstates[0]; i += kBlockThreads) dd[i] = F.rm_depth[0][i];
+    unsigned char* dc = dd + ((F.rm_nstates[0] + 15) & ~15);
+    dc[tid] = F.cls[tid];
+    dc[256 + tid] = F.ctx_of_byte[tid];
+  }
   {
     const uint4* src = reinterpret_cast<const uint4*>(U.trans);
     uint4* dst = reinterpret_cast<uint4*>(smem + Y.trans);
@@ -1474,6 +1494,26 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
         if (F.fixed_captures) {
           const int s = rec[0];
           for (int c = 2; c < ncap; ++c) rec[c] = F.cap_kind[c] == kCapFromStart ? s + F.cap_delta[c] : end - F.cap_delta[c];
+        }
+        if (ref && !F.anchored) {
+          const int s0 = rec[0];
+          int off = 0;
+          bool lost = false;
+          while (off < s0) {
+            // failure offset of the attempt at `off`: where its right-most path dies (find.go:545-569 resumes behind it)
+            unsigned st = F.rm_start[0][off == 0 ? kCtxBOT : s_fctx[in.At(off - 1)]];
+            int fo = off;
+            for (int p = off;; ++p) {
+              const unsigned k = p < in.len ? (unsigned)s_fcls[in.At(p)] : (unsigned)F.ncls;
+              const unsigned nx = s_rm[st * F.stride + k];
+              if (nx == 0xFFFFu) { fo = p - (int)s_rmd[st]; break; }
+              st = nx;
+            }
+            if (!(in.len > fo)) { lost = true; break; }
+            off = fo + 1;
+          }
+          if (lost) { found[i] = 0; for (int c = 0; c < ncap; ++c) rec[c] = unset; }
+          else if (off != s0) found[i] = 2;          // stepped over the leftmost-first start: ref_fix_kernel goes on from there
         }
       }
     }
@@ -1801,10 +1841,10 @@ hipError_t LaunchBatchRef(const DevTables& T, const uint8_t* concat, const uint6
 }
 
 hipError_t LaunchBatchRefFix(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,
-                             int32_t* spans, uint16_t* trace, hipStream_t stream) {
+                             int32_t* spans, uint16_t* trace, hipStream_t stream, int only_flagged) {
   if (nstr <= 0) return hipSuccess;
   dim3 block(64), grid((unsigned)((nstr + 63) / 64));
-  hipLaunchKernelGGL(ref_fix_kernel, grid, block, 0, stream, T, concat, offsets, nstr, found, spans, trace);
+  hipLaunchKernelGGL(ref_fix_kernel, grid, block, 0, stream, T, concat, offsets, nstr, found, spans, trace, only_flagged);
   return hipGetLastError();
 }
 
@@ -1815,18 +1855,20 @@ int BatchWindowFor(int64_t total_bytes, int64_t nstr) {
 }
 
 hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8_t* concat, const uint64_t* offsets, int64_t nstr,
-                             uint8_t* found, int32_t* spans, void* trace, hipStream_t stream, int window_bytes) {
+                             uint8_t* found, int32_t* spans, void* trace, hipStream_t stream, int window_bytes, int ref) {
   if (nstr <= 0) return hipSuccess;
   if (window_bytes <= 0) window_bytes = kBatchWindow;
   const bool t8 = U.nstates <= 256;
   const SearchLayout Y = SearchLdsLayout(U, F.ncap, spans != nullptr, t8 ? 1 : 2, window_bytes);
+  if (!spans) ref = 0;
+  const int rm_bytes = ref ? ((F.rm_nstates[0] * F.stride * 2 + 15) & ~15) + ((F.rm_nstates[0] + 15) & ~15) + 512 : 0;
   static int cus = 0;
   if (!cus) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
   }
   const int64_t ngroups = (nstr + kBlockThreads - 1) / kBlockThreads;
-  int per_cu = (160 * 1024) / (Y.total + 1024);
+  int per_cu = (160 * 1024) / (Y.total + rm_bytes + 1024);
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 8) per_cu = 8;
   int64_t grid = (int64_t)cus * per_cu * 4;
@@ -1839,8 +1881,8 @@ hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8
       if (e != hipSuccess) return e;                                                                                  \
       attr = true;                                                                                                    \
     }                                                                                                                 \
-    hipLaunchKernelGGL((batch_search_kernel<MODE, TT>), dim3((unsigned)grid), dim3(kBlockThreads), (size_t)Y.total, stream, U, F,   \
-                       concat, offsets, nstr, found, spans, (TT*)trace, window_bytes);                                \
+    hipLaunchKernelGGL((batch_search_kernel<MODE, TT>), dim3((unsigned)grid), dim3(kBlockThreads), (size_t)(Y.total + rm_bytes), stream, U, F,   \
+                       concat, offsets, nstr, found, spans, (TT*)trace, window_bytes, ref);                           \
   } while (0)
   if (U.mode == kModeDirect) { if (t8) RGX_GO(kModeDirect, uint8_t); else RGX_GO(kModeDirect, uint16_t); }
   else { if (t8) RGX_GO(kModeClassLds, uint8_t); else RGX_GO(kModeClassLds, uint16_t); }
@@ -1848,9 +1890,10 @@ hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8
   return hipGetLastError();
 }
 
-bool BatchSearchFits(const DevTables& U, const DevTables& F, bool want_spans, const uint8_t* concat) {
+bool BatchSearchFits(const DevTables& U, const DevTables& F, bool want_spans, const uint8_t* concat, bool with_ref) {
   if (U.mode == kModeClassGlobal || F.ncap > 32 || (((uintptr_t)concat) & 15) != 0) return false;
-  return SearchLdsLayout(U, F.ncap, want_spans, U.nstates <= 256 ? 1 : 2).total <= 150 * 1024;
+  const int rm_bytes = with_ref ? ((F.rm_nstates[0] * F.stride * 2 + 15) & ~15) + ((F.rm_nstates[0] + 15) & ~15) + 512 : 0;
+  return SearchLdsLayout(U, F.ncap, want_spans, U.nstates <= 256 ? 1 : 2).total + rm_bytes <= 150 * 1024;
 }
 
 hipError_t LaunchBatch(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,
