@@ -1393,19 +1393,17 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
   tab.cls = smem + Y.cls;
   tab.stride = U.stride;
   tab.nstates = U.nstates;
-  BtTabs B;
-  if (Y.bt_in_lds) {
-    B.st_nthreads = reinterpret_cast<const uint32_t*>(smem + Y.bt_nth);
-    B.bt_base = reinterpret_cast<const uint32_t*>(smem + Y.bt_base);
-    B.bt_match = reinterpret_cast<const uint32_t*>(smem + Y.bt_match);
-    B.bt_ops = reinterpret_cast<const uint32_t*>(smem + Y.bt_ops);
-    B.bt_parent = smem + Y.bt_parent;
-    B.start_ops = reinterpret_cast<const uint32_t*>(smem + Y.st_ops);
-    B.start_ops_pool = reinterpret_cast<const uint32_t*>(smem + Y.st_pool);
-  } else {
-    B.st_nthreads = U.st_nthreads; B.bt_base = U.bt_base; B.bt_match = U.bt_match; B.bt_ops = U.bt_ops;
-    B.bt_parent = U.bt_parent; B.start_ops = U.start_ops; B.start_ops_pool = U.start_ops_pool;
-  }
+  BtTabsLds BL;
+  BL.st_nthreads = (Lds32)(smem + Y.bt_nth);
+  BL.bt_base = (Lds32)(smem + Y.bt_base);
+  BL.bt_match = (Lds32)(smem + Y.bt_match);
+  BL.bt_ops = (Lds32)(smem + Y.bt_ops);
+  BL.bt_parent = (Lds8)(smem + Y.bt_parent);
+  BL.start_ops = (Lds32)(smem + Y.st_ops);
+  BL.start_ops_pool = (Lds32)(smem + Y.st_pool);
+  BtTabs BG;
+  BG.st_nthreads = U.st_nthreads; BG.bt_base = U.bt_base; BG.bt_match = U.bt_match; BG.bt_ops = U.bt_ops;
+  BG.bt_parent = U.bt_parent; BG.start_ops = U.start_ops; BG.start_ops_pool = U.start_ops_pool;
   unsigned char* const win = smem + Y.window;
   int32_t* const recs = reinterpret_cast<int32_t*>(smem + Y.recs);
   const int64_t ngroups = (nstr + kBlockThreads - 1) / kBlockThreads;
@@ -1430,93 +1428,103 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
     BatchInput in;
     in.g = concat + o0; in.lds = win; in.rel0 = (int)min(o0 - wb, (uint64_t)0x3FFFFFFF); in.wvalid = wvalid; in.len = (int)(o1 - o0);
     int end = -1;
-    // trace entry k at tr[k]: interleaved across the workgroup in LDS (conflict-free rows), contiguous in the global fallback
-    struct Tr {
-      TraceT* b; int ts;
-      __device__ __forceinline__ TraceT& operator[](int k) const { return b[k * ts]; }
-    } tr{nullptr, 1};
-    if (i < nstr) {
-      // ---- one forward walk; trace[k] = state after k bytes (only kept when spans are wanted)
-      if (want_spans) {
-        if (in.len + 2 <= kBatchTrace) { tr.b = reinterpret_cast<TraceT*>(smem + Y.trace) + tid; tr.ts = kBlockThreads; }
-        else { tr.b = gtrace + o0 + 2 * i; tr.ts = 1; }
+    // The walk and the back-trace, generic in where the state trace and the back-trace tables live (LDS-qualified or global
+    // pointers: a pointer that may be either is a FLAT access).  trace entry k at trb[k * ts]: interleaved across the workgroup in
+    // LDS (conflict-free rows), contiguous in the global fallback.
+    auto process = [&](auto trb, const int ts, const auto& B) {
+      auto tr = [&](int k) -> decltype(trb[0])& { return trb[k * ts]; };
+      if (i < nstr) {
+        // ---- one forward walk; trace[k] = state after k bytes (only kept when spans are wanted)
+        unsigned q = q0;
+        end = end0;
+        if (want_spans) tr(0) = (TraceT)q;
+        for (int at = 0;; ++at) {
+          const bool eot = at >= in.len;
+          const unsigned ed = eot ? tab.StepEot(q) : tab.Step(q, in.At(at));
+          if (ed & kMatchBefore) end = at;
+          if (ed & kMatchAfter) end = at + 1;
+          q = ed & kStateMask;
+          if (q == kDead || eot) break;
+          if (want_spans) tr(at + 1) = (TraceT)q;
+          else if (end >= 0) break;       // MatchBytes: any match will do
+        }
+        found[i] = end >= 0;
       }
-      unsigned q = q0;
-      end = end0;
-      if (want_spans) tr[0] = (TraceT)q;
-      for (int at = 0;; ++at) {
-        const bool eot = at >= in.len;
-        const unsigned ed = eot ? tab.StepEot(q) : tab.Step(q, in.At(at));
-        if (ed & kMatchBefore) end = at;
-        if (ed & kMatchAfter) end = at + 1;
-        q = ed & kStateMask;
-        if (q == kDead || eot) break;
-        if (want_spans) tr[at + 1] = (TraceT)q;
-        else if (end >= 0) break;       // MatchBytes: any match will do
+      if (!want_spans) return;
+      int32_t* rec = recs + tid * ncap;
+      if (i < nstr) {
+        for (int c = 0; c < ncap; ++c) rec[c] = unset;
+        if (end >= 0) {
+          // ---- back-trace from the winning thread at `end` until it passes Capture 0 (the match start)
+          unsigned setmask = 2u;
+          rec[1] = end;
+          int j;
+          if (U.lookahead) {
+            const unsigned qe = tr(end);
+            const int k = end < in.len ? tab.cls[in.At(end)] : U.ncls;
+            const unsigned m = B.bt_match[qe * stride + k];
+            j = (int)(m >> 24);
+            unsigned ops = (m & 0xFFFFFFu) & ~setmask;
+            while (ops) { const int c = __builtin_ctz(ops); ops &= ops - 1; rec[c] = end; setmask |= 1u << c; }
+            for (int p = end - 1; p >= 0 && !(setmask & 1u); --p) {
+              const unsigned base = B.bt_base[(unsigned)tr(p) * stride + tab.cls[in.At(p)]];
+              unsigned o = B.bt_ops[base + j] & ~setmask;
+              while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = p; setmask |= 1u << c; }
+              j = B.bt_parent[base + j];
+            }
+          } else {
+            j = (int)B.st_nthreads[tr(end)] - 1;
+            for (int p = end - 1; p >= 0 && !(setmask & 1u); --p) {
+              const unsigned base = B.bt_base[(unsigned)tr(p) * stride + tab.cls[in.At(p)]];
+              unsigned o = B.bt_ops[base + j] & ~setmask;
+              while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = p + 1; setmask |= 1u << c; }
+              j = B.bt_parent[base + j];
+            }
+            if (!(setmask & 1u)) {
+              unsigned o = B.start_ops_pool[B.start_ops[kCtxBOT] + j] & ~setmask;
+              while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = 0; setmask |= 1u << c; }
+            }
+          }
+          if (F.fixed_captures) {
+            const int s = rec[0];
+            for (int c = 2; c < ncap; ++c) rec[c] = F.cap_kind[c] == kCapFromStart ? s + F.cap_delta[c] : end - F.cap_delta[c];
+          }
+          if (ref && !F.anchored) {
+            const int s0 = rec[0];
+            int off = 0;
+            bool lost = false;
+            while (off < s0) {
+              // failure offset of the attempt at `off`: where its right-most path dies (find.go:545-569 resumes behind it)
+              unsigned st = F.rm_start[0][off == 0 ? kCtxBOT : s_fctx[in.At(off - 1)]];
+              int fo = off;
+              for (int p = off;; ++p) {
+                const unsigned k = p < in.len ? (unsigned)s_fcls[in.At(p)] : (unsigned)F.ncls;
+                const unsigned nx = s_rm[st * F.stride + k];
+                if (nx == 0xFFFFu) { fo = p - (int)s_rmd[st]; break; }
+                st = nx;
+              }
+              if (!(in.len > fo)) { lost = true; break; }
+              off = fo + 1;
+            }
+            if (lost) { found[i] = 0; for (int c = 0; c < ncap; ++c) rec[c] = unset; }
+            else if (off != s0) found[i] = 2;          // stepped over the leftmost-first start: ref_fix_kernel goes on from there
+          }
+        }
       }
-      found[i] = end >= 0;
+    };
+    {
+      typedef TraceT __attribute__((address_space(3)))* LdsTrace;
+      const bool short_str = in.len + 2 <= kBatchTrace;
+      if (!want_spans) process((TraceT*)nullptr, 1, BG);
+      else if (short_str) {
+        LdsTrace t = (LdsTrace)(smem + Y.trace) + tid;
+        if (Y.bt_in_lds) process(t, (int)kBlockThreads, BL); else process(t, (int)kBlockThreads, BG);
+      } else {
+        TraceT* t = gtrace + o0 + 2 * i;
+        if (Y.bt_in_lds) process(t, 1, BL); else process(t, 1, BG);
+      }
     }
     if (!want_spans) continue;
-    int32_t* rec = recs + tid * ncap;
-    if (i < nstr) {
-      for (int c = 0; c < ncap; ++c) rec[c] = unset;
-      if (end >= 0) {
-        // ---- back-trace from the winning thread at `end` until it passes Capture 0 (the match start)
-        unsigned setmask = 2u;
-        rec[1] = end;
-        int j;
-        if (U.lookahead) {
-          const unsigned qe = tr[end];
-          const int k = end < in.len ? tab.cls[in.At(end)] : U.ncls;
-          const unsigned m = B.bt_match[qe * stride + k];
-          j = (int)(m >> 24);
-          unsigned ops = (m & 0xFFFFFFu) & ~setmask;
-          while (ops) { const int c = __builtin_ctz(ops); ops &= ops - 1; rec[c] = end; setmask |= 1u << c; }
-          for (int p = end - 1; p >= 0 && !(setmask & 1u); --p) {
-            const unsigned base = B.bt_base[(unsigned)tr[p] * stride + tab.cls[in.At(p)]];
-            unsigned o = B.bt_ops[base + j] & ~setmask;
-            while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = p; setmask |= 1u << c; }
-            j = B.bt_parent[base + j];
-          }
-        } else {
-          j = (int)B.st_nthreads[tr[end]] - 1;
-          for (int p = end - 1; p >= 0 && !(setmask & 1u); --p) {
-            const unsigned base = B.bt_base[(unsigned)tr[p] * stride + tab.cls[in.At(p)]];
-            unsigned o = B.bt_ops[base + j] & ~setmask;
-            while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = p + 1; setmask |= 1u << c; }
-            j = B.bt_parent[base + j];
-          }
-          if (!(setmask & 1u)) {
-            unsigned o = B.start_ops_pool[B.start_ops[kCtxBOT] + j] & ~setmask;
-            while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = 0; setmask |= 1u << c; }
-          }
-        }
-        if (F.fixed_captures) {
-          const int s = rec[0];
-          for (int c = 2; c < ncap; ++c) rec[c] = F.cap_kind[c] == kCapFromStart ? s + F.cap_delta[c] : end - F.cap_delta[c];
-        }
-        if (ref && !F.anchored) {
-          const int s0 = rec[0];
-          int off = 0;
-          bool lost = false;
-          while (off < s0) {
-            // failure offset of the attempt at `off`: where its right-most path dies (find.go:545-569 resumes behind it)
-            unsigned st = F.rm_start[0][off == 0 ? kCtxBOT : s_fctx[in.At(off - 1)]];
-            int fo = off;
-            for (int p = off;; ++p) {
-              const unsigned k = p < in.len ? (unsigned)s_fcls[in.At(p)] : (unsigned)F.ncls;
-              const unsigned nx = s_rm[st * F.stride + k];
-              if (nx == 0xFFFFu) { fo = p - (int)s_rmd[st]; break; }
-              st = nx;
-            }
-            if (!(in.len > fo)) { lost = true; break; }
-            off = fo + 1;
-          }
-          if (lost) { found[i] = 0; for (int c = 0; c < ncap; ++c) rec[c] = unset; }
-          else if (off != s0) found[i] = 2;          // stepped over the leftmost-first start: ref_fix_kernel goes on from there
-        }
-      }
-    }
     __syncthreads();
     const int nrec_words = (int)(ilast - i0) * ncap;
     int32_t* const dst = spans + i0 * ncap;
