@@ -216,7 +216,17 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   };
   static const bool force_tickets = ExpEnv("RGX_TICKETS") != nullptr;
   P.use_tickets = force_tickets ? 1 : 0;
+  // Every scan but the exact kernel's may meet slices without a sync point in reach; the first scan marks them as it goes
+  // (a byte per slice, cleared here), so that the carry pass needs no scan of its own to find them.
+  bool marked = false;
+  if (!UseExactKernel(T, ilen)) {
+    if ((rc = Ensure(&c->d_unsynced, &c->slice_cap, nslices)) != RGX_OK) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_unsynced, 0, nslices, c->stream));
+    P.slice_unsynced = c->d_unsynced;
+    marked = true;
+  }
   if ((rc = run_scan(c->timing)) != RGX_OK) return rc;
+  P.slice_unsynced = nullptr;
   if (((uint32_t*)&c->h_read[2])[3]) {
     // a look-back spin hit its bound (block ids assumed dispatch order and the assumption failed): repeat with tickets,
     // which need no assumption at all
@@ -237,9 +247,11 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
       if (c->d_carry) { hipFree(c->d_carry); c->d_carry = nullptr; }
       if ((rc = Ensure(&c->d_carry, &cc, (int64_t)nslices + 64)) != RGX_OK) return rc;
     }
-    HIP_TRY(hipMemsetAsync(c->d_unsynced, 0, nslices, c->stream));
-    P.slice_unsynced = c->d_unsynced;
-    if ((rc = run_scan(false)) != RGX_OK) return rc;            // marks the unsynced slices
+    if (!marked) {
+      HIP_TRY(hipMemsetAsync(c->d_unsynced, 0, nslices, c->stream));
+      P.slice_unsynced = c->d_unsynced;
+      if ((rc = run_scan(false)) != RGX_OK) return rc;            // marks the unsynced slices
+    }
     HIP_TRY(hipMemsetAsync(c->d_carry, 0xFF, (size_t)nslices * 4, c->stream));
     HIP_TRY(LaunchCarryUs(T, d_buf, ilen, c->d_unsynced, c->d_carry, nslices, c->stream));
     P.slice_unsynced = nullptr;
@@ -257,7 +269,10 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     ntiles = ScanNumTiles(T, ilen, true);
     P.ntiles = ntiles;
     P.use_w = 1;
+    HIP_TRY(hipMemsetAsync(c->d_unsynced, 0, nslices, c->stream));      // this scan's marks replace the first scan's
+    P.slice_unsynced = c->d_unsynced;
     if ((rc = run_scan(c->timing)) != RGX_OK) return rc;
+    P.slice_unsynced = nullptr;
     if (c->timing) hipEventElapsedTime(&ms, c->ev0, c->ev1);
     unsynced = ((uint32_t*)&c->h_read[2])[1];
   }
@@ -283,7 +298,10 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     if (h_stats[1]) HIP_TRY(LaunchWSyncOrdered(T, d_buf, ilen, c->d_carry, c->d_trace, d_stats, c->stream));   // a thread really spans > 4 KiB
     HIP_TRY(LaunchWSyncFill(c->d_carry, ilen, c->stream));
     P.carry_in = c->d_carry;
+    HIP_TRY(hipMemsetAsync(c->d_unsynced, 0, nslices, c->stream));      // this scan's marks replace the earlier ones
+    P.slice_unsynced = c->d_unsynced;
     if ((rc = run_scan(c->timing)) != RGX_OK) return rc;
+    P.slice_unsynced = nullptr;
     if (c->timing) hipEventElapsedTime(&ms, c->ev0, c->ev1);
     unsynced = ((uint32_t*)&c->h_read[2])[1];
     carry_ready = true;
@@ -296,9 +314,11 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
       if (c->d_carry) { hipFree(c->d_carry); c->d_carry = nullptr; }
       if ((rc = Ensure(&c->d_carry, &cc, nslices)) != RGX_OK) return rc;
     }
-    HIP_TRY(hipMemsetAsync(c->d_unsynced, 0, nslices, c->stream));
-    P.slice_unsynced = c->d_unsynced;
-    if ((rc = run_scan(false)) != RGX_OK) return rc;            // marks the unsynced slices
+    if (!marked) {                                              // (the marks of the first scan stand unless a rescan came between)
+      HIP_TRY(hipMemsetAsync(c->d_unsynced, 0, nslices, c->stream));
+      P.slice_unsynced = c->d_unsynced;
+      if ((rc = run_scan(false)) != RGX_OK) return rc;            // marks the unsynced slices
+    }
     if (!carry_ready) HIP_TRY(hipMemsetAsync(c->d_carry, 0xFF, (size_t)nslices * 4, c->stream));
     HIP_TRY(LaunchCarry(T, d_buf, ilen, c->d_unsynced, c->d_carry, nslices, c->stream));
     P.slice_unsynced = nullptr;
