@@ -17,7 +17,8 @@ resident in HBM:
       (^/$-anchored patterns per line over a CSR view of the lines); with N GPUs the patterns are dealt round-robin.
 
 `value` = total input bytes of all ranks / max-over-ranks wall time per step.  The timed region is K steps repeated until it
-lasts at least 0.5 s (`repeats`), bracketed by barrier + synchronize: the sustained rate, not a cold one.
+lasts at least 0.5 s (`repeats`), bracketed by barrier + synchronize, after at least 2 s of untimed steps (`prewarm_s`: the first
+second or two of a process run the host side of a step ~30 us slower): the sustained rate, not a cold one.
 
 Extra objects: `roofline` (HBM: algorithmic bytes per launch of the dominant kernel / its duration from HIP events on the launch
 stream; `traffic` from the PMC passes kept under profiles/, named in `traffic_source`) and `cpu_baseline` (the oracle's
@@ -41,6 +42,7 @@ URL = r"(?P<full>(?P<proto>https?|ftp)://(?P<host>[\w.-]+)(?P<port>:\d+)?(?P<pat
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 METRIC = "input GB/s (FindAllBytes, 1 GiB buf) at 1/2/4/8 MI355X; bit-exact offsets"
 MIN_TIMED_SECONDS = 0.5
+PREWARM_SECONDS = float(os.environ.get("RGX_BENCH_PREWARM", "2.0"))
 KERNEL_NAMES = {1: "rgx::scan_exact_kernel", 2: "rgx::scan_rows_kernel (prefilter + verify)", 3: "rgx::scan_kernel (one attempt per start)",
                 4: "rgx::scan_us_kernel", 5: "rgx::scan_us_simple_kernel", 6: "rgx::scan_us_pair_kernel"}
 
@@ -106,6 +108,11 @@ def sustained(env, run_steps, steps, warmup):
     ranks; repeats)."""
     if warmup > 0:
         run_steps(warmup)
+    # a box that has just been handed out runs its first second or two of scans slower than the rest (clocks, first-touch of
+    # the buffers' pages): the untimed part lasts at least PREWARM_SECONDS so that the timed region is the steady state
+    t_pre = time.perf_counter()
+    while env.allmax(time.perf_counter() - t_pre) < PREWARM_SECONDS:
+        run_steps(steps)
     env.barrier()
     t0 = time.perf_counter()
     run_steps(steps)
@@ -135,7 +142,7 @@ def load_traffic(name):
 
 def base_line(env, args, value, ms_per_step, reps, dtype="u8", scaling="weak"):
     return {"metric": METRIC, "value": round(value, 2), "unit": "GB/s", "n_gpus": env.world, "steps": args.steps, "warmup": args.warmup,
-            "repeats": reps, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+            "repeats": reps, "prewarm_s": PREWARM_SECONDS, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": dtype, "data": "synthetic"}
 
 
