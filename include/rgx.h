@@ -44,7 +44,11 @@ typedef enum rgx_status {
   RGX_E_NOMEM = -7,
   RGX_E_CAPACITY = -8,       /* output capacity too small; count is in rgx_result.total          */
   RGX_E_BAD_BLOB = -9,
-  RGX_E_BUFFER_TOO_SMALL = -10 /* stream.ErrBufferTooSmall, stream/stream.go:85-101              */
+  RGX_E_BUFFER_TOO_SMALL = -10, /* stream.ErrBufferTooSmall, stream/stream.go:85-101              */
+  RGX_E_DIVERGES = -11       /* rgx_find_chunk / rgx_count_chunk: on THIS chunk the reference's FindReader loop would not
+                              * report what FindAllBytes reports (its restart rule steps over a match, its bytes.Index offset
+                              * recovery finds the match text earlier, or re-slicing changes the context of an attempt):
+                              * nothing was delivered -- run the chunk through the Go loop                       */
 } rgx_status;
 
 enum {
@@ -264,7 +268,14 @@ int64_t rgx_match_batch_device(const rgx_program* p, rgx_stream_ctx* c, const ui
  * The stub keeps the Go read loop (r.Read is the only I/O boundary, streaming.go:123).  Each filled
  * chunk (leftover + fresh bytes) is handed down; matches are returned chunk-relative together with
  * `keep_from`, the offset the caller must carry into the next chunk -- the function computes the
- * commit/defer decisions of streaming.go:183-244 (MaxLeftover deferral, committed, keepFrom).        */
+ * commit/defer decisions of streaming.go:183-244 (MaxLeftover deferral, committed, keepFrom).
+ * The matches are FindAllBytes' over the chunk.  The emitted loop is something else -- FindBytesReuse on chunk[searchPos:]
+ * (its restart rule; the re-slice makes searchPos the beginning of the text) and bytes.Index to recover the
+ * offset (Q4) -- and for programs whose FindBytesReuse the library reproduces (rgx_info.ref_find_offered, no empty matches) every
+ * gap between two matches is CHECKED on the device against exactly those three things: all pass -> the reference's loop
+ * reports these very matches; one fails -> RGX_E_DIVERGES and nothing is delivered (the stub replays the chunk through the Go
+ * loop).  RGX_FLAG_STDLIB_SEMANTICS switches the check off; for the other programs (memoising / TDFA FindBytes, empty
+ * matches) there is no check: plain FindAllBytes semantics, as DESIGN.md states.                                         */
 typedef struct rgx_stream_config {  /* stream.Config, stream/stream.go:21-39 */
   int64_t buffer_size;
   int64_t max_leftover;

@@ -18,7 +18,7 @@ class RgxError(RuntimeError):
 
 
 _STATUS = {0: "ok", -1: "invalid", -2: "syntax", -3: "unsupported", -4: "too large", -5: "no device", -6: "hip",
-           -7: "nomem", -8: "capacity", -9: "bad blob", -10: "buffer too small"}
+           -7: "nomem", -8: "capacity", -9: "bad blob", -10: "buffer too small", -11: "diverges from the reference"}
 
 RGX_OK = 0
 RGX_E_INVALID = -1
@@ -27,6 +27,7 @@ RGX_E_UNSUPPORTED = -3
 RGX_E_NO_DEVICE = -5
 RGX_E_CAPACITY = -8
 RGX_E_BUFFER_TOO_SMALL = -10
+RGX_E_DIVERGES = -11
 TRANSFORM_REPLACE, TRANSFORM_SELECT, TRANSFORM_REJECT = 0, 1, 2
 FLAG_UNMATCHED_MINUS1 = 1
 FLAG_STDLIB_SEMANTICS = 2

@@ -1226,17 +1226,50 @@ RGX_API int rgx_stream_config_resolve(const rgx_program* p, const rgx_stream_con
   return RGX_OK;
 }
 
+namespace {
+// Does the reference's FindReader loop report exactly the FindAllBytes matches of this chunk?  (rgx.h, RGX_E_DIVERGES.)  Only
+// asked for programs whose FindBytesReuse the library reproduces and that cannot match empty, in reference mode.
+bool ReaderCheckApplies(const rgx_program* p) {
+  const Tables& t = p->p.t;
+  return !(t.flags & RGX_FLAG_STDLIB_SEMANTICS) && p->p.dev.ref_find_ok && !t.can_match_empty;
+}
+int ReaderCheck(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_raw, size_t len, const int32_t* d_spans, int64_t n) {
+  const uint8_t* view = d_raw;
+  int rc = MatchView(p, c, d_raw, len, &view);
+  if (rc != RGX_OK) return rc;
+  unsigned* flag = reinterpret_cast<unsigned*>(c->d_cursor + 1);
+  unsigned h = 0;
+  HIP_TRY(hipMemsetAsync(flag, 0, 4, c->stream));
+  HIP_TRY(LaunchReaderCheck(p->p.dev, d_raw, view, (int32_t)len, d_spans, n, p->p.dev.ncap, flag, c->stream));
+  HIP_TRY(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (h) { SetError("the reference's FindReader loop diverges from FindAllBytes on this chunk (restart rule / bytes.Index / re-slicing): run it through the Go loop"); return RGX_E_DIVERGES; }
+  return RGX_OK;
+}
+}  // namespace
+
 RGX_API int64_t rgx_find_chunk(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* chunk, size_t data_len, int is_full,
                                int64_t max_leftover, int32_t* spans, size_t cap_records, int64_t* committed, int64_t* keep_from,
                                rgx_result* res) {
   // streaming.go:175-244.  All matches of the chunk are found in one scan; the commit/defer rule is applied
   // to the ordered list: the first match whose end crosses dataLen-MaxLeftover (when the buffer was full)
   // stops the loop, exactly like the `break` at streaming.go:204-207.
-  if (!committed || !keep_from) return RGX_E_INVALID;
-  rgx_result r;
-  int64_t w = rgx_find_all_bytes(p, c, chunk, data_len, -1, spans, cap_records, &r);
-  if (w < 0) return w;
-  const int ncap = r.ncap ? r.ncap : p->p.t.ncap;
+  int rc = CheckCtx(p, c);
+  if (rc != RGX_OK) return rc;
+  if (!committed || !keep_from || (!chunk && data_len) || (!spans && cap_records)) return RGX_E_INVALID;
+  rgx_result r{};
+  r.ncap = p->p.dev.ncap;
+  const int ncap = p->p.dev.ncap;
+  int64_t w = 0;
+  if (data_len > 0) {
+    if ((rc = Ensure(&c->d_in, &c->in_cap, (int64_t)data_len + 64)) != RGX_OK) return rc;
+    if ((rc = Ensure(&c->d_out, &c->out_cap, (int64_t)cap_records * ncap + 16)) != RGX_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_in, chunk, data_len, hipMemcpyHostToDevice, c->stream));
+    w = FindAllDevice(p, c, c->d_in, data_len, -1, c->d_out, cap_records, false, &r);
+    if (w < 0) return w;
+    if (ReaderCheckApplies(p) && (rc = ReaderCheck(p, c, c->d_in, data_len, c->d_out, w)) != RGX_OK) return rc;
+    if (w > 0) HIP_TRY(hipMemcpy(spans, c->d_out, (size_t)w * ncap * 4, hipMemcpyDeviceToHost));
+  }
   int64_t comm = 0, emitted = 0;
   for (int64_t i = 0; i < w; i++) {
     int64_t me = spans[i * ncap + 1];
@@ -1271,7 +1304,8 @@ RGX_API int64_t rgx_count_chunk(const rgx_program* p, rgx_stream_ctx* c, const u
   if (data_len == 0) { if (res) *res = r; return 0; }
   if ((rc = Ensure(&c->d_in, &c->in_cap, (int64_t)data_len + 64)) != RGX_OK) return rc;
   HIP_TRY(hipMemcpyAsync(c->d_in, chunk, data_len, hipMemcpyHostToDevice, c->stream));
-  if (!is_full) {
+  const bool check = ReaderCheckApplies(p);
+  if (!is_full && !check) {
     int64_t total = FindAllDevice(p, c, c->d_in, data_len, -1, nullptr, 0, true, &r);
     if (total < 0) return total;
     total = r.total;
@@ -1284,6 +1318,12 @@ RGX_API int64_t rgx_count_chunk(const rgx_program* p, rgx_stream_ctx* c, const u
   if ((rc = Ensure(&c->d_out, &c->out_cap, cap_records * ncap + 16)) != RGX_OK) return rc;
   int64_t w = FindAllDevice(p, c, c->d_in, data_len, -1, c->d_out, (size_t)cap_records, false, &r);
   if (w < 0) return w;
+  if (check && (rc = ReaderCheck(p, c, c->d_in, data_len, c->d_out, w)) != RGX_OK) return rc;
+  if (!is_full) {        // nothing is deferred from a chunk that is not full: every match counts
+    *committed = -1;
+    if (res) { *res = r; res->written = 0; }
+    return w;
+  }
   long long h2[2] = {0, 0};
   if (w > 0) {
     if ((rc = Ensure(&c->d_rdelta, &c->rdelta_cap, 4)) != RGX_OK) return rc;
@@ -1323,6 +1363,7 @@ RGX_API const char* rgx_status_str(int s) {
     case RGX_E_CAPACITY: return "output capacity too small";
     case RGX_E_BAD_BLOB: return "bad table blob";
     case RGX_E_BUFFER_TOO_SMALL: return "stream: buffer size too small";
+    case RGX_E_DIVERGES: return "the reference's FindReader loop diverges from FindAllBytes on this chunk";
   }
   return "unknown";
 }

@@ -124,4 +124,9 @@ hipError_t LaunchCommitPoint(const int32_t* spans, int64_t n, int ncap, int32_t 
 hipError_t LaunchUtf8Screen(const uint8_t* src, int64_t len, uint8_t* dst, unsigned* flag, hipStream_t stream);
 hipError_t LaunchUtf8ScreenBatch(const uint8_t* src, const uint64_t* offsets, int64_t nstr, uint8_t* dst, unsigned* flag, hipStream_t stream);
 
+// FindReader's loop against FindAllBytes over one chunk (rgx.h: RGX_E_DIVERGES): *flag |= 1 when a gap between two matches of the
+// ordered span table fails the context / restart-rule / bytes.Index checks.  raw: the chunk; view: what the automaton sees.
+hipError_t LaunchReaderCheck(const DevTables& T, const uint8_t* raw, const uint8_t* view, int32_t len, const int32_t* spans, int64_t n,
+                             int ncap, unsigned* flag, hipStream_t stream);
+
 }  // namespace rgx

@@ -1672,6 +1672,69 @@ hipError_t LaunchAttemptAt(const DevTables& T, const uint8_t* buf, int32_t len, 
 }
 
 namespace {
+// FindReader's loop against FindAllBytes (streaming.go:175-244).  Lane i checks the gap in front of match i (i == n: the tail
+// behind the last match): with p = the end of the previous match (0 for the first gap),
+//   context  the loop matches chunk[p:], so an attempt AT p sees the beginning of the text: harmless iff the automaton starts
+//            the same way there (start state, start accept and right-most path of context BOT = those of the real byte before p);
+//   Q1       FindBytesReuse walks attempt offsets p, fail(p)+1, ... : that sequence has to land on the match's start (every
+//            attempt before it fails, the start being the leftmost one with a match) and must not run out of text first;
+//   Q4       bytes.Index(chunk[p:], match text) has to be the match's own offset: no earlier copy of the text in the gap.
+// raw = the chunk's bytes, view = the bytes the automaton sees (broken UTF-8 sanitised; == raw otherwise).
+__global__ __launch_bounds__(256) void reader_check_kernel(DevTables T, const uint8_t* raw, const uint8_t* view, int32_t len,
+                                                           const int32_t* spans, long long n, int ncap, unsigned* flag) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  bool bad = false;
+  if (i <= n) {
+    const int p = i == 0 ? 0 : spans[(i - 1) * ncap + 1];
+    if (p > 0 && p < len) {
+      if (T.anchored) {
+        // an anchored pattern is tried once, at offset 0 of what it is given -- and the loop gives it chunk[p:] again and again
+        if (i == n && WalkGlobal(T, view + p, len - p, 0) >= 0) bad = true;
+      } else {
+        const int cx = T.ctx_of_byte[view[p - 1]];
+        if (T.start[kCtxBOT] != T.start[cx] || T.start_accept[kCtxBOT] != T.start_accept[cx] || T.rm_start[0][kCtxBOT] != T.rm_start[0][cx]) {
+          // the automaton starts differently at the beginning of a text than behind this byte (\b, ^, (?m)^): the attempt AT p is
+          // the only one that can tell (later ones see their real predecessor either way).  It has to fail both ways, with the
+          // same failure offset; a match there in either reading is left to the Go loop.
+          if (WalkGlobal(T, view + p, len - p, 0) >= 0 || WalkGlobal(T, view, len, p) >= 0) bad = true;
+          else if (RmFailOffset(T, 0, view + p, len - p, 0) + p != RmFailOffset(T, 0, view, len, p)) bad = true;
+        }
+      }
+    }
+    if (i < n && !bad) {
+      const int s = spans[i * ncap], e = spans[i * ncap + 1];
+      int off = p;
+      while (off < s) {
+        const int fo = RmFailOffset(T, 0, view, len, off);
+        if (!(len > fo)) { bad = true; break; }
+        off = fo + 1;
+      }
+      if (off != s) bad = true;
+      const int m = e - s;
+      if (!bad) {
+        if (m == 0) bad = s != p;
+        else
+          for (int q = p; q < s && !bad; ++q) {
+            if (raw[q] != raw[s] || q + m > len) continue;
+            int k = 1;
+            while (k < m && raw[q + k] == raw[s + k]) ++k;
+            if (k == m) bad = true;
+          }
+      }
+    }
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+}  // namespace
+hipError_t LaunchReaderCheck(const DevTables& T, const uint8_t* raw, const uint8_t* view, int32_t len, const int32_t* spans, int64_t n,
+                             int ncap, unsigned* flag, hipStream_t stream) {
+  const long long lanes = n + 1;
+  hipLaunchKernelGGL(reader_check_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream, T, raw, view, len, spans,
+                     (long long)n, ncap, flag);
+  return hipGetLastError();
+}
+
+namespace {
 // streaming.go:204-207 on an ordered span table: the first match whose end lies beyond `limit` stops the chunk's loop.  Match ends
 // increase with the row index, so the commit point is a binary search: out[0] = rows committed, out[1] = end of the last one.
 __global__ void commit_point_kernel(const int32_t* spans, long long n, int ncap, int32_t limit, long long* out) {

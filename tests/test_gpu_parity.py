@@ -269,18 +269,89 @@ def test_find_reader_equals_oracle_stream(torch_dev):
     got = run_gpu(data)
     assert got == run_oracle(data, cm.find) and len(got) > 60000
 
-    # (b) adversarial noise: the reference's FindBytesReuse skips candidate starts after a failed attempt (Q1,
-    # DESIGN.md), so its FindReader misses matches its own FindAllBytes reports.  The GPU path follows FindAllBytes;
-    # the same chunk protocol driven by a quirk-free "first match" must agree exactly.
+    # (b) adversarial noise: the reference's FindBytesReuse skips candidate starts after a failed attempt (Q1), so its FindReader
+    # misses matches its own FindAllBytes reports.  The library checks every chunk for exactly that and answers either the
+    # reference's own result or RGX_E_DIVERGES ("run this chunk through the Go loop") -- never something else.
+    from regengo_amd import _capi
+
     def first_match(b):
         r = cm.find_all(b, 1)
         return r[0] if r else None
 
     adv = synth.date_log_np(1 << 20, adversarial=True).tobytes()
-    got = run_gpu(adv)
-    assert got == run_oracle(adv, first_match)
     q1 = run_oracle(adv, cm.find)
-    assert len(q1) <= len(got)          # the quirk only ever loses matches
+    plain = run_oracle(adv, first_match)
+    assert len(q1) <= len(plain)          # the quirk only ever loses matches
+    try:
+        got = run_gpu(adv)
+        assert got == q1
+    except _capi.RgxError as ex:
+        assert ex.status == _capi.RGX_E_DIVERGES and q1 != plain
+
+
+def test_find_reader_is_the_reference_or_refuses(torch_dev):
+    """One chunk at a time (buffer larger than the data: nothing is deferred): rgx_find_chunk either returns exactly what the
+    reference's loop -- FindBytesReuse on chunk[searchPos:] with its restart rule, offsets through bytes.Index -- reports
+    (oracle: engines.find_reader over the generated-C FindBytes port), or RGX_E_DIVERGES, and it refuses only where the reference
+    really differs from FindAllBytes.  Patterns: the restart rule (dates in digit noise), re-slicing (a word boundary, an anchored
+    pattern: the loop hands `^` a new beginning of text after every match), bytes.Index (a match text that occurs earlier in the
+    gap)."""
+    import random
+    from oracle import engines as E
+    from oracle.gen_c import CMatcher
+    from regengo_amd import Config, _capi
+    rng = random.Random(4242)
+    cases = [
+        (r"(\d{4}-\d{2}-\d{2})", "0123456789-- x"),
+        (r"(?P<u>\w+)@(?P<d>\w+)", "ab@. "),
+        (r"\b(\d+)\b", "12a _."),
+        (r"(?P<k>[a-c]+)=(?P<v>\d+)", "abc=12 ;"),
+        (r"^(\d\d)", "0123 "),
+        (r"x(ab|a)c?", "xabc "),
+    ]
+    refused = agreed = 0
+    for pat, alphabet in cases:
+        c = _gpu(pat)
+        if not c.info.ref_find_offered or c.info.can_match_empty:
+            continue
+        o = E.Compiled(pat)
+        cm = CMatcher(pat)
+
+        def first_match(b):
+            r = cm.find_all(b, 1)
+            return r[0] if r else None
+
+        for trial in range(120):
+            n = rng.choice([5, 17, 64, 300, 2000])
+            data = "".join(rng.choice(alphabet) for _ in range(n)).encode()
+            ref, plain = [], []
+            cfg = E.StreamConfig(BufferSize=1 << 17)
+            E.find_reader(cm.find, o.sel.max_len, io.BytesIO(data).read, cfg, lambda m: ref.append((m.StreamOffset, m.match_bytes, list(m.caps))) or True)
+            E.find_reader(first_match, o.sel.max_len, io.BytesIO(data).read, cfg, lambda m: plain.append((m.StreamOffset, m.match_bytes, list(m.caps))) or True)
+            got = []
+            try:
+                c.FindReader(io.BytesIO(data), Config(BufferSize=1 << 17), lambda m: got.append((m.StreamOffset, m.Result.Match)) or True)
+                assert got == [(a, b) for a, b, _ in ref], (pat, data)
+                assert c.FindReaderCount(io.BytesIO(data), Config(BufferSize=1 << 17)) == len(ref)
+                agreed += 1
+            except _capi.RgxError as ex:
+                assert ex.status == _capi.RGX_E_DIVERGES, (pat, data, ex)
+                whole = [(r[0], data[r[0]:r[1]]) for r in cm.find_all(data)]        # FindAllBytes over the chunk, true context
+                reslice = [(a, b) for a, b, _ in plain]                              # the loop's re-slicing without the restart rule
+                # the loop's FindBytesReuse results at their TRUE offsets (bytes.Index may move one onto an earlier copy of its
+                # text and so, by accident, onto the very match the restart rule stepped over)
+                true_ref, q = [], 0
+                while q < len(data):
+                    r = cm.find(data[q:])
+                    if r is None:
+                        break
+                    true_ref.append((q + r[0], data[q + r[0]:q + r[1]]))
+                    q = q + r[1] if r[1] > r[0] else q + 1
+                assert [(a, b) for a, b, _ in ref] != whole or reslice != whole or true_ref != whole, (pat, data)
+                with pytest.raises(_capi.RgxError):
+                    c.FindReaderCount(io.BytesIO(data), Config(BufferSize=1 << 17))
+                refused += 1
+    assert agreed > 300 and refused > 20, (agreed, refused)
 
 
 def test_batch_find_and_match(torch_dev):
