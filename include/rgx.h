@@ -198,8 +198,10 @@ int64_t rgx_find_all_wait(const rgx_program* p, rgx_stream_ctx* c, rgx_result* r
  * loop's extra attempt at offset len for patterns that match empty) is replaced by the template's expansion; unknown
  * names and out-of-range indices expand to nothing (replace.go:393-453).  `d_out` receives the result; *out_len is
  * always set; RGX_E_CAPACITY when cap_out is too small (call again with *out_len bytes).  A malformed template is
- * RGX_E_INVALID (the reference panics).  Matches are taken in their true context: the reference's re-slicing quirks
- * (DESIGN.md Q1/Q4'/Q12) are not reproduced.                                                          */
+ * RGX_E_INVALID (the reference panics).  The emitted loop is FindBytesReuse on input[matchEnd:] + bytes.Index, like
+ * FindReader's: for programs whose FindBytesReuse the library reproduces (rgx_info.ref_find_offered, no empty matches) the
+ * result is that loop's or RGX_E_DIVERGES (see rgx_find_chunk); for the others matches are taken in their true context
+ * (the re-slicing quirks, DESIGN.md Q1/Q4'/Q12, are not reproduced).                                    */
 int64_t rgx_replace_all_bytes_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len,
                                      const char* tmpl, size_t tmpl_len, int first_only, uint8_t* d_out, size_t cap_out,
                                      int64_t* out_len, rgx_result* res);
@@ -225,6 +227,7 @@ int rgx_replace_template_check(const char* tmpl, size_t tmpl_len);
  * Template: replace.Parse + ValidateAndResolve (replace/template.go:45-291): an unknown name or an index beyond the
  * groups is RGX_E_INVALID (the reference returns a reader that yields the error); group texts go through
  * getCaptureByIndex (transform.go:288-320), which knows NAMED groups only -- `$1` of an unnamed group expands to nothing.
+ * The same identical-or-refused rule as rgx_find_chunk applies (RGX_E_DIVERGES: run the buffer through the Go processor).
  * Patterns that can match empty are RGX_E_UNSUPPORTED: the emitted loop drops a byte per empty match and panics on one
  * at the end of the data; keep the Go path for them.  Predicates and arbitrary callbacks run on the host
  * over rgx_find_all_bytes spans with the same *processed rule.                                     */

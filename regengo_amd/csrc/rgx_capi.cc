@@ -133,6 +133,26 @@ int MatchViewBatch(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_con
   return RGX_OK;
 }
 
+// Does the reference's FindReader loop report exactly the FindAllBytes matches of this chunk?  (rgx.h, RGX_E_DIVERGES.)  Only
+// asked for programs whose FindBytesReuse the library reproduces and that cannot match empty, in reference mode.
+bool ReaderCheckApplies(const rgx_program* p) {
+  const Tables& t = p->p.t;
+  return !(t.flags & RGX_FLAG_STDLIB_SEMANTICS) && p->p.dev.ref_find_ok && !t.can_match_empty;
+}
+int ReaderCheck(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_raw, size_t len, const int32_t* d_spans, int64_t n) {
+  const uint8_t* view = d_raw;
+  int rc = MatchView(p, c, d_raw, len, &view);
+  if (rc != RGX_OK) return rc;
+  unsigned* flag = reinterpret_cast<unsigned*>(c->d_cursor + 1);
+  unsigned h = 0;
+  HIP_TRY(hipMemsetAsync(flag, 0, 4, c->stream));
+  HIP_TRY(LaunchReaderCheck(p->p.dev, d_raw, view, (int32_t)len, d_spans, n, p->p.dev.ncap, flag, c->stream));
+  HIP_TRY(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (h) { SetError("the reference's FindReader loop diverges from FindAllBytes on this chunk (restart rule / bytes.Index / re-slicing): run it through the Go loop"); return RGX_E_DIVERGES; }
+  return RGX_OK;
+}
+
 // Core: scan (+ carry fallback) (+ captures).  Inputs/outputs are device pointers.
 int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n, int32_t* d_spans,
                       size_t cap_records, bool count_only, rgx_result* res, bool starts_only = false, int64_t own_lo = 0,
@@ -813,6 +833,8 @@ RGX_API int64_t rgx_replace_all_bytes_device(const rgx_program* p, rgx_stream_ct
     n = FindAllDevice(p, c, d_buf, len, first_only ? 1 : -1, c->d_rspans, (size_t)cap_rec - 2, false, &r);
     if (n < 0) return n;
   }
+  // (the emitted loop is FindBytesReuse on input[matchEnd:] + bytes.Index, like FindReader's: identical or refused, rgx.h)
+  if (len > 0 && ReaderCheckApplies(p) && (rc = ReaderCheck(p, c, d_buf, len, c->d_rspans, n)) != RGX_OK) return rc;
   // 2. the emitted loop also tries at offset len (FindBytesReuse on the empty remainder, find.go:545-569)
   if (t.can_match_empty && (!t.anchored || len == 0) && !(first_only && n > 0)) {
     int32_t* d_end = (int32_t*)(c->d_rspans + (cap_rec - 1) * ncap);
@@ -910,6 +932,9 @@ int64_t TransformChunkDevice(const rgx_program* p, rgx_stream_ctx* c, const uint
   if (len > 0) {
     n = FindAllDevice(p, c, d_data, len, -1, c->d_rspans, (size_t)cap_rec - 2, false, &r);
     if (n < 0) return n;
+    // the emitted processors run FindBytesReuse on data[processed:] + bytes.Index (transform.go:96-170, 380-571), like
+    // FindReader's loop: identical or refused (rgx.h, RGX_E_DIVERGES)
+    if (ReaderCheckApplies(p) && (rc = ReaderCheck(p, c, d_data, len, c->d_rspans, n)) != RGX_OK) return rc;
   }
   SplicePlan sp;
   long long gain = 0;
@@ -1226,27 +1251,6 @@ RGX_API int rgx_stream_config_resolve(const rgx_program* p, const rgx_stream_con
   return RGX_OK;
 }
 
-namespace {
-// Does the reference's FindReader loop report exactly the FindAllBytes matches of this chunk?  (rgx.h, RGX_E_DIVERGES.)  Only
-// asked for programs whose FindBytesReuse the library reproduces and that cannot match empty, in reference mode.
-bool ReaderCheckApplies(const rgx_program* p) {
-  const Tables& t = p->p.t;
-  return !(t.flags & RGX_FLAG_STDLIB_SEMANTICS) && p->p.dev.ref_find_ok && !t.can_match_empty;
-}
-int ReaderCheck(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_raw, size_t len, const int32_t* d_spans, int64_t n) {
-  const uint8_t* view = d_raw;
-  int rc = MatchView(p, c, d_raw, len, &view);
-  if (rc != RGX_OK) return rc;
-  unsigned* flag = reinterpret_cast<unsigned*>(c->d_cursor + 1);
-  unsigned h = 0;
-  HIP_TRY(hipMemsetAsync(flag, 0, 4, c->stream));
-  HIP_TRY(LaunchReaderCheck(p->p.dev, d_raw, view, (int32_t)len, d_spans, n, p->p.dev.ncap, flag, c->stream));
-  HIP_TRY(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  if (h) { SetError("the reference's FindReader loop diverges from FindAllBytes on this chunk (restart rule / bytes.Index / re-slicing): run it through the Go loop"); return RGX_E_DIVERGES; }
-  return RGX_OK;
-}
-}  // namespace
 
 RGX_API int64_t rgx_find_chunk(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* chunk, size_t data_len, int is_full,
                                int64_t max_leftover, int32_t* spans, size_t cap_records, int64_t* committed, int64_t* keep_from,

@@ -37,14 +37,18 @@ def test_replace_matches_oracle_on_corpus(gpu, corpus, kats):
     from regengo_amd import Compiled, _capi
     rng = random.Random(31)
     items = [(e["pattern"], e["inputs"]) for e in corpus] + [(c["pattern"], c["inputs"]) for c in kats["curated_cases"]]
-    checked = pats = 0
+    checked = pats = refused = strict_checked = 0
     for pat, inputs in items:
         try:
             c = Compiled(pat).to(0)
         except _capi.RgxError:
             continue
         o = E.Compiled(pat)
-        if c.info.lookahead_mode or "^" in pat or "\\b" in pat or "\\B" in pat or "\\A" in pat:
+        # Programs whose FindBytesReuse the library reproduces (and that cannot match empty) are held to the REFERENCE's loop, quirks
+        # included (oracle: quirks=True -- restart rule, re-slicing, bytes.Index): the answer is that, or RGX_E_DIVERGES.  The others
+        # keep the quirk-free reading (true leftmost-first matches in their real context).
+        strict = bool(c.info.ref_find_offered) and not c.info.can_match_empty
+        if not strict and (c.info.lookahead_mode or "^" in pat or "\\b" in pat or "\\B" in pat or "\\A" in pat):
             continue          # context-sensitive: the reference's re-slicing (Q12) changes what `^`/`\b` see; not the GPU's reading
         bs = [s.encode() for s in inputs]
         texts = bs + [b" ".join(bs), b"\n".join(bs * 3), b""]
@@ -53,13 +57,30 @@ def test_replace_matches_oracle_on_corpus(gpu, corpus, kats):
         tmpls = rng.sample(TEMPLATES, 4) + ["[$0]"]
         for b in texts:
             for t in tmpls:
-                exp = R.replace_all(o, b, t)
-                got = c.ReplaceAllBytes(b, t)
+                try:
+                    exp = R.replace_all(o, b, t, quirks=strict)
+                except NotImplementedError:
+                    continue
+                try:
+                    got = c.ReplaceAllBytes(b, t)
+                except _capi.RgxError as ex:
+                    assert strict and ex.status == _capi.RGX_E_DIVERGES, (pat, b, ex)
+                    refused += 1
+                    continue
                 assert got == exp, (pat, b, t, got, exp)
+                if strict:
+                    assert got == R.replace_all(o, b, t), (pat, b, t)       # the check passed: the quirks did not bite
+                    strict_checked += 1
                 checked += 1
-            assert c.ReplaceFirstBytes(b, "<$0>") == R.replace_all(o, b, "<$0>", first_only=True), (pat, b)
+            try:
+                first = c.ReplaceFirstBytes(b, "<$0>")
+                assert first == R.replace_all(o, b, "<$0>", quirks=strict, first_only=True), (pat, b)
+            except _capi.RgxError as ex:
+                assert strict and ex.status == _capi.RGX_E_DIVERGES
+            except NotImplementedError:
+                pass
         pats += 1
-    assert pats >= 75 and checked > 2500
+    assert pats >= 75 and checked > 2500 and strict_checked > 1000 and refused < checked // 4, (pats, checked, strict_checked, refused)
 
 
 def test_replace_large_and_closed_form(gpu):

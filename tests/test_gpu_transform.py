@@ -145,9 +145,26 @@ def test_chunk_protocol_matches_oracle(gpu, pi):
     from oracle import engines as E
     from oracle import transform as T
     from regengo_amd.stream import Config
+    from regengo_amd import _capi
     pat, tmpl, alphabet = PATTERNS[pi]
     c, o = dev(pat), E.Compiled(pat)
     rng = random.Random(100 + pi)
+    answered = refused = 0
+
+    def read_or_refused(reader):
+        """The device splice answers with the reference's output or refuses the buffer (RGX_E_DIVERGES: the emitted processor's
+        restart rule / re-slicing / bytes.Index would leave FindAllBytes there; the seeds hold such cases on purpose)."""
+        nonlocal answered, refused
+        try:
+            out = reader.read_all()
+            answered += 1
+            return out
+        except _capi.RgxError as ex:
+            assert ex.status == _capi.RGX_E_DIVERGES, ex
+            assert c.info.ref_find_offered and not c.info.can_match_empty
+            refused += 1
+            return None
+
     dl = c.info.default_max_leftover
     for trial in range(6):
         inp = make_input(rng, alphabet, SEEDS[pi], rng.choice([0, 1, 700, 5000, 30000]))
@@ -172,8 +189,10 @@ def test_chunk_protocol_matches_oracle(gpu, pi):
         want = T.replace_reader(o, r, tmpl, quirks=False, buffer_size=bs, max_leftover=ml)
         wout, werr = want.read_all(777)
         assert werr is None
-        assert got.read_all() == wout, ("replace", trial, bs, ml, len(inp))
-        assert got.chunks == want.chunks
+        gout = read_or_refused(got)
+        if gout is not None:
+            assert gout == wout, ("replace", trial, bs, ml, len(inp))
+            assert got.chunks == want.chunks
         # NewTransformReader with a host callback (spans from the device, splice on the host)
         g, r = srcs()
         gcb = lambda m, emit: (emit(b"<"), emit(m.Match[::-1]), emit(b">"))
@@ -196,7 +215,10 @@ def test_chunk_protocol_matches_oracle(gpu, pi):
                         with pytest.raises(RuntimeError):
                             gfn(g, pred, Config(sbs, 0)).read_all()
                         continue
-                    assert gfn(g, pred, Config(sbs, 0)).read_all() == wout, (kind, pred is None, trial, sbs)
+                    gout = read_or_refused(gfn(g, pred, Config(sbs, 0)))
+                    if gout is not None:
+                        assert gout == wout, (kind, pred is None, trial, sbs)
+    assert answered > 0 and answered >= refused // 4, (answered, refused)
 
 
 def test_large_replace_reader_closed_form(gpu):
