@@ -86,13 +86,14 @@ def test_random_patterns_replace_and_transform(torch_dev):
     from tests import _fuzzgen as F
     rng = random.Random(321)
     templates = ["", "<$0>", "[$1|$2]", "$$x${1}y", "$g7$0$0"]
-    done = 0
+    done = answered = refused = 0
     for p in F.gen_patterns(4242, 120):
         if any(a in p for a in ("^", "$", "\\b", "\\B")):
             continue
         try:
             o = E.Compiled(p)
-            c = Compiled(p).to(0)
+            c = Compiled(p, stdlib=True).to(0)      # the quirk-free reading: no identical-or-refused check
+            cref = Compiled(p).to(0)                # reference mode: the emitted loop's result, or RGX_E_DIVERGES
         except Exception:
             continue
         if c.info.can_match_empty or (F.has_empty_loop(o.prog) and not o.find_machine.memo):
@@ -102,6 +103,18 @@ def test_random_patterns_replace_and_transform(torch_dev):
             b = F.gen_input(rng, rng.choice([0, 7, 300, 2500]))
             for tmpl in templates:
                 assert c.ReplaceAllBytes(b, tmpl) == R.replace_all(o, b, tmpl), (p, tmpl, b)
+            if cref.info.ref_find_offered:
+                try:
+                    got = cref.ReplaceAllBytes(b, "<$0>")
+                    try:
+                        assert got == R.replace_all(o, b, "<$0>", quirks=True), (p, b)
+                        assert got == R.replace_all(o, b, "<$0>"), (p, b)          # answered: the quirks did not bite
+                    except NotImplementedError:
+                        pass
+                    answered += 1
+                except _capi.RgxError as ex:
+                    assert ex.status == _capi.RGX_E_DIVERGES, (p, b, ex)
+                    refused += 1
             assert c.ReplaceFirstBytes(b, "<$0>") == R.replace_all(o, b, "<$0>", first_only=True), (p, b)
             # streaming: buffers just above the pattern's MaxLeftover so that many chunks are cut
             dl = c.info.default_max_leftover
@@ -115,8 +128,8 @@ def test_random_patterns_replace_and_transform(torch_dev):
                     continue
                 assert got.read_all() == wout, ("reader", p, tmpl, bs, ml, b)
         done += 1
-    print("patterns", done)
-    assert done >= 40
+    print("patterns", done, "reference mode: answered", answered, "refused", refused)
+    assert done >= 40 and answered > 40
 
 
 @pytest.mark.parametrize("pat", [r"(?:a|\B)", r"(?:b|(?:01aa-)?|\B)", r"(?:ab)?\b", r"(\w+|\B)", r"(?:0+|\b)"])
