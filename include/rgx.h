@@ -256,7 +256,8 @@ int64_t rgx_count_all_device_owned(const rgx_program* p, rgx_stream_ctx* c, cons
 
 /* Batch: one independent input per string (BASELINE config C3: FindBytes over 10M strings).
  * `d_concat` all strings back to back, `d_offsets` nstr+1 uint64 CSR offsets, outputs `d_found`
- * (uint8 per string) and `d_spans` (nstr records of ncap int32, relative to the string's start).
+ * (uint8 per string) and `d_spans` (nstr records of ncap int32, relative to the string's start; the record of a string
+ * WITHOUT a match is unspecified -- FindBytes returns (nil, false) there -- read records only where found is set).
  * Semantics per string: FindBytesReuse, find.go:469-591 (first leftmost-first match).              */
 int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_concat,
                               const uint64_t* d_offsets, size_t nstr, uint8_t* d_found, int32_t* d_spans);

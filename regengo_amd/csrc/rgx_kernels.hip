@@ -1161,17 +1161,25 @@ __global__ __launch_bounds__(kBlockThreads) void batch_lds_kernel(DevTables T, c
         ResolveCapturesBatch<MODE>(tab, B, T, tab.cls, ctx_of_byte, in, s, e, tr, in_lds ? kBlockThreads : 1, rec);
       }
     }
+    // The records of a WAVE's 64 strings are contiguous in `spans` (and 16-byte aligned: a group starts at a multiple of 256
+    // strings): each wave copies its own, and a wave in which no string matched leaves its records alone (rgx.h: the record of a
+    // string without a match is unspecified) -- whole-line validators over log lines find nothing in nearly every wave, and
+    // their unset records were most of the kernel's traffic.  (No workgroup-wide vote: __syncthreads_or brings static LDS,
+    // which the 160 KiB dynamic allocation has no room for.)
     __syncthreads();
-    // records of the group are contiguous in `spans`: coalesced copy out of LDS
-    const int nrec_words = (int)(ilast - i0) * ncap;
-    int32_t* const dst = spans + i0 * ncap;
-    if (((i0 * ncap) & 3) == 0) {
-      for (int w = tid * 4; w < nrec_words; w += kBlockThreads * 4) {
-        if (w + 4 <= nrec_words) *reinterpret_cast<int4*>(dst + w) = *reinterpret_cast<const int4*>(recs + w);
-        else for (int k = w; k < nrec_words; ++k) dst[k] = recs[k];
+    {
+      const int wv = tid >> 6, ln = tid & 63;
+      const int64_t w0 = i0 + (int64_t)wv * 64;
+      const int nw = (int)(ilast - w0 < 64 ? (ilast - w0 < 0 ? 0 : ilast - w0) : 64);
+      if (__any(i < nstr && s >= 0) && nw > 0) {
+        const int nwords = nw * ncap;
+        const int32_t* const src = recs + wv * 64 * ncap;
+        int32_t* const dst = spans + w0 * ncap;
+        for (int w = ln * 4; w < nwords; w += 256) {
+          if (w + 4 <= nwords) *reinterpret_cast<int4*>(dst + w) = *reinterpret_cast<const int4*>(src + w);
+          else for (int k = w; k < nwords; ++k) dst[k] = src[k];
+        }
       }
-    } else {
-      for (int w = tid; w < nrec_words; w += kBlockThreads) dst[w] = recs[w];
     }
   }
 }
@@ -1525,16 +1533,25 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
       }
     }
     if (!want_spans) continue;
+    // The records of a WAVE's 64 strings are contiguous in `spans` (and 16-byte aligned: a group starts at a multiple of 256
+    // strings): each wave copies its own, and a wave in which no string matched leaves its records alone (rgx.h: the record of a
+    // string without a match is unspecified) -- whole-line validators over log lines find nothing in nearly every wave, and
+    // their unset records were most of the kernel's traffic.  (No workgroup-wide vote: __syncthreads_or brings static LDS,
+    // which the 160 KiB dynamic allocation has no room for.)
     __syncthreads();
-    const int nrec_words = (int)(ilast - i0) * ncap;
-    int32_t* const dst = spans + i0 * ncap;
-    if (((i0 * ncap) & 3) == 0) {
-      for (int w = tid * 4; w < nrec_words; w += kBlockThreads * 4) {
-        if (w + 4 <= nrec_words) *reinterpret_cast<int4*>(dst + w) = *reinterpret_cast<const int4*>(recs + w);
-        else for (int k = w; k < nrec_words; ++k) dst[k] = recs[k];
+    {
+      const int wv = tid >> 6, ln = tid & 63;
+      const int64_t w0 = i0 + (int64_t)wv * 64;
+      const int nw = (int)(ilast - w0 < 64 ? (ilast - w0 < 0 ? 0 : ilast - w0) : 64);
+      if (__any(i < nstr && end >= 0) && nw > 0) {
+        const int nwords = nw * ncap;
+        const int32_t* const src = recs + wv * 64 * ncap;
+        int32_t* const dst = spans + w0 * ncap;
+        for (int w = ln * 4; w < nwords; w += 256) {
+          if (w + 4 <= nwords) *reinterpret_cast<int4*>(dst + w) = *reinterpret_cast<const int4*>(src + w);
+          else for (int k = w; k < nwords; ++k) dst[k] = src[k];
+        }
       }
-    } else {
-      for (int w = tid; w < nrec_words; w += kBlockThreads) dst[w] = recs[w];
     }
   }
 }
