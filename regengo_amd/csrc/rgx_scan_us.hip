@@ -44,10 +44,23 @@ __device__ __forceinline__ int UPad(int rel) { return rel + ((rel >> 6) << 2); }
 constexpr unsigned kEDead = 1u << 24, kEFinal = 1u << 25, kEMatch = 1u << 26;
 constexpr unsigned kELoad0 = 1u << 31, kELoad1 = 1u << 30, kELoad2 = 1u << 29, kELoad3 = 1u << 28;
 
+// LDS-qualified pointer types.  The single-step walkers are real functions (not inlined): a plain pointer parameter is a generic
+// pointer there and every access through it a FLAT instruction -- the walker of the pair kernel then paid ~1300 cycles per byte
+// (two dependent FLAT loads, each behind a full waitcnt) where two ds_reads cost a tenth of that: `a.*b.*c`, whose every line
+// ends in a rewind, took 15 ms per GiB.
+#define RGX_LDS __attribute__((address_space(3)))
+typedef const unsigned char RGX_LDS* LdsU8c;
+typedef const uint16_t RGX_LDS* LdsU16c;
+typedef const unsigned RGX_LDS* LdsU32c;
+typedef const uint2 RGX_LDS* LdsU64c;
+typedef unsigned RGX_LDS* LdsU32;
+typedef int RGX_LDS* LdsI32;
+__device__ __forceinline__ void LdsOr(LdsU32 p, unsigned v) { __hip_atomic_fetch_or(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
 struct UIn {
   const uint8_t* g;          // global input
   const uint8_t* gcls;       // global byte -> class map (bytes outside the LDS window)
-  const unsigned char* tile; // LDS window: class id * 8
+  LdsU8c tile;               // LDS window: class id * 8
   int wb, wlim, len, eot8;   // wlim: staged positions (those at or beyond len hold the end-of-text class)
   __device__ __forceinline__ unsigned At8(int i) const {
     const unsigned rel = (unsigned)(i - wb);
@@ -103,7 +116,7 @@ struct UsOut {
 // began inside the slice is alive.  Reads anything the LDS window lacks from global memory.  The finishing path of the
 // wave-uniform loop below (rewinds, walks that leave the window) -- correct for every walk, just slow.
 template <int NREG, bool LOOK>
-__device__ __noinline__ void UsWalkSlow(const unsigned char* s_entb, const uint16_t* s_srow, const UIn& in, int pos, int a, int slice_end,
+__device__ __noinline__ void UsWalkSlow(LdsU8c s_entb, LdsU16c s_srow, const UIn in, int pos, int a, int slice_end,
                                         UsOut& out) {
 #define US_RECORD(S, E)                                               \
   if ((S) >= a && (S) < slice_end) {                                  \
@@ -119,8 +132,8 @@ __device__ __noinline__ void UsWalkSlow(const unsigned char* s_entb, const uint1
   unsigned pinfo = 0;
   for (;;) {
     const unsigned k8 = in.At8(i);
-    const uint2 ent = *reinterpret_cast<const uint2*>(s_entb + (row & 0xFFFFu) + k8);
-    const unsigned lo = ent.x, hi = ent.y;
+    const LdsU32c entp = (LdsU32c)(s_entb + (row & 0xFFFFu) + k8);
+    const unsigned lo = entp[0], hi = entp[1];
     const int i1 = i + 1;
     if (LOOK && (lo & kEMatch)) { pend = i; pinfo = hi; }
     if (lo & kEFinal) {
@@ -228,7 +241,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_kernel(DevTables T, UsD
     }
   }
   __syncthreads();
-  const UIn in{P.buf, U.cls, s_tile, wb, wlim, len, (int)eot8};
+  const UIn in{P.buf, U.cls, (LdsU8c)s_tile, wb, wlim, len, (int)eot8};
   const unsigned char* s_entb = reinterpret_cast<const unsigned char*>(s_ent);
 
   // ---- phase 1: the lane's walk
@@ -343,7 +356,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_kernel(DevTables T, UsD
   }
   if (cont != -1) {
     if (cont == -2) { out.mask = 0; out.ends = 0; out.last_end = -1; cont = pos; }
-    UsWalkSlow<NREG, LOOK>(s_entb, s_srow, in, cont, a, slice_end, out);
+    UsWalkSlow<NREG, LOOK>((LdsU8c)s_entb, (LdsU16c)s_srow, in, cont, a, slice_end, out);
   }
   unsigned long long mask = out.mask, ends = out.ends;
   const int last_end = out.last_end;
@@ -443,7 +456,7 @@ __host__ __device__ inline UsSLayout UsSLds(int nent4, int stride) {
 struct SIn {
   const uint8_t* g;
   const uint8_t* gcls4;        // byte -> class * 4 | 0x80 on reset bytes
-  const unsigned char* tile;   // LDS window of the same
+  LdsU8c tile;                 // LDS window of the same
   int wb, wlim, len, eot4;
   __device__ __forceinline__ unsigned At4(int i) const {
     const unsigned rel = (unsigned)(i - wb);
@@ -478,11 +491,11 @@ __device__ __forceinline__ int SliceStart(const SIn& in, const int32_t* carry_in
   int r = -1;
   if ((unsigned)(a - 4 - in.wb) < (unsigned)in.wlim && a + kSliceBytes - in.wb <= in.wlim) {
     // the slice and the byte before it sit in the window: four bytes per test (bit 7 of a tile byte = reset byte)
-    const unsigned char* row = in.tile + UPad(a - in.wb);  // the slice is one padded row of the tile
-    unsigned m = *reinterpret_cast<const unsigned*>(in.tile + UPad(a - 4 - in.wb)) & 0x80000000u;   // offset a - 1
+    const LdsU32c row = (LdsU32c)(in.tile + UPad(a - in.wb));  // the slice is one padded row of the tile
+    unsigned m = *(LdsU32c)(in.tile + UPad(a - 4 - in.wb)) & 0x80000000u;   // offset a - 1
     int base = a - 4;
     for (int d = 0; m == 0 && d < 16; ++d) {
-      m = reinterpret_cast<const unsigned*>(row)[d] & 0x80808080u;
+      m = row[d] & 0x80808080u;
       if (d == 15) m &= 0x00808080u;                       // offset a + 63 would give a sync point in the next slice
       base = a + 4 * d;
     }
@@ -618,24 +631,24 @@ __device__ __forceinline__ void UsFinishTile(const DevTables& T, const ScanParam
 
 // Single-step walker of one stretch [s, e]: consumes bytes s..e, records loads at [s, e) and ends at (s, e] (bit sets in LDS;
 // an end beyond the bit sets goes to *far).  Handles what the wave-uniform loop does not: rewinds, bytes outside the window.
-__device__ __noinline__ void UsSimpleSlow(const unsigned char* s_entb, const uint16_t* s_srow, unsigned* s_L, unsigned* s_E, int* far,
-                                          const SIn& in, int tb, int s, int e, int lookahead) {
+__device__ __noinline__ void UsSimpleSlow(LdsU8c s_entb, LdsU16c s_srow, LdsU32 s_L, LdsU32 s_E, LdsI32 far,
+                                          const SIn in, int tb, int s, int e, int lookahead) {   // (by value, see UsPairSlow)
   int i = s;
   unsigned row = s_srow[((i > 0 ? in.At4(i - 1) : (unsigned)in.eot4) & 0x7Cu) >> 2];
   int pend = -1;
   auto set_e = [&](int at) {
     const unsigned b = (unsigned)(at - tb);
-    if (b < (unsigned)kSBits) atomicOr(&s_E[b >> 5], 1u << (b & 31)); else *far = at;
+    if (b < (unsigned)kSBits) LdsOr(s_E + (b >> 5), 1u << (b & 31)); else *far = at;
   };
   for (;;) {
   while (i <= e) {
     const unsigned k4 = in.At4(i);
-    const unsigned ent = *reinterpret_cast<const unsigned*>(s_entb + (row & 0xFFFFu) + k4);
+    const unsigned ent = *(LdsU32c)(s_entb + (row & 0xFFFFu) + k4);
     if (lookahead && (ent & (1u << 29))) pend = i;
     if (ent & (1u << 30)) { set_e(i); pend = -1; }
     if ((ent & (1u << 31)) && i < e) {
       const unsigned b = (unsigned)(i - tb);
-      if (b < (unsigned)kSBits) atomicOr(&s_L[b >> 5], 1u << (b & 31));
+      if (b < (unsigned)kSBits) LdsOr(s_L + (b >> 5), 1u << (b & 31));
     }
     if (!lookahead && (ent & (1u << 29))) pend = i + 1;
     row = ent & 0xFFFFu;
@@ -754,7 +767,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_simple_kernel(DevTables
   US_STAMP()
   __syncthreads();
   US_STAMP()
-  const SIn in{P.buf, U.cls4, s_tile, wb, wlim, len, (int)eot4};
+  const SIn in{P.buf, U.cls4, (LdsU8c)s_tile, wb, wlim, len, (int)eot4};
   const unsigned char* s_entb = reinterpret_cast<const unsigned char*>(s_ent4);
 
   // ---- the lane's stretch [s, e]
@@ -887,7 +900,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_simple_kernel(DevTables
   }
   US_STAMP()
   if (slow && s >= 0)
-    UsSimpleSlow(s_entb, s_srow, s_L, s_E, s_far, in, tb, s, e < len ? e : len, U.lookahead);
+    UsSimpleSlow((LdsU8c)s_entb, (LdsU16c)s_srow, (LdsU32)s_L, (LdsU32)s_E, (LdsI32)s_far, in, tb, s, e < len ? e : len, U.lookahead);
   __syncthreads();
   US_STAMP()
 #ifdef RGX_US_PROFILE
@@ -938,8 +951,8 @@ __host__ __device__ inline UsPLayout UsPLds(int nent2, int stride) {
 struct PIn {
   const uint8_t* g;
   const uint8_t* gcls2;        // byte -> class | 0x80 on reset bytes
-  const unsigned char* tile;   // LDS: packed class nibbles
-  const unsigned* R;           // LDS: reset bits over the window
+  LdsU8c tile;                 // LDS: packed class nibbles
+  LdsU32c R;                   // LDS: reset bits over the window
   int wb, wlim, len, eot;
   __device__ __forceinline__ unsigned Cls(int i) const {          // class of byte i (the end-of-text class from len on)
     const unsigned rel = (unsigned)(i - wb);
@@ -979,27 +992,29 @@ __device__ __forceinline__ int PSliceStart(const PIn& in, const int32_t* carry_i
 }
 
 // single-step walker (second nibble = "no byte"): rewinds, bytes outside the window
-__device__ __noinline__ void UsPairSlow(const unsigned char* s_entb, const uint16_t* s_srow, unsigned* s_L, unsigned* s_E, int* far,
-                                        const PIn& in, int tb, int s, int e, int lookahead) {
+__device__ __noinline__ int UsPairSlow(LdsU8c s_entb, LdsU16c s_srow, LdsU32 s_L, LdsU32 s_E, LdsI32 far,
+                                        const PIn in, int tb, int s, int e, int lookahead) {   // (by value: a reference into the caller's frame is scratch memory, read on every step)
   int i = s;
+  int steps = 0;
   unsigned row = s_srow[i > 0 ? in.Cls(i - 1) : (unsigned)in.eot];
   int pend = -1;
   auto set_e = [&](int at) {
     const unsigned b = (unsigned)(at - tb);
-    if (b < (unsigned)kSBits) atomicOr(&s_E[b >> 5], 1u << (b & 31)); else *far = at;
+    if (b < (unsigned)kSBits) LdsOr(s_E + (b >> 5), 1u << (b & 31)); else *far = at;
   };
   for (;;) {
   while (i <= e) {
-    const unsigned ent = *reinterpret_cast<const unsigned*>(s_entb + (((row & 0xFFFFu) + (in.Cls(i) | 0xF0u)) << 2));
+    const unsigned ent = *(LdsU32c)(s_entb + (((row & 0xFFFFu) + (in.Cls(i) | 0xF0u)) << 2));
     if (lookahead && (ent & (1u << 27))) pend = i;
     if (ent & (1u << 29)) { set_e(i); pend = -1; }
     if ((ent & (1u << 31)) && i < e) {
       const unsigned b = (unsigned)(i - tb);
-      if (b < (unsigned)kSBits) atomicOr(&s_L[b >> 5], 1u << (b & 31));
+      if (b < (unsigned)kSBits) LdsOr(s_L + (b >> 5), 1u << (b & 31));
     }
     if (!lookahead && (ent & (1u << 27))) pend = i + 1;
     row = ent & 0xFFFFu;
     ++i;
+    ++steps;
     if (row == kPZoff) {
       if (pend < 0 || pend > e) break;
       set_e(pend);
@@ -1008,12 +1023,12 @@ __device__ __noinline__ void UsPairSlow(const unsigned char* s_entb, const uint1
       row = s_srow[in.Cls(i - 1)];
       pend = -1;
     } else if (row == 0) {
-      return;
+      return steps;
     }
   }
-  if (pend < 0 || pend > e) return;            // (see UsSimpleSlow)
+  if (pend < 0 || pend > e) return steps;            // (see UsSimpleSlow)
   set_e(pend);
-  if (pend >= e || pend >= in.len) return;
+  if (pend >= e || pend >= in.len) return steps;
   i = pend;
   row = s_srow[in.Cls(i - 1)];
   pend = -1;
@@ -1160,7 +1175,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
   US_STAMP()
   const int next_tile = P.use_tickets ? (int)s_misc[11] : tile + (int)gridDim.x;
   issue_loads(next_tile);                // in flight during this tile's walk
-  const PIn in{P.buf, U.cls2, s_tile, s_R, wb, wlim, len, (int)eot};
+  const PIn in{P.buf, U.cls2, (LdsU8c)s_tile, (LdsU32c)s_R, wb, wlim, len, (int)eot};
 
   // ---- the lane's stretch [s, e] (scan_us_simple_kernel has the commentary)
   const int slice = tile * kBlockThreads + tid;
@@ -1280,8 +1295,10 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
     if (fast && ((zrow & 0xFFFFu) == kPZoff || carry_end)) slow = true;
   }
   US_STAMP()
+  int slow_steps = 0;
   if (slow && s >= 0)
-    UsPairSlow(s_entb, s_srow, s_L, s_E, s_far, in, tb, s, e < len ? e : len, U.lookahead);
+    slow_steps = UsPairSlow((LdsU8c)s_entb, (LdsU16c)s_srow, (LdsU32)s_L, (LdsU32)s_E, (LdsI32)s_far, in, tb, s, e < len ? e : len, U.lookahead);
+  (void)slow_steps;
   __syncthreads();
   US_STAMP()
   if (have_prev) emit_prev();
@@ -1298,9 +1315,11 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
   }
   US_STAMP()
 #ifdef RGX_US_PROFILE
+  int pmaxsteps = slow_steps;
+  for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(pmaxsteps, d, 64); pmaxsteps = o > pmaxsteps ? o : pmaxsteps; }
   if ((blockIdx.x == 200 || blockIdx.x == 901) && (tid == 0 || tid == 130) && tile > 20000 && tile < 22000)
-    printf("blk %d tid %d tile %d: zero %lld | stage %lld | barrier %lld | sync search %lld | barrier+end+setup %lld | walk %lld | slow+barrier %lld | finish %lld\n",
-           blockIdx.x, tid, tile, tstamp[1] - tstamp[0], tstamp[2] - tstamp[1], tstamp[3] - tstamp[2], tstamp[4] - tstamp[3], tstamp[5] - tstamp[4],
+    printf("blk %d tid %d tile %d: s %d e %d slow %d steps %d wave-max-steps %d | zero %lld | stage %lld | barrier %lld | sync search %lld | barrier+end+setup %lld | walk %lld | slow+barrier %lld | finish %lld\n",
+           blockIdx.x, tid, tile, s - tb, (e < len ? e : len) - tb, (int)slow, slow_steps, pmaxsteps, tstamp[1] - tstamp[0], tstamp[2] - tstamp[1], tstamp[3] - tstamp[2], tstamp[4] - tstamp[3], tstamp[5] - tstamp[4],
            tstamp[6] - tstamp[5], tstamp[7] - tstamp[6], tstamp[8] - tstamp[7]);
   nstamp = 0;
   US_STAMP()
