@@ -68,7 +68,11 @@ def _worker(rank, world, port, pattern, data_bytes, kw, q):
         bases = []
         stop_after = kw.get("stop_after")
 
-        def on_rows(rows, k, base):
+        def on_rows(rows, k, base, win_lo=None):
+            if win_lo is not None:          # absolute=False: int32 rows relative to the window's first byte + that byte's offset
+                assert rows.dtype == torch.int32
+                from regengo_amd.dist import to_global
+                rows = to_global(rows, win_lo)
             got.append((k, rows.tolist()))
             bases.append(base)
             if stop_after is not None and len(got) >= stop_after:
@@ -81,7 +85,7 @@ def _worker(rank, world, port, pattern, data_bytes, kw, q):
             return True
 
         st = rd.find_reader(src, on_rows=None if kw.get("count_only") else on_rows, on_match=on_match if kw.get("per_match") else None,
-                            gather=kw.get("gather", False), count_only=kw.get("count_only", False))
+                            gather=kw.get("gather", False), count_only=kw.get("count_only", False), absolute=not kw.get("relative", False))
         q.put((rank, got, bases, st, seen))
     finally:
         if world > 1:
@@ -218,4 +222,13 @@ def test_reader_source_with_a_right_halo_longer_than_the_stream(built):
     exp = _expect(pat, data)
     for world in (1, 2):
         outs = _run(pat, data, world=world, W=4096, reader=True, unbounded_halo=1 << 16)
+        assert _merge(outs, world) == exp
+
+
+def test_window_relative_rows(built):
+    """absolute=False: the rows stay int32 and window-relative (what the kernel wrote), the window's stream offset comes along."""
+    data = _log(30_000, seed=21)
+    exp = _expect(DATE, data)
+    for world in (1, 2):
+        outs = _run(DATE, data, world=world, W=4096, relative=True)
         assert _merge(outs, world) == exp
