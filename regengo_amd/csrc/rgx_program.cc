@@ -287,6 +287,7 @@ int UploadUs(Program* p) {
   std::vector<uint16_t> srow2(stride);
   std::vector<uint8_t> cls2(256, 0);
   const bool pairs = simple && stride <= 15 && u.nstates + 1 <= 63;
+  bool has_rewind = false;
   if (pairs) {
     constexpr uint32_t kPitch2W = 257;                  // dwords per row; row offsets are kept in DWORDS (row + index is one SDWA add)
     const int nrows = u.nstates + 1;
@@ -311,7 +312,8 @@ int UploadUs(Program* p) {
           if (f1) v |= 1u << 29;
           if (f2) v |= 1u << 28;
           if (m1) v |= 1u << 27;
-          if (r2 >= 2 && !(u.sflags[r2 - 1] & 1)) v |= 1u << 26;         // the state after both bytes has a match pending
+          if (m2) v |= 1u << 26;                                           // (a match ends at the second byte)
+          if (r2 == 1 && r >= 2) has_rewind = true;                        // the rewind row can be entered: rgx_scan_us.hip, RW
           ent2[(size_t)r * kPitch2W + (k1 | (k2 << 4))] = v;
         }
     for (int k = 0; k < stride; k++) srow2[k] = (uint16_t)((srow4[k] / kPitch) * kPitch2W);
@@ -336,6 +338,7 @@ int UploadUs(Program* p) {
   if (pairs) {
     d.ent2 = (const uint32_t*)(b + off_ent2); d.start_row2 = (const uint16_t*)(b + off_srow2); d.cls2 = b + off_cls2;
     d.nent2 = (int32_t)ent2.size();
+    d.has_rewind = has_rewind ? 1 : 0;
   }
   p->usdev = d;
   p->d_arena_us = dptr;

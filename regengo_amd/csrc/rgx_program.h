@@ -124,6 +124,7 @@ struct UsDev {
   const uint16_t* start_row2;     // [ncls+1] in ent2 dword offsets
   const uint8_t* cls2;            // [256] byte -> class | 0x80 on reset bytes
   int32_t nent2;                  // (nstates + 1) * 257
+  int32_t has_rewind;             // the pair table's rewind row (row 1) can be entered: the kernel instance that handles rewinds in its fast walk
 };
 
 struct Program {

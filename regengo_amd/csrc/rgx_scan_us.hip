@@ -1041,6 +1041,11 @@ __device__ __forceinline__ unsigned PairEntryAddr(unsigned row, unsigned w) {
   return RowPlusByte<N>(row, w) << 2;
 }
 
+// RW: the automaton has a rewind row (a match can be final long after its end: `a.*b.*c` at the newline), and the wave-uniform
+// walk handles it itself -- it remembers where the last pending match ended (one more flag accumulator), and a lane that parks in
+// the rewind row takes that offset as its new start and walks again, with the rest of the wave, instead of handing its whole stretch
+// to the single-step walker (250 serial steps per wave: 14 ms per GiB for that pattern).  Automata without such a row keep the leaner loop.
+template <bool RW>
 __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T, UsDev U, ScanParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const UsPLayout Ly = UsPLds(U.nent2, U.stride);
@@ -1217,25 +1222,31 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
     }
   }
   // ---- wave-uniform walk: a trip = one dword of the packed tile = eight input bytes = four look-ups
-  {
+  int ws = s;                      // where this pass of the walk starts (RW: the end of the pending match after a rewind)
+  bool rw_more = false;
+  int rw_pass = 0;
+  do {
     const int first_valid = wb < 0 ? 0 : wb;
-    bool fast = s >= 0;
+    bool fast = s >= 0 && (rw_pass == 0 || rw_more);
+    rw_more = false;
     int e_eff = e < len ? e : len;
-    if (fast && (s < first_valid || e_eff >= wb + wlim)) { fast = false; slow = true; }
-    const int i0 = fast ? (s & ~7) : first_valid;
+    if (fast && (ws < first_valid || e_eff >= wb + wlim)) { fast = false; slow = true; }
+    const int i0 = fast ? (ws & ~7) : first_valid;
     int ntrips = fast ? ((e_eff - i0) >> 3) + 1 : 0;
 #pragma unroll
     for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(ntrips, d, 64); ntrips = o > ntrips ? o : ntrips; }
     const int trips = __builtin_amdgcn_readfirstlane(ntrips);
     US_STAMP()
     unsigned startrow = 0;
-    if (fast) startrow = s_srow[s > 0 ? in.Cls(s - 1) : eot];
-    const unsigned phase = fast ? (unsigned)(s & 7) : 8u;       // the byte of the first trip at which the lane enters its start state
+    if (fast) startrow = s_srow[ws > 0 ? in.Cls(ws - 1) : eot];
+    const unsigned phase = fast ? (unsigned)(ws & 7) : 8u;      // the byte of the first trip at which the lane enters its start state
     const unsigned sub0 = phase >> 1;                            // ... i.e. look-up sub0, with the first nibble made "no byte" when phase is odd
     const unsigned xmask = (fast && (phase & 1u)) ? 0xFu << (8 * sub0) : 0u;
     if (!fast) e_eff = -1;
     unsigned row = 0, zrow = 0;
     unsigned lacc = 0, eacc = 0, lword = 0, eword = 0;
+    unsigned macc = 0;               // RW: match flags (a match ends at this byte, not final yet)
+    int pm = -1, pf = -1;            // RW: offsets of the last match flag and of the last final flag
     const unsigned relmax = (unsigned)((wlim >> 1) - 4);
     unsigned relp = (unsigned)(i0 - wb) >> 1;
     int kl = e_eff - i0;                                         // loads count at offsets [0, kl) of the trip, ends at [0, kl]
@@ -1246,20 +1257,27 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
     const unsigned ent = *reinterpret_cast<const unsigned*>(s_entb + PairEntryAddr<N>(row, w)); \
     lacc = __builtin_amdgcn_alignbit(lacc, ent, 30);     /* (lacc << 2) | the two load flags */ \
     eacc = __builtin_amdgcn_alignbit(eacc, ent << 2, 30);                               \
+    if (RW) macc = __builtin_amdgcn_alignbit(macc, ent << 4, 30);                       \
     row = ent;                                                                          \
   }
 #define USP_FLUSH()                                                                     \
   {                                                                                     \
     unsigned ln = __builtin_bitreverse32(lacc) >> 24, en = __builtin_bitreverse32(eacc) >> 24;   /* byte j of the trip at bit j */ \
+    unsigned mn = RW ? __builtin_bitreverse32(macc) >> 24 : 0u;                         \
     bool parking = false;                                                               \
     if (__any(kl < 8)) {                                                                \
       const int kc = kl < 0 ? 0 : (kl > 8 ? 8 : kl);                                    \
       ln &= (1u << kc) - 1u;                                                            \
       en &= kl < 0 ? 0u : (2u << kc) - 1u;                                              \
+      mn &= kl < 0 ? 0u : (2u << kc) - 1u;                                              \
       parking = kl < 8;                                                                 \
       zrow = parking ? row : zrow;                                                      \
       row = parking ? 0u : row;                                                         \
       kl = parking ? 0x3FFFFFFF : kl;                                                   \
+    }                                                                                   \
+    if (RW) {                                                                           \
+      if (mn) pm = tb + (int)irel + 31 - __builtin_clz(mn);                             \
+      if (en) pf = tb + (int)irel + 31 - __builtin_clz(en);                             \
     }                                                                                   \
     const unsigned sh = irel & 31u;                                                     \
     lword |= ln << sh;                                                                  \
@@ -1292,12 +1310,29 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
 #undef USP_FLUSH
     // rewind, or a stretch that ends at a carry-pass position (scan_us_simple_kernel has the commentary)
     const bool carry_end = P.carry_in != nullptr && ek >= 0 && found_carry(P.carry_in, ek);
-    if (fast && ((zrow & 0xFFFFu) == kPZoff || carry_end)) slow = true;
-  }
+    const bool zpark = fast && (zrow & 0xFFFFu) == kPZoff;
+    if (RW && !carry_end) {
+      if (zpark) {
+        // the state died with an older match pending (UsPairSlow has the same steps): the match flag and a final flag of the same
+        // byte come in the order final, match (match, final with look-ahead) -- the match is still pending iff it is the later one
+        const bool pending = pm >= 0 && (U.lookahead ? pm > pf : pm >= pf);
+        const int pend = U.lookahead ? pm : pm + 1;
+        if (pending && pend <= e_eff) {
+          const unsigned b = (unsigned)(pend - tb);
+          if (b < (unsigned)kSBits) atomicOr(&s_E[b >> 5], 1u << (b & 31)); else *s_far = pend;
+          if (pend < len) { ws = pend; rw_more = true; }        // the search goes on from the match's end
+        }
+      }
+    } else if (fast && (zpark || carry_end)) {
+      slow = true;
+    }
+    ++rw_pass;
+  } while (RW && rw_pass < 6 && __any(rw_more));
+  if (RW && rw_more) slow = true;                                // (six rewinds in one stretch: the walker takes the rest)
   US_STAMP()
   int slow_steps = 0;
   if (slow && s >= 0)
-    slow_steps = UsPairSlow((LdsU8c)s_entb, (LdsU16c)s_srow, (LdsU32)s_L, (LdsU32)s_E, (LdsI32)s_far, in, tb, s, e < len ? e : len, U.lookahead);
+    slow_steps = UsPairSlow((LdsU8c)s_entb, (LdsU16c)s_srow, (LdsU32)s_L, (LdsU32)s_E, (LdsI32)s_far, in, tb, RW ? ws : s, e < len ? e : len, U.lookahead);
   (void)slow_steps;
   __syncthreads();
   US_STAMP()
@@ -1440,8 +1475,10 @@ hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t str
   static const bool no_simple = ExpEnv("RGX_NO_US_SIMPLE") != nullptr;
   static const bool no_pairs = ExpEnv("RGX_NO_US_PAIRS") != nullptr;
   if (U.ent2 && !no_simple && !no_pairs) {
-    static bool attr2 = false;
-    if (!attr2) { hipFuncSetAttribute((const void*)scan_us_pair_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr2 = true; }
+    const bool rw = U.has_rewind != 0;
+    const void* const fn = rw ? (const void*)scan_us_pair_kernel<true> : (const void*)scan_us_pair_kernel<false>;
+    static bool attr2[2] = {false, false};
+    if (!attr2[rw]) { hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr2[rw] = true; }
     // persistent workgroups: no more than the chip holds at once (the occupancy query is known to over-report by one for
     // SGPR-heavy kernels, and a workgroup that is not resident would stall every look-back behind it until the bounded spin
     // sends the scan to ticket mode)
@@ -1449,7 +1486,7 @@ hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t str
     // residency depends on the pattern's table size: asked per LDS footprint (and remembered), never carried over from another
     // pattern -- a grid sized for a small table deadlocks the look-back of a large one until the bounded spin gives up (1.4 s)
     static std::mutex mu;
-    static std::map<size_t, int> per_cu_of;
+    static std::map<size_t, int> per_cu_of;     // key: LDS footprint * 2 + kernel instance
     static int ncu = 0;
     int per_cu = 0;
     {
@@ -1459,21 +1496,24 @@ hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t str
         hipGetDevice(&dev);
         hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
       }
-      auto it = per_cu_of.find(shp);
+      auto it = per_cu_of.find(shp * 2 + (rw ? 1 : 0));
       if (it == per_cu_of.end()) {
         int q = 0;
-        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, scan_us_pair_kernel, kBlockThreads, shp) != hipSuccess || q < 1) q = 1;
+        hipError_t oe = rw ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, scan_us_pair_kernel<true>, kBlockThreads, shp)
+                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, scan_us_pair_kernel<false>, kBlockThreads, shp);
+        if (oe != hipSuccess || q < 1) q = 1;
         // 4 per CU measured best (16 waves: 3 leaves the SIMDs idle, 5 adds nothing); the SGPR count admits 6, so 4 is resident
         // with a margin even where the query over-reports by one; below that, one less than the query says
         if (q > 4) q = 4; else if (q > 2) q -= 1;
         if (ExpEnv("RGX_US_PER_CU")) q = atoi(ExpEnv("RGX_US_PER_CU"));
-        it = per_cu_of.emplace(shp, q).first;
+        it = per_cu_of.emplace(shp * 2 + (rw ? 1 : 0), q).first;
       }
       per_cu = it->second;
     }
     int nblk = per_cu * ncu;
     if (nblk > P.ntiles) nblk = P.ntiles;
-    hipLaunchKernelGGL(scan_us_pair_kernel, dim3(nblk), block, shp, stream, T, U, P);
+    if (rw) hipLaunchKernelGGL(scan_us_pair_kernel<true>, dim3(nblk), block, shp, stream, T, U, P);
+    else hipLaunchKernelGGL(scan_us_pair_kernel<false>, dim3(nblk), block, shp, stream, T, U, P);
     return hipGetLastError();
   }
   if (U.ent4 && !no_simple) {
