@@ -1186,19 +1186,36 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
   const int slice = tile * kBlockThreads + tid;
   const int a = tb + tid * kSliceBytes;
   int s = PSliceStart(in, P.carry_in, slice);
+  s_sync[tid] = s;
+  __syncthreads();
   if (s < 0 && a < len && !(P.carry_in && P.carry_in[slice] >= 0)) {
-    int lower = a - 1 - kUMaxLookBehind;
-    if (lower < 0) lower = 0;
-    int j = a - 2;
-    while (j >= lower && !in.Reset(j)) --j;
-    if (j < lower && lower > 0) {
+    // No sync point in the slice: some earlier lane walks it -- unless there is no reset byte in [a - 1 - kUMaxLookBehind, a - 2]
+    // either (then the slice is "unsynced" and the carry pass settles it).  Inside the tile that range is the sixteen slices before
+    // this one, whose answers are in s_sync; only the part in front of the tile is searched, a word of reset bits at a time.
+    // (Patterns whose only reset byte is the newline spent a third of the tile's time here, one byte per step.)
+    bool near = false;
+    for (int t = tid - 1; t >= 0 && t >= tid - kUMaxLookBehind / kSliceBytes && !near; --t) near = s_sync[t] >= 0;
+    if (!near && tid < kUMaxLookBehind / kSliceBytes) {
+      int lower = a - 1 - kUMaxLookBehind;
+      if (lower < 0) lower = 0;
+      int j = tb - 2;
+      while (j >= lower && !near) {
+        const unsigned rel = (unsigned)(j - wb);
+        if (rel < (unsigned)wlim) {
+          if (in.R[rel >> 5] & (0xFFFFFFFFu >> (31u - (rel & 31u)))) near = true;
+          else j -= (int)(rel & 31u) + 1;
+        } else {
+          if (in.Reset(j)) near = true; else --j;
+        }
+      }
+      if (!near && lower == 0) near = true;               // reached the start of the text: offset 0 is a sync point
+    }
+    if (!near) {
       atomicAdd(&P.counters[1], 1u);
       if (P.slice_unsynced) P.slice_unsynced[slice] = 1;
     }
   }
-  s_sync[tid] = s;
   US_STAMP()
-  __syncthreads();
   int e = 0x7FFFFFF0;
   bool slow = false;
   int ek = -1;
