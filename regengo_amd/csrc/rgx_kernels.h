@@ -26,6 +26,8 @@ struct ScanParams {
   int32_t starts_only;           // fixed-template patterns: write one int32 (match start) per match instead of ncap
   int32_t use_w;                 // sync points from the sync automaton W (rgx_dfa.h) instead of reset bytes: scan_kernel only
   int32_t use_tickets;           // 1: tile/group ids from the ticket counter; 0: blockIdx.x (bounded spin, host falls back)
+  int32_t us_rewind;             // pair kernel: take the instance that rewinds inside its fast walk (the program's earlier scans sent
+                                 // many lanes to the single-step walker: counters[2])
   int32_t debug;                 // experiment switches (RGX_DEBUG): 1 = unordered base (no look-back), 2 = no span stores
 };
 

@@ -1105,6 +1105,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
   __syncthreads();
   int tile = (int)s_misc[0];
   unsigned long long group_total = 0;
+  unsigned slow_lanes = 0;
   UsTileOut prev{};
   bool have_prev = false;
   // records of the previous tile: its look-back is resolved only now, one whole walk after its count was published -- the
@@ -1348,6 +1349,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
   if (RW && rw_more) slow = true;                                // (six rewinds in one stretch: the walker takes the rest)
   US_STAMP()
   int slow_steps = 0;
+  slow_lanes += (slow && s >= 0) ? 1u : 0u;
   if (slow && s >= 0)
     slow_steps = UsPairSlow((LdsU8c)s_entb, (LdsU16c)s_srow, (LdsU32)s_L, (LdsU32)s_E, (LdsI32)s_far, in, tb, RW ? ws : s, e < len ? e : len, U.lookahead);
   (void)slow_steps;
@@ -1380,6 +1382,14 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
  }
   if (have_prev) { __syncthreads(); emit_prev(); }
   if (tid == 0 && group_total) atomicAdd(P.total, group_total);
+  // how many lanes needed the single-step walker (one atomic per wave of a persistent workgroup): the host moves a program whose
+  // scans rewind a lot to the instance that rewinds in its fast walk
+  {
+    unsigned n = slow_lanes;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d, 64);
+    if ((tid & 63) == 0 && n) atomicAdd(&P.counters[2], n);
+  }
 }
 
 
@@ -1492,7 +1502,7 @@ hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t str
   static const bool no_simple = ExpEnv("RGX_NO_US_SIMPLE") != nullptr;
   static const bool no_pairs = ExpEnv("RGX_NO_US_PAIRS") != nullptr;
   if (U.ent2 && !no_simple && !no_pairs) {
-    const bool rw = U.has_rewind != 0;
+    const bool rw = U.has_rewind != 0 && P.us_rewind != 0;
     const void* const fn = rw ? (const void*)scan_us_pair_kernel<true> : (const void*)scan_us_pair_kernel<false>;
     static bool attr2[2] = {false, false};
     if (!attr2[rw]) { hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr2[rw] = true; }
