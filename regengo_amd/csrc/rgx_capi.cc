@@ -22,6 +22,7 @@ struct rgx_program {
   // learned at run time, kept with the PROGRAM so that every context (and a context handed from program to program,
   // rgx_stream_ctx_rebind) starts where the last scan ended: this pattern's texts need the sync automaton W
   mutable std::atomic<int> prefer_w{0};
+  mutable std::atomic<int> prefer_wsync{0};  // the blind walk of the sync automaton left slices without a sync point: exact sync points first (FindAllDevice)
   mutable std::atomic<int> prefer_rw{0};   // the pair kernel's rewinding instance (FindAllDevice: many lanes went to the single-step walker)
 };
 
@@ -241,23 +242,48 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   // Every scan but the exact kernel's may meet slices without a sync point in reach; the first scan marks them as it goes
   // (a byte per slice, cleared here), so that the carry pass needs no scan of its own to find them.
   bool marked = false;
+  bool carry_ready = false;
+  // Exact sync points from the optimistic chunk walk + ordered repair of the sync automaton, handed to the scan as per-slice
+  // start positions.  Taken after a scan whose blind walk proved little -- and FIRST, in place of that scan, once a program is
+  // known for it (two scans of `<tag attr="...">` patterns over a log became one; prefer_wsync).
+  auto wsync = [&]() -> int {
+    int64_t cc = 0;
+    if (c->d_carry) { hipFree(c->d_carry); c->d_carry = nullptr; }
+    if ((rc = Ensure(&c->d_carry, &cc, (int64_t)nslices + 64)) != RGX_OK) return rc;
+    const int32_t nchunks = WSyncChunks(ilen);
+    if ((rc = Ensure(&c->d_trace, &c->trace_cap, 2 * (int64_t)nchunks + 64)) != RGX_OK) return rc;   // per-chunk scratch (uint16)
+    uint32_t* d_stats = (uint32_t*)(c->d_carry + nslices + 8);
+    HIP_TRY(LaunchWSync(T, d_buf, ilen, c->d_carry, c->d_trace, d_stats, c->stream));
+    uint32_t h_stats[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(h_stats, d_stats, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (h_stats[1]) HIP_TRY(LaunchWSyncOrdered(T, d_buf, ilen, c->d_carry, c->d_trace, d_stats, c->stream));   // a thread really spans > 4 KiB
+    HIP_TRY(LaunchWSyncFill(c->d_carry, ilen, c->stream));
+    P.carry_in = c->d_carry;
+    carry_ready = true;
+    return RGX_OK;
+  };
+  const int pws = p->prefer_wsync.load(std::memory_order_relaxed);      // 1: exact sync points first; -1: tried, the carry pass is cheaper
+  const bool learn_ws = use_w && pws == 0;
+  const bool tm = c->timing || learn_ws;
+  if (use_w && pws > 0) { if ((rc = wsync()) != RGX_OK) return rc; }
   if (!UseExactKernel(T, ilen)) {
     if ((rc = Ensure(&c->d_unsynced, &c->slice_cap, nslices)) != RGX_OK) return rc;
     HIP_TRY(hipMemsetAsync(c->d_unsynced, 0, nslices, c->stream));
     P.slice_unsynced = c->d_unsynced;
     marked = true;
   }
-  if ((rc = run_scan(c->timing)) != RGX_OK) return rc;
+  if ((rc = run_scan(tm)) != RGX_OK) return rc;
   P.slice_unsynced = nullptr;
   if (((uint32_t*)&c->h_read[2])[3]) {
     // a look-back spin hit its bound (block ids assumed dispatch order and the assumption failed): repeat with tickets,
     // which need no assumption at all
     P.use_tickets = 1;
-    if ((rc = run_scan(c->timing)) != RGX_OK) return rc;
+    if ((rc = run_scan(tm)) != RGX_OK) return rc;
     if (((uint32_t*)&c->h_read[2])[3]) { SetError("look-back timed out in ticket mode"); return RGX_E_HIP; }
   }
   float ms = 0;
-  if (c->timing) hipEventElapsedTime(&ms, c->ev0, c->ev1);
+  if (tm) hipEventElapsedTime(&ms, c->ev0, c->ev1);
   uint32_t unsynced = ((uint32_t*)&c->h_read[2])[1];
   if (unsynced && !use_w && UseUsKernel(T, ilen, false)) {
     // the one-step-per-byte kernels: slices without a sync point in reach get their search positions from ONE walk of the
@@ -278,8 +304,8 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     HIP_TRY(LaunchCarryUs(T, d_buf, ilen, c->d_unsynced, c->d_carry, nslices, c->stream));
     P.slice_unsynced = nullptr;
     P.carry_in = c->d_carry;
-    if ((rc = run_scan(c->timing)) != RGX_OK) return rc;
-    if (c->timing) hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    if ((rc = run_scan(tm)) != RGX_OK) return rc;
+    if (tm) hipEventElapsedTime(&ms, c->ev0, c->ev1);
     const uint32_t still = ((uint32_t*)&c->h_read[2])[1];
     if (still) { SetError("slices without a search position after the carry pass"); return RGX_E_HIP; }
   } else
@@ -293,40 +319,31 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     P.use_w = 1;
     HIP_TRY(hipMemsetAsync(c->d_unsynced, 0, nslices, c->stream));      // this scan's marks replace the first scan's
     P.slice_unsynced = c->d_unsynced;
-    if ((rc = run_scan(c->timing)) != RGX_OK) return rc;
+    if ((rc = run_scan(tm)) != RGX_OK) return rc;
     P.slice_unsynced = nullptr;
-    if (c->timing) hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    if (tm) hipEventElapsedTime(&ms, c->ev0, c->ev1);
     unsynced = ((uint32_t*)&c->h_read[2])[1];
   }
-  bool carry_ready = false;
   const bool us_done = P.carry_in != nullptr && UseUsKernel(T, ilen, false) && !use_w;     // the branch above settled it
+  const bool many_unsynced = (int64_t)unsynced * 1024 > (int64_t)nslices;
   if (us_done) {
     // nothing left to do
   } else
-  if (unsynced && w_ok && (int64_t)unsynced * 1024 > (int64_t)nslices) {
-    // (a handful of unsynced slices goes straight to the carry pass below)
-    // the blind walk proves nothing for this pattern on this text (a thread may survive any byte): exact sync points
-    // from the optimistic chunk walk + ordered repair, handed to the scan as per-slice start positions
-    int64_t cc = 0;
-    if (c->d_carry) { hipFree(c->d_carry); c->d_carry = nullptr; }
-    if ((rc = Ensure(&c->d_carry, &cc, (int64_t)nslices + 64)) != RGX_OK) return rc;
-    const int32_t nchunks = WSyncChunks(ilen);
-    if ((rc = Ensure(&c->d_trace, &c->trace_cap, 2 * (int64_t)nchunks + 64)) != RGX_OK) return rc;   // per-chunk scratch (uint16)
-    uint32_t* d_stats = (uint32_t*)(c->d_carry + nslices + 8);
-    HIP_TRY(LaunchWSync(T, d_buf, ilen, c->d_carry, c->d_trace, d_stats, c->stream));
-    uint32_t h_stats[2] = {0, 0};
-    HIP_TRY(hipMemcpyAsync(h_stats, d_stats, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if (h_stats[1]) HIP_TRY(LaunchWSyncOrdered(T, d_buf, ilen, c->d_carry, c->d_trace, d_stats, c->stream));   // a thread really spans > 4 KiB
-    HIP_TRY(LaunchWSyncFill(c->d_carry, ilen, c->stream));
-    P.carry_in = c->d_carry;
+  if (unsynced && w_ok && !carry_ready && (many_unsynced || learn_ws)) {
+    // many: the blind walk proves nothing for this pattern on this text (a thread may survive any byte) -- exact sync points, one
+    // more scan, and later scans of this program start from them.  A handful: the carry pass below resolves them at the price of
+    // a second scan; whether a scan from exact sync points alone beats that depends on the pattern (they lie further apart than
+    // the blind walk's: the log-line pattern goes 20 -> 8 ms per GiB, the e-mail + rest-of-line pattern 70 -> 98), so the first
+    // such call of a program tries, times both scans and the program remembers the verdict.
+    const float t_blind = ms;
+    if ((rc = wsync()) != RGX_OK) return rc;
     HIP_TRY(hipMemsetAsync(c->d_unsynced, 0, nslices, c->stream));      // this scan's marks replace the earlier ones
     P.slice_unsynced = c->d_unsynced;
-    if ((rc = run_scan(c->timing)) != RGX_OK) return rc;
+    if ((rc = run_scan(tm)) != RGX_OK) return rc;
     P.slice_unsynced = nullptr;
-    if (c->timing) hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    if (tm) hipEventElapsedTime(&ms, c->ev0, c->ev1);
     unsynced = ((uint32_t*)&c->h_read[2])[1];
-    carry_ready = true;
+    p->prefer_wsync.store(many_unsynced || ms + 1.5f < 2.0f * t_blind ? 1 : -1, std::memory_order_relaxed);
   }
   if (unsynced && !us_done) {
     // rare path: some slices found no sync point; resolve their entry positions serially and rescan.
