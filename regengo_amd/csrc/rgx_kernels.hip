@@ -208,6 +208,22 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
       s_sync[tid] = ha >= 0 ? walk(ha, ha + kSliceBytes) : -1;
     }
     __syncthreads();
+    // The staged look-behind is four slices; when it holds no sync point, the first lanes of the tile would all go to the carry
+    // pass (and the whole text to a second scan) for want of one that lies a few hundred bytes back: the first wave walks the
+    // slices before the window straight from global memory, one per lane, as far as a lane may re-walk at all.
+    if (wave == 0) {
+      constexpr int kFar = (kMaxLookBehind - kHaloL) / kSliceBytes;
+      int sp = -1;
+      const bool need = wb > 0 && s_sync[0] < 0 && s_sync[1] < 0 && s_sync[2] < 0 && s_sync[3] < 0;     // uniform
+      if (need) {
+        const int ha = wb - (lane + 1) * kSliceBytes;
+        if (lane < kFar && ha >= 0) sp = walk(ha, ha + kSliceBytes);
+        const unsigned long long have = __ballot(sp >= 0);
+        sp = have ? __shfl(sp, __builtin_ctzll(have), 64) : -1;          // the nearest one
+      }
+      if (lane == 0) s_misc[10] = (unsigned)sp;
+    }
+    __syncthreads();
   }
   unsigned long long mask = 0;
   // ends of the matches recorded in `mask`, as a 128-bit set relative to a: the k-th start pairs with the k-th end (matches
@@ -236,6 +252,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
       while (s >= s_min && s_sync[s] < 0) --s;
       if (s >= s_min) pos = s_sync[s];
       else if (wb <= 0 && a <= kMaxLookBehind) pos = 0;      // close to the start of the buffer: offset 0 is a sync point
+      else if (s < 0 && (int)s_misc[10] >= 0 && a - (int)s_misc[10] <= kMaxLookBehind) pos = (int)s_misc[10];   // before the window
       else { synced = false; pos = slice_end; }
     } else {
       int lower = wb < 0 ? 0 : wb;
