@@ -1225,9 +1225,73 @@ struct PrivInput {
 };
 
 
+
+// The capture pass's own form of ResolveCapturesBatch, for a match that lies inside its lane's row with every table on chip.  The
+// general form pays six dependent LDS round trips per matched byte (forward: byte, transition; backward: state, byte, class,
+// pool offset, parent) with two waves per SIMD to hide them.  Here the forward walk reads its row a dword at a time (the next
+// one is in flight while this one is walked) and leaves the CELL (state * stride + class) in the trace, so the backward walk
+// needs neither the byte nor its class; the backward walk fetches four cells and their pool offsets before the four steps that
+// depend on each other through the thread index.  About 1.3 + 1.5 round trips per byte.
+typedef const uint16_t __attribute__((address_space(3)))* Lds16;
+template <int MODE, class TraceT, class LdsTraceP>
+__device__ __forceinline__ void ResolveCapturesPriv(Lds16 trans, Lds8 cls, const BtTabsLds& B, const DevTables& T, int ctx,
+                                                    const PrivInput& in, int s, int e, LdsTraceP tr, int32_t* rec) {
+  const int stride = T.stride;
+  const int ncap = T.ncap;
+  const int unset = T.unmatched_minus1 ? -1 : 0;
+  const int n = e - s;
+  unsigned q = T.start[ctx];
+  {
+    const Lds32 rowd = (Lds32)in.row;
+    int r = s - in.p0;
+    unsigned w = rowd[(r >> 2) << 8];
+    unsigned wn = rowd[((r >> 2) + 1) << 8];            // (one dword past the match at most: inside the 24 KiB window area)
+    for (int i = 0; i < n; ++i) {
+      const unsigned b = (w >> ((r & 3) << 3)) & 255u;
+      const unsigned k = cls[b];
+      const unsigned qn = MODE == kModeDirect ? trans[(q << 8) + b] : trans[q * stride + k];
+      tr[i * kBlockThreads] = (TraceT)(q * stride + k);
+      q = qn & kStateMask;
+      ++r;
+      if ((r & 3) == 0) { w = wn; wn = rowd[((r >> 2) + 1) << 8]; }
+    }
+  }
+  unsigned setmask = 3u;
+  for (int c = 2; c < ncap; ++c) rec[c] = unset;
+  rec[0] = s; rec[1] = e;
+  int j;
+  const int add = T.lookahead ? 0 : 1;
+  if (T.lookahead) {
+    const int k = e < in.len ? cls[in.At(e)] : T.ncls;
+    const unsigned m = B.bt_match[q * stride + k];
+    j = (int)(m >> 24);
+    unsigned ops = (m & 0xFFFFFFu) & ~setmask;
+    while (ops) { const int c = __builtin_ctz(ops); ops &= ops - 1; rec[c] = e; setmask |= 1u << c; }
+  } else {
+    j = (int)B.st_nthreads[q] - 1;
+  }
+  auto step = [&](unsigned base, int i) {
+    unsigned o = B.bt_ops[base + j] & ~setmask;
+    j = B.bt_parent[base + j];
+    while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = s + i + add; setmask |= 1u << c; }
+  };
+  int i = n - 1;
+  for (; i >= 3; i -= 4) {
+    const unsigned c0 = tr[i * kBlockThreads], c1 = tr[(i - 1) * kBlockThreads], c2 = tr[(i - 2) * kBlockThreads], c3 = tr[(i - 3) * kBlockThreads];
+    const unsigned b0 = B.bt_base[c0], b1 = B.bt_base[c1], b2 = B.bt_base[c2], b3 = B.bt_base[c3];
+    step(b0, i); step(b1, i - 1); step(b2, i - 2); step(b3, i - 3);
+  }
+  for (; i >= 0; --i) step(B.bt_base[tr[i * kBlockThreads]], i);
+  if (!T.lookahead) {
+    unsigned o = B.start_ops_pool[B.start_ops[ctx] + j] & ~setmask;
+    while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = s; setmask |= 1u << c; }
+  }
+}
+
 template <int MODE, class TraceT>
 __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, const uint8_t* buf, int32_t len, int32_t* spans,
-                                                                  int64_t nmatches, TraceT* gtrace, unsigned long long* cursor) {
+                                                                  int64_t nmatches, TraceT* gtrace, unsigned long long* cursor,
+                                                                  int debug_flags) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const BatchLayout Y = BatchLdsLayout(T, true, (int)sizeof(TraceT), kCapsWindow);
@@ -1272,6 +1336,7 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
   typedef TraceT __attribute__((address_space(3)))* LdsTrace;
   unsigned char* const win = smem + Y.window;
   int32_t* const recs = reinterpret_cast<int32_t*>(smem + Y.recs);
+  const bool no_priv = debug_flags & 1;
   const int64_t ngroups = (nmatches + kBlockThreads - 1) / kBlockThreads;
 
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -1305,6 +1370,12 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
       const int need = e - s + 1;
       if (need <= kBatchTrace) {
         LdsTrace tr = (LdsTrace)(smem + Y.trace) + tid;
+        const int cells = T.nstates * T.stride;
+        if (bt_lds && MODE != kModeClassGlobal && !no_priv && cells <= (sizeof(TraceT) == 1 ? 256 : 65536) && e + 4 - in.p0 <= in.nrow + 0 &&
+            (s == 0 || s - 1 >= in.p0)) {
+          const int ctx = s == 0 ? kCtxBOT : ctx_of_byte[in.At(s - 1)];
+          ResolveCapturesPriv<MODE, TraceT, LdsTrace>((Lds16)(smem + Y.trans), (Lds8)(smem + Y.cls), BL, T, ctx, in, s, e, tr, rec);
+        } else
         if (bt_lds) ResolveCapturesBatch<MODE, TraceT, PrivInput, BtTabsLds, LdsTrace>(tab, BL, T, tab.cls, ctx_of_byte, in, s, e, tr, kBlockThreads, rec);
         else ResolveCapturesBatch<MODE, TraceT, PrivInput, BtTabs, LdsTrace>(tab, BG, T, tab.cls, ctx_of_byte, in, s, e, tr, kBlockThreads, rec);
       } else {
@@ -1890,13 +1961,14 @@ hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, i
       if (e != hipSuccess) return e;
       attr_set[mi] = true;
     }
+    static const int dflags = ExpEnv("RGX_CAPS_NO_PRIV") ? 1 : 0;      // experiment switch: the general back-trace for every match
     const dim3 g((unsigned)grid), b(kBlockThreads);
     const size_t lds = (size_t)Y.total;
     switch (mi) {
-      case 0: hipLaunchKernelGGL((caps_lds_kernel<kModeDirect, uint8_t>), g, b, lds, stream, T, buf, len, spans, nmatches, (uint8_t*)trace, trace_cursor); break;
-      case 1: hipLaunchKernelGGL((caps_lds_kernel<kModeDirect, uint16_t>), g, b, lds, stream, T, buf, len, spans, nmatches, trace, trace_cursor); break;
-      case 2: hipLaunchKernelGGL((caps_lds_kernel<kModeClassLds, uint8_t>), g, b, lds, stream, T, buf, len, spans, nmatches, (uint8_t*)trace, trace_cursor); break;
-      default: hipLaunchKernelGGL((caps_lds_kernel<kModeClassLds, uint16_t>), g, b, lds, stream, T, buf, len, spans, nmatches, trace, trace_cursor); break;
+      case 0: hipLaunchKernelGGL((caps_lds_kernel<kModeDirect, uint8_t>), g, b, lds, stream, T, buf, len, spans, nmatches, (uint8_t*)trace, trace_cursor, dflags); break;
+      case 1: hipLaunchKernelGGL((caps_lds_kernel<kModeDirect, uint16_t>), g, b, lds, stream, T, buf, len, spans, nmatches, trace, trace_cursor, dflags); break;
+      case 2: hipLaunchKernelGGL((caps_lds_kernel<kModeClassLds, uint8_t>), g, b, lds, stream, T, buf, len, spans, nmatches, (uint8_t*)trace, trace_cursor, dflags); break;
+      default: hipLaunchKernelGGL((caps_lds_kernel<kModeClassLds, uint16_t>), g, b, lds, stream, T, buf, len, spans, nmatches, trace, trace_cursor, dflags); break;
     }
     return hipGetLastError();
   }
