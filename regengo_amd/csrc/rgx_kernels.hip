@@ -1288,13 +1288,87 @@ __device__ __forceinline__ void ResolveCapturesPriv(Lds16 trans, Lds8 cls, const
   }
 }
 
-template <int MODE, class TraceT>
+
+// The same walk with the trace kept IN the lane's row: a cell that fits a byte (states x stride <= 256) takes the place of the
+// input byte it was computed from -- the forward walk holds two dwords of the row in registers, so a byte is overwritten only
+// after it was read -- and the back-trace reads four cells with one load.  No trace area: 16 KiB of LDS less per workgroup, three
+// workgroups per CU where there were two (the pass waits on LDS latency: VALU busy 37 %, LDS a third of the cycles).
+typedef uint8_t __attribute__((address_space(3)))* Lds8w;
+template <int MODE>
+__device__ __forceinline__ void ResolveCapturesInRow(Lds16 trans, Lds8 cls, const BtTabsLds& B, const DevTables& T, int ctx,
+                                                     const PrivInput& in, int s, int e, int32_t* rec) {
+  const int stride = T.stride;
+  const int ncap = T.ncap;
+  const int unset = T.unmatched_minus1 ? -1 : 0;
+  const int n = e - s;
+  const Lds32 rowd = (Lds32)in.row;
+  const Lds8w roww = (Lds8w)in.row;
+  const int r0 = s - in.p0;
+  unsigned q = T.start[ctx];
+  {
+    int d = r0 >> 2;
+    int i = -(r0 & 3);                                     // index (relative to s) of byte 0 of dword d
+    unsigned w = rowd[d << 8];
+    while (i < n) {
+      const unsigned wn = rowd[(d + 1) << 8];
+      const unsigned k0 = cls[w & 255u], k1 = cls[(w >> 8) & 255u], k2 = cls[(w >> 16) & 255u], k3 = cls[w >> 24];
+#define RGX_FWD(t, kt)                                                                            \
+      if (i + t >= 0 && i + t < n) {                                                               \
+        const unsigned cell = q * stride + kt;                                                     \
+        const unsigned qn = MODE == kModeDirect ? trans[(q << 8) + ((w >> (8 * t)) & 255u)] : trans[cell]; \
+        roww[(d << 10) + t] = (uint8_t)cell;                                                       \
+        q = qn & kStateMask;                                                                       \
+      }
+      RGX_FWD(0, k0) RGX_FWD(1, k1) RGX_FWD(2, k2) RGX_FWD(3, k3)
+#undef RGX_FWD
+      i += 4; ++d; w = wn;
+    }
+  }
+  unsigned setmask = 3u;
+  for (int c = 2; c < ncap; ++c) rec[c] = unset;
+  rec[0] = s; rec[1] = e;
+  int j;
+  const int add = T.lookahead ? 0 : 1;
+  if (T.lookahead) {
+    const int k = e < in.len ? cls[in.At(e)] : T.ncls;     // (byte e itself was not overwritten: cells replace [s, e) only)
+    const unsigned m = B.bt_match[q * stride + k];
+    j = (int)(m >> 24);
+    unsigned ops = (m & 0xFFFFFFu) & ~setmask;
+    while (ops) { const int c = __builtin_ctz(ops); ops &= ops - 1; rec[c] = e; setmask |= 1u << c; }
+  } else {
+    j = (int)B.st_nthreads[q] - 1;
+  }
+  if (n > 0) {
+    int d = (r0 + n - 1) >> 2;
+    int i = (d << 2) - r0;                                 // index of byte 0 of dword d
+    unsigned w = rowd[d << 8];
+    while (i + 3 >= 0) {
+      const unsigned wp = d > 0 ? rowd[(d - 1) << 8] : 0u;
+      const unsigned b3 = B.bt_base[w >> 24], b2 = B.bt_base[(w >> 16) & 255u], b1 = B.bt_base[(w >> 8) & 255u], b0 = B.bt_base[w & 255u];
+#define RGX_BWD(t, bt)                                                                            \
+      if (i + t >= 0 && i + t < n) {                                                               \
+        unsigned o = B.bt_ops[bt + j] & ~setmask;                                                  \
+        j = B.bt_parent[bt + j];                                                                   \
+        while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = s + i + t + add; setmask |= 1u << c; } \
+      }
+      RGX_BWD(3, b3) RGX_BWD(2, b2) RGX_BWD(1, b1) RGX_BWD(0, b0)
+#undef RGX_BWD
+      i -= 4; --d; w = wp;
+    }
+  }
+  if (!T.lookahead) {
+    unsigned o = B.start_ops_pool[B.start_ops[ctx] + j] & ~setmask;
+    while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = s; setmask |= 1u << c; }
+  }
+}
+
+template <int MODE, class TraceT, bool INROW = false>
 __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, const uint8_t* buf, int32_t len, int32_t* spans,
                                                                   int64_t nmatches, TraceT* gtrace, unsigned long long* cursor,
                                                                   int debug_flags) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
-  const BatchLayout Y = BatchLdsLayout(T, true, (int)sizeof(TraceT), kCapsWindow);
+  const BatchLayout Y = BatchLdsLayout(T, true, INROW ? 0 : (int)sizeof(TraceT), kCapsWindow);
   const int ncap = T.ncap;
   {
     const uint4* src = reinterpret_cast<const uint4*>(T.trans);
@@ -1368,7 +1442,12 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
     int32_t* rec = recs + tid * ncap;
     if (i < nmatches) {
       const int need = e - s + 1;
-      if (need <= kBatchTrace) {
+      if (INROW && e + 4 - in.p0 <= in.nrow && (s == 0 || s - 1 >= in.p0)) {
+        // (the launch takes this instance only with the back-trace tables on chip and states x stride <= 256)
+        const int ctx = s == 0 ? kCtxBOT : ctx_of_byte[in.At(s - 1)];
+        ResolveCapturesInRow<MODE>((Lds16)(smem + Y.trans), (Lds8)(smem + Y.cls), BL, T, ctx, in, s, e, rec);
+      } else
+      if (!INROW && need <= kBatchTrace) {
         LdsTrace tr = (LdsTrace)(smem + Y.trace) + tid;
         const int cells = T.nstates * T.stride;
         if (bt_lds && MODE != kModeClassGlobal && !no_priv && cells <= (sizeof(TraceT) == 1 ? 256 : 65536) && e + 4 - in.p0 <= in.nrow + 0 &&
@@ -1939,7 +2018,11 @@ hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, i
   if (nmatches <= 0) return hipSuccess;
   static const bool force_old = ExpEnv("RGX_CAPS_OLD") != nullptr;
   const bool t8 = T.nstates <= 256;
-  const BatchLayout Y = BatchLdsLayout(T, true, t8 ? 1 : 2, kCapsWindow);
+  // the trace in the rows themselves (ResolveCapturesInRow) when a cell fits a byte; matches that do not fit their row then keep
+  // their trace in global memory
+  static const bool no_inrow = ExpEnv("RGX_CAPS_NO_INROW") != nullptr;
+  const bool inrow = !no_inrow && T.nstates * T.stride <= 256 && BatchLdsLayout(T, true, 0, kCapsWindow).bt_in_lds != 0;
+  const BatchLayout Y = BatchLdsLayout(T, true, inrow ? 0 : (t8 ? 1 : 2), kCapsWindow);
   if (!force_old && nmatches >= 64 && T.mode != kModeClassGlobal && Y.total <= 150 * 1024 && (((uintptr_t)buf) & 15) == 0 && T.ncap <= 32) {
     static int cus = 0;
     if (!cus) {
@@ -1952,10 +2035,11 @@ hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, i
     if (per_cu > 8) per_cu = 8;
     int64_t grid = (int64_t)cus * per_cu * 4;
     if (grid > ngroups) grid = ngroups;
-    const int mi = (T.mode == kModeDirect ? 0 : 1) * 2 + (t8 ? 0 : 1);
-    const void* fns[4] = {(const void*)caps_lds_kernel<kModeDirect, uint8_t>, (const void*)caps_lds_kernel<kModeDirect, uint16_t>,
-                          (const void*)caps_lds_kernel<kModeClassLds, uint8_t>, (const void*)caps_lds_kernel<kModeClassLds, uint16_t>};
-    static bool attr_set[4] = {false, false, false, false};
+    const int mi = inrow ? 4 + (T.mode == kModeDirect ? 0 : 1) : (T.mode == kModeDirect ? 0 : 1) * 2 + (t8 ? 0 : 1);
+    const void* fns[6] = {(const void*)caps_lds_kernel<kModeDirect, uint8_t>, (const void*)caps_lds_kernel<kModeDirect, uint16_t>,
+                          (const void*)caps_lds_kernel<kModeClassLds, uint8_t>, (const void*)caps_lds_kernel<kModeClassLds, uint16_t>,
+                          (const void*)caps_lds_kernel<kModeDirect, uint8_t, true>, (const void*)caps_lds_kernel<kModeClassLds, uint8_t, true>};
+    static bool attr_set[6] = {false, false, false, false, false, false};
     if (!attr_set[mi]) {
       hipError_t e = hipFuncSetAttribute(fns[mi], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       if (e != hipSuccess) return e;
@@ -1968,7 +2052,9 @@ hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, i
       case 0: hipLaunchKernelGGL((caps_lds_kernel<kModeDirect, uint8_t>), g, b, lds, stream, T, buf, len, spans, nmatches, (uint8_t*)trace, trace_cursor, dflags); break;
       case 1: hipLaunchKernelGGL((caps_lds_kernel<kModeDirect, uint16_t>), g, b, lds, stream, T, buf, len, spans, nmatches, trace, trace_cursor, dflags); break;
       case 2: hipLaunchKernelGGL((caps_lds_kernel<kModeClassLds, uint8_t>), g, b, lds, stream, T, buf, len, spans, nmatches, (uint8_t*)trace, trace_cursor, dflags); break;
-      default: hipLaunchKernelGGL((caps_lds_kernel<kModeClassLds, uint16_t>), g, b, lds, stream, T, buf, len, spans, nmatches, trace, trace_cursor, dflags); break;
+      case 3: hipLaunchKernelGGL((caps_lds_kernel<kModeClassLds, uint16_t>), g, b, lds, stream, T, buf, len, spans, nmatches, trace, trace_cursor, dflags); break;
+      case 4: hipLaunchKernelGGL((caps_lds_kernel<kModeDirect, uint8_t, true>), g, b, lds, stream, T, buf, len, spans, nmatches, (uint8_t*)trace, trace_cursor, dflags); break;
+      default: hipLaunchKernelGGL((caps_lds_kernel<kModeClassLds, uint8_t, true>), g, b, lds, stream, T, buf, len, spans, nmatches, (uint8_t*)trace, trace_cursor, dflags); break;
     }
     return hipGetLastError();
   }
