@@ -41,7 +41,7 @@ struct rgx_stream_ctx {
   unsigned long long* d_total = nullptr;     // the current scratch set's total (FindAllDevice::run_scan)
   unsigned long long* d_cursor = nullptr;    // trace cursor of the capture kernel: its own word, valid from ctx creation on
   bool own_stream = true;
-  uint8_t* d_unsynced = nullptr; int32_t* d_carry = nullptr; int64_t slice_cap = 0;
+  uint8_t* d_unsynced = nullptr; int32_t* d_carry = nullptr; int64_t slice_cap = 0, carry_cap = 0;
   uint16_t* d_trace = nullptr; int64_t trace_cap = 0;
   uint8_t* d_in = nullptr; int64_t in_cap = 0;       // staging for the host-buffer entry points
   uint8_t* d_san = nullptr; int64_t san_cap = 0;     // the sanitised copy of an input with broken UTF-8 (MatchView)
@@ -247,9 +247,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   // start positions.  Taken after a scan whose blind walk proved little -- and FIRST, in place of that scan, once a program is
   // known for it (two scans of `<tag attr="...">` patterns over a log became one; prefer_wsync).
   auto wsync = [&]() -> int {
-    int64_t cc = 0;
-    if (c->d_carry) { hipFree(c->d_carry); c->d_carry = nullptr; }
-    if ((rc = Ensure(&c->d_carry, &cc, (int64_t)nslices + 64)) != RGX_OK) return rc;
+    if ((rc = Ensure(&c->d_carry, &c->carry_cap, (int64_t)nslices + 64)) != RGX_OK) return rc;      // (kept between calls)
     const int32_t nchunks = WSyncChunks(ilen);
     if ((rc = Ensure(&c->d_trace, &c->trace_cap, 2 * (int64_t)nchunks + 64)) != RGX_OK) return rc;   // per-chunk scratch (uint16)
     uint32_t* d_stats = (uint32_t*)(c->d_carry + nslices + 8);
@@ -290,11 +288,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     // start-tracking automaton per run (LaunchCarryUs) -- linear, where the attempt-per-start carry pass below is quadratic
     // in the length of such a run (a 5 KB word cost it seconds)
     if ((rc = Ensure(&c->d_unsynced, &c->slice_cap, nslices)) != RGX_OK) return rc;
-    {
-      int64_t cc = 0;
-      if (c->d_carry) { hipFree(c->d_carry); c->d_carry = nullptr; }
-      if ((rc = Ensure(&c->d_carry, &cc, (int64_t)nslices + 64)) != RGX_OK) return rc;
-    }
+    if ((rc = Ensure(&c->d_carry, &c->carry_cap, (int64_t)nslices + 64)) != RGX_OK) return rc;
     if (!marked) {
       HIP_TRY(hipMemsetAsync(c->d_unsynced, 0, nslices, c->stream));
       P.slice_unsynced = c->d_unsynced;
@@ -349,9 +343,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     // rare path: some slices found no sync point; resolve their entry positions serially and rescan.
     if ((rc = Ensure(&c->d_unsynced, &c->slice_cap, nslices)) != RGX_OK) return rc;
     if (!carry_ready) {
-      int64_t cc = 0;
-      if (c->d_carry) { hipFree(c->d_carry); c->d_carry = nullptr; }
-      if ((rc = Ensure(&c->d_carry, &cc, nslices)) != RGX_OK) return rc;
+      if ((rc = Ensure(&c->d_carry, &c->carry_cap, (int64_t)nslices + 64)) != RGX_OK) return rc;
     }
     if (!marked) {                                              // (the marks of the first scan stand unless a rescan came between)
       HIP_TRY(hipMemsetAsync(c->d_unsynced, 0, nslices, c->stream));

@@ -214,7 +214,9 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
     if (wave == 0) {
       constexpr int kFar = (kMaxLookBehind - kHaloL) / kSliceBytes;
       int sp = -1;
-      const bool need = wb > 0 && s_sync[0] < 0 && s_sync[1] < 0 && s_sync[2] < 0 && s_sync[3] < 0;     // uniform
+      // (not when the host handed exact start positions down: a pattern that needs those proves little blind, the walk would
+      // run in most tiles for nothing -- 1.3 -> 1.8 ms on the `<tag attr="...">` patterns)
+      const bool need = wb > 0 && !P.carry_in && s_sync[0] < 0 && s_sync[1] < 0 && s_sync[2] < 0 && s_sync[3] < 0;     // uniform
       if (need) {
         const int ha = wb - (lane + 1) * kSliceBytes;
         if (lane < kFar && ha >= 0) sp = walk(ha, ha + kSliceBytes);
