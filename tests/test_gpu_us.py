@@ -145,10 +145,13 @@ def test_patterns_without_reset_bytes(torch_dev):
     for pat in pats:
         c = Compiled(pat, stdlib=True).to(0)
         cm = CMatcher(pat)
-        for t in texts:
-            exp, cnt = cm.find_all_np(np.frombuffer(t, dtype=np.uint8))
-            spans, res = c.FindAllSpans(t)
-            assert res.total == cnt, (pat, res.total, cnt)
-            assert np.array_equal(spans.cpu().numpy(), exp), pat
-            n, _r = c.CountAll(t)
-            assert n == cnt
+        want = [cm.find_all_np(np.frombuffer(t, dtype=np.uint8)) for t in texts]
+        # twice: a program remembers how its unsynced slices were best resolved (exact sync points first, or the carry pass), so
+        # the second round takes every text through the remembered strategy
+        for rnd in range(2):
+            for t, (exp, cnt) in zip(texts, want):
+                spans, res = c.FindAllSpans(t)
+                assert res.total == cnt, (pat, rnd, res.total, cnt)
+                assert np.array_equal(spans.cpu().numpy(), exp), (pat, rnd)
+                n, _r = c.CountAll(t)
+                assert n == cnt
