@@ -82,7 +82,7 @@ int Ensure(T** ptr, int64_t* cap, int64_t need) {
   // growing a buffer that already exists: leave 1/8 slack, so that a stream of slightly larger requests (windows with a few
   // more matches each) does not free and re-allocate gigabytes on every call
   const bool regrow = *ptr != nullptr;
-  if (*ptr) { hipFree(*ptr); *ptr = nullptr; *cap = 0; }
+  if (*ptr) { (void)hipFree(*ptr); *ptr = nullptr; *cap = 0; }
   int64_t n = std::max<int64_t>(need, 16);
   if (regrow) n += n / 8;
   if (hipMalloc((void**)ptr, (size_t)n * sizeof(T)) != hipSuccess) { SetError("hipMalloc failed"); (void)hipGetLastError(); return RGX_E_NOMEM; }
@@ -184,7 +184,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   // are not known to be zero; anything the kernel cannot vouch for is cleared with a real memset.
   const size_t desc_words = (size_t)ntiles_max + 4;
   if (c->desc_cap < (int64_t)(2 * desc_words) || !c->d_desc) {
-    if (c->d_desc) { hipFree(c->d_desc); c->d_desc = nullptr; c->desc_cap = 0; }
+    if (c->d_desc) { (void)hipFree(c->d_desc); c->d_desc = nullptr; c->desc_cap = 0; }
     if ((rc = Ensure(&c->d_desc, &c->desc_cap, (int64_t)(2 * desc_words + 64))) != RGX_OK) return rc;
     c->set_words = c->desc_cap / 2;
     c->dirty[0] = c->dirty[1] = c->set_words;
@@ -281,7 +281,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     if (((uint32_t*)&c->h_read[2])[3]) { SetError("look-back timed out in ticket mode"); return RGX_E_HIP; }
   }
   float ms = 0;
-  if (tm) hipEventElapsedTime(&ms, c->ev0, c->ev1);
+  if (tm) (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
   uint32_t unsynced = ((uint32_t*)&c->h_read[2])[1];
   if (unsynced && !use_w && UseUsKernel(T, ilen, false)) {
     // the one-step-per-byte kernels: slices without a sync point in reach get their search positions from ONE walk of the
@@ -299,7 +299,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     P.slice_unsynced = nullptr;
     P.carry_in = c->d_carry;
     if ((rc = run_scan(tm)) != RGX_OK) return rc;
-    if (tm) hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    if (tm) (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
     const uint32_t still = ((uint32_t*)&c->h_read[2])[1];
     if (still) { SetError("slices without a search position after the carry pass"); return RGX_E_HIP; }
   } else
@@ -315,7 +315,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     P.slice_unsynced = c->d_unsynced;
     if ((rc = run_scan(tm)) != RGX_OK) return rc;
     P.slice_unsynced = nullptr;
-    if (tm) hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    if (tm) (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
     unsynced = ((uint32_t*)&c->h_read[2])[1];
   }
   const bool us_done = P.carry_in != nullptr && UseUsKernel(T, ilen, false) && !use_w;     // the branch above settled it
@@ -335,7 +335,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     P.slice_unsynced = c->d_unsynced;
     if ((rc = run_scan(tm)) != RGX_OK) return rc;
     P.slice_unsynced = nullptr;
-    if (tm) hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    if (tm) (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
     unsynced = ((uint32_t*)&c->h_read[2])[1];
     p->prefer_wsync.store(many_unsynced || ms + 1.5f < 2.0f * t_blind ? 1 : -1, std::memory_order_relaxed);
   }
@@ -519,18 +519,18 @@ RGX_API int rgx_stream_ctx_create_on_stream(const rgx_program* p, void* hip_stre
 }
 RGX_API void rgx_stream_ctx_destroy(rgx_stream_ctx* c) {
   if (!c) return;
-  hipSetDevice(c->device);
-  if (c->stream || !c->own_stream) hipStreamSynchronize(c->stream);
-  if (c->stream && c->own_stream) hipStreamDestroy(c->stream);
-  if (c->d_cursor) hipFree(c->d_cursor);
-  if (c->ev0) hipEventDestroy(c->ev0);
-  if (c->ev1) hipEventDestroy(c->ev1);
+  (void)hipSetDevice(c->device);
+  if (c->stream || !c->own_stream) (void)hipStreamSynchronize(c->stream);
+  if (c->stream && c->own_stream) (void)hipStreamDestroy(c->stream);
+  if (c->d_cursor) (void)hipFree(c->d_cursor);
+  if (c->ev0) (void)hipEventDestroy(c->ev0);
+  if (c->ev1) (void)hipEventDestroy(c->ev1);
   for (int i = 0; i < 2; ++i)
-    for (hipEvent_t e : {c->pev0[i], c->pev1[i], c->pdone[i]}) if (e) hipEventDestroy(e);
+    for (hipEvent_t e : {c->pev0[i], c->pev1[i], c->pdone[i]}) if (e) (void)hipEventDestroy(e);
   for (void* p : {(void*)c->d_desc, (void*)c->d_unsynced, (void*)c->d_carry,
                   (void*)c->d_trace, (void*)c->d_in, (void*)c->d_san, (void*)c->d_out, (void*)c->d_rspans, (void*)c->d_rdelta, (void*)c->d_rtemp, (void*)c->d_tmpl})
-    if (p) hipFree(p);
-  if (c->h_read) hipHostFree(c->h_read);
+    if (p) (void)hipFree(p);
+  if (c->h_read) (void)hipHostFree(c->h_read);
   delete c;
 }
 RGX_API int rgx_stream_ctx_rebind(rgx_stream_ctx* c, const rgx_program* p) {
@@ -601,7 +601,7 @@ RGX_API int rgx_find_all_submit(const rgx_program* p, rgx_stream_ctx* c, const u
   const size_t desc_words = (size_t)ntiles_max + 4;
   if (c->desc_cap < (int64_t)(2 * desc_words) || !c->d_desc) {
     if (c->pend_count) HIP_TRY(hipStreamSynchronize(c->stream));      // (a scan in flight still uses the old sets)
-    if (c->d_desc) { hipFree(c->d_desc); c->d_desc = nullptr; c->desc_cap = 0; }
+    if (c->d_desc) { (void)hipFree(c->d_desc); c->d_desc = nullptr; c->desc_cap = 0; }
     if ((rc = Ensure(&c->d_desc, &c->desc_cap, (int64_t)(2 * desc_words + 64))) != RGX_OK) return rc;
     c->set_words = c->desc_cap / 2;
     c->dirty[0] = c->dirty[1] = c->set_words;
@@ -659,7 +659,7 @@ RGX_API int64_t rgx_find_all_wait(const rgx_program* p, rgx_stream_ctx* c, rgx_r
   }
   const int64_t total = (int64_t)h[0];
   float ms = 0;
-  if (pd.timed) hipEventElapsedTime(&ms, c->pev0[pd.slot], c->pev1[pd.slot]);
+  if (pd.timed) (void)hipEventElapsedTime(&ms, c->pev0[pd.slot], c->pev1[pd.slot]);
   if (res) { res->total = total; res->unsynced = 0; res->kernel_ms = ms; }
   if (total > (int64_t)pd.cap && (pd.n < 0 || pd.n > (int64_t)pd.cap)) {
     SetError("span capacity too small");
@@ -1087,7 +1087,7 @@ RGX_API int rgx_match_bytes_device(const rgx_program* p, rgx_stream_ctx* c, cons
     uint8_t f = 0;
     if (e == hipSuccess) e = hipMemcpyAsync(&f, d_found, 1, hipMemcpyDeviceToHost, c->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
-    hipFree(d_off); hipFree(d_found);
+    (void)hipFree(d_off); (void)hipFree(d_found);
     HIP_TRY(e);
     *matched = f;
     return RGX_OK;

@@ -1085,7 +1085,6 @@ __global__ __launch_bounds__(kBlockThreads) void batch_lds_kernel(DevTables T, c
   }
   unsigned char* const win = smem + Y.window;
   int32_t* const recs = reinterpret_cast<int32_t*>(smem + Y.recs);
-  const bool dyn = want_spans && !T.fixed_captures;
   const int64_t ngroups = (nstr + kBlockThreads - 1) / kBlockThreads;
 
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -1113,7 +1112,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_lds_kernel(DevTables T, c
       int rfo = -1;                      // REF: the offset at which the right-most path of this attempt failed, once known
       bool fresh = true, go = true;
       auto next_prefix = [&](int from) -> int {          // bytes.IndexByte(input[from:], prefix) + from, or -1
-        for (int j = from; j < in.len; ++j) if (in.At(j) == (unsigned)T.ref_prefix) return j;
+        for (int j = from; j < in.len; ++j) if (in.At(j) == T.ref_prefix) return j;
         return -1;
       };
       if (has_prefix) { pos = next_prefix(0); go = pos >= 0; }
@@ -1779,7 +1778,7 @@ hipError_t LaunchScan(const DevTables& T, const ScanParams& P, hipStream_t strea
   static bool attr_set[8] = {false, false, false, false, false, false, false, false};
   auto set_attr = [&](const void* fn, int mode) {
     if (!attr_set[mode]) {
-      hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
       attr_set[mode] = true;
     }
   };
