@@ -482,7 +482,6 @@ Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOption
       std::vector<int> pre; std::vector<int> pre_parent; std::vector<uint32_t> pre_ops;
       for (auto& l : leaves) {
         if (!b.NodeAccepts(l.node, k)) continue;
-        const Node& nd = b.nodes[l.node];
         int target = b.Target(l.node, k);
         if (std::find(pre.begin(), pre.end(), target) != pre.end()) continue;  // lower priority duplicate
         pre.push_back(target); pre_parent.push_back(l.parent); pre_ops.push_back(l.ops);
@@ -762,7 +761,6 @@ Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOption
         std::vector<int> targets;
         for (int node : src) {
           if (!b.NodeAccepts(node, k)) continue;
-          const Node& nd = b.nodes[node];
           targets.push_back(b.Target(node, k));
         }
         std::vector<int> leaves;

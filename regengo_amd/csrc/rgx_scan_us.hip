@@ -692,8 +692,6 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_simple_kernel(DevTables
   int* s_far = reinterpret_cast<int*>(s_misc + 10);
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63;
-  const int wave = tid >> 6;
   const int ncls = U.ncls;
 #ifdef RGX_US_PROFILE
   long long tstamp[8];
@@ -1505,7 +1503,11 @@ hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t str
     const bool rw = U.has_rewind != 0 && P.us_rewind != 0;
     const void* const fn = rw ? (const void*)scan_us_pair_kernel<true> : (const void*)scan_us_pair_kernel<false>;
     static bool attr2[2] = {false, false};
-    if (!attr2[rw]) { hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr2[rw] = true; }
+    if (!attr2[rw]) {
+      const hipError_t ae = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (ae != hipSuccess) return ae;
+      attr2[rw] = true;
+    }
     // persistent workgroups: no more than the chip holds at once (the occupancy query is known to over-report by one for
     // SGPR-heavy kernels, and a workgroup that is not resident would stall every look-back behind it until the bounded spin
     // sends the scan to ticket mode)
@@ -1520,8 +1522,7 @@ hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t str
       std::lock_guard<std::mutex> lock(mu);
       if (ncu == 0) {
         int dev = 0;
-        hipGetDevice(&dev);
-        hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev);
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
       }
       auto it = per_cu_of.find(shp * 2 + (rw ? 1 : 0));
       if (it == per_cu_of.end()) {
@@ -1545,7 +1546,11 @@ hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t str
   }
   if (U.ent4 && !no_simple) {
     static bool attr = false;
-    if (!attr) { hipFuncSetAttribute((const void*)scan_us_simple_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; }
+    if (!attr) {
+      const hipError_t ae = hipFuncSetAttribute((const void*)scan_us_simple_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      if (ae != hipSuccess) return ae;
+      attr = true;
+    }
     hipLaunchKernelGGL(scan_us_simple_kernel, grid, block, (size_t)UsSLds(U.nent4, U.stride).total, stream, T, U, P);
     return hipGetLastError();
   }
@@ -1553,7 +1558,11 @@ hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t str
 #define RGX_US(N, LK)                                                                                   \
   do {                                                                                                  \
     static bool attr = false;                                                                           \
-    if (!attr) { hipFuncSetAttribute((const void*)scan_us_kernel<N, LK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr = true; } \
+    if (!attr) {                                                                                        \
+      const hipError_t ae = hipFuncSetAttribute((const void*)scan_us_kernel<N, LK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
+      if (ae != hipSuccess) return ae;                                                                  \
+      attr = true;                                                                                      \
+    }                                                                                                   \
     hipLaunchKernelGGL((scan_us_kernel<N, LK>), grid, block, shmem, stream, T, U, P);                   \
   } while (0)
   if (U.lookahead) {
