@@ -207,6 +207,27 @@ int rgxt_info(void* hh, int32_t* out) {
 
 int rgxt_reset_bytes(void* hh, uint8_t* out256) { memcpy(out256, ((Handle*)hh)->t.reset_byte, 256); return 0; }
 
+// Analysis for the next step of the one-step-per-byte kernels: class PAIRS on which every live state of the anchored
+// automaton dies within two steps although neither class is a reset class by itself.  out[k1 * ncls + k2] = 1 for such a pair;
+// cls256 = the class of every byte value; returns ncls.
+int rgxt_reset_pairs(void* hh, uint8_t* cls256, uint8_t* out, int cap) {
+  const Tables& t = ((Handle*)hh)->t;
+  const int ncls = t.ncls, stride = t.ncls + 1;
+  memcpy(cls256, t.cls, 256);
+  if (ncls * ncls > cap) return -1;
+  for (int k1 = 0; k1 < ncls; k1++)
+    for (int k2 = 0; k2 < ncls; k2++) {
+      bool all_dead = true;
+      for (int q = 1; q < t.nstates && all_dead; q++) {
+        const unsigned q1 = t.trans[q * stride + k1] & kStateMask;
+        if (q1 == kDead) continue;
+        if ((t.trans[q1 * stride + k2] & kStateMask) != kDead) all_dead = false;
+      }
+      out[k1 * ncls + k2] = all_dead ? 1 : 0;
+    }
+  return ncls;
+}
+
 // FindAllBytes semantics (find.go:130-316) on the tables.
 int64_t rgxt_find_all(void* hh, const uint8_t* buf, int64_t len, int64_t n, int32_t* spans, int64_t cap) {
   const Tables& t = ((Handle*)hh)->t;

@@ -23,6 +23,7 @@ _lib.rgxt_roundtrip.restype = C.c_void_p
 _lib.rgxt_roundtrip.argtypes = [C.c_void_p]
 _lib.rgxt_sa_info.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
 _lib.rgxt_reset_bytes.argtypes = [C.c_void_p, C.c_void_p]
+_lib.rgxt_reset_pairs.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
 
 _lib.rgxt_sanitize_utf8.restype = C.c_int64
 _lib.rgxt_sanitize_utf8.argtypes = [C.c_char_p, C.c_int64, C.c_void_p]
@@ -127,6 +128,15 @@ class HostProgram:
         a = (C.c_uint8 * 256)()
         _lib.rgxt_reset_bytes(self.h, a)
         return bytes(a)
+
+    def reset_pairs(self):
+        """(class of every byte value, ncls, ncls x ncls matrix of class pairs after which every live state is dead)."""
+        cls = (C.c_uint8 * 256)()
+        out = (C.c_uint8 * (256 * 256))()
+        n = _lib.rgxt_reset_pairs(self.h, cls, out, 256 * 256)
+        if n < 0:
+            raise ValueError("too many classes")
+        return bytes(cls), n, bytes(out[: n * n])
 
 
 def prog_dump(pattern: str) -> str:
