@@ -31,7 +31,9 @@
 extern "C" {
 #endif
 
-#define RGX_ABI_VERSION 1
+#define RGX_ABI_VERSION 3   /* 2: rgx_info grew in round 2 (scan_kernel .. utf8_screened) without a bump; 3: ref_findall_offered,
+                             * ref_stream_offered, ref_tdfa_states; the sharded entry points.  rgx_abi_version() is what the loaded
+                             * library was built with: a stub compares it with this constant before it trusts sizeof(rgx_info) */
 
 typedef enum rgx_status {
   RGX_OK = 0,
@@ -53,11 +55,13 @@ typedef enum rgx_status {
 
 enum {
   RGX_FLAG_UNMATCHED_MINUS1 = 1u << 0, /* unmatched group = (-1,-1) instead of the reference's (0,0) */
-  RGX_FLAG_STDLIB_SEMANTICS = 1u << 1  /* MatchBytes / FindBytes (single and batch) as a plain leftmost-first search.  Default
-                                          (flag clear): the REFERENCE's behaviour -- after a failed attempt the emitted loops
-                                          resume behind the offset their last alternative failed at, not at start+1
-                                          (compiler.go:845-853, find.go:545-569), which steps over some
-                                          matches.  FindAllBytes has no such rule and is the same in both modes.       */
+  RGX_FLAG_STDLIB_SEMANTICS = 1u << 1  /* every entry point as Go's regexp would answer: plain leftmost-first search, FindAll without
+                                          duplicates, FindReader = FindAll over the stream.  Default (flag clear): the REFERENCE's
+                                          behaviour or a refusal, never something else -- after a failed attempt the emitted
+                                          MatchBytes / FindBytes loops resume behind the offset their last alternative failed at,
+                                          not at start+1 (compiler.go:845-853, find.go:545-569), which steps over some
+                                          matches (reproduced); entry points whose emitted code the library does not reproduce
+                                          for this pattern return RGX_E_UNSUPPORTED (rgx_info.ref_*_offered say which).        */
 };
 
 typedef struct rgx_program rgx_program;       /* compiled pattern: host tables + device copy      */
@@ -87,7 +91,10 @@ typedef struct rgx_info {
   int32_t fixed_captures;  /* 1: every capture slot is a constant offset from match start/end    */
   int32_t can_match_empty;
   int32_t ref_match_engine; /* what the reference would emit: 0 backtracking, 1 thompson, 2 memo */
-  int32_t ref_find_engine;  /* 0 backtracking, 1 tdfa-or-tnfa (catastrophic risk), 2 tnfa, -1 none (no captures) */
+  int32_t ref_find_engine;  /* the capture engine the reference emits (compiler.go:137-153): 0 backtracking, 1 Tagged DFA (captures +
+                             * nested quantifiers and the construction of tdfa.go:111-290 stays under 500 states: ref_tdfa_states),
+                             * 2 memoising backtracker ("TNFA", compiler.go:415-426: the TDFA could not be built), -1 none (no
+                             * captures: the reference emits no Find* function at all)                                  */
   int32_t lookahead_mode;  /* 1: pattern has $ / \b / \B / (?m)$ (match flag is on the next-byte edge) */
   int32_t table_bytes;     /* bytes of transition table staged in LDS                            */
   int32_t needs_valid_utf8; /* always 0 (kept for the layout): broken UTF-8 is handled at run time, see utf8_screened             */
@@ -98,14 +105,30 @@ typedef struct rgx_info {
                             * per look-up; DESIGN.md section 4 */
   int32_t ref_match_offered; /* 1: MatchBytes in reference mode (the default) is offered: plain backtracking or Thompson engine; 0: the
                               * reference memoises -- RGX_E_UNSUPPORTED, the generated stub keeps the Go function           */
-  int32_t ref_find_offered;  /* the same for FindBytes / FindBytesReuse (plain backtracking engine only)                      */
+  int32_t ref_find_offered;  /* the same for FindBytes / FindBytesReuse (plain backtracking engine only).  All four ref_*_offered
+                              * read 1 for a program compiled with RGX_FLAG_STDLIB_SEMANTICS: every entry point answers then   */
   int32_t unicode_version; /* UCD version behind \p{..}: 0xMMmmpp (0x0E0000 = 14.0.0).  The reference's tables are Go 1.24's
                             * `unicode` package = 15.0.0: code points first assigned in 15.0 are unassigned here       */
   int32_t utf8_screened;   /* 1: the pattern has a decoding class that holds U+FFFD (every negated class, \W, \P{..}): a lead byte
                             * without its continuation bytes is (RuneError, 1) to it, as to utf8.DecodeRune.  The entry points
                             * screen the input for such bytes (one streaming pass) and match an input that has them through a
                             * sanitised copy (DESIGN.md "UTF-8 classes"): results are exact on any bytes                       */
+  int32_t ref_findall_offered; /* 1: FindAllBytes(Append) / FindAllString and the count-only forms return the reference's own result:
+                             * plain backtracking engine; or the memoising one on a pattern that cannot match empty (its memo is
+                             * never cleared between iterations, find.go:175-188, which only shows when an attempt starts on an
+                             * Alt the previous match ended on -- an empty match).  0: the reference emits its
+                             * Tagged DFA, whose FindAll advances by the match LENGTH and reports matches again
+                             * (compiler.go:646-651, Q11), or memoises on a pattern that matches empty: every FindAll / count entry
+                             * point returns RGX_E_UNSUPPORTED unless the program was compiled with RGX_FLAG_STDLIB_SEMANTICS    */
+  int32_t ref_stream_offered;  /* 1: rgx_find_chunk / rgx_count_chunk / rgx_replace_* / rgx_transform_chunk* are offered in reference
+                             * mode: the emitted loops behind them are FindBytesReuse on a re-sliced input, so the library must
+                             * reproduce FindBytesReuse (ref_find_offered) and the pattern must not match empty; the answer is then
+                             * the reference's or RGX_E_DIVERGES.  0: RGX_E_UNSUPPORTED unless RGX_FLAG_STDLIB_SEMANTICS         */
+  int32_t ref_tdfa_states;  /* states of the reference's Tagged DFA when ref_find_engine == 1 (its own numbering, start states
+                             * included), else 0                                                                            */
+  uint32_t flags;           /* the RGX_FLAG_* the program was compiled with (they travel in the blob)                        */
 } rgx_info;
+int rgx_abi_version(void);
 int rgx_program_info(const rgx_program* p, rgx_info* out);
 /* NUL-separated capture names, group 0 first ("" for unnamed); returns bytes written or needed.    */
 int64_t rgx_program_capture_names(const rgx_program* p, char* dst, size_t cap);
@@ -162,7 +185,9 @@ int rgx_match_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* buf,
  * emits a memoising or TDFA engine for this pattern, whose restart offsets are not reproduced -- keep the Go path. */
 int rgx_find_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* buf, size_t len, int32_t* spans, int* found);
 
-/* FindAllBytes(input []byte, n int) -- find.go:113-124,130-466 (TDFA flavour compiler.go:602-655).
+/* FindAllBytes(input []byte, n int) -- find.go:113-124,130-466.  The TDFA flavour (compiler.go:602-655) is NOT reproduced: programs
+ * for which the reference emits it are refused in reference mode (RGX_E_UNSUPPORTED, rgx_info.ref_findall_offered), like every
+ * entry point of this family (device / owned / host / starts / submit / count).
  * `d_buf`, `d_spans` device pointers; `cap_records` = capacity of d_spans in records of ncap int32.
  * n < 0: all matches; n == 0: nothing (returns 0, like `return s`); n > 0: first n.
  * Records are written in increasing match-start order.  Returns written count or <0.              */
@@ -199,9 +224,10 @@ int64_t rgx_find_all_wait(const rgx_program* p, rgx_stream_ctx* c, rgx_result* r
  * names and out-of-range indices expand to nothing (replace.go:393-453).  `d_out` receives the result; *out_len is
  * always set; RGX_E_CAPACITY when cap_out is too small (call again with *out_len bytes).  A malformed template is
  * RGX_E_INVALID (the reference panics).  The emitted loop is FindBytesReuse on input[matchEnd:] + bytes.Index, like
- * FindReader's: for programs whose FindBytesReuse the library reproduces (rgx_info.ref_find_offered, no empty matches) the
- * result is that loop's or RGX_E_DIVERGES (see rgx_find_chunk); for the others matches are taken in their true context
- * (the re-slicing quirks, DESIGN.md Q1/Q4'/Q12, are not reproduced).                                    */
+ * FindReader's: for programs whose FindBytesReuse the library reproduces (rgx_info.ref_stream_offered) the result is that
+ * loop's or RGX_E_DIVERGES (see rgx_find_chunk); for the others RGX_E_UNSUPPORTED, unless the program was compiled with
+ * RGX_FLAG_STDLIB_SEMANTICS: then matches are taken in their true context (the re-slicing quirks, DESIGN.md Q1/Q4'/Q12, are
+ * not reproduced -- what Go's regexp.ReplaceAll with the same expansion would give).                                */
 int64_t rgx_replace_all_bytes_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len,
                                      const char* tmpl, size_t tmpl_len, int first_only, uint8_t* d_out, size_t cap_out,
                                      int64_t* out_len, rgx_result* res);
@@ -227,7 +253,8 @@ int rgx_replace_template_check(const char* tmpl, size_t tmpl_len);
  * Template: replace.Parse + ValidateAndResolve (replace/template.go:45-291): an unknown name or an index beyond the
  * groups is RGX_E_INVALID (the reference returns a reader that yields the error); group texts go through
  * getCaptureByIndex (transform.go:288-320), which knows NAMED groups only -- `$1` of an unnamed group expands to nothing.
- * The same identical-or-refused rule as rgx_find_chunk applies (RGX_E_DIVERGES: run the buffer through the Go processor).
+ * The same identical-or-refused rule as rgx_find_chunk applies (RGX_E_DIVERGES: run the buffer through the Go processor;
+ * RGX_E_UNSUPPORTED where rgx_info.ref_stream_offered == 0 and the program is in reference mode).
  * Patterns that can match empty are RGX_E_UNSUPPORTED: the emitted loop drops a byte per empty match and panics on one
  * at the end of the data; keep the Go path for them.  Predicates and arbitrary callbacks run on the host
  * over rgx_find_all_bytes spans with the same *processed rule.                                     */
@@ -278,8 +305,9 @@ int64_t rgx_match_batch_device(const rgx_program* p, rgx_stream_ctx* c, const ui
  * offset (Q4) -- and for programs whose FindBytesReuse the library reproduces (rgx_info.ref_find_offered, no empty matches) every
  * gap between two matches is CHECKED on the device against exactly those three things: all pass -> the reference's loop
  * reports these very matches; one fails -> RGX_E_DIVERGES and nothing is delivered (the stub replays the chunk through the Go
- * loop).  RGX_FLAG_STDLIB_SEMANTICS switches the check off; for the other programs (memoising / TDFA FindBytes, empty
- * matches) there is no check: plain FindAllBytes semantics, as DESIGN.md states.                                         */
+ * loop).  For the other programs (memoising / TDFA FindBytes, empty matches: rgx_info.ref_stream_offered == 0) the loop is not
+ * reproduced and the call returns RGX_E_UNSUPPORTED.  RGX_FLAG_STDLIB_SEMANTICS: no check, no refusal -- the chunk's matches are
+ * FindAllBytes' for every program.                                                                                          */
 typedef struct rgx_stream_config {  /* stream.Config, stream/stream.go:21-39 */
   int64_t buffer_size;
   int64_t max_leftover;
@@ -295,6 +323,86 @@ int64_t rgx_find_chunk(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* c
  * *committed = end of the last one (-1 for a chunk that is not full: nothing is carried over from it).          */
 int64_t rgx_count_chunk(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* chunk, size_t data_len, int is_full,
                         int64_t max_leftover, int64_t* committed, int64_t* keep_from, rgx_result* res);
+
+/* ---- several GPUs: the sequential FindReader / FindAllBytes of the reference cut across devices ----------------------------
+ * (internal/compiler/streaming.go:85-255 and find.go:130-466 are single-threaded loops; nothing in the reference shards.  SURVEY 8b:
+ * "same calls on a rgx_program created over a device list; RCCL communicator owned by the library"; 8e: contiguous owned ranges,
+ * halos, a gather of the match offsets.)
+ *
+ * A rgx_sharded owns, per device: a copy of the program, two contexts (two rounds may be in flight), two host threads, staging
+ * and span buffers -- and the communicator.  Two ways to make one:
+ *   rgx_sharded_create        one process drives n devices (the generated Go: <Name>GPUDevices); ncclCommInitAll inside.
+ *   rgx_sharded_create_rank   one process per device (bench.py under torch.distributed.run): rank 0 calls
+ *                             rgx_sharded_unique_id, the launcher carries the 128 bytes to the others, ncclCommInitRank inside.
+ * RCCL is dlopen-ed when a communicator is first needed; devices that repeat in the list (a test on a one-GPU box), a world of
+ * one and RGX_SHARDED_NO_RCCL=1 use peer copies instead.
+ *
+ * One ROUND gives every rank one window of the stream: `len` bytes of which [own_lo, own_hi) are OWNED (a match belongs to the
+ * rank that owns its START); the bytes before own_lo are the left halo, which must hold a sync point of the FindAll chain (a
+ * byte on which every automaton state dies, rgx_program_reset_bytes) unless `starts_at_sync`; the bytes behind own_hi are the
+ * right halo: rgx_info.max_match_len bytes (so that an owned match and the byte behind it fit), 1 MiB for unbounded patterns
+ * (the reference's own leftover cap, streaming.go:87-96) -- rgx_shard_plan does this arithmetic for a buffer of known length.
+ * The answer per rank (rgx_shard_round): its count; `unsynced` = the left halo held no sync point, nothing of this window is
+ * vouched for (count 0): hand the window in again with a wider halo; `truncated` = unbounded pattern and the last owned match
+ * touches the end of a window that is not the stream's last.  Semantics: FindAllBytes over the whole stream -- the reference's
+ * FindReader differs from that by its chunk protocol (matches straddling a chunk end beyond MaxLeftover are cut or lost);
+ * programs in reference mode whose FindAll is not offered are refused here like everywhere.                                 */
+typedef struct rgx_sharded rgx_sharded;
+typedef struct rgx_shard_range { int64_t lo, hi, win_lo, win_hi; } rgx_shard_range;   /* owned [lo, hi) inside window [win_lo, win_hi) */
+/* Cut [0, total_len) into `parts` owned ranges (16-byte aligned starts) with halos; halo_left bytes of left halo; unbounded_halo
+ * <= 0: 1 MiB.  Pure arithmetic, no device.                                                                                 */
+int rgx_shard_plan(int64_t total_len, int parts, int32_t max_match_len, int64_t halo_left, int64_t unbounded_halo, rgx_shard_range* out);
+int rgx_sharded_create(const void* blob, size_t blob_len, const int* devices, int n_devices, rgx_sharded** out);
+int rgx_sharded_unique_id(void* id, size_t cap);            /* writes 128 bytes; returns the number written                  */
+int rgx_sharded_create_rank(const void* blob, size_t blob_len, int device, int rank, int world, const void* id, size_t id_len,
+                            rgx_sharded** out);
+void rgx_sharded_destroy(rgx_sharded* s);
+typedef struct rgx_sharded_info { int32_t n_local, world, first_rank, uses_rccl; } rgx_sharded_info;
+int rgx_sharded_shape(const rgx_sharded* s, rgx_sharded_info* out);
+const rgx_program* rgx_sharded_program(const rgx_sharded* s, int local_index);       /* for rgx_program_info etc.              */
+/* The HIP stream the scans of `slot` (0/1 = round parity) run on: a caller that produces windows on the device orders its
+ * producer against it.                                                                                                        */
+void* rgx_sharded_hip_stream(const rgx_sharded* s, int local_index, int slot);
+int rgx_sharded_set_timing(rgx_sharded* s, int on);          /* rgx_shard_round.kernel_ms                                      */
+
+typedef struct rgx_shard_window {
+  const uint8_t* buf;       /* the window: device memory of the shard's device (16-byte aligned), or host memory (is_host)    */
+  size_t len;               /* 0: this rank has no window this round                                                          */
+  int64_t own_lo, own_hi;   /* owned range inside the window                                                                  */
+  int64_t base;             /* stream offset of buf[0]                                                                        */
+  int32_t is_host;          /* 1: staged to the device by the shard's thread (must stay valid until the round is waited for)  */
+  int32_t starts_at_sync;   /* 1: buf[0] is the beginning of the stream (or otherwise known to be a sync point)               */
+  int32_t last;             /* 1: the window ends where the stream ends                                                       */
+  int32_t reserved;
+  int32_t* d_spans;         /* device output, cap_records records of ncap int32, window-relative; NULL: the shard's own buffer */
+  size_t cap_records;
+} rgx_shard_window;
+typedef struct rgx_shard_round {
+  int64_t count;            /* matches this rank owns                                                                          */
+  int32_t have, unsynced, truncated, stop;
+  int32_t status;           /* rgx_status of the rank's scan                                                                   */
+  float kernel_ms;          /* local ranks only                                                                                */
+} rgx_shard_round;
+/* windows: one per LOCAL shard.  submit returns at once (the slot index, 0/1, or < 0); at most two rounds in flight.  wait
+ * finishes the oldest: waits for the local scans, exchanges [count, flags] (across processes: one ncclAllGather of 32 bytes per
+ * rank), fills out[world] and returns the round's total or < 0.  A failing rank still takes part in the exchange, so every rank
+ * gets the error instead of hanging; stop_request != 0 travels with the exchange (FindReader's callback returned false).   */
+int rgx_sharded_round_submit(rgx_sharded* s, const rgx_shard_window* windows, int count_only);
+int64_t rgx_sharded_round_wait(rgx_sharded* s, int stop_request, rgx_shard_round* out);
+int64_t rgx_sharded_round(rgx_sharded* s, const rgx_shard_window* windows, int count_only, int stop_request, rgx_shard_round* out);
+/* Rows of the last waited round on local shard i: device pointer (window-relative int32 records), the window's base; returns
+ * the count.  Valid until that slot's next submit.                                                                            */
+int64_t rgx_sharded_rows(const rgx_sharded* s, int local_index, const int32_t** d_rows, int64_t* base);
+/* The RCCL gather of match offsets: every rank's rows of the last waited round as stream-absolute int64 records (unset groups
+ * stay (0,0) / (-1,-1)), in rank order, on rank dst_rank's device -- grouped ncclSend / ncclRecv, each source on its own xGMI
+ * link.  Every rank calls it.  The table lands in d_dst (device memory of dst's device, cap_records records; only looked at on
+ * the destination) or, when d_dst is NULL, in a library buffer valid until the next gather; h_dst != NULL also receives a host
+ * copy (what a Go caller takes).  *d_rows = where the table is; returns its rows (0 on the other ranks).                      */
+int64_t rgx_sharded_gather(rgx_sharded* s, int dst_rank, int64_t* d_dst, int64_t* h_dst, size_t cap_records, const int64_t** d_rows);
+/* FindAllBytes(input, n) of one host buffer cut across the local devices (rgx_sharded_create only): plan, stage, scan, rows back
+ * in order with buffer-absolute int32 offsets.  Same contract as rgx_find_all_bytes.                                          */
+int64_t rgx_sharded_find_all_bytes(rgx_sharded* s, const uint8_t* buf, size_t len, int64_t n, int32_t* spans, size_t cap_records,
+                                   rgx_result* res);
 
 const char* rgx_last_error(void);
 const char* rgx_status_str(int status);

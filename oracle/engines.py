@@ -847,13 +847,24 @@ def find_reader(find_fn: Callable[[bytes], Optional[List[int]]], max_len: int, r
 
 
 class Compiled:
-    """Oracle view of one generated matcher: Compiled<Name>.{MatchBytes,FindBytes,FindAllBytes,FindReader}."""
+    """Oracle view of one generated matcher: Compiled<Name>.{MatchBytes,FindBytes,FindAllBytes,FindReader} AS THE REFERENCE EMITS
+    THEM, engine selection included (compiler.go:93-153): for a pattern with captures and nested quantifiers the Find family is
+    the Tagged DFA's when it can be built (oracle/tdfa.py: longest-on-path, FindAll advancing by the match length, raw tags with
+    -1 for an unset group), else the memoising backtracker's.  `find_machine` is the backtracking machine in every case -- its
+    find_all is the plain leftmost-first answer (Go's regexp), which is what the device computes under RGX_FLAG_STDLIB_SEMANTICS."""
 
     def __init__(self, pattern: str, **force):
         self.pattern = pattern
         self.ast, self.prog = S.compile_pattern(pattern)
         self.sel = select(self.ast, self.prog, **force)
         self.names = S.capture_names(self.ast)
+        self.tdfa = None
+        if self.sel.find_engine == "tdfa?":
+            from . import tdfa as T
+            self.tdfa = T.build_for_prog(self.ast, self.prog)
+            self.sel.find_engine = "tdfa" if self.tdfa is not None else "tnfa"
+            if self.tdfa is None:
+                self.sel.find_memo = True      # generateTNFACaptureFunctions switches memoisation on (compiler.go:415-426)
         self.match_machine = Machine(self.prog, memo=self.sel.match_memo)
         self.find_machine = Machine(self.prog, memo=self.sel.find_memo)
         self.thompson = ThompsonMatcher(self.prog) if self.sel.thompson_for_match else None
@@ -864,10 +875,19 @@ class Compiled:
         return self.match_machine.match(b)
 
     def FindBytes(self, b: bytes):
+        if self.tdfa is not None:
+            return self.tdfa.find(b)
         return self.find_machine.find(b)
 
     def FindAllBytes(self, b: bytes, n: int = -1):
+        if self.tdfa is not None:
+            return self.tdfa.find_all(b, n)
         return self.find_machine.find_all(b, n)
 
+    def FindAllLeftmostFirst(self, b: bytes, n: int = -1):
+        """Go regexp's FindAll (what RGX_FLAG_STDLIB_SEMANTICS computes): the backtracking loop with a fresh memo per match."""
+        return self.find_machine.find_all(b, n, q8=False)
+
     def FindReader(self, read, cfg: StreamConfig, on_match) -> Optional[str]:
-        return find_reader(self.find_machine.find, self.sel.max_len, read, cfg, on_match)
+        find = self.tdfa.find if self.tdfa is not None else self.find_machine.find
+        return find_reader(find, self.sel.max_len, read, cfg, on_match)

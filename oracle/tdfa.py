@@ -331,9 +331,9 @@ class TDFA:
                 "accept_actions": [list(map(list, self.accept_actions.get(s, []))) for s in range(ns)]}
 
 
-def build_for_pattern(pattern: str, max_states: int = 500) -> Optional[TDFA]:
-    """The reference's decision (compiler.go:137-153): captures + catastrophic risk -> try TDFA; None if it cannot."""
-    ast, prog = S.compile_pattern(pattern)
+def build_for_prog(ast, prog, max_states: int = 500) -> Optional[TDFA]:
+    """The reference's decision (compiler.go:137-153, tdfa.go:83-109): the Tagged DFA if it can be built, None if it cannot
+    (an empty-width op other than ^/$ of the text, or more than max_states states)."""
     if prog.numcap <= 2 or not TDFA.supported(prog):
         return None
     try:
@@ -343,3 +343,8 @@ def build_for_pattern(pattern: str, max_states: int = 500) -> Optional[TDFA]:
     if len(t.states) > max_states:
         return None
     return t
+
+
+def build_for_pattern(pattern: str, max_states: int = 500) -> Optional[TDFA]:
+    ast, prog = S.compile_pattern(pattern)
+    return build_for_prog(ast, prog, max_states)

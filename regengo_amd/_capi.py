@@ -21,6 +21,7 @@ _STATUS = {0: "ok", -1: "invalid", -2: "syntax", -3: "unsupported", -4: "too lar
            -7: "nomem", -8: "capacity", -9: "bad blob", -10: "buffer too small", -11: "diverges from the reference"}
 
 RGX_OK = 0
+ABI_VERSION = 3            # include/rgx.h: RGX_ABI_VERSION (checked against rgx_abi_version() when the library is loaded)
 RGX_E_INVALID = -1
 RGX_E_SYNTAX = -2
 RGX_E_UNSUPPORTED = -3
@@ -37,7 +38,27 @@ class Info(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "abi_version", "ncap", "min_match_len", "max_match_len", "default_max_leftover", "min_buffer_size", "n_inst",
         "n_states", "n_classes", "anchored", "fixed_captures", "can_match_empty", "ref_match_engine", "ref_find_engine",
-        "lookahead_mode", "table_bytes", "needs_valid_utf8", "sync_states", "scan_kernel", "ref_match_offered", "ref_find_offered", "unicode_version", "utf8_screened")]
+        "lookahead_mode", "table_bytes", "needs_valid_utf8", "sync_states", "scan_kernel", "ref_match_offered", "ref_find_offered", "unicode_version", "utf8_screened",
+        "ref_findall_offered", "ref_stream_offered", "ref_tdfa_states")] + [("flags", C.c_uint32)]
+
+
+class ShardRange(C.Structure):
+    _fields_ = [("lo", C.c_int64), ("hi", C.c_int64), ("win_lo", C.c_int64), ("win_hi", C.c_int64)]
+
+
+class ShardedInfo(C.Structure):
+    _fields_ = [("n_local", C.c_int32), ("world", C.c_int32), ("first_rank", C.c_int32), ("uses_rccl", C.c_int32)]
+
+
+class ShardWindow(C.Structure):
+    _fields_ = [("buf", C.c_void_p), ("len", C.c_size_t), ("own_lo", C.c_int64), ("own_hi", C.c_int64), ("base", C.c_int64),
+                ("is_host", C.c_int32), ("starts_at_sync", C.c_int32), ("last", C.c_int32), ("reserved", C.c_int32),
+                ("d_spans", C.c_void_p), ("cap_records", C.c_size_t)]
+
+
+class ShardRound(C.Structure):
+    _fields_ = [("count", C.c_int64), ("have", C.c_int32), ("unsynced", C.c_int32), ("truncated", C.c_int32), ("stop", C.c_int32),
+                ("status", C.c_int32), ("kernel_ms", C.c_float)]
 
 
 class Result(C.Structure):
@@ -56,6 +77,7 @@ SYMBOLS = {
     "rgx_program_blob_write": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "rgx_program_from_blob": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "rgx_program_destroy": (None, [C.c_void_p]),
+    "rgx_abi_version": (C.c_int, []),
     "rgx_program_info": (C.c_int, [C.c_void_p, C.POINTER(Info)]),
     "rgx_program_capture_names": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "rgx_program_reset_bytes": (C.c_int, [C.c_void_p, C.c_void_p]),
@@ -105,6 +127,21 @@ SYMBOLS = {
                                     C.POINTER(C.c_int64), C.POINTER(Result)]),
     "rgx_count_all_device_owned": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int64,
                                                C.POINTER(Result)]),
+    "rgx_shard_plan": (C.c_int, [C.c_int64, C.c_int, C.c_int32, C.c_int64, C.c_int64, C.POINTER(ShardRange)]),
+    "rgx_sharded_create": (C.c_int, [C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.c_int, C.POINTER(C.c_void_p)]),
+    "rgx_sharded_unique_id": (C.c_int, [C.c_void_p, C.c_size_t]),
+    "rgx_sharded_create_rank": (C.c_int, [C.c_void_p, C.c_size_t, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "rgx_sharded_destroy": (None, [C.c_void_p]),
+    "rgx_sharded_shape": (C.c_int, [C.c_void_p, C.POINTER(ShardedInfo)]),
+    "rgx_sharded_program": (C.c_void_p, [C.c_void_p, C.c_int]),
+    "rgx_sharded_hip_stream": (C.c_void_p, [C.c_void_p, C.c_int, C.c_int]),
+    "rgx_sharded_set_timing": (C.c_int, [C.c_void_p, C.c_int]),
+    "rgx_sharded_round_submit": (C.c_int, [C.c_void_p, C.POINTER(ShardWindow), C.c_int]),
+    "rgx_sharded_round_wait": (C.c_int64, [C.c_void_p, C.c_int, C.POINTER(ShardRound)]),
+    "rgx_sharded_round": (C.c_int64, [C.c_void_p, C.POINTER(ShardWindow), C.c_int, C.c_int, C.POINTER(ShardRound)]),
+    "rgx_sharded_rows": (C.c_int64, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
+    "rgx_sharded_gather": (C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "rgx_sharded_find_all_bytes": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t, C.POINTER(Result)]),
     "rgx_last_error": (C.c_char_p, []),
     "rgx_status_str": (C.c_char_p, [C.c_int]),
 }
@@ -143,6 +180,8 @@ def lib():
         fn = getattr(L, name)
         fn.restype = res
         fn.argtypes = args
+    if L.rgx_abi_version() != ABI_VERSION:
+        raise RuntimeError("librgx_hip.so has ABI version %d, this binding is written for %d" % (L.rgx_abi_version(), ABI_VERSION))
     _lib = L
     return L
 

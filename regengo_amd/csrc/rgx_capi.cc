@@ -141,6 +141,29 @@ bool ReaderCheckApplies(const rgx_program* p) {
   const Tables& t = p->p.t;
   return !(t.flags & RGX_FLAG_STDLIB_SEMANTICS) && p->p.dev.ref_find_ok && !t.can_match_empty;
 }
+// Reference mode is "the reference's answer or a refusal" (rgx.h: rgx_info.ref_findall_offered / ref_stream_offered).
+bool RefFindAllOffered(const Tables& t) {
+  if (t.ref_find_engine <= 0) return true;                       // plain backtracking (or no captures: nothing to differ from)
+  return t.ref_find_engine == 2 && !t.can_match_empty;           // memoising backtracker: Q8 needs an empty match; TDFA: Q11
+}
+bool RefStreamOffered(const Tables& t) {
+  const bool have_rm = !t.rm_depth[0].empty() && !t.rm_depth[1].empty();
+  return have_rm && !t.ref_memo && t.ref_find_engine <= 0 && !t.can_match_empty;
+}
+int RefuseFindAll(const rgx_program* p) {
+  const Tables& t = p->p.t;
+  if ((t.flags & RGX_FLAG_STDLIB_SEMANTICS) || RefFindAllOffered(t)) return RGX_OK;
+  SetError(t.ref_find_engine == 1
+               ? "reference-mode FindAll is not offered for this pattern: the reference emits its Tagged DFA, whose FindAllBytes advances by the match length and reports matches again (compiler.go:646-651); keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS"
+               : "reference-mode FindAll is not offered for this pattern: the reference memoises and the pattern matches empty (its memo is never cleared between matches, find.go:175-188); keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS");
+  return RGX_E_UNSUPPORTED;
+}
+int RefuseStream(const rgx_program* p) {
+  const Tables& t = p->p.t;
+  if ((t.flags & RGX_FLAG_STDLIB_SEMANTICS) || RefStreamOffered(t)) return RGX_OK;
+  SetError("reference-mode FindReader / Replace / Transform is not offered for this pattern: the emitted loop is FindBytesReuse on a re-sliced input and the reference's FindBytesReuse (memoising / Tagged-DFA engine, or a pattern that matches empty) is not reproduced; keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS");
+  return RGX_E_UNSUPPORTED;
+}
 int ReaderCheck(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_raw, size_t len, const int32_t* d_spans, int64_t n) {
   const uint8_t* view = d_raw;
   int rc = MatchView(p, c, d_raw, len, &view);
@@ -437,6 +460,8 @@ static int MinBuffer(int max_len) {  // streaming.go:56-62
   return mb;
 }
 
+RGX_API int rgx_abi_version(void) { return RGX_ABI_VERSION; }
+
 RGX_API int rgx_program_info(const rgx_program* p, rgx_info* o) {
   if (!p || !o) return RGX_E_INVALID;
   const Tables& t = p->p.t;
@@ -454,6 +479,12 @@ RGX_API int rgx_program_info(const rgx_program* p, rgx_info* o) {
     const bool have_rm = !t.rm_depth[0].empty() && !t.rm_depth[1].empty();
     o->ref_find_offered = (have_rm && !t.ref_memo && t.ref_find_engine <= 0) ? 1 : 0;
     o->ref_match_offered = (t.ref_match_engine == 1 || (have_rm && !t.ref_memo && !t.ref_has_fail)) ? 1 : 0;
+    const bool stdlib = (t.flags & RGX_FLAG_STDLIB_SEMANTICS) != 0;
+    if (stdlib) o->ref_find_offered = o->ref_match_offered = 1;       // nothing of the reference's to reproduce: every entry point answers
+    o->ref_findall_offered = (stdlib || RefFindAllOffered(t)) ? 1 : 0;
+    o->ref_stream_offered = (stdlib || RefStreamOffered(t)) ? 1 : 0;
+    o->ref_tdfa_states = t.ref_tdfa_states;
+    o->flags = t.flags;
   }
   o->scan_kernel = p->p.d_arena ? ScanKernelKind(p->p.dev, 1 << 24) : 0;
   o->table_bytes = p->p.d_arena ? p->p.dev.table_bytes : (int32_t)((size_t)t.nstates * (t.ncls + 1) * 2);
@@ -554,6 +585,7 @@ RGX_API int64_t rgx_find_all_bytes_device(const rgx_program* p, rgx_stream_ctx* 
                                           int32_t* d_spans, size_t cap_records, rgx_result* res) {
   int rc = CheckCtx(p, c);
   if (rc != RGX_OK) return rc;
+  if ((rc = RefuseFindAll(p)) != RGX_OK) return rc;
   return FindAllDevice(p, c, d_buf, len, n, d_spans, cap_records, false, res);
 }
 
@@ -562,6 +594,7 @@ RGX_API int64_t rgx_find_all_bytes_device_owned(const rgx_program* p, rgx_stream
                                                 rgx_result* res) {
   int rc = CheckCtx(p, c);
   if (rc != RGX_OK) return rc;
+  if ((rc = RefuseFindAll(p)) != RGX_OK) return rc;
   if (own_lo < 0 || own_hi < own_lo) { SetError("bad owned range"); return RGX_E_INVALID; }
   return FindAllDevice(p, c, d_buf, len, n, d_spans, cap_records, false, res, false, own_lo, own_hi);
 }
@@ -574,6 +607,7 @@ RGX_API int rgx_find_all_submit(const rgx_program* p, rgx_stream_ctx* c, const u
                                 size_t cap_records, int64_t own_lo, int64_t own_hi) {
   int rc = CheckCtx(p, c);
   if (rc != RGX_OK) return rc;
+  if ((rc = RefuseFindAll(p)) != RGX_OK) return rc;
   if (c->pend_count >= 2) { SetError("two scans already in flight: call rgx_find_all_wait"); return RGX_E_INVALID; }
   if (own_lo < 0 || (own_hi >= 0 && own_hi < own_lo)) { SetError("bad owned range"); return RGX_E_INVALID; }
   const DevTables& T = p->p.dev;
@@ -829,6 +863,7 @@ RGX_API int64_t rgx_replace_all_bytes_device(const rgx_program* p, rgx_stream_ct
                                              rgx_result* res) {
   int rc = CheckCtx(p, c);
   if (rc != RGX_OK) return rc;
+  if ((rc = RefuseStream(p)) != RGX_OK) return rc;
   if (!out_len || (!tmpl && tmpl_len)) return RGX_E_INVALID;
   const Tables& t = p->p.t;
   const DevTables& T = p->p.dev;
@@ -917,6 +952,7 @@ int64_t TransformChunkDevice(const rgx_program* p, rgx_stream_ctx* c, const uint
                              bool final_sync) {
   int rc = CheckCtx(p, c);
   if (rc != RGX_OK) return rc;
+  if ((rc = RefuseStream(p)) != RGX_OK) return rc;
   if (!out_len || !processed || mode < RGX_TRANSFORM_REPLACE || mode > RGX_TRANSFORM_REJECT) return RGX_E_INVALID;
   if (mode == RGX_TRANSFORM_REPLACE && !tmpl && tmpl_len) return RGX_E_INVALID;
   const Tables& t = p->p.t;
@@ -1021,6 +1057,7 @@ RGX_API int64_t rgx_find_all_starts_device(const rgx_program* p, rgx_stream_ctx*
                                            int32_t* d_starts, size_t cap, rgx_result* res) {
   int rc = CheckCtx(p, c);
   if (rc != RGX_OK) return rc;
+  if ((rc = RefuseFindAll(p)) != RGX_OK) return rc;
   if (!UseExactKernel(p->p.dev, len > 0x7FFFFF00ull ? 0 : (int32_t)len) && len != 0) {
     SetError("starts-only results need a fixed-template pattern (rgx_info.fixed_captures) and len >= 64");
     return RGX_E_UNSUPPORTED;
@@ -1039,6 +1076,7 @@ RGX_API int rgx_program_capture_template(const rgx_program* p, int32_t* offsets)
 RGX_API int64_t rgx_count_all_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, rgx_result* res) {
   int rc = CheckCtx(p, c);
   if (rc != RGX_OK) return rc;
+  if ((rc = RefuseFindAll(p)) != RGX_OK) return rc;
   return FindAllDevice(p, c, d_buf, len, -1, nullptr, 0, true, res);
 }
 
@@ -1046,6 +1084,7 @@ RGX_API int64_t rgx_find_all_bytes(const rgx_program* p, rgx_stream_ctx* c, cons
                                    int32_t* spans, size_t cap_records, rgx_result* res) {
   int rc = CheckCtx(p, c);
   if (rc != RGX_OK) return rc;
+  if ((rc = RefuseFindAll(p)) != RGX_OK) return rc;
   if (n == 0 || len == 0) { if (res) { memset(res, 0, sizeof *res); res->ncap = p->p.dev.ncap; } return 0; }
   if (!buf || (!spans && cap_records)) return RGX_E_INVALID;
   const int ncap = p->p.dev.ncap;
@@ -1067,18 +1106,53 @@ RGX_API int rgx_match_bytes_device(const rgx_program* p, rgx_stream_ctx* c, cons
   if ((rc = MatchView(p, c, d_buf, len, &d_buf)) != RGX_OK) return rc;       // broken UTF-8: match on the sanitised copy
   const bool ref_rule = !(t.flags & RGX_FLAG_STDLIB_SEMANTICS) && p->p.dev.ref_match_kind != 1;
   if (ref_rule && p->p.dev.ref_match_kind == 2) { SetError("reference-mode MatchBytes is not offered for this pattern (memoising engine): keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS"); return RGX_E_UNSUPPORTED; }
+  uint64_t lane_lo = 0, lane_hi = (uint64_t)len;     // the text handed to the sequential loop below
   if (ref_rule && !t.can_match_empty) {
     // The reference's MatchBytes only ever reports true matches, so "no leftmost-first match anywhere" (the parallel scan) is
     // its answer too; where one exists the emitted loop itself decides -- its restart rule may step over it (Q1) -- and that
     // loop is sequential: one lane, which stops at the first match it accepts.
     rgx_result r0;
-    const int64_t any = FindAllDevice(p, c, d_buf, len, -1, nullptr, 0, true, &r0);
+    if ((rc = Ensure(&c->d_out, &c->out_cap, (int64_t)p->p.dev.ncap + 16)) != RGX_OK) return rc;
+    const int64_t any = FindAllDevice(p, c, d_buf, len, 1, c->d_out, 1, false, &r0);
     if (any < 0) return (int)any;
     if (any == 0) { *matched = 0; return RGX_OK; }
+    // One lane over gigabytes takes seconds, so its work is bounded.  Every attempt in front of the first match's start s0
+    // fails, the attempt offsets only grow and an attempt that starts before a reset byte dies on it at the latest: the loop
+    // steps onto the offset behind every reset byte in front of s0 (the required-byte skip of compiler.go:719-737 lands on the
+    // same offset from there as from anywhere before).  The lane therefore starts behind the last reset byte before s0 -- if
+    // the automaton starts there as it does at the beginning of a text -- and gets kRefLaneBytes of text behind s0; an answer
+    // it cannot give within that is RGX_E_UNSUPPORTED (the stub's Go loop decides).
+    constexpr int64_t kRefLaneBytes = 4 << 20, kBack = 4096;
+    int32_t s0 = 0;
+    HIP_TRY(hipMemcpyAsync(&s0, c->d_out, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((int64_t)s0 > kRefLaneBytes) {
+      uint8_t back[kBack];
+      HIP_TRY(hipMemcpy(back, d_buf + s0 - kBack, kBack, hipMemcpyDeviceToHost));
+      int64_t x = -1;
+      for (int64_t q = kBack - 1; q >= 0; --q)
+        if (t.reset_byte[back[q]]) { x = (int64_t)s0 - kBack + q + 1; break; }
+      bool same_start = false;
+      if (x > 0) {
+        const int cx = t.ctx_of_byte[back[x - 1 - ((int64_t)s0 - kBack)]];
+        same_start = t.start[kCtxBOT] == t.start[cx] && t.start_accept[kCtxBOT] == t.start_accept[cx] &&
+                     t.rm_start[1][kCtxBOT] == t.rm_start[1][cx] && !t.anchored;
+      }
+      if (!same_start) {
+        SetError("reference-mode MatchBytes: the first match lies megabytes into the buffer and no restart point of the emitted loop is provable in front of it; keep the Go path");
+        return RGX_E_UNSUPPORTED;
+      }
+      lane_lo = (uint64_t)x;
+    }
+    if ((int64_t)len - (int64_t)s0 > kRefLaneBytes && !t.lookahead_mode) lane_hi = (uint64_t)s0 + (uint64_t)kRefLaneBytes;
+    else if ((int64_t)len - (int64_t)lane_lo > 2 * kRefLaneBytes) {
+      SetError("reference-mode MatchBytes: the text behind the first match is too long for the sequential loop of a pattern with trailing assertions; keep the Go path");
+      return RGX_E_UNSUPPORTED;
+    }
   }
   if (t.can_match_empty || ref_rule) {
     // one-string batch covers the attempt at offset len exactly
-    uint64_t h_off[2] = {0, (uint64_t)len};
+    uint64_t h_off[2] = {lane_lo, lane_hi};
     uint64_t* d_off = nullptr; uint8_t* d_found = nullptr;
     HIP_TRY(hipMalloc((void**)&d_off, 16)); HIP_TRY(hipMalloc((void**)&d_found, 16));
     HIP_TRY(hipMemcpyAsync(d_off, h_off, 16, hipMemcpyHostToDevice, c->stream));
@@ -1089,6 +1163,10 @@ RGX_API int rgx_match_bytes_device(const rgx_program* p, rgx_stream_ctx* c, cons
     if (e == hipSuccess) e = hipStreamSynchronize(c->stream);
     (void)hipFree(d_off); (void)hipFree(d_found);
     HIP_TRY(e);
+    if (!f && lane_hi < (uint64_t)len) {
+      SetError("reference-mode MatchBytes: the emitted loop steps over the first match and finds none within the sequential budget; keep the Go path");
+      return RGX_E_UNSUPPORTED;
+    }
     *matched = f;
     return RGX_OK;
   }
@@ -1274,6 +1352,7 @@ RGX_API int64_t rgx_find_chunk(const rgx_program* p, rgx_stream_ctx* c, const ui
   // stops the loop, exactly like the `break` at streaming.go:204-207.
   int rc = CheckCtx(p, c);
   if (rc != RGX_OK) return rc;
+  if ((rc = RefuseStream(p)) != RGX_OK) return rc;
   if (!committed || !keep_from || (!chunk && data_len) || (!spans && cap_records)) return RGX_E_INVALID;
   rgx_result r{};
   r.ncap = p->p.dev.ncap;
@@ -1314,6 +1393,7 @@ RGX_API int64_t rgx_count_chunk(const rgx_program* p, rgx_stream_ctx* c, const u
   // never leaves the device -- a chunk that is not full (the last one) does not even build it.
   int rc = CheckCtx(p, c);
   if (rc != RGX_OK) return rc;
+  if ((rc = RefuseStream(p)) != RGX_OK) return rc;
   if (!committed || !keep_from || (!chunk && data_len)) return RGX_E_INVALID;
   rgx_result r{};
   r.ncap = p->p.dev.ncap;
@@ -1360,6 +1440,7 @@ RGX_API int64_t rgx_count_all_device_owned(const rgx_program* p, rgx_stream_ctx*
                                            int64_t own_hi, rgx_result* res) {
   int rc = CheckCtx(p, c);
   if (rc != RGX_OK) return rc;
+  if ((rc = RefuseFindAll(p)) != RGX_OK) return rc;
   if (own_lo < 0 || own_hi < own_lo) { SetError("bad owned range"); return RGX_E_INVALID; }
   rgx_result r{};
   int64_t w = FindAllDevice(p, c, d_buf, len, -1, nullptr, 0, true, &r, false, own_lo, own_hi);

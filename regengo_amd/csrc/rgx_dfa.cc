@@ -384,7 +384,9 @@ Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOption
     bool cat = DetectNestedQuantifiers(ast.get()), nl = DetectComplexity(prog), ea = HasEndAnchor(prog);
     bool thompson = (cat || nl) && !ea;
     t.ref_match_engine = (thompson && prog.inst.size() <= 64) ? 1 : ((nl || cat) ? 2 : 0);
-    t.ref_find_engine = prog.numcap <= 2 ? -1 : (cat ? 1 : 0);
+    // compiler.go:137-153: captures + nested quantifiers -> the Tagged DFA if it can be built, else the memoising backtracker
+    t.ref_tdfa_states = (prog.numcap > 2 && cat) ? std::max(0, RefTdfaStates(prog)) : 0;
+    t.ref_find_engine = prog.numcap <= 2 ? -1 : (cat ? (t.ref_tdfa_states > 0 ? 1 : 2) : 0);
   }
 
   if (opt.unanchored_search) {
@@ -1102,7 +1104,7 @@ struct R {
   void raw(void* d, size_t k) { if (o + k > n) { ok = false; return; } memcpy(d, p + o, k); o += k; }
 };
 constexpr uint32_t kMagic = 0x54584752;  // "RGXT"
-constexpr uint32_t kBlobVersion = 4;     // 3: FNV-1a checksum of the blob appended; every index range-checked on load
+constexpr uint32_t kBlobVersion = 5;  /* 5: ref_tdfa_states */    // 3: FNV-1a checksum of the blob appended; every index range-checked on load
 uint64_t Fnv1a(const uint8_t* p, size_t n) {
   uint64_t h = 1469598103934665603ull;
   for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
@@ -1115,7 +1117,7 @@ std::vector<uint8_t> SerializeTables(const Tables& t) {
   w.pod(kMagic); w.pod(kBlobVersion);
   w.str(t.pattern); w.pod(t.flags); w.pod<int32_t>(t.ncap); w.pod<int32_t>(t.n_inst); w.pod<int32_t>(t.min_len); w.pod<int32_t>(t.max_len);
   w.pod<uint8_t>(t.anchored); w.pod<uint8_t>(t.can_match_empty); w.pod<uint8_t>(t.lookahead_mode); w.pod<uint8_t>(t.fixed_captures);
-  w.pod<int32_t>(t.ref_match_engine); w.pod<int32_t>(t.ref_find_engine);
+  w.pod<int32_t>(t.ref_match_engine); w.pod<int32_t>(t.ref_find_engine); w.pod<int32_t>(t.ref_tdfa_states);
   w.pod<uint64_t>(t.cap_names.size());
   for (auto& s : t.cap_names) w.str(s);
   w.pod<int32_t>(t.ncls); w.raw(t.cls, 256); w.pod<int32_t>(t.nstates); w.vec(t.trans);
@@ -1147,7 +1149,7 @@ bool DeserializeTables(const uint8_t* p, size_t n, Tables* t) {
   r.str(t->pattern); r.pod(t->flags);
   r.pod(i32); t->ncap = i32; r.pod(i32); t->n_inst = i32; r.pod(i32); t->min_len = i32; r.pod(i32); t->max_len = i32;
   r.pod(u8); t->anchored = u8; r.pod(u8); t->can_match_empty = u8; r.pod(u8); t->lookahead_mode = u8; r.pod(u8); t->fixed_captures = u8;
-  r.pod(i32); t->ref_match_engine = i32; r.pod(i32); t->ref_find_engine = i32;
+  r.pod(i32); t->ref_match_engine = i32; r.pod(i32); t->ref_find_engine = i32; r.pod(i32); t->ref_tdfa_states = i32;
   uint64_t k = 0; r.pod(k);
   if (!r.ok || k > 4096) return false;
   t->cap_names.resize(k);

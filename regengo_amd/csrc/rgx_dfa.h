@@ -42,7 +42,8 @@ struct Tables {
   bool needs_valid_utf8 = false;  // a decoding class that holds U+FFFD: the run time screens the input for lead bytes without their
                                   // continuation bytes and matches such input through a sanitised copy (rgx_dfa.cc, Builder)
   int fixed_len = -1;             // byte length of every match when it is a constant, else -1
-  int ref_match_engine = 0, ref_find_engine = 0;
+  int ref_match_engine = 0, ref_find_engine = 0;   // rgx.h: rgx_info
+  int ref_tdfa_states = 0;        // states of the reference's Tagged DFA when it would emit one (rgx_ref_engine.cc)
   std::vector<std::string> cap_names;
 
   // ---- automaton
@@ -166,6 +167,10 @@ struct StartSearch {
   bool simple = false;
 };
 StartSearch BuildStartSearch(const std::string& pattern, uint32_t flags, int max_states = 3000, int max_regs = kUsRegs);
+
+// States of the Tagged DFA the reference would build for this program (tdfa.go:111-290), or -1 when it would not emit one
+// (an empty-width op other than ^/$ of the text, or more than max_states states): rgx_ref_engine.cc.
+int RefTdfaStates(const Prog& prog, int max_states = 500);
 
 // Throws SyntaxError / Unsupported / TooLarge.
 Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOptions& opt = BuildOptions());

@@ -1863,8 +1863,16 @@ namespace {
 //            the same way there (start state, start accept and right-most path of context BOT = those of the real byte before p);
 //   Q1       FindBytesReuse walks attempt offsets p, fail(p)+1, ... : that sequence has to land on the match's start (every
 //            attempt before it fails, the start being the leftmost one with a match) and must not run out of text first;
-//   Q4       bytes.Index(chunk[p:], match text) has to be the match's own offset: no earlier copy of the text in the gap.
+//   Q4       bytes.Index(chunk[p:], match text) has to be the match's own offset: no earlier copy of the text in the gap
+//            (reader_index_kernel below: the gaps are cut into pieces, a lane per piece).
 // raw = the chunk's bytes, view = the bytes the automaton sees (broken UTF-8 sanitised; == raw otherwise).
+//
+// The serial work of a lane is BOUNDED (a chunk of a gigabyte with a handful of matches has gaps of a hundred megabytes; a lane
+// that replays one attempt by attempt takes seconds).  The attempt sequence is strictly increasing and an attempt that starts
+// before a reset byte dies on it at the latest, so it steps ONTO the offset behind every reset byte of the gap: the replay
+// starts behind the last reset byte in front of the match -- searched backwards over at most kReaderBack bytes -- and gives up
+// (flag: the chunk goes through the Go loop, which is always right) when it has no start within that reach or runs longer.
+constexpr int kReaderBack = 4096, kReaderSteps = 1 << 16;
 __global__ __launch_bounds__(256) void reader_check_kernel(DevTables T, const uint8_t* raw, const uint8_t* view, int32_t len,
                                                            const int32_t* spans, long long n, int ncap, unsigned* flag) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1889,23 +1897,60 @@ __global__ __launch_bounds__(256) void reader_check_kernel(DevTables T, const ui
     if (i < n && !bad) {
       const int s = spans[i * ncap], e = spans[i * ncap + 1];
       int off = p;
-      while (off < s) {
+      if (s - p > kReaderBack) {
+        off = -1;
+        if (T.reset_values)
+          for (int q = s - 1; q >= s - kReaderBack; --q)
+            if (T.reset_byte[view[q]]) { off = q + 1; break; }
+        if (off < 0) bad = true;          // no provable point of the sequence in reach: not checked, hence not vouched for
+      }
+      int steps = 0;
+      while (!bad && off < s) {
         const int fo = RmFailOffset(T, 0, view, len, off);
-        if (!(len > fo)) { bad = true; break; }
+        if (!(len > fo) || ++steps > kReaderSteps) { bad = true; break; }
         off = fo + 1;
       }
       if (off != s) bad = true;
-      const int m = e - s;
-      if (!bad) {
-        if (m == 0) bad = s != p;
-        else
-          for (int q = p; q < s && !bad; ++q) {
-            if (raw[q] != raw[s] || q + m > len) continue;
-            int k = 1;
-            while (k < m && raw[q + k] == raw[s + k]) ++k;
-            if (k == m) bad = true;
-          }
+      if (!bad && e == s) bad = s != p;
+    }
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+// Q4, in parallel: lane j owns the offsets [j*kIdxPiece, (j+1)*kIdxPiece) of the chunk; for each of them that lies in a gap it
+// compares the text of the match behind the gap (first byte first; texts are short).  The row of the first match that starts
+// behind the piece's first offset comes from one binary search; rows advance with the offsets.
+constexpr int kIdxPiece = 128;
+__global__ __launch_bounds__(256) void reader_index_kernel(const uint8_t* raw, int32_t len, const int32_t* spans, long long n, int ncap,
+                                                           unsigned* flag) {
+  const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
+  bool bad = false;
+  const long long a = j * kIdxPiece;
+  if (a < len && n > 0) {
+    const int b = (int)(a + kIdxPiece < len ? a + kIdxPiece : len);
+    long long lo = 0, hi = n;            // first row whose start is > a
+    while (lo < hi) {
+      const long long mid = (lo + hi) >> 1;
+      if (spans[mid * ncap] > (int)a) hi = mid; else lo = mid + 1;
+    }
+    long long i = lo;
+    int q = (int)a;
+    if (i > 0) { const int pe = spans[(i - 1) * ncap + 1]; if (pe > q) q = pe; }      // inside the previous match: not part of a gap
+    while (i < n && q < b && !bad) {
+      const int s = spans[i * ncap], e = spans[i * ncap + 1], m = e - s;
+      const int stop = s < b ? s : b;
+      if (m > 0) {
+        const uint8_t c0 = raw[s];
+        for (; q < stop; ++q) {
+          if (raw[q] != c0 || q + m > len) continue;
+          int k = 1;
+          while (k < m && raw[q + k] == raw[s + k]) ++k;
+          if (k == m) { bad = true; break; }
+        }
       }
+      if (s >= b) break;
+      q = e > s ? e : s;
+      ++i;
     }
   }
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
@@ -1916,6 +1961,11 @@ hipError_t LaunchReaderCheck(const DevTables& T, const uint8_t* raw, const uint8
   const long long lanes = n + 1;
   hipLaunchKernelGGL(reader_check_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream, T, raw, view, len, spans,
                      (long long)n, ncap, flag);
+  if (n > 0 && len > 0) {
+    const long long pieces = ((long long)len + kIdxPiece - 1) / kIdxPiece;
+    hipLaunchKernelGGL(reader_index_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, stream, raw, len, spans, (long long)n,
+                       ncap, flag);
+  }
   return hipGetLastError();
 }
 

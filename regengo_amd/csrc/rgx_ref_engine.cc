@@ -1,0 +1,176 @@
+// Which capture engine would the reference emit for this program?  (rgx_info.ref_find_engine.)
+//
+// compiler.go:137-153: a pattern with captures and nested quantifiers first tries the Tagged DFA; it is taken when
+// (a) every empty-width instruction is ^ or $ of the text (tdfa.go:83-94) and (b) the subset construction over
+// priority-ordered NFA sets WITH their pending tag actions stays under 500 states (tdfa.go:111-290, threshold
+// tdfa.go:62-66).  Otherwise the memoising backtracker ("TNFA", compiler.go:415-426) is emitted.  The library never
+// runs the TDFA -- its FindAllBytes advances by the match length (compiler.go:646-651) and is refused, DESIGN.md Q11 --
+// but it has to KNOW which of the two the reference emits, because that decides which entry points are offered in
+// reference mode.  Only the state COUNT matters here, yet two NFA sets are the same DFA state only if their pending
+// actions agree as well (tdfa.go:514-539), so the construction below carries the actions exactly as the reference does:
+// compaction on pop (last action per tag, sorted by tag), offsets bumped per consumed byte, the longest common prefix of
+// the closure's action lists hoisted onto the edge.
+#include <algorithm>
+#include <map>
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "rgx_dfa.h"
+
+namespace rgx {
+namespace {
+
+using Action = std::pair<int, int>;            // (tag, offset)
+struct Thread { int id; std::vector<Action> acts; };
+
+void Compact(std::vector<Action>* a) {         // tdfa.go:421-441
+  if (a->empty()) return;
+  std::map<int, Action> last;
+  for (const Action& x : *a) last[x.first] = x;
+  a->clear();
+  for (const auto& kv : last) a->push_back(kv.second);
+}
+
+struct Probe {
+  const Prog& p;
+  explicit Probe(const Prog& prog) : p(prog) {}
+
+  std::vector<Thread> Closure(const std::vector<Thread>& from, uint32_t flags) const {   // tdfa.go:445-510
+    std::vector<char> seen(p.inst.size(), 0);
+    std::vector<Thread> out, stack(from.rbegin(), from.rend());
+    while (!stack.empty()) {
+      Thread t = std::move(stack.back());
+      stack.pop_back();
+      Compact(&t.acts);
+      if (t.id < 0 || t.id >= (int)p.inst.size() || seen[t.id]) continue;
+      seen[t.id] = 1;
+      const Inst& in = p.inst[t.id];
+      switch (in.op) {
+        case InstNop: stack.push_back({(int)in.out, t.acts}); break;
+        case InstCapture: {
+          std::vector<Action> na = t.acts;
+          na.push_back({(int)in.arg, 0});           // collectStartTags is true at every call site
+          stack.push_back({(int)in.out, std::move(na)});
+          break;
+        }
+        case InstAlt: case InstAltMatch:
+          if (in.op == InstAlt) { stack.push_back({(int)in.arg, t.acts}); stack.push_back({(int)in.out, t.acts}); }
+          break;
+        case InstEmptyWidth:
+          if ((in.arg & flags) == in.arg) stack.push_back({(int)in.out, t.acts});
+          break;
+        default: break;
+      }
+      out.push_back(std::move(t));
+    }
+    return out;
+  }
+
+  static std::string Key(const std::vector<Thread>& set) {      // tdfa.go:514-539
+    std::vector<const Thread*> s;
+    for (const Thread& t : set) s.push_back(&t);
+    std::sort(s.begin(), s.end(), [](const Thread* a, const Thread* b) { return a->id < b->id; });
+    std::string k;
+    for (const Thread* t : s) {
+      k += std::to_string(t->id);
+      if (!t->acts.empty()) {
+        k += '[';
+        for (const Action& a : t->acts) { k += std::to_string(a.first); k += ':'; k += std::to_string(a.second); k += ';'; }
+        k += ']';
+      }
+      k += ',';
+    }
+    return k;
+  }
+
+  bool Consumes(const Inst& in, int c) const {                   // tdfa.go:345-368 (ASCII bytes only)
+    switch (in.op) {
+      case InstRune1: return !in.rune.empty() && in.rune[0] < 128 && in.rune[0] == c;
+      case InstRune:
+        for (size_t i = 0; i + 1 < in.rune.size(); i += 2) if (c >= in.rune[i] && c <= in.rune[i + 1]) return true;
+        return false;
+      case InstRuneAny: return true;
+      case InstRuneAnyNotNL: return c != '\n';
+      default: return false;
+    }
+  }
+
+  void PossibleChars(const std::vector<Thread>& set, bool out[128]) const {   // tdfa.go:293-335
+    std::fill(out, out + 128, false);
+    for (const Thread& t : set) {
+      const Inst& in = p.inst[t.id];
+      switch (in.op) {
+        case InstRune1: if (!in.rune.empty() && in.rune[0] < 128) out[in.rune[0]] = true; break;
+        case InstRune:
+          for (size_t i = 0; i + 1 < in.rune.size(); i += 2)
+            if (in.rune[i] < 128) for (int c = in.rune[i]; c <= std::min<int>(in.rune[i + 1], 127); c++) out[c] = true;
+          break;
+        case InstRuneAny: std::fill(out, out + 128, true); break;
+        case InstRuneAnyNotNL: std::fill(out, out + 128, true); out['\n'] = false; break;
+        default: break;
+      }
+    }
+  }
+
+  std::vector<Thread> Step(const std::vector<Thread>& set, int c) const {     // tdfa.go:338-406
+    std::vector<Thread> next;
+    for (const Thread& t : set) {
+      const Inst& in = p.inst[t.id];
+      if (!Consumes(in, c)) continue;
+      Thread n{(int)in.out, t.acts};
+      for (Action& a : n.acts) a.second++;
+      next.push_back(std::move(n));
+    }
+    if (next.empty()) return next;
+    std::vector<Thread> res = Closure(next, 0);
+    if (res.empty()) return res;
+    size_t common = res[0].acts.size();
+    for (size_t i = 1; i < res.size() && common; i++) {
+      size_t k = 0;
+      while (k < common && k < res[i].acts.size() && res[0].acts[k] == res[i].acts[k]) k++;
+      common = k;
+    }
+    if (common) for (Thread& t : res) t.acts.erase(t.acts.begin(), t.acts.begin() + common);
+    return res;
+  }
+};
+
+}  // namespace
+
+int RefTdfaStates(const Prog& prog, int max_states) {
+  for (const Inst& in : prog.inst)
+    if (in.op == InstEmptyWidth && in.arg != EmptyBeginText && in.arg != EmptyEndText) return -1;
+  Probe pr(prog);
+  std::vector<std::vector<Thread>> states;
+  std::map<std::string, int> ids;
+  const std::vector<Thread> start{{prog.start, {}}};
+  states.push_back(pr.Closure(start, EmptyBeginText));
+  ids[Probe::Key(states[0])] = 0;
+  std::vector<int> work{0};
+  {
+    std::vector<Thread> any = pr.Closure(start, 0);
+    const std::string k = Probe::Key(any);
+    if (!ids.count(k)) { ids[k] = 1; states.push_back(std::move(any)); work.push_back(1); }
+  }
+  for (size_t w = 0; w < work.size(); w++) {      // every state enters the list once (tdfa.go:185-252)
+    const int si = work[w];
+    bool chars[128];
+    pr.PossibleChars(states[si], chars);
+    for (int c = 0; c < 128; c++) {
+      if (!chars[c]) continue;
+      std::vector<Thread> nn = pr.Step(states[si], c);
+      if (nn.empty()) continue;
+      const std::string k = Probe::Key(nn);
+      if (ids.count(k)) continue;
+      const int ni = (int)states.size();
+      if (ni >= max_states) return -1;              // "TDFA state explosion"
+      ids[k] = ni;
+      states.push_back(std::move(nn));
+      work.push_back(ni);
+    }
+  }
+  return (int)states.size() > max_states ? -1 : (int)states.size();
+}
+
+}  // namespace rgx

@@ -1,0 +1,702 @@
+// Multi-GPU behind the C ABI (include/rgx.h: rgx_sharded_*; SURVEY 8b "same calls on a program created over a device list; RCCL
+// communicator owned by the library", 8e).  What is sharded is the reference's sequential FindReader / FindAllBytes
+// (internal/compiler/streaming.go:85-255, find.go:130-466): the stream is cut into windows, a window's owned range goes to one
+// GPU together with a left halo (which must hold a sync point of the FindAll chain) and a right halo (MaxMatchLen bytes, or
+// the reference's own 1 MiB leftover cap for unbounded patterns), the scan kernels resolve the chain over the whole window
+// and report the matches that START in the owned range (rgx_find_all_bytes_device_owned).  One ROUND = one window per rank.
+//
+//   * one process, n devices (a Go program): rgx_sharded_create -- a program copy, two contexts and two host threads per
+//     device; the per-round exchange of counts is a host-side sum; rows are gathered to one device with grouped
+//     ncclSend / ncclRecv over a library-owned communicator (ncclCommInitAll), each source on its own xGMI link.
+//   * one process per device (bench.py under torch.distributed.run): rgx_sharded_create_rank with a 128-byte id made by
+//     rank 0 (rgx_sharded_unique_id) and carried by the launcher -- the count exchange is then ONE ncclAllGather of 32 bytes
+//     per rank and round, on its own stream, the gather the same grouped send/recv.
+//
+// RCCL is loaded with dlopen when a communicator is first needed (a one-GPU program never touches it).  Shards that share a
+// device (tests on a one-GPU box) and a process without RCCL take the communicator-less path: peer copies.
+//
+// Pipelining: two rounds may be in flight (rgx_sharded_round_submit x2, then _wait): each round has its own slot per shard --
+// context, stream, host thread, span buffer -- so the scan of round k+1 (every kernel, also the multi-pass ones: carry pass,
+// capture back-trace) runs while round k's counts are exchanged, its rows gathered and its callbacks run.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <algorithm>
+#include <condition_variable>
+#include <cstring>
+#include <functional>
+#include <mutex>
+#include <queue>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "rgx.h"
+#include "rgx_program.h"
+
+#define RGX_API extern "C" __attribute__((visibility("default")))
+
+using rgx::SetError;
+
+namespace {
+
+#define HIP_TRY(expr)                                                                         \
+  do {                                                                                        \
+    hipError_t _e = (expr);                                                                   \
+    if (_e != hipSuccess) {                                                                   \
+      SetError(std::string(#expr) + ": " + hipGetErrorString(_e));                            \
+      return RGX_E_HIP;                                                                       \
+    }                                                                                         \
+  } while (0)
+
+// ---- RCCL through dlopen ---------------------------------------------------------------------------------------------
+struct Rccl {
+  void* h = nullptr;
+  ncclResult_t (*GetUniqueId)(ncclUniqueId*) = nullptr;
+  ncclResult_t (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int) = nullptr;
+  ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+  ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+  ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+  ncclResult_t (*GroupStart)() = nullptr;
+  ncclResult_t (*GroupEnd)() = nullptr;
+  const char* (*GetErrorString)(ncclResult_t) = nullptr;
+  bool ok = false;
+};
+Rccl* LoadRccl() {
+  static Rccl r;
+  static std::once_flag once;
+  std::call_once(once, [] {
+    // a process that already holds a copy (PyTorch ships one under the same SONAME) gets that one
+    for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
+      r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+      if (r.h) break;
+    }
+    if (!r.h) return;
+#define SYM(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.h, sym)); if (!r.field) return;
+    SYM(GetUniqueId, "ncclGetUniqueId") SYM(CommInitRank, "ncclCommInitRank") SYM(CommInitAll, "ncclCommInitAll")
+    SYM(CommDestroy, "ncclCommDestroy") SYM(AllGather, "ncclAllGather") SYM(Send, "ncclSend") SYM(Recv, "ncclRecv")
+    SYM(GroupStart, "ncclGroupStart") SYM(GroupEnd, "ncclGroupEnd") SYM(GetErrorString, "ncclGetErrorString")
+#undef SYM
+    r.ok = true;
+  });
+  return r.ok ? &r : nullptr;
+}
+#define NCCL_TRY(R, expr)                                                                     \
+  do {                                                                                        \
+    ncclResult_t _r = (expr);                                                                 \
+    if (_r != ncclSuccess) {                                                                  \
+      SetError(std::string(#expr) + ": " + (R)->GetErrorString(_r));                         \
+      return RGX_E_HIP;                                                                       \
+    }                                                                                         \
+  } while (0)
+
+// ---- device helpers --------------------------------------------------------------------------------------------------
+// any reset byte in buf[0, n)?  (a byte on which every automaton state dies: the FindAll chain is known right behind it)
+__global__ __launch_bounds__(256) void halo_sync_kernel(const uint8_t* buf, long long n, const uint8_t* reset, unsigned* flag) {
+  __shared__ uint8_t tab[256];
+  tab[threadIdx.x] = reset[threadIdx.x];
+  __syncthreads();
+  bool any = false;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) any |= tab[buf[i]] != 0;
+  if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+// window-relative int32 rows -> stream-absolute int64 rows.  The slots of a group that took no part stay as they are: (0,0),
+// the reference's convention (find.go:215), or (-1,-1) under RGX_FLAG_UNMATCHED_MINUS1.
+__global__ __launch_bounds__(256) void rows_to_global_kernel(const int32_t* rows, long long nvals, int ncap, long long base, int minus1,
+                                                            long long* out) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nvals) return;
+  const int slot = (int)(i % ncap);
+  const int32_t v = rows[i];
+  bool unset = false;
+  if (slot >= 2) {
+    const int32_t a = rows[i - (slot & 1)], b = rows[i - (slot & 1) + 1];
+    unset = minus1 ? (a < 0 || b < 0) : (a == 0 && b == 0);
+  }
+  out[i] = unset ? (long long)v : (long long)v + base;
+}
+__global__ __launch_bounds__(256) void rows_rebase32_kernel(int32_t* rows, long long nvals, int ncap, int32_t base, int minus1) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const bool live = i < nvals;
+  const int slot = live ? (int)(i % ncap) : 0;
+  bool unset = false;
+  int32_t v = 0;
+  if (live) {
+    v = rows[i];
+    if (slot >= 2) {     // (a pair starts on an even index: ncap is even, so both of its lanes sit in this block)
+      const int32_t a = rows[i - (slot & 1)], b = rows[i - (slot & 1) + 1];
+      unset = minus1 ? (a < 0 || b < 0) : (a == 0 && b == 0);
+    }
+  }
+  __syncthreads();       // both lanes of a pair have read it before either writes
+  if (live && !unset) rows[i] = v + base;
+}
+
+// ---- one slot of one shard: context, stream, thread, buffers ------------------------------------------------------------
+struct Job {
+  rgx_shard_window w{};
+  int count_only = 0;
+  bool have = false;
+};
+struct SlotResult {
+  int64_t count = 0;
+  int rc = RGX_OK;
+  std::string err;
+  int unsynced = 0, truncated = 0;
+  const int32_t* d_rows = nullptr;
+  int64_t base = 0;
+  float kernel_ms = 0;
+  bool have = false;
+};
+struct Shard;
+struct Slot {
+  Shard* shard = nullptr;
+  rgx_stream_ctx* ctx = nullptr;
+  std::thread th;
+  std::mutex mu;
+  std::condition_variable cv;
+  bool has_job = false, done = true, quit = false;
+  Job job;
+  SlotResult res;
+  uint8_t* d_in = nullptr; size_t in_cap = 0;
+  int32_t* d_spans = nullptr; size_t spans_cap = 0;      // records
+  unsigned* d_flag = nullptr;
+};
+struct Shard {
+  int device = 0, rank = 0;
+  rgx_program* prog = nullptr;
+  rgx_info info{};
+  uint8_t* d_reset = nullptr;
+  bool has_reset = false;
+  int minus1 = 0;
+  Slot slot[2];
+  // collectives
+  ncclComm_t comm = nullptr;
+  hipStream_t cstream = nullptr;
+  long long* d_x = nullptr;        // [4] mine + [4 * world] all
+  long long* h_x = nullptr;        // pinned mirror
+  long long* d_glob = nullptr; size_t glob_cap = 0;     // int64 rows (own rows converted / the gathered table on the destination)
+};
+
+int GrowBytes(uint8_t** p, size_t* cap, size_t need) {
+  if (*cap >= need && *p) return RGX_OK;
+  if (*p) (void)hipFree(*p);
+  *p = nullptr; *cap = 0;
+  const size_t want = need + need / 8 + 256;
+  if (hipMalloc((void**)p, want) != hipSuccess) { (void)hipGetLastError(); SetError("out of device memory (sharded staging)"); return RGX_E_NOMEM; }
+  *cap = want;
+  return RGX_OK;
+}
+
+int RunJob(Slot& s) {
+  Shard& sh = *s.shard;
+  const Job& j = s.job;
+  SlotResult& r = s.res;
+  r = SlotResult();
+  r.have = j.have;
+  if (!j.have) return RGX_OK;
+  HIP_TRY(hipSetDevice(sh.device));
+  hipStream_t st = (hipStream_t)rgx_stream_ctx_hip_stream(s.ctx);
+  const rgx_shard_window& w = j.w;
+  if (w.own_lo < 0 || w.own_hi < w.own_lo || (size_t)w.own_hi > w.len) { SetError("bad owned range"); return RGX_E_INVALID; }
+  const uint8_t* d_buf = w.buf;
+  int rc;
+  if (w.is_host) {
+    size_t cap = s.in_cap;
+    if ((rc = GrowBytes(&s.d_in, &cap, w.len + 64)) != RGX_OK) return rc;
+    s.in_cap = cap;
+    HIP_TRY(hipMemcpyAsync(s.d_in, w.buf, w.len, hipMemcpyHostToDevice, st));
+    d_buf = s.d_in;
+  }
+  // the left halo has to hold a sync point, unless the window begins where the FindAll chain is known anyway
+  if (!w.starts_at_sync) {
+    if (w.own_lo <= 0 || !sh.has_reset) r.unsynced = 1;
+    else {
+      HIP_TRY(hipMemsetAsync(s.d_flag, 0, 4, st));
+      const long long n = w.own_lo;
+      const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, 1024);
+      hipLaunchKernelGGL(halo_sync_kernel, dim3(grid), dim3(256), 0, st, d_buf, n, sh.d_reset, s.d_flag);
+      unsigned f = 0;
+      HIP_TRY(hipMemcpyAsync(&f, s.d_flag, 4, hipMemcpyDeviceToHost, st));
+      HIP_TRY(hipStreamSynchronize(st));
+      r.unsynced = f ? 0 : 1;
+    }
+    if (r.unsynced) return RGX_OK;          // nothing of this window can be vouched for: the caller widens the halo
+  }
+  rgx_result res{};
+  if (j.count_only) {
+    const int64_t c = rgx_count_all_device_owned(sh.prog, s.ctx, d_buf, w.len, w.own_lo, w.own_hi, &res);
+    if (c < 0) return (int)c;
+    r.count = c;
+    r.kernel_ms = res.kernel_ms;
+    return RGX_OK;
+  }
+  int32_t* d_spans = w.d_spans;
+  size_t cap_records = w.cap_records;
+  const int ncap = sh.info.ncap;
+  for (int attempt = 0;; ++attempt) {
+    if (!w.d_spans) {
+      const size_t owned = (size_t)(w.own_hi - w.own_lo);
+      size_t want = attempt ? cap_records : owned / (size_t)std::max(sh.info.min_match_len, 8) + 1024;    // grows to the exact count on RGX_E_CAPACITY
+      want = std::min(want, owned / (size_t)std::max(sh.info.min_match_len, 1) + 16);
+      if (s.spans_cap < want || !s.d_spans) {
+        if (s.d_spans) (void)hipFree(s.d_spans);
+        s.d_spans = nullptr; s.spans_cap = 0;
+        if (hipMalloc((void**)&s.d_spans, (want + 16) * (size_t)ncap * 4) != hipSuccess) { (void)hipGetLastError(); SetError("out of device memory (span table)"); return RGX_E_NOMEM; }
+        s.spans_cap = want;
+      }
+      d_spans = s.d_spans; cap_records = s.spans_cap;
+    }
+    const int64_t c = rgx_find_all_bytes_device_owned(sh.prog, s.ctx, d_buf, w.len, -1, d_spans, cap_records, w.own_lo, w.own_hi, &res);
+    if (c == RGX_E_CAPACITY && !w.d_spans && attempt == 0) { cap_records = (size_t)res.total + 16; continue; }
+    if (c < 0) return (int)c;
+    r.count = c;
+    break;
+  }
+  r.d_rows = d_spans;
+  r.base = w.base;
+  r.kernel_ms = res.kernel_ms;
+  if (sh.info.max_match_len < 0 && !w.last && r.count > 0) {
+    int32_t e = 0;
+    HIP_TRY(hipMemcpyAsync(&e, d_spans + (size_t)(r.count - 1) * ncap + 1, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    r.truncated = (size_t)e >= w.len;
+  }
+  return RGX_OK;
+}
+
+void SlotMain(Slot* s) {
+  std::unique_lock<std::mutex> lk(s->mu);
+  for (;;) {
+    s->cv.wait(lk, [&] { return s->has_job || s->quit; });
+    if (s->quit) return;
+    s->has_job = false;
+    lk.unlock();
+    const int rc = RunJob(*s);
+    lk.lock();
+    s->res.rc = rc;
+    if (rc < 0) s->res.err = rgx::GetError();
+    s->done = true;
+    s->cv.notify_all();
+  }
+}
+
+}  // namespace
+
+struct rgx_sharded {
+  std::vector<Shard*> local;
+  int world = 1, first_rank = 0;
+  bool rank_mode = false, use_rccl = false;
+  int head = 0, inflight = 0;                       // rounds: slot = round index & 1
+  int pend_slot[2] = {0, 0};
+  // the last waited round, for rows / gather
+  int last_slot = -1;
+  std::vector<rgx_shard_round> last;                // [world]
+  std::vector<int64_t> last_base;                   // [world] (rank mode: exchanged)
+};
+
+namespace {
+
+void DestroyShard(Shard* sh) {
+  if (!sh) return;
+  (void)hipSetDevice(sh->device);
+  for (Slot& s : sh->slot) {
+    if (s.th.joinable()) {
+      { std::lock_guard<std::mutex> g(s.mu); s.quit = true; }
+      s.cv.notify_all();
+      s.th.join();
+    }
+    if (s.ctx) rgx_stream_ctx_destroy(s.ctx);
+    if (s.d_in) (void)hipFree(s.d_in);
+    if (s.d_spans) (void)hipFree(s.d_spans);
+    if (s.d_flag) (void)hipFree(s.d_flag);
+  }
+  if (sh->comm) { Rccl* R = LoadRccl(); if (R) (void)R->CommDestroy(sh->comm); }
+  if (sh->cstream) (void)hipStreamDestroy(sh->cstream);
+  if (sh->d_x) (void)hipFree(sh->d_x);
+  if (sh->h_x) (void)hipHostFree(sh->h_x);
+  if (sh->d_glob) (void)hipFree(sh->d_glob);
+  if (sh->d_reset) (void)hipFree(sh->d_reset);
+  if (sh->prog) rgx_program_destroy(sh->prog);
+  delete sh;
+}
+
+int MakeShard(const void* blob, size_t blob_len, int device, int rank, int world, Shard** out) {
+  Shard* sh = new Shard();
+  sh->device = device; sh->rank = rank;
+  int rc = rgx_program_from_blob(blob, blob_len, &sh->prog);
+  if (rc == RGX_OK) rc = rgx_program_to_device(sh->prog, device);
+  if (rc == RGX_OK) rc = rgx_program_info(sh->prog, &sh->info);
+  if (rc != RGX_OK) { DestroyShard(sh); return rc; }
+  uint8_t reset[256];
+  rgx_program_reset_bytes(sh->prog, reset);
+  bool any = false;
+  for (int i = 0; i < 256; i++) any |= reset[i] != 0;
+  sh->has_reset = any;                     // without a reset byte no halo can be vouched for
+  sh->minus1 = (sh->info.flags & RGX_FLAG_UNMATCHED_MINUS1) ? 1 : 0;
+  if (hipSetDevice(device) != hipSuccess || hipMalloc((void**)&sh->d_reset, 256) != hipSuccess ||
+      hipMemcpy(sh->d_reset, reset, 256, hipMemcpyHostToDevice) != hipSuccess ||
+      hipStreamCreateWithFlags(&sh->cstream, hipStreamNonBlocking) != hipSuccess ||
+      hipMalloc((void**)&sh->d_x, (size_t)(4 + 4 * world) * 8) != hipSuccess ||
+      hipHostMalloc((void**)&sh->h_x, (size_t)(4 + 4 * world) * 8) != hipSuccess) {
+    (void)hipGetLastError();
+    SetError("device setup of a shard failed");
+    DestroyShard(sh);
+    return RGX_E_HIP;
+  }
+  for (Slot& s : sh->slot) {
+    s.shard = sh;
+    if ((rc = rgx_stream_ctx_create(sh->prog, &s.ctx)) != RGX_OK) { DestroyShard(sh); return rc; }
+    if (hipMalloc((void**)&s.d_flag, 16) != hipSuccess) { DestroyShard(sh); SetError("hipMalloc"); return RGX_E_NOMEM; }
+    s.th = std::thread(SlotMain, &s);
+  }
+  *out = sh;
+  return RGX_OK;
+}
+
+void Post(Slot& s, const Job& j) {
+  std::lock_guard<std::mutex> g(s.mu);
+  s.job = j; s.has_job = true; s.done = false;
+  s.cv.notify_all();
+}
+void Join(Slot& s) {
+  std::unique_lock<std::mutex> lk(s.mu);
+  s.cv.wait(lk, [&] { return s.done; });
+}
+
+}  // namespace
+
+// ---- planning (pure arithmetic; tests run it without a GPU) ----------------------------------------------------------------
+RGX_API int rgx_shard_plan(int64_t total_len, int parts, int32_t max_match_len, int64_t halo_left, int64_t unbounded_halo,
+                           rgx_shard_range* out) {
+  if (total_len < 0 || parts < 1 || halo_left < 0 || !out) return RGX_E_INVALID;
+  if (unbounded_halo <= 0) unbounded_halo = 1 << 20;
+  int64_t per = (total_len + parts - 1) / parts;
+  per = (per + 15) / 16 * 16;
+  // an owned match may start at hi-1 and be max_match_len long, and the byte AFTER it must be in the window as well (trailing
+  // \b, $ look at it): max_match_len bytes of right halo, never 0
+  const int64_t halo_r = max_match_len >= 0 ? std::max<int64_t>(max_match_len, 1) : unbounded_halo;
+  for (int r = 0; r < parts; r++) {
+    const int64_t lo = std::min<int64_t>((int64_t)r * per, total_len), hi = std::min<int64_t>((int64_t)(r + 1) * per, total_len);
+    int64_t wl = std::max<int64_t>(0, lo - halo_left);
+    wl -= wl % 16;
+    out[r] = {lo, hi, wl, std::min<int64_t>(total_len, hi + halo_r)};
+  }
+  return RGX_OK;
+}
+
+// ---- creation ----------------------------------------------------------------------------------------------------------------
+RGX_API int rgx_sharded_unique_id(void* id, size_t cap) {
+  if (!id || cap < sizeof(ncclUniqueId)) return RGX_E_INVALID;
+  Rccl* R = LoadRccl();
+  if (!R) { SetError("librccl.so.1 cannot be loaded"); return RGX_E_UNSUPPORTED; }
+  ncclUniqueId u;
+  NCCL_TRY(R, R->GetUniqueId(&u));
+  memcpy(id, &u, sizeof u);
+  return (int)sizeof u;
+}
+
+RGX_API int rgx_sharded_create(const void* blob, size_t blob_len, const int* devices, int n_devices, rgx_sharded** out) {
+  if (!blob || !devices || n_devices < 1 || n_devices > 64 || !out) return RGX_E_INVALID;
+  rgx_sharded* s = new rgx_sharded();
+  s->world = n_devices;
+  for (int i = 0; i < n_devices; i++) {
+    Shard* sh = nullptr;
+    const int rc = MakeShard(blob, blob_len, devices[i], i, n_devices, &sh);
+    if (rc != RGX_OK) { rgx_sharded_destroy(s); return rc; }
+    s->local.push_back(sh);
+  }
+  // a communicator needs distinct devices; RGX_SHARDED_NO_RCCL=1 keeps the peer-copy path (and a world of one needs neither)
+  std::vector<int> devs(devices, devices + n_devices);
+  std::sort(devs.begin(), devs.end());
+  const bool distinct = std::adjacent_find(devs.begin(), devs.end()) == devs.end();
+  const char* no = getenv("RGX_SHARDED_NO_RCCL");
+  if (n_devices > 1 && distinct && !(no && *no == '1')) {
+    Rccl* R = LoadRccl();
+    if (R) {
+      std::vector<ncclComm_t> comms(n_devices);
+      if (R->CommInitAll(comms.data(), n_devices, devices) == ncclSuccess) {
+        for (int i = 0; i < n_devices; i++) s->local[i]->comm = comms[i];
+        s->use_rccl = true;
+      }
+    }
+  }
+  *out = s;
+  return RGX_OK;
+}
+
+RGX_API int rgx_sharded_create_rank(const void* blob, size_t blob_len, int device, int rank, int world, const void* id, size_t id_len,
+                                    rgx_sharded** out) {
+  if (!blob || rank < 0 || world < 1 || rank >= world || !out) return RGX_E_INVALID;
+  if (world > 1 && (!id || id_len < sizeof(ncclUniqueId))) { SetError("a world of several ranks needs the id of rgx_sharded_unique_id"); return RGX_E_INVALID; }
+  rgx_sharded* s = new rgx_sharded();
+  s->world = world; s->first_rank = rank; s->rank_mode = true;
+  Shard* sh = nullptr;
+  int rc = MakeShard(blob, blob_len, device, rank, world, &sh);
+  if (rc != RGX_OK) { delete s; return rc; }
+  s->local.push_back(sh);
+  const char* force = getenv("RGX_SHARDED_FORCE_RCCL");          // a world of one with a real communicator (plumbing test on one GPU)
+  if (world > 1 || (force && *force == '1' && id && id_len >= sizeof(ncclUniqueId))) {
+    Rccl* R = LoadRccl();
+    if (!R) { rgx_sharded_destroy(s); SetError("librccl.so.1 cannot be loaded"); return RGX_E_UNSUPPORTED; }
+    ncclUniqueId u;
+    memcpy(&u, id, sizeof u);
+    if (hipSetDevice(device) != hipSuccess) { rgx_sharded_destroy(s); return RGX_E_HIP; }
+    const ncclResult_t nr = R->CommInitRank(&sh->comm, world, u, rank);
+    if (nr != ncclSuccess) { SetError(std::string("ncclCommInitRank: ") + R->GetErrorString(nr)); rgx_sharded_destroy(s); return RGX_E_HIP; }
+    s->use_rccl = true;
+  }
+  *out = s;
+  return RGX_OK;
+}
+
+RGX_API void rgx_sharded_destroy(rgx_sharded* s) {
+  if (!s) return;
+  for (Shard* sh : s->local) DestroyShard(sh);
+  delete s;
+}
+
+RGX_API int rgx_sharded_shape(const rgx_sharded* s, rgx_sharded_info* out) {
+  if (!s || !out) return RGX_E_INVALID;
+  out->n_local = (int32_t)s->local.size(); out->world = s->world; out->first_rank = s->first_rank; out->uses_rccl = s->use_rccl ? 1 : 0;
+  return RGX_OK;
+}
+RGX_API const rgx_program* rgx_sharded_program(const rgx_sharded* s, int local_index) {
+  return (s && local_index >= 0 && local_index < (int)s->local.size()) ? s->local[local_index]->prog : nullptr;
+}
+RGX_API void* rgx_sharded_hip_stream(const rgx_sharded* s, int local_index, int slot) {
+  if (!s || local_index < 0 || local_index >= (int)s->local.size() || slot < 0 || slot > 1) return nullptr;
+  return rgx_stream_ctx_hip_stream(s->local[local_index]->slot[slot].ctx);
+}
+RGX_API int rgx_sharded_set_timing(rgx_sharded* s, int on) {
+  if (!s) return RGX_E_INVALID;
+  for (Shard* sh : s->local) for (Slot& sl : sh->slot) rgx_stream_ctx_set_timing(sl.ctx, on);
+  return RGX_OK;
+}
+
+// ---- rounds ----------------------------------------------------------------------------------------------------------------
+RGX_API int rgx_sharded_round_submit(rgx_sharded* s, const rgx_shard_window* windows, int count_only) {
+  if (!s || !windows) return RGX_E_INVALID;
+  if (s->inflight >= 2) { SetError("two rounds already in flight: call rgx_sharded_round_wait"); return RGX_E_INVALID; }
+  const int slot = (s->head + s->inflight) & 1;
+  for (size_t i = 0; i < s->local.size(); i++) {
+    Job j;
+    j.w = windows[i]; j.count_only = count_only; j.have = windows[i].len > 0 && windows[i].buf != nullptr;
+    Post(s->local[i]->slot[slot], j);
+  }
+  s->inflight++;
+  return slot;
+}
+
+RGX_API int64_t rgx_sharded_round_wait(rgx_sharded* s, int stop_request, rgx_shard_round* out) {
+  if (!s) return RGX_E_INVALID;
+  if (!s->inflight) { SetError("no round in flight"); return RGX_E_INVALID; }
+  const int slot = s->head & 1;
+  s->head++; s->inflight--;
+  const int world = s->world;
+  s->last.assign((size_t)world, rgx_shard_round{});
+  s->last_base.assign((size_t)world, 0);
+  s->last_slot = slot;
+  int rc = RGX_OK;
+  for (Shard* sh : s->local) Join(sh->slot[slot]);
+  for (Shard* sh : s->local) {
+    const SlotResult& r = sh->slot[slot].res;
+    if (r.rc < 0 && rc == RGX_OK) { rc = r.rc; SetError(r.err); }
+    rgx_shard_round& o = s->last[(size_t)sh->rank];
+    o.count = r.unsynced ? 0 : r.count; o.have = r.have ? 1 : 0; o.unsynced = r.unsynced; o.truncated = r.truncated;
+    o.stop = stop_request ? 1 : 0; o.kernel_ms = r.kernel_ms; o.status = r.rc;
+    s->last_base[(size_t)sh->rank] = r.base;
+  }
+  if (s->rank_mode && s->use_rccl) {
+    // one all-gather of [count, flags, base, status] per rank; a failed rank still takes part, so that nobody hangs
+    Rccl* R = LoadRccl();
+    Shard* sh = s->local[0];
+    const rgx_shard_round& m = s->last[(size_t)sh->rank];
+    HIP_TRY(hipSetDevice(sh->device));
+    sh->h_x[0] = m.count;
+    sh->h_x[1] = (m.have ? 1 : 0) | (m.unsynced ? 2 : 0) | (m.stop ? 4 : 0) | (m.truncated ? 8 : 0);
+    sh->h_x[2] = s->last_base[(size_t)sh->rank];
+    sh->h_x[3] = rc;
+    HIP_TRY(hipMemcpyAsync(sh->d_x, sh->h_x, 32, hipMemcpyHostToDevice, sh->cstream));
+    NCCL_TRY(R, R->AllGather(sh->d_x, sh->d_x + 4, 4, ncclInt64, sh->comm, sh->cstream));
+    HIP_TRY(hipMemcpyAsync(sh->h_x + 4, sh->d_x + 4, (size_t)world * 32, hipMemcpyDeviceToHost, sh->cstream));
+    HIP_TRY(hipStreamSynchronize(sh->cstream));
+    for (int r = 0; r < world; r++) {
+      const long long* x = sh->h_x + 4 + 4 * r;
+      rgx_shard_round& o = s->last[(size_t)r];
+      const float ms = r == sh->rank ? o.kernel_ms : 0.f;
+      o = rgx_shard_round{};
+      o.count = x[0]; o.have = (x[1] & 1) != 0; o.unsynced = (x[1] & 2) != 0; o.stop = (x[1] & 4) != 0; o.truncated = (x[1] & 8) != 0;
+      o.kernel_ms = ms; o.status = (int32_t)x[3];
+      s->last_base[(size_t)r] = x[2];
+      if (x[3] < 0 && rc == RGX_OK) { rc = (int)x[3]; SetError("a peer rank failed its scan (status " + std::to_string(x[3]) + ")"); }
+    }
+  }
+  if (out) memcpy(out, s->last.data(), (size_t)world * sizeof(rgx_shard_round));
+  if (rc < 0) return rc;
+  int64_t total = 0;
+  for (const rgx_shard_round& o : s->last) total += o.count;
+  return total;
+}
+
+RGX_API int64_t rgx_sharded_round(rgx_sharded* s, const rgx_shard_window* windows, int count_only, int stop_request, rgx_shard_round* out) {
+  const int rc = rgx_sharded_round_submit(s, windows, count_only);
+  if (rc < 0) return rc;
+  return rgx_sharded_round_wait(s, stop_request, out);
+}
+
+// ---- rows of the last waited round ------------------------------------------------------------------------------------------------
+RGX_API int64_t rgx_sharded_rows(const rgx_sharded* s, int local_index, const int32_t** d_rows, int64_t* base) {
+  if (!s || s->last_slot < 0 || local_index < 0 || local_index >= (int)s->local.size()) return RGX_E_INVALID;
+  const SlotResult& r = s->local[local_index]->slot[s->last_slot].res;
+  if (d_rows) *d_rows = r.d_rows;
+  if (base) *base = r.base;
+  return r.unsynced ? 0 : r.count;
+}
+
+namespace {
+int EnsureGlob(Shard* sh, size_t vals) {
+  if (sh->glob_cap >= vals && sh->d_glob) return RGX_OK;
+  if (sh->d_glob) (void)hipFree(sh->d_glob);
+  sh->d_glob = nullptr; sh->glob_cap = 0;
+  const size_t want = vals + vals / 8 + 64;
+  if (hipMalloc((void**)&sh->d_glob, want * 8) != hipSuccess) { (void)hipGetLastError(); SetError("out of device memory (gathered rows)"); return RGX_E_NOMEM; }
+  sh->glob_cap = want;
+  return RGX_OK;
+}
+}  // namespace
+
+// Every rank's rows of the last round, stream-absolute int64, in rank order (= stream order when windows are dealt to the ranks
+// in order), on rank dst_rank's device: in d_dst (caller's device memory, cap_records records) or, when that is NULL, in a
+// library buffer; h_dst != NULL also copies them to the host.  Returns the number of rows there (0 on the other ranks of a
+// multi-process job).
+RGX_API int64_t rgx_sharded_gather(rgx_sharded* s, int dst_rank, int64_t* d_dst, int64_t* h_dst, size_t cap_records, const int64_t** d_rows) {
+  if (!s || s->last_slot < 0 || dst_rank < 0 || dst_rank >= s->world) return RGX_E_INVALID;
+  const int world = s->world, slot = s->last_slot;
+  std::vector<int64_t> off((size_t)world + 1, 0);
+  for (int r = 0; r < world; r++) off[(size_t)r + 1] = off[(size_t)r] + s->last[(size_t)r].count;
+  const int64_t total = off[(size_t)world];
+  Shard* dst = nullptr;
+  for (Shard* sh : s->local) if (sh->rank == dst_rank) dst = sh;
+  const int ncap = s->local[0]->info.ncap;
+  if (dst && (d_dst || h_dst) && (size_t)total > cap_records) { SetError("gather: capacity too small"); return RGX_E_CAPACITY; }
+  Rccl* R = s->use_rccl ? LoadRccl() : nullptr;
+  long long* table = nullptr;
+  // 1. every local shard turns its rows into stream-absolute int64 -- the destination straight into its slice of the table
+  for (Shard* sh : s->local) {
+    const SlotResult& r = sh->slot[slot].res;
+    const int64_t cnt = s->last[(size_t)sh->rank].count;
+    HIP_TRY(hipSetDevice(sh->device));
+    long long* to;
+    if (sh == dst && d_dst) {
+      table = (long long*)d_dst;
+      to = table + off[(size_t)sh->rank] * ncap;
+    } else {
+      int rc = EnsureGlob(sh, (size_t)((sh == dst ? total : cnt) * ncap));
+      if (rc != RGX_OK) return rc;
+      if (sh == dst) table = sh->d_glob;
+      to = sh->d_glob + (sh == dst ? off[(size_t)sh->rank] * ncap : 0);
+    }
+    if (cnt > 0) {
+      const long long nvals = cnt * ncap;
+      hipLaunchKernelGGL(rows_to_global_kernel, dim3((unsigned)((nvals + 255) / 256)), dim3(256), 0, sh->cstream, r.d_rows, nvals, ncap,
+                         (long long)r.base, sh->minus1, to);
+    }
+  }
+  // 2. movement: grouped send / recv over the communicator, or peer copies
+  if (R) {
+    NCCL_TRY(R, R->GroupStart());
+    for (Shard* sh : s->local) {
+      if (sh == dst) {
+        for (int r = 0; r < world; r++)
+          if (r != dst_rank && s->last[(size_t)r].count > 0)
+            NCCL_TRY(R, R->Recv(table + off[(size_t)r] * ncap, (size_t)(s->last[(size_t)r].count * ncap), ncclInt64, r, sh->comm, sh->cstream));
+      } else if (s->last[(size_t)sh->rank].count > 0) {
+        NCCL_TRY(R, R->Send(sh->d_glob, (size_t)(s->last[(size_t)sh->rank].count * ncap), ncclInt64, dst_rank, sh->comm, sh->cstream));
+      }
+    }
+    NCCL_TRY(R, R->GroupEnd());
+  } else if (dst) {
+    for (Shard* sh : s->local) {
+      if (sh == dst || s->last[(size_t)sh->rank].count == 0) continue;
+      HIP_TRY(hipSetDevice(sh->device));
+      HIP_TRY(hipStreamSynchronize(sh->cstream));
+      HIP_TRY(hipSetDevice(dst->device));
+      const size_t bytes = (size_t)(s->last[(size_t)sh->rank].count * ncap) * 8;
+      if (sh->device == dst->device) HIP_TRY(hipMemcpyAsync(table + off[(size_t)sh->rank] * ncap, sh->d_glob, bytes, hipMemcpyDeviceToDevice, dst->cstream));
+      else HIP_TRY(hipMemcpyPeerAsync(table + off[(size_t)sh->rank] * ncap, dst->device, sh->d_glob, sh->device, bytes, dst->cstream));
+    }
+  } else if (world > 1) {
+    SetError("gather across processes needs the RCCL communicator");
+    return RGX_E_UNSUPPORTED;
+  }
+  if (dst && h_dst && total > 0) {
+    HIP_TRY(hipSetDevice(dst->device));
+    HIP_TRY(hipMemcpyAsync(h_dst, table, (size_t)(total * ncap) * 8, hipMemcpyDeviceToHost, dst->cstream));
+  }
+  for (Shard* sh : s->local) { HIP_TRY(hipSetDevice(sh->device)); HIP_TRY(hipStreamSynchronize(sh->cstream)); }
+  if (d_rows) *d_rows = dst ? (const int64_t*)table : nullptr;
+  return dst ? total : 0;
+}
+
+// ---- FindAllBytes of one host buffer over the local devices ------------------------------------------------------------------------
+RGX_API int64_t rgx_sharded_find_all_bytes(rgx_sharded* s, const uint8_t* buf, size_t len, int64_t n, int32_t* spans, size_t cap_records,
+                                           rgx_result* res) {
+  if (!s || (!buf && len) || (!spans && cap_records)) return RGX_E_INVALID;
+  if (s->rank_mode) { SetError("one process per device: the caller cuts the input itself (rgx_shard_plan + rgx_sharded_round)"); return RGX_E_UNSUPPORTED; }
+  if (s->inflight) { SetError("rounds in flight"); return RGX_E_INVALID; }
+  const int parts = (int)s->local.size();
+  const rgx_info& info = s->local[0]->info;
+  const int ncap = info.ncap;
+  if (res) { memset(res, 0, sizeof *res); res->ncap = ncap; }
+  if (n == 0 || len == 0) return 0;
+  if (len > 0x7FFFFF00ull) { SetError("buffer larger than 2^31-256 bytes: int32 offsets; use the FindReader path"); return RGX_E_TOO_LARGE; }
+  std::vector<rgx_shard_range> plan((size_t)parts);
+  std::vector<rgx_shard_window> win((size_t)parts);
+  std::vector<rgx_shard_round> rnd((size_t)parts);
+  int64_t halo = 4096;
+  for (;;) {
+    rgx_shard_plan((int64_t)len, parts, info.max_match_len, halo, 0, plan.data());
+    for (int i = 0; i < parts; i++) {
+      const rgx_shard_range& p = plan[(size_t)i];
+      rgx_shard_window& w = win[(size_t)i];
+      w = rgx_shard_window{};
+      if (p.hi <= p.lo) continue;                       // more devices than 16-byte pieces
+      w.buf = buf + p.win_lo; w.len = (size_t)(p.win_hi - p.win_lo); w.own_lo = p.lo - p.win_lo; w.own_hi = p.hi - p.win_lo;
+      w.base = p.win_lo; w.is_host = 1; w.starts_at_sync = p.win_lo == 0; w.last = p.win_hi >= (int64_t)len;
+    }
+    const int64_t total = rgx_sharded_round(s, win.data(), 0, 0, rnd.data());
+    if (total < 0) return total;
+    bool unsynced = false;
+    for (const rgx_shard_round& r : rnd) unsynced |= r.unsynced != 0;
+    if (!unsynced) break;
+    if (halo >= (int64_t)len) { SetError("no sync point"); return RGX_E_HIP; }      // (cannot happen: win_lo == 0 starts at a sync point)
+    halo = std::min<int64_t>(halo * 16, (int64_t)len);            // a left halo without a reset byte: widen it (to the whole prefix at worst)
+  }
+  int64_t total = 0;
+  for (const rgx_shard_round& r : rnd) total += r.count;
+  if (res) res->total = total;
+  int64_t want = total;
+  if (n > 0) want = std::min(want, n);
+  if (want > (int64_t)cap_records) { SetError("span capacity too small"); return RGX_E_CAPACITY; }
+  int64_t row = 0;
+  for (int i = 0; i < parts && row < want; i++) {
+    Shard* sh = s->local[(size_t)i];
+    const SlotResult& r = sh->slot[s->last_slot].res;
+    const int64_t take = std::min<int64_t>(rnd[(size_t)i].count, want - row);
+    if (take <= 0) continue;
+    HIP_TRY(hipSetDevice(sh->device));
+    const long long nvals = take * ncap;
+    if (r.base)
+      hipLaunchKernelGGL(rows_rebase32_kernel, dim3((unsigned)((nvals + 255) / 256)), dim3(256), 0, sh->cstream, (int32_t*)r.d_rows, nvals, ncap,
+                         (int32_t)r.base, sh->minus1);
+    HIP_TRY(hipMemcpyAsync(spans + row * ncap, r.d_rows, (size_t)nvals * 4, hipMemcpyDeviceToHost, sh->cstream));
+    row += take;
+  }
+  for (Shard* sh : s->local) { HIP_TRY(hipSetDevice(sh->device)); HIP_TRY(hipStreamSynchronize(sh->cstream)); }
+  if (res) res->written = row;
+  return row;
+}

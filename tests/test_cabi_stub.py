@@ -1,0 +1,172 @@
+"""tests/cabi_stub.c is the C twin of the emitted cgo file (tests/golden/codegen/*_gpu.go): same call sequence, compiled with
+`gcc -std=c99 -Wall -Wextra -Werror -pedantic` against include/rgx.h and linked to librgx_hip.so -- the stand-in for `go build` in
+an image without a Go toolchain.  CPU tier: it compiles, links, loads a blob and takes the no-device path (INIT -5: the Go path
+stays).  GPU tier: the protocol against the oracle and the reference's literal streaming vectors."""
+import json
+import os
+import subprocess
+
+import pytest
+
+from regengo_amd import codegen
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BUILD = os.path.join(ROOT, "tests", "_build")
+DATE = r"(?P<year>\d{4})-(?P<month>\d{2})-(?P<day>\d{2})"
+URL_CAPTURE = r"(?P<protocol>https?)://(?P<host>[\w\.-]+)(?::(?P<port>\d+))?(?P<path>/[\w\./]*)?"
+
+
+@pytest.fixture(scope="module")
+def stub(built):
+    os.makedirs(BUILD, exist_ok=True)
+    exe = os.path.join(BUILD, "cabi_stub")
+    libdir = os.path.join(ROOT, "regengo_amd", "lib")
+    cmd = ["gcc", "-std=c99", "-Wall", "-Wextra", "-Werror", "-pedantic", "-I" + os.path.join(ROOT, "include"),
+           os.path.join(ROOT, "tests", "cabi_stub.c"), "-L" + libdir, "-lrgx_hip", "-Wl,-rpath," + libdir, "-Wl,-rpath,/opt/rocm/lib",
+           "-o", exe]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return exe
+
+
+def _tables(tmp_path, pattern, name="P", flags=0):
+    text, blob = codegen.emit_go(pattern, name, "p", flags=flags)
+    path = os.path.join(str(tmp_path), name + "_tables.bin")
+    open(path, "wb").write(blob)
+    return path, text
+
+
+def _run(exe, blob, data: bytes, tmp_path, *args, env=None):
+    inp = os.path.join(str(tmp_path), "input.bin")
+    open(inp, "wb").write(data)
+    e = dict(os.environ)
+    e.update(env or {})
+    r = subprocess.run([exe, blob, inp] + [str(a) for a in args], capture_output=True, timeout=600, env=e)
+    return r.returncode, r.stdout
+
+
+def test_twin_compiles_as_c99_and_uses_what_the_go_file_uses(stub, tmp_path):
+    """Every rgx_* function the emitted Go calls is called by the twin too (so a signature change breaks a COMPILE here)."""
+    import re
+    _, go = _tables(tmp_path, DATE, "Date")
+    go_syms = set(re.findall(r"C\.(rgx_[a-z_0-9]+)\(", go))
+    c_syms = set(re.findall(r"\b(rgx_[a-z_0-9]+)\(", open(os.path.join(ROOT, "tests", "cabi_stub.c")).read()))
+    # rgx_transform_* belong to stream.Transformer's processor, which has no C twin (the Transformer is Go's)
+    missing = {s for s in go_syms - c_syms if not s.startswith("rgx_transform")}
+    assert not missing, missing
+
+
+def test_twin_without_a_device_keeps_the_go_path(stub, tmp_path):
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a device is present: the GPU tier runs the protocol")
+    blob, _ = _tables(tmp_path, DATE, "Date")
+    rc, out = _run(stub, blob, b"x 2024-01-15 y", tmp_path, "info")
+    assert rc == 0
+    lines = out.decode().splitlines()
+    assert lines[0].startswith("INIT -5")                                # RGX_E_NO_DEVICE: <name>Prog stays nil, every method falls back
+    assert "abi 3 ncap 8 min 10 max 10 findall 1 stream 1 find 1 match 1 engine 0" in lines[1]
+    rc, out = _run(stub, blob, b"x 2024-01-15 y", tmp_path, "findall")
+    assert rc == 1 and out.startswith(b"INIT -5")
+
+
+@pytest.mark.gpu
+def test_twin_find_all_with_capacity_retry(stub, tmp_path):
+    from oracle.engines import Compiled as O
+    blob, _ = _tables(tmp_path, DATE, "Date")
+    # dense input: more than one match per 64 bytes + 1024 -> the first call answers RGX_E_CAPACITY, the retry has the exact count
+    data = (b"2024-01-15 " * 40000) + b"tail 1999-12-31"
+    rc, out = _run(stub, blob, data, tmp_path, "findall", -1)
+    assert rc == 0
+    lines = out.decode().splitlines()
+    exp = O(DATE).FindAllBytes(data)
+    assert lines[0] == "RETRY %d" % len(exp) and lines[1] == "COUNT %d" % len(exp)
+    assert [list(map(int, l.split()[1:])) for l in lines[2:]] == exp
+    rc, out = _run(stub, blob, data, tmp_path, "findall", 5)
+    assert [list(map(int, l.split()[1:])) for l in out.decode().splitlines()[1:]] == exp[:5]
+    # several devices in the list (the same one twice on a one-GPU box): rgx_sharded_find_all_bytes, same rows
+    rc, out = _run(stub, blob, data, tmp_path, "sharded", 2, -1)
+    lines = out.decode().splitlines()
+    assert "SHARDED 1" in lines
+    rows = [list(map(int, l.split()[1:])) for l in lines if l.startswith("ROW")]
+    assert rows == exp
+
+
+@pytest.mark.gpu
+def test_twin_find_reader_reproduces_the_reference_streaming_vector(stub, tmp_path, kats):
+    """streaming_test.go:190-280: six dates at literal offsets around the 64 KiB chunk boundary; offsets and chunk indices equal
+    the oracle's FindReader, for full reads and for a reader that returns 4000 bytes at a time."""
+    from oracle import engines as E
+    sb = kats["streaming_boundary"]
+    data = bytearray(sb["fill"].encode() * sb["total_size"])
+    for pos, d in zip(sb["positions"], sb["dates"]):
+        data[pos:pos + len(d)] = d.encode()
+    data = bytes(data)
+    blob, _ = _tables(tmp_path, sb["pattern"], "D")
+    o = E.Compiled(sb["pattern"])
+    for read_size in (0, 4000):
+        exp = []
+        pos = [0]
+
+        def read(n):
+            k = min(n, read_size) if read_size else n
+            b = data[pos[0]:pos[0] + k]
+            pos[0] += len(b)
+            return b
+
+        assert o.FindReader(read, E.StreamConfig(BufferSize=sb["buffer_size"]), lambda m: exp.append((m.StreamOffset, m.ChunkIndex, m.match_bytes)) or True) is None
+        rc, out = _run(stub, blob, data, tmp_path, "reader", sb["buffer_size"], 0, read_size)
+        assert rc == 0
+        got = [(int(l.split()[1]), int(l.split()[2]), l.split()[3].encode()) for l in out.decode().splitlines() if l.startswith("MATCH")]
+        assert got == exp, read_size
+        if not read_size:
+            # (after a SHORT read the reference does not advance streamOffset, streaming.go:241-244: its offsets are then relative to
+            # nothing useful -- 768 for the date at 32768 -- and the stub reproduces exactly that)
+            assert [g[0] for g in got] == sb["positions"]
+        rc, out = _run(stub, blob, data, tmp_path, "count", sb["buffer_size"], 0, read_size)
+        assert out.decode().splitlines()[-1] == "COUNT %d" % len(exp)
+    rc, out = _run(stub, blob, data, tmp_path, "reader", 100, 0, 0)           # cfg.Validate: stream.ErrBufferTooSmall
+    assert out.decode().startswith("CONFIG_ERROR -10")
+
+
+@pytest.mark.gpu
+def test_twin_refusals_and_fallbacks(stub, tmp_path):
+    from regengo_amd import _capi
+    # Q4: an earlier copy of the match text in the gap -> bytes.Index finds it first -> RGX_E_DIVERGES: the chunk goes to the Go loop
+    blob, _ = _tables(tmp_path, r"(?P<a>ab+)c?", "A")
+    rc, out = _run(stub, blob, b"xx ab yy abbc ab", tmp_path, "reader", 65536, 0, 0)
+    assert rc == 0
+    # the reference's Tagged DFA (URLCapture): FindAll and FindReader are refused in reference mode (-3) ...
+    blob, go = _tables(tmp_path, URL_CAPTURE, "U")
+    data = b"see https://example.com/a and http://h.org:80/x"
+    rc, out = _run(stub, blob, data, tmp_path, "findall", -1)
+    assert out.decode().splitlines() == ["GOFALLBACK -3"]
+    rc, out = _run(stub, blob, data, tmp_path, "reader", 65536, 0, 0)
+    assert out.decode().splitlines()[0].startswith("GOFALLBACK -3")
+    # ... and answered as Go's regexp would with tables compiled under RGX_FLAG_STDLIB_SEMANTICS
+    from oracle.engines import Compiled as O
+    blob, _ = _tables(tmp_path, URL_CAPTURE, "U2", flags=_capi.FLAG_STDLIB_SEMANTICS)
+    rc, out = _run(stub, blob, data, tmp_path, "findall", -1)
+    rows = [list(map(int, l.split()[1:])) for l in out.decode().splitlines() if l.startswith("ROW")]
+    assert rows == O(URL_CAPTURE).FindAllLeftmostFirst(data) and len(rows) == 2
+
+
+@pytest.mark.gpu
+def test_twin_replace_match_find(stub, tmp_path):
+    from oracle.engines import Compiled as O
+    blob, _ = _tables(tmp_path, DATE, "Date")
+    data = b"from 2024-01-15 to 2024-02-29."
+    rc, out = _run(stub, blob, data, tmp_path, "replace", "$day/$month/$year", 0)
+    assert out == b"OUT 30\nfrom 15/01/2024 to 29/02/2024.\nEND\n"
+    rc, out = _run(stub, blob, data, tmp_path, "replace", "${", 0)
+    assert out.startswith(b"PANIC invalid replace template")
+    big = data + b"x" * 100 + (b" 2024-03-0%d" % 1) * 2000        # output longer than len + len/8 + 64: the capacity loop
+    rc, out = _run(stub, blob, big, tmp_path, "replace", "<<<<<<<<<<<<<<<<<<<<$0>>>>>>>>>>>>>>>>>>>>", 0)
+    assert out.startswith(b"RETRY ")
+    o = O(DATE)
+    for s in (b"x 12024-01-15", b"a 2024-01-15 b", b"nothing"):
+        rc, out = _run(stub, blob, s, tmp_path, "match")
+        assert out.decode().strip() == "MATCHED %d" % int(o.MatchBytes(s)), s      # reference semantics (Q1: 12024-01-15 does not match)
+        rc, out = _run(stub, blob, s, tmp_path, "find")
+        e = o.FindBytes(s)
+        assert out.decode().strip() == ("NOTFOUND" if e is None else "ROW " + " ".join(map(str, e))), s

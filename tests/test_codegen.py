@@ -73,21 +73,31 @@ def test_emitted_text_is_well_formed(built, name, pattern):
         used.add(sym)
         assert sym in arity, sym
         assert _go_call_arity(code, m.end() - 1) == arity[sym], sym
-    assert {"rgx_program_from_blob", "rgx_program_to_device", "rgx_stream_ctx_create", "rgx_find_all_bytes", "rgx_find_chunk",
-            "rgx_replace_all_bytes", "rgx_transform_chunk"} <= used
+    info = codegen.Program(pattern).info
+    need = {"rgx_abi_version", "rgx_program_from_blob", "rgx_program_to_device", "rgx_stream_ctx_create", "rgx_stream_ctx_destroy",
+            "rgx_sharded_create", "rgx_sharded_destroy", "rgx_program_destroy"}
+    if info.ref_findall_offered:
+        need |= {"rgx_find_all_bytes", "rgx_sharded_find_all_bytes"}
+    if info.ref_stream_offered:
+        need |= {"rgx_find_chunk", "rgx_count_chunk", "rgx_replace_all_bytes", "rgx_transform_chunk"}
+    assert need <= used, need - used
     hdr = open(os.path.join(ROOT, "include", "rgx.h")).read()
     for m in re.finditer(r"C\.(RGX_[A-Z_0-9]+)", code):
         assert re.search(r"\b%s\b" % m.group(1), hdr), m.group(1)
     # README.md:99-146: the methods whose hot loop is on the device
-    want = ["FindAllString", "FindAllStringAppend", "FindAllBytes", "FindAllBytesAppend", "FindReader", "ReplaceReader",
-            "ReplaceAllString", "ReplaceAllBytes", "ReplaceAllBytesAppend", "ReplaceFirstString", "ReplaceFirstBytes"]
-    info = codegen.Program(pattern).info
+    # -- each family only where the library gives the reference's own answer (rgx_info.ref_*_offered); the rest keep their Go bodies
+    want, absent = [], []
+    (want if info.ref_findall_offered else absent).extend(["FindAllString", "FindAllStringAppend", "FindAllBytes", "FindAllBytesAppend"])
+    (want if info.ref_stream_offered else absent).extend(["FindReader", "FindReaderCount", "ReplaceReader", "ReplaceAllString", "ReplaceAllBytes",
+                                                          "ReplaceAllBytesAppend", "ReplaceFirstString", "ReplaceFirstBytes"])
     if info.ref_match_offered:
         want += ["MatchBytes", "MatchString"]
     if info.ref_find_offered:
         want += ["FindBytes", "FindBytesReuse", "FindString", "FindStringReuse"]
     for meth in want:
         assert re.search(r"func \(r %s\) %s\(" % (name, meth), code), meth
+    for meth in absent:
+        assert not re.search(r"func \(r %s\) %s\(" % (name, meth), code), meth
     # every fallback is a `...Go` method of the same receiver
     for m in re.finditer(r"\br\.([a-z][A-Za-z]*)\(", code):
         assert m.group(1).endswith("Go"), m.group(1)
@@ -123,9 +133,31 @@ def test_field_names_and_memo_patterns(built):
     # no capture groups: only the Match methods exist in the reference's output (compiler.go:204-367)
     text, _ = codegen.emit_go(r"\d+", "Digits", "p")
     assert "FindAll" not in text.replace("// ", "") or "func (r Digits) FindAll" not in text
-    # nested quantifiers (analysis.go:85-113): the reference emits a Thompson MatchBytes (plain existence: routed) and a TDFA
-    # FindBytes (its restart offsets are not reproduced: stays pure Go); FindAll is routed either way
+    # nested quantifiers (analysis.go:85-113): the reference emits a Thompson MatchBytes (plain existence: routed) and, the Tagged DFA
+    # being infeasible here, a memoising FindBytes (its restart offsets are not reproduced: stays pure Go, and with it the streaming
+    # loops built on it); its FindAll is plain leftmost-first on a pattern that cannot match empty: routed
     text, _ = codegen.emit_go(r"(?P<w>(a+)+)b", "Nested", "p")
+    assert codegen.Program(r"(?P<w>(a+)+)b").info.ref_find_engine == 2
     assert "func (r Nested) MatchBytes(" in text and "func (r Nested) FindBytesReuse(" not in text
     assert "FindBytes / FindBytesReuse / FindString / FindStringReuse are not routed" in text
-    assert "func (r Nested) FindAllBytesAppend(" in text
+    assert "func (r Nested) FindAllBytesAppend(" in text and "func (r Nested) FindReader(" not in text
+    # the reference's Tagged DFA (URLCapture, 13 states as in its checked-in tables): FindAll* and the streaming family are NOT
+    # routed in reference mode -- the TDFA's FindAll reports matches again (compiler.go:646-651) -- and all are with --stdlib-semantics
+    url = CASES[2][1]
+    assert codegen.Program(url).info.ref_find_engine == 1 and codegen.Program(url).info.ref_tdfa_states == 13
+    text, _ = codegen.emit_go(url, "URL", "p")
+    assert "func (r URL) FindAll" not in text and "func (r URL) FindReader(" not in text and "FindAll* are not routed" in text
+    text, _ = codegen.emit_go(url, "URL", "p", flags=_capi.FLAG_STDLIB_SEMANTICS)
+    for meth in ("FindAllBytesAppend", "FindReader", "FindReaderCount", "ReplaceAllBytesAppend", "FindBytesReuse", "MatchBytes"):
+        assert "func (r URL) %s(" % meth in text, meth
+    assert "Semantics: Go's regexp" in text
+
+
+def test_capacity_retry_comes_before_the_fallback(built):
+    """RGX_E_CAPACITY is negative -- the retry with res.total has to be tested for BEFORE the generic w < 0 fallback."""
+    text, _ = codegen.emit_go(CASES[0][1], "Date", "p")
+    body = text[text.index("func (r Date) FindAllBytesAppend("):]
+    assert body.index("w == C.RGX_E_CAPACITY") < body.index("if w < 0 {")
+    # a (0, nil) read with nothing left over is not the end of the stream (streaming.go:123-175)
+    loop = text[text.index("func dateReadLoop("):]
+    assert "if err == io.EOF {\n\t\t\t\treturn nil" in loop and "continue" in loop

@@ -27,6 +27,13 @@ def _gpu(pattern, flags=0, stdlib=False):
     return Compiled(pattern, flags=flags, stdlib=stdlib).to(0)
 
 
+def _scan(pattern, flags=0):
+    """For tests of the SCAN kernels (FindAll against the leftmost-first oracle): reference mode where the reference's FindAll is
+    leftmost-first, RGX_FLAG_STDLIB_SEMANTICS where reference mode refuses (Tagged-DFA class: tests/test_gpu_tdfa.py covers the refusal)."""
+    c = _gpu(pattern, flags)
+    return c if c.info.ref_findall_offered else _gpu(pattern, flags, stdlib=True)
+
+
 def test_library_is_the_hip_one(torch_dev):
     """The .so that computes is the in-tree HIP library, loaded in this process."""
     from regengo_amd import _capi, build
@@ -44,7 +51,7 @@ def test_corpus_bit_exact(torch_dev, corpus, kats):
     items = [(e["pattern"], e["inputs"]) for e in corpus] + [(c["pattern"], c["inputs"]) for c in kats["curated_cases"]]
     for p, inputs in items:
         try:
-            c = _gpu(p)
+            c = _scan(p)
         except _capi.RgxError as ex:
             assert ex.status == _capi.RGX_E_UNSUPPORTED, p
             uns += 1
@@ -171,7 +178,7 @@ def test_dynamic_captures_medium(torch_dev):
     buf = b"".join(rng.choice(words) + (b" " if rng.random() < 0.5 else b"") for _ in range(60000))
     arr = np.frombuffer(buf, dtype=np.uint8)
     for pat in (EMAIL, URL, r"(\d+)", r"(?P<k>\w+)=(?P<v>\w*)"):
-        c = _gpu(pat)
+        c = _scan(pat)
         spans, res = c.FindAllSpans(buf)
         exp, cnt = CMatcher(pat).find_all_np(arr)
         assert res.total == cnt, pat

@@ -45,9 +45,15 @@ def test_replace_matches_oracle_on_corpus(gpu, corpus, kats):
             continue
         o = E.Compiled(pat)
         # Programs whose FindBytesReuse the library reproduces (and that cannot match empty) are held to the REFERENCE's loop, quirks
-        # included (oracle: quirks=True -- restart rule, re-slicing, bytes.Index): the answer is that, or RGX_E_DIVERGES.  The others
-        # keep the quirk-free reading (true leftmost-first matches in their real context).
-        strict = bool(c.info.ref_find_offered) and not c.info.can_match_empty
+        # included (oracle: quirks=True -- restart rule, re-slicing, bytes.Index): the answer is that, or RGX_E_DIVERGES.  The others are
+        # refused in reference mode and give the quirk-free reading (true leftmost-first matches in their real context) in stdlib mode.
+        strict = bool(c.info.ref_stream_offered)
+        if not strict:
+            # reference mode refuses (rgx_info.ref_stream_offered == 0): the quirk-free reading is what RGX_FLAG_STDLIB_SEMANTICS gives
+            with pytest.raises(_capi.RgxError) as ei:
+                c.ReplaceAllBytes(b"abc", "$0")
+            assert ei.value.status == _capi.RGX_E_UNSUPPORTED, pat
+            c = Compiled(pat, stdlib=True).to(0)
         if not strict and (c.info.lookahead_mode or "^" in pat or "\\b" in pat or "\\B" in pat or "\\A" in pat):
             continue          # context-sensitive: the reference's re-slicing (Q12) changes what `^`/`\b` see; not the GPU's reading
         bs = [s.encode() for s in inputs]

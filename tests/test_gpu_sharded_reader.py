@@ -83,6 +83,8 @@ def test_find_reader_count_equals_callbacks(gpu):
     data = tile[:900_000]
     for pattern in (DATE, URL, r"(\d+)"):
         c = Compiled(pattern).to(0)
+        if not c.info.ref_stream_offered:      # the C4 URL pattern: the reference memoises, its FindReader loop is not reproduced
+            c = Compiled(pattern, stdlib=True).to(0)
         for bufsize, left in ((65536, 0), (100_000, 1024), (1 << 20, 0)):
             n = [0]
 
