@@ -39,6 +39,8 @@ sys.path.insert(0, ROOT)
 DATE = r"(?P<year>\d{4})-(?P<month>\d{2})-(?P<day>\d{2})"
 EMAIL = r"(?P<user>\w+)@(?P<domain>\w+)"
 URL = r"(?P<full>(?P<proto>https?|ftp)://(?P<host>[\w.-]+)(?P<port>:\d+)?(?P<path>/[\w./-]*)?)"
+# what the reference's FindReader drops per 1 MiB tile of the web-log corpus, by BufferSize (pinned by tests/test_ref_engine.py)
+C4_DROPPED_PER_MIB = {1 << 16: 9, 1 << 17: 7, 1 << 18: 3}
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
 METRIC = "input GB/s (FindAllBytes, 1 GiB buf) at 1/2/4/8 MI355X; bit-exact offsets"
 MIN_TIMED_SECONDS = 0.5
@@ -146,8 +148,39 @@ def base_line(env, args, value, ms_per_step, reps, dtype="u8", scaling="weak"):
             "dtype": dtype, "data": "synthetic"}
 
 
+
+def make_sharded(env, compiled):
+    """The C library's sharded context for this rank (csrc/rgx_sharded.hip: rgx_sharded_create_rank): the communicator is the
+    library's own (ncclCommInitRank inside, id made by rank 0 and carried over the launcher's process group); torch lends device
+    memory and the barrier of the timing harness, nothing on the data path."""
+    from regengo_amd.sharded import Sharded
+    uid = None
+    if env.world > 1:
+        box = [Sharded.unique_id() if env.rank == 0 else None]
+        env.dist.broadcast_object_list(box, src=0)
+        uid = box[0]
+    s = Sharded(compiled, device=env.local_rank, rank=env.rank, world=env.world, uid=uid)
+    s.set_timing(True)
+    return s
+
 # ------------------------------------------------------------------------------------------------------------------- C2
 def run_c2(env, args):
+    if os.environ.get("RGX_BENCH_PATH", "capi") != "dist":
+        try:
+            return run_c2_capi(env, args)
+        except Exception as ex:            # e.g. no usable librccl for N>1: the round-2 path still measures the kernels
+            if env.world == 1:
+                raise
+            sys.stderr.write("[bench] C-ABI sharded path failed on rank %d (%s); falling back to regengo_amd/dist.py\n" % (env.rank, ex))
+            ok = 0
+        if env.allmin_int(ok) == 0:
+            line = run_c2_dist(env, args)
+            line["config"]["path"] = "FALLBACK regengo_amd/dist.py over torch.distributed (the C-ABI sharded path failed to start)"
+            return line
+    return run_c2_dist(env, args)
+
+
+def run_c2_dist(env, args):
     torch, dist = env.torch, env.dist
     from regengo_amd import Compiled, synth
     from regengo_amd.dist import ShardedFinder, plan_shards
@@ -305,6 +338,153 @@ def run_c2(env, args):
     return line
 
 
+def run_c2_capi(env, args):
+    """The headline through the C library's sharded entry points for every N (RGX_BENCH_PATH=dist: the round-2 path over
+    regengo_amd/dist.py).  One step = one ROUND: this rank's owned range + halos of the global stream scanned in shard mode
+    (rgx_find_all_bytes_device_owned on the slot's own stream and host thread), full span table in HBM, count on the host and --
+    N>1 -- the round's ncclAllGather of [count, flags] done; two rounds are in flight, so round k+1 scans while round k is waited
+    for and exchanged."""
+    torch = env.torch
+    from regengo_amd import Compiled, synth
+    world, rank, dev = env.world, env.rank, env.dev
+    c = Compiled(DATE, name="Date").to(env.local_rank)
+    sh = make_sharded(env, c)
+
+    def build(L_total):
+        lo, hi, wl, wh = sh.plan(L_total, parts=world)[rank]
+        window = synth.date_log_torch(wh - wl, dev, adversarial=args.adversarial, start=wl)
+        cap = (wh - wl) // c.MinMatchLen + 1
+        outs = [torch.empty((cap, c.ncap), dtype=torch.int32, device=dev) for _ in range(2)]
+        torch.cuda.synchronize()              # the window was produced on torch's stream; the library scans on its own
+        fifo = []
+        nsub = [0]
+
+        def submit():
+            k = nsub[0] & 1
+            nsub[0] += 1
+            sh.submit([dict(buf=window, own=(lo - wl, hi - wl), base=wl, starts_at_sync=wl == 0, last=wh >= L_total, out=outs[k])])
+            fifo.append(k)
+
+        def wait():
+            total, rs = sh.wait()
+            k = fifo.pop(0)
+            me = rs[rank]
+            return outs[k][:me["count"]], me["count"], me, total, [r["count"] for r in rs], any(r["unsynced"] for r in rs)
+
+        return submit, wait, (lo, hi, wl, wh), window, outs, cap
+
+    def runner(submit, wait, sink):
+        def run_steps(k):
+            submit()
+            for _ in range(k - 1):
+                submit()
+                sink.append(wait())
+            sink.append(wait())
+        return run_steps
+
+    L = args.bytes
+    submit, wait, (lo, hi, wl, wh), window, outs, cap = build(L * world)
+    results = []
+    dt, reps = sustained(env, runner(submit, wait, results), args.steps, args.warmup)
+    timed = results[-args.steps * reps:]
+    owned, cnt, me, total, counts, _ = timed[-1]
+    kms = [r[2]["kernel_ms"] for r in timed]
+    redone = sum(1 for r in timed if r[5])          # a round with an unsynced halo would have to be handed in again: must be 0
+
+    parity = None
+    if not args.adversarial:
+        g0 = -(-lo // 50) * 50
+        starts = torch.arange(g0, hi, 50, dtype=torch.int64, device=dev)
+        starts = starts[starts + 10 <= L * world]
+        rel = (starts - wl).to(torch.int32)
+        exp = torch.stack([rel, rel + 10, rel, rel + 4, rel + 5, rel + 7, rel + 8, rel + 10], dim=1)
+        parity = bool(owned.shape == exp.shape and torch.equal(owned, exp))
+    parity_all = bool(env.allmin_int(1 if parity in (True, None) else 0))
+
+    alt = None
+    if args.no_alt:
+        alt = {"skipped": "--no-alt"}
+    else:
+        from regengo_amd import _capi
+        try:
+            starts_out = torch.empty(cap, dtype=torch.int32, device=dev)
+            for _ in range(2):
+                c.FindAllStarts(window, out=starts_out, capacity=cap)
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            ak = []
+            c.set_timing(True)
+            for _ in range(args.steps):
+                st, ares = c.FindAllStarts(window, out=starts_out, capacity=cap)
+                ak.append(ares.kernel_ms)
+            torch.cuda.synchronize()
+            adt = (time.perf_counter() - ta) / args.steps
+            tmpl, mlen = c.capture_template()
+            sp_full = c.FindAllSpans(window, out=outs[0], capacity=cap)[0]
+            same = bool(torch.equal(st[:, None] + torch.tensor(tmpl, dtype=torch.int32, device=dev)[None, :], sp_full))
+            akm = sum(ak) / len(ak)
+            alt = {"form": "starts_only (4 B/match) + capture template", "ms_per_step": round(adt * 1e3, 4), "kernel_ms": round(akm, 4),
+                   "GBps_kernel": round((wh - wl) / (akm * 1e-3) / 1e9, 1),
+                   "frac_of_hbm_peak": round((wh - wl) / (akm * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                   "spans_reconstructed_equal_full": same}
+        except _capi.RgxError as ex:
+            alt = {"error": str(ex)}
+
+    # N>1: the RCCL gather of every rank's rows to rank 0 (rgx_sharded_gather: stream-absolute int64 records, grouped send/recv),
+    # timed apart -- 64 B/match is larger than the input -- and checked on rank 0; then the strong-scaling point: ONE 1 GiB stream
+    gather_ms = gather_ok = None
+    strong = None
+    if world > 1:
+        submit()
+        owned, cnt, me, total, counts, _ = wait()
+        dst = torch.empty((total + 8, c.ncap), dtype=torch.int64, device=dev) if rank == 0 else None
+        env.barrier()
+        g0t = time.perf_counter()
+        n = sh.gather(0, out=dst)
+        env.barrier()
+        gather_ms = env.allmax((time.perf_counter() - g0t) * 1e3)
+        ok = True
+        if rank == 0 and not args.adversarial:
+            ok = n == total
+            st0 = torch.arange(0, total, dtype=torch.int64, device=dev) * 50
+            ok = ok and bool(torch.equal(dst[:total, 0], st0) and torch.equal(dst[:total, 7], st0 + 10))
+        gather_ok = bool(env.allmin_int(1 if ok else 0))
+        del window, outs, owned, timed, results, dst
+        torch.cuda.empty_cache()
+        s_submit, s_wait, _, s_window, s_outs, _ = build(L)
+        s_res = []
+        s_dt, s_reps = sustained(env, runner(s_submit, s_wait, s_res), args.steps, 2)
+        s_tot = s_res[-1][3]
+        strong = {"bytes_total": L, "ms_per_step": round(s_dt / (args.steps * s_reps) * 1e3, 4), "repeats": s_reps,
+                  "value_GBps": round(L / (s_dt / (args.steps * s_reps)) / 1e9, 2), "matches_total": int(s_tot),
+                  "parity_count": bool(args.adversarial or s_tot == (L - 10) // 50 + 1)}
+
+    nsteps = args.steps * reps
+    ms_per_step = dt / nsteps * 1e3
+    value = float(L) * world / (dt / nsteps) / 1e9
+    k_ms = sum(kms) / len(kms)
+    win_bytes = wh - wl
+    achieved = win_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
+    traffic, tsrc = load_traffic("c2")
+    line = base_line(env, args, value, ms_per_step, reps)
+    line["config"] = {"workload": "C2: Date DFA FindAllBytes over a 1 GiB synthetic date-log buffer per GPU"
+                                  + (" (adversarial noise)" if args.adversarial else ""),
+                      "pattern": DATE, "bytes_per_gpu": L, "matches_per_gpu": int(cnt), "matches_total": int(total),
+                      "span_record_bytes": 4 * c.ncap, "parallelism": "shard%d" % world,
+                      "path": "C ABI: rgx_sharded_round_submit / _wait (2 rounds in flight)" + (", library-owned RCCL communicator" if sh.uses_rccl else ""),
+                      "parity_closed_form": parity_all, "steps_redone": redone,
+                      "gather_ms": None if gather_ms is None else round(gather_ms, 3), "gather_rows_checked": gather_ok,
+                      "strong_scaling": strong, "alt_result_form": alt}
+    line["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
+                        "kernel": KERNEL_NAMES.get(c.info.scan_kernel, "rgx scan kernel"), "kernel_ms": round(k_ms, 4),
+                        "algorithmic_bytes_per_launch": win_bytes, "timed_launches": len(kms)}
+    if not args.no_cpu_baseline and world == 1:      # the CPU leg runs at N=1 only
+        line["cpu_baseline"] = cpu_baseline_findall(DATE, "c2", args.adversarial)
+    sh.close()
+    return line
+
+
 # ------------------------------------------------------------------------------------------------------------------- C3
 def email_truth_np(data, offsets):
     """Ground truth of FindBytes for (\\w+)@(\\w+) per string, vectorised: the first '@' with a word byte on both sides inside
@@ -421,10 +601,15 @@ def check_tile(tile, sha_expected):
 
 
 def run_c4(env, args):
-    torch, dist = env.torch, env.dist
+    """FindReader over the ranks through the C library (rgx_sharded_round_submit / _wait / _gather): the stream is cut into
+    ~1 GiB windows, window k is owned by rank k mod world, a round gives every rank one window (+ halos), two rounds in flight.
+    SEMANTICS: the rows are the reference's FindAllBytes over the whole stream.  The reference's FindReader is a chunk protocol on
+    top of FindBytesReuse and reports fewer: it drops every match that straddles `dataLen - MaxLeftover` of a chunk -- per 1 MiB of
+    this corpus 9 of 8992 with the default 64 KiB Config (tests/test_ref_engine.py::test_c4_find_reader_is_not_findall_over_the_stream
+    pins it); the per-chunk protocol itself is rgx_find_chunk's (single GPU, identical or refused)."""
+    torch = env.torch
     import numpy as np
     from regengo_amd import Compiled
-    from regengo_amd.dist import DeviceSource, ShardedReader
     world, rank, dev = env.world, env.rank, env.dev
     tile = corpus_tile()
     T = len(tile)
@@ -432,44 +617,83 @@ def run_c4(env, args):
     check_tile(tile, bytes(fx["tile_sha256"]).hex())
     A, U, Z = fx["a"].astype(np.int64), fx["u"].astype(np.int64), fx["z"].astype(np.int64)
     c = Compiled(URL, name="URL").to(env.local_rank)
-    c.set_timing(True)
+    assert c.info.ref_findall_offered, "C4's pattern: the reference memoises, its FindAllBytes is leftmost-first and offered"
+    sh = make_sharded(env, c)
     tiles_per_window = (1 << 30) // T
     W = tiles_per_window * T                    # ~1 GiB, a whole number of tiles
     nwin_total = args.windows * world           # weak scaling: `windows` (default 8 = 8 GiB) per GPU; 8 GPUs = the 64 GiB stream
     Ltot = nwin_total * W
+    HALO_L, HALO_R = 4096, 1 << 20              # unbounded pattern: the reference's own 1 MiB leftover cap as the right halo
     tt = torch.frombuffer(bytearray(tile), dtype=torch.uint8).to(dev)
-    resident = {}
 
     def gen(lo, hi):
-        """Bytes [lo, hi) of the periodic stream.  The rank's windows are generated once and stay resident in HBM (the timed
-        region starts with the input in place, as for the other configs)."""
-        key = (lo, hi)
-        t = resident.get(key)
-        if t is None:
-            ph = lo % T
-            reps = -(-(hi - lo + ph) // T)
-            t = tt.repeat(reps)[ph:ph + (hi - lo)].clone()      # fresh allocation: 16-byte aligned base
-            resident[key] = t
-        return t
+        ph = lo % T
+        reps = -(-(hi - lo + ph) // T)
+        return tt.repeat(reps)[ph:ph + (hi - lo)].clone()      # fresh allocation: 16-byte aligned base
 
-    reader = ShardedReader(c, dev, window_bytes=W, halo_left=4096)
-    src = DeviceSource(gen, Ltot)
-    st_last = [None]
+    # this rank's windows, generated once and resident in HBM (the timed region starts with the input in place)
+    wins = []
+    for t in range(args.windows):
+        k = t * world + rank
+        lo, hi = k * W, (k + 1) * W
+        wl = max(0, lo - HALO_L)
+        wl -= wl % 16
+        wh = min(Ltot, hi + HALO_R)
+        wins.append(dict(k=k, lo=lo, hi=hi, wl=wl, wh=wh, buf=gen(wl, wh)))
+    cap = len(A) + tiles_per_window * len(U) + len(Z) + 64
+    outs = [torch.empty((cap, c.ncap), dtype=torch.int32, device=dev) for _ in range(2)]
+    torch.cuda.synchronize()
+    stats = {}
+    # Rounds in flight.  The pair kernel and the capture pass each fill the GPU: a second round's kernels would only time-slice with
+    # the first's (same 14.8 ms per 8 windows, measured) and stretch every kernel's event-timed duration -- so ONE round at a time
+    # here; RGX_C4_DEPTH=2 for the experiment.  (The exact kernel's rounds, config c2, queue back to back on one stream instead.)
+    depth = max(1, min(2, int(os.environ.get("RGX_C4_DEPTH", "1"))))
 
-    def one_pass(on_rows=None, gather=False):
-        # a step leaves every window's rows in HBM as the kernel wrote them (int32, window-relative) plus the window's stream
-        # offset and global row base on the host; the gather pass turns them into stream-absolute int64 rows on rank 0
-        st_last[0] = reader.find_reader(src, on_rows=on_rows, gather=gather, absolute=gather)
-        return st_last[0]
+    def one_pass(on_rows=None, gather=False, table=None):
+        """All rounds of the stream.  on_rows(rows int32 window-relative, window, global row base); gather: every round's rows go to
+        rank 0, stream-absolute int64, into `table` there (the RCCL gather; every rank takes part)."""
+        count = 0
+        kms = 0.0
+        trunc = unsynced = 0
+        fifo = []
+
+        def submit(t):
+            w = wins[t]
+            slot = len(fifo_all) & 1
+            fifo_all.append(slot)
+            sh.submit([dict(buf=w["buf"], own=(w["lo"] - w["wl"], w["hi"] - w["wl"]), base=w["wl"], starts_at_sync=w["wl"] == 0,
+                            last=w["wh"] >= Ltot, out=outs[slot])])
+            fifo.append((t, slot))
+
+        fifo_all = []
+        tnext = 0
+        grow = 0
+        for t in range(args.windows):
+            while tnext < args.windows and tnext - t < depth:
+                submit(tnext)
+                tnext += 1
+            total, rs = sh.wait()
+            tt_, slot = fifo.pop(0)
+            me = rs[rank]
+            kms += me["kernel_ms"]
+            trunc += sum(1 for r in rs if r["truncated"])
+            unsynced += sum(1 for r in rs if r["unsynced"])
+            base = count + sum(r["count"] for r in rs[:rank])
+            if on_rows is not None:
+                on_rows(outs[slot][:me["count"]], wins[tt_], base)
+            if gather:
+                grow += sh.gather(0, out=table[grow:] if rank == 0 else None)
+            count += total
+        stats.update(count=count, kernel_ms=kms, truncated=trunc, unsynced=unsynced, rounds=args.windows, gathered=grow)
+        return stats
 
     def run_steps(k):
         for _ in range(k):
             one_pass()
 
-    one_pass()                                  # generates and pins the windows in HBM (untimed)
     dt, reps = sustained(env, run_steps, args.steps, args.warmup)
     nsteps = args.steps * reps
-    st = st_last[0]
+    k_ms_sum = stats["kernel_ms"]
     # parity pass (untimed, same path): every window's rows against the oracle's rows on the tile, extended periodically
     ntiles = Ltot // T
     exp_total = len(A) + (ntiles - 2) * len(U) + len(Z)
@@ -488,9 +712,10 @@ def run_c4(env, args):
     def rows_of_tile(tix):
         return len(A) if tix == 0 else (len(Z) if tix == ntiles - 1 else len(U))
 
-    def on_rows(rows, k, base, win_lo):
+    def on_rows(rows, w, base):
         # window k owns tiles [k*tpw, (k+1)*tpw): tile 0 -> A, the last tile of the stream -> Z shifted, the others U shifted.
         # rows are window-relative int32: the fixture rows are shifted into the window's frame
+        k, win_lo = w["k"], w["wl"]
         t0 = k * tiles_per_window
         n_exp = sum(rows_of_tile(t) for t in (t0, t0 + tiles_per_window - 1)) + (tiles_per_window - 2) * len(U)
         if rows.shape[0] != n_exp or base != (0 if k == 0 else len(A) + (t0 - 1) * len(U)):
@@ -502,36 +727,50 @@ def run_c4(env, args):
             okflag[0] &= bool(torch.equal(rows[lo:lo + ref.shape[0]].to(torch.int64), ref))
             checked[0] += 1
 
-    stp = one_pass(on_rows=on_rows)
-    parity = okflag[0] and stp["count"] == exp_total and stp["truncated_windows"] == 0
+    stp = dict(one_pass(on_rows=on_rows))
+    parity = okflag[0] and stp["count"] == exp_total and stp["truncated"] == 0 and stp["unsynced"] == 0
     parity_all = bool(env.allmin_int(1 if parity else 0))
-    gather_ms = None
-    if world > 1:
+    # the gather of every round's rows to rank 0 over the library's communicator (stream-absolute int64), timed as a pass with the
+    # gather minus one without; rank 0 checks the table's first and last tile against the fixture
+    gather_ms = gather_ok = None
+    if world > 1 or os.environ.get("RGX_BENCH_GATHER") == "1":
+        table = torch.empty((exp_total + 64, c.ncap), dtype=torch.int64, device=dev) if rank == 0 else None
         env.barrier()
         g0 = time.perf_counter()
-        one_pass(gather=True)
+        g = dict(one_pass(gather=True, table=table))
         env.barrier()
-        gather_ms = max(0.0, env.allmax((time.perf_counter() - g0) * 1e3) - dt / nsteps * 1e3)   # a pass with the gather minus one without
+        gather_ms = max(0.0, env.allmax((time.perf_counter() - g0) * 1e3) - dt / nsteps * 1e3)
+        ok = True
+        if rank == 0:
+            ok = g["gathered"] == exp_total and bool(torch.equal(table[:len(A)], Ad))
+            ok = ok and bool(torch.equal(table[exp_total - len(Z):exp_total], shift(Zd, (ntiles - 3) * T)))
+        gather_ok = bool(env.allmin_int(1 if ok else 0))
     ms_per_step = dt / nsteps * 1e3
     value = float(Ltot) / (dt / nsteps) / 1e9
-    k_ms = st["kernel_ms"] / max(st["windows"], 1)
-    win_bytes = W + 4096 + reader.halo_r
+    k_ms = k_ms_sum / max(args.windows, 1)
+    win_bytes = W + HALO_L + HALO_R
     achieved = win_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     traffic, tsrc = load_traffic("c4")
     line = base_line(env, args, value, ms_per_step, reps)
     line["config"] = {"workload": "C4: URL-with-alternation FindReader over a %.0f GiB stream, %d x ~1 GiB windows per GPU with halos, owned "
-                                  "round-robin by the ranks (ShardedReader), stream-absolute span rows" % (Ltot / 2**30, args.windows),
+                                  "round-robin by the ranks (C ABI: rgx_sharded_round_*), window-relative int32 rows + stream offsets" % (Ltot / 2**30, args.windows),
+                      "semantics": "the reference's FindAllBytes over the whole stream (its FindReader would drop %s of 8992 matches per MiB tile at "
+                                   "BufferSize 64/128/256 KiB: those straddling dataLen - MaxLeftover of a chunk; not reproduced across GPUs -- "
+                                   "the per-chunk protocol is rgx_find_chunk's)" % "/".join(str(C4_DROPPED_PER_MIB[k]) for k in sorted(C4_DROPPED_PER_MIB)),
                       "pattern": URL, "stream_bytes": Ltot, "bytes_per_gpu": args.windows * W, "window_bytes": W,
-                      "halo_left": 4096, "halo_right": reader.halo_r, "matches_total": int(stp["count"]), "expected_matches": int(exp_total),
+                      "halo_left": HALO_L, "halo_right": HALO_R, "matches_total": int(stp["count"]), "expected_matches": int(exp_total),
                       "span_record_bytes": 4 * c.ncap, "parallelism": "window round-robin over %d rank(s)" % world,
-                      "rounds": st["rounds"], "widened_halos": st["widened_halos"], "parity_oracle_fixture_periodic": parity_all,
-                      "parity_pieces_checked": checked[0], "gather_ms": None if gather_ms is None else round(gather_ms, 3)}
+                      "path": "C ABI: rgx_sharded_round_submit / _wait (%d round(s) in flight)" % depth + (", library-owned RCCL communicator" if sh.uses_rccl else ""),
+                      "rounds": stp["rounds"], "unsynced_halos": stp["unsynced"], "parity_oracle_fixture_periodic": parity_all,
+                      "parity_pieces_checked": checked[0], "gather_ms": None if gather_ms is None else round(gather_ms, 3),
+                      "gather_rows_checked": gather_ok}
     line["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                         "kernel": KERNEL_NAMES.get(c.info.scan_kernel, "rgx scan kernel"), "kernel_ms": round(k_ms, 4),
-                        "algorithmic_bytes_per_launch": win_bytes, "timed_launches": st["windows"]}
+                        "algorithmic_bytes_per_launch": win_bytes, "timed_launches": args.windows * nsteps}
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline_findall(URL, "c4", False)
+    sh.close()
     return line
 
 

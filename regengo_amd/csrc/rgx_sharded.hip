@@ -164,6 +164,10 @@ struct Slot {
   uint8_t* d_in = nullptr; size_t in_cap = 0;
   int32_t* d_spans = nullptr; size_t spans_cap = 0;      // records
   unsigned* d_flag = nullptr;
+  unsigned* h_flag = nullptr;                            // pinned: the halo check's answer of an asynchronous round
+  bool async = false;                                    // this round was queued with rgx_find_all_submit on the shard's actx
+  bool async_halo = false;
+  Job ajob;
 };
 struct Shard {
   int device = 0, rank = 0;
@@ -173,6 +177,9 @@ struct Shard {
   bool has_reset = false;
   int minus1 = 0;
   Slot slot[2];
+  rgx_stream_ctx* actx = nullptr;  // the context of asynchronous rounds (rgx_find_all_submit / _wait: both rounds in flight queue on ITS stream, so
+                                   // their kernels run back to back and never overlap -- kernels the library can launch that way, today the
+                                   // exact kernel, are not sped up by overlapping and their event timings stay those of one kernel)
   // collectives
   ncclComm_t comm = nullptr;
   hipStream_t cstream = nullptr;
@@ -284,6 +291,63 @@ void SlotMain(Slot* s) {
   }
 }
 
+
+// An asynchronous round on the caller's thread: halo check and scan are queued on the shard's actx stream and the call returns.
+// false: this window / program is not offered that way (rgx_find_all_submit said RGX_E_UNSUPPORTED, host memory, count only):
+// the slot's thread takes it.  Errors are kept in the slot's result and surface at the wait.
+bool TryAsync(Shard& sh, Slot& s, const Job& j) {
+  static const bool off = [] { const char* e = getenv("RGX_SHARDED_NO_ASYNC"); return e && *e == '1'; }();
+  if (off || !j.have || j.count_only || j.w.is_host) return false;
+  const rgx_shard_window& w = j.w;
+  if (w.own_lo < 0 || w.own_hi < w.own_lo || (size_t)w.own_hi > w.len) return false;
+  if (hipSetDevice(sh.device) != hipSuccess) return false;
+  hipStream_t st = (hipStream_t)rgx_stream_ctx_hip_stream(sh.actx);
+  int32_t* d_spans = w.d_spans;
+  size_t cap = w.cap_records;
+  if (!d_spans) {
+    const size_t want = (size_t)(w.own_hi - w.own_lo) / (size_t)std::max(sh.info.min_match_len, 1) + 16;
+    if (s.spans_cap < want || !s.d_spans) {
+      if (s.d_spans) (void)hipFree(s.d_spans);
+      s.d_spans = nullptr; s.spans_cap = 0;
+      if (hipMalloc((void**)&s.d_spans, (want + 16) * (size_t)sh.info.ncap * 4) != hipSuccess) { (void)hipGetLastError(); return false; }
+      s.spans_cap = want;
+    }
+    d_spans = s.d_spans; cap = s.spans_cap;
+  }
+  s.res = SlotResult();
+  s.res.have = true;
+  s.async_halo = false;
+  if (!w.starts_at_sync) {
+    if (w.own_lo <= 0 || !sh.has_reset) { s.res.unsynced = 1; s.async = true; s.ajob = j; s.ajob.have = false; return true; }
+    s.h_flag[0] = 0;
+    if (hipMemsetAsync(s.d_flag, 0, 4, st) != hipSuccess) return false;
+    const long long n = w.own_lo;
+    hipLaunchKernelGGL(halo_sync_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 1024)), dim3(256), 0, st, w.buf, n, sh.d_reset, s.d_flag);
+    if (hipMemcpyAsync(s.h_flag, s.d_flag, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+    s.async_halo = true;
+  }
+  const int rc = rgx_find_all_submit(sh.prog, sh.actx, w.buf, w.len, -1, d_spans, cap, w.own_lo, w.own_hi);
+  if (rc == RGX_E_UNSUPPORTED) return false;       // (a halo check may have been queued: harmless, the slot's thread repeats it)
+  s.async = true;
+  s.ajob = j;
+  s.ajob.w.d_spans = d_spans; s.ajob.w.cap_records = cap;
+  if (rc != RGX_OK) { s.res.rc = rc; s.res.err = rgx::GetError(); s.ajob.have = false; }
+  return true;
+}
+void WaitAsync(Shard& sh, Slot& s) {
+  s.async = false;
+  if (!s.ajob.have) return;                        // nothing was queued (an unsynced halo known up front, or an error at submit)
+  (void)hipSetDevice(sh.device);
+  rgx_result res{};
+  const int64_t c = rgx_find_all_wait(sh.prog, sh.actx, &res);
+  if (c < 0) { s.res.rc = (int)c; s.res.err = rgx::GetError(); return; }
+  s.res.count = c;
+  s.res.d_rows = s.ajob.w.d_spans;
+  s.res.base = s.ajob.w.base;
+  s.res.kernel_ms = res.kernel_ms;
+  if (s.async_halo && s.h_flag[0] == 0) { s.res.unsynced = 1; s.res.count = 0; }
+}
+
 }  // namespace
 
 struct rgx_sharded {
@@ -310,10 +374,12 @@ void DestroyShard(Shard* sh) {
       s.th.join();
     }
     if (s.ctx) rgx_stream_ctx_destroy(s.ctx);
+    if (s.h_flag) (void)hipHostFree(s.h_flag);
     if (s.d_in) (void)hipFree(s.d_in);
     if (s.d_spans) (void)hipFree(s.d_spans);
     if (s.d_flag) (void)hipFree(s.d_flag);
   }
+  if (sh->actx) rgx_stream_ctx_destroy(sh->actx);
   if (sh->comm) { Rccl* R = LoadRccl(); if (R) (void)R->CommDestroy(sh->comm); }
   if (sh->cstream) (void)hipStreamDestroy(sh->cstream);
   if (sh->d_x) (void)hipFree(sh->d_x);
@@ -350,9 +416,10 @@ int MakeShard(const void* blob, size_t blob_len, int device, int rank, int world
   for (Slot& s : sh->slot) {
     s.shard = sh;
     if ((rc = rgx_stream_ctx_create(sh->prog, &s.ctx)) != RGX_OK) { DestroyShard(sh); return rc; }
-    if (hipMalloc((void**)&s.d_flag, 16) != hipSuccess) { DestroyShard(sh); SetError("hipMalloc"); return RGX_E_NOMEM; }
+    if (hipMalloc((void**)&s.d_flag, 16) != hipSuccess || hipHostMalloc((void**)&s.h_flag, 16) != hipSuccess) { DestroyShard(sh); SetError("hipMalloc"); return RGX_E_NOMEM; }
     s.th = std::thread(SlotMain, &s);
   }
+  if ((rc = rgx_stream_ctx_create(sh->prog, &sh->actx)) != RGX_OK) { DestroyShard(sh); return rc; }
   *out = sh;
   return RGX_OK;
 }
@@ -473,7 +540,10 @@ RGX_API void* rgx_sharded_hip_stream(const rgx_sharded* s, int local_index, int 
 }
 RGX_API int rgx_sharded_set_timing(rgx_sharded* s, int on) {
   if (!s) return RGX_E_INVALID;
-  for (Shard* sh : s->local) for (Slot& sl : sh->slot) rgx_stream_ctx_set_timing(sl.ctx, on);
+  for (Shard* sh : s->local) {
+    for (Slot& sl : sh->slot) rgx_stream_ctx_set_timing(sl.ctx, on);
+    rgx_stream_ctx_set_timing(sh->actx, on);
+  }
   return RGX_OK;
 }
 
@@ -485,7 +555,9 @@ RGX_API int rgx_sharded_round_submit(rgx_sharded* s, const rgx_shard_window* win
   for (size_t i = 0; i < s->local.size(); i++) {
     Job j;
     j.w = windows[i]; j.count_only = count_only; j.have = windows[i].len > 0 && windows[i].buf != nullptr;
-    Post(s->local[i]->slot[slot], j);
+    Slot& sl = s->local[i]->slot[slot];
+    sl.async = false;
+    if (!TryAsync(*s->local[i], sl, j)) Post(sl, j);
   }
   s->inflight++;
   return slot;
@@ -501,7 +573,10 @@ RGX_API int64_t rgx_sharded_round_wait(rgx_sharded* s, int stop_request, rgx_sha
   s->last_base.assign((size_t)world, 0);
   s->last_slot = slot;
   int rc = RGX_OK;
-  for (Shard* sh : s->local) Join(sh->slot[slot]);
+  for (Shard* sh : s->local) {
+    if (sh->slot[slot].async) WaitAsync(*sh, sh->slot[slot]);
+    else Join(sh->slot[slot]);
+  }
   for (Shard* sh : s->local) {
     const SlotResult& r = sh->slot[slot].res;
     if (r.rc < 0 && rc == RGX_OK) { rc = r.rc; SetError(r.err); }

@@ -158,7 +158,10 @@ def _find_reader_rows(o, data, bufsize, leftover=0):
     return got
 
 
-C4_DROPPED_PER_MIB = {1 << 16: 9, 1 << 17: 7, 1 << 18: 3}      # bench.py quotes these (config c4, "reference_find_reader")
+import os
+import sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import C4_DROPPED_PER_MIB      # noqa: E402  (bench.py quotes these in config c4's "semantics")
 
 
 def test_c4_find_reader_is_not_findall_over_the_stream():
