@@ -832,10 +832,32 @@ def run_c5(env, args):
     counts = {}
     kms = {}
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    # the per-line patterns as ONE package: every line is staged once per launch and walked through all of them (rgx_multi_*);
+    # RGX_C5_NO_PACKAGE=1: one launch per pattern as in round 2
+    from regengo_amd import Package
+    line_progs = [(i, e, c) for i, e, c in progs if e["mode"] == "line"]
+    pk = None
+    in_pk = set()
+    if line_progs and os.environ.get("RGX_C5_NO_PACKAGE") != "1":
+        pk = Package([c for _, _, c in line_progs])
+        in_pk = {i for (i, _, _), a in zip(line_progs, pk.accepted) if a}
+    pk_ms = [0.0]
 
     def run_steps(k):
         for _ in range(k):
+            if pk is not None:
+                ev[0].record()
+                bits, cnts, _ = pk.FindBatchBits(lines, offs)
+                ev[1].record()
+                cl = cnts.tolist()
+                pk_ms[0] = ev[0].elapsed_time(ev[1])
+                for (i, _, _), a, n in zip(line_progs, pk.accepted, cl):
+                    if a:
+                        counts[i] = int(n)
+                        kms[i] = pk_ms[0] / max(len(in_pk), 1)
             for i, e, c in progs:
+                if i in in_pk:
+                    continue
                 if e["mode"] == "scan" and i in count_only:
                     w, res = c.CountAll(big)
                     counts[i] = int(w)
@@ -892,6 +914,8 @@ def run_c5(env, args):
                       "count_only_patterns": int(env.allsum(len(count_only))), "parity_counts_vs_oracle_fixture": nbad == 0, "patterns_with_wrong_count": nbad,
                       "scan_mode_mean_kernel_ms": round(tot_scan_ms / max(tot_nscan, 1), 4),
                       "line_mode_mean_call_ms": round(tot_line_ms / max(tot_nline, 1), 4),
+                      "line_mode_package": None if pk is None else {"programs": len(in_pk), "launches": pk.launches, "ms_per_pass": round(pk_ms[0], 3),
+                                                                    "rank": rank},
                       "setup_compile_s": round(setup_s, 1), "slowest_on_rank0": [[round(a, 3), b, m] for a, b, m in slow]}
     line["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None, "traffic_source": None,

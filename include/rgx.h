@@ -295,6 +295,23 @@ int64_t rgx_find_batch(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* c
 int64_t rgx_match_batch_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_concat,
                                const uint64_t* d_offsets, size_t nstr, uint8_t* d_matched);
 
+/* ---- a PACKAGE of patterns over one batch: FindBytes per string for many programs in one pass ---------------------------
+ * (the reference generates one matcher per pattern and has no notion of running several; BASELINE config C5 is its suite of ~250
+ * patterns over a shared corpus, 156 of them ^/$-anchored validators matched per line.)  The programs' class-compressed tables
+ * (and, in reference mode, their restart-rule automata) are staged in LDS together -- as many as fit, the list is cut into launches --
+ * and every string of the batch is read ONCE per launch and walked through all of them.  Per (program, string) the answer is that
+ * program's rgx_find_batch_device answer (reference semantics unless the program carries RGX_FLAG_STDLIB_SEMANTICS): bit i%64 of
+ * d_found_bits[p][i/64] (rows of ceil(nstr/64) words), d_counts[p] = strings with a match, and -- if d_se is not NULL -- the match's
+ * (start, end) at d_se[p][i][0..1], written only for strings with a match.  Capture records of matching strings: the program's own
+ * rgx_find_batch_device.  accepted[i] (may be NULL) = 1 if program i takes part; the others' rows are left alone (tables beyond
+ * 12 KiB, a program whose input needs the UTF-8 screen, reference mode not offered): use the single-program entry point for them.
+ * rgx_multi_create returns the number of launches one call makes (>= 1) or a negative status.                              */
+typedef struct rgx_multi rgx_multi;
+int rgx_multi_create(const rgx_program* const* progs, int n, uint8_t* accepted, rgx_multi** out);
+void rgx_multi_destroy(rgx_multi* m);
+int64_t rgx_find_batch_multi_device(const rgx_multi* m, rgx_stream_ctx* c, const uint8_t* d_concat, const uint64_t* d_offsets, size_t nstr,
+                                    uint64_t* d_found_bits, uint64_t* d_counts, int32_t* d_se);
+
 /* ---- streaming: FindReader (streaming.go:85-255) ------------------------------------------------
  * The stub keeps the Go read loop (r.Read is the only I/O boundary, streaming.go:123).  Each filled
  * chunk (leftover + fresh bytes) is handed down; matches are returned chunk-relative together with

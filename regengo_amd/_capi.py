@@ -120,6 +120,9 @@ SYMBOLS = {
     "rgx_find_bytes": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.POINTER(C.c_int)]),
     "rgx_find_batch": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]),
     "rgx_match_batch_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]),
+    "rgx_multi_create": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.POINTER(C.c_void_p)]),
+    "rgx_multi_destroy": (None, [C.c_void_p]),
+    "rgx_find_batch_multi_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p, C.c_void_p]),
     "rgx_stream_config_resolve": (C.c_int, [C.c_void_p, C.POINTER(StreamConfig), C.POINTER(StreamConfig)]),
     "rgx_find_chunk": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int64, C.c_void_p,
                                    C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(Result)]),

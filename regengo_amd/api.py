@@ -483,3 +483,46 @@ class Compiled:
 
         self.FindReader(r, cfg, cb)
         return out[0], out[1]
+
+
+class Package:
+    """Several compiled patterns matched against one batch of strings in ONE pass per group of programs (rgx_multi_*, include/rgx.h):
+    FindBytes per string and program -- found bits, counts, optionally (start, end) of the found ones.  Programs that cannot take part
+    (`accepted[i] == False`: large tables, UTF-8 screen, reference mode not offered) keep their own Compiled.FindBatchDevice."""
+
+    def __init__(self, compiled: Sequence["Compiled"]):
+        self._lib = _capi.lib()
+        self.progs = list(compiled)
+        for c in self.progs:
+            c._need_dev()
+        n = len(self.progs)
+        arr = (C.c_void_p * n)(*[c._h for c in self.progs])
+        acc = (C.c_uint8 * n)()
+        h = C.c_void_p()
+        self.launches = _capi.check(self._lib.rgx_multi_create(arr, n, acc, C.byref(h)))
+        self._h = h
+        self.accepted = [bool(a) for a in acc]
+        self._ctx_owner = self.progs[0]
+
+    def __del__(self):
+        try:
+            if getattr(self, "_h", None):
+                self._lib.rgx_multi_destroy(self._h)
+        except Exception:
+            pass
+
+    def FindBatchBits(self, concat, offsets, want_se: bool = False):
+        """-> (bits int64 [n, ceil(nstr/64)], counts int64 [n], se int32 [n, nstr, 2] or None); rows of programs that are not
+        accepted are zero."""
+        import torch
+        nstr = offsets.numel() - 1
+        n = len(self.progs)
+        words = (nstr + 63) // 64
+        bits = torch.zeros((n, max(words, 1)), dtype=torch.int64, device=concat.device)
+        counts = torch.zeros(n, dtype=torch.int64, device=concat.device)
+        se = torch.zeros((n, nstr, 2), dtype=torch.int32, device=concat.device) if want_se else None
+        own = self._ctx_owner
+        own._need_dev()
+        _capi.check(self._lib.rgx_find_batch_multi_device(self._h, own._ctx, concat.data_ptr(), offsets.data_ptr(), nstr, bits.data_ptr(),
+                                                          counts.data_ptr(), se.data_ptr() if want_se else None))
+        return bits, counts, se

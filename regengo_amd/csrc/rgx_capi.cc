@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <new>
+#include <vector>
 
 #include "rgx.h"
 #include "rgx_kernels.h"
@@ -1279,6 +1280,134 @@ RGX_API int64_t rgx_match_batch_device(const rgx_program* p, rgx_stream_ctx* c, 
   HIP_TRY(LaunchBatch(p->p.dev, d_concat, d_offsets, (int64_t)nstr, d_matched, nullptr, nullptr, 0, c->stream, window));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return (int64_t)nstr;
+}
+
+
+// ---------------------------------------------------------------- many programs, one pass over a batch (rgx.h: rgx_multi_*)
+struct rgx_multi {
+  int device = -1;
+  int n = 0;
+  struct Group { void* d_dir = nullptr; int nprog = 0, dir_bytes = 0, first_off = 0, tables_end = 0; };
+  std::vector<Group> groups;
+};
+
+RGX_API int rgx_multi_create(const rgx_program* const* progs, int n, uint8_t* accepted, rgx_multi** out) {
+  if (!progs || n < 1 || n > 65535 || !out) return RGX_E_INVALID;
+  const uint32_t kTablesBudget = getenv("RGX_MULTI_BUDGET") ? (uint32_t)atoi(getenv("RGX_MULTI_BUDGET")) : 20 * 1024;       // directory + tables of one launch (the input window takes 16 KiB more: three or four workgroups per CU)
+  rgx_multi* m = new rgx_multi();
+  m->n = n;
+  std::vector<int> take;
+  for (int i = 0; i < n; i++) {
+    const rgx_program* p = progs[i];
+    bool ok = p && p->p.d_arena != nullptr;
+    if (ok && m->device < 0) m->device = p->p.device;
+    ok = ok && p->p.device == m->device;
+    if (ok) {
+      const Tables& t = p->p.t;
+      const DevTables& T = p->p.dev;
+      const bool ref = !(t.flags & RGX_FLAG_STDLIB_SEMANTICS);
+      ok = !t.needs_valid_utf8 && (!ref || T.ref_find_ok) && T.trans_cls != nullptr;
+      const uint32_t need = (uint32_t)T.nstates * T.stride * 2 + 512 + (ref ? (uint32_t)T.rm_nstates[0] * (T.stride * 2 + 1) : 0) + 128;
+      ok = ok && need <= 12 * 1024;
+    }
+    if (accepted) accepted[i] = ok ? 1 : 0;
+    if (ok) take.push_back(i);
+  }
+  if (take.empty() || m->device < 0) { delete m; SetError("no program of the list can take the multi-program pass"); return RGX_E_UNSUPPORTED; }
+  {
+    // Order: ^-anchored programs first, those that survive the same first bytes next to each other -- the kernel walks programs four at
+    // a time and skips a four none of whose programs the wave's lines can start (a line that begins with a digit keeps the IP, date
+    // and number validators and drops the rest in whole fours).  Output rows follow the caller's list whatever the order here.
+    auto sig = [&](int i) {
+      const Tables& t = progs[i]->p.t;
+      std::string k(33, '\0');
+      k[0] = t.anchored ? 0 : 1;
+      const int stride = t.ncls + 1;
+      for (int b = 0; b < 256; b++) {
+        const uint16_t ed = t.trans[(size_t)t.start[kCtxBOT] * stride + t.cls[b]];
+        if ((ed & kStateMask) != kDead || (ed & (kMatchBefore | kMatchAfter)) || t.start_accept[kCtxBOT]) k[1 + (b >> 3)] |= (char)(1 << (b & 7));
+      }
+      return k;
+    };
+    std::vector<std::pair<std::string, int>> keyed;
+    for (int i : take) keyed.push_back({sig(i), i});
+    std::stable_sort(keyed.begin(), keyed.end(), [](const std::pair<std::string, int>& a, const std::pair<std::string, int>& b) { return a.first < b.first; });
+    for (size_t k = 0; k < take.size(); k++) take[k] = keyed[k].second;
+  }
+  if (hipSetDevice(m->device) != hipSuccess) { delete m; return RGX_E_NO_DEVICE; }
+  const size_t esz = MultiEntBytes();
+  size_t at = 0;
+  while (at < take.size()) {
+    // greedy: as many programs as the LDS budget holds.  Image = [directory][first[256][2] u64], then the tables' LDS ranges
+    size_t cnt = 0;
+    std::vector<uint8_t> host;
+    uint32_t cursor = 0;
+    size_t first_off = 0;
+    for (;;) {
+      const size_t tryn = cnt + 1;
+      if (at + tryn > take.size() || tryn > 128) break;
+      const size_t fo = ((tryn * esz) + 15) & ~(size_t)15;
+      std::vector<uint8_t> h(fo + 256 * 16);
+      uint32_t cur = (uint32_t)h.size();
+      for (size_t k = 0; k < tryn; k++) {
+        const rgx_program* p = progs[take[at + k]];
+        FillMultiEnt(h.data(), (int)k, take[at + k], p->p.dev, !(p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS) && !p->p.t.anchored, &cur);   // (a ^-anchored program has one attempt: no restart rule to follow)
+      }
+      if (cur > kTablesBudget && cnt > 0) break;
+      host.swap(h); cursor = cur; cnt = tryn; first_off = fo;
+      if (cur > kTablesBudget) break;        // a single program over the budget still goes alone (it passed the 12 KiB test)
+    }
+    {
+      // first[b]: bit k = program k may survive (or match on) a first byte b; programs that are not ^-anchored keep every bit
+      uint64_t* first = reinterpret_cast<uint64_t*>(host.data() + first_off);
+      for (size_t k = 0; k < cnt; k++) {
+        const Tables& t = progs[take[at + k]]->p.t;
+        const int stride = t.ncls + 1;
+        for (int b = 0; b < 256; b++) {
+          const uint16_t ed = t.trans[(size_t)t.start[kCtxBOT] * stride + t.cls[b]];
+          const bool alive = !t.anchored || (ed & kStateMask) != kDead || (ed & (kMatchBefore | kMatchAfter)) || t.start_accept[kCtxBOT];
+          if (alive) first[b * 2 + (k >> 6)] |= 1ull << (k & 63);
+        }
+      }
+    }
+    rgx_multi::Group g;
+    g.nprog = (int)cnt; g.dir_bytes = (int)host.size(); g.first_off = (int)first_off; g.tables_end = (int)cursor;
+    if (hipMalloc(&g.d_dir, host.size()) != hipSuccess || hipMemcpy(g.d_dir, host.data(), host.size(), hipMemcpyHostToDevice) != hipSuccess) {
+      (void)hipGetLastError();
+      rgx_multi_destroy(m);
+      SetError("out of device memory (multi-program directory)");
+      return RGX_E_NOMEM;
+    }
+    m->groups.push_back(g);
+    at += cnt;
+  }
+  *out = m;
+  return (int)m->groups.size();
+}
+
+RGX_API void rgx_multi_destroy(rgx_multi* m) {
+  if (!m) return;
+  if (m->device >= 0) (void)hipSetDevice(m->device);
+  for (auto& g : m->groups) if (g.d_dir) (void)hipFree(g.d_dir);
+  delete m;
+}
+
+RGX_API int64_t rgx_find_batch_multi_device(const rgx_multi* m, rgx_stream_ctx* c, const uint8_t* d_concat, const uint64_t* d_offsets, size_t nstr,
+                                            uint64_t* d_found_bits, uint64_t* d_counts, int32_t* d_se) {
+  if (!m || !c || !d_offsets || !d_found_bits || !d_counts || (nstr && !d_concat)) return RGX_E_INVALID;
+  if (c->device != m->device) { SetError("context and programs live on different devices"); return RGX_E_INVALID; }
+  if (nstr == 0) return 0;
+  if (((uintptr_t)d_concat & 15)) { SetError("input device pointer must be 16-byte aligned"); return RGX_E_INVALID; }
+  HIP_TRY(hipSetDevice(m->device));
+  const int64_t words = ((int64_t)nstr + 63) / 64;
+  HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)m->n * 8, c->stream));
+  HIP_TRY(hipMemsetAsync(d_found_bits, 0, (size_t)m->n * (size_t)words * 8, c->stream));      // the kernel writes the nonzero words only
+  for (const auto& g : m->groups)
+    HIP_TRY(LaunchBatchMulti(reinterpret_cast<const MultiEnt*>(g.d_dir), g.nprog, g.dir_bytes, g.first_off, g.tables_end, d_concat, d_offsets, (int64_t)nstr,
+                             reinterpret_cast<unsigned long long*>(d_found_bits), words, reinterpret_cast<unsigned long long*>(d_counts), d_se,
+                             c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return (int64_t)m->groups.size();
 }
 
 // ---------------------------------------------------------------- host-buffer forms of MatchBytes / FindBytes / batch

@@ -131,4 +131,14 @@ hipError_t LaunchUtf8ScreenBatch(const uint8_t* src, const uint64_t* offsets, in
 hipError_t LaunchReaderCheck(const DevTables& T, const uint8_t* raw, const uint8_t* view, int32_t len, const int32_t* spans, int64_t n,
                              int ncap, unsigned* flag, hipStream_t stream);
 
+// One pass over a batch for many programs (rgx_kernels.hip: batch_multi_kernel).  d_dir: device array of MultiEnt (the host packs it:
+// rgx_capi.cc, rgx_multi_create) followed by first[256][2] u64 (bit p of first[b]: program p survives a first byte b), all of it
+// dir_bytes long and copied to LDS offset 0; first_off = where first[] begins; lds_tables_end = end of the last table's LDS range.  found_bits [nprog][words_per_prog] (bit i%64 of word i/64), counts [nprog] (added to), se [nprog][nstr][2] or nullptr.
+struct MultiEnt;
+size_t MultiEntBytes();
+void FillMultiEnt(void* dst, int index, int row, const DevTables& T, bool ref, uint32_t* lds_cursor);
+hipError_t LaunchBatchMulti(const MultiEnt* d_dir, int nprog, int dir_bytes, int first_off, int lds_tables_end, const uint8_t* concat,
+                            const uint64_t* offsets, int64_t nstr, unsigned long long* found_bits, int64_t words_per_prog,
+                            unsigned long long* counts, int32_t* se, hipStream_t stream);
+
 }  // namespace rgx

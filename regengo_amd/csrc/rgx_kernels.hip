@@ -2250,4 +2250,246 @@ hipError_t LaunchBatch(const DevTables& T, const uint8_t* concat, const uint64_t
   return hipGetLastError();
 }
 
+
+// ---- one pass over a batch of strings for MANY programs (BASELINE config C5: the ^/$-anchored patterns of the suite are matched
+// per line of the shared corpus -- 146 launches that each read the same gigabyte).  A workgroup stages the class-compressed
+// transition tables of a group of programs (a few hundred bytes each for whole-line validators), their class / context maps and --
+// reference mode -- their right-most-path automata into LDS once, then takes groups of 256 strings: the bytes are staged as in
+// batch_lds_kernel, every lane walks ITS string through program after program (the lanes of a wave are always in the same
+// program: table reads differ only by state and byte).  Per (program, string) the loop is batch_lds_kernel's, FindBytes flavour:
+// first start position with a match -- by the reference's restart rule (rm_* automaton, rv = 0) for programs in reference mode.
+// Output: one bit per (program, string) (ballot: a 64-bit word per wave and program), a count per program, and -- only for strings
+// with a match -- (start, end).  Capture records of matching strings come from the program's own rgx_find_batch_device.
+struct MultiEnt {
+  const uint16_t* g_trans; const uint8_t* g_cls; const uint8_t* g_ctx; const uint16_t* g_rm_trans; const uint8_t* g_rm_depth;
+  uint32_t o_trans, o_cls, o_ctx, o_rm_trans, o_rm_depth;      // LDS byte offsets
+  uint32_t n_trans, n_rm, n_rmst;                               // entries to stage
+  uint16_t stride, row;                                         // row: the program's index in the caller's list (output rows)
+  uint16_t start[4], rm_start[4];
+  uint8_t start_accept[4];
+  uint8_t anchored, ctx_sensitive, ref, pad1;
+};
+namespace {
+__global__ __launch_bounds__(kBlockThreads) void batch_multi_kernel(const MultiEnt* __restrict__ dir, int nprog, int dir_bytes, int first_off, int window_off,
+                                                                     const uint8_t* concat, const uint64_t* offsets, int64_t nstr,
+                                                                     unsigned long long* found_bits, int64_t words_per_prog,
+                                                                     unsigned long long* counts, int32_t* se, int window_bytes) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  // directory first, then every program's tables
+  for (int i = tid; i < dir_bytes / 4; i += kBlockThreads) reinterpret_cast<uint32_t*>(smem)[i] = reinterpret_cast<const uint32_t*>(dir)[i];
+  __syncthreads();
+  const MultiEnt* const D = reinterpret_cast<const MultiEnt*>(smem);
+  // first[b] (behind the directory in the image, copied with it): bit p = program p can survive or match on a first byte b -- whole-line
+  // validators die on the first byte of nearly every line, and a program no lane of the wave keeps is skipped with one ballot
+  const unsigned long long* const first = reinterpret_cast<const unsigned long long*>(smem + first_off);
+  for (int p = 0; p < nprog; ++p) {
+    const MultiEnt& E = D[p];
+    uint16_t* t = reinterpret_cast<uint16_t*>(smem + E.o_trans);
+    for (unsigned i = tid; i < E.n_trans; i += kBlockThreads) t[i] = E.g_trans[i];
+    smem[E.o_cls + tid] = E.g_cls[tid];
+    smem[E.o_ctx + tid] = E.g_ctx[tid];
+    if (E.ref) {
+      uint16_t* r = reinterpret_cast<uint16_t*>(smem + E.o_rm_trans);
+      for (unsigned i = tid; i < E.n_rm; i += kBlockThreads) r[i] = E.g_rm_trans[i];
+      for (unsigned i = tid; i < E.n_rmst; i += kBlockThreads) smem[E.o_rm_depth + i] = E.g_rm_depth[i];
+    }
+  }
+  unsigned char* const win = smem + window_off;
+  const int64_t ngroups = (nstr + kBlockThreads - 1) / kBlockThreads;
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const int64_t i0 = grp * kBlockThreads;
+    const int64_t i = i0 + tid;
+    const int64_t ilast = min(i0 + (int64_t)kBlockThreads, nstr);
+    const uint64_t gb = offsets[i0], ge = offsets[ilast];
+    const uint64_t wb = gb & ~15ull;
+    const int wvalid = (int)min((uint64_t)window_bytes, ((ge - wb) + 15ull) & ~15ull);
+    __syncthreads();
+    for (int c = tid; c < (wvalid >> 4); c += kBlockThreads)
+      *reinterpret_cast<uint4*>(win + (c << 4)) = *reinterpret_cast<const uint4*>(concat + wb + ((uint64_t)c << 4));
+    uint64_t o0 = 0, o1 = 0;
+    if (i < nstr) { o0 = offsets[i]; o1 = offsets[i + 1]; }
+    __syncthreads();
+    BatchInput in;
+    in.g = concat + o0; in.lds = win; in.rel0 = (int)min(o0 - wb, (uint64_t)0x3FFFFFFF); in.wvalid = wvalid; in.len = (int)(o1 - o0);
+    const int wv = tid >> 6, ln = tid & 63;
+    const Lds8 winl = (Lds8)win;
+    unsigned long long cand0 = 0, cand1 = 0;
+    if (i < nstr) {
+      if (in.len == 0) cand0 = cand1 = ~0ull;          // the empty string: the end-of-text step decides
+      else { const int b0 = in.At(0); cand0 = first[b0 * 2]; cand1 = first[b0 * 2 + 1]; }
+    }
+    // Programs are walked FOUR at a time: the walk of one is a chain of dependent LDS reads (byte -> class -> edge) with a handful
+    // of instructions between them -- latency, not issue -- and four independent chains keep four reads in flight.  ^-anchored
+    // programs (all of a validator suite) need one attempt, and its outcome is the same under the reference's restart rule.
+    for (int p0 = 0; p0 < nprog; p0 += 4) {
+      const unsigned bits4 = (unsigned)((p0 < 64 ? cand0 >> p0 : cand1 >> (p0 - 64)) & 0xFull);
+      if (!__any(bits4 != 0)) continue;                       // (the rows were zeroed by the host)
+      const int np = nprog - p0 < 4 ? nprog - p0 : 4;
+      // (the directory is read through `dir`, not its LDS copy: the index is wave-uniform, so these are scalar loads into SGPRs and
+      // the table bases cost no vector instruction -- SQ counters of the first version: 620 M VALU + 537 M SALU wave-instructions per
+      // launch against 78 M LDS, a kernel bound by instruction issue, most of it the per-four set-up)
+      bool all_anchored = true;
+      for (int j = 0; j < np; ++j) all_anchored &= dir[p0 + j].anchored != 0;
+      int s4[4] = {-1, -1, -1, -1}, e4[4] = {-1, -1, -1, -1};
+      if (all_anchored) {
+        Lds16 t4[4]; Lds8 c4[4]; unsigned st4[4], q4[4]; int end4[4]; bool live[4];      // (LDS-qualified: a plain pointer here is a FLAT load)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const MultiEnt& E = dir[p0 + (j < np ? j : 0)];
+          t4[j] = (Lds16)(smem + E.o_trans); c4[j] = (Lds8)(smem + E.o_cls); st4[j] = E.stride;
+          q4[j] = E.start[kCtxBOT]; end4[j] = E.start_accept[kCtxBOT] ? 0 : -1;
+          live[j] = j < np && i < nstr && ((bits4 >> j) & 1u);
+        }
+        int at = 0;
+        while (live[0] | live[1] | live[2] | live[3]) {
+          const bool eot = at >= in.len;
+          int byte = 0;
+          if (!eot) {
+            const unsigned r = (unsigned)(in.rel0 + at);
+            byte = r < (unsigned)in.wvalid ? (int)winl[r] : (int)in.g[at];
+          }
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            if (live[j]) {
+              const unsigned k = eot ? st4[j] - 1 : (unsigned)c4[j][byte];
+              const unsigned ed = t4[j][q4[j] * st4[j] + k];
+              if (ed & kMatchBefore) end4[j] = at;
+              if (ed & kMatchAfter) end4[j] = at + 1;
+              q4[j] = ed & kStateMask;
+              if (q4[j] == kDead || eot) live[j] = false;
+            }
+          }
+          ++at;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (end4[j] >= 0 && j < np && i < nstr && ((bits4 >> j) & 1u)) { s4[j] = 0; e4[j] = end4[j]; }
+      } else {
+        for (int j = 0; j < np; ++j) {
+          const MultiEnt& E = D[p0 + j];
+          const bool mine = ((bits4 >> j) & 1u) != 0;
+          const uint16_t* const t = reinterpret_cast<const uint16_t*>(smem + E.o_trans);
+          const uint8_t* const cls = smem + E.o_cls;
+          const uint8_t* const ctxb = smem + E.o_ctx;
+          const uint16_t* const rm_trans = reinterpret_cast<const uint16_t*>(smem + E.o_rm_trans);
+          const uint8_t* const rm_depth = smem + E.o_rm_depth;
+          const unsigned stride = E.stride, eotc = stride - 1;
+          const bool REF = E.ref != 0;
+          int s = -1, e = -1;
+          if (i < nstr && (mine || !E.anchored)) {
+            int pos = 0, at = 0, end = -1;
+            unsigned q = 0, rq = 0;
+            int rfo = -1;
+            bool fresh = true;
+            while (true) {
+              if (fresh) {
+                int ctx = kCtxOther;
+                if (pos == 0) ctx = kCtxBOT;
+                else if (E.ctx_sensitive || REF) ctx = ctxb[in.At(pos - 1)];
+                q = E.start[ctx];
+                end = E.start_accept[ctx] ? pos : -1;
+                at = pos;
+                fresh = false;
+                if (REF) { rq = E.rm_start[ctx]; rfo = -1; }
+              }
+              const bool eot = at >= in.len;
+              const unsigned k = eot ? eotc : (unsigned)cls[in.At(at)];
+              const unsigned ed = t[q * stride + k];
+              if (ed & kMatchBefore) end = at;
+              if (ed & kMatchAfter) end = at + 1;
+              q = ed & kStateMask;
+              if (REF && rfo < 0) {
+                const unsigned nx = rm_trans[rq * stride + k];
+                if (nx == 0xFFFFu) rfo = at - (int)rm_depth[rq]; else rq = nx;
+              }
+              if (q == kDead || eot) {
+                if (end >= 0) { s = pos; e = end; break; }
+                if (E.anchored) break;
+                if (!REF) {
+                  ++pos;
+                  if (pos > in.len) break;
+                } else {
+                  if (rfo < 0 && !eot) { ++at; continue; }      // the DFA is dead, the right-most path is not: walk on until it is
+                  const int fo = rfo < 0 ? at : rfo;
+                  if (!(in.len > fo)) break;
+                  pos = fo + 1;
+                }
+                fresh = true;
+              } else {
+                ++at;
+              }
+            }
+          }
+          s4[j] = s; e4[j] = e;
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (j >= np) break;
+        const unsigned long long m = __ballot(s4[j] >= 0);
+        if (m) {
+          const int row = dir[p0 + j].row;
+          if (ln == 0) {
+            found_bits[(int64_t)row * words_per_prog + (i0 >> 6) + wv] = m;
+            atomicAdd(counts + row, (unsigned long long)__popcll(m));
+          }
+          if (se && s4[j] >= 0) { se[((int64_t)row * nstr + i) * 2] = s4[j]; se[((int64_t)row * nstr + i) * 2 + 1] = e4[j]; }
+        }
+      }
+    }
+  }
+}
+}  // namespace
+
+size_t MultiEntBytes() { return sizeof(MultiEnt); }
+// Host: entry `index` of a directory under construction; *lds_cursor = next free LDS byte (the caller starts it behind the directory).
+void FillMultiEnt(void* dst, int index, int row, const DevTables& T, bool ref, uint32_t* lds_cursor) {
+  MultiEnt& E = reinterpret_cast<MultiEnt*>(dst)[index];
+  E = MultiEnt{};
+  E.row = (uint16_t)row;
+  auto take = [&](uint32_t bytes) { const uint32_t at = *lds_cursor; *lds_cursor += (bytes + 15u) & ~15u; return at; };
+  E.g_trans = T.trans_cls; E.g_cls = T.cls; E.g_ctx = T.ctx_of_byte; E.g_rm_trans = T.rm_trans[0]; E.g_rm_depth = T.rm_depth[0];
+  E.stride = (uint16_t)T.stride;
+  E.n_trans = (uint32_t)T.nstates * (uint32_t)T.stride;
+  E.o_trans = take(E.n_trans * 2); E.o_cls = take(256); E.o_ctx = take(256);
+  E.ref = ref ? 1 : 0;
+  if (ref) {
+    E.n_rmst = (uint32_t)T.rm_nstates[0]; E.n_rm = E.n_rmst * (uint32_t)T.stride;
+    E.o_rm_trans = take(E.n_rm * 2); E.o_rm_depth = take(E.n_rmst);
+  }
+  for (int k = 0; k < 4; k++) { E.start[k] = T.start[k]; E.rm_start[k] = T.rm_start[0][k]; E.start_accept[k] = T.start_accept[k]; }
+  E.anchored = T.anchored; E.ctx_sensitive = T.ctx_sensitive;
+}
+
+hipError_t LaunchBatchMulti(const MultiEnt* d_dir, int nprog, int dir_bytes, int first_off, int lds_tables_end, const uint8_t* concat,
+                            const uint64_t* offsets, int64_t nstr, unsigned long long* found_bits, int64_t words_per_prog,
+                            unsigned long long* counts, int32_t* se, hipStream_t stream) {
+  if (nprog <= 0 || nstr <= 0) return hipSuccess;
+  const int window_off = (lds_tables_end + 15) & ~15;
+  // 256 log lines are ~19 KiB; a 16 KiB window (the tail of a group reads through L2) and a 20 KiB table budget keep three workgroups
+  // on a CU: measured 8.5 ms per pass of the suite's 156 validators against 12.0 with 32 + 40 KiB
+  const int window_bytes = getenv("RGX_MULTI_WINDOW") ? atoi(getenv("RGX_MULTI_WINDOW")) : kBatchWindow;
+  const size_t lds = (size_t)window_off + window_bytes + 16;
+  static bool attr = false;
+  if (!attr) {
+    hipError_t e = hipFuncSetAttribute((const void*)batch_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return e;
+    attr = true;
+  }
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
+  }
+  int per_cu = (int)((160 * 1024) / (lds + 1024));
+  if (per_cu < 1) per_cu = 1;
+  if (per_cu > 8) per_cu = 8;
+  const int64_t ngroups = (nstr + kBlockThreads - 1) / kBlockThreads;
+  int64_t grid = (int64_t)cus * per_cu;
+  if (grid > ngroups) grid = ngroups;
+  hipLaunchKernelGGL(batch_multi_kernel, dim3((unsigned)grid), dim3(kBlockThreads), lds, stream, d_dir, nprog, dir_bytes, first_off, window_off, concat,
+                     offsets, nstr, found_bits, words_per_prog, counts, se, window_bytes);
+  return hipGetLastError();
+}
+
 }  // namespace rgx
