@@ -197,6 +197,14 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   static const bool force_w = ExpEnv("RGX_FORCE_W") != nullptr;
   const bool w_ok = ScanSupportsW(T, ilen);
   bool use_w = w_ok && (c->prefer_w || T.reset_values == 0 || force_w);
+  // Programs of the one-step-per-byte kernels that have no reset byte at all (a thread may survive any byte: `(\s.*)?` behind an
+  // e-mail address, `[^\]]+`) used to fall back to the generic kernel with its attempt per start position (33 ms per GiB for the
+  // e-mail + rest-of-line pattern).  They keep their kernel now: the exact sync points of the sync automaton (LaunchWSync: one
+  // optimistic walk per 4 KiB chunk + repair) are handed over as per-slice start positions, like the carry pass's.
+  static const bool no_us_ws = ExpEnv("RGX_NO_US_WSYNC") != nullptr;
+  const bool us_ws = use_w && !no_us_ws && T.reset_values == 0 && UseUsKernel(T, ilen, false) && UsKernelVariant(T) != 4 &&     // (the register kernel
+                     p->prefer_wsync.load(std::memory_order_relaxed) != -2;      // walks every slice from behind: slower than the generic kernel's W path, measured)
+  if (us_ws) use_w = false;
   int32_t ntiles = ScanNumTiles(T, ilen, use_w);
   const int32_t ntiles_max = std::max(ntiles, std::max(ScanNumTiles(T, ilen, false), ScanNumTiles(T, ilen, true)));
   const int32_t nslices = (ilen + kSliceBytes - 1) / kSliceBytes;
@@ -285,9 +293,46 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     carry_ready = true;
     return RGX_OK;
   };
+  if (us_ws) {
+    if ((rc = Ensure(&c->d_carry, &c->carry_cap, (int64_t)nslices + 64)) != RGX_OK) return rc;
+    const int32_t nchunks = WSyncChunks(ilen);
+    if ((rc = Ensure(&c->d_trace, &c->trace_cap, 2 * (int64_t)nchunks + 64)) != RGX_OK) return rc;
+    uint32_t* d_stats = (uint32_t*)(c->d_carry + nslices + 8);
+    const bool fine = UsKernelVariant(T) != 4;
+    HIP_TRY(LaunchWSync(T, d_buf, ilen, c->d_carry, c->d_trace, d_stats, c->stream, fine));
+    uint32_t h_stats[2] = {0, 0};
+    HIP_TRY(hipMemcpyAsync(h_stats, d_stats, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (h_stats[1]) HIP_TRY(LaunchWSyncOrdered(T, d_buf, ilen, c->d_carry, c->d_trace, d_stats, c->stream, fine));
+    // the register-free kernels walk from a sync point to the next one, however far: slices without one are "covered"; the
+    // register kernel's lanes each walk their own slice from the nearest sync point at or before it: filled in from behind
+    if (UsKernelVariant(T) == 4) HIP_TRY(LaunchWSyncFill(c->d_carry, ilen, c->stream));
+    else HIP_TRY(LaunchWSyncCover(c->d_carry, ilen, c->stream));
+    P.carry_in = c->d_carry;
+    P.carry_sync = 1;
+    if ((rc = run_scan(c->timing)) != RGX_OK) return rc;
+    if (((uint32_t*)&c->h_read[2])[3]) {
+      P.use_tickets = 1;
+      if ((rc = run_scan(c->timing)) != RGX_OK) return rc;
+      if (((uint32_t*)&c->h_read[2])[3]) { SetError("look-back timed out in ticket mode"); return RGX_E_HIP; }
+    }
+    if (((uint32_t*)&c->h_read[2])[1]) {
+      // (the register kernel found a slice whose nearest sync point lies further back than the fill reaches: this program's texts
+      // go back to the generic kernel, which looks further)
+      p->prefer_wsync.store(-2, std::memory_order_relaxed);
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      c->dirty[0] = c->dirty[1] = c->set_words;
+      return FindAllDevice(p, c, d_buf, len, n, d_spans, cap_records, count_only, res, starts_only, own_lo, own_hi);
+    }
+  }
   const int pws = p->prefer_wsync.load(std::memory_order_relaxed);      // 1: exact sync points first; -1: tried, the carry pass is cheaper
   const bool learn_ws = use_w && pws == 0;
   const bool tm = c->timing || learn_ws;
+  float ms = 0;
+  uint32_t unsynced = 0;
+  if (us_ws) {
+    if (c->timing) (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+  } else {
   if (use_w && pws > 0) { if ((rc = wsync()) != RGX_OK) return rc; }
   if (!UseExactKernel(T, ilen)) {
     if ((rc = Ensure(&c->d_unsynced, &c->slice_cap, nslices)) != RGX_OK) return rc;
@@ -304,9 +349,8 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     if ((rc = run_scan(tm)) != RGX_OK) return rc;
     if (((uint32_t*)&c->h_read[2])[3]) { SetError("look-back timed out in ticket mode"); return RGX_E_HIP; }
   }
-  float ms = 0;
   if (tm) (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
-  uint32_t unsynced = ((uint32_t*)&c->h_read[2])[1];
+  unsynced = ((uint32_t*)&c->h_read[2])[1];
   if (unsynced && !use_w && UseUsKernel(T, ilen, false)) {
     // the one-step-per-byte kernels: slices without a sync point in reach get their search positions from ONE walk of the
     // start-tracking automaton per run (LaunchCarryUs) -- linear, where the attempt-per-start carry pass below is quadratic
@@ -380,6 +424,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     P.carry_in = c->d_carry;
     if ((rc = run_scan(false)) != RGX_OK) return rc;
   }
+  }   // !us_ws
   // more than one lane in fifty finished in the single-step walker: this program's texts rewind (`a.*b.*c`), later scans take the
   // kernel instance that rewinds in its fast walk (8 % slower per byte, many times faster than the walker)
   if (!P.us_rewind && (int64_t)((uint32_t*)&c->h_read[2])[2] * 50 > (int64_t)nslices) p->prefer_rw.store(1, std::memory_order_relaxed);

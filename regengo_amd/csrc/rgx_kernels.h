@@ -28,6 +28,9 @@ struct ScanParams {
   int32_t use_tickets;           // 1: tile/group ids from the ticket counter; 0: blockIdx.x (bounded spin, host falls back)
   int32_t us_rewind;             // pair kernel: take the instance that rewinds inside its fast walk (the program's earlier scans sent
                                  // many lanes to the single-step walker: counters[2])
+  int32_t carry_sync;            // 1: every carry_in position is a sync point in the strict sense (no thread that started before it is
+                                 // alive there: the sync automaton's answer) -- a stretch that ends at one needs no special care, unlike
+                                 // the carry pass's search positions, behind which an older thread may still decide a match's finality
   int32_t debug;                 // experiment switches (RGX_DEBUG): 1 = unordered base (no look-back), 2 = no span stores
 };
 
@@ -59,11 +62,14 @@ hipError_t LaunchCarry(const DevTables& T, const uint8_t* buf, int32_t len, cons
 // Exact sync points from the sync automaton walked optimistically over 4 KiB chunks + ordered repair (rgx_kernels.hip):
 // carry_in[slice] = the slice's offset where FindAll provably stands there, else -1.  scratch: 2*WSyncChunks(len)+16
 // uint16; stats: one uint32 (chunks walked in the serial pass).
+// fine: carry_in[slice] = the FIRST offset of the slice at which the loop provably stands (for the one-step-per-byte kernels).
 hipError_t LaunchWSync(const DevTables& T, const uint8_t* buf, int32_t len, int32_t* carry_in, uint16_t* scratch, uint32_t* stats,
-                       hipStream_t stream);
+                       hipStream_t stream, bool fine = false);
 hipError_t LaunchWSyncOrdered(const DevTables& T, const uint8_t* buf, int32_t len, int32_t* carry_in, uint16_t* scratch, uint32_t* stats,
-                              hipStream_t stream);
+                              hipStream_t stream, bool fine = false);
 hipError_t LaunchWSyncFill(int32_t* carry_in, int32_t len, hipStream_t stream);
+// the same for the one-step-per-byte kernels: slices that are not sync points are marked as covered by an earlier lane's stretch
+hipError_t LaunchWSyncCover(int32_t* carry_in, int32_t len, hipStream_t stream);
 int32_t WSyncChunks(int32_t len);
 // true when the scan of `len` bytes would run a kernel that can take its sync points from W (ScanParams::use_w)
 bool ScanSupportsW(const DevTables& T, int32_t len);

@@ -539,6 +539,38 @@ __device__ __forceinline__ unsigned WalkWSlice(const uint16_t* w, const uint8_t*
   return q;
 }
 
+// the same walk, also telling the FIRST offset of [a, a+64) at which the state is empty (-1: none): `first` comes in as a when the
+// entry state is empty.  For the one-step-per-byte kernels (FINE): their stretches then end at the first sync point of a slice, not
+// at the first slice that happens to BEGIN with one -- short stretches, and at most one match pending where a stretch leaves its tile.
+__device__ __forceinline__ unsigned WalkWSliceFirst(const uint16_t* w, const uint8_t* cls, int ncls, const uint8_t* buf, int len, int a,
+                                                    unsigned q, int* first) {
+  int f = q == 0 ? a : -1;
+  const int end = a + kSliceBytes <= len ? a + kSliceBytes : len;
+  if (a + kSliceBytes <= len) {
+    const uint4* src = reinterpret_cast<const uint4*>(buf + a);
+#pragma unroll 1
+    for (int v = 0; v < 4; ++v) {
+      const uint4 x = src[v];
+      const unsigned ws[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+      for (int d = 0; d < 4; ++d)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          q = w[q * ncls + cls[(ws[d] >> (8 * b)) & 0xFFu]];
+          const int at = a + v * 16 + d * 4 + b + 1;          // the state now stands at this offset
+          f = (f < 0 && q == 0 && at < end) ? at : f;
+        }
+    }
+  } else {
+    for (int i = a; i < len; ++i) {
+      q = w[q * ncls + cls[buf[i]]];
+      f = (f < 0 && q == 0 && i + 1 < end) ? i + 1 : f;
+    }
+  }
+  *first = f;
+  return q;
+}
+
 __device__ __forceinline__ void StageW(const DevTables& T, unsigned char* smem, int tid, int nthreads) {
   uint8_t* s_cls = smem;
   uint16_t* s_w = reinterpret_cast<uint16_t*>(smem + 256);
@@ -548,6 +580,7 @@ __device__ __forceinline__ void StageW(const DevTables& T, unsigned char* smem, 
 }
 
 // chunk_info[c] = optimistic exit state | (blind walk emptied inside the chunk) << 15
+template <bool FINE>
 __global__ __launch_bounds__(kBlockThreads) void w_opt_kernel(DevTables T, const uint8_t* buf, int32_t len, int32_t* carry_in,
                                                                uint16_t* chunk_info, int32_t nchunks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -562,8 +595,14 @@ __global__ __launch_bounds__(kBlockThreads) void w_opt_kernel(DevTables T, const
   for (int j = 0; j < kWChunkSlices; ++j) {
     const int a = c * kWChunkBytes + j * kSliceBytes;
     if (a >= len) break;
-    carry_in[a >> 6] = qo == 0 ? a : -1;
-    qo = WalkWSlice(s_w, s_cls, ncls, buf, len, a, qo);
+    if (FINE) {
+      int f;
+      qo = WalkWSliceFirst(s_w, s_cls, ncls, buf, len, a, qo, &f);
+      carry_in[a >> 6] = f;
+    } else {
+      carry_in[a >> 6] = qo == 0 ? a : -1;
+      qo = WalkWSlice(s_w, s_cls, ncls, buf, len, a, qo);
+    }
     if (!emptied) {
       // the blind walk is only needed until it empties (checked per byte inside the slice would be finer; per slice
       // boundary is enough: empty at a boundary => equal to the optimistic walk from there on)
@@ -623,6 +662,7 @@ __global__ __launch_bounds__(64) void w_fix_kernel(DevTables T, const uint8_t* b
 // state.  Lane c walks from that state until it empties (from there the optimistic answers stand) and fixes the slice
 // flags on the way.  If every chunk either is entered empty or empties inside, induction from chunk 0 (entered empty)
 // shows every assumption was right; chunks that do not empty are counted in *n_bad and the ordered pass takes over.
+template <bool FINE>
 __global__ __launch_bounds__(kBlockThreads) void w_spec_kernel(DevTables T, const uint8_t* buf, int32_t len, int32_t* carry_in,
                                                                 const uint16_t* chunk_info, int32_t nchunks, uint32_t* n_bad) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -636,13 +676,23 @@ __global__ __launch_bounds__(kBlockThreads) void w_spec_kernel(DevTables T, cons
   for (int j = 0; j < kWChunkSlices; ++j) {
     const int a = c * kWChunkBytes + j * kSliceBytes;
     if (a >= len) return;
-    carry_in[a >> 6] = -1;
-    q = WalkWSlice(s_w, s_cls, T.ncls, buf, len, a, q);
+    if (FINE) {
+      // the true state of this slice: its first empty offset replaces the optimistic one (which, a subset's, may lie earlier);
+      // from the offset where the true state empties on, both walks are the same -- the rest of the chunk stands
+      int f;
+      q = WalkWSliceFirst(s_w, s_cls, T.ncls, buf, len, a, q, &f);
+      carry_in[a >> 6] = f;
+      if (f >= 0) return;
+    } else {
+      carry_in[a >> 6] = -1;
+      q = WalkWSlice(s_w, s_cls, T.ncls, buf, len, a, q);
+    }
     if (q == 0) return;
   }
   atomicAdd(n_bad, 1u);
 }
 
+template <bool FINE>
 __global__ __launch_bounds__(kBlockThreads) void w_repair_kernel(DevTables T, const uint8_t* buf, int32_t len, int32_t* carry_in,
                                                                   const uint16_t* entry, int32_t nchunks) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -659,8 +709,15 @@ __global__ __launch_bounds__(kBlockThreads) void w_repair_kernel(DevTables T, co
     if (a >= len) break;
     if (unknown) { carry_in[a >> 6] = -1; continue; }      // nothing is vouched for in this chunk
     if (q == 0) break;                                     // converged: the rest was right already
-    carry_in[a >> 6] = -1;
-    q = WalkWSlice(s_w, s_cls, T.ncls, buf, len, a, q);
+    if (FINE) {
+      int f;
+      q = WalkWSliceFirst(s_w, s_cls, T.ncls, buf, len, a, q, &f);
+      carry_in[a >> 6] = f;
+      if (f >= 0) break;                                   // emptied inside this slice: from there on the optimistic walk is the true one
+    } else {
+      carry_in[a >> 6] = -1;
+      q = WalkWSlice(s_w, s_cls, T.ncls, buf, len, a, q);
+    }
   }
 }
 
@@ -1814,30 +1871,52 @@ __global__ __launch_bounds__(kBlockThreads) void w_fill_kernel(int32_t* carry_in
 
 // stage 1: optimistic chunk walk + parallel speculation; stats[1] = chunks the speculation could not settle
 hipError_t LaunchWSync(const DevTables& T, const uint8_t* buf, int32_t len, int32_t* carry_in, uint16_t* scratch, uint32_t* stats,
-                       hipStream_t stream) {
+                       hipStream_t stream, bool fine) {
   const int nchunks = (len + kWChunkBytes - 1) / kWChunkBytes;
   const size_t shmem = 256 + (((size_t)T.w_nstates * T.ncls * 2 + 15) & ~size_t(15));
   uint16_t* chunk_info = scratch;
   const dim3 grid((nchunks + kBlockThreads - 1) / kBlockThreads), block(kBlockThreads);
   hipError_t e = hipMemsetAsync(stats, 0, 8, stream);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(w_opt_kernel, grid, block, shmem, stream, T, buf, len, carry_in, chunk_info, nchunks);
-  hipLaunchKernelGGL(w_spec_kernel, grid, block, shmem, stream, T, buf, len, carry_in, chunk_info, nchunks, stats + 1);
+  if (fine) {
+    hipLaunchKernelGGL(w_opt_kernel<true>, grid, block, shmem, stream, T, buf, len, carry_in, chunk_info, nchunks);
+    hipLaunchKernelGGL(w_spec_kernel<true>, grid, block, shmem, stream, T, buf, len, carry_in, chunk_info, nchunks, stats + 1);
+  } else {
+    hipLaunchKernelGGL(w_opt_kernel<false>, grid, block, shmem, stream, T, buf, len, carry_in, chunk_info, nchunks);
+    hipLaunchKernelGGL(w_spec_kernel<false>, grid, block, shmem, stream, T, buf, len, carry_in, chunk_info, nchunks, stats + 1);
+  }
   return hipGetLastError();
 }
 // stage 2 (only when stats[1] != 0): redo the flags from scratch with the ordered pass
 hipError_t LaunchWSyncOrdered(const DevTables& T, const uint8_t* buf, int32_t len, int32_t* carry_in, uint16_t* scratch, uint32_t* stats,
-                              hipStream_t stream) {
+                              hipStream_t stream, bool fine) {
   const int nchunks = (len + kWChunkBytes - 1) / kWChunkBytes;
   const size_t shmem = 256 + (((size_t)T.w_nstates * T.ncls * 2 + 15) & ~size_t(15));
   uint16_t* chunk_info = scratch;
   uint16_t* entry = scratch + nchunks + 8;
   const dim3 grid((nchunks + kBlockThreads - 1) / kBlockThreads), block(kBlockThreads);
-  hipLaunchKernelGGL(w_opt_kernel, grid, block, shmem, stream, T, buf, len, carry_in, chunk_info, nchunks);
+  if (fine) hipLaunchKernelGGL(w_opt_kernel<true>, grid, block, shmem, stream, T, buf, len, carry_in, chunk_info, nchunks);
+  else hipLaunchKernelGGL(w_opt_kernel<false>, grid, block, shmem, stream, T, buf, len, carry_in, chunk_info, nchunks);
   hipLaunchKernelGGL(w_fix_kernel, dim3(1), dim3(64), shmem, stream, T, buf, len, chunk_info, entry, nchunks, stats);
-  hipLaunchKernelGGL(w_repair_kernel, grid, block, shmem, stream, T, buf, len, carry_in, entry, nchunks);
+  if (fine) hipLaunchKernelGGL(w_repair_kernel<true>, grid, block, shmem, stream, T, buf, len, carry_in, entry, nchunks);
+  else hipLaunchKernelGGL(w_repair_kernel<false>, grid, block, shmem, stream, T, buf, len, carry_in, entry, nchunks);
   return hipGetLastError();
 }
+namespace {
+// For the one-step-per-byte kernels (rgx_scan_us.hip) the stage-2 result is complete as it stands: a slice whose own offset is a
+// proven sync point starts a lane's stretch there, every other slice is covered by the stretch of the nearest such lane behind it
+// (those kernels walk on until the next sync point, however far).  "Covered" is any non-negative position outside the slice.
+__global__ __launch_bounds__(kBlockThreads) void w_cover_kernel(int32_t* carry_in, int32_t nslices) {
+  const int s = blockIdx.x * kBlockThreads + threadIdx.x;
+  if (s < nslices && carry_in[s] < 0) carry_in[s] = 0x7FFFFFF0;
+}
+}  // namespace
+hipError_t LaunchWSyncCover(int32_t* carry_in, int32_t len, hipStream_t stream) {
+  const int nslices = (len + kSliceBytes - 1) / kSliceBytes;
+  hipLaunchKernelGGL(w_cover_kernel, dim3((nslices + kBlockThreads - 1) / kBlockThreads), dim3(kBlockThreads), 0, stream, carry_in, nslices);
+  return hipGetLastError();
+}
+
 // stage 3: slices that are not sync points start from the nearest proven one behind them
 hipError_t LaunchWSyncFill(int32_t* carry_in, int32_t len, hipStream_t stream) {
   const int nslices = (len + kSliceBytes - 1) / kSliceBytes;

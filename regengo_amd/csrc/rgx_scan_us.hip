@@ -801,10 +801,11 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_simple_kernel(DevTables
       const int k0 = (tile + 1) * kBlockThreads;
       int found = -1;
       // (with the carry pass's positions at hand the search goes as far as it must: a match may run for kilobytes past the tile)
-      const int klim = P.carry_in ? 0x7FFFFFF : k0 + kSReach / kSliceBytes - 1;
+      const int klim = (P.carry_in && !P.carry_sync) ? 0x7FFFFFF : k0 + kSReach / kSliceBytes - 1;     // (sync-automaton positions: a stretch has to end
+                                                                                                    // within the bit sets' reach, or the program goes back to the generic kernel)
       for (int k = k0; k < klim && k * kSliceBytes < len && found < 0; ++k) { found = SliceStart(in, P.carry_in, k); ek = k; }
       if (found >= 0) e = found;
-      else if (!P.carry_in && k0 * kSliceBytes + kSReach - kSliceBytes < len) {
+      else if (!(P.carry_in && !P.carry_sync) && k0 * kSliceBytes + kSReach - kSliceBytes < len) {
         // no sync point in reach and the text goes on: leave the stretch to the carry pass
         atomicAdd(&P.counters[1], 1u);
         if (P.slice_unsynced && k0 * kSliceBytes < len) P.slice_unsynced[k0] = 1;
@@ -893,7 +894,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_simple_kernel(DevTables
     // position IS that match's end, and the byte that would make it final lies beyond the stretch: the single-step walker
     // finishes such stretches.  (Behind a reset byte nothing is pending, so the common scan never takes this path; testing the
     // parked row's pending bit instead sent every lane whose TRIP ended inside a later match to the slow walker: 5x.)
-    const bool carry_end = P.carry_in != nullptr && ek >= 0 && found_carry(P.carry_in, ek);
+    const bool carry_end = P.carry_in != nullptr && !P.carry_sync && ek >= 0 && found_carry(P.carry_in, ek);
     if (fast && ((zrow & 0xFFFFu) == kSZoff || carry_end)) slow = true;
   }
   US_STAMP()
@@ -1227,10 +1228,11 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
     } else {
       const int k0 = (tile + 1) * kBlockThreads;
       int found = -1;
-      const int klim = P.carry_in ? 0x7FFFFFF : k0 + kSReach / kSliceBytes - 1;
+      const int klim = (P.carry_in && !P.carry_sync) ? 0x7FFFFFF : k0 + kSReach / kSliceBytes - 1;     // (sync-automaton positions: a stretch has to end
+                                                                                                    // within the bit sets' reach, or the program goes back to the generic kernel)
       for (int k = k0; k < klim && k * kSliceBytes < len && found < 0; ++k) { found = PSliceStart(in, P.carry_in, k); ek = k; }
       if (found >= 0) e = found;
-      else if (!P.carry_in && k0 * kSliceBytes + kSReach - kSliceBytes < len) {
+      else if (!(P.carry_in && !P.carry_sync) && k0 * kSliceBytes + kSReach - kSliceBytes < len) {
         atomicAdd(&P.counters[1], 1u);
         if (P.slice_unsynced && k0 * kSliceBytes < len) P.slice_unsynced[k0] = 1;
         s = -1;
@@ -1325,7 +1327,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
 #undef USP_STEP
 #undef USP_FLUSH
     // rewind, or a stretch that ends at a carry-pass position (scan_us_simple_kernel has the commentary)
-    const bool carry_end = P.carry_in != nullptr && ek >= 0 && found_carry(P.carry_in, ek);
+    const bool carry_end = P.carry_in != nullptr && !P.carry_sync && ek >= 0 && found_carry(P.carry_in, ek);
     const bool zpark = fast && (zrow & 0xFFFFu) == kPZoff;
     if (RW && !carry_end) {
       if (zpark) {

@@ -26,6 +26,8 @@ for seed in range(first, first + nseeds):
             continue
         try:
             c = Compiled(p).to(0)
+            if not c.info.ref_findall_offered:          # Tagged-DFA class: refused in reference mode; the kernels are under test here
+                c = Compiled(p, stdlib=True).to(0)
         except _capi.RgxError:
             refused += 1
             continue
@@ -50,7 +52,12 @@ for seed in range(first, first + nseeds):
             tot += 1
             if not (res.total == cnt and got.shape == exp.shape and np.array_equal(got, exp)):
                 bad += 1
-                print("MISMATCH seed", seed, repr(p), "n", len(b), "gpu", int(res.total), "oracle", cnt, flush=True)
+                print("MISMATCH seed", seed, repr(p), "n", len(b), "gpu", int(res.total), "oracle", cnt, "kernel", c.info.scan_kernel, flush=True)
+                m = min(len(got), len(exp))
+                d = np.nonzero((got[:m] != exp[:m]).any(axis=1))[0]
+                if len(d):
+                    k = int(d[0])
+                    print("   row", k, "gpu", got[k].tolist(), "oracle", exp[k].tolist(), "text", b[max(0, exp[k][0] - 12):exp[k][1] + 12], flush=True)
                 if bad > 20:
                     sys.exit(1)
     print("seed", seed, "done; compared", tot, "bad", bad, "refused", refused, "%.0fs" % (time.time() - t0), flush=True)
