@@ -107,8 +107,9 @@ typedef struct rgx_info {
                               * reference memoises -- RGX_E_UNSUPPORTED, the generated stub keeps the Go function           */
   int32_t ref_find_offered;  /* the same for FindBytes / FindBytesReuse (plain backtracking engine only).  All four ref_*_offered
                               * read 1 for a program compiled with RGX_FLAG_STDLIB_SEMANTICS: every entry point answers then   */
-  int32_t unicode_version; /* UCD version behind \p{..}: 0xMMmmpp (0x0E0000 = 14.0.0).  The reference's tables are Go 1.24's
-                            * `unicode` package = 15.0.0: code points first assigned in 15.0 are unassigned here       */
+  int32_t unicode_version; /* UCD version behind \p{..}: 0xMMmmpp.  0x0F0000 = 15.0.0, the version of Go 1.24's `unicode` package (the
+                            * reference's tables): ICU 70's 14.0 plus the 4,489 code points first assigned in 15.0
+                            * (csrc/gen_unicode_tables.py says how they were obtained and checked)                          */
   int32_t utf8_screened;   /* 1: the pattern has a decoding class that holds U+FFFD (every negated class, \W, \P{..}): a lead byte
                             * without its continuation bytes is (RuneError, 1) to it, as to utf8.DecodeRune.  The entry points
                             * screen the input for such bytes (one streaming pass) and match an input that has them through a

@@ -1,4 +1,4 @@
-"""\\p{..} tables: the product's (generated from ICU 70's UCD, Unicode 14.0 -- regengo_amd/csrc/gen_unicode_tables.py) against
+"""\\p{..} tables: the product's (Unicode 15.0 = ICU 70's UCD 14.0 + the 4,489 code points first assigned in 15.0 -- regengo_amd/csrc/gen_unicode_tables.py) against
 two UCD copies it was NOT generated from: CPython's unicodedata (13.0, general categories; the oracle's source) and the
 `regex` module (a newer Unicode; Script property; the oracle's source for scripts).  The reference's tables are Go 1.24's
 `unicode` package (15.0.0; /root/reference/regengo.go:92 -> regexp/syntax parse.go unicodeTable); no copy of 15.0 exists in
@@ -51,7 +51,7 @@ def test_product_does_not_import_the_oracle():
 def test_unicode_version_is_reported():
     from regengo_amd import Compiled
     info = Compiled(r"\p{L}+").info
-    assert info.unicode_version == 0x0E0000          # ICU 70 = Unicode 14.0.0; Go 1.24 = 15.0.0 (stated gap)
+    assert info.unicode_version == 0x0F0000          # Unicode 15.0.0 = Go 1.24's: ICU 70's 14.0 + the 4,489 code points first assigned in 15.0
 
 
 def test_general_categories_agree_with_cpython_ucd_on_everything_assigned_in_13():
@@ -179,3 +179,22 @@ def test_simple_fold_orbits_and_case_insensitive_matching(built):
         for t in (ch.lower(), ch.upper()):
             if len(t) == 1 and t != ch and c not in (0x130, 0x131):          # Turkic dotted/dotless i: no simple folding
                 assert c in nxt, hex(c)
+
+
+def test_unicode_15_additions_are_in():
+    """Go 1.24's unicode package is 15.0.0.  The scripts 15.0 introduced exist, the largest block it added (CJK Extension H) is Han
+    and Lo, and code points that came later (15.1's Extension I, 16.0's U+1F777) are still unassigned."""
+    assert len(as_set(product_table("Kawi"))) == 86 and len(as_set(product_table("Nag_Mundari"))) == 42
+    han, lo, c_all = as_set(product_table("Han")), as_set(product_table("Lo")), None
+    assert set(range(0x31350, 0x323B0)) <= han and set(range(0x31350, 0x323B0)) <= lo
+    assert 0x323B0 not in han and 0x2EBF0 not in han                     # Extension J (17.0), Extension I (15.1)
+    so = as_set(product_table("So"))
+    assert {0x1F6DC, 0x1F774, 0x1F77F, 0x1FAF8} <= so and 0x1F777 not in so and 0x1F6D8 not in so
+    assert 0x1E030 in as_set(product_table("Cyrillic")) and 0x1E030 in as_set(product_table("Lm"))
+    assigned = set()
+    for name in ("L", "M", "N", "P", "S", "Z", "C"):
+        assigned |= as_set(product_table(name))
+    import unicodedata
+    old = sum(1 for cp in range(0x110000) if unicodedata.category(chr(cp)) != "Cn")          # CPython: 13.0
+    # 13.0 -> 14.0 added 838 characters, 14.0 -> 15.0 4,489 (the counts the two versions published)
+    assert len(assigned) == old + 838 + 4489
