@@ -130,13 +130,19 @@ def sustained(env, run_steps, steps, warmup):
 
 
 def load_traffic(name):
-    """HBM bytes per launch of the dominant kernel from the PMC passes kept under profiles/ (rocprofv3 --pmc in its own runs,
-    corrected as MI355X_MICROARCH.md prescribes: scripts/pmc_traffic.sh).  (traffic, source) or (None, None)."""
-    for rnd in ("r02",):
+    """HBM bytes per launch of the dominant kernel from the PMC passes kept under profiles/ (scripts/pmc_traffic.sh: rocprofv3 --pmc in
+    runs of their own, FETCH_SIZE and WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes).  Counters need the
+    profiler, so this run cannot measure them itself: it cites the file and the run id the file carries.  (traffic, source) or
+    (None, None)."""
+    for rnd in ("r03", "r02"):
         pj = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, name))
         if os.path.exists(pj):
             try:
-                return json.load(open(pj)).get("hbm_bytes_per_launch"), "profiles/%s_pmc_%s.json" % (rnd, name)
+                d = json.load(open(pj))
+                src = "profiles/%s_pmc_%s.json" % (rnd, name)
+                if d.get("run_id"):
+                    src += " (run %s)" % d["run_id"]
+                return d.get("hbm_bytes_per_launch"), src
             except (OSError, ValueError):
                 pass
     return None, None
