@@ -161,3 +161,22 @@ def test_capacity_retry_comes_before_the_fallback(built):
     # a (0, nil) read with nothing left over is not the end of the stream (streaming.go:123-175)
     loop = text[text.index("func dateReadLoop("):]
     assert "if err == io.EOF {\n\t\t\t\treturn nil" in loop and "continue" in loop
+
+
+def test_precompiled_replacers(built):
+    """replace.go:458-715: one set of five methods per -replacer template, validated when the code is generated
+    (compiler.go:371-416: an unknown group fails the generator)."""
+    text, _ = codegen.emit_go(CASES[0][1], "Date", "p", replacers=["$day/$month/$year", "[$0]"])
+    for k in (0, 1):
+        for meth in ("ReplaceAllString%d", "ReplaceAllBytes%d", "ReplaceAllBytesAppend%d", "ReplaceFirstString%d", "ReplaceFirstBytes%d"):
+            assert "func (r Date) %s(" % (meth % k) in text
+        assert "dateReplacer%d" % k in text
+    assert "const dateReplacer0 = `$day/$month/$year`" in text
+    for bad in ("$nosuch", "$9", "${"):
+        with pytest.raises(ValueError) as ei:
+            codegen.emit_go(CASES[0][1], "Date", "p", replacers=[bad])
+        assert str(ei.value).startswith("replacer[0]:")
+    # every fallback of the new methods is a ...Go method and every C call still matches the header
+    code = re.sub(r"//[^\n]*", "", text)
+    for m in re.finditer(r"\br\.([a-z][A-Za-z0-9]*)\(", code):
+        assert m.group(1).endswith("Go"), m.group(1)
