@@ -290,6 +290,18 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
       // position can only match if its first K bytes pass the level sets, so only those positions get a DFA walk.
       // Detection bits are gathered 32 bytes at a time without a branch; the (rare, divergent) walks run after each
       // 32-byte chunk, in position order, under the FindAll rule.
+      // A sync point in FRONT of the staged window (the far look-behind of the sync automaton, s_misc[10]): the prefilter reads
+      // the tile's bytes straight from LDS, so the stretch up to the window takes plain attempts (through Input::At, which falls
+      // back to global memory).  [Round 3: without this the prefilter read LDS in front of the window -- a 474-byte match across
+      // a tile edge made the lane behind it report a match that starts inside it; fuzz sweep seed 1023, tests/golden/regress.]
+      {
+        const int first_valid = wb < 0 ? 0 : wb;
+        while (pos < first_valid && pos < slice_end) {
+          const int end = Walk<MODE>(tab, in, T, s_ctx, pos);
+          if (end >= 0) pos = end > pos ? end : pos + 1;        // (pos < wb <= a: not a start of this slice)
+          else ++pos;
+        }
+      }
       const int K = T.sa_k;
       const int sh = 29 - K;
       const unsigned one = 1u << sh, one2 = (one << 1) | one, one4 = (one2 << 2) | one2;

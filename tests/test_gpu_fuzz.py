@@ -153,13 +153,12 @@ def test_lookahead_empty_matches_regression(torch_dev, pat):
         assert res.total == cnt and np.array_equal(spans.cpu().numpy(), exp), (pat, n)
 
 
-@pytest.mark.xfail(strict=False, reason="known defect (round 3 sweep, seed 1023): generic kernel + sync automaton, a 474-byte match across a tile edge on UTF-8 text")
-def test_known_defect_long_match_across_a_tile_edge_with_the_sync_automaton(torch_dev):
-    """`[^a]a{1,2}[^a]+` has no reset byte (sync points come from the sync automaton, generic kernel); on the head of the sweep's
-    seed-1023 input a match of 474 bytes crosses the first tile edge and the lane behind it reports a match that starts inside it
-    ([16429, 16461] for [16460, 16532]).  The sync automaton itself is sound on this input (tests/_hosttest w_sync: no sync point
-    inside the match for any blind start); blanking the text in front of the match makes the scan take the carry pass and the
-    result is right.  Kept as an expected failure with its fixture until the kernel-side cause is found (scripts/gpu_dbg_shrink.py)."""
+def test_long_match_across_a_tile_edge_with_the_sync_automaton(torch_dev):
+    """Regression (round-3 fuzz sweep, seed 1023).  `[^a]a{1,2}[^a]+` has no reset byte: the generic kernel takes its sync points from
+    the sync automaton, and when the four staged halo slices hold none -- here a match of 474 bytes crosses the first tile edge --
+    from the far look-behind, IN FRONT of the staged window.  The Shift-And prefilter then read LDS in front of the window and the
+    lane behind the match reported [16429, 16461] for [16460, 16532].  (The sync automaton itself was sound: tests/_hosttest w_sync
+    shows no sync point inside the match for any blind start.)"""
     import os
     from oracle.gen_c import CMatcher
     from regengo_amd import Compiled
