@@ -486,7 +486,14 @@ def run_c2_capi(env, args):
                         "kernel": KERNEL_NAMES.get(c.info.scan_kernel, "rgx scan kernel"), "kernel_ms": round(k_ms, 4),
                         "algorithmic_bytes_per_launch": win_bytes, "timed_launches": len(kms)}
     if not args.no_cpu_baseline and world == 1:      # the CPU leg runs at N=1 only
-        line["cpu_baseline"] = cpu_baseline_findall(DATE, "c2", args.adversarial)
+        # the CPU leg also checks the rows: the device's records whose match starts in the first 16 MiB against the port's (with the
+        # adversarial noise there is no closed form, so this is the line's parity: config.parity_rows_vs_cpu_port_head_16MiB)
+        head = 16 << 20
+        k = int((owned[:, 0] < head).sum().item())
+        line["cpu_baseline"] = cpu_baseline_findall(DATE, "c2", args.adversarial, check_rows=owned[:k].cpu().numpy(), check_head=head)
+        line["config"]["parity_rows_vs_cpu_port_head_16MiB"] = line["cpu_baseline"].pop("rows_equal_head", None)
+        if args.adversarial:
+            line["config"]["parity_closed_form"] = None      # no closed form with the adversarial noise
     sh.close()
     return line
 
@@ -933,7 +940,7 @@ def run_c5(env, args):
 
 
 # ------------------------------------------------------------------------------------------------------- CPU baselines
-def cpu_baseline_findall(pattern, which, adversarial):
+def cpu_baseline_findall(pattern, which, adversarial, check_rows=None, check_head=0):
     """The oracle's generated-C port of the reference's emitted FindAllBytes machine (oracle/gen_c.py), ONE core, timed on a
     bounded sample of the same workload, then the same port on every host core over disjoint slices."""
     import numpy as np
@@ -959,9 +966,16 @@ def cpu_baseline_findall(pattern, which, adversarial):
     for _ in range(passes):
         cnt = cm.lib.m_find_all(buf.ctypes.data, n, -1, out.ctypes.data, out.shape[0])
     dt = time.perf_counter() - t0
-    base = {"value": round(n * passes / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+    rows_equal = None
+    if check_rows is not None:
+        # rows the port found with a start below check_head (the head of the same stream) against the device's
+        kk = int(np.searchsorted(out[:cnt, 0], check_head))
+        rows_equal = bool(check_rows.shape == out[:kk].shape and np.array_equal(check_rows, out[:kk]))
+    base = {"value": round(n * passes / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port", "rows_equal_head": rows_equal,
             "sample": "%s, %d passes, FindAllBytes with full span output; matches=%d" % (what, passes, cnt),
             "host_cores_available": os.cpu_count()}
+    if rows_equal is None:
+        base.pop("rows_equal_head")
     # the same port on every host core: disjoint slices cut on period boundaries of the synthetic stream (+ look-ahead), one
     # thread each (ctypes drops the GIL).  Reported next to the one-core figure, never instead of it.
     import threading

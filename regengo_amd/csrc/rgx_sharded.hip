@@ -657,7 +657,10 @@ RGX_API int64_t rgx_sharded_gather(rgx_sharded* s, int dst_rank, int64_t* d_dst,
   Shard* dst = nullptr;
   for (Shard* sh : s->local) if (sh->rank == dst_rank) dst = sh;
   const int ncap = s->local[0]->info.ncap;
-  if (dst && (d_dst || h_dst) && (size_t)total > cap_records) { SetError("gather: capacity too small"); return RGX_E_CAPACITY; }
+  // (a destination whose buffer is too small still takes part -- into the library's buffer -- and reports RGX_E_CAPACITY afterwards:
+  // returning early would leave the other ranks in their sends)
+  const bool too_small = dst && (d_dst || h_dst) && (size_t)total > cap_records;
+  if (too_small) { d_dst = nullptr; h_dst = nullptr; }
   Rccl* R = s->use_rccl ? LoadRccl() : nullptr;
   long long* table = nullptr;
   // 1. every local shard turns its rows into stream-absolute int64 -- the destination straight into its slice of the table
@@ -714,6 +717,7 @@ RGX_API int64_t rgx_sharded_gather(rgx_sharded* s, int dst_rank, int64_t* d_dst,
   }
   for (Shard* sh : s->local) { HIP_TRY(hipSetDevice(sh->device)); HIP_TRY(hipStreamSynchronize(sh->cstream)); }
   if (d_rows) *d_rows = dst ? (const int64_t*)table : nullptr;
+  if (too_small) { SetError("gather: capacity too small (the table is in the library's buffer, *d_rows)"); return RGX_E_CAPACITY; }
   return dst ? total : 0;
 }
 
