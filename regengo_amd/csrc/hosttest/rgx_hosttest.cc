@@ -229,6 +229,35 @@ int rgxt_reset_pairs(void* hh, uint8_t* cls256, uint8_t* out, int cap) {
 }
 
 // FindAllBytes semantics (find.go:130-316) on the tables.
+// The capture pass's forward-only form for one-pass automata, on the host tables (rgx_kernels.hip: ResolveCapturesOnePass is the
+// same loop): returns 0 when the program is not one-pass.
+int rgxt_onepass(void* hh) { return IsOnePass(((Handle*)hh)->t) ? 1 : 0; }
+int rgxt_captures_onepass(void* hh, const uint8_t* buf, int64_t len, int64_t s, int64_t e, int32_t* out) {
+  const Tables& t = ((Handle*)hh)->t;
+  if (!IsOnePass(t)) return 0;
+  const bool minus1 = t.flags & 1u;
+  for (int c = 0; c < t.ncap; c++) out[c] = minus1 ? -1 : 0;
+  out[0] = (int32_t)s; out[1] = (int32_t)e;
+  const int stride = t.ncls + 1;
+  auto apply = [&](uint32_t ops, int64_t pos) { for (int c = 2; c < t.ncap; c++) if ((ops >> c) & 1u) out[c] = (int32_t)pos; };
+  const int ctx = s == 0 ? kCtxBOT : t.ctx_of_byte[buf[s - 1]];
+  unsigned q = t.start[ctx];
+  const uint32_t sbase = t.start_ops[ctx];
+  if (e == s) { apply(t.start_ops_pool[sbase + t.st_nthreads[q] - 1], s); return 1; }
+  uint32_t prev_base = 0;
+  for (int64_t i = s; i < e; i++) {
+    const size_t cell = (size_t)q * stride + t.cls[buf[i]];
+    const uint32_t base = t.bt_base[cell];
+    const unsigned P = t.bt_parent[base];
+    apply(i == s ? t.start_ops_pool[sbase + P] : t.bt_ops[prev_base + P], i);
+    prev_base = base;
+    q = t.trans[cell] & kStateMask;
+  }
+  apply(t.bt_ops[prev_base + t.st_nthreads[q] - 1], e);
+  (void)len;
+  return 1;
+}
+
 int64_t rgxt_find_all(void* hh, const uint8_t* buf, int64_t len, int64_t n, int32_t* spans, int64_t cap) {
   const Tables& t = ((Handle*)hh)->t;
   if (n == 0) return 0;

@@ -1112,6 +1112,20 @@ uint64_t Fnv1a(const uint8_t* p, size_t n) {
 }
 }  // namespace
 
+bool IsOnePass(const Tables& t) {
+  if (t.lookahead_mode || t.fixed_captures || t.ncap <= 2) return false;
+  const int stride = t.ncls + 1;
+  for (int q = 1; q < t.nstates; q++)
+    for (int k = 0; k < t.ncls; k++) {
+      const uint32_t b = t.bt_base[(size_t)q * stride + k];
+      if (b == 0xFFFFFFFFu) continue;
+      const unsigned nq = t.trans[(size_t)q * stride + k] & kStateMask;
+      const unsigned nt = t.st_nthreads[nq];
+      for (unsigned j = 1; j < nt; j++) if (t.bt_parent[b + j] != t.bt_parent[b]) return false;
+    }
+  return true;
+}
+
 std::vector<uint8_t> SerializeTables(const Tables& t) {
   W w;
   w.pod(kMagic); w.pod(kBlobVersion);

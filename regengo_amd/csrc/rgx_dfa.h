@@ -172,6 +172,11 @@ StartSearch BuildStartSearch(const std::string& pattern, uint32_t flags, int max
 // (an empty-width op other than ^/$ of the text, or more than max_states states): rgx_ref_engine.cc.
 int RefTdfaStates(const Prog& prog, int max_states = 500);
 
+// One-pass (RE2's term): on every edge exactly one thread of the source state consumes the byte, i.e. every thread of the next
+// state has the same parent -- the capture groups of a match then come out of ONE forward walk (rgx_kernels.hip:
+// ResolveCapturesOnePass).  Eager automata with dynamic captures only.
+bool IsOnePass(const Tables& t);
+
 // Throws SyntaxError / Unsupported / TooLarge.
 Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOptions& opt = BuildOptions());
 

@@ -1359,6 +1359,48 @@ __device__ __forceinline__ void ResolveCapturesPriv(Lds16 trans, Lds8 cls, const
 }
 
 
+// One-pass automata (DevTables::onepass): every edge has ONE consuming thread, so the thread a match's path takes through a state
+// does not depend on what follows -- the groups come out of the forward walk alone.  Step i looks up, next to the transition, the
+// edge's pool slice and the (single) parent P_i; the capture ops the path made BEFORE byte i -- those of edge i-1's thread P_i, or
+// the start closure's -- are known then and are applied in order, later assignments overwriting earlier ones (the back-trace's
+// "first one met going backwards").  No state trace, no second walk, and only the transition look-ups depend on each other.
+template <int MODE>
+__device__ __forceinline__ void ResolveCapturesOnePass(Lds16 trans, Lds8 cls, const BtTabsLds& B, const DevTables& T, int ctx,
+                                                       const PrivInput& in, int s, int e, int32_t* rec) {
+  const int stride = T.stride;
+  const int ncap = T.ncap;
+  const int unset = T.unmatched_minus1 ? -1 : 0;
+  const int n = e - s;
+  const Lds32 rowd = (Lds32)in.row;
+  for (int c = 2; c < ncap; ++c) rec[c] = unset;
+  rec[0] = s; rec[1] = e;
+  auto apply = [&](unsigned o, int pos) {
+    o &= ~3u;
+    while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = pos; }
+  };
+  unsigned q = T.start[ctx];
+  const unsigned sbase = B.start_ops[ctx];
+  if (n == 0) { apply(B.start_ops_pool[sbase + B.st_nthreads[q] - 1], s); return; }
+  int r = s - in.p0;
+  unsigned w = rowd[(r >> 2) << 8];
+  unsigned wn = rowd[((r >> 2) + 1) << 8];
+  unsigned prev_base = 0;
+  for (int i = 0; i < n; ++i) {
+    const unsigned b = (w >> ((r & 3) << 3)) & 255u;
+    const unsigned cell = q * stride + cls[b];
+    const unsigned qn = MODE == kModeDirect ? trans[(q << 8) + b] : trans[cell];
+    const unsigned base = B.bt_base[cell];
+    const unsigned P = B.bt_parent[base];
+    const unsigned o = i == 0 ? B.start_ops_pool[sbase + P] : B.bt_ops[prev_base + P];
+    if (o & ~3u) apply(o, s + i);
+    prev_base = base;
+    q = qn & kStateMask;
+    ++r;
+    if ((r & 3) == 0) { w = wn; wn = rowd[((r >> 2) + 1) << 8]; }
+  }
+  apply(B.bt_ops[prev_base + B.st_nthreads[q] - 1], e);
+}
+
 // The same walk with the trace kept IN the lane's row: a cell that fits a byte (states x stride <= 256) takes the place of the
 // input byte it was computed from -- the forward walk holds two dwords of the row in registers, so a byte is overwritten only
 // after it was read -- and the back-trace reads four cells with one load.  No trace area: 16 KiB of LDS less per workgroup, three
@@ -1515,7 +1557,8 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
       if (INROW && e + 4 - in.p0 <= in.nrow && (s == 0 || s - 1 >= in.p0)) {
         // (the launch takes this instance only with the back-trace tables on chip and states x stride <= 256)
         const int ctx = s == 0 ? kCtxBOT : ctx_of_byte[in.At(s - 1)];
-        ResolveCapturesInRow<MODE>((Lds16)(smem + Y.trans), (Lds8)(smem + Y.cls), BL, T, ctx, in, s, e, rec);
+        if (T.onepass && !(debug_flags & 2)) ResolveCapturesOnePass<MODE>((Lds16)(smem + Y.trans), (Lds8)(smem + Y.cls), BL, T, ctx, in, s, e, rec);
+        else ResolveCapturesInRow<MODE>((Lds16)(smem + Y.trans), (Lds8)(smem + Y.cls), BL, T, ctx, in, s, e, rec);
       } else
       if (!INROW && need <= kBatchTrace) {
         LdsTrace tr = (LdsTrace)(smem + Y.trace) + tid;
@@ -1523,7 +1566,8 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
         if (bt_lds && MODE != kModeClassGlobal && !no_priv && cells <= (sizeof(TraceT) == 1 ? 256 : 65536) && e + 4 - in.p0 <= in.nrow + 0 &&
             (s == 0 || s - 1 >= in.p0)) {
           const int ctx = s == 0 ? kCtxBOT : ctx_of_byte[in.At(s - 1)];
-          ResolveCapturesPriv<MODE, TraceT, LdsTrace>((Lds16)(smem + Y.trans), (Lds8)(smem + Y.cls), BL, T, ctx, in, s, e, tr, rec);
+          if (T.onepass && !(debug_flags & 2)) ResolveCapturesOnePass<MODE>((Lds16)(smem + Y.trans), (Lds8)(smem + Y.cls), BL, T, ctx, in, s, e, rec);
+          else ResolveCapturesPriv<MODE, TraceT, LdsTrace>((Lds16)(smem + Y.trans), (Lds8)(smem + Y.cls), BL, T, ctx, in, s, e, tr, rec);
         } else
         if (bt_lds) ResolveCapturesBatch<MODE, TraceT, PrivInput, BtTabsLds, LdsTrace>(tab, BL, T, tab.cls, ctx_of_byte, in, s, e, tr, kBlockThreads, rec);
         else ResolveCapturesBatch<MODE, TraceT, PrivInput, BtTabs, LdsTrace>(tab, BG, T, tab.cls, ctx_of_byte, in, s, e, tr, kBlockThreads, rec);

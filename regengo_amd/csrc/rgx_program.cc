@@ -113,6 +113,7 @@ int UploadTables(const Tables& t, std::vector<uint16_t>* direct_table, DevTables
   d.bt_pool_n = (int32_t)t.bt_parent.size();
   d.start_pool_n = (int32_t)t.start_ops_pool.size();
   d.fixed_captures = t.fixed_captures; d.unmatched_minus1 = (t.flags & RGX_FLAG_UNMATCHED_MINUS1) ? 1 : 0;
+  d.onepass = IsOnePass(t) ? 1 : 0;
 
   // choose the LDS layout
   Arena a;

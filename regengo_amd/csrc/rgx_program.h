@@ -83,7 +83,10 @@ struct DevTables {
   const UsDev* us;                // HOST pointer to the program's UsDev when the pattern is eligible for rgx_scan_us.hip, else nullptr
   uint16_t start[4];
   uint8_t start_accept[4];
-  uint8_t lookahead, ctx_sensitive, bot_sensitive, anchored, fixed_captures, unmatched_minus1, pad0, pad1;
+  uint8_t lookahead, ctx_sensitive, bot_sensitive, anchored, fixed_captures, unmatched_minus1;
+  uint8_t onepass;                // every edge of the automaton has ONE consuming thread (all threads of the next state descend from it): the
+                                  // capture groups of a match come out of a single forward walk (rgx_kernels.hip: ResolveCapturesOnePass)
+  uint8_t pad1;
 };
 
 // Device image of the start-tracking search automaton (rgx_dfa.h: StartSearch) for rgx_scan_us.hip.  Entries are 64 bit:

@@ -83,6 +83,15 @@ class HostProgram:
         c = _lib.rgxt_find_all(self.h, b, len(b), n, out, cap)
         return [list(out[i * ncap:(i + 1) * ncap]) for i in range(c)]
 
+    @property
+    def onepass(self) -> bool:
+        return bool(_lib.rgxt_onepass(self.h))
+
+    def captures_onepass(self, b: bytes, s: int, e: int):
+        """The forward-only capture resolution of one-pass automata (None: the program is not one-pass)."""
+        out = (C.c_int32 * self.info["ncap"])()
+        return list(out) if _lib.rgxt_captures_onepass(self.h, b, len(b), s, e, out) else None
+
     def find_all_sa(self, b: bytes):
         ncap = self.info["ncap"]
         cap = len(b) + 2

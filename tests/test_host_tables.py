@@ -297,3 +297,33 @@ def test_random_utf8_patterns_table_walk_equals_oracle(hostlib):
             compared += 1
     print("compared", compared, "refused", refused, "non-terminating", hangs)
     assert compared > 800 and refused < 40, (compared, refused)
+
+
+def test_onepass_forward_captures_equal_the_back_trace(corpus, kats, hostlib):
+    """Programs on whose every edge ONE thread consumes the byte (rgx_dfa.h: IsOnePass) get their capture groups from a single forward
+    walk on the device (ResolveCapturesOnePass).  The same loop on the host tables against the thread-parent back-trace, on every
+    match of every corpus input, and the property itself on patterns known either way."""
+    H = hostlib
+    items = [(e["pattern"], e["inputs"]) for e in corpus] + [(c["pattern"], c["inputs"]) for c in kats["curated_cases"]]
+    nprog = nmatch = 0
+    from regengo_amd import synth
+    tile = synth.web_log_tile(1 << 16)[:12000]
+    for p, inputs in items:
+        try:
+            hp = H.HostProgram(p)
+        except ValueError:
+            continue
+        if not hp.onepass:
+            continue
+        nprog += 1
+        bs = [s.encode() for s in inputs]
+        bs += [b" ".join(bs), b"x" + (bs[0] if bs else b"") + b"y", tile]
+        for b in bs:
+            for row in hp.find_all(b):
+                assert hp.captures_onepass(b, row[0], row[1]) == list(row), (p, b[:80], row)
+                nmatch += 1
+    assert nprog >= 20 and nmatch >= 700, (nprog, nmatch)
+    url = r"(?P<full>(?P<proto>https?|ftp)://(?P<host>[\w.-]+)(?P<port>:\d+)?(?P<path>/[\w./-]*)?)"
+    assert H.HostProgram(url).onepass
+    assert not H.HostProgram(r"(?P<user>[\w\.+-]+)@(?P<domain>[\w\.-]+)\.(?P<tld>[\w\.-]+)").onepass     # '.' feeds the loop AND the literal
+    assert not H.HostProgram(r"(\d{4})-(\d{2})").onepass                                               # fixed template: no capture pass at all
