@@ -335,7 +335,7 @@ def to_global(spans, base: int):
     if g.shape[0] == 0 or base == 0:
         return g
     pairs = g.view(g.shape[0], -1, 2)
-    unset = (pairs[:, :, 0] == 0) & (pairs[:, :, 1] == 0)
+    unset = ((pairs[:, :, 0] == 0) & (pairs[:, :, 1] == 0)) | (pairs[:, :, 0] < 0)      # (0,0), or (-1,-1) under FLAG_UNMATCHED_MINUS1
     unset[:, 0] = False
     return torch.where(unset[:, :, None], pairs, pairs + base).view(g.shape)
 
@@ -461,6 +461,12 @@ class ReaderSource:
 
 class ShardedReader:
     """FindReader / FindReaderCount (streaming.go:85-317) over one stream, sharded across the ranks of a process group.
+    (Round 3: the same protocol lives in the C library, csrc/rgx_sharded.hip; this class remains as its gloo-testable statement.)
+
+    SEMANTICS: the rows are FindAllBytes' over the whole stream.  The reference's FindReader differs from that by its chunk protocol --
+    no MaxLeftover deferral / keepFrom truncation and no Q1/Q4 check happen here, unlike the single-GPU rgx_find_chunk path, which is
+    identical-or-refused per chunk -- so on a stream where a match straddles `dataLen - MaxLeftover` of a chunk the reference reports
+    fewer matches (tests/test_ref_engine.py pins the counts for the bench corpus).
 
     The stream is cut into windows of `window_bytes`; window k is OWNED by rank k mod world (round t = windows t*world ..
     t*world+world-1, one per rank, so a round's rows are contiguous in the stream and the ranks finish together).  A rank scans
@@ -543,6 +549,7 @@ class ShardedReader:
         stats = {"count": 0, "rounds": 0, "windows": 0, "bytes": 0, "truncated_windows": 0, "widened_halos": 0, "kernel_ms": 0.0,
                  "stopped": False}
         stop_local = [False]
+        err_local = [None]    # a failure of this rank that has to travel with the next exchange (all ranks raise together)
         inflight = [0]        # scans queued and not yet waited for
         stash = []            # results taken out of the queue early (see the widened-halo path)
 
@@ -598,8 +605,16 @@ class ShardedReader:
                 if not count_only:
                     rows, info = take()
                 if bad:
-                    w = widen(w)
-                    stats["widened_halos"] += 1
+                    try:
+                        w = widen(w)
+                    except RuntimeError as ex:
+                        # the other ranks are on their way into the exchange: take part with an error flag, every rank raises together
+                        err_local[0] = str(ex)
+                        bad = False
+                        rows = rows[:0] if rows is not None else rows
+                    else:
+                        stats["widened_halos"] += 1
+                if bad:
                     own = (w.lo - w.win_lo, w.hi - w.win_lo)
                     if not count_only:
                         # results come back in submit order: take the scan already queued for the next round out first
@@ -620,12 +635,16 @@ class ShardedReader:
                 stats["bytes"] += w.hi - w.lo
             have = 1 if st is not None else 0
             counts, haves, stops = [cnt], [have], [1 if stop_local[0] else 0]
+            errs = [1 if err_local[0] else 0]
             if dist:
-                mine = torch.tensor([cnt, have, stops[0]], dtype=torch.int64, device=cdev)
-                allc = torch.empty(3 * world, dtype=torch.int64, device=cdev)
+                mine = torch.tensor([cnt, have, stops[0], errs[0]], dtype=torch.int64, device=cdev)
+                allc = torch.empty(4 * world, dtype=torch.int64, device=cdev)
                 dist.all_gather_into_tensor(allc, mine, group=self.group)
-                tri = allc.cpu().view(world, 3).tolist()
+                tri = allc.cpu().view(world, 4).tolist()
                 counts, haves, stops = [int(t[0]) for t in tri], [int(t[1]) for t in tri], [int(t[2]) for t in tri]
+                errs = [int(t[3]) for t in tri]
+            if any(errs):
+                raise RuntimeError(err_local[0] or "ShardedReader: rank %d could not find a sync point for its window (see its log)" % errs.index(1))
             stopped = any(stops)      # requests from the callbacks of earlier rounds: this round's rows are not delivered
             if stopped:
                 return True, True

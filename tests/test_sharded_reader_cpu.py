@@ -84,8 +84,13 @@ def _worker(rank, world, port, pattern, data_bytes, kw, q):
             seen.append((m["StreamOffset"], m["ChunkIndex"]))
             return True
 
-        st = rd.find_reader(src, on_rows=None if kw.get("count_only") else on_rows, on_match=on_match if kw.get("per_match") else None,
-                            gather=kw.get("gather", False), count_only=kw.get("count_only", False), absolute=not kw.get("relative", False))
+        try:
+            st = rd.find_reader(src, on_rows=None if kw.get("count_only") else on_rows, on_match=on_match if kw.get("per_match") else None,
+                                gather=kw.get("gather", False), count_only=kw.get("count_only", False), absolute=not kw.get("relative", False))
+        except RuntimeError as ex:
+            if not kw.get("expect_error"):
+                raise
+            st = {"error": str(ex)}
         q.put((rank, got, bases, st, seen))
     finally:
         if world > 1:
@@ -212,6 +217,19 @@ def test_to_global_keeps_unset_groups():
     from regengo_amd.dist import to_global
     t = torch.tensor([[5, 9, 0, 0, 6, 7], [0, 3, 0, 2, 0, 0]], dtype=torch.int32)
     assert to_global(t, 100).tolist() == [[105, 109, 0, 0, 106, 107], [100, 103, 100, 102, 0, 0]]
+    # FLAG_UNMATCHED_MINUS1: an unset group is (-1, -1) and stays so (it used to become base - 1)
+    t = torch.tensor([[5, 9, -1, -1, 6, 7]], dtype=torch.int32)
+    assert to_global(t, 100).tolist() == [[105, 109, -1, -1, 106, 107]]
+
+
+def test_a_rank_that_cannot_widen_its_halo_fails_every_rank(built):
+    """widen() used to raise on ONE rank while the others were already blocked in the round's all_gather -- a hang.  The
+    failure now travels with the exchange (a fourth int) and every rank raises together.  Here no halo up to halo_max holds a
+    sync point for the window behind a run of 3000 digits."""
+    data = b"a 2024-01-15 b " * 300
+    data = data[:1000] + b"7" * 3200 + data[4200:]
+    outs = _run(DATE, data, W=4096, halo_left=64, halo_max=1024, expect_error=True)
+    assert all("error" in st for _, _, _, st, _ in outs), [st for _, _, _, st, _ in outs]
 
 
 def test_reader_source_with_a_right_halo_longer_than_the_stream(built):
