@@ -267,6 +267,12 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
       HIP_TRY(hipStreamSynchronize(c->stream));
     }
     c->cur_set = 1 - s;
+    if (((uint32_t*)&c->h_read[2])[3] & 0x80000000u) {
+      // a lane of the generic kernel spent its step budget (rgx_kernels.hip: kLaneStepBudget): attempts that fail only after tens of
+      // KiB, from every start -- quadratic for the reference's loop as well; refused rather than left to hold the device
+      SetError("this text keeps this pattern's attempts running too long (quadratic work): keep the CPU path for it");
+      return RGX_E_UNSUPPORTED;
+    }
     return RGX_OK;
   };
   static const bool force_tickets = ExpEnv("RGX_TICKETS") != nullptr;
@@ -420,6 +426,17 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     }
     if (!carry_ready) HIP_TRY(hipMemsetAsync(c->d_carry, 0xFF, (size_t)nslices * 4, c->stream));
     HIP_TRY(LaunchCarry(T, d_buf, ilen, c->d_unsynced, c->d_carry, nslices, c->stream));
+    {
+      // the pass is serial per run of slices and quadratic when every attempt of a run walks far: past its step budget it stops
+      // and the call is refused (the alternative is a kernel that holds the device for minutes)
+      int32_t over = 0;
+      HIP_TRY(hipMemcpyAsync(&over, c->d_carry + nslices + 4, 4, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (over) {
+        SetError("this text keeps this pattern's attempts running too long for the serial carry pass (quadratic): keep the CPU path for it");
+        return RGX_E_UNSUPPORTED;
+      }
+    }
     P.slice_unsynced = nullptr;
     P.carry_in = c->d_carry;
     if ((rc = run_scan(false)) != RGX_OK) return rc;

@@ -70,7 +70,7 @@ __device__ __forceinline__ unsigned long long LookBack(unsigned long long* desc,
       }
       if (__any(dead)) {
         if (lane == 0) {
-          atomicExch(timeout_flag, 1u);
+          atomicOr(timeout_flag, 1u);
           if (host_flag) __hip_atomic_store(host_flag, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         break;
@@ -111,7 +111,7 @@ __device__ __forceinline__ unsigned long long LookBackResolve(unsigned long long
         }
       }
       if (__any(dead)) {
-        if (lane == 0) atomicExch(timeout_flag, 1u);
+        if (lane == 0) atomicOr(timeout_flag, 1u);
         break;
       }
       const unsigned long long pm = __ballot((d >> 62) == 2);

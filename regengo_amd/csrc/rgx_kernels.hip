@@ -65,7 +65,7 @@ struct Input {
 // match end or -1.
 template <int MODE>
 __device__ __forceinline__ int Walk(const Tab<MODE>& tab, const Input& in, const DevTables& T, const uint8_t* ctx_of_byte,
-                                    int pos) {
+                                    int pos, int* stopped_at = nullptr) {
   int ctx = kCtxOther;
   if (pos == 0) ctx = kCtxBOT;
   else if (T.ctx_sensitive) ctx = ctx_of_byte[in.At(pos - 1)];
@@ -83,8 +83,17 @@ __device__ __forceinline__ int Walk(const Tab<MODE>& tab, const Input& in, const
     if (q == kDead || eot) break;
     ++i;
   }
+  if (stopped_at) *stopped_at = i;
   return end;
 }
+
+// Attempts that fail only after a long walk, from every start of a slice, are quadratic work (the reference's loop is too: it is
+// the pattern/text pair, not the engine) -- but a kernel that holds the device for minutes is not an acceptable way to be slow.
+// A lane of the generic kernel may spend this many steps on its slice; past it the lane stops, raises bit 31 of counters[3], tiles
+// that start later return at once, and the host refuses the call (RGX_E_UNSUPPORTED).  An ordinary slice costs 64 starts x a few
+// bytes plus its look-behind; 4 M steps means the average attempt of the slice ran 64 KiB.
+constexpr int kLaneStepBudget = 1 << 22;
+constexpr unsigned kOverBudgetBit = 0x80000000u;
 
 __device__ __forceinline__ void WriteRecordFixed(int32_t* rec, int ncap, const uint8_t* kind, const int32_t* delta, int s, int e) {
   if ((ncap & 3) == 0) {
@@ -129,7 +138,10 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
   // which is what makes the look-back below deadlock-free without any residency assumption.
   // tile id: blockIdx.x, or (use_tickets) a ticket, which makes the look-back deadlock-free without assuming
   // anything about dispatch order -- see rgx_device_util.h
-  if (tid == 0) s_misc[0] = P.use_tickets ? atomicAdd(&P.counters[0], 1u) : blockIdx.x;
+  if (tid == 0) {
+    s_misc[0] = P.use_tickets ? atomicAdd(&P.counters[0], 1u) : blockIdx.x;
+    s_misc[11] = __hip_atomic_load(&P.counters[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kOverBudgetBit;
+  }
   // stage the tables while the ticket is in flight
   {
     const int nwords = T.table_bytes >> 2;
@@ -276,8 +288,13 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
         if (end >= 0) { mask = 1ull; RGX_NOTE_END(0, end) }
       }
     } else if (SA == 0) {
+      int spent = 0;
+      if (s_misc[11]) pos = slice_end;             // an earlier tile ran out of budget: the call is refused, do no more work
       while (pos < slice_end) {
-        int end = Walk<MODE>(tab, in, T, s_ctx, pos);
+        int at;
+        int end = Walk<MODE>(tab, in, T, s_ctx, pos, &at);
+        spent += at - pos + 1;
+        if (spent > kLaneStepBudget) { atomicOr(&P.counters[3], kOverBudgetBit); break; }
         if (end >= 0) {
           if (pos >= a) { mask |= 1ull << (pos - a); RGX_NOTE_END(pos, end) }
           pos = end > pos ? end : pos + 1;         // find.go:452-457
@@ -294,10 +311,15 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
       // the tile's bytes straight from LDS, so the stretch up to the window takes plain attempts (through Input::At, which falls
       // back to global memory).  [Round 3: without this the prefilter read LDS in front of the window -- a 474-byte match across
       // a tile edge made the lane behind it report a match that starts inside it; fuzz sweep seed 1023, tests/golden/regress.]
-      {
+      int spent = 0;                                 // steps of this lane's attempts (kLaneStepBudget)
+      bool over = s_misc[11] != 0;                   // an earlier tile ran out of budget: the call is refused, do no more work
+      if (!over) {
         const int first_valid = wb < 0 ? 0 : wb;
         while (pos < first_valid && pos < slice_end) {
-          const int end = Walk<MODE>(tab, in, T, s_ctx, pos);
+          int at;
+          const int end = Walk<MODE>(tab, in, T, s_ctx, pos, &at);
+          spent += at - pos + 1;
+          if (spent > kLaneStepBudget) { over = true; atomicOr(&P.counters[3], kOverBudgetBit); break; }
           if (end >= 0) pos = end > pos ? end : pos + 1;        // (pos < wb <= a: not a start of this slice)
           else ++pos;
         }
@@ -308,6 +330,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
       const unsigned dead = 7u << 29;             // level-set word of "no byte": history passes, no level survives
       int end_i = slice_end + K - 1;
       if (end_i > len) end_i = len;
+      if (over) end_i = 0;
       int i = pos & ~3;
       unsigned E = 0;
       // second necessary condition (rgx_program.cc: ComputeRequiredClass): the first byte at or after a start that is either
@@ -367,7 +390,10 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
           det &= det - 1;
           const int s = chunk0 + j - (K - 1);
           if (s < pos) continue;
-          const int e = Walk<MODE>(tab, in, T, s_ctx, s);
+          int at;
+          const int e = Walk<MODE>(tab, in, T, s_ctx, s, &at);
+          spent += at - s + 1;
+          if (spent > kLaneStepBudget) { atomicOr(&P.counters[3], kOverBudgetBit); det = 0; end_i = 0; break; }
           if (e >= 0) {
             if (s >= a) { mask |= 1ull << (s - a); RGX_NOTE_END(s, e) }
             pos = e > s ? e : s + 1;
@@ -455,8 +481,32 @@ __device__ int WalkGlobal(const DevTables& T, const uint8_t* buf, int len, int p
   return end;
 }
 
+// WalkGlobal that also charges its steps to a budget (the carry pass is one lane per run and quadratic in a run's length when every
+// attempt runs far: the budget turns "a kernel that runs for minutes" into a refusal the host reports)
+__device__ int WalkGlobalCharged(const DevTables& T, const uint8_t* buf, int len, int pos, long long* budget) {
+  int ctx = pos == 0 ? kCtxBOT : T.ctx_of_byte[buf[pos - 1]];
+  unsigned q = T.start[ctx];
+  int end = T.start_accept[ctx] ? pos : -1;
+  const bool direct = T.mode == kModeDirect;
+  int i = pos;
+  for (;; ++i) {
+    unsigned e;
+    const bool eot = i >= len;
+    if (eot) e = direct ? T.trans[(T.nstates << 8) + q] : T.trans[q * T.stride + T.ncls];
+    else e = direct ? StepDirectG(T, q, buf[i]) : StepG(T, q, buf[i]);
+    if (e & kMatchBefore) end = i;
+    if (e & kMatchAfter) end = i + 1;
+    q = e & kStateMask;
+    if (q == kDead || eot) break;
+  }
+  *budget -= (long long)(i - pos) + 1;
+  return end;
+}
+
+constexpr long long kCarryBudget = 1ll << 23;    // steps one lane of the carry pass may take (0.3 .. 1.3 us each: dependent global loads)
+
 __global__ void carry_kernel(DevTables T, const uint8_t* buf, int32_t len, const uint8_t* unsynced, int32_t* carry_in,
-                             int32_t nslices) {
+                             int32_t nslices, int32_t* over_budget) {
   const int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= nslices || !unsynced[s]) return;
   if (s > 0 && unsynced[s - 1]) return;  // not the head of a run
@@ -493,23 +543,25 @@ __global__ void carry_kernel(DevTables T, const uint8_t* buf, int32_t len, const
   }
   int cur = s;
   const int run_begin = s * kSliceBytes;
+  long long budget = kCarryBudget;
   // advance to the run
-  while (pos < run_begin) {
-    int end = WalkGlobal(T, buf, len, pos);
+  while (pos < run_begin && budget > 0) {
+    int end = WalkGlobalCharged(T, buf, len, pos, &budget);
     pos = (end >= 0) ? (end > pos ? end : pos + 1) : pos + 1;
   }
-  while (cur < nslices && unsynced[cur]) {
+  while (cur < nslices && unsynced[cur] && budget > 0) {
     const int a = cur * kSliceBytes;
     int e_slice = a + kSliceBytes;
     if (e_slice > len) e_slice = len;
     carry_in[cur] = pos < a ? a : pos;
     if (pos < a) pos = a;
-    while (pos < e_slice) {
-      int end = WalkGlobal(T, buf, len, pos);
+    while (pos < e_slice && budget > 0) {
+      int end = WalkGlobalCharged(T, buf, len, pos, &budget);
       pos = (end >= 0) ? (end > pos ? end : pos + 1) : pos + 1;
     }
     ++cur;
   }
+  if (budget <= 0) *over_budget = 1;      // the positions written so far are not to be used: the host refuses the call
 }
 
 // ---- exact sync points from the sync automaton, optimistically (rare path) -----------------------------------
@@ -2192,10 +2244,13 @@ hipError_t LaunchUtf8ScreenBatch(const uint8_t* src, const uint64_t* offsets, in
   return hipGetLastError();
 }
 
+// carry_in has room for nslices + 64 entries (the callers' Ensure): entry nslices + 4 is the pass's over-budget flag, cleared here
 hipError_t LaunchCarry(const DevTables& T, const uint8_t* buf, int32_t len, const uint8_t* slice_unsynced, int32_t* carry_in,
                        int32_t nslices, hipStream_t stream) {
   dim3 block(256), grid((nslices + 255) / 256);
-  hipLaunchKernelGGL(carry_kernel, grid, block, 0, stream, T, buf, len, slice_unsynced, carry_in, nslices);
+  hipError_t e = hipMemsetAsync(carry_in + nslices + 4, 0, 4, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(carry_kernel, grid, block, 0, stream, T, buf, len, slice_unsynced, carry_in, nslices, carry_in + nslices + 4);
   return hipGetLastError();
 }
 
