@@ -18,6 +18,7 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <type_traits>
 
 #include "rgx_device_util.h"
 #include "rgx_kernels.h"
@@ -1027,6 +1028,13 @@ struct BatchInput {
   }
 };
 
+// a string that lies inside the staged window whole
+struct BatchInputLds {
+  Lds8 lds;               // the string's first byte
+  int len;
+  __device__ __forceinline__ int At(int i) const { return lds[i]; }
+};
+
 template <int MODE>
 __device__ __forceinline__ int WalkBatch(const Tab<MODE>& tab, const BatchInput& in, const DevTables& T, const uint8_t* ctx_of_byte,
                                          int pos) {
@@ -1686,22 +1694,44 @@ __host__ __device__ inline SearchLayout SearchLdsLayout(const DevTables& U, int 
 template <int MODE, class TraceT>
 __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U, DevTables F, const uint8_t* concat,
                                                                       const uint64_t* offsets, int64_t nstr, uint8_t* found,
-                                                                      int32_t* spans, TraceT* gtrace, int window_bytes, int ref) {
+                                                                      int32_t* spans, TraceT* gtrace, int window_bytes, int ref_arg) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const bool want_spans = spans != nullptr;
+  const int ref = ref_arg & 1;
+  const int exp_skip = ref_arg >> 8;          // experiments (RGX_C3_SKIP, bits): 1 forward walk only, 2 no replay of the attempt offsets, 4 bytes through BatchInput::At
   const int ncap = F.ncap;
   const SearchLayout Y = SearchLdsLayout(U, ncap, want_spans, (int)sizeof(TraceT), window_bytes);
   // ref (FindBytes in reference mode, spans wanted): the replay of the reference's attempt offsets (ref_fix_kernel has the
   // commentary) runs right here, on the staged bytes, with the right-most-path automaton of F staged behind the layout:
   // [rm_trans u16][rm_depth u8][F.cls 256][F.ctx_of_byte 256].  Strings whose sequence steps over the leftmost-first start get
   // found = 2 and are finished by ref_fix_kernel (rare).
-  const int rm_cells = ref ? F.rm_nstates[0] * F.stride : 0;
+  // A small right-most-path automaton (DevTables::rm_small) is staged as its byte-indexed image instead: [state][byte] -> next state,
+  // or 0x80 | depth where the path dies; [state] the same for the end of the text; [previous byte] -> start state.  One look-up per
+  // step of the replay and none for the class, the depth or the start context.
+  const bool rm8 = ref && F.rm_small[0] != 0;
+  const int rm_cells = ref && !rm8 ? F.rm_nstates[0] * F.stride : 0;
   unsigned char* const rm_base = smem + Y.total;
   const uint16_t* const s_rm = reinterpret_cast<const uint16_t*>(rm_base);
   const uint8_t* const s_rmd = rm_base + ((rm_cells * 2 + 15) & ~15);
   const uint8_t* const s_fcls = s_rmd + ((F.rm_nstates[0] + 15) & ~15);
   const uint8_t* const s_fctx = s_fcls + 256;
+  const Lds8 s_rm8 = (Lds8)rm_base;
+  const Lds8 s_rm8eot = s_rm8 + F.rm_nstates[0] * 256;
+  const Lds8 s_rm8start = s_rm8eot + 32;
+  if (rm8) {
+    const int nst = F.rm_nstates[0];
+    for (int x = tid; x < nst * 256; x += kBlockThreads) {
+      const int st = x >> 8;
+      const unsigned nx = F.rm_trans[0][st * F.stride + F.cls[x & 255]];
+      rm_base[x] = nx == 0xFFFFu ? (unsigned char)(0x80u | F.rm_depth[0][st]) : (unsigned char)nx;
+    }
+    if (tid < nst) {
+      const unsigned nx = F.rm_trans[0][tid * F.stride + F.ncls];
+      rm_base[nst * 256 + tid] = nx == 0xFFFFu ? (unsigned char)(0x80u | F.rm_depth[0][tid]) : (unsigned char)nx;
+    }
+    rm_base[nst * 256 + 32 + tid] = (unsigned char)F.rm_start[0][F.ctx_of_byte[tid]];
+  } else
   if (ref) {
     uint16_t* d = reinterpret_cast<uint16_t*>(rm_base);
     for (int i = tid; i < rm_cells; i += kBlockThreads) d[i] = F.rm_trans[0][i];
@@ -1772,16 +1802,61 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
     // The walk and the back-trace, generic in where the state trace and the back-trace tables live (LDS-qualified or global
     // pointers: a pointer that may be either is a FLAT access).  trace entry k at trb[k * ts]: interleaved across the workgroup in
     // LDS (conflict-free rows), contiguous in the global fallback.
-    auto process = [&](auto trb, const int ts, const auto& B) {
+    auto process = [&](auto trb, const int ts, const auto& B, const auto& inp) {
       auto tr = [&](int k) -> decltype(trb[0])& { return trb[k * ts]; };
       if (i < nstr) {
         // ---- one forward walk; trace[k] = state after k bytes (only kept when spans are wanted)
         unsigned q = q0;
         end = end0;
         if (want_spans) tr(0) = (TraceT)q;
+        if constexpr (std::is_same<typename std::decay<decltype(inp)>::type, BatchInputLds>::value) {
+          // The string lies in LDS whole (and is short: its trace has a row of its own): four bytes per trip out of two aligned
+          // dwords (v_alignbyte; the next pair is in flight while these are walked), no per-byte end-of-text or dead-state branch
+          // -- the dead state's row is all zero (rgx_dfa.cc: state 0), so a lane that died keeps stepping 0 -> 0 without flags
+          // until the wave's trip ends.  Half the instructions per byte of the loop below (the kernel is bound by their issue).
+          const unsigned addr = (unsigned)(uintptr_t)inp.lds;
+          const Lds32 w32 = (Lds32)(uintptr_t)(addr & ~3u);
+          const unsigned sh = addr & 3u;
+          const int len = inp.len;
+          const Lds16 tl = (Lds16)(smem + Y.trans);
+          const Lds8 cl = (Lds8)(smem + Y.cls);
+          const bool look = U.lookahead != 0;               // uniform
+          unsigned lo = w32[0], hi = w32[1];
+          int at = 0;
+          while (at + 4 <= len && q != kDead) {
+            const unsigned b4 = __builtin_amdgcn_alignbyte(hi, lo, sh);
+            lo = hi; hi = w32[(at >> 2) + 2];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+              const unsigned c = (b4 >> (8 * k)) & 255u;
+              const unsigned ed = MODE == kModeDirect ? tl[(q << 8) + c] : tl[q * stride + cl[c]];
+              if (look && (ed & kMatchBefore)) end = at + k;
+              if (ed & kMatchAfter) end = at + k + 1;
+              q = ed & kStateMask;
+              tr(at + k + 1) = (TraceT)q;
+            }
+            at += 4;
+          }
+          if (q != kDead) {
+            const unsigned b4 = __builtin_amdgcn_alignbyte(hi, lo, sh);
+            for (int k = 0; at < len && q != kDead; ++k, ++at) {
+              const unsigned c = (b4 >> (8 * k)) & 255u;
+              const unsigned ed = MODE == kModeDirect ? tl[(q << 8) + c] : tl[q * stride + cl[c]];
+              if (ed & kMatchBefore) end = at;
+              if (ed & kMatchAfter) end = at + 1;
+              q = ed & kStateMask;
+              if (q != kDead) tr(at + 1) = (TraceT)q;
+            }
+            if (q != kDead) {                               // the end of the text
+              const unsigned ed = tab.StepEot(q);
+              if (ed & kMatchBefore) end = len;
+              if (ed & kMatchAfter) end = len + 1;
+            }
+          }
+        } else
         for (int at = 0;; ++at) {
-          const bool eot = at >= in.len;
-          const unsigned ed = eot ? tab.StepEot(q) : tab.Step(q, in.At(at));
+          const bool eot = at >= inp.len;
+          const unsigned ed = eot ? tab.StepEot(q) : tab.Step(q, inp.At(at));
           if (ed & kMatchBefore) end = at;
           if (ed & kMatchAfter) end = at + 1;
           q = ed & kStateMask;
@@ -1795,32 +1870,44 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
       int32_t* rec = recs + tid * ncap;
       if (i < nstr) {
         for (int c = 0; c < ncap; ++c) rec[c] = unset;
-        if (end >= 0) {
+        if (end >= 0 && !(exp_skip & 1)) {
           // ---- back-trace from the winning thread at `end` until it passes Capture 0 (the match start)
           unsigned setmask = 2u;
           rec[1] = end;
           int j;
+          // one step back over byte p along thread j: the ops of the edge's thread, then its parent.  Only the parent look-up
+          // depends on the step before it: four steps at a time, their states, bytes and edge slices fetched together.
+          auto back_step = [&](unsigned base, int pos) {
+            unsigned o = B.bt_ops[base + j] & ~setmask;
+            j = B.bt_parent[base + j];
+            while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = pos; setmask |= 1u << c; }
+          };
+          auto back = [&](int p, const int add) {
+            while (p >= 3 && !(setmask & 1u)) {
+              const unsigned t0 = tr(p), t1 = tr(p - 1), t2 = tr(p - 2), t3 = tr(p - 3);
+              const unsigned c0 = tab.cls[inp.At(p)], c1 = tab.cls[inp.At(p - 1)], c2 = tab.cls[inp.At(p - 2)], c3 = tab.cls[inp.At(p - 3)];
+              const unsigned b0 = B.bt_base[t0 * stride + c0], b1 = B.bt_base[t1 * stride + c1];
+              const unsigned b2 = B.bt_base[t2 * stride + c2], b3 = B.bt_base[t3 * stride + c3];
+              back_step(b0, p + add);
+              if (!(setmask & 1u)) back_step(b1, p - 1 + add);
+              if (!(setmask & 1u)) back_step(b2, p - 2 + add);
+              if (!(setmask & 1u)) back_step(b3, p - 3 + add);
+              p -= 4;
+            }
+            for (; p >= 0 && !(setmask & 1u); --p)
+              back_step(B.bt_base[(unsigned)tr(p) * stride + tab.cls[inp.At(p)]], p + add);
+          };
           if (U.lookahead) {
             const unsigned qe = tr(end);
-            const int k = end < in.len ? tab.cls[in.At(end)] : U.ncls;
+            const int k = end < inp.len ? tab.cls[inp.At(end)] : U.ncls;
             const unsigned m = B.bt_match[qe * stride + k];
             j = (int)(m >> 24);
             unsigned ops = (m & 0xFFFFFFu) & ~setmask;
             while (ops) { const int c = __builtin_ctz(ops); ops &= ops - 1; rec[c] = end; setmask |= 1u << c; }
-            for (int p = end - 1; p >= 0 && !(setmask & 1u); --p) {
-              const unsigned base = B.bt_base[(unsigned)tr(p) * stride + tab.cls[in.At(p)]];
-              unsigned o = B.bt_ops[base + j] & ~setmask;
-              while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = p; setmask |= 1u << c; }
-              j = B.bt_parent[base + j];
-            }
+            back(end - 1, 0);
           } else {
             j = (int)B.st_nthreads[tr(end)] - 1;
-            for (int p = end - 1; p >= 0 && !(setmask & 1u); --p) {
-              const unsigned base = B.bt_base[(unsigned)tr(p) * stride + tab.cls[in.At(p)]];
-              unsigned o = B.bt_ops[base + j] & ~setmask;
-              while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = p + 1; setmask |= 1u << c; }
-              j = B.bt_parent[base + j];
-            }
+            back(end - 1, 1);
             if (!(setmask & 1u)) {
               unsigned o = B.start_ops_pool[B.start_ops[kCtxBOT] + j] & ~setmask;
               while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = 0; setmask |= 1u << c; }
@@ -1830,21 +1917,35 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
             const int s = rec[0];
             for (int c = 2; c < ncap; ++c) rec[c] = F.cap_kind[c] == kCapFromStart ? s + F.cap_delta[c] : end - F.cap_delta[c];
           }
-          if (ref && !F.anchored) {
+          if (ref && !F.anchored && !(exp_skip & 2)) {
             const int s0 = rec[0];
             int off = 0;
             bool lost = false;
+            if (rm8) {
+              const unsigned st_bot = F.rm_start[0][kCtxBOT];
+              while (off < s0) {
+                unsigned st = off == 0 ? st_bot : (unsigned)s_rm8start[inp.At(off - 1)];
+                int fo;
+                for (int p = off;; ++p) {
+                  const unsigned e = p < inp.len ? (unsigned)s_rm8[(st << 8) + inp.At(p)] : (unsigned)s_rm8eot[st];
+                  if (e & 0x80u) { fo = p - (int)(e & 0x7Fu); break; }
+                  st = e;
+                }
+                if (!(inp.len > fo)) { lost = true; break; }
+                off = fo + 1;
+              }
+            } else
             while (off < s0) {
               // failure offset of the attempt at `off`: where its right-most path dies (find.go:545-569 resumes behind it)
-              unsigned st = F.rm_start[0][off == 0 ? kCtxBOT : s_fctx[in.At(off - 1)]];
+              unsigned st = F.rm_start[0][off == 0 ? kCtxBOT : s_fctx[inp.At(off - 1)]];
               int fo = off;
               for (int p = off;; ++p) {
-                const unsigned k = p < in.len ? (unsigned)s_fcls[in.At(p)] : (unsigned)F.ncls;
+                const unsigned k = p < inp.len ? (unsigned)s_fcls[inp.At(p)] : (unsigned)F.ncls;
                 const unsigned nx = s_rm[st * F.stride + k];
                 if (nx == 0xFFFFu) { fo = p - (int)s_rmd[st]; break; }
                 st = nx;
               }
-              if (!(in.len > fo)) { lost = true; break; }
+              if (!(inp.len > fo)) { lost = true; break; }
               off = fo + 1;
             }
             if (lost) { found[i] = 0; for (int c = 0; c < ncap; ++c) rec[c] = unset; }
@@ -1856,13 +1957,22 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
     {
       typedef TraceT __attribute__((address_space(3)))* LdsTrace;
       const bool short_str = in.len + 2 <= kBatchTrace;
-      if (!want_spans) process((TraceT*)nullptr, 1, BG);
+      // the ordinary group -- every string short, every byte of the group inside the staged window: the bytes come from LDS
+      // without the "or from global memory" select of BatchInput::At (a FLAT load per byte otherwise: 1.32 -> 1.15 ms on C3)
+      const bool all_lds = (ge - wb) <= (uint64_t)wvalid && !(exp_skip & 4);      // uniform
+      if (!want_spans) process((TraceT*)nullptr, 1, BG, in);
       else if (short_str) {
         LdsTrace t = (LdsTrace)(smem + Y.trace) + tid;
-        if (Y.bt_in_lds) process(t, (int)kBlockThreads, BL); else process(t, (int)kBlockThreads, BG);
+        if (Y.bt_in_lds) {
+          if (all_lds) {
+            BatchInputLds il;
+            il.lds = (Lds8)win + in.rel0; il.len = in.len;
+            process(t, (int)kBlockThreads, BL, il);
+          } else process(t, (int)kBlockThreads, BL, in);
+        } else process(t, (int)kBlockThreads, BG, in);
       } else {
         TraceT* t = gtrace + o0 + 2 * i;
-        if (Y.bt_in_lds) process(t, 1, BL); else process(t, 1, BG);
+        if (Y.bt_in_lds) process(t, 1, BL, in); else process(t, 1, BG, in);
       }
     }
     if (!want_spans) continue;
@@ -2352,6 +2462,13 @@ hipError_t LaunchBatchRefFix(const DevTables& T, const uint8_t* concat, const ui
   return hipGetLastError();
 }
 
+// LDS behind the search layout for the replay of the reference's attempt offsets (batch_search_kernel)
+static int SearchRmBytes(const DevTables& F, bool ref) {
+  if (!ref) return 0;
+  if (F.rm_small[0]) return F.rm_nstates[0] * 256 + 32 + 256;
+  return ((F.rm_nstates[0] * F.stride * 2 + 15) & ~15) + ((F.rm_nstates[0] + 15) & ~15) + 512;
+}
+
 int BatchWindowFor(int64_t total_bytes, int64_t nstr) {
   // a group of 256 strings should fit the window; short strings get the small window (one more workgroup per CU)
   if (nstr <= 0 || total_bytes < 0) return kBatchWindow;
@@ -2365,7 +2482,8 @@ hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8
   const bool t8 = U.nstates <= 256;
   const SearchLayout Y = SearchLdsLayout(U, F.ncap, spans != nullptr, t8 ? 1 : 2, window_bytes);
   if (!spans) ref = 0;
-  const int rm_bytes = ref ? ((F.rm_nstates[0] * F.stride * 2 + 15) & ~15) + ((F.rm_nstates[0] + 15) & ~15) + 512 : 0;
+  if (ExpEnv("RGX_C3_SKIP")) ref |= atoi(ExpEnv("RGX_C3_SKIP")) << 8;
+  const int rm_bytes = SearchRmBytes(F, (ref & 1) != 0);
   static int cus = 0;
   if (!cus) {
     int dev = 0;
@@ -2396,7 +2514,7 @@ hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8
 
 bool BatchSearchFits(const DevTables& U, const DevTables& F, bool want_spans, const uint8_t* concat, bool with_ref) {
   if (U.mode == kModeClassGlobal || F.ncap > 32 || (((uintptr_t)concat) & 15) != 0) return false;
-  const int rm_bytes = with_ref ? ((F.rm_nstates[0] * F.stride * 2 + 15) & ~15) + ((F.rm_nstates[0] + 15) & ~15) + 512 : 0;
+  const int rm_bytes = SearchRmBytes(F, with_ref);
   return SearchLdsLayout(U, F.ncap, want_spans, U.nstates <= 256 ? 1 : 2).total + rm_bytes <= 150 * 1024;
 }
 

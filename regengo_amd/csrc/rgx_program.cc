@@ -177,6 +177,8 @@ int UploadTables(const Tables& t, std::vector<uint16_t>* direct_table, DevTables
     d.rm_trans[v] = (const uint16_t*)(b + off_rmt[v]);
     d.rm_depth[v] = b + off_rmd[v];
     d.rm_nstates[v] = (int32_t)t.rm_depth[v].size();
+    d.rm_small[v] = !t.rm_depth[v].empty() && t.rm_depth[v].size() <= 32 ? 1 : 0;
+    for (uint8_t dp : t.rm_depth[v]) if (dp > 127) d.rm_small[v] = 0;
     for (int c = 0; c < 4; c++) d.rm_start[v][c] = t.rm_start[v][c];
   }
   d.ref_prefix = t.ref_prefix;

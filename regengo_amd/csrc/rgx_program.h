@@ -77,6 +77,7 @@ struct DevTables {
   const uint8_t* rm_depth[2];
   uint16_t rm_start[2][4];
   int32_t rm_nstates[2];          // rows of rm_trans[v] (each T.stride entries)
+  int32_t rm_small[2];            // at most 32 states and no depth above 127: the batch kernel composes a byte-indexed image of it
   int32_t ref_prefix;             // MatchBytes' required first byte, -1: none
   int32_t ref_find_ok;            // 1: FindBytesReuse in reference mode is offered (plain backtracking engine, no memo)
   int32_t ref_match_kind;         // 0: restart rule over rm_*[1]; 1: the Thompson matcher (plain existence); 2: not offered
