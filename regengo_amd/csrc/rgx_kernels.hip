@@ -1682,7 +1682,7 @@ __host__ __device__ inline SearchLayout SearchLdsLayout(const DevTables& U, int 
     L.st_ops = take(16);
     L.st_pool = take(U.start_pool_n * 4);
   }
-  L.window = take(window_bytes + 16);
+  L.window = take(window_bytes + 64);        // four waves' quarters, 16 bytes of slack behind each
   if (want_spans) {
     L.trace = take(kBlockThreads * kBatchTrace * trace_entry_bytes);
     L.recs = take(kBlockThreads * ncap * 4);
@@ -1783,21 +1783,32 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
   const int unset = F.unmatched_minus1 ? -1 : 0;
   const int stride = U.stride;
 
+  // Every WAVE works for itself from here on: it stages the bytes of its own 64 strings into its own quarter of the window, owns
+  // its lanes' trace rows and records, and copies its records out -- nothing in a group is shared between waves but the tables,
+  // so no wave waits at a barrier for the wave with the longest string of the group (a wave's own LDS traffic is ordered).
+  __syncthreads();                                  // the tables are staged
+  const int wave_id = tid >> 6, wave_lane = tid & 63;
+  const int wslice = (window_bytes >> 2) & ~15;     // bytes of the window a wave owns (+ 16 of slack behind each)
+  unsigned char* const wwin = win + wave_id * (wslice + 16);
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int64_t i0 = grp * kBlockThreads;
-    const int64_t i = i0 + tid;
-    const int64_t ilast = min(i0 + (int64_t)kBlockThreads, nstr);
+    const int64_t i0 = grp * kBlockThreads + wave_id * 64;       // the wave's first string
+    if (i0 >= nstr) break;
+    const int64_t i = i0 + wave_lane;
+    const int64_t ilast = min(i0 + (int64_t)64, nstr);
     const uint64_t gb = offsets[i0], ge = offsets[ilast];
     const uint64_t wb = gb & ~15ull;
-    const int wvalid = (int)min((uint64_t)window_bytes, ((ge - wb) + 15ull) & ~15ull);
-    __syncthreads();
-    for (int c = tid; c < (wvalid >> 4); c += kBlockThreads)
-      *reinterpret_cast<uint4*>(win + (c << 4)) = *reinterpret_cast<const uint4*>(concat + wb + ((uint64_t)c << 4));
+    const int wvalid = (int)min((uint64_t)wslice, ((ge - wb) + 15ull) & ~15ull);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int c = wave_lane; c < (wvalid >> 4); c += 64)
+      *reinterpret_cast<uint4*>(wwin + (c << 4)) = *reinterpret_cast<const uint4*>(concat + wb + ((uint64_t)c << 4));
     uint64_t o0 = 0, o1 = 0;
     if (i < nstr) { o0 = offsets[i]; o1 = offsets[i + 1]; }
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     BatchInput in;
-    in.g = concat + o0; in.lds = win; in.rel0 = (int)min(o0 - wb, (uint64_t)0x3FFFFFFF); in.wvalid = wvalid; in.len = (int)(o1 - o0);
+    in.g = concat + o0; in.lds = wwin; in.rel0 = (int)min(o0 - wb, (uint64_t)0x3FFFFFFF); in.wvalid = wvalid; in.len = (int)(o1 - o0);
     int end = -1;
     // The walk and the back-trace, generic in where the state trace and the back-trace tables live (LDS-qualified or global
     // pointers: a pointer that may be either is a FLAT access).  trace entry k at trb[k * ts]: interleaved across the workgroup in
@@ -1966,7 +1977,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
         if (Y.bt_in_lds) {
           if (all_lds) {
             BatchInputLds il;
-            il.lds = (Lds8)win + in.rel0; il.len = in.len;
+            il.lds = (Lds8)wwin + in.rel0; il.len = in.len;
             process(t, (int)kBlockThreads, BL, il);
           } else process(t, (int)kBlockThreads, BL, in);
         } else process(t, (int)kBlockThreads, BG, in);
@@ -1981,11 +1992,13 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
     // string without a match is unspecified) -- whole-line validators over log lines find nothing in nearly every wave, and
     // their unset records were most of the kernel's traffic.  (No workgroup-wide vote: __syncthreads_or brings static LDS,
     // which the 160 KiB dynamic allocation has no room for.)
-    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     {
-      const int wv = tid >> 6, ln = tid & 63;
-      const int64_t w0 = i0 + (int64_t)wv * 64;
-      const int nw = (int)(ilast - w0 < 64 ? (ilast - w0 < 0 ? 0 : ilast - w0) : 64);
+      const int wv = wave_id, ln = wave_lane;
+      const int64_t w0 = i0;
+      const int nw = (int)(ilast - w0);
       if (__any(i < nstr && end >= 0) && nw > 0) {
         const int nwords = nw * ncap;
         const int32_t* const src = recs + wv * 64 * ncap;
