@@ -1584,6 +1584,7 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
   int32_t* const recs = reinterpret_cast<int32_t*>(smem + Y.recs);
   const bool no_priv = debug_flags & 1;
   const int64_t ngroups = (nmatches + kBlockThreads - 1) / kBlockThreads;
+  __syncthreads();                                     // the tables are staged
 
   for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
     const int64_t i0 = grp * kBlockThreads;
@@ -1591,7 +1592,10 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
     const int64_t ilast = min(i0 + (int64_t)kBlockThreads, nmatches);
     int s = 0, e = 0;
     if (i < nmatches) { s = spans[i * ncap]; e = spans[i * ncap + 1]; }
-    __syncthreads();                                   // the previous group's records have left `recs`
+    // (a wave's rows, trace columns and records are its own, and it copies its own records out below: no workgroup barrier in
+    // the loop -- a wave with short matches does not wait for the one with the longest)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
     PrivInput in;
     in.g = buf; in.row = (Lds8)(win + (tid << 2)); in.len = len;
     in.p0 = (s > 0 ? s - 1 : 0) & ~15;
@@ -1637,16 +1641,21 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
         else ResolveCapturesBatch<MODE, TraceT, PrivInput, BtTabs, TraceT*>(tab, BG, T, tab.cls, ctx_of_byte, in, s, e, tr, 1, rec);
       }
     }
-    __syncthreads();
-    const int nrec_words = (int)(ilast - i0) * ncap;
-    int32_t* const dst = spans + i0 * ncap;
-    if (((i0 * ncap) & 3) == 0) {
-      for (int w = tid * 4; w < nrec_words; w += kBlockThreads * 4) {
-        if (w + 4 <= nrec_words) *reinterpret_cast<int4*>(dst + w) = *reinterpret_cast<const int4*>(recs + w);
-        else for (int k = w; k < nrec_words; ++k) dst[k] = recs[k];
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    {
+      // the wave's 64 records: contiguous in `spans` and 16-byte aligned (a group starts at a multiple of 256 matches)
+      const int wv = tid >> 6, ln = tid & 63;
+      const int64_t w0 = i0 + (int64_t)wv * 64;
+      const int nw = (int)(ilast - w0 < 64 ? (ilast - w0 < 0 ? 0 : ilast - w0) : 64);
+      const int nrec_words = nw * ncap;
+      const int32_t* const src = recs + wv * 64 * ncap;
+      int32_t* const dst = spans + w0 * ncap;
+      for (int w = ln * 4; w < nrec_words; w += 256) {
+        if (w + 4 <= nrec_words) *reinterpret_cast<int4*>(dst + w) = *reinterpret_cast<const int4*>(src + w);
+        else for (int k = w; k < nrec_words; ++k) dst[k] = src[k];
       }
-    } else {
-      for (int w = tid; w < nrec_words; w += kBlockThreads) dst[w] = recs[w];
     }
   }
 }
