@@ -198,7 +198,7 @@ constexpr int kUsMaxEntries = 4096;      // 32 KiB of LDS for the table at most 
 bool BuildUs(Program* p) {
   static const bool off = ExpEnv("RGX_NO_US") != nullptr;
   if (off || p->t.anchored || p->t.can_match_empty) return false;
-  for (int regs : {1, 2, 4}) {
+  for (int regs : {1, 2, 4, 8}) {
     try {
       StartSearch u = BuildStartSearch(p->t.pattern, p->t.flags, 2000, regs);
       if (!u.ok || (int64_t)u.nstates * (u.ncls + 1) > kUsMaxEntries) continue;
@@ -227,8 +227,10 @@ int UploadUs(Program* p) {
       if (nq == 0 && q != 0) lo |= 1u << 24;               // every thread dies on this edge (the dead state's own row stays all zero)
       if (e & kUsFinal) lo |= 1u << 25;
       if (e & (kUsBefore | kUsAfter)) lo |= 1u << 26;      // one flag: a construction is either lazy (before) or eager (after)
-      if (e & kUsSet) lo |= 1u << (31 - ((e >> kUsRegShift) & 7));
-      const uint32_t hi = (uint32_t)mi | ((uint32_t)u.oldest[nq] << 16);
+      const uint32_t rj = (e >> kUsRegShift) & 7;
+      if ((e & kUsSet) && rj < 4) lo |= 1u << (31 - rj);
+      uint32_t hi = (uint32_t)mi | ((uint32_t)u.oldest[nq] << 16);
+      if ((e & kUsSet) && rj >= 4) hi |= 1u << (24 + (rj - 4));      // registers 4..7 load from the high word (rgx_scan_us.hip: kEHLoad4..7)
       ent[(size_t)q * stride + k] = ((unsigned long long)hi << 32) | lo;
     }
   std::vector<uint16_t> srow(stride);
@@ -333,7 +335,7 @@ int UploadUs(Program* p) {
   UsDev d{};
   d.ent = (const unsigned long long*)(b + off_ent); d.cls = b + off_cls;
   d.start_row_of_cls = (const uint16_t*)(b + off_srow); d.reset_of_cls = b + off_rst;
-  d.nent = nent; d.stride = stride; d.ncls = u.ncls; d.nregs = u.nregs <= 1 ? 1 : (u.nregs <= 2 ? 2 : 4); d.lookahead = u.lookahead ? 1 : 0;
+  d.nent = nent; d.stride = stride; d.ncls = u.ncls; d.nregs = u.nregs <= 1 ? 1 : (u.nregs <= 2 ? 2 : (u.nregs <= 4 ? 4 : 8)); d.lookahead = u.lookahead ? 1 : 0;
   if (simple) {
     d.ent4 = (const uint32_t*)(b + off_ent4); d.start_row4 = (const uint16_t*)(b + off_srow4);
     d.nent4 = (int32_t)ent4.size(); d.rstmask = rstmask; d.cls4 = b + off_cls4;

@@ -105,7 +105,7 @@ struct UsDev {
   int32_t nent;                   // entries = nstates * stride
   int32_t stride;                 // ncls + 1
   int32_t ncls;
-  int32_t nregs;                  // registers the automaton uses (1, 2 or 4 in the kernel's instantiations)
+  int32_t nregs;                  // registers the automaton uses (1, 2, 4 or 8 in the kernel's instantiations)
   int32_t lookahead;              // 1: match flags are kUsBefore (lazy construction), 0: kUsAfter
   // "simple" automata (StartSearch::simple): register-free walk, scan_us_simple_kernel.  32-bit entries, rows of 260 bytes
   // (32 entries twice: the tile byte is class * 4, bit 7 set on reset bytes; one dword of padding spreads the rows over banks):

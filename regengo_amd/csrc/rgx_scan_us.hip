@@ -43,6 +43,7 @@ __device__ __forceinline__ int UPad(int rel) { return rel + ((rel >> 6) << 2); }
 // device entry fields (rgx_program.h: UsDev)
 constexpr unsigned kEDead = 1u << 24, kEFinal = 1u << 25, kEMatch = 1u << 26;
 constexpr unsigned kELoad0 = 1u << 31, kELoad1 = 1u << 30, kELoad2 = 1u << 29, kELoad3 = 1u << 28;
+constexpr unsigned kEHLoad4 = 1u << 24, kEHLoad5 = 1u << 25, kEHLoad6 = 1u << 26, kEHLoad7 = 1u << 27;   // registers 4..7: in the HIGH word of the entry
 
 // LDS-qualified pointer types.  The single-step walkers are real functions (not inlined): a plain pointer parameter is a generic
 // pointer there and every access through it a FLAT instruction -- the walker of the pair kernel then paid ~1300 cycles per byte
@@ -109,7 +110,9 @@ struct UsOut {
   int last_end;
 };
 
-#define US_START(info) (NREG == 1 ? r0 : (NREG == 2 ? (((info) & 1u) ? r1 : r0) : (((info) & 2u) ? (((info) & 1u) ? r3 : r2) : (((info) & 1u) ? r1 : r0))))
+#define US_START4(info) (((info) & 2u) ? (((info) & 1u) ? r3 : r2) : (((info) & 1u) ? r1 : r0))
+#define US_START(info) (NREG == 1 ? r0 : (NREG == 2 ? (((info) & 1u) ? r1 : r0) : (NREG == 4 ? US_START4(info) : \
+                        (((info) & 4u) ? (((info) & 2u) ? (((info) & 1u) ? r7 : r6) : (((info) & 1u) ? r5 : r4)) : US_START4(info)))))
 #define US_INFO(word) (LOOK ? ((word) & 255u) : (((word) >> 8) & 255u))
 
 // Per-lane single-step walker: from the sync point `pos` to the end of the slice [a, slice_end) and on until no thread that
@@ -126,8 +129,8 @@ __device__ __noinline__ void UsWalkSlow(LdsU8c s_entb, LdsU16c s_srow, const UIn
   }
   int i = pos;
   unsigned row = s_srow[(i > 0 ? in.At8(i - 1) : (unsigned)in.eot8) >> 3];   // offset 0: the begin-of-text start state sits in the EOT column
-  int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-  (void)r1; (void)r2; (void)r3;
+  int r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0;
+  (void)r1; (void)r2; (void)r3; (void)r4; (void)r5; (void)r6; (void)r7;
   int pend = -1;
   unsigned pinfo = 0;
   for (;;) {
@@ -148,6 +151,7 @@ __device__ __noinline__ void UsWalkSlow(LdsU8c s_entb, LdsU16c s_srow, const UIn
     if (NREG > 1 && (lo & kELoad1)) r1 = v;
     if (NREG > 2 && (lo & kELoad2)) r2 = v;
     if (NREG > 2 && (lo & kELoad3)) r3 = v;
+    if (NREG > 4) { if (hi & kEHLoad4) r4 = v; if (hi & kEHLoad5) r5 = v; if (hi & kEHLoad6) r6 = v; if (hi & kEHLoad7) r7 = v; }
     if (!LOOK && (lo & kEMatch)) { pend = i1; pinfo = hi; }
     row = lo;
     i = i1;
@@ -286,8 +290,8 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_kernel(DevTables T, UsD
     const unsigned phase = fast ? (unsigned)(pos & 3) : 4u;            // the sub-step at which the lane enters its start state
     int lim = fast ? slice_end : 0x7FFFFFFF;
     unsigned row = 0;                 // parked until its sub-step comes
-    int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-    (void)r1; (void)r2; (void)r3;
+    int r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0;
+    (void)r1; (void)r2; (void)r3; (void)r4; (void)r5; (void)r6; (void)r7;
     int pend = -1;
     unsigned pinfo = 0, hi_last = 0;
     const int send = slice_end;
@@ -330,6 +334,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_kernel(DevTables T, UsD
     r0 = ((int)lo < 0) ? v : r0;                                                                                \
     if (NREG > 1) r1 = (lo & kELoad1) ? v : r1;                                                                 \
     if (NREG > 2) { r2 = (lo & kELoad2) ? v : r2; r3 = (lo & kELoad3) ? v : r3; }                               \
+    if (NREG > 4) { r4 = (hi & kEHLoad4) ? v : r4; r5 = (hi & kEHLoad5) ? v : r5; r6 = (hi & kEHLoad6) ? v : r6; r7 = (hi & kEHLoad7) ? v : r7; } \
     if (!LOOK) {                                                                                                \
       const bool fa = (lo & kEMatch) != 0;                                                                      \
       pend = fa ? i1 : pend;                                                                                    \
@@ -1434,8 +1439,8 @@ __global__ __launch_bounds__(64) void carry_us_kernel(DevTables T, UsDev U, cons
   while (cur < nslices && unsynced[cur] && pos < len) {
     int i = pos;
     unsigned row = s_srow[(i > 0 ? cls8(i - 1) : (unsigned)U.ncls << 3) >> 3];
-    int r0 = 0, r1 = 0, r2 = 0, r3 = 0;
-    (void)r1; (void)r2; (void)r3;
+    int r0 = 0, r1 = 0, r2 = 0, r3 = 0, r4 = 0, r5 = 0, r6 = 0, r7 = 0;
+    (void)r1; (void)r2; (void)r3; (void)r4; (void)r5; (void)r6; (void)r7;
     int pend = -1;
     unsigned pinfo = 0;
     bool restarted = false;
@@ -1456,6 +1461,7 @@ __global__ __launch_bounds__(64) void carry_us_kernel(DevTables T, UsDev U, cons
       if (NREG > 1 && (lo & kELoad1)) r1 = v;
       if (NREG > 2 && (lo & kELoad2)) r2 = v;
       if (NREG > 2 && (lo & kELoad3)) r3 = v;
+      if (NREG > 4) { if (hi & kEHLoad4) r4 = v; if (hi & kEHLoad5) r5 = v; if (hi & kEHLoad6) r6 = v; if (hi & kEHLoad7) r7 = v; }
       if (!LOOK && (lo & kEMatch)) { pend = i1; pinfo = hi; }
       row = lo;
       i = i1;
@@ -1568,9 +1574,9 @@ hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t str
     hipLaunchKernelGGL((scan_us_kernel<N, LK>), grid, block, shmem, stream, T, U, P);                   \
   } while (0)
   if (U.lookahead) {
-    if (U.nregs <= 1) RGX_US(1, true); else if (U.nregs <= 2) RGX_US(2, true); else RGX_US(4, true);
+    if (U.nregs <= 1) RGX_US(1, true); else if (U.nregs <= 2) RGX_US(2, true); else if (U.nregs <= 4) RGX_US(4, true); else RGX_US(8, true);
   } else {
-    if (U.nregs <= 1) RGX_US(1, false); else if (U.nregs <= 2) RGX_US(2, false); else RGX_US(4, false);
+    if (U.nregs <= 1) RGX_US(1, false); else if (U.nregs <= 2) RGX_US(2, false); else if (U.nregs <= 4) RGX_US(4, false); else RGX_US(8, false);
   }
 #undef RGX_US
   return hipGetLastError();
@@ -1587,9 +1593,9 @@ hipError_t LaunchCarryUs(const DevTables& T, const uint8_t* buf, int32_t len, co
   dim3 block(64), grid((nslices + 63) / 64);
 #define RGX_CU(N, LK) hipLaunchKernelGGL((carry_us_kernel<N, LK>), grid, block, shmem, stream, T, U, buf, len, slice_unsynced, carry_in, nslices)
   if (U.lookahead) {
-    if (U.nregs <= 1) RGX_CU(1, true); else if (U.nregs <= 2) RGX_CU(2, true); else RGX_CU(4, true);
+    if (U.nregs <= 1) RGX_CU(1, true); else if (U.nregs <= 2) RGX_CU(2, true); else if (U.nregs <= 4) RGX_CU(4, true); else RGX_CU(8, true);
   } else {
-    if (U.nregs <= 1) RGX_CU(1, false); else if (U.nregs <= 2) RGX_CU(2, false); else RGX_CU(4, false);
+    if (U.nregs <= 1) RGX_CU(1, false); else if (U.nregs <= 2) RGX_CU(2, false); else if (U.nregs <= 4) RGX_CU(4, false); else RGX_CU(8, false);
   }
 #undef RGX_CU
   return hipGetLastError();
