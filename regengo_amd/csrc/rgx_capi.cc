@@ -202,7 +202,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   // e-mail + rest-of-line pattern).  They keep their kernel now: the exact sync points of the sync automaton (LaunchWSync: one
   // optimistic walk per 4 KiB chunk + repair) are handed over as per-slice start positions, like the carry pass's.
   static const bool no_us_ws = ExpEnv("RGX_NO_US_WSYNC") != nullptr;
-  const bool us_ws = use_w && !no_us_ws && T.reset_values == 0 && UseUsKernel(T, ilen, false) && UsKernelVariant(T) != 4 &&     // (the register kernel
+  const bool us_ws = use_w && !no_us_ws && T.reset_values == 0 && UseUsKernel(T, ilen, false) && (UsKernelVariant(T) != 4 || ExpEnv("RGX_US_WS4")) &&     // (the register kernel
                      p->prefer_wsync.load(std::memory_order_relaxed) != -2;      // walks every slice from behind: slower than the generic kernel's W path, measured)
   if (us_ws) use_w = false;
   int32_t ntiles = ScanNumTiles(T, ilen, use_w);

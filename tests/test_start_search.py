@@ -106,3 +106,19 @@ def test_start_search_with_few_registers(corpus, kats, hostlib):
                 assert u.find_all(b, 0, 16) == exp, (regs, p, b)
                 n += 1
     assert n > 300
+
+
+def test_five_concurrent_starts_need_five_registers(hostlib):
+    """`(\\w+\\s+){5}\\w+`: five word starts are alive at once.  Four registers are not enough (the product tries 1, 2, 4, 8 and the
+    register kernel has an instance for eight since round 3); with eight the walk equals the oracle."""
+    p = r"(?P<words>(?P<word>\w+\s+){5})(?P<end>\w+)"
+    with pytest.raises(ValueError):
+        hostlib.StartSearch(p, 0, 2000, 4)
+    u = hostlib.StartSearch(p, 0, 2000, 8)
+    assert 4 < u.nregs <= 8
+    o = E.Compiled(p)
+    text = b"a bb  ccc d e f g hh, i j k l m n o p q\nr s t u v w\tx y z 1 2 3 4 5 6 7 8 9 0 - a b c d e f"
+    exp = [tuple(m[:2]) for m in o.find_machine.find_all(text)]
+    assert len(exp) >= 3
+    assert u.find_all(text) == exp
+    assert u.find_all(text, 0, 5) == exp
