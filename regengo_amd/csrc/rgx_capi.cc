@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
+#include <mutex>
 #include <new>
 #include <vector>
 
@@ -25,6 +27,11 @@ struct rgx_program {
   mutable std::atomic<int> prefer_w{0};
   mutable std::atomic<int> prefer_wsync{0};  // the blind walk of the sync automaton left slices without a sync point: exact sync points first (FindAllDevice)
   mutable std::atomic<int> prefer_rw{0};   // the pair kernel's rewinding instance (FindAllDevice: many lanes went to the single-step walker)
+  // The ASCII twin (AsciiTwin below): the same pattern built for texts without a byte >= 0x80 (rgx_dfa.h: kFlagAsciiText).  Made on the
+  // first large scan of a program that misses the one-step-per-byte kernels; kept only if the twin reaches them.
+  mutable std::mutex twin_mu;
+  mutable std::unique_ptr<rgx_program> ascii_twin;
+  mutable std::atomic<int> ascii_state{0};   // 0 not tried, 1 there, -1 none
 };
 
 struct rgx_stream_ctx {
@@ -179,6 +186,34 @@ int ReaderCheck(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_raw, s
   return RGX_OK;
 }
 
+// `\p{L}+` is a 374-state automaton over 100 byte classes (581 x 100 with start tracking): it fits none of the one-step-per-byte
+// kernels and its scans run on the generic kernel, an attempt per start position, 7.4 ms per GiB.  On a text without a byte >= 0x80 it
+// is `[A-Za-z]+`: three states.  A program that misses those kernels therefore gets a twin built for such texts, and a scan of at
+// least 1 MiB first asks (one streaming pass, 0.15 ms per GiB) whether the text is one.  The matches are the full program's (the
+// automaton takes the same transitions when no high byte occurs); a text with a single such byte is scanned as before.
+const rgx_program* AsciiTwin(const rgx_program* p) {
+  const int st = p->ascii_state.load(std::memory_order_acquire);
+  if (st != 0) return st == 1 ? p->ascii_twin.get() : nullptr;
+  std::lock_guard<std::mutex> lock(p->twin_mu);
+  if (p->ascii_state.load() != 0) return p->ascii_state.load() == 1 ? p->ascii_twin.get() : nullptr;
+  int result = -1;
+  const Tables& t = p->p.t;
+  if (p->p.dev.us == nullptr && p->p.d_arena != nullptr && !(t.flags & kFlagAsciiText) && !t.anchored && !t.can_match_empty) {
+    try {
+      std::unique_ptr<rgx_program> tw(new rgx_program);
+      tw->p.t = BuildTables(t.pattern, t.flags | kFlagAsciiText);
+      tw->ascii_state.store(-1);
+      if (ProgramToDevice(&tw->p, p->p.device) == RGX_OK && tw->p.dev.us != nullptr && tw->p.t.ncap == t.ncap) {
+        p->ascii_twin = std::move(tw);
+        result = 1;
+      }
+    } catch (...) {
+    }
+  }
+  p->ascii_state.store(result, std::memory_order_release);
+  return result == 1 ? p->ascii_twin.get() : nullptr;
+}
+
 // Core: scan (+ carry fallback) (+ captures).  Inputs/outputs are device pointers.
 int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n, int32_t* d_spans,
                       size_t cap_records, bool count_only, rgx_result* res, bool starts_only = false, int64_t own_lo = 0,
@@ -190,6 +225,17 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   if (len > 0x7FFFFF00ull) { SetError("buffer larger than 2^31-256 bytes: shard it (FindReader path)"); return RGX_E_TOO_LARGE; }
   if ((uintptr_t)d_buf & 15) { SetError("input device pointer must be 16-byte aligned"); return RGX_E_INVALID; }
   if (!count_only && ((uintptr_t)d_spans & 15)) { SetError("span device pointer must be 16-byte aligned"); return RGX_E_INVALID; }
+  if (len >= (1u << 20) && p->ascii_state.load(std::memory_order_relaxed) >= 0) {
+    if (const rgx_program* tw = AsciiTwin(p)) {
+      unsigned* flag = reinterpret_cast<unsigned*>(c->d_cursor + 1);
+      unsigned h = 0;
+      HIP_TRY(hipMemsetAsync(flag, 0, 4, c->stream));
+      HIP_TRY(LaunchAsciiCheck(d_buf, (int64_t)len, flag, c->stream));
+      HIP_TRY(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (!h) return FindAllDevice(tw, c, d_buf, len, n, d_spans, cap_records, count_only, res, starts_only, own_lo, own_hi);
+    }
+  }
   { int vrc = MatchView(p, c, d_buf, len, &d_buf); if (vrc != RGX_OK) return vrc; }      // from here on d_buf = the bytes to match on
   const int32_t ilen = (int32_t)len;
   // sync points: reset bytes by default; the sync automaton W (rgx_dfa.h) when the pattern has no reset byte at all or

@@ -142,6 +142,7 @@ struct Builder {
         case InstRune1: {
           int32_t r = in.rune[0];
           if (r < 128) { nodes[pc].bytes.set(r); nodes[pc].out_pc = in.out; }
+          else if (p.ascii_text) { nodes[pc].out_pc = in.out; }      // (no byte of such a text begins it: the node accepts nothing)
           else {
             // multi-byte literal: compare the UTF-8 bytes (instructions.go:134-175)
             uint8_t e[4];
@@ -174,7 +175,7 @@ struct Builder {
           bool has_fffd = false, non_ascii = false;
           for (size_t i = 0; i + 1 < RR.size(); i += 2) {
             if (RR[i] < 128) seqs.push_back({{(int)RR[i], (int)std::min<int32_t>(RR[i + 1], 127)}});
-            if (RR[i + 1] >= 128) {
+            if (RR[i + 1] >= 128 && !p.ascii_text) {
               non_ascii = true;
               Utf8Split(RR[i], RR[i + 1], &seqs);
               if (RR[i] <= 0xFFFD && RR[i + 1] >= 0xFFFD) has_fffd = true;
@@ -196,10 +197,12 @@ struct Builder {
         }
         case InstRuneAny:  // one BYTE (instructions.go:298-311), not one rune
           nodes[pc].bytes.set();
+          if (p.ascii_text) for (int c = 128; c < 256; c++) nodes[pc].bytes.reset(c);
           nodes[pc].out_pc = in.out;
           break;
         case InstRuneAnyNotNL:
           nodes[pc].bytes.set();
+          if (p.ascii_text) for (int c = 128; c < 256; c++) nodes[pc].bytes.reset(c);
           nodes[pc].bytes.reset('\n');
           nodes[pc].out_pc = in.out;
           break;
@@ -369,6 +372,7 @@ std::vector<int> Successors(const Prog& p, int pc) {
 Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOptions& opt) {
   RegexpPtr ast = Simplify(Parse(pattern, kPerl));
   Prog prog = Compile(ast);
+  prog.ascii_text = (flags & kFlagAsciiText) != 0;
   Tables t;
   t.pattern = pattern;
   t.flags = flags;
@@ -846,10 +850,10 @@ static void MinimizeStartSearch(StartSearch* pu) {
 }
 
 StartSearch BuildStartSearch(const std::string& pattern, uint32_t flags, int max_states, int max_regs) {
-  (void)flags;
   StartSearch u;
   RegexpPtr ast = Simplify(Parse(pattern, kPerl));
   Prog prog = Compile(ast);
+  prog.ascii_text = (flags & kFlagAsciiText) != 0;
   if (IsAnchored(prog)) { u.why = "anchored"; return u; }
   if (MinMatchLen(ast.get()) < 1) { u.why = "can match empty"; return u; }
   // the search prefix  L: Alt(Capture0 -> start, AnyByte -> L)  (BuildOptions::unanchored_search)

@@ -106,6 +106,12 @@ struct Tables {
   std::string Describe() const;
 };
 
+// Internal build flag (never in a blob, never accepted by rgx_compile): the tables are for texts WITHOUT a byte >= 0x80.  Every class
+// keeps only its ASCII members, a non-ASCII literal matches nothing, "any byte" means a byte below 0x80.  On such a text the automaton
+// takes exactly the transitions the full one takes, so matches and groups are identical -- but `\p{L}+` is 3 states over 3 classes
+// instead of 374 over 100, and fits the one-step-per-byte kernels (rgx_program.cc: AsciiTwin).
+constexpr uint32_t kFlagAsciiText = 1u << 31;
+
 struct BuildOptions {
   int max_states = 12000;
   // Search automaton: the program is prefixed with a lowest-priority skip loop  L: Alt(Capture0 -> start, AnyByte -> L),

@@ -130,6 +130,8 @@ hipError_t LaunchCommitPoint(const int32_t* spans, int64_t n, int ncap, int32_t 
 // text holds a lead byte without its continuation bytes (*flag |= 1); with dst, writes the copy in which those bytes read 0xFF
 // (DecodeRune's (RuneError, 1) for every instruction; offsets unchanged).  The batch flavour keeps sequences inside their string.
 hipError_t LaunchUtf8Screen(const uint8_t* src, int64_t len, uint8_t* dst, unsigned* flag, hipStream_t stream);
+// *flag |= 1 when src[0, len) holds a byte >= 0x80 (src 16-byte aligned); the caller clears the flag
+hipError_t LaunchAsciiCheck(const uint8_t* src, int64_t len, unsigned* flag, hipStream_t stream);
 hipError_t LaunchUtf8ScreenBatch(const uint8_t* src, const uint64_t* offsets, int64_t nstr, uint8_t* dst, unsigned* flag, hipStream_t stream);
 
 // FindReader's loop against FindAllBytes over one chunk (rgx.h: RGX_E_DIVERGES): *flag |= 1 when a gap between two matches of the

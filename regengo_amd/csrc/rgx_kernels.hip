@@ -2415,6 +2415,28 @@ hipError_t LaunchUtf8ScreenBatch(const uint8_t* src, const uint64_t* offsets, in
 }
 
 // carry_in has room for nslices + 64 entries (the callers' Ensure): entry nslices + 4 is the pass's over-budget flag, cleared here
+// one streaming pass: is there a byte >= 0x80?  (rgx_capi.cc: the ASCII twin of a program)
+__global__ __launch_bounds__(256) void ascii_check_kernel(const uint8_t* src, long long len, unsigned* flag) {
+  const long long n16 = len >> 4;
+  const uint4* s = reinterpret_cast<const uint4*>(src);
+  unsigned acc = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n16; i += (long long)gridDim.x * 256) {
+    const uint4 v = s[i];
+    acc |= v.x | v.y | v.z | v.w;
+  }
+  if (blockIdx.x == 0 && threadIdx.x < (len & 15)) acc |= src[(n16 << 4) + threadIdx.x];
+  if (__any((acc & 0x80808080u) != 0) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+hipError_t LaunchAsciiCheck(const uint8_t* src, int64_t len, unsigned* flag, hipStream_t stream) {
+  if (len <= 0) return hipSuccess;
+  const long long n16 = len >> 4;
+  long long blocks = (n16 + 256 * 8 - 1) / (256 * 8);
+  if (blocks < 1) blocks = 1;
+  if (blocks > 256 * 16) blocks = 256 * 16;
+  hipLaunchKernelGGL(ascii_check_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, src, (long long)len, flag);
+  return hipGetLastError();
+}
+
 hipError_t LaunchCarry(const DevTables& T, const uint8_t* buf, int32_t len, const uint8_t* slice_unsynced, int32_t* carry_in,
                        int32_t nslices, hipStream_t stream) {
   dim3 block(256), grid((nslices + 255) / 256);

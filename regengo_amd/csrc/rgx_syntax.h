@@ -57,6 +57,7 @@ struct Prog {
   std::vector<Inst> inst;
   int start = 0;
   int numcap = 2;
+  bool ascii_text = false;     // set by the table builders for kFlagAsciiText (rgx_dfa.h): classes are cut down to their bytes < 0x80
   std::string Dump() const;
 };
 
