@@ -416,6 +416,15 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     }
     HIP_TRY(hipMemsetAsync(c->d_carry, 0xFF, (size_t)nslices * 4, c->stream));
     HIP_TRY(LaunchCarryUs(T, d_buf, ilen, c->d_unsynced, c->d_carry, nslices, c->stream));
+    {
+      int32_t over = 0;          // the walk's step budget (every rewind walks bytes again, out of global memory)
+      HIP_TRY(hipMemcpyAsync(&over, c->d_carry + nslices + 4, 4, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (over) {
+        SetError("this text keeps this pattern's matches pending too long for the serial carry pass (quadratic): keep the CPU path for it");
+        return RGX_E_UNSUPPORTED;
+      }
+    }
     P.slice_unsynced = nullptr;
     P.carry_in = c->d_carry;
     if ((rc = run_scan(tm)) != RGX_OK) return rc;

@@ -4,6 +4,12 @@
 
 namespace rgx {
 
+// Step budget of one lane of the kernels that may walk the same bytes again and again (rgx_kernels.hip has the reasoning): past it
+// the lane stops and raises bit 31 of ScanParams::counters[3]; the host refuses the call.
+constexpr int kLaneStepBudget = 1 << 22;
+constexpr unsigned kOverBudgetBit = 0x80000000u;
+
+
 // Look-back descriptor: one 8-byte granule per tile/group, written by ONE relaxed agent-scope store and polled with
 // relaxed agent-scope loads -- the data is the flag (cdna_hip_programming.md guideline 16, form R2); no other
 // memory is exchanged between workgroups, so no fence is needed.

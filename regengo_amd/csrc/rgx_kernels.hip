@@ -93,8 +93,7 @@ __device__ __forceinline__ int Walk(const Tab<MODE>& tab, const Input& in, const
 // A lane of the generic kernel may spend this many steps on its slice; past it the lane stops, raises bit 31 of counters[3], tiles
 // that start later return at once, and the host refuses the call (RGX_E_UNSUPPORTED).  An ordinary slice costs 64 starts x a few
 // bytes plus its look-behind; 4 M steps means the average attempt of the slice ran 64 KiB.
-constexpr int kLaneStepBudget = 1 << 22;
-constexpr unsigned kOverBudgetBit = 0x80000000u;
+// (kLaneStepBudget, kOverBudgetBit: rgx_device_util.h -- the single-step walkers of rgx_scan_us.hip are held to the same budget)
 
 __device__ __forceinline__ void WriteRecordFixed(int32_t* rec, int ncap, const uint8_t* kind, const int32_t* delta, int s, int e) {
   if ((ncap & 3) == 0) {

@@ -48,7 +48,11 @@ struct View {
 };
 
 // One anchored attempt from `pos`: the reference's per-searchStart machine run (find.go:213-297), as a DFA walk.
-__device__ __forceinline__ int WalkCls(const uint16_t* tab, int stride, const SaLds& L, const View& in, const DevTables& T, int pos) {
+// `left`: the lane's remaining step budget (rgx_device_util.h: kLaneStepBudget): a walk that would pass it stops, raises the flag
+// the host refuses the call on, and every later walk of the lane returns at once.
+__device__ __forceinline__ int WalkCls(const uint16_t* tab, int stride, const SaLds& L, const View& in, const DevTables& T, int pos,
+                                       int& left, unsigned* over) {
+  if (left <= 0) return -1;
   int ctx = kCtxOther;
   if (pos == 0) ctx = kCtxBOT;
   else if (T.ctx_sensitive) ctx = L.ctx[in.At(pos - 1)];
@@ -63,7 +67,9 @@ __device__ __forceinline__ int WalkCls(const uint16_t* tab, int stride, const Sa
     q = e & kStateMask;
     if (q == kDead || eot) break;
     ++i;
+    if (i - pos >= left) { atomicOr(over, kOverBudgetBit); left = 0; return -1; }
   }
+  left -= i - pos + 1;
   return end;
 }
 
@@ -189,6 +195,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_sa_kernel(DevTables T, Sca
   }
   const unsigned my_woff = cwave + cincl - ccnt;
   const bool listed = ctotal <= (unsigned)kWorkCap;     // uniform
+  int budget_left = kLaneStepBudget;
   if (listed) {
     L.woff[tid] = (unsigned short)my_woff;
     unsigned long long m = cur;
@@ -200,7 +207,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_sa_kernel(DevTables T, Sca
     __syncthreads();
     for (unsigned j = tid; j < ctotal; j += kBlockThreads) {
       const int s = tb0 + (int)L.wl[j];
-      const int e = WalkCls(tab, stride, L, in, T, s);
+      const int e = WalkCls(tab, stride, L, in, T, s, budget_left, &P.counters[3]);
       L.wend[j] = e < 0 ? kNoMatch : (e - s >= (int)kLongMatch ? kLongMatch : (unsigned short)(e - s));
     }
   }
@@ -241,9 +248,9 @@ __global__ __launch_bounds__(kBlockThreads) void scan_sa_kernel(DevTables T, Sca
           if (listed) {
             const unsigned short wlen = L.wend[jj];
             if (wlen == kNoMatch) continue;
-            e = wlen == kLongMatch ? WalkCls(tab, stride, L, in, T, s) : s + (int)wlen;
+            e = wlen == kLongMatch ? WalkCls(tab, stride, L, in, T, s, budget_left, &P.counters[3]) : s + (int)wlen;
           } else {
-            e = WalkCls(tab, stride, L, in, T, s);
+            e = WalkCls(tab, stride, L, in, T, s, budget_left, &P.counters[3]);
             if (e < 0) continue;
           }
           if (sl == tid) sel |= 1ull << b;
@@ -291,8 +298,8 @@ __global__ __launch_bounds__(kBlockThreads) void scan_sa_kernel(DevTables T, Sca
       if (T.fixed_len >= 0) e = s + T.fixed_len;
       else if (listed) {
         const unsigned short wlen = L.wend[my_woff + (unsigned)__popcll(cur & ((1ull << b) - 1ull))];
-        e = wlen == kLongMatch ? WalkCls(tab, stride, L, in, T, s) : s + (int)wlen;
-      } else e = WalkCls(tab, stride, L, in, T, s);
+        e = wlen == kLongMatch ? WalkCls(tab, stride, L, in, T, s, budget_left, &P.counters[3]) : s + (int)wlen;
+      } else e = WalkCls(tab, stride, L, in, T, s, budget_left, &P.counters[3]);
       if (idx < (unsigned long long)P.cap_records) {
         int32_t* rec = P.spans + idx * ncap;
         if (T.fixed_captures) {

@@ -120,7 +120,7 @@ struct UsOut {
 // wave-uniform loop below (rewinds, walks that leave the window) -- correct for every walk, just slow.
 template <int NREG, bool LOOK>
 __device__ __noinline__ void UsWalkSlow(LdsU8c s_entb, LdsU16c s_srow, const UIn in, int pos, int a, int slice_end,
-                                        UsOut& out) {
+                                        UsOut& out, unsigned* over) {
 #define US_RECORD(S, E)                                               \
   if ((S) >= a && (S) < slice_end) {                                  \
     out.mask |= 1ull << ((S) - a);                                    \
@@ -133,7 +133,9 @@ __device__ __noinline__ void UsWalkSlow(LdsU8c s_entb, LdsU16c s_srow, const UIn
   (void)r1; (void)r2; (void)r3; (void)r4; (void)r5; (void)r6; (void)r7;
   int pend = -1;
   unsigned pinfo = 0;
+  int budget = kLaneStepBudget;     // every rewind walks bytes again: quadratic on texts that keep matches pending (rgx_device_util.h)
   for (;;) {
+    if (--budget < 0) { atomicOr(over, kOverBudgetBit); break; }
     const unsigned k8 = in.At8(i);
     const LdsU32c entp = (LdsU32c)(s_entb + (row & 0xFFFFu) + k8);
     const unsigned lo = entp[0], hi = entp[1];
@@ -361,7 +363,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_kernel(DevTables T, UsD
   }
   if (cont != -1) {
     if (cont == -2) { out.mask = 0; out.ends = 0; out.last_end = -1; cont = pos; }
-    UsWalkSlow<NREG, LOOK>((LdsU8c)s_entb, (LdsU16c)s_srow, in, cont, a, slice_end, out);
+    UsWalkSlow<NREG, LOOK>((LdsU8c)s_entb, (LdsU16c)s_srow, in, cont, a, slice_end, out, &P.counters[3]);
   }
   unsigned long long mask = out.mask, ends = out.ends;
   const int last_end = out.last_end;
@@ -637,7 +639,8 @@ __device__ __forceinline__ void UsFinishTile(const DevTables& T, const ScanParam
 // Single-step walker of one stretch [s, e]: consumes bytes s..e, records loads at [s, e) and ends at (s, e] (bit sets in LDS;
 // an end beyond the bit sets goes to *far).  Handles what the wave-uniform loop does not: rewinds, bytes outside the window.
 __device__ __noinline__ void UsSimpleSlow(LdsU8c s_entb, LdsU16c s_srow, LdsU32 s_L, LdsU32 s_E, LdsI32 far,
-                                          const SIn in, int tb, int s, int e, int lookahead) {   // (by value, see UsPairSlow)
+                                          const SIn in, int tb, int s, int e, int lookahead, unsigned* over) {   // (by value, see UsPairSlow)
+  int budget = kLaneStepBudget;
   int i = s;
   unsigned row = s_srow[((i > 0 ? in.At4(i - 1) : (unsigned)in.eot4) & 0x7Cu) >> 2];
   int pend = -1;
@@ -647,6 +650,7 @@ __device__ __noinline__ void UsSimpleSlow(LdsU8c s_entb, LdsU16c s_srow, LdsU32 
   };
   for (;;) {
   while (i <= e) {
+    if (--budget < 0) { atomicOr(over, kOverBudgetBit); return; }
     const unsigned k4 = in.At4(i);
     const unsigned ent = *(LdsU32c)(s_entb + (row & 0xFFFFu) + k4);
     if (lookahead && (ent & (1u << 29))) pend = i;
@@ -904,7 +908,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_simple_kernel(DevTables
   }
   US_STAMP()
   if (slow && s >= 0)
-    UsSimpleSlow((LdsU8c)s_entb, (LdsU16c)s_srow, (LdsU32)s_L, (LdsU32)s_E, (LdsI32)s_far, in, tb, s, e < len ? e : len, U.lookahead);
+    UsSimpleSlow((LdsU8c)s_entb, (LdsU16c)s_srow, (LdsU32)s_L, (LdsU32)s_E, (LdsI32)s_far, in, tb, s, e < len ? e : len, U.lookahead, &P.counters[3]);
   __syncthreads();
   US_STAMP()
 #ifdef RGX_US_PROFILE
@@ -997,7 +1001,7 @@ __device__ __forceinline__ int PSliceStart(const PIn& in, const int32_t* carry_i
 
 // single-step walker (second nibble = "no byte"): rewinds, bytes outside the window
 __device__ __noinline__ int UsPairSlow(LdsU8c s_entb, LdsU16c s_srow, LdsU32 s_L, LdsU32 s_E, LdsI32 far,
-                                        const PIn in, int tb, int s, int e, int lookahead) {   // (by value: a reference into the caller's frame is scratch memory, read on every step)
+                                        const PIn in, int tb, int s, int e, int lookahead, unsigned* over) {   // (by value: a reference into the caller's frame is scratch memory, read on every step)
   int i = s;
   int steps = 0;
   unsigned row = s_srow[i > 0 ? in.Cls(i - 1) : (unsigned)in.eot];
@@ -1008,6 +1012,7 @@ __device__ __noinline__ int UsPairSlow(LdsU8c s_entb, LdsU16c s_srow, LdsU32 s_L
   };
   for (;;) {
   while (i <= e) {
+    if (steps >= kLaneStepBudget) { atomicOr(over, kOverBudgetBit); return steps; }
     const unsigned ent = *(LdsU32c)(s_entb + (((row & 0xFFFFu) + (in.Cls(i) | 0xF0u)) << 2));
     if (lookahead && (ent & (1u << 27))) pend = i;
     if (ent & (1u << 29)) { set_e(i); pend = -1; }
@@ -1356,7 +1361,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
   int slow_steps = 0;
   slow_lanes += (slow && s >= 0) ? 1u : 0u;
   if (slow && s >= 0)
-    slow_steps = UsPairSlow((LdsU8c)s_entb, (LdsU16c)s_srow, (LdsU32)s_L, (LdsU32)s_E, (LdsI32)s_far, in, tb, RW ? ws : s, e < len ? e : len, U.lookahead);
+    slow_steps = UsPairSlow((LdsU8c)s_entb, (LdsU16c)s_srow, (LdsU32)s_L, (LdsU32)s_E, (LdsI32)s_far, in, tb, RW ? ws : s, e < len ? e : len, U.lookahead, &P.counters[3]);
   (void)slow_steps;
   __syncthreads();
   US_STAMP()
@@ -1407,7 +1412,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
 // thread alive began at or behind the slice (entry field "oldest") or a match ends.
 template <int NREG, bool LOOK>
 __global__ __launch_bounds__(64) void carry_us_kernel(DevTables T, UsDev U, const uint8_t* buf, int32_t len, const uint8_t* unsynced,
-                                                      int32_t* carry_in, int32_t nslices) {
+                                                      int32_t* carry_in, int32_t nslices, int32_t* over_budget) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long* s_ent = reinterpret_cast<unsigned long long*>(smem);
   uint16_t* s_srow = reinterpret_cast<uint16_t*>(smem + U.nent * 8);
@@ -1436,6 +1441,7 @@ __global__ __launch_bounds__(64) void carry_us_kernel(DevTables T, UsDev U, cons
       a_cur += kSliceBytes;
     }
   };
+  int budget = kLaneStepBudget;      // (steps out of global memory, and every rewind walks bytes again: rgx_device_util.h)
   while (cur < nslices && unsynced[cur] && pos < len) {
     int i = pos;
     unsigned row = s_srow[(i > 0 ? cls8(i - 1) : (unsigned)U.ncls << 3) >> 3];
@@ -1445,6 +1451,7 @@ __global__ __launch_bounds__(64) void carry_us_kernel(DevTables T, UsDev U, cons
     unsigned pinfo = 0;
     bool restarted = false;
     while (!restarted) {
+      if (--budget < 0) { *over_budget = 1; return; }
       const unsigned k8 = cls8(i);
       const uint2 ent = *reinterpret_cast<const uint2*>(s_entb + (row & 0xFFFFu) + k8);
       const unsigned lo = ent.x, hi = ent.y;
@@ -1591,7 +1598,9 @@ hipError_t LaunchCarryUs(const DevTables& T, const uint8_t* buf, int32_t len, co
   const UsDev& U = *T.us;
   const size_t shmem = (size_t)U.nent * 8 + 64;
   dim3 block(64), grid((nslices + 63) / 64);
-#define RGX_CU(N, LK) hipLaunchKernelGGL((carry_us_kernel<N, LK>), grid, block, shmem, stream, T, U, buf, len, slice_unsynced, carry_in, nslices)
+  // carry_in has room for nslices + 64 entries: entry nslices + 4 is the pass's over-budget flag, cleared here (as in LaunchCarry)
+  { const hipError_t me = hipMemsetAsync(carry_in + nslices + 4, 0, 4, stream); if (me != hipSuccess) return me; }
+#define RGX_CU(N, LK) hipLaunchKernelGGL((carry_us_kernel<N, LK>), grid, block, shmem, stream, T, U, buf, len, slice_unsynced, carry_in, nslices, carry_in + nslices + 4)
   if (U.lookahead) {
     if (U.nregs <= 1) RGX_CU(1, true); else if (U.nregs <= 2) RGX_CU(2, true); else if (U.nregs <= 4) RGX_CU(4, true); else RGX_CU(8, true);
   } else {
