@@ -7,6 +7,8 @@ namespace rgx {
 // Step budget of one lane of the kernels that may walk the same bytes again and again (rgx_kernels.hip has the reasoning): past it
 // the lane stops and raises bit 31 of ScanParams::counters[3]; the host refuses the call.
 constexpr int kLaneStepBudget = 1 << 22;
+constexpr int kWalkerStepBudget = 1 << 24;     // the single-step walkers of rgx_scan_us.hip (steps out of LDS, 30 - 50 ns each: a run of
+                                               // 5000 bytes that rewinds at every byte is 12.5 M steps and is still answered)
 constexpr unsigned kOverBudgetBit = 0x80000000u;
 
 

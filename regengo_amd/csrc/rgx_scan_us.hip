@@ -133,7 +133,7 @@ __device__ __noinline__ void UsWalkSlow(LdsU8c s_entb, LdsU16c s_srow, const UIn
   (void)r1; (void)r2; (void)r3; (void)r4; (void)r5; (void)r6; (void)r7;
   int pend = -1;
   unsigned pinfo = 0;
-  int budget = kLaneStepBudget;     // every rewind walks bytes again: quadratic on texts that keep matches pending (rgx_device_util.h)
+  int budget = kWalkerStepBudget;     // every rewind walks bytes again: quadratic on texts that keep matches pending (rgx_device_util.h)
   for (;;) {
     if (--budget < 0) { atomicOr(over, kOverBudgetBit); break; }
     const unsigned k8 = in.At8(i);
@@ -640,7 +640,7 @@ __device__ __forceinline__ void UsFinishTile(const DevTables& T, const ScanParam
 // an end beyond the bit sets goes to *far).  Handles what the wave-uniform loop does not: rewinds, bytes outside the window.
 __device__ __noinline__ void UsSimpleSlow(LdsU8c s_entb, LdsU16c s_srow, LdsU32 s_L, LdsU32 s_E, LdsI32 far,
                                           const SIn in, int tb, int s, int e, int lookahead, unsigned* over) {   // (by value, see UsPairSlow)
-  int budget = kLaneStepBudget;
+  int budget = kWalkerStepBudget;
   int i = s;
   unsigned row = s_srow[((i > 0 ? in.At4(i - 1) : (unsigned)in.eot4) & 0x7Cu) >> 2];
   int pend = -1;
@@ -1012,7 +1012,7 @@ __device__ __noinline__ int UsPairSlow(LdsU8c s_entb, LdsU16c s_srow, LdsU32 s_L
   };
   for (;;) {
   while (i <= e) {
-    if (steps >= kLaneStepBudget) { atomicOr(over, kOverBudgetBit); return steps; }
+    if (steps >= kWalkerStepBudget) { atomicOr(over, kOverBudgetBit); return steps; }
     const unsigned ent = *(LdsU32c)(s_entb + (((row & 0xFFFFu) + (in.Cls(i) | 0xF0u)) << 2));
     if (lookahead && (ent & (1u << 27))) pend = i;
     if (ent & (1u << 29)) { set_e(i); pend = -1; }
@@ -1416,8 +1416,10 @@ __global__ __launch_bounds__(64) void carry_us_kernel(DevTables T, UsDev U, cons
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   unsigned long long* s_ent = reinterpret_cast<unsigned long long*>(smem);
   uint16_t* s_srow = reinterpret_cast<uint16_t*>(smem + U.nent * 8);
+  unsigned char* s_ccls = smem + U.nent * 8 + 64;       // the byte -> class map (one dependent global load less per step)
   for (int w = threadIdx.x; w < U.nent; w += 64) s_ent[w] = U.ent[w];
   if ((int)threadIdx.x <= U.ncls) s_srow[threadIdx.x] = U.start_row_of_cls[threadIdx.x];
+  for (int w = threadIdx.x; w < 256; w += 64) s_ccls[w] = U.cls[w];
   __syncthreads();
   const int s0 = blockIdx.x * 64 + threadIdx.x;
   if (s0 >= nslices || !unsynced[s0]) return;
@@ -1432,7 +1434,7 @@ __global__ __launch_bounds__(64) void carry_us_kernel(DevTables T, UsDev U, cons
   const unsigned char* s_entb = reinterpret_cast<const unsigned char*>(s_ent);
   int cur = s0;                                   // the next slice of the run that wants its search position
   int a_cur = cur * kSliceBytes;
-  auto cls8 = [&](int i) -> unsigned { return i < len ? (unsigned)U.cls[buf[i]] << 3 : (unsigned)U.ncls << 3; };
+  auto cls8 = [&](int i) -> unsigned { return i < len ? (unsigned)s_ccls[buf[i]] << 3 : (unsigned)U.ncls << 3; };
   // settle every slice of the run whose start lies at or before `upto`, given the last match (ms, me) that ended (ms = -1: none)
   auto settle = [&](int upto, int ms, int me) {
     while (cur < nslices && unsynced[cur] && a_cur <= upto) {
@@ -1441,7 +1443,8 @@ __global__ __launch_bounds__(64) void carry_us_kernel(DevTables T, UsDev U, cons
       a_cur += kSliceBytes;
     }
   };
-  int budget = kLaneStepBudget;      // (steps out of global memory, and every rewind walks bytes again: rgx_device_util.h)
+  int budget = kWalkerStepBudget;    // (every rewind walks bytes again: rgx_device_util.h; the steps come out of global memory,
+                                     // mostly cache hits on a run that is walked again and again: 0.1 - 1 us each)
   while (cur < nslices && unsynced[cur] && pos < len) {
     int i = pos;
     unsigned row = s_srow[(i > 0 ? cls8(i - 1) : (unsigned)U.ncls << 3) >> 3];
@@ -1596,7 +1599,7 @@ namespace rgx {
 hipError_t LaunchCarryUs(const DevTables& T, const uint8_t* buf, int32_t len, const uint8_t* slice_unsynced, int32_t* carry_in,
                          int32_t nslices, hipStream_t stream) {
   const UsDev& U = *T.us;
-  const size_t shmem = (size_t)U.nent * 8 + 64;
+  const size_t shmem = (size_t)U.nent * 8 + 64 + 256;
   dim3 block(64), grid((nslices + 63) / 64);
   // carry_in has room for nslices + 64 entries: entry nslices + 4 is the pass's over-budget flag, cleared here (as in LaunchCarry)
   { const hipError_t me = hipMemsetAsync(carry_in + nslices + 4, 0, 4, stream); if (me != hipSuccess) return me; }
