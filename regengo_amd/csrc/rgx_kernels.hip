@@ -2075,9 +2075,15 @@ int32_t ScanNumTiles(const DevTables& T, int32_t len, bool use_w) {
   return (len + per - 1) / per;
 }
 
+bool ScanSupportsW(const DevTables& T, int32_t len);
 int ScanKernelKind(const DevTables& T, int32_t len) {
   if (UseExactKernel(T, len)) return 1;
-  if (UseUsKernel(T, len, false)) return UsKernelVariant(T);
+  if (UseUsKernel(T, len, false)) {
+    // a pattern without a single reset byte takes its sync points from the sync automaton: the register-free kernels do (rgx_capi.cc:
+    // us_ws), the register kernel's programs scan on the generic kernel
+    if (T.reset_values == 0 && ScanSupportsW(T, len) && UsKernelVariant(T) == 4) return 3;
+    return UsKernelVariant(T);
+  }
   if (UseSaKernel(T, len) && !ExpEnv("RGX_NO_SA_KERNEL")) return 2;
   return 3;
 }
