@@ -23,6 +23,8 @@ CASES = [
     (r"x[a-z]*y|x", 6, "xay b\n"),                # long overshoot before the rewind
     (r"[\w.+-]+@[\w.-]+\.[a-z]{2,}", 4, "ab.@-+ z\n"),          # two start registers
     (r"(?P<major>\d+)\.(?P<minor>\d+)\.(?P<patch>\d+)", 4, "0123. a\n"),   # three
+    (r"(?P<words>(?P<word>\w+\s+){5})(?P<end>\w+)", 4, "ab_ 9\n\t."),         # five: the eight-register instance (round 3)
+    (r"(?:[a-c]+-){6}[a-c]+", 4, "abc- x\n"),                                  # seven
     (r"[a-q]+[0-9]|[c-z]{3}!", None, "acz09! "),
     (r"[^\s\"]+\"", None, "ab\" \n\t9"),
 ]
