@@ -198,7 +198,8 @@ const rgx_program* AsciiTwin(const rgx_program* p) {
   if (p->ascii_state.load() != 0) return p->ascii_state.load() == 1 ? p->ascii_twin.get() : nullptr;
   int result = -1;
   const Tables& t = p->p.t;
-  if (p->p.dev.us == nullptr && p->p.d_arena != nullptr && !(t.flags & kFlagAsciiText) && !t.anchored && !t.can_match_empty) {
+  if (p->p.dev.us == nullptr && p->p.d_arena != nullptr && !(t.flags & kFlagAsciiText) && !t.anchored && !t.can_match_empty &&
+      ScanKernelKind(p->p.dev, 1 << 24) == 3) {          // (only a program of the generic kernel has something to gain)
     try {
       std::unique_ptr<rgx_program> tw(new rgx_program);
       tw->p.t = BuildTables(t.pattern, t.flags | kFlagAsciiText);
@@ -233,7 +234,17 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
       HIP_TRY(LaunchAsciiCheck(d_buf, (int64_t)len, flag, c->stream));
       HIP_TRY(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
-      if (!h) return FindAllDevice(tw, c, d_buf, len, n, d_spans, cap_records, count_only, res, starts_only, own_lo, own_hi);
+      if (!h) {
+        // (a twin whose start states are all dead -- `\\p{Greek}+` -- matches nothing on such a text)
+        const Tables& tt = tw->p.t;
+        bool dead = true;
+        for (int cx = 0; cx < 4 && dead; cx++) {
+          if (tt.start_accept[cx]) dead = false;
+          for (int k = 0; k <= tt.ncls && dead; k++) if (tt.trans[(size_t)tt.start[cx] * (tt.ncls + 1) + k] != 0) dead = false;   // next state or a match flag
+        }
+        if (dead) return 0;
+        return FindAllDevice(tw, c, d_buf, len, n, d_spans, cap_records, count_only, res, starts_only, own_lo, own_hi);
+      }
     }
   }
   { int vrc = MatchView(p, c, d_buf, len, &d_buf); if (vrc != RGX_OK) return vrc; }      // from here on d_buf = the bytes to match on
