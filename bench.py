@@ -592,7 +592,7 @@ def run_c3(env, args):
                       "parity_generator_truth": parity_all, "parity_strings_checked": npar}
     line["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
-                        "kernel": "rgx batch kernel (ref_batch_kernel / batch_lds_kernel)", "kernel_ms": round(k_ms, 4),
+                        "kernel": "batch_search_kernel + ref_fix_kernel (the call: search automaton walk, back-trace, replay of the reference attempt offsets; flagged strings finished by ref_fix_kernel)", "kernel_ms": round(k_ms, 4),
                         "algorithmic_bytes_per_launch": alg, "timed_launches": len(kms),
                         "note": "event-bracketed call: includes the launch of the call's kernels"}
     if not args.no_cpu_baseline and env.world == 1:
