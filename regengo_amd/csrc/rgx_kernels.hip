@@ -1160,10 +1160,11 @@ __device__ __forceinline__ void ResolveCapturesBatch(const Tab<MODE>& tab, const
 struct BatchLayout {     // byte offsets into dynamic LDS (host and device compute it the same way)
   int trans, cls, ctx, bt_nth, bt_base, bt_parent, bt_ops, bt_match, st_ops, st_pool, window, trace, recs, rm_trans, rm_depth, total;
   int bt_in_lds;
+  int oph;          // one-pass edge table (caps_lds_kernel, INROW instances of one-pass programs): 8 bytes per (state, class) cell
 };
 
 __host__ __device__ inline BatchLayout BatchLdsLayout(const DevTables& T, bool want_spans, int trace_entry_bytes = 2,
-                                                      int window_bytes = kBatchWindow, bool ref_mode = false) {
+                                                      int window_bytes = kBatchWindow, bool ref_mode = false, bool onepass_h = false) {
   BatchLayout L{};
   int o = 0;
   auto take = [&](int bytes) { const int at = o; o += (bytes + 15) & ~15; return at; };
@@ -1182,6 +1183,7 @@ __host__ __device__ inline BatchLayout BatchLdsLayout(const DevTables& T, bool w
     L.bt_parent = take(T.bt_pool_n);
     L.st_ops = take(16);
     L.st_pool = take(T.start_pool_n * 4);
+    if (onepass_h) L.oph = take(cells * 8);
   }
   L.window = take(window_bytes + 16);
   if (dyn) L.trace = take(kBlockThreads * kBatchTrace * trace_entry_bytes);
@@ -1506,6 +1508,46 @@ __device__ __forceinline__ void ResolveCapturesOnePass(Lds16 trans, Lds8 cls, co
   apply(B.bt_ops[prev_base + B.st_nthreads[q] - 1], e);
 }
 
+// The one-pass walk over a COMPOSED edge table (caps_lds_kernel stages it for its in-row instances): cell (state, class) -> the next
+// state's row (state * stride), the edge's pool slice and its single parent in one 8-byte entry -- per byte the class of the byte, one
+// entry (the only look-up that depends on the step before) and the ops of the previous edge's thread: three LDS reads where the walk
+// above makes five (transition, slice, parent, ops, class), and no multiply on the chain.
+typedef const unsigned long long __attribute__((address_space(3)))* LdsU2;     // low word: next row | parent << 16, high word: pool slice
+__device__ __forceinline__ void ResolveCapturesOnePassH(LdsU2 H, Lds8 cls, const BtTabsLds& B, const DevTables& T, int ctx,
+                                                        const PrivInput& in, int s, int e, int32_t* rec) {
+  const int ncap = T.ncap;
+  const int unset = T.unmatched_minus1 ? -1 : 0;
+  const int n = e - s;
+  const Lds32 rowd = (Lds32)in.row;
+  for (int c = 2; c < ncap; ++c) rec[c] = unset;
+  rec[0] = s; rec[1] = e;
+  auto apply = [&](unsigned o, int pos) {
+    o &= ~3u;
+    while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = pos; }
+  };
+  const unsigned q0 = T.start[ctx];
+  const unsigned sbase = B.start_ops[ctx];
+  if (n == 0) { apply(B.start_ops_pool[sbase + B.st_nthreads[q0] - 1], s); return; }
+  int r = s - in.p0;
+  unsigned w = rowd[(r >> 2) << 8];
+  unsigned wn = rowd[((r >> 2) + 1) << 8];
+  unsigned qs = q0 * (unsigned)T.stride;            // the state's row in the cell numbering
+  unsigned prev_base = 0;
+  for (int i = 0; i < n; ++i) {
+    const unsigned b = (w >> ((r & 3) << 3)) & 255u;
+    const unsigned long long h = H[qs + cls[b]];
+    const unsigned hx = (unsigned)h, hy = (unsigned)(h >> 32);
+    const unsigned P = hx >> 16;
+    const unsigned o = i == 0 ? B.start_ops_pool[sbase + P] : B.bt_ops[prev_base + P];
+    if (o & ~3u) apply(o, s + i);
+    prev_base = hy;
+    qs = hx & 0xFFFFu;
+    ++r;
+    if ((r & 3) == 0) { w = wn; wn = rowd[((r >> 2) + 1) << 8]; }
+  }
+  apply(B.bt_ops[prev_base + B.st_nthreads[qs / (unsigned)T.stride] - 1], e);
+}
+
 // The same walk with the trace kept IN the lane's row: a cell that fits a byte (states x stride <= 256) takes the place of the
 // input byte it was computed from -- the forward walk holds two dwords of the row in registers, so a byte is overwritten only
 // after it was read -- and the back-trace reads four cells with one load.  No trace area: 16 KiB of LDS less per workgroup, three
@@ -1585,7 +1627,8 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
                                                                   int debug_flags) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
-  const BatchLayout Y = BatchLdsLayout(T, true, INROW ? 0 : (int)sizeof(TraceT), kCapsWindow);
+  const bool use_h = INROW && T.onepass != 0 && BatchLdsLayout(T, true, 0, kCapsWindow).bt_in_lds != 0;   // (uniform) ResolveCapturesOnePassH
+  const BatchLayout Y = BatchLdsLayout(T, true, INROW ? 0 : (int)sizeof(TraceT), kCapsWindow, false, use_h);
   const int ncap = T.ncap;
   {
     const uint4* src = reinterpret_cast<const uint4*>(T.trans);
@@ -1604,6 +1647,15 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
       for (int i = tid; i < T.bt_pool_n; i += kBlockThreads) smem[Y.bt_parent + i] = T.bt_parent[i];
       d = reinterpret_cast<uint32_t*>(smem + Y.st_ops);   if (tid < 4) d[tid] = T.start_ops[tid];
       d = reinterpret_cast<uint32_t*>(smem + Y.st_pool);  for (int i = tid; i < T.start_pool_n; i += kBlockThreads) d[i] = T.start_ops_pool[i];
+      if (use_h) {
+        unsigned long long* hh = reinterpret_cast<unsigned long long*>(smem + Y.oph);
+        for (int i = tid; i < cells; i += kBlockThreads) {
+          const unsigned qn = T.trans_cls[i] & kStateMask;
+          const unsigned base = T.bt_base[i];
+          const unsigned par = base == 0xFFFFFFFFu ? 0u : (unsigned)T.bt_parent[base];
+          hh[i] = (unsigned long long)((qn * (unsigned)T.stride) | (par << 16)) | ((unsigned long long)base << 32);
+        }
+      }
     }
   }
   Tab<MODE> tab;
@@ -1666,7 +1718,7 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
       if (INROW && e + 4 - in.p0 <= in.nrow && (s == 0 || s - 1 >= in.p0)) {
         // (the launch takes this instance only with the back-trace tables on chip and states x stride <= 256)
         const int ctx = s == 0 ? kCtxBOT : ctx_of_byte[in.At(s - 1)];
-        if (T.onepass && !(debug_flags & 2)) ResolveCapturesOnePass<MODE>((Lds16)(smem + Y.trans), (Lds8)(smem + Y.cls), BL, T, ctx, in, s, e, rec);
+        if (use_h && !(debug_flags & 2)) ResolveCapturesOnePassH((LdsU2)(smem + Y.oph), (Lds8)(smem + Y.cls), BL, T, ctx, in, s, e, rec);
         else ResolveCapturesInRow<MODE>((Lds16)(smem + Y.trans), (Lds8)(smem + Y.cls), BL, T, ctx, in, s, e, rec);
       } else
       if (!INROW && need <= kBatchTrace) {
@@ -2468,7 +2520,7 @@ hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, i
   // their trace in global memory
   static const bool no_inrow = ExpEnv("RGX_CAPS_NO_INROW") != nullptr;
   const bool inrow = !no_inrow && T.nstates * T.stride <= 256 && BatchLdsLayout(T, true, 0, kCapsWindow).bt_in_lds != 0;
-  const BatchLayout Y = BatchLdsLayout(T, true, inrow ? 0 : (t8 ? 1 : 2), kCapsWindow);
+  const BatchLayout Y = BatchLdsLayout(T, true, inrow ? 0 : (t8 ? 1 : 2), kCapsWindow, false, inrow && T.onepass != 0);
   if (!force_old && nmatches >= 64 && T.mode != kModeClassGlobal && Y.total <= 150 * 1024 && (((uintptr_t)buf) & 15) == 0 && T.ncap <= 32) {
     static int cus = 0;
     if (!cus) {
