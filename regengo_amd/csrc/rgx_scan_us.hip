@@ -386,6 +386,11 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_kernel(DevTables T, UsD
     if (tid == 0 && block_total) atomicAdd(P.total, (unsigned long long)block_total);
     return;
   }
+  if (block_total == 0) {
+    // nothing to place: publish the (empty) count and leave without waiting for the tiles in front (rgx_kernels.hip: scan_kernel)
+    if (wave == 0) LookBackPublish(P.tile_desc, tile, 0ull, lane);
+    return;
+  }
   if (wave == 0) {
     if (lane == 0 && block_total) atomicAdd(P.total, (unsigned long long)block_total);
     const unsigned long long excl = LookBack(P.tile_desc, tile, block_total, lane, &P.counters[3], 1, nullptr, !P.use_tickets);
@@ -625,6 +630,10 @@ __device__ __forceinline__ void UsFinishTile(const DevTables& T, const ScanParam
   const UsTileOut o = UsCountTile(P, tile, tb, len, s_L, s_E, s_misc, *s_far);
   if (P.count_only) {
     if (tid == 0 && o.block_total) atomicAdd(P.total, (unsigned long long)o.block_total);
+    return;
+  }
+  if (o.block_total == 0) {                    // (nothing to place: see scan_us_kernel)
+    if ((tid >> 6) == 0) LookBackPublish(P.tile_desc, tile, 0ull, tid & 63);
     return;
   }
   if ((tid >> 6) == 0) {
@@ -1372,7 +1381,8 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
     if (!P.count_only) {
       LookBackPublish(P.tile_desc, tile, o.block_total, tid);       // (lane 0 of wave 0 stores)
       prev = o;
-      have_prev = true;
+      have_prev = o.block_total != 0;      // a tile without a match needs no offset: its count stays a plain count in its descriptor,
+                                           // no resolve (a round trip to memory the whole workgroup would wait for) and no emission
     }
     unsigned* t1 = s_L; s_L = s_L2; s_L2 = t1;
     unsigned* t2 = s_E; s_E = s_E2; s_E2 = t2;
