@@ -1168,7 +1168,7 @@ __host__ __device__ inline BatchLayout BatchLdsLayout(const DevTables& T, bool w
   BatchLayout L{};
   int o = 0;
   auto take = [&](int bytes) { const int at = o; o += (bytes + 15) & ~15; return at; };
-  L.trans = take(T.table_bytes);
+  L.trans = take(onepass_h ? 0 : T.table_bytes);      // (the composed edge table replaces the transition table: rare fall-backs read it from global memory)
   L.cls = take(256);
   L.ctx = take(256);
   const bool dyn = want_spans && !T.fixed_captures;
@@ -1633,7 +1633,7 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
   {
     const uint4* src = reinterpret_cast<const uint4*>(T.trans);
     uint4* dst = reinterpret_cast<uint4*>(smem + Y.trans);
-    const int n16 = (T.table_bytes + 15) >> 4;
+    const int n16 = use_h ? 0 : (T.table_bytes + 15) >> 4;
     for (int i = tid; i < n16; i += kBlockThreads) dst[i] = src[i];
     smem[Y.cls + tid] = T.cls[tid];
     smem[Y.ctx + tid] = T.ctx_of_byte[tid];
@@ -1659,7 +1659,7 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
     }
   }
   Tab<MODE> tab;
-  tab.t = reinterpret_cast<const uint16_t*>(smem + Y.trans);
+  tab.t = use_h ? T.trans : reinterpret_cast<const uint16_t*>(smem + Y.trans);
   tab.cls = smem + Y.cls;
   tab.stride = T.stride;
   tab.nstates = T.nstates;
@@ -1718,7 +1718,7 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
       if (INROW && e + 4 - in.p0 <= in.nrow && (s == 0 || s - 1 >= in.p0)) {
         // (the launch takes this instance only with the back-trace tables on chip and states x stride <= 256)
         const int ctx = s == 0 ? kCtxBOT : ctx_of_byte[in.At(s - 1)];
-        if (use_h && !(debug_flags & 2)) ResolveCapturesOnePassH((LdsU2)(smem + Y.oph), (Lds8)(smem + Y.cls), BL, T, ctx, in, s, e, rec);
+        if (use_h) ResolveCapturesOnePassH((LdsU2)(smem + Y.oph), (Lds8)(smem + Y.cls), BL, T, ctx, in, s, e, rec);
         else ResolveCapturesInRow<MODE>((Lds16)(smem + Y.trans), (Lds8)(smem + Y.cls), BL, T, ctx, in, s, e, rec);
       } else
       if (!INROW && need <= kBatchTrace) {
