@@ -4,6 +4,7 @@ with two bytes per look-up), on inputs built to hit what is special about them: 
 end where a stretch ends, rewinds (a match followed by bytes that kept older threads alive), the end of the text inside a
 look-up pair, texts without a single sync point, shard ownership."""
 import random
+import zlib
 
 import numpy as np
 import pytest
@@ -63,19 +64,25 @@ def _texts(rng, alphabet, sizes):
 @pytest.mark.parametrize("pattern,kernel,alphabet", CASES)
 def test_us_kernels_equal_oracle(torch_dev, pattern, kernel, alphabet):
     from oracle.gen_c import CMatcher
-    from regengo_amd import Compiled
+    from regengo_amd import Compiled, _capi
     c = Compiled(pattern).to(0)
     if kernel is not None:
         assert c.info.scan_kernel == kernel, (pattern, c.info.scan_kernel)
     cm = CMatcher(pattern, q8=False)
-    rng = random.Random(hash(pattern) & 0xFFFF)
+    rng = random.Random(zlib.crc32(pattern.encode()) & 0xFFFF)      # (hash() of a str changes from process to process)
     sizes = [64, 65, 127, 128, 129, 1000, 16383, 16384, 16385, 16384 + 255, 16384 + 257, 32768, 40000, 70001, 200000]
     # (runs without a sync point are kept to a few KiB: the carry pass that resolves them restates the reference's loop, which
     # is quadratic in the length of such a run -- as the reference itself is)
     for b in _texts(rng, alphabet, sizes) + [b"", b"a", (alphabet[0] * 5000).encode(), (alphabet[-1] * 3000 + alphabet[0] * 2500).encode()]:
         arr = np.frombuffer(b, dtype=np.uint8).copy() if b else np.zeros(0, dtype=np.uint8)
         exp, cnt = cm.find_all_np(arr)
-        spans, res = c.FindAllSpans(b)
+        try:
+            spans, res = c.FindAllSpans(b)
+        except _capi.RgxError as ex:
+            # the rewinding patterns are quadratic on long runs (the reference's loop too): past the walkers' step budget the call
+            # is refused, never answered wrongly (tests/test_gpu_budget.py)
+            assert ex.status == _capi.RGX_E_UNSUPPORTED and "quadratic" in str(ex) and "|" in pattern, (pattern, len(b), str(ex))
+            continue
         got = spans.cpu().numpy()
         assert res.total == cnt and got.shape == exp.shape and np.array_equal(got, exp), (pattern, len(b), cnt, int(res.total))
         n, _ = c.CountAll(torch_dev.from_numpy(arr).cuda()) if len(b) else (0, None)
@@ -157,3 +164,21 @@ def test_patterns_without_reset_bytes(torch_dev):
                 assert np.array_equal(spans.cpu().numpy(), exp), (pat, rnd)
                 n, _r = c.CountAll(t)
                 assert n == cnt
+
+
+def test_rescan_after_the_carry_pass_survives_a_look_back_timeout(torch_dev):
+    """Round 3 regression (tests/golden/regress/us_long_runs_40000.bin, `x[a-z]*y|x`): two 6004-byte runs without a sync point keep the
+    workgroups of the first two tiles in their single-step walkers for so long that the third tile's look-back spin hits its bound.
+    The first scan of a call repeated itself with tickets in that case; the rescan after the carry pass did not look at the flag,
+    and the third tile's rows landed at offset 0 (count right, table wrong)."""
+    import os
+    from oracle.gen_c import CMatcher
+    from regengo_amd import Compiled
+    b = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "regress", "us_long_runs_40000.bin"), "rb").read()
+    pattern = r"x[a-z]*y|x"
+    c = Compiled(pattern).to(0)
+    exp, cnt = CMatcher(pattern, q8=False).find_all_np(np.frombuffer(b, dtype=np.uint8).copy())
+    for _ in range(3):
+        spans, res = c.FindAllSpans(b)
+        assert res.total == cnt == 4814
+        assert np.array_equal(spans.cpu().numpy(), exp)
