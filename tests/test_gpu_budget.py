@@ -34,7 +34,7 @@ def test_a_text_that_keeps_attempts_running_is_answered_or_refused_in_bounded_ti
     except _capi.RgxError as ex:
         assert ex.status == _capi.RGX_E_UNSUPPORTED
         assert "quadratic" in str(ex)
-    assert time.perf_counter() - t0 < 30.0
+    assert time.perf_counter() - t0 < 90.0      # (bounded: the budgets allow up to ~25 s of a single lane out of global memory)
     # the context is usable afterwards
     spans, res = c.FindAllSpans(b"abc9 " if "9" in pat else (b"ccz " if "z" in pat else b"q x q"))
     assert res.total == 1
