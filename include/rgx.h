@@ -31,8 +31,9 @@
 extern "C" {
 #endif
 
-#define RGX_ABI_VERSION 3   /* 2: rgx_info grew in round 2 (scan_kernel .. utf8_screened) without a bump; 3: ref_findall_offered,
-                             * ref_stream_offered, ref_tdfa_states; the sharded entry points.  rgx_abi_version() is what the loaded
+#define RGX_ABI_VERSION 4   /* 2: rgx_info grew in round 2 (scan_kernel .. utf8_screened) without a bump; 3: ref_findall_offered,
+                             * ref_stream_offered, ref_tdfa_states; the sharded entry points; 4: ref_replace_offered, the reference's Tagged DFA
+                             * runs on the device (rows of such programs: see rgx_find_bytes).  rgx_abi_version() is what the loaded
                              * library was built with: a stub compares it with this constant before it trusts sizeof(rgx_info) */
 
 typedef enum rgx_status {
@@ -55,13 +56,18 @@ typedef enum rgx_status {
 
 enum {
   RGX_FLAG_UNMATCHED_MINUS1 = 1u << 0, /* unmatched group = (-1,-1) instead of the reference's (0,0) */
-  RGX_FLAG_STDLIB_SEMANTICS = 1u << 1  /* every entry point as Go's regexp would answer: plain leftmost-first search, FindAll without
+  RGX_FLAG_STDLIB_SEMANTICS = 1u << 1, /* every entry point as Go's regexp would answer: plain leftmost-first search, FindAll without
                                           duplicates, FindReader = FindAll over the stream.  Default (flag clear): the REFERENCE's
                                           behaviour or a refusal, never something else -- after a failed attempt the emitted
                                           MatchBytes / FindBytes loops resume behind the offset their last alternative failed at,
                                           not at start+1 (compiler.go:845-853, find.go:545-569), which steps over some
                                           matches (reproduced); entry points whose emitted code the library does not reproduce
                                           for this pattern return RGX_E_UNSUPPORTED (rgx_info.ref_*_offered say which).        */
+  RGX_FLAG_FORCE_TDFA = 1u << 2        /* regengo.Options.ForceTDFA (regengo.go:43-45, `-force-tdfa`; compiler.go:137-153): the reference
+                                          emits its Tagged DFA for the capture functions whenever it can be built (under 500 states, no
+                                          empty-width op but ^ $), not only for patterns with nested quantifiers -- rgx_info.ref_find_engine
+                                          follows, and with it what reference mode means for the program.  (BASELINE config C3, "Email TDFA
+                                          with capture tags", is this option.)                                                  */
 };
 
 typedef struct rgx_program rgx_program;       /* compiled pattern: host tables + device copy      */
@@ -105,8 +111,10 @@ typedef struct rgx_info {
                             * per look-up; DESIGN.md section 4 */
   int32_t ref_match_offered; /* 1: MatchBytes in reference mode (the default) is offered: plain backtracking or Thompson engine; 0: the
                               * reference memoises -- RGX_E_UNSUPPORTED, the generated stub keeps the Go function           */
-  int32_t ref_find_offered;  /* the same for FindBytes / FindBytesReuse (plain backtracking engine only).  All four ref_*_offered
-                              * read 1 for a program compiled with RGX_FLAG_STDLIB_SEMANTICS: every entry point answers then   */
+  int32_t ref_find_offered;  /* the same for FindBytes / FindBytesReuse: the plain backtracking engine (restart rule reproduced) or
+                              * the Tagged DFA (ref_find_engine == 1: the reference's own tables and loop run on the device,
+                              * tdfa.go:831-1052).  All ref_*_offered read 1 for a program compiled with
+                              * RGX_FLAG_STDLIB_SEMANTICS: every entry point answers then   */
   int32_t unicode_version; /* UCD version behind \p{..}: 0xMMmmpp.  0x0F0000 = 15.0.0, the version of Go 1.24's `unicode` package (the
                             * reference's tables): ICU 70's 14.0 plus the 4,489 code points first assigned in 15.0
                             * (csrc/gen_unicode_tables.py says how they were obtained and checked)                          */
@@ -121,13 +129,17 @@ typedef struct rgx_info {
                              * Tagged DFA, whose FindAll advances by the match LENGTH and reports matches again
                              * (compiler.go:646-651, Q11), or memoises on a pattern that matches empty: every FindAll / count entry
                              * point returns RGX_E_UNSUPPORTED unless the program was compiled with RGX_FLAG_STDLIB_SEMANTICS    */
-  int32_t ref_stream_offered;  /* 1: rgx_find_chunk / rgx_count_chunk / rgx_replace_* / rgx_transform_chunk* are offered in reference
-                             * mode: the emitted loops behind them are FindBytesReuse on a re-sliced input, so the library must
+  int32_t ref_stream_offered;  /* 1: rgx_find_chunk / rgx_count_chunk (FindReader / FindReaderCount / FindReaderFirst) are offered in
+                             * reference mode: the emitted loop is FindBytesReuse on a re-sliced input, so the library must
                              * reproduce FindBytesReuse (ref_find_offered) and the pattern must not match empty; the answer is then
                              * the reference's or RGX_E_DIVERGES.  0: RGX_E_UNSUPPORTED unless RGX_FLAG_STDLIB_SEMANTICS         */
   int32_t ref_tdfa_states;  /* states of the reference's Tagged DFA when ref_find_engine == 1 (its own numbering, start states
                              * included), else 0                                                                            */
   uint32_t flags;           /* the RGX_FLAG_* the program was compiled with (they travel in the blob)                        */
+  int32_t ref_replace_offered; /* 1: rgx_replace_* / rgx_transform_chunk* are offered in reference mode -- as ref_stream_offered, but
+                             * only for the plain backtracking engine: under the Tagged DFA the emitted Replace / Transform loops
+                             * reuse ONE result struct across matches, so a group the engine leaves untouched expands to its text
+                             * in an EARLIER match (tdfa.go:1031-1046, replace.go:216): not reproduced, keep the Go path        */
 } rgx_info;
 int rgx_abi_version(void);
 int rgx_program_info(const rgx_program* p, rgx_info* out);
@@ -183,12 +195,22 @@ int rgx_match_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* buf,
  * ncap int32 (zeroes when nothing matches: the emitted function returns (nil, false)).  Host buffers.  Reference semantics by
  * default: the emitted loop restarts behind its failure offset, not at start+1 -- `12024-01-15` has no Date
  * match in the reference; RGX_FLAG_STDLIB_SEMANTICS gives the plain leftmost-first search.  RGX_E_UNSUPPORTED: the reference
- * emits a memoising or TDFA engine for this pattern, whose restart offsets are not reproduced -- keep the Go path. */
+ * emits its memoising engine for this pattern, whose restart offsets are not reproduced -- keep the Go path.
+ *
+ * Programs the reference emits with its TAGGED DFA (rgx_info.ref_find_engine == 1; tdfa.go:831-1052) run that automaton itself --
+ * the reference's tables (they travel in the blob in place of tdfa.go:584-794's Go literals), its loop: the first start offset
+ * with an accept, the LAST accept on that walk (longest-on-path), a byte >= 0x80 ends an attempt.  Their records
+ * (here, in rgx_find_batch*, rgx_find_chunk) are the reported tags: [0], [1] the match; a group that took part as usual; a group
+ * whose start tag is unset as (-1, -1) WHATEVER RGX_FLAG_UNMATCHED_MINUS1 says, meaning "the result struct's field is left
+ * untouched" (tdfa.go:1031-1046): FindBytes (fresh struct) leaves it nil, FindBytesReuse / FindReader keep the value of the
+ * previous call -- the stub skips the assignment, as the emitted code does.  RGX_E_UNSUPPORTED from such a program: an attempt
+ * per start offset is quadratic on this text and a lane ran out of its step budget -- keep the Go path for it.               */
 int rgx_find_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* buf, size_t len, int32_t* spans, int* found);
 
-/* FindAllBytes(input []byte, n int) -- find.go:113-124,130-466.  The TDFA flavour (compiler.go:602-655) is NOT reproduced: programs
- * for which the reference emits it are refused in reference mode (RGX_E_UNSUPPORTED, rgx_info.ref_findall_offered), like every
- * entry point of this family (device / owned / host / starts / submit / count).
+/* FindAllBytes(input []byte, n int) -- find.go:113-124,130-466.  The TDFA flavour's WRAPPER (compiler.go:602-655: it advances by the
+ * match length, not to the match end, and reports matches again -- DESIGN.md Q11) is NOT reproduced: programs for which the
+ * reference emits it are refused in reference mode (RGX_E_UNSUPPORTED, rgx_info.ref_findall_offered), like every entry point of
+ * this family (device / owned / host / starts / submit / count); their FindBytes / FindReader run (rgx_find_bytes).
  * `d_buf`, `d_spans` device pointers; `cap_records` = capacity of d_spans in records of ncap int32.
  * n < 0: all matches; n == 0: nothing (returns 0, like `return s`); n > 0: first n.
  * Records are written in increasing match-start order.  Returns written count or <0.              */
@@ -325,7 +347,12 @@ int64_t rgx_find_batch_multi_device(const rgx_multi* m, rgx_stream_ctx* c, const
  * reports these very matches; one fails -> RGX_E_DIVERGES and nothing is delivered (the stub replays the chunk through the Go
  * loop).  For the other programs (memoising / TDFA FindBytes, empty matches: rgx_info.ref_stream_offered == 0) the loop is not
  * reproduced and the call returns RGX_E_UNSUPPORTED.  RGX_FLAG_STDLIB_SEMANTICS: no check, no refusal -- the chunk's matches are
- * FindAllBytes' for every program.                                                                                          */
+ * FindAllBytes' for every program.
+ * Tagged-DFA programs (rgx_info.ref_find_engine == 1): the loop itself runs on the device -- the engine's FindBytesReuse on
+ * chunk[searchPos:] (every re-slice is the beginning of a text for ^ and its end the end of the text for $), searchPos = the end of
+ * the match -- over the ends of one attempt per start offset; rows as described at rgx_find_bytes ((-1, -1): field untouched, the
+ * stub's reused result keeps its previous value, which is what the callback sees in the reference too); the bytes.Index test
+ * as above (RGX_E_DIVERGES).                                                                                                 */
 typedef struct rgx_stream_config {  /* stream.Config, stream/stream.go:21-39 */
   int64_t buffer_size;
   int64_t max_leftover;

@@ -776,11 +776,28 @@ class StreamMatch:  # stream.Match[T] (stream/stream.go:66-79)
     match_bytes: bytes
     StreamOffset: int
     ChunkIndex: int
+    fields: Optional[List[Optional[bytes]]] = None   # reuse=True: the texts the callback reads from the REUSED result struct
 
 
 def find_reader(find_fn: Callable[[bytes], Optional[List[int]]], max_len: int, read: Callable[[int], bytes],
-                cfg: StreamConfig, on_match: Callable[[StreamMatch], bool]) -> Optional[str]:
-    """FindReader, streaming.go:85-255.  `read(k)` returns up to k bytes, b"" at EOF (io.Reader)."""
+                cfg: StreamConfig, on_match: Callable[[StreamMatch], bool], reuse: bool = False) -> Optional[str]:
+    """FindReader, streaming.go:85-255.  `read(k)` returns up to k bytes, b"" at EOF (io.Reader).
+    reuse=True models `reuseResult` (streaming.go:117): ONE result struct for the whole stream, whose fields are slices of `buf`.
+    The Tagged-DFA engine assigns a group's field only when its start tag is set (tdfa.go:1031-1046; find_fn reports the others as
+    (-1, -1)), so a field may keep the slice header of an earlier match -- and `buf` is overwritten in place by the leftover copy and
+    the next Read, so what the callback sees is whatever lies at those offsets NOW.  StreamMatch.fields holds exactly that."""
+    held: List[Optional[Tuple[int, int]]] = []      # per group: (lo, hi) into buf, None = nil
+
+    def fields_now(caps, sp):
+        if not reuse:
+            return None
+        while len(held) < len(caps) // 2:
+            held.append(None)
+        for g in range(len(caps) // 2):
+            if caps[2 * g] >= 0:
+                held[g] = (sp + caps[2 * g], sp + caps[2 * g + 1])
+        return [None if h is None else bytes(buf[h[0]:h[1]]) for h in held]
+
     mb = min_buffer(max_len)
     err = cfg.validate(mb)
     if err:
@@ -807,7 +824,7 @@ def find_reader(find_fn: Callable[[bytes], Optional[List[int]]], max_len: int, r
                     if idx < 0:
                         break
                     ms = sp + idx
-                    if not on_match(StreamMatch(caps, mbytes, stream_offset + ms, chunk_index)):
+                    if not on_match(StreamMatch(caps, mbytes, stream_offset + ms, chunk_index, fields_now(caps, sp))):
                         return None
                     sp = ms + len(mbytes) if len(mbytes) > 0 else sp + 1
             return None
@@ -829,7 +846,7 @@ def find_reader(find_fn: Callable[[bytes], Optional[List[int]]], max_len: int, r
             me = ms + len(mbytes)
             if is_full and me > data_len - cfg.MaxLeftover:
                 break
-            if not on_match(StreamMatch(caps, mbytes, stream_offset + ms, chunk_index)):
+            if not on_match(StreamMatch(caps, mbytes, stream_offset + ms, chunk_index, fields_now(caps, sp))):
                 return None
             committed = me
             sp = me if len(mbytes) > 0 else sp + 1
@@ -890,4 +907,4 @@ class Compiled:
 
     def FindReader(self, read, cfg: StreamConfig, on_match) -> Optional[str]:
         find = self.tdfa.find if self.tdfa is not None else self.find_machine.find
-        return find_reader(find, self.sel.max_len, read, cfg, on_match)
+        return find_reader(find, self.sel.max_len, read, cfg, on_match, reuse=self.tdfa is not None)

@@ -21,7 +21,7 @@ _STATUS = {0: "ok", -1: "invalid", -2: "syntax", -3: "unsupported", -4: "too lar
            -7: "nomem", -8: "capacity", -9: "bad blob", -10: "buffer too small", -11: "diverges from the reference"}
 
 RGX_OK = 0
-ABI_VERSION = 3            # include/rgx.h: RGX_ABI_VERSION (checked against rgx_abi_version() when the library is loaded)
+ABI_VERSION = 4            # include/rgx.h: RGX_ABI_VERSION (checked against rgx_abi_version() when the library is loaded)
 RGX_E_INVALID = -1
 RGX_E_SYNTAX = -2
 RGX_E_UNSUPPORTED = -3
@@ -32,6 +32,7 @@ RGX_E_DIVERGES = -11
 TRANSFORM_REPLACE, TRANSFORM_SELECT, TRANSFORM_REJECT = 0, 1, 2
 FLAG_UNMATCHED_MINUS1 = 1
 FLAG_STDLIB_SEMANTICS = 2
+FLAG_FORCE_TDFA = 1 << 2            # regengo.Options.ForceTDFA
 
 
 class Info(C.Structure):
@@ -39,7 +40,7 @@ class Info(C.Structure):
         "abi_version", "ncap", "min_match_len", "max_match_len", "default_max_leftover", "min_buffer_size", "n_inst",
         "n_states", "n_classes", "anchored", "fixed_captures", "can_match_empty", "ref_match_engine", "ref_find_engine",
         "lookahead_mode", "table_bytes", "needs_valid_utf8", "sync_states", "scan_kernel", "ref_match_offered", "ref_find_offered", "unicode_version", "utf8_screened",
-        "ref_findall_offered", "ref_stream_offered", "ref_tdfa_states")] + [("flags", C.c_uint32)]
+        "ref_findall_offered", "ref_stream_offered", "ref_tdfa_states")] + [("flags", C.c_uint32), ("ref_replace_offered", C.c_int32)]
 
 
 class ShardRange(C.Structure):

@@ -57,7 +57,8 @@ class BytesResult:
 
 
 class Compiled:
-    def __init__(self, pattern: str, name: str = "Pattern", flags: int = 0, device: Optional[int] = None, stdlib: bool = False):
+    def __init__(self, pattern: str, name: str = "Pattern", flags: int = 0, device: Optional[int] = None, stdlib: bool = False,
+                 force_tdfa: bool = False):
         """stdlib=False (the default): MatchBytes / FindBytes / FindBatch behave like the reference's emitted functions,
         restart rule included (SURVEY 5.9 Q1: a failed attempt resumes behind its failure offset, stepping over some matches);
         stdlib=True: the plain leftmost-first search (RGX_FLAG_STDLIB_SEMANTICS).  FindAllBytes is the same in both."""
@@ -66,6 +67,8 @@ class Compiled:
         self.name = name
         if stdlib:
             flags |= _capi.FLAG_STDLIB_SEMANTICS
+        if force_tdfa:          # regengo.Options.ForceTDFA: the reference's Tagged DFA for the capture functions whenever it can be built
+            flags |= _capi.FLAG_FORCE_TDFA
         self.stdlib = bool(flags & _capi.FLAG_STDLIB_SEMANTICS)
         h = C.c_void_p()
         _capi.check(self._lib.rgx_compile(pattern.encode("utf-8"), flags, C.byref(h)))
@@ -400,6 +403,8 @@ class Compiled:
         committed = C.c_int64()
         keep = C.c_int64()
         res = _capi.Result()
+        tdfa_reuse = self.info.ref_find_engine == 1 and not self.stdlib
+        held = [None] * (self.ncap // 2)
         while True:
             data = r.read(cfg.BufferSize - leftover)
             n = len(data)
@@ -419,7 +424,18 @@ class Compiled:
             chunk = bytes(buf[:data_len])
             for i in range(w):
                 rec = spans[i * self.ncap:(i + 1) * self.ncap]
-                m = Match(self._make_result(chunk, rec), stream_offset + rec[0], chunk_index)
+                if tdfa_reuse:
+                    # ONE result struct for the whole stream (streaming.go:117), its fields slices of `buf`; the Tagged DFA's
+                    # result construction assigns a group only when its start tag is set (tdfa.go:1031-1046; the record says
+                    # (-1, -1) otherwise) -- the field then still aliases the bytes of an earlier match's group, whatever
+                    # lies there by now
+                    for g in range(self.ncap // 2):
+                        if rec[2 * g] >= 0:
+                            held[g] = (rec[2 * g], rec[2 * g + 1])
+                    vals = [None if h is None else bytes(buf[h[0]:h[1]]) for h in held]
+                    m = Match(BytesResult(self.fields, vals, [int(x) for x in rec]), stream_offset + rec[0], chunk_index)
+                else:
+                    m = Match(self._make_result(chunk, rec), stream_offset + rec[0], chunk_index)
                 if not on_match(m):
                     return
             if n == 0:

@@ -339,6 +339,64 @@ static int64_t RmFailOffset(const Tables& t, int v, const uint8_t* buf, int64_t 
     st = nx;
   }
 }
+// ---- the reference's Tagged DFA as the product holds it (rgx_dfa.h: RefTdfa) -- tables for pinning against the emitted literals
+// (tests/golden/tdfa_tables.json) and the find loop of tdfa.go:831-1052 over them, the loop rgx_tdfa.hip runs per lane.
+int rgxt_tdfa_header(void* hh, int32_t* out8) {
+  const RefTdfa& d = ((Handle*)hh)->t.tdfa;
+  int32_t v[8] = {d.nstates, d.ntags, d.start_begin, d.start_any, (int32_t)d.pool.size(), d.init_begin, d.init_any, 0};
+  memcpy(out8, v, sizeof v);
+  return d.nstates;
+}
+int rgxt_tdfa_tables(void* hh, int16_t* trans, uint16_t* act, uint8_t* accept, uint16_t* acc_act, int16_t* pool) {
+  const RefTdfa& d = ((Handle*)hh)->t.tdfa;
+  if (!d.nstates) return 0;
+  memcpy(trans, d.trans.data(), d.trans.size() * 2); memcpy(act, d.act.data(), d.act.size() * 2);
+  memcpy(accept, d.accept.data(), d.accept.size()); memcpy(acc_act, d.acc_act.data(), d.acc_act.size() * 2);
+  memcpy(pool, d.pool.data(), d.pool.size() * 2);
+  return d.nstates;
+}
+// One attempt at `start` (tdfa.go:939-987): returns the match end or -1; tags[ntags] = the snapshot of the last accept.
+static int64_t TdfaAttempt(const RefTdfa& d, const uint8_t* buf, int64_t len, int64_t start, bool begin, int32_t* mtags) {
+  std::vector<int32_t> tags(d.ntags, -1);
+  tags[0] = (int32_t)start;
+  int st = begin ? d.start_begin : d.start_any;
+  { const uint16_t at = begin ? d.init_begin : d.init_any; for (int a = 0; a < d.pool[at]; a++) tags[d.pool[at + 1 + 2 * a]] = (int32_t)start; }
+  int64_t end = -1;
+  auto snap = [&](int64_t e) { end = e; memcpy(mtags, tags.data(), d.ntags * 4); };
+  if (d.accept[st] & 1) snap(start);
+  if (start == len && (d.accept[st] & 2)) snap(start);
+  for (int64_t i = start; i < len; i++) {
+    const int c = buf[i];
+    if (c >= 128) break;
+    const int ns = d.trans[(size_t)st * 128 + c];
+    if (ns < 0) break;
+    const uint16_t at = d.act[(size_t)st * 128 + c];
+    for (int a = 0; a < d.pool[at]; a++) tags[d.pool[at + 1 + 2 * a]] = (int32_t)(i + 1 - d.pool[at + 2 + 2 * a]);
+    st = ns;
+    const uint16_t aa = d.acc_act[st];
+    if (d.accept[st] & 1) { for (int a = 0; a < d.pool[aa]; a++) tags[d.pool[aa + 1 + 2 * a]] = (int32_t)(i + 1 - d.pool[aa + 2 + 2 * a]); snap(i + 1); }
+    if (i == len - 1 && (d.accept[st] & 2)) { for (int a = 0; a < d.pool[aa]; a++) tags[d.pool[aa + 1 + 2 * a]] = (int32_t)(i + 1 - d.pool[aa + 2 + 2 * a]); snap(i + 1); }
+  }
+  return end;
+}
+// FindBytes: 1 + out[ntags] (raw matchTags after the result construction's fix-ups: tags[1] = end, an open group closed at the
+// match end, an unset group (-1, -1) = "field left untouched"), 0 = no match, -3 = the program has no Tagged DFA.
+int rgxt_tdfa_find(void* hh, const uint8_t* buf, int64_t len, int32_t* out) {
+  const RefTdfa& d = ((Handle*)hh)->t.tdfa;
+  if (!d.nstates) return -3;
+  for (int64_t start = 0; start <= len; start++) {
+    const int64_t e = TdfaAttempt(d, buf, len, start, start == 0, out);
+    if (e < 0) continue;
+    out[1] = (int32_t)e;
+    for (int g = 1; g < d.ntags / 2; g++) {
+      if (out[2 * g] >= 0) { if (out[2 * g + 1] < 0) out[2 * g + 1] = out[1]; }
+      else out[2 * g + 1] = -1;
+    }
+    return 1;
+  }
+  return 0;
+}
+
 int rgxt_ref_find(void* hh, const uint8_t* buf, int64_t len, int32_t* out) {
   const Tables& t = ((Handle*)hh)->t;
   if (t.ref_memo || t.ref_find_engine > 0) return -3;

@@ -20,6 +20,8 @@
 
 using namespace rgx;
 
+static constexpr uint32_t kPublicFlags = RGX_FLAG_UNMATCHED_MINUS1 | RGX_FLAG_STDLIB_SEMANTICS | RGX_FLAG_FORCE_TDFA;
+
 struct rgx_program {
   Program p;
   // learned at run time, kept with the PROGRAM so that every context (and a context handed from program to program,
@@ -58,6 +60,7 @@ struct rgx_stream_ctx {
   long long* d_rdelta = nullptr; int64_t rdelta_cap = 0;     // [delta n+1][shift n+1]
   uint8_t* d_rtemp = nullptr; int64_t rtemp_cap = 0;         // hipcub temp + segments + literals
   int32_t* d_out = nullptr; int64_t out_cap = 0;
+  int32_t* d_tdfa = nullptr; int64_t tdfa_cap = 0;           // Tagged-DFA path: ends, (start, end) pairs, sync bits, counts, offsets (TdfaChainDevice)
   uint8_t* d_tmpl = nullptr; int64_t tmpl_cap = 0;           // resolved template (segments + literals) of the last splice
   std::string tmpl_key;                                      // what d_tmpl holds: "" = nothing
   // pinned host readback
@@ -154,10 +157,16 @@ bool RefFindAllOffered(const Tables& t) {
   if (t.ref_find_engine <= 0) return true;                       // plain backtracking (or no captures: nothing to differ from)
   return t.ref_find_engine == 2 && !t.can_match_empty;           // memoising backtracker: Q8 needs an empty match; TDFA: Q11
 }
-bool RefStreamOffered(const Tables& t) {
+// The reference's Tagged DFA is run as it is (rgx_tdfa.hip) when the program has one (rgx_dfa.h: RefTdfa; its tag file is the record)
+bool HasRefTdfa(const Tables& t) { return t.ref_find_engine == 1 && t.tdfa.nstates > 0 && t.tdfa.ntags == t.ncap; }
+bool RefTdfaMode(const rgx_program* p) { return !(p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS) && HasRefTdfa(p->p.t) && p->p.dev.tdfa != nullptr; }
+// Replace* / Transform: FindBytesReuse of the plain backtracking engine on a re-sliced input
+bool RefReplaceOffered(const Tables& t) {
   const bool have_rm = !t.rm_depth[0].empty() && !t.rm_depth[1].empty();
   return have_rm && !t.ref_memo && t.ref_find_engine <= 0 && !t.can_match_empty;
 }
+// FindReader / FindReaderCount: the same, or the Tagged DFA's FindBytesReuse
+bool RefStreamOffered(const Tables& t) { return RefReplaceOffered(t) || (HasRefTdfa(t) && !t.can_match_empty); }
 int RefuseFindAll(const rgx_program* p) {
   const Tables& t = p->p.t;
   if ((t.flags & RGX_FLAG_STDLIB_SEMANTICS) || RefFindAllOffered(t)) return RGX_OK;
@@ -166,10 +175,11 @@ int RefuseFindAll(const rgx_program* p) {
                : "reference-mode FindAll is not offered for this pattern: the reference memoises and the pattern matches empty (its memo is never cleared between matches, find.go:175-188); keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS");
   return RGX_E_UNSUPPORTED;
 }
-int RefuseStream(const rgx_program* p) {
+int RefuseStream(const rgx_program* p, bool splice = false) {
   const Tables& t = p->p.t;
-  if ((t.flags & RGX_FLAG_STDLIB_SEMANTICS) || RefStreamOffered(t)) return RGX_OK;
-  SetError("reference-mode FindReader / Replace / Transform is not offered for this pattern: the emitted loop is FindBytesReuse on a re-sliced input and the reference's FindBytesReuse (memoising / Tagged-DFA engine, or a pattern that matches empty) is not reproduced; keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS");
+  if ((t.flags & RGX_FLAG_STDLIB_SEMANTICS) || (splice ? RefReplaceOffered(t) : RefStreamOffered(t))) return RGX_OK;
+  if (!splice && HasRefTdfa(t) && !p->p.dev.tdfa && !t.can_match_empty) return RGX_OK;     // (not on a device yet: CheckCtx has the say)
+  SetError("reference-mode FindReader / Replace / Transform is not offered for this pattern: the emitted loop is FindBytesReuse on a re-sliced input and the reference's FindBytesReuse (memoising engine; Tagged-DFA engine under Replace / Transform; or a pattern that matches empty) is not reproduced; keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS");
   return RGX_E_UNSUPPORTED;
 }
 int ReaderCheck(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_raw, size_t len, const int32_t* d_spans, int64_t n) {
@@ -183,6 +193,92 @@ int ReaderCheck(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_raw, s
   HIP_TRY(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (h) { SetError("the reference's FindReader loop diverges from FindAllBytes on this chunk (restart rule / bytes.Index / re-slicing): run it through the Go loop"); return RGX_E_DIVERGES; }
+  return RGX_OK;
+}
+
+// ---- the reference's Tagged DFA (rgx_tdfa.hip).  FindReader's chain over one device buffer: the matches of the loop "FindBytesReuse
+// on buf[searchPos:]; searchPos = end of the match" (streaming.go:175-244 without its commit rule; max_n = 1: FindBytes), rows of
+// ncap int32 = the reported tags ((-1, -1): the group's field is left untouched, tdfa.go:1031-1046).  Returns the number of matches
+// (rows written: min(that, cap_records); d_rows may be NULL with cap_records 0: count only) or a negative status.
+int64_t TdfaChainDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t max_n, int32_t* d_rows,
+                        size_t cap_records, rgx_result* res) {
+  const TdfaDev& D = *p->p.dev.tdfa;
+  const Tables& t = p->p.t;
+  if (res) { memset(res, 0, sizeof *res); res->ncap = t.ncap; }
+  if (len == 0 || max_n == 0) return 0;               // `for searchPos < len(chunk)`
+  if (len > 0x7FFFFF00ull) { SetError("buffer larger than 2^31-256 bytes: shard it"); return RGX_E_TOO_LARGE; }
+  const int32_t ilen = (int32_t)len;
+  if (max_n < 0) max_n = INT64_MAX;
+  const int64_t cap_m = std::min<int64_t>((int64_t)len / std::max(t.min_len, 1) + 2, max_n);
+  const int64_t nslices = TdfaSlices(ilen), ntiles = TdfaSyncTiles(ilen);
+  const bool parallel = D.start_begin == D.start_any && !t.can_match_empty && len >= 8192 && max_n > 1;
+  const size_t scan_tmp = parallel ? TdfaScanTempBytes(nslices) : 0;
+  auto r4 = [](int64_t x) { return (x + 3) & ~int64_t(3); };
+  const int64_t o_ends = 0, o_se = o_ends + r4((int64_t)len + 1), o_sync = o_se + r4(2 * cap_m), o_counts = o_sync + r4(2 * nslices),
+                o_offs = o_counts + r4(nslices + 1), o_desc = o_offs + r4(nslices + 1), o_misc = o_desc + r4(2 * ntiles),
+                o_tmp = o_misc + 16, total = o_tmp + r4((int64_t)(scan_tmp + 3) / 4);
+  int rc;
+  if ((rc = Ensure(&c->d_tdfa, &c->tdfa_cap, total)) != RGX_OK) return rc;
+  int32_t* base = c->d_tdfa;
+  int32_t* ends = base + o_ends; int32_t* se = base + o_se;
+  unsigned long long* sync = (unsigned long long*)(base + o_sync);
+  int32_t* counts = base + o_counts; int32_t* offs = base + o_offs;
+  unsigned long long* desc = (unsigned long long*)(base + o_desc);
+  uint32_t* flags = (uint32_t*)(base + o_misc);
+  long long* out_n = (long long*)(base + o_misc + 2);
+  HIP_TRY(hipMemsetAsync(base + o_misc, 0, 64, c->stream));
+  HIP_TRY(LaunchTdfaEnds(D, d_buf, ilen, ends, flags, c->stream));
+  int64_t n = 0;
+  int32_t h[4] = {0, 0, 0, 0};
+  auto over_budget = [&]() {
+    SetError("the Tagged DFA's attempts on this text are too long to finish (an attempt per start offset is quadratic here, in the reference as well): keep the CPU path for it");
+    return RGX_E_UNSUPPORTED;
+  };
+  if (parallel) {
+    HIP_TRY(hipMemsetAsync(desc, 0, (size_t)ntiles * 8, c->stream));
+    HIP_TRY(LaunchTdfaSync(ends, ilen, sync, desc, flags, c->stream));
+    HIP_TRY(LaunchTdfaChain(ends, ilen, sync, counts, nullptr, nullptr, 0, 0, flags, c->stream));
+    HIP_TRY(LaunchTdfaScan(counts, offs, nslices, base + o_tmp, scan_tmp, c->stream));
+    HIP_TRY(hipMemcpyAsync(&h[0], flags, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&h[1], counts + nslices - 1, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&h[2], offs + nslices - 1, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((uint32_t)h[0] & kTdfaOverBudget) return over_budget();
+    if (h[0] & 1) { SetError("tdfa_sync_kernel: look-back timeout"); return RGX_E_HIP; }
+    n = (int64_t)h[1] + h[2];
+    if (n > cap_m) { SetError("internal: more Tagged-DFA matches than len / min_len"); return RGX_E_HIP; }
+    if (n > 0 && d_rows) HIP_TRY(LaunchTdfaChain(ends, ilen, sync, counts, offs, se, cap_m, 1, flags, c->stream));
+  } else {
+    HIP_TRY(LaunchTdfaChainSerial(D, d_buf, ilen, ends, se, cap_m, out_n, flags, c->stream));
+    long long hn = 0;
+    HIP_TRY(hipMemcpyAsync(&h[0], flags, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&hn, out_n, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((uint32_t)h[0] & kTdfaOverBudget) return over_budget();
+    n = hn;
+  }
+  if (res) { res->total = n; res->written = 0; }
+  if (d_rows && n > 0) {
+    const int64_t w = std::min<int64_t>(n, (int64_t)cap_records);
+    HIP_TRY(LaunchTdfaTags(D, d_buf, ilen, se, w, d_rows, c->stream));
+    if (res) res->written = w;
+    if (w < n) { HIP_TRY(hipStreamSynchronize(c->stream)); SetError("span capacity too small"); return RGX_E_CAPACITY; }
+  }
+  return n;
+}
+
+// bytes.Index (streaming.go:192) against the chain's rows: an earlier copy of a match's text in the gap in front of it moves the
+// offset the loop reports.  With one start state that can only happen to a match that was accepted BY the end of the text (the same
+// bytes earlier are not at the end) -- checked for every row all the same.
+int TdfaIndexCheck(rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, const int32_t* d_rows, int64_t n, int ncap) {
+  if (n <= 0) return RGX_OK;
+  unsigned* flag = reinterpret_cast<unsigned*>(c->d_cursor + 1);
+  unsigned h = 0;
+  HIP_TRY(hipMemsetAsync(flag, 0, 4, c->stream));
+  HIP_TRY(LaunchReaderIndex(d_buf, (int32_t)len, d_rows, n, ncap, flag, c->stream));
+  HIP_TRY(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (h) { SetError("the reference's FindReader loop reports a match of this chunk at an earlier copy of its text (bytes.Index, streaming.go:192): run it through the Go loop"); return RGX_E_DIVERGES; }
   return RGX_OK;
 }
 
@@ -554,6 +650,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
 RGX_API int rgx_compile(const char* pattern, uint32_t flags, rgx_program** out) {
   if (!pattern || !out) return RGX_E_INVALID;
   *out = nullptr;
+  if (flags & ~kPublicFlags) { SetError("unknown flag bits (RGX_FLAG_*)"); return RGX_E_INVALID; }   // kFlagAsciiText is the library's own
   try {
     auto* h = new rgx_program();
     h->p.t = BuildTables(pattern, flags);
@@ -586,6 +683,7 @@ RGX_API int rgx_program_from_blob(const void* blob, size_t len, rgx_program** ou
   if (!blob || !out) return RGX_E_INVALID;
   auto* h = new rgx_program();
   if (!DeserializeTables((const uint8_t*)blob, len, &h->p.t)) { delete h; SetError("bad table blob"); return RGX_E_BAD_BLOB; }
+  if (h->p.t.flags & ~kPublicFlags) { delete h; SetError("bad table blob: unknown flag bits"); return RGX_E_BAD_BLOB; }
   *out = h;
   return RGX_OK;
 }
@@ -621,14 +719,15 @@ RGX_API int rgx_program_info(const rgx_program* p, rgx_info* o) {
   o->unicode_version = UnicodeVersion();
   {
     const bool have_rm = !t.rm_depth[0].empty() && !t.rm_depth[1].empty();
-    o->ref_find_offered = (have_rm && !t.ref_memo && t.ref_find_engine <= 0) ? 1 : 0;
+    o->ref_find_offered = ((have_rm && !t.ref_memo && t.ref_find_engine <= 0) || HasRefTdfa(t)) ? 1 : 0;
     o->ref_match_offered = (t.ref_match_engine == 1 || (have_rm && !t.ref_memo && !t.ref_has_fail)) ? 1 : 0;
     const bool stdlib = (t.flags & RGX_FLAG_STDLIB_SEMANTICS) != 0;
     if (stdlib) o->ref_find_offered = o->ref_match_offered = 1;       // nothing of the reference's to reproduce: every entry point answers
     o->ref_findall_offered = (stdlib || RefFindAllOffered(t)) ? 1 : 0;
     o->ref_stream_offered = (stdlib || RefStreamOffered(t)) ? 1 : 0;
+    o->ref_replace_offered = (stdlib || RefReplaceOffered(t)) ? 1 : 0;
     o->ref_tdfa_states = t.ref_tdfa_states;
-    o->flags = t.flags;
+    o->flags = t.flags & kPublicFlags;
   }
   o->scan_kernel = p->p.d_arena ? ScanKernelKind(p->p.dev, 1 << 24) : 0;
   o->table_bytes = p->p.d_arena ? p->p.dev.table_bytes : (int32_t)((size_t)t.nstates * (t.ncls + 1) * 2);
@@ -703,7 +802,7 @@ RGX_API void rgx_stream_ctx_destroy(rgx_stream_ctx* c) {
   for (int i = 0; i < 2; ++i)
     for (hipEvent_t e : {c->pev0[i], c->pev1[i], c->pdone[i]}) if (e) (void)hipEventDestroy(e);
   for (void* p : {(void*)c->d_desc, (void*)c->d_unsynced, (void*)c->d_carry,
-                  (void*)c->d_trace, (void*)c->d_in, (void*)c->d_san, (void*)c->d_out, (void*)c->d_rspans, (void*)c->d_rdelta, (void*)c->d_rtemp, (void*)c->d_tmpl})
+                  (void*)c->d_trace, (void*)c->d_in, (void*)c->d_san, (void*)c->d_out, (void*)c->d_rspans, (void*)c->d_rdelta, (void*)c->d_rtemp, (void*)c->d_tmpl, (void*)c->d_tdfa})
     if (p) (void)hipFree(p);
   if (c->h_read) (void)hipHostFree(c->h_read);
   delete c;
@@ -1007,7 +1106,7 @@ RGX_API int64_t rgx_replace_all_bytes_device(const rgx_program* p, rgx_stream_ct
                                              rgx_result* res) {
   int rc = CheckCtx(p, c);
   if (rc != RGX_OK) return rc;
-  if ((rc = RefuseStream(p)) != RGX_OK) return rc;
+  if ((rc = RefuseStream(p, true)) != RGX_OK) return rc;
   if (!out_len || (!tmpl && tmpl_len)) return RGX_E_INVALID;
   const Tables& t = p->p.t;
   const DevTables& T = p->p.dev;
@@ -1096,7 +1195,7 @@ int64_t TransformChunkDevice(const rgx_program* p, rgx_stream_ctx* c, const uint
                              bool final_sync) {
   int rc = CheckCtx(p, c);
   if (rc != RGX_OK) return rc;
-  if ((rc = RefuseStream(p)) != RGX_OK) return rc;
+  if ((rc = RefuseStream(p, true)) != RGX_OK) return rc;
   if (!out_len || !processed || mode < RGX_TRANSFORM_REPLACE || mode > RGX_TRANSFORM_REJECT) return RGX_E_INVALID;
   if (mode == RGX_TRANSFORM_REPLACE && !tmpl && tmpl_len) return RGX_E_INVALID;
   const Tables& t = p->p.t;
@@ -1330,6 +1429,19 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
   if ((rc = MatchViewBatch(p, c, d_concat, d_offsets, nstr, &d_concat)) != RGX_OK) return rc;
   const DevTables& T = p->p.dev;
   const bool ref_mode = !(p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS);
+  if (RefTdfaMode(p)) {
+    // the reference emits its Tagged DFA for this pattern: its own tables, its own loop (tdfa.go:831-1052) -- rows are the reported
+    // tags, (-1, -1) = "field left untouched" whatever RGX_FLAG_UNMATCHED_MINUS1 says
+    if ((rc = Ensure(&c->d_tdfa, &c->tdfa_cap, 16)) != RGX_OK) return rc;
+    uint32_t* flags = (uint32_t*)c->d_tdfa;
+    uint32_t h = 0;
+    HIP_TRY(hipMemsetAsync(flags, 0, 4, c->stream));
+    HIP_TRY(LaunchTdfaBatch(*T.tdfa, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, flags, c->stream));
+    HIP_TRY(hipMemcpyAsync(&h, flags, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (h & kTdfaOverBudget) { SetError("the Tagged DFA's attempts on a string of this batch are too long to finish: keep the CPU path for it"); return RGX_E_UNSUPPORTED; }
+    return (int64_t)nstr;
+  }
   if (ref_mode && !T.ref_find_ok) {
     // reference mode: FindBytesReuse's own restart rule (find.go:545-569)
     SetError("reference-mode FindBytes is not offered for this pattern (memoising / TDFA engine): keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS");
@@ -1592,6 +1704,22 @@ RGX_API int64_t rgx_find_batch(const rgx_program* p, rgx_stream_ctx* c, const ui
 
 RGX_API int rgx_find_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* buf, size_t len, int32_t* spans, int* found) {
   if (!found || !spans) return RGX_E_INVALID;
+  if (p && c && c->prog == p && p->p.d_arena && RefTdfaMode(p) && len >= 4096) {
+    // one long text: the loop over start offsets is what runs in parallel (a lane per start), not one lane per text
+    int rc = CheckCtx(p, c);
+    if (rc != RGX_OK) return rc;
+    if (!buf) return RGX_E_INVALID;
+    const int ncap = p->p.t.ncap;
+    if ((rc = Ensure(&c->d_in, &c->in_cap, (int64_t)len + 64)) != RGX_OK) return rc;
+    if ((rc = Ensure(&c->d_out, &c->out_cap, (int64_t)ncap + 16)) != RGX_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream));
+    const int64_t n = TdfaChainDevice(p, c, c->d_in, len, 1, c->d_out, 1, nullptr);
+    if (n < 0) return (int)n;
+    *found = n > 0;
+    if (n > 0) HIP_TRY(hipMemcpy(spans, c->d_out, (size_t)ncap * 4, hipMemcpyDeviceToHost));
+    else memset(spans, 0, (size_t)ncap * 4);
+    return RGX_OK;
+  }
   const uint64_t offs[2] = {0, (uint64_t)len};
   uint8_t f = 0;
   const int64_t r = rgx_find_batch(p, c, buf, offs, 1, &f, spans);
@@ -1634,9 +1762,16 @@ RGX_API int64_t rgx_find_chunk(const rgx_program* p, rgx_stream_ctx* c, const ui
     if ((rc = Ensure(&c->d_in, &c->in_cap, (int64_t)data_len + 64)) != RGX_OK) return rc;
     if ((rc = Ensure(&c->d_out, &c->out_cap, (int64_t)cap_records * ncap + 16)) != RGX_OK) return rc;
     HIP_TRY(hipMemcpyAsync(c->d_in, chunk, data_len, hipMemcpyHostToDevice, c->stream));
-    w = FindAllDevice(p, c, c->d_in, data_len, -1, c->d_out, cap_records, false, &r);
-    if (w < 0) return w;
-    if (ReaderCheckApplies(p) && (rc = ReaderCheck(p, c, c->d_in, data_len, c->d_out, w)) != RGX_OK) return rc;
+    if (RefTdfaMode(p)) {
+      // the Tagged DFA's own loop over the chunk (rows: reported tags, (-1, -1) = field untouched) + the bytes.Index test
+      w = TdfaChainDevice(p, c, c->d_in, data_len, -1, c->d_out, cap_records, &r);
+      if (w < 0) return w;
+      if ((rc = TdfaIndexCheck(c, c->d_in, data_len, c->d_out, w, ncap)) != RGX_OK) return rc;
+    } else {
+      w = FindAllDevice(p, c, c->d_in, data_len, -1, c->d_out, cap_records, false, &r);
+      if (w < 0) return w;
+      if (ReaderCheckApplies(p) && (rc = ReaderCheck(p, c, c->d_in, data_len, c->d_out, w)) != RGX_OK) return rc;
+    }
     if (w > 0) HIP_TRY(hipMemcpy(spans, c->d_out, (size_t)w * ncap * 4, hipMemcpyDeviceToHost));
   }
   int64_t comm = 0, emitted = 0;
@@ -1674,7 +1809,8 @@ RGX_API int64_t rgx_count_chunk(const rgx_program* p, rgx_stream_ctx* c, const u
   if (data_len == 0) { if (res) *res = r; return 0; }
   if ((rc = Ensure(&c->d_in, &c->in_cap, (int64_t)data_len + 64)) != RGX_OK) return rc;
   HIP_TRY(hipMemcpyAsync(c->d_in, chunk, data_len, hipMemcpyHostToDevice, c->stream));
-  const bool check = ReaderCheckApplies(p);
+  const bool tdfa = RefTdfaMode(p);
+  const bool check = ReaderCheckApplies(p) || tdfa;
   if (!is_full && !check) {
     int64_t total = FindAllDevice(p, c, c->d_in, data_len, -1, nullptr, 0, true, &r);
     if (total < 0) return total;
@@ -1686,9 +1822,16 @@ RGX_API int64_t rgx_count_chunk(const rgx_program* p, rgx_stream_ctx* c, const u
   const int ncap = p->p.dev.ncap;
   const int64_t cap_records = (int64_t)(data_len / (size_t)std::max(p->p.t.min_len, 1)) + 2;
   if ((rc = Ensure(&c->d_out, &c->out_cap, cap_records * ncap + 16)) != RGX_OK) return rc;
-  int64_t w = FindAllDevice(p, c, c->d_in, data_len, -1, c->d_out, (size_t)cap_records, false, &r);
-  if (w < 0) return w;
-  if (check && (rc = ReaderCheck(p, c, c->d_in, data_len, c->d_out, w)) != RGX_OK) return rc;
+  int64_t w;
+  if (tdfa) {
+    w = TdfaChainDevice(p, c, c->d_in, data_len, -1, c->d_out, (size_t)cap_records, &r);
+    if (w < 0) return w;
+    if ((rc = TdfaIndexCheck(c, c->d_in, data_len, c->d_out, w, ncap)) != RGX_OK) return rc;
+  } else {
+    w = FindAllDevice(p, c, c->d_in, data_len, -1, c->d_out, (size_t)cap_records, false, &r);
+    if (w < 0) return w;
+    if (check && (rc = ReaderCheck(p, c, c->d_in, data_len, c->d_out, w)) != RGX_OK) return rc;
+  }
   if (!is_full) {        // nothing is deferred from a chunk that is not full: every match counts
     *committed = -1;
     if (res) { *res = r; res->written = 0; }

@@ -389,8 +389,11 @@ Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOption
     bool thompson = (cat || nl) && !ea;
     t.ref_match_engine = (thompson && prog.inst.size() <= 64) ? 1 : ((nl || cat) ? 2 : 0);
     // compiler.go:137-153: captures + nested quantifiers -> the Tagged DFA if it can be built, else the memoising backtracker
-    t.ref_tdfa_states = (prog.numcap > 2 && cat) ? std::max(0, RefTdfaStates(prog)) : 0;
-    t.ref_find_engine = prog.numcap <= 2 ? -1 : (cat ? (t.ref_tdfa_states > 0 ? 1 : 2) : 0);
+    const bool force_tdfa = (flags & (1u << 2)) != 0;          // RGX_FLAG_FORCE_TDFA = regengo.Options.ForceTDFA
+    if (prog.numcap > 2 && (cat || force_tdfa)) BuildRefTdfa(prog, prog.numcap / 2, &t.tdfa);
+    t.ref_tdfa_states = t.tdfa.nstates;
+    // (forced but infeasible: "falling back" to the TNFA functions, which memoise -- compiler.go:143-147, 415-426)
+    t.ref_find_engine = prog.numcap <= 2 ? -1 : ((cat || force_tdfa) ? (t.ref_tdfa_states > 0 ? 1 : 2) : 0);
   }
 
   if (opt.unanchored_search) {
@@ -1108,7 +1111,7 @@ struct R {
   void raw(void* d, size_t k) { if (o + k > n) { ok = false; return; } memcpy(d, p + o, k); o += k; }
 };
 constexpr uint32_t kMagic = 0x54584752;  // "RGXT"
-constexpr uint32_t kBlobVersion = 5;  /* 5: ref_tdfa_states */    // 3: FNV-1a checksum of the blob appended; every index range-checked on load
+constexpr uint32_t kBlobVersion = 6;  /* 5: ref_tdfa_states; 6: the Tagged DFA itself */    // 3: FNV-1a checksum of the blob appended; every index range-checked on load
 uint64_t Fnv1a(const uint8_t* p, size_t n) {
   uint64_t h = 1469598103934665603ull;
   for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
@@ -1147,6 +1150,12 @@ std::vector<uint8_t> SerializeTables(const Tables& t) {
   w.pod<int32_t>(t.w_nstates); w.pod<uint16_t>(t.w_start); w.vec(t.w_trans); w.pod<uint8_t>(t.needs_valid_utf8);
   for (int v = 0; v < 2; v++) { w.vec(t.rm_trans[v]); w.vec(t.rm_depth[v]); w.raw(t.rm_start[v], sizeof t.rm_start[v]); }
   w.pod<uint8_t>(t.ref_memo); w.pod<uint8_t>(t.ref_has_fail); w.pod<int32_t>(t.ref_prefix);
+  {  // the reference's Tagged DFA in place of tdfa.go:584-794's Go literals
+    const RefTdfa& d = t.tdfa;
+    w.pod<int32_t>(d.nstates); w.pod<int32_t>(d.ntags); w.pod<int32_t>(d.start_begin); w.pod<int32_t>(d.start_any);
+    w.pod<uint16_t>(d.init_begin); w.pod<uint16_t>(d.init_any);
+    w.vec(d.trans); w.vec(d.act); w.vec(d.accept); w.vec(d.acc_act); w.vec(d.pool);
+  }
   w.pod<uint64_t>(Fnv1a(w.b.data(), w.b.size()));
   return w.b;
 }
@@ -1181,7 +1190,34 @@ bool DeserializeTables(const uint8_t* p, size_t n, Tables* t) {
   r.pod(i32); t->w_nstates = i32; r.pod(t->w_start); r.vec(t->w_trans); r.pod(u8); t->needs_valid_utf8 = u8;
   for (int v = 0; v < 2; v++) { r.vec(t->rm_trans[v]); r.vec(t->rm_depth[v]); r.raw(t->rm_start[v], sizeof t->rm_start[v]); }
   r.pod(u8); t->ref_memo = u8; r.pod(u8); t->ref_has_fail = u8; r.pod(i32); t->ref_prefix = i32;
-  if (!r.ok) return false;
+  {
+    RefTdfa& d = t->tdfa;
+    r.pod(i32); d.nstates = i32; r.pod(i32); d.ntags = i32; r.pod(i32); d.start_begin = i32; r.pod(i32); d.start_any = i32;
+    r.pod(d.init_begin); r.pod(d.init_any);
+    r.vec(d.trans); r.vec(d.act); r.vec(d.accept); r.vec(d.acc_act); r.vec(d.pool);
+    if (!r.ok) return false;
+    if (d.nstates < 0 || d.nstates > 500 || d.nstates != t->ref_tdfa_states) return false;
+    if (d.nstates) {
+      const size_t S = (size_t)d.nstates;
+      if (d.ntags < 2 || d.ntags > 64 || d.start_begin < 0 || d.start_begin >= d.nstates || d.start_any < 0 || d.start_any >= d.nstates) return false;
+      if (d.trans.size() != S * 128 || d.act.size() != S * 128 || d.accept.size() != S || d.acc_act.size() != S || d.pool.empty()) return false;
+      for (int16_t e : d.trans) if (e < -1 || e >= d.nstates) return false;
+      auto list_ok = [&](uint16_t at) {          // [count, (tag, offset) x count] inside the pool, tags inside the tag file
+        if (at >= d.pool.size()) return false;
+        const int n = d.pool[at];
+        if (n < 0 || (size_t)at + 1 + 2 * (size_t)n > d.pool.size()) return false;
+        for (int a = 0; a < n; a++) if (d.pool[at + 1 + 2 * a] < 0 || d.pool[at + 1 + 2 * a] >= d.ntags || d.pool[at + 2 + 2 * a] < 0) return false;
+        return true;
+      };
+      if (d.pool[0] != 0) return false;
+      for (uint16_t a : d.act) if (!list_ok(a)) return false;
+      for (uint16_t a : d.acc_act) if (!list_ok(a)) return false;
+      if (!list_ok(d.init_begin) || !list_ok(d.init_any)) return false;
+      for (uint8_t a : d.accept) if (a > 3) return false;
+    } else if (!d.trans.empty() || !d.act.empty() || !d.accept.empty() || !d.acc_act.empty()) {
+      return false;
+    }
+  }
   for (int v = 0; v < 2; v++) {
     const size_t ns = t->rm_depth[v].size();
     if (t->rm_trans[v].size() != ns * (size_t)(t->ncls + 1)) return false;

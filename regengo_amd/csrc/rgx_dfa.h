@@ -28,6 +28,24 @@ struct TooLarge {
   std::string msg;
 };
 
+// The reference's Tagged DFA (tdfa.go:111-290 construction, 584-794 emitted tables) for programs it emits that engine for
+// (rgx_info.ref_find_engine == 1), state numbering and action order as the reference's own -- tests/golden/tdfa_tables.json holds
+// the literal tables of three checked-in matchers.  The emitted arrays `transitions[S][128]int`, `tagActionCount/Tags/Offsets
+// [S][128][A]int`, `acceptStates/acceptStatesEOT [S]bool`, `acceptAction{Count,Tags,Offsets}[S][A]int` are kept in one compact form:
+// a list of (tag, offset) actions lives in `pool` as [count, tag0, off0, tag1, off1, ...]; index 0 is the empty list.
+struct RefTdfa {
+  int nstates = 0;                 // 0: the reference does not emit a Tagged DFA for this program
+  int ntags = 0;                   // getTagCount(): 2 * max(len(captureNames), 1)
+  int start_begin = 0;             // state for an attempt at offset 0 of the text (^ holds)
+  int start_any = 0;               // ... anywhere else
+  std::vector<int16_t> trans;      // [S][128], -1: no transition (a byte >= 128 ends the attempt: tdfa.go:950-952)
+  std::vector<uint16_t> act;       // [S][128] -> pool: tag actions of the edge, applied BEFORE the state changes (tags[t] = i + 1 - off)
+  std::vector<uint8_t> accept;     // [S] bit 0: acceptStates, bit 1: acceptStatesEOT
+  std::vector<uint16_t> acc_act;   // [S] -> pool: acceptActions of the state
+  uint16_t init_begin = 0, init_any = 0;   // -> pool: initialTagsBegin / initialTagsAny (offsets unused: tags[t] = start)
+  std::vector<int16_t> pool;
+};
+
 struct Tables {
   // ---- identity / analysis (rgx_info)
   std::string pattern;
@@ -44,6 +62,7 @@ struct Tables {
   int fixed_len = -1;             // byte length of every match when it is a constant, else -1
   int ref_match_engine = 0, ref_find_engine = 0;   // rgx.h: rgx_info
   int ref_tdfa_states = 0;        // states of the reference's Tagged DFA when it would emit one (rgx_ref_engine.cc)
+  RefTdfa tdfa;                   // ... and the automaton itself (nstates == ref_tdfa_states), walked by rgx_tdfa.hip
   std::vector<std::string> cap_names;
 
   // ---- automaton
@@ -177,6 +196,8 @@ StartSearch BuildStartSearch(const std::string& pattern, uint32_t flags, int max
 // States of the Tagged DFA the reference would build for this program (tdfa.go:111-290), or -1 when it would not emit one
 // (an empty-width op other than ^/$ of the text, or more than max_states states): rgx_ref_engine.cc.
 int RefTdfaStates(const Prog& prog, int max_states = 500);
+// The whole automaton; false (out->nstates == 0) under the same conditions.  ncap_names = len(captureNames) = groups + 1.
+bool BuildRefTdfa(const Prog& prog, int ncap_names, RefTdfa* out, int max_states = 500);
 
 // One-pass (RE2's term): on every edge exactly one thread of the source state consumes the byte, i.e. every thread of the next
 // state has the same parent -- the capture groups of a match then come out of ONE forward walk (rgx_kernels.hip:

@@ -139,6 +139,34 @@ hipError_t LaunchUtf8ScreenBatch(const uint8_t* src, const uint64_t* offsets, in
 hipError_t LaunchReaderCheck(const DevTables& T, const uint8_t* raw, const uint8_t* view, int32_t len, const int32_t* spans, int64_t n,
                              int ncap, unsigned* flag, hipStream_t stream);
 
+// The Q4 half of LaunchReaderCheck alone (bytes.Index finds the match text earlier in the gap): any ordered span table.
+hipError_t LaunchReaderIndex(const uint8_t* raw, int32_t len, const int32_t* spans, int64_t n, int ncap, unsigned* flag, hipStream_t stream);
+
+// ---- the reference's Tagged DFA (rgx_tdfa.hip; rgx_program.h: TdfaDev).  ends[len + 1]: end of the attempt at every start offset
+// from startStateAny (-1: none); flags: one uint32, bit 31 = a lane ran out of its step budget, bit 0 = look-back timeout.
+constexpr unsigned kTdfaOverBudget = 0x80000000u;       // == kOverBudgetBit (rgx_device_util.h, device side)
+hipError_t LaunchTdfaEnds(const TdfaDev& D, const uint8_t* buf, int32_t len, int32_t* ends, uint32_t* flags, hipStream_t stream);
+// FindReader's chain over one buffer, serially (any program; max_n = 1: FindBytes): se[2i] = start (bit 31: attempt from
+// startStateBegin), se[2i + 1] = end; *out_n = matches
+hipError_t LaunchTdfaChainSerial(const TdfaDev& D, const uint8_t* buf, int32_t len, const int32_t* ends, int32_t* se, int64_t max_n,
+                                 long long* out_n, uint32_t* flags, hipStream_t stream);
+// ... and in parallel (programs with start_begin == start_any that cannot match empty): sync bits (TdfaSlices(len) words, desc =
+// TdfaSyncTiles(len) zeroed words), then LaunchTdfaChain twice: emit = 0 fills counts[TdfaSlices(len)], emit = 1 writes se behind
+// offs = the exclusive sum of the counts
+int64_t TdfaSyncTiles(int32_t len);
+int64_t TdfaSlices(int32_t len);
+hipError_t LaunchTdfaSync(const int32_t* ends, int32_t len, unsigned long long* sync, unsigned long long* desc, uint32_t* flags,
+                          hipStream_t stream);
+size_t TdfaScanTempBytes(int64_t n);
+hipError_t LaunchTdfaScan(const int32_t* counts, int32_t* offs, int64_t n, void* temp, size_t temp_bytes, hipStream_t stream);
+hipError_t LaunchTdfaChain(const int32_t* ends, int32_t len, const unsigned long long* sync, int32_t* counts, const int32_t* offs,
+                           int32_t* se, int64_t max_n, int emit, uint32_t* flags, hipStream_t stream);
+// rows[n][ntags]: the reported tags of every match of se (tdfa.go:998-1052: (-1, -1) = group left untouched)
+hipError_t LaunchTdfaTags(const TdfaDev& D, const uint8_t* buf, int32_t len, const int32_t* se, int64_t n, int32_t* rows, hipStream_t stream);
+// FindBytes per string of a batch: found[nstr], rows[nstr][ntags]
+hipError_t LaunchTdfaBatch(const TdfaDev& D, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found, int32_t* rows,
+                           uint32_t* flags, hipStream_t stream);
+
 // One pass over a batch for many programs (rgx_kernels.hip: batch_multi_kernel).  d_dir: device array of MultiEnt (the host packs it:
 // rgx_capi.cc, rgx_multi_create) followed by first[256][2] u64 (bit p of first[b]: program p survives a first byte b), all of it
 // dir_bytes long and copied to LDS offset 0; first_off = where first[] begins; lds_tables_end = end of the last table's LDS range.  found_bits [nprog][words_per_prog] (bit i%64 of word i/64), counts [nprog] (added to), se [nprog][nstr][2] or nullptr.

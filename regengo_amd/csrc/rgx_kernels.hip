@@ -2391,6 +2391,13 @@ hipError_t LaunchReaderCheck(const DevTables& T, const uint8_t* raw, const uint8
   return hipGetLastError();
 }
 
+hipError_t LaunchReaderIndex(const uint8_t* raw, int32_t len, const int32_t* spans, int64_t n, int ncap, unsigned* flag, hipStream_t stream) {
+  if (n <= 0 || len <= 0) return hipSuccess;
+  const long long pieces = ((long long)len + kIdxPiece - 1) / kIdxPiece;
+  hipLaunchKernelGGL(reader_index_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, stream, raw, len, spans, (long long)n, ncap, flag);
+  return hipGetLastError();
+}
+
 namespace {
 // streaming.go:204-207 on an ordered span table: the first match whose end lies beyond `limit` stops the chunk's loop.  Match ends
 // increase with the row index, so the commit point is a binary search: out[0] = rows committed, out[1] = end of the last one.

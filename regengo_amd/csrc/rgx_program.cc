@@ -12,8 +12,9 @@ void SetError(const std::string& s) { g_error = s; }
 const std::string& GetError() { return g_error; }
 
 Program::~Program() {
-  if (d_arena || d_arena_u || d_arena_us) {
+  if (d_arena || d_arena_u || d_arena_us || d_arena_tdfa) {
     hipSetDevice(device);
+    if (d_arena_tdfa) hipFree(d_arena_tdfa);
     if (d_arena) hipFree(d_arena);
     if (d_arena_u) hipFree(d_arena_u);
     if (d_arena_us) hipFree(d_arena_us);
@@ -351,6 +352,39 @@ int UploadUs(Program* p) {
 }
 }  // namespace
 
+namespace {
+// The reference's Tagged DFA (rgx_dfa.h: RefTdfa) packed for rgx_tdfa.hip: one 32-bit entry per (state, byte).
+int UploadTdfa(Program* p) {
+  const RefTdfa& r = p->t.tdfa;
+  const int S = r.nstates;
+  std::vector<uint32_t> ent((size_t)S * 128), sinfo(S);
+  for (int q = 0; q < S; q++) {
+    sinfo[q] = (uint32_t)r.accept[q] | ((uint32_t)r.acc_act[q] << 16);
+    for (int c = 0; c < 128; c++) {
+      const int nq = r.trans[(size_t)q * 128 + c];
+      uint32_t e = (uint32_t)r.act[(size_t)q * 128 + c] << 16;
+      if (nq < 0) e |= 1u << 10;
+      else e |= (uint32_t)nq | ((r.accept[nq] & 1u) ? 1u << 11 : 0u) | ((r.accept[nq] & 2u) ? 1u << 12 : 0u);
+      ent[(size_t)q * 128 + c] = e;
+    }
+  }
+  Arena a;
+  const size_t off_ent = a.AddVec(ent), off_si = a.AddVec(sinfo), off_pool = a.AddVec(r.pool);
+  void* dptr = nullptr;
+  if (hipMalloc(&dptr, a.host.size()) != hipSuccess) { SetError("hipMalloc(tdfa tables) failed"); return RGX_E_NOMEM; }
+  if (hipMemcpy(dptr, a.host.data(), a.host.size(), hipMemcpyHostToDevice) != hipSuccess) { hipFree(dptr); SetError("hipMemcpy(tdfa tables) failed"); return RGX_E_HIP; }
+  uint8_t* b = (uint8_t*)dptr;
+  TdfaDev d{};
+  d.ent = (const uint32_t*)(b + off_ent); d.sinfo = (const uint32_t*)(b + off_si); d.pool = (const int16_t*)(b + off_pool);
+  d.nstates = S; d.ntags = r.ntags; d.start_begin = r.start_begin; d.start_any = r.start_any;
+  d.init_begin = r.init_begin; d.init_any = r.init_any;
+  d.sinfo_begin = sinfo[r.start_begin]; d.sinfo_any = sinfo[r.start_any];
+  p->tdfadev = d;
+  p->d_arena_tdfa = dptr;
+  return RGX_OK;
+}
+}  // namespace
+
 int ProgramToDevice(Program* p, int device) {
   std::lock_guard<std::mutex> lock(p->mu);
   if (p->d_arena) {
@@ -376,6 +410,9 @@ int ProgramToDevice(Program* p, int device) {
   p->us_ok = BuildUs(p);
   if (p->us_ok && UploadUs(p) != RGX_OK) p->us_ok = false;
   p->dev.us = p->us_ok ? &p->usdev : nullptr;
+  // the reference's own Tagged DFA, when it emits one and the tag file is the record (ntags == ncap: always)
+  p->dev.tdfa = nullptr;
+  if (p->t.tdfa.nstates > 0 && p->t.tdfa.nstates <= 1000 && p->t.tdfa.ntags == p->t.ncap && UploadTdfa(p) == RGX_OK) p->dev.tdfa = &p->tdfadev;
   return RGX_OK;
 }
 

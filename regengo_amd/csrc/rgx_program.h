@@ -37,6 +37,7 @@ enum TableMode : int {
 };
 
 struct UsDev;
+struct TdfaDev;
 
 // Flat device image of one compiled pattern.  All pointers are device addresses.
 struct DevTables {
@@ -81,6 +82,7 @@ struct DevTables {
   int32_t ref_prefix;             // MatchBytes' required first byte, -1: none
   int32_t ref_find_ok;            // 1: FindBytesReuse in reference mode is offered (plain backtracking engine, no memo)
   int32_t ref_match_kind;         // 0: restart rule over rm_*[1]; 1: the Thompson matcher (plain existence); 2: not offered
+  const TdfaDev* tdfa;            // HOST pointer to the reference's Tagged DFA on the device (rgx_tdfa.hip) when the reference emits one, else nullptr
   const UsDev* us;                // HOST pointer to the program's UsDev when the pattern is eligible for rgx_scan_us.hip, else nullptr
   uint16_t start[4];
   uint8_t start_accept[4];
@@ -131,6 +133,21 @@ struct UsDev {
   int32_t has_rewind;             // the pair table's rewind row (row 1) can be entered: the kernel instance that handles rewinds in its fast walk
 };
 
+// Device image of the reference's Tagged DFA (rgx_dfa.h: RefTdfa; tdfa.go:584-794 emits the same content as Go array literals).
+//   ent[state * 128 + byte]  [0..9] next state  [10] no transition  [11] the next state is in acceptStates  [12] in acceptStatesEOT
+//                            [16..31] the edge's tag actions: index into pool
+//   sinfo[state]             [0] acceptStates  [1] acceptStatesEOT  [16..31] the state's acceptActions: index into pool
+//   pool                     action lists [count, tag0, offset0, tag1, offset1, ...]; index 0 = the empty list
+struct TdfaDev {
+  const uint32_t* ent;
+  const uint32_t* sinfo;
+  const int16_t* pool;
+  int32_t nstates, ntags;
+  int32_t start_begin, start_any;      // startStateBegin / startStateAny
+  int32_t init_begin, init_any;        // initialTagsBegin / initialTagsAny (pool indices)
+  uint32_t sinfo_begin, sinfo_any;     // sinfo of the two start states
+};
+
 struct Program {
   Tables t;
   // start-tracking search automaton for the one-step-per-byte scan kernel; built at upload; us_ok false: not eligible
@@ -138,6 +155,8 @@ struct Program {
   bool us_ok = false;
   UsDev usdev{};
   void* d_arena_us = nullptr;
+  TdfaDev tdfadev{};
+  void* d_arena_tdfa = nullptr;
   std::vector<uint8_t> blob_cache;
   // search automaton (BuildOptions::unanchored_search) for the per-string entry points; built lazily, absent when the
   // pattern is anchored or the automaton exceeds its state budget

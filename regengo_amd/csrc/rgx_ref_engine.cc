@@ -3,13 +3,15 @@
 // compiler.go:137-153: a pattern with captures and nested quantifiers first tries the Tagged DFA; it is taken when
 // (a) every empty-width instruction is ^ or $ of the text (tdfa.go:83-94) and (b) the subset construction over
 // priority-ordered NFA sets WITH their pending tag actions stays under 500 states (tdfa.go:111-290, threshold
-// tdfa.go:62-66).  Otherwise the memoising backtracker ("TNFA", compiler.go:415-426) is emitted.  The library never
-// runs the TDFA -- its FindAllBytes advances by the match length (compiler.go:646-651) and is refused, DESIGN.md Q11 --
-// but it has to KNOW which of the two the reference emits, because that decides which entry points are offered in
-// reference mode.  Only the state COUNT matters here, yet two NFA sets are the same DFA state only if their pending
-// actions agree as well (tdfa.go:514-539), so the construction below carries the actions exactly as the reference does:
-// compaction on pop (last action per tag, sorted by tag), offsets bumped per consumed byte, the longest common prefix of
-// the closure's action lists hoisted onto the edge.
+// tdfa.go:62-66).  Otherwise the memoising backtracker ("TNFA", compiler.go:415-426) is emitted.  The library has to KNOW
+// which of the two the reference emits (that decides what reference mode means for the program) and, for the Tagged DFA, it
+// RUNS the reference's own automaton on the device (rgx_tdfa.hip: FindBytes / FindBytesReuse / FindReader; only the
+// FindAllBytes wrapper, which advances by the match length and reports matches again, compiler.go:646-651, stays refused:
+// DESIGN.md Q11).  Two NFA sets are the same DFA state only if their pending actions agree as well (tdfa.go:514-539), so the
+// construction below carries the actions exactly as the reference does: compaction on pop (last action per tag, sorted by
+// tag), offsets bumped per consumed byte, the longest common prefix of the closure's action lists hoisted onto the edge --
+// and numbers the states in the reference's order (worklist, bytes ascending), so that the tables equal the emitted ones
+// literally (tests/golden/tdfa_tables.json).
 #include <algorithm>
 #include <map>
 #include <string>
@@ -113,7 +115,9 @@ struct Probe {
     }
   }
 
-  std::vector<Thread> Step(const std::vector<Thread>& set, int c) const {     // tdfa.go:338-406
+  // tdfa.go:338-406: the threads that consume c, their closure, and the hoisted common prefix of the closure's action lists
+  std::vector<Thread> Step(const std::vector<Thread>& set, int c, std::vector<Action>* hoisted) const {
+    hoisted->clear();
     std::vector<Thread> next;
     for (const Thread& t : set) {
       const Inst& in = p.inst[t.id];
@@ -131,27 +135,43 @@ struct Probe {
       while (k < common && k < res[i].acts.size() && res[0].acts[k] == res[i].acts[k]) k++;
       common = k;
     }
-    if (common) for (Thread& t : res) t.acts.erase(t.acts.begin(), t.acts.begin() + common);
+    if (common) {
+      hoisted->assign(res[0].acts.begin(), res[0].acts.begin() + common);
+      for (Thread& t : res) t.acts.erase(t.acts.begin(), t.acts.begin() + common);
+    }
     return res;
   }
 };
 
+bool Supported(const Prog& prog) {     // tdfa.go:83-94
+  for (const Inst& in : prog.inst)
+    if (in.op == InstEmptyWidth && in.arg != EmptyBeginText && in.arg != EmptyEndText) return false;
+  return true;
+}
+
 }  // namespace
 
-int RefTdfaStates(const Prog& prog, int max_states) {
-  for (const Inst& in : prog.inst)
-    if (in.op == InstEmptyWidth && in.arg != EmptyBeginText && in.arg != EmptyEndText) return -1;
+bool BuildRefTdfa(const Prog& prog, int ncap_names, RefTdfa* out, int max_states) {
+  *out = RefTdfa();
+  if (!Supported(prog)) return false;
   Probe pr(prog);
   std::vector<std::vector<Thread>> states;
   std::map<std::string, int> ids;
+  struct Edge { int from, c, to; std::vector<Action> acts; };
+  std::vector<Edge> edges;
   const std::vector<Thread> start{{prog.start, {}}};
   states.push_back(pr.Closure(start, EmptyBeginText));
   ids[Probe::Key(states[0])] = 0;
   std::vector<int> work{0};
+  std::vector<Action> init_begin = states[0].empty() ? std::vector<Action>() : states[0][0].acts, init_any;
+  int start_any = 0;
   {
     std::vector<Thread> any = pr.Closure(start, 0);
+    if (!any.empty()) init_any = any[0].acts;
     const std::string k = Probe::Key(any);
-    if (!ids.count(k)) { ids[k] = 1; states.push_back(std::move(any)); work.push_back(1); }
+    auto it = ids.find(k);
+    if (it != ids.end()) start_any = it->second;
+    else { start_any = 1; ids[k] = 1; states.push_back(std::move(any)); work.push_back(1); }
   }
   for (size_t w = 0; w < work.size(); w++) {      // every state enters the list once (tdfa.go:185-252)
     const int si = work[w];
@@ -159,18 +179,83 @@ int RefTdfaStates(const Prog& prog, int max_states) {
     pr.PossibleChars(states[si], chars);
     for (int c = 0; c < 128; c++) {
       if (!chars[c]) continue;
-      std::vector<Thread> nn = pr.Step(states[si], c);
+      std::vector<Action> hoisted;
+      std::vector<Thread> nn = pr.Step(states[si], c, &hoisted);
       if (nn.empty()) continue;
       const std::string k = Probe::Key(nn);
-      if (ids.count(k)) continue;
-      const int ni = (int)states.size();
-      if (ni >= max_states) return -1;              // "TDFA state explosion"
-      ids[k] = ni;
-      states.push_back(std::move(nn));
-      work.push_back(ni);
+      int ni;
+      auto it = ids.find(k);
+      if (it != ids.end()) ni = it->second;
+      else {
+        ni = (int)states.size();
+        if (ni >= max_states) return false;           // "TDFA state explosion"
+        ids[k] = ni;
+        states.push_back(std::move(nn));
+        work.push_back(ni);
+      }
+      edges.push_back({si, c, ni, std::move(hoisted)});
     }
   }
-  return (int)states.size() > max_states ? -1 : (int)states.size();
+  const int S = (int)states.size();
+  if (S > max_states) return false;
+  RefTdfa& t = *out;
+  t.nstates = S;
+  t.ntags = 2 * std::max(ncap_names, 1);
+  t.start_begin = 0;
+  t.start_any = start_any;
+  t.trans.assign((size_t)S * 128, -1);
+  t.act.assign((size_t)S * 128, 0);
+  t.accept.assign(S, 0);
+  t.acc_act.assign(S, 0);
+  t.pool.assign(1, 0);                                // index 0: the empty list
+  std::map<std::vector<Action>, uint16_t> lists;
+  auto intern = [&](const std::vector<Action>& a) -> uint16_t {
+    if (a.empty()) return 0;
+    auto it = lists.find(a);
+    if (it != lists.end()) return it->second;
+    const uint16_t at = (uint16_t)t.pool.size();
+    t.pool.push_back((int16_t)a.size());
+    for (const Action& x : a) { t.pool.push_back((int16_t)x.first); t.pool.push_back((int16_t)x.second); }
+    lists[a] = at;
+    return at;
+  };
+  bool overflow = false;
+  for (const Edge& e : edges) {
+    for (const Action& x : e.acts) if (x.second > 32000 || x.first >= t.ntags) overflow = true;
+    t.trans[(size_t)e.from * 128 + e.c] = (int16_t)e.to;
+    t.act[(size_t)e.from * 128 + e.c] = intern(e.acts);
+  }
+  auto is_match = [&](int id) { return prog.inst[id].op == InstMatch; };
+  for (int i = 0; i < S; i++) {
+    for (const Thread& th : states[i]) if (is_match(th.id)) { t.accept[i] |= 1; break; }
+    // acceptance at the end of the text (tdfa.go:254-276): the first Match of the closure under $ and ITS pending actions
+    for (Thread& th : pr.Closure(states[i], EmptyEndText)) {
+      if (!is_match(th.id)) continue;
+      t.accept[i] |= 2;
+      Compact(&th.acts);
+      t.acc_act[i] = intern(th.acts);
+      break;
+    }
+  }
+  for (int i = 0; i < S; i++) {                       // tdfa.go:278-288: accepting states that got no actions above
+    if (!(t.accept[i] & 1) || t.acc_act[i]) continue;
+    for (const Thread& th : states[i]) {
+      if (!is_match(th.id)) continue;
+      std::vector<Action> a = th.acts;
+      Compact(&a);
+      t.acc_act[i] = intern(a);
+      break;
+    }
+  }
+  t.init_begin = intern(init_begin);
+  t.init_any = intern(init_any);
+  if (overflow || t.pool.size() > 60000) { *out = RefTdfa(); return false; }   // (never seen: offsets grow only while states multiply)
+  return true;
+}
+
+int RefTdfaStates(const Prog& prog, int max_states) {
+  RefTdfa t;
+  return BuildRefTdfa(prog, 1, &t, max_states) ? t.nstates : -1;
 }
 
 }  // namespace rgx

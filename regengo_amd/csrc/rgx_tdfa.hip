@@ -1,0 +1,463 @@
+// The reference's Tagged DFA on the device: FindBytes / FindBytesReuse / FindReader for programs the reference emits with that
+// engine (rgx_info.ref_find_engine == 1).
+//
+// What is reproduced (internal/compiler/tdfa.go):
+//   831-994   the table-driven find loop: for start = 0 .. len: reset the tags, tags[0] = start, choose the start state (offset 0 of
+//             the text: startStateBegin, else startStateAny), walk -- a byte >= 128 or a missing transition ends the attempt, the edge's
+//             tag actions are applied before the state changes, every accepting state (or an EOT-accepting one on the last byte)
+//             applies its accept actions and snapshots the tags: the LAST accept of the FIRST start that has one wins
+//             (longest-on-path, not leftmost-first: SURVEY 5.9 Q6);
+//   998-1052  result construction: tags[1] = match end; a group whose start tag is set and whose end tag is not is closed at the
+//             match end; a group whose start tag is unset is LEFT UNTOUCHED in the reused result -- reported as (-1, -1), the
+//             caller (the emitted stub, tests/cabi_stub.c, regengo_amd/api.py) keeps the field's previous value;
+//   streaming.go:175-244   FindReader's loop over one chunk: FindBytesReuse on chunk[searchPos:] again and again, each re-slice
+//             making searchPos the beginning of a text (startStateBegin) and the chunk's end the end of the text (EOT accepts).
+// The prefix skip of tdfa.go:908-935 (bytes.IndexByte to the required first byte) changes no result -- an attempt at any other
+// byte dies on it -- and is not modelled.  What is NOT reproduced: the FindAllBytes wrapper (compiler.go:602-655, advances by the
+// match LENGTH and reports matches again, Q11): refused by rgx_capi.cc.
+//
+// How it is computed.  The walk of one attempt is a per-byte table walk with data-dependent length; the loop over start offsets is
+// what is parallel:
+//   tdfa_ends_kernel      one lane per start offset p of the buffer: the end of the attempt at p from startStateAny (-1: none).  Most
+//                         lanes die on their first byte.  Tables in LDS (one 32-bit entry per (state, byte): next state, the next
+//                         state's accept bits, the edge's action list), bytes through L1/L2 (neighbouring lanes read neighbouring
+//                         bytes).
+//   chain                 FindReader's sequence "first start >= searchPos with an accept; searchPos = its end" over those ends.
+//                         Programs whose two start states are one (no ^: the 9 unanchored TDFA patterns of the corpus) resolve it in
+//                         parallel: x is a SYNC POINT when no attempt that starts before x ends behind x (a running maximum of the
+//                         ends, tdfa_sync_kernel: decoupled look-back over 16 K-offset tiles); the loop provably stands at every sync
+//                         point, so a lane per 64 offsets walks the chain from its slice's first sync point to the next lane's
+//                         (tdfa_chain_kernel, twice: count, then emit behind the exclusive prefix).  Programs with ^ need
+//                         the attempt from startStateBegin at every chain position, which only the chain itself knows: one wave walks
+//                         it serially (tdfa_chain_serial_kernel; an anchored pattern has one attempt per match).
+//   tdfa_tags_kernel      one lane per match: the attempt again with the tag file in LDS, the result construction, the record.
+//   tdfa_batch_kernel     FindBytes per string of a batch (CSR): the loop over starts, the walk and the tags in one lane.
+// Every lane counts its steps against kLaneStepBudget (an attempt per start offset is quadratic on `(\d+\.)+x` over a run of
+// digits and dots, in the reference too); past it the lane stops and raises a flag, and the call is refused.
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+
+#include <cstdint>
+
+#include "rgx_device_util.h"
+#include "rgx_kernels.h"
+
+namespace rgx {
+namespace {
+
+#define TDFA_LDS __attribute__((address_space(3)))
+
+constexpr uint32_t kTNext = 0x3FFu;       // next state (at most 500 states)
+constexpr uint32_t kTDead = 1u << 10;     // no transition: the attempt ends
+constexpr uint32_t kTAcc = 1u << 11;      // the next state accepts (acceptStates)
+constexpr uint32_t kTAccEot = 1u << 12;   // the next state accepts at the end of the text (acceptStatesEOT)
+
+template <bool LDS> struct Tab;
+template <> struct Tab<true> { typedef const uint32_t TDFA_LDS* P; };
+template <> struct Tab<false> { typedef const uint32_t* P; };
+
+// One attempt without tags (tdfa.go:939-987 minus the tag traffic): the end of its last accept, or -1.
+template <class EntP>
+__device__ __forceinline__ int AttemptEnd(EntP ent, const uint8_t* buf, int len, int start, int st, uint32_t st_flags, int* steps) {
+  int end = -1;
+  if (st_flags & 1u) end = start;
+  if (start == len && (st_flags & 2u)) end = start;
+  uint32_t row = (uint32_t)st * 128u;
+  int i = start;
+  for (; i < len; ++i) {
+    const uint32_t c = buf[i];
+    if (c >= 128u) break;
+    const uint32_t e = ent[row + c];
+    if (e & kTDead) break;
+    row = (e & kTNext) * 128u;
+    if ((e & kTAcc) || ((e & kTAccEot) && i == len - 1)) end = i + 1;
+  }
+  *steps += i - start + 1;
+  return end;
+}
+
+// The same with the tag file (LDS, one column per lane: tag t of lane l at tags[t * 256 + l]) and the result construction.
+// Returns the end (>= 0: out[0 .. ntags) holds the reported tags) or -1.  Only called for attempts known to accept -- the walk
+// stops at `stop` = the end found by AttemptEnd (the snapshot of the last accept is the tag file right there).
+template <class EntP>
+__device__ __forceinline__ void AttemptTags(EntP ent, const int16_t* pool, const uint8_t* buf, int len, int start, int stop, int st,
+                                            int init_list, int ntags, int TDFA_LDS* tags, int32_t* out, const uint32_t* sinfo) {
+  for (int t = 0; t < ntags; ++t) tags[t * 256] = -1;
+  tags[0] = start;
+  for (int a = 0, n = pool[init_list]; a < n; ++a) tags[pool[init_list + 1 + 2 * a] * 256] = start;
+  uint32_t row = (uint32_t)st * 128u;
+  for (int i = start; i < stop; ++i) {
+    const uint32_t c = buf[i];
+    const uint32_t e = ent[row + c];
+    const int al = (int)(e >> 16);
+    if (al) for (int a = 0, n = pool[al]; a < n; ++a) tags[pool[al + 1 + 2 * a] * 256] = i + 1 - pool[al + 2 + 2 * a];
+    const uint32_t ns = e & kTNext;
+    row = ns * 128u;
+    if ((e & kTAcc) || ((e & kTAccEot) && i == len - 1)) {
+      // acceptActions of the state, applied to the live tags at every accept (tdfa.go:960-983), not only at the last one
+      const int aa = (int)(sinfo[ns] >> 16);
+      if (aa) for (int a = 0, n = pool[aa]; a < n; ++a) tags[pool[aa + 1 + 2 * a] * 256] = i + 1 - pool[aa + 2 + 2 * a];
+    }
+  }
+  // result construction (tdfa.go:998-1052)
+  out[0] = tags[0];
+  out[1] = stop;
+  for (int g = 1; g < ntags / 2; ++g) {
+    const int a = tags[(2 * g) * 256];
+    int b = tags[(2 * g + 1) * 256];
+    if (a >= 0) { if (b < 0) b = stop; }
+    else b = -1;
+    out[2 * g] = a;
+    out[2 * g + 1] = b;
+  }
+}
+
+template <bool LDS>
+__device__ __forceinline__ typename Tab<LDS>::P StageEnt(const TdfaDev& D, uint32_t* smem) {
+  if (LDS) {
+    const int n = D.nstates * 128;
+    for (int k = threadIdx.x; k < n; k += blockDim.x) smem[k] = D.ent[k];
+    __syncthreads();
+    return (typename Tab<LDS>::P)smem;
+  }
+  return (typename Tab<LDS>::P)D.ent;
+}
+
+// ---------------------------------------------------------------- ends: one lane per start offset
+template <bool LDS>
+__global__ __launch_bounds__(256) void tdfa_ends_kernel(TdfaDev D, const uint8_t* buf, int32_t len, int32_t* ends, uint32_t* flags) {
+  extern __shared__ uint32_t smem[];
+  typename Tab<LDS>::P ent = StageEnt<LDS>(D, smem);
+  const uint32_t fl = D.sinfo_any;
+  const int st = D.start_any;
+  const long long nth = (long long)gridDim.x * 256;
+  for (long long p = (long long)blockIdx.x * 256 + threadIdx.x; p <= len; p += nth) {
+    int steps = 0;
+    int e = -1;
+    // (first byte by hand: nearly every lane ends here)
+    if (p < len) {
+      const uint32_t c = buf[p];
+      if ((fl & 3u) || (c < 128u && !(ent[(uint32_t)st * 128u + c] & kTDead))) e = AttemptEnd(ent, buf, len, (int)p, st, fl, &steps);
+    } else if (fl & 3u) {
+      e = AttemptEnd(ent, buf, len, (int)p, st, fl, &steps);
+    }
+    if (steps > kLaneStepBudget) atomicOr(flags, kOverBudgetBit);
+    ends[p] = e;
+  }
+}
+
+// ---------------------------------------------------------------- the chain, serially (one wave): programs whose start state at the
+// beginning of a text differs from the one elsewhere (^), short buffers, and FindBytes (max_n = 1).
+// se[2 * i], se[2 * i + 1] = start, end of match i; se_begin bit: was the attempt made from startStateBegin.  *out_n = matches.
+template <bool LDS>
+__global__ __launch_bounds__(64) void tdfa_chain_serial_kernel(TdfaDev D, const uint8_t* buf, int32_t len, const int32_t* ends,
+                                                               int32_t* se, long long max_n, long long* out_n, uint32_t* flags) {
+  extern __shared__ uint32_t smem[];
+  typename Tab<LDS>::P ent = StageEnt<LDS>(D, smem);
+  const int lane = threadIdx.x;
+  const bool differs = D.start_begin != D.start_any;
+  long long n = 0;
+  int cur = 0;
+  int steps = 0;
+  while (cur < len && n < max_n) {            // `for searchPos < len(chunk)` (streaming.go:176)
+    int s = -1, e = -1, begin = 0;
+    // the attempt AT searchPos sees the beginning of a text
+    int e0 = -1;
+    if (lane == 0) e0 = differs ? AttemptEnd(ent, buf, len, cur, D.start_begin, D.sinfo_begin, &steps) : ends[cur];
+    e0 = __shfl(e0, 0, 64);
+    if (e0 >= 0) { s = cur; e = e0; begin = differs ? 1 : 0; }
+    else {
+      for (long long p0 = (long long)cur + 1; p0 <= len; p0 += 64) {
+        const long long p = p0 + lane;
+        const int v = p <= len ? ends[p] : -1;
+        const unsigned long long m = __ballot(v >= 0);
+        if (m) {
+          const int f = __builtin_ctzll(m);
+          s = (int)(p0 + f);
+          e = __shfl(v, f, 64);
+          break;
+        }
+      }
+    }
+    if (__shfl(steps, 0, 64) > kLaneStepBudget) { if (lane == 0) atomicOr(flags, kOverBudgetBit); break; }
+    if (s < 0) break;                          // `if !ok { break }`
+    if (lane == 0) { se[2 * n] = s | (begin ? (int)0x80000000u : 0); se[2 * n + 1] = e; }
+    ++n;
+    cur = e > s ? e : cur + 1;                 // streaming.go:236-243
+  }
+  if (lane == 0) *out_n = n;
+}
+
+// ---------------------------------------------------------------- the chain in parallel (start_begin == start_any)
+// run[x] = max(end[p] : p < x); x is a sync point iff run[x] <= x (no attempt that starts before x reaches past it -- whatever
+// the loop did before, it stands at some searchPos <= x whose next match starts at or behind x, and the search from x finds the
+// same one).  Written as a bit per offset: sync[x / 64] bit x % 64.  Tiles of 16384 offsets, 64 per lane; the running maximum
+// crosses tiles by decoupled look-back (descriptor: 2-bit status | max + 1).
+constexpr int kSyncTile = 16384;
+__global__ __launch_bounds__(256) void tdfa_sync_kernel(const int32_t* ends, int32_t len, unsigned long long* sync,
+                                                        unsigned long long* desc, uint32_t* flags) {
+  __shared__ int wave_max[4];
+  __shared__ int tile_excl;
+  const int tile = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long base = (long long)tile * kSyncTile + (long long)threadIdx.x * 64;
+  // this lane's 64 ends: running maximum inside the slice
+  int lmax = -1;
+  // (two passes over the slice instead of 64 registers: the second re-reads L2-hot lines)
+  for (int k = 0; k < 64; ++k) { const long long p = base + k; if (p <= len) { const int v = ends[p]; lmax = v > lmax ? v : lmax; } }
+  // exclusive running maximum across the lanes of the workgroup
+  int incl = lmax;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) { const int y = __shfl_up(incl, d, 64); if (lane >= d) incl = y > incl ? y : incl; }
+  if (lane == 63) wave_max[wave] = incl;
+  __syncthreads();
+  int excl = __shfl_up(incl, 1, 64);
+  if (lane == 0) excl = -1;
+  for (int w = 0; w < wave; ++w) excl = wave_max[w] > excl ? wave_max[w] : excl;
+  if (wave == 0) {
+    int tmax = wave_max[0];
+    for (int w = 1; w < 4; ++w) tmax = wave_max[w] > tmax ? wave_max[w] : tmax;
+    // look-back with max instead of sum: values are max + 1 (>= 0)
+    unsigned long long own = (unsigned long long)(tmax + 1);
+    unsigned long long ex = 0;
+    if (lane == 0) __hip_atomic_store(&desc[tile], (tile == 0 ? kDescPrefix : kDescAgg) | own, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (tile > 0) {
+      int idx = tile - 1 - lane;
+      bool dead = false;
+      while (true) {
+        unsigned long long d = kDescPrefix;
+        if (idx >= 0) {
+          d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          unsigned spins = 0;
+          while ((d >> 62) == 0) {
+            if (++spins > kLookBackSpinLimit * 20u) { dead = true; break; }
+            __builtin_amdgcn_s_sleep(8);
+            d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          }
+        }
+        if (__any(dead)) { if (lane == 0) atomicOr(flags, 1u); break; }
+        const unsigned long long pm = __ballot((d >> 62) == 2);
+        const int first = pm ? __builtin_ctzll(pm) : 64;
+        unsigned long long v = lane <= first ? (d & kDescValMask) : 0ull;
+#pragma unroll
+        for (int dd = 32; dd >= 1; dd >>= 1) { const unsigned long long y = __shfl_xor(v, dd, 64); v = y > v ? y : v; }
+        ex = v > ex ? v : ex;
+        if (pm) break;
+        idx -= 64;
+      }
+      if (lane == 0) {
+        const unsigned long long inc = own > ex ? own : ex;
+        __hip_atomic_store(&desc[tile], kDescPrefix | inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+    if (lane == 0) tile_excl = (int)ex - 1;
+  }
+  __syncthreads();
+  { const int te = tile_excl; excl = te > excl ? te : excl; }
+  // the bits of this lane's slice
+  unsigned long long bits = 0;
+  int run = excl;
+  for (int k = 0; k < 64; ++k) {
+    const long long p = base + k;
+    if (p > len) break;
+    if (run <= (int)p) bits |= 1ull << k;
+    const int v = ends[p];
+    run = v > run ? v : run;
+  }
+  if (base <= len) sync[base >> 6] = bits;
+}
+
+// Lane l owns the matches that START in [S, T): S = the first sync point of its slice (none: the slice belongs to an earlier lane's
+// stretch), T = the first sync point at or behind the next slice.  emit == 0: counts[l] = matches; emit == 1: writes them behind
+// offs[l] (exclusive sum of the counts).
+__global__ __launch_bounds__(256) void tdfa_chain_kernel(const int32_t* ends, int32_t len, const unsigned long long* sync, int32_t* counts,
+                                                         const int32_t* offs, int32_t* se, long long max_n, int emit, uint32_t* flags) {
+  const long long l = (long long)blockIdx.x * 256 + threadIdx.x;
+  const long long nslices = ((long long)len + 1 + 63) >> 6;     // offsets 0 .. len
+  if (l >= nslices) return;
+  const unsigned long long mine = sync[l];
+  if (!mine) { if (!emit) counts[l] = 0; return; }
+  int cur = (int)(l * 64 + __builtin_ctzll(mine));
+  // T: first sync point in a later slice (len + 1: none -- the stretch runs to the end)
+  long long T = (long long)len + 1;
+  for (long long j = l + 1; j < nslices; ++j) {
+    const unsigned long long w = sync[j];
+    if (w) { T = j * 64 + __builtin_ctzll(w); break; }
+  }
+  long long row = emit ? offs[l] : 0;
+  int cnt = 0, steps = 0;
+  while (cur < len && cur < T) {
+    // first start >= cur with an accept
+    int s = cur;
+    int e = ends[s];
+    while (e < 0) {
+      ++s;
+      if (s >= T || s > len) break;
+      e = ends[s];
+      if (++steps > kLaneStepBudget) break;
+    }
+    if (e < 0 || s >= T) break;
+    if (emit) { if (row < max_n) { se[2 * row] = s; se[2 * row + 1] = e; } ++row; }
+    ++cnt;
+    cur = e > s ? e : cur + 1;
+  }
+  if (steps > kLaneStepBudget) atomicOr(flags, kOverBudgetBit);
+  if (!emit) counts[l] = cnt;
+}
+
+// ---------------------------------------------------------------- tags: one lane per match
+template <bool LDS>
+__global__ __launch_bounds__(256) void tdfa_tags_kernel(TdfaDev D, const uint8_t* buf, int32_t len, const int32_t* se, long long n,
+                                                        int32_t* rows) {
+  extern __shared__ uint32_t smem[];
+  typename Tab<LDS>::P ent = StageEnt<LDS>(D, smem);
+  int TDFA_LDS* tags = (int TDFA_LDS*)(smem + (LDS ? D.nstates * 128 : 0)) + threadIdx.x;
+  const long long nth = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += nth) {
+    const int s0 = se[2 * i], e = se[2 * i + 1];
+    const bool begin = s0 < 0;                       // bit 31: the serial chain's attempt from startStateBegin
+    const int s = s0 & 0x7FFFFFFF;
+    AttemptTags(ent, D.pool, buf, len, s, e, begin ? D.start_begin : D.start_any, begin ? D.init_begin : D.init_any, D.ntags, tags,
+                rows + i * D.ntags, D.sinfo);
+  }
+}
+
+// ---------------------------------------------------------------- FindBytes per string of a batch
+template <bool LDS>
+__global__ __launch_bounds__(256) void tdfa_batch_kernel(TdfaDev D, const uint8_t* concat, const uint64_t* offsets, long long nstr,
+                                                         uint8_t* found, int32_t* rows, uint32_t* flags) {
+  extern __shared__ uint32_t smem[];
+  typename Tab<LDS>::P ent = StageEnt<LDS>(D, smem);
+  int TDFA_LDS* tags = (int TDFA_LDS*)(smem + (LDS ? D.nstates * 128 : 0)) + threadIdx.x;
+  const long long nth = (long long)gridDim.x * 256;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nstr; i += nth) {
+    const uint64_t o0 = offsets[i], o1 = offsets[i + 1];
+    const uint8_t* buf = concat + o0;
+    const int len = (int)(o1 - o0);
+    int steps = 0, s = 0, e = -1;
+    for (; s <= len; ++s) {
+      if (s == 0) e = AttemptEnd(ent, buf, len, 0, D.start_begin, D.sinfo_begin, &steps);
+      else {
+        const uint32_t fl = D.sinfo_any;
+        if (s < len) {
+          const uint32_t c = buf[s];
+          if (!(fl & 3u) && (c >= 128u || (ent[(uint32_t)D.start_any * 128u + c] & kTDead))) { ++steps; continue; }
+        } else if (!(fl & 3u)) break;
+        e = AttemptEnd(ent, buf, len, s, D.start_any, fl, &steps);
+      }
+      if (e >= 0 || steps > kLaneStepBudget) break;
+    }
+    if (steps > kLaneStepBudget) { atomicOr(flags, kOverBudgetBit); found[i] = 0; continue; }
+    found[i] = e >= 0 ? 1 : 0;
+    if (e >= 0) AttemptTags(ent, D.pool, buf, len, s, e, s == 0 ? D.start_begin : D.start_any, s == 0 ? D.init_begin : D.init_any, D.ntags,
+                            tags, rows + i * D.ntags, D.sinfo);
+  }
+}
+
+size_t TdfaShared(const TdfaDev& D, bool lds, bool with_tags) {
+  return (size_t)(lds ? D.nstates * 128 * 4 : 0) + (with_tags ? (size_t)D.ntags * 256 * 4 : 0);
+}
+bool TdfaInLds(const TdfaDev& D, bool with_tags) { return TdfaShared(D, true, with_tags) <= 120 * 1024; }
+
+template <class K>
+hipError_t AllowLds(K kernel, size_t bytes) {
+  if (bytes <= 48 * 1024) return hipSuccess;
+  return hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+int GridFor(long long items, int per_block, int cap) {
+  long long b = (items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  return (int)(b > cap ? cap : b);
+}
+
+}  // namespace
+
+hipError_t LaunchTdfaEnds(const TdfaDev& D, const uint8_t* buf, int32_t len, int32_t* ends, uint32_t* flags, hipStream_t stream) {
+  const bool lds = TdfaInLds(D, false);
+  const size_t sh = TdfaShared(D, lds, false);
+  const int grid = GridFor((long long)len + 1, 256 * 16, 1 << 20);       // a workgroup stages the table once for 4096 offsets or more
+  hipError_t rc;
+  if (lds) {
+    if ((rc = AllowLds(tdfa_ends_kernel<true>, sh)) != hipSuccess) return rc;
+    hipLaunchKernelGGL(tdfa_ends_kernel<true>, dim3(grid), dim3(256), sh, stream, D, buf, len, ends, flags);
+  } else {
+    hipLaunchKernelGGL(tdfa_ends_kernel<false>, dim3(grid), dim3(256), 0, stream, D, buf, len, ends, flags);
+  }
+  return hipGetLastError();
+}
+
+hipError_t LaunchTdfaChainSerial(const TdfaDev& D, const uint8_t* buf, int32_t len, const int32_t* ends, int32_t* se, int64_t max_n,
+                                 long long* out_n, uint32_t* flags, hipStream_t stream) {
+  const bool lds = TdfaInLds(D, false);
+  const size_t sh = TdfaShared(D, lds, false);
+  hipError_t rc;
+  if (lds) {
+    if ((rc = AllowLds(tdfa_chain_serial_kernel<true>, sh)) != hipSuccess) return rc;
+    hipLaunchKernelGGL(tdfa_chain_serial_kernel<true>, dim3(1), dim3(64), sh, stream, D, buf, len, ends, se, (long long)max_n, out_n, flags);
+  } else {
+    hipLaunchKernelGGL(tdfa_chain_serial_kernel<false>, dim3(1), dim3(64), 0, stream, D, buf, len, ends, se, (long long)max_n, out_n, flags);
+  }
+  return hipGetLastError();
+}
+
+int64_t TdfaSyncTiles(int32_t len) { return ((int64_t)len + 1 + kSyncTile - 1) / kSyncTile; }
+int64_t TdfaSlices(int32_t len) { return ((int64_t)len + 1 + 63) / 64; }
+
+hipError_t LaunchTdfaSync(const int32_t* ends, int32_t len, unsigned long long* sync, unsigned long long* desc, uint32_t* flags,
+                          hipStream_t stream) {
+  hipLaunchKernelGGL(tdfa_sync_kernel, dim3((unsigned)TdfaSyncTiles(len)), dim3(256), 0, stream, ends, len, sync, desc, flags);
+  return hipGetLastError();
+}
+
+hipError_t LaunchTdfaChain(const int32_t* ends, int32_t len, const unsigned long long* sync, int32_t* counts, const int32_t* offs,
+                           int32_t* se, int64_t max_n, int emit, uint32_t* flags, hipStream_t stream) {
+  const int64_t ns = TdfaSlices(len);
+  hipLaunchKernelGGL(tdfa_chain_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, ends, len, sync, counts, offs, se,
+                     (long long)max_n, emit, flags);
+  return hipGetLastError();
+}
+
+size_t TdfaScanTempBytes(int64_t n) {
+  size_t bytes = 0;
+  hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (int)n);
+  return bytes;
+}
+// offs[i] = counts[0] + .. + counts[i - 1] (a match is at least one byte long and len < 2^31: int32 holds every sum)
+hipError_t LaunchTdfaScan(const int32_t* counts, int32_t* offs, int64_t n, void* temp, size_t temp_bytes, hipStream_t stream) {
+  return hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, counts, offs, (int)n, stream);
+}
+
+hipError_t LaunchTdfaTags(const TdfaDev& D, const uint8_t* buf, int32_t len, const int32_t* se, int64_t n, int32_t* rows, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  const bool lds = TdfaInLds(D, true);
+  const size_t sh = TdfaShared(D, lds, true);
+  const int grid = GridFor(n, 256 * 4, 1 << 16);
+  hipError_t rc;
+  if (lds) {
+    if ((rc = AllowLds(tdfa_tags_kernel<true>, sh)) != hipSuccess) return rc;
+    hipLaunchKernelGGL(tdfa_tags_kernel<true>, dim3(grid), dim3(256), sh, stream, D, buf, len, se, (long long)n, rows);
+  } else {
+    if ((rc = AllowLds(tdfa_tags_kernel<false>, sh)) != hipSuccess) return rc;
+    hipLaunchKernelGGL(tdfa_tags_kernel<false>, dim3(grid), dim3(256), sh, stream, D, buf, len, se, (long long)n, rows);
+  }
+  return hipGetLastError();
+}
+
+hipError_t LaunchTdfaBatch(const TdfaDev& D, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found, int32_t* rows,
+                           uint32_t* flags, hipStream_t stream) {
+  if (nstr <= 0) return hipSuccess;
+  const bool lds = TdfaInLds(D, true);
+  const size_t sh = TdfaShared(D, lds, true);
+  const int grid = GridFor(nstr, 256 * 8, 1 << 16);
+  hipError_t rc;
+  if (lds) {
+    if ((rc = AllowLds(tdfa_batch_kernel<true>, sh)) != hipSuccess) return rc;
+    hipLaunchKernelGGL(tdfa_batch_kernel<true>, dim3(grid), dim3(256), sh, stream, D, concat, offsets, (long long)nstr, found, rows, flags);
+  } else {
+    if ((rc = AllowLds(tdfa_batch_kernel<false>, sh)) != hipSuccess) return rc;
+    hipLaunchKernelGGL(tdfa_batch_kernel<false>, dim3(grid), dim3(256), sh, stream, D, concat, offsets, (long long)nstr, found, rows, flags);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace rgx

@@ -127,3 +127,32 @@ def gen_patterns_u(seed: int, count: int):
 
 def gen_input_u(rng: random.Random, nchars: int) -> bytes:
     return "".join(rng.choice(ALPHABET_U) * rng.choice([1, 1, 1, 2, 5]) for _ in range(nchars)).encode("utf-8")
+
+
+# ---- texts that EXERCISE a Tagged DFA: random walks through the automaton's own transitions (uniform random text almost never
+# gets past the first two bytes of `https?://...`), cut short, restarted and salted with noise so that attempts fail late, accept
+# early and go on, overlap, and end exactly at the end of the text (the EOT accepts).
+def tdfa_guided_text(tables: dict, rng: random.Random, n: int, noise: float = 0.06) -> bytes:
+    trans = tables["transitions"]
+    alpha = sorted({c for row in trans for c in range(128) if row[c] >= 0}) or [97]
+    out = bytearray()
+    st = -1
+    while len(out) < n:
+        if st < 0:
+            st = rng.choice([0, tables.get("start_any", 0)])
+        live = [c for c in range(128) if trans[st][c] >= 0]
+        r = rng.random()
+        if not live or r < noise:
+            out.append(rng.choice(alpha) if rng.random() < 0.7 else rng.choice([32, 10, 0xC3, 0xA9, 47, 58]))
+            st = -1
+            continue
+        # prefer bytes that lead to DIFFERENT states (a class of 60 word bytes would otherwise drown the one '.' that moves on)
+        by_next = {}
+        for c in live:
+            by_next.setdefault(trans[st][c], []).append(c)
+        c = rng.choice(by_next[rng.choice(sorted(by_next))])
+        out.append(c)
+        st = trans[st][c]
+        if rng.random() < 0.02:
+            st = -1
+    return bytes(out[:n])

@@ -40,6 +40,10 @@ _lib.rgxt_us_find_all_simple.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_
 _lib.rgxt_ref_find.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p]
 _lib.rgxt_ref_match.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
 
+_lib.rgxt_tdfa_header.argtypes = [C.c_void_p, C.c_void_p]
+_lib.rgxt_tdfa_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 5
+_lib.rgxt_tdfa_find.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p]
+
 INFO = ["ncap", "min", "max", "ninst", "nstates", "ncls", "anchored", "fixed", "empty", "refm", "reff", "look", "maxthr"]
 
 
@@ -132,6 +136,34 @@ class HostProgram:
     def ref_match(self, b: bytes):
         r = _lib.rgxt_ref_match(self.h, b, len(b))
         return NotImplemented if r == -3 else bool(r)
+
+    def tdfa_tables(self):
+        """The reference's Tagged DFA as the product built it, in the shape of oracle.tdfa.TDFA.tables() (None: no TDFA)."""
+        hd = (C.c_int32 * 8)()
+        ns = _lib.rgxt_tdfa_header(self.h, hd)
+        if ns <= 0:
+            return None
+        ntags, sb, sa, npool, ib, ia = list(hd)[1:7]
+        trans = (C.c_int16 * (ns * 128))(); act = (C.c_uint16 * (ns * 128))(); acc = (C.c_uint8 * ns)()
+        acc_act = (C.c_uint16 * ns)(); pool = (C.c_int16 * npool)()
+        _lib.rgxt_tdfa_tables(self.h, trans, act, acc, acc_act, pool)
+
+        def lst(at):
+            return [[pool[at + 1 + 2 * a], pool[at + 2 + 2 * a]] for a in range(pool[at])]
+        return {"n_states": ns, "ntags": ntags, "start_begin": sb, "start_any": sa,
+                "transitions": [[trans[s * 128 + c] for c in range(128)] for s in range(ns)],
+                "tag_actions": [[lst(act[s * 128 + c]) for c in range(128)] for s in range(ns)],
+                "accept": [bool(acc[s] & 1) for s in range(ns)], "accept_eot": [bool(acc[s] & 2) for s in range(ns)],
+                "accept_actions": [lst(acc_act[s]) for s in range(ns)],
+                "initial_begin": lst(ib), "initial_any": lst(ia)}
+
+    def tdfa_find(self, b: bytes):
+        """tdfa.go:831-1052 over the product's tables: raw tags (see oracle.tdfa.TDFA.find), None, or NotImplemented."""
+        out = (C.c_int32 * 64)()
+        r = _lib.rgxt_tdfa_find(self.h, b, len(b), out)
+        if r == -3:
+            return NotImplemented
+        return list(out[:self.info["ncap"]]) if r == 1 else None
 
     def reset_bytes(self):
         a = (C.c_uint8 * 256)()

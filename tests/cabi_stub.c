@@ -146,7 +146,10 @@ static int read_loop(FILE* rd, size_t read_size, rgx_stream_config cfg, chunk_fn
   return rc < 0 ? rc : 0;
 }
 
-typedef struct reader_state { int32_t* spans; size_t cap; long long count; } reader_state;
+/* `held`: the reused result struct of FindReader (streaming.go:117) for a Tagged-DFA program -- per group the slice (lo, hi) of buf it
+ * was last assigned; the engine assigns a group only when its start tag is set (tdfa.go:1031-1046; the record says (-1, -1)
+ * otherwise), so a field may still alias the bytes of an earlier match's group -- whatever lies there NOW (FIELD lines). */
+typedef struct reader_state { int32_t* spans; size_t cap; long long count; int32_t held[128]; int have[64]; } reader_state;
 static int reader_chunk(rgx_stream_ctx* ctx, uint8_t* buf, size_t data_len, int is_full, long long stream_offset, int chunk_index,
                         long long max_leftover, void* user, long long* keep) {
   reader_state* st = (reader_state*)user;
@@ -161,6 +164,14 @@ static int reader_chunk(rgx_stream_ctx* ctx, uint8_t* buf, size_t data_len, int 
   for (i = 0; i < w; i++) {
     const int32_t* c = st->spans + i * g_ncap;
     printf("MATCH %lld %d %.*s\n", stream_offset + c[0], chunk_index, (int)(c[1] - c[0]), (const char*)buf + c[0]);
+    if (g_info.ref_find_engine == 1 && !(g_info.flags & RGX_FLAG_STDLIB_SEMANTICS)) {
+      int g;
+      for (g = 0; g < g_ncap / 2 && g < 64; g++) {
+        if (c[2 * g] >= 0) { st->held[2 * g] = c[2 * g]; st->held[2 * g + 1] = c[2 * g + 1]; st->have[g] = 1; }
+        if (st->have[g]) printf("FIELD %d %.*s\n", g, (int)(st->held[2 * g + 1] - st->held[2 * g]), (const char*)buf + st->held[2 * g]);
+        else printf("FIELD %d <nil>\n", g);
+      }
+    }
   }
   st->count += w;
   *keep = keep_from;
@@ -192,6 +203,7 @@ static int find_reader(FILE* rd, long long bufsize, long long max_leftover, size
   st.cap = (size_t)cfg.buffer_size / (size_t)(g_info.min_match_len > 1 ? g_info.min_match_len : 1) + 1;
   st.spans = (int32_t*)malloc(st.cap * (size_t)g_ncap * sizeof(int32_t) + 16);
   st.count = 0;
+  memset(st.have, 0, sizeof st.have);
   rc = read_loop(rd, read_size, cfg, count_only ? count_chunk : reader_chunk, &st);
   printf("COUNT %lld\n", st.count);
   free(st.spans);
@@ -260,9 +272,9 @@ int main(int argc, char** argv) {
     int rb = rgx_program_from_blob(blob, blob_len, &p);
     printf("INIT %d %s\n", rc, rgx_status_str(rc));
     if (rb == RGX_OK && rgx_program_info(p, &info) == RGX_OK)
-      printf("INFO abi %d ncap %d min %d max %d findall %d stream %d find %d match %d engine %d flags %u\n", info.abi_version, info.ncap,
+      printf("INFO abi %d ncap %d min %d max %d findall %d stream %d find %d match %d engine %d flags %u replace %d\n", info.abi_version, info.ncap,
              info.min_match_len, info.max_match_len, info.ref_findall_offered, info.ref_stream_offered, info.ref_find_offered,
-             info.ref_match_offered, info.ref_find_engine, info.flags);
+             info.ref_match_offered, info.ref_find_engine, info.flags, info.ref_replace_offered);
     else printf("BLOB_ERROR %d\n", rb);
     if (p) rgx_program_destroy(p);
     gpu_close();

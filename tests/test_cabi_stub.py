@@ -65,7 +65,7 @@ def test_twin_without_a_device_keeps_the_go_path(stub, tmp_path):
     assert rc == 0
     lines = out.decode().splitlines()
     assert lines[0].startswith("INIT -5")                                # RGX_E_NO_DEVICE: <name>Prog stays nil, every method falls back
-    assert "abi 3 ncap 8 min 10 max 10 findall 1 stream 1 find 1 match 1 engine 0" in lines[1]
+    assert "abi 4 ncap 8 min 10 max 10 findall 1 stream 1 find 1 match 1 engine 0 flags 0 replace 1" in lines[1]
     rc, out = _run(stub, blob, b"x 2024-01-15 y", tmp_path, "findall")
     assert rc == 1 and out.startswith(b"INIT -5")
 
@@ -136,19 +136,40 @@ def test_twin_refusals_and_fallbacks(stub, tmp_path):
     blob, _ = _tables(tmp_path, r"(?P<a>ab+)c?", "A")
     rc, out = _run(stub, blob, b"xx ab yy abbc ab", tmp_path, "reader", 65536, 0, 0)
     assert rc == 0
-    # the reference's Tagged DFA (URLCapture): FindAll and FindReader are refused in reference mode (-3) ...
+    # the reference's Tagged DFA (URLCapture): FindAll (the wrapper reports matches again) and Replace are refused in reference mode ...
     blob, go = _tables(tmp_path, URL_CAPTURE, "U")
-    data = b"see https://example.com/a and http://h.org:80/x"
+    data = b"see https://example.com/a and http://h.org:80/x then https://plain.net"
     rc, out = _run(stub, blob, data, tmp_path, "findall", -1)
     assert out.decode().splitlines() == ["GOFALLBACK -3"]
+    rc, out = _run(stub, blob, data, tmp_path, "replace", "<$host>", 0)
+    assert out.decode().splitlines() == ["GOFALLBACK -3"]
+    # ... while FindBytes and FindReader run the engine itself: the third match has neither port nor path, and the reused result
+    # struct still shows the second match's (tdfa.go:1031-1046 leaves the fields untouched) -- as oracle.find_reader(reuse=True) says
+    from oracle import engines as E
+    o = E.Compiled(URL_CAPTURE)
+    exp = []
+    import io
+    assert o.FindReader(io.BytesIO(data).read, E.StreamConfig(65536, 0), lambda m: exp.append((m.StreamOffset, m.match_bytes, m.fields)) or True) is None
     rc, out = _run(stub, blob, data, tmp_path, "reader", 65536, 0, 0)
-    assert out.decode().splitlines()[0].startswith("GOFALLBACK -3")
-    # ... and answered as Go's regexp would with tables compiled under RGX_FLAG_STDLIB_SEMANTICS
+    lines = out.decode().splitlines()
+    got, cur = [], None
+    for l in lines:
+        if l.startswith("MATCH"):
+            cur = (int(l.split()[1]), l.split()[3].encode(), [])
+            got.append(cur)
+        elif l.startswith("FIELD"):
+            txt = l.split(" ", 2)[2] if len(l.split(" ", 2)) > 2 else ""
+            cur[2].append(None if txt == "<nil>" else txt.encode())
+    assert [(a, b, c) for a, b, c in got] == exp and len(exp) == 3
+    assert exp[2][2][3] == b"80" and exp[2][2][4] == b"/x" and exp[0][2][3] is None          # port, path: stale; nil before any assignment
+    rc, out = _run(stub, blob, data, tmp_path, "find")
+    assert out.decode().strip() == "ROW " + " ".join(map(str, o.FindBytes(data)))
+    # ... and everything is answered as Go's regexp would with tables compiled under RGX_FLAG_STDLIB_SEMANTICS
     from oracle.engines import Compiled as O
     blob, _ = _tables(tmp_path, URL_CAPTURE, "U2", flags=_capi.FLAG_STDLIB_SEMANTICS)
     rc, out = _run(stub, blob, data, tmp_path, "findall", -1)
     rows = [list(map(int, l.split()[1:])) for l in out.decode().splitlines() if l.startswith("ROW")]
-    assert rows == O(URL_CAPTURE).FindAllLeftmostFirst(data) and len(rows) == 2
+    assert rows == O(URL_CAPTURE).FindAllLeftmostFirst(data) and len(rows) == 3
 
 
 @pytest.mark.gpu

@@ -79,7 +79,9 @@ def test_emitted_text_is_well_formed(built, name, pattern):
     if info.ref_findall_offered:
         need |= {"rgx_find_all_bytes", "rgx_sharded_find_all_bytes"}
     if info.ref_stream_offered:
-        need |= {"rgx_find_chunk", "rgx_count_chunk", "rgx_replace_all_bytes", "rgx_transform_chunk"}
+        need |= {"rgx_find_chunk", "rgx_count_chunk"}
+    if info.ref_replace_offered:
+        need |= {"rgx_replace_all_bytes", "rgx_transform_chunk"}
     assert need <= used, need - used
     hdr = open(os.path.join(ROOT, "include", "rgx.h")).read()
     for m in re.finditer(r"C\.(RGX_[A-Z_0-9]+)", code):
@@ -88,8 +90,9 @@ def test_emitted_text_is_well_formed(built, name, pattern):
     # -- each family only where the library gives the reference's own answer (rgx_info.ref_*_offered); the rest keep their Go bodies
     want, absent = [], []
     (want if info.ref_findall_offered else absent).extend(["FindAllString", "FindAllStringAppend", "FindAllBytes", "FindAllBytesAppend"])
-    (want if info.ref_stream_offered else absent).extend(["FindReader", "FindReaderCount", "ReplaceReader", "ReplaceAllString", "ReplaceAllBytes",
-                                                          "ReplaceAllBytesAppend", "ReplaceFirstString", "ReplaceFirstBytes"])
+    (want if info.ref_stream_offered else absent).extend(["FindReader", "FindReaderCount"])
+    (want if info.ref_replace_offered else absent).extend(["ReplaceReader", "ReplaceAllString", "ReplaceAllBytes",
+                                                           "ReplaceAllBytesAppend", "ReplaceFirstString", "ReplaceFirstBytes"])
     if info.ref_match_offered:
         want += ["MatchBytes", "MatchString"]
     if info.ref_find_offered:
@@ -103,7 +106,12 @@ def test_emitted_text_is_well_formed(built, name, pattern):
         assert m.group(1).endswith("Go"), m.group(1)
     # unmatched-group guard (find.go:394-406) for every group of both result structs
     ngroups = info.ncap // 2 - 1
-    assert len(re.findall(r"if c\[\d+\] <= c\[\d+\] && int\(c\[\d+\]\) <= len\(input\) \{", code)) == 2 * ngroups
+    if info.ref_find_engine == 1:
+        # Tagged-DFA program: the engine's own result construction (tdfa.go:1031-1046) -- assign a group only when its start tag is set
+        assert len(re.findall(r"if c\[\d+\] >= 0 \{", code)) == 2 * ngroups
+        assert "= nil" not in re.search(r"func \w+FillBytes\(.*?\n}\n", code, re.S).group(0)
+    else:
+        assert len(re.findall(r"if c\[\d+\] <= c\[\d+\] && int\(c\[\d+\]\) <= len\(input\) \{", code)) == 2 * ngroups
 
 
 @pytest.mark.parametrize("name,pattern", CASES)
@@ -141,12 +149,17 @@ def test_field_names_and_memo_patterns(built):
     assert "func (r Nested) MatchBytes(" in text and "func (r Nested) FindBytesReuse(" not in text
     assert "FindBytes / FindBytesReuse / FindString / FindStringReuse are not routed" in text
     assert "func (r Nested) FindAllBytesAppend(" in text and "func (r Nested) FindReader(" not in text
-    # the reference's Tagged DFA (URLCapture, 13 states as in its checked-in tables): FindAll* and the streaming family are NOT
-    # routed in reference mode -- the TDFA's FindAll reports matches again (compiler.go:646-651) -- and all are with --stdlib-semantics
+    # the reference's Tagged DFA (URLCapture, 13 states as in its checked-in tables): the engine itself runs on the device, so
+    # FindBytes* and FindReader / FindReaderCount ARE routed (fill: a group is assigned only when its start tag is set); FindAll* (the
+    # wrapper reports matches again, compiler.go:646-651) and Replace* (stale groups of the reused struct) are not -- all are with
+    # --stdlib-semantics
     url = CASES[2][1]
     assert codegen.Program(url).info.ref_find_engine == 1 and codegen.Program(url).info.ref_tdfa_states == 13
     text, _ = codegen.emit_go(url, "URL", "p")
-    assert "func (r URL) FindAll" not in text and "func (r URL) FindReader(" not in text and "FindAll* are not routed" in text
+    assert "func (r URL) FindAll" not in text and "FindAll* are not routed" in text
+    assert "func (r URL) FindReader(" in text and "func (r URL) FindReaderCount(" in text and "func (r URL) FindBytesReuse(" in text
+    assert "func (r URL) ReplaceAll" not in text and "Replace* / ReplaceReader are not routed" in text
+    assert "if c[6] >= 0 {\n\t\titem.Port = input[c[6]:c[7]]\n\t}" in text and "item.Port = nil" not in text
     text, _ = codegen.emit_go(url, "URL", "p", flags=_capi.FLAG_STDLIB_SEMANTICS)
     for meth in ("FindAllBytesAppend", "FindReader", "FindReaderCount", "ReplaceAllBytesAppend", "FindBytesReuse", "MatchBytes"):
         assert "func (r URL) %s(" % meth in text, meth

@@ -1,15 +1,168 @@
-"""GPU tier: patterns the reference emits with its Tagged-DFA engine.  The HIP path computes leftmost-first spans; on
-the reference's own inputs that is exactly what the restated TDFA returns (first match, all groups)."""
+"""GPU tier: patterns the reference emits with its Tagged-DFA engine (rgx_info.ref_find_engine == 1).
+
+Reference mode runs the reference's OWN automaton on the device (csrc/rgx_tdfa.hip over the tables of csrc/rgx_ref_engine.cc, which
+equal the emitted literals: tests/test_tdfa.py): FindBytes / FindBytesReuse / the batch form / FindReader / FindReaderCount are
+compared here with the restated emitted loop (oracle/tdfa.py: longest-on-path, a byte >= 0x80 ends an attempt, untouched groups)
+on the reference's inputs AND on texts where that loop differs from leftmost-first.  Only the FindAllBytes wrapper (advances by
+the match length, Q11) and Replace / Transform stay refused."""
 import io
 import json
 import os
+import random
+import zlib
 
 import pytest
 
 pytestmark = pytest.mark.gpu
 
 
-def test_tdfa_engine_patterns(built, kats, corpus):
+# Tagged-DFA-class patterns (captures + nested quantifiers, a construction under 500 states) on which the engine's longest-on-path
+# answer is NOT the leftmost-first one (lazy quantifiers): the device must follow the engine
+EXTRA = [r"(?P<x>(?:a+)+?)(?P<y>b+?)", r"(?P<x>(?:[a-c]+,)+?)(?P<y>\d+)?"]
+
+
+def _tdfa_items(kats, corpus):
+    pats = [c["pattern"] for c in kats["curated_cases"]] + [e["pattern"] for e in corpus] + EXTRA
+    inputs = {p: [] for p in EXTRA}
+    for c in kats["curated_cases"]:
+        inputs.setdefault(c["pattern"], []).extend(c["inputs"])
+    for e in corpus:
+        inputs.setdefault(e["pattern"], []).extend(e["inputs"])
+    from oracle import engines as E
+    out = []
+    for pat in dict.fromkeys(pats):
+        o = E.Compiled(pat)
+        if o.tdfa is not None:
+            out.append((pat, o, [s.encode() for s in inputs[pat]]))
+    return out
+
+
+def _texts(o, pat, count, lo, hi):
+    from tests import _fuzzgen as F
+    tb = o.tdfa.tables()
+    tb["start_any"] = o.tdfa.start_any
+    rnd = random.Random(zlib.crc32(pat.encode()))
+    return [F.tdfa_guided_text(tb, rnd, rnd.randint(lo, hi)) for _ in range(count)]
+
+
+def test_tdfa_find_is_the_reference_engine(built, kats, corpus):
+    """FindBytes per string (rgx_find_batch_device -> tdfa_batch_kernel) == oracle.tdfa.find: raw tags, (-1, -1) for a group the
+    result construction leaves untouched, on the reference's inputs and on guided random texts (attempts that fail late, accept
+    early and go on, end at the end of the text, hit a byte >= 0x80)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU; there is no CPU fallback")
+    from regengo_amd import Compiled
+    items = _tdfa_items(kats, corpus)
+    assert len(items) >= 12
+    checked = differs = untouched = 0
+    for pat, o, inputs in items:
+        c = Compiled(pat).to(0)                       # reference mode, no flag: rows are the engine's tags
+        assert c.info.ref_find_engine == 1 and c.info.ref_find_offered == 1 and c.info.ref_tdfa_states == len(o.tdfa.states), pat
+        strings = inputs + [b"", b"x", b"\xc3\xa9"] + _texts(o, pat, 300, 1, 120)
+        res = c.FindBatch(strings)
+        for b, r in zip(strings, res):
+            exp = o.tdfa.find(b)
+            assert (r is None) == (exp is None), (pat, b)
+            if r is None:
+                continue
+            assert r.spans == exp, (pat, b, r.spans, exp)
+            checked += 1
+            untouched += sum(1 for g in range(1, len(exp) // 2) if exp[2 * g] < 0)
+            lf = o.find_machine.find_all(b, 1, q8=False)
+            if not lf or lf[0][:2] != exp[:2]:
+                differs += 1
+        # the single-text entry point, short (one lane) and long (a lane per start offset + the serial chain with max_n = 1)
+        for b in strings[:6] + [b"\n".join(strings[-40:]), b" " * 5000 + strings[-1] + b" " + strings[-2]]:
+            r, ok = c.FindBytes(b)
+            exp = o.tdfa.find(b)
+            assert ok == (exp is not None), (pat, len(b))
+            if ok:
+                assert r.spans == exp, (pat, len(b))
+    assert checked >= 2000 and untouched >= 1000 and differs >= 300, (checked, untouched, differs)
+
+
+def test_tdfa_find_reader_is_the_reference_loop(built, kats, corpus):
+    """FindReader / FindReaderCount of a TDFA-class program in reference mode: rgx_find_chunk runs the engine's FindBytesReuse loop
+    over the chunk on the device.  Callbacks (offset, chunk index, raw tags) AND the texts the callback reads from the reused result
+    struct -- a group the engine leaves untouched keeps the slice of an earlier match, over a buffer that has moved on -- equal the
+    restated loop (oracle.engines.find_reader(reuse=True)); an answer may be withheld only as RGX_E_DIVERGES (bytes.Index)."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU; there is no CPU fallback")
+    from oracle import engines as E
+    from regengo_amd import Compiled, _capi
+    from regengo_amd.stream import Config
+    items = _tdfa_items(kats, corpus)
+    answered = diverged = stale = calls = 0
+    for pat, o, inputs in items:
+        c = Compiled(pat).to(0)
+        assert c.info.ref_stream_offered == 1 and c.info.ref_findall_offered == 0 and c.info.ref_replace_offered == 0, pat
+        rnd = random.Random(zlib.crc32(pat.encode()) ^ 7)
+        texts = [b" ".join(inputs), b"\n".join(_texts(o, pat, 40, 5, 90))]
+        texts.append(b" -- ".join(_texts(o, pat, 400, 5, 90)))          # ~20 KB: chunks of 8 KiB and more take the parallel chain
+        for text in texts:
+            for bufsize in (0, 256, 1024, 8192, 65536):
+                mb = E.min_buffer(o.sel.max_len)
+                if bufsize and bufsize < mb:
+                    continue
+                cfg_o = E.StreamConfig(bufsize, 0)
+                exp = []
+                err = o.FindReader(io.BytesIO(text).read, cfg_o, lambda m: exp.append((m.StreamOffset, m.ChunkIndex, m.caps, m.fields)) or True)
+                assert err is None
+                got = []
+                try:
+                    c.FindReader(io.BytesIO(text), Config(bufsize, 0), lambda m: got.append((m.StreamOffset, m.ChunkIndex, m.Result.spans,
+                                                                                             [m.Result.CaptureByIndex(g) for g in range(c.ncap // 2)])) or True)
+                except _capi.RgxError as ex:
+                    assert ex.status == _capi.RGX_E_DIVERGES, (pat, bufsize, ex)
+                    diverged += 1
+                    continue
+                calls += 1
+                assert len(got) == len(exp), (pat, bufsize, len(got), len(exp))
+                for g, e in zip(got, exp):
+                    # the oracle's tags are relative to chunk[searchPos:], the device's to the chunk: compare lengths and texts
+                    assert g[0] == e[0] and g[1] == e[1], (pat, bufsize, g, e)
+                    assert [x < 0 for x in g[2]] == [x < 0 for x in e[2]], (pat, bufsize, g, e)
+                    assert g[2][1] - g[2][0] == e[2][1] - e[2][0]
+                    assert g[3] == e[3], (pat, bufsize, g, e)
+                    if any(x < 0 for x in e[2]) and any(f for f, a in zip(e[3][1:], e[2][2::2]) if a < 0 and f):
+                        stale += 1
+                answered += len(got)
+                n = c.FindReaderCount(io.BytesIO(text), Config(bufsize, 0))
+                assert n == len(exp), (pat, bufsize)
+    assert answered >= 2000 and calls >= 100 and stale >= 20, (answered, calls, stale, diverged)
+
+
+def test_tdfa_chain_parallel_equals_serial_on_a_large_chunk(built):
+    """One 3 MiB chunk (BufferSize 4 MiB): ends per start offset, sync points from the running maximum, a lane per 64 offsets --
+    against the oracle's loop on a periodic text whose period the oracle answers directly."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU; there is no CPU fallback")
+    from oracle import engines as E
+    from regengo_amd import Compiled
+    from regengo_amd.stream import Config
+    pat = r"(?P<protocol>https?)://(?P<host>[\w\.-]+)(?::(?P<port>\d+))?(?P<path>/[\w\./]*)?"
+    o = E.Compiled(pat)
+    assert o.tdfa is not None
+    unit = b"GET http://a.example.org:8080/x/y.html 200 https://b.c - http://d:1 https://e.f/g?h http:/ no\n"
+    reps = (3 << 20) // len(unit)
+    text = unit * reps
+    per = []
+    o.FindReader(io.BytesIO(unit).read, E.StreamConfig(1 << 16, 0), lambda m: per.append((m.StreamOffset, m.caps[1] - m.caps[0])) or True)
+    assert len(per) >= 4
+    k5 = len(per)
+    c = Compiled(pat).to(0)
+    got = []
+    c.FindReader(io.BytesIO(text), Config(4 << 20, 0), lambda m: got.append((m.StreamOffset, len(m.Result.Match))) or True)
+    assert len(got) == reps * k5
+    for k in (0, 1, reps // 2, reps - 1):
+        assert got[k * k5:(k + 1) * k5] == [(off + k * len(unit), ln) for off, ln in per], k
+    assert c.FindReaderCount(io.BytesIO(text), Config(4 << 20, 0)) == reps * k5
+
+
+def test_tdfa_class_patterns_under_stdlib_flag_are_leftmost_first(built, kats, corpus):
     import torch
     if not torch.cuda.is_available():
         pytest.fail("GPU tests need a GPU; there is no CPU fallback")
@@ -43,8 +196,8 @@ def test_tdfa_engine_patterns(built, kats, corpus):
 
 
 def test_tdfa_class_findall_is_the_reference_or_refused(built, kats, corpus):
-    """for every corpus / curated pattern the reference emits with its Tagged DFA (or memoising on an empty
-    match), every FindAll / count / streaming entry point is REFUSED in reference mode -- the TDFA's FindAllBytes advances by the
+    """For every corpus / curated pattern the reference emits with its Tagged DFA (or memoising on an empty
+    match), every FindAll / count / Replace entry point is REFUSED in reference mode -- the TDFA's FindAllBytes advances by the
     match length (compiler.go:646-651; oracle.tdfa.find_all reproduces the duplicates) -- and answers as Go's regexp
     (oracle: leftmost-first) under RGX_FLAG_STDLIB_SEMANTICS.  For every other pattern the device's answer equals the oracle's
     restatement of what the reference emits (oracle.engines.Compiled.FindAllBytes dispatches on the engine)."""
@@ -63,10 +216,8 @@ def test_tdfa_class_findall_is_the_reference_or_refused(built, kats, corpus):
         texts = [s.encode() for s in inputs] + [b" ".join(s.encode() for s in inputs), tile]
         c = Compiled(pat).to(0)
         if o.tdfa is not None:
-            assert not c.info.ref_findall_offered and not c.info.ref_stream_offered, pat
-            from regengo_amd.stream import Config
+            assert not c.info.ref_findall_offered and not c.info.ref_replace_offered and c.info.ref_stream_offered, pat
             for call in (lambda: c.FindAllSpans(texts[-1]), lambda: c.CountAll(texts[-1]),
-                         lambda: c.FindReaderCount(io.BytesIO(texts[-1]), Config(0, 0)),
                          lambda: c.ReplaceAllBytes(texts[-1], "x")):
                 with pytest.raises(_capi.RgxError) as ei:
                     call()

@@ -41,8 +41,12 @@ def test_product_engine_selection_equals_the_oracle(built, corpus, kats):
         # the offer rules (include/rgx.h: rgx_info)
         assert info.ref_findall_offered == int(exp[0] <= 0 or (exp[0] == 2 and not info.can_match_empty)), p
         assert info.ref_stream_offered == int(info.ref_find_offered and not info.can_match_empty), p
-        if exp[0] >= 1:
-            assert not info.ref_find_offered and not info.ref_stream_offered, p
+        if exp[0] == 2:          # memoising backtracker: its FindBytesReuse is not reproduced
+            assert not info.ref_find_offered and not info.ref_stream_offered and not info.ref_replace_offered, p
+        if exp[0] == 1:          # Tagged DFA: the engine itself runs on the device; only its FindAll wrapper and Replace stay refused
+            assert info.ref_find_offered and info.ref_stream_offered == int(not info.can_match_empty) and not info.ref_replace_offered, p
+        if exp[0] == 0:
+            assert info.ref_replace_offered == info.ref_stream_offered, p
     assert seen[1] >= 15 and seen[2] >= 10 and seen[0] >= 50, seen     # every class is exercised by the corpus
 
 
@@ -59,7 +63,13 @@ def test_checked_in_tdfa_patterns_are_classified_tdfa(built):
             assert info.ref_find_engine == 0 and info.ref_findall_offered, name
             continue
         assert info.ref_find_engine == 1 and info.ref_tdfa_states == len(t["transitions"]), name
-        assert not info.ref_findall_offered and not info.ref_stream_offered
+        assert not info.ref_findall_offered and info.ref_stream_offered and info.ref_find_offered and not info.ref_replace_offered
+    # regengo.Options.ForceTDFA (regengo.go:43-45, cmd flag -force-tdfa; compiler.go:137-153): how TDFASemVer and the ipv4 pattern were
+    # generated -- RGX_FLAG_FORCE_TDFA selects the same engine, and the tables are the emitted ones (tests/test_tdfa.py)
+    for name, t in tabs.items():
+        info = codegen.Program(t["pattern"], _capi.FLAG_FORCE_TDFA).info
+        assert info.ref_find_engine == 1 and info.ref_tdfa_states == len(t["transitions"]), name
+        assert info.flags & _capi.FLAG_FORCE_TDFA
 
 
 def test_stdlib_flag_offers_everything(built):

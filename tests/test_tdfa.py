@@ -103,3 +103,55 @@ def test_q6_and_q11_are_real():
     ok = u.find_all_fixed(b)
     assert len(ok) == 1 and len(dup) > 1 and dup[0] == dup[1]
     assert t is not None
+
+
+def test_product_tables_are_the_emitted_tables(tables):
+    """The C++ construction (csrc/rgx_ref_engine.cc: BuildRefTdfa) -- the tables the HIP walker stages -- equals the literal tables of
+    the three checked-in TDFA matchers, and the oracle's on every TDFA-class pattern of the corpus (blob round trip included)."""
+    from tests._hosttest import HostProgram
+    for name, d in tables.items():
+        hp = HostProgram(d["pattern"])
+        for tb in (hp.tdfa_tables(), hp.roundtrip().tdfa_tables()):
+            assert tb is not None, name
+            assert tb["transitions"] == d["transitions"], name
+            assert tb["accept"] == d["accept"] and tb["accept_eot"] == d["accept_eot"], name
+            for s in range(tb["n_states"]):
+                for c in range(128):
+                    n = d["tag_action_count"][s][c]
+                    ref = [[d["tag_action_tags"][s][c][k], d["tag_action_offsets"][s][c][k]] for k in range(n)]
+                    assert ref == tb["tag_actions"][s][c], (name, s, c)
+                n = d["accept_action_count"][s]
+                ref = [[d["accept_action_tags"][s][k], d["accept_action_offsets"][s][k]] for k in range(n)]
+                assert ref == tb["accept_actions"][s], (name, s)
+            assert (tb["start_begin"], tb["start_any"]) == (d["start_begin"], d["start_any"])
+
+
+def test_product_tables_equal_the_oracle_on_the_corpus(kats, corpus):
+    import random
+    import zlib
+    from tests._hosttest import HostProgram
+    pats = [c["pattern"] for c in kats["curated_cases"]] + [e["pattern"] for e in corpus]
+    seen = 0
+    for pat in dict.fromkeys(pats):
+        o = E.Compiled(pat)
+        hp = HostProgram(pat)
+        tb = hp.tdfa_tables()
+        assert (tb is None) == (o.tdfa is None), pat
+        if tb is None:
+            continue
+        seen += 1
+        ob = o.tdfa.tables()
+        for k in ("n_states", "transitions", "tag_actions", "accept", "accept_eot", "accept_actions"):
+            assert tb[k] == ob[k], (pat, k)
+        assert tb["initial_begin"] == [list(a) for a in o.tdfa.initial_begin] and tb["initial_any"] == [list(a) for a in o.tdfa.initial_any]
+        assert tb["ntags"] == 2 * max(o.tdfa.ncap_names, 1)
+        # the find loop over the product's tables (what a lane of rgx_tdfa.hip runs) against the restated emitted loop
+        rnd = random.Random(zlib.crc32(pat.encode()))
+        alpha = sorted({c for row in ob["transitions"] for c in range(128) if row[c] >= 0})
+        texts = [b"", b"\xc3\xa9"]
+        for _ in range(60):
+            n = rnd.randint(1, 60)
+            texts.append(bytes(rnd.choice(alpha) if rnd.random() < 0.93 else rnd.choice([32, 10, 200]) for _ in range(n)))
+        for b in texts:
+            assert hp.tdfa_find(b) == o.tdfa.find(b), (pat, b)
+    assert seen >= 12
