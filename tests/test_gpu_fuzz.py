@@ -103,7 +103,7 @@ def test_random_patterns_replace_and_transform(torch_dev):
             b = F.gen_input(rng, rng.choice([0, 7, 300, 2500]))
             for tmpl in templates:
                 assert c.ReplaceAllBytes(b, tmpl) == R.replace_all(o, b, tmpl), (p, tmpl, b)
-            if cref.info.ref_find_offered:
+            if cref.info.ref_replace_offered:
                 try:
                     got = cref.ReplaceAllBytes(b, "<$0>")
                     try:

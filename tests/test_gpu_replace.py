@@ -47,7 +47,7 @@ def test_replace_matches_oracle_on_corpus(gpu, corpus, kats):
         # Programs whose FindBytesReuse the library reproduces (and that cannot match empty) are held to the REFERENCE's loop, quirks
         # included (oracle: quirks=True -- restart rule, re-slicing, bytes.Index): the answer is that, or RGX_E_DIVERGES.  The others are
         # refused in reference mode and give the quirk-free reading (true leftmost-first matches in their real context) in stdlib mode.
-        strict = bool(c.info.ref_stream_offered)
+        strict = bool(c.info.ref_replace_offered)
         if not strict:
             # reference mode refuses (rgx_info.ref_stream_offered == 0): the quirk-free reading is what RGX_FLAG_STDLIB_SEMANTICS gives
             with pytest.raises(_capi.RgxError) as ei:

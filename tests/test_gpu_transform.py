@@ -33,7 +33,7 @@ def dev(pattern):
     from regengo_amd import Compiled
     if pattern not in _c:
         c = Compiled(pattern).to(0)
-        if not c.info.ref_stream_offered and not c.info.can_match_empty:
+        if not c.info.ref_replace_offered and not c.info.can_match_empty:
             # reference mode refuses this program's streaming loops (memoising / Tagged-DFA FindBytesReuse): the quirk-free reading
             # under test here is RGX_FLAG_STDLIB_SEMANTICS
             c = Compiled(pattern, stdlib=True).to(0)
@@ -166,7 +166,7 @@ def test_chunk_protocol_matches_oracle(gpu, pi):
             return out
         except _capi.RgxError as ex:
             assert ex.status == _capi.RGX_E_DIVERGES, ex
-            assert not c.stdlib and c.info.ref_stream_offered
+            assert not c.stdlib and c.info.ref_replace_offered
             refused += 1
             return None
 
