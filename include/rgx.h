@@ -108,8 +108,7 @@ typedef struct rgx_info {
   int32_t scan_kernel;     /* which FindAll kernel a large buffer takes once the program is on a device (0 before): 1 exact
                             * (fixed-length class chain), 2 prefilter + verify, 3 generic (one attempt per start), 4 one step
                             * per byte with start registers, 5 register-free (simple automata), 6 register-free, two bytes
-                            * per look-up, 7 register-free, the transition function per class as a column of 4-bit next states
-                            * (at most 15 live states: the look-up address depends on the input byte only); DESIGN.md section 4 */
+                            * per look-up; DESIGN.md section 4 */
   int32_t ref_match_offered; /* 1: MatchBytes in reference mode (the default) is offered: plain backtracking or Thompson engine; 0: the
                               * reference memoises -- RGX_E_UNSUPPORTED, the generated stub keeps the Go function           */
   int32_t ref_find_offered;  /* the same for FindBytes / FindBytesReuse: the plain backtracking engine (restart rule reproduced) or

@@ -32,6 +32,9 @@ struct ScanParams {
                                  // alive there: the sync automaton's answer) -- a stretch that ends at one needs no special care, unlike
                                  // the carry pass's search positions, behind which an older thread may still decide a match's finality
   int32_t debug;                 // experiment switches (RGX_DEBUG): 1 = unordered base (no look-back), 2 = no span stores
+  uint32_t* census;              // nullable; persistent-workgroup kernels only: a residency census instead of a scan (LaunchScanUs) --
+                                 // every workgroup reports in at [0], waits (bounded) for all gridDim.x of them, and counts itself at
+                                 // [1] if it saw them all: [1] == gridDim.x <=> the whole grid was resident at the same time
 };
 
 // FindAllBytes scan: one pass over the input, ordered span records out.

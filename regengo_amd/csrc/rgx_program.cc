@@ -325,34 +325,7 @@ int UploadUs(Program* p) {
     for (int k = 0; k < stride; k++) srow2[k] = (uint16_t)((srow4[k] / kPitch) * kPitch2W);
     for (int c = 0; c < 256; c++) cls2[c] = (uint8_t)(u.cls[c] | (rst[u.cls[c]] ? 0x80 : 0));
   }
-  // column image (rgx_program.h: UsDev::col): the single-step image again, one 16-byte record per class
-  std::vector<uint32_t> col;
-  std::vector<uint8_t> scode(16, 0);
-  const bool cols = simple && stride <= 15 && u.nstates <= 16;
-  if (cols) {
-    col.assign(16 * 4, 0);
-    for (int k = 0; k < 16; k++) {
-      unsigned long long N = 0;
-      uint32_t F = 0, M = 0;
-      for (int q = 1; q < u.nstates; q++) {
-        unsigned next = (unsigned)q;                                // class 15, classes the automaton does not have: the state stays
-        if (k < stride) {
-          const uint32_t v = ent4[(size_t)(q + 1) * kPitchW + k];
-          const unsigned r = (v & 0xFFFFu) / kPitch;                // row index of the single-step image: 0 parked, 1 rewind, q + 1
-          if (r == 0) { next = (unsigned)q; M |= 1u << (16 + q); }  // (only at the end of the text) the walk is over
-          else next = r - 1;                                        // rewind row -> code 0
-          if (v >> 31) F |= 1u << q;
-          if ((v >> 30) & 1u) F |= 1u << (16 + q);
-          if ((v >> 29) & 1u) M |= 1u << q;
-        }
-        N |= (unsigned long long)next << (4 * q);
-      }
-      col[k * 4 + 0] = (uint32_t)N; col[k * 4 + 1] = (uint32_t)(N >> 32); col[k * 4 + 2] = F; col[k * 4 + 3] = M;
-    }
-    for (int k = 0; k < stride; k++) scode[k] = (uint8_t)(srow4[k] / kPitch - 1);
-  }
   Arena a;
-  const size_t off_col = a.AddVec(col), off_scode = a.AddVec(scode);
   const size_t off_ent2 = a.AddVec(ent2), off_srow2 = a.AddVec(srow2), off_cls2 = a.AddVec(cls2);
   const size_t off_ent = a.AddVec(ent), off_cls = a.Add(u.cls, 256), off_srow = a.AddVec(srow), off_rst = a.AddVec(rst);
   const size_t off_ent4 = a.AddVec(ent4), off_srow4 = a.AddVec(srow4), off_cls4 = a.AddVec(cls4);
@@ -373,7 +346,6 @@ int UploadUs(Program* p) {
     d.nent2 = (int32_t)ent2.size();
     d.has_rewind = has_rewind ? 1 : 0;
   }
-  if (cols) { d.col = (const uint4*)(b + off_col); d.scode = b + off_scode; }
   p->usdev = d;
   p->d_arena_us = dptr;
   return RGX_OK;

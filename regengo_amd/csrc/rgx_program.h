@@ -131,17 +131,6 @@ struct UsDev {
   const uint8_t* cls2;            // [256] byte -> class | 0x80 on reset bytes
   int32_t nent2;                  // (nstates + 1) * 257
   int32_t has_rewind;             // the pair table's rewind row (row 1) can be entered: the kernel instance that handles rewinds in its fast walk
-  // simple automata with at most 15 states besides the dead one and at most 15 classes: the transition function PER CLASS as a column
-  // of 4-bit next states (scan_us_col_kernel).  State codes: the automaton's own state number, 0 = "died with an older match
-  // pending" (the rewind row of the images above; also the inert code of a lane outside its stretch).  col[c] for class code c
-  // (ncls = end of text, 15 = "no byte": every state stays, no flag):
-  //   .x .y   next-state nibbles: code q -> bits [4q, 4q+4)         .z   bit q: load (a thread that began at this byte survived it),
-  //   bit 16+q: final (a match ends at this byte for good)           .w   bit q: a match ends here (single-step walker, rewinds),
-  //   bit 16+q: the walk is over (end of the text)
-  // The look-up address depends on the INPUT BYTE only -- the loads of a whole trip are issued together and the chain from state to
-  // state is two VALU operations (shift, mask) instead of an LDS round trip.
-  const uint4* col;               // [16] or nullptr
-  const uint8_t* scode;           // [ncls+1]: start state code after a byte of this class (index ncls: offset 0 of the text)
 };
 
 // Device image of the reference's Tagged DFA (rgx_dfa.h: RefTdfa; tdfa.go:584-794 emits the same content as Go array literals).

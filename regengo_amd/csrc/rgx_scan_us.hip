@@ -1085,6 +1085,18 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
 
   const int tid = threadIdx.x;
   const int ncls = U.ncls;
+  if (P.census) {
+    // residency census (LaunchScanUs): this very kernel with this very LDS footprint -- do gridDim.x workgroups run at the same time?
+    if (tid == 0) {
+      __hip_atomic_fetch_add(P.census, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const long long t0 = wall_clock64();                          // 100 MHz
+      bool all = false;
+      while (!(all = __hip_atomic_load(P.census, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= gridDim.x) && wall_clock64() - t0 < 50000)
+        __builtin_amdgcn_s_sleep(16);
+      if (all) __hip_atomic_fetch_add(P.census + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    return;
+  }
 #ifdef RGX_US_PROFILE
   long long tstamp[10];
   int nstamp = 0;
@@ -1414,458 +1426,6 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
 
 
 // =====================================================================================================================
-// Column form (round 4): simple automata with at most 15 live states and 15 classes (rgx_program.h: UsDev::col).  The pair kernel
-// above waits on its look-ups: four DEPENDENT random LDS reads per trip (next row = f(row, bytes)), each a 64-lane gather over 32
-// banks -- a third of the LDS cycles bank conflicts, 16 waves of a CU sharing the pipe, ~1000 cycles a trip.
-// Here the table is indexed by the input byte alone: a 16-byte record per class holds the whole transition function of that class
-// as 4-bit next states (plus the load / final / match flags as a bit per state), so
-//   * the eight record loads of a trip are issued back to back, before any of them is needed (addresses come from the tile);
-//   * records of different classes lie 16 bytes apart: sixteen classes cover the 64 banks exactly once -- lanes on the same class
-//     broadcast, lanes on different classes never collide;
-//   * what remains of the state-to-state chain is a shift and a mask.
-// The tile holds a byte per input byte (class << 4: the record's offset).  Everything else is the pair kernel's scheme: stretches
-// between sync points, L and E bit sets, the single-step walker for rewinds and bytes outside the window, count / look-back / emit.
-constexpr int kCRow = 72;                                          // 64 tile bytes + 8: 8-byte aligned rows, a lane stride of 18 dwords
-constexpr int kCPadded = (kUWindow / 64) * kCRow;
-__device__ __forceinline__ int CPad(int rel) { return rel + ((rel >> 6) << 3); }
-
-struct UsCLayout {
-  int cls, col, scode, tile, R, L, E, sync, delta, kind, misc, total;
-};
-__host__ __device__ inline UsCLayout UsCLds() {
-  UsCLayout l;
-  int o = 0;
-  l.cls = o; o += 256;
-  l.col = o; o += 256;
-  l.scode = o; o += 16;
-  l.tile = o; o += (kCPadded + 15) & ~15;
-  l.R = o; o += (kPRWords * 4 + 15) & ~15;
-  l.L = o; o += 2 * ((kSWords * 4 + 15) & ~15);
-  l.E = o; o += 2 * ((kSWords * 4 + 15) & ~15);
-  l.sync = o; o += kBlockThreads * 4;
-  l.delta = o; o += 32 * 4;
-  l.kind = o; o += 32;
-  l.misc = o; o += 32 * 4;
-  l.total = (o + 15) & ~15;
-  return l;
-}
-
-struct CIn {
-  const uint8_t* g;
-  const uint8_t* gcls2;        // byte -> class | 0x80 on reset bytes
-  LdsU8c tile;                 // LDS: class << 4 per input byte, 72-byte rows
-  LdsU32c R;                   // LDS: reset bits over the window
-  int wb, wlim, len, eot;
-  __device__ __forceinline__ unsigned Cls(int i) const {
-    const unsigned rel = (unsigned)(i - wb);
-    if (rel < (unsigned)wlim) return (unsigned)tile[CPad((int)rel)] >> 4;
-    if (i >= len) return (unsigned)eot;
-    return gcls2[g[i]] & 15u;
-  }
-  __device__ __forceinline__ bool Reset(int i) const {
-    const unsigned rel = (unsigned)(i - wb);
-    if (rel < (unsigned)wlim) return (R[rel >> 5] >> (rel & 31u)) & 1u;
-    if (i >= len) return false;
-    return (gcls2[g[i]] & 0x80u) != 0;
-  }
-};
-
-__device__ __forceinline__ int CSliceStart(const CIn& in, const int32_t* carry_in, int k) {
-  const int a = k * kSliceBytes;
-  if (a >= in.len) return -1;
-  if (carry_in) {
-    const int c = carry_in[k];
-    if (c >= 0) return (c >= a && c < a + kSliceBytes && c < in.len) ? c : -1;
-  }
-  if (a == 0) return 0;
-  int r = -1;
-  const int rel = a - in.wb;
-  if (rel >= 32 && rel + kSliceBytes <= in.wlim) {
-    const unsigned w0 = in.R[(rel >> 5) - 1] & 0x80000000u, w1 = in.R[rel >> 5], w2 = in.R[(rel >> 5) + 1] & 0x7FFFFFFFu;
-    if (w0) r = a;
-    else if (w1) r = a + __builtin_ctz(w1) + 1;
-    else if (w2) r = a + 32 + __builtin_ctz(w2) + 1;
-  } else {
-    for (int j = a - 1; j < a + kSliceBytes - 1 && r < 0; ++j)
-      if (in.Reset(j)) r = j + 1;
-  }
-  return (r >= 0 && r < in.len) ? r : -1;
-}
-
-// single-step walker over the column records (UsPairSlow has the commentary)
-__device__ __noinline__ int UsColSlow(LdsU32c s_col, LdsU8c s_scode, LdsU32 s_L, LdsU32 s_E, LdsI32 far, const CIn in, int tb, int s,
-                                       int e, int lookahead, unsigned* over) {
-  int i = s;
-  int steps = 0;
-  unsigned q = s_scode[i > 0 ? in.Cls(i - 1) : (unsigned)in.eot];
-  int pend = -1;
-  auto set_e = [&](int at) {
-    const unsigned b = (unsigned)(at - tb);
-    if (b < (unsigned)kSBits) LdsOr(s_E + (b >> 5), 1u << (b & 31)); else *far = at;
-  };
-  for (;;) {
-  while (i <= e) {
-    if (steps >= kWalkerStepBudget) { atomicOr(over, kOverBudgetBit); return steps; }
-    const LdsU32c rp = s_col + (in.Cls(i) << 2);
-    const uint4 rec = make_uint4(rp[0], rp[1], rp[2], rp[3]);
-    const bool mt = (rec.w >> q) & 1u, fin = (rec.z >> (16 + q)) & 1u, ld = (rec.z >> q) & 1u, done = (rec.w >> (16 + q)) & 1u;
-    if (lookahead && mt) pend = i;
-    if (fin) { set_e(i); pend = -1; }
-    if (ld && i < e) {
-      const unsigned b = (unsigned)(i - tb);
-      if (b < (unsigned)kSBits) LdsOr(s_L + (b >> 5), 1u << (b & 31));
-    }
-    if (!lookahead && mt) pend = i + 1;
-    const unsigned long long N = ((unsigned long long)rec.y << 32) | rec.x;
-    q = (unsigned)(N >> (4 * q)) & 15u;
-    ++i;
-    ++steps;
-    if (done) return steps;                    // the end of the text
-    if (q == 0) {
-      if (pend < 0 || pend > e) break;
-      set_e(pend);
-      if (pend >= in.len) break;
-      i = pend;
-      q = s_scode[in.Cls(i - 1)];
-      pend = -1;
-    }
-  }
-  if (pend < 0 || pend > e) return steps;
-  set_e(pend);
-  if (pend >= e || pend >= in.len) return steps;
-  i = pend;
-  q = s_scode[in.Cls(i - 1)];
-  pend = -1;
-  }
-}
-
-template <bool RW>
-__global__ __launch_bounds__(kBlockThreads) void scan_us_col_kernel(DevTables T, UsDev U, ScanParams P) {
-  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-  const UsCLayout Ly = UsCLds();
-  unsigned char* s_cls = smem + Ly.cls;
-  uint4* s_col = reinterpret_cast<uint4*>(smem + Ly.col);
-  unsigned char* s_scode = smem + Ly.scode;
-  unsigned char* s_tile = smem + Ly.tile;
-  unsigned* s_R = reinterpret_cast<unsigned*>(smem + Ly.R);
-  constexpr int kSetBytes = (kSWords * 4 + 15) & ~15;
-  unsigned* s_L = reinterpret_cast<unsigned*>(smem + Ly.L);
-  unsigned* s_E = reinterpret_cast<unsigned*>(smem + Ly.E);
-  unsigned* s_L2 = reinterpret_cast<unsigned*>(smem + Ly.L + kSetBytes);
-  unsigned* s_E2 = reinterpret_cast<unsigned*>(smem + Ly.E + kSetBytes);
-  int* s_sync = reinterpret_cast<int*>(smem + Ly.sync);
-  int32_t* s_delta = reinterpret_cast<int32_t*>(smem + Ly.delta);
-  unsigned char* s_kind = smem + Ly.kind;
-  unsigned* s_misc = reinterpret_cast<unsigned*>(smem + Ly.misc);
-  int* s_far = reinterpret_cast<int*>(s_misc + 10);
-
-  const int tid = threadIdx.x;
-  const int ncls = U.ncls;
-#ifdef RGX_US_PROFILE
-  long long tstamp[10];
-  int nstamp = 0;
-#endif
-  if (tid < 16) s_col[tid] = U.col[tid];
-  s_cls[tid] = U.cls2[tid];
-  if (tid < 16) s_scode[tid] = tid <= ncls ? U.scode[tid] : 0;
-  if (tid < T.ncap) { s_delta[tid] = T.cap_delta[tid]; s_kind[tid] = T.cap_kind[tid]; }
-  const int len = P.len;
-  const unsigned eot = (unsigned)ncls;
-  constexpr int kMaxPieces = (kUWindow / 16 + kBlockThreads - 1) / kBlockThreads;
-  uint4 v[kMaxPieces];
-  auto issue_loads = [&](int t) {
-    const int wb_ = t * kTileBytes - kHaloL;
-    const int first = wb_ < 0 ? 0 : wb_;
-    int last = t * kTileBytes + kTileBytes + kHaloR;
-    const int len_ext = ((len >> 5) + 1) << 5;
-    if (last > len_ext) last = len_ext;
-    const int nchunks = (last - first) >> 4;
-    const uint4* gsrc = reinterpret_cast<const uint4*>(P.buf + first);
-#pragma unroll
-    for (int q = 0; q < kMaxPieces; ++q) {
-      const int c = tid + q * kBlockThreads;
-      v[q] = make_uint4(0, 0, 0, 0);
-      if (t < P.ntiles && c < nchunks && first + (c << 4) + 16 <= len) v[q] = gsrc[c];
-    }
-  };
-  if (tid == 0) s_misc[0] = P.use_tickets ? atomicAdd(&P.counters[0], 1u) : blockIdx.x;
-  __syncthreads();
-  int tile = (int)s_misc[0];
-  unsigned long long group_total = 0;
-  unsigned slow_lanes = 0;
-  UsTileOut prev{};
-  bool have_prev = false;
-  auto emit_prev = [&]() {
-    if (tid < 64) {
-      const unsigned long long excl = LookBackResolve(P.tile_desc, prev.tile, prev.block_total, tid, &P.counters[3], !P.use_tickets);
-      if (tid == 0) { s_misc[8] = (unsigned)excl; s_misc[9] = (unsigned)(excl >> 32); }
-    }
-    __syncthreads();
-    UsEmitTile(T, P, prev, ((unsigned long long)s_misc[9] << 32) | s_misc[8], s_L2, s_delta, s_kind);
-  };
-  issue_loads(tile);
- while (tile < P.ntiles) {
-  __syncthreads();
-  US_STAMP()
-  if (tid == 0) { *s_far = -1; if (P.use_tickets) s_misc[11] = atomicAdd(&P.counters[0], 1u); }
-  for (int w = tid; w < kSWords; w += kBlockThreads) { s_L[w] = 0; s_E[w] = 0; }
-  US_STAMP()
-  const int tb = tile * kTileBytes;
-  const int wb = tb - kHaloL;
-
-  // ---- stage the window: 16 input bytes -> 16 class look-ups -> 16 record offsets (class << 4) + 16 reset bits
-  int wlim;
-  {
-    const int first = wb < 0 ? 0 : wb;
-    int last = tb + kTileBytes + kHaloR;
-    const int len_ext = ((len >> 5) + 1) << 5;
-    if (last > len_ext) last = len_ext;
-    wlim = last - wb;
-    const int nchunks = (last - first) >> 4;
-#pragma unroll
-    for (int q = 0; q < kMaxPieces; ++q) {
-      const int c = tid + q * kBlockThreads;
-      if (c >= nchunks) break;
-      const int abs0 = first + (c << 4);
-      unsigned cw[4];
-      if (abs0 + 16 <= len) {
-        const unsigned w[4] = {v[q].x, v[q].y, v[q].z, v[q].w};
-#pragma unroll
-        for (int d = 0; d < 4; ++d) {
-          const unsigned x = w[d];
-          cw[d] = (unsigned)s_cls[x & 255u] | ((unsigned)s_cls[(x >> 8) & 255u] << 8) | ((unsigned)s_cls[(x >> 16) & 255u] << 16) |
-                  ((unsigned)s_cls[x >> 24] << 24);
-        }
-      } else {
-        for (int d = 0; d < 4; ++d) {
-          unsigned x = 0;
-          for (int b = 0; b < 4; ++b) {
-            const int at = abs0 + 4 * d + b;
-            x |= (at < len ? (unsigned)s_cls[P.buf[at]] : eot) << (8 * b);
-          }
-          cw[d] = x;
-        }
-      }
-      unsigned rbits = 0;
-#pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const unsigned y = (cw[d] >> 7) & 0x01010101u;
-        rbits |= ((y * 0x01020408u) >> 24 & 15u) << (4 * d);
-        cw[d] = (cw[d] & 0x0F0F0F0Fu) << 4;
-      }
-      uint2* dst = reinterpret_cast<uint2*>(s_tile + CPad(abs0 - wb));     // (rows are 8-byte aligned; a 16-byte piece never straddles one)
-      dst[0] = make_uint2(cw[0], cw[1]);
-      dst[1] = make_uint2(cw[2], cw[3]);
-      reinterpret_cast<uint16_t*>(s_R)[(abs0 - wb) >> 4] = (uint16_t)rbits;
-    }
-  }
-  US_STAMP()
-  __syncthreads();
-  US_STAMP()
-  const int next_tile = P.use_tickets ? (int)s_misc[11] : tile + (int)gridDim.x;
-  issue_loads(next_tile);
-  const CIn in{P.buf, U.cls2, (LdsU8c)s_tile, (LdsU32c)s_R, wb, wlim, len, (int)eot};
-
-  // ---- the lane's stretch [s, e] (scan_us_simple_kernel has the commentary)
-  const int slice = tile * kBlockThreads + tid;
-  const int a = tb + tid * kSliceBytes;
-  int s = CSliceStart(in, P.carry_in, slice);
-  s_sync[tid] = s;
-  __syncthreads();
-  if (s < 0 && a < len && !(P.carry_in && P.carry_in[slice] >= 0)) {
-    bool near = false;
-    for (int t = tid - 1; t >= 0 && t >= tid - kUMaxLookBehind / kSliceBytes && !near; --t) near = s_sync[t] >= 0;
-    if (!near && tid < kUMaxLookBehind / kSliceBytes) {
-      int lower = a - 1 - kUMaxLookBehind;
-      if (lower < 0) lower = 0;
-      int j = tb - 2;
-      while (j >= lower && !near) {
-        const unsigned rel = (unsigned)(j - wb);
-        if (rel < (unsigned)wlim) {
-          if (in.R[rel >> 5] & (0xFFFFFFFFu >> (31u - (rel & 31u)))) near = true;
-          else j -= (int)(rel & 31u) + 1;
-        } else {
-          if (in.Reset(j)) near = true; else --j;
-        }
-      }
-      if (!near && lower == 0) near = true;
-    }
-    if (!near) {
-      atomicAdd(&P.counters[1], 1u);
-      if (P.slice_unsynced) P.slice_unsynced[slice] = 1;
-    }
-  }
-  US_STAMP()
-  int e = 0x7FFFFFF0;
-  bool slow = false;
-  int ek = -1;
-  if (s >= 0) {
-    int t = tid + 1;
-    while (t < kBlockThreads && s_sync[t] < 0) ++t;
-    if (t < kBlockThreads) {
-      e = s_sync[t];
-      ek = tile * kBlockThreads + t;
-    } else {
-      const int k0 = (tile + 1) * kBlockThreads;
-      int found = -1;
-      const int klim = (P.carry_in && !P.carry_sync) ? 0x7FFFFFF : k0 + kSReach / kSliceBytes - 1;
-      for (int k = k0; k < klim && k * kSliceBytes < len && found < 0; ++k) { found = CSliceStart(in, P.carry_in, k); ek = k; }
-      if (found >= 0) e = found;
-      else if (!(P.carry_in && !P.carry_sync) && k0 * kSliceBytes + kSReach - kSliceBytes < len) {
-        atomicAdd(&P.counters[1], 1u);
-        if (P.slice_unsynced && k0 * kSliceBytes < len) P.slice_unsynced[k0] = 1;
-        s = -1;
-      }
-    }
-  }
-  // ---- wave-uniform walk: a trip = eight input bytes = eight record loads (independent of the state) + eight shift-and-mask steps
-  int ws = s;
-  bool rw_more = false;
-  int rw_pass = 0;
-  const unsigned char* s_colb = reinterpret_cast<const unsigned char*>(s_col);
-  do {
-    const int first_valid = wb < 0 ? 0 : wb;
-    bool fast = s >= 0 && (rw_pass == 0 || rw_more);
-    rw_more = false;
-    int e_eff = e < len ? e : len;
-    if (fast && (ws < first_valid || e_eff >= wb + wlim)) { fast = false; slow = true; }
-    const int i0 = fast ? (ws & ~7) : first_valid;
-    int ntrips = fast ? ((e_eff - i0) >> 3) + 1 : 0;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(ntrips, d, 64); ntrips = o > ntrips ? o : ntrips; }
-    const int trips = __builtin_amdgcn_readfirstlane(ntrips);
-    US_STAMP()
-    unsigned startq = 0;
-    if (fast) startq = s_scode[ws > 0 ? in.Cls(ws - 1) : eot];
-    const unsigned phase = fast ? (unsigned)(ws & 7) : 8u;      // the byte of the first trip at which the lane enters its start state
-    if (!fast) e_eff = -1;
-    unsigned q = 0, zq = 1;          // state code (0: inert / died with a match pending); zq: the code the lane parked with
-    unsigned lword = 0, eword = 0;
-    int pm = -1, pf = -1;
-    const unsigned relmax = (unsigned)(wlim - 8);
-    unsigned rel = (unsigned)(i0 - wb);
-    int kl = e_eff - i0;
-    unsigned irel = (unsigned)(i0 - tb);
-#define USC_STEP(J, R, FIRST)                                                           \
-  {                                                                                     \
-    if (FIRST) q = phase == (unsigned)(J) ? startq : q;                                 \
-    const unsigned long long N = ((unsigned long long)(R).y << 32) | (R).x;            \
-    const unsigned f = (R).z >> q;                                                      \
-    acc = (acc << 1) | (f & 0x00010001u);            /* load flag in the low half, final flag in the high half */ \
-    if (RW) macc = (macc << 1) | (((R).w >> q) & 1u);                                   \
-    q = (unsigned)(N >> (q << 2)) & 15u;                                                \
-  }
-#define USC_TRIP(FIRST)                                                                 \
-  {                                                                                     \
-    const uint2 w2 = *reinterpret_cast<const uint2*>(s_tile + rel + ((rel >> 6) << 3)); \
-    const uint4 r0 = *reinterpret_cast<const uint4*>(s_colb + (w2.x & 0xF0u));          \
-    const uint4 r1 = *reinterpret_cast<const uint4*>(s_colb + ((w2.x >> 8) & 0xF0u));   \
-    const uint4 r2 = *reinterpret_cast<const uint4*>(s_colb + ((w2.x >> 16) & 0xF0u));  \
-    const uint4 r3 = *reinterpret_cast<const uint4*>(s_colb + (w2.x >> 24));            \
-    const uint4 r4 = *reinterpret_cast<const uint4*>(s_colb + (w2.y & 0xF0u));          \
-    const uint4 r5 = *reinterpret_cast<const uint4*>(s_colb + ((w2.y >> 8) & 0xF0u));   \
-    const uint4 r6 = *reinterpret_cast<const uint4*>(s_colb + ((w2.y >> 16) & 0xF0u));  \
-    const uint4 r7 = *reinterpret_cast<const uint4*>(s_colb + (w2.y >> 24));            \
-    unsigned acc = 0, macc = 0;                                                         \
-    USC_STEP(0, r0, FIRST) USC_STEP(1, r1, FIRST) USC_STEP(2, r2, FIRST) USC_STEP(3, r3, FIRST)   \
-    USC_STEP(4, r4, FIRST) USC_STEP(5, r5, FIRST) USC_STEP(6, r6, FIRST) USC_STEP(7, r7, FIRST)   \
-    const unsigned racc = __builtin_bitreverse32(acc);                                  \
-    unsigned ln = racc >> 24, en = (racc >> 8) & 0xFFu;          /* byte j of the trip at bit j */ \
-    unsigned mn = RW ? __builtin_bitreverse32(macc) >> 24 : 0u;                         \
-    bool parking = false;                                                               \
-    if (__any(kl < 8)) {                                                                \
-      const int kc = kl < 0 ? 0 : (kl > 8 ? 8 : kl);                                    \
-      ln &= (1u << kc) - 1u;                                                            \
-      en &= kl < 0 ? 0u : (2u << kc) - 1u;                                              \
-      mn &= kl < 0 ? 0u : (2u << kc) - 1u;                                              \
-      parking = kl < 8;                                                                 \
-      zq = parking ? q : zq;                                                            \
-      q = parking ? 0u : q;                                                             \
-      kl = parking ? 0x3FFFFFFF : kl;                                                   \
-    }                                                                                   \
-    if (RW) {                                                                           \
-      if (mn) pm = tb + (int)irel + 31 - __builtin_clz(mn);                             \
-      if (en) pf = tb + (int)irel + 31 - __builtin_clz(en);                             \
-    }                                                                                   \
-    const unsigned sh = irel & 31u;                                                     \
-    lword |= ln << sh;                                                                  \
-    eword |= en << sh;                                                                  \
-    const bool flush = parking || (sh == 24u && kl < 0x30000000);                       \
-    if (__any(flush)) {                                                                 \
-      if (flush) {                                                                      \
-        const unsigned wi = irel >> 5 > (unsigned)(kSWords - 1) ? (unsigned)(kSWords - 1) : irel >> 5; \
-        if (lword) atomicOr(&s_L[wi], lword);                                           \
-        if (eword) atomicOr(&s_E[wi], eword);                                           \
-        lword = 0; eword = 0;                                                           \
-      }                                                                                 \
-    }                                                                                   \
-    kl -= 8;                                                                            \
-    irel += 8;                                                                          \
-    rel += 8;                                                                           \
-    rel = rel > relmax ? relmax : rel;                                                  \
-  }
-    if (trips > 0) USC_TRIP(true)
-    for (int t = 1; t < trips; ++t) USC_TRIP(false)
-#undef USC_STEP
-#undef USC_TRIP
-    const bool carry_end = P.carry_in != nullptr && !P.carry_sync && ek >= 0 && found_carry(P.carry_in, ek);
-    const bool zpark = fast && zq == 0u;
-    if (RW && !carry_end) {
-      if (zpark) {
-        const bool pending = pm >= 0 && (U.lookahead ? pm > pf : pm >= pf);
-        const int pend = U.lookahead ? pm : pm + 1;
-        if (pending && pend <= e_eff) {
-          const unsigned b = (unsigned)(pend - tb);
-          if (b < (unsigned)kSBits) atomicOr(&s_E[b >> 5], 1u << (b & 31)); else *s_far = pend;
-          if (pend < len) { ws = pend; rw_more = true; }
-        }
-      }
-    } else if (fast && (zpark || carry_end)) {
-      slow = true;
-    }
-    ++rw_pass;
-  } while (RW && rw_pass < 6 && __any(rw_more));
-  if (RW && rw_more) slow = true;
-  US_STAMP()
-  slow_lanes += (slow && s >= 0) ? 1u : 0u;
-  if (slow && s >= 0)
-    UsColSlow((LdsU32c)s_col, (LdsU8c)s_scode, (LdsU32)s_L, (LdsU32)s_E, (LdsI32)s_far, in, tb, RW ? ws : s, e < len ? e : len, U.lookahead, &P.counters[3]);
-  __syncthreads();
-  US_STAMP()
-  if (have_prev) emit_prev();
-  {
-    const UsTileOut o = UsCountTile(P, tile, tb, len, s_L, s_E, s_misc, *s_far);
-    group_total += o.block_total;
-    if (!P.count_only) {
-      LookBackPublish(P.tile_desc, tile, o.block_total, tid);
-      prev = o;
-      have_prev = o.block_total != 0;
-    }
-    unsigned* t1 = s_L; s_L = s_L2; s_L2 = t1;
-    unsigned* t2 = s_E; s_E = s_E2; s_E2 = t2;
-  }
-  US_STAMP()
-#ifdef RGX_US_PROFILE
-  if ((blockIdx.x == 200 || blockIdx.x == 901) && (tid == 0 || tid == 130) && tile > 20000 && tile < 22000)
-    printf("COL blk %d tid %d tile %d: s %d e %d slow %d | zero %lld | stage %lld | barrier %lld | sync search %lld | end+setup %lld | walk %lld | slow+barrier %lld | finish %lld\n",
-           blockIdx.x, tid, tile, s - tb, (e < len ? e : len) - tb, (int)slow, tstamp[1] - tstamp[0], tstamp[2] - tstamp[1], tstamp[3] - tstamp[2], tstamp[4] - tstamp[3], tstamp[5] - tstamp[4],
-           tstamp[6] - tstamp[5], tstamp[7] - tstamp[6], tstamp[8] - tstamp[7]);
-  nstamp = 0;
-#endif
-  tile = next_tile;
- }
-  if (have_prev) { __syncthreads(); emit_prev(); }
-  if (tid == 0 && group_total) atomicAdd(P.total, group_total);
-  {
-    unsigned n = slow_lanes;
-#pragma unroll
-    for (int d = 32; d >= 1; d >>= 1) n += __shfl_xor(n, d, 64);
-    if ((tid & 63) == 0 && n) atomicAdd(&P.counters[2], n);
-  }
-}
-
-
-// =====================================================================================================================
 // Linear-time carry pass.  The other kernels' carry_kernel (rgx_kernels.hip) resolves slices without a sync point by replaying
 // the reference's loop -- an attempt per start position, quadratic in the length of a run without sync points (a 5 KB word took
 // it 5 s: one lane, tables in global memory).  With the start-tracking automaton the same answer is ONE walk over the run:
@@ -1969,8 +1529,6 @@ bool UseUsKernel(const DevTables& T, int32_t len, bool use_w) {
 int UsKernelVariant(const DevTables& T) {
   const UsDev& U = *T.us;
   static const bool no_simple = ExpEnv("RGX_NO_US_SIMPLE") != nullptr, no_pairs = ExpEnv("RGX_NO_US_PAIRS") != nullptr;
-  static const bool no_col = ExpEnv("RGX_NO_US_COL") != nullptr;
-  if (U.col && !no_simple && !no_col) return 7;
   if (U.ent2 && !no_simple && !no_pairs) return 6;
   if (U.ent4 && !no_simple) return 5;
   return 4;
@@ -1981,49 +1539,21 @@ hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t str
   dim3 grid(P.ntiles), block(kBlockThreads);
   static const bool no_simple = ExpEnv("RGX_NO_US_SIMPLE") != nullptr;
   static const bool no_pairs = ExpEnv("RGX_NO_US_PAIRS") != nullptr;
-  static const bool no_col = ExpEnv("RGX_NO_US_COL") != nullptr;
-  if (U.col && !no_simple && !no_col) {
-    // column form: the same persistent-workgroup launch as the pair kernel below; its LDS footprint does not depend on the pattern
-    const bool rw = U.has_rewind != 0 && P.us_rewind != 0;
-    const void* const fn = rw ? (const void*)scan_us_col_kernel<true> : (const void*)scan_us_col_kernel<false>;
-    const size_t shc = (size_t)UsCLds().total;
-    static std::mutex mu;
-    static int per_cu_c[2] = {0, 0};
-    static int ncu_c = 0;
-    int per_cu = 0;
-    {
-      std::lock_guard<std::mutex> lock(mu);
-      if (ncu_c == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu_c, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu_c <= 0) ncu_c = 256;
-      }
-      if (per_cu_c[rw] == 0) {
-        const hipError_t ae = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (ae != hipSuccess) return ae;
-        int q = 0;
-        hipError_t oe = rw ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, scan_us_col_kernel<true>, kBlockThreads, shc)
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, scan_us_col_kernel<false>, kBlockThreads, shc);
-        if (oe != hipSuccess || q < 1) q = 1;
-        if (q > 4) q = 4; else if (q > 2) q -= 1;          // (the margin of the pair kernel: the query over-reports by one for SGPR-heavy kernels)
-        if (ExpEnv("RGX_US_PER_CU")) q = atoi(ExpEnv("RGX_US_PER_CU"));
-        per_cu_c[rw] = q;
-      }
-      per_cu = per_cu_c[rw];
-    }
-    int nblk = per_cu * ncu_c;
-    if (nblk > P.ntiles) nblk = P.ntiles;
-    if (rw) hipLaunchKernelGGL(scan_us_col_kernel<true>, dim3(nblk), block, shc, stream, T, U, P);
-    else hipLaunchKernelGGL(scan_us_col_kernel<false>, dim3(nblk), block, shc, stream, T, U, P);
-    return hipGetLastError();
-  }
   if (U.ent2 && !no_simple && !no_pairs) {
     const bool rw = U.has_rewind != 0 && P.us_rewind != 0;
     const void* const fn = rw ? (const void*)scan_us_pair_kernel<true> : (const void*)scan_us_pair_kernel<false>;
-    static bool attr2[2] = {false, false};
-    if (!attr2[rw]) {
-      const hipError_t ae = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (ae != hipSuccess) return ae;
-      attr2[rw] = true;
+    {
+      // (the attribute is per device: several devices in one process, rgx_sharded_create, each need it once)
+      static std::mutex amu;
+      static unsigned long long attr_devs[2] = {0, 0};
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+      std::lock_guard<std::mutex> lock(amu);
+      if (!((attr_devs[rw] >> (dev & 63)) & 1ull)) {
+        const hipError_t ae = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (ae != hipSuccess) return ae;
+        attr_devs[rw] |= 1ull << (dev & 63);
+      }
     }
     // persistent workgroups: no more than the chip holds at once (the occupancy query is known to over-report by one for
     // SGPR-heavy kernels, and a workgroup that is not resident would stall every look-back behind it until the bounded spin
@@ -2032,26 +1562,51 @@ hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t str
     // residency depends on the pattern's table size: asked per LDS footprint (and remembered), never carried over from another
     // pattern -- a grid sized for a small table deadlocks the look-back of a large one until the bounded spin gives up (1.4 s)
     static std::mutex mu;
-    static std::map<size_t, int> per_cu_of;     // key: LDS footprint * 2 + kernel instance
-    static int ncu = 0;
-    int per_cu = 0;
+    static std::map<size_t, int> per_cu_of;     // key: (LDS footprint * 2 + kernel instance) * 64 + device
+    static std::map<int, int> ncu_of;
+    int per_cu = 0, ncu = 0;
     {
       std::lock_guard<std::mutex> lock(mu);
-      if (ncu == 0) {
-        int dev = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || ncu <= 0) ncu = 256;
+      int dev = 0;
+      if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+      auto nit = ncu_of.find(dev);
+      if (nit == ncu_of.end()) {
+        int n = 0;
+        if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+        nit = ncu_of.emplace(dev, n).first;
       }
-      auto it = per_cu_of.find(shp * 2 + (rw ? 1 : 0));
+      ncu = nit->second;
+      const size_t key = (shp * 2 + (rw ? 1 : 0)) * 64 + (size_t)(dev & 63);
+      auto it = per_cu_of.find(key);
       if (it == per_cu_of.end()) {
         int q = 0;
         hipError_t oe = rw ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, scan_us_pair_kernel<true>, kBlockThreads, shp)
                            : hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, scan_us_pair_kernel<false>, kBlockThreads, shp);
         if (oe != hipSuccess || q < 1) q = 1;
-        // 4 per CU measured best (16 waves: 3 leaves the SIMDs idle, 5 adds nothing); the SGPR count admits 6, so 4 is resident
-        // with a margin even where the query over-reports by one; below that, one less than the query says
-        if (q > 4) q = 4; else if (q > 2) q -= 1;
+        // 4 per CU measured best (16 waves: 3 leaves the SIMDs idle -- 0.78 against 0.88 ms per GiB for the URL pattern --, 5 adds
+        // nothing).  How many are really resident is ASKED of the device (round 4): the occupancy query is known to over-report by one
+        // for SGPR-heavy kernels, the old rule ("one less than the query says") therefore ran 3 where 4 fit, and a grid that is not
+        // resident stalls every look-back behind it until the bounded spin gives up.  A census launch of this very kernel with this
+        // very footprint (ScanParams::census: ~50 us, once per footprint and device) settles it.
+        if (q > 4) q = 4;
         if (ExpEnv("RGX_US_PER_CU")) q = atoi(ExpEnv("RGX_US_PER_CU"));
-        it = per_cu_of.emplace(shp * 2 + (rw ? 1 : 0), q).first;
+        uint32_t* d_census = nullptr;
+        if (q > 1 && hipMalloc((void**)&d_census, 8) == hipSuccess) {
+          for (; q > 1; --q) {
+            ScanParams C = P;
+            C.census = d_census;
+            uint32_t h[2] = {0, 0};
+            if (hipMemsetAsync(d_census, 0, 8, stream) != hipSuccess) { q = 1; break; }
+            if (rw) hipLaunchKernelGGL(scan_us_pair_kernel<true>, dim3(q * ncu), block, shp, stream, T, U, C);
+            else hipLaunchKernelGGL(scan_us_pair_kernel<false>, dim3(q * ncu), block, shp, stream, T, U, C);
+            if (hipMemcpyAsync(h, d_census, 8, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { q = 1; break; }
+            if (h[1] == (uint32_t)(q * ncu)) break;            // every workgroup saw every other one: q per CU are resident
+          }
+          (void)hipFree(d_census);
+        } else if (q > 2) {
+          q -= 1;
+        }
+        it = per_cu_of.emplace(key, q).first;
       }
       per_cu = it->second;
     }
