@@ -388,8 +388,11 @@ int64_t rgx_count_chunk(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* 
  * right halo: rgx_info.max_match_len bytes (so that an owned match and the byte behind it fit), 1 MiB for unbounded patterns
  * (the reference's own leftover cap, streaming.go:87-96) -- rgx_shard_plan does this arithmetic for a buffer of known length.
  * The answer per rank (rgx_shard_round): its count; `unsynced` = the left halo held no sync point, nothing of this window is
- * vouched for (count 0): hand the window in again with a wider halo; `truncated` = unbounded pattern and the last owned match
- * touches the end of a window that is not the stream's last.  Semantics: FindAllBytes over the whole stream -- the reference's
+ * vouched for (count 0): hand the window in again with a wider halo; `truncated` = unbounded pattern, a window that is not the
+ * stream's last, and an owned match may reach past it -- its right halo holds no byte on which every state dies (behind such a byte
+ * no owned match goes on), or the last owned match ends exactly where the window ends (the scan took that for the end of the text:
+ * `$` fired, a greedy match stopped): the rows of this window are not vouched for, hand it in again with a wider right halo
+ * (rgx_sharded_find_all_bytes does so itself, 16x per attempt).  Semantics: FindAllBytes over the whole stream -- the reference's
  * FindReader differs from that by its chunk protocol (matches straddling a chunk end beyond MaxLeftover are cut or lost);
  * programs in reference mode whose FindAll is not offered are refused here like everywhere.                                 */
 typedef struct rgx_sharded rgx_sharded;
@@ -445,7 +448,9 @@ int64_t rgx_sharded_rows(const rgx_sharded* s, int local_index, const int32_t** 
  * copy (what a Go caller takes).  *d_rows = where the table is; returns its rows (0 on the other ranks).                      */
 int64_t rgx_sharded_gather(rgx_sharded* s, int dst_rank, int64_t* d_dst, int64_t* h_dst, size_t cap_records, const int64_t** d_rows);
 /* FindAllBytes(input, n) of one host buffer cut across the local devices (rgx_sharded_create only): plan, stage, scan, rows back
- * in order with buffer-absolute int32 offsets.  Same contract as rgx_find_all_bytes.                                          */
+ * in order with buffer-absolute int32 offsets.  Same contract as rgx_find_all_bytes -- windows that report `unsynced` or
+ * `truncated` are scanned again with wider halos until every owned match is vouched for.  Calls on one handle are serialised
+ * inside (the generated FindAll*Append may be called by several goroutines).                                                    */
 int64_t rgx_sharded_find_all_bytes(rgx_sharded* s, const uint8_t* buf, size_t len, int64_t n, int32_t* spans, size_t cap_records,
                                    rgx_result* res);
 

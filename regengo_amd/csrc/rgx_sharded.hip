@@ -69,10 +69,17 @@ Rccl* LoadRccl() {
   static Rccl r;
   static std::once_flag once;
   std::call_once(once, [] {
-    // a process that already holds a copy (PyTorch ships one under the same SONAME) gets that one
-    for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
-      r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-      if (r.h) break;
+    // RGX_SHARDED_CCL_LIB=<path>: another implementation of the ten nccl* entry points used here (tests/ccl_shim.c: two PROCESSES on
+    // one device over POSIX shared memory, so that the multi-rank protocol below runs on a one-GPU box); otherwise RCCL -- a process
+    // that already holds a copy (PyTorch ships one under the same SONAME) gets that one
+    const char* over = getenv("RGX_SHARDED_CCL_LIB");
+    if (over && *over) {
+      r.h = dlopen(over, RTLD_NOW | RTLD_LOCAL);
+    } else {
+      for (const char* name : {"librccl.so.1", "/opt/rocm/lib/librccl.so.1", "librccl.so"}) {
+        r.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (r.h) break;
+      }
     }
     if (!r.h) return;
 #define SYM(field, sym) r.field = reinterpret_cast<decltype(r.field)>(dlsym(r.h, sym)); if (!r.field) return;
@@ -198,6 +205,31 @@ int GrowBytes(uint8_t** p, size_t* cap, size_t need) {
   return RGX_OK;
 }
 
+// The right edge of a window that is not the stream's last, unbounded pattern: the scan took the window's end for the end of the text
+// -- `$`, `\z`, a trailing `\b` fire there, a greedy match stops there, a match whose last byte lies beyond is not found at all.  None
+// of that touches an OWNED match when the right halo holds a byte on which every state dies at or behind own_hi - 1 (no owned match
+// reaches past it).  Otherwise the window is reported `truncated` -- also when the last owned row ends at the window's end -- and the
+// caller hands it in again with a wider right halo (rgx_sharded_find_all_bytes does; rgx.h: rgx_shard_round).
+int RightEdge(Shard& sh, Slot& s, const rgx_shard_window& w, const uint8_t* d_buf, const int32_t* d_spans, int64_t count, hipStream_t st,
+              int* truncated) {
+  *truncated = 0;
+  if (sh.info.max_match_len >= 0 || w.last) return RGX_OK;
+  const long long from = w.own_hi > 0 ? w.own_hi - 1 : 0;
+  unsigned f = 0;
+  if (sh.has_reset && (long long)w.len > from) {
+    HIP_TRY(hipMemsetAsync(s.d_flag + 1, 0, 4, st));
+    const long long n = (long long)w.len - from;
+    hipLaunchKernelGGL(halo_sync_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 1024)), dim3(256), 0, st, d_buf + from, n,
+                       sh.d_reset, s.d_flag + 1);
+    HIP_TRY(hipMemcpyAsync(&f, s.d_flag + 1, 4, hipMemcpyDeviceToHost, st));
+  }
+  int32_t e = 0;
+  if (d_spans && count > 0) HIP_TRY(hipMemcpyAsync(&e, d_spans + (size_t)(count - 1) * sh.info.ncap + 1, 4, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  *truncated = (!f || (size_t)e >= w.len) ? 1 : 0;
+  return RGX_OK;
+}
+
 int RunJob(Slot& s) {
   Shard& sh = *s.shard;
   const Job& j = s.job;
@@ -239,7 +271,7 @@ int RunJob(Slot& s) {
     if (c < 0) return (int)c;
     r.count = c;
     r.kernel_ms = res.kernel_ms;
-    return RGX_OK;
+    return RightEdge(sh, s, w, d_buf, nullptr, 0, st, &r.truncated);
   }
   int32_t* d_spans = w.d_spans;
   size_t cap_records = w.cap_records;
@@ -266,12 +298,7 @@ int RunJob(Slot& s) {
   r.d_rows = d_spans;
   r.base = w.base;
   r.kernel_ms = res.kernel_ms;
-  if (sh.info.max_match_len < 0 && !w.last && r.count > 0) {
-    int32_t e = 0;
-    HIP_TRY(hipMemcpyAsync(&e, d_spans + (size_t)(r.count - 1) * ncap + 1, 4, hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    r.truncated = (size_t)e >= w.len;
-  }
+  if ((rc = RightEdge(sh, s, w, d_buf, d_spans, r.count, st, &r.truncated)) != RGX_OK) return rc;
   return RGX_OK;
 }
 
@@ -319,11 +346,13 @@ bool TryAsync(Shard& sh, Slot& s, const Job& j) {
   s.async_halo = false;
   if (!w.starts_at_sync) {
     if (w.own_lo <= 0 || !sh.has_reset) { s.res.unsynced = 1; s.async = true; s.ajob = j; s.ajob.have = false; return true; }
+    // (its own flag word, d_flag[2]: when rgx_find_all_submit declines below, the slot's thread repeats the check on ITS stream with
+    // d_flag[0] -- the two must not share a word)
     s.h_flag[0] = 0;
-    if (hipMemsetAsync(s.d_flag, 0, 4, st) != hipSuccess) return false;
+    if (hipMemsetAsync(s.d_flag + 2, 0, 4, st) != hipSuccess) return false;
     const long long n = w.own_lo;
-    hipLaunchKernelGGL(halo_sync_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 1024)), dim3(256), 0, st, w.buf, n, sh.d_reset, s.d_flag);
-    if (hipMemcpyAsync(s.h_flag, s.d_flag, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
+    hipLaunchKernelGGL(halo_sync_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 1024)), dim3(256), 0, st, w.buf, n, sh.d_reset, s.d_flag + 2);
+    if (hipMemcpyAsync(s.h_flag, s.d_flag + 2, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
     s.async_halo = true;
   }
   const int rc = rgx_find_all_submit(sh.prog, sh.actx, w.buf, w.len, -1, d_spans, cap, w.own_lo, w.own_hi);
@@ -356,6 +385,8 @@ struct rgx_sharded {
   bool rank_mode = false, use_rccl = false;
   int head = 0, inflight = 0;                       // rounds: slot = round index & 1
   int pend_slot[2] = {0, 0};
+  std::mutex call_mu;                               // rgx_sharded_find_all_bytes: one call at a time (the generated stub's FindAll*Append is a
+                                                    // value-receiver method that goroutines may call concurrently on the ONE process-wide handle)
   // the last waited round, for rows / gather
   int last_slot = -1;
   std::vector<rgx_shard_round> last;                // [world]
@@ -590,13 +621,21 @@ RGX_API int64_t rgx_sharded_round_wait(rgx_sharded* s, int stop_request, rgx_sha
     Rccl* R = LoadRccl();
     Shard* sh = s->local[0];
     const rgx_shard_round& m = s->last[(size_t)sh->rank];
-    HIP_TRY(hipSetDevice(sh->device));
+    // No early return before the collective: a rank that leaves here strands its peers inside ncclAllGather.  A local failure
+    // (device, copy) is recorded, travels as this rank's status if the copy still works, and the all-gather is entered regardless.
+    auto note = [&](hipError_t e, const char* what) {
+      if (e != hipSuccess && rc == RGX_OK) { rc = RGX_E_HIP; SetError(std::string(what) + ": " + hipGetErrorString(e)); }
+    };
+    note(hipSetDevice(sh->device), "hipSetDevice");
     sh->h_x[0] = m.count;
     sh->h_x[1] = (m.have ? 1 : 0) | (m.unsynced ? 2 : 0) | (m.stop ? 4 : 0) | (m.truncated ? 8 : 0);
     sh->h_x[2] = s->last_base[(size_t)sh->rank];
     sh->h_x[3] = rc;
-    HIP_TRY(hipMemcpyAsync(sh->d_x, sh->h_x, 32, hipMemcpyHostToDevice, sh->cstream));
-    NCCL_TRY(R, R->AllGather(sh->d_x, sh->d_x + 4, 4, ncclInt64, sh->comm, sh->cstream));
+    note(hipMemcpyAsync(sh->d_x, sh->h_x, 32, hipMemcpyHostToDevice, sh->cstream), "hipMemcpyAsync(exchange)");
+    {
+      const ncclResult_t nr = R->AllGather(sh->d_x, sh->d_x + 4, 4, ncclInt64, sh->comm, sh->cstream);
+      if (nr != ncclSuccess) { SetError(std::string("ncclAllGather: ") + R->GetErrorString(nr)); return RGX_E_HIP; }
+    }
     HIP_TRY(hipMemcpyAsync(sh->h_x + 4, sh->d_x + 4, (size_t)world * 32, hipMemcpyDeviceToHost, sh->cstream));
     HIP_TRY(hipStreamSynchronize(sh->cstream));
     for (int r = 0; r < world; r++) {
@@ -726,6 +765,7 @@ RGX_API int64_t rgx_sharded_find_all_bytes(rgx_sharded* s, const uint8_t* buf, s
                                            rgx_result* res) {
   if (!s || (!buf && len) || (!spans && cap_records)) return RGX_E_INVALID;
   if (s->rank_mode) { SetError("one process per device: the caller cuts the input itself (rgx_shard_plan + rgx_sharded_round)"); return RGX_E_UNSUPPORTED; }
+  std::lock_guard<std::mutex> call_lock(s->call_mu);
   if (s->inflight) { SetError("rounds in flight"); return RGX_E_INVALID; }
   const int parts = (int)s->local.size();
   const rgx_info& info = s->local[0]->info;
@@ -736,9 +776,13 @@ RGX_API int64_t rgx_sharded_find_all_bytes(rgx_sharded* s, const uint8_t* buf, s
   std::vector<rgx_shard_range> plan((size_t)parts);
   std::vector<rgx_shard_window> win((size_t)parts);
   std::vector<rgx_shard_round> rnd((size_t)parts);
-  int64_t halo = 4096;
+  int64_t halo = 4096, halo_r = 0;                  // halo_r: right halo of an unbounded pattern (0: the default, 1 MiB)
+  if (const char* e = getenv("RGX_SHARDED_HALO_RIGHT")) {   // tuning knob (and how the tests reach the widening loop with small texts)
+    const long long v = atoll(e);
+    if (v > 0) halo_r = v;
+  }
   for (;;) {
-    rgx_shard_plan((int64_t)len, parts, info.max_match_len, halo, 0, plan.data());
+    rgx_shard_plan((int64_t)len, parts, info.max_match_len, halo, halo_r, plan.data());
     for (int i = 0; i < parts; i++) {
       const rgx_shard_range& p = plan[(size_t)i];
       rgx_shard_window& w = win[(size_t)i];
@@ -749,11 +793,20 @@ RGX_API int64_t rgx_sharded_find_all_bytes(rgx_sharded* s, const uint8_t* buf, s
     }
     const int64_t total = rgx_sharded_round(s, win.data(), 0, 0, rnd.data());
     if (total < 0) return total;
-    bool unsynced = false;
-    for (const rgx_shard_round& r : rnd) unsynced |= r.unsynced != 0;
-    if (!unsynced) break;
-    if (halo >= (int64_t)len) { SetError("no sync point"); return RGX_E_HIP; }      // (cannot happen: win_lo == 0 starts at a sync point)
-    halo = std::min<int64_t>(halo * 16, (int64_t)len);            // a left halo without a reset byte: widen it (to the whole prefix at worst)
+    bool unsynced = false, truncated = false;
+    for (const rgx_shard_round& r : rnd) { unsynced |= r.unsynced != 0; truncated |= r.truncated != 0; }
+    if (!unsynced && !truncated) break;
+    if (unsynced) {
+      if (halo >= (int64_t)len) { SetError("no sync point"); return RGX_E_HIP; }      // (cannot happen: win_lo == 0 starts at a sync point)
+      halo = std::min<int64_t>(halo * 16, (int64_t)len);            // a left halo without a reset byte: widen it (to the whole prefix at worst)
+    }
+    if (truncated) {
+      // unbounded pattern: an owned match may reach past its window (no byte on which every state dies in the right halo, or the
+      // last owned match ends where the window ends -- there the scan saw an end of text that is none).  Widen the right halo; a
+      // window that reaches the end of the buffer is `last` and cannot be truncated, so this terminates.
+      if (halo_r >= (int64_t)len) { SetError("truncated window that reaches the end of the buffer"); return RGX_E_HIP; }
+      halo_r = std::min<int64_t>((halo_r ? halo_r : (int64_t)1 << 20) * 16, (int64_t)len);
+    }
   }
   int64_t total = 0;
   for (const rgx_shard_round& r : rnd) total += r.count;

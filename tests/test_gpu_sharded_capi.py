@@ -194,3 +194,97 @@ def test_world_of_one_through_rccl(gpu):
     env = dict(os.environ, RGX_SHARDED_FORCE_RCCL="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     r = subprocess.run([sys.executable, "-c", _RANK_SCRIPT % (ROOT, URL)], capture_output=True, text=True, timeout=600, env=env)
     assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
+
+
+def test_two_process_world(gpu, tmp_path):
+    """The multi-RANK path of the C library -- rgx_sharded_create_rank(world = 2), the per-round exchange ([count, flags, base, status]
+    through the all-gather entry point), the grouped send / recv gather to either rank, a failing rank (every rank gets the error, none
+    hangs), stop requests, count-only rounds -- as two PROCESSES on device 0.  RCCL cannot form a world of two on one GPU, so the ten
+    nccl* entry points the library dlopens come from tests/ccl_shim.c (RGX_SHARDED_CCL_LIB; staged through POSIX shared memory, every
+    wait bounded): what is under test is the library's protocol, rank arithmetic and error paths, not RCCL."""
+    torch = gpu
+    import json
+    from regengo_amd import Compiled
+    build = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(build, exist_ok=True)
+    shim = os.path.join(build, "libccl_shim.so")
+    r = subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                        os.path.join(ROOT, "tests", "ccl_shim.c"), "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-Wl,-rpath,/opt/rocm/lib", "-o", shim],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    env = dict(os.environ)
+    env["RGX_SHARDED_CCL_LIB"] = shim
+    env.pop("RGX_SHARDED_NO_RCCL", None)
+    worker = os.path.join(ROOT, "tests", "_sharded_rank_worker.py")
+    procs = [subprocess.Popen([sys.executable, worker, str(rk), str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for rk in (0, 1)]
+    outs = []
+    for p in procs:
+        try:
+            o, _ = p.communicate(timeout=420)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            pytest.fail("a rank hung")
+        outs.append(o.decode(errors="replace"))
+    assert all(p.returncode == 0 for p in procs), "\n----\n".join(outs)
+    ranks = [json.load(open(os.path.join(str(tmp_path), "rank%d.json" % rk))) for rk in (0, 1)]
+    tile = _tile()
+    data = (tile * 3)[: 2 * len(tile) + 4321]
+    buf = torch.frombuffer(bytearray(data), dtype=torch.uint8).to("cuda:0")
+    for name, pattern in (("date", DATE), ("url", URL)):
+        c = Compiled(pattern).to(0)
+        whole = c.FindAllSpans(buf)[0].cpu().numpy().astype(np.int64)
+        # the plan both ranks used: 4 windows, window k owned by rank k % 2; round rd covers windows 2 rd and 2 rd + 1
+        from regengo_amd.sharded import Sharded
+        plan = Sharded(c, devices=[0]).plan(len(data), parts=4)
+        for rd in range(2):
+            lo, hi = plan[2 * rd][0], plan[2 * rd + 1][1]
+            exp = whole[(whole[:, 0] >= lo) & (whole[:, 0] < hi)]
+            exp_counts = [int(((whole[:, 0] >= plan[2 * rd + k][0]) & (whole[:, 0] < plan[2 * rd + k][1])).sum()) for k in (0, 1)]
+            for rk in (0, 1):
+                R = ranks[rk][name]["rounds"][rd]
+                assert R["counts"] == exp_counts and R["total"] == len(exp) and R["status"] == [0, 0] and R["unsynced"] == [False, False], (name, rd, rk, R)
+            # the gathered table, on rank 0 and on rank 1: rank order = stream order, stream-absolute offsets
+            for rk in (0, 1):
+                got = [t for (r_, dst, t) in ranks[rk][name]["tables"] if r_ == rd and dst == rk]
+                assert len(got) == 1 and np.array_equal(np.array(got[0], dtype=np.int64).reshape(-1, c.ncap), exp), (name, rd, rk)
+        for rk in (0, 1):
+            res = ranks[rk][name]
+            assert res["fail"] == -1, (name, rk, res["fail"])                  # RGX_E_INVALID of rank 1's window, seen by BOTH ranks
+            assert res["stop_seen"] == [False, True]
+            w0 = int(((whole[:, 0] >= plan[0][0]) & (whole[:, 0] < plan[0][1])).sum())
+            w1 = int(((whole[:, 0] >= plan[1][0]) & (whole[:, 0] < plan[1][1])).sum())
+            assert res["after_fail_total"] == w0 + w1 and res["count_only"] == [w0, w1]
+
+
+def test_sharded_find_all_bytes_widens_truncated_windows(gpu, monkeypatch):
+    """an unbounded pattern whose owned match reaches past the right halo of a window that is not the last.  The
+    scan of that window sees an end of text that is none (`$` fires, a greedy match stops, the next shard drops the match as not
+    owned): rgx_shard_round.truncated says so and rgx_sharded_find_all_bytes scans again with a wider right halo -- the merged table
+    equals ONE scan of the whole buffer, as rgx.h promises.  (The default right halo is the reference's 1 MiB leftover cap; a match
+    longer than that is a megabyte without a sync point, which the scan kernels refuse as quadratic -- so the halo is shrunk to 4 KiB
+    here, RGX_SHARDED_HALO_RIGHT, and the match is 40 KB.)"""
+    torch = gpu
+    from regengo_amd import Compiled
+    from regengo_amd.sharded import Sharded
+    monkeypatch.setenv("RGX_SHARDED_HALO_RIGHT", "4096")
+    line = b"GET /index.html 200 alpha beta\n"
+    head = (line * (300_000 // len(line) + 1))[:300_000 - 512 - 1] + b"\n"
+    run = b"x" * 40_000                                  # one match of 40 KB that starts 512 bytes before the edge of the two shards
+    data = head + run + b" tail\n"
+    data += (line * (600_000 // len(line)))[: 600_000 - len(data)]
+    buf = torch.frombuffer(bytearray(data), dtype=torch.uint8).to("cuda:0")
+    for pattern in (r"(?P<w>[a-z]+)", r"(?P<l>[^\n]+)", r"(?P<k>x+)(?P<t> tail)?$|GET"):
+        c = Compiled(pattern).to(0)
+        assert c.info.max_match_len < 0
+        whole = c.FindAllSpans(buf)[0].cpu().numpy()
+        s = Sharded(c, devices=[0, 0])
+        got, res = s.find_all_bytes(data)
+        assert res.total == len(whole) and np.array_equal(got, whole), (pattern, res.total, len(whole))
+        # the round itself reports the window as truncated (what a caller of rgx_sharded_round sees): 4 KiB of right halo inside the run
+        lo, hi = 0, 300_000
+        total, rs = s.round([dict(buf=buf[0:hi + 4096].clone(), own=(lo, hi), base=0, starts_at_sync=True, last=False), None])
+        assert rs[0]["truncated"], pattern
+        total, rs = s.round([dict(buf=buf[0:hi + 65536].clone(), own=(lo, hi), base=0, starts_at_sync=True, last=False), None])
+        assert not rs[0]["truncated"], pattern
+        s.close()
