@@ -155,33 +155,67 @@ def base_line(env, args, value, ms_per_step, reps, dtype="u8", scaling="weak"):
 
 
 
+class ShardedStartFailed(Exception):
+    """The C-ABI sharded path did not come up on some rank (agreed by all ranks: every rank raises this together)."""
+
+
 def make_sharded(env, compiled):
     """The C library's sharded context for this rank (csrc/rgx_sharded.hip: rgx_sharded_create_rank): the communicator is the
     library's own (ncclCommInitRank inside, id made by rank 0 and carried over the launcher's process group); torch lends device
-    memory and the barrier of the timing harness, nothing on the data path."""
+    memory and the barrier of the timing harness, nothing on the data path.
+    N > 1: creation and one probe round (an empty window per rank: the round's all-gather and nothing else) run under a WATCHDOG --
+    ncclCommInitRank and the first collective are where a mis-set-up node hangs, and a hang there would cost the whole scaling
+    record.  Whether the path came up is then AGREED over the launcher's process group: either every rank goes on with it or every
+    rank raises ShardedStartFailed (the callers fall back to regengo_amd/dist.py and say so in the JSON line)."""
+    import threading
     from regengo_amd.sharded import Sharded
-    uid = None
-    if env.world > 1:
+    if env.world == 1:
+        s = Sharded(compiled, device=env.local_rank, rank=0, world=1, uid=None)
+        s.set_timing(True)
+        return s
+    box = [None]
+    try:
         box = [Sharded.unique_id() if env.rank == 0 else None]
-        env.dist.broadcast_object_list(box, src=0)
-        uid = box[0]
-    s = Sharded(compiled, device=env.local_rank, rank=env.rank, world=env.world, uid=uid)
-    s.set_timing(True)
-    return s
+    except Exception as ex:                                    # no usable librccl on rank 0: everybody learns it from the None
+        sys.stderr.write("[bench] rgx_sharded_unique_id failed: %s\n" % ex)
+    env.dist.broadcast_object_list(box, src=0)
+    uid = box[0]
+    out = {}
+
+    def work():
+        try:
+            s = Sharded(compiled, device=env.local_rank, rank=env.rank, world=env.world, uid=uid)
+            total, rs = s.round([None])                        # the exchange alone: [count 0, have 0] from every rank
+            if total != 0 or len(rs) != env.world:
+                raise RuntimeError("probe round answered %r" % ((total, rs),))
+            out["s"] = s
+        except Exception as ex:
+            out["err"] = ex
+
+    if uid is not None:
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        th.join(float(os.environ.get("RGX_BENCH_INIT_TIMEOUT", "240")))
+        if th.is_alive():
+            out["err"] = "timeout: ncclCommInitRank / the first all-gather did not return"
+    else:
+        out["err"] = "no unique id"
+    ok = 1 if "s" in out else 0
+    if not ok:
+        sys.stderr.write("[bench] C-ABI sharded path failed to start on rank %d: %s\n" % (env.rank, out.get("err")))
+    if env.allmin_int(ok) == 0:
+        raise ShardedStartFailed(str(out.get("err", "another rank failed")))
+    out["s"].set_timing(True)
+    return out["s"]
 
 # ------------------------------------------------------------------------------------------------------------------- C2
 def run_c2(env, args):
     if os.environ.get("RGX_BENCH_PATH", "capi") != "dist":
         try:
             return run_c2_capi(env, args)
-        except Exception as ex:            # e.g. no usable librccl for N>1: the round-2 path still measures the kernels
-            if env.world == 1:
-                raise
-            sys.stderr.write("[bench] C-ABI sharded path failed on rank %d (%s); falling back to regengo_amd/dist.py\n" % (env.rank, ex))
-            ok = 0
-        if env.allmin_int(ok) == 0:
+        except ShardedStartFailed as ex:   # every rank raises it together (make_sharded): the round-2 path still measures the kernels
             line = run_c2_dist(env, args)
-            line["config"]["path"] = "FALLBACK regengo_amd/dist.py over torch.distributed (the C-ABI sharded path failed to start)"
+            line["config"]["path"] = "FALLBACK regengo_amd/dist.py over torch.distributed (the C-ABI sharded path failed to start: %s)" % ex
             return line
     return run_c2_dist(env, args)
 
