@@ -157,6 +157,28 @@ bool RefFindAllOffered(const Tables& t) {
   if (t.ref_find_engine <= 0) return true;                       // plain backtracking (or no captures: nothing to differ from)
   return t.ref_find_engine == 2 && !t.can_match_empty;           // memoising backtracker: Q8 needs an empty match; TDFA: Q11
 }
+// The per-string (batch) entry points are for SHORT strings.  Every kernel behind them but the forward walk of the search automaton
+// restarts an attempt at offset after offset of a string, as the emitted loop does (find.go:545-569): quadratic in the length of one
+// string when attempts run far (`a+b|ac` over a run of a), and one lane of the device would sit on that string for minutes -- a
+// library under a Go service must not have an input that does that.  So the longest string of a batch is measured (one pass over the
+// offsets) and a batch with a string beyond the kernel's bound is REFUSED in bounded time: rgx_find_all_bytes / FindReader are the
+// entry points for long texts (their kernels carry step budgets of their own).  total_bytes <= bound: nothing to measure.
+constexpr int64_t kBatchRestartMaxLen = 4096;      // restart-loop kernels: at most ~8 M steps of one lane
+constexpr int64_t kBatchSearchMaxLen = 1 << 16;    // search-automaton kernel in reference mode: linear, but strings its replay flags go to full attempts
+int BatchLengthGuard(rgx_stream_ctx* c, const uint64_t* d_offsets, size_t nstr, int64_t bound, int64_t total_bytes_or_neg) {
+  if (total_bytes_or_neg >= 0 && total_bytes_or_neg <= bound) return RGX_OK;
+  unsigned long long* d_max = c->d_cursor + 2;     // (d_cursor: [0] trace cursor, [1] flag words, [2] this)
+  unsigned long long h = 0;
+  HIP_TRY(hipMemsetAsync(d_max, 0, 8, c->stream));
+  HIP_TRY(LaunchMaxStringLen(d_offsets, (int64_t)nstr, d_max, c->stream));
+  HIP_TRY(hipMemcpyAsync(&h, d_max, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if ((int64_t)h <= bound) return RGX_OK;
+  SetError("a string of this batch is " + std::to_string(h) + " bytes long: the per-string entry points restart an attempt per offset (quadratic in the length of one string) and take strings of at most " +
+           std::to_string(bound) + " bytes with this pattern's kernel; use rgx_find_all_bytes / rgx_find_chunk for long texts");
+  return RGX_E_UNSUPPORTED;
+}
+
 // The reference's Tagged DFA is run as it is (rgx_tdfa.hip) when the program has one (rgx_dfa.h: RefTdfa; its tag file is the record)
 bool HasRefTdfa(const Tables& t) { return t.ref_find_engine == 1 && t.tdfa.nstates > 0 && t.tdfa.ntags == t.ncap; }
 bool RefTdfaMode(const rgx_program* p) { return !(p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS) && HasRefTdfa(p->p.t) && p->p.dev.tdfa != nullptr; }
@@ -783,7 +805,7 @@ RGX_API int rgx_stream_ctx_create_on_stream(const rgx_program* p, void* hip_stre
   bool stream_ok;
   if (use_given_stream) { c->stream = (hipStream_t)hip_stream; c->own_stream = false; stream_ok = true; }
   else stream_ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
-  bool ok = stream_ok && hipMalloc((void**)&c->d_cursor, 16) == hipSuccess &&
+  bool ok = stream_ok && hipMalloc((void**)&c->d_cursor, 32) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
                         hipHostMalloc((void**)&c->h_read, 128, hipHostMallocMapped) == hipSuccess &&
             hipHostGetDevicePointer((void**)&c->h_read_dev, c->h_read, 0) == hipSuccess;
@@ -1453,6 +1475,7 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
     uint64_t h_last = 0;
     HIP_TRY(hipMemcpyAsync(&h_last, d_offsets + nstr, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (!T.anchored && (rc = BatchLengthGuard(c, d_offsets, nstr, kBatchRestartMaxLen, (int64_t)h_last)) != RGX_OK) return rc;   // (anchored: one attempt)
     if ((rc = Ensure(&c->d_trace, &c->trace_cap, (int64_t)h_last + 2 * (int64_t)nstr + 64)) != RGX_OK) return rc;
     HIP_TRY(LaunchBatchRef(T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, c->d_trace, c->stream,
                            BatchWindowFor((int64_t)h_last, (int64_t)nstr)));
@@ -1467,6 +1490,7 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
     uint64_t h_last = 0;
     HIP_TRY(hipMemcpyAsync(&h_last, d_offsets + nstr, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
+    if (ref_mode && (rc = BatchLengthGuard(c, d_offsets, nstr, kBatchSearchMaxLen, (int64_t)h_last)) != RGX_OK) return rc;
     const int64_t need = ((int64_t)h_last + 2 * (int64_t)nstr + 64 + 1) / 2 * (U->nstates <= 256 ? 1 : 2);   // in uint16 units
     int64_t need_fix = ref_mode ? (int64_t)h_last + 2 * (int64_t)nstr + 64 : 0;
     if ((rc = Ensure(&c->d_trace, &c->trace_cap, std::max(need, need_fix))) != RGX_OK) return rc;
@@ -1479,6 +1503,7 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
     HIP_TRY(hipStreamSynchronize(c->stream));
     return (int64_t)nstr;
   }
+  if (!T.anchored && (rc = BatchLengthGuard(c, d_offsets, nstr, kBatchRestartMaxLen, -1)) != RGX_OK) return rc;
   uint16_t* trace = nullptr;
   int64_t stride = 0;
   int window = 0;
@@ -1512,6 +1537,7 @@ RGX_API int64_t rgx_match_batch_device(const rgx_program* p, rgx_stream_ctx* c, 
     // reference mode: MatchBytes' restart rule and prefix skip (compiler.go:740-871); the Thompson flavour (kind 1) has no such
     // rule and takes the plain path below
     if (p->p.dev.ref_match_kind == 2) { SetError("reference-mode MatchBytes is not offered for this pattern (memoising engine): keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS"); return RGX_E_UNSUPPORTED; }
+    if (!p->p.dev.anchored && (rc = BatchLengthGuard(c, d_offsets, nstr, kBatchRestartMaxLen, -1)) != RGX_OK) return rc;
     HIP_TRY(LaunchBatchRef(p->p.dev, d_concat, d_offsets, (int64_t)nstr, d_matched, nullptr, nullptr, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     return (int64_t)nstr;
@@ -1532,6 +1558,7 @@ RGX_API int64_t rgx_match_batch_device(const rgx_program* p, rgx_stream_ctx* c, 
       return (int64_t)nstr;
     }
   }
+  if (!p->p.dev.anchored && (rc = BatchLengthGuard(c, d_offsets, nstr, kBatchRestartMaxLen, -1)) != RGX_OK) return rc;
   HIP_TRY(LaunchBatch(p->p.dev, d_concat, d_offsets, (int64_t)nstr, d_matched, nullptr, nullptr, 0, c->stream, window));
   HIP_TRY(hipStreamSynchronize(c->stream));
   return (int64_t)nstr;
@@ -1654,6 +1681,7 @@ RGX_API int64_t rgx_find_batch_multi_device(const rgx_multi* m, rgx_stream_ctx* 
   if (nstr == 0) return 0;
   if (((uintptr_t)d_concat & 15)) { SetError("input device pointer must be 16-byte aligned"); return RGX_E_INVALID; }
   HIP_TRY(hipSetDevice(m->device));
+  { const int grc = BatchLengthGuard(c, d_offsets, nstr, kBatchRestartMaxLen, -1); if (grc != RGX_OK) return grc; }      // (lines, not megabytes)
   const int64_t words = ((int64_t)nstr + 63) / 64;
   HIP_TRY(hipMemsetAsync(d_counts, 0, (size_t)m->n * 8, c->stream));
   HIP_TRY(hipMemsetAsync(d_found_bits, 0, (size_t)m->n * (size_t)words * 8, c->stream));      // the kernel writes the nonzero words only

