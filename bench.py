@@ -582,7 +582,11 @@ def run_c3(env, args):
     import numpy as np
     from regengo_amd import Compiled, synth
     nstr = args.strings
-    c = Compiled(EMAIL, name="Email").to(env.local_rank)
+    # --force-tdfa: regengo.Options.ForceTDFA -- "Email TDFA with capture tags" in BASELINE.json's words: the reference's Tagged DFA
+    # for this pattern (4 states), its own tables and find loop on the device (csrc/rgx_tdfa.hip); default: the engine the reference
+    # selects by itself, backtracking with its restart rule
+    c = Compiled(EMAIL, name="Email", force_tdfa=bool(args.force_tdfa)).to(env.local_rank)
+    assert c.info.ref_find_engine == (1 if args.force_tdfa else 0)
     data, offsets = synth.email_batch_np(nstr, seed=0x5EED0003 + env.rank)
     concat = torch.from_numpy(data).to(env.dev)
     offs = torch.from_numpy(offsets).to(env.dev)
@@ -610,6 +614,11 @@ def run_c3(env, args):
     gs = spans[:npar].cpu().numpy()
     parity = bool((gf == tf).all() and (gs[tf == 1] == ts[tf == 1]).all())
     parity_all = bool(env.allmin_int(1 if parity else 0))
+    # ... and a sample spread over the WHOLE batch against the oracle's C port of the emitted matcher (found flag + every span)
+    nsample = min(nstr, 20000)
+    sample = np.unique(np.random.default_rng(0xC3).integers(0, nstr, size=nsample))
+    sample_ok = oracle_sample_check(EMAIL, bool(args.force_tdfa), data, offsets, sample, found, spans)
+    sample_all = bool(env.allmin_int(1 if sample_ok else 0))
     nfound = int(found.sum().item())
     ms_per_step = dt / nsteps * 1e3
     value = float(nbytes) * env.world / (dt / nsteps) / 1e9
@@ -623,14 +632,17 @@ def run_c3(env, args):
                       "pattern": EMAIL, "strings_per_gpu": nstr, "bytes_per_gpu": nbytes, "mean_string_bytes": round(nbytes / nstr, 2),
                       "strings_per_second": round(nstr * env.world / (dt / nsteps)), "found_per_gpu": nfound,
                       "span_record_bytes": 4 * c.ncap, "parallelism": "shard%d (independent batches)" % env.world,
-                      "parity_generator_truth": parity_all, "parity_strings_checked": npar}
+                      "engine": "the reference's Tagged DFA (Options.ForceTDFA): rgx_tdfa.hip" if args.force_tdfa else "the reference's default for this pattern: backtracking, restart rule reproduced",
+                      "parity_generator_truth": parity_all, "parity_strings_checked": npar,
+                      "parity_rows_vs_oracle_sample": sample_all, "oracle_sample_strings": int(len(sample))}
     line["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
-                        "kernel": "batch_search_kernel + ref_fix_kernel (the call: search automaton walk, back-trace, replay of the reference attempt offsets; flagged strings finished by ref_fix_kernel)", "kernel_ms": round(k_ms, 4),
+                        "kernel": "tdfa_batch_kernel (a lane per string: the loop over start offsets, the table walk, the tag file in LDS)" if args.force_tdfa else
+                                  "batch_search_kernel + ref_fix_kernel (the call: search automaton walk, back-trace, replay of the reference attempt offsets; flagged strings finished by ref_fix_kernel)", "kernel_ms": round(k_ms, 4),
                         "algorithmic_bytes_per_launch": alg, "timed_launches": len(kms),
                         "note": "event-bracketed call: includes the launch of the call's kernels"}
     if not args.no_cpu_baseline and env.world == 1:
-        line["cpu_baseline"] = cpu_baseline_batch(EMAIL, data, offsets)
+        line["cpu_baseline"] = cpu_baseline_batch(EMAIL, data, offsets, force_tdfa=bool(args.force_tdfa))
     return line
 
 
@@ -847,7 +859,13 @@ def run_c5(env, args):
             skipped.append(i)
             continue
         try:
-            stdlib = not (e["mode"] == "line" and e.get("semantics") == "reference")
+            # reference mode (the default) wherever the library offers the entry point this pattern is run through; the rest --
+            # FindAll of the Tagged-DFA class and of memoising patterns that match empty, per-line FindBytes of memoising ones --
+            # under RGX_FLAG_STDLIB_SEMANTICS (Go regexp's answer), as the fixture says
+            if e["mode"] == "line":
+                stdlib = e.get("semantics") != "reference"
+            else:
+                stdlib = not Compiled(e["pattern"]).info.ref_findall_offered
             c = Compiled(e["pattern"], stdlib=stdlib).to(env.local_rank, ctx_of=first_prog[0])      # one context for the whole suite
         except _capi.RgxError:
             skipped.append(i)
@@ -939,6 +957,30 @@ def run_c5(env, args):
         else:
             if not (e["found_min"] * ntiles <= counts[i] <= e["found_max"] * ntiles):
                 bad.append(i)
+    # parity of the ROWS (outside the timed region): every scan-mode table and every per-line result once more, checksummed on the
+    # device (regengo_amd/rowsum.py: slot-weighted row sums, plain and index-weighted -- a row with a wrong value, in a wrong slot or
+    # at a wrong index changes them) against the closed form of the oracle's rows on three tiles extended periodically
+    from regengo_amd import rowsum
+    rows_bad, rows_checked = [], 0
+    if ntiles >= 3 and not args.no_row_check:
+        for i, e, c in progs:
+            if e.get("oracle_timeout"):
+                continue
+            if e["mode"] == "scan" and "rs" in e and i not in count_only:
+                cap = need // c.ncap
+                spans, res = c.FindAllSpans(big, out=out_flat[:cap * c.ncap].view(cap, c.ncap), capacity=cap)
+                n_exp, h1, h2 = rowsum.periodic(e["rs"]["a"], e["rs"]["u"], e["rs"]["z"], ntiles, T)
+                rows_checked += 1
+                if int(res.total) != n_exp or rowsum.device(spans) != (h1, h2):
+                    rows_bad.append(i)
+            elif e["mode"] == "line" and "ls" in e:
+                found, sp = c.FindBatchDevice(lines, offs)
+                n_exp, h = rowsum.lines_periodic(e["ls"], ntiles, e["lines"])
+                rows_checked += 1
+                if int(found.sum().item()) != n_exp or rowsum.lines_device(found != 0, sp[:, :2]) != h:
+                    rows_bad.append(i)
+    nrows_bad = int(env.allsum(len(rows_bad)))
+    nrows_checked = int(env.allsum(rows_checked))
     nbad = int(env.allsum(len(bad)))
     npat = int(env.allsum(len(progs)))
     nskip = int(env.allsum(len(skipped)))
@@ -959,6 +1001,8 @@ def run_c5(env, args):
                       "patterns": npat, "patterns_skipped": nskip, "scan_mode": int(tot_nscan), "line_mode": int(tot_nline),
                       "corpus_bytes": N, "bytes_scanned_per_step": int(total_bytes), "parallelism": "patterns round-robin over %d rank(s)" % world,
                       "count_only_patterns": int(env.allsum(len(count_only))), "parity_counts_vs_oracle_fixture": nbad == 0, "patterns_with_wrong_count": nbad,
+                      "parity_rows_vs_oracle_fixture": (nrows_bad == 0 and nrows_checked > 0) if nrows_checked or not args.no_row_check else None,
+                      "patterns_row_checked": nrows_checked, "patterns_with_wrong_rows": nrows_bad,
                       "scan_mode_mean_kernel_ms": round(tot_scan_ms / max(tot_nscan, 1), 4),
                       "line_mode_mean_call_ms": round(tot_line_ms / max(tot_nline, 1), 4),
                       "line_mode_package": None if pk is None else {"programs": len(in_pk), "launches": pk.launches, "ms_per_pass": round(pk_ms[0], 3),
@@ -1040,9 +1084,50 @@ def cpu_baseline_findall(pattern, which, adversarial, check_rows=None, check_hea
     return base
 
 
-def cpu_baseline_batch(pattern, data, offsets):
+def oracle_sample_check(pattern, force_tdfa, data, offsets, sample, found, spans):
+    """The device's found flags and span records of the strings `sample` (indices into the batch) against the oracle's C port of the
+    matcher the reference emits for the pattern: the backtracking machine with its restart rule (oracle/gen_c.py: m_find) or, under
+    ForceTDFA, the Tagged DFA (oracle/tdfa_c.py).  The oracle is the checker here, never the thing measured."""
+    import numpy as np
+    import torch
+    idx = torch.from_numpy(sample).to(found.device)
+    gf = found[idx].cpu().numpy()
+    gs = spans[idx].cpu().numpy()
+    d = np.ascontiguousarray(data)
+    if force_tdfa:
+        from oracle.tdfa_c import CTdfa
+        ct = CTdfa(pattern, force=True)
+        sub_off = np.zeros(len(sample) + 1, dtype=np.uint64)
+        lens = (offsets[sample + 1] - offsets[sample]).astype(np.uint64)
+        sub_off[1:] = np.cumsum(lens)
+        sub = np.concatenate([d[int(offsets[i]):int(offsets[i + 1])] for i in sample]) if len(sample) else np.zeros(1, dtype=np.uint8)
+        ef, er = ct.find_batch_np(sub, sub_off)
+        return bool((gf == ef).all() and (gs[ef == 1] == er[ef == 1]).all())
+    from oracle.gen_c import CMatcher
+    cm = CMatcher(pattern)
+    out = np.zeros(cm.ncap, dtype=np.int32)
+    base, optr, find = d.ctypes.data, out.ctypes.data, cm.lib.m_find
+    for k, i in enumerate(sample.tolist()):
+        ok = find(base + int(offsets[i]), int(offsets[i + 1] - offsets[i]), optr)
+        if bool(ok) != bool(gf[k]) or (ok and not (gs[k] == out).all()):
+            return False
+    return True
+
+
+def cpu_baseline_batch(pattern, data, offsets, force_tdfa=False):
     """FindBytes per string with the generated-C port (m_find), one core, on the first 2M strings of the batch."""
     import numpy as np
+    if force_tdfa:
+        from oracle.tdfa_c import CTdfa
+        ct = CTdfa(pattern, force=True)
+        n = min(len(offsets) - 1, 4_000_000)
+        t0 = time.perf_counter()
+        ef, _ = ct.find_batch_np(data[:int(offsets[n])], offsets[:n + 1])
+        dt = time.perf_counter() - t0
+        nb = int(offsets[n])
+        return {"value": round(nb / dt / 1e9, 4), "unit": "GB/s", "cores": 1, "kind": "port",
+                "sample": "first %d strings of the batch (%d bytes), the emitted Tagged-DFA find loop as C (oracle/tdfa_c.py), one call over the batch; found=%d" % (n, nb, int(ef.sum())),
+                "strings_per_second": round(n / dt), "host_cores_available": os.cpu_count()}
     from oracle.gen_c import CMatcher
     cm = CMatcher(pattern)
     n = min(len(offsets) - 1, 2_000_000)
@@ -1097,6 +1182,8 @@ def main():
     ap.add_argument("--windows", type=int, default=8, help="c4: ~1 GiB windows per GPU")
     ap.add_argument("--max-patterns", type=int, default=0, help="c5: only the first K patterns of the suite")
     ap.add_argument("--max-span-gib", type=int, default=48, help="c5: patterns whose span table would be larger are counted only")
+    ap.add_argument("--no-row-check", action="store_true", help="c5: skip the row checksums after the timed region (counts are always checked)")
+    ap.add_argument("--force-tdfa", action="store_true", help="c3: regengo.Options.ForceTDFA -- the reference's Tagged DFA for the Email pattern (BASELINE config C3's wording), run by rgx_tdfa.hip")
     ap.add_argument("--adversarial", action="store_true", help="c2: noise alphabet with digits and '-' (config C2b)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-alt", action="store_true", help="c2: skip the starts-only alternative result form (keeps profiler passes to one kernel variant)")

@@ -16,4 +16,6 @@ BENCH_PATTERNS = [
 def build_oracle() -> str:
     for p in BENCH_PATTERNS:
         gen_c.CMatcher(p)
+    from . import tdfa_c
+    tdfa_c.CTdfa(BENCH_PATTERNS[1], force=True)          # bench.py --config c3 --force-tdfa
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "_build")

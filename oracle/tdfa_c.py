@@ -1,0 +1,182 @@
+"""ORACLE (test infrastructure, not product): the reference's Tagged-DFA matcher as C -- the shape of the code the reference emits in
+Go for that engine (internal/compiler/tdfa.go: 584-794 the tables as package-level array literals `transitions [S][128]int`,
+`tagActionCount / Tags / Offsets`, `acceptStates`, `acceptStatesEOT`, `acceptAction*`; 831-994 the find loop; 998-1052 the result
+construction; streaming.go:175-244 the FindReader chunk loop around FindBytesReuse), with the tables of oracle/tdfa.py (which are
+pinned against the literal tables of the checked-in generated files, tests/test_tdfa.py).  Compiled with gcc -O2 it is the bulk
+checker for the device's Tagged-DFA path and bench.py's `cpu_baseline` ("port") for `--config c3 --force-tdfa`.  It must equal
+oracle/tdfa.py's find() (tests/test_tdfa.py).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this."""
+from __future__ import annotations
+
+import ctypes
+import hashlib
+import os
+import subprocess
+
+from . import tdfa as T
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+BUILD = os.path.join(HERE, "_build")
+
+
+def emit_c(t: T.TDFA) -> str:
+    tb = t.tables()
+    S, ntags = tb["n_states"], max(t.ncap_names, 1) * 2
+    A = max([len(a) for row in tb["tag_actions"] for a in row] + [len(a) for a in tb["accept_actions"]] + [1])
+    o = []
+    w = o.append
+    w("#include <stdint.h>\n#include <string.h>\n#define S %d\n#define NT %d\n#define A %d\n" % (S, ntags, A))
+    w("static const int16_t transitions[S][128] = {%s};\n" % ",".join("{" + ",".join(map(str, row)) + "}" for row in tb["transitions"]))
+    w("static const uint8_t tagActionCount[S][128] = {%s};\n" % ",".join("{" + ",".join(str(len(a)) for a in row) + "}" for row in tb["tag_actions"]))
+
+    def pad(acts, k):
+        return "{" + ",".join(str(acts[j][k]) if j < len(acts) else "0" for j in range(A)) + "}"
+    w("static const int16_t tagActionTags[S][128][A] = {%s};\n" % ",".join("{" + ",".join(pad(a, 0) for a in row) + "}" for row in tb["tag_actions"]))
+    w("static const int16_t tagActionOffsets[S][128][A] = {%s};\n" % ",".join("{" + ",".join(pad(a, 1) for a in row) + "}" for row in tb["tag_actions"]))
+    w("static const uint8_t acceptStates[S] = {%s};\n" % ",".join("1" if x else "0" for x in tb["accept"]))
+    w("static const uint8_t acceptStatesEOT[S] = {%s};\n" % ",".join("1" if x else "0" for x in tb["accept_eot"]))
+    w("static const uint8_t acceptActionCount[S] = {%s};\n" % ",".join(str(len(a)) for a in tb["accept_actions"]))
+    w("static const int16_t acceptActionTags[S][A] = {%s};\n" % ",".join(pad(a, 0) for a in tb["accept_actions"]))
+    w("static const int16_t acceptActionOffsets[S][A] = {%s};\n" % ",".join(pad(a, 1) for a in tb["accept_actions"]))
+    setup_b = "".join("tags[%d] = (int32_t)start; " % a[0] for a in t.initial_begin)
+    setup_a = "".join("tags[%d] = (int32_t)start; " % a[0] for a in t.initial_any)
+    w(r"""
+/* findBytesInternal (tdfa.go:831-994): 1 and out[NT] = matchTags after the result construction's fix-ups (tags[1] = end; a group
+   whose start tag is set and whose end tag is not is closed at the match end; a group whose start tag is unset reads (-1, -1):
+   its field is left untouched), or 0.  (The bytes.IndexByte prefix skip, 908-935, changes no result and is left out.) */
+int t_find(const uint8_t* input, int64_t l, int32_t* out) {
+  int32_t tags[NT], matchTags[NT];
+  int64_t matchEnd = -1;
+  for (int j = 0; j < NT; j++) matchTags[j] = -1;
+  for (int64_t start = 0; start <= l; start++) {
+    int state;
+    for (int j = 0; j < NT; j++) tags[j] = -1;
+    tags[0] = (int32_t)start;
+    if (start == 0) { state = %d; %s} else { state = %d; %s}
+    if (acceptStates[state]) { matchEnd = start; memcpy(matchTags, tags, sizeof tags); }
+    if (start == l && acceptStatesEOT[state]) { matchEnd = start; memcpy(matchTags, tags, sizeof tags); }
+    for (int64_t i = start; i < l; i++) {
+      const uint8_t c = input[i];
+      if (c >= 128) break;
+      const int nextState = transitions[state][c];
+      if (nextState < 0) break;
+      for (int a = 0; a < tagActionCount[state][c]; a++) tags[tagActionTags[state][c][a]] = (int32_t)(i + 1 - tagActionOffsets[state][c][a]);
+      state = nextState;
+      if (acceptStates[state]) {
+        for (int a = 0; a < acceptActionCount[state]; a++) tags[acceptActionTags[state][a]] = (int32_t)(i + 1 - acceptActionOffsets[state][a]);
+        matchEnd = i + 1; memcpy(matchTags, tags, sizeof tags);
+      }
+      if (i == l - 1 && acceptStatesEOT[state]) {
+        for (int a = 0; a < acceptActionCount[state]; a++) tags[acceptActionTags[state][a]] = (int32_t)(i + 1 - acceptActionOffsets[state][a]);
+        matchEnd = i + 1; memcpy(matchTags, tags, sizeof tags);
+      }
+    }
+    if (matchEnd >= 0) {
+      matchTags[1] = (int32_t)matchEnd;
+      for (int g = 1; g < NT / 2; g++) {
+        if (matchTags[2 * g] >= 0) { if (matchTags[2 * g + 1] < 0) matchTags[2 * g + 1] = matchTags[1]; }
+        else matchTags[2 * g + 1] = -1;
+      }
+      memcpy(out, matchTags, sizeof matchTags);
+      return 1;
+    }
+  }
+  return 0;
+}
+
+/* FindBytes per string of a batch (CSR offsets): found[i], rows[i][NT] */
+int64_t t_find_batch(const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found, int32_t* rows) {
+  int64_t n = 0;
+  for (int64_t i = 0; i < nstr; i++) {
+    found[i] = (uint8_t)t_find(concat + offsets[i], (int64_t)(offsets[i + 1] - offsets[i]), rows + i * NT);
+    n += found[i];
+  }
+  return n;
+}
+
+/* the inner loop of FindReader over one chunk (streaming.go:175-244 without the MaxLeftover deferral and the bytes.Index offset
+   recovery): FindBytesReuse on chunk[searchPos:], searchPos = the end of the match.  Rows are chunk-relative. */
+int64_t t_chain(const uint8_t* chunk, int64_t l, int32_t* rows, int64_t cap) {
+  int64_t n = 0, sp = 0;
+  int32_t r[NT];
+  while (sp < l) {
+    if (!t_find(chunk + sp, l - sp, r)) break;
+    if (n < cap) for (int j = 0; j < NT; j++) rows[n * NT + j] = r[j] >= 0 ? r[j] + (int32_t)sp : -1;
+    n++;
+    sp = r[1] > r[0] ? sp + r[1] : sp + 1;
+  }
+  return n;
+}
+""" % (t.start_begin, setup_b, t.start_any, setup_a))
+    return "".join(o)
+
+
+class CTdfa:
+    """gcc-compiled port of the emitted Tagged-DFA matcher of one pattern (force=True: regengo.Options.ForceTDFA)."""
+
+    def __init__(self, pattern: str, force: bool = False, opt: str = "-O2"):
+        from . import engines as E
+        from . import syntax as S
+        ast, prog = S.compile_pattern(pattern)
+        if force:
+            if prog.numcap <= 2 or not T.TDFA.supported(prog):
+                raise ValueError("no Tagged DFA for this pattern")
+            self.t = T.TDFA(prog, len(S.capture_names(ast)))
+        else:
+            self.t = T.build_for_prog(ast, prog)
+            if self.t is None or not E.select(ast, prog).catastrophic:
+                raise ValueError("the reference does not emit a Tagged DFA for this pattern")
+        self.ntags = max(self.t.ncap_names, 1) * 2
+        src = emit_c(self.t)
+        os.makedirs(BUILD, exist_ok=True)
+        h = hashlib.sha256((src + opt).encode()).hexdigest()[:16]
+        so = os.path.join(BUILD, "t_%s.so" % h)
+        if not os.path.exists(so):
+            cfile = os.path.join(BUILD, "t_%s.c" % h)
+            with open(cfile, "w") as f:
+                f.write(src)
+            subprocess.run(["gcc", opt, "-std=c11", "-fPIC", "-shared", cfile, "-o", so + ".tmp"], check=True)
+            os.replace(so + ".tmp", so)
+        import shutil
+        import tempfile
+        tmpdir = os.path.join(tempfile.gettempdir(), "rgx_oracle_%d" % os.getuid())      # (loaded from outside the tree: oracle/gen_c.py says why)
+        os.makedirs(tmpdir, exist_ok=True)
+        priv = os.path.join(tmpdir, "t_%s_%d.so" % (h, os.getpid()))
+        shutil.copyfile(so, priv + ".tmp")
+        os.replace(priv + ".tmp", priv)
+        self.lib = ctypes.CDLL(priv)
+        try:
+            os.unlink(priv)
+        except OSError:
+            pass
+        self.lib.t_find.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+        self.lib.t_find_batch.restype = ctypes.c_int64
+        self.lib.t_find_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+        self.lib.t_chain.restype = ctypes.c_int64
+        self.lib.t_chain.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
+
+    def find(self, b: bytes):
+        import numpy as np
+        arr = np.frombuffer(b, dtype=np.uint8).copy() if len(b) else np.zeros(1, dtype=np.uint8)
+        out = np.zeros(self.ntags, dtype=np.int32)
+        return out.tolist() if self.lib.t_find(arr.ctypes.data, len(b), out.ctypes.data) else None
+
+    def find_batch_np(self, data, offsets):
+        """data: uint8 array, offsets: uint64/int64 array [n + 1] -> (found uint8 [n], rows int32 [n, ntags])"""
+        import numpy as np
+        n = len(offsets) - 1
+        found = np.zeros(n, dtype=np.uint8)
+        rows = np.zeros((n, self.ntags), dtype=np.int32)
+        d = np.ascontiguousarray(data)
+        o = np.ascontiguousarray(offsets.astype(np.uint64))
+        self.lib.t_find_batch(d.ctypes.data, o.ctypes.data, n, found.ctypes.data, rows.ctypes.data)
+        return found, rows
+
+    def chain_np(self, buf):
+        import numpy as np
+        l = int(buf.size)
+        cap = l + 1
+        rows = np.empty((cap, self.ntags), dtype=np.int32)
+        n = self.lib.t_chain(np.ascontiguousarray(buf).ctypes.data, l, rows.ctypes.data, cap)
+        return rows[:n]

@@ -21,6 +21,15 @@ constexpr unsigned long long kDescValMask = (1ull << 62) - 1;
 
 // Every spin is bounded: a poll costs ~1 us, a legitimate wait is far below a millisecond.
 constexpr unsigned kLookBackSpinLimit = 50000;
+// ... and so is every spin of TICKET mode (ids from a ticket counter: a predecessor is owned by a running workgroup by construction,
+// so the wait "cannot" fail -- but a device that spins for ever cannot be taken back from the host, and a kernel killed in that state
+// takes the node with it): bounded by the 100 MHz wall clock, far beyond any legitimate wait (the slowest predecessor is a lane at its
+// step budget, a few seconds); past it the timeout flag goes up and the host reports RGX_E_HIP instead of hanging.
+constexpr long long kTicketWaitTicks = 20ll * 100000000ll;         // 20 s
+// Wall-clock deadline of a budgeted loop, checked every few thousand steps next to the step count: step budgets bound the WORK of a
+// lane, but a step costs 30 ns out of LDS and over a microsecond as a dependent global load -- the same 2^22 steps are 0.1 s or 5 s.
+constexpr long long kLaneDeadlineTicks = 4ll * 100000000ll;        // 4 s per kernel launch
+__device__ __forceinline__ bool PastDeadline(long long t0) { return (long long)wall_clock64() - t0 > kLaneDeadlineTicks; }
 
 // Bits b of a slice starting at absolute offset a whose position a+b lies in [lo, hi).
 __device__ __forceinline__ unsigned long long OwnMask(int a, int lo, int hi) {
@@ -70,8 +79,14 @@ __device__ __forceinline__ unsigned long long LookBack(unsigned long long* desc,
       if (idx >= 0) {
         d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
+        long long t0 = 0;
         while ((d >> 62) == 0) {
-          if (bounded && ++spins > kLookBackSpinLimit) { dead = true; break; }   // ticket ids cannot deadlock: wait as long as it takes
+          ++spins;
+          if (bounded && spins > kLookBackSpinLimit) { dead = true; break; }
+          if (!bounded && (spins & 1023u) == 0) {               // ticket mode: bounded by the wall clock (kTicketWaitTicks)
+            const long long now = (long long)wall_clock64();
+            if (t0 == 0) t0 = now; else if (now - t0 > kTicketWaitTicks) { dead = true; break; }
+          }
           for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(8);
           d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
@@ -112,8 +127,14 @@ __device__ __forceinline__ unsigned long long LookBackResolve(unsigned long long
       if (idx >= 0) {
         d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         unsigned spins = 0;
+        long long t0 = 0;
         while ((d >> 62) == 0) {
-          if (bounded && ++spins > kLookBackSpinLimit) { dead = true; break; }
+          ++spins;
+          if (bounded && spins > kLookBackSpinLimit) { dead = true; break; }
+          if (!bounded && (spins & 1023u) == 0) {
+            const long long now = (long long)wall_clock64();
+            if (t0 == 0) t0 = now; else if (now - t0 > kTicketWaitTicks) { dead = true; break; }
+          }
           __builtin_amdgcn_s_sleep(8);
           d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }

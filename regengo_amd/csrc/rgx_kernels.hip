@@ -133,6 +133,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = tid >> 6;
+  const long long t_launch = (long long)wall_clock64();       // the lanes' wall-clock deadline (rgx_device_util.h: kLaneDeadlineTicks)
 
   // dynamic tile id: a ticket guarantees every predecessor tile is already owned by a running workgroup,
   // which is what makes the look-back below deadlock-free without any residency assumption.
@@ -293,8 +294,9 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
       while (pos < slice_end) {
         int at;
         int end = Walk<MODE>(tab, in, T, s_ctx, pos, &at);
+        const int spent0 = spent;
         spent += at - pos + 1;
-        if (spent > kLaneStepBudget) { atomicOr(&P.counters[3], kOverBudgetBit); break; }
+        if (spent > kLaneStepBudget || ((spent >> 16) != (spent0 >> 16) && PastDeadline(t_launch))) { atomicOr(&P.counters[3], kOverBudgetBit); break; }
         if (end >= 0) {
           if (pos >= a) { mask |= 1ull << (pos - a); RGX_NOTE_END(pos, end) }
           pos = end > pos ? end : pos + 1;         // find.go:452-457
@@ -318,8 +320,9 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
         while (pos < first_valid && pos < slice_end) {
           int at;
           const int end = Walk<MODE>(tab, in, T, s_ctx, pos, &at);
+          const int spent0 = spent;
           spent += at - pos + 1;
-          if (spent > kLaneStepBudget) { over = true; atomicOr(&P.counters[3], kOverBudgetBit); break; }
+          if (spent > kLaneStepBudget || ((spent >> 16) != (spent0 >> 16) && PastDeadline(t_launch))) { over = true; atomicOr(&P.counters[3], kOverBudgetBit); break; }
           if (end >= 0) pos = end > pos ? end : pos + 1;        // (pos < wb <= a: not a start of this slice)
           else ++pos;
         }
@@ -392,8 +395,9 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
           if (s < pos) continue;
           int at;
           const int e = Walk<MODE>(tab, in, T, s_ctx, s, &at);
+          const int spent0 = spent;
           spent += at - s + 1;
-          if (spent > kLaneStepBudget) { atomicOr(&P.counters[3], kOverBudgetBit); det = 0; end_i = 0; break; }
+          if (spent > kLaneStepBudget || ((spent >> 16) != (spent0 >> 16) && PastDeadline(t_launch))) { atomicOr(&P.counters[3], kOverBudgetBit); det = 0; end_i = 0; break; }
           if (e >= 0) {
             if (s >= a) { mask |= 1ull << (s - a); RGX_NOTE_END(s, e) }
             pos = e > s ? e : s + 1;
@@ -552,8 +556,16 @@ __global__ void carry_kernel(DevTables T, const uint8_t* buf, int32_t len, const
   int cur = s;
   const int run_begin = s * kSliceBytes;
   long long budget = kCarryBudget;
+  const long long t_launch = (long long)wall_clock64();
+  long long next_clock = budget - 65536;             // the wall-clock deadline is looked at every 65536 charged steps
+  auto deadline = [&]() {
+    if (budget > next_clock) return;
+    next_clock = budget - 65536;
+    if (PastDeadline(t_launch)) budget = -1;
+  };
   // advance to the run
   while (pos < run_begin && budget > 0) {
+    deadline();
     int end = WalkGlobalCharged(T, buf, len, pos, &budget);
     pos = (end >= 0) ? (end > pos ? end : pos + 1) : pos + 1;
   }
@@ -564,6 +576,7 @@ __global__ void carry_kernel(DevTables T, const uint8_t* buf, int32_t len, const
     carry_in[cur] = pos < a ? a : pos;
     if (pos < a) pos = a;
     while (pos < e_slice && budget > 0) {
+      deadline();
       int end = WalkGlobalCharged(T, buf, len, pos, &budget);
       pos = (end >= 0) ? (end > pos ? end : pos + 1) : pos + 1;
     }

@@ -1465,6 +1465,7 @@ __global__ __launch_bounds__(64) void carry_us_kernel(DevTables T, UsDev U, cons
       a_cur += kSliceBytes;
     }
   };
+  const long long t_launch = (long long)wall_clock64();
   int budget = kWalkerStepBudget;    // (every rewind walks bytes again: rgx_device_util.h; the steps come out of global memory,
                                      // mostly cache hits on a run that is walked again and again: 0.1 - 1 us each)
   while (cur < nslices && unsynced[cur] && pos < len) {
@@ -1476,7 +1477,7 @@ __global__ __launch_bounds__(64) void carry_us_kernel(DevTables T, UsDev U, cons
     unsigned pinfo = 0;
     bool restarted = false;
     while (!restarted) {
-      if (--budget < 0) { *over_budget = 1; return; }
+      if (--budget < 0 || ((budget & 0xFFFF) == 0 && PastDeadline(t_launch))) { *over_budget = 1; return; }
       const unsigned k8 = cls8(i);
       const uint2 ent = *reinterpret_cast<const uint2*>(s_entb + (row & 0xFFFFu) + k8);
       const unsigned lo = ent.x, hi = ent.y;

@@ -8,8 +8,10 @@ mkdir -p "$(dirname "$log")"
 echo "# gpu_fuzz_seeds.sh first=$first n=$n  $(date -u +%Y-%m-%dT%H:%M:%SZ)  $(rocm-smi --showproductname 2>/dev/null | grep -m1 -i 'card series' | sed 's/.*: *//')" >> "$log"
 ok=0; to=0; bad=0
 for ((s=first; s<first+n; s++)); do
-  out=$(timeout -k 5 120 python scripts/gpu_fuzz_sweep.py $s 1 2>&1 | grep -v amdgpu.ids)
-  rc=${PIPESTATUS[0]}
+  tmp=$(mktemp)
+  timeout -k 5 120 python scripts/gpu_fuzz_sweep.py $s 1 > "$tmp" 2>&1
+  rc=$?
+  out=$(grep -v amdgpu.ids "$tmp"); rm -f "$tmp"
   echo "$out" | grep -E "MISMATCH|row|REFUSED|TOTAL|Error|error" >> "$log"
   if [ $rc -eq 0 ]; then echo "seed $s: ok" >> "$log"; ok=$((ok+1));
   elif [ $rc -eq 124 ] || [ $rc -eq 137 ]; then

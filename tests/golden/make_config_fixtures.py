@@ -9,8 +9,11 @@ This script runs the ORACLE (oracle/gen_c.py: the generated-C port of the refere
 writes what the GPU result must reproduce at any size:
 
   tests/golden/c4_url_rows.npz   A, U, Z span rows of the C4 URL pattern + the tile's sha256
-  tests/golden/c5_counts.json    per pattern of the C5 suite: len(A), len(U), len(Z) (scan mode) or the number of lines of one
-                                 tile FindBytes matches (line mode: ^/$-anchored patterns run per line)
+  tests/golden/c5_counts.json    per pattern of the C5 suite: len(A), len(U), len(Z) and the linear row checksums of the three parts
+                                 (scan mode; regengo_amd/rowsum.py: "rs" = {a, u, z: {n, S, P, W, WP}} -- what bench.py --config c5
+                                 and the full-size test compare the DEVICE's span table with, rows not counts), or the number of
+                                 lines of one tile FindBytes matches and the checksum of their (line, start, end) ("ls": {n, Q, QJ};
+                                 line mode: ^/$-anchored patterns run per line)
 
 Run from the repo root:  python tests/golden/make_config_fixtures.py     (about 10 minutes of CPU; needs gcc)
 """
@@ -27,7 +30,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 
 from oracle.gen_c import CMatcher          # noqa: E402
-from regengo_amd import _capi, codegen, synth   # noqa: E402
+from regengo_amd import _capi, codegen, rowsum, synth   # noqa: E402
 
 URL = r"(?P<full>(?P<proto>https?|ftp)://(?P<host>[\w.-]+)(?P<port>:\d+)?(?P<path>/[\w./-]*)?)"
 
@@ -88,7 +91,15 @@ def main():
                 e["lines"] = len(lines)
                 if info.ref_find_offered:
                     e["semantics"] = "reference"
-                    e["found"] = int(sum(1 for ln in lines if cm.find(ln) is not None))
+                    find = cm.find
+                    if info.ref_find_engine == 1:         # the reference emits its Tagged DFA for this pattern: that engine's FindBytes
+                        from oracle.tdfa_c import CTdfa
+                        find = CTdfa(p).find
+                        e["engine"] = "tdfa"
+                    hits = [(j, find(ln)) for j, ln in enumerate(lines)]
+                    hits = [(j, r) for j, r in hits if r is not None]
+                    e["found"] = len(hits)
+                    e["ls"] = rowsum.lines_parts([j for j, _ in hits], [(r[0], r[1]) for _, r in hits])
                 else:
                     e["semantics"] = "stdlib"
                     lo = int(sum(1 for ln in lines if cm.find_all(ln, 1)))
@@ -99,6 +110,7 @@ def main():
                 a, u, z = auz(cm, tile)
                 e["a"], e["u"], e["z"] = int(len(a)), int(len(u)), int(len(z))
                 e["ncap"] = int(info.ncap)
+                e["rs"] = {"a": rowsum.parts(a), "u": rowsum.parts(u), "z": rowsum.parts(z)}
         except Timeout:
             e["oracle_timeout"] = True
             e.setdefault("mode", "line" if info.anchored else "scan")

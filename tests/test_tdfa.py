@@ -155,3 +155,39 @@ def test_product_tables_equal_the_oracle_on_the_corpus(kats, corpus):
         for b in texts:
             assert hp.tdfa_find(b) == o.tdfa.find(b), (pat, b)
     assert seen >= 12
+
+
+def test_c_port_of_the_emitted_tdfa_equals_the_restatement(kats, corpus):
+    """oracle/tdfa_c.py (the emitted tables as C arrays + the emitted loop: bulk checker and bench.py's cpu_baseline for
+    --config c3 --force-tdfa) against oracle/tdfa.py, single finds and the FindReader chunk loop."""
+    import random
+    import zlib
+    import numpy as np
+    from oracle.tdfa_c import CTdfa
+    from tests import _fuzzgen as F
+    pats = [(c["pattern"], False) for c in kats["curated_cases"]] + [(e["pattern"], False) for e in corpus] + [(r"(?P<user>\w+)@(?P<domain>\w+)", True)]
+    seen = 0
+    for pat, force in dict.fromkeys(pats):
+        try:
+            ct = CTdfa(pat, force=force)
+        except ValueError:
+            continue
+        seen += 1
+        t = ct.t
+        tb = t.tables()
+        tb["start_any"] = t.start_any
+        rnd = random.Random(zlib.crc32(pat.encode()) ^ 99)
+        for _ in range(60):
+            b = F.tdfa_guided_text(tb, rnd, rnd.randint(0, 100))
+            assert ct.find(b) == t.find(b), (pat, b)
+        text = b" ".join(F.tdfa_guided_text(tb, rnd, rnd.randint(5, 60)) for _ in range(40))
+        rows, sp = [], 0
+        while sp < len(text):
+            r = t.find(text[sp:])
+            if r is None:
+                break
+            rows.append([x + sp if x >= 0 else -1 for x in r])
+            sp = sp + r[1] if r[1] > r[0] else sp + 1
+        got = ct.chain_np(np.frombuffer(text, dtype=np.uint8))
+        assert got.tolist() == rows, pat
+    assert seen >= 12
