@@ -1081,6 +1081,25 @@ def cpu_baseline_findall(pattern, which, adversarial, check_rows=None, check_hea
         best = d1 if best is None else min(best, d1)
     base["all_cores"] = {"value": round(n / best / 1e9, 2), "unit": "GB/s", "cores": ncores, "matches": int(sum(counts)),
                          "sample": "the same bytes cut into %d slices, one thread per host core, best of 3" % ncores}
+    # BASELINE.md 3.1 / north_star: "next to the reference Go DFA timed on the box's own host cores".  When a Go toolchain is on the
+    # box the matcher is emitted in the reference's shape AS GO (oracle/gen_go.py), built and timed on the first 256 MiB of the same
+    # bytes -- that figure then IS the baseline (kind "go"), the C port's stays beside it; no Go: kind "port", and the probe says so.
+    import shutil
+    if shutil.which("go"):
+        from oracle import gen_go
+        g = gen_go.time_find_all(pattern, buf[:min(n, 1 << 28)].tobytes(), passes=2)
+        if g and "seconds_1" in g and g.get("matches", 0) > 0:
+            port = {k: base[k] for k in ("value", "unit", "cores", "kind", "sample")}
+            gb = g["bytes"] * g["passes"]
+            base.update({"value": round(gb / g["seconds_1"] / 1e9, 4), "cores": 1, "kind": "go",
+                         "sample": "first %d bytes of the same stream, %d passes, the reference-shaped matcher emitted as Go (%s), FindAllBytes with span output, one goroutine; matches=%d"
+                                   % (g["bytes"], g["passes"], g.get("go"), g["matches"]),
+                         "go_all_cores": {"value": round(gb / g["seconds_all"] / 1e9, 2), "unit": "GB/s", "cores": g["cores"], "matches": g["matches_all"]},
+                         "c_port": port})
+        else:
+            base["go_probe"] = "go found but the Go baseline did not run: %s" % ((g or {}).get("error", "pattern not emitted as Go"))
+    else:
+        base["go_probe"] = "no Go toolchain on this box (shutil.which('go') is None): the C port of the emitted matcher is the baseline"
     return base
 
 

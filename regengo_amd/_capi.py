@@ -103,6 +103,7 @@ SYMBOLS = {
                                        C.POINTER(Result)]),
     "rgx_find_all_starts_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p,
                                               C.c_size_t, C.POINTER(Result)]),
+    "rgx_find_all_starts": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t, C.POINTER(Result)]),
     "rgx_replace_all_bytes_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int,
                                                  C.c_void_p, C.c_size_t, C.POINTER(C.c_int64), C.POINTER(Result)]),
     "rgx_replace_all_bytes": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.c_int,

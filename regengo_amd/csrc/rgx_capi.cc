@@ -1330,6 +1330,21 @@ RGX_API int64_t rgx_find_all_starts_device(const rgx_program* p, rgx_stream_ctx*
   return FindAllDevice(p, c, d_buf, len, n, d_starts, cap, false, res, true);
 }
 
+RGX_API int64_t rgx_find_all_starts(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* buf, size_t len, int64_t n, int32_t* starts,
+                                    size_t cap, rgx_result* res) {
+  int rc = CheckCtx(p, c);
+  if (rc != RGX_OK) return rc;
+  if ((rc = RefuseFindAll(p)) != RGX_OK) return rc;
+  if (n == 0 || len == 0) { if (res) { memset(res, 0, sizeof *res); res->ncap = p->p.dev.ncap; } return 0; }
+  if (!buf || (!starts && cap)) return RGX_E_INVALID;
+  if ((rc = Ensure(&c->d_in, &c->in_cap, (int64_t)len + 64)) != RGX_OK) return rc;
+  if ((rc = Ensure(&c->d_out, &c->out_cap, (int64_t)cap + 16)) != RGX_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream));
+  const int64_t w = rgx_find_all_starts_device(p, c, c->d_in, len, n, c->d_out, cap, res);
+  if (w > 0) HIP_TRY(hipMemcpy(starts, c->d_out, (size_t)w * 4, hipMemcpyDeviceToHost));
+  return w;
+}
+
 RGX_API int rgx_program_capture_template(const rgx_program* p, int32_t* offsets) {
   if (!p || !offsets) return RGX_E_INVALID;
   const Tables& t = p->p.t;
@@ -1487,10 +1502,18 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
   const DevTables* U = no_search ? nullptr : SearchTables(const_cast<Program*>(&p->p));
   if (U && BatchSearchFits(*U, T, true, d_concat)) {
     // scratch for strings longer than the LDS trace: (bytes + 2 per string) entries
+    // total bytes (scratch sizes) and, in reference mode, the longest string (the length guard): one pass over the offsets, ONE
+    // synchronisation for both
     uint64_t h_last = 0;
+    unsigned long long h_max = 0;
+    if (ref_mode) {
+      HIP_TRY(hipMemsetAsync(c->d_cursor + 2, 0, 8, c->stream));
+      HIP_TRY(LaunchMaxStringLen(d_offsets, (int64_t)nstr, c->d_cursor + 2, c->stream));
+      HIP_TRY(hipMemcpyAsync(&h_max, c->d_cursor + 2, 8, hipMemcpyDeviceToHost, c->stream));
+    }
     HIP_TRY(hipMemcpyAsync(&h_last, d_offsets + nstr, 8, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (ref_mode && (rc = BatchLengthGuard(c, d_offsets, nstr, kBatchSearchMaxLen, (int64_t)h_last)) != RGX_OK) return rc;
+    if (ref_mode && (int64_t)h_max > kBatchSearchMaxLen) return BatchLengthGuard(c, d_offsets, nstr, kBatchSearchMaxLen, -1);   // (words the refusal)
     const int64_t need = ((int64_t)h_last + 2 * (int64_t)nstr + 64 + 1) / 2 * (U->nstates <= 256 ? 1 : 2);   // in uint16 units
     int64_t need_fix = ref_mode ? (int64_t)h_last + 2 * (int64_t)nstr + 64 : 0;
     if ((rc = Ensure(&c->d_trace, &c->trace_cap, std::max(need, need_fix))) != RGX_OK) return rc;

@@ -85,11 +85,25 @@ static long long find_all(const uint8_t* input, size_t len, long long n, int32_t
   bound = len / (size_t)minlen + 1;
   if (cap > bound) cap = bound;
   if (n > 0 && (size_t)n < cap) cap = (size_t)n;
+  /* <name>Template of the emitted file: a fixed-template pattern fetches one int32 per match and rebuilds the records */
+  int32_t tmpl[64];
+  int use_starts = !g_sharded && g_info.fixed_captures && g_ncap <= 64 && rgx_program_capture_template(g_prog, tmpl) >= 0;
   for (;;) {
     rgx_result res;
     free(spans);
     spans = (int32_t*)malloc(cap * (size_t)g_ncap * sizeof(int32_t) + 16);
-    if (g_sharded) w = rgx_sharded_find_all_bytes(g_sharded, input, len, n, spans, cap, &res);
+    if (use_starts) {
+      int32_t* starts = (int32_t*)malloc(cap * sizeof(int32_t) + 16);
+      long long i;
+      int k;
+      w = rgx_find_all_starts(g_prog, ctx, input, len, n, starts, cap, &res);
+      if (w == RGX_E_UNSUPPORTED) { free(starts); use_starts = 0; continue; }
+      if (w >= 0) {
+        printf("STARTS %lld\n", w);
+        for (i = 0; i < w; i++) for (k = 0; k < g_ncap; k++) spans[i * g_ncap + k] = starts[i] + tmpl[k];
+      }
+      free(starts);
+    } else if (g_sharded) w = rgx_sharded_find_all_bytes(g_sharded, input, len, n, spans, cap, &res);
     else w = rgx_find_all_bytes(g_prog, ctx, input, len, n, spans, cap, &res);
     if (w == RGX_E_CAPACITY && (size_t)res.total > cap) { /* BEFORE the generic fallback: RGX_E_CAPACITY is negative too */
       cap = (size_t)res.total;

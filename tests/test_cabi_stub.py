@@ -80,10 +80,17 @@ def test_twin_find_all_with_capacity_retry(stub, tmp_path):
     assert rc == 0
     lines = out.decode().splitlines()
     exp = O(DATE).FindAllBytes(data)
-    assert lines[0] == "RETRY %d" % len(exp) and lines[1] == "COUNT %d" % len(exp)
-    assert [list(map(int, l.split()[1:])) for l in lines[2:]] == exp
+    # (the Date pattern is a fixed template: the stub fetches 4 bytes per match -- rgx_find_all_starts -- and rebuilds the records)
+    assert lines[0] == "RETRY %d" % len(exp) and lines[1] == "STARTS %d" % len(exp) and lines[2] == "COUNT %d" % len(exp)
+    assert [list(map(int, l.split()[1:])) for l in lines[3:]] == exp
     rc, out = _run(stub, blob, data, tmp_path, "findall", 5)
-    assert [list(map(int, l.split()[1:])) for l in out.decode().splitlines()[1:]] == exp[:5]
+    assert [list(map(int, l.split()[1:])) for l in out.decode().splitlines() if l.startswith("ROW")] == exp[:5]
+    # a pattern without a fixed template takes the full records
+    blob2, _ = _tables(tmp_path, r"(?P<k>[a-z]+)=(?P<v>\d+)", "KV")
+    d2 = b"alpha=1 beta=22 x= gamma=333 " * 2000
+    rc, out = _run(stub, blob2, d2, tmp_path, "findall", -1)
+    assert b"STARTS" not in out
+    assert [list(map(int, l.split()[1:])) for l in out.decode().splitlines() if l.startswith("ROW")] == O(r"(?P<k>[a-z]+)=(?P<v>\d+)").FindAllBytes(d2)
     # several devices in the list (the same one twice on a one-GPU box): rgx_sharded_find_all_bytes, same rows
     rc, out = _run(stub, blob, data, tmp_path, "sharded", 2, -1)
     lines = out.decode().splitlines()

@@ -193,3 +193,100 @@ def test_precompiled_replacers(built):
     code = re.sub(r"//[^\n]*", "", text)
     for m in re.finditer(r"\br\.([a-z][A-Za-z0-9]*)\(", code):
         assert m.group(1).endswith("Go"), m.group(1)
+
+
+def _go_strip(text):
+    """comments and string / rune literals out (what a lexer drops or folds), newlines kept"""
+    out, i, n = [], 0, len(text)
+    while i < n:
+        c = text[i]
+        if text.startswith("//", i):
+            j = text.find("\n", i)
+            i = n if j < 0 else j
+        elif text.startswith("/*", i):
+            j = text.find("*/", i + 2)
+            out.append("\n" * text.count("\n", i, j + 2))
+            i = j + 2
+        elif c == "`":
+            j = text.find("`", i + 1)
+            out.append('""')
+            i = j + 1
+        elif c == '"' or c == "'":
+            j = i + 1
+            while text[j] != c:
+                j += 2 if text[j] == "\\" else 1
+            out.append('""' if c == '"' else "0")
+            i = j + 1
+        else:
+            out.append(c)
+            i += 1
+    return "".join(out)
+
+
+def _go_functions(code):
+    """(name, body) of every top-level func: brace matching on stripped text"""
+    for m in re.finditer(r"^func\b[^\n]*\{\s*$", code, re.M):
+        depth, j = 0, m.end() - 1
+        start = code.rfind("{", m.start(), m.end())
+        j = start
+        while True:
+            ch = code[j]
+            if ch == "{":
+                depth += 1
+            elif ch == "}":
+                depth -= 1
+                if depth == 0:
+                    break
+            j += 1
+        yield m.group(0), code[start:j + 1]
+
+
+@pytest.mark.parametrize("name,pattern", CASES + [("Nested", r"(?P<w>(a+)+)b"), ("KV", r"(?P<k>[a-z]+)=(?P<v>\d+)")])
+def test_emitted_go_passes_the_checks_a_compiler_front_end_makes(built, name, pattern):
+    """No Go toolchain exists in the authoring image, so the emitted file has never met `go build`.  What a
+    compiler's front end rejects without type information is checked here on the text: unbalanced delimiters, a local variable that
+    is declared and never used, an import that is never used, a `goto`/label mismatch, a cgo call to a function the header lacks
+    (test_emitted_text_is_well_formed), a method declared twice."""
+    for flags in (0, _capi.FLAG_STDLIB_SEMANTICS):
+        text, _ = codegen.emit_go(pattern, name, "patterns", flags=flags, replacers=["[$0]"] if flags else [])
+        code = _go_strip(text)
+        for a, b in ("()", "{}", "[]"):
+            assert code.count(a) == code.count(b), (a, flags)
+        # imports
+        imp = re.search(r"\bimport \(\n(.*?)\n\)", code, re.S).group(1)
+        for ln in imp.splitlines():
+            ln = ln.strip()
+            if not ln or ln.startswith("_"):
+                continue
+            alias = ln.split()[0] if len(ln.split()) > 1 else None
+            pkgname = alias or {'""': None}.get(ln)
+            if pkgname is None:          # a bare quoted path: recover the name from the original text
+                continue
+            assert re.search(r"\b%s\." % re.escape(pkgname), code), ("unused import", pkgname)
+        for pkg in ("io", "runtime", "sync", "unsafe"):
+            if re.search(r'^\t"%s"$' % pkg, text, re.M):
+                assert re.search(r"\b%s\." % pkg, code), ("unused import", pkg)
+        # functions: declared-and-unused locals, duplicate methods
+        seen = set()
+        for head, body in _go_functions(code):
+            sig = re.match(r"func (\([^)]*\) )?(\w+)", head)
+            key = (sig.group(1) or "", sig.group(2))
+            assert key not in seen, ("declared twice", key)
+            seen.add(key)
+            decl = []
+            for m in re.finditer(r"(?<![\w.])((?:\w+, )*\w+) :=", body):
+                decl += [x.strip() for x in m.group(1).split(",")]
+            decl += re.findall(r"\bvar (\w+)\b", body)
+            # named results and parameters are always "used"; only := / var locals are checked
+            for v in set(decl):
+                if v == "_":
+                    continue
+                uses = len(re.findall(r"(?<![\w.])%s\b" % re.escape(v), body))
+                assert uses >= 2, ("declared and not used", v, head.strip()[:80])
+        # every `C.<name>` type or constant besides the functions exists in the header or is a cgo builtin
+        hdr = open(os.path.join(ROOT, "include", "rgx.h")).read()
+        for m in re.finditer(r"\bC\.(\w+)", code):
+            nm = m.group(1)
+            if nm in ("int", "size_t", "int64_t", "int32_t", "uint8_t", "char", "GoString", "uint32_t"):
+                continue
+            assert re.search(r"\b%s\b" % nm, hdr), ("not in rgx.h", nm)
