@@ -8,6 +8,7 @@
 #include <vector>
 
 #include "../rgx_dfa.h"
+#include "../rgx_memo.h"
 #include "../rgx_syntax.h"
 
 using namespace rgx;
@@ -339,6 +340,52 @@ static int64_t RmFailOffset(const Tables& t, int v, const uint8_t* buf, int64_t 
     st = nx;
   }
 }
+// ---- the memoising engine's interpreter (rgx_memo.h) on the host: FindBytesReuse as the device computes it for such programs --
+// the DFA's attempt for "does an attempt at off match, and where does it end", the depth-first search with its visited vector for the
+// offset a failed attempt resumes behind.  1 + out[ncap] (leftmost-first groups of the match), 0, -3 (not interpreted), -4 (gave up).
+int rgxt_memo_find(void* hh, const uint8_t* buf, int64_t len, int32_t* out) {
+  const Tables& t = ((Handle*)hh)->t;
+  if (!t.ref_memo_interp || t.ncap <= 2 || t.ref_find_engine == 1 || !(t.ref_memo || t.ref_find_engine == 2)) return -3;
+  MemoHost h;
+  try {
+    const Prog prog = Compile(Simplify(Parse(t.pattern, kPerl)));
+    if (!BuildMemoProg(prog, &h)) return -3;
+  } catch (...) { return -3; }
+  const MemoView M = h.View();
+  std::vector<unsigned long long> vis((size_t)len + 2, 0), stk((size_t)(4 * (len + 1) + 64) * 16, 0);
+  const MemoScratch S{vis.data(), (int)len + 1, stk.data(), (int)stk.size()};
+  long long budget = 1ll << 40;
+  int64_t off = 0;
+  for (;;) {
+    const int64_t end = Walk(t, buf, len, off, nullptr, nullptr);
+    int mend = 0;
+    const int fo = MemoAttempt(M, buf, (int)len, (int)off, S, &mend, &budget);
+    if (fo == kMemoGaveUp) return -4;
+    if ((end >= 0) != (fo == kMemoMatched) || (end >= 0 && end != mend)) return -5;      // the automaton and the search disagree
+    if (end >= 0) { Captures(t, buf, len, off, end, out); return 1; }
+    if (t.anchored) return 0;
+    if (!(len > fo)) return 0;
+    off = fo + 1;
+  }
+}
+
+// one attempt of the interpreter on buf[0, len) from `start`: >= 0 failure offset, -1 matched (*mend), -2 gave up, -3 not interpreted
+int rgxt_memo_attempt(void* hh, const uint8_t* buf, int64_t len, int64_t start, int32_t* mend) {
+  const Tables& t = ((Handle*)hh)->t;
+  MemoHost h;
+  try {
+    const Prog prog = Compile(Simplify(Parse(t.pattern, kPerl)));
+    if (!BuildMemoProg(prog, &h)) return -3;
+  } catch (...) { return -3; }
+  std::vector<unsigned long long> vis(4096, 0), stk(4096, 0);
+  const MemoScratch S{vis.data(), 4096, stk.data(), 4096};
+  long long budget = 1ll << 22;
+  int m = 0;
+  const int r = MemoAttempt(h.View(), buf, (int)len, (int)start, S, &m, &budget);
+  *mend = m;
+  return r;
+}
+
 // ---- the reference's Tagged DFA as the product holds it (rgx_dfa.h: RefTdfa) -- tables for pinning against the emitted literals
 // (tests/golden/tdfa_tables.json) and the find loop of tdfa.go:831-1052 over them, the loop rgx_tdfa.hip runs per lane.
 int rgxt_tdfa_header(void* hh, int32_t* out8) {

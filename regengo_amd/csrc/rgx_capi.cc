@@ -60,6 +60,7 @@ struct rgx_stream_ctx {
   long long* d_rdelta = nullptr; int64_t rdelta_cap = 0;     // [delta n+1][shift n+1]
   uint8_t* d_rtemp = nullptr; int64_t rtemp_cap = 0;         // hipcub temp + segments + literals
   int32_t* d_out = nullptr; int64_t out_cap = 0;
+  unsigned long long* d_memo = nullptr; int64_t memo_cap = 0; int64_t memo_clean = 0;   // memoising engine: visited words (kept all zero over the first memo_clean) + stacks
   int32_t* d_tdfa = nullptr; int64_t tdfa_cap = 0;           // Tagged-DFA path: ends, (start, end) pairs, sync bits, counts, offsets (TdfaChainDevice)
   uint8_t* d_tmpl = nullptr; int64_t tmpl_cap = 0;           // resolved template (segments + literals) of the last splice
   std::string tmpl_key;                                      // what d_tmpl holds: "" = nothing
@@ -148,9 +149,13 @@ int MatchViewBatch(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_con
 
 // Does the reference's FindReader loop report exactly the FindAllBytes matches of this chunk?  (rgx.h, RGX_E_DIVERGES.)  Only
 // asked for programs whose FindBytesReuse the library reproduces and that cannot match empty, in reference mode.
+// The reference memoises in its capture functions (compiler.go:415-426 "TNFA", or analysis.go's complexity flags) and the library
+// interprets that engine (rgx_memo.h): FindBytesReuse's restart offsets come out of the depth-first search itself
+bool HasRefMemo(const Tables& t) { return t.ncap > 2 && t.ref_find_engine != 1 && (t.ref_memo || t.ref_find_engine == 2) && t.ref_memo_interp; }
+bool RefMemoMode(const rgx_program* p) { return !(p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS) && HasRefMemo(p->p.t) && p->p.dev.memo != nullptr; }
 bool ReaderCheckApplies(const rgx_program* p) {
   const Tables& t = p->p.t;
-  return !(t.flags & RGX_FLAG_STDLIB_SEMANTICS) && p->p.dev.ref_find_ok && !t.can_match_empty;
+  return !(t.flags & RGX_FLAG_STDLIB_SEMANTICS) && (p->p.dev.ref_find_ok || RefMemoMode(p)) && !t.can_match_empty;
 }
 // Reference mode is "the reference's answer or a refusal" (rgx.h: rgx_info.ref_findall_offered / ref_stream_offered).
 bool RefFindAllOffered(const Tables& t) {
@@ -185,7 +190,7 @@ bool RefTdfaMode(const rgx_program* p) { return !(p->p.t.flags & RGX_FLAG_STDLIB
 // Replace* / Transform: FindBytesReuse of the plain backtracking engine on a re-sliced input
 bool RefReplaceOffered(const Tables& t) {
   const bool have_rm = !t.rm_depth[0].empty() && !t.rm_depth[1].empty();
-  return have_rm && !t.ref_memo && t.ref_find_engine <= 0 && !t.can_match_empty;
+  return ((have_rm && !t.ref_memo && t.ref_find_engine <= 0) || HasRefMemo(t)) && !t.can_match_empty;
 }
 // FindReader / FindReaderCount: the same, or the Tagged DFA's FindBytesReuse
 bool RefStreamOffered(const Tables& t) { return RefReplaceOffered(t) || (HasRefTdfa(t) && !t.can_match_empty); }
@@ -204,7 +209,41 @@ int RefuseStream(const rgx_program* p, bool splice = false) {
   SetError("reference-mode FindReader / Replace / Transform is not offered for this pattern: the emitted loop is FindBytesReuse on a re-sliced input and the reference's FindBytesReuse (memoising engine; Tagged-DFA engine under Replace / Transform; or a pattern that matches empty) is not reproduced; keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS");
   return RGX_E_UNSUPPORTED;
 }
+// Scratch of the memoising engine's interpreter: nlanes lanes, each W visited words (all zero between launches) and cap stack words.
+int MemoScratchFor(rgx_stream_ctx* c, int64_t W, int64_t cap, int64_t want_lanes, int64_t* nlanes, unsigned long long** visited, unsigned long long** stack) {
+  const int64_t per = W + cap;
+  int64_t lanes = std::min<int64_t>(want_lanes, std::max<int64_t>(((int64_t)1 << 28) / per, 64));     // at most 2 GiB of scratch
+  lanes = std::max<int64_t>((lanes + 63) / 64 * 64, 64);
+  const int64_t need = lanes * per + 64;
+  if (c->memo_cap < need || !c->d_memo) {
+    int rc = Ensure(&c->d_memo, &c->memo_cap, need);
+    if (rc != RGX_OK) return rc;
+    c->memo_clean = 0;
+  }
+  // the visited words of a launch are its first lanes * W words: zeroed when they were not left zero by the launch before -- the
+  // kernels leave their visited words zero, but the STACKS of a launch lie right behind them and stay dirty
+  if (c->memo_clean < lanes * W) HIP_TRY(hipMemsetAsync(c->d_memo, 0, (size_t)(lanes * W) * 8, c->stream));
+  c->memo_clean = lanes * W;
+  *nlanes = lanes; *visited = c->d_memo; *stack = c->d_memo + lanes * W;
+  return RGX_OK;
+}
+
 int ReaderCheck(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_raw, size_t len, const int32_t* d_spans, int64_t n) {
+  if (RefMemoMode(p) && !p->p.dev.ref_find_ok) {
+    // the memoising engine: the gaps are replayed by the interpreter (rgx_kernels.hip: memo_reader_check_kernel)
+    unsigned* flag = reinterpret_cast<unsigned*>(c->d_cursor + 1);
+    unsigned h = 0;
+    int64_t nlanes = 0;
+    unsigned long long *vis = nullptr, *stk = nullptr;
+    int rc = MemoScratchFor(c, 4096, 4096, std::min<int64_t>(n + 1, 16384), &nlanes, &vis, &stk);
+    if (rc != RGX_OK) return rc;
+    HIP_TRY(hipMemsetAsync(flag, 0, 4, c->stream));
+    HIP_TRY(LaunchMemoReaderCheck(p->p.dev, d_raw, (int32_t)len, d_spans, n, p->p.dev.ncap, vis, 4096, stk, 4096, nlanes, flag, c->stream));
+    HIP_TRY(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (h) { SetError("the reference's FindReader loop (memoising engine) diverges from FindAllBytes on this chunk, or the replay is not vouched for: run it through the Go loop"); return RGX_E_DIVERGES; }
+    return RGX_OK;
+  }
   const uint8_t* view = d_raw;
   int rc = MatchView(p, c, d_raw, len, &view);
   if (rc != RGX_OK) return rc;
@@ -741,7 +780,7 @@ RGX_API int rgx_program_info(const rgx_program* p, rgx_info* o) {
   o->unicode_version = UnicodeVersion();
   {
     const bool have_rm = !t.rm_depth[0].empty() && !t.rm_depth[1].empty();
-    o->ref_find_offered = ((have_rm && !t.ref_memo && t.ref_find_engine <= 0) || HasRefTdfa(t)) ? 1 : 0;
+    o->ref_find_offered = ((have_rm && !t.ref_memo && t.ref_find_engine <= 0) || HasRefTdfa(t) || HasRefMemo(t)) ? 1 : 0;
     o->ref_match_offered = (t.ref_match_engine == 1 || (have_rm && !t.ref_memo && !t.ref_has_fail)) ? 1 : 0;
     const bool stdlib = (t.flags & RGX_FLAG_STDLIB_SEMANTICS) != 0;
     if (stdlib) o->ref_find_offered = o->ref_match_offered = 1;       // nothing of the reference's to reproduce: every entry point answers
@@ -824,7 +863,7 @@ RGX_API void rgx_stream_ctx_destroy(rgx_stream_ctx* c) {
   for (int i = 0; i < 2; ++i)
     for (hipEvent_t e : {c->pev0[i], c->pev1[i], c->pdone[i]}) if (e) (void)hipEventDestroy(e);
   for (void* p : {(void*)c->d_desc, (void*)c->d_unsynced, (void*)c->d_carry,
-                  (void*)c->d_trace, (void*)c->d_in, (void*)c->d_san, (void*)c->d_out, (void*)c->d_rspans, (void*)c->d_rdelta, (void*)c->d_rtemp, (void*)c->d_tmpl, (void*)c->d_tdfa})
+                  (void*)c->d_trace, (void*)c->d_in, (void*)c->d_san, (void*)c->d_out, (void*)c->d_rspans, (void*)c->d_rdelta, (void*)c->d_rtemp, (void*)c->d_tmpl, (void*)c->d_tdfa, (void*)c->d_memo})
     if (p) (void)hipFree(p);
   if (c->h_read) (void)hipHostFree(c->h_read);
   delete c;
@@ -1479,9 +1518,36 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
     if (h & kTdfaOverBudget) { SetError("the Tagged DFA's attempts on a string of this batch are too long to finish: keep the CPU path for it"); return RGX_E_UNSUPPORTED; }
     return (int64_t)nstr;
   }
+  if (ref_mode && !T.ref_find_ok && RefMemoMode(p)) {
+    // the reference memoises: the plain leftmost-first search (below, as under RGX_FLAG_STDLIB_SEMANTICS), then the replay of
+    // FindBytesReuse's attempt offsets with the failure offsets of the memoising machine itself (memo_fix_kernel)
+    unsigned long long h_max = 0;
+    uint64_t h_last = 0;
+    HIP_TRY(hipMemsetAsync(c->d_cursor + 2, 0, 8, c->stream));
+    HIP_TRY(LaunchMaxStringLen(d_offsets, (int64_t)nstr, c->d_cursor + 2, c->stream));
+    HIP_TRY(hipMemcpyAsync(&h_max, c->d_cursor + 2, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&h_last, d_offsets + nstr, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((int64_t)h_max > kBatchRestartMaxLen) return BatchLengthGuard(c, d_offsets, nstr, kBatchRestartMaxLen, -1);
+    if ((rc = Ensure(&c->d_trace, &c->trace_cap, (int64_t)h_last + 2 * (int64_t)nstr + 64)) != RGX_OK) return rc;
+    HIP_TRY(LaunchBatch(T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, c->d_trace, -1, c->stream, BatchWindowFor((int64_t)h_last, (int64_t)nstr)));
+    const int64_t W = (int64_t)h_max + 1, cap = 4 * W + 64;
+    int64_t nlanes = 0;
+    unsigned long long *vis = nullptr, *stk = nullptr;
+    if ((rc = MemoScratchFor(c, W, cap, std::min<int64_t>((int64_t)nstr, 65536), &nlanes, &vis, &stk)) != RGX_OK) return rc;
+    if ((rc = Ensure(&c->d_tdfa, &c->tdfa_cap, 16)) != RGX_OK) return rc;
+    uint32_t* flags = (uint32_t*)c->d_tdfa;
+    uint32_t h = 0;
+    HIP_TRY(hipMemsetAsync(flags, 0, 4, c->stream));
+    HIP_TRY(LaunchBatchMemoFix(T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, c->d_trace, vis, (int)W, stk, (int)cap, nlanes, flags, c->stream));
+    HIP_TRY(hipMemcpyAsync(&h, flags, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (h & kTdfaOverBudget) { SetError("the memoising engine's attempts on a string of this batch are too many to replay (stack / step budget): keep the Go path for it"); return RGX_E_UNSUPPORTED; }
+    return (int64_t)nstr;
+  }
   if (ref_mode && !T.ref_find_ok) {
     // reference mode: FindBytesReuse's own restart rule (find.go:545-569)
-    SetError("reference-mode FindBytes is not offered for this pattern (memoising / TDFA engine): keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS");
+    SetError("reference-mode FindBytes is not offered for this pattern (memoising engine beyond the interpreter's 64 Alt instructions): keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS");
     return RGX_E_UNSUPPORTED;
   }
   static const bool ref_one_pass = ExpEnv("RGX_REF_ONE_PASS") != nullptr;

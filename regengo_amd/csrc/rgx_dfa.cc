@@ -663,6 +663,17 @@ Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOption
     const bool use_thompson = (cat || nl) && !ea;
     t.ref_memo = nl || (cat && !use_thompson);
     {
+      // the memoising engine interpreted on the device (rgx_program.h: MemoDev): one visited word per offset, a bit per Alt
+      int nalt = 0;
+      bool ok = prog.inst.size() < 60000;
+      for (const Inst& in : prog.inst) {
+        if (in.op == InstAlt) nalt++;
+        if (in.op == InstRune && (in.rune.size() & 1)) ok = false;
+        if (in.op == InstRune1 && in.rune.empty()) ok = false;
+      }
+      t.ref_memo_interp = ok && nalt <= 64;
+    }
+    {
       int pc = prog.start;
       while (prog.inst[pc].op == InstNop || prog.inst[pc].op == InstCapture) pc = (int)prog.inst[pc].out;
       const Inst& in = prog.inst[pc];
@@ -1111,7 +1122,7 @@ struct R {
   void raw(void* d, size_t k) { if (o + k > n) { ok = false; return; } memcpy(d, p + o, k); o += k; }
 };
 constexpr uint32_t kMagic = 0x54584752;  // "RGXT"
-constexpr uint32_t kBlobVersion = 6;  /* 5: ref_tdfa_states; 6: the Tagged DFA itself */    // 3: FNV-1a checksum of the blob appended; every index range-checked on load
+constexpr uint32_t kBlobVersion = 7;  /* 5: ref_tdfa_states; 6: the Tagged DFA itself; 7: ref_memo_interp */    // 3: FNV-1a checksum of the blob appended; every index range-checked on load
 uint64_t Fnv1a(const uint8_t* p, size_t n) {
   uint64_t h = 1469598103934665603ull;
   for (size_t i = 0; i < n; i++) { h ^= p[i]; h *= 1099511628211ull; }
@@ -1149,7 +1160,7 @@ std::vector<uint8_t> SerializeTables(const Tables& t) {
   w.raw(t.sa_mask, sizeof t.sa_mask); w.pod<int32_t>(t.sa_k); w.pod<uint8_t>(t.sa_exact);
   w.pod<int32_t>(t.w_nstates); w.pod<uint16_t>(t.w_start); w.vec(t.w_trans); w.pod<uint8_t>(t.needs_valid_utf8);
   for (int v = 0; v < 2; v++) { w.vec(t.rm_trans[v]); w.vec(t.rm_depth[v]); w.raw(t.rm_start[v], sizeof t.rm_start[v]); }
-  w.pod<uint8_t>(t.ref_memo); w.pod<uint8_t>(t.ref_has_fail); w.pod<int32_t>(t.ref_prefix);
+  w.pod<uint8_t>(t.ref_memo); w.pod<uint8_t>(t.ref_has_fail); w.pod<int32_t>(t.ref_prefix); w.pod<uint8_t>(t.ref_memo_interp);
   {  // the reference's Tagged DFA in place of tdfa.go:584-794's Go literals
     const RefTdfa& d = t.tdfa;
     w.pod<int32_t>(d.nstates); w.pod<int32_t>(d.ntags); w.pod<int32_t>(d.start_begin); w.pod<int32_t>(d.start_any);
@@ -1189,7 +1200,7 @@ bool DeserializeTables(const uint8_t* p, size_t n, Tables* t) {
   r.raw(t->sa_mask, sizeof t->sa_mask); r.pod(i32); t->sa_k = i32; r.pod(u8); t->sa_exact = u8;
   r.pod(i32); t->w_nstates = i32; r.pod(t->w_start); r.vec(t->w_trans); r.pod(u8); t->needs_valid_utf8 = u8;
   for (int v = 0; v < 2; v++) { r.vec(t->rm_trans[v]); r.vec(t->rm_depth[v]); r.raw(t->rm_start[v], sizeof t->rm_start[v]); }
-  r.pod(u8); t->ref_memo = u8; r.pod(u8); t->ref_has_fail = u8; r.pod(i32); t->ref_prefix = i32;
+  r.pod(u8); t->ref_memo = u8; r.pod(u8); t->ref_has_fail = u8; r.pod(i32); t->ref_prefix = i32; r.pod(u8); t->ref_memo_interp = u8 != 0;
   {
     RefTdfa& d = t->tdfa;
     r.pod(i32); d.nstates = i32; r.pod(i32); d.ntags = i32; r.pod(i32); d.start_begin = i32; r.pod(i32); d.start_any = i32;

@@ -119,6 +119,9 @@ struct Tables {
   uint16_t rm_start[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};
   bool ref_memo = false;          // the reference memoises (analysis.go complexity / nested quantifiers): its restart offsets
                                   // depend on the visited set -- reference mode is not offered, the Go path keeps those functions
+  bool ref_memo_interp = false;   // ... and the library runs that engine itself: the depth-first search of the emitted code with its visited bit
+                                  // vector, interpreted over the instructions (rgx_program.h: MemoDev) -- offered when the program has at
+                                  // most 64 Alt instructions and no fold-case InstRune (which the reference's emitter cannot lower either)
   bool ref_has_fail = false;      // a reachable InstFail: MatchBytes returns false outright there (instructions.go:62-66)
   int ref_prefix = -1;            // MatchBytes' required first byte (compiler.go:719-737), -1: none
 

@@ -146,6 +146,15 @@ hipError_t LaunchUtf8ScreenBatch(const uint8_t* src, const uint64_t* offsets, in
 hipError_t LaunchReaderCheck(const DevTables& T, const uint8_t* raw, const uint8_t* view, int32_t len, const int32_t* spans, int64_t n,
                              int ncap, unsigned* flag, hipStream_t stream);
 
+// The memoising engine (rgx_memo.h; DevTables::memo).  Scratch: `visited` nlanes * W zeroed words (left zeroed), `stack` nlanes * cap
+// words; nlanes a multiple of 64; flags: bit 31 = a string / gap the interpreter gave up on (window, stack, budget).
+hipError_t LaunchBatchMemoFix(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found, int32_t* spans,
+                              uint16_t* trace, unsigned long long* visited, int W, unsigned long long* stack, int cap, int64_t nlanes,
+                              uint32_t* flags, hipStream_t stream);
+// LaunchReaderCheck for such a program (raw bytes: the interpreter decodes runes itself); *flag |= 1: diverges or not vouched for
+hipError_t LaunchMemoReaderCheck(const DevTables& T, const uint8_t* raw, int32_t len, const int32_t* spans, int64_t n, int ncap,
+                                 unsigned long long* visited, int W, unsigned long long* stack, int cap, int64_t nlanes, unsigned* flag,
+                                 hipStream_t stream);
 // The Q4 half of LaunchReaderCheck alone (bytes.Index finds the match text earlier in the gap): any ordered span table.
 hipError_t LaunchReaderIndex(const uint8_t* raw, int32_t len, const int32_t* spans, int64_t n, int ncap, unsigned* flag, hipStream_t stream);
 

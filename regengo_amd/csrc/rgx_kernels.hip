@@ -1045,6 +1045,54 @@ __global__ __launch_bounds__(64) void ref_fix_kernel(DevTables T, const uint8_t*
   ResolveCaptures(T, buf, len, s, e, tr, rec);
 }
 
+// ---- batch, reference mode, the MEMOISING engine (rgx_memo.h) ------------------------------------------------------------------------
+// The plain search has run (found flags + the record of the LEFTMOST-FIRST match of every string); this kernel replays FindBytesReuse's
+// attempt offsets as ref_fix_kernel does, with the failure offset of every attempt taken from the depth-first search itself
+// (MemoAttempt: the emitted machine with its visited bit vector).  A string WITHOUT a match needs no replay: the loop finds none
+// either.  Lanes are grid-strided over the strings; lane L owns visited words [L * W, (L + 1) * W) and stack entries [L * cap, ..).
+__global__ __launch_bounds__(64) void memo_fix_kernel(DevTables T, MemoDev M, const uint8_t* concat, const uint64_t* offsets, int64_t nstr,
+                                                      uint8_t* found, int32_t* spans, uint16_t* trace, unsigned long long* visited, int W,
+                                                      unsigned long long* stack, int cap, uint32_t* flags) {
+  __shared__ uint16_t s_trace[64 * kCapsLdsTrace];
+  const int64_t lane = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int64_t nlanes = (int64_t)gridDim.x * 64;
+  const MemoScratch S{visited + lane * W, W, stack + lane * cap, cap};
+  const long long t_launch = (long long)wall_clock64();
+  for (int64_t i = lane; i < nstr; i += nlanes) {
+    if (!found[i]) continue;
+    const uint64_t o0 = offsets[i], o1 = offsets[i + 1];
+    const uint8_t* buf = concat + o0;
+    const int len = (int)(o1 - o0);
+    int32_t* rec = spans + i * T.ncap;
+    const int s0 = rec[0];
+    long long budget = kLaneStepBudget;
+    int at = 0;
+    int off = MemoReplay(M, buf, len, 0, s0, S, &budget, &at);
+    if (off == s0) continue;                                   // the attempt at s0 is made, and it is the one that matches
+    bool gave_up = off == kMemoGaveUp || off == kMemoMatched;  // (a match before the leftmost-first start: the two disagree)
+    int s = -1, e = -1;
+    while (!gave_up && off >= 0) {                            // stepped over s0: full attempts from here on (find.go:545-569)
+      const int end = WalkGlobal(T, buf, len, off);
+      if (end >= 0) { s = off; e = end; break; }
+      int mend = 0;
+      const int fo = MemoAttempt(M, buf, len, off, S, &mend, &budget);
+      if (fo == kMemoGaveUp || fo == kMemoMatched || PastDeadline(t_launch)) { gave_up = true; break; }
+      if (!(len > fo)) break;
+      off = fo + 1;
+    }
+    if (gave_up) { atomicOr(flags, kOverBudgetBit); found[i] = 0; continue; }
+    found[i] = s >= 0;
+    if (s < 0) { for (int c = 0; c < T.ncap; ++c) rec[c] = T.unmatched_minus1 ? -1 : 0; continue; }
+    if (T.fixed_captures) {
+      for (int c = 0; c < T.ncap; ++c) rec[c] = T.cap_kind[c] == kCapFromStart ? s + T.cap_delta[c] : e - T.cap_delta[c];
+      continue;
+    }
+    const int need = e - s + 1;
+    uint16_t* tr = need <= kCapsLdsTrace ? s_trace + threadIdx.x * kCapsLdsTrace : trace + o0 + 2 * i;
+    ResolveCaptures(T, buf, len, s, e, tr, rec);
+  }
+}
+
 // ---- batch, staged (BASELINE config C3) -------------------------------------------------------------------
 // The per-lane kernel above reads everything -- tables, input bytes, back-trace pools -- through L1/L2 with one
 // dependent global load per DFA step (27 GB/s on 10 M short strings).  Here a persistent workgroup stages the
@@ -2423,6 +2471,75 @@ hipError_t LaunchMaxStringLen(const uint64_t* offsets, int64_t nstr, unsigned lo
   return hipGetLastError();
 }
 
+namespace {
+// FindReader's loop against FindAllBytes over one chunk for a program of the MEMOISING engine (reader_check_kernel has the three
+// conditions).  The loop calls FindBytesReuse on chunk[p:] -- p the end of the previous match -- so the attempts are replayed on that
+// slice: its first byte is the beginning of the text for ^ and \b, the visited vector is keyed by offsets of the slice.  Lane i
+// (grid-strided) checks the gap in front of match i:
+//   * the attempt AT p: on the slice and in its true context it has to do the same thing (fail at the same offset, or -- p is the
+//     start of match i -- match with the same end);
+//   * the sequence p, fail(p) + 1, ... lands on the match's start, every attempt before it failing.  An attempt that starts at or
+//     before a byte on which every state dies fails at that byte at the latest, so the sequence steps ONTO the offset behind every such
+//     byte: the replay starts behind the last one in front of the match (searched back kReaderBack bytes; none in reach: not vouched for).
+// bytes.Index (Q4) is reader_index_kernel's, as for every engine.
+__global__ __launch_bounds__(64) void memo_reader_check_kernel(DevTables T, MemoDev M, const uint8_t* raw, int32_t len, const int32_t* spans,
+                                                               long long n, int ncap, unsigned long long* visited, int W,
+                                                               unsigned long long* stack, int cap, unsigned* flag) {
+  const long long lane = (long long)blockIdx.x * 64 + threadIdx.x;
+  const long long nlanes = (long long)gridDim.x * 64;
+  const MemoScratch S{visited + lane * W, W, stack + lane * cap, cap};
+  bool bad = false;
+  for (long long i = lane; i <= n && !bad; i += nlanes) {
+    const int p = i == 0 ? 0 : spans[(i - 1) * ncap + 1];
+    const int s = i < n ? spans[i * ncap] : len, e = i < n ? spans[i * ncap + 1] : len;
+    if (p >= len) continue;
+    long long budget = kReaderSteps * 64ll;
+    int mend = 0, mend2 = 0;
+    // the attempt at p, on the slice chunk[p:]
+    const int a0 = MemoAttempt(M, raw + p, len - p, 0, S, &mend, &budget);
+    if (a0 == kMemoGaveUp) { bad = true; break; }
+    if (p > 0) {
+      const int a1 = MemoAttempt(M, raw, len, p, S, &mend2, &budget);
+      if (a1 == kMemoGaveUp || (a0 == kMemoMatched) != (a1 == kMemoMatched)) { bad = true; break; }
+      if (a0 == kMemoMatched ? mend + p != mend2 : a0 + p != a1) { bad = true; break; }
+    }
+    if (a0 == kMemoMatched) {
+      if (!(i < n && s == p && mend + p == e)) bad = true;      // the loop reports a match at p: it has to be FindAllBytes' next one
+      continue;
+    }
+    if (i < n && s == p) { bad = true; break; }                  // FindAllBytes has a match at p, the loop's attempt there fails
+    if (i == n) continue;                                        // the tail: no attempt behind p matches (FindAllBytes found none)
+    if (e == s) { bad = true; break; }                           // (empty matches are not offered)
+    // the sequence from behind the last reset byte in front of s (or from fail(p) + 1 when the gap is short)
+    int off = a0 + 1 + p;
+    if (!(len - p > a0)) { bad = true; break; }                  // the loop ran out of text at p although a match follows
+    if (s - off > kReaderBack) {
+      int q = s - 1;
+      off = -1;
+      if (T.reset_values)
+        for (; q >= s - kReaderBack; --q)
+          if (T.reset_byte[raw[q]]) { off = q + 1; break; }
+      if (off < 0) { bad = true; break; }
+    }
+    if (off > s) { bad = true; break; }
+    int at = 0;
+    const int r = MemoReplay(M, raw + p, len - p, off - p, s - p, S, &budget, &at);
+    if (r != s - p) { bad = true; break; }
+    // ... and the attempt at s matches with FindAllBytes' end (s > p here: its context is the true one)
+    const int am = MemoAttempt(M, raw + p, len - p, s - p, S, &mend, &budget);
+    if (am != kMemoMatched || mend + p != e) bad = true;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+}  // namespace
+hipError_t LaunchMemoReaderCheck(const DevTables& T, const uint8_t* raw, int32_t len, const int32_t* spans, int64_t n, int ncap,
+                                 unsigned long long* visited, int W, unsigned long long* stack, int cap, int64_t nlanes, unsigned* flag,
+                                 hipStream_t stream) {
+  hipLaunchKernelGGL(memo_reader_check_kernel, dim3((unsigned)(nlanes / 64)), dim3(64), 0, stream, T, *T.memo, raw, len, spans, (long long)n, ncap,
+                     visited, W, stack, cap, flag);
+  return LaunchReaderIndex(raw, len, spans, n, ncap, flag, stream);
+}
+
 hipError_t LaunchReaderIndex(const uint8_t* raw, int32_t len, const int32_t* spans, int64_t n, int ncap, unsigned* flag, hipStream_t stream) {
   if (n <= 0 || len <= 0) return hipSuccess;
   const long long pieces = ((long long)len + kIdxPiece - 1) / kIdxPiece;
@@ -2645,6 +2762,15 @@ hipError_t LaunchBatchRefFix(const DevTables& T, const uint8_t* concat, const ui
   if (nstr <= 0) return hipSuccess;
   dim3 block(64), grid((unsigned)((nstr + 63) / 64));
   hipLaunchKernelGGL(ref_fix_kernel, grid, block, 0, stream, T, concat, offsets, nstr, found, spans, trace, only_flagged);
+  return hipGetLastError();
+}
+
+hipError_t LaunchBatchMemoFix(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found, int32_t* spans,
+                              uint16_t* trace, unsigned long long* visited, int W, unsigned long long* stack, int cap, int64_t nlanes,
+                              uint32_t* flags, hipStream_t stream) {
+  if (nstr <= 0) return hipSuccess;
+  hipLaunchKernelGGL(memo_fix_kernel, dim3((unsigned)(nlanes / 64)), dim3(64), 0, stream, T, *T.memo, concat, offsets, nstr, found, spans, trace,
+                     visited, W, stack, cap, flags);
   return hipGetLastError();
 }
 

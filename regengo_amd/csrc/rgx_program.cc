@@ -1,5 +1,6 @@
 #include "rgx_program.h"
 
+#include <algorithm>
 #include <cstdlib>
 #include <cstring>
 
@@ -12,9 +13,10 @@ void SetError(const std::string& s) { g_error = s; }
 const std::string& GetError() { return g_error; }
 
 Program::~Program() {
-  if (d_arena || d_arena_u || d_arena_us || d_arena_tdfa) {
+  if (d_arena || d_arena_u || d_arena_us || d_arena_tdfa || d_arena_memo) {
     hipSetDevice(device);
     if (d_arena_tdfa) hipFree(d_arena_tdfa);
+    if (d_arena_memo) hipFree(d_arena_memo);
     if (d_arena) hipFree(d_arena);
     if (d_arena_u) hipFree(d_arena_u);
     if (d_arena_us) hipFree(d_arena_us);
@@ -385,6 +387,31 @@ int UploadTdfa(Program* p) {
 }
 }  // namespace
 
+namespace {
+// The program as instructions for the memoising engine's interpreter (rgx_memo.h), uploaded.
+bool UploadMemo(Program* p) {
+  MemoHost h;
+  try {
+    const Prog prog = Compile(Simplify(Parse(p->t.pattern, kPerl)));
+    if (!BuildMemoProg(prog, &h)) return false;
+  } catch (...) {
+    return false;
+  }
+  Arena a;
+  const size_t off_i = a.AddVec(h.inst), off_b = a.AddVec(h.bitmaps), off_r = a.AddVec(h.ranges), off_y = a.AddVec(h.bytes);
+  void* dptr = nullptr;
+  if (hipMalloc(&dptr, a.host.size()) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipMemcpy(dptr, a.host.data(), a.host.size(), hipMemcpyHostToDevice) != hipSuccess) { hipFree(dptr); return false; }
+  uint8_t* b = (uint8_t*)dptr;
+  MemoDev d{};
+  d.inst = (const MemoInst*)(b + off_i); d.bitmaps = (const uint32_t*)(b + off_b); d.ranges = (const int32_t*)(b + off_r); d.bytes = b + off_y;
+  d.ninst = (int32_t)h.inst.size(); d.start = h.start; d.nalt = h.nalt;
+  p->memodev = d;
+  p->d_arena_memo = dptr;
+  return true;
+}
+}  // namespace
+
 int ProgramToDevice(Program* p, int device) {
   std::lock_guard<std::mutex> lock(p->mu);
   if (p->d_arena) {
@@ -410,6 +437,11 @@ int ProgramToDevice(Program* p, int device) {
   p->us_ok = BuildUs(p);
   if (p->us_ok && UploadUs(p) != RGX_OK) p->us_ok = false;
   p->dev.us = p->us_ok ? &p->usdev : nullptr;
+  // the program as instructions, when the reference emits its memoising backtracker for the capture functions
+  p->dev.memo = nullptr;
+  if (p->t.ncap > 2 && p->t.ref_find_engine != 1 && (p->t.ref_memo || p->t.ref_find_engine == 2) && p->t.ref_memo_interp &&
+      !(p->t.flags & RGX_FLAG_STDLIB_SEMANTICS) && UploadMemo(p))
+    p->dev.memo = &p->memodev;
   // the reference's own Tagged DFA, when it emits one and the tag file is the record (ntags == ncap: always)
   p->dev.tdfa = nullptr;
   if (p->t.tdfa.nstates > 0 && p->t.tdfa.nstates <= 1000 && p->t.tdfa.ntags == p->t.ncap && UploadTdfa(p) == RGX_OK) p->dev.tdfa = &p->tdfadev;

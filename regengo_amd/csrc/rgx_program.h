@@ -9,6 +9,7 @@
 #include <vector>
 
 #include "rgx_dfa.h"
+#include "rgx_memo.h"
 
 namespace rgx {
 
@@ -38,6 +39,8 @@ enum TableMode : int {
 
 struct UsDev;
 struct TdfaDev;
+// Device image of the syntax.Prog itself, for the reference's memoising backtracker (rgx_memo.h has the why and the interpreter)
+typedef MemoView MemoDev;
 
 // Flat device image of one compiled pattern.  All pointers are device addresses.
 struct DevTables {
@@ -82,6 +85,8 @@ struct DevTables {
   int32_t ref_prefix;             // MatchBytes' required first byte, -1: none
   int32_t ref_find_ok;            // 1: FindBytesReuse in reference mode is offered (plain backtracking engine, no memo)
   int32_t ref_match_kind;         // 0: restart rule over rm_*[1]; 1: the Thompson matcher (plain existence); 2: not offered
+  const MemoDev* memo;            // HOST pointer to the program as instructions when the reference emits its memoising backtracker for FindBytes
+                                  // (ref_find_engine == 2) and the interpreter takes it (at most 64 Alt instructions), else nullptr
   const TdfaDev* tdfa;            // HOST pointer to the reference's Tagged DFA on the device (rgx_tdfa.hip) when the reference emits one, else nullptr
   const UsDev* us;                // HOST pointer to the program's UsDev when the pattern is eligible for rgx_scan_us.hip, else nullptr
   uint16_t start[4];
@@ -157,6 +162,8 @@ struct Program {
   void* d_arena_us = nullptr;
   TdfaDev tdfadev{};
   void* d_arena_tdfa = nullptr;
+  MemoDev memodev{};
+  void* d_arena_memo = nullptr;
   std::vector<uint8_t> blob_cache;
   // search automaton (BuildOptions::unanchored_search) for the per-string entry points; built lazily, absent when the
   // pattern is anchored or the automaton exceeds its state budget

@@ -19,6 +19,7 @@
 #include <vector>
 
 #include "rgx_dfa.h"
+#include "rgx_memo.h"
 
 namespace rgx {
 namespace {
@@ -250,6 +251,71 @@ bool BuildRefTdfa(const Prog& prog, int ncap_names, RefTdfa* out, int max_states
   t.init_begin = intern(init_begin);
   t.init_any = intern(init_any);
   if (overflow || t.pool.size() > 60000) { *out = RefTdfa(); return false; }   // (never seen: offsets grow only while states multiply)
+  return true;
+}
+
+// The program as instructions for the memoising engine's interpreter (rgx_memo.h).
+bool BuildMemoProg(const Prog& prog, MemoHost* out) {
+  *out = MemoHost();
+  const int n = (int)prog.inst.size();
+  if (n > 60000) return false;
+  out->inst.resize((size_t)n);
+  int nalt = 0;
+  for (int i = 0; i < n; i++) {
+    const Inst& in = prog.inst[i];
+    MemoInst m{};
+    m.out = (uint16_t)in.out;
+    switch (in.op) {
+      case InstFail: m.op = kMFail; break;
+      case InstMatch: m.op = kMMatch; break;
+      case InstNop: case InstAltMatch: m.op = kMNop; break;
+      case InstCapture: m.op = kMCapture; m.arg = in.arg; break;
+      case InstAlt: m.op = kMAlt; m.arg = in.arg; m.aux = (uint32_t)nalt++; break;
+      case InstEmptyWidth: m.op = kMEmpty; m.arg = in.arg; break;
+      case InstRuneAny: m.op = kMAny; break;
+      case InstRuneAnyNotNL: m.op = kMAnyNotNL; break;
+      case InstRune1: {
+        if (in.rune.empty()) return false;
+        const int32_t r = in.rune[0];
+        if (r < 128) { m.op = kMByte; m.arg = (uint32_t)r; }
+        else {
+          uint8_t enc[4];
+          const int k = EncodeRune(r, enc);
+          m.op = kMBytes; m.arg = (uint32_t)out->bytes.size(); m.aux = (uint32_t)k;
+          out->bytes.insert(out->bytes.end(), enc, enc + k);
+        }
+        break;
+      }
+      case InstRune: {
+        const std::vector<int32_t>& r = in.rune;
+        if (r.empty()) { m.op = kMNever; break; }          // generateRuneCheck -> true (charclass.go:79-81)
+        if (r.size() & 1) return false;                      // fold-case form: the reference's emitter indexes out of range (charclass.go:11-13)
+        bool all_ascii = true, has_ascii = false;
+        for (size_t k = 0; k + 1 < r.size(); k += 2) { if (r[k + 1] >= 128) all_ascii = false; if (r[k] < 128) has_ascii = true; }
+        m.arg = (uint32_t)(out->bitmaps.size() / 8);
+        out->bitmaps.resize(out->bitmaps.size() + 8, 0);
+        uint32_t* bm = &out->bitmaps[out->bitmaps.size() - 8];
+        for (size_t k = 0; k + 1 < r.size(); k += 2)
+          for (int32_t c = r[k]; c <= std::min<int32_t>(r[k + 1], 127); c++) if (c >= 0) bm[c >> 5] |= 1u << (c & 31);
+        if (all_ascii) m.op = kMCls;
+        else {
+          m.op = kMUCls; m.flag = has_ascii ? 1 : 0;
+          if (out->ranges.size() / 2 >= (1u << 20) || r.size() / 2 >= (1u << 12)) return false;
+          m.aux = (uint32_t)(out->ranges.size() / 2) | ((uint32_t)(r.size() / 2) << 20);
+          out->ranges.insert(out->ranges.end(), r.begin(), r.end());
+        }
+        break;
+      }
+      default: return false;
+    }
+    out->inst[(size_t)i] = m;
+  }
+  if (nalt > 64) return false;                               // one visited word per offset
+  if (out->bitmaps.empty()) out->bitmaps.assign(8, 0);
+  if (out->ranges.empty()) out->ranges.assign(2, 0);
+  if (out->bytes.empty()) out->bytes.assign(4, 0);
+  out->start = prog.start;
+  out->nalt = nalt;
   return true;
 }
 

@@ -43,6 +43,7 @@ _lib.rgxt_ref_match.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
 _lib.rgxt_tdfa_header.argtypes = [C.c_void_p, C.c_void_p]
 _lib.rgxt_tdfa_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 5
 _lib.rgxt_tdfa_find.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p]
+_lib.rgxt_memo_find.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p]
 
 INFO = ["ncap", "min", "max", "ninst", "nstates", "ncls", "anchored", "fixed", "empty", "refm", "reff", "look", "maxthr"]
 
@@ -164,6 +165,16 @@ class HostProgram:
         if r == -3:
             return NotImplemented
         return list(out[:self.info["ncap"]]) if r == 1 else None
+
+    def memo_find(self, b: bytes):
+        """FindBytesReuse of a program the reference emits with its memoising backtracker, as the device computes it (rgx_memo.h):
+        spans, None, NotImplemented (not such a program), or raises when the interpreter gave up / disagreed with the automaton."""
+        out = (C.c_int32 * self.info["ncap"])()
+        r = _lib.rgxt_memo_find(self.h, b, len(b), out)
+        if r == -3:
+            return NotImplemented
+        assert r >= 0, "memo interpreter: %d" % r
+        return list(out) if r == 1 else None
 
     def reset_bytes(self):
         a = (C.c_uint8 * 256)()

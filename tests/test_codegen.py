@@ -142,13 +142,19 @@ def test_field_names_and_memo_patterns(built):
     text, _ = codegen.emit_go(r"\d+", "Digits", "p")
     assert "FindAll" not in text.replace("// ", "") or "func (r Digits) FindAll" not in text
     # nested quantifiers (analysis.go:85-113): the reference emits a Thompson MatchBytes (plain existence: routed) and, the Tagged DFA
-    # being infeasible here, a memoising FindBytes (its restart offsets are not reproduced: stays pure Go, and with it the streaming
-    # loops built on it); its FindAll is plain leftmost-first on a pattern that cannot match empty: routed
+    # being infeasible here, a memoising FindBytes -- whose restart offsets come out of the depth-first search itself: the library
+    # INTERPRETS that engine (csrc/rgx_memo.h), so FindBytes* and the loops built on it are routed too; its FindAll is plain
+    # leftmost-first on a pattern that cannot match empty: routed
     text, _ = codegen.emit_go(r"(?P<w>(a+)+)b", "Nested", "p")
     assert codegen.Program(r"(?P<w>(a+)+)b").info.ref_find_engine == 2
-    assert "func (r Nested) MatchBytes(" in text and "func (r Nested) FindBytesReuse(" not in text
-    assert "FindBytes / FindBytesReuse / FindString / FindStringReuse are not routed" in text
-    assert "func (r Nested) FindAllBytesAppend(" in text and "func (r Nested) FindReader(" not in text
+    for meth in ("MatchBytes", "FindBytesReuse", "FindAllBytesAppend", "FindReader", "ReplaceAllBytesAppend"):
+        assert "func (r Nested) %s(" % meth in text, meth
+    # ... but not where the interpreter does not reach: more than 64 Alt instructions (one visited word per offset)
+    big = "(?P<w>(" + "|".join("a%db+" % k for k in range(70)) + ")+)c"
+    info = codegen.Program(big).info
+    if info.ref_find_engine == 2:
+        text, _ = codegen.emit_go(big, "Big", "p")
+        assert "func (r Big) FindBytesReuse(" not in text and "FindBytes / FindBytesReuse / FindString / FindStringReuse are not routed" in text
     # the reference's Tagged DFA (URLCapture, 13 states as in its checked-in tables): the engine itself runs on the device, so
     # FindBytes* and FindReader / FindReaderCount ARE routed (fill: a group is assigned only when its start tag is set); FindAll* (the
     # wrapper reports matches again, compiler.go:646-651) and Replace* (stale groups of the reused struct) are not -- all are with

@@ -315,6 +315,10 @@ def test_find_reader_is_the_reference_or_refuses(torch_dev):
         (r"(?P<k>[a-c]+)=(?P<v>\d+)", "abc=12 ;"),
         (r"^(\d\d)", "0123 "),
         (r"x(ab|a)c?", "xabc "),
+        # the memoising engine (round 4: interpreted, csrc/rgx_memo.h): BASELINE config C4's own URL pattern, nested quantifiers
+        (r"(?P<full>(?P<proto>https?|ftp)://(?P<host>[\w.-]+)(?P<port>:\d+)?(?P<path>/[\w./-]*)?)", "htps:/f.w-1 \n"),
+        (r"(?P<outer>(?P<inner>a+)+)b", "ab c"),
+        (r"(?P<words>(?P<word>\w+\s*)+)end", "end wx "),
     ]
     refused = agreed = 0
     for pat, alphabet in cases:

@@ -91,7 +91,8 @@ def test_reference_mode_equals_the_emitted_functions_on_the_corpus(torch_dev, co
                 assert (r is None) == (exp is None) and (r is None or r.spans == exp), ("FindBytes", pat, b, r and r.spans, exp)
                 nf += 1
         except _capi.RgxError as ex:
-            assert ex.status == _capi.RGX_E_UNSUPPORTED and o.sel.find_memo and o.tdfa is None, pat     # only the memoising engine is refused
+            # only the memoising engine beyond the interpreter (more than 64 Alts) is refused
+            assert ex.status == _capi.RGX_E_UNSUPPORTED and o.sel.find_memo and o.tdfa is None and not c.info.ref_find_offered, pat
             un_f += 1
     print("MatchBytes compared", nm, "patterns not offered", un_m, "| FindBytes compared", nf, "patterns not offered", un_f)
-    assert nm > 4000 and nf > 3500
+    assert nm > 4000 and nf > 3500 and un_f <= 2, (nm, nf, un_m, un_f)

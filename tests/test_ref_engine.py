@@ -41,8 +41,8 @@ def test_product_engine_selection_equals_the_oracle(built, corpus, kats):
         # the offer rules (include/rgx.h: rgx_info)
         assert info.ref_findall_offered == int(exp[0] <= 0 or (exp[0] == 2 and not info.can_match_empty)), p
         assert info.ref_stream_offered == int(info.ref_find_offered and not info.can_match_empty), p
-        if exp[0] == 2:          # memoising backtracker: its FindBytesReuse is not reproduced
-            assert not info.ref_find_offered and not info.ref_stream_offered and not info.ref_replace_offered, p
+        if exp[0] == 2:          # memoising backtracker: interpreted (csrc/rgx_memo.h) -- FindBytes offered, the loops built on it unless the pattern matches empty
+            assert info.ref_find_offered and info.ref_stream_offered == info.ref_replace_offered == int(not info.can_match_empty), p
         if exp[0] == 1:          # Tagged DFA: the engine itself runs on the device; only its FindAll wrapper and Replace stay refused
             assert info.ref_find_offered and info.ref_stream_offered == int(not info.can_match_empty) and not info.ref_replace_offered, p
         if exp[0] == 0:
@@ -199,3 +199,35 @@ def test_c4_find_reader_is_not_findall_over_the_stream():
             k = (s0 + m - 1) // stride         # the limit point stride * k + ... : chunk j covers [j*stride, j*stride + bufsize)
             limits = [j * stride + bufsize - ml for j in range(len(data) // stride + 1)]
             assert any(s0 < lim < s0 + m for lim in limits), (bufsize, s0, m)
+
+
+def test_memoising_engine_interpreter_equals_the_oracle(built, corpus, kats):
+    """The reference's memoising backtracker (compiler.go:415-426; its restart offsets depend on the visited set) is INTERPRETED by the
+    product (csrc/rgx_memo.h: the depth-first search of the emitted code over the instructions, one visited word per offset): the host
+    mirror of what the device runs -- automaton for "does the attempt at off match", interpreter for "where does a failed attempt
+    resume" -- equals oracle.Machine(memo).find on every memoising pattern of the corpus, fuzzed texts included; the mirror also
+    asserts that automaton and search never disagree about an attempt."""
+    import random
+    import zlib
+    from tests._hosttest import HostProgram
+    seen = cmp = 0
+    for pat, inputs in dict(_items(corpus, kats)).items():
+        o = E.Compiled(pat)
+        if o.tdfa is not None or not o.sel.find_memo or o.prog.numcap <= 2:
+            continue
+        hp = HostProgram(pat)
+        if hp.memo_find(b"") is NotImplemented:
+            continue
+        info = codegen.Program(pat).info
+        assert info.ref_find_offered and info.ref_find_engine in (0, 2), pat
+        assert info.ref_stream_offered == info.ref_replace_offered == int(not info.can_match_empty), pat
+        seen += 1
+        rnd = random.Random(zlib.crc32(pat.encode()))
+        bs = [s.encode() for s in inputs]
+        alpha = b"".join(bs) or b"ab"
+        texts = bs + [b"x" + s for s in bs] + [s + s for s in bs] + [s[:-1] for s in bs] + [b" ".join(bs), b""]
+        texts += [bytes(rnd.choice(alpha) for _ in range(rnd.randint(0, 120))) for _ in range(40)]
+        for b in texts:
+            assert hp.memo_find(b) == o.FindBytes(b), (pat, b)
+            cmp += 1
+    assert seen >= 14 and cmp >= 800, (seen, cmp)
