@@ -815,7 +815,8 @@ def run_c4(env, args):
                                   "round-robin by the ranks (C ABI: rgx_sharded_round_*), window-relative int32 rows + stream offsets" % (Ltot / 2**30, args.windows),
                       "semantics": "the reference's FindAllBytes over the whole stream (its FindReader would drop %s of 8992 matches per MiB tile at "
                                    "BufferSize 64/128/256 KiB: those straddling dataLen - MaxLeftover of a chunk; not reproduced across GPUs -- "
-                                   "the per-chunk protocol is rgx_find_chunk's)" % "/".join(str(C4_DROPPED_PER_MIB[k]) for k in sorted(C4_DROPPED_PER_MIB)),
+                                   "the per-chunk protocol is rgx_find_chunk's / rgx_count_chunk's, one GPU, the reference's FindReader or "
+                                   "refused: find_reader_reference_mode below)" % "/".join(str(C4_DROPPED_PER_MIB[k]) for k in sorted(C4_DROPPED_PER_MIB)),
                       "pattern": URL, "stream_bytes": Ltot, "bytes_per_gpu": args.windows * W, "window_bytes": W,
                       "halo_left": HALO_L, "halo_right": HALO_R, "matches_total": int(stp["count"]), "expected_matches": int(exp_total),
                       "span_record_bytes": 4 * c.ncap, "parallelism": "window round-robin over %d rank(s)" % world,
@@ -827,10 +828,39 @@ def run_c4(env, args):
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                         "kernel": KERNEL_NAMES.get(c.info.scan_kernel, "rgx scan kernel"), "kernel_ms": round(k_ms, 4),
                         "algorithmic_bytes_per_launch": win_bytes, "timed_launches": args.windows * nsteps}
+    if rank == 0 and c.info.ref_stream_offered:
+        line["config"]["find_reader_reference_mode"] = c4_reader_leg(c, tile, len(A), len(U), len(Z))
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline_findall(URL, "c4", False)
     sh.close()
     return line
+
+
+def c4_reader_leg(c, tile, na, nu, nz):
+    """The reference's own FindReader for C4's pattern (its memoising engine), through rgx_count_chunk in reference mode: the chunk
+    protocol on one GPU from host memory, every chunk's loop vouched for by the engine's interpreter on the device
+    (csrc/rgx_memo.h) or refused.  Bounded: 64 tiles in one chunk (== FindAllBytes of those bytes: nothing deferred), and one tile
+    at the default 64 KiB Config (8992 - 9: the matches the reference drops at chunk edges, pinned by tests/test_ref_engine.py)."""
+    import io
+    from regengo_amd.stream import Config
+    out = {}
+    try:
+        data = tile * 64
+        c.FindReaderCount(io.BytesIO(data[:4 << 20]), Config(128 << 20, 0))
+        t0 = time.perf_counter()
+        n = c.FindReaderCount(io.BytesIO(data), Config(128 << 20, 0))
+        dt = time.perf_counter() - t0
+        exp = na + 62 * nu + nz
+        out.update(one_chunk_bytes=len(data), one_chunk_matches=int(n), one_chunk_expected=int(exp), one_chunk_ms=round(dt * 1e3, 2),
+                   one_chunk_gbs_host_bytes_in=round(len(data) / dt / 1e9, 2))
+        from regengo_amd import synth
+        n64 = c.FindReaderCount(io.BytesIO(synth.web_log_tile(1 << 20)), Config(1 << 16, 0))
+        exp64 = 8992 - C4_DROPPED_PER_MIB[1 << 16]
+        out.update(mib_at_64k_matches=int(n64), mib_at_64k_expected=exp64)
+        out["status"] = "the reference's loop, reproduced" if n == exp and n64 == exp64 else "MISMATCH"
+    except Exception as e:          # a refusal (RGX_E_DIVERGES / RGX_E_UNSUPPORTED) is an answer too: reported, never hidden
+        out["status"] = "refused: %s" % e
+    return out
 
 
 # ------------------------------------------------------------------------------------------------------------------- C5

@@ -9,6 +9,7 @@
 
 #include "../rgx_dfa.h"
 #include "../rgx_memo.h"
+#include "../rgx_tiny.h"
 #include "../rgx_syntax.h"
 
 using namespace rgx;
@@ -91,6 +92,22 @@ void Captures(const Tables& t, const uint8_t* buf, int64_t len, int64_t s, int64
   // a group whose end slot is unset but start is set cannot happen on a winning path
 }
 }  // namespace
+
+template <int NREG>
+static int TinyRun(const std::vector<uint32_t>& img, const uint8_t* buf, int len, bool ref, int unset, int32_t* out) {
+  TinyLane<NREG> L;
+  for (int r = 0; r < NREG; ++r) L.R[r] = img[kTinyInit + r];
+  L.A = img[kTinyInit + 8]; L.q4 = img[kTinyInit + 9]; L.st4 = img[kTinyInit + 10];
+  const auto load_sel = [&](uint32_t cell32, uint32_t* s) { for (int r = 0; r < NREG; ++r) s[r] = img[kTinySel + (cell32 >> 5) * 8 + r]; };
+  for (int p = 0; p < len; ++p) {
+    const uint32_t* cm = &img[kTinyColmap + 2 * buf[p]];
+    if (ref) TinyStep<NREG, true>(L, cm[0], cm[1], load_sel, (uint32_t)p + 1u);
+    else TinyStep<NREG, false>(L, cm[0], cm[1], load_sel, (uint32_t)p + 1u);
+  }
+  const uint32_t* reg_of = &img[kTinyInit + 16];
+  const int ncap = (int)img[kTinyInit + 13];
+  return ref ? TinyFinish<NREG, true>(L, unset, ncap, reg_of, out) : TinyFinish<NREG, false>(L, unset, ncap, reg_of, out);
+}
 
 extern "C" {
 
@@ -383,6 +400,36 @@ int rgxt_memo_attempt(void* hh, const uint8_t* buf, int64_t len, int64_t start, 
   int m = 0;
   const int r = MemoAttempt(h.View(), buf, (int)len, (int)start, S, &m, &budget);
   *mend = m;
+  return r;
+}
+
+// The register-resident per-string kernel (rgx_tiny.h, rgx_batch_tiny.hip) on the host: the same image, the same step and finish functions.
+// hs = the search automaton, hm = the pattern's ordinary tables.  Returns -3: the automaton is not tiny (or, with ref, its restart rule
+// is not in the image), -2: the string is longer than the tag bytes hold, else 0 / 1 / 2 as TinyFinish does; out[ncap] = the record.
+int rgxt_tiny_find(void* hs, void* hm, const uint8_t* buf, int64_t len, int ref, int32_t* out) {
+  const Tables& u = ((Handle*)hs)->t;
+  const Tables& f = ((Handle*)hm)->t;
+  std::vector<uint32_t> img;
+  if (!BuildTinySearch(u, f, &img)) return -3;
+  if (ref && !f.anchored && !img[kTinyInit + 11]) return -3;
+  if (len > kTinyMaxLen) return -2;
+  const int unset = (f.flags & 1u) ? -1 : 0;
+  const bool replay = ref && !f.anchored;
+  int32_t rec[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  int r = -3;
+  switch (img[kTinyInit + 12]) {
+    case 1: r = TinyRun<1>(img, buf, (int)len, replay, unset, rec); break;
+    case 2: r = TinyRun<2>(img, buf, (int)len, replay, unset, rec); break;
+    case 3: r = TinyRun<3>(img, buf, (int)len, replay, unset, rec); break;
+    case 4: r = TinyRun<4>(img, buf, (int)len, replay, unset, rec); break;
+    case 5: r = TinyRun<5>(img, buf, (int)len, replay, unset, rec); break;
+    case 6: r = TinyRun<6>(img, buf, (int)len, replay, unset, rec); break;
+    case 7: r = TinyRun<7>(img, buf, (int)len, replay, unset, rec); break;
+    case 8: r = TinyRun<8>(img, buf, (int)len, replay, unset, rec); break;
+  }
+  if (r > 0)
+    for (int c = 0; c < f.ncap; c++)
+      out[c] = !f.fixed_captures || c < 2 ? rec[c] : (f.cap_kind[c] == kCapFromStart ? rec[0] + f.cap_delta[c] : rec[1] - f.cap_delta[c]);
   return r;
 }
 

@@ -1567,9 +1567,30 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
   static const bool no_search = ExpEnv("RGX_NO_SEARCH_DFA") != nullptr;
   const DevTables* U = no_search ? nullptr : SearchTables(const_cast<Program*>(&p->p));
   if (U && BatchSearchFits(*U, T, true, d_concat)) {
-    // scratch for strings longer than the LDS trace: (bytes + 2 per string) entries
-    // total bytes (scratch sizes) and, in reference mode, the longest string (the length guard): one pass over the offsets, ONE
-    // synchronisation for both
+    static const bool no_tiny = getenv("RGX_NO_TINY") != nullptr;      // diagnostic knob (tests compare the two kernels' answers)
+    if (U->tiny && !no_tiny && BatchTinyFits(*U, T, d_concat, (int64_t)nstr, ref_mode)) {
+      // a tiny automaton: the find, the groups and the restart rule in one pass in registers (rgx_tiny.h).  Launched before anybody has
+      // looked at the offsets: the kernel gives the batch up when a string is longer than its tag bytes hold (ctl[0]), and names the
+      // strings whose attempts the replay kernel has to walk one by one (ctl[1], the list behind)
+      if ((rc = Ensure(&c->d_tdfa, &c->tdfa_cap, (int64_t)(4 + kTinyListCap))) != RGX_OK) return rc;
+      uint32_t* ctl = (uint32_t*)c->d_tdfa;
+      uint32_t h_ctl[4] = {0, 0, 0, 0};
+      HIP_TRY(hipMemsetAsync(ctl, 0, 16, c->stream));
+      HIP_TRY(LaunchBatchTiny(*U, T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, ref_mode, ctl, c->stream));
+      if (ref_mode) HIP_TRY(LaunchBatchRefFixList(T, d_concat, d_offsets, d_found, d_spans, c->d_trace, ctl, kTinyListCap, c->stream));
+      HIP_TRY(hipMemcpyAsync(h_ctl, ctl, 16, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (!h_ctl[0]) {
+        if (ref_mode && h_ctl[1] >= kTinyListCap) {
+          // (more flagged strings than the list holds: every match is at most kTinyMaxLen bytes, the LDS trace of ref_fix_kernel holds it)
+          HIP_TRY(LaunchBatchRefFix(T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, c->d_trace, c->stream, 1));
+          HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        return (int64_t)nstr;
+      }
+    }
+    // scratch for strings longer than the LDS trace: (bytes + 2 per string) entries -- total bytes (scratch sizes) and, in reference
+    // mode, the longest string (the length guard): one pass over the offsets, ONE synchronisation for both
     uint64_t h_last = 0;
     unsigned long long h_max = 0;
     if (ref_mode) {

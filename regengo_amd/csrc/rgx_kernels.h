@@ -112,6 +112,19 @@ bool BatchSearchFits(const DevTables& U, const DevTables& F, bool want_spans, co
 hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8_t* concat, const uint64_t* offsets, int64_t nstr,
                              uint8_t* found, int32_t* spans, void* trace, hipStream_t stream, int window_bytes = 0, int ref = 0);
 
+// ... and for a TINY search automaton (U.tiny, rgx_tiny.h) over a batch of strings of at most kTinyMaxLen bytes: the whole find in one
+// lock-step pass, everything in registers (rgx_batch_tiny.hip).  The launch is OPTIMISTIC -- nobody has looked at the offsets yet: the
+// kernel measures the strings itself and gives the batch up (ctl[0] != 0: results void, take the general path) when one is longer.
+// ref: the reference's restart rule rides along; the strings whose attempts do not land on the match's start get found = 2 and are
+// listed (ctl[1] = how many, ctl[4..] = the first `cap` indices) for LaunchBatchRefFixList, which replays them one by one; more than
+// `cap` of them: LaunchBatchRefFix(only_flagged) over the whole batch.  ctl: 4 + cap words, ctl[0..3] zeroed by the caller.
+constexpr uint32_t kTinyListCap = 65536;
+bool BatchTinyFits(const DevTables& U, const DevTables& F, const uint8_t* concat, int64_t nstr, bool ref);
+hipError_t LaunchBatchTiny(const DevTables& U, const DevTables& F, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,
+                           int32_t* spans, bool ref, uint32_t* ctl, hipStream_t stream);
+hipError_t LaunchBatchRefFixList(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, uint8_t* found, int32_t* spans,
+                                 uint16_t* trace, const uint32_t* ctl, uint32_t cap, hipStream_t stream);
+
 // ---- Replace path (rgx_replace.hip).  A resolved template segment: kind 0 = literal bytes lits[a, a+b); kind 1 = the text of
 // capture group a (0 = the whole match).
 struct ReplSeg {

@@ -1007,12 +1007,8 @@ __global__ __launch_bounds__(64) void ref_batch_kernel(DevTables T, const uint8_
 // stands), runs out of text (no match for the reference: the record is cleared) or steps over s (rare: the emitted loop goes
 // on from there with full attempts, as ref_batch_kernel does).  The attempt-per-offset loop walks a word of n bytes n/2 times
 // (quadratic: 7.7 ms on the C3 batch against 1 ms for the plain search); this is linear.
-__global__ __launch_bounds__(64) void ref_fix_kernel(DevTables T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr,
-                                                     uint8_t* found, int32_t* spans, uint16_t* trace, int only_flagged) {
-  __shared__ uint16_t s_trace[64 * kCapsLdsTrace];
-  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
-  if (i >= nstr || !found[i]) return;           // no match anywhere in the string: the emitted loop finds none either
-  if (only_flagged && found[i] != 2) return;    // (the search kernel has replayed the others itself)
+__device__ void RefFixOne(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t i, uint8_t* found, int32_t* spans,
+                          uint16_t* trace, uint16_t* s_trace) {
   const uint64_t o0 = offsets[i], o1 = offsets[i + 1];
   const uint8_t* buf = concat + o0;
   const int len = (int)(o1 - o0);
@@ -1043,6 +1039,26 @@ __global__ __launch_bounds__(64) void ref_fix_kernel(DevTables T, const uint8_t*
   const int need = e - s + 1;
   uint16_t* tr = need <= kCapsLdsTrace ? s_trace + threadIdx.x * kCapsLdsTrace : trace + o0 + 2 * i;
   ResolveCaptures(T, buf, len, s, e, tr, rec);
+}
+
+__global__ __launch_bounds__(64) void ref_fix_kernel(DevTables T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr,
+                                                     uint8_t* found, int32_t* spans, uint16_t* trace, int only_flagged) {
+  __shared__ uint16_t s_trace[64 * kCapsLdsTrace];
+  const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= nstr || !found[i]) return;           // no match anywhere in the string: the emitted loop finds none either
+  if (only_flagged && found[i] != 2) return;    // (the search kernel has replayed the others itself)
+  RefFixOne(T, concat, offsets, i, found, spans, trace, s_trace);
+}
+
+// ... over a LIST of strings (batch_tiny_kernel names the few it flags: ctl[1] = how many, ctl + 4 = their indices, `cap` of them at most --
+// beyond that, and when ctl[0] is set -- the kernel gave the batch up --, this one does nothing and the host takes the whole-batch path)
+__global__ __launch_bounds__(64) void ref_fix_list_kernel(DevTables T, const uint8_t* concat, const uint64_t* offsets, uint8_t* found,
+                                                          int32_t* spans, uint16_t* trace, const uint32_t* ctl, uint32_t cap) {
+  __shared__ uint16_t s_trace[64 * kCapsLdsTrace];
+  if (ctl[0]) return;
+  const uint32_t n = ctl[1] < cap ? ctl[1] : 0u;
+  for (uint32_t k = blockIdx.x * 64 + threadIdx.x; k < n; k += gridDim.x * 64)
+    RefFixOne(T, concat, offsets, (int64_t)ctl[4 + k], found, spans, trace, s_trace);
 }
 
 // ---- batch, reference mode, the MEMOISING engine (rgx_memo.h) ------------------------------------------------------------------------
@@ -2454,6 +2470,7 @@ hipError_t LaunchReaderCheck(const DevTables& T, const uint8_t* raw, const uint8
 
 namespace {
 __global__ __launch_bounds__(256) void max_len_kernel(const uint64_t* offsets, long long nstr, unsigned long long* out) {
+  __shared__ unsigned long long s_m[4];
   unsigned long long m = 0;
   for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nstr; i += (long long)gridDim.x * 256) {
     const unsigned long long l = offsets[i + 1] - offsets[i];
@@ -2461,9 +2478,16 @@ __global__ __launch_bounds__(256) void max_len_kernel(const uint64_t* offsets, l
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { const unsigned long long o = __shfl_xor(m, d, 64); m = o > m ? o : m; }
-  if ((threadIdx.x & 63) == 0 && m) atomicMax(out, m);
+  if ((threadIdx.x & 63) == 0) s_m[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    // one atomic per workgroup, and only when it would raise the maximum (8192 waves on one address took 0.1 ms of a 0.4 ms call)
+    for (int w = 1; w < 4; ++w) m = s_m[w] > m ? s_m[w] : m;
+    if (m > __hip_atomic_load(out, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(out, m);
+  }
 }
 }  // namespace
+
 hipError_t LaunchMaxStringLen(const uint64_t* offsets, int64_t nstr, unsigned long long* out, hipStream_t stream) {
   if (nstr <= 0) return hipSuccess;
   const unsigned grid = (unsigned)std::min<long long>((nstr + 255) / 256, 2048);
@@ -2762,6 +2786,12 @@ hipError_t LaunchBatchRefFix(const DevTables& T, const uint8_t* concat, const ui
   if (nstr <= 0) return hipSuccess;
   dim3 block(64), grid((unsigned)((nstr + 63) / 64));
   hipLaunchKernelGGL(ref_fix_kernel, grid, block, 0, stream, T, concat, offsets, nstr, found, spans, trace, only_flagged);
+  return hipGetLastError();
+}
+
+hipError_t LaunchBatchRefFixList(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, uint8_t* found, int32_t* spans,
+                                 uint16_t* trace, const uint32_t* ctl, uint32_t cap, hipStream_t stream) {
+  hipLaunchKernelGGL(ref_fix_list_kernel, dim3(64), dim3(64), 0, stream, T, concat, offsets, found, spans, trace, ctl, cap);
   return hipGetLastError();
 }
 

@@ -5,6 +5,7 @@
 #include <cstring>
 
 #include "rgx.h"
+#include "rgx_tiny.h"
 
 namespace rgx {
 
@@ -13,8 +14,9 @@ void SetError(const std::string& s) { g_error = s; }
 const std::string& GetError() { return g_error; }
 
 Program::~Program() {
-  if (d_arena || d_arena_u || d_arena_us || d_arena_tdfa || d_arena_memo) {
+  if (d_arena || d_arena_u || d_arena_us || d_arena_tdfa || d_arena_memo || d_tiny) {
     hipSetDevice(device);
+    if (d_tiny) hipFree(d_tiny);
     if (d_arena_tdfa) hipFree(d_arena_tdfa);
     if (d_arena_memo) hipFree(d_arena_memo);
     if (d_arena) hipFree(d_arena);
@@ -461,6 +463,16 @@ const DevTables* SearchTables(Program* p) {
         if (UploadTables(p->u, &p->direct_table_u, &p->udev, &p->d_arena_u) == RGX_OK) {
           p->udev.unmatched_minus1 = p->dev.unmatched_minus1;
           p->u_state = 1;
+          // a tiny automaton gets the register-resident per-string kernel (rgx_tiny.h); best effort: without it batch_search_kernel runs
+          std::vector<uint32_t> img;
+          p->udev.tiny = nullptr;
+          if (BuildTinySearch(p->u, p->t, &img) && hipMalloc(&p->d_tiny, img.size() * 4) == hipSuccess) {
+            if (hipMemcpy(p->d_tiny, img.data(), img.size() * 4, hipMemcpyHostToDevice) == hipSuccess) {
+              p->udev.tiny = (const uint32_t*)p->d_tiny;
+              p->udev.tiny_replay = (int32_t)img[kTinyInit + 11];
+              p->udev.tiny_nreg = (int32_t)img[kTinyInit + 12];
+            }
+          }
         }
       } catch (...) {
         p->u_state = -1;   // too many states / unsupported: the restart loop over the anchored DFA still works

@@ -89,6 +89,9 @@ struct DevTables {
                                   // (ref_find_engine == 2) and the interpreter takes it (at most 64 Alt instructions), else nullptr
   const TdfaDev* tdfa;            // HOST pointer to the reference's Tagged DFA on the device (rgx_tdfa.hip) when the reference emits one, else nullptr
   const UsDev* us;                // HOST pointer to the program's UsDev when the pattern is eligible for rgx_scan_us.hip, else nullptr
+  const uint32_t* tiny;           // search automaton only: DEVICE pointer to its image for batch_tiny_kernel (rgx_tiny.h), nullptr when it is not tiny
+  int32_t tiny_nreg;              // ... its tag registers (1-8: the kernel's instantiations)
+  int32_t tiny_replay;            // ... and the image carries the reference's restart rule (right-most-path automaton of at most 8 states, depth 0)
   uint16_t start[4];
   uint8_t start_accept[4];
   uint8_t lookahead, ctx_sensitive, bot_sensitive, anchored, fixed_captures, unmatched_minus1;
@@ -174,6 +177,7 @@ struct Program {
   int device = -1;
   void* d_arena = nullptr;  // one allocation holding every table
   void* d_arena_u = nullptr;
+  void* d_tiny = nullptr;   // the search automaton's tiny image (rgx_tiny.h), when it has one
   DevTables dev{};
   DevTables udev{};
   std::vector<uint16_t> direct_table;  // host copy of the direct layout (mode 0)

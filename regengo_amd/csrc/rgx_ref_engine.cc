@@ -20,6 +20,7 @@
 
 #include "rgx_dfa.h"
 #include "rgx_memo.h"
+#include "rgx_tiny.h"
 
 namespace rgx {
 namespace {
@@ -322,6 +323,115 @@ bool BuildMemoProg(const Prog& prog, MemoHost* out) {
 int RefTdfaStates(const Prog& prog, int max_states) {
   RefTdfa t;
   return BuildRefTdfa(prog, 1, &t, max_states) ? t.nstates : -1;
+}
+
+// rgx_tiny.h: the image of a tiny search automaton -- byte-indexed columns of the two automata and the v_perm selectors of the tag
+// registers per edge, composed from the back-trace tables (parents and ops per thread of the target state)
+bool BuildTinySearch(const Tables& u, const Tables& f, std::vector<uint32_t>* img) {
+  const int S = u.nstates, C = u.ncls, stride = C + 1;
+  const int ncap = f.fixed_captures ? 2 : f.ncap;           // the slots tracked (fixed_captures: the others follow from start and end)
+  if (u.lookahead_mode || S < 2 || S > 6 || C > 8 || u.max_threads > 3 || ncap < 2 || ncap > 8) return false;
+  if ((int)u.st_nthreads.size() != S || (int)u.bt_base.size() != S * stride || u.start_ops.size() < 4) return false;
+  img->assign(kTinyWords, 0u);
+  uint32_t* cm = img->data() + kTinyColmap;
+  uint32_t* sel = img->data() + kTinySel;
+  uint32_t* ini = img->data() + kTinyInit;
+  // the replay columns: the right-most-path automaton of FindBytesReuse's branch order, when it has at most 8 states and dies AT a byte
+  const int fstride = f.ncls + 1;
+  const int nrm = f.rm_trans[0].empty() ? 0 : (int)f.rm_trans[0].size() / fstride;
+  bool rm_ok = nrm >= 1 && nrm <= 8 && (int)f.rm_depth[0].size() >= nrm;
+  for (int s = 0; rm_ok && s < nrm; ++s) if (f.rm_depth[0][s] != 0) rm_ok = false;
+  for (int ctx = 0; rm_ok && ctx < 4; ++ctx) if (f.rm_start[0][ctx] >= nrm) rm_ok = false;
+  for (int b = 0; b < 256; ++b) {
+    const int k = u.cls[b];
+    uint32_t col = (uint32_t)k << 28;                       // (states 0-5 in bits 0-22; bits 23-27 and 31 stay clear: col >> 23 = class * 32)
+    for (int s = 1; s < S; ++s) {
+      const uint32_t nx = u.trans[(size_t)s * stride + k] & kStateMask;
+      if (nx >= (uint32_t)S) return false;
+      col |= nx << (4 * s);
+    }
+    cm[2 * b + 0] = col;
+    uint32_t rc = 0;
+    if (rm_ok) {
+      const uint32_t restart = 8u | (uint32_t)f.rm_start[0][f.ctx_of_byte[b]];
+      for (int s = 0; s < nrm; ++s) {
+        const uint16_t e = f.rm_trans[0][(size_t)s * fstride + f.cls[b]];
+        if (e != 0xFFFFu && e >= 8) { rm_ok = false; break; }
+        rc |= (e == 0xFFFFu ? restart : (uint32_t)e) << (4 * s);
+      }
+    }
+    cm[2 * b + 1] = rc;
+  }
+  // per capture slot: its selector on every edge and its value at offset 0
+  std::vector<std::vector<uint32_t>> selc(ncap, std::vector<uint32_t>(64, kTinyIdentity));
+  std::vector<uint32_t> inic(ncap, 0xFFFFFFFFu);
+  for (int s = 1; s < S; ++s) {
+    for (int k = 0; k < C; ++k) {
+      const uint16_t e = u.trans[(size_t)s * stride + k];
+      const int nx = e & kStateMask;
+      if (nx == 0) continue;                       // every thread dies: byte 3 (the last match) keeps itself, the others no longer matter
+      const uint32_t base = u.bt_base[(size_t)s * stride + k];
+      const int nth = (int)u.st_nthreads[nx];
+      if (base == 0xFFFFFFFFu || nth < 1 || nth > 3 || base + nth > u.bt_parent.size()) return false;
+      const bool flagged = (e & kMatchAfter) != 0;
+      for (int c = 0; c < ncap; ++c) {
+        uint32_t w = kTinyIdentity;
+        for (int j = 0; j < nth; ++j) {
+          const int par = u.bt_parent[base + j];
+          if (par > 2) return false;
+          const uint32_t pick = ((u.bt_ops[base + j] >> c) & 1u) ? 4u : (uint32_t)par;      // 4: byte 0 of v_perm's first source = the offset
+          w = (w & ~(0xFFu << (8 * j))) | (pick << (8 * j));
+        }
+        if (flagged) w = (w & 0x00FFFFFFu) | (((w >> (8 * (nth - 1))) & 0xFFu) << 24);      // the Match thread is the last of the list
+        if (c == 1) w = flagged ? 0x04020100u : kTinyIdentity;                             // slot 1: the match end
+        selc[c][s * 8 + k] = w;
+      }
+    }
+  }
+  // offset 0: the start state's threads with the slots their initial closure assigns
+  const int q0 = u.start[kCtxBOT];
+  if (q0 <= 0 || q0 >= S) return false;
+  const int nth0 = (int)u.st_nthreads[q0];
+  if (nth0 < 1 || nth0 > 3 || u.start_ops[kCtxBOT] + nth0 > u.start_ops_pool.size()) return false;
+  for (int c = 0; c < ncap; ++c) {
+    uint32_t w = 0xFFFFFFFFu;
+    for (int j = 0; j < nth0; ++j)
+      if ((u.start_ops_pool[u.start_ops[kCtxBOT] + j] >> c) & 1u) w &= ~(0xFFu << (8 * j));
+    if (u.start_accept[kCtxBOT]) {                 // the empty match at offset 0: the Match thread is the last of the start state
+      w = (w & 0x00FFFFFFu) | (((w >> (8 * (nth0 - 1))) & 0xFFu) << 24);
+      if (c == 1) w = 0x00FFFFFFu;
+    }
+    inic[c] = w;
+  }
+  // slots that move together share a register (`(\w+)@(\w+)`: slot 2 is slot 0, the match end is slot 5: four registers for six slots);
+  // the match end has no thread bytes of its own -- it may ride in any register whose byte 3 takes the offset on every kMatchAfter edge
+  int nreg = 0;
+  std::vector<int> reg_of(ncap, -1), cap_of_reg;
+  for (int c = 0; c < ncap; ++c) {
+    if (c == 1) continue;
+    for (int r = 0; r < nreg && reg_of[c] < 0; ++r)
+      if (selc[cap_of_reg[r]] == selc[c] && inic[cap_of_reg[r]] == inic[c]) reg_of[c] = r;
+    if (reg_of[c] < 0) { reg_of[c] = nreg++; cap_of_reg.push_back(c); }
+  }
+  for (int r = 0; r < nreg && reg_of[1] < 0; ++r) {
+    const int d = cap_of_reg[r];
+    bool same = (inic[d] >> 24) == (inic[1] >> 24);
+    for (int cell = 0; same && cell < 64; ++cell) same = (selc[d][cell] >> 24) == (selc[1][cell] >> 24);
+    if (same) reg_of[1] = r;
+  }
+  if (reg_of[1] < 0) { reg_of[1] = nreg++; cap_of_reg.push_back(1); }
+  if (nreg > 8 || reg_of[0] != 0) return false;
+  for (int cell = 0; cell < 64; ++cell)
+    for (int r = 0; r < 8; ++r) sel[cell * 8 + r] = r < nreg ? selc[cap_of_reg[r]][cell] : kTinyIdentity;
+  for (int r = 0; r < nreg; ++r) ini[r] = inic[cap_of_reg[r]];
+  ini[8] = 0x01010101u;                            // offset 0 is FindBytesReuse's first attempt
+  ini[9] = (uint32_t)q0 << 2;
+  ini[10] = rm_ok ? (uint32_t)f.rm_start[0][kCtxBOT] << 2 : 0u;
+  ini[11] = rm_ok ? 1u : 0u;
+  ini[12] = (uint32_t)nreg;
+  ini[13] = (uint32_t)ncap;
+  for (int c = 0; c < ncap; ++c) ini[16 + c] = (uint32_t)reg_of[c];
+  return true;
 }
 
 }  // namespace rgx

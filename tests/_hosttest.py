@@ -44,6 +44,7 @@ _lib.rgxt_tdfa_header.argtypes = [C.c_void_p, C.c_void_p]
 _lib.rgxt_tdfa_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 5
 _lib.rgxt_tdfa_find.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p]
 _lib.rgxt_memo_find.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p]
+_lib.rgxt_tiny_find.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int64, C.c_int, C.c_void_p]
 
 INFO = ["ncap", "min", "max", "ninst", "nstates", "ncls", "anchored", "fixed", "empty", "refm", "reff", "look", "maxthr"]
 
@@ -116,6 +117,13 @@ class HostProgram:
         r = _lib.rgxt_search_first(sp.h, self.h, b, len(b), out)
         assert r >= 0, "winning thread without Capture 0"
         return list(out) if r == 1 else None
+
+    def tiny_find(self, sp: "HostProgram", b: bytes, ref: bool):
+        """csrc/rgx_tiny.h on the host (what batch_tiny_kernel runs per lane): (code, record) -- code 0 no match, 1 found, 2 found but
+        the reference's attempts step over its start (ref_fix_kernel's case), -2 string too long, -3 the automaton is not tiny."""
+        out = (C.c_int32 * self.info["ncap"])()
+        r = _lib.rgxt_tiny_find(sp.h, self.h, b, len(b), 1 if ref else 0, out)
+        return r, list(out)
 
     def w_sync(self, b: bytes, y: int = 0):
         """(number of W states, flags[len+1]): flags[i] = the sync automaton started blind at y is empty at offset i."""

@@ -1,0 +1,167 @@
+"""batch_tiny_kernel (csrc/rgx_batch_tiny.hip, rgx_tiny.h): FindBytes per string for tiny search automata -- one lock-step pass, the
+state, the capture groups (v_perm tag registers) and the reference's restart rule in registers -- against the oracle, in both modes,
+and against the kernel it stands in for (batch_search_kernel: RGX_NO_TINY=1 in a process of its own)."""
+import hashlib
+import json
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+EMAIL = r"(?P<user>\w+)@(?P<domain>\w+)"
+EXTRA = [EMAIL, r"\w+@\w+", r"(\w+)@", r"(?P<k>[a-z]+)=(?P<v>\d*)", r"(a+)(b+)", r"(\d+)-(\d+)", r"(?P<a>x|xy)(?P<b>y?z)", r"[a-c]+@|@[x-z]", r"a(b|c)d", r"(ab)+c"]
+
+
+@pytest.fixture(scope="module")
+def torch_dev():
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch
+
+
+def _tiny_patterns(corpus, kats, hostlib):
+    out = []
+    for p in dict.fromkeys([e["pattern"] for e in corpus] + [c["pattern"] for c in kats["curated_cases"]] + EXTRA):
+        try:
+            hp = hostlib.HostProgram(p)
+        except ValueError:
+            continue
+        if hp.info["anchored"]:
+            continue
+        sp = hp.search_program(p)
+        if sp is not None and hp.tiny_find(sp, b"", False)[0] != -3:
+            out.append(p)
+    return out
+
+
+def _texts(pat, inputs, rng):
+    from regengo_amd import synth
+    data, offs = synth.email_batch_np(300, seed=len(pat))
+    bs = [s.encode() for s in inputs] + [bytes(data[offs[i]:offs[i + 1]]) for i in range(300)]
+    alpha = sorted(set(b"".join(bs) + b" a@.-_1=xyz\n")) if pat not in (r"a(b|c)d", r"(ab)+c") else list(b"abcd")
+    bs += [bytes(rng.choice(alpha) for _ in range(rng.randrange(0, 57))) for _ in range(300)]
+    return [b[:56] for b in bs] + [b""]
+
+
+def test_tiny_kernel_equals_the_oracle_in_both_modes(torch_dev, corpus, kats, hostlib):
+    from oracle import engines as E
+    from regengo_amd import Compiled, _capi
+    rng = random.Random(31337)
+    inputs_of = {e["pattern"]: e["inputs"] for e in corpus}
+    inputs_of.update({c["pattern"]: c["inputs"] for c in kats["curated_cases"]})
+    pats = _tiny_patterns(corpus, kats, hostlib)
+    assert len(pats) >= 20
+    plain = ref = refused = 0
+    for pat in pats:
+        o = E.Compiled(pat)
+        strings = _texts(pat, inputs_of.get(pat, []), rng)
+        c = Compiled(pat, stdlib=True).to(0)
+        for b, r in zip(strings, c.FindBatch(strings)):
+            exp = o.find_machine.find_all(b, 1)
+            if exp:
+                assert r is not None and r.spans == exp[0], (pat, b, r and r.spans, exp[0])
+            elif r is not None:      # FindBytes also tries at offset len(b) (find.go:545-569); FindAll does not
+                assert r.spans[0] == len(b) and r.spans[1] == len(b), (pat, b, r.spans)
+            plain += 1
+        c = Compiled(pat).to(0)
+        try:
+            res = c.FindBatch(strings)
+        except _capi.RgxError as ex:
+            assert ex.status == _capi.RGX_E_UNSUPPORTED, pat
+            refused += 1
+            continue
+        for b, r in zip(strings, res):
+            exp = o.FindBytes(b)
+            assert (r is None) == (exp is None) and (r is None or r.spans == exp), (pat, b, r and r.spans, exp)
+            ref += 1
+    assert plain > 12000 and ref > 9000 and refused <= 2, (plain, ref, refused)
+
+
+_DIGEST = r"""
+import hashlib, json, sys
+sys.path.insert(0, %r)
+import numpy as np, torch
+from regengo_amd import Compiled, synth
+out = {}
+for pat in json.loads(sys.argv[1]):
+    for stdlib in (False, True):
+        c = Compiled(pat, stdlib=stdlib).to(0)
+        data, offs = synth.email_batch_np(300000, seed=11)
+        f, s = c.FindBatchDevice(torch.from_numpy(data).cuda(), torch.from_numpy(offs).cuda())
+        f = f.cpu().numpy(); s = s.cpu().numpy()
+        h = hashlib.sha256(f.tobytes()); h.update(np.ascontiguousarray(s[f != 0]).tobytes())
+        out[pat + "|" + str(stdlib)] = [h.hexdigest(), int(f.sum())]
+print(json.dumps(out))
+"""
+
+
+def test_tiny_kernel_equals_the_search_kernel_on_300k_strings(torch_dev):
+    """Config C3's batch at 300 k strings, four tiny patterns, both modes: found flags and the records of the found strings are the same
+    bytes with the register-resident kernel and with batch_search_kernel + ref_fix_kernel (RGX_NO_TINY=1)."""
+    pats = [EMAIL, r"\w+@\w+", r"(?P<k>[a-z]+)=(?P<v>\d*)", r"(a+)(b+)"]
+    res = []
+    for env in ({}, {"RGX_NO_TINY": "1"}):
+        e = dict(os.environ)
+        e.update(env)
+        r = subprocess.run([sys.executable, "-c", _DIGEST % ROOT, json.dumps(pats)], env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert res[0] == res[1]
+    assert res[0][EMAIL + "|False"][1] > 150000
+
+
+def test_tiny_kernel_c3_sample_vs_oracle(torch_dev):
+    from oracle.gen_c import CMatcher
+    from regengo_amd import Compiled, synth
+    torch = torch_dev
+    data, offs = synth.email_batch_np(500000, seed=0x5EED0003)
+    c = Compiled(EMAIL, name="Email").to(0)
+    f, s = c.FindBatchDevice(torch.from_numpy(data).cuda(), torch.from_numpy(offs).cuda())
+    f = f.cpu().numpy(); s = s.cpu().numpy()
+    cm = CMatcher(EMAIL)
+    n = 0
+    for i in range(0, 500000, 41):
+        b = np.ascontiguousarray(data[offs[i]:offs[i + 1]])
+        exp = cm.find(bytes(b))
+        assert bool(f[i]) == (exp is not None), i
+        if exp is not None:
+            assert s[i].tolist() == list(exp), (i, s[i].tolist(), exp)
+        n += 1
+    assert n > 12000
+
+
+def test_tiny_kernel_gives_up_on_a_long_string_and_lists_the_flagged(torch_dev):
+    """The launch is optimistic (nobody has measured the strings): one string beyond the tag bytes anywhere in the batch and the answer
+    comes from the general path instead; the strings whose attempts step over the match's start are replayed from the kernel's list, or
+    -- more of them than the list holds (65536) -- by the whole-batch pass.  All three against the oracle."""
+    from oracle import engines as E
+    from regengo_amd import Compiled
+    rng = random.Random(5)
+    pat = r"a(b|c)d"
+    o = E.Compiled(pat)
+    base = [bytes(rng.choice(b"abcd") for _ in range(rng.randrange(0, 30))) for _ in range(3000)]
+    exp = {b: o.FindBytes(b) for b in set(base) | {b"x" * 40 + b"aabd" + b"y" * 60}}
+    stepped = sum(1 for b in base if exp[b] is None and o.find_machine.find_all(b, 1))
+    assert stepped > 20            # (the reference's restart rule loses these matches)
+    c = Compiled(pat).to(0)
+    for strings in (base,                                             # a few flagged: the list
+                    base[:1500] + [b"x" * 40 + b"aabd" + b"y" * 60] + base[1500:],     # one string of 104 bytes: the general path
+                    base * 40):                                       # 120 k strings, thousands flagged ...
+        res = c.FindBatch(strings)
+        for b, r in zip(strings, res):
+            e = exp[b]
+            assert (r is None) == (e is None) and (r is None or r.spans == e), (pat, b, r and r.spans, e)
+    many = [b"aabd"] * 70000 + base                                   # ... and more flagged than the list holds
+    res = c.FindBatch(many)
+    e0 = o.FindBytes(b"aabd")
+    assert e0 is None and o.find_machine.find_all(b"aabd", 1)
+    for b, r in zip(many, res):
+        e = e0 if b == b"aabd" else exp[b]
+        assert (r is None) == (e is None) and (r is None or r.spans == e), (pat, b, r and r.spans, e)

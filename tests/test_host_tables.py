@@ -140,6 +140,56 @@ def test_search_automaton_equals_restart_loop(corpus, kats, hostlib):
     assert nosearch <= 8
 
 
+def test_tiny_search_image_equals_the_oracle(corpus, kats, hostlib):
+    """csrc/rgx_tiny.h (what batch_tiny_kernel runs per lane: columns per byte, v_perm tag registers, the restart rule riding along), run
+    on the host over the image the product builds: without the restart rule == the search automaton's walk + back-trace; with it == the
+    oracle's FindBytes (the reference's emitted loop), except where it reports "the attempts step over the start" (code 2: the device
+    hands those strings to ref_fix_kernel) -- and then the record's start really is not an attempt offset."""
+    rng = random.Random(9177)
+    items = [(e["pattern"], e["inputs"]) for e in corpus] + [(c["pattern"], c["inputs"]) for c in kats["curated_cases"]]
+    # config C3's pattern and relatives (the corpus holds few patterns this small whose FindBytes the reference backtracks plainly)
+    from regengo_amd import synth
+    data, offs = synth.email_batch_np(400, seed=77)
+    mails = [bytes(data[offs[i]:offs[i + 1]]).decode("latin-1") for i in range(400) if data[offs[i]:offs[i + 1]].max() < 128]
+    items += [(q, mails) for q in (r"(?P<user>\w+)@(?P<domain>\w+)", r"\w+@\w+", r"(\w+)@", r"(?P<k>[a-z]+)=(?P<v>\d*)", r"(a+)(b+)", r"(\d+)-(\d+)",
+                                   r"(?P<a>x|xy)(?P<b>y?z)", r"[a-c]+@|@[x-z]")]
+    items += [(q, ["abd", "acd", "ababc", "aabcabd", "abab"]) for q in (r"a(b|c)d", r"(ab)+c")]      # (attempt sequences that step over a match's start)
+    tiny = plain = ref = stepped = 0
+    for p, inputs in items:
+        try:
+            hp = hostlib.HostProgram(p)
+        except ValueError:
+            continue
+        if hp.info["anchored"]:
+            continue
+        sp = hp.search_program(p)
+        if sp is None or hp.tiny_find(sp, b"", False)[0] == -3:
+            continue
+        tiny += 1
+        o = E.Compiled(p)
+        with_ref = o.sel.find_engine == "backtracking" and hp.tiny_find(sp, b"", True)[0] != -3
+        alphabet = sorted(set(b"".join(x.encode("utf-8", "surrogateescape") if isinstance(x, str) else bytes(x) for x in inputs) + b" a@.-_1\n")) \
+            if inputs else list(b" a@.-_1\n")
+        texts = list(_mutations(inputs, rng)) + [bytes(rng.choice(alphabet) for _ in range(rng.randrange(0, 57))) for _ in range(80)]
+        for b in texts:
+            b = b[:56]
+            code, rec = hp.tiny_find(sp, b, False)
+            exp = hp.search_first(sp, b)
+            assert (rec if code == 1 else None) == exp, (p, b, code, rec, exp)
+            plain += 1
+            if not with_ref:
+                continue
+            code, rec = hp.tiny_find(sp, b, True)
+            m = o.FindBytes(b)
+            if code == 2:
+                stepped += 1
+                assert exp is not None and rec[0] == exp[0] and (m is None or list(m)[0] != exp[0]), (p, b, rec, m)
+                continue
+            assert (rec if code == 1 else None) == (None if m is None else list(m)), (p, b, code, rec, m)
+            ref += 1
+    assert tiny >= 20 and plain > 5000 and ref > 3000 and stepped > 0, (tiny, plain, ref, stepped)
+
+
 def test_sync_automaton_is_sound(corpus, kats, hostlib):
     """Wherever the sync automaton W -- started blind, anywhere -- reports the empty set, no FindAll match of the
     oracle that began earlier is still running: a worker may start there knowing nothing else.  Also: W exists for
