@@ -129,16 +129,20 @@ def sustained(env, run_steps, steps, warmup):
     return dt, reps
 
 
-def load_traffic(name):
+def load_traffic(name, kernel=None):
     """HBM bytes per launch of the dominant kernel from the PMC passes kept under profiles/ (scripts/pmc_traffic.sh: rocprofv3 --pmc in
     runs of their own, FETCH_SIZE and WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes).  Counters need the
-    profiler, so this run cannot measure them itself: it cites the file and the run id the file carries.  (traffic, source) or
-    (None, None)."""
-    for rnd in ("r03", "r02"):
+    profiler, so this run cannot measure them itself: it cites the file and the run id the file carries -- the newest round's, and only
+    a file that measured the kernel this run launches (`kernel`: a substring of its name).  (traffic, source) or (None, None)."""
+    for rnd in ("r04", "r03", "r02"):
         pj = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, name))
         if os.path.exists(pj):
             try:
                 d = json.load(open(pj))
+                if kernel and rnd >= "r04" and not any(kernel in k for k in d.get("kernel", [])):
+                    continue
+                if kernel and rnd < "r04" and kernel in ("batch_tiny", "tdfa_batch"):
+                    continue                      # (kernels that did not exist when that file was made)
                 src = "profiles/%s_pmc_%s.json" % (rnd, name)
                 if d.get("run_id"):
                     src += " (run %s)" % d["run_id"]
@@ -625,7 +629,7 @@ def run_c3(env, args):
     k_ms = sum(kms) / len(kms)
     alg = nbytes + 8 * (nstr + 1) + nstr + nstr * c.ncap * 4      # input bytes + CSR offsets + found flags + span records
     achieved = alg / (k_ms * 1e-3) / 1e9
-    traffic, tsrc = load_traffic("c3")
+    traffic, tsrc = load_traffic("c3", "tdfa_batch" if args.force_tdfa else "batch_tiny")
     line = base_line(env, args, value, ms_per_step, reps)
     line["config"] = {"workload": "C3: Email pattern FindBytes over a batch of %d strings per GPU (reference semantics), found flag + "
                                   "span record per string" % nstr,
@@ -638,7 +642,7 @@ def run_c3(env, args):
     line["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                         "kernel": "tdfa_batch_kernel (a lane per string: the loop over start offsets, the table walk, the tag file in LDS)" if args.force_tdfa else
-                                  "batch_search_kernel + ref_fix_kernel (the call: search automaton walk, back-trace, replay of the reference attempt offsets; flagged strings finished by ref_fix_kernel)", "kernel_ms": round(k_ms, 4),
+                                  "batch_tiny_kernel + ref_fix_list_kernel (the call: one lock-step pass per string in registers -- search automaton columns, v_perm tag registers for the groups, the reference's attempt offsets riding along; strings it flags replayed from its list.  Strings beyond 56 bytes would send the batch to batch_search_kernel: none here)", "kernel_ms": round(k_ms, 4),
                         "algorithmic_bytes_per_launch": alg, "timed_launches": len(kms),
                         "note": "event-bracketed call: includes the launch of the call's kernels"}
     if not args.no_cpu_baseline and env.world == 1:

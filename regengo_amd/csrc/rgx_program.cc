@@ -383,6 +383,8 @@ int UploadTdfa(Program* p) {
   d.nstates = S; d.ntags = r.ntags; d.start_begin = r.start_begin; d.start_any = r.start_any;
   d.init_begin = r.init_begin; d.init_any = r.init_any;
   d.sinfo_begin = sinfo[r.start_begin]; d.sinfo_any = sinfo[r.start_any];
+  d.any_never = (d.sinfo_any & 3u) ? 0 : 1;
+  for (int c = 0; c < 128 && d.any_never; c++) if (r.trans[(size_t)r.start_any * 128 + c] >= 0) d.any_never = 0;
   p->tdfadev = d;
   p->d_arena_tdfa = dptr;
   return RGX_OK;

@@ -154,6 +154,8 @@ struct TdfaDev {
   int32_t start_begin, start_any;      // startStateBegin / startStateAny
   int32_t init_begin, init_any;        // initialTagsBegin / initialTagsAny (pool indices)
   uint32_t sinfo_begin, sinfo_any;     // sinfo of the two start states
+  int32_t any_never;                   // 1: startStateAny neither accepts nor has a transition on any byte -- an attempt behind offset 0 cannot
+                                       // match (a pattern that begins with ^): the loop over start offsets is one attempt
 };
 
 struct Program {

@@ -57,8 +57,8 @@ template <> struct Tab<true> { typedef const uint32_t TDFA_LDS* P; };
 template <> struct Tab<false> { typedef const uint32_t* P; };
 
 // One attempt without tags (tdfa.go:939-987 minus the tag traffic): the end of its last accept, or -1.
-template <class EntP>
-__device__ __forceinline__ int AttemptEnd(EntP ent, const uint8_t* buf, int len, int start, int st, uint32_t st_flags, int* steps) {
+template <class EntP, class BufP>
+__device__ __forceinline__ int AttemptEnd(EntP ent, BufP buf, int len, int start, int st, uint32_t st_flags, int* steps) {
   int end = -1;
   if (st_flags & 1u) end = start;
   if (start == len && (st_flags & 2u)) end = start;
@@ -79,8 +79,8 @@ __device__ __forceinline__ int AttemptEnd(EntP ent, const uint8_t* buf, int len,
 // The same with the tag file (LDS, one column per lane: tag t of lane l at tags[t * 256 + l]) and the result construction.
 // Returns the end (>= 0: out[0 .. ntags) holds the reported tags) or -1.  Only called for attempts known to accept -- the walk
 // stops at `stop` = the end found by AttemptEnd (the snapshot of the last accept is the tag file right there).
-template <class EntP>
-__device__ __forceinline__ void AttemptTags(EntP ent, const int16_t* pool, const uint8_t* buf, int len, int start, int stop, int st,
+template <class EntP, class BufP>
+__device__ __forceinline__ void AttemptTags(EntP ent, const int16_t* pool, BufP buf, int len, int start, int stop, int st,
                                             int init_list, int ntags, int TDFA_LDS* tags, int32_t* out, const uint32_t* sinfo) {
   for (int t = 0; t < ntags; ++t) tags[t * 256] = -1;
   tags[0] = start;
@@ -322,41 +322,134 @@ __global__ __launch_bounds__(256) void tdfa_tags_kernel(TdfaDev D, const uint8_t
 }
 
 // ---------------------------------------------------------------- FindBytes per string of a batch
+// The loop over start offsets of one string (tdfa.go:831-1052), generic in where the string's bytes lie -- as ONE flat loop: an
+// iteration is one step of the current attempt, and an attempt that ends without an accept turns into the next start right there.
+// (As two nested loops a wave pays, for every start offset, the longest attempt any of its lanes makes there: 2.5 G VALU
+// wave-instructions per 10 M strings, 7.5 ms; flat, it pays the largest TOTAL of one lane.)
+// Attempts are CUT where they meet an earlier attempt of the same string.  The loop over start offsets is quadratic in the length of
+// a word (every start inside a word walks the rest of it), but the automaton is deterministic and acceptance is a property of the
+// state: an attempt that reaches state q behind byte p has, from there on, exactly the future every earlier attempt had that was in
+// q behind p -- and every earlier attempt FAILED (the loop stops at the first that accepts), so that future holds no accept.
+// ring[p & 63] = the state the most recent attempt held behind byte p (a column of bytes per lane), valid for p in [lo, hi]; the cut
+// attempt's result is its last accept so far.  `(\w+)@(\w+)` over a word: the second start is cut after one step.
+template <class EntP, class BufP>
+__device__ __forceinline__ void BatchOne(const TdfaDev& D, EntP ent, BufP buf, int len, int TDFA_LDS* tags, uint8_t TDFA_LDS* ring,
+                                         uint8_t* found, int32_t* row_out, uint32_t* flags) {
+  const bool cut = D.nstates <= 255;              // (a state fits the ring's bytes)
+  const int last = D.any_never ? 0 : len;         // (a pattern that begins with ^: no attempt behind offset 0 can match)
+  const uint32_t fl_any = D.sinfo_any;
+  const uint32_t row_any = (uint32_t)D.start_any * 128u;
+  // Where can an attempt begin at all?  Unless the start state accepts by itself, only on a byte it has a transition for: one pass
+  // over the first 64 bytes marks them, and a failed attempt jumps to the next mark instead of trying every offset in turn.
+  unsigned long long viable = ~0ull;
+  if (!(fl_any & 3u)) {
+    viable = 0ull;
+    const int n = len < 64 ? len : 64;
+    for (int k = 0; k < n; ++k) {
+      const uint32_t c = buf[k];
+      const bool ok = c < 128u && !(ent[row_any + (c & 127u)] & kTDead);
+      viable |= (unsigned long long)ok << k;
+    }
+  }
+  int s = 0, i = 0, steps = 0, lo = 1, hi = 0;
+  uint32_t row = (uint32_t)D.start_begin * 128u;
+  int end = -1;
+  if (D.sinfo_begin & 1u) end = 0;
+  if (len == 0 && (D.sinfo_begin & 2u)) end = 0;
+  int result = -2;                                // -2: running, -1: no match, -3: over budget, >= 0: the end of the match that starts at s
+  while (result == -2) {
+    ++steps;
+    // one step of the current attempt -- straight-line code, the decisions are selects (a wave runs this loop for its slowest lane)
+    const bool in_text = i < len;
+    const uint32_t c = in_text ? (uint32_t)buf[i] : 0x80u;
+    const uint32_t e = ent[row + (c & 127u)];
+    const bool dead = !in_text || c >= 128u || (e & kTDead);
+    const uint32_t ns = e & kTNext;
+    const int p = i + 1;
+    const bool acc = (e & kTAcc) || ((e & kTAccEot) && p == len);
+    bool hit = false;
+    if (cut) {
+      uint8_t TDFA_LDS* cell = ring + ((p & 63) << 8);
+      const bool inwin = p >= lo && p <= hi;
+      hit = !dead && inwin && *cell == (uint8_t)ns;            // an earlier (failed) attempt was here in this state: no accept ahead
+      if (!dead) *cell = (uint8_t)ns;
+      const bool fresh = !inwin && p != hi + 1;                  // not adjacent to what is known: start over from here
+      const int nlo = fresh ? p : lo, nhi = fresh || p > hi ? p : hi;
+      lo = dead ? lo : (nhi - nlo >= 64 ? nhi - 63 : nlo);
+      hi = dead ? hi : nhi;
+    }
+    end = !dead && acc ? p : end;
+    row = dead ? row : ns * 128u;
+    i = dead ? i : p;
+    const bool over = dead || hit;
+    const bool won = over && end >= 0;
+    // the next start: the next marked offset (offsets beyond the 64 marks one by one)
+    int ns_ = s + 1;
+    if (ns_ < 64) { const unsigned long long m = viable >> ns_; ns_ = m ? ns_ + __builtin_ctzll(m) : (len < 64 ? len : 64); }
+    const bool none = over && !won && (ns_ > last || (ns_ >= len && !(fl_any & 3u)));
+    const bool again = over && !won && !none;
+    s = again ? ns_ : s;
+    i = again ? ns_ : i;
+    row = again ? row_any : row;
+    end = again ? ((fl_any & 1u) || (ns_ == len && (fl_any & 2u)) ? ns_ : -1) : end;
+    result = won ? end : (none ? -1 : (over && steps > kLaneStepBudget ? -3 : result));
+  }
+  if (result == -3) { atomicOr(flags, kOverBudgetBit); *found = 0; return; }
+  *found = result >= 0 ? 1 : 0;
+  if (result >= 0) AttemptTags(ent, D.pool, buf, len, s, result, s == 0 ? D.start_begin : D.start_any, s == 0 ? D.init_begin : D.init_any,
+                               D.ntags, tags, row_out, D.sinfo);
+}
+
+constexpr int kTdfaWaveSlice = 6144;      // bytes of a wave's 64 strings staged in LDS (strings beyond it are read from global memory)
+
+// A wave takes 64 consecutive strings: their bytes are one contiguous range of `concat`, staged with coalesced 16-byte loads into
+// the wave's slice of LDS (the walk reads a byte per step: from global memory that is a load per lane per step, each from its own
+// cache line); a string that does not lie in the slice whole is walked where it is.
 template <bool LDS>
 __global__ __launch_bounds__(256) void tdfa_batch_kernel(TdfaDev D, const uint8_t* concat, const uint64_t* offsets, long long nstr,
                                                          uint8_t* found, int32_t* rows, uint32_t* flags) {
   extern __shared__ uint32_t smem[];
   typename Tab<LDS>::P ent = StageEnt<LDS>(D, smem);
-  int TDFA_LDS* tags = (int TDFA_LDS*)(smem + (LDS ? D.nstates * 128 : 0)) + threadIdx.x;
-  const long long nth = (long long)gridDim.x * 256;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < nstr; i += nth) {
-    const uint64_t o0 = offsets[i], o1 = offsets[i + 1];
-    const uint8_t* buf = concat + o0;
-    const int len = (int)(o1 - o0);
-    int steps = 0, s = 0, e = -1;
-    for (; s <= len; ++s) {
-      if (s == 0) e = AttemptEnd(ent, buf, len, 0, D.start_begin, D.sinfo_begin, &steps);
-      else {
-        const uint32_t fl = D.sinfo_any;
-        if (s < len) {
-          const uint32_t c = buf[s];
-          if (!(fl & 3u) && (c >= 128u || (ent[(uint32_t)D.start_any * 128u + c] & kTDead))) { ++steps; continue; }
-        } else if (!(fl & 3u)) break;
-        e = AttemptEnd(ent, buf, len, s, D.start_any, fl, &steps);
+  uint32_t* const after_ent = smem + (LDS ? D.nstates * 128 : 0);
+  int TDFA_LDS* tags = (int TDFA_LDS*)after_ent + threadIdx.x;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  uint8_t TDFA_LDS* const ring = (uint8_t TDFA_LDS*)(after_ent + D.ntags * 256) + threadIdx.x;      // [64][256] bytes: a column per lane
+  unsigned char* const wwin = reinterpret_cast<unsigned char*>(after_ent + D.ntags * 256 + 64 * 64) + wave * (kTdfaWaveSlice + 16);
+  const bool aligned = (((uintptr_t)concat) & 15) == 0;
+  const long long ngroups = (nstr + 255) / 256;
+  for (long long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    const long long i0 = grp * 256 + wave * 64;
+    if (i0 >= nstr) break;                               // (no workgroup barrier below: every wave works for itself)
+    const long long i = i0 + lane;
+    const long long ilast = i0 + 64 < nstr ? i0 + 64 : nstr;
+    const uint64_t gb = offsets[i0], ge = offsets[ilast];
+    const uint64_t wb = gb & ~15ull;
+    const uint64_t span = ((ge - wb) + 15ull) & ~15ull;
+    const int wvalid = aligned ? (int)(span < (uint64_t)kTdfaWaveSlice ? span : (uint64_t)kTdfaWaveSlice) : 0;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    for (int c = lane; c < (wvalid >> 4); c += 64)
+      *reinterpret_cast<uint4*>(wwin + (c << 4)) = *reinterpret_cast<const uint4*>(concat + wb + ((uint64_t)c << 4));
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (i < nstr) {
+      const uint64_t o0 = offsets[i], o1 = offsets[i + 1];
+      const int len = (int)(o1 - o0);
+      if ((o1 - wb) <= (uint64_t)wvalid) {
+        const uint8_t TDFA_LDS* lb = (const uint8_t TDFA_LDS*)wwin + (uint32_t)(o0 - wb);
+        BatchOne(D, ent, lb, len, tags, ring, found + i, rows + i * D.ntags, flags);
+      } else {
+        BatchOne(D, ent, concat + o0, len, tags, ring, found + i, rows + i * D.ntags, flags);
       }
-      if (e >= 0 || steps > kLaneStepBudget) break;
     }
-    if (steps > kLaneStepBudget) { atomicOr(flags, kOverBudgetBit); found[i] = 0; continue; }
-    found[i] = e >= 0 ? 1 : 0;
-    if (e >= 0) AttemptTags(ent, D.pool, buf, len, s, e, s == 0 ? D.start_begin : D.start_any, s == 0 ? D.init_begin : D.init_any, D.ntags,
-                            tags, rows + i * D.ntags, D.sinfo);
   }
 }
 
-size_t TdfaShared(const TdfaDev& D, bool lds, bool with_tags) {
-  return (size_t)(lds ? D.nstates * 128 * 4 : 0) + (with_tags ? (size_t)D.ntags * 256 * 4 : 0);
+size_t TdfaShared(const TdfaDev& D, bool lds, bool with_tags, bool with_window = false) {
+  return (size_t)(lds ? D.nstates * 128 * 4 : 0) + (with_tags ? (size_t)D.ntags * 256 * 4 : 0) + (with_window ? 64 * 256 + 4 * (size_t)(kTdfaWaveSlice + 16) : 0);
 }
-bool TdfaInLds(const TdfaDev& D, bool with_tags) { return TdfaShared(D, true, with_tags) <= 120 * 1024; }
+bool TdfaInLds(const TdfaDev& D, bool with_tags, bool with_window = false) { return TdfaShared(D, true, with_tags, with_window) <= 120 * 1024; }
 
 template <class K>
 hipError_t AllowLds(K kernel, size_t bytes) {
@@ -446,9 +539,13 @@ hipError_t LaunchTdfaTags(const TdfaDev& D, const uint8_t* buf, int32_t len, con
 hipError_t LaunchTdfaBatch(const TdfaDev& D, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found, int32_t* rows,
                            uint32_t* flags, hipStream_t stream) {
   if (nstr <= 0) return hipSuccess;
-  const bool lds = TdfaInLds(D, true);
-  const size_t sh = TdfaShared(D, lds, true);
-  const int grid = GridFor(nstr, 256 * 8, 1 << 16);
+  const bool lds = TdfaInLds(D, true, true);
+  const size_t sh = TdfaShared(D, lds, true, true);
+  int dev = 0, cus = 0;
+  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  int per_cu = (int)((160 * 1024) / (sh + 512));
+  per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
+  const int grid = GridFor(nstr, 256, cus * per_cu * 2);      // persistent workgroups: the table is staged once each
   hipError_t rc;
   if (lds) {
     if ((rc = AllowLds(tdfa_batch_kernel<true>, sh)) != hipSuccess) return rc;

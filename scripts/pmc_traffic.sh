@@ -6,6 +6,7 @@
 # run id; bench.py cites the file and the id in roofline.traffic_source (it does not re-measure: counters need the profiler).
 export TMPDIR=/tmp
 CFG=$1; KSUB=$2; OUT=$3; shift 3
+EXTRA=("$@")
 RUN=$(date -u +%Y%m%dT%H%M%SZ)-$(hostname | tr -cd 'a-zA-Z0-9' | tail -c 8)
 mkdir -p /tmp/pt $(dirname $OUT)
 rm -rf /tmp/pt/*
@@ -28,7 +29,7 @@ for f in glob.glob("/tmp/pt/*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         if ksub in r["Kernel_Name"]:
             acc[r["Counter_Name"]].append(float(r["Counter_Value"]))
-            names.add(r["Kernel_Name"].split("(")[0][:120])
+            names.add(r["Kernel_Name"].replace("(anonymous namespace)::", "")[:100])
 def med(v):
     v = sorted(v)
     return v[len(v) // 2] if v else None
