@@ -49,6 +49,8 @@ struct rgx_stream_ctx {
   int cur_set = 0;
   uint32_t* d_counters = nullptr;            // [4]
   unsigned long long* d_total = nullptr;     // the current scratch set's total (FindAllDevice::run_scan)
+  bool tickets = false;                      // scans of this context take their tile ids from the ticket counter: set once a look-back with static
+                                             // ids timed out (another scan shares the device) and by rgx_sharded (rounds in flight side by side)
   unsigned long long* d_cursor = nullptr;    // trace cursor of the capture kernel: its own word, valid from ctx creation on
   bool own_stream = true;
   uint8_t* d_unsynced = nullptr; int32_t* d_carry = nullptr; int64_t slice_cap = 0, carry_cap = 0;
@@ -499,13 +501,14 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     if (r != RGX_OK) return r;
     if ((((uint32_t*)&c->h_read[2])[3] & 1u) && !P.use_tickets) {
       P.use_tickets = 1;
+      c->tickets = true;                   // (whatever held the predecessors up is likely to be there for the next scan too)
       if ((r = run_scan_once(time_it)) != RGX_OK) return r;
       if (((uint32_t*)&c->h_read[2])[3] & 1u) { SetError("look-back timed out in ticket mode"); return RGX_E_HIP; }
     }
     return RGX_OK;
   };
   static const bool force_tickets = ExpEnv("RGX_TICKETS") != nullptr;
-  P.use_tickets = force_tickets ? 1 : 0;
+  P.use_tickets = (force_tickets || c->tickets) ? 1 : 0;
   // Every scan but the exact kernel's may meet slices without a sync point in reach; the first scan marks them as it goes
   // (a byte per slice, cleared here), so that the carry pass needs no scan of its own to find them.
   bool marked = false;
@@ -1494,6 +1497,12 @@ RGX_API int rgx_match_bytes_device(const rgx_program* p, rgx_stream_ctx* c, cons
   if (total < 0) return (int)total;
   *matched = total > 0;
   return RGX_OK;
+}
+
+// (internal, not exported: rgx_sharded.hip marks the contexts of its rounds)
+extern "C" void rgx_internal_ctx_prefer_tickets(rgx_stream_ctx* c) {
+  const char* e = getenv("RGX_PAIR_TICKETS");          // "0": leave them on static ids (comparison runs)
+  if (c && !(e && atoi(e) == 0)) c->tickets = true;
 }
 
 RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_concat, const uint64_t* d_offsets,

@@ -26,6 +26,8 @@ constexpr unsigned kLookBackSpinLimit = 50000;
 // takes the node with it): bounded by the 100 MHz wall clock, far beyond any legitimate wait (the slowest predecessor is a lane at its
 // step budget, a few seconds); past it the timeout flag goes up and the host reports RGX_E_HIP instead of hanging.
 constexpr long long kTicketWaitTicks = 20ll * 100000000ll;         // 20 s
+constexpr long long kStaticWaitTicks = 3000000ll;                   // 30 ms: static ids wait for workgroups that may not be resident (another
+                                                                    // scan on the device); past this the scan is repeated with tickets
 // Wall-clock deadline of a budgeted loop, checked every few thousand steps next to the step count: step budgets bound the WORK of a
 // lane, but a step costs 30 ns out of LDS and over a microsecond as a dependent global load -- the same 2^22 steps are 0.1 s or 5 s.
 constexpr long long kLaneDeadlineTicks = 4ll * 100000000ll;        // 4 s per kernel launch
@@ -83,9 +85,12 @@ __device__ __forceinline__ unsigned long long LookBack(unsigned long long* desc,
         while ((d >> 62) == 0) {
           ++spins;
           if (bounded && spins > kLookBackSpinLimit) { dead = true; break; }
-          if (!bounded && (spins & 1023u) == 0) {               // ticket mode: bounded by the wall clock (kTicketWaitTicks)
+          if ((spins & (bounded ? 255u : 1023u)) == 0) {
+            // the wall clock bounds both modes: ticket mode kTicketWaitTicks; static ids kStaticWaitTicks -- and no longer than the first
+            // workgroup that gave up (the flag is up: the scan is void and will be repeated with tickets, waiting on is pointless)
             const long long now = (long long)wall_clock64();
-            if (t0 == 0) t0 = now; else if (now - t0 > kTicketWaitTicks) { dead = true; break; }
+            if (t0 == 0) t0 = now; else if (now - t0 > (bounded ? kStaticWaitTicks : kTicketWaitTicks)) { dead = true; break; }
+            if (bounded && (__hip_atomic_load(timeout_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u)) { dead = true; break; }
           }
           for (int z = 0; z < nap; ++z) __builtin_amdgcn_s_sleep(8);
           d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -131,9 +136,10 @@ __device__ __forceinline__ unsigned long long LookBackResolve(unsigned long long
         while ((d >> 62) == 0) {
           ++spins;
           if (bounded && spins > kLookBackSpinLimit) { dead = true; break; }
-          if (!bounded && (spins & 1023u) == 0) {
+          if ((spins & (bounded ? 255u : 1023u)) == 0) {
             const long long now = (long long)wall_clock64();
-            if (t0 == 0) t0 = now; else if (now - t0 > kTicketWaitTicks) { dead = true; break; }
+            if (t0 == 0) t0 = now; else if (now - t0 > (bounded ? kStaticWaitTicks : kTicketWaitTicks)) { dead = true; break; }
+            if (bounded && (__hip_atomic_load(timeout_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u)) { dead = true; break; }
           }
           __builtin_amdgcn_s_sleep(8);
           d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);

@@ -1151,7 +1151,10 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
   issue_loads(tile);
  while (tile < P.ntiles) {
   __syncthreads();                       // everybody has read s_misc; the previous tile's bit sets are no longer needed
-  if (tid == 0) { *s_far = -1; if (P.use_tickets) s_misc[11] = atomicAdd(&P.counters[0], 1u); }
+  if (tid == 0) {
+    *s_far = -1;
+    if (P.use_tickets) s_misc[11] = atomicAdd(&P.counters[0], 1u);
+  }
   for (int w = tid; w < kSWords; w += kBlockThreads) { s_L[w] = 0; s_E[w] = 0; }
   US_STAMP()
   const int tb = tile * kTileBytes;
@@ -1386,6 +1389,10 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
   (void)slow_steps;
   __syncthreads();
   US_STAMP()
+  // (the previous tile's look-back is resolved BEFORE this tile's count is published -- in either mode the tiles it waits for were
+  // taken before it, by workgroups that have walked a whole tile since; the other order, count first, cost 0.91 -> 1.09 ms per GiB.
+  // Tickets are per tile: one ticket per four consecutive tiles made every workgroup wait for its predecessor's LAST tile before
+  // it published its own counts -- the launch serialised, 385 ms.)
   if (have_prev) emit_prev();
   {
     const UsTileOut o = UsCountTile(P, tile, tb, len, s_L, s_E, s_misc, *s_far);
@@ -1613,8 +1620,20 @@ hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t str
     }
     int nblk = per_cu * ncu;
     if (nblk > P.ntiles) nblk = P.ntiles;
-    if (rw) hipLaunchKernelGGL(scan_us_pair_kernel<true>, dim3(nblk), block, shp, stream, T, U, P);
-    else hipLaunchKernelGGL(scan_us_pair_kernel<false>, dim3(nblk), block, shp, stream, T, U, P);
+    // Static tile ids (workgroup b takes tiles b, b + grid, ...) make the look-back wait for workgroups that must be RESIDENT: a second
+    // scan on another stream of the same device -- two contexts, two goroutines -- takes CUs away, the non-resident workgroups' tiles
+    // are never counted, and every look-back behind them spins to its bound (two rounds of config C4 in flight: 12 ms -> 3.9 s per
+    // step before the bound became 30 ms of wall clock and the first workgroup to give up ends everybody's wait).  Tickets
+    // (ScanParams::use_tickets: an atomic per tile, fetched a tile ahead) are only ever held by running workgroups.  Which is faster
+    // depends on the pattern -- C4's URL scan 0.909 -> 0.860 ms per window with tickets (they balance uneven tiles), the C5 suite 150
+    // -> 155 ms (match-dense tiles meet their predecessors' counts a round earlier with static ids) -- so: static ids by default, a
+    // context that has seen one timeout keeps tickets (rgx_capi.cc), the sharded rounds (several in flight by design) always take
+    // them.  RGX_PAIR_TICKETS=1 forces tickets everywhere, =0 leaves the sharded rounds on static ids too (for comparison).
+    static const char* const pair_env = getenv("RGX_PAIR_TICKETS");
+    ScanParams Q = P;
+    if (pair_env && atoi(pair_env)) Q.use_tickets = 1;
+    if (rw) hipLaunchKernelGGL(scan_us_pair_kernel<true>, dim3(nblk), block, shp, stream, T, U, Q);
+    else hipLaunchKernelGGL(scan_us_pair_kernel<false>, dim3(nblk), block, shp, stream, T, U, Q);
     return hipGetLastError();
   }
   if (U.ent4 && !no_simple) {

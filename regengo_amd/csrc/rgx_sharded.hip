@@ -35,6 +35,8 @@
 #include "rgx.h"
 #include "rgx_program.h"
 
+extern "C" void rgx_internal_ctx_prefer_tickets(rgx_stream_ctx* c);      // rgx_capi.cc (not exported)
+
 #define RGX_API extern "C" __attribute__((visibility("default")))
 
 using rgx::SetError;
@@ -447,6 +449,7 @@ int MakeShard(const void* blob, size_t blob_len, int device, int rank, int world
   for (Slot& s : sh->slot) {
     s.shard = sh;
     if ((rc = rgx_stream_ctx_create(sh->prog, &s.ctx)) != RGX_OK) { DestroyShard(sh); return rc; }
+    rgx_internal_ctx_prefer_tickets(s.ctx);      // rounds run side by side on one device: tile ids from tickets (rgx_scan_us.hip: LaunchScanUs)
     if (hipMalloc((void**)&s.d_flag, 16) != hipSuccess || hipHostMalloc((void**)&s.h_flag, 16) != hipSuccess) { DestroyShard(sh); SetError("hipMalloc"); return RGX_E_NOMEM; }
     s.th = std::thread(SlotMain, &s);
   }

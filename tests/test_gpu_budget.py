@@ -76,3 +76,49 @@ def _csr(torch, strings):
         offs.append(offs[-1] + len(s))
     concat = torch.frombuffer(bytearray(b"".join(strings) + b"\0" * 16), dtype=torch.uint8).cuda()
     return concat, torch.tensor(offs, dtype=torch.int64, device="cuda")
+
+
+def test_two_contexts_scanning_side_by_side_do_not_stall():
+    """Two contexts (two host threads, two streams) run the persistent one-step-per-byte scan of the same pattern on one device at the
+    same time.  With static tile ids the second scan takes compute units away from the first, whose non-resident workgroups never count
+    their tiles: every look-back behind them used to spin to its bound (config C4 with two rounds in flight: 12 ms -> 3.9 s per step).
+    Now the first workgroup that gives up (30 ms of wall clock) ends everybody's wait, the scan is repeated with tickets and the context
+    keeps them: same rows as a scan on its own, in bounded time."""
+    import threading
+    import time
+    import torch
+    from regengo_amd import Compiled, synth
+    url = r"(?P<full>(?P<proto>https?|ftp)://(?P<host>[\w.-]+)(?P<port>:\d+)?(?P<path>/[\w./-]*)?)"
+    tile = synth.web_log_tile()
+    tile = tile[:tile.rfind(b"\n") + 1]
+    data = torch.frombuffer(bytearray(tile * 192), dtype=torch.uint8).cuda()      # ~192 MiB: a dozen rounds of the persistent grid
+    alone = Compiled(url, name="URL").to(0)
+    assert alone.info.scan_kernel == 6
+    want, res0 = alone.FindAllSpans(data)
+    want = want.clone()
+    torch.cuda.synchronize()
+    workers, outs, errs = [], [None, None], []
+    for k in range(2):
+        with torch.cuda.stream(torch.cuda.Stream()):
+            workers.append(Compiled(url, name="URL").to(0))                          # a context on a stream of its own
+
+    def run(k):
+        try:
+            for _ in range(6):
+                spans, res = workers[k].FindAllSpans(data)
+                assert res.unsynced == 0
+            outs[k] = spans.clone()
+        except Exception as ex:          # noqa: BLE001
+            errs.append(ex)
+
+    t0 = time.time()
+    th = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+    dt = time.time() - t0
+    torch.cuda.synchronize()
+    assert not errs, errs
+    assert all(o is not None and torch.equal(o, want) for o in outs)
+    assert dt < 20, "twelve 192 MiB scans took %.1f s: a look-back is spinning to its bound again" % dt
