@@ -125,6 +125,11 @@ hipError_t LaunchBatchTiny(const DevTables& U, const DevTables& F, const uint8_t
 hipError_t LaunchBatchRefFixList(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, uint8_t* found, int32_t* spans,
                                  uint16_t* trace, const uint32_t* ctl, uint32_t cap, hipStream_t stream);
 
+// The current device's CU count, and the 160 KiB dynamic-LDS allowance of a kernel -- both cached per DEVICE (a device list in one process
+// launches the same kernels on several devices).
+int DeviceCus();
+hipError_t AllowBigLds(const void* fn);
+
 // ---- Replace path (rgx_replace.hip).  A resolved template segment: kind 0 = literal bytes lits[a, a+b); kind 1 = the text of
 // capture group a (0 = the whole match).
 struct ReplSeg {

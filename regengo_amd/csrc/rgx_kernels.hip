@@ -18,7 +18,10 @@
 #include <hip/hip_runtime.h>
 
 #include <cstdlib>
+#include <mutex>
+#include <set>
 #include <type_traits>
+#include <utility>
 
 #include "rgx_device_util.h"
 #include "rgx_kernels.h"
@@ -2197,6 +2200,29 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
 
 }  // namespace
 
+// Per DEVICE, not per process: a library-owned device list (rgx_sharded_create) launches the same kernels on several devices of one
+// process, and both the dynamic-LDS allowance of a function and the CU count belong to the device.
+int DeviceCus() {
+  static std::mutex mu;
+  static int cus_of[64] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  std::lock_guard<std::mutex> g(mu);
+  if (!cus_of[dev] && (hipDeviceGetAttribute(&cus_of[dev], hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus_of[dev] <= 0)) cus_of[dev] = 256;
+  return cus_of[dev];
+}
+hipError_t AllowBigLds(const void* fn) {
+  static std::mutex mu;
+  static std::set<std::pair<int, const void*>> done;
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+  std::lock_guard<std::mutex> g(mu);
+  if (done.count({dev, fn})) return hipSuccess;
+  const hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  if (e == hipSuccess) done.insert({dev, fn});
+  return e;
+}
+
 size_t ScanSharedBytes(const DevTables& T) {
   size_t b = (kPaddedWindow + 15) & ~15;
   b += (T.table_bytes + 15) & ~15;
@@ -2252,13 +2278,7 @@ hipError_t LaunchScan(const DevTables& T, const ScanParams& P, hipStream_t strea
   }
   const size_t shmem = ScanSharedBytes(V);
   dim3 grid(P.ntiles), block(kBlockThreads);
-  static bool attr_set[8] = {false, false, false, false, false, false, false, false};
-  auto set_attr = [&](const void* fn, int mode) {
-    if (!attr_set[mode]) {
-      (void)hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      attr_set[mode] = true;
-    }
-  };
+  auto set_attr = [&](const void* fn, int) { (void)AllowBigLds(fn); };
 #define RGX_LAUNCH(M, S, SLOT)                                                        \
   do {                                                                                \
     set_attr((const void*)scan_kernel<M, S>, SLOT);                                   \
@@ -2702,11 +2722,7 @@ hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, i
   const bool inrow = !no_inrow && T.nstates * T.stride <= 256 && BatchLdsLayout(T, true, 0, kCapsWindow).bt_in_lds != 0;
   const BatchLayout Y = BatchLdsLayout(T, true, inrow ? 0 : (t8 ? 1 : 2), kCapsWindow, false, inrow && T.onepass != 0);
   if (!force_old && nmatches >= 64 && T.mode != kModeClassGlobal && Y.total <= 150 * 1024 && (((uintptr_t)buf) & 15) == 0 && T.ncap <= 32) {
-    static int cus = 0;
-    if (!cus) {
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    }
+    const int cus = DeviceCus();
     const int64_t ngroups = (nmatches + kBlockThreads - 1) / kBlockThreads;
     int per_cu = (160 * 1024) / (Y.total + 1024);
     if (per_cu < 1) per_cu = 1;
@@ -2717,12 +2733,7 @@ hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, i
     const void* fns[6] = {(const void*)caps_lds_kernel<kModeDirect, uint8_t>, (const void*)caps_lds_kernel<kModeDirect, uint16_t>,
                           (const void*)caps_lds_kernel<kModeClassLds, uint8_t>, (const void*)caps_lds_kernel<kModeClassLds, uint16_t>,
                           (const void*)caps_lds_kernel<kModeDirect, uint8_t, true>, (const void*)caps_lds_kernel<kModeClassLds, uint8_t, true>};
-    static bool attr_set[6] = {false, false, false, false, false, false};
-    if (!attr_set[mi]) {
-      hipError_t e = hipFuncSetAttribute(fns[mi], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return e;
-      attr_set[mi] = true;
-    }
+        { const hipError_t e = AllowBigLds(fns[mi]); if (e != hipSuccess) return e; }
     static const int dflags = ExpEnv("RGX_CAPS_NO_PRIV") ? 1 : 0;      // experiment switch: the general back-trace for every match
     const dim3 g((unsigned)grid), b(kBlockThreads);
     const size_t lds = (size_t)Y.total;
@@ -2748,25 +2759,16 @@ hipError_t LaunchBatchRef(const DevTables& T, const uint8_t* concat, const uint6
   static const bool force_old = ExpEnv("RGX_BATCH_OLD") != nullptr;
   const BatchLayout Y = BatchLdsLayout(T, spans != nullptr, 2, window_bytes, true);
   if (!force_old && T.mode != kModeClassGlobal && Y.total <= 150 * 1024 && (((uintptr_t)concat) & 15) == 0 && T.ncap <= 32) {
-    static int cus = 0;
-    if (!cus) {
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    }
+    const int cus = DeviceCus();
     const int64_t ngroups = (nstr + kBlockThreads - 1) / kBlockThreads;
     int per_cu = (160 * 1024) / (Y.total + 1024);
     if (per_cu < 1) per_cu = 1;
     if (per_cu > 6) per_cu = 6;
     int64_t grid = (int64_t)cus * per_cu * 4;
     if (grid > ngroups) grid = ngroups;
-    static bool attr_set[2] = {false, false};
-    const void* fn = T.mode == kModeDirect ? (const void*)batch_lds_kernel<kModeDirect, true> : (const void*)batch_lds_kernel<kModeClassLds, true>;
+        const void* fn = T.mode == kModeDirect ? (const void*)batch_lds_kernel<kModeDirect, true> : (const void*)batch_lds_kernel<kModeClassLds, true>;
     const int mi = T.mode == kModeDirect ? 0 : 1;
-    if (!attr_set[mi]) {
-      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return e;
-      attr_set[mi] = true;
-    }
+    { const hipError_t e = AllowBigLds(fn); if (e != hipSuccess) return e; }
     // scratch trace for matches longer than the LDS trace: CSR-shaped (string i owns [offsets[i] + 2i, offsets[i+1] + 2i + 2))
     if (T.mode == kModeDirect)
       hipLaunchKernelGGL((batch_lds_kernel<kModeDirect, true>), dim3((unsigned)grid), dim3(kBlockThreads), (size_t)Y.total, stream, T, concat,
@@ -2826,11 +2828,7 @@ hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8
   if (!spans) ref = 0;
   if (ExpEnv("RGX_C3_SKIP")) ref |= atoi(ExpEnv("RGX_C3_SKIP")) << 8;
   const int rm_bytes = SearchRmBytes(F, (ref & 1) != 0);
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-  }
+  const int cus = DeviceCus();
   const int64_t ngroups = (nstr + kBlockThreads - 1) / kBlockThreads;
   int per_cu = (160 * 1024) / (Y.total + rm_bytes + 1024);
   if (per_cu < 1) per_cu = 1;
@@ -2839,12 +2837,7 @@ hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8
   if (grid > ngroups) grid = ngroups;
 #define RGX_GO(MODE, TT)                                                                                              \
   do {                                                                                                                \
-    static bool attr = false;                                                                                         \
-    if (!attr) {                                                                                                      \
-      hipError_t e = hipFuncSetAttribute((const void*)batch_search_kernel<MODE, TT>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      if (e != hipSuccess) return e;                                                                                  \
-      attr = true;                                                                                                    \
-    }                                                                                                                 \
+    { const hipError_t e = AllowBigLds((const void*)batch_search_kernel<MODE, TT>); if (e != hipSuccess) return e; }  \
     hipLaunchKernelGGL((batch_search_kernel<MODE, TT>), dim3((unsigned)grid), dim3(kBlockThreads), (size_t)(Y.total + rm_bytes), stream, U, F,   \
                        concat, offsets, nstr, found, spans, (TT*)trace, window_bytes, ref);                           \
   } while (0)
@@ -2867,11 +2860,7 @@ hipError_t LaunchBatch(const DevTables& T, const uint8_t* concat, const uint64_t
   static const bool force_old = ExpEnv("RGX_BATCH_OLD") != nullptr;
   const BatchLayout Y = BatchLdsLayout(T, spans != nullptr, 2, window_bytes);
   if (!force_old && T.mode != kModeClassGlobal && Y.total <= 150 * 1024 && (((uintptr_t)concat) & 15) == 0 && T.ncap <= 32) {
-    static int cus = 0;
-    if (!cus) {
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-    }
+    const int cus = DeviceCus();
     const int64_t ngroups = (nstr + kBlockThreads - 1) / kBlockThreads;
     int per_cu = (160 * 1024) / (Y.total + 1024);
     if (per_cu < 1) per_cu = 1;
@@ -2879,14 +2868,9 @@ hipError_t LaunchBatch(const DevTables& T, const uint8_t* concat, const uint64_t
     int64_t grid = (int64_t)cus * per_cu * 4;      // a few groups per workgroup amortise the table staging; tail stays short
     if (grid > ngroups) grid = ngroups;
     static const int dbg = ExpEnv("RGX_BATCH_DEBUG") ? atoi(ExpEnv("RGX_BATCH_DEBUG")) : 0;
-    static bool attr_set[2] = {false, false};
-    const void* fn = T.mode == kModeDirect ? (const void*)batch_lds_kernel<kModeDirect> : (const void*)batch_lds_kernel<kModeClassLds>;
+        const void* fn = T.mode == kModeDirect ? (const void*)batch_lds_kernel<kModeDirect> : (const void*)batch_lds_kernel<kModeClassLds>;
     const int mi = T.mode == kModeDirect ? 0 : 1;
-    if (!attr_set[mi]) {
-      hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (e != hipSuccess) return e;
-      attr_set[mi] = true;
-    }
+    { const hipError_t e = AllowBigLds(fn); if (e != hipSuccess) return e; }
     if (T.mode == kModeDirect)
       hipLaunchKernelGGL((batch_lds_kernel<kModeDirect>), dim3((unsigned)grid), dim3(kBlockThreads), (size_t)Y.total, stream, T, concat,
                          offsets, nstr, found, spans, trace, trace_stride, dbg, window_bytes);
@@ -3120,17 +3104,8 @@ hipError_t LaunchBatchMulti(const MultiEnt* d_dir, int nprog, int dir_bytes, int
   // on a CU: measured 8.5 ms per pass of the suite's 156 validators against 12.0 with 32 + 40 KiB
   const int window_bytes = getenv("RGX_MULTI_WINDOW") ? atoi(getenv("RGX_MULTI_WINDOW")) : kBatchWindow;
   const size_t lds = (size_t)window_off + window_bytes + 16;
-  static bool attr = false;
-  if (!attr) {
-    hipError_t e = hipFuncSetAttribute((const void*)batch_multi_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    if (e != hipSuccess) return e;
-    attr = true;
-  }
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess) cus = 256;
-  }
+  { const hipError_t e = AllowBigLds((const void*)batch_multi_kernel); if (e != hipSuccess) return e; }
+  const int cus = DeviceCus();
   int per_cu = (int)((160 * 1024) / (lds + 1024));
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 8) per_cu = 8;

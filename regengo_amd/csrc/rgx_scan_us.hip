@@ -1637,24 +1637,14 @@ hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t str
     return hipGetLastError();
   }
   if (U.ent4 && !no_simple) {
-    static bool attr = false;
-    if (!attr) {
-      const hipError_t ae = hipFuncSetAttribute((const void*)scan_us_simple_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-      if (ae != hipSuccess) return ae;
-      attr = true;
-    }
+    { const hipError_t ae = AllowBigLds((const void*)scan_us_simple_kernel); if (ae != hipSuccess) return ae; }
     hipLaunchKernelGGL(scan_us_simple_kernel, grid, block, (size_t)UsSLds(U.nent4, U.stride).total, stream, T, U, P);
     return hipGetLastError();
   }
   const size_t shmem = (size_t)UsLds(U.nent, U.stride).total;
 #define RGX_US(N, LK)                                                                                   \
   do {                                                                                                  \
-    static bool attr = false;                                                                           \
-    if (!attr) {                                                                                        \
-      const hipError_t ae = hipFuncSetAttribute((const void*)scan_us_kernel<N, LK>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); \
-      if (ae != hipSuccess) return ae;                                                                  \
-      attr = true;                                                                                      \
-    }                                                                                                   \
+    { const hipError_t ae = AllowBigLds((const void*)scan_us_kernel<N, LK>); if (ae != hipSuccess) return ae; }  \
     hipLaunchKernelGGL((scan_us_kernel<N, LK>), grid, block, shmem, stream, T, U, P);                   \
   } while (0)
   if (U.lookahead) {

@@ -342,7 +342,8 @@ __device__ __forceinline__ void BatchOne(const TdfaDev& D, EntP ent, BufP buf, i
   // Where can an attempt begin at all?  Unless the start state accepts by itself, only on a byte it has a transition for: one pass
   // over the first 64 bytes marks them, and a failed attempt jumps to the next mark instead of trying every offset in turn.
   unsigned long long viable = ~0ull;
-  if (!(fl_any & 3u)) {
+  if (D.any_never) viable = 0ull;                 // (one attempt: nothing to mark)
+  else if (!(fl_any & 3u)) {
     viable = 0ull;
     const int n = len < 64 ? len : 64;
     for (int k = 0; k < n; ++k) {
