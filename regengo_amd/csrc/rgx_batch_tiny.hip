@@ -38,8 +38,8 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_kernel(const uint32_
   const int wave = tid >> 6, lane = tid & 63;
   unsigned char* const wwin = smem + kTinyImageBytes + wave * (wslice + 16);
   const uint32_t wwin_at = lds0 + kTinyImageBytes + wave * (wslice + 16);
-  const auto load_sel = [&](uint32_t cell32, uint32_t* s) {
-    const L32 q = (L32)(uintptr_t)(sel_at + cell32);       // one address; a second read is an offset of the same
+  const auto load_sel = [&](uint32_t cell_at, uint32_t* s) {
+    const L32 q = (L32)(uintptr_t)(sel_at + cell_at);      // one address; a second read is an offset of the same
     if (NREG == 1) s[0] = q[0];
     if (NREG == 2) { const u32x2 a = *(L64)q; s[0] = a.x; s[1] = a.y; }
     if (NREG == 3) { const u32x2 a = *(L64)q; s[0] = a.x; s[1] = a.y; s[2] = q[2]; }
@@ -50,6 +50,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_kernel(const uint32_
     if (NREG == 8) { const u32x4 b = *(L128)(q + 4); s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w; }
   };
   const int ntrack = (int)ini[13];                   // capture slots in the tag registers (uniform)
+  const uint32_t qmul = ini[14], cshift = ini[15];   // where an edge's selectors lie (rgx_tiny.h)
   uint32_t reg_of[8];
 #pragma unroll
   for (int c = 0; c < 8; ++c) reg_of[c] = ini[16 + c];
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_kernel(const uint32_
 #pragma unroll
       for (int k = 0; k < 4; ++k) cm[k] = *(L64)(uintptr_t)(cm_at + (((b4 >> (8 * k)) & 255u) << 3));
 #pragma unroll
-      for (int k = 0; k < 4; ++k) TinyStep<NREG, REF>(L, cm[k].x, cm[k].y, load_sel, (uint32_t)(4 * t + k + 1));
+      for (int k = 0; k < 4; ++k) TinyStep<NREG, REF>(L, cm[k].x, cm[k].y, load_sel, (uint32_t)(4 * t + k + 1), qmul, cshift);
     }
     {
       // the last 0-3 bytes, at the lane's own offset
@@ -103,7 +104,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_kernel(const uint32_
       for (int k = 0; k < 3; ++k)
         if (k < r) {
           const u32x2 cm = *(L64)(uintptr_t)(cm_at + (((b4 >> (8 * k)) & 255u) << 3));
-          TinyStep<NREG, REF>(L, cm.x, cm.y, load_sel, (uint32_t)(at + k + 1));
+          TinyStep<NREG, REF>(L, cm.x, cm.y, load_sel, (uint32_t)(at + k + 1), qmul, cshift);
         }
     }
     if (i < nstr) {

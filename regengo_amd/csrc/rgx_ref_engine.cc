@@ -421,8 +421,13 @@ bool BuildTinySearch(const Tables& u, const Tables& f, std::vector<uint32_t>* im
   }
   if (reg_of[1] < 0) { reg_of[1] = nreg++; cap_of_reg.push_back(1); }
   if (nreg > 8 || reg_of[0] != 0) return false;
-  for (int cell = 0; cell < 64; ++cell)
-    for (int r = 0; r < 8; ++r) sel[cell * 8 + r] = r < nreg ? selc[cap_of_reg[r]][cell] : kTinyIdentity;
+  // the cells dense (state * classes + class) and as far apart as the registers need: 16 or 32 bytes
+  const int stride_words = nreg <= 4 ? 4 : 8;
+  if (S * C * stride_words > kTinyInit - kTinySel) return false;
+  for (int w = kTinySel; w < kTinyInit; ++w) (*img)[w] = kTinyIdentity;
+  for (int q = 0; q < S; ++q)
+    for (int k = 0; k < C; ++k)
+      for (int r = 0; r < nreg; ++r) sel[(q * C + k) * stride_words + r] = selc[cap_of_reg[r]][q * 8 + k];
   for (int r = 0; r < nreg; ++r) ini[r] = inic[cap_of_reg[r]];
   ini[8] = 0x01010101u;                            // offset 0 is FindBytesReuse's first attempt
   ini[9] = (uint32_t)q0 << 2;
@@ -430,6 +435,8 @@ bool BuildTinySearch(const Tables& u, const Tables& f, std::vector<uint32_t>* im
   ini[11] = rm_ok ? 1u : 0u;
   ini[12] = (uint32_t)nreg;
   ini[13] = (uint32_t)ncap;
+  ini[14] = (uint32_t)(C * stride_words);         // byte offset per unit of state * 4: state * classes * stride bytes / 4
+  ini[15] = stride_words == 4 ? 24u : 23u;        // column word >> this = class * stride bytes
   for (int c = 0; c < ncap; ++c) ini[16 + c] = (uint32_t)reg_of[c];
   return true;
 }

@@ -36,13 +36,17 @@ namespace rgx {
 
 // The image (uint32 words), built by the host (rgx_ref_engine.cc: BuildTinySearch), staged into LDS by every workgroup:
 constexpr int kTinyColmap = 0;        // [256][2]: byte -> { column of the search automaton: a nibble per state (at most 6) = the next state, the byte's
-                                      //   class in bits 28-30 (word >> 23 = class * 32);  column of the right-most-path automaton: a nibble per
+                                      //   class in bits 28-30 (word >> 23 = class * 32, word >> 24 = class * 16);  column of the right-most-path automaton: a nibble per
                                       //   state = the next state, or 8 | the start state of the attempt that begins BEHIND this byte where the
                                       //   path dies at it }
-constexpr int kTinySel = 512;         // [state * 8 + class][8]: v_perm selectors of the tag registers on that edge
+constexpr int kTinySel = 512;         // [state * nclasses + class][4 or 8]: v_perm selectors of the tag registers on that edge -- the cells
+                                      // DENSE and 16 bytes apart when four registers do (32 otherwise): fifteen cells then lie in fifteen
+                                      // different groups of LDS banks (measured: no faster than 32-byte cells at state * 8 + class, which
+                                      // share four groups -- the kernel's LDS time is the bytes it reads, 8 + 16 per input byte, not their banks)
 constexpr int kTinyInit = 1024;       // [0..7] the tag registers at offset 0, [8] the attempt-offset register, [9] start state * 4, [10] start state * 4
                                       // of the right-most-path automaton at offset 0, [11] bit 0: the replay columns are valid, [12] registers in
-                                      // use, [13] capture slots tracked, [16..23] slot -> register (slots that move together share one)
+                                      // use, [13] capture slots tracked, [14] byte offset of a cell per unit of state * 4 (classes * stride / 4),
+                                      // [15] the shift that turns a column word into class * stride (23 or 24), [16..23] slot -> register
 constexpr int kTinyWords = 1048;
 constexpr int kTinyMaxLen = 56;       // a byte holds an offset or 0xFF = "unset"
 constexpr uint32_t kTinyIdentity = 0x03020100u;
@@ -77,13 +81,14 @@ struct TinyLane {
   uint32_t q4, st4;     // the two automata's states * 4
 };
 
-// One byte: its two words of the colmap, load_sel(cell * 32, s) = the NREG selectors of an edge (device: out of LDS), pos1 = the byte's offset + 1.
+// One byte: its two words of the colmap, load_sel(byte offset of the edge's cell, s) = its NREG selectors (device: out of LDS), pos1 = the
+// byte's offset + 1; qmul / cshift = words [14] / [15] of the image's init block.
 template <int NREG, bool REF, class SelLoad>
-RGX_TINY_HD void TinyStep(TinyLane<NREG>& L, uint32_t ucol, uint32_t rmcol, const SelLoad& load_sel, uint32_t pos1) {
-  const uint32_t cell32 = (L.q4 << 6) | (ucol >> 23);       // (state * 8 + class) * 32: the byte offset of the edge's selectors
+RGX_TINY_HD void TinyStep(TinyLane<NREG>& L, uint32_t ucol, uint32_t rmcol, const SelLoad& load_sel, uint32_t pos1, uint32_t qmul, uint32_t cshift) {
+  const uint32_t cell_at = L.q4 * qmul + (ucol >> cshift);  // (state * classes + class) * stride
   L.q4 = TinyBfe(ucol, L.q4, 3) << 2;
   uint32_t s[NREG];
-  load_sel(cell32, s);
+  load_sel(cell_at, s);
 #pragma unroll
   for (int r = 0; r < NREG; ++r) L.R[r] = TinyPerm(pos1, L.R[r], s[r]);
   if (REF) {
