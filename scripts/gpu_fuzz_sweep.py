@@ -1,14 +1,41 @@
 """One-off wide sweep of the differential test (tests/test_gpu_fuzz.py runs three seeds): many seeds, ASCII and UTF-8
 pattern generators, FindAllBytes on the GPU against the C oracle (Q8 off).  usage: gpu_fuzz_sweep.py [first_seed] [nseeds]
-Run it under `timeout`: the oracle is the reference's backtracker and some random patterns are catastrophic for it (seed 420
-held a 25-minute call; the GPU side of the same pattern takes microseconds)."""
-import random, sys, time
+The oracle is the reference's backtracker and some random patterns are catastrophic for it (seed 420 held a 25-minute call, seed 1133
+one of 101 s; the GPU side of the same pattern takes microseconds).  Its 70 KB calls therefore run in a CHILD process with a time
+limit of their own (no device context in the child): the process that holds the device context is never killed from outside while
+kernels are in flight -- three GPU boxes were lost to sweeps whose per-seed `timeout` fired behind such an oracle call."""
+import os, random, subprocess, sys, time
 sys.path.insert(0, ".")
 import numpy as np
 from oracle import engines as E
 from oracle.gen_c import CMatcher
 from regengo_amd import Compiled, _capi
 from tests import _fuzzgen as F
+
+_CHILD = r"""
+import sys
+sys.path.insert(0, ".")
+import numpy as np
+from oracle.gen_c import CMatcher
+cm = CMatcher(sys.argv[1], q8=False)
+b = sys.stdin.buffer.read()
+arr = np.frombuffer(b, dtype=np.uint8).copy() if len(b) else np.zeros(0, dtype=np.uint8)
+exp, cnt = cm.find_all_np(arr)
+sys.stdout.buffer.write(np.int64(cnt).tobytes() + np.ascontiguousarray(exp, dtype=np.int32).tobytes())
+"""
+
+
+def oracle_bounded(p, b, ncap, limit_s=20.0):
+    """(rows, count) from the C oracle in a child process, or None when it does not finish in limit_s (catastrophic backtracking)."""
+    try:
+        r = subprocess.run([sys.executable, "-c", _CHILD, p], input=b, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        return None
+    if r.returncode != 0 or len(r.stdout) < 8:
+        return None
+    cnt = int(np.frombuffer(r.stdout[:8], dtype=np.int64)[0])
+    return np.frombuffer(r.stdout[8:], dtype=np.int32).reshape(-1, ncap), cnt
+
 
 first = int(sys.argv[1]) if len(sys.argv) > 1 else 100
 nseeds = int(sys.argv[2]) if len(sys.argv) > 2 else 20
@@ -41,7 +68,15 @@ for seed in range(first, first + nseeds):
             b = F.gen_input_u(rng, max(n // 2, 1) if n else 0) if uni else F.gen_input(rng, n)
             arr = np.frombuffer(b, dtype=np.uint8).copy() if len(b) else np.zeros(0, dtype=np.uint8)
             t1 = time.time()
-            exp, cnt = cm.find_all_np(arr)
+            if n >= 20000:
+                got_o = oracle_bounded(p, b, c.ncap)
+                if got_o is None:
+                    print("ORACLE-SLOW seed", seed, repr(p), "n", len(b), "(no comparison)", flush=True)
+                    slow_oracle = True
+                    continue
+                exp, cnt = got_o
+            else:
+                exp, cnt = cm.find_all_np(arr)
             t2 = time.time()
             slow_oracle = slow_oracle or (t2 - t1 > 0.005 * max(1, len(b) // 1000))   # super-linear oracle: no 70 KB call
             try:
