@@ -426,7 +426,10 @@ typedef struct rgx_shard_window {
   int32_t is_host;          /* 1: staged to the device by the shard's thread (must stay valid until the round is waited for)  */
   int32_t starts_at_sync;   /* 1: buf[0] is the beginning of the stream (or otherwise known to be a sync point)               */
   int32_t last;             /* 1: the window ends where the stream ends                                                       */
-  int32_t reserved;
+  int32_t starts_only;      /* 1: the rows are match STARTS, one int32 each (d_spans then holds cap_records of them) -- programs
+                             * with a fixed capture template on the exact kernel only (rgx_find_all_starts_device's condition;
+                             * RGX_E_UNSUPPORTED otherwise): 4 bytes of output per match instead of 4 * ncap, the groups follow
+                             * from start + the template.  rgx_sharded_gather is not offered behind such a round.            */
   int32_t* d_spans;         /* device output, cap_records records of ncap int32, window-relative; NULL: the shard's own buffer */
   size_t cap_records;
 } rgx_shard_window;

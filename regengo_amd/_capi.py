@@ -53,7 +53,7 @@ class ShardedInfo(C.Structure):
 
 class ShardWindow(C.Structure):
     _fields_ = [("buf", C.c_void_p), ("len", C.c_size_t), ("own_lo", C.c_int64), ("own_hi", C.c_int64), ("base", C.c_int64),
-                ("is_host", C.c_int32), ("starts_at_sync", C.c_int32), ("last", C.c_int32), ("reserved", C.c_int32),
+                ("is_host", C.c_int32), ("starts_at_sync", C.c_int32), ("last", C.c_int32), ("starts_only", C.c_int32),
                 ("d_spans", C.c_void_p), ("cap_records", C.c_size_t)]
 
 

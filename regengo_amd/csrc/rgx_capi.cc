@@ -72,7 +72,7 @@ struct rgx_stream_ctx {
   // submit / wait (rgx_find_all_submit): up to two scans in flight
   struct Pending {
     const uint8_t* d_buf; size_t len; int64_t n; int32_t* d_spans; size_t cap; int64_t own_lo, own_hi;
-    int slot; bool trivial; bool timed;
+    int slot; bool trivial; bool timed; bool starts_only;
   };
   Pending pend[2];
   int pend_head = 0, pend_count = 0;
@@ -896,25 +896,50 @@ RGX_API int64_t rgx_find_all_bytes_device(const rgx_program* p, rgx_stream_ctx* 
   return FindAllDevice(p, c, d_buf, len, n, d_spans, cap_records, false, res);
 }
 
-RGX_API int64_t rgx_find_all_bytes_device_owned(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n,
-                                                int32_t* d_spans, size_t cap_records, int64_t own_lo, int64_t own_hi,
-                                                rgx_result* res) {
+namespace {
+// starts-only results (4 bytes per match, the groups follow from the program's capture template): the exact kernel's programs only
+int StartsOnlyOffered(const rgx_program* p, size_t len) {
+  if (UseExactKernel(p->p.dev, len > 0x7FFFFF00ull ? 0 : (int32_t)len) || len == 0) return RGX_OK;
+  SetError("starts-only results need a fixed-template pattern (rgx_info.fixed_captures) and len >= 64");
+  return RGX_E_UNSUPPORTED;
+}
+}  // namespace
+
+// (internal, not exported: the shard-mode scan with either record form -- rgx_sharded.hip's rounds, rgx_shard_window::starts_only)
+extern "C" int64_t rgx_internal_find_all_owned(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n,
+                                               int32_t* d_spans, size_t cap_records, int64_t own_lo, int64_t own_hi, int starts_only,
+                                               rgx_result* res) {
   int rc = CheckCtx(p, c);
   if (rc != RGX_OK) return rc;
   if ((rc = RefuseFindAll(p)) != RGX_OK) return rc;
   if (own_lo < 0 || own_hi < own_lo) { SetError("bad owned range"); return RGX_E_INVALID; }
-  return FindAllDevice(p, c, d_buf, len, n, d_spans, cap_records, false, res, false, own_lo, own_hi);
+  if (starts_only && (rc = StartsOnlyOffered(p, len)) != RGX_OK) return rc;
+  return FindAllDevice(p, c, d_buf, len, n, d_spans, cap_records, false, res, starts_only != 0, own_lo, own_hi);
+}
+
+RGX_API int64_t rgx_find_all_bytes_device_owned(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n,
+                                                int32_t* d_spans, size_t cap_records, int64_t own_lo, int64_t own_hi,
+                                                rgx_result* res) {
+  return rgx_internal_find_all_owned(p, c, d_buf, len, n, d_spans, cap_records, own_lo, own_hi, 0, res);
 }
 
 // ---- submit / wait: the same scan without the host waiting behind every launch (a FindReader-style pipeline scans chunk
 // k+1 while chunk k's results are consumed).  Only the exact kernel's fast path is launched asynchronously -- its total
 // arrives in pinned host memory and it leaves the other scratch set clean for the next launch; anything else, and any
 // launch that raises the rare-path flag, is (re)done by the synchronous path inside rgx_find_all_wait.
+extern "C" int rgx_internal_find_all_submit(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n,
+                                            int32_t* d_spans, size_t cap_records, int64_t own_lo, int64_t own_hi, int starts_only);
 RGX_API int rgx_find_all_submit(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n, int32_t* d_spans,
                                 size_t cap_records, int64_t own_lo, int64_t own_hi) {
+  return rgx_internal_find_all_submit(p, c, d_buf, len, n, d_spans, cap_records, own_lo, own_hi, 0);
+}
+// (internal, not exported: the same with either record form)
+extern "C" int rgx_internal_find_all_submit(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n,
+                                            int32_t* d_spans, size_t cap_records, int64_t own_lo, int64_t own_hi, int starts_only) {
   int rc = CheckCtx(p, c);
   if (rc != RGX_OK) return rc;
   if ((rc = RefuseFindAll(p)) != RGX_OK) return rc;
+  if (starts_only && (rc = StartsOnlyOffered(p, len)) != RGX_OK) return rc;
   if (c->pend_count >= 2) { SetError("two scans already in flight: call rgx_find_all_wait"); return RGX_E_INVALID; }
   if (own_lo < 0 || (own_hi >= 0 && own_hi < own_lo)) { SetError("bad owned range"); return RGX_E_INVALID; }
   const DevTables& T = p->p.dev;
@@ -922,7 +947,7 @@ RGX_API int rgx_find_all_submit(const rgx_program* p, rgx_stream_ctx* c, const u
   if (((uintptr_t)d_buf & 15) || ((uintptr_t)d_spans & 15)) { SetError("device pointers must be 16-byte aligned"); return RGX_E_INVALID; }
   const int slot = (c->pend_head + c->pend_count) & 1;
   rgx_stream_ctx::Pending& pd = c->pend[slot];
-  pd = {d_buf, len, n, d_spans, cap_records, own_lo, own_hi, slot, n == 0 || len == 0, false};
+  pd = {d_buf, len, n, d_spans, cap_records, own_lo, own_hi, slot, n == 0 || len == 0, false, starts_only != 0};
   if (pd.trivial) { c->pend_count++; return RGX_OK; }
   const int32_t ilen = (int32_t)len;
   static const bool no_self_clean = ExpEnv("RGX_NO_SELF_CLEAN") != nullptr;
@@ -952,6 +977,7 @@ RGX_API int rgx_find_all_submit(const rgx_program* p, rgx_stream_ctx* c, const u
   P.buf = d_buf; P.len = ilen; P.ntiles = ntiles; P.use_w = 0; P.spans = d_spans; P.cap_records = (int64_t)cap_records;
   P.own_lo = (int32_t)std::max<int64_t>(0, std::min<int64_t>(own_lo, ilen));
   P.own_hi = own_hi < 0 ? ilen : (int32_t)std::max<int64_t>(P.own_lo, std::min<int64_t>(own_hi, ilen));
+  P.starts_only = starts_only ? 1 : 0;
   static const bool force_tickets = ExpEnv("RGX_TICKETS") != nullptr;
   P.use_tickets = force_tickets ? 1 : 0;
   const int s = c->cur_set;
@@ -996,7 +1022,7 @@ RGX_API int64_t rgx_find_all_wait(const rgx_program* p, rgx_stream_ctx* c, rgx_r
     // finish, forget what the scratch sets hold, and redo this buffer through the synchronous path
     HIP_TRY(hipStreamSynchronize(c->stream));
     c->dirty[0] = c->dirty[1] = c->set_words;
-    return FindAllDevice(p, c, pd.d_buf, pd.len, pd.n, pd.d_spans, pd.cap, false, res, false, pd.own_lo, pd.own_hi);
+    return FindAllDevice(p, c, pd.d_buf, pd.len, pd.n, pd.d_spans, pd.cap, false, res, pd.starts_only, pd.own_lo, pd.own_hi);
   }
   const int64_t total = (int64_t)h[0];
   float ms = 0;
@@ -1365,10 +1391,7 @@ RGX_API int64_t rgx_find_all_starts_device(const rgx_program* p, rgx_stream_ctx*
   int rc = CheckCtx(p, c);
   if (rc != RGX_OK) return rc;
   if ((rc = RefuseFindAll(p)) != RGX_OK) return rc;
-  if (!UseExactKernel(p->p.dev, len > 0x7FFFFF00ull ? 0 : (int32_t)len) && len != 0) {
-    SetError("starts-only results need a fixed-template pattern (rgx_info.fixed_captures) and len >= 64");
-    return RGX_E_UNSUPPORTED;
-  }
+  if ((rc = StartsOnlyOffered(p, len)) != RGX_OK) return rc;
   return FindAllDevice(p, c, d_buf, len, n, d_starts, cap, false, res, true);
 }
 

@@ -36,6 +36,11 @@
 #include "rgx_program.h"
 
 extern "C" void rgx_internal_ctx_prefer_tickets(rgx_stream_ctx* c);      // rgx_capi.cc (not exported)
+extern "C" int64_t rgx_internal_find_all_owned(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n,
+                                               int32_t* d_spans, size_t cap_records, int64_t own_lo, int64_t own_hi, int starts_only,
+                                               rgx_result* res);
+extern "C" int rgx_internal_find_all_submit(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n,
+                                            int32_t* d_spans, size_t cap_records, int64_t own_lo, int64_t own_hi, int starts_only);
 
 #define RGX_API extern "C" __attribute__((visibility("default")))
 
@@ -291,7 +296,7 @@ int RunJob(Slot& s) {
       }
       d_spans = s.d_spans; cap_records = s.spans_cap;
     }
-    const int64_t c = rgx_find_all_bytes_device_owned(sh.prog, s.ctx, d_buf, w.len, -1, d_spans, cap_records, w.own_lo, w.own_hi, &res);
+    const int64_t c = rgx_internal_find_all_owned(sh.prog, s.ctx, d_buf, w.len, -1, d_spans, cap_records, w.own_lo, w.own_hi, w.starts_only, &res);
     if (c == RGX_E_CAPACITY && !w.d_spans && attempt == 0) { cap_records = (size_t)res.total + 16; continue; }
     if (c < 0) return (int)c;
     r.count = c;
@@ -357,7 +362,7 @@ bool TryAsync(Shard& sh, Slot& s, const Job& j) {
     if (hipMemcpyAsync(s.h_flag, s.d_flag + 2, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
     s.async_halo = true;
   }
-  const int rc = rgx_find_all_submit(sh.prog, sh.actx, w.buf, w.len, -1, d_spans, cap, w.own_lo, w.own_hi);
+  const int rc = rgx_internal_find_all_submit(sh.prog, sh.actx, w.buf, w.len, -1, d_spans, cap, w.own_lo, w.own_hi, w.starts_only);
   if (rc == RGX_E_UNSUPPORTED) return false;       // (a halo check may have been queued: harmless, the slot's thread repeats it)
   s.async = true;
   s.ajob = j;
@@ -391,6 +396,8 @@ struct rgx_sharded {
                                                     // value-receiver method that goroutines may call concurrently on the ONE process-wide handle)
   // the last waited round, for rows / gather
   int last_slot = -1;
+  int slot_starts[2] = {0, 0};      // the round queued in this slot asked for match starts (rgx_shard_window::starts_only)
+  int last_starts = 0;              // ... and so did the last waited round, on some rank
   std::vector<rgx_shard_round> last;                // [world]
   std::vector<int64_t> last_base;                   // [world] (rank mode: exchanged)
 };
@@ -586,6 +593,8 @@ RGX_API int rgx_sharded_round_submit(rgx_sharded* s, const rgx_shard_window* win
   if (!s || !windows) return RGX_E_INVALID;
   if (s->inflight >= 2) { SetError("two rounds already in flight: call rgx_sharded_round_wait"); return RGX_E_INVALID; }
   const int slot = (s->head + s->inflight) & 1;
+  s->slot_starts[slot] = 0;
+  for (size_t i = 0; i < s->local.size(); i++) if (windows[i].starts_only && !count_only) s->slot_starts[slot] = 1;
   for (size_t i = 0; i < s->local.size(); i++) {
     Job j;
     j.w = windows[i]; j.count_only = count_only; j.have = windows[i].len > 0 && windows[i].buf != nullptr;
@@ -606,6 +615,7 @@ RGX_API int64_t rgx_sharded_round_wait(rgx_sharded* s, int stop_request, rgx_sha
   s->last.assign((size_t)world, rgx_shard_round{});
   s->last_base.assign((size_t)world, 0);
   s->last_slot = slot;
+  s->last_starts = s->slot_starts[slot];
   int rc = RGX_OK;
   for (Shard* sh : s->local) {
     if (sh->slot[slot].async) WaitAsync(*sh, sh->slot[slot]);
@@ -631,7 +641,7 @@ RGX_API int64_t rgx_sharded_round_wait(rgx_sharded* s, int stop_request, rgx_sha
     };
     note(hipSetDevice(sh->device), "hipSetDevice");
     sh->h_x[0] = m.count;
-    sh->h_x[1] = (m.have ? 1 : 0) | (m.unsynced ? 2 : 0) | (m.stop ? 4 : 0) | (m.truncated ? 8 : 0);
+    sh->h_x[1] = (m.have ? 1 : 0) | (m.unsynced ? 2 : 0) | (m.stop ? 4 : 0) | (m.truncated ? 8 : 0) | (s->slot_starts[slot] ? 16 : 0);
     sh->h_x[2] = s->last_base[(size_t)sh->rank];
     sh->h_x[3] = rc;
     note(hipMemcpyAsync(sh->d_x, sh->h_x, 32, hipMemcpyHostToDevice, sh->cstream), "hipMemcpyAsync(exchange)");
@@ -649,6 +659,7 @@ RGX_API int64_t rgx_sharded_round_wait(rgx_sharded* s, int stop_request, rgx_sha
       o.count = x[0]; o.have = (x[1] & 1) != 0; o.unsynced = (x[1] & 2) != 0; o.stop = (x[1] & 4) != 0; o.truncated = (x[1] & 8) != 0;
       o.kernel_ms = ms; o.status = (int32_t)x[3];
       s->last_base[(size_t)r] = x[2];
+      if (x[1] & 16) s->last_starts = 1;          // (any rank: every rank then refuses the gather alike)
       if (x[3] < 0 && rc == RGX_OK) { rc = (int)x[3]; SetError("a peer rank failed its scan (status " + std::to_string(x[3]) + ")"); }
     }
   }
@@ -692,6 +703,11 @@ int EnsureGlob(Shard* sh, size_t vals) {
 // multi-process job).
 RGX_API int64_t rgx_sharded_gather(rgx_sharded* s, int dst_rank, int64_t* d_dst, int64_t* h_dst, size_t cap_records, const int64_t** d_rows) {
   if (!s || s->last_slot < 0 || dst_rank < 0 || dst_rank >= s->world) return RGX_E_INVALID;
+  if (s->last_starts) {
+    // (known to every rank through the round's exchange: nobody enters the collective)
+    SetError("the last round's rows are match starts (rgx_shard_window::starts_only): the gather moves full records");
+    return RGX_E_UNSUPPORTED;
+  }
   const int world = s->world, slot = s->last_slot;
   std::vector<int64_t> off((size_t)world + 1, 0);
   for (int r = 0; r < world; r++) off[(size_t)r + 1] = off[(size_t)r] + s->last[(size_t)r].count;

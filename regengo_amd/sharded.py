@@ -63,7 +63,7 @@ class Sharded:
 
     def _windows(self, windows):
         """windows: one entry per LOCAL shard: None, or a dict(buf=uint8 tensor on that device | bytes, own=(lo, hi), base=int,
-        starts_at_sync=bool, last=bool, out=int32 tensor [cap, ncap] on that device | None)."""
+        starts_at_sync=bool, last=bool, starts_only=bool, out=int32 tensor [cap, ncap] ([cap] with starts_only) on that device | None)."""
         import torch
         arr = (_capi.ShardWindow * self.n_local)()
         keep = []
@@ -81,6 +81,7 @@ class Sharded:
             arr[i].own_lo, arr[i].own_hi, arr[i].base = int(lo), int(hi), int(w.get("base", 0))
             arr[i].starts_at_sync = 1 if w.get("starts_at_sync", False) else 0
             arr[i].last = 1 if w.get("last", False) else 0
+            arr[i].starts_only = 1 if w.get("starts_only", False) else 0      # rows = int32 match starts (fixed-template programs)
             out = w.get("out")
             if out is not None:
                 arr[i].d_spans, arr[i].cap_records = out.data_ptr(), out.shape[0]

@@ -288,3 +288,52 @@ def test_sharded_find_all_bytes_widens_truncated_windows(gpu, monkeypatch):
         total, rs = s.round([dict(buf=buf[0:hi + 65536].clone(), own=(lo, hi), base=0, starts_at_sync=True, last=False), None])
         assert not rs[0]["truncated"], pattern
         s.close()
+
+
+def test_starts_only_rounds(gpu):
+    """rgx_shard_window::starts_only: a round's rows as 4-byte match starts (fixed-template programs on the exact kernel) -- two logical
+    shards, asynchronous and slot paths, two rounds in flight; start + the capture template == the full records of the same window;
+    the gather behind such a round and a program without a fixed template are refused."""
+    torch = gpu
+    from regengo_amd import Compiled, _capi, synth
+    from regengo_amd.sharded import Sharded
+    c = Compiled(DATE).to(0)
+    tmpl, _ = c.capture_template()
+    tm = torch.tensor(tmpl, dtype=torch.int32, device="cuda:0")
+    buf = synth.date_log_torch(8 << 20, torch.device("cuda:0"), adversarial=True)
+    full = c.FindAllSpans(buf)[0]
+    s = Sharded(c, devices=[0, 0])
+    plan = s.plan(buf.numel())
+    outs = [[torch.empty(buf.numel() // 10 + 16, dtype=torch.int32, device="cuda:0") for _ in plan] for _ in range(2)]
+
+    def windows(k):
+        ws = _windows(torch, buf, plan, outs[k])
+        for w in ws:
+            w["starts_only"] = True
+        return ws
+
+    s.submit(windows(0))
+    s.submit(windows(1))
+    for k in range(2):
+        total, rs = s.wait()
+        assert total == full.shape[0] and not any(r["unsynced"] for r in rs)
+        rows = []
+        for i, (lo, hi, wl, wh) in enumerate(plan):
+            st = outs[k][i][:rs[i]["count"]]
+            rows.append(st[:, None] + tm[None, :] + wl)
+        assert torch.equal(torch.cat(rows), full)
+    with pytest.raises(_capi.RgxError) as ei:
+        s.gather(0)
+    assert ei.value.status == _capi.RGX_E_UNSUPPORTED
+    total, rs = s.round(_windows(torch, buf, plan))            # a full-record round afterwards: the gather is offered again
+    assert s.gather(0) == full.shape[0]
+    s.close()
+    e = Compiled(EMAIL).to(0)
+    se = Sharded(e, devices=[0])
+    tile = torch.frombuffer(bytearray(_tile()), dtype=torch.uint8).cuda()
+    w = _windows(torch, tile, se.plan(tile.numel()))
+    w[0]["starts_only"] = True
+    with pytest.raises(_capi.RgxError) as ei:
+        se.round(w)
+    assert ei.value.status == _capi.RGX_E_UNSUPPORTED
+    se.close()
