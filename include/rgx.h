@@ -109,8 +109,10 @@ typedef struct rgx_info {
                             * (fixed-length class chain), 2 prefilter + verify, 3 generic (one attempt per start), 4 one step
                             * per byte with start registers, 5 register-free (simple automata), 6 register-free, two bytes
                             * per look-up; DESIGN.md section 4 */
-  int32_t ref_match_offered; /* 1: MatchBytes in reference mode (the default) is offered: plain backtracking or Thompson engine; 0: the
-                              * reference memoises -- RGX_E_UNSUPPORTED, the generated stub keeps the Go function           */
+  int32_t ref_match_offered; /* 1: MatchBytes in reference mode (the default) is offered: plain backtracking or Thompson engine, or --
+                              * the reference memoises its MatchBytes, or the program holds an InstFail -- the emitted function
+                              * interpreted on the device (strings / buffers up to 64 KiB, RGX_E_UNSUPPORTED beyond); 0: a memoising
+                              * program beyond the interpreter (more than 64 Alt instructions): the stub keeps the Go function */
   int32_t ref_find_offered;  /* the same for FindBytes / FindBytesReuse: the plain backtracking engine (restart rule reproduced) or
                               * the Tagged DFA (ref_find_engine == 1: the reference's own tables and loop run on the device,
                               * tdfa.go:831-1052).  All ref_*_offered read 1 for a program compiled with

@@ -387,6 +387,20 @@ int rgxt_memo_find(void* hh, const uint8_t* buf, int64_t len, int32_t* out) {
   }
 }
 
+// The emitted MatchBytes, interpreted (rgx_memo.h: MemoMatch -- what memo_match_kernel runs per lane): 1 / 0, -2 gave up, -3 not interpreted
+int rgxt_memo_match(void* hh, const uint8_t* buf, int64_t len) {
+  const Tables& t = ((Handle*)hh)->t;
+  MemoHost h;
+  try {
+    const Prog prog = Compile(Simplify(Parse(t.pattern, kPerl)));
+    if (!BuildMemoProg(prog, &h)) return -3;
+  } catch (...) { return -3; }
+  std::vector<unsigned long long> vis((size_t)len + 2, 0), stk(4 * (size_t)len + 128, 0);
+  const MemoScratch S{vis.data(), (int)len + 1, stk.data(), (int)stk.size()};
+  long long budget = 1ll << 24;
+  return MemoMatch(h.View(), buf, (int)len, t.ref_prefix, t.anchored, t.ref_memo, S, &budget);
+}
+
 // one attempt of the interpreter on buf[0, len) from `start`: >= 0 failure offset, -1 matched (*mend), -2 gave up, -3 not interpreted
 int rgxt_memo_attempt(void* hh, const uint8_t* buf, int64_t len, int64_t start, int32_t* mend) {
   const Tables& t = ((Handle*)hh)->t;

@@ -784,7 +784,7 @@ RGX_API int rgx_program_info(const rgx_program* p, rgx_info* o) {
   {
     const bool have_rm = !t.rm_depth[0].empty() && !t.rm_depth[1].empty();
     o->ref_find_offered = ((have_rm && !t.ref_memo && t.ref_find_engine <= 0) || HasRefTdfa(t) || HasRefMemo(t)) ? 1 : 0;
-    o->ref_match_offered = (t.ref_match_engine == 1 || (have_rm && !t.ref_memo && !t.ref_has_fail)) ? 1 : 0;
+    o->ref_match_offered = (t.ref_match_engine == 1 || (have_rm && !t.ref_memo && !t.ref_has_fail) || ((t.ref_memo || t.ref_has_fail) && t.ref_memo_interp)) ? 1 : 0;
     const bool stdlib = (t.flags & RGX_FLAG_STDLIB_SEMANTICS) != 0;
     if (stdlib) o->ref_find_offered = o->ref_match_offered = 1;       // nothing of the reference's to reproduce: every entry point answers
     o->ref_findall_offered = (stdlib || RefFindAllOffered(t)) ? 1 : 0;
@@ -1441,6 +1441,37 @@ RGX_API int64_t rgx_find_all_bytes(const rgx_program* p, rgx_stream_ctx* c, cons
   return w;
 }
 
+namespace {
+constexpr int64_t kMemoMatchMaxLen = 65536;
+// MatchBytes per string through the interpreter of the emitted code (ref_match_kind 3): a lane per string, its visited words and its
+// stack in the context's memo scratch.
+int64_t MemoMatchBatch(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_concat, const uint64_t* d_offsets, size_t nstr, uint8_t* d_matched) {
+  unsigned long long h_max = 0;
+  HIP_TRY(hipMemsetAsync(c->d_cursor + 2, 0, 8, c->stream));
+  HIP_TRY(LaunchMaxStringLen(d_offsets, (int64_t)nstr, c->d_cursor + 2, c->stream));
+  HIP_TRY(hipMemcpyAsync(&h_max, c->d_cursor + 2, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if ((int64_t)h_max > kMemoMatchMaxLen) {
+    SetError("a string of this batch is longer than 64 KiB: the interpreted MatchBytes of a memoising program is not offered for it, keep the Go path");
+    return RGX_E_UNSUPPORTED;
+  }
+  const int64_t W = (int64_t)h_max + 1, cap = 4 * W + 64;
+  int64_t nlanes = 0;
+  unsigned long long *vis = nullptr, *stk = nullptr;
+  int rc = MemoScratchFor(c, W, cap, std::min<int64_t>((int64_t)nstr, 65536), &nlanes, &vis, &stk);
+  if (rc != RGX_OK) return rc;
+  unsigned* flag = reinterpret_cast<unsigned*>(c->d_cursor + 1);
+  unsigned h = 0;
+  HIP_TRY(hipMemsetAsync(flag, 0, 4, c->stream));
+  HIP_TRY(LaunchBatchMemoMatch(p->p.dev, d_concat, d_offsets, (int64_t)nstr, d_matched, vis, (int)W, stk, (int)cap, nlanes, p->p.t.ref_memo ? 1 : 0,
+                               flag, c->stream));
+  HIP_TRY(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (h) { SetError("the emitted MatchBytes' attempts on a string of this batch are too many to interpret (stack / step budget): keep the Go path for it"); return RGX_E_UNSUPPORTED; }
+  return (int64_t)nstr;
+}
+}  // namespace
+
 RGX_API int rgx_match_bytes_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int* matched) {
   int rc = CheckCtx(p, c);
   if (rc != RGX_OK) return rc;
@@ -1450,7 +1481,26 @@ RGX_API int rgx_match_bytes_device(const rgx_program* p, rgx_stream_ctx* c, cons
   const Tables& t = p->p.t;
   if ((rc = MatchView(p, c, d_buf, len, &d_buf)) != RGX_OK) return rc;       // broken UTF-8: match on the sanitised copy
   const bool ref_rule = !(t.flags & RGX_FLAG_STDLIB_SEMANTICS) && p->p.dev.ref_match_kind != 1;
-  if (ref_rule && p->p.dev.ref_match_kind == 2) { SetError("reference-mode MatchBytes is not offered for this pattern (memoising engine): keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS"); return RGX_E_UNSUPPORTED; }
+  if (ref_rule && p->p.dev.ref_match_kind == 2) { SetError("reference-mode MatchBytes is not offered for this pattern (memoising engine beyond the interpreter's 64 Alt instructions): keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS"); return RGX_E_UNSUPPORTED; }
+  if (ref_rule && p->p.dev.ref_match_kind == 3) {
+    // the emitted MatchBytes itself, interpreted by ONE lane (rgx_memo.h: MemoMatch): a sequential loop whose every attempt may walk
+    // far -- offered for texts of at most kMemoMatchMaxLen bytes, beyond that the Go path keeps the call
+    if ((int64_t)len > kMemoMatchMaxLen) {
+      SetError("reference-mode MatchBytes of a memoising program is interpreted by one lane: offered up to 64 KiB of text, keep the Go path beyond");
+      return RGX_E_UNSUPPORTED;
+    }
+    uint64_t h_off[2] = {0, (uint64_t)len};
+    if ((rc = Ensure(&c->d_tdfa, &c->tdfa_cap, 16)) != RGX_OK) return rc;
+    uint64_t* d_off = (uint64_t*)c->d_tdfa;                    // [offsets 16 B][matched 1 B]
+    uint8_t* d_m = (uint8_t*)(c->d_tdfa + 4);
+    HIP_TRY(hipMemcpyAsync(d_off, h_off, 16, hipMemcpyHostToDevice, c->stream));
+    const int64_t r = MemoMatchBatch(p, c, d_buf, d_off, 1, d_m);
+    if (r < 0) return (int)r;
+    uint8_t f = 0;
+    HIP_TRY(hipMemcpy(&f, d_m, 1, hipMemcpyDeviceToHost));
+    *matched = f;
+    return RGX_OK;
+  }
   uint64_t lane_lo = 0, lane_hi = (uint64_t)len;     // the text handed to the sequential loop below
   if (ref_rule && !t.can_match_empty) {
     // The reference's MatchBytes only ever reports true matches, so "no leftmost-first match anywhere" (the parallel scan) is
@@ -1678,7 +1728,8 @@ RGX_API int64_t rgx_match_batch_device(const rgx_program* p, rgx_stream_ctx* c, 
   if (!(p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS) && p->p.dev.ref_match_kind != 1) {
     // reference mode: MatchBytes' restart rule and prefix skip (compiler.go:740-871); the Thompson flavour (kind 1) has no such
     // rule and takes the plain path below
-    if (p->p.dev.ref_match_kind == 2) { SetError("reference-mode MatchBytes is not offered for this pattern (memoising engine): keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS"); return RGX_E_UNSUPPORTED; }
+    if (p->p.dev.ref_match_kind == 2) { SetError("reference-mode MatchBytes is not offered for this pattern (memoising engine beyond the interpreter's 64 Alt instructions): keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS"); return RGX_E_UNSUPPORTED; }
+    if (p->p.dev.ref_match_kind == 3) return MemoMatchBatch(p, c, d_concat, d_offsets, nstr, d_matched);
     if (!p->p.dev.anchored && (rc = BatchLengthGuard(c, d_offsets, nstr, kBatchRestartMaxLen, -1)) != RGX_OK) return rc;
     HIP_TRY(LaunchBatchRef(p->p.dev, d_concat, d_offsets, (int64_t)nstr, d_matched, nullptr, nullptr, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));

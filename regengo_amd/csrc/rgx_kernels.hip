@@ -1064,6 +1064,23 @@ __global__ __launch_bounds__(64) void ref_fix_list_kernel(DevTables T, const uin
     RefFixOne(T, concat, offsets, (int64_t)ctl[4 + k], found, spans, trace, s_trace);
 }
 
+// ---- MatchBytes per string, interpreted (DevTables::ref_match_kind 3: the reference memoises its MatchBytes, or the program holds an
+// InstFail): the emitted loop itself, rgx_memo.h: MemoMatch.  Lanes are grid-strided over the strings as in memo_fix_kernel.
+__global__ __launch_bounds__(64) void memo_match_kernel(DevTables T, MemoDev M, const uint8_t* concat, const uint64_t* offsets, int64_t nstr,
+                                                        uint8_t* matched, unsigned long long* visited, int W, unsigned long long* stack, int cap,
+                                                        int use_memo, uint32_t* flags) {
+  const int64_t lane = (int64_t)blockIdx.x * 64 + threadIdx.x;
+  const int64_t nlanes = (int64_t)gridDim.x * 64;
+  const MemoScratch S{visited + lane * W, W, stack + lane * cap, cap};
+  for (int64_t i = lane; i < nstr; i += nlanes) {
+    const uint64_t o0 = offsets[i], o1 = offsets[i + 1];
+    long long budget = kLaneStepBudget;
+    const int r = MemoMatch(M, concat + o0, (int)(o1 - o0), T.ref_prefix, T.anchored != 0, use_memo != 0, S, &budget);
+    if (r == kMemoGaveUp) { atomicOr(flags, 1u); matched[i] = 0; }
+    else matched[i] = (uint8_t)r;
+  }
+}
+
 // ---- batch, reference mode, the MEMOISING engine (rgx_memo.h) ------------------------------------------------------------------------
 // The plain search has run (found flags + the record of the LEFTMOST-FIRST match of every string); this kernel replays FindBytesReuse's
 // attempt offsets as ref_fix_kernel does, with the failure offset of every attempt taken from the depth-first search itself
@@ -2794,6 +2811,15 @@ hipError_t LaunchBatchRefFix(const DevTables& T, const uint8_t* concat, const ui
 hipError_t LaunchBatchRefFixList(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, uint8_t* found, int32_t* spans,
                                  uint16_t* trace, const uint32_t* ctl, uint32_t cap, hipStream_t stream) {
   hipLaunchKernelGGL(ref_fix_list_kernel, dim3(64), dim3(64), 0, stream, T, concat, offsets, found, spans, trace, ctl, cap);
+  return hipGetLastError();
+}
+
+hipError_t LaunchBatchMemoMatch(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* matched,
+                                unsigned long long* visited, int W, unsigned long long* stack, int cap, int64_t nlanes, int use_memo, uint32_t* flags,
+                                hipStream_t stream) {
+  if (nstr <= 0) return hipSuccess;
+  hipLaunchKernelGGL(memo_match_kernel, dim3((unsigned)(nlanes / 64)), dim3(64), 0, stream, T, *T.memo, concat, offsets, nstr, matched, visited, W,
+                     stack, cap, use_memo, flags);
   return hipGetLastError();
 }
 

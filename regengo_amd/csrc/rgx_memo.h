@@ -29,7 +29,8 @@ namespace rgx {
 enum MemoOp : uint8_t { kMFail = 0, kMMatch, kMNop, kMCapture, kMAlt, kMEmpty, kMByte, kMBytes, kMCls, kMUCls, kMAny, kMAnyNotNL, kMNever };
 struct MemoInst {
   uint8_t op;        // MemoOp
-  uint8_t flag;      // kMUCls: the class has ASCII members (instructions.go:205-295: ASCII fast path, else utf8.DecodeRune)
+  uint8_t flag;      // kMUCls: the class has ASCII members (instructions.go:205-295: ASCII fast path, else utf8.DecodeRune);
+                     // kMAlt: bit 0 = a simple greedy loop -- MatchBytes tries its EXIT first (instructions.go:331-336,458-476)
   uint16_t out;
   uint32_t arg;      // kMAlt: the second branch; kMEmpty: EmptyOp bits; kMByte: the byte; kMBytes: offset into bytes; kMCls / kMUCls: bitmap index
   uint32_t aux;      // kMBytes: length; kMUCls: first range pair | pairs << 20;  kMAlt: dense number of this Alt (its bit in the visited word)
@@ -90,11 +91,15 @@ struct MemoScratch {
 constexpr int kMemoMatched = -1;   // the attempt matched: *mend = the match end
 constexpr int kMemoGaveUp = -2;    // it left the visited window, overflowed the stack or spent the budget: not vouched for
 constexpr int kMemoRanOut = -3;    // MemoReplay: the sequence of attempts ran out of text (FindBytesReuse returns "no match")
+constexpr int kMemoHardFail = -4;  // MatchBytes met an InstFail: the emitted function returns false outright (instructions.go:62-66)
 
 // One attempt of the memoising machine on the text buf[0, l) from offset `start` (backtracking.go:83-165 with instructions.go's blocks).
 // Returns the offset the machine held when it fell through TryFallback with an empty stack -- where FindBytesReuse resumes, plus
 // one (find.go:545-569) --, kMemoMatched or kMemoGaveUp.
-RGX_HD int MemoAttempt(const MemoView& M, const uint8_t* buf, int l, int start, const MemoScratch& S, int* mend, long long* budget) {
+// match_mode: the emitted MatchBytes (compiler.go:740-871) instead of FindBytesReuse -- simple greedy loops try their exit first, an
+// InstFail ends the whole call; use_memo = false: the plain backtracker (no visited vector: programs the reference does not memoise).
+RGX_HD int MemoAttempt(const MemoView& M, const uint8_t* buf, int l, int start, const MemoScratch& S, int* mend, long long* budget,
+                       bool match_mode = false, bool use_memo = true) {
   int pc = M.start, off = start, sp = 0, maxrel = -1, result = 0;
   bool done = false;
   while (!done) {
@@ -103,18 +108,22 @@ RGX_HD int MemoAttempt(const MemoView& M, const uint8_t* buf, int l, int start, 
     bool fail = false;
     switch (in.op) {
       case kMMatch: *mend = off; result = kMemoMatched; done = true; break;
-      case kMFail: case kMNever: fail = true; break;
+      case kMFail: if (match_mode) { result = kMemoHardFail; done = true; } else fail = true; break;
+      case kMNever: fail = true; break;
       case kMNop: case kMCapture: pc = in.out; break;
       case kMAlt: {
         const int rel = off - start;
         if (rel >= S.W || sp >= S.cap) { result = kMemoGaveUp; done = true; break; }
-        const unsigned long long bit = 1ull << in.aux;
-        const unsigned long long v = S.visited[rel];
-        if (v & bit) { fail = true; break; }                 // instructions.go:343-352: been through this Alt at this offset
-        S.visited[rel] = v | bit;
-        maxrel = rel > maxrel ? rel : maxrel;
-        S.stack[sp++] = ((unsigned long long)(unsigned)off << 16) | in.arg;
-        pc = in.out;
+        if (use_memo) {
+          const unsigned long long bit = 1ull << in.aux;
+          const unsigned long long v = S.visited[rel];
+          if (v & bit) { fail = true; break; }               // instructions.go:343-352: been through this Alt at this offset
+          S.visited[rel] = v | bit;
+          maxrel = rel > maxrel ? rel : maxrel;
+        }
+        const bool exit_first = match_mode && (in.flag & 1u);
+        S.stack[sp++] = ((unsigned long long)(unsigned)off << 16) | (exit_first ? (unsigned)in.out : in.arg);
+        pc = exit_first ? (int)in.arg : (int)in.out;
         break;
       }
       case kMEmpty: {
@@ -191,6 +200,36 @@ RGX_HD int MemoReplay(const MemoView& M, const uint8_t* buf, int l, int off, int
     off = fo + 1;
   }
   return off;
+}
+
+// The emitted MatchBytes (compiler.go:740-871): attempts from the first occurrence of the required first byte (`prefix` >= 0:
+// compiler.go:719-737) or from offset 0, a failed attempt resumes behind the offset where its last alternative failed.  1 / 0, or
+// kMemoGaveUp.
+RGX_HD int MemoMatch(const MemoView& M, const uint8_t* buf, int l, int prefix, bool anchored, bool use_memo, const MemoScratch& S, long long* budget) {
+  const bool has_prefix = prefix >= 0 && !anchored;
+  int off = 0;
+  if (has_prefix) {
+    while (off < l && buf[off] != (uint8_t)prefix) ++off;
+    if (off >= l) return 0;
+  }
+  for (;;) {
+    int mend = 0;
+    const int fo = MemoAttempt(M, buf, l, off, S, &mend, budget, true, use_memo);
+    if (fo == kMemoMatched) return 1;
+    if (fo == kMemoHardFail) return 0;
+    if (fo == kMemoGaveUp) return kMemoGaveUp;
+    if (anchored) return 0;
+    if (has_prefix) {
+      off = fo + 1;
+      if (!(l > off)) return 0;
+      while (off < l && buf[off] != (uint8_t)prefix) ++off;
+      if (off >= l) return 0;
+      if ((*budget -= 1) < 0) return kMemoGaveUp;
+    } else {
+      if (!(l > fo)) return 0;
+      off = fo + 1;
+    }
+  }
 }
 
 }  // namespace rgx

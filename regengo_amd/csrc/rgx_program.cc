@@ -443,9 +443,16 @@ int ProgramToDevice(Program* p, int device) {
   p->dev.us = p->us_ok ? &p->usdev : nullptr;
   // the program as instructions, when the reference emits its memoising backtracker for the capture functions
   p->dev.memo = nullptr;
-  if (p->t.ncap > 2 && p->t.ref_find_engine != 1 && (p->t.ref_memo || p->t.ref_find_engine == 2) && p->t.ref_memo_interp &&
-      !(p->t.flags & RGX_FLAG_STDLIB_SEMANTICS) && UploadMemo(p))
-    p->dev.memo = &p->memodev;
+  {
+    const bool stdlib = (p->t.flags & RGX_FLAG_STDLIB_SEMANTICS) != 0;
+    const bool for_find = p->t.ncap > 2 && p->t.ref_find_engine != 1 && (p->t.ref_memo || p->t.ref_find_engine == 2);
+    // ... and for MatchBytes where the restart rule has no automaton: the reference memoises it, or an InstFail ends it outright
+    const bool for_match = p->dev.ref_match_kind == 2 && (p->t.ref_memo || p->t.ref_has_fail);
+    if ((for_find || for_match) && p->t.ref_memo_interp && !stdlib && UploadMemo(p)) {
+      p->dev.memo = &p->memodev;
+      if (for_match) p->dev.ref_match_kind = 3;
+    }
+  }
   // the reference's own Tagged DFA, when it emits one and the tag file is the record (ntags == ncap: always)
   p->dev.tdfa = nullptr;
   if (p->t.tdfa.nstates > 0 && p->t.tdfa.nstates <= 1000 && p->t.tdfa.ntags == p->t.ncap && UploadTdfa(p) == RGX_OK) p->dev.tdfa = &p->tdfadev;

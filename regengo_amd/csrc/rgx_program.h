@@ -84,7 +84,8 @@ struct DevTables {
   int32_t rm_small[2];            // at most 32 states and no depth above 127: the batch kernel composes a byte-indexed image of it
   int32_t ref_prefix;             // MatchBytes' required first byte, -1: none
   int32_t ref_find_ok;            // 1: FindBytesReuse in reference mode is offered (plain backtracking engine, no memo)
-  int32_t ref_match_kind;         // 0: restart rule over rm_*[1]; 1: the Thompson matcher (plain existence); 2: not offered
+  int32_t ref_match_kind;         // 0: restart rule over rm_*[1]; 1: the Thompson matcher (plain existence); 2: not offered; 3: the emitted
+                                  // MatchBytes interpreted (rgx_memo.h: MemoMatch -- the reference memoises it, or the program holds an InstFail)
   const MemoDev* memo;            // HOST pointer to the program as instructions when the reference emits its memoising backtracker for FindBytes
                                   // (ref_find_engine == 2) and the interpreter takes it (at most 64 Alt instructions), else nullptr
   const TdfaDev* tdfa;            // HOST pointer to the reference's Tagged DFA on the device (rgx_tdfa.hip) when the reference emits one, else nullptr

@@ -271,7 +271,15 @@ bool BuildMemoProg(const Prog& prog, MemoHost* out) {
       case InstMatch: m.op = kMMatch; break;
       case InstNop: case InstAltMatch: m.op = kMNop; break;
       case InstCapture: m.op = kMCapture; m.arg = in.arg; break;
-      case InstAlt: m.op = kMAlt; m.arg = in.arg; m.aux = (uint32_t)nalt++; break;
+      case InstAlt: {
+        m.op = kMAlt; m.arg = in.arg; m.aux = (uint32_t)nalt++;
+        // a simple greedy loop (instructions.go:331-336,458-476): the Alt's first branch goes BACK to a one-rune instruction
+        if ((int)in.out < i) {
+          const InstOp o = prog.inst[in.out].op;
+          if (o == InstRune || o == InstRune1 || o == InstRuneAny || o == InstRuneAnyNotNL) m.flag = 1;
+        }
+        break;
+      }
       case InstEmptyWidth: m.op = kMEmpty; m.arg = in.arg; break;
       case InstRuneAny: m.op = kMAny; break;
       case InstRuneAnyNotNL: m.op = kMAnyNotNL; break;

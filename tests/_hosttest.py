@@ -44,6 +44,7 @@ _lib.rgxt_tdfa_header.argtypes = [C.c_void_p, C.c_void_p]
 _lib.rgxt_tdfa_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 5
 _lib.rgxt_tdfa_find.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p]
 _lib.rgxt_memo_find.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p]
+_lib.rgxt_memo_match.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
 _lib.rgxt_tiny_find.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int64, C.c_int, C.c_void_p]
 
 INFO = ["ncap", "min", "max", "ninst", "nstates", "ncls", "anchored", "fixed", "empty", "refm", "reff", "look", "maxthr"]
@@ -117,6 +118,12 @@ class HostProgram:
         r = _lib.rgxt_search_first(sp.h, self.h, b, len(b), out)
         assert r >= 0, "winning thread without Capture 0"
         return list(out) if r == 1 else None
+
+    def memo_match(self, b: bytes):
+        """csrc/rgx_memo.h: MemoMatch on the host (the emitted MatchBytes interpreted): True / False, or None when it gives up / the
+        program is not interpreted."""
+        r = _lib.rgxt_memo_match(self.h, b, len(b))
+        return None if r < 0 else bool(r)
 
     def tiny_find(self, sp: "HostProgram", b: bytes, ref: bool):
         """csrc/rgx_tiny.h on the host (what batch_tiny_kernel runs per lane): (code, record) -- code 0 no match, 1 found, 2 found but

@@ -96,3 +96,31 @@ def test_reference_mode_equals_the_emitted_functions_on_the_corpus(torch_dev, co
             un_f += 1
     print("MatchBytes compared", nm, "patterns not offered", un_m, "| FindBytes compared", nf, "patterns not offered", un_f)
     assert nm > 4000 and nf > 3500 and un_f <= 2, (nm, nf, un_m, un_f)
+
+
+def test_interpreted_match_bytes_on_the_device(torch_dev):
+    """MatchBytes of programs the reference memoises (backtracking MatchBytes: patterns that end in `$`) is the emitted function
+    interpreted by a lane per string (memo_match_kernel, csrc/rgx_memo.h: MemoMatch): batch and single-buffer calls equal
+    oracle.Machine.match; a text beyond 64 KiB is refused, not approximated."""
+    from oracle import engines as E
+    from regengo_amd import Compiled, _capi
+    rng = random.Random(77)
+    n = 0
+    for pat, alpha in ((r"(?:a+b?)+c$", b"abc x"), (r"(?:[ab]+c?)+d$", b"abcd "), (r"(?:\w+\s?)+:$", b"ab :1"),
+                       (r"(?P<k>(?:[a-z]+-?)+)=(?P<v>\d+)$", b"ab-=12 ")):
+        o = E.Compiled(pat)
+        assert o.thompson is None and o.sel.match_memo
+        c = Compiled(pat).to(0)
+        assert c.info.ref_match_offered
+        strings = [bytes(rng.choice(alpha) for _ in range(rng.randrange(0, 60))) for _ in range(400)] + [b""]
+        got = c.MatchBatchDevice(*_csr(torch_dev, strings)).cpu().tolist()
+        for b, m in zip(strings, got):
+            assert bool(m) == o.MatchBytes(b), (pat, b)
+            n += 1
+        for b in strings[:40]:
+            assert c.MatchBytes(b) == o.MatchBytes(b), (pat, b)
+            assert c.MatchBytes(torch_dev.frombuffer(bytearray(b or b"\0"), dtype=torch_dev.uint8).cuda()[:len(b)]) == o.MatchBytes(b), (pat, b)
+        with pytest.raises(_capi.RgxError) as ei:
+            c.MatchBytes(b"a" * 70000)
+        assert ei.value.status == _capi.RGX_E_UNSUPPORTED
+    assert n > 1500

@@ -231,3 +231,39 @@ def test_memoising_engine_interpreter_equals_the_oracle(built, corpus, kats):
             assert hp.memo_find(b) == o.FindBytes(b), (pat, b)
             cmp += 1
     assert seen >= 14 and cmp >= 800, (seen, cmp)
+
+
+def test_interpreted_match_bytes_equals_the_oracle(built, corpus, kats):
+    """MatchBytes of the programs whose restart rule has no automaton -- the reference memoises them, or they hold an InstFail --
+    is the emitted function itself, interpreted (csrc/rgx_memo.h: MemoMatch; exit-first greedy loops, the required-first-byte skip,
+    `return false` at an InstFail): the host mirror of what memo_match_kernel runs per lane equals oracle.Machine.match on every
+    such pattern of the corpus, fuzzed texts included -- and rgx_info offers MatchBytes for them."""
+    import random
+    import zlib
+    from tests._hosttest import HostProgram
+    seen = cmp = trues = 0
+    # (most memoising programs get the Thompson matcher for MatchBytes: the backtracking MatchBytes memoises when the pattern ends in $)
+    extra = [(r"(?:a+b?)+c$", ["aaabc", "aaa", "baac", "xaabac"]), (r"(?:[ab]+c?)+d$", ["abcabd", "abc", "d abd"]), (r"(?:\w+\s?)+:$", ["a b c:", "a b c", ": ", "a:"]),
+             (r"(?P<k>(?:[a-z]+-?)+)=(?P<v>\d+)$", ["ab-cd=12", "ab-cd=", "x=1 y=2"])]
+    for pat, inputs in list(dict(_items(corpus, kats)).items()) + extra:
+        o = E.Compiled(pat)
+        if o.thompson is not None or not o.sel.match_memo:
+            continue
+        hp = HostProgram(pat)
+        if hp.memo_match(b"") is None and not hp.info["anchored"]:
+            # (not interpreted: more than 64 Alts / a fold-case rune list)
+            assert not codegen.Program(pat).info.ref_match_offered, pat
+            continue
+        assert codegen.Program(pat).info.ref_match_offered, pat
+        seen += 1
+        rnd = random.Random(zlib.crc32(pat.encode()))
+        bs = [s.encode() for s in inputs]
+        alpha = b"".join(bs) or b"ab"
+        texts = bs + [b"x" + s for s in bs] + [s + s for s in bs] + [s[:-1] for s in bs] + [b" ".join(bs), b""]
+        texts += [bytes(rnd.choice(alpha) for _ in range(rnd.randint(0, 120))) for _ in range(40)]
+        for b in texts:
+            got = hp.memo_match(b)
+            assert got is not None and got == o.MatchBytes(b), (pat, b, got)
+            cmp += 1
+            trues += int(got)
+    assert seen >= 10 and cmp >= 600 and 40 < trues < cmp - 40, (seen, cmp, trues)
