@@ -104,11 +104,11 @@ typedef struct rgx_info {
   int32_t lookahead_mode;  /* 1: pattern has $ / \b / \B / (?m)$ (match flag is on the next-byte edge) */
   int32_t table_bytes;     /* bytes of transition table staged in LDS                            */
   int32_t needs_valid_utf8; /* always 0 (kept for the layout): broken UTF-8 is handled at run time, see utf8_screened             */
-  int32_t sync_states;     /* states of the sync automaton W (0: none), DESIGN.md 4.1                         */
+  int32_t sync_states;     /* states of the sync automaton W (0: none), DESIGN.md 5.1                         */
   int32_t scan_kernel;     /* which FindAll kernel a large buffer takes once the program is on a device (0 before): 1 exact
                             * (fixed-length class chain), 2 prefilter + verify, 3 generic (one attempt per start), 4 one step
                             * per byte with start registers, 5 register-free (simple automata), 6 register-free, two bytes
-                            * per look-up; DESIGN.md section 4 */
+                            * per look-up; DESIGN.md section 5 */
   int32_t ref_match_offered; /* 1: MatchBytes in reference mode (the default) is offered: plain backtracking or Thompson engine, or --
                               * the reference memoises its MatchBytes, or the program holds an InstFail -- the emitted function
                               * interpreted on the device (strings / buffers up to 64 KiB, RGX_E_UNSUPPORTED beyond); 0: a memoising

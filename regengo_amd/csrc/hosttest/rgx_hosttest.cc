@@ -226,7 +226,7 @@ int rgxt_info(void* hh, int32_t* out) {
 
 int rgxt_reset_bytes(void* hh, uint8_t* out256) { memcpy(out256, ((Handle*)hh)->t.reset_byte, 256); return 0; }
 
-// Analysis for the next step of the one-step-per-byte kernels: class PAIRS on which every live state of the anchored
+// Analysis for the next step of the one-step-per-byte kernels (profiles/HISTORY.md 7): class PAIRS on which every live state of the anchored
 // automaton dies within two steps although neither class is a reset class by itself.  out[k1 * ncls + k2] = 1 for such a pair;
 // cls256 = the class of every byte value; returns ncls.
 int rgxt_reset_pairs(void* hh, uint8_t* cls256, uint8_t* out, int cap) {

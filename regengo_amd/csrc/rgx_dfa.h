@@ -86,7 +86,7 @@ struct Tables {
   // ---- sync automaton W.  A W state is the set of NFA positions that threads STARTED BEFORE the current offset may
   // occupy (no priorities, no cut below Match, zero-width assertions assumed true: a superset of the truth).  Started
   // from "every position" it shrinks as bytes kill threads; state 0 is the empty set: no match that began earlier can
-  // still be running, i.e. the offset is a sync point of FindAll (DESIGN.md 4.1) -- provable with NO knowledge of the
+  // still be running, i.e. the offset is a sync point of FindAll (DESIGN.md 5.1) -- provable with NO knowledge of the
   // bytes before the walk began.  Generalises reset bytes to patterns such as `\s+(?P<msg>.*)` whose states survive
   // every single byte value.  w_nstates == 0: not built (state budget).
   int w_nstates = 0;

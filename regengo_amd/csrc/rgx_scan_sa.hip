@@ -318,7 +318,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_sa_kernel(DevTables T, Sca
 bool UseSaKernel(const DevTables& T, int32_t len) {
   // worth it when candidates are sparse enough to be verified from the per-tile work list: few bytes can start a
   // match (a literal or a small class leads the pattern).  Patterns led by a big class loop (\\w+...) have a candidate
-  // at almost every byte and stay on the walk-per-position kernel until run-head pruning lands.
+  // at almost every byte and stay on the walk-per-position kernel until run-head pruning lands (profiles/HISTORY.md section 7).
   return len >= 64 && !UseExactKernel(T, len) && T.sa_k >= 2 && T.sa_k <= 29 && T.sa_first_bytes <= 6 && !T.anchored &&
          T.ncap <= 32;
 }

@@ -1,4 +1,4 @@
-"""CPU-only analysis for DESIGN 7: the scan-mode patterns of the C5 suite that have NO reset byte (every byte value keeps some
+"""CPU-only analysis for profiles/HISTORY.md 7: the scan-mode patterns of the C5 suite that have NO reset byte (every byte value keeps some
 state alive, so the one-step-per-byte kernels cannot take them and they run on the generic kernel with the sync automaton).
 For each: how many class PAIRS kill every live state within two steps, how dense such pairs are in the web-log corpus and the
 longest stretch without one -- i.e. whether "reset pairs" would give those kernels their sync points.

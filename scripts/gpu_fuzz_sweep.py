@@ -84,7 +84,7 @@ for seed in range(first, first + nseeds):
             except _capi.RgxError as ex:
                 if ex.status != _capi.RGX_E_UNSUPPORTED:
                     raise
-                refused += 1                 # the step budgets of the fallback kernels (DESIGN 4.5): a refusal, not an answer
+                refused += 1                 # the step budgets of the fallback kernels (DESIGN 5.10): a refusal, not an answer
                 print("REFUSED seed", seed, repr(p), "n", len(b), str(ex)[:60], flush=True)
                 continue
             t3 = time.time()

@@ -154,7 +154,7 @@ def test_lookahead_empty_matches_regression(torch_dev, pat):
 
 
 def test_long_match_across_a_tile_edge_with_the_sync_automaton(torch_dev):
-    """Regression (round-3 fuzz sweep, seed 1023).  `[^a]a{1,2}[^a]+` has no reset byte: the generic kernel takes its sync points from
+    """Regression (round-3 fuzz sweep, seed 1023; profiles/HISTORY.md section 6b).  `[^a]a{1,2}[^a]+` has no reset byte: the generic kernel takes its sync points from
     the sync automaton, and when the four staged halo slices hold none -- here a match of 474 bytes crosses the first tile edge --
     from the far look-behind, IN FRONT of the staged window.  The Shift-And prefilter then read LDS in front of the window and the
     lane behind the match reported [16429, 16461] for [16460, 16532].  (The sync automaton itself was sound: tests/_hosttest w_sync

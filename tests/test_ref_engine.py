@@ -176,7 +176,7 @@ from bench import C4_DROPPED_PER_MIB      # noqa: E402  (bench.py quotes these i
 
 def test_c4_find_reader_is_not_findall_over_the_stream():
     """BASELINE config C4 names FindReader; what ShardedReader / rgx_sharded_* compute is the reference's FindAllBytes over the
-    whole stream.  The reference's FindReader is something else, by its chunk protocol: a full chunk commits
+    whole stream (DESIGN.md sections 6-7).  The reference's FindReader is something else, by its chunk protocol: a full chunk commits
     matches that end at or before dataLen - MaxLeftover and ALWAYS carries exactly the last MaxLeftover bytes (keepFrom = dataLen -
     MaxLeftover, streaming.go:204-244: `committed` never exceeds that limit) -- so a match that STRADDLES the limit is neither
     committed nor kept whole: the next chunk begins inside it and it is lost.  No Config avoids that; the chunk grid is fixed
