@@ -11,7 +11,7 @@ resident in HBM:
   c2  Date DFA FindAllBytes over a 1 GiB shard per GPU, full ordered span table [matches, 8] int32 in HBM, plus (N>1) the
       all_gather of per-rank match counts that fixes every rank's global row base.  Weak scaling.
   c3  Email pattern FindBytes over a batch of 10M strings per GPU (rgx_find_batch_device): found flag + span record per string.
-  c4  URL-with-alternation FindReader over a 64 GiB stream: 8 GiB per GPU in 1 GiB windows with halos, owned round-robin by
+  c4  URL-with-alternation FindReader over a 64 GiB stream: 8 GiB per GPU in 1.6 GiB windows with halos, owned round-robin by
       the ranks (regengo_amd/dist.py: ShardedReader), stream-absolute rows; the gather of all rows to rank 0 is timed apart.
   c5  the reference's 255-pattern suite (e2e corpus + benchmarks/curated), one launch per pattern over a shared 1 GiB corpus
       (^/$-anchored patterns per line over a CSR view of the lines); with N GPUs the patterns are dealt round-robin.
@@ -699,9 +699,11 @@ def run_c4(env, args):
     c = Compiled(URL, name="URL").to(env.local_rank)
     assert c.info.ref_findall_offered, "C4's pattern: the reference memoises, its FindAllBytes is leftmost-first and offered"
     sh = make_sharded(env, c)
-    tiles_per_window = (1 << 30) // T
+    # the window: as large as 32-bit window-relative rows comfortably allow -- 1.6 GiB, five per GPU = the 8 GiB share of the 64 GiB
+    # stream (per window ~0.19 ms of launches, synchronisations and round bookkeeping: 1 GiB windows 720 GB/s, 1.6 GiB 766, 1.9 GiB 783)
+    tiles_per_window = int(args.window_gib * (1 << 30)) // T
     W = tiles_per_window * T                    # ~1 GiB, a whole number of tiles
-    nwin_total = args.windows * world           # weak scaling: `windows` (default 8 = 8 GiB) per GPU; 8 GPUs = the 64 GiB stream
+    nwin_total = args.windows * world           # weak scaling: `windows` (default 5 x 1.6 GiB = 8 GiB) per GPU; 8 GPUs = the 64 GiB stream
     Ltot = nwin_total * W
     HALO_L, HALO_R = 4096, 1 << 20              # unbounded pattern: the reference's own 1 MiB leftover cap as the right halo
     tt = torch.frombuffer(bytearray(tile), dtype=torch.uint8).to(dev)
@@ -832,8 +834,8 @@ def run_c4(env, args):
     achieved = win_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     traffic, tsrc = load_traffic("c4")
     line = base_line(env, args, value, ms_per_step, reps)
-    line["config"] = {"workload": "C4: URL-with-alternation FindReader over a %.0f GiB stream, %d x ~1 GiB windows per GPU with halos, owned "
-                                  "round-robin by the ranks (C ABI: rgx_sharded_round_*), window-relative int32 rows + stream offsets" % (Ltot / 2**30, args.windows),
+    line["config"] = {"workload": "C4: URL-with-alternation FindReader over a %.0f GiB stream, %d x ~%.1f GiB windows per GPU with halos, owned "
+                                  "round-robin by the ranks (C ABI: rgx_sharded_round_*), window-relative int32 rows + stream offsets" % (Ltot / 2**30, args.windows, W / 2**30),
                       "semantics": "the reference's FindAllBytes over the whole stream (its FindReader would drop %s of 8992 matches per MiB tile at "
                                    "BufferSize 64/128/256 KiB: those straddling dataLen - MaxLeftover of a chunk; not reproduced across GPUs -- "
                                    "the per-chunk protocol is rgx_find_chunk's / rgx_count_chunk's, one GPU, the reference's FindReader or "
@@ -1249,7 +1251,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=None)
     ap.add_argument("--bytes", type=int, default=1 << 30, help="c2: shard size per GPU; c5: corpus size")
     ap.add_argument("--strings", type=int, default=10_000_000, help="c3: strings per GPU")
-    ap.add_argument("--windows", type=int, default=8, help="c4: ~1 GiB windows per GPU")
+    ap.add_argument("--windows", type=int, default=5, help="c4: windows per GPU (default 5 x 1.6 GiB = 8 GiB per GPU)")
+    ap.add_argument("--window-gib", type=float, default=1.6, help="c4: bytes per window in GiB (below 2: rows are window-relative int32)")
     ap.add_argument("--max-patterns", type=int, default=0, help="c5: only the first K patterns of the suite")
     ap.add_argument("--max-span-gib", type=int, default=48, help="c5: patterns whose span table would be larger are counted only")
     ap.add_argument("--no-row-check", action="store_true", help="c5: skip the row checksums after the timed region (counts are always checked)")
