@@ -175,7 +175,7 @@ hipError_t LaunchBatchMemoFix(const DevTables& T, const uint8_t* concat, const u
                               uint32_t* flags, hipStream_t stream);
 // LaunchReaderCheck for such a program (raw bytes: the interpreter decodes runes itself); *flag |= 1: diverges or not vouched for
 hipError_t LaunchMemoReaderCheck(const DevTables& T, const uint8_t* raw, int32_t len, const int32_t* spans, int64_t n, int ncap,
-                                 unsigned long long* visited, int W, unsigned long long* stack, int cap, int64_t nlanes, unsigned* flag,
+                                 unsigned long long* visited, int W, unsigned long long* stack, int cap, int64_t nlanes, unsigned* flag, int final_pass,
                                  hipStream_t stream);
 // The Q4 half of LaunchReaderCheck alone (bytes.Index finds the match text earlier in the gap): any ordered span table.
 hipError_t LaunchReaderIndex(const uint8_t* raw, int32_t len, const int32_t* spans, int64_t n, int ncap, unsigned* flag, hipStream_t stream);

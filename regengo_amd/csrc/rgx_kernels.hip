@@ -2545,12 +2545,14 @@ namespace {
 // bytes.Index (Q4) is reader_index_kernel's, as for every engine.
 __global__ __launch_bounds__(64) void memo_reader_check_kernel(DevTables T, MemoDev M, const uint8_t* raw, int32_t len, const int32_t* spans,
                                                                long long n, int ncap, unsigned long long* visited, int W,
-                                                               unsigned long long* stack, int cap, unsigned* flag) {
+                                                               unsigned long long* stack, int cap, unsigned* flag, int final_pass) {
   const long long lane = (long long)blockIdx.x * 64 + threadIdx.x;
   const long long nlanes = (long long)gridDim.x * 64;
   const MemoScratch S{visited + lane * W, W, stack + lane * cap, cap};
-  bool bad = false;
-  for (long long i = lane; i <= n && !bad; i += nlanes) {
+  // gave_up: the scratch of this pass (W visited words, cap stack entries) or the step budget did not do for a gap -- on the first pass,
+  // which runs many lanes with little scratch each, that asks for the second pass (flag bit 1); on the final pass it is a refusal
+  bool bad = false, gave_up = false;
+  for (long long i = lane; i <= n && !bad && !gave_up; i += nlanes) {
     const int p = i == 0 ? 0 : spans[(i - 1) * ncap + 1];
     const int s = i < n ? spans[i * ncap] : len, e = i < n ? spans[i * ncap + 1] : len;
     if (p >= len) continue;
@@ -2558,10 +2560,11 @@ __global__ __launch_bounds__(64) void memo_reader_check_kernel(DevTables T, Memo
     int mend = 0, mend2 = 0;
     // the attempt at p, on the slice chunk[p:]
     const int a0 = MemoAttempt(M, raw + p, len - p, 0, S, &mend, &budget);
-    if (a0 == kMemoGaveUp) { bad = true; break; }
+    if (a0 == kMemoGaveUp) { gave_up = true; break; }
     if (p > 0) {
       const int a1 = MemoAttempt(M, raw, len, p, S, &mend2, &budget);
-      if (a1 == kMemoGaveUp || (a0 == kMemoMatched) != (a1 == kMemoMatched)) { bad = true; break; }
+      if (a1 == kMemoGaveUp) { gave_up = true; break; }
+      if ((a0 == kMemoMatched) != (a1 == kMemoMatched)) { bad = true; break; }
       if (a0 == kMemoMatched ? mend + p != mend2 : a0 + p != a1) { bad = true; break; }
     }
     if (a0 == kMemoMatched) {
@@ -2585,19 +2588,24 @@ __global__ __launch_bounds__(64) void memo_reader_check_kernel(DevTables T, Memo
     if (off > s) { bad = true; break; }
     int at = 0;
     const int r = MemoReplay(M, raw + p, len - p, off - p, s - p, S, &budget, &at);
+    if (r == kMemoGaveUp) { gave_up = true; break; }
     if (r != s - p) { bad = true; break; }
     // ... and the attempt at s matches with FindAllBytes' end (s > p here: its context is the true one)
     const int am = MemoAttempt(M, raw + p, len - p, s - p, S, &mend, &budget);
-    if (am != kMemoMatched || mend + p != e) bad = true;
+    if (am == kMemoGaveUp) gave_up = true;
+    else if (am != kMemoMatched || mend + p != e) bad = true;
   }
+  if (gave_up && final_pass) bad = true;
+  if (__any(gave_up && !final_pass) && (threadIdx.x & 63) == 0) atomicOr(flag, 2u);
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
 }
 }  // namespace
 hipError_t LaunchMemoReaderCheck(const DevTables& T, const uint8_t* raw, int32_t len, const int32_t* spans, int64_t n, int ncap,
                                  unsigned long long* visited, int W, unsigned long long* stack, int cap, int64_t nlanes, unsigned* flag,
-                                 hipStream_t stream) {
+                                 int final_pass, hipStream_t stream) {
   hipLaunchKernelGGL(memo_reader_check_kernel, dim3((unsigned)(nlanes / 64)), dim3(64), 0, stream, T, *T.memo, raw, len, spans, (long long)n, ncap,
-                     visited, W, stack, cap, flag);
+                     visited, W, stack, cap, flag, final_pass);
+  if (final_pass == 2) return hipGetLastError();       // (the second pass of two: the bytes.Index test ran with the first)
   return LaunchReaderIndex(raw, len, spans, n, ncap, flag, stream);
 }
 

@@ -580,3 +580,32 @@ def test_required_class_prefilter_boundaries(torch_dev, pat, seed):
         spans, res = c.FindAllSpans(torch_dev.from_numpy(b).cuda())
         assert res.total == cnt and np.array_equal(spans.cpu().numpy(), exp), (pat, shift)
     assert cnt > 20
+
+
+def test_memo_reader_check_second_pass(torch_dev):
+    """The check of FindReader's loop for a memoising program runs in two passes (rgx_capi.cc: ReaderCheck): many lanes with 384 visited
+    words each, and -- when a gap needs more: here host names of 500-3000 bytes, whose attempts walk that far -- a second pass with
+    4096.  Both against the oracle's loop; a run beyond the second pass's reach is refused (RGX_E_DIVERGES), not answered wrongly."""
+    from oracle import engines as E
+    from oracle.gen_c import CMatcher
+    from regengo_amd import Config, _capi
+    pat = r"(?P<full>(?P<proto>https?|ftp)://(?P<host>[\w.-]+)(?P<port>:\d+)?(?P<path>/[\w./-]*)?)"
+    c = _gpu(pat)
+    assert c.info.ref_stream_offered and c.info.ref_find_engine != 1
+    o = E.Compiled(pat)
+    cm = CMatcher(pat)
+    answered = 0
+    for host_len in (100, 500, 1500, 3000, 6000):
+        data = (b"GET http://a.b/c x " * 5 + b"see https://" + b"h" * host_len + b".org/p and ftp://x.y then " + b"w" * host_len + b" http://q.r:80/ end\n") * 3
+        ref = []
+        E.find_reader(cm.find, o.sel.max_len, io.BytesIO(data).read, E.StreamConfig(BufferSize=1 << 17),
+                      lambda m: ref.append((m.StreamOffset, m.match_bytes)) or True)
+        got = []
+        try:
+            c.FindReader(io.BytesIO(data), Config(BufferSize=1 << 17), lambda m: got.append((m.StreamOffset, m.Result.Match)) or True)
+            assert got == ref, host_len
+            assert c.FindReaderCount(io.BytesIO(data), Config(BufferSize=1 << 17)) == len(ref)
+            answered += 1
+        except _capi.RgxError as ex:
+            assert ex.status == _capi.RGX_E_DIVERGES and host_len > 3000, (host_len, ex)
+    assert answered >= 4
