@@ -67,7 +67,8 @@ struct rgx_stream_ctx {
   uint8_t* d_tmpl = nullptr; int64_t tmpl_cap = 0;           // resolved template (segments + literals) of the last splice
   std::string tmpl_key;                                      // what d_tmpl holds: "" = nothing
   // pinned host readback
-  unsigned long long* h_read = nullptr;      // [16]: 0-3 the synchronous scan (total, rare-path flag, counters), 4-5 the splice,
+  uint32_t* d_tiny_ctl = nullptr; int tiny_set = 0;   // batch_tiny_kernel's two control sets (rgx_find_batch_device)
+  unsigned long long* h_read = nullptr;      // [16]: 0-3 the synchronous scan (total, rare-path flag, counters), 4-5 the splice, 6-7 the tiny batch's control words,
   unsigned long long* h_read_dev = nullptr;  //       8-11 / 12-15 the two in-flight scans of submit/wait; same words, device view
   // submit / wait (rgx_find_all_submit): up to two scans in flight
   struct Pending {
@@ -880,6 +881,7 @@ RGX_API void rgx_stream_ctx_destroy(rgx_stream_ctx* c) {
   for (void* p : {(void*)c->d_desc, (void*)c->d_unsynced, (void*)c->d_carry,
                   (void*)c->d_trace, (void*)c->d_in, (void*)c->d_san, (void*)c->d_out, (void*)c->d_rspans, (void*)c->d_rdelta, (void*)c->d_rtemp, (void*)c->d_tmpl, (void*)c->d_tdfa, (void*)c->d_memo})
     if (p) (void)hipFree(p);
+  if (c->d_tiny_ctl) (void)hipFree(c->d_tiny_ctl);
   if (c->h_read) (void)hipHostFree(c->h_read);
   delete c;
 }
@@ -1666,14 +1668,24 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
       // a tiny automaton: the find, the groups and the restart rule in one pass in registers (rgx_tiny.h).  Launched before anybody has
       // looked at the offsets: the kernel gives the batch up when a string is longer than its tag bytes hold (ctl[0]), and names the
       // strings whose attempts the replay kernel has to walk one by one (ctl[1], the list behind)
-      if ((rc = Ensure(&c->d_tdfa, &c->tdfa_cap, (int64_t)(4 + kTinyListCap))) != RGX_OK) return rc;
-      uint32_t* ctl = (uint32_t*)c->d_tdfa;
-      uint32_t h_ctl[4] = {0, 0, 0, 0};
-      HIP_TRY(hipMemsetAsync(ctl, 0, 16, c->stream));
+      // two control sets ([gave up, flagged, -, -] + the list), used alternately: the call's last kernel zeroes the other one and
+      // writes this one's four words to pinned host memory (words 6-7 of h_read), so the call is two launches and one synchronisation
+      constexpr size_t kSetWords = 4 + kTinyListCap;
+      if (!c->d_tiny_ctl) {
+        HIP_TRY(hipMalloc((void**)&c->d_tiny_ctl, 2 * kSetWords * 4));
+        HIP_TRY(hipMemsetAsync(c->d_tiny_ctl, 0, 2 * kSetWords * 4, c->stream));
+        c->tiny_set = 0;
+      }
+      uint32_t* ctl = c->d_tiny_ctl + (size_t)c->tiny_set * kSetWords;
+      uint32_t* other = c->d_tiny_ctl + (size_t)(1 - c->tiny_set) * kSetWords;
+      c->tiny_set = 1 - c->tiny_set;
+      volatile uint32_t* hc = reinterpret_cast<volatile uint32_t*>(c->h_read + 6);
+      hc[0] = hc[1] = hc[2] = hc[3] = 0;
       HIP_TRY(LaunchBatchTiny(*U, T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, ref_mode, ctl, c->stream));
-      if (ref_mode) HIP_TRY(LaunchBatchRefFixList(T, d_concat, d_offsets, d_found, d_spans, c->d_trace, ctl, kTinyListCap, c->stream));
-      HIP_TRY(hipMemcpyAsync(h_ctl, ctl, 16, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(LaunchBatchRefFixList(T, d_concat, d_offsets, d_found, d_spans, c->d_trace, ctl, kTinyListCap, reinterpret_cast<uint32_t*>(c->h_read_dev + 6),
+                                    other, ref_mode && !T.anchored, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
+      const uint32_t h_ctl[4] = {hc[0], hc[1], hc[2], hc[3]};
       if (!h_ctl[0]) {
         if (ref_mode && h_ctl[1] >= kTinyListCap) {
           // (more flagged strings than the list holds: every match is at most kTinyMaxLen bytes, the LDS trace of ref_fix_kernel holds it)

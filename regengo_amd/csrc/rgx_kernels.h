@@ -117,13 +117,16 @@ hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8
 // kernel measures the strings itself and gives the batch up (ctl[0] != 0: results void, take the general path) when one is longer.
 // ref: the reference's restart rule rides along; the strings whose attempts do not land on the match's start get found = 2 and are
 // listed (ctl[1] = how many, ctl[4..] = the first `cap` indices) for LaunchBatchRefFixList, which replays them one by one; more than
-// `cap` of them: LaunchBatchRefFix(only_flagged) over the whole batch.  ctl: 4 + cap words, ctl[0..3] zeroed by the caller.
+// `cap` of them: LaunchBatchRefFix(only_flagged) over the whole batch.  ctl: 4 + cap words, ctl[0..3] zero on entry -- the list
+// kernel of the call before zeroed them (two control sets used alternately) and hands this call's to the host through pinned memory
+// (host_ctl): a call is two launches and one synchronisation, no memset and no copy node.
 constexpr uint32_t kTinyListCap = 65536;
 bool BatchTinyFits(const DevTables& U, const DevTables& F, const uint8_t* concat, int64_t nstr, bool ref);
 hipError_t LaunchBatchTiny(const DevTables& U, const DevTables& F, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,
                            int32_t* spans, bool ref, uint32_t* ctl, hipStream_t stream);
 hipError_t LaunchBatchRefFixList(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, uint8_t* found, int32_t* spans,
-                                 uint16_t* trace, const uint32_t* ctl, uint32_t cap, hipStream_t stream);
+                                 uint16_t* trace, const uint32_t* ctl, uint32_t cap, uint32_t* host_ctl, uint32_t* other_ctl, bool do_fix,
+                                 hipStream_t stream);
 
 // The current device's CU count, and the 160 KiB dynamic-LDS allowance of a kernel -- both cached per DEVICE (a device list in one process
 // launches the same kernels on several devices).

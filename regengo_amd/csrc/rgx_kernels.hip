@@ -1054,12 +1054,20 @@ __global__ __launch_bounds__(64) void ref_fix_kernel(DevTables T, const uint8_t*
 }
 
 // ... over a LIST of strings (batch_tiny_kernel names the few it flags: ctl[1] = how many, ctl + 4 = their indices, `cap` of them at most --
-// beyond that, and when ctl[0] is set -- the kernel gave the batch up --, this one does nothing and the host takes the whole-batch path)
+// beyond that, and when ctl[0] is set -- the kernel gave the batch up --, this one replays nothing and the host takes the whole-batch
+// path).  It also PUBLISHES the call's control words: ctl[0..3] go to pinned host memory (the host reads them behind its one
+// synchronisation: no copy node in the stream) and the OTHER control set, the next call's, is zeroed (no memset node either).
 __global__ __launch_bounds__(64) void ref_fix_list_kernel(DevTables T, const uint8_t* concat, const uint64_t* offsets, uint8_t* found,
-                                                          int32_t* spans, uint16_t* trace, const uint32_t* ctl, uint32_t cap) {
+                                                          int32_t* spans, uint16_t* trace, const uint32_t* ctl, uint32_t cap, uint32_t* host_ctl,
+                                                          uint32_t* other_ctl, int do_fix) {
   __shared__ uint16_t s_trace[64 * kCapsLdsTrace];
-  if (ctl[0]) return;
-  const uint32_t n = ctl[1] < cap ? ctl[1] : 0u;
+  const uint32_t gave_up = ctl[0], flagged = ctl[1];
+  if (blockIdx.x == 0 && threadIdx.x < 4) {
+    __hip_atomic_store(host_ctl + threadIdx.x, ctl[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    other_ctl[threadIdx.x] = 0u;
+  }
+  if (gave_up || !do_fix) return;
+  const uint32_t n = flagged < cap ? flagged : 0u;
   for (uint32_t k = blockIdx.x * 64 + threadIdx.x; k < n; k += gridDim.x * 64)
     RefFixOne(T, concat, offsets, (int64_t)ctl[4 + k], found, spans, trace, s_trace);
 }
@@ -2817,8 +2825,10 @@ hipError_t LaunchBatchRefFix(const DevTables& T, const uint8_t* concat, const ui
 }
 
 hipError_t LaunchBatchRefFixList(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, uint8_t* found, int32_t* spans,
-                                 uint16_t* trace, const uint32_t* ctl, uint32_t cap, hipStream_t stream) {
-  hipLaunchKernelGGL(ref_fix_list_kernel, dim3(64), dim3(64), 0, stream, T, concat, offsets, found, spans, trace, ctl, cap);
+                                 uint16_t* trace, const uint32_t* ctl, uint32_t cap, uint32_t* host_ctl, uint32_t* other_ctl, bool do_fix,
+                                 hipStream_t stream) {
+  hipLaunchKernelGGL(ref_fix_list_kernel, dim3(do_fix ? 64 : 1), dim3(64), 0, stream, T, concat, offsets, found, spans, trace, ctl, cap, host_ctl,
+                     other_ctl, do_fix ? 1 : 0);
   return hipGetLastError();
 }
 
