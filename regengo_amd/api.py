@@ -360,12 +360,16 @@ class Compiled:
         sp = spans.cpu().tolist()
         return [self._make_result(strings[i], sp[i]) if f[i] else None for i in range(len(strings))]
 
-    def FindBatchDevice(self, concat, offsets):
+    def FindBatchDevice(self, concat, offsets, out=None):
+        """out=(found uint8 [nstr], spans int32 [nstr, ncap]): caller-owned result buffers (a steady stream of batches reuses them)."""
         import torch
         self._need_dev()
         nstr = offsets.numel() - 1
-        found = torch.empty(nstr, dtype=torch.uint8, device=concat.device)
-        spans = torch.empty((nstr, self.ncap), dtype=torch.int32, device=concat.device)
+        if out is not None:
+            found, spans = out
+        else:
+            found = torch.empty(nstr, dtype=torch.uint8, device=concat.device)
+            spans = torch.empty((nstr, self.ncap), dtype=torch.int32, device=concat.device)
         _capi.check(self._lib.rgx_find_batch_device(self._h, self._ctx, concat.data_ptr(), offsets.data_ptr(), nstr,
                                                     found.data_ptr(), spans.data_ptr()))
         return found, spans
