@@ -97,13 +97,12 @@ template <int NREG>
 static int TinyRun(const std::vector<uint32_t>& img, const uint8_t* buf, int len, bool ref, int unset, int32_t* out) {
   TinyLane<NREG> L;
   for (int r = 0; r < NREG; ++r) L.R[r] = img[kTinyInit + r];
-  L.A = img[kTinyInit + 8]; L.q4 = img[kTinyInit + 9]; L.st4 = img[kTinyInit + 10];
+  L.A = img[kTinyInit + 8]; L.q5 = img[kTinyInit + 9]; L.st4 = img[kTinyInit + 10];
   const auto load_sel = [&](uint32_t cell_at, uint32_t* s) { for (int r = 0; r < NREG; ++r) s[r] = img[kTinySel + cell_at / 4 + r]; };
-  const uint32_t qmul = img[kTinyInit + 14], cshift = img[kTinyInit + 15];
   for (int p = 0; p < len; ++p) {
     const uint32_t* cm = &img[kTinyColmap + 2 * buf[p]];
-    if (ref) TinyStep<NREG, true>(L, cm[0], cm[1], load_sel, (uint32_t)p + 1u, qmul, cshift);
-    else TinyStep<NREG, false>(L, cm[0], cm[1], load_sel, (uint32_t)p + 1u, qmul, cshift);
+    if (ref) TinyStep<NREG, true>(L, cm[0], cm[1], load_sel, (uint32_t)p + 1u);
+    else TinyStep<NREG, false>(L, cm[0], cm[1], load_sel, (uint32_t)p + 1u);
   }
   const uint32_t* reg_of = &img[kTinyInit + 16];
   const int ncap = (int)img[kTinyInit + 13];

@@ -5,6 +5,9 @@
 // the selectors, and the walk does not wait for those.
 #include <hip/hip_runtime.h>
 
+#include <atomic>
+#include <cstdlib>
+
 #include "rgx_kernels.h"
 #include "rgx_tiny.h"
 
@@ -35,7 +38,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_kernel(const uint32_
   const uint32_t lds0 = (uint32_t)(uintptr_t)(const unsigned char __attribute__((address_space(3)))*)smem;
   const uint32_t cm_at = lds0 + kTinyColmap * 4, sel_at = lds0 + kTinySel * 4;
   const L32 ini = (L32)(uintptr_t)(lds0 + kTinyInit * 4);
-  const int wave = tid >> 6, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;      // (the wave index in a scalar register)
   unsigned char* const wwin = smem + kTinyImageBytes + wave * (wslice + 16);
   const uint32_t wwin_at = lds0 + kTinyImageBytes + wave * (wslice + 16);
   const auto load_sel = [&](uint32_t cell_at, uint32_t* s) {
@@ -49,31 +52,110 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_kernel(const uint32_
     if (NREG == 7) { const u32x2 b = *(L64)(q + 4); s[4] = b.x; s[5] = b.y; s[6] = q[6]; }
     if (NREG == 8) { const u32x4 b = *(L128)(q + 4); s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w; }
   };
-  const int ntrack = (int)ini[13];                   // capture slots in the tag registers (uniform)
-  const uint32_t qmul = ini[14], cshift = ini[15];   // where an edge's selectors lie (rgx_tiny.h)
+  // uniform words of the image, in scalar registers
+  const int ntrack = (int)__builtin_amdgcn_readfirstlane(ini[13]);                   // capture slots in the tag registers
   uint32_t reg_of[8];
 #pragma unroll
-  for (int c = 0; c < 8; ++c) reg_of[c] = ini[16 + c];
-  const int64_t ngroups = (nstr + kBlockThreads - 1) / kBlockThreads;
-  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int64_t i0 = grp * kBlockThreads + wave * 64;          // the wave's first string
+  for (int c = 0; c < 8; ++c) reg_of[c] = __builtin_amdgcn_readfirstlane(ini[16 + c]);
+  // A wave's work on a group of 64 strings is a chain: their offsets, then their bytes, then the walk.  The three are software-pipelined
+  // over the wave's groups: while group g is walked, the bytes of group g + G are on their way into registers (at most four 16-byte
+  // pieces per lane: 64 strings of kTinyMaxLen bytes) and the offsets of group g + 2G behind them -- a wave never sits idle behind an
+  // HBM round trip with nothing else to do (measured before: 42 % of the wave-cycles parked in s_waitcnt).  Every load is issued
+  // WITHOUT a branch around it (a clamped index, a harmless address): the compiler waits for a load behind a branch where the branch ends.
+  const int ngroups = (int)((nstr + kBlockThreads - 1) / kBlockThreads);
+  const int G = (int)gridDim.x;
+  const uint8_t* const idle = reinterpret_cast<const uint8_t*>(img);
+  // the offsets of group g's strings: lanes behind the last string of the batch hold o0 = o1 = 0
+#define RGX_TINY_META(g, o0, o1)                                                            \
+  do {                                                                                      \
+    const int64_t i_ = (int64_t)(g) * kBlockThreads + wave * 64 + lane;                     \
+    const int64_t ii_ = i_ < nstr ? i_ : nstr - 1;                                          \
+    const uint64_t a_ = offsets[ii_], b_ = offsets[ii_ + 1];                                \
+    o0 = i_ < nstr ? a_ : 0ull;                                                             \
+    o1 = i_ < nstr ? b_ : 0ull;                                                             \
+  } while (0)
+  // the window of group g (uniform): from the 16-byte boundary at or below its first string to the end of its last
+#define RGX_TINY_WINDOW(g, o0, o1, wb, wvalid)                                                                                   \
+  do {                                                                                                                           \
+    const int64_t i0_ = (int64_t)(g) * kBlockThreads + wave * 64;                                                                \
+    wb = 0; wvalid = 0;                                                                                                          \
+    if ((g) < ngroups && i0_ < nstr) {                                                                                           \
+      const int nv_ = (int)(nstr - i0_ < 64 ? nstr - i0_ : 64);                                                                  \
+      const uint32_t bl_ = __builtin_amdgcn_readfirstlane((uint32_t)(o0)), bh_ = __builtin_amdgcn_readfirstlane((uint32_t)((o0) >> 32)); \
+      const uint32_t el_ = __builtin_amdgcn_readlane((uint32_t)(o1), nv_ - 1), eh_ = __builtin_amdgcn_readlane((uint32_t)((o1) >> 32), nv_ - 1); \
+      const uint64_t gb_ = ((uint64_t)bh_ << 32) | bl_, ge_ = ((uint64_t)eh_ << 32) | el_;                                      \
+      wb = gb_ & ~15ull;                                                                                                         \
+      const uint64_t span_ = ((ge_ - wb) + 15ull) & ~15ull;                                                                      \
+      wvalid = (int)(span_ < (uint64_t)wslice ? span_ : (uint64_t)wslice);                                                       \
+    }                                                                                                                            \
+  } while (0)
+#define RGX_TINY_PIECE(k, wb, wvalid) \
+  (*reinterpret_cast<const uint4*>((lane + 64 * (k)) < ((wvalid) >> 4) ? concat + (wb) + ((uint64_t)(lane + 64 * (k)) << 4) : idle))
+  // A group's results are stored when the NEXT group's bytes have gone to LDS, in front of the prefetches: the wait for a prefetched
+  // piece is then never a wait for the stores of the group just walked (stores and loads share one counter and the compiler counts
+  // stores in branches conservatively), only for stores a whole walk old.
+  int gprev = -1, fprev = -1;
+  int32_t rprev[8];
+  const auto flush = [&]() {
+    if (gprev < 0 || fprev < 0) return;
+    const int64_t i = (int64_t)gprev * kBlockThreads + wave * 64 + lane;
+    const int f = fprev;
+    found[i] = (uint8_t)f;
+    if (REF && f == 2) {
+      const uint32_t k = atomicAdd(ctl + 1, 1u);
+      if (k < kTinyListCap) ctl[4 + k] = (uint32_t)i;
+    }
+    if (f && !fixed) {                              // (rgx.h: the record of a string without a match is unspecified)
+      int2* dst = reinterpret_cast<int2*>(spans + i * ncap_out);
+#pragma unroll
+      for (int c = 0; c < 8; c += 2)
+        if (c < ncap_out) dst[c >> 1] = make_int2(rprev[c], rprev[c + 1]);
+    } else if (f) {
+      // every group lies at a fixed distance from the match's start or end (DevTables::fixed_captures): two slots tracked
+      int32_t* dst = spans + i * ncap_out;
+      dst[0] = rprev[0]; dst[1] = rprev[1];
+      for (int c = 2; c < ncap_out; ++c) dst[c] = cap_kind[c] == kCapFromStart ? rprev[0] + cap_delta[c] : rprev[1] - cap_delta[c];
+    }
+  };
+  uint4 p0, p1, p2, p3;
+  uint64_t o0c, o1c, o0n, o1n, wbc, wbn;
+  int wvc, wvn;
+  int grp = (int)blockIdx.x;
+  RGX_TINY_META(grp, o0c, o1c);
+  RGX_TINY_WINDOW(grp, o0c, o1c, wbc, wvc);
+  p0 = RGX_TINY_PIECE(0, wbc, wvc); p1 = RGX_TINY_PIECE(1, wbc, wvc); p2 = RGX_TINY_PIECE(2, wbc, wvc); p3 = RGX_TINY_PIECE(3, wbc, wvc);
+  RGX_TINY_META(grp + G, o0n, o1n);
+  uint32_t stop_next = __builtin_nontemporal_load(ctl);
+  for (; grp < ngroups; grp += G) {
+    const int64_t i0 = (int64_t)grp * kBlockThreads + wave * 64;  // the wave's first string
     if (i0 >= nstr) break;
-    if (__builtin_nontemporal_load(ctl) != 0u) break;            // a string too long for the tag bytes somewhere: the batch is given up
     const int64_t i = i0 + lane;
-    const int64_t ilast = i0 + 64 < nstr ? i0 + 64 : nstr;
-    const uint64_t gb = offsets[i0], ge = offsets[ilast];
-    const uint64_t wb = gb & ~15ull;
-    const uint64_t span = ((ge - wb) + 15ull) & ~15ull;
-    const int wvalid = (int)(span < (uint64_t)wslice ? span : (uint64_t)wslice);
+    const uint64_t wb = wbc;
+    const int wvalid = wvc;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
-    for (int c = lane; c < (wvalid >> 4); c += 64)
-      *reinterpret_cast<uint4*>(wwin + (c << 4)) = *reinterpret_cast<const uint4*>(concat + wb + ((uint64_t)c << 4));
-    uint64_t o0 = wb, o1 = wb;
-    if (i < nstr) { o0 = offsets[i]; o1 = offsets[i + 1]; }
+    {
+      const int nch = wvalid >> 4;
+      if (lane < nch) *reinterpret_cast<uint4*>(wwin + (lane << 4)) = p0;
+      if (lane + 64 < nch) *reinterpret_cast<uint4*>(wwin + ((lane + 64) << 4)) = p1;
+      if (lane + 128 < nch) *reinterpret_cast<uint4*>(wwin + ((lane + 128) << 4)) = p2;
+      if (lane + 192 < nch) *reinterpret_cast<uint4*>(wwin + ((lane + 192) << 4)) = p3;
+    }
+    const uint64_t o0 = i < nstr ? o0c : wb, o1 = i < nstr ? o1c : wb;
+    flush();
+    // the next group's bytes and the offsets of the one behind it: in flight during this group's walk
+    RGX_TINY_WINDOW(grp + G, o0n, o1n, wbn, wvn);
+    p0 = RGX_TINY_PIECE(0, wbn, wvn); p1 = RGX_TINY_PIECE(1, wbn, wvn); p2 = RGX_TINY_PIECE(2, wbn, wvn); p3 = RGX_TINY_PIECE(3, wbn, wvn);
+    o0c = o0n; o1c = o1n; wbc = wbn; wvc = wvn;
+    RGX_TINY_META(grp + 2 * G, o0n, o1n);
+    // a string too long for the tag bytes somewhere: the batch is given up.  The word is read behind the prefetches and looked at one
+    // group later: waiting for it then is waiting for loads that are needed then anyway, not for this group's stores
+    const uint32_t stop = stop_next;
+    stop_next = __builtin_nontemporal_load(ctl);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    if (__builtin_amdgcn_readfirstlane(stop) != 0u) break;
     int len = (int)(o1 - o0);
     // the launch is optimistic: a string longer than the tag bytes hold (then the wave's strings may not fit its slice either) voids the
     // batch -- the host takes the general path
@@ -84,7 +166,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_kernel(const uint32_
     TinyLane<NREG> L;
 #pragma unroll
     for (int r = 0; r < NREG; ++r) L.R[r] = ini[r];
-    L.A = ini[8]; L.q4 = ini[9]; L.st4 = ini[10];
+    L.A = ini[8]; L.q5 = ini[9]; L.st4 = ini[10];
     uint32_t lo = w32[0], hi = w32[1];
     const int ntrip = len >> 2;
     for (int t = 0; t < ntrip; ++t) {
@@ -94,7 +176,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_kernel(const uint32_
 #pragma unroll
       for (int k = 0; k < 4; ++k) cm[k] = *(L64)(uintptr_t)(cm_at + (((b4 >> (8 * k)) & 255u) << 3));
 #pragma unroll
-      for (int k = 0; k < 4; ++k) TinyStep<NREG, REF>(L, cm[k].x, cm[k].y, load_sel, (uint32_t)(4 * t + k + 1), qmul, cshift);
+      for (int k = 0; k < 4; ++k) TinyStep<NREG, REF>(L, cm[k].x, cm[k].y, load_sel, (uint32_t)(4 * t + k + 1));
     }
     {
       // the last 0-3 bytes, at the lane's own offset
@@ -104,30 +186,18 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_kernel(const uint32_
       for (int k = 0; k < 3; ++k)
         if (k < r) {
           const u32x2 cm = *(L64)(uintptr_t)(cm_at + (((b4 >> (8 * k)) & 255u) << 3));
-          TinyStep<NREG, REF>(L, cm.x, cm.y, load_sel, (uint32_t)(at + k + 1), qmul, cshift);
+          TinyStep<NREG, REF>(L, cm.x, cm.y, load_sel, (uint32_t)(at + k + 1));
         }
     }
-    if (i < nstr) {
-      int32_t rec[8];
-      const int f = TinyFinish<NREG, REF>(L, unset, ntrack, reg_of, rec);
-      found[i] = (uint8_t)f;
-      if (REF && f == 2) {
-        const uint32_t k = atomicAdd(ctl + 1, 1u);
-        if (k < kTinyListCap) ctl[4 + k] = (uint32_t)i;
-      }
-      if (f && !fixed) {                              // (rgx.h: the record of a string without a match is unspecified)
-        int2* dst = reinterpret_cast<int2*>(spans + i * ncap_out);
-#pragma unroll
-        for (int c = 0; c < 8; c += 2)
-          if (c < ncap_out) dst[c >> 1] = make_int2(rec[c], rec[c + 1]);
-      } else if (f) {
-        // every group lies at a fixed distance from the match's start or end (DevTables::fixed_captures): two slots tracked
-        int32_t* dst = spans + i * ncap_out;
-        dst[0] = rec[0]; dst[1] = rec[1];
-        for (int c = 2; c < ncap_out; ++c) dst[c] = cap_kind[c] == kCapFromStart ? rec[0] + cap_delta[c] : rec[1] - cap_delta[c];
-      }
-    }
+    // the results wait in registers for the next group's turn (below the loop for the last one)
+    fprev = -1;
+    if (i < nstr) fprev = TinyFinish<NREG, REF>(L, unset, ntrack, reg_of, rprev);
+    gprev = grp;
   }
+  flush();
+#undef RGX_TINY_META
+#undef RGX_TINY_WINDOW
+#undef RGX_TINY_PIECE
 }
 
 }  // namespace
@@ -146,19 +216,26 @@ hipError_t LaunchBatchTiny(const DevTables& U, const DevTables& F, const uint8_t
   // starts at a multiple of 16) and the round-up behind the last
   const int wslice = (64 * kTinyMaxLen + 15 + 15 + 15) & ~15;
   const size_t lds = (size_t)kTinyImageBytes + 4 * (size_t)(wslice + 16);
-  int dev = 0, cus = 0;
-  if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
-  int per_cu = (int)((160 * 1024) / (lds + 512));
-  if (per_cu > 8) per_cu = 8;
-  if (per_cu < 1) per_cu = 1;
+  const int cus = DeviceCus();
   const int64_t ngroups = (nstr + kBlockThreads - 1) / kBlockThreads;
-  int64_t grid = (int64_t)cus * per_cu * 2;
-  if (grid > ngroups) grid = ngroups;
   const int unset = F.unmatched_minus1 ? -1 : 0;
   const bool replay = ref && !F.anchored;
   const int fixed = F.fixed_captures ? 1 : 0;
+  // The grid is what is resident at once (a workgroup walks its groups in a software pipeline whose fill costs two HBM round trips:
+  // the more groups per workgroup the better), asked from the runtime per instance (a property of the kernel and the LDS size: the
+  // same on every device of the box, cached per process).
+  static std::atomic<int> per_cu_of[9][2];
+  static const int grid_x = getenv("RGX_TINY_GRID_X") ? atoi(getenv("RGX_TINY_GRID_X")) : 1;   // EXPERIMENT
 #define RGX_TINY_GO(N)                                                                                                                  \
   do {                                                                                                                                  \
+    const void* fn = replay ? (const void*)batch_tiny_kernel<N, true> : (const void*)batch_tiny_kernel<N, false>;                       \
+    int per_cu = per_cu_of[N][replay ? 1 : 0].load(std::memory_order_relaxed);                                                          \
+    if (per_cu == 0) {                                                                                                                  \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlockThreads, lds) != hipSuccess || per_cu < 1) per_cu = 4;        \
+      per_cu_of[N][replay ? 1 : 0].store(per_cu, std::memory_order_relaxed);                                                            \
+    }                                                                                                                                   \
+    int64_t grid = (int64_t)cus * per_cu * grid_x;                                                                                      \
+    if (grid > ngroups) grid = ngroups;                                                                                                 \
     if (replay) hipLaunchKernelGGL((batch_tiny_kernel<N, true>), dim3((unsigned)grid), dim3(kBlockThreads), lds, stream, U.tiny, concat, \
                                    offsets, nstr, found, spans, wslice, unset, F.ncap, fixed, F.cap_kind, F.cap_delta, ctl);            \
     else hipLaunchKernelGGL((batch_tiny_kernel<N, false>), dim3((unsigned)grid), dim3(kBlockThreads), lds, stream, U.tiny, concat,       \

@@ -347,16 +347,16 @@ bool BuildTinySearch(const Tables& u, const Tables& f, std::vector<uint32_t>* im
   // the replay columns: the right-most-path automaton of FindBytesReuse's branch order, when it has at most 8 states and dies AT a byte
   const int fstride = f.ncls + 1;
   const int nrm = f.rm_trans[0].empty() ? 0 : (int)f.rm_trans[0].size() / fstride;
-  bool rm_ok = nrm >= 1 && nrm <= 8 && (int)f.rm_depth[0].size() >= nrm;
+  bool rm_ok = nrm >= 1 && nrm <= 6 && (int)f.rm_depth[0].size() >= nrm;      // (six nibbles: bits 24-31 of the word hold the class's cell offset)
   for (int s = 0; rm_ok && s < nrm; ++s) if (f.rm_depth[0][s] != 0) rm_ok = false;
   for (int ctx = 0; rm_ok && ctx < 4; ++ctx) if (f.rm_start[0][ctx] >= nrm) rm_ok = false;
   for (int b = 0; b < 256; ++b) {
     const int k = u.cls[b];
-    uint32_t col = (uint32_t)k << 28;                       // (states 0-5 in bits 0-22; bits 23-27 and 31 stay clear: col >> 23 = class * 32)
+    uint32_t col = 0;                                       // (state 0 is dead: its field stays 0)
     for (int s = 1; s < S; ++s) {
       const uint32_t nx = u.trans[(size_t)s * stride + k] & kStateMask;
       if (nx >= (uint32_t)S) return false;
-      col |= nx << (4 * s);
+      col |= (nx * 5u) << (5 * s);
     }
     cm[2 * b + 0] = col;
     uint32_t rc = 0;
@@ -368,7 +368,7 @@ bool BuildTinySearch(const Tables& u, const Tables& f, std::vector<uint32_t>* im
         rc |= (e == 0xFFFFu ? restart : (uint32_t)e) << (4 * s);
       }
     }
-    cm[2 * b + 1] = rc;
+    cm[2 * b + 1] = (rc & 0x00FFFFFFu) | (TinyCellOffset(k) << 24);
   }
   // per capture slot: its selector on every edge and its value at offset 0
   std::vector<std::vector<uint32_t>> selc(ncap, std::vector<uint32_t>(64, kTinyIdentity));
@@ -429,22 +429,22 @@ bool BuildTinySearch(const Tables& u, const Tables& f, std::vector<uint32_t>* im
   }
   if (reg_of[1] < 0) { reg_of[1] = nreg++; cap_of_reg.push_back(1); }
   if (nreg > 8 || reg_of[0] != 0) return false;
-  // the cells dense (state * classes + class) and as far apart as the registers need: 16 or 32 bytes
+  // the cell of (state, class): state * 5 + the class's offset (rgx_tiny.h), the cells as far apart as the registers need: 16 or 32 bytes
   const int stride_words = nreg <= 4 ? 4 : 8;
-  if (S * C * stride_words > kTinyInit - kTinySel) return false;
   for (int w = kTinySel; w < kTinyInit; ++w) (*img)[w] = kTinyIdentity;
   for (int q = 0; q < S; ++q)
-    for (int k = 0; k < C; ++k)
-      for (int r = 0; r < nreg; ++r) sel[(q * C + k) * stride_words + r] = selc[cap_of_reg[r]][q * 8 + k];
+    for (int k = 0; k < C; ++k) {
+      const int cell = q * 5 + (int)TinyCellOffset(k);
+      if ((cell + 1) * stride_words > kTinyInit - kTinySel) return false;
+      for (int r = 0; r < nreg; ++r) sel[cell * stride_words + r] = selc[cap_of_reg[r]][q * 8 + k];
+    }
   for (int r = 0; r < nreg; ++r) ini[r] = inic[cap_of_reg[r]];
-  ini[8] = 0x01010101u;                            // offset 0 is FindBytesReuse's first attempt
-  ini[9] = (uint32_t)q0 << 2;
+  ini[8] = kTinyAttempt * 0x01010101u;             // offset 0 is FindBytesReuse's first attempt
+  ini[9] = (uint32_t)q0 * 5u;
   ini[10] = rm_ok ? (uint32_t)f.rm_start[0][kCtxBOT] << 2 : 0u;
   ini[11] = rm_ok ? 1u : 0u;
   ini[12] = (uint32_t)nreg;
   ini[13] = (uint32_t)ncap;
-  ini[14] = (uint32_t)(C * stride_words);         // byte offset per unit of state * 4: state * classes * stride bytes / 4
-  ini[15] = stride_words == 4 ? 24u : 23u;        // column word >> this = class * stride bytes
   for (int c = 0; c < ncap; ++c) ini[16 + c] = (uint32_t)reg_of[c];
   return true;
 }

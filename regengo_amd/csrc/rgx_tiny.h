@@ -35,21 +35,23 @@
 namespace rgx {
 
 // The image (uint32 words), built by the host (rgx_ref_engine.cc: BuildTinySearch), staged into LDS by every workgroup:
-constexpr int kTinyColmap = 0;        // [256][2]: byte -> { column of the search automaton: a nibble per state (at most 6) = the next state, the byte's
-                                      //   class in bits 28-30 (word >> 23 = class * 32, word >> 24 = class * 16);  column of the right-most-path automaton: a nibble per
-                                      //   state = the next state, or 8 | the start state of the attempt that begins BEHIND this byte where the
-                                      //   path dies at it }
-constexpr int kTinySel = 512;         // [state * nclasses + class][4 or 8]: v_perm selectors of the tag registers on that edge -- the cells
-                                      // DENSE and 16 bytes apart when four registers do (32 otherwise): fifteen cells then lie in fifteen
-                                      // different groups of LDS banks (measured: no faster than 32-byte cells at state * 8 + class, which
-                                      // share four groups -- the kernel's LDS time is the bytes it reads, 8 + 16 per input byte, not their banks)
-constexpr int kTinyInit = 1024;       // [0..7] the tag registers at offset 0, [8] the attempt-offset register, [9] start state * 4, [10] start state * 4
+constexpr int kTinyColmap = 0;        // [256][2]: byte -> { column of the search automaton: FIVE bits per state (at most 6) = the next state * 5, so that
+                                      //   the value extracted IS the next extraction's bit offset (one v_bfe_u32 per step);  column of the
+                                      //   right-most-path automaton: a nibble per state (at most 6) = the next state, or 8 | the start state of the
+                                      //   attempt that begins BEHIND this byte where the path dies at it, and in bits 24-31 the CELL OFFSET of the
+                                      //   byte's class (kTinySel) }
+constexpr int kTinySel = 512;         // [cell][4 or 8]: v_perm selectors of the tag registers on the edge (state, class); cell = state * 5 +
+                                      // offset(class), offset = class (classes 0-4) or 30 + class - 5 (classes 5-7): the cells of a state's
+                                      // first five classes lie in the gap in front of the next state's, so the cell is an ADD of two values the
+                                      // walk holds anyway -- no multiply (v_mul_lo_u32 is quarter rate), 64 cells of 16 bytes (four registers) or 32
+constexpr int kTinyInit = 1024;       // [0..7] the tag registers at offset 0, [8] the attempt-offset register, [9] start state * 5, [10] start state * 4
                                       // of the right-most-path automaton at offset 0, [11] bit 0: the replay columns are valid, [12] registers in
-                                      // use, [13] capture slots tracked, [14] byte offset of a cell per unit of state * 4 (classes * stride / 4),
-                                      // [15] the shift that turns a column word into class * stride (23 or 24), [16..23] slot -> register
+                                      // use, [13] capture slots tracked, [14..15] reserved, [16..23] slot -> register
 constexpr int kTinyWords = 1048;
 constexpr int kTinyMaxLen = 56;       // a byte holds an offset or 0xFF = "unset"
 constexpr uint32_t kTinyIdentity = 0x03020100u;
+constexpr uint32_t kTinyAttempt = 8u;   // the bit of an attempt-offset byte that says "FindBytesReuse makes an attempt here" (the restart flag of a nibble)
+RGX_TINY_HD uint32_t TinyCellOffset(int cls) { return cls < 5 ? (uint32_t)cls : (uint32_t)(30 + cls - 5); }
 
 struct Tables;
 // false: the automaton is not tiny (more than 8 states / 8 classes / 3 threads per state / 8 capture slots, or a look-ahead construction)
@@ -66,36 +68,43 @@ RGX_TINY_HD uint32_t TinyPerm(uint32_t s0, uint32_t s1, uint32_t sel) {
   return r;
 #endif
 }
+// v_bfe_u32: the offset operand counts modulo 32 (the hardware reads bits 4:0 -- TinyStep relies on it: a restart flag shifted into bit 5 is
+// not part of the next offset)
 RGX_TINY_HD uint32_t TinyBfe(uint32_t v, uint32_t off, uint32_t width) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return __builtin_amdgcn_ubfe(v, off, width);
 #else
-  return (v >> off) & ((1u << width) - 1u);
+  return (v >> (off & 31u)) & ((1u << width) - 1u);
 #endif
 }
 
 template <int NREG>
 struct TinyLane {
   uint32_t R[NREG];     // tag registers
-  uint32_t A;           // byte j: thread j began at an offset where FindBytesReuse makes an attempt
-  uint32_t q4, st4;     // the two automata's states * 4
+  uint32_t A;           // byte j: kTinyAttempt set = thread j began at an offset where FindBytesReuse makes an attempt
+  uint32_t q5, st4;     // the search automaton's state * 5; the right-most-path automaton's state * 4 (+ a stale flag in bit 5)
 };
 
-// One byte: its two words of the colmap, load_sel(byte offset of the edge's cell, s) = its NREG selectors (device: out of LDS), pos1 = the
-// byte's offset + 1; qmul / cshift = words [14] / [15] of the image's init block.
+// One byte: its two words of the colmap, load_sel(cell << kTinyCellShift<NREG>, s) = the edge's NREG selectors (device: out of LDS), pos1 = the
+// byte's offset + 1.  Eleven VALU instructions with four registers and the replay: add, bfe, the address, four + one v_perm, bfe, shift.
+template <int NREG>
+constexpr uint32_t kTinyCellShift = NREG <= 4 ? 4u : 5u;
+
 template <int NREG, bool REF, class SelLoad>
-RGX_TINY_HD void TinyStep(TinyLane<NREG>& L, uint32_t ucol, uint32_t rmcol, const SelLoad& load_sel, uint32_t pos1, uint32_t qmul, uint32_t cshift) {
-  const uint32_t cell_at = L.q4 * qmul + (ucol >> cshift);  // (state * classes + class) * stride
-  L.q4 = TinyBfe(ucol, L.q4, 3) << 2;
+RGX_TINY_HD void TinyStep(TinyLane<NREG>& L, uint32_t ucol, uint32_t rmcol, const SelLoad& load_sel, uint32_t pos1) {
+  const uint32_t cell = L.q5 + (rmcol >> 24);
+  L.q5 = TinyBfe(ucol, L.q5, 5);
   uint32_t s[NREG];
-  load_sel(cell_at, s);
+  load_sel(cell << kTinyCellShift<NREG>, s);
 #pragma unroll
   for (int r = 0; r < NREG; ++r) L.R[r] = TinyPerm(pos1, L.R[r], s[r]);
   if (REF) {
-    // the column holds, where the right-most path dies at this byte, 8 | the start state of the attempt that begins behind it
+    // the nibble holds, where the right-most path dies at this byte, 8 | the start state of the attempt that begins behind it: the thread
+    // that starts behind this byte takes the nibble as its attempt-offset byte (bit 3 is what counts), the next extraction's offset is the
+    // nibble * 4 -- the flag lands in bit 5, which v_bfe_u32 does not read
     const uint32_t e = TinyBfe(rmcol, L.st4, 4);
-    L.A = TinyPerm(e >> 3, L.A, s[0]);
-    L.st4 = (e & 7u) << 2;
+    L.A = TinyPerm(e, L.A, s[0]);
+    L.st4 = e << 2;
   }
 }
 
@@ -120,7 +129,7 @@ RGX_TINY_HD int TinyFinish(const TinyLane<NREG>& L, int unset, int ncap, const M
     }
   }
   if (!any) return 0;
-  return REF && (L.A >> 24) == 0u ? 2 : 1;
+  return REF && ((L.A >> 24) & kTinyAttempt) == 0u ? 2 : 1;
 }
 
 }  // namespace rgx
