@@ -59,78 +59,94 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_kernel(const uint32_
   for (int c = 0; c < 8; ++c) reg_of[c] = __builtin_amdgcn_readfirstlane(ini[16 + c]);
   // A wave's work on a group of 64 strings is a chain: their offsets, then their bytes, then the walk.  The three are software-pipelined
   // over the wave's groups: while group g is walked, the bytes of group g + G are on their way into registers (at most four 16-byte
-  // pieces per lane: 64 strings of kTinyMaxLen bytes) and the offsets of group g + 2G behind them -- a wave never sits idle behind an
-  // HBM round trip with nothing else to do (measured before: 42 % of the wave-cycles parked in s_waitcnt).  Every load is issued
-  // WITHOUT a branch around it (a clamped index, a harmless address): the compiler waits for a load behind a branch where the branch ends.
+  // pieces per lane: 64 strings of kTinyMaxLen bytes) and the offsets of group g + 2G behind them.  Every load is issued WITHOUT a
+  // branch around it (a clamped index, a harmless address): the compiler waits for a load behind a branch where the branch ends.
+  // The kernel is bound by VALU issue (a wave64 integer instruction occupies its SIMD for four cycles; PMC: SQ_INSTS_VALU x 4 / 1024
+  // SIMDs = the kernel's time), so everything around the walk is kept in SCALAR arithmetic: per group a uniform base (SGPR pair) and a
+  // 32-bit per-lane offset, no 64-bit VALU address computation, no VALU multiply.
   const int ngroups = (int)((nstr + kBlockThreads - 1) / kBlockThreads);
   const int G = (int)gridDim.x;
   const uint8_t* const idle = reinterpret_cast<const uint8_t*>(img);
-  // the offsets of group g's strings: lanes behind the last string of the batch hold o0 = o1 = 0
-#define RGX_TINY_META(g, o0, o1)                                                            \
-  do {                                                                                      \
-    const int64_t i_ = (int64_t)(g) * kBlockThreads + wave * 64 + lane;                     \
-    const int64_t ii_ = i_ < nstr ? i_ : nstr - 1;                                          \
-    const uint64_t a_ = offsets[ii_], b_ = offsets[ii_ + 1];                                \
-    o0 = i_ < nstr ? a_ : 0ull;                                                             \
-    o1 = i_ < nstr ? b_ : 0ull;                                                             \
+  const uint32_t lane_cap = (uint32_t)lane * (uint32_t)ncap_out;
+  // strings of group g that exist (uniform): 0 for a group behind the batch's end
+#define RGX_TINY_NV(g) ((g) < ngroups ? (int)min((int64_t)64, max((int64_t)0, nstr - ((int64_t)(g) * kBlockThreads + wave * 64))) : 0)
+  // the offsets of group g's strings, raw: lanes behind the group's last string repeat it (a group that does not exist: the batch's last string)
+#define RGX_TINY_META(g, a, b)                                                                      \
+  do {                                                                                              \
+    const int nv_ = RGX_TINY_NV(g);                                                                 \
+    const int64_t i0_ = nv_ ? (int64_t)(g) * kBlockThreads + wave * 64 : nstr - 1;                  \
+    const uint64_t* ob_ = offsets + i0_;                                                            \
+    const uint32_t lc_ = min((uint32_t)lane, (uint32_t)(nv_ ? nv_ - 1 : 0));                        \
+    a = ob_[lc_]; b = ob_[lc_ + 1];                                                                 \
   } while (0)
-  // the window of group g (uniform): from the 16-byte boundary at or below its first string to the end of its last
-#define RGX_TINY_WINDOW(g, o0, o1, wb, wvalid)                                                                                   \
-  do {                                                                                                                           \
-    const int64_t i0_ = (int64_t)(g) * kBlockThreads + wave * 64;                                                                \
-    wb = 0; wvalid = 0;                                                                                                          \
-    if ((g) < ngroups && i0_ < nstr) {                                                                                           \
-      const int nv_ = (int)(nstr - i0_ < 64 ? nstr - i0_ : 64);                                                                  \
-      const uint32_t bl_ = __builtin_amdgcn_readfirstlane((uint32_t)(o0)), bh_ = __builtin_amdgcn_readfirstlane((uint32_t)((o0) >> 32)); \
-      const uint32_t el_ = __builtin_amdgcn_readlane((uint32_t)(o1), nv_ - 1), eh_ = __builtin_amdgcn_readlane((uint32_t)((o1) >> 32), nv_ - 1); \
-      const uint64_t gb_ = ((uint64_t)bh_ << 32) | bl_, ge_ = ((uint64_t)eh_ << 32) | el_;                                      \
-      wb = gb_ & ~15ull;                                                                                                         \
-      const uint64_t span_ = ((ge_ - wb) + 15ull) & ~15ull;                                                                      \
-      wvalid = (int)(span_ < (uint64_t)wslice ? span_ : (uint64_t)wslice);                                                       \
-    }                                                                                                                            \
+  // the window of group g (uniform): from the 16-byte boundary at or below its first string to the end of its last; per lane the string's
+  // place in it and its length (32 bits: a string or a window that does not fit them voids the batch below)
+#define RGX_TINY_WINDOW(g, a, b, wb, wvalid, rel, len, toolong)                                                                   \
+  do {                                                                                                                            \
+    const int nv_ = RGX_TINY_NV(g);                                                                                               \
+    wb = 0; wvalid = 0;                                                                                                           \
+    if (nv_) {                                                                                                                    \
+      const uint32_t bl_ = __builtin_amdgcn_readfirstlane((uint32_t)(a)), bh_ = __builtin_amdgcn_readfirstlane((uint32_t)((a) >> 32)); \
+      const uint32_t el_ = __builtin_amdgcn_readlane((uint32_t)(b), nv_ - 1), eh_ = __builtin_amdgcn_readlane((uint32_t)((b) >> 32), nv_ - 1); \
+      const uint64_t gb_ = ((uint64_t)bh_ << 32) | bl_, ge_ = ((uint64_t)eh_ << 32) | el_;                                       \
+      wb = gb_ & ~15ull;                                                                                                          \
+      const uint64_t span_ = ((ge_ - wb) + 15ull) & ~15ull;                                                                       \
+      wvalid = (int)(span_ < (uint64_t)wslice ? span_ : (uint64_t)wslice);                                                        \
+    }                                                                                                                             \
+    rel = (uint32_t)(a) - (uint32_t)wb;                                                                                           \
+    toolong = ((b) - (a)) > (uint64_t)kTinyMaxLen;                                                                                \
+    len = lane < nv_ ? (int)((uint32_t)(b) - (uint32_t)(a)) : 0;                                                                  \
   } while (0)
-#define RGX_TINY_PIECE(k, wb, wvalid) \
-  (*reinterpret_cast<const uint4*>((lane + 64 * (k)) < ((wvalid) >> 4) ? concat + (wb) + ((uint64_t)(lane + 64 * (k)) << 4) : idle))
+#define RGX_TINY_PIECES(wb, wvalid)                                                                  \
+  do {                                                                                               \
+    const uint8_t* pb_ = (wvalid) ? concat + (wb) : idle;                                            \
+    const uint32_t nch_ = (uint32_t)(wvalid) >> 4;                                                   \
+    p0 = *reinterpret_cast<const uint4*>(pb_ + ((uint32_t)lane < nch_ ? (uint32_t)lane << 4 : 0u));                  \
+    p1 = *reinterpret_cast<const uint4*>(pb_ + ((uint32_t)lane + 64u < nch_ ? ((uint32_t)lane + 64u) << 4 : 0u));    \
+    p2 = *reinterpret_cast<const uint4*>(pb_ + ((uint32_t)lane + 128u < nch_ ? ((uint32_t)lane + 128u) << 4 : 0u));  \
+    p3 = *reinterpret_cast<const uint4*>(pb_ + ((uint32_t)lane + 192u < nch_ ? ((uint32_t)lane + 192u) << 4 : 0u));  \
+  } while (0)
   // A group's results are stored when the NEXT group's bytes have gone to LDS, in front of the prefetches: the wait for a prefetched
   // piece is then never a wait for the stores of the group just walked (stores and loads share one counter and the compiler counts
   // stores in branches conservatively), only for stores a whole walk old.
-  int gprev = -1, fprev = -1;
+  int gprev = -1, fprev = 0;
   int32_t rprev[8];
   const auto flush = [&]() {
-    if (gprev < 0 || fprev < 0) return;
-    const int64_t i = (int64_t)gprev * kBlockThreads + wave * 64 + lane;
+    if (gprev < 0) return;
+    const int nv = RGX_TINY_NV(gprev);
+    const int64_t i0 = (int64_t)gprev * kBlockThreads + wave * 64;
+    if (lane >= nv) return;
     const int f = fprev;
-    found[i] = (uint8_t)f;
+    (found + i0)[lane] = (uint8_t)f;
     if (REF && f == 2) {
       const uint32_t k = atomicAdd(ctl + 1, 1u);
-      if (k < kTinyListCap) ctl[4 + k] = (uint32_t)i;
+      if (k < kTinyListCap) ctl[4 + k] = (uint32_t)i0 + (uint32_t)lane;
     }
+    int32_t* const dst = spans + i0 * ncap_out + lane_cap;
     if (f && !fixed) {                              // (rgx.h: the record of a string without a match is unspecified)
-      int2* dst = reinterpret_cast<int2*>(spans + i * ncap_out);
+      int2* d2 = reinterpret_cast<int2*>(dst);
 #pragma unroll
       for (int c = 0; c < 8; c += 2)
-        if (c < ncap_out) dst[c >> 1] = make_int2(rprev[c], rprev[c + 1]);
+        if (c < ncap_out) d2[c >> 1] = make_int2(rprev[c], rprev[c + 1]);
     } else if (f) {
       // every group lies at a fixed distance from the match's start or end (DevTables::fixed_captures): two slots tracked
-      int32_t* dst = spans + i * ncap_out;
       dst[0] = rprev[0]; dst[1] = rprev[1];
       for (int c = 2; c < ncap_out; ++c) dst[c] = cap_kind[c] == kCapFromStart ? rprev[0] + cap_delta[c] : rprev[1] - cap_delta[c];
     }
   };
   uint4 p0, p1, p2, p3;
-  uint64_t o0c, o1c, o0n, o1n, wbc, wbn;
-  int wvc, wvn;
+  uint64_t an, bn, wbc, wbn;
+  uint32_t relc, reln;
+  int wvc, wvn, lenc, lenn;
+  bool longc, longn;
   int grp = (int)blockIdx.x;
-  RGX_TINY_META(grp, o0c, o1c);
-  RGX_TINY_WINDOW(grp, o0c, o1c, wbc, wvc);
-  p0 = RGX_TINY_PIECE(0, wbc, wvc); p1 = RGX_TINY_PIECE(1, wbc, wvc); p2 = RGX_TINY_PIECE(2, wbc, wvc); p3 = RGX_TINY_PIECE(3, wbc, wvc);
-  RGX_TINY_META(grp + G, o0n, o1n);
+  RGX_TINY_META(grp, an, bn);
+  RGX_TINY_WINDOW(grp, an, bn, wbc, wvc, relc, lenc, longc);
+  RGX_TINY_PIECES(wbc, wvc);
+  RGX_TINY_META(grp + G, an, bn);
   uint32_t stop_next = __builtin_nontemporal_load(ctl);
   for (; grp < ngroups; grp += G) {
-    const int64_t i0 = (int64_t)grp * kBlockThreads + wave * 64;  // the wave's first string
-    if (i0 >= nstr) break;
-    const int64_t i = i0 + lane;
-    const uint64_t wb = wbc;
+    if (RGX_TINY_NV(grp) == 0) break;
     const int wvalid = wvc;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -141,13 +157,15 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_kernel(const uint32_
       if (lane + 128 < nch) *reinterpret_cast<uint4*>(wwin + ((lane + 128) << 4)) = p2;
       if (lane + 192 < nch) *reinterpret_cast<uint4*>(wwin + ((lane + 192) << 4)) = p3;
     }
-    const uint64_t o0 = i < nstr ? o0c : wb, o1 = i < nstr ? o1c : wb;
     flush();
+    const uint32_t rel = relc;
+    int len = lenc;
+    const bool toolong = longc;
     // the next group's bytes and the offsets of the one behind it: in flight during this group's walk
-    RGX_TINY_WINDOW(grp + G, o0n, o1n, wbn, wvn);
-    p0 = RGX_TINY_PIECE(0, wbn, wvn); p1 = RGX_TINY_PIECE(1, wbn, wvn); p2 = RGX_TINY_PIECE(2, wbn, wvn); p3 = RGX_TINY_PIECE(3, wbn, wvn);
-    o0c = o0n; o1c = o1n; wbc = wbn; wvc = wvn;
-    RGX_TINY_META(grp + 2 * G, o0n, o1n);
+    RGX_TINY_WINDOW(grp + G, an, bn, wbn, wvn, reln, lenn, longn);
+    RGX_TINY_PIECES(wbn, wvn);
+    wbc = wbn; wvc = wvn; relc = reln; lenc = lenn; longc = longn;
+    RGX_TINY_META(grp + 2 * G, an, bn);
     // a string too long for the tag bytes somewhere: the batch is given up.  The word is read behind the prefetches and looked at one
     // group later: waiting for it then is waiting for loads that are needed then anyway, not for this group's stores
     const uint32_t stop = stop_next;
@@ -156,11 +174,13 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_kernel(const uint32_
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (__builtin_amdgcn_readfirstlane(stop) != 0u) break;
-    int len = (int)(o1 - o0);
     // the launch is optimistic: a string longer than the tag bytes hold (then the wave's strings may not fit its slice either) voids the
     // batch -- the host takes the general path
-    if (len > kTinyMaxLen || (o1 - wb) > (uint64_t)wvalid) { atomicOr(ctl, 1u); len = 0; }
-    const uint32_t addr = wwin_at + (uint32_t)(o0 - wb);
+    if (__builtin_amdgcn_ballot_w64(toolong) != 0ull) {
+      if (lane == 0) atomicOr(ctl, 1u);
+      len = 0;
+    }
+    const uint32_t addr = wwin_at + rel;
     const L32 w32 = (L32)(uintptr_t)(addr & ~3u);
     const uint32_t sh = addr & 3u;
     TinyLane<NREG> L;
@@ -190,14 +210,14 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_kernel(const uint32_
         }
     }
     // the results wait in registers for the next group's turn (below the loop for the last one)
-    fprev = -1;
-    if (i < nstr) fprev = TinyFinish<NREG, REF>(L, unset, ntrack, reg_of, rprev);
+    fprev = TinyFinish<NREG, REF>(L, unset, ntrack, reg_of, rprev);
     gprev = grp;
   }
   flush();
+#undef RGX_TINY_NV
+#undef RGX_TINY_PIECES
 #undef RGX_TINY_META
 #undef RGX_TINY_WINDOW
-#undef RGX_TINY_PIECE
 }
 
 }  // namespace

@@ -1193,16 +1193,20 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
           cw[d] = x;
         }
       }
-      unsigned packed[2] = {0, 0}, rbits = 0;
+      // (the kernel is bound by VALU issue: the packing in as few instructions as the ISA has them -- one v_perm per two dwords picks the
+      // packed bytes, one v_dot4_u32_u8 per dword gathers its four reset flags into a nibble; the multiply that did so before is
+      // quarter rate)
+      unsigned tt[4], yy[4];
 #pragma unroll
       for (int d = 0; d < 4; ++d) {
         unsigned t = cw[d] & 0x0F0F0F0Fu;
-        t |= t >> 4;                                      // byte 0 = c0 | c1 << 4, byte 2 = c2 | c3 << 4
-        const unsigned two = (t & 0xFFu) | ((t >> 8) & 0xFF00u);
-        packed[d >> 1] |= two << (16 * (d & 1));
-        const unsigned y = (cw[d] >> 7) & 0x01010101u;    // reset flags of the four bytes at bits 0, 8, 16, 24
-        rbits |= ((y * 0x01020408u) >> 24 & 15u) << (4 * d);
+        tt[d] = t | (t >> 4);                             // byte 0 = c0 | c1 << 4, byte 2 = c2 | c3 << 4
+        yy[d] = (cw[d] >> 7) & 0x01010101u;               // reset flags of the four bytes at bits 0, 8, 16, 24
       }
+      const unsigned packed[2] = {__builtin_amdgcn_perm(tt[1], tt[0], 0x06040200u), __builtin_amdgcn_perm(tt[3], tt[2], 0x06040200u)};
+      const unsigned rlo = __builtin_amdgcn_udot4(yy[0], 0x08040201u, __builtin_amdgcn_udot4(yy[1], 0x80402010u, 0u, false), false);
+      const unsigned rhi = __builtin_amdgcn_udot4(yy[2], 0x08040201u, __builtin_amdgcn_udot4(yy[3], 0x80402010u, 0u, false), false);
+      const unsigned rbits = rlo | (rhi << 8);
       const int relp = (abs0 - wb) >> 1;                  // packed offset: 8 bytes per piece, a 32-byte row holds four pieces
       uint32_t* dst = reinterpret_cast<uint32_t*>(s_tile + PPad(relp));
       dst[0] = packed[0]; dst[1] = packed[1];

@@ -108,27 +108,38 @@ RGX_TINY_HD void TinyStep(TinyLane<NREG>& L, uint32_t ucol, uint32_t rmcol, cons
   }
 }
 
+RGX_TINY_HD int32_t TinySbfe8(uint32_t v, uint32_t off) {      // the byte at bit `off`, sign-extended
+#if defined(__HIP_DEVICE_COMPILE__)
+  return __builtin_amdgcn_sbfe((int32_t)v, off, 8u);
+#else
+  return (int32_t)(int8_t)((v >> (off & 31u)) & 255u);
+#endif
+}
+
 // The end of the text: 0 = no match, 1 = found, rec[0..ncap) = the record, 2 = found by the plain search at a start where the reference makes
 // NO attempt (rec[0] = that start): its attempts step over it or run out of text first -- ref_fix_kernel replays them and goes on from
-// there.  reg_of[c] = the register of slot c (uniform).
+// there.  reg_of[c] = the register of slot c (uniform).  The last-match bytes of the registers are gathered into one word per four
+// registers (three v_perm), a slot is one signed bit-field extract (0xFF = unset = -1; offsets are < 128) and a max with `unset` (-1 or 0).
 template <int NREG, bool REF, class Map>
 RGX_TINY_HD int TinyFinish(const TinyLane<NREG>& L, int unset, int ncap, const Map& reg_of, int32_t* rec) {
-  uint32_t v[NREG];
-#pragma unroll
-  for (int r = 0; r < NREG; ++r) v[r] = L.R[r] >> 24;
-  bool any = false;
+  const auto gather4 = [&](int r0) {
+    const uint32_t a = L.R[r0 < NREG ? r0 : NREG - 1], b = L.R[r0 + 1 < NREG ? r0 + 1 : NREG - 1];
+    const uint32_t c = L.R[r0 + 2 < NREG ? r0 + 2 : NREG - 1], d = L.R[r0 + 3 < NREG ? r0 + 3 : NREG - 1];
+    const uint32_t ab = TinyPerm(b, a, 0x07030703u), cd = TinyPerm(d, c, 0x07030703u);
+    return TinyPerm(cd, ab, 0x05040100u);
+  };
+  const uint32_t w0 = gather4(0), w1 = NREG > 4 ? gather4(4) : 0u;
+  int32_t end = -1;
 #pragma unroll
   for (int c = 0; c < 8; ++c) {
     if (c < ncap) {
       const uint32_t want = reg_of[c];
-      uint32_t x = v[0];
-#pragma unroll
-      for (int r = 1; r < NREG; ++r) x = want == (uint32_t)r ? v[r] : x;
-      rec[c] = x == 0xFFu ? unset : (int32_t)x;
-      if (c == 1) any = x != 0xFFu;
+      const int32_t x = TinySbfe8(NREG > 4 && want >= 4u ? w1 : w0, (want & 3u) << 3);
+      rec[c] = x > unset ? x : unset;
+      if (c == 1) end = x;
     }
   }
-  if (!any) return 0;
+  if (end < 0) return 0;
   return REF && ((L.A >> 24) & kTinyAttempt) == 0u ? 2 : 1;
 }
 
