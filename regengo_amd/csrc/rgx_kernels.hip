@@ -1613,44 +1613,71 @@ __device__ __forceinline__ void ResolveCapturesOnePass(Lds16 trans, Lds8 cls, co
   apply(B.bt_ops[prev_base + B.st_nthreads[q] - 1], e);
 }
 
-// The one-pass walk over a COMPOSED edge table (caps_lds_kernel stages it for its in-row instances): cell (state, class) -> the next
-// state's row (state * stride), the edge's pool slice and its single parent in one 8-byte entry -- per byte the class of the byte, one
-// entry (the only look-up that depends on the step before) and the ops of the previous edge's thread: three LDS reads where the walk
-// above makes five (transition, slice, parent, ops, class), and no multiply on the chain.
-typedef const unsigned long long __attribute__((address_space(3)))* LdsU2;     // low word: next row | parent << 16, high word: pool slice
-__device__ __forceinline__ void ResolveCapturesOnePassH(LdsU2 H, Lds8 cls, const BtTabsLds& B, const DevTables& T, int ctx,
-                                                        const PrivInput& in, int s, int e, int32_t* rec) {
+// The one-pass walk over a COMPOSED edge table (caps_lds_kernel stages it for its in-row instances).  The pass is bound by VALU issue
+// (a wave64 integer instruction occupies its SIMD for four cycles; the walk below used to spend 17 of them per byte on shifts, masks
+// and address arithmetic), so the table holds ADDRESSES and the loop is four bytes per trip:
+//   cell (state, class), 8 bytes: word 0 = the LDS address of the next state's row of cells, word 1 = the LDS address of the edge's
+//   slice of the ops pool (low half) | the edge's single parent thread * 4 (high half);
+//   cell (state, the end-of-text column -- never taken inside a match): word 1 high half = (threads of the state - 1) * 4: the Match thread.
+// Per byte: extract it, its class (the only look-up keyed by the byte alone: all four of a trip are in flight together), one v_lshl_add
+// to the cell's address (the only look-up that waits for the step before), one SDWA add to the address of the ops word of the
+// PREVIOUS edge's thread (previous slice + this edge's parent), a compare -- five instructions.
+typedef unsigned OphCell __attribute__((ext_vector_type(2)));
+typedef const OphCell __attribute__((address_space(3)))* LdsU2;
+__device__ __forceinline__ void ResolveCapturesOnePassH(unsigned cls_at, unsigned start_slice_at, unsigned q0_row_at, unsigned eot_off,
+                                                        const DevTables& T, const PrivInput& in, int s, int e, int32_t* rec) {
   const int ncap = T.ncap;
   const int unset = T.unmatched_minus1 ? -1 : 0;
   const int n = e - s;
-  const Lds32 rowd = (Lds32)in.row;
   for (int c = 2; c < ncap; ++c) rec[c] = unset;
   rec[0] = s; rec[1] = e;
   auto apply = [&](unsigned o, int pos) {
     o &= ~3u;
     while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = pos; }
   };
-  const unsigned q0 = T.start[ctx];
-  const unsigned sbase = B.start_ops[ctx];
-  if (n == 0) { apply(B.start_ops_pool[sbase + B.st_nthreads[q0] - 1], s); return; }
-  int r = s - in.p0;
-  unsigned w = rowd[(r >> 2) << 8];
-  unsigned wn = rowd[((r >> 2) + 1) << 8];
-  unsigned qs = q0 * (unsigned)T.stride;            // the state's row in the cell numbering
-  unsigned prev_base = 0;
-  for (int i = 0; i < n; ++i) {
-    const unsigned b = (w >> ((r & 3) << 3)) & 255u;
-    const unsigned long long h = H[qs + cls[b]];
-    const unsigned hx = (unsigned)h, hy = (unsigned)(h >> 32);
-    const unsigned P = hx >> 16;
-    const unsigned o = i == 0 ? B.start_ops_pool[sbase + P] : B.bt_ops[prev_base + P];
-    if (o & ~3u) apply(o, s + i);
-    prev_base = hy;
-    qs = hx & 0xFFFFu;
-    ++r;
-    if ((r & 3) == 0) { w = wn; wn = rowd[((r >> 2) + 1) << 8]; }
+  const unsigned row_at = (unsigned)(uintptr_t)in.row;
+  const int r = s - in.p0;
+  const unsigned wlast = row_at + (unsigned)((kCapsRow / 4 - 1) << 10);      // the row's last dword (a dword of the row every 1 KiB)
+  unsigned wa = row_at + ((unsigned)(r >> 2) << 10);
+  unsigned w = *(Lds32)(uintptr_t)wa;
+  wa = min(wa + 1024u, wlast);
+  unsigned wn = *(Lds32)(uintptr_t)wa;
+  const unsigned sh = (unsigned)r & 3u;
+  unsigned hx = q0_row_at;          // the state's row of cells
+  unsigned pw1 = start_slice_at;    // low half: the previous edge's slice of the ops pool (offset s: the start state's slice of the start pool)
+#define RGX_OPH_STEP(k, pos)                                                                              \
+  {                                                                                                       \
+    const OphCell h = *(LdsU2)(uintptr_t)(hx + (ck[k] << 3));                                               \
+    const unsigned o = *(Lds32)(uintptr_t)((pw1 & 0xFFFFu) + (h.y >> 16));                                \
+    hx = h.x; pw1 = h.y;                                                                                  \
+    if (o > 3u) apply(o, (pos));                                                                          \
   }
-  apply(B.bt_ops[prev_base + B.st_nthreads[qs / (unsigned)T.stride] - 1], e);
+  const int ntrip = n >> 2;
+  int pos = s;
+  for (int t = 0; t < ntrip; ++t) {
+    const unsigned b4 = __builtin_amdgcn_alignbyte(wn, w, sh);
+    w = wn;
+    wa = min(wa + 1024u, wlast);
+    wn = *(Lds32)(uintptr_t)wa;
+    unsigned ck[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) ck[k] = *(Lds8)(uintptr_t)(cls_at + ((b4 >> (8 * k)) & 255u));
+    RGX_OPH_STEP(0, pos) RGX_OPH_STEP(1, pos + 1) RGX_OPH_STEP(2, pos + 2) RGX_OPH_STEP(3, pos + 3)
+    pos += 4;
+  }
+  {
+    const int rem = n & 3;
+    const unsigned b4 = __builtin_amdgcn_alignbyte(wn, w, sh);
+    unsigned ck[4];
+#pragma unroll
+    for (int k = 0; k < 3; ++k) ck[k] = *(Lds8)(uintptr_t)(cls_at + ((b4 >> (8 * k)) & 255u));
+    if (rem > 0) RGX_OPH_STEP(0, pos)
+    if (rem > 1) RGX_OPH_STEP(1, pos + 1)
+    if (rem > 2) RGX_OPH_STEP(2, pos + 2)
+  }
+#undef RGX_OPH_STEP
+  const OphCell hf = *(LdsU2)(uintptr_t)(hx + eot_off);
+  apply(*(Lds32)(uintptr_t)((pw1 & 0xFFFFu) + (hf.y >> 16)), e);
 }
 
 // The same walk with the trace kept IN the lane's row: a cell that fits a byte (states x stride <= 256) takes the place of the
@@ -1732,7 +1759,8 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
                                                                   int debug_flags) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
-  const bool use_h = INROW && T.onepass != 0 && BatchLdsLayout(T, true, 0, kCapsWindow).bt_in_lds != 0;   // (uniform) ResolveCapturesOnePassH
+  const bool use_h = INROW && T.onepass != 0 && BatchLdsLayout(T, true, 0, kCapsWindow).bt_in_lds != 0 &&       // (uniform) ResolveCapturesOnePassH
+                     BatchLdsLayout(T, true, 0, kCapsWindow, false, true).total < 65536;                       // (the table holds 16-bit LDS addresses)
   const BatchLayout Y = BatchLdsLayout(T, true, INROW ? 0 : (int)sizeof(TraceT), kCapsWindow, false, use_h);
   const int ncap = T.ncap;
   {
@@ -1753,12 +1781,19 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
       d = reinterpret_cast<uint32_t*>(smem + Y.st_ops);   if (tid < 4) d[tid] = T.start_ops[tid];
       d = reinterpret_cast<uint32_t*>(smem + Y.st_pool);  for (int i = tid; i < T.start_pool_n; i += kBlockThreads) d[i] = T.start_ops_pool[i];
       if (use_h) {
-        unsigned long long* hh = reinterpret_cast<unsigned long long*>(smem + Y.oph);
+        // the composed edge table (ResolveCapturesOnePassH has the layout): LDS addresses instead of indices
+        const unsigned lds0 = (unsigned)(uintptr_t)(const unsigned char __attribute__((address_space(3)))*)smem;
+        uint2* hh = reinterpret_cast<uint2*>(smem + Y.oph);
         for (int i = tid; i < cells; i += kBlockThreads) {
+          const int st = i / T.stride, k = i - st * T.stride;
           const unsigned qn = T.trans_cls[i] & kStateMask;
           const unsigned base = T.bt_base[i];
           const unsigned par = base == 0xFFFFFFFFu ? 0u : (unsigned)T.bt_parent[base];
-          hh[i] = (unsigned long long)((qn * (unsigned)T.stride) | (par << 16)) | ((unsigned long long)base << 32);
+          uint2 h;
+          h.x = lds0 + (unsigned)Y.oph + qn * (unsigned)T.stride * 8u;
+          h.y = ((lds0 + (unsigned)Y.bt_ops + (base == 0xFFFFFFFFu ? 0u : base) * 4u) & 0xFFFFu) | ((par * 4u) << 16);
+          if (k == T.ncls) h.y = ((unsigned)T.st_nthreads[st] - 1u) * 4u << 16;
+          hh[i] = h;
         }
       }
     }
@@ -1823,7 +1858,11 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
       if (INROW && e + 4 - in.p0 <= in.nrow && (s == 0 || s - 1 >= in.p0)) {
         // (the launch takes this instance only with the back-trace tables on chip and states x stride <= 256)
         const int ctx = s == 0 ? kCtxBOT : ctx_of_byte[in.At(s - 1)];
-        if (use_h) ResolveCapturesOnePassH((LdsU2)(smem + Y.oph), (Lds8)(smem + Y.cls), BL, T, ctx, in, s, e, rec);
+        if (use_h) {
+          const unsigned lds0 = (unsigned)(uintptr_t)(const unsigned char __attribute__((address_space(3)))*)smem;
+          ResolveCapturesOnePassH(lds0 + (unsigned)Y.cls, lds0 + (unsigned)Y.st_pool + BL.start_ops[ctx] * 4u,
+                                  lds0 + (unsigned)Y.oph + (unsigned)T.start[ctx] * (unsigned)T.stride * 8u, (unsigned)T.ncls * 8u, T, in, s, e, rec);
+        }
         else ResolveCapturesInRow<MODE>((Lds16)(smem + Y.trans), (Lds8)(smem + Y.cls), BL, T, ctx, in, s, e, rec);
       } else
       if (!INROW && need <= kBatchTrace) {
