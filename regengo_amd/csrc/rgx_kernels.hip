@@ -1841,6 +1841,13 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
       int n = ((len - in.p0) + 15) & ~15;
       in.nrow = n < kCapsRow ? (n < 0 ? 0 : n) : kCapsRow;
       if (i >= nmatches) in.nrow = 0;
+      // only the chunks the match reaches -- its bytes, the one in front, three behind (the walkers look a dword ahead): the pass is
+      // bound by these scattered 16-byte loads, and a URL of 30 bytes needs three or four of the row's six.  Bytes of the row behind
+      // them keep what the previous group left: nobody consumes them (PrivInput::At goes to memory beyond nrow)
+      {
+        const int need = (e + 4 - in.p0 + 15) & ~15;
+        if (need < in.nrow) in.nrow = need;
+      }
       uint4 v[kCapsRow / 16];
 #pragma unroll
       for (int c = 0; c < kCapsRow / 16; ++c)
@@ -1848,7 +1855,9 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
       unsigned* rowd = reinterpret_cast<unsigned*>(win) + tid;
 #pragma unroll
       for (int c = 0; c < kCapsRow / 16; ++c) {
-        rowd[(4 * c + 0) << 8] = v[c].x; rowd[(4 * c + 1) << 8] = v[c].y; rowd[(4 * c + 2) << 8] = v[c].z; rowd[(4 * c + 3) << 8] = v[c].w;
+        if ((c << 4) < in.nrow) {
+          rowd[(4 * c + 0) << 8] = v[c].x; rowd[(4 * c + 1) << 8] = v[c].y; rowd[(4 * c + 2) << 8] = v[c].z; rowd[(4 * c + 3) << 8] = v[c].w;
+        }
       }
     }
     // (a lane reads only its own row: no barrier between the staging and the walk)
