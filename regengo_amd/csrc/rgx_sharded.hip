@@ -217,23 +217,42 @@ int GrowBytes(uint8_t** p, size_t* cap, size_t need) {
 // of that touches an OWNED match when the right halo holds a byte on which every state dies at or behind own_hi - 1 (no owned match
 // reaches past it).  Otherwise the window is reported `truncated` -- also when the last owned row ends at the window's end -- and the
 // caller hands it in again with a wider right halo (rgx_sharded_find_all_bytes does; rgx.h: rgx_shard_round).
-int RightEdge(Shard& sh, Slot& s, const rgx_shard_window& w, const uint8_t* d_buf, const int32_t* d_spans, int64_t count, hipStream_t st,
-              int* truncated) {
+// (The reset-byte search of the right halo depends on the input alone: RunJob queues it IN FRONT of the scan -- QueueHaloChecks -- and its
+// answer lies in pinned memory once the scan's own synchronisation has passed; what is left here is the end of the last owned row.)
+bool RightEdgeApplies(const Shard& sh, const rgx_shard_window& w) { return !(sh.info.max_match_len >= 0 || w.last); }
+int RightEdge(Shard& sh, Slot& s, const rgx_shard_window& w, const int32_t* d_spans, int64_t count, hipStream_t st, int* truncated) {
   *truncated = 0;
-  if (sh.info.max_match_len >= 0 || w.last) return RGX_OK;
-  const long long from = w.own_hi > 0 ? w.own_hi - 1 : 0;
-  unsigned f = 0;
-  if (sh.has_reset && (long long)w.len > from) {
-    HIP_TRY(hipMemsetAsync(s.d_flag + 1, 0, 4, st));
+  if (!RightEdgeApplies(sh, w)) return RGX_OK;
+  s.h_flag[3] = 0;
+  if (d_spans && count > 0) {
+    HIP_TRY(hipMemcpyAsync(&s.h_flag[3], d_spans + (size_t)(count - 1) * sh.info.ncap + 1, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+  }
+  const unsigned f = s.h_flag[2];
+  const int32_t e = (int32_t)s.h_flag[3];
+  *truncated = (!f || (size_t)e >= w.len) ? 1 : 0;
+  return RGX_OK;
+}
+
+// Both halo checks of a window, queued without a synchronisation: flags d_flag[0] (left: a sync point in [0, own_lo)) and d_flag[1]
+// (right: a reset byte at or behind own_hi - 1), copied to the pinned words h_flag[1] and h_flag[2].  The scan that follows on the same
+// stream synchronises anyway -- four host round trips per window became three, and no copy lands in pageable memory.
+int QueueHaloChecks(Shard& sh, Slot& s, const rgx_shard_window& w, const uint8_t* d_buf, bool left, hipStream_t st) {
+  const bool right = RightEdgeApplies(sh, w) && sh.has_reset && (long long)w.len > (w.own_hi > 0 ? w.own_hi - 1 : 0);
+  s.h_flag[1] = 0; s.h_flag[2] = 0;
+  if (!left && !right) return RGX_OK;
+  HIP_TRY(hipMemsetAsync(s.d_flag, 0, 8, st));
+  if (left) {
+    const long long n = w.own_lo;
+    hipLaunchKernelGGL(halo_sync_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 1024)), dim3(256), 0, st, d_buf, n, sh.d_reset, s.d_flag);
+  }
+  if (right) {
+    const long long from = w.own_hi > 0 ? w.own_hi - 1 : 0;
     const long long n = (long long)w.len - from;
     hipLaunchKernelGGL(halo_sync_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 1024)), dim3(256), 0, st, d_buf + from, n,
                        sh.d_reset, s.d_flag + 1);
-    HIP_TRY(hipMemcpyAsync(&f, s.d_flag + 1, 4, hipMemcpyDeviceToHost, st));
   }
-  int32_t e = 0;
-  if (d_spans && count > 0) HIP_TRY(hipMemcpyAsync(&e, d_spans + (size_t)(count - 1) * sh.info.ncap + 1, 4, hipMemcpyDeviceToHost, st));
-  HIP_TRY(hipStreamSynchronize(st));
-  *truncated = (!f || (size_t)e >= w.len) ? 1 : 0;
+  HIP_TRY(hipMemcpyAsync(&s.h_flag[1], s.d_flag, 8, hipMemcpyDeviceToHost, st));
   return RGX_OK;
 }
 
@@ -257,32 +276,32 @@ int RunJob(Slot& s) {
     HIP_TRY(hipMemcpyAsync(s.d_in, w.buf, w.len, hipMemcpyHostToDevice, st));
     d_buf = s.d_in;
   }
-  // the left halo has to hold a sync point, unless the window begins where the FindAll chain is known anyway
-  if (!w.starts_at_sync) {
-    if (w.own_lo <= 0 || !sh.has_reset) r.unsynced = 1;
-    else {
-      HIP_TRY(hipMemsetAsync(s.d_flag, 0, 4, st));
-      const long long n = w.own_lo;
-      const unsigned grid = (unsigned)std::min<long long>((n + 255) / 256, 1024);
-      hipLaunchKernelGGL(halo_sync_kernel, dim3(grid), dim3(256), 0, st, d_buf, n, sh.d_reset, s.d_flag);
-      unsigned f = 0;
-      HIP_TRY(hipMemcpyAsync(&f, s.d_flag, 4, hipMemcpyDeviceToHost, st));
-      HIP_TRY(hipStreamSynchronize(st));
-      r.unsynced = f ? 0 : 1;
-    }
-    if (r.unsynced) return RGX_OK;          // nothing of this window can be vouched for: the caller widens the halo
-  }
+  // the left halo has to hold a sync point, unless the window begins where the FindAll chain is known anyway.  The check (and the right
+  // halo's) is queued in front of the scan and read behind it: a window whose left halo turns out to hold none is scanned for nothing
+  // (rare: the caller widens the halo and hands it in again) -- every other window saves a host round trip with the GPU idle
+  const bool left_check = !w.starts_at_sync && w.own_lo > 0 && sh.has_reset;
+  if (!w.starts_at_sync && !left_check) { r.unsynced = 1; return RGX_OK; }
+  if ((rc = QueueHaloChecks(sh, s, w, d_buf, left_check, st)) != RGX_OK) return rc;
+  // (the scan synchronises its stream on every path that ran a kernel; this covers the ones that did not)
+  const auto halo_says_unsynced = [&]() -> int {
+    HIP_TRY(hipStreamSynchronize(st));
+    return left_check && !s.h_flag[1] ? 1 : 0;
+  };
   rgx_result res{};
   if (j.count_only) {
     const int64_t c = rgx_count_all_device_owned(sh.prog, s.ctx, d_buf, w.len, w.own_lo, w.own_hi, &res);
+    const int u = halo_says_unsynced();
+    if (u < 0) return u;
+    if (u) { r.unsynced = 1; return RGX_OK; }          // nothing of this window can be vouched for: the caller widens the halo
     if (c < 0) return (int)c;
     r.count = c;
     r.kernel_ms = res.kernel_ms;
-    return RightEdge(sh, s, w, d_buf, nullptr, 0, st, &r.truncated);
+    return RightEdge(sh, s, w, nullptr, 0, st, &r.truncated);
   }
   int32_t* d_spans = w.d_spans;
   size_t cap_records = w.cap_records;
   const int ncap = sh.info.ncap;
+  int64_t c = 0;
   for (int attempt = 0;; ++attempt) {
     if (!w.d_spans) {
       const size_t owned = (size_t)(w.own_hi - w.own_lo);
@@ -296,16 +315,22 @@ int RunJob(Slot& s) {
       }
       d_spans = s.d_spans; cap_records = s.spans_cap;
     }
-    const int64_t c = rgx_internal_find_all_owned(sh.prog, s.ctx, d_buf, w.len, -1, d_spans, cap_records, w.own_lo, w.own_hi, w.starts_only, &res);
+    c = rgx_internal_find_all_owned(sh.prog, s.ctx, d_buf, w.len, -1, d_spans, cap_records, w.own_lo, w.own_hi, w.starts_only, &res);
     if (c == RGX_E_CAPACITY && !w.d_spans && attempt == 0) { cap_records = (size_t)res.total + 16; continue; }
-    if (c < 0) return (int)c;
-    r.count = c;
     break;
   }
+  {
+    const std::string scan_err = c < 0 ? rgx::GetError() : std::string();
+    const int u = halo_says_unsynced();
+    if (u < 0) return u;
+    if (u) { r.unsynced = 1; return RGX_OK; }            // nothing of this window can be vouched for: the caller widens the halo
+    if (c < 0) { SetError(scan_err); return (int)c; }
+  }
+  r.count = c;
   r.d_rows = d_spans;
   r.base = w.base;
   r.kernel_ms = res.kernel_ms;
-  if ((rc = RightEdge(sh, s, w, d_buf, d_spans, r.count, st, &r.truncated)) != RGX_OK) return rc;
+  if ((rc = RightEdge(sh, s, w, d_spans, r.count, st, &r.truncated)) != RGX_OK) return rc;
   return RGX_OK;
 }
 

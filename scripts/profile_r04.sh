@@ -1,12 +1,17 @@
 #!/bin/bash
 # Round-4 evidence in one go (on the MI355X box from the repo root; results under gpurun_out/r04/, copied into profiles/):
-#   un-profiled bench lines c2 (+ the adversarial C2b), c3 (default engine and --force-tdfa), c4, c5; rocprofv3 --kernel-trace --stats of
-#   each; PMC traffic + SQ counters of the dominant kernels of c2, c3, c4 (scripts/pmc_traffic.sh: separate passes).
+#   PMC traffic + SQ counters of the dominant kernels of c2, c3, c4 (scripts/pmc_traffic.sh: separate passes); un-profiled bench lines c2
+#   (+ the adversarial C2b), c3 (default engine and --force-tdfa), c4, c5; rocprofv3 --kernel-trace --stats of each.
 export TMPDIR=/tmp
 OUT=gpurun_out/r04
 mkdir -p $OUT /tmp/p
 cd /root/repo
 which=${1:-all}
+# the counter passes first, copied next to the older evidence: the bench lines below then cite THIS run's files (roofline.traffic_source)
+if [ $which = all ] || [ $which = c2 ]; then scripts/pmc_traffic.sh c2 scan_exact $OUT/r04_pmc_c2.json > /dev/null 2>&1; fi
+if [ $which = all ] || [ $which = c3 ]; then scripts/pmc_traffic.sh c3 batch_tiny $OUT/r04_pmc_c3.json > /dev/null 2>&1; fi
+if [ $which = all ] || [ $which = c4 ]; then scripts/pmc_traffic.sh c4 scan_us_pair $OUT/r04_pmc_c4.json > /dev/null 2>&1; fi
+cp $OUT/r04_pmc_*.json profiles/ 2>/dev/null
 for c in c2 c3 c4 c5; do
   [ $which != all ] && [ $which != $c ] && continue
   timeout 900 python bench.py --config $c > $OUT/r04_bench_$c.json 2> $OUT/bench_$c.err || echo "bench $c failed"
@@ -27,7 +32,4 @@ for c in c2 c3 c3t c4 c5; do
   f=$(find /tmp/p/kt_$c -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && grep -E '^"Name"|rgx::' "$f" > $OUT/r04_kernel_stats_$c.csv
 done
-if [ $which = all ] || [ $which = c2 ]; then scripts/pmc_traffic.sh c2 scan_exact $OUT/r04_pmc_c2.json > /dev/null 2>&1; fi
-if [ $which = all ] || [ $which = c3 ]; then scripts/pmc_traffic.sh c3 batch_tiny $OUT/r04_pmc_c3.json > /dev/null 2>&1; fi
-if [ $which = all ] || [ $which = c4 ]; then scripts/pmc_traffic.sh c4 scan_us_pair $OUT/r04_pmc_c4.json > /dev/null 2>&1; fi
 ls -la $OUT
