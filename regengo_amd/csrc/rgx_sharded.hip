@@ -109,14 +109,33 @@ Rccl* LoadRccl() {
 
 // ---- device helpers --------------------------------------------------------------------------------------------------
 // any reset byte in buf[0, n)?  (a byte on which every automaton state dies: the FindAll chain is known right behind it)
+// Sixteen bytes per thread and step (whole aligned chunks: the bytes of a chunk in front of buf or behind buf + n are masked out, the
+// chunk itself lies in pages the range touches); a wave that finds one STORES the flag -- the first form's atomicOr per wave cost the
+// 1 MiB right halo of a log 48 us, every one of its 4096 waves queueing on one word -- and workgroups that start later leave at once.
 __global__ __launch_bounds__(256) void halo_sync_kernel(const uint8_t* buf, long long n, const uint8_t* reset, unsigned* flag) {
   __shared__ uint8_t tab[256];
+  __shared__ unsigned seen;
+  if (threadIdx.x == 0) seen = __builtin_nontemporal_load(flag);
   tab[threadIdx.x] = reset[threadIdx.x];
   __syncthreads();
+  if (seen != 0u) return;                                   // (one answer for the whole workgroup)
+  const long long head = (long long)((uintptr_t)buf & 15);
+  const uint4* chunks = reinterpret_cast<const uint4*>(buf - head);
+  const long long nchunks = (head + n + 15) >> 4;
   bool any = false;
-  for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long long)gridDim.x * 256) any |= tab[buf[i]] != 0;
-  if (__any(any) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+  for (long long c = (long long)blockIdx.x * 256 + threadIdx.x; c < nchunks; c += (long long)gridDim.x * 256) {
+    const uint4 v = chunks[c];
+    const unsigned w[4] = {v.x, v.y, v.z, v.w};
+    const long long p0 = (c << 4) - head;                   // offset in buf of the chunk's byte 0
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const long long p = p0 + j;
+      any |= p >= 0 && p < n && tab[(w[j >> 2] >> (8 * (j & 3))) & 255u] != 0;
+    }
+  }
+  if (__any(any) && (threadIdx.x & 63) == 0) __builtin_nontemporal_store(1u, flag);
 }
+inline unsigned HaloGrid(long long n) { return (unsigned)std::min<long long>((n + 4095 + 15) / 4096, 1024); }   // 256 threads x 16 bytes
 // window-relative int32 rows -> stream-absolute int64 rows.  The slots of a group that took no part stay as they are: (0,0),
 // the reference's convention (find.go:215), or (-1,-1) under RGX_FLAG_UNMATCHED_MINUS1.
 __global__ __launch_bounds__(256) void rows_to_global_kernel(const int32_t* rows, long long nvals, int ncap, long long base, int minus1,
@@ -244,13 +263,12 @@ int QueueHaloChecks(Shard& sh, Slot& s, const rgx_shard_window& w, const uint8_t
   HIP_TRY(hipMemsetAsync(s.d_flag, 0, 8, st));
   if (left) {
     const long long n = w.own_lo;
-    hipLaunchKernelGGL(halo_sync_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 1024)), dim3(256), 0, st, d_buf, n, sh.d_reset, s.d_flag);
+    hipLaunchKernelGGL(halo_sync_kernel, dim3(HaloGrid(n)), dim3(256), 0, st, d_buf, n, sh.d_reset, s.d_flag);
   }
   if (right) {
     const long long from = w.own_hi > 0 ? w.own_hi - 1 : 0;
     const long long n = (long long)w.len - from;
-    hipLaunchKernelGGL(halo_sync_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 1024)), dim3(256), 0, st, d_buf + from, n,
-                       sh.d_reset, s.d_flag + 1);
+    hipLaunchKernelGGL(halo_sync_kernel, dim3(HaloGrid(n)), dim3(256), 0, st, d_buf + from, n, sh.d_reset, s.d_flag + 1);
   }
   HIP_TRY(hipMemcpyAsync(&s.h_flag[1], s.d_flag, 8, hipMemcpyDeviceToHost, st));
   return RGX_OK;
@@ -383,7 +401,7 @@ bool TryAsync(Shard& sh, Slot& s, const Job& j) {
     s.h_flag[0] = 0;
     if (hipMemsetAsync(s.d_flag + 2, 0, 4, st) != hipSuccess) return false;
     const long long n = w.own_lo;
-    hipLaunchKernelGGL(halo_sync_kernel, dim3((unsigned)std::min<long long>((n + 255) / 256, 1024)), dim3(256), 0, st, w.buf, n, sh.d_reset, s.d_flag + 2);
+    hipLaunchKernelGGL(halo_sync_kernel, dim3(HaloGrid(n)), dim3(256), 0, st, w.buf, n, sh.d_reset, s.d_flag + 2);
     if (hipMemcpyAsync(s.h_flag, s.d_flag + 2, 4, hipMemcpyDeviceToHost, st) != hipSuccess) return false;
     s.async_halo = true;
   }
