@@ -337,3 +337,38 @@ def test_starts_only_rounds(gpu):
         se.round(w)
     assert ei.value.status == _capi.RGX_E_UNSUPPORTED
     se.close()
+
+
+def test_halo_checks_at_the_edges_of_their_ranges(gpu):
+    """The two halo checks of a round (halo_sync_kernel: whole aligned 16-byte chunks, the bytes of a chunk outside the range masked
+    out): a reset byte counts exactly when it lies in [0, own_lo) for the left halo and in [own_hi - 1, len) for the right one -- at the
+    first byte, at the last byte, at every alignment of the range's start, and not one byte outside."""
+    torch = gpu
+    from regengo_amd import Compiled
+    from regengo_amd.sharded import Sharded
+    c = Compiled(r"(?P<w>[a-z]+)").to(0)               # unbounded; every byte that is not a lower-case letter is a reset byte
+    assert c.info.max_match_len < 0
+    s = Sharded(c, devices=[0])
+    n = 4096
+    for own_lo, own_hi in ((16, 2000), (17, 2001), (31, 2015), (1, 4000), (333, 4095)):
+        for where, expect_unsynced, expect_truncated in (
+                (None, True, True),                     # letters only: neither halo holds a reset byte
+                (0, False, True), (own_lo - 1, False, True), (own_lo, True, True),          # left range [0, own_lo)
+                (own_hi - 2, True, True), (own_hi - 1, True, False), (n - 1, True, False)):    # right range [own_hi - 1, n)
+            data = bytearray(b"a" * n)
+            if where is not None:
+                data[where] = ord(" ")
+            buf = torch.frombuffer(data, dtype=torch.uint8).to("cuda:0")
+            total, rs = s.round([dict(buf=buf, own=(own_lo, own_hi), base=0, starts_at_sync=False, last=False)])
+            assert bool(rs[0]["unsynced"]) == expect_unsynced, (own_lo, own_hi, where, rs[0])
+            if not expect_unsynced:
+                # (a window that is vouched for reports its right edge too)
+                assert bool(rs[0]["truncated"]) == expect_truncated, (own_lo, own_hi, where, rs[0])
+        # both halos in order: the window is neither unsynced nor truncated, and its rows are the owned matches
+        data = bytearray(b"a" * n)
+        data[own_lo - 1] = ord(" ")
+        data[own_hi + 5 if own_hi + 5 < n else n - 1] = ord(" ")
+        buf = torch.frombuffer(data, dtype=torch.uint8).to("cuda:0")
+        total, rs = s.round([dict(buf=buf, own=(own_lo, own_hi), base=0, starts_at_sync=False, last=False)])
+        assert not rs[0]["unsynced"] and not rs[0]["truncated"] and total == 1, (own_lo, own_hi, rs[0])
+    s.close()
