@@ -1493,6 +1493,18 @@ __global__ __launch_bounds__(kBlockThreads) void batch_lds_kernel(DevTables T, c
 // window of the group's span misses most of them (with 8 KiB three quarters of the lanes walked through global loads).
 constexpr int kCapsRow = 96;                                  // bytes per lane: six 16-byte loads
 constexpr int kCapsWindow = kCapsRow * kBlockThreads;         // 24 KiB
+// T.start[ctx] without a load: a dynamic index into the kernel-argument struct is a load from MEMORY (the argument segment; the compiler
+// also turns a select of four constant-index loads back into one), and a load from memory in the walk of the capture pass drains the
+// prefetched rows (PrivInput::AtRow has the why).  The four values are read once, in front of the loop, into scalar registers.
+struct StartRows {
+  unsigned v[4];
+  __device__ __forceinline__ explicit StartRows(const DevTables& T) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = __builtin_amdgcn_readfirstlane((unsigned)T.start[k]);
+  }
+  __device__ __forceinline__ unsigned Of(int ctx) const { return ctx == 0 ? v[0] : ctx == 1 ? v[1] : ctx == 2 ? v[2] : v[3]; }
+};
+
 struct PrivInput {
   const uint8_t* g;        // global: byte 0 of the text
   Lds8 row;                // LDS: this lane's dword 0 (dword j at row + j * 1024)
@@ -1503,6 +1515,12 @@ struct PrivInput {
     const unsigned r = (unsigned)(i - p0);
     if (r < (unsigned)nrow) return row[((r >> 2) << 10) + (r & 3u)];
     return g[i];
+  }
+  // a byte the caller KNOWS to lie in the row: no memory alternative -- a load from memory anywhere in the walk of the capture pass
+  // makes the compiler wait for every load in flight at the point where the two alternatives meet, the prefetched rows included
+  __device__ __forceinline__ int AtRow(int i) const {
+    const unsigned r = (unsigned)(i - p0);
+    return row[((r >> 2) << 10) + (r & 3u)];
   }
 };
 
@@ -1686,7 +1704,7 @@ __device__ __forceinline__ void ResolveCapturesOnePassH(unsigned cls_at, unsigne
 // workgroups per CU where there were two (the pass waits on LDS latency: VALU busy 37 %, LDS a third of the cycles).
 typedef uint8_t __attribute__((address_space(3)))* Lds8w;
 template <int MODE>
-__device__ __forceinline__ void ResolveCapturesInRow(Lds16 trans, Lds8 cls, const BtTabsLds& B, const DevTables& T, int ctx,
+__device__ __forceinline__ void ResolveCapturesInRow(Lds16 trans, Lds8 cls, const BtTabsLds& B, const DevTables& T, int ctx, unsigned q0,
                                                      const PrivInput& in, int s, int e, int32_t* rec) {
   const int stride = T.stride;
   const int ncap = T.ncap;
@@ -1695,7 +1713,7 @@ __device__ __forceinline__ void ResolveCapturesInRow(Lds16 trans, Lds8 cls, cons
   const Lds32 rowd = (Lds32)in.row;
   const Lds8w roww = (Lds8w)in.row;
   const int r0 = s - in.p0;
-  unsigned q = T.start[ctx];
+  unsigned q = q0;
   {
     int d = r0 >> 2;
     int i = -(r0 & 3);                                     // index (relative to s) of byte 0 of dword d
@@ -1721,7 +1739,7 @@ __device__ __forceinline__ void ResolveCapturesInRow(Lds16 trans, Lds8 cls, cons
   int j;
   const int add = T.lookahead ? 0 : 1;
   if (T.lookahead) {
-    const int k = e < in.len ? cls[in.At(e)] : T.ncls;     // (byte e itself was not overwritten: cells replace [s, e) only)
+    const int k = e < in.len ? cls[in.AtRow(e)] : T.ncls;  // (byte e itself was not overwritten: cells replace [s, e) only; e + 4 - p0 <= nrow: in the row)
     const unsigned m = B.bt_match[q * stride + k];
     j = (int)(m >> 24);
     unsigned ops = (m & 0xFFFFFFu) & ~setmask;
@@ -1823,35 +1841,74 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
   const int64_t ngroups = (nmatches + kBlockThreads - 1) / kBlockThreads;
   __syncthreads();                                     // the tables are staged
 
-  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-    const int64_t i0 = grp * kBlockThreads;
-    const int64_t i = i0 + tid;
+  // A group of 256 matches is a chain -- its (start, end) pairs, then the rows of text they name, then the walk, then its records --
+  // and the first two are memory round trips.  They are software-pipelined per WAVE (a wave's rows, trace columns and records are its
+  // own, and it copies its own records out: no workgroup barrier in the loop -- a wave with short matches does not wait for the one
+  // with the longest): while group g is walked, the rows of group g + G are on their way into registers and the pairs of group g + 2G
+  // behind them; the records of group g go out at the top of the next turn, IN FRONT of the next loads, so that waiting for a row is
+  // never waiting for the stores of the group just walked.  Loads carry no branch (a clamped index, a harmless address).
+  const int64_t G = gridDim.x;
+  const uint8_t* const idle = reinterpret_cast<const uint8_t*>(gtrace);      // (at least 64 bytes: rgx_capi.cc sizes it len + matches + 64)
+  const auto pair_of = [&](int64_t g) -> int2 {
+    int64_t i = g * kBlockThreads + tid;
+    if (i >= nmatches) i = nmatches - 1;
+    return *reinterpret_cast<const int2*>(spans + i * ncap);
+  };
+  // the row of a match: from the 16-byte boundary at or below the byte in front of it; only the chunks the match reaches -- its bytes,
+  // the one in front, three behind (the walkers look a dword ahead): a URL of 30 bytes needs three or four of the row's six.  Bytes of
+  // the row behind them keep what an earlier group left: nobody consumes them (PrivInput::At goes to memory beyond nrow)
+  const auto row_of = [&](int s, int e, bool valid, int& p0, int& nrow) {
+    p0 = (s > 0 ? s - 1 : 0) & ~15;
+    const int n = ((len - p0) + 15) & ~15;              // whole 16-byte chunks that begin inside the text (the last one may run past `len` inside its chunk: never a page)
+    nrow = n < kCapsRow ? (n < 0 ? 0 : n) : kCapsRow;
+    const int need = (e + 4 - p0 + 15) & ~15;
+    if (need < nrow) nrow = need;
+    if (!valid) nrow = 0;
+  };
+  uint4 v[kCapsRow / 16];
+  const auto fetch_row = [&](int p0, int nrow) {
+#pragma unroll
+    for (int c = 0; c < kCapsRow / 16; ++c) {
+      const uint8_t* src = (c << 4) < nrow ? buf + p0 + (c << 4) : idle;
+      v[c] = *reinterpret_cast<const uint4*>(src);
+    }
+  };
+  const auto copy_out = [&](int64_t g) {
+    // the wave's 64 records: contiguous in `spans` and 16-byte aligned (a group starts at a multiple of 256 matches)
+    const int64_t i0 = g * kBlockThreads;
     const int64_t ilast = min(i0 + (int64_t)kBlockThreads, nmatches);
-    int s = 0, e = 0;
-    if (i < nmatches) { s = spans[i * ncap]; e = spans[i * ncap + 1]; }
-    // (a wave's rows, trace columns and records are its own, and it copies its own records out below: no workgroup barrier in
-    // the loop -- a wave with short matches does not wait for the one with the longest)
+    const int wv = tid >> 6, ln = tid & 63;
+    const int64_t w0 = i0 + (int64_t)wv * 64;
+    const int nw = (int)(ilast - w0 < 64 ? (ilast - w0 < 0 ? 0 : ilast - w0) : 64);
+    const int nrec_words = nw * ncap;
+    const int32_t* const src = recs + wv * 64 * ncap;
+    int32_t* const dst = spans + w0 * ncap;
+    for (int w = ln * 4; w < nrec_words; w += 256) {
+      if (w + 4 <= nrec_words) *reinterpret_cast<int4*>(dst + w) = *reinterpret_cast<const int4*>(src + w);
+      else for (int k = w; k < nrec_words; ++k) dst[k] = src[k];
+    }
+  };
+  const StartRows starts(T);
+  int64_t grp = blockIdx.x;
+  int2 se = make_int2(0, 0), se_next = make_int2(0, 0);
+  int p0c = 0, nrowc = 0;
+  if (grp < ngroups) {
+    se = pair_of(grp);
+    row_of(se.x, se.y, grp * kBlockThreads + tid < nmatches, p0c, nrowc);
+    fetch_row(p0c, nrowc);
+    se_next = pair_of(grp + G);
+  }
+  int64_t gprev = -1;
+  for (; grp < ngroups; grp += G) {
+    const int64_t i = grp * kBlockThreads + tid;
+    const int s = se.x, e = se.y;
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     PrivInput in;
     in.g = buf; in.row = (Lds8)(win + (tid << 2)); in.len = len;
-    in.p0 = (s > 0 ? s - 1 : 0) & ~15;
+    in.p0 = p0c; in.nrow = nrowc;
     {
-      // whole 16-byte chunks that begin inside the text (the last one may run past `len` inside its chunk: never a page)
-      int n = ((len - in.p0) + 15) & ~15;
-      in.nrow = n < kCapsRow ? (n < 0 ? 0 : n) : kCapsRow;
-      if (i >= nmatches) in.nrow = 0;
-      // only the chunks the match reaches -- its bytes, the one in front, three behind (the walkers look a dword ahead): the pass is
-      // bound by these scattered 16-byte loads, and a URL of 30 bytes needs three or four of the row's six.  Bytes of the row behind
-      // them keep what the previous group left: nobody consumes them (PrivInput::At goes to memory beyond nrow)
-      {
-        const int need = (e + 4 - in.p0 + 15) & ~15;
-        if (need < in.nrow) in.nrow = need;
-      }
-      uint4 v[kCapsRow / 16];
-#pragma unroll
-      for (int c = 0; c < kCapsRow / 16; ++c)
-        v[c] = (c << 4) < in.nrow ? *reinterpret_cast<const uint4*>(buf + in.p0 + (c << 4)) : make_uint4(0, 0, 0, 0);
       unsigned* rowd = reinterpret_cast<unsigned*>(win) + tid;
 #pragma unroll
       for (int c = 0; c < kCapsRow / 16; ++c) {
@@ -1860,19 +1917,28 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
         }
       }
     }
+    if (gprev >= 0) copy_out(gprev);                    // (the records of the group walked last turn: LDS -> the span table)
+    {
+      // the next group's rows and the pairs of the one behind it: in flight during this group's walk
+      se = se_next;
+      row_of(se.x, se.y, (grp + G) * kBlockThreads + tid < nmatches && grp + G < ngroups, p0c, nrowc);
+      fetch_row(p0c, nrowc);
+      se_next = pair_of(grp + 2 * G);
+    }
     // (a lane reads only its own row: no barrier between the staging and the walk)
     int32_t* rec = recs + tid * ncap;
     if (i < nmatches) {
       const int need = e - s + 1;
       if (INROW && e + 4 - in.p0 <= in.nrow && (s == 0 || s - 1 >= in.p0)) {
-        // (the launch takes this instance only with the back-trace tables on chip and states x stride <= 256)
-        const int ctx = s == 0 ? kCtxBOT : ctx_of_byte[in.At(s - 1)];
+        // (the launch takes this instance only with the back-trace tables on chip and states x stride <= 256; the byte in front of
+        // the match lies in the row: p0 <= s - 1 < p0 + 16 <= p0 + nrow)
+        const int ctx = s == 0 ? kCtxBOT : ctx_of_byte[in.AtRow(s - 1)];
         if (use_h) {
           const unsigned lds0 = (unsigned)(uintptr_t)(const unsigned char __attribute__((address_space(3)))*)smem;
           ResolveCapturesOnePassH(lds0 + (unsigned)Y.cls, lds0 + (unsigned)Y.st_pool + BL.start_ops[ctx] * 4u,
-                                  lds0 + (unsigned)Y.oph + (unsigned)T.start[ctx] * (unsigned)T.stride * 8u, (unsigned)T.ncls * 8u, T, in, s, e, rec);
+                                  lds0 + (unsigned)Y.oph + starts.Of(ctx) * (unsigned)T.stride * 8u, (unsigned)T.ncls * 8u, T, in, s, e, rec);
         }
-        else ResolveCapturesInRow<MODE>((Lds16)(smem + Y.trans), (Lds8)(smem + Y.cls), BL, T, ctx, in, s, e, rec);
+        else ResolveCapturesInRow<MODE>((Lds16)(smem + Y.trans), (Lds8)(smem + Y.cls), BL, T, ctx, starts.Of(ctx), in, s, e, rec);
       } else
       if (!INROW && need <= kBatchTrace) {
         LdsTrace tr = (LdsTrace)(smem + Y.trace) + tid;
@@ -1891,22 +1957,13 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
         else ResolveCapturesBatch<MODE, TraceT, PrivInput, BtTabs, TraceT*>(tab, BG, T, tab.cls, ctx_of_byte, in, s, e, tr, 1, rec);
       }
     }
+    gprev = grp;
+  }
+  if (gprev >= 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    {
-      // the wave's 64 records: contiguous in `spans` and 16-byte aligned (a group starts at a multiple of 256 matches)
-      const int wv = tid >> 6, ln = tid & 63;
-      const int64_t w0 = i0 + (int64_t)wv * 64;
-      const int nw = (int)(ilast - w0 < 64 ? (ilast - w0 < 0 ? 0 : ilast - w0) : 64);
-      const int nrec_words = nw * ncap;
-      const int32_t* const src = recs + wv * 64 * ncap;
-      int32_t* const dst = spans + w0 * ncap;
-      for (int w = ln * 4; w < nrec_words; w += 256) {
-        if (w + 4 <= nrec_words) *reinterpret_cast<int4*>(dst + w) = *reinterpret_cast<const int4*>(src + w);
-        else for (int k = w; k < nrec_words; ++k) dst[k] = src[k];
-      }
-    }
+    copy_out(gprev);
   }
 }
 
