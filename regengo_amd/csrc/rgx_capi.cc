@@ -55,6 +55,7 @@ struct rgx_stream_ctx {
   bool own_stream = true;
   uint8_t* d_unsynced = nullptr; int32_t* d_carry = nullptr; int64_t slice_cap = 0, carry_cap = 0;
   uint16_t* d_trace = nullptr; int64_t trace_cap = 0;
+  int32_t* d_pairs = nullptr; int64_t pairs_cap = 0;   // (start, end) of every match between the scan and the capture pass (ScanParams::pairs)
   uint8_t* d_in = nullptr; int64_t in_cap = 0;       // staging for the host-buffer entry points
   uint8_t* d_san = nullptr; int64_t san_cap = 0;     // the sanitised copy of an input with broken UTF-8 (MatchView)
   // Replace path scratch
@@ -460,6 +461,14 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   P.own_hi = own_hi < 0 ? ilen : (int32_t)std::max<int64_t>(P.own_lo, std::min<int64_t>(own_hi, ilen));
   P.count_only = count_only ? 1 : 0;
   P.starts_only = starts_only ? 1 : 0;
+  // Dynamic groups: the scan leaves (start, end) of match k in a table of its own, 8 bytes apart, and the capture pass writes the
+  // whole record.  Written into slots 0-1 of the 4 x ncap-byte records they cost the capture pass -- which is bound by HBM traffic,
+  // 2.1 GB read + 0.7 GB written per 1.6 GiB window of config C4 -- a fetch of the entire span table to read a sixth of it.
+  // (Out of memory for the table: the old form, nothing lost.)
+  static const bool no_pairs = getenv("RGX_NO_PAIRS") != nullptr;      // (the records' slots 0-1 instead: for A/B measurements)
+  if (!count_only && !starts_only && !T.fixed_captures && !UseExactKernel(T, ilen) && d_spans && cap_records > 0 && !no_pairs) {
+    if (Ensure(&c->d_pairs, &c->pairs_cap, (int64_t)cap_records * 2) == RGX_OK) P.pairs = c->d_pairs;
+  }
   P.us_rewind = p->prefer_rw.load(std::memory_order_relaxed);
 
   auto run_scan_once = [&](bool time_it) -> int {
@@ -714,7 +723,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     int64_t need = (int64_t)len + written + 64;
     if ((rc = Ensure(&c->d_trace, &c->trace_cap, need)) != RGX_OK) return rc;
     HIP_TRY(hipMemsetAsync(c->d_cursor, 0, 8, c->stream));
-    HIP_TRY(LaunchCaptures(T, d_buf, ilen, d_spans, written, c->d_trace, c->d_cursor, c->stream));
+    HIP_TRY(LaunchCaptures(T, d_buf, ilen, d_spans, P.pairs, written, c->d_trace, c->d_cursor, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
   }
   if (res) res->written = written;
@@ -879,7 +888,7 @@ RGX_API void rgx_stream_ctx_destroy(rgx_stream_ctx* c) {
   for (int i = 0; i < 2; ++i)
     for (hipEvent_t e : {c->pev0[i], c->pev1[i], c->pdone[i]}) if (e) (void)hipEventDestroy(e);
   for (void* p : {(void*)c->d_desc, (void*)c->d_unsynced, (void*)c->d_carry,
-                  (void*)c->d_trace, (void*)c->d_in, (void*)c->d_san, (void*)c->d_out, (void*)c->d_rspans, (void*)c->d_rdelta, (void*)c->d_rtemp, (void*)c->d_tmpl, (void*)c->d_tdfa, (void*)c->d_memo})
+                  (void*)c->d_trace, (void*)c->d_pairs, (void*)c->d_in, (void*)c->d_san, (void*)c->d_out, (void*)c->d_rspans, (void*)c->d_rdelta, (void*)c->d_rtemp, (void*)c->d_tmpl, (void*)c->d_tdfa, (void*)c->d_memo})
     if (p) (void)hipFree(p);
   if (c->d_tiny_ctl) (void)hipFree(c->d_tiny_ctl);
   if (c->h_read) (void)hipHostFree(c->h_read);
@@ -1256,7 +1265,7 @@ RGX_API int64_t rgx_replace_all_bytes_device(const rgx_program* p, rgx_stream_ct
         int64_t need = (int64_t)len + 64;
         if ((rc = Ensure(&c->d_trace, &c->trace_cap, need)) != RGX_OK) return rc;
         HIP_TRY(hipMemsetAsync(c->d_cursor, 0, 8, c->stream));
-        HIP_TRY(LaunchCaptures(T, d_buf ? d_buf : (const uint8_t*)c->d_rspans, ilen, c->d_rspans + n * ncap, 1, c->d_trace, c->d_cursor,
+        HIP_TRY(LaunchCaptures(T, d_buf ? d_buf : (const uint8_t*)c->d_rspans, ilen, c->d_rspans + n * ncap, nullptr, 1, c->d_trace, c->d_cursor,
                                c->stream));
       }
       n++;

@@ -24,6 +24,8 @@ struct ScanParams {
   uint8_t* slice_unsynced;       // nullable; set to 1 for slices that found no sync point
   int32_t count_only;
   int32_t starts_only;           // fixed-template patterns: write one int32 (match start) per match instead of ncap
+  int32_t* pairs;                // programs with dynamic groups, or NULL: match k's (start, end) go HERE, 8 bytes apart, instead of into slots 0-1 of its
+                                 // ncap x 4-byte record -- the capture pass reads them back, and reading 8 of every 48 bytes fetched the whole table
   int32_t use_w;                 // sync points from the sync automaton W (rgx_dfa.h) instead of reset bytes: scan_kernel only
   int32_t use_tickets;           // 1: tile/group ids from the ticket counter; 0: blockIdx.x (bounded spin, host falls back)
   int32_t us_rewind;             // pair kernel: take the instance that rewinds inside its fast walk (the program's earlier scans sent
@@ -79,7 +81,7 @@ bool ScanSupportsW(const DevTables& T, int32_t len);
 
 // Capture groups for patterns whose captures are not a fixed template: per-match state trace + back-trace.
 // `trace` is scratch of at least (len + nmatches + 64) uint16; `trace_cursor` a zeroed uint64.
-hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, int32_t* spans, int64_t nmatches, uint16_t* trace,
+hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, int32_t* spans, const int32_t* pairs, int64_t nmatches, uint16_t* trace,
                           unsigned long long* trace_cursor, hipStream_t stream);
 
 // Batch (one string per lane): FindBytes / MatchBytes per string, CSR offsets.

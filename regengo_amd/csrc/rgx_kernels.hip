@@ -463,7 +463,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
         e = T.fixed_len >= 0 ? s + T.fixed_len : Walk<MODE>(tab, in, T, s_ctx, s);
       }
       if (idx < (unsigned long long)P.cap_records) {
-        int32_t* rec = P.spans + idx * ncap;
+        int32_t* rec = P.pairs ? P.pairs + idx * 2 : P.spans + idx * ncap;         // (pairs: only with dynamic groups)
         if (T.fixed_captures) WriteRecordFixed(rec, ncap, s_kind, s_delta, s, e);
         else { rec[0] = s; rec[1] = e; }
       }
@@ -897,13 +897,13 @@ __device__ void ResolveCaptures(const DevTables& T, const uint8_t* buf, int len,
 
 constexpr int kCapsLdsTrace = 96;  // uint16 entries of LDS trace per lane (matches up to 95 bytes stay on chip)
 
-__global__ __launch_bounds__(64) void caps_kernel(DevTables T, const uint8_t* buf, int32_t len, int32_t* spans, int64_t nmatches,
-                                                  uint16_t* trace, unsigned long long* cursor) {
+__global__ __launch_bounds__(64) void caps_kernel(DevTables T, const uint8_t* buf, int32_t len, int32_t* spans, const int32_t* pairs,
+                                                  int64_t nmatches, uint16_t* trace, unsigned long long* cursor) {
   __shared__ uint16_t s_trace[64 * kCapsLdsTrace];
   const int64_t m = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (m >= nmatches) return;
   int32_t* rec = spans + m * T.ncap;
-  const int s = rec[0], e = rec[1];
+  const int s = pairs ? pairs[2 * m] : rec[0], e = pairs ? pairs[2 * m + 1] : rec[1];      // (ScanParams::pairs)
   const int need = e - s + 1;
   uint16_t* tr;
   if (need <= kCapsLdsTrace) tr = s_trace + threadIdx.x * kCapsLdsTrace;
@@ -1773,8 +1773,8 @@ __device__ __forceinline__ void ResolveCapturesInRow(Lds16 trans, Lds8 cls, cons
 
 template <int MODE, class TraceT, bool INROW = false>
 __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, const uint8_t* buf, int32_t len, int32_t* spans,
-                                                                  int64_t nmatches, TraceT* gtrace, unsigned long long* cursor,
-                                                                  int debug_flags) {
+                                                                  const int32_t* pairs, int64_t nmatches, TraceT* gtrace,
+                                                                  unsigned long long* cursor, int debug_flags) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const bool use_h = INROW && T.onepass != 0 && BatchLdsLayout(T, true, 0, kCapsWindow).bt_in_lds != 0 &&       // (uniform) ResolveCapturesOnePassH
@@ -1852,7 +1852,8 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
   const auto pair_of = [&](int64_t g) -> int2 {
     int64_t i = g * kBlockThreads + tid;
     if (i >= nmatches) i = nmatches - 1;
-    return *reinterpret_cast<const int2*>(spans + i * ncap);
+    // (ScanParams::pairs: the scan left them 8 bytes apart; without, slots 0-1 of the records)
+    return pairs ? *reinterpret_cast<const int2*>(pairs + 2 * i) : *reinterpret_cast<const int2*>(spans + i * ncap);
   };
   // the row of a match: from the 16-byte boundary at or below the byte in front of it; only the chunks the match reaches -- its bytes,
   // the one in front, three behind (the walkers look a dword ahead): a URL of 30 bytes needs three or four of the row's six.  Bytes of
@@ -2849,7 +2850,7 @@ hipError_t LaunchCarry(const DevTables& T, const uint8_t* buf, int32_t len, cons
   return hipGetLastError();
 }
 
-hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, int32_t* spans, int64_t nmatches, uint16_t* trace,
+hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, int32_t* spans, const int32_t* pairs, int64_t nmatches, uint16_t* trace,
                           unsigned long long* trace_cursor, hipStream_t stream) {
   if (nmatches <= 0) return hipSuccess;
   static const bool force_old = ExpEnv("RGX_CAPS_OLD") != nullptr;
@@ -2876,17 +2877,17 @@ hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, i
     const dim3 g((unsigned)grid), b(kBlockThreads);
     const size_t lds = (size_t)Y.total;
     switch (mi) {
-      case 0: hipLaunchKernelGGL((caps_lds_kernel<kModeDirect, uint8_t>), g, b, lds, stream, T, buf, len, spans, nmatches, (uint8_t*)trace, trace_cursor, dflags); break;
-      case 1: hipLaunchKernelGGL((caps_lds_kernel<kModeDirect, uint16_t>), g, b, lds, stream, T, buf, len, spans, nmatches, trace, trace_cursor, dflags); break;
-      case 2: hipLaunchKernelGGL((caps_lds_kernel<kModeClassLds, uint8_t>), g, b, lds, stream, T, buf, len, spans, nmatches, (uint8_t*)trace, trace_cursor, dflags); break;
-      case 3: hipLaunchKernelGGL((caps_lds_kernel<kModeClassLds, uint16_t>), g, b, lds, stream, T, buf, len, spans, nmatches, trace, trace_cursor, dflags); break;
-      case 4: hipLaunchKernelGGL((caps_lds_kernel<kModeDirect, uint8_t, true>), g, b, lds, stream, T, buf, len, spans, nmatches, (uint8_t*)trace, trace_cursor, dflags); break;
-      default: hipLaunchKernelGGL((caps_lds_kernel<kModeClassLds, uint8_t, true>), g, b, lds, stream, T, buf, len, spans, nmatches, (uint8_t*)trace, trace_cursor, dflags); break;
+      case 0: hipLaunchKernelGGL((caps_lds_kernel<kModeDirect, uint8_t>), g, b, lds, stream, T, buf, len, spans, pairs, nmatches, (uint8_t*)trace, trace_cursor, dflags); break;
+      case 1: hipLaunchKernelGGL((caps_lds_kernel<kModeDirect, uint16_t>), g, b, lds, stream, T, buf, len, spans, pairs, nmatches, trace, trace_cursor, dflags); break;
+      case 2: hipLaunchKernelGGL((caps_lds_kernel<kModeClassLds, uint8_t>), g, b, lds, stream, T, buf, len, spans, pairs, nmatches, (uint8_t*)trace, trace_cursor, dflags); break;
+      case 3: hipLaunchKernelGGL((caps_lds_kernel<kModeClassLds, uint16_t>), g, b, lds, stream, T, buf, len, spans, pairs, nmatches, trace, trace_cursor, dflags); break;
+      case 4: hipLaunchKernelGGL((caps_lds_kernel<kModeDirect, uint8_t, true>), g, b, lds, stream, T, buf, len, spans, pairs, nmatches, (uint8_t*)trace, trace_cursor, dflags); break;
+      default: hipLaunchKernelGGL((caps_lds_kernel<kModeClassLds, uint8_t, true>), g, b, lds, stream, T, buf, len, spans, pairs, nmatches, (uint8_t*)trace, trace_cursor, dflags); break;
     }
     return hipGetLastError();
   }
   dim3 block(64), grid((unsigned)((nmatches + 63) / 64));
-  hipLaunchKernelGGL(caps_kernel, grid, block, 0, stream, T, buf, len, spans, nmatches, trace, trace_cursor);
+  hipLaunchKernelGGL(caps_kernel, grid, block, 0, stream, T, buf, len, spans, pairs, nmatches, trace, trace_cursor);
   return hipGetLastError();
 }
 

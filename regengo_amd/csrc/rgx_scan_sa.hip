@@ -301,7 +301,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_sa_kernel(DevTables T, Sca
         e = wlen == kLongMatch ? WalkCls(tab, stride, L, in, T, s, budget_left, &P.counters[3]) : s + (int)wlen;
       } else e = WalkCls(tab, stride, L, in, T, s, budget_left, &P.counters[3]);
       if (idx < (unsigned long long)P.cap_records) {
-        int32_t* rec = P.spans + idx * ncap;
+        int32_t* rec = P.pairs ? P.pairs + idx * 2 : P.spans + idx * ncap;         // (pairs: only with dynamic groups)
         if (T.fixed_captures) {
           for (int c = 0; c < ncap; ++c) rec[c] = L.capk[c] == kCapFromStart ? s + L.capd[c] : e - L.capd[c];
         } else {

@@ -416,7 +416,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_kernel(DevTables T, UsD
         if (P.starts_only) {
           P.spans[idx] = s;
         } else {
-          int32_t* rec = P.spans + idx * ncap;
+          int32_t* rec = P.pairs ? P.pairs + idx * 2 : P.spans + idx * ncap;       // (pairs: only with dynamic groups)
           if (T.fixed_captures) UsWriteFixed(rec, ncap, s_kind, s_delta, s, e);
           else { rec[0] = s; rec[1] = e; }
         }
@@ -595,7 +595,7 @@ __device__ __forceinline__ void UsEmitTile(const DevTables& T, const ScanParams&
   auto emit = [&](unsigned long long idx, int st, int pe) {
     if (idx >= (unsigned long long)P.cap_records) return;
     if (P.starts_only) { P.spans[idx] = st; return; }
-    int32_t* rec = P.spans + idx * ncap;
+    int32_t* rec = P.pairs ? P.pairs + idx * 2 : P.spans + idx * ncap;             // (pairs: only with dynamic groups)
     if (T.fixed_captures) UsWriteFixed(rec, ncap, s_kind, s_delta, st, pe);
     else { rec[0] = st; rec[1] = pe; }
   };
