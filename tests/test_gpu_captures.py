@@ -68,3 +68,41 @@ def test_capture_rows_with_unmatched_minus_one(torch_dev):
     assert minus.any() and np.array_equal(minus[:, 0::2], minus[:, 1::2])
     assert not exp[minus].any()
     assert np.array_equal(np.where(minus, 0, got), exp)
+
+
+def test_pairs_table_and_record_slots_agree(torch_dev):
+    """The scan hands (start, end) of every match to the capture pass in a table of its own (ScanParams::pairs) or -- RGX_NO_PAIRS=1,
+    read once per process: a child process here -- in slots 0-1 of the records: the same rows either way, for a program of the pair
+    kernel, one of the register kernels and one of the generic kernel, with a span table that is exactly as large as the matches."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = r'''
+import hashlib, json, sys
+sys.path.insert(0, %r)
+import torch
+from regengo_amd import Compiled, synth
+tile = synth.web_log_tile()
+buf = torch.frombuffer(bytearray(tile * 3), dtype=torch.uint8).to("cuda:0")
+out = {}
+for p in (r"(?P<full>(?P<proto>https?|ftp)://(?P<host>[\w.-]+)(?P<port>:\d+)?(?P<path>/[\w./-]*)?)",
+          r"(?P<u>[\w.+-]+)@(?P<h>[\w-]+(?:\.[\w-]+)*)(?P<p>:\d+)?", r"(?P<w>\w+)\s(?P<rest>.*)"):
+    c = Compiled(p, stdlib=True).to(0)
+    n = int(c.CountAll(buf)[0])
+    rows = c.FindAllSpans(buf, capacity=n)[0]
+    assert rows.shape[0] == n
+    out[p] = [n, hashlib.sha256(rows.cpu().numpy().tobytes()).hexdigest()]
+print(json.dumps(out))
+''' % root
+    res = []
+    for no_pairs in ("", "1"):
+        env = dict(os.environ)
+        env.pop("RGX_NO_PAIRS", None)
+        if no_pairs:
+            env["RGX_NO_PAIRS"] = "1"
+        r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, env=env, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res.append(json.loads(r.stdout.strip().splitlines()[-1]))
+    assert res[0] == res[1] and all(v[0] > 1000 for v in res[0].values()), res
