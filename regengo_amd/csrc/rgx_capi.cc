@@ -467,7 +467,10 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   // (Out of memory for the table: the old form, nothing lost.)
   static const bool no_pairs = getenv("RGX_NO_PAIRS") != nullptr;      // (the records' slots 0-1 instead: for A/B measurements)
   if (!count_only && !starts_only && !T.fixed_captures && !UseExactKernel(T, ilen) && d_spans && cap_records > 0 && !no_pairs) {
-    if (Ensure(&c->d_pairs, &c->pairs_cap, (int64_t)cap_records * 2) == RGX_OK) P.pairs = c->d_pairs;
+    // (as many pairs as the text can hold matches: a generous capacity of the caller's does not become memory here)
+    const int64_t most = (int64_t)len / std::max<int64_t>(p->p.t.min_len, 1) + 16;
+    const int64_t npairs = std::min<int64_t>((int64_t)cap_records, most);
+    if (Ensure(&c->d_pairs, &c->pairs_cap, npairs * 2) == RGX_OK) { P.pairs = c->d_pairs; P.cap_records = npairs; }
   }
   P.us_rewind = p->prefer_rw.load(std::memory_order_relaxed);
 
