@@ -545,7 +545,10 @@ __device__ __forceinline__ UsTileOut UsCountTile(const ScanParams& P, int tile, 
   const int wave = tid >> 6;
   constexpr int kTailChunks = kSReach / 64;          // 18
   const unsigned long long* E64 = reinterpret_cast<const unsigned long long*>(s_E);
-  const bool filter = P.own_lo > 0 || P.own_hi < len;
+  // (shard mode: only matches whose START the rank owns.  Every match this tile reports starts in [tb, tb + kSBits) -- its lanes' stretches
+  // begin at sync points of the tile, the bit sets hold nothing else -- so a tile that lies inside the owned range needs no look at its
+  // starts: of a window's thousands of tiles only the first and the last few filter)
+  const bool filter = (P.own_lo > 0 || P.own_hi < len) && (tb < P.own_lo || tb + kSBits > P.own_hi);
   auto owned_bits = [&](unsigned long long bits, int chunk) -> unsigned long long {
     if (!filter) return bits;
     unsigned long long keep = 0, x = bits;
