@@ -70,7 +70,12 @@ class Env:
                 dist.init_process_group("nccl", device_id=torch.device("cuda", self.local_rank))
             else:
                 dist.init_process_group(backend)
-        assert self.world == args.gpus or self.world == 1, "launch with torch.distributed.run for --gpus > 1"
+        if self.world != args.gpus:
+            # main() re-launches `--gpus N` under torch.distributed.run when no launcher is in front; a world that still differs from
+            # --gpus is a mis-launch, and scanning on fewer GPUs than the line would claim is not an answer
+            raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python -m torch.distributed.run "
+                             "--nproc-per-node %d ... bench.py --gpus %d), or run `python bench.py --gpus %d` with no launcher in "
+                             "front and it starts its own ranks" % (args.gpus, self.world, args.gpus, args.gpus, args.gpus))
         self.dev = "cuda:%d" % self.local_rank
         torch.cuda.set_device(self.local_rank)
         self.cdev = self.dev if (self.world == 1 or dist.get_backend() == "nccl") else "cpu"   # where small collectives live
@@ -533,6 +538,7 @@ def run_c2_capi(env, args):
                       "pattern": DATE, "bytes_per_gpu": L, "matches_per_gpu": int(cnt), "matches_total": int(total),
                       "span_record_bytes": 4 * c.ncap, "parallelism": "shard%d" % world,
                       "path": "C ABI: rgx_sharded_round_submit / _wait (2 rounds in flight)" + (", library-owned RCCL communicator" if sh.uses_rccl else ""),
+                      "ranks_formed": int(sh.world), "communicator": sh.communicator,
                       "parity_closed_form": parity_all, "steps_redone": redone,
                       "gather_ms": None if gather_ms is None else round(gather_ms, 3), "gather_rows_checked": gather_ok,
                       "strong_scaling": strong, "alt_result_form": alt}
@@ -846,6 +852,7 @@ def run_c4(env, args):
                       "halo_left": HALO_L, "halo_right": HALO_R, "matches_total": int(stp["count"]), "expected_matches": int(exp_total),
                       "span_record_bytes": 4 * c.ncap, "parallelism": "window round-robin over %d rank(s)" % world,
                       "path": "C ABI: rgx_sharded_round_submit / _wait (%d round(s) in flight)" % depth + (", library-owned RCCL communicator" if sh.uses_rccl else ""),
+                      "ranks_formed": int(sh.world), "communicator": sh.communicator,
                       "rounds": stp["rounds"], "unsynced_halos": stp["unsynced"], "parity_oracle_fixture_periodic": parity_all,
                       "parity_pieces_checked": checked[0], "gather_ms": None if gather_ms is None else round(gather_ms, 3),
                       "gather_rows_checked": gather_ok}
@@ -908,6 +915,7 @@ def run_c5(env, args):
     skipped = []
     lines = offs = None
     first_prog = [None]
+    sem = {}                     # (mode, semantics) -> patterns: which answer each pattern is timed and checked under
     t_setup = time.perf_counter()
     for i, e in mine:
         if e["mode"] == "unsupported":
@@ -922,6 +930,7 @@ def run_c5(env, args):
             else:
                 stdlib = not Compiled(e["pattern"]).info.ref_findall_offered
             c = Compiled(e["pattern"], stdlib=stdlib).to(env.local_rank, ctx_of=first_prog[0])      # one context for the whole suite
+            sem[(e["mode"], "stdlib" if stdlib else "reference")] = sem.get((e["mode"], "stdlib" if stdlib else "reference"), 0) + 1
         except _capi.RgxError:
             skipped.append(i)
             continue
@@ -1054,6 +1063,12 @@ def run_c5(env, args):
     line["config"] = {"workload": "C5: the reference's %d-pattern suite (e2e corpus + benchmarks/curated), one launch per pattern over a "
                                   "shared %.2f GiB corpus; ^/$-anchored patterns per line (CSR view)" % (len(ents), N / 2**30),
                       "patterns": npat, "patterns_skipped": nskip, "scan_mode": int(tot_nscan), "line_mode": int(tot_nline),
+                      # reference mode = the generated matcher's answer; stdlib = RGX_FLAG_STDLIB_SEMANTICS (Go regexp's leftmost-first), used
+                      # where the library refuses the reference's loop (Q8, Q11) -- disclosed, not hidden in the total
+                      "scan_mode_reference": int(env.allsum(sem.get(("scan", "reference"), 0))),
+                      "scan_mode_stdlib": int(env.allsum(sem.get(("scan", "stdlib"), 0))),
+                      "line_mode_reference": int(env.allsum(sem.get(("line", "reference"), 0))),
+                      "line_mode_stdlib": int(env.allsum(sem.get(("line", "stdlib"), 0))),
                       "corpus_bytes": N, "bytes_scanned_per_step": int(total_bytes), "parallelism": "patterns round-robin over %d rank(s)" % world,
                       "count_only_patterns": int(env.allsum(len(count_only))), "parity_counts_vs_oracle_fixture": nbad == 0, "patterns_with_wrong_count": nbad,
                       "parity_rows_vs_oracle_fixture": (nrows_bad == 0 and nrows_checked > 0) if nrows_checked or not args.no_row_check else None,
@@ -1245,6 +1260,73 @@ def cpu_baseline_suite(ents, tile):
                       "%.0f s of CPU" % tot_t, "host_cores_available": os.cpu_count()}
 
 
+def other_config_legs(budget_s):
+    """Short legs of the other BASELINE configurations, each a run of this file in a process of its own (`--config cN
+    --no-cpu-baseline`, full size, default steps) so that the driver-timed default line carries them: value, ms per step, the dominant
+    kernel's duration and roofline fraction, and every in-run parity flag of that line.  Bounded: a leg that does not fit what is left
+    of `budget_s` is reported as skipped."""
+    import subprocess
+    legs = [("c3", ["--config", "c3"], 150), ("c3_tdfa", ["--config", "c3", "--force-tdfa"], 150),
+            ("c4", ["--config", "c4"], 240), ("c5", ["--config", "c5"], 300)]
+    out = {}
+    t_all = time.perf_counter()
+    for name, argv, limit in legs:
+        left = budget_s - (time.perf_counter() - t_all)
+        if left < 30:
+            out[name] = {"skipped": "time budget of the default run (%d s) spent" % budget_s}
+            continue
+        t0 = time.perf_counter()
+        try:
+            p = subprocess.run([sys.executable, os.path.abspath(__file__)] + argv + ["--no-cpu-baseline"], capture_output=True, text=True,
+                               timeout=min(limit, left), cwd=ROOT)
+            rows = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+            if p.returncode != 0 or not rows:
+                out[name] = {"error": "rc %d: %s" % (p.returncode, p.stderr.strip()[-300:])}
+                continue
+            j = json.loads(rows[-1])
+        except subprocess.TimeoutExpired:
+            out[name] = {"error": "no line within %d s" % min(limit, left)}
+            continue
+        cfg, rf = j["config"], j["roofline"]
+        leg = {"workload": cfg["workload"], "value": j["value"], "unit": j["unit"], "ms_per_step": j["ms_per_step"], "steps": j["steps"],
+               "repeats": j["repeats"], "kernel": rf["kernel"][:80], "kernel_ms": rf["kernel_ms"], "roofline_frac": rf["frac"],
+               "algorithmic_bytes_per_launch": rf["algorithmic_bytes_per_launch"], "wall_s": round(time.perf_counter() - t0, 1)}
+        leg.update({k: v for k, v in cfg.items() if k.startswith("parity_") or k.startswith("scan_mode_") or k.startswith("line_mode_st")
+                    or k.startswith("line_mode_ref") or k in ("patterns", "patterns_skipped", "patterns_with_wrong_count", "patterns_with_wrong_rows",
+                                                               "matches_total", "expected_matches", "strings_per_second", "engine", "unsynced_halos")})
+        out[name] = leg
+    return out
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` with no launcher in front (WORLD_SIZE unset): start the ranks ourselves -- the same command line
+    under `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port <free>`, one process per
+    GPU, stdout passed through (rank 0 prints the JSON line).  Fewer than N visible GPUs is an error, never a silent N=1 run;
+    RGX_BENCH_ONE_DEVICE=1 (every rank on device 0: the multi-RANK code on a one-GPU box, with a CCL test double named by
+    RGX_SHARDED_CCL_LIB and the harness's own collectives over gloo) is the stated exception."""
+    import socket
+    import subprocess
+    one_dev = os.environ.get("RGX_BENCH_ONE_DEVICE") == "1"
+    env = dict(os.environ)
+    if one_dev:
+        env.setdefault("RGX_BENCH_BACKEND", "gloo")
+    else:
+        import torch
+        have = torch.cuda.device_count()
+        if have < n:
+            sys.stderr.write("bench.py: --gpus %d but %d GPU(s) visible here; refusing to run fewer ranks than the line would claim "
+                             "(RGX_BENCH_ONE_DEVICE=1 + RGX_SHARDED_CCL_LIB put every rank on device 0 for protocol tests)\n" % (n, have))
+            return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--config", default="c2", choices=["c2", "c3", "c4", "c5"])
@@ -1261,6 +1343,7 @@ def main():
     ap.add_argument("--force-tdfa", action="store_true", help="c3: regengo.Options.ForceTDFA -- the reference's Tagged DFA for the Email pattern (BASELINE config C3's wording), run by rgx_tdfa.hip")
     ap.add_argument("--adversarial", action="store_true", help="c2: noise alphabet with digits and '-' (config C2b)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-other-configs", action="store_true", help="c2 at N=1: leave out the short legs of c3 / c3 --force-tdfa / c4 / c5 (`other_configs`)")
     ap.add_argument("--no-alt", action="store_true", help="c2: skip the starts-only alternative result form (keeps profiler passes to one kernel variant)")
     args = ap.parse_args()
     defaults = {"c2": (20, 3), "c3": (10, 2), "c4": (3, 1), "c5": (1, 1)}
@@ -1268,8 +1351,15 @@ def main():
         args.steps = defaults[args.config][0]
     if args.warmup is None:
         args.warmup = defaults[args.config][1]
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus))
     env = Env(args)
     line = {"c2": run_c2, "c3": run_c3, "c4": run_c4, "c5": run_c5}[args.config](env, args)
+    if (args.config == "c2" and env.world == 1 and not args.no_other_configs and not args.adversarial and not args.no_cpu_baseline
+            and os.environ.get("RGX_BENCH_OTHER_CONFIGS", "1") != "0"):
+        # (profiler and test runs pass --no-cpu-baseline or --no-other-configs: one config per process there)
+        env.torch.cuda.empty_cache()
+        line["other_configs"] = other_config_legs(float(os.environ.get("RGX_BENCH_OTHER_BUDGET", "420")))
     if env.rank == 0:
         print(json.dumps(line))
     env.close()

@@ -29,6 +29,10 @@ class Sharded:
         info = _capi.ShardedInfo()
         _capi.check(self._lib.rgx_sharded_shape(self._h, C.byref(info)))
         self.n_local, self.world, self.first_rank, self.uses_rccl = info.n_local, info.world, info.first_rank, bool(info.uses_rccl)
+        import os
+        # what the world's exchange runs over (rgx_sharded_shape.uses_rccl + the library named by RGX_SHARDED_CCL_LIB, if any)
+        self.communicator = ("none (one rank, or logical shards of one process)" if not self.uses_rccl else
+                             "test double %s" % os.path.basename(os.environ["RGX_SHARDED_CCL_LIB"]) if os.environ.get("RGX_SHARDED_CCL_LIB") else "librccl")
         self.info = _capi.Info()
         _capi.check(self._lib.rgx_program_info(self._lib.rgx_sharded_program(self._h, 0), C.byref(self.info)))
         self.ncap = self.info.ncap

@@ -196,6 +196,46 @@ def test_world_of_one_through_rccl(gpu):
     assert r.returncode == 0 and "RCCL_WORLD1_OK" in r.stdout, (r.stdout[-2000:], r.stderr[-3000:])
 
 
+def _build_shim():
+    build = os.path.join(ROOT, "tests", "_build")
+    os.makedirs(build, exist_ok=True)
+    shim = os.path.join(build, "libccl_shim.so")
+    r = subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
+                        os.path.join(ROOT, "tests", "ccl_shim.c"), "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-Wl,-rpath,/opt/rocm/lib", "-o", shim],
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    return shim
+
+
+def test_bench_gpus_2_starts_its_own_ranks(gpu):
+    """`python bench.py --gpus 2` with NO launcher in front starts two ranks itself (torch.distributed.run inside),
+    the library forms a world of two (over the CCL test double on this one-GPU box: RGX_BENCH_ONE_DEVICE=1), and the line says so:
+    n_gpus 2, ranks_formed 2, the gathered table checked on rank 0.  Without the exception variable, asking for more GPUs than the
+    box has is an error -- never a silent one-GPU run that prints n_gpus: 1."""
+    import json
+    torch = gpu
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(RGX_SHARDED_CCL_LIB=_build_shim(), RGX_BENCH_ONE_DEVICE="1", RGX_BENCH_PREWARM="0.2")
+    env.pop("RGX_SHARDED_NO_RCCL", None)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bytes", str(1 << 26), "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    rows = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert p.returncode == 0 and len(rows) == 1, (p.stdout[-2000:], p.stderr[-3000:])
+    j = json.loads(rows[0])
+    cfg = j["config"]
+    assert j["n_gpus"] == 2 and cfg["ranks_formed"] == 2 and cfg["gather_rows_checked"] is True and cfg["parity_closed_form"] is True, j
+    assert cfg["communicator"].startswith("test double") and "FALLBACK" not in cfg["path"], cfg
+    assert cfg["matches_total"] == ((2 << 26) - 10) // 50 + 1 and cfg["strong_scaling"]["parity_count"] is True
+    if torch.cuda.device_count() < 2:
+        env.pop("RGX_BENCH_ONE_DEVICE")
+        q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bytes", str(1 << 26), "--no-cpu-baseline"],
+                           capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
+        assert q.returncode != 0 and not any(ln.startswith("{") for ln in q.stdout.splitlines()), q.stdout[-1000:]
+        assert "GPU(s) visible" in q.stderr
+
+
 def test_two_process_world(gpu, tmp_path):
     """The multi-RANK path of the C library -- rgx_sharded_create_rank(world = 2), the per-round exchange ([count, flags, base, status]
     through the all-gather entry point), the grouped send / recv gather to either rank, a failing rank (every rank gets the error, none
@@ -205,13 +245,7 @@ def test_two_process_world(gpu, tmp_path):
     torch = gpu
     import json
     from regengo_amd import Compiled
-    build = os.path.join(ROOT, "tests", "_build")
-    os.makedirs(build, exist_ok=True)
-    shim = os.path.join(build, "libccl_shim.so")
-    r = subprocess.run(["gcc", "-shared", "-fPIC", "-O1", "-Wall", "-Werror", "-D__HIP_PLATFORM_AMD__", "-I/opt/rocm/include",
-                        os.path.join(ROOT, "tests", "ccl_shim.c"), "-L/opt/rocm/lib", "-lamdhip64", "-lrt", "-Wl,-rpath,/opt/rocm/lib", "-o", shim],
-                       capture_output=True, text=True)
-    assert r.returncode == 0, r.stderr
+    shim = _build_shim()
     env = dict(os.environ)
     env["RGX_SHARDED_CCL_LIB"] = shim
     env.pop("RGX_SHARDED_NO_RCCL", None)
