@@ -1073,6 +1073,7 @@ def run_c5(env, args):
                       "count_only_patterns": int(env.allsum(len(count_only))), "parity_counts_vs_oracle_fixture": nbad == 0, "patterns_with_wrong_count": nbad,
                       "parity_rows_vs_oracle_fixture": (nrows_bad == 0 and nrows_checked > 0) if nrows_checked or not args.no_row_check else None,
                       "patterns_row_checked": nrows_checked, "patterns_with_wrong_rows": nrows_bad,
+                      "wrong_on_rank0": {"counts": bad[:8], "rows": rows_bad[:8]},
                       "scan_mode_mean_kernel_ms": round(tot_scan_ms / max(tot_nscan, 1), 4),
                       "line_mode_mean_call_ms": round(tot_line_ms / max(tot_nline, 1), 4),
                       "line_mode_package": None if pk is None else {"programs": len(in_pk), "launches": pk.launches, "ms_per_pass": round(pk_ms[0], 3),

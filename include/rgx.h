@@ -63,11 +63,15 @@ enum {
                                           not at start+1 (compiler.go:845-853, find.go:545-569), which steps over some
                                           matches (reproduced); entry points whose emitted code the library does not reproduce
                                           for this pattern return RGX_E_UNSUPPORTED (rgx_info.ref_*_offered say which).        */
-  RGX_FLAG_FORCE_TDFA = 1u << 2        /* regengo.Options.ForceTDFA (regengo.go:43-45, `-force-tdfa`; compiler.go:137-153): the reference
+  RGX_FLAG_FORCE_TDFA = 1u << 2,       /* regengo.Options.ForceTDFA (regengo.go:43-45, `-force-tdfa`; compiler.go:137-153): the reference
                                           emits its Tagged DFA for the capture functions whenever it can be built (under 500 states, no
                                           empty-width op but ^ $), not only for patterns with nested quantifiers -- rgx_info.ref_find_engine
                                           follows, and with it what reference mode means for the program.  (BASELINE config C3, "Email TDFA
                                           with capture tags", is this option.)                                                  */
+  RGX_FLAG_NO_PREFILTER_SCAN = 1u << 3 /* FindAll never takes the filter + candidate kernel (csrc/rgx_scan_fc.hip), whatever the pattern's
+                                          first bytes look like: the program's other scan kernel from the first call on.  Results are the
+                                          same either way (the library picks by measured speed); the flag is for measurements and for the
+                                          tests of those other kernels.                                                            */
 };
 
 typedef struct rgx_program rgx_program;       /* compiled pattern: host tables + device copy      */

@@ -33,6 +33,7 @@ TRANSFORM_REPLACE, TRANSFORM_SELECT, TRANSFORM_REJECT = 0, 1, 2
 FLAG_UNMATCHED_MINUS1 = 1
 FLAG_STDLIB_SEMANTICS = 2
 FLAG_FORCE_TDFA = 1 << 2            # regengo.Options.ForceTDFA
+FLAG_NO_PREFILTER_SCAN = 1 << 3     # FindAll never takes rgx_scan_fc.hip (measurements, tests of the other scan kernels)
 
 
 class Info(C.Structure):

@@ -58,7 +58,7 @@ class BytesResult:
 
 class Compiled:
     def __init__(self, pattern: str, name: str = "Pattern", flags: int = 0, device: Optional[int] = None, stdlib: bool = False,
-                 force_tdfa: bool = False):
+                 force_tdfa: bool = False, no_prefilter_scan: bool = False):
         """stdlib=False (the default): MatchBytes / FindBytes / FindBatch behave like the reference's emitted functions,
         restart rule included (SURVEY 5.9 Q1: a failed attempt resumes behind its failure offset, stepping over some matches);
         stdlib=True: the plain leftmost-first search (RGX_FLAG_STDLIB_SEMANTICS).  FindAllBytes is the same in both."""
@@ -67,6 +67,8 @@ class Compiled:
         self.name = name
         if stdlib:
             flags |= _capi.FLAG_STDLIB_SEMANTICS
+        if no_prefilter_scan:   # FindAll on the program's other scan kernel from the first call (RGX_FLAG_NO_PREFILTER_SCAN)
+            flags |= _capi.FLAG_NO_PREFILTER_SCAN
         if force_tdfa:          # regengo.Options.ForceTDFA: the reference's Tagged DFA for the capture functions whenever it can be built
             flags |= _capi.FLAG_FORCE_TDFA
         self.stdlib = bool(flags & _capi.FLAG_STDLIB_SEMANTICS)

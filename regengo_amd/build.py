@@ -14,7 +14,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "regengo_amd", "csrc")
 LIBDIR = os.path.join(ROOT, "regengo_amd", "lib")
 
-PRODUCT_SOURCES = ["rgx_syntax.cc", "rgx_dfa.cc", "rgx_ref_engine.cc", "rgx_program.cc", "rgx_kernels.hip", "rgx_scan_exact.hip", "rgx_scan_sa.hip", "rgx_scan_us.hip", "rgx_tdfa.hip", "rgx_batch_tiny.hip", "rgx_replace.hip", "rgx_sharded.hip", "rgx_capi.cc"]
+PRODUCT_SOURCES = ["rgx_syntax.cc", "rgx_dfa.cc", "rgx_ref_engine.cc", "rgx_program.cc", "rgx_kernels.hip", "rgx_scan_exact.hip", "rgx_scan_sa.hip", "rgx_scan_us.hip", "rgx_scan_fc.hip", "rgx_tdfa.hip", "rgx_batch_tiny.hip", "rgx_replace.hip", "rgx_sharded.hip", "rgx_capi.cc"]
 PRODUCT_LINK = ["-ldl", "-lpthread"]          # extra link arguments of the product library (RCCL itself is dlopen-ed: rgx_sharded.hip)
 HOSTTEST_SOURCES = ["rgx_syntax.cc", "rgx_dfa.cc", "rgx_ref_engine.cc", "hosttest/rgx_hosttest.cc"]
 

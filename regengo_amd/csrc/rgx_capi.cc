@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <chrono>
+#include <functional>
 #include <memory>
 #include <mutex>
 #include <new>
@@ -20,7 +22,7 @@
 
 using namespace rgx;
 
-static constexpr uint32_t kPublicFlags = RGX_FLAG_UNMATCHED_MINUS1 | RGX_FLAG_STDLIB_SEMANTICS | RGX_FLAG_FORCE_TDFA;
+static constexpr uint32_t kPublicFlags = RGX_FLAG_UNMATCHED_MINUS1 | RGX_FLAG_STDLIB_SEMANTICS | RGX_FLAG_FORCE_TDFA | RGX_FLAG_NO_PREFILTER_SCAN;
 
 struct rgx_program {
   Program p;
@@ -29,6 +31,13 @@ struct rgx_program {
   mutable std::atomic<int> prefer_w{0};
   mutable std::atomic<int> prefer_wsync{0};  // the blind walk of the sync automaton left slices without a sync point: exact sync points first (FindAllDevice)
   mutable std::atomic<int> prefer_rw{0};   // the pair kernel's rewinding instance (FindAllDevice: many lanes went to the single-step walker)
+  // rgx_scan_fc.hip or the program's other scan kernel: which is faster depends on the text as much as on the pattern (how many starts the
+  // prefilter passes, how long the candidates walk), so the first two LARGE scans of a program take one each, timed on the host from the
+  // first launch to the complete table, and the program stays with the faster: 1 = the filter + candidate kernel, -1 = the other, 0 = open
+  mutable std::atomic<int> fc_pref{0};
+  mutable std::atomic<int> fc_us_per_gib{0}, other_us_per_gib{0};
+  mutable std::atomic<int> fc_bad{0};      // scans of this program that the filter + candidate kernel gave up (rgx_scan_fc.hip: no sync point in a tile's
+                                           // halo, more candidates than lanes, a long walk); from the second on the program stays with its other kernel
   // The ASCII twin (AsciiTwin below): the same pattern built for texts without a byte >= 0x80 (rgx_dfa.h: kFlagAsciiText).  Made on the
   // first large scan of a program that misses the one-step-per-byte kernels; kept only if the twin reaches them.
   mutable std::mutex twin_mu;
@@ -436,7 +445,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
                      p->prefer_wsync.load(std::memory_order_relaxed) != -2;      // walks every slice from behind: slower than the generic kernel's W path, measured)
   if (us_ws) use_w = false;
   int32_t ntiles = ScanNumTiles(T, ilen, use_w);
-  const int32_t ntiles_max = std::max(ntiles, std::max(ScanNumTiles(T, ilen, false), ScanNumTiles(T, ilen, true)));
+  const int32_t ntiles_max = std::max(std::max(ntiles, UseFcKernel(T, ilen) ? FcNumTiles(ilen) : 0), std::max(ScanNumTiles(T, ilen, false), ScanNumTiles(T, ilen, true)));
   const int32_t nslices = (ilen + kSliceBytes - 1) / kSliceBytes;
   int rc;
   // Device scratch: TWO sets of [total u64][trace cursor u64][counters 4 x u32][look-back descriptors ...], used
@@ -474,6 +483,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   }
   P.us_rewind = p->prefer_rw.load(std::memory_order_relaxed);
 
+  int fc_now = 0;                // != 0: the launch below is rgx_scan_fc.hip's, in this mode
   auto run_scan_once = [&](bool time_it) -> int {
     const int s = c->cur_set;
     unsigned long long* set = c->d_desc + (size_t)s * c->set_words;
@@ -489,7 +499,8 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     P.host_result = self_clean ? c->h_read_dev : nullptr;
     c->h_read[0] = 0; c->h_read[1] = 0; c->h_read[2] = 0; c->h_read[3] = 0;
     if (time_it) HIP_TRY(hipEventRecord(c->ev0, c->stream));
-    HIP_TRY(LaunchScan(T, P, c->stream));
+    if (fc_now) HIP_TRY(LaunchScanFc(T, P, fc_now, c->stream));
+    else HIP_TRY(LaunchScan(T, P, c->stream));
     if (time_it) HIP_TRY(hipEventRecord(c->ev1, c->stream));
     c->dirty[s] = (int64_t)desc_words;
     if (self_clean) {
@@ -534,6 +545,67 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   };
   static const bool force_tickets = ExpEnv("RGX_TICKETS") != nullptr;
   P.use_tickets = (force_tickets || c->tickets) ? 1 : 0;
+  // The filter + candidate kernel first, where the program's level sets are a selective prefilter (rgx_scan_fc.hip; DevTables::fc_mode): one
+  // launch, the input read once, and -- mode 2 -- the capture groups resolved in the candidates' walk: complete records, no capture pass.
+  // Optimistic: a launch that gave up (a tile whose halo holds no reset byte, more candidates than lanes in a tile, a candidate that walks
+  // for kilobytes) is void and the program's other kernel runs below; a program that gave up twice stays there.
+  const bool fc_big = len >= (size_t(8) << 20);
+  const int fc_pref = p->fc_pref.load(std::memory_order_relaxed);
+  const bool fc_open = fc_pref == 0 && fc_big;                 // still comparing: this call is timed
+  int fcm = (!use_w && !us_ws && !c->prefer_w && p->fc_bad.load(std::memory_order_relaxed) < 2 && fc_pref >= 0) ? UseFcKernel(T, ilen) : 0;
+  if (fcm && fc_open && p->fc_us_per_gib.load(std::memory_order_relaxed) != 0) fcm = 0;      // the kernel has its time: the other one's turn
+  const auto fc_t0 = std::chrono::steady_clock::now();
+  auto fc_rate = [&]() -> int {
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - fc_t0).count();
+    return std::max(1, (int)(us * (double)(size_t(1) << 30) / (double)len));
+  };
+  struct OtherTimer {          // the other path has many ways out: whichever it takes, its time is noted (successful or not: a refusal is quick)
+    std::function<void()> f;
+    ~OtherTimer() { if (f) f(); }
+  } other_timer;
+  if (fcm) {
+    const ScanParams keep = P;
+    P.ntiles = FcNumTiles(ilen);
+    if (fcm == 2) { P.pairs = nullptr; P.cap_records = (int64_t)cap_records; }
+    fc_now = fcm;
+    rc = run_scan(c->timing);              // (static tile ids, bounded look-back spins; once more with tickets if one gave up)
+    fc_now = 0;
+    if (rc != RGX_OK) return rc;
+    const uint32_t* const hc = (const uint32_t*)&c->h_read[2];
+    if (!(hc[2] & kFcGaveUpBit) && !(hc[3] & 1u)) {
+      float fms = 0;
+      if (c->timing) (void)hipEventElapsedTime(&fms, c->ev0, c->ev1);
+      const int64_t ftotal = (int64_t)c->h_read[0];
+      int64_t fwritten = count_only ? 0 : std::min<int64_t>(ftotal, (int64_t)cap_records);
+      if (res) { res->total = ftotal; res->unsynced = 0; res->kernel_ms = fms; }
+      if (count_only) return ftotal;
+      if (ftotal > (int64_t)cap_records && (n < 0 || n > (int64_t)cap_records)) {
+        if (res) res->written = 0;
+        SetError("span capacity too small");
+        return RGX_E_CAPACITY;
+      }
+      if (n > 0) fwritten = std::min<int64_t>(fwritten, n);
+      if (fcm != 2 && !T.fixed_captures && fwritten > 0 && !starts_only) {
+        int64_t need = (int64_t)len + fwritten + 64;
+        if ((rc = Ensure(&c->d_trace, &c->trace_cap, need)) != RGX_OK) return rc;
+        HIP_TRY(hipMemsetAsync(c->d_cursor, 0, 8, c->stream));
+        HIP_TRY(LaunchCaptures(T, d_buf, ilen, d_spans, P.pairs, fwritten, c->d_trace, c->d_cursor, c->stream));
+        HIP_TRY(hipStreamSynchronize(c->stream));
+      }
+      if (res) res->written = fwritten;
+      if (fc_open) p->fc_us_per_gib.store(fc_rate(), std::memory_order_relaxed);
+      return fwritten;
+    }
+    p->fc_bad.fetch_add(1, std::memory_order_relaxed);
+    if (getenv("RGX_FC_VERBOSE")) fprintf(stderr, "[rgx] filter + candidate kernel gave up (mode %d, len %d): counters[2] = 0x%08x, counters[3] = 0x%08x\n", fcm, ilen, hc[2], hc[3]);
+    P = keep;
+  } else if (fc_open && UseFcKernel(T, ilen) && p->fc_us_per_gib.load(std::memory_order_relaxed) != 0) {
+    other_timer.f = [&]() {
+      const int other = fc_rate(), mine = p->fc_us_per_gib.load(std::memory_order_relaxed);
+      p->other_us_per_gib.store(other, std::memory_order_relaxed);
+      p->fc_pref.store(mine <= other ? 1 : -1, std::memory_order_relaxed);
+    };
+  }
   // Every scan but the exact kernel's may meet slices without a sync point in reach; the first scan marks them as it goes
   // (a byte per slice, cleared here), so that the carry pass needs no scan of its own to find them.
   bool marked = false;

@@ -52,6 +52,14 @@ bool UseSaKernel(const DevTables& T, int32_t len);
 int SaTileBytes();
 hipError_t LaunchScanSa(const DevTables& T, const ScanParams& P, const uint16_t* class_table, hipStream_t stream);  // tiles (= look-back descriptors) the scan of `len` bytes uses
 
+// rgx_scan_fc.hip: Shift-Or filter + one lane per candidate start (programs with DevTables::fc_mode); UseFcKernel: 0 = no, else the
+// kernel mode (2: the candidate walk resolves the capture groups -- records complete, no capture pass).  Optimistic: counters[2] bit 31
+// up after the launch = results void (no sync point in a tile's halo, more candidates than lanes, a candidate that walks too far)
+constexpr unsigned kFcGaveUpBit = 0x80000000u;
+int UseFcKernel(const DevTables& T, int32_t len);
+int32_t FcNumTiles(int32_t len);
+hipError_t LaunchScanFc(const DevTables& T, const ScanParams& P, int mode, hipStream_t stream);
+
 // rgx_scan_us.hip: one table step per input byte over the start-tracking search automaton (rgx_program.h: UsDev); takes
 // unanchored patterns that cannot match empty whenever sync points come from reset bytes or the carry pass (not use_w)
 bool UseUsKernel(const DevTables& T, int32_t len, bool use_w);

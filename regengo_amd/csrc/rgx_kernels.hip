@@ -2372,6 +2372,7 @@ int32_t ScanNumTiles(const DevTables& T, int32_t len, bool use_w) {
 bool ScanSupportsW(const DevTables& T, int32_t len);
 int ScanKernelKind(const DevTables& T, int32_t len) {
   if (UseExactKernel(T, len)) return 1;
+  if (UseFcKernel(T, len)) return 7;          // (first choice; a text that defeats its prefilter sends the program to the kind below: rgx_capi.cc)
   if (UseUsKernel(T, len, false)) {
     // a pattern without a single reset byte takes its sync points from the sync automaton: the register-free kernels do (rgx_capi.cc:
     // us_ws), the register kernel's programs scan on the generic kernel

@@ -14,9 +14,10 @@ void SetError(const std::string& s) { g_error = s; }
 const std::string& GetError() { return g_error; }
 
 Program::~Program() {
-  if (d_arena || d_arena_u || d_arena_us || d_arena_tdfa || d_arena_memo || d_tiny) {
+  if (d_arena || d_arena_u || d_arena_us || d_arena_tdfa || d_arena_memo || d_tiny || d_arena_fc) {
     hipSetDevice(device);
     if (d_tiny) hipFree(d_tiny);
+    if (d_arena_fc) hipFree(d_arena_fc);
     if (d_arena_tdfa) hipFree(d_arena_tdfa);
     if (d_arena_memo) hipFree(d_arena_memo);
     if (d_arena) hipFree(d_arena);
@@ -93,6 +94,38 @@ struct Arena {
 }  // namespace
 
 namespace {
+// rgx_scan_fc.hip takes a program when its Shift-And level sets are a SELECTIVE prefilter: a start position survives only where its
+// first bytes pass small classes, so few positions get a walk of the automaton.  The estimate: the share of positions of ordinary text
+// (weights below: a rough model of English / log text -- it only has to tell `https?://` from `\\w+@`) that pass the first levels.  Texts
+// that defeat it (timestamps everywhere under `\\d+\\.\\d+`) are caught at run time: a tile with more candidates than lanes gives the
+// call up and the program remembers (rgx_capi.cc).
+int FcModeOf(const Tables& t, bool onepass) {
+  if (t.flags & (1u << 3)) return 0;                          // RGX_FLAG_NO_PREFILTER_SCAN
+  if (t.anchored || t.lookahead_mode || t.can_match_empty || t.sa_exact || t.sa_k < 2 || t.sa_k > 29 || t.ncap > 32) return 0;
+  for (int c = 0; c < 4; c++) if (t.start_accept[c]) return 0;
+  bool has_reset = false;
+  for (int c = 0; c < 256; c++) has_reset = has_reset || t.reset_byte[c];
+  if (!has_reset) return 0;
+  auto weight = [](int c) -> double {
+    if (c == ' ') return 0.15;
+    if (c >= 'a' && c <= 'z') return 0.026;
+    if (c >= '0' && c <= '9') return 0.012;
+    if (c >= 'A' && c <= 'Z') return 0.004;
+    if (c == '\n' || c == '.' || c == ',' || c == '-' || c == '/' || c == ':' || c == '_' || c == '"' || c == '=') return 0.006;
+    if (c > 32 && c < 127) return 0.002;
+    return 0.0002;
+  };
+  double p = 1.0;
+  for (int j = 0; j < t.sa_k && j < 4; j++) {
+    double w = 0;
+    for (int c = 0; c < 256; c++) if ((t.sa_mask[c] >> j) & 1u) w += weight(c);
+    p *= w < 1.0 ? w : 1.0;
+  }
+  if (p > 1.0 / 96.0) return 0;
+  if (t.fixed_captures || t.ncap <= 2) return 1;
+  return onepass && t.ncap <= 16 ? 2 : 1;
+}
+
 // Builds the device image of one table set: picks the LDS layout, packs every table into one arena, uploads it.
 int UploadTables(const Tables& t, std::vector<uint16_t>* direct_table, DevTables* out, void** out_arena) {
   const int stride = t.ncls + 1;
@@ -119,6 +152,7 @@ int UploadTables(const Tables& t, std::vector<uint16_t>* direct_table, DevTables
   d.start_pool_n = (int32_t)t.start_ops_pool.size();
   d.fixed_captures = t.fixed_captures; d.unmatched_minus1 = (t.flags & RGX_FLAG_UNMATCHED_MINUS1) ? 1 : 0;
   d.onepass = IsOnePass(t) ? 1 : 0;
+  d.fc_mode = (uint8_t)FcModeOf(t, d.onepass != 0);
 
   // choose the LDS layout
   Arena a;
@@ -197,6 +231,105 @@ int UploadTables(const Tables& t, std::vector<uint16_t>* direct_table, DevTables
 }  // namespace
 
 namespace {
+// The LDS image of rgx_scan_fc.hip (rgx_program.h: FcDev has the layout).  Mode 2 (the candidate walk resolves the groups) needs every
+// ops word to name at most two record slots and everything addressable in 15 bits; otherwise the program takes mode 1.
+int UploadFc(Program* p) {
+  const Tables& t = p->t;
+  const DevTables& d = p->dev;
+  const int stride = t.ncls + 1;
+  const int K = t.sa_k;
+  int mode = d.fc_mode;
+  const int cells_bytes = ((t.nstates * stride * 8) + 15) & ~15;
+  const int scrap = (t.ncap - 2) * fc::kThreads * 4;
+  auto slots_of = [&](uint32_t o, uint32_t* out) -> bool {     // the two 16-bit slot offsets of an ops mask; false: more than two groups
+    o &= ~3u;
+    uint32_t lo = (uint32_t)scrap, hi = (uint32_t)scrap;
+    int n = 0;
+    while (o) {
+      const int c = __builtin_ctz(o); o &= o - 1;
+      if (n == 0) lo = (uint32_t)(c - 2) * fc::kThreads * 4; else if (n == 1) hi = (uint32_t)(c - 2) * fc::kThreads * 4; else return false;
+      n++;
+    }
+    *out = lo | (hi << 16);
+    return true;
+  };
+  std::vector<uint32_t> pool;
+  if (mode == 2) {
+    pool.resize(t.bt_ops.size() + t.start_ops_pool.size() + 1, (uint32_t)scrap | ((uint32_t)scrap << 16));
+    for (size_t i = 0; i < t.bt_ops.size() && mode == 2; i++) if (!slots_of(t.bt_ops[i], &pool[i])) mode = 1;
+    for (size_t i = 0; i < t.start_ops_pool.size() && mode == 2; i++) if (!slots_of(t.start_ops_pool[i], &pool[t.bt_ops.size() + i])) mode = 1;
+  }
+  int ops_bytes = mode == 2 ? (int)((pool.size() * 4 + 15) & ~size_t(15)) : 16;
+  if (mode == 2 && fc::kCellsOff + cells_bytes + 2 * ops_bytes > 32768) { mode = 1; ops_bytes = 16; }
+  // every workgroup copies the image for its 16 KiB tile: it has to be small next to it
+  if (cells_bytes + 2 * ops_bytes > 8 * 1024) return RGX_E_UNSUPPORTED;
+  const int cells_at = fc::kCellsOff, ops_at = cells_at + cells_bytes;
+  const int b_bytes = cells_bytes + 2 * ops_bytes;
+  const int rows_off = ops_at + 2 * ops_bytes;
+  const int rec_off = rows_off + (((fc::kRows + 1) * fc::kRowBytes + 15) & ~15);
+  const int lds_total = rec_off + (mode == 2 ? (t.ncap - 1) * fc::kThreads * 4 : 0);
+  std::vector<uint8_t> img((size_t)fc::kFixedBytes + b_bytes + sizeof(FcSlowPtrs) + 16, 0);
+  // part A
+  for (int c = 0; c < 256; c++) {
+    const uint32_t f = ~t.sa_mask[c] & ((K >= 32) ? ~0u : ((1u << K) - 1u));
+    if (K <= 16) { const uint16_t f16 = (uint16_t)f; memcpy(&img[fc::kSa + c * 2], &f16, 2); }
+    else memcpy(&img[fc::kSa + c * 4], &f, 4);
+    img[fc::kCls8 + c] = (uint8_t)(t.cls[c] << 3);
+    img[fc::kReset + c] = t.reset_byte[c];
+    img[fc::kCtx + c] = t.ctx_of_byte[c];
+  }
+  if (stride > 32) return RGX_E_UNSUPPORTED;                   // class * 8 in a byte
+  if (t.fixed_captures)
+    for (int c = 0; c < t.ncap && c < 32; c++) { img[fc::kKind + c] = t.cap_kind[c]; memcpy(&img[fc::kDelta + c * 4], &t.cap_delta[c], 4); }
+  for (int cx = 0; cx < 4; cx++) {
+    const uint32_t row = (uint32_t)(cells_at + t.start[cx] * stride * 8);
+    const uint32_t sl = mode == 2 ? (uint32_t)(ops_at + ((int)t.bt_ops.size() + (int)t.start_ops[cx]) * 4) : (uint32_t)ops_at;
+    memcpy(&img[fc::kSrow + cx * 4], &row, 4);
+    memcpy(&img[fc::kSslice + cx * 4], &sl, 4);
+  }
+  // part B
+  uint8_t* const B = img.data() + fc::kFixedBytes;
+  for (int i = 0; i < t.nstates * stride; i++) {
+    const int st = i / stride, k = i - st * stride;
+    const uint32_t tr = (st == 0 || k == t.ncls) ? 0u : (uint32_t)t.trans[i];
+    const uint32_t qn = tr & kStateMask;
+    uint32_t x = (uint32_t)(cells_at + qn * stride * 8);
+    uint32_t y = ((uint32_t)ops_at & 0xFFFFu) | ((uint32_t)ops_bytes << 16);
+    if (qn != 0) {
+      if (mode == 2) {
+        const uint32_t base = t.bt_base[i];
+        y = ((uint32_t)(ops_at + base * 4) & 0xFFFFu) | (((uint32_t)t.bt_parent[base] * 4u) << 16);
+        if (tr & kMatchAfter) x |= 0x80000000u | (((uint32_t)(ops_at + (base + t.st_nthreads[qn] - 1) * 4) & 0x7FFFu) << 16);
+      } else if (tr & kMatchAfter) {
+        x |= 0x80000000u;
+      }
+    }
+    memcpy(B + i * 8, &x, 4);
+    memcpy(B + i * 8 + 4, &y, 4);
+  }
+  if (mode == 2) {
+    // the pool, and behind it as many "no group" words: where the ops word of an edge into the dead state is looked up
+    const uint32_t none = (uint32_t)scrap | ((uint32_t)scrap << 16);
+    for (int i = 0; i < 2 * ops_bytes / 4; i++) memcpy(B + cells_bytes + i * 4, (size_t)i < pool.size() ? &pool[i] : &none, 4);
+  }
+  FcSlowPtrs sp{};
+  sp.trans_cls = d.trans_cls; sp.cls = d.cls; sp.ctx_of_byte = d.ctx_of_byte; sp.bt_base = d.bt_base; sp.bt_parent = d.bt_parent;
+  sp.bt_ops = d.bt_ops; sp.st_nthreads = d.st_nthreads; sp.start_ops = d.start_ops; sp.start_ops_pool = d.start_ops_pool;
+  for (int cx = 0; cx < 4; cx++) sp.start[cx] = t.start[cx];
+  sp.stride = stride; sp.ncap = t.ncap; sp.ctx_sensitive = t.ctx_sensitive ? 1 : 0; sp.unmatched_minus1 = d.unmatched_minus1;
+  memcpy(img.data() + fc::kFixedBytes + b_bytes, &sp, sizeof sp);
+  void* dptr = nullptr;
+  if (hipMalloc(&dptr, img.size()) != hipSuccess) { SetError("hipMalloc(fc image) failed"); return RGX_E_NOMEM; }
+  if (hipMemcpy(dptr, img.data(), img.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dptr); return RGX_E_HIP; }
+  FcDev f{};
+  f.img = (const uint8_t*)dptr; f.mode = mode; f.b_bytes = b_bytes; f.ops_bytes = ops_bytes; f.rows_off = rows_off; f.rec_off = rec_off;
+  f.lds_total = lds_total;
+  p->fcdev = f;
+  p->d_arena_fc = dptr;
+  p->dev.fc_mode = (uint8_t)mode;
+  return RGX_OK;
+}
+
 constexpr int kUsMaxEntries = 4096;      // 32 KiB of LDS for the table at most (most automata: a few hundred bytes)
 
 // Start-tracking search automaton: the fewest registers (1, 2, 4) with which the pattern is eligible and the table fits.
@@ -441,6 +574,8 @@ int ProgramToDevice(Program* p, int device) {
   p->us_ok = BuildUs(p);
   if (p->us_ok && UploadUs(p) != RGX_OK) p->us_ok = false;
   p->dev.us = p->us_ok ? &p->usdev : nullptr;
+  p->dev.fc = nullptr;
+  if (p->dev.fc_mode != 0 && UploadFc(p) == RGX_OK) p->dev.fc = &p->fcdev; else p->dev.fc_mode = 0;
   // the program as instructions, when the reference emits its memoising backtracker for the capture functions
   p->dev.memo = nullptr;
   {

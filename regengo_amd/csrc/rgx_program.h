@@ -39,6 +39,7 @@ enum TableMode : int {
 
 struct UsDev;
 struct TdfaDev;
+struct FcDev;
 // Device image of the syntax.Prog itself, for the reference's memoising backtracker (rgx_memo.h has the why and the interpreter)
 typedef MemoView MemoDev;
 
@@ -89,6 +90,7 @@ struct DevTables {
   const MemoDev* memo;            // HOST pointer to the program as instructions when the reference emits its memoising backtracker for FindBytes
                                   // (ref_find_engine == 2) and the interpreter takes it (at most 64 Alt instructions), else nullptr
   const TdfaDev* tdfa;            // HOST pointer to the reference's Tagged DFA on the device (rgx_tdfa.hip) when the reference emits one, else nullptr
+  const FcDev* fc;                // HOST pointer to the program's FcDev when fc_mode != 0 (rgx_scan_fc.hip), else nullptr
   const UsDev* us;                // HOST pointer to the program's UsDev when the pattern is eligible for rgx_scan_us.hip, else nullptr
   const uint32_t* tiny;           // search automaton only: DEVICE pointer to its image for batch_tiny_kernel (rgx_tiny.h), nullptr when it is not tiny
   int32_t tiny_nreg;              // ... its tag registers (1-8: the kernel's instantiations)
@@ -96,9 +98,10 @@ struct DevTables {
   uint16_t start[4];
   uint8_t start_accept[4];
   uint8_t lookahead, ctx_sensitive, bot_sensitive, anchored, fixed_captures, unmatched_minus1;
+  uint8_t fc_mode;                // rgx_scan_fc.hip (filter + candidates): 0 = not for this program; 1 = its level sets are a selective prefilter, the candidate
+                                  // walk finds the match ends; 2 = ... and, the automaton being one-pass, resolves the capture groups on its way
   uint8_t onepass;                // every edge of the automaton has ONE consuming thread (all threads of the next state descend from it): the
                                   // capture groups of a match come out of a single forward walk (rgx_kernels.hip: ResolveCapturesOnePass)
-  uint8_t pad1;
 };
 
 // Device image of the start-tracking search automaton (rgx_dfa.h: StartSearch) for rgx_scan_us.hip.  Entries are 64 bit:
@@ -142,6 +145,40 @@ struct UsDev {
   int32_t has_rewind;             // the pair table's rewind row (row 1) can be entered: the kernel instance that handles rewinds in its fast walk
 };
 
+// rgx_scan_fc.hip (filter + candidates).  The kernel runs one workgroup per 16 KiB tile, so whatever a workgroup needs of the program
+// must cost it next to nothing: the host composes the kernel's LDS tables ONCE (rgx_program.cc: BuildFcImage) and a workgroup copies
+// them, 16 bytes per lane.  LDS layout (byte offsets; the kernel's dynamic segment begins at LDS address 0):
+//   part A, fixed offsets   [kFcSa, +1024) Shift-Or words (16 bit when K <= 16)   [kFcCls8, +256) byte -> class * 8   [kFcReset, +256)
+//                           [kFcCtx, +256) StartCtx by the byte in front   [kFcKind, +32) [kFcDelta, +128) fixed capture template
+//                           [kFcSrow, +16) start state's row of cells per StartCtx   [kFcSslice, +16) its slice of the ops pool
+//   work area               [kFcMisc, +256)   [kFcList, +kFcListBytes) the tile's candidates
+//   part B, at cells_off    cells [nstates * stride] of 8 bytes, then the ops pool twice its size (second half zero: rgx_scan_fc.hip)
+//   rows_off                the tile: 257 rows of 80 bytes;   rec_off: (ncap - 1) x lanes record slots (mode 2; the last row is scrap)
+// cell (state, class): x = [0..15] LDS address of the next state's row  [16..30] LDS address of the ops word of the next state's Match
+// thread  [31] a match ends right behind this byte;  y = [0..15] LDS address of the edge's slice of the ops pool  [16..31] the edge's
+// single parent thread * 4 -- or, on an edge into the dead state, ops_bytes.  An ops word names the (at most two) record slots the
+// thread assigns: two 16-bit byte offsets into the lane's column of record slots, scrap = (ncap - 2) * lanes * 4.
+namespace fc {
+constexpr int kThreads = 256;
+constexpr int kSa = 0, kCls8 = 1024, kReset = 1280, kCtx = 1536, kKind = 1792, kDelta = 1824, kSrow = 1952, kSslice = 1968, kFixedBytes = 1984;
+constexpr int kMisc = kFixedBytes, kList = kMisc + 256, kListBytes = (kThreads / 64) * kThreads * 2, kCellsOff = kList + kListBytes;
+constexpr int kRowBytes = 80, kRows = kThreads;
+}  // namespace fc
+struct FcDev {
+  const uint8_t* img;             // device: part A (fc::kFixedBytes), part B (b_bytes), then the slow path's table pointers (FcSlowPtrs)
+  int32_t mode;                   // 1: the walk finds the match ends; 2: it resolves the capture groups too (one-pass automata)
+  int32_t b_bytes;                // part B: cells + 2 x ops pool, copied to LDS offset fc::kCellsOff
+  int32_t ops_bytes;              // bytes of the ops pool (the zero region behind it is as large)
+  int32_t rows_off, rec_off, lds_total;
+};
+// (at img + kFixedBytes + b_bytes) the plain tables in memory, for the rare match whose groups the fast walk cannot vouch for
+struct FcSlowPtrs {
+  const uint16_t* trans_cls; const uint8_t* cls; const uint8_t* ctx_of_byte; const uint32_t* bt_base; const uint8_t* bt_parent;
+  const uint32_t* bt_ops; const uint32_t* st_nthreads; const uint32_t* start_ops; const uint32_t* start_ops_pool;
+  uint16_t start[4];
+  int32_t stride, ncap, ctx_sensitive, unmatched_minus1;
+};
+
 // Device image of the reference's Tagged DFA (rgx_dfa.h: RefTdfa; tdfa.go:584-794 emits the same content as Go array literals).
 //   ent[state * 128 + byte]  [0..9] next state  [10] no transition  [11] the next state is in acceptStates  [12] in acceptStatesEOT
 //                            [16..31] the edge's tag actions: index into pool
@@ -168,6 +205,8 @@ struct Program {
   void* d_arena_us = nullptr;
   TdfaDev tdfadev{};
   void* d_arena_tdfa = nullptr;
+  FcDev fcdev{};
+  void* d_arena_fc = nullptr;
   MemoDev memodev{};
   void* d_arena_memo = nullptr;
   std::vector<uint8_t> blob_cache;

@@ -1,0 +1,681 @@
+// The filter + candidate kernel for gfx950: FindAllBytes for patterns whose Shift-And level sets are a SELECTIVE prefilter -- a
+// match can only begin where its first K bytes pass K small byte classes (`https?://...`, `GET|POST ...`; `[a-z]+@...` is not one).
+// The reference walks its matcher from every searchStart (internal/compiler/find.go:130-316) and skips ahead to a required first
+// byte where it can (compiler.go:719-764); the data-parallel form of that skip:
+//
+//   filter      every lane runs the branch-free Shift-Or byte loop of rgx_scan_exact.hip over its 64-byte slice (2 VALU per byte):
+//               a 64-bit mask of candidate starts per slice.
+//   candidates  the tile's candidates are compacted, in position order, into a list in LDS and DEALT one per lane: lanes 0..n-1
+//               walk, dense, whatever slice a candidate came from.  The walk is the anchored leftmost-first DFA from the
+//               candidate's start over a composed cell table (next row, match flag, capture ops of the edge) straight out of the
+//               tile's rows in LDS -- for one-pass automata it resolves the capture groups in the same walk (the group assignments
+//               of the single path, written to the lane's record as they are met), so there is NO separate capture pass and the
+//               input is read from HBM exactly once.  Bytes that cannot begin a match are never walked: on a web log one byte in
+//               four belongs to a URL, the rest costs the filter's two instructions.
+//   chain       FindAll keeps the leftmost match and resumes at its end (find.go:452-457).  The walked candidates (start, end) are
+//               in position order; a candidate is reported iff it succeeded and no earlier reported match covers its start --
+//               decided by a prefix maximum of the ends (the common case: nothing overlaps), serially by one lane otherwise.  The
+//               chain enters a tile at a sync point: the offset behind the nearest reset byte (every DFA state dies on it) in the
+//               256 bytes in front of the tile's owned range; candidates between it and the range are walked too (their matches
+//               may cover owned starts) and not reported.
+//   order       one decoupled look-back per tile over the counts; records leave in match order.
+//
+// One workgroup = one 16 KiB tile, as many workgroups as tiles: the latencies of a tile (its loads, its look-back) hide behind the
+// other workgroups of the CU.  [Measured and rejected, round 5: PERSISTENT workgroups (512 lanes, tickets, the next tile's loads in
+// flight, the look-back resolved a tile later by the last wave, eight descriptor windows per round trip) -- bit-exact, 2.65 ms per
+// 1.6 GiB window of the URL pattern against 1.34 + 0.47 for the pair kernel and its capture pass: persistent workgroups run in step,
+// every tile of a generation publishes its count at the same moment, every look-back then waits for the slowest workgroup of the
+// generation, and the waiting wave holds its whole workgroup at the next barrier.]
+// The launch is OPTIMISTIC: a tile without a sync point in its halo, with more candidates than lanes, or a candidate that walks
+// further than kFcMaxSteps raises ScanParams::counters[2] bit 31 -- the results are void, the host runs the program's other kernel
+// (rgx_capi.cc) and the program remembers.  HBM-bound byte work: no MFMA.
+#include <hip/hip_runtime.h>
+
+#include <cstdlib>
+
+#include "rgx_device_util.h"
+#include "rgx_kernels.h"
+
+namespace rgx {
+
+namespace {
+
+using namespace fc;
+constexpr int kFcThreads = fc::kThreads;
+constexpr int kFcWaves = kFcThreads / 64;
+constexpr int kFcRows = fc::kRows;                          // slices staged per tile, one per lane
+constexpr int kFcHalo = 4;                                  // slices in front of the owned range: where the sync point is looked for
+constexpr int kFcOwned = kFcRows - kFcHalo - 1;             // the last slice only supplies its neighbour's look-ahead
+constexpr int kFcOwnBytes = kFcOwned * kSliceBytes;
+constexpr int kFcRowBytes = fc::kRowBytes;                  // 64 data + 16 pad: conflict-free ds_read_b128 (rgx_scan_exact.hip)
+constexpr int kFcWinBytes = kFcRows * kSliceBytes;
+constexpr int kFcRounds = 2;                                // candidates per lane at most: a tile's prefilter may pass more starts than it has lanes
+constexpr int kFcCap = kFcRounds * kFcThreads;              // candidates per tile
+constexpr int kFcSeg = kFcThreads;                          // ... and per wave (its segment of the list)
+constexpr int kFcKeep = 14;                                 // capture slots of a record held in registers (ncap <= 16)
+constexpr int kFcMaxSteps = 2048;                           // bytes one candidate may walk before the call is given up
+constexpr unsigned kFcGaveUp = kFcGaveUpBit;                // counters[2]; low bits: 1 no sync point, 2 too many candidates, 4 long walk, 8 LDS base
+
+typedef unsigned v4u __attribute__((ext_vector_type(4)));
+typedef const unsigned char __attribute__((address_space(3)))* Lds8c;
+typedef const unsigned short __attribute__((address_space(3)))* Lds16c;
+typedef const unsigned __attribute__((address_space(3)))* Lds32c;
+typedef unsigned __attribute__((address_space(3)))* Lds32w;
+typedef unsigned FcCell __attribute__((ext_vector_type(2)));
+typedef const FcCell __attribute__((address_space(3)))* LdsCell;
+
+// What a launch needs, and no more: a workgroup lives for one 16 KiB tile, every scalar register it loads is loaded 100 000 times.
+struct FcParams {
+  const uint8_t* buf;
+  const uint8_t* img;              // FcDev::img
+  int32_t* spans;
+  int32_t* pairs;
+  unsigned long long* desc;
+  uint32_t* counters;
+  unsigned long long* total;
+  long long cap_records;
+  int32_t len, ntiles, own_lo, own_hi;
+  int32_t b_bytes, rows_off, rec_off, ops_bytes;
+  int32_t K, ncap;
+  uint32_t flags;
+};
+constexpr uint32_t kFcCountOnly = 1, kFcStartsOnly = 2, kFcTickets = 4, kFcFixedCaps = 8, kFcCtxSens = 16, kFcMinus1 = 32;
+
+// (byte B of w) << sh in ONE instruction (SDWA source select)
+template <int B>
+__device__ __forceinline__ unsigned FcByteTimes(unsigned w, unsigned sh) {
+  unsigned r;
+  if (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(sh), "v"(w));
+  else if (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(sh), "v"(w));
+  else if (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(sh), "v"(w));
+  else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(sh), "v"(w));
+  return r;
+}
+__device__ __forceinline__ unsigned FcShlOr1(unsigned e, unsigned f) {
+  unsigned r;
+  asm("v_lshl_or_b32 %0, %1, 1, %2" : "=v"(r) : "v"(e), "v"(f));
+  return r;
+}
+// a + (low half of b);  (low half of a) + (high half of b);  a + (high half of b): one instruction each
+__device__ __forceinline__ unsigned FcAddLo(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_0" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ unsigned FcAddLoHi(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:WORD_1" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ unsigned FcAddHi(unsigned a, unsigned b) {
+  unsigned r;
+  asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+template <int B>
+__device__ __forceinline__ unsigned FcByte(unsigned w) {
+  if (B == 0) return w & 255u;
+  if (B == 3) return w >> 24;
+  return __builtin_amdgcn_ubfe(w, 8 * B, 8);
+}
+__device__ __forceinline__ unsigned FcDppScanAdd(unsigned x) {
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, true);
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, true);
+  return x;
+}
+// inclusive running maximum over the 64 lanes (values >= 0)
+__device__ __forceinline__ int FcWaveScanMax(int v, int lane) {
+  int x = v;
+#pragma unroll
+  for (int d = 1; d < 64; d <<= 1) {
+    const int y = __shfl_up(x, d, 64);
+    if (lane >= d) x = x > y ? x : y;
+  }
+  return x;
+}
+
+// [Measured and rejected, round 5: a look-back that asks for 4 (or 8) windows of 64 descriptors per poll instead of one.  The look-back is
+// what a tile waits for longest (`\\[(INFO|WARN|ERROR)\\]` over 1.6 GiB: 0.96 ms with it, 0.51 ms with the bases made up), but not because
+// the prefixes propagate too slowly: with 4 windows in flight the same scan took 1.16 ms, with 8 windows 1.5 -- the polls of a hundred
+// thousand tiles then read 4-8 times as many descriptor lines, and those lines are the ones the counts are being stored to.]
+// The capture groups of ONE match out of the plain tables in memory (the rare lane whose fast walk assigned a group behind the end of its
+// match: the continuation it tried did not match).  The one-pass walk of rgx_kernels.hip: ResolveCapturesOnePass.
+__device__ __forceinline__ void FcResolveSlow(const FcSlowPtrs* sp, const uint8_t* buf, int s, int e, Lds32w recw) {
+  const FcSlowPtrs& S = *sp;
+  const int unset = S.unmatched_minus1 ? -1 : 0;
+  for (int c = 2; c < S.ncap; ++c) recw[(c - 2) * kFcThreads] = (unsigned)unset;
+  auto apply = [&](unsigned o, int pos) {
+    o &= ~3u;
+    while (o) { const int c = __builtin_ctz(o); o &= o - 1; recw[(c - 2) * kFcThreads] = (unsigned)pos; }
+  };
+  const int ctx = s == 0 ? kCtxBOT : (S.ctx_sensitive ? (int)S.ctx_of_byte[buf[s - 1]] : kCtxOther);
+  unsigned q = S.start[ctx];
+  const unsigned sbase = S.start_ops[ctx];
+  unsigned prev_base = 0;
+  for (int i = 0; i < e - s; ++i) {
+    const unsigned cell = q * S.stride + S.cls[buf[s + i]];
+    const unsigned base = S.bt_base[cell];
+    const unsigned P = S.bt_parent[base];
+    apply(i == 0 ? S.start_ops_pool[sbase + P] : S.bt_ops[prev_base + P], s + i);
+    prev_base = base;
+    q = S.trans_cls[cell] & kStateMask;
+  }
+  apply(S.bt_ops[prev_base + S.st_nthreads[q] - 1], e);
+}
+
+// PER: dwords between two harvests of the accept history (4 * PER <= 33 - K); W16: 16-bit Shift-Or words (K <= 16).
+// MODE 1: the walk finds the match end only (records from the capture template, (start, end) pairs for the capture pass, starts, counts);
+// MODE 2: one-pass automata -- the walk also resolves the capture groups.
+template <int PER, bool W16, int MODE>
+__global__ __launch_bounds__(kFcThreads) void scan_fc_kernel(FcParams P) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // (the dynamic segment is the kernel's only LDS: it begins at LDS address 0, which is what lets the tables be addressed by
+  // compile-time constants and the image carry LDS addresses; checked)
+  const unsigned lds0 = (unsigned)(uintptr_t)(const unsigned char __attribute__((address_space(3)))*)smem;
+  const int K = P.K;
+  const int len = P.len;
+  const int ncap = P.ncap;
+  unsigned* const misc = reinterpret_cast<unsigned*>(smem + kMisc);
+  // misc: [0] tile  [2] P0  [3] chain conflict inside a wave  [4] the call is void already  [8..) candidates per wave
+  // [16..) reported matches per stretch  [24..) largest end per stretch  [32..) smallest successful start per stretch  [40..41] base
+  const bool tickets = (P.flags & kFcTickets) != 0;
+  const bool count_only = (P.flags & kFcCountOnly) != 0;
+
+  int tile = (int)blockIdx.x;
+  if (tid == 0) {
+    misc[4] = (__hip_atomic_load(&P.counters[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kFcGaveUp) | (lds0 != 0u ? 1u : 0u);
+    misc[3] = 0;
+    if (lds0 != 0u) atomicOr(&P.counters[2], kFcGaveUp | 8u);
+  }
+  if (tickets) {
+    if (tid == 0) misc[0] = atomicAdd(&P.counters[0], 1u);
+    __syncthreads();
+    tile = (int)misc[0];
+  }
+  if (tile >= P.ntiles) return;
+  const int tb = tile * kFcOwnBytes;                         // first owned byte
+  const int wb = tb - kFcHalo * kSliceBytes;                 // first byte of the window (negative for tile 0)
+  // A tile outside the shard's owned range (the halos of a window: a MiB on the right) reports nothing: its count is zero, nothing is
+  // loaded or walked; the last tile still resolves its look-back, for the total.
+  if (tb >= P.own_hi || tb + kFcOwnBytes <= P.own_lo) {      // uniform
+    if (wave == 0 && !count_only) {
+      if (tile == P.ntiles - 1 || (tile & 63) == 63) {
+        const unsigned long long ex = LookBack(P.desc, tile, 0ull, lane, &P.counters[3], 1, nullptr, !tickets);
+        if (lane == 0 && tile == P.ntiles - 1) *P.total = ex;
+      } else {
+        LookBackPublish(P.desc, tile, 0ull, lane);
+      }
+    }
+    return;
+  }
+
+  // ---- the window's loads first (HBM round trip), the program's LDS image behind them (L2: the same few KiB for every workgroup)
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(P.buf), 0, (len + 15) & ~15, 0x00020000);
+  v4u pv[4];                                                  // the window as 16-byte chunks, chunk c = tid + k * threads
+  {
+    const int vo = wb + (tid << 4);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pv[k] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, vo + k * (kFcThreads << 4), 0, 0);
+  }
+  {
+    const v4u* const ga = reinterpret_cast<const v4u*>(P.img);
+    if (tid < kFixedBytes / 16) *reinterpret_cast<v4u*>(smem + (tid << 4)) = ga[tid];
+    const v4u* const gb = reinterpret_cast<const v4u*>(P.img + kFixedBytes);
+    const int nb = P.b_bytes >> 4;
+    for (int c = tid; c < nb; c += kFcThreads) *reinterpret_cast<v4u*>(smem + kCellsOff + (c << 4)) = gb[c];
+  }
+  unsigned char* const rows = smem + P.rows_off;
+  const unsigned rows_at = (unsigned)P.rows_off;
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const int c = tid + k * kFcThreads;
+    *reinterpret_cast<v4u*>(rows + (c >> 2) * kFcRowBytes + ((c & 3) << 4)) = pv[k];
+  }
+  __syncthreads();                                                                        // B0
+  if (misc[4] != 0) {                                        // the call is void already: be out of the way (successors still find a count)
+    if (wave == 0) LookBackPublish(P.desc, tile, 0ull, lane);
+    return;
+  }
+#ifdef RGX_EXPERIMENT
+  const unsigned dbg = P.flags >> 8;
+  if (dbg == 1) { if (wave == 0) LookBackPublish(P.desc, tile, 0ull, lane); if (tid == 0 && tile == P.ntiles - 1) *P.total = 0; return; }
+#endif
+
+  unsigned short* const list = reinterpret_cast<unsigned short*>(smem + kList);
+  const unsigned rec_at = (unsigned)P.rec_off + ((unsigned)tid << 2);                 // slot c of this lane: rec_at + (c - 2) * lanes * 4
+  const Lds32w recw = (Lds32w)(uintptr_t)rec_at;
+  const int unset = (P.flags & kFcMinus1) ? -1 : 0;
+  const int nla = (K + 2) >> 2;                                // look-ahead dwords: ceil((K - 1) / 4)
+  const unsigned dead_row = (unsigned)kCellsOff;               // state 0's row of cells
+
+  // ---- filter: candidate mask of this lane's slice (the byte loop of rgx_scan_exact.hip, look-ahead from the next row)
+  const int a = wb + tid * kSliceBytes;
+  unsigned long long cur = 0;
+  {
+    const uint4* row = reinterpret_cast<const uint4*>(rows + tid * kFcRowBytes);
+    const uint4 r0 = row[0], r1 = row[1], r2 = row[2], r3 = row[3];
+    const uint4 n0 = row[5], n1 = row[6];
+    unsigned E = ~0u, det0 = 0, det1 = 0, det2 = ~0u;
+    const int hsh = 33 - K - 4 * PER;
+    const unsigned tsh = W16 ? 1u : 2u;
+#define FC_LU(W, B)                                                                                            \
+  (W16 ? (unsigned)*(Lds16c)(uintptr_t)(FcByteTimes<B>(W, tsh) + (unsigned)kSa)                                 \
+       : *(Lds32c)(uintptr_t)(FcByteTimes<B>(W, tsh) + (unsigned)kSa))
+#define FC_WORD(W)                                          \
+    {                                                       \
+      E = FcShlOr1(E, FC_LU(W, 0));                         \
+      E = FcShlOr1(E, FC_LU(W, 1));                         \
+      E = FcShlOr1(E, FC_LU(W, 2));                         \
+      E = FcShlOr1(E, FC_LU(W, 3));                         \
+    }
+#define FC_HARVEST(DET, NBITS) DET = __builtin_amdgcn_alignbit(DET, E << (33 - K - (NBITS)), 32 - (NBITS));
+#define FC_STEPW(W, IDX, DET)                                                     \
+    FC_WORD(W)                                                                    \
+    if (((IDX) + 1) % PER == 0) { DET = __builtin_amdgcn_alignbit(DET, E << hsh, 32 - 4 * PER); }
+    FC_STEPW(r0.x, 0, det0) FC_STEPW(r0.y, 1, det0) FC_STEPW(r0.z, 2, det0) FC_STEPW(r0.w, 3, det0)
+    FC_STEPW(r1.x, 4, det0) FC_STEPW(r1.y, 5, det0) FC_STEPW(r1.z, 6, det0) FC_STEPW(r1.w, 7, det0)
+    FC_STEPW(r2.x, 8, det1) FC_STEPW(r2.y, 9, det1) FC_STEPW(r2.z, 10, det1) FC_STEPW(r2.w, 11, det1)
+    FC_STEPW(r3.x, 12, det1) FC_STEPW(r3.y, 13, det1) FC_STEPW(r3.z, 14, det1) FC_STEPW(r3.w, 15, det1)
+#define FC_LA(W, J)                                                               \
+    if (nla > (J)) {                                                              \
+      FC_WORD(W)                                                                  \
+      if (((J) + 1) % PER == 0) { det2 = __builtin_amdgcn_alignbit(det2, E << hsh, 32 - 4 * PER); } \
+      else if (nla == (J) + 1) { FC_HARVEST(det2, 4 * (((J) % PER) + 1)) }       \
+    }
+    FC_LA(n0.x, 0) FC_LA(n0.y, 1) FC_LA(n0.z, 2) FC_LA(n0.w, 3)
+    FC_LA(n1.x, 4) FC_LA(n1.y, 5) FC_LA(n1.z, 6)
+#undef FC_LA
+#undef FC_STEPW
+#undef FC_HARVEST
+#undef FC_WORD
+#undef FC_LU
+    const unsigned p0 = __builtin_bitreverse32(~det0);
+    const unsigned p1 = __builtin_bitreverse32(~det1);
+    const unsigned p2 = nla ? __builtin_bitreverse32(~det2 << (32 - 4 * nla)) : 0u;
+    const unsigned lo = K > 1 ? __builtin_amdgcn_alignbit(p1, p0, K - 1) : p0;
+    const unsigned hi = K > 1 ? __builtin_amdgcn_alignbit(p2, p1, K - 1) : p1;
+    cur = ((unsigned long long)hi << 32) | lo;
+    const int nvalid = len - K - a + 1;                      // a match needs at least K bytes
+    if (a < 0 || nvalid <= 0 || tid == kFcRows - 1) cur = 0;
+    else if (nvalid < 64) cur &= (1ull << nvalid) - 1ull;
+  }
+
+  // ---- the chain's entry: behind the nearest reset byte of the halo (offset 0 of the text is one); the halo's candidates in front
+  // of it are not part of the chain.  Wave 0 alone needs it now (its first lanes are the halo), the others after the walk.
+  if (wave == 0) {
+    int p0s = wb <= 0 ? 0 : -1;
+    if (p0s < 0) {
+      for (int blk = 0; blk < kFcHalo && p0s < 0; ++blk) {
+        const int rel = kFcHalo * kSliceBytes - 1 - blk * 64 - lane;        // nearest byte first
+        const unsigned b = rows[(rel >> 6) * kFcRowBytes + (rel & 63)];
+        const unsigned long long m = __ballot(smem[kReset + b] != 0);
+        if (m) p0s = wb + kFcHalo * kSliceBytes - blk * 64 - __builtin_ctzll(m);
+      }
+    }
+    if (lane == 0) {
+      misc[2] = (unsigned)p0s;
+      if (p0s < 0) atomicOr(&P.counters[2], kFcGaveUp | 1u);
+    }
+    if (p0s < 0) cur = 0;
+    else if (tid < kFcHalo) {
+      const int d = p0s - a;
+      if (d >= 64) cur = 0;
+      else if (d > 0) cur &= ~0ull << d;
+    }
+  }
+  // ---- the wave's candidates, in position order, into the wave's own segment of the list
+  const unsigned ccnt = (unsigned)__popcll(cur);
+  const unsigned cincl = FcDppScanAdd(ccnt);
+  const unsigned wtot = (unsigned)__builtin_amdgcn_readlane((int)cincl, 63);
+  if (wtot <= (unsigned)kFcSeg) {
+    unsigned long long m = cur;
+    unsigned k = (unsigned)wave * kFcSeg + cincl - ccnt;
+    while (m) {
+      list[k++] = (unsigned short)(tid * kSliceBytes + __builtin_ctzll(m));
+      m &= m - 1;
+    }
+  }
+  if (lane == 0) misc[8 + wave] = wtot;
+  __syncthreads();                                                                        // B1
+#ifdef RGX_EXPERIMENT
+  if (dbg == 2) { if (wave == 0) LookBackPublish(P.desc, tile, 0ull, lane); if (tid == 0 && tile == P.ntiles - 1) *P.total = 0; return; }
+#endif
+  const int P0 = (int)misc[2];
+  unsigned ntot = 0;
+  unsigned segbase[kFcWaves];    // first list index of every wave's segment
+  bool seg_over = false;
+#pragma unroll
+  for (int w = 0; w < kFcWaves; ++w) { segbase[w] = ntot; ntot += misc[8 + w]; seg_over = seg_over || misc[8 + w] > (unsigned)kFcSeg; }
+  if (ntot > (unsigned)kFcCap || seg_over) {                   // uniform
+    if (tid == 0) atomicOr(&P.counters[2], kFcGaveUp | 2u);
+    ntot = 0;
+  }
+  if (P0 < 0) ntot = 0;
+#ifdef RGX_EXPERIMENT
+  if (dbg == 3) ntot = 0;
+#endif
+  const bool two = ntot > (unsigned)kFcThreads;                // uniform: a second round of candidates (the prefilter passes more than lanes)
+
+  // ---- candidates: lane j walks candidate j (and, rarely, candidate j + lanes)
+  const int lim = (len - wb < kFcWinBytes ? len - wb : kFcWinBytes);      // bytes of the window that exist: the fast walk stays inside them
+  auto walk = [&](unsigned j, int& s, int& e) {
+    s = -1; e = -1;
+    if (j >= ntot) return;
+    int seg = 0;
+#pragma unroll
+    for (int w = 1; w < kFcWaves; ++w) if (j >= segbase[w]) seg = w;
+    const int rel0 = (int)list[seg * kFcSeg + (int)(j - segbase[seg])];
+    s = wb + rel0;
+    // start state: by the byte in front (Walk() of rgx_kernels.hip)
+    unsigned ctx = kCtxOther;
+    if (s == 0) ctx = kCtxBOT;
+    else if (P.flags & kFcCtxSens) ctx = smem[kCtx + rows[((rel0 - 1) >> 6) * kFcRowBytes + ((rel0 - 1) & 63)]];
+    unsigned hx = *(Lds32c)(uintptr_t)((unsigned)kSrow + (ctx << 2));        // the state's row of cells (low half)
+    unsigned pw1 = 0;                                                         // low half: the previous edge's slice of the ops pool
+    unsigned mfin = 0;                                                        // cell.x of the last edge that ended a match
+    int elast = -1;                                                           // ... and the offset of its byte
+    if (MODE == 2) {
+      pw1 = *(Lds32c)(uintptr_t)((unsigned)kSslice + (ctx << 2));
+#pragma unroll 4
+      for (int c = 2; c < ncap; ++c) recw[(c - 2) * kFcThreads] = (unsigned)unset;
+    }
+    int rel = rel0;
+    int pos = s;
+    unsigned D = (unsigned)rel >> 2;
+    const unsigned sh = (unsigned)rel & 3u;
+    const unsigned Dmax = (unsigned)(kFcRows * 16 - 1);
+    auto dw = [&](unsigned d) -> unsigned {
+      d = d < Dmax ? d : Dmax;
+      return *(Lds32c)(uintptr_t)(rows_at + (d << 2) + (d & ~15u));
+    };
+    // The walk is a chain of DEPENDENT look-ups -- the cell of byte i names the row of byte i + 1 -- and an LDS round trip is ~100 cycles,
+    // so what a step may wait for is ONE round trip: the classes of a trip's four bytes are asked for a trip ahead (they depend on the
+    // bytes alone); the ops word of the edge just taken and the NEXT byte's cell are asked for together; and the record slots of a step are
+    // written behind the reads of the step after it (a write in front of them would hold them back: they might alias).
+    unsigned w0 = dw(D), w1 = dw(D + 1), w2 = dw(D + 2);
+    unsigned b4 = __builtin_amdgcn_alignbyte(w1, w0, sh);
+    unsigned c0 = *(Lds8c)(uintptr_t)(FcByte<0>(b4) + (unsigned)kCls8), c1 = *(Lds8c)(uintptr_t)(FcByte<1>(b4) + (unsigned)kCls8);
+    unsigned c2 = *(Lds8c)(uintptr_t)(FcByte<2>(b4) + (unsigned)kCls8), c3 = *(Lds8c)(uintptr_t)(FcByte<3>(b4) + (unsigned)kCls8);
+    unsigned po = (unsigned)((ncap - 2) * kFcThreads * 4) * 0x10001u;         // the ops word whose slots are still to be written ("none": scrap twice)
+    int ppk = 0;                                                              // ... and the offset they get
+    int steps = 0;
+#define FC_CELL(H, CK) const FcCell H = *(LdsCell)(uintptr_t)FcAddLo(CK, hx);
+#define FC_AFTER(H, KK)                                                                                 \
+      {                                                                                                 \
+        const int pk = pos + (KK);                                                                      \
+        unsigned o = 0;                                                                                 \
+        if (MODE == 2) o = *(Lds32c)(uintptr_t)FcAddLoHi(pw1, H.y);                                     \
+        if ((int)H.x < 0) { elast = pk; mfin = H.x; }                                                   \
+        hx = H.x;                                                                                       \
+        if (MODE == 2) { pw1 = H.y; po = o; ppk = pk; }                                                 \
+      }
+#define FC_WRITE()                                                                                      \
+      if (MODE == 2) {                                                                                  \
+        *(Lds32w)(uintptr_t)FcAddLo(rec_at, po) = (unsigned)ppk;                                        \
+        *(Lds32w)(uintptr_t)FcAddHi(rec_at, po) = (unsigned)ppk;                                        \
+      }
+    while ((hx & 0xFFFFu) != dead_row && rel + 4 <= lim) {
+      // the next trip's bytes and their classes
+      ++D;
+      const unsigned w3 = dw(D + 2);
+      const unsigned b4n = __builtin_amdgcn_alignbyte(w2, w1, sh);
+      w1 = w2; w2 = w3;
+      const unsigned n0 = *(Lds8c)(uintptr_t)(FcByte<0>(b4n) + (unsigned)kCls8), n1 = *(Lds8c)(uintptr_t)(FcByte<1>(b4n) + (unsigned)kCls8);
+      const unsigned n2 = *(Lds8c)(uintptr_t)(FcByte<2>(b4n) + (unsigned)kCls8), n3 = *(Lds8c)(uintptr_t)(FcByte<3>(b4n) + (unsigned)kCls8);
+      FC_CELL(h0, c0)
+      FC_WRITE()                    // (the last step of the trip before)
+      FC_AFTER(h0, 0)
+      FC_CELL(h1, c1)
+      FC_WRITE()
+      FC_AFTER(h1, 1)
+      FC_CELL(h2, c2)
+      FC_WRITE()
+      FC_AFTER(h2, 2)
+      FC_CELL(h3, c3)
+      FC_WRITE()
+      FC_AFTER(h3, 3)
+      c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+      pos += 4; rel += 4; steps += 4;
+      if (steps > kFcMaxSteps) break;
+    }
+    if (MODE == 2) {                                           // the slots of the last step taken
+      *(Lds32w)(uintptr_t)FcAddLo(rec_at, po) = (unsigned)ppk;
+      *(Lds32w)(uintptr_t)FcAddHi(rec_at, po) = (unsigned)ppk;
+    }
+#undef FC_CELL
+#undef FC_AFTER
+#undef FC_WRITE
+    // the rest byte by byte: the last bytes of the window, and whatever lies behind it (out of memory)
+    if ((hx & 0xFFFFu) != dead_row && steps <= kFcMaxSteps) {
+      while ((hx & 0xFFFFu) != dead_row && pos < len && steps <= kFcMaxSteps) {
+        const unsigned b1 = (unsigned)rel < (unsigned)kFcWinBytes ? rows[(rel >> 6) * kFcRowBytes + (rel & 63)] : P.buf[pos];
+        const unsigned ck = *(Lds8c)(uintptr_t)(b1 + (unsigned)kCls8);
+        const FcCell h = *(LdsCell)(uintptr_t)FcAddLo(ck, hx);
+        if (MODE == 2) {
+          const unsigned o = *(Lds32c)(uintptr_t)FcAddLoHi(pw1, h.y);
+          *(Lds32w)(uintptr_t)FcAddLo(rec_at, o) = (unsigned)pos;
+          *(Lds32w)(uintptr_t)FcAddHi(rec_at, o) = (unsigned)pos;
+          pw1 = h.y;
+        }
+        if ((int)h.x < 0) { elast = pos; mfin = h.x; }
+        hx = h.x;
+        ++pos; ++rel; ++steps;
+      }
+    }
+    if (steps > kFcMaxSteps && (hx & 0xFFFFu) != dead_row) {
+      atomicOr(&P.counters[2], kFcGaveUp | 4u);
+      elast = -1;
+    }
+    e = elast >= 0 ? elast + 1 : -1;
+    if (MODE == 2 && e >= 0) {
+      // A group assigned at or behind the end of the match belongs to a continuation that did not match (`host:` without a digit): its
+      // slot holds an offset >= e.  Rare: such a match is resolved again, alone, out of the tables in memory.
+      int top = 0;
+#pragma unroll 4
+      for (int c = 2; c < ncap; ++c) { const int v = (int)recw[(c - 2) * kFcThreads]; top = v > top ? v : top; }
+      if (top >= e) {
+        FcResolveSlow(reinterpret_cast<const FcSlowPtrs*>(P.img + kFixedBytes + P.b_bytes), P.buf, s, e, recw);
+      } else {
+        const unsigned fo = *(Lds32c)(uintptr_t)((mfin >> 16) & 0x7FFFu);       // the Match thread's groups end here
+        *(Lds32w)(uintptr_t)FcAddLo(rec_at, fo) = (unsigned)e;
+        *(Lds32w)(uintptr_t)FcAddHi(rec_at, fo) = (unsigned)e;
+      }
+    }
+  };
+  int sr[kFcRounds], er[kFcRounds];
+  int keep[kFcKeep];               // the groups of the first round's record while the second round uses the lane's record slots
+  walk((unsigned)tid, sr[0], er[0]);
+  sr[1] = -1; er[1] = -1;
+  if (two) {
+    if (MODE == 2) {
+#pragma unroll
+      for (int c = 0; c < kFcKeep; ++c) if (c < ncap - 2) keep[c] = (int)recw[c * kFcThreads];
+    }
+    walk((unsigned)tid + kFcThreads, sr[1], er[1]);
+  }
+
+  // ---- chain: a successful candidate is reported iff no earlier reported match covers its start.  Every wave decides for its own
+  // candidates (of a round) as if nothing reached into them from an earlier stretch; whether something did is known behind the barrier.
+  // Stretch r * waves + w = the candidates of wave w in round r: the list in position order.
+  bool acc[kFcRounds], mine[kFcRounds];
+  unsigned long long mb[kFcRounds];
+#pragma unroll
+  for (int r = 0; r < kFcRounds; ++r) {
+    const bool ok = er[r] >= 0;
+    const int incl = FcWaveScanMax(ok ? er[r] : 0, lane);
+    int excl = __shfl_up(incl, 1, 64);
+    if (lane == 0) excl = 0;
+    const int M = P0 > excl ? P0 : excl;
+    acc[r] = ok && sr[r] >= M;
+    const unsigned long long okb = __ballot(ok);
+    if (__ballot(ok && sr[r] < M) != 0ull && lane == 0) misc[3] = 1;
+    mine[r] = acc[r] && sr[r] >= tb && sr[r] >= P.own_lo && sr[r] < P.own_hi;     // (s < tb + own: lanes of the owned slices only)
+    mb[r] = __ballot(mine[r]);
+    if (lane == 0) {
+      const int st = r * kFcWaves + wave;
+      misc[16 + st] = (unsigned)__popcll(mb[r]);
+      misc[24 + st] = (unsigned)__builtin_amdgcn_readlane(incl, 63);
+      misc[32 + st] = okb ? (unsigned)__builtin_amdgcn_readlane(sr[r], __builtin_ctzll(okb)) : 0x7FFFFFFFu;
+    }
+    if (!two) break;
+  }
+  __syncthreads();                                                                        // B2
+  const int nst = two ? kFcRounds * kFcWaves : kFcWaves;
+  bool conflict = misc[3] != 0;
+  {
+    int run = 0;
+    for (int st = 0; st < nst; ++st) {
+      if ((int)misc[32 + st] < run) conflict = true;
+      const int t = (int)misc[24 + st];
+      run = t > run ? t : run;
+    }
+  }
+  if (conflict) {                                              // uniform; rare: some candidate starts inside an earlier one's match
+    // (the walks are over: the tile's rows are free to hold the list of (start, end))
+    int* const cs = reinterpret_cast<int*>(rows);
+    int* const ce = cs + kFcCap;
+#pragma unroll
+    for (int r = 0; r < kFcRounds; ++r) { cs[tid + r * kFcThreads] = sr[r]; ce[tid + r * kFcThreads] = er[r]; }
+    __syncthreads();
+    if (tid == 0) {
+      int pos = P0;
+      for (unsigned j = 0; j < ntot; ++j) {
+        const int sj = cs[j], ej = ce[j];
+        if (ej >= 0 && sj >= pos) pos = ej; else ce[j] = -1;
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < kFcRounds; ++r) {
+      acc[r] = er[r] >= 0 && ce[tid + r * kFcThreads] >= 0;
+      mine[r] = acc[r] && sr[r] >= tb && sr[r] >= P.own_lo && sr[r] < P.own_hi;
+      mb[r] = __ballot(mine[r]);
+      if (lane == 0) misc[16 + r * kFcWaves + wave] = (unsigned)__popcll(mb[r]);
+    }
+    __syncthreads();
+  }
+  unsigned offr[kFcRounds] = {0, 0}, ttot = 0;
+  for (int st = 0; st < nst; ++st) {
+    const unsigned t = misc[16 + st];
+    if (st < wave) offr[0] += t;
+    if (st < kFcWaves + wave) offr[1] += t;
+    ttot += t;
+  }
+  if (count_only) {                                            // (no order wanted: the counts are simply added up)
+    if (tid == 0 && ttot) atomicAdd(P.total, (unsigned long long)ttot);
+    return;
+  }
+  // Nothing to place: the count is out and the workgroup leaves without waiting for its base.  One tile in 64 stays for the look-back all
+  // the same: it leaves an inclusive prefix behind, so that a text WITHOUT matches does not end in one tile (the last) walking back through
+  // a hundred thousand zero counts, one window per round trip (1.1 ms per 1.6 GiB, measured).
+  if (ttot == 0 && tile != P.ntiles - 1 && (tile & 63) != 63) {
+    if (wave == 0) LookBackPublish(P.desc, tile, 0ull, lane);
+    return;
+  }
+  if (wave == 0) {
+    unsigned long long ex = 0;
+#ifdef RGX_EXPERIMENT
+    if (dbg == 4) { LookBackPublish(P.desc, tile, (unsigned long long)ttot, lane); ex = (unsigned long long)tile * 64; } else
+#endif
+    ex = LookBack(P.desc, tile, (unsigned long long)ttot, lane, &P.counters[3], 1, nullptr, !tickets);
+    if (lane == 0) {
+      misc[40] = (unsigned)ex;
+      misc[41] = (unsigned)(ex >> 32);
+      if (tile == P.ntiles - 1) *P.total = ex + ttot;
+    }
+  }
+  __syncthreads();                                                                        // B3
+  const unsigned long long base = ((unsigned long long)misc[41] << 32) | misc[40];
+#ifdef RGX_EXPERIMENT
+  if (dbg == 5) return;
+#endif
+#pragma unroll
+  for (int r = 0; r < kFcRounds; ++r) {
+    if (mine[r]) {
+      const int s = sr[r], e = er[r];
+      const unsigned long long idx = base + offr[r] + (unsigned)__popcll(mb[r] & ((1ull << lane) - 1ull));
+      if (idx < (unsigned long long)P.cap_records) {
+        if (MODE == 2) {
+          // the groups: in the lane's record slots -- but for the first round's record when there was a second one (kept in registers)
+          int g[kFcKeep];
+#pragma unroll
+          for (int c = 0; c < kFcKeep; ++c) g[c] = c < ncap - 2 ? ((r == 0 && two) ? keep[c] : (int)recw[c * kFcThreads]) : 0;
+          int32_t* const rec = P.spans + idx * ncap;
+          if ((ncap & 3) == 0) {
+            int4 v;
+            v.x = s; v.y = e; v.z = g[0]; v.w = g[1];
+            *reinterpret_cast<int4*>(rec) = v;
+#pragma unroll
+            for (int c = 4; c < kFcKeep + 2; c += 4) {
+              if (c < ncap) {
+                v.x = g[c - 2]; v.y = g[c - 1]; v.z = g[c]; v.w = g[c + 1];
+                *reinterpret_cast<int4*>(rec + c) = v;
+              }
+            }
+          } else {
+            rec[0] = s; rec[1] = e;
+#pragma unroll
+            for (int c = 2; c < kFcKeep + 2; ++c) if (c < ncap) rec[c] = g[c - 2];
+          }
+        } else if (P.flags & kFcStartsOnly) {
+          P.spans[idx] = s;
+        } else if (P.flags & kFcFixedCaps) {
+          int32_t* const rec = P.spans + idx * ncap;
+          const int* const delta = reinterpret_cast<const int*>(smem + kDelta);
+          for (int c = 0; c < ncap; ++c) rec[c] = smem[kKind + c] == kCapFromStart ? s + delta[c] : e - delta[c];
+        } else {
+          int32_t* const rec = P.pairs ? P.pairs + idx * 2 : P.spans + idx * ncap;
+          rec[0] = s; rec[1] = e;
+        }
+      }
+    }
+    if (!two) break;
+  }
+}
+
+}  // namespace
+
+int FcTileBytes() { return kFcOwnBytes; }
+int32_t FcNumTiles(int32_t len) { return (int32_t)(((int64_t)len + kFcOwnBytes - 1) / kFcOwnBytes); }
+
+// 0: not this kernel; 1: the walk finds the ends (fixed capture template, pairs for the capture pass, counts); 2: one-pass automaton,
+// groups resolved in the walk.  DevTables::fc_mode / fc: the pattern's side of it (rgx_program.cc: selectivity of the level sets, the
+// LDS image).
+int UseFcKernel(const DevTables& T, int32_t len) {
+  static const bool off = getenv("RGX_NO_FC_KERNEL") != nullptr;      // (A/B measurements: both kernels are correct, the switch picks the speed)
+  if (off || T.fc_mode == 0 || T.fc == nullptr || len < 64 || UseExactKernel(T, len)) return 0;
+  return T.fc->mode;
+}
+
+hipError_t LaunchScanFc(const DevTables& T, const ScanParams& S, int mode, hipStream_t stream) {
+  const FcDev& F = *T.fc;
+  const int K = T.sa_k;
+  const void* fn;
+  const bool w16 = K <= 16;
+#define FC_PICK(M)                                                                                                   \
+  (w16 ? (const void*)scan_fc_kernel<4, true, M> : K <= 17 ? (const void*)scan_fc_kernel<4, false, M>               \
+       : K <= 25 ? (const void*)scan_fc_kernel<2, false, M> : (const void*)scan_fc_kernel<1, false, M>)
+  fn = mode == 2 ? FC_PICK(2) : FC_PICK(1);
+#undef FC_PICK
+  { const hipError_t ae = AllowBigLds(fn); if (ae != hipSuccess) return ae; }
+  FcParams P{};
+  P.buf = S.buf; P.img = F.img; P.spans = S.spans; P.pairs = S.pairs; P.desc = S.tile_desc; P.counters = S.counters; P.total = S.total;
+  P.cap_records = S.cap_records;
+  P.len = S.len; P.ntiles = S.ntiles; P.own_lo = S.own_lo; P.own_hi = S.own_hi;
+  P.b_bytes = F.b_bytes; P.rows_off = F.rows_off; P.rec_off = F.rec_off; P.ops_bytes = F.ops_bytes;
+  P.K = K; P.ncap = T.ncap;
+  P.flags = (S.count_only ? kFcCountOnly : 0u) | (S.starts_only ? kFcStartsOnly : 0u) | (S.use_tickets ? kFcTickets : 0u) |
+            (T.fixed_captures ? kFcFixedCaps : 0u) | (T.ctx_sensitive ? kFcCtxSens : 0u) | (T.unmatched_minus1 ? kFcMinus1 : 0u);
+  if (const char* e = ExpEnv("RGX_FC_DEBUG")) P.flags |= (uint32_t)atoi(e) << 8;
+  void* args[] = {(void*)&P};
+  return hipLaunchKernel(fn, dim3(S.ntiles < 1 ? 1 : S.ntiles), dim3(kFcThreads), args, (size_t)F.lds_total, stream);
+}
+
+}  // namespace rgx

@@ -67,7 +67,7 @@ def _texts(rng, alphabet, sizes):
 def test_us_kernels_equal_oracle(torch_dev, pattern, kernel, alphabet):
     from oracle.gen_c import CMatcher
     from regengo_amd import Compiled, _capi
-    c = Compiled(pattern).to(0)
+    c = Compiled(pattern, no_prefilter_scan=True).to(0)      # (the kernels under test, not rgx_scan_fc.hip: tests/test_gpu_fc.py)
     if kernel is not None:
         assert c.info.scan_kernel == kernel, (pattern, c.info.scan_kernel)
     cm = CMatcher(pattern, q8=False)
@@ -102,7 +102,7 @@ def test_us_kernel_matches_at_tile_and_stretch_borders(torch_dev):
     from oracle.gen_c import CMatcher
     from regengo_amd import Compiled
     for pattern, unit in [(r"(\d+)", b"7"), (r"\w+@\w+", b"a@b"), (r"ab+c|a", b"abbb")]:
-        c = Compiled(pattern).to(0)
+        c = Compiled(pattern, no_prefilter_scan=True).to(0)
         cm = CMatcher(pattern, q8=False)
         for border in (16384, 32768):
             for shift in range(-6, 7):
