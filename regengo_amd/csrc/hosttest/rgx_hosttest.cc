@@ -505,6 +505,38 @@ int rgxt_tdfa_find(void* hh, const uint8_t* buf, int64_t len, int32_t* out) {
   return 0;
 }
 
+// The same find through the merged-attempts automaton (rgx_dfa.h: BuildTdfaMerged), walked as rgx_tdfa.hip: WalkMerged walks it:
+// 1 + out[0..1] = (start, end) of the winning attempt, 0 = no match, -3 = no Tagged DFA / automaton not built / text beyond 255 bytes.
+int rgxt_tdfa_merged_find(void* hh, const uint8_t* buf, int64_t len, int32_t* out) {
+  const RefTdfa& d = ((Handle*)hh)->t.tdfa;
+  if (!d.nstates || len > 255) return -3;
+  bool any_never = !(d.accept[d.start_any] & 3);
+  for (int c = 0; c < 128 && any_never; c++) if (d.trans[(size_t)d.start_any * 128 + c] >= 0) any_never = false;
+  std::vector<unsigned long long> ment;
+  std::vector<uint8_t> mcls8;
+  int ns = 0, ncls = 0, bot = 0;
+  if (!BuildTdfaMerged(d, any_never, &ment, &mcls8, &ns, &ncls, &bot)) return -3;
+  unsigned row = (unsigned)bot, R = 0;
+  int start = 0, end = -1;
+  for (int64_t i = 0; i < len; i++) {
+    const unsigned long long e = ment[(row + mcls8[buf[i]]) / 8];
+    const unsigned x = (unsigned)e, sel = (unsigned)(e >> 32);
+    unsigned nr = 0;
+    for (int j = 0; j < 4; j++) {
+      const unsigned s = (sel >> (8 * j)) & 255u;
+      nr |= (s < 4 ? (R >> (8 * s)) & 255u : (unsigned)i & 255u) << (8 * j);
+    }
+    R = nr;
+    const unsigned fl = i + 1 == len ? x >> 20 : x >> 17;
+    if (fl & 1u) { start = (int)((R >> ((fl & 6u) << 2)) & 255u); end = (int)i + 1; }
+    row = x & 0xFFFFu;
+    if (x & (1u << 16)) break;
+  }
+  if (end < 0) return 0;
+  out[0] = start; out[1] = end;
+  return 1;
+}
+
 int rgxt_ref_find(void* hh, const uint8_t* buf, int64_t len, int32_t* out) {
   const Tables& t = ((Handle*)hh)->t;
   if (t.ref_memo || t.ref_find_engine > 0) return -3;

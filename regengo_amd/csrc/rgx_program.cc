@@ -3,6 +3,8 @@
 #include <algorithm>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <tuple>
 
 #include "rgx.h"
 #include "rgx_tiny.h"
@@ -505,8 +507,19 @@ int UploadTdfa(Program* p) {
       ent[(size_t)q * 128 + c] = e;
     }
   }
+  bool any_never = !(sinfo[r.start_any] & 3u);
+  for (int c = 0; c < 128 && any_never; c++) if (r.trans[(size_t)r.start_any * 128 + c] >= 0) any_never = false;
+  std::vector<unsigned long long> ment;
+  std::vector<uint8_t> mcls8;
+  int m_nstates = 0, m_ncls = 0, m_bot = 0;
+  std::vector<unsigned long long> tent;
+  std::vector<uint32_t> tacc;
+  if (!BuildTdfaMerged(r, any_never, &ment, &mcls8, &m_nstates, &m_ncls, &m_bot, &tent, &tacc)) { ment.assign(1, 0ull); mcls8.assign(256, 0); m_nstates = 0; tent.clear(); }
+  const int tag_packed = tent.empty() ? 0 : 1;
+  if (!tag_packed) { tent.assign(1, 0ull); tacc.assign(1, 0u); }
   Arena a;
   const size_t off_ent = a.AddVec(ent), off_si = a.AddVec(sinfo), off_pool = a.AddVec(r.pool);
+  const size_t off_ment = a.AddVec(ment), off_mcls = a.AddVec(mcls8), off_tent = a.AddVec(tent), off_tacc = a.AddVec(tacc);
   void* dptr = nullptr;
   if (hipMalloc(&dptr, a.host.size()) != hipSuccess) { SetError("hipMalloc(tdfa tables) failed"); return RGX_E_NOMEM; }
   if (hipMemcpy(dptr, a.host.data(), a.host.size(), hipMemcpyHostToDevice) != hipSuccess) { hipFree(dptr); SetError("hipMemcpy(tdfa tables) failed"); return RGX_E_HIP; }
@@ -518,6 +531,10 @@ int UploadTdfa(Program* p) {
   d.sinfo_begin = sinfo[r.start_begin]; d.sinfo_any = sinfo[r.start_any];
   d.any_never = (d.sinfo_any & 3u) ? 0 : 1;
   for (int c = 0; c < 128 && d.any_never; c++) if (r.trans[(size_t)r.start_any * 128 + c] >= 0) d.any_never = 0;
+  d.ment = (const unsigned long long*)(b + off_ment); d.mcls8 = b + off_mcls;
+  d.m_nstates = m_nstates; d.m_ncls = m_ncls; d.m_bot_row = m_bot;
+  d.pool_n = (int32_t)r.pool.size();
+  d.tent = (const unsigned long long*)(b + off_tent); d.tacc = (const uint32_t*)(b + off_tacc); d.tag_packed = tag_packed;
   p->tdfadev = d;
   p->d_arena_tdfa = dptr;
   return RGX_OK;

@@ -194,6 +194,22 @@ struct TdfaDev {
   uint32_t sinfo_begin, sinfo_any;     // sinfo of the two start states
   int32_t any_never;                   // 1: startStateAny neither accepts nor has a transition on any byte -- an attempt behind offset 0 cannot
                                        // match (a pattern that begins with ^): the loop over start offsets is one attempt
+  // The loop over start offsets as ONE forward walk (rgx_program.cc: BuildTdfaMerged; rgx_tdfa.hip: BatchOneMerged): the automaton M whose
+  // state is the list of Tagged-DFA states the attempts still alive are in, oldest start first -- two attempts in one state have one
+  // future, the older stands for both -- plus whether an attempt has accepted yet.  ment[M-state][class], 8 bytes:
+  //   x  [0..15] byte offset of the next M-state's row   [16] nothing alive can change the answer any more   [17] an attempt accepts behind
+  //      this byte: it is slot [18..19] of the new list, the oldest that does   [20] / [21..22] the same counting the end-of-text accepts
+  //      (read at a string's last byte)
+  //   y  v_perm_b32 selector: new slot j = old slot (byte value 0..3) or this byte's offset, a fresh attempt (byte value 4)
+  // mcls8[byte] = class * 8; m_nstates == 0: not built (more than 4 attempts alive at once, a start state that accepts, too many states).
+  const unsigned long long* ment;
+  const uint8_t* mcls8;
+  int32_t m_nstates, m_ncls, m_bot_row;
+  int32_t pool_n;                      // entries of pool
+  // the tag walk's packed table (rgx_dfa.h: BuildTdfaMerged), [nstates][m_ncls] + tacc[nstates]; tag_packed == 0: not representable
+  const unsigned long long* tent;
+  const uint32_t* tacc;
+  int32_t tag_packed;
 };
 
 struct Program {

@@ -449,4 +449,151 @@ bool BuildTinySearch(const Tables& u, const Tables& f, std::vector<uint32_t>* im
   return true;
 }
 
+// The reference's find loop -- for start = 0, 1, ...: walk the Tagged DFA from `start`; the first start whose walk meets an accepting
+// state wins, with its LAST accept (tdfa.go:831-994) -- as one automaton M over byte classes.  At every byte each attempt still alive
+// takes its transition and a fresh attempt begins; attempts that meet in one state merge into the oldest (the automaton is deterministic
+// and acceptance is a property of the state: from there on they accept or fail together, and the oldest start wins either way); once an
+// attempt has accepted, younger ones are dropped and no fresh one begins.  M-state = (the live attempts' states, oldest first; mode:
+// 0 nobody has accepted, 1 the youngest of the list is the attempt that has, 2 that attempt is dead and the list holds older ones;
+// the beginning of the text, whose fresh attempt leaves startStateBegin).  false: not built (rgx_program.h: TdfaDev).
+bool BuildTdfaMerged(const RefTdfa& r, bool any_never, std::vector<unsigned long long>* ment, std::vector<uint8_t>* mcls8, int* m_nstates,
+                     int* m_ncls, int* bot_row, std::vector<unsigned long long>* tent, std::vector<uint32_t>* tacc) {
+  const int S = r.nstates;
+  if (S <= 0 || (r.accept[r.start_begin] & 3) || (r.accept[r.start_any] & 3)) return false;
+  // byte classes: bytes whose columns (next state and tag actions per state) are equal; class 0 = "every attempt dies" (bytes >= 128 among them)
+  std::vector<int> cls_of(256, 0);
+  std::vector<std::vector<int16_t>> cols;          // next state per state
+  std::vector<std::vector<int32_t>> keys;          // ... and the action list with it (the class's identity)
+  std::vector<int> rep;                            // a byte of the class
+  cols.push_back(std::vector<int16_t>(S, -1));
+  keys.push_back(std::vector<int32_t>(2 * S, -1));
+  rep.push_back(-1);
+  for (int b = 0; b < 128; b++) {
+    std::vector<int16_t> col(S);
+    std::vector<int32_t> key(2 * S);
+    bool all_dead = true;
+    for (int q = 0; q < S; q++) {
+      col[q] = r.trans[(size_t)q * 128 + b];
+      key[2 * q] = col[q];
+      key[2 * q + 1] = col[q] < 0 ? -1 : (int32_t)r.act[(size_t)q * 128 + b];
+      all_dead = all_dead && col[q] < 0;
+    }
+    int k = all_dead ? 0 : -1;
+    for (size_t j = 1; j < keys.size() && k < 0; j++) if (keys[j] == key) k = (int)j;
+    if (k < 0) { k = (int)cols.size(); cols.push_back(col); keys.push_back(key); rep.push_back(b); }
+    cls_of[b] = k;
+  }
+  const int ncls = (int)cols.size();
+  // The tag walk's table (rgx_tdfa.hip: TagsPacked): per (state, class) x = next state | the flags of TdfaDev::ent, y = the edge's tag
+  // actions as up to four bytes (tag << 4 | offset; 0xF0 = none); tacc[state] = the state's accept actions the same way.  Left empty when
+  // a list does not fit (more than four actions, a tag beyond 14, an offset beyond 15): the generic walk reads the lists from the pool.
+  if (tent && tacc) {
+    tent->clear(); tacc->clear();
+    bool ok = S * ncls * 8 <= 32768;
+    const uint32_t none4 = (uint32_t)(r.ntags << 4) * 0x01010101u;        // "no action": the scrap column behind the tags
+    ok = ok && r.ntags <= 14;
+    auto pack = [&](int list, uint32_t* out) -> bool {
+      uint32_t w = none4;
+      const int n = list ? r.pool[list] : 0;
+      if (n > 4) return false;
+      for (int a = 0; a < n; a++) {
+        const int tag = r.pool[list + 1 + 2 * a], off = r.pool[list + 2 + 2 * a];
+        if (tag < 0 || tag >= r.ntags || off < 0 || off > 15) return false;
+        w = (w & ~(0xFFu << (8 * a))) | ((uint32_t)(tag << 4 | off) << (8 * a));
+      }
+      *out = w;
+      return true;
+    };
+    std::vector<unsigned long long> te((size_t)S * ncls, 0ull);
+    std::vector<uint32_t> ta(S, none4);
+    for (int q = 0; q < S && ok; q++) {
+      ok = pack(r.acc_act[q], &ta[q]);
+      for (int k = 0; k < ncls && ok; k++) {
+        const int nq = cols[k][q];
+        uint32_t x = 0, y = none4;
+        if (nq < 0) x = 1u << 10;
+        else {
+          x = (uint32_t)nq | ((r.accept[nq] & 1u) ? 1u << 11 : 0u) | ((r.accept[nq] & 2u) ? 1u << 12 : 0u);
+          ok = pack(r.act[(size_t)q * 128 + rep[k]], &y);
+        }
+        te[(size_t)q * ncls + k] = (unsigned long long)x | ((unsigned long long)y << 32);
+      }
+    }
+    if (ok) { *tent = te; *tacc = ta; }
+  }
+  if (ncls > 32) return false;
+  struct MS { std::vector<int> list; int mode; bool bot; };
+  std::vector<MS> ms;
+  std::map<std::tuple<std::vector<int>, int, bool>, int> ids;
+  auto intern = [&](const std::vector<int>& list, int mode, bool bot) -> int {
+    auto key = std::make_tuple(list, mode, bot);
+    auto it = ids.find(key);
+    if (it != ids.end()) return it->second;
+    ms.push_back({list, mode, bot});
+    ids.emplace(key, (int)ms.size() - 1);
+    return (int)ms.size() - 1;
+  };
+  const int bot = intern({}, 0, true);
+  std::vector<unsigned long long> ent;
+  for (size_t x = 0; x < ms.size(); x++) {
+    if (ms.size() > 255) return false;
+    ent.resize((x + 1) * ncls, 0ull);
+    const MS cur = ms[x];
+    for (int k = 0; k < ncls; k++) {
+      // the attempts in front of this byte, oldest first: (state, slot they come from; 4 = fresh)
+      std::vector<std::pair<int, int>> cand;
+      for (size_t j = 0; j < cur.list.size(); j++) cand.push_back({cur.list[j], (int)j});
+      if (cur.mode == 0 && (cur.bot || !any_never)) cand.push_back({cur.bot ? r.start_begin : r.start_any, 4});
+      std::vector<int> nl, par;
+      int best_slot = -1;                          // where the attempt that has accepted (mode 1: the last of the list) goes
+      for (size_t j = 0; j < cand.size(); j++) {
+        const int nq = cols[k][cand[j].first];
+        if (nq < 0) continue;
+        bool dup = false;
+        for (int have : nl) dup = dup || have == nq;
+        if (dup) continue;                         // an older attempt is in this state: it stands for both
+        if (cur.mode == 1 && j + 1 == cur.list.size() && cand[j].second != 4) best_slot = (int)nl.size();
+        nl.push_back(nq); par.push_back(cand[j].second);
+      }
+      int a = -1, a_eot = -1;
+      for (size_t j = 0; j < nl.size(); j++) {
+        if (a < 0 && (r.accept[nl[j]] & 1)) a = (int)j;
+        if (a_eot < 0 && (r.accept[nl[j]] & 3)) a_eot = (int)j;
+      }
+      // (an end-of-text accept of an attempt younger than the one that accepts anyway does not count)
+      if (a >= 0 && a_eot > a) a_eot = a;
+      if (cur.mode == 1 && best_slot >= 0) { /* the attempt that has accepted is alive: attempts behind it were dropped when it did */ }
+      int nmode = cur.mode;
+      std::vector<int> keep = nl;
+      if (a >= 0) { keep.resize(a + 1); nmode = 1; }
+      else if (cur.mode == 1) {
+        // nobody accepts on this byte; is the attempt that has still there?  (it is the last of the list, if alive and not merged away)
+        if (best_slot < 0) nmode = 2;
+        else if (best_slot + 1 < (int)keep.size()) return false;      // (cannot be: nothing is younger than it)
+      }
+      if ((int)nl.size() > 4) return false;
+      const bool fresh_possible = nmode == 0 && !any_never;
+      const bool done = keep.empty() ? !fresh_possible || nmode != 0 : false;
+      const int nx = intern(keep, keep.empty() && nmode == 1 ? 2 : nmode, false);
+      unsigned sel = 0;
+      for (size_t j = 0; j < 4; j++) sel |= (unsigned)(j < par.size() ? par[j] : 0) << (8 * j);
+      unsigned lo = (unsigned)nx;                  // (row offsets filled in below)
+      if (done) lo |= 1u << 16;
+      if (a >= 0) lo |= (1u << 17) | ((unsigned)a << 18);
+      if (a_eot >= 0) lo |= (1u << 20) | ((unsigned)a_eot << 21);
+      ent[x * ncls + k] = (unsigned long long)lo | ((unsigned long long)sel << 32);
+    }
+  }
+  if ((size_t)ms.size() * ncls * 8 > 40000) return false;
+  for (auto& e : ent) {
+    const unsigned nx = (unsigned)(e & 0xFFFFu);
+    e = (e & ~0xFFFFull) | (unsigned long long)(nx * (unsigned)ncls * 8u);
+  }
+  mcls8->assign(256, 0);
+  for (int b = 0; b < 256; b++) (*mcls8)[b] = (uint8_t)(cls_of[b] * 8);
+  *ment = ent; *m_nstates = (int)ms.size(); *m_ncls = ncls; *bot_row = bot * ncls * 8;
+  return true;
+}
+
+
 }  // namespace rgx

@@ -79,9 +79,9 @@ __device__ __forceinline__ int AttemptEnd(EntP ent, BufP buf, int len, int start
 // The same with the tag file (LDS, one column per lane: tag t of lane l at tags[t * 256 + l]) and the result construction.
 // Returns the end (>= 0: out[0 .. ntags) holds the reported tags) or -1.  Only called for attempts known to accept -- the walk
 // stops at `stop` = the end found by AttemptEnd (the snapshot of the last accept is the tag file right there).
-template <class EntP, class BufP>
-__device__ __forceinline__ void AttemptTags(EntP ent, const int16_t* pool, BufP buf, int len, int start, int stop, int st,
-                                            int init_list, int ntags, int TDFA_LDS* tags, int32_t* out, const uint32_t* sinfo) {
+template <class EntP, class BufP, class PoolP = const int16_t*, class SinfoP = const uint32_t*>
+__device__ __forceinline__ void AttemptTags(EntP ent, PoolP pool, BufP buf, int len, int start, int stop, int st,
+                                            int init_list, int ntags, int TDFA_LDS* tags, int32_t* out, SinfoP sinfo) {
   for (int t = 0; t < ntags; ++t) tags[t * 256] = -1;
   tags[0] = start;
   for (int a = 0, n = pool[init_list]; a < n; ++a) tags[pool[init_list + 1 + 2 * a] * 256] = start;
@@ -334,8 +334,8 @@ __global__ __launch_bounds__(256) void tdfa_tags_kernel(TdfaDev D, const uint8_t
 // attempt's result is its last accept so far.  `(\w+)@(\w+)` over a word: the second start is cut after one step.
 template <class EntP, class BufP>
 __device__ __forceinline__ void BatchOne(const TdfaDev& D, EntP ent, BufP buf, int len, int TDFA_LDS* tags, uint8_t TDFA_LDS* ring,
-                                         uint8_t* found, int32_t* row_out, uint32_t* flags) {
-  const bool cut = D.nstates <= 255;              // (a state fits the ring's bytes)
+                                         uint8_t* found, int32_t* row_out, uint32_t* flags, bool have_ring = true) {
+  const bool cut = have_ring && D.nstates <= 255;  // (a state fits the ring's bytes; no ring where the merged walk takes all but the longest strings)
   const int last = D.any_never ? 0 : len;         // (a pattern that begins with ^: no attempt behind offset 0 can match)
   const uint32_t fl_any = D.sinfo_any;
   const uint32_t row_any = (uint32_t)D.start_any * 128u;
@@ -401,6 +401,114 @@ __device__ __forceinline__ void BatchOne(const TdfaDev& D, EntP ent, BufP buf, i
                                D.ntags, tags, row_out, D.sinfo);
 }
 
+// The same answer in ONE forward walk over the merged-attempts automaton (rgx_program.h: TdfaDev::ment): a byte costs its class, one
+// 8-byte entry keyed by the state, one v_perm_b32 that moves the live attempts' start offsets (a byte each) to their new slots, and
+// two selects when an attempt accepts -- against a loop over start offsets that a wave runs for its slowest lane (10 M e-mail strings:
+// 145 steps per wave for strings of 24 bytes; 1.0 G VALU + 0.66 G SALU wave-instructions, profiles/r05_sq_tdfa_batch_before.txt).
+// Strings of at most 255 bytes (a start offset is a byte).  Returns through *bs, *be the winning attempt's start and end, or *be < 0.
+__device__ __forceinline__ void WalkMerged(unsigned ment_at, unsigned mcls_at, unsigned bot_row, unsigned buf_at, int len, int* bs, int* be) {
+  typedef unsigned MEnt __attribute__((ext_vector_type(2)));
+  typedef const MEnt TDFA_LDS* EntP;
+  typedef const uint8_t TDFA_LDS* ClsP;
+  typedef const unsigned TDFA_LDS* WordP;
+  unsigned row = bot_row, R = 0;
+  int start = 0, end = -1, i = 0;
+  bool alive = len > 0;
+  // four bytes per trip: their classes depend on the bytes alone (four look-ups in flight together), only the entries wait for one another
+  const unsigned sh = buf_at & 3u;
+  unsigned wa = buf_at & ~3u;
+  unsigned w0 = *(WordP)(uintptr_t)wa, w1 = *(WordP)(uintptr_t)(wa + 4);
+#define TDFA_MSTEP(KK)                                                                     \
+  if (alive) {                                                                             \
+    const MEnt e = *(EntP)(uintptr_t)(ment_at + row + k8[KK]);                             \
+    R = __builtin_amdgcn_perm((unsigned)i, R, e.y);                                        \
+    const unsigned fl = i + 1 == len ? e.x >> 20 : e.x >> 17;                              \
+    if (fl & 1u) { start = (int)((R >> ((fl & 6u) << 2)) & 255u); end = i + 1; }           \
+    row = e.x & 0xFFFFu;                                                                   \
+    ++i;                                                                                   \
+    alive = !(e.x & (1u << 16)) && i < len;                                                \
+  }
+  while (alive) {
+    const unsigned b4 = __builtin_amdgcn_alignbyte(w1, w0, sh);
+    wa += 4;
+    w0 = w1;
+    w1 = *(WordP)(uintptr_t)(wa + 4);                       // (one dword past the string at most: inside the wave's window, which is 16 bytes longer)
+    unsigned k8[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) k8[k] = *(ClsP)(uintptr_t)(mcls_at + ((b4 >> (8 * k)) & 255u));
+    TDFA_MSTEP(0) TDFA_MSTEP(1) TDFA_MSTEP(2) TDFA_MSTEP(3)
+  }
+#undef TDFA_MSTEP
+  *bs = start; *be = end;
+}
+
+// The tag walk of the winning attempt over the packed table (rgx_dfa.h: BuildTdfaMerged): what AttemptTags computes, with ONE dependent
+// look-up per byte -- the entry names the next state, says whether it accepts, and carries the edge's tag actions as bytes (tag << 4 |
+// offset; "none" is the scrap column behind the tags), so the two actions almost every list has are two unconditional stores.
+__device__ __forceinline__ void TagsPacked(unsigned tent_at, unsigned tacc_at, unsigned mcls_at, unsigned ncls8, unsigned buf_at, int len,
+                                           int start, int stop, int st, const int16_t TDFA_LDS* pool, int init_list, int ntags,
+                                           int TDFA_LDS* tags, int32_t* out) {
+  typedef unsigned MEnt __attribute__((ext_vector_type(2)));
+  typedef const MEnt TDFA_LDS* EntP;
+  typedef const uint8_t TDFA_LDS* ClsP;
+  typedef const unsigned TDFA_LDS* WordP;
+  typedef int TDFA_LDS* TagP;
+  for (int t = 0; t < ntags; ++t) tags[t * 256] = -1;
+  tags[0] = start;
+  for (int a = 0, n = pool[init_list]; a < n; ++a) tags[pool[init_list + 1 + 2 * a] * 256] = start;
+  const unsigned tags_at = (unsigned)(uintptr_t)tags;
+  const unsigned none2 = (unsigned)(ntags << 4) * 0x0101u;
+  const unsigned none4 = none2 * 0x10001u;
+  auto apply = [&](unsigned w, int p1) {
+    // the first two actions unconditionally ("none" lands in the scrap column), the rare third and fourth behind a test
+    const unsigned a0 = w & 255u, a1 = (w >> 8) & 255u;
+    *(TagP)(uintptr_t)(tags_at + ((a0 >> 4) << 10)) = p1 - (int)(a0 & 15u);
+    *(TagP)(uintptr_t)(tags_at + ((a1 >> 4) << 10)) = p1 - (int)(a1 & 15u);
+    if ((w >> 16) != none2) {
+      const unsigned a2 = (w >> 16) & 255u, a3 = w >> 24;
+      *(TagP)(uintptr_t)(tags_at + ((a2 >> 4) << 10)) = p1 - (int)(a2 & 15u);
+      *(TagP)(uintptr_t)(tags_at + ((a3 >> 4) << 10)) = p1 - (int)(a3 & 15u);
+    }
+  };
+  unsigned row = (unsigned)st * ncls8;
+  int i = start;
+  const unsigned sa = buf_at + (unsigned)start;
+  const unsigned sh = sa & 3u;
+  unsigned wa = sa & ~3u;
+  unsigned w0 = *(WordP)(uintptr_t)wa, w1 = *(WordP)(uintptr_t)(wa + 4);
+#define TDFA_TSTEP(KK)                                                                     \
+  if (i < stop) {                                                                          \
+    const MEnt e = *(EntP)(uintptr_t)(tent_at + row + k8[KK]);                             \
+    const unsigned ns = e.x & kTNext;                                                      \
+    const bool acc = (e.x & kTAcc) || ((e.x & kTAccEot) && i + 1 == len);                  \
+    const unsigned aw = *(WordP)(uintptr_t)(tacc_at + (ns << 2));                          \
+    apply(e.y, i + 1);                                                                     \
+    apply(acc ? aw : none4, i + 1);                                                        \
+    row = ns * ncls8;                                                                      \
+    ++i;                                                                                   \
+  }
+  while (i < stop) {
+    const unsigned b4 = __builtin_amdgcn_alignbyte(w1, w0, sh);
+    wa += 4;
+    w0 = w1;
+    w1 = *(WordP)(uintptr_t)(wa + 4);
+    unsigned k8[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) k8[k] = *(ClsP)(uintptr_t)(mcls_at + ((b4 >> (8 * k)) & 255u));
+    TDFA_TSTEP(0) TDFA_TSTEP(1) TDFA_TSTEP(2) TDFA_TSTEP(3)
+  }
+#undef TDFA_TSTEP
+  // result construction (tdfa.go:998-1052), as AttemptTags; a group is one 8-byte store (rows are ntags * 4 bytes apart, ntags even)
+  *reinterpret_cast<int2*>(out) = make_int2(tags[0], stop);
+  for (int g = 1; g < ntags / 2; ++g) {
+    const int a = tags[(2 * g) * 256];
+    int b = tags[(2 * g + 1) * 256];
+    if (a >= 0) { if (b < 0) b = stop; }
+    else b = -1;
+    *reinterpret_cast<int2*>(out + 2 * g) = make_int2(a, b);
+  }
+}
+
 constexpr int kTdfaWaveSlice = 6144;      // bytes of a wave's 64 strings staged in LDS (strings beyond it are read from global memory)
 
 // A wave takes 64 consecutive strings: their bytes are one contiguous range of `concat`, staged with coalesced 16-byte loads into
@@ -412,10 +520,39 @@ __global__ __launch_bounds__(256) void tdfa_batch_kernel(TdfaDev D, const uint8_
   extern __shared__ uint32_t smem[];
   typename Tab<LDS>::P ent = StageEnt<LDS>(D, smem);
   uint32_t* const after_ent = smem + (LDS ? D.nstates * 128 : 0);
+  // the merged-attempts automaton behind everything else (TdfaShared: with_window)
+  const bool merged = D.m_nstates > 0;
+  const int m_bytes = merged ? D.m_nstates * D.m_ncls * 8 : 0;
+  const int ring_words = merged ? 256 : 64 * 64;            // (merged: no ring -- the scrap column of the packed tag walk sits there)
+  unsigned char* const mreg = reinterpret_cast<unsigned char*>(after_ent + D.ntags * 256 + ring_words) + 4 * (kTdfaWaveSlice + 16);
+  if (merged) {
+    for (int w = threadIdx.x; w < m_bytes / 8; w += 256) reinterpret_cast<unsigned long long*>(mreg)[w] = D.ment[w];
+    mreg[m_bytes + threadIdx.x] = D.mcls8[threadIdx.x];
+    __syncthreads();
+  }
+  const unsigned ment_at = (unsigned)(uintptr_t)(const unsigned char TDFA_LDS*)mreg;
+  const unsigned mcls_at = ment_at + (unsigned)m_bytes;
+  // ... and the action pool and the states' accept words, which the tag walk of every found string reads per byte
+  const int16_t TDFA_LDS* const lpool = (const int16_t TDFA_LDS*)(mreg + m_bytes + 256);
+  const uint32_t TDFA_LDS* const lsinfo = (const uint32_t TDFA_LDS*)(mreg + m_bytes + 256 + ((D.pool_n * 2 + 15) & ~15));
+  unsigned char* const treg = mreg + m_bytes + 256 + ((D.pool_n * 2 + 15) & ~15) + ((D.nstates * 4 + 15) & ~15);
+  const bool packed = merged && D.tag_packed != 0;
+  const int t_bytes = packed ? D.nstates * D.m_ncls * 8 : 0;
+  if (merged) {
+    for (int w = threadIdx.x; w < D.pool_n; w += 256) ((int16_t TDFA_LDS*)lpool)[w] = D.pool[w];
+    for (int w = threadIdx.x; w < D.nstates; w += 256) ((uint32_t TDFA_LDS*)lsinfo)[w] = D.sinfo[w];
+    if (packed) {
+      for (int w = threadIdx.x; w < t_bytes / 8; w += 256) reinterpret_cast<unsigned long long*>(treg)[w] = D.tent[w];
+      for (int w = threadIdx.x; w < D.nstates; w += 256) reinterpret_cast<uint32_t*>(treg + t_bytes)[w] = D.tacc[w];
+    }
+    __syncthreads();
+  }
+  const unsigned tent_at = (unsigned)(uintptr_t)(const unsigned char TDFA_LDS*)treg;
+  const unsigned tacc_at = tent_at + (unsigned)t_bytes;
   int TDFA_LDS* tags = (int TDFA_LDS*)after_ent + threadIdx.x;
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
   uint8_t TDFA_LDS* const ring = (uint8_t TDFA_LDS*)(after_ent + D.ntags * 256) + threadIdx.x;      // [64][256] bytes: a column per lane
-  unsigned char* const wwin = reinterpret_cast<unsigned char*>(after_ent + D.ntags * 256 + 64 * 64) + wave * (kTdfaWaveSlice + 16);
+  unsigned char* const wwin = reinterpret_cast<unsigned char*>(after_ent + D.ntags * 256 + ring_words) + wave * (kTdfaWaveSlice + 16);
   const bool aligned = (((uintptr_t)concat) & 15) == 0;
   const long long ngroups = (nstr + 255) / 256;
   for (long long grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
@@ -439,16 +576,28 @@ __global__ __launch_bounds__(256) void tdfa_batch_kernel(TdfaDev D, const uint8_
       const int len = (int)(o1 - o0);
       if ((o1 - wb) <= (uint64_t)wvalid) {
         const uint8_t TDFA_LDS* lb = (const uint8_t TDFA_LDS*)wwin + (uint32_t)(o0 - wb);
-        BatchOne(D, ent, lb, len, tags, ring, found + i, rows + i * D.ntags, flags);
+        if (merged && len <= 255) {
+          int bs, be;
+          WalkMerged(ment_at, mcls_at, (unsigned)D.m_bot_row, (unsigned)(uintptr_t)lb, len, &bs, &be);
+          found[i] = be >= 0 ? 1 : 0;
+          if (be >= 0) {
+            if (packed) TagsPacked(tent_at, tacc_at, mcls_at, (unsigned)D.m_ncls * 8u, (unsigned)(uintptr_t)lb, len, bs, be, bs == 0 ? D.start_begin : D.start_any,
+                                   lpool, bs == 0 ? D.init_begin : D.init_any, D.ntags, tags, rows + i * D.ntags);
+            else AttemptTags(ent, lpool, lb, len, bs, be, bs == 0 ? D.start_begin : D.start_any, bs == 0 ? D.init_begin : D.init_any,
+                             D.ntags, tags, rows + i * D.ntags, lsinfo);
+          }
+        } else
+        BatchOne(D, ent, lb, len, tags, ring, found + i, rows + i * D.ntags, flags, !merged);
       } else {
-        BatchOne(D, ent, concat + o0, len, tags, ring, found + i, rows + i * D.ntags, flags);
+        BatchOne(D, ent, concat + o0, len, tags, ring, found + i, rows + i * D.ntags, flags, !merged);
       }
     }
   }
 }
 
 size_t TdfaShared(const TdfaDev& D, bool lds, bool with_tags, bool with_window = false) {
-  return (size_t)(lds ? D.nstates * 128 * 4 : 0) + (with_tags ? (size_t)D.ntags * 256 * 4 : 0) + (with_window ? 64 * 256 + 4 * (size_t)(kTdfaWaveSlice + 16) : 0);
+  return (size_t)(lds ? D.nstates * 128 * 4 : 0) + (with_tags ? (size_t)D.ntags * 256 * 4 : 0) +
+         (with_window ? (D.m_nstates > 0 ? 256 * 4 : 64 * 256) + 4 * (size_t)(kTdfaWaveSlice + 16) + (D.m_nstates > 0 ? (size_t)D.m_nstates * D.m_ncls * 8 + 256 + 16 + (((size_t)D.pool_n * 2 + 15) & ~size_t(15)) + (size_t)D.nstates * 4 + 32 + (D.tag_packed ? (size_t)D.nstates * D.m_ncls * 8 + (size_t)D.nstates * 4 + 16 : 0) : 0) : 0);
 }
 bool TdfaInLds(const TdfaDev& D, bool with_tags, bool with_window = false) { return TdfaShared(D, true, with_tags, with_window) <= 120 * 1024; }
 

@@ -43,6 +43,7 @@ _lib.rgxt_ref_match.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
 _lib.rgxt_tdfa_header.argtypes = [C.c_void_p, C.c_void_p]
 _lib.rgxt_tdfa_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 5
 _lib.rgxt_tdfa_find.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p]
+_lib.rgxt_tdfa_merged_find.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p]
 _lib.rgxt_memo_find.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p]
 _lib.rgxt_memo_match.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
 _lib.rgxt_tiny_find.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int64, C.c_int, C.c_void_p]
@@ -180,6 +181,15 @@ class HostProgram:
         if r == -3:
             return NotImplemented
         return list(out[:self.info["ncap"]]) if r == 1 else None
+
+    def tdfa_merged_find(self, b: bytes):
+        """The winning attempt's (start, end) through the merged-attempts automaton (rgx_dfa.h: BuildTdfaMerged), walked as the device
+        walks it; None: no match; NotImplemented: not built for this program / text."""
+        out = (C.c_int32 * 2)()
+        r = _lib.rgxt_tdfa_merged_find(self.h, b, len(b), out)
+        if r == -3:
+            return NotImplemented
+        return (out[0], out[1]) if r == 1 else None
 
     def memo_find(self, b: bytes):
         """FindBytesReuse of a program the reference emits with its memoising backtracker, as the device computes it (rgx_memo.h):

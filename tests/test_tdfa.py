@@ -131,7 +131,7 @@ def test_product_tables_equal_the_oracle_on_the_corpus(kats, corpus):
     import zlib
     from tests._hosttest import HostProgram
     pats = [c["pattern"] for c in kats["curated_cases"]] + [e["pattern"] for e in corpus]
-    seen = 0
+    seen = built_merged = 0
     for pat in dict.fromkeys(pats):
         o = E.Compiled(pat)
         hp = HostProgram(pat)
@@ -152,9 +152,18 @@ def test_product_tables_equal_the_oracle_on_the_corpus(kats, corpus):
         for _ in range(60):
             n = rnd.randint(1, 60)
             texts.append(bytes(rnd.choice(alpha) if rnd.random() < 0.93 else rnd.choice([32, 10, 200]) for _ in range(n)))
+        merged = 0
         for b in texts:
-            assert hp.tdfa_find(b) == o.tdfa.find(b), (pat, b)
-    assert seen >= 12
+            want = o.tdfa.find(b)
+            assert hp.tdfa_find(b) == want, (pat, b)
+            # ... and the same loop as ONE forward walk over the merged-attempts automaton (rgx_dfa.h: BuildTdfaMerged; what
+            # rgx_tdfa.hip's per-string kernel walks): the winning attempt's start and end
+            m = hp.tdfa_merged_find(b)
+            if m is not NotImplemented:
+                merged += 1
+                assert m == (None if want is None else (want[0], want[1])), (pat, b, m, want)
+        built_merged += 1 if merged else 0
+    assert seen >= 12 and built_merged >= 8
 
 
 def test_c_port_of_the_emitted_tdfa_equals_the_restatement(kats, corpus):
