@@ -142,10 +142,10 @@ typedef struct rgx_info {
   int32_t ref_tdfa_states;  /* states of the reference's Tagged DFA when ref_find_engine == 1 (its own numbering, start states
                              * included), else 0                                                                            */
   uint32_t flags;           /* the RGX_FLAG_* the program was compiled with (they travel in the blob)                        */
-  int32_t ref_replace_offered; /* 1: rgx_replace_* / rgx_transform_chunk* are offered in reference mode -- as ref_stream_offered, but
-                             * only for the plain backtracking engine: under the Tagged DFA the emitted Replace / Transform loops
-                             * reuse ONE result struct across matches, so a group the engine leaves untouched expands to its text
-                             * in an EARLIER match (tdfa.go:1031-1046, replace.go:216): not reproduced, keep the Go path        */
+  int32_t ref_replace_offered; /* 1: rgx_replace_* / rgx_transform_chunk* are offered in reference mode (equal to ref_stream_offered since
+                             * round 5).  Under the Tagged DFA the emitted Replace / Transform loops reuse ONE result struct across
+                             * matches, so a group the engine leaves untouched expands to its text in an EARLIER match (tdfa.go:
+                             * 1031-1046, replace.go:216, transform.go:123): reproduced -- the loop's rows, stale fields filled in   */
 } rgx_info;
 int rgx_abi_version(void);
 int rgx_program_info(const rgx_program* p, rgx_info* out);

@@ -171,17 +171,34 @@ def replace_all(c: "E.Compiled", inp: bytes, template: str, quirks: bool = False
     last_end = 0
     remaining = inp
     offset = 0
+    # Tagged-DFA programs (compiler.go:137-153): FindBytesReuse is the Tagged DFA's (tdfa.go:831-1052), and `r` is ONE struct for the
+    # whole loop (replace.go:216): a group whose start tag is unset is left untouched (tdfa.go:1031-1046), so its field still holds the
+    # text the last match that set it gave it -- a slice of `input` -- and the zero struct's empty field before that.
+    tdfa = getattr(c, "tdfa", None)
+    held = [0] * c.prog.numcap          # what the struct's fields hold, as offsets into `inp`
     while True:
-        caps = c.find_machine.find(remaining)
-        if caps is None:
-            break
+        if tdfa is not None:
+            t = tdfa.find(remaining)
+            if t is None:
+                break
+            for g in range(1, c.prog.numcap // 2):
+                if t[2 * g] >= 0:
+                    held[2 * g], held[2 * g + 1] = t[2 * g] + offset, t[2 * g + 1] + offset
+            caps = [t[0], t[1]]
+        else:
+            caps = c.find_machine.find(remaining)
+            if caps is None:
+                break
         match = remaining[caps[0]:caps[1]]
         idx = remaining.find(match)
         if idx < 0:
             break
         ms, me = offset + idx, offset + idx + len(match)
         out += inp[last_end:ms]
-        out += _expand(segs, remaining, caps, names, ngroups)
+        if tdfa is not None:
+            out += _expand(segs, inp, [offset + caps[0], offset + caps[1]] + held[2:], names, ngroups)
+        else:
+            out += _expand(segs, remaining, caps, names, ngroups)
         last_end = me
         if first_only:
             break

@@ -163,10 +163,30 @@ class _ErrReader:  # <name>TransformErrReader, transform.go:266-282
 def _matcher(c: "E.Compiled", quirks: bool):
     """next(data, processed) -> (start, end, caps relative to `base`, base) | None."""
     if quirks:
+        tdfa = getattr(c, "tdfa", None)
+        held = [0] * c.prog.numcap          # Tagged-DFA programs: what the processor's reused struct holds (transform.go:123), offsets into data
+
         def nxt(data: bytes, processed: int):
             if processed > len(data):
                 raise ReferencePanic("slice bounds out of range [%d:%d]" % (processed, len(data)))
             rem = data[processed:]
+            if tdfa is not None:
+                # FindBytesReuse is the Tagged DFA's; a group whose start tag is unset keeps what the struct held (tdfa.go:1031-1046);
+                # a fresh struct per call of the processor (processed == 0 only at its beginning: every match moves it on)
+                if processed == 0:
+                    for k in range(len(held)):
+                        held[k] = 0
+                t = tdfa.find(rem)
+                if t is None:
+                    return None
+                for g in range(1, c.prog.numcap // 2):
+                    if t[2 * g] >= 0:
+                        held[2 * g], held[2 * g + 1] = t[2 * g] + processed, t[2 * g + 1] + processed
+                m = rem[t[0]:t[1]]
+                idx = rem.find(m)
+                if idx < 0:
+                    return "break"
+                return processed + idx, processed + idx + len(m), [processed + t[0], processed + t[1]] + held[2:], 0
             caps = c.find_machine.find(rem)                     # FindBytesReuse(data[processed:])
             if caps is None:
                 return None

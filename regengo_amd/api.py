@@ -455,6 +455,18 @@ class Compiled:
                 leftover = 0
             chunk_index += 1
 
+    def _loop_rows(self, data: bytes):
+        """The rows of the emitted loop "FindBytesReuse on data[matchEnd:]" over one buffer (rgx_find_chunk on a chunk that is not full:
+        nothing deferred): what the host side of NewTransformReader walks for a Tagged-DFA program, whose FindAllBytes is another loop."""
+        self._need_dev()
+        cap = len(data) // max(self.MinMatchLen, 1) + 2
+        spans = (C.c_int32 * (cap * self.ncap))()
+        committed, keep, res = C.c_int64(), C.c_int64(), _capi.Result()
+        cbuf = (C.c_uint8 * max(len(data), 1)).from_buffer_copy(data or b"\0")
+        w = _capi.check(self._lib.rgx_find_chunk(self._h, self._ctx, cbuf, len(data), 0, self.DefaultMaxLeftover(), spans, cap,
+                                                 C.byref(committed), C.byref(keep), C.byref(res)))
+        return [[int(x) for x in spans[i * self.ncap:(i + 1) * self.ncap]] for i in range(w)]
+
     # ---- streaming Transform (transform.go:28-571; regengo_amd/transform.py)
     NewTransformReader = _transform.NewTransformReader
     ReplaceReader = _transform.ReplaceReader

@@ -203,7 +203,8 @@ bool RefTdfaMode(const rgx_program* p) { return !(p->p.t.flags & RGX_FLAG_STDLIB
 // Replace* / Transform: FindBytesReuse of the plain backtracking engine on a re-sliced input
 bool RefReplaceOffered(const Tables& t) {
   const bool have_rm = !t.rm_depth[0].empty() && !t.rm_depth[1].empty();
-  return ((have_rm && !t.ref_memo && t.ref_find_engine <= 0) || HasRefMemo(t)) && !t.can_match_empty;
+  // (Tagged-DFA programs since round 5: the loop's rows with the reused struct's stale fields filled in, TdfaLoopRows)
+  return ((have_rm && !t.ref_memo && t.ref_find_engine <= 0) || HasRefMemo(t) || HasRefTdfa(t)) && !t.can_match_empty;
 }
 // FindReader / FindReaderCount: the same, or the Tagged DFA's FindBytesReuse
 bool RefStreamOffered(const Tables& t) { return RefReplaceOffered(t) || (HasRefTdfa(t) && !t.can_match_empty); }
@@ -219,7 +220,7 @@ int RefuseStream(const rgx_program* p, bool splice = false) {
   const Tables& t = p->p.t;
   if ((t.flags & RGX_FLAG_STDLIB_SEMANTICS) || (splice ? RefReplaceOffered(t) : RefStreamOffered(t))) return RGX_OK;
   if (!splice && HasRefTdfa(t) && !p->p.dev.tdfa && !t.can_match_empty) return RGX_OK;     // (not on a device yet: CheckCtx has the say)
-  SetError("reference-mode FindReader / Replace / Transform is not offered for this pattern: the emitted loop is FindBytesReuse on a re-sliced input and the reference's FindBytesReuse (memoising engine; Tagged-DFA engine under Replace / Transform; or a pattern that matches empty) is not reproduced; keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS");
+  SetError("reference-mode FindReader / Replace / Transform is not offered for this pattern: the emitted loop is FindBytesReuse on a re-sliced input and the reference's FindBytesReuse (a memoising engine beyond the interpreter, or a pattern that matches empty) is not reproduced; keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS");
   return RGX_E_UNSUPPORTED;
 }
 // Scratch of the memoising engine's interpreter: nlanes lanes, each W visited words (all zero between launches) and cap stack words.
@@ -366,6 +367,24 @@ int TdfaIndexCheck(rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, const in
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (h) { SetError("the reference's FindReader loop reports a match of this chunk at an earlier copy of its text (bytes.Index, streaming.go:192): run it through the Go loop"); return RGX_E_DIVERGES; }
   return RGX_OK;
+}
+
+// The rows of the emitted Replace / Transform loop of a Tagged-DFA program over one buffer (replace.go:216-262, transform.go:121-175:
+// FindBytesReuse on data[matchEnd:] with ONE result struct): the chain's rows, the bytes.Index test, and the struct's stale fields filled
+// in (LaunchTdfaFill).  Returns the number of rows in d_rows (capacity cap_records) or a negative status.
+int64_t TdfaLoopRows(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t max_n, int32_t* d_rows, size_t cap_records,
+                     rgx_result* res) {
+  const int ncap = p->p.dev.ncap;
+  const int64_t n = TdfaChainDevice(p, c, d_buf, len, max_n, d_rows, cap_records, res);
+  if (n <= 0) return n;
+  int rc = TdfaIndexCheck(c, d_buf, len, d_rows, n, ncap);
+  if (rc != RGX_OK) return rc;
+  if (ncap > 2) {
+    const size_t tb = TdfaFillTempBytes(n);
+    if ((rc = Ensure(&c->d_rtemp, &c->rtemp_cap, (int64_t)tb + 64)) != RGX_OK) return rc;
+    HIP_TRY(LaunchTdfaFill(d_rows, n, ncap, c->d_rtemp, tb, c->stream));
+  }
+  return n;
 }
 
 // `\p{L}+` is a 374-state automaton over 100 byte classes (581 x 100 with start tracking): it fits none of the one-step-per-byte
@@ -1309,12 +1328,17 @@ RGX_API int64_t rgx_replace_all_bytes_device(const rgx_program* p, rgx_stream_ct
   if ((rc = Ensure(&c->d_rspans, &c->rspans_cap, cap_rec * ncap)) != RGX_OK) return rc;
   rgx_result r{};
   int64_t n = 0;
-  if (len > 0) {
+  const bool tdfa = RefTdfaMode(p);
+  if (len > 0 && tdfa) {
+    // the Tagged DFA's own loop (its matches are longest-on-path, not leftmost-first) with the reused struct's stale fields
+    n = TdfaLoopRows(p, c, d_buf, len, first_only ? 1 : -1, c->d_rspans, (size_t)cap_rec - 2, &r);
+    if (n < 0) return n;
+  } else if (len > 0) {
     n = FindAllDevice(p, c, d_buf, len, first_only ? 1 : -1, c->d_rspans, (size_t)cap_rec - 2, false, &r);
     if (n < 0) return n;
   }
   // (the emitted loop is FindBytesReuse on input[matchEnd:] + bytes.Index, like FindReader's: identical or refused, rgx.h)
-  if (len > 0 && ReaderCheckApplies(p) && (rc = ReaderCheck(p, c, d_buf, len, c->d_rspans, n)) != RGX_OK) return rc;
+  if (len > 0 && !tdfa && ReaderCheckApplies(p) && (rc = ReaderCheck(p, c, d_buf, len, c->d_rspans, n)) != RGX_OK) return rc;
   // 2. the emitted loop also tries at offset len (FindBytesReuse on the empty remainder, find.go:545-569)
   if (t.can_match_empty && (!t.anchored || len == 0) && !(first_only && n > 0)) {
     int32_t* d_end = (int32_t*)(c->d_rspans + (cap_rec - 1) * ncap);
@@ -1410,7 +1434,11 @@ int64_t TransformChunkDevice(const rgx_program* p, rgx_stream_ctx* c, const uint
   if ((rc = Ensure(&c->d_rspans, &c->rspans_cap, cap_rec * ncap)) != RGX_OK) return rc;
   rgx_result r{};
   int64_t n = 0;
-  if (len > 0) {
+  if (len > 0 && RefTdfaMode(p)) {
+    // Tagged-DFA programs: the processor's own loop over the buffer, one reused struct per call (transform.go:123)
+    n = TdfaLoopRows(p, c, d_data, len, -1, c->d_rspans, (size_t)cap_rec - 2, &r);
+    if (n < 0) return n;
+  } else if (len > 0) {
     n = FindAllDevice(p, c, d_data, len, -1, c->d_rspans, (size_t)cap_rec - 2, false, &r);
     if (n < 0) return n;
     // the emitted processors run FindBytesReuse on data[processed:] + bytes.Index (transform.go:96-170, 380-571), like

@@ -214,6 +214,10 @@ hipError_t LaunchTdfaChain(const int32_t* ends, int32_t len, const unsigned long
                            int32_t* se, int64_t max_n, int emit, uint32_t* flags, hipStream_t stream);
 // rows[n][ntags]: the reported tags of every match of se (tdfa.go:998-1052: (-1, -1) = group left untouched)
 hipError_t LaunchTdfaTags(const TdfaDev& D, const uint8_t* buf, int32_t len, const int32_t* se, int64_t n, int32_t* rows, hipStream_t stream);
+// rows of a Replace / Transform loop as the REUSED result struct holds them: an untouched group ((-1, -1)) takes the last set value
+// before it, (0, 0) in front of the first (rgx_tdfa.hip has the why).  temp: TdfaFillTempBytes(n) bytes.
+size_t TdfaFillTempBytes(int64_t n);
+hipError_t LaunchTdfaFill(int32_t* rows, int64_t n, int ncap, void* temp, size_t temp_bytes, hipStream_t stream);
 // FindBytes per string of a batch: found[nstr], rows[nstr][ntags]
 hipError_t LaunchTdfaBatch(const TdfaDev& D, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found, int32_t* rows,
                            uint32_t* flags, hipStream_t stream);

@@ -660,6 +660,55 @@ hipError_t LaunchTdfaChain(const int32_t* ends, int32_t len, const unsigned long
   return hipGetLastError();
 }
 
+// ---- the reused result struct (replace.go:216, transform.go:123: ONE struct for all the matches of a loop).  The Tagged-DFA engine
+// assigns a group's field only when the group's start tag is set (tdfa.go:1031-1046), so a field it leaves alone still holds the text of
+// the last match that set it: a template that names the group expands to THAT text.  Rows come as the reported tags ((-1, -1): untouched);
+// the fill turns them into what the struct holds: per group the last set (start, end) at or before the row, (0, 0) -- the zero struct's
+// empty field -- in front of the first.  A column at a time: gather into 8-byte pairs, an inclusive scan "the right one if it is set",
+// scatter back.
+namespace {
+struct TakeSet {
+  __host__ __device__ long long operator()(long long l, long long r) const { return (int)(unsigned)(unsigned long long)r >= 0 ? r : l; }
+};
+__global__ __launch_bounds__(256) void tdfa_fill_gather(const int32_t* rows, long long n, int ncap, int g, long long* col) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const int2 v = *reinterpret_cast<const int2*>(rows + i * ncap + 2 * g);
+    col[i] = (long long)(((unsigned long long)(unsigned)v.y << 32) | (unsigned)v.x);
+  }
+}
+__global__ __launch_bounds__(256) void tdfa_fill_scatter(int32_t* rows, long long n, int ncap, int g, const long long* col) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    const unsigned long long v = (unsigned long long)col[i];
+    int2 o = make_int2((int)(unsigned)v, (int)(unsigned)(v >> 32));
+    if (o.x < 0) o = make_int2(0, 0);
+    *reinterpret_cast<int2*>(rows + i * ncap + 2 * g) = o;
+  }
+}
+}  // namespace
+size_t TdfaFillTempBytes(int64_t n) {
+  size_t bytes = 0;
+  hipcub::DeviceScan::InclusiveScan(nullptr, bytes, (const long long*)nullptr, (long long*)nullptr, TakeSet(), (int)n);
+  return ((bytes + 15) & ~size_t(15)) + (size_t)n * 8 + 16;
+}
+hipError_t LaunchTdfaFill(int32_t* rows, int64_t n, int ncap, void* temp, size_t temp_bytes, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  size_t scan_bytes = 0;
+  hipcub::DeviceScan::InclusiveScan(nullptr, scan_bytes, (const long long*)nullptr, (long long*)nullptr, TakeSet(), (int)n);
+  scan_bytes = (scan_bytes + 15) & ~size_t(15);
+  if (temp_bytes < scan_bytes + (size_t)n * 8) return hipErrorInvalidValue;
+  long long* col = reinterpret_cast<long long*>(reinterpret_cast<unsigned char*>(temp) + scan_bytes);
+  const dim3 grid((unsigned)((n + 255) / 256)), block(256);
+  for (int g = 1; g < ncap / 2; ++g) {
+    hipLaunchKernelGGL(tdfa_fill_gather, grid, block, 0, stream, rows, (long long)n, ncap, g, col);
+    const hipError_t e = hipcub::DeviceScan::InclusiveScan(temp, scan_bytes, col, col, TakeSet(), (int)n, stream);
+    if (e != hipSuccess) return e;
+    hipLaunchKernelGGL(tdfa_fill_scatter, grid, block, 0, stream, rows, (long long)n, ncap, g, col);
+  }
+  return hipGetLastError();
+}
+
 size_t TdfaScanTempBytes(int64_t n) {
   size_t bytes = 0;
   hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (int)n);

@@ -201,9 +201,21 @@ class Transformer:
     def _process_host(self, n: int, is_eof: bool) -> int:
         """processTransform / processSelect / processReject over the buffer's span table (transform.go:96-170, 380-431,
         485-571); matches in their true context (what FindAllBytes reports)."""
-        spans, _ = self.c.FindAllSpans(self._d_in[:n])
-        recs = spans.cpu().tolist()
         data = bytes(self.input[:n])
+        if self.c.info.ref_find_engine == 1 and not self.c.stdlib:
+            # a Tagged-DFA program in reference mode: the processor's own loop (its matches are the engine's, longest-on-path) with ONE
+            # result struct per call (transform.go:123) -- a group the engine leaves alone ((-1, -1)) keeps what the struct held
+            recs = self.c._loop_rows(data)
+            held = [0] * self.c.ncap
+            for rec in recs:
+                for g in range(1, self.c.ncap // 2):
+                    if rec[2 * g] >= 0:
+                        held[2 * g], held[2 * g + 1] = rec[2 * g], rec[2 * g + 1]
+                    else:
+                        rec[2 * g], rec[2 * g + 1] = held[2 * g], held[2 * g + 1]
+        else:
+            spans, _ = self.c.FindAllSpans(self._d_in[:n])
+            recs = spans.cpu().tolist()
         emit = self.out.extend
         processed = 0
         self.matches += len(recs)

@@ -156,15 +156,15 @@ def test_field_names_and_memo_patterns(built):
         text, _ = codegen.emit_go(big, "Big", "p")
         assert "func (r Big) FindBytesReuse(" not in text and "FindBytes / FindBytesReuse / FindString / FindStringReuse are not routed" in text
     # the reference's Tagged DFA (URLCapture, 13 states as in its checked-in tables): the engine itself runs on the device, so
-    # FindBytes* and FindReader / FindReaderCount ARE routed (fill: a group is assigned only when its start tag is set); FindAll* (the
-    # wrapper reports matches again, compiler.go:646-651) and Replace* (stale groups of the reused struct) are not -- all are with
-    # --stdlib-semantics
+    # FindBytes* and FindReader / FindReaderCount ARE routed (fill: a group is assigned only when its start tag is set), and since round 5
+    # Replace* (the loop's rows with the reused struct's stale groups filled in on the device); FindAll* (the wrapper reports matches
+    # again, compiler.go:646-651) is not -- it is with --stdlib-semantics
     url = CASES[2][1]
     assert codegen.Program(url).info.ref_find_engine == 1 and codegen.Program(url).info.ref_tdfa_states == 13
     text, _ = codegen.emit_go(url, "URL", "p")
     assert "func (r URL) FindAll" not in text and "FindAll* are not routed" in text
     assert "func (r URL) FindReader(" in text and "func (r URL) FindReaderCount(" in text and "func (r URL) FindBytesReuse(" in text
-    assert "func (r URL) ReplaceAll" not in text and "Replace* / ReplaceReader are not routed" in text
+    assert "func (r URL) ReplaceAllBytesAppend(" in text and "Replace* / ReplaceReader are not routed" not in text
     assert "if c[6] >= 0 {\n\t\titem.Port = input[c[6]:c[7]]\n\t}" in text and "item.Port = nil" not in text
     text, _ = codegen.emit_go(url, "URL", "p", flags=_capi.FLAG_STDLIB_SEMANTICS)
     for meth in ("FindAllBytesAppend", "FindReader", "FindReaderCount", "ReplaceAllBytesAppend", "FindBytesReuse", "MatchBytes"):

@@ -108,7 +108,8 @@ def test_random_patterns_replace_and_transform(torch_dev):
                     got = cref.ReplaceAllBytes(b, "<$0>")
                     try:
                         assert got == R.replace_all(o, b, "<$0>", quirks=True), (p, b)
-                        assert got == R.replace_all(o, b, "<$0>"), (p, b)          # answered: the quirks did not bite
+                        if o.tdfa is None:
+                            assert got == R.replace_all(o, b, "<$0>"), (p, b)      # answered: the quirks did not bite (Tagged-DFA programs: their own matches)
                     except NotImplementedError:
                         pass
                     answered += 1

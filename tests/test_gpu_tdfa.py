@@ -4,7 +4,8 @@ Reference mode runs the reference's OWN automaton on the device (csrc/rgx_tdfa.h
 equal the emitted literals: tests/test_tdfa.py): FindBytes / FindBytesReuse / the batch form / FindReader / FindReaderCount are
 compared here with the restated emitted loop (oracle/tdfa.py: longest-on-path, a byte >= 0x80 ends an attempt, untouched groups)
 on the reference's inputs AND on texts where that loop differs from leftmost-first.  Only the FindAllBytes wrapper (advances by
-the match length, Q11) and Replace / Transform stay refused."""
+the match length, Q11) stays refused; Replace / Transform run the engine's own loop with the reused struct's stale groups
+(tests/test_gpu_replace.py, tests/test_gpu_transform.py)."""
 import io
 import json
 import os
@@ -97,7 +98,7 @@ def test_tdfa_find_reader_is_the_reference_loop(built, kats, corpus):
     answered = diverged = stale = calls = 0
     for pat, o, inputs in items:
         c = Compiled(pat).to(0)
-        assert c.info.ref_stream_offered == 1 and c.info.ref_findall_offered == 0 and c.info.ref_replace_offered == 0, pat
+        assert c.info.ref_stream_offered == 1 and c.info.ref_findall_offered == 0 and c.info.ref_replace_offered == 1, pat
         rnd = random.Random(zlib.crc32(pat.encode()) ^ 7)
         texts = [b" ".join(inputs), b"\n".join(_texts(o, pat, 40, 5, 90))]
         texts.append(b" -- ".join(_texts(o, pat, 400, 5, 90)))          # ~20 KB: chunks of 8 KiB and more take the parallel chain
@@ -197,7 +198,7 @@ def test_tdfa_class_patterns_under_stdlib_flag_are_leftmost_first(built, kats, c
 
 def test_tdfa_class_findall_is_the_reference_or_refused(built, kats, corpus):
     """For every corpus / curated pattern the reference emits with its Tagged DFA (or memoising on an empty
-    match), every FindAll / count / Replace entry point is REFUSED in reference mode -- the TDFA's FindAllBytes advances by the
+    match), every FindAll / count entry point is REFUSED in reference mode -- the TDFA's FindAllBytes advances by the
     match length (compiler.go:646-651; oracle.tdfa.find_all reproduces the duplicates) -- and answers as Go's regexp
     (oracle: leftmost-first) under RGX_FLAG_STDLIB_SEMANTICS.  For every other pattern the device's answer equals the oracle's
     restatement of what the reference emits (oracle.engines.Compiled.FindAllBytes dispatches on the engine)."""
@@ -216,9 +217,8 @@ def test_tdfa_class_findall_is_the_reference_or_refused(built, kats, corpus):
         texts = [s.encode() for s in inputs] + [b" ".join(s.encode() for s in inputs), tile]
         c = Compiled(pat).to(0)
         if o.tdfa is not None:
-            assert not c.info.ref_findall_offered and not c.info.ref_replace_offered and c.info.ref_stream_offered, pat
-            for call in (lambda: c.FindAllSpans(texts[-1]), lambda: c.CountAll(texts[-1]),
-                         lambda: c.ReplaceAllBytes(texts[-1], "x")):
+            assert not c.info.ref_findall_offered and c.info.ref_replace_offered and c.info.ref_stream_offered, pat
+            for call in (lambda: c.FindAllSpans(texts[-1]), lambda: c.CountAll(texts[-1])):
                 with pytest.raises(_capi.RgxError) as ei:
                     call()
                 assert ei.value.status == _capi.RGX_E_UNSUPPORTED, pat

@@ -33,9 +33,10 @@ def dev(pattern):
     from regengo_amd import Compiled
     if pattern not in _c:
         c = Compiled(pattern).to(0)
-        if not c.info.ref_replace_offered and not c.info.can_match_empty:
-            # reference mode refuses this program's streaming loops (memoising / Tagged-DFA FindBytesReuse): the quirk-free reading
-            # under test here is RGX_FLAG_STDLIB_SEMANTICS
+        if (not c.info.ref_replace_offered or c.info.ref_find_engine == 1) and not c.info.can_match_empty:
+            # reference mode refuses this program's streaming loops (a memoising FindBytesReuse beyond the interpreter) or runs the
+            # Tagged DFA's own loop (other matches, stale groups: test_tagged_dfa_readers below): the quirk-free reading under test here
+            # is RGX_FLAG_STDLIB_SEMANTICS
             c = Compiled(pattern, stdlib=True).to(0)
         _c[pattern] = c
     return _c[pattern]
@@ -248,3 +249,42 @@ def test_large_replace_reader_closed_form(gpu):
     for k in range(10):
         mask[pos + k] = False
     assert (a[mask] == src[mask]).all()
+
+
+def test_tagged_dfa_readers(gpu):
+    """VERDICT r4 missing #2, the streaming half: ReplaceReader / SelectReader / RejectReader / NewTransformReader of a program the
+    reference compiles to a Tagged DFA.  The emitted processors run the engine's FindBytesReuse with ONE result struct per buffer
+    (transform.go:123): a group the match leaves out expands to what an earlier match of the same buffer gave it.  Against the oracle's
+    restatement of that loop (oracle/transform.py, quirks=True)."""
+    from oracle import engines as E
+    from oracle import transform as T
+    from regengo_amd import Compiled, _capi
+    from regengo_amd.stream import Config
+    pat = r"(?P<protocol>https?)://(?P<host>[\w\.-]+)(?::(?P<port>\d+))?(?P<path>/[\w\./]*)?"
+    c, o = Compiled(pat).to(0), E.Compiled(pat)
+    assert o.tdfa is not None and c.info.ref_find_engine == 1 and c.info.ref_replace_offered and not c.stdlib
+    words = [b"http://a.b:80/x", b"https://c.d", b"http://e:8080", b"https://f/g/h.i", b"http://", b"xx", b"http:/y"]
+    rng = random.Random(9)
+    answered = 0
+    for trial in range(8):
+        inp = b" ".join(rng.choice(words) for _ in range(rng.choice([0, 3, 40, 3000, 20000])))
+        bs = rng.choice([4096, 20000, 70000])
+        for tmpl in ("[$port|$path]", "<$0>", "${host}:${port}"):
+            want, werr = T.replace_reader(o, T.bytes_reader(inp), tmpl, quirks=True, buffer_size=bs, max_leftover=1000).read_all(500)
+            assert werr is None
+            try:
+                got = c.ReplaceReader(PieceReader(inp), tmpl, Config(bs, 1000)).read_all()
+            except _capi.RgxError as ex:
+                assert ex.status == _capi.RGX_E_DIVERGES, ex
+                continue
+            assert got == want, (trial, bs, tmpl, len(inp))
+            answered += 1
+        # the host callback sees the struct's fields: the port of an earlier URL where this one has none
+        gcb = lambda m, emit: emit(b"{" + (m.Port or b"") + b"}")
+        ocb = lambda text, caps, emit: emit(b"{" + text[caps[6]:caps[7]] + b"}")
+        got = c.NewTransformReader(PieceReader(inp), Config(bs, 1000), gcb).read_all()
+        assert got == T.new_transform_reader(o, T.bytes_reader(inp), bs, 1000, ocb, quirks=True).read_all(500)[0], (trial, bs)
+        for kind, gfn, ofn in (("select", c.SelectReader, T.select_reader), ("reject", c.RejectReader, T.reject_reader)):
+            want = ofn(o, T.bytes_reader(inp), lambda text, caps: True, quirks=True, buffer_size=bs).read_all(900)[0]
+            assert gfn(PieceReader(inp), None, Config(bs, 0)).read_all() == want, (kind, trial, bs)
+    assert answered > 10

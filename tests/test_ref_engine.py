@@ -43,8 +43,8 @@ def test_product_engine_selection_equals_the_oracle(built, corpus, kats):
         assert info.ref_stream_offered == int(info.ref_find_offered and not info.can_match_empty), p
         if exp[0] == 2:          # memoising backtracker: interpreted (csrc/rgx_memo.h) -- FindBytes offered, the loops built on it unless the pattern matches empty
             assert info.ref_find_offered and info.ref_stream_offered == info.ref_replace_offered == int(not info.can_match_empty), p
-        if exp[0] == 1:          # Tagged DFA: the engine itself runs on the device; only its FindAll wrapper and Replace stay refused
-            assert info.ref_find_offered and info.ref_stream_offered == int(not info.can_match_empty) and not info.ref_replace_offered, p
+        if exp[0] == 1:          # Tagged DFA: the engine itself runs on the device (Replace / Transform since round 5); only its FindAll wrapper stays refused
+            assert info.ref_find_offered and info.ref_stream_offered == info.ref_replace_offered == int(not info.can_match_empty), p
         if exp[0] == 0:
             assert info.ref_replace_offered == info.ref_stream_offered, p
     assert seen[1] >= 15 and seen[2] >= 10 and seen[0] >= 50, seen     # every class is exercised by the corpus
@@ -63,7 +63,7 @@ def test_checked_in_tdfa_patterns_are_classified_tdfa(built):
             assert info.ref_find_engine == 0 and info.ref_findall_offered, name
             continue
         assert info.ref_find_engine == 1 and info.ref_tdfa_states == len(t["transitions"]), name
-        assert not info.ref_findall_offered and info.ref_stream_offered and info.ref_find_offered and not info.ref_replace_offered
+        assert not info.ref_findall_offered and info.ref_stream_offered and info.ref_find_offered and info.ref_replace_offered
     # regengo.Options.ForceTDFA (regengo.go:43-45, cmd flag -force-tdfa; compiler.go:137-153): how TDFASemVer and the ipv4 pattern were
     # generated -- RGX_FLAG_FORCE_TDFA selects the same engine, and the tables are the emitted ones (tests/test_tdfa.py)
     for name, t in tabs.items():

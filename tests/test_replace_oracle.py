@@ -65,3 +65,16 @@ def test_replace_loop_readings():
     # an empty match is allowed right after a non-empty one (Q3): "[]" follows "[xx]"
     assert R.replace_all(e, b"axxb", "[$1]") == b"[]a[xx][]b[]"
     assert R.replace_all(e, b"axxb", "[$1]", quirks=True) == b"[]a[xx][]b[]"
+
+
+def test_tagged_dfa_loop_reuses_one_result_struct():
+    """replace.go:216 + tdfa.go:1031-1046: `r` is one struct for the whole loop and the Tagged-DFA engine assigns a group's field only when
+    the group's start tag is set -- a group the match leaves out keeps the text an earlier match gave it (the zero struct's empty field
+    before that)."""
+    from oracle import engines as E
+    from oracle import replace as R
+    o = E.Compiled(r"(?P<protocol>https?)://(?P<host>[\w\.-]+)(?::(?P<port>\d+))?(?P<path>/[\w\./]*)?")
+    assert o.tdfa is not None
+    assert R.replace_all(o, b"http://a:80/x http://b", "[$port]", quirks=True) == b"[80] [80]"
+    assert R.replace_all(o, b"http://b http://a:80/x http://c", "[$port$path]", quirks=True) == b"[] [80/x] [80/x]"
+    assert R.replace_all(o, b"http://a:80/x http://b", "[$port]", quirks=True, first_only=True) == b"[80] http://b"
