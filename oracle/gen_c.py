@@ -193,6 +193,12 @@ def emit_c(prog: S.Prog, memo: bool, name: str = "m", q8: bool = True) -> str:
         w("    if (l > end) { off = end + 1; memset(caps, 0, sizeof caps); caps[0] = off; if (visited) memset(visited, 0, vwords * 4); } else break;\n")
     w("  }\n  if (found) for (int c = 0; c < NCAP; c++) out[c] = (int32_t)caps[c];\n")
     w("  free(stack); free(cstack); free(visited); (void)vwords;\n  return found;\n}\n")
+    # FindBytes per string of a CSR batch in ONE call (bench.py's cpu_baseline of config C3: a call per string through ctypes measured
+    # the call overhead, 0.45 us per string, more than the matcher)
+    w("long long m_find_batch(const unsigned char *concat, const unsigned long long *offsets, long long nstr, unsigned char *found, int *spans) {\n")
+    w("  long long n = 0;\n  for (long long i = 0; i < nstr; i++) {\n")
+    w("    int f = m_find(concat + offsets[i], (long long)(offsets[i + 1] - offsets[i]), spans + i * %d);\n" % ncap)
+    w("    found[i] = (unsigned char)f; n += f;\n  }\n  return n;\n}\n")
     return "".join(o)
 
 
@@ -237,6 +243,8 @@ class CMatcher:
         self.lib.m_find_all.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
         self.lib.m_find.restype = ctypes.c_int
         self.lib.m_find.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
+        self.lib.m_find_batch.restype = ctypes.c_int64
+        self.lib.m_find_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
 
     def find_all_np(self, buf, n: int = -1, cap: Optional[int] = None):
         """buf: numpy uint8 array (contiguous).  Returns int32 array [count, ncap]."""

@@ -2028,6 +2028,12 @@ RGX_API int rgx_match_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8
   if (rc != RGX_OK) return rc;
   if (!matched || (len && !buf)) return RGX_E_INVALID;
   if (len > 0x7FFFFF00ull) { SetError("buffer larger than 2^31-256 bytes"); return RGX_E_TOO_LARGE; }
+  // (what the device entry point would refuse for its length is refused HERE, before the text crosses PCIe -- the emitted stub
+  // routes inputs of a megabyte and more, and a refusal that costs a copy of them is a tax on the Go path that answers the call)
+  if (!(p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS) && p->p.dev.ref_match_kind == 3 && (int64_t)len > kMemoMatchMaxLen) {
+    SetError("reference-mode MatchBytes of a memoising program is interpreted by one lane: offered up to 64 KiB of text, keep the Go path beyond");
+    return RGX_E_UNSUPPORTED;
+  }
   if ((rc = Ensure(&c->d_in, &c->in_cap, (int64_t)len + 64)) != RGX_OK) return rc;
   if (len) HIP_TRY(hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream));
   return rgx_match_bytes_device(p, c, c->d_in, len, matched);
@@ -2076,6 +2082,13 @@ RGX_API int rgx_find_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8_
     if (n > 0) HIP_TRY(hipMemcpy(spans, c->d_out, (size_t)ncap * 4, hipMemcpyDeviceToHost));
     else memset(spans, 0, (size_t)ncap * 4);
     return RGX_OK;
+  }
+  // One text through the per-string kernels: a lane is a sequential loop, so they take strings of at most kBatchSearchMaxLen bytes of an
+  // unanchored pattern (BatchLengthGuard) -- refused here, before the text crosses PCIe, not behind the copy
+  if (p && p->p.d_arena && !p->p.dev.anchored && (int64_t)len > kBatchSearchMaxLen) {
+    SetError("FindBytes of one text of " + std::to_string(len) + " bytes: the per-string kernels take strings of at most " + std::to_string(kBatchSearchMaxLen) +
+             " bytes of an unanchored pattern (a lane is a sequential loop); keep the Go path, or use rgx_find_all_bytes with n = 1 for the leftmost-first match");
+    return RGX_E_UNSUPPORTED;
   }
   const uint64_t offs[2] = {0, (uint64_t)len};
   uint8_t f = 0;
