@@ -1016,8 +1016,10 @@ RGX_API int64_t rgx_find_all_bytes_device(const rgx_program* p, rgx_stream_ctx* 
 namespace {
 // starts-only results (4 bytes per match, the groups follow from the program's capture template): the exact kernel's programs only
 int StartsOnlyOffered(const rgx_program* p, size_t len) {
-  if (UseExactKernel(p->p.dev, len > 0x7FFFFF00ull ? 0 : (int32_t)len) || len == 0) return RGX_OK;
-  SetError("starts-only results need a fixed-template pattern (rgx_info.fixed_captures) and len >= 64");
+  // a property of the PROGRAM (a fixed-length class chain with a fixed capture template: the exact kernel's programs), not of the window:
+  // the tail window of a stream may be a few bytes long, and the kernels that take such a window write starts as well
+  if (UseExactKernel(p->p.dev, len > 0x7FFFFF00ull ? 0 : (int32_t)std::max<size_t>(len, 64)) || len == 0) return RGX_OK;
+  SetError("starts-only results need a fixed-template pattern of fixed length (rgx_info.fixed_captures; the exact kernel's programs)");
   return RGX_E_UNSUPPORTED;
 }
 }  // namespace

@@ -463,9 +463,13 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
         e = T.fixed_len >= 0 ? s + T.fixed_len : Walk<MODE>(tab, in, T, s_ctx, s);
       }
       if (idx < (unsigned long long)P.cap_records) {
-        int32_t* rec = P.pairs ? P.pairs + idx * 2 : P.spans + idx * ncap;         // (pairs: only with dynamic groups)
-        if (T.fixed_captures) WriteRecordFixed(rec, ncap, s_kind, s_delta, s, e);
-        else { rec[0] = s; rec[1] = e; }
+        if (P.starts_only) {                                                       // (fixed-template programs: a window too short for the exact kernel)
+          P.spans[idx] = s;
+        } else {
+          int32_t* rec = P.pairs ? P.pairs + idx * 2 : P.spans + idx * ncap;       // (pairs: only with dynamic groups)
+          if (T.fixed_captures) WriteRecordFixed(rec, ncap, s_kind, s_delta, s, e);
+          else { rec[0] = s; rec[1] = e; }
+        }
       }
       ++idx;
     }

@@ -238,7 +238,9 @@ int GrowBytes(uint8_t** p, size_t* cap, size_t need) {
 // caller hands it in again with a wider right halo (rgx_sharded_find_all_bytes does; rgx.h: rgx_shard_round).
 // (The reset-byte search of the right halo depends on the input alone: RunJob queues it IN FRONT of the scan -- QueueHaloChecks -- and its
 // answer lies in pinned memory once the scan's own synchronisation has passed; what is left here is the end of the last owned row.)
-bool RightEdgeApplies(const Shard& sh, const rgx_shard_window& w) { return !(sh.info.max_match_len >= 0 || w.last); }
+// (not for rows that are match starts: such rounds are the exact kernel's programs, whose matches are bounded -- and the check below reads
+// slot 1 of full records)
+bool RightEdgeApplies(const Shard& sh, const rgx_shard_window& w) { return !(sh.info.max_match_len >= 0 || w.last || w.starts_only); }
 int RightEdge(Shard& sh, Slot& s, const rgx_shard_window& w, const int32_t* d_spans, int64_t count, hipStream_t st, int* truncated) {
   *truncated = 0;
   if (!RightEdgeApplies(sh, w)) return RGX_OK;

@@ -362,6 +362,16 @@ def test_starts_only_rounds(gpu):
     total, rs = s.round(_windows(torch, buf, plan))            # a full-record round afterwards: the gather is offered again
     assert s.gather(0) == full.shape[0]
     s.close()
+    # the tail window of a stream may be a few bytes long -- starts-only is a property of the program, not of the window
+    # (the exact kernel wants 64 bytes; the kernel that takes a shorter window writes starts as well)
+    s2 = Sharded(c, devices=[0])
+    for tail in (b"x 2024-01-15 y 1999-12-31", b"2024-01-15", b"abc", b"x" * 63):
+        tb = torch.frombuffer(bytearray(tail), dtype=torch.uint8).cuda()
+        so = torch.empty(8, dtype=torch.int32, device="cuda")
+        total, rs = s2.round([dict(buf=tb, own=(0, len(tail)), base=0, starts_at_sync=True, last=True, out=so, starts_only=True)])
+        want = c.FindAllSpans(tail)[0][:, 0]
+        assert total == want.shape[0] and torch.equal(so[:total], want), tail
+    s2.close()
     e = Compiled(EMAIL).to(0)
     se = Sharded(e, devices=[0])
     tile = torch.frombuffer(bytearray(_tile()), dtype=torch.uint8).cuda()
