@@ -219,6 +219,214 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_kernel(const uint32_
 #undef RGX_TINY_WINDOW
 }
 
+
+// The same walk with the workgroup's 256 strings SORTED BY LENGTH before they are dealt to the waves.  A wave walks its strings in lock
+// step, to the longest of them: of the lane-steps the kernel above issues on lengths drawn evenly from [8, 40] 61% do work.  Here a
+// group is the workgroup's 256 strings; a counting sort by the number of 4-byte trips (16 bins: an LDS add per string returns its
+// rank in the bin, every wave turns the 16 counts into the bins' starts with four DPP adds, a permute fetches the lane's) gives each
+// wave the quarter of the group whose lengths are closest: on the same lengths the four waves walk to 4, 6, 8 and 10 trips instead of
+// 10 each.  The quarter a wave takes rotates with the group (the waves of a workgroup sit on one SIMD each; a fixed quarter would
+// hand one SIMD the long strings of every group).  Price: the waves meet twice per group (the sort needs all lengths, the staged
+// bytes and the order must be in LDS before the walk), and a wave's results go to the places of its strings -- 24-byte records
+// scattered over the group's 6 KiB, which the L2 puts together again.
+// Measured (config C3, 10 M strings of 8-40 bytes, PMC in profiles/r05_sq_batch_tiny_sorted.txt): SQ_INSTS_VALU 107.5 M -> 82.8 M per
+// launch (-23%, as counted above), the call 0.224 -> 0.212..0.216 ms; lengths from [20, 56]: 0.287 -> 0.268 ms.  The time follows the
+// instruction count only that far: with the sort the kernel is no longer bound by VALU issue (82.8 M x 4 cycles / 1024 SIMDs = 72% of
+// its cycles) -- a group still takes as long as its longest wave, the waves that are done early wait at the barrier, and what is
+// resident (eight waves a SIMD at 64 registers) does not fill the gap.  RGX_TINY_WAVE=1 (experiment builds) runs the kernel above.
+template <int NREG, bool REF>
+__attribute__((amdgpu_waves_per_eu(NREG <= 4 ? 8 : 1, NREG <= 4 ? 8 : 6)))      // (64 registers: eight waves a SIMD, what the LDS allows)
+__global__ __launch_bounds__(kBlockThreads) void batch_tiny_sorted_kernel(const uint32_t* __restrict__ img, const uint8_t* __restrict__ concat,
+                                                                           const uint64_t* __restrict__ offsets, int64_t nstr,
+                                                                           uint8_t* __restrict__ found, int32_t* __restrict__ spans, int wslice, int unset,
+                                                                           int ncap_out, int fixed, const uint8_t* __restrict__ cap_kind,
+                                                                           const int32_t* __restrict__ cap_delta, uint32_t* ctl) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  const int tid = threadIdx.x;
+  {
+    uint32_t* d = reinterpret_cast<uint32_t*>(smem);
+    for (int i = tid; i < kTinyWords; i += kBlockThreads) d[i] = img[i];
+  }
+  unsigned char* const win = smem + kTinyImageBytes;
+  uint32_t* const hist = reinterpret_cast<uint32_t*>(win + wslice + 16);            // [2][16] + [32] the stop word
+  uint32_t* const perm = hist + 48;                                                 // [256]: place in the window | length << 14 | string << 20
+  if (tid < 48) hist[tid] = 0;
+  __syncthreads();
+  const uint32_t lds0 = (uint32_t)(uintptr_t)(const unsigned char __attribute__((address_space(3)))*)smem;
+  const uint32_t cm_at = lds0 + kTinyColmap * 4, sel_at = lds0 + kTinySel * 4;
+  const L32 ini = (L32)(uintptr_t)(lds0 + kTinyInit * 4);
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  const uint32_t win_at = lds0 + kTinyImageBytes;
+  const auto load_sel = [&](uint32_t cell_at, uint32_t* s) {
+    const L32 q = (L32)(uintptr_t)(sel_at + cell_at);
+    if (NREG == 1) s[0] = q[0];
+    if (NREG == 2) { const u32x2 a = *(L64)q; s[0] = a.x; s[1] = a.y; }
+    if (NREG == 3) { const u32x2 a = *(L64)q; s[0] = a.x; s[1] = a.y; s[2] = q[2]; }
+    if (NREG >= 4) { const u32x4 a = *(L128)q; s[0] = a.x; s[1] = a.y; s[2] = a.z; s[3] = a.w; }
+    if (NREG == 5) s[4] = q[4];
+    if (NREG == 6) { const u32x2 b = *(L64)(q + 4); s[4] = b.x; s[5] = b.y; }
+    if (NREG == 7) { const u32x2 b = *(L64)(q + 4); s[4] = b.x; s[5] = b.y; s[6] = q[6]; }
+    if (NREG == 8) { const u32x4 b = *(L128)(q + 4); s[4] = b.x; s[5] = b.y; s[6] = b.z; s[7] = b.w; }
+  };
+  const int ntrack = (int)__builtin_amdgcn_readfirstlane(ini[13]);
+  uint32_t reg_of[8];
+#pragma unroll
+  for (int c = 0; c < 8; ++c) reg_of[c] = __builtin_amdgcn_readfirstlane(ini[16 + c]);
+  const int ngroups = (int)((nstr + kBlockThreads - 1) / kBlockThreads);
+  const int G = (int)gridDim.x;
+  const uint8_t* const idle = reinterpret_cast<const uint8_t*>(img);
+  // the software pipeline of the kernel above, a workgroup wide: offsets two groups ahead, bytes one group ahead; the window's ends
+  // are the group's first and last offsets, fetched as scalars
+#define RGX_TINY_NV(g) ((g) < ngroups ? (int)min((int64_t)kBlockThreads, nstr - (int64_t)(g) * kBlockThreads) : 0)
+#define RGX_TINY_META(g, a, b, gb, ge)                                                              \
+  do {                                                                                              \
+    const int nv_ = RGX_TINY_NV(g);                                                                 \
+    const int64_t i0_ = nv_ ? (int64_t)(g) * kBlockThreads : nstr - 1;                              \
+    const uint64_t* ob_ = offsets + i0_;                                                            \
+    const uint32_t lc_ = min((uint32_t)tid, (uint32_t)(nv_ ? nv_ - 1 : 0));                         \
+    a = ob_[lc_]; b = ob_[lc_ + 1];                                                                 \
+    gb = ob_[0]; ge = ob_[nv_ ? nv_ : 1];                                                           \
+  } while (0)
+#define RGX_TINY_WINDOW(g, a, b, gb, ge, wb, wvalid, rel, len)                                                                    \
+  do {                                                                                                                            \
+    const int nv_ = RGX_TINY_NV(g);                                                                                               \
+    wb = 0; wvalid = 0;                                                                                                           \
+    if (nv_) {                                                                                                                    \
+      wb = (gb) & ~15ull;                                                                                                         \
+      const uint64_t span_ = (((ge) - wb) + 15ull) & ~15ull;                                                                      \
+      wvalid = (int)(span_ < (uint64_t)wslice ? span_ : (uint64_t)wslice);                                                        \
+    }                                                                                                                             \
+    rel = (uint32_t)(a) - (uint32_t)wb;                                                                                           \
+    len = tid < nv_ ? (int)((uint32_t)(b) - (uint32_t)(a)) : 0;                                                                   \
+    /* a string too long for the tag bytes, or one behind it that the window does not hold: no walk (the batch is void) */      \
+    if (((b) - (a)) > (uint64_t)kTinyMaxLen) len = -1;                                                                            \
+    else if ((a) - wb + (uint64_t)len > (uint64_t)wvalid) len = 0;                                                                \
+  } while (0)
+#define RGX_TINY_PIECES(wb, wvalid)                                                                  \
+  do {                                                                                               \
+    const uint8_t* pb_ = (wvalid) ? concat + (wb) : idle;                                            \
+    const uint32_t nch_ = (uint32_t)(wvalid) >> 4;                                                   \
+    p0 = *reinterpret_cast<const uint4*>(pb_ + ((uint32_t)tid < nch_ ? (uint32_t)tid << 4 : 0u));                  \
+    p1 = *reinterpret_cast<const uint4*>(pb_ + ((uint32_t)tid + 256u < nch_ ? ((uint32_t)tid + 256u) << 4 : 0u));  \
+  } while (0)
+  int gprev = -1, fprev = 0, pprev = 0;
+  int32_t rprev[8];
+  const auto flush = [&]() {
+    if (gprev < 0) return;
+    const int nv = RGX_TINY_NV(gprev);
+    const int64_t i0 = (int64_t)gprev * kBlockThreads;
+    gprev = -1;
+    if (pprev >= nv) return;
+    const int f = fprev;
+    (found + i0)[pprev] = (uint8_t)f;
+    if (REF && f == 2) {
+      const uint32_t k = atomicAdd(ctl + 1, 1u);
+      if (k < kTinyListCap) ctl[4 + k] = (uint32_t)i0 + (uint32_t)pprev;
+    }
+    int32_t* const dst = spans + i0 * ncap_out + (uint32_t)pprev * (uint32_t)ncap_out;
+    if (f && !fixed) {
+      int2* d2 = reinterpret_cast<int2*>(dst);
+#pragma unroll
+      for (int c = 0; c < 8; c += 2)
+        if (c < ncap_out) d2[c >> 1] = make_int2(rprev[c], rprev[c + 1]);
+    } else if (f) {
+      dst[0] = rprev[0]; dst[1] = rprev[1];
+      for (int c = 2; c < ncap_out; ++c) dst[c] = cap_kind[c] == kCapFromStart ? rprev[0] + cap_delta[c] : rprev[1] - cap_delta[c];
+    }
+  };
+  uint4 p0, p1;
+  uint64_t an, bn, gbn, gen, wbc, wbn;
+  uint32_t relc, reln;
+  int wvc, wvn, lenc, lenn;
+  int grp = (int)blockIdx.x;
+  RGX_TINY_META(grp, an, bn, gbn, gen);
+  RGX_TINY_WINDOW(grp, an, bn, gbn, gen, wbc, wvc, relc, lenc);
+  RGX_TINY_PIECES(wbc, wvc);
+  RGX_TINY_META(grp + G, an, bn, gbn, gen);
+  uint32_t stop_next = __builtin_nontemporal_load(ctl);
+  for (int it = 0; grp < ngroups; grp += G, ++it) {
+    uint32_t* const h = hist + ((it & 1) << 4);
+    // the optimistic launch: a string longer than the tag bytes hold voids the batch -- the host takes the general path
+    if (__builtin_amdgcn_ballot_w64(lenc < 0) != 0ull && lane == 0) atomicOr(ctl, 1u);
+    if (stop_next != 0u) hist[32] = 1u;                       // (one wave seeing the word is all waves leaving together, below)
+    const int len0 = lenc < 0 ? 0 : lenc;
+    const uint32_t bin = (uint32_t)len0 >> 2;                 // <= 14
+    const uint32_t rank = atomicAdd(&h[bin], 1u);
+    __syncthreads();                                          // every wave is done with the group before: its bytes and order may go
+    {
+      const int nch = wvc >> 4;
+      if (tid < nch) *reinterpret_cast<uint4*>(win + (tid << 4)) = p0;
+      if (tid + 256 < nch) *reinterpret_cast<uint4*>(win + ((tid + 256) << 4)) = p1;
+      if (nch > 512) {
+        // strings of more than 32 bytes on average: the second half of the window is fetched now, not a group ahead (registers)
+        const uint8_t* const pb = concat + wbc;
+        if (tid + 512 < nch) *reinterpret_cast<uint4*>(win + ((tid + 512) << 4)) = *reinterpret_cast<const uint4*>(pb + ((tid + 512) << 4));
+        if (tid + 768 < nch) *reinterpret_cast<uint4*>(win + ((tid + 768) << 4)) = *reinterpret_cast<const uint4*>(pb + ((tid + 768) << 4));
+      }
+    }
+    {
+      // the bins' starts: the 16 counts in the lanes of a row, an inclusive scan of the row, the lane's bin fetched by a permute
+      const uint32_t hv = h[lane & 15];
+      uint32_t x = hv;
+      x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);
+      x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);
+      x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
+      x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
+      const uint32_t start = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(bin << 2), (int)(x - hv));
+      perm[start + rank] = relc | ((uint32_t)len0 << 14) | ((uint32_t)tid << 20);
+    }
+    if (tid < 16) hist[(((it + 1) & 1) << 4) + tid] = 0;       // the next group's counts (last read a group ago)
+    const uint32_t halt = hist[32];
+    flush();
+    RGX_TINY_WINDOW(grp + G, an, bn, gbn, gen, wbn, wvn, reln, lenn);
+    RGX_TINY_PIECES(wbn, wvn);
+    wbc = wbn; wvc = wvn; relc = reln; lenc = lenn;
+    RGX_TINY_META(grp + 2 * G, an, bn, gbn, gen);
+    stop_next = __builtin_nontemporal_load(ctl);
+    if (__builtin_amdgcn_readfirstlane(halt) != 0u) break;    // (the same word for every wave: written before the barrier above)
+    __syncthreads();
+    const uint32_t e = perm[(((uint32_t)wave + (uint32_t)it) & 3u) * 64u + (uint32_t)lane];
+    const uint32_t rel = e & 16383u;
+    const int len = (int)((e >> 14) & 63u);
+    const uint32_t addr = win_at + rel;
+    const L32 w32 = (L32)(uintptr_t)(addr & ~3u);
+    const uint32_t sh = addr & 3u;
+    TinyLane<NREG> L;
+#pragma unroll
+    for (int r = 0; r < NREG; ++r) L.R[r] = ini[r];
+    L.A = ini[8]; L.q5 = ini[9]; L.st4 = ini[10];
+    uint32_t lo = w32[0], hi = w32[1];
+    const int ntrip = len >> 2;
+    for (int t = 0; t < ntrip; ++t) {
+      const uint32_t b4 = __builtin_amdgcn_alignbyte(hi, lo, sh);
+      lo = hi; hi = w32[t + 2];
+      u32x2 cm[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) cm[k] = *(L64)(uintptr_t)(cm_at + (((b4 >> (8 * k)) & 255u) << 3));
+#pragma unroll
+      for (int k = 0; k < 4; ++k) TinyStep<NREG, REF>(L, cm[k].x, cm[k].y, load_sel, (uint32_t)(4 * t + k + 1));
+    }
+    {
+      const int r = len & 3, at = ntrip << 2;
+      const uint32_t b4 = __builtin_amdgcn_alignbyte(hi, lo, sh);
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+        if (k < r) {
+          const u32x2 cm = *(L64)(uintptr_t)(cm_at + (((b4 >> (8 * k)) & 255u) << 3));
+          TinyStep<NREG, REF>(L, cm.x, cm.y, load_sel, (uint32_t)(at + k + 1));
+        }
+    }
+    fprev = TinyFinish<NREG, REF>(L, unset, ntrack, reg_of, rprev);
+    gprev = grp;
+    pprev = (int)(e >> 20);
+  }
+  flush();
+#undef RGX_TINY_NV
+#undef RGX_TINY_PIECES
+#undef RGX_TINY_META
+#undef RGX_TINY_WINDOW
+}
+
 }  // namespace
 
 bool BatchTinyFits(const DevTables& U, const DevTables& F, const uint8_t* concat, int64_t nstr, bool ref) {
@@ -231,10 +439,11 @@ bool BatchTinyFits(const DevTables& U, const DevTables& F, const uint8_t* concat
 hipError_t LaunchBatchTiny(const DevTables& U, const DevTables& F, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,
                            int32_t* spans, bool ref, uint32_t* ctl, hipStream_t stream) {
   if (nstr <= 0) return hipSuccess;
-  // the wave's 64 strings lie in its slice whole: 64 x the longest the tag bytes allow, the 15 bytes in front of the first (the window
-  // starts at a multiple of 16) and the round-up behind the last
-  const int wslice = (64 * kTinyMaxLen + 15 + 15 + 15) & ~15;
-  const size_t lds = (size_t)kTinyImageBytes + 4 * (size_t)(wslice + 16);
+  // the workgroup's 256 strings lie in its window whole: 256 x the longest the tag bytes allow, the 15 bytes in front of the first (the
+  // window starts at a multiple of 16) and the round-up behind the last.  (The kernel without the sort: the same per wave.)
+  static const bool per_wave = ExpEnv("RGX_TINY_WAVE") != nullptr;
+  const int wslice = per_wave ? (64 * kTinyMaxLen + 15 + 15 + 15) & ~15 : (kBlockThreads * kTinyMaxLen + 15 + 15 + 15) & ~15;
+  const size_t lds = per_wave ? (size_t)kTinyImageBytes + 4 * (size_t)(wslice + 16) : (size_t)kTinyImageBytes + (size_t)(wslice + 16) + (48 + kBlockThreads) * 4;
   const int cus = DeviceCus();
   const int64_t ngroups = (nstr + kBlockThreads - 1) / kBlockThreads;
   const int unset = F.unmatched_minus1 ? -1 : 0;
@@ -248,7 +457,8 @@ hipError_t LaunchBatchTiny(const DevTables& U, const DevTables& F, const uint8_t
   static std::atomic<int> per_cu_of[9][2];
 #define RGX_TINY_GO(N)                                                                                                                  \
   do {                                                                                                                                  \
-    const void* fn = replay ? (const void*)batch_tiny_kernel<N, true> : (const void*)batch_tiny_kernel<N, false>;                       \
+    const void* fn = per_wave ? (replay ? (const void*)batch_tiny_kernel<N, true> : (const void*)batch_tiny_kernel<N, false>)           \
+                              : (replay ? (const void*)batch_tiny_sorted_kernel<N, true> : (const void*)batch_tiny_sorted_kernel<N, false>); \
     int per_cu = per_cu_of[N][replay ? 1 : 0].load(std::memory_order_relaxed);                                                          \
     if (per_cu == 0) {                                                                                                                  \
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlockThreads, lds) != hipSuccess || per_cu < 1) per_cu = 4;        \
@@ -256,10 +466,9 @@ hipError_t LaunchBatchTiny(const DevTables& U, const DevTables& F, const uint8_t
     }                                                                                                                                   \
     int64_t grid = (int64_t)cus * per_cu * kTinyGridRounds;                                                                             \
     if (grid > ngroups) grid = ngroups;                                                                                                 \
-    if (replay) hipLaunchKernelGGL((batch_tiny_kernel<N, true>), dim3((unsigned)grid), dim3(kBlockThreads), lds, stream, U.tiny, concat, \
-                                   offsets, nstr, found, spans, wslice, unset, F.ncap, fixed, F.cap_kind, F.cap_delta, ctl);            \
-    else hipLaunchKernelGGL((batch_tiny_kernel<N, false>), dim3((unsigned)grid), dim3(kBlockThreads), lds, stream, U.tiny, concat,       \
-                            offsets, nstr, found, spans, wslice, unset, F.ncap, fixed, F.cap_kind, F.cap_delta, ctl);                   \
+    void* args[] = {(void*)&U.tiny, (void*)&concat, (void*)&offsets, (void*)&nstr, (void*)&found, (void*)&spans, (void*)&wslice,        \
+                    (void*)&unset, (void*)&F.ncap, (void*)&fixed, (void*)&F.cap_kind, (void*)&F.cap_delta, (void*)&ctl};                \
+    if (hipLaunchKernel(fn, dim3((unsigned)grid), dim3(kBlockThreads), args, lds, stream) != hipSuccess) return hipGetLastError();      \
   } while (0)
   switch (U.tiny_nreg) {
     case 1: RGX_TINY_GO(1); break;

@@ -571,7 +571,10 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   const bool fc_big = len >= (size_t(8) << 20);
   const int fc_pref = p->fc_pref.load(std::memory_order_relaxed);
   const bool fc_open = fc_pref == 0 && fc_big;                 // still comparing: this call is timed
-  int fcm = (!use_w && !us_ws && !c->prefer_w && p->fc_bad.load(std::memory_order_relaxed) < 2 && fc_pref >= 0) ? UseFcKernel(T, ilen) : 0;
+  // (a pattern without a reset byte: its tiles are chained through the look-back from offset 0 of the text, which must then be where the
+  // chain begins -- not a window of a sharded round with a left halo)
+  const bool fc_sync_ok = T.reset_values == 0 ? own_lo <= 0 : (!use_w && !us_ws && !c->prefer_w);
+  int fcm = (fc_sync_ok && p->fc_bad.load(std::memory_order_relaxed) < 2 && fc_pref >= 0) ? UseFcKernel(T, ilen) : 0;
   if (fcm && fc_open && p->fc_us_per_gib.load(std::memory_order_relaxed) != 0) fcm = 0;      // the kernel has its time: the other one's turn
   const auto fc_t0 = std::chrono::steady_clock::now();
   auto fc_rate = [&]() -> int {
@@ -623,6 +626,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
       const int other = fc_rate(), mine = p->fc_us_per_gib.load(std::memory_order_relaxed);
       p->other_us_per_gib.store(other, std::memory_order_relaxed);
       p->fc_pref.store(mine <= other ? 1 : -1, std::memory_order_relaxed);
+      if (getenv("RGX_FC_VERBOSE")) fprintf(stderr, "[rgx] filter + candidate kernel %d us per GiB, the other path %d: %s\n", mine, other, mine <= other ? "taken" : "left");
     };
   }
   // Every scan but the exact kernel's may meet slices without a sync point in reach; the first scan marks them as it goes

@@ -67,6 +67,29 @@ __device__ __forceinline__ unsigned long long WaveSum64(unsigned long long v) {
 // by construction) or equal blockIdx.x (predecessors were dispatched earlier on every GPU observed, but HIP does not
 // promise dispatch order) -- so the spin is bounded and a timeout raises *timeout_flag; the host then repeats the
 // scan in ticket mode.  Results never depend on the assumption, only speed does.
+//
+// MAXHI: the value is a PAIR -- bits [0, 31) a count (added up), bits [31, 62) an offset (the MAXIMUM is taken): rgx_scan_fc.hip's tiles
+// of patterns without a reset byte hand the end of their last match along with their count.
+template <bool MAXHI>
+__device__ __forceinline__ unsigned long long LookBackCombine(unsigned long long a, unsigned long long b) {
+  if (!MAXHI) return a + b;
+  const unsigned long long lo = ((a & 0x7FFFFFFFull) + (b & 0x7FFFFFFFull)) & 0x7FFFFFFFull;
+  const unsigned long long ha = a >> 31, hb = b >> 31;
+  return lo | ((ha > hb ? ha : hb) << 31);
+}
+template <bool MAXHI>
+__device__ __forceinline__ unsigned long long LookBackWaveReduce(unsigned long long v) {
+  if (!MAXHI) return WaveSum64(v);
+  unsigned lo = (unsigned)(v & 0x7FFFFFFFull), hi = (unsigned)(v >> 31);
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) {
+    lo += (unsigned)__shfl_xor((int)lo, d, 64);
+    const unsigned o = (unsigned)__shfl_xor((int)hi, d, 64);
+    hi = o > hi ? o : hi;
+  }
+  return (unsigned long long)(lo & 0x7FFFFFFFu) | ((unsigned long long)hi << 31);
+}
+template <bool MAXHI = false>
 __device__ __forceinline__ unsigned long long LookBack(unsigned long long* desc, int id, unsigned long long own, int lane,
                                                         unsigned* timeout_flag, int nap = 1,
                                                         unsigned long long* host_flag = nullptr, bool bounded = true) {
@@ -105,12 +128,12 @@ __device__ __forceinline__ unsigned long long LookBack(unsigned long long* desc,
       }
       const unsigned long long pm = __ballot((d >> 62) == 2);
       const int first = pm ? __builtin_ctzll(pm) : 64;
-      excl += WaveSum64(lane <= first ? (d & kDescValMask) : 0ull);
+      excl = LookBackCombine<MAXHI>(excl, LookBackWaveReduce<MAXHI>(lane <= first ? (d & kDescValMask) : 0ull));
       if (pm) break;
       idx -= 64;
     }
     if (lane == 0)
-      __hip_atomic_store(&desc[id], kDescPrefix | (excl + own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(&desc[id], kDescPrefix | LookBackCombine<MAXHI>(excl, own), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
   return excl;
 }

@@ -105,9 +105,7 @@ int FcModeOf(const Tables& t, bool onepass) {
   if (t.flags & (1u << 3)) return 0;                          // RGX_FLAG_NO_PREFILTER_SCAN
   if (t.anchored || t.lookahead_mode || t.can_match_empty || t.sa_exact || t.sa_k < 2 || t.sa_k > 29 || t.ncap > 32) return 0;
   for (int c = 0; c < 4; c++) if (t.start_accept[c]) return 0;
-  bool has_reset = false;
-  for (int c = 0; c < 256; c++) has_reset = has_reset || t.reset_byte[c];
-  if (!has_reset) return 0;
+  // (a pattern without a reset byte has no sync points: the kernel then chains its tiles through the look-back -- rgx_scan_fc.hip: carry)
   auto weight = [](int c) -> double {
     if (c == ' ') return 0.15;
     if (c >= 'a' && c <= 'z') return 0.026;
@@ -264,7 +262,7 @@ int UploadFc(Program* p) {
   int ops_bytes = mode == 2 ? (int)((pool.size() * 4 + 15) & ~size_t(15)) : 16;
   if (mode == 2 && fc::kCellsOff + cells_bytes + 2 * ops_bytes > 32768) { mode = 1; ops_bytes = 16; }
   // every workgroup copies the image for its 16 KiB tile: it has to be small next to it
-  if (cells_bytes + 2 * ops_bytes > 8 * 1024) return RGX_E_UNSUPPORTED;
+  if (cells_bytes + 2 * ops_bytes > 16 * 1024) return RGX_E_UNSUPPORTED;
   const int cells_at = fc::kCellsOff, ops_at = cells_at + cells_bytes;
   const int b_bytes = cells_bytes + 2 * ops_bytes;
   const int rows_off = ops_at + 2 * ops_bytes;

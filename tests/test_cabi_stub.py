@@ -143,16 +143,21 @@ def test_twin_refusals_and_fallbacks(stub, tmp_path):
     blob, _ = _tables(tmp_path, r"(?P<a>ab+)c?", "A")
     rc, out = _run(stub, blob, b"xx ab yy abbc ab", tmp_path, "reader", 65536, 0, 0)
     assert rc == 0
-    # the reference's Tagged DFA (URLCapture): FindAll (the wrapper reports matches again) and Replace are refused in reference mode ...
+    # the reference's Tagged DFA (URLCapture): FindAll is refused in reference mode (the wrapper reports matches again) ...
     blob, go = _tables(tmp_path, URL_CAPTURE, "U")
     data = b"see https://example.com/a and http://h.org:80/x then https://plain.net"
     rc, out = _run(stub, blob, data, tmp_path, "findall", -1)
     assert out.decode().splitlines() == ["GOFALLBACK -3"]
-    rc, out = _run(stub, blob, data, tmp_path, "replace", "<$host>", 0)
-    assert out.decode().splitlines() == ["GOFALLBACK -3"]
+    # ... Replace runs the engine's own loop over ONE result struct (round 5): a group the third match does not assign expands to what
+    # the second left there -- as oracle.replace says
+    from oracle import engines as E
+    from oracle import replace as R
+    rc, out = _run(stub, blob, data, tmp_path, "replace", "<$host$port>", 0)
+    exp = R.replace_all(E.Compiled(URL_CAPTURE), data, "<$host$port>", quirks=True)
+    assert rc == 0 and out == b"OUT %d\n%s\nEND\n" % (len(exp), exp)
+    assert b"<plain.net80>" in out
     # ... while FindBytes and FindReader run the engine itself: the third match has neither port nor path, and the reused result
     # struct still shows the second match's (tdfa.go:1031-1046 leaves the fields untouched) -- as oracle.find_reader(reuse=True) says
-    from oracle import engines as E
     o = E.Compiled(URL_CAPTURE)
     exp = []
     import io

@@ -25,6 +25,15 @@ CASES = [
 ]
 
 
+# patterns WITHOUT a reset byte (some thread survives any byte): the tiles' chains are joined by the look-back (the end of a tile's last
+# match travels with its count), a tile that finds an earlier match reaching past its first candidate gives the call up
+CARRY_CASES = [
+    (r'\[(?P<d>[^\]]+)\] "(?P<m>[^"]+)"', '[]" ab\n', [b'[a b] "x"', b'[ab] "', b'[] "x"', b'[a]  "x"', b'[a\nb] "q\nr"']),
+    (r'GET (?P<p>[^?]+)\?(?P<q>[^#]+)#', 'GET ?#ab\n', [b'GET a?b#', b'GET ?b#', b'GET a b?\n#', b'GET a?#', b'GET a??b##']),
+    (r'\[(?P<ts>[^\]]+)\]\s+(?P<lvl>[A-Z]+):\s+(?P<msg>[^;]+);', '[]A: ;x\n', [b'[x] A: x;', b'[x]A: x;', b'[x x]\nAA:  x x;', b'[] A: x;', b'[x] A:;', b'[[x] A: ];']),
+]
+
+
 @pytest.fixture(scope="module")
 def torch_dev(built):
     import torch
@@ -170,3 +179,32 @@ def test_fc_text_without_a_match(torch_dev):
     assert res.total == 0 and spans.shape[0] == 0
     n, _ = c.CountAll(data)
     assert n == 0
+
+
+@pytest.mark.parametrize("pattern,alphabet,words", CARRY_CASES)
+def test_fc_patterns_without_a_reset_byte(torch_dev, pattern, alphabet, words):
+    from oracle.gen_c import CMatcher
+    from regengo_amd import Compiled
+    c = Compiled(pattern).to(0)
+    assert c.info.scan_kernel == 7, (pattern, c.info.scan_kernel)
+    assert not any(c.reset_bytes()), pattern
+    cm = CMatcher(pattern, q8=False)
+    rng = random.Random(zlib.crc32(pattern.encode()) & 0xFFFF)
+    sizes = [64, 65, 1000, TILE - 1, TILE, TILE + 1, 2 * TILE + 63, 40000, 70001, 200000, 1 << 20, 3 << 20]
+    for b in _texts(rng, alphabet, words, sizes) + [b"", words[0], words[0] * 3000]:
+        _check(c, cm, b, torch_dev)
+    # a match that runs across a tile border (and one across several tiles, past the first candidates of the tiles behind it: the call
+    # is given up, the program's other kernel answers) -- every time with a fresh program: one that gave up twice stays with the other kernel
+    for gap in (10, 300, 2000):
+        for at in (TILE - 5, TILE - gap // 2, 2 * TILE - 1):
+            c2 = Compiled(pattern).to(0)
+            w = words[0]
+            cut = max(1, len(w) // 2)
+            body = (alphabet[-2] * gap).encode()                  # a byte the open part of the match runs over
+            buf = bytearray(b" " * (3 * TILE))
+            span = w[:cut] + body + w[cut:]
+            buf[at - cut:at - cut + len(span)] = span
+            for k in range(0, 3 * TILE - 64, 997):                # short matches everywhere else
+                if not (at - cut - len(w) - 2 < k < at - cut + len(span) + 2):
+                    buf[k:k + len(w)] = w
+            _check(c2, cm, bytes(buf), torch_dev, ("straddle", gap, at))
