@@ -225,20 +225,33 @@ int RefuseStream(const rgx_program* p, bool splice = false) {
 }
 // Scratch of the memoising engine's interpreter: nlanes lanes, each W visited words (all zero between launches) and cap stack words.
 int MemoScratchFor(rgx_stream_ctx* c, int64_t W, int64_t cap, int64_t want_lanes, int64_t* nlanes, unsigned long long** visited, unsigned long long** stack) {
+  // Lane L owns visited words [L * W, ..) and stack entries [L * cap, ..).  The scratch holds the lanes that WORK: the callers ask for
+  // min(items, 65536) lanes and the kernels stride their items over the grid, so of a grid rounded up to whole waves the lanes behind
+  // `want_lanes` never touch memory (one 64 KiB MatchBytes: one lane's 2.6 MB, not a wave's 168 MB).  In all it is held to 512 MiB (the reader check's first pass: 65536 lanes of 8 KB) --
+  // fewer lanes then, whole waves of them because every lane of the grid has items -- and a buffer left behind by an unusual call
+  // (long strings) is given back by the next ordinary one: a service that pools contexts does not keep GiBs of HBM for good.
   const int64_t per = W + cap;
-  int64_t lanes = std::min<int64_t>(want_lanes, std::max<int64_t>(((int64_t)1 << 28) / per, 64));     // at most 2 GiB of scratch
-  lanes = std::max<int64_t>((lanes + 63) / 64 * 64, 64);
-  const int64_t need = lanes * per + 64;
+  constexpr int64_t kMemoWords = (int64_t)1 << 26;
+  const int64_t fit = std::max<int64_t>(kMemoWords / per, 1);
+  int64_t rows, grid;
+  if (want_lanes <= fit) { rows = std::max<int64_t>(want_lanes, 1); grid = (rows + 63) / 64 * 64; }
+  else { rows = grid = std::max<int64_t>(fit / 64 * 64, 64); }
+  const int64_t need = rows * per + 64;
+  if (c->d_memo && c->memo_cap > 4 * need && c->memo_cap > ((int64_t)1 << 23)) {
+    (void)hipStreamSynchronize(c->stream);
+    (void)hipFree(c->d_memo);
+    c->d_memo = nullptr; c->memo_cap = 0; c->memo_clean = 0;
+  }
   if (c->memo_cap < need || !c->d_memo) {
     int rc = Ensure(&c->d_memo, &c->memo_cap, need);
     if (rc != RGX_OK) return rc;
     c->memo_clean = 0;
   }
-  // the visited words of a launch are its first lanes * W words: zeroed when they were not left zero by the launch before -- the
+  // the visited words of a launch are its first rows * W words: zeroed when they were not left zero by the launch before -- the
   // kernels leave their visited words zero, but the STACKS of a launch lie right behind them and stay dirty
-  if (c->memo_clean < lanes * W) HIP_TRY(hipMemsetAsync(c->d_memo, 0, (size_t)(lanes * W) * 8, c->stream));
-  c->memo_clean = lanes * W;
-  *nlanes = lanes; *visited = c->d_memo; *stack = c->d_memo + lanes * W;
+  if (c->memo_clean < rows * W) HIP_TRY(hipMemsetAsync(c->d_memo, 0, (size_t)(rows * W) * 8, c->stream));
+  c->memo_clean = rows * W;
+  *nlanes = grid; *visited = c->d_memo; *stack = c->d_memo + rows * W;
   return RGX_OK;
 }
 
@@ -569,7 +582,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   // Optimistic: a launch that gave up (a tile whose halo holds no reset byte, more candidates than lanes in a tile, a candidate that walks
   // for kilobytes) is void and the program's other kernel runs below; a program that gave up twice stays there.
   const bool fc_big = len >= (size_t(8) << 20);
-  const int fc_pref = p->fc_pref.load(std::memory_order_relaxed);
+  const int fc_pref = ExpEnv("RGX_FC_FORCE") ? 1 : p->fc_pref.load(std::memory_order_relaxed);      // (experiment builds: stage timings)
   const bool fc_open = fc_pref == 0 && fc_big;                 // still comparing: this call is timed
   // (a pattern without a reset byte: its tiles are chained through the look-back from offset 0 of the text, which must then be where the
   // chain begins -- not a window of a sharded round with a left halo)

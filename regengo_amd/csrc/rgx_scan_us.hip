@@ -1577,13 +1577,16 @@ hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t str
     // residency depends on the pattern's table size: asked per LDS footprint (and remembered), never carried over from another
     // pattern -- a grid sized for a small table deadlocks the look-back of a large one until the bounded spin gives up (1.4 s)
     static std::mutex mu;
-    static std::map<size_t, int> per_cu_of;     // key: (LDS footprint * 2 + kernel instance) * 64 + device
+    struct Residency { int per_cu; int asked; unsigned launches; int recounts; };
+    static std::map<size_t, Residency> per_cu_of;     // key: (LDS footprint * 2 + kernel instance) * 64 + device
     static std::map<int, int> ncu_of;
     int per_cu = 0, ncu = 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) dev = 0;
+    const size_t key = (shp * 2 + (rw ? 1 : 0)) * 64 + (size_t)(dev & 63);
+    bool count_now = false;
     {
       std::lock_guard<std::mutex> lock(mu);
-      int dev = 0;
-      if (hipGetDevice(&dev) != hipSuccess) dev = 0;
       auto nit = ncu_of.find(dev);
       if (nit == ncu_of.end()) {
         int n = 0;
@@ -1591,39 +1594,55 @@ hipError_t LaunchScanUs(const DevTables& T, const ScanParams& P, hipStream_t str
         nit = ncu_of.emplace(dev, n).first;
       }
       ncu = nit->second;
-      const size_t key = (shp * 2 + (rw ? 1 : 0)) * 64 + (size_t)(dev & 63);
       auto it = per_cu_of.find(key);
-      if (it == per_cu_of.end()) {
-        int q = 0;
-        hipError_t oe = rw ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, scan_us_pair_kernel<true>, kBlockThreads, shp)
-                           : hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, scan_us_pair_kernel<false>, kBlockThreads, shp);
-        if (oe != hipSuccess || q < 1) q = 1;
-        // 4 per CU measured best (16 waves: 3 leaves the SIMDs idle -- 0.78 against 0.88 ms per GiB for the URL pattern --, 5 adds
-        // nothing).  How many are really resident is ASKED of the device (round 4): the occupancy query is known to over-report by one
-        // for SGPR-heavy kernels, the old rule ("one less than the query says") therefore ran 3 where 4 fit, and a grid that is not
-        // resident stalls every look-back behind it until the bounded spin gives up.  A census launch of this very kernel with this
-        // very footprint (ScanParams::census: ~50 us, once per footprint and device) settles it.
-        if (q > 4) q = 4;
-        if (ExpEnv("RGX_US_PER_CU")) q = atoi(ExpEnv("RGX_US_PER_CU"));
-        uint32_t* d_census = nullptr;
-        if (q > 1 && hipMalloc((void**)&d_census, 8) == hipSuccess) {
-          for (; q > 1; --q) {
-            ScanParams C = P;
-            C.census = d_census;
-            uint32_t h[2] = {0, 0};
-            if (hipMemsetAsync(d_census, 0, 8, stream) != hipSuccess) { q = 1; break; }
-            if (rw) hipLaunchKernelGGL(scan_us_pair_kernel<true>, dim3(q * ncu), block, shp, stream, T, U, C);
-            else hipLaunchKernelGGL(scan_us_pair_kernel<false>, dim3(q * ncu), block, shp, stream, T, U, C);
-            if (hipMemcpyAsync(h, d_census, 8, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { q = 1; break; }
-            if (h[1] == (uint32_t)(q * ncu)) break;            // every workgroup saw every other one: q per CU are resident
-          }
-          (void)hipFree(d_census);
-        } else if (q > 2) {
-          q -= 1;
+      if (it == per_cu_of.end()) count_now = true;
+      else {
+        per_cu = it->second.per_cu;
+        // A census that came out BELOW what was asked for may have been taken while another stream held CUs (sharded slots, a second
+        // context): such a value is not kept for good -- it is taken again after 256 launches, up to four times.
+        if (it->second.per_cu < it->second.asked && it->second.recounts < 4 && ++it->second.launches >= 256u) {
+          it->second.launches = 0;
+          ++it->second.recounts;
+          count_now = true;
         }
-        it = per_cu_of.emplace(key, q).first;
       }
-      per_cu = it->second;
+    }
+    if (count_now) {
+      // (outside the lock: the census synchronises the stream, and nobody else's first launch should wait behind that; two threads
+      // that count at the same moment both see each other's workgroups and come out low -- the larger answer is the one kept)
+      int q = 0;
+      hipError_t oe = rw ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, scan_us_pair_kernel<true>, kBlockThreads, shp)
+                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&q, scan_us_pair_kernel<false>, kBlockThreads, shp);
+      if (oe != hipSuccess || q < 1) q = 1;
+      // 4 per CU measured best (16 waves: 3 leaves the SIMDs idle -- 0.78 against 0.88 ms per GiB for the URL pattern --, 5 adds
+      // nothing).  How many are really resident is ASKED of the device (round 4): the occupancy query is known to over-report by one
+      // for SGPR-heavy kernels, the old rule ("one less than the query says") therefore ran 3 where 4 fit, and a grid that is not
+      // resident stalls every look-back behind it until the bounded spin gives up.  A census launch of this very kernel with this
+      // very footprint (ScanParams::census: ~50 us, once per footprint and device) settles it.
+      if (q > 4) q = 4;
+      if (ExpEnv("RGX_US_PER_CU")) q = atoi(ExpEnv("RGX_US_PER_CU"));
+      const int asked = q;
+      uint32_t* d_census = nullptr;
+      if (q > 1 && hipMalloc((void**)&d_census, 8) == hipSuccess) {
+        for (; q > 1; --q) {
+          ScanParams C = P;
+          C.census = d_census;
+          uint32_t h[2] = {0, 0};
+          if (hipMemsetAsync(d_census, 0, 8, stream) != hipSuccess) { q = 1; break; }
+          if (rw) hipLaunchKernelGGL(scan_us_pair_kernel<true>, dim3(q * ncu), block, shp, stream, T, U, C);
+          else hipLaunchKernelGGL(scan_us_pair_kernel<false>, dim3(q * ncu), block, shp, stream, T, U, C);
+          if (hipMemcpyAsync(h, d_census, 8, hipMemcpyDeviceToHost, stream) != hipSuccess || hipStreamSynchronize(stream) != hipSuccess) { q = 1; break; }
+          if (h[1] == (uint32_t)(q * ncu)) break;            // every workgroup saw every other one: q per CU are resident
+        }
+        (void)hipFree(d_census);
+      } else if (q > 2) {
+        q -= 1;
+      }
+      std::lock_guard<std::mutex> lock(mu);
+      auto it = per_cu_of.find(key);
+      if (it == per_cu_of.end()) it = per_cu_of.emplace(key, Residency{q, asked, 0u, 0}).first;
+      else if (q > it->second.per_cu) it->second.per_cu = q;
+      per_cu = it->second.per_cu;
     }
     int nblk = per_cu * ncu;
     if (nblk > P.ntiles) nblk = P.ntiles;
