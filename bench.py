@@ -705,7 +705,7 @@ def run_c4(env, args):
     check_tile(tile, bytes(fx["tile_sha256"]).hex())
     A, U, Z = fx["a"].astype(np.int64), fx["u"].astype(np.int64), fx["z"].astype(np.int64)
     c = Compiled(URL, name="URL").to(env.local_rank)
-    assert c.info.ref_findall_offered, "C4's pattern: the reference memoises, its FindAllBytes is leftmost-first and offered"
+    assert c.info.ref_findall_offered == 1, "C4's pattern: the reference memoises, its FindAllBytes is leftmost-first and offered"
     sh = make_sharded(env, c)
     # the window: as large as 32-bit window-relative rows comfortably allow -- 1.6 GiB, five per GPU = the 8 GiB share of the 64 GiB
     # stream (per window ~0.19 ms of launches, synchronisations and round bookkeeping: 1 GiB windows 720 GB/s, 1.6 GiB 766, 1.9 GiB 783)
@@ -734,10 +734,14 @@ def run_c4(env, args):
     outs = [torch.empty((cap, c.ncap), dtype=torch.int32, device=dev) for _ in range(2)]
     torch.cuda.synchronize()
     stats = {}
-    # Rounds in flight.  The pair kernel and the capture pass each fill the GPU: a second round's kernels would only time-slice with
-    # the first's (same 14.8 ms per 8 windows, measured) and stretch every kernel's event-timed duration -- so ONE round at a time
-    # here; RGX_C4_DEPTH=2 for the experiment.  (The exact kernel's rounds, config c2, queue back to back on one stream instead.)
-    depth = max(1, min(2, int(os.environ.get("RGX_C4_DEPTH", "1"))))
+    # Rounds in flight.  Two (round 5): with the filter + candidate kernel one window is ONE kernel, and the host's part of a round
+    # (its wait, the halo answers, the next submit: ~0.13 ms) hides behind the other round's kernel -- 975 -> 1086 GB/s.  (With the pair
+    # kernel + capture pass of rounds 2-4 a second round only time-sliced with the first: same time per 8 windows, measured then.)  Two
+    # windows' kernels overlap, though, and an event-timed duration then counts the other window's share of the GPU too: the roofline's
+    # kernel time comes from a second TIMED region with one round in flight (`value_one_round_in_flight` in the line).
+    # RGX_C4_DEPTH=1 runs everything one round at a time.
+    depth = max(1, min(2, int(os.environ.get("RGX_C4_DEPTH", "2"))))
+    cur_depth = [depth]
 
     def one_pass(on_rows=None, gather=False, table=None):
         """All rounds of the stream.  on_rows(rows int32 window-relative, window, global row base); gather: every round's rows go to
@@ -759,7 +763,7 @@ def run_c4(env, args):
         tnext = 0
         grow = 0
         for t in range(args.windows):
-            while tnext < args.windows and tnext - t < depth:
+            while tnext < args.windows and tnext - t < cur_depth[0]:
                 submit(tnext)
                 tnext += 1
             total, rs = sh.wait()
@@ -771,7 +775,9 @@ def run_c4(env, args):
             base = count + sum(r["count"] for r in rs[:rank])
             if on_rows is not None:
                 on_rows(outs[slot][:me["count"]], wins[tt_], base)
-            if gather:
+            if gather == "offsets":
+                grow += sh.gather_offsets(0, out=table[grow:] if rank == 0 else None)
+            elif gather:
                 grow += sh.gather(0, out=table[grow:] if rank == 0 else None)
             count += total
         stats.update(count=count, kernel_ms=kms, truncated=trunc, unsynced=unsynced, rounds=args.windows, gathered=grow)
@@ -783,7 +789,14 @@ def run_c4(env, args):
 
     dt, reps = sustained(env, run_steps, args.steps, args.warmup)
     nsteps = args.steps * reps
+    k_ms_overlapped = stats["kernel_ms"] / max(args.windows, 1)
+    dt1, nsteps1 = dt, nsteps
+    if depth > 1:                     # the same steps, one round in flight: the kernel's own duration (and what the overlap is worth)
+        cur_depth[0] = 1
+        dt1, reps1 = sustained(env, run_steps, args.steps, 1)
+        nsteps1 = args.steps * reps1
     k_ms_sum = stats["kernel_ms"]
+    cur_depth[0] = 1                  # (the parity and gather passes below look at one round's rows at a time)
     # parity pass (untimed, same path): every window's rows against the oracle's rows on the tile, extended periodically
     ntiles = Ltot // T
     exp_total = len(A) + (ntiles - 2) * len(U) + len(Z)
@@ -822,19 +835,35 @@ def run_c4(env, args):
     parity_all = bool(env.allmin_int(1 if parity else 0))
     # the gather of every round's rows to rank 0 over the library's communicator (stream-absolute int64), timed as a pass with the
     # gather minus one without; rank 0 checks the table's first and last tile against the fixture
-    gather_ms = gather_ok = None
+    gather_ms = gather_ok = gather_offsets_ms = gather_offsets_ok = None
     if world > 1 or os.environ.get("RGX_BENCH_GATHER") == "1":
         table = torch.empty((exp_total + 64, c.ncap), dtype=torch.int64, device=dev) if rank == 0 else None
         env.barrier()
         g0 = time.perf_counter()
         g = dict(one_pass(gather=True, table=table))
         env.barrier()
-        gather_ms = max(0.0, env.allmax((time.perf_counter() - g0) * 1e3) - dt / nsteps * 1e3)
+        gather_ms = max(0.0, env.allmax((time.perf_counter() - g0) * 1e3) - dt1 / nsteps1 * 1e3)
         ok = True
         if rank == 0:
             ok = g["gathered"] == exp_total and bool(torch.equal(table[:len(A)], Ad))
             ok = ok and bool(torch.equal(table[exp_total - len(Z):exp_total], shift(Zd, (ntiles - 3) * T)))
         gather_ok = bool(env.allmin_int(1 if ok else 0))
+        # the compact form (rgx_sharded_gather_offsets): 8 bytes per match instead of 8 * ncap; checked against the fixture's (start, end)
+        wtable = torch.empty(exp_total + 64, dtype=torch.int64, device=dev) if rank == 0 else None
+        env.barrier()
+        g0 = time.perf_counter()
+        g = dict(one_pass(gather="offsets", table=wtable))
+        env.barrier()
+        gather_offsets_ms = max(0.0, env.allmax((time.perf_counter() - g0) * 1e3) - dt1 / nsteps1 * 1e3)
+        ok = True
+        if rank == 0:
+            m40 = (1 << 40) - 1
+            ws = wtable[:exp_total] & m40
+            we = ws + (wtable[:exp_total] >> 40)
+            zs = shift(Zd, (ntiles - 3) * T)
+            ok = g["gathered"] == exp_total and bool(torch.equal(ws[:len(A)], Ad[:, 0])) and bool(torch.equal(we[:len(A)], Ad[:, 1]))
+            ok = ok and bool(torch.equal(ws[exp_total - len(Z):], zs[:, 0])) and bool(torch.equal(we[exp_total - len(Z):], zs[:, 1]))
+        gather_offsets_ok = bool(env.allmin_int(1 if ok else 0))
     ms_per_step = dt / nsteps * 1e3
     value = float(Ltot) / (dt / nsteps) / 1e9
     k_ms = k_ms_sum / max(args.windows, 1)
@@ -855,11 +884,16 @@ def run_c4(env, args):
                       "ranks_formed": int(sh.world), "communicator": sh.communicator,
                       "rounds": stp["rounds"], "unsynced_halos": stp["unsynced"], "parity_oracle_fixture_periodic": parity_all,
                       "parity_pieces_checked": checked[0], "gather_ms": None if gather_ms is None else round(gather_ms, 3),
-                      "gather_rows_checked": gather_ok}
+                      "gather_rows_checked": gather_ok,
+                      "gather_offsets_ms": None if gather_offsets_ms is None else round(gather_offsets_ms, 3),
+                      "gather_offsets_bytes_per_match": 8, "gather_bytes_per_match": 8 * c.ncap, "gather_offsets_checked": gather_offsets_ok}
     line["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
                         "kernel": KERNEL_NAMES.get(c.info.scan_kernel, "rgx scan kernel"), "kernel_ms": round(k_ms, 4),
-                        "algorithmic_bytes_per_launch": win_bytes, "timed_launches": args.windows * nsteps}
+                        "algorithmic_bytes_per_launch": win_bytes, "timed_launches": args.windows * nsteps1}
+    if depth > 1:
+        line["roofline"]["kernel_ms_source"] = "the timed region with ONE round in flight (below); with two in flight the windows' kernels overlap and an event-timed duration reads %.4f ms" % k_ms_overlapped
+        line["value_one_round_in_flight"] = {"value": round(float(Ltot) / (dt1 / nsteps1) / 1e9, 2), "ms_per_step": round(dt1 / nsteps1 * 1e3, 4), "steps": nsteps1}
     if rank == 0 and c.info.ref_stream_offered:
         line["config"]["find_reader_reference_mode"] = c4_reader_leg(c, tile, len(A), len(U), len(Z))
     if not args.no_cpu_baseline and world == 1:
@@ -928,7 +962,7 @@ def run_c5(env, args):
             if e["mode"] == "line":
                 stdlib = e.get("semantics") != "reference"
             else:
-                stdlib = not Compiled(e["pattern"]).info.ref_findall_offered
+                stdlib = Compiled(e["pattern"]).info.ref_findall_offered != 1
             c = Compiled(e["pattern"], stdlib=stdlib).to(env.local_rank, ctx_of=first_prog[0])      # one context for the whole suite
             sem[(e["mode"], "stdlib" if stdlib else "reference")] = sem.get((e["mode"], "stdlib" if stdlib else "reference"), 0) + 1
         except _capi.RgxError:

@@ -131,10 +131,15 @@ typedef struct rgx_info {
   int32_t ref_findall_offered; /* 1: FindAllBytes(Append) / FindAllString and the count-only forms return the reference's own result:
                              * plain backtracking engine; or the memoising one on a pattern that cannot match empty (its memo is
                              * never cleared between iterations, find.go:175-188, which only shows when an attempt starts on an
-                             * Alt the previous match ended on -- an empty match).  0: the reference emits its
-                             * Tagged DFA, whose FindAll advances by the match LENGTH and reports matches again
-                             * (compiler.go:646-651, Q11), or memoises on a pattern that matches empty: every FindAll / count entry
-                             * point returns RGX_E_UNSUPPORTED unless the program was compiled with RGX_FLAG_STDLIB_SEMANTICS    */
+                             * Alt the previous match ended on -- an empty match).  2 (round 5): the reference emits
+                             * its Tagged DFA, whose FindAll WRAPPER advances by the match LENGTH and reports matches again
+                             * (compiler.go:646-651, Q11) -- reproduced, duplicates included, for a WHOLE text on one device:
+                             * rgx_find_all_bytes(_device) and rgx_count_all_device answer, the forms that cut a text (owned
+                             * ranges, starts-only rows, submit / wait, rgx_sharded_*) return RGX_E_UNSUPPORTED; rows hold
+                             * (-1, -1) for a group that took no part (the wrapper's FindBytes fills a fresh struct).  0: that
+                             * engine on a pattern with `^` (an attempt then depends on the slice it is made in), or the memoising
+                             * one on a pattern that matches empty: every FindAll / count entry point returns RGX_E_UNSUPPORTED
+                             * unless the program was compiled with RGX_FLAG_STDLIB_SEMANTICS                                    */
   int32_t ref_stream_offered;  /* 1: rgx_find_chunk / rgx_count_chunk (FindReader / FindReaderCount / FindReaderFirst) are offered in
                              * reference mode: the emitted loop is FindBytesReuse on a re-sliced input, so the library must
                              * reproduce FindBytesReuse (ref_find_offered) and the pattern must not match empty; the answer is then
@@ -214,9 +219,9 @@ int rgx_match_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* buf,
 int rgx_find_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* buf, size_t len, int32_t* spans, int* found);
 
 /* FindAllBytes(input []byte, n int) -- find.go:113-124,130-466.  The TDFA flavour's WRAPPER (compiler.go:602-655: it advances by the
- * match length, not to the match end, and reports matches again -- DESIGN.md Q11) is NOT reproduced: programs for which the
- * reference emits it are refused in reference mode (RGX_E_UNSUPPORTED, rgx_info.ref_findall_offered), like every entry point of
- * this family (device / owned / host / starts / submit / count); their FindBytes / FindReader run (rgx_find_bytes).
+ * match length, not to the match end, and reports matches again -- DESIGN.md Q11) is reproduced since round 5 for whole texts:
+ * this entry point, rgx_find_all_bytes and rgx_count_all_device (rgx_info.ref_findall_offered == 2; a text whose chase would need
+ * more than 2 GiB of tables, and every other entry point of the family -- owned / starts / submit / sharded -- RGX_E_UNSUPPORTED).
  * `d_buf`, `d_spans` device pointers; `cap_records` = capacity of d_spans in records of ncap int32.
  * n < 0: all matches; n == 0: nothing (returns 0, like `return s`); n > 0: first n.
  * Records are written in increasing match-start order.  Returns written count or <0.              */
@@ -461,6 +466,13 @@ int64_t rgx_sharded_rows(const rgx_sharded* s, int local_index, const int32_t** 
  * the destination) or, when d_dst is NULL, in a library buffer valid until the next gather; h_dst != NULL also receives a host
  * copy (what a Go caller takes).  *d_rows = where the table is; returns its rows (0 on the other ranks).                      */
 int64_t rgx_sharded_gather(rgx_sharded* s, int dst_rank, int64_t* d_dst, int64_t* h_dst, size_t cap_records, const int64_t** d_rows);
+/* The compact form of that gather -- the match OFFSETS alone (north_star: "RCCL gather of match offsets"): one 64-bit word per match,
+ * bits [0, 40) the stream-absolute start, bits [40, 64) the length; 8 bytes per match over xGMI instead of 8 * ncap.  The capture
+ * groups stay with the rank that scanned the window (rgx_sharded_rows).  Same protocol, same buffers' rules (cap_matches words);
+ * RGX_E_TOO_LARGE when a start lies beyond 2^40 or a match is 2^24 bytes or longer (use rgx_sharded_gather).  Replaces nothing in
+ * the reference: its FindReader hands every match to one callback in stream order (streaming.go:219-232) -- this is what reaches
+ * that callback's rank when the callback needs where the matches are, not their groups.                                          */
+int64_t rgx_sharded_gather_offsets(rgx_sharded* s, int dst_rank, uint64_t* d_dst, uint64_t* h_dst, size_t cap_matches, const uint64_t** d_words);
 /* FindAllBytes(input, n) of one host buffer cut across the local devices (rgx_sharded_create only): plan, stage, scan, rows back
  * in order with buffer-absolute int32 offsets.  Same contract as rgx_find_all_bytes -- windows that report `unsynced` or
  * `truncated` are scanned again with wider halos until every owned match is vouched for.  Calls on one handle are serialised

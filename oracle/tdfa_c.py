@@ -108,6 +108,24 @@ int64_t t_chain(const uint8_t* chunk, int64_t l, int32_t* rows, int64_t cap) {
   }
   return n;
 }
+
+/* FindAllBytes(input, n) as the emitted WRAPPER computes it (compiler.go:602-655): FindBytes on input[offset:], the row appended,
+   `offset += len(result.Match)` (1 for an empty match) -- the match LENGTH, so a match behind the offset is found and reported again
+   (quirk Q11).  Rows absolute; unset tags stay -1.  Returns the rows of the loop (written: min(that, cap)). */
+int64_t t_find_all(const uint8_t* input, int64_t l, int64_t nmax, int32_t* rows, int64_t cap) {
+  int64_t n = 0, off = 0;
+  int32_t r[NT];
+  if (nmax == 0) return 0;
+  while (off < l) {
+    if (!t_find(input + off, l - off, r)) break;
+    if (n < cap) for (int j = 0; j < NT; j++) rows[n * NT + j] = r[j] >= 0 ? r[j] + (int32_t)off : -1;
+    n++;
+    if (nmax > 0 && n >= nmax) break;
+    const int32_t mlen = r[1] - r[0];
+    off += mlen > 0 ? mlen : 1;
+  }
+  return n;
+}
 """ % (t.start_begin, setup_b, t.start_any, setup_a))
     return "".join(o)
 
@@ -155,6 +173,8 @@ class CTdfa:
         self.lib.t_find_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
         self.lib.t_chain.restype = ctypes.c_int64
         self.lib.t_chain.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
+        self.lib.t_find_all.restype = ctypes.c_int64
+        self.lib.t_find_all.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
 
     def find(self, b: bytes):
         import numpy as np
@@ -180,3 +200,13 @@ class CTdfa:
         rows = np.empty((cap, self.ntags), dtype=np.int32)
         n = self.lib.t_chain(np.ascontiguousarray(buf).ctypes.data, l, rows.ctypes.data, cap)
         return rows[:n]
+
+    def find_all_np(self, buf, n: int = -1):
+        """The wrapper's FindAllBytes (quirk Q11) over a uint8 array: rows int32 [count, ntags], absolute offsets."""
+        import numpy as np
+        l = int(buf.size)
+        b = np.ascontiguousarray(buf)
+        cnt = self.lib.t_find_all(b.ctypes.data, l, n, None, 0)
+        rows = np.empty((max(cnt, 1), self.ntags), dtype=np.int32)
+        self.lib.t_find_all(b.ctypes.data, l, n, rows.ctypes.data, cnt)
+        return rows[:cnt]

@@ -147,6 +147,7 @@ SYMBOLS = {
     "rgx_sharded_round": (C.c_int64, [C.c_void_p, C.POINTER(ShardWindow), C.c_int, C.c_int, C.POINTER(ShardRound)]),
     "rgx_sharded_rows": (C.c_int64, [C.c_void_p, C.c_int, C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]),
     "rgx_sharded_gather": (C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
+    "rgx_sharded_gather_offsets": (C.c_int64, [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_void_p)]),
     "rgx_sharded_find_all_bytes": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_void_p, C.c_size_t, C.POINTER(Result)]),
     "rgx_last_error": (C.c_char_p, []),
     "rgx_status_str": (C.c_char_p, [C.c_int]),

@@ -59,7 +59,10 @@ struct rgx_stream_ctx {
   uint32_t* d_counters = nullptr;            // [4]
   unsigned long long* d_total = nullptr;     // the current scratch set's total (FindAllDevice::run_scan)
   bool tickets = false;                      // scans of this context take their tile ids from the ticket counter: set once a look-back with static
-                                             // ids timed out (another scan shares the device) and by rgx_sharded (rounds in flight side by side)
+                                             // ids timed out (another scan shares the device)
+  bool tickets_pref = false;                 // ... and asked for by rgx_sharded (rounds in flight side by side): the kernels with PERSISTENT
+                                             // workgroups then take tickets from the start (their grid must be resident for static ids); the
+                                             // filter + candidate kernel does not -- a workgroup's predecessors were dispatched before it
   unsigned long long* d_cursor = nullptr;    // trace cursor of the capture kernel: its own word, valid from ctx creation on
   bool own_stream = true;
   uint8_t* d_unsynced = nullptr; int32_t* d_carry = nullptr; int64_t slice_cap = 0, carry_cap = 0;
@@ -74,6 +77,8 @@ struct rgx_stream_ctx {
   int32_t* d_out = nullptr; int64_t out_cap = 0;
   unsigned long long* d_memo = nullptr; int64_t memo_cap = 0; int64_t memo_clean = 0;   // memoising engine: visited words (kept all zero over the first memo_clean) + stacks
   int32_t* d_tdfa = nullptr; int64_t tdfa_cap = 0;           // Tagged-DFA path: ends, (start, end) pairs, sync bits, counts, offsets (TdfaChainDevice)
+  int32_t* d_q11 = nullptr; int64_t q11_cap = 0;             // Tagged-DFA FindAll wrapper (TdfaFindAllDevice): the tiles' maps, entries and bases
+  int32_t* d_q11se = nullptr; int64_t q11se_cap = 0;         // ... and the (start, end) of its rows
   uint8_t* d_tmpl = nullptr; int64_t tmpl_cap = 0;           // resolved template (segments + literals) of the last splice
   std::string tmpl_key;                                      // what d_tmpl holds: "" = nothing
   // pinned host readback
@@ -173,7 +178,14 @@ bool ReaderCheckApplies(const rgx_program* p) {
 // Reference mode is "the reference's answer or a refusal" (rgx.h: rgx_info.ref_findall_offered / ref_stream_offered).
 bool RefFindAllOffered(const Tables& t) {
   if (t.ref_find_engine <= 0) return true;                       // plain backtracking (or no captures: nothing to differ from)
-  return t.ref_find_engine == 2 && !t.can_match_empty;           // memoising backtracker: Q8 needs an empty match; TDFA: Q11
+  return t.ref_find_engine == 2 && !t.can_match_empty;           // memoising backtracker: Q8 needs an empty match; TDFA: Q11, below
+}
+// Tagged-DFA programs: the emitted WRAPPER (compiler.go:602-655, quirk Q11: it advances by the match length and reports matches again)
+// reproduced on the device -- one text, one device (rgx_find_all_bytes(_device), rgx_count_all_device; TdfaFindAllDevice), for programs
+// whose two start states are one (no `^`: an attempt does not depend on the slice it is made in).  Owned ranges, starts-only rows,
+// submit / wait and the sharded rounds stay refused for this class: the wrapper's offsets do not restart at a window's edge.
+bool RefTdfaFindAllOffered(const Tables& t) {
+  return t.ref_find_engine == 1 && t.tdfa.nstates > 0 && t.tdfa.nstates <= 1000 && t.tdfa.ntags == t.ncap && t.tdfa.start_begin == t.tdfa.start_any;
 }
 // The per-string (batch) entry points are for SHORT strings.  Every kernel behind them but the forward walk of the search automaton
 // restarts an attempt at offset after offset of a string, as the emitted loop does (find.go:545-569): quadratic in the length of one
@@ -208,9 +220,10 @@ bool RefReplaceOffered(const Tables& t) {
 }
 // FindReader / FindReaderCount: the same, or the Tagged DFA's FindBytesReuse
 bool RefStreamOffered(const Tables& t) { return RefReplaceOffered(t) || (HasRefTdfa(t) && !t.can_match_empty); }
-int RefuseFindAll(const rgx_program* p) {
+int RefuseFindAll(const rgx_program* p, bool whole_text = false) {
   const Tables& t = p->p.t;
   if ((t.flags & RGX_FLAG_STDLIB_SEMANTICS) || RefFindAllOffered(t)) return RGX_OK;
+  if (whole_text && RefTdfaFindAllOffered(t) && p->p.dev.tdfa) return RGX_OK;
   SetError(t.ref_find_engine == 1
                ? "reference-mode FindAll is not offered for this pattern: the reference emits its Tagged DFA, whose FindAllBytes advances by the match length and reports matches again (compiler.go:646-651); keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS"
                : "reference-mode FindAll is not offered for this pattern: the reference memoises and the pattern matches empty (its memo is never cleared between matches, find.go:175-188); keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS");
@@ -365,6 +378,91 @@ int64_t TdfaChainDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* 
     if (w < n) { HIP_TRY(hipStreamSynchronize(c->stream)); SetError("span capacity too small"); return RGX_E_CAPACITY; }
   }
   return n;
+}
+
+// FindAllBytes(input, n) of a Tagged-DFA program as the emitted wrapper answers it (compiler.go:602-655, quirk Q11; rgx_tdfa.hip has the
+// method): rows of ncap int32 = the reported tags ((-1, -1): the group took no part -- the wrapper's FindBytes fills a fresh struct),
+// duplicates included.  Bounded: the tiles' maps (tiles x entries x 8 bytes) within kQ11MapBytes -- a text whose longest match is
+// kilobytes long AND that is hundreds of MiB long is refused.  Returns the rows of the loop (written: min(that, cap_records)).
+constexpr int64_t kQ11MapBytes = int64_t(2) << 30;
+int64_t TdfaFindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n, int32_t* d_rows, size_t cap_records,
+                          bool count_only, rgx_result* res) {
+  const TdfaDev& D = *p->p.dev.tdfa;
+  const Tables& t = p->p.t;
+  if (res) { memset(res, 0, sizeof *res); res->ncap = t.ncap; }
+  if (len == 0 || n == 0) return 0;                      // `if n == 0 { return s }`, `for offset < len(input)`
+  if (len > 0x7FFFFF00ull) { SetError("buffer larger than 2^31-256 bytes: keep the Go path"); return RGX_E_TOO_LARGE; }
+  if (!count_only && !d_rows && cap_records) return RGX_E_INVALID;
+  const int32_t ilen = (int32_t)len;
+  const int64_t ns = TdfaSlices(ilen), nt = TdfaQ11Tiles(ilen);
+  const size_t scan_tmp = TdfaQ11ScanTempBytes(ns);
+  auto r4 = [](int64_t x) { return (x + 3) & ~int64_t(3); };
+  const int64_t o_ends = 0, o_mask = o_ends + r4((int64_t)len + 1), o_rev = o_mask + r4(2 * ns), o_misc = o_rev + r4(ns), o_tmp = o_misc + 16,
+                total = o_tmp + r4((int64_t)(scan_tmp + 3) / 4);
+  int rc;
+  if ((rc = Ensure(&c->d_tdfa, &c->tdfa_cap, total)) != RGX_OK) return rc;
+  int32_t* base = c->d_tdfa;
+  int32_t* ends = base + o_ends;
+  unsigned long long* accmask = (unsigned long long*)(base + o_mask);
+  int* rev = base + o_rev;
+  uint32_t* flags = (uint32_t*)(base + o_misc);          // [0] budget / internal flags  [1] the longest step  [2..3] the rows (64 bits)
+  long long* d_total = (long long*)(base + o_misc + 2);
+  hipEvent_t e0 = c->timing ? c->ev0 : nullptr;
+  if (e0) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+  HIP_TRY(hipMemsetAsync(base + o_misc, 0, 64, c->stream));
+  HIP_TRY(LaunchTdfaEnds(D, d_buf, ilen, ends, flags, c->stream));
+  HIP_TRY(LaunchTdfaQ11Index(ends, ilen, accmask, rev, flags + 1, base + o_tmp, scan_tmp, c->stream));
+  uint32_t h[2] = {0, 0};
+  HIP_TRY(hipMemcpyAsync(h, flags, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (h[0] & kTdfaOverBudget) {
+    SetError("the Tagged DFA's attempts on this text are too long to finish (an attempt per start offset is quadratic here, in the reference as well): keep the CPU path for it");
+    return RGX_E_UNSUPPORTED;
+  }
+  int64_t rows = 0;
+  if (h[1] != 0) {                                        // (no accepting offset at all: FindBytes finds nothing, the loop ends at once)
+    const int E = (int)std::min<int64_t>((int64_t)h[1], TdfaQ11TileBytes());
+    const int64_t nmaps = nt * E;
+    if (nmaps * 8 > kQ11MapBytes) {
+      SetError("Tagged-DFA FindAll: a match of " + std::to_string(h[1]) + " bytes in a text of " + std::to_string(len) +
+               " -- the tables of the wrapper's chase would take more than 2 GiB; keep the Go path for this text");
+      return RGX_E_UNSUPPORTED;
+    }
+    const int64_t q_exit = 0, q_cnt = q_exit + r4(nmaps), q_ent = q_cnt + r4(nmaps), q_base = q_ent + r4(nt), q_total = q_base + r4(2 * nt);
+    if ((rc = Ensure(&c->d_q11, &c->q11_cap, q_total)) != RGX_OK) return rc;
+    int32_t* q = c->d_q11;
+    HIP_TRY(LaunchTdfaQ11Chain(ends, ilen, accmask, rev, E, q + q_exit, q + q_cnt, q + q_ent, (long long*)(q + q_base), d_total, flags, c->stream));
+    long long hrows = 0;
+    HIP_TRY(hipMemcpyAsync(h, flags, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&hrows, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (h[0] & 2u) { SetError("internal: Tagged-DFA FindAll entered a tile beyond its map"); return RGX_E_HIP; }
+    rows = hrows;
+    if (n > 0 && rows > n) rows = n;                      // `if n > 0 && len(results) >= n { break }`
+    if (res) res->total = rows;
+    if (!count_only && rows > 0) {
+      if (rows > (int64_t)cap_records) {
+        if (res) res->written = 0;
+        SetError("span capacity too small");
+        return RGX_E_CAPACITY;
+      }
+      if ((rc = Ensure(&c->d_q11se, &c->q11se_cap, 2 * rows + 16)) != RGX_OK) return rc;
+      HIP_TRY(LaunchTdfaQ11Emit(ends, ilen, accmask, rev, q + q_ent, (const long long*)(q + q_base), rows, c->d_q11se, c->stream));
+      HIP_TRY(LaunchTdfaTags(D, d_buf, ilen, c->d_q11se, rows, d_rows, c->stream));
+      if (res) res->written = rows;
+    }
+  }
+  if (c->timing) {
+    HIP_TRY(hipEventRecord(c->ev1, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+    if (res) res->kernel_ms = ms;                         // (the whole pipeline: its kernels wait for the host between them)
+  } else {
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
+  if (res) res->total = rows;
+  return rows;
 }
 
 // bytes.Index (streaming.go:192) against the chain's rows: an earlier copy of a match's text in the gap in front of it moves the
@@ -576,7 +674,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     return RGX_OK;
   };
   static const bool force_tickets = ExpEnv("RGX_TICKETS") != nullptr;
-  P.use_tickets = (force_tickets || c->tickets) ? 1 : 0;
+  P.use_tickets = (force_tickets || c->tickets || c->tickets_pref) ? 1 : 0;
   // The filter + candidate kernel first, where the program's level sets are a selective prefilter (rgx_scan_fc.hip; DevTables::fc_mode): one
   // launch, the input read once, and -- mode 2 -- the capture groups resolved in the candidates' walk: complete records, no capture pass.
   // Optimistic: a launch that gave up (a tile whose halo holds no reset byte, more candidates than lanes in a tile, a candidate that walks
@@ -601,6 +699,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   if (fcm) {
     const ScanParams keep = P;
     P.ntiles = FcNumTiles(ilen);
+    P.use_tickets = (force_tickets || c->tickets) ? 1 : 0;
     if (fcm == 2) { P.pairs = nullptr; P.cap_records = (int64_t)cap_records; }
     fc_now = fcm;
     rc = run_scan(c->timing);              // (static tile ids, bounded look-back spins; once more with tickets if one gave up)
@@ -920,7 +1019,7 @@ RGX_API int rgx_program_info(const rgx_program* p, rgx_info* o) {
     o->ref_match_offered = (t.ref_match_engine == 1 || (have_rm && !t.ref_memo && !t.ref_has_fail) || ((t.ref_memo || t.ref_has_fail) && t.ref_memo_interp)) ? 1 : 0;
     const bool stdlib = (t.flags & RGX_FLAG_STDLIB_SEMANTICS) != 0;
     if (stdlib) o->ref_find_offered = o->ref_match_offered = 1;       // nothing of the reference's to reproduce: every entry point answers
-    o->ref_findall_offered = (stdlib || RefFindAllOffered(t)) ? 1 : 0;
+    o->ref_findall_offered = (stdlib || RefFindAllOffered(t)) ? 1 : (RefTdfaFindAllOffered(t) ? 2 : 0);      // 2: whole texts on one device only (the Tagged DFA's wrapper), rgx.h
     o->ref_stream_offered = (stdlib || RefStreamOffered(t)) ? 1 : 0;
     o->ref_replace_offered = (stdlib || RefReplaceOffered(t)) ? 1 : 0;
     o->ref_tdfa_states = t.ref_tdfa_states;
@@ -999,7 +1098,7 @@ RGX_API void rgx_stream_ctx_destroy(rgx_stream_ctx* c) {
   for (int i = 0; i < 2; ++i)
     for (hipEvent_t e : {c->pev0[i], c->pev1[i], c->pdone[i]}) if (e) (void)hipEventDestroy(e);
   for (void* p : {(void*)c->d_desc, (void*)c->d_unsynced, (void*)c->d_carry,
-                  (void*)c->d_trace, (void*)c->d_pairs, (void*)c->d_in, (void*)c->d_san, (void*)c->d_out, (void*)c->d_rspans, (void*)c->d_rdelta, (void*)c->d_rtemp, (void*)c->d_tmpl, (void*)c->d_tdfa, (void*)c->d_memo})
+                  (void*)c->d_trace, (void*)c->d_pairs, (void*)c->d_in, (void*)c->d_san, (void*)c->d_out, (void*)c->d_rspans, (void*)c->d_rdelta, (void*)c->d_rtemp, (void*)c->d_tmpl, (void*)c->d_tdfa, (void*)c->d_memo, (void*)c->d_q11, (void*)c->d_q11se})
     if (p) (void)hipFree(p);
   if (c->d_tiny_ctl) (void)hipFree(c->d_tiny_ctl);
   if (c->h_read) (void)hipHostFree(c->h_read);
@@ -1026,7 +1125,8 @@ RGX_API int64_t rgx_find_all_bytes_device(const rgx_program* p, rgx_stream_ctx* 
                                           int32_t* d_spans, size_t cap_records, rgx_result* res) {
   int rc = CheckCtx(p, c);
   if (rc != RGX_OK) return rc;
-  if ((rc = RefuseFindAll(p)) != RGX_OK) return rc;
+  if ((rc = RefuseFindAll(p, true)) != RGX_OK) return rc;
+  if (RefTdfaMode(p)) return TdfaFindAllDevice(p, c, d_buf, len, n, d_spans, cap_records, false, res);
   return FindAllDevice(p, c, d_buf, len, n, d_spans, cap_records, false, res);
 }
 
@@ -1566,7 +1666,8 @@ RGX_API int rgx_program_capture_template(const rgx_program* p, int32_t* offsets)
 RGX_API int64_t rgx_count_all_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, rgx_result* res) {
   int rc = CheckCtx(p, c);
   if (rc != RGX_OK) return rc;
-  if ((rc = RefuseFindAll(p)) != RGX_OK) return rc;
+  if ((rc = RefuseFindAll(p, true)) != RGX_OK) return rc;
+  if (RefTdfaMode(p)) return TdfaFindAllDevice(p, c, d_buf, len, -1, nullptr, 0, true, res);
   return FindAllDevice(p, c, d_buf, len, -1, nullptr, 0, true, res);
 }
 
@@ -1574,14 +1675,15 @@ RGX_API int64_t rgx_find_all_bytes(const rgx_program* p, rgx_stream_ctx* c, cons
                                    int32_t* spans, size_t cap_records, rgx_result* res) {
   int rc = CheckCtx(p, c);
   if (rc != RGX_OK) return rc;
-  if ((rc = RefuseFindAll(p)) != RGX_OK) return rc;
+  if ((rc = RefuseFindAll(p, true)) != RGX_OK) return rc;
   if (n == 0 || len == 0) { if (res) { memset(res, 0, sizeof *res); res->ncap = p->p.dev.ncap; } return 0; }
   if (!buf || (!spans && cap_records)) return RGX_E_INVALID;
   const int ncap = p->p.dev.ncap;
   if ((rc = Ensure(&c->d_in, &c->in_cap, (int64_t)len + 64)) != RGX_OK) return rc;
   if ((rc = Ensure(&c->d_out, &c->out_cap, (int64_t)cap_records * ncap + 16)) != RGX_OK) return rc;
   HIP_TRY(hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream));
-  int64_t w = FindAllDevice(p, c, c->d_in, len, n, c->d_out, cap_records, false, res);
+  int64_t w = RefTdfaMode(p) ? TdfaFindAllDevice(p, c, c->d_in, len, n, c->d_out, cap_records, false, res)
+                             : FindAllDevice(p, c, c->d_in, len, n, c->d_out, cap_records, false, res);
   if (w > 0) HIP_TRY(hipMemcpy(spans, c->d_out, (size_t)w * ncap * 4, hipMemcpyDeviceToHost));
   return w;
 }
@@ -1720,7 +1822,7 @@ RGX_API int rgx_match_bytes_device(const rgx_program* p, rgx_stream_ctx* c, cons
 // (internal, not exported: rgx_sharded.hip marks the contexts of its rounds)
 extern "C" void rgx_internal_ctx_prefer_tickets(rgx_stream_ctx* c) {
   const char* e = getenv("RGX_PAIR_TICKETS");          // "0": leave them on static ids (comparison runs)
-  if (c && !(e && atoi(e) == 0)) c->tickets = true;
+  if (c && !(e && atoi(e) == 0)) c->tickets_pref = true;
 }
 
 RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_concat, const uint64_t* d_offsets,

@@ -184,6 +184,47 @@ __device__ __forceinline__ unsigned long long LookBackResolve(unsigned long long
   return excl;
 }
 
+// What the predecessors of `id` hand over (combined as LookBack combines), WITHOUT publishing anything for `id` itself: for a workgroup
+// that needs its base before its own count is complete (rgx_scan_fc.hip: a tile with a second round of candidates writes its rows at
+// once); it publishes its inclusive prefix itself, at the end.  Executed by one full wave; bounded like LookBack.
+template <bool MAXHI>
+__device__ __forceinline__ unsigned long long LookBackPred(unsigned long long* desc, int id, int lane, unsigned* timeout_flag, bool bounded = true) {
+  unsigned long long excl = 0;
+  if (id > 0) {
+    int idx = id - 1 - lane;
+    bool dead = false;
+    while (true) {
+      unsigned long long d = kDescPrefix;
+      if (idx >= 0) {
+        d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        unsigned spins = 0;
+        long long t0 = 0;
+        while ((d >> 62) == 0) {
+          ++spins;
+          if (bounded && spins > kLookBackSpinLimit) { dead = true; break; }
+          if ((spins & (bounded ? 255u : 1023u)) == 0) {
+            const long long now = (long long)wall_clock64();
+            if (t0 == 0) t0 = now; else if (now - t0 > (bounded ? kStaticWaitTicks : kTicketWaitTicks)) { dead = true; break; }
+            if (bounded && (__hip_atomic_load(timeout_flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u)) { dead = true; break; }
+          }
+          __builtin_amdgcn_s_sleep(8);
+          d = __hip_atomic_load(&desc[idx], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (__any(dead)) {
+        if (lane == 0) atomicOr(timeout_flag, 1u);
+        break;
+      }
+      const unsigned long long pm = __ballot((d >> 62) == 2);
+      const int first = pm ? __builtin_ctzll(pm) : 64;
+      excl = LookBackCombine<MAXHI>(excl, LookBackWaveReduce<MAXHI>(lane <= first ? (d & kDescValMask) : 0ull));
+      if (pm) break;
+      idx -= 64;
+    }
+  }
+  return excl;
+}
+
 // (A two-level variant, a 256-descriptor window (four per lane) -- super-blocks of 64 groups with an arrival atomic per group -- and persistent workgroups with
 // ticketed or round-robin chunk ids were both measured SLOWER on the 1 GiB scan than this one-level form with one
 // descriptor per workgroup: the returning atomics and the per-round simultaneous finishes cost more than they saved.)

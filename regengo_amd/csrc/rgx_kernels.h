@@ -214,6 +214,18 @@ hipError_t LaunchTdfaChain(const int32_t* ends, int32_t len, const unsigned long
                            int32_t* se, int64_t max_n, int emit, uint32_t* flags, hipStream_t stream);
 // rows[n][ntags]: the reported tags of every match of se (tdfa.go:998-1052: (-1, -1) = group left untouched)
 hipError_t LaunchTdfaTags(const TdfaDev& D, const uint8_t* buf, int32_t len, const int32_t* se, int64_t n, int32_t* rows, hipStream_t stream);
+// FindAllBytes of Tagged-DFA programs as the emitted wrapper computes it (compiler.go:602-655, quirk Q11; rgx_tdfa.hip has the method):
+// the index over ends[] (accepting offsets per 64, the next slice with one, the longest step), the tiles' maps + their composition
+// (tent / tbase / *total), the (start, end) of the rows.
+int64_t TdfaQ11Tiles(int32_t len);
+int TdfaQ11TileBytes();
+size_t TdfaQ11ScanTempBytes(int64_t nslices);
+hipError_t LaunchTdfaQ11Index(const int32_t* ends, int32_t len, unsigned long long* accmask, int* rev, unsigned* hmax, void* temp, size_t temp_bytes,
+                              hipStream_t stream);
+hipError_t LaunchTdfaQ11Chain(const int32_t* ends, int32_t len, const unsigned long long* accmask, const int* rev, int E, int32_t* fexit, int32_t* fcnt,
+                              int32_t* tent, long long* tbase, long long* total, uint32_t* flags, hipStream_t stream);
+hipError_t LaunchTdfaQ11Emit(const int32_t* ends, int32_t len, const unsigned long long* accmask, const int* rev, const int32_t* tent,
+                             const long long* tbase, int64_t limit, int32_t* se, hipStream_t stream);
 // rows of a Replace / Transform loop as the REUSED result struct holds them: an untouched group ((-1, -1)) takes the last set value
 // before it, (0, 0) in front of the first (rgx_tdfa.hip has the why).  temp: TdfaFillTempBytes(n) bytes.
 size_t TdfaFillTempBytes(int64_t n);

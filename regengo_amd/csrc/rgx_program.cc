@@ -267,7 +267,11 @@ int UploadFc(Program* p) {
   const int b_bytes = cells_bytes + 2 * ops_bytes;
   const int rows_off = ops_at + 2 * ops_bytes;
   const int rec_off = rows_off + (((fc::kRows + 1) * fc::kRowBytes + 15) & ~15);
-  const int lds_total = rec_off + (mode == 2 ? (t.ncap - 1) * fc::kThreads * 4 : 0);
+  // behind the record slots: the rows of second rounds that wait for the workgroup's base, start + NW packed registers each (NW by
+  // mode and ncap as LaunchScanFc picks the kernel instance)
+  const int ovf_off = rec_off + (mode == 2 ? (t.ncap - 1) * fc::kThreads * 4 : 0);
+  const int nw = mode == 2 ? (t.ncap <= 8 ? 4 : t.ncap <= 12 ? 6 : 8) : 2;
+  const int lds_total = ovf_off + fc::kOvfRows * (nw + 1) * 4;
   std::vector<uint8_t> img((size_t)fc::kFixedBytes + b_bytes + sizeof(FcSlowPtrs) + 16, 0);
   // part A
   for (int c = 0; c < 256; c++) {
@@ -322,7 +326,7 @@ int UploadFc(Program* p) {
   if (hipMalloc(&dptr, img.size()) != hipSuccess) { SetError("hipMalloc(fc image) failed"); return RGX_E_NOMEM; }
   if (hipMemcpy(dptr, img.data(), img.size(), hipMemcpyHostToDevice) != hipSuccess) { (void)hipFree(dptr); return RGX_E_HIP; }
   FcDev f{};
-  f.img = (const uint8_t*)dptr; f.mode = mode; f.b_bytes = b_bytes; f.ops_bytes = ops_bytes; f.rows_off = rows_off; f.rec_off = rec_off;
+  f.img = (const uint8_t*)dptr; f.mode = mode; f.b_bytes = b_bytes; f.ops_bytes = ops_bytes; f.rows_off = rows_off; f.rec_off = rec_off; f.ovf_off = ovf_off;
   f.lds_total = lds_total;
   p->fcdev = f;
   p->d_arena_fc = dptr;

@@ -163,13 +163,14 @@ constexpr int kThreads = 256;
 constexpr int kSa = 0, kCls8 = 1024, kReset = 1280, kCtx = 1536, kKind = 1792, kDelta = 1824, kSrow = 1952, kSslice = 1968, kFixedBytes = 1984;
 constexpr int kMisc = kFixedBytes, kList = kMisc + 256, kListBytes = (kThreads / 64) * kThreads * 2, kCellsOff = kList + kListBytes;
 constexpr int kRowBytes = 80, kRows = kThreads;
+constexpr int kOvfRows = 64;     // rows of second rounds of candidates that wait in LDS for the workgroup's base (rgx_scan_fc.hip)
 }  // namespace fc
 struct FcDev {
   const uint8_t* img;             // device: part A (fc::kFixedBytes), part B (b_bytes), then the slow path's table pointers (FcSlowPtrs)
   int32_t mode;                   // 1: the walk finds the match ends; 2: it resolves the capture groups too (one-pass automata)
   int32_t b_bytes;                // part B: cells + 2 x ops pool, copied to LDS offset fc::kCellsOff
   int32_t ops_bytes;              // bytes of the ops pool (the zero region behind it is as large)
-  int32_t rows_off, rec_off, lds_total;
+  int32_t rows_off, rec_off, ovf_off, lds_total;
 };
 // (at img + kFixedBytes + b_bytes) the plain tables in memory, for the rare match whose groups the fast walk cannot vouch for
 struct FcSlowPtrs {

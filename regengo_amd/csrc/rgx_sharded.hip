@@ -151,6 +151,18 @@ __global__ __launch_bounds__(256) void rows_to_global_kernel(const int32_t* rows
   }
   out[i] = unset ? (long long)v : (long long)v + base;
 }
+// window-relative int32 rows -> ONE 64-bit word per match: bits [0, 40) the stream-absolute start, bits [40, 64) the length (the
+// compact form of the gather: 8 bytes per match instead of 8 * ncap).  A start beyond 2^40 or a match of 2^24 bytes or more raises *bad.
+__global__ __launch_bounds__(256) void rows_to_offsets_kernel(const int32_t* rows, long long n, int ncap, long long base, unsigned long long* out,
+                                                             unsigned* bad) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int2 se = *reinterpret_cast<const int2*>(rows + i * ncap);
+  const unsigned long long start = (unsigned long long)(base + se.x);
+  const unsigned long long mlen = (unsigned long long)(se.y - se.x);
+  if ((start >> 40) != 0 || (mlen >> 24) != 0) atomicOr(bad, 1u);
+  out[i] = (start & ((1ull << 40) - 1ull)) | (mlen << 40);
+}
 __global__ __launch_bounds__(256) void rows_rebase32_kernel(int32_t* rows, long long nvals, int ncap, int32_t base, int minus1) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
   const bool live = i < nvals;
@@ -219,6 +231,7 @@ struct Shard {
   long long* d_x = nullptr;        // [4] mine + [4 * world] all
   long long* h_x = nullptr;        // pinned mirror
   long long* d_glob = nullptr; size_t glob_cap = 0;     // int64 rows (own rows converted / the gathered table on the destination)
+  unsigned h_bad = 0;                                   // rgx_sharded_gather_offsets: a row did not fit its 64-bit word
 };
 
 int GrowBytes(uint8_t** p, size_t* cap, size_t need) {
@@ -746,7 +759,8 @@ int EnsureGlob(Shard* sh, size_t vals) {
 // in order), on rank dst_rank's device: in d_dst (caller's device memory, cap_records records) or, when that is NULL, in a
 // library buffer; h_dst != NULL also copies them to the host.  Returns the number of rows there (0 on the other ranks of a
 // multi-process job).
-RGX_API int64_t rgx_sharded_gather(rgx_sharded* s, int dst_rank, int64_t* d_dst, int64_t* h_dst, size_t cap_records, const int64_t** d_rows) {
+// `compact`: one 64-bit word per match (rows_to_offsets_kernel) instead of a record of ncap int64.
+static int64_t GatherImpl(rgx_sharded* s, int dst_rank, int64_t* d_dst, int64_t* h_dst, size_t cap_records, const int64_t** d_rows, bool compact) {
   if (!s || s->last_slot < 0 || dst_rank < 0 || dst_rank >= s->world) return RGX_E_INVALID;
   if (s->last_starts) {
     // (known to every rank through the round's exchange: nobody enters the collective)
@@ -759,7 +773,8 @@ RGX_API int64_t rgx_sharded_gather(rgx_sharded* s, int dst_rank, int64_t* d_dst,
   const int64_t total = off[(size_t)world];
   Shard* dst = nullptr;
   for (Shard* sh : s->local) if (sh->rank == dst_rank) dst = sh;
-  const int ncap = s->local[0]->info.ncap;
+  const int rcap = s->local[0]->info.ncap;          // int32 per row as the scan left it
+  const int ncap = compact ? 1 : rcap;               // 64-bit words per row of the table
   // (a destination whose buffer is too small still takes part -- into the library's buffer -- and reports RGX_E_CAPACITY afterwards:
   // returning early would leave the other ranks in their sends)
   const bool too_small = dst && (d_dst || h_dst) && (size_t)total > cap_records;
@@ -776,12 +791,21 @@ RGX_API int64_t rgx_sharded_gather(rgx_sharded* s, int dst_rank, int64_t* d_dst,
       table = (long long*)d_dst;
       to = table + off[(size_t)sh->rank] * ncap;
     } else {
-      int rc = EnsureGlob(sh, (size_t)((sh == dst ? total : cnt) * ncap));
+      int rc = EnsureGlob(sh, (size_t)((sh == dst ? total : cnt) * ncap) + 1);
       if (rc != RGX_OK) return rc;
       if (sh == dst) table = sh->d_glob;
       to = sh->d_glob + (sh == dst ? off[(size_t)sh->rank] * ncap : 0);
     }
-    if (cnt > 0) {
+    if (cnt > 0 && compact) {
+      // (the flag word: the shard's own scratch, behind whatever of it this call uses -- EnsureGlob leaves 64 words of slack)
+      int rc = EnsureGlob(sh, 1);
+      if (rc != RGX_OK) return rc;
+      unsigned* const bad = reinterpret_cast<unsigned*>(sh->d_glob + sh->glob_cap - 1);
+      HIP_TRY(hipMemsetAsync(bad, 0, 4, sh->cstream));
+      hipLaunchKernelGGL(rows_to_offsets_kernel, dim3((unsigned)((cnt + 255) / 256)), dim3(256), 0, sh->cstream, r.d_rows, (long long)cnt, rcap,
+                         (long long)r.base, (unsigned long long*)to, bad);
+      HIP_TRY(hipMemcpyAsync(&sh->h_bad, bad, 4, hipMemcpyDeviceToHost, sh->cstream));
+    } else if (cnt > 0) {
       const long long nvals = cnt * ncap;
       hipLaunchKernelGGL(rows_to_global_kernel, dim3((unsigned)((nvals + 255) / 256)), dim3(256), 0, sh->cstream, r.d_rows, nvals, ncap,
                          (long long)r.base, sh->minus1, to);
@@ -820,8 +844,21 @@ RGX_API int64_t rgx_sharded_gather(rgx_sharded* s, int dst_rank, int64_t* d_dst,
   }
   for (Shard* sh : s->local) { HIP_TRY(hipSetDevice(sh->device)); HIP_TRY(hipStreamSynchronize(sh->cstream)); }
   if (d_rows) *d_rows = dst ? (const int64_t*)table : nullptr;
+  if (compact)
+    for (Shard* sh : s->local)
+      if (sh->h_bad) { sh->h_bad = 0; SetError("gather of offsets: a start beyond 2^40 or a match of 2^24 bytes or more -- use rgx_sharded_gather"); return RGX_E_TOO_LARGE; }
   if (too_small) { SetError("gather: capacity too small (the table is in the library's buffer, *d_rows)"); return RGX_E_CAPACITY; }
   return dst ? total : 0;
+}
+
+RGX_API int64_t rgx_sharded_gather(rgx_sharded* s, int dst_rank, int64_t* d_dst, int64_t* h_dst, size_t cap_records, const int64_t** d_rows) {
+  return GatherImpl(s, dst_rank, d_dst, h_dst, cap_records, d_rows, false);
+}
+// The compact form: the match OFFSETS alone, one 64-bit word per match -- bits [0, 40) the stream-absolute start, bits [40, 64) the
+// length -- 8 bytes per match over xGMI instead of 8 * ncap (96 for the URL pattern of config C4: 3.5 GB per rank and 8 GiB of stream
+// become 0.3 GB).  The groups stay with the rank that scanned (rgx_sharded_rows).  Same protocol as rgx_sharded_gather.
+RGX_API int64_t rgx_sharded_gather_offsets(rgx_sharded* s, int dst_rank, uint64_t* d_dst, uint64_t* h_dst, size_t cap_matches, const uint64_t** d_words) {
+  return GatherImpl(s, dst_rank, (int64_t*)d_dst, (int64_t*)h_dst, cap_matches, (const int64_t**)d_words, true);
 }
 
 // ---- FindAllBytes of one host buffer over the local devices ------------------------------------------------------------------------

@@ -709,6 +709,148 @@ hipError_t LaunchTdfaFill(int32_t* rows, int64_t n, int ncap, void* temp, size_t
   return hipGetLastError();
 }
 
+// ---------------------------------------------------------------- FindAllBytes of Tagged-DFA programs: the emitted WRAPPER (quirk Q11)
+// compiler.go:602-655: `result, ok := FindBytes(input[offset:])`, the row is appended, then `offset += len(result.Match)` (or 1 for an
+// empty match) -- the match LENGTH, not its end: a match that begins behind `offset` is found again from the new offset and reported
+// again, until the offsets have walked past its start.  With a(o) = the first start >= o whose attempt accepts (FindBytes: "the first
+// start offset that reaches an accepting state wins", tdfa.go:831-994) the wrapper is the pointer chase
+//     o -> o + max(1, end[a(o)] - a(o)),   one row (a(o), end[a(o)], its tags) per step, from o = 0 while o < len and a(o) exists.
+// Every attempt is independent of the slice it is made in when both start states are one (no `^`): end[] is tdfa_ends_kernel's.  In
+// parallel: the text in tiles of kQ11Tile offsets; a step enters a tile no further than H = the longest step behind its first offset, so
+// a tile has at most E = min(H, tile) ENTRY offsets, and for each of them a lane walks the tile: where the chase leaves it and how
+// many rows it wrote on the way (q11_map_kernel).  One lane then composes the tiles' maps from offset 0 (a dependent look-up per tile:
+// 65 536 per GiB) and notes every tile's real entry and its first row's index; a lane per tile walks its tile once more and writes the
+// (start, end) of its rows, whose tags are tdfa_tags_kernel's as for every other row of this engine.
+constexpr int kQ11Tile = 16384;
+namespace {
+// accmask[s] bit b: the attempt from offset 64 s + b accepts; *hmax: the longest step (atomicMax)
+__global__ __launch_bounds__(256) void q11_mask_kernel(const int32_t* ends, int32_t len, unsigned long long* accmask, long long nslices, unsigned* hmax) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = ((long long)blockIdx.x * 256 + threadIdx.x) >> 6, nwaves = ((long long)gridDim.x * 256) >> 6;
+  int best = 0;
+  for (long long s = wave; s < nslices; s += nwaves) {
+    const long long p = s * 64 + lane;
+    const int v = p <= len ? ends[p] : -1;
+    const unsigned long long m = __ballot(v >= 0);
+    if (v >= 0) { const int h = v - (int)p > 1 ? v - (int)p : 1; best = h > best ? h : best; }
+    if (lane == 0) accmask[s] = m;
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(best, d, 64); best = o > best ? o : best; }
+  if (lane == 0 && best > 0) atomicMax(hmax, (unsigned)best);
+}
+struct Q11NzIdx {          // slice ns - 1 - i when it holds an accepting offset: the reverse scan's input
+  const unsigned long long* m; long long ns;
+  __host__ __device__ int operator()(long long i) const { const long long s = ns - 1 - i; return m[s] ? (int)s : 0x7FFFFFFF; }
+};
+// the first accepting offset >= o (o <= len), or -1.  rev[i] = the first slice >= ns - 1 - i with an accepting offset
+__device__ __forceinline__ int Q11Next(const unsigned long long* accmask, const int* rev, long long ns, int o) {
+  const long long s = o >> 6;
+  const unsigned long long m = accmask[s] >> (o & 63);
+  if (m) return o + __builtin_ctzll(m);
+  if (s + 1 >= ns) return -1;
+  const int s2 = rev[ns - 2 - s];
+  if (s2 == 0x7FFFFFFF) return -1;
+  return s2 * 64 + __builtin_ctzll(accmask[s2]);
+}
+// lane (tile t, entry i): the chase from offset t * tile + i through the tile.  fexit: the offset it leaves with (>= the tile's end, or
+// >= len: the wrapper's loop ends), -1: FindBytes found nothing more (the loop ends), -2: not an offset of the text; fcnt: rows written
+__global__ __launch_bounds__(256) void q11_map_kernel(const int32_t* ends, int32_t len, const unsigned long long* accmask, const int* rev,
+                                                      long long ns, int E, long long nmaps, int32_t* fexit, int32_t* fcnt) {
+  const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (k >= nmaps) return;
+  const long long t = k / E;
+  const int i = (int)(k - t * E);
+  const long long tend = (t + 1) * kQ11Tile;
+  long long o = t * kQ11Tile + i;
+  int cnt = 0, ex = -2;
+  if (o < len) {
+    for (;;) {
+      if (o >= tend || o >= len) { ex = (int)(o < 0x7FFFFFFF ? o : 0x7FFFFFFF); break; }
+      const int a = Q11Next(accmask, rev, ns, (int)o);
+      if (a < 0) { ex = -1; break; }
+      ++cnt;
+      const int h = ends[a] - a;
+      o += h > 0 ? h : 1;
+    }
+  }
+  fexit[k] = ex; fcnt[k] = cnt;
+}
+// ONE lane: the tiles' maps composed from offset 0.  tent[t] = the offset the chase enters tile t with (-1: it never does), tbase[t] =
+// the index of the tile's first row; *total = the rows of the wrapper's loop.  flags bit 1: an entry beyond the map (internal error)
+__global__ void q11_compose_kernel(const int32_t* fexit, const int32_t* fcnt, int32_t len, int E, int32_t* tent, long long* tbase,
+                                   long long* total, uint32_t* flags) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  long long rows = 0;
+  long long cur = 0;
+  while (cur < len) {
+    const long long t = cur / kQ11Tile;
+    const int i = (int)(cur - t * kQ11Tile);
+    if (i >= E) { atomicOr(flags, 2u); break; }
+    tent[t] = (int)cur; tbase[t] = rows;
+    const int ex = fexit[t * E + i];
+    rows += fcnt[t * E + i];
+    if (ex < 0) break;
+    cur = ex;
+  }
+  *total = rows;
+}
+// lane t: the rows of tile t, (start, end) into se from row tbase[t] on (rows at or beyond `limit` are not written: FindAllBytes(n))
+__global__ __launch_bounds__(256) void q11_emit_kernel(const int32_t* ends, int32_t len, const unsigned long long* accmask, const int* rev,
+                                                       long long ns, long long ntiles, const int32_t* tent, const long long* tbase,
+                                                       long long limit, int32_t* se) {
+  const long long t = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (t >= ntiles) return;
+  long long o = tent[t];
+  if (o < 0) return;
+  long long j = tbase[t];
+  const long long tend = (t + 1) * kQ11Tile;
+  while (o < tend && o < len && j < limit) {
+    const int a = Q11Next(accmask, rev, ns, (int)o);
+    if (a < 0) break;
+    const int e = ends[a];
+    se[2 * j] = a; se[2 * j + 1] = e;
+    ++j;
+    o += e - a > 0 ? e - a : 1;
+  }
+}
+}  // namespace
+int64_t TdfaQ11Tiles(int32_t len) { return ((int64_t)len + kQ11Tile - 1) / kQ11Tile; }
+int TdfaQ11TileBytes() { return kQ11Tile; }
+size_t TdfaQ11ScanTempBytes(int64_t nslices) {
+  size_t bytes = 0;
+  hipcub::CountingInputIterator<long long> cnt(0);
+  hipcub::TransformInputIterator<int, Q11NzIdx, hipcub::CountingInputIterator<long long>> in(cnt, Q11NzIdx{nullptr, nslices});
+  hipcub::DeviceScan::InclusiveScan(nullptr, bytes, in, (int*)nullptr, hipcub::Min(), (int)nslices);
+  return bytes;
+}
+// accmask[nslices], rev[nslices], *hmax (zeroed by the caller) from ends[0 .. len]
+hipError_t LaunchTdfaQ11Index(const int32_t* ends, int32_t len, unsigned long long* accmask, int* rev, unsigned* hmax, void* temp, size_t temp_bytes,
+                              hipStream_t stream) {
+  const int64_t ns = TdfaSlices(len);
+  hipLaunchKernelGGL(q11_mask_kernel, dim3((unsigned)std::min<int64_t>((ns + 3) / 4, 1 << 16)), dim3(256), 0, stream, ends, len, accmask, (long long)ns, hmax);
+  hipcub::CountingInputIterator<long long> cnt(0);
+  hipcub::TransformInputIterator<int, Q11NzIdx, hipcub::CountingInputIterator<long long>> in(cnt, Q11NzIdx{accmask, ns});
+  return hipcub::DeviceScan::InclusiveScan(temp, temp_bytes, in, rev, hipcub::Min(), (int)ns, stream);
+}
+hipError_t LaunchTdfaQ11Chain(const int32_t* ends, int32_t len, const unsigned long long* accmask, const int* rev, int E, int32_t* fexit, int32_t* fcnt,
+                              int32_t* tent, long long* tbase, long long* total, uint32_t* flags, hipStream_t stream) {
+  const int64_t ns = TdfaSlices(len), nt = TdfaQ11Tiles(len);
+  const long long nmaps = (long long)nt * E;
+  hipLaunchKernelGGL(q11_map_kernel, dim3((unsigned)((nmaps + 255) / 256)), dim3(256), 0, stream, ends, len, accmask, rev, (long long)ns, E, nmaps, fexit, fcnt);
+  hipError_t e = hipMemsetAsync(tent, 0xFF, (size_t)nt * 4, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(q11_compose_kernel, dim3(1), dim3(64), 0, stream, fexit, fcnt, len, E, tent, tbase, total, flags);
+  return hipGetLastError();
+}
+hipError_t LaunchTdfaQ11Emit(const int32_t* ends, int32_t len, const unsigned long long* accmask, const int* rev, const int32_t* tent,
+                             const long long* tbase, int64_t limit, int32_t* se, hipStream_t stream) {
+  const int64_t ns = TdfaSlices(len), nt = TdfaQ11Tiles(len);
+  hipLaunchKernelGGL(q11_emit_kernel, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, stream, ends, len, accmask, rev, (long long)ns, (long long)nt, tent,
+                     tbase, (long long)limit, se);
+  return hipGetLastError();
+}
+
 size_t TdfaScanTempBytes(int64_t n) {
   size_t bytes = 0;
   hipcub::DeviceScan::ExclusiveSum(nullptr, bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (int)n);

@@ -127,6 +127,27 @@ class Sharded:
             return int(_capi.check(self._lib.rgx_sharded_gather(self._h, dst_rank, out.data_ptr(), None, out.shape[0], C.byref(p))))
         return int(_capi.check(self._lib.rgx_sharded_gather(self._h, dst_rank, None, None, 0, C.byref(p))))
 
+    def gather_offsets(self, dst_rank: int = 0, out=None, host: bool = False):
+        """The compact form (rgx_sharded_gather_offsets): one uint64 per match, bits [0, 40) the stream-absolute start, bits [40, 64)
+        the length.  out: int64/uint64 tensor [cap] on dst's device -> the match count; host=True: a numpy uint64 array [n]."""
+        import numpy as np
+        p = C.c_void_p()
+        if host:
+            cap = sum(self._last_counts) if getattr(self, "_last_counts", None) else 0
+            h = np.empty(max(cap, 1), dtype=np.uint64)
+            n = _capi.check(self._lib.rgx_sharded_gather_offsets(self._h, dst_rank, None, h.ctypes.data, h.shape[0], C.byref(p)))
+            return h[:n]
+        if out is not None:
+            return int(_capi.check(self._lib.rgx_sharded_gather_offsets(self._h, dst_rank, out.data_ptr(), None, out.shape[0], C.byref(p))))
+        return int(_capi.check(self._lib.rgx_sharded_gather_offsets(self._h, dst_rank, None, None, 0, C.byref(p))))
+
+    @staticmethod
+    def split_offsets(words):
+        """(start, end) int64 arrays / tensors of gather_offsets' words."""
+        mask = (1 << 40) - 1
+        start = words & mask
+        return start, start + (words >> 40)
+
     def round_counts(self, windows, **kw):
         total, rs = self.round(windows, **kw)
         self._last_counts = [r["count"] for r in rs]

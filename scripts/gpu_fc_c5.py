@@ -14,7 +14,7 @@ tot_fc = tot_other = 0.0
 for i, e in enumerate(fx["patterns"]):
     if e["mode"] != "scan":
         continue
-    stdlib = not Compiled(e["pattern"]).info.ref_findall_offered
+    stdlib = Compiled(e["pattern"]).info.ref_findall_offered != 1
     c = Compiled(e["pattern"], stdlib=stdlib).to(0)
     if c.info.scan_kernel != 7:
         continue

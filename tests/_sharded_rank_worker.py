@@ -53,6 +53,7 @@ def main():
         s.submit([win(2 + rank)])
         rounds = []
         tables = []
+        offset_tables = []
         for rd in range(2):
             total, rs = s.wait()
             s._last_counts = [r["count"] for r in rs]
@@ -68,8 +69,16 @@ def main():
                     tables.append((rd, dst, t[:n].cpu().numpy().tolist()))
                 else:
                     assert n == 0
+                tw = torch.empty(cap, dtype=torch.int64, device="cuda:0")
+                nw = s.gather_offsets(dst, out=tw)
+                if dst == rank:
+                    assert nw == total, (nw, total)
+                    offset_tables.append((rd, dst, tw[:nw].cpu().numpy().tolist()))
+                else:
+                    assert nw == 0
         res["rounds"] = rounds
         res["tables"] = tables
+        res["offset_tables"] = offset_tables
         # ---- a failing rank: rank 1 hands in a window whose owned range lies outside it -- BOTH ranks must get the error, none may hang
         bad = win(rank)
         if rank == 1:

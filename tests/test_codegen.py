@@ -76,8 +76,11 @@ def test_emitted_text_is_well_formed(built, name, pattern):
     info = codegen.Program(pattern).info
     need = {"rgx_abi_version", "rgx_program_from_blob", "rgx_program_to_device", "rgx_stream_ctx_create", "rgx_stream_ctx_destroy",
             "rgx_sharded_create", "rgx_sharded_destroy", "rgx_program_destroy"}
-    if info.ref_findall_offered:
+    if info.ref_findall_offered == 1:
         need |= {"rgx_find_all_bytes", "rgx_sharded_find_all_bytes"}
+    elif info.ref_findall_offered == 2:            # the Tagged DFA's wrapper: one device only
+        need |= {"rgx_find_all_bytes"}
+        assert "rgx_sharded_find_all_bytes" not in used
     if info.ref_stream_offered:
         need |= {"rgx_find_chunk", "rgx_count_chunk"}
     if info.ref_replace_offered:
@@ -157,12 +160,18 @@ def test_field_names_and_memo_patterns(built):
         assert "func (r Big) FindBytesReuse(" not in text and "FindBytes / FindBytesReuse / FindString / FindStringReuse are not routed" in text
     # the reference's Tagged DFA (URLCapture, 13 states as in its checked-in tables): the engine itself runs on the device, so
     # FindBytes* and FindReader / FindReaderCount ARE routed (fill: a group is assigned only when its start tag is set), and since round 5
-    # Replace* (the loop's rows with the reused struct's stale groups filled in on the device); FindAll* (the wrapper reports matches
-    # again, compiler.go:646-651) is not -- it is with --stdlib-semantics
+    # Replace* (the loop's rows with the reused struct's stale groups filled in on the device) and FindAll* -- the WRAPPER's loop, which
+    # reports matches again (compiler.go:646-651): one device, fresh structs (rgx_info.ref_findall_offered == 2)
     url = CASES[2][1]
     assert codegen.Program(url).info.ref_find_engine == 1 and codegen.Program(url).info.ref_tdfa_states == 13
     text, _ = codegen.emit_go(url, "URL", "p")
-    assert "func (r URL) FindAll" not in text and "FindAll* are not routed" in text
+    assert codegen.Program(url).info.ref_findall_offered == 2
+    assert "func (r URL) FindAllBytesAppend(" in text and "FindAll* are not routed" not in text and "rgx_sharded_find_all_bytes" not in text
+    assert "item := &URLBytesResult{}\n\t\ts = append(s, item)" in text
+    # ... a Tagged-DFA pattern with `^` in it: an attempt depends on the slice it is made in -- FindAll* stay in Go
+    text_a, _ = codegen.emit_go(r"^/api/(?P<v>v\d+)/(?P<name>\w+)", "Api", "p")
+    if codegen.Program(r"^/api/(?P<v>v\d+)/(?P<name>\w+)").info.ref_find_engine == 1:
+        assert "func (r Api) FindAll" not in text_a and "FindAll* are not routed" in text_a
     assert "func (r URL) FindReader(" in text and "func (r URL) FindReaderCount(" in text and "func (r URL) FindBytesReuse(" in text
     assert "func (r URL) ReplaceAllBytesAppend(" in text and "Replace* / ReplaceReader are not routed" not in text
     assert "if c[6] >= 0 {\n\t\titem.Port = input[c[6]:c[7]]\n\t}" in text and "item.Port = nil" not in text

@@ -32,7 +32,7 @@ def test_capture_rows_of_every_length_and_alignment(torch_dev, pattern, make):
     from oracle.gen_c import CMatcher
     from regengo_amd import Compiled
     c = Compiled(pattern).to(0)
-    if not c.info.ref_findall_offered:         # Tagged-DFA class: refused in reference mode (tests/test_gpu_tdfa.py); the kernels are
+    if c.info.ref_findall_offered != 1:         # Tagged-DFA class: refused in reference mode (tests/test_gpu_tdfa.py); the kernels are
         c = Compiled(pattern, stdlib=True).to(0)     # what is under test here, against the leftmost-first oracle
     cm = CMatcher(pattern, q8=False)
     parts = []
@@ -56,7 +56,7 @@ def test_capture_rows_with_unmatched_minus_one(torch_dev):
     from regengo_amd import Compiled, _capi
     pattern = r"(?P<k>\w+)=(?P<v>\d+)?(?P<semi>;)?"
     c = Compiled(pattern, flags=_capi.FLAG_UNMATCHED_MINUS1).to(0)
-    if not c.info.ref_findall_offered:
+    if c.info.ref_findall_offered != 1:
         c = Compiled(pattern, flags=_capi.FLAG_UNMATCHED_MINUS1, stdlib=True).to(0)
     text = b"".join(b" " * (i % 9) + b"k" * (1 + i % 70) + b"=" + (b"12" * (i % 5)) + (b";" if i % 3 else b"") + b"\n" for i in range(400))
     spans, res = c.FindAllSpans(text)

@@ -31,7 +31,7 @@ def _scan(pattern, flags=0):
     """For tests of the SCAN kernels (FindAll against the leftmost-first oracle): reference mode where the reference's FindAll is
     leftmost-first, RGX_FLAG_STDLIB_SEMANTICS where reference mode refuses (Tagged-DFA class: tests/test_gpu_tdfa.py covers the refusal)."""
     c = _gpu(pattern, flags)
-    return c if c.info.ref_findall_offered else _gpu(pattern, flags, stdlib=True)
+    return c if c.info.ref_findall_offered == 1 else _gpu(pattern, flags, stdlib=True)
 
 
 def test_library_is_the_hip_one(torch_dev):

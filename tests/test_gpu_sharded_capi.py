@@ -80,6 +80,14 @@ def test_logical_shards_equal_one_scan(gpu, pattern, ndev):
     assert s.gather(0, out=dst) == total and torch.equal(dst[:total], whole)
     h = s.gather(0, host=True)
     assert np.array_equal(h, whole.cpu().numpy())
+    # the compact form: one 64-bit word per match, start | length << 40 (rgx_sharded_gather_offsets) -- device buffer and host copy
+    words = torch.empty(total + 8, dtype=torch.int64, device="cuda:0")
+    assert s.gather_offsets(0, out=words) == total
+    st, en = Sharded.split_offsets(words[:total])
+    assert torch.equal(st, whole[:, 0]) and torch.equal(en, whole[:, 1])
+    hw = s.gather_offsets(0, host=True).astype(np.int64)
+    hst, hen = Sharded.split_offsets(hw)
+    assert np.array_equal(hst, whole[:, 0].cpu().numpy()) and np.array_equal(hen, whole[:, 1].cpu().numpy())
     # count-only rounds (FindReaderCount across devices)
     total2, _ = s.round(_windows(torch, buf, plan), count_only=True)
     assert total2 == total
@@ -282,6 +290,10 @@ def test_two_process_world(gpu, tmp_path):
             for rk in (0, 1):
                 got = [t for (r_, dst, t) in ranks[rk][name]["tables"] if r_ == rd and dst == rk]
                 assert len(got) == 1 and np.array_equal(np.array(got[0], dtype=np.int64).reshape(-1, c.ncap), exp), (name, rd, rk)
+                # ... and the compact form of the same gather (8 bytes per match: start | length << 40)
+                gw = [t for (r_, dst, t) in ranks[rk][name]["offset_tables"] if r_ == rd and dst == rk]
+                w = np.array(gw[0], dtype=np.int64)
+                assert len(gw) == 1 and np.array_equal(w & ((1 << 40) - 1), exp[:, 0]) and np.array_equal((w & ((1 << 40) - 1)) + (w >> 40), exp[:, 1]), (name, rd, rk)
         for rk in (0, 1):
             res = ranks[rk][name]
             assert res["fail"] == -1, (name, rk, res["fail"])                  # RGX_E_INVALID of rank 1's window, seen by BOTH ranks

@@ -98,7 +98,7 @@ def test_tdfa_find_reader_is_the_reference_loop(built, kats, corpus):
     answered = diverged = stale = calls = 0
     for pat, o, inputs in items:
         c = Compiled(pat).to(0)
-        assert c.info.ref_stream_offered == 1 and c.info.ref_findall_offered == 0 and c.info.ref_replace_offered == 1, pat
+        assert c.info.ref_stream_offered == 1 and c.info.ref_findall_offered in (0, 2) and c.info.ref_replace_offered == 1, pat
         rnd = random.Random(zlib.crc32(pat.encode()) ^ 7)
         texts = [b" ".join(inputs), b"\n".join(_texts(o, pat, 40, 5, 90))]
         texts.append(b" -- ".join(_texts(o, pat, 400, 5, 90)))          # ~20 KB: chunks of 8 KiB and more take the parallel chain
@@ -209,7 +209,7 @@ def test_tdfa_class_findall_is_the_reference_or_refused(built, kats, corpus):
     from regengo_amd import Compiled, _capi, synth
     items = [(e["pattern"], e["inputs"]) for e in corpus] + [(c["pattern"], c["inputs"]) for c in kats["curated_cases"]]
     tile = synth.web_log_tile(1 << 17)[:6000]
-    refused = answered = dup_seen = 0
+    refused = answered = dup_seen = wrapped = wrapper_rows = 0
     for pat, inputs in items:
         o = E.Compiled(pat)
         if o.prog.numcap <= 2:
@@ -217,21 +217,75 @@ def test_tdfa_class_findall_is_the_reference_or_refused(built, kats, corpus):
         texts = [s.encode() for s in inputs] + [b" ".join(s.encode() for s in inputs), tile]
         c = Compiled(pat).to(0)
         if o.tdfa is not None:
-            assert not c.info.ref_findall_offered and c.info.ref_replace_offered and c.info.ref_stream_offered, pat
-            for call in (lambda: c.FindAllSpans(texts[-1]), lambda: c.CountAll(texts[-1])):
+            # The emitted WRAPPER (compiler.go:602-655, quirk Q11: `offset += len(result.Match)`, matches reported again) is reproduced
+            # for whole texts on one device when the two start states are one (rgx_info.ref_findall_offered == 2); a pattern with `^`
+            # stays refused, and so do the forms that cut the text (owned ranges)
+            whole = o.tdfa.start_begin == o.tdfa.start_any
+            assert c.info.ref_findall_offered == (2 if whole else 0) and c.info.ref_replace_offered and c.info.ref_stream_offered, pat
+            calls = [lambda: c.FindAllSpans(texts[-1], own=(0, len(texts[-1])))]
+            if not whole:
+                calls += [lambda: c.FindAllSpans(texts[-1]), lambda: c.CountAll(texts[-1])]
+            for call in calls:
                 with pytest.raises(_capi.RgxError) as ei:
                     call()
                 assert ei.value.status == _capi.RGX_E_UNSUPPORTED, pat
-            refused += 1
+            refused += 0 if whole else 1
             cs = Compiled(pat, stdlib=True).to(0)
             for b in texts:
                 got = cs.FindAllSpans(b)[0].cpu().tolist()
                 assert got == o.FindAllLeftmostFirst(b), (pat, b[:80])
                 ref = o.FindAllBytes(b) if all(x < 128 for x in b) else None
                 if ref is not None and len(ref) != len(got):
-                    dup_seen += 1            # the reference really answers something else here: that is why it is refused
-        elif c.info.ref_findall_offered:
+                    dup_seen += 1            # the reference really answers something else here
+                if whole and ref is not None:
+                    rows = c.FindAllSpans(b)[0].cpu().tolist()
+                    assert rows == ref, (pat, b[:80], rows[:4], ref[:4])
+                    assert c.CountAll(b)[0] == len(ref), (pat, b[:80])
+                    if len(ref) > 2:
+                        assert c.FindAllSpans(b, n=2)[0].cpu().tolist() == o.FindAllBytes(b, 2), (pat, b[:80])
+                    wrapper_rows += len(ref)
+            wrapped += 1 if whole else 0
+        elif c.info.ref_findall_offered == 1:
             for b in texts[:-1]:
                 assert c.FindAllSpans(b)[0].cpu().tolist() == o.FindAllBytes(b), (pat, b[:80])
             answered += 1
-    assert refused >= 15 and answered >= 60 and dup_seen >= 5, (refused, answered, dup_seen)
+    assert refused + wrapped >= 15 and wrapped >= 8 and answered >= 60 and dup_seen >= 5 and wrapper_rows > 200, (refused, wrapped, answered, dup_seen, wrapper_rows)
+
+
+def test_tdfa_findall_wrapper_over_many_tiles(built):
+    """The wrapper's chase (compiler.go:602-655, quirk Q11) over texts of many 16 KiB tiles: the device's rows equal the C port of the
+    emitted code (oracle/tdfa_c.py: t_find_all, itself equal to oracle.tdfa.find_all on the small texts of the test above) -- the web
+    log (a URL-shaped program: ~4 rows per match), a text with ONE accepting offset 150 KB in (the chase walks up to it in steps of
+    the match's length), a text without any, n > 0, and the count-only form."""
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU; there is no CPU fallback")
+    from oracle.tdfa_c import CTdfa
+    from oracle import engines as E
+    from regengo_amd import Compiled, synth
+    pat = r"(?P<protocol>https?)://(?P<host>[\w\.-]+)(?::(?P<port>\d+))?(?P<path>/[\w\./]*)?"
+    o = CTdfa(pat)
+    c = Compiled(pat).to(0)
+    assert c.info.ref_findall_offered == 2
+    log = np.frombuffer(synth.web_log_tile(1 << 20), dtype=np.uint8)
+    small = log[:30000]
+    assert o.find_all_np(small).tolist() == E.Compiled(pat).FindAllBytes(small.tobytes())          # the C port against the restatement
+    lonely = np.full(200_000, ord(" "), dtype=np.uint8)      # (the reference's loop is quadratic here: 7 000 rows, each found by a scan)
+    lonely[150_000:150_000 + 21] = np.frombuffer(b"http://a.b-c.org:80/x", dtype=np.uint8)
+    texts = [log, np.concatenate([log, log[:777_001]]), lonely, np.full(300_000, ord("x"), dtype=np.uint8)]
+    for t in texts:
+        exp = o.find_all_np(t)
+        rows, res = c.FindAllSpans(t.tobytes(), capacity=len(exp) + 8)
+        assert res.total == len(exp) and np.array_equal(rows.cpu().numpy(), exp), (len(t), res.total, len(exp))
+        assert c.CountAll(t.tobytes())[0] == len(exp)
+        if len(exp) > 10:
+            r7, _ = c.FindAllSpans(t.tobytes(), n=7)
+            assert np.array_equal(r7.cpu().numpy(), exp[:7])
+    dup = len(o.find_all_np(log)) / max(len(Compiled(pat, stdlib=True).to(0).FindAllSpans(log.tobytes())[0]), 1)
+    assert dup > 2.0, dup                       # the reference really reports every match several times on this text
+    # a capacity below the rows: RGX_E_CAPACITY with the count in res.total (the emitted stub's retry protocol)
+    from regengo_amd import _capi
+    with pytest.raises(_capi.RgxError) as ei:
+        c.FindAllSpans(log.tobytes(), capacity=100)
+    assert ei.value.status == _capi.RGX_E_CAPACITY

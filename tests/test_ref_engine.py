@@ -39,11 +39,14 @@ def test_product_engine_selection_equals_the_oracle(built, corpus, kats):
         assert (info.ref_find_engine, info.ref_tdfa_states) == exp, p
         seen[info.ref_find_engine] += 1
         # the offer rules (include/rgx.h: rgx_info)
-        assert info.ref_findall_offered == int(exp[0] <= 0 or (exp[0] == 2 and not info.can_match_empty)), p
+        # FindAll: the plain backtracking loop and the memoising one away from empty matches (1); the Tagged DFA's WRAPPER (quirk Q11) for
+        # whole texts when its two start states are one (2, round 5); refused otherwise (0)
+        whole = exp[0] == 1 and o.tdfa.start_begin == o.tdfa.start_any
+        assert info.ref_findall_offered == (1 if (exp[0] <= 0 or (exp[0] == 2 and not info.can_match_empty)) else 2 if whole else 0), p
         assert info.ref_stream_offered == int(info.ref_find_offered and not info.can_match_empty), p
         if exp[0] == 2:          # memoising backtracker: interpreted (csrc/rgx_memo.h) -- FindBytes offered, the loops built on it unless the pattern matches empty
             assert info.ref_find_offered and info.ref_stream_offered == info.ref_replace_offered == int(not info.can_match_empty), p
-        if exp[0] == 1:          # Tagged DFA: the engine itself runs on the device (Replace / Transform since round 5); only its FindAll wrapper stays refused
+        if exp[0] == 1:          # Tagged DFA: the engine itself runs on the device (Replace / Transform, and the FindAll wrapper for whole texts, since round 5)
             assert info.ref_find_offered and info.ref_stream_offered == info.ref_replace_offered == int(not info.can_match_empty), p
         if exp[0] == 0:
             assert info.ref_replace_offered == info.ref_stream_offered, p
@@ -60,10 +63,10 @@ def test_checked_in_tdfa_patterns_are_classified_tdfa(built):
         # (TDFASemVer and the ipv4 pattern are generated with ForceTDFA: no nested quantifier of their own -- rgx_info reports the
         # default selection, so only the state count of a default-TDFA pattern is comparable)
         if E.Compiled(t["pattern"]).sel.find_engine != "tdfa":
-            assert info.ref_find_engine == 0 and info.ref_findall_offered, name
+            assert info.ref_find_engine == 0 and info.ref_findall_offered == 1, name
             continue
         assert info.ref_find_engine == 1 and info.ref_tdfa_states == len(t["transitions"]), name
-        assert not info.ref_findall_offered and info.ref_stream_offered and info.ref_find_offered and info.ref_replace_offered
+        assert info.ref_findall_offered == 2 and info.ref_stream_offered and info.ref_find_offered and info.ref_replace_offered      # (2: the wrapper's loop, whole texts)
     # regengo.Options.ForceTDFA (regengo.go:43-45, cmd flag -force-tdfa; compiler.go:137-153): how TDFASemVer and the ipv4 pattern were
     # generated -- RGX_FLAG_FORCE_TDFA selects the same engine, and the tables are the emitted ones (tests/test_tdfa.py)
     for name, t in tabs.items():
