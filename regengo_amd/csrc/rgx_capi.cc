@@ -428,10 +428,13 @@ int64_t TdfaFindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t
                " -- the tables of the wrapper's chase would take more than 2 GiB; keep the Go path for this text");
       return RGX_E_UNSUPPORTED;
     }
-    const int64_t q_exit = 0, q_cnt = q_exit + r4(nmaps), q_ent = q_cnt + r4(nmaps), q_base = q_ent + r4(nt), q_total = q_base + r4(2 * nt);
+    const int64_t ng = TdfaQ11Groups(ilen), gmaps = ng * E;
+    const int64_t q_exit = 0, q_cnt = q_exit + r4(nmaps), q_ent = q_cnt + r4(nmaps), q_base = q_ent + r4(nt), q_gexit = q_base + r4(2 * nt),
+                  q_gcnt = q_gexit + r4(gmaps), q_gent = q_gcnt + r4(gmaps), q_gbase = q_gent + r4(ng), q_total = q_gbase + r4(2 * ng);
     if ((rc = Ensure(&c->d_q11, &c->q11_cap, q_total)) != RGX_OK) return rc;
     int32_t* q = c->d_q11;
-    HIP_TRY(LaunchTdfaQ11Chain(ends, ilen, accmask, rev, E, q + q_exit, q + q_cnt, q + q_ent, (long long*)(q + q_base), d_total, flags, c->stream));
+    HIP_TRY(LaunchTdfaQ11Chain(ends, ilen, accmask, rev, E, q + q_exit, q + q_cnt, q + q_gexit, q + q_gcnt, q + q_gent, (long long*)(q + q_gbase),
+                               q + q_ent, (long long*)(q + q_base), d_total, flags, c->stream));
     long long hrows = 0;
     HIP_TRY(hipMemcpyAsync(h, flags, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(&hrows, d_total, 8, hipMemcpyDeviceToHost, c->stream));

@@ -222,8 +222,10 @@ int TdfaQ11TileBytes();
 size_t TdfaQ11ScanTempBytes(int64_t nslices);
 hipError_t LaunchTdfaQ11Index(const int32_t* ends, int32_t len, unsigned long long* accmask, int* rev, unsigned* hmax, void* temp, size_t temp_bytes,
                               hipStream_t stream);
+int64_t TdfaQ11Groups(int32_t len);
 hipError_t LaunchTdfaQ11Chain(const int32_t* ends, int32_t len, const unsigned long long* accmask, const int* rev, int E, int32_t* fexit, int32_t* fcnt,
-                              int32_t* tent, long long* tbase, long long* total, uint32_t* flags, hipStream_t stream);
+                              int32_t* gexit, int32_t* gcnt, int32_t* gent, long long* gbase, int32_t* tent, long long* tbase, long long* total,
+                              uint32_t* flags, hipStream_t stream);
 hipError_t LaunchTdfaQ11Emit(const int32_t* ends, int32_t len, const unsigned long long* accmask, const int* rev, const int32_t* tent,
                              const long long* tbase, int64_t limit, int32_t* se, hipStream_t stream);
 // rows of a Replace / Transform loop as the REUSED result struct holds them: an untouched group ((-1, -1)) takes the last set value

@@ -776,24 +776,71 @@ __global__ __launch_bounds__(256) void q11_map_kernel(const int32_t* ends, int32
   }
   fexit[k] = ex; fcnt[k] = cnt;
 }
-// ONE lane: the tiles' maps composed from offset 0.  tent[t] = the offset the chase enters tile t with (-1: it never does), tbase[t] =
-// the index of the tile's first row; *total = the rows of the wrapper's loop.  flags bit 1: an entry beyond the map (internal error)
-__global__ void q11_compose_kernel(const int32_t* fexit, const int32_t* fcnt, int32_t len, int E, int32_t* tent, long long* tbase,
+// The tiles' maps composed, in two levels (one lane walking 65 536 maps per GiB, a dependent look-up each, took ~60 ms of a 75 ms call):
+// lane (group g of kQ11Group tiles, entry i) composes the group's maps -- gexit / gcnt, as fexit / fcnt for the group --, ONE lane then
+// walks the groups from offset 0 (gent[g] = the offset the chase enters group g with, -1: never; gbase[g] = the index of its first row;
+// *total = the rows of the wrapper's loop), and a lane per group walks its tiles once more: tent[t], tbase[t] for every tile entered.
+// flags bit 1: an entry beyond a map (internal error).
+constexpr int kQ11Group = 64;
+__global__ __launch_bounds__(256) void q11_group_kernel(const int32_t* fexit, const int32_t* fcnt, int32_t len, int E, long long ntiles, long long nmaps,
+                                                        int32_t* gexit, int32_t* gcnt, uint32_t* flags) {
+  const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (k >= nmaps) return;
+  const long long g = k / E;
+  const int i = (int)(k - g * E);
+  const long long gend = (g + 1) * kQ11Group * (long long)kQ11Tile;
+  long long cur = g * kQ11Group * (long long)kQ11Tile + i;
+  int cnt = 0, ex = -2;
+  if (cur < len) {
+    for (;;) {
+      if (cur >= gend || cur >= len) { ex = (int)(cur < 0x7FFFFFFF ? cur : 0x7FFFFFFF); break; }
+      const long long t = cur / kQ11Tile;
+      const int j = (int)(cur - t * kQ11Tile);
+      if (j >= E) { atomicOr(flags, 2u); ex = -1; break; }
+      const int e1 = fexit[t * E + j];
+      cnt += fcnt[t * E + j];
+      if (e1 < 0) { ex = -1; break; }
+      cur = e1;
+    }
+  }
+  gexit[k] = ex; gcnt[k] = cnt;
+}
+__global__ void q11_compose_kernel(const int32_t* gexit, const int32_t* gcnt, int32_t len, int E, int32_t* gent, long long* gbase,
                                    long long* total, uint32_t* flags) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   long long rows = 0;
   long long cur = 0;
+  const long long gbytes = (long long)kQ11Group * kQ11Tile;
   while (cur < len) {
-    const long long t = cur / kQ11Tile;
-    const int i = (int)(cur - t * kQ11Tile);
+    const long long g = cur / gbytes;
+    const int i = (int)(cur - g * gbytes);
     if (i >= E) { atomicOr(flags, 2u); break; }
-    tent[t] = (int)cur; tbase[t] = rows;
-    const int ex = fexit[t * E + i];
-    rows += fcnt[t * E + i];
+    gent[g] = (int)cur; gbase[g] = rows;
+    const int ex = gexit[g * E + i];
+    rows += gcnt[g * E + i];
     if (ex < 0) break;
     cur = ex;
   }
   *total = rows;
+}
+__global__ __launch_bounds__(256) void q11_expand_kernel(const int32_t* fexit, const int32_t* fcnt, int32_t len, int E, long long ngroups,
+                                                         const int32_t* gent, const long long* gbase, int32_t* tent, long long* tbase) {
+  const long long g = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (g >= ngroups) return;
+  long long cur = gent[g];
+  if (cur < 0) return;
+  long long rows = gbase[g];
+  const long long gend = (g + 1) * kQ11Group * (long long)kQ11Tile;
+  while (cur < gend && cur < len) {
+    const long long t = cur / kQ11Tile;
+    const int j = (int)(cur - t * kQ11Tile);
+    if (j >= E) break;                                      // (flagged by q11_group_kernel)
+    tent[t] = (int)cur; tbase[t] = rows;
+    const int e1 = fexit[t * E + j];
+    rows += fcnt[t * E + j];
+    if (e1 < 0) break;
+    cur = e1;
+  }
 }
 // lane t: the rows of tile t, (start, end) into se from row tbase[t] on (rows at or beyond `limit` are not written: FindAllBytes(n))
 __global__ __launch_bounds__(256) void q11_emit_kernel(const int32_t* ends, int32_t len, const unsigned long long* accmask, const int* rev,
@@ -833,14 +880,20 @@ hipError_t LaunchTdfaQ11Index(const int32_t* ends, int32_t len, unsigned long lo
   hipcub::TransformInputIterator<int, Q11NzIdx, hipcub::CountingInputIterator<long long>> in(cnt, Q11NzIdx{accmask, ns});
   return hipcub::DeviceScan::InclusiveScan(temp, temp_bytes, in, rev, hipcub::Min(), (int)ns, stream);
 }
+int64_t TdfaQ11Groups(int32_t len) { return (TdfaQ11Tiles(len) + kQ11Group - 1) / kQ11Group; }
+// fexit / fcnt: tiles x E; gexit / gcnt: groups x E; tent / tbase: tiles; gent / gbase: groups
 hipError_t LaunchTdfaQ11Chain(const int32_t* ends, int32_t len, const unsigned long long* accmask, const int* rev, int E, int32_t* fexit, int32_t* fcnt,
-                              int32_t* tent, long long* tbase, long long* total, uint32_t* flags, hipStream_t stream) {
-  const int64_t ns = TdfaSlices(len), nt = TdfaQ11Tiles(len);
-  const long long nmaps = (long long)nt * E;
+                              int32_t* gexit, int32_t* gcnt, int32_t* gent, long long* gbase, int32_t* tent, long long* tbase, long long* total,
+                              uint32_t* flags, hipStream_t stream) {
+  const int64_t ns = TdfaSlices(len), nt = TdfaQ11Tiles(len), ng = TdfaQ11Groups(len);
+  const long long nmaps = (long long)nt * E, gmaps = (long long)ng * E;
   hipLaunchKernelGGL(q11_map_kernel, dim3((unsigned)((nmaps + 255) / 256)), dim3(256), 0, stream, ends, len, accmask, rev, (long long)ns, E, nmaps, fexit, fcnt);
+  hipLaunchKernelGGL(q11_group_kernel, dim3((unsigned)((gmaps + 255) / 256)), dim3(256), 0, stream, fexit, fcnt, len, E, (long long)nt, gmaps, gexit, gcnt, flags);
   hipError_t e = hipMemsetAsync(tent, 0xFF, (size_t)nt * 4, stream);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(q11_compose_kernel, dim3(1), dim3(64), 0, stream, fexit, fcnt, len, E, tent, tbase, total, flags);
+  if ((e = hipMemsetAsync(gent, 0xFF, (size_t)ng * 4, stream)) != hipSuccess) return e;
+  hipLaunchKernelGGL(q11_compose_kernel, dim3(1), dim3(64), 0, stream, gexit, gcnt, len, E, gent, gbase, total, flags);
+  hipLaunchKernelGGL(q11_expand_kernel, dim3((unsigned)((ng + 255) / 256)), dim3(256), 0, stream, fexit, fcnt, len, E, (long long)ng, gent, gbase, tent, tbase);
   return hipGetLastError();
 }
 hipError_t LaunchTdfaQ11Emit(const int32_t* ends, int32_t len, const unsigned long long* accmask, const int* rev, const int32_t* tent,
