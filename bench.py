@@ -46,7 +46,9 @@ METRIC = "input GB/s (FindAllBytes, 1 GiB buf) at 1/2/4/8 MI355X; bit-exact offs
 MIN_TIMED_SECONDS = 0.5
 PREWARM_SECONDS = float(os.environ.get("RGX_BENCH_PREWARM", "2.0"))
 KERNEL_NAMES = {1: "rgx::scan_exact_kernel", 2: "rgx::scan_rows_kernel (prefilter + verify)", 3: "rgx::scan_kernel (one attempt per start)",
-                4: "rgx::scan_us_kernel", 5: "rgx::scan_us_simple_kernel", 6: "rgx::scan_us_pair_kernel"}
+                4: "rgx::scan_us_kernel", 5: "rgx::scan_us_simple_kernel", 6: "rgx::scan_us_pair_kernel",
+                7: "rgx::scan_fc_kernel (filter + candidates, groups resolved in the walk)"}
+KERNEL_SUBSTR = {1: "scan_exact", 4: "scan_us_kernel", 5: "scan_us_simple", 6: "scan_us_pair", 7: "scan_fc"}
 
 
 class Env:
@@ -869,7 +871,7 @@ def run_c4(env, args):
     k_ms = k_ms_sum / max(args.windows, 1)
     win_bytes = W + HALO_L + HALO_R
     achieved = win_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
-    traffic, tsrc = load_traffic("c4")
+    traffic, tsrc = load_traffic("c4", KERNEL_SUBSTR.get(c.info.scan_kernel))
     line = base_line(env, args, value, ms_per_step, reps)
     line["config"] = {"workload": "C4: URL-with-alternation FindReader over a %.0f GiB stream, %d x ~%.1f GiB windows per GPU with halos, owned "
                                   "round-robin by the ranks (C ABI: rgx_sharded_round_*), window-relative int32 rows + stream offsets" % (Ltot / 2**30, args.windows, W / 2**30),

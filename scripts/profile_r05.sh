@@ -10,7 +10,7 @@ which=${1:-all}
 # the counter passes first, copied next to the older evidence: the bench lines below then cite THIS run's files (roofline.traffic_source)
 if [ $which = all ] || [ $which = c2 ]; then scripts/pmc_traffic.sh c2 scan_exact $OUT/r05_pmc_c2.json > /dev/null 2>&1; fi
 if [ $which = all ] || [ $which = c3 ]; then scripts/pmc_traffic.sh c3 batch_tiny $OUT/r05_pmc_c3.json > /dev/null 2>&1; scripts/pmc_traffic.sh c3 tdfa_batch $OUT/r05_pmc_c3t.json --force-tdfa > /dev/null 2>&1; fi
-if [ $which = all ] || [ $which = c4 ]; then scripts/pmc_traffic.sh c4 scan_us_pair $OUT/r05_pmc_c4.json > /dev/null 2>&1; fi
+if [ $which = all ] || [ $which = c4 ]; then scripts/pmc_traffic.sh c4 scan_fc $OUT/r05_pmc_c4.json > /dev/null 2>&1; fi
 cp $OUT/r05_pmc_*.json profiles/ 2>/dev/null
 for c in c2 c3 c4 c5; do
   [ $which != all ] && [ $which != $c ] && continue
