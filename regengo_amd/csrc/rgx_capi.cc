@@ -36,6 +36,10 @@ struct rgx_program {
   // first launch to the complete table, and the program stays with the faster: 1 = the filter + candidate kernel, -1 = the other, 0 = open
   mutable std::atomic<int> fc_pref{0};
   mutable std::atomic<int> fc_us_per_gib{0}, other_us_per_gib{0};
+  // The capture pass keeps every match's text in a per-lane row in LDS; a match that does not fit walks its trace through memory while its
+  // wave waits.  A pass says how many trace entries went that way (its cursor); a program whose matches run long (`...(?P<extra>.*)?` to
+  // the end of a line) takes the long-row instance of the kernel from its second pass on (rgx_kernels.hip: kCapsRowLong).
+  mutable std::atomic<int> caps_long{0};
   mutable std::atomic<int> fc_bad{0};      // scans of this program that the filter + candidate kernel gave up (rgx_scan_fc.hip: no sync point in a tile's
                                            // halo, more candidates than lanes, a long walk); from the second on the program stays with its other kernel
   // The ASCII twin (AsciiTwin below): the same pattern built for texts without a byte >= 0x80 (rgx_dfa.h: kFlagAsciiText).  Made on the
@@ -531,6 +535,21 @@ const rgx_program* AsciiTwin(const rgx_program* p) {
 }
 
 // Core: scan (+ carry fallback) (+ captures).  Inputs/outputs are device pointers.
+// The capture pass behind a scan (dynamic groups): launch, wait, and learn from its trace cursor whether this program's matches
+// outgrow the kernel's rows (more than two trace entries in memory per match on average: a few per cent of long matches stall
+// their waves a hundredfold).
+int CapturePass(const rgx_program* p, rgx_stream_ctx* c, const DevTables& T, const uint8_t* d_buf, int32_t ilen, int32_t* d_spans,
+                const int32_t* pairs, int64_t n) {
+  HIP_TRY(hipMemsetAsync(c->d_cursor, 0, 8, c->stream));
+  const bool long_rows = p->caps_long.load(std::memory_order_relaxed) != 0;
+  HIP_TRY(LaunchCaptures(T, d_buf, ilen, d_spans, pairs, n, c->d_trace, c->d_cursor, c->stream, long_rows));
+  unsigned long long used = 0;
+  if (!long_rows && n >= 4096) HIP_TRY(hipMemcpyAsync(&used, c->d_cursor, 8, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (!long_rows && n >= 4096 && used > 2ull * (unsigned long long)n) p->caps_long.store(1, std::memory_order_relaxed);
+  return RGX_OK;
+}
+
 int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n, int32_t* d_spans,
                       size_t cap_records, bool count_only, rgx_result* res, bool starts_only = false, int64_t own_lo = 0,
                       int64_t own_hi = -1) {
@@ -725,9 +744,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
       if (fcm != 2 && !T.fixed_captures && fwritten > 0 && !starts_only) {
         int64_t need = (int64_t)len + fwritten + 64;
         if ((rc = Ensure(&c->d_trace, &c->trace_cap, need)) != RGX_OK) return rc;
-        HIP_TRY(hipMemsetAsync(c->d_cursor, 0, 8, c->stream));
-        HIP_TRY(LaunchCaptures(T, d_buf, ilen, d_spans, P.pairs, fwritten, c->d_trace, c->d_cursor, c->stream));
-        HIP_TRY(hipStreamSynchronize(c->stream));
+        if ((rc = CapturePass(p, c, T, d_buf, ilen, d_spans, P.pairs, fwritten)) != RGX_OK) return rc;
       }
       if (res) res->written = fwritten;
       if (fc_open) p->fc_us_per_gib.store(fc_rate(), std::memory_order_relaxed);
@@ -935,9 +952,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     // dynamic capture groups: second kernel over the (much smaller) match list
     int64_t need = (int64_t)len + written + 64;
     if ((rc = Ensure(&c->d_trace, &c->trace_cap, need)) != RGX_OK) return rc;
-    HIP_TRY(hipMemsetAsync(c->d_cursor, 0, 8, c->stream));
-    HIP_TRY(LaunchCaptures(T, d_buf, ilen, d_spans, P.pairs, written, c->d_trace, c->d_cursor, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((rc = CapturePass(p, c, T, d_buf, ilen, d_spans, P.pairs, written)) != RGX_OK) return rc;
   }
   if (res) res->written = written;
   return written;

@@ -90,7 +90,7 @@ bool ScanSupportsW(const DevTables& T, int32_t len);
 // Capture groups for patterns whose captures are not a fixed template: per-match state trace + back-trace.
 // `trace` is scratch of at least (len + nmatches + 64) uint16; `trace_cursor` a zeroed uint64.
 hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, int32_t* spans, const int32_t* pairs, int64_t nmatches, uint16_t* trace,
-                          unsigned long long* trace_cursor, hipStream_t stream);
+                          unsigned long long* trace_cursor, hipStream_t stream, bool long_rows = false);
 
 // Batch (one string per lane): FindBytes / MatchBytes per string, CSR offsets.
 hipError_t LaunchBatch(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,

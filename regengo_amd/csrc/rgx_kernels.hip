@@ -1497,6 +1497,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_lds_kernel(DevTables T, c
 // window of the group's span misses most of them (with 8 KiB three quarters of the lanes walked through global loads).
 constexpr int kCapsRow = 96;                                  // bytes per lane: six 16-byte loads
 constexpr int kCapsWindow = kCapsRow * kBlockThreads;         // 24 KiB
+constexpr int kCapsRowLong = 192;                             // the long-row instance: twelve 16-byte loads, 48 KiB of rows
 // T.start[ctx] without a load: a dynamic index into the kernel-argument struct is a load from MEMORY (the argument segment; the compiler
 // also turns a select of four constant-index loads back into one), and a load from memory in the walk of the capture pass drains the
 // prefetched rows (PrivInput::AtRow has the why).  The four values are read once, in front of the loop, into scalar registers.
@@ -1514,6 +1515,7 @@ struct PrivInput {
   Lds8 row;                // LDS: this lane's dword 0 (dword j at row + j * 1024)
   int p0;                  // text offset of the row's first byte (16-byte aligned)
   int nrow;                // valid bytes in the row
+  int rowcap;              // bytes a row can hold (kCapsRow, or the long-row instance's)
   int len;
   __device__ __forceinline__ int At(int i) const {
     const unsigned r = (unsigned)(i - p0);
@@ -1659,7 +1661,7 @@ __device__ __forceinline__ void ResolveCapturesOnePassH(unsigned cls_at, unsigne
   };
   const unsigned row_at = (unsigned)(uintptr_t)in.row;
   const int r = s - in.p0;
-  const unsigned wlast = row_at + (unsigned)((kCapsRow / 4 - 1) << 10);      // the row's last dword (a dword of the row every 1 KiB)
+  const unsigned wlast = row_at + (unsigned)((in.rowcap / 4 - 1) << 10);     // the row's last dword (a dword of the row every 1 KiB)
   unsigned wa = row_at + ((unsigned)(r >> 2) << 10);
   unsigned w = *(Lds32)(uintptr_t)wa;
   wa = min(wa + 1024u, wlast);
@@ -1775,15 +1777,18 @@ __device__ __forceinline__ void ResolveCapturesInRow(Lds16 trans, Lds8 cls, cons
   }
 }
 
-template <int MODE, class TraceT, bool INROW = false>
+// ROW: bytes of text a lane keeps (kCapsRow; kCapsRowLong for programs whose matches run long -- `URL(?P<extra>.*)?` to the end of a
+// line: a match that does not fit its row walks its trace through memory while its wave waits, 3.7 ms for 6.9 M such matches where
+// 14.7 M URLs take 0.47; LaunchCaptures picks the instance, rgx_capi.cc learns which from the trace cursor of the program's first pass)
+template <int MODE, class TraceT, bool INROW = false, int ROW = kCapsRow>
 __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, const uint8_t* buf, int32_t len, int32_t* spans,
                                                                   const int32_t* pairs, int64_t nmatches, TraceT* gtrace,
                                                                   unsigned long long* cursor, int debug_flags) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
-  const bool use_h = INROW && T.onepass != 0 && BatchLdsLayout(T, true, 0, kCapsWindow).bt_in_lds != 0 &&       // (uniform) ResolveCapturesOnePassH
-                     BatchLdsLayout(T, true, 0, kCapsWindow, false, true).total < 65536;                       // (the table holds 16-bit LDS addresses)
-  const BatchLayout Y = BatchLdsLayout(T, true, INROW ? 0 : (int)sizeof(TraceT), kCapsWindow, false, use_h);
+  const bool use_h = INROW && T.onepass != 0 && BatchLdsLayout(T, true, 0, ROW * kBlockThreads).bt_in_lds != 0 &&       // (uniform) ResolveCapturesOnePassH
+                     BatchLdsLayout(T, true, 0, ROW * kBlockThreads, false, true).total < 65536;                       // (the table holds 16-bit LDS addresses)
+  const BatchLayout Y = BatchLdsLayout(T, true, INROW ? 0 : (int)sizeof(TraceT), ROW * kBlockThreads, false, use_h);
   const int ncap = T.ncap;
   {
     const uint4* src = reinterpret_cast<const uint4*>(T.trans);
@@ -1865,15 +1870,15 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
   const auto row_of = [&](int s, int e, bool valid, int& p0, int& nrow) {
     p0 = (s > 0 ? s - 1 : 0) & ~15;
     const int n = ((len - p0) + 15) & ~15;              // whole 16-byte chunks that begin inside the text (the last one may run past `len` inside its chunk: never a page)
-    nrow = n < kCapsRow ? (n < 0 ? 0 : n) : kCapsRow;
+    nrow = n < ROW ? (n < 0 ? 0 : n) : ROW;
     const int need = (e + 4 - p0 + 15) & ~15;
     if (need < nrow) nrow = need;
     if (!valid) nrow = 0;
   };
-  uint4 v[kCapsRow / 16];
+  uint4 v[ROW / 16];
   const auto fetch_row = [&](int p0, int nrow) {
 #pragma unroll
-    for (int c = 0; c < kCapsRow / 16; ++c) {
+    for (int c = 0; c < ROW / 16; ++c) {
       const uint8_t* src = (c << 4) < nrow ? buf + p0 + (c << 4) : idle;
       v[c] = *reinterpret_cast<const uint4*>(src);
     }
@@ -1912,11 +1917,11 @@ __global__ __launch_bounds__(kBlockThreads) void caps_lds_kernel(DevTables T, co
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     PrivInput in;
     in.g = buf; in.row = (Lds8)(win + (tid << 2)); in.len = len;
-    in.p0 = p0c; in.nrow = nrowc;
+    in.p0 = p0c; in.nrow = nrowc; in.rowcap = ROW;
     {
       unsigned* rowd = reinterpret_cast<unsigned*>(win) + tid;
 #pragma unroll
-      for (int c = 0; c < kCapsRow / 16; ++c) {
+      for (int c = 0; c < ROW / 16; ++c) {
         if ((c << 4) < in.nrow) {
           rowd[(4 * c + 0) << 8] = v[c].x; rowd[(4 * c + 1) << 8] = v[c].y; rowd[(4 * c + 2) << 8] = v[c].z; rowd[(4 * c + 3) << 8] = v[c].w;
         }
@@ -2856,7 +2861,7 @@ hipError_t LaunchCarry(const DevTables& T, const uint8_t* buf, int32_t len, cons
 }
 
 hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, int32_t* spans, const int32_t* pairs, int64_t nmatches, uint16_t* trace,
-                          unsigned long long* trace_cursor, hipStream_t stream) {
+                          unsigned long long* trace_cursor, hipStream_t stream, bool long_rows) {
   if (nmatches <= 0) return hipSuccess;
   static const bool force_old = ExpEnv("RGX_CAPS_OLD") != nullptr;
   const bool t8 = T.nstates <= 256;
@@ -2864,7 +2869,9 @@ hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, i
   // their trace in global memory
   static const bool no_inrow = ExpEnv("RGX_CAPS_NO_INROW") != nullptr;
   const bool inrow = !no_inrow && T.nstates * T.stride <= 256 && BatchLdsLayout(T, true, 0, kCapsWindow).bt_in_lds != 0;
-  const BatchLayout Y = BatchLdsLayout(T, true, inrow ? 0 : (t8 ? 1 : 2), kCapsWindow, false, inrow && T.onepass != 0);
+  // (the long-row instance: in-row programs only -- the others keep their trace beside the row, 63 bytes of match at most)
+  const bool lrow = long_rows && inrow && BatchLdsLayout(T, true, 0, kCapsRowLong * kBlockThreads, false, T.onepass != 0).total <= 150 * 1024;
+  const BatchLayout Y = BatchLdsLayout(T, true, inrow ? 0 : (t8 ? 1 : 2), lrow ? kCapsRowLong * kBlockThreads : kCapsWindow, false, inrow && T.onepass != 0);
   if (!force_old && nmatches >= 64 && T.mode != kModeClassGlobal && Y.total <= 150 * 1024 && (((uintptr_t)buf) & 15) == 0 && T.ncap <= 32) {
     const int cus = DeviceCus();
     const int64_t ngroups = (nmatches + kBlockThreads - 1) / kBlockThreads;
@@ -2873,10 +2880,11 @@ hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, i
     if (per_cu > 8) per_cu = 8;
     int64_t grid = (int64_t)cus * per_cu * 4;
     if (grid > ngroups) grid = ngroups;
-    const int mi = inrow ? 4 + (T.mode == kModeDirect ? 0 : 1) : (T.mode == kModeDirect ? 0 : 1) * 2 + (t8 ? 0 : 1);
-    const void* fns[6] = {(const void*)caps_lds_kernel<kModeDirect, uint8_t>, (const void*)caps_lds_kernel<kModeDirect, uint16_t>,
+    const int mi = lrow ? 6 + (T.mode == kModeDirect ? 0 : 1) : inrow ? 4 + (T.mode == kModeDirect ? 0 : 1) : (T.mode == kModeDirect ? 0 : 1) * 2 + (t8 ? 0 : 1);
+    const void* fns[8] = {(const void*)caps_lds_kernel<kModeDirect, uint8_t>, (const void*)caps_lds_kernel<kModeDirect, uint16_t>,
                           (const void*)caps_lds_kernel<kModeClassLds, uint8_t>, (const void*)caps_lds_kernel<kModeClassLds, uint16_t>,
-                          (const void*)caps_lds_kernel<kModeDirect, uint8_t, true>, (const void*)caps_lds_kernel<kModeClassLds, uint8_t, true>};
+                          (const void*)caps_lds_kernel<kModeDirect, uint8_t, true>, (const void*)caps_lds_kernel<kModeClassLds, uint8_t, true>,
+                          (const void*)caps_lds_kernel<kModeDirect, uint8_t, true, kCapsRowLong>, (const void*)caps_lds_kernel<kModeClassLds, uint8_t, true, kCapsRowLong>};
         { const hipError_t e = AllowBigLds(fns[mi]); if (e != hipSuccess) return e; }
     static const int dflags = ExpEnv("RGX_CAPS_NO_PRIV") ? 1 : 0;      // experiment switch: the general back-trace for every match
     const dim3 g((unsigned)grid), b(kBlockThreads);
@@ -2887,7 +2895,9 @@ hipError_t LaunchCaptures(const DevTables& T, const uint8_t* buf, int32_t len, i
       case 2: hipLaunchKernelGGL((caps_lds_kernel<kModeClassLds, uint8_t>), g, b, lds, stream, T, buf, len, spans, pairs, nmatches, (uint8_t*)trace, trace_cursor, dflags); break;
       case 3: hipLaunchKernelGGL((caps_lds_kernel<kModeClassLds, uint16_t>), g, b, lds, stream, T, buf, len, spans, pairs, nmatches, trace, trace_cursor, dflags); break;
       case 4: hipLaunchKernelGGL((caps_lds_kernel<kModeDirect, uint8_t, true>), g, b, lds, stream, T, buf, len, spans, pairs, nmatches, (uint8_t*)trace, trace_cursor, dflags); break;
-      default: hipLaunchKernelGGL((caps_lds_kernel<kModeClassLds, uint8_t, true>), g, b, lds, stream, T, buf, len, spans, pairs, nmatches, (uint8_t*)trace, trace_cursor, dflags); break;
+      case 5: hipLaunchKernelGGL((caps_lds_kernel<kModeClassLds, uint8_t, true>), g, b, lds, stream, T, buf, len, spans, pairs, nmatches, (uint8_t*)trace, trace_cursor, dflags); break;
+      case 6: hipLaunchKernelGGL((caps_lds_kernel<kModeDirect, uint8_t, true, kCapsRowLong>), g, b, lds, stream, T, buf, len, spans, pairs, nmatches, (uint8_t*)trace, trace_cursor, dflags); break;
+      default: hipLaunchKernelGGL((caps_lds_kernel<kModeClassLds, uint8_t, true, kCapsRowLong>), g, b, lds, stream, T, buf, len, spans, pairs, nmatches, (uint8_t*)trace, trace_cursor, dflags); break;
     }
     return hipGetLastError();
   }

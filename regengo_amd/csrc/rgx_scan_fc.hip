@@ -18,14 +18,18 @@
 //               chain enters a tile at a sync point: the offset behind the nearest reset byte (every DFA state dies on it) in the
 //               256 bytes in front of the tile's owned range; candidates between it and the range are walked too (their matches
 //               may cover owned starts) and not reported.
-//   order       one decoupled look-back per tile over the counts; records leave in match order.
+//   order       one decoupled look-back per WORKGROUP over the counts; records leave in match order.
 //
-// One workgroup = one 16 KiB tile, as many workgroups as tiles: the latencies of a tile (its loads, its look-back) hide behind the
-// other workgroups of the CU.  [Measured and rejected, round 5: PERSISTENT workgroups (512 lanes, tickets, the next tile's loads in
-// flight, the look-back resolved a tile later by the last wave, eight descriptor windows per round trip) -- bit-exact, 2.65 ms per
-// 1.6 GiB window of the URL pattern against 1.34 + 0.47 for the pair kernel and its capture pass: persistent workgroups run in step,
-// every tile of a generation publishes its count at the same moment, every look-back then waits for the slowest workgroup of the
-// generation, and the waiting wave holds its whole workgroup at the next barrier.]
+// One workgroup = FOUR 16 KiB tiles, one behind the other (kFcSub), on ONE look-back descriptor: the next tile's loads are in flight
+// while this one is filtered and walked, the program's LDS image is copied once per 64 KiB, and a tile's rows wait -- packed, in
+// registers -- for the workgroup's base (the kernel's own comment has the layout and the stage timings that led here: with one tile
+// per workgroup a hundred thousand look-backs per 1.6 GiB resolved in tile order and marched the resident workgroups in step -- load,
+// walk, WAIT, 0.52 of 1.86 ms; now 0.12 of 1.57).  [Measured and rejected, round 5: PERSISTENT workgroups (512 lanes, tickets, the
+// look-back resolved a tile later by the last wave, eight descriptor windows per round trip) -- bit-exact, 2.65 ms per 1.6 GiB window
+// of the URL pattern: persistent workgroups run in step, every tile of a generation publishes its count at the same moment, every
+// look-back then waits for the slowest workgroup of the generation.  And: asking for the base EARLY (a tile with a second round of
+// candidates resolving the look-back of the predecessors at once) -- 10.7 ms: the predecessors publish when THEY are through, so every
+// such wait is a whole workgroup long and they chain.]
 // The launch is OPTIMISTIC: a tile without a sync point in its halo, with more candidates than lanes, or a candidate that walks
 // further than kFcMaxSteps raises ScanParams::counters[2] bit 31 -- the results are void, the host runs the program's other kernel
 // (rgx_capi.cc) and the program remembers.  HBM-bound byte work: no MFMA.
@@ -113,6 +117,10 @@ __device__ __forceinline__ unsigned FcAddHi(unsigned a, unsigned b) {
   unsigned r;
   asm("v_add_u32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(r) : "v"(a), "v"(b));
   return r;
+}
+__device__ __forceinline__ unsigned FcWide(unsigned v) {
+  asm("" : "+v"(v));
+  return v;
 }
 template <int B>
 __device__ __forceinline__ unsigned FcByte(unsigned w) {
@@ -524,19 +532,19 @@ __global__ __launch_bounds__(kFcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
         int pos = s;
         unsigned D = (unsigned)rel >> 2;
         const unsigned sh = (unsigned)rel & 3u;
-        const unsigned Dmax = (unsigned)(kFcRows * 16 - 1);
-        auto dw = [&](unsigned d) -> unsigned {
-          d = d < Dmax ? d : Dmax;
-          return *(Lds32c)(uintptr_t)(rows_at + (d << 2) + (d & ~15u));
-        };
+        // (dword d of the window; the look-ahead runs two dwords past the bytes a trip may use -- at the window's end into the spare
+        // row UploadFc leaves behind the rows: read, never used)
+        auto dw = [&](unsigned d) -> unsigned { return *(Lds32c)(uintptr_t)(rows_at + (d << 2) + (d & ~15u)); };
         // The walk is a chain of DEPENDENT look-ups -- the cell of byte i names the row of byte i + 1 -- and an LDS round trip is ~100 cycles,
         // so what a step may wait for is ONE round trip: the classes of a trip's four bytes are asked for a trip ahead (they depend on the
         // bytes alone); the ops word of the edge just taken and the NEXT byte's cell are asked for together; and the record slots of a step are
         // written behind the reads of the step after it (a write in front of them would hold them back: they might alias).
         unsigned w0 = dw(D), w1 = dw(D + 1), w2 = dw(D + 2);
         unsigned b4 = __builtin_amdgcn_alignbyte(w1, w0, sh);
-        unsigned c0 = *(Lds8c)(uintptr_t)(FcByte<0>(b4) + (unsigned)kCls8), c1 = *(Lds8c)(uintptr_t)(FcByte<1>(b4) + (unsigned)kCls8);
-        unsigned c2 = *(Lds8c)(uintptr_t)(FcByte<2>(b4) + (unsigned)kCls8), c3 = *(Lds8c)(uintptr_t)(FcByte<3>(b4) + (unsigned)kCls8);
+        // (FcWide: the class bytes as 32-bit values the compiler cannot narrow again -- carried round the loop as bytes they were
+        // masked with 0xFF at every use: four v_and per trip of a loop that is bound by VALU issue)
+        unsigned c0 = FcWide(*(Lds8c)(uintptr_t)(FcByte<0>(b4) + (unsigned)kCls8)), c1 = FcWide(*(Lds8c)(uintptr_t)(FcByte<1>(b4) + (unsigned)kCls8));
+        unsigned c2 = FcWide(*(Lds8c)(uintptr_t)(FcByte<2>(b4) + (unsigned)kCls8)), c3 = FcWide(*(Lds8c)(uintptr_t)(FcByte<3>(b4) + (unsigned)kCls8));
         unsigned po = (unsigned)((ncap - 2) * kFcThreads * 4) * 0x10001u;         // the ops word whose slots are still to be written ("none": scrap twice)
         int ppk = 0;                                                              // ... and the offset they get
         int steps = 0;
@@ -555,14 +563,18 @@ __global__ __launch_bounds__(kFcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
             *(Lds32w)(uintptr_t)FcAddLo(rec_at, po) = (unsigned)ppk;                                        \
             *(Lds32w)(uintptr_t)FcAddHi(rec_at, po) = (unsigned)ppk;                                        \
           }
-        while ((hx & 0xFFFFu) != dead_row && rel + 4 <= lim) {
+        // (one loop variable: `pos`, against the last position a whole trip may start at -- inside the window, within the step budget;
+        // rel and steps follow from it behind the loop)
+        const int trips_max = lim - rel0 >= 4 ? ((lim - rel0) >> 2 < kFcMaxSteps / 4 + 1 ? (lim - rel0) >> 2 : kFcMaxSteps / 4 + 1) : 0;
+        const int pos_end = s + (trips_max << 2);
+        while ((hx & 0xFFFFu) != dead_row && pos < pos_end) {
           // the next trip's bytes and their classes
           ++D;
           const unsigned w3 = dw(D + 2);
           const unsigned b4n = __builtin_amdgcn_alignbyte(w2, w1, sh);
           w1 = w2; w2 = w3;
-          const unsigned n0 = *(Lds8c)(uintptr_t)(FcByte<0>(b4n) + (unsigned)kCls8), n1 = *(Lds8c)(uintptr_t)(FcByte<1>(b4n) + (unsigned)kCls8);
-          const unsigned n2 = *(Lds8c)(uintptr_t)(FcByte<2>(b4n) + (unsigned)kCls8), n3 = *(Lds8c)(uintptr_t)(FcByte<3>(b4n) + (unsigned)kCls8);
+          const unsigned n0 = FcWide(*(Lds8c)(uintptr_t)(FcByte<0>(b4n) + (unsigned)kCls8)), n1 = FcWide(*(Lds8c)(uintptr_t)(FcByte<1>(b4n) + (unsigned)kCls8));
+          const unsigned n2 = FcWide(*(Lds8c)(uintptr_t)(FcByte<2>(b4n) + (unsigned)kCls8)), n3 = FcWide(*(Lds8c)(uintptr_t)(FcByte<3>(b4n) + (unsigned)kCls8));
           FC_CELL(h0, c0)
           FC_WRITE()                    // (the last step of the trip before)
           FC_AFTER(h0, 0)
@@ -576,9 +588,10 @@ __global__ __launch_bounds__(kFcThreads) __attribute__((amdgpu_waves_per_eu(4, 4
           FC_WRITE()
           FC_AFTER(h3, 3)
           c0 = n0; c1 = n1; c2 = n2; c3 = n3;
-          pos += 4; rel += 4; steps += 4;
-          if (steps > kFcMaxSteps) break;
+          pos += 4;
         }
+        rel = rel0 + (pos - s);
+        steps = pos - s;
         if (MODE == 2) {                                           // the slots of the last step taken
           *(Lds32w)(uintptr_t)FcAddLo(rec_at, po) = (unsigned)ppk;
           *(Lds32w)(uintptr_t)FcAddHi(rec_at, po) = (unsigned)ppk;

@@ -718,9 +718,11 @@ hipError_t LaunchTdfaFill(int32_t* rows, int64_t n, int ncap, void* temp, size_t
 // Every attempt is independent of the slice it is made in when both start states are one (no `^`): end[] is tdfa_ends_kernel's.  In
 // parallel: the text in tiles of kQ11Tile offsets; a step enters a tile no further than H = the longest step behind its first offset, so
 // a tile has at most E = min(H, tile) ENTRY offsets, and for each of them a lane walks the tile: where the chase leaves it and how
-// many rows it wrote on the way (q11_map_kernel).  One lane then composes the tiles' maps from offset 0 (a dependent look-up per tile:
-// 65 536 per GiB) and notes every tile's real entry and its first row's index; a lane per tile walks its tile once more and writes the
-// (start, end) of its rows, whose tags are tdfa_tags_kernel's as for every other row of this engine.
+// many rows it wrote on the way (q11_map_kernel).  The maps are composed in two levels (groups of 64 tiles in parallel, ONE lane over the
+// groups from offset 0: 1024 dependent look-ups per GiB, then a lane per group for its tiles) into every tile's real entry and its first
+// row's index; a lane per tile walks its tile once more and writes the (start, end) of its rows, whose tags are tdfa_tags_kernel's as
+// for every other row of this engine.  The web log, 1 GiB: 43 M (URL-shaped programs) to 180 M rows (version numbers) in 24-30 ms;
+// the C port of the emitted loop takes 6-30 s per GiB of it (and minutes where matches are rare: every row is found by a scan).
 constexpr int kQ11Tile = 16384;
 namespace {
 // accmask[s] bit b: the attempt from offset 64 s + b accepts; *hmax: the longest step (atomicMax)

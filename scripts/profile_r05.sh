@@ -28,7 +28,9 @@ for c in c2 c3 c3t c4 c5; do
   [ $c = c2 ] && st="--steps 20 --warmup 3 --no-alt"; [ $c = c5 ] && st="--steps 1 --warmup 0"; [ $c = c4 ] && st="--steps 1 --warmup 0"; [ $c = c3 ] && st="--steps 3 --warmup 1"
   [ $c = c3t ] && { st="--steps 3 --warmup 1 --force-tdfa"; cfg=c3; }
   rm -rf /tmp/p/kt_$c
-  timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p/kt_$c -o kt -- python bench.py --config $cfg --no-cpu-baseline $st > $OUT/r05_bench_${c}_under_rocprof.json 2> /tmp/kt_$c.err
+  # (c4: ONE round in flight under the profiler -- with two, the windows' kernels overlap and a traced duration counts the other window's share
+  # of the GPU; the bench line's roofline takes its kernel time from a one-round region for the same reason)
+  RGX_C4_DEPTH=1 timeout 900 rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p/kt_$c -o kt -- python bench.py --config $cfg --no-cpu-baseline $st > $OUT/r05_bench_${c}_under_rocprof.json 2> /tmp/kt_$c.err
   f=$(find /tmp/p/kt_$c -name "*kernel_stats.csv" | head -1)
   [ -n "$f" ] && grep -E '^"Name"|rgx::' "$f" > $OUT/r05_kernel_stats_$c.csv
 done
