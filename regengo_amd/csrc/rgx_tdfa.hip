@@ -595,6 +595,160 @@ __global__ __launch_bounds__(256) void tdfa_batch_kernel(TdfaDev D, const uint8_
   }
 }
 
+// The same per-string work with the workgroup's 256 strings SORTED BY LENGTH before they are dealt to the waves, and the loads of the
+// next group in flight during the walk (round 5; rgx_batch_tiny.hip: batch_tiny_sorted_kernel has the scheme and what it measured there).
+// The kernel above is bound by VALU issue (PMC, profiles/r05_pmc_c3t.json: 330 M wave-instructions x 4 cycles / 1024 SIMDs = 0.54 of
+// its 0.69 ms on config C3) and a wave runs both of its walks -- the merged-attempts walk, then the tag walk of the winner -- to its
+// LONGEST string; and every group costs it two HBM round trips it sits through (offsets, then bytes).  Here a group is the workgroup's
+// 256 strings in ONE window; a counting sort by len / 4 (64 bins: an LDS add per string returns its rank in the bin, every wave turns
+// the counts into the bins' starts with one DPP scan, a permute fetches the lane's) hands each wave the quarter whose lengths are
+// closest, the quarter rotating with the group; the next group's offsets and the first 8 KiB of its bytes wait in registers.  A string
+// that does not lie in the window whole, or is longer than the merged walk's 255 bytes, takes BatchOne from memory (rare: the flag in
+// its entry).  Only for programs with the merged automaton AND the packed tag table (every Tagged-DFA pattern of the corpus has both).
+constexpr int kTdfaSortedSlice = 256 * 48;       // bytes of a workgroup's 256 strings staged in LDS
+constexpr uint32_t kTsSlow = 1u << 30, kTsValid = 1u << 31;
+
+__device__ __forceinline__ unsigned TdfaDppScanAdd(unsigned x) {
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xF, 0xF, true);
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xF, 0xF, true);
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xF, 0xF, true);
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xA, 0xF, true);
+  x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xC, 0xF, true);
+  return x;
+}
+
+size_t TdfaSortedShared(const TdfaDev& D) {
+  return (size_t)(D.ntags + 1) * 256 * 4 + (size_t)(kTdfaSortedSlice + 32) + (128 + 16 + 256) * 4 + (size_t)D.m_nstates * D.m_ncls * 8 + 256 +
+         (((size_t)D.pool_n * 2 + 15) & ~size_t(15)) + (((size_t)D.nstates * 4 + 15) & ~size_t(15)) + (size_t)D.nstates * D.m_ncls * 8 +
+         (size_t)D.nstates * 4 + 16;
+}
+
+__global__ __launch_bounds__(256) void tdfa_batch_sorted_kernel(TdfaDev D, const uint8_t* concat, const uint64_t* offsets, long long nstr,
+                                                                uint8_t* found, int32_t* rows, uint32_t* flags) {
+  extern __shared__ uint32_t smem[];
+  const int tid = threadIdx.x;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  // LDS: the tag columns (a column per lane, the scrap column of the packed tag walk behind them) | the window | the sort's counts
+  // (two sets of 64, used in turn) and the order | the merged automaton, byte classes, action pool, accept words, packed tag table
+  int TDFA_LDS* const tags = (int TDFA_LDS*)smem + tid;
+  unsigned char* const win = reinterpret_cast<unsigned char*>(smem + (D.ntags + 1) * 256);
+  uint32_t* const hist = reinterpret_cast<uint32_t*>(win + kTdfaSortedSlice + 32);
+  uint32_t* const perm = hist + 128 + 16;
+  unsigned char* const mreg = reinterpret_cast<unsigned char*>(perm + 256);
+  const int m_bytes = D.m_nstates * D.m_ncls * 8;
+  const int16_t TDFA_LDS* const lpool = (const int16_t TDFA_LDS*)(mreg + m_bytes + 256);
+  unsigned char* const sreg = mreg + m_bytes + 256 + ((D.pool_n * 2 + 15) & ~15);
+  unsigned char* const treg = sreg + ((D.nstates * 4 + 15) & ~15);
+  const int t_bytes = D.nstates * D.m_ncls * 8;
+  for (int w = tid; w < m_bytes / 8; w += 256) reinterpret_cast<unsigned long long*>(mreg)[w] = D.ment[w];
+  mreg[m_bytes + tid] = D.mcls8[tid];
+  for (int w = tid; w < D.pool_n; w += 256) ((int16_t TDFA_LDS*)lpool)[w] = D.pool[w];
+  for (int w = tid; w < D.nstates; w += 256) reinterpret_cast<uint32_t*>(sreg)[w] = D.sinfo[w];
+  for (int w = tid; w < t_bytes / 8; w += 256) reinterpret_cast<unsigned long long*>(treg)[w] = D.tent[w];
+  for (int w = tid; w < D.nstates; w += 256) reinterpret_cast<uint32_t*>(treg + t_bytes)[w] = D.tacc[w];
+  if (tid < 128 + 16) hist[tid] = 0;
+  __syncthreads();
+  const unsigned ment_at = (unsigned)(uintptr_t)(const unsigned char TDFA_LDS*)mreg;
+  const unsigned mcls_at = ment_at + (unsigned)m_bytes;
+  const unsigned tent_at = (unsigned)(uintptr_t)(const unsigned char TDFA_LDS*)treg;
+  const unsigned tacc_at = tent_at + (unsigned)t_bytes;
+  const unsigned win_at = (unsigned)(uintptr_t)(const unsigned char TDFA_LDS*)win;
+  const long long ngroups = (nstr + 255) / 256;
+  const long long G = gridDim.x;
+  const uint8_t* const idle = reinterpret_cast<const uint8_t*>(D.ment);
+  // (the software pipeline of batch_tiny_sorted_kernel: offsets two groups ahead, bytes one group ahead, every load without a branch
+  // around it -- a clamped index, a harmless address)
+#define TDFA_NV(g) ((g) < ngroups ? (int)((nstr - (g) * 256) < 256 ? (nstr - (g) * 256) : 256) : 0)
+#define TDFA_META(g, a, b, gb, ge)                                                                  \
+  do {                                                                                              \
+    const int nv_ = TDFA_NV(g);                                                                     \
+    const long long i0_ = nv_ ? (g) * 256 : nstr - 1;                                               \
+    const uint64_t* ob_ = offsets + i0_;                                                            \
+    const uint32_t lc_ = min((uint32_t)tid, (uint32_t)(nv_ ? nv_ - 1 : 0));                         \
+    a = ob_[lc_]; b = ob_[lc_ + 1];                                                                 \
+    gb = ob_[0]; ge = ob_[nv_ ? nv_ : 1];                                                           \
+  } while (0)
+  // per lane: the string's place in the window and its sort entry's flags; len -1: the string takes the slow path
+#define TDFA_WINDOW(g, a, b, gb, ge, wb, wvalid, rel, len)                                                                        \
+  do {                                                                                                                            \
+    const int nv_ = TDFA_NV(g);                                                                                                   \
+    wb = 0; wvalid = 0;                                                                                                           \
+    if (nv_) {                                                                                                                    \
+      wb = (gb) & ~15ull;                                                                                                         \
+      const uint64_t span_ = (((ge) - wb) + 15ull) & ~15ull;                                                                      \
+      wvalid = (int)(span_ < (uint64_t)kTdfaSortedSlice ? span_ : (uint64_t)kTdfaSortedSlice);                                    \
+    }                                                                                                                             \
+    rel = (uint32_t)((a) - wb) & 16383u;                                                                                          \
+    len = tid < nv_ ? (int)((uint32_t)(b) - (uint32_t)(a)) : -2;                                                                  \
+    if (tid < nv_ && (((b) - (a)) > 255ull || (b) - wb > (uint64_t)wvalid)) len = -1;                                             \
+  } while (0)
+#define TDFA_PIECES(wb, wvalid)                                                                      \
+  do {                                                                                               \
+    const uint8_t* pb_ = (wvalid) ? concat + (wb) : idle;                                            \
+    const uint32_t nch_ = (uint32_t)(wvalid) >> 4;                                                   \
+    p0 = *reinterpret_cast<const uint4*>(pb_ + ((uint32_t)tid < nch_ ? (uint32_t)tid << 4 : 0u));                  \
+    p1 = *reinterpret_cast<const uint4*>(pb_ + ((uint32_t)tid + 256u < nch_ ? ((uint32_t)tid + 256u) << 4 : 0u));  \
+  } while (0)
+  uint4 p0, p1;
+  uint64_t an, bn, gbn, gen, wbc, wbn;
+  uint32_t relc, reln;
+  int wvc, wvn, lenc, lenn;
+  long long grp = blockIdx.x;
+  TDFA_META(grp, an, bn, gbn, gen);
+  TDFA_WINDOW(grp, an, bn, gbn, gen, wbc, wvc, relc, lenc);
+  TDFA_PIECES(wbc, wvc);
+  TDFA_META(grp + G, an, bn, gbn, gen);
+  for (int it = 0; grp < ngroups; grp += G, ++it) {
+    uint32_t* const h = hist + ((it & 1) << 6);
+    // bins: len / 4 (a trip of either walk is four bytes); slow strings last, lanes behind the batch's end first (they do nothing)
+    const uint32_t bin = lenc < 0 ? (lenc == -1 ? 63u : 0u) : (uint32_t)lenc >> 2;
+    const uint32_t rank = atomicAdd(&h[bin], 1u);
+    __syncthreads();                                          // every wave is done with the group before: its bytes and order may go
+    {
+      const int nch = wvc >> 4;
+      if (tid < nch) *reinterpret_cast<uint4*>(win + (tid << 4)) = p0;
+      if (tid + 256 < nch) *reinterpret_cast<uint4*>(win + ((tid + 256) << 4)) = p1;
+      const uint8_t* const pb = concat + wbc;                 // (strings of more than 32 bytes on average: the rest is fetched now)
+      for (int c = tid + 512; c < nch; c += 256) *reinterpret_cast<uint4*>(win + (c << 4)) = *reinterpret_cast<const uint4*>(pb + ((size_t)c << 4));
+    }
+    {
+      const uint32_t hv = h[lane];
+      const uint32_t x = TdfaDppScanAdd(hv);
+      const uint32_t start = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(bin << 2), (int)(x - hv));
+      perm[start + rank] = relc | ((uint32_t)(lenc < 0 ? 0 : lenc) << 14) | ((uint32_t)tid << 22) | (lenc == -1 ? kTsSlow : 0u) | (lenc != -2 ? kTsValid : 0u);
+    }
+    if (tid < 64) hist[(((it + 1) & 1) << 6) + tid] = 0;      // the next group's counts (last read a group ago)
+    const long long i0 = grp * 256;
+    TDFA_WINDOW(grp + G, an, bn, gbn, gen, wbn, wvn, reln, lenn);
+    TDFA_PIECES(wbn, wvn);
+    wbc = wbn; wvc = wvn; relc = reln; lenc = lenn;
+    TDFA_META(grp + 2 * G, an, bn, gbn, gen);
+    __syncthreads();
+    const uint32_t e = perm[(((uint32_t)wave + (uint32_t)it) & 3u) * 64u + (uint32_t)lane];
+    if (e & kTsValid) {
+      const long long i = i0 + (long long)((e >> 22) & 255u);
+      const int len = (int)((e >> 14) & 255u);
+      if (!(e & kTsSlow)) {
+        const unsigned lb = win_at + (e & 16383u);
+        int bs, be;
+        WalkMerged(ment_at, mcls_at, (unsigned)D.m_bot_row, lb, len, &bs, &be);
+        found[i] = be >= 0 ? 1 : 0;
+        if (be >= 0)
+          TagsPacked(tent_at, tacc_at, mcls_at, (unsigned)D.m_ncls * 8u, lb, len, bs, be, bs == 0 ? D.start_begin : D.start_any, lpool,
+                     bs == 0 ? D.init_begin : D.init_any, D.ntags, tags, rows + i * D.ntags);
+      } else {
+        const uint64_t o0 = offsets[i], o1 = offsets[i + 1];
+        BatchOne(D, D.ent, concat + o0, (int)(o1 - o0), tags, (uint8_t TDFA_LDS*)nullptr, found + i, rows + i * D.ntags, flags, false);
+      }
+    }
+  }
+#undef TDFA_NV
+#undef TDFA_META
+#undef TDFA_WINDOW
+#undef TDFA_PIECES
+}
+
 size_t TdfaShared(const TdfaDev& D, bool lds, bool with_tags, bool with_window = false) {
   return (size_t)(lds ? D.nstates * 128 * 4 : 0) + (with_tags ? (size_t)D.ntags * 256 * 4 : 0) +
          (with_window ? (D.m_nstates > 0 ? 256 * 4 : 64 * 256) + 4 * (size_t)(kTdfaWaveSlice + 16) + (D.m_nstates > 0 ? (size_t)D.m_nstates * D.m_ncls * 8 + 256 + 16 + (((size_t)D.pool_n * 2 + 15) & ~size_t(15)) + (size_t)D.nstates * 4 + 32 + (D.tag_packed ? (size_t)D.nstates * D.m_ncls * 8 + (size_t)D.nstates * 4 + 16 : 0) : 0) : 0);
@@ -935,10 +1089,24 @@ hipError_t LaunchTdfaTags(const TdfaDev& D, const uint8_t* buf, int32_t len, con
 hipError_t LaunchTdfaBatch(const TdfaDev& D, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found, int32_t* rows,
                            uint32_t* flags, hipStream_t stream) {
   if (nstr <= 0) return hipSuccess;
-  const bool lds = TdfaInLds(D, true, true);
-  const size_t sh = TdfaShared(D, lds, true, true);
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+  // the sorted, pipelined form: programs with the merged automaton and the packed tag table, batches worth a sort (RGX_TDFA_UNSORTED:
+  // experiment builds run the kernel below)
+  static const bool unsorted = ExpEnv("RGX_TDFA_UNSORTED") != nullptr;
+  if (!unsorted && D.m_nstates > 0 && D.tag_packed != 0 && (((uintptr_t)concat) & 15) == 0 && nstr >= 256 &&
+      TdfaSortedShared(D) <= 64 * 1024) {
+    const size_t shs = TdfaSortedShared(D);
+    hipError_t rc;
+    if ((rc = AllowLds(tdfa_batch_sorted_kernel, shs)) != hipSuccess) return rc;
+    int per_cu = (int)((160 * 1024) / (shs + 512));             // (what the LDS allows; the registers may allow less: the grid is a few times
+    per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);        // what is resident either way)
+    const int grid = GridFor(nstr, 256, cus * per_cu * 4);    // (a few times what is resident: late workgroups even out the tail)
+    hipLaunchKernelGGL(tdfa_batch_sorted_kernel, dim3(grid), dim3(256), shs, stream, D, concat, offsets, (long long)nstr, found, rows, flags);
+    return hipGetLastError();
+  }
+  const bool lds = TdfaInLds(D, true, true);
+  const size_t sh = TdfaShared(D, lds, true, true);
   int per_cu = (int)((160 * 1024) / (sh + 512));
   per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);
   const int grid = GridFor(nstr, 256, cus * per_cu * 2);      // persistent workgroups: the table is staged once each

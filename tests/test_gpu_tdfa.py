@@ -83,6 +83,53 @@ def test_tdfa_find_is_the_reference_engine(built, kats, corpus):
     assert checked >= 2000 and untouched >= 1000 and differs >= 300, (checked, untouched, differs)
 
 
+def test_tdfa_batch_sorted_groups(built, kats, corpus):
+    """The batch kernel's sorted form (tdfa_batch_sorted_kernel: a workgroup's 256 strings in one window, dealt to the waves by
+    length): many groups, a last group that is not full, groups whose strings outgrow the window (those behind it are walked out of
+    memory), strings beyond the merged walk's 255 bytes, empty strings, all lengths mixed in every group -- rows == oracle.tdfa.find
+    at the string's own place in the batch."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU; there is no CPU fallback")
+    from regengo_amd import Compiled
+    from oracle import engines as E
+    pats = [r"(?P<user>\w+)@(?P<domain>\w+)"] + EXTRA
+    items = _tdfa_items(kats, corpus)
+    pats += [it[0] for it in items[:3]]
+    checked = found = 0
+    for pat in dict.fromkeys(pats):
+        o = E.Compiled(pat, force_tdfa=True) if pat.startswith("(?P<user>") else E.Compiled(pat)
+        assert o.tdfa is not None, pat
+        c = Compiled(pat, force_tdfa=True).to(0) if pat.startswith("(?P<user>") else Compiled(pat).to(0)
+        rnd = random.Random(zlib.crc32(pat.encode()) ^ 0x50)
+        tb = o.tdfa.tables()
+        tb["start_any"] = o.tdfa.start_any
+        from tests import _fuzzgen as F
+        strings = []
+        # groups of short strings (the common case), a stretch of long ones (window overflow), the odd string beyond 255 bytes
+        for k in range(256 * 5 + 77):
+            r = rnd.random()
+            if 600 <= k < 900:
+                n = rnd.randint(40, 250)
+            elif r < 0.02:
+                n = rnd.randint(256, 300)
+            elif r < 0.05:
+                n = 0
+            else:
+                n = rnd.randint(1, 56)
+            strings.append(F.tdfa_guided_text(tb, rnd, n) if n else b"")
+        res = c.FindBatch(strings)
+        assert len(res) == len(strings)
+        for b, r in zip(strings, res):
+            exp = o.tdfa.find(b)
+            assert (r is None) == (exp is None), (pat, b)
+            checked += 1
+            if r is not None:
+                assert r.spans == exp, (pat, b, r.spans, exp)
+                found += 1
+    assert checked >= 6 * 1300 and found >= 1500, (checked, found)
+
+
 def test_tdfa_find_reader_is_the_reference_loop(built, kats, corpus):
     """FindReader / FindReaderCount of a TDFA-class program in reference mode: rgx_find_chunk runs the engine's FindBytesReuse loop
     over the chunk on the device.  Callbacks (offset, chunk index, raw tags) AND the texts the callback reads from the reused result
