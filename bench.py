@@ -668,7 +668,7 @@ def run_c3(env, args):
                       "parity_rows_vs_oracle_sample": sample_all, "oracle_sample_strings": int(len(sample))}
     line["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
-                        "kernel": "tdfa_batch_kernel (a lane per string: the loop over start offsets, the table walk, the tag file in LDS)" if args.force_tdfa else
+                        "kernel": "tdfa_batch_sorted_kernel (a lane per string, a workgroup's 256 strings dealt to the waves by length: the merged-attempts walk, the tag walk, the tag file in LDS)" if args.force_tdfa else
                                   "batch_tiny_kernel + ref_fix_list_kernel (the call: one lock-step pass per string in registers -- search automaton columns, v_perm tag registers for the groups, the reference's attempt offsets riding along; strings it flags replayed from its list.  Strings beyond 56 bytes would send the batch to batch_search_kernel: none here)", "kernel_ms": round(k_ms, 4),
                         "algorithmic_bytes_per_launch": alg, "timed_launches": len(kms),
                         "note": "event-bracketed call: includes the launch of the call's kernels"}

@@ -624,7 +624,7 @@ size_t TdfaSortedShared(const TdfaDev& D) {
          (size_t)D.nstates * 4 + 16;
 }
 
-__global__ __launch_bounds__(256) void tdfa_batch_sorted_kernel(TdfaDev D, const uint8_t* concat, const uint64_t* offsets, long long nstr,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void tdfa_batch_sorted_kernel(TdfaDev D, const uint8_t* concat, const uint64_t* offsets, long long nstr,
                                                                 uint8_t* found, int32_t* rows, uint32_t* flags) {
   extern __shared__ uint32_t smem[];
   const int tid = threadIdx.x;
