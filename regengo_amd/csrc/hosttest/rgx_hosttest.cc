@@ -537,6 +537,21 @@ int rgxt_tdfa_merged_find(void* hh, const uint8_t* buf, int64_t len, int32_t* ou
   return 1;
 }
 
+// TdfaDev::tag_acc_last as the product computes it (rgx_program.cc): 1 = every accepting state's accept list names the same tags (the
+// device's tag walk applies the accept actions once, at the end), 0 = not so, -1 = no Tagged DFA / no packed tag table.
+int rgxt_tdfa_acc_last(void* hh) {
+  const RefTdfa& d = ((Handle*)hh)->t.tdfa;
+  if (!d.nstates) return -1;
+  bool any_never = !(d.accept[d.start_any] & 3);
+  for (int c = 0; c < 128 && any_never; c++) if (d.trans[(size_t)d.start_any * 128 + c] >= 0) any_never = false;
+  std::vector<unsigned long long> ment, tent;
+  std::vector<uint8_t> mcls8;
+  std::vector<uint32_t> tacc;
+  int ns = 0, ncls = 0, bot = 0, acc_last = 0;
+  if (!BuildTdfaMerged(d, any_never, &ment, &mcls8, &ns, &ncls, &bot, &tent, &tacc, &acc_last) || tent.empty()) return -1;
+  return acc_last;
+}
+
 int rgxt_ref_find(void* hh, const uint8_t* buf, int64_t len, int32_t* out) {
   const Tables& t = ((Handle*)hh)->t;
   if (t.ref_memo || t.ref_find_engine > 0) return -3;

@@ -206,7 +206,8 @@ bool BuildRefTdfa(const Prog& prog, int ncap_names, RefTdfa* out, int max_states
 // accept: tdfa.go:831-994) as ONE automaton over byte classes, for rgx_tdfa.hip's per-string kernel; rgx_program.h: TdfaDev has the entry
 // layout.  false: not built (a start state that accepts, more than four attempts alive at once, more than 255 states).
 bool BuildTdfaMerged(const RefTdfa& r, bool any_never, std::vector<unsigned long long>* ment, std::vector<uint8_t>* mcls8, int* m_nstates,
-                     int* m_ncls, int* bot_row, std::vector<unsigned long long>* tent = nullptr, std::vector<uint32_t>* tacc = nullptr);
+                     int* m_ncls, int* bot_row, std::vector<unsigned long long>* tent = nullptr, std::vector<uint32_t>* tacc = nullptr,
+                     int* acc_last = nullptr);
 
 // One-pass (RE2's term): on every edge exactly one thread of the source state consumes the byte, i.e. every thread of the next
 // state has the same parent -- the capture groups of a match then come out of ONE forward walk (rgx_kernels.hip:

@@ -516,7 +516,8 @@ int UploadTdfa(Program* p) {
   int m_nstates = 0, m_ncls = 0, m_bot = 0;
   std::vector<unsigned long long> tent;
   std::vector<uint32_t> tacc;
-  if (!BuildTdfaMerged(r, any_never, &ment, &mcls8, &m_nstates, &m_ncls, &m_bot, &tent, &tacc)) { ment.assign(1, 0ull); mcls8.assign(256, 0); m_nstates = 0; tent.clear(); }
+  int acc_last = 0;
+  if (!BuildTdfaMerged(r, any_never, &ment, &mcls8, &m_nstates, &m_ncls, &m_bot, &tent, &tacc, &acc_last)) { ment.assign(1, 0ull); mcls8.assign(256, 0); m_nstates = 0; tent.clear(); }
   const int tag_packed = tent.empty() ? 0 : 1;
   if (!tag_packed) { tent.assign(1, 0ull); tacc.assign(1, 0u); }
   Arena a;
@@ -536,7 +537,7 @@ int UploadTdfa(Program* p) {
   d.ment = (const unsigned long long*)(b + off_ment); d.mcls8 = b + off_mcls;
   d.m_nstates = m_nstates; d.m_ncls = m_ncls; d.m_bot_row = m_bot;
   d.pool_n = (int32_t)r.pool.size();
-  d.tent = (const unsigned long long*)(b + off_tent); d.tacc = (const uint32_t*)(b + off_tacc); d.tag_packed = tag_packed;
+  d.tent = (const unsigned long long*)(b + off_tent); d.tacc = (const uint32_t*)(b + off_tacc); d.tag_packed = tag_packed; d.tag_acc_last = tag_packed ? acc_last : 0;
   p->tdfadev = d;
   p->d_arena_tdfa = dptr;
   return RGX_OK;

@@ -211,6 +211,8 @@ struct TdfaDev {
   const unsigned long long* tent;
   const uint32_t* tacc;
   int32_t tag_packed;
+  int32_t tag_acc_last;                // 1: every accepting state's accept list names the same tags -- the tag walk applies the accept actions once,
+                                       // behind its last byte (rgx_ref_engine.cc: BuildTdfaMerged has the argument)
 };
 
 struct Program {

@@ -457,8 +457,9 @@ bool BuildTinySearch(const Tables& u, const Tables& f, std::vector<uint32_t>* im
 // 0 nobody has accepted, 1 the youngest of the list is the attempt that has, 2 that attempt is dead and the list holds older ones;
 // the beginning of the text, whose fresh attempt leaves startStateBegin).  false: not built (rgx_program.h: TdfaDev).
 bool BuildTdfaMerged(const RefTdfa& r, bool any_never, std::vector<unsigned long long>* ment, std::vector<uint8_t>* mcls8, int* m_nstates,
-                     int* m_ncls, int* bot_row, std::vector<unsigned long long>* tent, std::vector<uint32_t>* tacc) {
+                     int* m_ncls, int* bot_row, std::vector<unsigned long long>* tent, std::vector<uint32_t>* tacc, int* acc_last) {
   const int S = r.nstates;
+  if (acc_last) *acc_last = 0;
   if (S <= 0 || (r.accept[r.start_begin] & 3) || (r.accept[r.start_any] & 3)) return false;
   // byte classes: bytes whose columns (next state and tag actions per state) are equal; class 0 = "every attempt dies" (bytes >= 128 among them)
   std::vector<int> cls_of(256, 0);
@@ -520,6 +521,46 @@ bool BuildTdfaMerged(const RefTdfa& r, bool any_never, std::vector<unsigned long
       }
     }
     if (ok) { *tent = te; *tacc = ta; }
+    // Accept actions write the LIVE tags at every accept of the walk (tdfa.go:939-987), but tags are write-only and the last write
+    // wins.  The tag walk may apply the accept actions ONCE, behind its last byte (where the attempt's last accept is), when no write
+    // of an EARLIER accept can be the last write of its tag: for every state A that accepts in the middle of a text and every tag t of
+    // its list, every way on from A to a state B the walk can stop in (one that accepts, at the end of the text or anywhere) writes t
+    // again -- on an edge, or in B's own list.  pend[q][t]: arriving in q with such a write of t still standing, the walk can stop with it.
+    if (ok && acc_last) {
+      const int nt = r.ntags;
+      auto list_has = [&](int list, int t) -> bool {
+        const int n = list ? r.pool[list] : 0;
+        for (int a = 0; a < n; a++) if (r.pool[list + 1 + 2 * a] == t) return true;
+        return false;
+      };
+      std::vector<uint8_t> pend((size_t)S * nt, 0);
+      for (int q = 0; q < S; q++)
+        for (int t = 0; t < nt; t++) pend[(size_t)q * nt + t] = (r.accept[q] & 3) && !list_has(r.acc_act[q], t) ? 1 : 0;
+      for (bool changed = true; changed;) {
+        changed = false;
+        for (int q = 0; q < S; q++)
+          for (int k = 1; k < ncls; k++) {
+            const int nq = cols[k][q];
+            if (nq < 0) continue;
+            const int list = r.act[(size_t)q * 128 + rep[k]];
+            for (int t = 0; t < nt; t++)
+              if (!pend[(size_t)q * nt + t] && pend[(size_t)nq * nt + t] && !list_has(list, t)) { pend[(size_t)q * nt + t] = 1; changed = true; }
+          }
+      }
+      bool fine = true;
+      for (int q = 0; q < S && fine; q++) {
+        if (!(r.accept[q] & 1)) continue;
+        const int n = r.acc_act[q] ? r.pool[r.acc_act[q]] : 0;
+        for (int a = 0; a < n && fine; a++) {
+          const int t = r.pool[r.acc_act[q] + 1 + 2 * a];
+          for (int k = 1; k < ncls && fine; k++) {
+            const int nq = cols[k][q];
+            if (nq >= 0 && pend[(size_t)nq * nt + t] && !list_has(r.act[(size_t)q * 128 + rep[k]], t)) fine = false;
+          }
+        }
+      }
+      *acc_last = fine ? 1 : 0;
+    }
   }
   if (ncls > 32) return false;
   struct MS { std::vector<int> list; int mode; bool bot; };

@@ -411,9 +411,13 @@ __device__ __forceinline__ void WalkMerged(unsigned ment_at, unsigned mcls_at, u
   typedef const MEnt TDFA_LDS* EntP;
   typedef const uint8_t TDFA_LDS* ClsP;
   typedef const unsigned TDFA_LDS* WordP;
-  unsigned row = bot_row, R = 0;
-  int start = 0, end = -1, i = 0;
-  bool alive = len > 0;
+  // (the end-of-text flags matter at a string's LAST byte only: the loop takes the bytes in front of it with the plain flags, the last
+  // byte is a step of its own behind the loop; the winner's start stays in its slot of R -- a copy of R and of the flags per accept --
+  // and is taken out once, at the end: the walk is bound by VALU issue and both were paid at every byte)
+  unsigned row = bot_row, R = 0, Racc = 0, facc = 0, lastx = 0;
+  int end = -1, i = 0;
+  const int lm1 = len - 1;
+  bool alive = lm1 > 0;
   // four bytes per trip: their classes depend on the bytes alone (four look-ups in flight together), only the entries wait for one another
   const unsigned sh = buf_at & 3u;
   unsigned wa = buf_at & ~3u;
@@ -422,29 +426,37 @@ __device__ __forceinline__ void WalkMerged(unsigned ment_at, unsigned mcls_at, u
   if (alive) {                                                                             \
     const MEnt e = *(EntP)(uintptr_t)(ment_at + row + k8[KK]);                             \
     R = __builtin_amdgcn_perm((unsigned)i, R, e.y);                                        \
-    const unsigned fl = i + 1 == len ? e.x >> 20 : e.x >> 17;                              \
-    if (fl & 1u) { start = (int)((R >> ((fl & 6u) << 2)) & 255u); end = i + 1; }           \
-    row = e.x & 0xFFFFu;                                                                   \
     ++i;                                                                                   \
-    alive = !(e.x & (1u << 16)) && i < len;                                                \
+    if (e.x & (1u << 17)) { Racc = R; facc = e.x >> 18; end = i; }                         \
+    row = e.x & 0xFFFFu;                                                                   \
+    lastx = e.x;                                                                           \
+    alive = !(e.x & (1u << 16)) && i < lm1;                                                \
   }
   while (alive) {
     const unsigned b4 = __builtin_amdgcn_alignbyte(w1, w0, sh);
     wa += 4;
     w0 = w1;
-    w1 = *(WordP)(uintptr_t)(wa + 4);                       // (one dword past the string at most: inside the wave's window, which is 16 bytes longer)
+    w1 = *(WordP)(uintptr_t)(wa + 4);                       // (one dword past the string at most: inside the window, which is 16 bytes longer)
     unsigned k8[4];
 #pragma unroll
     for (int k = 0; k < 4; ++k) k8[k] = *(ClsP)(uintptr_t)(mcls_at + ((b4 >> (8 * k)) & 255u));
     TDFA_MSTEP(0) TDFA_MSTEP(1) TDFA_MSTEP(2) TDFA_MSTEP(3)
   }
 #undef TDFA_MSTEP
+  if (len > 0 && i == lm1 && !(lastx & (1u << 16))) {
+    const unsigned c = *(ClsP)(uintptr_t)(mcls_at + (unsigned)*(ClsP)(uintptr_t)(buf_at + (unsigned)lm1));
+    const MEnt e = *(EntP)(uintptr_t)(ment_at + row + c);
+    R = __builtin_amdgcn_perm((unsigned)i, R, e.y);
+    if (e.x & (1u << 20)) { Racc = R; facc = e.x >> 21; end = len; }
+  }
+  const int start = (int)((Racc >> ((facc & 3u) << 3)) & 255u);
   *bs = start; *be = end;
 }
 
 // The tag walk of the winning attempt over the packed table (rgx_dfa.h: BuildTdfaMerged): what AttemptTags computes, with ONE dependent
 // look-up per byte -- the entry names the next state, says whether it accepts, and carries the edge's tag actions as bytes (tag << 4 |
 // offset; "none" is the scrap column behind the tags), so the two actions almost every list has are two unconditional stores.
+template <bool LAST>
 __device__ __forceinline__ void TagsPacked(unsigned tent_at, unsigned tacc_at, unsigned mcls_at, unsigned ncls8, unsigned buf_at, int len,
                                            int start, int stop, int st, const int16_t TDFA_LDS* pool, int init_list, int ntags,
                                            int TDFA_LDS* tags, int32_t* out) {
@@ -476,14 +488,18 @@ __device__ __forceinline__ void TagsPacked(unsigned tent_at, unsigned tacc_at, u
   const unsigned sh = sa & 3u;
   unsigned wa = sa & ~3u;
   unsigned w0 = *(WordP)(uintptr_t)wa, w1 = *(WordP)(uintptr_t)(wa + 4);
+  unsigned ns = (unsigned)st;
+  // LAST (TdfaDev::tag_acc_last): the accept actions once, behind the walk's last byte -- `stop` is the end of the attempt's last accept
 #define TDFA_TSTEP(KK)                                                                     \
   if (i < stop) {                                                                          \
     const MEnt e = *(EntP)(uintptr_t)(tent_at + row + k8[KK]);                             \
-    const unsigned ns = e.x & kTNext;                                                      \
-    const bool acc = (e.x & kTAcc) || ((e.x & kTAccEot) && i + 1 == len);                  \
-    const unsigned aw = *(WordP)(uintptr_t)(tacc_at + (ns << 2));                          \
+    ns = e.x & kTNext;                                                                     \
     apply(e.y, i + 1);                                                                     \
-    apply(acc ? aw : none4, i + 1);                                                        \
+    if (!LAST) {                                                                           \
+      const bool acc = (e.x & kTAcc) || ((e.x & kTAccEot) && i + 1 == len);                \
+      const unsigned aw = *(WordP)(uintptr_t)(tacc_at + (ns << 2));                        \
+      apply(acc ? aw : none4, i + 1);                                                      \
+    }                                                                                      \
     row = ns * ncls8;                                                                      \
     ++i;                                                                                   \
   }
@@ -498,6 +514,7 @@ __device__ __forceinline__ void TagsPacked(unsigned tent_at, unsigned tacc_at, u
     TDFA_TSTEP(0) TDFA_TSTEP(1) TDFA_TSTEP(2) TDFA_TSTEP(3)
   }
 #undef TDFA_TSTEP
+  if (LAST && stop > start) apply(*(WordP)(uintptr_t)(tacc_at + (ns << 2)), stop);
   // result construction (tdfa.go:998-1052), as AttemptTags; a group is one 8-byte store (rows are ntags * 4 bytes apart, ntags even)
   *reinterpret_cast<int2*>(out) = make_int2(tags[0], stop);
   for (int g = 1; g < ntags / 2; ++g) {
@@ -581,7 +598,7 @@ __global__ __launch_bounds__(256) void tdfa_batch_kernel(TdfaDev D, const uint8_
           WalkMerged(ment_at, mcls_at, (unsigned)D.m_bot_row, (unsigned)(uintptr_t)lb, len, &bs, &be);
           found[i] = be >= 0 ? 1 : 0;
           if (be >= 0) {
-            if (packed) TagsPacked(tent_at, tacc_at, mcls_at, (unsigned)D.m_ncls * 8u, (unsigned)(uintptr_t)lb, len, bs, be, bs == 0 ? D.start_begin : D.start_any,
+            if (packed) TagsPacked<false>(tent_at, tacc_at, mcls_at, (unsigned)D.m_ncls * 8u, (unsigned)(uintptr_t)lb, len, bs, be, bs == 0 ? D.start_begin : D.start_any,
                                    lpool, bs == 0 ? D.init_begin : D.init_any, D.ntags, tags, rows + i * D.ntags);
             else AttemptTags(ent, lpool, lb, len, bs, be, bs == 0 ? D.start_begin : D.start_any, bs == 0 ? D.init_begin : D.init_any,
                              D.ntags, tags, rows + i * D.ntags, lsinfo);
@@ -734,9 +751,14 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
         int bs, be;
         WalkMerged(ment_at, mcls_at, (unsigned)D.m_bot_row, lb, len, &bs, &be);
         found[i] = be >= 0 ? 1 : 0;
-        if (be >= 0)
-          TagsPacked(tent_at, tacc_at, mcls_at, (unsigned)D.m_ncls * 8u, lb, len, bs, be, bs == 0 ? D.start_begin : D.start_any, lpool,
-                     bs == 0 ? D.init_begin : D.init_any, D.ntags, tags, rows + i * D.ntags);
+        if (be >= 0) {
+          if (D.tag_acc_last)
+            TagsPacked<true>(tent_at, tacc_at, mcls_at, (unsigned)D.m_ncls * 8u, lb, len, bs, be, bs == 0 ? D.start_begin : D.start_any, lpool,
+                             bs == 0 ? D.init_begin : D.init_any, D.ntags, tags, rows + i * D.ntags);
+          else
+            TagsPacked<false>(tent_at, tacc_at, mcls_at, (unsigned)D.m_ncls * 8u, lb, len, bs, be, bs == 0 ? D.start_begin : D.start_any, lpool,
+                              bs == 0 ? D.init_begin : D.init_any, D.ntags, tags, rows + i * D.ntags);
+        }
       } else {
         const uint64_t o0 = offsets[i], o1 = offsets[i + 1];
         BatchOne(D, D.ent, concat + o0, (int)(o1 - o0), tags, (uint8_t TDFA_LDS*)nullptr, found + i, rows + i * D.ntags, flags, false);

@@ -44,6 +44,7 @@ _lib.rgxt_tdfa_header.argtypes = [C.c_void_p, C.c_void_p]
 _lib.rgxt_tdfa_tables.argtypes = [C.c_void_p] + [C.c_void_p] * 5
 _lib.rgxt_tdfa_find.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p]
 _lib.rgxt_tdfa_merged_find.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p]
+_lib.rgxt_tdfa_acc_last.argtypes = [C.c_void_p]
 _lib.rgxt_memo_find.argtypes = [C.c_void_p, C.c_char_p, C.c_int64, C.c_void_p]
 _lib.rgxt_memo_match.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
 _lib.rgxt_tiny_find.argtypes = [C.c_void_p, C.c_void_p, C.c_char_p, C.c_int64, C.c_int, C.c_void_p]
@@ -190,6 +191,11 @@ class HostProgram:
         if r == -3:
             return NotImplemented
         return (out[0], out[1]) if r == 1 else None
+
+    def tdfa_acc_last(self):
+        """TdfaDev::tag_acc_last as the product computes it: 1 / 0, None when the program has no packed tag table."""
+        r = _lib.rgxt_tdfa_acc_last(self.h)
+        return None if r < 0 else r
 
     def memo_find(self, b: bytes):
         """FindBytesReuse of a program the reference emits with its memoising backtracker, as the device computes it (rgx_memo.h):

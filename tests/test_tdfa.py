@@ -166,6 +166,84 @@ def test_product_tables_equal_the_oracle_on_the_corpus(kats, corpus):
     assert seen >= 12 and built_merged >= 8
 
 
+def test_accept_actions_once_flag(kats, corpus):
+    """TdfaDev::tag_acc_last (the tag walk applies the accept actions once, behind its last byte) is set exactly when no earlier
+    accept's write can be the last write of its tag (every way on to a state the walk can stop in writes the tag again) --
+    recomputed here from the oracle's tables -- and, independently of the argument in rgx_ref_engine.cc, a walk that applies the
+    accept actions only at its last accept gives the emitted loop's tags on those programs (simulated here over the oracle's tables
+    on guided texts)."""
+    import random
+    import zlib
+    from tests._hosttest import HostProgram
+    from tests import _fuzzgen as F
+    pats = [c["pattern"] for c in kats["curated_cases"]] + [e["pattern"] for e in corpus]
+    pats += [r"(?P<x>(?:a+)+?)(?P<y>b+?)", r"(?P<x>(?:[a-c]+,)+?)(?P<y>\d+)?", r"(?P<a>(?:x+)+)(?P<b>y)?(?P<c>z+)?"]
+    on = off = sims = 0
+    for pat in dict.fromkeys(pats):
+        o = E.Compiled(pat)
+        if o.tdfa is None:
+            continue
+        got = HostProgram(pat).tdfa_acc_last()
+        if got is None:
+            continue
+        t = o.tdfa
+        # pend[q][tag]: arriving in q with an earlier accept's write of `tag` still standing, the walk can stop with it standing
+        ns_, ntags_ = len(t.states), max(t.ncap_names, 1) * 2
+        acc_tags = {q: {tag for tag, _ in t.accept_actions.get(q, [])} for q in range(ns_)}
+        stops = [q for q in range(ns_) if t.accept.get(q) or t.accept_eot.get(q)]
+        pend = {(q, tag) for q in stops for tag in range(ntags_) if tag not in acc_tags[q]}
+        grew = True
+        while grew:
+            grew = False
+            for q in range(ns_):
+                for c, nq in t.trans[q].items():
+                    wr = {tag for tag, _ in t.tag_actions[q].get(c, [])}
+                    for tag in range(ntags_):
+                        if (q, tag) not in pend and (nq, tag) in pend and tag not in wr:
+                            pend.add((q, tag))
+                            grew = True
+        fine = all(not ((nq, tag) in pend and tag not in {x for x, _ in t.tag_actions[q].get(c, [])})
+                   for q in range(ns_) if t.accept.get(q) for tag in acc_tags[q] for c, nq in t.trans[q].items())
+        assert got == (1 if fine else 0), (pat, got, fine)
+        on += got
+        off += 1 - got
+        if not got:
+            continue
+        tb = t.tables()
+        tb["start_any"] = t.start_any
+        rnd = random.Random(zlib.crc32(pat.encode()) ^ 7)
+        for _ in range(40):
+            b = F.tdfa_guided_text(tb, rnd, rnd.randint(1, 80))
+            want = t.find(b)
+            if want is None:
+                continue
+            # the winning attempt again, accept actions at its end only
+            start, stop = want[0], want[1]
+            ntags = max(t.ncap_names, 1) * 2
+            tags = [-1] * ntags
+            tags[0] = start
+            state = t.start_begin if start == 0 else t.start_any
+            for tg, _ in (t.initial_begin if start == 0 else t.initial_any):
+                tags[tg] = start
+            for i in range(start, stop):
+                c = b[i]
+                for tg, of in t.tag_actions[state].get(c, []):
+                    tags[tg] = i + 1 - of
+                state = t.trans[state][c]
+            for tg, of in t.accept_actions.get(state, []):
+                tags[tg] = stop - of
+            tags[1] = stop
+            for g in range(1, t.ncap_names):
+                if tags[2 * g] >= 0:
+                    if tags[2 * g + 1] < 0:
+                        tags[2 * g + 1] = stop
+                else:
+                    tags[2 * g + 1] = -1
+            assert tags == want, (pat, b, tags, want)
+            sims += 1
+    assert on >= 5 and sims >= 100, (on, off, sims)
+
+
 def test_c_port_of_the_emitted_tdfa_equals_the_restatement(kats, corpus):
     """oracle/tdfa_c.py (the emitted tables as C arrays + the emitted loop: bulk checker and bench.py's cpu_baseline for
     --config c3 --force-tdfa) against oracle/tdfa.py, single finds and the FindReader chunk loop."""
