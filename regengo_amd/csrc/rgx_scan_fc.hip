@@ -189,7 +189,7 @@ __device__ __forceinline__ void FcResolveSlow(const FcSlowPtrs* sp, const uint8_
 // 64 KiB.  A tile that needed a second round of candidates resolves the look-back right there (its predecessors only: the own count is
 // not out yet) and the workgroup writes its rows as they come from then on.
 template <int PER, bool W16, int MODE, int NW>
-__global__ __launch_bounds__(kFcThreads) __attribute__((amdgpu_waves_per_eu(4, 4))) void scan_fc_kernel(FcParams P) {
+__global__ __launch_bounds__(kFcThreads) __attribute__((amdgpu_waves_per_eu(MODE == 1 ? 5 : 4, MODE == 1 ? 5 : 4))) void scan_fc_kernel(FcParams P) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
