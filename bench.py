@@ -656,7 +656,7 @@ def run_c3(env, args):
     k_ms = sum(kms) / len(kms)
     alg = nbytes + 8 * (nstr + 1) + nstr + nstr * c.ncap * 4      # input bytes + CSR offsets + found flags + span records
     achieved = alg / (k_ms * 1e-3) / 1e9
-    traffic, tsrc = load_traffic("c3", "tdfa_batch" if args.force_tdfa else "batch_tiny")
+    traffic, tsrc = load_traffic("c3t" if args.force_tdfa else "c3", "tdfa_batch_sorted" if args.force_tdfa else "batch_tiny")
     line = base_line(env, args, value, ms_per_step, reps)
     line["config"] = {"workload": "C3: Email pattern FindBytes over a batch of %d strings per GPU (reference semantics), found flag + "
                                   "span record per string" % nstr,

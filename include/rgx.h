@@ -136,9 +136,12 @@ typedef struct rgx_info {
                              * (compiler.go:646-651, Q11) -- reproduced, duplicates included, for a WHOLE text on one device:
                              * rgx_find_all_bytes(_device) and rgx_count_all_device answer, the forms that cut a text (owned
                              * ranges, starts-only rows, submit / wait, rgx_sharded_*) return RGX_E_UNSUPPORTED; rows hold
-                             * (-1, -1) for a group that took no part (the wrapper's FindBytes fills a fresh struct).  0: that
-                             * engine on a pattern with `^` (an attempt then depends on the slice it is made in), or the memoising
-                             * one on a pattern that matches empty: every FindAll / count entry point returns RGX_E_UNSUPPORTED
+                             * (-1, -1) for a group that took no part (the wrapper's FindBytes fills a fresh struct).  A pattern
+                             * that begins with `^` (startStateAny can neither accept nor move) is offered the same way: its
+                             * wrapper is a chain of anchored attempts, one where the last match ended.  0: that engine on a
+                             * pattern whose two start states differ otherwise (an attempt then depends on the slice it is made
+                             * in), or the memoising one on a pattern that matches empty: every FindAll / count entry point
+                             * returns RGX_E_UNSUPPORTED
                              * unless the program was compiled with RGX_FLAG_STDLIB_SEMANTICS                                    */
   int32_t ref_stream_offered;  /* 1: rgx_find_chunk / rgx_count_chunk (FindReader / FindReaderCount / FindReaderFirst) are offered in
                              * reference mode: the emitted loop is FindBytesReuse on a re-sliced input, so the library must

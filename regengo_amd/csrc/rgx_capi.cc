@@ -188,8 +188,16 @@ bool RefFindAllOffered(const Tables& t) {
 // reproduced on the device -- one text, one device (rgx_find_all_bytes(_device), rgx_count_all_device; TdfaFindAllDevice), for programs
 // whose two start states are one (no `^`: an attempt does not depend on the slice it is made in).  Owned ranges, starts-only rows,
 // submit / wait and the sharded rounds stay refused for this class: the wrapper's offsets do not restart at a window's edge.
+// A program whose startStateAny neither accepts nor moves (a pattern that begins with ^; TdfaDev::any_never) is offered too: its
+// wrapper is a chain of anchored attempts (rgx_tdfa.hip: tdfa_q11_anchored_kernel).
+bool TdfaAnyNever(const RefTdfa& r) {
+  if (r.nstates <= 0 || (r.accept[r.start_any] & 3)) return false;
+  for (int c = 0; c < 128; c++) if (r.trans[(size_t)r.start_any * 128 + c] >= 0) return false;
+  return true;
+}
 bool RefTdfaFindAllOffered(const Tables& t) {
-  return t.ref_find_engine == 1 && t.tdfa.nstates > 0 && t.tdfa.nstates <= 1000 && t.tdfa.ntags == t.ncap && t.tdfa.start_begin == t.tdfa.start_any;
+  return t.ref_find_engine == 1 && t.tdfa.nstates > 0 && t.tdfa.nstates <= 1000 && t.tdfa.ntags == t.ncap &&
+         (t.tdfa.start_begin == t.tdfa.start_any || TdfaAnyNever(t.tdfa));
 }
 // The per-string (batch) entry points are for SHORT strings.  Every kernel behind them but the forward walk of the search automaton
 // restarts an attempt at offset after offset of a string, as the emitted loop does (find.go:545-569): quadratic in the length of one
@@ -398,6 +406,48 @@ int64_t TdfaFindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t
   if (len > 0x7FFFFF00ull) { SetError("buffer larger than 2^31-256 bytes: keep the Go path"); return RGX_E_TOO_LARGE; }
   if (!count_only && !d_rows && cap_records) return RGX_E_INVALID;
   const int32_t ilen = (int32_t)len;
+  if (D.any_never && D.start_begin != D.start_any) {
+    // a pattern that begins with ^: the wrapper's loop is a chain of anchored attempts (one lane: count, then the rows)
+    int rc;
+    if ((rc = Ensure(&c->d_tdfa, &c->tdfa_cap, 64)) != RGX_OK) return rc;
+    uint32_t* flags = (uint32_t*)c->d_tdfa;
+    long long* d_total = (long long*)(c->d_tdfa + 2);
+    if (c->timing) HIP_TRY(hipEventRecord(c->ev0, c->stream));
+    HIP_TRY(hipMemsetAsync(c->d_tdfa, 0, 64, c->stream));
+    const int64_t max_n = n > 0 ? n : INT64_MAX;
+    HIP_TRY(LaunchTdfaQ11Anchored(D, d_buf, ilen, nullptr, 0, max_n, d_total, flags, c->stream));
+    uint32_t hf = 0;
+    long long hrows = 0;
+    HIP_TRY(hipMemcpyAsync(&hf, flags, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(&hrows, d_total, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if (hf & kTdfaOverBudget) {
+      SetError("the Tagged DFA's attempts on this text are too long to finish: keep the CPU path for it");
+      return RGX_E_UNSUPPORTED;
+    }
+    if (res) res->total = hrows;
+    if (!count_only && hrows > 0) {
+      if (hrows > (int64_t)cap_records) {
+        if (res) res->written = 0;
+        SetError("span capacity too small");
+        return RGX_E_CAPACITY;
+      }
+      if ((rc = Ensure(&c->d_q11se, &c->q11se_cap, 2 * hrows + 16)) != RGX_OK) return rc;
+      HIP_TRY(LaunchTdfaQ11Anchored(D, d_buf, ilen, c->d_q11se, hrows, hrows, d_total, flags, c->stream));
+      HIP_TRY(LaunchTdfaTags(D, d_buf, ilen, c->d_q11se, hrows, d_rows, c->stream));
+      if (res) res->written = hrows;
+    }
+    if (c->timing) {
+      HIP_TRY(hipEventRecord(c->ev1, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      float ms = 0;
+      (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
+      if (res) res->kernel_ms = ms;
+    } else {
+      HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    return hrows;
+  }
   const int64_t ns = TdfaSlices(ilen), nt = TdfaQ11Tiles(ilen);
   const size_t scan_tmp = TdfaQ11ScanTempBytes(ns);
   auto r4 = [](int64_t x) { return (x + 3) & ~int64_t(3); };

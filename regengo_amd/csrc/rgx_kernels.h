@@ -199,6 +199,9 @@ constexpr unsigned kTdfaOverBudget = 0x80000000u;       // == kOverBudgetBit (rg
 hipError_t LaunchTdfaEnds(const TdfaDev& D, const uint8_t* buf, int32_t len, int32_t* ends, uint32_t* flags, hipStream_t stream);
 // FindReader's chain over one buffer, serially (any program; max_n = 1: FindBytes): se[2i] = start (bit 31: attempt from
 // startStateBegin), se[2i + 1] = end; *out_n = matches
+// the FindAllBytes wrapper of a program with TdfaDev::any_never (a pattern that begins with ^): a chain of anchored attempts, one lane
+hipError_t LaunchTdfaQ11Anchored(const TdfaDev& D, const uint8_t* buf, int32_t len, int32_t* se, int64_t cap, int64_t max_n, long long* out_n,
+                                 uint32_t* flags, hipStream_t stream);
 hipError_t LaunchTdfaChainSerial(const TdfaDev& D, const uint8_t* buf, int32_t len, const int32_t* ends, int32_t* se, int64_t max_n,
                                  long long* out_n, uint32_t* flags, hipStream_t stream);
 // ... and in parallel (programs with start_begin == start_any that cannot match empty): sync bits (TdfaSlices(len) words, desc =

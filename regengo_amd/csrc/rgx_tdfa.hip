@@ -188,6 +188,30 @@ __global__ __launch_bounds__(64) void tdfa_chain_serial_kernel(TdfaDev D, const 
   if (lane == 0) *out_n = n;
 }
 
+// The FindAllBytes wrapper (compiler.go:602-655) of a program whose startStateAny can neither accept nor move (a pattern that begins
+// with ^: TdfaDev::any_never).  FindBytes(input[offset:]) tries start 0 of the slice from startStateBegin and every later start from
+// startStateAny -- which cannot match -- so the wrapper's loop is a chain of ANCHORED attempts: one at offset 0, the next where the match
+// ended (`offset += len(result.Match)`, and the match began at the slice's offset 0, so that IS its end), until an attempt fails
+// (`if !ok { break }`).  One lane; a text has one such match as a rule.  se = nullptr: count only; rows beyond `cap` are counted, not written.
+template <bool LDS>
+__global__ __launch_bounds__(64) void tdfa_q11_anchored_kernel(TdfaDev D, const uint8_t* buf, int32_t len, int32_t* se, long long cap,
+                                                               long long max_n, long long* out_n, uint32_t* flags) {
+  extern __shared__ uint32_t smem[];
+  typename Tab<LDS>::P ent = StageEnt<LDS>(D, smem);
+  if (threadIdx.x != 0) return;
+  long long n = 0;
+  int cur = 0, steps = 0;
+  while (cur < len && n < max_n) {
+    const int e = AttemptEnd(ent, buf, len, cur, D.start_begin, D.sinfo_begin, &steps);
+    if (steps > kLaneStepBudget) { atomicOr(flags, kOverBudgetBit); break; }
+    if (e < 0) break;
+    if (se && n < cap) { se[2 * n] = cur | (int)0x80000000u; se[2 * n + 1] = e; }
+    ++n;
+    cur = e > cur ? e : cur + 1;                // (`if matchLen > 0 { offset += matchLen } else { offset++ }`)
+  }
+  *out_n = n;
+}
+
 // ---------------------------------------------------------------- the chain in parallel (start_begin == start_any)
 // run[x] = max(end[p] : p < x); x is a sync point iff run[x] <= x (no attempt that starts before x reaches past it -- whatever
 // the loop did before, it stands at some searchPos <= x whose next match starts at or behind x, and the search from x finds the
@@ -815,6 +839,20 @@ hipError_t LaunchTdfaChainSerial(const TdfaDev& D, const uint8_t* buf, int32_t l
     hipLaunchKernelGGL(tdfa_chain_serial_kernel<true>, dim3(1), dim3(64), sh, stream, D, buf, len, ends, se, (long long)max_n, out_n, flags);
   } else {
     hipLaunchKernelGGL(tdfa_chain_serial_kernel<false>, dim3(1), dim3(64), 0, stream, D, buf, len, ends, se, (long long)max_n, out_n, flags);
+  }
+  return hipGetLastError();
+}
+
+hipError_t LaunchTdfaQ11Anchored(const TdfaDev& D, const uint8_t* buf, int32_t len, int32_t* se, int64_t cap, int64_t max_n, long long* out_n,
+                                 uint32_t* flags, hipStream_t stream) {
+  const bool lds = TdfaInLds(D, false);
+  const size_t sh = TdfaShared(D, lds, false);
+  hipError_t rc;
+  if (lds) {
+    if ((rc = AllowLds(tdfa_q11_anchored_kernel<true>, sh)) != hipSuccess) return rc;
+    hipLaunchKernelGGL(tdfa_q11_anchored_kernel<true>, dim3(1), dim3(64), sh, stream, D, buf, len, se, (long long)cap, (long long)max_n, out_n, flags);
+  } else {
+    hipLaunchKernelGGL(tdfa_q11_anchored_kernel<false>, dim3(1), dim3(64), 0, stream, D, buf, len, se, (long long)cap, (long long)max_n, out_n, flags);
   }
   return hipGetLastError();
 }

@@ -244,9 +244,9 @@ def test_tdfa_class_patterns_under_stdlib_flag_are_leftmost_first(built, kats, c
 
 
 def test_tdfa_class_findall_is_the_reference_or_refused(built, kats, corpus):
-    """For every corpus / curated pattern the reference emits with its Tagged DFA (or memoising on an empty
-    match), every FindAll / count entry point is REFUSED in reference mode -- the TDFA's FindAllBytes advances by the
-    match length (compiler.go:646-651; oracle.tdfa.find_all reproduces the duplicates) -- and answers as Go's regexp
+    """For every corpus / curated pattern the reference emits with its Tagged DFA, FindAll / count over a whole text on one device
+    is the emitted wrapper's answer -- the TDFA's FindAllBytes advances by the match length (compiler.go:646-651;
+    oracle.tdfa.find_all reproduces the duplicates) -- the forms that cut the text are REFUSED, and the program answers as Go's regexp
     (oracle: leftmost-first) under RGX_FLAG_STDLIB_SEMANTICS.  For every other pattern the device's answer equals the oracle's
     restatement of what the reference emits (oracle.engines.Compiled.FindAllBytes dispatches on the engine)."""
     import torch
@@ -256,7 +256,7 @@ def test_tdfa_class_findall_is_the_reference_or_refused(built, kats, corpus):
     from regengo_amd import Compiled, _capi, synth
     items = [(e["pattern"], e["inputs"]) for e in corpus] + [(c["pattern"], c["inputs"]) for c in kats["curated_cases"]]
     tile = synth.web_log_tile(1 << 17)[:6000]
-    refused = answered = dup_seen = wrapped = wrapper_rows = 0
+    refused = answered = dup_seen = wrapped = wrapper_rows = anchored_rows = anchored_chains = 0
     for pat, inputs in items:
         o = E.Compiled(pat)
         if o.prog.numcap <= 2:
@@ -265,18 +265,24 @@ def test_tdfa_class_findall_is_the_reference_or_refused(built, kats, corpus):
         c = Compiled(pat).to(0)
         if o.tdfa is not None:
             # The emitted WRAPPER (compiler.go:602-655, quirk Q11: `offset += len(result.Match)`, matches reported again) is reproduced
-            # for whole texts on one device when the two start states are one (rgx_info.ref_findall_offered == 2); a pattern with `^`
-            # stays refused, and so do the forms that cut the text (owned ranges)
-            whole = o.tdfa.start_begin == o.tdfa.start_any
-            assert c.info.ref_findall_offered == (2 if whole else 0) and c.info.ref_replace_offered and c.info.ref_stream_offered, pat
+            # for whole texts on one device (rgx_info.ref_findall_offered == 2): when the two start states are one (the pointer chase over
+            # the per-offset attempt ends), and when startStateAny can neither accept nor move (a pattern that begins with `^`: the
+            # wrapper's loop is a chain of anchored attempts); the forms that cut the text (owned ranges) stay refused
+            t = o.tdfa
+            whole = t.start_begin == t.start_any
+            anch = not whole and not t.trans[t.start_any] and not t.accept.get(t.start_any) and not t.accept_eot.get(t.start_any)
+            offered = whole or anch
+            assert c.info.ref_findall_offered == (2 if offered else 0) and c.info.ref_replace_offered and c.info.ref_stream_offered, pat
+            if anch:
+                texts += [x + x for x in texts[:len(inputs)]] + [texts[0] + texts[0] + b"?" + texts[0]]
             calls = [lambda: c.FindAllSpans(texts[-1], own=(0, len(texts[-1])))]
-            if not whole:
+            if not offered:
                 calls += [lambda: c.FindAllSpans(texts[-1]), lambda: c.CountAll(texts[-1])]
             for call in calls:
                 with pytest.raises(_capi.RgxError) as ei:
                     call()
                 assert ei.value.status == _capi.RGX_E_UNSUPPORTED, pat
-            refused += 0 if whole else 1
+            refused += 0 if offered else 1
             cs = Compiled(pat, stdlib=True).to(0)
             for b in texts:
                 got = cs.FindAllSpans(b)[0].cpu().tolist()
@@ -284,19 +290,24 @@ def test_tdfa_class_findall_is_the_reference_or_refused(built, kats, corpus):
                 ref = o.FindAllBytes(b) if all(x < 128 for x in b) else None
                 if ref is not None and len(ref) != len(got):
                     dup_seen += 1            # the reference really answers something else here
-                if whole and ref is not None:
+                if offered and ref is not None:
                     rows = c.FindAllSpans(b)[0].cpu().tolist()
                     assert rows == ref, (pat, b[:80], rows[:4], ref[:4])
                     assert c.CountAll(b)[0] == len(ref), (pat, b[:80])
                     if len(ref) > 2:
                         assert c.FindAllSpans(b, n=2)[0].cpu().tolist() == o.FindAllBytes(b, 2), (pat, b[:80])
+                    if len(ref) >= 2:
+                        assert c.FindAllSpans(b, n=1)[0].cpu().tolist() == o.FindAllBytes(b, 1), (pat, b[:80])
                     wrapper_rows += len(ref)
-            wrapped += 1 if whole else 0
+                    anchored_rows += len(ref) if anch else 0
+                    anchored_chains += 1 if anch and len(ref) >= 2 else 0
+            wrapped += 1 if offered else 0
         elif c.info.ref_findall_offered == 1:
             for b in texts[:-1]:
                 assert c.FindAllSpans(b)[0].cpu().tolist() == o.FindAllBytes(b), (pat, b[:80])
             answered += 1
-    assert refused + wrapped >= 15 and wrapped >= 8 and answered >= 60 and dup_seen >= 5 and wrapper_rows > 200, (refused, wrapped, answered, dup_seen, wrapper_rows)
+    assert refused + wrapped >= 15 and wrapped >= 15 and answered >= 60 and dup_seen >= 5 and wrapper_rows > 200 and anchored_rows >= 20, (
+        refused, wrapped, answered, dup_seen, wrapper_rows, anchored_rows, anchored_chains)
 
 
 def test_tdfa_findall_wrapper_over_many_tiles(built):

@@ -40,8 +40,10 @@ def test_product_engine_selection_equals_the_oracle(built, corpus, kats):
         seen[info.ref_find_engine] += 1
         # the offer rules (include/rgx.h: rgx_info)
         # FindAll: the plain backtracking loop and the memoising one away from empty matches (1); the Tagged DFA's WRAPPER (quirk Q11) for
-        # whole texts when its two start states are one (2, round 5); refused otherwise (0)
-        whole = exp[0] == 1 and o.tdfa.start_begin == o.tdfa.start_any
+        # whole texts when its two start states are one or startStateAny can neither accept nor move -- a pattern that begins with ^
+        # (2, round 5); refused otherwise (0)
+        whole = exp[0] == 1 and (o.tdfa.start_begin == o.tdfa.start_any or
+                                 not (o.tdfa.trans[o.tdfa.start_any] or o.tdfa.accept.get(o.tdfa.start_any) or o.tdfa.accept_eot.get(o.tdfa.start_any)))
         assert info.ref_findall_offered == (1 if (exp[0] <= 0 or (exp[0] == 2 and not info.can_match_empty)) else 2 if whole else 0), p
         assert info.ref_stream_offered == int(info.ref_find_offered and not info.can_match_empty), p
         if exp[0] == 2:          # memoising backtracker: interpreted (csrc/rgx_memo.h) -- FindBytes offered, the loops built on it unless the pattern matches empty
