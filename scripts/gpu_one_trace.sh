@@ -1,7 +1,7 @@
 export TMPDIR=/tmp
 cd /root/repo
 mkdir -p gpurun_out/s5
-for idx in 114 221 234; do
+for idx in ${@:-114 221 234}; do
 p=$(python - $idx <<'PY'
 import json, sys
 print(json.load(open("tests/golden/c5_counts.json"))["patterns"][int(sys.argv[1])]["pattern"])
