@@ -589,9 +589,18 @@ __device__ __forceinline__ UsTileOut UsCountTile(const ScanParams& P, int tile, 
   return o;
 }
 
-// Phase 3: span records in match order, `base` = matches before this tile
+// Phase 3: span records in match order, `base` = matches before this tile.
+// `scratch` (LDS the caller can spare: kUsEmitPass (start, end) pairs per wave): a wave with MANY matches -- `\b\w+\b` over a log ends
+// one every four bytes, 15 per lane -- writes them through it.  A lane's own loop over its bits sends, per trip, 64 records to 64 places
+// a lane's worth of records apart (16-byte pieces of 64 different lines per store instruction: the kernel with rows took 2.75 ms
+// against 0.60 count-only, most of it waiting for stores; the loop's body -- the record's fields, the 64-bit index -- also runs for the
+// wave's LONGEST lane).  Here the lanes drop (start, end) at the match's rank in the wave's stretch of `scratch`, a pass of
+// kUsEmitPass at a time, and the wave then writes the pass in rank order: lane j record j -- whole lines per store, every lane busy.
+constexpr unsigned kUsEmitPass = 256;
+constexpr unsigned kUsEmitDense = 128;      // matches per wave from which the detour pays
 __device__ __forceinline__ void UsEmitTile(const DevTables& T, const ScanParams& P, const UsTileOut& o, unsigned long long base,
-                                           const unsigned* s_L, const int32_t* s_delta, const unsigned char* s_kind) {
+                                           const unsigned* s_L, const int32_t* s_delta, const unsigned char* s_kind,
+                                           unsigned char* scratch = nullptr) {
   const int tid = threadIdx.x;
   constexpr int kTailChunks = kSReach / 64;
   const int ncap = T.ncap;
@@ -602,7 +611,34 @@ __device__ __forceinline__ void UsEmitTile(const DevTables& T, const ScanParams&
     if (T.fixed_captures) UsWriteFixed(rec, ncap, s_kind, s_delta, st, pe);
     else { rec[0] = st; rec[1] = pe; }
   };
-  {
+  const unsigned wave_total = (unsigned)__builtin_amdgcn_readlane((int)o.incl, 63);     // uniform in the wave
+  if (scratch != nullptr && wave_total >= kUsEmitDense) {
+    uint2* const buf = reinterpret_cast<uint2*>(scratch) + (unsigned)(tid >> 6) * kUsEmitPass;
+    const unsigned lane = (unsigned)tid & 63u;
+    const unsigned long long wbase = base + o.wave_off;
+    unsigned long long x = o.mbits;
+    unsigned rank = o.incl - o.cnt;
+    for (unsigned pb = 0; pb < wave_total; pb += kUsEmitPass) {
+      while (x && rank < pb + kUsEmitPass) {
+        const int b = __builtin_ctzll(x);
+        x &= x - 1;
+        const int pe = o.tb + tid * 64 + b;
+        buf[rank - pb] = make_uint2((unsigned)UsStartOf(s_L, o.tb, pe), (unsigned)pe);
+        ++rank;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const unsigned n = wave_total - pb < kUsEmitPass ? wave_total - pb : kUsEmitPass;
+      for (unsigned j = lane; j < n; j += 64u) {
+        const uint2 se = buf[j];
+        emit(wbase + pb + j, (int)se.x, (int)se.y);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  } else {
     unsigned long long idx = base + o.wave_off + (o.incl - o.cnt);
     unsigned long long x = o.mbits;
     while (x) {
@@ -945,6 +981,7 @@ constexpr int kPWindowP = kUWindow / 2;                           // packed byte
 constexpr int kPPadded = kPWindowP + (kPWindowP / 32) * 4;        // 32-byte rows (one slice) padded to 36: a lane stride of 9 dwords
 constexpr unsigned kPZoff = 257;                                  // row 1, in dwords (a row: 256 entries + one dword of padding)
 constexpr int kPRWords = kUWindow / 32;                           // reset bits over the window
+static_assert(kPPadded >= (kBlockThreads / 64) * (int)kUsEmitPass * 8, "the emission's detour through LDS takes the window's bytes");
 __device__ __forceinline__ int PPad(int relp) { return relp + ((relp >> 5) << 2); }
 
 struct UsPLayout {
@@ -1149,7 +1186,8 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_pair_kernel(DevTables T
       if (tid == 0) { s_misc[8] = (unsigned)excl; s_misc[9] = (unsigned)(excl >> 32); }
     }
     __syncthreads();
-    UsEmitTile(T, P, prev, ((unsigned long long)s_misc[9] << 32) | s_misc[8], s_L2, s_delta, s_kind);
+    // (the walk of the tile behind `prev` is over and the next tile is staged behind the loop's first barrier: the window's bytes are free)
+    UsEmitTile(T, P, prev, ((unsigned long long)s_misc[9] << 32) | s_misc[8], s_L2, s_delta, s_kind, s_tile);
   };
   issue_loads(tile);
  while (tile < P.ntiles) {
