@@ -145,6 +145,7 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
   if (tid == 0) {
     s_misc[0] = P.use_tickets ? atomicAdd(&P.counters[0], 1u) : blockIdx.x;
     s_misc[11] = __hip_atomic_load(&P.counters[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & kOverBudgetBit;
+    s_misc[12] = 0;                             // some lane of the workgroup walks a match again in phase 3 (the window's bytes stay)
   }
   // stage the tables while the ticket is in flight
   {
@@ -417,6 +418,10 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
   const unsigned cnt = (unsigned)__popcll(mask);
   const unsigned incl = (unsigned)WaveInclusiveScan(cnt, lane);
   if (lane == 63) s_misc[1 + wave] = incl;
+  {
+    const unsigned long long walks_again = __ballot(mask != 0ull && !ends_ok);
+    if (lane == 0 && walks_again) s_misc[12] = 1;
+  }
   __syncthreads();
   unsigned wave_off = 0, block_total = 0;
 #pragma unroll
@@ -446,7 +451,50 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
   const unsigned long long base = ((unsigned long long)s_misc[9] << 32) | s_misc[8];
 
   // ---- phase 3: emit span records in match order
-  if (mask) {
+  // A wave with MANY matches whose ends were all recorded (`[\p{L}\p{N}]+` over a log: a match every four bytes) sends them through LDS
+  // (rgx_scan_us.hip: UsEmitTile has the why and what it measured): (start, end) at the match's rank in the wave's stretch of the
+  // window's bytes -- every walk is over, the barrier above was passed by all -- a pass of 256 at a time, then lane j writes record j.
+  const unsigned wave_total = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);
+  if (wave_total >= 128u && s_misc[12] == 0u) {                 // (no lane of the WORKGROUP reads the window's bytes any more)
+    uint2* const buf = reinterpret_cast<uint2*>(s_tile) + (unsigned)wave * 256u;
+    static_assert(kPaddedWindow >= (kBlockThreads / 64) * 256 * 8, "the emission's detour through LDS takes the window's bytes");
+    const int ncap = T.ncap;
+    const unsigned long long wbase = base + wave_off;
+    unsigned long long pair = mask ? mask_all : 0ull;
+    unsigned rank = incl - cnt;
+    for (unsigned pb = 0; pb < wave_total; pb += 256u) {
+      while (pair && rank < pb + 256u) {
+        const int b = __builtin_ctzll(pair);
+        pair &= pair - 1;
+        int e;
+        if (ends_lo) { e = a + __builtin_ctzll(ends_lo); ends_lo &= ends_lo - 1; }
+        else { e = a + 64 + __builtin_ctzll(ends_hi); ends_hi &= ends_hi - 1; }
+        if (!((mask >> b) & 1ull)) continue;                  // a match of the slice this shard does not own
+        buf[rank - pb] = make_uint2((unsigned)(a + b), (unsigned)e);
+        ++rank;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      const unsigned n = wave_total - pb < 256u ? wave_total - pb : 256u;
+      for (unsigned j = (unsigned)lane; j < n; j += 64u) {
+        const uint2 se = buf[j];
+        const unsigned long long idx = wbase + pb + j;
+        if (idx < (unsigned long long)P.cap_records) {
+          if (P.starts_only) {
+            P.spans[idx] = (int)se.x;
+          } else {
+            int32_t* rec = P.pairs ? P.pairs + idx * 2 : P.spans + idx * ncap;
+            if (T.fixed_captures) WriteRecordFixed(rec, ncap, s_kind, s_delta, (int)se.x, (int)se.y);
+            else { rec[0] = (int)se.x; rec[1] = (int)se.y; }
+          }
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+  } else if (mask) {
     unsigned long long idx = base + wave_off + (incl - cnt);
     const int ncap = T.ncap;
     unsigned long long pair = ends_ok ? mask_all : mask;      // with recorded ends: walk ALL starts to keep the pairing
