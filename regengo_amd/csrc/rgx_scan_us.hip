@@ -319,17 +319,23 @@ __global__ __launch_bounds__(kBlockThreads) void scan_us_kernel(DevTables T, UsD
       /* event block, every lane predicated: a match ends for good (kUsFinal), or every thread died */         \
       const bool fin = (lo & kEFinal) != 0, dead = (lo & kEDead) != 0;                                          \
       const unsigned inf = US_INFO(pinfo);                                                                      \
-      const int ps = (inf & 0x80u) ? US_START(inf) : pend - (int)(inf & 0x7Fu);                                 \
+      /* (the start: a register or a distance -- both computed, one bit-select: as a ternary the compiler made a divergent branch of it) */ \
+      const int ps_reg = US_START(inf), ps_rel = pend - (int)(inf & 0x7Fu);                                     \
+      const int psel = __builtin_amdgcn_sbfe((int)inf, 7, 1);                                                   \
+      const int ps = (ps_reg & psel) | (ps_rel & ~psel);                                                        \
       const bool ev = (fin || dead) && pend >= 0;                                                               \
-      const bool rec = ev && ps >= a && ps < send;                                                              \
+      const unsigned sd = (unsigned)(ps - a);                                                                   \
+      const bool rec = ev && sd < (unsigned)(send - a);                                                         \
       const int re = pend - a - 1;                                                                              \
-      out.mask |= rec ? 1ull << ((ps - a) & 63) : 0ull;                                                         \
+      out.mask |= rec ? 1ull << (sd & 63u) : 0ull;                                                              \
       out.ends |= (rec && re < 64) ? 1ull << (re & 63) : 0ull;                                                  \
       out.last_end = (rec && re >= 64) ? pend : out.last_end;                                                   \
-      /* a dead lane parks; if its pending match leaves room before the slice's end the search has to rewind there */ \
-      const bool stop = pend < 0 || ps >= send || pend >= send || pend >= len;                                  \
-      cont = (dead && !stop && lim != 0x7FFFFFFF) ? pend : cont;                                                \
-      lim = dead ? 0x7FFFFFFF : lim;                                                                            \
+      if (__any(dead)) {                                                                                        \
+        /* a dead lane parks; if its pending match leaves room before the slice's end the search has to rewind there */ \
+        const bool stop = pend < 0 || ps >= send || pend >= send || pend >= len;                                \
+        cont = (dead && !stop && lim != 0x7FFFFFFF) ? pend : cont;                                              \
+        lim = dead ? 0x7FFFFFFF : lim;                                                                          \
+      }                                                                                                         \
       pend = (fin || dead) ? -1 : pend;                                                                         \
     }                                                                                                           \
     const int v = i1 - (int)((lo >> 16) & 0x7Fu);                                                               \
