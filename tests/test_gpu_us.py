@@ -184,3 +184,51 @@ def test_rescan_after_the_carry_pass_survives_a_look_back_timeout(torch_dev):
         spans, res = c.FindAllSpans(b)
         assert res.total == cnt == 4814
         assert np.array_equal(spans.cpu().numpy(), exp)
+
+
+def test_rows_of_dense_matches_go_through_lds(built):
+    """A wave with 128 matches or more writes its rows through LDS (rgx_scan_us.hip: UsEmitTile, rgx_kernels.hip: phase 3): (start, end)
+    at the match's rank, a pass of 256 at a time, then lane j record j.  Texts where a match ends every 2-5 bytes (several passes per
+    wave, tiles whose waves differ: dense next to sparse next to empty), the pair / generic / register kernels, fixed templates and
+    (start, end) records, n > 0, a capacity one row short, owned ranges that cut the dense stretch -- rows == the C port of the emitted
+    matcher."""
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU; there is no CPU fallback")
+    from oracle.gen_c import CMatcher
+    from regengo_amd import Compiled, _capi, synth
+    rnd = random.Random(0xD3A5E)
+    words = [b"a", b"bc", b"def", b"x1", b"42", b"7", b"hello", b"Zq"]
+    dense = b" ".join(rnd.choice(words) for _ in range(60000))                      # a match every ~3 bytes
+    sparse = (b"." * 5000 + b" tail ") * 8
+    mixed = dense[:70000] + sparse + dense[70000:150000] + b"." * 40000 + dense[150000:]
+    log = synth.web_log_tile()[:180000]
+    kinds = set()
+    checked = 0
+    for pat in (r"\b\w+\b", r"(?P<w>\w+)", r"[a-z]+", r"\d+", r"[\p{L}\p{N}]+", r"\S+", r"(?P<a>[a-z])(?P<b>\w*)", r"\w+\s*"):
+        cm = CMatcher(pat, q8=False)
+        c = Compiled(pat, stdlib=True).to(0)
+        kinds.add(c.info.scan_kernel)
+        for text in (mixed, log, dense[:4097], dense[:300]):
+            arr = np.frombuffer(text, dtype=np.uint8).copy()
+            exp, cnt = cm.find_all_np(arr)
+            buf = torch.from_numpy(arr).cuda()
+            spans, res = c.FindAllSpans(buf)
+            assert res.total == cnt and np.array_equal(spans.cpu().numpy(), exp), (pat, len(text), cnt, int(res.total))
+            assert int(c.CountAll(buf)[0]) == cnt, (pat, len(text))
+            checked += 1
+            if cnt > 1000:
+                k = cnt // 3
+                assert np.array_equal(c.FindAllSpans(buf, n=k)[0].cpu().numpy(), exp[:k]), (pat, "n")
+                with pytest.raises(_capi.RgxError) as ei:
+                    c.FindAllSpans(buf, capacity=cnt - 1)
+                assert ei.value.status == _capi.RGX_E_CAPACITY, pat
+                n = len(text)
+                for lo, hi in ((1, n - 1), (16383, 16385), (n // 3 + 7, 2 * n // 3 + 1), (70001, 70001 + 5100)):
+                    if lo >= n:
+                        continue
+                    got, r = c.FindAllSpans(buf, own=(lo, min(hi, n)))
+                    keep = (exp[:, 0] >= lo) & (exp[:, 0] < min(hi, n))
+                    assert r.total == int(keep.sum()) and np.array_equal(got.cpu().numpy(), exp[keep]), (pat, lo, hi)
+    assert checked == 32 and len(kinds) >= 2, (checked, kinds)
