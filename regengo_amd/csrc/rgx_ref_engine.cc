@@ -111,7 +111,9 @@ struct Probe {
             if (in.rune[i] < 128) for (int c = in.rune[i]; c <= std::min<int>(in.rune[i + 1], 127); c++) out[c] = true;
           break;
         case InstRuneAny: std::fill(out, out + 128, true); break;
-        case InstRuneAnyNotNL: std::fill(out, out + 128, true); out['\n'] = false; break;
+        case InstRuneAnyNotNL:                       // (adds: a '\n' another thread of the set consumes -- `.[^a]` -- stays possible)
+          for (int c = 0; c < 128; c++) if (c != '\n') out[c] = true;
+          break;
         default: break;
       }
     }

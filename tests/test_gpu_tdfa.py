@@ -130,6 +130,55 @@ def test_tdfa_batch_sorted_groups(built, kats, corpus):
     assert checked >= 6 * 1300 and found >= 1500, (checked, found)
 
 
+def test_tdfa_batch_on_random_patterns_of_the_class(built):
+    """FindBytes per string in reference mode for RANDOM patterns the reference would emit with its Tagged DFA (tests/_fuzzgen.py:
+    captures + nested quantifiers): automata the corpus does not have -- programs with and without the merged-attempts automaton,
+    with and without the packed tag table, with the accept actions applied once and at every accept (TdfaDev::tag_acc_last off) --
+    batches large enough for the sorted kernel, rows == oracle.tdfa.find."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU; there is no CPU fallback")
+    from oracle import engines as E
+    from regengo_amd import Compiled, _capi
+    from tests import _fuzzgen as F
+    from tests._hosttest import HostProgram
+    progs = checked = found = 0
+    flags = {0: 0, 1: 0, None: 0}
+    for seed in range(50, 56):
+        for pat in F.gen_patterns(seed, 60):
+            try:
+                o = E.Compiled(pat)
+            except Exception:
+                continue
+            if o.tdfa is None or len(o.tdfa.states) > 200:
+                continue
+            try:
+                c = Compiled(pat).to(0)
+            except _capi.RgxError:
+                continue
+            if c.info.ref_find_engine != 1 or not c.info.ref_find_offered:
+                continue
+            tb = o.tdfa.tables()
+            tb["start_any"] = o.tdfa.start_any
+            rnd = random.Random(zlib.crc32(pat.encode()) ^ seed)
+            strings = [b"", b"\xc3\xa9"] + [F.tdfa_guided_text(tb, rnd, rnd.randint(1, 70)) for _ in range(330)]
+            try:
+                res = c.FindBatch(strings)
+            except _capi.RgxError as ex:
+                assert ex.status == _capi.RGX_E_UNSUPPORTED, (pat, ex)      # (over budget: the engine is quadratic on some texts)
+                continue
+            for b, r in zip(strings, res):
+                exp = o.tdfa.find(b)
+                assert (r is None) == (exp is None), (pat, b)
+                if r is not None:
+                    assert r.spans == exp, (pat, b, r.spans, exp)
+                    found += 1
+                checked += 1
+            progs += 1
+            flags[HostProgram(pat).tdfa_acc_last()] += 1
+    assert progs >= 30 and checked >= 10000 and found >= 2000 and flags[1] >= 10 and flags[0] + flags[None] >= 5, (progs, checked, found, flags)
+
+
 def test_tdfa_find_reader_is_the_reference_loop(built, kats, corpus):
     """FindReader / FindReaderCount of a TDFA-class program in reference mode: rgx_find_chunk runs the engine's FindBytesReuse loop
     over the chunk on the device.  Callbacks (offset, chunk index, raw tags) AND the texts the callback reads from the reused result

@@ -166,6 +166,47 @@ def test_product_tables_equal_the_oracle_on_the_corpus(kats, corpus):
     assert seen >= 12 and built_merged >= 8
 
 
+def test_product_tables_equal_the_oracle_on_random_patterns():
+    """The same comparison over RANDOM patterns of the class (tests/_fuzzgen.py: captures + nested quantifiers): the product's
+    construction (csrc/rgx_ref_engine.cc: BuildRefTdfa) against the oracle's restatement of tdfa.go, tables and find loop.  (Round 5:
+    `.[^a]` -- a set whose `.` thread came after a class thread that consumes '\n' lost the newline from its possible bytes in the
+    product; no pattern of the corpus has such a set.)"""
+    import random
+    import zlib
+    from tests import _fuzzgen as F
+    from tests._hosttest import HostProgram
+    seen = finds = 0
+    for seed in range(50, 70):
+        for pat in F.gen_patterns(seed, 60):
+            try:
+                o = E.Compiled(pat)
+            except Exception:
+                continue
+            hp = HostProgram(pat)
+            tb = hp.tdfa_tables()
+            assert (tb is None) == (o.tdfa is None), pat
+            if tb is None:
+                continue
+            seen += 1
+            ob = o.tdfa.tables()
+            for k in ("n_states", "transitions", "tag_actions", "accept", "accept_eot", "accept_actions"):
+                assert tb[k] == ob[k], (pat, k)
+            assert tb["initial_begin"] == [list(a) for a in o.tdfa.initial_begin] and tb["initial_any"] == [list(a) for a in o.tdfa.initial_any], pat
+            if len(o.tdfa.states) > 120:
+                continue
+            ob["start_any"] = o.tdfa.start_any
+            rnd = random.Random(zlib.crc32(pat.encode()))
+            for _ in range(12):
+                b = F.tdfa_guided_text(ob, rnd, rnd.randint(1, 60))
+                want = o.tdfa.find(b)
+                assert hp.tdfa_find(b) == want, (pat, b)
+                m = hp.tdfa_merged_find(b)
+                if m is not NotImplemented:
+                    assert m == (None if want is None else (want[0], want[1])), (pat, b, m, want)
+                finds += 1
+    assert seen >= 120 and finds >= 1000, (seen, finds)
+
+
 def test_accept_actions_once_flag(kats, corpus):
     """TdfaDev::tag_acc_last (the tag walk applies the accept actions once, behind its last byte) is set exactly when no earlier
     accept's write can be the last write of its tag (every way on to a state the walk can stop in writes the tag again) --
@@ -178,9 +219,15 @@ def test_accept_actions_once_flag(kats, corpus):
     from tests import _fuzzgen as F
     pats = [c["pattern"] for c in kats["curated_cases"]] + [e["pattern"] for e in corpus]
     pats += [r"(?P<x>(?:a+)+?)(?P<y>b+?)", r"(?P<x>(?:[a-c]+,)+?)(?P<y>\d+)?", r"(?P<a>(?:x+)+)(?P<b>y)?(?P<c>z+)?"]
+    # ... and random patterns of the class (tests/_fuzzgen.py): automata the corpus does not have, programs the flag is OFF for among them
+    for seed in range(50, 58):
+        pats += F.gen_patterns(seed, 60)
     on = off = sims = 0
     for pat in dict.fromkeys(pats):
-        o = E.Compiled(pat)
+        try:
+            o = E.Compiled(pat)
+        except Exception:
+            continue
         if o.tdfa is None:
             continue
         got = HostProgram(pat).tdfa_acc_last()
@@ -241,7 +288,7 @@ def test_accept_actions_once_flag(kats, corpus):
                     tags[2 * g + 1] = -1
             assert tags == want, (pat, b, tags, want)
             sims += 1
-    assert on >= 5 and sims >= 100, (on, off, sims)
+    assert on >= 30 and off >= 3 and sims >= 600, (on, off, sims)
 
 
 def test_c_port_of_the_emitted_tdfa_equals_the_restatement(kats, corpus):
