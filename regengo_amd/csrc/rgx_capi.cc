@@ -1077,14 +1077,14 @@ RGX_API int rgx_program_info(const rgx_program* p, rgx_info* o) {
   o->default_max_leftover = DefaultMaxLeftover(t.max_len); o->min_buffer_size = MinBuffer(t.max_len);
   o->n_inst = t.n_inst; o->n_states = t.nstates; o->n_classes = t.ncls; o->anchored = t.anchored;
   o->fixed_captures = t.fixed_captures; o->can_match_empty = t.can_match_empty;
-  o->ref_match_engine = t.ref_match_engine; o->ref_find_engine = t.ref_find_engine; o->lookahead_mode = t.lookahead_mode;
+  o->ref_match_engine = t.ref_match_engine == 3 ? 1 : t.ref_match_engine; o->ref_find_engine = t.ref_find_engine; o->lookahead_mode = t.lookahead_mode;
   o->needs_valid_utf8 = 0;          // (historic field: broken UTF-8 is handled at run time since the input screen, rgx.h)
   o->utf8_screened = t.needs_valid_utf8 ? 1 : 0; o->sync_states = t.w_nstates;
   o->unicode_version = UnicodeVersion();
   {
     const bool have_rm = !t.rm_depth[0].empty() && !t.rm_depth[1].empty();
     o->ref_find_offered = ((have_rm && !t.ref_memo && t.ref_find_engine <= 0) || HasRefTdfa(t) || HasRefMemo(t)) ? 1 : 0;
-    o->ref_match_offered = (t.ref_match_engine == 1 || (have_rm && !t.ref_memo && !t.ref_has_fail) || ((t.ref_memo || t.ref_has_fail) && t.ref_memo_interp)) ? 1 : 0;
+    o->ref_match_offered = t.ref_match_engine == 3 ? 0 : ((t.ref_match_engine == 1 || (have_rm && !t.ref_memo && !t.ref_has_fail) || ((t.ref_memo || t.ref_has_fail) && t.ref_memo_interp)) ? 1 : 0);
     const bool stdlib = (t.flags & RGX_FLAG_STDLIB_SEMANTICS) != 0;
     if (stdlib) o->ref_find_offered = o->ref_match_offered = 1;       // nothing of the reference's to reproduce: every entry point answers
     o->ref_findall_offered = (stdlib || RefFindAllOffered(t)) ? 1 : (RefTdfaFindAllOffered(t) ? 2 : 0);      // 2: whole texts on one device only (the Tagged DFA's wrapper), rgx.h
@@ -1796,7 +1796,7 @@ RGX_API int rgx_match_bytes_device(const rgx_program* p, rgx_stream_ctx* c, cons
   const Tables& t = p->p.t;
   if ((rc = MatchView(p, c, d_buf, len, &d_buf)) != RGX_OK) return rc;       // broken UTF-8: match on the sanitised copy
   const bool ref_rule = !(t.flags & RGX_FLAG_STDLIB_SEMANTICS) && p->p.dev.ref_match_kind != 1;
-  if (ref_rule && p->p.dev.ref_match_kind == 2) { SetError("reference-mode MatchBytes is not offered for this pattern (memoising engine beyond the interpreter's 64 Alt instructions): keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS"); return RGX_E_UNSUPPORTED; }
+  if (ref_rule && p->p.dev.ref_match_kind == 2) { SetError("reference-mode MatchBytes is not offered for this pattern (a memoising engine beyond the interpreter's 64 Alt instructions, or the Thompson matcher on a pattern with ^ / \\b / (?m)$: its threads stop at empty-width instructions): keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS"); return RGX_E_UNSUPPORTED; }
   if (ref_rule && p->p.dev.ref_match_kind == 3) {
     // the emitted MatchBytes itself, interpreted by ONE lane (rgx_memo.h: MemoMatch): a sequential loop whose every attempt may walk
     // far -- offered for texts of at most kMemoMatchMaxLen bytes, beyond that the Go path keeps the call
@@ -2053,7 +2053,7 @@ RGX_API int64_t rgx_match_batch_device(const rgx_program* p, rgx_stream_ctx* c, 
   if (!(p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS) && p->p.dev.ref_match_kind != 1) {
     // reference mode: MatchBytes' restart rule and prefix skip (compiler.go:740-871); the Thompson flavour (kind 1) has no such
     // rule and takes the plain path below
-    if (p->p.dev.ref_match_kind == 2) { SetError("reference-mode MatchBytes is not offered for this pattern (memoising engine beyond the interpreter's 64 Alt instructions): keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS"); return RGX_E_UNSUPPORTED; }
+    if (p->p.dev.ref_match_kind == 2) { SetError("reference-mode MatchBytes is not offered for this pattern (a memoising engine beyond the interpreter's 64 Alt instructions, or the Thompson matcher on a pattern with ^ / \\b / (?m)$: its threads stop at empty-width instructions): keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS"); return RGX_E_UNSUPPORTED; }
     if (p->p.dev.ref_match_kind == 3) return MemoMatchBatch(p, c, d_concat, d_offsets, nstr, d_matched);
     if (!p->p.dev.anchored && (rc = BatchLengthGuard(c, d_offsets, nstr, kBatchRestartMaxLen, -1)) != RGX_OK) return rc;
     HIP_TRY(LaunchBatchRef(p->p.dev, d_concat, d_offsets, (int64_t)nstr, d_matched, nullptr, nullptr, c->stream));

@@ -388,6 +388,11 @@ Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOption
     bool cat = DetectNestedQuantifiers(ast.get()), nl = DetectComplexity(prog), ea = HasEndAnchor(prog);
     bool thompson = (cat || nl) && !ea;
     t.ref_match_engine = (thompson && prog.inst.size() <= 64) ? 1 : ((nl || cat) ? 2 : 0);
+    // The emitted Thompson matcher's closures follow Nop / Capture / Alt only (analysis.go:492-497): a thread that reaches an
+    // empty-width instruction -- ^, \b, (?m)$ -- stops there, so `^(a+)+b` never matches and `(a+)+\bx` loses that branch.  That is not
+    // plain existence: such programs get no reference-mode MatchBytes (3: rgx_info reports the engine as 1 and ref_match_offered 0).
+    if (t.ref_match_engine == 1)
+      for (const Inst& in : prog.inst) if (in.op == InstEmptyWidth) { t.ref_match_engine = 3; break; }
     // compiler.go:137-153: captures + nested quantifiers -> the Tagged DFA if it can be built, else the memoising backtracker
     const bool force_tdfa = (flags & (1u << 2)) != 0;          // RGX_FLAG_FORCE_TDFA = regengo.Options.ForceTDFA
     if (prog.numcap > 2 && (cat || force_tdfa)) BuildRefTdfa(prog, prog.numcap / 2, &t.tdfa);

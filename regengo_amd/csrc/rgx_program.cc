@@ -223,7 +223,7 @@ int UploadTables(const Tables& t, std::vector<uint16_t>* direct_table, DevTables
   d.ref_prefix = t.ref_prefix;
   const bool have_rm = !t.rm_depth[0].empty() && !t.rm_depth[1].empty();
   d.ref_find_ok = (have_rm && !t.ref_memo && t.ref_find_engine <= 0) ? 1 : 0;
-  d.ref_match_kind = t.ref_match_engine == 1 ? 1 : ((have_rm && !t.ref_memo && !t.ref_has_fail) ? 0 : 2);
+  d.ref_match_kind = t.ref_match_engine == 1 ? 1 : (t.ref_match_engine == 3 ? 2 : ((have_rm && !t.ref_memo && !t.ref_has_fail) ? 0 : 2));   // (3: rgx_dfa.cc)
   *out = d;
   *out_arena = dptr;
   return RGX_OK;
@@ -602,7 +602,7 @@ int ProgramToDevice(Program* p, int device) {
     const bool stdlib = (p->t.flags & RGX_FLAG_STDLIB_SEMANTICS) != 0;
     const bool for_find = p->t.ncap > 2 && p->t.ref_find_engine != 1 && (p->t.ref_memo || p->t.ref_find_engine == 2);
     // ... and for MatchBytes where the restart rule has no automaton: the reference memoises it, or an InstFail ends it outright
-    const bool for_match = p->dev.ref_match_kind == 2 && (p->t.ref_memo || p->t.ref_has_fail);
+    const bool for_match = p->dev.ref_match_kind == 2 && p->t.ref_match_engine != 3 && (p->t.ref_memo || p->t.ref_has_fail);
     if ((for_find || for_match) && p->t.ref_memo_interp && !stdlib && UploadMemo(p)) {
       p->dev.memo = &p->memodev;
       if (for_match) p->dev.ref_match_kind = 3;

@@ -272,3 +272,64 @@ def test_interpreted_match_bytes_equals_the_oracle(built, corpus, kats):
             cmp += 1
             trues += int(got)
     assert seen >= 10 and cmp >= 600 and 40 < trues < cmp - 40, (seen, cmp, trues)
+
+
+def test_reference_engines_on_random_patterns(built):
+    """The reference-mode engines against the oracle's restatement of the emitted functions on RANDOM patterns (tests/_fuzzgen.py) --
+    automata the corpus does not have: engine selection, FindBytes through the restart rule's automaton (backtracking programs) and
+    through the interpreter (memoising programs), MatchBytes through its restart rule / as plain existence (the Thompson matcher) /
+    interpreted.  A Thompson program with an empty-width instruction is NOT plain existence -- the emitted closures stop at ^, \\b,
+    (?m)$ (analysis.go:492-497: `^(a+)+b` never matches) -- and is refused (round 5: this test found the product answering it)."""
+    import random
+    from oracle import syntax as S
+    from tests import _fuzzgen as F
+    from tests._hosttest import HostProgram
+    rng = random.Random(31)
+    n = dict(pats=0, ref_find=0, memo_find=0, ref_match=0, memo_match=0, thompson_dead=0)
+    pats = [r"^(a+)+b", r"(a+)+\bx", r"(?m)(?:a+)+$x?"]
+    for seed in range(100, 112):
+        pats += F.gen_patterns(seed, 60)
+    for p in dict.fromkeys(pats):
+        try:
+            o = E.Compiled(p)
+        except Exception:
+            continue
+        if F.has_empty_loop(o.prog) and not o.find_machine.memo:
+            continue                       # the reference's own functions would not terminate on this pattern
+        try:
+            hp = HostProgram(p)
+        except ValueError:
+            continue
+        n["pats"] += 1
+        info = codegen.Program(p).info
+        exp = (-1, 0) if o.prog.numcap <= 2 else (1, len(o.tdfa.states)) if o.sel.find_engine == "tdfa" else (2 if o.sel.find_engine == "tnfa" else 0, 0)
+        assert (info.ref_find_engine, info.ref_tdfa_states) == exp, p
+        dead = o.thompson is not None and any(i.op == S.InstEmptyWidth for i in o.prog.inst)
+        if dead:
+            n["thompson_dead"] += 1
+            assert info.ref_match_engine == 1 and not info.ref_match_offered and hp.ref_match(b"a") is NotImplemented, p
+        for _ in range(6):
+            b = F.gen_input(rng, rng.choice([0, 1, 5, 40, 120]))
+            if o.tdfa is None:             # (the Tagged DFA: tests/test_tdfa.py)
+                want = o.FindBytes(b)
+                got = hp.ref_find(b)
+                if got is not NotImplemented:
+                    assert got == want, (p, b, got, want)
+                    n["ref_find"] += 1
+                got = hp.memo_find(b)
+                if got is not NotImplemented:
+                    assert got == want, (p, b, got, want)
+                    n["memo_find"] += 1
+            if dead:
+                continue
+            want = o.MatchBytes(b)
+            got = hp.ref_match(b)
+            if got is not NotImplemented:
+                assert got == want, (p, b, got, want)
+                n["ref_match"] += 1
+            else:
+                got = hp.memo_match(b)
+                if got is not None:
+                    assert got == want, (p, b, got, want)
+                    n["memo_match"] += 1
+    assert n["pats"] >= 500 and n["ref_find"] >= 2500 and n["memo_find"] >= 50 and n["ref_match"] >= 3000 and n["thompson_dead"] >= 3, n
