@@ -124,3 +124,23 @@ def test_interpreted_match_bytes_on_the_device(torch_dev):
             c.MatchBytes(b"a" * 70000)
         assert ei.value.status == _capi.RGX_E_UNSUPPORTED
     assert n > 1500
+
+
+def test_thompson_matcher_with_empty_width_instructions_is_refused(torch_dev):
+    """The emitted Thompson matcher's threads stop at empty-width instructions (analysis.go:492-497): `^(a+)+b` never matches in the
+    reference.  The library does not answer plain existence for such a program in reference mode -- it refuses (the stub keeps the Go
+    function); under RGX_FLAG_STDLIB_SEMANTICS it answers as Go's regexp."""
+    from regengo_amd import Compiled, _capi
+    for pat, text, go in ((r"^(a+)+b", b"aab", True), (r"(a+)+\bx", b"aa x", False), (r"(a+)+\b x", b"aa x", True)):
+        c = Compiled(pat).to(0)
+        assert c.info.ref_match_engine == 1 and not c.info.ref_match_offered, pat
+        with pytest.raises(_capi.RgxError) as ei:
+            c.MatchBytes(text)
+        assert ei.value.status == _capi.RGX_E_UNSUPPORTED, pat
+        strs = [text, b"", b"zz"]
+        concat = torch_dev.frombuffer(bytearray(b"".join(strs)), dtype=torch_dev.uint8).cuda()
+        offs = torch_dev.tensor([0, len(strs[0]), len(strs[0]), len(strs[0]) + 2], dtype=torch_dev.int64).cuda()
+        with pytest.raises(_capi.RgxError) as ei:
+            c.MatchBatchDevice(concat, offs)
+        assert ei.value.status == _capi.RGX_E_UNSUPPORTED, pat
+        assert Compiled(pat, stdlib=True).to(0).MatchBytes(text) is go, pat
