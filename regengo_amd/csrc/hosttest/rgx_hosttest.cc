@@ -568,7 +568,8 @@ int rgxt_ref_find(void* hh, const uint8_t* buf, int64_t len, int32_t* out) {
 int rgxt_ref_match(void* hh, const uint8_t* buf, int64_t len) {
   const Tables& t = ((Handle*)hh)->t;
   if (t.ref_match_engine == 3) return -3;                // (the Thompson matcher on a pattern with empty-width instructions: not reproduced)
-  if (t.ref_match_engine == 1) {                         // the Thompson matcher has no restart quirk: plain existence
+  if (t.ref_match_engine == 4) for (int64_t i = 0; i < len; i++) if (buf[i] >= 0x80) return -3;      // (answered for ASCII texts only)
+  if (t.ref_match_engine == 1 || t.ref_match_engine == 4) {      // the Thompson matcher has no restart quirk: plain existence
     for (int64_t pos = 0; pos <= len; pos++) {
       if (t.anchored && pos > 0) break;
       if (Walk(t, buf, len, pos, nullptr, nullptr) >= 0) return 1;

@@ -151,6 +151,21 @@ int MatchView(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, siz
   *out = c->d_san;
   return RGX_OK;
 }
+// The Thompson matcher of a program whose instructions could consume a byte >= 0x80 (Tables::ref_match_engine == 4, rgx_dfa.cc) steps
+// over bytes where Go's regexp steps over runes: on ASCII text the two agree, on other text the emitted function's answer is not
+// reproduced -- the call is refused and the stub keeps the Go function for that text.
+int ThompsonAsciiGuard(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_bytes, size_t nbytes) {
+  if ((p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS) || p->p.t.ref_match_engine != 4 || nbytes == 0) return RGX_OK;
+  unsigned* flag = reinterpret_cast<unsigned*>(c->d_cursor + 1);
+  unsigned h = 0;
+  HIP_TRY(hipMemsetAsync(flag, 0, 4, c->stream));
+  HIP_TRY(LaunchAsciiCheck(d_bytes, (int64_t)nbytes, flag, c->stream));
+  HIP_TRY(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (!h) return RGX_OK;
+  SetError("reference-mode MatchBytes: the reference emits its Thompson matcher for this pattern, which steps over bytes (a class ends at 127, `.` takes one byte): on a text with bytes >= 0x80 its answer is not reproduced -- keep the Go path for this text, or compile with RGX_FLAG_STDLIB_SEMANTICS");
+  return RGX_E_UNSUPPORTED;
+}
 // Batch flavour (sequences stay inside their string): the copy is made in the same pass.
 int MatchViewBatch(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_concat, const uint64_t* d_offsets, size_t nstr,
                    const uint8_t** out) {
@@ -1077,14 +1092,14 @@ RGX_API int rgx_program_info(const rgx_program* p, rgx_info* o) {
   o->default_max_leftover = DefaultMaxLeftover(t.max_len); o->min_buffer_size = MinBuffer(t.max_len);
   o->n_inst = t.n_inst; o->n_states = t.nstates; o->n_classes = t.ncls; o->anchored = t.anchored;
   o->fixed_captures = t.fixed_captures; o->can_match_empty = t.can_match_empty;
-  o->ref_match_engine = t.ref_match_engine == 3 ? 1 : t.ref_match_engine; o->ref_find_engine = t.ref_find_engine; o->lookahead_mode = t.lookahead_mode;
+  o->ref_match_engine = (t.ref_match_engine == 3 || t.ref_match_engine == 4) ? 1 : t.ref_match_engine; o->ref_find_engine = t.ref_find_engine; o->lookahead_mode = t.lookahead_mode;
   o->needs_valid_utf8 = 0;          // (historic field: broken UTF-8 is handled at run time since the input screen, rgx.h)
   o->utf8_screened = t.needs_valid_utf8 ? 1 : 0; o->sync_states = t.w_nstates;
   o->unicode_version = UnicodeVersion();
   {
     const bool have_rm = !t.rm_depth[0].empty() && !t.rm_depth[1].empty();
     o->ref_find_offered = ((have_rm && !t.ref_memo && t.ref_find_engine <= 0) || HasRefTdfa(t) || HasRefMemo(t)) ? 1 : 0;
-    o->ref_match_offered = t.ref_match_engine == 3 ? 0 : ((t.ref_match_engine == 1 || (have_rm && !t.ref_memo && !t.ref_has_fail) || ((t.ref_memo || t.ref_has_fail) && t.ref_memo_interp)) ? 1 : 0);
+    o->ref_match_offered = t.ref_match_engine == 3 ? 0 : ((t.ref_match_engine == 1 || t.ref_match_engine == 4 || (have_rm && !t.ref_memo && !t.ref_has_fail) || ((t.ref_memo || t.ref_has_fail) && t.ref_memo_interp)) ? 1 : 0);
     const bool stdlib = (t.flags & RGX_FLAG_STDLIB_SEMANTICS) != 0;
     if (stdlib) o->ref_find_offered = o->ref_match_offered = 1;       // nothing of the reference's to reproduce: every entry point answers
     o->ref_findall_offered = (stdlib || RefFindAllOffered(t)) ? 1 : (RefTdfaFindAllOffered(t) ? 2 : 0);      // 2: whole texts on one device only (the Tagged DFA's wrapper), rgx.h
@@ -1794,6 +1809,7 @@ RGX_API int rgx_match_bytes_device(const rgx_program* p, rgx_stream_ctx* c, cons
   // A whole-buffer MatchBytes is "does FindAll find anything", except that the search also tries the empty
   // match at offset len (compiler.go:845-853 retries while l > offset) which FindAll never does (find.go:209-211).
   const Tables& t = p->p.t;
+  if ((rc = ThompsonAsciiGuard(p, c, d_buf, len)) != RGX_OK) return rc;
   if ((rc = MatchView(p, c, d_buf, len, &d_buf)) != RGX_OK) return rc;       // broken UTF-8: match on the sanitised copy
   const bool ref_rule = !(t.flags & RGX_FLAG_STDLIB_SEMANTICS) && p->p.dev.ref_match_kind != 1;
   if (ref_rule && p->p.dev.ref_match_kind == 2) { SetError("reference-mode MatchBytes is not offered for this pattern (a memoising engine beyond the interpreter's 64 Alt instructions, or the Thompson matcher on a pattern with ^ / \\b / (?m)$: its threads stop at empty-width instructions): keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS"); return RGX_E_UNSUPPORTED; }
@@ -2049,6 +2065,12 @@ RGX_API int64_t rgx_match_batch_device(const rgx_program* p, rgx_stream_ctx* c, 
   if (rc != RGX_OK) return rc;
   if (nstr == 0) return 0;
   if (!d_concat || !d_offsets || !d_matched) return RGX_E_INVALID;
+  if (!(p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS) && p->p.t.ref_match_engine == 4) {
+    uint64_t h_ends[1] = {0};
+    HIP_TRY(hipMemcpyAsync(h_ends, d_offsets + nstr, 8, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    if ((rc = ThompsonAsciiGuard(p, c, d_concat, (size_t)h_ends[0])) != RGX_OK) return rc;     // (the batch's bytes: offsets[0] = 0 by the CSR contract)
+  }
   if ((rc = MatchViewBatch(p, c, d_concat, d_offsets, nstr, &d_concat)) != RGX_OK) return rc;
   if (!(p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS) && p->p.dev.ref_match_kind != 1) {
     // reference mode: MatchBytes' restart rule and prefix skip (compiler.go:740-871); the Thompson flavour (kind 1) has no such

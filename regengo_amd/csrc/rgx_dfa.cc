@@ -393,6 +393,16 @@ Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOption
     // plain existence: such programs get no reference-mode MatchBytes (3: rgx_info reports the engine as 1 and ref_match_offered 0).
     if (t.ref_match_engine == 1)
       for (const Inst& in : prog.inst) if (in.op == InstEmptyWidth) { t.ref_match_engine = 3; break; }
+    // The emitted Thompson matcher steps over BYTES (thompson.go:197-303): a class range is clamped to 127, `.` takes any single byte,
+    // a literal beyond ASCII is compared as byte(r).  On ASCII text that is plain existence; on other text it is not, unless no
+    // instruction of the program can consume a byte >= 0x80 either way (every range ends below 128, no `.`): 4 = answered for ASCII
+    // texts only (the text is screened per call), 1 = answered for every text.
+    if (t.ref_match_engine == 1)
+      for (const Inst& in : prog.inst) {
+        bool high = in.op == InstRuneAny || in.op == InstRuneAnyNotNL;
+        if (in.op == InstRune1 || in.op == InstRune) for (int r : in.rune) high = high || r >= 128;
+        if (high) { t.ref_match_engine = 4; break; }
+      }
     // compiler.go:137-153: captures + nested quantifiers -> the Tagged DFA if it can be built, else the memoising backtracker
     const bool force_tdfa = (flags & (1u << 2)) != 0;          // RGX_FLAG_FORCE_TDFA = regengo.Options.ForceTDFA
     if (prog.numcap > 2 && (cat || force_tdfa)) BuildRefTdfa(prog, prog.numcap / 2, &t.tdfa);

@@ -223,7 +223,7 @@ int UploadTables(const Tables& t, std::vector<uint16_t>* direct_table, DevTables
   d.ref_prefix = t.ref_prefix;
   const bool have_rm = !t.rm_depth[0].empty() && !t.rm_depth[1].empty();
   d.ref_find_ok = (have_rm && !t.ref_memo && t.ref_find_engine <= 0) ? 1 : 0;
-  d.ref_match_kind = t.ref_match_engine == 1 ? 1 : (t.ref_match_engine == 3 ? 2 : ((have_rm && !t.ref_memo && !t.ref_has_fail) ? 0 : 2));   // (3: rgx_dfa.cc)
+  d.ref_match_kind = (t.ref_match_engine == 1 || t.ref_match_engine == 4) ? 1 : (t.ref_match_engine == 3 ? 2 : ((have_rm && !t.ref_memo && !t.ref_has_fail) ? 0 : 2));   // (3: rgx_dfa.cc)
   *out = d;
   *out_arena = dptr;
   return RGX_OK;

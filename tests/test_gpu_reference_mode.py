@@ -64,7 +64,7 @@ def test_reference_mode_equals_the_emitted_functions_on_the_corpus(torch_dev, co
     from regengo_amd import Compiled, _capi
     rng = random.Random(7)
     items = [(e["pattern"], e["inputs"]) for e in corpus] + [(c["pattern"], c["inputs"]) for c in kats["curated_cases"]]
-    nm = nf = un_m = un_f = 0
+    nm = nf = un_m = un_f = hi_m = 0
     for pat, inputs in items:
         try:
             c = Compiled(pat).to(0)
@@ -77,8 +77,17 @@ def test_reference_mode_equals_the_emitted_functions_on_the_corpus(torch_dev, co
         strings += [bytes(rng.choice(alpha) for _ in range(rng.randint(0, 90))) for _ in range(6)]
         concat, offs = _csr(torch_dev, strings)
         try:
-            mt = c.MatchBatchDevice(concat, offs).cpu().tolist()
-            for b, m in zip(strings, mt):
+            mstrings = strings
+            try:
+                mt = c.MatchBatchDevice(concat, offs).cpu().tolist()
+            except _capi.RgxError as ex:
+                # the Thompson matcher steps over bytes: a batch with a byte >= 0x80 is refused for a program that could consume one
+                if not (ex.status == _capi.RGX_E_UNSUPPORTED and o.thompson is not None and any(x >= 0x80 for x in b"".join(strings))):
+                    raise
+                mstrings = [s for s in strings if all(x < 0x80 for x in s)]
+                mt = c.MatchBatchDevice(*_csr(torch_dev, mstrings)).cpu().tolist()
+                hi_m += 1
+            for b, m in zip(mstrings, mt):
                 assert bool(m) == o.MatchBytes(b), ("MatchBytes", pat, b)
                 nm += 1
         except _capi.RgxError as ex:
@@ -144,3 +153,61 @@ def test_thompson_matcher_with_empty_width_instructions_is_refused(torch_dev):
             c.MatchBatchDevice(concat, offs)
         assert ei.value.status == _capi.RGX_E_UNSUPPORTED, pat
         assert Compiled(pat, stdlib=True).to(0).MatchBytes(text) is go, pat
+
+
+def test_reference_mode_on_random_patterns(torch_dev):
+    """The same comparison over RANDOM patterns (tests/_fuzzgen.py; every engine class: backtracking with its restart rule, memoising,
+    Tagged DFA, Thompson): MatchBytes and FindBytes per string on the device == the oracle's restatement of the emitted functions, or a
+    refusal that rgx_info announces (ref_match_offered / ref_find_offered == 0) -- never another answer."""
+    from oracle import engines as E
+    from regengo_amd import Compiled, _capi
+    from tests import _fuzzgen as F
+    rng = random.Random(77)
+    nm = nf = un_m = un_f = pats = hi_m = 0
+    for seed in range(100, 106):
+        for pat in F.gen_patterns(seed, 60):
+            try:
+                o = E.Compiled(pat)
+            except Exception:
+                continue
+            if F.has_empty_loop(o.prog) and not o.find_machine.memo:
+                continue                   # the reference's own functions would not terminate on this pattern
+            if o.tdfa is not None and len(o.tdfa.states) > 200:
+                continue
+            try:
+                c = Compiled(pat).to(0)
+            except _capi.RgxError:
+                continue
+            pats += 1
+            strings = [b"", b"a", b"\xc3\xa9"] + [F.gen_input(rng, rng.choice([1, 3, 8, 20, 50])) for _ in range(260)]
+            concat, offs = _csr(torch_dev, strings)
+            try:
+                mstrings = strings
+                try:
+                    mt = c.MatchBatchDevice(concat, offs).cpu().tolist()
+                except _capi.RgxError as ex:
+                    if not (ex.status == _capi.RGX_E_UNSUPPORTED and o.thompson is not None and c.info.ref_match_offered):
+                        raise
+                    # (the Thompson matcher steps over bytes: answered for ASCII texts only when an instruction could consume a high byte)
+                    mstrings = [s for s in strings if all(x < 0x80 for x in s)]
+                    mt = c.MatchBatchDevice(*_csr(torch_dev, mstrings)).cpu().tolist()
+                    hi_m += 1
+                assert c.info.ref_match_offered, pat
+                for b, m in zip(mstrings, mt):
+                    assert bool(m) == o.MatchBytes(b), ("MatchBytes", pat, b)
+                    nm += 1
+            except _capi.RgxError as ex:
+                assert ex.status == _capi.RGX_E_UNSUPPORTED, (pat, ex)
+                un_m += 1                  # (announced, or a string the interpreter's budget refuses)
+            try:
+                res = c.FindBatch(strings)
+                assert c.info.ref_find_offered, pat
+                for b, r in zip(strings, res):
+                    exp = o.FindBytes(b)
+                    assert (r is None) == (exp is None) and (r is None or r.spans == exp), ("FindBytes", pat, b, r and r.spans, exp)
+                    nf += 1
+            except _capi.RgxError as ex:
+                assert ex.status == _capi.RGX_E_UNSUPPORTED, (pat, ex)
+                un_f += 1
+    print("patterns", pats, "MatchBytes compared", nm, "refused", un_m, "| FindBytes compared", nf, "refused", un_f)
+    assert pats >= 250 and nm > 50000 and nf > 50000 and un_m <= pats // 5 and un_f <= pats // 5, (pats, nm, nf, un_m, un_f)

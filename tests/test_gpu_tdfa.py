@@ -142,7 +142,7 @@ def test_tdfa_batch_on_random_patterns_of_the_class(built):
     from regengo_amd import Compiled, _capi
     from tests import _fuzzgen as F
     from tests._hosttest import HostProgram
-    progs = checked = found = 0
+    progs = checked = found = wrapped = wrapper_rows = 0
     flags = {0: 0, 1: 0, None: 0}
     for seed in range(50, 56):
         for pat in F.gen_patterns(seed, 60):
@@ -176,6 +176,15 @@ def test_tdfa_batch_on_random_patterns_of_the_class(built):
                 checked += 1
             progs += 1
             flags[HostProgram(pat).tdfa_acc_last()] += 1
+            # ... and the FindAll wrapper (quirk Q11) where it is offered: the pointer chase, or the chain of anchored attempts
+            if c.info.ref_findall_offered == 2:
+                text = b" ".join(s for s in strings[:80] if all(x < 128 for x in s))
+                ref = o.tdfa.find_all(text)
+                assert c.FindAllSpans(text)[0].cpu().tolist() == ref, (pat, text[:60])
+                assert int(c.CountAll(text)[0]) == len(ref), pat
+                wrapped += 1
+                wrapper_rows += len(ref)
+    assert wrapped >= 20 and wrapper_rows >= 500, (wrapped, wrapper_rows)
     assert progs >= 30 and checked >= 10000 and found >= 2000 and flags[1] >= 10 and flags[0] + flags[None] >= 5, (progs, checked, found, flags)
 
 

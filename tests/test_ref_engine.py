@@ -285,8 +285,8 @@ def test_reference_engines_on_random_patterns(built):
     from tests import _fuzzgen as F
     from tests._hosttest import HostProgram
     rng = random.Random(31)
-    n = dict(pats=0, ref_find=0, memo_find=0, ref_match=0, memo_match=0, thompson_dead=0)
-    pats = [r"^(a+)+b", r"(a+)+\bx", r"(?m)(?:a+)+$x?"]
+    n = dict(pats=0, ref_find=0, memo_find=0, ref_match=0, memo_match=0, thompson_dead=0, thompson_high=0)
+    pats = [r"^(a+)+b", r"(a+)+\bx", r"(?m)(?:a+)+$x?", r"(?:a+.)+b", r"(?:[^x]+y)+z", "(?:\u00e9+a)+b"]
     for seed in range(100, 112):
         pats += F.gen_patterns(seed, 60)
     for p in dict.fromkeys(pats):
@@ -308,8 +308,7 @@ def test_reference_engines_on_random_patterns(built):
         if dead:
             n["thompson_dead"] += 1
             assert info.ref_match_engine == 1 and not info.ref_match_offered and hp.ref_match(b"a") is NotImplemented, p
-        for _ in range(6):
-            b = F.gen_input(rng, rng.choice([0, 1, 5, 40, 120]))
+        for b in [F.gen_input(rng, rng.choice([0, 1, 5, 40, 120])) for _ in range(6)] + [b"\xc3\xa9", b"aa\xc3\xa9b", b"ab\xff."]:
             if o.tdfa is None:             # (the Tagged DFA: tests/test_tdfa.py)
                 want = o.FindBytes(b)
                 got = hp.ref_find(b)
@@ -327,9 +326,13 @@ def test_reference_engines_on_random_patterns(built):
             if got is not NotImplemented:
                 assert got == want, (p, b, got, want)
                 n["ref_match"] += 1
+            elif o.thompson is not None:
+                # the Thompson matcher steps over bytes: a program that could consume a byte >= 0x80 is answered for ASCII texts only
+                assert any(x >= 0x80 for x in b), (p, b)
+                n["thompson_high"] += 1
             else:
                 got = hp.memo_match(b)
                 if got is not None:
                     assert got == want, (p, b, got, want)
                     n["memo_match"] += 1
-    assert n["pats"] >= 500 and n["ref_find"] >= 2500 and n["memo_find"] >= 50 and n["ref_match"] >= 3000 and n["thompson_dead"] >= 3, n
+    assert n["pats"] >= 500 and n["ref_find"] >= 2500 and n["memo_find"] >= 50 and n["ref_match"] >= 3000 and n["thompson_dead"] >= 3 and n["thompson_high"] >= 5, n
