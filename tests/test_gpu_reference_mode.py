@@ -211,3 +211,53 @@ def test_reference_mode_on_random_patterns(torch_dev):
                 un_f += 1
     print("patterns", pats, "MatchBytes compared", nm, "refused", un_m, "| FindBytes compared", nf, "refused", un_f)
     assert pats >= 250 and nm > 50000 and nf > 50000 and un_m <= pats // 5 and un_f <= pats // 5, (pats, nm, nf, un_m, un_f)
+
+
+def test_find_reader_on_random_patterns(torch_dev):
+    """FindReader / FindReaderCount in reference mode over RANDOM patterns (every engine class the reference emits): one chunk at a time
+    (the buffer is larger than the data), the callbacks' (StreamOffset, Match) are exactly what the emitted loop reports -- FindBytesReuse
+    on chunk[searchPos:] again and again, offsets through bytes.Index (oracle: engines.find_reader over the engine's FindBytes) -- or the
+    call says RGX_E_DIVERGES / RGX_E_UNSUPPORTED; never another answer."""
+    import io
+    from oracle import engines as E
+    from regengo_amd import Compiled, Config, _capi
+    from tests import _fuzzgen as F
+    rng = random.Random(99)
+    agreed = refused = progs = rows = 0
+    for seed in range(100, 104):
+        for pat in F.gen_patterns(seed, 60):
+            try:
+                o = E.Compiled(pat)
+            except Exception:
+                continue
+            if F.has_empty_loop(o.prog) and not o.find_machine.memo:
+                continue
+            if o.tdfa is not None and len(o.tdfa.states) > 120:
+                continue
+            try:
+                c = Compiled(pat).to(0)
+            except _capi.RgxError:
+                continue
+            if not c.info.ref_stream_offered or c.info.can_match_empty:
+                continue
+            progs += 1
+            for trial in range(8):
+                data = b" ".join(F.gen_input(rng, rng.choice([3, 9, 30])) for _ in range(rng.choice([1, 4, 12])))
+                if o.tdfa is not None:
+                    data = bytes(x for x in data if x < 0x80)
+                ref = []
+                cfg = E.StreamConfig(BufferSize=1 << 17)
+                E.find_reader(o.FindBytes, o.sel.max_len, io.BytesIO(data).read, cfg, lambda m: ref.append((m.StreamOffset, m.match_bytes)) or True)
+                got = []
+                try:
+                    c.FindReader(io.BytesIO(data), Config(BufferSize=1 << 17), lambda m: got.append((m.StreamOffset, m.Result.Match)) or True)
+                except _capi.RgxError as ex:
+                    assert ex.status in (_capi.RGX_E_DIVERGES, _capi.RGX_E_UNSUPPORTED), (pat, data, ex)
+                    refused += 1
+                    continue
+                assert got == ref, (pat, data, got[:4], ref[:4])
+                assert c.FindReaderCount(io.BytesIO(data), Config(BufferSize=1 << 17)) == len(ref), (pat, data)
+                agreed += 1
+                rows += len(ref)
+    print("programs", progs, "agreed", agreed, "refused", refused, "rows", rows)
+    assert progs >= 120 and agreed >= 800 and rows >= 1500 and refused <= agreed // 3, (progs, agreed, refused, rows)

@@ -162,3 +162,61 @@ def test_tagged_dfa_programs_replace_with_the_reused_struct(gpu):
         if pat is urlc:
             assert c.ReplaceAllBytes(b"http://a:80/x http://b", "[$port]") == b"[80] [80]"
             assert c.ReplaceAllBytes(b"http://b http://a:80/x", "[$port]") == b"[] [80]"
+
+
+def test_replace_on_random_patterns(gpu):
+    """ReplaceAllBytes / ReplaceFirstBytes in reference mode over RANDOM patterns (tests/_fuzzgen.py: every engine class): the emitted
+    loop's answer -- FindBytesReuse on the re-sliced input, bytes.Index, the reused struct of the Tagged DFA (oracle.replace,
+    quirks=True) -- or RGX_E_DIVERGES / RGX_E_UNSUPPORTED; never another answer."""
+    from oracle import engines as E
+    from oracle import replace as R
+    from regengo_amd import Compiled, _capi
+    from tests import _fuzzgen as F
+    rng = random.Random(1234)
+    progs = checked = refused = 0
+    for seed in range(100, 104):
+        for pat in F.gen_patterns(seed, 60):
+            try:
+                o = E.Compiled(pat)
+            except Exception:
+                continue
+            if F.has_empty_loop(o.prog) and not o.find_machine.memo:
+                continue
+            if o.tdfa is not None and len(o.tdfa.states) > 120:
+                continue
+            try:
+                c = Compiled(pat).to(0)
+            except _capi.RgxError:
+                continue
+            if not c.info.ref_replace_offered or c.info.can_match_empty:
+                continue
+            progs += 1
+            ngroups = o.prog.numcap // 2 - 1
+            tmpls = ["[$0]", "<$1>" if ngroups >= 1 else "-", "$0$0"] + (["$2.$1"] if ngroups >= 2 else [])
+            for trial in range(5):
+                b = b" ".join(F.gen_input(rng, rng.choice([3, 9, 30])) for _ in range(rng.choice([1, 4, 10])))
+                if o.tdfa is not None:
+                    b = bytes(x for x in b if x < 0x80)
+                for t in tmpls:
+                    try:
+                        exp = R.replace_all(o, b, t, quirks=True)
+                    except NotImplementedError:
+                        continue
+                    try:
+                        got = c.ReplaceAllBytes(b, t)
+                    except _capi.RgxError as ex:
+                        assert ex.status in (_capi.RGX_E_DIVERGES, _capi.RGX_E_UNSUPPORTED), (pat, b, ex)
+                        refused += 1
+                        continue
+                    assert got == exp, (pat, b, t, got, exp)
+                    checked += 1
+                try:
+                    first = c.ReplaceFirstBytes(b, "<$0>")
+                    assert first == R.replace_all(o, b, "<$0>", quirks=True, first_only=True), (pat, b)
+                    checked += 1
+                except _capi.RgxError as ex:
+                    assert ex.status in (_capi.RGX_E_DIVERGES, _capi.RGX_E_UNSUPPORTED), (pat, b, ex)
+                except NotImplementedError:
+                    pass
+    print("programs", progs, "checked", checked, "refused", refused)
+    assert progs >= 120 and checked >= 1500 and refused <= checked // 3, (progs, checked, refused)
