@@ -163,7 +163,7 @@ def test_reference_mode_on_random_patterns(torch_dev):
     from regengo_amd import Compiled, _capi
     from tests import _fuzzgen as F
     rng = random.Random(77)
-    nm = nf = un_m = un_f = pats = hi_m = 0
+    nm = nf = un_m = un_f = pats = hi_m = nall = 0
     for seed in range(100, 106):
         for pat in F.gen_patterns(seed, 60):
             try:
@@ -209,6 +209,13 @@ def test_reference_mode_on_random_patterns(torch_dev):
             except _capi.RgxError as ex:
                 assert ex.status == _capi.RGX_E_UNSUPPORTED, (pat, ex)
                 un_f += 1
+            # FindAllBytes in reference mode where the emitted loop is offered as such (the Tagged DFA's wrapper: tests/test_gpu_tdfa.py)
+            if c.info.ref_findall_offered == 1 and not c.info.can_match_empty:
+                for k in (0, 40, 200):
+                    text = b" ".join(strings[3 + k:3 + k + 30])
+                    assert c.FindAllSpans(text)[0].cpu().tolist() == o.FindAllBytes(text), ("FindAllBytes", pat, text[:80])
+                    nall += 1
+    assert nall >= 400, nall
     print("patterns", pats, "MatchBytes compared", nm, "refused", un_m, "| FindBytes compared", nf, "refused", un_f)
     assert pats >= 250 and nm > 50000 and nf > 50000 and un_m <= pats // 5 and un_f <= pats // 5, (pats, nm, nf, un_m, un_f)
 
