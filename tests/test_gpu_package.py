@@ -72,3 +72,70 @@ def test_package_equals_every_programs_own_find_batch(built, corpus):
         assert np.array_equal(se[k][hit], sp[hit, :2]), c.pattern
         nfound += len(hit)
     assert nfound > 100          # the planted lines are found: the comparison is not vacuous
+
+
+def test_package_on_random_patterns(built):
+    """The package (many programs, one pass over the lines: rgx_multi_*) over RANDOM patterns, reference mode and stdlib mode: every
+    accepted program's found flags, counts and (start, end) == its own FindBatch (which tests/test_gpu_reference_mode.py holds against
+    the oracle on the same kind of patterns), and == the oracle directly on a sample."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU; there is no CPU fallback")
+    from oracle import engines as E
+    from regengo_amd import Compiled, Package, _capi
+    from tests import _fuzzgen as F
+    rng = random.Random(4)
+    lines = [b"", b"a", b"\xc3\xa9 x"] + [F.gen_input(rng, rng.choice([1, 4, 12, 30, 70])) for _ in range(1500)]
+    lines = [l.replace(b"\n", b" ") for l in lines]
+    offs = np.zeros(len(lines) + 1, dtype=np.int64)
+    offs[1:] = np.cumsum([len(l) for l in lines])
+    concat = torch.frombuffer(bytearray(b"".join(lines) + b"\0" * 16), dtype=torch.uint8).to("cuda:0")
+    offsets = torch.from_numpy(offs).to("cuda:0")
+    compared = direct = 0
+    for stdlib in (False, True):
+        progs, oracles = [], []
+        for seed in (100, 101):
+            for pat in F.gen_patterns(seed, 60):
+                try:
+                    o = E.Compiled(pat)
+                except Exception:
+                    continue
+                if F.has_empty_loop(o.prog) and not o.find_machine.memo:
+                    continue
+                try:
+                    c = Compiled(pat, stdlib=stdlib).to(0)
+                except _capi.RgxError:
+                    continue
+                progs.append(c)
+                oracles.append(o)
+        pk = Package(progs)
+        assert sum(pk.accepted) >= len(progs) // 3 and pk.launches >= 1, (sum(pk.accepted), len(progs))
+        bits, counts, se = pk.FindBatchBits(concat, offsets, want_se=True)
+        flags = _bits_to_flags(bits, len(lines))
+        se = se.cpu().numpy()
+        counts = counts.cpu().tolist()
+        for k, c in enumerate(progs):
+            if not pk.accepted[k]:
+                assert not flags[k].any() and counts[k] == 0
+                continue
+            try:
+                found, spans = c.FindBatchDevice(concat, offsets)
+            except _capi.RgxError as ex:
+                assert ex.status == _capi.RGX_E_UNSUPPORTED
+                continue
+            f = found.cpu().numpy()
+            assert np.array_equal(flags[k], f), (c.pattern, stdlib, int(np.nonzero(flags[k] != f)[0][0]))
+            assert counts[k] == int(f.sum()), c.pattern
+            sp = spans.cpu().numpy()
+            hit = np.nonzero(f)[0]
+            assert np.array_equal(se[k][hit], sp[hit, :2]), (c.pattern, stdlib)
+            compared += 1
+            o = oracles[k]
+            if not stdlib and o.tdfa is None:
+                for i in range(0, 60):
+                    exp = o.FindBytes(lines[i])
+                    assert bool(flags[k][i]) == (exp is not None), (c.pattern, lines[i])
+                    if exp is not None:
+                        assert list(se[k][i]) == exp[:2], (c.pattern, lines[i])
+                    direct += 1
+    assert compared >= 80 and direct >= 2000, (compared, direct)
