@@ -288,3 +288,66 @@ def test_tagged_dfa_readers(gpu):
             want = ofn(o, T.bytes_reader(inp), lambda text, caps: True, quirks=True, buffer_size=bs).read_all(900)[0]
             assert gfn(PieceReader(inp), None, Config(bs, 0)).read_all() == want, (kind, trial, bs)
     assert answered > 10
+
+
+def test_readers_on_random_patterns(gpu):
+    """ReplaceReader / SelectReader / RejectReader in reference mode over RANDOM patterns (every engine class), small inputs in one
+    buffer and larger ones in several: the emitted processors' output (oracle/transform.py, quirks=True) or RGX_E_DIVERGES /
+    RGX_E_UNSUPPORTED -- never other bytes."""
+    from oracle import engines as E
+    from oracle import transform as T
+    from regengo_amd import Compiled, _capi
+    from regengo_amd.stream import Config
+    from tests import _fuzzgen as F
+    rng = random.Random(777)
+    progs = answered = refused = 0
+    for seed in range(100, 103):
+        for pat in F.gen_patterns(seed, 60):
+            try:
+                o = E.Compiled(pat)
+            except Exception:
+                continue
+            if F.has_empty_loop(o.prog) and not o.find_machine.memo:
+                continue
+            if o.tdfa is not None and len(o.tdfa.states) > 120:
+                continue
+            try:
+                c = Compiled(pat).to(0)
+            except _capi.RgxError:
+                continue
+            if not c.info.ref_replace_offered or c.info.can_match_empty:
+                continue
+            progs += 1
+            dl = c.info.default_max_leftover
+            for trial in range(3):
+                nwords = rng.choice([2, 10, 60]) if dl < 4096 else rng.choice([2, 10])
+                inp = b" ".join(F.gen_input(rng, rng.choice([3, 9, 30])) for _ in range(nwords))
+                if o.tdfa is not None:
+                    inp = bytes(x for x in inp if x < 0x80)
+                bs = 0 if dl >= 4096 or trial == 0 else dl + 200
+                for kind in ("replace", "select", "reject"):
+                    try:
+                        if kind == "replace":
+                            want, werr = T.replace_reader(o, T.bytes_reader(inp), "[$0]", quirks=True, buffer_size=bs or 64 * 1024).read_all(900)
+                            assert werr is None
+                            reader = c.ReplaceReader(PieceReader(inp), "[$0]", Config(bs, 0))
+                        elif kind == "select":
+                            want = T.select_reader(o, T.bytes_reader(inp), lambda text, caps: True, quirks=True, buffer_size=bs or 64 * 1024).read_all(900)[0]
+                            reader = c.SelectReader(PieceReader(inp), None, Config(bs, 0))
+                        else:
+                            want = T.reject_reader(o, T.bytes_reader(inp), lambda text, caps: True, quirks=True, buffer_size=bs or 64 * 1024).read_all(900)[0]
+                            reader = c.RejectReader(PieceReader(inp), None, Config(bs, 0))
+                    except (RuntimeError, NotImplementedError):
+                        continue               # (the reference spins on this buffer size, or the oracle does not restate this case)
+                    try:
+                        got = reader.read_all()
+                    except _capi.RgxError as ex:
+                        assert ex.status in (_capi.RGX_E_DIVERGES, _capi.RGX_E_UNSUPPORTED), (pat, kind, inp, ex)
+                        refused += 1
+                        continue
+                    except RuntimeError:
+                        continue
+                    assert got == want, (pat, kind, bs, inp, got[:80], want[:80])
+                    answered += 1
+    print("programs", progs, "answered", answered, "refused", refused)
+    assert progs >= 90 and answered >= 500 and refused <= answered // 2, (progs, answered, refused)
