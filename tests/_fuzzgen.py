@@ -156,3 +156,13 @@ def tdfa_guided_text(tables: dict, rng: random.Random, n: int, noise: float = 0.
         if rng.random() < 0.02:
             st = -1
     return bytes(out[:n])
+
+
+def fuzz_seeds(lo, hi):
+    """The seeds of a random-pattern test: its own few by default, RGX_FUZZ_SEEDS=lo:hi for a wide sweep (scripts/gpu_ref_fuzz.sh)."""
+    import os
+    v = os.environ.get("RGX_FUZZ_SEEDS")
+    if v:
+        a, b = v.split(":")
+        return range(int(a), int(b))
+    return range(lo, hi)

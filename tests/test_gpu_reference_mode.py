@@ -164,7 +164,7 @@ def test_reference_mode_on_random_patterns(torch_dev):
     from tests import _fuzzgen as F
     rng = random.Random(77)
     nm = nf = un_m = un_f = pats = hi_m = nall = 0
-    for seed in range(100, 106):
+    for seed in F.fuzz_seeds(100, 106):
         for pat in F.gen_patterns(seed, 60):
             try:
                 o = E.Compiled(pat)
@@ -231,7 +231,7 @@ def test_find_reader_on_random_patterns(torch_dev):
     from tests import _fuzzgen as F
     rng = random.Random(99)
     agreed = refused = progs = rows = 0
-    for seed in range(100, 104):
+    for seed in F.fuzz_seeds(100, 104):
         for pat in F.gen_patterns(seed, 60):
             try:
                 o = E.Compiled(pat)

@@ -174,7 +174,7 @@ def test_replace_on_random_patterns(gpu):
     from tests import _fuzzgen as F
     rng = random.Random(1234)
     progs = checked = refused = 0
-    for seed in range(100, 104):
+    for seed in F.fuzz_seeds(100, 104):
         for pat in F.gen_patterns(seed, 60):
             try:
                 o = E.Compiled(pat)

@@ -144,7 +144,7 @@ def test_tdfa_batch_on_random_patterns_of_the_class(built):
     from tests._hosttest import HostProgram
     progs = checked = found = wrapped = wrapper_rows = 0
     flags = {0: 0, 1: 0, None: 0}
-    for seed in range(50, 56):
+    for seed in F.fuzz_seeds(50, 56):
         for pat in F.gen_patterns(seed, 60):
             try:
                 o = E.Compiled(pat)

@@ -301,7 +301,7 @@ def test_readers_on_random_patterns(gpu):
     from tests import _fuzzgen as F
     rng = random.Random(777)
     progs = answered = refused = 0
-    for seed in range(100, 103):
+    for seed in F.fuzz_seeds(100, 103):
         for pat in F.gen_patterns(seed, 60):
             try:
                 o = E.Compiled(pat)
