@@ -101,10 +101,9 @@ typedef struct rgx_info {
   int32_t fixed_captures;  /* 1: every capture slot is a constant offset from match start/end    */
   int32_t can_match_empty;
   int32_t ref_match_engine; /* what the reference would emit: 0 backtracking, 1 thompson, 2 memo.  (The emitted Thompson matcher's
-                             * threads stop at empty-width instructions -- ^, \b, (?m)$ -- analysis.go:492-497: a pattern that has
-                             * one reads 1 here and ref_match_offered 0; and it steps over BYTES -- a class ends at 127, `.`
-                             * takes one byte: a program one of whose instructions could consume a byte >= 0x80 is answered for
-                             * ASCII texts only, rgx_match_bytes* return RGX_E_UNSUPPORTED for a text / batch with such a byte) */
+                             * threads stop at empty-width instructions -- ^, \b, (?m)$ -- analysis.go:492-497, and it steps over
+                             * BYTES -- a class ends at 127, `.` takes one byte: where that is not plain existence the library
+                             * interprets the emitted function itself, csrc/rgx_thompson.h; a single text up to 16 MiB) */
   int32_t ref_find_engine;  /* the capture engine the reference emits (compiler.go:137-153): 0 backtracking, 1 Tagged DFA (captures +
                              * nested quantifiers and the construction of tdfa.go:111-290 stays under 500 states: ref_tdfa_states),
                              * 2 memoising backtracker ("TNFA", compiler.go:415-426: the TDFA could not be built), -1 none (no

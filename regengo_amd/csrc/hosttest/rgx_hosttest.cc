@@ -9,6 +9,7 @@
 
 #include "../rgx_dfa.h"
 #include "../rgx_memo.h"
+#include "../rgx_thompson.h"
 #include "../rgx_tiny.h"
 #include "../rgx_syntax.h"
 
@@ -567,8 +568,18 @@ int rgxt_ref_find(void* hh, const uint8_t* buf, int64_t len, int32_t* out) {
 }
 int rgxt_ref_match(void* hh, const uint8_t* buf, int64_t len) {
   const Tables& t = ((Handle*)hh)->t;
-  if (t.ref_match_engine == 3) return -3;                // (the Thompson matcher on a pattern with empty-width instructions: not reproduced)
-  if (t.ref_match_engine == 4) for (int64_t i = 0; i < len; i++) if (buf[i] >= 0x80) return -3;      // (answered for ASCII texts only)
+  // the Thompson matcher where it is not plain existence (rgx_thompson.h): a program with an empty-width instruction, always; a program
+  // an instruction of which could consume a byte >= 0x80, on a text that holds one -- the emitted function interpreted, as on the device
+  bool interp = t.ref_match_engine == 3;
+  if (t.ref_match_engine == 4) for (int64_t i = 0; i < len && !interp; i++) interp = buf[i] >= 0x80;
+  if (interp) {
+    ThomHost h;
+    try {
+      const Prog prog = Compile(Simplify(Parse(t.pattern, kPerl)));
+      if (!BuildThompson(prog, &h)) return -3;
+    } catch (...) { return -3; }
+    return ThomMatch(h.View(), buf, len);
+  }
   if (t.ref_match_engine == 1 || t.ref_match_engine == 4) {      // the Thompson matcher has no restart quirk: plain existence
     for (int64_t pos = 0; pos <= len; pos++) {
       if (t.anchored && pos > 0) break;

@@ -151,20 +151,33 @@ int MatchView(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, siz
   *out = c->d_san;
   return RGX_OK;
 }
-// The Thompson matcher of a program whose instructions could consume a byte >= 0x80 (Tables::ref_match_engine == 4, rgx_dfa.cc) steps
-// over bytes where Go's regexp steps over runes: on ASCII text the two agree, on other text the emitted function's answer is not
-// reproduced -- the call is refused and the stub keeps the Go function for that text.
-int ThompsonAsciiGuard(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_bytes, size_t nbytes) {
-  if ((p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS) || p->p.t.ref_match_engine != 4 || nbytes == 0) return RGX_OK;
-  unsigned* flag = reinterpret_cast<unsigned*>(c->d_cursor + 1);
-  unsigned h = 0;
-  HIP_TRY(hipMemsetAsync(flag, 0, 4, c->stream));
-  HIP_TRY(LaunchAsciiCheck(d_bytes, (int64_t)nbytes, flag, c->stream));
-  HIP_TRY(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
-  if (!h) return RGX_OK;
-  SetError("reference-mode MatchBytes: the reference emits its Thompson matcher for this pattern, which steps over bytes (a class ends at 127, `.` takes one byte): on a text with bytes >= 0x80 its answer is not reproduced -- keep the Go path for this text, or compile with RGX_FLAG_STDLIB_SEMANTICS");
-  return RGX_E_UNSUPPORTED;
+// The reference's Thompson matcher where it is not plain existence (Tables::ref_match_engine, rgx_dfa.cc): a program
+// with an empty-width instruction (3) is the emitted function interpreted, always (rgx_thompson.h, a lane per string); a program an
+// instruction of which could consume a byte >= 0x80 (4) steps over bytes where Go's regexp steps over runes -- on ASCII text the two
+// agree and the plain path answers, on other text the interpreter does.  *interp: take the interpreter.  Without the uploaded constants
+// (a rune list the emitter itself mishandles) the call is refused.
+constexpr int64_t kThomMatchMaxLen = 16ll << 20;     // one lane walks a single text: linear, ~50 cycles a byte
+int ThompsonRoute(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_bytes, size_t nbytes, bool* interp) {
+  *interp = false;
+  const int eng = p->p.t.ref_match_engine;
+  if ((p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS) || (eng != 3 && eng != 4)) return RGX_OK;
+  bool need = eng == 3;
+  if (eng == 4 && nbytes > 0) {
+    unsigned* flag = reinterpret_cast<unsigned*>(c->d_cursor + 1);
+    unsigned h = 0;
+    HIP_TRY(hipMemsetAsync(flag, 0, 4, c->stream));
+    HIP_TRY(LaunchAsciiCheck(d_bytes, (int64_t)nbytes, flag, c->stream));
+    HIP_TRY(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    need = h != 0;
+  }
+  if (!need) return RGX_OK;
+  if (!p->p.d_arena_thom) {
+    SetError("reference-mode MatchBytes: the reference emits its Thompson matcher for this pattern, which is not plain existence here (threads stop at ^ / \\b / (?m)$; bytes >= 0x80 are not decoded) and whose constants could not be built: keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS");
+    return RGX_E_UNSUPPORTED;
+  }
+  *interp = true;
+  return RGX_OK;
 }
 // Batch flavour (sequences stay inside their string): the copy is made in the same pass.
 int MatchViewBatch(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_concat, const uint64_t* d_offsets, size_t nstr,
@@ -1099,7 +1112,12 @@ RGX_API int rgx_program_info(const rgx_program* p, rgx_info* o) {
   {
     const bool have_rm = !t.rm_depth[0].empty() && !t.rm_depth[1].empty();
     o->ref_find_offered = ((have_rm && !t.ref_memo && t.ref_find_engine <= 0) || HasRefTdfa(t) || HasRefMemo(t)) ? 1 : 0;
-    o->ref_match_offered = t.ref_match_engine == 3 ? 0 : ((t.ref_match_engine == 1 || t.ref_match_engine == 4 || (have_rm && !t.ref_memo && !t.ref_has_fail) || ((t.ref_memo || t.ref_has_fail) && t.ref_memo_interp)) ? 1 : 0);
+    bool thom_ok = true;                             // (the emitted Thompson matcher interpreted: rgx_thompson.h)
+    if (t.ref_match_engine == 3) {
+      ThomHost th;
+      try { thom_ok = BuildThompson(Compile(Simplify(Parse(t.pattern, kPerl))), &th); } catch (...) { thom_ok = false; }
+    }
+    o->ref_match_offered = t.ref_match_engine == 3 ? (thom_ok ? 1 : 0) : ((t.ref_match_engine == 1 || t.ref_match_engine == 4 || (have_rm && !t.ref_memo && !t.ref_has_fail) || ((t.ref_memo || t.ref_has_fail) && t.ref_memo_interp)) ? 1 : 0);
     const bool stdlib = (t.flags & RGX_FLAG_STDLIB_SEMANTICS) != 0;
     if (stdlib) o->ref_find_offered = o->ref_match_offered = 1;       // nothing of the reference's to reproduce: every entry point answers
     o->ref_findall_offered = (stdlib || RefFindAllOffered(t)) ? 1 : (RefTdfaFindAllOffered(t) ? 2 : 0);      // 2: whole texts on one device only (the Tagged DFA's wrapper), rgx.h
@@ -1809,7 +1827,27 @@ RGX_API int rgx_match_bytes_device(const rgx_program* p, rgx_stream_ctx* c, cons
   // A whole-buffer MatchBytes is "does FindAll find anything", except that the search also tries the empty
   // match at offset len (compiler.go:845-853 retries while l > offset) which FindAll never does (find.go:209-211).
   const Tables& t = p->p.t;
-  if ((rc = ThompsonAsciiGuard(p, c, d_buf, len)) != RGX_OK) return rc;
+  {
+    bool interp = false;
+    if ((rc = ThompsonRoute(p, c, d_buf, len, &interp)) != RGX_OK) return rc;
+    if (interp) {
+      if ((int64_t)len > kThomMatchMaxLen) {
+        SetError("reference-mode MatchBytes of this pattern is the emitted Thompson matcher interpreted by one lane: offered up to 16 MiB of text, keep the Go path beyond");
+        return RGX_E_UNSUPPORTED;
+      }
+      uint64_t h_off[2] = {0, (uint64_t)len};
+      if ((rc = Ensure(&c->d_tdfa, &c->tdfa_cap, 16)) != RGX_OK) return rc;
+      uint64_t* d_off = (uint64_t*)c->d_tdfa;                    // [offsets 16 B][matched 1 B]
+      uint8_t* d_m = (uint8_t*)(c->d_tdfa + 4);
+      HIP_TRY(hipMemcpyAsync(d_off, h_off, 16, hipMemcpyHostToDevice, c->stream));
+      HIP_TRY(LaunchThompsonMatch(p->p.thomdev, d_buf, d_off, 1, d_m, c->stream));
+      uint8_t f = 0;
+      HIP_TRY(hipMemcpyAsync(&f, d_m, 1, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      *matched = f;
+      return RGX_OK;
+    }
+  }
   if ((rc = MatchView(p, c, d_buf, len, &d_buf)) != RGX_OK) return rc;       // broken UTF-8: match on the sanitised copy
   const bool ref_rule = !(t.flags & RGX_FLAG_STDLIB_SEMANTICS) && p->p.dev.ref_match_kind != 1;
   if (ref_rule && p->p.dev.ref_match_kind == 2) { SetError("reference-mode MatchBytes is not offered for this pattern (a memoising engine beyond the interpreter's 64 Alt instructions, or the Thompson matcher on a pattern with ^ / \\b / (?m)$: its threads stop at empty-width instructions): keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS"); return RGX_E_UNSUPPORTED; }
@@ -2065,11 +2103,19 @@ RGX_API int64_t rgx_match_batch_device(const rgx_program* p, rgx_stream_ctx* c, 
   if (rc != RGX_OK) return rc;
   if (nstr == 0) return 0;
   if (!d_concat || !d_offsets || !d_matched) return RGX_E_INVALID;
-  if (!(p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS) && p->p.t.ref_match_engine == 4) {
+  if (!(p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS) && (p->p.t.ref_match_engine == 3 || p->p.t.ref_match_engine == 4)) {
     uint64_t h_ends[1] = {0};
-    HIP_TRY(hipMemcpyAsync(h_ends, d_offsets + nstr, 8, hipMemcpyDeviceToHost, c->stream));
-    HIP_TRY(hipStreamSynchronize(c->stream));
-    if ((rc = ThompsonAsciiGuard(p, c, d_concat, (size_t)h_ends[0])) != RGX_OK) return rc;     // (the batch's bytes: offsets[0] = 0 by the CSR contract)
+    if (p->p.t.ref_match_engine == 4) {
+      HIP_TRY(hipMemcpyAsync(h_ends, d_offsets + nstr, 8, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+    }
+    bool interp = false;
+    if ((rc = ThompsonRoute(p, c, d_concat, (size_t)h_ends[0], &interp)) != RGX_OK) return rc;     // (the batch's bytes: [0, offsets[nstr]))
+    if (interp) {
+      HIP_TRY(LaunchThompsonMatch(p->p.thomdev, d_concat, d_offsets, (int64_t)nstr, d_matched, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      return (int64_t)nstr;
+    }
   }
   if ((rc = MatchViewBatch(p, c, d_concat, d_offsets, nstr, &d_concat)) != RGX_OK) return rc;
   if (!(p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS) && p->p.dev.ref_match_kind != 1) {

@@ -179,6 +179,8 @@ hipError_t LaunchReaderCheck(const DevTables& T, const uint8_t* raw, const uint8
 
 // The memoising engine (rgx_memo.h; DevTables::memo).  Scratch: `visited` nlanes * W zeroed words (left zeroed), `stack` nlanes * cap
 // words; nlanes a multiple of 64; flags: bit 31 = a string / gap the interpreter gave up on (window, stack, budget).
+// MatchBytes per string, the reference's Thompson matcher interpreted (rgx_thompson.h; Program::thomdev)
+hipError_t LaunchThompsonMatch(const ThomDev& M, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* matched, hipStream_t stream);
 // MatchBytes per string, the emitted loop interpreted (ref_match_kind 3); flags: nonzero = a lane gave up (stack / step budget)
 hipError_t LaunchBatchMemoMatch(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* matched,
                                 unsigned long long* visited, int W, unsigned long long* stack, int cap, int64_t nlanes, int use_memo, uint32_t* flags,

@@ -1141,6 +1141,24 @@ __global__ __launch_bounds__(64) void memo_match_kernel(DevTables T, MemoDev M, 
   }
 }
 
+// ---- MatchBytes per string, the reference's Thompson matcher interpreted (rgx_thompson.h): a lane per string, the two
+// tables of the emitted function in LDS (closure of Out and the byte set per consuming instruction: 2.5 KiB).
+__global__ __launch_bounds__(256) void thompson_match_kernel(ThomDev M, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* matched) {
+  __shared__ unsigned long long s_clo[64];
+  __shared__ uint32_t s_set[64 * 8];
+  for (int w = threadIdx.x; w < 64; w += 256) s_clo[w] = M.closure_out[w];
+  for (int w = threadIdx.x; w < 64 * 8; w += 256) s_set[w] = M.byteset[w];
+  __syncthreads();
+  ThomDev L = M;
+  L.closure_out = s_clo;
+  L.byteset = s_set;
+  const int64_t nth = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nstr; i += nth) {
+    const uint64_t o0 = offsets[i], o1 = offsets[i + 1];
+    matched[i] = (uint8_t)ThomMatch(L, concat + o0, (long long)(o1 - o0));
+  }
+}
+
 // ---- batch, reference mode, the MEMOISING engine (rgx_memo.h) ------------------------------------------------------------------------
 // The plain search has run (found flags + the record of the LEFTMOST-FIRST match of every string); this kernel replays FindBytesReuse's
 // attempt offsets as ref_fix_kernel does, with the failure offset of every attempt taken from the depth-first search itself
@@ -3007,6 +3025,14 @@ hipError_t LaunchBatchMemoMatch(const DevTables& T, const uint8_t* concat, const
   if (nstr <= 0) return hipSuccess;
   hipLaunchKernelGGL(memo_match_kernel, dim3((unsigned)(nlanes / 64)), dim3(64), 0, stream, T, *T.memo, concat, offsets, nstr, matched, visited, W,
                      stack, cap, use_memo, flags);
+  return hipGetLastError();
+}
+
+hipError_t LaunchThompsonMatch(const ThomDev& M, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* matched, hipStream_t stream) {
+  if (nstr <= 0) return hipSuccess;
+  int64_t grid = (nstr + 255) / 256;
+  if (grid > 4096) grid = 4096;
+  hipLaunchKernelGGL(thompson_match_kernel, dim3((unsigned)grid), dim3(256), 0, stream, M, concat, offsets, nstr, matched);
   return hipGetLastError();
 }
 

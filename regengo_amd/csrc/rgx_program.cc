@@ -16,12 +16,13 @@ void SetError(const std::string& s) { g_error = s; }
 const std::string& GetError() { return g_error; }
 
 Program::~Program() {
-  if (d_arena || d_arena_u || d_arena_us || d_arena_tdfa || d_arena_memo || d_tiny || d_arena_fc) {
+  if (d_arena || d_arena_u || d_arena_us || d_arena_tdfa || d_arena_memo || d_arena_thom || d_tiny || d_arena_fc) {
     hipSetDevice(device);
     if (d_tiny) hipFree(d_tiny);
     if (d_arena_fc) hipFree(d_arena_fc);
     if (d_arena_tdfa) hipFree(d_arena_tdfa);
     if (d_arena_memo) hipFree(d_arena_memo);
+    if (d_arena_thom) hipFree(d_arena_thom);
     if (d_arena) hipFree(d_arena);
     if (d_arena_u) hipFree(d_arena_u);
     if (d_arena_us) hipFree(d_arena_us);
@@ -569,6 +570,31 @@ bool UploadMemo(Program* p) {
 }
 }  // namespace
 
+namespace {
+// The emitted Thompson matcher's constants (rgx_thompson.h), uploaded: programs whose MatchBytes is that function and not plain existence
+bool UploadThompson(Program* p) {
+  ThomHost h;
+  try {
+    const Prog prog = Compile(Simplify(Parse(p->t.pattern, kPerl)));
+    if (!BuildThompson(prog, &h)) return false;
+  } catch (...) {
+    return false;
+  }
+  Arena a;
+  const size_t off_c = a.AddVec(h.closure_out), off_b = a.AddVec(h.byteset);
+  void* dptr = nullptr;
+  if (hipMalloc(&dptr, a.host.size()) != hipSuccess) { (void)hipGetLastError(); return false; }
+  if (hipMemcpy(dptr, a.host.data(), a.host.size(), hipMemcpyHostToDevice) != hipSuccess) { hipFree(dptr); return false; }
+  uint8_t* b = (uint8_t*)dptr;
+  ThomDev d = h.View();
+  d.closure_out = (const unsigned long long*)(b + off_c);
+  d.byteset = (const uint32_t*)(b + off_b);
+  p->thomdev = d;
+  p->d_arena_thom = dptr;
+  return true;
+}
+}  // namespace
+
 int ProgramToDevice(Program* p, int device) {
   std::lock_guard<std::mutex> lock(p->mu);
   if (p->d_arena) {
@@ -607,6 +633,11 @@ int ProgramToDevice(Program* p, int device) {
       p->dev.memo = &p->memodev;
       if (for_match) p->dev.ref_match_kind = 3;
     }
+  }
+  // the emitted Thompson matcher itself, where MatchBytes is not plain existence (Tables::ref_match_engine 3 / 4): with
+  // it the program's MatchBytes is offered (kind 1 + Program::d_arena_thom), without it a program of kind 3 stays refused
+  if ((p->t.ref_match_engine == 3 || p->t.ref_match_engine == 4) && !(p->t.flags & RGX_FLAG_STDLIB_SEMANTICS) && UploadThompson(p)) {
+    if (p->t.ref_match_engine == 3) p->dev.ref_match_kind = 1;
   }
   // the reference's own Tagged DFA, when it emits one and the tag file is the record (ntags == ncap: always)
   p->dev.tdfa = nullptr;

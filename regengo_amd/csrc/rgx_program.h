@@ -10,6 +10,7 @@
 
 #include "rgx_dfa.h"
 #include "rgx_memo.h"
+#include "rgx_thompson.h"
 
 namespace rgx {
 
@@ -42,6 +43,8 @@ struct TdfaDev;
 struct FcDev;
 // Device image of the syntax.Prog itself, for the reference's memoising backtracker (rgx_memo.h has the why and the interpreter)
 typedef MemoView MemoDev;
+// ... and of the emitted Thompson matcher's constants (rgx_thompson.h), where MatchBytes is that function interpreted
+typedef ThomView ThomDev;
 
 // Flat device image of one compiled pattern.  All pointers are device addresses.
 struct DevTables {
@@ -228,6 +231,8 @@ struct Program {
   void* d_arena_fc = nullptr;
   MemoDev memodev{};
   void* d_arena_memo = nullptr;
+  ThomDev thomdev{};
+  void* d_arena_thom = nullptr;
   std::vector<uint8_t> blob_cache;
   // search automaton (BuildOptions::unanchored_search) for the per-string entry points; built lazily, absent when the
   // pattern is anchored or the automaton exceeds its state budget

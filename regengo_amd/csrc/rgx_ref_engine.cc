@@ -20,6 +20,7 @@
 
 #include "rgx_dfa.h"
 #include "rgx_memo.h"
+#include "rgx_thompson.h"
 #include "rgx_tiny.h"
 
 namespace rgx {
@@ -254,6 +255,67 @@ bool BuildRefTdfa(const Prog& prog, int ncap_names, RefTdfa* out, int max_states
   t.init_begin = intern(init_begin);
   t.init_any = intern(init_any);
   if (overflow || t.pool.size() > 60000) { *out = RefTdfa(); return false; }   // (never seen: offsets grow only while states multiply)
+  return true;
+}
+
+// The emitted Thompson matcher's constants (rgx_thompson.h): closures over Nop / Capture / Alt only, the byte conditions as thompson.go:197-303
+// writes them.
+bool BuildThompson(const Prog& prog, ThomHost* out) {
+  *out = ThomHost();
+  const int n = (int)prog.inst.size();
+  if (n > 64 || n <= 0) return false;
+  auto closure = [&](int s0) -> unsigned long long {            // analysis.go:462-501
+    unsigned long long res = 0;
+    std::vector<char> seen(n + 1, 0);
+    std::vector<int> q{s0};
+    for (size_t h = 0; h < q.size(); h++) {
+      const int st = q[h];
+      if (st < 0 || st > n || seen[st]) continue;
+      seen[st] = 1;
+      if (st < 64) res |= 1ull << st;
+      if (st >= n) continue;
+      const Inst& in = prog.inst[st];
+      if (in.op == InstNop || in.op == InstCapture) q.push_back((int)in.out);
+      else if (in.op == InstAlt) { q.push_back((int)in.out); q.push_back((int)in.arg); }
+    }
+    return res;
+  };
+  out->n = n;
+  out->closure_out.assign(64, 0);
+  out->byteset.assign(64 * 8, 0);
+  for (int k = 0; k < n; k++) {
+    const Inst& in = prog.inst[k];
+    if (in.op == InstMatch) out->accept_mask |= 1ull << k;
+    if (in.op != InstRune && in.op != InstRune1 && in.op != InstRuneAny && in.op != InstRuneAnyNotNL) continue;
+    out->char_mask |= 1ull << k;
+    if ((int)in.out < n) out->closure_out[k] = closure((int)in.out);
+    for (int c = 0; c < 256; c++) {
+      bool ok = false;
+      if (in.op == InstRuneAny) ok = true;
+      else if (in.op == InstRuneAnyNotNL) ok = c != 0x0A;
+      else if (in.op == InstRune1) ok = !in.rune.empty() && c == (in.rune[0] & 0xFF);          // `byte(r)`
+      else {
+        const std::vector<int32_t>& r = in.rune;
+        if (r.empty()) ok = false;
+        else if (r.size() == 2 && r[0] == r[1]) {
+          const bool fold = (in.arg & kFoldCase) != 0;
+          if (fold && r[0] < 128) ok = (c | 0x20) == ((r[0] | 0x20) & 0xFF);
+          else ok = c == (r[0] & 0xFF);
+        } else {
+          if (r.size() & 1) return false;
+          for (size_t i = 0; i + 1 < r.size(); i += 2) {
+            const int lo = r[i], hi = r[i + 1];
+            if (lo == hi) { if (lo < 128 && c == lo) ok = true; }
+            else if (lo < 128 && c >= lo && c <= std::min(hi, 127)) ok = true;
+          }
+        }
+      }
+      if (ok) out->byteset[k * 8 + (c >> 5)] |= 1u << (c & 31);
+    }
+  }
+  out->start_closure = closure(prog.start);
+  const Inst& st = prog.inst[prog.start];
+  out->anchored = (st.op == InstEmptyWidth && (st.arg & EmptyBeginText)) ? 1 : 0;               // analysis.go:117-124
   return true;
 }
 

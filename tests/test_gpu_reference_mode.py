@@ -135,24 +135,32 @@ def test_interpreted_match_bytes_on_the_device(torch_dev):
     assert n > 1500
 
 
-def test_thompson_matcher_with_empty_width_instructions_is_refused(torch_dev):
-    """The emitted Thompson matcher's threads stop at empty-width instructions (analysis.go:492-497): `^(a+)+b` never matches in the
-    reference.  The library does not answer plain existence for such a program in reference mode -- it refuses (the stub keeps the Go
-    function); under RGX_FLAG_STDLIB_SEMANTICS it answers as Go's regexp."""
-    from regengo_amd import Compiled, _capi
-    for pat, text, go in ((r"^(a+)+b", b"aab", True), (r"(a+)+\bx", b"aa x", False), (r"(a+)+\b x", b"aa x", True)):
+def test_thompson_matcher_is_the_emitted_function(torch_dev):
+    """The emitted Thompson matcher's threads stop at empty-width instructions (analysis.go:492-497: `^(a+)+b` never matches in the
+    reference) and it steps over bytes (a class ends at 127, `.` takes one byte).  Where that is not plain existence the library
+    interprets the emitted function (csrc/rgx_thompson.h): single texts and batches == oracle.ThompsonMatcher; under
+    RGX_FLAG_STDLIB_SEMANTICS the program answers as Go's regexp."""
+    from oracle import engines as E
+    from regengo_amd import Compiled
+    cases = ((r"^(a+)+b", [b"aab", b"b", b""], [True, False, False]),
+             (r"(a+)+\bx", [b"aa x", b"aax", b"a x"], [False, False, False]),
+             (r"(a+)+\b x", [b"aa x", b"aa  x"], [True, False]),
+             (r"(?:a+.)+b", [b"aa\xc3\xa9b", b"aaxb", b"a\xffb"], [True, True, True]),
+             (r"(?:[^x]+y)+z", [b"\xc3\xa9yz", b"ayz"], [True, True]))
+    for pat, texts, go in cases:
+        o = E.Compiled(pat)
+        assert o.thompson is not None, pat
         c = Compiled(pat).to(0)
-        assert c.info.ref_match_engine == 1 and not c.info.ref_match_offered, pat
-        with pytest.raises(_capi.RgxError) as ei:
-            c.MatchBytes(text)
-        assert ei.value.status == _capi.RGX_E_UNSUPPORTED, pat
-        strs = [text, b"", b"zz"]
-        concat = torch_dev.frombuffer(bytearray(b"".join(strs)), dtype=torch_dev.uint8).cuda()
-        offs = torch_dev.tensor([0, len(strs[0]), len(strs[0]), len(strs[0]) + 2], dtype=torch_dev.int64).cuda()
-        with pytest.raises(_capi.RgxError) as ei:
-            c.MatchBatchDevice(concat, offs)
-        assert ei.value.status == _capi.RGX_E_UNSUPPORTED, pat
-        assert Compiled(pat, stdlib=True).to(0).MatchBytes(text) is go, pat
+        assert c.info.ref_match_engine == 1 and c.info.ref_match_offered, pat
+        want = [o.MatchBytes(b) for b in texts]
+        assert [c.MatchBytes(b) for b in texts] == want, (pat, want)
+        concat, offs = _csr(torch_dev, texts)
+        assert [bool(x) for x in c.MatchBatchDevice(concat, offs).cpu().tolist()] == want, pat
+        cs = Compiled(pat, stdlib=True).to(0)       # (leftmost-first existence; `.` takes one byte there too: DESIGN.md Q2)
+        assert [cs.MatchBytes(b) for b in texts] == [len(o.FindAllLeftmostFirst(b)) > 0 for b in texts], pat
+        if all(x < 0x80 for b in texts for x in b):
+            assert [cs.MatchBytes(b) for b in texts] == go, (pat, go)
+    assert E.Compiled(r"^(a+)+b").MatchBytes(b"aab") is False and E.Compiled(r"(?:[^x]+y)+z").MatchBytes(b"\xc3\xa9yz") is False
 
 
 def test_reference_mode_on_random_patterns(torch_dev):
