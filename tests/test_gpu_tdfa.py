@@ -268,6 +268,59 @@ def test_tdfa_chain_parallel_equals_serial_on_a_large_chunk(built):
     assert c.FindReaderCount(io.BytesIO(text), Config(4 << 20, 0)) == reps * k5
 
 
+def test_tdfa_find_reader_on_random_patterns_large_chunks(built):
+    """FindReader of RANDOM Tagged-DFA programs over chunks of tens of KiB (the chain of attempts in parallel: ends per start offset,
+    sync points from the running maximum, a lane per 64 offsets; programs with ^: the serial chain): the callbacks' (StreamOffset,
+    Match) == the emitted loop's (oracle: engines.find_reader over the C port of the emitted Tagged DFA, oracle/tdfa_c.py), or
+    RGX_E_DIVERGES."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU; there is no CPU fallback")
+    from oracle import engines as E
+    from oracle.tdfa_c import CTdfa
+    from regengo_amd import Compiled, _capi
+    from regengo_amd.stream import Config
+    from tests import _fuzzgen as F
+    progs = agreed = refused = rows = parallel = 0
+    for seed in F.fuzz_seeds(60, 68):
+        for pat in F.gen_patterns(seed, 60):
+            try:
+                o = E.Compiled(pat)
+            except Exception:
+                continue
+            if o.tdfa is None or len(o.tdfa.states) > 80:
+                continue
+            try:
+                c = Compiled(pat).to(0)
+            except _capi.RgxError:
+                continue
+            if c.info.ref_find_engine != 1 or not c.info.ref_stream_offered or c.info.can_match_empty:
+                continue
+            ct = CTdfa(pat)
+            tb = o.tdfa.tables()
+            tb["start_any"] = o.tdfa.start_any
+            rnd = random.Random(zlib.crc32(pat.encode()) ^ 0x77)
+            words = [bytes(x for x in F.tdfa_guided_text(tb, rnd, rnd.randint(1, 40)) if x < 0x80) for _ in range(400)]
+            text = b" ".join(rnd.choice(words) for _ in range(2500))[:60000]
+            ref = []
+            E.find_reader(ct.find, o.sel.max_len, io.BytesIO(text).read, E.StreamConfig(BufferSize=1 << 17), lambda m: ref.append((m.StreamOffset, m.match_bytes)) or True)
+            progs += 1
+            parallel += int(o.tdfa.start_begin == o.tdfa.start_any)
+            got = []
+            try:
+                c.FindReader(io.BytesIO(text), Config(BufferSize=1 << 17), lambda m: got.append((m.StreamOffset, m.Result.Match)) or True)
+            except _capi.RgxError as ex:
+                assert ex.status in (_capi.RGX_E_DIVERGES, _capi.RGX_E_UNSUPPORTED), (pat, ex)
+                refused += 1
+                continue
+            assert got == ref, (pat, len(got), len(ref), got[:3], ref[:3])
+            assert c.FindReaderCount(io.BytesIO(text), Config(BufferSize=1 << 17)) == len(ref), pat
+            agreed += 1
+            rows += len(ref)
+    print("programs", progs, "of them with one start state", parallel, "agreed", agreed, "refused", refused, "rows", rows)
+    assert progs >= 18 and agreed >= 12 and rows >= 5000 and parallel >= 5, (progs, parallel, agreed, refused, rows)
+
+
 def test_tdfa_class_patterns_under_stdlib_flag_are_leftmost_first(built, kats, corpus):
     import torch
     if not torch.cuda.is_available():
