@@ -2291,6 +2291,10 @@ RGX_API int rgx_match_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8
     SetError("reference-mode MatchBytes of a memoising program is interpreted by one lane: offered up to 64 KiB of text, keep the Go path beyond");
     return RGX_E_UNSUPPORTED;
   }
+  if (!(p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS) && p->p.t.ref_match_engine == 3 && (int64_t)len > kThomMatchMaxLen) {
+    SetError("reference-mode MatchBytes of this pattern is the emitted Thompson matcher interpreted by one lane: offered up to 16 MiB of text, keep the Go path beyond");
+    return RGX_E_UNSUPPORTED;
+  }
   if ((rc = Ensure(&c->d_in, &c->in_cap, (int64_t)len + 64)) != RGX_OK) return rc;
   if (len) HIP_TRY(hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream));
   return rgx_match_bytes_device(p, c, c->d_in, len, matched);
