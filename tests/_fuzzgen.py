@@ -166,3 +166,10 @@ def fuzz_seeds(lo, hi):
         a, b = v.split(":")
         return range(int(a), int(b))
     return range(lo, hi)
+
+
+def fuzz_default() -> bool:
+    """True when a random-pattern test runs its own seeds (its count thresholds apply); False under RGX_FUZZ_SEEDS (a sweep: one seed per
+    process, only mismatches count)."""
+    import os
+    return not os.environ.get("RGX_FUZZ_SEEDS")

@@ -223,9 +223,11 @@ def test_reference_mode_on_random_patterns(torch_dev):
                     text = b" ".join(strings[3 + k:3 + k + 30])
                     assert c.FindAllSpans(text)[0].cpu().tolist() == o.FindAllBytes(text), ("FindAllBytes", pat, text[:80])
                     nall += 1
-    assert nall >= 400, nall
+    if F.fuzz_default():
+        assert nall >= 400, nall
     print("patterns", pats, "MatchBytes compared", nm, "refused", un_m, "| FindBytes compared", nf, "refused", un_f)
-    assert pats >= 250 and nm > 50000 and nf > 50000 and un_m <= pats // 5 and un_f <= pats // 5, (pats, nm, nf, un_m, un_f)
+    if F.fuzz_default():
+        assert pats >= 250 and nm > 50000 and nf > 50000 and un_m <= pats // 5 and un_f <= pats // 5, (pats, nm, nf, un_m, un_f)
 
 
 def test_find_reader_on_random_patterns(torch_dev):
@@ -275,4 +277,5 @@ def test_find_reader_on_random_patterns(torch_dev):
                 agreed += 1
                 rows += len(ref)
     print("programs", progs, "agreed", agreed, "refused", refused, "rows", rows)
-    assert progs >= 120 and agreed >= 800 and rows >= 1500 and refused <= agreed // 3, (progs, agreed, refused, rows)
+    if F.fuzz_default():
+        assert progs >= 120 and agreed >= 800 and rows >= 1500 and refused <= agreed // 3, (progs, agreed, refused, rows)

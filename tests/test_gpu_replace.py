@@ -219,4 +219,5 @@ def test_replace_on_random_patterns(gpu):
                 except NotImplementedError:
                     pass
     print("programs", progs, "checked", checked, "refused", refused)
-    assert progs >= 120 and checked >= 1500 and refused <= checked // 3, (progs, checked, refused)
+    if F.fuzz_default():
+        assert progs >= 120 and checked >= 1500 and refused <= checked // 3, (progs, checked, refused)

@@ -184,8 +184,10 @@ def test_tdfa_batch_on_random_patterns_of_the_class(built):
                 assert int(c.CountAll(text)[0]) == len(ref), pat
                 wrapped += 1
                 wrapper_rows += len(ref)
-    assert wrapped >= 20 and wrapper_rows >= 500, (wrapped, wrapper_rows)
-    assert progs >= 30 and checked >= 10000 and found >= 2000 and flags[1] >= 10 and flags[0] + flags[None] >= 5, (progs, checked, found, flags)
+    if F.fuzz_default():
+        assert wrapped >= 20 and wrapper_rows >= 500, (wrapped, wrapper_rows)
+    if F.fuzz_default():
+        assert progs >= 30 and checked >= 10000 and found >= 2000 and flags[1] >= 10 and flags[0] + flags[None] >= 5, (progs, checked, found, flags)
 
 
 def test_tdfa_find_reader_is_the_reference_loop(built, kats, corpus):
@@ -318,7 +320,8 @@ def test_tdfa_find_reader_on_random_patterns_large_chunks(built):
             agreed += 1
             rows += len(ref)
     print("programs", progs, "of them with one start state", parallel, "agreed", agreed, "refused", refused, "rows", rows)
-    assert progs >= 18 and agreed >= 12 and rows >= 5000 and parallel >= 5, (progs, parallel, agreed, refused, rows)
+    if F.fuzz_default():
+        assert progs >= 18 and agreed >= 12 and rows >= 5000 and parallel >= 5, (progs, parallel, agreed, refused, rows)
 
 
 def test_tdfa_class_patterns_under_stdlib_flag_are_leftmost_first(built, kats, corpus):

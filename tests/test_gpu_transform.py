@@ -350,4 +350,5 @@ def test_readers_on_random_patterns(gpu):
                     assert got == want, (pat, kind, bs, inp, got[:80], want[:80])
                     answered += 1
     print("programs", progs, "answered", answered, "refused", refused)
-    assert progs >= 90 and answered >= 500 and refused <= answered // 2, (progs, answered, refused)
+    if F.fuzz_default():
+        assert progs >= 90 and answered >= 500 and refused <= answered // 2, (progs, answered, refused)
