@@ -31,9 +31,11 @@
 extern "C" {
 #endif
 
-#define RGX_ABI_VERSION 4   /* 2: rgx_info grew in round 2 (scan_kernel .. utf8_screened) without a bump; 3: ref_findall_offered,
+#define RGX_ABI_VERSION 5   /* 2: rgx_info grew in round 2 (scan_kernel .. utf8_screened) without a bump; 3: ref_findall_offered,
                              * ref_stream_offered, ref_tdfa_states; the sharded entry points; 4: ref_replace_offered, the reference's Tagged DFA
-                             * runs on the device (rows of such programs: see rgx_find_bytes).  rgx_abi_version() is what the loaded
+                             * runs on the device (rows of such programs: see rgx_find_bytes); 5: ref_findall_offered takes the value 2
+                             * (round 5, unbumped then), rgx_find_chunks(_device), rgx_shard_window grew by reader_buffer_size /
+                             * reader_max_leftover (FindReader's chunk grid).  rgx_abi_version() is what the loaded
                              * library was built with: a stub compares it with this constant before it trusts sizeof(rgx_info) */
 
 typedef enum rgx_status {
@@ -385,6 +387,42 @@ int64_t rgx_find_chunk(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* c
                        int is_full, int64_t max_leftover, int32_t* spans, size_t cap_records,
                        int64_t* committed, int64_t* keep_from, rgx_result* res);
 
+/* FindReader over a RUN of chunks in one call -- streaming.go:110-250 as it behaves with a reader that fills the buffer (bytes.Reader,
+ * a file: `isFull` on every read but the last).  The deferral `break` (204-210) stands in front of the commit, so committed <=
+ * dataLen - MaxLeftover and keepFrom (227-236) is dataLen - MaxLeftover after every full read: chunk k of such a stream is
+ *     stream[k * stride, k * stride + BufferSize),   stride = BufferSize - MaxLeftover,
+ * a fixed grid of INDEPENDENT texts (^ $ \b see a chunk's edges), each scanned by FindBytesReuse on chunk[searchPos:] from its first byte,
+ * each reporting its matches up to the first one that ENDS behind its keep point -- the next chunk's first byte; that match and whatever
+ * follows it in the chunk are left to the next chunk, whose loop begins in the match's middle: the reference drops or cuts such a match
+ * (9 of 8992 URLs per MiB of web log at the default 64 KiB Config) and so does this entry point.  A chunk that is not full -- the
+ * stream's last -- reports all its matches.
+ *   `d_block` (device memory, 16-byte aligned for the fast path) holds `len` bytes of the stream from a chunk start on; buffer_size /
+ *   max_leftover are the RESOLVED Config (rgx_stream_config_resolve: max_leftover in [1, buffer_size / 2]).  The run = every full chunk
+ *   that fits plus -- `final` != 0: the reader hit EOF (or returned a short read) behind these bytes -- the short chunk behind them.
+ *   final == 0: the bytes from res->next_from on (the last full chunk's keep point) are the head of the next run's block.
+ * Rows: ncap int32 per reported match, offsets relative to d_block, in stream order; an unset group reads as rgx_find_chunk's rows do ((0, 0)
+ * or (-1, -1): never rebased).  A row's ChunkIndex is min(start / stride, res->chunks - 1) + the run's first chunk index, its StreamOffset
+ * the block's stream offset + start (stream/stream.go:66-79).  d_spans == NULL with cap_records == 0: count only.
+ * Reference mode: the reference's loop or a refusal, as rgx_find_chunk -- RGX_E_DIVERGES: a gap of this run fails the check, hand the
+ * run's chunks to rgx_find_chunk one by one (or to the Go loop); RGX_E_UNSUPPORTED where rgx_find_chunk says so.  res->mode: 1 = one scan
+ * for the whole run (programs without an empty-width instruction on the exact / filter + candidate kernels, stride >= 32 KiB,
+ * max_leftover >= 4 KiB; Tagged-DFA programs whose two start states are one); 2 = chunk by chunk on the device (everything else: the
+ * same answers, a call's worth of synchronisations per chunk).  Returns the rows written (RGX_E_CAPACITY: res->rows has the count). */
+typedef struct rgx_chunks_result {
+  int64_t rows;          /* matches the loop reports from the run's chunks                                      */
+  int64_t chunks;        /* chunks of the run (the final short one included)                                    */
+  int64_t next_from;     /* where the next run's block begins, relative to d_block (== len behind a final run)  */
+  int32_t ncap;
+  int32_t mode;
+  float kernel_ms;       /* scan-kernel time when the context's timing is on                                    */
+  int32_t reserved;
+} rgx_chunks_result;
+int64_t rgx_find_chunks_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_block, size_t len, int64_t buffer_size,
+                               int64_t max_leftover, int final, int32_t* d_spans, size_t cap_records, rgx_chunks_result* res);
+/* The same with host buffers (what the generated FindReader calls with the blocks it reads: H2D copy of the block, D2H copy of the rows). */
+int64_t rgx_find_chunks(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* block, size_t len, int64_t buffer_size,
+                        int64_t max_leftover, int final, int32_t* spans, size_t cap_records, rgx_chunks_result* res);
+
 /* FindReaderCount's chunk (streaming.go:258-277): the commit/defer rule of rgx_find_chunk without the span table leaving the
  * device.  Returns the number of matches the emitted loop would have reported from this chunk; *keep_from as above;
  * *committed = end of the last one (-1 for a chunk that is not full: nothing is carried over from it).          */
@@ -449,6 +487,11 @@ typedef struct rgx_shard_window {
                              * from start + the template.  rgx_sharded_gather is not offered behind such a round.            */
   int32_t* d_spans;         /* device output, cap_records records of ncap int32, window-relative; NULL: the shard's own buffer */
   size_t cap_records;
+  int64_t reader_buffer_size;   /* > 0: the window is a RUN OF FindReader CHUNKS (rgx_find_chunks_device: chunk k of the window =        */
+  int64_t reader_max_leftover;  /* buf[k * stride, k * stride + reader_buffer_size)); it begins at a chunk start, ranks own chunk ranges:  */
+                                /* no halo, never `unsynced` / `truncated`.  own_lo / own_hi / starts_at_sync / starts_only are ignored,   */
+                                /* `last` = the stream ends where the window ends (rgx_find_chunks_device's `final`).  Rows as there,      */
+                                /* window-relative; rgx_shard_round.count = the reference's FindReader callbacks from these chunks.        */
 } rgx_shard_window;
 typedef struct rgx_shard_round {
   int64_t count;            /* matches this rank owns                                                                          */

@@ -83,7 +83,7 @@ def emit_c(prog: S.Prog, memo: bool, name: str = "m", q8: bool = True) -> str:
         w(_DECODE_RUNE_C)
     w("static inline int is_word(uint8_t c){return (c>='0'&&c<='9')||(c>='A'&&c<='Z')||c=='_'||(c>='a'&&c<='z');}\n")
     w("typedef struct { int64_t off; int32_t pc; } frame_t;\n")
-    if memo and not q8:
+    if memo:
         w("static int64_t* touched = 0; static int64_t ntouched = 0, captouched = 0;\n")
     # one attempt from `start`; captures in caps; returns 1 on match (offset in *end), else 0 (failure offset in *end)
     w("static int attempt(const uint8_t* input, int64_t l, int64_t start, int64_t* caps, int64_t* end,"
@@ -110,12 +110,11 @@ def emit_c(prog: S.Prog, memo: bool, name: str = "m", q8: bool = True) -> str:
         elif op == S.InstAlt:
             if memo:
                 w("  { int64_t idx = (int64_t)%d * (l + 1) + offset; uint32_t bit = 1u << (idx & 31);\n" % i)
-                if q8:
-                    w("    if (visited[idx >> 5] & bit) goto TryFallback; visited[idx >> 5] |= bit; }\n")
-                else:
-                    w("    if (visited[idx >> 5] & bit) goto TryFallback; visited[idx >> 5] |= bit;\n")
-                    w("    if (ntouched == captouched) { captouched = captouched ? 2 * captouched : 1024;"
-                      " touched = (int64_t*)realloc(touched, 8 * captouched); }\n    touched[ntouched++] = idx >> 5; }\n")
+                # (the words an attempt marks are listed: a caller that wants a clean vector for its next attempt clears exactly those --
+                # the same as the memset over the whole vector it stands for, without its cost on a 4 MiB chunk)
+                w("    if (visited[idx >> 5] & bit) goto TryFallback; visited[idx >> 5] |= bit;\n")
+                w("    if (ntouched == captouched) { captouched = captouched ? 2 * captouched : 1024;"
+                  " touched = (int64_t*)realloc(touched, 8 * captouched); }\n    touched[ntouched++] = idx >> 5; }\n")
             w("  if (sp == *scap) { *scap *= 2; stack = *stk = (frame_t*)realloc(stack, sizeof(frame_t) * *scap);"
               " cstack = *cstk = (int64_t*)realloc(cstack, sizeof(int64_t) * NCAP * *scap); }\n")
             w("  stack[sp].off = offset; stack[sp].pc = %d; memcpy(cstack + sp*NCAP, caps, sizeof(int64_t)*NCAP); sp++;\n" % ins.arg)
@@ -175,24 +174,69 @@ def emit_c(prog: S.Prog, memo: bool, name: str = "m", q8: bool = True) -> str:
     w("      if (caps[1] > ss) ss = caps[1]; else ss++;\n    } else ss++;\n")
     if memo and not q8:
         w("    for (int64_t k = 0; k < ntouched; k++) visited[touched[k]] = 0;\n    ntouched = 0;\n")
+    elif memo:
+        w("    ntouched = 0;\n")          # (Q8: the vector is NOT cleared between the iterations; only the list starts over)
     w("  }\n")
     w("  free(stack); free(cstack); free(visited);\n  return count;\n}\n\n")
-    # FindBytesReuse (find.go:469-591): Q1 restart from the failure offset
+    # FindBytesReuse (find.go:469-591): Q1 restart from the failure offset.  The scratch is the caller's: `visited` all zero on entry
+    # (NINST * (l + 1) bits at least) and all zero again on return.
+    w("static int find_core(const uint8_t* input, int64_t l, int64_t* caps, frame_t** stk, int64_t** cstk, int64_t* scap, uint32_t* visited) {\n")
+    w("  int64_t off = 0, end; memset(caps, 0, sizeof(int64_t) * NCAP);\n")
+    w("  int found = 0;\n  for (;;) {\n")
+    w("    if (attempt(input, l, off, caps, &end, stk, cstk, scap, visited)) { caps[1] = end; found = 1; break; }\n")
+    clear = "for (int64_t k = 0; k < ntouched; k++) visited[touched[k]] = 0; ntouched = 0; " if memo else ""
+    if anchored:
+        w("    break;\n")
+    else:
+        w("    if (l > end) { off = end + 1; memset(caps, 0, sizeof(int64_t) * NCAP); caps[0] = off; %s} else break;\n" % clear)
+    w("  }\n  %s\n  return found;\n}\n" % clear)
     w("int %s_find(const uint8_t* input, int64_t l, int32_t* out) {\n" % name)
-    w("  int64_t off = 0, scap = 64, end; int64_t caps[NCAP]; memset(caps, 0, sizeof caps);\n")
+    w("  int64_t scap = 64; int64_t caps[NCAP];\n")
     w("  frame_t* stack = (frame_t*)malloc(sizeof(frame_t) * scap); int64_t* cstack = (int64_t*)malloc(sizeof(int64_t) * NCAP * scap);\n")
     if memo:
         w("  int64_t vwords = ((int64_t)NINST * (l + 1) + 31) / 32; uint32_t* visited = (uint32_t*)calloc(vwords, 4);\n")
     else:
-        w("  uint32_t* visited = 0; int64_t vwords = 0;\n")
-    w("  int found = 0;\n  for (;;) {\n")
-    w("    if (attempt(input, l, off, caps, &end, &stack, &cstack, &scap, visited)) { caps[1] = end; found = 1; break; }\n")
-    if anchored:
-        w("    break;\n")
+        w("  uint32_t* visited = 0;\n")
+    w("  const int found = find_core(input, l, caps, &stack, &cstack, &scap, visited);\n")
+    w("  if (found) for (int c = 0; c < NCAP; c++) out[c] = (int32_t)caps[c];\n")
+    w("  free(stack); free(cstack); free(visited);\n  return found;\n}\n")
+    # FindReader (streaming.go:85-255) over a stream held in memory, read as bytes.Reader delivers it: every Read fills what it is given
+    # until the stream runs out, then (0, io.EOF).  One row of 3 + NCAP int64 per callback: Match.StreamOffset, Match.ChunkIndex, the stream
+    # offset of the chunk's first byte, and the result struct's spans relative to the chunk (the slice offsets FindBytesReuse returned + searchPos).
+    w("#define _GNU_SOURCE\n" if False else "")
+    w("static const uint8_t* index_bytes(const uint8_t* h, int64_t hl, const uint8_t* n, int64_t nl) {\n")
+    w("  if (nl == 0) return h;\n  for (int64_t i = 0; i + nl <= hl; i++) { if (h[i] == n[0] && memcmp(h + i, n, nl) == 0) return h + i; }\n  return 0;\n}\n")
+    w("int64_t %s_find_reader(const uint8_t* stream, int64_t total, int64_t B, int64_t ML, int64_t* rows, int64_t cap) {\n" % name)
+    w("  uint8_t* buf = (uint8_t*)malloc(B > 0 ? B : 1); int64_t leftover = 0, streamOffset = 0, chunkIndex = 0, rd = 0, nrows = 0, scap = 64;\n")
+    w("  int64_t caps[NCAP];\n")
+    w("  frame_t* stack = (frame_t*)malloc(sizeof(frame_t) * scap); int64_t* cstack = (int64_t*)malloc(sizeof(int64_t) * NCAP * scap);\n")
+    if memo:
+        w("  uint32_t* visited = (uint32_t*)calloc(((int64_t)NINST * (B + 1) + 31) / 32 + 1, 4);\n")
     else:
-        w("    if (l > end) { off = end + 1; memset(caps, 0, sizeof caps); caps[0] = off; if (visited) memset(visited, 0, vwords * 4); } else break;\n")
-    w("  }\n  if (found) for (int c = 0; c < NCAP; c++) out[c] = (int32_t)caps[c];\n")
-    w("  free(stack); free(cstack); free(visited); (void)vwords;\n  return found;\n}\n")
+        w("  uint32_t* visited = 0;\n")
+    w("  for (;;) {\n")
+    w("    int64_t want = B - leftover, n = total - rd < want ? total - rd : want;            /* r.Read(buf[leftover:]) */\n")
+    w("    const int eof = n == 0;\n")
+    w("    if (eof && leftover == 0) break;\n")
+    w("    memcpy(buf + leftover, stream + rd, n); rd += n;\n")
+    w("    const int64_t dataLen = leftover + n; const int isFull = !eof && n == B - leftover;\n")
+    w("    int64_t sp = 0, committed = 0;\n")
+    w("    while (sp < dataLen) {\n")
+    w("      if (!find_core(buf + sp, dataLen - sp, caps, &stack, &cstack, &scap, visited)) break;\n")
+    w("      const int64_t mlen = caps[1] - caps[0];\n")
+    w("      const uint8_t* at = index_bytes(buf + sp, dataLen - sp, buf + sp + caps[0], mlen);    /* bytes.Index(chunk[searchPos:], result.Match) */\n")
+    w("      if (!at) break;\n")
+    w("      const int64_t matchStart = at - buf, matchEnd = matchStart + mlen;\n")
+    w("      if (isFull && matchEnd > dataLen - ML) break;                                          /* deferred to the next chunk */\n")
+    w("      if (nrows < cap) { int64_t* r = rows + nrows * (3 + NCAP); r[0] = streamOffset + matchStart; r[1] = chunkIndex; r[2] = streamOffset;\n")
+    w("        for (int c = 0; c < NCAP; c++) r[3 + c] = caps[c] + sp; }\n")
+    w("      nrows++;\n      committed = matchEnd;\n")
+    w("      if (mlen > 0) sp = matchEnd; else sp++;\n    }\n")
+    w("    if (eof) break;                                                                          /* the leftover chunk was the stream's last */\n")
+    w("    if (isFull) { int64_t keepFrom = dataLen - ML; if (keepFrom < committed) keepFrom = committed;\n")
+    w("      leftover = dataLen - keepFrom; streamOffset += keepFrom; memmove(buf, buf + keepFrom, leftover); } else leftover = 0;\n")
+    w("    chunkIndex++;\n  }\n")
+    w("  free(buf); free(stack); free(cstack); free(visited);\n  return nrows;\n}\n")
     # FindBytes per string of a CSR batch in ONE call (bench.py's cpu_baseline of config C3: a call per string through ctypes measured
     # the call overhead, 0.45 us per string, more than the matcher)
     w("long long m_find_batch(const unsigned char *concat, const unsigned long long *offsets, long long nstr, unsigned char *found, int *spans) {\n")
@@ -210,6 +254,13 @@ class CMatcher:
         ast, prog = S.compile_pattern(pattern)
         self.prog = prog
         sel = E.select(ast, prog)
+        if sel.find_engine == "tdfa?":
+            # (as engines.Compiled: captures + nested quantifiers -> the Tagged DFA when it can be built -- oracle/tdfa_c.py is that
+            # engine's port, this matcher then stands for the pattern's leftmost-first matches only --, else the memoising functions,
+            # compiler.go:137-153, 415-426)
+            from . import tdfa as T
+            if T.build_for_prog(ast, prog) is None:
+                sel.find_memo = True
         self.ncap = prog.numcap
         self.memo = sel.find_memo
         src = emit_c(prog, sel.find_memo, q8=q8)
@@ -245,6 +296,18 @@ class CMatcher:
         self.lib.m_find.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p]
         self.lib.m_find_batch.restype = ctypes.c_int64
         self.lib.m_find_batch.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_void_p]
+        self.lib.m_find_reader.restype = ctypes.c_int64
+        self.lib.m_find_reader.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
+
+    def find_reader_np(self, stream, buffer_size: int, max_leftover: int):
+        """FindReader over `stream` (numpy uint8) read as bytes.Reader delivers it, with a RESOLVED Config: int64 rows
+        [callbacks, 3 + ncap] = StreamOffset, ChunkIndex, the chunk's stream offset, the result struct's spans relative to the chunk."""
+        import numpy as np
+        st = np.ascontiguousarray(stream)
+        n = self.lib.m_find_reader(st.ctypes.data, int(st.size), buffer_size, max_leftover, None, 0)
+        rows = np.empty((max(n, 1), 3 + self.ncap), dtype=np.int64)
+        self.lib.m_find_reader(st.ctypes.data, int(st.size), buffer_size, max_leftover, rows.ctypes.data, n)
+        return rows[:n]
 
     def find_all_np(self, buf, n: int = -1, cap: Optional[int] = None):
         """buf: numpy uint8 array (contiguous).  Returns int32 array [count, ncap]."""

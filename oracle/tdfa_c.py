@@ -26,7 +26,7 @@ def emit_c(t: T.TDFA) -> str:
     A = max([len(a) for row in tb["tag_actions"] for a in row] + [len(a) for a in tb["accept_actions"]] + [1])
     o = []
     w = o.append
-    w("#include <stdint.h>\n#include <string.h>\n#define S %d\n#define NT %d\n#define A %d\n" % (S, ntags, A))
+    w("#include <stdint.h>\n#include <stdlib.h>\n#include <string.h>\n#define S %d\n#define NT %d\n#define A %d\n" % (S, ntags, A))
     w("static const int16_t transitions[S][128] = {%s};\n" % ",".join("{" + ",".join(map(str, row)) + "}" for row in tb["transitions"]))
     w("static const uint8_t tagActionCount[S][128] = {%s};\n" % ",".join("{" + ",".join(str(len(a)) for a in row) + "}" for row in tb["tag_actions"]))
 
@@ -126,6 +126,47 @@ int64_t t_find_all(const uint8_t* input, int64_t l, int64_t nmax, int32_t* rows,
   }
   return n;
 }
+
+/* FindReader (streaming.go:85-255) over a stream held in memory, read as bytes.Reader delivers it (every Read fills what it is given until
+   the stream runs out, then (0, io.EOF)).  One row of 3 + NT int64 per callback: Match.StreamOffset, Match.ChunkIndex, the stream offset of
+   the chunk's first byte, and the reported tags relative to the chunk (-1: the group's field is left untouched, tdfa.go:1031-1046). */
+static const uint8_t* t_index_bytes(const uint8_t* h, int64_t hl, const uint8_t* n, int64_t nl) {
+  if (nl == 0) return h;
+  for (int64_t i = 0; i + nl <= hl; i++) if (h[i] == n[0] && memcmp(h + i, n, nl) == 0) return h + i;
+  return 0;
+}
+int64_t t_find_reader(const uint8_t* stream, int64_t total, int64_t B, int64_t ML, int64_t* rows, int64_t cap) {
+  static uint8_t* buf = 0; static int64_t bufcap = 0;
+  if (bufcap < B) { buf = (uint8_t*)realloc(buf, B); bufcap = B; }
+  int64_t leftover = 0, streamOffset = 0, chunkIndex = 0, rd = 0, nrows = 0;
+  int32_t r[NT];
+  for (;;) {
+    int64_t want = B - leftover, n = total - rd < want ? total - rd : want;
+    const int eof = n == 0;
+    if (eof && leftover == 0) break;
+    memcpy(buf + leftover, stream + rd, n); rd += n;
+    const int64_t dataLen = leftover + n; const int isFull = !eof && n == B - leftover;
+    int64_t sp = 0, committed = 0;
+    while (sp < dataLen) {
+      if (!t_find(buf + sp, dataLen - sp, r)) break;
+      const int64_t mlen = r[1] - r[0];
+      const uint8_t* at = t_index_bytes(buf + sp, dataLen - sp, buf + sp + r[0], mlen);
+      if (!at) break;
+      const int64_t matchStart = at - buf, matchEnd = matchStart + mlen;
+      if (isFull && matchEnd > dataLen - ML) break;
+      if (nrows < cap) { int64_t* o = rows + nrows * (3 + NT); o[0] = streamOffset + matchStart; o[1] = chunkIndex; o[2] = streamOffset;
+        for (int j = 0; j < NT; j++) o[3 + j] = r[j] >= 0 ? r[j] + sp : -1; }
+      nrows++;
+      committed = matchEnd;
+      if (mlen > 0) sp = matchEnd; else sp++;
+    }
+    if (eof) break;
+    if (isFull) { int64_t keepFrom = dataLen - ML; if (keepFrom < committed) keepFrom = committed;
+      leftover = dataLen - keepFrom; streamOffset += keepFrom; memmove(buf, buf + keepFrom, leftover); } else leftover = 0;
+    chunkIndex++;
+  }
+  return nrows;
+}
 """ % (t.start_begin, setup_b, t.start_any, setup_a))
     return "".join(o)
 
@@ -175,6 +216,18 @@ class CTdfa:
         self.lib.t_chain.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
         self.lib.t_find_all.restype = ctypes.c_int64
         self.lib.t_find_all.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
+        self.lib.t_find_reader.restype = ctypes.c_int64
+        self.lib.t_find_reader.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64]
+
+    def find_reader_np(self, stream, buffer_size: int, max_leftover: int):
+        """FindReader over `stream` (numpy uint8) read as bytes.Reader delivers it, with a RESOLVED Config: int64 rows [callbacks, 3 + ntags]
+        = StreamOffset, ChunkIndex, the chunk's stream offset, the reported tags relative to the chunk (-1: field untouched)."""
+        import numpy as np
+        st = np.ascontiguousarray(stream)
+        n = self.lib.t_find_reader(st.ctypes.data, int(st.size), buffer_size, max_leftover, None, 0)
+        rows = np.empty((max(n, 1), 3 + self.ntags), dtype=np.int64)
+        self.lib.t_find_reader(st.ctypes.data, int(st.size), buffer_size, max_leftover, rows.ctypes.data, n)
+        return rows[:n]
 
     def find(self, b: bytes):
         import numpy as np

@@ -21,7 +21,7 @@ _STATUS = {0: "ok", -1: "invalid", -2: "syntax", -3: "unsupported", -4: "too lar
            -7: "nomem", -8: "capacity", -9: "bad blob", -10: "buffer too small", -11: "diverges from the reference"}
 
 RGX_OK = 0
-ABI_VERSION = 4            # include/rgx.h: RGX_ABI_VERSION (checked against rgx_abi_version() when the library is loaded)
+ABI_VERSION = 5            # include/rgx.h: RGX_ABI_VERSION (checked against rgx_abi_version() when the library is loaded)
 RGX_E_INVALID = -1
 RGX_E_SYNTAX = -2
 RGX_E_UNSUPPORTED = -3
@@ -55,7 +55,13 @@ class ShardedInfo(C.Structure):
 class ShardWindow(C.Structure):
     _fields_ = [("buf", C.c_void_p), ("len", C.c_size_t), ("own_lo", C.c_int64), ("own_hi", C.c_int64), ("base", C.c_int64),
                 ("is_host", C.c_int32), ("starts_at_sync", C.c_int32), ("last", C.c_int32), ("starts_only", C.c_int32),
-                ("d_spans", C.c_void_p), ("cap_records", C.c_size_t)]
+                ("d_spans", C.c_void_p), ("cap_records", C.c_size_t),
+                ("reader_buffer_size", C.c_int64), ("reader_max_leftover", C.c_int64)]
+
+
+class ChunksResult(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("chunks", C.c_int64), ("next_from", C.c_int64), ("ncap", C.c_int32), ("mode", C.c_int32),
+                ("kernel_ms", C.c_float), ("reserved", C.c_int32)]
 
 
 class ShardRound(C.Structure):
@@ -129,6 +135,10 @@ SYMBOLS = {
     "rgx_stream_config_resolve": (C.c_int, [C.c_void_p, C.POINTER(StreamConfig), C.POINTER(StreamConfig)]),
     "rgx_find_chunk": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int64, C.c_void_p,
                                    C.c_size_t, C.POINTER(C.c_int64), C.POINTER(C.c_int64), C.POINTER(Result)]),
+    "rgx_find_chunks_device": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_size_t,
+                                           C.POINTER(ChunksResult)]),
+    "rgx_find_chunks": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int64, C.c_int, C.c_void_p, C.c_size_t,
+                                    C.POINTER(ChunksResult)]),
     "rgx_count_chunk": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int, C.c_int64, C.POINTER(C.c_int64),
                                     C.POINTER(C.c_int64), C.POINTER(Result)]),
     "rgx_count_all_device_owned": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_int64, C.c_int64,

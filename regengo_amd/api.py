@@ -455,6 +455,138 @@ class Compiled:
                 leftover = 0
             chunk_index += 1
 
+    # ---- FindReader over a run of chunks (rgx_find_chunks_device): the fixed-stride grid a buffer-filling reader produces
+    def FindChunksDevice(self, data, cfg: Config, final: bool = True, capacity: Optional[int] = None, out=None, count_only: bool = False):
+        """data: uint8 tensor on the program's device holding the stream from a chunk start on; cfg: a RESOLVED Config.  Returns
+        (rows int32 tensor [n, ncap] block-relative | None, ChunksResult)."""
+        import torch
+        self._need_dev()
+        res = _capi.ChunksResult()
+        if count_only:
+            _capi.check(self._lib.rgx_find_chunks_device(self._h, self._ctx, data.data_ptr(), data.numel(), cfg.BufferSize, cfg.MaxLeftover,
+                                                         1 if final else 0, None, 0, C.byref(res)))
+            return None, res
+        cap = capacity if capacity is not None else data.numel() // max(self.MinMatchLen, 1) + 2
+        for _ in range(2):
+            if out is None or out.shape[0] < cap:
+                out = torch.empty((cap, self.ncap), dtype=torch.int32, device=data.device)
+            w = self._lib.rgx_find_chunks_device(self._h, self._ctx, data.data_ptr(), data.numel(), cfg.BufferSize, cfg.MaxLeftover,
+                                                 1 if final else 0, out.data_ptr(), out.shape[0], C.byref(res))
+            if w == _capi.RGX_E_CAPACITY and res.rows > out.shape[0]:
+                cap = int(res.rows) + 16
+                out = None
+                continue
+            break
+        _capi.check(w)
+        return out[:w], res
+
+    def FindReaderBlocks(self, r, cfg: Config, on_match: Callable[[Match], bool], block_bytes: int = 64 << 20) -> None:
+        """FindReader with the chunks of a RUN answered by one call (rgx_find_chunks).  The reads are the reference's own -- BufferSize
+        bytes, then BufferSize - MaxLeftover at a time (streaming.go:123) -- appended to one block while they come back full; a
+        short read, EOF or a full block ends the run.  Same callbacks as FindReader (StreamOffset, ChunkIndex, the reused struct of a
+        Tagged-DFA program included); a run the library does not vouch for (RGX_E_DIVERGES) goes chunk by chunk through rgx_find_chunk."""
+        self._need_dev()
+        cfg = self._resolve(cfg)
+        B, ML = cfg.BufferSize, cfg.MaxLeftover
+        S = B - ML
+        nmax = max((block_bytes - B) // S + 1, 1)              # full chunks per run
+        block = bytearray((nmax - 1) * S + B)
+        cap = len(block) // max(self.MinMatchLen, 1) + 2
+        spans = (C.c_int32 * (cap * self.ncap))()
+        res = _capi.ChunksResult()
+        tdfa_reuse = self.info.ref_find_engine == 1 and not self.stdlib
+        held = [None] * (self.ncap // 2)
+        prev_chunk = bytes(B)      # the chunk in front of the run's first (what the reference's buffer still holds behind a short chunk)
+        stream_offset = 0          # of block[0]
+        chunk_index = 0            # of the run's first chunk
+        leftover = 0               # bytes at the head of the block carried over from the run before
+        while True:
+            fill, nfull, final, eof = leftover, 0, False, False
+            while nfull < nmax:
+                want = B - (fill - nfull * S)
+                data = r.read(want)
+                n = len(data)
+                if n == 0:                                      # EOF: what is left over is one more chunk, which reports everything
+                    eof = True
+                    final = fill - nfull * S > 0
+                    break
+                block[fill:fill + n] = data
+                fill += n
+                if n < want:                                    # a short read: this chunk is not full (streaming.go:177)
+                    final = True
+                    break
+                nfull += 1
+            if nfull == 0 and not final:
+                return
+            rows = self._run_rows(block, fill, B, ML, final, spans, cap, res)
+            nchunks = nfull + (1 if final else 0)
+            for rec in rows:
+                k = min(rec[0] // S, nchunks - 1)
+                cs = k * S
+                clen = min(B, fill - cs)
+                rel = [rec[0] - cs, rec[1] - cs]
+                for g in range(1, self.ncap // 2):
+                    a, b = rec[2 * g], rec[2 * g + 1]
+                    rel += [a, b] if ((a == 0 and b == 0) or a < 0) else [a - cs, b - cs]
+                if tdfa_reuse:
+                    # ONE result struct for the stream (streaming.go:117), its fields slices of the reference's ONE buffer, which holds
+                    # chunk k now: a field an earlier match set reads whatever lies at its offsets in THIS chunk -- behind a short chunk's
+                    # end, what the chunk before left there
+                    for g in range(self.ncap // 2):
+                        if rel[2 * g] >= 0:
+                            held[g] = (rel[2 * g], rel[2 * g + 1])
+                    before = bytes(block[cs - S:cs - S + B]) if cs >= S else prev_chunk
+                    bufnow = bytes(block[cs:cs + clen]) + before[clen:]
+                    vals = [None if h is None else bufnow[h[0]:h[1]] for h in held]
+                    m = Match(BytesResult(self.fields, vals, rel), stream_offset + rec[0], chunk_index + k)
+                else:
+                    m = Match(self._make_result(bytes(block[cs:cs + clen]), rel), stream_offset + rec[0], chunk_index + k)
+                if not on_match(m):
+                    return
+            if eof:
+                return
+            if nfull > 0:
+                prev_chunk = bytes(block[(nfull - 1) * S:(nfull - 1) * S + B])
+            stream_offset += nfull * S
+            if final:
+                # behind a short read the reference zeroes leftover and does NOT advance streamOffset past the short chunk (streaming.go:241-244)
+                prev_chunk = bytes(block[nfull * S:fill]) + prev_chunk[fill - nfull * S:]
+                leftover = 0
+                chunk_index += nfull + 1
+            else:
+                leftover = fill - nfull * S                     # == MaxLeftover
+                block[:leftover] = block[nfull * S:fill]
+                chunk_index += nfull
+
+    def _run_rows(self, block, fill, B, ML, final, spans, cap, res):
+        """rows (lists of ncap ints, block-relative) the reference's loop reports from the chunks of block[:fill]"""
+        S = B - ML
+        cbuf = (C.c_uint8 * fill).from_buffer(block)
+        w = self._lib.rgx_find_chunks(self._h, self._ctx, cbuf, fill, B, ML, 1 if final else 0, spans, cap, C.byref(res))
+        del cbuf
+        if w != _capi.RGX_E_DIVERGES:
+            _capi.check(w)
+            return [[int(x) for x in spans[i * self.ncap:(i + 1) * self.ncap]] for i in range(w)]
+        # chunk by chunk: rgx_find_chunk vouches for (or refuses) one chunk at a time
+        rows = []
+        kfull = (fill - B) // S + 1 if fill >= B else 0
+        nchunks = kfull + (1 if final and kfull * S < fill else 0)
+        committed, keep, r1 = C.c_int64(), C.c_int64(), _capi.Result()
+        for k in range(nchunks):
+            cs = k * S
+            clen = min(B, fill - cs)
+            piece = (C.c_uint8 * clen).from_buffer_copy(bytes(block[cs:cs + clen]))
+            w = _capi.check(self._lib.rgx_find_chunk(self._h, self._ctx, piece, clen, 1 if k < kfull else 0, ML, spans, cap, C.byref(committed),
+                                                     C.byref(keep), C.byref(r1)))
+            for i in range(w):
+                rec = [int(x) for x in spans[i * self.ncap:(i + 1) * self.ncap]]
+                out = [rec[0] + cs, rec[1] + cs]
+                for g in range(1, self.ncap // 2):
+                    a, b = rec[2 * g], rec[2 * g + 1]
+                    out += [a, b] if ((a == 0 and b == 0) or a < 0) else [a + cs, b + cs]
+                rows.append(out)
+        return rows
+
     def _loop_rows(self, data: bytes):
         """The rows of the emitted loop "FindBytesReuse on data[matchEnd:]" over one buffer (rgx_find_chunk on a chunk that is not full:
         nothing deferred): what the host side of NewTransformReader walks for a Tagged-DFA program, whose FindAllBytes is another loop."""

@@ -83,6 +83,8 @@ struct rgx_stream_ctx {
   int32_t* d_tdfa = nullptr; int64_t tdfa_cap = 0;           // Tagged-DFA path: ends, (start, end) pairs, sync bits, counts, offsets (TdfaChainDevice)
   int32_t* d_q11 = nullptr; int64_t q11_cap = 0;             // Tagged-DFA FindAll wrapper (TdfaFindAllDevice): the tiles' maps, entries and bases
   int32_t* d_q11se = nullptr; int64_t q11se_cap = 0;         // ... and the (start, end) of its rows
+  uint32_t* d_glist = nullptr; int64_t glist_cap = 0;        // FindChunksDevice: [0] rows the quick gap test could not settle, [4..] their indices
+  uint8_t* d_blk = nullptr; int64_t blk_cap = 0;             // rgx_find_chunks: the host block's copy (d_in stages single chunks of it)
   uint8_t* d_tmpl = nullptr; int64_t tmpl_cap = 0;           // resolved template (segments + literals) of the last splice
   std::string tmpl_key;                                      // what d_tmpl holds: "" = nothing
   // pinned host readback
@@ -353,8 +355,9 @@ int ReaderCheck(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_raw, s
 // on buf[searchPos:]; searchPos = end of the match" (streaming.go:175-244 without its commit rule; max_n = 1: FindBytes), rows of
 // ncap int32 = the reported tags ((-1, -1): the group's field is left untouched, tdfa.go:1031-1046).  Returns the number of matches
 // (rows written: min(that, cap_records); d_rows may be NULL with cap_records 0: count only) or a negative status.
+constexpr int64_t kGridNotTaken = -1000;      // (FindAllDevice has the comment)
 int64_t TdfaChainDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t max_n, int32_t* d_rows,
-                        size_t cap_records, rgx_result* res) {
+                        size_t cap_records, rgx_result* res, const ReaderGrid* grid = nullptr) {
   const TdfaDev& D = *p->p.dev.tdfa;
   const Tables& t = p->p.t;
   if (res) { memset(res, 0, sizeof *res); res->ncap = t.ncap; }
@@ -365,6 +368,8 @@ int64_t TdfaChainDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* 
   const int64_t cap_m = std::min<int64_t>((int64_t)len / std::max(t.min_len, 1) + 2, max_n);
   const int64_t nslices = TdfaSlices(ilen), ntiles = TdfaSyncTiles(ilen);
   const bool parallel = D.start_begin == D.start_any && !t.can_match_empty && len >= 8192 && max_n > 1;
+  if (grid && !parallel) return kGridNotTaken;       // (the serial chain knows no grid: such a program goes chunk by chunk)
+  const ReaderGrid G = grid ? *grid : ReaderGrid();
   const size_t scan_tmp = parallel ? TdfaScanTempBytes(nslices) : 0;
   auto r4 = [](int64_t x) { return (x + 3) & ~int64_t(3); };
   const int64_t o_ends = 0, o_se = o_ends + r4((int64_t)len + 1), o_sync = o_se + r4(2 * cap_m), o_counts = o_sync + r4(2 * nslices),
@@ -380,7 +385,7 @@ int64_t TdfaChainDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* 
   uint32_t* flags = (uint32_t*)(base + o_misc);
   long long* out_n = (long long*)(base + o_misc + 2);
   HIP_TRY(hipMemsetAsync(base + o_misc, 0, 64, c->stream));
-  HIP_TRY(LaunchTdfaEnds(D, d_buf, ilen, ends, flags, c->stream));
+  HIP_TRY(LaunchTdfaEnds(D, d_buf, ilen, ends, flags, c->stream, G));
   int64_t n = 0;
   int32_t h[4] = {0, 0, 0, 0};
   auto over_budget = [&]() {
@@ -389,8 +394,8 @@ int64_t TdfaChainDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* 
   };
   if (parallel) {
     HIP_TRY(hipMemsetAsync(desc, 0, (size_t)ntiles * 8, c->stream));
-    HIP_TRY(LaunchTdfaSync(ends, ilen, sync, desc, flags, c->stream));
-    HIP_TRY(LaunchTdfaChain(ends, ilen, sync, counts, nullptr, nullptr, 0, 0, flags, c->stream));
+    HIP_TRY(LaunchTdfaSync(ends, ilen, sync, desc, flags, c->stream, G));
+    HIP_TRY(LaunchTdfaChain(ends, ilen, sync, counts, nullptr, nullptr, 0, 0, flags, c->stream, G));
     HIP_TRY(LaunchTdfaScan(counts, offs, nslices, base + o_tmp, scan_tmp, c->stream));
     HIP_TRY(hipMemcpyAsync(&h[0], flags, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(&h[1], counts + nslices - 1, 4, hipMemcpyDeviceToHost, c->stream));
@@ -400,7 +405,7 @@ int64_t TdfaChainDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* 
     if (h[0] & 1) { SetError("tdfa_sync_kernel: look-back timeout"); return RGX_E_HIP; }
     n = (int64_t)h[1] + h[2];
     if (n > cap_m) { SetError("internal: more Tagged-DFA matches than len / min_len"); return RGX_E_HIP; }
-    if (n > 0 && d_rows) HIP_TRY(LaunchTdfaChain(ends, ilen, sync, counts, offs, se, cap_m, 1, flags, c->stream));
+    if (n > 0 && d_rows) HIP_TRY(LaunchTdfaChain(ends, ilen, sync, counts, offs, se, cap_m, 1, flags, c->stream, G));
   } else {
     HIP_TRY(LaunchTdfaChainSerial(D, d_buf, ilen, ends, se, cap_m, out_n, flags, c->stream));
     long long hn = 0;
@@ -413,7 +418,7 @@ int64_t TdfaChainDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* 
   if (res) { res->total = n; res->written = 0; }
   if (d_rows && n > 0) {
     const int64_t w = std::min<int64_t>(n, (int64_t)cap_records);
-    HIP_TRY(LaunchTdfaTags(D, d_buf, ilen, se, w, d_rows, c->stream));
+    HIP_TRY(LaunchTdfaTags(D, d_buf, ilen, se, w, d_rows, c->stream, G));
     if (res) res->written = w;
     if (w < n) { HIP_TRY(hipStreamSynchronize(c->stream)); SetError("span capacity too small"); return RGX_E_CAPACITY; }
   }
@@ -553,12 +558,12 @@ int64_t TdfaFindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t
 // bytes.Index (streaming.go:192) against the chain's rows: an earlier copy of a match's text in the gap in front of it moves the
 // offset the loop reports.  With one start state that can only happen to a match that was accepted BY the end of the text (the same
 // bytes earlier are not at the end) -- checked for every row all the same.
-int TdfaIndexCheck(rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, const int32_t* d_rows, int64_t n, int ncap) {
+int TdfaIndexCheck(rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, const int32_t* d_rows, int64_t n, int ncap, const ReaderGrid* grid = nullptr) {
   if (n <= 0) return RGX_OK;
   unsigned* flag = reinterpret_cast<unsigned*>(c->d_cursor + 1);
   unsigned h = 0;
   HIP_TRY(hipMemsetAsync(flag, 0, 4, c->stream));
-  HIP_TRY(LaunchReaderIndex(d_buf, (int32_t)len, d_rows, n, ncap, flag, c->stream));
+  HIP_TRY(LaunchReaderIndex(d_buf, (int32_t)len, d_rows, n, ncap, flag, c->stream, grid ? *grid : ReaderGrid()));
   HIP_TRY(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   if (h) { SetError("the reference's FindReader loop reports a match of this chunk at an earlier copy of its text (bytes.Index, streaming.go:192): run it through the Go loop"); return RGX_E_DIVERGES; }
@@ -628,9 +633,11 @@ int CapturePass(const rgx_program* p, rgx_stream_ctx* c, const DevTables& T, con
   return RGX_OK;
 }
 
+// grid != nullptr: the buffer is a run of FindReader chunks (ScanParams::grid_stride; FindChunksDevice below) -- taken by the exact and the
+// filter + candidate kernels only; kGridNotTaken: this program / text goes chunk by chunk.
 int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n, int32_t* d_spans,
                       size_t cap_records, bool count_only, rgx_result* res, bool starts_only = false, int64_t own_lo = 0,
-                      int64_t own_hi = -1) {
+                      int64_t own_hi = -1, const ReaderGrid* grid = nullptr) {
   const DevTables& T = p->p.dev;
   if (res) memset(res, 0, sizeof *res);
   if (res) res->ncap = T.ncap;
@@ -655,7 +662,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
           for (int k = 0; k <= tt.ncls && dead; k++) if (tt.trans[(size_t)tt.start[cx] * (tt.ncls + 1) + k] != 0) dead = false;   // next state or a match flag
         }
         if (dead) return 0;
-        return FindAllDevice(tw, c, d_buf, len, n, d_spans, cap_records, count_only, res, starts_only, own_lo, own_hi);
+        return FindAllDevice(tw, c, d_buf, len, n, d_spans, cap_records, count_only, res, starts_only, own_lo, own_hi, grid);
       }
     }
   }
@@ -700,6 +707,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   P.own_hi = own_hi < 0 ? ilen : (int32_t)std::max<int64_t>(P.own_lo, std::min<int64_t>(own_hi, ilen));
   P.count_only = count_only ? 1 : 0;
   P.starts_only = starts_only ? 1 : 0;
+  if (grid) { P.grid_stride = grid->stride; P.grid_free = grid->free_from; }
   // Dynamic groups: the scan leaves (start, end) of match k in a table of its own, 8 bytes apart, and the capture pass writes the
   // whole record.  Written into slots 0-1 of the 4 x ncap-byte records they cost the capture pass -- which is bound by HBM traffic,
   // 2.1 GB read + 0.7 GB written per 1.6 GiB window of config C4 -- a fetch of the entire span table to read a sixth of it.
@@ -787,6 +795,12 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   const bool fc_sync_ok = T.reset_values == 0 ? own_lo <= 0 : (!use_w && !us_ws && !c->prefer_w);
   int fcm = (fc_sync_ok && p->fc_bad.load(std::memory_order_relaxed) < 2 && fc_pref >= 0) ? UseFcKernel(T, ilen) : 0;
   if (fcm && fc_open && p->fc_us_per_gib.load(std::memory_order_relaxed) != 0) fcm = 0;      // the kernel has its time: the other one's turn
+  if (grid) {
+    // a chunk grid: this kernel or the exact one, whatever the program has learned about plain scans (the alternative is a call per chunk);
+    // not a pattern without a reset byte (its tiles are chained from offset 0 of ONE text)
+    fcm = (T.reset_values != 0 && !use_w && !us_ws) ? UseFcKernel(T, ilen) : 0;
+    if (!fcm && !UseExactKernel(T, ilen)) return kGridNotTaken;
+  }
   const auto fc_t0 = std::chrono::steady_clock::now();
   auto fc_rate = [&]() -> int {
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - fc_t0).count();
@@ -825,13 +839,14 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
         if ((rc = CapturePass(p, c, T, d_buf, ilen, d_spans, P.pairs, fwritten)) != RGX_OK) return rc;
       }
       if (res) res->written = fwritten;
-      if (fc_open) p->fc_us_per_gib.store(fc_rate(), std::memory_order_relaxed);
+      if (fc_open && !grid) p->fc_us_per_gib.store(fc_rate(), std::memory_order_relaxed);
       return fwritten;
     }
+    if (grid) return kGridNotTaken;          // (this run of chunks holds something the kernel gives up on: says nothing about the program's plain scans)
     p->fc_bad.fetch_add(1, std::memory_order_relaxed);
     if (getenv("RGX_FC_VERBOSE")) fprintf(stderr, "[rgx] filter + candidate kernel gave up (mode %d, len %d): counters[2] = 0x%08x, counters[3] = 0x%08x\n", fcm, ilen, hc[2], hc[3]);
     P = keep;
-  } else if (fc_open && UseFcKernel(T, ilen) && p->fc_us_per_gib.load(std::memory_order_relaxed) != 0) {
+  } else if (fc_open && !grid && UseFcKernel(T, ilen) && p->fc_us_per_gib.load(std::memory_order_relaxed) != 0) {
     other_timer.f = [&]() {
       const int other = fc_rate(), mine = p->fc_us_per_gib.load(std::memory_order_relaxed);
       p->other_us_per_gib.store(other, std::memory_order_relaxed);
@@ -919,6 +934,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   }
   if (tm) (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
   unsynced = ((uint32_t*)&c->h_read[2])[1];
+  if (grid && unsynced) return kGridNotTaken;      // (a slice of candidates packed too densely for a sync point: the carry passes know no grid)
   if (unsynced && !use_w && UseUsKernel(T, ilen, false)) {
     // the one-step-per-byte kernels: slices without a sync point in reach get their search positions from ONE walk of the
     // start-tracking automaton per run (LaunchCarryUs) -- linear, where the attempt-per-start carry pass below is quadratic
@@ -1199,7 +1215,7 @@ RGX_API void rgx_stream_ctx_destroy(rgx_stream_ctx* c) {
   for (int i = 0; i < 2; ++i)
     for (hipEvent_t e : {c->pev0[i], c->pev1[i], c->pdone[i]}) if (e) (void)hipEventDestroy(e);
   for (void* p : {(void*)c->d_desc, (void*)c->d_unsynced, (void*)c->d_carry,
-                  (void*)c->d_trace, (void*)c->d_pairs, (void*)c->d_in, (void*)c->d_san, (void*)c->d_out, (void*)c->d_rspans, (void*)c->d_rdelta, (void*)c->d_rtemp, (void*)c->d_tmpl, (void*)c->d_tdfa, (void*)c->d_memo, (void*)c->d_q11, (void*)c->d_q11se})
+                  (void*)c->d_trace, (void*)c->d_pairs, (void*)c->d_in, (void*)c->d_san, (void*)c->d_out, (void*)c->d_rspans, (void*)c->d_rdelta, (void*)c->d_rtemp, (void*)c->d_tmpl, (void*)c->d_tdfa, (void*)c->d_memo, (void*)c->d_q11, (void*)c->d_q11se, (void*)c->d_glist, (void*)c->d_blk})
     if (p) (void)hipFree(p);
   if (c->d_tiny_ctl) (void)hipFree(c->d_tiny_ctl);
   if (c->h_read) (void)hipHostFree(c->h_read);
@@ -2480,6 +2496,250 @@ RGX_API int64_t rgx_count_chunk(const rgx_program* p, rgx_stream_ctx* c, const u
   *keep_from = std::max<int64_t>((int64_t)data_len - max_leftover, h2[1]);
   if (res) { *res = r; res->written = 0; }
   return h2[0];
+}
+
+// ---- FindReader over a RUN of chunks (rgx.h: rgx_find_chunks_device).  streaming.go:110-250 with a reader that fills the buffer: the
+// deferral `break` (204-210) stands in front of the commit, so committed <= dataLen - MaxLeftover and keepFrom (227-236) IS
+// dataLen - MaxLeftover after every full read -- chunk k is stream[k * stride, k * stride + BufferSize), stride = BufferSize - MaxLeftover:
+// a fixed grid of independent texts.  A chunk reports the matches of its own chain (FindBytesReuse on chunk[searchPos:]) up to the first one
+// that ends behind its keep point, i.e. behind the next chunk's first byte; a chunk that is not full (the stream's last) reports all.
+namespace {
+__global__ __launch_bounds__(256) void chunk_rows_rebase_kernel(const int32_t* src, long long nrows, int ncap, int32_t base, int32_t* dst) {
+  // rows of one chunk into the run's table: block-relative offsets; an unset group -- (0, 0) or (-1, -1) -- stays what it is
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= nrows * (ncap / 2)) return;
+  const long long r = i / (ncap / 2);
+  const int g = (int)(i - r * (ncap / 2));
+  int a = src[r * ncap + 2 * g], b = src[r * ncap + 2 * g + 1];
+  if (g == 0 || !((a == 0 && b == 0) || a < 0)) { a += base; b += base; }
+  dst[r * ncap + 2 * g] = a;
+  dst[r * ncap + 2 * g + 1] = b;
+}
+
+struct ChunkRun {
+  int64_t B, ML, S;          // BufferSize, MaxLeftover, stride
+  int64_t kfull;             // full chunks
+  bool tail;                 // ... and a final chunk that is not full, at kfull * S
+  int64_t scan_len;          // bytes of the block the run's chunks cover
+  int64_t own_hi;            // matches that start at or behind it are not this run's
+  int64_t chunks() const { return kfull + (tail ? 1 : 0); }
+};
+
+int GridGapCheck(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, const int32_t* d_rows, int64_t n, const ReaderGrid& G) {
+  if (n <= 0) return RGX_OK;
+  const DevTables& T = p->p.dev;
+  int rc;
+  if ((rc = Ensure(&c->d_glist, &c->glist_cap, n + 16)) != RGX_OK) return rc;
+  uint32_t hn = 0;
+  HIP_TRY(hipMemsetAsync(c->d_glist, 0, 16, c->stream));
+  HIP_TRY(LaunchReaderGridQuick(T, d_buf, d_rows, n, T.ncap, G, c->d_glist + 4, c->d_glist, c->stream));
+  HIP_TRY(hipMemcpyAsync(&hn, c->d_glist, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (hn == 0) return RGX_OK;
+  unsigned* flag = reinterpret_cast<unsigned*>(c->d_cursor + 1);
+  unsigned h = 0;
+  HIP_TRY(hipMemsetAsync(flag, 0, 4, c->stream));
+  if (RefMemoMode(p) && !T.ref_find_ok) {
+    int64_t nlanes = 0;
+    unsigned long long *vis = nullptr, *stk = nullptr;
+    if ((rc = MemoScratchFor(c, 4096, 4096, std::min<int64_t>(hn, 16384), &nlanes, &vis, &stk)) != RGX_OK) return rc;
+    HIP_TRY(LaunchMemoReaderGridSlow(T, d_buf, (int32_t)len, d_rows, T.ncap, G, c->d_glist + 4, hn, vis, 4096, stk, 4096, nlanes, flag, c->stream));
+  } else {
+    HIP_TRY(LaunchReaderGridSlow(T, d_buf, (int32_t)len, d_rows, T.ncap, G, c->d_glist + 4, hn, flag, c->stream));
+  }
+  HIP_TRY(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (h) { SetError("the reference's FindReader loop diverges from these chunks' matches (restart rule), or the replay is not vouched for: run the run through the Go loop"); return RGX_E_DIVERGES; }
+  return RGX_OK;
+}
+
+// One chunk the way rgx_find_chunk answers it, on bytes that are on the device already: rows (chunk-relative) into c->d_out, *nrep = the
+// leading rows the loop reports (all of them from a chunk that is not full).
+int64_t OneChunkDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_chunk, size_t clen, bool is_full, int64_t ML, float* ms) {
+  const int ncap = p->p.dev.ncap;
+  const int64_t cap_records = (int64_t)(clen / (size_t)std::max(p->p.t.min_len, 1)) + 2;
+  int rc;
+  if ((rc = Ensure(&c->d_out, &c->out_cap, cap_records * ncap + 16)) != RGX_OK) return rc;
+  rgx_result r{};
+  int64_t w;
+  if (RefTdfaMode(p)) {
+    w = TdfaChainDevice(p, c, d_chunk, clen, -1, c->d_out, (size_t)cap_records, &r);
+    if (w < 0) return w;
+    if ((rc = TdfaIndexCheck(c, d_chunk, clen, c->d_out, w, ncap)) != RGX_OK) return rc;
+  } else {
+    w = FindAllDevice(p, c, d_chunk, clen, -1, c->d_out, (size_t)cap_records, false, &r);
+    if (w < 0) return w;
+    if (ReaderCheckApplies(p) && (rc = ReaderCheck(p, c, d_chunk, clen, c->d_out, w)) != RGX_OK) return rc;
+  }
+  if (ms) *ms += r.kernel_ms;
+  if (!is_full || w == 0) return w;
+  long long h2[2] = {0, 0};
+  if ((rc = Ensure(&c->d_rdelta, &c->rdelta_cap, 4)) != RGX_OK) return rc;
+  HIP_TRY(LaunchCommitPoint(c->d_out, w, ncap, (int32_t)((int64_t)clen - ML), c->d_rdelta, c->stream));
+  HIP_TRY(hipMemcpyAsync(h2, c->d_rdelta, 16, hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  return h2[0];
+}
+
+int64_t FindChunksDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_block, size_t len, int64_t B, int64_t ML, int final,
+                         int32_t* d_spans, size_t cap_records, rgx_chunks_result* res) {
+  const Tables& t = p->p.t;
+  const DevTables& T = p->p.dev;
+  const int ncap = T.ncap;
+  if (res) { memset(res, 0, sizeof *res); res->ncap = ncap; }
+  if (B < 2 || ML < 1 || ML > B / 2) { SetError("chunk grid: BufferSize / MaxLeftover are not a resolved stream.Config (rgx_stream_config_resolve: MaxLeftover in [1, BufferSize / 2])"); return RGX_E_INVALID; }
+  if (len > 0x7FFFFF00ull) { SetError("block larger than 2^31-256 bytes: hand it in as several runs"); return RGX_E_TOO_LARGE; }
+  if ((!d_spans && cap_records) || (!d_block && len)) return RGX_E_INVALID;
+  ChunkRun R{};
+  R.B = B; R.ML = ML; R.S = B - ML;
+  R.kfull = (int64_t)len >= B ? ((int64_t)len - B) / R.S + 1 : 0;
+  R.tail = final != 0 && R.kfull * R.S < (int64_t)len;
+  R.scan_len = R.tail ? (int64_t)len : (R.kfull > 0 ? (R.kfull - 1) * R.S + B : 0);
+  R.own_hi = R.tail ? (int64_t)len : R.kfull * R.S;
+  if (res) { res->chunks = R.chunks(); res->next_from = R.tail ? (int64_t)len : R.kfull * R.S; }
+  if (R.chunks() == 0) return 0;
+  const bool stdlib = (t.flags & RGX_FLAG_STDLIB_SEMANTICS) != 0;
+  const bool tdfa = RefTdfaMode(p);
+  ReaderGrid G;
+  G.stride = (int32_t)R.S; G.bufsize = (int32_t)B;
+  G.free_from = R.tail ? (int32_t)(R.kfull * R.S) : 0x7FFFFFFF;
+  G.own_hi = (int32_t)R.own_hi;
+  int64_t rows = kGridNotTaken;
+  float ms = 0;
+  // ---- the grid kernels: ONE scan for the whole run.  Programs without an empty-width instruction that cannot match empty and need no
+  // input screen (a chunk's edge is the end of a text for a broken rune), chunks no shorter than kGridMinStride apart, and a MaxLeftover
+  // no candidate's walk reaches across (the exact kernel: K bytes; the filter + candidate kernel gives a walk up after 2 KiB) -- then the
+  // only thing a chunk's edge does to a match is to defer it.  A Tagged-DFA program: its own chain with the grid (any MaxLeftover: an
+  // attempt ends where its chunk's text ends).
+  const bool plain_ok = !tdfa && !t.lookahead_mode && !t.ctx_sensitive && !t.bot_sensitive && !t.can_match_empty && !t.anchored &&
+                        !t.needs_valid_utf8 && R.S >= kGridMinStride && ((uintptr_t)d_block & 15) == 0 &&
+                        ML >= (UseExactKernel(T, (int32_t)std::min<int64_t>(R.scan_len, 0x7FFFFF00)) ? (int64_t)T.sa_k + 1 : 4096) &&
+                        (stdlib || ReaderCheckApplies(p));
+  const bool tdfa_ok = tdfa && R.S >= 64 && R.chunks() > 1;
+  int32_t* rows_dst = d_spans;
+  size_t rows_cap = cap_records;
+  auto own_table = [&](int64_t need) -> int {        // (count-only callers: the rows live in the context)
+    int rc = Ensure(&c->d_out, &c->out_cap, need * ncap + 16);
+    if (rc != RGX_OK) return rc;
+    rows_dst = c->d_out; rows_cap = (size_t)need;
+    return RGX_OK;
+  };
+  if (plain_ok) {
+    rgx_result r{};
+    if (!d_spans) {
+      const int64_t cnt = FindAllDevice(p, c, d_block, (size_t)R.scan_len, -1, nullptr, 0, true, &r, false, 0, R.own_hi, &G);
+      if (cnt != kGridNotTaken) {
+        if (cnt < 0) return cnt;
+        rows = r.total;
+        ms = r.kernel_ms;
+        if (!stdlib && rows > 0) {                     // (the gap check wants the rows)
+          int rc = own_table(rows);
+          if (rc != RGX_OK) return rc;
+          rows = FindAllDevice(p, c, d_block, (size_t)R.scan_len, -1, rows_dst, rows_cap, false, &r, false, 0, R.own_hi, &G);
+          if (rows != kGridNotTaken && rows < 0) return rows;
+        }
+      }
+    } else {
+      rows = FindAllDevice(p, c, d_block, (size_t)R.scan_len, -1, d_spans, cap_records, false, &r, false, 0, R.own_hi, &G);
+      if (rows == RGX_E_CAPACITY) { if (res) res->rows = r.total; return rows; }
+      if (rows != kGridNotTaken && rows < 0) return rows;
+      ms = r.kernel_ms;
+    }
+    if (rows >= 0 && !stdlib) {
+      int rc = GridGapCheck(p, c, d_block, (size_t)R.scan_len, rows_dst, rows, G);
+      if (rc != RGX_OK) return rc;
+    }
+  } else if (tdfa_ok) {
+    rgx_result r{};
+    if (!d_spans) {
+      rows = TdfaChainDevice(p, c, d_block, (size_t)R.scan_len, -1, nullptr, 0, &r, &G);
+      if (rows != kGridNotTaken && rows < 0) return rows;
+      if (rows > 0) {
+        int rc = own_table(rows);
+        if (rc != RGX_OK) return rc;
+        rows = TdfaChainDevice(p, c, d_block, (size_t)R.scan_len, -1, rows_dst, rows_cap, &r, &G);
+        if (rows < 0) return rows;
+      }
+    } else {
+      rows = TdfaChainDevice(p, c, d_block, (size_t)R.scan_len, -1, d_spans, cap_records, &r, &G);
+      if (rows == RGX_E_CAPACITY) { if (res) res->rows = r.total; return rows; }
+      if (rows != kGridNotTaken && rows < 0) return rows;
+    }
+    if (rows > 0) {
+      int rc = TdfaIndexCheck(c, d_block, (size_t)R.scan_len, rows_dst, rows, ncap, &G);
+      if (rc != RGX_OK) return rc;
+    }
+  }
+  if (rows >= 0) {
+    if (res) { res->rows = rows; res->mode = 1; res->kernel_ms = ms; }
+    return rows;
+  }
+  // ---- chunk by chunk (every other program / geometry): rgx_find_chunk's path per chunk, the bytes staged when the chunk does not begin
+  // on a 16-byte boundary.  Correct for everything the chunk protocol is offered for; a call and several synchronisations per chunk.
+  int64_t total = 0;
+  for (int64_t k = 0; k < R.chunks(); ++k) {
+    const int64_t cs = k * R.S;
+    const bool full = k < R.kfull;
+    const size_t clen = (size_t)(full ? B : (int64_t)len - cs);
+    const uint8_t* d_chunk = d_block + cs;
+    if ((uintptr_t)d_chunk & 15) {
+      int rc = Ensure(&c->d_in, &c->in_cap, (int64_t)clen + 64);
+      if (rc != RGX_OK) return rc;
+      HIP_TRY(hipMemcpyAsync(c->d_in, d_chunk, clen, hipMemcpyDeviceToDevice, c->stream));
+      d_chunk = c->d_in;
+    }
+    const int64_t nrep = OneChunkDevice(p, c, d_chunk, clen, full, ML, &ms);
+    if (nrep < 0) return nrep;
+    if (d_spans && nrep > 0) {
+      if (total + nrep > (int64_t)cap_records) {
+        // (count on, so that the caller learns how many rows the run has)
+      } else {
+        const long long items = nrep * (ncap / 2);
+        hipLaunchKernelGGL(chunk_rows_rebase_kernel, dim3((unsigned)((items + 255) / 256)), dim3(256), 0, c->stream, c->d_out, (long long)nrep, ncap,
+                           (int32_t)cs, d_spans + total * ncap);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(c->stream));      // (the next chunk overwrites c->d_out)
+      }
+    }
+    total += nrep;
+  }
+  if (res) { res->rows = total; res->mode = 2; res->kernel_ms = ms; }
+  if (d_spans && total > (int64_t)cap_records) { SetError("span capacity too small"); return RGX_E_CAPACITY; }
+  return total;
+}
+}  // namespace
+
+extern "C" int64_t rgx_internal_find_chunks(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_block, size_t len, int64_t B, int64_t ML, int final,
+                                            int32_t* d_spans, size_t cap_records, rgx_chunks_result* res) {
+  return FindChunksDevice(p, c, d_block, len, B, ML, final, d_spans, cap_records, res);
+}
+RGX_API int64_t rgx_find_chunks_device(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_block, size_t len, int64_t buffer_size,
+                                       int64_t max_leftover, int final, int32_t* d_spans, size_t cap_records, rgx_chunks_result* res) {
+  int rc = CheckCtx(p, c);
+  if (rc != RGX_OK) return rc;
+  if ((rc = RefuseStream(p)) != RGX_OK) return rc;
+  return FindChunksDevice(p, c, d_block, len, buffer_size, max_leftover, final, d_spans, cap_records, res);
+}
+RGX_API int64_t rgx_find_chunks(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* block, size_t len, int64_t buffer_size, int64_t max_leftover,
+                                int final, int32_t* spans, size_t cap_records, rgx_chunks_result* res) {
+  int rc = CheckCtx(p, c);
+  if (rc != RGX_OK) return rc;
+  if ((rc = RefuseStream(p)) != RGX_OK) return rc;
+  if ((!block && len) || (!spans && cap_records)) return RGX_E_INVALID;
+  const int ncap = p->p.dev.ncap;
+  if (len == 0) return FindChunksDevice(p, c, nullptr, 0, buffer_size, max_leftover, final, nullptr, 0, res);
+  // (the block and the run's rows in buffers of their own: the chunk-by-chunk path stages single chunks through d_in and keeps a chunk's
+  // rows in d_out)
+  if ((rc = Ensure(&c->d_blk, &c->blk_cap, (int64_t)len + 64)) != RGX_OK) return rc;
+  uint8_t* d_blk = c->d_blk;
+  if ((rc = Ensure(&c->d_rspans, &c->rspans_cap, (int64_t)cap_records * ncap + 16)) != RGX_OK) return rc;
+  HIP_TRY(hipMemcpyAsync(d_blk, block, len, hipMemcpyHostToDevice, c->stream));
+  rgx_chunks_result r{};
+  const int64_t w = FindChunksDevice(p, c, d_blk, len, buffer_size, max_leftover, final, spans ? c->d_rspans : nullptr, cap_records, &r);
+  if (res) *res = r;
+  if (w < 0) return w;
+  if (spans && w > 0) HIP_TRY(hipMemcpy(spans, c->d_rspans, (size_t)w * ncap * 4, hipMemcpyDeviceToHost));
+  return w;
 }
 
 RGX_API int64_t rgx_count_all_device_owned(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t own_lo,

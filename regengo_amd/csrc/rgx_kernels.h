@@ -37,7 +37,38 @@ struct ScanParams {
   uint32_t* census;              // nullable; persistent-workgroup kernels only: a residency census instead of a scan (LaunchScanUs) --
                                  // every workgroup reports in at [0], waits (bounded) for all gridDim.x of them, and counts itself at
                                  // [1] if it saw them all: [1] == gridDim.x <=> the whole grid was resident at the same time
+  // FindReader's chunk grid (streaming.go:175-244 with an always-fill reader; rgx.h: rgx_find_chunks_device): the buffer is a run of
+  // chunks that begin every `grid_stride` bytes (BufferSize - MaxLeftover).  Every chunk is a TEXT of its own: the FindAll chain
+  // restarts at each multiple of the stride up to `grid_free`, and a match is reported iff it ENDS at or before the next one (the
+  // reference defers the others to the next chunk, whose chain begins in their middle) -- except matches that start at or behind
+  // grid_free, the start of the run's last, short chunk, which reports everything (0x7FFFFFFF: every chunk is full).  0: no grid.
+  // rgx_scan_exact.hip and rgx_scan_fc.hip only (kGridMinStride: at most one boundary in reach of a tile).
+  int32_t grid_stride, grid_free;
 };
+constexpr int32_t kGridMinStride = 32768;
+// The same grid for the kernels that take it as a whole (rgx_tdfa.hip, the reader checks): bufsize = BufferSize, the length of a full chunk.
+struct ReaderGrid {
+  int32_t stride = 0, free_from = 0x7FFFFFFF, bufsize = 0;
+  int32_t own_hi = 0x7FFFFFFF;      // matches that start at or behind it belong to a chunk that is not part of this run (the bytes behind the last
+                                    // full chunk's keep point are only its look-ahead): not reported
+};
+// start of the chunk that owns a match starting at s; the end of that chunk's text (an attempt from s sees the end of the text there)
+__host__ __device__ inline int32_t GridChunkStart(int32_t s, const ReaderGrid& g) {
+  if (!g.stride) return 0;
+  if (s >= g.free_from) return g.free_from;
+  return (int32_t)(((uint32_t)s / (uint32_t)g.stride) * (uint32_t)g.stride);
+}
+__host__ __device__ inline int32_t GridTextEnd(int32_t s, int32_t len, const ReaderGrid& g) {
+  if (!g.stride || s >= g.free_from) return len;
+  const uint32_t e = ((uint32_t)s / (uint32_t)g.stride) * (uint32_t)g.stride + (uint32_t)g.bufsize;
+  return e < (uint32_t)len ? (int32_t)e : len;
+}
+// The offset at which the chunk that owns a match starting at s stops reporting (ScanParams::grid_stride): device and host.
+__host__ __device__ inline int32_t GridBound(int32_t s, int32_t stride, int32_t free_from) {
+  if (s >= free_from) return 0x7FFFFFFF;
+  const uint32_t b = ((uint32_t)s / (uint32_t)stride + 1u) * (uint32_t)stride;
+  return b > 0x7FFFFFFFu ? 0x7FFFFFFF : (int32_t)b;
+}
 
 // FindAllBytes scan: one pass over the input, ordered span records out.
 hipError_t LaunchScan(const DevTables& T, const ScanParams& P, hipStream_t stream);
@@ -192,13 +223,25 @@ hipError_t LaunchBatchMemoFix(const DevTables& T, const uint8_t* concat, const u
 hipError_t LaunchMemoReaderCheck(const DevTables& T, const uint8_t* raw, int32_t len, const int32_t* spans, int64_t n, int ncap,
                                  unsigned long long* visited, int W, unsigned long long* stack, int cap, int64_t nlanes, unsigned* flag, int final_pass,
                                  hipStream_t stream);
+// The same check over the rows of a chunk grid (rgx_kernels.hip: reader_grid_quick_kernel has the argument), programs without an empty-width
+// instruction only: the quick test lists the rows it cannot settle (list: n words, *nlist zeroed by the caller), the slow kernels replay
+// those (*flag |= 1: the loop diverges on one of them, or a lane ran out of budget / scratch).
+hipError_t LaunchReaderGridQuick(const DevTables& T, const uint8_t* view, const int32_t* spans, int64_t n, int ncap, ReaderGrid grid, uint32_t* list,
+                                 uint32_t* nlist, hipStream_t stream);
+hipError_t LaunchReaderGridSlow(const DevTables& T, const uint8_t* view, int32_t len, const int32_t* spans, int ncap, ReaderGrid grid, const uint32_t* list,
+                                uint32_t nlist, unsigned* flag, hipStream_t stream);
+hipError_t LaunchMemoReaderGridSlow(const DevTables& T, const uint8_t* raw, int32_t len, const int32_t* spans, int ncap, ReaderGrid grid, const uint32_t* list,
+                                    uint32_t nlist, unsigned long long* visited, int W, unsigned long long* stack, int cap, int64_t nlanes, unsigned* flag,
+                                    hipStream_t stream);
 // The Q4 half of LaunchReaderCheck alone (bytes.Index finds the match text earlier in the gap): any ordered span table.
-hipError_t LaunchReaderIndex(const uint8_t* raw, int32_t len, const int32_t* spans, int64_t n, int ncap, unsigned* flag, hipStream_t stream);
+hipError_t LaunchReaderIndex(const uint8_t* raw, int32_t len, const int32_t* spans, int64_t n, int ncap, unsigned* flag, hipStream_t stream,
+                             ReaderGrid grid = ReaderGrid());
 
 // ---- the reference's Tagged DFA (rgx_tdfa.hip; rgx_program.h: TdfaDev).  ends[len + 1]: end of the attempt at every start offset
 // from startStateAny (-1: none); flags: one uint32, bit 31 = a lane ran out of its step budget, bit 0 = look-back timeout.
 constexpr unsigned kTdfaOverBudget = 0x80000000u;       // == kOverBudgetBit (rgx_device_util.h, device side)
-hipError_t LaunchTdfaEnds(const TdfaDev& D, const uint8_t* buf, int32_t len, int32_t* ends, uint32_t* flags, hipStream_t stream);
+hipError_t LaunchTdfaEnds(const TdfaDev& D, const uint8_t* buf, int32_t len, int32_t* ends, uint32_t* flags, hipStream_t stream,
+                          ReaderGrid grid = ReaderGrid());
 // FindReader's chain over one buffer, serially (any program; max_n = 1: FindBytes): se[2i] = start (bit 31: attempt from
 // startStateBegin), se[2i + 1] = end; *out_n = matches
 // the FindAllBytes wrapper of a program with TdfaDev::any_never (a pattern that begins with ^): a chain of anchored attempts, one lane
@@ -212,13 +255,14 @@ hipError_t LaunchTdfaChainSerial(const TdfaDev& D, const uint8_t* buf, int32_t l
 int64_t TdfaSyncTiles(int32_t len);
 int64_t TdfaSlices(int32_t len);
 hipError_t LaunchTdfaSync(const int32_t* ends, int32_t len, unsigned long long* sync, unsigned long long* desc, uint32_t* flags,
-                          hipStream_t stream);
+                          hipStream_t stream, ReaderGrid grid = ReaderGrid());
 size_t TdfaScanTempBytes(int64_t n);
 hipError_t LaunchTdfaScan(const int32_t* counts, int32_t* offs, int64_t n, void* temp, size_t temp_bytes, hipStream_t stream);
 hipError_t LaunchTdfaChain(const int32_t* ends, int32_t len, const unsigned long long* sync, int32_t* counts, const int32_t* offs,
-                           int32_t* se, int64_t max_n, int emit, uint32_t* flags, hipStream_t stream);
+                           int32_t* se, int64_t max_n, int emit, uint32_t* flags, hipStream_t stream, ReaderGrid grid = ReaderGrid());
 // rows[n][ntags]: the reported tags of every match of se (tdfa.go:998-1052: (-1, -1) = group left untouched)
-hipError_t LaunchTdfaTags(const TdfaDev& D, const uint8_t* buf, int32_t len, const int32_t* se, int64_t n, int32_t* rows, hipStream_t stream);
+hipError_t LaunchTdfaTags(const TdfaDev& D, const uint8_t* buf, int32_t len, const int32_t* se, int64_t n, int32_t* rows, hipStream_t stream,
+                          ReaderGrid grid = ReaderGrid());
 // FindAllBytes of Tagged-DFA programs as the emitted wrapper computes it (compiler.go:602-655, quirk Q11; rgx_tdfa.hip has the method):
 // the index over ends[] (accepting offsets per 64, the next slice with one, the longest step), the tiles' maps + their composition
 // (tent / tbase / *total), the (start, end) of the rows.

@@ -2648,7 +2648,7 @@ __global__ __launch_bounds__(256) void reader_check_kernel(DevTables T, const ui
 // behind the piece's first offset comes from one binary search; rows advance with the offsets.
 constexpr int kIdxPiece = 128;
 __global__ __launch_bounds__(256) void reader_index_kernel(const uint8_t* raw, int32_t len, const int32_t* spans, long long n, int ncap,
-                                                           unsigned* flag) {
+                                                           unsigned* flag, ReaderGrid grid) {
   const long long j = (long long)blockIdx.x * 256 + threadIdx.x;
   bool bad = false;
   const long long a = j * kIdxPiece;
@@ -2665,6 +2665,10 @@ __global__ __launch_bounds__(256) void reader_index_kernel(const uint8_t* raw, i
     while (i < n && q < b && !bad) {
       const int s = spans[i * ncap], e = spans[i * ncap + 1], m = e - s;
       const int stop = s < b ? s : b;
+      if (grid.stride) {             // (a chunk grid: the loop searched chunk[searchPos:] -- nothing in front of the match's own chunk)
+        const int cs = GridChunkStart(s, grid);
+        if (q < cs) q = cs < stop ? cs : stop;
+      }
       if (m > 0) {
         const uint8_t c0 = raw[s];
         for (; q < stop; ++q) {
@@ -2690,7 +2694,7 @@ hipError_t LaunchReaderCheck(const DevTables& T, const uint8_t* raw, const uint8
   if (n > 0 && len > 0) {
     const long long pieces = ((long long)len + kIdxPiece - 1) / kIdxPiece;
     hipLaunchKernelGGL(reader_index_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, stream, raw, len, spans, (long long)n,
-                       ncap, flag);
+                       ncap, flag, ReaderGrid());
   }
   return hipGetLastError();
 }
@@ -2799,10 +2803,130 @@ hipError_t LaunchMemoReaderCheck(const DevTables& T, const uint8_t* raw, int32_t
   return LaunchReaderIndex(raw, len, spans, n, ncap, flag, stream);
 }
 
-hipError_t LaunchReaderIndex(const uint8_t* raw, int32_t len, const int32_t* spans, int64_t n, int ncap, unsigned* flag, hipStream_t stream) {
+namespace {
+// ---- FindReader's loop against the rows of a CHUNK GRID (rgx.h: rgx_find_chunks_device; ScanParams::grid_stride), for programs WITHOUT an
+// empty-width instruction that cannot match empty.  Row i is a reported match (s, e) of the chunk that owns s -- the text chunk[cs, ce) --
+// and the loop reached it from p = the end of the chunk's previous reported match, or the chunk's first byte.  What reader_check_kernel
+// asks of a gap shrinks, for such a program, to ONE thing:
+//   context  there is none: an attempt does not look at the byte in front of it, nor at the end of the text unless it walks there;
+//   Q4       bytes.Index cannot find the match's text earlier in the gap: the path that matched it needs nothing but those bytes, so an
+//            attempt at the copy would have matched too -- and FindAllBytes found no match that starts in the gap;
+//   Q1       the attempt offsets p, fail(p) + 1, ... must land ON s.  Every attempt in the gap fails (same argument), and an attempt that is
+//            made at or in front of a reset byte dies on it at the latest -- its failure offset is that byte's or smaller -- so when the
+//            byte in front of s is one, the sequence steps onto s whatever it did before; so it does when s == p.  (The attempt AT s
+//            then matches as FindAllBytes' did: the memoising engine's visited vector is per attempt, rgx_memo.h.)
+// reader_grid_quick_kernel settles a row by that test (one byte load) or lists it; the listed rows are replayed by
+// reader_grid_slow_kernel / memo_reader_grid_slow_kernel, the bodies of reader_check_kernel / memo_reader_check_kernel on the chunk's text.
+__global__ __launch_bounds__(256) void reader_grid_quick_kernel(const uint8_t* reset_byte, const uint8_t* view, const int32_t* spans, long long n,
+                                                                int ncap, ReaderGrid grid, uint32_t* list, uint32_t* nlist) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int s = spans[i * ncap];
+  const int cs = GridChunkStart(s, grid);
+  int p = cs;
+  if (i > 0 && spans[(i - 1) * ncap] >= cs) p = spans[(i - 1) * ncap + 1];
+  if (s == p || reset_byte[view[s - 1]]) return;
+  list[atomicAdd(nlist, 1u)] = (uint32_t)i;
+}
+
+__global__ __launch_bounds__(256) void reader_grid_slow_kernel(DevTables T, const uint8_t* view, int32_t len, const int32_t* spans, int ncap,
+                                                               ReaderGrid grid, const uint32_t* list, uint32_t nlist, unsigned* flag) {
+  const uint32_t j = blockIdx.x * 256 + threadIdx.x;
+  bool bad = false;
+  if (j < nlist) {
+    const long long i = list[j];
+    const int s0 = spans[i * ncap];
+    const int cs = GridChunkStart(s0, grid), tl = GridTextEnd(s0, len, grid) - cs;
+    const uint8_t* const text = view + cs;
+    int p = 0;
+    if (i > 0 && spans[(i - 1) * ncap] >= cs) p = spans[(i - 1) * ncap + 1] - cs;
+    const int s = s0 - cs;
+    int off = p;
+    if (s - p > kReaderBack) {
+      off = -1;
+      if (T.reset_values)
+        for (int q = s - 1; q >= s - kReaderBack; --q)
+          if (T.reset_byte[text[q]]) { off = q + 1; break; }
+      if (off < 0) bad = true;
+    }
+    int steps = 0;
+    while (!bad && off < s) {
+      const int fo = RmFailOffset(T, 0, text, tl, off);
+      if (!(tl > fo) || ++steps > kReaderSteps) { bad = true; break; }
+      off = fo + 1;
+    }
+    if (off != s) bad = true;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+__global__ __launch_bounds__(64) void memo_reader_grid_slow_kernel(DevTables T, MemoDev M, const uint8_t* raw, int32_t len, const int32_t* spans, int ncap,
+                                                                   ReaderGrid grid, const uint32_t* list, uint32_t nlist,
+                                                                   unsigned long long* visited, int W, unsigned long long* stack, int cap, unsigned* flag) {
+  const long long lane = (long long)blockIdx.x * 64 + threadIdx.x;
+  const long long nlanes = (long long)gridDim.x * 64;
+  const MemoScratch S{visited + lane * W, W, stack + lane * cap, cap};
+  bool bad = false;
+  for (long long j = lane; j < (long long)nlist && !bad; j += nlanes) {
+    const long long i = list[j];
+    const int s0 = spans[i * ncap];
+    const int cs = GridChunkStart(s0, grid), tl = GridTextEnd(s0, len, grid) - cs;
+    const uint8_t* const text = raw + cs;
+    int p = 0;
+    if (i > 0 && spans[(i - 1) * ncap] >= cs) p = spans[(i - 1) * ncap + 1] - cs;
+    const int s = s0 - cs, e = spans[i * ncap + 1] - cs;
+    long long budget = kReaderSteps * 64ll;
+    int mend = 0;
+    // (s > p: the quick test settles s == p.)  The attempt at p, on the slice chunk[p:] -- it fails; then the sequence up to s; then the
+    // attempt at s, which has to match with FindAllBytes' end.  A lane that runs out of scratch or budget does not vouch for the call.
+    const int a0 = MemoAttempt(M, text + p, tl - p, 0, S, &mend, &budget);
+    if (a0 < 0 || !(tl - p > a0)) { bad = true; break; }           // (kMemoMatched / kMemoGaveUp are negative)
+    int off = a0 + 1 + p;
+    if (s - off > kReaderBack) {
+      off = -1;
+      if (T.reset_values)
+        for (int q = s - 1; q >= s - kReaderBack; --q)
+          if (T.reset_byte[text[q]]) { off = q + 1; break; }
+      if (off < 0) { bad = true; break; }
+    }
+    if (off > s) { bad = true; break; }
+    int at = 0;
+    const int r = MemoReplay(M, text + p, tl - p, off - p, s - p, S, &budget, &at);
+    if (r != s - p) { bad = true; break; }
+    const int am = MemoAttempt(M, text + p, tl - p, s - p, S, &mend, &budget);
+    if (am != kMemoMatched || mend + p != e) bad = true;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+}  // namespace
+
+hipError_t LaunchReaderGridQuick(const DevTables& T, const uint8_t* view, const int32_t* spans, int64_t n, int ncap, ReaderGrid grid, uint32_t* list,
+                                 uint32_t* nlist, hipStream_t stream) {
+  if (n <= 0) return hipSuccess;
+  hipLaunchKernelGGL(reader_grid_quick_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, stream, T.reset_byte, view, spans, (long long)n, ncap,
+                     grid, list, nlist);
+  return hipGetLastError();
+}
+hipError_t LaunchReaderGridSlow(const DevTables& T, const uint8_t* view, int32_t len, const int32_t* spans, int ncap, ReaderGrid grid, const uint32_t* list,
+                                uint32_t nlist, unsigned* flag, hipStream_t stream) {
+  if (nlist == 0) return hipSuccess;
+  hipLaunchKernelGGL(reader_grid_slow_kernel, dim3((nlist + 255) / 256), dim3(256), 0, stream, T, view, len, spans, ncap, grid, list, nlist, flag);
+  return hipGetLastError();
+}
+hipError_t LaunchMemoReaderGridSlow(const DevTables& T, const uint8_t* raw, int32_t len, const int32_t* spans, int ncap, ReaderGrid grid, const uint32_t* list,
+                                    uint32_t nlist, unsigned long long* visited, int W, unsigned long long* stack, int cap, int64_t nlanes, unsigned* flag,
+                                    hipStream_t stream) {
+  if (nlist == 0) return hipSuccess;
+  hipLaunchKernelGGL(memo_reader_grid_slow_kernel, dim3((unsigned)(nlanes / 64)), dim3(64), 0, stream, T, *T.memo, raw, len, spans, ncap, grid, list, nlist,
+                     visited, W, stack, cap, flag);
+  return hipGetLastError();
+}
+
+hipError_t LaunchReaderIndex(const uint8_t* raw, int32_t len, const int32_t* spans, int64_t n, int ncap, unsigned* flag, hipStream_t stream,
+                             ReaderGrid grid) {
   if (n <= 0 || len <= 0) return hipSuccess;
   const long long pieces = ((long long)len + kIdxPiece - 1) / kIdxPiece;
-  hipLaunchKernelGGL(reader_index_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, stream, raw, len, spans, (long long)n, ncap, flag);
+  hipLaunchKernelGGL(reader_index_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, stream, raw, len, spans, (long long)n, ncap, flag, grid);
   return hipGetLastError();
 }
 

@@ -294,6 +294,14 @@ __global__ __launch_bounds__(kExactThreads) void scan_exact_kernel(DevTables T, 
     if (LAG && lane == 63) cur = 0;
     unsigned long long s_sel = owner ? cur : 0ull;
     bool slow = P.carry_in != nullptr;
+    // FindReader's chunk grid (ScanParams::grid_stride): gb = the first chunk start at or behind the tile's first byte, when a candidate of this
+    // tile can reach it -- the chain restarts there and a candidate that straddles it is deferred (never reported by this chunk; the
+    // next chunk begins in its middle).  At most one in reach (kGridMinStride); such a tile resolves its chain lane by lane.
+    int gb = 0x7FFFFFFF;                                      // uniform
+    if (P.grid_stride) {
+      const int first = GridBound(tb0 <= 0 ? 0 : tb0 - 1, P.grid_stride, 0x7FFFFFFF);      // the first chunk start at or behind tb0
+      if (first <= P.grid_free && first < tb0 + kWaveRows * kSliceBytes + K) { gb = first; slow = true; }
+    }
     if (K > 1 && smin < K && !slow) {
       // candidates of the previous slice within K-1 positions of a: bit u <-> position a-(K-1)+u
       const unsigned pt = prev_hi >> (33 - K);
@@ -315,6 +323,15 @@ __global__ __launch_bounds__(kExactThreads) void scan_exact_kernel(DevTables T, 
       bool synced = true;
       if (carried >= 0) {
         pos = carried;
+      } else if (gb >= a - 64 && gb <= a) {
+        // a chunk begins in the slice before (or right here): its chain starts at gb, whatever lies in front of it
+        pos = gb;
+        unsigned long long m = gb == a ? 0ull : (prev & (~0ull << (gb - (a - 64))));
+        while (m) {
+          const int s = a - 64 + __builtin_ctzll(m);
+          m &= m - 1;
+          if (s >= pos) pos = s + K;
+        }
       } else if (a > 0 && K > 1) {
         // x = a is a sync point iff no candidate starts in [a-K+1, a)
         if (prev >> (65 - K)) {
@@ -350,7 +367,13 @@ __global__ __launch_bounds__(kExactThreads) void scan_exact_kernel(DevTables T, 
           const int b = __builtin_ctzll(m);
           m &= m - 1;
           const int s = a + b;
-          if (s >= pos) { s_sel |= 1ull << b; pos = s + K; }
+          if (s >= pos) {
+            // (grid: a match in front of gb that ends behind it takes its place in the chain -- nothing it covers is reported -- but is
+            // itself deferred, and the chain of the chunk that begins at gb starts there)
+            const int e = s + K, lim = s < gb ? gb : 0x7FFFFFFF;
+            if (e <= lim) s_sel |= 1ull << b;
+            pos = e < lim ? e : lim;
+          }
         }
       }
     }

@@ -84,6 +84,7 @@ struct FcParams {
   int32_t b_bytes, rows_off, rec_off, ops_bytes, ovf_off;
   int32_t K, ncap;
   uint32_t flags;
+  int32_t grid_stride, grid_free;  // ScanParams::grid_*: FindReader's chunk grid (0: none)
 };
 constexpr uint32_t kFcCountOnly = 1, kFcStartsOnly = 2, kFcTickets = 4, kFcFixedCaps = 8, kFcCtxSens = 16, kFcMinus1 = 32, kFcCarry = 64;
 
@@ -370,6 +371,14 @@ __global__ __launch_bounds__(kFcThreads) __attribute__((amdgpu_waves_per_eu(MODE
     const int tb = tile * kFcOwnBytes;                         // first owned byte
     const int wb = tb - kFcHalo * kSliceBytes;                 // first byte of the window (negative for tile 0)
     const bool active = tile_active(tile);                     // uniform
+    // FindReader's chunk grid: the first chunk start behind the window's first byte (at most one is in reach of a tile's candidates and
+    // their walks: kGridMinStride).  A candidate in front of it covers nothing behind it -- the chain restarts there -- and is reported
+    // only when its match ends at or before it (the reference defers the others: streaming.go:204-210).
+    int gb = 0x7FFFFFFF;                                        // uniform
+    if (P.grid_stride) {
+      const int first = GridBound(wb <= 0 ? 0 : wb, P.grid_stride, 0x7FFFFFFF);
+      if (first <= P.grid_free) gb = first;
+    }
     if (active) {
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -646,17 +655,21 @@ __global__ __launch_bounds__(kFcThreads) __attribute__((amdgpu_waves_per_eu(MODE
       // candidates (of a round) as if nothing reached into them from an earlier stretch; whether something did is known behind the barrier.
       // Stretch r * waves + w = the candidates of wave w in round r: the list in position order.
       bool acc[kFcRounds] = {false, false};
+      // (grid: what a match covers ends at its chunk's end; whether it is reported is decided by its real end)
+      int cv[kFcRounds];
+#pragma unroll
+      for (int r = 0; r < kFcRounds; ++r) cv[r] = (sr[r] < gb && er[r] > gb) ? gb : er[r];
 #pragma unroll
       for (int r = 0; r < kFcRounds; ++r) {
         const bool ok = er[r] >= 0;
-        const int incl = FcWaveScanMax(ok ? er[r] : 0, lane);
+        const int incl = FcWaveScanMax(ok ? cv[r] : 0, lane);
         int excl = __shfl_up(incl, 1, 64);
         if (lane == 0) excl = 0;
         const int M = P0 > excl ? P0 : excl;
         acc[r] = ok && sr[r] >= M;
         const unsigned long long okb = __ballot(ok);
         if (__ballot(ok && sr[r] < M) != 0ull && lane == 0) misc[3] = 1;
-        mine[r] = acc[r] && sr[r] >= tb && sr[r] >= P.own_lo && sr[r] < P.own_hi;     // (s < tb + own: lanes of the owned slices only)
+        mine[r] = acc[r] && sr[r] >= tb && sr[r] >= P.own_lo && sr[r] < P.own_hi && cv[r] == er[r];     // (s < tb + own: lanes of the owned slices only)
         mb[r] = __ballot(mine[r]);
         if (lane == 0) {                                           // one 16-byte word per stretch: rows, largest end, first successful start
           uint4 q;
@@ -691,7 +704,7 @@ __global__ __launch_bounds__(kFcThreads) __attribute__((amdgpu_waves_per_eu(MODE
         int* const cs = reinterpret_cast<int*>(rows);
         int* const ce = cs + kFcCap;
 #pragma unroll
-        for (int r = 0; r < kFcRounds; ++r) { cs[tid + r * kFcThreads] = sr[r]; ce[tid + r * kFcThreads] = er[r]; }
+        for (int r = 0; r < kFcRounds; ++r) { cs[tid + r * kFcThreads] = sr[r]; ce[tid + r * kFcThreads] = cv[r]; }
         __syncthreads();
         if (tid == 0) {
           int pos = P0;
@@ -706,7 +719,7 @@ __global__ __launch_bounds__(kFcThreads) __attribute__((amdgpu_waves_per_eu(MODE
 #pragma unroll
         for (int r = 0; r < kFcRounds; ++r) {
           acc[r] = er[r] >= 0 && ce[tid + r * kFcThreads] >= 0;
-          mine[r] = acc[r] && sr[r] >= tb && sr[r] >= P.own_lo && sr[r] < P.own_hi;
+          mine[r] = acc[r] && sr[r] >= tb && sr[r] >= P.own_lo && sr[r] < P.own_hi && cv[r] == er[r];
           mb[r] = __ballot(mine[r]);
           if (lane == 0) misc[16 + 4 * (r * kFcWaves + wave)] = (unsigned)__popcll(mb[r]);
         }
@@ -856,6 +869,7 @@ hipError_t LaunchScanFc(const DevTables& T, const ScanParams& S, int mode, hipSt
   P.len = S.len; P.ntiles = S.ntiles; P.own_lo = S.own_lo; P.own_hi = S.own_hi;
   P.b_bytes = F.b_bytes; P.rows_off = F.rows_off; P.rec_off = F.rec_off; P.ops_bytes = F.ops_bytes; P.ovf_off = F.ovf_off;
   P.K = K; P.ncap = T.ncap;
+  P.grid_stride = S.grid_stride; P.grid_free = S.grid_free;
   P.flags = (S.count_only ? kFcCountOnly : 0u) | (S.starts_only ? kFcStartsOnly : 0u) | (S.use_tickets ? kFcTickets : 0u) |
             (T.fixed_captures ? kFcFixedCaps : 0u) | (T.ctx_sensitive ? kFcCtxSens : 0u) | (T.unmatched_minus1 ? kFcMinus1 : 0u) |
             (T.reset_values == 0 ? kFcCarry : 0u);

@@ -39,6 +39,8 @@ extern "C" void rgx_internal_ctx_prefer_tickets(rgx_stream_ctx* c);      // rgx_
 extern "C" int64_t rgx_internal_find_all_owned(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n,
                                                int32_t* d_spans, size_t cap_records, int64_t own_lo, int64_t own_hi, int starts_only,
                                                rgx_result* res);
+extern "C" int64_t rgx_internal_find_chunks(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_block, size_t len, int64_t B, int64_t ML, int final,
+                                            int32_t* d_spans, size_t cap_records, rgx_chunks_result* res);      // rgx_capi.cc: FindChunksDevice
 extern "C" int rgx_internal_find_all_submit(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n,
                                             int32_t* d_spans, size_t cap_records, int64_t own_lo, int64_t own_hi, int starts_only);
 
@@ -309,6 +311,38 @@ int RunJob(Slot& s) {
     HIP_TRY(hipMemcpyAsync(s.d_in, w.buf, w.len, hipMemcpyHostToDevice, st));
     d_buf = s.d_in;
   }
+  if (w.reader_buffer_size > 0) {
+    // A run of FindReader chunks (rgx.h: rgx_shard_window::reader_buffer_size): every chunk start is the beginning of a text, so the window
+    // needs no halo and nothing of it can be unsynced or truncated -- ranks own chunk ranges.  Rows: rgx_find_chunks_device's.
+    rgx_chunks_result cr{};
+    int32_t* d_spans = w.d_spans;
+    size_t cap_records = w.cap_records;
+    const int ncap = sh.info.ncap;
+    int64_t c = 0;
+    for (int attempt = 0;; ++attempt) {
+      if (j.count_only) { d_spans = nullptr; cap_records = 0; }
+      else if (!w.d_spans) {
+        size_t want = attempt ? cap_records : w.len / (size_t)std::max(sh.info.min_match_len, 8) + 1024;
+        want = std::min(want, w.len / (size_t)std::max(sh.info.min_match_len, 1) + 16);
+        if (s.spans_cap < want || !s.d_spans) {
+          if (s.d_spans) (void)hipFree(s.d_spans);
+          s.d_spans = nullptr; s.spans_cap = 0;
+          if (hipMalloc((void**)&s.d_spans, (want + 16) * (size_t)ncap * 4) != hipSuccess) { (void)hipGetLastError(); SetError("out of device memory (span table)"); return RGX_E_NOMEM; }
+          s.spans_cap = want;
+        }
+        d_spans = s.d_spans; cap_records = s.spans_cap;
+      }
+      c = rgx_internal_find_chunks(sh.prog, s.ctx, d_buf, w.len, w.reader_buffer_size, w.reader_max_leftover, w.last, d_spans, cap_records, &cr);
+      if (c == RGX_E_CAPACITY && !w.d_spans && !j.count_only && attempt == 0) { cap_records = (size_t)cr.rows + 16; continue; }
+      break;
+    }
+    if (c < 0) return (int)c;
+    r.count = c;
+    r.d_rows = j.count_only ? nullptr : d_spans;
+    r.base = w.base;
+    r.kernel_ms = cr.kernel_ms;
+    return RGX_OK;
+  }
   // the left halo has to hold a sync point, unless the window begins where the FindAll chain is known anyway.  The check (and the right
   // halo's) is queued in front of the scan and read behind it: a window whose left halo turns out to hold none is scanned for nothing
   // (rare: the caller widens the halo and hands it in again) -- every other window saves a host round trip with the GPU idle
@@ -389,7 +423,7 @@ void SlotMain(Slot* s) {
 // the slot's thread takes it.  Errors are kept in the slot's result and surface at the wait.
 bool TryAsync(Shard& sh, Slot& s, const Job& j) {
   static const bool off = [] { const char* e = getenv("RGX_SHARDED_NO_ASYNC"); return e && *e == '1'; }();
-  if (off || !j.have || j.count_only || j.w.is_host) return false;
+  if (off || !j.have || j.count_only || j.w.is_host || j.w.reader_buffer_size > 0) return false;      // (a run of reader chunks: the slot's thread)
   const rgx_shard_window& w = j.w;
   if (w.own_lo < 0 || w.own_hi < w.own_lo || (size_t)w.own_hi > w.len) return false;
   if (hipSetDevice(sh.device) != hipSuccess) return false;

@@ -125,7 +125,7 @@ __device__ __forceinline__ typename Tab<LDS>::P StageEnt(const TdfaDev& D, uint3
 
 // ---------------------------------------------------------------- ends: one lane per start offset
 template <bool LDS>
-__global__ __launch_bounds__(256) void tdfa_ends_kernel(TdfaDev D, const uint8_t* buf, int32_t len, int32_t* ends, uint32_t* flags) {
+__global__ __launch_bounds__(256) void tdfa_ends_kernel(TdfaDev D, const uint8_t* buf, int32_t len, int32_t* ends, uint32_t* flags, ReaderGrid grid) {
   extern __shared__ uint32_t smem[];
   typename Tab<LDS>::P ent = StageEnt<LDS>(D, smem);
   const uint32_t fl = D.sinfo_any;
@@ -137,7 +137,8 @@ __global__ __launch_bounds__(256) void tdfa_ends_kernel(TdfaDev D, const uint8_t
     // (first byte by hand: nearly every lane ends here)
     if (p < len) {
       const uint32_t c = buf[p];
-      if ((fl & 3u) || (c < 128u && !(ent[(uint32_t)st * 128u + c] & kTDead))) e = AttemptEnd(ent, buf, len, (int)p, st, fl, &steps);
+      // (FindReader's chunk grid: the attempt is made in the chunk that owns p, whose text ends where the chunk ends -- acceptStatesEOT)
+      if ((fl & 3u) || (c < 128u && !(ent[(uint32_t)st * 128u + c] & kTDead))) e = AttemptEnd(ent, buf, GridTextEnd((int)p, len, grid), (int)p, st, fl, &steps);
     } else if (fl & 3u) {
       e = AttemptEnd(ent, buf, len, (int)p, st, fl, &steps);
     }
@@ -218,8 +219,15 @@ __global__ __launch_bounds__(64) void tdfa_q11_anchored_kernel(TdfaDev D, const 
 // same one).  Written as a bit per offset: sync[x / 64] bit x % 64.  Tiles of 16384 offsets, 64 per lane; the running maximum
 // crosses tiles by decoupled look-back (descriptor: 2-bit status | max + 1).
 constexpr int kSyncTile = 16384;
+// (FindReader's chunk grid: a match covers nothing behind the end of its chunk -- the chain restarts there -- so its end counts as
+// min(end, GridBound(start)) here and in the chain, and every chunk start comes out a sync point.)
+__device__ __forceinline__ int GridCover(int p, int e, const ReaderGrid& g) {
+  if (!g.stride || e < 0) return e;
+  const int b = GridBound(p, g.stride, g.free_from);
+  return e < b ? e : b;
+}
 __global__ __launch_bounds__(256) void tdfa_sync_kernel(const int32_t* ends, int32_t len, unsigned long long* sync,
-                                                        unsigned long long* desc, uint32_t* flags) {
+                                                        unsigned long long* desc, uint32_t* flags, ReaderGrid grid) {
   __shared__ int wave_max[4];
   __shared__ int tile_excl;
   const int tile = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -227,7 +235,7 @@ __global__ __launch_bounds__(256) void tdfa_sync_kernel(const int32_t* ends, int
   // this lane's 64 ends: running maximum inside the slice
   int lmax = -1;
   // (two passes over the slice instead of 64 registers: the second re-reads L2-hot lines)
-  for (int k = 0; k < 64; ++k) { const long long p = base + k; if (p <= len) { const int v = ends[p]; lmax = v > lmax ? v : lmax; } }
+  for (int k = 0; k < 64; ++k) { const long long p = base + k; if (p <= len) { const int v = GridCover((int)p, ends[p], grid); lmax = v > lmax ? v : lmax; } }
   // exclusive running maximum across the lanes of the workgroup
   int incl = lmax;
 #pragma unroll
@@ -284,7 +292,7 @@ __global__ __launch_bounds__(256) void tdfa_sync_kernel(const int32_t* ends, int
     const long long p = base + k;
     if (p > len) break;
     if (run <= (int)p) bits |= 1ull << k;
-    const int v = ends[p];
+    const int v = GridCover((int)p, ends[p], grid);
     run = v > run ? v : run;
   }
   if (base <= len) sync[base >> 6] = bits;
@@ -294,7 +302,7 @@ __global__ __launch_bounds__(256) void tdfa_sync_kernel(const int32_t* ends, int
 // stretch), T = the first sync point at or behind the next slice.  emit == 0: counts[l] = matches; emit == 1: writes them behind
 // offs[l] (exclusive sum of the counts).
 __global__ __launch_bounds__(256) void tdfa_chain_kernel(const int32_t* ends, int32_t len, const unsigned long long* sync, int32_t* counts,
-                                                         const int32_t* offs, int32_t* se, long long max_n, int emit, uint32_t* flags) {
+                                                         const int32_t* offs, int32_t* se, long long max_n, int emit, uint32_t* flags, ReaderGrid grid) {
   const long long l = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long nslices = ((long long)len + 1 + 63) >> 6;     // offsets 0 .. len
   if (l >= nslices) return;
@@ -319,10 +327,15 @@ __global__ __launch_bounds__(256) void tdfa_chain_kernel(const int32_t* ends, in
       e = ends[s];
       if (++steps > kLaneStepBudget) break;
     }
-    if (e < 0 || s >= T) break;
-    if (emit) { if (row < max_n) { se[2 * row] = s; se[2 * row + 1] = e; } ++row; }
-    ++cnt;
-    cur = e > s ? e : cur + 1;
+    if (e < 0 || s >= T || s >= grid.own_hi) break;
+    // (grid: a match that ends behind its chunk is deferred -- the reference's loop breaks there, streaming.go:204-210 -- and the next
+    // chunk's chain begins at the chunk's end, a sync point: this lane's stretch is over)
+    const int ce = GridCover(s, e, grid);
+    if (ce == e) {
+      if (emit) { if (row < max_n) { se[2 * row] = s; se[2 * row + 1] = e; } ++row; }
+      ++cnt;
+    }
+    cur = ce > s ? ce : cur + 1;
   }
   if (steps > kLaneStepBudget) atomicOr(flags, kOverBudgetBit);
   if (!emit) counts[l] = cnt;
@@ -331,7 +344,7 @@ __global__ __launch_bounds__(256) void tdfa_chain_kernel(const int32_t* ends, in
 // ---------------------------------------------------------------- tags: one lane per match
 template <bool LDS>
 __global__ __launch_bounds__(256) void tdfa_tags_kernel(TdfaDev D, const uint8_t* buf, int32_t len, const int32_t* se, long long n,
-                                                        int32_t* rows) {
+                                                        int32_t* rows, ReaderGrid grid) {
   extern __shared__ uint32_t smem[];
   typename Tab<LDS>::P ent = StageEnt<LDS>(D, smem);
   int TDFA_LDS* tags = (int TDFA_LDS*)(smem + (LDS ? D.nstates * 128 : 0)) + threadIdx.x;
@@ -340,7 +353,7 @@ __global__ __launch_bounds__(256) void tdfa_tags_kernel(TdfaDev D, const uint8_t
     const int s0 = se[2 * i], e = se[2 * i + 1];
     const bool begin = s0 < 0;                       // bit 31: the serial chain's attempt from startStateBegin
     const int s = s0 & 0x7FFFFFFF;
-    AttemptTags(ent, D.pool, buf, len, s, e, begin ? D.start_begin : D.start_any, begin ? D.init_begin : D.init_any, D.ntags, tags,
+    AttemptTags(ent, D.pool, buf, GridTextEnd(s, len, grid), s, e, begin ? D.start_begin : D.start_any, begin ? D.init_begin : D.init_any, D.ntags, tags,
                 rows + i * D.ntags, D.sinfo);
   }
 }
@@ -815,16 +828,16 @@ int GridFor(long long items, int per_block, int cap) {
 
 }  // namespace
 
-hipError_t LaunchTdfaEnds(const TdfaDev& D, const uint8_t* buf, int32_t len, int32_t* ends, uint32_t* flags, hipStream_t stream) {
+hipError_t LaunchTdfaEnds(const TdfaDev& D, const uint8_t* buf, int32_t len, int32_t* ends, uint32_t* flags, hipStream_t stream, ReaderGrid grid) {
   const bool lds = TdfaInLds(D, false);
   const size_t sh = TdfaShared(D, lds, false);
-  const int grid = GridFor((long long)len + 1, 256 * 16, 1 << 20);       // a workgroup stages the table once for 4096 offsets or more
+  const int nwg = GridFor((long long)len + 1, 256 * 16, 1 << 20);       // a workgroup stages the table once for 4096 offsets or more
   hipError_t rc;
   if (lds) {
     if ((rc = AllowLds(tdfa_ends_kernel<true>, sh)) != hipSuccess) return rc;
-    hipLaunchKernelGGL(tdfa_ends_kernel<true>, dim3(grid), dim3(256), sh, stream, D, buf, len, ends, flags);
+    hipLaunchKernelGGL(tdfa_ends_kernel<true>, dim3(nwg), dim3(256), sh, stream, D, buf, len, ends, flags, grid);
   } else {
-    hipLaunchKernelGGL(tdfa_ends_kernel<false>, dim3(grid), dim3(256), 0, stream, D, buf, len, ends, flags);
+    hipLaunchKernelGGL(tdfa_ends_kernel<false>, dim3(nwg), dim3(256), 0, stream, D, buf, len, ends, flags, grid);
   }
   return hipGetLastError();
 }
@@ -861,16 +874,16 @@ int64_t TdfaSyncTiles(int32_t len) { return ((int64_t)len + 1 + kSyncTile - 1) /
 int64_t TdfaSlices(int32_t len) { return ((int64_t)len + 1 + 63) / 64; }
 
 hipError_t LaunchTdfaSync(const int32_t* ends, int32_t len, unsigned long long* sync, unsigned long long* desc, uint32_t* flags,
-                          hipStream_t stream) {
-  hipLaunchKernelGGL(tdfa_sync_kernel, dim3((unsigned)TdfaSyncTiles(len)), dim3(256), 0, stream, ends, len, sync, desc, flags);
+                          hipStream_t stream, ReaderGrid grid) {
+  hipLaunchKernelGGL(tdfa_sync_kernel, dim3((unsigned)TdfaSyncTiles(len)), dim3(256), 0, stream, ends, len, sync, desc, flags, grid);
   return hipGetLastError();
 }
 
 hipError_t LaunchTdfaChain(const int32_t* ends, int32_t len, const unsigned long long* sync, int32_t* counts, const int32_t* offs,
-                           int32_t* se, int64_t max_n, int emit, uint32_t* flags, hipStream_t stream) {
+                           int32_t* se, int64_t max_n, int emit, uint32_t* flags, hipStream_t stream, ReaderGrid grid) {
   const int64_t ns = TdfaSlices(len);
   hipLaunchKernelGGL(tdfa_chain_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, ends, len, sync, counts, offs, se,
-                     (long long)max_n, emit, flags);
+                     (long long)max_n, emit, flags, grid);
   return hipGetLastError();
 }
 
@@ -1130,18 +1143,19 @@ hipError_t LaunchTdfaScan(const int32_t* counts, int32_t* offs, int64_t n, void*
   return hipcub::DeviceScan::ExclusiveSum(temp, temp_bytes, counts, offs, (int)n, stream);
 }
 
-hipError_t LaunchTdfaTags(const TdfaDev& D, const uint8_t* buf, int32_t len, const int32_t* se, int64_t n, int32_t* rows, hipStream_t stream) {
+hipError_t LaunchTdfaTags(const TdfaDev& D, const uint8_t* buf, int32_t len, const int32_t* se, int64_t n, int32_t* rows, hipStream_t stream,
+                          ReaderGrid grid) {
   if (n <= 0) return hipSuccess;
   const bool lds = TdfaInLds(D, true);
   const size_t sh = TdfaShared(D, lds, true);
-  const int grid = GridFor(n, 256 * 4, 1 << 16);
+  const int nwg = GridFor(n, 256 * 4, 1 << 16);
   hipError_t rc;
   if (lds) {
     if ((rc = AllowLds(tdfa_tags_kernel<true>, sh)) != hipSuccess) return rc;
-    hipLaunchKernelGGL(tdfa_tags_kernel<true>, dim3(grid), dim3(256), sh, stream, D, buf, len, se, (long long)n, rows);
+    hipLaunchKernelGGL(tdfa_tags_kernel<true>, dim3(nwg), dim3(256), sh, stream, D, buf, len, se, (long long)n, rows, grid);
   } else {
     if ((rc = AllowLds(tdfa_tags_kernel<false>, sh)) != hipSuccess) return rc;
-    hipLaunchKernelGGL(tdfa_tags_kernel<false>, dim3(grid), dim3(256), sh, stream, D, buf, len, se, (long long)n, rows);
+    hipLaunchKernelGGL(tdfa_tags_kernel<false>, dim3(nwg), dim3(256), sh, stream, D, buf, len, se, (long long)n, rows, grid);
   }
   return hipGetLastError();
 }

@@ -67,7 +67,8 @@ class Sharded:
 
     def _windows(self, windows):
         """windows: one entry per LOCAL shard: None, or a dict(buf=uint8 tensor on that device | bytes, own=(lo, hi), base=int,
-        starts_at_sync=bool, last=bool, starts_only=bool, out=int32 tensor [cap, ncap] ([cap] with starts_only) on that device | None)."""
+        starts_at_sync=bool, last=bool, starts_only=bool, reader=(BufferSize, MaxLeftover) | None, out=int32 tensor [cap, ncap] ([cap] with
+        starts_only) on that device | None)."""
         import torch
         arr = (_capi.ShardWindow * self.n_local)()
         keep = []
@@ -86,6 +87,8 @@ class Sharded:
             arr[i].starts_at_sync = 1 if w.get("starts_at_sync", False) else 0
             arr[i].last = 1 if w.get("last", False) else 0
             arr[i].starts_only = 1 if w.get("starts_only", False) else 0      # rows = int32 match starts (fixed-template programs)
+            if w.get("reader"):                                               # (BufferSize, MaxLeftover): the window is a run of FindReader chunks
+                arr[i].reader_buffer_size, arr[i].reader_max_leftover = int(w["reader"][0]), int(w["reader"][1])
             out = w.get("out")
             if out is not None:
                 arr[i].d_spans, arr[i].cap_records = out.data_ptr(), out.shape[0]

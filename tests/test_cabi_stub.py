@@ -65,7 +65,7 @@ def test_twin_without_a_device_keeps_the_go_path(stub, tmp_path):
     assert rc == 0
     lines = out.decode().splitlines()
     assert lines[0].startswith("INIT -5")                                # RGX_E_NO_DEVICE: <name>Prog stays nil, every method falls back
-    assert "abi 4 ncap 8 min 10 max 10 findall 1 stream 1 find 1 match 1 engine 0 flags 0 replace 1" in lines[1]
+    assert "abi 5 ncap 8 min 10 max 10 findall 1 stream 1 find 1 match 1 engine 0 flags 0 replace 1" in lines[1]
     rc, out = _run(stub, blob, b"x 2024-01-15 y", tmp_path, "findall")
     assert rc == 1 and out.startswith(b"INIT -5")
 

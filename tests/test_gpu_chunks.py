@@ -1,0 +1,301 @@
+"""GPU tier: FindReader over a RUN of chunks in one call (include/rgx.h: rgx_find_chunks_device) against the reference's FindReader
+(internal/compiler/streaming.go:85-255) as the oracle's C ports run it over the same stream (oracle/gen_c.py: m_find_reader,
+oracle/tdfa_c.py: t_find_reader -- both literal restatements of the read loop with a reader that fills the buffer, checked against
+oracle.engines.find_reader on the CPU tier: tests/test_oracle.py).  What is compared is what the callback sees: StreamOffset, ChunkIndex
+and every group's text position -- for the plain engine (Date: rgx_scan_exact.hip), the memoising engine (URL: rgx_scan_fc.hip) and the
+Tagged DFA (URLCapture: rgx_tdfa.hip), at 64 KiB / 1 MiB / 4 MiB buffers, matches that straddle a chunk's keep point (dropped, and the
+next chunk's loop starts in their middle) included."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+DATE = r"(?P<year>\d{4})-(?P<month>\d{2})-(?P<day>\d{2})"
+URL = r"(?P<full>(?P<proto>https?|ftp)://(?P<host>[\w.-]+)(?P<port>:\d+)?(?P<path>/[\w./-]*)?)"
+URLC = r"(?P<protocol>https?)://(?P<host>[\w\.-]+)(?::(?P<port>\d+))?(?P<path>/[\w\./]*)?"
+
+
+@pytest.fixture(scope="module")
+def torch_dev(built):
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU; there is no CPU fallback")
+    return torch
+
+
+def _oracle(pattern):
+    from oracle import engines as E
+    comp = E.Compiled(pattern)
+    if comp.tdfa is not None:
+        from oracle.tdfa_c import CTdfa
+        return CTdfa(pattern), comp
+    from oracle.gen_c import CMatcher
+    return CMatcher(pattern), comp
+
+
+def _resolved(comp, B, ML):
+    from oracle import engines as E
+    mb = E.min_buffer(comp.sel.max_len)
+    cfg = E.StreamConfig(B, ML)
+    assert cfg.validate(mb) is None
+    return cfg.apply_defaults(mb, E.default_max_leftover(comp.sel.max_len))
+
+
+def _same(dev_rows, chunks, S, exp, ncap, base=0, first_chunk=0):
+    """device rows (block-relative int32 [n, ncap]) against the oracle's callbacks (int64 [n, 3 + ncap]: StreamOffset, ChunkIndex, the
+    chunk's stream offset, chunk-relative spans).  A group that is empty on one side has to be empty on the other (an unset group reads
+    (0, 0) relative to the block here and relative to the slice there: `input[0:0]` either way); a Tagged-DFA row's -1 is -1."""
+    assert dev_rows.shape[0] == exp.shape[0], (dev_rows.shape, exp.shape)
+    if dev_rows.shape[0] == 0:
+        return
+    d = dev_rows.astype(np.int64)
+    assert np.array_equal(d[:, 0] + base, exp[:, 0]), "StreamOffset"
+    ck = np.minimum(d[:, 0] // S, chunks - 1) + first_chunk
+    assert np.array_equal(ck, exp[:, 1]), "ChunkIndex"
+    assert np.array_equal(d[:, 1] + base, exp[:, 2] + exp[:, 4]), "match end"
+    for g in range(1, ncap // 2):
+        da, db = d[:, 2 * g], d[:, 2 * g + 1]
+        ea, eb = exp[:, 3 + 2 * g], exp[:, 4 + 2 * g]
+        unset_e = (ea < 0) | (ea == eb)
+        unset_d = (da < 0) | (da == db)
+        assert np.array_equal(unset_e, unset_d), ("group %d: set on one side only" % g)
+        assert np.array_equal((ea < 0), (da < 0)), ("group %d: untouched on one side only" % g)
+        m = ~unset_e
+        assert np.array_equal(da[m] + base, exp[m, 2] + ea[m]) and np.array_equal(db[m] + base, exp[m, 2] + eb[m]), "group %d" % g
+
+
+CONFIGS = [(65536, 0), (1 << 20, 0), (4 << 20, 1 << 20), (65536 + 4096, 5000)]
+
+
+@pytest.mark.parametrize("pattern,mode", [(DATE, 1), (URL, 1), (URLC, 1)])
+def test_a_run_of_chunks_is_the_references_find_reader(torch_dev, pattern, mode):
+    """64 MiB of the web log: every callback of the reference's FindReader, at three buffer sizes.  The stream is NOT a whole number of
+    tiles of the corpus, so chunk edges fall everywhere; the last chunk is short and reports everything."""
+    torch = torch_dev
+    from regengo_amd import Compiled, synth
+    from regengo_amd.stream import Config
+    cm, comp = _oracle(pattern)
+    c = Compiled(pattern).to(0)
+    assert c.info.ref_stream_offered == 1
+    tile = synth.web_log_tile(1 << 20)
+    n = (64 << 20) + 12345
+    host = np.frombuffer((tile * 65)[:n], dtype=np.uint8)
+    dev = torch.from_numpy(host.copy()).cuda()
+    for B, ML in CONFIGS:
+        rc = _resolved(comp, B, ML)
+        cfg = c._resolve(Config(B, ML))
+        assert (cfg.BufferSize, cfg.MaxLeftover) == (rc.BufferSize, rc.MaxLeftover)
+        exp = cm.find_reader_np(host, rc.BufferSize, rc.MaxLeftover)
+        rows, res = c.FindChunksDevice(dev, cfg, final=True)
+        S = cfg.BufferSize - cfg.MaxLeftover
+        assert res.mode == mode, (pattern, B, ML, res.mode)
+        assert res.next_from == n and res.chunks == (n - cfg.BufferSize) // S + 2
+        _same(rows.cpu().numpy(), int(res.chunks), S, exp, c.ncap)
+        # the count-only form
+        _, r2 = c.FindChunksDevice(dev, cfg, final=True, count_only=True)
+        assert r2.rows == exp.shape[0]
+        # (what the run drops: FindAllBytes over the stream has more rows -- the straddlers)
+    spans, _ = Compiled(pattern, stdlib=True).to(0).FindAllSpans(dev[: 8 << 20])
+    rc = _resolved(comp, 65536, 0)
+    exp8 = cm.find_reader_np(host[: 8 << 20], rc.BufferSize, rc.MaxLeftover)
+    assert spans.shape[0] > exp8.shape[0], "the 64 KiB grid drops matches that straddle a keep point"
+
+
+@pytest.mark.parametrize("pattern", [DATE, URL, URLC])
+def test_runs_follow_each_other(torch_dev, pattern):
+    """A stream handed over as several runs (final = 0: the block ends somewhere behind the last full chunk, the next block begins at
+    next_from): the same callbacks as one run."""
+    torch = torch_dev
+    from regengo_amd import Compiled, synth
+    from regengo_amd.stream import Config
+    cm, comp = _oracle(pattern)
+    c = Compiled(pattern).to(0)
+    tile = synth.web_log_tile(1 << 20)
+    n = (9 << 20) + 777
+    host = np.frombuffer((tile * 10)[:n], dtype=np.uint8)
+    cfg = c._resolve(Config(256 << 10, 0))
+    S = cfg.BufferSize - cfg.MaxLeftover
+    exp = cm.find_reader_np(host, cfg.BufferSize, cfg.MaxLeftover)
+    got, base, first, pos = [], 0, 0, 0
+    block_bytes = (3 << 20) + 4321                      # not a whole number of chunks: the tail is carried into the next block
+    while True:
+        final = pos + block_bytes >= n
+        blk = host[pos: n if final else pos + block_bytes]
+        pad = (-blk.ctypes.data) % 16                   # (device blocks are 16-byte aligned; torch's allocations are)
+        dev = torch.from_numpy(blk.copy()).cuda()
+        rows, res = c.FindChunksDevice(dev, cfg, final=final)
+        r = rows.cpu().numpy().astype(np.int64)
+        ck = np.minimum(r[:, 0] // S, max(int(res.chunks) - 1, 0)) + first
+        got.append((r, ck, pos))
+        if final:
+            assert res.next_from == blk.size
+            break
+        assert res.next_from == res.chunks * S and res.chunks >= 1
+        pos += int(res.next_from)
+        first += int(res.chunks)
+    so = np.concatenate([r[:, 0] + p for r, _, p in got])
+    ck = np.concatenate([k for _, k, _ in got])
+    assert np.array_equal(so, exp[:, 0]) and np.array_equal(ck, exp[:, 1])
+    ends = np.concatenate([r[:, 1] + p for r, _, p in got])
+    assert np.array_equal(ends, exp[:, 2] + exp[:, 4])
+
+
+def test_chunk_edges_everywhere(torch_dev):
+    """Dates planted so that one straddles every possible offset of a keep point, candidates packed against each other (the exact kernel's
+    serial chain), and a stride that is not a multiple of anything: the exact kernel's grid against the oracle, edge by edge."""
+    torch = torch_dev
+    import random
+    from regengo_amd import Compiled
+    from regengo_amd.stream import Config
+    cm, comp = _oracle(DATE)
+    c = Compiled(DATE).to(0)
+    rng = random.Random(5)
+    for B, ML in [(65536, 1024), (65536 + 37, 1111), (70001, 33000)]:
+        cfg = c._resolve(Config(B, ML))
+        S = cfg.BufferSize - cfg.MaxLeftover
+        parts, size = [], 0
+        nchunks = 40
+        k = 1
+        while size < nchunks * S + 5000:
+            # a date (or a run of dates, or digits around one) that lies across the next keep point, at a random phase
+            target = k * S + rng.randrange(-12, 3)
+            fill = target - size
+            if fill > 0:
+                parts.append(bytes(rng.choice(b"abc \n-0123456789") if rng.random() < 0.2 else 0x20 for _ in range(fill)))
+                size += fill
+            w = rng.choice([b"2024-01-15", b"2024-01-152024-01-16", b"12024-01-15", b"2024-01-1", b"2024-01-15-2024-01-16", b"20242024-01-15"])
+            parts.append(w)
+            size += len(w)
+            k += 1
+        host = np.frombuffer(b"".join(parts), dtype=np.uint8)
+        exp = cm.find_reader_np(host, cfg.BufferSize, cfg.MaxLeftover)
+        dev = torch.from_numpy(host.copy()).cuda()
+        try:
+            rows, res = c.FindChunksDevice(dev, cfg, final=True)
+        except Exception as ex:          # RGX_E_DIVERGES: the restart rule steps over a date behind a digit (`12024-01-15`): legitimate, checked below
+            assert getattr(ex, "status", 0) == -11, ex
+            rows = None
+        if rows is not None:
+            _same(rows.cpu().numpy(), int(res.chunks), S, exp, c.ncap)
+        # under plain leftmost-first semantics nothing is refused: compare with the grid applied to FindAllBytes per chunk
+        cs = Compiled(DATE, stdlib=True).to(0)
+        rows, res = cs.FindChunksDevice(dev, cfg, final=True)
+        assert res.mode == 1
+        got = rows.cpu().numpy()
+        want = []
+        nch = int(res.chunks)
+        for j in range(nch):
+            lo = j * S
+            chunk = host[lo: lo + cfg.BufferSize]
+            full = chunk.size == cfg.BufferSize
+            r, _ = cm.find_all_np(np.ascontiguousarray(chunk))
+            for row in r:
+                if full and row[1] > chunk.size - cfg.MaxLeftover:
+                    break
+                want.append(row + lo)
+        want = np.array(want, dtype=np.int32).reshape(-1, c.ncap)
+        assert got.shape == want.shape and np.array_equal(got, want), (B, ML, got.shape, want.shape)
+
+
+@pytest.mark.parametrize("pattern", [r"\w+", r"(?P<k>id|took)=(?P<v>\w*)", r"\b\w+@\w+\b", r"^\d{4}", URL + r"(?P<extra>.*)?"])
+def test_other_programs_go_chunk_by_chunk_with_the_same_answers(torch_dev, pattern):
+    """Programs outside the grid kernels' reach (an assertion, no prefilter, suffix matches of `\\w+` behind a dropped straddler): mode 2,
+    the same callbacks -- or a refusal where rgx_find_chunk refuses."""
+    torch = torch_dev
+    from regengo_amd import Compiled, synth
+    from regengo_amd.stream import Config
+    from regengo_amd._capi import RgxError
+    cm, comp = _oracle(pattern)
+    c = Compiled(pattern).to(0)
+    host = np.frombuffer(synth.web_log_tile(1 << 20)[: 700000], dtype=np.uint8)
+    dev = torch.from_numpy(host.copy()).cuda()
+    cfg = c._resolve(Config(65536, 0))
+    S = cfg.BufferSize - cfg.MaxLeftover
+    try:
+        rows, res = c.FindChunksDevice(dev, cfg, final=True)
+    except RgxError as ex:
+        assert ex.status in (-3, -11), ex
+        return
+    exp = cm.find_reader_np(host, cfg.BufferSize, cfg.MaxLeftover)
+    _same(rows.cpu().numpy(), int(res.chunks), S, exp, c.ncap)
+
+
+@pytest.mark.parametrize("pattern", [DATE, URL, URLC])
+def test_find_reader_blocks_mirror(torch_dev, pattern):
+    """The host protocol (what the emitted FindReader does with rgx_find_chunks): the reference's reads appended to a block, a run per
+    block, the callbacks -- against oracle.engines.find_reader itself (pure Python: a small stream), the reused struct's fields of a
+    Tagged-DFA program included."""
+    import io
+    from oracle import engines as E
+    from regengo_amd import Compiled, synth
+    from regengo_amd.stream import Config
+    comp = E.Compiled(pattern)
+    c = Compiled(pattern).to(0)
+    data = synth.web_log_tile(1 << 20)[:300000]
+    for B, ML, blk in [(65536, 0, 200000), (65536, 1000, 1 << 20), (70000, 30000, 150000)]:
+        exp = []
+        pos = [0]
+
+        def read(k):
+            d = data[pos[0]:pos[0] + k]
+            pos[0] += len(d)
+            return d
+        assert comp.FindReader(read, E.StreamConfig(B, ML), lambda m: exp.append((m.StreamOffset, m.ChunkIndex, m.match_bytes, m.fields)) or True) is None
+        got = []
+        c.FindReaderBlocks(io.BytesIO(data), Config(B, ML), lambda m: got.append(m) or True, block_bytes=blk)
+        assert len(got) == len(exp), (pattern, B, ML, len(got), len(exp))
+        for g, e in zip(got, exp):
+            assert (g.StreamOffset, g.ChunkIndex, g.Result.Match) == e[:3], (pattern, B, ML, g.StreamOffset, e[:2])
+            if e[3] is not None:
+                assert [g.Result.CaptureByIndex(i) for i in range(len(e[3]))] == e[3], (pattern, g.StreamOffset)
+
+
+def test_sharded_rounds_of_reader_chunks(torch_dev):
+    """rgx_shard_window::reader_buffer_size: ranks own CHUNK RANGES of the stream -- no halo, nothing unsynced or truncated -- and the
+    rows of the rounds, in window order, are the reference's FindReader callbacks over the whole stream.  Two logical shards on one
+    device, windows of a different number of chunks each."""
+    torch = torch_dev
+    from regengo_amd import Compiled, synth
+    from regengo_amd.sharded import Sharded
+    from regengo_amd.stream import Config
+    cm, comp = _oracle(URL)
+    c = Compiled(URL).to(0)
+    n = (5 << 20) + 999
+    host = np.frombuffer((synth.web_log_tile(1 << 20) * 6)[:n], dtype=np.uint8)
+    dev = torch.from_numpy(host.copy()).cuda()
+    cfg = c._resolve(Config(128 << 10, 0))
+    B, ML = cfg.BufferSize, cfg.MaxLeftover
+    S = B - ML
+    exp = cm.find_reader_np(host, B, ML)
+    sh = Sharded(c, devices=[0, 0])
+    nchunks_total = (n - B) // S + 2
+    # windows of 7 and 5 chunks alternately
+    wins, k = [], 0
+    while k < nchunks_total:
+        take = min(7 if len(wins) % 2 == 0 else 5, nchunks_total - k)
+        last = k + take == nchunks_total
+        lo = k * S
+        hi = n if last else (k + take - 1) * S + B
+        wins.append((k, take, lo, hi, last))
+        k += take
+    so, ck = [], []
+    for i in range(0, len(wins), 2):
+        pair = wins[i:i + 2]
+        ws, outs = [], []
+        for (k0, take, lo, hi, last) in pair:
+            b = dev[lo:hi].clone()                                  # (a 16-byte aligned copy of the window)
+            out = torch.empty(((hi - lo) // 8 + 16, c.ncap), dtype=torch.int32, device="cuda")
+            outs.append(out)
+            ws.append(dict(buf=b, base=lo, last=last, reader=(B, ML), out=out))
+        while len(ws) < 2:
+            ws.append(None)
+        total, rs = sh.round(ws)
+        assert all(not r["unsynced"] and not r["truncated"] and r["status"] == 0 for r in rs), rs
+        for li, (k0, take, lo, hi, last) in enumerate(pair):
+            cnt = rs[li]["count"]
+            r = outs[li][:cnt].cpu().numpy().astype(np.int64)
+            so.append(r[:, 0] + lo)
+            ck.append(np.minimum(r[:, 0] // S, take - 1) + k0)
+    so, ck = np.concatenate(so), np.concatenate(ck)
+    assert np.array_equal(so, exp[:, 0]) and np.array_equal(ck, exp[:, 1])
+    sh.close()

@@ -208,3 +208,48 @@ def test_generated_c_matches_python_machine(corpus, built):
             assert cm.find(b) == o.find_machine.find(b), (e["pattern"], b)
             n += 1
     assert n > 300
+
+
+@pytest.mark.parametrize("pattern", [
+    r"(?P<year>\d{4})-(?P<month>\d{2})-(?P<day>\d{2})",                                                        # plain backtracking
+    r"(?P<full>(?P<proto>https?|ftp)://(?P<host>[\w.-]+)(?P<port>:\d+)?(?P<path>/[\w./-]*)?)",                # memoising
+    r"(?P<protocol>https?)://(?P<host>[\w\.-]+)(?::(?P<port>\d+))?(?P<path>/[\w\./]*)?",                      # Tagged DFA (URLCapture)
+    r"\w+",                                                                                                    # suffix matches behind a dropped straddler
+])
+def test_c_find_reader_equals_the_restated_loop(pattern):
+    """oracle/gen_c.py: m_find_reader and oracle/tdfa_c.py: t_find_reader -- the bulk checkers of the GPU tier's chunk runs
+    (tests/test_gpu_chunks.py) -- against oracle.engines.find_reader, the block-for-block restatement of streaming.go:85-255 that the
+    reference's literal streaming scenario pins (tests/golden/kats.json): the same callbacks (StreamOffset, ChunkIndex, spans) over a
+    stream of several chunks, at the default Config and at ones whose keep points fall elsewhere."""
+    import numpy as np
+    from oracle import engines as E
+    from regengo_amd import synth
+    comp = E.Compiled(pattern)
+    if comp.tdfa is not None:
+        from oracle.tdfa_c import CTdfa
+        cm = CTdfa(pattern)
+    else:
+        from oracle.gen_c import CMatcher
+        cm = CMatcher(pattern)
+    data = synth.web_log_tile(1 << 20)[:150000]
+    arr = np.frombuffer(data, dtype=np.uint8)
+    for B, ML in [(65536, 0), (65536, 100), (70000, 33000)]:
+        rows = []
+        pos = [0]
+
+        def read(k):
+            d = data[pos[0]:pos[0] + k]
+            pos[0] += len(d)
+            return d
+        assert comp.FindReader(read, E.StreamConfig(B, ML), lambda m: rows.append(m) or True) is None
+        rc = E.StreamConfig(B, ML).apply_defaults(E.min_buffer(comp.sel.max_len), E.default_max_leftover(comp.sel.max_len))
+        got = cm.find_reader_np(arr, rc.BufferSize, rc.MaxLeftover)
+        assert len(rows) == got.shape[0] and len(rows) > 100, (pattern, B, ML, len(rows), got.shape)
+        for m, g in zip(rows, got):
+            assert (m.StreamOffset, m.ChunkIndex) == (g[0], g[1])
+            # m.caps are relative to chunk[searchPos:]; the C rows to the chunk: the match's own start ties the two together
+            sp = int(g[3]) - m.caps[0]
+            want = [c + sp if c >= 0 else -1 for c in m.caps]
+            if comp.tdfa is None:
+                want = [c + sp for c in m.caps]
+            assert [int(x) for x in g[3:]] == want, (pattern, m.StreamOffset)
