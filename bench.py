@@ -870,15 +870,29 @@ def run_c4(env, args):
     value = float(Ltot) / (dt / nsteps) / 1e9
     k_ms = k_ms_sum / max(args.windows, 1)
     win_bytes = W + HALO_L + HALO_R
+    # ---- the same stream as the reference's FindReader reports it (round 6): windows that are RUNS OF CHUNKS of a stream.Config
+    # (rgx_shard_window::reader_buffer_size -> rgx_find_chunks_device).  This is the line's `value`; the FindAllBytes-semantics numbers
+    # above stay beside it (`value_findall_semantics`).
+    for w in wins:
+        w["buf"] = None
+    del wins[:]
+    torch.cuda.empty_cache()
+    rd = c4_reader_grid(env, args, c, sh, tile, A, U, Z, gen, outs, cap)
     achieved = win_bytes / (k_ms * 1e-3) / 1e9 if k_ms > 0 else 0.0
     traffic, tsrc = load_traffic("c4", KERNEL_SUBSTR.get(c.info.scan_kernel))
-    line = base_line(env, args, value, ms_per_step, reps)
-    line["config"] = {"workload": "C4: URL-with-alternation FindReader over a %.0f GiB stream, %d x ~%.1f GiB windows per GPU with halos, owned "
-                                  "round-robin by the ranks (C ABI: rgx_sharded_round_*), window-relative int32 rows + stream offsets" % (Ltot / 2**30, args.windows, W / 2**30),
-                      "semantics": "the reference's FindAllBytes over the whole stream (its FindReader would drop %s of 8992 matches per MiB tile at "
-                                   "BufferSize 64/128/256 KiB: those straddling dataLen - MaxLeftover of a chunk; not reproduced across GPUs -- "
-                                   "the per-chunk protocol is rgx_find_chunk's / rgx_count_chunk's, one GPU, the reference's FindReader or "
-                                   "refused: find_reader_reference_mode below)" % "/".join(str(C4_DROPPED_PER_MIB[k]) for k in sorted(C4_DROPPED_PER_MIB)),
+    line = base_line(env, args, rd["value"], rd["ms_per_step"], rd["reps"])
+    line["value_findall_semantics"] = {"value": round(value, 2), "ms_per_step": round(ms_per_step, 4), "repeats": reps,
+                                       "what": "FindAllBytes over the whole stream in windows with halos (rounds 2-5's c4 value): keeps the %s of 8992 matches per MiB "
+                                               "tile that the reference's FindReader drops at BufferSize 64/128/256 KiB" % "/".join(str(C4_DROPPED_PER_MIB[k]) for k in sorted(C4_DROPPED_PER_MIB))}
+    line["config"] = {"workload": "C4: URL-with-alternation FindReader over a %.0f GiB stream chunked with overlap (stream.Config{BufferSize %d, MaxLeftover %d}: chunk k = "
+                                  "stream[k * %d, +%d)), %d windows of %d chunks (~%.1f GiB) per GPU, chunk ranges owned round-robin by the ranks (C ABI: "
+                                  "rgx_sharded_round_* with rgx_shard_window::reader_buffer_size), window-relative int32 rows + stream offsets"
+                                  % (rd["stream_bytes"] / 2**30, rd["B"], rd["ML"], rd["S"], rd["B"], args.windows, rd["chunks_per_window"], rd["window_bytes"] / 2**30),
+                      "semantics": "the reference's FindReader (streaming.go:85-255) with a reader that fills the buffer: every chunk an independent text scanned by "
+                                   "FindBytesReuse on chunk[searchPos:], a match reported iff it ends at or before dataLen - MaxLeftover (all of them in the "
+                                   "stream's last chunk); the emitted loop's restart rule checked per gap on the device (reference mode)",
+                      "reader": rd["report"],
+                      "findall_semantics_config": "%d x ~%.1f GiB windows per GPU with halos %d / %d" % (args.windows, W / 2**30, HALO_L, HALO_R),
                       "pattern": URL, "stream_bytes": Ltot, "bytes_per_gpu": args.windows * W, "window_bytes": W,
                       "halo_left": HALO_L, "halo_right": HALO_R, "matches_total": int(stp["count"]), "expected_matches": int(exp_total),
                       "span_record_bytes": 4 * c.ncap, "parallelism": "window round-robin over %d rank(s)" % world,
@@ -889,19 +903,158 @@ def run_c4(env, args):
                       "gather_rows_checked": gather_ok,
                       "gather_offsets_ms": None if gather_offsets_ms is None else round(gather_offsets_ms, 3),
                       "gather_offsets_bytes_per_match": 8, "gather_bytes_per_match": 8 * c.ncap, "gather_offsets_checked": gather_offsets_ok}
-    line["roofline"] = {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
-                        "kernel": KERNEL_NAMES.get(c.info.scan_kernel, "rgx scan kernel"), "kernel_ms": round(k_ms, 4),
-                        "algorithmic_bytes_per_launch": win_bytes, "timed_launches": args.windows * nsteps1}
+    r_ach = rd["window_bytes"] / (rd["kernel_ms"] * 1e-3) / 1e9 if rd["kernel_ms"] > 0 else 0.0
+    line["roofline"] = {"bound": "hbm", "achieved": round(r_ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(r_ach / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": tsrc,
+                        "kernel": KERNEL_NAMES.get(c.info.scan_kernel, "rgx scan kernel"), "kernel_ms": round(rd["kernel_ms"], 4),
+                        "algorithmic_bytes_per_launch": rd["window_bytes"], "timed_launches": rd["timed_launches"],
+                        "kernel_ms_source": "HIP events around the scan kernel of a window's run of chunks, the timed region with ONE round in flight",
+                        "findall_semantics": {"achieved": round(achieved, 1), "frac": round(achieved / HBM_PEAK_GBS, 4), "kernel_ms": round(k_ms, 4),
+                                              "algorithmic_bytes_per_launch": win_bytes, "timed_launches": args.windows * nsteps1}}
+    line["value_one_round_in_flight"] = rd["one_round"]
     if depth > 1:
-        line["roofline"]["kernel_ms_source"] = "the timed region with ONE round in flight (below); with two in flight the windows' kernels overlap and an event-timed duration reads %.4f ms" % k_ms_overlapped
-        line["value_one_round_in_flight"] = {"value": round(float(Ltot) / (dt1 / nsteps1) / 1e9, 2), "ms_per_step": round(dt1 / nsteps1 * 1e3, 4), "steps": nsteps1}
+        line["value_findall_semantics"]["one_round_in_flight"] = {"value": round(float(Ltot) / (dt1 / nsteps1) / 1e9, 2), "ms_per_step": round(dt1 / nsteps1 * 1e3, 4), "steps": nsteps1}
     if rank == 0 and c.info.ref_stream_offered:
         line["config"]["find_reader_reference_mode"] = c4_reader_leg(c, tile, len(A), len(U), len(Z))
     if not args.no_cpu_baseline and world == 1:
         line["cpu_baseline"] = cpu_baseline_findall(URL, "c4", False)
     sh.close()
     return line
+
+
+def c4_reader_grid(env, args, c, sh, tile, A, U, Z, gen, outs, cap):
+    """C4 as the reference's FindReader: every rank's windows are runs of whole chunks of ONE stream.Config grid over the stream
+    (chunk k = stream[k * stride, k * stride + BufferSize), stride = BufferSize - MaxLeftover), answered by rgx_find_chunks_device behind
+    rgx_sharded_round_*.  Parity inside the run: (1) sampled tiles of every window against the oracle fixture's rows with the grid's
+    rule applied (a row is reported iff it ends at or before the next chunk start); (2) a run of ~64 MiB against the oracle's C port of the
+    read loop itself (oracle/gen_c.py: m_find_reader), every callback."""
+    import numpy as np
+    torch = env.torch
+    from regengo_amd.stream import Config
+    world, rank, dev = env.world, env.rank, env.dev
+    T = len(tile)
+    cfg = c._resolve(Config(args.reader_buffer, 0))
+    B, ML = cfg.BufferSize, cfg.MaxLeftover
+    S = B - ML
+    nW = max((int(args.window_gib * (1 << 30)) - B) // S + 1, 1)           # chunks per window
+    Wlen = (nW - 1) * S + B
+    nwin_total = args.windows * world
+    Ltot = (nwin_total * nW - 1) * S + B                                   # the stream ends with the last window's last full chunk (+ its leftover)
+    wins = []
+    for t in range(args.windows):
+        k = t * world + rank
+        lo = k * nW * S
+        wins.append(dict(k=k, lo=lo, buf=gen(lo, lo + Wlen), last=k == nwin_total - 1))
+    torch.cuda.synchronize()
+    stats = {}
+    cur_depth = [max(1, min(2, int(os.environ.get("RGX_C4_DEPTH", "2"))))]
+
+    def one_pass(on_rows=None):
+        count, kms, bad = 0, 0.0, 0
+        fifo, nsub, tnext = [], [0], 0
+
+        def submit(t):
+            w = wins[t]
+            slot = nsub[0] & 1
+            nsub[0] += 1
+            sh.submit([dict(buf=w["buf"], base=w["lo"], last=w["last"], reader=(B, ML), out=outs[slot])])
+            fifo.append((t, slot))
+
+        for t in range(args.windows):
+            while tnext < args.windows and tnext - t < cur_depth[0]:
+                submit(tnext)
+                tnext += 1
+            total, rs = sh.wait()
+            tt_, slot = fifo.pop(0)
+            me = rs[rank]
+            kms += me["kernel_ms"]
+            bad += sum(1 for r in rs if r["truncated"] or r["unsynced"] or r["status"] != 0)
+            if on_rows is not None:
+                on_rows(outs[slot][:me["count"]], wins[tt_])
+            count += total
+        stats.update(count=count, kernel_ms=kms, bad=bad)
+        return stats
+
+    def run_steps(k):
+        for _ in range(k):
+            one_pass()
+
+    dt, reps = sustained(env, run_steps, args.steps, args.warmup)
+    nsteps = args.steps * reps
+    cur_depth[0] = 1
+    dt1, reps1 = sustained(env, run_steps, args.steps, 1)
+    nsteps1 = args.steps * reps1
+    k_ms = stats["kernel_ms"] / max(args.windows, 1)
+    # ---- parity 1: sampled tiles of every window, fixture rows + the grid's rule
+    Ud, Ad = torch.from_numpy(U).to(dev), torch.from_numpy(A).to(dev)
+    ok = [True]
+    pieces = [0]
+
+    def shift(ref, by):
+        pairs = ref.view(ref.shape[0], -1, 2)
+        unset = (pairs[:, :, 0] == 0) & (pairs[:, :, 1] == 0)
+        unset[:, 0] = False
+        return torch.where(unset[:, :, None], pairs, pairs + by).view(ref.shape)
+
+    def on_rows(rows, w):
+        lo = w["lo"]
+        nch = nW + (1 if w["last"] else 0)
+        t_first = -(-lo // T)                                               # tiles wholly inside the window
+        t_last = (lo + Wlen) // T - 1
+        starts = rows[:, 0].contiguous()
+        for tix in sorted({t_first, t_first + 1, (t_first + t_last) // 2, t_last - 1}):
+            if tix == 0:
+                ref = Ad
+            else:
+                ref = shift(Ud, (tix - 1) * T - lo)
+            ck = torch.clamp(torch.div(ref[:, 0], S, rounding_mode="floor"), max=nch - 1)
+            bound = torch.where(ck == nch - 1 if w["last"] else torch.zeros_like(ck, dtype=torch.bool), torch.full_like(ck, 1 << 40), (ck + 1) * S)
+            keep = (ref[:, 1] <= bound) & (ref[:, 0] < (Wlen if w["last"] else nW * S))
+            ref = ref[keep]
+            a = int(torch.searchsorted(starts, torch.tensor([tix * T - lo], device=dev, dtype=starts.dtype))[0])
+            b = int(torch.searchsorted(starts, torch.tensor([(tix + 1) * T - lo], device=dev, dtype=starts.dtype))[0])
+            ok[0] &= bool(b - a == ref.shape[0] and torch.equal(rows[a:b].to(torch.int64), ref))
+            pieces[0] += 1
+
+    stp = dict(one_pass(on_rows=on_rows))
+    parity_tiles = bool(env.allmin_int(1 if ok[0] and stp["bad"] == 0 else 0))
+    # ---- parity 2 (rank 0): a run of 21 chunks (or fewer) against the C port of the reference's read loop, every callback
+    oracle = None
+    if rank == 0 and not args.no_cpu_baseline:
+        try:
+            from oracle.gen_c import CMatcher
+            nck = max(1, min(nW, (64 << 20) // S + 1))
+            Lo = (nck - 1) * S + B
+            stream = gen(0, Lo)
+            rows, res = c.FindChunksDevice(stream, cfg, final=True)
+            exp = CMatcher(URL).find_reader_np(stream.cpu().numpy(), B, ML)
+            r = rows.cpu().numpy().astype(np.int64)
+            same = r.shape[0] == exp.shape[0] and np.array_equal(r[:, 0], exp[:, 0]) and np.array_equal(r[:, 1], exp[:, 2] + exp[:, 4]) and \
+                np.array_equal(np.minimum(r[:, 0] // S, int(res.chunks) - 1), exp[:, 1])
+            for g in range(1, c.ncap // 2):
+                da, db, ea, eb = r[:, 2 * g], r[:, 2 * g + 1], exp[:, 3 + 2 * g], exp[:, 4 + 2 * g]
+                m = ea != eb
+                same = same and np.array_equal(m, da != db) and np.array_equal(da[m], exp[m, 2] + ea[m]) and np.array_equal(db[m], exp[m, 2] + eb[m])
+            allrows, _ = Compiled_stdlib_count(c, stream)
+            oracle = {"bytes": Lo, "chunks": int(res.chunks), "callbacks": int(exp.shape[0]), "device_rows": int(r.shape[0]), "identical": bool(same),
+                      "find_all_bytes_rows_over_the_same_bytes": allrows, "mode": int(res.mode)}
+        except Exception as e:
+            oracle = {"error": str(e)}
+    value = float(Ltot) / (dt / nsteps) / 1e9
+    report = {"buffer_size": B, "max_leftover": ML, "stride": S, "chunks_per_window": nW, "chunks_total": nwin_total * nW + 1,
+              "callbacks_total": int(stp["count"]), "parity_fixture_tiles_with_the_grid_rule": parity_tiles, "parity_pieces_checked": pieces[0],
+              "parity_oracle_read_loop": oracle, "rounds_in_flight": 2}
+    return dict(value=value, ms_per_step=dt / nsteps * 1e3, reps=reps, kernel_ms=k_ms, B=B, ML=ML, S=S, chunks_per_window=nW, window_bytes=Wlen,
+                stream_bytes=Ltot, timed_launches=args.windows * nsteps1, report=report,
+                one_round={"value": round(float(Ltot) / (dt1 / nsteps1) / 1e9, 2), "ms_per_step": round(dt1 / nsteps1 * 1e3, 4), "steps": nsteps1})
+
+
+def Compiled_stdlib_count(c, stream):
+    """rows of FindAllBytes (plain leftmost-first) over the same bytes: what the chunk grid drops shows in the difference"""
+    from regengo_amd import Compiled
+    cs = Compiled(c.pattern, stdlib=True).to(stream.device.index or 0)
+    n, _ = cs.CountAll(stream)
+    return int(n), None
 
 
 def c4_reader_leg(c, tile, na, nu, nz):
@@ -1420,6 +1573,7 @@ def main():
     ap.add_argument("--bytes", type=int, default=1 << 30, help="c2: shard size per GPU; c5: corpus size")
     ap.add_argument("--strings", type=int, default=10_000_000, help="c3: strings per GPU")
     ap.add_argument("--windows", type=int, default=5, help="c4: windows per GPU (default 5 x 1.6 GiB = 8 GiB per GPU)")
+    ap.add_argument("--reader-buffer", type=int, default=4 << 20, help="c4: stream.Config.BufferSize of the FindReader chunk grid (docs/streaming.md suggests 1-4 MiB; the default Config's 64 KiB works too)")
     ap.add_argument("--window-gib", type=float, default=1.6, help="c4: bytes per window in GiB (below 2: rows are window-relative int32)")
     ap.add_argument("--max-patterns", type=int, default=0, help="c5: only the first K patterns of the suite")
     ap.add_argument("--max-span-gib", type=int, default=48, help="c5: patterns whose span table would be larger are counted only")

@@ -84,7 +84,7 @@ def emit_c(prog: S.Prog, memo: bool, name: str = "m", q8: bool = True) -> str:
     w("static inline int is_word(uint8_t c){return (c>='0'&&c<='9')||(c>='A'&&c<='Z')||c=='_'||(c>='a'&&c<='z');}\n")
     w("typedef struct { int64_t off; int32_t pc; } frame_t;\n")
     if memo:
-        w("static int64_t* touched = 0; static int64_t ntouched = 0, captouched = 0;\n")
+        w("static __thread int64_t* touched = 0; static __thread int64_t ntouched = 0, captouched = 0;   /* (per thread: bench.py runs slices on all cores) */\n")
     # one attempt from `start`; captures in caps; returns 1 on match (offset in *end), else 0 (failure offset in *end)
     w("static int attempt(const uint8_t* input, int64_t l, int64_t start, int64_t* caps, int64_t* end,"
       " frame_t** stk, int64_t** cstk, int64_t* scap, uint32_t* visited) {\n")
