@@ -401,7 +401,13 @@ Tables BuildTables(const std::string& pattern, uint32_t flags, const BuildOption
       for (const Inst& in : prog.inst) {
         bool high = in.op == InstRuneAny || in.op == InstRuneAnyNotNL;
         if (in.op == InstRune1 || in.op == InstRune) for (int r : in.rune) high = high || r >= 128;
-        if (high) { t.ref_match_engine = 4; break; }
+        if (high && t.ref_match_engine == 1) t.ref_match_engine = 4;
+        // ... unless a literal beyond ASCII truncates to an ASCII byte: `c == byte(r)` (thompson.go InstRune1 and the one-rune class) makes
+        // U+0141 match 'A' (0x41), so not even an ASCII text is answered by plain existence -- the emitted function interpreted, always
+        // (`(\u0141+)+` on "A" is true in the reference)
+        const bool one_rune = in.op == InstRune1 || (in.op == InstRune && in.rune.size() == 2 && in.rune[0] == in.rune[1]) ||
+                              (in.op == InstRune && in.rune.size() == 1);
+        if (one_rune && !in.rune.empty() && in.rune[0] >= 128 && (in.rune[0] & 0xFF) < 128) { t.ref_match_engine = 3; break; }
       }
     // compiler.go:137-153: captures + nested quantifiers -> the Tagged DFA if it can be built, else the memoising backtracker
     const bool force_tdfa = (flags & (1u << 2)) != 0;          // RGX_FLAG_FORCE_TDFA = regengo.Options.ForceTDFA

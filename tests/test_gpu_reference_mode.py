@@ -146,7 +146,10 @@ def test_thompson_matcher_is_the_emitted_function(torch_dev):
              (r"(a+)+\bx", [b"aa x", b"aax", b"a x"], [False, False, False]),
              (r"(a+)+\b x", [b"aa x", b"aa  x"], [True, False]),
              (r"(?:a+.)+b", [b"aa\xc3\xa9b", b"aaxb", b"a\xffb"], [True, True, True]),
-             (r"(?:[^x]+y)+z", [b"\xc3\xa9yz", b"ayz"], [True, True]))
+             (r"(?:[^x]+y)+z", [b"\xc3\xa9yz", b"ayz"], [True, True]),
+             # a literal beyond ASCII is compared as byte(r): U+0141 matches 'A'  -- interpreted on ASCII texts too
+             ("(\u0141+)+", [b"A", b"b"], [False, False]),
+             ("(a\u0141+)+", [b"aA", b"a"], [False, False]))
     for pat, texts, go in cases:
         o = E.Compiled(pat)
         assert o.thompson is not None, pat

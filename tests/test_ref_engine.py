@@ -334,3 +334,18 @@ def test_reference_engines_on_random_patterns(built):
                     assert got == want, (p, b, got, want)
                     n["memo_match"] += 1
     assert n["pats"] >= 500 and n["ref_find"] >= 2500 and n["memo_find"] >= 50 and n["ref_match"] >= 3000 and n["thompson_dead"] >= 3 and n["thompson_high"] >= 5, n
+
+
+def test_thompson_literal_beyond_ascii_truncates_to_a_byte(built):
+    """the emitted Thompson matcher compares `c == byte(r)` (thompson.go: InstRune1 and the one-rune class), so U+0141
+    matches 'A' (0x41): such a program is the emitted function interpreted on EVERY text -- an ASCII text is not answered by plain
+    existence either (engine class 3, not 4)."""
+    from oracle import engines as E
+    from tests import _hosttest as H
+    for pat, texts in [("(Ł+)+", [b"A", b"AAA", b"b", "Ł".encode(), b""]), ("(aŁ+)+", [b"aA", b"a", b"aAA x", "aŁ".encode()]),
+                       ("(é+)+x", [b"x", "éx".encode(), b"\xe9x"])]:
+        o = E.Compiled(pat)
+        assert o.thompson is not None, pat
+        h = H.HostProgram(pat)
+        for b in texts:
+            assert h.ref_match(b) == (1 if o.MatchBytes(b) else 0), (pat, b, o.MatchBytes(b), h.ref_match(b))
