@@ -12,6 +12,7 @@
  *
  * usage: cabi_stub <tables.bin> <input file> <command> [args]      (results as text lines on stdout; exit 0 unless the plumbing broke)
  *   info | match | find | findall <n> | reader <bufsize> <maxleftover> <readsize> | count <bufsize> <maxleftover> <readsize> |
+ *   runs <bufsize> <maxleftover> <readsize> <blockbytes> [ndev] | countruns ... (FindReader over runs of chunks: rgx_find_chunks) |
  *   replace <template> <first_only> | sharded <ndev> <n>
  * Built with:  gcc -std=c99 -Wall -Wextra -Werror -pedantic -Iinclude tests/cabi_stub.c -Lregengo_amd/lib -lrgx_hip */
 #include <rgx.h>
@@ -224,6 +225,148 @@ static int find_reader(FILE* rd, long long bufsize, long long max_leftover, size
   return rc;
 }
 
+/* ---- FindReader over RUNS of chunks (round 6; the emitted <name>ReadRuns + FindReader): the reference's reads -- BufferSize bytes, then
+ * BufferSize - MaxLeftover at a time -- appended to ONE block while they come back full; a short read, EOF or a full block ends the run,
+ * and the run's chunks are answered by one rgx_find_chunks call (several devices: a rgx_sharded_round of chunk ranges + the gather of
+ * the rows).  Same MATCH / FIELD lines as `reader`. */
+typedef struct run_state { int32_t* spans; size_t cap; long long count; int32_t held[128]; int have[64]; uint8_t* prev; int ndev; int count_only; } run_state;
+static long long run_rows(rgx_stream_ctx* ctx, uint8_t* block, size_t fill, rgx_stream_config cfg, int final, int nchunks, run_state* st) {
+  const long long B = cfg.buffer_size, ML = cfg.max_leftover, S = B - ML;
+  rgx_chunks_result cr;
+  long long w;
+  if (g_sharded && nchunks >= 2 * st->ndev && !st->count_only) { /* <name>ShardedRun: ranks (here: devices) own chunk ranges */
+    rgx_shard_window wins[8];
+    rgx_shard_round rounds[8];
+    const int per = (nchunks + st->ndev - 1) / st->ndev;
+    long long total;
+    int i;
+    memset(wins, 0, sizeof wins);
+    for (i = 0; i < st->ndev; i++) {
+      const int k0 = i * per, k1 = k0 + per < nchunks ? k0 + per : nchunks;
+      size_t lo, hi;
+      if (k0 >= k1) continue;
+      lo = (size_t)k0 * (size_t)S;
+      hi = (size_t)(k1 - 1) * (size_t)S + (size_t)B;
+      if (k1 == nchunks || hi > fill) hi = fill;
+      wins[i].buf = block + lo; wins[i].len = hi - lo; wins[i].base = (int64_t)lo; wins[i].is_host = 1;
+      wins[i].last = (final && k1 == nchunks) ? 1 : 0;
+      wins[i].reader_buffer_size = B; wins[i].reader_max_leftover = ML;
+    }
+    total = rgx_sharded_round(g_sharded, wins, 0, 0, rounds);
+    if (total >= 0) {
+      int64_t* rows64 = (int64_t*)malloc(((size_t)total + 1) * (size_t)g_ncap * 8);
+      const int64_t n = rgx_sharded_gather(g_sharded, 0, NULL, rows64, (size_t)total, NULL);
+      long long j;
+      if (n == total) {
+        if ((size_t)n > st->cap) { st->cap = (size_t)n; st->spans = (int32_t*)realloc(st->spans, st->cap * (size_t)g_ncap * 4 + 16); }
+        for (j = 0; j < n * g_ncap; j++) st->spans[j] = (int32_t)rows64[j];
+        free(rows64);
+        printf("SHARDEDRUN %d chunks %d\n", st->ndev, nchunks);
+        return n;
+      }
+      free(rows64);
+    }
+    /* (any failure: one device is still right) */
+  }
+  for (;;) {
+    w = rgx_find_chunks(g_prog, ctx, block, fill, B, ML, final, st->count_only ? NULL : st->spans, st->count_only ? 0 : st->cap, &cr);
+    if (w == RGX_E_CAPACITY && (size_t)cr.rows > st->cap) {
+      st->cap = (size_t)cr.rows;
+      st->spans = (int32_t*)realloc(st->spans, st->cap * (size_t)g_ncap * 4 + 16);
+      continue;
+    }
+    return w;
+  }
+}
+static int find_reader_runs(FILE* rd, long long bufsize, long long max_leftover, size_t read_size, long long block_bytes, int ndev, int count_only) {
+  rgx_stream_config in, cfg;
+  run_state st;
+  rgx_stream_ctx* ctx;
+  uint8_t* block;
+  long long B, ML, S, nmax, stream_offset = 0;
+  size_t leftover = 0;
+  int chunk_index = 0, rc, done = 0;
+  in.buffer_size = bufsize; in.max_leftover = max_leftover;
+  rc = rgx_stream_config_resolve(g_prog, &in, &cfg);
+  if (rc != RGX_OK) { printf("CONFIG_ERROR %d %s\n", rc, rgx_status_str(rc)); return 0; }
+  B = cfg.buffer_size; ML = cfg.max_leftover; S = B - ML;
+  nmax = (block_bytes - B) / S + 1;
+  if (nmax < 1) nmax = 1;
+  block = (uint8_t*)malloc((size_t)((nmax - 1) * S + B));
+  memset(&st, 0, sizeof st);
+  st.cap = (size_t)((nmax - 1) * S + B) / 64 + 1024;
+  st.spans = (int32_t*)malloc(st.cap * (size_t)g_ncap * 4 + 16);
+  st.prev = (uint8_t*)calloc((size_t)B, 1);
+  st.ndev = ndev; st.count_only = count_only;
+  ctx = get_ctx();
+  if (!ctx) return RGX_E_NO_DEVICE;
+  while (!done) {
+    size_t fill = leftover;
+    long long nfull = 0, w, i;
+    int final = 0, nchunks;
+    while (nfull < nmax) { /* the reference's reads, one per chunk: rd.Read(buf[leftover:]) */
+      size_t want = (size_t)(nfull * S + B) - fill, ask = want, n;
+      if (read_size && ask > read_size) ask = read_size;
+      n = fread(block + fill, 1, ask, rd);
+      if (n == 0 && feof(rd)) { final = fill - (size_t)(nfull * S) > 0; done = 1; break; }
+      fill += n;
+      if (n < want) { final = 1; break; } /* a short read: this chunk is not full (streaming.go:177) */
+      nfull++;
+    }
+    nchunks = (int)nfull + (final ? 1 : 0);
+    if (fill > 0 && nchunks > 0) {
+      w = run_rows(ctx, block, fill, cfg, final, nchunks, &st);
+      if (w < 0) { /* findReaderChunkGo would take the run's chunks one by one; the twin can only say so */
+        printf("GOFALLBACK %lld run at chunk %d (%d chunks)\n", w, chunk_index, nchunks);
+      } else if (count_only) {
+        st.count += w;
+      } else {
+        for (i = 0; i < w; i++) {
+          const int32_t* c = st.spans + i * g_ncap;
+          long long k = c[0] / S;
+          size_t lo, clen;
+          if (k > nchunks - 1) k = nchunks - 1;
+          lo = (size_t)(k * S);
+          clen = fill - lo < (size_t)B ? fill - lo : (size_t)B;
+          printf("MATCH %lld %d %.*s\n", stream_offset + c[0], chunk_index + (int)k, (int)(c[1] - c[0]), (const char*)block + c[0]);
+          if (g_info.ref_find_engine == 1 && !(g_info.flags & RGX_FLAG_STDLIB_SEMANTICS)) {
+            /* the reused struct's fields are slices of the reference's ONE buffer, which holds chunk k now: a field an earlier match set
+             * shows what lies at its offsets in THIS chunk (behind a short chunk's end: what the chunk before left there) */
+            const uint8_t* before = lo >= (size_t)S ? block + lo - (size_t)S : st.prev;
+            int g;
+            for (g = 0; g < g_ncap / 2 && g < 64; g++) {
+              if (c[2 * g] >= 0) { st.held[2 * g] = c[2 * g] - (int32_t)lo; st.held[2 * g + 1] = c[2 * g + 1] - (int32_t)lo; st.have[g] = 1; }
+              if (st.have[g]) {
+                int x;
+                printf("FIELD %d ", g);
+                for (x = st.held[2 * g]; x < st.held[2 * g + 1]; x++) putchar((size_t)x < clen ? block[lo + (size_t)x] : before[x]);
+                putchar('\n');
+              } else printf("FIELD %d <nil>\n", g);
+            }
+          }
+        }
+        st.count += w;
+      }
+    }
+    if (done) break;
+    if (nfull > 0) memcpy(st.prev, block + (size_t)((nfull - 1) * S), (size_t)B);
+    stream_offset += nfull * S;
+    if (final) { /* behind a short read the reference zeroes leftover and does not advance streamOffset past the short chunk (241-244) */
+      memcpy(st.prev, block + (size_t)(nfull * S), fill - (size_t)(nfull * S));
+      leftover = 0;
+      chunk_index += (int)nfull + 1;
+    } else {
+      leftover = fill - (size_t)(nfull * S);
+      memmove(block, block + (size_t)(nfull * S), leftover);
+      chunk_index += (int)nfull;
+    }
+  }
+  printf("COUNT %lld\n", st.count);
+  put_ctx(ctx);
+  free(block); free(st.spans); free(st.prev);
+  return 0;
+}
+
 /* ---- <name>Replace ---------------------------------------------------------------------------------------------------------------- */
 static int replace_all(const uint8_t* input, size_t len, const char* tmpl, int first_only) {
   rgx_stream_ctx* ctx = get_ctx();
@@ -278,6 +421,7 @@ int main(int argc, char** argv) {
   cmd = argv[3];
   if (!blob || !input) { fprintf(stderr, "cannot read inputs\n"); return 2; }
   if (strcmp(cmd, "sharded") == 0 && argc > 4) ndev = atoi(argv[4]);
+  if ((strcmp(cmd, "runs") == 0 || strcmp(cmd, "countruns") == 0) && argc > 8) ndev = atoi(argv[8]);
   rc = init(blob, blob_len, devices, ndev);
   if (strcmp(cmd, "info") == 0) {
     /* works without a device: the blob loads, rgx_program_to_device says RGX_E_NO_DEVICE and the Go path stays */
@@ -326,6 +470,12 @@ int main(int argc, char** argv) {
     FILE* rd = fopen(argv[2], "rb");
     if (argc < 7) return 2;
     rc = find_reader(rd, atoll(argv[4]), atoll(argv[5]), (size_t)atoll(argv[6]), strcmp(cmd, "count") == 0);
+    fclose(rd);
+    if (rc < 0) printf("ERROR %d\n", rc);
+  } else if (strcmp(cmd, "runs") == 0 || strcmp(cmd, "countruns") == 0) { /* runs <bufsize> <maxleftover> <readsize> <blockbytes> [ndev] */
+    FILE* rd = fopen(argv[2], "rb");
+    if (argc < 8) return 2;
+    rc = find_reader_runs(rd, atoll(argv[4]), atoll(argv[5]), (size_t)atoll(argv[6]), atoll(argv[7]), ndev, strcmp(cmd, "countruns") == 0);
     fclose(rd);
     if (rc < 0) printf("ERROR %d\n", rc);
   } else if (strcmp(cmd, "replace") == 0) {

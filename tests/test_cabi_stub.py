@@ -209,3 +209,51 @@ def test_twin_replace_match_find(stub, tmp_path):
         rc, out = _run(stub, blob, s, tmp_path, "find")
         e = o.FindBytes(s)
         assert out.decode().strip() == ("NOTFOUND" if e is None else "ROW " + " ".join(map(str, e))), s
+
+
+def _matches(out: bytes):
+    got, cur = [], None
+    for l in out.decode("latin-1").splitlines():
+        if l.startswith("MATCH"):
+            p = l.split(" ", 3)
+            cur = (int(p[1]), int(p[2]), p[3], [])
+            got.append(cur)
+        elif l.startswith("FIELD"):
+            cur[3].append(l.split(" ", 2)[2] if len(l.split(" ", 2)) > 2 else "")
+    return got
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pattern,name", [(DATE, "Date"), (URL_CAPTURE, "U")])
+def test_twin_find_reader_in_runs_of_chunks(stub, tmp_path, kats, pattern, name):
+    """The emitted FindReader of round 6 (<name>ReadRuns + rgx_find_chunks): the same MATCH / FIELD lines as the chunk-by-chunk loop it
+    replaces (`reader`: rgx_find_chunk per chunk), for full reads, for a reader that returns 4000 bytes at a time, for blocks of one,
+    three and many chunks, over one device and cut across two (rgx_sharded_round with reader windows + rgx_sharded_gather) -- and the
+    reference's literal streaming vector at its literal offsets."""
+    from regengo_amd import synth
+    sb = kats["streaming_boundary"]
+    data = bytearray(sb["fill"].encode() * sb["total_size"])
+    for pos, d in zip(sb["positions"], sb["dates"]):
+        data[pos:pos + len(d)] = d.encode()
+    blob, _ = _tables(tmp_path, pattern, name)
+    for what, stream in (("vector", bytes(data)), ("weblog", synth.web_log_tile(1 << 20)[:700001])):
+        if what == "vector" and pattern != DATE:
+            continue
+        for bufsize, ml in ((65536, 0), (70000, 20000)):
+            for read_size in (0, 4000):
+                rc, ref = _run(stub, blob, stream, tmp_path, "reader", bufsize, ml, read_size)
+                assert rc == 0 and b"GOFALLBACK" not in ref
+                want = _matches(ref)
+                assert len(want) > 3
+                for block, ndev in ((1, 1), (200000, 1), (64 << 20, 1), (64 << 20, 2), (300000, 2)):
+                    rc, out = _run(stub, blob, stream, tmp_path, "runs", bufsize, ml, read_size, block, ndev)
+                    assert rc == 0 and b"GOFALLBACK" not in out, out[-200:]
+                    assert _matches(out) == want, (what, bufsize, ml, read_size, block, ndev)
+                    assert out.splitlines()[-1] == ref.splitlines()[-1]                       # COUNT
+                    if ndev == 2 and read_size == 0 and block > (1 << 20) and len(stream) > 4 * bufsize:
+                        assert b"SHARDEDRUN 2" in out
+                rc, out = _run(stub, blob, stream, tmp_path, "countruns", bufsize, ml, read_size, 64 << 20, 1)
+                assert out.splitlines()[-1] == ref.splitlines()[-1]
+        if what == "vector" and pattern == DATE:
+            rc, out = _run(stub, blob, stream, tmp_path, "runs", sb["buffer_size"], 0, 0, 64 << 20, 1)
+            assert [m[0] for m in _matches(out)] == sb["positions"]

@@ -82,7 +82,9 @@ def test_emitted_text_is_well_formed(built, name, pattern):
         need |= {"rgx_find_all_bytes"}
         assert "rgx_sharded_find_all_bytes" not in used
     if info.ref_stream_offered:
-        need |= {"rgx_find_chunk", "rgx_count_chunk"}
+        # FindReader hands the device RUNS of chunks (round 6); several devices: a round of chunk ranges + the gather of the rows
+        need |= {"rgx_find_chunks", "rgx_sharded_round", "rgx_sharded_gather"}
+        assert "reader_buffer_size" in code and "runtime.Pinner" in code
     if info.ref_replace_offered:
         need |= {"rgx_replace_all_bytes", "rgx_transform_chunk"}
     assert need <= used, need - used
@@ -187,8 +189,10 @@ def test_capacity_retry_comes_before_the_fallback(built):
     body = text[text.index("func (r Date) FindAllBytesAppend("):]
     assert body.index("w == C.RGX_E_CAPACITY") < body.index("if w < 0 {")
     # a (0, nil) read with nothing left over is not the end of the stream (streaming.go:123-175)
-    loop = text[text.index("func dateReadLoop("):]
-    assert "if err == io.EOF {\n\t\t\t\treturn nil" in loop and "continue" in loop
+    # (the run loop: such a read is a chunk that is not full -- nothing to hand down, the chunk index moves on, the loop reads again)
+    loop = text[text.index("func dateReadRuns("):text.index("func dateRunRows(")]
+    assert "if n == 0 && err != nil {" in loop and "if n < want {" in loop and "chunkIndex += nfull + 1" in loop
+    assert "if nfull > 0 || (final && fill > 0) {" in loop and "return rerr" in loop
 
 
 def test_precompiled_replacers(built):
