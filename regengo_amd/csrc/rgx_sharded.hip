@@ -149,7 +149,8 @@ __global__ __launch_bounds__(256) void rows_to_global_kernel(const int32_t* rows
   bool unset = false;
   if (slot >= 2) {
     const int32_t a = rows[i - (slot & 1)], b = rows[i - (slot & 1) + 1];
-    unset = minus1 ? (a < 0 || b < 0) : (a == 0 && b == 0);
+    // (a negative slot is never an offset: (-1, -1) is also how a Tagged-DFA program's rows say "field left untouched", whatever the flag)
+    unset = (a < 0 || b < 0) || (!minus1 && a == 0 && b == 0);
   }
   out[i] = unset ? (long long)v : (long long)v + base;
 }
@@ -175,7 +176,7 @@ __global__ __launch_bounds__(256) void rows_rebase32_kernel(int32_t* rows, long 
     v = rows[i];
     if (slot >= 2) {     // (a pair starts on an even index: ncap is even, so both of its lanes sit in this block)
       const int32_t a = rows[i - (slot & 1)], b = rows[i - (slot & 1) + 1];
-      unset = minus1 ? (a < 0 || b < 0) : (a == 0 && b == 0);
+      unset = (a < 0 || b < 0) || (!minus1 && a == 0 && b == 0);
     }
   }
   __syncthreads();       // both lanes of a pair have read it before either writes
