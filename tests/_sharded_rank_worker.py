@@ -1,6 +1,6 @@
-"""One RANK of the two-process world of tests/test_gpu_sharded_capi.py::test_two_process_world: both processes use device 0, the
-library's multi-rank path (rgx_sharded_create_rank, world = 2) runs over tests/ccl_shim.c (RGX_SHARDED_CCL_LIB).
-usage: _sharded_rank_worker.py <rank> <workdir>      -> writes <workdir>/rank<r>.json"""
+"""One RANK of the multi-process worlds of tests/test_gpu_sharded_capi.py::test_multi_process_world: every process uses device 0, the
+library's multi-rank path (rgx_sharded_create_rank, world = 2 / 4 / 8) runs over tests/ccl_shim.c (RGX_SHARDED_CCL_LIB).
+usage: _sharded_rank_worker.py <rank> <workdir> [world]      -> writes <workdir>/rank<r>.json"""
 import json
 import os
 import sys
@@ -9,14 +9,30 @@ import time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
+READER_CFG = (65536, 0)          # the reader rounds' stream.Config (unresolved)
+READER_CHUNKS = 3                # chunks per window of a reader round
+
+
+def stream_bytes():
+    from regengo_amd import synth
+    tile = synth.web_log_tile()
+    tile = tile[:tile.rfind(b"\n") + 1]
+    return (tile * 3)[: 2 * len(tile) + 4321]
+
+
+def nwindows(world):
+    return 2 * world + world // 2          # the last round is uneven: only half the ranks have a window
+
 
 def main():
     rank, work = int(sys.argv[1]), sys.argv[2]
+    world = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     import numpy as np
     import torch
-    from regengo_amd import Compiled, _capi, synth
+    from regengo_amd import Compiled, _capi
     from regengo_amd.sharded import Sharded
-    world = 2
+    from regengo_amd.stream import Config
+    mid = world // 2                       # the rank that fails / asks to stop: a middle one
 
     def fresh_uid(tag):
         """a communicator needs an id of its own (as with RCCL): rank 0 makes it, the launcher -- here a file -- carries it"""
@@ -28,39 +44,41 @@ def main():
             return uid
         t0 = time.time()
         while not os.path.exists(idf):
-            if time.time() - t0 > 120:
+            if time.time() - t0 > 240:
                 raise RuntimeError("no unique id from rank 0")
             time.sleep(0.05)
         return open(idf, "rb").read()
-    out = {"rank": rank}
-    tile = synth.web_log_tile()
-    tile = tile[:tile.rfind(b"\n") + 1]
-    data = (tile * 3)[: 2 * len(tile) + 4321]
+    out = {"rank": rank, "world": world}
+    data = stream_bytes()
     buf = torch.frombuffer(bytearray(data), dtype=torch.uint8).to("cuda:0")
+    nwin = nwindows(world)
+    nrounds = -(-nwin // world)
     for name, pattern in (("date", r"(?P<year>\d{4})-(?P<month>\d{2})-(?P<day>\d{2})"),
                           ("url", r"(?P<full>(?P<proto>https?|ftp)://(?P<host>[\w.-]+)(?P<port>:\d+)?(?P<path>/[\w./-]*)?)")):
         c = Compiled(pattern).to(0)
         s = Sharded(c, device=0, rank=rank, world=world, uid=fresh_uid(name))
         assert (s.n_local, s.world, s.first_rank, s.uses_rccl) == (1, world, rank, True)
         res = {}
-        # ---- two rounds in flight, the stream cut into 4 windows dealt round-robin: window k belongs to rank k % 2
-        plan = s.plan(len(data), parts=4)
+        # ---- two rounds in flight; the stream cut into nwin windows dealt round-robin: window k belongs to rank k % world, round k // world
+        plan = s.plan(len(data), parts=nwin)
 
         def win(k):
+            if k >= nwin:
+                return None
             lo, hi, wl, wh = plan[k]
             return dict(buf=buf[wl:wh].clone(), own=(lo - wl, hi - wl), base=wl, starts_at_sync=wl == 0, last=wh >= len(data))
-        s.submit([win(rank)])
-        s.submit([win(2 + rank)])
-        rounds = []
-        tables = []
-        offset_tables = []
-        for rd in range(2):
+        rounds, tables, offset_tables = [], [], []
+        submitted = 0
+        for rd in range(nrounds):
+            while submitted < nrounds and submitted - rd < 2:
+                s.submit([win(submitted * world + rank)])
+                submitted += 1
             total, rs = s.wait()
             s._last_counts = [r["count"] for r in rs]
             rounds.append({"total": total, "counts": [r["count"] for r in rs], "status": [r["status"] for r in rs],
-                           "unsynced": [r["unsynced"] for r in rs]})
-            # the gather of match offsets: to rank 0, then to rank 1 (every rank calls; the table lands on the destination only)
-            for dst in (0, 1):
+                           "unsynced": [r["unsynced"] for r in rs], "have": [r["have"] for r in rs]})
+            # the gather of match offsets: to rank 0, then to the LAST rank (every rank calls; the table lands on the destination only)
+            for dst in (0, world - 1):
                 cap = total + 4
                 t = torch.empty((cap, s.ncap), dtype=torch.int64, device="cuda:0")
                 n = s.gather(dst, out=t)
@@ -79,9 +97,9 @@ def main():
         res["rounds"] = rounds
         res["tables"] = tables
         res["offset_tables"] = offset_tables
-        # ---- a failing rank: rank 1 hands in a window whose owned range lies outside it -- BOTH ranks must get the error, none may hang
+        # ---- a failing rank in the MIDDLE hands in a window whose owned range lies outside it -- EVERY rank must get the error, none may hang
         bad = win(rank)
-        if rank == 1:
+        if rank == mid:
             bad["own"] = (0, bad["buf"].numel() + 100)
         s.submit([bad])
         try:
@@ -89,13 +107,43 @@ def main():
             res["fail"] = "no error"
         except _capi.RgxError as ex:
             res["fail"] = ex.status
-        # ---- the handle is still usable; a stop request of one rank reaches both
-        total, rs = s.round([win(rank)], stop=(rank == 1))
+        # ---- the handle is still usable; a stop request of the middle rank reaches everybody
+        total, rs = s.round([win(rank)], stop=(rank == mid))
         res["after_fail_total"] = total
         res["stop_seen"] = [r["stop"] for r in rs]
         # ---- count only
         total, rs = s.round([win(rank)], count_only=True)
         res["count_only"] = [r["count"] for r in rs]
+        # ---- the reference's FindReader across the ranks: windows that are RUNS OF CHUNKS (rgx_shard_window::reader_buffer_size), chunk
+        # ranges dealt round-robin -- no halo; rows gathered to the last rank in stream order
+        cfg = c._resolve(Config(*READER_CFG))
+        B, ML = cfg.BufferSize, cfg.MaxLeftover
+        S = B - ML
+        nchunks = (len(data) - B) // S + 2                 # full chunks + the short one at the end
+        nrw = -(-nchunks // READER_CHUNKS)
+        rr = []
+        for rd in range(-(-nrw // world)):
+            k = rd * world + rank
+            w = None
+            if k < nrw:
+                k0 = k * READER_CHUNKS
+                k1 = min(k0 + READER_CHUNKS, nchunks)
+                last = k1 == nchunks
+                lo = k0 * S
+                hi = len(data) if last else (k1 - 1) * S + B
+                w = dict(buf=buf[lo:hi].clone(), base=lo, last=last, reader=(B, ML))
+            total, rs = s.round_counts([w])
+            assert all(r["status"] == 0 and not r["unsynced"] and not r["truncated"] for r in rs), rs
+            t = torch.empty((total + 4, s.ncap), dtype=torch.int64, device="cuda:0")
+            n = s.gather(world - 1, out=t)
+            ent = {"total": total, "counts": [r["count"] for r in rs]}
+            if rank == world - 1:
+                assert n == total
+                ent["starts"] = t[:n, 0].cpu().numpy().tolist()
+                ent["ends"] = t[:n, 1].cpu().numpy().tolist()
+            rr.append(ent)
+        res["reader_rounds"] = rr
+        res["reader_cfg"] = [B, ML]
         s.close()
         out[name] = res
     json.dump(out, open(os.path.join(work, "rank%d.json" % rank), "w"))

@@ -1,8 +1,8 @@
 /* TEST DOUBLE of the ten nccl* entry points csrc/rgx_sharded.hip uses (it dlopens them: RGX_SHARDED_CCL_LIB=<this .so>), so that the
  * library's multi-RANK path -- rgx_sharded_create_rank(world > 1), the 32-byte all-gather of a round, the grouped send / recv gather,
- * a failing rank, stop requests -- runs as two PROCESSES on a box with one GPU, where RCCL itself cannot form a world of two.
+ * a failing rank, stop requests -- runs as two, four or eight PROCESSES on a box with one GPU, where RCCL itself cannot form such a world.
  * Not a collective library: every transfer is staged through a POSIX shared-memory segment (device -> host -> shm -> host ->
- * device), ranks meet at sense-reversing barriers, send / recv pairs hand 1 MiB chunks through a mailbox per (source, destination).
+ * device), ranks meet at sense-reversing barriers, send / recv pairs hand 256 KiB chunks through a mailbox per (source, destination).
  * Every wait is bounded (30 s): a protocol error in the library under test shows as ncclSystemError, never as a hang.
  *
  * Built by tests/test_gpu_sharded_capi.py:  gcc -shared -fPIC -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include tests/ccl_shim.c
@@ -20,9 +20,9 @@
 #include <time.h>
 #include <unistd.h>
 
-#define MAXR 4
+#define MAXR 8
 #define SLOT 4096
-#define CHUNK (1 << 20)
+#define CHUNK (1 << 18)
 
 typedef struct mbox {
   atomic_int full;

@@ -215,10 +215,11 @@ def _build_shim():
     return shim
 
 
-def test_bench_gpus_2_starts_its_own_ranks(gpu):
-    """`python bench.py --gpus 2` with NO launcher in front starts two ranks itself (torch.distributed.run inside),
-    the library forms a world of two (over the CCL test double on this one-GPU box: RGX_BENCH_ONE_DEVICE=1), and the line says so:
-    n_gpus 2, ranks_formed 2, the gathered table checked on rank 0.  Without the exception variable, asking for more GPUs than the
+@pytest.mark.parametrize("nranks", [2, 8])
+def test_bench_starts_its_own_ranks(gpu, nranks):
+    """`python bench.py --gpus N` with NO launcher in front starts N ranks itself (torch.distributed.run
+    inside), the library forms a world of N (over the CCL test double on this one-GPU box: RGX_BENCH_ONE_DEVICE=1), and the line says so:
+    n_gpus N, ranks_formed N, the gathered table checked on rank 0.  Without the exception variable, asking for more GPUs than the
     box has is an error -- never a silent one-GPU run that prints n_gpus: 1."""
     import json
     torch = gpu
@@ -227,16 +228,16 @@ def test_bench_gpus_2_starts_its_own_ranks(gpu):
         env.pop(k, None)
     env.update(RGX_SHARDED_CCL_LIB=_build_shim(), RGX_BENCH_ONE_DEVICE="1", RGX_BENCH_PREWARM="0.2")
     env.pop("RGX_SHARDED_NO_RCCL", None)
-    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bytes", str(1 << 26), "--steps", "3", "--warmup", "1",
-                        "--no-cpu-baseline"], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(nranks), "--bytes", str(1 << 26), "--steps", "3", "--warmup", "1",
+                        "--no-cpu-baseline", "--no-other-configs"], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
     rows = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert p.returncode == 0 and len(rows) == 1, (p.stdout[-2000:], p.stderr[-3000:])
     j = json.loads(rows[0])
     cfg = j["config"]
-    assert j["n_gpus"] == 2 and cfg["ranks_formed"] == 2 and cfg["gather_rows_checked"] is True and cfg["parity_closed_form"] is True, j
+    assert j["n_gpus"] == nranks and cfg["ranks_formed"] == nranks and cfg["gather_rows_checked"] is True and cfg["parity_closed_form"] is True, j
     assert cfg["communicator"].startswith("test double") and "FALLBACK" not in cfg["path"], cfg
-    assert cfg["matches_total"] == ((2 << 26) - 10) // 50 + 1 and cfg["strong_scaling"]["parity_count"] is True
-    if torch.cuda.device_count() < 2:
+    assert cfg["matches_total"] == ((nranks << 26) - 10) // 50 + 1 and cfg["strong_scaling"]["parity_count"] is True
+    if torch.cuda.device_count() < 2 and nranks == 2:
         env.pop("RGX_BENCH_ONE_DEVICE")
         q = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--bytes", str(1 << 26), "--no-cpu-baseline"],
                            capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
@@ -244,63 +245,83 @@ def test_bench_gpus_2_starts_its_own_ranks(gpu):
         assert "GPU(s) visible" in q.stderr
 
 
-def test_two_process_world(gpu, tmp_path):
-    """The multi-RANK path of the C library -- rgx_sharded_create_rank(world = 2), the per-round exchange ([count, flags, base, status]
-    through the all-gather entry point), the grouped send / recv gather to either rank, a failing rank (every rank gets the error, none
-    hangs), stop requests, count-only rounds -- as two PROCESSES on device 0.  RCCL cannot form a world of two on one GPU, so the ten
-    nccl* entry points the library dlopens come from tests/ccl_shim.c (RGX_SHARDED_CCL_LIB; staged through POSIX shared memory, every
-    wait bounded): what is under test is the library's protocol, rank arithmetic and error paths, not RCCL."""
+@pytest.mark.parametrize("world", [2, 4, 8])
+def test_multi_process_world(gpu, tmp_path, world):
+    """The multi-RANK path of the C library -- rgx_sharded_create_rank(world = 2 / 4 / 8), the per-round exchange ([count, flags, base,
+    status] through the all-gather entry point), the grouped send / recv gather to the first and to the LAST rank (world - 1 sources),
+    an uneven last round (windows % world != 0: ranks without a window still take part), a failing MIDDLE rank (every rank gets the
+    error, none hangs), a stop request raised by a middle rank, count-only rounds, and rounds of FindReader chunk ranges
+    (rgx_shard_window::reader_buffer_size) against the oracle's C port of the read loop -- as `world` PROCESSES on device 0.  RCCL cannot
+    form such a world on one GPU, so the ten nccl* entry points the library dlopens come from tests/ccl_shim.c (RGX_SHARDED_CCL_LIB;
+    staged through POSIX shared memory, every wait bounded): what is under test is the library's protocol, rank arithmetic and error
+    paths, not RCCL.  (when a real 8-GPU lease comes, the only new thing is the transport.)"""
     torch = gpu
     import json
     from regengo_amd import Compiled
+    from tests import _sharded_rank_worker as W
     shim = _build_shim()
     env = dict(os.environ)
     env["RGX_SHARDED_CCL_LIB"] = shim
     env.pop("RGX_SHARDED_NO_RCCL", None)
     worker = os.path.join(ROOT, "tests", "_sharded_rank_worker.py")
-    procs = [subprocess.Popen([sys.executable, worker, str(rk), str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for rk in (0, 1)]
+    procs = [subprocess.Popen([sys.executable, worker, str(rk), str(tmp_path), str(world)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+             for rk in range(world)]
     outs = []
     for p in procs:
         try:
-            o, _ = p.communicate(timeout=420)
+            o, _ = p.communicate(timeout=900)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()
             pytest.fail("a rank hung")
         outs.append(o.decode(errors="replace"))
-    assert all(p.returncode == 0 for p in procs), "\n----\n".join(outs)
-    ranks = [json.load(open(os.path.join(str(tmp_path), "rank%d.json" % rk))) for rk in (0, 1)]
-    tile = _tile()
-    data = (tile * 3)[: 2 * len(tile) + 4321]
+    assert all(p.returncode == 0 for p in procs), "\n----\n".join(o[-3000:] for o in outs)
+    ranks = [json.load(open(os.path.join(str(tmp_path), "rank%d.json" % rk))) for rk in range(world)]
+    data = W.stream_bytes()
     buf = torch.frombuffer(bytearray(data), dtype=torch.uint8).to("cuda:0")
+    nwin = W.nwindows(world)
+    nrounds = -(-nwin // world)
+    mid = world // 2
     for name, pattern in (("date", DATE), ("url", URL)):
         c = Compiled(pattern).to(0)
         whole = c.FindAllSpans(buf)[0].cpu().numpy().astype(np.int64)
-        # the plan both ranks used: 4 windows, window k owned by rank k % 2; round rd covers windows 2 rd and 2 rd + 1
         from regengo_amd.sharded import Sharded
-        plan = Sharded(c, devices=[0]).plan(len(data), parts=4)
-        for rd in range(2):
-            lo, hi = plan[2 * rd][0], plan[2 * rd + 1][1]
-            exp = whole[(whole[:, 0] >= lo) & (whole[:, 0] < hi)]
-            exp_counts = [int(((whole[:, 0] >= plan[2 * rd + k][0]) & (whole[:, 0] < plan[2 * rd + k][1])).sum()) for k in (0, 1)]
-            for rk in (0, 1):
+        plan = Sharded(c, devices=[0]).plan(len(data), parts=nwin)
+
+        def owned(k):
+            return (whole[:, 0] >= plan[k][0]) & (whole[:, 0] < plan[k][1])
+        for rd in range(nrounds):
+            ks = [k for k in range(rd * world, (rd + 1) * world) if k < nwin]
+            exp = whole[(whole[:, 0] >= plan[ks[0]][0]) & (whole[:, 0] < plan[ks[-1]][1])]
+            exp_counts = [int(owned(rd * world + r).sum()) if rd * world + r < nwin else 0 for r in range(world)]
+            for rk in range(world):
                 R = ranks[rk][name]["rounds"][rd]
-                assert R["counts"] == exp_counts and R["total"] == len(exp) and R["status"] == [0, 0] and R["unsynced"] == [False, False], (name, rd, rk, R)
-            # the gathered table, on rank 0 and on rank 1: rank order = stream order, stream-absolute offsets
-            for rk in (0, 1):
+                assert R["counts"] == exp_counts and R["total"] == len(exp) and R["status"] == [0] * world and R["unsynced"] == [False] * world, (name, rd, rk, R)
+                assert R["have"] == [rd * world + r < nwin for r in range(world)], (name, rd, R["have"])
+            # the gathered table, on rank 0 and on the last rank: rank order = stream order, stream-absolute offsets
+            for rk in (0, world - 1):
                 got = [t for (r_, dst, t) in ranks[rk][name]["tables"] if r_ == rd and dst == rk]
                 assert len(got) == 1 and np.array_equal(np.array(got[0], dtype=np.int64).reshape(-1, c.ncap), exp), (name, rd, rk)
-                # ... and the compact form of the same gather (8 bytes per match: start | length << 40)
                 gw = [t for (r_, dst, t) in ranks[rk][name]["offset_tables"] if r_ == rd and dst == rk]
                 w = np.array(gw[0], dtype=np.int64)
                 assert len(gw) == 1 and np.array_equal(w & ((1 << 40) - 1), exp[:, 0]) and np.array_equal((w & ((1 << 40) - 1)) + (w >> 40), exp[:, 1]), (name, rd, rk)
-        for rk in (0, 1):
+        per = [int(owned(r).sum()) for r in range(world)]
+        for rk in range(world):
             res = ranks[rk][name]
-            assert res["fail"] == -1, (name, rk, res["fail"])                  # RGX_E_INVALID of rank 1's window, seen by BOTH ranks
-            assert res["stop_seen"] == [False, True]
-            w0 = int(((whole[:, 0] >= plan[0][0]) & (whole[:, 0] < plan[0][1])).sum())
-            w1 = int(((whole[:, 0] >= plan[1][0]) & (whole[:, 0] < plan[1][1])).sum())
-            assert res["after_fail_total"] == w0 + w1 and res["count_only"] == [w0, w1]
+            assert res["fail"] == -1, (name, rk, res["fail"])                  # RGX_E_INVALID of the middle rank's window, seen by EVERY rank
+            assert res["stop_seen"] == [r == mid for r in range(world)]
+            assert res["after_fail_total"] == sum(per) and res["count_only"] == per
+        # ---- the reader rounds: the reference's FindReader callbacks over the whole stream, in stream order on the last rank
+        from oracle.gen_c import CMatcher
+        B, ML = ranks[0][name]["reader_cfg"]
+        exp = CMatcher(pattern).find_reader_np(np.frombuffer(data, dtype=np.uint8), B, ML)
+        last = ranks[world - 1][name]["reader_rounds"]
+        starts = np.array([x for e in last for x in e["starts"]], dtype=np.int64)
+        ends = np.array([x for e in last for x in e["ends"]], dtype=np.int64)
+        assert np.array_equal(starts, exp[:, 0]) and np.array_equal(ends, exp[:, 2] + exp[:, 4]), (name, len(starts), exp.shape)
+        for rk in range(world):
+            assert [e["total"] for e in ranks[rk][name]["reader_rounds"]] == [e["total"] for e in last]
+            assert sum(e["total"] for e in ranks[rk][name]["reader_rounds"]) == exp.shape[0]
 
 
 def test_sharded_find_all_bytes_widens_truncated_windows(gpu, monkeypatch):
