@@ -1026,6 +1026,7 @@ def c4_reader_grid(env, args, c, sh, tile, A, U, Z, gen, outs, cap):
             nck = max(1, min(nW, (64 << 20) // S + 1))
             Lo = (nck - 1) * S + B
             stream = gen(0, Lo)
+            torch.cuda.synchronize()
             rows, res = c.FindChunksDevice(stream, cfg, final=True)
             exp = CMatcher(URL).find_reader_np(stream.cpu().numpy(), B, ML)
             r = rows.cpu().numpy().astype(np.int64)

@@ -369,7 +369,11 @@ class DeviceSource:
         wl = max(0, lo - halo_l)
         wl -= wl % 16
         wh = min(L, hi + halo_r)
-        return StreamWindow(k, lo, hi, wl, wh, wh >= L, self.gen(wl, wh), wl == 0)
+        buf = self.gen(wl, wh)
+        if getattr(buf, "is_cuda", False):
+            import torch
+            torch.cuda.current_stream(buf.device).synchronize()     # produced on torch's stream, scanned on the library's: it has to be there first
+        return StreamWindow(k, lo, hi, wl, wh, wh >= L, buf, wl == 0)
 
     def windows(self, rank: int, world: int, W: int, halo_l: int, halo_r: int):
         k = rank

@@ -66,7 +66,9 @@ def main():
             if k >= nwin:
                 return None
             lo, hi, wl, wh = plan[k]
-            return dict(buf=buf[wl:wh].clone(), own=(lo - wl, hi - wl), base=wl, starts_at_sync=wl == 0, last=wh >= len(data))
+            b = buf[wl:wh].clone()
+            torch.cuda.synchronize()       # the copy runs on torch's stream, the scan on the library's: it has to be there first
+            return dict(buf=b, own=(lo - wl, hi - wl), base=wl, starts_at_sync=wl == 0, last=wh >= len(data))
         rounds, tables, offset_tables = [], [], []
         submitted = 0
         for rd in range(nrounds):
@@ -110,6 +112,8 @@ def main():
         # ---- the handle is still usable; a stop request of the middle rank reaches everybody
         total, rs = s.round([win(rank)], stop=(rank == mid))
         res["after_fail_total"] = total
+        res["after_fail_counts"] = [r["count"] for r in rs]
+        res["after_fail_flags"] = [[r["unsynced"], r["truncated"], r["status"], r["have"]] for r in rs]
         res["stop_seen"] = [r["stop"] for r in rs]
         # ---- count only
         total, rs = s.round([win(rank)], count_only=True)
@@ -132,6 +136,7 @@ def main():
                 lo = k0 * S
                 hi = len(data) if last else (k1 - 1) * S + B
                 w = dict(buf=buf[lo:hi].clone(), base=lo, last=last, reader=(B, ML))
+                torch.cuda.synchronize()
             total, rs = s.round_counts([w])
             assert all(r["status"] == 0 and not r["unsynced"] and not r["truncated"] for r in rs), rs
             t = torch.empty((total + 4, s.ncap), dtype=torch.int64, device="cuda:0")

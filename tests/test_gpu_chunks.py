@@ -287,6 +287,7 @@ def test_sharded_rounds_of_reader_chunks(torch_dev):
             out = torch.empty(((hi - lo) // 8 + 16, c.ncap), dtype=torch.int32, device="cuda")
             outs.append(out)
             ws.append(dict(buf=b, base=lo, last=last, reader=(B, ML), out=out))
+        torch.cuda.synchronize()                                    # (the copies ran on torch's stream, the scans run on the library's)
         while len(ws) < 2:
             ws.append(None)
         total, rs = sh.round(ws)

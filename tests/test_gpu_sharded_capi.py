@@ -42,6 +42,7 @@ def _windows(torch, buf, plan, out_rows=None):
             continue
         ws.append(dict(buf=buf[wl:wh].clone(), own=(lo - wl, hi - wl), base=wl, starts_at_sync=wl == 0, last=wh >= L,
                        out=None if out_rows is None else out_rows[i]))
+    torch.cuda.synchronize()          # the copies run on torch's stream, the scans on the library's own: they have to be there first
     return ws
 
 
@@ -310,6 +311,7 @@ def test_multi_process_world(gpu, tmp_path, world):
             res = ranks[rk][name]
             assert res["fail"] == -1, (name, rk, res["fail"])                  # RGX_E_INVALID of the middle rank's window, seen by EVERY rank
             assert res["stop_seen"] == [r == mid for r in range(world)]
+            assert res["after_fail_counts"] == per, (name, rk, res["after_fail_counts"], per, res["after_fail_flags"])
             assert res["after_fail_total"] == sum(per) and res["count_only"] == per
         # ---- the reader rounds: the reference's FindReader callbacks over the whole stream, in stream order on the last rank
         from oracle.gen_c import CMatcher
@@ -350,9 +352,11 @@ def test_sharded_find_all_bytes_widens_truncated_windows(gpu, monkeypatch):
         assert res.total == len(whole) and np.array_equal(got, whole), (pattern, res.total, len(whole))
         # the round itself reports the window as truncated (what a caller of rgx_sharded_round sees): 4 KiB of right halo inside the run
         lo, hi = 0, 300_000
-        total, rs = s.round([dict(buf=buf[0:hi + 4096].clone(), own=(lo, hi), base=0, starts_at_sync=True, last=False), None])
+        w1, w2 = buf[0:hi + 4096].clone(), buf[0:hi + 65536].clone()
+        torch.cuda.synchronize()
+        total, rs = s.round([dict(buf=w1, own=(lo, hi), base=0, starts_at_sync=True, last=False), None])
         assert rs[0]["truncated"], pattern
-        total, rs = s.round([dict(buf=buf[0:hi + 65536].clone(), own=(lo, hi), base=0, starts_at_sync=True, last=False), None])
+        total, rs = s.round([dict(buf=w2, own=(lo, hi), base=0, starts_at_sync=True, last=False), None])
         assert not rs[0]["truncated"], pattern
         s.close()
 
