@@ -1020,9 +1020,9 @@ def c4_reader_grid(env, args, c, sh, tile, A, U, Z, gen, outs, cap):
     parity_tiles = bool(env.allmin_int(1 if ok[0] and stp["bad"] == 0 else 0))
     # ---- parity 2 (rank 0): a run of 21 chunks (or fewer) against the C port of the reference's read loop, every callback
     oracle = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0:
         try:
-            from oracle.gen_c import CMatcher
+            from oracle.gen_c import CMatcher              # (the CHECKER: the C port of the reference's read loop, ~3 s of one core)
             nck = max(1, min(nW, (64 << 20) // S + 1))
             Lo = (nck - 1) * S + B
             stream = gen(0, Lo)
@@ -1532,6 +1532,17 @@ def other_config_legs(budget_s):
         leg.update({k: v for k, v in cfg.items() if k.startswith("parity_") or k.startswith("scan_mode_") or k.startswith("line_mode_st")
                     or k.startswith("line_mode_ref") or k in ("patterns", "patterns_skipped", "patterns_with_wrong_count", "patterns_with_wrong_rows",
                                                                "matches_total", "expected_matches", "strings_per_second", "engine", "unsynced_halos")})
+        # the suite with the reference's own FindAllBytes EVERYWHERE (the nine Tagged-DFA patterns through their FindAll wrapper, which
+        # reports matches again: `value` times them under plain leftmost-first semantics, scan_mode_stdlib) -- the honest reference-mode figure
+        w = cfg.get("tdfa_findall_wrapper_reference_mode")
+        if isinstance(w, dict):
+            leg["value_with_reference_findall_everywhere"] = w.get("value_with_reference_findall_everywhere")
+            leg["ms_with_reference_findall_everywhere"] = w.get("suite_ms_with_reference_findall_everywhere")
+            leg["reference_findall_rows_equal_c_port_head"] = w.get("all_rows_equal_c_port_head")
+        if name == "c4":
+            leg["value_findall_semantics"] = j.get("value_findall_semantics", {}).get("value")
+            leg["reader"] = {k: v for k, v in cfg.get("reader", {}).items() if k != "parity_oracle_read_loop"}
+            leg["reader_parity_oracle_read_loop_identical"] = (cfg.get("reader", {}).get("parity_oracle_read_loop") or {}).get("identical")
         out[name] = leg
     return out
 

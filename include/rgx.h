@@ -18,8 +18,9 @@
  *     Unmatched groups read (0,0) -- the reference zero-initialises the array and never writes -1
  *     (find.go:215, find.go:394-406: such a group becomes `input[0:0]`).  Pass
  *     RGX_FLAG_UNMATCHED_MINUS1 at program creation to get (-1,-1) instead (stdlib convention).
- *   - a program handle is immutable after creation and may be shared by threads; calls that use the
- *     same `rgx_stream_ctx` must be serialised by the caller.
+ *   - a program handle may be shared by threads (its tables are immutable after creation; what it LEARNS about its texts in
+ *     its first calls is kept in atomics and ends at rgx_program_freeze, below); calls that use the same `rgx_stream_ctx`
+ *     must be serialised by the caller.
  */
 #ifndef RGX_H
 #define RGX_H
@@ -191,6 +192,30 @@ void rgx_stream_ctx_destroy(rgx_stream_ctx* c);
 void* rgx_stream_ctx_hip_stream(const rgx_stream_ctx* c);
 /* Bracket the scan kernel with HIP events on the ctx stream; rgx_result.kernel_ms then holds its duration. */
 int rgx_stream_ctx_set_timing(rgx_stream_ctx* c, int on);
+
+/* ---- what a program has LEARNED, and the end of learning ------------------------------------------------------------------
+ * A program's tables are immutable after creation, but a few choices between equivalent kernels are made at run time, from the first
+ * calls' texts: the filter + candidate kernel or the program's other scan kernel (the first two scans of 8 MiB or more take one each,
+ * timed; the program keeps the faster), the capture pass's row length, the sync automaton / exact sync points for texts without reset
+ * bytes, the pair kernel's rewinding instance, the ASCII twin.  Results never depend on them (every kernel is checked against the same
+ * oracle); time does, and the first calls are slower by design.  rgx_program_tuning reports the choices; rgx_program_freeze ends the
+ * learning -- nothing of the program is written afterwards, every later call takes the kernels chosen so far (an open choice: the
+ * filter + candidate kernel where the program has one).  A service warms a program up on representative text, freezes it, and shares it.
+ * Learning is safe from several threads either way (relaxed atomics; two threads may both run an experiment).                       */
+typedef struct rgx_tuning {
+  int32_t frozen;
+  int32_t scan_kernel_choice;   /* 1: the filter + candidate kernel, -1: the program's other kernel, 0: open                        */
+  int32_t fc_us_per_gib, other_us_per_gib;   /* the two timed scans (0: not made)                                                   */
+  int32_t fc_gave_up;           /* scans the filter + candidate kernel gave up (from the second on the program stays with the other)  */
+  int32_t captures_long_rows;   /* 1: the capture pass's long-row instance (matches beyond ~76 bytes are common)                      */
+  int32_t sync_automaton;       /* 1: sync points from the sync automaton W (slices without a reset byte were met)                    */
+  int32_t exact_sync_points;    /* 1: exact sync points first; -1: tried, the carry pass is cheaper; -2: back to the generic kernel   */
+  int32_t rewinding_walk;       /* 1: the pair kernel's rewinding instance                                                            */
+  int32_t ascii_twin;           /* 1: a twin for texts without a byte >= 0x80 exists; -1: none (or not wanted)                        */
+  int32_t reserved[6];
+} rgx_tuning;
+int rgx_program_tuning(const rgx_program* p, rgx_tuning* out);
+int rgx_program_freeze(rgx_program* p);
 
 /* ---- run time ---------------------------------------------------------------------------------- */
 typedef struct rgx_result {

@@ -44,6 +44,11 @@ class Info(C.Structure):
         "ref_findall_offered", "ref_stream_offered", "ref_tdfa_states")] + [("flags", C.c_uint32), ("ref_replace_offered", C.c_int32)]
 
 
+class Tuning(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("frozen", "scan_kernel_choice", "fc_us_per_gib", "other_us_per_gib", "fc_gave_up", "captures_long_rows",
+                                         "sync_automaton", "exact_sync_points", "rewinding_walk", "ascii_twin")] + [("reserved", C.c_int32 * 6)]
+
+
 class ShardRange(C.Structure):
     _fields_ = [("lo", C.c_int64), ("hi", C.c_int64), ("win_lo", C.c_int64), ("win_hi", C.c_int64)]
 
@@ -87,6 +92,8 @@ SYMBOLS = {
     "rgx_program_destroy": (None, [C.c_void_p]),
     "rgx_abi_version": (C.c_int, []),
     "rgx_program_info": (C.c_int, [C.c_void_p, C.POINTER(Info)]),
+    "rgx_program_tuning": (C.c_int, [C.c_void_p, C.POINTER(Tuning)]),
+    "rgx_program_freeze": (C.c_int, [C.c_void_p]),
     "rgx_program_capture_names": (C.c_int64, [C.c_void_p, C.c_void_p, C.c_size_t]),
     "rgx_program_reset_bytes": (C.c_int, [C.c_void_p, C.c_void_p]),
     "rgx_unicode_table": (C.c_int64, [C.c_char_p, C.c_void_p, C.c_size_t]),

@@ -134,6 +134,17 @@ class Compiled:
         _capi.check(self._lib.rgx_program_info(self._h, C.byref(self.info)))     # table_bytes / scan_kernel are known now
         return self
 
+    def tuning(self) -> dict:
+        """what the program has learned about its texts so far (rgx_program_tuning)"""
+        t = _capi.Tuning()
+        _capi.check(self._lib.rgx_program_tuning(self._h, C.byref(t)))
+        return {n: int(getattr(t, n)) for n, _ in t._fields_ if n != "reserved"}
+
+    def freeze(self) -> "Compiled":
+        """end the learning: the program is immutable from here on (rgx_program_freeze)"""
+        _capi.check(self._lib.rgx_program_freeze(self._h))
+        return self
+
     def set_timing(self, on: bool = True):
         self._need_dev()
         self._lib.rgx_stream_ctx_set_timing(self._ctx, 1 if on else 0)

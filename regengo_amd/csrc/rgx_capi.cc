@@ -47,6 +47,10 @@ struct rgx_program {
   mutable std::mutex twin_mu;
   mutable std::unique_ptr<rgx_program> ascii_twin;
   mutable std::atomic<int> ascii_state{0};   // 0 not tried, 1 there, -1 none
+  // rgx_program_freeze: nothing above is written any more -- the program is immutable from then on (what include/rgx.h promises of a
+  // shared handle: the first calls of a program LEARN which of its kernels suits its texts, a service that wants the same answer
+  // time for every call warms the program up and freezes it)
+  mutable std::atomic<int> frozen{0};
 };
 
 struct rgx_stream_ctx {
@@ -629,16 +633,40 @@ int CapturePass(const rgx_program* p, rgx_stream_ctx* c, const DevTables& T, con
   unsigned long long used = 0;
   if (!long_rows && n >= 4096) HIP_TRY(hipMemcpyAsync(&used, c->d_cursor, 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
-  if (!long_rows && n >= 4096 && used > 2ull * (unsigned long long)n) p->caps_long.store(1, std::memory_order_relaxed);
+  if (!long_rows && n >= 4096 && used > 2ull * (unsigned long long)n && !p->frozen.load(std::memory_order_relaxed)) p->caps_long.store(1, std::memory_order_relaxed);
   return RGX_OK;
 }
 
 // grid != nullptr: the buffer is a run of FindReader chunks (ScanParams::grid_stride; FindChunksDevice below) -- taken by the exact and the
 // filter + candidate kernels only; kGridNotTaken: this program / text goes chunk by chunk.
+// (the learning of fc_pref: the OTHER path's time is noted by the caller of the body, and only when the call succeeded -- a refusal or an
+// error is quick and would make the other path look fast for the lifetime of the program: ADVICE r5)
+struct FcLearn {
+  bool pending = false;
+  std::chrono::steady_clock::time_point t0;
+};
+int64_t FindAllDeviceBody(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n, int32_t* d_spans,
+                          size_t cap_records, bool count_only, rgx_result* res, bool starts_only, int64_t own_lo, int64_t own_hi,
+                          const ReaderGrid* grid, FcLearn* learn);
 int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n, int32_t* d_spans,
                       size_t cap_records, bool count_only, rgx_result* res, bool starts_only = false, int64_t own_lo = 0,
                       int64_t own_hi = -1, const ReaderGrid* grid = nullptr) {
+  FcLearn learn;
+  const int64_t r = FindAllDeviceBody(p, c, d_buf, len, n, d_spans, cap_records, count_only, res, starts_only, own_lo, own_hi, grid, &learn);
+  if (learn.pending && r >= 0 && len > 0 && !p->frozen.load(std::memory_order_relaxed)) {
+    const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - learn.t0).count();
+    const int other = std::max(1, (int)(us * (double)(size_t(1) << 30) / (double)len)), mine = p->fc_us_per_gib.load(std::memory_order_relaxed);
+    p->other_us_per_gib.store(other, std::memory_order_relaxed);
+    p->fc_pref.store(mine <= other ? 1 : -1, std::memory_order_relaxed);
+    if (getenv("RGX_FC_VERBOSE")) fprintf(stderr, "[rgx] filter + candidate kernel %d us per GiB, the other path %d: %s\n", mine, other, mine <= other ? "taken" : "left");
+  }
+  return r;
+}
+int64_t FindAllDeviceBody(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n, int32_t* d_spans,
+                          size_t cap_records, bool count_only, rgx_result* res, bool starts_only, int64_t own_lo, int64_t own_hi,
+                          const ReaderGrid* grid, FcLearn* learn) {
   const DevTables& T = p->p.dev;
+  const bool frozen = p->frozen.load(std::memory_order_relaxed) != 0;
   if (res) memset(res, 0, sizeof *res);
   if (res) res->ncap = T.ncap;
   if (n == 0 || len == 0) return 0;  // find.go:142-144 (`n == 0`), find.go:209-211 (no attempt at searchStart >= l)
@@ -789,7 +817,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   // for kilobytes) is void and the program's other kernel runs below; a program that gave up twice stays there.
   const bool fc_big = len >= (size_t(8) << 20);
   const int fc_pref = ExpEnv("RGX_FC_FORCE") ? 1 : p->fc_pref.load(std::memory_order_relaxed);      // (experiment builds: stage timings)
-  const bool fc_open = fc_pref == 0 && fc_big;                 // still comparing: this call is timed
+  const bool fc_open = fc_pref == 0 && fc_big && !frozen;      // still comparing: this call is timed
   // (a pattern without a reset byte: its tiles are chained through the look-back from offset 0 of the text, which must then be where the
   // chain begins -- not a window of a sharded round with a left halo)
   const bool fc_sync_ok = T.reset_values == 0 ? own_lo <= 0 : (!use_w && !us_ws && !c->prefer_w);
@@ -806,10 +834,6 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - fc_t0).count();
     return std::max(1, (int)(us * (double)(size_t(1) << 30) / (double)len));
   };
-  struct OtherTimer {          // the other path has many ways out: whichever it takes, its time is noted (successful or not: a refusal is quick)
-    std::function<void()> f;
-    ~OtherTimer() { if (f) f(); }
-  } other_timer;
   if (fcm) {
     const ScanParams keep = P;
     P.ntiles = FcNumTiles(ilen);
@@ -843,16 +867,12 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
       return fwritten;
     }
     if (grid) return kGridNotTaken;          // (this run of chunks holds something the kernel gives up on: says nothing about the program's plain scans)
-    p->fc_bad.fetch_add(1, std::memory_order_relaxed);
+    if (!frozen) p->fc_bad.fetch_add(1, std::memory_order_relaxed);
     if (getenv("RGX_FC_VERBOSE")) fprintf(stderr, "[rgx] filter + candidate kernel gave up (mode %d, len %d): counters[2] = 0x%08x, counters[3] = 0x%08x\n", fcm, ilen, hc[2], hc[3]);
     P = keep;
   } else if (fc_open && !grid && UseFcKernel(T, ilen) && p->fc_us_per_gib.load(std::memory_order_relaxed) != 0) {
-    other_timer.f = [&]() {
-      const int other = fc_rate(), mine = p->fc_us_per_gib.load(std::memory_order_relaxed);
-      p->other_us_per_gib.store(other, std::memory_order_relaxed);
-      p->fc_pref.store(mine <= other ? 1 : -1, std::memory_order_relaxed);
-      if (getenv("RGX_FC_VERBOSE")) fprintf(stderr, "[rgx] filter + candidate kernel %d us per GiB, the other path %d: %s\n", mine, other, mine <= other ? "taken" : "left");
-    };
+    learn->pending = true;           // (FindAllDevice notes the time when this call comes back with rows)
+    learn->t0 = fc_t0;
   }
   // Every scan but the exact kernel's may meet slices without a sync point in reach; the first scan marks them as it goes
   // (a byte per slice, cleared here), so that the carry pass needs no scan of its own to find them.
@@ -902,14 +922,14 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     if (((uint32_t*)&c->h_read[2])[1]) {
       // (the register kernel found a slice whose nearest sync point lies further back than the fill reaches: this program's texts
       // go back to the generic kernel, which looks further)
-      p->prefer_wsync.store(-2, std::memory_order_relaxed);
+      if (!frozen) p->prefer_wsync.store(-2, std::memory_order_relaxed);
       HIP_TRY(hipStreamSynchronize(c->stream));
       c->dirty[0] = c->dirty[1] = c->set_words;
       return FindAllDevice(p, c, d_buf, len, n, d_spans, cap_records, count_only, res, starts_only, own_lo, own_hi);
     }
   }
   const int pws = p->prefer_wsync.load(std::memory_order_relaxed);      // 1: exact sync points first; -1: tried, the carry pass is cheaper
-  const bool learn_ws = use_w && pws == 0;
+  const bool learn_ws = use_w && pws == 0 && !frozen;
   const bool tm = c->timing || learn_ws;
   float ms = 0;
   uint32_t unsynced = 0;
@@ -968,7 +988,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     // slices without a reset byte in reach: take the sync points from W from now on (this context remembers)
     use_w = true;
     c->prefer_w = true;
-    p->prefer_w.store(1, std::memory_order_relaxed);
+    if (!frozen) p->prefer_w.store(1, std::memory_order_relaxed);
     ntiles = ScanNumTiles(T, ilen, true);
     P.ntiles = ntiles;
     P.use_w = 1;
@@ -998,7 +1018,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
     P.slice_unsynced = nullptr;
     if (tm) (void)hipEventElapsedTime(&ms, c->ev0, c->ev1);
     unsynced = ((uint32_t*)&c->h_read[2])[1];
-    p->prefer_wsync.store(many_unsynced || ms + 1.5f < 2.0f * t_blind ? 1 : -1, std::memory_order_relaxed);
+    if (!frozen) p->prefer_wsync.store(many_unsynced || ms + 1.5f < 2.0f * t_blind ? 1 : -1, std::memory_order_relaxed);
   }
   if (unsynced && !us_done) {
     // rare path: some slices found no sync point; resolve their entry positions serially and rescan.
@@ -1031,7 +1051,7 @@ int64_t FindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_
   }   // !us_ws
   // more than one lane in fifty finished in the single-step walker: this program's texts rewind (`a.*b.*c`), later scans take the
   // kernel instance that rewinds in its fast walk (8 % slower per byte, many times faster than the walker)
-  if (!P.us_rewind && (int64_t)((uint32_t*)&c->h_read[2])[2] * 50 > (int64_t)nslices) p->prefer_rw.store(1, std::memory_order_relaxed);
+  if (!frozen && !P.us_rewind && (int64_t)((uint32_t*)&c->h_read[2])[2] * 50 > (int64_t)nslices) p->prefer_rw.store(1, std::memory_order_relaxed);
   const int64_t total = (int64_t)c->h_read[0];
   int64_t written = count_only ? 0 : std::min<int64_t>(total, (int64_t)cap_records);
   if (res) { res->total = total; res->unsynced = (int32_t)unsynced; res->kernel_ms = ms; }
@@ -1147,6 +1167,22 @@ RGX_API int rgx_program_info(const rgx_program* p, rgx_info* o) {
   return RGX_OK;
 }
 
+RGX_API int rgx_program_freeze(rgx_program* p) {
+  if (!p) return RGX_E_INVALID;
+  p->frozen.store(1, std::memory_order_relaxed);
+  if (rgx_program* tw = p->ascii_twin.get()) tw->frozen.store(1, std::memory_order_relaxed);
+  if (p->ascii_state.load() == 0) p->ascii_state.store(-1);       // (no twin is made behind a freeze)
+  return RGX_OK;
+}
+RGX_API int rgx_program_tuning(const rgx_program* p, rgx_tuning* o) {
+  if (!p || !o) return RGX_E_INVALID;
+  memset(o, 0, sizeof *o);
+  o->frozen = p->frozen.load(); o->scan_kernel_choice = p->fc_pref.load(); o->fc_us_per_gib = p->fc_us_per_gib.load();
+  o->other_us_per_gib = p->other_us_per_gib.load(); o->fc_gave_up = p->fc_bad.load(); o->captures_long_rows = p->caps_long.load();
+  o->sync_automaton = p->prefer_w.load(); o->exact_sync_points = p->prefer_wsync.load(); o->rewinding_walk = p->prefer_rw.load();
+  o->ascii_twin = p->ascii_state.load();
+  return RGX_OK;
+}
 RGX_API int64_t rgx_unicode_table(const char* name, int32_t* dst, size_t cap_pairs) {
   if (!name) return RGX_E_INVALID;
   std::vector<int32_t> tab;

@@ -42,6 +42,16 @@ static void put_ctx(rgx_stream_ctx* c) {
   if (g_pooled < POOL) g_pool[g_pooled++] = c;
   else rgx_stream_ctx_destroy(c);
 }
+static void gpu_freeze(void) { /* <Name>GPUFreeze: the end of what the library learns about this pattern's texts */
+  int i;
+  if (!g_prog) return;
+  rgx_program_freeze(g_prog);
+  if (g_sharded) {
+    rgx_sharded_info si;
+    if (rgx_sharded_shape(g_sharded, &si) == RGX_OK)
+      for (i = 0; i < si.n_local; i++) rgx_program_freeze((rgx_program*)rgx_sharded_program(g_sharded, i));
+  }
+}
 static void gpu_close(void) { /* <Name>GPUClose */
   while (g_pooled > 0) rgx_stream_ctx_destroy(g_pool[--g_pooled]);
   if (g_sharded) { rgx_sharded_destroy(g_sharded); g_sharded = NULL; }
@@ -439,6 +449,7 @@ int main(int argc, char** argv) {
     return 0;
   }
   if (rc != RGX_OK) { printf("INIT %d %s: %s\n", rc, rgx_status_str(rc), rgx_last_error()); return 1; }
+  if (getenv("RGX_TWIN_FREEZE")) gpu_freeze(); /* a caller that froze the pattern before its first call: every answer the same */
   if (strcmp(cmd, "match") == 0) {
     rgx_stream_ctx* ctx = get_ctx();
     int m = 0;

@@ -300,3 +300,57 @@ def test_sharded_rounds_of_reader_chunks(torch_dev):
     so, ck = np.concatenate(so), np.concatenate(ck)
     assert np.array_equal(so, exp[:, 0]) and np.array_equal(ck, exp[:, 1])
     sh.close()
+
+
+def test_a_program_learns_from_two_threads_and_freezes(torch_dev):
+    """a program is shared by threads while it still LEARNS (which scan kernel suits its texts: the first two scans of
+    8 MiB or more take one each, timed) -- two contexts of ONE program scan from two threads during exactly those calls, every result
+    is the oracle's; rgx_program_freeze then ends the learning and rgx_program_tuning does not move any more."""
+    import ctypes as C
+    import threading
+    torch = torch_dev
+    from oracle.gen_c import CMatcher
+    from regengo_amd import Compiled, _capi, synth
+    lib = _capi.lib()
+    tile = synth.web_log_tile(1 << 20)
+    host = np.frombuffer((tile * 13)[: (12 << 20) + 999], dtype=np.uint8)
+    exp, cnt = CMatcher(URL).find_all_np(host)
+    c = Compiled(URL).to(0)
+    assert c.tuning()["scan_kernel_choice"] == 0 and not c.tuning()["frozen"]
+    bufs = [torch.from_numpy(host.copy()).cuda() for _ in range(2)]
+    outs = [torch.empty((cnt + 16, c.ncap), dtype=torch.int32, device="cuda") for _ in range(2)]
+    torch.cuda.synchronize()
+    ctxs = []
+    for _ in range(2):
+        h = C.c_void_p()
+        _capi.check(lib.rgx_stream_ctx_create(c._h, C.byref(h)))
+        ctxs.append(h)
+    bad = []
+
+    def work(i):
+        res = _capi.Result()
+        for it in range(4):
+            w = lib.rgx_find_all_bytes_device(c._h, ctxs[i], bufs[i].data_ptr(), bufs[i].numel(), -1, outs[i].data_ptr(), outs[i].shape[0], C.byref(res))
+            if w != cnt or not np.array_equal(outs[i][:cnt].cpu().numpy(), exp):
+                bad.append((i, it, int(w)))
+    th = [threading.Thread(target=work, args=(i,)) for i in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not bad, bad
+    t1 = c.tuning()
+    assert t1["scan_kernel_choice"] in (1, -1) and t1["fc_us_per_gib"] > 0 and t1["other_us_per_gib"] > 0, t1
+    c.freeze()
+    t2 = c.tuning()
+    assert t2["frozen"] == 1
+    for i in range(2):
+        work(i)
+    assert not bad and c.tuning() == t2
+    # a program frozen before its first call takes the filter + candidate kernel where it has one, and never experiments
+    f = Compiled(URL).to(0).freeze()
+    spans, res = f.FindAllSpans(bufs[0])
+    assert res.total == cnt and np.array_equal(spans.cpu().numpy(), exp)
+    assert f.tuning()["scan_kernel_choice"] == 0 and f.tuning()["fc_us_per_gib"] == 0
+    for h in ctxs:
+        lib.rgx_stream_ctx_destroy(h)
