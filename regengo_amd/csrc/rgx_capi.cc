@@ -761,6 +761,7 @@ int64_t FindAllDeviceBody(const rgx_program* p, rgx_stream_ctx* c, const uint8_t
     c->d_total = set;
     c->d_counters = (uint32_t*)(set + 2);
     P.tile_desc = set + 4; P.counters = c->d_counters; P.total = c->d_total;
+    P.grid_nlist = set + 1;                // (the set's second word, zeroed with it: the fused gap test's counter, read back with the total)
     P.clean_next = self_clean ? other : nullptr;
     P.host_result = self_clean ? c->h_read_dev : nullptr;
     c->h_read[0] = 0; c->h_read[1] = 0; c->h_read[2] = 0; c->h_read[3] = 0;
@@ -834,8 +835,10 @@ int64_t FindAllDeviceBody(const rgx_program* p, rgx_stream_ctx* c, const uint8_t
     const double us = std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - fc_t0).count();
     return std::max(1, (int)(us * (double)(size_t(1) << 30) / (double)len));
   };
+  if (grid && grid->fused_n) *grid->fused_n = -1;
   if (fcm) {
     const ScanParams keep = P;
+    if (grid && grid->fuse_list && !count_only) { P.grid_list = grid->fuse_list; P.grid_list_cap = grid->fuse_cap; }
     P.ntiles = FcNumTiles(ilen);
     P.use_tickets = (force_tickets || c->tickets) ? 1 : 0;
     if (fcm == 2) { P.pairs = nullptr; P.cap_records = (int64_t)cap_records; }
@@ -864,6 +867,7 @@ int64_t FindAllDeviceBody(const rgx_program* p, rgx_stream_ctx* c, const uint8_t
       }
       if (res) res->written = fwritten;
       if (fc_open && !grid) p->fc_us_per_gib.store(fc_rate(), std::memory_order_relaxed);
+      if (P.grid_list && grid->fused_n) *grid->fused_n = (long long)c->h_read[1];
       return fwritten;
     }
     if (grid) return kGridNotTaken;          // (this run of chunks holds something the kernel gives up on: says nothing about the program's plain scans)
@@ -2561,16 +2565,22 @@ struct ChunkRun {
   int64_t chunks() const { return kfull + (tail ? 1 : 0); }
 };
 
-int GridGapCheck(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, const int32_t* d_rows, int64_t n, const ReaderGrid& G) {
+constexpr uint32_t kFuseListCap = 1u << 20;      // rows the scan itself may list (ScanParams::grid_list); more: the quick kernel over all rows
+int GridGapCheck(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, const int32_t* d_rows, int64_t n, const ReaderGrid& G,
+                 long long fused_n) {
   if (n <= 0) return RGX_OK;
   const DevTables& T = p->p.dev;
   int rc;
-  if ((rc = Ensure(&c->d_glist, &c->glist_cap, n + 16)) != RGX_OK) return rc;
   uint32_t hn = 0;
-  HIP_TRY(hipMemsetAsync(c->d_glist, 0, 16, c->stream));
-  HIP_TRY(LaunchReaderGridQuick(T, d_buf, d_rows, n, T.ncap, G, c->d_glist + 4, c->d_glist, c->stream));
-  HIP_TRY(hipMemcpyAsync(&hn, c->d_glist, 4, hipMemcpyDeviceToHost, c->stream));
-  HIP_TRY(hipStreamSynchronize(c->stream));
+  if (fused_n >= 0 && fused_n <= (long long)kFuseListCap) {
+    hn = (uint32_t)fused_n;                // the scan listed them (c->d_glist + 4 ...)
+  } else {
+    if ((rc = Ensure(&c->d_glist, &c->glist_cap, std::max<int64_t>(n, kFuseListCap) + 16)) != RGX_OK) return rc;
+    HIP_TRY(hipMemsetAsync(c->d_glist, 0, 16, c->stream));
+    HIP_TRY(LaunchReaderGridQuick(T, d_buf, d_rows, n, T.ncap, G, c->d_glist + 4, c->d_glist, c->stream));
+    HIP_TRY(hipMemcpyAsync(&hn, c->d_glist, 4, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipStreamSynchronize(c->stream));
+  }
   if (hn == 0) return RGX_OK;
   unsigned* flag = reinterpret_cast<unsigned*>(c->d_cursor + 1);
   unsigned h = 0;
@@ -2660,8 +2670,14 @@ int64_t FindChunksDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t*
     rows_dst = c->d_out; rows_cap = (size_t)need;
     return RGX_OK;
   };
+  long long fused_n = -1;
   if (plain_ok) {
     rgx_result r{};
+    if (!stdlib) {             // (reference mode: the scan lists the rows the gap test cannot settle by itself)
+      int rc = Ensure(&c->d_glist, &c->glist_cap, (int64_t)kFuseListCap + 16);
+      if (rc != RGX_OK) return rc;
+      G.fuse_list = c->d_glist + 4; G.fuse_cap = kFuseListCap; G.fused_n = &fused_n;
+    }
     if (!d_spans) {
       const int64_t cnt = FindAllDevice(p, c, d_block, (size_t)R.scan_len, -1, nullptr, 0, true, &r, false, 0, R.own_hi, &G);
       if (cnt != kGridNotTaken) {
@@ -2682,7 +2698,7 @@ int64_t FindChunksDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t*
       ms = r.kernel_ms;
     }
     if (rows >= 0 && !stdlib) {
-      int rc = GridGapCheck(p, c, d_block, (size_t)R.scan_len, rows_dst, rows, G);
+      int rc = GridGapCheck(p, c, d_block, (size_t)R.scan_len, rows_dst, rows, G, fused_n);
       if (rc != RGX_OK) return rc;
     }
   } else if (tdfa_ok) {

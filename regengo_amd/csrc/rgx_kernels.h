@@ -44,6 +44,13 @@ struct ScanParams {
   // grid_free, the start of the run's last, short chunk, which reports everything (0x7FFFFFFF: every chunk is full).  0: no grid.
   // rgx_scan_exact.hip and rgx_scan_fc.hip only (kGridMinStride: at most one boundary in reach of a tile).
   int32_t grid_stride, grid_free;
+  // ... and the reader's gap test fused into the scan (rgx_scan_fc.hip only; rgx_kernels.hip: reader_grid_quick_kernel has the test): a
+  // reported row whose match does not begin behind a reset byte is listed -- *grid_nlist counts them (zeroed with the scratch set),
+  // grid_list[k] = the row's index for k < grid_list_cap.  The byte in front of a match is in LDS when the row is made; read back from
+  // memory by a kernel of its own it costs a second pass over the input's cache lines (0.3 ms per 1.6 GiB window).  nullptr: not asked for.
+  uint32_t* grid_list;
+  unsigned long long* grid_nlist;
+  uint32_t grid_list_cap;
 };
 constexpr int32_t kGridMinStride = 32768;
 // The same grid for the kernels that take it as a whole (rgx_tdfa.hip, the reader checks): bufsize = BufferSize, the length of a full chunk.
@@ -51,6 +58,11 @@ struct ReaderGrid {
   int32_t stride = 0, free_from = 0x7FFFFFFF, bufsize = 0;
   int32_t own_hi = 0x7FFFFFFF;      // matches that start at or behind it belong to a chunk that is not part of this run (the bytes behind the last
                                     // full chunk's keep point are only its look-ahead): not reported
+  // host side only (FindAllDevice): ask the scan to list the rows that do not begin behind a reset byte (ScanParams::grid_list) -- *fused_n:
+  // how many it listed (-1: this kernel does not list: run reader_grid_quick_kernel)
+  uint32_t* fuse_list = nullptr;
+  uint32_t fuse_cap = 0;
+  long long* fused_n = nullptr;
 };
 // start of the chunk that owns a match starting at s; the end of that chunk's text (an attempt from s sees the end of the text there)
 __host__ __device__ inline int32_t GridChunkStart(int32_t s, const ReaderGrid& g) {

@@ -2841,7 +2841,7 @@ __global__ __launch_bounds__(256) void reader_grid_slow_kernel(DevTables T, cons
     int p = 0;
     if (i > 0 && spans[(i - 1) * ncap] >= cs) p = spans[(i - 1) * ncap + 1] - cs;
     const int s = s0 - cs;
-    int off = p;
+    int off = p;                            // (s == p -- a row the fused test listed -- is settled: the loop below does not run)
     if (s - p > kReaderBack) {
       off = -1;
       if (T.reset_values)
@@ -2875,9 +2875,10 @@ __global__ __launch_bounds__(64) void memo_reader_grid_slow_kernel(DevTables T, 
     int p = 0;
     if (i > 0 && spans[(i - 1) * ncap] >= cs) p = spans[(i - 1) * ncap + 1] - cs;
     const int s = s0 - cs, e = spans[i * ncap + 1] - cs;
+    if (s == p) continue;                   // (a row the scan's fused test listed although the loop stands right there: settled)
     long long budget = kReaderSteps * 64ll;
     int mend = 0;
-    // (s > p: the quick test settles s == p.)  The attempt at p, on the slice chunk[p:] -- it fails; then the sequence up to s; then the
+    // The attempt at p, on the slice chunk[p:] -- it fails; then the sequence up to s; then the
     // attempt at s, which has to match with FindAllBytes' end.  A lane that runs out of scratch or budget does not vouch for the call.
     const int a0 = MemoAttempt(M, text + p, tl - p, 0, S, &mend, &budget);
     if (a0 < 0 || !(tl - p > a0)) { bad = true; break; }           // (kMemoMatched / kMemoGaveUp are negative)

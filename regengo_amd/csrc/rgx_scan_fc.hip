@@ -85,6 +85,9 @@ struct FcParams {
   int32_t K, ncap;
   uint32_t flags;
   int32_t grid_stride, grid_free;  // ScanParams::grid_*: FindReader's chunk grid (0: none)
+  uint32_t* glist;                 // ScanParams::grid_list / grid_nlist / grid_list_cap: rows that do not begin behind a reset byte
+  unsigned long long* gnlist;
+  uint32_t glist_cap;
 };
 constexpr uint32_t kFcCountOnly = 1, kFcStartsOnly = 2, kFcTickets = 4, kFcFixedCaps = 8, kFcCtxSens = 16, kFcMinus1 = 32, kFcCarry = 64;
 
@@ -268,10 +271,12 @@ __global__ __launch_bounds__(kFcThreads) __attribute__((amdgpu_waves_per_eu(MODE
   // ---- a finished candidate: packed for the wait.  A row's fields as 16-bit words, two to a register: MODE 2 -- [0] end - start,
   // [c - 1] group slot c as its distance from the start (0xFFFF: unset; the lane's record slots hold -1 for that), [2 * NW - 1] the
   // row's place among the workgroup's rows (0xFFFF: nothing to report); MODE 1 (NW = 2) -- register 0 the end, register 1 the place.
-  auto pack = [&](int s, int e, unsigned place, unsigned (&Rw)[NW]) {
-    if (MODE != 2) { Rw[0] = (unsigned)e; Rw[1] = place; return; }
+  // (sus: the row goes on the reader's list when it is written -- bit 15 of the length field / bit 31 of the end: a walk is at most
+  // kFcMaxSteps long, a text shorter than 2^31)
+  auto pack = [&](int s, int e, unsigned place, unsigned (&Rw)[NW], bool sus) {
+    if (MODE != 2) { Rw[0] = (unsigned)e | (sus ? 0x80000000u : 0u); Rw[1] = place; return; }
     unsigned v[2 * NW];
-    v[0] = (unsigned)(e - s) & 0xFFFFu;
+    v[0] = ((unsigned)(e - s) & 0x7FFFu) | (sus ? 0x8000u : 0u);
 #pragma unroll
     for (int c = 2; c < 2 * NW; ++c) {
       const int g = c < ncap ? (int)recw[(c - 2) * kFcThreads] : -1;
@@ -283,8 +288,12 @@ __global__ __launch_bounds__(kFcThreads) __attribute__((amdgpu_waves_per_eu(MODE
   };
   auto place_of = [&](const unsigned (&Rw)[NW]) -> unsigned { return MODE == 2 ? Rw[NW - 1] >> 16 : Rw[1]; };
   // the row of (s, e) at index idx; group(c): slot c + 2's value, "unset" applied
-  auto emit_row = [&](const int s, const int e, unsigned long long idx, auto group) {
+  auto emit_row = [&](const int s, const int e, unsigned long long idx, bool sus, auto group) {
     if (idx >= (unsigned long long)P.cap_records) return;
+    if (sus) {
+      const unsigned long long k = atomicAdd(P.gnlist, 1ull);
+      if (k < (unsigned long long)P.glist_cap) P.glist[k] = (unsigned)idx;
+    }
     if (MODE == 2) {
       int g[2 * NW - 2];
 #pragma unroll
@@ -318,14 +327,15 @@ __global__ __launch_bounds__(kFcThreads) __attribute__((amdgpu_waves_per_eu(MODE
     }
   };
   auto emit_packed = [&](const int s, const unsigned (&Rw)[NW], unsigned long long idx) {
-    const int e = MODE == 2 ? s + (int)(Rw[0] & 0xFFFFu) : (int)Rw[0];
-    emit_row(s, e, idx, [&](int c) -> int {
+    const int e = MODE == 2 ? s + (int)(Rw[0] & 0x7FFFu) : (int)(Rw[0] & 0x7FFFFFFFu);
+    const bool sus = MODE == 2 ? (Rw[0] & 0x8000u) != 0 : (Rw[0] >> 31) != 0;
+    emit_row(s, e, idx, sus, [&](int c) -> int {
       const unsigned d = (Rw[(c + 1) >> 1] >> (((c + 1) & 1) * 16)) & 0xFFFFu;
       return d == 0xFFFFu ? unset : s + (int)d;
     });
   };
-  auto emit_slots = [&](const int s, const int e, unsigned long long idx) {       // (the groups still in the lane's record slots)
-    emit_row(s, e, idx, [&](int c) -> int {
+  auto emit_slots = [&](const int s, const int e, unsigned long long idx, bool sus) {       // (the groups still in the lane's record slots)
+    emit_row(s, e, idx, sus, [&](int c) -> int {
       const int g = c + 2 < ncap ? (int)recw[c * kFcThreads] : -1;
       return g < 0 ? unset : g;
     });
@@ -391,6 +401,7 @@ __global__ __launch_bounds__(kFcThreads) __attribute__((amdgpu_waves_per_eu(MODE
     if (tid == 0) misc[3] = 0;
     if (misc[4] != 0) { voided = true; break; }                // the call is void already: be out of the way
     int sr[kFcRounds] = {-1, -1}, er[kFcRounds] = {-1, -1};
+    bool susr[kFcRounds] = {false, false};      // the candidate does not begin behind a reset byte (asked for by the reader's runs: P.glist)
     unsigned rec_w[NW];              // the first round's candidate, packed (the second round's stays in the lane's record slots)
     bool mine[kFcRounds] = {false, false};
     unsigned long long mb[kFcRounds] = {0ull, 0ull};
@@ -516,7 +527,7 @@ __global__ __launch_bounds__(kFcThreads) __attribute__((amdgpu_waves_per_eu(MODE
 
       // ---- candidates: lane j walks candidate j (and, rarely, candidate j + lanes)
       const int lim = (len - wb < kFcWinBytes ? len - wb : kFcWinBytes);      // bytes of the window that exist: the fast walk stays inside them
-      auto walk = [&](unsigned j, int& s, int& e) {
+      auto walk = [&](unsigned j, int& s, int& e, bool& sus) {
         s = -1; e = -1;
         if (j >= ntot) return;
         int seg = 0;
@@ -524,6 +535,7 @@ __global__ __launch_bounds__(kFcThreads) __attribute__((amdgpu_waves_per_eu(MODE
         for (int w = 1; w < kFcWaves; ++w) if (j >= segbase[w]) seg = w;
         const int rel0 = (int)list[seg * kFcSeg + (int)(j - segbase[seg])];
         s = wb + rel0;
+        if (P.glist) sus = rel0 == 0 || smem[kReset + rows[((rel0 - 1) >> 6) * kFcRowBytes + ((rel0 - 1) & 63)]] == 0;
         // start state: by the byte in front (Walk() of rgx_kernels.hip)
         unsigned ctx = kCtxOther;
         if (s == 0) ctx = kCtxBOT;
@@ -645,10 +657,10 @@ __global__ __launch_bounds__(kFcThreads) __attribute__((amdgpu_waves_per_eu(MODE
           }
         }
       };
-      walk((unsigned)tid, sr[0], er[0]);
+      walk((unsigned)tid, sr[0], er[0], susr[0]);
       if (two) {                                                   // (the second walk takes the lane's record slots)
-        pack(sr[0], er[0], 0xFFFFu, rec_w);
-        walk((unsigned)tid + kFcThreads, sr[1], er[1]);
+        pack(sr[0], er[0], 0xFFFFu, rec_w, susr[0]);
+        walk((unsigned)tid + kFcThreads, sr[1], er[1], susr[1]);
       }
 
       // ---- chain: a successful candidate is reported iff no earlier reported match covers its start.  Every wave decides for its own
@@ -756,7 +768,7 @@ __global__ __launch_bounds__(kFcThreads) __attribute__((amdgpu_waves_per_eu(MODE
       if (novf + r1tot <= (unsigned)kFcOvf) {
         if (mine[1]) {
           unsigned tw[NW];
-          pack(sr[1], er[1], nacc + offr[1] + (unsigned)__popcll(mb[1] & ((1ull << lane) - 1ull)), tw);
+          pack(sr[1], er[1], nacc + offr[1] + (unsigned)__popcll(mb[1] & ((1ull << lane) - 1ull)), tw, susr[1]);
           unsigned* const o = ovf + (novf + r1off + (unsigned)__popcll(mb[1] & ((1ull << lane) - 1ull))) * (NW + 1);
           o[0] = (unsigned)sr[1];
 #pragma unroll
@@ -780,10 +792,10 @@ __global__ __launch_bounds__(kFcThreads) __attribute__((amdgpu_waves_per_eu(MODE
       const unsigned rank0 = (unsigned)__popcll(mb[0] & ((1ull << lane) - 1ull));
       if (base_known) {
         const unsigned long long base = (carry ? (pred & 0x7FFFFFFFull) : pred) + nacc;
-        if (mine[0]) { if (two) emit_packed(sr[0], rec_w, base + offr[0] + rank0); else emit_slots(sr[0], er[0], base + offr[0] + rank0); }
-        if (mine[1]) emit_slots(sr[1], er[1], base + offr[1] + (unsigned)__popcll(mb[1] & ((1ull << lane) - 1ull)));
+        if (mine[0]) { if (two) emit_packed(sr[0], rec_w, base + offr[0] + rank0); else emit_slots(sr[0], er[0], base + offr[0] + rank0, susr[0]); }
+        if (mine[1]) emit_slots(sr[1], er[1], base + offr[1] + (unsigned)__popcll(mb[1] & ((1ull << lane) - 1ull)), susr[1]);
       } else if (mb[0] != 0ull) {                                  // (per wave: one of its lanes has a row to keep)
-        if (!two) pack(sr[0], er[0], 0xFFFFu, rec_w);
+        if (!two) pack(sr[0], er[0], 0xFFFFu, rec_w, susr[0]);
         const unsigned place = mine[0] ? nacc + offr[0] + rank0 : 0xFFFFu;
         if (MODE == 2) rec_w[NW - 1] = (rec_w[NW - 1] & 0xFFFFu) | (place << 16); else rec_w[1] = place;
 #pragma unroll
@@ -870,6 +882,7 @@ hipError_t LaunchScanFc(const DevTables& T, const ScanParams& S, int mode, hipSt
   P.b_bytes = F.b_bytes; P.rows_off = F.rows_off; P.rec_off = F.rec_off; P.ops_bytes = F.ops_bytes; P.ovf_off = F.ovf_off;
   P.K = K; P.ncap = T.ncap;
   P.grid_stride = S.grid_stride; P.grid_free = S.grid_free;
+  P.glist = S.grid_list; P.gnlist = S.grid_nlist; P.glist_cap = S.grid_list_cap;
   P.flags = (S.count_only ? kFcCountOnly : 0u) | (S.starts_only ? kFcStartsOnly : 0u) | (S.use_tickets ? kFcTickets : 0u) |
             (T.fixed_captures ? kFcFixedCaps : 0u) | (T.ctx_sensitive ? kFcCtxSens : 0u) | (T.unmatched_minus1 ? kFcMinus1 : 0u) |
             (T.reset_values == 0 ? kFcCarry : 0u);

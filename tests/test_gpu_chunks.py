@@ -354,3 +354,45 @@ def test_a_program_learns_from_two_threads_and_freezes(torch_dev):
     assert f.tuning()["scan_kernel_choice"] == 0 and f.tuning()["fc_us_per_gib"] == 0
     for h in ctxs:
         lib.rgx_stream_ctx_destroy(h)
+
+
+def test_matches_that_do_not_begin_behind_a_reset_byte(torch_dev):
+    """The gap test: a row whose match begins behind a reset byte (or where the loop stands anyway) is settled by one byte -- in the scan
+    itself for the filter + candidate kernel (ScanParams::grid_list); the others are replayed by the memoising engine's interpreter.
+    URLs glued to word characters (`ref=http://..` is behind a reset byte, `xhttp://..` is not) must come out as the reference's loop
+    reports them; and where its restart rule steps OVER a match (`hhttp://x.y`: the attempt at the first h fails at the second, the
+    loop resumes behind it) the run is refused (RGX_E_DIVERGES), never answered differently."""
+    torch = torch_dev
+    import random
+    from regengo_amd import Compiled
+    from regengo_amd._capi import RgxError
+    from regengo_amd.stream import Config
+    cm, comp = _oracle(URL)
+    c = Compiled(URL).to(0)
+    cfg = c._resolve(Config(65536, 0))
+    S = cfg.BufferSize - cfg.MaxLeftover
+    rng = random.Random(11)
+    words = [b"ref=http://a.b/c", b"xhttp://w.w", b"_https://k.k:80/", b"see the request from", b"http://plain.org/x", b"9ftp://f.f", b"-- took 12 ms",
+             b"t", b"user=alice_1 id=77"]
+
+    def text(extra, n):
+        parts, size = [], 0
+        while size < n:
+            # (one URL in four words: a 16 KiB tile of the filter + candidate kernel takes 512 candidates)
+            w = rng.choice(words + extra) if rng.random() < 0.25 else rng.choice([b"see the request from", b"-- took 12 ms", b"user=alice_1 id=77", b"t"])
+            parts.append(w + (b" " if rng.random() < 0.8 else b"\n"))
+            size += len(parts[-1])
+        return np.frombuffer(b"".join(parts)[:n], dtype=np.uint8)
+    host = text([], 5 * S + 7777)
+    exp = cm.find_reader_np(host, cfg.BufferSize, cfg.MaxLeftover)
+    rows, res = c.FindChunksDevice(torch.from_numpy(host.copy()).cuda(), cfg, final=True)
+    assert res.mode == 1 and exp.shape[0] > 1000, (res.mode, exp.shape)
+    _same(rows.cpu().numpy(), int(res.chunks), S, exp, c.ncap)
+    # ... and a text on which the reference's loop loses matches
+    host = text([b"hhttp://x.y", b"ftphttp://q.q:80/"], 3 * S + 99)      # (`ftp` + `http://`: the attempt at f fails at the h the match begins at)
+    exp = cm.find_reader_np(host, cfg.BufferSize, cfg.MaxLeftover)
+    allrows, _ = Compiled(URL, stdlib=True).to(0).FindChunksDevice(torch.from_numpy(host.copy()).cuda(), cfg, final=True)
+    assert allrows.shape[0] > exp.shape[0]                                   # plain leftmost-first finds the stepped-over ones
+    with pytest.raises(RgxError) as ei:
+        c.FindChunksDevice(torch.from_numpy(host.copy()).cuda(), cfg, final=True)
+    assert ei.value.status == -11
