@@ -376,9 +376,11 @@ int64_t TdfaChainDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* 
   const ReaderGrid G = grid ? *grid : ReaderGrid();
   const size_t scan_tmp = parallel ? TdfaScanTempBytes(nslices) : 0;
   auto r4 = [](int64_t x) { return (x + 3) & ~int64_t(3); };
+  // (sparse ends: programs whose start state does not accept -- ends[] written where an attempt accepts, accmask says where; rgx_tdfa.hip)
+  const bool sparse = TdfaSparseEndsOffered(D) && ((uintptr_t)d_buf & 15) == 0 && len >= 4096;
   const int64_t o_ends = 0, o_se = o_ends + r4((int64_t)len + 1), o_sync = o_se + r4(2 * cap_m), o_counts = o_sync + r4(2 * nslices),
                 o_offs = o_counts + r4(nslices + 1), o_desc = o_offs + r4(nslices + 1), o_misc = o_desc + r4(2 * ntiles),
-                o_tmp = o_misc + 16, total = o_tmp + r4((int64_t)(scan_tmp + 3) / 4);
+                o_acc = o_misc + 16, o_tmp = o_acc + r4(2 * nslices + 2), total = o_tmp + r4((int64_t)(scan_tmp + 3) / 4);
   int rc;
   if ((rc = Ensure(&c->d_tdfa, &c->tdfa_cap, total)) != RGX_OK) return rc;
   int32_t* base = c->d_tdfa;
@@ -389,7 +391,9 @@ int64_t TdfaChainDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* 
   uint32_t* flags = (uint32_t*)(base + o_misc);
   long long* out_n = (long long*)(base + o_misc + 2);
   HIP_TRY(hipMemsetAsync(base + o_misc, 0, 64, c->stream));
-  HIP_TRY(LaunchTdfaEnds(D, d_buf, ilen, ends, flags, c->stream, G));
+  unsigned long long* const accmask = sparse ? (unsigned long long*)(base + o_acc) : nullptr;
+  if (sparse) HIP_TRY(LaunchTdfaEndsSparse(D, d_buf, ilen, ends, accmask, flags + 8, flags, c->stream, G));
+  else HIP_TRY(LaunchTdfaEnds(D, d_buf, ilen, ends, flags, c->stream, G));
   int64_t n = 0;
   int32_t h[4] = {0, 0, 0, 0};
   auto over_budget = [&]() {
@@ -398,8 +402,8 @@ int64_t TdfaChainDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* 
   };
   if (parallel) {
     HIP_TRY(hipMemsetAsync(desc, 0, (size_t)ntiles * 8, c->stream));
-    HIP_TRY(LaunchTdfaSync(ends, ilen, sync, desc, flags, c->stream, G));
-    HIP_TRY(LaunchTdfaChain(ends, ilen, sync, counts, nullptr, nullptr, 0, 0, flags, c->stream, G));
+    HIP_TRY(LaunchTdfaSync(ends, ilen, sync, desc, flags, c->stream, G, accmask));
+    HIP_TRY(LaunchTdfaChain(ends, ilen, sync, counts, nullptr, nullptr, 0, 0, flags, c->stream, G, accmask));
     HIP_TRY(LaunchTdfaScan(counts, offs, nslices, base + o_tmp, scan_tmp, c->stream));
     HIP_TRY(hipMemcpyAsync(&h[0], flags, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(&h[1], counts + nslices - 1, 4, hipMemcpyDeviceToHost, c->stream));
@@ -409,9 +413,9 @@ int64_t TdfaChainDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* 
     if (h[0] & 1) { SetError("tdfa_sync_kernel: look-back timeout"); return RGX_E_HIP; }
     n = (int64_t)h[1] + h[2];
     if (n > cap_m) { SetError("internal: more Tagged-DFA matches than len / min_len"); return RGX_E_HIP; }
-    if (n > 0 && d_rows) HIP_TRY(LaunchTdfaChain(ends, ilen, sync, counts, offs, se, cap_m, 1, flags, c->stream, G));
+    if (n > 0 && d_rows) HIP_TRY(LaunchTdfaChain(ends, ilen, sync, counts, offs, se, cap_m, 1, flags, c->stream, G, accmask));
   } else {
-    HIP_TRY(LaunchTdfaChainSerial(D, d_buf, ilen, ends, se, cap_m, out_n, flags, c->stream));
+    HIP_TRY(LaunchTdfaChainSerial(D, d_buf, ilen, ends, se, cap_m, out_n, flags, c->stream, accmask));
     long long hn = 0;
     HIP_TRY(hipMemcpyAsync(&h[0], flags, 4, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipMemcpyAsync(&hn, out_n, 8, hipMemcpyDeviceToHost, c->stream));
@@ -501,8 +505,10 @@ int64_t TdfaFindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t
   hipEvent_t e0 = c->timing ? c->ev0 : nullptr;
   if (e0) HIP_TRY(hipEventRecord(c->ev0, c->stream));
   HIP_TRY(hipMemsetAsync(base + o_misc, 0, 64, c->stream));
-  HIP_TRY(LaunchTdfaEnds(D, d_buf, ilen, ends, flags, c->stream));
-  HIP_TRY(LaunchTdfaQ11Index(ends, ilen, accmask, rev, flags + 1, base + o_tmp, scan_tmp, c->stream));
+  const bool sparse = TdfaSparseEndsOffered(D) && ((uintptr_t)d_buf & 15) == 0 && len >= 4096;
+  if (sparse) HIP_TRY(LaunchTdfaEndsSparse(D, d_buf, ilen, ends, accmask, flags + 1, flags, c->stream));
+  else HIP_TRY(LaunchTdfaEnds(D, d_buf, ilen, ends, flags, c->stream));
+  HIP_TRY(LaunchTdfaQ11Index(ends, ilen, accmask, rev, flags + 1, base + o_tmp, scan_tmp, c->stream, sparse));
   uint32_t h[2] = {0, 0};
   HIP_TRY(hipMemcpyAsync(h, flags, 8, hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
@@ -562,8 +568,17 @@ int64_t TdfaFindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t
 // bytes.Index (streaming.go:192) against the chain's rows: an earlier copy of a match's text in the gap in front of it moves the
 // offset the loop reports.  With one start state that can only happen to a match that was accepted BY the end of the text (the same
 // bytes earlier are not at the end) -- checked for every row all the same.
+// ... and not at all when it cannot fail: with ONE start state and no state that accepts at the end of the text ONLY, the attempt at an
+// earlier copy of the match's text walks the same states over the same bytes and accepts as well -- the chain, which takes the FIRST
+// accepting start at or behind searchPos, would have taken the copy (4.5 ms per GiB of web log saved: the check reads every gap).
+bool TdfaIndexCheckNeeded(const RefTdfa& r) {
+  if (r.start_begin != r.start_any) return true;
+  for (int q = 0; q < r.nstates; q++) if ((r.accept[(size_t)q] & 2) && !(r.accept[(size_t)q] & 1)) return true;
+  return false;
+}
 int TdfaIndexCheck(rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, const int32_t* d_rows, int64_t n, int ncap, const ReaderGrid* grid = nullptr) {
   if (n <= 0) return RGX_OK;
+  if (c->prog && !TdfaIndexCheckNeeded(c->prog->p.t.tdfa)) return RGX_OK;
   unsigned* flag = reinterpret_cast<unsigned*>(c->d_cursor + 1);
   unsigned h = 0;
   HIP_TRY(hipMemsetAsync(flag, 0, 4, c->stream));

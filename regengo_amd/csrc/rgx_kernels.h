@@ -260,18 +260,25 @@ hipError_t LaunchTdfaEnds(const TdfaDev& D, const uint8_t* buf, int32_t len, int
 hipError_t LaunchTdfaQ11Anchored(const TdfaDev& D, const uint8_t* buf, int32_t len, int32_t* se, int64_t cap, int64_t max_n, long long* out_n,
                                  uint32_t* flags, hipStream_t stream);
 hipError_t LaunchTdfaChainSerial(const TdfaDev& D, const uint8_t* buf, int32_t len, const int32_t* ends, int32_t* se, int64_t max_n,
-                                 long long* out_n, uint32_t* flags, hipStream_t stream);
+                                 long long* out_n, uint32_t* flags, hipStream_t stream, const unsigned long long* accmask = nullptr);
+// The same ends[] SPARSE (rgx_tdfa.hip: tdfa_ends_sparse_kernel; programs whose start state does not accept): accmask[TdfaSlices(len)]
+// says which attempts accept, ends[p] is written for those p alone, *hmax (zeroed by the caller) = the longest match.  The kernels
+// below take `accmask` (nullptr: ends[] is dense).
+bool TdfaSparseEndsOffered(const TdfaDev& D);
+hipError_t LaunchTdfaEndsSparse(const TdfaDev& D, const uint8_t* buf, int32_t len, int32_t* ends, unsigned long long* accmask, unsigned* hmax, uint32_t* flags,
+                                hipStream_t stream, ReaderGrid grid = ReaderGrid());
 // ... and in parallel (programs with start_begin == start_any that cannot match empty): sync bits (TdfaSlices(len) words, desc =
 // TdfaSyncTiles(len) zeroed words), then LaunchTdfaChain twice: emit = 0 fills counts[TdfaSlices(len)], emit = 1 writes se behind
 // offs = the exclusive sum of the counts
 int64_t TdfaSyncTiles(int32_t len);
 int64_t TdfaSlices(int32_t len);
 hipError_t LaunchTdfaSync(const int32_t* ends, int32_t len, unsigned long long* sync, unsigned long long* desc, uint32_t* flags,
-                          hipStream_t stream, ReaderGrid grid = ReaderGrid());
+                          hipStream_t stream, ReaderGrid grid = ReaderGrid(), const unsigned long long* accmask = nullptr);
 size_t TdfaScanTempBytes(int64_t n);
 hipError_t LaunchTdfaScan(const int32_t* counts, int32_t* offs, int64_t n, void* temp, size_t temp_bytes, hipStream_t stream);
 hipError_t LaunchTdfaChain(const int32_t* ends, int32_t len, const unsigned long long* sync, int32_t* counts, const int32_t* offs,
-                           int32_t* se, int64_t max_n, int emit, uint32_t* flags, hipStream_t stream, ReaderGrid grid = ReaderGrid());
+                           int32_t* se, int64_t max_n, int emit, uint32_t* flags, hipStream_t stream, ReaderGrid grid = ReaderGrid(),
+                           const unsigned long long* accmask = nullptr);
 // rows[n][ntags]: the reported tags of every match of se (tdfa.go:998-1052: (-1, -1) = group left untouched)
 hipError_t LaunchTdfaTags(const TdfaDev& D, const uint8_t* buf, int32_t len, const int32_t* se, int64_t n, int32_t* rows, hipStream_t stream,
                           ReaderGrid grid = ReaderGrid());
@@ -282,7 +289,7 @@ int64_t TdfaQ11Tiles(int32_t len);
 int TdfaQ11TileBytes();
 size_t TdfaQ11ScanTempBytes(int64_t nslices);
 hipError_t LaunchTdfaQ11Index(const int32_t* ends, int32_t len, unsigned long long* accmask, int* rev, unsigned* hmax, void* temp, size_t temp_bytes,
-                              hipStream_t stream);
+                              hipStream_t stream, bool have_mask = false);
 int64_t TdfaQ11Groups(int32_t len);
 hipError_t LaunchTdfaQ11Chain(const int32_t* ends, int32_t len, const unsigned long long* accmask, const int* rev, int E, int32_t* fexit, int32_t* fcnt,
                               int32_t* gexit, int32_t* gcnt, int32_t* gent, long long* gbase, int32_t* tent, long long* tbase, long long* total,

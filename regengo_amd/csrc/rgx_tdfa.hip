@@ -147,12 +147,166 @@ __global__ __launch_bounds__(256) void tdfa_ends_kernel(TdfaDev D, const uint8_t
   }
 }
 
+// ---------------------------------------------------------------- ends, SPARSE (round 6): filter + candidates
+// tdfa_ends_kernel gives every start offset a lane and writes 4 bytes per input byte; almost every lane's attempt dies on its first
+// byte, the few that walk do so out of global memory, one dependent load per step, while the other 63 lanes of their wave wait:
+// 8.7 ms per GiB of web log, 1.5 % of what the memory system moves.  Only an offset whose byte the start state has a transition on can
+// accept -- for `https?://...` the 'h's -- so (programs whose start state does not accept; rgx_scan_fc.hip's shape):
+//   tile        16 KiB of input + 1 KiB behind it staged in LDS by coalesced 16-byte loads, the automaton's entries next to it;
+//   filter      a lane per 64-byte slice: one look-up per byte in a 256-byte table "the start state moves on this byte";
+//   candidates  compacted in position order into a list in LDS and dealt one per lane, round after round: dense waves walk, out of LDS;
+//   result      accmask[slice] bit b: the attempt from offset 64 slice + b accepts; ends[p] is written for THOSE p only (the array
+//               stays as large as the text but is touched where a match begins: every consumer asks the mask first); *hmax: the longest
+//               match (the FindAll wrapper's step bound).
+constexpr int kSpTile = 16384, kSpHalo = 1024, kSpList = 4096;
+struct SpLds {
+  unsigned long long acc[256];                     // the tile's accept bits, a word per slice
+  unsigned short list[kSpList];
+  unsigned cnt[4];
+  unsigned char first[256];                        // 1: the start state has a transition on this byte
+  __attribute__((aligned(16))) unsigned char tile[kSpTile + kSpHalo + 16];
+};
+template <bool LDS>
+__global__ __launch_bounds__(256) void tdfa_ends_sparse_kernel(TdfaDev D, const uint8_t* buf, int32_t len, int32_t* ends, unsigned long long* accmask,
+                                                               long long nslices, unsigned* hmax, uint32_t* flags, ReaderGrid grid, int dbg) {
+  extern __shared__ uint32_t smem[];
+  SpLds& L = *reinterpret_cast<SpLds*>(smem);
+  uint32_t* const ent_lds = smem + (sizeof(SpLds) + 3) / 4;
+  if (LDS) for (int k = threadIdx.x; k < D.nstates * 128; k += 256) ent_lds[k] = D.ent[k];
+  typename Tab<LDS>::P ent = LDS ? (typename Tab<LDS>::P)ent_lds : (typename Tab<LDS>::P)D.ent;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int st = D.start_any;
+  L.first[tid] = (tid < 128 && !(D.ent[(uint32_t)st * 128u + (uint32_t)tid] & kTDead)) ? 1 : 0;
+  const long long ntiles = ((long long)len + kSpTile - 1) / kSpTile;
+  int best = 0, steps = 0;
+  for (long long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    const long long tb = t * kSpTile;
+    const int have = (int)((long long)len - tb < kSpTile + kSpHalo ? (long long)len - tb : kSpTile + kSpHalo);     // bytes of the text in the LDS window
+    __syncthreads();                                 // (the tile of the round before is done with; first[] and the table are there)
+    for (int c = tid; c * 16 < kSpTile + kSpHalo; c += 256) {
+      uint4 v = uint4{0u, 0u, 0u, 0u};
+      if (c * 16 + 16 <= have) v = *reinterpret_cast<const uint4*>(buf + tb + c * 16);
+      else if (c * 16 < have) { unsigned char tmp[16]; for (int k = 0; k < 16; ++k) tmp[k] = c * 16 + k < have ? buf[tb + c * 16 + k] : 0; v = *reinterpret_cast<const uint4*>(tmp); }
+      *reinterpret_cast<uint4*>(L.tile + c * 16) = v;
+    }
+    L.acc[tid] = 0ull;
+    __syncthreads();
+#ifdef RGX_EXPERIMENT
+    if (dbg == 1) continue;
+#endif
+    // ---- filter: this lane's slice
+    unsigned long long cur = 0;
+    {
+      const int a = tid * 64;
+      const uint4* row = reinterpret_cast<const uint4*>(L.tile + a);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const uint4 w = row[q];
+        const unsigned ws[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) cur |= (unsigned long long)L.first[(ws[d] >> (8 * b)) & 255u] << (q * 16 + d * 4 + b);
+        }
+      }
+      const int nvalid = have - a < 64 ? have - a : 64;       // offsets of the slice that are offsets of the text (an attempt at len cannot accept here)
+      if (nvalid <= 0) cur = 0; else if (nvalid < 64) cur &= (1ull << nvalid) - 1ull;
+    }
+#ifdef RGX_EXPERIMENT
+    if (dbg == 2) { if (cur == 0x123456789ull) accmask[0] = cur; continue; }
+#endif
+    // ---- the candidates, in position order, into the list
+    const unsigned ccnt = (unsigned)__popcll(cur);
+    unsigned incl = ccnt;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) { const unsigned y = __shfl_up(incl, d, 64); if (lane >= d) incl += y; }
+    if (lane == 63) L.cnt[wave] = incl;
+    __syncthreads();
+    unsigned wbase = 0, ntot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) { if (w < wave) wbase += L.cnt[w]; ntot += L.cnt[w]; }
+    const bool fits = ntot <= (unsigned)kSpList;       // uniform
+    if (fits) {
+      unsigned k = wbase + incl - ccnt;
+      unsigned long long m = cur;
+      while (m) { L.list[k++] = (unsigned short)(tid * 64 + __builtin_ctzll(m)); m &= m - 1; }
+    }
+    __syncthreads();
+    auto attempt = [&](int rel) {
+      const int s = (int)tb + rel;
+      const int tend = GridTextEnd(s, len, grid);
+      int end = -1;
+      uint32_t rowi = (uint32_t)st * 128u;
+      int i = s;
+      // (two loops: the bytes of the LDS window by ds_read, what lies behind it -- rare -- out of memory; ONE loop with a select between
+      // the two compiles to a flat load per step, global-memory latency on the walk's critical path: 3.4 ms per GiB instead of ~1)
+      const int lds_hi = (int)tb + have < tend ? (int)tb + have : tend;
+      bool alive = true;
+      for (; i < lds_hi; ++i) {
+        const uint32_t c = (uint32_t)L.tile[i - (int)tb];
+        if (c >= 128u) { alive = false; break; }
+        const uint32_t e = ent[rowi + c];
+        if (e & kTDead) { alive = false; break; }
+        rowi = (e & kTNext) * 128u;
+        if ((e & kTAcc) || ((e & kTAccEot) && i == tend - 1)) end = i + 1;
+      }
+      if (alive) {
+        for (; i < tend; ++i) {
+          const uint32_t c = (uint32_t)buf[i];
+          if (c >= 128u) break;
+          const uint32_t e = ent[rowi + c];
+          if (e & kTDead) break;
+          rowi = (e & kTNext) * 128u;
+          if ((e & kTAcc) || ((e & kTAccEot) && i == tend - 1)) end = i + 1;
+        }
+      }
+      steps += i - s + 1;
+      if (end >= 0) {
+        ends[s] = end;
+        atomicOr(&L.acc[rel >> 6], 1ull << (rel & 63));
+        const int h = end - s > 1 ? end - s : 1;
+        best = h > best ? h : best;
+      }
+    };
+#ifdef RGX_EXPERIMENT
+    if (dbg == 3) continue;
+#endif
+    if (fits) {
+      for (unsigned j = (unsigned)tid; j < ntot; j += 256) attempt((int)L.list[j]);
+    } else {
+      // (a tile of nothing but candidates: every lane takes its own slice's)
+      unsigned long long m = cur;
+      while (m) { attempt(tid * 64 + __builtin_ctzll(m)); m &= m - 1; }
+    }
+    __syncthreads();
+    const long long sl = tb / 64 + tid;
+    if (sl < nslices) accmask[sl] = L.acc[tid];
+    if (__syncthreads_or(steps > kLaneStepBudget ? 1 : 0)) {       // (uniform: nobody is left behind at the next tile's barrier)
+      if (tid == 0) atomicOr(flags, kOverBudgetBit);
+      break;
+    }
+  }
+#pragma unroll
+  for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(best, d, 64); best = o > best ? o : best; }
+  // (only a wave that would RAISE the maximum: one device-scope address takes ~88 atomics per microsecond -- a quarter of a million
+  // waves on it were 3.0 of the kernel's 3.4 ms)
+  if (lane == 0 && best > 0 && (unsigned)best > __hip_atomic_load(hmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(hmax, (unsigned)best);
+}
+
+// The end of the attempt at p (-1: none) for the kernels below, whichever form ends[] has: dense (accmask == nullptr: every offset
+// written) or sparse (written where the mask says an attempt accepts).
+__device__ __forceinline__ int EndAt(const int32_t* ends, const unsigned long long* accmask, long long p) {
+  if (accmask && !((accmask[p >> 6] >> (p & 63)) & 1ull)) return -1;
+  return ends[p];
+}
+
 // ---------------------------------------------------------------- the chain, serially (one wave): programs whose start state at the
 // beginning of a text differs from the one elsewhere (^), short buffers, and FindBytes (max_n = 1).
 // se[2 * i], se[2 * i + 1] = start, end of match i; se_begin bit: was the attempt made from startStateBegin.  *out_n = matches.
 template <bool LDS>
 __global__ __launch_bounds__(64) void tdfa_chain_serial_kernel(TdfaDev D, const uint8_t* buf, int32_t len, const int32_t* ends,
-                                                               int32_t* se, long long max_n, long long* out_n, uint32_t* flags) {
+                                                               int32_t* se, long long max_n, long long* out_n, uint32_t* flags,
+                                                               const unsigned long long* accmask) {
   extern __shared__ uint32_t smem[];
   typename Tab<LDS>::P ent = StageEnt<LDS>(D, smem);
   const int lane = threadIdx.x;
@@ -164,13 +318,13 @@ __global__ __launch_bounds__(64) void tdfa_chain_serial_kernel(TdfaDev D, const 
     int s = -1, e = -1, begin = 0;
     // the attempt AT searchPos sees the beginning of a text
     int e0 = -1;
-    if (lane == 0) e0 = differs ? AttemptEnd(ent, buf, len, cur, D.start_begin, D.sinfo_begin, &steps) : ends[cur];
+    if (lane == 0) e0 = differs ? AttemptEnd(ent, buf, len, cur, D.start_begin, D.sinfo_begin, &steps) : EndAt(ends, accmask, cur);
     e0 = __shfl(e0, 0, 64);
     if (e0 >= 0) { s = cur; e = e0; begin = differs ? 1 : 0; }
     else {
       for (long long p0 = (long long)cur + 1; p0 <= len; p0 += 64) {
         const long long p = p0 + lane;
-        const int v = p <= len ? ends[p] : -1;
+        const int v = p <= len ? EndAt(ends, accmask, p) : -1;
         const unsigned long long m = __ballot(v >= 0);
         if (m) {
           const int f = __builtin_ctzll(m);
@@ -227,7 +381,7 @@ __device__ __forceinline__ int GridCover(int p, int e, const ReaderGrid& g) {
   return e < b ? e : b;
 }
 __global__ __launch_bounds__(256) void tdfa_sync_kernel(const int32_t* ends, int32_t len, unsigned long long* sync,
-                                                        unsigned long long* desc, uint32_t* flags, ReaderGrid grid) {
+                                                        unsigned long long* desc, uint32_t* flags, ReaderGrid grid, const unsigned long long* accmask) {
   __shared__ int wave_max[4];
   __shared__ int tile_excl;
   const int tile = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -235,7 +389,13 @@ __global__ __launch_bounds__(256) void tdfa_sync_kernel(const int32_t* ends, int
   // this lane's 64 ends: running maximum inside the slice
   int lmax = -1;
   // (two passes over the slice instead of 64 registers: the second re-reads L2-hot lines)
-  for (int k = 0; k < 64; ++k) { const long long p = base + k; if (p <= len) { const int v = GridCover((int)p, ends[p], grid); lmax = v > lmax ? v : lmax; } }
+  unsigned long long mybits = 0;         // sparse ends: this lane's 64 offsets are one word of the mask
+  if (accmask) {
+    if (base <= len) mybits = accmask[base >> 6];
+    for (unsigned long long m = mybits; m; m &= m - 1) { const long long p = base + __builtin_ctzll(m); const int v = GridCover((int)p, ends[p], grid); lmax = v > lmax ? v : lmax; }
+  } else {
+    for (int k = 0; k < 64; ++k) { const long long p = base + k; if (p <= len) { const int v = GridCover((int)p, ends[p], grid); lmax = v > lmax ? v : lmax; } }
+  }
   // exclusive running maximum across the lanes of the workgroup
   int incl = lmax;
 #pragma unroll
@@ -288,12 +448,33 @@ __global__ __launch_bounds__(256) void tdfa_sync_kernel(const int32_t* ends, int
   // the bits of this lane's slice
   unsigned long long bits = 0;
   int run = excl;
-  for (int k = 0; k < 64; ++k) {
-    const long long p = base + k;
-    if (p > len) break;
-    if (run <= (int)p) bits |= 1ull << k;
-    const int v = GridCover((int)p, ends[p], grid);
-    run = v > run ? v : run;
+  if (accmask) {
+    // between two accepting offsets `run` does not move: offsets p with run <= p are a suffix of each stretch
+    int k0 = 0;
+    const int kend = (long long)len - base + 1 < 64 ? (int)((long long)len - base + 1) : 64;      // offsets of the slice that exist (<= len)
+    unsigned long long m = mybits;
+    while (k0 < kend) {
+      const int k1 = m ? __builtin_ctzll(m) : kend;                 // the next accepting offset (or the end of the slice)
+      // offsets [k0, k1]: sync iff run <= base + k
+      int from = run - (int)base;
+      if (from < k0) from = k0;
+      const int to = k1 < kend ? k1 : kend - 1;
+      if (from <= to) bits |= ((to >= 63 ? ~0ull : ((1ull << (to + 1)) - 1ull)) & ~((1ull << from) - 1ull));
+      if (k1 >= kend) break;
+      const long long p = base + k1;
+      const int v = GridCover((int)p, ends[p], grid);
+      run = v > run ? v : run;
+      m &= m - 1;
+      k0 = k1 + 1;
+    }
+  } else {
+    for (int k = 0; k < 64; ++k) {
+      const long long p = base + k;
+      if (p > len) break;
+      if (run <= (int)p) bits |= 1ull << k;
+      const int v = GridCover((int)p, ends[p], grid);
+      run = v > run ? v : run;
+    }
   }
   if (base <= len) sync[base >> 6] = bits;
 }
@@ -302,7 +483,8 @@ __global__ __launch_bounds__(256) void tdfa_sync_kernel(const int32_t* ends, int
 // stretch), T = the first sync point at or behind the next slice.  emit == 0: counts[l] = matches; emit == 1: writes them behind
 // offs[l] (exclusive sum of the counts).
 __global__ __launch_bounds__(256) void tdfa_chain_kernel(const int32_t* ends, int32_t len, const unsigned long long* sync, int32_t* counts,
-                                                         const int32_t* offs, int32_t* se, long long max_n, int emit, uint32_t* flags, ReaderGrid grid) {
+                                                         const int32_t* offs, int32_t* se, long long max_n, int emit, uint32_t* flags, ReaderGrid grid,
+                                                         const unsigned long long* accmask) {
   const long long l = (long long)blockIdx.x * 256 + threadIdx.x;
   const long long nslices = ((long long)len + 1 + 63) >> 6;     // offsets 0 .. len
   if (l >= nslices) return;
@@ -320,12 +502,26 @@ __global__ __launch_bounds__(256) void tdfa_chain_kernel(const int32_t* ends, in
   while (cur < len && cur < T) {
     // first start >= cur with an accept
     int s = cur;
-    int e = ends[s];
-    while (e < 0) {
-      ++s;
-      if (s >= T || s > len) break;
+    int e = -1;
+    if (accmask) {
+      // the next accepting offset at or behind cur: word by word through the mask
+      long long w = s >> 6;
+      unsigned long long m = accmask[w] & (~0ull << (s & 63));
+      while (!m) {
+        ++w;
+        if (w * 64 >= T || w >= nslices) break;
+        m = accmask[w];
+        if (++steps > kLaneStepBudget) break;
+      }
+      if (m) { s = (int)(w * 64 + __builtin_ctzll(m)); if (s < T && s <= len) e = ends[s]; } else s = (int)T;
+    } else {
       e = ends[s];
-      if (++steps > kLaneStepBudget) break;
+      while (e < 0) {
+        ++s;
+        if (s >= T || s > len) break;
+        e = ends[s];
+        if (++steps > kLaneStepBudget) break;
+      }
     }
     if (e < 0 || s >= T || s >= grid.own_hi) break;
     // (grid: a match that ends behind its chunk is deferred -- the reference's loop breaks there, streaming.go:204-210 -- and the next
@@ -842,16 +1038,39 @@ hipError_t LaunchTdfaEnds(const TdfaDev& D, const uint8_t* buf, int32_t len, int
   return hipGetLastError();
 }
 
+bool TdfaSparseEndsOffered(const TdfaDev& D) { return (D.sinfo_any & 3u) == 0; }
+hipError_t LaunchTdfaEndsSparse(const TdfaDev& D, const uint8_t* buf, int32_t len, int32_t* ends, unsigned long long* accmask, unsigned* hmax, uint32_t* flags,
+                                hipStream_t stream, ReaderGrid grid) {
+  const bool lds = (size_t)D.nstates * 512 + sizeof(SpLds) + 64 <= 150 * 1024;
+  const size_t sh = sizeof(SpLds) + 16 + (lds ? (size_t)D.nstates * 512 : 0);
+  const long long ntiles = ((long long)len + kSpTile - 1) / kSpTile;
+  const int nwg = (int)std::min<long long>(std::max<long long>(ntiles, 1), 1 << 20);
+  const long long ns = TdfaSlices(len);
+  const int dbg = ExpEnv("RGX_SP_DEBUG") ? atoi(ExpEnv("RGX_SP_DEBUG")) : 0;       // (experiment builds: stage timings)
+  hipError_t rc;
+  // (the last slices -- offset len itself among them -- may lie behind the last tile: no attempt accepts there)
+  if ((rc = hipMemsetAsync(accmask + (ntiles * (kSpTile / 64) < ns ? ntiles * (kSpTile / 64) : ns), 0,
+                           (size_t)(ns - std::min<long long>(ntiles * (kSpTile / 64), ns)) * 8, stream)) != hipSuccess) return rc;
+  if (lds) {
+    if ((rc = AllowLds(tdfa_ends_sparse_kernel<true>, sh)) != hipSuccess) return rc;
+    hipLaunchKernelGGL(tdfa_ends_sparse_kernel<true>, dim3(nwg), dim3(256), sh, stream, D, buf, len, ends, accmask, ns, hmax, flags, grid, dbg);
+  } else {
+    if ((rc = AllowLds(tdfa_ends_sparse_kernel<false>, sh)) != hipSuccess) return rc;
+    hipLaunchKernelGGL(tdfa_ends_sparse_kernel<false>, dim3(nwg), dim3(256), sh, stream, D, buf, len, ends, accmask, ns, hmax, flags, grid, dbg);
+  }
+  return hipGetLastError();
+}
+
 hipError_t LaunchTdfaChainSerial(const TdfaDev& D, const uint8_t* buf, int32_t len, const int32_t* ends, int32_t* se, int64_t max_n,
-                                 long long* out_n, uint32_t* flags, hipStream_t stream) {
+                                 long long* out_n, uint32_t* flags, hipStream_t stream, const unsigned long long* accmask) {
   const bool lds = TdfaInLds(D, false);
   const size_t sh = TdfaShared(D, lds, false);
   hipError_t rc;
   if (lds) {
     if ((rc = AllowLds(tdfa_chain_serial_kernel<true>, sh)) != hipSuccess) return rc;
-    hipLaunchKernelGGL(tdfa_chain_serial_kernel<true>, dim3(1), dim3(64), sh, stream, D, buf, len, ends, se, (long long)max_n, out_n, flags);
+    hipLaunchKernelGGL(tdfa_chain_serial_kernel<true>, dim3(1), dim3(64), sh, stream, D, buf, len, ends, se, (long long)max_n, out_n, flags, accmask);
   } else {
-    hipLaunchKernelGGL(tdfa_chain_serial_kernel<false>, dim3(1), dim3(64), 0, stream, D, buf, len, ends, se, (long long)max_n, out_n, flags);
+    hipLaunchKernelGGL(tdfa_chain_serial_kernel<false>, dim3(1), dim3(64), 0, stream, D, buf, len, ends, se, (long long)max_n, out_n, flags, accmask);
   }
   return hipGetLastError();
 }
@@ -874,16 +1093,17 @@ int64_t TdfaSyncTiles(int32_t len) { return ((int64_t)len + 1 + kSyncTile - 1) /
 int64_t TdfaSlices(int32_t len) { return ((int64_t)len + 1 + 63) / 64; }
 
 hipError_t LaunchTdfaSync(const int32_t* ends, int32_t len, unsigned long long* sync, unsigned long long* desc, uint32_t* flags,
-                          hipStream_t stream, ReaderGrid grid) {
-  hipLaunchKernelGGL(tdfa_sync_kernel, dim3((unsigned)TdfaSyncTiles(len)), dim3(256), 0, stream, ends, len, sync, desc, flags, grid);
+                          hipStream_t stream, ReaderGrid grid, const unsigned long long* accmask) {
+  hipLaunchKernelGGL(tdfa_sync_kernel, dim3((unsigned)TdfaSyncTiles(len)), dim3(256), 0, stream, ends, len, sync, desc, flags, grid, accmask);
   return hipGetLastError();
 }
 
 hipError_t LaunchTdfaChain(const int32_t* ends, int32_t len, const unsigned long long* sync, int32_t* counts, const int32_t* offs,
-                           int32_t* se, int64_t max_n, int emit, uint32_t* flags, hipStream_t stream, ReaderGrid grid) {
+                           int32_t* se, int64_t max_n, int emit, uint32_t* flags, hipStream_t stream, ReaderGrid grid,
+                           const unsigned long long* accmask) {
   const int64_t ns = TdfaSlices(len);
   hipLaunchKernelGGL(tdfa_chain_kernel, dim3((unsigned)((ns + 255) / 256)), dim3(256), 0, stream, ends, len, sync, counts, offs, se,
-                     (long long)max_n, emit, flags, grid);
+                     (long long)max_n, emit, flags, grid, accmask);
   return hipGetLastError();
 }
 
@@ -950,7 +1170,7 @@ hipError_t LaunchTdfaFill(int32_t* rows, int64_t n, int ncap, void* temp, size_t
 // row's index; a lane per tile walks its tile once more and writes the (start, end) of its rows, whose tags are tdfa_tags_kernel's as
 // for every other row of this engine.  The web log, 1 GiB: 43 M (URL-shaped programs) to 180 M rows (version numbers) in 24-30 ms;
 // the C port of the emitted loop takes 6-30 s per GiB of it (and minutes where matches are rare: every row is found by a scan).
-constexpr int kQ11Tile = 16384;
+constexpr int kQ11Tile = 16384;      // (4096 with groups of 256, measured in round 6: 13.7 -> 15.2 ms URL-shaped, 23.5 -> 28.6 version numbers)
 namespace {
 // accmask[s] bit b: the attempt from offset 64 s + b accepts; *hmax: the longest step (atomicMax)
 __global__ __launch_bounds__(256) void q11_mask_kernel(const int32_t* ends, int32_t len, unsigned long long* accmask, long long nslices, unsigned* hmax) {
@@ -966,7 +1186,7 @@ __global__ __launch_bounds__(256) void q11_mask_kernel(const int32_t* ends, int3
   }
 #pragma unroll
   for (int d = 32; d >= 1; d >>= 1) { const int o = __shfl_xor(best, d, 64); best = o > best ? o : best; }
-  if (lane == 0 && best > 0) atomicMax(hmax, (unsigned)best);
+  if (lane == 0 && best > 0 && (unsigned)best > __hip_atomic_load(hmax, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(hmax, (unsigned)best);
 }
 struct Q11NzIdx {          // slice ns - 1 - i when it holds an accepting offset: the reverse scan's input
   const unsigned long long* m; long long ns;
@@ -1102,9 +1322,10 @@ size_t TdfaQ11ScanTempBytes(int64_t nslices) {
 }
 // accmask[nslices], rev[nslices], *hmax (zeroed by the caller) from ends[0 .. len]
 hipError_t LaunchTdfaQ11Index(const int32_t* ends, int32_t len, unsigned long long* accmask, int* rev, unsigned* hmax, void* temp, size_t temp_bytes,
-                              hipStream_t stream) {
+                              hipStream_t stream, bool have_mask) {
   const int64_t ns = TdfaSlices(len);
-  hipLaunchKernelGGL(q11_mask_kernel, dim3((unsigned)std::min<int64_t>((ns + 3) / 4, 1 << 16)), dim3(256), 0, stream, ends, len, accmask, (long long)ns, hmax);
+  // (have_mask: LaunchTdfaEndsSparse left accmask and *hmax behind)
+  if (!have_mask) hipLaunchKernelGGL(q11_mask_kernel, dim3((unsigned)std::min<int64_t>((ns + 3) / 4, 1 << 16)), dim3(256), 0, stream, ends, len, accmask, (long long)ns, hmax);
   hipcub::CountingInputIterator<long long> cnt(0);
   hipcub::TransformInputIterator<int, Q11NzIdx, hipcub::CountingInputIterator<long long>> in(cnt, Q11NzIdx{accmask, ns});
   return hipcub::DeviceScan::InclusiveScan(temp, temp_bytes, in, rev, hipcub::Min(), (int)ns, stream);
