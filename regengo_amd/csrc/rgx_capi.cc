@@ -2415,6 +2415,58 @@ RGX_API int rgx_find_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8_
     else memset(spans, 0, (size_t)ncap * 4);
     return RGX_OK;
   }
+  // One LONG text of an unanchored pattern (round 6; find.go:469-591 over megabytes): the per-string kernels give a text one lane, so the
+  // leftmost-first match comes from the parallel FindAll scan with n = 1 -- in reference mode it is the emitted loop's answer iff the
+  // loop's attempt offsets 0, fail + 1, ... land ON its start (every attempt in front of it fails: the scan found no match there), which
+  // is the reader's gap test for that one row (rgx_kernels.hip: reader_grid_slow_kernel / memo_reader_grid_slow_kernel, from behind the
+  // last reset byte in front of the match).  The loop steps over the match: RGX_E_UNSUPPORTED, the Go path keeps the call.
+  if (p && c && c->prog == p && p->p.d_arena && !p->p.dev.anchored && (int64_t)len > kBatchSearchMaxLen && !RefTdfaMode(p)) {
+    int rc = CheckCtx(p, c);
+    if (rc != RGX_OK) return rc;
+    if (!buf) return RGX_E_INVALID;
+    const Tables& t = p->p.t;
+    const bool stdlib = (t.flags & RGX_FLAG_STDLIB_SEMANTICS) != 0;
+    const bool ref_ok = p->p.dev.ref_find_ok || RefMemoMode(p) || t.ncap <= 2;
+    if (!stdlib && !ref_ok) {
+      SetError("reference-mode FindBytes is not offered for this pattern (a memoising engine beyond the interpreter): keep the Go path, or compile with RGX_FLAG_STDLIB_SEMANTICS");
+      return RGX_E_UNSUPPORTED;
+    }
+    if (len > 0x7FFFFF00ull) { SetError("text larger than 2^31-256 bytes: keep the Go path"); return RGX_E_TOO_LARGE; }
+    const int ncap = t.ncap;
+    if ((rc = Ensure(&c->d_in, &c->in_cap, (int64_t)len + 64)) != RGX_OK) return rc;
+    if ((rc = Ensure(&c->d_out, &c->out_cap, (int64_t)ncap + 16)) != RGX_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream));
+    rgx_result r{};
+    const int64_t w = FindAllDevice(p, c, c->d_in, len, 1, c->d_out, 1, false, &r);
+    if (w < 0) return (int)w;
+    if (w == 0) { *found = 0; memset(spans, 0, (size_t)ncap * 4); return RGX_OK; }
+    if (!stdlib && ncap > 2) {
+      if ((rc = Ensure(&c->d_glist, &c->glist_cap, 16)) != RGX_OK) return rc;
+      unsigned* flag = reinterpret_cast<unsigned*>(c->d_cursor + 1);
+      unsigned h = 0;
+      HIP_TRY(hipMemsetAsync(flag, 0, 4, c->stream));
+      HIP_TRY(hipMemsetAsync(c->d_glist, 0, 32, c->stream));        // list[4] = row 0
+      const uint8_t* view = c->d_in;
+      if ((rc = MatchView(p, c, c->d_in, len, &view)) != RGX_OK) return rc;
+      if (RefMemoMode(p) && !p->p.dev.ref_find_ok) {
+        int64_t nlanes = 0;
+        unsigned long long *vis = nullptr, *stk = nullptr;
+        if ((rc = MemoScratchFor(c, 4096, 4096, 1, &nlanes, &vis, &stk)) != RGX_OK) return rc;
+        HIP_TRY(LaunchMemoReaderGridSlow(p->p.dev, c->d_in, (int32_t)len, c->d_out, ncap, ReaderGrid(), c->d_glist + 4, 1, vis, 4096, stk, 4096, nlanes, flag, c->stream));
+      } else {
+        HIP_TRY(LaunchReaderGridSlow(p->p.dev, view, (int32_t)len, c->d_out, ncap, ReaderGrid(), c->d_glist + 4, 1, flag, c->stream));
+      }
+      HIP_TRY(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if (h) {
+        SetError("reference-mode FindBytes: the emitted loop's restart rule steps over the leftmost-first match of this text (or its attempts in front of the match are not vouched for): keep the Go path");
+        return RGX_E_UNSUPPORTED;
+      }
+    }
+    HIP_TRY(hipMemcpy(spans, c->d_out, (size_t)ncap * 4, hipMemcpyDeviceToHost));
+    *found = 1;
+    return RGX_OK;
+  }
   // One text through the per-string kernels: a lane is a sequential loop, so they take strings of at most kBatchSearchMaxLen bytes of an
   // unanchored pattern (BatchLengthGuard) -- refused here, before the text crosses PCIe, not behind the copy
   if (p && p->p.d_arena && !p->p.dev.anchored && (int64_t)len > kBatchSearchMaxLen) {

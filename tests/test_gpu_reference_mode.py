@@ -282,3 +282,41 @@ def test_find_reader_on_random_patterns(torch_dev):
     print("programs", progs, "agreed", agreed, "refused", refused, "rows", rows)
     if F.fuzz_default():
         assert progs >= 120 and agreed >= 800 and rows >= 1500 and refused <= agreed // 3, (progs, agreed, refused, rows)
+
+
+def test_find_bytes_of_one_long_text(torch_dev):
+    """VERDICT r5 item 5 (find.go:469-591 over megabytes): FindBytes of ONE 64 MiB text of an unanchored pattern is answered on the device --
+    the leftmost-first match from the parallel scan, and in reference mode the check that the emitted loop's attempts land on its start
+    (plain engine: the right-most-path automaton; memoising engine: the interpreter) -- == the oracle's C port of FindBytesReuse; where
+    the restart rule steps over the match (`12024-01-15`) the call is refused, never answered differently; under
+    RGX_FLAG_STDLIB_SEMANTICS it is plain leftmost-first."""
+    from oracle.gen_c import CMatcher
+    from regengo_amd import Compiled, _capi, synth
+    DATE = r"(?P<year>\d{4})-(?P<month>\d{2})-(?P<day>\d{2})"
+    URL = r"(?P<full>(?P<proto>https?|ftp)://(?P<host>[\w.-]+)(?P<port>:\d+)?(?P<path>/[\w./-]*)?)"
+    n = 64 << 20
+    noise = (b"lorem ipsum dolor sit amet, consectetur adipiscing elit 12:34:56 [INFO] id=77 took 12 ms\n" * (n // 80 + 1))[:n]
+    for pat, hit, miss in ((DATE, b"2024-01-15", b"12024-02-16"), (URL, b"https://a.b-c.org:443/x/y", b"hhttp://x.y/z")):
+        cm = CMatcher(pat)
+        c = Compiled(pat).to(0)
+        cs = Compiled(pat, stdlib=True).to(0)
+        for where in (70000, 40 << 20, n - 100):
+            t = bytearray(noise)
+            t[where:where + len(hit)] = hit
+            t = bytes(t)
+            exp = cm.find(t)
+            r, ok = c.FindBytes(t)
+            assert exp is not None and ok and list(r.spans) == exp and r.Match == hit, (pat, where)
+            assert list(cs.FindBytes(t)[0].spans[:2]) == exp[:2]
+        assert c.FindBytes(noise) == (None, False) and cm.find(noise) is None
+        # the restart rule steps over a match: the reference reports the LATER one (or none) -- refused here, plain leftmost-first under the flag
+        t = bytearray(noise)
+        t[1 << 20:(1 << 20) + len(miss)] = miss
+        t[50 << 20:(50 << 20) + len(hit)] = hit
+        t = bytes(t)
+        exp = cm.find(t)
+        assert exp is not None and exp[0] == 50 << 20, (pat, exp)
+        with pytest.raises(_capi.RgxError) as ei:
+            c.FindBytes(t)
+        assert ei.value.status == -3
+        assert cs.FindBytes(t)[0].spans[0] == (1 << 20) + 1
