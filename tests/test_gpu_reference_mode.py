@@ -295,28 +295,33 @@ def test_find_bytes_of_one_long_text(torch_dev):
     DATE = r"(?P<year>\d{4})-(?P<month>\d{2})-(?P<day>\d{2})"
     URL = r"(?P<full>(?P<proto>https?|ftp)://(?P<host>[\w.-]+)(?P<port>:\d+)?(?P<path>/[\w./-]*)?)"
     n = 64 << 20
-    noise = (b"lorem ipsum dolor sit amet, consectetur adipiscing elit 12:34:56 [INFO] id=77 took 12 ms\n" * (n // 80 + 1))[:n]
-    for pat, hit, miss in ((DATE, b"2024-01-15", b"12024-02-16"), (URL, b"https://a.b-c.org:443/x/y", b"hhttp://x.y/z")):
+    line = b"lorem ipsum dolor sit amet, consectetur adipiscing elit 12:34:56 [INFO] id=77 took 12 ms\n"
+    L = len(line)
+    noise = (line * (n // L + 1))[:n]
+    # (miss: a text on which the emitted loop steps over a match -- the attempt at its first byte fails `skip` bytes in, on the LAST
+    # alternative's path, and the loop resumes behind that offset: `ftp` + `http://...` loses the URL that begins at the h)
+    for pat, hit, miss, skip in ((DATE, b"2024-01-15", b"12024-02-16", 1), (URL, b"https://a.b-c.org:443/x/y", b"ftphttp://x.y/z", 3)):
         cm = CMatcher(pat)
         c = Compiled(pat).to(0)
         cs = Compiled(pat, stdlib=True).to(0)
-        for where in (70000, 40 << 20, n - 100):
+        for where in (70000 // L * L, (40 << 20) // L * L, (n - 200) // L * L):          # (at the beginning of a line: behind a newline)
             t = bytearray(noise)
             t[where:where + len(hit)] = hit
             t = bytes(t)
             exp = cm.find(t)
             r, ok = c.FindBytes(t)
-            assert exp is not None and ok and list(r.spans) == exp and r.Match == hit, (pat, where)
+            assert exp is not None and ok and list(r.spans) == exp and r.Match == t[exp[0]:exp[1]] and r.Match.startswith(hit), (pat, where)
             assert list(cs.FindBytes(t)[0].spans[:2]) == exp[:2]
         assert c.FindBytes(noise) == (None, False) and cm.find(noise) is None
         # the restart rule steps over a match: the reference reports the LATER one (or none) -- refused here, plain leftmost-first under the flag
         t = bytearray(noise)
-        t[1 << 20:(1 << 20) + len(miss)] = miss
-        t[50 << 20:(50 << 20) + len(hit)] = hit
+        at_miss, at_hit = (1 << 20) // L * L, (50 << 20) // L * L
+        t[at_miss:at_miss + len(miss)] = miss
+        t[at_hit:at_hit + len(hit)] = hit
         t = bytes(t)
         exp = cm.find(t)
-        assert exp is not None and exp[0] == 50 << 20, (pat, exp)
+        assert exp is not None and exp[0] == at_hit, (pat, exp)
         with pytest.raises(_capi.RgxError) as ei:
             c.FindBytes(t)
         assert ei.value.status == -3
-        assert cs.FindBytes(t)[0].spans[0] == (1 << 20) + 1
+        assert cs.FindBytes(t)[0].spans[0] == at_miss + skip
