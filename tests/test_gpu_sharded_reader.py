@@ -110,8 +110,14 @@ def test_bench_config_lines_at_reduced_size(gpu):
     assert r["config"]["parity_generator_truth"] and r["roofline"]["frac"] > 0 and r["config"]["workload"].startswith("C3")
     r = _bench(["--config", "c4", "--windows", "2", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
     assert r["config"]["parity_oracle_fixture_periodic"] and r["config"]["matches_total"] == r["config"]["expected_matches"] > 10_000_000
+    # (round 6) the line's value is the reference's FindReader over the chunk grid: fixture tiles with the grid's rule + the C port of the read loop
+    rd = r["config"]["reader"]
+    assert rd["parity_fixture_tiles_with_the_grid_rule"] is True and rd["parity_oracle_read_loop"]["identical"] is True and rd["parity_oracle_read_loop"]["mode"] == 1, rd
+    assert rd["callbacks_total"] < r["config"]["matches_total"] and r["value_findall_semantics"]["value"] > 0 and r["roofline"]["frac"] > 0
     r = _bench(["--config", "c5", "--bytes", str(64 << 20), "--max-patterns", "60", "--steps", "1", "--warmup", "0", "--no-cpu-baseline"])
     assert r["config"]["parity_counts_vs_oracle_fixture"], r["config"]
     assert r["config"]["patterns"] + r["config"]["patterns_skipped"] == 60
     r = _bench(["--bytes", str(1 << 26), "--steps", "3", "--warmup", "1", "--no-cpu-baseline"])
-    assert r["config"]["parity_closed_form"] and r["repeats"] >= 1 and r["roofline"]["traffic_source"] is None or True
+    assert r["config"]["parity_closed_form"] is True and r["repeats"] >= 1
+    # (the PMC traffic is cited from profiles/ only for the kernel and size the run launched: a 64 MiB run cites a file or nothing, never a guess)
+    assert r["roofline"]["traffic"] is None or (r["roofline"]["traffic_source"] or "").startswith("profiles/")
