@@ -265,7 +265,17 @@ bool RefReplaceOffered(const Tables& t) {
   return ((have_rm && !t.ref_memo && t.ref_find_engine <= 0) || HasRefMemo(t) || HasRefTdfa(t)) && !t.can_match_empty;
 }
 // FindReader / FindReaderCount: the same, or the Tagged DFA's FindBytesReuse
-bool RefStreamOffered(const Tables& t) { return RefReplaceOffered(t) || (HasRefTdfa(t) && !t.can_match_empty); }
+// ... and, round 6, patterns that can match EMPTY and hold no empty-width instruction (`a*`, `\d*`, `x?`), plain or memoising engine: an
+// attempt of such a pattern succeeds at EVERY offset, at offset 0 of whatever slice it is made in, so the loop of streaming.go:175-244
+// never restarts (no Q1), bytes.Index finds the match's text at offset 0 of the slice (no Q4), the slice's first byte is no different
+// from any other (no context), and FindBytesReuse starts every call with a clean memo (no Q8): the loop's matches -- `searchPos++` behind
+// an empty one, the empty match right behind a non-empty one -- are FindAllBytes' over the chunk, which the scan kernels reproduce
+// (find.go:209-211, 452-457).  One chunk per call only (rgx_find_chunk / rgx_count_chunk): a run of chunks reports an empty match AT a
+// keep point twice, once per chunk, and a row's chunk would no longer follow from its offset.
+bool EmptyStreamOffered(const Tables& t) {
+  return t.can_match_empty && t.ref_find_engine != 1 && !t.lookahead_mode && !t.ctx_sensitive && !t.bot_sensitive && !t.anchored;
+}
+bool RefStreamOffered(const Tables& t) { return RefReplaceOffered(t) || (HasRefTdfa(t) && !t.can_match_empty) || EmptyStreamOffered(t); }
 int RefuseFindAll(const rgx_program* p, bool whole_text = false) {
   const Tables& t = p->p.t;
   if ((t.flags & RGX_FLAG_STDLIB_SEMANTICS) || RefFindAllOffered(t)) return RGX_OK;
@@ -2712,6 +2722,10 @@ int64_t FindChunksDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t*
   if (res) { res->chunks = R.chunks(); res->next_from = R.tail ? (int64_t)len : R.kfull * R.S; }
   if (R.chunks() == 0) return 0;
   const bool stdlib = (t.flags & RGX_FLAG_STDLIB_SEMANTICS) != 0;
+  if (t.can_match_empty && !stdlib) {
+    SetError("a pattern that matches empty reports an empty match AT a chunk's keep point from both chunks: rows of a run no longer say which chunk they belong to; hand the chunks to rgx_find_chunk one by one");
+    return RGX_E_UNSUPPORTED;
+  }
   const bool tdfa = RefTdfaMode(p);
   ReaderGrid G;
   G.stride = (int32_t)R.S; G.bufsize = (int32_t)B;

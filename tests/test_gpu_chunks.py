@@ -396,3 +396,40 @@ def test_matches_that_do_not_begin_behind_a_reset_byte(torch_dev):
     with pytest.raises(RgxError) as ei:
         c.FindChunksDevice(torch.from_numpy(host.copy()).cuda(), cfg, final=True)
     assert ei.value.status == -11
+
+
+@pytest.mark.parametrize("pattern", [r"(?P<a>a*)", r"(?P<d>\d*)", r"(?P<x>x?)(?P<y>y*)", r"(?P<w>\w*)\s?"])
+def test_patterns_that_match_empty_stream_chunk_by_chunk(torch_dev, pattern):
+    """VERDICT r5 'missing' 6: FindReader of a pattern that can match empty (and holds no empty-width instruction) -- every attempt of the
+    emitted loop succeeds at offset 0 of its slice, so the loop's matches (`searchPos++` behind an empty one, streaming.go:238-242) are
+    FindAllBytes' over the chunk; offered one chunk per call (rgx_find_chunk: the Python mirror's FindReader) == oracle.engines.find_reader,
+    an empty match at a keep point reported by both chunks included; a RUN of chunks is refused for such a pattern (the rows would not say
+    which chunk they belong to)."""
+    import io
+    from oracle import engines as E
+    from regengo_amd import Compiled
+    from regengo_amd._capi import RgxError
+    from regengo_amd.stream import Config
+    import random
+    rng = random.Random(4)
+    comp = E.Compiled(pattern)
+    c = Compiled(pattern).to(0)
+    assert c.info.can_match_empty and c.info.ref_stream_offered == 1
+    data = bytes(rng.choice(b"aa1xy \n") for _ in range(150000))
+    for B, ML in ((65536, 0), (65536, 7)):
+        exp = []
+        pos = [0]
+
+        def read(k):
+            d = data[pos[0]:pos[0] + k]
+            pos[0] += len(d)
+            return d
+        assert comp.FindReader(read, E.StreamConfig(B, ML), lambda m: exp.append((m.StreamOffset, m.ChunkIndex, m.match_bytes)) or True) is None
+        got = []
+        c.FindReader(io.BytesIO(data), Config(B, ML), lambda m: got.append((m.StreamOffset, m.ChunkIndex, m.Result.Match)) or True)
+        assert got == exp and len(exp) > 50000, (pattern, B, ML, len(got), len(exp))
+        assert c.FindReaderCount(io.BytesIO(data), Config(B, ML)) == len(exp)
+    import torch
+    with pytest.raises(RgxError) as ei:
+        c.FindChunksDevice(torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda(), c._resolve(Config(65536, 0)))
+    assert ei.value.status == -3
