@@ -346,8 +346,9 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_sorted_kernel(const 
   uint32_t stop_next = __builtin_nontemporal_load(ctl);
   for (int it = 0; grp < ngroups; grp += G, ++it) {
     uint32_t* const h = hist + ((it & 1) << 4);
-    // the optimistic launch: a string longer than the tag bytes hold voids the batch -- the host takes the general path
-    if (__builtin_amdgcn_ballot_w64(lenc < 0) != 0ull && lane == 0) atomicOr(ctl, 1u);
+    // the optimistic launch: a group with a string longer than the tag bytes hold is LEFT ALONE (hist[34 + parity]: read behind the barrier)
+    // and listed for the general kernel; only more such groups than the list holds void the batch -- the host takes the general path
+    if (__builtin_amdgcn_ballot_w64(lenc < 0) != 0ull && lane == 0) hist[34 + (it & 1)] = 1u;
     if (stop_next != 0u) hist[32] = 1u;                       // (one wave seeing the word is all waves leaving together, below)
     const int len0 = lenc < 0 ? 0 : lenc;
     const uint32_t bin = (uint32_t)len0 >> 2;                 // <= 14
@@ -377,6 +378,12 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_sorted_kernel(const 
     }
     if (tid < 16) hist[(((it + 1) & 1) << 4) + tid] = 0;       // the next group's counts (last read a group ago)
     const uint32_t halt = hist[32];
+    const bool gbad = __builtin_amdgcn_readfirstlane(hist[34 + (it & 1)]) != 0u;      // (written before the barrier above, cleared two groups on)
+    if (tid == 16) hist[34 + ((it + 1) & 1)] = 0;
+    if (gbad && tid == 0) {
+      const uint32_t k = atomicAdd(ctl + 2, 1u);
+      if (k < kTinyGroupCap) ctl[4 + kTinyListCap + k] = (uint32_t)grp; else atomicOr(ctl, 1u);
+    }
     flush();
     RGX_TINY_WINDOW(grp + G, an, bn, gbn, gen, wbn, wvn, reln, lenn);
     RGX_TINY_PIECES(wbn, wvn);
@@ -386,8 +393,8 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_sorted_kernel(const 
     if (__builtin_amdgcn_readfirstlane(halt) != 0u) break;    // (the same word for every wave: written before the barrier above)
     __syncthreads();
     const uint32_t e = perm[(((uint32_t)wave + (uint32_t)it) & 3u) * 64u + (uint32_t)lane];
-    const uint32_t rel = e & 16383u;
-    const int len = (int)((e >> 14) & 63u);
+    const uint32_t rel = gbad ? 0u : (e & 16383u);
+    const int len = gbad ? 0 : (int)((e >> 14) & 63u);
     const uint32_t addr = win_at + rel;
     const L32 w32 = (L32)(uintptr_t)(addr & ~3u);
     const uint32_t sh = addr & 3u;
@@ -417,7 +424,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_sorted_kernel(const 
         }
     }
     fprev = TinyFinish<NREG, REF>(L, unset, ntrack, reg_of, rprev);
-    gprev = grp;
+    gprev = gbad ? -1 : grp;                                   // (a group left to the general kernel writes nothing)
     pprev = (int)(e >> 20);
   }
   flush();

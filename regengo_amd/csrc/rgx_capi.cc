@@ -116,6 +116,14 @@ namespace {
     }                                                                                         \
   } while (0)
 
+// Device -> host copies of results: ordered on the context's stream (created non-blocking: a plain hipMemcpy on the null stream does NOT
+// wait for the kernels queued on it), complete on return.
+static inline hipError_t CopyOut(rgx_stream_ctx* c, void* dst, const void* src, size_t bytes) {
+  hipError_t rc = hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToHost, c->stream);
+  return rc != hipSuccess ? rc : hipStreamSynchronize(c->stream);
+}
+
+
 template <class T>
 int Ensure(T** ptr, int64_t* cap, int64_t need) {
   if (*cap >= need && *ptr) return RGX_OK;
@@ -588,7 +596,11 @@ bool TdfaIndexCheckNeeded(const RefTdfa& r) {
 }
 int TdfaIndexCheck(rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, const int32_t* d_rows, int64_t n, int ncap, const ReaderGrid* grid = nullptr) {
   if (n <= 0) return RGX_OK;
-  if (c->prog && !TdfaIndexCheckNeeded(c->prog->p.t.tdfa)) return RGX_OK;
+  if (c->prog && !TdfaIndexCheckNeeded(c->prog->p.t.tdfa)) {
+    // (no test to run -- but the rows are complete when this returns, as they are behind the test: callers hand them to other streams)
+    HIP_TRY(hipStreamSynchronize(c->stream));
+    return RGX_OK;
+  }
   unsigned* flag = reinterpret_cast<unsigned*>(c->d_cursor + 1);
   unsigned h = 0;
   HIP_TRY(hipMemsetAsync(flag, 0, 4, c->stream));
@@ -1833,7 +1845,7 @@ RGX_API int64_t rgx_find_all_starts(const rgx_program* p, rgx_stream_ctx* c, con
   if ((rc = Ensure(&c->d_out, &c->out_cap, (int64_t)cap + 16)) != RGX_OK) return rc;
   HIP_TRY(hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream));
   const int64_t w = rgx_find_all_starts_device(p, c, c->d_in, len, n, c->d_out, cap, res);
-  if (w > 0) HIP_TRY(hipMemcpy(starts, c->d_out, (size_t)w * 4, hipMemcpyDeviceToHost));
+  if (w > 0) HIP_TRY(CopyOut(c, starts, c->d_out, (size_t)w * 4));
   return w;
 }
 
@@ -1866,7 +1878,7 @@ RGX_API int64_t rgx_find_all_bytes(const rgx_program* p, rgx_stream_ctx* c, cons
   HIP_TRY(hipMemcpyAsync(c->d_in, buf, len, hipMemcpyHostToDevice, c->stream));
   int64_t w = RefTdfaMode(p) ? TdfaFindAllDevice(p, c, c->d_in, len, n, c->d_out, cap_records, false, res)
                              : FindAllDevice(p, c, c->d_in, len, n, c->d_out, cap_records, false, res);
-  if (w > 0) HIP_TRY(hipMemcpy(spans, c->d_out, (size_t)w * ncap * 4, hipMemcpyDeviceToHost));
+  if (w > 0) HIP_TRY(CopyOut(c, spans, c->d_out, (size_t)w * ncap * 4));
   return w;
 }
 
@@ -1947,7 +1959,7 @@ RGX_API int rgx_match_bytes_device(const rgx_program* p, rgx_stream_ctx* c, cons
     const int64_t r = MemoMatchBatch(p, c, d_buf, d_off, 1, d_m);
     if (r < 0) return (int)r;
     uint8_t f = 0;
-    HIP_TRY(hipMemcpy(&f, d_m, 1, hipMemcpyDeviceToHost));
+    HIP_TRY(CopyOut(c, &f, d_m, 1));
     *matched = f;
     return RGX_OK;
   }
@@ -1973,7 +1985,7 @@ RGX_API int rgx_match_bytes_device(const rgx_program* p, rgx_stream_ctx* c, cons
     HIP_TRY(hipStreamSynchronize(c->stream));
     if ((int64_t)s0 > kRefLaneBytes) {
       uint8_t back[kBack];
-      HIP_TRY(hipMemcpy(back, d_buf + s0 - kBack, kBack, hipMemcpyDeviceToHost));
+      HIP_TRY(CopyOut(c, back, d_buf + s0 - kBack, kBack));
       int64_t x = -1;
       for (int64_t q = kBack - 1; q >= 0; --q)
         if (t.reset_byte[back[q]]) { x = (int64_t)s0 - kBack + q + 1; break; }
@@ -2106,7 +2118,7 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
       // strings whose attempts the replay kernel has to walk one by one (ctl[1], the list behind)
       // two control sets ([gave up, flagged, -, -] + the list), used alternately: the call's last kernel zeroes the other one and
       // writes this one's four words to pinned host memory (words 6-7 of h_read), so the call is two launches and one synchronisation
-      constexpr size_t kSetWords = 4 + kTinyListCap;
+      constexpr size_t kSetWords = 4 + kTinyListCap + kTinyGroupCap;
       if (!c->d_tiny_ctl) {
         HIP_TRY(hipMalloc((void**)&c->d_tiny_ctl, 2 * kSetWords * 4));
         HIP_TRY(hipMemsetAsync(c->d_tiny_ctl, 0, 2 * kSetWords * 4, c->stream));
@@ -2122,10 +2134,33 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
                                     other, ref_mode && !T.anchored, c->stream));
       HIP_TRY(hipStreamSynchronize(c->stream));
       const uint32_t h_ctl[4] = {hc[0], hc[1], hc[2], hc[3]};
-      if (!h_ctl[0]) {
+      const bool groups_left = h_ctl[2] != 0;      // groups of 256 strings the kernel left alone: one of their strings is beyond its tag bytes
+      const bool fused_ok = !ref_mode || BatchSearchFits(*U, T, true, d_concat, true);
+      if (!h_ctl[0] && (!groups_left || (h_ctl[2] <= kTinyGroupCap && fused_ok))) {
         if (ref_mode && h_ctl[1] >= kTinyListCap) {
           // (more flagged strings than the list holds: every match is at most kTinyMaxLen bytes, the LDS trace of ref_fix_kernel holds it)
           HIP_TRY(LaunchBatchRefFix(T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, c->d_trace, c->stream, 1));
+          HIP_TRY(hipStreamSynchronize(c->stream));
+        }
+        if (groups_left) {
+          // those groups through the general kernel (the preamble of the whole-batch path below: scratch by the batch's bytes, the length
+          // guard of reference mode), the strings it flags finished by the replay kernel -- flagged ones ONLY: the tiny kernel's rows are final
+          uint64_t h_last = 0;
+          unsigned long long h_max = 0;
+          if (ref_mode) {
+            HIP_TRY(hipMemsetAsync(c->d_cursor + 2, 0, 8, c->stream));
+            HIP_TRY(LaunchMaxStringLen(d_offsets, (int64_t)nstr, c->d_cursor + 2, c->stream));
+            HIP_TRY(hipMemcpyAsync(&h_max, c->d_cursor + 2, 8, hipMemcpyDeviceToHost, c->stream));
+          }
+          HIP_TRY(hipMemcpyAsync(&h_last, d_offsets + nstr, 8, hipMemcpyDeviceToHost, c->stream));
+          HIP_TRY(hipStreamSynchronize(c->stream));
+          if (ref_mode && (int64_t)h_max > kBatchSearchMaxLen) return BatchLengthGuard(c, d_offsets, nstr, kBatchSearchMaxLen, -1);
+          const int64_t need = ((int64_t)h_last + 2 * (int64_t)nstr + 64 + 1) / 2 * (U->nstates <= 256 ? 1 : 2);
+          const int64_t need_fix = ref_mode ? (int64_t)h_last + 2 * (int64_t)nstr + 64 : 0;
+          if ((rc = Ensure(&c->d_trace, &c->trace_cap, std::max(need, need_fix))) != RGX_OK) return rc;
+          HIP_TRY(LaunchBatchSearch(*U, T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, c->d_trace, c->stream,
+                                    BatchWindowFor((int64_t)h_last, (int64_t)nstr), ref_mode ? 1 : 0, ctl + 4 + kTinyListCap, (int)h_ctl[2]));
+          if (ref_mode) HIP_TRY(LaunchBatchRefFix(T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, c->d_trace, c->stream, 1));
           HIP_TRY(hipStreamSynchronize(c->stream));
         }
         return (int64_t)nstr;
@@ -2421,7 +2456,7 @@ RGX_API int rgx_find_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8_
     const int64_t n = TdfaChainDevice(p, c, c->d_in, len, 1, c->d_out, 1, nullptr);
     if (n < 0) return (int)n;
     *found = n > 0;
-    if (n > 0) HIP_TRY(hipMemcpy(spans, c->d_out, (size_t)ncap * 4, hipMemcpyDeviceToHost));
+    if (n > 0) HIP_TRY(CopyOut(c, spans, c->d_out, (size_t)ncap * 4));
     else memset(spans, 0, (size_t)ncap * 4);
     return RGX_OK;
   }
@@ -2473,7 +2508,7 @@ RGX_API int rgx_find_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8_
         return RGX_E_UNSUPPORTED;
       }
     }
-    HIP_TRY(hipMemcpy(spans, c->d_out, (size_t)ncap * 4, hipMemcpyDeviceToHost));
+    HIP_TRY(CopyOut(c, spans, c->d_out, (size_t)ncap * 4));
     *found = 1;
     return RGX_OK;
   }
@@ -2536,7 +2571,7 @@ RGX_API int64_t rgx_find_chunk(const rgx_program* p, rgx_stream_ctx* c, const ui
       if (w < 0) return w;
       if (ReaderCheckApplies(p) && (rc = ReaderCheck(p, c, c->d_in, data_len, c->d_out, w)) != RGX_OK) return rc;
     }
-    if (w > 0) HIP_TRY(hipMemcpy(spans, c->d_out, (size_t)w * ncap * 4, hipMemcpyDeviceToHost));
+    if (w > 0) HIP_TRY(CopyOut(c, spans, c->d_out, (size_t)w * ncap * 4));
   }
   int64_t comm = 0, emitted = 0;
   for (int64_t i = 0; i < w; i++) {
@@ -2871,7 +2906,7 @@ RGX_API int64_t rgx_find_chunks(const rgx_program* p, rgx_stream_ctx* c, const u
   const int64_t w = FindChunksDevice(p, c, d_blk, len, buffer_size, max_leftover, final, spans ? c->d_rspans : nullptr, cap_records, &r);
   if (res) *res = r;
   if (w < 0) return w;
-  if (spans && w > 0) HIP_TRY(hipMemcpy(spans, c->d_rspans, (size_t)w * ncap * 4, hipMemcpyDeviceToHost));
+  if (spans && w > 0) HIP_TRY(CopyOut(c, spans, c->d_rspans, (size_t)w * ncap * 4));
   return w;
 }
 

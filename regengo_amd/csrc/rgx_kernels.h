@@ -163,7 +163,8 @@ hipError_t LaunchBatchRefFix(const DevTables& T, const uint8_t* concat, const ui
 // longer than the LDS trace.
 bool BatchSearchFits(const DevTables& U, const DevTables& F, bool want_spans, const uint8_t* concat, bool with_ref = false);
 hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8_t* concat, const uint64_t* offsets, int64_t nstr,
-                             uint8_t* found, int32_t* spans, void* trace, hipStream_t stream, int window_bytes = 0, int ref = 0);
+                             uint8_t* found, int32_t* spans, void* trace, hipStream_t stream, int window_bytes = 0, int ref = 0,
+                             const uint32_t* glist = nullptr, int nglist = 0);      // glist: only these groups of 256 strings
 
 // ... and for a TINY search automaton (U.tiny, rgx_tiny.h) over a batch of strings of at most kTinyMaxLen bytes: the whole find in one
 // lock-step pass, everything in registers (rgx_batch_tiny.hip).  The launch is OPTIMISTIC -- nobody has looked at the offsets yet: the
@@ -174,6 +175,10 @@ hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8
 // kernel of the call before zeroed them (two control sets used alternately) and hands this call's to the host through pinned memory
 // (host_ctl): a call is two launches and one synchronisation, no memset and no copy node.
 constexpr uint32_t kTinyListCap = 65536;
+// ... and a GROUP of 256 strings that holds a string beyond kTinyMaxLen is left alone and listed (ctl[2] = how many, ctl[4 + kTinyListCap ..)
+// = the first kTinyGroupCap group indices) for LaunchBatchSearch over those groups: one long line no longer sends ten million strings
+// to the general kernel (round 6; more than kTinyGroupCap such groups: the batch is given up as before)
+constexpr uint32_t kTinyGroupCap = 16384;
 bool BatchTinyFits(const DevTables& U, const DevTables& F, const uint8_t* concat, int64_t nstr, bool ref);
 hipError_t LaunchBatchTiny(const DevTables& U, const DevTables& F, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,
                            int32_t* spans, bool ref, uint32_t* ctl, hipStream_t stream);

@@ -2086,7 +2086,8 @@ __host__ __device__ inline SearchLayout SearchLdsLayout(const DevTables& U, int 
 template <int MODE, class TraceT>
 __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U, DevTables F, const uint8_t* concat,
                                                                       const uint64_t* offsets, int64_t nstr, uint8_t* found,
-                                                                      int32_t* spans, TraceT* gtrace, int window_bytes, int ref_arg) {
+                                                                      int32_t* spans, TraceT* gtrace, int window_bytes, int ref_arg,
+                                                                      const uint32_t* glist, int nglist) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   const bool want_spans = spans != nullptr;
@@ -2182,9 +2183,12 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
   const int wave_id = tid >> 6, wave_lane = tid & 63;
   const int wslice = (window_bytes >> 2) & ~15;     // bytes of the window a wave owns (+ 16 of slack behind each)
   unsigned char* const wwin = win + wave_id * (wslice + 16);
-  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+  // (glist: only these groups of 256 strings -- the ones rgx_batch_tiny.hip left because they hold a string beyond its tag bytes)
+  const int64_t nloop = glist ? (int64_t)nglist : ngroups;
+  for (int64_t gi = blockIdx.x; gi < nloop; gi += gridDim.x) {
+    const int64_t grp = glist ? (int64_t)glist[gi] : gi;
     const int64_t i0 = grp * kBlockThreads + wave_id * 64;       // the wave's first string
-    if (i0 >= nstr) break;
+    if (i0 >= nstr) { if (glist) continue; break; }
     const int64_t i = i0 + wave_lane;
     const int64_t ilast = min(i0 + (int64_t)64, nstr);
     const uint64_t gb = offsets[i0], ge = offsets[ilast];
@@ -3184,8 +3188,9 @@ int BatchWindowFor(int64_t total_bytes, int64_t nstr) {
 }
 
 hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8_t* concat, const uint64_t* offsets, int64_t nstr,
-                             uint8_t* found, int32_t* spans, void* trace, hipStream_t stream, int window_bytes, int ref) {
-  if (nstr <= 0) return hipSuccess;
+                             uint8_t* found, int32_t* spans, void* trace, hipStream_t stream, int window_bytes, int ref,
+                             const uint32_t* glist, int nglist) {
+  if (nstr <= 0 || (glist && nglist <= 0)) return hipSuccess;
   if (window_bytes <= 0) window_bytes = kBatchWindow;
   const bool t8 = U.nstates <= 256;
   const SearchLayout Y = SearchLdsLayout(U, F.ncap, spans != nullptr, t8 ? 1 : 2, window_bytes);
@@ -3193,7 +3198,7 @@ hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8
   if (ExpEnv("RGX_C3_SKIP")) ref |= atoi(ExpEnv("RGX_C3_SKIP")) << 8;
   const int rm_bytes = SearchRmBytes(F, (ref & 1) != 0);
   const int cus = DeviceCus();
-  const int64_t ngroups = (nstr + kBlockThreads - 1) / kBlockThreads;
+  const int64_t ngroups = glist ? (int64_t)nglist : (nstr + kBlockThreads - 1) / kBlockThreads;
   int per_cu = (160 * 1024) / (Y.total + rm_bytes + 1024);
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 8) per_cu = 8;
@@ -3203,7 +3208,7 @@ hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8
   do {                                                                                                                \
     { const hipError_t e = AllowBigLds((const void*)batch_search_kernel<MODE, TT>); if (e != hipSuccess) return e; }  \
     hipLaunchKernelGGL((batch_search_kernel<MODE, TT>), dim3((unsigned)grid), dim3(kBlockThreads), (size_t)(Y.total + rm_bytes), stream, U, F,   \
-                       concat, offsets, nstr, found, spans, (TT*)trace, window_bytes, ref);                           \
+                       concat, offsets, nstr, found, spans, (TT*)trace, window_bytes, ref, glist, nglist);            \
   } while (0)
   if (U.mode == kModeDirect) { if (t8) RGX_GO(kModeDirect, uint8_t); else RGX_GO(kModeDirect, uint16_t); }
   else { if (t8) RGX_GO(kModeClassLds, uint8_t); else RGX_GO(kModeClassLds, uint16_t); }

@@ -165,3 +165,56 @@ def test_tiny_kernel_gives_up_on_a_long_string_and_lists_the_flagged(torch_dev):
     for b, r in zip(many, res):
         e = e0 if b == b"aabd" else exp[b]
         assert (r is None) == (e is None) and (r is None or r.spans == e), (pat, b, r and r.spans, e)
+
+
+@pytest.mark.parametrize("pattern", [EMAIL, r"(?P<k>[a-z]+)=(?P<v>\d*)", r"(\d+)-(\d+)"])
+def test_a_few_long_lines_do_not_void_the_batch(torch_dev, pattern):
+    """the tiny kernel holds a string's offsets in tag BYTES (strings of at most 56 bytes); one longer line used to send
+    the whole batch to the general kernel.  Now a GROUP of 256 strings that holds such a line is left alone and listed, the general kernel
+    takes those groups (LaunchBatchSearch over a group list) and everything else stays in registers: a batch of short lines with long ones
+    sprinkled in == the oracle's C port string by string, in both modes; long lines in EVERY group, more groups than the list holds
+    included (the old whole-batch path)."""
+    torch = torch_dev
+    from oracle.gen_c import CMatcher
+    from regengo_amd import Compiled, synth
+    rng = random.Random(5)
+    cm = CMatcher(pattern)
+    for nstr, every in ((200_000, 997), (50_000, 50), (5_000_000, 100_003)):
+        data, offs = synth.email_batch_np(nstr, seed=0x5EED0003)
+        strs_long = {}
+        # splice long lines in: rebuild the CSR with every `every`-th string made 60-200 bytes long
+        lens = np.diff(offs).astype(np.int64)
+        idx = np.arange(0, nstr, every)
+        add = np.array([rng.randrange(60, 201) for _ in idx], dtype=np.int64)
+        new_lens = lens.copy()
+        new_lens[idx] = add
+        noffs = np.zeros(nstr + 1, dtype=np.int64)
+        np.cumsum(new_lens, out=noffs[1:])
+        out = np.empty(int(noffs[-1]), dtype=np.uint8)
+        # bulk copy of the unchanged strings, then the long ones
+        keep = np.ones(nstr, dtype=bool)
+        keep[idx] = False
+        src_pos = np.repeat(offs[:-1][keep] - noffs[:-1][keep], lens[keep]) + np.arange(int(noffs[-1]))[np.repeat(keep, new_lens)]
+        out[np.repeat(keep, new_lens)] = data[src_pos]
+        alpha = np.frombuffer(b"abcxyz019 @=-_.", dtype=np.uint8)
+        for i, n in zip(idx, add):
+            out[noffs[i]:noffs[i] + n] = alpha[np.random.RandomState(int(i) & 0xFFFF).randint(0, len(alpha), int(n))]
+        concat = torch.from_numpy(out).cuda()
+        doffs = torch.from_numpy(noffs.astype(np.int64)).cuda()
+        exp_found = np.zeros(nstr, dtype=np.uint8)
+        exp_spans = np.zeros((nstr, cm.ncap), dtype=np.int32)
+        uoffs = noffs.astype(np.uint64)                  # (kept alive across the call)
+        cm.lib.m_find_batch(out.ctypes.data, uoffs.ctypes.data, nstr, exp_found.ctypes.data, exp_spans.ctypes.data)
+        for stdlib in (False, True):
+            c = Compiled(pattern, stdlib=stdlib).to(0)
+            found, spans = c.FindBatchDevice(concat, doffs)
+            f = found.cpu().numpy()
+            sp = spans.cpu().numpy()
+            if stdlib:
+                # plain leftmost-first: the same rows wherever the reference's loop does not step over a match (checked on the found flags of
+                # reference mode: a string found there has the leftmost-first match or a later one)
+                assert (f >= exp_found).all()
+                continue
+            assert np.array_equal(f, exp_found), (pattern, nstr, every, int((f != exp_found).sum()))
+            m = exp_found.astype(bool)
+            assert np.array_equal(sp[m], exp_spans[m]), (pattern, nstr, every)
