@@ -26,7 +26,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_kernel(const uint32_
                                                                     const uint64_t* __restrict__ offsets, int64_t nstr,
                                                                     uint8_t* __restrict__ found, int32_t* __restrict__ spans, int wslice, int unset,
                                                                     int ncap_out, int fixed, const uint8_t* __restrict__ cap_kind,
-                                                                    const int32_t* __restrict__ cap_delta, uint32_t* ctl) {
+                                                                    const int32_t* __restrict__ cap_delta, uint32_t* ctl, uint8_t* __restrict__ gmap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   {
@@ -240,7 +240,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_sorted_kernel(const 
                                                                            const uint64_t* __restrict__ offsets, int64_t nstr,
                                                                            uint8_t* __restrict__ found, int32_t* __restrict__ spans, int wslice, int unset,
                                                                            int ncap_out, int fixed, const uint8_t* __restrict__ cap_kind,
-                                                                           const int32_t* __restrict__ cap_delta, uint32_t* ctl) {
+                                                                           const int32_t* __restrict__ cap_delta, uint32_t* ctl, uint8_t* __restrict__ gmap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
   {
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_sorted_kernel(const 
     for (int i = tid; i < kTinyWords; i += kBlockThreads) d[i] = img[i];
   }
   unsigned char* const win = smem + kTinyImageBytes;
-  uint32_t* const hist = reinterpret_cast<uint32_t*>(win + wslice + 16);            // [2][16] + [32] the stop word
+  uint32_t* const hist = reinterpret_cast<uint32_t*>(win + wslice + 16);            // [2][16] counts + [34, 35] "this group is left alone"
   uint32_t* const perm = hist + 48;                                                 // [256]: place in the window | length << 14 | string << 20
   if (tid < 48) hist[tid] = 0;
   __syncthreads();
@@ -299,7 +299,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_sorted_kernel(const 
     rel = (uint32_t)(a) - (uint32_t)wb;                                                                                           \
     len = tid < nv_ ? (int)((uint32_t)(b) - (uint32_t)(a)) : 0;                                                                   \
     /* a string too long for the tag bytes, or one behind it that the window does not hold: no walk (the batch is void) */      \
-    if (((b) - (a)) > (uint64_t)kTinyMaxLen) len = -1;                                                                            \
+    if (((b) - (a)) > (uint64_t)kTinyMaxLen) len = -(int)min((b) - (a), (uint64_t)0x7FFFFFFF);     /* (minus its length) */      \
     else if ((a) - wb + (uint64_t)len > (uint64_t)wvalid) len = 0;                                                                \
   } while (0)
 #define RGX_TINY_PIECES(wb, wvalid)                                                                  \
@@ -343,13 +343,23 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_sorted_kernel(const 
   RGX_TINY_WINDOW(grp, an, bn, gbn, gen, wbc, wvc, relc, lenc);
   RGX_TINY_PIECES(wbc, wvc);
   RGX_TINY_META(grp + G, an, bn, gbn, gen);
-  uint32_t stop_next = __builtin_nontemporal_load(ctl);
+  bool told = false;
   for (int it = 0; grp < ngroups; grp += G, ++it) {
     uint32_t* const h = hist + ((it & 1) << 4);
     // the optimistic launch: a group with a string longer than the tag bytes hold is LEFT ALONE (hist[34 + parity]: read behind the barrier)
-    // and listed for the general kernel; only more such groups than the list holds void the batch -- the host takes the general path
-    if (__builtin_amdgcn_ballot_w64(lenc < 0) != 0ull && lane == 0) hist[34 + (it & 1)] = 1u;
-    if (stop_next != 0u) hist[32] = 1u;                       // (one wave seeing the word is all waves leaving together, below)
+    // and marked in the group map (a byte per group, written for EVERY group: nothing to zero) for the general kernel; ctl[2] tells the
+    // host that there are such groups.  (A list of them behind a counter was tried first: atomics WITH a return on one address run at
+    // 75 ns apiece across the chip, 270 ns when other waves poll the same cache line -- 8000 marked groups of 31000 took 2.2 ms.)
+    if (__builtin_amdgcn_ballot_w64(lenc < 0) != 0ull) {
+      // ... and ctl[3] = the longest string of the marked groups (the host's length guard of the general kernel without a pass of its own)
+      int m = lenc < 0 ? -lenc : 0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
+      if (lane == 0) {
+        hist[34 + (it & 1)] = 1u;
+        if ((uint32_t)m > __hip_atomic_load(ctl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(ctl + 3, (uint32_t)m);
+      }
+    }
     const int len0 = lenc < 0 ? 0 : lenc;
     const uint32_t bin = (uint32_t)len0 >> 2;                 // <= 14
     const uint32_t rank = atomicAdd(&h[bin], 1u);
@@ -377,20 +387,17 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_sorted_kernel(const 
       perm[start + rank] = relc | ((uint32_t)len0 << 14) | ((uint32_t)tid << 20);
     }
     if (tid < 16) hist[(((it + 1) & 1) << 4) + tid] = 0;       // the next group's counts (last read a group ago)
-    const uint32_t halt = hist[32];
     const bool gbad = __builtin_amdgcn_readfirstlane(hist[34 + (it & 1)]) != 0u;      // (written before the barrier above, cleared two groups on)
     if (tid == 16) hist[34 + ((it + 1) & 1)] = 0;
-    if (gbad && tid == 0) {
-      const uint32_t k = atomicAdd(ctl + 2, 1u);
-      if (k < kTinyGroupCap) ctl[4 + kTinyListCap + k] = (uint32_t)grp; else atomicOr(ctl, 1u);
+    if (tid == 0) {
+      gmap[grp] = gbad ? (uint8_t)1 : (uint8_t)0;
+      if (gbad && !told) { ctl[2] = 1u; told = true; }        // (a plain store of the same word by whoever has such a group: once a workgroup)
     }
     flush();
     RGX_TINY_WINDOW(grp + G, an, bn, gbn, gen, wbn, wvn, reln, lenn);
     RGX_TINY_PIECES(wbn, wvn);
     wbc = wbn; wvc = wvn; relc = reln; lenc = lenn;
     RGX_TINY_META(grp + 2 * G, an, bn, gbn, gen);
-    stop_next = __builtin_nontemporal_load(ctl);
-    if (__builtin_amdgcn_readfirstlane(halt) != 0u) break;    // (the same word for every wave: written before the barrier above)
     __syncthreads();
     const uint32_t e = perm[(((uint32_t)wave + (uint32_t)it) & 3u) * 64u + (uint32_t)lane];
     const uint32_t rel = gbad ? 0u : (e & 16383u);
@@ -444,7 +451,7 @@ bool BatchTinyFits(const DevTables& U, const DevTables& F, const uint8_t* concat
 }
 
 hipError_t LaunchBatchTiny(const DevTables& U, const DevTables& F, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,
-                           int32_t* spans, bool ref, uint32_t* ctl, hipStream_t stream) {
+                           int32_t* spans, bool ref, uint32_t* ctl, uint8_t* gmap, hipStream_t stream) {
   if (nstr <= 0) return hipSuccess;
   // the workgroup's 256 strings lie in its window whole: 256 x the longest the tag bytes allow, the 15 bytes in front of the first (the
   // window starts at a multiple of 16) and the round-up behind the last.  (The kernel without the sort: the same per wave.)
@@ -474,7 +481,7 @@ hipError_t LaunchBatchTiny(const DevTables& U, const DevTables& F, const uint8_t
     int64_t grid = (int64_t)cus * per_cu * kTinyGridRounds;                                                                             \
     if (grid > ngroups) grid = ngroups;                                                                                                 \
     void* args[] = {(void*)&U.tiny, (void*)&concat, (void*)&offsets, (void*)&nstr, (void*)&found, (void*)&spans, (void*)&wslice,        \
-                    (void*)&unset, (void*)&F.ncap, (void*)&fixed, (void*)&F.cap_kind, (void*)&F.cap_delta, (void*)&ctl};                \
+                    (void*)&unset, (void*)&F.ncap, (void*)&fixed, (void*)&F.cap_kind, (void*)&F.cap_delta, (void*)&ctl, (void*)&gmap};                \
     if (hipLaunchKernel(fn, dim3((unsigned)grid), dim3(kBlockThreads), args, lds, stream) != hipSuccess) return hipGetLastError();      \
   } while (0)
   switch (U.tiny_nreg) {

@@ -93,6 +93,7 @@ struct rgx_stream_ctx {
   std::string tmpl_key;                                      // what d_tmpl holds: "" = nothing
   // pinned host readback
   uint32_t* d_tiny_ctl = nullptr; int tiny_set = 0;   // batch_tiny_kernel's two control sets (rgx_find_batch_device)
+  uint8_t* d_gmap = nullptr; int64_t gmap_cap = 0;    // ... and its map of the groups it left to the general kernel (a byte per 256 strings)
   unsigned long long* h_read = nullptr;      // [16]: 0-3 the synchronous scan (total, rare-path flag, counters), 4-5 the splice, 6-7 the tiny batch's control words,
   unsigned long long* h_read_dev = nullptr;  //       8-11 / 12-15 the two in-flight scans of submit/wait; same words, device view
   // submit / wait (rgx_find_all_submit): up to two scans in flight
@@ -1292,7 +1293,7 @@ RGX_API void rgx_stream_ctx_destroy(rgx_stream_ctx* c) {
   for (int i = 0; i < 2; ++i)
     for (hipEvent_t e : {c->pev0[i], c->pev1[i], c->pdone[i]}) if (e) (void)hipEventDestroy(e);
   for (void* p : {(void*)c->d_desc, (void*)c->d_unsynced, (void*)c->d_carry,
-                  (void*)c->d_trace, (void*)c->d_pairs, (void*)c->d_in, (void*)c->d_san, (void*)c->d_out, (void*)c->d_rspans, (void*)c->d_rdelta, (void*)c->d_rtemp, (void*)c->d_tmpl, (void*)c->d_tdfa, (void*)c->d_memo, (void*)c->d_q11, (void*)c->d_q11se, (void*)c->d_glist, (void*)c->d_blk})
+                  (void*)c->d_trace, (void*)c->d_pairs, (void*)c->d_in, (void*)c->d_san, (void*)c->d_out, (void*)c->d_rspans, (void*)c->d_rdelta, (void*)c->d_rtemp, (void*)c->d_tmpl, (void*)c->d_tdfa, (void*)c->d_memo, (void*)c->d_q11, (void*)c->d_q11se, (void*)c->d_glist, (void*)c->d_blk, (void*)c->d_gmap})
     if (p) (void)hipFree(p);
   if (c->d_tiny_ctl) (void)hipFree(c->d_tiny_ctl);
   if (c->h_read) (void)hipHostFree(c->h_read);
@@ -2114,11 +2115,12 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
     static const bool no_tiny = getenv("RGX_NO_TINY") != nullptr;      // diagnostic knob (tests compare the two kernels' answers)
     if (U->tiny && !no_tiny && BatchTinyFits(*U, T, d_concat, (int64_t)nstr, ref_mode)) {
       // a tiny automaton: the find, the groups and the restart rule in one pass in registers (rgx_tiny.h).  Launched before anybody has
-      // looked at the offsets: the kernel gives the batch up when a string is longer than its tag bytes hold (ctl[0]), and names the
-      // strings whose attempts the replay kernel has to walk one by one (ctl[1], the list behind)
-      // two control sets ([gave up, flagged, -, -] + the list), used alternately: the call's last kernel zeroes the other one and
+      // looked at the offsets: the kernel leaves a group of 256 strings alone when one of them is longer than its tag bytes hold (d_gmap,
+      // ctl[2]: there are such groups; the general kernel takes them below), and names the strings whose attempts the replay kernel has
+      // to walk one by one (ctl[1], the list behind)
+      // two control sets ([gave up, flagged, groups left, -] + the list), used alternately: the call's last kernel zeroes the other one and
       // writes this one's four words to pinned host memory (words 6-7 of h_read), so the call is two launches and one synchronisation
-      constexpr size_t kSetWords = 4 + kTinyListCap + kTinyGroupCap;
+      constexpr size_t kSetWords = 4 + kTinyListCap;
       if (!c->d_tiny_ctl) {
         HIP_TRY(hipMalloc((void**)&c->d_tiny_ctl, 2 * kSetWords * 4));
         HIP_TRY(hipMemsetAsync(c->d_tiny_ctl, 0, 2 * kSetWords * 4, c->stream));
@@ -2129,14 +2131,16 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
       c->tiny_set = 1 - c->tiny_set;
       volatile uint32_t* hc = reinterpret_cast<volatile uint32_t*>(c->h_read + 6);
       hc[0] = hc[1] = hc[2] = hc[3] = 0;
-      HIP_TRY(LaunchBatchTiny(*U, T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, ref_mode, ctl, c->stream));
+      if ((rc = Ensure(&c->d_gmap, &c->gmap_cap, (int64_t)(nstr / 256) + 64)) != RGX_OK) return rc;
+      HIP_TRY(LaunchBatchTiny(*U, T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, ref_mode, ctl, c->d_gmap, c->stream));
+      c->h_read[4] = 0;
       HIP_TRY(LaunchBatchRefFixList(T, d_concat, d_offsets, d_found, d_spans, c->d_trace, ctl, kTinyListCap, reinterpret_cast<uint32_t*>(c->h_read_dev + 6),
-                                    other, ref_mode && !T.anchored, c->stream));
+                                    other, ref_mode && !T.anchored, c->stream, (int64_t)nstr, c->h_read_dev + 4));
       HIP_TRY(hipStreamSynchronize(c->stream));
       const uint32_t h_ctl[4] = {hc[0], hc[1], hc[2], hc[3]};
-      const bool groups_left = h_ctl[2] != 0;      // groups of 256 strings the kernel left alone: one of their strings is beyond its tag bytes
+      const bool groups_left = h_ctl[2] != 0;      // groups of 256 strings the kernel left alone (d_gmap): one of their strings is beyond its tag bytes
       const bool fused_ok = !ref_mode || BatchSearchFits(*U, T, true, d_concat, true);
-      if (!h_ctl[0] && (!groups_left || (h_ctl[2] <= kTinyGroupCap && fused_ok))) {
+      if (!h_ctl[0] && (!groups_left || fused_ok)) {
         if (ref_mode && h_ctl[1] >= kTinyListCap) {
           // (more flagged strings than the list holds: every match is at most kTinyMaxLen bytes, the LDS trace of ref_fix_kernel holds it)
           HIP_TRY(LaunchBatchRefFix(T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, c->d_trace, c->stream, 1));
@@ -2145,22 +2149,16 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
         if (groups_left) {
           // those groups through the general kernel (the preamble of the whole-batch path below: scratch by the batch's bytes, the length
           // guard of reference mode), the strings it flags finished by the replay kernel -- flagged ones ONLY: the tiny kernel's rows are final
-          uint64_t h_last = 0;
-          unsigned long long h_max = 0;
-          if (ref_mode) {
-            HIP_TRY(hipMemsetAsync(c->d_cursor + 2, 0, 8, c->stream));
-            HIP_TRY(LaunchMaxStringLen(d_offsets, (int64_t)nstr, c->d_cursor + 2, c->stream));
-            HIP_TRY(hipMemcpyAsync(&h_max, c->d_cursor + 2, 8, hipMemcpyDeviceToHost, c->stream));
-          }
-          HIP_TRY(hipMemcpyAsync(&h_last, d_offsets + nstr, 8, hipMemcpyDeviceToHost, c->stream));
-          HIP_TRY(hipStreamSynchronize(c->stream));
+          // (the batch's bytes and the longest string of those groups came with the control words: no pass over the offsets, no round trip)
+          const uint64_t h_last = (uint64_t)((volatile unsigned long long*)c->h_read)[4];
+          const unsigned long long h_max = h_ctl[3];
           if (ref_mode && (int64_t)h_max > kBatchSearchMaxLen) return BatchLengthGuard(c, d_offsets, nstr, kBatchSearchMaxLen, -1);
           const int64_t need = ((int64_t)h_last + 2 * (int64_t)nstr + 64 + 1) / 2 * (U->nstates <= 256 ? 1 : 2);
           const int64_t need_fix = ref_mode ? (int64_t)h_last + 2 * (int64_t)nstr + 64 : 0;
           if ((rc = Ensure(&c->d_trace, &c->trace_cap, std::max(need, need_fix))) != RGX_OK) return rc;
           HIP_TRY(LaunchBatchSearch(*U, T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, c->d_trace, c->stream,
-                                    BatchWindowFor((int64_t)h_last, (int64_t)nstr), ref_mode ? 1 : 0, ctl + 4 + kTinyListCap, (int)h_ctl[2]));
-          if (ref_mode) HIP_TRY(LaunchBatchRefFix(T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, c->d_trace, c->stream, 1));
+                                    BatchWindowFor((int64_t)h_last, (int64_t)nstr), ref_mode ? 1 : 0, c->d_gmap));
+          if (ref_mode) HIP_TRY(LaunchBatchRefFix(T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, c->d_trace, c->stream, 1, c->d_gmap));
           HIP_TRY(hipStreamSynchronize(c->stream));
         }
         return (int64_t)nstr;

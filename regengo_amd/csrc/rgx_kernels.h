@@ -156,7 +156,8 @@ hipError_t LaunchBatchRef(const DevTables& T, const uint8_t* concat, const uint6
 // which replays the reference's attempt offsets with failure offsets only (linear; the attempt-per-offset loop is quadratic in
 // the length of a word).  Not for anchored patterns (nothing to replay) -- harmless there.
 hipError_t LaunchBatchRefFix(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,
-                             int32_t* spans, uint16_t* trace, hipStream_t stream, int only_flagged = 0);
+                             int32_t* spans, uint16_t* trace, hipStream_t stream, int only_flagged = 0,
+                             const uint8_t* gmap = nullptr);      // gmap: only the marked groups of 256 strings (LaunchBatchTiny)
 
 // Same entry points through the search automaton U (rgx_program.h: SearchTables): one forward walk per string.
 // `trace` is scratch of (total bytes + 2*nstr + 64) entries of uint8 (U.nstates <= 256) or uint16, used by strings
@@ -164,7 +165,7 @@ hipError_t LaunchBatchRefFix(const DevTables& T, const uint8_t* concat, const ui
 bool BatchSearchFits(const DevTables& U, const DevTables& F, bool want_spans, const uint8_t* concat, bool with_ref = false);
 hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8_t* concat, const uint64_t* offsets, int64_t nstr,
                              uint8_t* found, int32_t* spans, void* trace, hipStream_t stream, int window_bytes = 0, int ref = 0,
-                             const uint32_t* glist = nullptr, int nglist = 0);      // glist: only these groups of 256 strings
+                             const uint8_t* gmap = nullptr);      // gmap: a byte per group of 256 strings, only the marked groups
 
 // ... and for a TINY search automaton (U.tiny, rgx_tiny.h) over a batch of strings of at most kTinyMaxLen bytes: the whole find in one
 // lock-step pass, everything in registers (rgx_batch_tiny.hip).  The launch is OPTIMISTIC -- nobody has looked at the offsets yet: the
@@ -175,16 +176,15 @@ hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8
 // kernel of the call before zeroed them (two control sets used alternately) and hands this call's to the host through pinned memory
 // (host_ctl): a call is two launches and one synchronisation, no memset and no copy node.
 constexpr uint32_t kTinyListCap = 65536;
-// ... and a GROUP of 256 strings that holds a string beyond kTinyMaxLen is left alone and listed (ctl[2] = how many, ctl[4 + kTinyListCap ..)
-// = the first kTinyGroupCap group indices) for LaunchBatchSearch over those groups: one long line no longer sends ten million strings
-// to the general kernel (round 6; more than kTinyGroupCap such groups: the batch is given up as before)
-constexpr uint32_t kTinyGroupCap = 16384;
+// ... and a GROUP of 256 strings that holds a string beyond kTinyMaxLen is left alone and marked in `gmap` (a byte per group, written
+// for every group; ctl[2] != 0: there are marked groups, ctl[3] = their longest string) for LaunchBatchSearch over those groups: one long line no longer sends ten
+// million strings to the general kernel (round 6).
 bool BatchTinyFits(const DevTables& U, const DevTables& F, const uint8_t* concat, int64_t nstr, bool ref);
 hipError_t LaunchBatchTiny(const DevTables& U, const DevTables& F, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,
-                           int32_t* spans, bool ref, uint32_t* ctl, hipStream_t stream);
+                           int32_t* spans, bool ref, uint32_t* ctl, uint8_t* gmap, hipStream_t stream);
 hipError_t LaunchBatchRefFixList(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, uint8_t* found, int32_t* spans,
                                  uint16_t* trace, const uint32_t* ctl, uint32_t cap, uint32_t* host_ctl, uint32_t* other_ctl, bool do_fix,
-                                 hipStream_t stream);
+                                 hipStream_t stream, int64_t nstr = 0, unsigned long long* host_last = nullptr);   // host_last: offsets[nstr] published
 
 // The current device's CU count, and the 160 KiB dynamic-LDS allowance of a kernel -- both cached per DEVICE (a device list in one process
 // launches the same kernels on several devices).

@@ -1097,8 +1097,16 @@ __device__ void RefFixOne(const DevTables& T, const uint8_t* concat, const uint6
 }
 
 __global__ __launch_bounds__(64) void ref_fix_kernel(DevTables T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr,
-                                                     uint8_t* found, int32_t* spans, uint16_t* trace, int only_flagged) {
+                                                     uint8_t* found, int32_t* spans, uint16_t* trace, int only_flagged, const uint8_t* gmap) {
   __shared__ uint16_t s_trace[64 * kCapsLdsTrace];
+  if (gmap) {                                   // (only the marked groups of 256 strings: the tiny kernel's rows elsewhere are final)
+    if (!gmap[blockIdx.x]) return;
+    for (int q = 0; q < 4; ++q) {
+      const int64_t i = (int64_t)blockIdx.x * 256 + q * 64 + threadIdx.x;
+      if (i < nstr && found[i] && (!only_flagged || found[i] == 2)) RefFixOne(T, concat, offsets, i, found, spans, trace, s_trace);
+    }
+    return;
+  }
   const int64_t i = (int64_t)blockIdx.x * 64 + threadIdx.x;
   if (i >= nstr || !found[i]) return;           // no match anywhere in the string: the emitted loop finds none either
   if (only_flagged && found[i] != 2) return;    // (the search kernel has replayed the others itself)
@@ -1111,13 +1119,15 @@ __global__ __launch_bounds__(64) void ref_fix_kernel(DevTables T, const uint8_t*
 // synchronisation: no copy node in the stream) and the OTHER control set, the next call's, is zeroed (no memset node either).
 __global__ __launch_bounds__(64) void ref_fix_list_kernel(DevTables T, const uint8_t* concat, const uint64_t* offsets, uint8_t* found,
                                                           int32_t* spans, uint16_t* trace, const uint32_t* ctl, uint32_t cap, uint32_t* host_ctl,
-                                                          uint32_t* other_ctl, int do_fix) {
+                                                          uint32_t* other_ctl, int do_fix, int64_t nstr, unsigned long long* host_last) {
   __shared__ uint16_t s_trace[64 * kCapsLdsTrace];
   const uint32_t gave_up = ctl[0], flagged = ctl[1];
   if (blockIdx.x == 0 && threadIdx.x < 4) {
     __hip_atomic_store(host_ctl + threadIdx.x, ctl[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
     other_ctl[threadIdx.x] = 0u;
   }
+  // (the batch's bytes: what the host sizes the general kernel's scratch by when groups were left to it)
+  if (blockIdx.x == 0 && threadIdx.x == 4 && host_last) __hip_atomic_store(host_last, (unsigned long long)offsets[nstr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (gave_up || !do_fix) return;
   const uint32_t n = flagged < cap ? flagged : 0u;
   for (uint32_t k = blockIdx.x * 64 + threadIdx.x; k < n; k += gridDim.x * 64)
@@ -2087,9 +2097,15 @@ template <int MODE, class TraceT>
 __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U, DevTables F, const uint8_t* concat,
                                                                       const uint64_t* offsets, int64_t nstr, uint8_t* found,
                                                                       int32_t* spans, TraceT* gtrace, int window_bytes, int ref_arg,
-                                                                      const uint32_t* glist, int nglist) {
+                                                                      const uint8_t* gmap) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
   const int tid = threadIdx.x;
+  if (gmap) {      // a workgroup none of whose groups is marked leaves before it stages a table (a few marked groups of tens of thousands)
+    const int64_t ng = (nstr + kBlockThreads - 1) / kBlockThreads;
+    bool any = false;
+    for (int64_t g = blockIdx.x; g < ng; g += gridDim.x) any |= gmap[g] != 0;
+    if (!any) return;
+  }
   const bool want_spans = spans != nullptr;
   const int ref = ref_arg & 1;
   const int exp_skip = ref_arg >> 8;          // experiments (RGX_C3_SKIP, bits): 1 forward walk only, 2 no replay of the attempt offsets, 4 bytes through BatchInput::At
@@ -2183,12 +2199,11 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
   const int wave_id = tid >> 6, wave_lane = tid & 63;
   const int wslice = (window_bytes >> 2) & ~15;     // bytes of the window a wave owns (+ 16 of slack behind each)
   unsigned char* const wwin = win + wave_id * (wslice + 16);
-  // (glist: only these groups of 256 strings -- the ones rgx_batch_tiny.hip left because they hold a string beyond its tag bytes)
-  const int64_t nloop = glist ? (int64_t)nglist : ngroups;
-  for (int64_t gi = blockIdx.x; gi < nloop; gi += gridDim.x) {
-    const int64_t grp = glist ? (int64_t)glist[gi] : gi;
+  // (gmap: only the marked groups of 256 strings -- the ones rgx_batch_tiny.hip left because they hold a string beyond its tag bytes)
+  for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
+    if (gmap && !gmap[grp]) continue;
     const int64_t i0 = grp * kBlockThreads + wave_id * 64;       // the wave's first string
-    if (i0 >= nstr) { if (glist) continue; break; }
+    if (i0 >= nstr) break;
     const int64_t i = i0 + wave_lane;
     const int64_t ilast = min(i0 + (int64_t)64, nstr);
     const uint64_t gb = offsets[i0], ge = offsets[ilast];
@@ -3133,18 +3148,20 @@ hipError_t LaunchBatchRef(const DevTables& T, const uint8_t* concat, const uint6
 }
 
 hipError_t LaunchBatchRefFix(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,
-                             int32_t* spans, uint16_t* trace, hipStream_t stream, int only_flagged) {
+                             int32_t* spans, uint16_t* trace, hipStream_t stream, int only_flagged, const uint8_t* gmap) {
   if (nstr <= 0) return hipSuccess;
-  dim3 block(64), grid((unsigned)((nstr + 63) / 64));
-  hipLaunchKernelGGL(ref_fix_kernel, grid, block, 0, stream, T, concat, offsets, nstr, found, spans, trace, only_flagged);
+  // (gmap: a workgroup per group of 256 strings, which walks the group's four quarters when it is marked -- a quarter as many workgroups to
+  // dispatch for the few groups that are)
+  dim3 block(64), grid((unsigned)(gmap ? (nstr + 255) / 256 : (nstr + 63) / 64));
+  hipLaunchKernelGGL(ref_fix_kernel, grid, block, 0, stream, T, concat, offsets, nstr, found, spans, trace, only_flagged, gmap);
   return hipGetLastError();
 }
 
 hipError_t LaunchBatchRefFixList(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, uint8_t* found, int32_t* spans,
                                  uint16_t* trace, const uint32_t* ctl, uint32_t cap, uint32_t* host_ctl, uint32_t* other_ctl, bool do_fix,
-                                 hipStream_t stream) {
+                                 hipStream_t stream, int64_t nstr, unsigned long long* host_last) {
   hipLaunchKernelGGL(ref_fix_list_kernel, dim3(do_fix ? 64 : 1), dim3(64), 0, stream, T, concat, offsets, found, spans, trace, ctl, cap, host_ctl,
-                     other_ctl, do_fix ? 1 : 0);
+                     other_ctl, do_fix ? 1 : 0, nstr, host_last);
   return hipGetLastError();
 }
 
@@ -3189,8 +3206,8 @@ int BatchWindowFor(int64_t total_bytes, int64_t nstr) {
 
 hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8_t* concat, const uint64_t* offsets, int64_t nstr,
                              uint8_t* found, int32_t* spans, void* trace, hipStream_t stream, int window_bytes, int ref,
-                             const uint32_t* glist, int nglist) {
-  if (nstr <= 0 || (glist && nglist <= 0)) return hipSuccess;
+                             const uint8_t* gmap) {
+  if (nstr <= 0) return hipSuccess;
   if (window_bytes <= 0) window_bytes = kBatchWindow;
   const bool t8 = U.nstates <= 256;
   const SearchLayout Y = SearchLdsLayout(U, F.ncap, spans != nullptr, t8 ? 1 : 2, window_bytes);
@@ -3198,7 +3215,7 @@ hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8
   if (ExpEnv("RGX_C3_SKIP")) ref |= atoi(ExpEnv("RGX_C3_SKIP")) << 8;
   const int rm_bytes = SearchRmBytes(F, (ref & 1) != 0);
   const int cus = DeviceCus();
-  const int64_t ngroups = glist ? (int64_t)nglist : (nstr + kBlockThreads - 1) / kBlockThreads;
+  const int64_t ngroups = (nstr + kBlockThreads - 1) / kBlockThreads;
   int per_cu = (160 * 1024) / (Y.total + rm_bytes + 1024);
   if (per_cu < 1) per_cu = 1;
   if (per_cu > 8) per_cu = 8;
@@ -3208,7 +3225,7 @@ hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8
   do {                                                                                                                \
     { const hipError_t e = AllowBigLds((const void*)batch_search_kernel<MODE, TT>); if (e != hipSuccess) return e; }  \
     hipLaunchKernelGGL((batch_search_kernel<MODE, TT>), dim3((unsigned)grid), dim3(kBlockThreads), (size_t)(Y.total + rm_bytes), stream, U, F,   \
-                       concat, offsets, nstr, found, spans, (TT*)trace, window_bytes, ref, glist, nglist);            \
+                       concat, offsets, nstr, found, spans, (TT*)trace, window_bytes, ref, gmap);            \
   } while (0)
   if (U.mode == kModeDirect) { if (t8) RGX_GO(kModeDirect, uint8_t); else RGX_GO(kModeDirect, uint16_t); }
   else { if (t8) RGX_GO(kModeClassLds, uint8_t); else RGX_GO(kModeClassLds, uint16_t); }
