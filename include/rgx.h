@@ -212,7 +212,9 @@ typedef struct rgx_tuning {
   int32_t exact_sync_points;    /* 1: exact sync points first; -1: tried, the carry pass is cheaper; -2: back to the generic kernel   */
   int32_t rewinding_walk;       /* 1: the pair kernel's rewinding instance                                                            */
   int32_t ascii_twin;           /* 1: a twin for texts without a byte >= 0x80 exists; -1: none (or not wanted)                        */
-  int32_t reserved[6];
+  int32_t batch_tiny_level;     /* rgx_find_batch_device, tiny search automata: 0 the instances for strings <= 56 bytes, 1 / 2 the ones for  */
+                                /* strings <= 254 bytes (LDS windows of 34 / 64 KiB a group of 256 strings)                               */
+  int32_t reserved[5];
 } rgx_tuning;
 int rgx_program_tuning(const rgx_program* p, rgx_tuning* out);
 int rgx_program_freeze(rgx_program* p);

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_kernel(const uint32_
     (found + i0)[lane] = (uint8_t)f;
     if (REF && f == 2) {
       const uint32_t k = atomicAdd(ctl + 1, 1u);
-      if (k < kTinyListCap) ctl[4 + k] = (uint32_t)i0 + (uint32_t)lane;
+      if (k < kTinyListCap) ctl[kTinyCtlHead + k] = (uint32_t)i0 + (uint32_t)lane;
     }
     int32_t* const dst = spans + i0 * ncap_out + lane_cap;
     if (f && !fixed) {                              // (rgx.h: the record of a string without a match is unspecified)
@@ -234,8 +234,14 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_kernel(const uint32_
 // instruction count only that far: with the sort the kernel is no longer bound by VALU issue (82.8 M x 4 cycles / 1024 SIMDs = 72% of
 // its cycles) -- a group still takes as long as its longest wave, the waves that are done early wait at the barrier, and what is
 // resident (eight waves a SIMD at 64 registers) does not fill the gap.  RGX_TINY_WAVE=1 (experiment builds) runs the kernel above.
-template <int NREG, bool REF>
-__attribute__((amdgpu_waves_per_eu(NREG <= 4 ? 8 : 1, NREG <= 4 ? 8 : 6)))      // (64 registers: eight waves a SIMD, what the LDS allows)
+// WIDE (round 6): strings of up to kTinyWideMaxLen bytes -- a tag byte holds any offset below 0xFF, what bounded the kernel at 56 bytes was
+// the LDS window (256 strings x 56 bytes = eight workgroups a CU) and the 6-bit length field of the sort.  The wide instances take a
+// window of `wslice` bytes chosen by the host (34 KiB: four workgroups a CU, or 64 KiB: two), order entries of 16 + 8 + 8 bits, bins of 16
+// bytes, and read a record's bytes unsigned; a group whose bytes do not fit the window is left to the general kernel like a group with a
+// string beyond the tag bytes.  They also report what the batch looked like (ctl[3]: its longest string, ctl[4]: its largest group) so
+// that the host can go back to the narrow instance.
+template <int NREG, bool REF, bool WIDE>
+__attribute__((amdgpu_waves_per_eu(WIDE ? 1 : (NREG <= 4 ? 8 : 1), WIDE ? 4 : (NREG <= 4 ? 8 : 6))))      // (narrow: 64 registers, eight waves a SIMD, what the LDS allows)
 __global__ __launch_bounds__(kBlockThreads) void batch_tiny_sorted_kernel(const uint32_t* __restrict__ img, const uint8_t* __restrict__ concat,
                                                                            const uint64_t* __restrict__ offsets, int64_t nstr,
                                                                            uint8_t* __restrict__ found, int32_t* __restrict__ spans, int wslice, int unset,
@@ -274,6 +280,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_sorted_kernel(const 
   for (int c = 0; c < 8; ++c) reg_of[c] = __builtin_amdgcn_readfirstlane(ini[16 + c]);
   const int ngroups = (int)((nstr + kBlockThreads - 1) / kBlockThreads);
   const int G = (int)gridDim.x;
+  constexpr int kMaxLen = WIDE ? kTinyWideMaxLen : kTinyMaxLen;
   const uint8_t* const idle = reinterpret_cast<const uint8_t*>(img);
   // the software pipeline of the kernel above, a workgroup wide: offsets two groups ahead, bytes one group ahead; the window's ends
   // are the group's first and last offsets, fetched as scalars
@@ -287,19 +294,22 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_sorted_kernel(const 
     a = ob_[lc_]; b = ob_[lc_ + 1];                                                                 \
     gb = ob_[0]; ge = ob_[nv_ ? nv_ : 1];                                                           \
   } while (0)
-#define RGX_TINY_WINDOW(g, a, b, gb, ge, wb, wvalid, rel, len)                                                                    \
+#define RGX_TINY_WINDOW(g, a, b, gb, ge, wb, wvalid, rel, len, spn)                                                                  \
   do {                                                                                                                            \
     const int nv_ = RGX_TINY_NV(g);                                                                                               \
-    wb = 0; wvalid = 0;                                                                                                           \
+    wb = 0; wvalid = 0; spn = 0;                                                                                                  \
     if (nv_) {                                                                                                                    \
       wb = (gb) & ~15ull;                                                                                                         \
       const uint64_t span_ = (((ge) - wb) + 15ull) & ~15ull;                                                                      \
+      spn = (uint32_t)min(span_, (uint64_t)0xFFFFFFF0u);                                                                          \
       wvalid = (int)(span_ < (uint64_t)wslice ? span_ : (uint64_t)wslice);                                                        \
     }                                                                                                                             \
     rel = (uint32_t)(a) - (uint32_t)wb;                                                                                           \
     len = tid < nv_ ? (int)((uint32_t)(b) - (uint32_t)(a)) : 0;                                                                   \
-    /* a string too long for the tag bytes, or one behind it that the window does not hold: no walk (the batch is void) */      \
-    if (((b) - (a)) > (uint64_t)kTinyMaxLen) len = -(int)min((b) - (a), (uint64_t)0x7FFFFFFF);     /* (minus its length) */      \
+    /* a string too long for the tag bytes (or, WIDE, a group the window does not hold): minus its length -- the group is left */ \
+    /* alone; a string behind such a one that the window does not hold: no walk */                                                \
+    if (((b) - (a)) > (uint64_t)kMaxLen) len = -(int)min((b) - (a), (uint64_t)0x7FFFFFFF);                                        \
+    else if (WIDE && spn > (uint32_t)wslice) len = -(int)max((uint32_t)((b) - (a)), 1u);                                          \
     else if ((a) - wb + (uint64_t)len > (uint64_t)wvalid) len = 0;                                                                \
   } while (0)
 #define RGX_TINY_PIECES(wb, wvalid)                                                                  \
@@ -321,7 +331,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_sorted_kernel(const 
     (found + i0)[pprev] = (uint8_t)f;
     if (REF && f == 2) {
       const uint32_t k = atomicAdd(ctl + 1, 1u);
-      if (k < kTinyListCap) ctl[4 + k] = (uint32_t)i0 + (uint32_t)pprev;
+      if (k < kTinyListCap) ctl[kTinyCtlHead + k] = (uint32_t)i0 + (uint32_t)pprev;
     }
     int32_t* const dst = spans + i0 * ncap_out + (uint32_t)pprev * (uint32_t)ncap_out;
     if (f && !fixed) {
@@ -336,14 +346,15 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_sorted_kernel(const 
   };
   uint4 p0, p1;
   uint64_t an, bn, gbn, gen, wbc, wbn;
-  uint32_t relc, reln;
+  uint32_t relc, reln, spanc, spann;
   int wvc, wvn, lenc, lenn;
   int grp = (int)blockIdx.x;
   RGX_TINY_META(grp, an, bn, gbn, gen);
-  RGX_TINY_WINDOW(grp, an, bn, gbn, gen, wbc, wvc, relc, lenc);
+  RGX_TINY_WINDOW(grp, an, bn, gbn, gen, wbc, wvc, relc, lenc, spanc);
   RGX_TINY_PIECES(wbc, wvc);
   RGX_TINY_META(grp + G, an, bn, gbn, gen);
-  bool told = false;
+  uint32_t nleft = 0, nlong = 0;                              // groups this workgroup left alone, because of a string beyond kTinyWideMaxLen (thread 0's counts)
+  uint32_t seen_len = 0, seen_span = 0;                       // WIDE: the longest string / the largest group met
   for (int it = 0; grp < ngroups; grp += G, ++it) {
     uint32_t* const h = hist + ((it & 1) << 4);
     // the optimistic launch: a group with a string longer than the tag bytes hold is LEFT ALONE (hist[34 + parity]: read behind the barrier)
@@ -356,12 +367,13 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_sorted_kernel(const 
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) m = max(m, __shfl_xor(m, o));
       if (lane == 0) {
-        hist[34 + (it & 1)] = 1u;
+        atomicOr(&hist[34 + (it & 1)], m > kTinyWideMaxLen ? 3u : 1u);       // (bit 1: a string no instance of this kernel takes)
         if ((uint32_t)m > __hip_atomic_load(ctl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(ctl + 3, (uint32_t)m);
       }
     }
     const int len0 = lenc < 0 ? 0 : lenc;
-    const uint32_t bin = (uint32_t)len0 >> 2;                 // <= 14
+    const uint32_t bin = (uint32_t)len0 >> (WIDE ? 4 : 2);    // <= 15
+    if (WIDE) { seen_len = max(seen_len, (uint32_t)(lenc < 0 ? -lenc : lenc)); seen_span = max(seen_span, spanc); }
     const uint32_t rank = atomicAdd(&h[bin], 1u);
     __syncthreads();                                          // every wave is done with the group before: its bytes and order may go
     {
@@ -369,10 +381,20 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_sorted_kernel(const 
       if (tid < nch) *reinterpret_cast<uint4*>(win + (tid << 4)) = p0;
       if (tid + 256 < nch) *reinterpret_cast<uint4*>(win + ((tid + 256) << 4)) = p1;
       if (nch > 512) {
-        // strings of more than 32 bytes on average: the second half of the window is fetched now, not a group ahead (registers)
+        // strings of more than 32 bytes on average: the rest of the window is fetched now, not a group ahead (registers)
         const uint8_t* const pb = concat + wbc;
-        if (tid + 512 < nch) *reinterpret_cast<uint4*>(win + ((tid + 512) << 4)) = *reinterpret_cast<const uint4*>(pb + ((tid + 512) << 4));
-        if (tid + 768 < nch) *reinterpret_cast<uint4*>(win + ((tid + 768) << 4)) = *reinterpret_cast<const uint4*>(pb + ((tid + 768) << 4));
+        if (!WIDE) {
+          if (tid + 512 < nch) *reinterpret_cast<uint4*>(win + ((tid + 512) << 4)) = *reinterpret_cast<const uint4*>(pb + ((tid + 512) << 4));
+          if (tid + 768 < nch) *reinterpret_cast<uint4*>(win + ((tid + 768) << 4)) = *reinterpret_cast<const uint4*>(pb + ((tid + 768) << 4));
+        } else {
+          for (int k = tid + 512; k < nch; k += 4 * kBlockThreads) {       // (four loads in flight a turn)
+            uint4 v[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (k + u * kBlockThreads < nch) v[u] = *reinterpret_cast<const uint4*>(pb + ((k + u * kBlockThreads) << 4));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (k + u * kBlockThreads < nch) *reinterpret_cast<uint4*>(win + ((k + u * kBlockThreads) << 4)) = v[u];
+          }
+        }
       }
     }
     {
@@ -384,24 +406,26 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_sorted_kernel(const 
       x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);
       x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);
       const uint32_t start = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(bin << 2), (int)(x - hv));
-      perm[start + rank] = relc | ((uint32_t)len0 << 14) | ((uint32_t)tid << 20);
+      perm[start + rank] = WIDE ? relc | ((uint32_t)len0 << 16) | ((uint32_t)tid << 24) : relc | ((uint32_t)len0 << 14) | ((uint32_t)tid << 20);
     }
     if (tid < 16) hist[(((it + 1) & 1) << 4) + tid] = 0;       // the next group's counts (last read a group ago)
-    const bool gbad = __builtin_amdgcn_readfirstlane(hist[34 + (it & 1)]) != 0u;      // (written before the barrier above, cleared two groups on)
+    const uint32_t gflag = __builtin_amdgcn_readfirstlane(hist[34 + (it & 1)]);       // (written before the barrier above, cleared two groups on)
+    const bool gbad = gflag != 0u;
     if (tid == 16) hist[34 + ((it + 1) & 1)] = 0;
     if (tid == 0) {
       gmap[grp] = gbad ? (uint8_t)1 : (uint8_t)0;
-      if (gbad && !told) { ctl[2] = 1u; told = true; }        // (a plain store of the same word by whoever has such a group: once a workgroup)
+      nleft += gbad ? 1u : 0u;                                // (ctl[2] += the workgroup's count when it leaves: no return waited for)
+      nlong += gflag >> 1;
     }
     flush();
-    RGX_TINY_WINDOW(grp + G, an, bn, gbn, gen, wbn, wvn, reln, lenn);
+    RGX_TINY_WINDOW(grp + G, an, bn, gbn, gen, wbn, wvn, reln, lenn, spann);
     RGX_TINY_PIECES(wbn, wvn);
-    wbc = wbn; wvc = wvn; relc = reln; lenc = lenn;
+    wbc = wbn; wvc = wvn; relc = reln; lenc = lenn; spanc = spann;
     RGX_TINY_META(grp + 2 * G, an, bn, gbn, gen);
     __syncthreads();
     const uint32_t e = perm[(((uint32_t)wave + (uint32_t)it) & 3u) * 64u + (uint32_t)lane];
-    const uint32_t rel = gbad ? 0u : (e & 16383u);
-    const int len = gbad ? 0 : (int)((e >> 14) & 63u);
+    const uint32_t rel = gbad ? 0u : (WIDE ? e & 65535u : e & 16383u);
+    const int len = gbad ? 0 : (WIDE ? (int)((e >> 16) & 255u) : (int)((e >> 14) & 63u));
     const uint32_t addr = win_at + rel;
     const L32 w32 = (L32)(uintptr_t)(addr & ~3u);
     const uint32_t sh = addr & 3u;
@@ -430,11 +454,21 @@ __global__ __launch_bounds__(kBlockThreads) void batch_tiny_sorted_kernel(const 
           TinyStep<NREG, REF>(L, cm.x, cm.y, load_sel, (uint32_t)(at + k + 1));
         }
     }
-    fprev = TinyFinish<NREG, REF>(L, unset, ntrack, reg_of, rprev);
+    fprev = TinyFinish<NREG, REF, WIDE>(L, unset, ntrack, reg_of, rprev);
     gprev = gbad ? -1 : grp;                                   // (a group left to the general kernel writes nothing)
-    pprev = (int)(e >> 20);
+    pprev = (int)(e >> (WIDE ? 24 : 20));
   }
   flush();
+  if (tid == 0 && nleft) atomicAdd(ctl + 2, nleft);
+  if (tid == 0 && nlong) atomicAdd(ctl + 5, nlong);
+  if (WIDE) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { seen_len = max(seen_len, (uint32_t)__shfl_xor((int)seen_len, o)); seen_span = max(seen_span, (uint32_t)__shfl_xor((int)seen_span, o)); }
+    if (lane == 0) {
+      if (seen_len > __hip_atomic_load(ctl + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(ctl + 3, seen_len);
+      if (seen_span > __hip_atomic_load(ctl + 4, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) atomicMax(ctl + 4, seen_span);
+    }
+  }
 #undef RGX_TINY_NV
 #undef RGX_TINY_PIECES
 #undef RGX_TINY_META
@@ -450,13 +484,20 @@ bool BatchTinyFits(const DevTables& U, const DevTables& F, const uint8_t* concat
   return U.tiny_nreg >= 1 && U.tiny_nreg <= 8;
 }
 
+// level: 0 = the narrow instances (strings of at most kTinyMaxLen bytes, eight workgroups a CU), 1 / 2 = the wide ones (kTinyWideMaxLen) with
+// a window of 34 KiB (four workgroups a CU: groups of 256 strings of ~130 bytes on average) / 64 KiB (two: any group of such strings).
+int BatchTinyWindow(int level) {
+  if (level <= 0) return (kBlockThreads * kTinyMaxLen + 15 + 15 + 15) & ~15;
+  return level == 1 ? 34 * 1024 : 65520;
+}
 hipError_t LaunchBatchTiny(const DevTables& U, const DevTables& F, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,
-                           int32_t* spans, bool ref, uint32_t* ctl, uint8_t* gmap, hipStream_t stream) {
+                           int32_t* spans, bool ref, uint32_t* ctl, uint8_t* gmap, hipStream_t stream, int level) {
   if (nstr <= 0) return hipSuccess;
   // the workgroup's 256 strings lie in its window whole: 256 x the longest the tag bytes allow, the 15 bytes in front of the first (the
   // window starts at a multiple of 16) and the round-up behind the last.  (The kernel without the sort: the same per wave.)
   static const bool per_wave = ExpEnv("RGX_TINY_WAVE") != nullptr;
-  const int wslice = per_wave ? (64 * kTinyMaxLen + 15 + 15 + 15) & ~15 : (kBlockThreads * kTinyMaxLen + 15 + 15 + 15) & ~15;
+  if (per_wave) level = 0;
+  const int wslice = per_wave ? (64 * kTinyMaxLen + 15 + 15 + 15) & ~15 : BatchTinyWindow(level);
   const size_t lds = per_wave ? (size_t)kTinyImageBytes + 4 * (size_t)(wslice + 16) : (size_t)kTinyImageBytes + (size_t)(wslice + 16) + (48 + kBlockThreads) * 4;
   const int cus = DeviceCus();
   const int64_t ngroups = (nstr + kBlockThreads - 1) / kBlockThreads;
@@ -468,20 +509,23 @@ hipError_t LaunchBatchTiny(const DevTables& U, const DevTables& F, const uint8_t
   // round trips, so few workgroups with many groups each would be best -- but the groups are dealt statically, and workgroups that
   // start later even out the tail (measured on config C3, 39063 groups: 1x resident 0.231 ms, 2x 0.217, 3x 0.212, 6x 0.211).
   constexpr int kTinyGridRounds = 4;
-  static std::atomic<int> per_cu_of[9][2];
+  static std::atomic<int> per_cu_of[9][2][3];
+#define RGX_TINY_FN(N, R, W) (const void*)batch_tiny_sorted_kernel<N, R, W>
 #define RGX_TINY_GO(N)                                                                                                                  \
   do {                                                                                                                                  \
     const void* fn = per_wave ? (replay ? (const void*)batch_tiny_kernel<N, true> : (const void*)batch_tiny_kernel<N, false>)           \
-                              : (replay ? (const void*)batch_tiny_sorted_kernel<N, true> : (const void*)batch_tiny_sorted_kernel<N, false>); \
-    int per_cu = per_cu_of[N][replay ? 1 : 0].load(std::memory_order_relaxed);                                                          \
+                   : level > 0 ? (replay ? RGX_TINY_FN(N, true, true) : RGX_TINY_FN(N, false, true))                                    \
+                               : (replay ? RGX_TINY_FN(N, true, false) : RGX_TINY_FN(N, false, false));                                 \
+    int per_cu = per_cu_of[N][replay ? 1 : 0][level].load(std::memory_order_relaxed);                                                   \
     if (per_cu == 0) {                                                                                                                  \
-      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlockThreads, lds) != hipSuccess || per_cu < 1) per_cu = 4;        \
-      per_cu_of[N][replay ? 1 : 0].store(per_cu, std::memory_order_relaxed);                                                            \
+      if (lds > 64 * 1024) { const hipError_t e = AllowBigLds(fn); if (e != hipSuccess) return e; }                                     \
+      if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlockThreads, lds) != hipSuccess || per_cu < 1) per_cu = level > 0 ? 2 : 4; \
+      per_cu_of[N][replay ? 1 : 0][level].store(per_cu, std::memory_order_relaxed);                                                     \
     }                                                                                                                                   \
     int64_t grid = (int64_t)cus * per_cu * kTinyGridRounds;                                                                             \
     if (grid > ngroups) grid = ngroups;                                                                                                 \
     void* args[] = {(void*)&U.tiny, (void*)&concat, (void*)&offsets, (void*)&nstr, (void*)&found, (void*)&spans, (void*)&wslice,        \
-                    (void*)&unset, (void*)&F.ncap, (void*)&fixed, (void*)&F.cap_kind, (void*)&F.cap_delta, (void*)&ctl, (void*)&gmap};                \
+                    (void*)&unset, (void*)&F.ncap, (void*)&fixed, (void*)&F.cap_kind, (void*)&F.cap_delta, (void*)&ctl, (void*)&gmap};  \
     if (hipLaunchKernel(fn, dim3((unsigned)grid), dim3(kBlockThreads), args, lds, stream) != hipSuccess) return hipGetLastError();      \
   } while (0)
   switch (U.tiny_nreg) {
@@ -495,6 +539,7 @@ hipError_t LaunchBatchTiny(const DevTables& U, const DevTables& F, const uint8_t
     default: RGX_TINY_GO(8); break;
   }
 #undef RGX_TINY_GO
+#undef RGX_TINY_FN
   return hipGetLastError();
 }
 

@@ -17,6 +17,7 @@
 #include "rgx.h"
 #include "rgx_kernels.h"
 #include "rgx_program.h"
+#include "rgx_tiny.h"
 
 #define RGX_API extern "C" __attribute__((visibility("default")))
 
@@ -51,6 +52,7 @@ struct rgx_program {
   // shared handle: the first calls of a program LEARN which of its kernels suits its texts, a service that wants the same answer
   // time for every call warms the program up and freezes it)
   mutable std::atomic<int> frozen{0};
+  mutable std::atomic<int> tiny_level{0};   // rgx_find_batch_device: the register kernel's instance (0: strings <= 56 bytes; 1, 2: <= 254, LDS windows of 34 / 64 KiB)
 };
 
 struct rgx_stream_ctx {
@@ -94,8 +96,8 @@ struct rgx_stream_ctx {
   // pinned host readback
   uint32_t* d_tiny_ctl = nullptr; int tiny_set = 0;   // batch_tiny_kernel's two control sets (rgx_find_batch_device)
   uint8_t* d_gmap = nullptr; int64_t gmap_cap = 0;    // ... and its map of the groups it left to the general kernel (a byte per 256 strings)
-  unsigned long long* h_read = nullptr;      // [16]: 0-3 the synchronous scan (total, rare-path flag, counters), 4-5 the splice, 6-7 the tiny batch's control words,
-  unsigned long long* h_read_dev = nullptr;  //       8-11 / 12-15 the two in-flight scans of submit/wait; same words, device view
+  unsigned long long* h_read = nullptr;      // [32]: 0-3 the synchronous scan (total, rare-path flag, counters), 4-5 the splice, 6-7 the tiny batch's control words,
+  unsigned long long* h_read_dev = nullptr;  //       8-11 / 12-15 the two in-flight scans of submit/wait, 16-18 the tiny batch's extras; same words, device view
   // submit / wait (rgx_find_all_submit): up to two scans in flight
   struct Pending {
     const uint8_t* d_buf; size_t len; int64_t n; int32_t* d_spans; size_t cap; int64_t own_lo, own_hi;
@@ -1222,7 +1224,7 @@ RGX_API int rgx_program_tuning(const rgx_program* p, rgx_tuning* o) {
   o->frozen = p->frozen.load(); o->scan_kernel_choice = p->fc_pref.load(); o->fc_us_per_gib = p->fc_us_per_gib.load();
   o->other_us_per_gib = p->other_us_per_gib.load(); o->fc_gave_up = p->fc_bad.load(); o->captures_long_rows = p->caps_long.load();
   o->sync_automaton = p->prefer_w.load(); o->exact_sync_points = p->prefer_wsync.load(); o->rewinding_walk = p->prefer_rw.load();
-  o->ascii_twin = p->ascii_state.load();
+  o->ascii_twin = p->ascii_state.load(); o->batch_tiny_level = p->tiny_level.load();
   return RGX_OK;
 }
 RGX_API int64_t rgx_unicode_table(const char* name, int32_t* dst, size_t cap_pairs) {
@@ -1276,7 +1278,7 @@ RGX_API int rgx_stream_ctx_create_on_stream(const rgx_program* p, void* hip_stre
   else stream_ok = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) == hipSuccess;
   bool ok = stream_ok && hipMalloc((void**)&c->d_cursor, 32) == hipSuccess &&
             hipEventCreate(&c->ev0) == hipSuccess && hipEventCreate(&c->ev1) == hipSuccess &&
-                        hipHostMalloc((void**)&c->h_read, 128, hipHostMallocMapped) == hipSuccess &&
+                        hipHostMalloc((void**)&c->h_read, 256, hipHostMallocMapped) == hipSuccess &&
             hipHostGetDevicePointer((void**)&c->h_read_dev, c->h_read, 0) == hipSuccess;
   if (!ok) { SetError("ctx allocation failed"); rgx_stream_ctx_destroy(c); return RGX_E_HIP; }
   *out = c;
@@ -2120,7 +2122,7 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
       // to walk one by one (ctl[1], the list behind)
       // two control sets ([gave up, flagged, groups left, -] + the list), used alternately: the call's last kernel zeroes the other one and
       // writes this one's four words to pinned host memory (words 6-7 of h_read), so the call is two launches and one synchronisation
-      constexpr size_t kSetWords = 4 + kTinyListCap;
+      constexpr size_t kSetWords = kTinyCtlHead + kTinyListCap;
       if (!c->d_tiny_ctl) {
         HIP_TRY(hipMalloc((void**)&c->d_tiny_ctl, 2 * kSetWords * 4));
         HIP_TRY(hipMemsetAsync(c->d_tiny_ctl, 0, 2 * kSetWords * 4, c->stream));
@@ -2131,30 +2133,52 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
       c->tiny_set = 1 - c->tiny_set;
       volatile uint32_t* hc = reinterpret_cast<volatile uint32_t*>(c->h_read + 6);
       hc[0] = hc[1] = hc[2] = hc[3] = 0;
+      c->h_read[16] = 0; c->h_read[17] = 0; c->h_read[18] = 0;
+      // which instance: the program remembers what its batches look like (narrow: strings of at most 56 bytes, eight workgroups a CU; wide:
+      // up to 254 bytes with an LDS window of 34 or 64 KiB) -- learned from the control words below, fixed by rgx_program_freeze
+      const int level = p->tiny_level.load(std::memory_order_relaxed);
+      const bool frozen = p->frozen.load(std::memory_order_relaxed) != 0;
       if ((rc = Ensure(&c->d_gmap, &c->gmap_cap, (int64_t)(nstr / 256) + 64)) != RGX_OK) return rc;
-      HIP_TRY(LaunchBatchTiny(*U, T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, ref_mode, ctl, c->d_gmap, c->stream));
-      c->h_read[4] = 0;
-      HIP_TRY(LaunchBatchRefFixList(T, d_concat, d_offsets, d_found, d_spans, c->d_trace, ctl, kTinyListCap, reinterpret_cast<uint32_t*>(c->h_read_dev + 6),
-                                    other, ref_mode && !T.anchored, c->stream, (int64_t)nstr, c->h_read_dev + 4));
+      HIP_TRY(LaunchBatchTiny(*U, T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, ref_mode, ctl, c->d_gmap, c->stream, level));
+      // (the list pass has no scratch: a flagged string whose match is beyond its LDS trace -- wide instances only -- stays flagged and
+      // raises a word; LaunchBatchRefFix below finishes it once the batch's size is known)
+      HIP_TRY(LaunchBatchRefFixList(T, d_concat, d_offsets, d_found, d_spans, nullptr, ctl, kTinyListCap, reinterpret_cast<uint32_t*>(c->h_read_dev + 6),
+                                    other, ref_mode && !T.anchored, c->stream, (int64_t)nstr, c->h_read_dev + 16));
       HIP_TRY(hipStreamSynchronize(c->stream));
       const uint32_t h_ctl[4] = {hc[0], hc[1], hc[2], hc[3]};
-      const bool groups_left = h_ctl[2] != 0;      // groups of 256 strings the kernel left alone (d_gmap): one of their strings is beyond its tag bytes
+      const volatile unsigned long long* hx = c->h_read + 16;
+      const uint64_t h_last = (uint64_t)hx[0];      // the batch's bytes
+      const uint32_t h_span = (uint32_t)hx[1], h_long = (uint32_t)(hx[1] >> 32);
+      const bool h_wants_trace = hx[2] != 0;
+      const int64_t ngroups = ((int64_t)nstr + 255) / 256;
+      const bool groups_left = h_ctl[2] != 0;      // groups of 256 strings the kernel left alone (d_gmap): a string beyond its tag bytes, or more bytes than its window
+      if (!frozen && !h_ctl[0]) {
+        // more than a quarter of the groups would be taken by the next wider instance (left, and not because of a string beyond what a
+        // tag byte holds): up; a wide instance whose batch the narrower one holds, or more than half of whose groups hold such a string: back
+        const int64_t rescuable = (int64_t)h_ctl[2] - (int64_t)h_long;
+        int next = level;
+        if (level < 2 && rescuable * 4 > ngroups) next = level + 1;
+        else if (level > 0 && h_ctl[3] <= (uint32_t)kTinyMaxLen) next = 0;
+        else if (level == 2 && h_span <= (uint32_t)BatchTinyWindow(1)) next = 1;
+        else if (level > 0 && (int64_t)h_long * 2 > ngroups) next = 0;
+        if (next != level) p->tiny_level.store(next, std::memory_order_relaxed);
+      }
       const bool fused_ok = !ref_mode || BatchSearchFits(*U, T, true, d_concat, true);
       if (!h_ctl[0] && (!groups_left || fused_ok)) {
-        if (ref_mode && h_ctl[1] >= kTinyListCap) {
-          // (more flagged strings than the list holds: every match is at most kTinyMaxLen bytes, the LDS trace of ref_fix_kernel holds it)
+        const int64_t need_fix = ref_mode ? (int64_t)h_last + 2 * (int64_t)nstr + 64 : 0;
+        if (ref_mode && (h_ctl[1] >= kTinyListCap || h_wants_trace)) {
+          // more flagged strings than the list holds, or one whose match the list pass's LDS trace does not hold
+          if ((rc = Ensure(&c->d_trace, &c->trace_cap, need_fix)) != RGX_OK) return rc;
           HIP_TRY(LaunchBatchRefFix(T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, c->d_trace, c->stream, 1));
           HIP_TRY(hipStreamSynchronize(c->stream));
         }
         if (groups_left) {
           // those groups through the general kernel (the preamble of the whole-batch path below: scratch by the batch's bytes, the length
           // guard of reference mode), the strings it flags finished by the replay kernel -- flagged ones ONLY: the tiny kernel's rows are final
-          // (the batch's bytes and the longest string of those groups came with the control words: no pass over the offsets, no round trip)
-          const uint64_t h_last = (uint64_t)((volatile unsigned long long*)c->h_read)[4];
+          // (the batch's bytes and the longest string came with the control words: no pass over the offsets, no round trip)
           const unsigned long long h_max = h_ctl[3];
           if (ref_mode && (int64_t)h_max > kBatchSearchMaxLen) return BatchLengthGuard(c, d_offsets, nstr, kBatchSearchMaxLen, -1);
           const int64_t need = ((int64_t)h_last + 2 * (int64_t)nstr + 64 + 1) / 2 * (U->nstates <= 256 ? 1 : 2);
-          const int64_t need_fix = ref_mode ? (int64_t)h_last + 2 * (int64_t)nstr + 64 : 0;
           if ((rc = Ensure(&c->d_trace, &c->trace_cap, std::max(need, need_fix))) != RGX_OK) return rc;
           HIP_TRY(LaunchBatchSearch(*U, T, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, c->d_trace, c->stream,
                                     BatchWindowFor((int64_t)h_last, (int64_t)nstr), ref_mode ? 1 : 0, c->d_gmap));

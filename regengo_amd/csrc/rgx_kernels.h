@@ -171,20 +171,24 @@ hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8
 // lock-step pass, everything in registers (rgx_batch_tiny.hip).  The launch is OPTIMISTIC -- nobody has looked at the offsets yet: the
 // kernel measures the strings itself and gives the batch up (ctl[0] != 0: results void, take the general path) when one is longer.
 // ref: the reference's restart rule rides along; the strings whose attempts do not land on the match's start get found = 2 and are
-// listed (ctl[1] = how many, ctl[4..] = the first `cap` indices) for LaunchBatchRefFixList, which replays them one by one; more than
-// `cap` of them: LaunchBatchRefFix(only_flagged) over the whole batch.  ctl: 4 + cap words, ctl[0..3] zero on entry -- the list
+// listed (ctl[1] = how many, ctl[kTinyCtlHead..] = the first `cap` indices) for LaunchBatchRefFixList, which replays them one by one; more than
+// `cap` of them: LaunchBatchRefFix(only_flagged) over the whole batch.  ctl: kTinyCtlHead + cap words, the head zero on entry -- the list
 // kernel of the call before zeroed them (two control sets used alternately) and hands this call's to the host through pinned memory
 // (host_ctl): a call is two launches and one synchronisation, no memset and no copy node.
 constexpr uint32_t kTinyListCap = 65536;
+constexpr int kTinyCtlHead = 8;       // control words in front of the list: [0] gave up, [1] flagged, [2] groups left to the general kernel, [3] the
+                                      // longest string (narrow instances: of those groups; wide: of the batch), [4] wide: the largest group's bytes,
+                                      // [5] groups left because of a string beyond kTinyWideMaxLen (no instance takes those)
 // ... and a GROUP of 256 strings that holds a string beyond kTinyMaxLen is left alone and marked in `gmap` (a byte per group, written
 // for every group; ctl[2] != 0: there are marked groups, ctl[3] = their longest string) for LaunchBatchSearch over those groups: one long line no longer sends ten
 // million strings to the general kernel (round 6).
 bool BatchTinyFits(const DevTables& U, const DevTables& F, const uint8_t* concat, int64_t nstr, bool ref);
 hipError_t LaunchBatchTiny(const DevTables& U, const DevTables& F, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found,
-                           int32_t* spans, bool ref, uint32_t* ctl, uint8_t* gmap, hipStream_t stream);
+                           int32_t* spans, bool ref, uint32_t* ctl, uint8_t* gmap, hipStream_t stream, int level = 0);
+int BatchTinyWindow(int level);      // the LDS window of level 0 (strings <= kTinyMaxLen) / 1 / 2 (the wide instances: <= kTinyWideMaxLen), bytes
 hipError_t LaunchBatchRefFixList(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, uint8_t* found, int32_t* spans,
                                  uint16_t* trace, const uint32_t* ctl, uint32_t cap, uint32_t* host_ctl, uint32_t* other_ctl, bool do_fix,
-                                 hipStream_t stream, int64_t nstr = 0, unsigned long long* host_last = nullptr);   // host_last: offsets[nstr] published
+                                 hipStream_t stream, int64_t nstr = 0, unsigned long long* host_last = nullptr);   // host_last[0..2]: offsets[nstr], ctl[4] | ctl[5] << 32, "a replay wants scratch"
 
 // The current device's CU count, and the 160 KiB dynamic-LDS allowance of a kernel -- both cached per DEVICE (a device list in one process
 // launches the same kernels on several devices).

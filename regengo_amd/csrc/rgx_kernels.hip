@@ -1062,7 +1062,9 @@ __global__ __launch_bounds__(64) void ref_batch_kernel(DevTables T, const uint8_
 // stands), runs out of text (no match for the reference: the record is cleared) or steps over s (rare: the emitted loop goes
 // on from there with full attempts, as ref_batch_kernel does).  The attempt-per-offset loop walks a word of n bytes n/2 times
 // (quadratic: 7.7 ms on the C3 batch against 1 ms for the plain search); this is linear.
-__device__ void RefFixOne(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t i, uint8_t* found, int32_t* spans,
+// Returns true -- and leaves the string flagged -- when the match is longer than the LDS trace and there is no scratch (trace == nullptr:
+// the tiny batch's list pass runs before the host knows the batch's size; it then runs LaunchBatchRefFix with scratch).
+__device__ bool RefFixOne(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t i, uint8_t* found, int32_t* spans,
                           uint16_t* trace, uint16_t* s_trace) {
   const uint64_t o0 = offsets[i], o1 = offsets[i + 1];
   const uint8_t* buf = concat + o0;
@@ -1076,7 +1078,7 @@ __device__ void RefFixOne(const DevTables& T, const uint8_t* concat, const uint6
     if (!(len > fo)) { lost = true; break; }
     off = fo + 1;
   }
-  if (!lost && off == s0) { found[i] = 1; return; }   // the attempt at s0 is made, and it is the one that matches
+  if (!lost && off == s0) { found[i] = 1; return false; }   // the attempt at s0 is made, and it is the one that matches
   int s = -1, e = -1;
   while (!lost) {                                // stepped over s0: full attempts from here on (find.go:545-569)
     const int end = WalkGlobal(T, buf, len, off);
@@ -1086,14 +1088,16 @@ __device__ void RefFixOne(const DevTables& T, const uint8_t* concat, const uint6
     off = fo + 1;
   }
   found[i] = s >= 0;
-  if (s < 0) { for (int c = 0; c < T.ncap; ++c) rec[c] = T.unmatched_minus1 ? -1 : 0; return; }
+  if (s < 0) { for (int c = 0; c < T.ncap; ++c) rec[c] = T.unmatched_minus1 ? -1 : 0; return false; }
   if (T.fixed_captures) {
     for (int c = 0; c < T.ncap; ++c) rec[c] = T.cap_kind[c] == kCapFromStart ? s + T.cap_delta[c] : e - T.cap_delta[c];
-    return;
+    return false;
   }
   const int need = e - s + 1;
+  if (need > kCapsLdsTrace && !trace) { found[i] = 2; return true; }
   uint16_t* tr = need <= kCapsLdsTrace ? s_trace + threadIdx.x * kCapsLdsTrace : trace + o0 + 2 * i;
   ResolveCaptures(T, buf, len, s, e, tr, rec);
+  return false;
 }
 
 __global__ __launch_bounds__(64) void ref_fix_kernel(DevTables T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr,
@@ -1113,7 +1117,7 @@ __global__ __launch_bounds__(64) void ref_fix_kernel(DevTables T, const uint8_t*
   RefFixOne(T, concat, offsets, i, found, spans, trace, s_trace);
 }
 
-// ... over a LIST of strings (batch_tiny_kernel names the few it flags: ctl[1] = how many, ctl + 4 = their indices, `cap` of them at most --
+// ... over a LIST of strings (batch_tiny_kernel names the few it flags: ctl[1] = how many, ctl + kTinyCtlHead = their indices, `cap` of them at most --
 // beyond that, and when ctl[0] is set -- the kernel gave the batch up --, this one replays nothing and the host takes the whole-batch
 // path).  It also PUBLISHES the call's control words: ctl[0..3] go to pinned host memory (the host reads them behind its one
 // synchronisation: no copy node in the stream) and the OTHER control set, the next call's, is zeroed (no memset node either).
@@ -1122,16 +1126,19 @@ __global__ __launch_bounds__(64) void ref_fix_list_kernel(DevTables T, const uin
                                                           uint32_t* other_ctl, int do_fix, int64_t nstr, unsigned long long* host_last) {
   __shared__ uint16_t s_trace[64 * kCapsLdsTrace];
   const uint32_t gave_up = ctl[0], flagged = ctl[1];
-  if (blockIdx.x == 0 && threadIdx.x < 4) {
-    __hip_atomic_store(host_ctl + threadIdx.x, ctl[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-    other_ctl[threadIdx.x] = 0u;
+  if (blockIdx.x == 0 && threadIdx.x < 4) __hip_atomic_store(host_ctl + threadIdx.x, ctl[threadIdx.x], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  if (blockIdx.x == 0 && threadIdx.x < kTinyCtlHead) other_ctl[threadIdx.x] = 0u;
+  // (the batch's bytes: what the host sizes the general kernel's scratch by when groups were left to it; [1]: the largest group's bytes as
+  // the wide instances saw it | the groups no instance takes << 32; [2] is raised by a replay below that wants the scratch)
+  if (blockIdx.x == 0 && threadIdx.x == 8 && host_last) {
+    __hip_atomic_store(host_last, (unsigned long long)offsets[nstr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(host_last + 1, (unsigned long long)ctl[4] | ((unsigned long long)ctl[5] << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
-  // (the batch's bytes: what the host sizes the general kernel's scratch by when groups were left to it)
-  if (blockIdx.x == 0 && threadIdx.x == 4 && host_last) __hip_atomic_store(host_last, (unsigned long long)offsets[nstr], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   if (gave_up || !do_fix) return;
   const uint32_t n = flagged < cap ? flagged : 0u;
   for (uint32_t k = blockIdx.x * 64 + threadIdx.x; k < n; k += gridDim.x * 64)
-    RefFixOne(T, concat, offsets, (int64_t)ctl[4 + k], found, spans, trace, s_trace);
+    if (RefFixOne(T, concat, offsets, (int64_t)ctl[kTinyCtlHead + k], found, spans, trace, s_trace) && host_last)
+      __hip_atomic_store(host_last + 2, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
 }
 
 // ---- MatchBytes per string, interpreted (DevTables::ref_match_kind 3: the reference memoises its MatchBytes, or the program holds an

@@ -48,7 +48,8 @@ constexpr int kTinyInit = 1024;       // [0..7] the tag registers at offset 0, [
                                       // of the right-most-path automaton at offset 0, [11] bit 0: the replay columns are valid, [12] registers in
                                       // use, [13] capture slots tracked, [14..15] reserved, [16..23] slot -> register
 constexpr int kTinyWords = 1048;
-constexpr int kTinyMaxLen = 56;       // a byte holds an offset or 0xFF = "unset"
+constexpr int kTinyMaxLen = 56;       // a byte holds an offset or 0xFF = "unset"; 56: the narrow instances' LDS window (256 strings a workgroup, eight workgroups a CU)
+constexpr int kTinyWideMaxLen = 254;  // ... the wide instances' (rgx_batch_tiny.hip): what a tag byte holds
 constexpr uint32_t kTinyIdentity = 0x03020100u;
 constexpr uint32_t kTinyAttempt = 8u;   // the bit of an attempt-offset byte that says "FindBytesReuse makes an attempt here" (the restart flag of a nibble)
 RGX_TINY_HD uint32_t TinyCellOffset(int cls) { return cls < 5 ? (uint32_t)cls : (uint32_t)(30 + cls - 5); }
@@ -120,7 +121,8 @@ RGX_TINY_HD int32_t TinySbfe8(uint32_t v, uint32_t off) {      // the byte at bi
 // NO attempt (rec[0] = that start): its attempts step over it or run out of text first -- ref_fix_kernel replays them and goes on from
 // there.  reg_of[c] = the register of slot c (uniform).  The last-match bytes of the registers are gathered into one word per four
 // registers (three v_perm), a slot is one signed bit-field extract (0xFF = unset = -1; offsets are < 128) and a max with `unset` (-1 or 0).
-template <int NREG, bool REF, class Map>
+// WIDE: offsets up to 254 -- the byte is read unsigned and 0xFF becomes -1 by a compare.
+template <int NREG, bool REF, bool WIDE = false, class Map>
 RGX_TINY_HD int TinyFinish(const TinyLane<NREG>& L, int unset, int ncap, const Map& reg_of, int32_t* rec) {
   const auto gather4 = [&](int r0) {
     const uint32_t a = L.R[r0 < NREG ? r0 : NREG - 1], b = L.R[r0 + 1 < NREG ? r0 + 1 : NREG - 1];
@@ -134,7 +136,8 @@ RGX_TINY_HD int TinyFinish(const TinyLane<NREG>& L, int unset, int ncap, const M
   for (int c = 0; c < 8; ++c) {
     if (c < ncap) {
       const uint32_t want = reg_of[c];
-      const int32_t x = TinySbfe8(NREG > 4 && want >= 4u ? w1 : w0, (want & 3u) << 3);
+      int32_t x = TinySbfe8(NREG > 4 && want >= 4u ? w1 : w0, (want & 3u) << 3);
+      if (WIDE) x = x == -1 ? -1 : (x & 255);
       rec[c] = x > unset ? x : unset;
       if (c == 1) end = x;
     }

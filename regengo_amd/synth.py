@@ -91,14 +91,14 @@ def date_log_expected(n: int, every: int = 50):
     return np.stack([s, s + 10, s, s + 4, s + 5, s + 7, s + 8, s + 10], axis=1)
 
 
-def email_batch_np(nstr: int, seed: int = 0x5EED0003):
-    """C3: strings for (?P<user>\\w+)@(?P<domain>\\w+): length U[8,40]; 80% contain word@word with padding, 10% no '@',
+def email_batch_np(nstr: int, seed: int = 0x5EED0003, lo: int = 8, hi: int = 40):
+    """C3: strings for (?P<user>\\w+)@(?P<domain>\\w+): length U[lo,hi] (C3: U[8,40]); 80% contain word@word with padding, 10% no '@',
     5% leading/trailing '@', 5% contain a byte >= 0x80.  Returns (concat uint8, offsets int64[nstr+1])."""
     ids = np.arange(nstr, dtype=np.uint64)
     r0 = splitmix64_np(seed, ids * np.uint64(4))
     r1 = splitmix64_np(seed, ids * np.uint64(4) + np.uint64(1))
     r2 = splitmix64_np(seed, ids * np.uint64(4) + np.uint64(2))
-    lens = (8 + (r0 >> np.uint64(40)) % np.uint64(33)).astype(np.int64)
+    lens = (lo + (r0 >> np.uint64(40)) % np.uint64(hi - lo + 1)).astype(np.int64)
     offsets = np.zeros(nstr + 1, dtype=np.int64)
     np.cumsum(lens, out=offsets[1:])
     total = int(offsets[-1])

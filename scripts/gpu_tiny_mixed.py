@@ -8,7 +8,9 @@ from regengo_amd import Compiled, synth
 
 EMAIL = r"(?P<user>\w+)@(?P<domain>\w+)"
 nstr = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
-data, offs = synth.email_batch_np(nstr, seed=0x5EED0003)
+# RGX_BATCH_LENS=lo,hi: every string's length drawn from U[lo,hi] (default: C3's U[8,40])
+BLO, BHI = (int(x) for x in os.environ.get("RGX_BATCH_LENS", "8,40").split(","))
+data, offs = synth.email_batch_np(nstr, seed=0x5EED0003, lo=BLO, hi=BHI)
 lens = np.diff(offs).astype(np.int64)
 rng = random.Random(5)
 LO, HI = (int(x) for x in sys.argv[3].split(",")) if len(sys.argv) > 3 else (60, 200)
@@ -28,12 +30,15 @@ for every in EVERY:
     doffs = torch.from_numpy(noffs).cuda()
     for stdlib in (False, True):
         c = Compiled(EMAIL, stdlib=stdlib).to(0)
-        for _ in range(3):
+        for _ in range(4):
             c.FindBatchDevice(concat, doffs)
+        lvl = c.tuning()["batch_tiny_level"]
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(10):
             found, spans = c.FindBatchDevice(concat, doffs)
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) * 100
-        print("every=%-7d stdlib=%d  %.3f ms  %.1f GB/s  found=%d" % (every, stdlib, ms, len(out) / ms / 1e6, int(found.sum())), flush=True)
+        alg = len(out) + 8 * (nstr + 1) + nstr + nstr * c.ncap * 4
+        print("every=%-7d stdlib=%d  %.3f ms  %.1f GB/s of input  %.3f of HBM peak by algorithmic bytes  level=%d found=%d"
+              % (every, stdlib, ms, len(out) / ms / 1e6, alg / ms / 1e6 / 8000.0, lvl, int(found.sum())), flush=True)

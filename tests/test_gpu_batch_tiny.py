@@ -218,3 +218,115 @@ def test_a_few_long_lines_do_not_void_the_batch(torch_dev, pattern):
             assert np.array_equal(f, exp_found), (pattern, nstr, every, int((f != exp_found).sum()))
             m = exp_found.astype(bool)
             assert np.array_equal(sp[m], exp_spans[m]), (pattern, nstr, every)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pattern", [EMAIL, r"(?P<k>[a-z]+)=(?P<v>\d*)", r"(\d+)-(\d+)"])
+def test_lines_of_up_to_254_bytes_stay_in_registers(torch_dev, pattern):
+    """the register kernel's WIDE instances (strings of up to 254 bytes: a tag byte holds any offset below 0xFF; LDS
+    windows of 34 / 64 KiB a group).  A program learns them from its batches: the first batch of U[8,200]-byte lines leaves every group to
+    the general kernel and raises the level, the next ones run in registers -- rows == the oracle's C port string by string on every
+    call, whatever instance took it; lines of 100-254 bytes need the 64 KiB window (level 2), short lines bring the narrow instances
+    back, lines beyond 254 bytes in every group send the program back to level 0, and a frozen program stays where it is."""
+    torch = torch_dev
+    from oracle.gen_c import CMatcher
+    from regengo_amd import Compiled, synth
+    cm = CMatcher(pattern)
+
+    def batch(nstr, lo, hi, seed, long_every=0):
+        data, offs = synth.email_batch_np(nstr, seed=seed, lo=lo, hi=hi)
+        if pattern != EMAIL:                       # something for the other patterns to find
+            data = data.copy()
+            r = np.random.RandomState(seed & 0xFFFF)
+            pos = r.randint(0, len(data) - 8, size=nstr // 2)
+            for k, tok in enumerate((b"ab=12", b"7-45", b"x=", b"100-2")):
+                for j, ch in enumerate(tok):
+                    data[pos[k::4] + j] = ch
+        if long_every:                             # lines beyond the tag bytes: whole strings replaced by longer ones is what test_a_few_long_lines does; here: merge neighbours
+            keep = np.ones(nstr + 1, dtype=bool)
+            keep[1:nstr:long_every] = False        # dropping an inner offset merges two neighbouring strings
+            offs = offs[keep]
+        return data, offs
+
+    def check(c, data, offs, what):
+        nstr = len(offs) - 1
+        uoffs = offs.astype(np.uint64)
+        exp_found = np.zeros(nstr, dtype=np.uint8)
+        exp_spans = np.zeros((nstr, cm.ncap), dtype=np.int32)
+        cm.lib.m_find_batch(data.ctypes.data, uoffs.ctypes.data, nstr, exp_found.ctypes.data, exp_spans.ctypes.data)
+        found, spans = c.FindBatchDevice(torch.from_numpy(data).cuda(), torch.from_numpy(offs.astype(np.int64)).cuda())
+        f, sp = found.cpu().numpy(), spans.cpu().numpy()
+        assert np.array_equal(f, exp_found), (pattern, what, int((f != exp_found).sum()))
+        m = exp_found.astype(bool)
+        assert np.array_equal(sp[m], exp_spans[m]), (pattern, what)
+
+    c = Compiled(pattern).to(0)
+    assert c.tuning()["batch_tiny_level"] == 0
+    d1, o1 = batch(120_000, 8, 200, 0x5EED0101)
+    check(c, d1, o1, "U[8,200] at level 0")
+    assert c.tuning()["batch_tiny_level"] == 1                      # more than a quarter of the groups were left: the wide instances
+    check(c, d1, o1, "U[8,200] at level 1")
+    assert c.tuning()["batch_tiny_level"] == 1
+    d2, o2 = batch(60_000, 100, 254, 0x5EED0102)                    # groups of ~45 KiB: beyond the 34 KiB window
+    check(c, d2, o2, "U[100,254] at level 1")
+    assert c.tuning()["batch_tiny_level"] == 2
+    check(c, d2, o2, "U[100,254] at level 2")
+    assert c.tuning()["batch_tiny_level"] == 2
+    check(c, d1, o1, "U[8,200] at level 2")                         # the largest group fits the smaller window: back to level 1
+    assert c.tuning()["batch_tiny_level"] == 1
+    d3, o3 = batch(100_000, 8, 40, 0x5EED0103)
+    check(c, d3, o3, "U[8,40] at level 1")
+    assert c.tuning()["batch_tiny_level"] == 0
+    check(c, d3, o3, "U[8,40] at level 0")
+    d4, o4 = batch(100_000, 100, 200, 0x5EED0104, long_every=64)    # a line of 200-400 bytes in every group
+    check(c, d4, o4, "merged lines at level 0")
+    assert c.tuning()["batch_tiny_level"] == 0                      # nothing a wider instance could do
+    check(c, d1, o1, "U[8,200] again")
+    assert c.tuning()["batch_tiny_level"] == 1
+    d5, o5 = batch(100_000, 30, 254, 0x5EED0105, long_every=997)    # a few lines beyond the tag bytes at a wide level: their groups are left, the rest stays
+    check(c, d5, o5, "a few merged lines at level 1")
+    assert c.tuning()["batch_tiny_level"] in (1, 2)
+    c.freeze()
+    lvl = c.tuning()["batch_tiny_level"]
+    check(c, d3, o3, "frozen")
+    assert c.tuning()["batch_tiny_level"] == lvl
+    # plain leftmost-first semantics through the same instances
+    cs = Compiled(pattern, stdlib=True).to(0)
+    for _ in range(2):
+        found, spans = cs.FindBatchDevice(torch.from_numpy(d1).cuda(), torch.from_numpy(o1.astype(np.int64)).cuda())
+    assert cs.tuning()["batch_tiny_level"] == 1
+    import re
+    rx = re.compile(pattern.encode(), re.ASCII)
+    f, sp = found.cpu().numpy(), spans.cpu().numpy()
+    for i in list(range(0, 2000)) + list(range(len(o1) - 2000, len(o1) - 1)):
+        s = bytes(d1[o1[i]:o1[i + 1]])
+        m = rx.search(s)
+        assert bool(f[i]) == (m is not None), (pattern, i, s)
+        if m:
+            assert (sp[i, 0], sp[i, 1]) == m.span(), (pattern, i, s)
+
+
+@pytest.mark.gpu
+def test_wide_instance_flagged_string_with_a_long_match(torch_dev):
+    """A string the reference's restart rule steps over (found by the plain search at a start where no attempt is made) whose LATER match is
+    longer than the list pass's LDS trace: the list pass has no scratch (the batch's size is not known yet), leaves the string flagged
+    and says so; the host then runs the replay with scratch.  Rows == the oracle for every string."""
+    from oracle import engines as E
+    from regengo_amd import Compiled
+    rng = random.Random(11)
+    pat = r"a(b|c)(d+)(e*)"
+    o = E.Compiled(pat)
+    fill = [bytes(rng.choice(b"abcde ") for _ in range(rng.randrange(60, 200))) for _ in range(4000)]
+    special = [b"aabd " + b"ac" + b"d" * n + b"e" * m + b" tail" for n, m in ((120, 0), (100, 30), (97, 1), (10, 2), (200, 20))]
+    c = Compiled(pat).to(0)
+    c.FindBatch(fill)                                   # the program learns the wide instances
+    if c.tuning()["batch_tiny_level"] == 0:
+        pytest.skip("no tiny search automaton for this pattern")
+    strings = fill[:2000] + special + fill[2000:] + special
+    exp = {b: o.FindBytes(b) for b in set(strings)}
+    assert exp[special[0]] is not None and exp[special[0]][0] == 5            # the match at 1 is stepped over, the one at 5 is found
+    for _ in range(2):
+        res = c.FindBatch(strings)
+        for b, r in zip(strings, res):
+            e = exp[b]
+            assert (r is None) == (e is None) and (r is None or r.spans == e), (b, r and r.spans, e)
