@@ -174,6 +174,7 @@ int MatchView(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, siz
 // agree and the plain path answers, on other text the interpreter does.  *interp: take the interpreter.  Without the uploaded constants
 // (a rune list the emitter itself mishandles) the call is refused.
 constexpr int64_t kThomMatchMaxLen = 16ll << 20;     // one lane walks a single text: linear, ~50 cycles a byte
+constexpr int64_t kThomScanMinLen = 64 << 10;        // ... from here on an unanchored program's text is cut into chunks (thompson_scan_kernel)
 int ThompsonRoute(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_bytes, size_t nbytes, bool* interp) {
   *interp = false;
   const int eng = p->p.t.ref_match_engine;
@@ -1927,8 +1928,26 @@ RGX_API int rgx_match_bytes_device(const rgx_program* p, rgx_stream_ctx* c, cons
     bool interp = false;
     if ((rc = ThompsonRoute(p, c, d_buf, len, &interp)) != RGX_OK) return rc;
     if (interp) {
+      const ThomDev& M = p->p.thomdev;
+      if (!M.anchored && (int64_t)len >= kThomScanMinLen) {
+        // a long text: a lane per chunk behind a halo in which the set of the emitted loop is bracketed from both sides (rgx_kernels.hip:
+        // thompson_scan_kernel); a lane that cannot tell asks for a longer halo, at most twice
+        if (M.start_closure & M.accept_mask) { *matched = 1; return RGX_OK; }        // (the empty pattern: thompson.go:103)
+        unsigned* flag = reinterpret_cast<unsigned*>(c->d_cursor + 1);
+        const int chunk = (int)std::min<int64_t>(std::max<int64_t>(((int64_t)len / (DeviceCus() * 2048) + 63) & ~int64_t(63), 256), 8192);
+        for (int halo = 256; halo <= 65536; halo *= 16) {
+          unsigned h = 0;
+          HIP_TRY(hipMemsetAsync(flag, 0, 4, c->stream));
+          HIP_TRY(LaunchThompsonScan(M, d_buf, (int64_t)len, chunk, halo, flag, c->stream));
+          HIP_TRY(hipMemcpyAsync(&h, flag, 4, hipMemcpyDeviceToHost, c->stream));
+          HIP_TRY(hipStreamSynchronize(c->stream));
+          if (h & 1u) { *matched = 1; return RGX_OK; }
+          if (!(h & 2u)) { *matched = 0; return RGX_OK; }
+        }
+        // (sets that do not meet within 64 KiB: the one lane below, while the text is short enough for it)
+      }
       if ((int64_t)len > kThomMatchMaxLen) {
-        SetError("reference-mode MatchBytes of this pattern is the emitted Thompson matcher interpreted by one lane: offered up to 16 MiB of text, keep the Go path beyond");
+        SetError("reference-mode MatchBytes of this pattern is the emitted Thompson matcher interpreted by one lane (an anchored program, or a text on which the parallel form's two bracketing sets do not meet): offered up to 16 MiB of text, keep the Go path beyond");
         return RGX_E_UNSUPPORTED;
       }
       uint64_t h_off[2] = {0, (uint64_t)len};
@@ -2429,7 +2448,7 @@ RGX_API int rgx_match_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8
     SetError("reference-mode MatchBytes of a memoising program is interpreted by one lane: offered up to 64 KiB of text, keep the Go path beyond");
     return RGX_E_UNSUPPORTED;
   }
-  if (!(p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS) && p->p.t.ref_match_engine == 3 && (int64_t)len > kThomMatchMaxLen) {
+  if (!(p->p.t.flags & RGX_FLAG_STDLIB_SEMANTICS) && p->p.t.ref_match_engine == 3 && (int64_t)len > kThomMatchMaxLen && p->p.thomdev.anchored) {
     SetError("reference-mode MatchBytes of this pattern is the emitted Thompson matcher interpreted by one lane: offered up to 16 MiB of text, keep the Go path beyond");
     return RGX_E_UNSUPPORTED;
   }

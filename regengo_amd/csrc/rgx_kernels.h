@@ -233,6 +233,9 @@ hipError_t LaunchReaderCheck(const DevTables& T, const uint8_t* raw, const uint8
 // words; nlanes a multiple of 64; flags: bit 31 = a string / gap the interpreter gave up on (window, stack, budget).
 // MatchBytes per string, the reference's Thompson matcher interpreted (rgx_thompson.h; Program::thomdev)
 hipError_t LaunchThompsonMatch(const ThomDev& M, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* matched, hipStream_t stream);
+// ... of ONE long text, unanchored programs: a lane per `chunk` bytes behind a halo of `halo` bytes (both multiples of 8); flags (zeroed by the
+// caller): bit 0 = the matcher accepts, bit 1 = a lane could not tell (repeat with a longer halo, or LaunchThompsonMatch)
+hipError_t LaunchThompsonScan(const ThomDev& M, const uint8_t* buf, int64_t len, int chunk, int halo, unsigned* flags, hipStream_t stream);
 // MatchBytes per string, the emitted loop interpreted (ref_match_kind 3); flags: nonzero = a lane gave up (stack / step budget)
 hipError_t LaunchBatchMemoMatch(const DevTables& T, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* matched,
                                 unsigned long long* visited, int W, unsigned long long* stack, int cap, int64_t nlanes, int use_memo, uint32_t* flags,

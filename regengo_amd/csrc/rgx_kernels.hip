@@ -1158,6 +1158,60 @@ __global__ __launch_bounds__(64) void memo_match_kernel(DevTables T, MemoDev M, 
   }
 }
 
+// ---- MatchBytes of ONE long text by the Thompson matcher, in parallel (round 6; the unanchored form, thompson.go:103-121).  The step
+// cur' = step(cur, byte) | start_closure is MONOTONE in the set (a union over the set's bits), so the set S the emitted loop holds at an
+// offset is bracketed by two walks that begin `halo` bytes earlier: L from the start closure alone (the attempts that begin in the halo:
+// a subset of S) and U from EVERY instruction (a superset).  A lane owns `chunk` bytes; it walks its halo with both sets and its chunk
+// with both until they are equal -- from there on the one set IS the emitted loop's.  An accept of L is an accept of the loop (the answer
+// is 1 whatever the other lanes find: MatchBytes is "does any step accept"); an accept of U alone cannot be decided here: flags bit 1,
+// the host repeats with a longer halo (or hands the text to the one lane of thompson_match_kernel).  No accept of U in any chunk: 0.
+// The threads of an attempt die at the first byte nothing consumes, so the two sets meet within a match's length of most texts.
+__global__ __launch_bounds__(256) void thompson_scan_kernel(ThomDev M, const uint8_t* buf, long long len, int chunk, int halo, unsigned* flags) {
+  __shared__ unsigned long long s_clo[64];
+  __shared__ uint32_t s_set[64 * 8];
+  for (int w = threadIdx.x; w < 64; w += 256) s_clo[w] = M.closure_out[w];
+  for (int w = threadIdx.x; w < 64 * 8; w += 256) s_set[w] = M.byteset[w];
+  __syncthreads();
+  const long long k0 = ((long long)blockIdx.x * 256 + threadIdx.x) * (long long)chunk;
+  if (k0 >= len) return;
+  const long long k1 = min(k0 + (long long)chunk, len);
+  long long i = max(k0 - (long long)halo, 0ll);
+  const unsigned long long start = M.start_closure, acc = M.accept_mask, cm = M.char_mask;
+  const auto step = [&](unsigned long long cur, unsigned c) {
+    unsigned long long m = cur & cm, nxt = 0;
+    while (m) {
+      const int k = __builtin_ctzll(m);
+      m &= m - 1;
+      if ((s_set[k * 8 + (c >> 5)] >> (c & 31u)) & 1u) nxt |= s_clo[k];
+    }
+    return nxt;
+  };
+  unsigned long long L = start, U = i == 0 ? start : (M.n >= 64 ? ~0ull : ((1ull << M.n) - 1ull));
+  bool same = U == L;
+  // the text eight bytes at a time where it is aligned (chunk and halo are multiples of 8: so is every lane's first offset)
+  const bool wide = (((uintptr_t)buf) & 7) == 0;
+  while (i < k1) {
+    unsigned long long w8 = 0;
+    int nb = 1;
+    if (wide && i + 8 <= len) { w8 = *reinterpret_cast<const unsigned long long*>(buf + i); nb = 8; }
+    else w8 = buf[i];
+    if ((i & 1023) == 0 && (__hip_atomic_load(flags, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) & 1u)) return;      // somebody's set accepted
+    for (int b = 0; b < nb && i < k1; ++b, ++i) {
+      const unsigned c = (unsigned)(w8 >> (8 * b)) & 255u;
+      const unsigned long long nl = step(L, c);
+      const bool own = i >= k0;
+      if (own && (nl & acc)) { atomicOr(flags, 1u); return; }
+      if (!same) {
+        const unsigned long long nu = step(U, c);
+        if (own && (nu & acc)) { atomicOr(flags, 2u); return; }      // (L did not accept: this lane cannot tell)
+        U = nu | start;
+      }
+      L = nl | start;
+      if (!same) same = U == L;
+    }
+  }
+}
+
 // ---- MatchBytes per string, the reference's Thompson matcher interpreted (rgx_thompson.h): a lane per string, the two
 // tables of the emitted function in LDS (closure of Out and the byte set per consuming instruction: 2.5 KiB).
 __global__ __launch_bounds__(256) void thompson_match_kernel(ThomDev M, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* matched) {
@@ -3178,6 +3232,13 @@ hipError_t LaunchBatchMemoMatch(const DevTables& T, const uint8_t* concat, const
   if (nstr <= 0) return hipSuccess;
   hipLaunchKernelGGL(memo_match_kernel, dim3((unsigned)(nlanes / 64)), dim3(64), 0, stream, T, *T.memo, concat, offsets, nstr, matched, visited, W,
                      stack, cap, use_memo, flags);
+  return hipGetLastError();
+}
+
+hipError_t LaunchThompsonScan(const ThomDev& M, const uint8_t* buf, int64_t len, int chunk, int halo, unsigned* flags, hipStream_t stream) {
+  if (len <= 0) return hipSuccess;
+  const int64_t lanes = (len + chunk - 1) / chunk;
+  hipLaunchKernelGGL(thompson_scan_kernel, dim3((unsigned)((lanes + 255) / 256)), dim3(256), 0, stream, M, buf, (long long)len, chunk, halo, flags);
   return hipGetLastError();
 }
 

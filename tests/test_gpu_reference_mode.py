@@ -325,3 +325,55 @@ def test_find_bytes_of_one_long_text(torch_dev):
             c.FindBytes(t)
         assert ei.value.status == -3
         assert cs.FindBytes(t)[0].spans[0] == at_miss + skip
+
+
+@pytest.mark.gpu
+def test_thompson_matcher_over_one_long_text(torch_dev):
+    """the interpreted Thompson matcher (programs whose threads stop at an empty-width instruction, or texts with a
+    byte >= 0x80) over ONE long text -- a lane per chunk behind a halo in which the emitted loop's set is bracketed from both sides
+    (rgx_kernels.hip: thompson_scan_kernel) instead of one lane for the whole text (refused beyond 16 MiB).  Answers == the host mirror
+    of the emitted function (rgx_thompson.h through hosttest; itself == oracle.ThompsonMatcher on short texts, tests/test_ref_engine.py):
+    texts of 100 KiB to 48 MiB without a match, with one planted at the very end / on a chunk edge / in the first bytes, with near
+    misses everywhere, texts of one repeated byte (the sets of `(a+)+...` stay alive), and a text no chunk of which holds a byte that
+    kills a thread."""
+    torch = torch_dev
+    from oracle import engines as E
+    from regengo_amd import Compiled
+    from tests._hosttest import HostProgram
+    rng = np.random.default_rng(7)
+    cases = ((r"(a+)+(?:\bx| y)", b"aa y", b"aa x", False),                       # (the thread that reaches \b stops there: Q16)
+             (r"(?:a+.)+b", b"aa\xffb", b"aa\xc3\xa9c", True),                    # (`.` takes ONE byte)
+             (r"(?:[^x]+y)+z", b"ayz", b"\xc3\xa9yz", True),                      # (a class ends at 127)
+             (r"(\w+\s+)+(?:end\b|fin)!", b"go to fin!", b"go to end!", False))
+    for pat, hit, miss, high in cases:
+        o = E.Compiled(pat)
+        assert o.thompson is not None, pat
+        hp = HostProgram(pat)
+        c = Compiled(pat).to(0)
+        assert hp.ref_match(hit) == 1 and hp.ref_match(miss) == 0, pat
+        alphabet = np.frombuffer(b"ab xyz\n" + (b"\xc3\xa9" if high else b"cd"), dtype=np.uint8)
+        for size in (100_000, 3_000_001, 48 << 20):
+            base = alphabet[rng.integers(0, len(alphabet), size=size)]
+            # near misses sprinkled in
+            for pos in rng.integers(0, size - 64, size=size // 5000):
+                base[pos:pos + len(miss)] = np.frombuffer(miss, dtype=np.uint8)
+            want0 = hp.ref_match(base.tobytes())
+            t = torch.from_numpy(base).cuda()
+            assert c.MatchBytes(t) == bool(want0), (pat, size, "random text")
+            for where in (size - len(hit), 0, (size // 2) & ~255, ((size // 2) & ~255) - 2, 7):
+                b2 = base.copy()
+                b2[where:where + len(hit)] = np.frombuffer(hit, dtype=np.uint8)
+                want = hp.ref_match(b2.tobytes())
+                assert want == 1
+                assert c.MatchBytes(torch.from_numpy(b2).cuda()) is True, (pat, size, where)
+        # (programs that are interpreted on every text; the others answer an ASCII text through the scan kernels, which refuse a text that
+        # keeps a match pending for megabytes)
+        for fill in (() if high else (b"a", b"\n", b"ab")):
+            mono = np.frombuffer(fill * (8_000_000 // len(fill)), dtype=np.uint8).copy()
+            assert c.MatchBytes(torch.from_numpy(mono).cuda()) == bool(hp.ref_match(mono.tobytes())), (pat, fill)
+            mono[-len(hit):] = np.frombuffer(hit, dtype=np.uint8)
+            assert c.MatchBytes(torch.from_numpy(mono).cuda()) == bool(hp.ref_match(mono.tobytes())), (pat, fill, "hit at the end")
+    # the host entry point takes such a text too (it used to refuse beyond 16 MiB before the copy)
+    c = Compiled(cases[0][0]).to(0)
+    big = b"aa x " * ((20 << 20) // 5 + 1)
+    assert c.MatchBytes(big) is False and c.MatchBytes(big + b"aa y") is True
