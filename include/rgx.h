@@ -106,7 +106,8 @@ typedef struct rgx_info {
   int32_t ref_match_engine; /* what the reference would emit: 0 backtracking, 1 thompson, 2 memo.  (The emitted Thompson matcher's
                              * threads stop at empty-width instructions -- ^, \b, (?m)$ -- analysis.go:492-497, and it steps over
                              * BYTES -- a class ends at 127, `.` takes one byte: where that is not plain existence the library
-                             * interprets the emitted function itself, csrc/rgx_thompson.h; a single text up to 16 MiB) */
+                             * interprets the emitted function itself, csrc/rgx_thompson.h; one long text: in parallel for unanchored programs,
+                             * up to 16 MiB for anchored ones) */
   int32_t ref_find_engine;  /* the capture engine the reference emits (compiler.go:137-153): 0 backtracking, 1 Tagged DFA (captures +
                              * nested quantifiers and the construction of tdfa.go:111-290 stays under 500 states: ref_tdfa_states),
                              * 2 memoising backtracker ("TNFA", compiler.go:415-426: the TDFA could not be built), -1 none (no
