@@ -141,7 +141,7 @@ def load_traffic(name, kernel=None):
     runs of their own, FETCH_SIZE and WRITE_SIZE in separate passes, corrected as MI355X_MICROARCH.md prescribes).  Counters need the
     profiler, so this run cannot measure them itself: it cites the file and the run id the file carries -- the newest round's, and only
     a file that measured the kernel this run launches (`kernel`: a substring of its name).  (traffic, source) or (None, None)."""
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         pj = os.path.join(ROOT, "profiles", "%s_pmc_%s.json" % (rnd, name))
         if os.path.exists(pj):
             try:
