@@ -460,6 +460,8 @@ int64_t TdfaChainDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* 
 // duplicates included.  Bounded: the tiles' maps (tiles x entries x 8 bytes) within kQ11MapBytes -- a text whose longest match is
 // kilobytes long AND that is hundreds of MiB long is refused.  Returns the rows of the loop (written: min(that, cap_records)).
 constexpr int64_t kQ11MapBytes = int64_t(2) << 30;
+constexpr int kQ11CheckWorkFrom = 1024;            // (matches this long: the map pass's work is bounded before it is queued)
+constexpr double kQ11MaxSteps = 1.0e11;           // chase steps of the map pass (~a tenth of a second of the device)
 int64_t TdfaFindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t* d_buf, size_t len, int64_t n, int32_t* d_rows, size_t cap_records,
                           bool count_only, rgx_result* res) {
   const TdfaDev& D = *p->p.dev.tdfa;
@@ -546,6 +548,22 @@ int64_t TdfaFindAllDevice(const rgx_program* p, rgx_stream_ctx* c, const uint8_t
       SetError("Tagged-DFA FindAll: a match of " + std::to_string(h[1]) + " bytes in a text of " + std::to_string(len) +
                " -- the tables of the wrapper's chase would take more than 2 GiB; keep the Go path for this text");
       return RGX_E_UNSUPPORTED;
+    }
+    if (E > kQ11CheckWorkFrom) {
+      // ... and the TIME: a lane of the map pass (tiles x E of them) steps once per accepting offset of its tile at most, so E x the
+      // text's accepting offsets bounds the pass -- long matches among millions of short ones would keep it busy for minutes (counted
+      // only when a match is long: the usual text's E is tens of bytes)
+      unsigned long long* d_acc = (unsigned long long*)(base + o_misc + 4);
+      unsigned long long h_acc = 0;
+      HIP_TRY(hipMemsetAsync(d_acc, 0, 8, c->stream));
+      HIP_TRY(LaunchTdfaQ11Accepting(accmask, ilen, d_acc, c->stream));
+      HIP_TRY(hipMemcpyAsync(&h_acc, d_acc, 8, hipMemcpyDeviceToHost, c->stream));
+      HIP_TRY(hipStreamSynchronize(c->stream));
+      if ((double)h_acc * (double)E > kQ11MaxSteps) {
+        SetError("Tagged-DFA FindAll: a match of " + std::to_string(h[1]) + " bytes among " + std::to_string(h_acc) + " accepting offsets -- the wrapper's chase would take " +
+                 std::to_string((double)h_acc * (double)E) + " steps on the device; keep the Go path for this text");
+        return RGX_E_UNSUPPORTED;
+      }
     }
     const int64_t ng = TdfaQ11Groups(ilen), gmaps = ng * E;
     const int64_t q_exit = 0, q_cnt = q_exit + r4(nmaps), q_ent = q_cnt + r4(nmaps), q_base = q_ent + r4(nt), q_gexit = q_base + r4(2 * nt),
@@ -1194,11 +1212,11 @@ RGX_API int rgx_program_info(const rgx_program* p, rgx_info* o) {
     const bool have_rm = !t.rm_depth[0].empty() && !t.rm_depth[1].empty();
     o->ref_find_offered = ((have_rm && !t.ref_memo && t.ref_find_engine <= 0) || HasRefTdfa(t) || HasRefMemo(t)) ? 1 : 0;
     bool thom_ok = true;                             // (the emitted Thompson matcher interpreted: rgx_thompson.h)
-    if (t.ref_match_engine == 3) {
+    if (t.ref_match_engine == 3 || t.ref_match_engine == 4) {      // (4: interpreted on texts with a byte >= 0x80 -- not offered if that cannot be)
       ThomHost th;
       try { thom_ok = BuildThompson(Compile(Simplify(Parse(t.pattern, kPerl))), &th); } catch (...) { thom_ok = false; }
     }
-    o->ref_match_offered = t.ref_match_engine == 3 ? (thom_ok ? 1 : 0) : ((t.ref_match_engine == 1 || t.ref_match_engine == 4 || (have_rm && !t.ref_memo && !t.ref_has_fail) || ((t.ref_memo || t.ref_has_fail) && t.ref_memo_interp)) ? 1 : 0);
+    o->ref_match_offered = (t.ref_match_engine == 3 || t.ref_match_engine == 4) ? (thom_ok ? 1 : 0) : ((t.ref_match_engine == 1 || (have_rm && !t.ref_memo && !t.ref_has_fail) || ((t.ref_memo || t.ref_has_fail) && t.ref_memo_interp)) ? 1 : 0);
     const bool stdlib = (t.flags & RGX_FLAG_STDLIB_SEMANTICS) != 0;
     if (stdlib) o->ref_find_offered = o->ref_match_offered = 1;       // nothing of the reference's to reproduce: every entry point answers
     o->ref_findall_offered = (stdlib || RefFindAllOffered(t)) ? 1 : (RefTdfaFindAllOffered(t) ? 2 : 0);      // 2: whole texts on one device only (the Tagged DFA's wrapper), rgx.h

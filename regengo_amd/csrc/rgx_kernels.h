@@ -300,6 +300,8 @@ hipError_t LaunchTdfaTags(const TdfaDev& D, const uint8_t* buf, int32_t len, con
 int64_t TdfaQ11Tiles(int32_t len);
 int TdfaQ11TileBytes();
 size_t TdfaQ11ScanTempBytes(int64_t nslices);
+// *out (zeroed by the caller) += the accepting offsets of the text (the bits of accmask)
+hipError_t LaunchTdfaQ11Accepting(const unsigned long long* accmask, int32_t len, unsigned long long* out, hipStream_t stream);
 hipError_t LaunchTdfaQ11Index(const int32_t* ends, int32_t len, unsigned long long* accmask, int* rev, unsigned* hmax, void* temp, size_t temp_bytes,
                               hipStream_t stream, bool have_mask = false);
 int64_t TdfaQ11Groups(int32_t len);

@@ -163,8 +163,16 @@ __global__ __launch_bounds__(256) void rows_to_offsets_kernel(const int32_t* row
   const int2 se = *reinterpret_cast<const int2*>(rows + i * ncap);
   const unsigned long long start = (unsigned long long)(base + se.x);
   const unsigned long long mlen = (unsigned long long)(se.y - se.x);
-  if ((start >> 40) != 0 || (mlen >> 24) != 0) atomicOr(bad, 1u);
-  out[i] = (start & ((1ull << 40) - 1ull)) | (mlen << 40);
+  unsigned long long w = (start & ((1ull << 40) - 1ull)) | (mlen << 40);
+  // (a row that does not fit becomes the word of all ones -- which no row that fits may be, so that word is refused as well: the rank that
+  // RECEIVES the table sees it too, offsets_any_bad_kernel)
+  if ((start >> 40) != 0 || (mlen >> 24) != 0 || w == ~0ull) { atomicOr(bad, 1u); w = ~0ull; }
+  out[i] = w;
+}
+__global__ __launch_bounds__(256) void offsets_any_bad_kernel(const unsigned long long* words, long long n, unsigned* bad) {
+  const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+  const bool hit = i < n && words[i] == ~0ull;
+  if (__builtin_amdgcn_ballot_w64(hit) != 0ull && (threadIdx.x & 63) == 0) atomicOr(bad, 1u);
 }
 __global__ __launch_bounds__(256) void rows_rebase32_kernel(int32_t* rows, long long nvals, int ncap, int32_t base, int minus1) {
   const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -873,6 +881,18 @@ static int64_t GatherImpl(rgx_sharded* s, int dst_rank, int64_t* d_dst, int64_t*
     SetError("gather across processes needs the RCCL communicator");
     return RGX_E_UNSUPPORTED;
   }
+  if (compact && R && dst && total > 0 && (int)s->local.size() < world) {
+    // rows of other PROCESSES arrived: one of them did not fit its word iff the table holds the word of all ones (the rank
+    // that owns such a row returns RGX_E_TOO_LARGE by itself -- the rank that receives the table has to as well)
+    HIP_TRY(hipSetDevice(dst->device));
+    int rc = EnsureGlob(dst, 1);
+    if (rc != RGX_OK) return rc;
+    unsigned* const bad = reinterpret_cast<unsigned*>(dst->d_glob + dst->glob_cap - 1);
+    if (s->last[(size_t)dst->rank].count == 0) HIP_TRY(hipMemsetAsync(bad, 0, 4, dst->cstream));      // (else: the conversion above zeroed it and may have raised it)
+    hipLaunchKernelGGL(offsets_any_bad_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, dst->cstream, (const unsigned long long*)table,
+                       (long long)total, bad);
+    HIP_TRY(hipMemcpyAsync(&dst->h_bad, bad, 4, hipMemcpyDeviceToHost, dst->cstream));
+  }
   if (dst && h_dst && total > 0) {
     HIP_TRY(hipSetDevice(dst->device));
     HIP_TRY(hipMemcpyAsync(h_dst, table, (size_t)(total * ncap) * 8, hipMemcpyDeviceToHost, dst->cstream));
@@ -881,7 +901,7 @@ static int64_t GatherImpl(rgx_sharded* s, int dst_rank, int64_t* d_dst, int64_t*
   if (d_rows) *d_rows = dst ? (const int64_t*)table : nullptr;
   if (compact)
     for (Shard* sh : s->local)
-      if (sh->h_bad) { sh->h_bad = 0; SetError("gather of offsets: a start beyond 2^40 or a match of 2^24 bytes or more -- use rgx_sharded_gather"); return RGX_E_TOO_LARGE; }
+      if (sh->h_bad) { sh->h_bad = 0; SetError("gather of offsets: a start beyond 2^40 or a match of 2^24 bytes or more (on this rank or in the rows it received) -- use rgx_sharded_gather"); return RGX_E_TOO_LARGE; }
   if (too_small) { SetError("gather: capacity too small (the table is in the library's buffer, *d_rows)"); return RGX_E_CAPACITY; }
   return dst ? total : 0;
 }

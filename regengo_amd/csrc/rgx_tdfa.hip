@@ -1330,6 +1330,23 @@ hipError_t LaunchTdfaQ11Index(const int32_t* ends, int32_t len, unsigned long lo
   hipcub::TransformInputIterator<int, Q11NzIdx, hipcub::CountingInputIterator<long long>> in(cnt, Q11NzIdx{accmask, ns});
   return hipcub::DeviceScan::InclusiveScan(temp, temp_bytes, in, rev, hipcub::Min(), (int)ns, stream);
 }
+// the accepting offsets of the text (accmask's bits): a lane of q11_map_kernel steps at most once per accepting offset of its tile, so
+// E times this bounds the chase's work (the host refuses a text whose maps would take minutes: ADVICE r5)
+__global__ __launch_bounds__(256) void q11_popcount_kernel(const unsigned long long* accmask, long long ns, unsigned long long* out) {
+  __shared__ unsigned long long s_sum[4];
+  unsigned long long v = 0;
+  for (long long k = (long long)blockIdx.x * 256 + threadIdx.x; k < ns; k += (long long)gridDim.x * 256) v += (unsigned long long)__builtin_popcountll(accmask[k]);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += (unsigned long long)__shfl_xor((long long)v, o);
+  if ((threadIdx.x & 63) == 0) s_sum[threadIdx.x >> 6] = v;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, s_sum[0] + s_sum[1] + s_sum[2] + s_sum[3]);
+}
+hipError_t LaunchTdfaQ11Accepting(const unsigned long long* accmask, int32_t len, unsigned long long* out, hipStream_t stream) {
+  const int64_t ns = TdfaSlices(len);
+  hipLaunchKernelGGL(q11_popcount_kernel, dim3((unsigned)std::min<int64_t>((ns + 255) / 256, 1024)), dim3(256), 0, stream, accmask, (long long)ns, out);
+  return hipGetLastError();
+}
 int64_t TdfaQ11Groups(int32_t len) { return (TdfaQ11Tiles(len) + kQ11Group - 1) / kQ11Group; }
 // fexit / fcnt: tiles x E; gexit / gcnt: groups x E; tent / tbase: tiles; gent / gbase: groups
 hipError_t LaunchTdfaQ11Chain(const int32_t* ends, int32_t len, const unsigned long long* accmask, const int* rev, int E, int32_t* fexit, int32_t* fcnt,

@@ -118,6 +118,19 @@ def main():
         # ---- count only
         total, rs = s.round([win(rank)], count_only=True)
         res["count_only"] = [r["count"] for r in rs]
+        # ---- the compact gather of a round in which the MIDDLE rank's window lies beyond 2^40 in its stream: its starts do not fit the
+        # 40 bits of a word -- the rank that owns them AND the rank that receives the table must say so
+        far = win(rank)
+        if rank == mid:
+            far["base"] = (1 << 40) + 4096
+        total, rs = s.round([far])
+        try:
+            s.gather_offsets(0)
+            res["offsets_overflow"] = 0
+        except _capi.RgxError as ex:
+            res["offsets_overflow"] = ex.status
+        n = s.gather(0)                               # (the full records take any offset)
+        res["far_gather_rows"] = n
         # ---- the reference's FindReader across the ranks: windows that are RUNS OF CHUNKS (rgx_shard_window::reader_buffer_size), chunk
         # ranges dealt round-robin -- no halo; rows gathered to the last rank in stream order
         cfg = c._resolve(Config(*READER_CFG))

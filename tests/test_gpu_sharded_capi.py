@@ -313,6 +313,9 @@ def test_multi_process_world(gpu, tmp_path, world):
             assert res["stop_seen"] == [r == mid for r in range(world)]
             assert res["after_fail_counts"] == per, (name, rk, res["after_fail_counts"], per, res["after_fail_flags"])
             assert res["after_fail_total"] == sum(per) and res["count_only"] == per
+            # starts beyond 2^40 on the middle rank: RGX_E_TOO_LARGE (-4) there and on rank 0, which receives the words; the records go through
+            assert res["offsets_overflow"] == (-4 if rk in (0, mid) and per[mid] > 0 else 0), (name, rk, res["offsets_overflow"])
+            assert res["far_gather_rows"] == (sum(per) if rk == 0 else 0), (name, rk, res["far_gather_rows"])
         # ---- the reader rounds: the reference's FindReader callbacks over the whole stream, in stream order on the last rank
         from oracle.gen_c import CMatcher
         B, ML = ranks[0][name]["reader_cfg"]

@@ -461,3 +461,32 @@ def test_tdfa_findall_wrapper_over_many_tiles(built):
     with pytest.raises(_capi.RgxError) as ei:
         c.FindAllSpans(log.tobytes(), capacity=100)
     assert ei.value.status == _capi.RGX_E_CAPACITY
+
+
+@pytest.mark.gpu
+def test_tdfa_findall_wrapper_bounds_its_work(built):
+    """the wrapper's map pass launches tiles x E lanes (E = the longest match, up to a tile) and a lane steps once per accepting
+    offset of its tile -- a 16 KiB match among tens of millions of one-byte matches would keep the device busy for minutes.  The work is
+    bounded before the pass is queued (E x the text's accepting offsets): a text of that shape is refused, a smaller one of the same shape
+    is answered, rows == the C port of the emitted code."""
+    import numpy as np
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU; there is no CPU fallback")
+    from oracle.tdfa_c import CTdfa
+    from regengo_amd import Compiled, _capi
+    pat = r"(?P<w>(?:a+)+|b)"
+    c = Compiled(pat).to(0)
+    if c.info.ref_findall_offered != 2:
+        pytest.skip("not a Tagged-DFA program with the FindAll wrapper")
+    o = CTdfa(pat)
+    small = np.full(400_000, ord("b"), dtype=np.uint8)
+    small[100_000:100_000 + 3000] = ord("a")
+    exp = o.find_all_np(small)
+    rows, res = c.FindAllSpans(small.tobytes(), capacity=len(exp) + 8)
+    assert res.total == len(exp) and np.array_equal(rows.cpu().numpy(), exp)
+    big = torch.full((96 << 20,), ord("b"), dtype=torch.uint8, device="cuda")
+    big[1_000_000:1_000_000 + 16384] = ord("a")
+    with pytest.raises(_capi.RgxError) as ei:
+        c.CountAll(big)
+    assert ei.value.status == _capi.RGX_E_UNSUPPORTED and "chase" in str(ei.value)
