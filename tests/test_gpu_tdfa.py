@@ -475,7 +475,7 @@ def test_tdfa_findall_wrapper_bounds_its_work(built):
         pytest.fail("GPU tests need a GPU; there is no CPU fallback")
     from oracle.tdfa_c import CTdfa
     from regengo_amd import Compiled, _capi
-    pat = r"(?P<w>(?:a+)+|b)"
+    pat = r"(?P<p>(?:a+c?)+|b)"
     c = Compiled(pat).to(0)
     if c.info.ref_findall_offered != 2:
         pytest.skip("not a Tagged-DFA program with the FindAll wrapper")
