@@ -516,9 +516,9 @@ hipError_t LaunchBatchTiny(const DevTables& U, const DevTables& F, const uint8_t
     const void* fn = per_wave ? (replay ? (const void*)batch_tiny_kernel<N, true> : (const void*)batch_tiny_kernel<N, false>)           \
                    : level > 0 ? (replay ? RGX_TINY_FN(N, true, true) : RGX_TINY_FN(N, false, true))                                    \
                                : (replay ? RGX_TINY_FN(N, true, false) : RGX_TINY_FN(N, false, false));                                 \
+    if (lds > 64 * 1024) { const hipError_t e = AllowBigLds(fn); if (e != hipSuccess) return e; }   /* (cached per device) */           \
     int per_cu = per_cu_of[N][replay ? 1 : 0][level].load(std::memory_order_relaxed);                                                   \
     if (per_cu == 0) {                                                                                                                  \
-      if (lds > 64 * 1024) { const hipError_t e = AllowBigLds(fn); if (e != hipSuccess) return e; }                                     \
       if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, fn, kBlockThreads, lds) != hipSuccess || per_cu < 1) per_cu = level > 0 ? 2 : 4; \
       per_cu_of[N][replay ? 1 : 0][level].store(per_cu, std::memory_order_relaxed);                                                     \
     }                                                                                                                                   \
