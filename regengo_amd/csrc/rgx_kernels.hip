@@ -2147,7 +2147,7 @@ __host__ __device__ inline SearchLayout SearchLdsLayout(const DevTables& U, int 
   }
   L.window = take(window_bytes + 64);        // four waves' quarters, 16 bytes of slack behind each
   if (want_spans) {
-    L.trace = take(kBlockThreads * kBatchTrace * trace_entry_bytes);
+    L.trace = take(kBlockThreads * (kBatchTrace + 1) * trace_entry_bytes);      // row 0 + the ring (batch_search_kernel)
     L.recs = take(kBlockThreads * ncap * 4);
   }
   L.total = o;
@@ -2282,12 +2282,22 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
     BatchInput in;
     in.g = concat + o0; in.lds = wwin; in.rel0 = (int)min(o0 - wb, (uint64_t)0x3FFFFFFF); in.wvalid = wvalid; in.len = (int)(o1 - o0);
     int end = -1;
+    bool redo = false;                     // (RING: the back-trace left the rows the ring still holds -- the lane takes the trace in memory)
     // The walk and the back-trace, generic in where the state trace and the back-trace tables live (LDS-qualified or global
     // pointers: a pointer that may be either is a FLAT access).  trace entry k at trb[k * ts]: interleaved across the workgroup in
     // LDS (conflict-free rows), contiguous in the global fallback.
-    auto process = [&](auto trb, const int ts, const auto& B, const auto& inp) {
-      auto tr = [&](int k) -> decltype(trb[0])& { return trb[k * ts]; };
-      if (i < nstr) {
+    // RING (round 6): the LDS trace is a RING of kBatchTrace rows behind row 0 -- position p >= 1 lives in row ((p - 1) & 63) + 1, the
+    // state at position 0 in row 0 for good.  A string of any length walks with its trace on chip; the back-trace needs the rows
+    // between the match's start and the walk's last byte only, and finds them there unless that stretch is longer than the ring (a
+    // match of more than ~60 bytes, or a walk that runs on far behind the match: `redo`).  Strings that fit a plain row of their
+    // own never wrap: the same rows as before.  [Until round 6 a string beyond 62 bytes -- a log line -- wrote its trace to memory, a
+    // byte store per step and lane: 2 M lines of U[8,200] bytes took 1.4-2.05 ms where short strings of the same volume take 0.55.]
+    auto process = [&](auto trb, const int ts, const auto& B, const auto& inp, const bool act, auto ring_tag) {
+      constexpr bool RING = decltype(ring_tag)::value;
+      constexpr int kRingMask = kBatchTrace - 1;
+      auto tr = [&](int k) -> decltype(trb[0])& { return trb[(RING ? (k > 0 ? ((k - 1) & kRingMask) + 1 : 0) : k) * ts]; };
+      int wl = 0;                          // the last position whose state was written
+      if (act) {
         // ---- one forward walk; trace[k] = state after k bytes (only kept when spans are wanted)
         unsigned q = q0;
         end = end0;
@@ -2309,6 +2319,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
           while (at + 4 <= len && q != kDead) {
             const unsigned b4 = __builtin_amdgcn_alignbyte(hi, lo, sh);
             lo = hi; hi = w32[(at >> 2) + 2];
+            const int rb = RING ? (at & kRingMask) : at;        // (a trip begins at a multiple of four: its four rows do not wrap)
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
               const unsigned c = (b4 >> (8 * k)) & 255u;
@@ -2316,7 +2327,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
               if (look && (ed & kMatchBefore)) end = at + k;
               if (ed & kMatchAfter) end = at + k + 1;
               q = ed & kStateMask;
-              tr(at + k + 1) = (TraceT)q;
+              trb[(rb + k + 1) * ts] = (TraceT)q;
             }
             at += 4;
           }
@@ -2336,6 +2347,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
               if (ed & kMatchAfter) end = len + 1;
             }
           }
+          wl = at;
         } else
         for (int at = 0;; ++at) {
           const bool eot = at >= inp.len;
@@ -2344,16 +2356,19 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
           if (ed & kMatchAfter) end = at + 1;
           q = ed & kStateMask;
           if (q == kDead || eot) break;
-          if (want_spans) tr(at + 1) = (TraceT)q;
+          if (want_spans) { tr(at + 1) = (TraceT)q; wl = at + 1; }
           else if (end >= 0) break;       // MatchBytes: any match will do
         }
         found[i] = end >= 0;
       }
       if (!want_spans) return;
       int32_t* rec = recs + tid * ncap;
-      if (i < nstr) {
+      if (act) {
         for (int c = 0; c < ncap; ++c) rec[c] = unset;
-        if (end >= 0 && !(exp_skip & 1)) {
+        // (RING: the rows of positions below lowv have been written over -- position 0 has a row of its own)
+        const int lowv = RING ? wl - kRingMask : 0;
+        if (RING && end >= 0 && end > 0 && end < lowv) redo = true;
+        else if (end >= 0 && !(exp_skip & 1)) {
           // ---- back-trace from the winning thread at `end` until it passes Capture 0 (the match start)
           unsigned setmask = 2u;
           rec[1] = end;
@@ -2366,7 +2381,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
             while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = pos; setmask |= 1u << c; }
           };
           auto back = [&](int p, const int add) {
-            while (p >= 3 && !(setmask & 1u)) {
+            while (p >= 3 && p - 3 >= lowv && !(setmask & 1u)) {
               const unsigned t0 = tr(p), t1 = tr(p - 1), t2 = tr(p - 2), t3 = tr(p - 3);
               const unsigned c0 = tab.cls[inp.At(p)], c1 = tab.cls[inp.At(p - 1)], c2 = tab.cls[inp.At(p - 2)], c3 = tab.cls[inp.At(p - 3)];
               const unsigned b0 = B.bt_base[t0 * stride + c0], b1 = B.bt_base[t1 * stride + c1];
@@ -2377,8 +2392,10 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
               if (!(setmask & 1u)) back_step(b3, p - 3 + add);
               p -= 4;
             }
-            for (; p >= 0 && !(setmask & 1u); --p)
+            for (; p >= 0 && !(setmask & 1u); --p) {
+              if (RING && p > 0 && p < lowv) { redo = true; break; }
               back_step(B.bt_base[(unsigned)tr(p) * stride + tab.cls[inp.At(p)]], p + add);
+            }
           };
           if (U.lookahead) {
             const unsigned qe = tr(end);
@@ -2391,7 +2408,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
           } else {
             j = (int)B.st_nthreads[tr(end)] - 1;
             back(end - 1, 1);
-            if (!(setmask & 1u)) {
+            if (!(setmask & 1u) && !redo) {
               unsigned o = B.start_ops_pool[B.start_ops[kCtxBOT] + j] & ~setmask;
               while (o) { const int c = __builtin_ctz(o); o &= o - 1; rec[c] = 0; setmask |= 1u << c; }
             }
@@ -2400,7 +2417,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
             const int s = rec[0];
             for (int c = 2; c < ncap; ++c) rec[c] = F.cap_kind[c] == kCapFromStart ? s + F.cap_delta[c] : end - F.cap_delta[c];
           }
-          if (ref && !F.anchored && !(exp_skip & 2)) {
+          if (ref && !F.anchored && !(exp_skip & 2) && !redo) {
             const int s0 = rec[0];
             int off = 0;
             bool lost = false;
@@ -2439,23 +2456,27 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
     };
     {
       typedef TraceT __attribute__((address_space(3)))* LdsTrace;
-      const bool short_str = in.len + 2 <= kBatchTrace;
-      // the ordinary group -- every string short, every byte of the group inside the staged window: the bytes come from LDS
+      // the ordinary group -- every byte of the group inside the staged window: the bytes come from LDS
       // without the "or from global memory" select of BatchInput::At (a FLAT load per byte otherwise: 1.32 -> 1.15 ms on C3)
       const bool all_lds = (ge - wb) <= (uint64_t)wvalid && !(exp_skip & 4);      // uniform
-      if (!want_spans) process((TraceT*)nullptr, 1, BG, in);
-      else if (short_str) {
+      const bool act = i < nstr;
+      typedef std::integral_constant<bool, true> Ring;
+      typedef std::integral_constant<bool, false> NoRing;
+      if (!want_spans) process((TraceT*)nullptr, 1, BG, in, act, NoRing{});
+      else {
         LdsTrace t = (LdsTrace)(smem + Y.trace) + tid;
         if (Y.bt_in_lds) {
           if (all_lds) {
             BatchInputLds il;
             il.lds = (Lds8)wwin + in.rel0; il.len = in.len;
-            process(t, (int)kBlockThreads, BL, il);
-          } else process(t, (int)kBlockThreads, BL, in);
-        } else process(t, (int)kBlockThreads, BG, in);
-      } else {
-        TraceT* t = gtrace + o0 + 2 * i;
-        if (Y.bt_in_lds) process(t, 1, BL, in); else process(t, 1, BG, in);
+            process(t, (int)kBlockThreads, BL, il, act, Ring{});
+          } else process(t, (int)kBlockThreads, BL, in, act, Ring{});
+        } else process(t, (int)kBlockThreads, BG, in, act, Ring{});
+        if (__any(redo)) {                  // (rare: a match, or the walk behind it, longer than the ring -- the trace in memory, those lanes alone)
+          TraceT* tg = gtrace + o0 + 2 * i;
+          const bool again = redo;
+          if (Y.bt_in_lds) process(tg, 1, BL, in, again, NoRing{}); else process(tg, 1, BG, in, again, NoRing{});
+        }
       }
     }
     if (!want_spans) continue;
@@ -3269,7 +3290,10 @@ static int SearchRmBytes(const DevTables& F, bool ref) {
 int BatchWindowFor(int64_t total_bytes, int64_t nstr) {
   // a group of 256 strings should fit the window; short strings get the small window (one more workgroup per CU)
   if (nstr <= 0 || total_bytes < 0) return kBatchWindow;
-  return (total_bytes / nstr) * kBlockThreads <= 7168 ? 8192 : kBatchWindow;
+  const int64_t group = (total_bytes / nstr) * kBlockThreads;
+  // (lines of ~60 bytes and more: 32 KiB, lines of ~120 and more: 64 KiB -- LaunchBatchSearch steps down again where the program's tables
+  // leave no room; a wave whose 64 strings do not fit its quarter reads them through the "LDS or memory" select)
+  return group <= 7168 ? 8192 : group <= 15360 ? kBatchWindow : group <= 30720 ? 2 * kBatchWindow : 4 * kBatchWindow;
 }
 
 hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8_t* concat, const uint64_t* offsets, int64_t nstr,
@@ -3278,10 +3302,12 @@ hipError_t LaunchBatchSearch(const DevTables& U, const DevTables& F, const uint8
   if (nstr <= 0) return hipSuccess;
   if (window_bytes <= 0) window_bytes = kBatchWindow;
   const bool t8 = U.nstates <= 256;
-  const SearchLayout Y = SearchLdsLayout(U, F.ncap, spans != nullptr, t8 ? 1 : 2, window_bytes);
   if (!spans) ref = 0;
   if (ExpEnv("RGX_C3_SKIP")) ref |= atoi(ExpEnv("RGX_C3_SKIP")) << 8;
   const int rm_bytes = SearchRmBytes(F, (ref & 1) != 0);
+  // (a window beyond the default one only where two workgroups still fit a CU)
+  while (window_bytes > kBatchWindow && SearchLdsLayout(U, F.ncap, spans != nullptr, t8 ? 1 : 2, window_bytes).total + rm_bytes + 1024 > 80 * 1024) window_bytes >>= 1;
+  const SearchLayout Y = SearchLdsLayout(U, F.ncap, spans != nullptr, t8 ? 1 : 2, window_bytes);
   const int cus = DeviceCus();
   const int64_t ngroups = (nstr + kBlockThreads - 1) / kBlockThreads;
   int per_cu = (160 * 1024) / (Y.total + rm_bytes + 1024);
