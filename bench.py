@@ -672,21 +672,22 @@ def run_c3(env, args):
                                   "batch_tiny_kernel + ref_fix_list_kernel (the call: one lock-step pass per string in registers -- search automaton columns, v_perm tag registers for the groups, the reference's attempt offsets riding along; strings it flags replayed from its list.  Groups holding a string beyond 56 bytes would go to batch_search_kernel: none here; `long_lines`: the wide instances)", "kernel_ms": round(k_ms, 4),
                         "algorithmic_bytes_per_launch": alg, "timed_launches": len(kms),
                         "note": "event-bracketed call: includes the launch of the call's kernels"}
-    if not args.force_tdfa and env.rank == 0:
-        line["long_lines"] = c3_long_lines(env)
+    if env.rank == 0:
+        line["long_lines"] = c3_long_lines(env, force_tdfa=bool(args.force_tdfa))
     if not args.no_cpu_baseline and env.world == 1:
         line["cpu_baseline"] = cpu_baseline_batch(EMAIL, data, offsets, force_tdfa=bool(args.force_tdfa))
     return line
 
 
-def c3_long_lines(env, nstr=2_000_000, lo=8, hi=200):
+def c3_long_lines(env, nstr=2_000_000, lo=8, hi=200, force_tdfa=False):
     """The same call over lines of U[8,200] bytes (what log lines look like; C3's strings are U[8,40]): the register kernel's wide
-    instances, which a program learns from its first batch (rgx_tuning.batch_tiny_level).  A program of its own -- C3's keeps its
-    level.  Rows of a sample against the oracle's C port."""
+    instances (--force-tdfa: the Tagged-DFA batch kernel's wide window), which a program learns from its first batch
+    (rgx_tuning.batch_tiny_level / batch_tdfa_wide).  A program of its own -- C3's keeps its level.  Rows of a sample against the
+    oracle's C port."""
     torch = env.torch
     import numpy as np
     from regengo_amd import Compiled, synth
-    c = Compiled(EMAIL, name="Email").to(env.local_rank)
+    c = Compiled(EMAIL, name="Email", force_tdfa=force_tdfa).to(env.local_rank)
     data, offsets = synth.email_batch_np(nstr, seed=0x5EED0303, lo=lo, hi=hi)
     concat, offs = torch.from_numpy(data).to(env.dev), torch.from_numpy(offsets).to(env.dev)
     out = (torch.empty(nstr, dtype=torch.uint8, device=env.dev), torch.empty((nstr, c.ncap), dtype=torch.int32, device=env.dev))
@@ -704,12 +705,13 @@ def c3_long_lines(env, nstr=2_000_000, lo=8, hi=200):
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) * 1e3 / reps
     sample = np.unique(np.random.default_rng(0xC31).integers(0, nstr, size=20000))
-    ok = oracle_sample_check(EMAIL, False, data, offsets, sample, found, spans)
+    ok = oracle_sample_check(EMAIL, force_tdfa, data, offsets, sample, found, spans)
     nbytes = int(offsets[-1])
     alg = nbytes + 8 * (nstr + 1) + nstr + nstr * c.ncap * 4
     return {"strings": nstr, "lengths": "U[%d,%d]" % (lo, hi), "bytes": nbytes, "ms_per_call": round(ms, 4), "GBps_input": round(nbytes / ms / 1e6, 1),
             "frac_of_hbm_peak_by_algorithmic_bytes": round(alg / ms / 1e6 / HBM_PEAK_GBS, 4), "first_call_ms_general_kernel": round(first_ms, 3),
-            "batch_tiny_level": c.tuning()["batch_tiny_level"], "parity_rows_vs_oracle_sample": bool(ok), "oracle_sample_strings": int(len(sample))}
+            "batch_tiny_level": c.tuning()["batch_tiny_level"], "batch_tdfa_wide": c.tuning()["batch_tdfa_wide"],
+            "parity_rows_vs_oracle_sample": bool(ok), "oracle_sample_strings": int(len(sample))}
 
 
 # ------------------------------------------------------------------------------------------------------------------- C4
@@ -1574,7 +1576,7 @@ def other_config_legs(budget_s):
             leg["value_with_reference_findall_everywhere"] = w.get("value_with_reference_findall_everywhere")
             leg["ms_with_reference_findall_everywhere"] = w.get("suite_ms_with_reference_findall_everywhere")
             leg["reference_findall_rows_equal_c_port_head"] = w.get("all_rows_equal_c_port_head")
-        if name == "c3" and isinstance(j.get("long_lines"), dict):
+        if name in ("c3", "c3_tdfa") and isinstance(j.get("long_lines"), dict):
             leg["long_lines"] = j["long_lines"]
         if name == "c4":
             leg["value_findall_semantics"] = j.get("value_findall_semantics", {}).get("value")

@@ -46,7 +46,7 @@ class Info(C.Structure):
 
 class Tuning(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("frozen", "scan_kernel_choice", "fc_us_per_gib", "other_us_per_gib", "fc_gave_up", "captures_long_rows",
-                                         "sync_automaton", "exact_sync_points", "rewinding_walk", "ascii_twin", "batch_tiny_level")] + [("reserved", C.c_int32 * 5)]
+                                         "sync_automaton", "exact_sync_points", "rewinding_walk", "ascii_twin", "batch_tiny_level", "batch_tdfa_wide")] + [("reserved", C.c_int32 * 4)]
 
 
 class ShardRange(C.Structure):

@@ -52,6 +52,7 @@ struct rgx_program {
   // shared handle: the first calls of a program LEARN which of its kernels suits its texts, a service that wants the same answer
   // time for every call warms the program up and freezes it)
   mutable std::atomic<int> frozen{0};
+  mutable std::atomic<int> tdfa_wide{0};    // rgx_find_batch_device, Tagged-DFA programs: the sorted kernel's 32 KiB window (lines) instead of 12 KiB
   mutable std::atomic<int> tiny_level{0};   // rgx_find_batch_device: the register kernel's instance (0: strings <= 56 bytes; 1, 2: <= 254, LDS windows of 34 / 64 KiB)
 };
 
@@ -1243,7 +1244,7 @@ RGX_API int rgx_program_tuning(const rgx_program* p, rgx_tuning* o) {
   o->frozen = p->frozen.load(); o->scan_kernel_choice = p->fc_pref.load(); o->fc_us_per_gib = p->fc_us_per_gib.load();
   o->other_us_per_gib = p->other_us_per_gib.load(); o->fc_gave_up = p->fc_bad.load(); o->captures_long_rows = p->caps_long.load();
   o->sync_automaton = p->prefer_w.load(); o->exact_sync_points = p->prefer_wsync.load(); o->rewinding_walk = p->prefer_rw.load();
-  o->ascii_twin = p->ascii_state.load(); o->batch_tiny_level = p->tiny_level.load();
+  o->ascii_twin = p->ascii_state.load(); o->batch_tiny_level = p->tiny_level.load(); o->batch_tdfa_wide = p->tdfa_wide.load();
   return RGX_OK;
 }
 RGX_API int64_t rgx_unicode_table(const char* name, int32_t* dst, size_t cap_pairs) {
@@ -2094,12 +2095,19 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
     // tags, (-1, -1) = "field left untouched" whatever RGX_FLAG_UNMATCHED_MINUS1 says
     if ((rc = Ensure(&c->d_tdfa, &c->tdfa_cap, 16)) != RGX_OK) return rc;
     uint32_t* flags = (uint32_t*)c->d_tdfa;
-    uint32_t h = 0;
-    HIP_TRY(hipMemsetAsync(flags, 0, 4, c->stream));
-    HIP_TRY(LaunchTdfaBatch(*T.tdfa, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, flags, c->stream));
-    HIP_TRY(hipMemcpyAsync(&h, flags, 4, hipMemcpyDeviceToHost, c->stream));
+    uint32_t h[3] = {0, 0, 0};
+    // (the sorted kernel's window: 12 KiB a group of 256 strings, or 32 KiB for lines -- learned from what the last batch looked like)
+    const int wide = p->tdfa_wide.load(std::memory_order_relaxed);
+    HIP_TRY(hipMemsetAsync(flags, 0, 12, c->stream));
+    HIP_TRY(LaunchTdfaBatch(*T.tdfa, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, flags, c->stream, wide));
+    HIP_TRY(hipMemcpyAsync(h, flags, 12, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
-    if (h & kTdfaOverBudget) { SetError("the Tagged DFA's attempts on a string of this batch are too long to finish: keep the CPU path for it"); return RGX_E_UNSUPPORTED; }
+    if (h[0] & kTdfaOverBudget) { SetError("the Tagged DFA's attempts on a string of this batch are too long to finish: keep the CPU path for it"); return RGX_E_UNSUPPORTED; }
+    if (!p->frozen.load(std::memory_order_relaxed)) {
+      // a quarter of the strings walked out of memory because their group was beyond the window: the wide one; every group within the narrow one: back
+      if (!wide && (int64_t)h[1] * 4 > (int64_t)nstr) p->tdfa_wide.store(1, std::memory_order_relaxed);
+      else if (wide && (int64_t)h[2] >= ((int64_t)nstr + 255) / 256) p->tdfa_wide.store(0, std::memory_order_relaxed);
+    }
     return (int64_t)nstr;
   }
   if (ref_mode && !T.ref_find_ok && RefMemoMode(p)) {

@@ -314,9 +314,11 @@ hipError_t LaunchTdfaQ11Emit(const int32_t* ends, int32_t len, const unsigned lo
 // before it, (0, 0) in front of the first (rgx_tdfa.hip has the why).  temp: TdfaFillTempBytes(n) bytes.
 size_t TdfaFillTempBytes(int64_t n);
 hipError_t LaunchTdfaFill(int32_t* rows, int64_t n, int ncap, void* temp, size_t temp_bytes, hipStream_t stream);
-// FindBytes per string of a batch: found[nstr], rows[nstr][ntags]
+// FindBytes per string of a batch: found[nstr], rows[nstr][ntags].  flags: three zeroed words -- [0] budget bits, [1] += strings that
+// left the sorted kernel's window (and were walked out of memory, slowly), [2] += groups of 256 strings the narrow window would hold;
+// wide: the 32 KiB window (lines of ~120 bytes) instead of the 12 KiB one
 hipError_t LaunchTdfaBatch(const TdfaDev& D, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found, int32_t* rows,
-                           uint32_t* flags, hipStream_t stream);
+                           uint32_t* flags, hipStream_t stream, int wide = 0);
 
 // One pass over a batch for many programs (rgx_kernels.hip: batch_multi_kernel).  d_dir: device array of MultiEnt (the host packs it:
 // rgx_capi.cc, rgx_multi_create) followed by first[256][2] u64 (bit p of first[b]: program p survives a first byte b), all of it

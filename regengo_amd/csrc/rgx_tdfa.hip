@@ -855,8 +855,9 @@ __global__ __launch_bounds__(256) void tdfa_batch_kernel(TdfaDev D, const uint8_
 // closest, the quarter rotating with the group; the next group's offsets and the first 8 KiB of its bytes wait in registers.  A string
 // that does not lie in the window whole, or is longer than the merged walk's 255 bytes, takes BatchOne from memory (rare: the flag in
 // its entry).  Only for programs with the merged automaton AND the packed tag table (every Tagged-DFA pattern of the corpus has both).
-constexpr int kTdfaSortedSlice = 256 * 48;       // bytes of a workgroup's 256 strings staged in LDS
-constexpr uint32_t kTsSlow = 1u << 30, kTsValid = 1u << 31;
+constexpr int kTdfaSortedSlice = 256 * 48;       // bytes of a workgroup's 256 strings staged in LDS: strings of ~45 bytes on average ...
+constexpr int kTdfaSortedSliceWide = 32768;      // ... and lines of ~120 (round 6: a program learns which from its batches, TdfaSortedWindow)
+constexpr uint32_t kTsSlow = 1u << 31;           // a sort entry: place in the window (15 bits) | length << 15 (8) | string << 23 (8) | slow
 
 __device__ __forceinline__ unsigned TdfaDppScanAdd(unsigned x) {
   x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
@@ -868,22 +869,25 @@ __device__ __forceinline__ unsigned TdfaDppScanAdd(unsigned x) {
   return x;
 }
 
-size_t TdfaSortedShared(const TdfaDev& D) {
-  return (size_t)(D.ntags + 1) * 256 * 4 + (size_t)(kTdfaSortedSlice + 32) + (128 + 16 + 256) * 4 + (size_t)D.m_nstates * D.m_ncls * 8 + 256 +
+size_t TdfaSortedShared(const TdfaDev& D, int wslice = kTdfaSortedSlice) {
+  return (size_t)(D.ntags + 1) * 256 * 4 + (size_t)(wslice + 32) + (128 + 16 + 256) * 4 + (size_t)D.m_nstates * D.m_ncls * 8 + 256 +
          (((size_t)D.pool_n * 2 + 15) & ~size_t(15)) + (((size_t)D.nstates * 4 + 15) & ~size_t(15)) + (size_t)D.nstates * D.m_ncls * 8 +
          (size_t)D.nstates * 4 + 16;
 }
 
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) void tdfa_batch_sorted_kernel(TdfaDev D, const uint8_t* concat, const uint64_t* offsets, long long nstr,
-                                                                uint8_t* found, int32_t* rows, uint32_t* flags) {
+                                                                uint8_t* found, int32_t* rows, uint32_t* flags, int wslice) {
   extern __shared__ uint32_t smem[];
   const int tid = threadIdx.x;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+  // flags[1] += the strings that took the slow path because their group did not fit the window (no longer than 255 bytes themselves),
+  // flags[2] += the groups the NARROW window would have held: what the host learns the window from
+  uint32_t nslow = 0, nfit = 0;
   // LDS: the tag columns (a column per lane, the scrap column of the packed tag walk behind them) | the window | the sort's counts
   // (two sets of 64, used in turn) and the order | the merged automaton, byte classes, action pool, accept words, packed tag table
   int TDFA_LDS* const tags = (int TDFA_LDS*)smem + tid;
   unsigned char* const win = reinterpret_cast<unsigned char*>(smem + (D.ntags + 1) * 256);
-  uint32_t* const hist = reinterpret_cast<uint32_t*>(win + kTdfaSortedSlice + 32);
+  uint32_t* const hist = reinterpret_cast<uint32_t*>(win + wslice + 32);
   uint32_t* const perm = hist + 128 + 16;
   unsigned char* const mreg = reinterpret_cast<unsigned char*>(perm + 256);
   const int m_bytes = D.m_nstates * D.m_ncls * 8;
@@ -927,11 +931,13 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     if (nv_) {                                                                                                                    \
       wb = (gb) & ~15ull;                                                                                                         \
       const uint64_t span_ = (((ge) - wb) + 15ull) & ~15ull;                                                                      \
-      wvalid = (int)(span_ < (uint64_t)kTdfaSortedSlice ? span_ : (uint64_t)kTdfaSortedSlice);                                    \
+      wvalid = (int)(span_ < (uint64_t)wslice ? span_ : (uint64_t)wslice);                                                        \
+      nfit += span_ <= (uint64_t)kTdfaSortedSlice ? 1u : 0u;                                                                      \
     }                                                                                                                             \
-    rel = (uint32_t)((a) - wb) & 16383u;                                                                                          \
+    rel = (uint32_t)((a) - wb) & 32767u;                                                                                          \
     len = tid < nv_ ? (int)((uint32_t)(b) - (uint32_t)(a)) : -2;                                                                  \
     if (tid < nv_ && (((b) - (a)) > 255ull || (b) - wb > (uint64_t)wvalid)) len = -1;                                             \
+    nslow += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(tid < nv_ && ((b) - (a)) <= 255ull && (b) - wb > (uint64_t)wvalid));  \
   } while (0)
 #define TDFA_PIECES(wb, wvalid)                                                                      \
   do {                                                                                               \
@@ -966,7 +972,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
       const uint32_t hv = h[lane];
       const uint32_t x = TdfaDppScanAdd(hv);
       const uint32_t start = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(bin << 2), (int)(x - hv));
-      perm[start + rank] = relc | ((uint32_t)(lenc < 0 ? 0 : lenc) << 14) | ((uint32_t)tid << 22) | (lenc == -1 ? kTsSlow : 0u) | (lenc != -2 ? kTsValid : 0u);
+      perm[start + rank] = relc | ((uint32_t)(lenc < 0 ? 0 : lenc) << 15) | ((uint32_t)tid << 23) | (lenc == -1 ? kTsSlow : 0u);
     }
     if (tid < 64) hist[(((it + 1) & 1) << 6) + tid] = 0;      // the next group's counts (last read a group ago)
     const long long i0 = grp * 256;
@@ -976,11 +982,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     TDFA_META(grp + 2 * G, an, bn, gbn, gen);
     __syncthreads();
     const uint32_t e = perm[(((uint32_t)wave + (uint32_t)it) & 3u) * 64u + (uint32_t)lane];
-    if (e & kTsValid) {
-      const long long i = i0 + (long long)((e >> 22) & 255u);
-      const int len = (int)((e >> 14) & 255u);
+    const long long i = i0 + (long long)((e >> 23) & 255u);
+    if (i < nstr) {
+      const int len = (int)((e >> 15) & 255u);
       if (!(e & kTsSlow)) {
-        const unsigned lb = win_at + (e & 16383u);
+        const unsigned lb = win_at + (e & 32767u);
         int bs, be;
         WalkMerged(ment_at, mcls_at, (unsigned)D.m_bot_row, lb, len, &bs, &be);
         found[i] = be >= 0 ? 1 : 0;
@@ -998,6 +1004,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
       }
     }
   }
+  if (lane == 0 && nslow) atomicAdd(flags + 1, nslow);
+  if (tid == 0 && nfit) atomicAdd(flags + 2, nfit);
 #undef TDFA_NV
 #undef TDFA_META
 #undef TDFA_WINDOW
@@ -1399,7 +1407,7 @@ hipError_t LaunchTdfaTags(const TdfaDev& D, const uint8_t* buf, int32_t len, con
 }
 
 hipError_t LaunchTdfaBatch(const TdfaDev& D, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found, int32_t* rows,
-                           uint32_t* flags, hipStream_t stream) {
+                           uint32_t* flags, hipStream_t stream, int wide) {
   if (nstr <= 0) return hipSuccess;
   int dev = 0, cus = 0;
   if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
@@ -1408,13 +1416,16 @@ hipError_t LaunchTdfaBatch(const TdfaDev& D, const uint8_t* concat, const uint64
   static const bool unsorted = ExpEnv("RGX_TDFA_UNSORTED") != nullptr;
   if (!unsorted && D.m_nstates > 0 && D.tag_packed != 0 && (((uintptr_t)concat) & 15) == 0 && nstr >= 256 &&
       TdfaSortedShared(D) <= 64 * 1024) {
-    const size_t shs = TdfaSortedShared(D);
+    // (wide: the window for lines of ~120 bytes -- three workgroups a CU instead of five or six; where the program's tables leave no room
+    // for it the narrow one stays)
+    const int wslice = wide && TdfaSortedShared(D, kTdfaSortedSliceWide) <= 76 * 1024 ? kTdfaSortedSliceWide : kTdfaSortedSlice;
+    const size_t shs = TdfaSortedShared(D, wslice);
     hipError_t rc;
     if ((rc = AllowLds(tdfa_batch_sorted_kernel, shs)) != hipSuccess) return rc;
     int per_cu = (int)((160 * 1024) / (shs + 512));             // (what the LDS allows; the registers may allow less: the grid is a few times
     per_cu = per_cu < 1 ? 1 : (per_cu > 8 ? 8 : per_cu);        // what is resident either way)
     const int grid = GridFor(nstr, 256, cus * per_cu * 4);    // (a few times what is resident: late workgroups even out the tail)
-    hipLaunchKernelGGL(tdfa_batch_sorted_kernel, dim3(grid), dim3(256), shs, stream, D, concat, offsets, (long long)nstr, found, rows, flags);
+    hipLaunchKernelGGL(tdfa_batch_sorted_kernel, dim3(grid), dim3(256), shs, stream, D, concat, offsets, (long long)nstr, found, rows, flags, wslice);
     return hipGetLastError();
   }
   const bool lds = TdfaInLds(D, true, true);

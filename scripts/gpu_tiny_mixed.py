@@ -8,6 +8,7 @@ from regengo_amd import Compiled, synth
 
 EMAIL = r"(?P<user>\w+)@(?P<domain>\w+)"
 nstr = int(sys.argv[1]) if len(sys.argv) > 1 else 8_000_000
+# RGX_FORCE_TDFA=1: the reference-mode program through the reference's Tagged DFA (Options.ForceTDFA)
 # RGX_BATCH_LENS=lo,hi: every string's length drawn from U[lo,hi] (default: C3's U[8,40])
 BLO, BHI = (int(x) for x in os.environ.get("RGX_BATCH_LENS", "8,40").split(","))
 data, offs = synth.email_batch_np(nstr, seed=0x5EED0003, lo=BLO, hi=BHI)
@@ -29,7 +30,7 @@ for every in EVERY:
     concat = torch.from_numpy(out).cuda()
     doffs = torch.from_numpy(noffs).cuda()
     for stdlib in (False, True):
-        c = Compiled(EMAIL, stdlib=stdlib).to(0)
+        c = Compiled(EMAIL, stdlib=stdlib, force_tdfa=bool(os.environ.get("RGX_FORCE_TDFA")) and not stdlib).to(0)
         for _ in range(4):
             c.FindBatchDevice(concat, doffs)
         lvl = c.tuning()["batch_tiny_level"]

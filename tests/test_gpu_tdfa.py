@@ -490,3 +490,52 @@ def test_tdfa_findall_wrapper_bounds_its_work(built):
     with pytest.raises(_capi.RgxError) as ei:
         c.CountAll(big)
     assert ei.value.status == _capi.RGX_E_UNSUPPORTED and "chase" in str(ei.value)
+
+
+@pytest.mark.gpu
+def test_tdfa_batch_over_lines_learns_the_wide_window(built, kats, corpus):
+    """Round 6: the sorted batch kernel's window is a launch parameter (12 KiB: strings of ~45 bytes; 32 KiB: lines of ~120) a program
+    learns from its batches -- lines of U[8,200] bytes used to leave the window and be walked out of memory (2 M lines: 8 ms, 26 GB/s).
+    Rows == oracle.tdfa.find per string on every call, whichever window took it; the level goes up after a batch of lines, back after
+    a batch of short strings, and stays under rgx_program_freeze."""
+    import torch
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a GPU; there is no CPU fallback")
+    from regengo_amd import Compiled
+    from oracle import engines as E
+    from tests import _fuzzgen as F
+    items = _tdfa_items(kats, corpus)
+    for pat in dict.fromkeys([r"(?P<user>\w+)@(?P<domain>\w+)"] + [it[0] for it in items[:2]]):
+        forced = pat.startswith("(?P<user>")
+        o = E.Compiled(pat, force_tdfa=True) if forced else E.Compiled(pat)
+        c = Compiled(pat, force_tdfa=True).to(0) if forced else Compiled(pat).to(0)
+        rnd = random.Random(zlib.crc32(pat.encode()) ^ 0x66)
+        tb = o.tdfa.tables()
+        tb["start_any"] = o.tdfa.start_any
+        lines = [F.tdfa_guided_text(tb, rnd, rnd.randint(8, 200)) for _ in range(256 * 6 + 31)]
+        short = [F.tdfa_guided_text(tb, rnd, rnd.randint(1, 40)) for _ in range(256 * 4 + 5)]
+        long_ = [F.tdfa_guided_text(tb, rnd, rnd.randint(150, 255)) for _ in range(256 * 3)]          # ~52 KiB a group: beyond the wide window too
+
+        def check(strings, what):
+            res = c.FindBatch(strings)
+            for b, r in zip(strings, res):
+                exp = o.tdfa.find(b)
+                assert (r is None) == (exp is None), (pat, what, b)
+                if r is not None:
+                    assert r.spans == exp, (pat, what, b, r.spans, exp)
+        assert c.tuning()["batch_tdfa_wide"] == 0
+        check(lines, "lines, narrow window")
+        if c.tuning()["batch_tdfa_wide"] == 0:
+            continue                                   # (a program without the sorted kernel: nothing to learn)
+        check(lines, "lines, wide window")
+        assert c.tuning()["batch_tdfa_wide"] == 1
+        check(long_, "groups beyond the wide window")
+        assert c.tuning()["batch_tdfa_wide"] == 1
+        check(short, "short strings, wide window")
+        assert c.tuning()["batch_tdfa_wide"] == 0
+        check(short, "short strings, narrow window")
+        check(lines, "lines again")
+        c.freeze()
+        lvl = c.tuning()["batch_tdfa_wide"]
+        check(short, "frozen")
+        assert c.tuning()["batch_tdfa_wide"] == lvl
