@@ -37,7 +37,7 @@ def _lines(nstr, lo, hi, seed):
             line += rng.choice(words) + b" "
         out += line[:n]
         offs.append(len(out))
-    return np.frombuffer(bytes(out), dtype=np.uint8), np.array(offs, dtype=np.int64)
+    return np.frombuffer(bytes(out), dtype=np.uint8).copy(), np.array(offs, dtype=np.int64)
 
 
 @pytest.mark.gpu
