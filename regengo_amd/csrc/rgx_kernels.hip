@@ -2475,6 +2475,7 @@ __global__ __launch_bounds__(kBlockThreads) void batch_search_kernel(DevTables U
         if (__any(redo)) {                  // (rare: a match, or the walk behind it, longer than the ring -- the trace in memory, those lanes alone)
           TraceT* tg = gtrace + o0 + 2 * i;
           const bool again = redo;
+          redo = false;                     // (the second pass is the whole answer of those lanes, the replay of the attempt offsets included)
           if (Y.bt_in_lds) process(tg, 1, BL, in, again, NoRing{}); else process(tg, 1, BG, in, again, NoRing{});
         }
       }

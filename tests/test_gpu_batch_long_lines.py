@@ -81,3 +81,72 @@ def test_general_kernel_on_lines(torch_dev, pattern):
                     a, b = mm.span(nm)
                     if a >= 0:
                         assert (sp[i, 2 * g], sp[i, 2 * g + 1]) == (a, b), (pattern, nm, i, s, sp[i].tolist())
+
+
+@pytest.mark.gpu
+def test_lines_of_random_patterns(torch_dev):
+    """RANDOM patterns (tests/_fuzzgen.py: every engine class) over batches of LINES of 0-300 bytes, three calls each (a program learns
+    its instance -- the register kernel's wide levels, the Tagged-DFA kernel's wide window -- from the first): found flags and records ==
+    the oracle's C port of the matcher the reference emits (oracle/gen_c.py: m_find_batch; Tagged-DFA programs: oracle/tdfa_c.py), or a
+    refusal -- never another answer.  The short random strings of tests/test_gpu_reference_mode.py never leave the narrow instances."""
+    torch = torch_dev
+    from oracle import engines as E
+    from oracle.gen_c import CMatcher
+    from oracle.tdfa_c import CTdfa
+    from regengo_amd import Compiled, _capi
+    from tests import _fuzzgen as F
+    rng = random.Random(4242)
+    pats = compared = refused = wide = tdfa_wide = 0
+    for seed in F.fuzz_seeds(700, 703):
+        for pat in F.gen_patterns(seed, 40):
+            try:
+                o = E.Compiled(pat)
+            except Exception:
+                continue
+            if F.has_empty_loop(o.prog) and not o.find_machine.memo:
+                continue
+            if o.tdfa is not None and len(o.tdfa.states) > 200:
+                continue
+            try:
+                c = Compiled(pat).to(0)
+            except _capi.RgxError:
+                continue
+            if not c.info.ref_find_offered:
+                continue
+            try:
+                port = CTdfa(pat) if c.info.ref_find_engine == 1 else CMatcher(pat)
+            except Exception:
+                continue
+            nstr = 256 * 5 + 9
+            top = 301 if pats % 2 else 251        # (lines beyond 254 bytes in every group keep the register kernel at its narrow level: every other program sees none)
+            strings = [F.gen_input(rng, rng.randrange(0, top)) for _ in range(nstr)]
+            data = np.frombuffer(b"".join(strings) + b"\0", dtype=np.uint8).copy()
+            offs = np.zeros(nstr + 1, dtype=np.int64)
+            np.cumsum([len(s) for s in strings], out=offs[1:])
+            if c.info.ref_find_engine == 1:
+                ef, er = port.find_batch_np(data, offs)
+            else:
+                uoffs = offs.astype(np.uint64)
+                ef = np.zeros(nstr, dtype=np.uint8)
+                er = np.zeros((nstr, port.ncap), dtype=np.int32)
+                port.lib.m_find_batch(data.ctypes.data, uoffs.ctypes.data, nstr, ef.ctypes.data, er.ctypes.data)
+            concat, doffs = torch.from_numpy(data).cuda(), torch.from_numpy(offs).cuda()
+            pats += 1
+            for call in range(3):
+                try:
+                    found, spans = c.FindBatchDevice(concat, doffs)
+                except _capi.RgxError as ex:
+                    assert ex.status == _capi.RGX_E_UNSUPPORTED, (pat, ex)
+                    refused += 1
+                    break
+                f, sp = found.cpu().numpy(), spans.cpu().numpy()
+                assert np.array_equal(f != 0, ef != 0), (pat, call, int(((f != 0) != (ef != 0)).sum()), c.tuning())
+                m = ef.astype(bool)
+                assert np.array_equal(sp[m], er[m]), (pat, call, c.tuning())
+                compared += nstr
+            t = c.tuning()
+            wide += t["batch_tiny_level"] > 0
+            tdfa_wide += t["batch_tdfa_wide"] > 0
+    print("patterns", pats, "strings compared", compared, "refused", refused, "programs at a wide register level", wide, "Tagged-DFA programs at the wide window", tdfa_wide)
+    if F.fuzz_default():
+        assert pats >= 40 and compared >= 100_000 and wide >= 3 and tdfa_wide >= 2, (pats, compared, refused, wide, tdfa_wide)
