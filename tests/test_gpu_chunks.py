@@ -433,3 +433,75 @@ def test_patterns_that_match_empty_stream_chunk_by_chunk(torch_dev, pattern):
     with pytest.raises(RgxError) as ei:
         c.FindChunksDevice(torch.frombuffer(bytearray(data), dtype=torch.uint8).cuda(), c._resolve(Config(65536, 0)))
     assert ei.value.status == -3
+
+
+def test_runs_of_chunks_of_random_patterns(torch_dev):
+    """RANDOM patterns (tests/_fuzzgen.py: every engine class the reference emits) over a run of chunks in ONE call: the rows of
+    rgx_find_chunks_device == every callback of the reference's read loop as the oracle's C ports run it over the same stream
+    (StreamOffset, ChunkIndex, groups) -- whichever way the library takes the run (mode 1: the grid in the scan kernels / the Tagged
+    DFA's chain; mode 2: chunk by chunk) -- or a refusal (RGX_E_UNSUPPORTED / RGX_E_DIVERGES): never another answer.  Texts of ~400 KiB
+    of the pattern's own alphabet with its matches sprinkled in, two geometries (64 KiB chunks at the default leftover; chunks of
+    70 000 bytes with 20 000 kept back)."""
+    torch = torch_dev
+    import random
+    from oracle import engines as E
+    from oracle.gen_c import CMatcher
+    from oracle.tdfa_c import CTdfa
+    from regengo_amd import Compiled, _capi
+    from regengo_amd.stream import Config
+    from tests import _fuzzgen as F
+    rng = random.Random(909)
+    pats = compared = refused = grid = rows_total = 0
+    for seed in F.fuzz_seeds(800, 803):
+        for pat in F.gen_patterns(seed, 30):
+            try:
+                o = E.Compiled(pat)
+            except Exception:
+                continue
+            if F.has_empty_loop(o.prog) and not o.find_machine.memo:
+                continue
+            if o.tdfa is not None and len(o.tdfa.states) > 200:
+                continue
+            try:
+                c = Compiled(pat).to(0)
+            except _capi.RgxError:
+                continue
+            if not c.info.ref_stream_offered:
+                continue
+            try:
+                port = CTdfa(pat) if o.tdfa is not None else CMatcher(pat)
+            except Exception:
+                continue
+            parts, total = [], 0
+            while total < 400_000:
+                s = F.gen_input(rng, rng.choice([3, 10, 40, 120])) + rng.choice([b" ", b"\n", b"", b"  "])
+                parts.append(s)
+                total += len(s)
+            host = np.frombuffer(b"".join(parts), dtype=np.uint8).copy()
+            dev = torch.from_numpy(host).cuda()
+            pats += 1
+            for B, ML in ((65536, 0), (70000, 20000)):
+                try:
+                    rc = _resolved(o, B, ML)
+                except AssertionError:
+                    continue                       # (a buffer below the program's minimum: Config.Validate refuses, nothing to compare)
+                cfg = c._resolve(Config(B, ML))
+                assert (cfg.BufferSize, cfg.MaxLeftover) == (rc.BufferSize, rc.MaxLeftover), pat
+                exp = port.find_reader_np(host, rc.BufferSize, rc.MaxLeftover)
+                try:
+                    rows, res = c.FindChunksDevice(dev, cfg, final=True)
+                except _capi.RgxError as ex:
+                    assert ex.status in (_capi.RGX_E_UNSUPPORTED, _capi.RGX_E_DIVERGES), (pat, B, ML, ex)
+                    refused += 1
+                    continue
+                S = cfg.BufferSize - cfg.MaxLeftover
+                try:
+                    _same(rows.cpu().numpy(), int(res.chunks), S, exp, c.ncap)
+                except AssertionError as ex:
+                    raise AssertionError((pat, B, ML, res.mode, str(ex)))
+                compared += 1
+                grid += res.mode == 1
+                rows_total += exp.shape[0]
+    print("patterns", pats, "runs compared", compared, "of them through the grid", grid, "refused", refused, "callbacks", rows_total)
+    if F.fuzz_default():
+        assert pats >= 40 and compared >= 40 and grid >= 10, (pats, compared, grid, refused)
