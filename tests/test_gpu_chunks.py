@@ -452,6 +452,7 @@ def test_runs_of_chunks_of_random_patterns(torch_dev):
     from tests import _fuzzgen as F
     rng = random.Random(909)
     pats = compared = refused = grid = rows_total = 0
+    why = {}
     for seed in F.fuzz_seeds(800, 803):
         for pat in F.gen_patterns(seed, 30):
             try:
@@ -493,6 +494,7 @@ def test_runs_of_chunks_of_random_patterns(torch_dev):
                 except _capi.RgxError as ex:
                     assert ex.status in (_capi.RGX_E_UNSUPPORTED, _capi.RGX_E_DIVERGES), (pat, B, ML, ex)
                     refused += 1
+                    why[(ex.status, str(ex)[:90])] = why.get((ex.status, str(ex)[:90]), 0) + 1
                     continue
                 S = cfg.BufferSize - cfg.MaxLeftover
                 try:
@@ -503,5 +505,7 @@ def test_runs_of_chunks_of_random_patterns(torch_dev):
                 grid += res.mode == 1
                 rows_total += exp.shape[0]
     print("patterns", pats, "runs compared", compared, "of them through the grid", grid, "refused", refused, "callbacks", rows_total)
+    for k, v in sorted(why.items(), key=lambda kv: -kv[1]):
+        print("  refused", v, k)
     if F.fuzz_default():
         assert pats >= 40 and compared >= 40 and grid >= 10, (pats, compared, grid, refused)
