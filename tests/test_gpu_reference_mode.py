@@ -377,3 +377,84 @@ def test_thompson_matcher_over_one_long_text(torch_dev):
     c = Compiled(cases[0][0]).to(0)
     big = b"aa x " * ((20 << 20) // 5 + 1)
     assert c.MatchBytes(big) is False and c.MatchBytes(big + b"aa y") is True
+
+
+@pytest.mark.gpu
+def test_one_long_text_of_random_patterns(torch_dev):
+    """RANDOM patterns over ONE long text (300 KB of the pattern's own alphabet, matches sprinkled in, a prefix without any match for
+    half of them): `FindBytes` (the parallel scan with n = 1 + the restart-rule test of that row; Tagged-DFA programs: a lane per start
+    offset) == the oracle's C port of the emitted matcher, and `MatchBytes` == the host mirror of the emitted function (the interpreted
+    Thompson matcher walks such a text a lane per chunk since round 6) -- or RGX_E_UNSUPPORTED (the loop steps over the match, a text
+    that keeps attempts pending, an engine that is not offered): never another answer."""
+    torch = torch_dev
+    from oracle import engines as E
+    from oracle.gen_c import CMatcher
+    from oracle.tdfa_c import CTdfa
+    from regengo_amd import Compiled, _capi
+    from tests import _fuzzgen as F
+    from tests._hosttest import HostProgram
+    rng = random.Random(31337)
+    pats = nfind = nmatch = ref_f = ref_m = thom = 0
+    for seed in F.fuzz_seeds(900, 903):
+        for pat in F.gen_patterns(seed, 30):
+            try:
+                o = E.Compiled(pat)
+            except Exception:
+                continue
+            if F.has_empty_loop(o.prog) and not o.find_machine.memo:
+                continue
+            if o.tdfa is not None and len(o.tdfa.states) > 200:
+                continue
+            try:
+                c = Compiled(pat).to(0)
+            except _capi.RgxError:
+                continue
+            parts, total = [], 0
+            quiet = rng.random() < 0.5
+            if quiet:
+                parts.append(bytes(rng.choice(b" \n.,;") for _ in range(150_000)))
+                total = 150_000
+            while total < 300_000:
+                s = F.gen_input(rng, rng.choice([3, 10, 40, 120])) + rng.choice([b" ", b"\n", b"", b"  "])
+                parts.append(s)
+                total += len(s)
+            text = b"".join(parts)
+            arr = np.frombuffer(text, dtype=np.uint8)
+            pats += 1
+            if c.info.ref_find_offered:
+                try:
+                    port = CTdfa(pat) if c.info.ref_find_engine == 1 else CMatcher(pat)
+                except Exception:
+                    port = None
+                if port is not None:
+                    if c.info.ref_find_engine == 1:
+                        ef, er = port.find_batch_np(arr, np.array([0, len(text)], dtype=np.int64))
+                        want = er[0].tolist() if ef[0] else None
+                    else:
+                        out = np.zeros(port.ncap, dtype=np.int32)
+                        ok = port.lib.m_find(arr.ctypes.data, len(text), out.ctypes.data)
+                        want = out.tolist() if ok else None
+                    try:
+                        got = c.FindBytes(text)
+                        r, ok = got if isinstance(got, tuple) else (got, got is not None)
+                        assert (want is None) == (not ok), ("FindBytes", pat, want, r and r.spans)
+                        if want is not None:
+                            assert r.spans == want, ("FindBytes", pat, want, r.spans)
+                        nfind += 1
+                    except _capi.RgxError as ex:
+                        assert ex.status == _capi.RGX_E_UNSUPPORTED, ("FindBytes", pat, ex)
+                        ref_f += 1
+            if c.info.ref_match_offered:
+                hp = HostProgram(pat)
+                wantm = hp.ref_match(text)
+                if wantm in (0, 1):
+                    try:
+                        assert c.MatchBytes(torch.from_numpy(arr.copy()).cuda()) == bool(wantm), ("MatchBytes", pat, wantm)
+                        nmatch += 1
+                        thom += o.thompson is not None and c.info.ref_match_engine == 1
+                    except _capi.RgxError as ex:
+                        assert ex.status == _capi.RGX_E_UNSUPPORTED, ("MatchBytes", pat, ex)
+                        ref_m += 1
+    print("patterns", pats, "FindBytes compared", nfind, "refused", ref_f, "| MatchBytes compared", nmatch, "refused", ref_m, "| Thompson programs", thom)
+    if F.fuzz_default():
+        assert pats >= 40 and nfind >= 20 and nmatch >= 30, (pats, nfind, ref_f, nmatch, ref_m)
