@@ -2551,8 +2551,18 @@ RGX_API int rgx_find_bytes(const rgx_program* p, rgx_stream_ctx* c, const uint8_
     rgx_result r{};
     const int64_t w = FindAllDevice(p, c, c->d_in, len, 1, c->d_out, 1, false, &r);
     if (w < 0) return (int)w;
-    if (w == 0) { *found = 0; memset(spans, 0, (size_t)ncap * 4); return RGX_OK; }
-    if (!stdlib && ncap > 2) {
+    if (w == 0) {
+      // (the scan makes no attempt AT offset len, find.go:209-211 -- FindBytes does, and a pattern that can match empty may match there
+      // and nowhere else: `$`, `x*\b$`.  Found by the random-pattern test over long texts.)
+      if (t.can_match_empty) {
+        SetError("FindBytes of one long text: the pattern can match empty and the text holds no match in front of its end -- the attempt at the end of the text is the emitted loop's own; keep the Go path");
+        return RGX_E_UNSUPPORTED;
+      }
+      *found = 0; memset(spans, 0, (size_t)ncap * 4); return RGX_OK;
+    }
+    // (programs without capture groups: the reference emits no Find* function for them -- the restart rule of the function it WOULD emit is
+    // applied like everywhere else in the library where its automaton exists, so that the short and the long text of one program agree)
+    if (!stdlib && (ncap > 2 || p->p.dev.ref_find_ok || RefMemoMode(p))) {
       if ((rc = Ensure(&c->d_glist, &c->glist_cap, 16)) != RGX_OK) return rc;
       unsigned* flag = reinterpret_cast<unsigned*>(c->d_cursor + 1);
       unsigned h = 0;

@@ -118,8 +118,15 @@ def test_lines_of_random_patterns(torch_dev):
             except Exception:
                 continue
             nstr = 256 * 5 + 9
-            top = 301 if pats % 2 else 251        # (lines beyond 254 bytes in every group keep the register kernel at its narrow level: every other program sees none)
-            strings = [F.gen_input(rng, rng.randrange(0, top)) for _ in range(nstr)]
+            # three kinds of batch in turn: lines of up to 250 bytes (the register kernel's wide levels), lines of up to 300 (a line beyond
+            # the tag bytes in every group: the narrow level stays, the general kernel takes everything), short strings with a long line
+            # in one of sixty (the groups that hold one are left to the general kernel, the rest stays in registers)
+            kind = pats % 3
+            if kind == 2:
+                strings = [F.gen_input(rng, rng.randrange(60, 301) if rng.random() < 1 / 60 else rng.randrange(0, 41)) for _ in range(nstr)]
+            else:
+                top = 301 if kind else 251
+                strings = [F.gen_input(rng, rng.randrange(0, top)) for _ in range(nstr)]
             data = np.frombuffer(b"".join(strings) + b"\0", dtype=np.uint8).copy()
             offs = np.zeros(nstr + 1, dtype=np.int64)
             np.cumsum([len(s) for s in strings], out=offs[1:])
