@@ -456,3 +456,62 @@ def test_halo_checks_at_the_edges_of_their_ranges(gpu):
         total, rs = s.round([dict(buf=buf, own=(own_lo, own_hi), base=0, starts_at_sync=False, last=False)])
         assert not rs[0]["unsynced"] and not rs[0]["truncated"] and total == 1, (own_lo, own_hi, rs[0])
     s.close()
+
+
+@pytest.mark.gpu
+def test_sharded_find_all_of_random_patterns(gpu):
+    """RANDOM patterns through rgx_sharded_find_all_bytes over 2, 3 and 5 logical shards of one device (windows with halos, sync points
+    in the halos, windows widened where a halo holds none, matches across window edges): the rows of the stream == the rows of ONE scan
+    of the same program over the same bytes (itself against the oracle's C port in the differential sweeps, tests/test_gpu_fuzz.py) --
+    or both refuse."""
+    torch = gpu
+    import random
+    from oracle import engines as E
+    from regengo_amd import Compiled, _capi
+    from regengo_amd.sharded import Sharded
+    from tests import _fuzzgen as F
+    rng = random.Random(1234)
+    pats = compared = refused = rows_total = 0
+    for seed in F.fuzz_seeds(1000, 1003):
+        for pat in F.gen_patterns(seed, 30):
+            try:
+                o = E.Compiled(pat)
+            except Exception:
+                continue
+            if F.has_empty_loop(o.prog) and not o.find_machine.memo:
+                continue
+            try:
+                c = Compiled(pat).to(0)
+            except _capi.RgxError:
+                continue
+            if c.info.ref_findall_offered != 1:
+                continue
+            parts, total = [], 0
+            while total < 600_000:
+                s = F.gen_input(rng, rng.choice([3, 10, 40, 120, 400])) + rng.choice([b" ", b"\n", b"", b"  "])
+                parts.append(s)
+                total += len(s)
+            text = b"".join(parts)
+            try:
+                whole = c.FindAllSpans(text)[0].cpu().numpy()
+            except _capi.RgxError as ex:
+                assert ex.status in (_capi.RGX_E_UNSUPPORTED, _capi.RGX_E_DIVERGES), (pat, ex)
+                whole = None
+            pats += 1
+            for ndev in (2, 3, 5):
+                s = Sharded(c, devices=[0] * ndev)
+                try:
+                    rows, res = s.find_all_bytes(text)
+                except _capi.RgxError as ex:
+                    assert ex.status in (_capi.RGX_E_UNSUPPORTED, _capi.RGX_E_DIVERGES), (pat, ndev, ex)
+                    refused += 1
+                    s.close()
+                    continue
+                s.close()
+                assert whole is not None, (pat, ndev, "the shards answered what one scan refused")
+                assert res.total == whole.shape[0] and np.array_equal(rows, whole), (pat, ndev, res.total, whole.shape)
+                compared += 1
+                rows_total += whole.shape[0]
+    print("patterns", pats, "sharded scans compared", compared, "refused", refused, "rows", rows_total)
+    if F.fuzz_default():
+        assert pats >= 40 and compared >= 90, (pats, compared, refused)
