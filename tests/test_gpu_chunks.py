@@ -453,7 +453,7 @@ def test_runs_of_chunks_of_random_patterns(torch_dev):
     rng = random.Random(909)
     pats = compared = refused = grid = rows_total = 0
     why = {}
-    for seed in F.fuzz_seeds(800, 803):
+    for seed in F.fuzz_seeds(800, 802):
         for pat in F.gen_patterns(seed, 30):
             try:
                 o = E.Compiled(pat)

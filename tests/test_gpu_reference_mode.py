@@ -395,7 +395,7 @@ def test_one_long_text_of_random_patterns(torch_dev):
     from tests._hosttest import HostProgram
     rng = random.Random(31337)
     pats = nfind = nmatch = ref_f = ref_m = thom = 0
-    for seed in F.fuzz_seeds(900, 903):
+    for seed in F.fuzz_seeds(900, 902):
         for pat in F.gen_patterns(seed, 30):
             try:
                 o = E.Compiled(pat)

@@ -472,7 +472,7 @@ def test_sharded_find_all_of_random_patterns(gpu):
     from tests import _fuzzgen as F
     rng = random.Random(1234)
     pats = compared = refused = rows_total = 0
-    for seed in F.fuzz_seeds(1000, 1003):
+    for seed in F.fuzz_seeds(1000, 1002):
         for pat in F.gen_patterns(seed, 30):
             try:
                 o = E.Compiled(pat)
