@@ -215,7 +215,8 @@ typedef struct rgx_tuning {
   int32_t ascii_twin;           /* 1: a twin for texts without a byte >= 0x80 exists; -1: none (or not wanted)                        */
   int32_t batch_tiny_level;     /* rgx_find_batch_device, tiny search automata: 0 the instances for strings <= 56 bytes, 1 / 2 the ones for  */
                                 /* strings <= 254 bytes (LDS windows of 34 / 64 KiB a group of 256 strings)                               */
-  int32_t batch_tdfa_wide;      /* rgx_find_batch_device, Tagged-DFA programs: 1 the sorted kernel's 32 KiB window (lines of ~120 bytes)     */
+  int32_t batch_tdfa_wide;      /* rgx_find_batch_device, Tagged-DFA programs: the sorted kernel's window -- 0: 12 KiB, 1: 32 KiB (lines of  */
+                                /* ~120 bytes), 2: 64 KiB (any lines of up to 255 bytes)                                                  */
   int32_t reserved[4];
 } rgx_tuning;
 int rgx_program_tuning(const rgx_program* p, rgx_tuning* out);

@@ -2095,18 +2095,21 @@ RGX_API int64_t rgx_find_batch_device(const rgx_program* p, rgx_stream_ctx* c, c
     // tags, (-1, -1) = "field left untouched" whatever RGX_FLAG_UNMATCHED_MINUS1 says
     if ((rc = Ensure(&c->d_tdfa, &c->tdfa_cap, 16)) != RGX_OK) return rc;
     uint32_t* flags = (uint32_t*)c->d_tdfa;
-    uint32_t h[3] = {0, 0, 0};
-    // (the sorted kernel's window: 12 KiB a group of 256 strings, or 32 KiB for lines -- learned from what the last batch looked like)
+    uint32_t h[4] = {0, 0, 0, 0};
+    // (the sorted kernel's window: 12 KiB a group of 256 strings, 32 KiB for lines of ~120 bytes, 64 KiB for any lines of up to 255 --
+    // learned from what the last batch looked like)
     const int wide = p->tdfa_wide.load(std::memory_order_relaxed);
-    HIP_TRY(hipMemsetAsync(flags, 0, 12, c->stream));
+    HIP_TRY(hipMemsetAsync(flags, 0, 16, c->stream));
     HIP_TRY(LaunchTdfaBatch(*T.tdfa, d_concat, d_offsets, (int64_t)nstr, d_found, d_spans, flags, c->stream, wide));
-    HIP_TRY(hipMemcpyAsync(h, flags, 12, hipMemcpyDeviceToHost, c->stream));
+    HIP_TRY(hipMemcpyAsync(h, flags, 16, hipMemcpyDeviceToHost, c->stream));
     HIP_TRY(hipStreamSynchronize(c->stream));
     if (h[0] & kTdfaOverBudget) { SetError("the Tagged DFA's attempts on a string of this batch are too long to finish: keep the CPU path for it"); return RGX_E_UNSUPPORTED; }
     if (!p->frozen.load(std::memory_order_relaxed)) {
       // a quarter of the strings walked out of memory because their group was beyond the window: the wide one; every group within the narrow one: back
-      if (!wide && (int64_t)h[1] * 4 > (int64_t)nstr) p->tdfa_wide.store(1, std::memory_order_relaxed);
-      else if (wide && (int64_t)h[2] >= ((int64_t)nstr + 255) / 256) p->tdfa_wide.store(0, std::memory_order_relaxed);
+      const int64_t ngroups = ((int64_t)nstr + 255) / 256;
+      if (wide < 2 && (int64_t)h[1] * 4 > (int64_t)nstr) p->tdfa_wide.store(wide + 1, std::memory_order_relaxed);
+      else if (wide && (int64_t)h[2] >= ngroups) p->tdfa_wide.store(0, std::memory_order_relaxed);
+      else if (wide == 2 && (int64_t)h[3] >= ngroups) p->tdfa_wide.store(1, std::memory_order_relaxed);
     }
     return (int64_t)nstr;
   }

@@ -314,9 +314,9 @@ hipError_t LaunchTdfaQ11Emit(const int32_t* ends, int32_t len, const unsigned lo
 // before it, (0, 0) in front of the first (rgx_tdfa.hip has the why).  temp: TdfaFillTempBytes(n) bytes.
 size_t TdfaFillTempBytes(int64_t n);
 hipError_t LaunchTdfaFill(int32_t* rows, int64_t n, int ncap, void* temp, size_t temp_bytes, hipStream_t stream);
-// FindBytes per string of a batch: found[nstr], rows[nstr][ntags].  flags: three zeroed words -- [0] budget bits, [1] += strings that
-// left the sorted kernel's window (and were walked out of memory, slowly), [2] += groups of 256 strings the narrow window would hold;
-// wide: the 32 KiB window (lines of ~120 bytes) instead of the 12 KiB one
+// FindBytes per string of a batch: found[nstr], rows[nstr][ntags].  flags: four zeroed words -- [0] budget bits, [1] += strings that
+// left the sorted kernel's window (and were walked out of memory, slowly), [2] / [3] += groups of 256 strings the 12 / 32 KiB window
+// would hold; wide: 0 the 12 KiB window, 1 the 32 KiB one (lines of ~120 bytes), 2 the 64 KiB one (any lines of up to 255 bytes)
 hipError_t LaunchTdfaBatch(const TdfaDev& D, const uint8_t* concat, const uint64_t* offsets, int64_t nstr, uint8_t* found, int32_t* rows,
                            uint32_t* flags, hipStream_t stream, int wide = 0);
 

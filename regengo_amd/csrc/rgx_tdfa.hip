@@ -856,8 +856,9 @@ __global__ __launch_bounds__(256) void tdfa_batch_kernel(TdfaDev D, const uint8_
 // that does not lie in the window whole, or is longer than the merged walk's 255 bytes, takes BatchOne from memory (rare: the flag in
 // its entry).  Only for programs with the merged automaton AND the packed tag table (every Tagged-DFA pattern of the corpus has both).
 constexpr int kTdfaSortedSlice = 256 * 48;       // bytes of a workgroup's 256 strings staged in LDS: strings of ~45 bytes on average ...
-constexpr int kTdfaSortedSliceWide = 32768;      // ... and lines of ~120 (round 6: a program learns which from its batches, TdfaSortedWindow)
-constexpr uint32_t kTsSlow = 1u << 31;           // a sort entry: place in the window (15 bits) | length << 15 (8) | string << 23 (8) | slow
+constexpr int kTdfaSortedSliceWide = 32768;      // ... lines of ~120 (round 6: a program learns which from its batches) ...
+constexpr int kTdfaSortedSliceWidest = 65520;    // ... and any group of 256 strings of up to 255 bytes
+constexpr uint32_t kTsSlow = 0xFFFFu;            // a sort entry: place in the window (16 bits; kTsSlow: the string takes the slow path) | length << 16 (8) | string << 24 (8)
 
 __device__ __forceinline__ unsigned TdfaDppScanAdd(unsigned x) {
   x += (unsigned)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xF, 0xF, true);
@@ -882,7 +883,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
   // flags[1] += the strings that took the slow path because their group did not fit the window (no longer than 255 bytes themselves),
   // flags[2] += the groups the NARROW window would have held: what the host learns the window from
-  uint32_t nslow = 0, nfit = 0;
+  uint32_t nslow = 0, nfit = 0, nfit1 = 0;
   // LDS: the tag columns (a column per lane, the scrap column of the packed tag walk behind them) | the window | the sort's counts
   // (two sets of 64, used in turn) and the order | the merged automaton, byte classes, action pool, accept words, packed tag table
   int TDFA_LDS* const tags = (int TDFA_LDS*)smem + tid;
@@ -933,8 +934,9 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
       const uint64_t span_ = (((ge) - wb) + 15ull) & ~15ull;                                                                      \
       wvalid = (int)(span_ < (uint64_t)wslice ? span_ : (uint64_t)wslice);                                                        \
       nfit += span_ <= (uint64_t)kTdfaSortedSlice ? 1u : 0u;                                                                      \
+      nfit1 += span_ <= (uint64_t)kTdfaSortedSliceWide ? 1u : 0u;                                                                 \
     }                                                                                                                             \
-    rel = (uint32_t)((a) - wb) & 32767u;                                                                                          \
+    rel = (uint32_t)((a) - wb) & 65535u;                                                                                          \
     len = tid < nv_ ? (int)((uint32_t)(b) - (uint32_t)(a)) : -2;                                                                  \
     if (tid < nv_ && (((b) - (a)) > 255ull || (b) - wb > (uint64_t)wvalid)) len = -1;                                             \
     nslow += (uint32_t)__popcll(__builtin_amdgcn_ballot_w64(tid < nv_ && ((b) - (a)) <= 255ull && (b) - wb > (uint64_t)wvalid));  \
@@ -972,7 +974,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
       const uint32_t hv = h[lane];
       const uint32_t x = TdfaDppScanAdd(hv);
       const uint32_t start = (uint32_t)__builtin_amdgcn_ds_bpermute((int)(bin << 2), (int)(x - hv));
-      perm[start + rank] = relc | ((uint32_t)(lenc < 0 ? 0 : lenc) << 15) | ((uint32_t)tid << 23) | (lenc == -1 ? kTsSlow : 0u);
+      perm[start + rank] = (lenc == -1 ? kTsSlow : relc) | ((uint32_t)(lenc < 0 ? 0 : lenc) << 16) | ((uint32_t)tid << 24);
     }
     if (tid < 64) hist[(((it + 1) & 1) << 6) + tid] = 0;      // the next group's counts (last read a group ago)
     const long long i0 = grp * 256;
@@ -982,11 +984,11 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
     TDFA_META(grp + 2 * G, an, bn, gbn, gen);
     __syncthreads();
     const uint32_t e = perm[(((uint32_t)wave + (uint32_t)it) & 3u) * 64u + (uint32_t)lane];
-    const long long i = i0 + (long long)((e >> 23) & 255u);
+    const long long i = i0 + (long long)(e >> 24);
     if (i < nstr) {
-      const int len = (int)((e >> 15) & 255u);
-      if (!(e & kTsSlow)) {
-        const unsigned lb = win_at + (e & 32767u);
+      const int len = (int)((e >> 16) & 255u);
+      if ((e & 65535u) != kTsSlow) {
+        const unsigned lb = win_at + (e & 65535u);
         int bs, be;
         WalkMerged(ment_at, mcls_at, (unsigned)D.m_bot_row, lb, len, &bs, &be);
         found[i] = be >= 0 ? 1 : 0;
@@ -1006,6 +1008,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(6, 6))) voi
   }
   if (lane == 0 && nslow) atomicAdd(flags + 1, nslow);
   if (tid == 0 && nfit) atomicAdd(flags + 2, nfit);
+  if (tid == 0 && nfit1) atomicAdd(flags + 3, nfit1);
 #undef TDFA_NV
 #undef TDFA_META
 #undef TDFA_WINDOW
@@ -1418,7 +1421,9 @@ hipError_t LaunchTdfaBatch(const TdfaDev& D, const uint8_t* concat, const uint64
       TdfaSortedShared(D) <= 64 * 1024) {
     // (wide: the window for lines of ~120 bytes -- three workgroups a CU instead of five or six; where the program's tables leave no room
     // for it the narrow one stays)
-    const int wslice = wide && TdfaSortedShared(D, kTdfaSortedSliceWide) <= 76 * 1024 ? kTdfaSortedSliceWide : kTdfaSortedSlice;
+    int wslice = kTdfaSortedSlice;
+    if (wide >= 2 && TdfaSortedShared(D, kTdfaSortedSliceWidest) <= 100 * 1024) wslice = kTdfaSortedSliceWidest;       // (one or two workgroups a CU)
+    else if (wide >= 1 && TdfaSortedShared(D, kTdfaSortedSliceWide) <= 76 * 1024) wslice = kTdfaSortedSliceWide;
     const size_t shs = TdfaSortedShared(D, wslice);
     hipError_t rc;
     if ((rc = AllowLds(tdfa_batch_sorted_kernel, shs)) != hipSuccess) return rc;

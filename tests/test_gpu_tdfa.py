@@ -494,7 +494,7 @@ def test_tdfa_findall_wrapper_bounds_its_work(built):
 
 @pytest.mark.gpu
 def test_tdfa_batch_over_lines_learns_the_wide_window(built, kats, corpus):
-    """Round 6: the sorted batch kernel's window is a launch parameter (12 KiB: strings of ~45 bytes; 32 KiB: lines of ~120) a program
+    """Round 6: the sorted batch kernel's window is a launch parameter (12 KiB: strings of ~45 bytes; 32 KiB: lines of ~120; 64 KiB: any lines of up to 255 bytes) a program
     learns from its batches -- lines of U[8,200] bytes used to leave the window and be walked out of memory (2 M lines: 8 ms, 26 GB/s).
     Rows == oracle.tdfa.find per string on every call, whichever window took it; the level goes up after a batch of lines, back after
     a batch of short strings, and stays under rgx_program_freeze."""
@@ -529,7 +529,11 @@ def test_tdfa_batch_over_lines_learns_the_wide_window(built, kats, corpus):
             continue                                   # (a program without the sorted kernel: nothing to learn)
         check(lines, "lines, wide window")
         assert c.tuning()["batch_tdfa_wide"] == 1
-        check(long_, "groups beyond the wide window")
+        check(long_, "groups beyond the 32 KiB window")
+        assert c.tuning()["batch_tdfa_wide"] == 2
+        check(long_, "the 64 KiB window")
+        assert c.tuning()["batch_tdfa_wide"] == 2
+        check(lines, "lines, 64 KiB window")                           # every group within 32 KiB: a step back
         assert c.tuning()["batch_tdfa_wide"] == 1
         check(short, "short strings, wide window")
         assert c.tuning()["batch_tdfa_wide"] == 0
