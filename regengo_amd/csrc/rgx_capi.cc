@@ -1110,7 +1110,10 @@ int64_t FindAllDeviceBody(const rgx_program* p, rgx_stream_ctx* c, const uint8_t
     }
     P.slice_unsynced = nullptr;
     P.carry_in = c->d_carry;
+    P.carry_partial = carry_ready ? 0 : 1;      // (the marking scan ran without positions: the rescan's other slices sync as it did)
     if ((rc = run_scan(false)) != RGX_OK) return rc;
+    // (every slice has a position or a sync point now -- a slice left without one would have been skipped silently)
+    if (((uint32_t*)&c->h_read[2])[1]) { SetError("slices without a search position after the carry pass"); return RGX_E_HIP; }
   }
   }   // !us_ws
   // more than one lane in fifty finished in the single-step walker: this program's texts rewind (`a.*b.*c`), later scans take the

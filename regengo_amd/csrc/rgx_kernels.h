@@ -33,6 +33,9 @@ struct ScanParams {
   int32_t carry_sync;            // 1: every carry_in position is a sync point in the strict sense (no thread that started before it is
                                  // alive there: the sync automaton's answer) -- a stretch that ends at one needs no special care, unlike
                                  // the carry pass's search positions, behind which an older thread may still decide a match's finality
+  int32_t carry_partial;         // 1: carry_in holds positions for the slices an earlier scan of THIS call marked unsynced and nothing else (the
+                                 // carry pass behind a scan without carry_in): every other slice looks for its sync point exactly as that scan
+                                 // did, the far look-behind included (scan_kernel)
   int32_t debug;                 // experiment switches (RGX_DEBUG): 1 = unordered base (no look-back), 2 = no span stores
   uint32_t* census;              // nullable; persistent-workgroup kernels only: a residency census instead of a scan (LaunchScanUs) --
                                  // every workgroup reports in at [0], waits (bounded) for all gridDim.x of them, and counts itself at

@@ -233,7 +233,10 @@ __global__ __launch_bounds__(kBlockThreads) void scan_kernel(DevTables T, ScanPa
       int sp = -1;
       // (not when the host handed exact start positions down: a pattern that needs those proves little blind, the walk would
       // run in most tiles for nothing -- 1.3 -> 1.8 ms on the `<tag attr="...">` patterns)
-      const bool need = wb > 0 && !P.carry_in && s_sync[0] < 0 && s_sync[1] < 0 && s_sync[2] < 0 && s_sync[3] < 0;     // uniform
+      // (... but the rescan behind the CARRY pass has positions for the slices the first scan marked and for no other: a slice that
+      // found its sync point in the far look-behind then has to find it there again -- it was left without any, and without a scan:
+      // 11 of 6465 matches of `[^a][a-b0-1](a-|a|a){2}(?:1\.)*` on a random text, found by the sharded sweep of round 6)
+      const bool need = wb > 0 && (!P.carry_in || P.carry_partial) && s_sync[0] < 0 && s_sync[1] < 0 && s_sync[2] < 0 && s_sync[3] < 0;     // uniform
       if (need) {
         const int ha = wb - (lane + 1) * kSliceBytes;
         if (lane < kFar && ha >= 0) sp = walk(ha, ha + kSliceBytes);

@@ -498,6 +498,17 @@ def test_sharded_find_all_of_random_patterns(gpu):
                 assert ex.status in (_capi.RGX_E_UNSUPPORTED, _capi.RGX_E_DIVERGES), (pat, ex)
                 whole = None
             pats += 1
+            if whole is not None:
+                # the same bytes again on the same program (what it learned in the first call picks other passes: the carry pass
+                # instead of exact sync points) and on a program frozen before its first call (no learning at all): the same rows.
+                # [Round 6: the rescan behind the carry pass skipped slices that had found their sync point in the far look-behind --
+                # 11 of 6465 matches of `[^a][a-b0-1](a-|a|a){2}(?:1\.)*` were lost on every call but a program's first.]
+                again = c.FindAllSpans(text)[0].cpu().numpy()
+                assert np.array_equal(again, whole), (pat, "second call", again.shape, whole.shape)
+                cf = Compiled(pat).to(0)
+                cf.freeze()
+                fr = cf.FindAllSpans(text)[0].cpu().numpy()
+                assert np.array_equal(fr, whole), (pat, "frozen program", fr.shape, whole.shape)
             for ndev in (2, 3, 5):
                 s = Sharded(c, devices=[0] * ndev)
                 try:
