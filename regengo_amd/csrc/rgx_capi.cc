@@ -96,6 +96,7 @@ struct rgx_stream_ctx {
   std::string tmpl_key;                                      // what d_tmpl holds: "" = nothing
   // pinned host readback
   uint32_t* d_tiny_ctl = nullptr; int tiny_set = 0;   // batch_tiny_kernel's two control sets (rgx_find_batch_device)
+  bool us_ws_failed = false;                          // FindAllDevice: the call repeats itself without the sync automaton's per-slice positions
   uint8_t* d_gmap = nullptr; int64_t gmap_cap = 0;    // ... and its map of the groups it left to the general kernel (a byte per 256 strings)
   unsigned long long* h_read = nullptr;      // [32]: 0-3 the synchronous scan (total, rare-path flag, counters), 4-5 the splice, 6-7 the tiny batch's control words,
   unsigned long long* h_read_dev = nullptr;  //       8-11 / 12-15 the two in-flight scans of submit/wait, 16-18 the tiny batch's extras; same words, device view
@@ -766,8 +767,11 @@ int64_t FindAllDeviceBody(const rgx_program* p, rgx_stream_ctx* c, const uint8_t
   // e-mail + rest-of-line pattern).  They keep their kernel now: the exact sync points of the sync automaton (LaunchWSync: one
   // optimistic walk per 4 KiB chunk + repair) are handed over as per-slice start positions, like the carry pass's.
   static const bool no_us_ws = ExpEnv("RGX_NO_US_WSYNC") != nullptr;
+  // (c->us_ws_failed: this very call already tried it and repeats itself without -- a FROZEN program cannot remember that in prefer_wsync,
+  // and repeated itself for ever: a stack overflow, found by the sharded sweep of round 6 on `(?:[^a]|.)+`)
   const bool us_ws = use_w && !no_us_ws && T.reset_values == 0 && UseUsKernel(T, ilen, false) && (UsKernelVariant(T) != 4 || ExpEnv("RGX_US_WS4")) &&     // (the register kernel
-                     p->prefer_wsync.load(std::memory_order_relaxed) != -2;      // walks every slice from behind: slower than the generic kernel's W path, measured)
+                     p->prefer_wsync.load(std::memory_order_relaxed) != -2 && !c->us_ws_failed;      // walks every slice from behind: slower than the generic kernel's W path, measured)
+  c->us_ws_failed = false;
   if (us_ws) use_w = false;
   int32_t ntiles = ScanNumTiles(T, ilen, use_w);
   const int32_t ntiles_max = std::max(std::max(ntiles, UseFcKernel(T, ilen) ? FcNumTiles(ilen) : 0), std::max(ScanNumTiles(T, ilen, false), ScanNumTiles(T, ilen, true)));
@@ -989,6 +993,7 @@ int64_t FindAllDeviceBody(const rgx_program* p, rgx_stream_ctx* c, const uint8_t
       if (!frozen) p->prefer_wsync.store(-2, std::memory_order_relaxed);
       HIP_TRY(hipStreamSynchronize(c->stream));
       c->dirty[0] = c->dirty[1] = c->set_words;
+      c->us_ws_failed = true;
       return FindAllDevice(p, c, d_buf, len, n, d_spans, cap_records, count_only, res, starts_only, own_lo, own_hi);
     }
   }
